@@ -1,0 +1,186 @@
+/*
+ * x3d2_hip.h -- C ABI of the MI355X-native backend for x3d2's per-timestep
+ * hot path (libx3d2_hip.so).
+ *
+ * This is the drop-in boundary: every entry point replaces one deferred
+ * type-bound procedure of the reference's `base_backend_t`
+ * (/root/reference/src/backend/backend.f90:13-62, interfaces :64-391) or one
+ * hook of `poisson_fft_t` (/root/reference/src/poisson_fft.f90:45-62), or a
+ * constructor the reference's concrete backends supply.  A Fortran
+ * `bind(C)` interface block for these prototypes is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every `double *` named f/u/du/... is a
+ *    DEVICE pointer to one field block of x3d_block_elems() doubles
+ *    (the reference's allocator block, src/allocator.f90:64-93).
+ *  - return value: 0 = ok, non-zero = error (message: x3d_last_error()).
+ *    The reference has no status codes -- it `error stop`s
+ *    (e.g. src/backend/omp/backend.f90:349-351); a Fortran shim turns non-zero
+ *    into `error stop trim(msg)`.
+ *  - all calls are issued from one host thread per device and are ordered
+ *    on the context's HIP stream (results of call k are visible to call k+1);
+ *    only the functions that return host scalars synchronise.
+ *  - DEVICE LAYOUT (backend-private, like the reference's per-backend layouts,
+ *    src/ordering.f90:42-69 vs src/backend/cuda/kernels/reorder.f90:34,129):
+ *    every block, whatever its DIR_X/Y/Z/C tag, is Cartesian x-fastest with a
+ *    padded pitch: elem(i,j,k) = f[i + nxp*(j + nyp*k)], 0-based,
+ *    nxp = round_up(nx_vert, 16), nyp = ny_vert, nzp = nz_vert.
+ *    `dir` only selects the direction an operator works along.  A reorder is
+ *    therefore a device copy and sum_{y,z}intox an axpy.
+ */
+#ifndef X3D2_HIP_H
+#define X3D2_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* constants mirrored from src/common.f90:23-39 */
+enum { X3D_DIR_X = 1, X3D_DIR_Y = 2, X3D_DIR_Z = 3, X3D_DIR_C = 4 };
+enum { X3D_BC_PERIODIC = 0, X3D_BC_NEUMANN = 1, X3D_BC_DIRICHLET = 2, X3D_BC_HALO = -1 };
+enum { X3D_X_FACE = 1100, X3D_Y_FACE = 1010, X3D_Z_FACE = 110 };
+#define X3D_N_HALO 4 /* src/backend/backend.f90:28-29 */
+
+typedef struct x3d_backend x3d_backend; /* omp_backend_t / cuda_backend_t analogue */
+typedef struct x3d_tdsops x3d_tdsops;   /* device copy of one tdsops_t          */
+typedef struct x3d_poisson x3d_poisson; /* poisson_fft_t extension              */
+
+const char *x3d_last_error(void);
+int x3d_abi_version(void);
+
+/* ---- construction: omp_backend_t(mesh, allocator), src/backend/omp/backend.f90:66-114 +
+ *      allocator_t(dims, SZ), src/allocator.f90:64-93.
+ * dims_vert: local vertex counts (mesh%get_dims(VERT)); stream: hipStream_t or NULL. */
+int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream);
+int x3d_backend_destroy(x3d_backend *b);
+int x3d_backend_set_stream(x3d_backend *b, void *stream);
+size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
+int x3d_padded_dims(const x3d_backend *b, int dims_out[3]); /* get_padded_dims(DIR_C) */
+int x3d_device_sync(x3d_backend *b);
+
+/* block storage for callers without their own device allocator
+ * (cuda_allocator_t%create_block, src/backend/cuda/allocator.f90:81-90) */
+int x3d_block_alloc(x3d_backend *b, double **out);
+int x3d_block_free(x3d_backend *b, double *p);
+int x3d_block_fill(x3d_backend *b, double *f, double c); /* field_t%fill, src/field.f90:47-55 */
+
+/* ---- alloc_tdsops (src/backend/backend.f90:352-372): device copy of the
+ * arrays the host-side factory tdsops_init (src/tdsops.f90:63-203) produced.
+ * coeffs[9]; coeffs_s/coeffs_e[4*9] with row r (0..3) = coeffs_s(:, r+1);
+ * dist_* have n_rhs entries, stretch* n_tds entries. */
+int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, int n_rhs, int move,
+                      int periodic, const double *coeffs, const double *coeffs_s,
+                      const double *coeffs_e, const double *dist_fw, const double *dist_bw,
+                      const double *dist_sa, const double *dist_sc, const double *dist_af,
+                      const double *stretch, const double *stretch_correct);
+int x3d_tdsops_destroy(x3d_tdsops *t);
+
+/* ---- tds_solve (src/backend/backend.f90:131-150; omp: src/backend/omp/backend.f90:340-391
+ * + src/backend/omp/exec_dist.f90:16-65).
+ * Local form: the pencil direction is not decomposed (nproc_dir(dir)==1), the
+ * periodic wrap / reduced 2x2 system is closed on the device. */
+int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+
+/* Distributed form, one call per phase of exec_dist_tds_compact; halo and
+ * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):
+ *   x3d_pack_halos     = copy_into_buffers   (src/backend/omp/backend.f90:714-737)
+ *   <caller exchanges u_send_* -> u_recv_* with pprev/pnext: sendrecv_fields>
+ *   x3d_tds_dist_fwd   = der_univ_dist loop   (exec_dist.f90:36-47); fills du_send_s/e
+ *   <caller exchanges du_send_* -> du_recv_*>
+ *   x3d_tds_dist_bwd   = der_univ_subs loop   (exec_dist.f90:55-63) */
+int x3d_npencils(const x3d_backend *b, int dir);
+int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir);
+int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, double *du_send_e,
+                     const double *u, const double *u_recv_s, const double *u_recv_e,
+                     const x3d_tdsops *t, int dir);
+int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
+                     const double *du_recv_e, const x3d_tdsops *t, int dir);
+
+/* ---- transeq_x / transeq_y / transeq_z (src/backend/backend.f90:64-92; omp:
+ * src/backend/omp/backend.f90:145-184, 235-338; exec_dist.f90:67-186).
+ * `dir` selects which one; u,v,w and du,dv,dw are passed exactly as the
+ * caller passes them to transeq_<dir> (the permutation that makes the
+ * advecting component first, :158-184, is applied inside).
+ * Local form (direction not decomposed): */
+int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                const x3d_tdsops *der2nd_sym);
+/* Distributed form for ONE component (transeq_dist_component, :299-338):
+ * rhs = -1/2 (conv*du/dx + d(u*conv)/dx) + nu d2u/dx2.  send/recv are
+ * [3][npencil] (du, dud, d2u boundary values), halos [4][npencil]. */
+int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double *send_s, double *send_e,
+                         const double *u, const double *u_recv_s, const double *u_recv_e,
+                         const double *conv, const double *conv_recv_s, const double *conv_recv_e,
+                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u);
+int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
+                         const double *recv_s, const double *recv_e, const double *conv, double nu,
+                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u);
+
+/* ---- reorder / sum_yintox / sum_zintox (src/backend/backend.f90:152-186) */
+int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr_code);
+int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from);
+
+/* ---- veccopy / vecadd / vecmult / field_scale / field_shift (:188-236, 273-291) */
+int x3d_veccopy(x3d_backend *b, double *dst, const double *src);
+int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
+int x3d_vecmult(x3d_backend *b, double *y, const double *x);
+int x3d_field_scale(x3d_backend *b, double *f, double a);
+int x3d_field_shift(x3d_backend *b, double *f, double a);
+/* fused time-integrator update (an extension, not in base_backend_t):
+ * y = base + sum_i c[i]*x[i], nterm <= 5; base may be y itself.  Collapses the
+ * veccopy/vecadd chains of src/time_integrator.f90:166-282 into one pass. */
+int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
+                const double *const *x);
+
+/* ---- reductions over the unpadded extent dims[3] of the field's data_loc.
+ * Rank-local values; the caller does the cross-rank reduction (the reference
+ * calls MPI_Allreduce inside: src/backend/omp/backend.f90:708, 805-808, 1063). */
+int x3d_scalar_product(x3d_backend *b, const double *x, const double *y, const int dims[3],
+                       double *out);
+int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double *max_abs,
+                      double *sum_abs);
+int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out);
+/* slice_max_sum (:252-271): plane i_slice (1-based) normal to `dir` */
+int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
+                      double *max_val, double *sum_val);
+
+/* ---- field_set_face / field_set_face_from_field (:293-337; omp :903-1021), Y_FACE and X_FACE */
+int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], double c_start, double c_end,
+                       int face);
+int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start,
+                                  const int dims[3], double c_end, int face,
+                                  double flow_rate_diff);
+
+/* ---- copy_data_to_f / copy_f_to_data via set/get_field_data
+ * (src/backend/backend.f90:402-466): host Cartesian array [nz][ny][nx]
+ * (x fastest, unpadded extents dims) <-> device block. */
+int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3]);
+int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3]);
+
+/* ---- init_poisson_fft (src/backend/backend.f90:374-389) + poisson_fft_t hooks
+ * (src/poisson_fft.f90:45-62).  Single-rank periodic (000) solver:
+ * cell dims n[3]; waves_re[nz][ny][nx/2+1] (host, real part = imaginary part,
+ * src/poisson_fft.f90:654-831); ax..bz host arrays of n[0], n[1], n[2]. */
+int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n[3], const double *waves_re,
+                       const double *ax, const double *bx, const double *ay, const double *by,
+                       const double *az, const double *bz);
+int x3d_poisson_destroy(x3d_poisson *p);
+int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);  /* fft_forward            */
+int x3d_poisson_postprocess_000(x3d_poisson *p);                  /* fft_postprocess_000    */
+int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);      /* fft_backward           */
+int x3d_poisson_solve_000(x3d_poisson *p, double *f);             /* poisson_000, :216-226  */
+/* test hook: download / upload the spectral workspace [nz][ny][nx/2+1] complex */
+int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
+int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
+
+/* ---- measurement support: HIP-event timing on the backend's stream */
+int x3d_timer_start(x3d_backend *b);
+int x3d_timer_stop_ms(x3d_backend *b, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X3D2_HIP_H */

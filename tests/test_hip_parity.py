@@ -1,0 +1,274 @@
+"""GPU parity tests proper: the HIP backend (through the C ABI) against
+ (a) golden vectors produced by the real reference (tests/golden/ref_*.npz/csv),
+ (b) the oracle restatement on the same seeded inputs.
+Tolerances are floating-point (FP64): stated per assertion."""
+import numpy as np
+import pytest
+
+from util import OPNAMES, load_golden, namelist, product_mesh, read_csv, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12  # relative, max-norm; reference-vs-HIP differences are re-association + FMA only
+
+
+def make_solver(g, poisson="CG"):
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.solver import Solver, SolverConfig
+    c = namelist(g)
+    mesh = product_mesh(c)
+    backend = HipBackend(mesh)
+    cfg = SolverConfig(Re=c["Re"], dt=c["dt"], time_intg=c["time_intg"], poisson_solver_type=poisson,
+                       interpl_scheme=c["interpl"], der2nd_scheme=c["der2nd"])
+    return Solver(backend, mesh, cfg)
+
+
+def set_inputs(s, g):
+    from x3d2_amd.common import VERT
+    for f, k in ((s.u, "in.u"), (s.v, "in.v"), (s.w, "in.w")):
+        f.set_data_loc(VERT)
+        s.backend.set_field_data(f, g[k])
+
+
+SINGLE = ["p000_rk3", "c010_rk3", "n111_rk2"]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_set_get_field_data_roundtrip(name):
+    g = load_golden(name)
+    s = make_solver(g)
+    set_inputs(s, g)
+    assert np.array_equal(s.backend.get_field_data(s.u), g["in.u"])
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_tds_solve_all_operators_all_directions(name):
+    """24 operators (8 per direction), incl. n_rhs = n_tds+1 and every closure"""
+    from x3d2_amd.common import DIR_X, VERT, move_data_loc
+    g = load_golden(name)
+    s = make_solver(g)
+    set_inputs(s, g)
+    b, al = s.backend, s.backend.allocator
+    for d, (dn, dp) in enumerate(zip("xyz", (s.xdirps, s.ydirps, s.zdirps)), 1):
+        for op in OPNAMES:
+            t = getattr(dp, op)
+            src = al.get_block(DIR_X, VERT)
+            b.veccopy(src, s.u)
+            if op.endswith("p2v"):
+                src.set_data_loc(move_data_loc(VERT, d, 1))
+            a, out = al.get_block(d), al.get_block(d)
+            if d == 1:
+                b.veccopy(a, src)
+                a.set_data_loc(src.data_loc)
+            else:
+                b.reorder(a, src, 10 + d)
+            b.tds_solve(out, a, t)
+            got = b.get_field_data(out)
+            ref = g[f"tds.{dn}.{op}"]
+            assert got.shape == ref.shape, (dn, op)
+            assert relerr(got, ref) < TOL, (dn, op, relerr(got, ref))
+            for f in (src, a, out):
+                al.release_block(f)
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_transeq_div_grad_curl_reductions(name):
+    from x3d2_amd.common import CELL, DIR_X, DIR_Z, VERT
+    g = load_golden(name)
+    s = make_solver(g)
+    set_inputs(s, g)
+    b, al = s.backend, s.backend.allocator
+    rhs = [al.get_block(DIR_X) for _ in range(3)]
+    s.transeq(rhs, [s.u, s.v, s.w])
+    for f, k in zip(rhs, ("du", "dv", "dw")):
+        assert f.data_loc == VERT
+        assert relerr(b.get_field_data(f), g["transeq." + k]) < TOL, k
+    b.transeq_x(*rhs, s.u, s.v, s.w, s.nu, s.xdirps)
+    for f, k in zip(rhs, ("du", "dv", "dw")):
+        assert relerr(b.get_field_data(f), g["transeq_x." + k]) < TOL, k
+    div_u = al.get_block(DIR_Z)
+    s.divergence_v2p(div_u, s.u, s.v, s.w)
+    assert div_u.data_loc == CELL
+    assert relerr(b.get_field_data(div_u), g["div.div_u"]) < TOL
+    mx, mean = b.field_max_mean(div_u)
+    assert abs(mx - g["div.max"][0]) <= 1e-12 * abs(mx)
+    assert abs(mean - g["div.mean"][0]) <= 1e-12 * abs(mean)
+    s.gradient_p2v(*rhs, div_u)
+    for f, k in zip(rhs, ("dpdx", "dpdy", "dpdz")):
+        assert f.data_loc == VERT
+        assert relerr(b.get_field_data(f), g["grad." + k]) < TOL, k
+    for f in rhs:
+        f.set_data_loc(VERT)
+    s.curl(*rhs, s.u, s.v, s.w)
+    for f, k in zip(rhs, "ijk"):
+        assert relerr(b.get_field_data(f), g["curl." + k]) < TOL, k
+    ens = 0.5 * sum(b.scalar_product(f, f) for f in rhs) / s.ngrid
+    assert abs(ens - g["curl.enstrophy"][0]) <= 1e-12 * abs(ens)
+
+
+@pytest.mark.parametrize("name", ["p000_rk3", "p000_ab3", "c010_rk3", "n111_rk2"])
+def test_time_integrator_two_steps(name):
+    from x3d2_amd.common import DIR_X
+    g = load_golden(name)
+    s = make_solver(g)
+    set_inputs(s, g)
+    b, al = s.backend, s.backend.allocator
+    ns = s.time_integrator.nstage
+    for it in range(1, 2 * ns + 1):
+        rhs = [al.get_block(DIR_X) for _ in range(3)]
+        s.transeq(rhs, [s.u, s.v, s.w])
+        s.time_integrator.step([s.u, s.v, s.w], rhs, s.dt)
+        for f in rhs:
+            al.release_block(f)
+        if it == ns:
+            for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+                assert relerr(b.get_field_data(f), g["step1." + k]) < TOL, k
+    for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+        assert relerr(b.get_field_data(f), g["step2." + k]) < TOL, k
+
+
+def test_spectral_postprocess_against_reference_kernel():
+    """process_spectral_000 in/out dumped from the reference's own kernel"""
+    g = load_golden("p000_rk3")
+    s = make_solver(g, poisson="FFT")
+    p = s.backend.poisson_fft
+    assert np.allclose(p.waves, g["spec.waves_re"], rtol=1e-13, atol=1e-14)
+    for k in ("ax", "bx", "ay", "by", "az", "bz"):
+        assert np.allclose(getattr(p, k), g["spec." + k], rtol=1e-14, atol=1e-16)
+    p.set_spectral(g["spec.in_re"] + 1j * g["spec.in_im"])
+    p.fft_postprocess_000()
+    ref = g["spec.out_re"] + 1j * g["spec.out_im"]
+    assert relerr(p.get_spectral(), ref) < 1e-13
+
+
+def test_fft_forward_backward_match_dft_definition():
+    """fft_forward = unnormalised r2c DFT (e^{-i}), fft_backward its unnormalised
+    inverse: the reference's tests/verification/test_fft.f90 property
+    (forward then backward == N * input, 1e-10) plus a direct comparison of the
+    spectrum with the DFT definition (numpy)."""
+    from x3d2_amd.common import CELL, DIR_C
+    g = load_golden("p000_rk3")
+    s = make_solver(g, poisson="FFT")
+    b, al, p = s.backend, s.backend.allocator, s.backend.poisson_fft
+    rng = np.random.default_rng(3)
+    nx, ny, nz = s.mesh.get_dims(CELL)
+    x = rng.standard_normal((nz, ny, nx))
+    f = al.get_block(DIR_C, CELL)
+    b.set_field_data(f, x)
+    p.fft_forward(f)
+    assert relerr(p.get_spectral(), np.fft.rfftn(x, axes=(0, 1, 2))) < 1e-13
+    p.fft_backward(f)
+    assert relerr(b.get_field_data(f) / x.size, x) < 1e-13
+
+
+def test_poisson_solve_against_oracle_and_projection():
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import DIR_Z, VERT
+    n = (48, 40, 56)
+    case = make_tgv(n)
+    s = case.solver
+    b, al = s.backend, s.backend.allocator
+    rng = np.random.default_rng(0)
+    data = [rng.standard_normal((n[2], n[1], n[0])) for _ in range(3)]
+    twopi = 6.283185307179586
+    om = orc.Mesh(list(n), [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
+    o = orc.Solver(om, poisson="FFT")
+    for f, of, d in zip((s.u, s.v, s.w), (o.u, o.v, o.w), data):
+        f.set_data_loc(VERT)
+        of.data_loc = orc.VERT
+        b.set_field_data(f, d)
+        o.backend.set_field_data(of, d)
+    s.pressure_correction(s.u, s.v, s.w)
+    o.pressure_correction(o.u, o.v, o.w)
+    for f, of in zip((s.u, s.v, s.w), (o.u, o.v, o.w)):
+        assert relerr(b.get_field_data(f), o.backend.get_field_data(of)) < 1e-11
+    div_u = al.get_block(DIR_Z)
+    s.divergence_v2p(div_u, s.u, s.v, s.w)
+    mx, _ = b.field_max_mean(div_u)
+    assert mx < 5e-12
+
+
+@pytest.mark.parametrize("name,intg", [("tgv32_rk3_nopoisson", "RK3"), ("tgv32_ab3_nopoisson", "AB3")])
+def test_tgv_trace_no_poisson_vs_reference_csv(name, intg):
+    """the reference's own xcompact monitoring.csv (32^3, Poisson off)"""
+    from x3d2_amd import make_tgv
+    ref = read_csv(name)
+    case = make_tgv(32, time_intg=intg, poisson="CG")
+    case.solver.n_output = 2
+    rows = np.array(case.run(n_iters=6))
+    assert np.allclose(rows[:, 1], ref[:, 1], rtol=1e-11)       # enstrophy
+    assert np.allclose(rows[1:, 2], ref[1:, 2], rtol=1e-9)      # max |div u|
+    assert np.allclose(rows[1:, 3], ref[1:, 3], rtol=1e-9)      # mean |div u|
+
+
+def test_tgv64_full_step_vs_survey_trace_and_oracle():
+    """TGV 64^3, RK3, FFT Poisson (BASELINE config 0): enstrophy at t = 0 and
+    0.01 recorded from the reference in SURVEY.md 8c (north-star tolerance:
+    1e-6 relative; observed ~1e-12), max|div u| at round-off."""
+    from x3d2_amd import make_tgv
+    case = make_tgv(64)
+    case.solver.n_output = 10
+    rows = case.run(n_iters=10)
+    assert abs(rows[0][1] - 3.749999996799e-01) / 0.375 < 1e-12
+    assert abs(rows[1][1] - 3.749898433321e-01) / 0.375 < 1e-11
+    assert rows[1][2] < 1e-12
+
+
+def test_blas1_reorder_faces():
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import DIR_X, DIR_Y, DIR_Z, RDR_X2Y, RDR_Y2Z, RDR_Z2X, VERT, Y_FACE
+    case = make_tgv((20, 12, 16), poisson="CG")
+    s = case.solver
+    b, al = s.backend, s.backend.allocator
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal((16, 12, 20)), rng.standard_normal((16, 12, 20))
+    fx, fy = al.get_block(DIR_X, VERT), al.get_block(DIR_X, VERT)
+    b.set_field_data(fx, x); b.set_field_data(fy, y)
+    b.vecadd(0.3, fx, -1.7, fy)                      # tests/unit/test_vecadd.f90
+    assert np.allclose(b.get_field_data(fy), 0.3 * x - 1.7 * y, rtol=1e-15, atol=1e-15)
+    b.vecmult(fy, fx)
+    assert np.allclose(b.get_field_data(fy), (0.3 * x - 1.7 * y) * x, rtol=1e-15, atol=1e-15)
+    b.field_scale(fy, 2.0); b.field_shift(fy, 0.5)
+    assert np.allclose(b.get_field_data(fy), 2.0 * (0.3 * x - 1.7 * y) * x + 0.5, rtol=1e-15, atol=1e-15)
+    # X -> Y -> Z -> X round trip (tests/unit/test_reordering.f90)
+    a, c, d = al.get_block(DIR_Y), al.get_block(DIR_Z), al.get_block(DIR_X)
+    b.reorder(a, fx, RDR_X2Y); b.reorder(c, a, RDR_Y2Z); b.reorder(d, c, RDR_Z2X)
+    assert d.data_loc == VERT and np.array_equal(b.get_field_data(d), x)
+    # sum_yintox (tests/unit/test_sum_intox.f90)
+    b.sum_yintox(d, a)
+    assert np.array_equal(b.get_field_data(d), 2 * x)
+    # scalar product / volume integral (tests/unit/test_scalar_product.f90)
+    assert abs(b.scalar_product(fx, fx) - np.sum(x * x)) < 1e-10
+    assert abs(b.field_volume_integral(fx) - x.sum()) < 1e-10
+    mx, sm = b.slice_max_sum(fx, 3)
+    assert mx == x[:, :, 2].max() and abs(sm - x[:, :, 2].sum()) < 1e-12
+    # lincomb extension == chained vecadd
+    b.set_field_data(fy, y)
+    b.lincomb(fy, fy, [0.25, -0.5], [fx, d])
+    assert np.allclose(b.get_field_data(fy), y + 0.25 * x - 0.5 * 2 * x, rtol=1e-15, atol=1e-15)
+    # faces
+    b.field_set_face(fx, 1.5, -2.5, Y_FACE)
+    got = b.get_field_data(fx)
+    assert np.all(got[:, 0, :] == 1.5) and np.all(got[:, -1, :] == -2.5)
+    assert np.array_equal(got[:, 1:-1, :], x[:, 1:-1, :])
+
+
+def test_error_behaviour_matches_reference():
+    """precondition failures the reference `error stop`s on"""
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import DIR_C, DIR_X, DIR_Y, X3dError
+    case = make_tgv((16, 16, 16), poisson="CG")
+    s = case.solver
+    b, al = s.backend, s.backend.allocator
+    fx, fy, fc = al.get_block(DIR_X), al.get_block(DIR_Y), al.get_block(DIR_C)
+    with pytest.raises(X3dError, match="DIR mismatch"):
+        b.tds_solve(fy, fx, s.xdirps.der1st)
+    with pytest.raises(X3dError, match="incompatible"):
+        b.vecadd(1.0, fx, 1.0, fy)
+    with pytest.raises(X3dError, match="DIR_C"):
+        b.vecadd(1.0, fc, 1.0, fc)
+    with pytest.raises(X3dError, match="data_loc"):
+        b.scalar_product(fx, fx)
+    with pytest.raises(X3dError):
+        b.transeq_y(fy, fy, fy, fy, fy, fy, s.nu, s.ydirps)  # NULL_LOC -> mesh%get_n stops

@@ -1,0 +1,109 @@
+"""ctypes binding of libx3d2_hip.so (the C ABI declared in include/x3d2_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this
+module never needs a GPU, but every compute entry point does."""
+import ctypes
+import os
+import subprocess
+
+from .common import X3dError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libx3d2_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+VP = ctypes.c_void_p
+I, D, SZT = ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); kept in step with include/x3d2_hip.h
+# (tests/test_abi.py parses the header and compares)
+PROTOTYPES = {
+    "x3d_last_error": (ctypes.c_char_p, []),
+    "x3d_abi_version": (I, []),
+    "x3d_backend_create": (I, [ctypes.POINTER(VP), c_int_p, I, VP]),
+    "x3d_backend_destroy": (I, [VP]),
+    "x3d_backend_set_stream": (I, [VP, VP]),
+    "x3d_block_elems": (SZT, [VP]),
+    "x3d_padded_dims": (I, [VP, c_int_p]),
+    "x3d_device_sync": (I, [VP]),
+    "x3d_block_alloc": (I, [VP, ctypes.POINTER(VP)]),
+    "x3d_block_free": (I, [VP, VP]),
+    "x3d_block_fill": (I, [VP, VP, D]),
+    "x3d_tdsops_create": (I, [VP, ctypes.POINTER(VP), I, I, I, I] + [c_double_p] * 10),
+    "x3d_tdsops_destroy": (I, [VP]),
+    "x3d_tds_solve": (I, [VP, VP, VP, VP, I]),
+    "x3d_npencils": (I, [VP, I]),
+    "x3d_pack_halos": (I, [VP, VP, VP, VP, I, I]),
+    "x3d_tds_dist_fwd": (I, [VP, VP, VP, VP, VP, VP, VP, VP, I]),
+    "x3d_tds_dist_bwd": (I, [VP, VP, VP, VP, VP, VP, I]),
+    "x3d_transeq": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP]),
+    "x3d_transeq_dist_fwd": (I, [VP, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "x3d_transeq_dist_bwd": (I, [VP, I, VP, VP, VP, VP, VP, D, VP, VP, VP]),
+    "x3d_reorder": (I, [VP, VP, VP, I]),
+    "x3d_sum_intox": (I, [VP, VP, VP, I]),
+    "x3d_veccopy": (I, [VP, VP, VP]),
+    "x3d_vecadd": (I, [VP, D, VP, D, VP]),
+    "x3d_vecmult": (I, [VP, VP, VP]),
+    "x3d_field_scale": (I, [VP, VP, D]),
+    "x3d_field_shift": (I, [VP, VP, D]),
+    "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
+    "x3d_scalar_product": (I, [VP, VP, VP, c_int_p, c_double_p]),
+    "x3d_field_max_sum": (I, [VP, VP, c_int_p, c_double_p, c_double_p]),
+    "x3d_field_volume_integral": (I, [VP, VP, c_int_p, c_double_p]),
+    "x3d_slice_max_sum": (I, [VP, VP, c_int_p, I, I, c_double_p, c_double_p]),
+    "x3d_field_set_face": (I, [VP, VP, c_int_p, D, D, I]),
+    "x3d_field_set_face_from_field": (I, [VP, VP, VP, c_int_p, D, I, D]),
+    "x3d_set_field_data": (I, [VP, VP, c_double_p, c_int_p]),
+    "x3d_get_field_data": (I, [VP, c_double_p, VP, c_int_p]),
+    "x3d_poisson_create": (I, [VP, ctypes.POINTER(VP), c_int_p] + [c_double_p] * 7),
+    "x3d_poisson_destroy": (I, [VP]),
+    "x3d_poisson_fft_forward": (I, [VP, VP]),
+    "x3d_poisson_postprocess_000": (I, [VP]),
+    "x3d_poisson_fft_backward": (I, [VP, VP]),
+    "x3d_poisson_solve_000": (I, [VP, VP]),
+    "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
+    "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
+    "x3d_timer_start": (I, [VP]),
+    "x3d_timer_stop_ms": (I, [VP, ctypes.POINTER(ctypes.c_float)]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """hipcc-compile every HIP source for gfx950 into x3d2_amd/libx3d2_hip.so
+    (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise X3dError("building libx3d2_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the HIP backend; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise X3dError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                       " (the HIP backend has no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing from the .so
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise X3dError(load().x3d_last_error().decode())
+
+
+def ints(*v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])

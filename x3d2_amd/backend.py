@@ -1,0 +1,326 @@
+"""hip_backend_t: the MI355X backend behind x3d2's operator interface.
+
+Mirrors the reference's abstract `base_backend_t`
+(/root/reference/src/backend/backend.f90:13-62) operation for operation --
+same names, argument order and meaning, same `data_loc` bookkeeping and the
+same precondition failures (raised instead of `error stop`) as the OpenMP
+implementation (src/backend/omp/backend.f90).  All arithmetic on field data
+happens in libx3d2_hip.so through the C ABI (include/x3d2_hip.h); this class
+only sequences calls and does the neighbour exchanges.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .common import (DIR_C, DIR_X, DIR_Y, DIR_Z, N_HALO, NULL_LOC, X_FACE, Y_FACE, Z_FACE, X3dError,
+                     get_rdr_from_dirs, move_data_loc)
+from .field import Allocator
+from .parallel import Comm
+from .tdsops import Tdsops
+
+VP = ctypes.c_void_p
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class HipBackend:
+    n_halo = N_HALO  # src/backend/backend.f90:28-29
+
+    def __init__(self, mesh, device=None, comm=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise X3dError("x3d2_amd: no HIP device available -- the HIP backend has no CPU path")
+        self.mesh = mesh
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        torch.cuda.set_device(self.device)
+        self.comm = comm if comm is not None else Comm()
+        self.stream = torch.cuda.current_stream(self.device)
+        h = VP()
+        dims = _lib.ints(*mesh.vert_dims)
+        _lib.check(self.lib.x3d_backend_create(ctypes.byref(h), dims, self.device.index,
+                                               VP(self.stream.cuda_stream)))
+        self.h = h
+        self.nblock = int(self.lib.x3d_block_elems(h))
+        pd = _lib.ints(0, 0, 0)
+        _lib.check(self.lib.x3d_padded_dims(h, pd))
+        self.padded_dims = tuple(pd)
+        self.allocator = Allocator(self.nblock, self.device)
+        self.poisson_fft = None
+        self._halo = {}
+        self._tdsops = []
+
+    def __del__(self):
+        try:
+            for t in self._tdsops:
+                self.lib.x3d_tdsops_destroy(t)
+            self.lib.x3d_backend_destroy(self.h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ helpers
+    def _dims(self, data_loc):
+        return _lib.ints(*self.mesh.get_dims(data_loc))
+
+    def _decomposed(self, direction):
+        return int(self.mesh.nproc_dir[direction - 1]) > 1
+
+    def _buffers(self, direction, rows, tag):
+        """exchange buffers [rows][npencil], cached per (dir, rows, tag)
+        (the reference sizes them once in the constructor,
+        src/backend/omp/backend.f90:84-112)"""
+        key = (direction, rows, tag)
+        if key not in self._halo:
+            npn = self.lib.x3d_npencils(self.h, direction)
+            self._halo[key] = tuple(torch.zeros(rows * npn, dtype=torch.float64, device=self.device)
+                                    for _ in range(4))
+        return self._halo[key]
+
+    def sync(self):
+        _lib.check(self.lib.x3d_device_sync(self.h))
+
+    # ------------------------------------------------------------ alloc_tdsops
+    def alloc_tdsops(self, n_tds, delta, operation, scheme, bc_start, bc_end, stretch=None,
+                     stretch_correct=None, n_halo=None, from_to=None, sym=None, c_nu=None, nu0_nu=None):
+        """src/backend/backend.f90:352-372: host factory + device copy"""
+        t = Tdsops(n_tds, delta, operation, scheme, bc_start, bc_end, stretch, stretch_correct, n_halo,
+                   from_to, sym, c_nu, nu0_nu)
+        h = VP()
+        cs = np.ascontiguousarray(t.coeffs_s.reshape(-1))
+        ce = np.ascontiguousarray(t.coeffs_e.reshape(-1))
+        _lib.check(self.lib.x3d_tdsops_create(
+            self.h, ctypes.byref(h), t.n_tds, t.n_rhs, t.move, int(t.periodic), _dp(t.coeffs), _dp(cs),
+            _dp(ce), _dp(t.dist_fw), _dp(t.dist_bw), _dp(t.dist_sa), _dp(t.dist_sc), _dp(t.dist_af),
+            _dp(t.stretch), _dp(t.stretch_correct)))
+        t.handle = h
+        self._tdsops.append(h)
+        return t
+
+    # ------------------------------------------------------------ transeq
+    def transeq_x(self, du, dv, dw, u, v, w, nu, dirps):
+        self._transeq(DIR_X, du, dv, dw, u, v, w, nu, dirps)
+
+    def transeq_y(self, du, dv, dw, u, v, w, nu, dirps):
+        self._transeq(DIR_Y, du, dv, dw, u, v, w, nu, dirps)
+
+    def transeq_z(self, du, dv, dw, u, v, w, nu, dirps):
+        self._transeq(DIR_Z, du, dv, dw, u, v, w, nu, dirps)
+
+    def _transeq(self, direction, du, dv, dw, u, v, w, nu, dirps):
+        if dirps.dir != direction:
+            raise X3dError("transeq: dirps%dir does not match the call")
+        # mesh%get_n error-stops on NULL_LOC (src/mesh.f90:274-305); it is
+        # evaluated by transeq_halo_exchange (src/backend/omp/backend.f90:272)
+        self.mesh.get_n(direction, u.data_loc)
+        if not self._decomposed(direction):
+            _lib.check(self.lib.x3d_transeq(self.h, direction, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr,
+                                            float(nu), dirps.der1st.handle, dirps.der1st_sym.handle,
+                                            dirps.der2nd.handle, dirps.der2nd_sym.handle))
+        else:
+            self._transeq_dist(direction, du, dv, dw, u, v, w, nu, dirps)
+        for r in (du, dv, dw):
+            r.set_data_loc(u.data_loc)  # :333
+
+    def _transeq_dist(self, direction, du, dv, dw, u, v, w, nu, dirps):
+        """transeq_omp_dist with the permutation of :145-184"""
+        if direction == DIR_X:
+            rhs, fld = (du, dv, dw), (u, v, w)
+        elif direction == DIR_Y:
+            rhs, fld = (dv, du, dw), (v, u, w)
+        else:
+            rhs, fld = (dw, du, dv), (w, u, v)
+        d = direction - 1
+        prev, nxt = int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
+        n = self.mesh.get_n(direction, u.data_loc)
+        halos = []
+        pairs = []
+        for i, f in enumerate(fld):  # transeq_halo_exchange, :264-297
+            ss, se, rs, re = self._buffers(direction, N_HALO, "u%d" % i)
+            _lib.check(self.lib.x3d_pack_halos(self.h, ss.data_ptr(), se.data_ptr(), f.ptr, n, direction))
+            pairs.append((ss, se, rs, re))
+            halos.append((rs, re))
+        self.stream.synchronize()
+        self.comm.sendrecv(pairs, prev, nxt)
+        ops = [(dirps.der1st, dirps.der1st_sym, dirps.der2nd),
+               (dirps.der1st_sym, dirps.der1st, dirps.der2nd_sym),
+               (dirps.der1st_sym, dirps.der1st, dirps.der2nd_sym)]
+        bs, be, brs, bre = self._buffers(direction, 3, "b")
+        for i in range(3):
+            t_du, t_dud, t_d2u = ops[i]
+            _lib.check(self.lib.x3d_transeq_dist_fwd(
+                self.h, direction, rhs[i].ptr, bs.data_ptr(), be.data_ptr(), fld[i].ptr,
+                halos[i][0].data_ptr(), halos[i][1].data_ptr(), fld[0].ptr, halos[0][0].data_ptr(),
+                halos[0][1].data_ptr(), t_du.handle, t_dud.handle, t_d2u.handle))
+            self.stream.synchronize()
+            self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
+            _lib.check(self.lib.x3d_transeq_dist_bwd(
+                self.h, direction, rhs[i].ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), fld[0].ptr,
+                float(nu), t_du.handle, t_dud.handle, t_d2u.handle))
+
+    # ------------------------------------------------------------ tds_solve
+    def tds_solve(self, du, u, tdsops):
+        """src/backend/omp/backend.f90:340-391"""
+        if u.dir != du.dir:
+            raise X3dError("DIR mismatch between fields in tds_solve.")
+        if u.data_loc != NULL_LOC:
+            du.set_data_loc(move_data_loc(u.data_loc, u.dir, tdsops.move))
+        direction = u.dir
+        if direction == DIR_C:
+            raise X3dError("tds_solve needs a directional field")
+        if not self._decomposed(direction):
+            _lib.check(self.lib.x3d_tds_solve(self.h, du.ptr, u.ptr, tdsops.handle, direction))
+            return
+        d = direction - 1
+        prev, nxt = int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
+        ss, se, rs, re = self._buffers(direction, N_HALO, "u0")
+        _lib.check(self.lib.x3d_pack_halos(self.h, ss.data_ptr(), se.data_ptr(), u.ptr, tdsops.n_tds,
+                                           direction))
+        self.stream.synchronize()
+        self.comm.sendrecv([(ss, se, rs, re)], prev, nxt)
+        bs, be, brs, bre = self._buffers(direction, 1, "b1")
+        _lib.check(self.lib.x3d_tds_dist_fwd(self.h, du.ptr, bs.data_ptr(), be.data_ptr(), u.ptr,
+                                             rs.data_ptr(), re.data_ptr(), tdsops.handle, direction))
+        self.stream.synchronize()
+        self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
+        _lib.check(self.lib.x3d_tds_dist_bwd(self.h, du.ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(),
+                                             tdsops.handle, direction))
+
+    # ------------------------------------------------------------ reorder / sums
+    def reorder(self, u_, u, direction):
+        """src/backend/omp/backend.f90:393-452"""
+        dir_from, dir_to = direction // 10, direction % 10
+        if u.dir != dir_from or u_.dir != dir_to:
+            raise X3dError("reorder: field directions do not match the reorder code")
+        _lib.check(self.lib.x3d_reorder(self.h, u_.ptr, u.ptr, int(direction)))
+        u_.set_data_loc(u.data_loc)  # :449-450
+
+    def sum_yintox(self, u, u_):
+        if u.dir != DIR_X or u_.dir != DIR_Y:
+            raise X3dError("sum_yintox: u must be DIR_X and u_ DIR_Y")
+        _lib.check(self.lib.x3d_sum_intox(self.h, u.ptr, u_.ptr, DIR_Y))
+
+    def sum_zintox(self, u, u_):
+        if u.dir != DIR_X or u_.dir != DIR_Z:
+            raise X3dError("sum_zintox: u must be DIR_X and u_ DIR_Z")
+        _lib.check(self.lib.x3d_sum_intox(self.h, u.ptr, u_.ptr, DIR_Z))
+
+    # ------------------------------------------------------------ BLAS-1
+    def veccopy(self, dst, src):
+        if src.dir != dst.dir:
+            raise X3dError("Called vector copy with incompatible fields")
+        if dst.dir == DIR_C:
+            raise X3dError("veccopy does not support DIR_C fields")
+        _lib.check(self.lib.x3d_veccopy(self.h, dst.ptr, src.ptr))
+
+    def vecadd(self, a, x, b, y):
+        if x.dir != y.dir:
+            raise X3dError("Called vector add with incompatible fields")
+        if y.dir == DIR_C:
+            raise X3dError("vecadd does not support DIR_C fields")
+        _lib.check(self.lib.x3d_vecadd(self.h, float(a), x.ptr, float(b), y.ptr))
+
+    def vecmult(self, y, x):
+        if x.dir != y.dir:
+            raise X3dError("Called vector multiply with incompatible fields")
+        if y.dir == DIR_C:
+            raise X3dError("vecmult does not support DIR_C fields")
+        _lib.check(self.lib.x3d_vecmult(self.h, y.ptr, x.ptr))
+
+    def field_scale(self, f, a):
+        _lib.check(self.lib.x3d_field_scale(self.h, f.ptr, float(a)))
+
+    def field_shift(self, f, a):
+        _lib.check(self.lib.x3d_field_shift(self.h, f.ptr, float(a)))
+
+    def lincomb(self, y, base, coeffs, xs):
+        """extension: y = base + sum c_i x_i in one pass (time-integrator fusion)"""
+        n = len(xs)
+        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        p = (VP * n)(*[x.ptr for x in xs])
+        _lib.check(self.lib.x3d_lincomb(self.h, y.ptr, base.ptr, n, c, p))
+
+    # ------------------------------------------------------------ reductions
+    def scalar_product(self, x, y):
+        """src/backend/omp/backend.f90:651-712"""
+        if x.data_loc == NULL_LOC or y.data_loc == NULL_LOC:
+            raise X3dError("You must set the data_loc before calling scalar product")
+        if x.data_loc != y.data_loc:
+            raise X3dError("Called scalar product with incompatible fields")
+        out = ctypes.c_double()
+        _lib.check(self.lib.x3d_scalar_product(self.h, x.ptr, y.ptr, self._dims(x.data_loc), ctypes.byref(out)))
+        return self.comm.allreduce(out.value, "sum")
+
+    def field_max_mean(self, f, enforced_data_loc=None):
+        """returns (max_val, mean_val), src/backend/omp/backend.f90:739-810"""
+        if f.data_loc == NULL_LOC and enforced_data_loc is None:
+            raise X3dError("The input field to field_max_mean does not have a valid f%data_loc.")
+        loc = f.data_loc if enforced_data_loc is None else enforced_data_loc
+        if f.dir == DIR_C:
+            raise X3dError("field_max_mean does not support DIR_C fields!")
+        mx, sm = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self.lib.x3d_field_max_sum(self.h, f.ptr, self._dims(loc), ctypes.byref(mx), ctypes.byref(sm)))
+        nglob = float(np.prod(self.mesh.get_global_dims(loc)))
+        return self.comm.allreduce(mx.value, "max"), self.comm.allreduce(sm.value / nglob, "sum")
+
+    def slice_max_sum(self, f, i_slice, enforced_data_loc=None):
+        """rank-local (max, sum); the caller reduces (src/backend/omp/backend.f90:812-872)"""
+        if f.data_loc == NULL_LOC and enforced_data_loc is None:
+            raise X3dError("The input field to slice_max_sum does not have a valid f%data_loc.")
+        loc = f.data_loc if enforced_data_loc is None else enforced_data_loc
+        mx, sm = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self.lib.x3d_slice_max_sum(self.h, f.ptr, self._dims(loc), f.dir, int(i_slice),
+                                              ctypes.byref(mx), ctypes.byref(sm)))
+        return mx.value, sm.value
+
+    def field_volume_integral(self, f):
+        if f.data_loc == NULL_LOC:
+            raise X3dError("You must set the data_loc before calling volume integral.")
+        if f.dir != DIR_X:
+            raise X3dError("Volume integral can only be called on DIR_X fields.")
+        out = ctypes.c_double()
+        _lib.check(self.lib.x3d_field_volume_integral(self.h, f.ptr, self._dims(f.data_loc), ctypes.byref(out)))
+        return self.comm.allreduce(out.value, "sum")
+
+    # ------------------------------------------------------------ faces
+    def field_set_face(self, f, c_start, c_end, face):
+        if f.dir != DIR_X:
+            raise X3dError("Setting a field face is only supported for DIR_X fields.")
+        if f.data_loc == NULL_LOC:
+            raise X3dError("field_set_face require a valid data_loc.")
+        _lib.check(self.lib.x3d_field_set_face(self.h, f.ptr, self._dims(f.data_loc), float(c_start),
+                                               float(c_end), int(face)))
+
+    def field_set_face_from_field(self, f, f_start, c_end, face, flow_rate_diff=0.0):
+        if f.dir != DIR_X:
+            raise X3dError("field_set_face_from_field: only supported for DIR_X fields.")
+        if f.data_loc == NULL_LOC:
+            raise X3dError("field_set_face_from_field: requires a valid data_loc.")
+        _lib.check(self.lib.x3d_field_set_face_from_field(self.h, f.ptr, f_start.ptr, self._dims(f.data_loc),
+                                                          float(c_end), int(face), float(flow_rate_diff)))
+
+    # ------------------------------------------------------------ host <-> field
+    def set_field_data(self, f, data, loc=None):
+        """src/backend/backend.f90:436-466.  data: numpy [nz, ny, nx] (x fastest);
+        the extent is that of loc (default: f%data_loc, VERT if unset)."""
+        loc = (f.data_loc if f.data_loc != NULL_LOC else 0) if loc is None else loc
+        nx, ny, nz = self.mesh.get_dims(loc)
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        if a.shape != (nz, ny, nx):
+            raise X3dError(f"set_field_data: array shape {a.shape} != {(nz, ny, nx)}")
+        _lib.check(self.lib.x3d_set_field_data(self.h, f.ptr, _dp(a), _lib.ints(nx, ny, nz)))
+
+    def get_field_data(self, f, loc=None):
+        loc = (f.data_loc if f.data_loc != NULL_LOC else 0) if loc is None else loc
+        nx, ny, nz = self.mesh.get_dims(loc)
+        out = np.empty((nz, ny, nx), dtype=np.float64)
+        _lib.check(self.lib.x3d_get_field_data(self.h, _dp(out), f.ptr, _lib.ints(nx, ny, nz)))
+        return out
+
+    # ------------------------------------------------------------ Poisson
+    def init_poisson_fft(self, mesh, xdirps, ydirps, zdirps, lowmem=None):
+        from .poisson_fft import HipPoissonFFT
+        self.poisson_fft = HipPoissonFFT(self, mesh, xdirps, ydirps, zdirps)
+        return self.poisson_fft

@@ -1,0 +1,539 @@
+// Backend context, block storage, tdsops device tables, BLAS-1 field ops,
+// reductions, face setters and host<->device field copies.
+//
+// Reference behaviour mirrored here (paths under /root/reference):
+//   src/backend/omp/backend.f90:66-114 (constructor), :529-614 (vec ops),
+//   :651-712 (scalar_product), :739-810 (field_max_mean), :812-872
+//   (slice_max_sum), :874-901 (scale/shift), :903-1021 (face setters),
+//   :1023-1066 (volume integral), src/backend/backend.f90:402-466
+//   (get/set_field_data), src/allocator.f90:64-93 (padding).
+#include "common.h"
+
+#include <cmath>
+
+static thread_local char g_err[512] = "";
+
+void x3d_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *x3d_last_error(void) { return g_err; }
+extern "C" int x3d_abi_version(void) { return 1; }
+
+PencilGeom x3d_geom(const x3d_backend *b, int dir)
+{
+    PencilGeom g;
+    const long nxp = b->nxp, nyp = b->nyp;
+    switch (dir) {
+    case X3D_DIR_X:  // pencil (y,z): lanes run over y
+        g.np = b->ny * b->nz; g.dim0 = b->ny; g.s0 = nxp; g.s1 = nxp * nyp; g.rs = 1; break;
+    case X3D_DIR_Y:  // pencil (x,z): lanes run over x
+        g.np = b->nx * b->nz; g.dim0 = b->nx; g.s0 = 1; g.s1 = nxp * nyp; g.rs = nxp; break;
+    default:         // DIR_Z, pencil (x,y)
+        g.np = b->nx * b->ny; g.dim0 = b->nx; g.s0 = 1; g.s1 = nxp; g.rs = nxp * nyp; break;
+    }
+    return g;
+}
+
+extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream)
+{
+    X3D_REQUIRE(out && dims_vert, "x3d_backend_create: null argument");
+    X3D_REQUIRE(dims_vert[0] > 0 && dims_vert[1] > 0 && dims_vert[2] > 0,
+                "x3d_backend_create: dims must be positive");
+    int ndev = 0;
+    X3D_HIP(hipGetDeviceCount(&ndev));
+    X3D_REQUIRE(ndev > 0, "x3d_backend_create: no HIP device visible (the HIP backend has no CPU path)");
+    X3D_REQUIRE(device >= 0 && device < ndev, "x3d_backend_create: device %d out of range", device);
+    X3D_HIP(hipSetDevice(device));
+    x3d_backend *b = new x3d_backend();
+    memset(b, 0, sizeof *b);
+    b->device = device;
+    b->stream = (hipStream_t)stream;
+    b->nx = dims_vert[0]; b->ny = dims_vert[1]; b->nz = dims_vert[2];
+    b->nxp = (b->nx + 15) / 16 * 16;
+    b->nyp = b->ny;
+    b->nzp = b->nz;
+    b->nblock = (size_t)b->nxp * b->nyp * b->nzp;
+    int npmax = b->ny * b->nz;
+    if (b->nx * b->nz > npmax) npmax = b->nx * b->nz;
+    if (b->nx * b->ny > npmax) npmax = b->nx * b->ny;
+    X3D_HIP(hipMalloc(&b->send_s, sizeof(double) * 3 * (size_t)npmax));
+    X3D_HIP(hipMalloc(&b->send_e, sizeof(double) * 3 * (size_t)npmax));
+    for (int i = 0; i < 2; i++) X3D_HIP(hipMalloc(&b->scratch[i], sizeof(double) * b->nblock));
+    b->red_cap = 4096;
+    X3D_HIP(hipMalloc(&b->red_buf, sizeof(double) * 2 * b->red_cap));
+    X3D_HIP(hipHostMalloc(&b->red_host, sizeof(double) * 2 * b->red_cap));
+    X3D_HIP(hipEventCreate(&b->ev0));
+    X3D_HIP(hipEventCreate(&b->ev1));
+    *out = b;
+    return 0;
+}
+
+extern "C" int x3d_backend_destroy(x3d_backend *b)
+{
+    if (!b) return 0;
+    hipFree(b->send_s); hipFree(b->send_e);
+    hipFree(b->scratch[0]); hipFree(b->scratch[1]);
+    hipFree(b->red_buf); hipHostFree(b->red_host);
+    hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+    delete b;
+    return 0;
+}
+
+extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)
+{
+    X3D_REQUIRE(b, "null backend");
+    b->stream = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" size_t x3d_block_elems(const x3d_backend *b) { return b ? b->nblock : 0; }
+
+extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])
+{
+    X3D_REQUIRE(b && d, "null argument");
+    d[0] = b->nxp; d[1] = b->nyp; d[2] = b->nzp;
+    return 0;
+}
+
+extern "C" int x3d_device_sync(x3d_backend *b)
+{
+    X3D_REQUIRE(b, "null backend");
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int x3d_block_alloc(x3d_backend *b, double **out)
+{
+    X3D_REQUIRE(b && out, "null argument");
+    X3D_HIP(hipMalloc(out, sizeof(double) * b->nblock));
+    return 0;
+}
+
+extern "C" int x3d_block_free(x3d_backend *b, double *p)
+{
+    (void)b;
+    X3D_HIP(hipFree(p));
+    return 0;
+}
+
+// ---------------------------------------------------------------- BLAS-1
+// Whole padded blocks, like the reference (src/backend/omp/backend.f90:545-557):
+// streaming, 16 B per lane, grid-stride over at most 2048 workgroups.
+template <class F>
+__global__ void __launch_bounds__(256) k_map2(double2 *__restrict__ y, const double2 *__restrict__ x,
+                                              size_t n2, F f)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += st) {
+        double2 a = x[i], c = y[i];
+        c.x = f(a.x, c.x);
+        c.y = f(a.y, c.y);
+        y[i] = c;
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_map1(double2 *__restrict__ y, size_t n2, F f)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += st) {
+        double2 c = y[i];
+        c.x = f(c.x);
+        c.y = f(c.y);
+        y[i] = c;
+    }
+}
+
+static inline int stream_grid(size_t n2)
+{
+    size_t g = (n2 + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g ? g : 1));
+}
+
+struct OpCopy { __device__ double operator()(double x, double) const { return x; } };
+struct OpAxpby { double a, b; __device__ double operator()(double x, double y) const { return a * x + b * y; } };
+struct OpMul { __device__ double operator()(double x, double y) const { return y * x; } };
+struct OpAdd { __device__ double operator()(double x, double y) const { return y + x; } };
+struct OpScale { double a; __device__ double operator()(double y) const { return a * y; } };
+struct OpShift { double a; __device__ double operator()(double y) const { return y + a; } };
+struct OpFill { double a; __device__ double operator()(double) const { return a; } };
+
+extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
+{
+    X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+
+extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
+{
+    X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map2<OpAxpby>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
+                       (const double2 *)x, n2, OpAxpby{a, bb});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
+{
+    X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map2<OpMul>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
+                       (const double2 *)x, n2, OpMul{});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
+{
+    X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map1<OpScale>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+                       OpScale{a});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
+{
+    X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map1<OpShift>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+                       OpShift{a});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
+{
+    X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map1<OpFill>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+                       OpFill{c});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// reorder: every DIR_* tag shares one physical layout -> a device copy.
+// (reference: src/backend/omp/backend.f90:393-452; codes src/common.f90:23-26)
+extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
+{
+    X3D_REQUIRE(b && u_ && u, "x3d_reorder: null argument");
+    int from = rdr / 10, to = rdr % 10;
+    X3D_REQUIRE(from >= 1 && from <= 4 && to >= 1 && to <= 4 && from != to,
+                "x3d_reorder: invalid reorder code %d", rdr);
+    if (u_ == u) return 0;
+    X3D_HIP(hipMemcpyAsync(u_, u, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+
+// sum_yintox / sum_zintox: u += u_ (src/backend/omp/backend.f90:454-527)
+extern "C" int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from)
+{
+    X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
+    X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_map2<OpAdd>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)u,
+                       (const double2 *)u_, n2, OpAdd{});
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// y = base + sum_i c[i] * x[i]  (one pass instead of a veccopy/vecadd chain)
+struct LinArgs {
+    const double2 *x[5];
+    double c[5];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_lincomb(double2 *__restrict__ y, const double2 *base, size_t n2,
+                                                 LinArgs a)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += st) {
+        double2 r = base[i];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (k < a.n) {
+                double2 v = a.x[k][i];
+                r.x = a.c[k] * v.x + r.x;
+                r.y = a.c[k] * v.y + r.y;
+            }
+        y[i] = r;
+    }
+}
+
+extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
+                           const double *const *x)
+{
+    X3D_REQUIRE(b && y && base && c && x, "x3d_lincomb: null argument");
+    X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_lincomb: nterm must be 1..5");
+    LinArgs a;
+    a.n = nterm;
+    for (int k = 0; k < 5; k++) {
+        a.x[k] = (const double2 *)(k < nterm ? x[k] : x[0]);
+        a.c[k] = k < nterm ? c[k] : 0.0;
+    }
+    size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_lincomb, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
+                       (const double2 *)base, n2, a);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- reductions
+// Two-stage, deterministic: per-workgroup partials in a fixed order, final
+// sum on the host in index order (no atomics -> bitwise reproducible).
+enum { RED_DOT = 0, RED_ABS = 1, RED_SUM = 2 };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_reduce(const double *__restrict__ x, const double *__restrict__ y,
+                                                int nx, int ny, int nz, long nxp, long nyp,
+                                                double *__restrict__ part_sum,
+                                                double *__restrict__ part_max)
+{
+    __shared__ double ssum[4], smax[4];
+    double s = 0.0, m = 0.0;
+    const long nrow = (long)ny * nz;
+    for (long r = blockIdx.x; r < nrow; r += gridDim.x) {
+        const long j = r % ny, k = r / ny;
+        const long off = nxp * (j + nyp * k);
+        for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+            double v = x[off + i];
+            if (MODE == RED_DOT) s += v * y[off + i];
+            else if (MODE == RED_ABS) { v = fabs(v); s += v; m = fmax(m, v); }
+            else s += v;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        m = fmax(m, __shfl_down(m, o));
+    }
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (ln == 0) { ssum[wv] = s; smax[wv] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        part_max[blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
+}
+
+template <int MODE>
+static int run_reduce(x3d_backend *b, const double *x, const double *y, const int dims[3], double *sum,
+                      double *mx)
+{
+    X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 &&
+                    dims[2] <= b->nzp,
+                "reduction: dims (%d,%d,%d) outside the block", dims[0], dims[1], dims[2]);
+    long nrow = (long)dims[1] * dims[2];
+    int grid = (int)(nrow < 2048 ? nrow : 2048);
+    hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(256), 0, b->stream, x, y, dims[0], dims[1], dims[2],
+                       (long)b->nxp, (long)b->nyp, b->red_buf, b->red_buf + b->red_cap);
+    X3D_HIP(hipGetLastError());
+    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(double) * 2 * b->red_cap, hipMemcpyDeviceToHost,
+                           b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    double s = 0.0, m = 0.0;
+    for (int i = 0; i < grid; i++) {
+        s += b->red_host[i];
+        m = fmax(m, b->red_host[b->red_cap + i]);
+    }
+    if (sum) *sum = s;
+    if (mx) *mx = m;
+    return 0;
+}
+
+extern "C" int x3d_scalar_product(x3d_backend *b, const double *x, const double *y, const int dims[3],
+                                  double *out)
+{
+    X3D_REQUIRE(b && x && y && dims && out, "x3d_scalar_product: null argument");
+    return run_reduce<RED_DOT>(b, x, y, dims, out, nullptr);
+}
+
+extern "C" int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double *max_abs,
+                                 double *sum_abs)
+{
+    X3D_REQUIRE(b && f && dims && max_abs && sum_abs, "x3d_field_max_sum: null argument");
+    return run_reduce<RED_ABS>(b, f, f, dims, sum_abs, max_abs);
+}
+
+extern "C" int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out)
+{
+    X3D_REQUIRE(b && f && dims && out, "x3d_field_volume_integral: null argument");
+    return run_reduce<RED_SUM>(b, f, f, dims, out, nullptr);
+}
+
+// slice_max_sum: signed max and sum over the plane i_slice of direction dir
+__global__ void __launch_bounds__(256) k_slice(const double *__restrict__ f, int n0, int n1, long s0, long s1,
+                                               long off, double *__restrict__ part_sum,
+                                               double *__restrict__ part_max)
+{
+    __shared__ double ssum[4], smax[4];
+    double s = 0.0, m = -HUGE_VAL;
+    const long n = (long)n0 * n1;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        double v = f[off + (q % n0) * s0 + (q / n0) * s1];
+        s += v;
+        m = fmax(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        m = fmax(m, __shfl_down(m, o));
+    }
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (ln == 0) { ssum[wv] = s; smax[wv] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        part_max[blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
+}
+
+extern "C" int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
+                                 double *max_val, double *sum_val)
+{
+    X3D_REQUIRE(b && f && dims && max_val && sum_val, "x3d_slice_max_sum: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "slice_max_sum does not support DIR_C fields!");
+    X3D_REQUIRE(i_slice >= 1 && i_slice <= dims[dir - 1], "slice_max_sum: i_slice out of range");
+    const long nxp = b->nxp, nyp = b->nyp;
+    int n0, n1; long s0, s1, off;
+    if (dir == X3D_DIR_X) { n0 = dims[1]; n1 = dims[2]; s0 = nxp; s1 = nxp * nyp; off = i_slice - 1; }
+    else if (dir == X3D_DIR_Y) { n0 = dims[0]; n1 = dims[2]; s0 = 1; s1 = nxp * nyp; off = nxp * (i_slice - 1); }
+    else { n0 = dims[0]; n1 = dims[1]; s0 = 1; s1 = nxp; off = nxp * nyp * (i_slice - 1); }
+    long n = (long)n0 * n1;
+    int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_slice, dim3(grid), dim3(256), 0, b->stream, f, n0, n1, s0, s1, off, b->red_buf,
+                       b->red_buf + b->red_cap);
+    X3D_HIP(hipGetLastError());
+    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(double) * 2 * b->red_cap, hipMemcpyDeviceToHost,
+                           b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    double s = 0.0, m = -HUGE_VAL;
+    for (int i = 0; i < grid; i++) {
+        s += b->red_host[i];
+        m = fmax(m, b->red_host[b->red_cap + i]);
+    }
+    *max_val = m;
+    *sum_val = s;
+    return 0;
+}
+
+// ---------------------------------------------------------------- faces
+// field_set_face(Y_FACE): plane y=1 <- c_start, plane y=ny <- c_end
+// (src/backend/omp/backend.f90:903-952; only Y_FACE is supported there).
+__global__ void k_set_face_y(double *__restrict__ f, const double *__restrict__ src, int nx, int ny, int nz,
+                             long nxp, long nyp, double c_start, double c_end, int from_field)
+{
+    long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (q >= (long)nx * nz) return;
+    long i = q % nx, k = q / nx;
+    long lo = i + nxp * (0 + nyp * k), hi = i + nxp * ((ny - 1) + nyp * k);
+    f[lo] = from_field ? src[lo] : c_start;
+    f[hi] = from_field ? src[hi] : c_end;
+}
+
+// field_set_face_from_field(X_FACE): inflow plane from f_start, convective
+// outflow at x = nx (src/backend/omp/backend.f90:978-1003)
+__global__ void k_set_face_x_from(double *__restrict__ f, const double *__restrict__ src, int nx, int ny,
+                                  int nz, long nxp, long nyp, double c_end, double frd)
+{
+    long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (q >= (long)ny * nz) return;
+    long j = q % ny, k = q / ny;
+    long row = nxp * (j + nyp * k);
+    f[row] = src[row];
+    double fd = f[row + nx - 1], fd1 = f[row + nx - 2];
+    f[row + nx - 1] = fd - c_end * (fd - fd1) + frd;
+}
+
+extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], double c_start, double c_end,
+                                  int face)
+{
+    X3D_REQUIRE(b && f && dims, "x3d_field_set_face: null argument");
+    X3D_REQUIRE(face != X3D_X_FACE, "Setting X_FACE is not yet supported.");
+    X3D_REQUIRE(face != X3D_Z_FACE, "Setting Z_FACE is not yet supported.");
+    X3D_REQUIRE(face == X3D_Y_FACE, "face is undefined.");
+    long n = (long)dims[0] * dims[2];
+    hipLaunchKernelGGL(k_set_face_y, dim3((n + 255) / 256), dim3(256), 0, b->stream, f, (const double *)nullptr,
+                       dims[0], dims[1], dims[2], (long)b->nxp, (long)b->nyp, c_start, c_end, 0);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
+                                             double c_end, int face, double flow_rate_diff)
+{
+    X3D_REQUIRE(b && f && f_start && dims, "x3d_field_set_face_from_field: null argument");
+    if (face == X3D_Y_FACE) {
+        long n = (long)dims[0] * dims[2];
+        hipLaunchKernelGGL(k_set_face_y, dim3((n + 255) / 256), dim3(256), 0, b->stream, f, f_start, dims[0],
+                           dims[1], dims[2], (long)b->nxp, (long)b->nyp, 0.0, 0.0, 1);
+    } else if (face == X3D_X_FACE) {
+        long n = (long)dims[1] * dims[2];
+        hipLaunchKernelGGL(k_set_face_x_from, dim3((n + 255) / 256), dim3(256), 0, b->stream, f, f_start,
+                           dims[0], dims[1], dims[2], (long)b->nxp, (long)b->nyp, c_end, flow_rate_diff);
+    } else {
+        X3D_REQUIRE(false, "field_set_face_from_field: only X_FACE and Y_FACE supported.");
+    }
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- host <-> field
+extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3])
+{
+    X3D_REQUIRE(b && f && host && dims, "x3d_set_field_data: null argument");
+    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp,
+                "x3d_set_field_data: dims exceed the block");
+    hipMemcpy3DParms p;
+    memset(&p, 0, sizeof p);
+    p.srcPtr = make_hipPitchedPtr((void *)host, sizeof(double) * dims[0], dims[0], dims[1]);
+    p.dstPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
+    p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
+    p.kind = hipMemcpyHostToDevice;
+    X3D_HIP(hipMemcpy3DAsync(&p, b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3])
+{
+    X3D_REQUIRE(b && f && host && dims, "x3d_get_field_data: null argument");
+    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp,
+                "x3d_get_field_data: dims exceed the block");
+    hipMemcpy3DParms p;
+    memset(&p, 0, sizeof p);
+    p.srcPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
+    p.dstPtr = make_hipPitchedPtr((void *)host, sizeof(double) * dims[0], dims[0], dims[1]);
+    p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
+    p.kind = hipMemcpyDeviceToHost;
+    X3D_HIP(hipMemcpy3DAsync(&p, b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- timing
+extern "C" int x3d_timer_start(x3d_backend *b)
+{
+    X3D_REQUIRE(b, "null backend");
+    X3D_HIP(hipEventRecord(b->ev0, b->stream));
+    return 0;
+}
+
+extern "C" int x3d_timer_stop_ms(x3d_backend *b, float *ms)
+{
+    X3D_REQUIRE(b && ms, "null argument");
+    X3D_HIP(hipEventRecord(b->ev1, b->stream));
+    X3D_HIP(hipEventSynchronize(b->ev1));
+    X3D_HIP(hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return 0;
+}

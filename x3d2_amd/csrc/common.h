@@ -1,0 +1,87 @@
+// Internal definitions shared by the HIP translation units of libx3d2_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/x3d2_hip.h"
+
+#define X3D_NH 4
+
+void x3d_set_error(const char *fmt, ...);
+
+#define X3D_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            x3d_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                          __LINE__);                                                           \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+#define X3D_REQUIRE(cond, ...)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            x3d_set_error(__VA_ARGS__);                                                        \
+            return 2;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+// Pencil enumeration for one direction of the Cartesian-pitched block:
+// pencil p -> base = (p % dim0) * s0 + (p / dim0) * s1, rows advance by rs.
+struct PencilGeom {
+    int np;    // number of pencils (real, unpadded cross-section)
+    int dim0;  // extent of the fastest cross-section index
+    long s0, s1, rs;
+};
+
+struct x3d_backend {
+    int device;
+    hipStream_t stream;
+    int nx, ny, nz;     // local vertex dims
+    int nxp, nyp, nzp;  // pitched dims
+    size_t nblock;      // elements per block
+    // boundary-value exchange buffers for the local (non-decomposed) forms:
+    // [3 ops][npencil_max] each
+    double *send_s, *send_e;
+    // two scratch blocks for the transeq intermediates (dud, d2u):
+    // transeq_dist_component gets the same two from the pool,
+    // src/backend/omp/backend.f90:319-320
+    double *scratch[2];
+    double *red_buf;  // reduction partials (device)
+    double *red_host; // pinned host landing zone
+    int red_cap;
+    hipEvent_t ev0, ev1;
+};
+
+// Device-side view of one tdsops_t: row tables prepared on the host from the
+// reference's arrays (see tdsops.hip).  All table pointers are device arrays
+// indexed by the 1-based row j (entry 0 unused).
+struct TdsTab {
+    int n_tds, n_rhs;
+    const double *F;    // forward multiplier  (rows 1,2: dist_af; >=3: dist_fw)
+    const double *A;    // forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
+    const double *W;    // weights of d_k in du_2 (backward chain), see tdsops.hip
+    const double *Bw;   // dist_bw
+    const double *Sa, *Sc, *St, *Stc;  // dist_sa, dist_sc, stretch, stretch_correct
+    const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
+    double last_r;      // dist_fw(1)
+    double bw1;         // dist_bw(1)
+    double rs_s, rs_e;  // 1/(1 - sa(1)^2), 1/(1 - sc(n)^2)
+    double sa1, scn;
+};
+
+struct x3d_tdsops {
+    x3d_backend *b;
+    int n_tds, n_rhs, move, periodic;
+    double *dev;  // one allocation holding all tables
+    TdsTab tab;
+};
+
+PencilGeom x3d_geom(const x3d_backend *b, int dir);
+
+static inline int x3d_dir_ok(int dir) { return dir >= X3D_DIR_X && dir <= X3D_DIR_Z; }

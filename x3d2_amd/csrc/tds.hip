@@ -1,0 +1,541 @@
+// DistD2 compact-scheme kernels: tds_solve and the fused transport-equation
+// component, one pencil per lane, two sweeps.
+//
+// Reference arithmetic restated for CDNA4 (paths under /root/reference):
+//   src/backend/omp/kernels/distributed.f90:11-168  der_univ_dist
+//   src/backend/omp/kernels/distributed.f90:170-229 der_univ_subs
+//   src/backend/omp/kernels/distributed.f90:231-337 der_univ_fused_subs
+//   src/backend/omp/exec_dist.f90:16-65, 67-186     the two-phase drivers
+//
+// Structure (differs from the reference's three sweeps on purpose):
+//   forward sweep  : RHS stencil + forward elimination d_j, written once;
+//                    accumulates S = sum_k W_k d_k so that the first unknown of
+//                    the backward chain, du_1, is known when the sweep ends
+//                    (W_k = prod_{l<k} (-dist_bw_l)): du_1 and d_n are what the
+//                    2x2 reduced systems need, so they can be exchanged NOW.
+//   backward sweep : back-substitution, reduced-system substitution, stretching
+//                    and (transeq) the skew-symmetric combination fused in one
+//                    reverse pass that writes the final result.
+// Every table is indexed by the wave-uniform row j -> scalar loads; lanes only
+// differ in their pencil base address.  Loads are coalesced whenever lanes run
+// over x (dir Y/Z); dir X goes through LDS tile transposes (xdir.hip).
+#include "common.h"
+
+// ------------------------------------------------------------------ tables
+extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, int n_rhs, int move,
+                                 int periodic, const double *coeffs, const double *coeffs_s,
+                                 const double *coeffs_e, const double *dist_fw, const double *dist_bw,
+                                 const double *dist_sa, const double *dist_sc, const double *dist_af,
+                                 const double *stretch, const double *stretch_correct)
+{
+    X3D_REQUIRE(b && out && coeffs && coeffs_s && coeffs_e && dist_fw && dist_bw && dist_sa && dist_sc &&
+                    dist_af && stretch && stretch_correct,
+                "x3d_tdsops_create: null argument");
+    X3D_REQUIRE(n_rhs == n_tds || n_rhs == n_tds + 1, "x3d_tdsops_create: n_rhs must be n_tds or n_tds+1");
+    X3D_REQUIRE(n_tds >= 8, "x3d_tdsops_create: n_tds=%d too small (the 4+4 boundary rows need n>=8)", n_tds);
+    const int n = n_tds, nr = n_rhs, L = nr + 2;  // tables are 1-based, one spare entry
+    // layout: F A W Bw Sa Sc St Stc (8 tables of L) + 81 stencil coefficients
+    std::vector<double> h((size_t)8 * L + 81, 0.0);
+    double *F = &h[0], *A = &h[L], *W = &h[2 * L], *Bw = &h[3 * L], *Sa = &h[4 * L], *Sc = &h[5 * L],
+           *St = &h[6 * L], *Stc = &h[7 * L], *Cs = &h[8 * L];
+    for (int j = 1; j <= nr; j++) {
+        const bool real_row = j <= n;  // row n_tds+1 of a v2p operator is junk in the reference too
+        if (j <= 2) {                  // distributed.f90:45,56: du = rhs*faf(j)
+            F[j] = dist_af[j - 1];
+            A[j] = 0.0;
+        } else {
+            F[j] = real_row ? dist_fw[j - 1] : 0.0;
+            // distributed.f90:83: one alpha = faf(5) for the bulk rows 5..n_rhs-4
+            A[j] = (j >= 5 && j <= nr - 4) ? dist_af[4] : (real_row ? dist_af[j - 1] : 0.0);
+        }
+        if (real_row) {
+            Sa[j] = dist_sa[j - 1];
+            Sc[j] = dist_sc[j - 1];
+            St[j] = stretch[j - 1];
+            Stc[j] = stretch_correct[j - 1];
+        }
+        // dist_bw is read for rows 1..n-2 only (distributed.f90:154-163)
+        Bw[j] = (j <= n - 2) ? dist_bw[j - 1] : 0.0;
+    }
+    // du_2 = sum_{k=2}^{n-1} W_k d_k from du_j = d_j - bw_j du_{j+1}, j = n-2..2,
+    // with du_{n-1} = d_{n-1} untouched by the backward pass
+    W[2] = 1.0;
+    for (int k = 2; k <= n - 2; k++) W[k + 1] = W[k] * (-dist_bw[k - 1]);
+    memcpy(Cs, coeffs_s, sizeof(double) * 36);
+    memcpy(Cs + 36, coeffs_e, sizeof(double) * 36);
+    memcpy(Cs + 72, coeffs, sizeof(double) * 9);
+
+    x3d_tdsops *t = new x3d_tdsops();
+    t->b = b; t->n_tds = n; t->n_rhs = nr; t->move = move; t->periodic = periodic;
+    X3D_HIP(hipMalloc(&t->dev, sizeof(double) * h.size()));
+    X3D_HIP(hipMemcpy(t->dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    TdsTab &tb = t->tab;
+    tb.n_tds = n; tb.n_rhs = nr;
+    tb.F = t->dev; tb.A = t->dev + L; tb.W = t->dev + 2 * L; tb.Bw = t->dev + 3 * L;
+    tb.Sa = t->dev + 4 * L; tb.Sc = t->dev + 5 * L; tb.St = t->dev + 6 * L; tb.Stc = t->dev + 7 * L;
+    tb.Cs = t->dev + 8 * L;
+    tb.last_r = dist_fw[0];
+    tb.bw1 = dist_bw[0];
+    tb.sa1 = dist_sa[0];
+    tb.scn = dist_sc[n - 1];
+    tb.rs_s = 1.0 / (1.0 - dist_sa[0] * dist_sa[0]);          // distributed.f90:196-198
+    tb.rs_e = 1.0 / (1.0 - dist_sc[n - 1] * dist_sc[n - 1]);  // distributed.f90:203-205
+    *out = t;
+    return 0;
+}
+
+extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
+{
+    if (!t) return 0;
+    hipFree(t->dev);
+    delete t;
+    return 0;
+}
+
+extern "C" int x3d_npencils(const x3d_backend *b, int dir)
+{
+    if (!b || !x3d_dir_ok(dir)) return -1;
+    return x3d_geom(b, dir).np;
+}
+
+// ------------------------------------------------------------------ kernels
+// Extended pencil row jj in [-3, n_rhs+4] (1-based).  HB: halos come from
+// exchange buffers [4][np]; otherwise the direction is not decomposed and the
+// halo is the periodic image, exactly what sendrecv_fields' nproc==1 branch
+// produces (src/backend/omp/sendrecv.f90:20-22): u_s(r) = u(n_wrap-4+r),
+// u_e(r) = u(r).
+template <bool HB>
+__device__ __forceinline__ double ext_row(const double *__restrict__ u, long base, long rs, int jj, int nr,
+                                          int n_wrap, const double *__restrict__ hs,
+                                          const double *__restrict__ he, int np, int p)
+{
+    if (jj < 1) {
+        if (HB) return hs[(long)(jj + 3) * np + p];
+        return u[base + (long)(n_wrap + jj - 1) * rs];
+    }
+    if (jj > nr) {
+        const int r = jj - nr - 1;
+        if (HB) return he[(long)r * np + p];
+        return u[base + (long)r * rs];
+    }
+    return u[base + (long)(jj - 1) * rs];
+}
+
+__device__ __forceinline__ double dot9(const double *__restrict__ c, const double (&w)[9])
+{
+    // same left-to-right order as distributed.f90:89-93
+    return c[0] * w[0] + c[1] * w[1] + c[2] * w[2] + c[3] * w[3] + c[4] * w[4] + c[5] * w[5] + c[6] * w[6] +
+           c[7] * w[7] + c[8] * w[8];
+}
+
+__device__ __forceinline__ const double *stencil_row(const double *__restrict__ Cs, int j, int nr)
+{
+    if (j <= 4) return Cs + (j - 1) * 9;
+    if (j > nr - 4) return Cs + 36 + (j - (nr - 4) - 1) * 9;
+    return Cs + 72;
+}
+
+__device__ __forceinline__ long pencil_base(const PencilGeom &g, int p)
+{
+    return (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1;
+}
+
+// forward sweep, one operator (der_univ_dist without its backward loop)
+template <bool HB>
+__global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *__restrict__ send_s,
+                                                double *__restrict__ send_e, const double *__restrict__ u,
+                                                const double *__restrict__ hs, const double *__restrict__ he,
+                                                TdsTab t, PencilGeom g, int n_wrap)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p), rs = g.rs;
+    const int n = t.n_tds, nr = t.n_rhs;
+    double w[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) w[m] = ext_row<HB>(u, base, rs, m - 3, nr, n_wrap, hs, he, g.np, p);
+    double dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
+
+    auto row = [&](int j, const double *__restrict__ c, double wnext) {
+        const double acc = dot9(c, w);
+        const double dj = t.F[j] * (acc - t.A[j] * dprev);
+        if (j <= n) {
+            d[base + (long)(j - 1) * rs] = dj;
+            S += t.W[j] * dj;
+            if (j == 1) d1 = dj;
+            if (j == n) dn = dj;
+        }
+        dprev = dj;
+#pragma unroll
+        for (int m = 0; m < 8; m++) w[m] = w[m + 1];
+        w[8] = wnext;
+    };
+
+    for (int j = 1; j <= 4; j++)
+        row(j, stencil_row(t.Cs, j, nr), ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p));
+    {
+        const double *__restrict__ c = t.Cs + 72;
+        const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7],
+                     c8 = c[8];
+        const double cb[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+#pragma unroll 4
+        for (int j = 5; j <= nr - 4; j++) {
+            // rows j+5 <= n_rhs+1: interior except for the very last bulk row
+            const double wn = (j + 5 <= nr) ? u[base + (long)(j + 4) * rs]
+                                            : ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p);
+            row(j, cb, wn);
+        }
+    }
+    for (int j = (nr - 3 > 5 ? nr - 3 : 5); j <= nr; j++) {
+        const double wn = (j < nr) ? ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p) : 0.0;
+        row(j, stencil_row(t.Cs, j, nr), wn);
+    }
+    send_e[p] = dn;                                 // distributed.f90:147-151
+    send_s[p] = t.last_r * (d1 - t.bw1 * S);         // distributed.f90:161-166 with du_2 = S
+}
+
+// backward sweep fused with der_univ_subs
+__global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const double *__restrict__ own_s,
+                                                const double *__restrict__ recv_s,
+                                                const double *__restrict__ recv_e, TdsTab t, PencilGeom g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p), rs = g.rs;
+    const int n = t.n_tds;
+    const double dn = du[base + (long)(n - 1) * rs];
+    const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);  // distributed.f90:196-199
+    const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
+    du[base + (long)(n - 1) * rs] = du_e * t.St[n];               // :224-228
+    double nxt = du[base + (long)(n - 2) * rs];                   // row n-1: no backward update
+    du[base + (long)(n - 2) * rs] = (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1];
+#pragma unroll 4
+    for (int j = n - 2; j >= 2; j--) {
+        const double cur = du[base + (long)(j - 1) * rs] - t.Bw[j] * nxt;  // :154-160
+        du[base + (long)(j - 1) * rs] = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];  // :215-222
+        nxt = cur;
+    }
+    du[base] = du_s * t.St[1];  // :209-213
+}
+
+// forward sweep of one transport-equation component: three operators share
+// the loads of u and conv (exec_dist.f90:114-160)
+template <bool HB, bool SAME>
+__global__ void __launch_bounds__(64)
+    k_transeq_fwd(double *__restrict__ d_du, double *__restrict__ d_dud, double *__restrict__ d_d2u,
+                  double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
+                  const double *__restrict__ us, const double *__restrict__ ue, const double *__restrict__ cv,
+                  const double *__restrict__ cs, const double *__restrict__ ce, TdsTab t1, TdsTab t2, TdsTab t3,
+                  PencilGeom g, int n_wrap, int npmax)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p), rs = g.rs;
+    const int n = t1.n_tds;  // n_rhs == n_tds for first/second derivatives (src/tdsops.f90:114-123)
+    double wu[9], wp[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) {
+        wu[m] = ext_row<HB>(u, base, rs, m - 3, n, n_wrap, us, ue, g.np, p);
+        const double c = SAME ? wu[m] : ext_row<HB>(cv, base, rs, m - 3, n, n_wrap, cs, ce, g.np, p);
+        wp[m] = wu[m] * c;  // ud = u*v incl. the halo products, exec_dist.f90:133-149
+    }
+    double p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
+
+    auto row = [&](int j, const double *__restrict__ c1, const double *__restrict__ c2,
+                   const double *__restrict__ c3, double un, double pn) {
+        const double a1 = dot9(c1, wu), a3 = dot9(c3, wu), a2 = dot9(c2, wp);
+        const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
+        const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
+        const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
+        const long o = base + (long)(j - 1) * rs;
+        d_du[o] = e1; d_dud[o] = e2; d_d2u[o] = e3;
+        S1 += t1.W[j] * e1; S2 += t2.W[j] * e2; S3 += t3.W[j] * e3;
+        if (j == 1) { f1 = e1; f2 = e2; f3 = e3; }
+        if (j == n) { l1 = e1; l2 = e2; l3 = e3; }
+        p1 = e1; p2 = e2; p3 = e3;
+#pragma unroll
+        for (int m = 0; m < 8; m++) { wu[m] = wu[m + 1]; wp[m] = wp[m + 1]; }
+        wu[8] = un; wp[8] = pn;
+    };
+    auto nextrow = [&](int jj, double &un, double &pn) {
+        un = ext_row<HB>(u, base, rs, jj, n, n_wrap, us, ue, g.np, p);
+        const double c = SAME ? un : ext_row<HB>(cv, base, rs, jj, n, n_wrap, cs, ce, g.np, p);
+        pn = un * c;
+    };
+
+    for (int j = 1; j <= 4; j++) {
+        double un, pn;
+        nextrow(j + 5, un, pn);
+        row(j, stencil_row(t1.Cs, j, n), stencil_row(t2.Cs, j, n), stencil_row(t3.Cs, j, n), un, pn);
+    }
+    {
+        double b1[9], b2[9], b3[9];
+#pragma unroll
+        for (int m = 0; m < 9; m++) { b1[m] = t1.Cs[72 + m]; b2[m] = t2.Cs[72 + m]; b3[m] = t3.Cs[72 + m]; }
+#pragma unroll 2
+        for (int j = 5; j <= n - 4; j++) {
+            double un, pn;
+            if (j + 5 <= n) {
+                un = u[base + (long)(j + 4) * rs];
+                pn = un * (SAME ? un : cv[base + (long)(j + 4) * rs]);
+            } else {
+                nextrow(j + 5, un, pn);
+            }
+            row(j, b1, b2, b3, un, pn);
+        }
+    }
+    for (int j = (n - 3 > 5 ? n - 3 : 5); j <= n; j++) {
+        double un = 0.0, pn = 0.0;
+        if (j < n) nextrow(j + 5, un, pn);
+        row(j, stencil_row(t1.Cs, j, n), stencil_row(t2.Cs, j, n), stencil_row(t3.Cs, j, n), un, pn);
+    }
+    send_e[p] = l1; send_e[npmax + p] = l2; send_e[2 * npmax + p] = l3;
+    send_s[p] = t1.last_r * (f1 - t1.bw1 * S1);
+    send_s[npmax + p] = t2.last_r * (f2 - t2.bw1 * S2);
+    send_s[2 * npmax + p] = t3.last_r * (f3 - t3.bw1 * S3);
+}
+
+// backward sweep fused with der_univ_fused_subs (distributed.f90:231-337)
+__global__ void __launch_bounds__(64)
+    k_transeq_bwd(double *__restrict__ rhs, const double *__restrict__ d_dud, const double *__restrict__ d_d2u,
+                  const double *__restrict__ cv, const double *__restrict__ own_s,
+                  const double *__restrict__ recv_s, const double *__restrict__ recv_e, double nu, TdsTab t1,
+                  TdsTab t2, TdsTab t3, PencilGeom g, int npmax)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p), rs = g.rs;
+    const int n = t1.n_tds;
+    const long on = base + (long)(n - 1) * rs;
+    const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
+    const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
+    const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
+    double n1 = rhs[on], n2 = d_dud[on], n3 = d_d2u[on];
+    const double du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
+    const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
+    const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
+    // row n (:328-335)
+    rhs[on] = -0.5 * (cv[on] * du_e * t1.St[n] + dud_e * t2.St[n]) +
+              nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
+
+    auto emit = [&](int j, double c1, double c2, double c3) {
+        const long o = base + (long)(j - 1) * rs;
+        const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
+        const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
+        const double temp_d2u = t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
+        rhs[o] = -0.5 * (cv[o] * temp_du + temp_dud) + nu * temp_d2u;  // :315-324
+    };
+    {
+        const long o = base + (long)(n - 2) * rs;  // row n-1: forward values, no backward update
+        n1 = rhs[o]; n2 = d_dud[o]; n3 = d_d2u[o];
+        emit(n - 1, n1, n2, n3);
+    }
+#pragma unroll 2
+    for (int j = n - 2; j >= 2; j--) {
+        const long o = base + (long)(j - 1) * rs;
+        const double c1 = rhs[o] - t1.Bw[j] * n1;
+        const double c2 = d_dud[o] - t2.Bw[j] * n2;
+        const double c3 = d_d2u[o] - t3.Bw[j] * n3;
+        emit(j, c1, c2, c3);
+        n1 = c1; n2 = c2; n3 = c3;
+    }
+    // row 1 (:304-311)
+    rhs[base] = -0.5 * (cv[base] * du_s * t1.St[1] + dud_s * t2.St[1]) +
+                nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
+}
+
+// copy_into_buffers (src/backend/omp/backend.f90:714-737): rows 1..4 and n-3..n
+__global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ send_e,
+                             const double *__restrict__ u, int n, PencilGeom g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p);
+#pragma unroll
+    for (int r = 0; r < X3D_NH; r++) {
+        send_s[(long)r * g.np + p] = u[base + (long)r * g.rs];
+        send_e[(long)r * g.np + p] = u[base + (long)(n - X3D_NH + r) * g.rs];
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t);  // xdir.hip
+int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                     const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+
+static inline dim3 grid_for(const PencilGeom &g) { return dim3((g.np + 63) / 64); }
+
+static int check_len(const x3d_backend *b, const x3d_tdsops *t, int dir, const char *who)
+{
+    const int ext = dir == X3D_DIR_X ? b->nx : (dir == X3D_DIR_Y ? b->ny : b->nz);
+    X3D_REQUIRE(t->n_rhs <= ext, "%s: operator needs %d rows but the block has %d along dir %d", who, t->n_rhs,
+                ext, dir);
+    return 0;
+}
+
+extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir)
+{
+    X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos: bad dir %d", dir);
+    PencilGeom g = x3d_geom(b, dir);
+    hipLaunchKernelGGL(k_pack_halos, dim3((g.np + 255) / 256), dim3(256), 0, b->stream, send_s, send_e, u, n, g);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, double *du_send_e,
+                                const double *u, const double *u_recv_s, const double *u_recv_e,
+                                const x3d_tdsops *t, int dir)
+{
+    X3D_REQUIRE(b && du && du_send_s && du_send_e && u && u_recv_s && u_recv_e && t,
+                "x3d_tds_dist_fwd: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_fwd: bad dir %d", dir);
+    X3D_REQUIRE(du != u, "x3d_tds_dist_fwd: du and u must be distinct blocks");
+    if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
+    PencilGeom g = x3d_geom(b, dir);
+    hipLaunchKernelGGL(k_tds_fwd<true>, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_send_e, u,
+                       u_recv_s, u_recv_e, t->tab, g, t->n_tds);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
+                                const double *du_recv_e, const x3d_tdsops *t, int dir)
+{
+    X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
+    PencilGeom g = x3d_geom(b, dir);
+    hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_recv_s, du_recv_e,
+                       t->tab, g);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// Local form: sendrecv_fields with nproc==1 hands every rank its own buffers
+// back swapped (src/backend/omp/sendrecv.f90:20-22): recv_s = send_e, recv_e = send_s.
+extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+{
+    X3D_REQUIRE(b && du && u && t, "x3d_tds_solve: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve: bad dir %d", dir);
+    X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
+    if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
+    if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t);
+    return x3d_generic_tds_local(b, du, u, t, dir);
+}
+
+int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+{
+    PencilGeom g = x3d_geom(b, dir);
+    hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, u,
+                       (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
+    hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, b->send_s,
+                       t->tab, g);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int npmax_of(const x3d_backend *b)
+{
+    int m = b->ny * b->nz;
+    if (b->nx * b->nz > m) m = b->nx * b->nz;
+    if (b->nx * b->ny > m) m = b->nx * b->ny;
+    return m;
+}
+
+static int transeq_check(const x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2,
+                         const x3d_tdsops *t3)
+{
+    X3D_REQUIRE(t1->n_tds == t2->n_tds && t1->n_tds == t3->n_tds && t1->n_rhs == t1->n_tds &&
+                    t2->n_rhs == t2->n_tds && t3->n_rhs == t3->n_tds,
+                "transeq: the three operators must share n_tds == n_rhs");
+    return check_len(b, t1, dir, "transeq");
+}
+
+extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double *send_s, double *send_e,
+                                    const double *u, const double *u_recv_s, const double *u_recv_e,
+                                    const double *conv, const double *conv_recv_s, const double *conv_recv_e,
+                                    const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
+{
+    X3D_REQUIRE(b && rhs && send_s && send_e && u && u_recv_s && u_recv_e && conv && conv_recv_s &&
+                    conv_recv_e && t_du && t_dud && t_d2u,
+                "x3d_transeq_dist_fwd: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_fwd: bad dir %d", dir);
+    if (int rc = transeq_check(b, dir, t_du, t_dud, t_d2u)) return rc;
+    PencilGeom g = x3d_geom(b, dir);
+    // [3][npencil] boundary buffers are contiguous with stride np
+    hipLaunchKernelGGL((k_transeq_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0],
+                       b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
+                       t_du->tab, t_dud->tab, t_d2u->tab, g, t_du->n_tds, g.np);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
+                                    const double *recv_s, const double *recv_e, const double *conv, double nu,
+                                    const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
+{
+    X3D_REQUIRE(b && rhs && send_s && recv_s && recv_e && conv && t_du && t_dud && t_d2u,
+                "x3d_transeq_dist_bwd: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
+    PencilGeom g = x3d_geom(b, dir);
+    hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
+                       conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+{
+    if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3);
+    return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3);
+}
+
+int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+{
+    PencilGeom g = x3d_geom(b, dir);
+    const int npm = npmax_of(b);
+    const double *z = nullptr;
+    if (u == conv)
+        hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, rhs,
+                           b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
+                           t2->tab, t3->tab, g, t1->n_tds, npm);
+    else
+        hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, rhs,
+                           b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
+                           t2->tab, t3->tab, g, t1->n_tds, npm);
+    hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
+                       conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab, g, npm);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// transeq_x/y/z -> transeq_omp_dist with the component permutation of
+// src/backend/omp/backend.f90:145-184 and the operator pairing of :246-260
+extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                           const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                           const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                           const x3d_tdsops *der2nd_sym)
+{
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym,
+                "x3d_transeq: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq: bad dir %d", dir);
+    if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
+    double *r[3];
+    const double *f[3];
+    if (dir == X3D_DIR_X) { r[0] = du; r[1] = dv; r[2] = dw; f[0] = u; f[1] = v; f[2] = w; }
+    else if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; f[0] = v; f[1] = u; f[2] = w; }
+    else { r[0] = dw; r[1] = du; r[2] = dv; f[0] = w; f[1] = u; f[2] = v; }
+    for (int c = 0; c < 3; c++) {
+        X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq: outputs alias inputs");
+    }
+    if (int rc = transeq_component_local(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym)) return rc;
+    if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym)) return rc;
+    return 0;
+}

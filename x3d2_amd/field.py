@@ -1,0 +1,61 @@
+"""field_t and allocator_t mirrors
+(/root/reference/src/field.f90:5-23, src/allocator.f90:64-179): a pool of
+equally sized device blocks handed out with a direction tag and a data_loc.
+
+Blocks are torch CUDA tensors (PyTorch is the device-memory plumbing); the
+kernels only ever see their raw pointers."""
+import torch
+
+from .common import DIR_C, DIR_X, DIR_Y, DIR_Z, NULL_LOC, X3dError
+
+
+class Field:
+    """field_t: flat device block + dir + data_loc + refcount."""
+    __slots__ = ("data", "dir", "data_loc", "refcount", "id")
+
+    def __init__(self, data, ident):
+        self.data, self.dir, self.data_loc, self.refcount, self.id = data, DIR_X, NULL_LOC, 0, ident
+
+    @property
+    def ptr(self):
+        return self.data.data_ptr()
+
+    def set_data_loc(self, data_loc):
+        self.data_loc = data_loc
+
+    def fill(self, c):
+        self.data.fill_(c)  # field_t%fill, src/field.f90:47-55
+
+
+class Allocator:
+    """allocator_t: LIFO free list, blocks are never freed before destroy
+    (src/allocator.f90:113-179)."""
+
+    def __init__(self, nblock_elems, device):
+        self.n = int(nblock_elems)
+        self.device = device
+        self.free = []
+        self.next_id = 0
+
+    def create_block(self):
+        self.next_id += 1
+        return Field(torch.zeros(self.n, dtype=torch.float64, device=self.device), self.next_id)
+
+    def get_block(self, direction, data_loc=None):
+        if direction not in (DIR_X, DIR_Y, DIR_Z, DIR_C):
+            raise X3dError("Undefined direction, allocator cannot provide a shape.")
+        f = self.free.pop() if self.free else self.create_block()
+        f.dir = direction
+        f.data_loc = NULL_LOC if data_loc is None else data_loc  # :139-145
+        f.refcount = 1
+        return f
+
+    def release_block(self, f):
+        f.refcount = 0
+        self.free.append(f)
+
+    def get_block_ids(self):
+        return [f.id for f in reversed(self.free)]
+
+    def destroy(self):
+        self.free.clear()

@@ -1,0 +1,156 @@
+"""solver_t mirror (/root/reference/src/solver.f90): the "Incompact3D
+algorithm" sequencing -- transeq -> time integrator -> pressure correction --
+over the backend's operator interface.  No arithmetic on field data here."""
+import numpy as np
+
+from .common import (BC_DIRICHLET, BC_NEUMANN, CELL, DIR_C, DIR_X, DIR_Y, DIR_Z, RDR_C2Z, RDR_X2Y, RDR_X2Z,
+                     RDR_Z2C, VERT, X3dError)
+from .tdsops import Dirps
+from .time_integrator import TimeIntegrator
+from .vector_calculus import VectorCalculus
+
+
+class SolverConfig:
+    """the solver_params namelist (src/config.f90:170-173)"""
+
+    def __init__(self, Re=1600.0, dt=1e-3, n_iters=10, n_output=0, time_intg="RK3", poisson_solver_type="FFT",
+                 der1st_scheme="compact6", der2nd_scheme="compact6", interpl_scheme="classic",
+                 stagder_scheme="compact6", lowmem_transeq=False):
+        self.Re, self.dt, self.n_iters, self.n_output = Re, dt, n_iters, n_output
+        self.time_intg, self.poisson_solver_type = time_intg, poisson_solver_type
+        self.der1st_scheme, self.der2nd_scheme = der1st_scheme, der2nd_scheme
+        self.interpl_scheme, self.stagder_scheme = interpl_scheme, stagder_scheme
+        self.lowmem_transeq = lowmem_transeq
+
+
+def allocate_tdsops(dirps, backend, mesh, der1st_scheme, der2nd_scheme, interpl_scheme, stagder_scheme):
+    """src/solver.f90:214-289"""
+    d0 = dirps.dir - 1
+    d = float(mesh.d[d0])
+    bc_start, bc_end = int(mesh.BCs[d0, 0]), int(mesh.BCs[d0, 1])
+    # FFT Poisson needs Neumann pressure BCs: Dirichlet -> Neumann for the midpoint operators (:232-245)
+    bc_mp_start = BC_NEUMANN if bc_start == BC_DIRICHLET else bc_start
+    bc_mp_end = BC_NEUMANN if bc_end == BC_DIRICHLET else bc_end
+    n_vert, n_cell = mesh.get_n(dirps.dir, VERT), mesh.get_n(dirps.dir, CELL)
+    vds, vds2, vd2s, mds = mesh.vert_ds[d0], mesh.vert_ds2[d0], mesh.vert_d2s[d0], mesh.midp_ds[d0]
+    A = backend.alloc_tdsops
+    dirps.der1st = A(n_vert, d, "first-deriv", der1st_scheme, bc_start, bc_end, stretch=vds[:n_vert])
+    dirps.der1st_sym = A(n_vert, d, "first-deriv", der1st_scheme, bc_start, bc_end, stretch=vds[:n_vert],
+                         sym=True)
+    dirps.der2nd = A(n_vert, d, "second-deriv", der2nd_scheme, bc_start, bc_end, stretch=vds2[:n_vert],
+                     stretch_correct=vd2s[:n_vert])
+    dirps.der2nd_sym = A(n_vert, d, "second-deriv", der2nd_scheme, bc_start, bc_end, stretch=vds2[:n_vert],
+                         stretch_correct=vd2s[:n_vert], sym=True)
+    dirps.stagder_v2p = A(n_cell, d, "stag-deriv", stagder_scheme, bc_mp_start, bc_mp_end, from_to="v2p",
+                          stretch=mds[:n_cell])
+    dirps.stagder_p2v = A(n_vert, d, "stag-deriv", stagder_scheme, bc_mp_start, bc_mp_end, from_to="p2v",
+                          stretch=vds[:n_vert])
+    dirps.interpl_v2p = A(n_cell, d, "interpolate", interpl_scheme, bc_mp_start, bc_mp_end, from_to="v2p",
+                          stretch=np.ones(n_cell))
+    dirps.interpl_p2v = A(n_vert, d, "interpolate", interpl_scheme, bc_mp_start, bc_mp_end, from_to="p2v",
+                          stretch=np.ones(n_vert))
+
+
+class Solver:
+    def __init__(self, backend, mesh, cfg=None):
+        """src/solver.f90:110-212"""
+        cfg = cfg or SolverConfig()
+        self.backend, self.mesh, self.cfg = backend, mesh, cfg
+        self.xdirps, self.ydirps, self.zdirps = Dirps(DIR_X), Dirps(DIR_Y), Dirps(DIR_Z)
+        self.vector_calculus = VectorCalculus(backend)
+        al = backend.allocator
+        self.u, self.v, self.w = (al.get_block(DIR_X) for _ in range(3))
+        self.nvars = 3
+        self.time_integrator = TimeIntegrator(backend, al, cfg.time_intg, self.nvars)
+        self.dt, self.nu = cfg.dt, 1.0 / cfg.Re
+        self.n_iters, self.n_output = cfg.n_iters, cfg.n_output
+        self.ngrid = int(np.prod(mesh.get_global_dims(VERT)))
+        self.current_iter = 0
+        for dp in (self.xdirps, self.ydirps, self.zdirps):
+            allocate_tdsops(dp, backend, mesh, cfg.der1st_scheme, cfg.der2nd_scheme, cfg.interpl_scheme,
+                            cfg.stagder_scheme)
+        if cfg.poisson_solver_type == "FFT":
+            backend.init_poisson_fft(mesh, self.xdirps, self.ydirps, self.zdirps)
+            self.poisson = self.poisson_fft
+        elif cfg.poisson_solver_type == "CG":
+            self.poisson = self.poisson_cg
+        else:
+            raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
+        self.transeq = self.transeq_default
+
+    # ---- src/solver.f90:291-389
+    def transeq_default(self, rhs, variables):
+        b, al = self.backend, self.backend.allocator
+        du, dv, dw = rhs
+        u, v, w = variables
+        b.transeq_x(du, dv, dw, u, v, w, self.nu, self.xdirps)
+        u_y, v_y, w_y, du_y, dv_y, dw_y = (al.get_block(DIR_Y) for _ in range(6))
+        b.reorder(u_y, u, RDR_X2Y)
+        b.reorder(v_y, v, RDR_X2Y)
+        b.reorder(w_y, w, RDR_X2Y)
+        b.transeq_y(du_y, dv_y, dw_y, u_y, v_y, w_y, self.nu, self.ydirps)
+        for f in (u_y, v_y, w_y):
+            al.release_block(f)
+        b.sum_yintox(du, du_y)
+        b.sum_yintox(dv, dv_y)
+        b.sum_yintox(dw, dw_y)
+        for f in (du_y, dv_y, dw_y):
+            al.release_block(f)
+        u_z, v_z, w_z, du_z, dv_z, dw_z = (al.get_block(DIR_Z) for _ in range(6))
+        b.reorder(u_z, u, RDR_X2Z)
+        b.reorder(v_z, v, RDR_X2Z)
+        b.reorder(w_z, w, RDR_X2Z)
+        b.transeq_z(du_z, dv_z, dw_z, u_z, v_z, w_z, self.nu, self.zdirps)
+        for f in (u_z, v_z, w_z):
+            al.release_block(f)
+        b.sum_zintox(du, du_z)
+        b.sum_zintox(dv, dv_z)
+        b.sum_zintox(dw, dw_z)
+        for f in (du_z, dv_z, dw_z):
+            al.release_block(f)
+
+    # ---- :603-651
+    def divergence_v2p(self, div_u, u, v, w):
+        x, y, z = self.xdirps, self.ydirps, self.zdirps
+        self.vector_calculus.divergence_v2c(div_u, u, v, w, x.stagder_v2p, x.interpl_v2p, y.stagder_v2p,
+                                            y.interpl_v2p, z.stagder_v2p, z.interpl_v2p)
+
+    def gradient_p2v(self, dpdx, dpdy, dpdz, pressure):
+        x, y, z = self.xdirps, self.ydirps, self.zdirps
+        self.vector_calculus.gradient_c2v(dpdx, dpdy, dpdz, pressure, x.stagder_p2v, x.interpl_p2v,
+                                          y.stagder_p2v, y.interpl_p2v, z.stagder_p2v, z.interpl_p2v)
+
+    def curl(self, o_i_hat, o_j_hat, o_k_hat, u, v, w):
+        self.vector_calculus.curl(o_i_hat, o_j_hat, o_k_hat, u, v, w, self.xdirps.der1st,
+                                  self.ydirps.der1st, self.zdirps.der1st)
+
+    # ---- :653-691
+    def poisson_fft(self, pressure, div_u):
+        b, al = self.backend, self.backend.allocator
+        p_temp = al.get_block(DIR_C)
+        b.reorder(p_temp, div_u, RDR_Z2C)
+        temp = al.get_block(DIR_C)
+        b.poisson_fft.solve_poisson(p_temp, temp)
+        al.release_block(temp)
+        b.reorder(pressure, p_temp, RDR_C2Z)
+        al.release_block(p_temp)
+
+    def poisson_cg(self, pressure, div_u):
+        pressure.fill(0.0)  # placeholder in the reference too, :680-691
+
+    # ---- :693-739
+    def pressure_correction(self, u, v, w):
+        b, al = self.backend, self.backend.allocator
+        div_u = al.get_block(DIR_Z)
+        self.divergence_v2p(div_u, u, v, w)
+        p = al.get_block(DIR_Z)
+        self.poisson(p, div_u)
+        al.release_block(div_u)
+        dpdx, dpdy, dpdz = (al.get_block(DIR_X) for _ in range(3))
+        self.gradient_p2v(dpdx, dpdy, dpdz, p)
+        al.release_block(p)
+        b.vecadd(-1.0, dpdx, 1.0, u)
+        b.vecadd(-1.0, dpdy, 1.0, v)
+        b.vecadd(-1.0, dpdz, 1.0, w)
+        for f in (dpdx, dpdy, dpdz):
+            al.release_block(f)

@@ -1,0 +1,95 @@
+"""time_intg_t mirror (/root/reference/src/time_integrator.f90): explicit
+Adams-Bashforth 1-4 and Runge-Kutta 1-4 expressed through the backend's
+veccopy/vecadd, with the same `olds` block ownership and stage counters."""
+from .common import DIR_X, X3dError
+
+
+class TimeIntegrator:
+    # rk_a(j, istage, order) and rk_b(j, order), :83-106
+    RK_A = {1: ((0.0, 0.0, 0.0),) * 3,
+            2: ((0.5, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),
+            3: ((0.5, 0.0, 0.0), (0.0, 3.0 / 4.0, 0.0), (0.0, 0.0, 0.0)),
+            4: ((0.5, 0.0, 0.0), (0.0, 0.5, 0.0), (0.0, 0.0, 1.0))}
+    RK_B = {1: (1.0, 0.0, 0.0, 0.0), 2: (0.0, 1.0, 0.0, 0.0),
+            3: (2.0 / 9.0, 1.0 / 3.0, 4.0 / 9.0, 0.0), 4: (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)}
+    # Adams-Bashforth, :110-118
+    AB = {1: (1.0, 0.0, 0.0, 0.0), 2: (1.5, -0.5, 0.0, 0.0),
+          3: (23.0 / 12.0, -4.0 / 3.0, 5.0 / 12.0, 0.0),
+          4: (55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -3.0 / 8.0)}
+
+    def __init__(self, backend, allocator, method, nvars=3):
+        self.backend, self.allocator, self.sname = backend, allocator, method
+        self.gdt = 0.0
+        try:
+            self.order = int(method[2])
+        except (ValueError, IndexError):
+            raise X3dError("Error reading integration order")
+        if self.order >= 5 or self.order < 1:
+            raise X3dError("Integration order >4 is not supported")
+        if method[:2] == "AB":
+            self.nstep, self.nstage, self.nolds = self.order, 1, self.order - 1
+            self.step = self.adams_bashforth
+        elif method[:2] == "RK":
+            self.nstep, self.nstage, self.nolds = 1, self.order, self.order
+            self.step = self.runge_kutta
+        else:
+            raise X3dError("Integration method " + method + " is not defined")
+        self.nvars, self.istep, self.istage = nvars, 1, 1
+        self.olds = [[allocator.get_block(DIR_X) for _ in range(self.nolds)] for _ in range(nvars)]
+
+    def finalize(self):
+        for row in self.olds:
+            for f in row:
+                self.allocator.release_block(f)
+        self.olds = []
+
+    def runge_kutta(self, curr, deriv, dt):
+        """:166-231"""
+        b, ns = self.backend, self.nstage
+        a, bb = self.RK_A[ns], self.RK_B[ns]
+        self.gdt = bb[self.istage - 1] * dt
+        if self.istage == ns:
+            for i in range(self.nvars):
+                if ns > 1:
+                    b.veccopy(curr[i], self.olds[i][0])
+                for j in range(1, ns):
+                    b.vecadd(bb[j - 1] * dt, self.olds[i][j], 1.0, curr[i])
+                b.vecadd(bb[ns - 1] * dt, deriv[i], 1.0, curr[i])
+            self.istage = 1
+        else:
+            for i in range(self.nvars):
+                if self.istage == 1:
+                    b.veccopy(self.olds[i][0], curr[i])
+                b.veccopy(self.olds[i][self.istage], deriv[i])
+                if self.istage > 1:
+                    b.veccopy(curr[i], self.olds[i][0])
+                for j in range(1, self.istage + 1):
+                    b.vecadd(a[self.istage - 1][j - 1] * dt, self.olds[i][j], 1.0, curr[i])
+            self.istage += 1
+
+    def adams_bashforth(self, curr, deriv, dt):
+        """:233-282"""
+        b = self.backend
+        self.gdt = dt
+        nstep = min(self.istep, self.nstep)
+        c = self.AB[nstep]
+        for i in range(self.nvars):
+            b.vecadd(c[0] * dt, deriv[i], 1.0, curr[i])
+            for j in range(2, nstep + 1):
+                b.vecadd(c[j - 1] * dt, self.olds[i][j - 2], 1.0, curr[i])
+            if nstep < self.nstep:
+                if self.istep > 1:
+                    self._rotate(self.olds[i], nstep)
+            elif self.nstep > 2:
+                self._rotate(self.olds[i], nstep - 1)
+            if self.nstep > 1:
+                b.veccopy(self.olds[i][0], deriv[i])
+        self.istep += 1
+
+    @staticmethod
+    def _rotate(sol, n):
+        """:284-300"""
+        last = sol[n - 1]
+        for i in range(n - 1, 0, -1):
+            sol[i] = sol[i - 1]
+        sol[0] = last
