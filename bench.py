@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Taylor-Green vortex, full fractional step (transeq ->
+RK/AB substep -> pressure correction with the FFT Poisson solve), FP64, on N
+MI355X GPUs of one node.  Metric (BASELINE.json): DoF*steps/s, whole job.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full time step (3 substeps for RK3) of the 512^3-per-GPU TGV
+(BASELINE.json configs[2]; weak scaling: the global grid grows with N).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (dominant kernel: the fused transport-equation component, timed with
+HIP events inside the timed region) and `cpu_baseline` (the oracle restatement
+of the reference's OpenMP path on the host cores, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def decomposition(n_gpus):
+    """x stays whole (src/poisson_fft.f90:131); y/z split as evenly as possible"""
+    table = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}
+    if n_gpus not in table:
+        raise SystemExit(f"--gpus {n_gpus}: supported 1, 2, 4, 8")
+    return table[n_gpus]
+
+
+def cpu_baseline(n, steps):
+    """oracle (CPU restatement of the reference OpenMP backend, SZ=16 layout)
+    timed on this host's cores: TGV n^3 RK3 full step incl. FFT Poisson."""
+    from oracle import x3d_oracle as orc
+    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    twopi = 6.283185307179586
+    mesh = orc.Mesh([n] * 3, [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
+    s = orc.Solver(mesh, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT")
+    s.init_tgv()
+    s.step()  # warm-up (first touch, library load)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step()
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / dt, "unit": "DoF*steps/s", "cores": threads, "kind": "port",
+            "sample": f"TGV {n}^3 RK3 full fractional step (FFT Poisson), {steps} steps after 1 warm-up, "
+                      f"oracle/x3d_oracle (C+OpenMP kernels, numpy FFT) on {threads} threads",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=512, help="grid points per GPU per direction")
+    ap.add_argument("--time-intg", default="RK3")
+    ap.add_argument("--no-poisson", action="store_true", help="BASELINE configs[1]: derivatives + RK only")
+    ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from x3d2_amd import make_tgv
+    from x3d2_amd.parallel import Comm
+
+    nproc_dir = decomposition(args.gpus)
+    dims = tuple(args.n * p for p in nproc_dir)
+    comm = Comm()
+    case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
+                    poisson="CG" if args.no_poisson else "FFT", comm=comm)
+    solver, backend = case.solver, case.solver.backend
+    nstage = solver.time_integrator.nstage
+
+    def sync_all():
+        torch.cuda.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        it += 1
+        case.step(it)
+    backend.prof_enable(True)
+    backend.prof_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it += 1
+        case.step(it)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    dof_global = dims[0] * dims[1] * dims[2]
+    dof_local = args.n ** 3
+    value = dof_global * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel class: one transport-equation
+    # component = k_transeq_fwd + k_transeq_bwd (64 B/DoF for the three
+    # components of one direction: u-component reads 1 + writes 1, the other two
+    # read 2 + write 1 fields)
+    prof = {}
+    for kind in backend.KINDS:
+        n_l, ms = backend.prof_get(kind)
+        prof[kind] = {"launches": n_l, "ms": ms}
+    n_f, ms_f = backend.prof_get("transeq_fwd")
+    n_b, ms_b = backend.prof_get("transeq_bwd")
+    per_dir = {}
+    for d, name in ((1, "x"), (2, "y"), (3, "z")):
+        nf, mf = backend.prof_get("transeq_fwd", d)
+        nb, mb = backend.prof_get("transeq_bwd", d)
+        if nf:
+            per_dir[name] = {"ms_per_component": (mf + mb) / nf,
+                             "GB/s": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
+    bytes_per_launch = (64.0 / 3.0) * dof_local  # average over the three components
+    avg_ms = (ms_f + ms_b) / max(n_f, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("n") == args.n:
+                traffic = tj.get("transeq_component_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "transeq component (k_transeq_fwd + k_transeq_bwd)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_ms, "launches": n_f, "per_direction": per_dir,
+                "share_of_step": (ms_f + ms_b) / (elapsed * 1e3)}
+
+    out = {
+        "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step",
+        "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"TGV {dims[0]}x{dims[1]}x{dims[2]} all-periodic, Re=1600, dt=1e-3, "
+                               f"{args.time_intg} ({nstage} substeps/step), compact6/classic schemes, "
+                               + ("no pressure solve (configs[1])" if args.no_poisson
+                                  else "rocFFT Poisson (configs[2])"),
+                   "per_gpu": f"{args.n}^3", "nproc_dir": list(nproc_dir),
+                   "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}"},
+        "dof_substeps_per_s": value * nstage,
+        "roofline": roofline,
+        "kernel_ms": prof,
+    }
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

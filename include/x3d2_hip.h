@@ -179,6 +179,14 @@ int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);
 int x3d_timer_stop_ms(x3d_backend *b, float *ms);
+/* per-kernel-class timers (HIP events around every launch while enabled);
+ * dir = 1..3 selects a pencil direction, 0 sums over all */
+enum { X3D_K_TRANSEQ_FWD = 0, X3D_K_TRANSEQ_BWD = 1, X3D_K_TDS_FWD = 2, X3D_K_TDS_BWD = 3,
+       X3D_K_BLAS1 = 4, X3D_K_COPY = 5, X3D_K_REDUCE = 6, X3D_K_FFT = 7, X3D_K_SPECTRAL = 8,
+       X3D_K_PACK = 9 };
+int x3d_prof_enable(x3d_backend *b, int on);
+int x3d_prof_reset(x3d_backend *b);
+int x3d_prof_get(x3d_backend *b, int kind, int dir, long *count, double *total_ms);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,22 @@ class HipBackend:
     def sync(self):
         _lib.check(self.lib.x3d_device_sync(self.h))
 
+    # ------------------------------------------------------------ per-kernel timers
+    KINDS = {"transeq_fwd": 0, "transeq_bwd": 1, "tds_fwd": 2, "tds_bwd": 3, "blas1": 4, "copy": 5,
+             "reduce": 6, "fft": 7, "spectral": 8, "pack": 9}
+
+    def prof_enable(self, on=True):
+        _lib.check(self.lib.x3d_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        _lib.check(self.lib.x3d_prof_reset(self.h))
+
+    def prof_get(self, kind, direction=0):
+        """(launch count, summed device ms) of one kernel class"""
+        n, ms = ctypes.c_long(), ctypes.c_double()
+        _lib.check(self.lib.x3d_prof_get(self.h, self.KINDS[kind], direction, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
     # ------------------------------------------------------------ alloc_tdsops
     def alloc_tdsops(self, n_tds, delta, operation, scheme, bc_start, bc_end, stretch=None,
                      stretch_correct=None, n_halo=None, from_to=None, sym=None, c_nu=None, nu0_nu=None):

@@ -78,6 +78,7 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
     if (!b) return 0;
     hipFree(b->send_s); hipFree(b->send_e);
     hipFree(b->scratch[0]); hipFree(b->scratch[1]);
+    x3d_prof_enable_c(b, 0);
     hipFree(b->red_buf); hipHostFree(b->red_host);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     delete b;
@@ -168,6 +169,7 @@ struct OpFill { double a; __device__ double operator()(double) const { return a;
 extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 {
     X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
+    ProfScope ps(b, X3D_K_COPY);
     X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
@@ -175,6 +177,7 @@ extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
 {
     X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpAxpby>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
                        (const double2 *)x, n2, OpAxpby{a, bb});
@@ -185,6 +188,7 @@ extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, 
 extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
 {
     X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpMul>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
                        (const double2 *)x, n2, OpMul{});
@@ -195,6 +199,7 @@ extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
 extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 {
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpScale>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
                        OpScale{a});
@@ -205,6 +210,7 @@ extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 {
     X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpShift>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
                        OpShift{a});
@@ -215,6 +221,7 @@ extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 {
     X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpFill>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
                        OpFill{c});
@@ -231,6 +238,7 @@ extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
     X3D_REQUIRE(from >= 1 && from <= 4 && to >= 1 && to <= 4 && from != to,
                 "x3d_reorder: invalid reorder code %d", rdr);
     if (u_ == u) return 0;
+    ProfScope ps(b, X3D_K_COPY);
     X3D_HIP(hipMemcpyAsync(u_, u, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
@@ -240,6 +248,7 @@ extern "C" int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int di
 {
     X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
     X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
+    ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpAdd>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)u,
                        (const double2 *)u_, n2, OpAdd{});
@@ -277,6 +286,7 @@ extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nt
 {
     X3D_REQUIRE(b && y && base && c && x, "x3d_lincomb: null argument");
     X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_lincomb: nterm must be 1..5");
+    ProfScope ps(b, X3D_K_BLAS1);
     LinArgs a;
     a.n = nterm;
     for (int k = 0; k < 5; k++) {
@@ -336,6 +346,7 @@ static int run_reduce(x3d_backend *b, const double *x, const double *y, const in
                 "reduction: dims (%d,%d,%d) outside the block", dims[0], dims[1], dims[2]);
     long nrow = (long)dims[1] * dims[2];
     int grid = (int)(nrow < 2048 ? nrow : 2048);
+    ProfScope ps(b, X3D_K_REDUCE);
     hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(256), 0, b->stream, x, y, dims[0], dims[1], dims[2],
                        (long)b->nxp, (long)b->nyp, b->red_buf, b->red_buf + b->red_cap);
     X3D_HIP(hipGetLastError());

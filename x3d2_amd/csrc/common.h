@@ -56,6 +56,19 @@ struct x3d_backend {
     double *red_host; // pinned host landing zone
     int red_cap;
     hipEvent_t ev0, ev1;
+    struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
+};
+
+// kernel classes timed by the profiler; index = kind * 4 + dir (dir 0 = n/a)
+// (X3D_K_* are declared in include/x3d2_hip.h)
+#define X3D_K_NKINDS 10
+void x3d_prof_begin(x3d_backend *b, int kind, int dir);
+void x3d_prof_end(x3d_backend *b);
+int x3d_prof_enable_c(x3d_backend *b, int on);
+struct ProfScope {
+    x3d_backend *b;
+    ProfScope(x3d_backend *b_, int kind, int dir = 0) : b(b_) { if (b->prof) x3d_prof_begin(b, kind, dir); }
+    ~ProfScope() { if (b->prof) x3d_prof_end(b); }
 };
 
 // Device-side view of one tdsops_t: row tables prepared on the host from the

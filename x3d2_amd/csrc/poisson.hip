@@ -137,6 +137,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
 extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 1);
     X3D_FFT(hipfftSetStream(p->plan_fw, p->b->stream));
     X3D_FFT(hipfftExecD2Z(p->plan_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c));
     return 0;
@@ -148,6 +149,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
     const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     dim3 grid((p->nxs + 255) / 256, p->ny, p->nz);
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
     hipLaunchKernelGGL(k_process_spectral_000, grid, dim3(256), 0, p->b->stream, p->c, p->waves, p->nxs, p->ny,
                        p->nz, p->nx, ax, bx, ay, by, az, bz);
     X3D_HIP(hipGetLastError());
@@ -157,6 +159,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
 {
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_bw, p->b->stream));
     X3D_FFT(hipfftExecZ2D(p->plan_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f_out));
     return 0;

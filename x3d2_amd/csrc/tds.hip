@@ -381,6 +381,7 @@ extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, co
     X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
+    ProfScope ps(b, X3D_K_PACK, dir);
     hipLaunchKernelGGL(k_pack_halos, dim3((g.np + 255) / 256), dim3(256), 0, b->stream, send_s, send_e, u, n, g);
     X3D_HIP(hipGetLastError());
     return 0;
@@ -396,6 +397,7 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     X3D_REQUIRE(du != u, "x3d_tds_dist_fwd: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     PencilGeom g = x3d_geom(b, dir);
+    ProfScope ps(b, X3D_K_TDS_FWD, dir);
     hipLaunchKernelGGL(k_tds_fwd<true>, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_send_e, u,
                        u_recv_s, u_recv_e, t->tab, g, t->n_tds);
     X3D_HIP(hipGetLastError());
@@ -408,6 +410,7 @@ extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_sen
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
+    ProfScope ps(b, X3D_K_TDS_BWD, dir);
     hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_recv_s, du_recv_e,
                        t->tab, g);
     X3D_HIP(hipGetLastError());
@@ -429,10 +432,16 @@ extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const 
 int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
     PencilGeom g = x3d_geom(b, dir);
-    hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, u,
-                       (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
-    hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, b->send_s,
-                       t->tab, g);
+    {
+        ProfScope ps(b, X3D_K_TDS_FWD, dir);
+        hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, u,
+                           (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
+    }
+    {
+        ProfScope ps(b, X3D_K_TDS_BWD, dir);
+        hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, b->send_s,
+                           t->tab, g);
+    }
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -466,6 +475,7 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     if (int rc = transeq_check(b, dir, t_du, t_dud, t_d2u)) return rc;
     PencilGeom g = x3d_geom(b, dir);
     // [3][npencil] boundary buffers are contiguous with stride np
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
     hipLaunchKernelGGL((k_transeq_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0],
                        b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
                        t_du->tab, t_dud->tab, t_d2u->tab, g, t_du->n_tds, g.np);
@@ -481,6 +491,7 @@ extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const 
                 "x3d_transeq_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
+    ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
     hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
                        conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
     X3D_HIP(hipGetLastError());
@@ -500,16 +511,22 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
     PencilGeom g = x3d_geom(b, dir);
     const int npm = npmax_of(b);
     const double *z = nullptr;
-    if (u == conv)
-        hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, rhs,
-                           b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
-                           t2->tab, t3->tab, g, t1->n_tds, npm);
-    else
-        hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, rhs,
-                           b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
-                           t2->tab, t3->tab, g, t1->n_tds, npm);
-    hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
-                       conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab, g, npm);
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+        if (u == conv)
+            hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, rhs,
+                               b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
+                               t2->tab, t3->tab, g, t1->n_tds, npm);
+        else
+            hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, rhs,
+                               b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
+                               t2->tab, t3->tab, g, t1->n_tds, npm);
+    }
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
+        hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
+                           conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab, g, npm);
+    }
     X3D_HIP(hipGetLastError());
     return 0;
 }
