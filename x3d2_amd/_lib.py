@@ -91,6 +91,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own HIP runtime and must be the one the
+    # process initialises (loading /opt/rocm's copy first leaves two runtimes)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise X3dError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
                        " (the HIP backend has no CPU fallback)")

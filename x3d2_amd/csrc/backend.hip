@@ -63,7 +63,8 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     if (b->nx * b->ny > npmax) npmax = b->nx * b->ny;
     X3D_HIP(hipMalloc(&b->send_s, sizeof(double) * 3 * (size_t)npmax));
     X3D_HIP(hipMalloc(&b->send_e, sizeof(double) * 3 * (size_t)npmax));
-    for (int i = 0; i < 2; i++) X3D_HIP(hipMalloc(&b->scratch[i], sizeof(double) * b->nblock));
+    for (int i = 0; i < 3; i++)
+        X3D_HIP(hipMalloc(&b->scratch[i], sizeof(double) * (b->nblock + 64 * (size_t)b->nxp)));
     b->red_cap = 4096;
     X3D_HIP(hipMalloc(&b->red_buf, sizeof(double) * 2 * b->red_cap));
     X3D_HIP(hipHostMalloc(&b->red_host, sizeof(double) * 2 * b->red_cap));
@@ -77,7 +78,7 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
 {
     if (!b) return 0;
     hipFree(b->send_s); hipFree(b->send_e);
-    hipFree(b->scratch[0]); hipFree(b->scratch[1]);
+    hipFree(b->scratch[0]); hipFree(b->scratch[1]); hipFree(b->scratch[2]);
     x3d_prof_enable_c(b, 0);
     hipFree(b->red_buf); hipHostFree(b->red_host);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);

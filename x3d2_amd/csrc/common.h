@@ -51,7 +51,7 @@ struct x3d_backend {
     // two scratch blocks for the transeq intermediates (dud, d2u):
     // transeq_dist_component gets the same two from the pool,
     // src/backend/omp/backend.f90:319-320
-    double *scratch[2];
+    double *scratch[3];  // + slack of 64 rows: x-direction kernels keep them wave-transposed
     double *red_buf;  // reduction partials (device)
     double *red_host; // pinned host landing zone
     int red_cap;

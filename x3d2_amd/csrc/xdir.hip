@@ -1,20 +1,394 @@
-// x-direction operators.  In the Cartesian-pitched block an x pencil is
-// contiguous, so "one pencil per lane" has lanes 4 KB apart: the generic
-// kernels of tds.hip are correct here but uncoalesced.  x3d_xdir_* is the seam
-// where the LDS-tile-transposed variant plugs in (kernel K3).
+// x-direction operators for the Cartesian-pitched block (kernel family K3).
+//
+// An x pencil is contiguous in memory, so "one pencil per lane" would put the
+// 64 lanes of a wave 4 KB apart.  Instead a wave owns 64 consecutive rows
+// (= 64 pencils = one contiguous [64][nxp] slab) and streams it in tiles of
+// 16 columns: each tile is fetched with 16-byte loads, 128 B contiguous per 8
+// lanes, transposed through a wave-private LDS tile (pitch 65 doubles ->
+// conflict-free both ways), and consumed by the lane that owns the row.  The
+// arithmetic is the same two-sweep DistD2 formulation as tds.hip; the
+// forward-eliminated intermediates live in wave-transposed scratch
+// ([wave][row j][lane], coalesced as is), the final result goes back through
+// an LDS tile so that global stores are coalesced too.
+//
+// Reference arithmetic: src/backend/omp/kernels/distributed.f90:11-337 (see tds.hip).
 #include "common.h"
 
 int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
 int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
                               double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+int npmax_of(const x3d_backend *b);
+
+#define TW 16        // tile width (columns)
+#define TP 65        // LDS pitch in doubles
+#define TILE (TW * TP)
+
+__device__ __forceinline__ double dot9x(const double *__restrict__ c, const double (&w)[9])
+{
+    return c[0] * w[0] + c[1] * w[1] + c[2] * w[2] + c[3] * w[3] + c[4] * w[4] + c[5] * w[5] + c[6] * w[6] +
+           c[7] * w[7] + c[8] * w[8];
+}
+
+__device__ __forceinline__ const double *stencil_row_x(const double *__restrict__ Cs, int j, int nr)
+{
+    if (j <= 4) return Cs + (j - 1) * 9;
+    if (j > nr - 4) return Cs + 36 + (j - (nr - 4) - 1) * 9;
+    return Cs + 72;
+}
+
+// cooperative tile fetch: 8 x (16 B per lane); lane -> row (lane>>3)+8i, columns 2*(lane&7), +1
+struct TileRegs { double2 v[8]; };
+
+__device__ __forceinline__ void tile_load(TileRegs &r, const double *__restrict__ slab, long pitch, int col0,
+                                          int rows_valid, int lane)
+{
+    const int cp = (lane & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int row = (lane >> 3) + 8 * i;
+        row = row < rows_valid ? row : rows_valid - 1;  // partial wave: replicate a valid row
+        r.v[i] = *reinterpret_cast<const double2 *>(slab + (long)row * pitch + col0 + cp);
+    }
+}
+
+__device__ __forceinline__ void tile_to_lds(const TileRegs &r, double *__restrict__ lds, int lane)
+{
+    const int cp = (lane & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = (lane >> 3) + 8 * i;
+        lds[cp * TP + row] = r.v[i].x;
+        lds[(cp + 1) * TP + row] = r.v[i].y;
+    }
+}
+
+__device__ __forceinline__ void tile_store(const double *__restrict__ lds, double *__restrict__ slab, long pitch,
+                                           int col0, int rows_valid, int lane)
+{
+    const int cp = (lane & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = (lane >> 3) + 8 * i;
+        if (row < rows_valid) {
+            double2 v;
+            v.x = lds[cp * TP + row];
+            v.y = lds[(cp + 1) * TP + row];
+            *reinterpret_cast<double2 *>(slab + (long)row * pitch + col0 + cp) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- tds, forward
+// d (wave-transposed scratch): d[(wave*n + (j-1))*64 + lane]
+__global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double *__restrict__ send_s,
+                                                 double *__restrict__ send_e, const double *__restrict__ u,
+                                                 TdsTab t, int np, long pitch, int n_wrap)
+{
+    __shared__ double lds[TILE];
+    const int lane = threadIdx.x, wave = blockIdx.x;
+    const int p = wave * 64 + lane;
+    int rows_valid = np - wave * 64;
+    rows_valid = rows_valid > 64 ? 64 : rows_valid;
+    const double *__restrict__ slab = u + (long)wave * 64 * pitch;
+    const int n = t.n_tds, nr = t.n_rhs;
+    const int my = lane < rows_valid ? lane : rows_valid - 1;
+    const double *__restrict__ mine = slab + (long)my * pitch;
+    // periodic images (sendrecv_fields nproc==1): u_s(r) = u(n_wrap-4+r), u_e(r) = u(r)
+    double w[9];
+#pragma unroll
+    for (int m = 0; m < 5; m++) w[m] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) w[5 + m] = mine[n_wrap - 4 + m];
+    double he[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) he[m] = mine[m];
+    double dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
+    double *__restrict__ dw = d + (long)wave * n * 64 + lane;
+
+    const int ntile = (nr + TW - 1) / TW;
+    TileRegs regs;
+    tile_load(regs, slab, pitch, 0, rows_valid, lane);
+    for (int tI = 0; tI <= ntile; tI++) {
+        __syncthreads();
+        if (tI < ntile) tile_to_lds(regs, lds, lane);
+        __syncthreads();
+        if (tI + 1 < ntile) tile_load(regs, slab, pitch, (tI + 1) * TW, rows_valid, lane);
+#pragma unroll 4
+        for (int c = 0; c < TW; c++) {
+            const int e = tI * TW + c + 1;  // element fed into the window
+            if (e > nr + 4) break;
+            const double ve = e <= nr ? lds[c * TP + lane] : he[e - nr - 1];
+#pragma unroll
+            for (int m = 0; m < 8; m++) w[m] = w[m + 1];
+            w[8] = ve;
+            const int j = e - 4;
+            if (j >= 1 && j <= nr) {
+                const double acc = dot9x(stencil_row_x(t.Cs, j, nr), w);
+                const double dj = t.F[j] * (acc - t.A[j] * dprev);
+                if (j <= n) {
+                    dw[(long)(j - 1) * 64] = dj;
+                    S += t.W[j] * dj;
+                    if (j == 1) d1 = dj;
+                    if (j == n) dn = dj;
+                }
+                dprev = dj;
+            }
+        }
+    }
+    if (lane < rows_valid) {
+        send_e[p] = dn;
+        send_s[p] = t.last_r * (d1 - t.bw1 * S);
+    }
+}
+
+// ---------------------------------------------------------------- tds, backward + subs
+__global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const double *__restrict__ d,
+                                                 const double *__restrict__ own_s,
+                                                 const double *__restrict__ recv_s,
+                                                 const double *__restrict__ recv_e, TdsTab t, int np, long pitch)
+{
+    __shared__ double lds[TILE];
+    const int lane = threadIdx.x, wave = blockIdx.x;
+    int rows_valid = np - wave * 64;
+    rows_valid = rows_valid > 64 ? 64 : rows_valid;
+    const int p = wave * 64 + (lane < rows_valid ? lane : rows_valid - 1);
+    double *__restrict__ slab = du + (long)wave * 64 * pitch;
+    const int n = t.n_tds;
+    const double *__restrict__ dw = d + (long)wave * n * 64 + lane;
+    const double dn = dw[(long)(n - 1) * 64];
+    const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);
+    const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);
+    double nxt = 0.0;
+    const int ntile = (n + TW - 1) / TW;
+    for (int tI = ntile - 1; tI >= 0; tI--) {
+        __syncthreads();
+#pragma unroll 4
+        for (int c = TW - 1; c >= 0; c--) {
+            const int j = tI * TW + c + 1;
+            double out = 0.0;
+            if (j <= n) {
+                if (j == n) {
+                    out = du_e * t.St[n];
+                    nxt = dn;
+                } else if (j == 1) {
+                    out = du_s * t.St[1];
+                } else {
+                    const double dj = dw[(long)(j - 1) * 64];
+                    const double cur = (j == n - 1) ? dj : dj - t.Bw[j] * nxt;
+                    out = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];
+                    nxt = cur;
+                }
+            }
+            lds[c * TP + lane] = out;
+        }
+        __syncthreads();
+        tile_store(lds, slab, pitch, tI * TW, rows_valid, lane);
+    }
+}
+
+// ---------------------------------------------------------------- transeq, forward
+template <bool SAME>
+__global__ void __launch_bounds__(64)
+    k_xtranseq_fwd(double *__restrict__ d1a, double *__restrict__ d2a, double *__restrict__ d3a,
+                   double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
+                   const double *__restrict__ cv, TdsTab t1, TdsTab t2, TdsTab t3, int np, long pitch,
+                   int npmax)
+{
+    __shared__ double lu[TILE], lc[SAME ? 1 : TILE];
+    const int lane = threadIdx.x, wave = blockIdx.x;
+    const int p = wave * 64 + lane;
+    int rows_valid = np - wave * 64;
+    rows_valid = rows_valid > 64 ? 64 : rows_valid;
+    const double *__restrict__ su = u + (long)wave * 64 * pitch;
+    const double *__restrict__ sc = cv + (long)wave * 64 * pitch;
+    const int n = t1.n_tds;
+    const int my = lane < rows_valid ? lane : rows_valid - 1;
+    double wu[9], wp[9], heu[4], hep[4];
+#pragma unroll
+    for (int m = 0; m < 5; m++) { wu[m] = 0.0; wp[m] = 0.0; }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const double a = su[(long)my * pitch + n - 4 + m];
+        const double c = SAME ? a : sc[(long)my * pitch + n - 4 + m];
+        wu[5 + m] = a; wp[5 + m] = a * c;
+        const double a2 = su[(long)my * pitch + m];
+        const double c2 = SAME ? a2 : sc[(long)my * pitch + m];
+        heu[m] = a2; hep[m] = a2 * c2;
+    }
+    double p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
+    const long wo = (long)wave * n * 64 + lane;
+    const int ntile = (n + TW - 1) / TW;
+    TileRegs ru, rc;
+    tile_load(ru, su, pitch, 0, rows_valid, lane);
+    if (!SAME) tile_load(rc, sc, pitch, 0, rows_valid, lane);
+    for (int tI = 0; tI <= ntile; tI++) {
+        __syncthreads();
+        if (tI < ntile) {
+            tile_to_lds(ru, lu, lane);
+            if (!SAME) tile_to_lds(rc, lc, lane);
+        }
+        __syncthreads();
+        if (tI + 1 < ntile) {
+            tile_load(ru, su, pitch, (tI + 1) * TW, rows_valid, lane);
+            if (!SAME) tile_load(rc, sc, pitch, (tI + 1) * TW, rows_valid, lane);
+        }
+#pragma unroll 2
+        for (int c = 0; c < TW; c++) {
+            const int e = tI * TW + c + 1;
+            if (e > n + 4) break;
+            double ve, vp;
+            if (e <= n) {
+                ve = lu[c * TP + lane];
+                vp = ve * (SAME ? ve : lc[c * TP + lane]);
+            } else {
+                ve = heu[e - n - 1];
+                vp = hep[e - n - 1];
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) { wu[m] = wu[m + 1]; wp[m] = wp[m + 1]; }
+            wu[8] = ve; wp[8] = vp;
+            const int j = e - 4;
+            if (j >= 1) {
+                const double a1 = dot9x(stencil_row_x(t1.Cs, j, n), wu);
+                const double a3 = dot9x(stencil_row_x(t3.Cs, j, n), wu);
+                const double a2 = dot9x(stencil_row_x(t2.Cs, j, n), wp);
+                const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
+                const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
+                const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
+                const long o = wo + (long)(j - 1) * 64;
+                d1a[o] = e1; d2a[o] = e2; d3a[o] = e3;
+                S1 += t1.W[j] * e1; S2 += t2.W[j] * e2; S3 += t3.W[j] * e3;
+                if (j == 1) { f1 = e1; f2 = e2; f3 = e3; }
+                if (j == n) { l1 = e1; l2 = e2; l3 = e3; }
+                p1 = e1; p2 = e2; p3 = e3;
+            }
+        }
+    }
+    if (lane < rows_valid) {
+        send_e[p] = l1; send_e[npmax + p] = l2; send_e[2 * npmax + p] = l3;
+        send_s[p] = t1.last_r * (f1 - t1.bw1 * S1);
+        send_s[npmax + p] = t2.last_r * (f2 - t2.bw1 * S2);
+        send_s[2 * npmax + p] = t3.last_r * (f3 - t3.bw1 * S3);
+    }
+}
+
+// ---------------------------------------------------------------- transeq, backward + fused subs
+__global__ void __launch_bounds__(64)
+    k_xtranseq_bwd(double *__restrict__ rhs, const double *__restrict__ d1a, const double *__restrict__ d2a,
+                   const double *__restrict__ d3a, const double *__restrict__ cv,
+                   const double *__restrict__ own_s, const double *__restrict__ recv_s,
+                   const double *__restrict__ recv_e, double nu, TdsTab t1, TdsTab t2, TdsTab t3, int np,
+                   long pitch, int npmax)
+{
+    __shared__ double lo[TILE], lc[TILE];
+    const int lane = threadIdx.x, wave = blockIdx.x;
+    int rows_valid = np - wave * 64;
+    rows_valid = rows_valid > 64 ? 64 : rows_valid;
+    const int p = wave * 64 + (lane < rows_valid ? lane : rows_valid - 1);
+    double *__restrict__ so = rhs + (long)wave * 64 * pitch;
+    const double *__restrict__ sc = cv + (long)wave * 64 * pitch;
+    const int n = t1.n_tds;
+    const long wo = (long)wave * n * 64 + lane;
+    const long on = wo + (long)(n - 1) * 64;
+    const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
+    const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
+    const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
+    double n1 = d1a[on], n2 = d2a[on], n3 = d3a[on];
+    const double du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
+    const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
+    const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
+    const int ntile = (n + TW - 1) / TW;
+    TileRegs rc;
+    tile_load(rc, sc, pitch, (ntile - 1) * TW, rows_valid, lane);
+    for (int tI = ntile - 1; tI >= 0; tI--) {
+        __syncthreads();
+        tile_to_lds(rc, lc, lane);
+        __syncthreads();
+        if (tI > 0) tile_load(rc, sc, pitch, (tI - 1) * TW, rows_valid, lane);
+#pragma unroll 2
+        for (int c = TW - 1; c >= 0; c--) {
+            const int j = tI * TW + c + 1;
+            double out = 0.0;
+            if (j <= n) {
+                const double v = lc[c * TP + lane];
+                if (j == n) {
+                    out = -0.5 * (v * du_e * t1.St[n] + dud_e * t2.St[n]) +
+                          nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
+                } else if (j == 1) {
+                    out = -0.5 * (v * du_s * t1.St[1] + dud_s * t2.St[1]) +
+                          nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
+                } else {
+                    const long o = wo + (long)(j - 1) * 64;
+                    double c1 = d1a[o], c2 = d2a[o], c3 = d3a[o];
+                    if (j != n - 1) {
+                        c1 -= t1.Bw[j] * n1; c2 -= t2.Bw[j] * n2; c3 -= t3.Bw[j] * n3;
+                    }
+                    const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
+                    const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
+                    const double temp_d2u =
+                        t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
+                    out = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;
+                    n1 = c1; n2 = c2; n3 = c3;
+                }
+            }
+            lo[c * TP + lane] = out;
+        }
+        __syncthreads();
+        tile_store(lo, so, pitch, tI * TW, rows_valid, lane);
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static bool xdir_tiled()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_XDIR_GENERIC");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
 
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t)
 {
-    return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X);
+    if (!xdir_tiled()) return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X);
+    const int np = b->ny * b->nz, nw = (np + 63) / 64;
+    {
+        ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
+        hipLaunchKernelGGL(k_xtds_fwd, dim3(nw), dim3(64), 0, b->stream, b->scratch[2], b->send_s, b->send_e, u,
+                           t->tab, np, (long)b->nxp, t->n_tds);
+    }
+    {
+        ProfScope ps(b, X3D_K_TDS_BWD, X3D_DIR_X);
+        hipLaunchKernelGGL(k_xtds_bwd, dim3(nw), dim3(64), 0, b->stream, du, b->scratch[2], b->send_s, b->send_e,
+                           b->send_s, t->tab, np, (long)b->nxp);
+    }
+    X3D_HIP(hipGetLastError());
+    return 0;
 }
 
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
 {
-    return x3d_generic_transeq_local(b, X3D_DIR_X, rhs, u, conv, nu, t1, t2, t3);
+    if (!xdir_tiled()) return x3d_generic_transeq_local(b, X3D_DIR_X, rhs, u, conv, nu, t1, t2, t3);
+    const int np = b->ny * b->nz, nw = (np + 63) / 64, npm = npmax_of(b);
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
+        if (u == conv)
+            hipLaunchKernelGGL(k_xtranseq_fwd<true>, dim3(nw), dim3(64), 0, b->stream, b->scratch[2],
+                               b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, conv, t1->tab, t2->tab,
+                               t3->tab, np, (long)b->nxp, npm);
+        else
+            hipLaunchKernelGGL(k_xtranseq_fwd<false>, dim3(nw), dim3(64), 0, b->stream, b->scratch[2],
+                               b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, conv, t1->tab, t2->tab,
+                               t3->tab, np, (long)b->nxp, npm);
+    }
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_BWD, X3D_DIR_X);
+        hipLaunchKernelGGL(k_xtranseq_bwd, dim3(nw), dim3(64), 0, b->stream, rhs, b->scratch[2], b->scratch[0],
+                           b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab,
+                           np, (long)b->nxp, npm);
+    }
+    X3D_HIP(hipGetLastError());
+    return 0;
 }
