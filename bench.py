@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-granular", action="store_true",
+                    help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     args = ap.parse_args()
 
     import torch
@@ -87,7 +89,7 @@ def main():
     dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()
     case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
-                    poisson="CG" if args.no_poisson else "FFT", comm=comm)
+                    poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular)
     solver, backend = case.solver, case.solver.backend
     nstage = solver.time_integrator.nstage
 
@@ -164,6 +166,7 @@ def main():
                                + ("no pressure solve (configs[1])" if args.no_poisson
                                   else "rocFFT Poisson (configs[2])"),
                    "per_gpu": f"{args.n}^3", "nproc_dir": list(nproc_dir),
+                   "driver": "op-granular" if args.op_granular else "fused",
                    "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}"},
         "dof_substeps_per_s": value * nstage,
         "roofline": roofline,

@@ -82,6 +82,10 @@ int x3d_tdsops_destroy(x3d_tdsops *t);
  * Local form: the pencil direction is not decomposed (nproc_dir(dir)==1), the
  * periodic wrap / reduced 2x2 system is closed on the device. */
 int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+/* fusion extension (not in base_backend_t): accumulate != 0 gives
+ * du += scale * tds_solve(u); folds sum_{y,z}intox / vecadd into the solve */
+int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
+                      int accumulate, double scale);
 
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):
@@ -108,6 +112,11 @@ int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, con
                 const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                 const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                 const x3d_tdsops *der2nd_sym);
+/* fusion extension: accumulate != 0 gives d{u,v,w} += transeq_<dir>(u,v,w) */
+int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                    const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                    const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                    const x3d_tdsops *der2nd_sym, int accumulate);
 /* Distributed form for ONE component (transeq_dist_component, :299-338):
  * rhs = -1/2 (conv*du/dx + d(u*conv)/dx) + nu d2u/dx2.  send/recv are
  * [3][npencil] (du, dud, d2u boundary values), halos [4][npencil]. */

@@ -272,3 +272,71 @@ def test_error_behaviour_matches_reference():
         b.scalar_product(fx, fx)
     with pytest.raises(X3dError):
         b.transeq_y(fy, fy, fy, fy, fy, fy, s.nu, s.ydirps)  # NULL_LOC -> mesh%get_n stops
+
+
+# ---------------------------------------------------------------- fused driver
+def make_solver_fused(g, poisson="CG"):
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.solver import Solver, SolverConfig
+    c = namelist(g)
+    mesh = product_mesh(c)
+    cfg = SolverConfig(Re=c["Re"], dt=c["dt"], time_intg=c["time_intg"], poisson_solver_type=poisson,
+                       interpl_scheme=c["interpl"], der2nd_scheme=c["der2nd"], fused=True)
+    return Solver(HipBackend(mesh), mesh, cfg)
+
+
+@pytest.mark.parametrize("name", ["p000_rk3", "p000_ab3", "c010_rk3", "n111_rk2"])
+def test_fused_transeq_and_time_integrator_vs_reference(name):
+    """the fused driver (accumulating y/z passes, lincomb RK/AB, block swaps)
+    against the same reference vectors as the op-granular sequence"""
+    from x3d2_amd.common import DIR_X
+    g = load_golden(name)
+    s = make_solver_fused(g)
+    set_inputs(s, g)
+    b, al = s.backend, s.backend.allocator
+    if "transeq.du" in g:
+        rhs = [al.get_block(DIR_X) for _ in range(3)]
+        s.transeq(rhs, [s.u, s.v, s.w])
+        for f, k in zip(rhs, ("du", "dv", "dw")):
+            assert relerr(b.get_field_data(f), g["transeq." + k]) < TOL, k
+        for f in rhs:
+            al.release_block(f)
+    ns = s.time_integrator.nstage
+    for it in range(1, 2 * ns + 1):
+        rhs = [al.get_block(DIR_X) for _ in range(3)]
+        s.transeq(rhs, [s.u, s.v, s.w])
+        s.time_integrator.step([s.u, s.v, s.w], rhs, s.dt)
+        for f in rhs:
+            al.release_block(f)
+        if it == ns:
+            for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+                assert relerr(b.get_field_data(f), g["step1." + k]) < TOL, k
+    for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+        assert relerr(b.get_field_data(f), g["step2." + k]) < TOL, k
+
+
+@pytest.mark.parametrize("name,intg", [("tgv32_rk3_nopoisson", "RK3"), ("tgv32_ab3_nopoisson", "AB3")])
+def test_fused_tgv_trace_no_poisson_vs_reference_csv(name, intg):
+    from x3d2_amd import make_tgv
+    ref = read_csv(name)
+    case = make_tgv(32, time_intg=intg, poisson="CG", fused=True)
+    case.solver.n_output = 2
+    rows = np.array(case.run(n_iters=6))
+    assert np.allclose(rows[:, 1], ref[:, 1], rtol=1e-11)
+    assert np.allclose(rows[1:, 2], ref[1:, 2], rtol=1e-9)
+    assert np.allclose(rows[1:, 3], ref[1:, 3], rtol=1e-9)
+
+
+def test_fused_full_step_matches_op_granular_and_survey_trace():
+    """fused pressure correction (no reorders, accumulating tds) == op-granular
+    sequence == reference trace, TGV 64^3 RK3 with the FFT Poisson solve"""
+    from x3d2_amd import make_tgv
+    a = make_tgv(64, fused=True)
+    b = make_tgv(64, fused=False)
+    a.solver.n_output = b.solver.n_output = 10
+    ra, rb = a.run(n_iters=10), b.run(n_iters=10)
+    assert abs(ra[1][1] - 3.749898433321e-01) / 0.375 < 1e-11
+    assert abs(ra[1][1] - rb[1][1]) / 0.375 < 1e-13
+    assert ra[1][2] < 1e-12
+    for fa, fb in ((a.solver.u, b.solver.u), (a.solver.v, b.solver.v), (a.solver.w, b.solver.w)):
+        assert relerr(a.solver.backend.get_field_data(fa), b.solver.backend.get_field_data(fb)) < 1e-12

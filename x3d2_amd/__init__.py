@@ -9,7 +9,7 @@ from .tdsops import Dirps, Tdsops  # noqa: F401
 
 
 def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT", comm=None,
-             device=None):
+             device=None, fused=False):
     """TGV set-up of examples/TGV/input.x3d on an n^3 (or (nx,ny,nz)) grid."""
     from .backend import HipBackend
     from .case import TGVCase
@@ -19,5 +19,6 @@ def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3"
     mesh = Mesh(dims, nproc_dir, (twopi,) * 3, ("periodic",) * 2, ("periodic",) * 2, ("periodic",) * 2,
                 nrank=rank)
     backend = HipBackend(mesh, device=device, comm=comm)
-    solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson))
+    solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson,
+                                                 fused=fused))
     return TGVCase(solver)

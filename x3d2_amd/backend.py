@@ -176,6 +176,39 @@ class HipBackend:
                 self.h, direction, rhs[i].ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), fld[0].ptr,
                 float(nu), t_du.handle, t_dud.handle, t_d2u.handle))
 
+    # ------------------------------------------------------------ fused-driver forms
+    def transeq_dir(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate=False):
+        """transeq_<dir> on blocks of ANY tag (all tags share one device layout);
+        accumulate: d{u,v,w} += result -- folds reorder + sum_{y,z}intox of
+        transeq_default (src/solver.f90:320-377) into the derivative pass."""
+        if not self._decomposed(direction):
+            _lib.check(self.lib.x3d_transeq_acc(self.h, direction, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr,
+                                                float(nu), dirps.der1st.handle, dirps.der1st_sym.handle,
+                                                dirps.der2nd.handle, dirps.der2nd_sym.handle, int(accumulate)))
+            return
+        if not accumulate:
+            self._transeq_dist(direction, du, dv, dw, u, v, w, nu, dirps)
+            return
+        tmp = [self.allocator.get_block(DIR_X) for _ in range(3)]
+        self._transeq_dist(direction, tmp[0], tmp[1], tmp[2], u, v, w, nu, dirps)
+        for t, r in zip(tmp, (du, dv, dw)):
+            _lib.check(self.lib.x3d_vecadd(self.h, 1.0, t.ptr, 1.0, r.ptr))
+            self.allocator.release_block(t)
+
+    def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
+        """tds_solve with an explicit direction; accumulate: du += scale * result"""
+        if not self._decomposed(direction):
+            _lib.check(self.lib.x3d_tds_solve_acc(self.h, du.ptr, u.ptr, tdsops.handle, direction,
+                                                  int(accumulate), float(scale)))
+            return
+        if not accumulate:
+            self._tds_dist(du, u, tdsops, direction)
+            return
+        tmp = self.allocator.get_block(DIR_X)
+        self._tds_dist(tmp, u, tdsops, direction)
+        _lib.check(self.lib.x3d_vecadd(self.h, float(scale), tmp.ptr, 1.0, du.ptr))
+        self.allocator.release_block(tmp)
+
     # ------------------------------------------------------------ tds_solve
     def tds_solve(self, du, u, tdsops):
         """src/backend/omp/backend.f90:340-391"""
@@ -189,6 +222,10 @@ class HipBackend:
         if not self._decomposed(direction):
             _lib.check(self.lib.x3d_tds_solve(self.h, du.ptr, u.ptr, tdsops.handle, direction))
             return
+        self._tds_dist(du, u, tdsops, direction)
+
+    def _tds_dist(self, du, u, tdsops, direction):
+        """tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact"""
         d = direction - 1
         prev, nxt = int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
         ss, se, rs, re = self._buffers(direction, N_HALO, "u0")

@@ -194,28 +194,37 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
     send_s[p] = t.last_r * (d1 - t.bw1 * S);         // distributed.f90:161-166 with du_2 = S
 }
 
-// backward sweep fused with der_univ_subs
-__global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const double *__restrict__ own_s,
+// backward sweep fused with der_univ_subs.  d (forward-eliminated values) may
+// alias du (in-place, ACC = false only).  ACC: du += scale * result, which is
+// how the fused driver folds sum_yintox/sum_zintox and the velocity correction
+// vecadd(-1, dpdx, 1, u) into this pass.
+template <bool ACC>
+__global__ void __launch_bounds__(64) k_tds_bwd(double *du, const double *d, const double *__restrict__ own_s,
                                                 const double *__restrict__ recv_s,
-                                                const double *__restrict__ recv_e, TdsTab t, PencilGeom g)
+                                                const double *__restrict__ recv_e, TdsTab t, PencilGeom g,
+                                                double scale)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t.n_tds;
-    const double dn = du[base + (long)(n - 1) * rs];
+    auto put = [&](long o, double v) {
+        if (ACC) du[o] = du[o] + scale * v;
+        else du[o] = v;
+    };
+    const double dn = d[base + (long)(n - 1) * rs];
     const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);  // distributed.f90:196-199
     const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
-    du[base + (long)(n - 1) * rs] = du_e * t.St[n];               // :224-228
-    double nxt = du[base + (long)(n - 2) * rs];                   // row n-1: no backward update
-    du[base + (long)(n - 2) * rs] = (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1];
+    put(base + (long)(n - 1) * rs, du_e * t.St[n]);               // :224-228
+    double nxt = d[base + (long)(n - 2) * rs];                    // row n-1: no backward update
+    put(base + (long)(n - 2) * rs, (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1]);
 #pragma unroll 4
     for (int j = n - 2; j >= 2; j--) {
-        const double cur = du[base + (long)(j - 1) * rs] - t.Bw[j] * nxt;  // :154-160
-        du[base + (long)(j - 1) * rs] = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];  // :215-222
+        const double cur = d[base + (long)(j - 1) * rs] - t.Bw[j] * nxt;  // :154-160
+        put(base + (long)(j - 1) * rs, (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j]);  // :215-222
         nxt = cur;
     }
-    du[base] = du_s * t.St[1];  // :209-213
+    put(base, du_s * t.St[1]);  // :209-213
 }
 
 // forward sweep of one transport-equation component: three operators share
@@ -295,12 +304,15 @@ __global__ void __launch_bounds__(64)
     send_s[2 * npmax + p] = t3.last_r * (f3 - t3.bw1 * S3);
 }
 
-// backward sweep fused with der_univ_fused_subs (distributed.f90:231-337)
+// backward sweep fused with der_univ_fused_subs (distributed.f90:231-337).
+// d_du may alias rhs (in-place form, ACC = false); ACC: rhs += result.
+template <bool ACC>
 __global__ void __launch_bounds__(64)
-    k_transeq_bwd(double *__restrict__ rhs, const double *__restrict__ d_dud, const double *__restrict__ d_d2u,
-                  const double *__restrict__ cv, const double *__restrict__ own_s,
-                  const double *__restrict__ recv_s, const double *__restrict__ recv_e, double nu, TdsTab t1,
-                  TdsTab t2, TdsTab t3, PencilGeom g, int npmax)
+    k_transeq_bwd(double *rhs, const double *d_du, const double *__restrict__ d_dud,
+                  const double *__restrict__ d_d2u, const double *__restrict__ cv,
+                  const double *__restrict__ own_s, const double *__restrict__ recv_s,
+                  const double *__restrict__ recv_e, double nu, TdsTab t1, TdsTab t2, TdsTab t3, PencilGeom g,
+                  int npmax)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
@@ -310,38 +322,42 @@ __global__ void __launch_bounds__(64)
     const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
     const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
     const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
-    double n1 = rhs[on], n2 = d_dud[on], n3 = d_d2u[on];
+    auto put = [&](long o, double v) {
+        if (ACC) rhs[o] = rhs[o] + v;
+        else rhs[o] = v;
+    };
+    double n1 = d_du[on], n2 = d_dud[on], n3 = d_d2u[on];
     const double du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
     const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
     const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
     // row n (:328-335)
-    rhs[on] = -0.5 * (cv[on] * du_e * t1.St[n] + dud_e * t2.St[n]) +
-              nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
+    put(on, -0.5 * (cv[on] * du_e * t1.St[n] + dud_e * t2.St[n]) +
+                nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]));
 
     auto emit = [&](int j, double c1, double c2, double c3) {
         const long o = base + (long)(j - 1) * rs;
         const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
         const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
         const double temp_d2u = t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
-        rhs[o] = -0.5 * (cv[o] * temp_du + temp_dud) + nu * temp_d2u;  // :315-324
+        put(o, -0.5 * (cv[o] * temp_du + temp_dud) + nu * temp_d2u);  // :315-324
     };
     {
         const long o = base + (long)(n - 2) * rs;  // row n-1: forward values, no backward update
-        n1 = rhs[o]; n2 = d_dud[o]; n3 = d_d2u[o];
+        n1 = d_du[o]; n2 = d_dud[o]; n3 = d_d2u[o];
         emit(n - 1, n1, n2, n3);
     }
 #pragma unroll 2
     for (int j = n - 2; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
-        const double c1 = rhs[o] - t1.Bw[j] * n1;
+        const double c1 = d_du[o] - t1.Bw[j] * n1;
         const double c2 = d_dud[o] - t2.Bw[j] * n2;
         const double c3 = d_d2u[o] - t3.Bw[j] * n3;
         emit(j, c1, c2, c3);
         n1 = c1; n2 = c2; n3 = c3;
     }
     // row 1 (:304-311)
-    rhs[base] = -0.5 * (cv[base] * du_s * t1.St[1] + dud_s * t2.St[1]) +
-                nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
+    put(base, -0.5 * (cv[base] * du_s * t1.St[1] + dud_s * t2.St[1]) +
+                  nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]));
 }
 
 // copy_into_buffers (src/backend/omp/backend.f90:714-737): rows 1..4 and n-3..n
@@ -359,12 +375,15 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 }
 
 // ------------------------------------------------------------------ launchers
-int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t);  // xdir.hip
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
-int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+// xdir.hip
+int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
-                     const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+                     const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
+int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                          double scale);
+int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                              int acc);
 
 static inline dim3 grid_for(const PencilGeom &g) { return dim3((g.np + 63) / 64); }
 
@@ -411,36 +430,48 @@ extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_sen
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
-    hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_recv_s, du_recv_e,
-                       t->tab, g);
+    hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)du, du_send_s,
+                       du_recv_s, du_recv_e, t->tab, g, 1.0);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 // Local form: sendrecv_fields with nproc==1 hands every rank its own buffers
 // back swapped (src/backend/omp/sendrecv.f90:20-22): recv_s = send_e, recv_e = send_s.
-extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
+                                 int accumulate, double scale)
 {
     X3D_REQUIRE(b && du && u && t, "x3d_tds_solve: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve: bad dir %d", dir);
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
-    if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t);
-    return x3d_generic_tds_local(b, du, u, t, dir);
+    if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t, accumulate, scale);
+    return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+{
+    return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);
+}
+
+int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                          double scale)
 {
     PencilGeom g = x3d_geom(b, dir);
+    double *d = acc ? b->scratch[2] : du;  // the accumulate form must not clobber du
     {
         ProfScope ps(b, X3D_K_TDS_FWD, dir);
-        hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, u,
+        hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
                            (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
     }
     {
         ProfScope ps(b, X3D_K_TDS_BWD, dir);
-        hipLaunchKernelGGL(k_tds_bwd, grid_for(g), dim3(64), 0, b->stream, du, b->send_s, b->send_e, b->send_s,
-                           t->tab, g);
+        if (acc)
+            hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)d,
+                               b->send_s, b->send_e, b->send_s, t->tab, g, scale);
+        else
+            hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)d,
+                               b->send_s, b->send_e, b->send_s, t->tab, g, 1.0);
     }
     X3D_HIP(hipGetLastError());
     return 0;
@@ -492,40 +523,50 @@ extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const 
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
-    hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
-                       conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
+    hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)rhs,
+                       b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab,
+                       t_d2u->tab, g, g.np);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                                   int acc)
 {
-    if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3);
-    return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3);
+    if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
+    return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
 }
 
 int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                              int acc)
 {
     PencilGeom g = x3d_geom(b, dir);
+    double *d1 = b->scratch[2];
     const int npm = npmax_of(b);
     const double *z = nullptr;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
         if (u == conv)
-            hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, rhs,
+            hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
         else
-            hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, rhs,
+            hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
     }
     {
         ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
-        hipLaunchKernelGGL(k_transeq_bwd, grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0], b->scratch[1],
-                           conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab, g, npm);
+        if (acc)
+            hipLaunchKernelGGL(k_transeq_bwd<true>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)d1,
+                               b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
+                               t2->tab, t3->tab, g, npm);
+        else
+            hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)d1,
+                               b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
+                               t2->tab, t3->tab, g, npm);
     }
     X3D_HIP(hipGetLastError());
     return 0;
@@ -537,6 +578,14 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, doub
                            const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                            const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                            const x3d_tdsops *der2nd_sym)
+{
+    return x3d_transeq_acc(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0);
+}
+
+extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                               const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                               const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                               const x3d_tdsops *der2nd_sym, int accumulate)
 {
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym,
                 "x3d_transeq: null argument");
@@ -551,8 +600,9 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, doub
     for (int c = 0; c < 3; c++) {
         X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq: outputs alias inputs");
     }
-    if (int rc = transeq_component_local(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd)) return rc;
-    if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym)) return rc;
-    if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym)) return rc;
+    const int a = accumulate;
+    if (int rc = transeq_component_local(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, a)) return rc;
+    if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
+    if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
     return 0;
 }

@@ -14,9 +14,11 @@
 // Reference arithmetic: src/backend/omp/kernels/distributed.f90:11-337 (see tds.hip).
 #include "common.h"
 
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                          double scale);
 int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                              int acc);
 int npmax_of(const x3d_backend *b);
 
 #define TW 16        // tile width (columns)
@@ -62,8 +64,9 @@ __device__ __forceinline__ void tile_to_lds(const TileRegs &r, double *__restric
     }
 }
 
+template <bool ACC>
 __device__ __forceinline__ void tile_store(const double *__restrict__ lds, double *__restrict__ slab, long pitch,
-                                           int col0, int rows_valid, int lane)
+                                           int col0, int rows_valid, int lane, double scale)
 {
     const int cp = (lane & 7) * 2;
 #pragma unroll
@@ -73,7 +76,13 @@ __device__ __forceinline__ void tile_store(const double *__restrict__ lds, doubl
             double2 v;
             v.x = lds[cp * TP + row];
             v.y = lds[(cp + 1) * TP + row];
-            *reinterpret_cast<double2 *>(slab + (long)row * pitch + col0 + cp) = v;
+            double2 *dst = reinterpret_cast<double2 *>(slab + (long)row * pitch + col0 + cp);
+            if (ACC) {
+                const double2 o = *dst;
+                v.x = o.x + scale * v.x;
+                v.y = o.y + scale * v.y;
+            }
+            *dst = v;
         }
     }
 }
@@ -142,10 +151,12 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
 }
 
 // ---------------------------------------------------------------- tds, backward + subs
+template <bool ACC>
 __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const double *__restrict__ d,
                                                  const double *__restrict__ own_s,
                                                  const double *__restrict__ recv_s,
-                                                 const double *__restrict__ recv_e, TdsTab t, int np, long pitch)
+                                                 const double *__restrict__ recv_e, TdsTab t, int np, long pitch,
+                                                 double scale)
 {
     __shared__ double lds[TILE];
     const int lane = threadIdx.x, wave = blockIdx.x;
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const 
             lds[c * TP + lane] = out;
         }
         __syncthreads();
-        tile_store(lds, slab, pitch, tI * TW, rows_valid, lane);
+        tile_store<ACC>(lds, slab, pitch, tI * TW, rows_valid, lane, scale);
     }
 }
 
@@ -273,6 +284,7 @@ __global__ void __launch_bounds__(64)
 }
 
 // ---------------------------------------------------------------- transeq, backward + fused subs
+template <bool ACC>
 __global__ void __launch_bounds__(64)
     k_xtranseq_bwd(double *__restrict__ rhs, const double *__restrict__ d1a, const double *__restrict__ d2a,
                    const double *__restrict__ d3a, const double *__restrict__ cv,
@@ -334,7 +346,7 @@ __global__ void __launch_bounds__(64)
             lo[c * TP + lane] = out;
         }
         __syncthreads();
-        tile_store(lo, so, pitch, tI * TW, rows_valid, lane);
+        tile_store<ACC>(lo, so, pitch, tI * TW, rows_valid, lane, 1.0);
     }
 }
 
@@ -349,9 +361,9 @@ static bool xdir_tiled()
     return mode == 1;
 }
 
-int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t)
+int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale)
 {
-    if (!xdir_tiled()) return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X);
+    if (!xdir_tiled()) return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X, acc, scale);
     const int np = b->ny * b->nz, nw = (np + 63) / 64;
     {
         ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
@@ -360,17 +372,21 @@ int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *
     }
     {
         ProfScope ps(b, X3D_K_TDS_BWD, X3D_DIR_X);
-        hipLaunchKernelGGL(k_xtds_bwd, dim3(nw), dim3(64), 0, b->stream, du, b->scratch[2], b->send_s, b->send_e,
-                           b->send_s, t->tab, np, (long)b->nxp);
+        if (acc)
+            hipLaunchKernelGGL(k_xtds_bwd<true>, dim3(nw), dim3(64), 0, b->stream, du, b->scratch[2], b->send_s,
+                               b->send_e, b->send_s, t->tab, np, (long)b->nxp, scale);
+        else
+            hipLaunchKernelGGL(k_xtds_bwd<false>, dim3(nw), dim3(64), 0, b->stream, du, b->scratch[2], b->send_s,
+                               b->send_e, b->send_s, t->tab, np, (long)b->nxp, 1.0);
     }
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
-                     const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+                     const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc)
 {
-    if (!xdir_tiled()) return x3d_generic_transeq_local(b, X3D_DIR_X, rhs, u, conv, nu, t1, t2, t3);
+    if (!xdir_tiled()) return x3d_generic_transeq_local(b, X3D_DIR_X, rhs, u, conv, nu, t1, t2, t3, acc);
     const int np = b->ny * b->nz, nw = (np + 63) / 64, npm = npmax_of(b);
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
@@ -385,9 +401,14 @@ int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double 
     }
     {
         ProfScope ps(b, X3D_K_TRANSEQ_BWD, X3D_DIR_X);
-        hipLaunchKernelGGL(k_xtranseq_bwd, dim3(nw), dim3(64), 0, b->stream, rhs, b->scratch[2], b->scratch[0],
-                           b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab, t2->tab, t3->tab,
-                           np, (long)b->nxp, npm);
+        if (acc)
+            hipLaunchKernelGGL(k_xtranseq_bwd<true>, dim3(nw), dim3(64), 0, b->stream, rhs, b->scratch[2],
+                               b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
+                               t2->tab, t3->tab, np, (long)b->nxp, npm);
+        else
+            hipLaunchKernelGGL(k_xtranseq_bwd<false>, dim3(nw), dim3(64), 0, b->stream, rhs, b->scratch[2],
+                               b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
+                               t2->tab, t3->tab, np, (long)b->nxp, npm);
     }
     X3D_HIP(hipGetLastError());
     return 0;

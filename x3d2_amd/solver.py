@@ -15,12 +15,16 @@ class SolverConfig:
 
     def __init__(self, Re=1600.0, dt=1e-3, n_iters=10, n_output=0, time_intg="RK3", poisson_solver_type="FFT",
                  der1st_scheme="compact6", der2nd_scheme="compact6", interpl_scheme="classic",
-                 stagder_scheme="compact6", lowmem_transeq=False):
+                 stagder_scheme="compact6", lowmem_transeq=False, fused=False):
         self.Re, self.dt, self.n_iters, self.n_output = Re, dt, n_iters, n_output
         self.time_intg, self.poisson_solver_type = time_intg, poisson_solver_type
         self.der1st_scheme, self.der2nd_scheme = der1st_scheme, der2nd_scheme
         self.interpl_scheme, self.stagder_scheme = interpl_scheme, stagder_scheme
         self.lowmem_transeq = lowmem_transeq
+        # fused = False: op-granular sequences exactly as the reference issues them;
+        # fused = True : same arithmetic with reorders / sums / axpy chains folded
+        #                into the kernels
+        self.fused = fused
 
 
 def allocate_tdsops(dirps, backend, mesh, der1st_scheme, der2nd_scheme, interpl_scheme, stagder_scheme):
@@ -61,7 +65,8 @@ class Solver:
         al = backend.allocator
         self.u, self.v, self.w = (al.get_block(DIR_X) for _ in range(3))
         self.nvars = 3
-        self.time_integrator = TimeIntegrator(backend, al, cfg.time_intg, self.nvars)
+        self.fused = bool(cfg.fused)
+        self.time_integrator = TimeIntegrator(backend, al, cfg.time_intg, self.nvars, fused=self.fused)
         self.dt, self.nu = cfg.dt, 1.0 / cfg.Re
         self.n_iters, self.n_output = cfg.n_iters, cfg.n_output
         self.ngrid = int(np.prod(mesh.get_global_dims(VERT)))
@@ -76,7 +81,9 @@ class Solver:
             self.poisson = self.poisson_cg
         else:
             raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
-        self.transeq = self.transeq_default
+        self.transeq = self.transeq_fused if self.fused else self.transeq_default
+        if self.fused:
+            self.pressure_correction = self.pressure_correction_fused
 
     # ---- src/solver.f90:291-389
     def transeq_default(self, rhs, variables):
@@ -107,6 +114,55 @@ class Solver:
         b.sum_zintox(dv, dv_z)
         b.sum_zintox(dw, dw_z)
         for f in (du_z, dv_z, dw_z):
+            al.release_block(f)
+
+    def transeq_fused(self, rhs, variables):
+        """transeq_default without the 6 reorders and 6 sum_*intox: every block
+        shares one device layout, so the y and z passes read u, v, w in place and
+        accumulate straight into du, dv, dw."""
+        b = self.backend
+        du, dv, dw = rhs
+        u, v, w = variables
+        b.mesh.get_n(DIR_X, u.data_loc)
+        b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
+        b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
+        b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
+        for f in rhs:
+            f.set_data_loc(u.data_loc)
+
+    def pressure_correction_fused(self, u, v, w):
+        """pressure_correction (:693-739) = divergence_v2c + Poisson + gradient_c2v +
+        velocity update with the 10 reorders removed and the 5 vecadd's folded
+        into the accumulating form of the last tds_solve of each chain."""
+        b, al = self.backend, self.backend.allocator
+        x, y, z = self.xdirps, self.ydirps, self.zdirps
+        t1, t2, t3, a1, a2 = (al.get_block(DIR_X) for _ in range(5))
+        # divergence_v2c, src/vector_calculus.f90:142-246
+        b.tds_apply(t1, u, x.stagder_v2p, DIR_X)
+        b.tds_apply(t2, v, x.interpl_v2p, DIR_X)
+        b.tds_apply(t3, w, x.interpl_v2p, DIR_X)
+        b.tds_apply(a1, t1, y.interpl_v2p, DIR_Y)
+        b.tds_apply(a1, t2, y.stagder_v2p, DIR_Y, accumulate=True)
+        b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
+        div = t1
+        b.tds_apply(div, a1, z.interpl_v2p, DIR_Z)
+        b.tds_apply(div, a2, z.stagder_v2p, DIR_Z, accumulate=True)
+        # poisson: the cell-centred divergence is already Cartesian (no Z2C / C2Z)
+        p = div
+        if self.cfg.poisson_solver_type == "FFT":
+            b.poisson_fft.solve_poisson(p, None)
+        else:
+            p.fill(0.0)
+        # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
+        b.tds_apply(t2, p, z.interpl_p2v, DIR_Z)        # p_sxy
+        b.tds_apply(t3, p, z.stagder_p2v, DIR_Z)        # dpdz_sxy
+        b.tds_apply(a1, t2, y.interpl_p2v, DIR_Y)       # p_sx
+        b.tds_apply(a2, t2, y.stagder_p2v, DIR_Y)       # dpdy_sx
+        b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)       # dpdz_sx
+        b.tds_apply(u, a1, x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
+        b.tds_apply(v, a2, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+        b.tds_apply(w, t1, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+        for f in (t1, t2, t3, a1, a2):
             al.release_block(f)
 
     # ---- :603-651

@@ -17,8 +17,9 @@ class TimeIntegrator:
           3: (23.0 / 12.0, -4.0 / 3.0, 5.0 / 12.0, 0.0),
           4: (55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -3.0 / 8.0)}
 
-    def __init__(self, backend, allocator, method, nvars=3):
+    def __init__(self, backend, allocator, method, nvars=3, fused=False):
         self.backend, self.allocator, self.sname = backend, allocator, method
+        self.fused = fused
         self.gdt = 0.0
         try:
             self.order = int(method[2])
@@ -28,10 +29,10 @@ class TimeIntegrator:
             raise X3dError("Integration order >4 is not supported")
         if method[:2] == "AB":
             self.nstep, self.nstage, self.nolds = self.order, 1, self.order - 1
-            self.step = self.adams_bashforth
+            self.step = self.adams_bashforth_fused if fused else self.adams_bashforth
         elif method[:2] == "RK":
             self.nstep, self.nstage, self.nolds = 1, self.order, self.order
-            self.step = self.runge_kutta
+            self.step = self.runge_kutta_fused if fused else self.runge_kutta
         else:
             raise X3dError("Integration method " + method + " is not defined")
         self.nvars, self.istep, self.istage = nvars, 1, 1
@@ -84,6 +85,55 @@ class TimeIntegrator:
                 self._rotate(self.olds[i], nstep - 1)
             if self.nstep > 1:
                 b.veccopy(self.olds[i][0], deriv[i])
+        self.istep += 1
+
+    # ---- fused forms: same update formulas, one pass per variable.  The
+    # veccopy's become block swaps (the Field objects keep their identity, the
+    # device buffers change hands) and each vecadd chain becomes one lincomb.
+    @staticmethod
+    def _swap(a, b):
+        a.data, b.data = b.data, a.data
+
+    def runge_kutta_fused(self, curr, deriv, dt):
+        b, ns = self.backend, self.nstage
+        a, bb = self.RK_A[ns], self.RK_B[ns]
+        self.gdt = bb[self.istage - 1] * dt
+        if self.istage == ns:
+            for i in range(self.nvars):
+                terms = [(bb[j - 1] * dt, self.olds[i][j]) for j in range(1, ns) if bb[j - 1] != 0.0]
+                terms.append((bb[ns - 1] * dt, deriv[i]))
+                base = self.olds[i][0] if ns > 1 else curr[i]
+                b.lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms])
+            self.istage = 1
+        else:
+            st = self.istage
+            for i in range(self.nvars):
+                if st == 1:
+                    self._swap(self.olds[i][0], curr[i])     # olds1 <- curr (curr is rewritten below)
+                self._swap(self.olds[i][st], deriv[i])       # olds_{st+1} <- deriv
+                terms = [(a[st - 1][j - 1] * dt, self.olds[i][j]) for j in range(1, st + 1)
+                         if a[st - 1][j - 1] != 0.0]
+                if terms:
+                    b.lincomb(curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms])
+                else:
+                    b.veccopy(curr[i], self.olds[i][0])
+            self.istage += 1
+
+    def adams_bashforth_fused(self, curr, deriv, dt):
+        b = self.backend
+        self.gdt = dt
+        nstep = min(self.istep, self.nstep)
+        c = self.AB[nstep]
+        for i in range(self.nvars):
+            terms = [(c[0] * dt, deriv[i])] + [(c[j - 1] * dt, self.olds[i][j - 2]) for j in range(2, nstep + 1)]
+            b.lincomb(curr[i], curr[i], [x for x, _ in terms], [f for _, f in terms])
+            if nstep < self.nstep:
+                if self.istep > 1:
+                    self._rotate(self.olds[i], nstep)
+            elif self.nstep > 2:
+                self._rotate(self.olds[i], nstep - 1)
+            if self.nstep > 1:
+                self._swap(self.olds[i][0], deriv[i])
         self.istep += 1
 
     @staticmethod
