@@ -375,6 +375,20 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 }
 
 // ------------------------------------------------------------------ launchers
+// fused.hip: single-launch checkpoint/recompute form for non-decomposed directions
+int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                        double scale);
+int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                            const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
+static bool use_fused_kernels()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_TWO_SWEEP");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
 // xdir.hip
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
@@ -446,6 +460,7 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t, accumulate, scale);
+    if (use_fused_kernels()) return x3d_fused_tds_local(b, du, u, t, dir, accumulate, scale);
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
@@ -535,6 +550,7 @@ static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const d
                                    int acc)
 {
     if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
+    if (use_fused_kernels()) return x3d_fused_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
     return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
 }
 
