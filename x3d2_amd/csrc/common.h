@@ -10,6 +10,7 @@
 #include "../../include/x3d2_hip.h"
 
 #define X3D_NH 4
+#define X3D_CK 16  // checkpoint spacing of the block-recompute backward sweep
 
 void x3d_set_error(const char *fmt, ...);
 

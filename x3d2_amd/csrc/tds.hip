@@ -140,8 +140,11 @@ __device__ __forceinline__ long pencil_base(const PencilGeom &g, int p)
     return (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1;
 }
 
-// forward sweep, one operator (der_univ_dist without its backward loop)
-template <bool HB>
+// forward sweep, one operator (der_univ_dist without its backward loop).
+// CKPT: keep only every X3D_CK-th forward-eliminated value (compact buffer
+// [j/CK][pencil]); the block-recompute backward kernel of fused.hip rebuilds
+// the rest from the inputs.
+template <bool HB, bool CKPT>
 __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *__restrict__ send_s,
                                                 double *__restrict__ send_e, const double *__restrict__ u,
                                                 const double *__restrict__ hs, const double *__restrict__ he,
@@ -160,7 +163,11 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
         const double acc = dot9(c, w);
         const double dj = t.F[j] * (acc - t.A[j] * dprev);
         if (j <= n) {
-            d[base + (long)(j - 1) * rs] = dj;
+            if (CKPT) {
+                if (j % X3D_CK == 0) d[(long)(j / X3D_CK) * g.np + p] = dj;
+            } else {
+                d[base + (long)(j - 1) * rs] = dj;
+            }
             S += t.W[j] * dj;
             if (j == 1) d1 = dj;
             if (j == n) dn = dj;
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *du, const double *d, con
 
 // forward sweep of one transport-equation component: three operators share
 // the loads of u and conv (exec_dist.f90:114-160)
-template <bool HB, bool SAME>
+template <bool HB, bool SAME, bool CKPT>
 __global__ void __launch_bounds__(64)
     k_transeq_fwd(double *__restrict__ d_du, double *__restrict__ d_dud, double *__restrict__ d_d2u,
                   double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
@@ -256,8 +263,15 @@ __global__ void __launch_bounds__(64)
         const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
         const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
         const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
-        const long o = base + (long)(j - 1) * rs;
-        d_du[o] = e1; d_dud[o] = e2; d_d2u[o] = e3;
+        if (CKPT) {
+            if (j % X3D_CK == 0) {  // compact [j/CK][op][pencil] in d_du
+                const long o = (long)(j / X3D_CK) * 3 * g.np + p;
+                d_du[o] = e1; d_du[o + g.np] = e2; d_du[o + 2 * (long)g.np] = e3;
+            }
+        } else {
+            const long o = base + (long)(j - 1) * rs;
+            d_du[o] = e1; d_dud[o] = e2; d_d2u[o] = e3;
+        }
         S1 += t1.W[j] * e1; S2 += t2.W[j] * e2; S3 += t3.W[j] * e3;
         if (j == 1) { f1 = e1; f2 = e2; f3 = e3; }
         if (j == n) { l1 = e1; l2 = e2; l3 = e3; }
@@ -375,11 +389,19 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 }
 
 // ------------------------------------------------------------------ launchers
-// fused.hip: single-launch checkpoint/recompute form for non-decomposed directions
-int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                        double scale);
-int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
-                            const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
+// fused.hip: block-recompute backward sweep (checkpoint form)
+int x3d_ck_bwd_tds(x3d_backend *b, double *du, const double *u, const double *hs, const double *he,
+                   const double *ckpt, const double *own_s, const double *recv_s, const double *recv_e,
+                   const x3d_tdsops *t, int dir, int acc, double scale);
+int x3d_ck_bwd_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *us, const double *ue,
+                       const double *conv, const double *cs, const double *ce, const double *ckpt,
+                       const double *own_s, const double *recv_s, const double *recv_e, int bstride, double nu,
+                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
+static int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                               double scale);
+static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                                   int acc);
 static bool use_fused_kernels()
 {
     static int mode = -1;
@@ -431,7 +453,7 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-    hipLaunchKernelGGL(k_tds_fwd<true>, grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_send_e, u,
+    hipLaunchKernelGGL((k_tds_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_send_e, u,
                        u_recv_s, u_recv_e, t->tab, g, t->n_tds);
     X3D_HIP(hipGetLastError());
     return 0;
@@ -476,7 +498,7 @@ int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d
     double *d = acc ? b->scratch[2] : du;  // the accumulate form must not clobber du
     {
         ProfScope ps(b, X3D_K_TDS_FWD, dir);
-        hipLaunchKernelGGL(k_tds_fwd<false>, grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
+        hipLaunchKernelGGL((k_tds_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
                            (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
     }
     {
@@ -522,7 +544,7 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     PencilGeom g = x3d_geom(b, dir);
     // [3][npencil] boundary buffers are contiguous with stride np
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-    hipLaunchKernelGGL((k_transeq_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0],
+    hipLaunchKernelGGL((k_transeq_fwd<true, false, false>), grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0],
                        b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
                        t_du->tab, t_dud->tab, t_d2u->tab, g, t_du->n_tds, g.np);
     X3D_HIP(hipGetLastError());
@@ -565,11 +587,11 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
         if (u == conv)
-            hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, d1,
+            hipLaunchKernelGGL((k_transeq_fwd<false, true, false>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
         else
-            hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d1,
+            hipLaunchKernelGGL((k_transeq_fwd<false, false, false>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
     }
@@ -621,4 +643,46 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
     if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
     if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
     return 0;
+}
+
+// ------------------------------------------------------------------ checkpoint form, local
+// forward kernel keeps 1/CK of the eliminated values; the backward kernel
+// (fused.hip) recomputes each block from the inputs.  ~7 field passes per
+// transport-equation component instead of 10-11, 3.5 instead of 4 per tds_solve.
+static int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                               double scale)
+{
+    PencilGeom g = x3d_geom(b, dir);
+    const double *z = nullptr;
+    {
+        ProfScope ps(b, X3D_K_TDS_FWD, dir);
+        hipLaunchKernelGGL((k_tds_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2],
+                           b->send_s, b->send_e, u, z, z, t->tab, g, t->n_tds);
+    }
+    X3D_HIP(hipGetLastError());
+    return x3d_ck_bwd_tds(b, du, u, z, z, b->scratch[2], b->send_s, b->send_e, b->send_s, t, dir, acc, scale);
+}
+
+static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
+                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+                                   int acc)
+{
+    PencilGeom g = x3d_geom(b, dir);
+    const int npm = npmax_of(b);
+    const double *z = nullptr;
+    double *ck = b->scratch[2];
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+        if (u == conv)
+            hipLaunchKernelGGL((k_transeq_fwd<false, true, true>), grid_for(g), dim3(64), 0, b->stream, ck, ck, ck,
+                               b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab, t2->tab, t3->tab, g, t1->n_tds,
+                               npm);
+        else
+            hipLaunchKernelGGL((k_transeq_fwd<false, false, true>), grid_for(g), dim3(64), 0, b->stream, ck, ck, ck,
+                               b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab, t2->tab, t3->tab, g, t1->n_tds,
+                               npm);
+    }
+    X3D_HIP(hipGetLastError());
+    return x3d_ck_bwd_transeq(b, dir, rhs, u, z, z, conv, z, z, ck, b->send_s, b->send_e, b->send_s, npm, nu, t1,
+                              t2, t3, acc);
 }
