@@ -201,12 +201,16 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
     send_s[p] = t.last_r * (d1 - t.bw1 * S);         // distributed.f90:161-166 with du_2 = S
 }
 
-// backward sweep fused with der_univ_subs.  d (forward-eliminated values) may
-// alias du (in-place, ACC = false only).  ACC: du += scale * result, which is
-// how the fused driver folds sum_yintox/sum_zintox and the velocity correction
-// vecadd(-1, dpdx, 1, u) into this pass.
+// backward sweep fused with der_univ_subs.  d holds the forward-eliminated
+// values and never aliases du (the launchers keep it in backend scratch), so
+// both are __restrict__ and the loads of a batch of UB rows are issued before
+// the serial back-substitution touches them.  ACC: du += scale * result, which
+// is how the fused driver folds sum_yintox/sum_zintox and the velocity
+// correction vecadd(-1, dpdx, 1, u) into this pass.
+#define UB 8
 template <bool ACC>
-__global__ void __launch_bounds__(64) k_tds_bwd(double *du, const double *d, const double *__restrict__ own_s,
+__global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const double *__restrict__ d,
+                                                const double *__restrict__ own_s,
                                                 const double *__restrict__ recv_s,
                                                 const double *__restrict__ recv_e, TdsTab t, PencilGeom g,
                                                 double scale)
@@ -215,23 +219,46 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *du, const double *d, con
     if (p >= g.np) return;
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t.n_tds;
-    auto put = [&](long o, double v) {
-        if (ACC) du[o] = du[o] + scale * v;
+    auto put = [&](long o, double v, double old) {
+        if (ACC) du[o] = old + scale * v;
         else du[o] = v;
     };
     const double dn = d[base + (long)(n - 1) * rs];
     const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);  // distributed.f90:196-199
     const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
-    put(base + (long)(n - 1) * rs, du_e * t.St[n]);               // :224-228
-    double nxt = d[base + (long)(n - 2) * rs];                    // row n-1: no backward update
-    put(base + (long)(n - 2) * rs, (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1]);
-#pragma unroll 4
-    for (int j = n - 2; j >= 2; j--) {
-        const double cur = d[base + (long)(j - 1) * rs] - t.Bw[j] * nxt;  // :154-160
-        put(base + (long)(j - 1) * rs, (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j]);  // :215-222
+    {
+        const long o = base + (long)(n - 1) * rs;
+        put(o, du_e * t.St[n], ACC ? du[o] : 0.0);  // :224-228
+    }
+    double nxt = d[base + (long)(n - 2) * rs];  // row n-1: no backward update
+    {
+        const long o = base + (long)(n - 2) * rs;
+        put(o, (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1], ACC ? du[o] : 0.0);
+    }
+    int j = n - 2;
+    for (; j - UB + 1 >= 2; j -= UB) {
+        double dv[UB], ov[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const long o = base + (long)(j - k - 1) * rs;
+            dv[k] = d[o];
+            ov[k] = ACC ? du[o] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const int jj = j - k;
+            const double cur = dv[k] - t.Bw[jj] * nxt;                                      // :154-160
+            put(base + (long)(jj - 1) * rs, (cur - t.Sa[jj] * du_s - t.Sc[jj] * du_e) * t.St[jj], ov[k]);  // :215-222
+            nxt = cur;
+        }
+    }
+    for (; j >= 2; j--) {
+        const long o = base + (long)(j - 1) * rs;
+        const double cur = d[o] - t.Bw[j] * nxt;
+        put(o, (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j], ACC ? du[o] : 0.0);
         nxt = cur;
     }
-    put(base, du_s * t.St[1]);  // :209-213
+    put(base, du_s * t.St[1], ACC ? du[base] : 0.0);  // :209-213
 }
 
 // forward sweep of one transport-equation component: three operators share
@@ -319,10 +346,13 @@ __global__ void __launch_bounds__(64)
 }
 
 // backward sweep fused with der_univ_fused_subs (distributed.f90:231-337).
-// d_du may alias rhs (in-place form, ACC = false); ACC: rhs += result.
+// The three forward-eliminated arrays live in backend scratch and never alias
+// rhs; ACC: rhs += result.  Loads of UT rows are batched ahead of the serial
+// back-substitution.
+#define UT 4
 template <bool ACC>
 __global__ void __launch_bounds__(64)
-    k_transeq_bwd(double *rhs, const double *d_du, const double *__restrict__ d_dud,
+    k_transeq_bwd(double *__restrict__ rhs, const double *__restrict__ d_du, const double *__restrict__ d_dud,
                   const double *__restrict__ d_d2u, const double *__restrict__ cv,
                   const double *__restrict__ own_s, const double *__restrict__ recv_s,
                   const double *__restrict__ recv_e, double nu, TdsTab t1, TdsTab t2, TdsTab t3, PencilGeom g,
@@ -336,8 +366,8 @@ __global__ void __launch_bounds__(64)
     const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
     const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
     const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
-    auto put = [&](long o, double v) {
-        if (ACC) rhs[o] = rhs[o] + v;
+    auto put = [&](long o, double v, double old) {
+        if (ACC) rhs[o] = old + v;
         else rhs[o] = v;
     };
     double n1 = d_du[on], n2 = d_dud[on], n3 = d_d2u[on];
@@ -346,32 +376,49 @@ __global__ void __launch_bounds__(64)
     const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
     // row n (:328-335)
     put(on, -0.5 * (cv[on] * du_e * t1.St[n] + dud_e * t2.St[n]) +
-                nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]));
+                nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]), ACC ? rhs[on] : 0.0);
 
-    auto emit = [&](int j, double c1, double c2, double c3) {
-        const long o = base + (long)(j - 1) * rs;
+    auto emit = [&](int j, double c1, double c2, double c3, double v, double old) {
         const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
         const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
         const double temp_d2u = t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
-        put(o, -0.5 * (cv[o] * temp_du + temp_dud) + nu * temp_d2u);  // :315-324
+        put(base + (long)(j - 1) * rs, -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u, old);  // :315-324
     };
     {
         const long o = base + (long)(n - 2) * rs;  // row n-1: forward values, no backward update
         n1 = d_du[o]; n2 = d_dud[o]; n3 = d_d2u[o];
-        emit(n - 1, n1, n2, n3);
+        emit(n - 1, n1, n2, n3, cv[o], ACC ? rhs[o] : 0.0);
     }
-#pragma unroll 2
-    for (int j = n - 2; j >= 2; j--) {
+    int j = n - 2;
+    for (; j - UT + 1 >= 2; j -= UT) {
+        double a1[UT], a2[UT], a3[UT], vv[UT], ov[UT];
+#pragma unroll
+        for (int k = 0; k < UT; k++) {
+            const long o = base + (long)(j - k - 1) * rs;
+            a1[k] = d_du[o]; a2[k] = d_dud[o]; a3[k] = d_d2u[o]; vv[k] = cv[o];
+            ov[k] = ACC ? rhs[o] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < UT; k++) {
+            const int jj = j - k;
+            const double c1 = a1[k] - t1.Bw[jj] * n1;
+            const double c2 = a2[k] - t2.Bw[jj] * n2;
+            const double c3 = a3[k] - t3.Bw[jj] * n3;
+            emit(jj, c1, c2, c3, vv[k], ov[k]);
+            n1 = c1; n2 = c2; n3 = c3;
+        }
+    }
+    for (; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
         const double c1 = d_du[o] - t1.Bw[j] * n1;
         const double c2 = d_dud[o] - t2.Bw[j] * n2;
         const double c3 = d_d2u[o] - t3.Bw[j] * n3;
-        emit(j, c1, c2, c3);
+        emit(j, c1, c2, c3, cv[o], ACC ? rhs[o] : 0.0);
         n1 = c1; n2 = c2; n3 = c3;
     }
     // row 1 (:304-311)
     put(base, -0.5 * (cv[base] * du_s * t1.St[1] + dud_s * t2.St[1]) +
-                  nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]));
+                  nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]), ACC ? rhs[base] : 0.0);
 }
 
 // copy_into_buffers (src/backend/omp/backend.f90:714-737): rows 1..4 and n-3..n
@@ -406,8 +453,11 @@ static bool use_fused_kernels()
 {
     static int mode = -1;
     if (mode < 0) {
-        const char *e = getenv("X3D_TWO_SWEEP");
-        mode = (e && e[0] == '1') ? 0 : 1;
+        // the checkpoint/recompute form is kept for experiments: on MI355X its
+        // backward kernel is register-bound (255 VGPRs, 1 wave/SIMD) and slower
+        // than streaming the intermediates (profiles/README.md)
+        const char *e = getenv("X3D_CHECKPOINT");
+        mode = (e && e[0] == '1') ? 1 : 0;
     }
     return mode == 1;
 }
@@ -453,8 +503,9 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-    hipLaunchKernelGGL((k_tds_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, du, du_send_s, du_send_e, u,
-                       u_recv_s, u_recv_e, t->tab, g, t->n_tds);
+    (void)du;  // the eliminated values stay in backend scratch until x3d_tds_dist_bwd
+    hipLaunchKernelGGL((k_tds_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2], du_send_s,
+                       du_send_e, u, u_recv_s, u_recv_e, t->tab, g, t->n_tds);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -466,8 +517,8 @@ extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_sen
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
-    hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)du, du_send_s,
-                       du_recv_s, du_recv_e, t->tab, g, 1.0);
+    hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
+                       du_send_s, du_recv_s, du_recv_e, t->tab, g, 1.0);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -495,7 +546,7 @@ int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d
                           double scale)
 {
     PencilGeom g = x3d_geom(b, dir);
-    double *d = acc ? b->scratch[2] : du;  // the accumulate form must not clobber du
+    double *d = b->scratch[2];
     {
         ProfScope ps(b, X3D_K_TDS_FWD, dir);
         hipLaunchKernelGGL((k_tds_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
@@ -544,8 +595,9 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     PencilGeom g = x3d_geom(b, dir);
     // [3][npencil] boundary buffers are contiguous with stride np
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-    hipLaunchKernelGGL((k_transeq_fwd<true, false, false>), grid_for(g), dim3(64), 0, b->stream, rhs, b->scratch[0],
-                       b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
+    (void)rhs;
+    hipLaunchKernelGGL((k_transeq_fwd<true, false, false>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2],
+                       b->scratch[0], b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
                        t_du->tab, t_dud->tab, t_d2u->tab, g, t_du->n_tds, g.np);
     X3D_HIP(hipGetLastError());
     return 0;
@@ -560,8 +612,8 @@ extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const 
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
-    hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)rhs,
-                       b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab,
+    hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs,
+                       (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab,
                        t_d2u->tab, g, g.np);
     X3D_HIP(hipGetLastError());
     return 0;
