@@ -21,9 +21,15 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
                               int acc);
 int npmax_of(const x3d_backend *b);
 
-#define TW 16        // tile width (columns)
+#ifndef X3D_XTW
+#define X3D_XTW 16   // tile width (columns): 128 B contiguous per row per fetch (32 costs too many VGPRs)
+#endif
+#define TW X3D_XTW
 #define TP 65        // LDS pitch in doubles
 #define TILE (TW * TP)
+#define TLD (TW / 2) // 16-byte loads per lane per tile: 64 rows * TW cols / (64 lanes * 2)
+#define LPR (TW / 2) // lanes per row in a fetch
+#define RPF (64 / LPR) // rows per fetch instruction
 
 __device__ __forceinline__ double dot9x(const double *__restrict__ c, const double (&w)[9])
 {
@@ -38,16 +44,17 @@ __device__ __forceinline__ const double *stencil_row_x(const double *__restrict_
     return Cs + 72;
 }
 
-// cooperative tile fetch: 8 x (16 B per lane); lane -> row (lane>>3)+8i, columns 2*(lane&7), +1
-struct TileRegs { double2 v[8]; };
+// cooperative tile fetch: TLD x (16 B per lane); LPR lanes cover one row
+// segment of TW columns (TW*8 B contiguous), RPF rows per instruction
+struct TileRegs { double2 v[TLD]; };
 
 __device__ __forceinline__ void tile_load(TileRegs &r, const double *__restrict__ slab, long pitch, int col0,
                                           int rows_valid, int lane)
 {
-    const int cp = (lane & 7) * 2;
+    const int cp = (lane % LPR) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int row = (lane >> 3) + 8 * i;
+    for (int i = 0; i < TLD; i++) {
+        int row = (lane / LPR) + RPF * i;
         row = row < rows_valid ? row : rows_valid - 1;  // partial wave: replicate a valid row
         r.v[i] = *reinterpret_cast<const double2 *>(slab + (long)row * pitch + col0 + cp);
     }
@@ -55,10 +62,10 @@ __device__ __forceinline__ void tile_load(TileRegs &r, const double *__restrict_
 
 __device__ __forceinline__ void tile_to_lds(const TileRegs &r, double *__restrict__ lds, int lane)
 {
-    const int cp = (lane & 7) * 2;
+    const int cp = (lane % LPR) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = (lane >> 3) + 8 * i;
+    for (int i = 0; i < TLD; i++) {
+        const int row = (lane / LPR) + RPF * i;
         lds[cp * TP + row] = r.v[i].x;
         lds[(cp + 1) * TP + row] = r.v[i].y;
     }
@@ -68,10 +75,10 @@ template <bool ACC>
 __device__ __forceinline__ void tile_store(const double *__restrict__ lds, double *__restrict__ slab, long pitch,
                                            int col0, int rows_valid, int lane, double scale)
 {
-    const int cp = (lane & 7) * 2;
+    const int cp = (lane % LPR) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = (lane >> 3) + 8 * i;
+    for (int i = 0; i < TLD; i++) {
+        const int row = (lane / LPR) + RPF * i;
         if (row < rows_valid) {
             double2 v;
             v.x = lds[cp * TP + row];
@@ -114,6 +121,9 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
     double dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
     double *__restrict__ dw = d + (long)wave * n * 64 + lane;
 
+    double cb[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) cb[m] = t.Cs[72 + m];
     const int ntile = (nr + TW - 1) / TW;
     TileRegs regs;
     tile_load(regs, slab, pitch, 0, rows_valid, lane);
@@ -132,7 +142,7 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
             w[8] = ve;
             const int j = e - 4;
             if (j >= 1 && j <= nr) {
-                const double acc = dot9x(stencil_row_x(t.Cs, j, nr), w);
+                const double acc = (j > 4 && j <= nr - 4) ? dot9x(cb, w) : dot9x(stencil_row_x(t.Cs, j, nr), w);
                 const double dj = t.F[j] * (acc - t.A[j] * dprev);
                 if (j <= n) {
                     dw[(long)(j - 1) * 64] = dj;
@@ -172,23 +182,24 @@ __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const 
     double nxt = 0.0;
     const int ntile = (n + TW - 1) / TW;
     for (int tI = ntile - 1; tI >= 0; tI--) {
+        double dv[TW];
+#pragma unroll
+        for (int c = 0; c < TW; c++) {  // unconditional, clamped: lets the loads issue back to back
+            int j = tI * TW + c + 1;
+            j = j <= n ? j : n;
+            dv[c] = dw[(long)(j - 1) * 64];
+        }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll
         for (int c = TW - 1; c >= 0; c--) {
             const int j = tI * TW + c + 1;
             double out = 0.0;
             if (j <= n) {
-                if (j == n) {
-                    out = du_e * t.St[n];
-                    nxt = dn;
-                } else if (j == 1) {
-                    out = du_s * t.St[1];
-                } else {
-                    const double dj = dw[(long)(j - 1) * 64];
-                    const double cur = (j == n - 1) ? dj : dj - t.Bw[j] * nxt;
-                    out = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];
-                    nxt = cur;
-                }
+                const double cur = (j >= n - 1) ? dv[c] : dv[c] - t.Bw[j] * nxt;
+                out = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];
+                out = (j == n) ? du_e * t.St[j] : out;
+                out = (j == 1) ? du_s * t.St[j] : out;
+                nxt = cur;
             }
             lds[c * TP + lane] = out;
         }
@@ -228,6 +239,9 @@ __global__ void __launch_bounds__(64)
     }
     double p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
     const long wo = (long)wave * n * 64 + lane;
+    double b1[9], b2[9], b3[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) { b1[m] = t1.Cs[72 + m]; b2[m] = t2.Cs[72 + m]; b3[m] = t3.Cs[72 + m]; }
     const int ntile = (n + TW - 1) / TW;
     TileRegs ru, rc;
     tile_load(ru, su, pitch, 0, rows_valid, lane);
@@ -260,9 +274,10 @@ __global__ void __launch_bounds__(64)
             wu[8] = ve; wp[8] = vp;
             const int j = e - 4;
             if (j >= 1) {
-                const double a1 = dot9x(stencil_row_x(t1.Cs, j, n), wu);
-                const double a3 = dot9x(stencil_row_x(t3.Cs, j, n), wu);
-                const double a2 = dot9x(stencil_row_x(t2.Cs, j, n), wp);
+                const bool bulk = j > 4 && j <= n - 4;
+                const double a1 = bulk ? dot9x(b1, wu) : dot9x(stencil_row_x(t1.Cs, j, n), wu);
+                const double a3 = bulk ? dot9x(b3, wu) : dot9x(stencil_row_x(t3.Cs, j, n), wu);
+                const double a2 = bulk ? dot9x(b2, wp) : dot9x(stencil_row_x(t2.Cs, j, n), wp);
                 const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
                 const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
                 const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
@@ -317,33 +332,43 @@ __global__ void __launch_bounds__(64)
         tile_to_lds(rc, lc, lane);
         __syncthreads();
         if (tI > 0) tile_load(rc, sc, pitch, (tI - 1) * TW, rows_valid, lane);
-#pragma unroll 2
-        for (int c = TW - 1; c >= 0; c--) {
-            const int j = tI * TW + c + 1;
-            double out = 0.0;
-            if (j <= n) {
-                const double v = lc[c * TP + lane];
-                if (j == n) {
-                    out = -0.5 * (v * du_e * t1.St[n] + dud_e * t2.St[n]) +
-                          nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
-                } else if (j == 1) {
-                    out = -0.5 * (v * du_s * t1.St[1] + dud_s * t2.St[1]) +
-                          nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
-                } else {
-                    const long o = wo + (long)(j - 1) * 64;
-                    double c1 = d1a[o], c2 = d2a[o], c3 = d3a[o];
-                    if (j != n - 1) {
-                        c1 -= t1.Bw[j] * n1; c2 -= t2.Bw[j] * n2; c3 -= t3.Bw[j] * n3;
-                    }
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {  // two half-tiles: their d loads are issued as one batch
+            constexpr int HB_ = TW / 2;
+            double a1[HB_], a2[HB_], a3[HB_];
+#pragma unroll
+            for (int k = 0; k < HB_; k++) {
+                int j = tI * TW + h * HB_ + k + 1;
+                j = j <= n ? j : n;
+                const long o = wo + (long)(j - 1) * 64;
+                a1[k] = d1a[o]; a2[k] = d2a[o]; a3[k] = d3a[o];
+            }
+#pragma unroll
+            for (int k = HB_ - 1; k >= 0; k--) {
+                const int c = h * HB_ + k;
+                const int j = tI * TW + c + 1;
+                double out = 0.0;
+                if (j <= n) {
+                    const double v = lc[c * TP + lane];
+                    const bool keep = j >= n - 1;  // rows n, n-1: forward values (distributed.f90:154)
+                    const double c1 = keep ? a1[k] : a1[k] - t1.Bw[j] * n1;
+                    const double c2 = keep ? a2[k] : a2[k] - t2.Bw[j] * n2;
+                    const double c3 = keep ? a3[k] : a3[k] - t3.Bw[j] * n3;
                     const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
                     const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
                     const double temp_d2u =
                         t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
                     out = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;
+                    if (j == n)
+                        out = -0.5 * (v * du_e * t1.St[n] + dud_e * t2.St[n]) +
+                              nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
+                    if (j == 1)
+                        out = -0.5 * (v * du_s * t1.St[1] + dud_s * t2.St[1]) +
+                              nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
                     n1 = c1; n2 = c2; n3 = c3;
                 }
+                lo[c * TP + lane] = out;
             }
-            lo[c * TP + lane] = out;
         }
         __syncthreads();
         tile_store<ACC>(lo, so, pitch, tI * TW, rows_valid, lane, 1.0);
