@@ -185,6 +185,35 @@ int x3d_poisson_solve_000(x3d_poisson *p, double *f);             /* poisson_000
 int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
 int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
 
+/* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
+ * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
+ * src/decomp/decomp_2decompfft.f90:42-48).  Only LOCAL stages live here; the
+ * caller exchanges the packed buffers between them (peer r's chunk is
+ * contiguous, sizes from x3d_pfft_sizes) -- see x3d2_amd/poisson_fft.py.
+ *   fwd_x ; pack_xy | exchange(py group) | unpack_xy ; fft_y ;
+ *   pack_yz | exchange(pz group) | unpack_yz ; fft_z ; postprocess_000 ;
+ *   fft_z(inv) ; pack_zy | exchange | unpack_zy ; fft_y(inv) ;
+ *   pack_yx | exchange | unpack_yx ; bwd_x                                   */
+typedef struct x3d_pfft x3d_pfft;
+int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob_cell[3], int py, int pz, int ry, int rz);
+int x3d_pfft_destroy(x3d_pfft *p);
+int x3d_pfft_sizes(const x3d_pfft *p, long out[8]); /* xs,xoff,ys,yoff,yl,zl,nxs,max complex count */
+int x3d_pfft_set_waves(x3d_pfft *p, const double *waves_re, const double *ax, const double *bx,
+                       const double *ay, const double *by, const double *az, const double *bz);
+int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in);
+int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out);
+int x3d_pfft_fft_y(x3d_pfft *p, int inverse);
+int x3d_pfft_fft_z(x3d_pfft *p, int inverse);
+int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf);
+int x3d_pfft_unpack_xy(x3d_pfft *p, const double *recvbuf);
+int x3d_pfft_pack_yx(x3d_pfft *p, double *sendbuf);
+int x3d_pfft_unpack_yx(x3d_pfft *p, const double *recvbuf);
+int x3d_pfft_pack_yz(x3d_pfft *p, double *sendbuf);
+int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf);
+int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf);
+int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf);
+int x3d_pfft_postprocess_000(x3d_pfft *p);
+
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);
 int x3d_timer_stop_ms(x3d_backend *b, float *ms);

@@ -1,0 +1,39 @@
+"""worker for the multi-rank GPU parity test: N processes share cuda:0, exchange
+through gloo (host-staged); each rank runs the decomposed TGV and rank 0 compares
+the monitoring series with the values passed in (single-rank run)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    nproc_dir = tuple(int(x) for x in sys.argv[1].split(","))
+    dims = tuple(int(x) for x in sys.argv[2].split(","))
+    n_iters = int(sys.argv[3])
+    fused = sys.argv[4] == "fused"
+    poisson = sys.argv[5]
+    out = sys.argv[6]
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    torch.cuda.set_device(0)
+    from x3d2_amd import make_tgv
+    from x3d2_amd.parallel import Comm
+    case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, poisson=poisson, comm=Comm(), fused=fused)
+    case.solver.n_output = n_iters
+    rows = case.run(n_iters=n_iters)
+    s = case.solver
+    local = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
+    np.savez(out + f".{rank}.npz", u=local[0], v=local[1], w=local[2], offset=np.array(s.mesh.n_offset),
+             rows=np.array(rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

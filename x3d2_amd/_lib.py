@@ -67,6 +67,23 @@ PROTOTYPES = {
     "x3d_poisson_solve_000": (I, [VP, VP]),
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
+    "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
+    "x3d_pfft_destroy": (I, [VP]),
+    "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_pfft_set_waves": (I, [VP] + [c_double_p] * 7),
+    "x3d_pfft_fwd_x": (I, [VP, VP]),
+    "x3d_pfft_bwd_x": (I, [VP, VP]),
+    "x3d_pfft_fft_y": (I, [VP, I]),
+    "x3d_pfft_fft_z": (I, [VP, I]),
+    "x3d_pfft_pack_xy": (I, [VP, VP]),
+    "x3d_pfft_unpack_xy": (I, [VP, VP]),
+    "x3d_pfft_pack_yx": (I, [VP, VP]),
+    "x3d_pfft_unpack_yx": (I, [VP, VP]),
+    "x3d_pfft_pack_yz": (I, [VP, VP]),
+    "x3d_pfft_unpack_yz": (I, [VP, VP]),
+    "x3d_pfft_pack_zy": (I, [VP, VP]),
+    "x3d_pfft_unpack_zy": (I, [VP, VP]),
+    "x3d_pfft_postprocess_000": (I, [VP]),
     "x3d_timer_start": (I, [VP]),
     "x3d_timer_stop_ms": (I, [VP, ctypes.POINTER(ctypes.c_float)]),
     "x3d_prof_enable": (I, [VP, I]),

@@ -374,6 +374,6 @@ class HipBackend:
 
     # ------------------------------------------------------------ Poisson
     def init_poisson_fft(self, mesh, xdirps, ydirps, zdirps, lowmem=None):
-        from .poisson_fft import HipPoissonFFT
-        self.poisson_fft = HipPoissonFFT(self, mesh, xdirps, ydirps, zdirps)
+        from .poisson_fft import make_poisson_fft
+        self.poisson_fft = make_poisson_fft(self, mesh, xdirps, ydirps, zdirps)
         return self.poisson_fft

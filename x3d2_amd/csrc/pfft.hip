@@ -1,0 +1,357 @@
+// Distributed spectral Poisson solver (all-periodic, 000): pencil FFT over a
+// [1, py, pz] decomposition -- x whole, y split over py ranks, z over pz ranks
+// -- the same 2-D decomposition 2decomp&FFT gives the reference's CPU backend
+// (/root/reference/src/decomp/decomp_2decompfft.f90:42-48,
+// src/backend/omp/poisson_fft.f90:72-97).  This file holds the LOCAL stages
+// (rocFFT batched 1-D transforms, pack/unpack, spectral post-processing); the
+// two transposes per direction are exchanges between the stages, done by the
+// caller over RCCL (x3d2_amd/poisson_fft.py).
+//
+//   X pencils  f[zl][yl][nx]   --R2C x-->  C0[zl][yl][nxs]            (x fastest)
+//   --xy exchange in the py group-->       C1[zl][xs][ny]             (y fastest)
+//   --C2C y-->  --yz exchange in the pz group--> C2[xs][ys][nz]       (z fastest)
+//   --C2C z--> process_spectral_000 --> inverse path.
+// xs / ys are this rank's shares of the nx/2+1 x-modes / ny y-modes
+// (first `rem` ranks get one extra), all pencil axes are contiguous for rocFFT.
+#include <hipfft/hipfft.h>
+
+#include "common.h"
+
+#define X3D_FFT(expr)                                                                          \
+    do {                                                                                       \
+        hipfftResult r_ = (expr);                                                              \
+        if (r_ != HIPFFT_SUCCESS) {                                                            \
+            x3d_set_error("%s failed: hipfft error %d (%s:%d)", #expr, (int)r_, __FILE__,      \
+                          __LINE__);                                                           \
+            return 3;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+static inline int share(int n, int p, int r) { return n / p + (r < n % p ? 1 : 0); }
+static inline int share_off(int n, int p, int r) { return r * (n / p) + (r < n % p ? r : n % p); }
+
+struct x3d_pfft {
+    x3d_backend *b;
+    int nx, ny, nz, nxs;          // global cell dims
+    int py, pz, ry, rz;
+    int yl, zl;                   // local physical extents (ny/py, nz/pz)
+    int xs, xoff, ys, yoff;       // spectral shares of this rank
+    hipfftHandle plan_r2c, plan_c2r, plan_y, plan_z;
+    double2 *c0, *c1, *c2;        // stage buffers
+    double *waves, *ab;
+    void *work;
+};
+
+// dst[i*d0 + j*d1 + k*d2] = src[i*s0 + j*s1 + k*s2]; i is the fastest loop index
+__global__ void __launch_bounds__(256) k_permute(double2 *__restrict__ dst, const double2 *__restrict__ src, int n0,
+                                                 int n1, int n2, long d0, long d1, long d2, long s0, long s1, long s2)
+{
+    const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long tot = (long)n0 * n1 * n2;
+    if (q >= tot) return;
+    const int i = (int)(q % n0);
+    const int j = (int)((q / n0) % n1);
+    const int k = (int)(q / ((long)n0 * n1));
+    dst[i * d0 + j * d1 + k * d2] = src[i * s0 + j * s1 + k * s2];
+}
+
+static int permute(x3d_backend *b, double2 *dst, const double2 *src, int n0, int n1, int n2, long d0, long d1,
+                   long d2, long s0, long s1, long s2)
+{
+    const long tot = (long)n0 * n1 * n2;
+    if (tot == 0) return 0;
+    ProfScope ps(b, X3D_K_PACK);
+    hipLaunchKernelGGL(k_permute, dim3((tot + 255) / 256), dim3(256), 0, b->stream, dst, src, n0, n1, n2, d0, d1, d2,
+                       s0, s1, s2);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// process_spectral_000 on the z-fastest spectral pencils C2[xs][ys][nz]
+// (src/backend/omp/kernels/spectral_processing.f90:7-106, offsets = sp_st)
+__global__ void __launch_bounds__(256)
+    k_process_spectral_000_z(double2 *__restrict__ c, const double *__restrict__ waves, int xs, int ys, int nz,
+                             int xoff, int yoff, int nx, int ny, const double *__restrict__ ax,
+                             const double *__restrict__ bx, const double *__restrict__ ay,
+                             const double *__restrict__ by, const double *__restrict__ az,
+                             const double *__restrict__ bz)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;  // iz - 1
+    const int jl = blockIdx.y, il = blockIdx.z;
+    if (k >= nz) return;
+    const int i = il + xoff, j = jl + yoff;
+    const size_t idx = ((size_t)il * ys + jl) * nz + k;
+    double2 v = c[idx];
+    double div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
+    const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
+    const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
+    double tr, tc;
+    tr = div_r; tc = div_c;
+    div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
+    if (fz) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+    if (fy) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+    const double wv = waves[idx];
+    if (wv < 1.e-16) { div_r = 0.0; div_c = 0.0; }
+    else { div_r = -div_r / wv; div_c = -div_c / wv; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
+    if (fz) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+    if (fy) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+    c[idx] = make_double2(div_r, div_c);
+}
+
+extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry, int rz)
+{
+    X3D_REQUIRE(b && out && nglob, "x3d_pfft_create: null argument");
+    X3D_REQUIRE(py >= 1 && pz >= 1 && ry >= 0 && ry < py && rz >= 0 && rz < pz, "x3d_pfft_create: bad rank grid");
+    X3D_REQUIRE(nglob[1] % py == 0 && nglob[2] % pz == 0, "x3d_pfft_create: ny, nz must divide by py, pz");
+    x3d_pfft *p = new x3d_pfft();
+    memset(p, 0, sizeof *p);
+    p->b = b;
+    p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2]; p->nxs = nglob[0] / 2 + 1;
+    p->py = py; p->pz = pz; p->ry = ry; p->rz = rz;
+    p->yl = p->ny / py; p->zl = p->nz / pz;
+    X3D_REQUIRE(p->nx <= b->nxp && p->yl <= b->nyp && p->zl <= b->nzp, "x3d_pfft_create: local block too small");
+    p->xs = share(p->nxs, py, ry); p->xoff = share_off(p->nxs, py, ry);
+    p->ys = share(p->ny, pz, rz); p->yoff = share_off(p->ny, pz, rz);
+    const size_t n0 = (size_t)p->zl * p->yl * p->nxs, n1 = (size_t)p->zl * p->xs * p->ny,
+                 n2 = (size_t)p->xs * p->ys * p->nz;
+    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
+    X3D_HIP(hipMalloc(&p->c1, sizeof(double2) * n1));
+    X3D_HIP(hipMalloc(&p->c2, sizeof(double2) * n2));
+    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * n2));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));
+    int nxv[1] = {p->nx}, nyv[1] = {p->ny}, nzv[1] = {p->nz};
+    size_t ws[4] = {0, 0, 0, 0};
+    hipfftHandle *pl[4] = {&p->plan_r2c, &p->plan_c2r, &p->plan_y, &p->plan_z};
+    for (int i = 0; i < 4; i++) {
+        X3D_FFT(hipfftCreate(pl[i]));
+        X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
+    }
+    int rembed[1] = {b->nxp}, cembed[1] = {p->nxs};
+    X3D_FFT(hipfftMakePlanMany(p->plan_r2c, 1, nxv, rembed, 1, b->nxp, cembed, 1, p->nxs, HIPFFT_D2Z,
+                               p->yl * p->zl, &ws[0]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_c2r, 1, nxv, cembed, 1, p->nxs, rembed, 1, b->nxp, HIPFFT_Z2D,
+                               p->yl * p->zl, &ws[1]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, nyv, nyv, 1, p->ny, nyv, 1, p->ny, HIPFFT_Z2Z, p->zl * p->xs, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, HIPFFT_Z2Z, p->xs * p->ys, &ws[3]));
+    size_t wmax = 0;
+    for (int i = 0; i < 4; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
+    if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
+    for (int i = 0; i < 4; i++) X3D_FFT(hipfftSetWorkArea(*pl[i], p->work));
+    *out = p;
+    return 0;
+}
+
+extern "C" int x3d_pfft_destroy(x3d_pfft *p)
+{
+    if (!p) return 0;
+    hipfftDestroy(p->plan_r2c); hipfftDestroy(p->plan_c2r); hipfftDestroy(p->plan_y); hipfftDestroy(p->plan_z);
+    hipFree(p->c0); hipFree(p->c1); hipFree(p->c2); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
+    delete p;
+    return 0;
+}
+
+// out = {xs, xoff, ys, yoff, yl, zl, nxs, n_exchange_max (complex elements)}
+extern "C" int x3d_pfft_sizes(const x3d_pfft *p, long out[8])
+{
+    X3D_REQUIRE(p && out, "null argument");
+    const long n0 = (long)p->zl * p->yl * p->nxs, n1 = (long)p->zl * p->xs * p->ny, n2 = (long)p->xs * p->ys * p->nz;
+    long m = n0 > n1 ? n0 : n1;
+    m = m > n2 ? m : n2;
+    out[0] = p->xs; out[1] = p->xoff; out[2] = p->ys; out[3] = p->yoff; out[4] = p->yl; out[5] = p->zl;
+    out[6] = p->nxs; out[7] = m;
+    return 0;
+}
+
+// waves_re: this rank's block [xs][ys][nz] (z fastest); ax..bz: global-length arrays
+extern "C" int x3d_pfft_set_waves(x3d_pfft *p, const double *waves_re, const double *ax, const double *bx,
+                                  const double *ay, const double *by, const double *az, const double *bz)
+{
+    X3D_REQUIRE(p && waves_re && ax && bx && ay && by && az && bz, "null argument");
+    const size_t n2 = (size_t)p->xs * p->ys * p->nz;
+    X3D_HIP(hipMemcpy(p->waves, waves_re, sizeof(double) * n2, hipMemcpyHostToDevice));
+    double *d = p->ab;
+    const double *src[6] = {ax, bx, ay, by, az, bz};
+    const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
+    for (int i = 0; i < 6; i++) {
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        d += len[i];
+    }
+    return 0;
+}
+
+extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in)
+{
+    X3D_REQUIRE(p && f_in, "null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 1);
+    X3D_FFT(hipfftSetStream(p->plan_r2c, p->b->stream));
+    X3D_FFT(hipfftExecD2Z(p->plan_r2c, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+    return 0;
+}
+
+extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out)
+{
+    X3D_REQUIRE(p && f_out, "null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 2);
+    X3D_FFT(hipfftSetStream(p->plan_c2r, p->b->stream));
+    X3D_FFT(hipfftExecZ2D(p->plan_c2r, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+    return 0;
+}
+
+extern "C" int x3d_pfft_fft_y(x3d_pfft *p, int inverse)
+{
+    X3D_REQUIRE(p, "null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 3);
+    X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
+    X3D_FFT(hipfftExecZ2Z(p->plan_y, (hipfftDoubleComplex *)p->c1, (hipfftDoubleComplex *)p->c1,
+                          inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    return 0;
+}
+
+extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
+{
+    X3D_REQUIRE(p, "null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 3);
+    X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
+    X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->c2, (hipfftDoubleComplex *)p->c2,
+                          inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    return 0;
+}
+
+// ---- exchange buffers.  Peer r's chunk is contiguous; element counts and
+// offsets follow from x3d_pfft_sizes (see poisson_fft.py: _xy_layout/_yz_layout).
+// xy: send chunk r = C0[:, :, xoff_r : xoff_r+xs_r] packed [zl][yl][xs_r];
+//     recv chunk r = [zl][yl][xs] from the rank owning y-slab r  ->  C1[z][x][r*yl + y]
+extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf)
+{
+    X3D_REQUIRE(p && sendbuf, "null argument");
+    double2 *s = (double2 *)sendbuf;
+    long off = 0;
+    for (int r = 0; r < p->py; r++) {
+        const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
+        if (int rc = permute(p->b, s + off, p->c0 + xo, xr, p->yl, p->zl, 1, xr, (long)xr * p->yl, 1, p->nxs,
+                             (long)p->nxs * p->yl))
+            return rc;
+        off += (long)xr * p->yl * p->zl;
+    }
+    return 0;
+}
+
+extern "C" int x3d_pfft_unpack_xy(x3d_pfft *p, const double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const double2 *s = (const double2 *)recvbuf;
+    const long chunk = (long)p->xs * p->yl * p->zl;
+    for (int r = 0; r < p->py; r++)  // src [zl][yl][xs] -> dst C1[z][x][r*yl + y]
+        if (int rc = permute(p->b, p->c1 + (long)r * p->yl, s + r * chunk, p->xs, p->yl, p->zl, p->ny, 1,
+                             (long)p->xs * p->ny, 1, p->xs, (long)p->xs * p->yl))
+            return rc;
+    return 0;
+}
+
+// inverse of the pair above: C1 -> chunks [zl][yl][xs] per y-slab owner -> C0 columns
+extern "C" int x3d_pfft_pack_yx(x3d_pfft *p, double *sendbuf)
+{
+    X3D_REQUIRE(p && sendbuf, "null argument");
+    double2 *s = (double2 *)sendbuf;
+    const long chunk = (long)p->xs * p->yl * p->zl;
+    for (int r = 0; r < p->py; r++)
+        if (int rc = permute(p->b, s + r * chunk, p->c1 + (long)r * p->yl, p->xs, p->yl, p->zl, 1, p->xs,
+                             (long)p->xs * p->yl, p->ny, 1, (long)p->xs * p->ny))
+            return rc;
+    return 0;
+}
+
+extern "C" int x3d_pfft_unpack_yx(x3d_pfft *p, const double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const double2 *s = (const double2 *)recvbuf;
+    long off = 0;
+    for (int r = 0; r < p->py; r++) {
+        const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
+        if (int rc = permute(p->b, p->c0 + xo, s + off, xr, p->yl, p->zl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
+                             (long)xr * p->yl))
+            return rc;
+        off += (long)xr * p->yl * p->zl;
+    }
+    return 0;
+}
+
+// yz: send chunk r = C1[:, :, yoff_r : yoff_r+ys_r] packed [zl][xs][ys_r];
+//     recv chunk r = [zl][xs][ys] from the rank owning z-slab r  ->  C2[x][y][r*zl + z]
+extern "C" int x3d_pfft_pack_yz(x3d_pfft *p, double *sendbuf)
+{
+    X3D_REQUIRE(p && sendbuf, "null argument");
+    double2 *s = (double2 *)sendbuf;
+    long off = 0;
+    for (int r = 0; r < p->pz; r++) {
+        const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
+        if (int rc = permute(p->b, s + off, p->c1 + yo, yr, p->xs, p->zl, 1, yr, (long)yr * p->xs, 1, p->ny,
+                             (long)p->ny * p->xs))
+            return rc;
+        off += (long)yr * p->xs * p->zl;
+    }
+    return 0;
+}
+
+extern "C" int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const double2 *s = (const double2 *)recvbuf;
+    const long chunk = (long)p->ys * p->xs * p->zl;
+    for (int r = 0; r < p->pz; r++)  // src [zl][xs][ys] -> dst C2[x][y][r*zl + z]
+        if (int rc = permute(p->b, p->c2 + (long)r * p->zl, s + r * chunk, p->ys, p->xs, p->zl, p->nz,
+                             (long)p->ys * p->nz, 1, 1, p->ys, (long)p->ys * p->xs))
+            return rc;
+    return 0;
+}
+
+extern "C" int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf)
+{
+    X3D_REQUIRE(p && sendbuf, "null argument");
+    double2 *s = (double2 *)sendbuf;
+    const long chunk = (long)p->ys * p->xs * p->zl;
+    for (int r = 0; r < p->pz; r++)
+        if (int rc = permute(p->b, s + r * chunk, p->c2 + (long)r * p->zl, p->ys, p->xs, p->zl, 1, p->ys,
+                             (long)p->ys * p->xs, p->nz, (long)p->ys * p->nz, 1))
+            return rc;
+    return 0;
+}
+
+extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const double2 *s = (const double2 *)recvbuf;
+    long off = 0;
+    for (int r = 0; r < p->pz; r++) {
+        const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
+        if (int rc = permute(p->b, p->c1 + yo, s + off, yr, p->xs, p->zl, 1, p->ny, (long)p->ny * p->xs, 1, yr,
+                             (long)yr * p->xs))
+            return rc;
+        off += (long)yr * p->xs * p->zl;
+    }
+    return 0;
+}
+
+extern "C" int x3d_pfft_postprocess_000(x3d_pfft *p)
+{
+    X3D_REQUIRE(p, "null argument");
+    if (p->xs == 0 || p->ys == 0) return 0;
+    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+                 *bz = az + p->nz;
+    dim3 grid((p->nz + 255) / 256, p->ys, p->xs);
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
+    hipLaunchKernelGGL(k_process_spectral_000_z, grid, dim3(256), 0, p->b->stream, p->c2, p->waves, p->xs, p->ys,
+                       p->nz, p->xoff, p->yoff, p->nx, p->ny, ax, bx, ay, by, az, bz);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}

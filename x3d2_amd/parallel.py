@@ -1,10 +1,14 @@
 """Neighbour exchange = the reference's sendrecv_fields
 (/root/reference/src/backend/omp/sendrecv.f90:10-36,
-src/backend/cuda/sendrecv.f90:13-100) on torch.distributed.
+src/backend/cuda/sendrecv.f90:13-100) and the pencil transposes of the FFT
+Poisson solver, on torch.distributed.
 
-One process per GPU; backend "nccl" is RCCL over xGMI on ROCm.  The pattern is
-point-to-point with the two ring neighbours of the pencil direction, batched
-into one group (batch_isend_irecv = ncclGroupStart/End), never a collective."""
+One process per GPU; backend "nccl" is RCCL over xGMI on ROCm.  Every pattern
+is point-to-point with known peers (the two ring neighbours of a pencil
+direction; the py or pz peers of a transpose), batched into one group
+(batch_isend_irecv = ncclGroupStart/End) -- no bulk collective on the data path.
+With the "gloo" backend (CPU tests, or several ranks sharing one GPU in the
+GPU parity tests) device buffers are staged through host memory."""
 import torch
 import torch.distributed as dist
 
@@ -15,30 +19,73 @@ class Comm:
         self.group = group
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.size = dist.get_world_size(group) if self.enabled else 1
+        self.backend = dist.get_backend(group) if self.enabled else None
+        self.host_staged = self.backend == "gloo"
 
-    def sendrecv(self, pairs, prev, nxt):
-        """pairs: list of (send_s, send_e, recv_s, recv_e) tensors.
-        send_s -> prev (arrives in prev's recv_e), send_e -> next
-        (arrives in next's recv_s); tag-free ordering = posting order."""
-        if prev == self.rank and nxt == self.rank:
-            for send_s, send_e, recv_s, recv_e in pairs:  # nproc == 1 branch, :20-22
-                recv_s.copy_(send_e)
-                recv_e.copy_(send_s)
+    # ------------------------------------------------------------ p2p core
+    def _exchange(self, sends, recvs):
+        """sends: [(tensor, peer)], recvs: [(tensor, peer)]; posting order
+        defines the matching between a pair of ranks"""
+        if not sends and not recvs:
             return
-        ops = []
-        for send_s, send_e, recv_s, recv_e in pairs:
-            ops.append(dist.P2POp(dist.isend, send_s, prev, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_e, nxt, self.group))
-            ops.append(dist.P2POp(dist.isend, send_e, nxt, self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_s, prev, self.group))
+        if self.host_staged:
+            s_host = [(t.detach().to("cpu", copy=True), p) for t, p in sends]
+            r_host = [(torch.empty(t.shape, dtype=t.dtype, device="cpu"), p) for t, p in recvs]
+            ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in s_host]
+            ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in r_host]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for (dst, _), (src, _) in zip(recvs, r_host):
+                dst.copy_(src)
+            return
+        ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+        ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    # ------------------------------------------------------------ halo / boundary exchange
+    def sendrecv(self, pairs, prev, nxt):
+        """pairs: list of (send_s, send_e, recv_s, recv_e) tensors.
+        send_s -> prev (arrives in prev's recv_e), send_e -> next (arrives in
+        next's recv_s)."""
+        if prev == self.rank and nxt == self.rank:
+            for send_s, send_e, recv_s, recv_e in pairs:  # nproc == 1 branch, sendrecv.f90:20-22
+                recv_s.copy_(send_e)
+                recv_e.copy_(send_s)
+            return
+        sends, recvs = [], []
+        for send_s, send_e, recv_s, recv_e in pairs:
+            # with two ranks prev == nxt: the peer posts (send_s, send_e) in this
+            # order too, so its send_s must land in our recv_e and its send_e in recv_s
+            sends += [(send_s, prev), (send_e, nxt)]
+            recvs += [(recv_e, nxt), (recv_s, prev)]
+        self._exchange(sends, recvs)
+
+    # ------------------------------------------------------------ transposes
+    def alltoall(self, sendbuf, send_counts, recvbuf, recv_counts, peers):
+        """personalised exchange among `peers` (global ranks, own rank
+        included at its position): chunk i of sendbuf goes to peers[i], chunk i of
+        recvbuf comes from peers[i]; counts in elements of the buffers' dtype."""
+        so = ro = 0
+        sends, recvs = [], []
+        for cnt_s, cnt_r, peer in zip(send_counts, recv_counts, peers):
+            if peer == self.rank:
+                recvbuf[ro:ro + cnt_r].copy_(sendbuf[so:so + cnt_s])
+            else:
+                if cnt_s:
+                    sends.append((sendbuf[so:so + cnt_s], peer))
+                if cnt_r:
+                    recvs.append((recvbuf[ro:ro + cnt_r], peer))
+            so += cnt_s
+            ro += cnt_r
+        self._exchange(sends, recvs)
+
+    # ------------------------------------------------------------ scalars
     def allreduce(self, value, op="sum"):
         if self.size == 1:
             return value
         t = torch.tensor([value], dtype=torch.float64)
-        if dist.get_backend(self.group) == "nccl":
+        if self.backend == "nccl":
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
