@@ -1,0 +1,588 @@
+!> hip_backend_t: the reference-side shim of the MI355X backend.  Extends the
+!> reference's abstract types and forwards every operation to libx3d2_hip.so
+!> through m_x3d2_hip_capi; solver.f90, vector_calculus.f90, time_integrator.f90
+!> and the cases are used UNCHANGED.  Single MPI rank per device; directions
+!> decomposed across ranks need a GPU-aware MPI for the sendrecv of device
+!> buffers and are rejected here (the Python driver covers multi-GPU over RCCL).
+!>
+!> Pattern followed: src/backend/cuda/{allocator,tdsops,backend,poisson_fft}.f90.
+module m_hip_common
+  implicit none
+  integer, parameter :: SZ = 16 !! only sets the padding of the host-visible shapes
+end module m_hip_common
+
+module m_hip_allocator
+  use iso_c_binding
+  use m_allocator, only: allocator_t
+  use m_common, only: dp
+  use m_field, only: field_t
+  use m_x3d2_hip_capi
+  implicit none
+
+  type, extends(field_t) :: hip_field_t
+    type(c_ptr) :: dev = c_null_ptr      !! device block (x3d_block_alloc)
+    type(c_ptr) :: handle = c_null_ptr   !! library backend
+    integer :: dims3(3) = 0
+  contains
+    procedure :: fill => fill_hip
+    procedure :: get_shape => get_shape_hip
+    procedure :: set_shape => set_shape_hip
+  end type hip_field_t
+
+  type, extends(allocator_t) :: hip_allocator_t
+    type(c_ptr) :: handle = c_null_ptr
+  contains
+    procedure :: create_block => create_hip_block
+  end type hip_allocator_t
+
+contains
+
+  function hip_allocator_init(dims, sz, device) result(allocator)
+    integer, intent(in) :: dims(3), sz, device
+    type(hip_allocator_t) :: allocator
+    allocator%allocator_t = allocator_t(dims, sz)
+    call x3d_check(x3d_backend_create(allocator%handle, int(dims, c_int), int(device, c_int), c_null_ptr))
+  end function hip_allocator_init
+
+  function create_hip_block(self, next) result(ptr)
+    class(hip_allocator_t), intent(inout) :: self
+    class(field_t), pointer, intent(in) :: next
+    class(field_t), pointer :: ptr
+    type(hip_field_t), pointer :: newblock
+    allocate (newblock)
+    self%next_id = self%next_id + 1
+    newblock%refcount = 0
+    newblock%next => next
+    newblock%id = self%next_id
+    newblock%handle = self%handle
+    call x3d_check(x3d_block_alloc(self%handle, newblock%dev))
+    ptr => newblock
+  end function create_hip_block
+
+  subroutine fill_hip(self, c)
+    class(hip_field_t) :: self
+    real(dp), intent(in) :: c
+    call x3d_check(x3d_block_fill(self%handle, self%dev, real(c, c_double)))
+  end subroutine fill_hip
+
+  function get_shape_hip(self) result(dims)
+    class(hip_field_t) :: self
+    integer :: dims(3)
+    dims = self%dims3
+  end function get_shape_hip
+
+  subroutine set_shape_hip(self, dims)
+    class(hip_field_t) :: self
+    integer, intent(in) :: dims(3)
+    self%dims3 = dims
+  end subroutine set_shape_hip
+
+  function dev(f) result(p)
+    !! device pointer of a field handed through the abstract interface
+    class(field_t), intent(in) :: f
+    type(c_ptr) :: p
+    select type (f)
+    type is (hip_field_t)
+      p = f%dev
+    class default
+      error stop 'hip backend: field is not a hip_field_t'
+    end select
+  end function dev
+
+end module m_hip_allocator
+
+module m_hip_tdsops
+  use iso_c_binding
+  use m_common, only: dp
+  use m_tdsops, only: tdsops_t, tdsops_init
+  use m_x3d2_hip_capi
+  implicit none
+  type, extends(tdsops_t) :: hip_tdsops_t
+    type(c_ptr) :: handle = c_null_ptr
+  end type hip_tdsops_t
+contains
+  function hip_tdsops_init(backend, n_tds, delta, operation, scheme, bc_start, bc_end, stretch, &
+                           stretch_correct, n_halo, from_to, sym, c_nu, nu0_nu) result(t)
+    type(c_ptr), intent(in) :: backend
+    integer, intent(in) :: n_tds
+    real(dp), intent(in) :: delta
+    character(*), intent(in) :: operation, scheme
+    integer, intent(in) :: bc_start, bc_end
+    real(dp), optional, intent(in) :: stretch(:), stretch_correct(:)
+    integer, optional, intent(in) :: n_halo
+    character(*), optional, intent(in) :: from_to
+    logical, optional, intent(in) :: sym
+    real(dp), optional, intent(in) :: c_nu, nu0_nu
+    type(hip_tdsops_t) :: t
+    ! host-side factory of the reference, unchanged (src/tdsops.f90:63-203)
+    t%tdsops_t = tdsops_init(n_tds, delta, operation, scheme, bc_start, bc_end, stretch, &
+                             stretch_correct, n_halo, from_to, sym, c_nu, nu0_nu)
+    ! dist_fw(2) is never assigned by preprocess_dist; the library never reads it either
+    call x3d_check(x3d_tdsops_create( &
+                   backend, t%handle, int(t%n_tds, c_int), int(t%n_rhs, c_int), int(t%move, c_int), &
+                   merge(1_c_int, 0_c_int, t%periodic), t%coeffs, t%coeffs_s, t%coeffs_e, t%dist_fw, &
+                   t%dist_bw, t%dist_sa, t%dist_sc, t%dist_af, t%stretch, t%stretch_correct))
+  end function hip_tdsops_init
+end module m_hip_tdsops
+
+module m_hip_poisson_fft
+  use iso_c_binding
+  use m_common, only: dp, CELL
+  use m_field, only: field_t
+  use m_mesh, only: mesh_t
+  use m_poisson_fft, only: poisson_fft_t
+  use m_tdsops, only: dirps_t
+  use m_hip_allocator, only: dev
+  use m_x3d2_hip_capi
+  implicit none
+  type, extends(poisson_fft_t) :: hip_poisson_fft_t
+    type(c_ptr) :: handle = c_null_ptr
+  contains
+    procedure :: fft_forward => fft_forward_hip
+    procedure :: fft_backward => fft_backward_hip
+    procedure :: fft_postprocess_000 => fft_postprocess_000_hip
+    procedure :: fft_forward_010 => fw_unsupported
+    procedure :: fft_forward_100 => fw_unsupported
+    procedure :: fft_forward_110 => fw_unsupported
+    procedure :: fft_backward_010 => bw_unsupported
+    procedure :: fft_backward_100 => bw_unsupported
+    procedure :: fft_backward_110 => bw_unsupported
+    procedure :: fft_postprocess_010 => pp_unsupported
+    procedure :: fft_postprocess_100 => pp_unsupported
+    procedure :: fft_postprocess_110 => pp_unsupported
+    procedure :: enforce_periodicity_x => fp_unsupported
+    procedure :: undo_periodicity_x => fp_unsupported
+    procedure :: enforce_periodicity_y => fp_unsupported
+    procedure :: undo_periodicity_y => fp_unsupported
+    procedure :: enforce_periodicity_xy => fp_unsupported
+    procedure :: undo_periodicity_xy => fp_unsupported
+  end type hip_poisson_fft_t
+contains
+  subroutine hip_poisson_fft_setup(self, backend, mesh, xdirps, ydirps, zdirps)
+    class(hip_poisson_fft_t), intent(inout) :: self
+    type(c_ptr), intent(in) :: backend
+    type(mesh_t), intent(in) :: mesh
+    type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
+    integer :: dims(3), nspec(3)
+    real(dp), allocatable :: wre(:, :, :)
+    if (mesh%par%nproc > 1) error stop 'hip shim: FFT Poisson solver is single rank here'
+    dims = mesh%get_global_dims(CELL)
+    nspec = [dims(1)/2 + 1, dims(2), dims(3)]
+    ! wave numbers and BC dispatch: the reference's own base_init (src/poisson_fft.f90:120-204)
+    call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
+    if (.not. (self%periodic_x .and. self%periodic_y .and. self%periodic_z)) then
+      error stop 'hip shim: only the all-periodic (000) Poisson solver is available yet'
+    end if
+    allocate (wre(nspec(1), nspec(2), nspec(3)))
+    wre = real(self%waves, dp)
+    call x3d_check(x3d_poisson_create(backend, self%handle, int(dims, c_int), wre, self%ax, self%bx, &
+                                      self%ay, self%by, self%az, self%bz))
+  end subroutine hip_poisson_fft_setup
+
+  subroutine fft_forward_hip(self, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_fft_forward(self%handle, dev(f_in)))
+  end subroutine
+  subroutine fft_backward_hip(self, f_out)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    call x3d_check(x3d_poisson_fft_backward(self%handle, dev(f_out)))
+  end subroutine
+  subroutine fft_postprocess_000_hip(self)
+    class(hip_poisson_fft_t) :: self
+    call x3d_check(x3d_poisson_postprocess_000(self%handle))
+  end subroutine
+  subroutine fw_unsupported(self, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(in) :: f_in
+    error stop 'HIP backend does not support this fft_forward variant yet!'
+  end subroutine
+  subroutine bw_unsupported(self, f_out)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    error stop 'HIP backend does not support this fft_backward variant yet!'
+  end subroutine
+  subroutine pp_unsupported(self)
+    class(hip_poisson_fft_t) :: self
+    error stop 'HIP backend does not support this fft_postprocess variant yet!'
+  end subroutine
+  subroutine fp_unsupported(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    error stop 'HIP backend does not support enforce/undo periodicity yet!'
+  end subroutine
+end module m_hip_poisson_fft
+
+module m_hip_backend
+  use iso_c_binding
+  use mpi
+  use m_allocator, only: allocator_t
+  use m_base_backend, only: base_backend_t
+  use m_common, only: dp, MPI_X3D2_DP, DIR_X, DIR_Y, DIR_Z, DIR_C, NULL_LOC, move_data_loc, &
+                      get_dirs_from_rdr
+  use m_field, only: field_t
+  use m_mesh, only: mesh_t
+  use m_tdsops, only: tdsops_t, dirps_t
+  use m_hip_allocator, only: hip_allocator_t, hip_field_t, dev
+  use m_hip_tdsops, only: hip_tdsops_t, hip_tdsops_init
+  use m_hip_poisson_fft, only: hip_poisson_fft_t, hip_poisson_fft_setup
+  use m_x3d2_hip_capi
+  implicit none
+
+  type, extends(base_backend_t) :: hip_backend_t
+    type(c_ptr) :: handle = c_null_ptr
+  contains
+    procedure :: alloc_tdsops => alloc_hip_tdsops
+    procedure :: transeq_x => transeq_x_hip
+    procedure :: transeq_y => transeq_y_hip
+    procedure :: transeq_z => transeq_z_hip
+    procedure :: transeq_species => transeq_species_hip
+    procedure :: tds_solve => tds_solve_hip
+    procedure :: reorder => reorder_hip
+    procedure :: sum_yintox => sum_yintox_hip
+    procedure :: sum_zintox => sum_zintox_hip
+    procedure :: veccopy => veccopy_hip
+    procedure :: vecadd => vecadd_hip
+    procedure :: vecmult => vecmult_hip
+    procedure :: scalar_product => scalar_product_hip
+    procedure :: field_max_mean => field_max_mean_hip
+    procedure :: slice_max_sum => slice_max_sum_hip
+    procedure :: field_scale => field_scale_hip
+    procedure :: field_shift => field_shift_hip
+    procedure :: field_volume_integral => field_volume_integral_hip
+    procedure :: field_set_face => field_set_face_hip
+    procedure :: field_set_face_from_field => field_set_face_from_field_hip
+    procedure :: compute_vorticity => derived_unsupported
+    procedure :: compute_qcriterion => derived_unsupported
+    procedure :: copy_data_to_f => copy_data_to_f_hip
+    procedure :: copy_f_to_data => copy_f_to_data_hip
+    procedure :: init_poisson_fft => init_hip_poisson_fft
+  end type hip_backend_t
+
+contains
+
+  function hip_backend_init(mesh, allocator) result(backend)
+    type(mesh_t), target, intent(inout) :: mesh
+    class(allocator_t), target, intent(inout) :: allocator
+    type(hip_backend_t) :: backend
+    call backend%base_init()
+    backend%mesh => mesh
+    select type (allocator)
+    type is (hip_allocator_t)
+      backend%allocator => allocator
+      backend%handle = allocator%handle
+    class default
+      error stop 'hip_backend_t needs a hip_allocator_t'
+    end select
+    if (any(mesh%par%nproc_dir /= 1)) then
+      error stop 'hip shim: one rank per run (use the Python driver for multi-GPU)'
+    end if
+  end function hip_backend_init
+
+  function tds_handle(t) result(h)
+    class(tdsops_t), intent(in) :: t
+    type(c_ptr) :: h
+    select type (t)
+    type is (hip_tdsops_t)
+      h = t%handle
+    class default
+      error stop 'hip backend: tdsops is not a hip_tdsops_t'
+    end select
+  end function tds_handle
+
+  subroutine alloc_hip_tdsops(self, tdsops, n_tds, delta, operation, scheme, bc_start, bc_end, &
+                              stretch, stretch_correct, n_halo, from_to, sym, c_nu, nu0_nu)
+    class(hip_backend_t) :: self
+    class(tdsops_t), allocatable, intent(inout) :: tdsops
+    integer, intent(in) :: n_tds
+    real(dp), intent(in) :: delta
+    character(*), intent(in) :: operation, scheme
+    integer, intent(in) :: bc_start, bc_end
+    real(dp), optional, intent(in) :: stretch(:), stretch_correct(:)
+    integer, optional, intent(in) :: n_halo
+    character(*), optional, intent(in) :: from_to
+    logical, optional, intent(in) :: sym
+    real(dp), optional, intent(in) :: c_nu, nu0_nu
+    allocate (hip_tdsops_t :: tdsops)
+    select type (tdsops)
+    type is (hip_tdsops_t)
+      tdsops = hip_tdsops_init(self%handle, n_tds, delta, operation, scheme, bc_start, bc_end, &
+                               stretch, stretch_correct, n_halo, from_to, sym, c_nu, nu0_nu)
+    end select
+  end subroutine alloc_hip_tdsops
+
+  subroutine transeq_any(self, dir, du, dv, dw, u, v, w, nu, dirps)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir
+    class(field_t), intent(inout) :: du, dv, dw
+    class(field_t), intent(in) :: u, v, w
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    integer :: n
+    n = self%mesh%get_n(u) ! error-stops on NULL_LOC like transeq_halo_exchange
+    call x3d_check(x3d_transeq(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), &
+                               dev(w), real(nu, c_double), tds_handle(dirps%der1st), &
+                               tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), &
+                               tds_handle(dirps%der2nd_sym)))
+    call du%set_data_loc(u%data_loc)
+    call dv%set_data_loc(u%data_loc)
+    call dw%set_data_loc(u%data_loc)
+  end subroutine transeq_any
+
+  subroutine transeq_x_hip(self, du, dv, dw, u, v, w, nu, dirps)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: du, dv, dw
+    class(field_t), intent(in) :: u, v, w
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    call transeq_any(self, DIR_X, du, dv, dw, u, v, w, nu, dirps)
+  end subroutine
+  subroutine transeq_y_hip(self, du, dv, dw, u, v, w, nu, dirps)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: du, dv, dw
+    class(field_t), intent(in) :: u, v, w
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    call transeq_any(self, DIR_Y, du, dv, dw, u, v, w, nu, dirps)
+  end subroutine
+  subroutine transeq_z_hip(self, du, dv, dw, u, v, w, nu, dirps)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: du, dv, dw
+    class(field_t), intent(in) :: u, v, w
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    call transeq_any(self, DIR_Z, du, dv, dw, u, v, w, nu, dirps)
+  end subroutine
+
+  subroutine transeq_species_hip(self, dspec, uvw, spec, nu, dirps, sync)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: dspec
+    class(field_t), intent(in) :: uvw, spec
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    logical, intent(in) :: sync
+    error stop 'HIP backend: species transport is not supported yet'
+  end subroutine
+
+  subroutine tds_solve_hip(self, du, u, tdsops)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: du
+    class(field_t), intent(in) :: u
+    class(tdsops_t), intent(in) :: tdsops
+    if (u%dir /= du%dir) error stop 'DIR mismatch between fields in tds_solve.'
+    if (u%data_loc /= NULL_LOC) then
+      call du%set_data_loc(move_data_loc(u%data_loc, u%dir, tdsops%move))
+    end if
+    call x3d_check(x3d_tds_solve(self%handle, dev(du), dev(u), tds_handle(tdsops), int(u%dir, c_int)))
+  end subroutine tds_solve_hip
+
+  subroutine reorder_hip(self, u_, u, direction)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: u_
+    class(field_t), intent(in) :: u
+    integer, intent(in) :: direction
+    call x3d_check(x3d_reorder(self%handle, dev(u_), dev(u), int(direction, c_int)))
+    call u_%set_data_loc(u%data_loc)
+  end subroutine reorder_hip
+
+  subroutine sum_yintox_hip(self, u, u_)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: u
+    class(field_t), intent(in) :: u_
+    call x3d_check(x3d_sum_intox(self%handle, dev(u), dev(u_), int(DIR_Y, c_int)))
+  end subroutine
+  subroutine sum_zintox_hip(self, u, u_)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: u
+    class(field_t), intent(in) :: u_
+    call x3d_check(x3d_sum_intox(self%handle, dev(u), dev(u_), int(DIR_Z, c_int)))
+  end subroutine
+
+  subroutine veccopy_hip(self, dst, src)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: dst
+    class(field_t), intent(in) :: src
+    if (src%dir /= dst%dir) error stop 'Called vector copy with incompatible fields'
+    if (dst%dir == DIR_C) error stop 'veccopy does not support DIR_C fields'
+    call x3d_check(x3d_veccopy(self%handle, dev(dst), dev(src)))
+  end subroutine
+  subroutine vecadd_hip(self, a, x, b, y)
+    class(hip_backend_t) :: self
+    real(dp), intent(in) :: a
+    class(field_t), intent(in) :: x
+    real(dp), intent(in) :: b
+    class(field_t), intent(inout) :: y
+    if (x%dir /= y%dir) error stop 'Called vector add with incompatible fields'
+    if (y%dir == DIR_C) error stop 'vecadd does not support DIR_C fields'
+    call x3d_check(x3d_vecadd(self%handle, real(a, c_double), dev(x), real(b, c_double), dev(y)))
+  end subroutine
+  subroutine vecmult_hip(self, y, x)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: y
+    class(field_t), intent(in) :: x
+    if (x%dir /= y%dir) error stop 'Called vector multiply with incompatible fields'
+    if (y%dir == DIR_C) error stop 'vecmult does not support DIR_C fields'
+    call x3d_check(x3d_vecmult(self%handle, dev(y), dev(x)))
+  end subroutine
+
+  real(dp) function scalar_product_hip(self, x, y) result(s)
+    class(hip_backend_t) :: self
+    class(field_t), intent(in) :: x, y
+    real(c_double) :: v
+    integer :: ierr
+    if ((x%data_loc == NULL_LOC) .or. (y%data_loc == NULL_LOC)) then
+      error stop 'You must set the data_loc before calling scalar product'
+    end if
+    if (x%data_loc /= y%data_loc) error stop 'Called scalar product with incompatible fields'
+    call x3d_check(x3d_scalar_product(self%handle, dev(x), dev(y), int(self%mesh%get_dims(x%data_loc), c_int), v))
+    s = v
+    call MPI_Allreduce(MPI_IN_PLACE, s, 1, MPI_X3D2_DP, MPI_SUM, MPI_COMM_WORLD, ierr)
+  end function scalar_product_hip
+
+  subroutine field_max_mean_hip(self, max_val, mean_val, f, enforced_data_loc)
+    class(hip_backend_t) :: self
+    real(dp), intent(out) :: max_val, mean_val
+    class(field_t), intent(in) :: f
+    integer, optional, intent(in) :: enforced_data_loc
+    integer :: data_loc, ierr
+    real(c_double) :: mx, sm
+    if (f%data_loc == NULL_LOC .and. (.not. present(enforced_data_loc))) then
+      error stop 'The input field to hip::field_max_mean does not have a valid f%data_loc.'
+    end if
+    data_loc = f%data_loc
+    if (present(enforced_data_loc)) data_loc = enforced_data_loc
+    if (f%dir == DIR_C) error stop 'field_max_mean does not support DIR_C fields!'
+    call x3d_check(x3d_field_max_sum(self%handle, dev(f), int(self%mesh%get_dims(data_loc), c_int), mx, sm))
+    max_val = mx
+    mean_val = sm/product(self%mesh%get_global_dims(data_loc))
+    call MPI_Allreduce(MPI_IN_PLACE, max_val, 1, MPI_X3D2_DP, MPI_MAX, MPI_COMM_WORLD, ierr)
+    call MPI_Allreduce(MPI_IN_PLACE, mean_val, 1, MPI_X3D2_DP, MPI_SUM, MPI_COMM_WORLD, ierr)
+  end subroutine field_max_mean_hip
+
+  subroutine slice_max_sum_hip(self, max_val, sum_val, f, i_slice, enforced_data_loc)
+    class(hip_backend_t) :: self
+    real(dp), intent(out) :: max_val, sum_val
+    class(field_t), intent(in) :: f
+    integer, intent(in) :: i_slice
+    integer, optional, intent(in) :: enforced_data_loc
+    integer :: data_loc
+    real(c_double) :: mx, sm
+    data_loc = f%data_loc
+    if (present(enforced_data_loc)) data_loc = enforced_data_loc
+    if (data_loc == NULL_LOC) error stop 'slice_max_sum needs a valid data_loc'
+    call x3d_check(x3d_slice_max_sum(self%handle, dev(f), int(self%mesh%get_dims(data_loc), c_int), &
+                                     int(f%dir, c_int), int(i_slice, c_int), mx, sm))
+    max_val = mx; sum_val = sm
+  end subroutine slice_max_sum_hip
+
+  subroutine field_scale_hip(self, f, a)
+    class(hip_backend_t) :: self
+    class(field_t), intent(in) :: f
+    real(dp), intent(in) :: a
+    call x3d_check(x3d_field_scale(self%handle, dev(f), real(a, c_double)))
+  end subroutine
+  subroutine field_shift_hip(self, f, a)
+    class(hip_backend_t) :: self
+    class(field_t), intent(in) :: f
+    real(dp), intent(in) :: a
+    call x3d_check(x3d_field_shift(self%handle, dev(f), real(a, c_double)))
+  end subroutine
+
+  real(dp) function field_volume_integral_hip(self, f) result(s)
+    class(hip_backend_t) :: self
+    class(field_t), intent(in) :: f
+    real(c_double) :: v
+    integer :: ierr
+    if (f%data_loc == NULL_LOC) error stop 'You must set the data_loc before calling volume integral.'
+    if (f%dir /= DIR_X) error stop 'Volume integral can only be called on DIR_X fields.'
+    call x3d_check(x3d_field_volume_integral(self%handle, dev(f), int(self%mesh%get_dims(f%data_loc), c_int), v))
+    s = v
+    call MPI_Allreduce(MPI_IN_PLACE, s, 1, MPI_X3D2_DP, MPI_SUM, MPI_COMM_WORLD, ierr)
+  end function field_volume_integral_hip
+
+  subroutine field_set_face_hip(self, f, c_start, c_end, face, bc_start, bc_end, flow_rate_diff)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: f
+    real(dp), intent(in) :: c_start, c_end
+    integer, intent(in) :: face
+    integer, optional, intent(in) :: bc_start, bc_end
+    real(dp), optional, intent(in) :: flow_rate_diff
+    if (f%dir /= DIR_X) error stop 'Setting a field face is only supported for DIR_X fields.'
+    if (f%data_loc == NULL_LOC) error stop 'field_set_face require a valid data_loc.'
+    call x3d_check(x3d_field_set_face(self%handle, dev(f), int(self%mesh%get_dims(f%data_loc), c_int), &
+                                      real(c_start, c_double), real(c_end, c_double), int(face, c_int)))
+  end subroutine field_set_face_hip
+
+  subroutine field_set_face_from_field_hip(self, f, f_start, c_end, face, bc_start, bc_end, flow_rate_diff)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: f
+    class(field_t), intent(in) :: f_start
+    real(dp), intent(in) :: c_end
+    integer, intent(in) :: face
+    integer, optional, intent(in) :: bc_start, bc_end
+    real(dp), optional, intent(in) :: flow_rate_diff
+    real(dp) :: frd
+    frd = 0._dp
+    if (present(flow_rate_diff)) frd = flow_rate_diff
+    if (f%dir /= DIR_X) error stop 'field_set_face_from_field: only supported for DIR_X fields.'
+    if (f%data_loc == NULL_LOC) error stop 'field_set_face_from_field: requires a valid data_loc.'
+    call x3d_check(x3d_field_set_face_from_field(self%handle, dev(f), dev(f_start), &
+                                                 int(self%mesh%get_dims(f%data_loc), c_int), &
+                                                 real(c_end, c_double), int(face, c_int), real(frd, c_double)))
+  end subroutine field_set_face_from_field_hip
+
+  subroutine derived_unsupported(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: field_out
+    class(field_t), intent(in) :: dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz
+    error stop 'HIP backend: snapshot fields (vorticity / Q) are not supported yet'
+  end subroutine
+
+  subroutine copy_extent(self, shp, ext, hx, hy)
+    !! whole padded DIR_C host arrays are exchanged (src/backend/omp/backend.f90:1068-1082):
+    !! copy what both the host array and the device block hold
+    class(hip_backend_t) :: self
+    integer, intent(in) :: shp(3)
+    integer(c_int), intent(out) :: ext(3), hx, hy
+    integer(c_int) :: pd(3)
+    call x3d_check(x3d_padded_dims(self%handle, pd))
+    hx = shp(1); hy = shp(2)
+    ext = [min(int(shp(1), c_int), pd(1)), min(int(shp(2), c_int), pd(2)), min(int(shp(3), c_int), pd(3))]
+  end subroutine
+
+  subroutine copy_data_to_f_hip(self, f, data)
+    class(hip_backend_t), intent(inout) :: self
+    class(field_t), intent(inout) :: f
+    real(dp), dimension(:, :, :), intent(in) :: data
+    integer(c_int) :: ext(3), hx, hy
+    if (f%dir /= DIR_C) error stop 'hip shim: copy_data_to_f expects a DIR_C field (set_field_data default)'
+    call copy_extent(self, shape(data), ext, hx, hy)
+    call x3d_check(x3d_set_field_data_pitched(self%handle, dev(f), data, hx, hy, ext))
+  end subroutine
+
+  subroutine copy_f_to_data_hip(self, data, f)
+    class(hip_backend_t), intent(inout) :: self
+    real(dp), dimension(:, :, :), intent(out) :: data
+    class(field_t), intent(in) :: f
+    integer(c_int) :: ext(3), hx, hy
+    if (f%dir /= DIR_C) error stop 'hip shim: copy_f_to_data expects a DIR_C field (get_field_data default)'
+    call copy_extent(self, shape(data), ext, hx, hy)
+    data = 0._dp
+    call x3d_check(x3d_get_field_data_pitched(self%handle, data, dev(f), hx, hy, ext))
+  end subroutine
+
+  subroutine init_hip_poisson_fft(self, mesh, xdirps, ydirps, zdirps, lowmem)
+    class(hip_backend_t) :: self
+    type(mesh_t), intent(in) :: mesh
+    type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
+    logical, optional, intent(in) :: lowmem
+    allocate (hip_poisson_fft_t :: self%poisson_fft)
+    select type (poisson_fft => self%poisson_fft)
+    type is (hip_poisson_fft_t)
+      call hip_poisson_fft_setup(poisson_fft, self%handle, mesh, xdirps, ydirps, zdirps)
+    end select
+  end subroutine init_hip_poisson_fft
+
+end module m_hip_backend

@@ -1,0 +1,250 @@
+!> ISO_C_BINDING interface block for libx3d2_hip.so (include/x3d2_hip.h).
+!> This is the reference-side binding a maintainer adds next to
+!> src/backend/cuda/ : every procedure below is what the corresponding deferred
+!> procedure of base_backend_t (src/backend/backend.f90:13-62) or hook of
+!> poisson_fft_t (src/poisson_fft.f90:45-62) forwards to.  Compile-checked with
+!> ROCm flang (see INTEGRATION.md); field arguments are device pointers
+!> (type(c_ptr), value) held by the hip_field_t extension of field_t.
+module m_x3d2_hip_capi
+  use iso_c_binding
+  implicit none
+
+  interface
+    function x3d_last_error() bind(C, name='x3d_last_error') result(msg)
+      import :: c_ptr
+      type(c_ptr) :: msg
+    end function
+    integer(c_int) function x3d_backend_create(handle, dims_vert, device, stream) &
+      bind(C, name='x3d_backend_create')
+      import :: c_ptr, c_int
+      type(c_ptr), intent(out) :: handle
+      integer(c_int), intent(in) :: dims_vert(3)
+      integer(c_int), value :: device
+      type(c_ptr), value :: stream
+    end function
+    integer(c_int) function x3d_backend_destroy(b) bind(C, name='x3d_backend_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+    end function
+    integer(c_size_t) function x3d_block_elems(b) bind(C, name='x3d_block_elems')
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: b
+    end function
+    integer(c_int) function x3d_block_alloc(b, blk) bind(C, name='x3d_block_alloc')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: blk
+    end function
+    integer(c_int) function x3d_block_fill(b, f, c) bind(C, name='x3d_block_fill')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), value :: c
+    end function
+    ! alloc_tdsops: device copy of the arrays tdsops_init produced on the host
+    integer(c_int) function x3d_tdsops_create(b, t, n_tds, n_rhs, move, periodic, coeffs, &
+                                              coeffs_s, coeffs_e, dist_fw, dist_bw, dist_sa, &
+                                              dist_sc, dist_af, stretch, stretch_correct) &
+      bind(C, name='x3d_tdsops_create')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: t
+      integer(c_int), value :: n_tds, n_rhs, move, periodic
+      real(c_double), intent(in) :: coeffs(*), coeffs_s(*), coeffs_e(*), dist_fw(*), dist_bw(*), &
+                                    dist_sa(*), dist_sc(*), dist_af(*), stretch(*), stretch_correct(*)
+    end function
+    ! tds_solve
+    integer(c_int) function x3d_tds_solve(b, du, u, t, dir) bind(C, name='x3d_tds_solve')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, du, u, t
+      integer(c_int), value :: dir
+    end function
+    ! transeq_x / transeq_y / transeq_z
+    integer(c_int) function x3d_transeq(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, &
+                                        der2nd, der2nd_sym) bind(C, name='x3d_transeq')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der1st_sym, der2nd, der2nd_sym
+      integer(c_int), value :: dir
+      real(c_double), value :: nu
+    end function
+    ! distributed phases of exec_dist_tds_compact / exec_dist_transeq_compact
+    integer(c_int) function x3d_npencils(b, dir) bind(C, name='x3d_npencils')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      integer(c_int), value :: dir
+    end function
+    integer(c_int) function x3d_pack_halos(b, send_s, send_e, u, n, dir) bind(C, name='x3d_pack_halos')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, send_s, send_e, u
+      integer(c_int), value :: n, dir
+    end function
+    integer(c_int) function x3d_tds_dist_fwd(b, du, du_send_s, du_send_e, u, u_recv_s, u_recv_e, t, dir) &
+      bind(C, name='x3d_tds_dist_fwd')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, du, du_send_s, du_send_e, u, u_recv_s, u_recv_e, t
+      integer(c_int), value :: dir
+    end function
+    integer(c_int) function x3d_tds_dist_bwd(b, du, du_send_s, du_recv_s, du_recv_e, t, dir) &
+      bind(C, name='x3d_tds_dist_bwd')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, du, du_send_s, du_recv_s, du_recv_e, t
+      integer(c_int), value :: dir
+    end function
+    ! reorder / sum_yintox / sum_zintox
+    integer(c_int) function x3d_reorder(b, u_, u, rdr) bind(C, name='x3d_reorder')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, u_, u
+      integer(c_int), value :: rdr
+    end function
+    integer(c_int) function x3d_sum_intox(b, u, u_, dir_from) bind(C, name='x3d_sum_intox')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, u, u_
+      integer(c_int), value :: dir_from
+    end function
+    ! veccopy / vecadd / vecmult / field_scale / field_shift
+    integer(c_int) function x3d_veccopy(b, dst, src) bind(C, name='x3d_veccopy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, dst, src
+    end function
+    integer(c_int) function x3d_vecadd(b, a, x, bb, y) bind(C, name='x3d_vecadd')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, x, y
+      real(c_double), value :: a, bb
+    end function
+    integer(c_int) function x3d_vecmult(b, y, x) bind(C, name='x3d_vecmult')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, y, x
+    end function
+    integer(c_int) function x3d_field_scale(b, f, a) bind(C, name='x3d_field_scale')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), value :: a
+    end function
+    integer(c_int) function x3d_field_shift(b, f, a) bind(C, name='x3d_field_shift')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), value :: a
+    end function
+    ! reductions (rank-local; the shim adds MPI_Allreduce like the reference)
+    integer(c_int) function x3d_scalar_product(b, x, y, dims, s) bind(C, name='x3d_scalar_product')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, x, y
+      integer(c_int), intent(in) :: dims(3)
+      real(c_double), intent(out) :: s
+    end function
+    integer(c_int) function x3d_field_max_sum(b, f, dims, max_abs, sum_abs) bind(C, name='x3d_field_max_sum')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      integer(c_int), intent(in) :: dims(3)
+      real(c_double), intent(out) :: max_abs, sum_abs
+    end function
+    integer(c_int) function x3d_field_volume_integral(b, f, dims, s) bind(C, name='x3d_field_volume_integral')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      integer(c_int), intent(in) :: dims(3)
+      real(c_double), intent(out) :: s
+    end function
+    integer(c_int) function x3d_slice_max_sum(b, f, dims, dir, i_slice, max_val, sum_val) &
+      bind(C, name='x3d_slice_max_sum')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      integer(c_int), intent(in) :: dims(3)
+      integer(c_int), value :: dir, i_slice
+      real(c_double), intent(out) :: max_val, sum_val
+    end function
+    ! faces
+    integer(c_int) function x3d_field_set_face(b, f, dims, c_start, c_end, face) bind(C, name='x3d_field_set_face')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      integer(c_int), intent(in) :: dims(3)
+      real(c_double), value :: c_start, c_end
+      integer(c_int), value :: face
+    end function
+    integer(c_int) function x3d_field_set_face_from_field(b, f, f_start, dims, c_end, face, flow_rate_diff) &
+      bind(C, name='x3d_field_set_face_from_field')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f, f_start
+      integer(c_int), intent(in) :: dims(3)
+      real(c_double), value :: c_end, flow_rate_diff
+      integer(c_int), value :: face
+    end function
+    ! copy_data_to_f / copy_f_to_data (Cartesian host arrays)
+    integer(c_int) function x3d_set_field_data(b, f, host, dims) bind(C, name='x3d_set_field_data')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), intent(in) :: host(*)
+      integer(c_int), intent(in) :: dims(3)
+    end function
+    integer(c_int) function x3d_get_field_data(b, host, f, dims) bind(C, name='x3d_get_field_data')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), intent(out) :: host(*)
+      integer(c_int), intent(in) :: dims(3)
+    end function
+    integer(c_int) function x3d_set_field_data_pitched(b, f, host, hx, hy, dims) &
+      bind(C, name='x3d_set_field_data_pitched')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), intent(in) :: host(*)
+      integer(c_int), value :: hx, hy
+      integer(c_int), intent(in) :: dims(3)
+    end function
+    integer(c_int) function x3d_get_field_data_pitched(b, host, f, hx, hy, dims) &
+      bind(C, name='x3d_get_field_data_pitched')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, f
+      real(c_double), intent(out) :: host(*)
+      integer(c_int), value :: hx, hy
+      integer(c_int), intent(in) :: dims(3)
+    end function
+    integer(c_int) function x3d_padded_dims(b, dims) bind(C, name='x3d_padded_dims')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      integer(c_int), intent(out) :: dims(3)
+    end function
+    integer(c_int) function x3d_device_sync(b) bind(C, name='x3d_device_sync')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+    end function
+    ! init_poisson_fft + poisson_fft_t hooks
+    integer(c_int) function x3d_poisson_create(b, p, n, waves_re, ax, bx, ay, by, az, bz) &
+      bind(C, name='x3d_poisson_create')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: p
+      integer(c_int), intent(in) :: n(3)
+      real(c_double), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
+    end function
+    integer(c_int) function x3d_poisson_fft_forward(p, f_in) bind(C, name='x3d_poisson_fft_forward')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_in
+    end function
+    integer(c_int) function x3d_poisson_postprocess_000(p) bind(C, name='x3d_poisson_postprocess_000')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+    end function
+    integer(c_int) function x3d_poisson_fft_backward(p, f_out) bind(C, name='x3d_poisson_fft_backward')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out
+    end function
+  end interface
+
+contains
+
+  !> the reference has no status codes: turn a non-zero return into `error stop`
+  subroutine x3d_check(rc)
+    integer(c_int), intent(in) :: rc
+    character(kind=c_char), pointer :: msg(:)
+    character(len=512) :: text
+    integer :: i
+    if (rc == 0) return
+    call c_f_pointer(x3d_last_error(), msg, [512])
+    text = ''
+    do i = 1, 512
+      if (msg(i) == c_null_char) exit
+      text(i:i) = msg(i)
+    end do
+    print *, trim(text)
+    error stop 'libx3d2_hip'
+  end subroutine x3d_check
+
+end module m_x3d2_hip_capi

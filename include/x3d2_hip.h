@@ -168,6 +168,12 @@ int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_sta
  * (x fastest, unpadded extents dims) <-> device block. */
 int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3]);
 int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3]);
+/* same with a padded host array (leading dims hx, hy): what copy_data_to_f /
+ * copy_f_to_data see, whole padded DIR_C arrays (src/backend/omp/backend.f90:1068-1082) */
+int x3d_set_field_data_pitched(x3d_backend *b, double *f, const double *host, int hx, int hy,
+                               const int dims[3]);
+int x3d_get_field_data_pitched(x3d_backend *b, double *host, const double *f, int hx, int hy,
+                               const int dims[3]);
 
 /* ---- init_poisson_fft (src/backend/backend.f90:374-389) + poisson_fft_t hooks
  * (src/poisson_fft.f90:45-62).  Single-rank periodic (000) solver:

@@ -1,0 +1,241 @@
+"""CPU tests of the host-side mirror (no GPU): the product's own tdsops
+factory, mesh geometry and wave numbers against the reference fixtures and the
+oracle; allocator / data_loc semantics; the time integrator (restating the
+reference's tests/verification/test_time_integrator.f90) on a numpy backend;
+the neighbour exchange over gloo with two ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import OPNAMES, load_golden, namelist, product_mesh
+
+SINGLE = ["p000_rk3", "c010_rk3", "n111_rk2"]
+
+
+class RecordingBackend:
+    """alloc_tdsops without a device: host factory only"""
+
+    def alloc_tdsops(self, *a, **kw):
+        from x3d2_amd.tdsops import Tdsops
+        return Tdsops(*a, **kw)
+
+
+def product_dirps(mesh, c):
+    from x3d2_amd.common import DIR_X, DIR_Y, DIR_Z
+    from x3d2_amd.solver import allocate_tdsops
+    from x3d2_amd.tdsops import Dirps
+    out = []
+    for d in (DIR_X, DIR_Y, DIR_Z):
+        dp = Dirps(d)
+        allocate_tdsops(dp, RecordingBackend(), mesh, "compact6", c["der2nd"], c["interpl"], "compact6")
+        out.append(dp)
+    return out
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_product_mesh_geometry_vs_reference(name):
+    g = load_golden(name)
+    m = product_mesh(namelist(g))
+    for d, dn in enumerate("xyz"):
+        for k in ("vert_coords", "vert_ds", "vert_ds2", "vert_d2s", "midp_coords", "midp_ds"):
+            assert np.allclose(getattr(m, k)[d], g[f"geo.{k}.{dn}"], rtol=1e-13, atol=1e-14), (k, dn)
+    assert list(m.vert_dims) == [int(v) for v in g["meta.vert_dims"]]
+    assert list(m.cell_dims) == [int(v) for v in g["meta.cell_dims"]]
+    for d, dn in enumerate("xyz"):
+        assert list(m.BCs[d]) == [int(v) for v in g[f"meta.BCs_{dn}"]]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_product_tdsops_factory_vs_reference(name):
+    g = load_golden(name)
+    c = namelist(g)
+    dirps = product_dirps(product_mesh(c), c)
+    for dn, dp in zip("xyz", dirps):
+        for op in OPNAMES:
+            t, pre = getattr(dp, op), f"tdsops.{dn}.{op}"
+            sc = g[pre + ".scalars"]
+            assert (t.n_tds, t.n_rhs, t.move, int(t.periodic)) == tuple(int(x) for x in sc[:4]), pre
+            assert np.allclose([t.alpha, t.a, t.b, t.c], sc[4:8], rtol=1e-15, atol=0), pre
+            assert np.allclose(t.coeffs, g[pre + ".coeffs"], rtol=1e-15, atol=1e-300)
+            assert np.allclose(t.coeffs_s, g[pre + ".coeffs_s"], rtol=1e-15, atol=1e-300)
+            assert np.allclose(t.coeffs_e, g[pre + ".coeffs_e"], rtol=1e-15, atol=1e-300)
+            n = t.n_tds
+            for k in ("dist_fw", "dist_bw", "dist_sa", "dist_sc", "dist_af"):
+                mine, ref = getattr(t, k)[:n].copy(), g[f"{pre}.{k}"][:n].copy()
+                if k == "dist_fw":
+                    mine[1] = ref[1] = 0.0      # never assigned by the reference
+                if k == "dist_bw":
+                    mine[n - 2:] = ref[n - 2:] = 0.0
+                assert np.allclose(mine, ref, rtol=1e-14, atol=1e-300), (pre, k)
+            assert np.allclose(t.stretch, g[pre + ".stretch"], rtol=1e-14)
+            assert np.allclose(t.stretch_correct, g[pre + ".stretch_correct"], rtol=1e-14, atol=1e-15)
+
+
+def test_product_tdsops_known_answers_from_survey():
+    """known-answer values printed from the reference's tdsops_init:
+    n = 64, delta = 2 pi / 64, periodic"""
+    from x3d2_amd.common import BC_DIRICHLET, BC_PERIODIC
+    from x3d2_amd.tdsops import Tdsops
+    d = 6.283185307179586 / 64
+    t = Tdsops(64, d, "first-deriv", "compact6", BC_PERIODIC, BC_PERIODIC)
+    assert abs(t.a - 7.9223793894632353) < 1e-14 and abs(t.b - 2.8294212105225836e-01) < 1e-15
+    assert abs(t.dist_fw[0] - 1.1458980337503153) < 1e-15 and abs(t.dist_fw[2] - 1.125) < 1e-15
+    assert abs(t.dist_sa[0] - 3.8196601125010510e-01) < 1e-15 and abs(t.dist_sa[2] + 1.4589803375031546e-01) < 1e-15
+    assert t.dist_sa[63] < 1e-26
+    t2 = Tdsops(64, d, "second-deriv", "compact6", BC_PERIODIC, BC_PERIODIC)
+    assert abs(t2.a - 1.1318497314518605e+02) < 1e-12 and abs(t2.dist_sa[0] - 1.8826230851010042e-01) < 1e-15
+    t3 = Tdsops(64, d, "first-deriv", "compact6", BC_DIRICHLET, BC_DIRICHLET)
+    assert abs(t3.dist_fw[0] - 2.2360679774997894) < 1e-14 and t3.dist_sa[0] == 0.0
+    assert abs(t3.dist_sa[1] - 2.7639320225002101e-01) < 1e-15
+    t4 = Tdsops(64, d, "stag-deriv", "compact6", BC_PERIODIC, BC_PERIODIC, from_to="v2p")
+    assert (t4.n_rhs, t4.move) == (64, 1) and abs(t4.alpha - 1.4516129032258066e-01) < 1e-16
+
+
+def test_product_factory_matches_oracle_hyperviscous_and_errors():
+    from oracle import x3d_oracle as orc
+    from x3d2_amd.common import BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, X3dError
+    from x3d2_amd.tdsops import Tdsops
+    for bc in ((BC_PERIODIC, BC_PERIODIC), (BC_NEUMANN, BC_DIRICHLET)):
+        a = Tdsops(40, 0.1, "second-deriv", "compact6-hyperviscous", *bc, c_nu=0.22, nu0_nu=63.0, sym=True)
+        o = orc.Tdsops(40, 0.1, "second-deriv", "compact6-hyperviscous", *bc, c_nu=0.22, nu0_nu=63.0, sym=True)
+        for k in ("coeffs", "coeffs_s", "coeffs_e", "dist_sa", "dist_sc", "dist_af"):
+            assert np.allclose(getattr(a, k), getattr(o, k), rtol=1e-14, atol=1e-300), k
+    with pytest.raises(X3dError, match="Dirichlet BC is not supported"):
+        Tdsops(16, 0.1, "interpolate", "classic", BC_DIRICHLET, BC_DIRICHLET, from_to="v2p")
+    with pytest.raises(X3dError, match="operation is not defined"):
+        Tdsops(16, 0.1, "third-deriv", "compact6", BC_PERIODIC, BC_PERIODIC)
+    with pytest.raises(X3dError, match="requires c_nu"):
+        Tdsops(16, 0.1, "second-deriv", "compact6-hyperviscous", BC_PERIODIC, BC_PERIODIC)
+
+
+def test_wave_numbers_vs_reference():
+    from x3d2_amd.poisson_fft import wave_numbers
+    g = load_golden("p000_rk3")
+    c = namelist(g)
+    m = product_mesh(c)
+    dirps = product_dirps(m, c)
+    for d, dn in enumerate("xyz"):
+        s = dirps[d].stagder_v2p
+        n = int(m.global_cell_dims[d])
+        a, b, k, e, k2 = wave_numbers(n, m.L[d], m.d[d], True, s.a, s.b, s.alpha)
+        assert np.allclose(a, g[f"spec.a{dn}"], rtol=1e-14, atol=1e-16)
+        assert np.allclose(b, g[f"spec.b{dn}"], rtol=1e-14, atol=1e-16)
+        assert np.allclose(k2, g[f"spec.k2{dn}_re"], rtol=1e-13, atol=1e-16)
+
+
+def test_allocator_and_data_loc_semantics():
+    """src/allocator.f90:113-162: LIFO pool, get_block resets data_loc unless given"""
+    import torch
+    from x3d2_amd.common import CELL, DIR_X, DIR_Y, NULL_LOC, VERT, move_data_loc
+    from x3d2_amd.field import Allocator
+    al = Allocator(64, torch.device("cpu"))
+    a = al.get_block(DIR_X, VERT)
+    b = al.get_block(DIR_Y)
+    assert (a.dir, a.data_loc, b.dir, b.data_loc) == (DIR_X, VERT, DIR_Y, NULL_LOC)
+    ida = a.id
+    al.release_block(a)
+    c = al.get_block(DIR_Y)
+    assert c.id == ida and c.data_loc == NULL_LOC and c.dir == DIR_Y  # tests/unit/test_allocator.f90
+    assert move_data_loc(VERT, 1, 1) == 10 and move_data_loc(CELL, 3, -1) == 110
+    assert al.get_block_ids() == []
+
+
+class NumpyField:
+    def __init__(self, v):
+        self.data, self.dir, self.data_loc = np.array([v], dtype=float), 1, 0
+
+
+class NumpyBackend:
+    def veccopy(self, dst, src): dst.data = src.data.copy()
+    def vecadd(self, a, x, b, y): y.data = a * x.data + b * y.data
+    def lincomb(self, y, base, c, xs):
+        r = base.data.copy()
+        for ci, xi in zip(c, xs):
+            r = ci * xi.data + r
+        y.data = r
+
+
+class NumpyAllocator:
+    def get_block(self, d, loc=None): return NumpyField(0.0)
+    def release_block(self, f): pass
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("method", ["AB1", "AB2", "AB3", "AB4", "RK1", "RK2", "RK3", "RK4"])
+def test_time_integrator_order(method, fused):
+    """y' = -y through time_intg_t, observed order within +-0.25 of the nominal one
+    (tests/verification/test_time_integrator.f90:166-173); AB start-up uses lower order"""
+    from x3d2_amd.time_integrator import TimeIntegrator
+    errs = []
+    for nstep in (64, 128, 256):
+        ti = TimeIntegrator(NumpyBackend(), NumpyAllocator(), method, nvars=1, fused=fused)
+        y, dt = NumpyField(1.0), 1.0 / nstep
+        for _ in range(nstep):
+            for _ in range(ti.nstage):
+                d = NumpyField(-y.data[0])
+                ti.step([y], [d], dt)
+        errs.append(abs(y.data[0] - np.exp(-1.0)))
+    order = np.log2(errs[0] / errs[1]), np.log2(errs[1] / errs[2])
+    nominal = int(method[2])
+    if method.startswith("AB"):
+        nominal = min(nominal, 2) if nominal > 2 else nominal  # Euler start-up limits AB3/AB4 here
+        assert order[1] > nominal - 0.3
+    else:
+        assert abs(order[1] - nominal) < 0.25, order
+
+
+GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+dist.init_process_group("gloo")
+from x3d2_amd.parallel import Comm
+from x3d2_amd.mesh import Mesh
+c = Comm(); r = c.rank
+m = Mesh((8, 8, 16), (1, 1, 2), (1.0,) * 3, ("periodic",) * 2, ("periodic",) * 2, ("periodic",) * 2, nrank=r)
+prev, nxt = int(m.pprev[2]), int(m.pnext[2])
+ss, se = torch.full((4,), 10.0 * r + 1), torch.full((4,), 10.0 * r + 2)
+rs, re = torch.zeros(4), torch.zeros(4)
+c.sendrecv([(ss, se, rs, re)], prev, nxt)
+o = 1 - r
+assert torch.all(rs == 10.0 * o + 2) and torch.all(re == 10.0 * o + 1), (r, rs, re)   # prev's send_e, next's send_s
+send = torch.arange(6, dtype=torch.float64) + 100 * r
+recv = torch.zeros(5 if r == 0 else 7, dtype=torch.float64)
+# rank 0 sends [2 to self, 4 to 1]; rank 1 sends [3 to 0, 3 to self]
+c.alltoall(send, [2, 4] if r == 0 else [3, 3], recv, [2, 3] if r == 0 else [4, 3], [0, 1])
+exp = [0, 1, 100, 101, 102] if r == 0 else [2, 3, 4, 5, 103, 104, 105]
+assert recv.tolist() == [float(v) for v in exp], (r, recv)
+assert c.allreduce(float(r + 1), "sum") == 3.0 and c.allreduce(float(r), "max") == 1.0
+assert list(m.BCs[2]) == ([0, -1] if r == 0 else [-1, 0]) and m.n_offset[2] == 8 * r and m.vert_dims[2] == 8
+dist.destroy_process_group()
+'''
+
+
+def test_neighbour_exchange_and_alltoall_two_ranks_gloo(tmp_path):
+    """N > 1 path on CPU: world_size 2, gloo"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = tmp_path / "w.py"
+    w.write_text(GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(w), root],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mesh_decomposition_matches_reference_two_ranks():
+    """rank-local extents / BC_HALO faces of the 2-rank reference run"""
+    g = load_golden("p000_rk3_z2")
+    from x3d2_amd.mesh import Mesh
+    for r in range(2):
+        m = Mesh((8, 12, 32), (1, 1, 2), (6.283185307179586,) * 3, ("periodic",) * 2, ("periodic",) * 2,
+                 ("periodic",) * 2, nrank=r)
+        assert list(m.vert_dims) == [8, 12, 16] and list(m.n_offset) == [0, 0, 16 * r]
+        # first rank keeps the global BC at its start, last rank at its end, inner faces are BC_HALO
+        # (src/mesh.f90:116-133)
+        assert list(m.BCs[2]) == ([0, -1] if r == 0 else [-1, 0]) and list(m.BCs[0]) == [0, 0]
+        assert (int(m.pprev[2]), int(m.pnext[2])) == (1 - r, 1 - r)
+    assert [int(v) for v in g["meta.vert_dims"]] == [8, 12, 16]
+    assert [int(v) for v in g["meta.BCs_z"]] == [0, -1]          # rank 0 of the reference run

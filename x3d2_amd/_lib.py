@@ -59,6 +59,8 @@ PROTOTYPES = {
     "x3d_field_set_face_from_field": (I, [VP, VP, VP, c_int_p, D, I, D]),
     "x3d_set_field_data": (I, [VP, VP, c_double_p, c_int_p]),
     "x3d_get_field_data": (I, [VP, c_double_p, VP, c_int_p]),
+    "x3d_set_field_data_pitched": (I, [VP, VP, c_double_p, I, I, c_int_p]),
+    "x3d_get_field_data_pitched": (I, [VP, c_double_p, VP, I, I, c_int_p]),
     "x3d_poisson_create": (I, [VP, ctypes.POINTER(VP), c_int_p] + [c_double_p] * 7),
     "x3d_poisson_destroy": (I, [VP]),
     "x3d_poisson_fft_forward": (I, [VP, VP]),

@@ -503,12 +503,25 @@ extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const do
 // ---------------------------------------------------------------- host <-> field
 extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3])
 {
+    X3D_REQUIRE(dims, "x3d_set_field_data: null argument");
+    return x3d_set_field_data_pitched(b, f, host, dims[0], dims[1], dims);
+}
+
+extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3])
+{
+    X3D_REQUIRE(dims, "x3d_get_field_data: null argument");
+    return x3d_get_field_data_pitched(b, host, f, dims[0], dims[1], dims);
+}
+
+extern "C" int x3d_set_field_data_pitched(x3d_backend *b, double *f, const double *host, int hx, int hy,
+                                          const int dims[3])
+{
     X3D_REQUIRE(b && f && host && dims, "x3d_set_field_data: null argument");
-    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp,
+    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp && dims[0] <= hx && dims[1] <= hy,
                 "x3d_set_field_data: dims exceed the block");
     hipMemcpy3DParms p;
     memset(&p, 0, sizeof p);
-    p.srcPtr = make_hipPitchedPtr((void *)host, sizeof(double) * dims[0], dims[0], dims[1]);
+    p.srcPtr = make_hipPitchedPtr((void *)host, sizeof(double) * hx, hx, hy);
     p.dstPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
     p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
     p.kind = hipMemcpyHostToDevice;
@@ -517,15 +530,16 @@ extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host,
     return 0;
 }
 
-extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3])
+extern "C" int x3d_get_field_data_pitched(x3d_backend *b, double *host, const double *f, int hx, int hy,
+                                          const int dims[3])
 {
     X3D_REQUIRE(b && f && host && dims, "x3d_get_field_data: null argument");
-    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp,
+    X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp && dims[0] <= hx && dims[1] <= hy,
                 "x3d_get_field_data: dims exceed the block");
     hipMemcpy3DParms p;
     memset(&p, 0, sizeof p);
     p.srcPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
-    p.dstPtr = make_hipPitchedPtr((void *)host, sizeof(double) * dims[0], dims[0], dims[1]);
+    p.dstPtr = make_hipPitchedPtr((void *)host, sizeof(double) * hx, hx, hy);
     p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
     p.kind = hipMemcpyDeviceToHost;
     X3D_HIP(hipMemcpy3DAsync(&p, b->stream));
