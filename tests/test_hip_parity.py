@@ -385,3 +385,24 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, tmp_path):
         assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
     assert abs(rows[-1][1] - rrows[-1][1]) < 1e-12 * abs(rrows[-1][1])
     assert rows[-1][2] < 1e-11
+
+
+def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
+    """fortran/_build/xcompact_hip = the reference's own solver.f90 / cases /
+    monitoring (compiled from /root/reference in the build container) linked
+    with the hip_backend_t shim over the C ABI.  TGV 64^3, RK3, FFT Poisson:
+    monitoring.csv must reproduce the reference trace of SURVEY.md 8c."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "xcompact_hip")
+    if not os.path.exists(exe):
+        pytest.skip("shim binary not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, os.path.join(root, "fortran", "tgv64.x3d")], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = np.loadtxt(tmp_path / "monitoring.csv", delimiter=",", comments="#")
+    assert abs(rows[0, 1] - 3.749999996799e-01) < 2e-13
+    assert abs(rows[1, 1] - 3.749898433321e-01) < 2e-13
+    assert abs(rows[2, 1] - 3.749874980813e-01) < 2e-13
+    assert rows[:, 2].max() < 1e-13
