@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked):
+kernel-trace stats of the bench command, PMC FETCH/WRITE per kernel with the
+gfx950 correction (FETCH_SIZE counts 64 B per 128-B request -> x2; calibrated
+here on k_tds_fwd, which reads exactly one 1 GiB field), and traffic.json that
+bench.py reads for roofline.traffic.
+
+    python tools_summarize.py <prof_tag> <pmc_tag> <round>
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+prof_tag, pmc_tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+stats = glob.glob(f"gpurun_out/prof_{prof_tag}/*/*kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
+pmc = json.load(open(f"gpurun_out/pmc_{pmc_tag}_summary.json"))
+GiB = 1024.0 ** 3
+rows = []
+for k, v in pmc.items():
+    fetch = v.get("FETCH_SIZE", 0.0) * 1024 * 2     # KB -> B, x2 (MI355X_MICROARCH.md, HBM section)
+    write = v.get("WRITE_SIZE", 0.0) * 1024
+    rows.append((k, v.get("n", 0), fetch, write))
+rows.sort(key=lambda r: -(r[2] + r[3]))
+with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as f:
+    f.write("kernel,launches,fetch_bytes_corrected,write_bytes,total_GiB\n")
+    for k, n, fe, wr in rows:
+        f.write(f"\"{k}\",{n},{fe:.0f},{wr:.0f},{(fe + wr) / GiB:.3f}\n")
+
+
+def avg(prefix):
+    sel = [(n, fe + wr) for k, n, fe, wr in rows if prefix in k]
+    tot = sum(n for n, _ in sel)
+    return sum(n * b for n, b in sel) / tot if tot else 0.0
+
+
+comp = avg("transeq_fwd") + avg("transeq_bwd")   # matches k_transeq_* and k_xtranseq_*
+calib = [fe for k, n, fe, wr in rows if k.endswith("k_tds_fwd<false, false>")]
+json.dump({"n": 512, "round": rnd, "transeq_component_bytes_per_launch": comp,
+           "calibration_k_tds_fwd_fetch_GiB": calib[0] / GiB if calib else None,
+           "note": "HBM bytes per (k_*transeq_fwd + k_*transeq_bwd) pair from rocprofv3 --pmc FETCH_SIZE / "
+                   "WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md"},
+          open("profiles/traffic.json", "w"), indent=1)
+print("component traffic GiB:", comp / GiB)
