@@ -77,11 +77,14 @@ struct ProfScope {
 // indexed by the 1-based row j (entry 0 unused).
 struct TdsTab {
     int n_tds, n_rhs;
+    int chunk;          // rows per wave of the on-chip chunk-parallel solve (32 or 64)
     const double *F;    // forward multiplier  (rows 1,2: dist_af; >=3: dist_fw)
     const double *A;    // forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
     const double *W;    // weights of d_k in du_2 (backward chain), see tdsops.hip
     const double *Bw;   // dist_bw
     const double *Sa, *Sc, *St, *Stc;  // dist_sa, dist_sc, stretch, stretch_correct
+    const double *PF;   // chunk-local forward carry multipliers  (onchip.hip), chunk = X3D_CHUNK rows
+    const double *QB;   // chunk-local backward carry multipliers
     const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
     double last_r;      // dist_fw(1)
     double bw1;         // dist_bw(1)

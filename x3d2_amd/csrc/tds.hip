@@ -34,10 +34,10 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     X3D_REQUIRE(n_rhs == n_tds || n_rhs == n_tds + 1, "x3d_tdsops_create: n_rhs must be n_tds or n_tds+1");
     X3D_REQUIRE(n_tds >= 8, "x3d_tdsops_create: n_tds=%d too small (the 4+4 boundary rows need n>=8)", n_tds);
     const int n = n_tds, nr = n_rhs, L = nr + 2;  // tables are 1-based, one spare entry
-    // layout: F A W Bw Sa Sc St Stc (8 tables of L) + 81 stencil coefficients
-    std::vector<double> h((size_t)8 * L + 81, 0.0);
+    // layout: F A W Bw Sa Sc St Stc PF QB (10 tables of L) + 81 stencil coefficients
+    std::vector<double> h((size_t)10 * L + 81, 0.0);
     double *F = &h[0], *A = &h[L], *W = &h[2 * L], *Bw = &h[3 * L], *Sa = &h[4 * L], *Sc = &h[5 * L],
-           *St = &h[6 * L], *Stc = &h[7 * L], *Cs = &h[8 * L];
+           *St = &h[6 * L], *Stc = &h[7 * L], *PF = &h[8 * L], *QB = &h[9 * L], *Cs = &h[10 * L];
     for (int j = 1; j <= nr; j++) {
         const bool real_row = j <= n;  // row n_tds+1 of a v2p operator is junk in the reference too
         if (j <= 2) {                  // distributed.f90:45,56: du = rhs*faf(j)
@@ -61,6 +61,20 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // with du_{n-1} = d_{n-1} untouched by the backward pass
     W[2] = 1.0;
     for (int k = 2; k <= n - 2; k++) W[k + 1] = W[k] * (-dist_bw[k - 1]);
+    // chunk-parallel form (onchip.hip): e_j = ehat_j + PF_j * e_{s-1}, X_j = Xhat_j + QB_j * X_{t+1}
+    // for a chunk [s, t] of `chunk` rows, with g_l = -F_l A_l and h_l = -bw_l (2 <= l <= n-2, else 0)
+    const int chunk = nr <= 256 ? 32 : 64;
+    for (int s0 = 1; s0 <= nr; s0 += chunk) {
+        const int t0 = s0 + chunk - 1 < nr ? s0 + chunk - 1 : nr;
+        double pr = 1.0;
+        for (int j = s0; j <= t0; j++) { pr *= -F[j] * A[j]; PF[j] = pr; }
+        pr = 1.0;
+        for (int j = t0; j >= s0; j--) {
+            const double hj = (j >= 2 && j <= n - 2) ? -dist_bw[j - 1] : 0.0;
+            pr *= hj;
+            QB[j] = pr;
+        }
+    }
     memcpy(Cs, coeffs_s, sizeof(double) * 36);
     memcpy(Cs + 36, coeffs_e, sizeof(double) * 36);
     memcpy(Cs + 72, coeffs, sizeof(double) * 9);
@@ -70,10 +84,11 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * h.size()));
     X3D_HIP(hipMemcpy(t->dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
     TdsTab &tb = t->tab;
-    tb.n_tds = n; tb.n_rhs = nr;
+    tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
     tb.F = t->dev; tb.A = t->dev + L; tb.W = t->dev + 2 * L; tb.Bw = t->dev + 3 * L;
     tb.Sa = t->dev + 4 * L; tb.Sc = t->dev + 5 * L; tb.St = t->dev + 6 * L; tb.Stc = t->dev + 7 * L;
-    tb.Cs = t->dev + 8 * L;
+    tb.PF = t->dev + 8 * L; tb.QB = t->dev + 9 * L;
+    tb.Cs = t->dev + 10 * L;
     tb.last_r = dist_fw[0];
     tb.bw1 = dist_bw[0];
     tb.sa1 = dist_sa[0];
@@ -449,6 +464,17 @@ static int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, cons
 static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
                                    double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
                                    int acc);
+int x3d_onchip_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
+                   double scale);  // onchip.hip
+static bool use_onchip()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_NO_ONCHIP");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
 static bool use_fused_kernels()
 {
     static int mode = -1;
@@ -533,6 +559,7 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t, accumulate, scale);
+    if (use_onchip() && t->n_rhs <= 8 * t->tab.chunk) return x3d_onchip_tds(b, du, u, t, dir, accumulate, scale);
     if (use_fused_kernels()) return x3d_fused_tds_local(b, du, u, t, dir, accumulate, scale);
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
