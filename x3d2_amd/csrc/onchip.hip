@@ -17,7 +17,7 @@
 // re-association only (~1e-16 relative).
 #include "common.h"
 
-#define MAXC 8   // waves per workgroup: 512 threads leave 256 VGPRs per lane for the register-resident chunk
+#define MAXC 16  // waves per workgroup (1024 threads -> 128 VGPRs per lane; the 32-row chunk needs ~95)
 
 __device__ __forceinline__ double ext_row_c(const double *__restrict__ u, long base, long rs, int jj, int nr,
                                             int n_wrap)

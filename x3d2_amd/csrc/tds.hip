@@ -63,7 +63,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     for (int k = 2; k <= n - 2; k++) W[k + 1] = W[k] * (-dist_bw[k - 1]);
     // chunk-parallel form (onchip.hip): e_j = ehat_j + PF_j * e_{s-1}, X_j = Xhat_j + QB_j * X_{t+1}
     // for a chunk [s, t] of `chunk` rows, with g_l = -F_l A_l and h_l = -bw_l (2 <= l <= n-2, else 0)
-    const int chunk = nr <= 256 ? 32 : 64;
+    const int chunk = nr <= 512 ? 32 : 64;
     for (int s0 = 1; s0 <= nr; s0 += chunk) {
         const int t0 = s0 + chunk - 1 < nr ? s0 + chunk - 1 : nr;
         double pr = 1.0;
@@ -559,7 +559,7 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t, accumulate, scale);
-    if (use_onchip() && t->n_rhs <= 8 * t->tab.chunk) return x3d_onchip_tds(b, du, u, t, dir, accumulate, scale);
+    if (use_onchip() && t->n_rhs <= 512) return x3d_onchip_tds(b, du, u, t, dir, accumulate, scale);
     if (use_fused_kernels()) return x3d_fused_tds_local(b, du, u, t, dir, accumulate, scale);
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
