@@ -78,19 +78,31 @@ struct ProfScope {
 struct TdsTab {
     int n_tds, n_rhs;
     int chunk;          // rows per wave of the on-chip chunk-parallel solve (32 or 64)
-    const double *F;    // forward multiplier  (rows 1,2: dist_af; >=3: dist_fw)
-    const double *A;    // forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
-    const double *W;    // weights of d_k in du_2 (backward chain), see tdsops.hip
-    const double *Bw;   // dist_bw
-    const double *Sa, *Sc, *St, *Stc;  // dist_sa, dist_sc, stretch, stretch_correct
-    const double *PF;   // chunk-local forward carry multipliers  (onchip.hip), chunk = X3D_CHUNK rows
-    const double *QB;   // chunk-local backward carry multipliers
+    // Row tables are interleaved so that one wide scalar load fetches everything a
+    // sweep needs for row j (1-based; record 0 unused):
+    //   RF[4*j + {0,1,2,3}] = F, A, W, PF     forward sweep
+    //   RB[8*j + {0..5}]    = Bw, Sa, Sc, St, Stc, QB   backward sweep / substitution
+    // F  forward multiplier  (rows 1,2: dist_af; >=3: dist_fw)
+    // A  forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
+    // W  weights of d_k in du_2 (backward chain), see tds.hip
+    // PF/QB chunk-local carry multipliers (onchip.hip)
+    const double *RF, *RB;
     const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
     double last_r;      // dist_fw(1)
     double bw1;         // dist_bw(1)
     double rs_s, rs_e;  // 1/(1 - sa(1)^2), 1/(1 - sc(n)^2)
     double sa1, scn;
 };
+#define T_F(t, j) ((t).RF[4 * (j) + 0])
+#define T_A(t, j) ((t).RF[4 * (j) + 1])
+#define T_W(t, j) ((t).RF[4 * (j) + 2])
+#define T_PF(t, j) ((t).RF[4 * (j) + 3])
+#define T_BW(t, j) ((t).RB[8 * (j) + 0])
+#define T_SA(t, j) ((t).RB[8 * (j) + 1])
+#define T_SC(t, j) ((t).RB[8 * (j) + 2])
+#define T_ST(t, j) ((t).RB[8 * (j) + 3])
+#define T_STC(t, j) ((t).RB[8 * (j) + 4])
+#define T_QB(t, j) ((t).RB[8 * (j) + 5])
 
 struct x3d_tdsops {
     x3d_backend *b;

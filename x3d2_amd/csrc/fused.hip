@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64)
         for (int o = 0; o < NOPS; o++) {
             const TdsTab &t = T.t[o];
             const double acc = dot9f(stencil_row_f(t.Cs, j, nr), (NOPS == 3 && o == 1) ? wp : wu);
-            e[o] = t.F[j] * (acc - t.A[j] * prev[o]);
+            e[o] = T_F(t, j) * (acc - T_A(t, j) * prev[o]);
             prev[o] = e[o];
         }
     };
@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(64)
         double r;
         if (NOPS == 1) {
             const TdsTab &t = T.t[0];
-            if (is_last) r = xe[0] * t.St[j];
-            else if (is_first) r = xs[0] * t.St[j];
-            else r = (c[0] - t.Sa[j] * xs[0] - t.Sc[j] * xe[0]) * t.St[j];
+            if (is_last) r = xe[0] * T_ST(t, j);
+            else if (is_first) r = xs[0] * T_ST(t, j);
+            else r = (c[0] - T_SA(t, j) * xs[0] - T_SC(t, j) * xe[0]) * T_ST(t, j);
             r = ACC ? out[o_] + scale * r : r;
         } else {
             const TdsTab &a = T.t[0], &b2 = T.t[NOPS > 1 ? 1 : 0], &d2 = T.t[NOPS > 2 ? 2 : 0];
@@ -99,12 +99,12 @@ __global__ void __launch_bounds__(64)
             if (is_last || is_first) {  // distributed.f90:304-311, 328-335
                 const double s1 = is_last ? xe[0] : xs[0], s2 = is_last ? xe[i1] : xs[i1],
                              s3 = is_last ? xe[i2] : xs[i2];
-                r = -0.5 * (v * s1 * a.St[j] + s2 * b2.St[j]) + nu * (s3 * d2.St[j] + s1 * a.St[j] * d2.Stc[j]);
+                r = -0.5 * (v * s1 * T_ST(a, j) + s2 * T_ST(b2, j)) + nu * (s3 * T_ST(d2, j) + s1 * T_ST(a, j) * T_STC(d2, j));
             } else {  // :315-324
-                const double temp_du = a.St[j] * (c[0] - a.Sa[j] * xs[0] - a.Sc[j] * xe[0]);
-                const double temp_dud = b2.St[j] * (c[i1] - b2.Sa[j] * xs[i1] - b2.Sc[j] * xe[i1]);
+                const double temp_du = T_ST(a, j) * (c[0] - T_SA(a, j) * xs[0] - T_SC(a, j) * xe[0]);
+                const double temp_dud = T_ST(b2, j) * (c[i1] - T_SA(b2, j) * xs[i1] - T_SC(b2, j) * xe[i1]);
                 const double temp_d2u =
-                    d2.St[j] * (c[i2] - d2.Sa[j] * xs[i2] - d2.Sc[j] * xe[i2]) + temp_du * d2.Stc[j];
+                    T_ST(d2, j) * (c[i2] - T_SA(d2, j) * xs[i2] - T_SC(d2, j) * xe[i2]) + temp_du * T_STC(d2, j);
                 r = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;
             }
             r = ACC ? out[o_] + r : r;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64)
                 double c[NOPS];
 #pragma unroll
                 for (int o = 0; o < NOPS; o++)  // rows n, n-1 keep their forward values (:154: j = n-2..2)
-                    c[o] = (j >= n - 1) ? dl[q][o] : dl[q][o] - T.t[o].Bw[j] * nxt[o];
+                    c[o] = (j >= n - 1) ? dl[q][o] : dl[q][o] - T_BW(T.t[o], j) * nxt[o];
                 emit(j, c, j == 1, j == n);
 #pragma unroll
                 for (int o = 0; o < NOPS; o++) nxt[o] = c[o];

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64 * MAXC)
             else
                 acc = cs[0] * w[0] + cs[1] * w[1] + cs[2] * w[2] + cs[3] * w[3] + cs[4] * w[4] + cs[5] * w[5] +
                       cs[6] * w[6] + cs[7] * w[7] + cs[8] * w[8];
-            e = t.F[j] * (acc - t.A[j] * prev);
+            e = T_F(t, j) * (acc - T_A(t, j) * prev);
             prev = e;
         }
         const double feed = (q + 5 < M) ? x[(q + 5) % M] : hr[(q + 5 - M) & 3];
@@ -91,15 +91,15 @@ __global__ void __launch_bounds__(64 * MAXC)
         double carry = 0.0;
         for (int cc = 0; cc < c; cc++) {
             const int tt = (cc + 1) * M < nr ? (cc + 1) * M : nr;
-            carry = ends[cc][lane] + t.PF[tt] * carry;
+            carry = ends[cc][lane] + T_PF(t, tt) * carry;
         }
         double nxt = 0.0;
 #pragma unroll
         for (int q = M - 1; q >= 0; q--) {
             const int j = s + q;
             if (j <= n) {
-                const double e = x[q] + t.PF[j] * carry;
-                const double hj = (j >= 2 && j <= n - 2) ? -t.Bw[j] : 0.0;  // rows 1, n-1, n: no update
+                const double e = x[q] + T_PF(t, j) * carry;
+                const double hj = (j >= 2 && j <= n - 2) ? -T_BW(t, j) : 0.0;  // rows 1, n-1, n: no update
                 x[q] = e + hj * nxt;
                 nxt = x[q];
             }
@@ -114,12 +114,12 @@ __global__ void __launch_bounds__(64 * MAXC)
         double carry = 0.0;
         for (int cc = C - 1; cc > c; cc--) {
             const int ss = cc * M + 1;
-            if (ss <= n) carry = starts[cc][lane] + t.QB[ss] * carry;
+            if (ss <= n) carry = starts[cc][lane] + T_QB(t, ss) * carry;
         }
 #pragma unroll
         for (int q = 0; q < M; q++) {
             const int j = s + q;
-            if (j <= n) x[q] = x[q] + t.QB[j] * carry;
+            if (j <= n) x[q] = x[q] + T_QB(t, j) * carry;
             if (j == n) misc[1][lane] = x[q];
             if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
@@ -142,9 +142,9 @@ __global__ void __launch_bounds__(64 * MAXC)
         for (int k = 0; k < 8; k++) {
             const int q = q0 + k, j = s + q;
             if (j <= n) {
-                double r = (x[q] - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];  // :215-222
-                r = (j == 1) ? du_s * t.St[j] : r;                               // :209-213
-                r = (j == n) ? du_e * t.St[j] : r;                               // :224-228
+                double r = (x[q] - T_SA(t, j) * du_s - T_SC(t, j) * du_e) * T_ST(t, j);  // :215-222
+                r = (j == 1) ? du_s * T_ST(t, j) : r;                               // :209-213
+                r = (j == n) ? du_e * T_ST(t, j) : r;                               // :224-228
                 if (active) du[base + (long)(j - 1) * rs] = ACC ? old[k] + scale * r : r;
             }
         }

@@ -81,14 +81,21 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
 
     x3d_tdsops *t = new x3d_tdsops();
     t->b = b; t->n_tds = n; t->n_rhs = nr; t->move = move; t->periodic = periodic;
-    X3D_HIP(hipMalloc(&t->dev, sizeof(double) * h.size()));
-    X3D_HIP(hipMemcpy(t->dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    // device image: interleaved row records (common.h) so that one wide scalar
+    // load serves a row: RF[4j..] = F A W PF ; RB[8j..] = Bw Sa Sc St Stc QB - - ; then Cs
+    std::vector<double> img((size_t)12 * L + 81, 0.0);
+    for (int j = 0; j < L; j++) {
+        double *rf = &img[(size_t)4 * j], *rb = &img[(size_t)4 * L + (size_t)8 * j];
+        rf[0] = F[j]; rf[1] = A[j]; rf[2] = W[j]; rf[3] = PF[j];
+        rb[0] = Bw[j]; rb[1] = Sa[j]; rb[2] = Sc[j]; rb[3] = St[j]; rb[4] = Stc[j]; rb[5] = QB[j];
+    }
+    memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
+    X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
+    X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
     TdsTab &tb = t->tab;
     tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
-    tb.F = t->dev; tb.A = t->dev + L; tb.W = t->dev + 2 * L; tb.Bw = t->dev + 3 * L;
-    tb.Sa = t->dev + 4 * L; tb.Sc = t->dev + 5 * L; tb.St = t->dev + 6 * L; tb.Stc = t->dev + 7 * L;
-    tb.PF = t->dev + 8 * L; tb.QB = t->dev + 9 * L;
-    tb.Cs = t->dev + 10 * L;
+    tb.RF = t->dev; tb.RB = t->dev + (size_t)4 * L;
+    tb.Cs = t->dev + (size_t)12 * L;
     tb.last_r = dist_fw[0];
     tb.bw1 = dist_bw[0];
     tb.sa1 = dist_sa[0];
@@ -176,14 +183,14 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
 
     auto row = [&](int j, const double *__restrict__ c, double wnext) {
         const double acc = dot9(c, w);
-        const double dj = t.F[j] * (acc - t.A[j] * dprev);
+        const double dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
         if (j <= n) {
             if (CKPT) {
                 if (j % X3D_CK == 0) d[(long)(j / X3D_CK) * g.np + p] = dj;
             } else {
                 d[base + (long)(j - 1) * rs] = dj;
             }
-            S += t.W[j] * dj;
+            S += T_W(t, j) * dj;
             if (j == 1) d1 = dj;
             if (j == n) dn = dj;
         }
@@ -243,12 +250,12 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const d
     const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
     {
         const long o = base + (long)(n - 1) * rs;
-        put(o, du_e * t.St[n], ACC ? du[o] : 0.0);  // :224-228
+        put(o, du_e * T_ST(t, n), ACC ? du[o] : 0.0);  // :224-228
     }
     double nxt = d[base + (long)(n - 2) * rs];  // row n-1: no backward update
     {
         const long o = base + (long)(n - 2) * rs;
-        put(o, (nxt - t.Sa[n - 1] * du_s - t.Sc[n - 1] * du_e) * t.St[n - 1], ACC ? du[o] : 0.0);
+        put(o, (nxt - T_SA(t, n - 1) * du_s - T_SC(t, n - 1) * du_e) * T_ST(t, n - 1), ACC ? du[o] : 0.0);
     }
     int j = n - 2;
     for (; j - UB + 1 >= 2; j -= UB) {
@@ -262,18 +269,18 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const d
 #pragma unroll
         for (int k = 0; k < UB; k++) {
             const int jj = j - k;
-            const double cur = dv[k] - t.Bw[jj] * nxt;                                      // :154-160
-            put(base + (long)(jj - 1) * rs, (cur - t.Sa[jj] * du_s - t.Sc[jj] * du_e) * t.St[jj], ov[k]);  // :215-222
+            const double cur = dv[k] - T_BW(t, jj) * nxt;                                      // :154-160
+            put(base + (long)(jj - 1) * rs, (cur - T_SA(t, jj) * du_s - T_SC(t, jj) * du_e) * T_ST(t, jj), ov[k]);  // :215-222
             nxt = cur;
         }
     }
     for (; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
-        const double cur = d[o] - t.Bw[j] * nxt;
-        put(o, (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j], ACC ? du[o] : 0.0);
+        const double cur = d[o] - T_BW(t, j) * nxt;
+        put(o, (cur - T_SA(t, j) * du_s - T_SC(t, j) * du_e) * T_ST(t, j), ACC ? du[o] : 0.0);
         nxt = cur;
     }
-    put(base, du_s * t.St[1], ACC ? du[base] : 0.0);  // :209-213
+    put(base, du_s * T_ST(t, 1), ACC ? du[base] : 0.0);  // :209-213
 }
 
 // forward sweep of one transport-equation component: three operators share
@@ -302,9 +309,9 @@ __global__ void __launch_bounds__(64)
     auto row = [&](int j, const double *__restrict__ c1, const double *__restrict__ c2,
                    const double *__restrict__ c3, double un, double pn) {
         const double a1 = dot9(c1, wu), a3 = dot9(c3, wu), a2 = dot9(c2, wp);
-        const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
-        const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
-        const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
+        const double e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
+        const double e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
+        const double e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
         if (CKPT) {
             if (j % X3D_CK == 0) {  // compact [j/CK][op][pencil] in d_du
                 const long o = (long)(j / X3D_CK) * 3 * g.np + p;
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(64)
             const long o = base + (long)(j - 1) * rs;
             d_du[o] = e1; d_dud[o] = e2; d_d2u[o] = e3;
         }
-        S1 += t1.W[j] * e1; S2 += t2.W[j] * e2; S3 += t3.W[j] * e3;
+        S1 += T_W(t1, j) * e1; S2 += T_W(t2, j) * e2; S3 += T_W(t3, j) * e3;
         if (j == 1) { f1 = e1; f2 = e2; f3 = e3; }
         if (j == n) { l1 = e1; l2 = e2; l3 = e3; }
         p1 = e1; p2 = e2; p3 = e3;
@@ -390,13 +397,13 @@ __global__ void __launch_bounds__(64)
     const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
     const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
     // row n (:328-335)
-    put(on, -0.5 * (cv[on] * du_e * t1.St[n] + dud_e * t2.St[n]) +
-                nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]), ACC ? rhs[on] : 0.0);
+    put(on, -0.5 * (cv[on] * du_e * T_ST(t1, n) + dud_e * T_ST(t2, n)) +
+                nu * (d2u_e * T_ST(t3, n) + du_e * T_ST(t1, n) * T_STC(t3, n)), ACC ? rhs[on] : 0.0);
 
     auto emit = [&](int j, double c1, double c2, double c3, double v, double old) {
-        const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
-        const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
-        const double temp_d2u = t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
+        const double temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
+        const double temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
+        const double temp_d2u = T_ST(t3, j) * (c3 - T_SA(t3, j) * d2u_s - T_SC(t3, j) * d2u_e) + temp_du * T_STC(t3, j);
         put(base + (long)(j - 1) * rs, -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u, old);  // :315-324
     };
     {
@@ -416,24 +423,24 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int k = 0; k < UT; k++) {
             const int jj = j - k;
-            const double c1 = a1[k] - t1.Bw[jj] * n1;
-            const double c2 = a2[k] - t2.Bw[jj] * n2;
-            const double c3 = a3[k] - t3.Bw[jj] * n3;
+            const double c1 = a1[k] - T_BW(t1, jj) * n1;
+            const double c2 = a2[k] - T_BW(t2, jj) * n2;
+            const double c3 = a3[k] - T_BW(t3, jj) * n3;
             emit(jj, c1, c2, c3, vv[k], ov[k]);
             n1 = c1; n2 = c2; n3 = c3;
         }
     }
     for (; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
-        const double c1 = d_du[o] - t1.Bw[j] * n1;
-        const double c2 = d_dud[o] - t2.Bw[j] * n2;
-        const double c3 = d_d2u[o] - t3.Bw[j] * n3;
+        const double c1 = d_du[o] - T_BW(t1, j) * n1;
+        const double c2 = d_dud[o] - T_BW(t2, j) * n2;
+        const double c3 = d_d2u[o] - T_BW(t3, j) * n3;
         emit(j, c1, c2, c3, cv[o], ACC ? rhs[o] : 0.0);
         n1 = c1; n2 = c2; n3 = c3;
     }
     // row 1 (:304-311)
-    put(base, -0.5 * (cv[base] * du_s * t1.St[1] + dud_s * t2.St[1]) +
-                  nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]), ACC ? rhs[base] : 0.0);
+    put(base, -0.5 * (cv[base] * du_s * T_ST(t1, 1) + dud_s * T_ST(t2, 1)) +
+                  nu * (d2u_s * T_ST(t3, 1) + du_s * T_ST(t1, 1) * T_STC(t3, 1)), ACC ? rhs[base] : 0.0);
 }
 
 // copy_into_buffers (src/backend/omp/backend.f90:714-737): rows 1..4 and n-3..n

@@ -143,10 +143,10 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
             const int j = e - 4;
             if (j >= 1 && j <= nr) {
                 const double acc = (j > 4 && j <= nr - 4) ? dot9x(cb, w) : dot9x(stencil_row_x(t.Cs, j, nr), w);
-                const double dj = t.F[j] * (acc - t.A[j] * dprev);
+                const double dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
                 if (j <= n) {
                     dw[(long)(j - 1) * 64] = dj;
-                    S += t.W[j] * dj;
+                    S += T_W(t, j) * dj;
                     if (j == 1) d1 = dj;
                     if (j == n) dn = dj;
                 }
@@ -195,10 +195,10 @@ __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const 
             const int j = tI * TW + c + 1;
             double out = 0.0;
             if (j <= n) {
-                const double cur = (j >= n - 1) ? dv[c] : dv[c] - t.Bw[j] * nxt;
-                out = (cur - t.Sa[j] * du_s - t.Sc[j] * du_e) * t.St[j];
-                out = (j == n) ? du_e * t.St[j] : out;
-                out = (j == 1) ? du_s * t.St[j] : out;
+                const double cur = (j >= n - 1) ? dv[c] : dv[c] - T_BW(t, j) * nxt;
+                out = (cur - T_SA(t, j) * du_s - T_SC(t, j) * du_e) * T_ST(t, j);
+                out = (j == n) ? du_e * T_ST(t, j) : out;
+                out = (j == 1) ? du_s * T_ST(t, j) : out;
                 nxt = cur;
             }
             lds[c * TP + lane] = out;
@@ -278,12 +278,12 @@ __global__ void __launch_bounds__(64)
                 const double a1 = bulk ? dot9x(b1, wu) : dot9x(stencil_row_x(t1.Cs, j, n), wu);
                 const double a3 = bulk ? dot9x(b3, wu) : dot9x(stencil_row_x(t3.Cs, j, n), wu);
                 const double a2 = bulk ? dot9x(b2, wp) : dot9x(stencil_row_x(t2.Cs, j, n), wp);
-                const double e1 = t1.F[j] * (a1 - t1.A[j] * p1);
-                const double e2 = t2.F[j] * (a2 - t2.A[j] * p2);
-                const double e3 = t3.F[j] * (a3 - t3.A[j] * p3);
+                const double e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
+                const double e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
+                const double e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
                 const long o = wo + (long)(j - 1) * 64;
                 d1a[o] = e1; d2a[o] = e2; d3a[o] = e3;
-                S1 += t1.W[j] * e1; S2 += t2.W[j] * e2; S3 += t3.W[j] * e3;
+                S1 += T_W(t1, j) * e1; S2 += T_W(t2, j) * e2; S3 += T_W(t3, j) * e3;
                 if (j == 1) { f1 = e1; f2 = e2; f3 = e3; }
                 if (j == n) { l1 = e1; l2 = e2; l3 = e3; }
                 p1 = e1; p2 = e2; p3 = e3;
@@ -351,20 +351,20 @@ __global__ void __launch_bounds__(64)
                 if (j <= n) {
                     const double v = lc[c * TP + lane];
                     const bool keep = j >= n - 1;  // rows n, n-1: forward values (distributed.f90:154)
-                    const double c1 = keep ? a1[k] : a1[k] - t1.Bw[j] * n1;
-                    const double c2 = keep ? a2[k] : a2[k] - t2.Bw[j] * n2;
-                    const double c3 = keep ? a3[k] : a3[k] - t3.Bw[j] * n3;
-                    const double temp_du = t1.St[j] * (c1 - t1.Sa[j] * du_s - t1.Sc[j] * du_e);
-                    const double temp_dud = t2.St[j] * (c2 - t2.Sa[j] * dud_s - t2.Sc[j] * dud_e);
+                    const double c1 = keep ? a1[k] : a1[k] - T_BW(t1, j) * n1;
+                    const double c2 = keep ? a2[k] : a2[k] - T_BW(t2, j) * n2;
+                    const double c3 = keep ? a3[k] : a3[k] - T_BW(t3, j) * n3;
+                    const double temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
+                    const double temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
                     const double temp_d2u =
-                        t3.St[j] * (c3 - t3.Sa[j] * d2u_s - t3.Sc[j] * d2u_e) + temp_du * t3.Stc[j];
+                        T_ST(t3, j) * (c3 - T_SA(t3, j) * d2u_s - T_SC(t3, j) * d2u_e) + temp_du * T_STC(t3, j);
                     out = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;
                     if (j == n)
-                        out = -0.5 * (v * du_e * t1.St[n] + dud_e * t2.St[n]) +
-                              nu * (d2u_e * t3.St[n] + du_e * t1.St[n] * t3.Stc[n]);
+                        out = -0.5 * (v * du_e * T_ST(t1, n) + dud_e * T_ST(t2, n)) +
+                              nu * (d2u_e * T_ST(t3, n) + du_e * T_ST(t1, n) * T_STC(t3, n));
                     if (j == 1)
-                        out = -0.5 * (v * du_s * t1.St[1] + dud_s * t2.St[1]) +
-                              nu * (d2u_s * t3.St[1] + du_s * t1.St[1] * t3.Stc[1]);
+                        out = -0.5 * (v * du_s * T_ST(t1, 1) + dud_s * T_ST(t2, 1)) +
+                              nu * (d2u_s * T_ST(t3, 1) + du_s * T_ST(t1, 1) * T_STC(t3, 1));
                     n1 = c1; n2 = c2; n3 = c3;
                 }
                 lo[c * TP + lane] = out;
