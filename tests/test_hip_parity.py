@@ -406,3 +406,17 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
     assert abs(rows[1, 1] - 3.749898433321e-01) < 2e-13
     assert abs(rows[2, 1] - 3.749874980813e-01) < 2e-13
     assert rows[:, 2].max() < 1e-13
+
+
+@pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC"])
+def test_optional_kernel_families_pass_the_same_parity_tests(env):
+    """the opt-in kernel families (single-pass on-chip tds_solve, checkpoint /
+    block-recompute sweeps, generic x-direction kernels) must give the same results"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **{env: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
+                        "tds_solve_all or transeq_div_grad or fused_transeq_and_time"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

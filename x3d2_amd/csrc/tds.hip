@@ -477,8 +477,11 @@ static bool use_onchip()
 {
     static int mode = -1;
     if (mode < 0) {
-        const char *e = getenv("X3D_NO_ONCHIP");
-        mode = (e && e[0] == '1') ? 0 : 1;
+        // opt-in: the single-pass on-chip solve halves the HBM traffic of tds_solve but
+        // is issue-bound on MI355X (one 16-wave workgroup per CU) and only matches the
+        // two-sweep kernels' time (profiles/README.md)
+        const char *e = getenv("X3D_ONCHIP");
+        mode = (e && e[0] == '1') ? 1 : 0;
     }
     return mode == 1;
 }
