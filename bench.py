@@ -37,8 +37,7 @@ def cpu_baseline(n, steps):
     """oracle (CPU restatement of the reference OpenMP backend, SZ=16 layout)
     timed on this host's cores: TGV n^3 RK3 full step incl. FFT Poisson."""
     from oracle import x3d_oracle as orc
-    cores = os.cpu_count() or 1
-    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    threads = int(os.environ["OMP_NUM_THREADS"])
     twopi = 6.283185307179586
     mesh = orc.Mesh([n] * 3, [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
     s = orc.Solver(mesh, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT")
@@ -68,6 +67,16 @@ def main():
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     args = ap.parse_args()
+
+    # the CPU baseline uses the physical cores of the host (set before libgomp starts)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except ImportError:
+        phys = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(phys))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
     import torch
     import torch.distributed as dist
@@ -154,7 +163,12 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_f, "per_direction": per_dir,
-                "share_of_step": (ms_f + ms_b) / (elapsed * 1e3)}
+                "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
+                # SURVEY.md 8d headline convention: the reference's derivative pass of one sub-step
+                # (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time our
+                # transeq phase takes (reorders and sums are folded into the kernels here)
+                "tdsops_pass_GBs_survey_convention":
+                    432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
 
     out = {
         "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step",
