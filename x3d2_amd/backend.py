@@ -158,8 +158,7 @@ class HipBackend:
             _lib.check(self.lib.x3d_pack_halos(self.h, ss.data_ptr(), se.data_ptr(), f.ptr, n, direction))
             pairs.append((ss, se, rs, re))
             halos.append((rs, re))
-        self.stream.synchronize()
-        self.comm.sendrecv(pairs, prev, nxt)
+        self.comm.sendrecv(pairs, prev, nxt)  # stream-ordered (RCCL) or self-synchronising (host staged)
         ops = [(dirps.der1st, dirps.der1st_sym, dirps.der2nd),
                (dirps.der1st_sym, dirps.der1st, dirps.der2nd_sym),
                (dirps.der1st_sym, dirps.der1st, dirps.der2nd_sym)]
@@ -170,7 +169,6 @@ class HipBackend:
                 self.h, direction, rhs[i].ptr, bs.data_ptr(), be.data_ptr(), fld[i].ptr,
                 halos[i][0].data_ptr(), halos[i][1].data_ptr(), fld[0].ptr, halos[0][0].data_ptr(),
                 halos[0][1].data_ptr(), t_du.handle, t_dud.handle, t_d2u.handle))
-            self.stream.synchronize()
             self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
             _lib.check(self.lib.x3d_transeq_dist_bwd(
                 self.h, direction, rhs[i].ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), fld[0].ptr,
@@ -231,12 +229,10 @@ class HipBackend:
         ss, se, rs, re = self._buffers(direction, N_HALO, "u0")
         _lib.check(self.lib.x3d_pack_halos(self.h, ss.data_ptr(), se.data_ptr(), u.ptr, tdsops.n_tds,
                                            direction))
-        self.stream.synchronize()
         self.comm.sendrecv([(ss, se, rs, re)], prev, nxt)
         bs, be, brs, bre = self._buffers(direction, 1, "b1")
         _lib.check(self.lib.x3d_tds_dist_fwd(self.h, du.ptr, bs.data_ptr(), be.data_ptr(), u.ptr,
                                              rs.data_ptr(), re.data_ptr(), tdsops.handle, direction))
-        self.stream.synchronize()
         self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
         _lib.check(self.lib.x3d_tds_dist_bwd(self.h, du.ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(),
                                              tdsops.handle, direction))

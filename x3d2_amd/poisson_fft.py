@@ -46,7 +46,8 @@ def wave_numbers(n, L, d, periodic, c_a, c_b, c_alpha):
 def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
-    if mesh.nproc > 1:
+    import os
+    if mesh.nproc > 1 or os.environ.get("X3D_FORCE_PENCIL_FFT") == "1":
         return HipPencilPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
     return HipPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
 
@@ -211,7 +212,7 @@ class HipPencilPoissonFFT(HipPoissonFFT):
             pass
 
     def _xchg(self, send_counts, recv_counts, peers):
-        self.backend.stream.synchronize()
+        # stream-ordered: RCCL ops wait on the current stream, host staging (gloo) synchronises itself
         self.backend.comm.alltoall(self.sendbuf, send_counts, self.recvbuf, recv_counts, peers)
 
     def fft_forward(self, f_in):
