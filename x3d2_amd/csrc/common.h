@@ -87,6 +87,8 @@ struct TdsTab {
     // W  weights of d_k in du_2 (backward chain), see tds.hip
     // PF/QB chunk-local carry multipliers (onchip.hip)
     const double *RF, *RB;
+    const double *TL;   // lane tables of the wave-per-pencil x kernels (xscan.hip): [entry][64 lanes], or null
+    int Q;              // rows per lane there (4 or 8), 0 if unavailable
     const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
     double last_r;      // dist_fw(1)
     double bw1;         // dist_bw(1)

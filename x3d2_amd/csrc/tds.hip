@@ -90,12 +90,58 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         rb[0] = Bw[j]; rb[1] = Sa[j]; rb[2] = Sc[j]; rb[3] = St[j]; rb[4] = Stc[j]; rb[5] = QB[j];
     }
     memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
+    // lane tables for the wave-per-pencil x kernels (xscan.hip): lane l owns rows l*Q+1..(l+1)*Q
+    const int Q = nr <= 256 ? 4 : (nr <= 512 ? 8 : 0);
+    const size_t tl_off = img.size();
+    if (Q) {
+        const int NE = 9 * Q + 12;
+        img.resize(tl_off + (size_t)NE * 64, 0.0);
+        double *tl = &img[tl_off];
+        auto E = [&](int e, int l) -> double & { return tl[(size_t)e * 64 + l]; };
+        double G[64], HL[64];
+        for (int l = 0; l < 64; l++) {
+            double pg = 1.0;
+            for (int q = 0; q < Q; q++) {
+                const int j = l * Q + q + 1;
+                const bool in = j <= nr, real = j <= n;
+                const double f = in ? F[j] : 0.0, a = in ? A[j] : 0.0;
+                E(0 * Q + q, l) = f;
+                E(1 * Q + q, l) = a;
+                pg *= -f * a;
+                E(2 * Q + q, l) = pg;
+                E(3 * Q + q, l) = (j >= 1 && j <= n - 2) ? -dist_bw[j - 1] : 0.0;  // incl. row 1: X_1 = e_1 - bw_1 X_2
+                E(5 * Q + q, l) = real ? Sa[j] : 0.0;
+                E(6 * Q + q, l) = real ? Sc[j] : 0.0;
+                E(7 * Q + q, l) = real ? St[j] : 0.0;
+                E(8 * Q + q, l) = real ? Stc[j] : 0.0;
+            }
+            G[l] = pg;
+            double ph = 1.0;
+            for (int q = Q - 1; q >= 0; q--) { ph *= E(3 * Q + q, l); E(4 * Q + q, l) = ph; }
+            HL[l] = ph;
+        }
+        double mf[64], mb[64];
+        for (int l = 0; l < 64; l++) { mf[l] = G[l]; mb[l] = HL[l]; }
+        for (int k = 0; k < 6; k++) {  // data-independent multipliers of the Kogge-Stone steps
+            const int d = 1 << k;
+            double nf[64], nb[64];
+            for (int l = 0; l < 64; l++) {
+                E(9 * Q + k, l) = mf[l];
+                E(9 * Q + 6 + k, l) = mb[l];
+                nf[l] = l >= d ? mf[l] * mf[l - d] : mf[l];
+                nb[l] = l + d < 64 ? mb[l] * mb[l + d] : mb[l];
+            }
+            for (int l = 0; l < 64; l++) { mf[l] = nf[l]; mb[l] = nb[l]; }
+        }
+    }
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
     X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
     TdsTab &tb = t->tab;
     tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
     tb.RF = t->dev; tb.RB = t->dev + (size_t)4 * L;
     tb.Cs = t->dev + (size_t)12 * L;
+    tb.Q = Q;
+    tb.TL = Q ? t->dev + tl_off : nullptr;
     tb.last_r = dist_fw[0];
     tb.bw1 = dist_bw[0];
     tb.sa1 = dist_sa[0];

@@ -386,8 +386,26 @@ static bool xdir_tiled()
     return mode == 1;
 }
 
+int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done);
+int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
+static bool use_xscan()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_NO_XSCAN");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale)
 {
+    if (use_xscan() && xdir_tiled()) {
+        bool done = false;
+        if (int rc = x3d_xscan_tds(b, du, u, t, acc, scale, &done)) return rc;
+        if (done) return 0;
+    }
     if (!xdir_tiled()) return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X, acc, scale);
     const int np = b->ny * b->nz, nw = (np + 63) / 64;
     {
@@ -411,6 +429,11 @@ int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc)
 {
+    if (use_xscan() && xdir_tiled()) {
+        bool done = false;
+        if (int rc = x3d_xscan_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;
+        if (done) return 0;
+    }
     if (!xdir_tiled()) return x3d_generic_transeq_local(b, X3D_DIR_X, rhs, u, conv, nu, t1, t2, t3, acc);
     const int np = b->ny * b->nz, nw = (np + 63) / 64, npm = npmax_of(b);
     {
