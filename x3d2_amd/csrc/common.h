@@ -89,6 +89,7 @@ struct TdsTab {
     const double *RF, *RB;
     const double *TL;   // lane tables of the wave-per-pencil x kernels (xscan.hip): [entry][64 lanes], or null
     int Q;              // rows per lane there (4 or 8), 0 if unavailable
+    int bulk_only;      // 1: start/end stencils equal the bulk stencil (periodic / BC_HALO both ends)
     const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
     double last_r;      // dist_fw(1)
     double bw1;         // dist_bw(1)

@@ -141,6 +141,10 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     tb.RF = t->dev; tb.RB = t->dev + (size_t)4 * L;
     tb.Cs = t->dev + (size_t)12 * L;
     tb.Q = Q;
+    tb.bulk_only = 1;
+    for (int r = 0; r < 4; r++)
+        for (int m = 0; m < 9; m++)
+            if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) tb.bulk_only = 0;
     tb.TL = Q ? t->dev + tl_off : nullptr;
     tb.last_r = dist_fw[0];
     tb.bw1 = dist_bw[0];

@@ -32,6 +32,18 @@ int npmax_of(const x3d_backend *b);
 #define LT_MB(k) (9 * Q + 6 + (k))
 #define LT_N(Q_) (9 * (Q_) + 12)
 
+// what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
+struct XOp {
+    const double *TL, *Cs;
+    double last_r, rs_s, rs_e, sa1, scn;
+    int n_tds, n_rhs, bulk_only;
+};
+static XOp xop_of(const x3d_tdsops *t)
+{
+    const TdsTab &b = t->tab;
+    return XOp{b.TL, b.Cs, b.last_r, b.rs_s, b.rs_e, b.sa1, b.scn, b.n_tds, b.n_rhs, b.bulk_only};
+}
+
 __device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
 {
     const double r = __shfl_up(v, d, 64);
@@ -54,10 +66,13 @@ __device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, 
 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
 // values (before the reduced-system substitution), du1 and xn broadcast to all lanes
-template <int Q>
+template <int Q, bool FAST>
 __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)[Q], double &du1, double &xn,
-                                           const double *__restrict__ lt, const TdsTab &t, int lane, int first)
+                                           const double *__restrict__ lt, const XOp &t, int &lane, int first)
 {
+    // PHASE(x): the lane-table reads of the next phase may not be issued before x is known; without
+    // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
+#define PHASE(x) asm volatile("" : "+v"(lane) : "v"(x))
     const int nr = t.n_rhs, n = t.n_tds;
     const double *__restrict__ cb = t.Cs + 72;
     const double c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3], c4 = cb[4], c5 = cb[5], c6 = cb[6], c7 = cb[7],
@@ -68,7 +83,7 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
         acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
                  c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
     // boundary rows (1..4 and n_rhs-3..n_rhs) use their own stencils: only the two end lanes get here
-    if (first <= 4 || first + Q - 1 > nr - 4) {
+    if (!FAST && !t.bulk_only && (first <= 4 || first + Q - 1 > nr - 4)) {
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = first + q;
@@ -88,11 +103,13 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     }
     // ---- scan of the lane-end values, then carry-in = true e at the end of lane l-1
     double v = prev;
+    PHASE(X[Q / 2]);
 #pragma unroll
     for (int k = 0; k < 6; k++) v += lt[LT_MF(k) * 64 + lane] * shfl_up_d(v, 1 << k, lane);
     double carry = shfl_up_d(v, 1, lane);
     // ---- apply, lane-local back-substitution from zero
     double nxt = 0.0;
+    PHASE(carry);
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
         X[q] = (X[q] + lt[LT_PF(q) * 64 + lane] * carry) + lt[LT_H(q) * 64 + lane] * nxt;
@@ -100,6 +117,7 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     }
     if (n == nr) {}  // (row n_rhs = n+1 of a v2p operator carries F = H = 0 in the tables)
     v = nxt;
+    PHASE(X[Q / 2]);
 #pragma unroll
     for (int k = 0; k < 6; k++) v += lt[LT_MB(k) * 64 + lane] * shfl_down_d(v, 1 << k, lane);
     carry = shfl_down_d(v, 1, lane);
@@ -107,11 +125,39 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     for (int q = 0; q < Q; q++) X[q] = X[q] + lt[LT_QB(q) * 64 + lane] * carry;
     // du_1 = last_r * X_1 (X_1 = e_1 - bw_1 X_2, distributed.f90:161-166); X_n = e_n
     du1 = t.last_r * __shfl(X[0], 0, 64);
-    const int ln = (n - 1) / Q, qn = (n - 1) % Q;
-    double xsel = 0.0;
+    if (FAST) {
+        xn = __shfl(X[Q - 1], 63, 64);
+    } else {
+        const int ln = (n - 1) / Q, qn = (n - 1) % Q;
+        double xsel = 0.0;
 #pragma unroll
-    for (int q = 0; q < Q; q++) xsel = (q == qn) ? X[q] : xsel;
-    xn = __shfl(xsel, ln, 64);
+        for (int q = 0; q < Q; q++) xsel = (q == qn) ? X[q] : xsel;
+        xn = __shfl(xsel, ln, 64);
+    }
+    PHASE(xn);
+#undef PHASE
+}
+
+// nr == 64*Q and n_wrap == nr: every lane's body is a full aligned vector and the halos are
+// the neighbours' rows or the periodic image -> no per-lane branches at all
+template <int Q>
+__device__ __forceinline__ void load_window_exact(double (&w)[Q + 8], const double *__restrict__ row, int lane,
+                                                  int nr)
+{
+    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
+#pragma unroll
+    for (int m = 0; m < Q / 2; m++) {
+        const double2 t2 = body[m];
+        w[4 + 2 * m] = t2.x;
+        w[5 + 2 * m] = t2.y;
+    }
+    const int il = lane == 0 ? nr - 4 : lane * Q - 4;       // rows first-4..first-1 (periodic image for lane 0)
+    const int ir = lane == 63 ? 0 : lane * Q + Q;           // rows last+1..last+4
+    const double2 *__restrict__ hl = reinterpret_cast<const double2 *>(row + il);
+    const double2 *__restrict__ hr = reinterpret_cast<const double2 *>(row + ir);
+    const double2 a0 = hl[0], a1 = hl[1], b0 = hr[0], b1 = hr[1];
+    w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
+    w[Q + 4] = b0.x; w[Q + 5] = b0.y; w[Q + 6] = b1.x; w[Q + 7] = b1.y;
 }
 
 template <int Q>
@@ -133,46 +179,63 @@ __device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__
 }
 
 // ---------------------------------------------------------------- tds_solve
-template <int Q, bool ACC>
-__global__ void __launch_bounds__(256) k_xscan_tds(double *__restrict__ du, const double *__restrict__ u, TdsTab t,
+template <int Q, bool ACC, bool FAST>
+__global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, const double *__restrict__ u, XOp t,
                                                    int np, long pitch, int n_wrap, double scale)
 {
     extern __shared__ double lt[];  // [LT_N(Q)][64]
     for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int n = t.n_tds, nr = t.n_rhs;
     const int first = lane * Q + 1;
     const bool interior = first - 4 >= 1 && first + Q + 3 <= nr;
+    const bool exact = FAST || (nr == 64 * Q && n_wrap == nr);
     for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
         const double *__restrict__ row = u + (long)p * pitch;
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop (no 150-VGPR hoist)
         double w[Q + 8], X[Q], du1, xn;
-        load_window<Q>(w, row, first, nr, n_wrap, interior);
-        scan_solve<Q>(w, X, du1, xn, lt, t, lane, first);
+        if (FAST || exact) load_window_exact<Q>(w, row, lane, nr);
+        else load_window<Q>(w, row, first, nr, n_wrap, interior);
+        scan_solve<Q, FAST>(w, X, du1, xn, lt, t, lane, first);
         const double du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
         const double du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
         double *__restrict__ orow = du + (long)p * pitch;
+        double r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = first + q;
-            if (j <= n) {
-                double r = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) *
-                           lt[LT_ST(q) * 64 + lane];
-                r = (j == 1) ? du_s * lt[LT_ST(q) * 64 + lane] : r;
-                r = (j == n) ? du_e * lt[LT_ST(q) * 64 + lane] : r;
-                orow[j - 1] = ACC ? orow[j - 1] + scale * r : r;
+            const double st = lt[LT_ST(q) * 64 + lane];
+            r[q] = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) * st;
+            r[q] = (j == 1) ? du_s * st : r[q];
+            r[q] = (j == n) ? du_e * st : r[q];
+        }
+        if (FAST || (exact && n == nr)) {
+            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
+#pragma unroll
+            for (int m = 0; m < Q / 2; m++) {
+                double2 v2;
+                if (ACC) { v2 = o2[m]; v2.x += scale * r[2 * m]; v2.y += scale * r[2 * m + 1]; }
+                else { v2.x = r[2 * m]; v2.y = r[2 * m + 1]; }
+                o2[m] = v2;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = first + q;
+                if (j <= n) orow[j - 1] = ACC ? orow[j - 1] + scale * r[q] : r[q];
             }
         }
     }
 }
 
 // ---------------------------------------------------------------- transeq component
-template <int Q, bool SAME, bool ACC>
-__global__ void __launch_bounds__(512)
-    k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, TdsTab t1,
-                    TdsTab t2, TdsTab t3, int np, long pitch, double nu)
+template <int Q, bool SAME, bool ACC, bool FAST>
+__global__ void __launch_bounds__(FAST ? 768 : 512)
+    k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
+                    XOp t2, XOp t3, int np, long pitch, double nu)
 {
     extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64]
     constexpr int LN = LT_N(Q) * 64;
@@ -182,7 +245,7 @@ __global__ void __launch_bounds__(512)
         lt[2 * LN + i] = t3.TL[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int n = t1.n_tds;
@@ -192,45 +255,67 @@ __global__ void __launch_bounds__(512)
     for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
         const double *__restrict__ ru = u + (long)p * pitch;
         const double *__restrict__ rc = cv + (long)p * pitch;
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
         double wu[Q + 8], wp[Q + 8], vq[Q];
-        load_window<Q>(wu, ru, first, n, n, interior);
+        const bool exact = FAST || n == 64 * Q;
+        if (exact) load_window_exact<Q>(wu, ru, lane, n);
+        else load_window<Q>(wu, ru, first, n, n, interior);
         if (SAME) {
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wu[m];
 #pragma unroll
             for (int q = 0; q < Q; q++) vq[q] = wu[q + 4];
         } else {
-            load_window<Q>(wp, rc, first, n, n, interior);
+            if (exact) load_window_exact<Q>(wp, rc, lane, n);
+            else load_window<Q>(wp, rc, first, n, n, interior);
 #pragma unroll
             for (int q = 0; q < Q; q++) vq[q] = wp[q + 4];
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];  // ud = u*conv incl. halo products
         }
-        double X1[Q], X2[Q], X3[Q], a1, b1, a2, b2, a3, b3;
-        scan_solve<Q>(wu, X1, a1, b1, l1, t1, lane, first);
-        scan_solve<Q>(wp, X2, a2, b2, l2, t2, lane, first);
-        scan_solve<Q>(wu, X3, a3, b3, l3, t3, lane, first);
-        const double du_s = t1.rs_s * (a1 - t1.sa1 * b1), du_e = t1.rs_e * (b1 - t1.scn * a1);
-        const double dud_s = t2.rs_s * (a2 - t2.sa1 * b2), dud_e = t2.rs_e * (b2 - t2.scn * a2);
-        const double d2u_s = t3.rs_s * (a3 - t3.sa1 * b3), d2u_e = t3.rs_e * (b3 - t3.scn * a3);
-        double *__restrict__ orow = rhs + (long)p * pitch;
+        // one operator at a time, substituted at once (distributed.f90:304-335 written per operator:
+        // rows 1 and n take du_s*st / du_e*st, which is what the general formula gives with these temps)
+        auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
+            double a, b;
+            scan_solve<Q, FAST>(w, T, a, b, l, t, lane, first);
+            const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = first + q;
-            if (j <= n) {
-                const double st1 = l1[LT_ST(q) * 64 + lane], st2 = l2[LT_ST(q) * 64 + lane],
-                             st3 = l3[LT_ST(q) * 64 + lane], stc = l3[LT_STC(q) * 64 + lane];
-                const double v = vq[q];
-                const double temp_du = st1 * (X1[q] - l1[LT_SA(q) * 64 + lane] * du_s - l1[LT_SC(q) * 64 + lane] * du_e);
-                const double temp_dud = st2 * (X2[q] - l2[LT_SA(q) * 64 + lane] * dud_s - l2[LT_SC(q) * 64 + lane] * dud_e);
-                const double temp_d2u =
-                    st3 * (X3[q] - l3[LT_SA(q) * 64 + lane] * d2u_s - l3[LT_SC(q) * 64 + lane] * d2u_e) + temp_du * stc;
-                double r = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;  // distributed.f90:315-324
-                if (j == 1)
-                    r = -0.5 * (v * du_s * st1 + dud_s * st2) + nu * (d2u_s * st3 + du_s * st1 * stc);  // :304-311
-                if (j == n)
-                    r = -0.5 * (v * du_e * st1 + dud_e * st2) + nu * (d2u_e * st3 + du_e * st1 * stc);  // :328-335
-                orow[j - 1] = ACC ? orow[j - 1] + r : r;
+            for (int q = 0; q < Q; q++) {
+                const int j = first + q;
+                const double st = l[LT_ST(q) * 64 + lane];
+                double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                x = (j == 1) ? s_ * st : x;
+                x = (j == n) ? e_ * st : x;
+                T[q] = x;
+            }
+        };
+        double r[Q], T[Q];
+        solve_subs(wp, T, l2, t2);  // d(u*conv)/dx first: wp is dead afterwards
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = T[q];
+        asm volatile("" : "+v"(lane) : "v"(r[0]));  // order the operators: bounds the live lane-table reads
+        solve_subs(wu, T, l1, t1);  // du/dx
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        asm volatile("" : "+v"(lane) : "v"(r[0]));
+        solve_subs(wu, T, l3, t3);  // d2u/dx2
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] += nu * T[q];
+        double *__restrict__ orow = rhs + (long)p * pitch;
+        if (exact) {
+            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
+#pragma unroll
+            for (int m = 0; m < Q / 2; m++) {
+                double2 v2;
+                if (ACC) { v2 = o2[m]; v2.x += r[2 * m]; v2.y += r[2 * m + 1]; }
+                else { v2.x = r[2 * m]; v2.y = r[2 * m + 1]; }
+                o2[m] = v2;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = first + q;
+                if (j <= n) orow[j - 1] = ACC ? orow[j - 1] + r[q] : r[q];
             }
         }
     }
@@ -245,33 +330,40 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
     if (!xscan_ok(t)) return 0;
     const int Q = t->tab.Q, np = b->ny * b->nz;
     const size_t lds = sizeof(double) * LT_N(Q) * 64;
-    int blocks = (np + 3) / 4;
-    blocks = blocks > 2048 ? 2048 : blocks;
+    int blocks = (np + 7) / 8;
+    blocks = blocks > 768 ? 768 : blocks;  // 43 KB of lane tables per 8-wave workgroup: 3 per CU
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
-#define LAUNCH(Q_, A_, SC_)                                                                                    \
-    hipLaunchKernelGGL((k_xscan_tds<Q_, A_>), dim3(blocks), dim3(256), lds, b->stream, du, u, t->tab, np,     \
+    // FAST: periodic-type stencils on a pencil the 64 lanes tile exactly, p2p or v2v (n_rhs == n_tds)
+    const bool fast = t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
+#define LAUNCH(Q_, A_, F_, SC_)                                                                                \
+    hipLaunchKernelGGL((k_xscan_tds<Q_, A_, F_>), dim3(blocks), dim3(512), lds, b->stream, du, u, xop_of(t), np, \
                        (long)b->nxp, t->n_tds, SC_)
-    if (Q == 8) { if (acc) LAUNCH(8, true, scale); else LAUNCH(8, false, 1.0); }
-    else { if (acc) LAUNCH(4, true, scale); else LAUNCH(4, false, 1.0); }
+#define PICK(Q_)                                                                                               \
+    do {                                                                                                       \
+        if (fast) { if (acc) LAUNCH(Q_, true, true, scale); else LAUNCH(Q_, false, true, 1.0); }               \
+        else { if (acc) LAUNCH(Q_, true, false, scale); else LAUNCH(Q_, false, false, 1.0); }                  \
+    } while (0)
+    if (Q == 8) PICK(8); else PICK(4);
+#undef PICK
 #undef LAUNCH
     X3D_HIP(hipGetLastError());
     *done = true;
     return 0;
 }
 
-template <int Q, bool SAME, bool ACC>
+template <int Q, bool SAME, bool ACC, bool FAST>
 static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                           const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int np, int blocks,
                           size_t lds)
 {
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-        X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq<Q, SAME, ACC>,
+        X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq<Q, SAME, ACC, FAST>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC>), dim3(blocks), dim3(512), lds, b->stream, rhs, u, conv, t1->tab,
-                       t2->tab, t3->tab, np, (long)b->nxp, nu);
+    hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(FAST ? 768 : 512), lds, b->stream, rhs, u, conv, xop_of(t1),
+                       xop_of(t2), xop_of(t3), np, (long)b->nxp, nu);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -285,17 +377,20 @@ int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double
     const size_t lds = sizeof(double) * 3 * LT_N(Q) * 64;
     if (lds > 160 * 1024) return 0;
     int blocks = (np + 7) / 8;
-    blocks = blocks > 256 ? 256 : blocks;  // one 8-wave workgroup per CU (129 KB of lane tables in LDS)
+    blocks = blocks > 256 ? 256 : blocks;  // one 8/12-wave workgroup per CU (129 KB of lane tables in LDS)
     const bool same = u == conv;
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
     int rc;
-#define GO(Q_)                                                                                                 \
-    (same ? (acc ? launch_transeq<Q_, true, true>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)           \
-                 : launch_transeq<Q_, true, false>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds))         \
-          : (acc ? launch_transeq<Q_, false, true>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)          \
-                 : launch_transeq<Q_, false, false>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)))
+    const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q;
+#define GO2(Q_, F_)                                                                                            \
+    (same ? (acc ? launch_transeq<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)       \
+                 : launch_transeq<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds))     \
+          : (acc ? launch_transeq<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)      \
+                 : launch_transeq<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)))
+#define GO(Q_) (fast ? GO2(Q_, true) : GO2(Q_, false))
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO
+#undef GO2
     if (rc) return rc;
     *done = true;
     return 0;
