@@ -123,7 +123,7 @@ program dump_golden
   use m_mesh
   use m_omp_backend
   use m_omp_common, only: SZ
-  use m_omp_spectral, only: process_spectral_000
+  use m_omp_spectral, only: process_spectral_000, process_spectral_010
   use m_solver, only: solver_t
   use m_tdsops, only: tdsops_t, dirps_t
   use m_dump_io
@@ -150,7 +150,9 @@ program dump_golden
   complex(dp), allocatable :: spec(:, :, :)
   real(dp), allocatable :: sre(:, :, :), sim(:, :, :)
   real(dp) :: s, mx, mn
-  logical :: all_periodic
+  logical :: all_periodic, is_010
+  integer :: dg
+  character(1) :: dtag
 
   call MPI_Init(ierr)
   call MPI_Comm_rank(MPI_COMM_WORLD, nrank, ierr)
@@ -333,6 +335,66 @@ program dump_golden
     sre = real(spec, dp); sim = aimag(spec)
     call dump_r3('spec.out_re', sre)
     call dump_r3('spec.out_im', sim)
+  end if
+
+  ! ---- spectral, non-periodic y (010): base_init -> waves, transfer functions, the
+  !      stretching matrices (src/poisson_fft.f90:275-652) and the reference's
+  !      process_spectral_010 (OMP kernel; it ignores stretching) on a deterministic array
+  is_010 = mesh%grid%periodic_BC(1) .and. (.not. mesh%grid%periodic_BC(2)) &
+           .and. mesh%grid%periodic_BC(3)
+  if (nproc == 1 .and. is_010) then
+    nspec = [cdims(1)/2 + 1, cdims(2), cdims(3)]
+    call pois%base_init(mesh, solver%xdirps, solver%ydirps, solver%zdirps, &
+                        nspec, [0, 0, 0])
+    call dump_r1('spec.ax', pois%ax); call dump_r1('spec.bx', pois%bx)
+    call dump_r1('spec.ay', pois%ay); call dump_r1('spec.by', pois%by)
+    call dump_r1('spec.az', pois%az); call dump_r1('spec.bz', pois%bz)
+    call dump_r1('spec.k2x_re', real(pois%k2x, dp))
+    call dump_r1('spec.k2y_re', real(pois%k2y, dp))
+    call dump_r1('spec.k2z_re', real(pois%k2z, dp))
+    call dump_r1('spec.kx_re', real(pois%kx, dp))
+    call dump_r1('spec.ky_re', real(pois%ky, dp))
+    call dump_r1('spec.kz_re', real(pois%kz, dp))
+    allocate (sre(nspec(1), nspec(2), nspec(3)), sim(nspec(1), nspec(2), nspec(3)))
+    sre = real(pois%waves, dp); sim = aimag(pois%waves)
+    call dump_r3('spec.waves_re', sre)
+    call dump_r3('spec.waves_im', sim)
+    if (pois%stretched_y) then
+      call dump_r1('spec.trans_x', pois%trans_x_re)
+      call dump_r1('spec.trans_y', pois%trans_y_re)
+      call dump_r1('spec.trans_z', pois%trans_z_re)
+      call dump_s('spec.stretched_y_sym', merge(1._dp, 0._dp, pois%stretched_y_sym))
+      do dg = 1, 5
+        write (dtag, '(I1)') dg
+        if (pois%stretched_y_sym) then
+          call dump_r3('spec.a_odd_re.'//dtag, pois%a_odd_re(:, :, :, dg))
+          call dump_r3('spec.a_odd_im.'//dtag, pois%a_odd_im(:, :, :, dg))
+          call dump_r3('spec.a_even_re.'//dtag, pois%a_even_re(:, :, :, dg))
+          call dump_r3('spec.a_even_im.'//dtag, pois%a_even_im(:, :, :, dg))
+        else
+          call dump_r3('spec.a_re.'//dtag, pois%a_re(:, :, :, dg))
+          call dump_r3('spec.a_im.'//dtag, pois%a_im(:, :, :, dg))
+        end if
+      end do
+    end if
+    allocate (spec(nspec(1), nspec(2), nspec(3)))
+    do k = 1, nspec(3)
+      do j = 1, nspec(2)
+        do i = 1, nspec(1)
+          spec(i, j, k) = cmplx(hashval(i, j, k, 4), hashval(i, j, k, 5), kind=dp)
+        end do
+      end do
+    end do
+    sre = real(spec, dp); sim = aimag(spec)
+    call dump_r3('spec.in_re', sre)
+    call dump_r3('spec.in_im', sim)
+    call process_spectral_010( &
+      spec, pois%waves, nspec(1), nspec(2), nspec(3), 0, 0, 0, &
+      cdims(1), cdims(2), cdims(3), &
+      pois%ax, pois%bx, pois%ay, pois%by, pois%az, pois%bz)
+    sre = real(spec, dp); sim = aimag(spec)
+    call dump_r3('spec.out010_re', sre)
+    call dump_r3('spec.out010_im', sim)
   end if
 
   call dump_close()

@@ -45,6 +45,13 @@ der2nd_scheme = '{der2nd}'
 interpl_scheme = '{interpl}'
 stagder_scheme = 'compact6'
 /End
+&channel_nml
+init_noise = 0. 0. 0.
+inlet_noise = 0. 0. 0.
+rotation = {rotation}
+omega_rot = {omega_rot}
+n_rotate = {n_rotate}
+/End
 """
 
 TWO_PI = "6.283185307179586d0"
@@ -56,7 +63,7 @@ def cfg(**kw):
              bcy="'periodic', 'periodic'", bcz="'periodic', 'periodic'",
              stretching="'uniform', 'uniform', 'uniform'", beta="1d0, 1d0, 1d0",
              Re="1600d0", time_intg="RK3", dt="0.001d0", n_iters=4, n_output=2,
-             der2nd="compact6", interpl="classic")
+             der2nd="compact6", interpl="classic", rotation="F", omega_rot="0d0", n_rotate=0)
     d.update(kw)
     return d
 
@@ -76,6 +83,15 @@ DUMPS = {
                     bcy="'dirichlet', 'dirichlet'",
                     stretching="'uniform', 'top-bottom', 'uniform'",
                     beta="1d0, 0.259065151d0, 1d0", Re="4200d0", dt="0.005d0"),
+    # 010 Poisson inputs: uniform y, 'bottom' (full pentadiagonal) and 'centred' stretching
+    "c010u_rk3": cfg(dims="12, 17, 8", L="4d0, 2d0, 2d0", bcy="'dirichlet', 'dirichlet'",
+                     Re="4200d0", dt="0.005d0"),
+    "c010b_rk3": cfg(dims="12, 17, 8", L="4d0, 2d0, 2d0", bcy="'dirichlet', 'dirichlet'",
+                     stretching="'uniform', 'bottom', 'uniform'", beta="1d0, 0.5d0, 1d0",
+                     Re="4200d0", dt="0.005d0"),
+    "c010c_rk3": cfg(dims="12, 17, 8", L="4d0, 2d0, 2d0", bcy="'dirichlet', 'dirichlet'",
+                     stretching="'uniform', 'centred', 'uniform'", beta="1d0, 1.3d0, 1d0",
+                     Re="4200d0", dt="0.005d0"),
     # every non-periodic closure: Neumann x, Dirichlet y, Neumann z,
     # 'optimised' interpolation (hyperviscous der2nd cannot be reached through
     # the reference's allocate_tdsops: it never passes c_nu/nu0_nu)
@@ -93,6 +109,13 @@ TRACES = {
     "tgv32_ab3_nopoisson": cfg(dims="32, 32, 32", time_intg="AB3", n_iters=6, n_output=2),
     "tgv64_rk3_nopoisson": cfg(dims="64, 64, 64", n_iters=4, n_output=2),
     "tgv32_rk3_nopoisson_z2": cfg(dims="32, 32, 32", nproc="1, 1, 2", n_iters=6, n_output=2),
+    # channel case hooks (bulk-velocity shift, rotation forcing switched off at iter 3, wall stamping),
+    # deterministic: no noise; stretched top-bottom mesh
+    "channel17_rk3_nopoisson": cfg(case="channel", dims="16, 17, 12", L="4d0, 2d0, 2d0",
+                                   bcy="'dirichlet', 'dirichlet'",
+                                   stretching="'uniform', 'top-bottom', 'uniform'",
+                                   beta="1d0, 0.259065151d0, 1d0", Re="4200d0", dt="0.005d0",
+                                   rotation="T", omega_rot="0.12d0", n_rotate=3, n_iters=6, n_output=2),
 }
 
 
@@ -181,6 +204,9 @@ KEEP = {
     "p000_rk3_z1": ("meta.", "in.", "tds.z.", "transeq.", "div.", "grad.", "curl.", "step2."),
     "p000_rk3_y2": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2."),
     "p000_rk3_y1": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2."),
+    "c010u_rk3": ("meta.", "in.", "spec.", "step2."),
+    "c010b_rk3": ("meta.", "in.", "spec.", "step2."),
+    "c010c_rk3": ("meta.", "in.", "spec.", "step2."),
 }
 
 
