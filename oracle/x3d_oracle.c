@@ -913,3 +913,201 @@ void orc_process_spectral_000(double *div, const double *waves_re, const double 
 }
 
 int orc_sz(void) { return SZ; }
+
+/* ---------------------------------------------------------------------------
+ * Non-periodic y (010) spectral post-processing.
+ *   src/backend/omp/kernels/spectral_processing.f90:108-283  process_spectral_010
+ *   src/backend/cuda/kernels/spectral_processing.f90:385-702 process_spectral_010_fw /
+ *       _poisson (pentadiagonal, stretched y) / _bw   [CUDA Fortran: cannot be built here]
+ * The OMP kernel is fw -> divide by waves -> bw; the CUDA fw / bw kernels carry the
+ * same arithmetic as the OMP kernel's first two / last two loops, so pinning
+ * orc_process_spectral_010 against the reference's OMP kernel (tests/golden/ref_c010*.npz)
+ * pins fw and bw too.  The pentadiagonal solve is pinned by the stretching matrices
+ * (dumped from the reference's base_init) and by div(grad(p)) = f, the acceptance
+ * check of tests/verification/test_poisson_bc.f90.
+ * div: interleaved complex, (i, j, k) with i fastest.
+ * ------------------------------------------------------------------------- */
+#define C_IDX(i, j, k) (((size_t)((k) - 1) * ny_spec + ((j) - 1)) * nx_spec + ((i) - 1))
+
+void orc_spectral_010_fw(double *div, int nx_spec, int ny_spec, int nz_spec, int x_sp_st, int y_sp_st,
+                         int z_sp_st, int nx, int ny, int nz, const double *ax, const double *bx,
+                         const double *ay, const double *by, const double *az, const double *bz)
+{
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int j = 1; j <= ny_spec; j++)
+            for (int i = 1; i <= nx_spec; i++) {
+                size_t id = C_IDX(i, j, k);
+                int ix = i + x_sp_st, iz = k + z_sp_st;
+                double div_r = div[2 * id] / nx / ny / nz, div_c = div[2 * id + 1] / nx / ny / nz;
+                double tmp_r = div_r, tmp_c = div_c;
+                div_r = tmp_r * bz[iz - 1] + tmp_c * az[iz - 1];
+                div_c = tmp_c * bz[iz - 1] - tmp_r * az[iz - 1];
+                if (iz > nz / 2 + 1) { div_r = -div_r; div_c = -div_c; }
+                tmp_r = div_r; tmp_c = div_c;
+                div_r = tmp_r * bx[ix - 1] + tmp_c * ax[ix - 1];
+                div_c = tmp_c * bx[ix - 1] - tmp_r * ax[ix - 1];
+                if (ix > nx / 2 + 1) { div_r = -div_r; div_c = -div_c; }
+                div[2 * id] = div_r; div[2 * id + 1] = div_c;
+            }
+    /* paired split j <-> ny_spec - j + 2 (for even ny_spec the middle row pairs with itself:
+     * both stores hit it, the second one stays, as in the reference) */
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int j = 2; j <= ny_spec / 2 + 1; j++)
+            for (int i = 1; i <= nx_spec; i++) {
+                int jr = ny_spec - j + 2, iy = j + y_sp_st, iy_r = jr + y_sp_st;
+                size_t il = C_IDX(i, j, k), ir = C_IDX(i, jr, k);
+                double l_r = div[2 * il], l_c = div[2 * il + 1], r_r = div[2 * ir], r_c = div[2 * ir + 1];
+                double a = ay[iy - 1], b = by[iy - 1], a2 = ay[iy_r - 1], b2 = by[iy_r - 1];
+                div[2 * il] = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
+                div[2 * il + 1] = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
+                div[2 * ir] = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
+                div[2 * ir + 1] = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
+            }
+}
+
+void orc_spectral_010_bw(double *div, int nx_spec, int ny_spec, int nz_spec, int x_sp_st, int y_sp_st,
+                         int z_sp_st, int nx, int ny, int nz, const double *ax, const double *bx,
+                         const double *ay, const double *by, const double *az, const double *bz)
+{
+    (void)ny;
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int j = 2; j <= ny_spec / 2 + 1; j++)
+            for (int i = 1; i <= nx_spec; i++) {
+                int jr = ny_spec - j + 2, iy = j + y_sp_st, iy_r = jr + y_sp_st;
+                size_t il = C_IDX(i, j, k), ir = C_IDX(i, jr, k);
+                double l_r = div[2 * il], l_c = div[2 * il + 1], r_r = div[2 * ir], r_c = div[2 * ir + 1];
+                double a = ay[iy - 1], b = by[iy - 1], a2 = ay[iy_r - 1], b2 = by[iy_r - 1];
+                div[2 * il] = l_r * b - l_c * a + r_r * a + r_c * b;
+                div[2 * il + 1] = l_r * a + l_c * b - r_r * b + r_c * a;
+                div[2 * ir] = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
+                div[2 * ir + 1] = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
+            }
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int j = 1; j <= ny_spec; j++)
+            for (int i = 1; i <= nx_spec; i++) {
+                size_t id = C_IDX(i, j, k);
+                int ix = i + x_sp_st, iz = k + z_sp_st;
+                double div_r = div[2 * id], div_c = div[2 * id + 1];
+                double tmp_r = div_r, tmp_c = div_c;
+                div_r = tmp_r * bz[iz - 1] - tmp_c * az[iz - 1];
+                div_c = tmp_c * bz[iz - 1] + tmp_r * az[iz - 1];
+                if (iz > nz / 2 + 1) { div_r = -div_r; div_c = -div_c; }
+                tmp_r = div_r; tmp_c = div_c;
+                div_r = tmp_r * bx[ix - 1] - tmp_c * ax[ix - 1];
+                div_c = tmp_c * bx[ix - 1] + tmp_r * ax[ix - 1];
+                if (ix > nx / 2 + 1) { div_r = -div_r; div_c = -div_c; }
+                div[2 * id] = div_r; div[2 * id + 1] = div_c;
+            }
+}
+
+/* uniform y: -div / waves per part, zero where |waves| < 1e-16, and the (nx/2+1, *, nz/2+1) line */
+void orc_spectral_010_divide(double *div, const double *waves_re, const double *waves_im, int nx_spec,
+                             int ny_spec, int nz_spec, int nx, int nz)
+{
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int j = 1; j <= ny_spec; j++)
+            for (int i = 1; i <= nx_spec; i++) {
+                size_t id = C_IDX(i, j, k);
+                double div_r = div[2 * id], div_c = div[2 * id + 1];
+                double tmp_r = waves_re[id], tmp_c = waves_im[id];
+                div_r = fabs(tmp_r) < 1.e-16 ? 0.0 : -div_r / tmp_r;
+                div_c = fabs(tmp_c) < 1.e-16 ? 0.0 : -div_c / tmp_c;
+                if (i == nx / 2 + 1 && k == nz / 2 + 1) { div_r = 0.0; div_c = 0.0; }
+                div[2 * id] = div_r; div[2 * id + 1] = div_c;
+            }
+}
+
+void orc_process_spectral_010(double *div, const double *waves_re, const double *waves_im, int nx_spec,
+                              int ny_spec, int nz_spec, int x_sp_st, int y_sp_st, int z_sp_st, int nx,
+                              int ny, int nz, const double *ax, const double *bx, const double *ay,
+                              const double *by, const double *az, const double *bz)
+{
+    orc_spectral_010_fw(div, nx_spec, ny_spec, nz_spec, x_sp_st, y_sp_st, z_sp_st, nx, ny, nz, ax, bx, ay,
+                        by, az, bz);
+    orc_spectral_010_divide(div, waves_re, waves_im, nx_spec, ny_spec, nz_spec, nx, nz);
+    orc_spectral_010_bw(div, nx_spec, ny_spec, nz_spec, x_sp_st, y_sp_st, z_sp_st, nx, ny, nz, ax, bx, ay,
+                        by, az, bz);
+}
+
+/* process_spectral_010_poisson (CUDA kernel :462-617): pentadiagonal solve along y per (i, k),
+ * rows j = 1..n mapped to spectral rows jm = inc*j + off - inc/2 (odd rows: inc 2, off 0; even
+ * rows: inc 2, off 1; all rows: inc 1, off 0).  a_re / a_im: [5][nz_spec][n][nx_spec] (diagonal
+ * index slowest), MODIFIED in place like the reference's device copies. */
+void orc_spectral_010_penta(double *div, double *a_re, double *a_im, int off, int inc, int nx_spec,
+                            int ny_spec, int nz_spec, int n, int nx, int nz)
+{
+    const double eps = 1.e-16;
+    const size_t dstride = (size_t)nz_spec * n * nx_spec;
+#define A_(M, i, j, k, d) M[((d) - 1) * dstride + ((size_t)((k) - 1) * n + ((j) - 1)) * nx_spec + ((i) - 1)]
+#define RE(i, j, k) div[2 * C_IDX(i, j, k)]
+#define IM(i, j, k) div[2 * C_IDX(i, j, k) + 1]
+#pragma omp parallel for collapse(2)
+    for (int k = 1; k <= nz_spec; k++)
+        for (int i = 1; i <= nx_spec; i++) {
+            double tmp_r, tmp_c, div_r, div_c;
+            for (int j = 1; j <= n - 2; j++) {
+                int jm = inc * j + off - inc / 2;
+                tmp_r = fabs(A_(a_re, i, j, k, 3)) > eps ? A_(a_re, i, j + 1, k, 2) / A_(a_re, i, j, k, 3) : 0.0;
+                tmp_c = fabs(A_(a_im, i, j, k, 3)) > eps ? A_(a_im, i, j + 1, k, 2) / A_(a_im, i, j, k, 3) : 0.0;
+                RE(i, jm + inc, k) = RE(i, jm + inc, k) - tmp_r * RE(i, jm, k);
+                IM(i, jm + inc, k) = IM(i, jm + inc, k) - tmp_c * IM(i, jm, k);
+                A_(a_re, i, j + 1, k, 3) -= tmp_r * A_(a_re, i, j, k, 4);
+                A_(a_im, i, j + 1, k, 3) -= tmp_c * A_(a_im, i, j, k, 4);
+                A_(a_re, i, j + 1, k, 4) -= tmp_r * A_(a_re, i, j, k, 5);
+                A_(a_im, i, j + 1, k, 4) -= tmp_c * A_(a_im, i, j, k, 5);
+                tmp_r = fabs(A_(a_re, i, j, k, 3)) > eps ? A_(a_re, i, j + 2, k, 1) / A_(a_re, i, j, k, 3) : 0.0;
+                tmp_c = fabs(A_(a_im, i, j, k, 3)) > eps ? A_(a_im, i, j + 2, k, 1) / A_(a_im, i, j, k, 3) : 0.0;
+                RE(i, jm + 2 * inc, k) = RE(i, jm + 2 * inc, k) - tmp_r * RE(i, jm, k);
+                IM(i, jm + 2 * inc, k) = IM(i, jm + 2 * inc, k) - tmp_c * IM(i, jm, k);
+                A_(a_re, i, j + 2, k, 2) -= tmp_r * A_(a_re, i, j, k, 4);
+                A_(a_im, i, j + 2, k, 2) -= tmp_c * A_(a_im, i, j, k, 4);
+                A_(a_re, i, j + 2, k, 3) -= tmp_r * A_(a_re, i, j, k, 5);
+                A_(a_im, i, j + 2, k, 3) -= tmp_c * A_(a_im, i, j, k, 5);
+            }
+            /* last two rows */
+            tmp_r = fabs(A_(a_re, i, n - 1, k, 3)) > eps ? A_(a_re, i, n, k, 2) / A_(a_re, i, n - 1, k, 3) : 0.0;
+            tmp_c = fabs(A_(a_im, i, n - 1, k, 3)) > eps ? A_(a_im, i, n, k, 2) / A_(a_im, i, n - 1, k, 3) : 0.0;
+            div_r = A_(a_re, i, n, k, 3) - tmp_r * A_(a_re, i, n - 1, k, 4);
+            div_c = A_(a_im, i, n, k, 3) - tmp_c * A_(a_im, i, n - 1, k, 4);
+            int nm = inc * n + off - inc / 2;
+            if (fabs(div_r) > eps) {
+                tmp_r = tmp_r / div_r;
+                div_r = RE(i, nm, k) / div_r - tmp_r * RE(i, nm - inc, k);
+            } else { tmp_r = 0.0; div_r = 0.0; }
+            if (fabs(div_c) > eps) {
+                tmp_c = tmp_c / div_c;
+                div_c = IM(i, nm, k) / div_c - tmp_c * IM(i, nm - inc, k);
+            } else { tmp_c = 0.0; div_c = 0.0; }
+            RE(i, nm, k) = div_r; IM(i, nm, k) = div_c;
+            tmp_r = fabs(A_(a_re, i, n - 1, k, 3)) > eps ? 1.0 / A_(a_re, i, n - 1, k, 3) : 0.0;
+            tmp_c = fabs(A_(a_im, i, n - 1, k, 3)) > eps ? 1.0 / A_(a_im, i, n - 1, k, 3) : 0.0;
+            div_r = A_(a_re, i, n - 1, k, 4) * tmp_r;
+            div_c = A_(a_im, i, n - 1, k, 4) * tmp_c;
+            RE(i, nm - inc, k) = RE(i, nm - inc, k) * tmp_r - RE(i, nm, k) * div_r;
+            IM(i, nm - inc, k) = IM(i, nm - inc, k) * tmp_c - IM(i, nm, k) * div_c;
+            const int zero_mode = (i == nx / 2 + 1 && k == nz / 2 + 1);
+            if (zero_mode) {
+                RE(i, nm, k) = 0.0; IM(i, nm, k) = 0.0;
+                RE(i, nm - inc, k) = 0.0; IM(i, nm - inc, k) = 0.0;
+            }
+            for (int j = n - 2; j >= 1; j--) {
+                int jm = inc * j + off - inc / 2;
+                tmp_r = fabs(A_(a_re, i, j, k, 3)) > eps ? 1.0 / A_(a_re, i, j, k, 3) : 0.0;
+                tmp_c = fabs(A_(a_im, i, j, k, 3)) > eps ? 1.0 / A_(a_im, i, j, k, 3) : 0.0;
+                RE(i, jm, k) = tmp_r * (RE(i, jm, k) - A_(a_re, i, j, k, 4) * RE(i, jm + inc, k) -
+                                        A_(a_re, i, j, k, 5) * RE(i, jm + 2 * inc, k));
+                IM(i, jm, k) = tmp_c * (IM(i, jm, k) - A_(a_im, i, j, k, 4) * IM(i, jm + inc, k) -
+                                        A_(a_im, i, j, k, 5) * IM(i, jm + 2 * inc, k));
+                if (zero_mode) { RE(i, jm, k) = 0.0; IM(i, jm, k) = 0.0; }
+            }
+        }
+#undef A_
+#undef RE
+#undef IM
+}
+#undef C_IDX
