@@ -187,6 +187,20 @@ int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);  /* fft_forward
 int x3d_poisson_postprocess_000(x3d_poisson *p);                  /* fft_postprocess_000    */
 int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);      /* fft_backward           */
 int x3d_poisson_solve_000(x3d_poisson *p, double *f);             /* poisson_000, :216-226  */
+/* ---- non-periodic y (010), single rank like the reference (src/poisson_fft.f90:177-180):
+ * the same create call with the 010 waves and ay/by = sin/cos((i-1) pi / 2n);
+ * poisson_010 = enforce_periodicity_y ; fft_forward ; fft_postprocess_010 ; fft_backward ;
+ * undo_periodicity_y (src/poisson_fft.f90:228-242).  f_out != f_in (DIR_C blocks). */
+int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in);
+int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in);
+/* stretched y: the matrices of stretching_matrix (src/poisson_fft.f90:275-652), host arrays
+ * [5][nz][n][nx/2+1] (diagonal -2..+2 slowest; real part = imaginary part).  sym != 0
+ * ('centred' / 'top-bottom'): a0 = odd rows, a1 = even rows, n = ny/2; sym == 0 ('bottom'):
+ * a0 = full system, n = ny, a1 ignored.  Factored once on the device (the reference
+ * re-copies and re-eliminates them at every solve, src/backend/cuda/poisson_fft.f90:868-913). */
+int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double *a0, const double *a1);
+int x3d_poisson_postprocess_010(x3d_poisson *p);                  /* fft_postprocess_010    */
+int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_010          */
 /* test hook: download / upload the spectral workspace [nz][ny][nx/2+1] complex */
 int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
 int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);

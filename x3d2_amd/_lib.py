@@ -67,6 +67,11 @@ PROTOTYPES = {
     "x3d_poisson_postprocess_000": (I, [VP]),
     "x3d_poisson_fft_backward": (I, [VP, VP]),
     "x3d_poisson_solve_000": (I, [VP, VP]),
+    "x3d_poisson_enforce_periodicity_y": (I, [VP, VP, VP]),
+    "x3d_poisson_undo_periodicity_y": (I, [VP, VP, VP]),
+    "x3d_poisson_set_stretching": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
+    "x3d_poisson_postprocess_010": (I, [VP]),
+    "x3d_poisson_solve_010": (I, [VP, VP, VP]),
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),

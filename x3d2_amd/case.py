@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-from .common import DIR_X, DIR_Z, VERT
+from .common import BC_DIRICHLET, CELL, DIR_X, DIR_Z, VERT, Y_FACE
 
 
 class Monitoring:
@@ -115,3 +115,76 @@ class TGVCase(BaseCase):
         s.backend.set_field_data(s.u, np.sin(x) * np.cos(y) * np.cos(z))
         s.backend.set_field_data(s.v, -np.cos(x) * np.sin(y) * np.cos(z))
         s.w.fill(0.0)
+
+
+class ChannelConfig:
+    """channel_config_t, src/config.f90:46-54, 207-249 (namelist channel_nml)"""
+
+    def __init__(self, init_noise=(0.0, 0.0, 0.0), inlet_noise=(0.0, 0.0, 0.0), rotation=False, omega_rot=0.0,
+                 n_rotate=0, seed=None):
+        self.init_noise, self.inlet_noise = tuple(init_noise), tuple(inlet_noise)
+        self.rotation, self.omega_rot, self.n_rotate = bool(rotation), float(omega_rot), int(n_rotate)
+        self.seed = seed  # the reference draws unseeded random_number; a seed makes runs repeatable
+
+
+class ChannelCase(BaseCase):
+    """src/case/channel.f90: bulk velocity held at 2/3 by a shift of u, optional rotation forcing
+    for the first n_rotate iterations, no-slip y walls stamped after each sub-step.
+
+    The reference rebuilds the wall values on the host and uploads three full DIR_C blocks per
+    sub-step (:97-130); here the three wall fields live on the device, are zero-filled once when
+    inlet_noise = 0 (the example's setting) and only rewritten when noise is asked for."""
+
+    def __init__(self, solver, channel_cfg=None):
+        self.channel_cfg = channel_cfg or ChannelConfig()
+        self.rng = np.random.default_rng(self.channel_cfg.seed)
+        self.bc_start_y = None
+        super().__init__(solver)
+
+    def initial_conditions(self):  # :139-189
+        s, m = self.solver, self.solver.mesh
+        nx, ny, nz = m.get_dims(VERT)
+        y = m.vert_coords[1][None, :, None] - m.L[1] / 2.0
+        um = np.exp(-0.2 * y * y)
+        noise = [self.channel_cfg.inlet_noise[2]] * 3  # :154 takes inlet_noise(3) for all three
+        shape = (nz, ny, nx)
+        fields = []
+        for c, base in enumerate((1.0 - y * y, 0.0, 0.0)):
+            r = self.rng.random(shape) if noise[c] != 0.0 else 0.5
+            f = base + noise[c] * um * (2 * r - 1.0) * np.ones(shape)
+            f[:, 0, :] = 0.0
+            f[:, -1, :] = 0.0
+            fields.append(f)
+        for f, a in zip((s.u, s.v, s.w), fields):
+            f.set_data_loc(VERT)
+            s.backend.set_field_data(f, a)
+
+    def define_BC(self):  # :53-137
+        s, b = self.solver, self.solver.backend
+        ub = b.field_volume_integral(s.u) / float(np.prod(s.mesh.get_global_dims(CELL)))
+        b.field_shift(s.u, 2.0 / 3.0 - ub)
+        noise = self.channel_cfg.inlet_noise
+        first = self.bc_start_y is None
+        if first:
+            self.bc_start_y = [b.allocator.get_block(DIR_X, VERT) for _ in range(3)]
+            for f in self.bc_start_y:
+                f.set_data_loc(VERT)
+                f.fill(0.0)
+        if any(n != 0.0 for n in noise):
+            nx, ny, nz = s.mesh.get_dims(VERT)
+            for f, n in zip(self.bc_start_y, noise):
+                a = np.zeros((nz, ny, nx))
+                a[:, 0, :] = n * (2.0 * self.rng.random((nz, nx)) - 1.0)
+                a[:, -1, :] = n * (2.0 * self.rng.random((nz, nx)) - 1.0)
+                b.set_field_data(f, a)
+
+    def forcings(self, du, dv, dw, it):  # :191-207
+        c, s = self.channel_cfg, self.solver
+        if c.rotation and it < c.n_rotate:
+            s.backend.vecadd(-c.omega_rot, s.v, 1.0, du)
+            s.backend.vecadd(c.omega_rot, s.u, 1.0, dv)
+
+    def apply_BC(self, u, v, w):  # :214-231
+        b = self.solver.backend
+        for f, st in zip((u, v, w), self.bc_start_y):
+            b.field_set_face_from_field(f, st, 0.0, Y_FACE)

@@ -72,6 +72,7 @@ class Mesh:
         self.stretching = [str(s) for s in stretching]
         self.beta = np.array(beta, dtype=np.float64)
         self.stretched = [s != "uniform" for s in self.stretching]
+        self.alpha = np.zeros(3)  # geo%alpha, src/mesh_content.f90:166, 185
         self._obtain_coordinates()
 
     def is_root(self):
@@ -101,6 +102,7 @@ class Mesh:
                 raise X3dError("Invalid stretching type")
             L_inf = L / 2
             alpha = abs((L_inf - math.sqrt((pi * beta) ** 2 + L_inf ** 2)) / (2 * beta * L_inf))
+            self.alpha[dr] = alpha
             r = math.sqrt((alpha * beta + 1) / (alpha * beta))
             const = math.sqrt(beta) / (2 * math.sqrt(alpha) * math.sqrt(alpha * beta + 1))
             s = self.d[dr] / L

@@ -43,6 +43,113 @@ def wave_numbers(n, L, d, periodic, c_a, c_b, c_alpha):
     return a, b, k, e, k2
 
 
+def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs):
+    """src/poisson_fft.f90:275-652: pentadiagonal spectral operators for a stretched y
+    (JCP 228 (2009) 5989, Sec. 5).  Real and imaginary copies of the reference are equal
+    (every wave number is cmplx(1,1)*x), one copy is kept.  Layout [5][nz][n][nx_spec].
+    Entries the reference leaves unset or reads past ky(ny) for (never used by the solve)
+    are zero here."""
+    pi = 4 * np.arctan(1.0)
+    nxs, nys, nzs = pf.nx_spec, pf.ny_spec, pf.nz_spec
+
+    def transfer(t, e, d, n):
+        tmp = e[:n] * d
+        it = t.interpl_v2p
+        return 2 * (it.a * np.cos(tmp * 0.5) + it.b * np.cos(tmp * 1.5) + it.c * np.cos(tmp * 2.5)
+                    + it.d * np.cos(tmp * 3.5)) / (1.0 + 2 * it.alpha * np.cos(tmp))
+
+    tx = transfer(xd, exs, mesh.d[0], nxs)
+    ty = transfer(yd, eys, mesh.d[1], nys)
+    tz = transfer(zd, ezs, mesh.d[2], nzs)
+    pf.trans_x, pf.trans_y, pf.trans_z = tx, ty, tz
+    kyp = np.concatenate([pf.ky, np.zeros(4)])
+    TX, TZ = tx[None, None, :], tz[:, None, None]
+    KX, KZ = pf.kx[None, None, :nxs], pf.kz[:nzs, None, None]
+
+    def km(iy):  # get_km(ix, iy, iz), iy 1-based array -> [nz, len(iy), nx]
+        return (TX * kyp[np.asarray(iy) - 1][None, :, None]) * TZ
+
+    def tyv(iy):
+        return ty[np.asarray(iy) - 1][None, :, None]
+
+    kind = mesh.stretching[1]
+    L, beta, alpha = mesh.L[1], mesh.beta[1], mesh.alpha[1]
+    a0 = (alpha / pi + 1.0 / (2 * pi * beta)) * L
+    if kind == "bottom":
+        pf.stretched_y_sym = False
+        a1 = -1.0 / (4 * pi * beta) * L
+        n = nys
+        a = np.zeros((5, nzs, n, nxs))
+        iy = np.arange(1, n + 1)
+        K = km(iy)
+        kma = km(np.clip(iy - 1, 1, None)) + km(iy + 1)
+        kma[:, 0, :] = km([2])[:, 0, :]
+        kma[:, n - 1, :] = km([n - 1])[:, 0, :]
+        a[2] = -((KX * tyv(iy)) * TZ) ** 2 - ((KZ * tyv(iy)) * TX) ** 2 - a0 ** 2 * K ** 2 \
+            - (a1 ** 2 * K) * kma
+        a[3] = ((a0 * a1) * km(iy + 1)) * (K + km(iy + 1))
+        a[4, :, :n - 2] = (-(a1 * a1 * km(iy + 1)) * km(iy + 2))[:, :n - 2]
+        a[1, :, 1:] = (((a0 * a1) * km(np.clip(iy - 1, 1, None))) * (K + km(np.clip(iy - 1, 1, None))))[:, 1:]
+        a[0, :, 2:] = (-(a1 * a1 * km(np.clip(iy - 1, 1, None))) * km(np.clip(iy - 2, 1, None)))[:, 2:]
+        a[2, 0, 0, 0] = 1.0; a[3, 0, 0, 0] = 0.0; a[4, 0, 0, 0] = 0.0
+        pf.a_full = a
+        return
+    pf.stretched_y_sym = True
+    a1 = {"centred": 1.0, "top-bottom": -1.0}.get(kind, 0.0) / (4 * pi * beta) * L
+    n = nys // 2
+    j = np.arange(1, n + 1)
+    out = {}
+    for name, iyv in (("odd", 2 * j - 1), ("even", 2 * j)):
+        ev = name == "even"
+        a = np.zeros((5, nzs, n, nxs))
+        K = km(iyv)
+        Kp2, Kp4 = km(iyv + 2), km(iyv + 4)
+        Km2, Km4 = km(np.clip(iyv - 2, 1, None)), km(np.clip(iyv - 4, 1, None))
+        # diagonal
+        c1 = np.full(n, a0 * a0); c2 = np.full(n, a1 * a1)
+        kma = Km2 + Kp2
+        kma[:, 0, :] = km([4 if ev else 3])[:, 0, :]
+        kma[:, n - 1, :] = Km2[:, n - 1, :]
+        if ev:
+            c1[0] = a0 * a0 - a1 * a1
+            c1[n - 1] = (a0 + a1) * (a0 + a1)
+        C1, C2 = c1[None, :, None], c2[None, :, None]
+        a[2] = -((KX * tyv(iyv)) * TZ) ** 2 - ((KZ * tyv(iyv)) * TX) ** 2 - C1 * K ** 2 - (C2 * K) * kma
+        # diagonal + 1
+        c1 = np.full(n, a0 * a1); c2 = np.full(n, a0 * a1)
+        if ev:
+            if n >= 2:
+                c1[n - 2] = a0 * a1; c2[n - 2] = (a0 + a1) * a1
+            c1[n - 1] = 0.0; c2[n - 1] = 0.0
+            c1[0] = a0 * a1 - a1 * a1; c2[0] = a0 * a1
+        else:
+            c1[0] = 2 * a0 * a1; c2[0] = 2 * a0 * a1
+        C1, C2 = c1[None, :, None], c2[None, :, None]
+        a[3] = C1 * (K * Kp2) + C2 * Kp2 ** 2
+        # diagonal + 2
+        c1 = np.full(n, a1 * a1)
+        if not ev:
+            c1[0] = 2 * a1 * a1
+        a[4, :, :max(n - 2, 0)] = (-((c1[None, :, None] * Kp2) * Kp4))[:, :max(n - 2, 0)]
+        # diagonal - 1
+        c1 = np.full(n, a0 * a1); c2 = np.full(n, a0 * a1)
+        if ev:
+            c1[n - 1] = (a0 + a1) * a1; c2[n - 1] = a0 * a1
+            if n >= 2:
+                c1[1] = a0 * a1; c2[1] = (a0 + a1) * a1
+        C1, C2 = c1[None, :, None], c2[None, :, None]
+        a[1, :, 1:] = (C1 * (K * Km2) + C2 * Km2 ** 2)[:, 1:]
+        # diagonal - 2
+        a[0, :, 2:] = (-(((a1 * a1) * Km2) * Km4))[:, 2:]
+        out[name] = a
+    zero = (pf.k2x[:nxs][None, :] < 1e-15) & (pf.k2z[:nzs][:, None] < 1e-15)  # [nz, nx]
+    ao = out["odd"]
+    ao[2, :, 0, :][zero] = 1.0
+    ao[3, :, 0, :][zero] = 0.0
+    ao[4, :, 0, :][zero] = 0.0
+    pf.a_odd, pf.a_even = out["odd"], out["even"]
+
+
 def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
@@ -62,11 +169,24 @@ class HipPoissonFFT:
         self.periodic_x, self.periodic_y, self.periodic_z = mesh.periodic_BC
         if mesh.stretched[0] or mesh.stretched[2]:
             raise X3dError("FFT based Poisson solver does not support stretching in x- or z-directions!")
-        if not (self.periodic_x and self.periodic_y and self.periodic_z):
-            raise X3dError("HIP Poisson solver: only the all-periodic (000) case is implemented in this round")
+        # BC dispatch, src/poisson_fft.f90:171-203
+        if self.periodic_x and self.periodic_y and self.periodic_z:
+            self.case = "000"
+        elif self.periodic_x and (not self.periodic_y) and self.periodic_z:
+            if mesh.nproc > 1:
+                raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
+            self.case = "010"
+        elif self.periodic_z:
+            raise X3dError("HIP Poisson solver: the 100 / 110 cases are not implemented")
+        else:
+            raise X3dError("Requested BCs are not supported in FFT-based Poisson solver!")
         self.nx_spec, self.ny_spec, self.nz_spec = self.nx_glob // 2 + 1, self.ny_glob, self.nz_glob
         self.sp_st = (0, 0, 0)
+        self.stretched_y = False
         self._waves_set(mesh, xdirps, ydirps, zdirps)
+        if self.case == "010" and mesh.stretched[1]:
+            self.stretched_y = True
+            stretching_matrix(self, mesh, xdirps, ydirps, zdirps, *self._es)
         self._create()
 
     def _create(self):
@@ -81,7 +201,15 @@ class HipPoissonFFT:
             backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob),
             *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
         self.h = h
-        self.poisson = self.poisson_000
+        self.poisson = self.poisson_000 if self.case == "000" else self.poisson_010
+        if self.stretched_y:
+            if self.stretched_y_sym:
+                a0, a1 = self.a_odd, self.a_even
+            else:
+                a0, a1 = self.a_full, self.a_full
+            _lib.check(backend.lib.x3d_poisson_set_stretching(self.h, int(self.stretched_y_sym), dp(a0), dp(a1)))
+            if not getattr(self, "keep_matrices", False):  # GBs at production sizes; the device holds the factors
+                self.a_odd = self.a_even = self.a_full = None
 
     def __del__(self):
         try:
@@ -99,6 +227,7 @@ class HipPoissonFFT:
         self.az, self.bz, self.kz, ezs, k2z = wave_numbers(self.nz_glob, mesh.L[2], mesh.d[2],
                                                            self.periodic_z, sz.a, sz.b, sz.alpha)
         self.k2x, self.k2y, self.k2z = k2x, k2y, k2z
+        self._es = (eys, exs, ezs)
 
         def transfer(t, e, d):
             r = e * d
@@ -141,6 +270,24 @@ class HipPoissonFFT:
         self.fft_forward(f)
         self.fft_postprocess_000()
         self.fft_backward(f)
+
+    def fft_postprocess_010(self):
+        _lib.check(self.backend.lib.x3d_poisson_postprocess_010(self.h))
+
+    def enforce_periodicity_y(self, f_out, f_in):
+        _lib.check(self.backend.lib.x3d_poisson_enforce_periodicity_y(self.h, f_out.ptr, f_in.ptr))
+
+    def undo_periodicity_y(self, f_out, f_in):
+        _lib.check(self.backend.lib.x3d_poisson_undo_periodicity_y(self.h, f_out.ptr, f_in.ptr))
+
+    def poisson_010(self, f, temp):  # :228-242
+        if temp is None:
+            raise X3dError("poisson_010 needs a scratch block")
+        self.enforce_periodicity_y(temp, f)
+        self.fft_forward(temp)       # fft_forward_010 => fft_forward (src/backend/cuda/poisson_fft.f90:79-86)
+        self.fft_postprocess_010()
+        self.fft_backward(temp)
+        self.undo_periodicity_y(f, temp)
 
     def solve_poisson(self, f, temp):  # :206-214
         self.poisson(f, temp)

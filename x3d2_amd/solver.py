@@ -150,7 +150,7 @@ class Solver:
         # poisson: the cell-centred divergence is already Cartesian (no Z2C / C2Z)
         p = div
         if self.cfg.poisson_solver_type == "FFT":
-            b.poisson_fft.solve_poisson(p, None)
+            b.poisson_fft.solve_poisson(p, t2)  # t2 is free here: scratch of poisson_010
         else:
             p.fill(0.0)
         # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
