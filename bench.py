@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
+                    help="channel: BASELINE configs[4]-style wall-bounded case (1 GPU), dims from --dims")
+    ap.add_argument("--dims", default="1024,257,512", help="channel vertex dims nx,ny,nz")
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     args = ap.parse_args()
@@ -97,8 +100,17 @@ def main():
     nproc_dir = decomposition(args.gpus)
     dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()
-    case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
-                    poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular)
+    if args.case == "channel":
+        if args.gpus != 1:
+            raise SystemExit("channel: single GPU (the reference rejects non-periodic Poisson on >1 rank, "
+                             "src/poisson_fft.f90:177-180)")
+        from x3d2_amd import make_channel
+        dims = tuple(int(v) for v in args.dims.split(","))
+        case = make_channel(dims, time_intg=args.time_intg, poisson="CG" if args.no_poisson else "FFT",
+                            fused=not args.op_granular, rotation=True, omega_rot=0.12, n_rotate=5000, comm=comm)
+    else:
+        case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
+                        poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular)
     solver, backend = case.solver, case.solver.backend
     nstage = solver.time_integrator.nstage
 
@@ -126,7 +138,7 @@ def main():
         elapsed = float(t.item())
 
     dof_global = dims[0] * dims[1] * dims[2]
-    dof_local = args.n ** 3
+    dof_local = args.n ** 3 if args.case == "tgv" else dof_global
     value = dof_global * args.steps / elapsed
 
     # ---- roofline of the dominant kernel class: one transport-equation
@@ -171,22 +183,27 @@ def main():
                     432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
 
     out = {
-        "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step",
+        "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step" if args.case == "tgv"
+                  else "DoF*steps/s, channel (stretched y, 010 Poisson), full fractional step",
         "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"TGV {dims[0]}x{dims[1]}x{dims[2]} all-periodic, Re=1600, dt=1e-3, "
-                               f"{args.time_intg} ({nstage} substeps/step), compact6/classic schemes, "
+        "config": {"workload": (f"TGV {dims[0]}x{dims[1]}x{dims[2]} all-periodic, Re=1600, dt=1e-3, "
+                                if args.case == "tgv" else
+                                f"channel {dims[0]}x{dims[1]}x{dims[2]} verts, y Dirichlet + top-bottom "
+                                f"stretching, Re=4200, dt=5e-3, rotation forcing, ")
+                               + f"{args.time_intg} ({nstage} substeps/step), compact6/classic schemes, "
                                + ("no pressure solve (configs[1])" if args.no_poisson
-                                  else "rocFFT Poisson (configs[2])"),
-                   "per_gpu": f"{args.n}^3", "nproc_dir": list(nproc_dir),
+                                  else "rocFFT Poisson (configs[2])" if args.case == "tgv"
+                                  else "rocFFT Poisson 010, pentadiagonal spectral solve"),
+                   "per_gpu": f"{args.n}^3" if args.case == "tgv" else args.dims, "nproc_dir": list(nproc_dir),
                    "driver": "op-granular" if args.op_granular else "fused",
                    "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}"},
         "dof_substeps_per_s": value * nstage,
         "roofline": roofline,
         "kernel_ms": prof,
     }
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
     if rank == 0:
         print(json.dumps(out))

@@ -141,19 +141,19 @@ module m_hip_poisson_fft
     procedure :: fft_forward => fft_forward_hip
     procedure :: fft_backward => fft_backward_hip
     procedure :: fft_postprocess_000 => fft_postprocess_000_hip
-    procedure :: fft_forward_010 => fw_unsupported
+    procedure :: fft_forward_010 => fft_forward_hip
     procedure :: fft_forward_100 => fw_unsupported
     procedure :: fft_forward_110 => fw_unsupported
-    procedure :: fft_backward_010 => bw_unsupported
+    procedure :: fft_backward_010 => fft_backward_hip
     procedure :: fft_backward_100 => bw_unsupported
     procedure :: fft_backward_110 => bw_unsupported
-    procedure :: fft_postprocess_010 => pp_unsupported
+    procedure :: fft_postprocess_010 => fft_postprocess_010_hip
     procedure :: fft_postprocess_100 => pp_unsupported
     procedure :: fft_postprocess_110 => pp_unsupported
     procedure :: enforce_periodicity_x => fp_unsupported
     procedure :: undo_periodicity_x => fp_unsupported
-    procedure :: enforce_periodicity_y => fp_unsupported
-    procedure :: undo_periodicity_y => fp_unsupported
+    procedure :: enforce_periodicity_y => enforce_periodicity_y_hip
+    procedure :: undo_periodicity_y => undo_periodicity_y_hip
     procedure :: enforce_periodicity_xy => fp_unsupported
     procedure :: undo_periodicity_xy => fp_unsupported
   end type hip_poisson_fft_t
@@ -170,13 +170,22 @@ contains
     nspec = [dims(1)/2 + 1, dims(2), dims(3)]
     ! wave numbers and BC dispatch: the reference's own base_init (src/poisson_fft.f90:120-204)
     call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
-    if (.not. (self%periodic_x .and. self%periodic_y .and. self%periodic_z)) then
-      error stop 'hip shim: only the all-periodic (000) Poisson solver is available yet'
+    if (.not. (self%periodic_x .and. self%periodic_z)) then
+      error stop 'hip shim: the 100 / 110 Poisson solvers are not available yet'
     end if
     allocate (wre(nspec(1), nspec(2), nspec(3)))
     wre = real(self%waves, dp)
     call x3d_check(x3d_poisson_create(backend, self%handle, int(dims, c_int), wre, self%ax, self%bx, &
                                       self%ay, self%by, self%az, self%bz))
+    ! stretched y: hand over the real parts of the matrices base_init built
+    ! (src/poisson_fft.f90:275-652; imaginary parts are equal); factored once on the device
+    if (self%stretched_y) then
+      if (self%stretched_y_sym) then
+        call x3d_check(x3d_poisson_set_stretching(self%handle, 1_c_int, self%a_odd_re, self%a_even_re))
+      else
+        call x3d_check(x3d_poisson_set_stretching(self%handle, 0_c_int, self%a_re, self%a_re))
+      end if
+    end if
   end subroutine hip_poisson_fft_setup
 
   subroutine fft_forward_hip(self, f_in)
@@ -192,6 +201,22 @@ contains
   subroutine fft_postprocess_000_hip(self)
     class(hip_poisson_fft_t) :: self
     call x3d_check(x3d_poisson_postprocess_000(self%handle))
+  end subroutine
+  subroutine fft_postprocess_010_hip(self)
+    class(hip_poisson_fft_t) :: self
+    call x3d_check(x3d_poisson_postprocess_010(self%handle))
+  end subroutine
+  subroutine enforce_periodicity_y_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_enforce_periodicity_y(self%handle, dev(f_out), dev(f_in)))
+  end subroutine
+  subroutine undo_periodicity_y_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_undo_periodicity_y(self%handle, dev(f_out), dev(f_in)))
   end subroutine
   subroutine fw_unsupported(self, f_in)
     class(hip_poisson_fft_t) :: self

@@ -226,6 +226,28 @@ module m_x3d2_hip_capi
       import :: c_ptr, c_int
       type(c_ptr), value :: p, f_out
     end function
+    ! non-periodic y (010)
+    integer(c_int) function x3d_poisson_enforce_periodicity_y(p, f_out, f_in) &
+      bind(C, name='x3d_poisson_enforce_periodicity_y')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out, f_in
+    end function
+    integer(c_int) function x3d_poisson_undo_periodicity_y(p, f_out, f_in) &
+      bind(C, name='x3d_poisson_undo_periodicity_y')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out, f_in
+    end function
+    integer(c_int) function x3d_poisson_set_stretching(p, sym, a0, a1) &
+      bind(C, name='x3d_poisson_set_stretching')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: p
+      integer(c_int), value :: sym
+      real(c_double), intent(in) :: a0(*), a1(*)
+    end function
+    integer(c_int) function x3d_poisson_postprocess_010(p) bind(C, name='x3d_poisson_postprocess_010')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+    end function
   end interface
 
 contains

@@ -184,3 +184,27 @@ def test_channel_steps_with_poisson_vs_oracle(stretching, beta, fused):
     assert abs(ens - eo[0]) < 1e-10 * abs(eo[0])
     # div u after the projection: the residual the reference algorithm itself leaves
     assert abs(dmax - eo[1]) < 1e-6 * eo[1] + 1e-13 and dmax < 1e-6
+
+
+def test_unchanged_reference_channel_case_through_fortran_shim(tmp_path):
+    """fortran/_build/xcompact_hip: the reference's own channel case (case/channel.f90, solver.f90,
+    poisson_fft.f90 incl. stretching_matrix) on the HIP backend with the 010 FFT Poisson solve --
+    a configuration the reference itself only supports on its CUDA backend.  Its monitoring.csv
+    must agree with the Python host driver of this package on the same library."""
+    import os
+    import subprocess
+    from x3d2_amd import make_channel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "xcompact_hip")
+    if not os.path.exists(exe):
+        pytest.skip("shim binary not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, os.path.join(root, "fortran", "channel33.x3d")], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = np.loadtxt(tmp_path / "monitoring.csv", delimiter=",", comments="#")
+    case = make_channel((32, 33, 16), rotation=True, omega_rot=0.12, n_rotate=3)
+    case.solver.n_output = 2
+    mine = np.array(case.run(n_iters=6))
+    assert rows.shape[0] == mine.shape[0] == 4
+    assert np.allclose(rows[:, 1], mine[:, 1], rtol=1e-11, atol=0), (rows[:, 1], mine[:, 1])
+    assert np.all(rows[1:, 2] < 1e-5) and np.allclose(rows[1:, 2], mine[1:, 2], rtol=1e-3)
