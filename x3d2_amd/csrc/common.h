@@ -112,6 +112,7 @@ struct x3d_tdsops {
     int n_tds, n_rhs, move, periodic;
     double *dev;  // one allocation holding all tables
     TdsTab tab;
+    double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
 };
 
 PencilGeom x3d_geom(const x3d_backend *b, int dir);

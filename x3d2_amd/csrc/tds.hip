@@ -80,6 +80,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     memcpy(Cs + 72, coeffs, sizeof(double) * 9);
 
     x3d_tdsops *t = new x3d_tdsops();
+    for (int m = 0; m < 9; m++) t->coeffs[m] = coeffs[m];
     t->b = b; t->n_tds = n; t->n_rhs = nr; t->move = move; t->periodic = periodic;
     // device image: interleaved row records (common.h) so that one wide scalar
     // load serves a row: RF[4j..] = F A W PF ; RB[8j..] = Bw Sa Sc St Stc QB - - ; then Cs

@@ -16,6 +16,10 @@
 // Row tables live in LDS as [entry][lane] (conflict-free ds_read_b64).
 #include "common.h"
 
+#ifndef XSCAN_EXP
+#define XSCAN_EXP 0  // timing experiments only (1: no stores, 2: no loads, 3: no scans)
+#endif
+
 int npmax_of(const x3d_backend *b);
 
 // lane-table entry indices (per operator): 8*Q row entries then the scan multipliers
@@ -36,12 +40,16 @@ int npmax_of(const x3d_backend *b);
 struct XOp {
     const double *TL, *Cs;
     double last_r, rs_s, rs_e, sa1, scn;
+    double c[9];  // bulk stencil by value: kernel arguments live in SGPRs (a load through Cs would be a
+                  // VMEM load per pencil and operator, the stores may alias it)
     int n_tds, n_rhs, bulk_only;
 };
 static XOp xop_of(const x3d_tdsops *t)
 {
     const TdsTab &b = t->tab;
-    return XOp{b.TL, b.Cs, b.last_r, b.rs_s, b.rs_e, b.sa1, b.scn, b.n_tds, b.n_rhs, b.bulk_only};
+    XOp o{b.TL, b.Cs, b.last_r, b.rs_s, b.rs_e, b.sa1, b.scn, {0}, b.n_tds, b.n_rhs, b.bulk_only};
+    for (int m = 0; m < 9; m++) o.c[m] = t->coeffs[m];
+    return o;
 }
 
 __device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
@@ -74,9 +82,8 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
 #define PHASE(x) asm volatile("" : "+v"(lane) : "v"(x))
     const int nr = t.n_rhs, n = t.n_tds;
-    const double *__restrict__ cb = t.Cs + 72;
-    const double c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3], c4 = cb[4], c5 = cb[5], c6 = cb[6], c7 = cb[7],
-                 c8 = cb[8];
+    const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
+                 c7 = t.c[7], c8 = t.c[8];
     double acc[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++)
@@ -104,9 +111,13 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     // ---- scan of the lane-end values, then carry-in = true e at the end of lane l-1
     double v = prev;
     PHASE(X[Q / 2]);
+#if XSCAN_EXP == 3
+    double carry = v;
+#else
 #pragma unroll
     for (int k = 0; k < 6; k++) v += lt[LT_MF(k) * 64 + lane] * shfl_up_d(v, 1 << k, lane);
     double carry = shfl_up_d(v, 1, lane);
+#endif
     // ---- apply, lane-local back-substitution from zero
     double nxt = 0.0;
     PHASE(carry);
@@ -118,9 +129,13 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     if (n == nr) {}  // (row n_rhs = n+1 of a v2p operator carries F = H = 0 in the tables)
     v = nxt;
     PHASE(X[Q / 2]);
+#if XSCAN_EXP == 3
+    carry = v;
+#else
 #pragma unroll
     for (int k = 0; k < 6; k++) v += lt[LT_MB(k) * 64 + lane] * shfl_down_d(v, 1 << k, lane);
     carry = shfl_down_d(v, 1, lane);
+#endif
 #pragma unroll
     for (int q = 0; q < Q; q++) X[q] = X[q] + lt[LT_QB(q) * 64 + lane] * carry;
     // du_1 = last_r * X_1 (X_1 = e_1 - bw_1 X_2, distributed.f90:161-166); X_n = e_n
@@ -160,6 +175,92 @@ __device__ __forceinline__ void load_window_exact(double (&w)[Q + 8], const doub
     w[Q + 4] = b0.x; w[Q + 5] = b0.y; w[Q + 6] = b1.x; w[Q + 7] = b1.y;
 }
 
+// FAST path: only the lane's own Q rows come from memory (4 aligned 16-byte loads, issued one
+// pencil ahead); the 4+4 halo rows are the neighbour lanes' rows (periodic wrap across the wave)
+template <int Q>
+__device__ __forceinline__ void load_body(double (&b)[Q], const double *__restrict__ row, int lane)
+{
+    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
+#pragma unroll
+    for (int m = 0; m < Q / 2; m++) {
+        const double2 t2 = body[m];
+        b[2 * m] = t2.x;
+        b[2 * m + 1] = t2.y;
+    }
+}
+template <int Q>
+__device__ __forceinline__ void window_from_body(double (&w)[Q + 8], const double (&b)[Q], int lane)
+{
+    const int lp = (lane + 63) & 63, ln = (lane + 1) & 63;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        w[m] = __shfl(b[Q - 4 + m], lp, 64);
+        w[Q + 4 + m] = __shfl(b[m], ln, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) w[4 + q] = b[q];
+}
+
+// ---- stores: a lane owns Q = 8 consecutive rows (64 B).  Storing them as four 16-byte pieces makes
+// every store instruction touch 16 B of each 64-byte sector (measured: the kernel then runs at
+// 3.2 TB/s); a 4x4 transpose of the 16-byte pairs inside each quad of lanes lets every instruction
+// write whole 64-byte sectors instead (5.0 TB/s).  T_j[m] = P_m[j]: rotate left by j, quad_perm
+// DPP by the register index, rotate left by j again, read out reversed.
+__device__ __forceinline__ double dpp_quad(double v, int k)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (k == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x93, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x93, 0xf, 0xf, false); }
+    if (k == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    if (k == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x39, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x39, 0xf, 0xf, false); }
+    return __hiloint2double(hi, lo);
+}
+// (scalars, not arrays: LLVM turns `c ? a[i] : a[k]` into a dynamically indexed stack array)
+__device__ __forceinline__ void rotl_pairs(double &a0, double &a1, double &b0, double &b1, double &c0, double &c1,
+                                           double &d0, double &d1, int j)
+{
+    const bool r1 = j & 1, r2 = j & 2;
+    double t0 = a0, t1 = a1;  // rotate left by one pair where r1
+    a0 = r1 ? b0 : a0; a1 = r1 ? b1 : a1;
+    b0 = r1 ? c0 : b0; b1 = r1 ? c1 : b1;
+    c0 = r1 ? d0 : c0; c1 = r1 ? d1 : c1;
+    d0 = r1 ? t0 : d0; d1 = r1 ? t1 : d1;
+    t0 = a0; t1 = a1;         // by two pairs where r2
+    a0 = r2 ? c0 : a0; a1 = r2 ? c1 : a1;
+    c0 = r2 ? t0 : c0; c1 = r2 ? t1 : c1;
+    t0 = b0; t1 = b1;
+    b0 = r2 ? d0 : b0; b1 = r2 ? d1 : b1;
+    d0 = r2 ? t0 : d0; d1 = r2 ? t1 : d1;
+}
+// out row = orow[0 .. 64*8): lane l holds r[0..8) = rows 8l .. 8l+7
+template <bool ACC>
+__device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lane, const double (&r)[8],
+                                              double scale)
+{
+    const int j = lane & 3;
+    double a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3], c0 = r[4], c1 = r[5], d0 = r[6], d1 = r[7];
+    rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
+    b0 = dpp_quad(b0, 1); b1 = dpp_quad(b1, 1);
+    c0 = dpp_quad(c0, 2); c1 = dpp_quad(c1, 2);
+    d0 = dpp_quad(d0, 3); d1 = dpp_quad(d1, 3);
+    rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
+    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + (lane & ~3) * 8) + j;
+    // instruction m stores T[m] = D[(-m) & 3]: D[0] = a, D[3] = d, D[2] = c, D[1] = b
+    double2 v0, v1, v2, v3;
+    if (ACC) {
+        v0 = o2[0]; v1 = o2[4]; v2 = o2[8]; v3 = o2[12];
+        v0.x += scale * a0; v0.y += scale * a1;
+        v1.x += scale * d0; v1.y += scale * d1;
+        v2.x += scale * c0; v2.y += scale * c1;
+        v3.x += scale * b0; v3.y += scale * b1;
+    } else {
+        v0.x = a0; v0.y = a1; v1.x = d0; v1.y = d1; v2.x = c0; v2.y = c1; v3.x = b0; v3.y = b1;
+    }
+    o2[0] = v0; o2[4] = v1; o2[8] = v2; o2[12] = v3;
+}
+
 template <int Q>
 __device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__restrict__ row, int first, int nr,
                                             int n_wrap, bool interior)
@@ -193,11 +294,21 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
     const int first = lane * Q + 1;
     const bool interior = first - 4 >= 1 && first + Q + 3 <= nr;
     const bool exact = FAST || (nr == 64 * Q && n_wrap == nr);
-    for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
+    const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
+    double nb[Q];  // FAST: next pencil's rows, in flight while this one is solved
+    if (FAST && p0 < np) load_body<Q>(nb, u + (long)p0 * pitch, lane);
+    for (int p = p0; p < np; p += nwaves) {
         const double *__restrict__ row = u + (long)p * pitch;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop (no 150-VGPR hoist)
         double w[Q + 8], X[Q], du1, xn;
-        if (FAST || exact) load_window_exact<Q>(w, row, lane, nr);
+        if (FAST) {
+            window_from_body<Q>(w, nb, lane);
+#if XSCAN_EXP == 2
+            for (int q = 0; q < Q; q++) nb[q] = nb[q] * 1.0000001 + lane;
+#else
+            if (p + nwaves < np) load_body<Q>(nb, u + (long)(p + nwaves) * pitch, lane);
+#endif
+        } else if (exact) load_window_exact<Q>(w, row, lane, nr);
         else load_window<Q>(w, row, first, nr, n_wrap, interior);
         scan_solve<Q, FAST>(w, X, du1, xn, lt, t, lane, first);
         const double du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
@@ -212,7 +323,12 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
             r[q] = (j == 1) ? du_s * st : r[q];
             r[q] = (j == n) ? du_e * st : r[q];
         }
-        if (FAST || (exact && n == nr)) {
+#if XSCAN_EXP == 1
+        if (r[0] != 12345.678) continue;
+#endif
+        if (FAST && Q == 8) {
+            if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, scale);
+        } else if (FAST || (exact && n == nr)) {
             double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) {
@@ -252,12 +368,35 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
     const int first = lane * Q + 1;
     const bool interior = first - 4 >= 1 && first + Q + 3 <= n;
     const double *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
-    for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
+    const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
+    double nbu[Q], nbc[Q];  // FAST: next pencil's rows of u and conv, in flight during the solve
+    if (FAST && p0 < np) {
+        load_body<Q>(nbu, u + (long)p0 * pitch, lane);
+        if (!SAME) load_body<Q>(nbc, cv + (long)p0 * pitch, lane);
+    }
+    for (int p = p0; p < np; p += nwaves) {
         const double *__restrict__ ru = u + (long)p * pitch;
         const double *__restrict__ rc = cv + (long)p * pitch;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
         double wu[Q + 8], wp[Q + 8], vq[Q];
         const bool exact = FAST || n == 64 * Q;
+        if (FAST) {
+            window_from_body<Q>(wu, nbu, lane);
+            if (!SAME) {
+                window_from_body<Q>(wp, nbc, lane);
+#pragma unroll
+                for (int q = 0; q < Q; q++) vq[q] = nbc[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; q++) vq[q] = nbu[q];
+            }
+            if (p + nwaves < np) {
+                load_body<Q>(nbu, u + (long)(p + nwaves) * pitch, lane);
+                if (!SAME) load_body<Q>(nbc, cv + (long)(p + nwaves) * pitch, lane);
+            }
+#pragma unroll
+            for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
+        } else {
         if (exact) load_window_exact<Q>(wu, ru, lane, n);
         else load_window<Q>(wu, ru, first, n, n, interior);
         if (SAME) {
@@ -272,6 +411,7 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
             for (int q = 0; q < Q; q++) vq[q] = wp[q + 4];
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];  // ud = u*conv incl. halo products
+        }
         }
         // one operator at a time, substituted at once (distributed.f90:304-335 written per operator:
         // rows 1 and n take du_s*st / du_e*st, which is what the general formula gives with these temps)
@@ -302,7 +442,9 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] += nu * T[q];
         double *__restrict__ orow = rhs + (long)p * pitch;
-        if (exact) {
+        if (FAST && Q == 8) {
+            if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, 1.0);
+        } else if (exact) {
             double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) {
