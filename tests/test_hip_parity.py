@@ -421,3 +421,49 @@ def test_optional_kernel_families_pass_the_same_parity_tests(env):
                         "tds_solve_all or transeq_div_grad or fused_transeq_and_time"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_fft512_strided_passes_and_fused_z_pass():
+    """ny = nz = 512 switches the single-rank Poisson solver to its own strided 512-point FFT kernels
+    (csrc/fft512.hip: y pass, and z forward + process_spectral_000 + z backward in one kernel).
+    (1) fft_forward against numpy's FFT, (2) the fused solve against the unfused hooks and against
+    the rocFFT-only path (X3D_NO_FFT512=1) on the same input, (3) the oracle's spectral operator."""
+    import os
+    import subprocess
+    import sys
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims = (20, 512, 512)
+    twopi = 6.283185307179586
+    mesh = Mesh(dims, (1, 1, 1), (twopi,) * 3, ("periodic",) * 2, ("periodic",) * 2, ("periodic",) * 2)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig())
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((512, 512, 20))
+    blk = al.get_block(DIR_C, CELL)
+    b.set_field_data(blk, f, CELL)
+    pf.fft_forward(blk)
+    ref = np.fft.rfftn(f, axes=(0, 1, 2))
+    assert relerr(pf.get_spectral(), ref) < 1e-13
+    pf.fft_postprocess_000()
+    pf.fft_backward(blk)
+    unfused = b.get_field_data(blk, CELL)
+    b.set_field_data(blk, f, CELL)
+    pf.solve_poisson(blk, None)
+    fused = b.get_field_data(blk, CELL)
+    assert relerr(fused, unfused) < 1e-13
+    om = orc.Mesh(list(dims), [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
+    osol = orc.Solver(om, poisson="FFT").poisson_fft.solve(f)
+    assert relerr(fused, osol) < 1e-11
+    if os.environ.get("X3D_NO_FFT512") != "1":  # same test on the rocFFT-only path
+        np.save("/tmp/x3d_fft512_fused.npy", fused)
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
+                            "fft512_strided"], env=dict(os.environ, X3D_NO_FFT512="1"), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+    else:
+        other = np.load("/tmp/x3d_fft512_fused.npy")
+        assert relerr(fused, other) < 1e-12

@@ -1,0 +1,260 @@
+// 512-point complex FFTs along a strided axis of the spectral array c[nz][ny][nxs]
+// (kernel family K5f), replacing rocFFT's strided column passes in the single-rank Poisson solve:
+//   src/backend/omp/poisson_fft.f90:89-97, 129-137   fft_forward / fft_backward (unnormalised DFT,
+//                                                    forward e^{-i}; 2decomp&FFT / cuFFT there)
+//   src/backend/omp/kernels/spectral_processing.f90:7-106 process_spectral_000 (fused into the z pass)
+//
+// A workgroup (8 waves) owns 8 x-adjacent modes (128 contiguous bytes per row) x 512 points along
+// the axis.  Rows are loaded cooperatively (8 rows x 128 B per wave instruction) into an LDS tile
+// [mode][point]; wave w then transforms pencil w entirely on chip: lane l holds points l + 64 k,
+// three radix-8 passes (512 = 8 x 8 x 8) with two in-LDS exchanges, natural-order output in the same
+// register layout.  For the z axis the forward transform, the spectral division and the backward
+// transform are done in ONE kernel: the spectrum is read once and written once (2 passes instead
+// of 6 + the 1.5 of a separate process_spectral_000).
+#include "common.h"
+
+#define FP 584  // LDS pitch per pencil in double2 (= 8 mod 16: the 8 modes of a row go to different banks)
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// 8-point DFT, decimation in frequency, natural-order output.  S = -1 forward, +1 backward.
+template <int S>
+__device__ __forceinline__ void fft8(double2 (&a)[8])
+{
+    const double h = 0.70710678118654752440;
+    double2 b[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        b[k] = cadd(a[k], a[k + 4]);
+        b[k + 4] = csub(a[k], a[k + 4]);
+    }
+    // b[4+k] *= W8^k: W8^1 = (1 + S i)/sqrt2, W8^2 = S i, W8^3 = (-1 + S i)/sqrt2
+    {
+        double2 t = b[5];
+        b[5] = make_double2(h * (t.x - S * t.y), h * (t.y + S * t.x));
+        t = b[6];
+        b[6] = make_double2(-S * t.y, S * t.x);
+        t = b[7];
+        b[7] = make_double2(h * (-t.x - S * t.y), h * (-t.y + S * t.x));
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o += 4) {
+        const double2 c0 = cadd(b[o], b[o + 2]), c1 = cadd(b[o + 1], b[o + 3]), c2 = csub(b[o], b[o + 2]);
+        const double2 d = csub(b[o + 1], b[o + 3]);
+        const double2 c3 = make_double2(-S * d.y, S * d.x);  // * W4^1 = S i
+        const int r = o ? 1 : 0;
+        a[r] = cadd(c0, c1);
+        a[r + 4] = csub(c0, c1);
+        a[r + 2] = cadd(c2, c3);
+        a[r + 6] = csub(c2, c3);
+    }
+}
+
+// W512^e for the transform direction S; tw holds the first half, W^(e+256) = -W^e
+template <int S>
+__device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int e)
+{
+    double2 w = tw[e & 255];
+    const double sg = (e & 256) ? -1.0 : 1.0;
+    return make_double2(sg * w.x, (S > 0 ? -sg : sg) * w.y);
+}
+
+// one pencil per wave: in/out a[k] = point l + 64 k; pen = this wave's LDS region (FP double2)
+template <int S>
+__device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict__ pen,
+                                            const double2 *__restrict__ tw, int l)
+{
+    // pass A: over n1 (stride 64), twiddle W512^(l k1)
+    fft8<S>(a);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) {
+        a[k1] = cmul(a[k1], twiddle<S>(tw, l * k1));
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) pen[k1 * 72 + l] = a[k1];
+    // no barrier: the region belongs to this wave alone and a wave's LDS operations execute in order
+    // pass B: lane (k1 = l >> 3, b = l & 7) takes T1[k1][b + 8 a], twiddle W64^(b q1) = W512^(8 b q1)
+    {
+        const int k1 = l >> 3, b = l & 7;
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = pen[k1 * 72 + b + 8 * q];
+        fft8<S>(a);
+#pragma unroll
+        for (int q1 = 1; q1 < 8; q1++) {
+            a[q1] = cmul(a[q1], twiddle<S>(tw, 8 * b * q1));
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) pen[(k1 * 8 + q1) * 9 + b] = a[q1];
+    }
+    // pass C: lane (k1 = l & 7, q1 = l >> 3) takes T2[k1][q1][b]; output X[k1 + 8 q1 + 64 q2] = X[l + 64 q2]
+    {
+        const int k1 = l & 7, q1 = l >> 3;
+#pragma unroll
+        for (int b = 0; b < 8; b++) a[b] = pen[(k1 * 8 + q1) * 9 + b];
+        fft8<S>(a);
+    }
+}
+
+struct Spec000 {
+    const double *waves, *ax, *bx, *ay, *by, *az, *bz;
+    int nx, ny, nz;
+};
+
+// MODE 0: forward, MODE 1: backward, MODE 2: forward + process_spectral_000 + backward (z axis only)
+template <int MODE, int NP>
+__global__ void __launch_bounds__(64 * NP, 16 / NP)
+    k_fft512(double2 *__restrict__ c, const double2 *__restrict__ twg, long stride_axis, long stride_other,
+             int nxs, Spec000 sp)
+{
+    extern __shared__ double2 tile[];  // [NP][FP] + 256 twiddles
+    double2 *__restrict__ tws = tile + NP * FP;
+    if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * NP, m = tid & (NP - 1), r = tid / NP;
+    const long base = (long)blockIdx.y * stride_other + i0;
+    const bool valid = i0 + m < nxs;
+    // ---- cooperative load: NP * 16 contiguous bytes per row
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int z = it * 64 + r;
+        tile[m * FP + z] = valid ? c[base + (long)z * stride_axis + m] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double2 *__restrict__ pen = tile + w * FP;
+    double2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = pen[l + 64 * k];
+    __syncthreads();
+    if (MODE == 1) fft512_wave<1>(a, pen, tws, l);
+    else fft512_wave<-1>(a, pen, tws, l);
+    if (MODE == 2) {
+        // natural order back to the tile, spectral division in the row-cooperative layout (waves is
+        // read as 64 contiguous bytes per row), then the backward transform
+#pragma unroll
+        for (int k = 0; k < 8; k++) pen[l + 64 * k] = a[k];
+        __syncthreads();
+        const int j = blockIdx.y, i = i0 + m;
+        if (valid) {
+            const double ayj = sp.ay[j], byj = sp.by[j], axi = sp.ax[i], bxi = sp.bx[i];
+            // the reference divides by nx, ny, nz and by waves per element (8 FP64 divisions); here one
+            // reciprocal of the product and one of waves: <= 2 ulp apart, far inside the parity tolerance
+            const double rn = 1.0 / sp.nx / sp.ny / sp.nz;
+            const bool fy = (j + 1) > sp.ny / 2 + 1;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int k = it * 64 + r;
+                double2 v = tile[m * FP + k];
+                // src/backend/omp/kernels/spectral_processing.f90:36-99, same order as k_process_spectral_000
+                double div_r = v.x * rn, div_c = v.y * rn;
+                const double azk = sp.az[k], bzk = sp.bz[k];
+                const bool fz = (k + 1) > sp.nz / 2 + 1;
+                double tr, tc;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+                const double wv = sp.waves[((size_t)k * sp.ny + j) * nxs + i];
+                const double rw = wv < 1.e-16 ? 0.0 : -1.0 / wv;
+                div_r = div_r * rw; div_c = div_c * rw;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+                tile[m * FP + k] = make_double2(div_r, div_c);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = pen[l + 64 * k];
+        __syncthreads();
+        fft512_wave<1>(a, pen, tws, l);
+    }
+    // ---- natural order back to the tile, cooperative store
+#pragma unroll
+    for (int k = 0; k < 8; k++) pen[l + 64 * k] = a[k];
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int z = it * 64 + r;
+            c[base + (long)z * stride_axis + m] = tile[m * FP + z];
+        }
+    }
+}
+
+static double2 *g_tw = nullptr;  // W512^k = exp(-2 pi i k / 512), first half, shared by all plans
+
+template <int MODE, int NP>
+static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_other, int nxs, int nother,
+                     const Spec000 &sp)
+{
+    static bool attr = false;
+    const int lds = sizeof(double2) * (NP * FP + 256);
+    if (!attr) {
+        X3D_HIP(hipFuncSetAttribute((const void *)k_fft512<MODE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds));
+        attr = true;
+    }
+    dim3 grid((nxs + NP - 1) / NP, nother);
+    hipLaunchKernelGGL((k_fft512<MODE, NP>), grid, dim3(64 * NP), lds, b->stream, c, g_tw, stride_axis,
+                       stride_other, nxs, sp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_fft512_init()
+{
+    if (g_tw) return 0;
+    std::vector<double2> h(256);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < 256; k++) {
+        const long double t = -2.0L * pi * k / 512.0L;
+        h[k] = make_double2((double)cosl(t), (double)sinl(t));
+    }
+    X3D_HIP(hipMalloc(&g_tw, sizeof(double2) * 256));
+    X3D_HIP(hipMemcpy(g_tw, h.data(), sizeof(double2) * 256, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// axis: 1 = y (ny must be 512), 2 = z (nz must be 512); mode 0 fwd, 1 bwd, 2 fused z pass
+int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
+                   const double *ab, int nx)
+{
+    const long sy = nxs, sz = (long)nxs * ny;
+    const long stride_axis = axis == 1 ? sy : sz, stride_other = axis == 1 ? sz : sy;
+    const int nother = axis == 1 ? nz : ny;
+    X3D_REQUIRE((axis == 1 ? ny : nz) == 512, "x3d_fft512_run: axis length must be 512");
+    X3D_REQUIRE(mode != 2 || axis == 2, "x3d_fft512_run: the fused pass is the z pass");
+    Spec000 sp{};
+    if (mode == 2) {
+        const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+        sp = Spec000{waves, ax, bx, ay, by, az, bz, nx, ny, nz};
+    }
+    static int wide = -1;  // rows of 256 B (16 modes, one 16-wave workgroup per CU) instead of 128 B
+    if (wide < 0) {
+        const char *e = getenv("X3D_FFT512_WIDE");
+        wide = e ? atoi(e) : 1;  // measured: y pass 0.53 vs 0.58 ms with 16 modes, z pass 0.90 vs 0.96 with 8
+    }
+    const bool w16 = (wide & axis) != 0;  // bit 0: y pass, bit 1: z pass
+    ProfScope ps(b, mode == 2 ? X3D_K_SPECTRAL : X3D_K_FFT, axis);
+#define GO(M_)                                                                                             \
+    (w16 ? launch512<M_, 16>(b, c, stride_axis, stride_other, nxs, nother, sp)                             \
+         : launch512<M_, 8>(b, c, stride_axis, stride_other, nxs, nother, sp))
+    if (mode == 0) return GO(0);
+    if (mode == 1) return GO(1);
+    return GO(2);
+#undef GO
+}

@@ -24,7 +24,14 @@ struct x3d_poisson {
     // stretched y (010): factored pentadiagonal operators, [5][nz][n][nxs] each
     int stretched, sym;   // sym: odd/even rows decoupled (centred, top-bottom); else one full system
     double *lu[2];        // sym: odd, even; else lu[0] only
+    // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
+    int fast512;
+    hipfftHandle plan_x_fw, plan_x_bw;
 };
+
+int x3d_fft512_init();
+int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
+                   const double *ab, int nx);
 
 #define X3D_FFT(expr)                                                                          \
     do {                                                                                       \
@@ -123,6 +130,17 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
     if (p->work_size) X3D_HIP(hipMalloc(&p->work, p->work_size));
     X3D_FFT(hipfftSetWorkArea(p->plan_fw, p->work));
     X3D_FFT(hipfftSetWorkArea(p->plan_bw, p->work));
+    const char *no512 = getenv("X3D_NO_FFT512");
+    if (p->ny == 512 && p->nz == 512 && !(no512 && no512[0] == '1')) {
+        // batched 1-D r2c / c2r along x straight on the pitched block (rows nxp apart -> nxs complex)
+        int nn[1] = {p->nx}, re[1] = {b->nxp}, ce[1] = {p->nxs};
+        const int batch = p->ny * p->nz;
+        X3D_REQUIRE(b->nyp == p->ny, "x3d_poisson_create: fast path needs nyp == ny");
+        X3D_FFT(hipfftPlanMany(&p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, batch));
+        X3D_FFT(hipfftPlanMany(&p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch));
+        if (int rc = x3d_fft512_init()) return rc;
+        p->fast512 = 1;
+    }
     *out = p;
     return 0;
 }
@@ -132,6 +150,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     if (!p) return 0;
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
+    if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
     hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
     hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
@@ -141,6 +160,15 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
 extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
+    if (p->fast512) {
+        {
+            ProfScope ps(p->b, X3D_K_FFT, 1);
+            X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c));
+        }
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
+        return x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 0, nullptr, nullptr, p->nx);
+    }
     ProfScope ps(p->b, X3D_K_FFT, 1);
     X3D_FFT(hipfftSetStream(p->plan_fw, p->b->stream));
     X3D_FFT(hipfftExecD2Z(p->plan_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c));
@@ -163,6 +191,14 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
 {
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
+    if (p->fast512) {
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 1, nullptr, nullptr, p->nx)) return rc;
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
+        ProfScope ps(p->b, X3D_K_FFT, 2);
+        X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
+        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f_out));
+        return 0;
+    }
     ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_bw, p->b->stream));
     X3D_FFT(hipfftExecZ2D(p->plan_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f_out));
@@ -171,6 +207,21 @@ extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
 
 extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
 {
+    X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
+    if (p->fast512) {  // x r2c ; y ; z forward + process_spectral_000 + z backward in one pass ; y ; x c2r
+        {
+            ProfScope ps(p->b, X3D_K_FFT, 1);
+            X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
+        }
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 2, p->waves, p->ab, p->nx)) return rc;
+        if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
+        ProfScope ps(p->b, X3D_K_FFT, 2);
+        X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
+        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f));
+        return 0;
+    }
     if (int rc = x3d_poisson_fft_forward(p, f)) return rc;
     if (int rc = x3d_poisson_postprocess_000(p)) return rc;
     return x3d_poisson_fft_backward(p, f);
