@@ -467,3 +467,63 @@ def test_fft512_strided_passes_and_fused_z_pass():
     else:
         other = np.load("/tmp/x3d_fft512_fused.npy")
         assert relerr(fused, other) < 1e-12
+
+
+@pytest.mark.parametrize("nx", [512, 256, 128, 192, 500])
+def test_x_direction_scan_kernels_full_size_pencils(nx):
+    """the wave-per-pencil x kernels (csrc/xscan.hip) only engage for pencils of 64*Q points
+    (FAST path: 512 -> Q = 8 with prefetch / shuffled halos / quad-transposed stores, 256 -> Q = 4)
+    or, generic path, any n <= 512 that 64 lanes cover (192, 500); 128 uses the LDS-tiled kernels.
+    Every x operator, transeq_x, and the fused driver's accumulating forms against the oracle."""
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import DIR_X, VERT, move_data_loc
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims = (nx, 12, 10)
+    L = (6.283185307179586, 2.0, 3.0)
+    per = ("periodic",) * 2
+    mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True))
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
+    o = orc.Solver(om, poisson="CG")
+    rng = np.random.default_rng(nx)
+    b, al = s.backend, s.backend.allocator
+    fields = []
+    for fo, fp in ((o.u, s.u), (o.v, s.v), (o.w, s.w)):
+        a = rng.standard_normal((10, 12, nx))
+        fo.data_loc = orc.VERT
+        o.backend.set_field_data(fo, a)
+        fp.set_data_loc(VERT)
+        b.set_field_data(fp, a)
+        fields.append(a)
+    # all 8 operators along x
+    for op in OPNAMES:
+        t_h, t_o = getattr(s.xdirps, op), getattr(o.xdirps, op)
+        src_h, src_o = al.get_block(DIR_X, VERT), o.backend.get_block(orc.DIR_X, orc.VERT)
+        b.veccopy(src_h, s.u)
+        src_o.data[...] = o.u.data
+        if op.endswith("p2v"):
+            src_h.set_data_loc(move_data_loc(VERT, 1, 1))
+            src_o.data_loc = orc.move_data_loc(orc.VERT, 1, 1)
+        out_h, out_o = al.get_block(DIR_X), o.backend.get_block(orc.DIR_X)
+        b.tds_solve(out_h, src_h, t_h)
+        o.backend.tds_solve(out_o, src_o, t_o)
+        ref = o.backend.get_field_data(out_o)
+        assert relerr(b.get_field_data(out_h), ref) < TOL, op
+        # accumulating form: out += -0.5 * T(u)
+        b.tds_apply(out_h, src_h, t_h, DIR_X, accumulate=True, scale=-0.5)
+        assert relerr(b.get_field_data(out_h), 0.5 * ref) < TOL, op + " (accumulate)"
+        for f in (src_h, out_h):
+            al.release_block(f)
+    # transeq along x only, then the whole fused right-hand side (x writes, y and z accumulate)
+    rhs_h = [al.get_block(DIR_X) for _ in range(3)]
+    rhs_o = [o.backend.get_block(orc.DIR_X) for _ in range(3)]
+    b.transeq_x(*rhs_h, s.u, s.v, s.w, s.nu, s.xdirps)
+    o.backend.transeq_x(*rhs_o, o.u, o.v, o.w, o.nu, o.xdirps)
+    for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
+        assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+    s.transeq(rhs_h, [s.u, s.v, s.w])
+    o.transeq(rhs_o, [o.u, o.v, o.w])
+    for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
+        assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
