@@ -408,7 +408,7 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
     assert rows[:, 2].max() < 1e-13
 
 
-@pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN"])
+@pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN"])
 def test_optional_kernel_families_pass_the_same_parity_tests(env):
     """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
     block-recompute sweeps, generic x-direction kernels, LDS-tiled x kernels instead of
@@ -418,7 +418,7 @@ def test_optional_kernel_families_pass_the_same_parity_tests(env):
     import sys
     e = dict(os.environ, **{env: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
-                        "tds_solve_all or transeq_div_grad or fused_transeq_and_time"],
+                        "tds_solve_all or transeq_div_grad or fused_transeq_and_time or 512_row_pencils or full_size_pencils"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
 
@@ -523,6 +523,59 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
     o.backend.transeq_x(*rhs_o, o.u, o.v, o.w, o.nu, o.xdirps)
     for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+    s.transeq(rhs_h, [s.u, s.v, s.w])
+    o.transeq(rhs_o, [o.u, o.v, o.w])
+    for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
+        assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+
+
+@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512)])
+def test_yz_operators_on_512_row_pencils(dims):
+    """y / z pencils of 512 rows (the bench size): every operator incl. accumulating forms against the
+    oracle.  This is the size at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import DIR_X, VERT, move_data_loc
+    from x3d2_amd.solver import Solver, SolverConfig
+    L = (2.0, 3.0, 2.5)
+    per = ("periodic",) * 2
+    mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True))
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
+    o = orc.Solver(om, poisson="CG")
+    rng = np.random.default_rng(7)
+    b, al = s.backend, s.backend.allocator
+    for fo, fp in ((o.u, s.u), (o.v, s.v), (o.w, s.w)):
+        a = rng.standard_normal((dims[2], dims[1], dims[0]))
+        fo.data_loc = orc.VERT
+        o.backend.set_field_data(fo, a)
+        fp.set_data_loc(VERT)
+        b.set_field_data(fp, a)
+    d = 2 if dims[1] == 512 else 3
+    dp_h, dp_o = (s.ydirps, o.ydirps) if d == 2 else (s.zdirps, o.zdirps)
+    for op in OPNAMES:
+        t_h, t_o = getattr(dp_h, op), getattr(dp_o, op)
+        loc = move_data_loc(VERT, d, 1) if op.endswith("p2v") else VERT
+        src_h, src_o = al.get_block(DIR_X, VERT), o.backend.get_block(orc.DIR_X, orc.VERT)
+        b.veccopy(src_h, s.u)
+        src_o.data[...] = o.u.data
+        src_h.set_data_loc(loc)
+        src_o.data_loc = loc
+        a_o, out_o = o.backend.get_block(d), o.backend.get_block(d)
+        o.backend.reorder(a_o, src_o, 10 + d)
+        o.backend.tds_solve(out_o, a_o, t_o)
+        ref = o.backend.get_field_data(out_o)
+        out_h = al.get_block(DIR_X)
+        b.tds_apply(out_h, src_h, t_h, d)
+        out_h.set_data_loc(out_o.data_loc)
+        assert relerr(b.get_field_data(out_h), ref) < TOL, op
+        b.tds_apply(out_h, src_h, t_h, d, accumulate=True, scale=0.25)
+        assert relerr(b.get_field_data(out_h), 1.25 * ref) < TOL, op + " (accumulate)"
+        for f in (src_h, out_h):
+            al.release_block(f)
+    rhs_h = [al.get_block(DIR_X) for _ in range(3)]
+    rhs_o = [o.backend.get_block(orc.DIR_X) for _ in range(3)]
     s.transeq(rhs_h, [s.u, s.v, s.w])
     o.transeq(rhs_o, [o.u, o.v, o.w])
     for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):

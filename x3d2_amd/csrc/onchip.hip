@@ -168,3 +168,161 @@ int x3d_onchip_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops
     X3D_HIP(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// K1e: the same chunk-parallel single-pass solve for 512-row pencils with TWO workgroups per CU.
+// K1c needs 16 waves x 128 VGPRs = a whole CU for 64 pencils, so its load, compute and store phases
+// cannot overlap with anything (0.77 ms vs 0.85 ms for the two-sweep pair; at 256 rows, where two
+// 8-wave workgroups fit, it is 36 % faster).  Here a workgroup is 8 waves and owns 32 pencils: the
+// two halves of a wave are two different 32-row chunks of the same 32 pencils (lane = x + 32 h,
+// chunk = 2 wave + h), every half-wave row access is 256 contiguous bytes.  The row index now differs
+// between the halves, so the row tables cannot come from scalar loads: they are staged in LDS once per
+// workgroup ([table][row], 2 distinct addresses per wave access = broadcast reads).
+// ---------------------------------------------------------------------------------------------
+#define K1E_M 32
+#define K1E_TAB 8  // F A PF HB QB SA SC ST
+
+struct Coef9 { double c[9]; };
+
+template <bool ACC>
+__global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups per CU, <= 128 VGPRs
+    k_tds_onchip2(double *__restrict__ du, const double *__restrict__ u, TdsTab t, PencilGeom g, double scale,
+                  Coef9 cf)
+{
+    // periodic-type operator on 512-row pencils only (n_tds = n_rhs = 512, bulk stencil everywhere):
+    // no row guards, no boundary stencils, wrap-around halos by index arithmetic
+    extern __shared__ double lds[];  // K1E_TAB tables of LR rows, then ends[16][32], starts[16][32], misc[2][32]
+    constexpr int M = K1E_M, n = 512, LR = 520;
+    double *tF = lds, *tA = tF + LR, *tPF = tA + LR, *tHB = tPF + LR, *tQB = tHB + LR, *tSA = tQB + LR,
+           *tSC = tSA + LR, *tST = tSC + LR;
+    double *ends = tST + LR, *starts = ends + 16 * 32, *misc = starts + 16 * 32;
+    for (int j = threadIdx.x; j < LR; j += blockDim.x) {
+        const bool in = j >= 1 && j <= n;
+        tF[j] = in ? T_F(t, j) : 0.0;
+        tA[j] = in ? T_A(t, j) : 0.0;
+        tPF[j] = in ? T_PF(t, j) : 0.0;
+        tHB[j] = (in && j >= 2 && j <= n - 2) ? -T_BW(t, j) : 0.0;  // rows 1, n-1, n: no backward update
+        tQB[j] = in ? T_QB(t, j) : 0.0;
+        tSA[j] = in ? T_SA(t, j) : 0.0;
+        tSC[j] = in ? T_SC(t, j) : 0.0;
+        tST[j] = in ? T_ST(t, j) : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xl = lane & 31, c = 2 * wv + (lane >> 5);
+    const int p = blockIdx.x * 32 + xl;  // np is a multiple of 32 (launcher)
+    const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1, rs = g.rs;
+    const int s = c * M + 1;
+    // addresses as (wave-uniform row pointer) + (one 32-bit per-lane element offset): with 40 per-lane
+    // 64-bit addresses in flight the kernel spills (a block has < 2^31 elements)
+    const unsigned off = (unsigned)(base + (long)(s - 1) * rs);
+
+    // ---- P1: load the chunk + 4 + 4 halo rows (periodic image), chunk-local forward elimination in place
+    double x[M], w[9], hr[4];
+#pragma unroll
+    for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
+#pragma unroll
+    for (int m = 0; m < 4; m++) w[m] = u[(unsigned)(base + (long)((s - 5 + m + n) & (n - 1)) * rs)];
+#pragma unroll
+    for (int m = 0; m < 4; m++) hr[m] = u[(unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs)];
+#pragma unroll
+    for (int m = 0; m < 5; m++) w[4 + m] = x[m];
+    const double c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
+                 c7 = cf.c[7], c8 = cf.c[8];  // kernel arguments: SGPRs
+    double prev = 0.0;
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        const int j = s + q;
+        const double acc = c0 * w[0] + c1 * w[1] + c2 * w[2] + c3 * w[3] + c4 * w[4] + c5 * w[5] + c6 * w[6] +
+                           c7 * w[7] + c8 * w[8];
+        const double e = tF[j] * (acc - tA[j] * prev);
+        prev = e;
+        const double feed = (q + 5 < M) ? x[(q + 5) % M] : hr[(q + 5 - M) & 3];
+        x[q] = e;
+#pragma unroll
+        for (int m = 0; m < 8; m++) w[m] = w[m + 1];
+        w[8] = feed;
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live range of the LDS table reads
+    }
+    ends[c * 32 + xl] = prev;
+    __syncthreads();
+
+    // ---- P2: forward carry (serial over the chunks before this one), chunk-local back-substitution
+    {
+        double carry = 0.0;
+        for (int cc = 0; cc < c; cc++) carry = ends[cc * 32 + xl] + tPF[(cc + 1) * M] * carry;
+        double nxt = 0.0;
+#pragma unroll
+        for (int q = M - 1; q >= 0; q--) {
+            const int j = s + q;
+            const double e = x[q] + tPF[j] * carry;
+            x[q] = e + tHB[j] * nxt;
+            nxt = x[q];
+            if ((q & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        starts[c * 32 + xl] = x[0];
+    }
+    __syncthreads();
+
+    // ---- P3: backward carry; publish du_1 and X_n
+    {
+        double carry = 0.0;
+        for (int cc = 15; cc > c; cc--) carry = starts[cc * 32 + xl] + tQB[cc * M + 1] * carry;
+#pragma unroll
+        for (int q = 0; q < M; q++) {
+            x[q] = x[q] + tQB[s + q] * carry;
+            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == 15) misc[32 + xl] = x[M - 1];
+        if (c == 0) misc[xl] = t.last_r * (x[0] - t.bw1 * x[1]);  // distributed.f90:161-166
+    }
+    __syncthreads();
+
+    // ---- P4: reduced 2x2 systems with the periodic self-exchange, substitution, store
+    const double du1 = misc[xl], xn = misc[32 + xl];
+    const double du_s = t.rs_s * (du1 - t.sa1 * xn);
+    const double du_e = t.rs_e * (xn - t.scn * du1);
+#pragma unroll
+    for (int q0 = 0; q0 < M; q0 += 4) {
+        double old[4];
+        if (ACC) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) old[k] = (du + (long)(q0 + k) * rs)[off];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + k, j = s + q;
+            double r = (x[q] - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
+            r = (j == 1) ? du_s * tST[j] : r;                             // :209-213
+            r = (j == n) ? du_e * tST[j] : r;                             // :224-228
+            (du + (long)q * rs)[off] = ACC ? old[k] + scale * r : r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
+                    bool *done)
+{
+    *done = false;
+    PencilGeom g = x3d_geom(b, dir);
+    if (!(t->tab.bulk_only && t->n_tds == 512 && t->n_rhs == 512 && g.dim0 % 32 == 0 && g.np % 32 == 0)) return 0;
+    const size_t lds = sizeof(double) * ((size_t)K1E_TAB * 520 + 2 * 16 * 32 + 64);
+    static bool attr = false;
+    if (!attr) {
+        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr = true;
+    }
+    ProfScope ps(b, X3D_K_TDS_FWD, dir);
+    dim3 grid(g.np / 32), block(512);
+    Coef9 cf;
+    for (int m = 0; m < 9; m++) cf.c[m] = t->coeffs[m];
+    if (acc) hipLaunchKernelGGL(k_tds_onchip2<true>, grid, block, lds, b->stream, du, u, t->tab, g, scale, cf);
+    else hipLaunchKernelGGL(k_tds_onchip2<false>, grid, block, lds, b->stream, du, u, t->tab, g, 1.0, cf);
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}

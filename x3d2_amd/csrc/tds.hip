@@ -524,6 +524,19 @@ static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const d
                                    int acc);
 int x3d_onchip_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
                    double scale);  // onchip.hip
+int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
+                    bool *done);  // onchip.hip (K1e)
+static bool use_onchip2()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        // default on: single-pass solve for periodic 512-row y/z pencils, 0.50 ms vs 0.85 ms for the
+        // two-sweep pair (profiles/README.md); X3D_NO_ONCHIP2=1 falls back
+        const char *e = getenv("X3D_NO_ONCHIP2");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
 static bool use_onchip()
 {
     static int mode = -1;
@@ -620,6 +633,11 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     if (dir == X3D_DIR_X) return x3d_xdir_tds(b, du, u, t, accumulate, scale);
+    if (use_onchip2()) {
+        bool done = false;
+        if (int rc = x3d_onchip2_tds(b, du, u, t, dir, accumulate, scale, &done)) return rc;
+        if (done) return 0;
+    }
     if (use_onchip() && t->n_rhs <= 512) return x3d_onchip_tds(b, du, u, t, dir, accumulate, scale);
     if (use_fused_kernels()) return x3d_fused_tds_local(b, du, u, t, dir, accumulate, scale);
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
