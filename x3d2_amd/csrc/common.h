@@ -81,7 +81,7 @@ struct TdsTab {
     // Row tables are interleaved so that one wide scalar load fetches everything a
     // sweep needs for row j (1-based; record 0 unused):
     //   RF[4*j + {0,1,2,3}] = F, A, W, PF     forward sweep
-    //   RB[8*j + {0..5}]    = Bw, Sa, Sc, St, Stc, QB   backward sweep / substitution
+    //   RB[8*j + {0..7}]    = Bw, Sa, Sc, St, Stc, QB, PF16, QB16   backward sweep / substitution
     // F  forward multiplier  (rows 1,2: dist_af; >=3: dist_fw)
     // A  forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
     // W  weights of d_k in du_2 (backward chain), see tds.hip
@@ -106,6 +106,8 @@ struct TdsTab {
 #define T_ST(t, j) ((t).RB[8 * (j) + 3])
 #define T_STC(t, j) ((t).RB[8 * (j) + 4])
 #define T_QB(t, j) ((t).RB[8 * (j) + 5])
+#define T_PF16(t, j) ((t).RB[8 * (j) + 6])  // carry multipliers for 16-row chunks
+#define T_QB16(t, j) ((t).RB[8 * (j) + 7])
 
 struct x3d_tdsops {
     x3d_backend *b;

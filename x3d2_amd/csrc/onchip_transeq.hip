@@ -1,0 +1,311 @@
+// Single-pass transport-equation component for periodic 512-row y / z pencils (kernel family K1t).
+//
+// The two-sweep kernels (tds.hip) move 11 field passes per component: u, conv in; three
+// forward-eliminated arrays out and back in; conv again; rhs read-modify-write.  Here the pencil
+// stays on chip: a workgroup (8 waves) owns 16 pencils (128 contiguous bytes per row), the four
+// quarters of a wave are four different 16-row chunks (lane = x + 16 h, chunk = 4 wave + h), and
+// the three operators are solved one after the other with the chunk-parallel scheme of
+// onchip.hip (chunk-local sweeps from zero + exact carry correction through LDS), each one
+// substituted at once and accumulated into the result held in registers:
+//   r = -1/2 (v du + dud) + nu (d2u + du stc)          src/backend/omp/kernels/distributed.f90:231-337
+// HBM traffic: u, conv in, rhs out (+ rhs in when accumulating); the second reads of u / conv
+// come from L2 / Infinity Cache.  Row tables are staged in LDS per operator ([table][row]: the row
+// index differs between the quarters of a wave, so scalar loads cannot serve it).
+// STATUS: opt-in (X3D_ONCHIP_TRANSEQ=1), parity-tested, NOT faster yet: with the result r[16] live across
+// three operator solves the kernel needs ~110 VGPRs at the 128-VGPR budget of two workgroups per CU,
+// LLVM spills ~350 dwords (1.4 KB of scratch per lane = 90 KB per wave) and the scratch reservation
+// throttles the waves in flight: 6.4 ms per component against 2.2 ms for the two-sweep pair.  A single
+// operator of the same structure (onchip.hip, K1e) needs 76 VGPRs and runs at 4.3 TB/s.
+//   src/backend/omp/kernels/distributed.f90:11-168   der_univ_dist
+//   src/backend/omp/exec_dist.f90:67-186             exec_dist_transeq_compact
+#include "common.h"
+
+#define TQ_M 16   // rows per chunk
+#define TQ_C 32   // chunks per pencil
+#define TQ_LR 520 // padded rows per LDS table
+
+
+// tables in LDS: FA[j][2], PH[j][2] (PF, HB), SS[j][2] (SA, SC), QB[j], ST[j], STC3[j]
+// keeps the LDS table reads of a row next to their use: without it LLVM reads the tables of all 16 rows
+// (and of the loops that follow) up front and spills them straight to scratch
+#define ROW_FENCE()                                \
+    do {                                           \
+        __asm__ volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+struct TqLds {
+    double2 *FA, *PH, *SS;
+    double *QB, *ST, *STC3, *ends, *starts, *misc;
+};
+
+// what the kernel needs of one operator (kernel arguments: SGPRs)
+struct TqOp {
+    const double *RF, *RB;
+    double last_r, bw1, rs_s, rs_e, sa1, scn;
+    double c[9];
+};
+
+__device__ __forceinline__ void tq_stage_tables(const TqLds &L, const double *RF, const double *RB,
+                                                const double *RB3)
+{
+    constexpr int n = 512;
+    // laundered: otherwise the staging loads of all three operators are hoisted to the top of the kernel
+    // (read-only memory, nothing orders them) and ~100 VGPRs of table values are spilled until their turn
+    for (int j = threadIdx.x; j < TQ_LR; j += blockDim.x) {
+        const bool in = j >= 1 && j <= n;
+        int jj = in ? j : 1;
+        asm volatile("" : "+v"(jj));  // (laundering the pointers instead turns the loads into flat loads)
+        const double f = RF[4 * jj], a = RF[4 * jj + 1];
+        const double bw = RB[8 * jj], sa = RB[8 * jj + 1], sc = RB[8 * jj + 2], st = RB[8 * jj + 3],
+                     pf16 = RB[8 * jj + 6], qb16 = RB[8 * jj + 7], stc3 = RB3[8 * jj + 4];
+        const double hb = (j >= 2 && j <= n - 2) ? -bw : 0.0;  // rows 1, n-1, n: no backward update
+        L.FA[j] = in ? make_double2(f, a) : make_double2(0.0, 0.0);
+        L.PH[j] = in ? make_double2(pf16, hb) : make_double2(0.0, 0.0);
+        L.SS[j] = in ? make_double2(sa, sc) : make_double2(0.0, 0.0);
+        L.QB[j] = in ? qb16 : 0.0;
+        L.ST[j] = in ? st : 0.0;
+        L.STC3[j] = in ? stc3 : 0.0;
+    }
+}
+
+// one operator on this lane's chunk: x[] holds the 16 input rows, hl / hr the 4 + 4 neighbouring rows.
+// On return x[] holds the substituted derivative rows (what the reference calls temp_du etc.).
+__device__ __forceinline__ void tq_solve(double (&x)[TQ_M], const double (&hl)[4], const double (&hr)[4],
+                                         const TqLds &L, const TqOp &t, int s, int c, int xl, double &s_out,
+                                         double &e_out)
+{
+    constexpr int M = TQ_M, n = 512;
+    const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
+                 c7 = t.c[7], c8 = t.c[8];
+    double w[9];
+#pragma unroll
+    for (int m = 0; m < 4; m++) w[m] = hl[m];
+#pragma unroll
+    for (int m = 0; m < 5; m++) w[4 + m] = x[m];
+    double prev = 0.0;
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        const double2 fa = L.FA[s + q];
+        const double acc = c0 * w[0] + c1 * w[1] + c2 * w[2] + c3 * w[3] + c4 * w[4] + c5 * w[5] + c6 * w[6] +
+                           c7 * w[7] + c8 * w[8];
+        const double e = fa.x * (acc - fa.y * prev);
+        prev = e;
+        const double feed = (q + 5 < M) ? x[(q + 5) % M] : hr[(q + 5 - M) & 3];
+        x[q] = e;
+#pragma unroll
+        for (int m = 0; m < 8; m++) w[m] = w[m + 1];
+        w[8] = feed;
+        if (q & 1) ROW_FENCE();
+    }
+    L.ends[c * 16 + xl] = prev;
+    __syncthreads();
+    {   // forward carry, chunk-local back-substitution
+        double carry = 0.0;
+        for (int cc = 0; cc < c; cc++) carry = L.ends[cc * 16 + xl] + L.PH[(cc + 1) * M].x * carry;
+        double nxt = 0.0;
+#pragma unroll
+        for (int q = M - 1; q >= 0; q--) {
+            const double2 ph = L.PH[s + q];
+            x[q] = (x[q] + ph.x * carry) + ph.y * nxt;
+            nxt = x[q];
+            if ((q & 1) == 0) ROW_FENCE();
+        }
+        L.starts[c * 16 + xl] = x[0];
+    }
+    __syncthreads();
+    {   // backward carry; publish du_1 and X_n
+        double carry = 0.0;
+        for (int cc = TQ_C - 1; cc > c; cc--) carry = L.starts[cc * 16 + xl] + L.QB[cc * M + 1] * carry;
+#pragma unroll
+        for (int q = 0; q < M; q++) {
+            x[q] = x[q] + L.QB[s + q] * carry;
+            if ((q & 3) == 3) ROW_FENCE();
+        }
+        if (c == TQ_C - 1) L.misc[16 + xl] = x[M - 1];
+        if (c == 0) L.misc[xl] = t.last_r * (x[0] - t.bw1 * x[1]);  // distributed.f90:161-166
+    }
+    __syncthreads();
+    const double du1 = L.misc[xl], xn = L.misc[16 + xl];
+    s_out = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange (sendrecv.f90:20-22)
+    e_out = t.rs_e * (xn - t.scn * du1);
+}
+
+// substitution of row q (distributed.f90:304-335 written per operator: rows 1 and n take du_s * st / du_e * st)
+#define TQ_SUBS(q)                                                     \
+    ({                                                                 \
+        const int j_ = s + (q);                                        \
+        const double2 ss_ = L.SS[j_];                                  \
+        const double st_ = L.ST[j_];                                   \
+        double v_ = st_ * (x[q] - ss_.x * s_ - ss_.y * e_);            \
+        v_ = (j_ == 1) ? s_ * st_ : v_;                                \
+        v_ = (j_ == 512) ? e_ * st_ : v_;                              \
+        v_;                                                            \
+    })
+
+template <bool SAME, bool ACC>
+__global__ void __launch_bounds__(512, 4)  // two workgroups per CU
+    k_transeq_onchip(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, TqOp o1,
+                     TqOp o2, TqOp o3, PencilGeom g, double nu)
+{
+    extern __shared__ double lds[];
+    constexpr int M = TQ_M, n = 512;
+    TqLds L;
+    L.FA = reinterpret_cast<double2 *>(lds);
+    L.PH = L.FA + TQ_LR;
+    L.SS = L.PH + TQ_LR;
+    L.QB = reinterpret_cast<double *>(L.SS + TQ_LR);
+    L.ST = L.QB + TQ_LR;
+    L.STC3 = L.ST + TQ_LR;
+    L.ends = L.STC3 + TQ_LR;
+    L.starts = L.ends + TQ_C * 16;
+    L.misc = L.starts + TQ_C * 16;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xl = lane & 15, c = 4 * wv + (lane >> 4);
+    const int p = blockIdx.x * 16 + xl;
+    const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1, rs = g.rs;
+    const int s = c * M + 1;
+    const unsigned off = (unsigned)(base + (long)(s - 1) * rs);
+#define offl(m) ((unsigned)(base + (long)((s - 5 + (m) + n) & (n - 1)) * rs))
+#define offr(m) ((unsigned)(base + (long)((s + M - 1 + (m)) & (n - 1)) * rs))
+    double r[M], x[M], hl[4], hr[4];
+
+    // ---- operator 2 first: d(u conv)/dx, input = u * conv
+    tq_stage_tables(L, o2.RF, o2.RB, o3.RB);
+#pragma unroll
+    for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { hl[m] = u[offl(m)]; hr[m] = u[offr(m)]; }
+    if (SAME) {
+#pragma unroll
+        for (int q = 0; q < M; q++) x[q] = x[q] * x[q];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { hl[m] = hl[m] * hl[m]; hr[m] = hr[m] * hr[m]; }
+    } else {
+#pragma unroll
+        for (int q0 = 0; q0 < M; q0 += 4) {
+            double t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t4[k] = (cv + (long)(q0 + k) * rs)[off];
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[q0 + k] *= t4[k];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) { hl[m] *= cv[offl(m)]; hr[m] *= cv[offr(m)]; }
+    }
+    __syncthreads();  // tables staged
+    double s_, e_;
+    tq_solve(x, hl, hr, L, o2, s, c, xl, s_, e_);
+    // the substituted values are consumed in the loop that produces them: left in x[] for a later loop,
+    // LLVM sinks the arithmetic there while the table reads stay here
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        r[q] = -0.5 * TQ_SUBS(q);
+        if ((q & 3) == 3) ROW_FENCE();
+    }
+    __syncthreads();
+
+    // ---- operator 1: du/dx; r += -1/2 v du + nu stc du
+    // (u is read again, from L2 / Infinity Cache: keeping the first copy in registers would cost 48 VGPRs;
+    //  the laundered pointer stops the compiler from doing exactly that)
+    tq_stage_tables(L, o1.RF, o1.RB, o3.RB);
+    {
+        const double *__restrict__ u1 = u;
+        unsigned off1 = off;
+        asm volatile("" : "+v"(off1));  // opaque offset: no CSE with the first read of u, and the loads stay
+                                        // global (a laundered pointer degrades them to flat loads with 64-bit
+                                        // per-lane addresses)
+#pragma unroll
+        for (int q = 0; q < M; q++) x[q] = (u1 + (long)q * rs)[off1];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { hl[m] = u1[offl(m)]; hr[m] = u1[offr(m)]; }
+    }
+    __syncthreads();
+    tq_solve(x, hl, hr, L, o1, s, c, xl, s_, e_);
+    {
+        const double *__restrict__ vp = SAME ? u : cv;
+        unsigned offv = off;
+        asm volatile("" : "+v"(offv));
+#pragma unroll
+        for (int q0 = 0; q0 < M; q0 += 4) {
+            double v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v4[k] = (vp + (long)(q0 + k) * rs)[offv];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q = q0 + k;
+                const double d = TQ_SUBS(q);
+                r[q] = r[q] - 0.5 * (v4[k] * d) + nu * (d * L.STC3[s + q]);
+            }
+            ROW_FENCE();
+        }
+    }
+    __syncthreads();
+
+    // ---- operator 3: d2u/dx2; rhs = [rhs +] r + nu d2u
+    tq_stage_tables(L, o3.RF, o3.RB, o3.RB);
+    {
+        const double *__restrict__ u3 = u;
+        unsigned off3 = off;
+        asm volatile("" : "+v"(off3));
+#pragma unroll
+        for (int q = 0; q < M; q++) x[q] = (u3 + (long)q * rs)[off3];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { hl[m] = u3[offl(m)]; hr[m] = u3[offr(m)]; }
+    }
+    __syncthreads();
+    tq_solve(x, hl, hr, L, o3, s, c, xl, s_, e_);
+#pragma unroll
+    for (int q0 = 0; q0 < M; q0 += 4) {
+        double o4[4];
+        if (ACC) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) o4[k] = (rhs + (long)(q0 + k) * rs)[off];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + k;
+            const double val = r[q] + nu * TQ_SUBS(q);
+            (rhs + (long)q * rs)[off] = ACC ? o4[k] + val : val;
+        }
+        ROW_FENCE();
+    }
+}
+
+int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
+{
+    *done = false;
+    PencilGeom g = x3d_geom(b, dir);
+    const x3d_tdsops *ts[3] = {t1, t2, t3};
+    for (int o = 0; o < 3; o++)
+        if (!(ts[o]->tab.bulk_only && ts[o]->n_tds == 512 && ts[o]->n_rhs == 512)) return 0;
+    if (g.dim0 % 16 != 0 || g.np % 16 != 0) return 0;
+    TqOp P[3];
+    for (int o = 0; o < 3; o++) {
+        const TdsTab &tb = ts[o]->tab;
+        P[o] = TqOp{tb.RF, tb.RB, tb.last_r, tb.bw1, tb.rs_s, tb.rs_e, tb.sa1, tb.scn, {0}};
+        for (int m = 0; m < 9; m++) P[o].c[m] = ts[o]->coeffs[m];
+    }
+    const size_t lds = sizeof(double) * ((size_t)9 * TQ_LR + 2 * TQ_C * 16 + 32);
+    const bool same = u == conv;
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+    dim3 grid(g.np / 16), block(512);
+#define GO(S_, A_)                                                                                          \
+    do {                                                                                                    \
+        static bool attr = false;                                                                           \
+        if (!attr) {                                                                                        \
+            X3D_HIP(hipFuncSetAttribute((const void *)k_transeq_onchip<S_, A_>,                             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+            attr = true;                                                                                    \
+        }                                                                                                   \
+        hipLaunchKernelGGL((k_transeq_onchip<S_, A_>), grid, block, lds, b->stream, rhs, u, conv, P[0], P[1], P[2], g, \
+                           nu);                                                                             \
+    } while (0)
+    if (same) { if (acc) GO(true, true); else GO(true, false); }
+    else { if (acc) GO(false, true); else GO(false, false); }
+#undef GO
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}

@@ -75,6 +75,18 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             QB[j] = pr;
         }
     }
+    // the same for 16-row chunks (onchip_transeq.hip)
+    std::vector<double> PF16(L, 0.0), QB16(L, 0.0);
+    for (int s0 = 1; s0 <= nr; s0 += 16) {
+        const int t0 = s0 + 15 < nr ? s0 + 15 : nr;
+        double pr = 1.0;
+        for (int j = s0; j <= t0; j++) { pr *= -F[j] * A[j]; PF16[j] = pr; }
+        pr = 1.0;
+        for (int j = t0; j >= s0; j--) {
+            pr *= (j >= 2 && j <= n - 2) ? -dist_bw[j - 1] : 0.0;
+            QB16[j] = pr;
+        }
+    }
     memcpy(Cs, coeffs_s, sizeof(double) * 36);
     memcpy(Cs + 36, coeffs_e, sizeof(double) * 36);
     memcpy(Cs + 72, coeffs, sizeof(double) * 9);
@@ -83,12 +95,13 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     for (int m = 0; m < 9; m++) t->coeffs[m] = coeffs[m];
     t->b = b; t->n_tds = n; t->n_rhs = nr; t->move = move; t->periodic = periodic;
     // device image: interleaved row records (common.h) so that one wide scalar
-    // load serves a row: RF[4j..] = F A W PF ; RB[8j..] = Bw Sa Sc St Stc QB - - ; then Cs
+    // load serves a row: RF[4j..] = F A W PF ; RB[8j..] = Bw Sa Sc St Stc QB PF16 QB16 ; then Cs
     std::vector<double> img((size_t)12 * L + 81, 0.0);
     for (int j = 0; j < L; j++) {
         double *rf = &img[(size_t)4 * j], *rb = &img[(size_t)4 * L + (size_t)8 * j];
         rf[0] = F[j]; rf[1] = A[j]; rf[2] = W[j]; rf[3] = PF[j];
         rb[0] = Bw[j]; rb[1] = Sa[j]; rb[2] = Sc[j]; rb[3] = St[j]; rb[4] = Stc[j]; rb[5] = QB[j];
+        rb[6] = PF16[j]; rb[7] = QB16[j];
     }
     memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
     // lane tables for the wave-per-pencil x kernels (xscan.hip): lane l owns rows l*Q+1..(l+1)*Q
@@ -537,6 +550,17 @@ static bool use_onchip2()
     }
     return mode == 1;
 }
+int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
+static bool use_onchip_transeq()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_ONCHIP_TRANSEQ");
+        mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    return mode == 1;
+}
 static bool use_onchip()
 {
     static int mode = -1;
@@ -730,6 +754,11 @@ static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const d
                                    int acc)
 {
     if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
+    if (use_onchip_transeq()) {
+        bool done = false;
+        if (int rc = x3d_onchip_transeq(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;
+        if (done) return 0;
+    }
     if (use_fused_kernels()) return x3d_fused_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
     return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
 }
