@@ -30,17 +30,17 @@ with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as f:
         f.write(f"\"{k}\",{n},{fe:.0f},{wr:.0f},{(fe + wr) / GiB:.3f}\n")
 
 
-def avg(prefix):
-    sel = [(n, fe + wr) for k, n, fe, wr in rows if prefix in k]
-    tot = sum(n for n, _ in sel)
-    return sum(n * b for n, b in sel) / tot if tot else 0.0
-
-
-comp = avg("transeq_fwd") + avg("transeq_bwd")   # matches k_transeq_* and k_xtranseq_*
-calib = [fe for k, n, fe, wr in rows if k.endswith("k_tds_fwd<false, false>")]
+# one transport-equation component = k_transeq_fwd + k_transeq_bwd (y, z two-sweep), k_xtranseq_fwd + _bwd
+# (x, LDS-tiled) or ONE k_xscan_transeq / k_transeq_onchip launch (single pass)
+heads = ("k_transeq_fwd", "k_xtranseq_fwd", "k_xscan_transeq", "k_transeq_onchip")
+tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k)
+n_comp = sum(n for k, n, fe, wr in rows if any(h in k for h in heads))
+comp = tot_bytes / n_comp if n_comp else 0.0
+calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
 json.dump({"n": 512, "round": rnd, "transeq_component_bytes_per_launch": comp,
-           "calibration_k_tds_fwd_fetch_GiB": calib[0] / GiB if calib else None,
-           "note": "HBM bytes per (k_*transeq_fwd + k_*transeq_bwd) pair from rocprofv3 --pmc FETCH_SIZE / "
-                   "WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md"},
+           "components_profiled": n_comp,
+           "note": "HBM bytes per transport-equation component (all k_*transeq* kernels / number of components) "
+                   "from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
+                   "MI355X_MICROARCH.md (calibrated in round 1 on k_tds_fwd: one 1 GiB field read = 0.508 GiB raw)"},
           open("profiles/traffic.json", "w"), indent=1)
-print("component traffic GiB:", comp / GiB)
+print("component traffic GiB:", comp / GiB, "components:", n_comp)

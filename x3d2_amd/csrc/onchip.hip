@@ -217,32 +217,36 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     // 64-bit addresses in flight the kernel spills (a block has < 2^31 elements)
     const unsigned off = (unsigned)(base + (long)(s - 1) * rs);
 
-    // ---- P1: load the chunk + 4 + 4 halo rows (periodic image), chunk-local forward elimination in place
-    double x[M], w[9], hr[4];
+    // ---- P1: load the chunk + 4 + 4 halo rows (periodic image), chunk-local forward elimination in place.
+    // x[q] is overwritten by the eliminated value, so the 4 original rows behind the current one are kept
+    // in p0..p3; the rows ahead are still original in x[] (the last 4 come from the right halo, loaded late)
+    double x[M], hr[4];
 #pragma unroll
     for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
-#pragma unroll
-    for (int m = 0; m < 4; m++) w[m] = u[(unsigned)(base + (long)((s - 5 + m + n) & (n - 1)) * rs)];
-#pragma unroll
-    for (int m = 0; m < 4; m++) hr[m] = u[(unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs)];
-#pragma unroll
-    for (int m = 0; m < 5; m++) w[4 + m] = x[m];
+    double p0 = u[(unsigned)(base + (long)((s - 5 + n) & (n - 1)) * rs)],
+           p1 = u[(unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs)],
+           p2 = u[(unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs)],
+           p3 = u[(unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs)];
     const double c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
                  c7 = cf.c[7], c8 = cf.c[8];  // kernel arguments: SGPRs
     double prev = 0.0;
 #pragma unroll
     for (int q = 0; q < M; q++) {
         const int j = s + q;
-        const double acc = c0 * w[0] + c1 * w[1] + c2 * w[2] + c3 * w[3] + c4 * w[4] + c5 * w[5] + c6 * w[6] +
-                           c7 * w[7] + c8 * w[8];
+        if (q == M - 12) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) hr[m] = u[(unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs)];
+        }
+#define AHEAD(d) ((q + (d) < M) ? x[(q + (d)) % M] : hr[(q + (d) - M) & 3])
+        const double cur = x[q];
+        const double acc = c0 * p0 + c1 * p1 + c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2) +
+                           c7 * AHEAD(3) + c8 * AHEAD(4);
+#undef AHEAD
         const double e = tF[j] * (acc - tA[j] * prev);
         prev = e;
-        const double feed = (q + 5 < M) ? x[(q + 5) % M] : hr[(q + 5 - M) & 3];
         x[q] = e;
-#pragma unroll
-        for (int m = 0; m < 8; m++) w[m] = w[m + 1];
-        w[8] = feed;
-        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live range of the LDS table reads
+        p0 = p1; p1 = p2; p2 = p3; p3 = cur;
+        if (q & 1) __builtin_amdgcn_sched_barrier(0);  // bound the live range of the LDS table reads
     }
     ends[c * 32 + xl] = prev;
     __syncthreads();
@@ -258,24 +262,17 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
             const double e = x[q] + tPF[j] * carry;
             x[q] = e + tHB[j] * nxt;
             nxt = x[q];
-            if ((q & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            if ((q & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         }
         starts[c * 32 + xl] = x[0];
     }
     __syncthreads();
 
-    // ---- P3: backward carry; publish du_1 and X_n
-    {
-        double carry = 0.0;
-        for (int cc = 15; cc > c; cc--) carry = starts[cc * 32 + xl] + tQB[cc * M + 1] * carry;
-#pragma unroll
-        for (int q = 0; q < M; q++) {
-            x[q] = x[q] + tQB[s + q] * carry;
-            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c == 15) misc[32 + xl] = x[M - 1];
-        if (c == 0) misc[xl] = t.last_r * (x[0] - t.bw1 * x[1]);  // distributed.f90:161-166
-    }
+    // ---- P3: backward carry (applied on the fly in P4); publish du_1 and X_n
+    double carry = 0.0;
+    for (int cc = 15; cc > c; cc--) carry = starts[cc * 32 + xl] + tQB[cc * M + 1] * carry;
+    if (c == 15) misc[32 + xl] = x[M - 1];  // carry = 0 there
+    if (c == 0) misc[xl] = t.last_r * ((x[0] + tQB[1] * carry) - t.bw1 * (x[1] + tQB[2] * carry));  // :161-166
     __syncthreads();
 
     // ---- P4: reduced 2x2 systems with the periodic self-exchange, substitution, store
@@ -283,18 +280,19 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     const double du_s = t.rs_s * (du1 - t.sa1 * xn);
     const double du_e = t.rs_e * (xn - t.scn * du1);
 #pragma unroll
-    for (int q0 = 0; q0 < M; q0 += 4) {
-        double old[4];
+    for (int q0 = 0; q0 < M; q0 += 2) {
+        double old[2];
         if (ACC) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) old[k] = (du + (long)(q0 + k) * rs)[off];
+            for (int k = 0; k < 2; k++) old[k] = (du + (long)(q0 + k) * rs)[off];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 2; k++) {
             const int q = q0 + k, j = s + q;
-            double r = (x[q] - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
-            r = (j == 1) ? du_s * tST[j] : r;                             // :209-213
-            r = (j == n) ? du_e * tST[j] : r;                             // :224-228
+            const double X = x[q] + tQB[j] * carry;
+            double r = (X - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
+            r = (j == 1) ? du_s * tST[j] : r;                           // :209-213
+            r = (j == n) ? du_e * tST[j] : r;                           // :224-228
             (du + (long)q * rs)[off] = ACC ? old[k] + scale * r : r;
         }
         __builtin_amdgcn_sched_barrier(0);
