@@ -11,11 +11,13 @@
 // HBM traffic: u, conv in, rhs out (+ rhs in when accumulating); the second reads of u / conv
 // come from L2 / Infinity Cache.  Row tables are staged in LDS per operator ([table][row]: the row
 // index differs between the quarters of a wave, so scalar loads cannot serve it).
-// STATUS: opt-in (X3D_ONCHIP_TRANSEQ=1), parity-tested, NOT faster yet: with the result r[16] live across
-// three operator solves the kernel needs ~110 VGPRs at the 128-VGPR budget of two workgroups per CU,
-// LLVM spills ~350 dwords (1.4 KB of scratch per lane = 90 KB per wave) and the scratch reservation
-// throttles the waves in flight: 6.4 ms per component against 2.2 ms for the two-sweep pair.  A single
-// operator of the same structure (onchip.hip, K1e) needs 76 VGPRs and runs at 4.3 TB/s.
+// STATUS: opt-in (X3D_ONCHIP_TRANSEQ=1), parity-tested, NOT faster yet.  One operator of this structure
+// needs 76 VGPRs (onchip.hip, K1e: 106 with 32-row chunks, 4.9 TB/s); with the result r[16] live across
+// three solves the budget of two workgroups per CU (128 VGPRs) is only just enough, and LLVM's scheduling
+// (table reads and next-operator loads hoisted over the current operator) spills: 350 dwords written as three
+// consecutive blocks (6.4 ms per component), 70-200 as a loop over the operators (2.7 ms with conv = u,
+// 4.3 ms otherwise) against 2.1-2.3 ms for the two-sweep pair.  Accumulating into rhs by read-modify-write
+// instead of r[] spills as well.  Next step: hand-scheduled inner loops or 3 waves/SIMD with 12-wave groups.
 //   src/backend/omp/kernels/distributed.f90:11-168   der_univ_dist
 //   src/backend/omp/exec_dist.f90:67-186             exec_dist_transeq_compact
 #include "common.h"
@@ -69,33 +71,35 @@ __device__ __forceinline__ void tq_stage_tables(const TqLds &L, const double *RF
     }
 }
 
-// one operator on this lane's chunk: x[] holds the 16 input rows, hl / hr the 4 + 4 neighbouring rows.
-// On return x[] holds the substituted derivative rows (what the reference calls temp_du etc.).
-__device__ __forceinline__ void tq_solve(double (&x)[TQ_M], const double (&hl)[4], const double (&hr)[4],
-                                         const TqLds &L, const TqOp &t, int s, int c, int xl, double &s_out,
-                                         double &e_out)
+// one operator on this lane's chunk: x[] holds the 16 input rows, hl the 4 rows before; the 4 rows after
+// are fetched late through load_hr(m).  On return x[] holds the back-substituted chunk-local values; the
+// backward carry and the reduced-system values s_, e_ are returned and applied by TQ_SUBS.
+template <class LoadHr>
+__device__ __forceinline__ void tq_solve(double (&x)[TQ_M], const double (&hl)[4], LoadHr &&load_hr, const TqLds &L,
+                                         const TqOp &t, int s, int c, int xl, double &s_out, double &e_out,
+                                         double &carry_out)
 {
-    constexpr int M = TQ_M, n = 512;
+    constexpr int M = TQ_M;
     const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
                  c7 = t.c[7], c8 = t.c[8];
-    double w[9];
-#pragma unroll
-    for (int m = 0; m < 4; m++) w[m] = hl[m];
-#pragma unroll
-    for (int m = 0; m < 5; m++) w[4 + m] = x[m];
+    double p0 = hl[0], p1 = hl[1], p2 = hl[2], p3 = hl[3], hr[4];
     double prev = 0.0;
 #pragma unroll
     for (int q = 0; q < M; q++) {
+        if (q == 4) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) hr[m] = load_hr(m);
+        }
+#define AHEAD(d) ((q + (d) < M) ? x[(q + (d)) % M] : hr[(q + (d) - M) & 3])
         const double2 fa = L.FA[s + q];
-        const double acc = c0 * w[0] + c1 * w[1] + c2 * w[2] + c3 * w[3] + c4 * w[4] + c5 * w[5] + c6 * w[6] +
-                           c7 * w[7] + c8 * w[8];
+        const double cur = x[q];
+        const double acc = c0 * p0 + c1 * p1 + c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2) +
+                           c7 * AHEAD(3) + c8 * AHEAD(4);
+#undef AHEAD
         const double e = fa.x * (acc - fa.y * prev);
         prev = e;
-        const double feed = (q + 5 < M) ? x[(q + 5) % M] : hr[(q + 5 - M) & 3];
         x[q] = e;
-#pragma unroll
-        for (int m = 0; m < 8; m++) w[m] = w[m + 1];
-        w[8] = feed;
+        p0 = p1; p1 = p2; p2 = p3; p3 = cur;
         if (q & 1) ROW_FENCE();
     }
     L.ends[c * 16 + xl] = prev;
@@ -114,39 +118,38 @@ __device__ __forceinline__ void tq_solve(double (&x)[TQ_M], const double (&hl)[4
         L.starts[c * 16 + xl] = x[0];
     }
     __syncthreads();
-    {   // backward carry; publish du_1 and X_n
-        double carry = 0.0;
-        for (int cc = TQ_C - 1; cc > c; cc--) carry = L.starts[cc * 16 + xl] + L.QB[cc * M + 1] * carry;
-#pragma unroll
-        for (int q = 0; q < M; q++) {
-            x[q] = x[q] + L.QB[s + q] * carry;
-            if ((q & 3) == 3) ROW_FENCE();
-        }
-        if (c == TQ_C - 1) L.misc[16 + xl] = x[M - 1];
-        if (c == 0) L.misc[xl] = t.last_r * (x[0] - t.bw1 * x[1]);  // distributed.f90:161-166
-    }
+    // backward carry (applied on the fly by TQ_SUBS); publish du_1 and X_n
+    double carry = 0.0;
+    for (int cc = TQ_C - 1; cc > c; cc--) carry = L.starts[cc * 16 + xl] + L.QB[cc * M + 1] * carry;
+    if (c == TQ_C - 1) L.misc[16 + xl] = x[M - 1];  // carry = 0 there
+    if (c == 0)
+        L.misc[xl] = t.last_r * ((x[0] + L.QB[1] * carry) - t.bw1 * (x[1] + L.QB[2] * carry));  // :161-166
     __syncthreads();
     const double du1 = L.misc[xl], xn = L.misc[16 + xl];
     s_out = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange (sendrecv.f90:20-22)
     e_out = t.rs_e * (xn - t.scn * du1);
+    carry_out = carry;
 }
 
 // substitution of row q (distributed.f90:304-335 written per operator: rows 1 and n take du_s * st / du_e * st)
-#define TQ_SUBS(q)                                                     \
-    ({                                                                 \
-        const int j_ = s + (q);                                        \
-        const double2 ss_ = L.SS[j_];                                  \
-        const double st_ = L.ST[j_];                                   \
-        double v_ = st_ * (x[q] - ss_.x * s_ - ss_.y * e_);            \
-        v_ = (j_ == 1) ? s_ * st_ : v_;                                \
-        v_ = (j_ == 512) ? e_ * st_ : v_;                              \
-        v_;                                                            \
+#define TQ_SUBS(q)                                                                   \
+    ({                                                                               \
+        const int j_ = s + (q);                                                      \
+        const double2 ss_ = L.SS[j_];                                                \
+        const double st_ = L.ST[j_];                                                 \
+        const double X_ = x[q] + L.QB[j_] * cy;                                      \
+        double v_ = st_ * (X_ - ss_.x * s_ - ss_.y * e_);                            \
+        v_ = (j_ == 1) ? s_ * st_ : v_;                                              \
+        v_ = (j_ == 512) ? e_ * st_ : v_;                                            \
+        v_;                                                                          \
     })
+
+struct TqOps { TqOp o[3]; };  // order of evaluation: d(u conv)/dx, du/dx, d2u/dx2
 
 template <bool SAME, bool ACC>
 __global__ void __launch_bounds__(512, 4)  // two workgroups per CU
-    k_transeq_onchip(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, TqOp o1,
-                     TqOp o2, TqOp o3, PencilGeom g, double nu)
+    k_transeq_onchip(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, TqOps P,
+                     PencilGeom g, double nu)
 {
     extern __shared__ double lds[];
     constexpr int M = TQ_M, n = 512;
@@ -168,107 +171,89 @@ __global__ void __launch_bounds__(512, 4)  // two workgroups per CU
     const unsigned off = (unsigned)(base + (long)(s - 1) * rs);
 #define offl(m) ((unsigned)(base + (long)((s - 5 + (m) + n) & (n - 1)) * rs))
 #define offr(m) ((unsigned)(base + (long)((s + M - 1 + (m)) & (n - 1)) * rs))
-    double r[M], x[M], hl[4], hr[4];
-
-    // ---- operator 2 first: d(u conv)/dx, input = u * conv
-    tq_stage_tables(L, o2.RF, o2.RB, o3.RB);
+    double r[M];
 #pragma unroll
-    for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
+    for (int q = 0; q < M; q++) r[q] = 0.0;
+    // One operator per trip of a REAL loop: written as three consecutive blocks, LLVM interleaves the
+    // operators (table reads and address arithmetic of the next one hoisted over the current one) and spills
+    // ~350 dwords; a loop body is scheduled on its own and fits (one operator alone needs 76 VGPRs).
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+        const TqOp &op = P.o[k];
+        tq_stage_tables(L, op.RF, op.RB, P.o[2].RB);
+        double x[M], hl[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) { hl[m] = u[offl(m)]; hr[m] = u[offr(m)]; }
-    if (SAME) {
+        for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
 #pragma unroll
-        for (int q = 0; q < M; q++) x[q] = x[q] * x[q];
+        for (int m = 0; m < 4; m++) hl[m] = u[offl(m)];
+        const bool prod = k == 0;  // the first operator acts on u * conv
+        if (prod) {
+            if (SAME) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) { hl[m] = hl[m] * hl[m]; hr[m] = hr[m] * hr[m]; }
-    } else {
+                for (int q = 0; q < M; q++) x[q] = x[q] * x[q];
 #pragma unroll
-        for (int q0 = 0; q0 < M; q0 += 4) {
-            double t4[4];
+                for (int m = 0; m < 4; m++) hl[m] = hl[m] * hl[m];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) t4[k] = (cv + (long)(q0 + k) * rs)[off];
+                for (int q0 = 0; q0 < M; q0 += 4) {
+                    double t4[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) x[q0 + k] *= t4[k];
-        }
+                    for (int kk = 0; kk < 4; kk++) t4[kk] = (cv + (long)(q0 + kk) * rs)[off];
 #pragma unroll
-        for (int m = 0; m < 4; m++) { hl[m] *= cv[offl(m)]; hr[m] *= cv[offr(m)]; }
-    }
-    __syncthreads();  // tables staged
-    double s_, e_;
-    tq_solve(x, hl, hr, L, o2, s, c, xl, s_, e_);
-    // the substituted values are consumed in the loop that produces them: left in x[] for a later loop,
-    // LLVM sinks the arithmetic there while the table reads stay here
+                    for (int kk = 0; kk < 4; kk++) x[q0 + kk] *= t4[kk];
+                }
 #pragma unroll
-    for (int q = 0; q < M; q++) {
-        r[q] = -0.5 * TQ_SUBS(q);
-        if ((q & 3) == 3) ROW_FENCE();
-    }
-    __syncthreads();
-
-    // ---- operator 1: du/dx; r += -1/2 v du + nu stc du
-    // (u is read again, from L2 / Infinity Cache: keeping the first copy in registers would cost 48 VGPRs;
-    //  the laundered pointer stops the compiler from doing exactly that)
-    tq_stage_tables(L, o1.RF, o1.RB, o3.RB);
-    {
-        const double *__restrict__ u1 = u;
-        unsigned off1 = off;
-        asm volatile("" : "+v"(off1));  // opaque offset: no CSE with the first read of u, and the loads stay
-                                        // global (a laundered pointer degrades them to flat loads with 64-bit
-                                        // per-lane addresses)
-#pragma unroll
-        for (int q = 0; q < M; q++) x[q] = (u1 + (long)q * rs)[off1];
-#pragma unroll
-        for (int m = 0; m < 4; m++) { hl[m] = u1[offl(m)]; hr[m] = u1[offr(m)]; }
-    }
-    __syncthreads();
-    tq_solve(x, hl, hr, L, o1, s, c, xl, s_, e_);
-    {
-        const double *__restrict__ vp = SAME ? u : cv;
-        unsigned offv = off;
-        asm volatile("" : "+v"(offv));
-#pragma unroll
-        for (int q0 = 0; q0 < M; q0 += 4) {
-            double v4[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v4[k] = (vp + (long)(q0 + k) * rs)[offv];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int q = q0 + k;
-                const double d = TQ_SUBS(q);
-                r[q] = r[q] - 0.5 * (v4[k] * d) + nu * (d * L.STC3[s + q]);
+                for (int m = 0; m < 4; m++) hl[m] *= cv[offl(m)];
             }
-            ROW_FENCE();
         }
-    }
-    __syncthreads();
-
-    // ---- operator 3: d2u/dx2; rhs = [rhs +] r + nu d2u
-    tq_stage_tables(L, o3.RF, o3.RB, o3.RB);
-    {
-        const double *__restrict__ u3 = u;
-        unsigned off3 = off;
-        asm volatile("" : "+v"(off3));
+        __syncthreads();  // tables staged
+        double s_, e_, cy;
+        tq_solve(x, hl,
+                 [&](int m) {
+                     const double a = u[offr(m)];
+                     return prod ? (SAME ? a * a : a * cv[offr(m)]) : a;
+                 },
+                 L, op, s, c, xl, s_, e_, cy);
+        // the substituted values are consumed in the loop that produces them
+        if (k == 0) {
 #pragma unroll
-        for (int q = 0; q < M; q++) x[q] = (u3 + (long)q * rs)[off3];
+            for (int q = 0; q < M; q++) {
+                r[q] = -0.5 * TQ_SUBS(q);
+                if (q & 1) ROW_FENCE();
+            }
+        } else if (k == 1) {
+            const double *__restrict__ vp = SAME ? u : cv;
 #pragma unroll
-        for (int m = 0; m < 4; m++) { hl[m] = u3[offl(m)]; hr[m] = u3[offr(m)]; }
-    }
-    __syncthreads();
-    tq_solve(x, hl, hr, L, o3, s, c, xl, s_, e_);
+            for (int q0 = 0; q0 < M; q0 += 4) {
+                double v4[4];
 #pragma unroll
-    for (int q0 = 0; q0 < M; q0 += 4) {
-        double o4[4];
-        if (ACC) {
+                for (int kk = 0; kk < 4; kk++) v4[kk] = (vp + (long)(q0 + kk) * rs)[off];
 #pragma unroll
-            for (int k = 0; k < 4; k++) o4[k] = (rhs + (long)(q0 + k) * rs)[off];
+                for (int kk = 0; kk < 4; kk++) {
+                    const int q = q0 + kk;
+                    const double d = TQ_SUBS(q);
+                    r[q] = r[q] - 0.5 * (v4[kk] * d) + nu * (d * L.STC3[s + q]);
+                }
+                ROW_FENCE();
+            }
+        } else {
+#pragma unroll
+            for (int q0 = 0; q0 < M; q0 += 4) {
+                double o4[4];
+                if (ACC) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) o4[kk] = (rhs + (long)(q0 + kk) * rs)[off];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int q = q0 + kk;
+                    const double val = r[q] + nu * TQ_SUBS(q);
+                    (rhs + (long)q * rs)[off] = ACC ? o4[kk] + val : val;
+                }
+                ROW_FENCE();
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int q = q0 + k;
-            const double val = r[q] + nu * TQ_SUBS(q);
-            (rhs + (long)q * rs)[off] = ACC ? o4[k] + val : val;
-        }
-        ROW_FENCE();
+        __syncthreads();  // tables and carries are reused by the next operator
     }
 }
 
@@ -281,11 +266,13 @@ int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, co
     for (int o = 0; o < 3; o++)
         if (!(ts[o]->tab.bulk_only && ts[o]->n_tds == 512 && ts[o]->n_rhs == 512)) return 0;
     if (g.dim0 % 16 != 0 || g.np % 16 != 0) return 0;
-    TqOp P[3];
+    TqOps P;
+    const int order[3] = {1, 0, 2};  // evaluation order: dud (t2), du (t1), d2u (t3)
     for (int o = 0; o < 3; o++) {
-        const TdsTab &tb = ts[o]->tab;
-        P[o] = TqOp{tb.RF, tb.RB, tb.last_r, tb.bw1, tb.rs_s, tb.rs_e, tb.sa1, tb.scn, {0}};
-        for (int m = 0; m < 9; m++) P[o].c[m] = ts[o]->coeffs[m];
+        const x3d_tdsops *tt = ts[order[o]];
+        const TdsTab &tb = tt->tab;
+        P.o[o] = TqOp{tb.RF, tb.RB, tb.last_r, tb.bw1, tb.rs_s, tb.rs_e, tb.sa1, tb.scn, {0}};
+        for (int m = 0; m < 9; m++) P.o[o].c[m] = tt->coeffs[m];
     }
     const size_t lds = sizeof(double) * ((size_t)9 * TQ_LR + 2 * TQ_C * 16 + 32);
     const bool same = u == conv;
@@ -299,8 +286,7 @@ int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((k_transeq_onchip<S_, A_>), grid, block, lds, b->stream, rhs, u, conv, P[0], P[1], P[2], g, \
-                           nu);                                                                             \
+        hipLaunchKernelGGL((k_transeq_onchip<S_, A_>), grid, block, lds, b->stream, rhs, u, conv, P, g, nu); \
     } while (0)
     if (same) { if (acc) GO(true, true); else GO(true, false); }
     else { if (acc) GO(false, true); else GO(false, false); }
