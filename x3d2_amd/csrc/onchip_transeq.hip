@@ -11,13 +11,13 @@
 // HBM traffic: u, conv in, rhs out (+ rhs in when accumulating); the second reads of u / conv
 // come from L2 / Infinity Cache.  Row tables are staged in LDS per operator ([table][row]: the row
 // index differs between the quarters of a wave, so scalar loads cannot serve it).
-// STATUS: opt-in (X3D_ONCHIP_TRANSEQ=1), parity-tested, NOT faster yet.  One operator of this structure
-// needs 76 VGPRs (onchip.hip, K1e: 106 with 32-row chunks, 4.9 TB/s); with the result r[16] live across
-// three solves the budget of two workgroups per CU (128 VGPRs) is only just enough, and LLVM's scheduling
-// (table reads and next-operator loads hoisted over the current operator) spills: 350 dwords written as three
-// consecutive blocks (6.4 ms per component), 70-200 as a loop over the operators (2.7 ms with conv = u,
-// 4.3 ms otherwise) against 2.1-2.3 ms for the two-sweep pair.  Accumulating into rhs by read-modify-write
-// instead of r[] spills as well.  Next step: hand-scheduled inner loops or 3 waves/SIMD with 12-wave groups.
+// STATUS: opt-in (X3D_ONCHIP_TRANSEQ=1), parity-tested, not faster yet: 2.5 ms (conv != u) / 2.8 ms per
+// component against 2.3 / 2.1 ms for the two-sweep pair, although it moves 4 HBM passes instead of 11.
+// History: written as three consecutive operator blocks LLVM interleaved them (350 spilled dwords, 6.4 ms);
+// as a real loop over the operators with per-trip opaque offsets (otherwise the loop-invariant loads of u
+// are hoisted and kept for all trips) it is down to 40-100 spilled dwords.  What remains is latency: a
+// workgroup runs 3 operators x 4 barrier-separated phases with two serial 31-step carry chains each, and only
+// two workgroups fit a CU.  Next: log-step carry scan, all three table sets resident, 16 rows x 32 pencils.
 //   src/backend/omp/kernels/distributed.f90:11-168   der_univ_dist
 //   src/backend/omp/exec_dist.f90:67-186             exec_dist_transeq_compact
 #include "common.h"
@@ -181,11 +181,18 @@ __global__ void __launch_bounds__(512, 4)  // two workgroups per CU
     for (int k = 0; k < 3; k++) {
         const TqOp &op = P.o[k];
         tq_stage_tables(L, op.RF, op.RB, P.o[2].RB);
+        // opaque per-trip offsets: u and conv are loop-invariant, and LLVM would otherwise hoist their loads
+        // out of the operator loop and keep 24-48 rows in registers for all three trips
+        unsigned offk = off;
+        long basek = base;
+        asm volatile("" : "+v"(offk), "+v"(basek));
+#define offlk(m) ((unsigned)(basek + (long)((s - 5 + (m) + n) & (n - 1)) * rs))
+#define offrk(m) ((unsigned)(basek + (long)((s + M - 1 + (m)) & (n - 1)) * rs))
         double x[M], hl[4];
 #pragma unroll
-        for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
+        for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[offk];
 #pragma unroll
-        for (int m = 0; m < 4; m++) hl[m] = u[offl(m)];
+        for (int m = 0; m < 4; m++) hl[m] = u[offlk(m)];
         const bool prod = k == 0;  // the first operator acts on u * conv
         if (prod) {
             if (SAME) {
@@ -198,20 +205,20 @@ __global__ void __launch_bounds__(512, 4)  // two workgroups per CU
                 for (int q0 = 0; q0 < M; q0 += 4) {
                     double t4[4];
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) t4[kk] = (cv + (long)(q0 + kk) * rs)[off];
+                    for (int kk = 0; kk < 4; kk++) t4[kk] = (cv + (long)(q0 + kk) * rs)[offk];
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) x[q0 + kk] *= t4[kk];
                 }
 #pragma unroll
-                for (int m = 0; m < 4; m++) hl[m] *= cv[offl(m)];
+                for (int m = 0; m < 4; m++) hl[m] *= cv[offlk(m)];
             }
         }
         __syncthreads();  // tables staged
         double s_, e_, cy;
         tq_solve(x, hl,
                  [&](int m) {
-                     const double a = u[offr(m)];
-                     return prod ? (SAME ? a * a : a * cv[offr(m)]) : a;
+                     const double a = u[offrk(m)];
+                     return prod ? (SAME ? a * a : a * cv[offrk(m)]) : a;
                  },
                  L, op, s, c, xl, s_, e_, cy);
         // the substituted values are consumed in the loop that produces them
@@ -227,7 +234,7 @@ __global__ void __launch_bounds__(512, 4)  // two workgroups per CU
             for (int q0 = 0; q0 < M; q0 += 4) {
                 double v4[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) v4[kk] = (vp + (long)(q0 + kk) * rs)[off];
+                for (int kk = 0; kk < 4; kk++) v4[kk] = (vp + (long)(q0 + kk) * rs)[offk];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     const int q = q0 + kk;
