@@ -26,8 +26,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def decomposition(n_gpus):
-    """x stays whole (src/poisson_fft.f90:131); y/z split as evenly as possible"""
-    table = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4)}
+    """x stays whole (src/poisson_fft.f90:131).  z slabs only (the layout the reference's GPU backend needs
+    too, src/backend/cuda/poisson_fft.f90:219): y stays local (single-pass kernels, no y exchanges, no x-y
+    transpose in the Poisson solve) and the one remaining transpose pair is an all-to-all among ALL ranks, so
+    every GPU drives all of its N-1 point-to-point xGMI links at once instead of one or three of them."""
+    table = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 1, 4), 8: (1, 1, 8)}
     if n_gpus not in table:
         raise SystemExit(f"--gpus {n_gpus}: supported 1, 2, 4, 8")
     return table[n_gpus]

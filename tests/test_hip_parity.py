@@ -368,14 +368,15 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path):
     return g, parts[0]["rows"]
 
 
-@pytest.mark.parametrize("nproc_dir,fused", [((1, 1, 2), False), ((1, 2, 1), True), ((1, 2, 2), True)])
-def test_multirank_full_step_matches_single_rank(nproc_dir, fused, tmp_path):
+@pytest.mark.parametrize("nproc_dir,fused,dims", [((1, 1, 2), False, (48, 96, 96)), ((1, 2, 1), True, (48, 96, 96)),
+                                                  ((1, 2, 2), True, (48, 96, 96)),
+                                                  ((1, 1, 4), True, (32, 48, 192))])  # bench layout: z slabs
+def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_path):
     """DistD2 across ranks (halo + reduced-system exchange) and the pencil FFT
     Poisson solver: ranks share cuda:0 and exchange through gloo; the result
     must equal the single-rank run up to the DistD2 truncation
     (dist_sa(n_local) ~ 1e-16 for >= 40 points per rank, src/tdsops.f90:196-201)."""
     from x3d2_amd import make_tgv
-    dims = (48, 96, 96)
     g, rows = _run_ranks(nproc_dir, dims, 2, fused, "FFT", tmp_path)
     ref = make_tgv(dims, fused=fused)
     ref.solver.n_output = 2
