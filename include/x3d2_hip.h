@@ -205,6 +205,23 @@ int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_0
 int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
 int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
 
+/* ---- distributed 000 solver for z-slab decompositions [1, 1, pz] with ny = 512 (the layout of
+ * bench.py on N GPUs and of the reference's GPU backend, src/backend/cuda/poisson_fft.f90:219): one
+ * all-to-all pair per solve, no pack / unpack passes (csrc/sfft.hip).  Buffers are device arrays of
+ * 2 * pz * chunk doubles (x3d_sfft_sizes: chunk, zl, ys, nxs); peer r's chunk is contiguous.
+ *   forward_local(f, S) | all-to-all S -> R | fft_z(R, 0) ; postprocess_000(R) ; fft_z(R, 1)
+ *   | all-to-all R -> S | backward_local(S, f) */
+typedef struct x3d_sfft x3d_sfft;
+int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz);
+int x3d_sfft_destroy(x3d_sfft *p);
+int x3d_sfft_sizes(const x3d_sfft *p, long out[4]);
+int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx, const double *ay,
+                       const double *by, const double *az, const double *bz);
+int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf);
+int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir);
+int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf);
+int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out);
+
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
  * src/decomp/decomp_2decompfft.f90:42-48).  Only LOCAL stages live here; the

@@ -370,7 +370,9 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path):
 
 @pytest.mark.parametrize("nproc_dir,fused,dims", [((1, 1, 2), False, (48, 96, 96)), ((1, 2, 1), True, (48, 96, 96)),
                                                   ((1, 2, 2), True, (48, 96, 96)),
-                                                  ((1, 1, 4), True, (32, 48, 192))])  # bench layout: z slabs
+                                                  ((1, 1, 4), True, (32, 48, 192)),   # bench layout: z slabs
+                                                  ((1, 1, 2), True, (16, 512, 128)),  # ny = 512: slab FFT solver
+                                                  ((1, 1, 4), False, (16, 512, 192))])
 def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_path):
     """DistD2 across ranks (halo + reduced-system exchange) and the pencil FFT
     Poisson solver: ranks share cuda:0 and exchange through gloo; the result
@@ -385,7 +387,7 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
     for name, f in zip("uvw", (ref.solver.u, ref.solver.v, ref.solver.w)):
         assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
     assert abs(rows[-1][1] - rrows[-1][1]) < 1e-12 * abs(rrows[-1][1])
-    assert rows[-1][2] < 1e-11
+    assert rows[-1][2] < max(1e-11, 3 * rrows[-1][2])  # max |div u|: round-off level of the single-rank run
 
 
 def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
@@ -581,3 +583,39 @@ def test_yz_operators_on_512_row_pencils(dims):
     o.transeq(rhs_o, [o.u, o.v, o.w])
     for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+
+
+def test_slab_poisson_solver_single_rank_emulation():
+    """csrc/sfft.hip with pz = 1 (exchanges = self copies): y pass through the exchange layout, strided rocFFT
+    z pass, slab spectral kernel -- against the single-rank solver and the oracle"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("X3D_FORCE_PENCIL_FFT") != "slab":
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
+                            "slab_poisson_solver"], env=dict(os.environ, X3D_FORCE_PENCIL_FFT="slab"),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.poisson_fft import HipSlabPoissonFFT
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims = (24, 512, 40)
+    twopi = 6.283185307179586
+    per = ("periodic",) * 2
+    mesh = Mesh(dims, (1, 1, 1), (twopi, 3.0, 2.0), per, per, per)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig())
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert isinstance(pf, HipSlabPoissonFFT)
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((dims[2], dims[1], dims[0]))
+    blk = al.get_block(DIR_C, CELL)
+    b.set_field_data(blk, f, CELL)
+    pf.solve_poisson(blk, None)
+    got = b.get_field_data(blk, CELL)
+    om = orc.Mesh(list(dims), [1, 1, 1], [twopi, 3.0, 2.0], list(per), list(per), list(per))
+    ref = orc.Solver(om, poisson="FFT").poisson_fft.solve(f)
+    assert relerr(got, ref) < 1e-11

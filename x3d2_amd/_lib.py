@@ -74,6 +74,14 @@ PROTOTYPES = {
     "x3d_poisson_solve_010": (I, [VP, VP, VP]),
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
+    "x3d_sfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),
+    "x3d_sfft_destroy": (I, [VP]),
+    "x3d_sfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_sfft_set_waves": (I, [VP] + [c_double_p] * 7),
+    "x3d_sfft_forward_local": (I, [VP, VP, VP]),
+    "x3d_sfft_fft_z": (I, [VP, VP, I]),
+    "x3d_sfft_postprocess_000": (I, [VP, VP]),
+    "x3d_sfft_backward_local": (I, [VP, VP, VP]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
     "x3d_pfft_destroy": (I, [VP]),
     "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

@@ -108,8 +108,8 @@ struct Spec000 {
 // MODE 0: forward, MODE 1: backward, MODE 2: forward + process_spectral_000 + backward (z axis only)
 template <int MODE, int NP>
 __global__ void __launch_bounds__(64 * NP, 16 / NP)
-    k_fft512(double2 *__restrict__ c, const double2 *__restrict__ twg, long stride_axis, long stride_other,
-             int nxs, Spec000 sp)
+    k_fft512(double2 *c, const double2 *__restrict__ twg, long stride_axis, long stride_other, int nxs, Spec000 sp,
+             double2 *xbuf, int ys)
 {
     extern __shared__ double2 tile[];  // [NP][FP] + 256 twiddles
     double2 *__restrict__ tws = tile + NP * FP;
@@ -118,11 +118,19 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     const int i0 = blockIdx.x * NP, m = tid & (NP - 1), r = tid / NP;
     const long base = (long)blockIdx.y * stride_other + i0;
     const bool valid = i0 + m < nxs;
+    // slab-exchange addressing (multi-rank solver, y axis only): point t of the axis lives in chunk t / ys of
+    // xbuf = [chunk][other][ys][nxs], the layout the z all-to-all sends and receives (pfft.hip, x3d_sfft_*).
+    // MODE 0 stores there (forward y pass = pack), MODE 1 loads from there (backward y pass = unpack).
+    auto xaddr = [&](int t) {
+        const int ch = t / ys, tt = t - ch * ys;
+        return (((long)ch * gridDim.y + blockIdx.y) * ys + tt) * nxs + i0 + m;
+    };
     // ---- cooperative load: NP * 16 contiguous bytes per row
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int z = it * 64 + r;
-        tile[m * FP + z] = valid ? c[base + (long)z * stride_axis + m] : make_double2(0.0, 0.0);
+        const double2 *__restrict__ src = (MODE == 1 && xbuf) ? xbuf + xaddr(z) : c + base + (long)z * stride_axis + m;
+        tile[m * FP + z] = valid ? *src : make_double2(0.0, 0.0);
     }
     __syncthreads();
     double2 *__restrict__ pen = tile + w * FP;
@@ -190,7 +198,8 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int z = it * 64 + r;
-            c[base + (long)z * stride_axis + m] = tile[m * FP + z];
+            double2 *__restrict__ dstp = (MODE == 0 && xbuf) ? xbuf + xaddr(z) : c + base + (long)z * stride_axis + m;
+            *dstp = tile[m * FP + z];
         }
     }
 }
@@ -199,7 +208,7 @@ static double2 *g_tw = nullptr;  // W512^k = exp(-2 pi i k / 512), first half, s
 
 template <int MODE, int NP>
 static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_other, int nxs, int nother,
-                     const Spec000 &sp)
+                     const Spec000 &sp, double2 *xbuf, int ys)
 {
     static bool attr = false;
     const int lds = sizeof(double2) * (NP * FP + 256);
@@ -210,7 +219,7 @@ static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_o
     }
     dim3 grid((nxs + NP - 1) / NP, nother);
     hipLaunchKernelGGL((k_fft512<MODE, NP>), grid, dim3(64 * NP), lds, b->stream, c, g_tw, stride_axis,
-                       stride_other, nxs, sp);
+                       stride_other, nxs, sp, xbuf, ys);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -230,14 +239,25 @@ int x3d_fft512_init()
 }
 
 // axis: 1 = y (ny must be 512), 2 = z (nz must be 512); mode 0 fwd, 1 bwd, 2 fused z pass
+int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
+                     const double *ab, int nx, double2 *xbuf, int ys);
+
 int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
                    const double *ab, int nx)
+{
+    return x3d_fft512_run_x(b, c, nxs, ny, nz, axis, mode, waves, ab, nx, nullptr, 1);
+}
+
+// xbuf != null (y axis, mode 0 or 1): the far side of the pass is the slab-exchange buffer (see k_fft512)
+int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
+                     const double *ab, int nx, double2 *xbuf, int ys)
 {
     const long sy = nxs, sz = (long)nxs * ny;
     const long stride_axis = axis == 1 ? sy : sz, stride_other = axis == 1 ? sz : sy;
     const int nother = axis == 1 ? nz : ny;
     X3D_REQUIRE((axis == 1 ? ny : nz) == 512, "x3d_fft512_run: axis length must be 512");
     X3D_REQUIRE(mode != 2 || axis == 2, "x3d_fft512_run: the fused pass is the z pass");
+    X3D_REQUIRE(!xbuf || (axis == 1 && mode != 2 && ys > 0 && 512 % ys == 0), "x3d_fft512_run: bad slab exchange");
     Spec000 sp{};
     if (mode == 2) {
         const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
@@ -251,8 +271,8 @@ int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis
     const bool w16 = (wide & axis) != 0;  // bit 0: y pass, bit 1: z pass
     ProfScope ps(b, mode == 2 ? X3D_K_SPECTRAL : X3D_K_FFT, axis);
 #define GO(M_)                                                                                             \
-    (w16 ? launch512<M_, 16>(b, c, stride_axis, stride_other, nxs, nother, sp)                             \
-         : launch512<M_, 8>(b, c, stride_axis, stride_other, nxs, nother, sp))
+    (w16 ? launch512<M_, 16>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys)                   \
+         : launch512<M_, 8>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys))
     if (mode == 0) return GO(0);
     if (mode == 1) return GO(1);
     return GO(2);

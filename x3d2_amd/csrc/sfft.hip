@@ -1,0 +1,242 @@
+// Distributed spectral Poisson solver (000) for z-slab decompositions [1, 1, pz] with ny = 512:
+// the layout bench.py uses on N GPUs, and the one the reference's own GPU backend requires
+// (/root/reference/src/backend/cuda/poisson_fft.py:219 "1,1,N"; hooks src/poisson_fft.f90:45-62,
+// CPU analogue through 2decomp&FFT: src/backend/omp/poisson_fft.f90:72-137).
+//
+// y is local, so there is ONE transpose pair per solve and no separate pack / unpack pass at all:
+//   f[zl][ny][nx]  --rocFFT R2C x-->  C0[zl][ny][nxs]
+//   --k_fft512 (y forward), storing straight into the exchange layout-->  S[r][zl][ys][nxs]
+//        (chunk r = the y-range that rank r will own, contiguous -> sent as is)
+//   --all-to-all among the pz ranks-->  R[r][zl][ys][nxs] = R[nz][ys][nxs]  (chunks arrive in z order)
+//   --32x32 LDS-tiled transpose to T[ys*nxs][nz], rocFFT C2C z (contiguous), process_spectral_000, inverse z,
+//     transpose back (rocFFT's strided 1-D plan on R itself takes 2.05 ms per direction at 512^3, the
+//     transpose + contiguous transform 0.42 + 0.45)
+//   --all-to-all back (chunk r of R = rank r's z-range, contiguous)-->  S
+//   --k_fft512 (y backward), loading from the exchange layout-->  C0  --rocFFT C2R x-->  f
+// ~19 field passes per solve against ~30 for the generic pencil solver (pfft.hip: contiguous-axis rocFFT
+// stages with pack / transpose passes around every exchange).
+#include <hipfft/hipfft.h>
+
+#include "common.h"
+
+#define X3D_FFT(expr)                                                                          \
+    do {                                                                                       \
+        hipfftResult r_ = (expr);                                                              \
+        if (r_ != HIPFFT_SUCCESS) {                                                            \
+            x3d_set_error("%s failed: hipfft error %d (%s:%d)", #expr, (int)r_, __FILE__,      \
+                          __LINE__);                                                           \
+            return 3;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+int x3d_fft512_init();
+int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
+                     const double *ab, int nx, double2 *xbuf, int ys);
+
+struct x3d_sfft {
+    x3d_backend *b;
+    int nx, ny, nz, nxs;  // global cell dims (ny = 512)
+    int pz, rz, zl, ys;   // ranks along z, this rank, local z extent, this rank's share of the y modes
+    hipfftHandle plan_x_fw, plan_x_bw, plan_z;
+    double2 *c0;          // [zl][ny][nxs]
+    double2 *t;           // [ys*nxs][nz]: z-contiguous copy of the received array
+    double *waves, *ab;   // [ys][nxs][nz]; ax bx ay by az bz
+    void *work;
+};
+
+// 32 x 32 tiles through LDS: src [nB][nA] (A contiguous) -> dst [nA][nB] (B contiguous), 512-byte rows both ways
+__global__ void __launch_bounds__(256)
+    k_sfft_transpose(double2 *__restrict__ dst, const double2 *__restrict__ src, int nA, int nB)
+{
+    __shared__ double2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int bb = b0 + ty + 8 * r, aa = a0 + tx;
+        if (aa < nA && bb < nB) tile[ty + 8 * r][tx] = src[(long)bb * nA + aa];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int aa = a0 + ty + 8 * r, bb = b0 + tx;
+        if (aa < nA && bb < nB) dst[(long)aa * nB + bb] = tile[tx][ty + 8 * r];
+    }
+}
+
+// process_spectral_000 (src/backend/omp/kernels/spectral_processing.f90:7-106) on T[ys][nxs][nz] (z fastest):
+// y index offset = rz * ys (sp_st(2)), one thread per mode
+__global__ void __launch_bounds__(256)
+    k_process_spectral_000_slab(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ys, int nz,
+                                int yoff, int nx, int ny, const double *__restrict__ ax, const double *__restrict__ bx,
+                                const double *__restrict__ ay, const double *__restrict__ by,
+                                const double *__restrict__ az, const double *__restrict__ bz)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, jl = blockIdx.z;
+    if (k >= nz) return;
+    const int j = jl + yoff;
+    const size_t idx = ((size_t)jl * nxs + i) * nz + k;
+    double2 v = c[idx];
+    double div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
+    const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
+    const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
+    double tr, tc;
+    tr = div_r; tc = div_c;
+    div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
+    if (fz) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+    if (fy) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+    const double wv = waves[idx];
+    if (wv < 1.e-16) { div_r = 0.0; div_c = 0.0; }
+    else { div_r = -div_r / wv; div_c = -div_c / wv; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
+    if (fz) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+    if (fy) { div_r = -div_r; div_c = -div_c; }
+    tr = div_r; tc = div_c;
+    div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+    c[idx] = make_double2(div_r, div_c);
+}
+
+extern "C" int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz)
+{
+    X3D_REQUIRE(b && out && nglob, "x3d_sfft_create: null argument");
+    X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft_create: bad rank grid");
+    X3D_REQUIRE(nglob[1] == 512, "x3d_sfft_create: the slab solver needs ny = 512 (got %d)", nglob[1]);
+    X3D_REQUIRE(nglob[2] % pz == 0 && 512 % pz == 0, "x3d_sfft_create: nz and ny must divide by pz");
+    x3d_sfft *p = new x3d_sfft();
+    memset(p, 0, sizeof *p);
+    p->b = b;
+    p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2]; p->nxs = nglob[0] / 2 + 1;
+    p->pz = pz; p->rz = rz; p->zl = p->nz / pz; p->ys = p->ny / pz;
+    X3D_REQUIRE(p->nx <= b->nxp && p->ny == b->nyp && p->zl <= b->nzp, "x3d_sfft_create: local block mismatch");
+    const size_t n0 = (size_t)p->zl * p->ny * p->nxs;
+    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
+    X3D_HIP(hipMalloc(&p->t, sizeof(double2) * (size_t)p->nz * p->ys * p->nxs));
+    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));
+    int nn[1] = {p->nx}, re[1] = {b->nxp}, ce[1] = {p->nxs}, nzv[1] = {p->nz};
+    const int batch = p->ny * p->zl, zstride = p->ys * p->nxs;
+    hipfftHandle *pl[3] = {&p->plan_x_fw, &p->plan_x_bw, &p->plan_z};
+    size_t ws[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        X3D_FFT(hipfftCreate(pl[i]));
+        X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
+    }
+    X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, batch, &ws[0]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch, &ws[1]));
+    // z transform on the z-contiguous copy T[ys*nxs][nz]
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, HIPFFT_Z2Z, zstride, &ws[2]));
+    size_t wmax = 0;
+    for (int i = 0; i < 3; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
+    if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
+    for (int i = 0; i < 3; i++) X3D_FFT(hipfftSetWorkArea(*pl[i], p->work));
+    if (int rc = x3d_fft512_init()) return rc;
+    *out = p;
+    return 0;
+}
+
+extern "C" int x3d_sfft_destroy(x3d_sfft *p)
+{
+    if (!p) return 0;
+    hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); hipfftDestroy(p->plan_z);
+    hipFree(p->c0); hipFree(p->t); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
+    delete p;
+    return 0;
+}
+
+// out = {chunk (complex elements per peer), zl, ys, nxs}
+extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
+{
+    X3D_REQUIRE(p && out, "null argument");
+    out[0] = (long)p->zl * p->ys * p->nxs; out[1] = p->zl; out[2] = p->ys; out[3] = p->nxs;
+    return 0;
+}
+
+// waves: this rank's spectral block [ys][nxs][nz], z fastest (real part = imaginary part); ax..bz: full arrays
+extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx,
+                                  const double *ay, const double *by, const double *az, const double *bz)
+{
+    X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
+    X3D_HIP(hipMemcpy(p->waves, waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs, hipMemcpyHostToDevice));
+    const double *src[6] = {ax, bx, ay, by, az, bz};
+    const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
+    double *d = p->ab;
+    for (int i = 0; i < 6; i++) {
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        d += len[i];
+    }
+    return 0;
+}
+
+// x R2C, y forward; the result lands in sendbuf as [peer][zl][ys][nxs]
+extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf)
+{
+    X3D_REQUIRE(p && f_in && sendbuf, "null argument");
+    {
+        ProfScope ps(p->b, X3D_K_FFT, 1);
+        X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+        X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+    }
+    return x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 0, nullptr, nullptr, p->nx, (double2 *)sendbuf,
+                            p->ys);
+}
+
+// dir 0: received array R[nz][ys][nxs] -> T[ys*nxs][nz], forward z transform (the spectrum stays in T);
+// dir 1: backward z transform of T, then back to R
+extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const int W = p->ys * p->nxs;
+    if (dir == 0) {
+        ProfScope ps(p->b, X3D_K_PACK);
+        hipLaunchKernelGGL(k_sfft_transpose, dim3((W + 31) / 32, (p->nz + 31) / 32), dim3(256), 0, p->b->stream, p->t,
+                           (const double2 *)recvbuf, W, p->nz);
+        X3D_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(p->b, X3D_K_FFT, 3);
+        X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
+        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->t, (hipfftDoubleComplex *)p->t,
+                              dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    }
+    if (dir == 1) {
+        ProfScope ps(p->b, X3D_K_PACK);
+        hipLaunchKernelGGL(k_sfft_transpose, dim3((p->nz + 31) / 32, (W + 31) / 32), dim3(256), 0, p->b->stream,
+                           (double2 *)recvbuf, (const double2 *)p->t, p->nz, W);
+        X3D_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+                 *bz = az + p->nz;
+    dim3 grid((p->nz + 255) / 256, p->nxs, p->ys);
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
+    hipLaunchKernelGGL(k_process_spectral_000_slab, grid, dim3(256), 0, p->b->stream, p->t, p->waves, p->nxs, p->ys,
+                       p->nz, p->rz * p->ys, p->nx, p->ny, ax, bx, ay, by, az, bz);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// y backward from the exchange layout, x C2R
+extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out)
+{
+    X3D_REQUIRE(p && recvbuf && f_out, "null argument");
+    if (int rc = x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 1, nullptr, nullptr, p->nx,
+                                  (double2 *)recvbuf, p->ys))
+        return rc;
+    ProfScope ps(p->b, X3D_K_FFT, 2);
+    X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
+    X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+    return 0;
+}

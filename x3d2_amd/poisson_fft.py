@@ -154,7 +154,14 @@ def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
     import os
-    if mesh.nproc > 1 or os.environ.get("X3D_FORCE_PENCIL_FFT") == "1":
+    force = os.environ.get("X3D_FORCE_PENCIL_FFT")  # "1": generic pencil solver, "slab": slab solver
+    if mesh.nproc > 1 or force in ("1", "slab"):
+        ny = int(mesh.get_global_dims(CELL)[1])
+        pz = int(mesh.nproc_dir[2])
+        slab_ok = (int(mesh.nproc_dir[1]) == 1 and ny == 512 and 512 % pz == 0 and all(mesh.periodic_BC)
+                   and os.environ.get("X3D_NO_SLAB_FFT") != "1")
+        if slab_ok and force != "1":
+            return HipSlabPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
         return HipPencilPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
     return HipPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
 
@@ -392,6 +399,72 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         self._xchg(self.cnt_xy_recv, self.cnt_xy_send, self.peers_y)
         _lib.check(lib.x3d_pfft_unpack_yx(h, rb))
         _lib.check(lib.x3d_pfft_bwd_x(h, f_out.ptr))
+
+    def get_spectral(self):
+        raise X3dError("get_spectral: single-rank test hook")
+
+    def set_spectral(self, c):
+        raise X3dError("set_spectral: single-rank test hook")
+
+
+class HipSlabPoissonFFT(HipPoissonFFT):
+    """000 solver over a z-slab decomposition [1, 1, pz] with ny = 512 (csrc/sfft.hip): y is local, the strided
+    y pass writes / reads the exchange layout directly, one all-to-all pair per solve among all pz ranks (every
+    xGMI link of a GPU is used at once), z transform strided on the received array.  The hooks keep the
+    reference's meaning (src/poisson_fft.f90:45-62): fft_forward leaves the full 3-D spectrum in this rank's
+    block [nz][ys][nx/2+1], fft_postprocess_000 divides, fft_backward returns to physical space."""
+
+    def _create(self):
+        import torch
+        backend, mesh = self.backend, self.mesh
+        self.pz, self.rz = int(mesh.nproc_dir[2]), int(mesh.nrank_dir[2])
+        h = VP()
+        _lib.check(backend.lib.x3d_sfft_create(
+            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz))
+        self.h = h
+        sz = (ctypes.c_long * 4)()
+        _lib.check(backend.lib.x3d_sfft_sizes(h, sz))
+        self.chunk, self.zl, self.ys, nxs = [int(v) for v in sz]
+        ysl = slice(self.rz * self.ys, (self.rz + 1) * self.ys)
+        wl = np.ascontiguousarray(np.transpose(self.waves_block(slice(None), ysl), (1, 2, 0)),
+                                  dtype=np.float64)  # [ys][nxs][nz], z fastest
+        self._keep = [wl] + [np.ascontiguousarray(a, dtype=np.float64) for a in
+                             (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
+        _lib.check(backend.lib.x3d_sfft_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
+        n = 2 * self.pz * self.chunk
+        self.sbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.rbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        npy = int(mesh.nproc_dir[1])
+        ry = int(mesh.nrank_dir[1])
+        self.peers = [ry + npy * r for r in range(self.pz)]
+        self.counts = [2 * self.chunk] * self.pz
+        self.poisson = self.poisson_000
+
+    def __del__(self):
+        try:
+            self.backend.lib.x3d_sfft_destroy(self.h)
+        except Exception:
+            pass
+
+    def fft_forward(self, f_in):
+        lib = self.backend.lib
+        _lib.check(lib.x3d_sfft_forward_local(self.h, f_in.ptr, self.sbuf.data_ptr()))
+        self.backend.comm.alltoall(self.sbuf, self.counts, self.rbuf, self.counts, self.peers)
+        _lib.check(lib.x3d_sfft_fft_z(self.h, self.rbuf.data_ptr(), 0))
+
+    def fft_postprocess_000(self):
+        _lib.check(self.backend.lib.x3d_sfft_postprocess_000(self.h, self.rbuf.data_ptr()))
+
+    def fft_backward(self, f_out):
+        lib = self.backend.lib
+        _lib.check(lib.x3d_sfft_fft_z(self.h, self.rbuf.data_ptr(), 1))
+        self.backend.comm.alltoall(self.rbuf, self.counts, self.sbuf, self.counts, self.peers)
+        _lib.check(lib.x3d_sfft_backward_local(self.h, self.sbuf.data_ptr(), f_out.ptr))
+
+    def poisson_000(self, f, temp):
+        self.fft_forward(f)
+        self.fft_postprocess_000()
+        self.fft_backward(f)
 
     def get_spectral(self):
         raise X3dError("get_spectral: single-rank test hook")
