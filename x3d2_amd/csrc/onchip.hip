@@ -184,6 +184,18 @@ int x3d_onchip_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops
 
 struct Coef9 { double c[9]; };
 
+// (wave-uniform pointer) + (32-bit per-lane BYTE offset): the form the backend turns into
+// global_load/store v, v_off, s[base:base+1].  With an element offset it cannot prove that 8*off fits 32
+// bits and builds a 64-bit address in two VGPRs per access (77 v_lshl_add_u64 in this kernel).
+__device__ __forceinline__ double ldg(const double *base, unsigned boff)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + boff);
+}
+__device__ __forceinline__ void stg(double *base, unsigned boff, double v)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + boff) = v;
+}
+
 template <bool ACC>
 __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups per CU, <= 128 VGPRs
     k_tds_onchip2(double *__restrict__ du, const double *__restrict__ u, TdsTab t, PencilGeom g, double scale,
@@ -215,18 +227,18 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     const int s = c * M + 1;
     // addresses as (wave-uniform row pointer) + (one 32-bit per-lane element offset): with 40 per-lane
     // 64-bit addresses in flight the kernel spills (a block has < 2^31 elements)
-    const unsigned off = (unsigned)(base + (long)(s - 1) * rs);
+    const unsigned off = (unsigned)(base + (long)(s - 1) * rs) * 8u;  // bytes; a block is < 4 GiB
 
     // ---- P1: load the chunk + 4 + 4 halo rows (periodic image), chunk-local forward elimination in place.
     // x[q] is overwritten by the eliminated value, so the 4 original rows behind the current one are kept
     // in p0..p3; the rows ahead are still original in x[] (the last 4 come from the right halo, loaded late)
     double x[M], hr[4];
 #pragma unroll
-    for (int q = 0; q < M; q++) x[q] = (u + (long)q * rs)[off];
-    double p0 = u[(unsigned)(base + (long)((s - 5 + n) & (n - 1)) * rs)],
-           p1 = u[(unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs)],
-           p2 = u[(unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs)],
-           p3 = u[(unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs)];
+    for (int q = 0; q < M; q++) x[q] = ldg(u + (long)q * rs, off);
+    double p0 = ldg(u, (unsigned)(base + (long)((s - 5 + n) & (n - 1)) * rs) * 8u),
+           p1 = ldg(u, (unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs) * 8u),
+           p2 = ldg(u, (unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs) * 8u),
+           p3 = ldg(u, (unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs) * 8u);
     const double c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
                  c7 = cf.c[7], c8 = cf.c[8];  // kernel arguments: SGPRs
     double prev = 0.0;
@@ -235,7 +247,7 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
         const int j = s + q;
         if (q == M - 12) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) hr[m] = u[(unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs)];
+            for (int m = 0; m < 4; m++) hr[m] = ldg(u, (unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs) * 8u);
         }
 #define AHEAD(d) ((q + (d) < M) ? x[(q + (d)) % M] : hr[(q + (d) - M) & 3])
         const double cur = x[q];
@@ -284,7 +296,7 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
         double old[2];
         if (ACC) {
 #pragma unroll
-            for (int k = 0; k < 2; k++) old[k] = (du + (long)(q0 + k) * rs)[off];
+            for (int k = 0; k < 2; k++) old[k] = ldg(du + (long)(q0 + k) * rs, off);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -293,7 +305,7 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
             double r = (X - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
             r = (j == 1) ? du_s * tST[j] : r;                           // :209-213
             r = (j == n) ? du_e * tST[j] : r;                           // :224-228
-            (du + (long)q * rs)[off] = ACC ? old[k] + scale * r : r;
+            stg(du + (long)q * rs, off, ACC ? old[k] + scale * r : r);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
