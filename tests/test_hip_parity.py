@@ -532,10 +532,10 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
 
 
-@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512)])
+@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512), (32, 256, 8), (64, 8, 256)])
 def test_yz_operators_on_512_row_pencils(dims):
-    """y / z pencils of 512 rows (the bench size): every operator incl. accumulating forms against the
-    oracle.  This is the size at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""
+    """y / z pencils of 512 (the bench size) and 256 rows: every operator incl. accumulating forms against
+    the oracle.  These are the sizes at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""
     from oracle import x3d_oracle as orc
     from x3d2_amd import Mesh
     from x3d2_amd.backend import HipBackend
@@ -555,7 +555,7 @@ def test_yz_operators_on_512_row_pencils(dims):
         o.backend.set_field_data(fo, a)
         fp.set_data_loc(VERT)
         b.set_field_data(fp, a)
-    d = 2 if dims[1] == 512 else 3
+    d = 2 if dims[1] >= 256 else 3
     dp_h, dp_o = (s.ydirps, o.ydirps) if d == 2 else (s.zdirps, o.zdirps)
     for op in OPNAMES:
         t_h, t_o = getattr(dp_h, op), getattr(dp_o, op)

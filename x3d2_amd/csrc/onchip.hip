@@ -196,15 +196,16 @@ __device__ __forceinline__ void stg(double *base, unsigned boff, double v)
     *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + boff) = v;
 }
 
-template <bool ACC>
+// M = 32: 512-row pencils, M = 16: 256-row pencils (16 chunks either way)
+template <bool ACC, int M>
 __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups per CU, <= 128 VGPRs
     k_tds_onchip2(double *__restrict__ du, const double *__restrict__ u, TdsTab t, PencilGeom g, double scale,
                   Coef9 cf)
 {
-    // periodic-type operator on 512-row pencils only (n_tds = n_rhs = 512, bulk stencil everywhere):
+    // periodic-type operator on pencils of exactly 16 * M rows (n_tds = n_rhs, bulk stencil everywhere):
     // no row guards, no boundary stencils, wrap-around halos by index arithmetic
     extern __shared__ double lds[];  // K1E_TAB tables of LR rows, then ends[16][32], starts[16][32], misc[2][32]
-    constexpr int M = K1E_M, n = 512, LR = 520;
+    constexpr int n = 16 * M, LR = n + 8;
     double *tF = lds, *tA = tF + LR, *tPF = tA + LR, *tHB = tPF + LR, *tQB = tHB + LR, *tSA = tQB + LR,
            *tSC = tSA + LR, *tST = tSC + LR;
     double *ends = tST + LR, *starts = ends + 16 * 32, *misc = starts + 16 * 32;
@@ -212,9 +213,9 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
         const bool in = j >= 1 && j <= n;
         tF[j] = in ? T_F(t, j) : 0.0;
         tA[j] = in ? T_A(t, j) : 0.0;
-        tPF[j] = in ? T_PF(t, j) : 0.0;
+        tPF[j] = in ? (M == 32 ? T_PF(t, j) : T_PF16(t, j)) : 0.0;  // chunk-local products for M-row chunks
         tHB[j] = (in && j >= 2 && j <= n - 2) ? -T_BW(t, j) : 0.0;  // rows 1, n-1, n: no backward update
-        tQB[j] = in ? T_QB(t, j) : 0.0;
+        tQB[j] = in ? (M == 32 ? T_QB(t, j) : T_QB16(t, j)) : 0.0;
         tSA[j] = in ? T_SA(t, j) : 0.0;
         tSC[j] = in ? T_SC(t, j) : 0.0;
         tST[j] = in ? T_ST(t, j) : 0.0;
@@ -311,18 +312,16 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     }
 }
 
-int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
-                    bool *done)
+template <int M>
+static int launch_onchip2(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, const PencilGeom &g,
+                          int dir, int acc, double scale)
 {
-    *done = false;
-    PencilGeom g = x3d_geom(b, dir);
-    if (!(t->tab.bulk_only && t->n_tds == 512 && t->n_rhs == 512 && g.dim0 % 32 == 0 && g.np % 32 == 0)) return 0;
-    const size_t lds = sizeof(double) * ((size_t)K1E_TAB * 520 + 2 * 16 * 32 + 64);
+    const size_t lds = sizeof(double) * ((size_t)K1E_TAB * (16 * M + 8) + 2 * 16 * 32 + 64);
     static bool attr = false;
     if (!attr) {
-        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<false, M>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<true, M>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         attr = true;
     }
@@ -330,9 +329,22 @@ int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsop
     dim3 grid(g.np / 32), block(512);
     Coef9 cf;
     for (int m = 0; m < 9; m++) cf.c[m] = t->coeffs[m];
-    if (acc) hipLaunchKernelGGL(k_tds_onchip2<true>, grid, block, lds, b->stream, du, u, t->tab, g, scale, cf);
-    else hipLaunchKernelGGL(k_tds_onchip2<false>, grid, block, lds, b->stream, du, u, t->tab, g, 1.0, cf);
+    if (acc) hipLaunchKernelGGL((k_tds_onchip2<true, M>), grid, block, lds, b->stream, du, u, t->tab, g, scale, cf);
+    else hipLaunchKernelGGL((k_tds_onchip2<false, M>), grid, block, lds, b->stream, du, u, t->tab, g, 1.0, cf);
     X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
+                    bool *done)
+{
+    *done = false;
+    PencilGeom g = x3d_geom(b, dir);
+    const int n = t->n_tds;
+    if (!(t->tab.bulk_only && (n == 512 || n == 256) && t->n_rhs == n && g.dim0 % 32 == 0 && g.np % 32 == 0)) return 0;
+    const int rc = n == 512 ? launch_onchip2<32>(b, du, u, t, g, dir, acc, scale)
+                            : launch_onchip2<16>(b, du, u, t, g, dir, acc, scale);
+    if (rc) return rc;
     *done = true;
     return 0;
 }
