@@ -261,6 +261,36 @@ __device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lan
     o2[0] = v0; o2[4] = v1; o2[8] = v2; o2[12] = v3;
 }
 
+// Q = 4: a lane owns 32 B, a pair of lanes one 64-byte sector: 2 x 2 transpose of the 16-byte pairs
+template <bool ACC>
+__device__ __forceinline__ void store_rows_q4(double *__restrict__ orow, int lane, const double (&r)[4],
+                                              double scale)
+{
+    const bool odd = lane & 1;
+    const double s0 = odd ? r[0] : r[2], s1 = odd ? r[1] : r[3];  // what the partner needs
+    int lo, hi;
+    lo = __double2loint(s0); hi = __double2hiint(s0);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false);
+    const double g0 = __hiloint2double(hi, lo);
+    lo = __double2loint(s1); hi = __double2hiint(s1);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false);
+    const double g1 = __hiloint2double(hi, lo);
+    // instruction m writes bytes [32 m + 16 p, +16) of the pair's sector: pair p of lane m of the pair
+    const double a0 = odd ? g0 : r[0], a1 = odd ? g1 : r[1];  // m = 0: P_0[p]
+    const double b0 = odd ? r[2] : g0, b1 = odd ? r[3] : g1;  // m = 1: P_1[p]
+    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + (lane & ~1) * 4) + (lane & 1);
+    double2 v0, v1;
+    if (ACC) {
+        v0 = o2[0]; v1 = o2[2];
+        v0.x += scale * a0; v0.y += scale * a1; v1.x += scale * b0; v1.y += scale * b1;
+    } else {
+        v0.x = a0; v0.y = a1; v1.x = b0; v1.y = b1;
+    }
+    o2[0] = v0; o2[2] = v1;
+}
+
 template <int Q>
 __device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__restrict__ row, int first, int nr,
                                             int n_wrap, bool interior)
@@ -326,9 +356,10 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 #if XSCAN_EXP == 1
         if (r[0] != 12345.678) continue;
 #endif
-        if (FAST && Q == 8) {
+        if (FAST) {
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, scale);
-        } else if (FAST || (exact && n == nr)) {
+            else store_rows_q4<ACC>(orow, lane, r, scale);
+        } else if (exact && n == nr) {
             double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) {
@@ -442,8 +473,9 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] += nu * T[q];
         double *__restrict__ orow = rhs + (long)p * pitch;
-        if (FAST && Q == 8) {
+        if (FAST) {
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, 1.0);
+            else store_rows_q4<ACC>(orow, lane, r, 1.0);
         } else if (exact) {
             double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
 #pragma unroll
