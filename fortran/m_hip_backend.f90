@@ -388,7 +388,13 @@ contains
     real(dp), intent(in) :: nu
     type(dirps_t), intent(in) :: dirps
     logical, intent(in) :: sync
-    error stop 'HIP backend: species transport is not supported yet'
+    integer :: n
+    ! single-rank shim (like transeq_any): periodic / boundary closures are local, `sync` has nothing to do
+    n = self%mesh%get_n(spec)
+    call x3d_check(x3d_transeq_species(self%handle, int(dirps%dir, c_int), dev(dspec), dev(uvw), dev(spec), &
+                                       real(nu, c_double), tds_handle(dirps%der1st), &
+                                       tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), 0_c_int))
+    call dspec%set_data_loc(spec%data_loc)
   end subroutine
 
   subroutine tds_solve_hip(self, du, u, tdsops)

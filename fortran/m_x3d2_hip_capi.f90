@@ -89,6 +89,14 @@ module m_x3d2_hip_capi
       type(c_ptr), value :: b, du, du_send_s, du_recv_s, du_recv_e, t
       integer(c_int), value :: dir
     end function
+    ! transeq_species
+    integer(c_int) function x3d_transeq_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, &
+                                                accumulate) bind(C, name='x3d_transeq_species')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, dspec, uvw, spec, der1st, der1st_sym, der2nd
+      integer(c_int), value :: dir, accumulate
+      real(c_double), value :: nu
+    end function
     ! reorder / sum_yintox / sum_zintox
     integer(c_int) function x3d_reorder(b, u_, u, rdr) bind(C, name='x3d_reorder')
       import :: c_ptr, c_int

@@ -117,6 +117,14 @@ int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw,
                     const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                     const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                     const x3d_tdsops *der2nd_sym, int accumulate);
+/* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
+ * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
+ * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below
+ * with u = spec, conv = uvw). */
+int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                        int accumulate);
+
 /* Distributed form for ONE component (transeq_dist_component, :299-338):
  * rhs = -1/2 (conv*du/dx + d(u*conv)/dx) + nu d2u/dx2.  send/recv are
  * [3][npencil] (du, dud, d2u boundary values), halos [4][npencil]. */

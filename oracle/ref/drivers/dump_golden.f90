@@ -263,6 +263,39 @@ program dump_golden
   call dump_field('transeq_x.dv', dv, VERT)
   call dump_field('transeq_x.dw', dw, VERT)
 
+  ! ---- transported scalar: the reference's solver%transeq_species (x, y, z passes with reorders and sums)
+  !      on a deterministic field, diffusivity 0.37 nu
+  block
+    class(field_t), pointer :: spec, dspec
+    type(flist_t), allocatable :: curr4(:), deriv1(:)
+    real(dp), allocatable :: s0(:, :, :)
+    allocate (s0(pdims(1), pdims(2), pdims(3)))
+    s0 = 0._dp
+    do k = 1, dims(3)
+      do j = 1, dims(2)
+        do i = 1, dims(1)
+          s0(i, j, k) = hashval(i + mesh%par%n_offset(1), j + mesh%par%n_offset(2), &
+                                k + mesh%par%n_offset(3), 6)
+        end do
+      end do
+    end do
+    call dump_r3('in.s', s0(1:dims(1), 1:dims(2), 1:dims(3)))
+    spec => allocator%get_block(DIR_X)
+    dspec => allocator%get_block(DIR_X)
+    call spec%set_data_loc(VERT)
+    call backend%set_field_data(spec, s0)
+    if (.not. allocated(solver%nu_species)) allocate (solver%nu_species(1))
+    solver%nu_species(1) = 0.37_dp*solver%nu
+    allocate (curr4(4), deriv1(1))
+    curr4(1)%ptr => solver%u; curr4(2)%ptr => solver%v; curr4(3)%ptr => solver%w
+    curr4(4)%ptr => spec
+    deriv1(1)%ptr => dspec
+    call solver%transeq_species(deriv1, curr4)
+    call dump_field('species.rhs', dspec, VERT)
+    call allocator%release_block(spec)
+    call allocator%release_block(dspec)
+  end block
+
   div_u => allocator%get_block(DIR_Z)
   call solver%divergence_v2p(div_u, solver%u, solver%v, solver%w)
   call dump_field('div.div_u', div_u, CELL)

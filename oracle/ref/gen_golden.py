@@ -200,10 +200,10 @@ def stitch(per_rank):
 # keep fixtures small: which records each dump keeps (None = all)
 KEEP = {
     "p000_ab3": ("meta.", "in.", "step1.", "step2."),
-    "p000_rk3_z2": ("meta.", "in.", "tds.z.", "transeq.", "div.", "grad.", "curl.", "step2."),
-    "p000_rk3_z1": ("meta.", "in.", "tds.z.", "transeq.", "div.", "grad.", "curl.", "step2."),
-    "p000_rk3_y2": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2."),
-    "p000_rk3_y1": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2."),
+    "p000_rk3_z2": ("meta.", "in.", "tds.z.", "transeq.", "div.", "grad.", "curl.", "step2.", "species."),
+    "p000_rk3_z1": ("meta.", "in.", "tds.z.", "transeq.", "div.", "grad.", "curl.", "step2.", "species."),
+    "p000_rk3_y2": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2.", "species."),
+    "p000_rk3_y1": ("meta.", "in.", "tds.y.", "transeq.", "div.", "grad.", "curl.", "step2.", "species."),
     "c010u_rk3": ("meta.", "in.", "spec.", "step2."),
     "c010b_rk3": ("meta.", "in.", "spec.", "step2."),
     "c010c_rk3": ("meta.", "in.", "spec.", "step2."),

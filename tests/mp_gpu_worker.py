@@ -12,6 +12,19 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def set_species(case):
+    """transported scalars start as smooth functions of the GLOBAL coordinates"""
+    from x3d2_amd.common import VERT
+    s = case.solver
+    m = s.mesh
+    x = m.vert_coords[0][None, None, :]
+    y = m.vert_coords[1][None, :, None]
+    z = m.vert_coords[2][:, None, None]
+    for i, f in enumerate(s.species):
+        f.set_data_loc(VERT)
+        s.backend.set_field_data(f, np.cos((i + 1) * x) * np.sin(y) * np.cos(2 * z) + 0.3)
+
+
 def main():
     nproc_dir = tuple(int(x) for x in sys.argv[1].split(","))
     dims = tuple(int(x) for x in sys.argv[2].split(","))
@@ -24,13 +37,17 @@ def main():
     torch.cuda.set_device(0)
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
-    case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, poisson=poisson, comm=Comm(), fused=fused)
+    nsp = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+    case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, poisson=poisson, comm=Comm(), fused=fused, n_species=nsp,
+                    pr_species=[0.7] * nsp)
+    set_species(case)
     case.solver.n_output = n_iters
     rows = case.run(n_iters=n_iters)
     s = case.solver
     local = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
+    extra = {"s%d" % i: s.backend.get_field_data(f) for i, f in enumerate(s.species)}
     np.savez(out + f".{rank}.npz", u=local[0], v=local[1], w=local[2], offset=np.array(s.mesh.n_offset),
-             rows=np.array(rows))
+             rows=np.array(rows), **extra)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -9,7 +9,7 @@ from .tdsops import Dirps, Tdsops  # noqa: F401
 
 
 def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT", comm=None,
-             device=None, fused=False):
+             device=None, fused=False, n_species=0, pr_species=None):
     """TGV set-up of examples/TGV/input.x3d on an n^3 (or (nx,ny,nz)) grid."""
     from .backend import HipBackend
     from .case import TGVCase
@@ -20,7 +20,7 @@ def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3"
                 nrank=rank)
     backend = HipBackend(mesh, device=device, comm=comm)
     solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson,
-                                                 fused=fused))
+                                                 fused=fused, n_species=n_species, pr_species=pr_species))
     return TGVCase(solver)
 
 

@@ -174,6 +174,45 @@ class HipBackend:
                 self.h, direction, rhs[i].ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), fld[0].ptr,
                 float(nu), t_du.handle, t_dud.handle, t_d2u.handle))
 
+    def transeq_species(self, dspec, uvw, spec, nu, dirps, sync=True, accumulate=False, direction=None):
+        """src/backend/omp/backend.f90:186-233: convection-diffusion of one transported scalar along
+        dirps%dir.  `sync` (halo exchange of the momentum field needed) is honoured implicitly: the halos of
+        uvw are packed whenever the direction is decomposed.  direction / accumulate: fused-driver form on
+        blocks of any tag."""
+        d = dirps.dir if direction is None else direction
+        self.mesh.get_n(d, spec.data_loc)
+        if not self._decomposed(d):
+            _lib.check(self.lib.x3d_transeq_species(self.h, d, dspec.ptr, uvw.ptr, spec.ptr, float(nu),
+                                                    dirps.der1st.handle, dirps.der1st_sym.handle,
+                                                    dirps.der2nd.handle, int(accumulate)))
+        else:
+            out = dspec if not accumulate else self.allocator.get_block(DIR_X)
+            i = d - 1
+            prev, nxt = int(self.mesh.pprev[i]), int(self.mesh.pnext[i])
+            n = self.mesh.get_n(d, spec.data_loc)
+            pairs, halos = [], []
+            for k, f in enumerate((spec, uvw)):
+                ss, se, rs, re = self._buffers(d, N_HALO, "u%d" % k)
+                _lib.check(self.lib.x3d_pack_halos(self.h, ss.data_ptr(), se.data_ptr(), f.ptr, n, d))
+                pairs.append((ss, se, rs, re))
+                halos.append((rs, re))
+            self.comm.sendrecv(pairs, prev, nxt)
+            bs, be, brs, bre = self._buffers(d, 3, "b")
+            t = (dirps.der1st, dirps.der1st_sym, dirps.der2nd)
+            _lib.check(self.lib.x3d_transeq_dist_fwd(
+                self.h, d, out.ptr, bs.data_ptr(), be.data_ptr(), spec.ptr, halos[0][0].data_ptr(),
+                halos[0][1].data_ptr(), uvw.ptr, halos[1][0].data_ptr(), halos[1][1].data_ptr(), t[0].handle,
+                t[1].handle, t[2].handle))
+            self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
+            _lib.check(self.lib.x3d_transeq_dist_bwd(
+                self.h, d, out.ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), uvw.ptr, float(nu),
+                t[0].handle, t[1].handle, t[2].handle))
+            if accumulate:
+                _lib.check(self.lib.x3d_vecadd(self.h, 1.0, out.ptr, 1.0, dspec.ptr))
+                self.allocator.release_block(out)
+        if not accumulate:
+            dspec.set_data_loc(spec.data_loc)
+
     # ------------------------------------------------------------ fused-driver forms
     def transeq_dir(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate=False):
         """transeq_<dir> on blocks of ANY tag (all tags share one device layout);

@@ -67,7 +67,7 @@ class BaseCase:
         """body of the sub_iter loop, base_case.f90:261-289"""
         s = self.solver
         al = s.backend.allocator
-        curr = [s.u, s.v, s.w]
+        curr = [s.u, s.v, s.w] + list(s.species)  # base_case.f90:236-241
         self.define_BC()
         deriv = [al.get_block(DIR_X) for _ in range(s.nvars)]
         s.transeq(deriv, curr)

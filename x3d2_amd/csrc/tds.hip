@@ -832,6 +832,19 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
     return 0;
 }
 
+// transeq_species (src/backend/omp/backend.f90:186-233): one convection-diffusion component of a transported
+// scalar: field = spec, advecting velocity = uvw, operators (der1st, der1st_sym, der2nd), local direction
+extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec,
+                                   double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                   const x3d_tdsops *der2nd, int accumulate)
+{
+    X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_species: bad dir %d", dir);
+    X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
+    if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
+    return transeq_component_local(b, dir, dspec, spec, uvw, nu, der1st, der1st_sym, der2nd, accumulate);
+}
+
 // ------------------------------------------------------------------ checkpoint form, local
 // forward kernel keeps 1/CK of the eliminated values; the backward kernel
 // (fused.hip) recomputes each block from the inputs.  ~7 field passes per

@@ -15,12 +15,15 @@ class SolverConfig:
 
     def __init__(self, Re=1600.0, dt=1e-3, n_iters=10, n_output=0, time_intg="RK3", poisson_solver_type="FFT",
                  der1st_scheme="compact6", der2nd_scheme="compact6", interpl_scheme="classic",
-                 stagder_scheme="compact6", lowmem_transeq=False, fused=False):
+                 stagder_scheme="compact6", lowmem_transeq=False, fused=False, n_species=0, pr_species=None):
         self.Re, self.dt, self.n_iters, self.n_output = Re, dt, n_iters, n_output
         self.time_intg, self.poisson_solver_type = time_intg, poisson_solver_type
         self.der1st_scheme, self.der2nd_scheme = der1st_scheme, der2nd_scheme
         self.interpl_scheme, self.stagder_scheme = interpl_scheme, stagder_scheme
         self.lowmem_transeq = lowmem_transeq
+        # transported scalars (src/config.f90:36-37, 161-162): Prandtl / Schmidt number per species, default 1
+        self.n_species = int(n_species)
+        self.pr_species = [1.0] * self.n_species if pr_species is None else [float(x) for x in pr_species]
         # fused = False: op-granular sequences exactly as the reference issues them;
         # fused = True : same arithmetic with reorders / sums / axpy chains folded
         #                into the kernels
@@ -65,6 +68,16 @@ class Solver:
         al = backend.allocator
         self.u, self.v, self.w = (al.get_block(DIR_X) for _ in range(3))
         self.nvars = 3
+        # transported species (src/solver.f90:139-155): one DIR_X block each, nu_i = 1 / (Re Pr_i)
+        self.nspecies = int(getattr(cfg, "n_species", 0))
+        self.species = []
+        self.nu_species = []
+        if self.nspecies > 0:
+            if len(cfg.pr_species) != self.nspecies:
+                raise X3dError("pr_species needs one entry per species")
+            self.nvars += self.nspecies
+            self.nu_species = [1.0 / cfg.Re / pr for pr in cfg.pr_species]
+            self.species = [al.get_block(DIR_X) for _ in range(self.nspecies)]
         self.fused = bool(cfg.fused)
         self.time_integrator = TimeIntegrator(backend, al, cfg.time_intg, self.nvars, fused=self.fused)
         self.dt, self.nu = cfg.dt, 1.0 / cfg.Re
@@ -88,8 +101,8 @@ class Solver:
     # ---- src/solver.f90:291-389
     def transeq_default(self, rhs, variables):
         b, al = self.backend, self.backend.allocator
-        du, dv, dw = rhs
-        u, v, w = variables
+        du, dv, dw = rhs[:3]
+        u, v, w = variables[:3]
         b.transeq_x(du, dv, dw, u, v, w, self.nu, self.xdirps)
         u_y, v_y, w_y, du_y, dv_y, dw_y = (al.get_block(DIR_Y) for _ in range(6))
         b.reorder(u_y, u, RDR_X2Y)
@@ -115,20 +128,53 @@ class Solver:
         b.sum_zintox(dw, dw_z)
         for f in (du_z, dv_z, dw_z):
             al.release_block(f)
+        if self.nspecies > 0:  # :384-387
+            self.transeq_species(rhs[3:], variables)
+
+    # ---- src/solver.f90:507-601
+    def transeq_species(self, rhs, variables):
+        """skew-symmetric convection-diffusion of the transported species, velocity grid in and out"""
+        b, al = self.backend, self.backend.allocator
+        u, v, w = variables[:3]
+        for i, r in enumerate(rhs):
+            b.transeq_species(r, u, variables[3 + i], self.nu_species[i], self.xdirps, i <= 0)
+        for vel, dirps, rdr, summ in ((v, self.ydirps, RDR_X2Y, b.sum_yintox), (w, self.zdirps, RDR_X2Z, b.sum_zintox)):
+            d = dirps.dir
+            vel_d, spec_d, dspec_d = (al.get_block(d) for _ in range(3))
+            b.reorder(vel_d, vel, rdr)
+            for i, r in enumerate(rhs):
+                b.reorder(spec_d, variables[3 + i], rdr)
+                b.transeq_species(dspec_d, vel_d, spec_d, self.nu_species[i], dirps, i <= 0)
+                summ(r, dspec_d)
+            for f in (vel_d, spec_d, dspec_d):
+                al.release_block(f)
+
+    def transeq_species_fused(self, rhs, variables):
+        """the same without reorders / sums: y and z contributions accumulate in place"""
+        b = self.backend
+        vel = variables[:3]
+        for i, r in enumerate(rhs):
+            spec = variables[3 + i]
+            for k, dirps in enumerate((self.xdirps, self.ydirps, self.zdirps)):
+                b.transeq_species(r, vel[k], spec, self.nu_species[i], dirps, i <= 0, accumulate=k > 0,
+                                  direction=dirps.dir)
+            r.set_data_loc(spec.data_loc)
 
     def transeq_fused(self, rhs, variables):
         """transeq_default without the 6 reorders and 6 sum_*intox: every block
         shares one device layout, so the y and z passes read u, v, w in place and
         accumulate straight into du, dv, dw."""
         b = self.backend
-        du, dv, dw = rhs
-        u, v, w = variables
+        du, dv, dw = rhs[:3]
+        u, v, w = variables[:3]
         b.mesh.get_n(DIR_X, u.data_loc)
         b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
         b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
         b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
-        for f in rhs:
+        for f in rhs[:3]:
             f.set_data_loc(u.data_loc)
+        if self.nspecies > 0:
+            self.transeq_species_fused(rhs[3:], variables)
 
     def pressure_correction_fused(self, u, v, w):
         """pressure_correction (:693-739) = divergence_v2c + Poisson + gradient_c2v +
