@@ -279,8 +279,8 @@ module m_hip_backend
     procedure :: field_volume_integral => field_volume_integral_hip
     procedure :: field_set_face => field_set_face_hip
     procedure :: field_set_face_from_field => field_set_face_from_field_hip
-    procedure :: compute_vorticity => derived_unsupported
-    procedure :: compute_qcriterion => derived_unsupported
+    procedure :: compute_vorticity => compute_vorticity_hip
+    procedure :: compute_qcriterion => compute_qcriterion_hip
     procedure :: copy_data_to_f => copy_data_to_f_hip
     procedure :: copy_f_to_data => copy_f_to_data_hip
     procedure :: init_poisson_fft => init_hip_poisson_fft
@@ -564,11 +564,21 @@ contains
                                                  real(c_end, c_double), int(face, c_int), real(frd, c_double)))
   end subroutine field_set_face_from_field_hip
 
-  subroutine derived_unsupported(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz)
+  subroutine compute_vorticity_hip(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz)
     class(hip_backend_t) :: self
     class(field_t), intent(inout) :: field_out
     class(field_t), intent(in) :: dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz
-    error stop 'HIP backend: snapshot fields (vorticity / Q) are not supported yet'
+    type(c_ptr) :: g(9)
+    g = [dev(dudx), dev(dudy), dev(dudz), dev(dvdx), dev(dvdy), dev(dvdz), dev(dwdx), dev(dwdy), dev(dwdz)]
+    call x3d_check(x3d_compute_vorticity(self%handle, dev(field_out), g))
+  end subroutine
+  subroutine compute_qcriterion_hip(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz)
+    class(hip_backend_t) :: self
+    class(field_t), intent(inout) :: field_out
+    class(field_t), intent(in) :: dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz
+    type(c_ptr) :: g(9)
+    g = [dev(dudx), dev(dudy), dev(dudz), dev(dvdx), dev(dvdy), dev(dvdz), dev(dwdx), dev(dwdy), dev(dwdz)]
+    call x3d_check(x3d_compute_qcriterion(self%handle, dev(field_out), g))
   end subroutine
 
   subroutine copy_extent(self, shp, ext, hx, hy)

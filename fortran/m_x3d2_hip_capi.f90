@@ -97,6 +97,17 @@ module m_x3d2_hip_capi
       integer(c_int), value :: dir, accumulate
       real(c_double), value :: nu
     end function
+    ! compute_vorticity / compute_qcriterion: grads = 9 device blocks
+    integer(c_int) function x3d_compute_vorticity(b, out, grads) bind(C, name='x3d_compute_vorticity')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, out
+      type(c_ptr), intent(in) :: grads(9)
+    end function
+    integer(c_int) function x3d_compute_qcriterion(b, out, grads) bind(C, name='x3d_compute_qcriterion')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, out
+      type(c_ptr), intent(in) :: grads(9)
+    end function
     ! reorder / sum_yintox / sum_zintox
     integer(c_int) function x3d_reorder(b, u_, u, rdr) bind(C, name='x3d_reorder')
       import :: c_ptr, c_int

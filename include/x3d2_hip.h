@@ -146,6 +146,11 @@ int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
 int x3d_vecmult(x3d_backend *b, double *y, const double *x);
 int x3d_field_scale(x3d_backend *b, double *f, double a);
 int x3d_field_shift(x3d_backend *b, double *f, double a);
+/* compute_vorticity / compute_qcriterion (src/backend/backend.f90:53-54, omp :616-649): pointwise,
+ * grads = {dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz} device blocks, out distinct from them:
+ * |curl u| and Q = -1/2 (dudx^2 + dvdy^2 + dwdz^2) - dudy dvdx - dudz dwdx - dvdz dwdy */
+int x3d_compute_vorticity(x3d_backend *b, double *out, const double *const grads[9]);
+int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grads[9]);
 /* fused time-integrator update (an extension, not in base_backend_t):
  * y = base + sum_i c[i]*x[i], nterm <= 5; base may be y itself.  Collapses the
  * veccopy/vecadd chains of src/time_integrator.f90:166-282 into one pass. */

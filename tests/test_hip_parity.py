@@ -666,3 +666,30 @@ def test_multirank_species_transport_matches_single_rank(nproc_dir, fused, tmp_p
     b = ref.solver.backend
     assert relerr(g["s0"], b.get_field_data(ref.solver.species[0])) < 1e-11
     assert relerr(g["u"], b.get_field_data(ref.solver.u)) < 1e-11
+
+
+def test_compute_vorticity_and_qcriterion():
+    """pointwise snapshot fields of base_backend_t (src/backend/omp/backend.f90:616-649) on random gradients"""
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import DIR_X, VERT
+    g0 = load_golden("p000_rk3")
+    mesh = product_mesh(namelist(g0))
+    b = HipBackend(mesh)
+    al = b.allocator
+    nx, ny, nz = mesh.get_dims(VERT)
+    rng = np.random.default_rng(9)
+    host = [rng.standard_normal((nz, ny, nx)) for _ in range(9)]
+    blocks = []
+    for a in host:
+        f = al.get_block(DIR_X, VERT)
+        f.fill(0.0)
+        b.set_field_data(f, a)
+        blocks.append(f)
+    out = al.get_block(DIR_X, VERT)
+    dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz = host
+    b.compute_vorticity(out, *blocks)
+    ref = np.sqrt((dwdy - dvdz) ** 2 + (dudz - dwdx) ** 2 + (dvdx - dudy) ** 2)
+    assert relerr(b.get_field_data(out), ref) < 1e-15
+    b.compute_qcriterion(out, *blocks)
+    ref = -0.5 * (dudx * dudx + dvdy * dvdy + dwdz * dwdz) - dudy * dvdx - dudz * dwdx - dvdz * dwdy
+    assert relerr(b.get_field_data(out), ref) < 1e-14

@@ -323,6 +323,22 @@ class HipBackend:
     def field_shift(self, f, a):
         _lib.check(self.lib.x3d_field_shift(self.h, f.ptr, float(a)))
 
+    def _from_gradients(self, fn, field_out, grads):
+        if len(grads) != 9:
+            raise X3dError("nine gradient fields expected")
+        p = (VP * 9)(*[g.ptr for g in grads])
+        _lib.check(fn(self.h, field_out.ptr, p))
+
+    def compute_vorticity(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz):
+        """|curl u| from the nine velocity gradients (src/backend/omp/backend.f90:616-630)"""
+        self._from_gradients(self.lib.x3d_compute_vorticity, field_out,
+                             (dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz))
+
+    def compute_qcriterion(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz):
+        """Q-criterion (src/backend/omp/backend.f90:632-649)"""
+        self._from_gradients(self.lib.x3d_compute_qcriterion, field_out,
+                             (dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz))
+
     def lincomb(self, y, base, coeffs, xs):
         """extension: y = base + sum c_i x_i in one pass (time-integrator fusion)"""
         n = len(xs)

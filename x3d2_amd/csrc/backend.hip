@@ -197,6 +197,56 @@ extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
     return 0;
 }
 
+// compute_vorticity / compute_qcriterion (src/backend/omp/backend.f90:616-649): pointwise functions of the nine
+// velocity gradients, whole padded blocks like the reference.  g = {dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz}
+struct Grad9 { const double2 *g[9]; };
+template <bool QCRIT>
+__global__ void __launch_bounds__(256) k_from_gradients(double2 *__restrict__ out, Grad9 G, size_t n2)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += st) {
+        double2 v[9];
+#pragma unroll
+        for (int m = 0; m < 9; m++) v[m] = G.g[m][i];
+        auto f = [](double dudx, double dudy, double dudz, double dvdx, double dvdy, double dvdz, double dwdx,
+                    double dwdy, double dwdz) {
+            if (QCRIT)
+                return -0.5 * (dudx * dudx + dvdy * dvdy + dwdz * dwdz) - dudy * dvdx - dudz * dwdx - dvdz * dwdy;
+            return sqrt((dwdy - dvdz) * (dwdy - dvdz) + (dudz - dwdx) * (dudz - dwdx) +
+                        (dvdx - dudy) * (dvdx - dudy));
+        };
+        out[i] = make_double2(f(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x),
+                              f(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y));
+    }
+}
+
+static int from_gradients(x3d_backend *b, double *out, const double *const g[9], bool qcrit)
+{
+    X3D_REQUIRE(b && out && g, "derive_field_from_gradients: null argument");
+    Grad9 G;
+    for (int m = 0; m < 9; m++) {
+        X3D_REQUIRE(g[m] && g[m] != out, "derive_field_from_gradients: bad gradient block %d", m);
+        G.g[m] = (const double2 *)g[m];
+    }
+    ProfScope ps(b, X3D_K_BLAS1);
+    const size_t n2 = b->nblock / 2;
+    if (qcrit) hipLaunchKernelGGL(k_from_gradients<true>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)out, G, n2);
+    else hipLaunchKernelGGL(k_from_gradients<false>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)out, G, n2);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_compute_vorticity(x3d_backend *b, double *out, const double *const grads[9])
+{
+    return from_gradients(b, out, grads, false);
+}
+
+extern "C" int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grads[9])
+{
+    return from_gradients(b, out, grads, true);
+}
+
 extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 {
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
