@@ -16,6 +16,13 @@
 // Row tables live in LDS as [entry][lane] (conflict-free ds_read_b64).
 #include "common.h"
 
+// FAST transeq kernel: one workgroup per CU (129 KB of lane tables).  Measured: 12 waves with next-pencil
+// prefetch (163 VGPRs) 0.96 ms per component, 16 waves without it (123 VGPRs) 0.90 ms.
+#ifndef XS_TQ_THREADS
+#define XS_TQ_THREADS 1024
+#define XS_NOPREF 1
+#endif
+
 #ifndef XSCAN_EXP
 #define XSCAN_EXP 0  // timing experiments only (1: no stores, 2: no loads, 3: no scans)
 #endif
@@ -380,7 +387,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 
 // ---------------------------------------------------------------- transeq component
 template <int Q, bool SAME, bool ACC, bool FAST>
-__global__ void __launch_bounds__(FAST ? 768 : 512)
+__global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
                     XOp t2, XOp t3, int np, long pitch, double nu)
 {
@@ -401,10 +408,12 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
     const double *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
     double nbu[Q], nbc[Q];  // FAST: next pencil's rows of u and conv, in flight during the solve
+#ifndef XS_NOPREF
     if (FAST && p0 < np) {
         load_body<Q>(nbu, u + (long)p0 * pitch, lane);
         if (!SAME) load_body<Q>(nbc, cv + (long)p0 * pitch, lane);
     }
+#endif
     for (int p = p0; p < np; p += nwaves) {
         const double *__restrict__ ru = u + (long)p * pitch;
         const double *__restrict__ rc = cv + (long)p * pitch;
@@ -412,6 +421,10 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
         double wu[Q + 8], wp[Q + 8], vq[Q];
         const bool exact = FAST || n == 64 * Q;
         if (FAST) {
+#ifdef XS_NOPREF
+            load_body<Q>(nbu, u + (long)p * pitch, lane);
+            if (!SAME) load_body<Q>(nbc, cv + (long)p * pitch, lane);
+#endif
             window_from_body<Q>(wu, nbu, lane);
             if (!SAME) {
                 window_from_body<Q>(wp, nbc, lane);
@@ -421,10 +434,12 @@ __global__ void __launch_bounds__(FAST ? 768 : 512)
 #pragma unroll
                 for (int q = 0; q < Q; q++) vq[q] = nbu[q];
             }
+#ifndef XS_NOPREF
             if (p + nwaves < np) {
                 load_body<Q>(nbu, u + (long)(p + nwaves) * pitch, lane);
                 if (!SAME) load_body<Q>(nbc, cv + (long)(p + nwaves) * pitch, lane);
             }
+#endif
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
         } else {
@@ -536,7 +551,7 @@ static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const do
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(FAST ? 768 : 512), lds, b->stream, rhs, u, conv, xop_of(t1),
+    hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(FAST ? XS_TQ_THREADS : 512), lds, b->stream, rhs, u, conv, xop_of(t1),
                        xop_of(t2), xop_of(t3), np, (long)b->nxp, nu);
     X3D_HIP(hipGetLastError());
     return 0;
