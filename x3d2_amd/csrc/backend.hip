@@ -320,15 +320,20 @@ __global__ void __launch_bounds__(256) k_lincomb(double2 *__restrict__ y, const 
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += st) {
-        double2 r = base[i];
+        // streamed once: nontemporal (double2 has no builtin overload: two 8-byte accesses fuse back to 16)
+        const double *bp = reinterpret_cast<const double *>(base + i);
+        double2 r = make_double2(__builtin_nontemporal_load(bp), __builtin_nontemporal_load(bp + 1));
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (k < a.n) {
-                double2 v = a.x[k][i];
-                r.x = a.c[k] * v.x + r.x;
-                r.y = a.c[k] * v.y + r.y;
+                const double *xp = reinterpret_cast<const double *>(a.x[k] + i);
+                const double vx = __builtin_nontemporal_load(xp), vy = __builtin_nontemporal_load(xp + 1);
+                r.x = a.c[k] * vx + r.x;
+                r.y = a.c[k] * vy + r.y;
             }
-        y[i] = r;
+        double *yp = reinterpret_cast<double *>(y + i);
+        __builtin_nontemporal_store(r.x, yp);
+        __builtin_nontemporal_store(r.y, yp + 1);
     }
 }
 
