@@ -2,6 +2,7 @@
 # usage (on the GPU box): tools_prof.sh <tag>  -> gpurun_out/prof_<tag>/ + kernel stats on stdout
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_$tag  # a repeated tag must not pick up the previous run's stats
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/prof_$tag.log 2>&1
 f=$(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
 python - "$f" <<'PY'
