@@ -92,10 +92,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    # X3D_BENCH_SHARE_GPU=1 (dry runs of the multi-rank path on a one-GPU box): all ranks on cuda:0, exchanges
+    # staged through gloo -- never what the driver measures
+    share = os.environ.get("X3D_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
@@ -136,7 +142,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
