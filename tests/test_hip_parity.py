@@ -532,7 +532,8 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
 
 
-@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512), (32, 256, 8), (64, 8, 256)])
+@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512), (32, 256, 8), (64, 8, 256), (40, 256, 9), (72, 8, 256),
+                                  (128, 256, 8)])
 def test_yz_operators_on_512_row_pencils(dims):
     """y / z pencils of 512 (the bench size) and 256 rows: every operator incl. accumulating forms against
     the oracle.  These are the sizes at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""

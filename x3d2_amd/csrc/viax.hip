@@ -1,0 +1,153 @@
+// K3t: y/z transport-equation components through the wave-per-pencil scan kernel (xscan.hip, K3s).
+//
+// The lane-per-pencil two-sweep pair of tds.hip moves 11 field passes per component (3 intermediate arrays
+// written by the forward sweep and read back by the backward sweep).  The scan kernel does a component in one
+// pass, but wants its pencils contiguous.  For periodic pencils of 64 Q rows this file therefore
+//     T   = transpose(field)          [z][y][x] -> [z][x][y]   (dir y)   or   [y][x][z]   (dir z)
+//     tmp = k_xscan_transeq(T, T0)    one pass, pencils 8 Q*64 bytes long
+//     rhs (+)= transpose^-1(tmp)
+// = 2 + 3 (2) + 3 (2) passes at the streaming rate instead of 11, all three intermediates in the backend's
+// scratch blocks that the two-sweep path would have used for its own intermediates.
+// Same arithmetic as x3d_xdir_transeq, i.e. exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:79-190)
+// + the 2x2 reduced systems of der_univ_subs, and the component permutation of
+// src/backend/omp/backend.f90:145-184.
+#include "common.h"
+
+int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                         const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
+                         int dirtag, bool *done);
+bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+
+// dst[c*dC + a*dA + b] (+)= src[c*sC + b*sB + a]: 64 x 64 tiles through LDS, 512-byte rows on both sides
+template <bool ACC, bool NT>
+__global__ void __launch_bounds__(256)
+    k_transpose64(double *__restrict__ dst, const double *__restrict__ src, int nA, int nB, long dA, long dC, long sB,
+                  long sC)
+{
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const double *__restrict__ sp = src + (long)blockIdx.z * sC;
+    double *__restrict__ dp = dst + (long)blockIdx.z * dC;
+    const bool full = a0 + 64 <= nA && b0 + 64 <= nB;
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            {
+            const double *q = &sp[a0 + tx + (long)(b0 + ty + 4 * r) * sB];
+            tile[ty + 4 * r][tx] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            double *q = &dp[(long)(a0 + ty + 4 * r) * dA + b0 + tx];
+            const double v = tile[tx][ty + 4 * r];
+            if (ACC) *q += v;
+            else *q = v;
+        }
+    } else {
+        for (int r = 0; r < 16; r++) {
+            const int bb = b0 + ty + 4 * r, aa = a0 + tx;
+            if (aa < nA && bb < nB) tile[ty + 4 * r][tx] = sp[aa + (long)bb * sB];
+        }
+        __syncthreads();
+        for (int r = 0; r < 16; r++) {
+            const int aa = a0 + ty + 4 * r, bb = b0 + tx;
+            if (aa < nA && bb < nB) {
+                double *q = &dp[(long)aa * dA + bb];
+                const double v = tile[tx][ty + 4 * r];
+                if (ACC) *q += v;
+                else *q = v;
+            }
+        }
+    }
+}
+
+static bool use_via_x()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_NO_VIA_X"), *f = getenv("X3D_NO_XSCAN");
+        mode = ((e && e[0] == '1') || (f && f[0] == '1')) ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+struct ViaGeom {
+    int nA, nB, nC;        // forward transpose: A = x (contiguous in the block), B = the pencil direction, C = the other
+    long f_dA, f_dC, f_sB, f_sC;
+    int np;
+    long pitch;
+};
+
+static ViaGeom via_geom(const x3d_backend *b, int dir)
+{
+    ViaGeom g;
+    const long px = b->nxp, pxy = (long)b->nxp * b->nyp;
+    if (dir == X3D_DIR_Y) {  // T[z][x][y]
+        g.nA = b->nx; g.nB = b->ny; g.nC = b->nz;
+        g.f_sB = px; g.f_sC = pxy;
+        g.f_dA = b->ny; g.f_dC = (long)b->nx * b->ny;
+        g.pitch = b->ny; g.np = b->nx * b->nz;
+    } else {  // T[y][x][z]
+        g.nA = b->nx; g.nB = b->nz; g.nC = b->ny;
+        g.f_sB = pxy; g.f_sC = px;
+        g.f_dA = b->nz; g.f_dC = (long)b->nx * b->nz;
+        g.pitch = b->nz; g.np = b->nx * b->ny;
+    }
+    return g;
+}
+
+static int to_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *T, const double *f)
+{
+    ProfScope ps(b, X3D_K_PACK, dir);
+    dim3 grid((g.nA + 63) / 64, (g.nB + 63) / 64, g.nC);
+    hipLaunchKernelGGL((k_transpose64<false, false>), grid, dim3(256), 0, b->stream, T, f, g.nA, g.nB, g.f_dA, g.f_dC, g.f_sB,
+                       g.f_sC);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *r, const double *T, int acc)
+{
+    ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
+    // inverse: A' = the pencil direction (contiguous in T), B' = x
+    dim3 grid((g.nB + 63) / 64, (g.nA + 63) / 64, g.nC);
+    if (acc)
+        hipLaunchKernelGGL((k_transpose64<true, true>), grid, dim3(256), 0, b->stream, r, T, g.nB, g.nA, g.f_sB, g.f_sC, g.f_dA,
+                           g.f_dC);
+    else
+        hipLaunchKernelGGL((k_transpose64<false, true>), grid, dim3(256), 0, b->stream, r, T, g.nB, g.nA, g.f_sB, g.f_sC,
+                           g.f_dA, g.f_dC);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// r[c] (+)= transeq component c of direction dir (y or z); f[0] is the advecting component
+int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                      const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                      const x3d_tdsops *der2nd_sym, int acc, bool *done)
+{
+    *done = false;
+    if (!use_via_x() || dir == X3D_DIR_X) return 0;
+    if (!x3d_xscan_fast_ok(der1st, der1st_sym, der2nd) || !x3d_xscan_fast_ok(der1st_sym, der1st, der2nd_sym)) return 0;
+    const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+    if (der1st->n_tds != n) return 0;
+    const ViaGeom g = via_geom(b, dir);
+    if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
+    double *T0 = b->scratch[0], *T1 = b->scratch[1], *tmp = b->scratch[2];
+    bool ok = false;
+    if (int rc = to_pencils(b, dir, g, T0, f[0])) return rc;
+    if (int rc = x3d_xscan_transeq_np(b, tmp, T0, T0, nu, der1st, der1st_sym, der2nd, 0, g.np, g.pitch, dir, &ok)) return rc;
+    if (!ok) return 0;  // nothing written to r yet
+    if (int rc = from_pencils(b, dir, g, r[0], tmp, acc)) return rc;
+    for (int c = 1; c < 3; c++) {
+        if (int rc = to_pencils(b, dir, g, T1, f[c])) return rc;
+        if (int rc = x3d_xscan_transeq_np(b, tmp, T1, T0, nu, der1st_sym, der1st, der2nd_sym, 0, g.np, g.pitch, dir, &ok))
+            return rc;
+        X3D_REQUIRE(ok, "x3d_transeq_via_x: scan kernel refused component %d", c);
+        if (int rc = from_pencils(b, dir, g, r[c], tmp, acc)) return rc;
+    }
+    *done = true;
+    return 0;
+}

@@ -543,7 +543,7 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
 template <int Q, bool SAME, bool ACC, bool FAST>
 static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                           const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int np, int blocks,
-                          size_t lds)
+                          size_t lds, long pitch)
 {
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
@@ -552,30 +552,33 @@ static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const do
         attr_set = true;
     }
     hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(FAST ? XS_TQ_THREADS : 512), lds, b->stream, rhs, u, conv, xop_of(t1),
-                       xop_of(t2), xop_of(t3), np, (long)b->nxp, nu);
+                       xop_of(t2), xop_of(t3), np, pitch, nu);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
-                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
+// np pencils of contiguous rows, `pitch` doubles apart: the x pencils of the Cartesian block, or the pencils
+// of a transposed copy (tds.hip, transeq_via_x)
+int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                         const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
+                         int dirtag, bool *done)
 {
     *done = false;
     if (!xscan_ok(t1) || !xscan_ok(t2) || !xscan_ok(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return 0;
-    const int Q = t1->tab.Q, np = b->ny * b->nz;
+    const int Q = t1->tab.Q;
     const size_t lds = sizeof(double) * 3 * LT_N(Q) * 64;
     if (lds > 160 * 1024) return 0;
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;  // one 8/12-wave workgroup per CU (129 KB of lane tables in LDS)
     const bool same = u == conv;
-    ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dirtag);
     int rc;
     const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q;
 #define GO2(Q_, F_)                                                                                            \
-    (same ? (acc ? launch_transeq<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)       \
-                 : launch_transeq<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds))     \
-          : (acc ? launch_transeq<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)      \
-                 : launch_transeq<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds)))
+    (same ? (acc ? launch_transeq<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)       \
+                 : launch_transeq<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch))     \
+          : (acc ? launch_transeq<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)      \
+                 : launch_transeq<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)))
 #define GO(Q_) (fast ? GO2(Q_, true) : GO2(Q_, false))
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO
@@ -583,4 +586,18 @@ int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double
     if (rc) return rc;
     *done = true;
     return 0;
+}
+
+int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
+{
+    return x3d_xscan_transeq_np(b, rhs, u, conv, nu, t1, t2, t3, acc, b->ny * b->nz, (long)b->nxp, X3D_DIR_X, done);
+}
+
+// true when the branch-free kernels apply to these operators (periodic / halo ends, n = 64 Q rows)
+bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3)
+{
+    if (!xscan_ok(t1) || !xscan_ok(t2) || !xscan_ok(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return false;
+    return t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * t1->tab.Q &&
+           t2->n_tds == t1->n_tds && t3->n_tds == t1->n_tds;
 }
