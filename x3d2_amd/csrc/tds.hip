@@ -136,7 +136,9 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         }
         double mf[64], mb[64];
         for (int l = 0; l < 64; l++) { mf[l] = G[l]; mb[l] = HL[l]; }
-        for (int k = 0; k < 6; k++) {  // data-independent multipliers of the Kogge-Stone steps
+        // data-independent multipliers of the wave scans (xscan.hip, scan_solve): Kogge-Stone steps
+        // 1, 2, 4, 8 inside each row of 16 lanes (DPP row shifts), then two steps across the rows
+        for (int k = 0; k < 4; k++) {
             const int d = 1 << k;
             double nf[64], nb[64];
             for (int l = 0; l < 64; l++) {
@@ -146,6 +148,18 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                 nb[l] = l + d < 64 ? mb[l] * mb[l + d] : mb[l];
             }
             for (int l = 0; l < 64; l++) { mf[l] = nf[l]; mb[l] = nb[l]; }
+        }
+        for (int l = 0; l < 64; l++) {
+            double c15 = 1.0, c31 = 1.0, d16 = 1.0, d32 = 1.0;
+            for (int i = l & ~15; i <= l; i++) c15 *= G[i];   // row start .. l: carries lane 15 / 47 into rows 1 / 3
+            for (int i = 32; i <= l; i++) c31 *= G[i];        // 32 .. l: carries lane 31 into rows 2, 3
+            for (int i = l; i <= (l | 15); i++) d16 *= HL[i]; // l .. row end: carries lane 16 / 48 into rows 0 / 2
+            for (int i = l; i <= 31; i++) d32 *= HL[i];       // l .. 31: carries lane 32 into rows 0, 1
+            const int row = l >> 4;
+            E(9 * Q + 4, l) = (row == 1 || row == 3) ? c15 : 0.0;
+            E(9 * Q + 5, l) = row >= 2 ? c31 : 0.0;
+            E(9 * Q + 6 + 4, l) = (row == 0 || row == 2) ? d16 : 0.0;
+            E(9 * Q + 6 + 5, l) = row < 2 ? d32 : 0.0;
         }
     }
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));

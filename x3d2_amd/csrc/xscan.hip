@@ -59,6 +59,20 @@ static XOp xop_of(const x3d_tdsops *t)
     return o;
 }
 
+// DPP move of a double; lanes whose source lane does not exist (or whose row is masked out) read 0
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ double dpp0(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
 {
     const double r = __shfl_up(v, d, 64);
@@ -121,9 +135,15 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
 #if XSCAN_EXP == 3
     double carry = v;
 #else
-#pragma unroll
-    for (int k = 0; k < 6; k++) v += lt[LT_MF(k) * 64 + lane] * shfl_up_d(v, 1 << k, lane);
-    double carry = shfl_up_d(v, 1, lane);
+    // prefix scan without LDS traffic: in-row Kogge-Stone by DPP row shifts, then lane 15 / 47 into rows
+    // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0
+    v += lt[LT_MF(0) * 64 + lane] * dpp0<0x111>(v);
+    v += lt[LT_MF(1) * 64 + lane] * dpp0<0x112>(v);
+    v += lt[LT_MF(2) * 64 + lane] * dpp0<0x114>(v);
+    v += lt[LT_MF(3) * 64 + lane] * dpp0<0x118>(v);
+    v += lt[LT_MF(4) * 64 + lane] * dpp0<0x142, 0xA>(v);
+    v += lt[LT_MF(5) * 64 + lane] * dpp0<0x143, 0xC>(v);
+    double carry = dpp0<0x138>(v);  // wave_shr:1
 #endif
     // ---- apply, lane-local back-substitution from zero
     double nxt = 0.0;
@@ -139,9 +159,17 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
 #if XSCAN_EXP == 3
     carry = v;
 #else
-#pragma unroll
-    for (int k = 0; k < 6; k++) v += lt[LT_MB(k) * 64 + lane] * shfl_down_d(v, 1 << k, lane);
-    carry = shfl_down_d(v, 1, lane);
+    // suffix scan: row shifts the other way, then lane 16 / 48 into rows 0 / 2 and lane 32 into rows 0, 1
+    v += lt[LT_MB(0) * 64 + lane] * dpp0<0x101>(v);
+    v += lt[LT_MB(1) * 64 + lane] * dpp0<0x102>(v);
+    v += lt[LT_MB(2) * 64 + lane] * dpp0<0x104>(v);
+    v += lt[LT_MB(3) * 64 + lane] * dpp0<0x108>(v);
+    {
+        const double s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
+        v += lt[LT_MB(4) * 64 + lane] * (lane < 32 ? s16 : s48);
+        v += lt[LT_MB(5) * 64 + lane] * readlane_d(v, 32);
+    }
+    carry = dpp0<0x130>(v);  // wave_shl:1
 #endif
 #pragma unroll
     for (int q = 0; q < Q; q++) X[q] = X[q] + lt[LT_QB(q) * 64 + lane] * carry;
@@ -198,11 +226,11 @@ __device__ __forceinline__ void load_body(double (&b)[Q], const double *__restri
 template <int Q>
 __device__ __forceinline__ void window_from_body(double (&w)[Q + 8], const double (&b)[Q], int lane)
 {
-    const int lp = (lane + 63) & 63, ln = (lane + 1) & 63;
+    (void)lane;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        w[m] = __shfl(b[Q - 4 + m], lp, 64);
-        w[Q + 4 + m] = __shfl(b[m], ln, 64);
+        w[m] = dpp0<0x13C>(b[Q - 4 + m]);      // wave_ror:1: from lane - 1, periodic wrap
+        w[Q + 4 + m] = dpp0<0x134>(b[m]);      // wave_rol:1: from lane + 1
     }
 #pragma unroll
     for (int q = 0; q < Q; q++) w[4 + q] = b[q];
