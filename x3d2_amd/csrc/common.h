@@ -68,8 +68,12 @@ void x3d_prof_end(x3d_backend *b);
 int x3d_prof_enable_c(x3d_backend *b, int on);
 struct ProfScope {
     x3d_backend *b;
-    ProfScope(x3d_backend *b_, int kind, int dir = 0) : b(b_) { if (b->prof) x3d_prof_begin(b, kind, dir); }
-    ~ProfScope() { if (b->prof) x3d_prof_end(b); }
+    bool on;  // false: the caller times a group of launches as one (scopes do not nest)
+    ProfScope(x3d_backend *b_, int kind, int dir = 0, bool on_ = true) : b(b_), on(on_ && b_->prof)
+    {
+        if (on) x3d_prof_begin(b, kind, dir);
+    }
+    ~ProfScope() { if (on) x3d_prof_end(b); }
 };
 
 // Device-side view of one tdsops_t: row tables prepared on the host from the

@@ -73,6 +73,17 @@ static bool use_via_x()
     return mode == 1;
 }
 
+static int via_slabs(int nC)
+{
+    static int n = -1;
+    if (n < 0) {
+        const char *e = getenv("X3D_VIA_SLABS");
+        n = e ? atoi(e) : 1;
+        if (n < 1) n = 1;
+    }
+    return n > nC ? nC : n;
+}
+
 struct ViaGeom {
     int nA, nB, nC;        // forward transpose: A = x (contiguous in the block), B = the pencil direction, C = the other
     long f_dA, f_dC, f_sB, f_sC;
@@ -98,21 +109,24 @@ static ViaGeom via_geom(const x3d_backend *b, int dir)
     return g;
 }
 
-static int to_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *T, const double *f)
+// (c0, nc): the slab of C planes to move
+static int to_pencils(x3d_backend *b, const ViaGeom &g, double *T, const double *f, int c0, int nc)
 {
-    ProfScope ps(b, X3D_K_PACK, dir);
-    dim3 grid((g.nA + 63) / 64, (g.nB + 63) / 64, g.nC);
-    hipLaunchKernelGGL((k_transpose64<false, false>), grid, dim3(256), 0, b->stream, T, f, g.nA, g.nB, g.f_dA, g.f_dC, g.f_sB,
-                       g.f_sC);
+    dim3 grid((g.nA + 63) / 64, (g.nB + 63) / 64, nc);
+    hipLaunchKernelGGL((k_transpose64<false, false>), grid, dim3(256), 0, b->stream, T + c0 * g.f_dC, f + c0 * g.f_sC,
+                       g.nA, g.nB, g.f_dA, g.f_dC, g.f_sB, g.f_sC);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *r, const double *T, int acc)
+static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *r, const double *T, int acc, int c0,
+                        int nc)
 {
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
     // inverse: A' = the pencil direction (contiguous in T), B' = x
-    dim3 grid((g.nB + 63) / 64, (g.nA + 63) / 64, g.nC);
+    dim3 grid((g.nB + 63) / 64, (g.nA + 63) / 64, nc);
+    r += c0 * g.f_sC;
+    T += c0 * g.f_dC;
     if (acc)
         hipLaunchKernelGGL((k_transpose64<true, true>), grid, dim3(256), 0, b->stream, r, T, g.nB, g.nA, g.f_sB, g.f_sC, g.f_dA,
                            g.f_dC);
@@ -136,17 +150,32 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
     const ViaGeom g = via_geom(b, dir);
     if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
     double *T0 = b->scratch[0], *T1 = b->scratch[1], *tmp = b->scratch[2];
-    bool ok = false;
-    if (int rc = to_pencils(b, dir, g, T0, f[0])) return rc;
-    if (int rc = x3d_xscan_transeq_np(b, tmp, T0, T0, nu, der1st, der1st_sym, der2nd, 0, g.np, g.pitch, dir, &ok)) return rc;
-    if (!ok) return 0;  // nothing written to r yet
-    if (int rc = from_pencils(b, dir, g, r[0], tmp, acc)) return rc;
-    for (int c = 1; c < 3; c++) {
-        if (int rc = to_pencils(b, dir, g, T1, f[c])) return rc;
-        if (int rc = x3d_xscan_transeq_np(b, tmp, T1, T0, nu, der1st_sym, der1st, der2nd_sym, 0, g.np, g.pitch, dir, &ok))
-            return rc;
-        X3D_REQUIRE(ok, "x3d_transeq_via_x: scan kernel refused component %d", c);
-        if (int rc = from_pencils(b, dir, g, r[c], tmp, acc)) return rc;
+    // slabs of C planes: the transposed copies and the scan kernel's output of one slab are produced and
+    // consumed back to back, so that most of their re-reads hit the 256 MB Infinity Cache
+    const int nslab = via_slabs(g.nC);
+    for (int sl = 0; sl < nslab; sl++) {
+        const int c0 = (int)((long)g.nC * sl / nslab), nc = (int)((long)g.nC * (sl + 1) / nslab) - c0;
+        const long off = c0 * g.f_dC;  // pencils c0 * nA ... of the transposed copies
+        const int np = nc * g.nA;
+        for (int c = 0; c < 3; c++) {
+            bool ok = false;
+            double *T = c == 0 ? T0 : T1;
+            // profiler: transpose + scan kernel = the component's "forward" launch, the accumulating
+            // inverse transpose its "backward" launch (bench.py prices a component as fwd + bwd)
+            {
+                ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+                if (int rc = to_pencils(b, g, T, f[c], c0, nc)) return rc;
+                if (int rc = x3d_xscan_transeq_np(b, tmp + off, T + off, T0 + off, nu, c == 0 ? der1st : der1st_sym,
+                                                  c == 0 ? der1st_sym : der1st, c == 0 ? der2nd : der2nd_sym, 0, np,
+                                                  g.pitch, -1, &ok))
+                    return rc;
+            }
+            if (!ok) {
+                X3D_REQUIRE(sl == 0 && c == 0, "x3d_transeq_via_x: scan kernel refused component %d", c);
+                return 0;  // nothing written to r yet
+            }
+            if (int rc = from_pencils(b, dir, g, r[c], tmp, acc, c0, nc)) return rc;
+        }
     }
     *done = true;
     return 0;

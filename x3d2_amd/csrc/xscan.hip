@@ -599,7 +599,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;  // one 8/12-wave workgroup per CU (129 KB of lane tables in LDS)
     const bool same = u == conv;
-    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dirtag);
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dirtag, dirtag >= 0);  // dirtag < 0: timed by the caller
     int rc;
     const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q;
 #define GO2(Q_, F_)                                                                                            \
