@@ -156,6 +156,20 @@ int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grad
  * veccopy/vecadd chains of src/time_integrator.f90:166-282 into one pass. */
 int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
                 const double *const *x);
+/* fusion extension of the pair above for the last direction (y or z) of transeq_default when its pencils
+ * run through the single-pass scan kernel (csrc/viax.hip): x3d_transeq_defer computes the three components
+ * like x3d_transeq_acc(accumulate = 1) but leaves "d{u,v,w} += result" pending -- the results stay in
+ * the blocks pu, pv, pw in pencil layout; *deferred = 0 when this path does not apply (nothing was done: call
+ * x3d_transeq_acc).  x3d_lincomb_pending is x3d_lincomb with term x[ipend] completed on the fly,
+ *   x[ipend] + pending -> d;  store != 0: x[ipend] = d;  y = base + sum_i c[i] * (i == ipend ? d : x[i]),
+ * bit-identical to x3d_pending_flush (x[ipend] += pending) followed by x3d_lincomb. */
+int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv, double *pw, const double *u,
+                      const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                      const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                      int *deferred);
+int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend);
+int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm, const double *c,
+                        double *const *x, int ipend, const double *pend, int store);
 
 /* ---- reductions over the unpadded extent dims[3] of the field's data_loc.
  * Rank-local values; the caller does the cross-rank reduction (the reference

@@ -720,3 +720,68 @@ def test_tgv512_fast_paths_match_general_kernels():
     assert fast[-1, 2] < 1e-10 and general[-1, 2] < 1e-10
     # enstrophy of the Taylor-Green vortex at t = 0 on a 2 pi box: 3/8
     assert abs(fast[0, 1] - 0.375) < 1e-6
+
+
+@pytest.mark.parametrize("intg", ["RK3", "RK4", "AB3"])
+def test_deferred_transeq_accumulation_is_bit_identical(intg):
+    """fused driver with the last accumulation of transeq folded into the RK stage's linear combination
+    (csrc/viax.hip: x3d_transeq_defer / x3d_lincomb_pending; engages for 256 / 512-row periodic z pencils):
+    bit-identical to the same run with X3D_NO_DEFER=1, and equal to the oracle's steps."""
+    import os
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.case import BaseCase
+    from x3d2_amd.common import VERT
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims, L = (16, 256, 256), (2.0, 3.0, 2.5)
+    per = ("periodic",) * 2
+    rng = np.random.default_rng(11)
+    init = [0.3 * rng.standard_normal((dims[2], dims[1], dims[0])) for _ in range(3)]
+
+    class _Case(BaseCase):  # no forcings / BC hooks, like the TGV case
+        def initial_conditions(self):
+            pass
+
+    def run(no_defer):
+        if no_defer:
+            os.environ["X3D_NO_DEFER"] = "1"
+        else:
+            os.environ.pop("X3D_NO_DEFER", None)
+        try:
+            mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
+            s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True, time_intg=intg,
+                                                            dt=1e-3, Re=100.0))
+            case = _Case(s)
+            for f, a in zip((s.u, s.v, s.w), init):
+                f.set_data_loc(VERT)
+                s.backend.set_field_data(f, a)
+            calls = {"n": 0}
+            real = s.backend.lincomb_pending
+
+            def counted(*args, **kw):
+                calls["n"] += 1
+                return real(*args, **kw)
+            s.backend.lincomb_pending = counted
+            for it in (1, 2):
+                case.step(it)
+            return [s.backend.get_field_data(f, VERT) for f in (s.u, s.v, s.w)], calls["n"]
+        finally:
+            os.environ.pop("X3D_NO_DEFER", None)
+
+    fused, n_fused = run(False)
+    plain, n_plain = run(True)
+    assert n_plain == 0
+    if intg.startswith("RK"):
+        assert n_fused == 3 * 2 * int(intg[2])  # every stage of every variable took the fused kernel
+    for a, b_ in zip(fused, plain):
+        assert np.array_equal(a, b_)
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
+    o = orc.Solver(om, poisson="CG", time_intg=intg, dt=1e-3, Re=100.0)
+    for fo, a in zip((o.u, o.v, o.w), init):
+        fo.data_loc = orc.VERT
+        o.backend.set_field_data(fo, a)
+    for it in (1, 2):
+        o.step(pressure=False)  # (the HIP run's "CG" placeholder pressure is zero)
+    for a, fo, nm in zip(fused, (o.u, o.v, o.w), "uvw"):
+        assert relerr(a, o.backend.get_field_data(fo, orc.VERT)) < TOL, nm

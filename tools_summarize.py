@@ -34,13 +34,13 @@ with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as f:
 # (x, LDS-tiled) or ONE k_xscan_transeq / k_transeq_onchip launch (single pass)
 heads = ("k_transeq_fwd", "k_xtranseq_fwd", "k_xscan_transeq", "k_transeq_onchip")
 # + the transposes of the y / z components that run through the scan kernel (viax.hip)
-tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_transpose64" in k)
+tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_transpose" in k)
 n_comp = sum(n for k, n, fe, wr in rows if any(h in k for h in heads))
 comp = tot_bytes / n_comp if n_comp else 0.0
 calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
 json.dump({"n": 512, "round": rnd, "transeq_component_bytes_per_launch": comp,
            "components_profiled": n_comp,
-           "note": "HBM bytes per transport-equation component (all k_*transeq* + k_transpose64 kernels / number of components) "
+           "note": "HBM bytes per transport-equation component (all k_*transeq* + k_transpose64 + k_transpose_lincomb kernels / number of components; the latter also does the RK stage's linear combination) "
                    "from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
                    "MI355X_MICROARCH.md (calibrated in round 1 on k_tds_fwd: one 1 GiB field read = 0.508 GiB raw)"},
           open("profiles/traffic.json", "w"), indent=1)

@@ -232,6 +232,29 @@ class HipBackend:
             _lib.check(self.lib.x3d_vecadd(self.h, 1.0, t.ptr, 1.0, r.ptr))
             self.allocator.release_block(t)
 
+    def transeq_dir_defer(self, direction, pend, u, v, w, nu, dirps):
+        """transeq_dir(accumulate=True) with the accumulation left pending (csrc/viax.hip): the results stay in
+        the blocks `pend` (pencil layout) until lincomb_pending / pending_flush.  False: not applicable here,
+        nothing was done."""
+        if self._decomposed(direction):
+            return False
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_defer(self.h, direction, pend[0].ptr, pend[1].ptr, pend[2].ptr, u.ptr, v.ptr,
+                                              w.ptr, float(nu), dirps.der1st.handle, dirps.der1st_sym.handle,
+                                              dirps.der2nd.handle, dirps.der2nd_sym.handle, ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def pending_flush(self, direction, r_ptr, pend):
+        _lib.check(self.lib.x3d_pending_flush(self.h, direction, r_ptr, pend.ptr))
+
+    def lincomb_pending(self, y, base, coeffs, xs, ipend, pend, direction, store):
+        """lincomb with term xs[ipend] completed on the fly from its pending transeq component"""
+        n = len(xs)
+        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        p = (VP * n)(*[x.ptr for x in xs])
+        _lib.check(self.lib.x3d_lincomb_pending(self.h, direction, y.ptr, base.ptr, n, c, p, int(ipend), pend.ptr,
+                                                int(bool(store))))
+
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""
         if not self._decomposed(direction):

@@ -70,9 +70,15 @@ class BaseCase:
         curr = [s.u, s.v, s.w] + list(s.species)  # base_case.f90:236-241
         self.define_BC()
         deriv = [al.get_block(DIR_X) for _ in range(s.nvars)]
-        s.transeq(deriv, curr)
-        self.forcings(deriv[0], deriv[1], deriv[2], it)
-        s.time_integrator.step(curr, deriv, s.dt)
+        if s.fused and type(self).forcings is BaseCase.forcings:
+            # nothing touches the derivatives between transeq and the RK / AB stage: the last accumulation of
+            # transeq may be folded into the stage's linear combination (Solver.transeq_fused)
+            pending = s.transeq(deriv, curr, defer=True)
+            s.time_integrator.step(curr, deriv, s.dt, pending=pending)
+        else:
+            s.transeq(deriv, curr)
+            self.forcings(deriv[0], deriv[1], deriv[2], it)
+            s.time_integrator.step(curr, deriv, s.dt)
         for f in deriv:
             al.release_block(f)
         self.apply_BC(s.u, s.v, s.w)

@@ -180,3 +180,163 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
     *done = true;
     return 0;
 }
+
+// ---------------------------------------------------------------- deferred accumulation (fused RK stage)
+// The last direction's accumulating transposes can be folded into the time integrator's linear
+// combination (time_integrator.py, runge_kutta_fused): x3d_transeq_defer leaves the scan kernel's outputs in
+// pend[c] (pencil layout), x3d_lincomb_pending then computes, per point,
+//     d = x[ipend] + transpose^-1(pend);  [x[ipend] = d;]  y = base + sum_k c[k] * (k == ipend ? d : x[k])
+// in the summation order of k_lincomb (backend.hip): bit-identical to from_pencils followed by x3d_lincomb, with
+// 4 field passes fewer per variable and RK3 step.
+struct LinPend {
+    const double *x[5];
+    double c[5];
+    int n, ipend;
+};
+
+__device__ __forceinline__ double2 ldnt2(const double *p)
+{
+    return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256)
+    k_transpose_lincomb(double *y, const double *base, double *xp, const double *__restrict__ src, int nA, int nB,
+                        long dA, long dC, long sB, long sC, LinPend a)
+{
+    __shared__ double tile[64][65];
+    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const double *__restrict__ sp = src + (long)blockIdx.z * sC;
+    const long cof = (long)blockIdx.z * dC;
+    const bool full = a0 + 64 <= nA && b0 + 64 <= nB && (dA & 1) == 0 && (dC & 1) == 0;
+    if (full) {
+        {
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                tile[ty + 4 * r][tx] = __builtin_nontemporal_load(&sp[a0 + tx + (long)(b0 + ty + 4 * r) * sB]);
+        }
+        __syncthreads();
+        // 16-byte accesses along the contiguous index of the block, every term streamed once
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll 2
+        for (int r = 0; r < 8; r++) {
+            const int al = ty + 8 * r;
+            const long i = cof + (long)(a0 + al) * dA + b0 + 2 * tx;
+            double2 d = ldnt2(xp + i);
+            d.x += tile[2 * tx][al];
+            d.y += tile[2 * tx + 1][al];
+            if (STORE) { xp[i] = d.x; xp[i + 1] = d.y; }
+            double2 v = ldnt2(base + i);
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < a.n) {
+                    double2 t = d;
+                    if (k != a.ipend) t = ldnt2(a.x[k] + i);
+                    v.x = a.c[k] * t.x + v.x;
+                    v.y = a.c[k] * t.y + v.y;
+                }
+            __builtin_nontemporal_store(v.x, y + i);
+            __builtin_nontemporal_store(v.y, y + i + 1);
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = 0; r < 16; r++) {
+        const int bb = b0 + ty + 4 * r, aa = a0 + tx;
+        if (aa < nA && bb < nB) tile[ty + 4 * r][tx] = sp[aa + (long)bb * sB];
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; r++) {
+        const int aa = a0 + ty + 4 * r, bb = b0 + tx;
+        if (aa < nA && bb < nB) {
+            const long i = cof + (long)aa * dA + bb;
+            const double d = xp[i] + tile[tx][ty + 4 * r];
+            if (STORE) xp[i] = d;
+            double v = base[i];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (k < a.n) v = a.c[k] * (k == a.ipend ? d : a.x[k][i]) + v;
+            y[i] = v;
+        }
+    }
+}
+
+static int defer_perm(int dir, int c)  // component c of direction dir -> index into (du, dv, dw)
+{
+    static const int py[3] = {1, 0, 2}, pz[3] = {2, 0, 1};
+    return dir == X3D_DIR_Y ? py[c] : pz[c];
+}
+
+extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv, double *pw, const double *u,
+                                 const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                                 const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                                 const x3d_tdsops *der2nd_sym, int *deferred)
+{
+    X3D_REQUIRE(b && pu && pv && pw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && deferred,
+                "x3d_transeq_defer: null argument");
+    *deferred = 0;
+    if (!use_via_x() || (dir != X3D_DIR_Y && dir != X3D_DIR_Z)) return 0;
+    if (!x3d_xscan_fast_ok(der1st, der1st_sym, der2nd) || !x3d_xscan_fast_ok(der1st_sym, der1st, der2nd_sym)) return 0;
+    const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+    if (der1st->n_tds != n) return 0;
+    const ViaGeom g = via_geom(b, dir);
+    if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
+    double *pend[3] = {pu, pv, pw};
+    const double *fld[3] = {u, v, w};
+    double *T0 = b->scratch[0], *T1 = b->scratch[1];
+    for (int c = 0; c < 3; c++) {
+        const int m = defer_perm(dir, c);
+        double *T = c == 0 ? T0 : T1;
+        bool ok = false;
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+        if (int rc = to_pencils(b, g, T, fld[m], 0, g.nC)) return rc;
+        if (int rc = x3d_xscan_transeq_np(b, pend[m], T, T0, nu, c == 0 ? der1st : der1st_sym,
+                                          c == 0 ? der1st_sym : der1st, c == 0 ? der2nd : der2nd_sym, 0, g.np, g.pitch,
+                                          -1, &ok))
+            return rc;
+        if (!ok) {
+            X3D_REQUIRE(c == 0, "x3d_transeq_defer: scan kernel refused component %d", c);
+            return 0;
+        }
+    }
+    *deferred = 1;
+    return 0;
+}
+
+// r += transpose^-1(pend): the plain completion of a deferred component
+extern "C" int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend)
+{
+    X3D_REQUIRE(b && r && pend, "x3d_pending_flush: null argument");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_pending_flush: dir must be Y or Z");
+    return from_pencils(b, dir, via_geom(b, dir), r, pend, 1, 0, via_geom(b, dir).nC);
+}
+
+extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm,
+                                   const double *c, double *const *x, int ipend, const double *pend, int store)
+{
+    X3D_REQUIRE(b && y && base && c && x && pend, "x3d_lincomb_pending: null argument");
+    X3D_REQUIRE(nterm >= 1 && nterm <= 5 && ipend >= 0 && ipend < nterm, "x3d_lincomb_pending: bad term count / index");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_lincomb_pending: dir must be Y or Z");
+    X3D_REQUIRE(y != x[ipend] && base != x[ipend], "x3d_lincomb_pending: the pending term aliases y or base");
+    const ViaGeom g = via_geom(b, dir);
+    LinPend a;
+    a.n = nterm;
+    a.ipend = ipend;
+    for (int k = 0; k < 5; k++) {
+        a.x[k] = k < nterm ? x[k] : x[0];
+        a.c[k] = k < nterm ? c[k] : 0.0;
+    }
+    // booked as the component's "backward" launch although it also does the RK stage's combination:
+    // bench.py's roofline for the transeq component stays conservative
+    ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
+    dim3 grid((g.nB + 63) / 64, (g.nA + 63) / 64, g.nC);
+    if (store)
+        hipLaunchKernelGGL(k_transpose_lincomb<true>, grid, dim3(256), 0, b->stream, y, base, x[ipend], pend, g.nB, g.nA,
+                           g.f_sB, g.f_sC, g.f_dA, g.f_dC, a);
+    else
+        hipLaunchKernelGGL(k_transpose_lincomb<false>, grid, dim3(256), 0, b->stream, y, base, x[ipend], pend, g.nB,
+                           g.nA, g.f_sB, g.f_sC, g.f_dA, g.f_dC, a);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,6 +1,7 @@
 """solver_t mirror (/root/reference/src/solver.f90): the "Incompact3D
 algorithm" sequencing -- transeq -> time integrator -> pressure correction --
 over the backend's operator interface.  No arithmetic on field data here."""
+import os
 import numpy as np
 
 from .common import (BC_DIRICHLET, BC_NEUMANN, CELL, DIR_C, DIR_X, DIR_Y, DIR_Z, RDR_C2Z, RDR_X2Y, RDR_X2Z,
@@ -160,21 +161,37 @@ class Solver:
                                   direction=dirps.dir)
             r.set_data_loc(spec.data_loc)
 
-    def transeq_fused(self, rhs, variables):
+    def transeq_fused(self, rhs, variables, defer=False):
         """transeq_default without the 6 reorders and 6 sum_*intox: every block
         shares one device layout, so the y and z passes read u, v, w in place and
-        accumulate straight into du, dv, dw."""
+        accumulate straight into du, dv, dw.
+
+        defer: the caller (BaseCase.substep) hands the result straight to the fused RK stage; when the z
+        pencils run through the scan kernel, their accumulation into du, dv, dw is then left pending and
+        returned as {buffer address of d*: (pending block, direction)} for TimeIntegrator to fold into its
+        linear combination (one pass less over d* and the new velocity)."""
         b = self.backend
         du, dv, dw = rhs[:3]
         u, v, w = variables[:3]
         b.mesh.get_n(DIR_X, u.data_loc)
         b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
         b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
-        b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
+        pending = None
+        if defer and os.environ.get("X3D_NO_DEFER") != "1":
+            al = b.allocator
+            pend = [al.get_block(DIR_X) for _ in range(3)]
+            if b.transeq_dir_defer(DIR_Z, pend, u, v, w, self.nu, self.zdirps):
+                pending = {r.data.data_ptr(): (pf, DIR_Z) for r, pf in zip((du, dv, dw), pend)}
+            else:
+                for pf in pend:
+                    al.release_block(pf)
+        if pending is None:
+            b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
         for f in rhs[:3]:
             f.set_data_loc(u.data_loc)
         if self.nspecies > 0:
             self.transeq_species_fused(rhs[3:], variables)
+        return pending
 
     def pressure_correction_fused(self, u, v, w):
         """pressure_correction (:693-739) = divergence_v2c + Poisson + gradient_c2v +

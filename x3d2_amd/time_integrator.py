@@ -94,7 +94,29 @@ class TimeIntegrator:
     def _swap(a, b):
         a.data, b.data = b.data, a.data
 
-    def runge_kutta_fused(self, curr, deriv, dt):
+    def _lincomb(self, y, base, coefs, fields, pending, store):
+        """lincomb; a term whose transeq component is still pending (Solver.transeq_fused(defer=True)) is
+        completed inside the same kernel"""
+        b = self.backend
+        if pending:
+            for k, f in enumerate(fields):
+                ent = pending.pop(f.data.data_ptr(), None)
+                if ent is not None:
+                    pf, direction = ent
+                    b.lincomb_pending(y, base, coefs, fields, k, pf, direction, store)
+                    self.allocator.release_block(pf)
+                    return
+        b.lincomb(y, base, coefs, fields)
+
+    def _flush(self, pending):
+        """complete the pending components no linear combination consumed"""
+        for ptr, (pf, direction) in list((pending or {}).items()):
+            self.backend.pending_flush(direction, ptr, pf)
+            self.allocator.release_block(pf)
+        if pending:
+            pending.clear()
+
+    def runge_kutta_fused(self, curr, deriv, dt, pending=None):
         b, ns = self.backend, self.nstage
         a, bb = self.RK_A[ns], self.RK_B[ns]
         self.gdt = bb[self.istage - 1] * dt
@@ -103,7 +125,9 @@ class TimeIntegrator:
                 terms = [(bb[j - 1] * dt, self.olds[i][j]) for j in range(1, ns) if bb[j - 1] != 0.0]
                 terms.append((bb[ns - 1] * dt, deriv[i]))
                 base = self.olds[i][0] if ns > 1 else curr[i]
-                b.lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms])
+                # the derivative of the last stage is not needed afterwards: no store
+                self._lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms], pending, False)
+            self._flush(pending)
             self.istage = 1
         else:
             st = self.istage
@@ -114,13 +138,16 @@ class TimeIntegrator:
                 terms = [(a[st - 1][j - 1] * dt, self.olds[i][j]) for j in range(1, st + 1)
                          if a[st - 1][j - 1] != 0.0]
                 if terms:
-                    b.lincomb(curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms])
+                    self._lincomb(curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms], pending,
+                                  True)
                 else:
                     b.veccopy(curr[i], self.olds[i][0])
+            self._flush(pending)
             self.istage += 1
 
-    def adams_bashforth_fused(self, curr, deriv, dt):
+    def adams_bashforth_fused(self, curr, deriv, dt, pending=None):
         b = self.backend
+        self._flush(pending)
         self.gdt = dt
         nstep = min(self.istep, self.nstep)
         c = self.AB[nstep]
