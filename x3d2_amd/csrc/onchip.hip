@@ -198,7 +198,7 @@ __device__ __forceinline__ void stg(double *base, unsigned boff, double v)
 }
 
 // M = 32: 512-row pencils, M = 16: 256-row pencils (16 chunks either way)
-template <bool ACC, int M>
+template <bool ACC, int M, bool NARROW>
 __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups per CU, <= 128 VGPRs
     k_tds_onchip2(double *__restrict__ du, const double *__restrict__ u, TdsTab t, PencilGeom g, double scale,
                   Coef9 cf)
@@ -210,18 +210,6 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     double *tF = lds, *tA = tF + LR, *tPF = tA + LR, *tHB = tPF + LR, *tQB = tHB + LR, *tSA = tQB + LR,
            *tSC = tSA + LR, *tST = tSC + LR;
     double *ends = tST + LR, *starts = ends + 16 * 32, *misc = starts + 16 * 32;
-    for (int j = threadIdx.x; j < LR; j += blockDim.x) {
-        const bool in = j >= 1 && j <= n;
-        tF[j] = in ? T_F(t, j) : 0.0;
-        tA[j] = in ? T_A(t, j) : 0.0;
-        tPF[j] = in ? (M == 32 ? T_PF(t, j) : T_PF16(t, j)) : 0.0;  // chunk-local products for M-row chunks
-        tHB[j] = (in && j >= 2 && j <= n - 2) ? -T_BW(t, j) : 0.0;  // rows 1, n-1, n: no backward update
-        tQB[j] = in ? (M == 32 ? T_QB(t, j) : T_QB16(t, j)) : 0.0;
-        tSA[j] = in ? T_SA(t, j) : 0.0;
-        tSC[j] = in ? T_SC(t, j) : 0.0;
-        tST[j] = in ? T_ST(t, j) : 0.0;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xl = lane & 31, c = 2 * wv + (lane >> 5);
     const int p = blockIdx.x * 32 + xl;  // np is a multiple of 32 (launcher)
@@ -241,6 +229,19 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
            p1 = ldg(u, (unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs) * 8u),
            p2 = ldg(u, (unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs) * 8u),
            p3 = ldg(u, (unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs) * 8u);
+    // the row tables are staged while the loads above are in flight
+    for (int j = threadIdx.x; j < LR; j += blockDim.x) {
+        const bool in = j >= 1 && j <= n;
+        tF[j] = in ? T_F(t, j) : 0.0;
+        tA[j] = in ? T_A(t, j) : 0.0;
+        tPF[j] = in ? (M == 32 ? T_PF(t, j) : T_PF16(t, j)) : 0.0;  // chunk-local products for M-row chunks
+        tHB[j] = (in && j >= 2 && j <= n - 2) ? -T_BW(t, j) : 0.0;  // rows 1, n-1, n: no backward update
+        tQB[j] = in ? (M == 32 ? T_QB(t, j) : T_QB16(t, j)) : 0.0;
+        tSA[j] = in ? T_SA(t, j) : 0.0;
+        tSC[j] = in ? T_SC(t, j) : 0.0;
+        tST[j] = in ? T_ST(t, j) : 0.0;
+    }
+    __syncthreads();
     const double c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
                  c7 = cf.c[7], c8 = cf.c[8];  // kernel arguments: SGPRs
     double prev = 0.0;
@@ -253,8 +254,10 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
         }
 #define AHEAD(d) ((q + (d) < M) ? x[(q + (d)) % M] : hr[(q + (d) - M) & 3])
         const double cur = x[q];
-        const double acc = c0 * p0 + c1 * p1 + c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2) +
-                           c7 * AHEAD(3) + c8 * AHEAD(4);
+        // NARROW: compact6 / classic stencils reach 2 rows only: skip the zero taps (adding 0 * x is exact)
+        const double acc = NARROW ? c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2)
+                                  : c0 * p0 + c1 * p1 + c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2) +
+                                        c7 * AHEAD(3) + c8 * AHEAD(4);
 #undef AHEAD
         const double e = tF[j] * (acc - tA[j] * prev);
         prev = e;
@@ -305,8 +308,8 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
             const int q = q0 + k, j = s + q;
             const double X = x[q] + tQB[j] * carry;
             double r = (X - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
-            r = (j == 1) ? du_s * tST[j] : r;                           // :209-213
-            r = (j == n) ? du_e * tST[j] : r;                           // :224-228
+            if (q == 0) r = (c == 0) ? du_s * tST[j] : r;        // row 1, :209-213
+            if (q == M - 1) r = (c == 15) ? du_e * tST[j] : r;   // row n, :224-228
             stg(du + (long)q * rs, off, ACC ? old[k] + scale * r : r);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -320,18 +323,20 @@ static int launch_onchip2(x3d_backend *b, double *du, const double *u, const x3d
     const size_t lds = sizeof(double) * ((size_t)K1E_TAB * (16 * M + 8) + 2 * 16 * 32 + 64);
     static bool attr = false;
     if (!attr) {
-        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<false, M>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        X3D_HIP(hipFuncSetAttribute((const void *)k_tds_onchip2<true, M>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        const void *ks[4] = {(const void *)k_tds_onchip2<false, M, false>, (const void *)k_tds_onchip2<true, M, false>,
+                             (const void *)k_tds_onchip2<false, M, true>, (const void *)k_tds_onchip2<true, M, true>};
+        for (const void *k : ks) X3D_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
     dim3 grid(g.np / 32), block(512);
     Coef9 cf;
     for (int m = 0; m < 9; m++) cf.c[m] = t->coeffs[m];
-    if (acc) hipLaunchKernelGGL((k_tds_onchip2<true, M>), grid, block, lds, b->stream, du, u, t->tab, g, scale, cf);
-    else hipLaunchKernelGGL((k_tds_onchip2<false, M>), grid, block, lds, b->stream, du, u, t->tab, g, 1.0, cf);
+    const bool narrow = cf.c[0] == 0.0 && cf.c[1] == 0.0 && cf.c[7] == 0.0 && cf.c[8] == 0.0;
+#define GO(A_, N_, S_) hipLaunchKernelGGL((k_tds_onchip2<A_, M, N_>), grid, block, lds, b->stream, du, u, t->tab, g, S_, cf)
+    if (acc) { if (narrow) GO(true, true, scale); else GO(true, false, scale); }
+    else { if (narrow) GO(false, true, 1.0); else GO(false, false, 1.0); }
+#undef GO
     X3D_HIP(hipGetLastError());
     return 0;
 }

@@ -95,7 +95,7 @@ __device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, 
 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
 // values (before the reduced-system substitution), du1 and xn broadcast to all lanes
-template <int Q, bool FAST>
+template <int Q, bool FAST, bool NARROW = false>
 __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)[Q], double &du1, double &xn,
                                            const double *__restrict__ lt, const XOp &t, int &lane, int first)
 {
@@ -106,10 +106,18 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
                  c7 = t.c[7], c8 = t.c[8];
     double acc[Q];
+    // NARROW: the compact6 / classic stencils only reach 2 rows: skip the zero taps (adding 0 * w is exact,
+    // so both forms give the same bits); chosen by the launcher from the operators' coefficients
+    if (NARROW) {
 #pragma unroll
-    for (int q = 0; q < Q; q++)
-        acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
-                 c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
+        for (int q = 0; q < Q; q++)
+            acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
+                     c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
+    }
     // boundary rows (1..4 and n_rhs-3..n_rhs) use their own stencils: only the two end lanes get here
     if (!FAST && !t.bulk_only && (first <= 4 || first + Q - 1 > nr - 4)) {
 #pragma unroll
@@ -345,7 +353,7 @@ __device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__
 }
 
 // ---------------------------------------------------------------- tds_solve
-template <int Q, bool ACC, bool FAST>
+template <int Q, bool ACC, int FAST>  // FAST: 0 general, 1 branch-free periodic form, 2 the same with the 5-tap stencil
 __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, const double *__restrict__ u, XOp t,
                                                    int np, long pitch, int n_wrap, double scale)
 {
@@ -375,7 +383,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 #endif
         } else if (exact) load_window_exact<Q>(w, row, lane, nr);
         else load_window<Q>(w, row, first, nr, n_wrap, interior);
-        scan_solve<Q, FAST>(w, X, du1, xn, lt, t, lane, first);
+        scan_solve<Q, (FAST != 0), (FAST == 2)>(w, X, du1, xn, lt, t, lane, first);
         const double du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
         const double du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
         double *__restrict__ orow = du + (long)p * pitch;
@@ -385,8 +393,13 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
             const int j = first + q;
             const double st = lt[LT_ST(q) * 64 + lane];
             r[q] = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) * st;
-            r[q] = (j == 1) ? du_s * st : r[q];
-            r[q] = (j == n) ? du_e * st : r[q];
+            if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
+                if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
+                if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+            } else {
+                r[q] = (j == 1) ? du_s * st : r[q];
+                r[q] = (j == n) ? du_e * st : r[q];
+            }
         }
 #if XSCAN_EXP == 1
         if (r[0] != 12345.678) continue;
@@ -414,7 +427,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 }
 
 // ---------------------------------------------------------------- transeq component
-template <int Q, bool SAME, bool ACC, bool FAST>
+template <int Q, bool SAME, bool ACC, int FAST>
 __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
                     XOp t2, XOp t3, int np, long pitch, double nu)
@@ -491,15 +504,20 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
         // rows 1 and n take du_s*st / du_e*st, which is what the general formula gives with these temps)
         auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
             double a, b;
-            scan_solve<Q, FAST>(w, T, a, b, l, t, lane, first);
+            scan_solve<Q, (FAST != 0), (FAST == 2)>(w, T, a, b, l, t, lane, first);
             const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = first + q;
                 const double st = l[LT_ST(q) * 64 + lane];
                 double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
-                x = (j == 1) ? s_ * st : x;
-                x = (j == n) ? e_ * st : x;
+                if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
+                    if (q == 0) x = (lane == 0) ? s_ * st : x;
+                    if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                } else {
+                    x = (j == 1) ? s_ * st : x;
+                    x = (j == n) ? e_ * st : x;
+                }
                 T[q] = x;
             }
         };
@@ -539,6 +557,12 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
 }
 
 // ---------------------------------------------------------------- launchers
+// bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
+static bool stencil_narrow(const x3d_tdsops *t)
+{
+    return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
+}
+
 static bool xscan_ok(const x3d_tdsops *t) { return t->tab.TL != nullptr && (t->tab.Q == 4 || t->tab.Q == 8); }
 
 int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done)
@@ -552,13 +576,15 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
     // FAST: periodic-type stencils on a pencil the 64 lanes tile exactly, p2p or v2v (n_rhs == n_tds)
     const bool fast = t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
+    const bool narrow = stencil_narrow(t);
 #define LAUNCH(Q_, A_, F_, SC_)                                                                                \
     hipLaunchKernelGGL((k_xscan_tds<Q_, A_, F_>), dim3(blocks), dim3(512), lds, b->stream, du, u, xop_of(t), np, \
                        (long)b->nxp, t->n_tds, SC_)
 #define PICK(Q_)                                                                                               \
     do {                                                                                                       \
-        if (fast) { if (acc) LAUNCH(Q_, true, true, scale); else LAUNCH(Q_, false, true, 1.0); }               \
-        else { if (acc) LAUNCH(Q_, true, false, scale); else LAUNCH(Q_, false, false, 1.0); }                  \
+        if (fast && narrow) { if (acc) LAUNCH(Q_, true, 2, scale); else LAUNCH(Q_, false, 2, 1.0); }           \
+        else if (fast) { if (acc) LAUNCH(Q_, true, 1, scale); else LAUNCH(Q_, false, 1, 1.0); }                \
+        else { if (acc) LAUNCH(Q_, true, 0, scale); else LAUNCH(Q_, false, 0, 1.0); }                          \
     } while (0)
     if (Q == 8) PICK(8); else PICK(4);
 #undef PICK
@@ -568,7 +594,7 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
     return 0;
 }
 
-template <int Q, bool SAME, bool ACC, bool FAST>
+template <int Q, bool SAME, bool ACC, int FAST>
 static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                           const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int np, int blocks,
                           size_t lds, long pitch)
@@ -602,12 +628,13 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dirtag, dirtag >= 0);  // dirtag < 0: timed by the caller
     int rc;
     const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q;
+    const bool narrow = stencil_narrow(t1) && stencil_narrow(t2) && stencil_narrow(t3);
 #define GO2(Q_, F_)                                                                                            \
     (same ? (acc ? launch_transeq<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)       \
                  : launch_transeq<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch))     \
           : (acc ? launch_transeq<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)      \
                  : launch_transeq<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)))
-#define GO(Q_) (fast ? GO2(Q_, true) : GO2(Q_, false))
+#define GO(Q_) (fast ? (narrow ? GO2(Q_, 2) : GO2(Q_, 1)) : GO2(Q_, 0))
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO
 #undef GO2
