@@ -134,6 +134,7 @@ def main():
         case.step(it)
     backend.prof_enable(True)
     backend.prof_reset()
+    backend.rk_fused_passes = 0
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -168,7 +169,14 @@ def main():
             per_dir[name] = {"ms_per_component": (mf + mb) / nf,
                              "GB/s": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
     bytes_per_launch = (64.0 / 3.0) * dof_local  # average over the three components
+    # the last direction's accumulation is folded into the RK stage's linear combination (csrc/viax.hip,
+    # k_transpose_lincomb, booked as transeq_bwd of direction 0): those launches also move the stage's own
+    # algorithmic bytes (base + older derivatives read, new velocity written)
+    n_fused = n_b - sum(backend.prof_get("transeq_bwd", d)[0] for d in (1, 2, 3))
+    rk_bytes = 8.0 * dof_local * getattr(backend, "rk_fused_passes", 0)
     avg_ms = (ms_f + ms_b) / max(n_f, 1)
+    transeq_bytes = bytes_per_launch
+    bytes_per_launch = transeq_bytes + rk_bytes / max(n_f, 1)  # per component, RK-stage share included
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -180,9 +188,14 @@ def main():
                 traffic = tj.get("transeq_component_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "transeq component (k_transeq_fwd + k_transeq_bwd)",
+    roofline = {"bound": "hbm",
+                "kernel": "transeq component: k_xscan_transeq (x) / k_transpose64 + k_xscan_transeq + accumulating "
+                          "k_transpose64 (y, z); the last direction's accumulation is fused with the RK stage "
+                          "(k_transpose_lincomb), whose algorithmic bytes are then included",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "transeq_bytes_per_launch": transeq_bytes, "rk_stage_fused_launches": n_fused,
+                "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
                 "avg_launch_ms": avg_ms, "launches": n_f, "per_direction": per_dir,
                 "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
                 # SURVEY.md 8d headline convention: the reference's derivative pass of one sub-step

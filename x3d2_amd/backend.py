@@ -254,6 +254,8 @@ class HipBackend:
         p = (VP * n)(*[x.ptr for x in xs])
         _lib.check(self.lib.x3d_lincomb_pending(self.h, direction, y.ptr, base.ptr, n, c, p, int(ipend), pend.ptr,
                                                 int(bool(store))))
+        # field passes the linear combination itself needs (base + the other terms + y): bench.py's roofline
+        self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
 
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""

@@ -327,9 +327,9 @@ extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const dou
         a.x[k] = k < nterm ? x[k] : x[0];
         a.c[k] = k < nterm ? c[k] : 0.0;
     }
-    // booked as the component's "backward" launch although it also does the RK stage's combination:
-    // bench.py's roofline for the transeq component stays conservative
-    ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
+    // booked as a "backward" launch of direction 0 (n/a): bench.py adds the RK stage's own algorithmic bytes
+    // for these launches (HipBackend.rk_fused_passes)
+    ProfScope ps(b, X3D_K_TRANSEQ_BWD, 0);
     dim3 grid((g.nB + 63) / 64, (g.nA + 63) / 64, g.nC);
     if (store)
         hipLaunchKernelGGL(k_transpose_lincomb<true>, grid, dim3(256), 0, b->stream, y, base, x[ipend], pend, g.nB, g.nA,
