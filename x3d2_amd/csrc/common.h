@@ -119,6 +119,7 @@ struct x3d_tdsops {
     double *dev;  // one allocation holding all tables
     TdsTab tab;
     double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
+    unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
 };
 
 PencilGeom x3d_geom(const x3d_backend *b, int dir);

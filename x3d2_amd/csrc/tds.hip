@@ -174,6 +174,16 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         for (int m = 0; m < 9; m++)
             if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) tb.bulk_only = 0;
     tb.TL = Q ? t->dev + tl_off : nullptr;
+    t->tl_hash = 1469598103934665603ull;
+    if (Q) {
+        const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&img[tl_off]);
+        for (size_t i = 0; i < (img.size() - tl_off) * sizeof(double); i++)
+            t->tl_hash = (t->tl_hash ^ bytes[i]) * 1099511628211ull;
+        for (int m = 0; m < 9; m++) {  // + the bulk stencil and the scalars the kernels take by value
+            const unsigned char *cb = reinterpret_cast<const unsigned char *>(&coeffs[m]);
+            for (size_t i = 0; i < sizeof(double); i++) t->tl_hash = (t->tl_hash ^ cb[i]) * 1099511628211ull;
+        }
+    }
     tb.last_r = dist_fw[0];
     tb.bw1 = dist_bw[0];
     tb.sa1 = dist_sa[0];

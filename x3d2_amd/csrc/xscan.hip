@@ -556,6 +556,125 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     }
 }
 
+// ---------------------------------------------------------------- K3y: y pencils without transposed copies
+// One workgroup = 16 waves = the 16 x-adjacent y pencils of one z plane.  The tile [16 x][n y] goes through
+// LDS: the workgroup reads it from the Cartesian block in 128-byte row segments (16 doubles of x per y),
+// every wave picks its pencil out of LDS (lane l: rows l Q .. l Q + Q - 1, contiguous), solves the three
+// operators exactly like k_xscan_transeq, writes its result back into the tile, and the workgroup adds the
+// tile to rhs in 128-byte segments again: u, conv and rhs are touched once each (3-4 field passes instead of
+// the 8 of the transposed-copy route in viax.hip), all inside one 2 MB page per tile.
+// LDS: lane tables + 16 (n + 4) doubles of tile; for n = 512 this fits only when der1st and der1st_sym have
+// identical lane tables (periodic operators: they do), which the launcher checks.
+template <int Q, bool SAME, bool ACC, int FAST>
+__global__ void __launch_bounds__(1024)
+    k_ytile_transeq(double *rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1, XOp t2, XOp t3,
+                    int share12, int ntx, int ntiles, long prow, long pplane, double nu)
+{
+    extern __shared__ double lt[];
+    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = t1.TL[i];
+        if (!share12) lt[LN + i] = t2.TL[i];
+        lt[(share12 ? 1 : 2) * LN + i] = t3.TL[i];
+    }
+    const double *__restrict__ l1 = lt, *__restrict__ l2 = share12 ? lt : lt + LN,
+                 *__restrict__ l3 = lt + (share12 ? 1 : 2) * LN;
+    double *tile = lt + (share12 ? 2 : 3) * LN;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int first = lane * Q + 1;
+    // cooperative mapping: item i of thread t is the double2 (row y, columns 2c, 2c + 1)
+    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    auto fill = [&](const double *__restrict__ src) {
+        double2 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
+            tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
+        }
+    };
+    auto pick = [&](double (&b)[Q]) {
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) {
+            const double2 t2_ = src[m];
+            b[2 * m] = t2_.x;
+            b[2 * m + 1] = t2_.y;
+        }
+    };
+    __syncthreads();
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
+        double wu[Q + 8], wp[Q + 8], vq[Q];
+        {
+            double b[Q];
+            fill(u + off);
+            __syncthreads();
+            pick(b);
+            window_from_body<Q>(wu, b, lane);
+            if (!SAME) {
+                __syncthreads();
+                fill(cv + off);
+                __syncthreads();
+                pick(b);
+                window_from_body<Q>(wp, b, lane);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) vq[q] = b[q];
+#pragma unroll
+            for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
+        }
+        __syncthreads();  // every wave has its rows: the tile may be overwritten by the results
+        auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
+            double a, b;
+            scan_solve<Q, true, (FAST == 2)>(w, T, a, b, l, t, lane, first);
+            const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const double st = l[LT_ST(q) * 64 + lane];
+                double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                if (q == 0) x = (lane == 0) ? s_ * st : x;
+                if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                T[q] = x;
+            }
+        };
+        double r[Q], T[Q];
+        solve_subs(wp, T, l2, t2);
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = T[q];
+        asm volatile("" : "+v"(lane) : "v"(r[0]));
+        solve_subs(wu, T, l1, t1);
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        asm volatile("" : "+v"(lane) : "v"(r[0]));
+        solve_subs(wu, T, l3, t3);
+        {
+            double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+            for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+        }
+        __syncthreads();
+        {
+            double *__restrict__ o = rhs + off;
+            double2 old[NI];
+            if (ACC) {
+#pragma unroll
+                for (int i = 0; i < NI; i++) old[i] = *reinterpret_cast<const double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                if (ACC) { v.x += old[i].x; v.y += old[i].y; }
+                *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+            }
+        }
+        __syncthreads();  // the tile is free again
+    }
+}
+
 // ---------------------------------------------------------------- launchers
 // bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
 static bool stencil_narrow(const x3d_tdsops *t)
@@ -655,4 +774,62 @@ bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tds
     if (!xscan_ok(t1) || !xscan_ok(t2) || !xscan_ok(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return false;
     return t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * t1->tab.Q &&
            t2->n_tds == t1->n_tds && t3->n_tds == t1->n_tds;
+}
+
+// K3y launcher: one transeq component along y, straight from / to the Cartesian block
+static bool use_ytile()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("X3D_NO_YTILE");
+        mode = (e && e[0] == '1') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+template <int Q, bool SAME, bool ACC, int FAST>
+static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                        const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq<Q, SAME, ACC, FAST>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int ntx = b->nx / 16, ntiles = ntx * b->nz;
+    const int blocks = ntiles > 256 ? 256 : ntiles;
+    hipLaunchKernelGGL((k_ytile_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(1024), lds, b->stream, rhs, u, conv,
+                       xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles, (long)b->nxp,
+                       (long)b->nxp * b->nyp, nu);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_ytile_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
+{
+    *done = false;
+    if (!use_ytile() || !x3d_xscan_fast_ok(t1, t2, t3)) return 0;
+    const int Q = t1->tab.Q;
+    if (b->ny != 64 * Q || b->nx % 16 != 0) return 0;
+    const int share12 = t1->tl_hash == t2->tl_hash;
+    const size_t lds = sizeof(double) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    if (lds > 160 * 1024) return 0;
+    const bool same = u == conv;
+    const bool narrow = stencil_narrow(t1) && stencil_narrow(t2) && stencil_narrow(t3);
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_Y);
+    int rc;
+#define GO2(Q_, F_)                                                                                     \
+    (same ? (acc ? launch_ytile<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)       \
+                 : launch_ytile<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds))     \
+          : (acc ? launch_ytile<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)      \
+                 : launch_ytile<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)))
+#define GO(Q_) (narrow ? GO2(Q_, 2) : GO2(Q_, 1))
+    rc = Q == 8 ? GO(8) : GO(4);
+#undef GO
+#undef GO2
+    if (rc) return rc;
+    *done = true;
+    return 0;
 }
