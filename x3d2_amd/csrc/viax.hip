@@ -17,7 +17,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
                          const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
                          int dirtag, bool *done);
 bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
-int x3d_ytile_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 
 // dst[c*dC + a*dA + b] (+)= src[c*sC + b*sB + a]: 64 x 64 tiles through LDS, 512-byte rows on both sides
@@ -151,13 +151,13 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
     if (der1st->n_tds != n) return 0;
     const ViaGeom g = via_geom(b, dir);
     if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
-    if (dir == X3D_DIR_Y) {
+    {
         // K3y (xscan.hip): the same kernel fed through an LDS tile, no transposed copies
         bool ok = false;
-        if (int rc = x3d_ytile_transeq(b, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, acc, &ok)) return rc;
+        if (int rc = x3d_ytile_transeq(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, acc, &ok)) return rc;
         if (ok) {
             for (int c = 1; c < 3; c++) {
-                if (int rc = x3d_ytile_transeq(b, r[c], f[c], f[0], nu, der1st_sym, der1st, der2nd_sym, acc, &ok)) return rc;
+                if (int rc = x3d_ytile_transeq(b, dir, r[c], f[c], f[0], nu, der1st_sym, der1st, der2nd_sym, acc, &ok)) return rc;
                 X3D_REQUIRE(ok, "x3d_transeq_via_x: tile kernel refused component %d", c);
             }
             *done = true;

@@ -18,9 +18,14 @@
 
 // FAST transeq kernel: one workgroup per CU (129 KB of lane tables).  Measured: 12 waves with next-pencil
 // prefetch (163 VGPRs) 0.96 ms per component, 16 waves without it (123 VGPRs) 0.90 ms.
+#ifndef YT_NOPREF
+#define YT_PREF 1  // K3y: next tile's u rows prefetched into registers (same-box A/B: 1.05 -> 0.92 ms per component)
+#endif
 #ifndef XS_TQ_THREADS
 #define XS_TQ_THREADS 1024
+#ifndef XS_PREF
 #define XS_NOPREF 1
+#endif
 #endif
 
 #ifndef XSCAN_EXP
@@ -585,10 +590,11 @@ __global__ void __launch_bounds__(1024)
     const int first = lane * Q + 1;
     // cooperative mapping: item i of thread t is the double2 (row y, columns 2c, 2c + 1)
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
-    auto fill = [&](const double *__restrict__ src) {
-        double2 v[NI];
+    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
 #pragma unroll
         for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+    };
+    auto to_tile = [&](const double2 (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
@@ -605,19 +611,31 @@ __global__ void __launch_bounds__(1024)
         }
     };
     __syncthreads();
+#ifdef YT_PREF
+    double2 nxt[NI];  // next tile's u rows, in flight during the solve
+    if ((int)blockIdx.x < ntiles) gload(nxt, u + (long)(blockIdx.x / ntx) * pplane + (long)(blockIdx.x % ntx) * 16);
+#endif
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
         double wu[Q + 8], wp[Q + 8], vq[Q];
         {
             double b[Q];
-            fill(u + off);
+            double2 gu[NI], gc[NI];
+#ifdef YT_PREF
+#pragma unroll
+            for (int i = 0; i < NI; i++) gu[i] = nxt[i];
+#else
+            gload(gu, u + off);  // both fields in flight at once: one exposed memory latency per tile, not two
+#endif
+            if (!SAME) gload(gc, cv + off);
+            to_tile(gu);
             __syncthreads();
             pick(b);
             window_from_body<Q>(wu, b, lane);
             if (!SAME) {
                 __syncthreads();
-                fill(cv + off);
+                to_tile(gc);
                 __syncthreads();
                 pick(b);
                 window_from_body<Q>(wp, b, lane);
@@ -628,6 +646,12 @@ __global__ void __launch_bounds__(1024)
             for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
         }
         __syncthreads();  // every wave has its rows: the tile may be overwritten by the results
+#ifdef YT_PREF
+        {
+            const int tn = tl + gridDim.x;
+            if (tn < ntiles) gload(nxt, u + (long)(tn / ntx) * pplane + (long)(tn % ntx) * 16);
+        }
+#endif
         auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
             double a, b;
             scan_solve<Q, true, (FAST == 2)>(w, T, a, b, l, t, lane, first);
@@ -652,18 +676,13 @@ __global__ void __launch_bounds__(1024)
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l3, t3);
         {
+            double *__restrict__ o = rhs + off;
+            double2 old[NI];
+            if (ACC) gload(old, o);  // in flight while the results go through the tile
             double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
-        }
-        __syncthreads();
-        {
-            double *__restrict__ o = rhs + off;
-            double2 old[NI];
-            if (ACC) {
-#pragma unroll
-                for (int i = 0; i < NI; i++) old[i] = *reinterpret_cast<const double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc);
-            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
@@ -789,7 +808,8 @@ static bool use_ytile()
 
 template <int Q, bool SAME, bool ACC, int FAST>
 static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
-                        const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds)
+                        const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds,
+                        int dir)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -797,34 +817,41 @@ static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const doub
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int ntx = b->nx / 16, ntiles = ntx * b->nz;
+    // y: rows nxp apart, one tile row per z plane; z: rows nxp * nyp apart, one tile row per y
+    const long pxy = (long)b->nxp * b->nyp;
+    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
     const int blocks = ntiles > 256 ? 256 : ntiles;
     hipLaunchKernelGGL((k_ytile_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(1024), lds, b->stream, rhs, u, conv,
-                       xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles, (long)b->nxp,
-                       (long)b->nxp * b->nyp, nu);
+                       xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles,
+                       dir == X3D_DIR_Y ? (long)b->nxp : pxy, dir == X3D_DIR_Y ? pxy : (long)b->nxp, nu);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-int x3d_ytile_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
 {
     *done = false;
     if (!use_ytile() || !x3d_xscan_fast_ok(t1, t2, t3)) return 0;
     const int Q = t1->tab.Q;
-    if (b->ny != 64 * Q || b->nx % 16 != 0) return 0;
+    if ((dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
+    if (dir == X3D_DIR_Z) {
+        static int zt = -1;
+        if (zt < 0) { const char *e = getenv("X3D_ZTILE"); zt = (e && e[0] == '1') ? 1 : 0; }
+        if (!zt) return 0;
+    }
     const int share12 = t1->tl_hash == t2->tl_hash;
     const size_t lds = sizeof(double) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4));
     if (lds > 160 * 1024) return 0;
     const bool same = u == conv;
     const bool narrow = stencil_narrow(t1) && stencil_narrow(t2) && stencil_narrow(t3);
-    ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_Y);
+    ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
     int rc;
 #define GO2(Q_, F_)                                                                                     \
-    (same ? (acc ? launch_ytile<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)       \
-                 : launch_ytile<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds))     \
-          : (acc ? launch_ytile<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)      \
-                 : launch_ytile<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds)))
+    (same ? (acc ? launch_ytile<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)       \
+                 : launch_ytile<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir))     \
+          : (acc ? launch_ytile<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)      \
+                 : launch_ytile<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)))
 #define GO(Q_) (narrow ? GO2(Q_, 2) : GO2(Q_, 1))
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO
