@@ -32,7 +32,7 @@ with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as f:
 
 # one transport-equation component = k_transeq_fwd + k_transeq_bwd (y, z two-sweep), k_xtranseq_fwd + _bwd
 # (x, LDS-tiled) or ONE k_xscan_transeq / k_transeq_onchip launch (single pass)
-heads = ("k_transeq_fwd", "k_xtranseq_fwd", "k_xscan_transeq", "k_transeq_onchip")
+heads = ("k_transeq_fwd", "k_xtranseq_fwd", "k_xscan_transeq", "k_ytile_transeq", "k_transeq_onchip")
 # + the transposes of the y / z components that run through the scan kernel (viax.hip)
 tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_transpose" in k)
 n_comp = sum(n for k, n, fe, wr in rows if any(h in k for h in heads))
