@@ -101,6 +101,10 @@ int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, double *du_s
                      const x3d_tdsops *t, int dir);
 int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
                      const double *du_recv_e, const x3d_tdsops *t, int dir);
+/* fusion extension: accumulate != 0 gives du += scale * result */
+int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
+                     const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
+                         double scale);
 
 /* ---- transeq_x / transeq_y / transeq_z (src/backend/backend.f90:64-92; omp:
  * src/backend/omp/backend.f90:145-184, 235-338; exec_dist.f90:67-186).
@@ -135,6 +139,11 @@ int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double *send_s, d
 int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
                          const double *recv_s, const double *recv_e, const double *conv, double nu,
                          const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u);
+/* fusion extension: accumulate != 0 gives rhs += result (folds the fused driver's vecadd) */
+int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, const double *send_s,
+                         const double *recv_s, const double *recv_e, const double *conv, double nu,
+                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
+                             int accumulate);
 
 /* ---- reorder / sum_yintox / sum_zintox (src/backend/backend.f90:152-186) */
 int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr_code);

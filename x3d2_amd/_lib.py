@@ -40,12 +40,14 @@ PROTOTYPES = {
     "x3d_pack_halos": (I, [VP, VP, VP, VP, I, I]),
     "x3d_tds_dist_fwd": (I, [VP, VP, VP, VP, VP, VP, VP, VP, I]),
     "x3d_tds_dist_bwd": (I, [VP, VP, VP, VP, VP, VP, I]),
+    "x3d_tds_dist_bwd_acc": (I, [VP, VP, VP, VP, VP, VP, I, I, D]),
     "x3d_transeq": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP]),
     "x3d_compute_vorticity": (I, [VP, VP, ctypes.POINTER(VP)]),
     "x3d_compute_qcriterion": (I, [VP, VP, ctypes.POINTER(VP)]),
     "x3d_transeq_species": (I, [VP, I, VP, VP, VP, D, VP, VP, VP, I]),
     "x3d_transeq_dist_fwd": (I, [VP, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "x3d_transeq_dist_bwd": (I, [VP, I, VP, VP, VP, VP, VP, D, VP, VP, VP]),
+    "x3d_transeq_dist_bwd_acc": (I, [VP, I, VP, VP, VP, VP, VP, D, VP, VP, VP, I]),
     "x3d_reorder": (I, [VP, VP, VP, I]),
     "x3d_sum_intox": (I, [VP, VP, VP, I]),
     "x3d_veccopy": (I, [VP, VP, VP]),

@@ -140,8 +140,8 @@ class HipBackend:
         for r in (du, dv, dw):
             r.set_data_loc(u.data_loc)  # :333
 
-    def _transeq_dist(self, direction, du, dv, dw, u, v, w, nu, dirps):
-        """transeq_omp_dist with the permutation of :145-184"""
+    def _transeq_dist(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate=False):
+        """transeq_omp_dist with the permutation of :145-184; accumulate: d* += result (fused driver)"""
         if direction == DIR_X:
             rhs, fld = (du, dv, dw), (u, v, w)
         elif direction == DIR_Y:
@@ -170,9 +170,9 @@ class HipBackend:
                 halos[i][0].data_ptr(), halos[i][1].data_ptr(), fld[0].ptr, halos[0][0].data_ptr(),
                 halos[0][1].data_ptr(), t_du.handle, t_dud.handle, t_d2u.handle))
             self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
-            _lib.check(self.lib.x3d_transeq_dist_bwd(
+            _lib.check(self.lib.x3d_transeq_dist_bwd_acc(
                 self.h, direction, rhs[i].ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(), fld[0].ptr,
-                float(nu), t_du.handle, t_dud.handle, t_d2u.handle))
+                float(nu), t_du.handle, t_dud.handle, t_d2u.handle, int(bool(accumulate))))
 
     def transeq_species(self, dspec, uvw, spec, nu, dirps, sync=True, accumulate=False, direction=None):
         """src/backend/omp/backend.f90:186-233: convection-diffusion of one transported scalar along
@@ -223,14 +223,7 @@ class HipBackend:
                                                 float(nu), dirps.der1st.handle, dirps.der1st_sym.handle,
                                                 dirps.der2nd.handle, dirps.der2nd_sym.handle, int(accumulate)))
             return
-        if not accumulate:
-            self._transeq_dist(direction, du, dv, dw, u, v, w, nu, dirps)
-            return
-        tmp = [self.allocator.get_block(DIR_X) for _ in range(3)]
-        self._transeq_dist(direction, tmp[0], tmp[1], tmp[2], u, v, w, nu, dirps)
-        for t, r in zip(tmp, (du, dv, dw)):
-            _lib.check(self.lib.x3d_vecadd(self.h, 1.0, t.ptr, 1.0, r.ptr))
-            self.allocator.release_block(t)
+        self._transeq_dist(direction, du, dv, dw, u, v, w, nu, dirps, accumulate=accumulate)
 
     def transeq_dir_defer(self, direction, pend, u, v, w, nu, dirps):
         """transeq_dir(accumulate=True) with the accumulation left pending (csrc/viax.hip): the results stay in
@@ -263,13 +256,7 @@ class HipBackend:
             _lib.check(self.lib.x3d_tds_solve_acc(self.h, du.ptr, u.ptr, tdsops.handle, direction,
                                                   int(accumulate), float(scale)))
             return
-        if not accumulate:
-            self._tds_dist(du, u, tdsops, direction)
-            return
-        tmp = self.allocator.get_block(DIR_X)
-        self._tds_dist(tmp, u, tdsops, direction)
-        _lib.check(self.lib.x3d_vecadd(self.h, float(scale), tmp.ptr, 1.0, du.ptr))
-        self.allocator.release_block(tmp)
+        self._tds_dist(du, u, tdsops, direction, accumulate=accumulate, scale=scale)
 
     # ------------------------------------------------------------ tds_solve
     def tds_solve(self, du, u, tdsops):
@@ -286,8 +273,9 @@ class HipBackend:
             return
         self._tds_dist(du, u, tdsops, direction)
 
-    def _tds_dist(self, du, u, tdsops, direction):
-        """tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact"""
+    def _tds_dist(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
+        """tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact;
+        accumulate: du += scale * result (fused driver)"""
         d = direction - 1
         prev, nxt = int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
         ss, se, rs, re = self._buffers(direction, N_HALO, "u0")
@@ -298,8 +286,8 @@ class HipBackend:
         _lib.check(self.lib.x3d_tds_dist_fwd(self.h, du.ptr, bs.data_ptr(), be.data_ptr(), u.ptr,
                                              rs.data_ptr(), re.data_ptr(), tdsops.handle, direction))
         self.comm.sendrecv([(bs, be, brs, bre)], prev, nxt)
-        _lib.check(self.lib.x3d_tds_dist_bwd(self.h, du.ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(),
-                                             tdsops.handle, direction))
+        _lib.check(self.lib.x3d_tds_dist_bwd_acc(self.h, du.ptr, bs.data_ptr(), brs.data_ptr(), bre.data_ptr(),
+                                                 tdsops.handle, direction, int(bool(accumulate)), float(scale)))
 
     # ------------------------------------------------------------ reorder / sums
     def reorder(self, u_, u, direction):

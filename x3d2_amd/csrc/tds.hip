@@ -664,17 +664,28 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     return 0;
 }
 
-extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
-                                const double *du_recv_e, const x3d_tdsops *t, int dir)
+extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
+                                    const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
+                                    double scale)
 {
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
-    hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
-                       du_send_s, du_recv_s, du_recv_e, t->tab, g, 1.0);
+    if (accumulate)  // fusion extension: du += scale * result (folds the vecadd of the fused driver)
+        hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
+                           du_send_s, du_recv_s, du_recv_e, t->tab, g, scale);
+    else
+        hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
+                           du_send_s, du_recv_s, du_recv_e, t->tab, g, 1.0);
     X3D_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
+                                const double *du_recv_e, const x3d_tdsops *t, int dir)
+{
+    return x3d_tds_dist_bwd_acc(b, du, du_send_s, du_recv_s, du_recv_e, t, dir, 0, 1.0);
 }
 
 // Local form: sendrecv_fields with nproc==1 hands every rank its own buffers
@@ -763,20 +774,33 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     return 0;
 }
 
-extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
-                                    const double *recv_s, const double *recv_e, const double *conv, double nu,
-                                    const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
+extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, const double *send_s,
+                                        const double *recv_s, const double *recv_e, const double *conv, double nu,
+                                        const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
+                                        int accumulate)
 {
     X3D_REQUIRE(b && rhs && send_s && recv_s && recv_e && conv && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
-    hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs,
-                       (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu, t_du->tab, t_dud->tab,
-                       t_d2u->tab, g, g.np);
+    if (accumulate)  // fusion extension: rhs += result
+        hipLaunchKernelGGL(k_transeq_bwd<true>, grid_for(g), dim3(64), 0, b->stream, rhs,
+                           (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
+                           t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
+    else
+        hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs,
+                           (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
+                           t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
     X3D_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
+                                    const double *recv_s, const double *recv_e, const double *conv, double nu,
+                                    const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
+{
+    return x3d_transeq_dist_bwd_acc(b, dir, rhs, send_s, recv_s, recv_e, conv, nu, t_du, t_dud, t_d2u, 0);
 }
 
 static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,

@@ -175,22 +175,20 @@ class Solver:
         u, v, w = variables[:3]
         b.mesh.get_n(DIR_X, u.data_loc)
         b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
-        # the direction whose accumulation may be deferred goes last: z, or y when z is decomposed
-        dirps = {DIR_Y: self.ydirps, DIR_Z: self.zdirps}
-        last = DIR_Y if (b._decomposed(DIR_Z) and not b._decomposed(DIR_Y)) else DIR_Z
-        first = DIR_Z if last == DIR_Y else DIR_Y
-        b.transeq_dir(first, du, dv, dw, u, v, w, self.nu, dirps[first], accumulate=True)
+        b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
+        # z last: its accumulation may be deferred (when z is decomposed it is not: the y components then
+        # take the tile kernel K3y, which is cheaper than transposed copies + the fused RK stage)
         pending = None
-        if defer and os.environ.get("X3D_NO_DEFER") != "1":
+        if defer and os.environ.get("X3D_NO_DEFER") != "1" and not b._decomposed(DIR_Z):
             al = b.allocator
             pend = [al.get_block(DIR_X) for _ in range(3)]
-            if b.transeq_dir_defer(last, pend, u, v, w, self.nu, dirps[last]):
-                pending = {r.data.data_ptr(): (pf, last) for r, pf in zip((du, dv, dw), pend)}
+            if b.transeq_dir_defer(DIR_Z, pend, u, v, w, self.nu, self.zdirps):
+                pending = {r.data.data_ptr(): (pf, DIR_Z) for r, pf in zip((du, dv, dw), pend)}
             else:
                 for pf in pend:
                     al.release_block(pf)
         if pending is None:
-            b.transeq_dir(last, du, dv, dw, u, v, w, self.nu, dirps[last], accumulate=True)
+            b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
         for f in rhs[:3]:
             f.set_data_loc(u.data_loc)
         if self.nspecies > 0:
