@@ -722,8 +722,8 @@ def test_tgv512_fast_paths_match_general_kernels():
     assert abs(fast[0, 1] - 0.375) < 1e-6
 
 
-@pytest.mark.parametrize("intg", ["RK3", "RK4", "AB3"])
-def test_deferred_transeq_accumulation_is_bit_identical(intg):
+@pytest.mark.parametrize("intg,nspec", [("RK3", 0), ("RK4", 0), ("AB3", 0), ("RK3", 1)])
+def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec):
     """fused driver with the last accumulation of transeq folded into the RK stage's linear combination
     (csrc/viax.hip: x3d_transeq_defer / x3d_lincomb_pending; engages for 256 / 512-row periodic z pencils):
     bit-identical to the same run with X3D_NO_DEFER=1, and equal to the oracle's steps."""
@@ -737,7 +737,7 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg):
     dims, L = (16, 256, 256), (2.0, 3.0, 2.5)
     per = ("periodic",) * 2
     rng = np.random.default_rng(11)
-    init = [0.3 * rng.standard_normal((dims[2], dims[1], dims[0])) for _ in range(3)]
+    init = [0.3 * rng.standard_normal((dims[2], dims[1], dims[0])) for _ in range(3 + nspec)]
 
     class _Case(BaseCase):  # no forcings / BC hooks, like the TGV case
         def initial_conditions(self):
@@ -751,9 +751,9 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg):
         try:
             mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
             s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True, time_intg=intg,
-                                                            dt=1e-3, Re=100.0))
+                                                            dt=1e-3, Re=100.0, n_species=nspec))
             case = _Case(s)
-            for f, a in zip((s.u, s.v, s.w), init):
+            for f, a in zip([s.u, s.v, s.w] + list(s.species), init):
                 f.set_data_loc(VERT)
                 s.backend.set_field_data(f, a)
             calls = {"n": 0}
@@ -765,7 +765,7 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg):
             s.backend.lincomb_pending = counted
             for it in (1, 2):
                 case.step(it)
-            return [s.backend.get_field_data(f, VERT) for f in (s.u, s.v, s.w)], calls["n"]
+            return [s.backend.get_field_data(f, VERT) for f in [s.u, s.v, s.w] + list(s.species)], calls["n"]
         finally:
             os.environ.pop("X3D_NO_DEFER", None)
 
@@ -776,6 +776,8 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg):
         assert n_fused == 3 * 2 * int(intg[2])  # every stage of every variable took the fused kernel
     for a, b_ in zip(fused, plain):
         assert np.array_equal(a, b_)
+    if nspec:
+        return  # (species transport against the oracle: test_transeq_species_vs_reference)
     om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
     o = orc.Solver(om, poisson="CG", time_intg=intg, dt=1e-3, Re=100.0)
     for fo, a in zip((o.u, o.v, o.w), init):
