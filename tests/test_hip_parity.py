@@ -472,6 +472,39 @@ def test_fft512_strided_passes_and_fused_z_pass():
         assert relerr(fused, other) < 1e-12
 
 
+def test_r2c512_x_pass_against_numpy():
+    """nx = ny = nz = 512: the x pass of the Poisson solver is the single-kernel real-to-complex transform of
+    csrc/fft512.hip (two real rows as one complex 512-point FFT): full forward transform against numpy's, and
+    against rocFFT's x pass (X3D_NO_R2C512=1) on the same input."""
+    import os
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims = (512, 512, 512)
+    twopi = 6.283185307179586
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((512, 512, 512))
+    spectra = []
+    for env in (None, "1"):
+        if env:
+            os.environ["X3D_NO_R2C512"] = env
+        try:
+            mesh = Mesh(dims, (1, 1, 1), (twopi,) * 3, ("periodic",) * 2, ("periodic",) * 2, ("periodic",) * 2)
+            s = Solver(HipBackend(mesh), mesh, SolverConfig())
+            b, pf = s.backend, s.backend.poisson_fft
+            blk = b.allocator.get_block(DIR_C, CELL)
+            b.set_field_data(blk, f, CELL)
+            pf.fft_forward(blk)
+            spectra.append(pf.get_spectral())
+            del s, b, pf, blk
+        finally:
+            os.environ.pop("X3D_NO_R2C512", None)
+    assert relerr(spectra[0], spectra[1]) < 1e-14
+    ref = np.fft.rfftn(f, axes=(0, 1, 2))
+    assert relerr(spectra[0], ref) < 1e-13
+
+
 @pytest.mark.parametrize("nx", [512, 256, 128, 192, 500])
 def test_x_direction_scan_kernels_full_size_pencils(nx):
     """the wave-per-pencil x kernels (csrc/xscan.hip) only engage for pencils of 64*Q points

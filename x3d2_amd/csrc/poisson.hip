@@ -26,6 +26,7 @@ struct x3d_poisson {
     double *lu[2];        // sym: odd, even; else lu[0] only
     // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
     int fast512;
+    int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels
     hipfftHandle plan_x_fw, plan_x_bw;
 };
 
@@ -140,6 +141,8 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
         X3D_FFT(hipfftPlanMany(&p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch));
         if (int rc = x3d_fft512_init()) return rc;
         p->fast512 = 1;
+        const char *no_r2c = getenv("X3D_NO_R2C512");
+        p->r2c512 = p->nx == 512 && (batch % 2) == 0 && !(no_r2c && no_r2c[0] == '1');
     }
     *out = p;
     return 0;
@@ -157,15 +160,24 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     return 0;
 }
 
+int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);
+
+// x pass of the fast path: real rows (nxp apart) -> nxs complex modes
+static int x_forward_512(x3d_poisson *p, const double *f)
+{
+    ProfScope ps(p->b, X3D_K_FFT, 1);
+    if (p->r2c512)
+        return x3d_fft512_r2c(p->b, (double2 *)p->c, f, (long)p->ny * p->nz, p->b->nxp, p->nxs);
+    X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+    X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
+    return 0;
+}
+
 extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
     if (p->fast512) {
-        {
-            ProfScope ps(p->b, X3D_K_FFT, 1);
-            X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
-            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c));
-        }
+        if (int rc = x_forward_512(p, f_in)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
         return x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 0, nullptr, nullptr, p->nx);
     }
@@ -209,11 +221,7 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
 {
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
     if (p->fast512) {  // x r2c ; y ; z forward + process_spectral_000 + z backward in one pass ; y ; x c2r
-        {
-            ProfScope ps(p->b, X3D_K_FFT, 1);
-            X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
-            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
-        }
+        if (int rc = x_forward_512(p, f)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 2, p->waves, p->ab, p->nx)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
