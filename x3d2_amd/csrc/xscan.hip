@@ -78,6 +78,25 @@ __device__ __forceinline__ double readlane_d(double v, int l)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                             __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// ---- two pencils per wave: every lane-table value read from LDS serves both (the kernels are LDS-pipe
+// bound on the table reads), and the two independent dependency chains interleave.  The solver below is
+// written once over T = double or V2.
+struct V2 { double a, b; };
+__device__ __forceinline__ V2 operator+(V2 x, V2 y) { return V2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ V2 operator-(V2 x, V2 y) { return V2{x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ V2 operator*(V2 x, V2 y) { return V2{x.a * y.a, x.b * y.b}; }
+__device__ __forceinline__ V2 operator*(double c, V2 x) { return V2{c * x.a, c * x.b}; }
+__device__ __forceinline__ V2 operator*(V2 x, double c) { return V2{x.a * c, x.b * c}; }
+__device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.a += y.a; x.b += y.b; return x; }
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
+__device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
+template <class T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ V2 zero_of<V2>() { return V2{0.0, 0.0}; }
+__device__ __forceinline__ double first_of(double x) { return x; }
+__device__ __forceinline__ double first_of(V2 x) { return x.a; }
+
 __device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
 {
     const double r = __shfl_up(v, d, 64);
@@ -100,17 +119,17 @@ __device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, 
 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
 // values (before the reduced-system substitution), du1 and xn broadcast to all lanes
-template <int Q, bool FAST, bool NARROW = false>
-__device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)[Q], double &du1, double &xn,
+template <int Q, bool FAST, bool NARROW = false, class T = double>
+__device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du1, T &xn,
                                            const double *__restrict__ lt, const XOp &t, int &lane, int first)
 {
     // PHASE(x): the lane-table reads of the next phase may not be issued before x is known; without
     // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
-#define PHASE(x) asm volatile("" : "+v"(lane) : "v"(x))
+#define PHASE(x) asm volatile("" : "+v"(lane) : "v"(first_of(x)))
     const int nr = t.n_rhs, n = t.n_tds;
     const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
                  c7 = t.c[7], c8 = t.c[8];
-    double acc[Q];
+    T acc[Q];
     // NARROW: the compact6 / classic stencils only reach 2 rows: skip the zero taps (adding 0 * w is exact,
     // so both forms give the same bits); chosen by the launcher from the operators' coefficients
     if (NARROW) {
@@ -136,17 +155,17 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
         }
     }
     // ---- lane-local forward elimination from zero
-    double prev = 0.0;
+    T prev = zero_of<T>();
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         X[q] = lt[LT_F(q) * 64 + lane] * (acc[q] - lt[LT_A(q) * 64 + lane] * prev);
         prev = X[q];
     }
     // ---- scan of the lane-end values, then carry-in = true e at the end of lane l-1
-    double v = prev;
+    T v = prev;
     PHASE(X[Q / 2]);
 #if XSCAN_EXP == 3
-    double carry = v;
+    T carry = v;
 #else
     // prefix scan without LDS traffic: in-row Kogge-Stone by DPP row shifts, then lane 15 / 47 into rows
     // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0
@@ -156,10 +175,10 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     v += lt[LT_MF(3) * 64 + lane] * dpp0<0x118>(v);
     v += lt[LT_MF(4) * 64 + lane] * dpp0<0x142, 0xA>(v);
     v += lt[LT_MF(5) * 64 + lane] * dpp0<0x143, 0xC>(v);
-    double carry = dpp0<0x138>(v);  // wave_shr:1
+    T carry = dpp0<0x138>(v);  // wave_shr:1
 #endif
     // ---- apply, lane-local back-substitution from zero
-    double nxt = 0.0;
+    T nxt = zero_of<T>();
     PHASE(carry);
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
@@ -178,7 +197,7 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
     v += lt[LT_MB(2) * 64 + lane] * dpp0<0x104>(v);
     v += lt[LT_MB(3) * 64 + lane] * dpp0<0x108>(v);
     {
-        const double s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
+        const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
         v += lt[LT_MB(4) * 64 + lane] * (lane < 32 ? s16 : s48);
         v += lt[LT_MB(5) * 64 + lane] * readlane_d(v, 32);
     }
@@ -187,9 +206,9 @@ __device__ __forceinline__ void scan_solve(const double (&w)[Q + 8], double (&X)
 #pragma unroll
     for (int q = 0; q < Q; q++) X[q] = X[q] + lt[LT_QB(q) * 64 + lane] * carry;
     // du_1 = last_r * X_1 (X_1 = e_1 - bw_1 X_2, distributed.f90:161-166); X_n = e_n
-    du1 = t.last_r * __shfl(X[0], 0, 64);
-    if (FAST) {
-        xn = __shfl(X[Q - 1], 63, 64);
+    du1 = t.last_r * readlane_d(X[0], 0);
+    if constexpr (FAST) {
+        xn = readlane_d(X[Q - 1], 63);
     } else {
         const int ln = (n - 1) / Q, qn = (n - 1) % Q;
         double xsel = 0.0;
@@ -236,8 +255,8 @@ __device__ __forceinline__ void load_body(double (&b)[Q], const double *__restri
         b[2 * m + 1] = t2.y;
     }
 }
-template <int Q>
-__device__ __forceinline__ void window_from_body(double (&w)[Q + 8], const double (&b)[Q], int lane)
+template <int Q, class T = double>
+__device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q], int lane)
 {
     (void)lane;
 #pragma unroll
@@ -561,6 +580,101 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     }
 }
 
+// ---------------------------------------------------------------- transeq component, two pencils per wave
+// FAST form only (periodic-type operators, n = 64 Q).  8 waves x 2 pencils per workgroup: the same 16 pencils
+// in flight per CU as k_xscan_transeq, half the LDS table traffic.
+template <int Q, bool SAME, bool ACC, bool NARROW>
+__global__ void __launch_bounds__(512)
+    k_xscan_transeq2(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
+                     XOp t2, XOp t3, int np, long pitch, double nu)
+{
+    extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64]
+    constexpr int LN = LT_N(Q) * 64;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = t1.TL[i];
+        lt[LN + i] = t2.TL[i];
+        lt[2 * LN + i] = t3.TL[i];
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int first = lane * Q + 1;
+    const double *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
+    // next pair's rows of u and conv, in flight during the solve (256-VGPR budget: 8 waves per CU)
+    double nua[Q], nub[Q], nca[Q], ncb[Q];
+    const int pstart = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
+    if (pstart < np) {
+        load_body<Q>(nua, u + (long)pstart * pitch, lane);
+        load_body<Q>(nub, u + (long)(pstart + 1) * pitch, lane);
+        if (!SAME) {
+            load_body<Q>(nca, cv + (long)pstart * pitch, lane);
+            load_body<Q>(ncb, cv + (long)(pstart + 1) * pitch, lane);
+        }
+    }
+    for (int p = pstart; p < np; p += 2 * nwaves) {
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
+        V2 wu[Q + 8], wp[Q + 8], vq[Q];
+        {
+            V2 b2[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) b2[q] = V2{nua[q], nub[q]};
+            window_from_body<Q, V2>(wu, b2, lane);
+            if (!SAME) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) b2[q] = V2{nca[q], ncb[q]};
+                window_from_body<Q, V2>(wp, b2, lane);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) vq[q] = b2[q];
+            const int pn = p + 2 * nwaves;
+            if (pn < np) {
+                load_body<Q>(nua, u + (long)pn * pitch, lane);
+                load_body<Q>(nub, u + (long)(pn + 1) * pitch, lane);
+                if (!SAME) {
+                    load_body<Q>(nca, cv + (long)pn * pitch, lane);
+                    load_body<Q>(ncb, cv + (long)(pn + 1) * pitch, lane);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
+        }
+        auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const double *__restrict__ l, const XOp &t) {
+            V2 a, b;
+            scan_solve<Q, true, NARROW, V2>(w, T, a, b, l, t, lane, first);
+            const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const double st = l[LT_ST(q) * 64 + lane];
+                V2 x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                if (q == 0) x = (lane == 0) ? s_ * st : x;
+                if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                T[q] = x;
+            }
+        };
+        V2 r[Q], T[Q];
+        solve_subs(wp, T, l2, t2);
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = T[q];
+        asm volatile("" : "+v"(lane) : "v"(r[0].a));
+        solve_subs(wu, T, l1, t1);
+#pragma unroll
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        asm volatile("" : "+v"(lane) : "v"(r[0].a));
+        solve_subs(wu, T, l3, t3);
+        double ra[Q], rb[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const V2 v = r[q] + nu * T[q];
+            ra[q] = v.a;
+            rb[q] = v.b;
+        }
+        double *__restrict__ oa = rhs + (long)p * pitch, *__restrict__ ob = oa + pitch;
+        if constexpr (Q == 8) { store_rows_q8<ACC>(oa, lane, ra, 1.0); store_rows_q8<ACC>(ob, lane, rb, 1.0); }
+        else { store_rows_q4<ACC>(oa, lane, ra, 1.0); store_rows_q4<ACC>(ob, lane, rb, 1.0); }
+    }
+}
+
 // ---------------------------------------------------------------- K3y: y pencils without transposed copies
 // One workgroup = 16 waves = the 16 x-adjacent y pencils of one z plane.  The tile [16 x][n y] goes through
 // LDS: the workgroup reads it from the Cartesian block in 128-byte row segments (16 doubles of x per y),
@@ -773,6 +887,33 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
           : (acc ? launch_transeq<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)      \
                  : launch_transeq<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)))
 #define GO(Q_) (fast ? (narrow ? GO2(Q_, 2) : GO2(Q_, 1)) : GO2(Q_, 0))
+    static int p2 = -1;
+    if (p2 < 0) { const char *e = getenv("X3D_XSCAN_P1"); p2 = (e && e[0] == '1') ? 0 : 1; }  // same-box A/B: 0.61 -> 0.59 ms
+    if (p2 && fast && np % 2 == 0) {
+        const int blocks2 = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
+#define LP2(Q_, S_, A_, N_)                                                                                    \
+        do {                                                                                                   \
+            static bool at = false;                                                                            \
+            if (!at) {                                                                                         \
+                X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2<Q_, S_, A_, N_>,                    \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+                at = true;                                                                                     \
+            }                                                                                                  \
+            hipLaunchKernelGGL((k_xscan_transeq2<Q_, S_, A_, N_>), dim3(blocks2), dim3(512), lds, b->stream, rhs, u, \
+                               conv, xop_of(t1), xop_of(t2), xop_of(t3), np, pitch, nu);                       \
+        } while (0)
+#define LP2N(Q_, S_, A_) do { if (narrow) LP2(Q_, S_, A_, true); else LP2(Q_, S_, A_, false); } while (0)
+#define LP2A(Q_, S_) do { if (acc) LP2N(Q_, S_, true); else LP2N(Q_, S_, false); } while (0)
+#define LP2S(Q_) do { if (same) LP2A(Q_, true); else LP2A(Q_, false); } while (0)
+        if (Q == 8) LP2S(8); else LP2S(4);
+#undef LP2S
+#undef LP2A
+#undef LP2N
+#undef LP2
+        X3D_HIP(hipGetLastError());
+        *done = true;
+        return 0;
+    }
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO
 #undef GO2
