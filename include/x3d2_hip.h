@@ -87,6 +87,12 @@ int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
 int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
                       int accumulate, double scale);
 
+/* fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
+ *   mode 0: out1 = A(in1) + B(in2) (out2 unused)      mode 1: out1 = A(in1), out2 = B(in1) (in2 unused)
+ * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
+int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):
  *   x3d_pack_halos     = copy_into_buffers   (src/backend/omp/backend.f90:714-737)

@@ -412,7 +412,8 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
 
 
 @pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_ONCHIP_TRANSEQ", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN",
-                                 "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_ZTILE", "X3D_XSCAN_P1"])
+                                 "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_ZTILE", "X3D_XSCAN_P1",
+                                 "X3D_NO_TDS_PAIR"])
 def test_optional_kernel_families_pass_the_same_parity_tests(env):
     """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
     block-recompute sweeps, generic x-direction kernels, LDS-tiled x kernels instead of
@@ -619,6 +620,37 @@ def test_yz_operators_on_512_row_pencils(dims):
     o.transeq(rhs_o, [o.u, o.v, o.w])
     for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+
+    # operator pairs of the pressure correction (x3d_tds_solve_pair; one tile kernel for y pencils)
+    def oracle_op(fo, t_o):
+        src_o = o.backend.get_block(orc.DIR_X, orc.VERT)
+        src_o.data[...] = fo.data
+        src_o.data_loc = fo.data_loc
+        a_o, out_o = o.backend.get_block(d), o.backend.get_block(d)
+        o.backend.reorder(a_o, src_o, 10 + d)
+        o.backend.tds_solve(out_o, a_o, t_o)
+        return o.backend.get_field_data(out_o)
+    for opa, opb in (("interpl_v2p", "stagder_v2p"), ("interpl_p2v", "stagder_p2v")):
+        loc = VERT if opa.endswith("v2p") else move_data_loc(VERT, d, 1)
+        ins = [al.get_block(DIR_X), al.get_block(DIR_X)]
+        for f_, src in zip(ins, (s.u, s.v)):
+            b.veccopy(f_, src)
+            f_.set_data_loc(loc)
+        for fo in (o.u, o.v):
+            fo.data_loc = loc
+        o1, o2 = al.get_block(DIR_X), al.get_block(DIR_X)
+        ta, tb = getattr(dp_h, opa), getattr(dp_h, opb)
+        ra, rb2 = oracle_op(o.u, getattr(dp_o, opa)), oracle_op(o.v, getattr(dp_o, opb))
+        rb1 = oracle_op(o.u, getattr(dp_o, opb))
+        b.tds_pair(0, o1, None, ins[0], ins[1], ta, tb, d)
+        o1.set_data_loc(move_data_loc(loc, d, ta.move))
+        assert relerr(b.get_field_data(o1), ra + rb2) < TOL, (opa, opb, "mode 0")
+        b.tds_pair(1, o1, o2, ins[0], None, ta, tb, d)
+        o2.set_data_loc(move_data_loc(loc, d, tb.move))
+        assert relerr(b.get_field_data(o1), ra) < TOL, (opa, opb, "mode 1 / A")
+        assert relerr(b.get_field_data(o2), rb1) < TOL, (opa, opb, "mode 1 / B")
+        for fo in (o.u, o.v):
+            fo.data_loc = orc.VERT
 
 
 def test_slab_poisson_solver_single_rank_emulation():

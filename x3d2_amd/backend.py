@@ -250,6 +250,20 @@ class HipBackend:
         # field passes the linear combination itself needs (base + the other terms + y): bench.py's roofline
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
 
+    def tds_pair(self, mode, out1, out2, in1, in2, t_a, t_b, direction):
+        """two tds_solve's that share an output (mode 0: out1 = A(in1) + B(in2)) or an input
+        (mode 1: out1 = A(in1), out2 = B(in1)): one kernel where the pencils allow (csrc/xscan.hip)"""
+        if self._decomposed(direction):
+            self.tds_apply(out1, in1, t_a, direction)
+            if mode == 0:
+                self.tds_apply(out1, in2, t_b, direction, accumulate=True)
+            else:
+                self.tds_apply(out2, in1, t_b, direction)
+            return
+        _lib.check(self.lib.x3d_tds_solve_pair(self.h, direction, int(mode), out1.ptr,
+                                               out2.ptr if out2 is not None else None, in1.ptr,
+                                               in2.ptr if in2 is not None else None, t_a.handle, t_b.handle))
+
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""
         if not self._decomposed(direction):

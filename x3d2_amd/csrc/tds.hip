@@ -708,6 +708,32 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
+int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                       const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // xscan.hip
+
+// fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
+//   mode 0: out1 = A(in1) + B(in2)          mode 1: out1 = A(in1), out2 = B(in1)
+// one kernel for periodic 256 / 512-row y pencils (xscan.hip, k_ytile_tds_pair), else the two tds_solve's
+extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                                  const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb)
+{
+    X3D_REQUIRE(b && out1 && in1 && ta && tb && (mode == 0 ? in2 != nullptr : out2 != nullptr),
+                "x3d_tds_solve_pair: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_solve_pair: mode must be 0 or 1");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve_pair: bad dir %d", dir);
+    X3D_REQUIRE(out1 != in1 && out1 != in2 && out2 != in1 && (mode == 0 || out1 != out2),
+                "x3d_tds_solve_pair: outputs alias inputs");
+    if (int rc = check_len(b, ta, dir, "tds_solve_pair")) return rc;
+    if (int rc = check_len(b, tb, dir, "tds_solve_pair")) return rc;
+    if (dir == X3D_DIR_Y) {
+        bool done = false;
+        if (int rc = x3d_ytile_tds_pair(b, mode, out1, out2, in1, in2, ta, tb, &done)) return rc;
+        if (done) return 0;
+    }
+    if (int rc = x3d_tds_solve_acc(b, out1, in1, ta, dir, 0, 1.0)) return rc;
+    return mode == 0 ? x3d_tds_solve_acc(b, out1, in2, tb, dir, 1, 1.0) : x3d_tds_solve_acc(b, out2, in1, tb, dir, 0, 1.0);
+}
+
 extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
     return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);

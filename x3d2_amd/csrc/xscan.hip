@@ -808,6 +808,122 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// ---------------------------------------------------------------- K3y for tds_solve pairs (pressure correction)
+// The y operators of divergence_v2c / gradient_c2v come in pairs that share an output or an input
+// (src/vector_calculus.f90:142-332 as sequenced by pressure_correction_fused):
+//   MODE 0:  out  = A(in1) + B(in2)      (interpl_y(du_x) + stagder_y(dv_x):   3 field passes instead of 2 + 3)
+//   MODE 1:  out1 = A(in1), out2 = B(in1) (interpl_y(p), stagder_y(p):         3 instead of 2 + 2)
+// Same tile mechanics as k_ytile_transeq, same arithmetic as k_xscan_tds (MODE 0 adds the two results exactly
+// like the accumulating form: old + 1.0 * r).
+template <int Q, int MODE, bool NARROW>
+__global__ void __launch_bounds__(1024)
+    k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
+                     XOp ta, XOp tb, int ntx, int ntiles, long prow, long pplane)
+{
+    extern __shared__ double lt[];
+    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = ta.TL[i];
+        lt[LN + i] = tb.TL[i];
+    }
+    const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
+    double *tile = lt + 2 * LN;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int first = lane * Q + 1;
+    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+    };
+    auto to_tile = [&](const double2 (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
+            tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
+        }
+    };
+    auto pick = [&](double (&b)[Q]) {
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) {
+            const double2 t2_ = src[m];
+            b[2 * m] = t2_.x;
+            b[2 * m + 1] = t2_.y;
+        }
+    };
+    auto put = [&](const double (&r)[Q]) {
+        double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m], r[2 * m + 1]);
+    };
+    auto from_tile = [&](double *o) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) =
+                make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+    };
+    // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange)
+    auto solve = [&](const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ l, const XOp &t) {
+        double X[Q], du1, xn;
+        scan_solve<Q, true, NARROW>(w, X, du1, xn, l, t, lane, first);
+        const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const double st = l[LT_ST(q) * 64 + lane];
+            r[q] = (X[q] - l[LT_SA(q) * 64 + lane] * du_s - l[LT_SC(q) * 64 + lane] * du_e) * st;
+            if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
+            if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+        }
+    };
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    __syncthreads();
+    double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
+    if ((int)blockIdx.x < ntiles) gload(nxt, in1 + tile_off(blockIdx.x));
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        asm volatile("" : "+v"(lane));
+        double w[Q + 8], b[Q], ra[Q], rb[Q];
+        double2 g2[NI];
+        if (MODE == 0) gload(g2, in2 + off);
+        to_tile(nxt);
+        __syncthreads();
+        pick(b);
+        window_from_body<Q>(w, b, lane);
+        __syncthreads();  // the tile is free
+        {
+            const int tn = tl + gridDim.x;
+            if (tn < ntiles) gload(nxt, in1 + tile_off(tn));
+        }
+        solve(w, ra, la, ta);
+        if (MODE == 0) {
+            to_tile(g2);
+            __syncthreads();
+            pick(b);
+            window_from_body<Q>(w, b, lane);
+            __syncthreads();
+            asm volatile("" : "+v"(lane) : "v"(ra[0]));
+            solve(w, rb, lb, tb);
+#pragma unroll
+            for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
+            put(ra);
+            __syncthreads();
+            from_tile(out1 + off);
+        } else {
+            put(ra);
+            __syncthreads();
+            from_tile(out1 + off);
+            asm volatile("" : "+v"(lane) : "v"(ra[0]));
+            solve(w, rb, lb, tb);
+            __syncthreads();  // out1's tile has been read
+            put(rb);
+            __syncthreads();
+            from_tile(out2 + off);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- launchers
 // bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
 static bool stencil_narrow(const x3d_tdsops *t)
@@ -998,6 +1114,48 @@ int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, con
 #undef GO
 #undef GO2
     if (rc) return rc;
+    *done = true;
+    return 0;
+}
+
+// K3y pair launcher: see k_ytile_tds_pair; y direction only (the z form would be page-bound like X3D_ZTILE)
+int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                       const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_TDS_PAIR"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (!on || !use_ytile() || !xscan_ok(ta) || !xscan_ok(tb) || ta->tab.Q != tb->tab.Q) return 0;
+    const int Q = ta->tab.Q;
+    auto fast = [&](const x3d_tdsops *t) {
+        return t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
+    };
+    if (!fast(ta) || !fast(tb) || b->ny != 64 * Q || b->nx % 16 != 0) return 0;
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    if (lds > 160 * 1024) return 0;
+    const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
+    const long pxy = (long)b->nxp * b->nyp;
+    const int ntx = b->nx / 16, ntiles = ntx * b->nz;
+    const int blocks = ntiles > 256 ? 256 : ntiles;
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Y);
+#define GO(Q_, M_, N_)                                                                                          \
+    do {                                                                                                        \
+        static bool at = false;                                                                                 \
+        if (!at) {                                                                                              \
+            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_tds_pair<Q_, M_, N_>,                             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            at = true;                                                                                          \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, in1, \
+                           in2, xop_of(ta), xop_of(tb), ntx, ntiles, (long)b->nxp, pxy);                        \
+    } while (0)
+#define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
+#define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else GON(Q_, 1); } while (0)
+    if (Q == 8) GOM(8); else GOM(4);
+#undef GOM
+#undef GON
+#undef GO
+    X3D_HIP(hipGetLastError());
     *done = true;
     return 0;
 }

@@ -206,12 +206,10 @@ class Solver:
         b.tds_apply(t1, u, x.stagder_v2p, DIR_X)
         b.tds_apply(t2, v, x.interpl_v2p, DIR_X)
         b.tds_apply(t3, w, x.interpl_v2p, DIR_X)
-        b.tds_apply(a1, t1, y.interpl_v2p, DIR_Y)
-        b.tds_apply(a1, t2, y.stagder_v2p, DIR_Y, accumulate=True)
+        b.tds_pair(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p, DIR_Y)   # a1 = interpl(t1) + stagder(t2)
         b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
         div = t1
-        b.tds_apply(div, a1, z.interpl_v2p, DIR_Z)
-        b.tds_apply(div, a2, z.stagder_v2p, DIR_Z, accumulate=True)
+        b.tds_pair(0, div, None, a1, a2, z.interpl_v2p, z.stagder_v2p, DIR_Z)
         # poisson: the cell-centred divergence is already Cartesian (no Z2C / C2Z)
         p = div
         if self.cfg.poisson_solver_type == "FFT":
@@ -219,10 +217,8 @@ class Solver:
         else:
             p.fill(0.0)
         # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
-        b.tds_apply(t2, p, z.interpl_p2v, DIR_Z)        # p_sxy
-        b.tds_apply(t3, p, z.stagder_p2v, DIR_Z)        # dpdz_sxy
-        b.tds_apply(a1, t2, y.interpl_p2v, DIR_Y)       # p_sx
-        b.tds_apply(a2, t2, y.stagder_p2v, DIR_Y)       # dpdy_sx
+        b.tds_pair(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v, DIR_Z)    # p_sxy, dpdz_sxy
+        b.tds_pair(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
         b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)       # dpdz_sx
         b.tds_apply(u, a1, x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
         b.tds_apply(v, a2, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
