@@ -671,22 +671,22 @@ def test_slab_poisson_solver_single_rank_emulation():
     from x3d2_amd.common import CELL, DIR_C
     from x3d2_amd.poisson_fft import HipSlabPoissonFFT
     from x3d2_amd.solver import Solver, SolverConfig
-    dims = (24, 512, 40)
     twopi = 6.283185307179586
     per = ("periodic",) * 2
-    mesh = Mesh(dims, (1, 1, 1), (twopi, 3.0, 2.0), per, per, per)
-    s = Solver(HipBackend(mesh), mesh, SolverConfig())
-    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
-    assert isinstance(pf, HipSlabPoissonFFT)
-    rng = np.random.default_rng(5)
-    f = rng.standard_normal((dims[2], dims[1], dims[0]))
-    blk = al.get_block(DIR_C, CELL)
-    b.set_field_data(blk, f, CELL)
-    pf.solve_poisson(blk, None)
-    got = b.get_field_data(blk, CELL)
-    om = orc.Mesh(list(dims), [1, 1, 1], [twopi, 3.0, 2.0], list(per), list(per), list(per))
-    ref = orc.Solver(om, poisson="FFT").poisson_fft.solve(f)
-    assert relerr(got, ref) < 1e-11
+    for dims in ((24, 512, 40), (512, 512, 8)):  # nx = 512: the x pass is k_r2c512 (csrc/fft512.hip)
+        mesh = Mesh(dims, (1, 1, 1), (twopi, 3.0, 2.0), per, per, per)
+        s = Solver(HipBackend(mesh), mesh, SolverConfig())
+        b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+        assert isinstance(pf, HipSlabPoissonFFT)
+        rng = np.random.default_rng(5)
+        f = rng.standard_normal((dims[2], dims[1], dims[0]))
+        blk = al.get_block(DIR_C, CELL)
+        b.set_field_data(blk, f, CELL)
+        pf.solve_poisson(blk, None)
+        got = b.get_field_data(blk, CELL)
+        om = orc.Mesh(list(dims), [1, 1, 1], [twopi, 3.0, 2.0], list(per), list(per), list(per))
+        ref = orc.Solver(om, poisson="FFT").poisson_fft.solve(f)
+        assert relerr(got, ref) < 1e-11, dims
 
 
 @pytest.mark.parametrize("name", SINGLE)

@@ -33,6 +33,8 @@ int x3d_fft512_init();
 int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
                      const double *ab, int nx, double2 *xbuf, int ys);
 
+int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);  // fft512.hip
+
 struct x3d_sfft {
     x3d_backend *b;
     int nx, ny, nz, nxs;  // global cell dims (ny = 512)
@@ -181,8 +183,15 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
     {
         ProfScope ps(p->b, X3D_K_FFT, 1);
-        X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
-        X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+        static int own = -1;  // single-kernel real-to-complex x pass (fft512.hip), as in the single-rank solver
+        if (own < 0) { const char *e = getenv("X3D_NO_R2C512"); own = (e && e[0] == '1') ? 0 : 1; }
+        const long rows = (long)p->zl * p->ny;
+        if (own && p->nx == 512 && rows % 2 == 0) {
+            if (int rc = x3d_fft512_r2c(p->b, p->c0, f_in, rows, p->b->nxp, p->nxs)) return rc;
+        } else {
+            X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+        }
     }
     return x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 0, nullptr, nullptr, p->nx, (double2 *)sendbuf,
                             p->ys);
