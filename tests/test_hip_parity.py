@@ -412,7 +412,7 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
 
 
 @pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_ONCHIP_TRANSEQ", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN",
-                                 "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_ZTILE", "X3D_XSCAN_P1",
+                                 "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_NO_ZTILE", "X3D_XSCAN_P1",
                                  "X3D_NO_TDS_PAIR"])
 def test_optional_kernel_families_pass_the_same_parity_tests(env):
     """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
@@ -795,6 +795,14 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec):
     (csrc/viax.hip: x3d_transeq_defer / x3d_lincomb_pending; engages for 256 / 512-row periodic z pencils):
     bit-identical to the same run with X3D_NO_DEFER=1, and equal to the oracle's steps."""
     import os
+    import subprocess
+    import sys
+    if os.environ.get("X3D_NO_ZTILE") != "1":  # the deferred route serves the z pencils the tile kernel does not take
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
+                            "deferred_transeq_accumulation and %s-%d" % (intg, nspec)],
+                           env=dict(os.environ, X3D_NO_ZTILE="1"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+        return
     from oracle import x3d_oracle as orc
     from x3d2_amd import Mesh
     from x3d2_amd.backend import HipBackend

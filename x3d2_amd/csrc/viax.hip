@@ -17,6 +17,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
                          const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
                          int dirtag, bool *done);
 bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
 int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 
@@ -292,6 +293,9 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv
                 "x3d_transeq_defer: null argument");
     *deferred = 0;
     if (!use_via_x() || (dir != X3D_DIR_Y && dir != X3D_DIR_Z)) return 0;
+    if (x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd) &&
+        x3d_ytile_applicable(b, dir, der1st_sym, der1st, der2nd_sym))
+        return 0;  // the tile kernel + plain lincomb is faster than transposed copies + the fused RK stage
     if (!x3d_xscan_fast_ok(der1st, der1st_sym, der2nd) || !x3d_xscan_fast_ok(der1st_sym, der1st, der2nd_sym)) return 0;
     const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
     if (der1st->n_tds != n) return 0;
