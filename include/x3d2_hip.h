@@ -183,6 +183,16 @@ int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv, double *p
                       const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
                       int *deferred);
 int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend);
+/* the same fusion when the last direction's pencils take the tile kernel (csrc/xscan.hip, k_ytile_transeq): the
+ * component itself is computed inside the stage's linear combination.  x3d_transeq_stage_ok != 0: applicable.
+ * kind 0: advecting component (der1st, der1st_sym, der2nd; conv == u), kind 1: the others (der1st_sym, der1st,
+ * der2nd_sym).  Equal to x3d_transeq_species(dspec = x[ipend], accumulate = 1) followed by x3d_lincomb. */
+int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                         const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym);
+int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const double *u, const double *conv, double nu,
+                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                        const x3d_tdsops *der2nd_sym, double *y, const double *base, int nterm, const double *c,
+                        double *const *x, int ipend, int store);
 int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm, const double *c,
                         double *const *x, int ipend, const double *pend, int store);
 

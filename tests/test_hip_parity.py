@@ -789,17 +789,20 @@ def test_tgv512_fast_paths_match_general_kernels():
     assert abs(fast[0, 1] - 0.375) < 1e-6
 
 
+@pytest.mark.parametrize("route", ["tile", "copies"])
 @pytest.mark.parametrize("intg,nspec", [("RK3", 0), ("RK4", 0), ("AB3", 0), ("RK3", 1)])
-def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec):
+def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec, route):
     """fused driver with the last accumulation of transeq folded into the RK stage's linear combination
     (csrc/viax.hip: x3d_transeq_defer / x3d_lincomb_pending; engages for 256 / 512-row periodic z pencils):
     bit-identical to the same run with X3D_NO_DEFER=1, and equal to the oracle's steps."""
     import os
     import subprocess
     import sys
-    if os.environ.get("X3D_NO_ZTILE") != "1":  # the deferred route serves the z pencils the tile kernel does not take
+    # route "tile": the z components are computed inside the stage kernel (k_ytile_transeq<EPI>); "copies": the
+    # transposed-copy route that serves the z pencils the tile kernel does not take (forced by X3D_NO_ZTILE=1)
+    if route == "copies" and os.environ.get("X3D_NO_ZTILE") != "1":
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
-                            "deferred_transeq_accumulation and %s-%d" % (intg, nspec)],
+                            "deferred_transeq_accumulation and copies and %s-%d" % (intg, nspec)],
                            env=dict(os.environ, X3D_NO_ZTILE="1"), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
         return
@@ -823,6 +826,8 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec):
             os.environ["X3D_NO_DEFER"] = "1"
         else:
             os.environ.pop("X3D_NO_DEFER", None)
+        if route == "tile":
+            os.environ["X3D_STAGE_IN_TILE"] = "1"  # (opt-in: solver.py, transeq_fused)
         try:
             mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
             s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True, time_intg=intg,
@@ -832,17 +837,19 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec):
                 f.set_data_loc(VERT)
                 s.backend.set_field_data(f, a)
             calls = {"n": 0}
-            real = s.backend.lincomb_pending
+            name = "transeq_lincomb" if route == "tile" else "lincomb_pending"
+            real = getattr(s.backend, name)
 
             def counted(*args, **kw):
                 calls["n"] += 1
                 return real(*args, **kw)
-            s.backend.lincomb_pending = counted
+            setattr(s.backend, name, counted)
             for it in (1, 2):
                 case.step(it)
             return [s.backend.get_field_data(f, VERT) for f in [s.u, s.v, s.w] + list(s.species)], calls["n"]
         finally:
             os.environ.pop("X3D_NO_DEFER", None)
+            os.environ.pop("X3D_STAGE_IN_TILE", None)
 
     fused, n_fused = run(False)
     plain, n_plain = run(True)

@@ -237,6 +237,33 @@ class HipBackend:
                                               dirps.der2nd.handle, dirps.der2nd_sym.handle, ctypes.byref(flag)))
         return bool(flag.value)
 
+    def transeq_stage_ok(self, direction, dirps):
+        """the tile kernel takes this direction's pencils: the last direction of transeq can be computed
+        inside the RK / AB stage (transeq_lincomb)"""
+        if self._decomposed(direction):
+            return False
+        return bool(self.lib.x3d_transeq_stage_ok(self.h, direction, dirps.der1st.handle, dirps.der1st_sym.handle,
+                                                  dirps.der2nd.handle, dirps.der2nd_sym.handle))
+
+    def transeq_lincomb(self, direction, kind, u_ptr, conv_ptr, nu, dirps, y, base, coeffs, xs, ipend, store):
+        """lincomb with term xs[ipend] completed by one transeq component computed in the same kernel"""
+        n = len(xs)
+        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        p = (VP * n)(*[x.ptr for x in xs])
+        _lib.check(self.lib.x3d_transeq_lincomb(self.h, direction, int(kind), u_ptr, conv_ptr, float(nu),
+                                                dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                                dirps.der2nd_sym.handle, y.ptr, base.ptr, n, c, p, int(ipend),
+                                                int(bool(store))))
+        self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
+        self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
+
+    def transeq_component_acc(self, direction, kind, rhs_ptr, u_ptr, conv_ptr, nu, dirps):
+        """rhs += one transeq component (kind as in transeq_lincomb)"""
+        ops = (dirps.der1st, dirps.der1st_sym, dirps.der2nd) if kind == 0 else \
+              (dirps.der1st_sym, dirps.der1st, dirps.der2nd_sym)
+        _lib.check(self.lib.x3d_transeq_species(self.h, direction, rhs_ptr, conv_ptr, u_ptr, float(nu), ops[0].handle,
+                                                ops[1].handle, ops[2].handle, 1))
+
     def pending_flush(self, direction, r_ptr, pend):
         _lib.check(self.lib.x3d_pending_flush(self.h, direction, r_ptr, pend.ptr))
 
@@ -249,6 +276,7 @@ class HipBackend:
                                                 int(bool(store))))
         # field passes the linear combination itself needs (base + the other terms + y): bench.py's roofline
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
+        self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
 
     def tds_pair(self, mode, out1, out2, in1, in2, t_a, t_b, direction):
         """two tds_solve's that share an output (mode 0: out1 = A(in1) + B(in2)) or an input

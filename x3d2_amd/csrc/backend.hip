@@ -68,6 +68,7 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     b->red_cap = 4096;
     X3D_HIP(hipMalloc(&b->red_buf, sizeof(double) * 2 * b->red_cap));
     X3D_HIP(hipHostMalloc(&b->red_host, sizeof(double) * 2 * b->red_cap));
+    X3D_HIP(hipMalloc(&b->epi_dev, 256));
     X3D_HIP(hipEventCreate(&b->ev0));
     X3D_HIP(hipEventCreate(&b->ev1));
     *out = b;
@@ -80,7 +81,7 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
     hipFree(b->send_s); hipFree(b->send_e);
     hipFree(b->scratch[0]); hipFree(b->scratch[1]); hipFree(b->scratch[2]);
     x3d_prof_enable_c(b, 0);
-    hipFree(b->red_buf); hipHostFree(b->red_host);
+    hipFree(b->red_buf); hipHostFree(b->red_host); hipFree(b->epi_dev);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     delete b;
     return 0;

@@ -582,6 +582,8 @@ int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, co
 int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // viax.hip
+int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);  // xscan.hip
 static bool use_onchip_transeq()
 {
     static int mode = -1;
@@ -834,6 +836,12 @@ static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const d
                                    int acc)
 {
     if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
+    if (!use_onchip_transeq() && !use_fused_kernels()) {
+        // K3y (xscan.hip): periodic 256 / 512-row pencils straight from the Cartesian block
+        bool done = false;
+        if (int rc = x3d_ytile_transeq(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;
+        if (done) return 0;
+    }
     if (use_onchip_transeq()) {
         bool done = false;
         if (int rc = x3d_onchip_transeq(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;

@@ -18,6 +18,10 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
                          int dirtag, bool *done);
 bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
 bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
+                              const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
+                              bool *done);
 int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 
@@ -357,5 +361,43 @@ extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const dou
         hipLaunchKernelGGL(k_transpose_lincomb<false>, grid, dim3(256), 0, b->stream, y, base, x[ipend], pend, g.nB,
                            g.nA, g.f_sB, g.f_sC, g.f_dA, g.f_dC, a);
     X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- RK stage inside the tile kernel
+// When the last direction's pencils take the tile kernel (xscan.hip, k_ytile_transeq), the whole component
+// is computed inside the stage's linear combination: x[ipend] (= rhs, holding the other directions'
+// contributions) + this component -> d; store != 0: x[ipend] = d; y = base + sum_i c[i] * (i == ipend ? d : x[i]).
+// kind 0: the advecting component (operators der1st, der1st_sym, der2nd; conv == u), kind 1: the other two
+// (der1st_sym, der1st, der2nd_sym), src/backend/omp/backend.f90:246-260.
+// Bit-identical to x3d_transeq_species(accumulate = 1) followed by x3d_lincomb.
+extern "C" int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                    const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym)
+{
+    if (!b || !der1st || !der1st_sym || !der2nd || !der2nd_sym || (dir != X3D_DIR_Y && dir != X3D_DIR_Z)) return 0;
+    return use_via_x() && x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd) &&
+           x3d_ytile_applicable(b, dir, der1st_sym, der1st, der2nd_sym);
+}
+
+extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const double *u, const double *conv, double nu,
+                                   const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                                   const x3d_tdsops *der2nd_sym, double *y, const double *base, int nterm,
+                                   const double *c, double *const *x, int ipend, int store)
+{
+    X3D_REQUIRE(b && u && conv && der1st && der1st_sym && der2nd && der2nd_sym && y && base && c && x,
+                "x3d_transeq_lincomb: null argument");
+    X3D_REQUIRE(nterm >= 1 && nterm <= 5 && ipend >= 0 && ipend < nterm, "x3d_transeq_lincomb: bad term count / index");
+    X3D_REQUIRE(kind == 0 || kind == 1, "x3d_transeq_lincomb: kind must be 0 or 1");
+    X3D_REQUIRE(x[ipend] != u && x[ipend] != conv && y != x[ipend] && base != x[ipend],
+                "x3d_transeq_lincomb: the pending term aliases an input");
+    X3D_REQUIRE(x3d_transeq_stage_ok(b, dir, der1st, der1st_sym, der2nd, der2nd_sym),
+                "x3d_transeq_lincomb: the tile kernel does not take these pencils (see x3d_transeq_stage_ok)");
+    bool done = false;
+    const x3d_tdsops *t1 = kind == 0 ? der1st : der1st_sym, *t2 = kind == 0 ? der1st_sym : der1st,
+                     *t3 = kind == 0 ? der2nd : der2nd_sym;
+    if (int rc = x3d_ytile_transeq_lincomb(b, dir, x[ipend], u, conv, nu, t1, t2, t3, y, base, nterm, c, x, ipend, store,
+                                           &done))
+        return rc;
+    X3D_REQUIRE(done, "x3d_transeq_lincomb: tile kernel refused");
     return 0;
 }

@@ -684,10 +684,23 @@ __global__ void __launch_bounds__(512)
 // the 8 of the transposed-copy route in viax.hip), all inside one 2 MB page per tile.
 // LDS: lane tables + 16 (n + 4) doubles of tile; for n = 512 this fits only when der1st and der1st_sym have
 // identical lane tables (periodic operators: they do), which the launcher checks.
-template <int Q, bool SAME, bool ACC, int FAST>
+// EPI: the component is the LAST contribution to rhs and the RK / AB stage follows at once: the store phase also
+// does the stage's linear combination (time_integrator.py, runge_kutta_fused), per point
+//     d = rhs + result;  [rhs = d;]  y = base + sum_k c[k] * (k == ipend ? d : x[k])
+// in the summation order of k_lincomb (backend.hip): bit-identical to the accumulating form followed by
+// x3d_lincomb, without re-reading d (and without writing it after the last stage).
+struct TileEpi {
+    double *y;
+    const double *base;
+    const double *x[5];
+    double c[5];
+    int n, ipend, store;
+};
+
+template <int Q, bool SAME, bool ACC, int FAST, bool EPI = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq(double *rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1, XOp t2, XOp t3,
-                    int share12, int ntx, int ntiles, long prow, long pplane, double nu)
+                    int share12, int ntx, int ntiles, long prow, long pplane, double nu, const TileEpi *epp)
 {
     extern __shared__ double lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
@@ -789,7 +802,7 @@ __global__ void __launch_bounds__(1024)
         for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l3, t3);
-        {
+        if constexpr (!EPI) {
             double *__restrict__ o = rhs + off;
             double2 old[NI];
             if (ACC) gload(old, o);  // in flight while the results go through the tile
@@ -802,6 +815,48 @@ __global__ void __launch_bounds__(1024)
                 double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                 if (ACC) { v.x += old[i].x; v.y += old[i].y; }
                 *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+            }
+        } else {
+            // the first two terms other than the pending one travel with `old` and `base` (all an RK3 stage has);
+            // further ones (RK4) are loaded in the loop
+            // the stage's description is read here, per tile, through a laundered pointer: as kernel arguments (or
+            // hoisted out of the tile loop) its 27 scalars stay live across the solves, and with the three
+            // operator descriptors the SGPR file overflows into VGPRs (330 spilled)
+            const TileEpi *pe = epp;
+            asm volatile("" : "+s"(pe) : "v"(T[0]));
+            const TileEpi epi = *pe;
+            double2 old[NI], bs[NI];
+            // (the addresses are tied to the last solve: issued any earlier the loads stay live across the solves)
+            int cce = cc;
+            asm volatile("" : "+v"(cce) : "v"(T[0]));
+            auto eload = [&](double2 (&v)[NI], const double *src) {
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cce);
+            };
+            eload(old, rhs + off);
+            eload(bs, epi.base + off);
+            double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+            for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const long at = off + (long)(cy + 128 * i) * prow + 2 * cce;
+                double2 d = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                d.x += old[i].x;
+                d.y += old[i].y;
+                if (epi.store) *reinterpret_cast<double2 *>(rhs + at) = d;
+                double2 v = bs[i];
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    if (k < epi.n) {
+                        double2 t = d;
+                        if (k != epi.ipend) t = *reinterpret_cast<const double2 *>(epi.x[k] + at);
+                        v.x = epi.c[k] * t.x + v.x;
+                        v.y = epi.c[k] * t.y + v.y;
+                    }
+                *reinterpret_cast<double2 *>(epi.y + at) = v;
             }
         }
         __syncthreads();  // the tile is free again
@@ -1057,8 +1112,8 @@ static bool use_ytile()
 {
     static int mode = -1;
     if (mode < 0) {
-        const char *e = getenv("X3D_NO_YTILE");
-        mode = (e && e[0] == '1') ? 0 : 1;
+        const char *e = getenv("X3D_NO_YTILE"), *f = getenv("X3D_NO_VIA_X"), *g = getenv("X3D_NO_XSCAN");
+        mode = ((e && e[0] == '1') || (f && f[0] == '1') || (g && g[0] == '1')) ? 0 : 1;  // (those two: two-sweep K1)
     }
     return mode == 1;
 }
@@ -1066,7 +1121,7 @@ static bool use_ytile()
 template <int Q, bool SAME, bool ACC, int FAST>
 static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                         const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds,
-                        int dir)
+                        int dir, const TileEpi *epi)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1078,9 +1133,26 @@ static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const doub
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
     const int blocks = ntiles > 256 ? 256 : ntiles;
+    if (epi) {
+        // one device slot is enough: copy and kernel are ordered on the backend's stream
+        X3D_HIP(hipMemcpyAsync(b->epi_dev, epi, sizeof(TileEpi), hipMemcpyHostToDevice, b->stream));
+        static bool at2 = false;
+        if (!at2) {
+            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq<Q, SAME, true, FAST, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            at2 = true;
+        }
+        hipLaunchKernelGGL((k_ytile_transeq<Q, SAME, true, FAST, true>), dim3(blocks), dim3(1024), lds, b->stream, rhs, u,
+                           conv, xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles,
+                           dir == X3D_DIR_Y ? (long)b->nxp : pxy, dir == X3D_DIR_Y ? pxy : (long)b->nxp, nu,
+                           (const TileEpi *)b->epi_dev);
+        X3D_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL((k_ytile_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(1024), lds, b->stream, rhs, u, conv,
                        xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles,
-                       dir == X3D_DIR_Y ? (long)b->nxp : pxy, dir == X3D_DIR_Y ? pxy : (long)b->nxp, nu);
+                       dir == X3D_DIR_Y ? (long)b->nxp : pxy, dir == X3D_DIR_Y ? pxy : (long)b->nxp, nu,
+                       (const TileEpi *)nullptr);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -1097,8 +1169,31 @@ bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x
     return sizeof(double) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4)) <= 160 * 1024;
 }
 
+static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc,
+                              const TileEpi *epi, bool *done);
+
 int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
+{
+    return ytile_transeq_impl(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, nullptr, done);
+}
+
+// the component + the stage's linear combination (TileEpi); rhs is x[ipend]
+int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
+                              const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
+                              bool *done)
+{
+    TileEpi e;
+    e.y = y; e.base = base; e.n = nterm; e.ipend = ipend; e.store = store;
+    for (int k = 0; k < 5; k++) { e.x[k] = k < nterm ? x[k] : x[0]; e.c[k] = k < nterm ? c[k] : 0.0; }
+    return ytile_transeq_impl(b, dir, rhs, u, conv, nu, t1, t2, t3, 1, &e, done);
+}
+
+static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc,
+                              const TileEpi *epi, bool *done)
 {
     *done = false;
     if (!use_ytile() || !x3d_xscan_fast_ok(t1, t2, t3)) return 0;
@@ -1117,10 +1212,10 @@ int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, con
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
     int rc;
 #define GO2(Q_, F_)                                                                                     \
-    (same ? (acc ? launch_ytile<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)       \
-                 : launch_ytile<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir))     \
-          : (acc ? launch_ytile<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)      \
-                 : launch_ytile<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir)))
+    (same ? (acc ? launch_ytile<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir, epi)       \
+                 : launch_ytile<Q_, true, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir, epi))     \
+          : (acc ? launch_ytile<Q_, false, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir, epi)      \
+                 : launch_ytile<Q_, false, false, F_>(b, rhs, u, conv, nu, t1, t2, t3, share12, lds, dir, epi)))
 #define GO(Q_) (narrow ? GO2(Q_, 2) : GO2(Q_, 1))
     rc = Q == 8 ? GO(8) : GO(4);
 #undef GO

@@ -166,10 +166,11 @@ class Solver:
         shares one device layout, so the y and z passes read u, v, w in place and
         accumulate straight into du, dv, dw.
 
-        defer: the caller (BaseCase.substep) hands the result straight to the fused RK stage; when the z
-        pencils run through the scan kernel, their accumulation into du, dv, dw is then left pending and
-        returned as {buffer address of d*: (pending block, direction)} for TimeIntegrator to fold into its
-        linear combination (one pass less over d* and the new velocity)."""
+        defer: the caller (BaseCase.substep) hands the result straight to the fused RK / AB stage; the z
+        contribution to du, dv, dw is then left pending and returned as {buffer address of d*: description}
+        for TimeIntegrator to fold into its linear combinations: ("tile", ...) = the component is computed
+        inside the stage's kernel (csrc/xscan.hip, k_ytile_transeq<EPI>), ("copies", block, dir) = its result
+        waits in pencil layout for the transposing stage kernel (csrc/viax.hip)."""
         b = self.backend
         du, dv, dw = rhs[:3]
         u, v, w = variables[:3]
@@ -180,13 +181,26 @@ class Solver:
         # take the tile kernel K3y, which is cheaper than transposed copies + the fused RK stage)
         pending = None
         if defer and os.environ.get("X3D_NO_DEFER") != "1" and not b._decomposed(DIR_Z):
-            al = b.allocator
-            pend = [al.get_block(DIR_X) for _ in range(3)]
-            if b.transeq_dir_defer(DIR_Z, pend, u, v, w, self.nu, self.zdirps):
-                pending = {r.data.data_ptr(): (pf, DIR_Z) for r, pf in zip((du, dv, dw), pend)}
+            if b.transeq_stage_ok(DIR_Z, self.zdirps):
+                if os.environ.get("X3D_STAGE_IN_TILE") != "1":
+                    # default: tile kernel (accumulating) + plain lincomb; the stage inside the tile kernel saves
+                    # one read of d* but runs its extra streams at the tile pattern's rate: 59.15 vs 59.4 ms per
+                    # step at 512^3 (same-box A/B) -- opt-in
+                    pending = None
+                else:
+                    # the z components are computed inside the stage's linear combinations; entries in the
+                    # integrator's variable order, w (the advecting component of z) last: its own update comes last
+                    pending = {du.data.data_ptr(): ("tile", DIR_Z, 1, u.ptr, w.ptr, self.nu, self.zdirps),
+                               dv.data.data_ptr(): ("tile", DIR_Z, 1, v.ptr, w.ptr, self.nu, self.zdirps),
+                               dw.data.data_ptr(): ("tile", DIR_Z, 0, w.ptr, w.ptr, self.nu, self.zdirps)}
             else:
-                for pf in pend:
-                    al.release_block(pf)
+                al = b.allocator
+                pend = [al.get_block(DIR_X) for _ in range(3)]
+                if b.transeq_dir_defer(DIR_Z, pend, u, v, w, self.nu, self.zdirps):
+                    pending = {r.data.data_ptr(): ("copies", pf, DIR_Z) for r, pf in zip((du, dv, dw), pend)}
+                else:
+                    for pf in pend:
+                        al.release_block(pf)
         if pending is None:
             b.transeq_dir(DIR_Z, du, dv, dw, u, v, w, self.nu, self.zdirps, accumulate=True)
         for f in rhs[:3]:

@@ -100,19 +100,30 @@ class TimeIntegrator:
         b = self.backend
         if pending:
             for k, f in enumerate(fields):
-                ent = pending.pop(f.data.data_ptr(), None)
-                if ent is not None:
-                    pf, direction = ent
+                ptr = f.data.data_ptr()
+                ent = pending.pop(ptr, None)
+                if ent is None:
+                    continue
+                if ent[0] == "tile":
+                    _, direction, kind, u_ptr, conv_ptr, nu, dirps = ent
+                    b.transeq_lincomb(direction, kind, u_ptr, conv_ptr, nu, dirps, y, base, coefs, fields, k, store)
+                else:
+                    _, pf, direction = ent
                     b.lincomb_pending(y, base, coefs, fields, k, pf, direction, store)
                     self.allocator.release_block(pf)
-                    return
+                return
         b.lincomb(y, base, coefs, fields)
 
     def _flush(self, pending):
         """complete the pending components no linear combination consumed"""
-        for ptr, (pf, direction) in list((pending or {}).items()):
-            self.backend.pending_flush(direction, ptr, pf)
-            self.allocator.release_block(pf)
+        for ptr, ent in list((pending or {}).items()):
+            if ent[0] == "tile":
+                _, direction, kind, u_ptr, conv_ptr, nu, dirps = ent
+                self.backend.transeq_component_acc(direction, kind, ptr, u_ptr, conv_ptr, nu, dirps)
+            else:
+                _, pf, direction = ent
+                self.backend.pending_flush(direction, ptr, pf)
+                self.allocator.release_block(pf)
         if pending:
             pending.clear()
 
