@@ -125,6 +125,16 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
         const int ch = t / ys, tt = t - ch * ys;
         return (((long)ch * gridDim.y + blockIdx.y) * ys + tt) * nxs + i0 + m;
     };
+    // MODE 2: the wave numbers of this thread's 8 spectral points, requested before anything else (their
+    // latency used to be exposed between the two transforms)
+    double rw8[8];
+    if (MODE == 2 && valid) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const double wv = sp.waves[((size_t)(it * 64 + r) * sp.ny + blockIdx.y) * nxs + i0 + m];
+            rw8[it] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
+        }
+    }
     // ---- cooperative load: NP * 16 contiguous bytes per row
 #pragma unroll
     for (int it = 0; it < 8; it++) {
@@ -170,8 +180,7 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
                 if (fy) { div_r = -div_r; div_c = -div_c; }
                 tr = div_r; tc = div_c;
                 div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
-                const double wv = sp.waves[((size_t)k * sp.ny + j) * nxs + i];
-                const double rw = wv < 1.e-16 ? 0.0 : -1.0 / wv;
+                const double rw = rw8[it];
                 div_r = div_r * rw; div_c = div_c * rw;
                 tr = div_r; tc = div_c;
                 div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;

@@ -710,7 +710,7 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
-int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // xscan.hip
 
 // fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
@@ -727,9 +727,9 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
                 "x3d_tds_solve_pair: outputs alias inputs");
     if (int rc = check_len(b, ta, dir, "tds_solve_pair")) return rc;
     if (int rc = check_len(b, tb, dir, "tds_solve_pair")) return rc;
-    if (dir == X3D_DIR_Y) {
+    if (dir != X3D_DIR_X) {
         bool done = false;
-        if (int rc = x3d_ytile_tds_pair(b, mode, out1, out2, in1, in2, ta, tb, &done)) return rc;
+        if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, &done)) return rc;
         if (done) return 0;
     }
     if (int rc = x3d_tds_solve_acc(b, out1, in1, ta, dir, 0, 1.0)) return rc;

@@ -1,4 +1,6 @@
-// K3t: y/z transport-equation components through the wave-per-pencil scan kernel (xscan.hip, K3s).
+// K3t: y/z transport-equation components through the wave-per-pencil scan kernel (xscan.hip, K3s) on
+// transposed copies -- the route for periodic 256 / 512-row pencils that the tile kernel K3y (xscan.hip,
+// k_ytile_transeq: no copies at all) does not take, e.g. nx not a multiple of 16.
 //
 // The lane-per-pencil two-sweep pair of tds.hip moves 11 field passes per component (3 intermediate arrays
 // written by the forward sweep and read back by the backward sweep).  The scan kernel does a component in one

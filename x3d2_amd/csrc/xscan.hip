@@ -1225,8 +1225,8 @@ static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double
     return 0;
 }
 
-// K3y pair launcher: see k_ytile_tds_pair; y direction only (the z form would be page-bound like X3D_ZTILE)
-int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+// K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq)
+int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done)
 {
     *done = false;
@@ -1237,14 +1237,16 @@ int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, con
     auto fast = [&](const x3d_tdsops *t) {
         return t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
     };
-    if (!fast(ta) || !fast(tb) || b->ny != 64 * Q || b->nx % 16 != 0) return 0;
+    if (!fast(ta) || !fast(tb) || (dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
+    if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return 0; }
     const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16, ntiles = ntx * b->nz;
+    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     const int blocks = ntiles > 256 ? 256 : ntiles;
-    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Y);
+    ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_)                                                                                          \
     do {                                                                                                        \
         static bool at = false;                                                                                 \
@@ -1254,7 +1256,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int mode, double *out1, double *out2, con
             at = true;                                                                                          \
         }                                                                                                       \
         hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, in1, \
-                           in2, xop_of(ta), xop_of(tb), ntx, ntiles, (long)b->nxp, pxy);                        \
+                           in2, xop_of(ta), xop_of(tb), ntx, ntiles, rstride, ostride);                        \
     } while (0)
 #define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else GON(Q_, 1); } while (0)
