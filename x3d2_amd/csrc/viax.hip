@@ -20,6 +20,9 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
                          int dirtag, bool *done);
 bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
 bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
+int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                       const x3d_tdsops *der2nd_sym, int acc, bool *done);
 int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                               const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
                               const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
@@ -159,8 +162,11 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
     const ViaGeom g = via_geom(b, dir);
     if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
     {
-        // K3y (xscan.hip): the same kernel fed through an LDS tile, no transposed copies
+        // K3y (xscan.hip): the same kernel fed through an LDS tile, no transposed copies; all three components in
+        // one launch when the operators allow
         bool ok = false;
+        if (int rc = x3d_ytile_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, acc, &ok)) return rc;
+        if (ok) { *done = true; return 0; }
         if (int rc = x3d_ytile_transeq(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, acc, &ok)) return rc;
         if (ok) {
             for (int c = 1; c < 3; c++) {

@@ -863,6 +863,125 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// ---------------------------------------------------------------- K3y, the three components of a direction at once
+// transeq_<dir> = three components that share the advecting velocity (src/backend/omp/backend.f90:145-184):
+// component 0 is (u0, conv = u0), components 1, 2 are (u1, u0), (u2, u0).  One workgroup does all three for
+// its tile, keeping its pencil's rows of u0 in registers: u0 is read once instead of three times (9 field
+// passes instead of 11).  Needs der1st == der1st_sym and der2nd == der2nd_sym as lane tables (periodic
+// operators), so that all components use the same two table sets (tD1 for du and d(u conv), tD2 for d2u).
+template <int Q, bool ACC, bool NARROW>
+__global__ void __launch_bounds__(1024)
+    k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
+                     const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
+                     int ntiles, long prow, long pplane, double nu)
+{
+    extern __shared__ double lt[];
+    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = tD1.TL[i];
+        lt[LN + i] = tD2.TL[i];
+    }
+    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    double *tile = lt + 2 * LN;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int first = lane * Q + 1;
+    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+    };
+    auto to_tile = [&](const double2 (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
+            tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
+        }
+    };
+    auto pick = [&](double (&b)[Q]) {
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) {
+            const double2 t2_ = src[m];
+            b[2 * m] = t2_.x;
+            b[2 * m + 1] = t2_.y;
+        }
+    };
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    __syncthreads();
+    double2 nxt[NI];  // the rows needed next (next component's field, or the next tile's u0), in flight during the solves
+    if ((int)blockIdx.x < ntiles) gload(nxt, u0 + tile_off(blockIdx.x));
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        double cb[Q];  // this pencil's rows of the advecting velocity
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            asm volatile("" : "+v"(lane));
+            double wu[Q + 8], wp[Q + 8];
+            {
+                double b[Q];
+                to_tile(nxt);
+                __syncthreads();
+                pick(b);
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) cb[q] = b[q];
+                }
+                window_from_body<Q>(wu, b, lane);
+                window_from_body<Q>(wp, cb, lane);
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
+            }
+            __syncthreads();  // every wave has its rows: the tile may be overwritten by the results
+            {
+                const int tn = tl + gridDim.x;
+                const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
+                if (c < 2 || tn < ntiles) gload(nxt, nsrc);
+            }
+            auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
+                double a, b;
+                scan_solve<Q, true, NARROW>(w, T, a, b, l, t, lane, first);
+                const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const double st = l[LT_ST(q) * 64 + lane];
+                    double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                    if (q == 0) x = (lane == 0) ? s_ * st : x;
+                    if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                    T[q] = x;
+                }
+            };
+            double r[Q], T[Q];
+            solve_subs(wp, T, l1, tD1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = T[q];
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            solve_subs(wu, T, l1, tD1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            solve_subs(wu, T, l3, tD2);
+            {
+                double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+                double2 old[NI];
+                if (ACC) gload(old, o);
+                double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+#pragma unroll
+                for (int m = 0; m < Q / 2; m++)
+                    dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                    if (ACC) { v.x += old[i].x; v.y += old[i].y; }
+                    *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+                }
+            }
+            __syncthreads();  // the tile is free again
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K3y for tds_solve pairs (pressure correction)
 // The y operators of divergence_v2c / gradient_c2v come in pairs that share an output or an input
 // (src/vector_calculus.f90:142-332 as sequenced by pressure_correction_fused):
@@ -1265,6 +1384,53 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
 #undef GON
 #undef GO
     X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+// K3y, three components in one launch (k_ytile_transeq3); f[0] is the advecting component
+int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_TILE3"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
+    if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
+    const int Q = der1st->tab.Q;
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    if (lds > 160 * 1024) return 0;
+    const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
+    const long pxy = (long)b->nxp * b->nyp;
+    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const int blocks = ntiles > 256 ? 256 : ntiles;
+    const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    // (profiler: three components = three "forward" launches of this direction, in one kernel)
+#define GO(Q_, A_, N_)                                                                                          \
+    do {                                                                                                        \
+        static bool at = false;                                                                                 \
+        if (!at) {                                                                                              \
+            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq3<Q_, A_, N_>,                             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            at = true;                                                                                          \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, ntiles, rstride, ostride, nu); \
+    } while (0)
+#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+        if (Q == 8) GOA(8); else GOA(4);
+    }
+#undef GOA
+#undef GON
+#undef GO
+    X3D_HIP(hipGetLastError());
+    if (b->prof) {  // count the launch as three components (bench.py divides the direction's time by the count)
+        for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
+    }
     *done = true;
     return 0;
 }
