@@ -584,6 +584,9 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // viax.hip
 int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);  // xscan.hip
+int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
+                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // xscan.hip
 static bool use_onchip_transeq()
 {
     static int mode = -1;
@@ -914,6 +917,12 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
         X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq: outputs alias inputs");
     }
     const int a = accumulate;
+    if (dir == X3D_DIR_X) {
+        // the three components in one launch of the scan kernel (xscan.hip), the advecting velocity read once
+        bool done = false;
+        if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;
+        if (done) return 0;
+    }
     if (dir != X3D_DIR_X && !use_onchip_transeq() && !use_fused_kernels()) {
         // K3t (viax.hip): periodic pencils of 256 / 512 rows go through the single-pass scan kernel
         bool done = false;

@@ -675,6 +675,97 @@ __global__ void __launch_bounds__(512)
     }
 }
 
+// ---------------------------------------------------------------- transeq_x: the three components at once
+// Two pencils per wave as above; the pair's rows of the advecting velocity u0 stay in registers for the three
+// components (u0, u0), (u1, u0), (u2, u0): 6 field passes instead of 8.  der1st == der1st_sym and
+// der2nd == der2nd_sym as lane tables (periodic operators): two table sets in LDS.
+template <int Q, bool ACC, bool NARROW>
+__global__ void __launch_bounds__(512)
+    k_xscan_transeq2x3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
+                       const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2,
+                       XOp tD1, XOp tD2, int np, long pitch, double nu)
+{
+    extern __shared__ double lt[];  // [2][LT_N(Q)][64]
+    constexpr int LN = LT_N(Q) * 64;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = tD1.TL[i];
+        lt[LN + i] = tD2.TL[i];
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int first = lane * Q + 1;
+    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    double na[Q], nb[Q];  // the rows needed next (next component's field, or the next pair's u0)
+    const int pstart = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
+    if (pstart < np) {
+        load_body<Q>(na, u0 + (long)pstart * pitch, lane);
+        load_body<Q>(nb, u0 + (long)(pstart + 1) * pitch, lane);
+    }
+    for (int p = pstart; p < np; p += 2 * nwaves) {
+        V2 cb[Q];
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loops
+            V2 wu[Q + 8], wp[Q + 8];
+            {
+                V2 b2[Q];
+#pragma unroll
+                for (int q = 0; q < Q; q++) b2[q] = V2{na[q], nb[q]};
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) cb[q] = b2[q];
+                }
+                window_from_body<Q, V2>(wu, b2, lane);
+                window_from_body<Q, V2>(wp, cb, lane);
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
+                const int pn = p + 2 * nwaves;
+                const double *nsrc = c == 0 ? u1 + (long)p * pitch : (c == 1 ? u2 + (long)p * pitch
+                                                                             : u0 + (long)(pn < np ? pn : p) * pitch);
+                if (c < 2 || pn < np) {
+                    load_body<Q>(na, nsrc, lane);
+                    load_body<Q>(nb, nsrc + pitch, lane);
+                }
+            }
+            auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const double *__restrict__ l, const XOp &t) {
+                V2 a, b;
+                scan_solve<Q, true, NARROW, V2>(w, T, a, b, l, t, lane, first);
+                const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const double st = l[LT_ST(q) * 64 + lane];
+                    V2 x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                    if (q == 0) x = (lane == 0) ? s_ * st : x;
+                    if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                    T[q] = x;
+                }
+            };
+            V2 r[Q], T[Q];
+            solve_subs(wp, T, l1, tD1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = T[q];
+            asm volatile("" : "+v"(lane) : "v"(r[0].a));
+            solve_subs(wu, T, l1, tD1);
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+            asm volatile("" : "+v"(lane) : "v"(r[0].a));
+            solve_subs(wu, T, l3, tD2);
+            double ra[Q], rb[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const V2 v = r[q] + nu * T[q];
+                ra[q] = v.a;
+                rb[q] = v.b;
+            }
+            double *oa = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + (long)p * pitch, *ob = oa + pitch;
+            if constexpr (Q == 8) { store_rows_q8<ACC>(oa, lane, ra, 1.0); store_rows_q8<ACC>(ob, lane, rb, 1.0); }
+            else { store_rows_q4<ACC>(oa, lane, ra, 1.0); store_rows_q4<ACC>(ob, lane, rb, 1.0); }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K3y: y pencils without transposed copies
 // One workgroup = 16 waves = the 16 x-adjacent y pencils of one z plane.  The tile [16 x][n y] goes through
 // LDS: the workgroup reads it from the Cartesian block in 128-byte row segments (16 doubles of x per y),
@@ -1430,6 +1521,53 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     X3D_HIP(hipGetLastError());
     if (b->prof) {  // count the launch as three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
+    }
+    *done = true;
+    return 0;
+}
+
+// transeq_x in one launch (k_xscan_transeq2x3); f[0] is the advecting component
+int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
+                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) {
+        const char *names[4] = {"X3D_NO_TILE3", "X3D_XSCAN_P1", "X3D_NO_XSCAN", "X3D_XDIR_GENERIC"};
+        on = 1;
+        for (const char *nm : names) { const char *e = getenv(nm); if (e && e[0] == '1') on = 0; }
+    }
+    if (!on || !x3d_xscan_fast_ok(der1st, der1st_sym, der2nd) || !x3d_xscan_fast_ok(der1st_sym, der1st, der2nd_sym)) return 0;
+    if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
+    const int Q = der1st->tab.Q, np = b->ny * b->nz;
+    if (b->nx != 64 * Q || np % 2) return 0;
+    const size_t lds = sizeof(double) * 2 * LT_N(Q) * 64;
+    const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
+    const int blocks = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
+#define GO(Q_, A_, N_)                                                                                          \
+    do {                                                                                                        \
+        static bool at = false;                                                                                 \
+        if (!at) {                                                                                              \
+            X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2x3<Q_, A_, N_>,                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+            at = true;                                                                                          \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), np, (long)b->nxp, nu);             \
+    } while (0)
+#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
+        if (Q == 8) GOA(8); else GOA(4);
+    }
+#undef GOA
+#undef GON
+#undef GO
+    X3D_HIP(hipGetLastError());
+    if (b->prof) {  // three components (bench.py divides the direction's time by the count)
+        for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X); }
     }
     *done = true;
     return 0;
