@@ -135,6 +135,8 @@ def main():
     backend.prof_enable(True)
     backend.prof_reset()
     backend.rk_fused_passes = 0
+    backend.rk_fused_launches = 0
+    tq3_before = int(backend.lib.x3d_backend_counter(backend.h, 0))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -167,16 +169,19 @@ def main():
         nb, mb = backend.prof_get("transeq_bwd", d)
         if nf:
             per_dir[name] = {"ms_per_component": (mf + mb) / nf,
-                             "GB/s": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
-    bytes_per_launch = (64.0 / 3.0) * dof_local  # average over the three components
-    # the last direction's accumulation is folded into the RK stage's linear combination (csrc/viax.hip,
-    # k_transpose_lincomb, booked as transeq_bwd of direction 0): those launches also move the stage's own
-    # algorithmic bytes (base + older derivatives read, new velocity written)
-    n_fused = n_b - sum(backend.prof_get("transeq_bwd", d)[0] for d in (1, 2, 3))
+                             "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9,
+                             "GB/s_at_48B_per_3_components": 16.0 * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
+    # algorithmic bytes: three components issued one by one = 64 B/DoF (the advecting velocity is
+    # an input of each: 2 + 3 + 3 field passes); the three-in-one kernels read it once -> the fused floor of
+    # 48 B/DoF (6 passes) is what such a launch has to move, so it is priced at that
+    n_tq3 = int(backend.lib.x3d_backend_counter(backend.h, 0)) - tq3_before
+    comps3 = min(3 * n_tq3, n_f)
+    transeq_bytes = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0) * dof_local / max(n_f, 1)
+    # launches whose accumulation is folded into the RK stage also move the stage's own algorithmic bytes
     rk_bytes = 8.0 * dof_local * getattr(backend, "rk_fused_passes", 0)
+    n_fused = getattr(backend, "rk_fused_launches", 0)
     avg_ms = (ms_f + ms_b) / max(n_f, 1)
-    transeq_bytes = bytes_per_launch
-    bytes_per_launch = transeq_bytes + rk_bytes / max(n_f, 1)  # per component, RK-stage share included
+    bytes_per_launch = transeq_bytes + rk_bytes / max(n_f, 1)  # per component
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -189,9 +194,9 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm",
-                "kernel": "transeq component: k_xscan_transeq (x) / k_transpose64 + k_xscan_transeq + accumulating "
-                          "k_transpose64 (y, z); the last direction's accumulation is fused with the RK stage "
-                          "(k_transpose_lincomb), whose algorithmic bytes are then included",
+                "kernel": "transeq component (one third of a k_xscan_transeq2x3 (x) / k_ytile_transeq3 (y, z) launch at "
+                          "512^3; launches that also do the RK stage include its algorithmic bytes)",
+                "three_in_one_launches": n_tq3,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "transeq_bytes_per_launch": transeq_bytes, "rk_stage_fused_launches": n_fused,

@@ -55,6 +55,8 @@ int x3d_abi_version(void);
  * dims_vert: local vertex counts (mesh%get_dims(VERT)); stream: hipStream_t or NULL. */
 int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream);
 int x3d_backend_destroy(x3d_backend *b);
+/* diagnostics: which = 0 -> launches of the three-components-in-one transeq kernels since creation */
+long x3d_backend_counter(const x3d_backend *b, int which);
 int x3d_backend_set_stream(x3d_backend *b, void *stream);
 size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
 int x3d_padded_dims(const x3d_backend *b, int dims_out[3]); /* get_padded_dims(DIR_C) */

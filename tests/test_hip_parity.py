@@ -413,7 +413,7 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
 
 @pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_ONCHIP_TRANSEQ", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN",
                                  "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_NO_ZTILE", "X3D_XSCAN_P1",
-                                 "X3D_NO_TDS_PAIR"])
+                                 "X3D_NO_TDS_PAIR", "X3D_NO_TILE3"])
 def test_optional_kernel_families_pass_the_same_parity_tests(env):
     """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
     block-recompute sweeps, generic x-direction kernels, LDS-tiled x kernels instead of

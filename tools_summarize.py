@@ -35,7 +35,8 @@ with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as f:
 heads = ("k_transeq_fwd", "k_xtranseq_fwd", "k_xscan_transeq", "k_ytile_transeq", "k_transeq_onchip")
 # + the transposes of the y / z components that run through the scan kernel (viax.hip)
 tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_transpose" in k)
-n_comp = sum(n for k, n, fe, wr in rows if any(h in k for h in heads))
+# (k_xscan_transeq2x3 / k_ytile_transeq3: three components per launch)
+n_comp = sum(n * (3 if ("transeq2x3" in k or "transeq3" in k) else 1) for k, n, fe, wr in rows if any(h in k for h in heads))
 comp = tot_bytes / n_comp if n_comp else 0.0
 calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
 json.dump({"n": 512, "round": rnd, "transeq_component_bytes_per_launch": comp,

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "x3d_vecmult": (I, [VP, VP, VP]),
     "x3d_field_scale": (I, [VP, VP, D]),
     "x3d_field_shift": (I, [VP, VP, D]),
+    "x3d_backend_counter": (ctypes.c_long, [VP, I]),
     "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
     "x3d_transeq_defer": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, c_int_p]),
     "x3d_pending_flush": (I, [VP, I, VP, VP]),

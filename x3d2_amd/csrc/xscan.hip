@@ -1519,6 +1519,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 #undef GON
 #undef GO
     X3D_HIP(hipGetLastError());
+    b->n_tq3++;
     if (b->prof) {  // count the launch as three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
     }
@@ -1566,6 +1567,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 #undef GON
 #undef GO
     X3D_HIP(hipGetLastError());
+    b->n_tq3++;
     if (b->prof) {  // three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X); }
     }
