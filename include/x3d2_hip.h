@@ -94,6 +94,11 @@ int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tds
  * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
 int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+/* fusion extension: y = base + sum_i c[i]*x[i] (x3d_lincomb: the RK / AB stage) followed by du = tds_solve(y)
+ * (the first x operators of divergence_v2c): one kernel for periodic 256 / 512-point x pencils, y is not read
+ * back; otherwise the two calls one after the other.  y may be base. */
+int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
+                          int nterm, const double *c, const double *const *x);
 
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):

@@ -413,7 +413,7 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
 
 @pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_ONCHIP_TRANSEQ", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN",
                                  "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_NO_ZTILE", "X3D_XSCAN_P1",
-                                 "X3D_NO_TDS_PAIR", "X3D_NO_TILE3"])
+                                 "X3D_NO_TDS_PAIR", "X3D_NO_TILE3", "X3D_NO_TDS_LINCOMB"])
 def test_optional_kernel_families_pass_the_same_parity_tests(env):
     """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
     block-recompute sweeps, generic x-direction kernels, LDS-tiled x kernels instead of
@@ -555,6 +555,19 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
         assert relerr(b.get_field_data(out_h), 0.5 * ref) < TOL, op + " (accumulate)"
         for f in (src_h, out_h):
             al.release_block(f)
+    # the RK stage's linear combination as the prologue of an x operator (x3d_tds_solve_lincomb): same bits as
+    # lincomb followed by tds_solve
+    y1, y2, d1, d2 = (al.get_block(DIR_X, VERT) for _ in range(4))
+    coefs = [0.3, -1.7, 0.01]
+    b.lincomb(y1, s.u, coefs, [s.v, s.w, s.u])
+    b.tds_apply(d1, y1, s.xdirps.stagder_v2p, DIR_X)
+    b.tds_lincomb(d2, s.xdirps.stagder_v2p, DIR_X, y2, s.u, coefs, [s.v, s.w, s.u])
+    for f in (d1, d2):
+        f.set_data_loc(move_data_loc(VERT, 1, 1))
+    assert np.array_equal(b.get_field_data(y1), b.get_field_data(y2))
+    assert np.array_equal(b.get_field_data(d1), b.get_field_data(d2))
+    for f in (y1, y2, d1, d2):
+        al.release_block(f)
     # transeq along x only, then the whole fused right-hand side (x writes, y and z accumulate)
     rhs_h = [al.get_block(DIR_X) for _ in range(3)]
     rhs_o = [o.backend.get_block(orc.DIR_X) for _ in range(3)]

@@ -278,6 +278,18 @@ class HipBackend:
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
         self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
 
+    def tds_lincomb(self, du, tdsops, direction, y, base, coeffs, xs):
+        """y = base + sum c_i x_i (lincomb) and du = tds_solve(y) in one kernel where the pencils allow
+        (csrc/xscan.hip, k_xscan_tds_lin: y is not read back)"""
+        if self._decomposed(direction):
+            self.lincomb(y, base, coeffs, xs)
+            self.tds_apply(du, y, tdsops, direction)
+            return
+        n = len(xs)
+        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        p = (VP * n)(*[x.ptr for x in xs])
+        _lib.check(self.lib.x3d_tds_solve_lincomb(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p))
+
     def tds_pair(self, mode, out1, out2, in1, in2, t_a, t_b, direction):
         """two tds_solve's that share an output (mode 0: out1 = A(in1) + B(in2)) or an input
         (mode 1: out1 = A(in1), out2 = B(in1)): one kernel where the pencils allow (csrc/xscan.hip)"""

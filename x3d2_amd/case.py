@@ -1,6 +1,7 @@
 """Flow cases: mirror of base_case_t%run (/root/reference/src/case/base_case.f90:181-353),
 the TGV case (src/case/tgv.f90) and the monitoring series
 (src/postprocess/monitoring.f90:46-90)."""
+import os
 import time
 
 import numpy as np
@@ -70,19 +71,30 @@ class BaseCase:
         curr = [s.u, s.v, s.w] + list(s.species)  # base_case.f90:236-241
         self.define_BC()
         deriv = [al.get_block(DIR_X) for _ in range(s.nvars)]
+        # nothing reads the new velocity between the stage and the pressure correction when the case has no
+        # BC hook: its update may then be formed inside the pressure correction's first kernels
+        defer_upd = (s.fused and type(self).apply_BC is BaseCase.apply_BC and os.environ.get("X3D_NO_DEFER") != "1"
+                     and s.time_integrator.sname.upper().startswith("RK"))
         if s.fused and type(self).forcings is BaseCase.forcings:
             # nothing touches the derivatives between transeq and the RK / AB stage: the last accumulation of
             # transeq may be folded into the stage's linear combination (Solver.transeq_fused)
             pending = s.transeq(deriv, curr, defer=True)
-            s.time_integrator.step(curr, deriv, s.dt, pending=pending)
+            s.time_integrator.step(curr, deriv, s.dt, pending=pending, defer_update=defer_upd)
         else:
             s.transeq(deriv, curr)
             self.forcings(deriv[0], deriv[1], deriv[2], it)
-            s.time_integrator.step(curr, deriv, s.dt)
-        for f in deriv:
-            al.release_block(f)
+            if s.fused:
+                s.time_integrator.step(curr, deriv, s.dt, defer_update=defer_upd)
+            else:
+                s.time_integrator.step(curr, deriv, s.dt)
+        if not defer_upd:
+            for f in deriv:
+                al.release_block(f)
+            deriv = []
         self.apply_BC(s.u, s.v, s.w)
         s.pressure_correction(s.u, s.v, s.w)
+        for f in deriv:  # (kept until the deferred updates that read them were done)
+            al.release_block(f)
 
     def step(self, it):
         for _ in range(self.solver.time_integrator.nstage):

@@ -739,6 +739,31 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
     return mode == 0 ? x3d_tds_solve_acc(b, out1, in2, tb, dir, 1, 1.0) : x3d_tds_solve_acc(b, out2, in1, tb, dir, 0, 1.0);
 }
 
+int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
+                          const double *c, const double *const *x, bool *done);  // xscan.hip
+extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
+                           const double *const *x);
+
+// fusion extension: y = base + sum_i c[i] x[i] (x3d_lincomb) followed by du = tds_solve(y), in one kernel for
+// periodic 256 / 512-point x pencils (y is not read back); otherwise the two calls one after the other
+extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
+                                     const double *base, int nterm, const double *c, const double *const *x)
+{
+    X3D_REQUIRE(b && du && t && y && base && c && x, "x3d_tds_solve_lincomb: null argument");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve_lincomb: bad dir %d", dir);
+    X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_tds_solve_lincomb: nterm must be 1..5");
+    X3D_REQUIRE(du != y && du != base, "x3d_tds_solve_lincomb: du aliases an input");
+    for (int k = 0; k < nterm; k++) X3D_REQUIRE(du != x[k], "x3d_tds_solve_lincomb: du aliases an input");
+    if (int rc = check_len(b, t, dir, "tds_solve_lincomb")) return rc;
+    if (dir == X3D_DIR_X) {
+        bool done = false;
+        if (int rc = x3d_xscan_tds_lincomb(b, du, t, y, base, nterm, c, x, &done)) return rc;
+        if (done) return 0;
+    }
+    if (int rc = x3d_lincomb(b, y, base, nterm, c, x)) return rc;
+    return x3d_tds_solve_acc(b, du, y, t, dir, 0, 1.0);
+}
+
 extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
     return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);

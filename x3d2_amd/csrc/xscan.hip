@@ -450,6 +450,61 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
     }
 }
 
+// ---------------------------------------------------------------- tds_solve of a field that is still to be formed
+// The first x operators of the pressure correction act on the velocity the RK / AB stage has just produced
+// (y = base + sum c_k x_k, src/time_integrator.f90:166-282 -> divergence_v2c, src/vector_calculus.f90:160-175).
+// Here the stage's linear combination is the kernel's prologue: y is formed in registers (summation order of
+// k_lincomb, bit-identical), stored, and solved at once -- y is not read back (one field pass less per variable).
+struct LinRows {
+    double *y;
+    const double *base;
+    const double *x[5];
+    double c[5];
+    int n;
+};
+
+template <int Q, bool NARROW>
+__global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
+{
+    extern __shared__ double lt[];  // [LT_N(Q)][64]
+    for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int first = lane * Q + 1;
+    for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
+        const long ro = (long)p * pitch;
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
+        double b[Q];
+        load_body<Q>(b, lr.base + ro, lane);
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (k < lr.n) {
+                double xk[Q];
+                load_body<Q>(xk, lr.x[k] + ro, lane);
+#pragma unroll
+                for (int q = 0; q < Q; q++) b[q] = lr.c[k] * xk[q] + b[q];
+            }
+        if constexpr (Q == 8) store_rows_q8<false>(lr.y + ro, lane, b, 1.0);
+        else store_rows_q4<false>(lr.y + ro, lane, b, 1.0);
+        double w[Q + 8], X[Q], du1, xn;
+        window_from_body<Q>(w, b, lane);
+        scan_solve<Q, true, NARROW>(w, X, du1, xn, lt, t, lane, first);
+        const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+        double r[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const double st = lt[LT_ST(q) * 64 + lane];
+            r[q] = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) * st;
+            if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
+            if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+        }
+        if constexpr (Q == 8) store_rows_q8<false>(du + ro, lane, r, 1.0);
+        else store_rows_q4<false>(du + ro, lane, r, 1.0);
+    }
+}
+
 // ---------------------------------------------------------------- transeq component
 template <int Q, bool SAME, bool ACC, int FAST>
 __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
@@ -1571,6 +1626,38 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     if (b->prof) {  // three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X); }
     }
+    *done = true;
+    return 0;
+}
+
+// du = tdsops(y) with y = base + sum c_k x_k formed (and stored) by the same kernel; x direction
+int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
+                          const double *c, const double *const *x, bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) {
+        const char *names[3] = {"X3D_NO_TDS_LINCOMB", "X3D_NO_XSCAN", "X3D_XDIR_GENERIC"};
+        on = 1;
+        for (const char *nm : names) { const char *e = getenv(nm); if (e && e[0] == '1') on = 0; }
+    }
+    if (!on || !xscan_ok(t)) return 0;
+    const int Q = t->tab.Q;
+    if (!(t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds && b->nx == 64 * Q)) return 0;
+    const int np = b->ny * b->nz;
+    const size_t lds = sizeof(double) * LT_N(Q) * 64;
+    int blocks = (np + 7) / 8;
+    blocks = blocks > 768 ? 768 : blocks;
+    LinRows lr;
+    lr.y = y; lr.base = base; lr.n = nterm;
+    for (int k = 0; k < 5; k++) { lr.x[k] = k < nterm ? x[k] : x[0]; lr.c[k] = k < nterm ? c[k] : 0.0; }
+    const bool narrow = stencil_narrow(t);
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
+#define GO(Q_, N_) hipLaunchKernelGGL((k_xscan_tds_lin<Q_, N_>), dim3(blocks), dim3(512), lds, b->stream, du, lr, xop_of(t), np, (long)b->nxp)
+    if (Q == 8) { if (narrow) GO(8, true); else GO(8, false); }
+    else { if (narrow) GO(4, true); else GO(4, false); }
+#undef GO
+    X3D_HIP(hipGetLastError());
     *done = true;
     return 0;
 }

@@ -217,9 +217,15 @@ class Solver:
         x, y, z = self.xdirps, self.ydirps, self.zdirps
         t1, t2, t3, a1, a2 = (al.get_block(DIR_X) for _ in range(5))
         # divergence_v2c, src/vector_calculus.f90:142-246
-        b.tds_apply(t1, u, x.stagder_v2p, DIR_X)
-        b.tds_apply(t2, v, x.interpl_v2p, DIR_X)
-        b.tds_apply(t3, w, x.interpl_v2p, DIR_X)
+        # (a velocity update the time integrator left pending is formed by the operator's own kernel)
+        upd = self.time_integrator.pending_update
+        for out, fld, op in ((t1, u, x.stagder_v2p), (t2, v, x.interpl_v2p), (t3, w, x.interpl_v2p)):
+            spec = upd.pop(fld.data.data_ptr(), None)
+            if spec is None:
+                b.tds_apply(out, fld, op, DIR_X)
+            else:
+                b.tds_lincomb(out, op, DIR_X, *spec)
+        self.time_integrator.flush_updates()
         b.tds_pair(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p, DIR_Y)   # a1 = interpl(t1) + stagder(t2)
         b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
         div = t1

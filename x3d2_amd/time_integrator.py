@@ -19,6 +19,7 @@ class TimeIntegrator:
 
     def __init__(self, backend, allocator, method, nvars=3, fused=False):
         self.backend, self.allocator, self.sname = backend, allocator, method
+        self.defer_update, self.pending_update = False, {}
         self.fused = fused
         self.gdt = 0.0
         try:
@@ -94,9 +95,12 @@ class TimeIntegrator:
     def _swap(a, b):
         a.data, b.data = b.data, a.data
 
-    def _lincomb(self, y, base, coefs, fields, pending, store):
+    def _lincomb(self, y, base, coefs, fields, pending, store, var=None):
         """lincomb; a term whose transeq component is still pending (Solver.transeq_fused(defer=True)) is
-        completed inside the same kernel"""
+        completed inside the same kernel.  With defer_update (set by step(..., defer_update=True)) the update
+        of the first three variables is not executed but left in self.pending_update for the pressure
+        correction, whose first x operators form the new velocity in their own kernel
+        (Solver.pressure_correction_fused, csrc/xscan.hip k_xscan_tds_lin)."""
         b = self.backend
         if pending:
             for k, f in enumerate(fields):
@@ -112,7 +116,16 @@ class TimeIntegrator:
                     b.lincomb_pending(y, base, coefs, fields, k, pf, direction, store)
                     self.allocator.release_block(pf)
                 return
+        if self.defer_update and var is not None and var < 3:
+            self.pending_update[y.data.data_ptr()] = (y, base, list(coefs), list(fields))
+            return
         b.lincomb(y, base, coefs, fields)
+
+    def flush_updates(self):
+        """execute the deferred updates nobody consumed"""
+        for y, base, coefs, fields in list(self.pending_update.values()):
+            self.backend.lincomb(y, base, coefs, fields)
+        self.pending_update.clear()
 
     def _flush(self, pending):
         """complete the pending components no linear combination consumed"""
@@ -127,8 +140,9 @@ class TimeIntegrator:
         if pending:
             pending.clear()
 
-    def runge_kutta_fused(self, curr, deriv, dt, pending=None):
+    def runge_kutta_fused(self, curr, deriv, dt, pending=None, defer_update=False):
         b, ns = self.backend, self.nstage
+        self.defer_update = bool(defer_update)
         a, bb = self.RK_A[ns], self.RK_B[ns]
         self.gdt = bb[self.istage - 1] * dt
         if self.istage == ns:
@@ -137,7 +151,7 @@ class TimeIntegrator:
                 terms.append((bb[ns - 1] * dt, deriv[i]))
                 base = self.olds[i][0] if ns > 1 else curr[i]
                 # the derivative of the last stage is not needed afterwards: no store
-                self._lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms], pending, False)
+                self._lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms], pending, False, var=i)
             self._flush(pending)
             self.istage = 1
         else:
@@ -150,14 +164,15 @@ class TimeIntegrator:
                          if a[st - 1][j - 1] != 0.0]
                 if terms:
                     self._lincomb(curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms], pending,
-                                  True)
+                                  True, var=i)
                 else:
                     b.veccopy(curr[i], self.olds[i][0])
             self._flush(pending)
             self.istage += 1
 
-    def adams_bashforth_fused(self, curr, deriv, dt, pending=None):
+    def adams_bashforth_fused(self, curr, deriv, dt, pending=None, defer_update=False):
         b = self.backend
+        self.defer_update = False  # (the AB update rotates its history right after the combination)
         self._flush(pending)
         self.gdt = dt
         nstep = min(self.istep, self.nstep)
