@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
         }
-        __syncthreads();  // every wave has its rows: the tile may be overwritten by the results
+        // (no barrier here: until the store phase a wave only rewrites its own pencil's region of the tile)
 #ifdef YT_PREF
         {
             const int tn = tl + gridDim.x;
@@ -1078,7 +1078,7 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
             }
-            __syncthreads();  // every wave has its rows: the tile may be overwritten by the results
+            // (no barrier here: until the store phase a wave only rewrites its own pencil's region of the tile)
             {
                 const int tn = tl + gridDim.x;
                 const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
