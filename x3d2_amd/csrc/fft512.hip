@@ -103,6 +103,7 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
 struct Spec000 {
     const double *waves, *ax, *bx, *ay, *by, *az, *bz;
     int nx, ny, nz;
+    const double *rwT;  // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), z fastest; null: use waves
 };
 
 // MODE 0: forward, MODE 1: backward, MODE 2: forward + process_spectral_000 + backward (z axis only)
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     // MODE 2: the wave numbers of this thread's 8 spectral points, requested before anything else (their
     // latency used to be exposed between the two transforms)
     double rw8[8];
-    if (MODE == 2 && valid) {
+    if (MODE == 2 && valid && !sp.rwT) {
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const double wv = sp.waves[((size_t)(it * 64 + r) * sp.ny + blockIdx.y) * nxs + i0 + m];
@@ -150,7 +151,46 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     __syncthreads();
     if (MODE == 1) fft512_wave<1>(a, pen, tws, l);
     else fft512_wave<-1>(a, pen, tws, l);
-    if (MODE == 2) {
+    if (MODE == 2 && sp.rwT) {
+        // spectral division in the transform's own register layout (lane l holds points l + 64 k of mode
+        // i0 + w): the reciprocal wave numbers come from a z-fastest copy, no trip through the tile, no barrier
+        // between the two transforms (src/backend/omp/kernels/spectral_processing.f90:36-99, same operation order)
+        const int i = i0 + w, j = blockIdx.y;
+        if (i < nxs) {
+            const double ayj = sp.ay[j], byj = sp.by[j], axi = sp.ax[i], bxi = sp.bx[i];
+            const double rn = 1.0 / sp.nx / sp.ny / sp.nz;
+            const bool fy = (j + 1) > sp.ny / 2 + 1;
+            const double *__restrict__ rwp = sp.rwT + ((size_t)j * nxs + i) * 512;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = l + 64 * kk;
+                double div_r = a[kk].x * rn, div_c = a[kk].y * rn;
+                const double azk = sp.az[k], bzk = sp.bz[k];
+                const bool fz = (k + 1) > sp.nz / 2 + 1;
+                double tr, tc;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+                const double rw = rwp[k];
+                div_r = div_r * rw; div_c = div_c * rw;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+                a[kk] = make_double2(div_r, div_c);
+            }
+        }
+        fft512_wave<1>(a, pen, tws, l);
+    } else if (MODE == 2) {
         // natural order back to the tile, spectral division in the row-cooperative layout (waves is
         // read as 64 contiguous bytes per row), then the backward transform
 #pragma unroll
@@ -250,6 +290,8 @@ int x3d_fft512_init()
 // axis: 1 = y (ny must be 512), 2 = z (nz must be 512); mode 0 fwd, 1 bwd, 2 fused z pass
 int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
                      const double *ab, int nx, double2 *xbuf, int ys);
+static const double *g_rwT = nullptr;  // set by x3d_fft512_set_rwT for the next fused z pass (poisson.hip)
+void x3d_fft512_set_rwT(const double *rwT) { g_rwT = rwT; }
 
 int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
                    const double *ab, int nx)
@@ -270,7 +312,7 @@ int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int ax
     Spec000 sp{};
     if (mode == 2) {
         const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
-        sp = Spec000{waves, ax, bx, ay, by, az, bz, nx, ny, nz};
+        sp = Spec000{waves, ax, bx, ay, by, az, bz, nx, ny, nz, g_rwT};
     }
     static int wide = -1;  // rows of 256 B (16 modes, one 16-wave workgroup per CU) instead of 128 B
     if (wide < 0) {

@@ -18,6 +18,7 @@ struct x3d_poisson {
     hipfftHandle plan_fw, plan_bw;
     double2 *c;           // spectral workspace [nz][ny][nxs]
     double *waves;        // [nz][ny][nxs]
+    double *rwT;          // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), for the fused z pass of fft512.hip
     double *ab;           // ax bx ay by az bz
     void *work;
     size_t work_size;
@@ -141,6 +142,21 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
         X3D_FFT(hipfftPlanMany(&p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch));
         if (int rc = x3d_fft512_init()) return rc;
         p->fast512 = 1;
+        {   // z-fastest reciprocal wave numbers for the fused z pass (spectral division in the transform's layout)
+            const char *no_rwt = getenv("X3D_NO_RWT");
+            if (!(no_rwt && no_rwt[0] == '1')) {
+                const size_t nsr = (size_t)p->nz * p->ny * p->nxs;
+                std::vector<double> h(nsr);
+                for (int k = 0; k < p->nz; k++)
+                    for (int j = 0; j < p->ny; j++)
+                        for (int i = 0; i < p->nxs; i++) {
+                            const double wv = waves_re[((size_t)k * p->ny + j) * p->nxs + i];
+                            h[((size_t)j * p->nxs + i) * p->nz + k] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
+                        }
+                X3D_HIP(hipMalloc(&p->rwT, sizeof(double) * nsr));
+                X3D_HIP(hipMemcpy(p->rwT, h.data(), sizeof(double) * nsr, hipMemcpyHostToDevice));
+            }
+        }
         const char *no_r2c = getenv("X3D_NO_R2C512");
         p->r2c512 = p->nx == 512 && (batch % 2) == 0 && !(no_r2c && no_r2c[0] == '1');
     }
@@ -154,13 +170,14 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
     if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
-    hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
+    hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->rwT);
     hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
     return 0;
 }
 
 int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);
+void x3d_fft512_set_rwT(const double *rwT);
 
 // x pass of the fast path: real rows (nxp apart) -> nxs complex modes
 static int x_forward_512(x3d_poisson *p, const double *f)
@@ -223,7 +240,9 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
     if (p->fast512) {  // x r2c ; y ; z forward + process_spectral_000 + z backward in one pass ; y ; x c2r
         if (int rc = x_forward_512(p, f)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
+        x3d_fft512_set_rwT(p->rwT);
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 2, p->waves, p->ab, p->nx)) return rc;
+        x3d_fft512_set_rwT(nullptr);
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
         ProfScope ps(p->b, X3D_K_FFT, 2);
         X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
