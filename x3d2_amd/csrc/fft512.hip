@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     double2 a[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) a[k] = pen[l + 64 * k];
-    __syncthreads();
+    // (no barrier: from here to the cooperative store a wave only touches its own pencil's region of the tile)
     if (MODE == 1) fft512_wave<1>(a, pen, tws, l);
     else fft512_wave<-1>(a, pen, tws, l);
     if (MODE == 2 && sp.rwT) {
