@@ -55,7 +55,8 @@ int x3d_abi_version(void);
  * dims_vert: local vertex counts (mesh%get_dims(VERT)); stream: hipStream_t or NULL. */
 int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream);
 int x3d_backend_destroy(x3d_backend *b);
-/* diagnostics: which = 0 -> launches of the three-components-in-one transeq kernels since creation */
+/* diagnostics: which = 0 -> launches of the three-components-in-one transeq kernels since creation,
+ * 1 -> those of them that also applied a pending velocity correction (x3d_transeq_x_update) */
 long x3d_backend_counter(const x3d_backend *b, int which);
 int x3d_backend_set_stream(x3d_backend *b, void *stream);
 size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
@@ -134,6 +135,15 @@ int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw,
                     const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                     const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                     const x3d_tdsops *der2nd_sym, int accumulate);
+/* fusion extension: transeq_x on a velocity whose pressure-gradient correction is still pending:
+ * u += scale * tds_solve(gu, op_u), v += scale * tds_solve(gv, op_vw), w += scale * tds_solve(gw, op_vw) (the last x
+ * operators of gradient_c2v + solver.f90:731-733) is applied per pencil inside the transeq kernel, then
+ * du, dv, dw = transeq_x(u, v, w).  *done = 0: not applicable, nothing was done.  Bit-identical to
+ * x3d_tds_solve_acc x 3 followed by x3d_transeq. */
+int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, double *u, double *v, double *w, double nu,
+                         const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                         const x3d_tdsops *der2nd_sym, const double *gu, const double *gv, const double *gw,
+                         const x3d_tdsops *op_u, const x3d_tdsops *op_vw, double scale, int *done);
 /* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
  * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
  * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below

@@ -882,3 +882,67 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec, route):
         o.step(pressure=False)  # (the HIP run's "CG" placeholder pressure is zero)
     for a, fo, nm in zip(fused, (o.u, o.v, o.w), "uvw"):
         assert relerr(a, o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
+
+
+@pytest.mark.parametrize("nx", [256, 512])
+def test_deferred_velocity_correction_in_transeq_x(nx):
+    """fused driver, periodic x pencils of 256 / 512 points: between the sub-steps of a step the pressure-gradient
+    correction of the velocity is left to the next transeq_x kernel (k_xscan_transeq2x3<UPD>,
+    x3d_transeq_x_update), and the RK update to the divergence's first x operators (k_xscan_tds_lin): bit-identical
+    to the run with X3D_NO_DEFER=1, and equal to the oracle's steps"""
+    import os
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.case import BaseCase
+    from x3d2_amd.common import VERT
+    from x3d2_amd.solver import Solver, SolverConfig
+    dims, L = (nx, 16, 24), (2.0, 3.0, 2.5)
+    per = ("periodic",) * 2
+    rng = np.random.default_rng(13)
+    init = [0.3 * rng.standard_normal((dims[2], dims[1], dims[0])) for _ in range(3)]
+
+    class _Case(BaseCase):
+        def initial_conditions(self):
+            pass
+
+    def run(no_defer):
+        if no_defer:
+            os.environ["X3D_NO_DEFER"] = "1"
+        try:
+            mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
+            s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="FFT", fused=True, time_intg="RK3",
+                                                            dt=1e-3, Re=100.0))
+            case = _Case(s)
+            for f, a in zip((s.u, s.v, s.w), init):
+                f.set_data_loc(VERT)
+                s.backend.set_field_data(f, a)
+            calls = {"n": 0}
+            real = s.backend.transeq_x_update
+
+            def counted(*args, **kw):
+                ok = real(*args, **kw)
+                calls["n"] += int(ok)
+                return ok
+            s.backend.transeq_x_update = counted
+            for it in (1, 2):
+                case.step(it)
+            assert s.pending_grad is None
+            return [s.backend.get_field_data(f, VERT) for f in (s.u, s.v, s.w)], calls["n"]
+        finally:
+            os.environ.pop("X3D_NO_DEFER", None)
+
+    fused, n_fused = run(False)
+    plain, n_plain = run(True)
+    assert n_plain == 0 and n_fused == 2 * 2  # two of the three sub-steps of each step
+    for a, b_ in zip(fused, plain):
+        assert np.array_equal(a, b_)
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
+    o = orc.Solver(om, poisson="FFT", time_intg="RK3", dt=1e-3, Re=100.0)
+    for fo, a in zip((o.u, o.v, o.w), init):
+        fo.data_loc = orc.VERT
+        o.backend.set_field_data(fo, a)
+    for it in (1, 2):
+        o.step()
+    for a, fo, nm in zip(fused, (o.u, o.v, o.w), "uvw"):
+        assert relerr(a, o.backend.get_field_data(fo, orc.VERT)) < 1e-10, nm

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "x3d_field_shift": (I, [VP, VP, D]),
     "x3d_backend_counter": (ctypes.c_long, [VP, I]),
     "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
+    "x3d_transeq_x_update": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, VP, VP, VP, VP, VP, D, c_int_p]),
     "x3d_transeq_defer": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, c_int_p]),
     "x3d_pending_flush": (I, [VP, I, VP, VP]),
     "x3d_transeq_stage_ok": (I, [VP, I, VP, VP, VP, VP]),

@@ -225,6 +225,16 @@ class HipBackend:
             return
         self._transeq_dist(direction, du, dv, dw, u, v, w, nu, dirps, accumulate=accumulate)
 
+    def transeq_x_update(self, du, dv, dw, u, v, w, nu, dirps, grads, op_u, op_vw, scale):
+        """transeq_x with the pending correction u,v,w += scale * tds_solve(grads) applied inside the kernel
+        (csrc/xscan.hip, k_xscan_transeq2x3<UPD>); False: not applicable, nothing was done"""
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_x_update(self.h, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
+                                                 dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                                 dirps.der2nd_sym.handle, grads[0].ptr, grads[1].ptr, grads[2].ptr,
+                                                 op_u.handle, op_vw.handle, float(scale), ctypes.byref(flag)))
+        return bool(flag.value)
+
     def transeq_dir_defer(self, direction, pend, u, v, w, nu, dirps):
         """transeq_dir(accumulate=True) with the accumulation left pending (csrc/viax.hip): the results stay in
         the blocks `pend` (pencil layout) until lincomb_pending / pending_flush.  False: not applicable here,

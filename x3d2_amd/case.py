@@ -64,7 +64,7 @@ class BaseCase:
     def postprocess(self, it, t):
         return self.monitoring.write_step(t, self.solver.u, self.solver.v, self.solver.w)
 
-    def substep(self, it):
+    def substep(self, it, last=True):
         """body of the sub_iter loop, base_case.f90:261-289"""
         s = self.solver
         al = s.backend.allocator
@@ -92,13 +92,24 @@ class BaseCase:
                 al.release_block(f)
             deriv = []
         self.apply_BC(s.u, s.v, s.w)
-        s.pressure_correction(s.u, s.v, s.w)
+        # not the last sub-step of the step and no hook looks at the velocity before the next transeq: its
+        # pressure-gradient correction can wait for that kernel (Solver.transeq_fused)
+        defer_grad = (not last and s.fused and type(self).define_BC is BaseCase.define_BC
+                      and type(self).apply_BC is BaseCase.apply_BC)
+        if defer_grad:
+            s.pressure_correction(s.u, s.v, s.w, defer_grad=True)
+        else:
+            s.pressure_correction(s.u, s.v, s.w)
         for f in deriv:  # (kept until the deferred updates that read them were done)
             al.release_block(f)
 
-    def step(self, it):
-        for _ in range(self.solver.time_integrator.nstage):
-            self.substep(it)
+    def step(self, it, more=False):
+        """one time step.  more=True: another step follows at once and nothing looks at the fields in between, so
+        the last sub-step's velocity correction may also wait for the next transeq_x kernel; whoever reads the
+        velocity next without going through step() must call solver.flush_grad() first (run() does)."""
+        ns = self.solver.time_integrator.nstage
+        for i in range(ns):
+            self.substep(it, last=(i == ns - 1 and not more))
 
     def run(self, n_iters=None, verbose=False):
         s = self.solver
@@ -107,7 +118,8 @@ class BaseCase:
         start = s.current_iter + 1
         for it in range(start, n_iters + 1):
             t0 = time.perf_counter()
-            self.step(it)
+            output_due = s.n_output > 0 and it % s.n_output == 0
+            self.step(it, more=(it < n_iters and not output_due))
             s.current_iter = it
             if s.n_output > 0 and it % s.n_output == 0:
                 row = self.postprocess(it, it * s.dt)
@@ -116,6 +128,7 @@ class BaseCase:
                           % (row[0], it, row[1], row[2], row[3]))
             s.backend.sync()
             self.step_times.append(time.perf_counter() - t0)
+        s.flush_grad()
         return self.monitoring.rows
 
 

@@ -87,10 +87,12 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
     return 0;
 }
 
-// which = 0: launches of the three-components-in-one transeq kernels since creation
+// which = 0: launches of the three-components-in-one transeq kernels since creation; 1: those of them that
+// also applied a pending velocity correction
 extern "C" long x3d_backend_counter(const x3d_backend *b, int which)
 {
-    return (b && which == 0) ? b->n_tq3 : -1;
+    if (!b) return -1;
+    return which == 0 ? b->n_tq3 : (which == 1 ? b->n_upd : -1);
 }
 
 extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)

@@ -56,6 +56,7 @@ struct x3d_backend {
     double *red_buf;  // reduction partials (device)
     double *red_host; // pinned host landing zone
     int red_cap;
+    long n_upd;       // ... of those, launches that also applied the pending velocity correction (UPD form)
     long n_tq3;       // launches of the three-components-in-one transeq kernels (bench.py prices them at 48 B/DoF)
     void *epi_dev;    // 256-byte device slot for the RK-stage description of k_ytile_transeq<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;

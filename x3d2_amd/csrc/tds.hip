@@ -127,7 +127,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                 E(5 * Q + q, l) = real ? Sa[j] : 0.0;
                 E(6 * Q + q, l) = real ? Sc[j] : 0.0;
                 E(7 * Q + q, l) = real ? St[j] : 0.0;
-                E(8 * Q + q, l) = real ? Stc[j] : 0.0;
+                E(8 * Q + 12 + q, l) = real ? Stc[j] : 0.0;  // (last block: kernels that do not need it stage 8 Q + 12 entries)
             }
             G[l] = pg;
             double ph = 1.0;
@@ -142,8 +142,8 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             const int d = 1 << k;
             double nf[64], nb[64];
             for (int l = 0; l < 64; l++) {
-                E(9 * Q + k, l) = mf[l];
-                E(9 * Q + 6 + k, l) = mb[l];
+                E(8 * Q + k, l) = mf[l];
+                E(8 * Q + 6 + k, l) = mb[l];
                 nf[l] = l >= d ? mf[l] * mf[l - d] : mf[l];
                 nb[l] = l + d < 64 ? mb[l] * mb[l + d] : mb[l];
             }
@@ -156,10 +156,10 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             for (int i = l; i <= (l | 15); i++) d16 *= HL[i]; // l .. row end: carries lane 16 / 48 into rows 0 / 2
             for (int i = l; i <= 31; i++) d32 *= HL[i];       // l .. 31: carries lane 32 into rows 0, 1
             const int row = l >> 4;
-            E(9 * Q + 4, l) = (row == 1 || row == 3) ? c15 : 0.0;
-            E(9 * Q + 5, l) = row >= 2 ? c31 : 0.0;
-            E(9 * Q + 6 + 4, l) = (row == 0 || row == 2) ? d16 : 0.0;
-            E(9 * Q + 6 + 5, l) = row < 2 ? d32 : 0.0;
+            E(8 * Q + 4, l) = (row == 1 || row == 3) ? c15 : 0.0;
+            E(8 * Q + 5, l) = row >= 2 ? c31 : 0.0;
+            E(8 * Q + 6 + 4, l) = (row == 0 || row == 2) ? d16 : 0.0;
+            E(8 * Q + 6 + 5, l) = row < 2 ? d32 : 0.0;
         }
     }
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
@@ -586,7 +586,8 @@ int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, con
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);  // xscan.hip
 int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // xscan.hip
+                       const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
+                       const x3d_tdsops *op_i, double scale, bool *done);  // xscan.hip
 static bool use_onchip_transeq()
 {
     static int mode = -1;
@@ -945,7 +946,9 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
     if (dir == X3D_DIR_X) {
         // the three components in one launch of the scan kernel (xscan.hip), the advecting velocity read once
         bool done = false;
-        if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;
+        if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, nullptr, nullptr, nullptr,
+                                        0.0, &done))
+            return rc;
         if (done) return 0;
     }
     if (dir != X3D_DIR_X && !use_onchip_transeq() && !use_fused_kernels()) {
@@ -957,6 +960,36 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
     if (int rc = transeq_component_local(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, a)) return rc;
     if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
     if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
+    return 0;
+}
+
+// fusion extension: transeq_x (all three components, du dv dw written) on a velocity whose pressure-gradient
+// correction is still pending: first u += scale * tds_solve(gu, op_u), v += scale * tds_solve(gv, op_vw),
+// w += scale * tds_solve(gw, op_vw) (the last x operators of gradient_c2v + the velocity update of
+// src/solver.f90:731-733), per pencil, inside the transeq kernel.  *done = 0: not applicable here, nothing was
+// done (issue x3d_tds_solve_acc x 3 and x3d_transeq).  Bit-identical to that sequence.
+extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, double *u, double *v, double *w,
+                                    double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                    const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, const double *gu,
+                                    const double *gv, const double *gw, const x3d_tdsops *op_u,
+                                    const x3d_tdsops *op_vw, double scale, int *done)
+{
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && gu && gv && gw &&
+                    op_u && op_vw && done,
+                "x3d_transeq_x_update: null argument");
+    *done = 0;
+    if (int rc = transeq_check(b, X3D_DIR_X, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = check_len(b, op_u, X3D_DIR_X, "transeq_x_update")) return rc;
+    if (int rc = check_len(b, op_vw, X3D_DIR_X, "transeq_x_update")) return rc;
+    double *r[3] = {du, dv, dw};
+    const double *f[3] = {u, v, w}, *g[3] = {gu, gv, gw};
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 3; k++)
+            X3D_REQUIRE(r[c] != f[k] && r[c] != g[k] && f[c] != g[k], "x3d_transeq_x_update: arguments alias");
+    bool ok = false;
+    if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, g, op_u, op_vw, scale, &ok))
+        return rc;
+    *done = ok ? 1 : 0;
     return 0;
 }
 

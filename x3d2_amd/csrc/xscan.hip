@@ -43,10 +43,11 @@ int npmax_of(const x3d_backend *b);
 #define LT_SA(q) (5 * Q + (q))
 #define LT_SC(q) (6 * Q + (q))
 #define LT_ST(q) (7 * Q + (q))
-#define LT_STC(q) (8 * Q + (q))
-#define LT_MF(k) (9 * Q + (k))
-#define LT_MB(k) (9 * Q + 6 + (k))
+#define LT_MF(k) (8 * Q + (k))
+#define LT_MB(k) (8 * Q + 6 + (k))
+#define LT_STC(q) (8 * Q + 12 + (q))  // last: only the d2u operator of a transeq component reads it
 #define LT_N(Q_) (9 * (Q_) + 12)
+#define LT_NC(Q_) (8 * (Q_) + 12)     // entries without the STC block
 
 // what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
 struct XOp {
@@ -734,24 +735,38 @@ __global__ void __launch_bounds__(512)
 // Two pencils per wave as above; the pair's rows of the advecting velocity u0 stay in registers for the three
 // components (u0, u0), (u1, u0), (u2, u0): 6 field passes instead of 8.  der1st == der1st_sym and
 // der2nd == der2nd_sym as lane tables (periodic operators): two table sets in LDS.
-template <int Q, bool ACC, bool NARROW>
+//
+// UPD: the velocity is still waiting for the previous sub-step's pressure-gradient correction
+// u_c += scale * tds_solve(g_c)  (gradient_c2v's last x operators, src/vector_calculus.f90:318-330 +
+// src/solver.f90:731-733): done here, per pencil, before the component is used -- u_c is written, not read back
+// (12 field passes instead of 9 + 6).  Four table sets, three of them without the STC block: 156 KB of LDS.
+struct XUpd {
+    const double *g[3];  // gradient inputs of u0, u1, u2
+    double scale;
+};
+
+template <int Q, bool ACC, bool NARROW, bool UPD>
 __global__ void __launch_bounds__(512)
-    k_xscan_transeq2x3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
-                       const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2,
-                       XOp tD1, XOp tD2, int np, long pitch, double nu)
+    k_xscan_transeq2x3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2, double *u0,
+                       double *u1, double *u2, XOp tD1, XOp tD2, int np, long pitch, double nu, XUpd upd, XOp tS,
+                       XOp tI)
 {
-    extern __shared__ double lt[];  // [2][LT_N(Q)][64]
-    constexpr int LN = LT_N(Q) * 64;
-    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
-        lt[i] = tD1.TL[i];
-        lt[LN + i] = tD2.TL[i];
+    extern __shared__ double lt[];
+    constexpr int LNF = LT_N(Q) * 64, LNC = LT_NC(Q) * 64, L1N = UPD ? LNC : LNF;
+    for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
+    for (int i = threadIdx.x; i < LNF; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
+    if (UPD) {
+        for (int i = threadIdx.x; i < LNC; i += blockDim.x) {
+            lt[L1N + LNF + i] = tS.TL[i];
+            lt[L1N + LNF + LNC + i] = tI.TL[i];
+        }
     }
     __syncthreads();
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int first = lane * Q + 1;
-    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
     double na[Q], nb[Q];  // the rows needed next (next component's field, or the next pair's u0)
     const int pstart = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
     if (pstart < np) {
@@ -768,6 +783,45 @@ __global__ void __launch_bounds__(512)
                 V2 b2[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) b2[q] = V2{na[q], nb[q]};
+                const int pn = p + 2 * nwaves;
+                {
+                    const double *nsrc = c == 0 ? u1 + (long)p * pitch : (c == 1 ? u2 + (long)p * pitch
+                                                                                 : u0 + (long)(pn < np ? pn : p) * pitch);
+                    if (c < 2 || pn < np) {
+                        load_body<Q>(na, nsrc, lane);
+                        load_body<Q>(nb, nsrc + pitch, lane);
+                    }
+                }
+                if constexpr (UPD) {
+                    // u_c += scale * tds_solve(g_c), arithmetic of k_xscan_tds<ACC>: old + scale * r
+                    const double *gsrc = (c == 0 ? upd.g[0] : (c == 1 ? upd.g[1] : upd.g[2])) + (long)p * pitch;
+                    double ga[Q], gb[Q];
+                    load_body<Q>(ga, gsrc, lane);
+                    load_body<Q>(gb, gsrc + pitch, lane);
+                    V2 g2[Q], wg[Q + 8], X[Q], du1, xn;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) g2[q] = V2{ga[q], gb[q]};
+                    window_from_body<Q, V2>(wg, g2, lane);
+                    const double *__restrict__ lg = lt + L1N + LNF + (c == 0 ? 0 : LNC);
+                    const XOp &tg = c == 0 ? tS : tI;
+                    scan_solve<Q, true, NARROW, V2>(wg, X, du1, xn, lg, tg, lane, first);
+                    const V2 du_s = tg.rs_s * (du1 - tg.sa1 * xn), du_e = tg.rs_e * (xn - tg.scn * du1);
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const double st = lg[LT_ST(q) * 64 + lane];
+                        V2 r = (X[q] - lg[LT_SA(q) * 64 + lane] * du_s - lg[LT_SC(q) * 64 + lane] * du_e) * st;
+                        if (q == 0) r = (lane == 0) ? du_s * st : r;
+                        if (q == Q - 1) r = (lane == 63) ? du_e * st : r;
+                        b2[q] = b2[q] + upd.scale * r;
+                    }
+                    double ua[Q], ub[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; q++) { ua[q] = b2[q].a; ub[q] = b2[q].b; }
+                    double *uw = (c == 0 ? u0 : (c == 1 ? u1 : u2)) + (long)p * pitch;
+                    if constexpr (Q == 8) { store_rows_q8<false>(uw, lane, ua, 1.0); store_rows_q8<false>(uw + pitch, lane, ub, 1.0); }
+                    else { store_rows_q4<false>(uw, lane, ua, 1.0); store_rows_q4<false>(uw + pitch, lane, ub, 1.0); }
+                    asm volatile("" : "+v"(lane) : "v"(b2[0].a));
+                }
                 if (c == 0) {
 #pragma unroll
                     for (int q = 0; q < Q; q++) cb[q] = b2[q];
@@ -776,13 +830,6 @@ __global__ void __launch_bounds__(512)
                 window_from_body<Q, V2>(wp, cb, lane);
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
-                const int pn = p + 2 * nwaves;
-                const double *nsrc = c == 0 ? u1 + (long)p * pitch : (c == 1 ? u2 + (long)p * pitch
-                                                                             : u0 + (long)(pn < np ? pn : p) * pitch);
-                if (c < 2 || pn < np) {
-                    load_body<Q>(na, nsrc, lane);
-                    load_body<Q>(nb, nsrc + pitch, lane);
-                }
             }
             auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const double *__restrict__ l, const XOp &t) {
                 V2 a, b;
@@ -1584,10 +1631,12 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     return 0;
 }
 
-// transeq_x in one launch (k_xscan_transeq2x3); f[0] is the advecting component
+// transeq_x in one launch (k_xscan_transeq2x3); f[0] is the advecting component.  upd_g != null: the pending
+// correction f[c] += scale * tds_solve(upd_g[c]) with op_s (c = 0) / op_i (c = 1, 2) is applied first (UPD form)
 int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
+                       const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
+                       const x3d_tdsops *op_i, double scale, bool *done)
 {
     *done = false;
     static int on = -1;
@@ -1600,21 +1649,34 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q, np = b->ny * b->nz;
     if (b->nx != 64 * Q || np % 2) return 0;
-    const size_t lds = sizeof(double) * 2 * LT_N(Q) * 64;
-    const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
+    const bool upd = upd_g != nullptr;
+    if (upd) {
+        auto ok = [&](const x3d_tdsops *t) {
+            return xscan_ok(t) && t->tab.Q == Q && t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
+        };
+        if (!ok(op_s) || !ok(op_i)) return 0;
+    }
+    const size_t lds = sizeof(double) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
+    if (lds > 160 * 1024) return 0;
+    const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd) && (!upd || (stencil_narrow(op_s) && stencil_narrow(op_i)));
     const int blocks = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
-#define GO(Q_, A_, N_)                                                                                          \
+    XUpd xu{};
+    if (upd) { xu.g[0] = upd_g[0]; xu.g[1] = upd_g[1]; xu.g[2] = upd_g[2]; xu.scale = scale; }
+    const x3d_tdsops *ts = upd ? op_s : der1st, *ti = upd ? op_i : der1st;
+#define GO(Q_, A_, N_, U_)                                                                                      \
     do {                                                                                                        \
         static bool at = false;                                                                                 \
         if (!at) {                                                                                              \
-            X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2x3<Q_, A_, N_>,                           \
+            X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2x3<Q_, A_, N_, U_>,                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
             at = true;                                                                                          \
         }                                                                                                       \
-        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
-                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), np, (long)b->nxp, nu);             \
+        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
+                           r[2], (double *)f[0], (double *)f[1], (double *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
+                           (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti));                                       \
     } while (0)
-#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GOU(Q_, A_, N_) do { if (upd) GO(Q_, A_, N_, true); else GO(Q_, A_, N_, false); } while (0)
+#define GON(Q_, A_) do { if (narrow) GOU(Q_, A_, true); else GOU(Q_, A_, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
@@ -1622,9 +1684,11 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     }
 #undef GOA
 #undef GON
+#undef GOU
 #undef GO
     X3D_HIP(hipGetLastError());
     b->n_tq3++;
+    if (upd) b->n_upd++;
     if (b->prof) {  // three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X); }
     }

@@ -95,6 +95,7 @@ class Solver:
             self.poisson = self.poisson_cg
         else:
             raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
+        self.pending_grad = None
         self.transeq = self.transeq_fused if self.fused else self.transeq_default
         if self.fused:
             self.pressure_correction = self.pressure_correction_fused
@@ -175,7 +176,18 @@ class Solver:
         du, dv, dw = rhs[:3]
         u, v, w = variables[:3]
         b.mesh.get_n(DIR_X, u.data_loc)
-        b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
+        if self.pending_grad is not None:
+            # the previous sub-step's velocity correction is still pending (pressure_correction_fused(defer_grad)):
+            # the x kernel applies it to each pencil before using it
+            g, self.pending_grad = self.pending_grad, None
+            x = self.xdirps
+            if not b.transeq_x_update(du, dv, dw, u, v, w, self.nu, x, g, x.stagder_p2v, x.interpl_p2v, -1.0):
+                self._apply_grad(g, u, v, w)
+                b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
+            for f in g:
+                b.allocator.release_block(f)
+        else:
+            b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
         b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
         # z last: its accumulation may be deferred (when z is decomposed it is not: the y components then
         # take the tile kernel K3y, which is cheaper than transposed copies + the fused RK stage)
@@ -209,7 +221,7 @@ class Solver:
             self.transeq_species_fused(rhs[3:], variables)
         return pending
 
-    def pressure_correction_fused(self, u, v, w):
+    def pressure_correction_fused(self, u, v, w, defer_grad=False):
         """pressure_correction (:693-739) = divergence_v2c + Poisson + gradient_c2v +
         velocity update with the 10 reorders removed and the 5 vecadd's folded
         into the accumulating form of the last tds_solve of each chain."""
@@ -240,11 +252,31 @@ class Solver:
         b.tds_pair(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v, DIR_Z)    # p_sxy, dpdz_sxy
         b.tds_pair(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
         b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)       # dpdz_sx
-        b.tds_apply(u, a1, x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
-        b.tds_apply(v, a2, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
-        b.tds_apply(w, t1, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+        if (defer_grad and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_DEFER_GRAD") != "1"
+                and self.nspecies == 0):
+            # the next sub-step's transeq_x applies the correction inside its own kernel (transeq_fused)
+            self.pending_grad = (a1, a2, t1)
+            for f in (t2, t3):
+                al.release_block(f)
+            return
+        self._apply_grad((a1, a2, t1), u, v, w)
         for f in (t1, t2, t3, a1, a2):
             al.release_block(f)
+
+    def _apply_grad(self, g, u, v, w):
+        """velocity correction, src/solver.f90:731-733 folded into the last x operators of gradient_c2v"""
+        b, x = self.backend, self.xdirps
+        b.tds_apply(u, g[0], x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
+        b.tds_apply(v, g[1], x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+        b.tds_apply(w, g[2], x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+
+    def flush_grad(self):
+        """apply a pending velocity correction now (anything that reads u, v, w before the next transeq)"""
+        if self.pending_grad is not None:
+            g, self.pending_grad = self.pending_grad, None
+            self._apply_grad(g, self.u, self.v, self.w)
+            for f in g:
+                self.backend.allocator.release_block(f)
 
     # ---- :603-651
     def divergence_v2p(self, div_u, u, v, w):
