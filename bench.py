@@ -172,25 +172,25 @@ def main():
             per_dir[name] = {"ms_per_component": (mf + mb) / nf,
                              "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9,
                              "GB/s_at_48B_per_3_components": 16.0 * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
-    # algorithmic bytes: SURVEY.md 8d's per-unit figure, unit = one component: 24 B/DoF, 16 when conv == u, i.e.
-    # 64 B/DoF per three components (the advecting velocity counted as an input of each).  The three-in-one
-    # kernels read it once; what such a launch has to move is the fused floor of 48 B/DoF (same
-    # table): reported next to the headline figure as *_at_fused_floor
+    # algorithmic bytes per launch.  SURVEY.md 8d's per-unit figures price every operation on its own: a transeq
+    # component 24 B/DoF (16 when conv == u) = 64 B/DoF per direction, an accumulating tds_solve 24 B/DoF.  The fused
+    # launches of this backend have a smaller compulsory traffic -- a three-in-one launch reads the advecting
+    # velocity once (the table's "fully fused floor" of 48 B/DoF), and a transeq_x launch that also applies the
+    # pending velocity correction reads 3 gradients and writes u, v, w on top (+48 B/DoF, the velocity itself
+    # being an input it reads anyway).  Headline `achieved` / `frac`: that compulsory traffic of what a launch
+    # does; `achieved_survey_per_unit`: the per-operation figures (larger: the fusion removed re-reads).
     n_tq3 = int(backend.lib.x3d_backend_counter(backend.h, 0)) - tq3_before
-    comps3 = min(3 * n_tq3, n_f)
-    transeq_bytes = (64.0 / 3.0) * dof_local
-    floor_bytes = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0) * dof_local / max(n_f, 1)
-    # launches whose accumulation is folded into the RK stage also move the stage's own algorithmic bytes
-    rk_bytes = 8.0 * dof_local * getattr(backend, "rk_fused_passes", 0)
-    # transeq_x launches that also apply the previous sub-step's velocity correction (three accumulating
-    # tds_solve's: gradient in, velocity in and out = 24 B/DoF each) carry those algorithmic bytes as well
     n_upd = int(backend.lib.x3d_backend_counter(backend.h, 1)) - upd_before
-    rk_bytes += 72.0 * dof_local * n_upd
+    comps3 = min(3 * n_tq3, n_f)
+    rk_bytes = 8.0 * dof_local * getattr(backend, "rk_fused_passes", 0)  # RK stage done by a transeq launch
     n_fused = getattr(backend, "rk_fused_launches", 0)
+    total_floor = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0 + 48.0 * n_upd) * dof_local + rk_bytes
+    total_survey = (n_f * (64.0 / 3.0) + 72.0 * n_upd) * dof_local + rk_bytes
     avg_ms = (ms_f + ms_b) / max(n_f, 1)
-    bytes_per_launch = transeq_bytes + rk_bytes / max(n_f, 1)  # per component
+    transeq_bytes = (64.0 / 3.0) * dof_local
+    bytes_per_launch = total_floor / max(n_f, 1)  # per component
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
-    achieved_floor = (floor_bytes + rk_bytes / max(n_f, 1)) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
+    achieved_survey = total_survey / max(n_f, 1) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -203,12 +203,12 @@ def main():
             traffic = None
     roofline = {"bound": "hbm",
                 "kernel": "transeq component (one third of a k_xscan_transeq2x3 (x) / k_ytile_transeq3 (y, z) launch at "
-                          "512^3; launches that also do the RK stage include its algorithmic bytes)",
-                "three_in_one_launches": n_tq3, "launches_with_velocity_correction": n_upd, "achieved_at_fused_floor": achieved_floor,
-                "frac_at_fused_floor": achieved_floor / HBM_PEAK_GBS,
+                          "512^3; x launches that also apply the pending velocity correction include its bytes)",
+                "three_in_one_launches": n_tq3, "launches_with_velocity_correction": n_upd,
+                "achieved_survey_per_unit": achieved_survey, "frac_survey_per_unit": achieved_survey / HBM_PEAK_GBS,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "transeq_bytes_per_launch": transeq_bytes, "rk_stage_fused_launches": n_fused,
+                "survey_transeq_bytes_per_component": transeq_bytes, "rk_stage_fused_launches": n_fused,
                 "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
                 "avg_launch_ms": avg_ms, "launches": n_f, "per_direction": per_dir,
                 "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
