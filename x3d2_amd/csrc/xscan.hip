@@ -1259,7 +1259,8 @@ __global__ void __launch_bounds__(1024)
         __syncthreads();
         pick(b);
         window_from_body<Q>(w, b, lane);
-        __syncthreads();  // the tile is free
+        // (barriers only before COOPERATIVE accesses to the tile: a wave's own results go to its own pencil's region)
+        if (MODE == 0) __syncthreads();  // all rows picked: the second input may overwrite the tile
         {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) gload(nxt, in1 + tile_off(tn));
@@ -1270,7 +1271,6 @@ __global__ void __launch_bounds__(1024)
             __syncthreads();
             pick(b);
             window_from_body<Q>(w, b, lane);
-            __syncthreads();
             asm volatile("" : "+v"(lane) : "v"(ra[0]));
             solve(w, rb, lb, tb);
 #pragma unroll
