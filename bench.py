@@ -56,6 +56,28 @@ def cpu_baseline(n, steps):
             "seconds": dt}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here, as FRESH children of a
+    parent that has not touched the GPU (never re-exec a process that has), one per device, rendezvous on
+    127.0.0.1; rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +95,8 @@ def main():
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     # the CPU baseline uses the physical cores of the host (set before libgomp starts)
     try:

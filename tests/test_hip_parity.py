@@ -411,14 +411,13 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
     assert rows[:, 2].max() < 1e-13
 
 
-@pytest.mark.parametrize("env", ["X3D_ONCHIP", "X3D_NO_ONCHIP2", "X3D_ONCHIP_TRANSEQ", "X3D_CHECKPOINT", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN",
-                                 "X3D_NO_VIA_X", "X3D_NO_YTILE", "X3D_NO_ZTILE", "X3D_XSCAN_P1",
+@pytest.mark.parametrize("env", ["X3D_NO_ONCHIP2", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN", "X3D_NO_YTILE", "X3D_XSCAN_P1",
                                  "X3D_NO_TDS_PAIR", "X3D_NO_TILE3", "X3D_NO_TDS_LINCOMB"])
-def test_optional_kernel_families_pass_the_same_parity_tests(env):
-    """the non-default kernel families (single-pass on-chip tds_solve, checkpoint /
-    block-recompute sweeps, generic x-direction kernels, LDS-tiled x kernels instead of
-    the wave-per-pencil scan, y/z transeq without the scan kernel (two-sweep), y through
-    transposed copies instead of the LDS tile, z through the LDS tile) must give the same results"""
+def test_fallback_kernel_families_pass_the_same_parity_tests(env):
+    """the kernels other sizes / boundary conditions fall back to must give the same results on the sizes the
+    fast paths take: two-sweep tds_solve instead of the on-chip one, generic / LDS-tiled x kernels instead of
+    the wave-per-pencil scan, two-sweep y/z transeq, y through transposed copies instead of the LDS tile, one
+    pencil per wave, separate kernels instead of the pair / three-in-one / lincomb fusions"""
     import os
     import subprocess
     import sys

@@ -272,3 +272,39 @@ def test_product_stretching_matrices_match_reference(name):
             sl = {1: slice(2, n), 2: slice(1, n), 3: slice(0, n), 4: slice(0, n - 1), 5: slice(0, n - 2)}[dg]
             ref = g[f"spec.{tag}_re.{dg}"][:, sl]
             assert np.max(np.abs(mine[dg - 1][:, sl] - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-300), (tag, dg)
+
+
+def test_fused_x_entry_points_refuse_a_decomposed_x_direction():
+    """transeq_x_update closes every pencil with the periodic self-exchange: with x decomposed it must decline
+    (False = nothing done) before touching the library, like the other fused x entry points"""
+    import types
+    from x3d2_amd.backend import HipBackend
+    b = HipBackend.__new__(HipBackend)
+    b.mesh = types.SimpleNamespace(nproc_dir=(2, 1, 1))
+    b.lib = None  # any call into the library would raise
+    assert b.transeq_x_update(*([None] * 12)) is False
+    assert b.transeq_dir_defer(1, None, None, None, None, 0.0, None) is False
+    assert b.transeq_stage_ok(1, None) is False
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two fresh rank processes itself (rendezvous on
+    127.0.0.1) instead of exiting; checked with a stand-in for the rank body"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, runpy\n"
+        "sys.argv = ['bench.py', '--gpus', '2']\n"
+        "if 'WORLD_SIZE' in os.environ:\n"
+        "    print('{\"rank\": %s, \"world\": %s, \"addr\": \"%s\"}' % (os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'])) if os.environ['RANK'] == '0' else None\n"
+        "    sys.exit(0)\n"
+    )
+    # the children re-run bench.py itself; intercept them with sitecustomize-free means: a wrapper bench that
+    # imports spawn_ranks from the real file
+    w = tmp_path / "bench.py"
+    src = open(os.path.join(root, "bench.py")).read()
+    body = src.split("def main():")[0]
+    w.write_text(body + "\n" + code + "sys.exit(spawn_ranks(2))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(w)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"rank": 0, "world": 2, "addr": "127.0.0.1"' in r.stdout

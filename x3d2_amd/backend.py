@@ -52,6 +52,7 @@ class HipBackend:
         self.poisson_fft = None
         self._halo = {}
         self._tdsops = []
+        self.before_read = []  # callables run before field data leaves the device (Solver.flush_grad)
 
     def __del__(self):
         try:
@@ -228,6 +229,8 @@ class HipBackend:
     def transeq_x_update(self, du, dv, dw, u, v, w, nu, dirps, grads, op_u, op_vw, scale):
         """transeq_x with the pending correction u,v,w += scale * tds_solve(grads) applied inside the kernel
         (csrc/xscan.hip, k_xscan_transeq2x3<UPD>); False: not applicable, nothing was done"""
+        if self._decomposed(DIR_X):
+            return False  # (the kernel closes each pencil with the periodic self-exchange: local pencils only)
         flag = ctypes.c_int(0)
         _lib.check(self.lib.x3d_transeq_x_update(self.h, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
                                                  dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
@@ -494,6 +497,8 @@ class HipBackend:
         _lib.check(self.lib.x3d_set_field_data(self.h, f.ptr, _dp(a), _lib.ints(nx, ny, nz)))
 
     def get_field_data(self, f, loc=None):
+        for hook in self.before_read:
+            hook()
         loc = (f.data_loc if f.data_loc != NULL_LOC else 0) if loc is None else loc
         nx, ny, nz = self.mesh.get_dims(loc)
         out = np.empty((nz, ny, nx), dtype=np.float64)

@@ -18,6 +18,7 @@ class Monitoring:
 
     def write_step(self, t, u, v, w):
         s = self.solver
+        s.flush_grad()  # a velocity correction left pending by step(more=True) is completed first
         b, al = s.backend, s.backend.allocator
         du, dv, dw = (al.get_block(DIR_X, VERT) for _ in range(3))
         s.curl(du, dv, dw, u, v, w)
@@ -36,6 +37,7 @@ class Monitoring:
     def kinetic_energy(self):
         """1/(2N) sum (u^2+v^2+w^2): not written by the reference, asked for by the north star"""
         s = self.solver
+        s.flush_grad()
         b = s.backend
         return 0.5 * (b.scalar_product(s.u, s.u) + b.scalar_product(s.v, s.v)
                       + b.scalar_product(s.w, s.w)) / s.ngrid

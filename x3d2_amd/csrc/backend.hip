@@ -9,6 +9,8 @@
 //   (get/set_field_data), src/allocator.f90:64-93 (padding).
 #include "common.h"
 
+#include <unordered_set>
+
 #include <cmath>
 
 static thread_local char g_err[512] = "";
@@ -69,6 +71,7 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     X3D_HIP(hipMalloc(&b->red_buf, sizeof(double) * 2 * b->red_cap));
     X3D_HIP(hipHostMalloc(&b->red_host, sizeof(double) * 2 * b->red_cap));
     X3D_HIP(hipMalloc(&b->epi_dev, 256));
+    b->lds_optin = new std::unordered_set<const void *>();
     X3D_HIP(hipEventCreate(&b->ev0));
     X3D_HIP(hipEventCreate(&b->ev1));
     *out = b;
@@ -83,7 +86,17 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
     x3d_prof_enable_c(b, 0);
     hipFree(b->red_buf); hipHostFree(b->red_host); hipFree(b->epi_dev);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+    delete static_cast<std::unordered_set<const void *> *>(b->lds_optin);
     delete b;
+    return 0;
+}
+
+int x3d_lds_optin(x3d_backend *b, const void *kernel)
+{
+    auto *seen = static_cast<std::unordered_set<const void *> *>(b->lds_optin);
+    if (seen->count(kernel)) return 0;
+    X3D_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    seen->insert(kernel);
     return 0;
 }
 

@@ -10,7 +10,6 @@
 #include "../../include/x3d2_hip.h"
 
 #define X3D_NH 4
-#define X3D_CK 16  // checkpoint spacing of the block-recompute backward sweep
 
 void x3d_set_error(const char *fmt, ...);
 
@@ -31,6 +30,16 @@ void x3d_set_error(const char *fmt, ...);
             return 2;                                                                          \
         }                                                                                      \
     } while (0)
+
+// Between the store and the load phase of a WAVE-PRIVATE exchange through LDS: a wave's LDS operations execute
+// in order, so no s_barrier is needed, but the compiler must not move one lane's load over another lane's store
+// (plain C++ semantics would allow it).  Emits no instruction.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Pencil enumeration for one direction of the Cartesian-pitched block:
 // pencil p -> base = (p % dim0) * s0 + (p / dim0) * s1, rows advance by rs.
@@ -61,7 +70,16 @@ struct x3d_backend {
     void *epi_dev;    // 256-byte device slot for the RK-stage description of k_ytile_transeq<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
+    void *lds_optin;        // kernels of this backend's device whose dynamic-LDS limit has been raised (backend.hip)
 };
+
+// > 64 KB of dynamic LDS needs an opt-in per kernel and DEVICE: raise the limit to the CU's 160 KB once per
+// (backend, kernel) -- not a process-wide flag, and not the first call's size
+int x3d_lds_optin(x3d_backend *b, const void *kernel);
+#define X3D_LDS_OPTIN(b, kernel)                                                               \
+    do {                                                                                       \
+        if (int rc_ = x3d_lds_optin((b), (const void *)(kernel))) return rc_;                  \
+    } while (0)
 
 // kernel classes timed by the profiler; index = kind * 4 + dir (dir 0 = n/a)
 // (X3D_K_* are declared in include/x3d2_hip.h)

@@ -70,6 +70,7 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
                                             const double2 *__restrict__ tw, int l)
 {
     // pass A: over n1 (stride 64), twiddle W512^(l k1)
+    wave_lds_fence();  // (the caller's reads of this region, e.g. pass C of a previous transform, come first)
     fft8<S>(a);
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) {
@@ -77,7 +78,8 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
     }
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) pen[k1 * 72 + l] = a[k1];
-    // no barrier: the region belongs to this wave alone and a wave's LDS operations execute in order
+    // no block barrier: the region belongs to this wave alone and a wave's LDS operations execute in order
+    wave_lds_fence();
     // pass B: lane (k1 = l >> 3, b = l & 7) takes T1[k1][b + 8 a], twiddle W64^(b q1) = W512^(8 b q1)
     {
         const int k1 = l >> 3, b = l & 7;
@@ -92,12 +94,14 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
         for (int q1 = 0; q1 < 8; q1++) pen[(k1 * 8 + q1) * 9 + b] = a[q1];
     }
     // pass C: lane (k1 = l & 7, q1 = l >> 3) takes T2[k1][q1][b]; output X[k1 + 8 q1 + 64 q2] = X[l + 64 q2]
+    wave_lds_fence();
     {
         const int k1 = l & 7, q1 = l >> 3;
 #pragma unroll
         for (int b = 0; b < 8; b++) a[b] = pen[(k1 * 8 + q1) * 9 + b];
         fft8<S>(a);
     }
+    wave_lds_fence();
 }
 
 struct Spec000 {
@@ -259,13 +263,8 @@ template <int MODE, int NP>
 static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_other, int nxs, int nother,
                      const Spec000 &sp, double2 *xbuf, int ys)
 {
-    static bool attr = false;
     const int lds = sizeof(double2) * (NP * FP + 256);
-    if (!attr) {
-        X3D_HIP(hipFuncSetAttribute((const void *)k_fft512<MODE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds));
-        attr = true;
-    }
+    X3D_LDS_OPTIN(b, (k_fft512<MODE, NP>));
     dim3 grid((nxs + NP - 1) / NP, nother);
     hipLaunchKernelGGL((k_fft512<MODE, NP>), grid, dim3(64 * NP), lds, b->stream, c, g_tw, stride_axis,
                        stride_other, nxs, sp, xbuf, ys);
@@ -353,6 +352,7 @@ __global__ void __launch_bounds__(512)
         fft512_wave<-1>(a, pen, tws, l);
 #pragma unroll
         for (int k = 0; k < 8; k++) pen[l + 64 * k] = a[k];  // (wave-private region, LDS operations in order)
+        wave_lds_fence();
         double2 *__restrict__ ca = c + 2 * pr * crow, *__restrict__ cb = ca + crow;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -369,12 +369,8 @@ __global__ void __launch_bounds__(512)
 int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow)
 {
     X3D_REQUIRE(g_tw && nrows % 2 == 0, "x3d_fft512_r2c: not initialised / odd number of rows");
-    static bool attr = false;
     const int lds = sizeof(double2) * (8 * FP + 256);
-    if (!attr) {
-        X3D_HIP(hipFuncSetAttribute((const void *)k_r2c512, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    X3D_LDS_OPTIN(b, k_r2c512);
     const long npairs = nrows / 2;
     long blocks = (npairs + 7) / 8;
     if (blocks > 2048) blocks = 2048;

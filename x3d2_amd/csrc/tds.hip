@@ -75,7 +75,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             QB[j] = pr;
         }
     }
-    // the same for 16-row chunks (onchip_transeq.hip)
+    // the same for 16-row chunks (onchip.hip, 256-row pencils)
     std::vector<double> PF16(L, 0.0), QB16(L, 0.0);
     for (int s0 = 1; s0 <= nr; s0 += 16) {
         const int t0 = s0 + 15 < nr ? s0 + 15 : nr;
@@ -251,11 +251,8 @@ __device__ __forceinline__ long pencil_base(const PencilGeom &g, int p)
     return (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1;
 }
 
-// forward sweep, one operator (der_univ_dist without its backward loop).
-// CKPT: keep only every X3D_CK-th forward-eliminated value (compact buffer
-// [j/CK][pencil]); the block-recompute backward kernel of fused.hip rebuilds
-// the rest from the inputs.
-template <bool HB, bool CKPT>
+// forward sweep, one operator (der_univ_dist without its backward loop)
+template <bool HB>
 __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *__restrict__ send_s,
                                                 double *__restrict__ send_e, const double *__restrict__ u,
                                                 const double *__restrict__ hs, const double *__restrict__ he,
@@ -274,11 +271,7 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
         const double acc = dot9(c, w);
         const double dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
         if (j <= n) {
-            if (CKPT) {
-                if (j % X3D_CK == 0) d[(long)(j / X3D_CK) * g.np + p] = dj;
-            } else {
-                __builtin_nontemporal_store(dj, &d[base + (long)(j - 1) * rs]);
-            }
+            __builtin_nontemporal_store(dj, &d[base + (long)(j - 1) * rs]);
             S += T_W(t, j) * dj;
             if (j == 1) d1 = dj;
             if (j == n) dn = dj;
@@ -373,7 +366,7 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const d
 
 // forward sweep of one transport-equation component: three operators share
 // the loads of u and conv (exec_dist.f90:114-160)
-template <bool HB, bool SAME, bool CKPT>
+template <bool HB, bool SAME>
 __global__ void __launch_bounds__(64)
     k_transeq_fwd(double *__restrict__ d_du, double *__restrict__ d_dud, double *__restrict__ d_d2u,
                   double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
@@ -400,12 +393,7 @@ __global__ void __launch_bounds__(64)
         const double e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
         const double e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
         const double e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
-        if (CKPT) {
-            if (j % X3D_CK == 0) {  // compact [j/CK][op][pencil] in d_du
-                const long o = (long)(j / X3D_CK) * 3 * g.np + p;
-                d_du[o] = e1; d_du[o + g.np] = e2; d_du[o + 2 * (long)g.np] = e3;
-            }
-        } else {
+        {
             const long o = base + (long)(j - 1) * rs;
             __builtin_nontemporal_store(e1, &d_du[o]); __builtin_nontemporal_store(e2, &d_dud[o]);
             __builtin_nontemporal_store(e3, &d_d2u[o]);
@@ -549,21 +537,6 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 }
 
 // ------------------------------------------------------------------ launchers
-// fused.hip: block-recompute backward sweep (checkpoint form)
-int x3d_ck_bwd_tds(x3d_backend *b, double *du, const double *u, const double *hs, const double *he,
-                   const double *ckpt, const double *own_s, const double *recv_s, const double *recv_e,
-                   const x3d_tdsops *t, int dir, int acc, double scale);
-int x3d_ck_bwd_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *us, const double *ue,
-                       const double *conv, const double *cs, const double *ce, const double *ckpt,
-                       const double *own_s, const double *recv_s, const double *recv_e, int bstride, double nu,
-                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
-static int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                               double scale);
-static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
-                                   int acc);
-int x3d_onchip_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                   double scale);  // onchip.hip
 int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
                     bool *done);  // onchip.hip (K1e)
 static bool use_onchip2()
@@ -577,8 +550,6 @@ static bool use_onchip2()
     }
     return mode == 1;
 }
-int x3d_onchip_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
-                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // viax.hip
@@ -588,39 +559,6 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
                        const x3d_tdsops *op_i, double scale, bool *done);  // xscan.hip
-static bool use_onchip_transeq()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("X3D_ONCHIP_TRANSEQ");
-        mode = (e && e[0] == '1') ? 1 : 0;
-    }
-    return mode == 1;
-}
-static bool use_onchip()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        // opt-in: the single-pass on-chip solve halves the HBM traffic of tds_solve but
-        // is issue-bound on MI355X (one 16-wave workgroup per CU) and only matches the
-        // two-sweep kernels' time (profiles/README.md)
-        const char *e = getenv("X3D_ONCHIP");
-        mode = (e && e[0] == '1') ? 1 : 0;
-    }
-    return mode == 1;
-}
-static bool use_fused_kernels()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        // the checkpoint/recompute form is kept for experiments: on MI355X its
-        // backward kernel is register-bound (255 VGPRs, 1 wave/SIMD) and slower
-        // than streaming the intermediates (profiles/README.md)
-        const char *e = getenv("X3D_CHECKPOINT");
-        mode = (e && e[0] == '1') ? 1 : 0;
-    }
-    return mode == 1;
-}
 // xdir.hip
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
@@ -664,7 +602,7 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
     (void)du;  // the eliminated values stay in backend scratch until x3d_tds_dist_bwd
-    hipLaunchKernelGGL((k_tds_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2], du_send_s,
+    hipLaunchKernelGGL((k_tds_fwd<true>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2], du_send_s,
                        du_send_e, u, u_recv_s, u_recv_e, t->tab, g, t->n_tds);
     X3D_HIP(hipGetLastError());
     return 0;
@@ -709,8 +647,6 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
         if (int rc = x3d_onchip2_tds(b, du, u, t, dir, accumulate, scale, &done)) return rc;
         if (done) return 0;
     }
-    if (use_onchip() && t->n_rhs <= 512) return x3d_onchip_tds(b, du, u, t, dir, accumulate, scale);
-    if (use_fused_kernels()) return x3d_fused_tds_local(b, du, u, t, dir, accumulate, scale);
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
@@ -777,7 +713,7 @@ int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d
     double *d = b->scratch[2];
     {
         ProfScope ps(b, X3D_K_TDS_FWD, dir);
-        hipLaunchKernelGGL((k_tds_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
+        hipLaunchKernelGGL((k_tds_fwd<false>), grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
                            (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
     }
     {
@@ -824,7 +760,7 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     // [3][npencil] boundary buffers are contiguous with stride np
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
     (void)rhs;
-    hipLaunchKernelGGL((k_transeq_fwd<true, false, false>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2],
+    hipLaunchKernelGGL((k_transeq_fwd<true, false>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2],
                        b->scratch[0], b->scratch[1], send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e,
                        t_du->tab, t_dud->tab, t_d2u->tab, g, t_du->n_tds, g.np);
     X3D_HIP(hipGetLastError());
@@ -865,18 +801,12 @@ static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const d
                                    int acc)
 {
     if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
-    if (!use_onchip_transeq() && !use_fused_kernels()) {
+    {
         // K3y (xscan.hip): periodic 256 / 512-row pencils straight from the Cartesian block
         bool done = false;
         if (int rc = x3d_ytile_transeq(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;
         if (done) return 0;
     }
-    if (use_onchip_transeq()) {
-        bool done = false;
-        if (int rc = x3d_onchip_transeq(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, &done)) return rc;
-        if (done) return 0;
-    }
-    if (use_fused_kernels()) return x3d_fused_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
     return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
 }
 
@@ -891,11 +821,11 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
         if (u == conv)
-            hipLaunchKernelGGL((k_transeq_fwd<false, true, false>), grid_for(g), dim3(64), 0, b->stream, d1,
+            hipLaunchKernelGGL((k_transeq_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
         else
-            hipLaunchKernelGGL((k_transeq_fwd<false, false, false>), grid_for(g), dim3(64), 0, b->stream, d1,
+            hipLaunchKernelGGL((k_transeq_fwd<false, false>), grid_for(g), dim3(64), 0, b->stream, d1,
                                b->scratch[0], b->scratch[1], b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab,
                                t2->tab, t3->tab, g, t1->n_tds, npm);
     }
@@ -951,7 +881,7 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
             return rc;
         if (done) return 0;
     }
-    if (dir != X3D_DIR_X && !use_onchip_transeq() && !use_fused_kernels()) {
+    if (dir != X3D_DIR_X) {
         // K3t (viax.hip): periodic pencils of 256 / 512 rows go through the single-pass scan kernel
         bool done = false;
         if (int rc = x3d_transeq_via_x(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;
@@ -1004,46 +934,4 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
     return transeq_component_local(b, dir, dspec, spec, uvw, nu, der1st, der1st_sym, der2nd, accumulate);
-}
-
-// ------------------------------------------------------------------ checkpoint form, local
-// forward kernel keeps 1/CK of the eliminated values; the backward kernel
-// (fused.hip) recomputes each block from the inputs.  ~7 field passes per
-// transport-equation component instead of 10-11, 3.5 instead of 4 per tds_solve.
-static int x3d_fused_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                               double scale)
-{
-    PencilGeom g = x3d_geom(b, dir);
-    const double *z = nullptr;
-    {
-        ProfScope ps(b, X3D_K_TDS_FWD, dir);
-        hipLaunchKernelGGL((k_tds_fwd<false, true>), grid_for(g), dim3(64), 0, b->stream, b->scratch[2],
-                           b->send_s, b->send_e, u, z, z, t->tab, g, t->n_tds);
-    }
-    X3D_HIP(hipGetLastError());
-    return x3d_ck_bwd_tds(b, du, u, z, z, b->scratch[2], b->send_s, b->send_e, b->send_s, t, dir, acc, scale);
-}
-
-static int x3d_fused_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
-                                   int acc)
-{
-    PencilGeom g = x3d_geom(b, dir);
-    const int npm = npmax_of(b);
-    const double *z = nullptr;
-    double *ck = b->scratch[2];
-    {
-        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-        if (u == conv)
-            hipLaunchKernelGGL((k_transeq_fwd<false, true, true>), grid_for(g), dim3(64), 0, b->stream, ck, ck, ck,
-                               b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab, t2->tab, t3->tab, g, t1->n_tds,
-                               npm);
-        else
-            hipLaunchKernelGGL((k_transeq_fwd<false, false, true>), grid_for(g), dim3(64), 0, b->stream, ck, ck, ck,
-                               b->send_s, b->send_e, u, z, z, conv, z, z, t1->tab, t2->tab, t3->tab, g, t1->n_tds,
-                               npm);
-    }
-    X3D_HIP(hipGetLastError());
-    return x3d_ck_bwd_transeq(b, dir, rhs, u, z, z, conv, z, z, ck, b->send_s, b->send_e, b->send_s, npm, nu, t1,
-                              t2, t3, acc);
 }

@@ -1336,12 +1336,7 @@ static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const do
                           const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int np, int blocks,
                           size_t lds, long pitch)
 {
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-        X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq<Q, SAME, ACC, FAST>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    X3D_LDS_OPTIN(b, (k_xscan_transeq<Q, SAME, ACC, FAST>));  // > 64 KB of dynamic LDS needs the opt-in
     hipLaunchKernelGGL((k_xscan_transeq<Q, SAME, ACC, FAST>), dim3(blocks), dim3(FAST ? XS_TQ_THREADS : 512), lds, b->stream, rhs, u, conv, xop_of(t1),
                        xop_of(t2), xop_of(t3), np, pitch, nu);
     X3D_HIP(hipGetLastError());
@@ -1378,12 +1373,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
         const int blocks2 = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
 #define LP2(Q_, S_, A_, N_)                                                                                    \
         do {                                                                                                   \
-            static bool at = false;                                                                            \
-            if (!at) {                                                                                         \
-                X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2<Q_, S_, A_, N_>,                    \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-                at = true;                                                                                     \
-            }                                                                                                  \
+            X3D_LDS_OPTIN(b, (k_xscan_transeq2<Q_, S_, A_, N_>));                                              \
             hipLaunchKernelGGL((k_xscan_transeq2<Q_, S_, A_, N_>), dim3(blocks2), dim3(512), lds, b->stream, rhs, u, \
                                conv, xop_of(t1), xop_of(t2), xop_of(t3), np, pitch, nu);                       \
         } while (0)
@@ -1437,12 +1427,7 @@ static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const doub
                         const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds,
                         int dir, const TileEpi *epi)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq<Q, SAME, ACC, FAST>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    X3D_LDS_OPTIN(b, (k_ytile_transeq<Q, SAME, ACC, FAST>));
     // y: rows nxp apart, one tile row per z plane; z: rows nxp * nyp apart, one tile row per y
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
@@ -1450,12 +1435,7 @@ static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const doub
     if (epi) {
         // one device slot is enough: copy and kernel are ordered on the backend's stream
         X3D_HIP(hipMemcpyAsync(b->epi_dev, epi, sizeof(TileEpi), hipMemcpyHostToDevice, b->stream));
-        static bool at2 = false;
-        if (!at2) {
-            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq<Q, SAME, true, FAST, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            at2 = true;
-        }
+        X3D_LDS_OPTIN(b, (k_ytile_transeq<Q, SAME, true, FAST, true>));
         hipLaunchKernelGGL((k_ytile_transeq<Q, SAME, true, FAST, true>), dim3(blocks), dim3(1024), lds, b->stream, rhs, u,
                            conv, xop_of(t1), xop_of(t2), xop_of(t3), share12, ntx, ntiles,
                            dir == X3D_DIR_Y ? (long)b->nxp : pxy, dir == X3D_DIR_Y ? pxy : (long)b->nxp, nu,
@@ -1563,12 +1543,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_)                                                                                          \
     do {                                                                                                        \
-        static bool at = false;                                                                                 \
-        if (!at) {                                                                                              \
-            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_tds_pair<Q_, M_, N_>,                             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-            at = true;                                                                                          \
-        }                                                                                                       \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_>));                                                       \
         hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, in1, \
                            in2, xop_of(ta), xop_of(tb), ntx, ntiles, rstride, ostride);                        \
     } while (0)
@@ -1604,12 +1579,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
 #define GO(Q_, A_, N_)                                                                                          \
     do {                                                                                                        \
-        static bool at = false;                                                                                 \
-        if (!at) {                                                                                              \
-            X3D_HIP(hipFuncSetAttribute((const void *)k_ytile_transeq3<Q_, A_, N_>,                             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-            at = true;                                                                                          \
-        }                                                                                                       \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_>));                                                       \
         hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
                            f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, ntiles, rstride, ostride, nu); \
     } while (0)
@@ -1665,12 +1635,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     const x3d_tdsops *ts = upd ? op_s : der1st, *ti = upd ? op_i : der1st;
 #define GO(Q_, A_, N_, U_)                                                                                      \
     do {                                                                                                        \
-        static bool at = false;                                                                                 \
-        if (!at) {                                                                                              \
-            X3D_HIP(hipFuncSetAttribute((const void *)k_xscan_transeq2x3<Q_, A_, N_, U_>,                       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-            at = true;                                                                                          \
-        }                                                                                                       \
+        X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_>));                                                 \
         hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
                            r[2], (double *)f[0], (double *)f[1], (double *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
                            (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti));                                       \

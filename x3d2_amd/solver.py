@@ -96,6 +96,8 @@ class Solver:
         else:
             raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
         self.pending_grad = None
+        # readers of field data outside step() (get_field_data) first complete a pending velocity correction
+        backend.before_read.append(self.flush_grad)
         self.transeq = self.transeq_fused if self.fused else self.transeq_default
         if self.fused:
             self.pressure_correction = self.pressure_correction_fused
