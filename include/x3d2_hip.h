@@ -95,6 +95,36 @@ int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tds
  * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
 int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+/* ---- decomposed (BC_HALO) y / z directions in ONE pass + a boundary-strip correction, and plane ranges.
+ * The reference's exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-65, 67-186)
+ * sweep, exchange one boundary value per pencil and operator with pprev / pnext, and sweep again.  Here the tile
+ * kernels do the whole local solve in one pass with the neighbours' boundary values taken as zero and hand out
+ * their own (bnd_send); after the exchange x3d_*_halo_fix adds what the received values contribute -- on the rows
+ * where dist_sa / dist_sc are still above 2^-60 (the decay src/tdsops.f90:196-201 relies on for its 2 x 2
+ * truncation).  Same linear system as the reference's.  Buffers (device):
+ *   halo rows  [side 2][field nf][4][np]: side 0 = rows 1..4 (sent to pprev) / rows -3..0 (received from pprev),
+ *                                         side 1 = rows n-3..n (to pnext) / n+1..n+4 (from pnext)
+ *              (copy_into_buffers + sendrecv_fields, src/backend/omp/backend.f90:714-737, sendrecv.f90:10-36)
+ *   boundary   [side 2][nb][np]: send side 0 = du_1 (to pprev), 1 = du_n (to pnext); recv side 0 = pprev's du_n,
+ *              1 = pnext's du_1 (exec_dist.f90:52-54, 163-168)
+ * x3d_transeq_tile / x3d_tds_pair_tile with halo_recv == bnd_send == NULL are the local (periodic) forms over a
+ * range of planes [other0, other0 + nother) (nother < 0: all), for overlapping an exchange with the remaining
+ * planes.  *done == 0: pencils not served by the tile kernels, nothing was written. */
+int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2]); /* rows 1..out[0], n-out[1]+1..n get a correction */
+int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir);
+int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
+                     const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                     const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int accumulate, const double *halo_recv,
+                     double *bnd_send, int other0, int nother, int *done);
+int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
+                         const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der2nd,
+                         const double *bnd_recv);
+/* modes 0, 1 of x3d_tds_solve_pair, mode 2: out1 = A(in1) */
+int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                      const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
+                      double *bnd_send, int other0, int nother, int *done);
+int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const x3d_tdsops *ta,
+                          const x3d_tdsops *tb, const double *bnd_recv);
 /* fusion extension: y = base + sum_i c[i]*x[i] (x3d_lincomb: the RK / AB stage) followed by du = tds_solve(y)
  * (the first x operators of divergence_v2c): one kernel for periodic 256 / 512-point x pencils, y is not read
  * back; otherwise the two calls one after the other.  y may be base. */

@@ -28,7 +28,7 @@ def battery(name, fused, rank, comm):
     from x3d2_amd.backend import HipBackend
     from x3d2_amd.common import DIR_X, DIR_Z, VERT, move_data_loc
     from x3d2_amd.solver import Solver, SolverConfig
-    g = load_golden(name)
+    g = dict(np.load(name)) if name.endswith(".npz") else load_golden(name)
     c = namelist(g)
     mesh = product_mesh(c, rank)
     d = 1 + [int(p) > 1 for p in c["nproc"]].index(True)
@@ -77,6 +77,7 @@ def battery(name, fused, rank, comm):
         s.time_integrator.step(curr, rhs, s.dt)
     for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
         out["step2." + k] = b.get_field_data(f)
+    out["halo_launches"] = np.array([b.halo_launches])
     return out
 
 

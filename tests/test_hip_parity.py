@@ -369,6 +369,7 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0):
             a = p[name]
             full[oz:oz + a.shape[0], oy:oy + a.shape[1], ox:ox + a.shape[2]] = a
         g[name] = full
+    g["halo_launches"] = int(parts[0]["halo_launches"][0])
     return g, parts[0]["rows"]
 
 
@@ -376,7 +377,12 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0):
                                                   ((1, 2, 2), True, (48, 96, 96)),
                                                   ((1, 1, 4), True, (32, 48, 192)),   # bench layout: z slabs
                                                   ((1, 1, 2), True, (16, 512, 128)),  # ny = 512: slab FFT solver
-                                                  ((1, 1, 4), False, (16, 512, 192))])
+                                                  ((1, 1, 4), False, (16, 512, 192)),
+                                                  # 256 / 512 rows per rank: single-pass HALO kernels + strip corrections
+                                                  ((1, 1, 2), True, (32, 512, 512)),   # slab solver, z halo, y local tile
+                                                  ((1, 2, 1), True, (32, 512, 64)),    # y halo
+                                                  ((1, 2, 2), True, (32, 512, 512)),   # y and z halo, pencil solver
+                                                  ((1, 1, 2), False, (32, 64, 1024))])
 def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_path):
     """DistD2 across ranks (halo + reduced-system exchange) and the pencil FFT
     Poisson solver: ranks share cuda:0 and exchange through gloo; the result
@@ -384,6 +390,10 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
     (dist_sa(n_local) ~ 1e-16 for >= 40 points per rank, src/tdsops.f90:196-201)."""
     from x3d2_amd import make_tgv
     g, rows = _run_ranks(nproc_dir, dims, 2, fused, "FFT", tmp_path)
+    halo = g.pop("halo_launches")
+    local = [d // p for d, p in zip(dims, nproc_dir)]
+    if any(p > 1 and n in (256, 512) for p, n in zip(nproc_dir[1:], local[1:])) and dims[0] % 16 == 0:
+        assert halo > 0  # 256 / 512 rows per rank: the single-pass kernels must have taken the decomposed direction
     ref = make_tgv(dims, fused=fused)
     ref.solver.n_output = 2
     rrows = ref.run(n_iters=2)
@@ -429,6 +439,31 @@ def test_two_rank_operators_vs_reference_two_rank_run(name, dn, fused, tmp_path)
         assert abs(p["div.maxmean"][0] - g["div.max"][0]) <= 1e-12 * g["div.max"][0]
         assert abs(p["div.maxmean"][1] - g["div.mean"][0]) <= 1e-12 * g["div.mean"][0]
         assert abs(p["curl.enstrophy"][0] - g["curl.enstrophy"][0]) <= 1e-12 * g["curl.enstrophy"][0]
+
+
+@pytest.mark.parametrize("dims,nproc,dn,fused", [((32, 16, 512), (1, 1, 2), "z", False), ((32, 16, 512), (1, 1, 2), "z", True),
+                                                 ((32, 512, 16), (1, 2, 1), "y", True),
+                                                 ((32, 16, 1024), (1, 1, 2), "z", True)])
+def test_two_rank_single_pass_kernels_vs_oracle(dims, nproc, dn, fused, tmp_path):
+    """256 / 512 points per rank along the split direction: the decomposed direction runs on the single-pass
+    tile kernels (HALO forms: neighbour rows from the exchange, own boundary values out, boundary-strip
+    correction after the second exchange) instead of the two-sweep DistD2 kernels.  Every operator of the
+    split direction, transeq + species, divergence, gradient, curl, two RK3 steps on two ranks sharing cuda:0
+    against the ORACLE on two ranks (the oracle's distributed form is pinned to the reference's two-rank run in
+    test_oracle_vs_reference.py)."""
+    from util import BATTERY_FIELDS, oracle_battery, stitch_ranks, synthetic_case
+    g = synthetic_case(dims, nproc)
+    path = str(tmp_path / "case.npz")
+    np.savez(path, **g)
+    parts = _run_fixture_worker([path, "fused" if fused else "op"], tmp_path, 29523)
+    offs = [p["offset"] for p in parts]
+    assert all(int(p["halo_launches"][0]) >= 8 + 3 * 7 for p in parts)  # the single-pass path did run
+    full, oparts = oracle_battery(g, 2)
+    for k in BATTERY_FIELDS(dn):
+        assert relerr(stitch_ranks(parts, offs, k), full[k]) < TOL, k
+    for p, o in zip(parts, oparts):
+        assert relerr(p["species.rhs"], o["species.rhs"]) < TOL
+        assert abs(p["curl.enstrophy"][0] - o["curl.enstrophy"][0]) <= 1e-12 * o["curl.enstrophy"][0]
 
 
 def test_tgv_trace_two_ranks_vs_reference_two_rank_run(tmp_path):

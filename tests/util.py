@@ -123,3 +123,113 @@ def stitch_ranks(parts, offsets, name):
         ox, oy, oz = (int(v) for v in o)
         full[oz:oz + a.shape[0], oy:oy + a.shape[1], ox:ox + a.shape[2]] = a
     return full
+
+
+def BATTERY_FIELDS(dn):
+    return [f"tds.{dn}.{op}" for op in OPNAMES] + ["transeq.du", "transeq.dv", "transeq.dw", "div.div_u", "grad.dpdx",
+            "grad.dpdy", "grad.dpdz", "curl.i", "curl.j", "curl.k", "step2.u", "step2.v", "step2.w"]
+
+
+def oracle_battery(g, nranks):
+    """the operator sequence oracle/ref/drivers/dump_golden.f90 drives the reference with, on the ORACLE with
+    nranks ranks (threads exchanging in lock step) decomposed as the namelist in g says; inputs g["in.*"] are
+    global arrays.  Returns (dict of stitched global fields, list of per-rank dicts)."""
+    from oracle import x3d_oracle as orc
+    c = namelist(g)
+    d = 1 + [int(p) > 1 for p in c["nproc"]].index(True)
+    dn = "xyz"[d - 1]
+
+    def local(key, mesh):
+        ox, oy, oz = (int(v) for v in mesh.n_offset)
+        nx, ny, nz = (int(v) for v in mesh.vert_dims)
+        return g[key][oz:oz + nz, oy:oy + ny, ox:ox + nx]
+
+    def body(rank, comm):
+        mesh = orc.Mesh(c["dims"], c["nproc"], c["L"], c["bcx"], c["bcy"], c["bcz"], c["stretching"], c["beta"],
+                        rank=rank)
+        s = orc.Solver(mesh, Re=c["Re"], dt=c["dt"], time_intg=c["time_intg"], poisson="CG", comm=comm,
+                       interpl=c["interpl"], der2nd=c["der2nd"])
+        b = s.backend
+        out = {}
+        for f, k in ((s.u, "in.u"), (s.v, "in.v"), (s.w, "in.w")):
+            f.data_loc = orc.VERT
+            b.set_field_data(f, local(k, s.mesh))
+        dp = (s.xdirps, s.ydirps, s.zdirps)[d - 1]
+        for op in OPNAMES:
+            src = b.get_block(orc.DIR_X, orc.VERT)
+            b.veccopy(src, s.u)
+            if op.endswith("p2v"):
+                src.data_loc = orc.move_data_loc(orc.VERT, d, 1)
+            a, o = b.get_block(d), b.get_block(d)
+            b.reorder(a, src, orc.RDR[(1, d)])
+            b.tds_solve(o, a, getattr(dp, op))
+            out[f"tds.{dn}.{op}"] = b.get_field_data(o)
+        rhs = [b.get_block(orc.DIR_X) for _ in range(3)]
+        s.transeq(rhs, [s.u, s.v, s.w])
+        for f, k in zip(rhs, ("du", "dv", "dw")):
+            out["transeq." + k] = b.get_field_data(f)
+        spec = b.get_block(orc.DIR_X, orc.VERT)
+        b.set_field_data(spec, local("in.s", s.mesh))
+        srhs = b.get_block(orc.DIR_X)
+        s.transeq_species([srhs], [s.u, s.v, s.w, spec], [0.37 * s.nu])
+        out["species.rhs"] = b.get_field_data(srhs, orc.VERT)
+        div_u = b.get_block(orc.DIR_Z)
+        s.divergence_v2p(div_u, s.u, s.v, s.w)
+        out["div.div_u"] = b.get_field_data(div_u)
+        out["div.maxmean"] = np.array(b.field_max_mean(div_u))
+        s.gradient_p2v(*rhs, div_u)
+        for f, k in zip(rhs, ("dpdx", "dpdy", "dpdz")):
+            out["grad." + k] = b.get_field_data(f)
+        for f in rhs:
+            f.data_loc = orc.VERT
+        s.curl(*rhs, s.u, s.v, s.w)
+        for f, k in zip(rhs, "ijk"):
+            out["curl." + k] = b.get_field_data(f)
+        out["curl.enstrophy"] = np.array([0.5 * sum(b.scalar_product(f, f) for f in rhs) / s.ngrid])
+        for it in range(2 * s.time_integrator.nstage):
+            r3 = [b.get_block(orc.DIR_X) for _ in range(3)]
+            s.transeq(r3, [s.u, s.v, s.w])
+            s.time_integrator.step([s.u, s.v, s.w], r3, s.dt)
+        for f, k in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+            out["step2." + k] = b.get_field_data(f)
+        return out, s.mesh.n_offset.copy()
+
+    res = run_rank_threads(nranks, body)
+    parts, offs = [r[0] for r in res], [r[1] for r in res]
+    full = {k: stitch_ranks(parts, offs, k) for k in BATTERY_FIELDS(dn) + ["species.rhs"]}
+    return full, parts
+
+
+NML = """&domain_settings
+flow_case_name = 'tgv'
+L_global = 6.283185307179586d0, 6.283185307179586d0, 6.283185307179586d0
+dims_global = {dims}
+nproc_dir = {nproc}
+BC_x = 'periodic', 'periodic'
+BC_y = 'periodic', 'periodic'
+BC_z = 'periodic', 'periodic'
+stretching = 'uniform', 'uniform', 'uniform'
+beta = 1d0, 1d0, 1d0
+/End
+&solver_params
+Re = 1600d0
+time_intg = 'RK3'
+dt = 0.001d0
+interpl_scheme = 'classic'
+der2nd_scheme = 'compact6'
+/End
+"""
+
+
+def synthetic_case(dims, nproc, seed=7):
+    """a fixture-shaped dict (namelist + global inputs) for the operator battery: smooth fields + 10 % noise"""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = dims
+    x = np.arange(nx)[None, None, :] * (2 * np.pi / nx)
+    y = np.arange(ny)[None, :, None] * (2 * np.pi / ny)
+    z = np.arange(nz)[:, None, None] * (2 * np.pi / nz)
+    g = {"cfg.namelist": np.frombuffer(NML.format(dims=", ".join(map(str, dims)),
+                                                  nproc=", ".join(map(str, nproc))).encode(), dtype=np.uint8)}
+    for k, (a, b_, c) in zip(("in.u", "in.v", "in.w", "in.s"), ((1, 2, 1), (2, 1, 3), (1, 1, 2), (3, 2, 1))):
+        g[k] = np.sin(a * x + 0.3) * np.cos(b_ * y) * np.cos(c * z + 0.1) + 0.1 * rng.standard_normal((nz, ny, nx))
+    return g

@@ -9,6 +9,7 @@ happens in libx3d2_hip.so through the C ABI (include/x3d2_hip.h); this class
 only sequences calls and does the neighbour exchanges.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -53,6 +54,7 @@ class HipBackend:
         self._halo = {}
         self._tdsops = []
         self.before_read = []  # callables run before field data leaves the device (Solver.flush_grad)
+        self.halo_launches = 0  # single-pass launches on decomposed directions (tests assert the path engaged)
 
     def __del__(self):
         try:
@@ -143,6 +145,11 @@ class HipBackend:
 
     def _transeq_dist(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate=False):
         """transeq_omp_dist with the permutation of :145-184; accumulate: d* += result (fused driver)"""
+        if self.halo_tile_ok(direction, dirps):  # single-pass kernels + boundary-strip correction
+            h = self.transeq_halo_begin(direction, u, v, w)
+            hb = self.transeq_halo_main(direction, du, dv, dw, u, v, w, nu, dirps, accumulate, h)
+            self.transeq_halo_finish(direction, du, dv, dw, u, v, w, nu, dirps, hb)
+            return
         if direction == DIR_X:
             rhs, fld = (du, dv, dw), (u, v, w)
         elif direction == DIR_Y:
@@ -213,6 +220,222 @@ class HipBackend:
                 self.allocator.release_block(out)
         if not accumulate:
             dspec.set_data_loc(spec.data_loc)
+
+    # ------------------------------------------------------------ decomposed directions, single pass
+    # exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-186) on the tile
+    # kernels' HALO forms (csrc/xscan.hip): begin = pack the 4 + 4 boundary rows and start their exchange,
+    # main = the whole local solve in one kernel (waits for the rows; starts the exchange of its boundary
+    # values), finish = the contribution of the neighbours' boundary values on the boundary strips.  The
+    # handles let the caller put independent kernels between the three calls (parallel.Comm.isendrecv).
+    def _halo_buffers(self, direction, nf, nb, tag):
+        key = ("halo", direction, nf, nb, tag)
+        if key not in self._halo:
+            npn = self.lib.x3d_npencils(self.h, direction)
+            z = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+            self._halo[key] = (z(2 * nf * N_HALO * npn), z(2 * nf * N_HALO * npn), z(2 * nb * npn), z(2 * nb * npn))
+        return self._halo[key]
+
+    @staticmethod
+    def _halves(t):
+        h = t.numel() // 2
+        return t[:h], t[h:]
+
+    def _neighbours(self, direction):
+        d = direction - 1
+        return int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
+
+    @staticmethod
+    def _component_order(direction, a, b, c):
+        """the advecting component first (src/backend/omp/backend.f90:145-184)"""
+        return (a, b, c) if direction == DIR_X else ((b, a, c) if direction == DIR_Y else (c, a, b))
+
+    def halo_tile_ok(self, direction, dirps):
+        """the single-pass kernels take this decomposed direction's transeq (probe: a launch over zero planes)"""
+        if direction == DIR_X or not self._decomposed(direction) or os.environ.get("X3D_NO_HALO_TILE") == "1":
+            return False
+        key = ("tq_ok", direction, id(dirps))
+        if key not in self._halo:
+            hs, hr, bs, br = self._halo_buffers(direction, 3, 9, "tq")
+            flag = ctypes.c_int(0)
+            p = hr.data_ptr()  # (any valid device address: nothing is launched)
+            _lib.check(self.lib.x3d_transeq_tile(self.h, direction, p, p + 8, p + 16, p + 24, p + 32, p + 40, 0.0,
+                                                 dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                                 dirps.der2nd_sym.handle, 1, hr.data_ptr(), bs.data_ptr(), 0, 0,
+                                                 ctypes.byref(flag)))
+            self._halo[key] = bool(flag.value)
+        return self._halo[key]
+
+    def transeq_halo_begin(self, direction, u, v, w):
+        f = self._component_order(direction, u, v, w)
+        hs, hr, _, _ = self._halo_buffers(direction, 3, 9, "tq")
+        n = self.mesh.get_n(direction, u.data_loc)
+        ptrs = (VP * 3)(*[x.ptr for x in f])
+        _lib.check(self.lib.x3d_pack_halos_multi(self.h, hs.data_ptr(), ptrs, 3, n, direction))
+        return self.comm.isendrecv([self._halves(hs) + self._halves(hr)], *self._neighbours(direction))
+
+    def transeq_halo_main(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate, handle):
+        _, hr, bs, br = self._halo_buffers(direction, 3, 9, "tq")
+        handle.wait()
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_tile(self.h, direction, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
+                                             dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                             dirps.der2nd_sym.handle, int(bool(accumulate)), hr.data_ptr(),
+                                             bs.data_ptr(), 0, -1, ctypes.byref(flag)))
+        if not flag.value:
+            raise X3dError("transeq_halo_main: tile kernel refused (halo_tile_ok was not consulted)")
+        self.halo_launches += 1
+        return self.comm.isendrecv([self._halves(bs) + self._halves(br)], *self._neighbours(direction))
+
+    def transeq_halo_finish(self, direction, du, dv, dw, u, v, w, nu, dirps, handle):
+        _, _, _, br = self._halo_buffers(direction, 3, 9, "tq")
+        handle.wait()
+        _lib.check(self.lib.x3d_transeq_halo_fix(self.h, direction, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr,
+                                                 float(nu), dirps.der1st.handle, dirps.der2nd.handle, br.data_ptr()))
+
+    def transeq_planes(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate, other0, nother):
+        """transeq_<dir> of a LOCAL y / z direction over the planes [other0, other0 + nother) of the coordinate
+        its tiles are stacked along (z for y pencils); False: these pencils are not served by the tile kernel"""
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_tile(self.h, direction, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
+                                             dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                             dirps.der2nd_sym.handle, int(bool(accumulate)), None, None, int(other0),
+                                             int(nother), ctypes.byref(flag)))
+        return bool(flag.value)
+
+    # jobs: (mode, out1, out2, in1, in2, ta, tb) with the modes of x3d_tds_pair_tile
+    def _job_sizes(self, job):
+        return (2 if job[0] == 0 else 1), (1 if job[0] == 2 else 2)
+
+    def tds_tile_ok(self, direction, job, halo):
+        """the tile kernel takes this job (probe: zero planes)"""
+        mode, out1, out2, in1, in2, ta, tb = job
+        key = ("tds_ok", direction, mode, id(ta), id(tb), bool(halo))
+        if key not in self._halo:
+            if os.environ.get("X3D_NO_HALO_TILE") == "1" and halo:
+                self._halo[key] = False
+            else:
+                flag = ctypes.c_int(0)
+                hp = bp = None
+                if halo:
+                    nf, nb = self._job_sizes(job)
+                    _, hr, bs, _ = self._halo_buffers(direction, nf, nb, "job0")
+                    hp, bp = hr.data_ptr(), bs.data_ptr()
+                _lib.check(self.lib.x3d_tds_pair_tile(
+                    self.h, direction, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
+                    in2.ptr if in2 is not None else None, ta.handle, tb.handle if tb is not None else None, hp, bp, 0, 0,
+                    ctypes.byref(flag)))
+                self._halo[key] = bool(flag.value)
+        return self._halo[key]
+
+    def tds_tile_planes(self, direction, job, other0, nother):
+        """one job of a LOCAL direction over a range of planes (tile kernel)"""
+        mode, out1, out2, in1, in2, ta, tb = job
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_tds_pair_tile(
+            self.h, direction, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
+            in2.ptr if in2 is not None else None, ta.handle, tb.handle if tb is not None else None, None, None,
+            int(other0), int(nother), ctypes.byref(flag)))
+        if not flag.value:
+            raise X3dError("tds_tile_planes: tile kernel refused (tds_tile_ok was not consulted)")
+
+    def tds_job_local(self, direction, job):
+        """one job of a local direction with the default kernels (pair kernel / K1e / two-sweep)"""
+        mode, out1, out2, in1, in2, ta, tb = job
+        if mode == 2:
+            self.tds_apply(out1, in1, ta, direction)
+        else:
+            self.tds_pair(mode, out1, out2, in1, in2, ta, tb, direction)
+
+    def tds_halo_begin(self, direction, job, k):
+        mode, out1, out2, in1, in2, ta, tb = job
+        nf, nb = self._job_sizes(job)
+        hs, hr, _, _ = self._halo_buffers(direction, nf, nb, "job%d" % k)
+        ptrs = (VP * nf)(*[f.ptr for f in (in1, in2)[:nf]])
+        _lib.check(self.lib.x3d_pack_halos_multi(self.h, hs.data_ptr(), ptrs, nf, ta.n_tds, direction))
+        return self.comm.isendrecv([self._halves(hs) + self._halves(hr)], *self._neighbours(direction))
+
+    def tds_halo_main(self, direction, job, k, handle):
+        mode, out1, out2, in1, in2, ta, tb = job
+        nf, nb = self._job_sizes(job)
+        _, hr, bs, br = self._halo_buffers(direction, nf, nb, "job%d" % k)
+        handle.wait()
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_tds_pair_tile(
+            self.h, direction, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
+            in2.ptr if in2 is not None else None, ta.handle, tb.handle if tb is not None else None, hr.data_ptr(),
+            bs.data_ptr(), 0, -1, ctypes.byref(flag)))
+        if not flag.value:
+            raise X3dError("tds_halo_main: tile kernel refused (tds_tile_ok was not consulted)")
+        self.halo_launches += 1
+        return self.comm.isendrecv([self._halves(bs) + self._halves(br)], *self._neighbours(direction))
+
+    def tds_halo_finish(self, direction, job, k, handle):
+        mode, out1, out2, in1, in2, ta, tb = job
+        nf, nb = self._job_sizes(job)
+        _, _, _, br = self._halo_buffers(direction, nf, nb, "job%d" % k)
+        handle.wait()
+        _lib.check(self.lib.x3d_tds_pair_halo_fix(self.h, direction, mode, out1.ptr,
+                                                  out2.ptr if out2 is not None else None, ta.handle,
+                                                  tb.handle if tb is not None else None, br.data_ptr()))
+
+    def tds_jobs(self, direction, jobs, lead=None, after_lead=None, between=None):
+        """run tds_solve jobs of one direction.
+        Local direction: lead = list of (other0, nother) plane ranges to do FIRST, after which after_lead() is
+        called (it starts the next direction's halo exchange on those planes) and the remaining planes follow.
+        Decomposed direction: pack + exchange the boundary rows, single-pass kernels, exchange the boundary
+        values, between() (kernels that do not depend on this direction's strips), strip corrections.
+        Falls back to the default kernels (tds_pair / tds_apply: two-sweep DistD2 where decomposed)."""
+        if not self._decomposed(direction):
+            nall = int(self.mesh.vert_dims[2] if direction == DIR_Y else self.mesh.vert_dims[1])
+            if lead and direction != DIR_X and all(self.tds_tile_ok(direction, j, False) for j in jobs):
+                rest, pos = [], 0
+                for o0, no in sorted(lead):
+                    if o0 > pos:
+                        rest.append((pos, o0 - pos))
+                    pos = o0 + no
+                if pos < nall:
+                    rest.append((pos, nall - pos))
+                for rng in lead:
+                    for j in jobs:
+                        self.tds_tile_planes(direction, j, *rng)
+                if after_lead:
+                    after_lead()
+                for rng in rest:
+                    for j in jobs:
+                        self.tds_tile_planes(direction, j, *rng)
+            else:
+                for j in jobs:
+                    self.tds_job_local(direction, j)
+                if after_lead:
+                    after_lead()
+            if between:
+                between()
+            return
+        if direction != DIR_X and all(self.tds_tile_ok(direction, j, True) for j in jobs):
+            hs = [self.tds_halo_begin(direction, j, k) for k, j in enumerate(jobs)]
+            hb = [self.tds_halo_main(direction, j, k, hs[k]) for k, j in enumerate(jobs)]
+            if after_lead:
+                after_lead()
+            if between:
+                between()
+            for k, j in enumerate(jobs):
+                self.tds_halo_finish(direction, j, k, hb[k])
+            return
+        for j in jobs:  # two-sweep DistD2 with its own exchanges
+            self.tds_job_local(direction, j)
+        if after_lead:
+            after_lead()
+        if between:
+            between()
+
+    def halo_strip_rows(self, *ops):
+        """(ws, we): rows 1..ws and n-we+1..n are touched by the strip corrections of these operators"""
+        out = (ctypes.c_int * 2)()
+        ws = we = 0
+        for t in ops:
+            _lib.check(self.lib.x3d_tdsops_halo_rows(t.handle, out))
+            ws, we = max(ws, out[0]), max(we, out[1])
+        return ws, we
 
     # ------------------------------------------------------------ fused-driver forms
     def transeq_dir(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate=False):
@@ -343,6 +566,13 @@ class HipBackend:
     def _tds_dist(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact;
         accumulate: du += scale * result (fused driver)"""
+        if not accumulate and direction != DIR_X:
+            job = (2, du, None, u, None, tdsops, None)
+            if self.tds_tile_ok(direction, job, True):  # single-pass kernel + boundary-strip correction
+                h = self.tds_halo_begin(direction, job, 0)
+                hb = self.tds_halo_main(direction, job, 0, h)
+                self.tds_halo_finish(direction, job, 0, hb)
+                return
         d = direction - 1
         prev, nxt = int(self.mesh.pprev[d]), int(self.mesh.pnext[d])
         ss, se, rs, re = self._buffers(direction, N_HALO, "u0")

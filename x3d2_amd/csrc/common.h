@@ -141,8 +141,18 @@ struct x3d_tdsops {
     TdsTab tab;
     double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
+    int halo_ws, halo_we;        // rows 1..ws / n-we+1..n: where |dist_sa| / |dist_sc| >= 2^-60 (xscan.hip, *_halo_fix)
 };
 
 PencilGeom x3d_geom(const x3d_backend *b, int dir);
+
+// decomposed direction through the tile kernels (xscan.hip, HALO forms)
+struct TileHalo {
+    const double *recv;  // halo rows [side 2][field nf][4][np] (side 0: rows -3..0 from prev, 1: n+1..n+4 from next)
+    double *bsend;       // boundary values out [side 2][nb][np]: side 0 = du_1 (goes to prev), 1 = X_n (to next)
+    int np, nf, nb;      // pencils of the direction, fields, operators per pencil
+};
+
+
 
 static inline int x3d_dir_ok(int dir) { return dir >= X3D_DIR_X && dir <= X3D_DIR_Z; }

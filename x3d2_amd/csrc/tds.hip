@@ -190,6 +190,15 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     tb.scn = dist_sc[n - 1];
     tb.rs_s = 1.0 / (1.0 - dist_sa[0] * dist_sa[0]);          // distributed.f90:196-198
     tb.rs_e = 1.0 / (1.0 - dist_sc[n - 1] * dist_sc[n - 1]);  // distributed.f90:203-205
+    // rows that still feel the reduced system's unknowns: |dist_sa(j)| decays from row 1, |dist_sc(j)| from row n
+    // (the same decay lets the reference truncate the coupling to a 2 x 2 system, src/tdsops.f90:196-201)
+    const double tiny = 8.673617379884035e-19;  // 2^-60
+    t->halo_ws = 1;
+    t->halo_we = 1;
+    for (int j = 1; j <= n; j++) {
+        if (fabs(dist_sa[j - 1]) >= tiny) t->halo_ws = j;
+        if (fabs(dist_sc[j - 1]) >= tiny && n - j + 1 > t->halo_we) t->halo_we = n - j + 1;
+    }
     *out = t;
     return 0;
 }
@@ -199,6 +208,15 @@ extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
     if (!t) return 0;
     hipFree(t->dev);
     delete t;
+    return 0;
+}
+
+// rows 1..out[0] and n-out[1]+1..n: where the coupling to the reduced system's unknowns is still above 2^-60,
+// i.e. the rows x3d_*_halo_fix touch
+extern "C" int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2])
+{
+    X3D_REQUIRE(t && out, "x3d_tdsops_halo_rows: null argument");
+    out[0] = t->halo_ws; out[1] = t->halo_we;
     return 0;
 }
 
@@ -536,6 +554,23 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
     }
 }
 
+// the same for nf fields at once, in the layout the HALO tile kernels read and ONE message per neighbour carries:
+// send[side][field][4][np], side 0 = rows 1..4 (to prev), side 1 = rows n-3..n (to next)
+struct PackFields { const double *f[3]; };
+__global__ void k_pack_halos_multi(double *__restrict__ send, PackFields pf, int nf, int n, PencilGeom g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const long base = pencil_base(g, p);
+    const int k = blockIdx.y;  // field
+    const double *__restrict__ u = pf.f[k];
+#pragma unroll
+    for (int r = 0; r < X3D_NH; r++) {
+        send[((long)k * X3D_NH + r) * g.np + p] = u[base + (long)r * g.rs];
+        send[((long)(nf + k) * X3D_NH + r) * g.np + p] = u[base + (long)(n - X3D_NH + r) * g.rs];
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
                     bool *done);  // onchip.hip (K1e)
@@ -651,7 +686,16 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
 }
 
 int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                       const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // xscan.hip
+                       const x3d_tdsops *ta, const x3d_tdsops *tb, const TileHalo *halo, int other0, int nother,
+                       bool *done);  // xscan.hip
+int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *brecv,
+                     const x3d_tdsops *ta, const x3d_tdsops *tb);  // xscan.hip
+int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, double *const r[3], const double *conv, double nu,
+                                const double *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd);  // xscan.hip
+int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                       const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother,
+                       bool *done);  // xscan.hip
 
 // fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
 //   mode 0: out1 = A(in1) + B(in2)          mode 1: out1 = A(in1), out2 = B(in1)
@@ -669,7 +713,7 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
     if (int rc = check_len(b, tb, dir, "tds_solve_pair")) return rc;
     if (dir != X3D_DIR_X) {
         bool done = false;
-        if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, &done)) return rc;
+        if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, nullptr, 0, -1, &done)) return rc;
         if (done) return 0;
     }
     if (int rc = x3d_tds_solve_acc(b, out1, in1, ta, dir, 0, 1.0)) return rc;
@@ -934,4 +978,113 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
     return transeq_component_local(b, dir, dspec, spec, uvw, nu, der1st, der1st_sym, der2nd, accumulate);
+}
+
+
+// ------------------------------------------------------------------ decomposed directions, single pass
+// exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-186) do: sweep -> exchange
+// the boundary values -> substitution sweep.  Here the tile kernels (xscan.hip, HALO forms) do the whole local
+// solve in one pass with the neighbours' boundary values taken as zero and hand out their own; after the
+// exchange x3d_*_halo_fix adds what the received values contribute, on the boundary strips only.  Same linear
+// system; the result differs from the three-sweep order by re-association and by coupling terms < 2^-60.
+
+// send[side 2][field nf][4][np]: rows 1..4 (side 0, for prev) and n-3..n (side 1, for next) of nf <= 3 fields
+extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir)
+{
+    X3D_REQUIRE(b && send && fields, "x3d_pack_halos_multi: null argument");
+    X3D_REQUIRE(nf >= 1 && nf <= 3, "x3d_pack_halos_multi: 1..3 fields");
+    X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos_multi: bad dir %d", dir);
+    PencilGeom g = x3d_geom(b, dir);
+    PackFields pf{};
+    for (int k = 0; k < nf; k++) { X3D_REQUIRE(fields[k], "x3d_pack_halos_multi: null field"); pf.f[k] = fields[k]; }
+    ProfScope ps(b, X3D_K_PACK, dir);
+    hipLaunchKernelGGL(k_pack_halos_multi, dim3((g.np + 255) / 256, nf), dim3(256), 0, b->stream, send, pf, nf, n, g);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// transeq_<dir> (all three components) of a y or z direction through the tile kernel, over the planes
+// [other0, other0 + nother) of the coordinate the tiles are stacked along (z for y pencils, y for z pencils;
+// nother < 0: all) -- a plane range lets the caller overlap a neighbour exchange with the rest.
+// halo_recv == NULL: local (periodic) direction.  Otherwise the direction is decomposed: halo_recv[2][3][4][np]
+// holds the neighbours' rows of the fields in COMPONENT order (dir y: v, u, w; dir z: w, u, v: the advecting one
+// first, src/backend/omp/backend.f90:145-184) and bnd_send[2][9][np] receives this rank's boundary values
+// ([component * 3 + {d(u conv), du, d2u}]).  *done = 0: these pencils are not served here (use x3d_transeq_acc /
+// the two-sweep x3d_transeq_dist_* calls).
+extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                                const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                                const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                                int accumulate, const double *halo_recv, double *bnd_send, int other0, int nother,
+                                int *done)
+{
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
+                "x3d_transeq_tile: null argument");
+    X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_transeq_tile: halo_recv and bnd_send go together");
+    *done = 0;
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_tile: dir must be y or z");
+    if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
+    double *r[3];
+    const double *f[3];
+    if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; f[0] = v; f[1] = u; f[2] = w; }
+    else { r[0] = dw; r[1] = du; r[2] = dv; f[0] = w; f[1] = u; f[2] = v; }
+    for (int c = 0; c < 3; c++) X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_tile: outputs alias inputs");
+    const TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, 3, 9};
+    bool ok = false;
+    if (int rc = x3d_ytile_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, accumulate,
+                                    halo_recv ? &th : nullptr, other0, nother, &ok))
+        return rc;
+    *done = ok ? 1 : 0;
+    return 0;
+}
+
+// ... and the contribution of the received boundary values bnd_recv[2][9][np] (side 0: from prev = its X_n,
+// side 1: from next = its du_1), added to du, dv, dw
+extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
+                                    const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+                                    const x3d_tdsops *der2nd, const double *bnd_recv)
+{
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der2nd && bnd_recv, "x3d_transeq_halo_fix: null argument");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_halo_fix: dir must be y or z");
+    double *r[3];
+    if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; }
+    else { r[0] = dw; r[1] = du; r[2] = dv; }
+    return x3d_transeq_halo_fix_launch(b, dir, r, dir == X3D_DIR_Y ? v : w, nu, bnd_recv, der1st, der2nd);
+}
+
+// tds_solve pairs / single operators of a y or z direction through the tile kernel (modes of x3d_tds_solve_pair,
+// + mode 2: out1 = A(in1)), over a plane range as above.  halo_recv == NULL: local direction.  Otherwise
+// halo_recv[2][nf][4][np] with nf = 2 (mode 0: in1, in2) or 1, and bnd_send[2][nb][np], nb = 2 (modes 0, 1: A, B) or 1
+extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                                 const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
+                                 double *bnd_send, int other0, int nother, int *done)
+{
+    X3D_REQUIRE(b && out1 && in1 && ta && done, "x3d_tds_pair_tile: null argument");
+    X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_tds_pair_tile: halo_recv and bnd_send go together");
+    *done = 0;
+    X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_tile: mode must be 0, 1 or 2");
+    X3D_REQUIRE((mode == 0 ? in2 != nullptr : true) && (mode == 1 ? out2 != nullptr : true) && (mode == 2 || tb),
+                "x3d_tds_pair_tile: null argument");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_tile: dir must be y or z");
+    X3D_REQUIRE(out1 != in1 && out1 != in2 && out2 != in1 && (mode != 1 || out1 != out2),
+                "x3d_tds_pair_tile: outputs alias inputs");
+    if (mode == 2) tb = ta;
+    if (int rc = check_len(b, ta, dir, "tds_pair_tile")) return rc;
+    if (int rc = check_len(b, tb, dir, "tds_pair_tile")) return rc;
+    const TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, mode == 0 ? 2 : 1, mode == 2 ? 1 : 2};
+    bool ok = false;
+    if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv ? &th : nullptr, other0,
+                                    nother, &ok))
+        return rc;
+    *done = ok ? 1 : 0;
+    return 0;
+}
+
+extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
+                                     const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
+{
+    X3D_REQUIRE(b && out1 && ta && bnd_recv && (mode == 2 || tb) && (mode != 1 || out2), "x3d_tds_pair_halo_fix: null argument");
+    X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_halo_fix: mode must be 0, 1 or 2");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_halo_fix: dir must be y or z");
+    return x3d_tds_halo_fix(b, dir, mode, out1, out2, bnd_recv, ta, mode == 2 ? ta : tb);
 }

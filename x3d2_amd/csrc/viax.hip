@@ -22,7 +22,8 @@ bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tds
 bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
 int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, bool *done);
+                       const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother,
+                       bool *done);
 int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
                               const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
                               const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
@@ -165,7 +166,8 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
         // K3y (xscan.hip): the same kernel fed through an LDS tile, no transposed copies; all three components in
         // one launch when the operators allow
         bool ok = false;
-        if (int rc = x3d_ytile_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, acc, &ok)) return rc;
+        if (int rc = x3d_ytile_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, acc, nullptr, 0, -1, &ok))
+            return rc;
         if (ok) { *done = true; return 0; }
         if (int rc = x3d_ytile_transeq(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, acc, &ok)) return rc;
         if (ok) {

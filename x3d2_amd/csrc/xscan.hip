@@ -269,6 +269,29 @@ __device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q],
     for (int q = 0; q < Q; q++) w[4 + q] = b[q];
 }
 
+// decomposed direction (BC_HALO ends): rows -3..0 and n+1..n+4 of the pencil are the neighbour ranks' rows, handed
+// over in hl[0..3] / hl[4..7] (this wave's 8 halo values, staged in LDS) instead of the periodic image
+template <int Q, class T = double>
+__device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b)[Q], int lane,
+                                                      const double *__restrict__ hl)
+{
+    window_from_body<Q, T>(w, b, lane);
+    const bool first = lane == 0, last = lane == 63;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const double hs = hl[m], he = hl[4 + m];
+        w[m] = first ? hs : w[m];
+        w[Q + 4 + m] = last ? he : w[Q + 4 + m];
+    }
+}
+
+// HALO forms of the tile kernels (K3y): the reduced 2 x 2 systems of a decomposed direction couple to the
+// NEIGHBOUR ranks' boundary values (src/backend/omp/kernels/distributed.f90:186-206), which do not exist yet
+// when this rank's sweep runs.  The kernel closes every operator with recv_s = recv_e = 0, stores its own
+// boundary values du_1 / X_n for the exchange ([side][op][pencil]), and k_*_halo_fix adds the terms linear in
+// the received values afterwards -- on the boundary strips only: dist_sa / dist_sc decay by 0.15 - 0.38 per row
+// (src/tdsops.f90:196-201 relies on the same decay), so beyond ~45 rows they are below 2^-60.
+
 // ---- stores: a lane owns Q = 8 consecutive rows (64 B).  Storing them as four 16-byte pieces makes
 // every store instruction touch 16 B of each 64-byte sector (measured: the kernel then runs at
 // 3.2 TB/s); a 4x4 transpose of the 16-byte pairs inside each quad of lanes lets every instruction
@@ -1062,11 +1085,11 @@ __global__ void __launch_bounds__(1024)
 // its tile, keeping its pencil's rows of u0 in registers: u0 is read once instead of three times (9 field
 // passes instead of 11).  Needs der1st == der1st_sym and der2nd == der2nd_sym as lane tables (periodic
 // operators), so that all components use the same two table sets (tD1 for du and d(u conv), tD2 for d2u).
-template <int Q, bool ACC, bool NARROW>
+template <int Q, bool ACC, bool NARROW, bool HALO>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
                      const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
-                     int ntiles, long prow, long pplane, double nu)
+                     int tile0, int ntiles, long prow, long pplane, double nu, TileHalo th)
 {
     extern __shared__ double lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
@@ -1076,6 +1099,9 @@ __global__ void __launch_bounds__(1024)
     }
     const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
     double *tile = lt + 2 * LN;
+    // HALO: [16 pencils][8] halo values of the current field, then the same for the advecting velocity u0
+    double *hal = tile + 16 * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
+    ntiles += tile0;  // tiles [tile0, tile0 + ntiles) (a range of planes: overlap of the neighbour exchange)
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
@@ -1101,10 +1127,20 @@ __global__ void __launch_bounds__(1024)
         }
     };
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    // HALO: thread t < 128 carries halo value (pencil t >> 3, slot t & 7: 0..3 start side, 4..7 end side) of field f
+    auto hload = [&](int tl, int f) {
+        const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
+        const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;  // pencil = x + nx * other
+        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.np + pp];
+    };
     __syncthreads();
     double2 nxt[NI];  // the rows needed next (next component's field, or the next tile's u0), in flight during the solves
-    if ((int)blockIdx.x < ntiles) gload(nxt, u0 + tile_off(blockIdx.x));
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    double hnx = 0.0;
+    if (tile0 + (int)blockIdx.x < ntiles) {
+        gload(nxt, u0 + tile_off(tile0 + blockIdx.x));
+        if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
+    }
+    for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         double cb[Q];  // this pencil's rows of the advecting velocity
 #pragma unroll 1
@@ -1114,14 +1150,23 @@ __global__ void __launch_bounds__(1024)
             {
                 double b[Q];
                 to_tile(nxt);
+                if (HALO && threadIdx.x < 128) {
+                    hal[threadIdx.x] = hnx;
+                    if (c == 0) hal0[threadIdx.x] = hnx;
+                }
                 __syncthreads();
                 pick(b);
                 if (c == 0) {
 #pragma unroll
                     for (int q = 0; q < Q; q++) cb[q] = b[q];
                 }
-                window_from_body<Q>(wu, b, lane);
-                window_from_body<Q>(wp, cb, lane);
+                if constexpr (HALO) {
+                    window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
+                    window_from_body_halo<Q>(wp, cb, lane, hal0 + wave * 8);
+                } else {
+                    window_from_body<Q>(wu, b, lane);
+                    window_from_body<Q>(wp, cb, lane);
+                }
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
             }
@@ -1129,13 +1174,26 @@ __global__ void __launch_bounds__(1024)
             {
                 const int tn = tl + gridDim.x;
                 const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
-                if (c < 2 || tn < ntiles) gload(nxt, nsrc);
+                if (c < 2 || tn < ntiles) {
+                    gload(nxt, nsrc);
+                    if (HALO && threadIdx.x < 128) hnx = hload(c < 2 ? tl : tn, c < 2 ? c + 1 : 0);
+                }
             }
 
-            auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
+            auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t,
+                                  int op) {
                 double a, b;
                 scan_solve<Q, true, NARROW>(w, T, a, b, l, t, lane, first);
-                const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+                double s_, e_;
+                if constexpr (HALO) {
+                    // recv_s = recv_e = 0 for now; own boundary values (wave-uniform) parked in LDS, written out
+                    // after the third component for the exchange (k_transeq_halo_fix)
+                    s_ = t.rs_s * a; e_ = t.rs_e * b;
+                    bnd[(wave * 9 + c * 3 + op) * 2] = a;
+                    bnd[(wave * 9 + c * 3 + op) * 2 + 1] = b;
+                } else {
+                    s_ = t.rs_s * (a - t.sa1 * b); e_ = t.rs_e * (b - t.scn * a);
+                }
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     const double st = l[LT_ST(q) * 64 + lane];
@@ -1146,15 +1204,15 @@ __global__ void __launch_bounds__(1024)
                 }
             };
             double r[Q], T[Q];
-            solve_subs(wp, T, l1, tD1);
+            solve_subs(wp, T, l1, tD1, 0);
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = T[q];
             asm volatile("" : "+v"(lane) : "v"(r[0]));
-            solve_subs(wu, T, l1, tD1);
+            solve_subs(wu, T, l1, tD1, 1);
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
             asm volatile("" : "+v"(lane) : "v"(r[0]));
-            solve_subs(wu, T, l3, tD2);
+            solve_subs(wu, T, l3, tD2, 2);
             {
                 // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component)
                 double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
@@ -1174,6 +1232,11 @@ __global__ void __launch_bounds__(1024)
             }
             __syncthreads();  // the tile is free again
         }
+        if (HALO && threadIdx.x < 288) {  // 16 pencils x 9 operators x {du_1, X_n} (the barrier above ordered them)
+            const int hw = threadIdx.x / 18, k = threadIdx.x % 18;
+            const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;
+            th.bsend[((long)(k & 1) * th.nb + (k >> 1)) * th.np + pp] = bnd[threadIdx.x];
+        }
     }
 }
 
@@ -1184,19 +1247,22 @@ __global__ void __launch_bounds__(1024)
 //   MODE 1:  out1 = A(in1), out2 = B(in1) (interpl_y(p), stagder_y(p):         3 instead of 2 + 2)
 // Same tile mechanics as k_ytile_transeq, same arithmetic as k_xscan_tds (MODE 0 adds the two results exactly
 // like the accumulating form: old + 1.0 * r).
-template <int Q, int MODE, bool NARROW>
+template <int Q, int MODE, bool NARROW, bool HALO>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
-                     XOp ta, XOp tb, int ntx, int ntiles, long prow, long pplane)
+                     XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th)
 {
     extern __shared__ double lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = ta.TL[i];
-        lt[LN + i] = tb.TL[i];
+        if (MODE != 2) lt[LN + i] = tb.TL[i];
     }
     const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
     double *tile = lt + 2 * LN;
+    double *hal = tile + 16 * TP, *bnd = hal + 128;  // HALO: [16 pencils][8] halo values of the input in the tile;
+                                                     // [16 pencils][2 ops][du_1, X_n]
+    ntiles += tile0;                                 // tiles [tile0, tile0 + ntiles)
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
@@ -1232,11 +1298,19 @@ __global__ void __launch_bounds__(1024)
             *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) =
                 make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
     };
-    // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange)
-    auto solve = [&](const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ l, const XOp &t) {
+    // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange; HALO:
+    // with recv_s = recv_e = 0, the own boundary values stored for the exchange -- see TileHalo)
+    auto solve = [&](const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ l, const XOp &t, int op) {
         double X[Q], du1, xn;
         scan_solve<Q, true, NARROW>(w, X, du1, xn, l, t, lane, first);
-        const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+        double du_s, du_e;
+        if constexpr (HALO) {
+            du_s = t.rs_s * du1; du_e = t.rs_e * xn;
+            bnd[(wave * 2 + op) * 2] = du1;  // (wave-uniform values, parked in LDS until the tile is done)
+            bnd[(wave * 2 + op) * 2 + 1] = xn;
+        } else {
+            du_s = t.rs_s * (du1 - t.sa1 * xn); du_e = t.rs_e * (xn - t.scn * du1);
+        }
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const double st = l[LT_ST(q) * 64 + lane];
@@ -1246,50 +1320,157 @@ __global__ void __launch_bounds__(1024)
         }
     };
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    auto hload = [&](int tl, int f) {  // thread t < 128: halo value (pencil t >> 3, slot t & 7) of input f
+        const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
+        const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;
+        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.np + pp];
+    };
     __syncthreads();
     double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
-    if ((int)blockIdx.x < ntiles) gload(nxt, in1 + tile_off(blockIdx.x));
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    double hnx = 0.0;
+    if (tile0 + (int)blockIdx.x < ntiles) {
+        gload(nxt, in1 + tile_off(tile0 + blockIdx.x));
+        if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
+    }
+    for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         asm volatile("" : "+v"(lane));
         double w[Q + 8], b[Q], ra[Q], rb[Q];
         double2 g2[NI];
-        if (MODE == 0) gload(g2, in2 + off);
+        double h2 = 0.0;
+        if (MODE == 0) {
+            gload(g2, in2 + off);
+            if (HALO && threadIdx.x < 128) h2 = hload(tl, 1);
+        }
         to_tile(nxt);
+        if (HALO && threadIdx.x < 128) hal[threadIdx.x] = hnx;
         __syncthreads();
         pick(b);
-        window_from_body<Q>(w, b, lane);
+        if constexpr (HALO) window_from_body_halo<Q>(w, b, lane, hal + wave * 8);
+        else window_from_body<Q>(w, b, lane);
         // (barriers only before COOPERATIVE accesses to the tile: a wave's own results go to its own pencil's region)
         if (MODE == 0) __syncthreads();  // all rows picked: the second input may overwrite the tile
         {
             const int tn = tl + gridDim.x;
-            if (tn < ntiles) gload(nxt, in1 + tile_off(tn));
+            if (tn < ntiles) {
+                gload(nxt, in1 + tile_off(tn));
+                if (HALO && MODE != 0 && threadIdx.x < 128) hnx = hload(tn, 0);
+            }
         }
-        solve(w, ra, la, ta);
+        solve(w, ra, la, ta, 0);
         if (MODE == 0) {
             to_tile(g2);
+            if (HALO && threadIdx.x < 128) {
+                hal[threadIdx.x] = h2;
+                // (requested here, not before the first solve: one halo value in flight at a time)
+                const int tn = tl + gridDim.x;
+                if (tn < ntiles) hnx = hload(tn, 0);
+            }
             __syncthreads();
             pick(b);
-            window_from_body<Q>(w, b, lane);
+            if constexpr (HALO) window_from_body_halo<Q>(w, b, lane, hal + wave * 8);
+            else window_from_body<Q>(w, b, lane);
             asm volatile("" : "+v"(lane) : "v"(ra[0]));
-            solve(w, rb, lb, tb);
+            solve(w, rb, lb, tb, 1);
 #pragma unroll
             for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
             put(ra);
             __syncthreads();
             from_tile(out1 + off);
-        } else {
+        } else if (MODE == 1) {
             put(ra);
             __syncthreads();
             from_tile(out1 + off);
             asm volatile("" : "+v"(lane) : "v"(ra[0]));
-            solve(w, rb, lb, tb);
+            solve(w, rb, lb, tb, 1);
             __syncthreads();  // out1's tile has been read
             put(rb);
             __syncthreads();
             from_tile(out2 + off);
+        } else {  // MODE 2: a single operator (a tds_solve of a decomposed direction through the tile mechanics)
+            put(ra);
+            __syncthreads();
+            from_tile(out1 + off);
+        }
+        if (HALO && threadIdx.x < 64) {  // 16 pencils x 2 operators x {du_1, X_n} (ordered by the barriers above)
+            const int hw = threadIdx.x >> 2, k = threadIdx.x & 3;
+            const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;
+            if ((k >> 1) < th.nb) th.bsend[((long)(k & 1) * th.nb + (k >> 1)) * th.np + pp] = bnd[threadIdx.x];
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- HALO: the terms linear in the received values
+// One pencil per lane, lanes across x (every access a contiguous row segment), rows wave-uniform -> the row tables
+// come from scalar loads.  With ds = -rs_s sa_1 recv_s and de = -rs_e sc_n recv_e (what the neighbours' values
+// add to du_s, du_e of src/backend/omp/kernels/distributed.f90:196-206):
+//     x_j += -st_j (sa_j ds + sc_j de)   (2 <= j <= n - 1),   x_1 += st_1 ds,   x_n += st_n de
+// on rows 1..ws and n-we+1..n (the launcher cuts where |sa_j|, |sc_j| < 2^-60; ws + we >= n: every row).
+__device__ __forceinline__ double halo_fix_row(const TdsTab &t, int j, int n, double ds, double de)
+{
+    const double st = T_ST(t, j);
+    if (j == 1) return st * ds;
+    if (j == n) return st * de;
+    return -st * (T_SA(t, j) * ds + T_SC(t, j) * de);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    k_tds_halo_fix(double *__restrict__ out1, double *__restrict__ out2, const double *__restrict__ brecv, TdsTab ta,
+                   TdsTab tb, PencilGeom g, int ws, int we)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const int nb = MODE == 2 ? 1 : 2, n = ta.n_tds, seg = blockIdx.y;  // seg 0: start strip, 1: end strip
+    const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1;
+    const double dsa = -ta.rs_s * ta.sa1 * brecv[p], dea = -ta.rs_e * ta.scn * brecv[(long)nb * g.np + p];
+    double dsb = 0.0, deb = 0.0;
+    if (MODE != 2) {
+        dsb = -tb.rs_s * tb.sa1 * brecv[(long)g.np + p];
+        deb = -tb.rs_e * tb.scn * brecv[(long)(nb + 1) * g.np + p];
+    }
+    const int j0 = seg == 0 ? 1 : (n - we + 1 > ws ? n - we + 1 : ws + 1), j1 = seg == 0 ? (ws < n ? ws : n) : n;
+    for (int j = j0; j <= j1; j++) {
+        const long o = base + (long)(j - 1) * g.rs;
+        const double fa = halo_fix_row(ta, j, n, dsa, dea);
+        if (MODE == 0) out1[o] += fa + halo_fix_row(tb, j, n, dsb, deb);
+        else out1[o] += fa;
+        if (MODE == 1) out2[o] += halo_fix_row(tb, j, n, dsb, deb);
+    }
+}
+
+// transeq_<dir>, three components: rhs_c += -1/2 (v ddu + ddud) + nu (dd2u + ddu stc)
+// (src/backend/omp/kernels/distributed.f90:304-335 is linear in du, dud, d2u); brecv = [side][c * 3 + op][np],
+// op 0 = d(u conv) (tD1), 1 = du (tD1), 2 = d2u (tD2); v = the advecting velocity
+__global__ void __launch_bounds__(256)
+    k_transeq_halo_fix(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
+                       const double *__restrict__ v, const double *__restrict__ brecv, TdsTab t1, TdsTab t2,
+                       PencilGeom g, double nu, int ws, int we)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.np) return;
+    const int n = t1.n_tds, seg = blockIdx.y;
+    const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1, np = g.np;
+    double ds[9], de[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const TdsTab &t = (k % 3 == 2) ? t2 : t1;
+        ds[k] = -t.rs_s * t.sa1 * brecv[k * np + p];
+        de[k] = -t.rs_e * t.scn * brecv[(9 + k) * np + p];
+    }
+    double *__restrict__ rhs[3] = {rhs0, rhs1, rhs2};
+    const int j0 = seg == 0 ? 1 : (n - we + 1 > ws ? n - we + 1 : ws + 1), j1 = seg == 0 ? (ws < n ? ws : n) : n;
+    for (int j = j0; j <= j1; j++) {
+        const long o = base + (long)(j - 1) * g.rs;
+        const double vj = v[o], stc = T_STC(t2, j);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double ddud = halo_fix_row(t1, j, n, ds[3 * c], de[3 * c]);
+            const double ddu = halo_fix_row(t1, j, n, ds[3 * c + 1], de[3 * c + 1]);
+            const double dd2u = halo_fix_row(t2, j, n, ds[3 * c + 2], de[3 * c + 2]);
+            rhs[c][o] += -0.5 * (vj * ddu + ddud) + nu * (dd2u + ddu * stc);
+        }
     }
 }
 
@@ -1519,9 +1700,21 @@ static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double
     return 0;
 }
 
-// K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq)
+// tile range of a launch: planes [other0, other0 + nother) of the coordinate the tile rows run over (z for y
+// pencils, y for z pencils); nother < 0: all of them
+static void tile_range(const x3d_backend *b, int dir, int other0, int nother, int ntx, int *tile0, int *ntiles)
+{
+    const int nall = dir == X3D_DIR_Y ? b->nz : b->ny;
+    if (nother < 0) { other0 = 0; nother = nall; }
+    *tile0 = other0 * ntx;
+    *ntiles = nother * ntx;
+}
+
+// K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq).
+// mode 2: out1 = A(in1) only.  halo != null: decomposed direction (TileHalo: nf = 1 or 2 inputs, nb operators)
 int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                       const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done)
+                       const x3d_tdsops *ta, const x3d_tdsops *tb, const TileHalo *halo, int other0, int nother,
+                       bool *done)
 {
     *done = false;
     static int on = -1;
@@ -1533,35 +1726,74 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     };
     if (!fast(ta) || !fast(tb) || (dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
     if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return 0; }
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const int ntx = b->nx / 16;
+    int tile0, ntiles;
+    tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
+    if (ntiles <= 0) { *done = true; return 0; }
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     const int blocks = ntiles > 256 ? 256 : ntiles;
+    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GO(Q_, M_, N_)                                                                                          \
+#define GO(Q_, M_, N_, H_)                                                                                      \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_>));                                                       \
-        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, in1, \
-                           in2, xop_of(ta), xop_of(tb), ntx, ntiles, rstride, ostride);                        \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_>));                                                   \
+        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
+                           in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th);         \
     } while (0)
-#define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
-#define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else GON(Q_, 1); } while (0)
+#define GOH(Q_, M_, N_) do { if (halo) GO(Q_, M_, N_, true); else GO(Q_, M_, N_, false); } while (0)
+#define GON(Q_, M_) do { if (narrow) GOH(Q_, M_, true); else GOH(Q_, M_, false); } while (0)
+#define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
 #undef GON
+#undef GOH
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;
     return 0;
 }
 
-// K3y, three components in one launch (k_ytile_transeq3); f[0] is the advecting component
+// rows 1..ws and n-we+1..n carry more than 2^-60 of the reduced system's coupling (tds.hip, x3d_tdsops_create)
+int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *brecv,
+                     const x3d_tdsops *ta, const x3d_tdsops *tb)
+{
+    const PencilGeom g = x3d_geom(b, dir);
+    const int ws = mode == 2 ? ta->halo_ws : (ta->halo_ws > tb->halo_ws ? ta->halo_ws : tb->halo_ws);
+    const int we = mode == 2 ? ta->halo_we : (ta->halo_we > tb->halo_we ? ta->halo_we : tb->halo_we);
+    dim3 grid((g.np + 255) / 256, ws + we >= ta->n_tds ? 1 : 2);
+    const int ws1 = grid.y == 1 ? ta->n_tds : ws;
+    ProfScope ps(b, X3D_K_TDS_BWD, dir);
+    if (mode == 0) hipLaunchKernelGGL(k_tds_halo_fix<0>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we);
+    else if (mode == 1) hipLaunchKernelGGL(k_tds_halo_fix<1>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we);
+    else hipLaunchKernelGGL(k_tds_halo_fix<2>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, ta->tab, g, ws1, we);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, double *const r[3], const double *conv, double nu,
+                                const double *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd)
+{
+    const PencilGeom g = x3d_geom(b, dir);
+    const int ws = der1st->halo_ws > der2nd->halo_ws ? der1st->halo_ws : der2nd->halo_ws;
+    const int we = der1st->halo_we > der2nd->halo_we ? der1st->halo_we : der2nd->halo_we;
+    dim3 grid((g.np + 255) / 256, ws + we >= der1st->n_tds ? 1 : 2);
+    const int ws1 = grid.y == 1 ? der1st->n_tds : ws;
+    ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
+    hipLaunchKernelGGL(k_transeq_halo_fix, grid, dim3(256), 0, b->stream, r[0], r[1], r[2], conv, brecv, der1st->tab,
+                       der2nd->tab, g, nu, ws1, we);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// K3y, three components in one launch (k_ytile_transeq3); f[0] is the advecting component.
+// halo != null: decomposed direction (TileHalo: nf = 3 fields in the order f[0..2], nb = 9 boundary values)
 int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
+                       const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother, bool *done)
 {
     *done = false;
     static int on = -1;
@@ -1569,21 +1801,26 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 256 + 288 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const int ntx = b->nx / 16;
+    int tile0, ntiles;
+    tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
+    if (ntiles <= 0) { *done = true; return 0; }
     const int blocks = ntiles > 256 ? 256 : ntiles;
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
-#define GO(Q_, A_, N_)                                                                                          \
+#define GO(Q_, A_, N_, H_)                                                                                      \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_>));                                                       \
-        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
-                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, ntiles, rstride, ostride, nu); \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_>));                                                   \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, tile0, ntiles, rstride, ostride, nu, th); \
     } while (0)
-#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GOH(Q_, A_, N_) do { if (halo) GO(Q_, A_, N_, true); else GO(Q_, A_, N_, false); } while (0)
+#define GON(Q_, A_) do { if (narrow) GOH(Q_, A_, true); else GOH(Q_, A_, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
@@ -1591,6 +1828,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     }
 #undef GOA
 #undef GON
+#undef GOH
 #undef GO
     X3D_HIP(hipGetLastError());
     b->n_tq3++;

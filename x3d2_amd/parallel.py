@@ -9,8 +9,32 @@ direction; the py or pz peers of a transpose), batched into one group
 (batch_isend_irecv = ncclGroupStart/End) -- no bulk collective on the data path.
 With the "gloo" backend (CPU tests, or several ranks sharing one GPU in the
 GPU parity tests) device buffers are staged through host memory."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class _Done:
+    """an exchange that has already completed (self-exchange, host-staged transport)"""
+
+    def wait(self):
+        pass
+
+
+DONE = _Done()
+
+
+class _Pending:
+    """an exchange in flight on RCCL's stream: wait() makes the CURRENT stream wait for it (no host block)"""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 class Comm:
@@ -21,6 +45,10 @@ class Comm:
         self.size = dist.get_world_size(group) if self.enabled else 1
         self.backend = dist.get_backend(group) if self.enabled else None
         self.host_staged = self.backend == "gloo"
+        # exchanges started on a second HIP stream overlap with kernels of the compute stream that do not
+        # depend on them (X3D_NO_OVERLAP=1: every exchange is ordered on the compute stream, for A/B runs)
+        self.overlap = os.environ.get("X3D_NO_OVERLAP") != "1"
+        self._cstream = None
 
     # ------------------------------------------------------------ p2p core
     def _exchange(self, sends, recvs):
@@ -43,6 +71,27 @@ class Comm:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    def _comm_stream(self):
+        if self._cstream is None:
+            self._cstream = torch.cuda.Stream()
+        return self._cstream
+
+    def _start(self, sends, recvs):
+        """post a group of point-to-point transfers behind everything queued on the current stream, on the
+        communication stream: kernels launched on the compute stream afterwards run beside it"""
+        if not sends and not recvs:
+            return DONE
+        if self.host_staged or not self.overlap:
+            self._exchange(sends, recvs)
+            return DONE
+        cs = self._comm_stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):  # RCCL's own stream waits for the stream that is current at posting time
+            ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+            ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
+            works = dist.batch_isend_irecv(ops)
+        return _Pending(works)
+
     # ------------------------------------------------------------ halo / boundary exchange
     def sendrecv(self, pairs, prev, nxt):
         """pairs: list of (send_s, send_e, recv_s, recv_e) tensors.
@@ -60,6 +109,17 @@ class Comm:
             sends += [(send_s, prev), (send_e, nxt)]
             recvs += [(recv_e, nxt), (recv_s, prev)]
         self._exchange(sends, recvs)
+
+    def isendrecv(self, pairs, prev, nxt):
+        """sendrecv started now and completed by the returned handle's wait()"""
+        if prev == self.rank and nxt == self.rank:
+            self.sendrecv(pairs, prev, nxt)
+            return DONE
+        sends, recvs = [], []
+        for send_s, send_e, recv_s, recv_e in pairs:
+            sends += [(send_s, prev), (send_e, nxt)]
+            recvs += [(recv_e, nxt), (recv_s, prev)]
+        return self._start(sends, recvs)
 
     # ------------------------------------------------------------ transposes
     def alltoall(self, sendbuf, send_counts, recvbuf, recv_counts, peers):
@@ -79,6 +139,27 @@ class Comm:
             so += cnt_s
             ro += cnt_r
         self._exchange(sends, recvs)
+
+    def ialltoall(self, sendbuf, send_counts, recvbuf, recv_counts, peers, send_off=0, recv_off=0, stride=None):
+        """one part of a personalised exchange, started now: peer i gets send_counts[i] elements that start at
+        send_off + i * stride of sendbuf (stride: elements between two peers' chunks; default: packed), and
+        delivers recv_counts[i] elements to recv_off + i * stride of recvbuf.  The Poisson solver sends its
+        spectrum in several such parts so that transforms of one part run beside the transfer of another."""
+        sends, recvs = [], []
+        so = ro = 0
+        for i, (cnt_s, cnt_r, peer) in enumerate(zip(send_counts, recv_counts, peers)):
+            s0 = send_off + (i * stride if stride is not None else so)
+            r0 = recv_off + (i * stride if stride is not None else ro)
+            if peer == self.rank:
+                recvbuf[r0:r0 + cnt_r].copy_(sendbuf[s0:s0 + cnt_s])
+            else:
+                if cnt_s:
+                    sends.append((sendbuf[s0:s0 + cnt_s], peer))
+                if cnt_r:
+                    recvs.append((recvbuf[r0:r0 + cnt_r], peer))
+            so += cnt_s
+            ro += cnt_r
+        return self._start(sends, recvs)
 
     # ------------------------------------------------------------ scalars
     def allreduce(self, value, op="sum"):

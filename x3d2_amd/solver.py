@@ -190,6 +190,13 @@ class Solver:
                 b.allocator.release_block(f)
         else:
             b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
+        if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
+            self._transeq_yz_decomposed(du, dv, dw, u, v, w)
+            for f in rhs[:3]:
+                f.set_data_loc(u.data_loc)
+            if self.nspecies > 0:
+                self.transeq_species_fused(rhs[3:], variables)
+            return None
         b.transeq_dir(DIR_Y, du, dv, dw, u, v, w, self.nu, self.ydirps, accumulate=True)
         # z last: its accumulation may be deferred (when z is decomposed it is not: the y components then
         # take the tile kernel K3y, which is cheaper than transposed copies + the fused RK stage)
@@ -223,6 +230,35 @@ class Solver:
             self.transeq_species_fused(rhs[3:], variables)
         return pending
 
+    def _transeq_yz_decomposed(self, du, dv, dw, u, v, w):
+        """the y and z contributions when at least one of the two directions is decomposed: the boundary rows
+        of u, v, w travel while the first half of a local direction is computed, the decomposed directions run
+        their single-pass kernels, their boundary values travel while the second half of the local direction is
+        computed, and the boundary strips are corrected last (HipBackend.transeq_halo_*).  Directions the
+        single-pass kernels do not take use the two-sweep DistD2 form with its own exchanges."""
+        b, nu = self.backend, self.nu
+        dirs = ((DIR_Y, self.ydirps), (DIR_Z, self.zdirps))
+        halo = [(d, dp) for d, dp in dirs if b.halo_tile_ok(d, dp)]
+        slow = [(d, dp) for d, dp in dirs if b._decomposed(d) and not b.halo_tile_ok(d, dp)]
+        local = [(d, dp) for d, dp in dirs if not b._decomposed(d)]
+        hs = {d: b.transeq_halo_begin(d, u, v, w) for d, _ in halo}
+        second = []
+        for d, dp in local:
+            nall = int(b.mesh.vert_dims[2] if d == DIR_Y else b.mesh.vert_dims[1])
+            h = nall // 2 if halo else nall
+            if b.transeq_planes(d, du, dv, dw, u, v, w, nu, dp, True, 0, h):
+                if h < nall:
+                    second.append((d, dp, h, nall - h))
+            else:
+                b.transeq_dir(d, du, dv, dw, u, v, w, nu, dp, accumulate=True)
+        hb = {d: b.transeq_halo_main(d, du, dv, dw, u, v, w, nu, dp, True, hs[d]) for d, dp in halo}
+        for d, dp, o0, no in second:
+            b.transeq_planes(d, du, dv, dw, u, v, w, nu, dp, True, o0, no)
+        for d, dp in slow:
+            b.transeq_dir(d, du, dv, dw, u, v, w, nu, dp, accumulate=True)
+        for d, dp in halo:
+            b.transeq_halo_finish(d, du, dv, dw, u, v, w, nu, dp, hb[d])
+
     def pressure_correction_fused(self, u, v, w, defer_grad=False):
         """pressure_correction (:693-739) = divergence_v2c + Poisson + gradient_c2v +
         velocity update with the 10 reorders removed and the 5 vecadd's folded
@@ -240,10 +276,16 @@ class Solver:
             else:
                 b.tds_lincomb(out, op, DIR_X, *spec)
         self.time_integrator.flush_updates()
-        b.tds_pair(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p, DIR_Y)   # a1 = interpl(t1) + stagder(t2)
-        b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
         div = t1
-        b.tds_pair(0, div, None, a1, a2, z.interpl_v2p, z.stagder_v2p, DIR_Z)
+        jy = [(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p),   # a1 = interpl(t1) + stagder(t2)
+              (2, a2, None, t3, None, y.interpl_v2p, None)]
+        jz = [(0, div, None, a1, a2, z.interpl_v2p, z.stagder_v2p)]
+        if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
+            self._div_grad_decomposed(jy, jz, forward=True)
+        else:
+            b.tds_pair(*jy[0], DIR_Y)
+            b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
+            b.tds_pair(*jz[0], DIR_Z)
         # poisson: the cell-centred divergence is already Cartesian (no Z2C / C2Z)
         p = div
         if self.cfg.poisson_solver_type == "FFT":
@@ -251,9 +293,15 @@ class Solver:
         else:
             p.fill(0.0)
         # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
-        b.tds_pair(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v, DIR_Z)    # p_sxy, dpdz_sxy
-        b.tds_pair(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
-        b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)       # dpdz_sx
+        jz = [(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v)]    # p_sxy, dpdz_sxy
+        jy = [(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v),   # p_sx, dpdy_sx
+              (2, t1, None, t3, None, y.interpl_p2v, None)]          # dpdz_sx
+        if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
+            self._div_grad_decomposed(jy, jz, forward=False)
+        else:
+            b.tds_pair(*jz[0], DIR_Z)
+            b.tds_pair(*jy[0], DIR_Y)
+            b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)
         if (defer_grad and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_DEFER_GRAD") != "1"
                 and self.nspecies == 0):
             # the next sub-step's transeq_x applies the correction inside its own kernel (transeq_fused)
@@ -264,6 +312,42 @@ class Solver:
         self._apply_grad((a1, a2, t1), u, v, w)
         for f in (t1, t2, t3, a1, a2):
             al.release_block(f)
+
+    def _div_grad_decomposed(self, jy, jz, forward):
+        """the y and z operators of divergence_v2c (forward: y then z) / gradient_c2v (z then y) with at least
+        one decomposed direction.  Exchanges are hidden behind the planes that do not need them:
+        forward, z decomposed, y local: the y jobs do the 4 + 4 boundary z planes first, their rows leave for the
+          neighbours, the remaining planes follow;
+        backward, z decomposed, y local: while the z job's boundary values travel the y jobs run on the z planes
+          its strip correction does not touch, the strip planes follow the correction."""
+        b = self.backend
+        ly, lz = not b._decomposed(DIR_Y), not b._decomposed(DIR_Z)
+        nz = int(b.mesh.vert_dims[2])
+        if forward:
+            if ly and not lz and nz > 2 * 4 and b.tds_tile_ok(DIR_Z, jz[0], True):
+                state = {}
+                b.tds_jobs(DIR_Y, jy, lead=[(0, 4), (nz - 4, 4)],
+                           after_lead=lambda: state.update(h=[b.tds_halo_begin(DIR_Z, j, k) for k, j in enumerate(jz)]))
+                hb = [b.tds_halo_main(DIR_Z, j, k, state["h"][k]) for k, j in enumerate(jz)]
+                for k, j in enumerate(jz):
+                    b.tds_halo_finish(DIR_Z, j, k, hb[k])
+            else:
+                b.tds_jobs(DIR_Y, jy)
+                b.tds_jobs(DIR_Z, jz)
+            return
+        if ly and not lz and b.tds_tile_ok(DIR_Z, jz[0], True) and all(b.tds_tile_ok(DIR_Y, j, False) for j in jy):
+            ws, we = b.halo_strip_rows(jz[0][5], jz[0][6])
+            if ws + we < nz:
+                def interior():
+                    for j in jy:
+                        b.tds_tile_planes(DIR_Y, j, ws, nz - ws - we)
+                b.tds_jobs(DIR_Z, jz, between=interior)
+                for j in jy:
+                    b.tds_tile_planes(DIR_Y, j, 0, ws)
+                    b.tds_tile_planes(DIR_Y, j, nz - we, we)
+                return
+        b.tds_jobs(DIR_Z, jz)
+        b.tds_jobs(DIR_Y, jy)
 
     def _apply_grad(self, g, u, v, w):
         """velocity correction, src/solver.f90:731-733 folded into the last x operators of gradient_c2v"""
