@@ -276,12 +276,14 @@ __device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b
                                                       const double *__restrict__ hl)
 {
     window_from_body<Q, T>(w, b, lane);
-    const bool first = lane == 0, last = lane == 63;
+    // (two one-lane branches: selects on all lanes keep 8 more values live where the kernels have no room)
+    if (lane == 0) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const double hs = hl[m], he = hl[4 + m];
-        w[m] = first ? hs : w[m];
-        w[Q + 4 + m] = last ? he : w[Q + 4 + m];
+        for (int m = 0; m < 4; m++) w[m] = hl[m];
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) w[Q + 4 + m] = hl[4 + m];
     }
 }
 
@@ -1260,6 +1262,10 @@ __global__ void __launch_bounds__(1024)
     }
     const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
     double *tile = lt + 2 * LN;
+    // HALO, MODE 0: no room for the next tile's rows next to the second input's (with them in flight across the
+    // solves the kernel spills inside the tile loop, and every reload is an exposed memory latency: 1.40 ms
+    // against 0.95 for the local form): this tile's rows are requested at its top instead
+    constexpr bool NOPREF = HALO && MODE == 0;
     double *hal = tile + 16 * TP, *bnd = hal + 128;  // HALO: [16 pencils][8] halo values of the input in the tile;
                                                      // [16 pencils][2 ops][du_1, X_n]
     ntiles += tile0;                                 // tiles [tile0, tile0 + ntiles)
@@ -1328,7 +1334,7 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
     double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
     double hnx = 0.0;
-    if (tile0 + (int)blockIdx.x < ntiles) {
+    if (!NOPREF && tile0 + (int)blockIdx.x < ntiles) {
         gload(nxt, in1 + tile_off(tile0 + blockIdx.x));
         if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
     }
@@ -1342,6 +1348,10 @@ __global__ void __launch_bounds__(1024)
             gload(g2, in2 + off);
             if (HALO && threadIdx.x < 128) h2 = hload(tl, 1);
         }
+        if (NOPREF) {
+            gload(nxt, in1 + off);
+            if (threadIdx.x < 128) hnx = hload(tl, 0);
+        }
         to_tile(nxt);
         if (HALO && threadIdx.x < 128) hal[threadIdx.x] = hnx;
         __syncthreads();
@@ -1350,22 +1360,17 @@ __global__ void __launch_bounds__(1024)
         else window_from_body<Q>(w, b, lane);
         // (barriers only before COOPERATIVE accesses to the tile: a wave's own results go to its own pencil's region)
         if (MODE == 0) __syncthreads();  // all rows picked: the second input may overwrite the tile
-        {
+        if (!NOPREF) {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) {
                 gload(nxt, in1 + tile_off(tn));
-                if (HALO && MODE != 0 && threadIdx.x < 128) hnx = hload(tn, 0);
+                if (HALO && threadIdx.x < 128) hnx = hload(tn, 0);
             }
         }
         solve(w, ra, la, ta, 0);
         if (MODE == 0) {
             to_tile(g2);
-            if (HALO && threadIdx.x < 128) {
-                hal[threadIdx.x] = h2;
-                // (requested here, not before the first solve: one halo value in flight at a time)
-                const int tn = tl + gridDim.x;
-                if (tn < ntiles) hnx = hload(tn, 0);
-            }
+            if (HALO && threadIdx.x < 128) hal[threadIdx.x] = h2;
             __syncthreads();
             pick(b);
             if constexpr (HALO) window_from_body_halo<Q>(w, b, lane, hal + wave * 8);
