@@ -320,6 +320,14 @@ int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf);
 int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir);
 int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf);
 int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out);
+/* overlap of the all-to-all with the z stage (the reference issues cuFFTMp's slab transposes and its z
+ * transforms one after the other, src/backend/cuda/poisson_fft.f90:519,568): a rank's share of ys y modes is cut
+ * into `parts` pieces of ysc = ys / parts; S = [peer][part][zl][ysc][nxs], R = [part][peer][zl][ysc][nxs]; piece m
+ * is sent / received as pz messages of zl * ysc * nxs complex numbers and transformed by the *_part calls while
+ * the other pieces are in flight (x3d2_amd/poisson_fft.py, HipSlabPoissonFFT.poisson_000) */
+int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
+int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part);
+int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
 
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,

@@ -207,6 +207,22 @@ recv = torch.zeros(5 if r == 0 else 7, dtype=torch.float64)
 c.alltoall(send, [2, 4] if r == 0 else [3, 3], recv, [2, 3] if r == 0 else [4, 3], [0, 1])
 exp = [0, 1, 100, 101, 102] if r == 0 else [2, 3, 4, 5, 103, 104, 105]
 assert recv.tolist() == [float(v) for v in exp], (r, recv)
+# asynchronous forms (host-staged here: complete at once): strided parts of a personalised exchange, as the slab
+# Poisson solver sends them: S = [peer][part][2], R = [part][peer][2]
+S = torch.arange(8, dtype=torch.float64) + 100 * r
+R = torch.zeros(8, dtype=torch.float64)
+hs = [c.ialltoall(S, R, 2, [0, 1], send_off=2 * k, send_stride=4, recv_off=4 * k, recv_stride=2) for k in range(2)]
+for h in hs:
+    h.wait()
+# part k of what peer p sends here: elements [4 r + 2 k, +2) of its S
+want = []
+for part in range(2):
+    for p in range(2):
+        want += [100 * p + 4 * r + 2 * part, 100 * p + 4 * r + 2 * part + 1]
+assert R.tolist() == [float(v) for v in want], (r, R, want)
+rs2, re2 = torch.zeros(4), torch.zeros(4)
+c.isendrecv([(ss, se, rs2, re2)], prev, nxt).wait()
+assert torch.equal(rs2, rs) and torch.equal(re2, re)
 assert c.allreduce(float(r + 1), "sum") == 3.0 and c.allreduce(float(r), "max") == 1.0
 assert list(m.BCs[2]) == ([0, -1] if r == 0 else [-1, 0]) and m.n_offset[2] == 8 * r and m.vert_dims[2] == 8
 dist.destroy_process_group()

@@ -95,6 +95,9 @@ PROTOTYPES = {
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
     "x3d_sfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),
+    "x3d_sfft_create_parts": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I]),
+    "x3d_sfft_fft_z_part": (I, [VP, VP, I, I]),
+    "x3d_sfft_postprocess_000_part": (I, [VP, VP, I]),
     "x3d_sfft_destroy": (I, [VP]),
     "x3d_sfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
     "x3d_sfft_set_waves": (I, [VP] + [c_double_p] * 7),

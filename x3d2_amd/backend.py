@@ -73,7 +73,7 @@ class HipBackend:
         """X3D_EMULATE_DECOMP=z (or yz): treat these directions as decomposed although this rank owns them whole
         (its neighbours are itself, every exchange a device copy): the code path and the kernels of an N > 1 run
         in ONE process, which is how their local cost is measured on a one-GPU box"""
-        if "xyz"[direction - 1] in self._emulate:
+        if "xyz"[direction - 1] in getattr(self, "_emulate", ""):
             return True
         return int(self.mesh.nproc_dir[direction - 1]) > 1
 

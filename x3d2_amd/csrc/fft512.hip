@@ -114,7 +114,7 @@ struct Spec000 {
 template <int MODE, int NP>
 __global__ void __launch_bounds__(64 * NP, 16 / NP)
     k_fft512(double2 *c, const double2 *__restrict__ twg, long stride_axis, long stride_other, int nxs, Spec000 sp,
-             double2 *xbuf, int ys)
+             double2 *xbuf, int ys, int ysc)
 {
     extern __shared__ double2 tile[];  // [NP][FP] + 256 twiddles
     double2 *__restrict__ tws = tile + NP * FP;
@@ -123,12 +123,13 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     const int i0 = blockIdx.x * NP, m = tid & (NP - 1), r = tid / NP;
     const long base = (long)blockIdx.y * stride_other + i0;
     const bool valid = i0 + m < nxs;
-    // slab-exchange addressing (multi-rank solver, y axis only): point t of the axis lives in chunk t / ys of
-    // xbuf = [chunk][other][ys][nxs], the layout the z all-to-all sends and receives (pfft.hip, x3d_sfft_*).
+    // slab-exchange addressing (multi-rank solver, y axis only): point t of the axis belongs to peer t / ys and,
+    // inside that peer's share, to part (t % ys) / ysc: xbuf = [peer][part][other][ysc][nxs], the layout the z
+    // all-to-all sends and receives part by part (sfft.hip; ysc = ys: one part).
     // MODE 0 stores there (forward y pass = pack), MODE 1 loads from there (backward y pass = unpack).
     auto xaddr = [&](int t) {
-        const int ch = t / ys, tt = t - ch * ys;
-        return (((long)ch * gridDim.y + blockIdx.y) * ys + tt) * nxs + i0 + m;
+        const int ch = t / ys, tt = t - ch * ys, pt = tt / ysc, t3 = tt - pt * ysc;
+        return ((((long)ch * (ys / ysc) + pt) * gridDim.y + blockIdx.y) * ysc + t3) * nxs + i0 + m;
     };
     // MODE 2: the wave numbers of this thread's 8 spectral points, requested before anything else (their
     // latency used to be exposed between the two transforms)
@@ -261,13 +262,13 @@ static double2 *g_tw = nullptr;  // W512^k = exp(-2 pi i k / 512), first half, s
 
 template <int MODE, int NP>
 static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_other, int nxs, int nother,
-                     const Spec000 &sp, double2 *xbuf, int ys)
+                     const Spec000 &sp, double2 *xbuf, int ys, int ysc)
 {
     const int lds = sizeof(double2) * (NP * FP + 256);
     X3D_LDS_OPTIN(b, (k_fft512<MODE, NP>));
     dim3 grid((nxs + NP - 1) / NP, nother);
     hipLaunchKernelGGL((k_fft512<MODE, NP>), grid, dim3(64 * NP), lds, b->stream, c, g_tw, stride_axis,
-                       stride_other, nxs, sp, xbuf, ys);
+                       stride_other, nxs, sp, xbuf, ys, ysc);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -288,26 +289,27 @@ int x3d_fft512_init()
 
 // axis: 1 = y (ny must be 512), 2 = z (nz must be 512); mode 0 fwd, 1 bwd, 2 fused z pass
 int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
-                     const double *ab, int nx, double2 *xbuf, int ys);
+                     const double *ab, int nx, double2 *xbuf, int ys, int ysc);
 static const double *g_rwT = nullptr;  // set by x3d_fft512_set_rwT for the next fused z pass (poisson.hip)
 void x3d_fft512_set_rwT(const double *rwT) { g_rwT = rwT; }
 
 int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
                    const double *ab, int nx)
 {
-    return x3d_fft512_run_x(b, c, nxs, ny, nz, axis, mode, waves, ab, nx, nullptr, 1);
+    return x3d_fft512_run_x(b, c, nxs, ny, nz, axis, mode, waves, ab, nx, nullptr, 1, 1);
 }
 
 // xbuf != null (y axis, mode 0 or 1): the far side of the pass is the slab-exchange buffer (see k_fft512)
 int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
-                     const double *ab, int nx, double2 *xbuf, int ys)
+                     const double *ab, int nx, double2 *xbuf, int ys, int ysc)
 {
     const long sy = nxs, sz = (long)nxs * ny;
     const long stride_axis = axis == 1 ? sy : sz, stride_other = axis == 1 ? sz : sy;
     const int nother = axis == 1 ? nz : ny;
     X3D_REQUIRE((axis == 1 ? ny : nz) == 512, "x3d_fft512_run: axis length must be 512");
     X3D_REQUIRE(mode != 2 || axis == 2, "x3d_fft512_run: the fused pass is the z pass");
-    X3D_REQUIRE(!xbuf || (axis == 1 && mode != 2 && ys > 0 && 512 % ys == 0), "x3d_fft512_run: bad slab exchange");
+    X3D_REQUIRE(!xbuf || (axis == 1 && mode != 2 && ys > 0 && 512 % ys == 0 && ysc > 0 && ys % ysc == 0),
+                "x3d_fft512_run: bad slab exchange");
     Spec000 sp{};
     if (mode == 2) {
         const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
@@ -321,8 +323,8 @@ int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int ax
     const bool w16 = (wide & axis) != 0;  // bit 0: y pass, bit 1: z pass
     ProfScope ps(b, mode == 2 ? X3D_K_SPECTRAL : X3D_K_FFT, axis);
 #define GO(M_)                                                                                             \
-    (w16 ? launch512<M_, 16>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys)                   \
-         : launch512<M_, 8>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys))
+    (w16 ? launch512<M_, 16>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys, ysc)              \
+         : launch512<M_, 8>(b, c, stride_axis, stride_other, nxs, nother, sp, xbuf, ys, ysc))
     if (mode == 0) return GO(0);
     if (mode == 1) return GO(1);
     return GO(2);

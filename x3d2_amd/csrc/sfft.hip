@@ -12,6 +12,9 @@
 //     transpose back (rocFFT's strided 1-D plan on R itself takes 2.05 ms per direction at 512^3, the
 //     transpose + contiguous transform 0.42 + 0.45)
 //   --all-to-all back (chunk r of R = rank r's z-range, contiguous)-->  S
+// Overlap: a rank's share of the y modes is cut into `parts` pieces, S = [peer][part][zl][ysc][nxs] and
+// R = [part][peer][zl][ysc][nxs] = [part][nz][ysc][nxs]: the pieces travel one after the other on the communication
+// stream while the z stage of the pieces that have arrived runs (x3d_sfft_fft_z / _postprocess_000 take a part).
 //   --k_fft512 (y backward), loading from the exchange layout-->  C0  --rocFFT C2R x-->  f
 // ~19 field passes per solve against ~30 for the generic pencil solver (pfft.hip: contiguous-axis rocFFT
 // stages with pack / transpose passes around every exchange).
@@ -31,7 +34,7 @@
 
 int x3d_fft512_init();
 int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
-                     const double *ab, int nx, double2 *xbuf, int ys);
+                     const double *ab, int nx, double2 *xbuf, int ys, int ysc);
 
 int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);  // fft512.hip
 
@@ -39,6 +42,7 @@ struct x3d_sfft {
     x3d_backend *b;
     int nx, ny, nz, nxs;  // global cell dims (ny = 512)
     int pz, rz, zl, ys;   // ranks along z, this rank, local z extent, this rank's share of the y modes
+    int parts, ysc;       // the share is exchanged and z-transformed in `parts` pieces of ysc y modes (overlap)
     hipfftHandle plan_x_fw, plan_x_bw, plan_z;
     double2 *c0;          // [zl][ny][nxs]
     double2 *t;           // [ys*nxs][nz]: z-contiguous copy of the received array
@@ -106,7 +110,13 @@ __global__ void __launch_bounds__(256)
     c[idx] = make_double2(div_r, div_c);
 }
 
+extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
 extern "C" int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz)
+{
+    return x3d_sfft_create_parts(b, out, nglob, pz, rz, 1);
+}
+
+extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts)
 {
     X3D_REQUIRE(b && out && nglob, "x3d_sfft_create: null argument");
     X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft_create: bad rank grid");
@@ -117,6 +127,9 @@ extern "C" int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3
     p->b = b;
     p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2]; p->nxs = nglob[0] / 2 + 1;
     p->pz = pz; p->rz = rz; p->zl = p->nz / pz; p->ys = p->ny / pz;
+    X3D_REQUIRE(parts >= 1 && p->ys % parts == 0, "x3d_sfft_create: %d y modes per rank do not split into %d parts",
+                p->ys, parts);
+    p->parts = parts; p->ysc = p->ys / parts;
     X3D_REQUIRE(p->nx <= b->nxp && p->ny == b->nyp && p->zl <= b->nzp, "x3d_sfft_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs;
     X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
@@ -124,7 +137,7 @@ extern "C" int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3
     X3D_HIP(hipMalloc(&p->waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs));
     X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));
     int nn[1] = {p->nx}, re[1] = {b->nxp}, ce[1] = {p->nxs}, nzv[1] = {p->nz};
-    const int batch = p->ny * p->zl, zstride = p->ys * p->nxs;
+    const int batch = p->ny * p->zl, zstride = p->ysc * p->nxs;  // (z plan: one part at a time)
     hipfftHandle *pl[3] = {&p->plan_x_fw, &p->plan_x_bw, &p->plan_z};
     size_t ws[3] = {0, 0, 0};
     for (int i = 0; i < 3; i++) {
@@ -161,6 +174,10 @@ extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
     return 0;
 }
 
+// dir 0 / 1 and the spectral division for ONE part of the received array (see the header comment)
+extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part);
+extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
+
 // waves: this rank's spectral block [ys][nxs][nz], z fastest (real part = imaginary part); ax..bz: full arrays
 extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx,
                                   const double *ay, const double *by, const double *az, const double *bz)
@@ -194,46 +211,64 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
         }
     }
     return x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 0, nullptr, nullptr, p->nx, (double2 *)sendbuf,
-                            p->ys);
+                            p->ys, p->ysc);
 }
 
-// dir 0: received array R[nz][ys][nxs] -> T[ys*nxs][nz], forward z transform (the spectrum stays in T);
-// dir 1: backward z transform of T, then back to R
-extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
+// dir 0: part `part` of the received array, R_m[nz][ysc][nxs] -> T_m[ysc*nxs][nz], forward z transform (the
+// spectrum stays in T); dir 1: backward z transform of T_m, then back to R_m
+extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part)
 {
-    X3D_REQUIRE(p && recvbuf, "null argument");
-    const int W = p->ys * p->nxs;
+    X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_fft_z_part: bad argument");
+    const int W = p->ysc * p->nxs;
+    double2 *R = (double2 *)recvbuf + (size_t)part * p->nz * W, *T = p->t + (size_t)part * p->nz * W;
     if (dir == 0) {
         ProfScope ps(p->b, X3D_K_PACK);
-        hipLaunchKernelGGL(k_sfft_transpose, dim3((W + 31) / 32, (p->nz + 31) / 32), dim3(256), 0, p->b->stream, p->t,
-                           (const double2 *)recvbuf, W, p->nz);
+        hipLaunchKernelGGL(k_sfft_transpose, dim3((W + 31) / 32, (p->nz + 31) / 32), dim3(256), 0, p->b->stream, T,
+                           (const double2 *)R, W, p->nz);
         X3D_HIP(hipGetLastError());
     }
     {
         ProfScope ps(p->b, X3D_K_FFT, 3);
         X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->t, (hipfftDoubleComplex *)p->t,
+        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)T, (hipfftDoubleComplex *)T,
                               dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     }
     if (dir == 1) {
         ProfScope ps(p->b, X3D_K_PACK);
-        hipLaunchKernelGGL(k_sfft_transpose, dim3((p->nz + 31) / 32, (W + 31) / 32), dim3(256), 0, p->b->stream,
-                           (double2 *)recvbuf, (const double2 *)p->t, p->nz, W);
+        hipLaunchKernelGGL(k_sfft_transpose, dim3((p->nz + 31) / 32, (W + 31) / 32), dim3(256), 0, p->b->stream, R,
+                           (const double2 *)T, p->nz, W);
         X3D_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    for (int m = 0; m < p->parts; m++)
+        if (int rc = x3d_sfft_fft_z_part(p, recvbuf, dir, m)) return rc;
+    return 0;
+}
+
+extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part)
+{
+    X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_postprocess_000_part: bad argument");
+    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+                 *bz = az + p->nz;
+    const size_t off = (size_t)part * p->nz * p->ysc * p->nxs;  // waves[ys][nxs][nz] and T share the part offset
+    dim3 grid((p->nz + 255) / 256, p->nxs, p->ysc);
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
+    hipLaunchKernelGGL(k_process_spectral_000_slab, grid, dim3(256), 0, p->b->stream, p->t + off, p->waves + off, p->nxs,
+                       p->ysc, p->nz, p->rz * p->ys + part * p->ysc, p->nx, p->ny, ax, bx, ay, by, az, bz);
+    X3D_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
-                 *bz = az + p->nz;
-    dim3 grid((p->nz + 255) / 256, p->nxs, p->ys);
-    ProfScope ps(p->b, X3D_K_SPECTRAL);
-    hipLaunchKernelGGL(k_process_spectral_000_slab, grid, dim3(256), 0, p->b->stream, p->t, p->waves, p->nxs, p->ys,
-                       p->nz, p->rz * p->ys, p->nx, p->ny, ax, bx, ay, by, az, bz);
-    X3D_HIP(hipGetLastError());
+    for (int m = 0; m < p->parts; m++)
+        if (int rc = x3d_sfft_postprocess_000_part(p, recvbuf, m)) return rc;
     return 0;
 }
 
@@ -242,7 +277,7 @@ extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, doubl
 {
     X3D_REQUIRE(p && recvbuf && f_out, "null argument");
     if (int rc = x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 1, nullptr, nullptr, p->nx,
-                                  (double2 *)recvbuf, p->ys))
+                                  (double2 *)recvbuf, p->ys, p->ysc))
         return rc;
     ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));

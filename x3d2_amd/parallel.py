@@ -140,25 +140,21 @@ class Comm:
             ro += cnt_r
         self._exchange(sends, recvs)
 
-    def ialltoall(self, sendbuf, send_counts, recvbuf, recv_counts, peers, send_off=0, recv_off=0, stride=None):
-        """one part of a personalised exchange, started now: peer i gets send_counts[i] elements that start at
-        send_off + i * stride of sendbuf (stride: elements between two peers' chunks; default: packed), and
-        delivers recv_counts[i] elements to recv_off + i * stride of recvbuf.  The Poisson solver sends its
-        spectrum in several such parts so that transforms of one part run beside the transfer of another."""
+    def ialltoall(self, sendbuf, recvbuf, count, peers, send_off=0, send_stride=None, recv_off=0, recv_stride=None):
+        """one part of a personalised exchange, started now: peer i gets `count` elements that start at
+        send_off + i * send_stride of sendbuf and delivers `count` elements to recv_off + i * recv_stride of
+        recvbuf (strides default to count: packed).  The slab Poisson solver sends its spectrum in several such
+        parts so that the z transforms of one part run beside the transfer of the others."""
+        ss = count if send_stride is None else send_stride
+        rs = count if recv_stride is None else recv_stride
         sends, recvs = [], []
-        so = ro = 0
-        for i, (cnt_s, cnt_r, peer) in enumerate(zip(send_counts, recv_counts, peers)):
-            s0 = send_off + (i * stride if stride is not None else so)
-            r0 = recv_off + (i * stride if stride is not None else ro)
+        for i, peer in enumerate(peers):
+            s0, r0 = send_off + i * ss, recv_off + i * rs
             if peer == self.rank:
-                recvbuf[r0:r0 + cnt_r].copy_(sendbuf[s0:s0 + cnt_s])
+                recvbuf[r0:r0 + count].copy_(sendbuf[s0:s0 + count])
             else:
-                if cnt_s:
-                    sends.append((sendbuf[s0:s0 + cnt_s], peer))
-                if cnt_r:
-                    recvs.append((recvbuf[r0:r0 + cnt_r], peer))
-            so += cnt_s
-            ro += cnt_r
+                sends.append((sendbuf[s0:s0 + count], peer))
+                recvs.append((recvbuf[r0:r0 + count], peer))
         return self._start(sends, recvs)
 
     # ------------------------------------------------------------ scalars

@@ -412,15 +412,27 @@ class HipSlabPoissonFFT(HipPoissonFFT):
     y pass writes / reads the exchange layout directly, one all-to-all pair per solve among all pz ranks (every
     xGMI link of a GPU is used at once), z transform strided on the received array.  The hooks keep the
     reference's meaning (src/poisson_fft.f90:45-62): fft_forward leaves the full 3-D spectrum in this rank's
-    block [nz][ys][nx/2+1], fft_postprocess_000 divides, fft_backward returns to physical space."""
+    block [nz][ys][nx/2+1], fft_postprocess_000 divides, fft_backward returns to physical space.
+
+    Overlap (poisson_000): this rank's share of the y modes travels in `parts` pieces on the communication
+    stream (parallel.Comm.ialltoall); the z stage of a piece (transpose, z transform, spectral division, inverse
+    transform, transpose) runs as soon as the piece has arrived, beside the transfer of the next ones, and its
+    result leaves at once.  X3D_SLAB_PARTS (default 4; 1 = no overlap)."""
 
     def _create(self):
+        import os
         import torch
         backend, mesh = self.backend, self.mesh
         self.pz, self.rz = int(mesh.nproc_dir[2]), int(mesh.nrank_dir[2])
+        ys = self.ny_glob // self.pz
+        parts = int(os.environ.get("X3D_SLAB_PARTS", "4"))
+        while parts > 1 and ys % parts:
+            parts -= 1
+        self.parts = max(parts, 1)
         h = VP()
-        _lib.check(backend.lib.x3d_sfft_create(
-            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz))
+        _lib.check(backend.lib.x3d_sfft_create_parts(
+            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz,
+            self.parts))
         self.h = h
         sz = (ctypes.c_long * 4)()
         _lib.check(backend.lib.x3d_sfft_sizes(h, sz))
@@ -437,7 +449,7 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         npy = int(mesh.nproc_dir[1])
         ry = int(mesh.nrank_dir[1])
         self.peers = [ry + npy * r for r in range(self.pz)]
-        self.counts = [2 * self.chunk] * self.pz
+        self.sub = 2 * self.chunk // self.parts  # doubles per (peer, part) message
         self.poisson = self.poisson_000
 
     def __del__(self):
@@ -446,10 +458,22 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         except Exception:
             pass
 
+    # S = [peer][part][...], R = [part][peer][...] (csrc/sfft.hip)
+    def _send_part(self, m):
+        return self.backend.comm.ialltoall(self.sbuf, self.rbuf, self.sub, self.peers, send_off=m * self.sub,
+                                           send_stride=self.parts * self.sub, recv_off=m * self.pz * self.sub,
+                                           recv_stride=self.sub)
+
+    def _return_part(self, m):
+        return self.backend.comm.ialltoall(self.rbuf, self.sbuf, self.sub, self.peers, send_off=m * self.pz * self.sub,
+                                           send_stride=self.sub, recv_off=m * self.sub,
+                                           recv_stride=self.parts * self.sub)
+
     def fft_forward(self, f_in):
         lib = self.backend.lib
         _lib.check(lib.x3d_sfft_forward_local(self.h, f_in.ptr, self.sbuf.data_ptr()))
-        self.backend.comm.alltoall(self.sbuf, self.counts, self.rbuf, self.counts, self.peers)
+        for hnd in [self._send_part(m) for m in range(self.parts)]:
+            hnd.wait()
         _lib.check(lib.x3d_sfft_fft_z(self.h, self.rbuf.data_ptr(), 0))
 
     def fft_postprocess_000(self):
@@ -458,13 +482,26 @@ class HipSlabPoissonFFT(HipPoissonFFT):
     def fft_backward(self, f_out):
         lib = self.backend.lib
         _lib.check(lib.x3d_sfft_fft_z(self.h, self.rbuf.data_ptr(), 1))
-        self.backend.comm.alltoall(self.rbuf, self.counts, self.sbuf, self.counts, self.peers)
+        for hnd in [self._return_part(m) for m in range(self.parts)]:
+            hnd.wait()
         _lib.check(lib.x3d_sfft_backward_local(self.h, self.sbuf.data_ptr(), f_out.ptr))
 
     def poisson_000(self, f, temp):
-        self.fft_forward(f)
-        self.fft_postprocess_000()
-        self.fft_backward(f)
+        """fft_forward ; fft_postprocess_000 ; fft_backward (src/poisson_fft.f90:216-226) with the pieces of the
+        spectrum pipelined: transfer of piece m + 1 beside the z stage of piece m"""
+        lib, h, rb = self.backend.lib, self.h, self.rbuf.data_ptr()
+        _lib.check(lib.x3d_sfft_forward_local(h, f.ptr, self.sbuf.data_ptr()))
+        there = [self._send_part(m) for m in range(self.parts)]
+        back = []
+        for m in range(self.parts):
+            there[m].wait()
+            _lib.check(lib.x3d_sfft_fft_z_part(h, rb, 0, m))
+            _lib.check(lib.x3d_sfft_postprocess_000_part(h, rb, m))
+            _lib.check(lib.x3d_sfft_fft_z_part(h, rb, 1, m))
+            back.append(self._return_part(m))
+        for hnd in back:
+            hnd.wait()
+        _lib.check(lib.x3d_sfft_backward_local(h, self.sbuf.data_ptr(), f.ptr))
 
     def get_spectral(self):
         raise X3dError("get_spectral: single-rank test hook")
