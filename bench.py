@@ -25,15 +25,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def decomposition(n_gpus):
-    """x stays whole (src/poisson_fft.f90:131).  z slabs only (the layout the reference's GPU backend needs
-    too, src/backend/cuda/poisson_fft.f90:219): y stays local (single-pass kernels, no y exchanges, no x-y
-    transpose in the Poisson solve) and the one remaining transpose pair is an all-to-all among ALL ranks, so
-    every GPU drives all of its N-1 point-to-point xGMI links at once instead of one or three of them."""
-    table = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 1, 4), 8: (1, 1, 8)}
-    if n_gpus not in table:
+def decomposition(n_gpus, kind="slabs"):
+    """x stays whole (src/poisson_fft.f90:131).
+    "slabs" (default) = [1, 1, N], the layout the reference's GPU backend needs too
+    (src/backend/cuda/poisson_fft.f90:219): y stays local -- no y exchanges at all, and the Poisson solve needs
+    ONE transpose pair, an all-to-all among ALL ranks in which every GPU drives all of its N - 1 point-to-point
+    xGMI links at once.  "pencils" = [1, 2, N / 2] (BASELINE configs[3]'s 2-D split, [1, 2, 4] on 8 GPUs): half
+    the halo surface in z, but y halos on top and TWO transpose pairs per solve, the x-y one between pairs of ranks
+    only (one link each): offered for comparison, not what the headline number uses."""
+    if n_gpus not in (1, 2, 4, 8):
         raise SystemExit(f"--gpus {n_gpus}: supported 1, 2, 4, 8")
-    return table[n_gpus]
+    if kind == "pencils" and n_gpus > 1:
+        return (1, 2, n_gpus // 2)
+    return (1, 1, n_gpus)
 
 
 def cpu_baseline(n, steps):
@@ -92,6 +96,8 @@ def main():
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
                     help="channel: BASELINE configs[4]-style wall-bounded case (1 GPU), dims from --dims")
     ap.add_argument("--dims", default="1024,257,512", help="channel vertex dims nx,ny,nz")
+    ap.add_argument("--decomp", default="slabs", choices=["slabs", "pencils"],
+                    help="N > 1: z slabs [1,1,N] (default) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     args = ap.parse_args()
@@ -130,7 +136,7 @@ def main():
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
 
-    nproc_dir = decomposition(args.gpus)
+    nproc_dir = decomposition(args.gpus, args.decomp)
     dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()
     if args.case == "channel":

@@ -32,9 +32,14 @@ def main():
     fused = sys.argv[4] == "fused"
     poisson = sys.argv[5]
     out = sys.argv[6]
-    dist.init_process_group("gloo")
+    if os.environ.get("X3D_TEST_NCCL") == "1":  # one device per rank, RCCL (tests/test_hip_parity.py, nccl test)
+        lr = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+    else:
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
     rank = dist.get_rank()
-    torch.cuda.set_device(0)
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
     nsp = int(sys.argv[7]) if len(sys.argv) > 7 else 0

@@ -347,13 +347,15 @@ def test_fused_full_step_matches_op_granular_and_survey_trace():
 
 
 # ---------------------------------------------------------------- multi-rank (DistD2 + pencil FFT)
-def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0):
+def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0, nccl=False):
     import os
     import subprocess
     import sys
     nproc = int(np.prod(nproc_dir))
     out = str(tmp_path / "mp")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nccl:
+        env["X3D_TEST_NCCL"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", "29517",
            os.path.join(os.path.dirname(__file__), "mp_gpu_worker.py"), ",".join(map(str, nproc_dir)),
@@ -402,6 +404,29 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
         assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
     assert abs(rows[-1][1] - rrows[-1][1]) < 1e-12 * abs(rrows[-1][1])
     assert rows[-1][2] < max(1e-11, 3 * rrows[-1][2])  # max |div u|: round-off level of the single-rank run
+
+
+@pytest.mark.parametrize("nproc_dir,dims", [((1, 1, 2), (32, 512, 512)), ((1, 2, 1), (32, 512, 64)),
+                                            ((1, 1, 4), (32, 512, 1024)), ((1, 2, 4), (32, 512, 1024))])
+def test_multirank_over_rccl_one_device_per_rank(nproc_dir, dims, tmp_path):
+    """the N > 1 path as bench.py runs it: one process per GPU, backend "nccl" (RCCL over xGMI), exchanges
+    started on the communication stream and overlapped with kernels (Comm.isendrecv / ialltoall), single-pass
+    HALO kernels, slab / pencil Poisson solver -- against the single-rank run.  Needs as many devices as ranks:
+    skipped on the one-GPU boxes, runs wherever the tests see a multi-GPU node."""
+    import torch
+    from x3d2_amd import make_tgv
+    nproc = int(np.prod(nproc_dir))
+    if torch.cuda.device_count() < nproc:
+        pytest.skip(f"{nproc} devices needed, {torch.cuda.device_count()} visible")
+    g, rows = _run_ranks(nproc_dir, dims, 2, True, "FFT", tmp_path, nccl=True)
+    assert g.pop("halo_launches") > 0
+    ref = make_tgv(dims, fused=True)
+    ref.solver.n_output = 2
+    rrows = ref.run(n_iters=2)
+    b = ref.solver.backend
+    for name, f in zip("uvw", (ref.solver.u, ref.solver.v, ref.solver.w)):
+        assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
+    assert abs(rows[-1][1] - rrows[-1][1]) < 1e-12 * abs(rrows[-1][1])
 
 
 def _run_fixture_worker(args, tmp_path, port):
