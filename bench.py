@@ -41,10 +41,18 @@ def decomposition(n_gpus, kind="slabs"):
 
 
 def cpu_baseline(n, steps):
-    """oracle (CPU restatement of the reference OpenMP backend, SZ=16 layout)
-    timed on this host's cores: TGV n^3 RK3 full step incl. FFT Poisson."""
+    """oracle (CPU restatement of the reference OpenMP backend, SZ=16 layout: C + OpenMP kernels for every
+    operator, reorder, sum and BLAS-1 pass, pocketfft with one worker per core for the DFT) timed on this host's
+    cores: TGV n^3 RK3 full step incl. FFT Poisson.  n = 0: 512^3 (the GPU leg's size) when the host has the
+    memory for it (~60 GiB), else 256^3."""
     from oracle import x3d_oracle as orc
     threads = int(os.environ["OMP_NUM_THREADS"])
+    if n <= 0:
+        try:
+            import psutil
+            n = 512 if psutil.virtual_memory().available > 256 * 2 ** 30 else 256
+        except ImportError:
+            n = 256
     twopi = 6.283185307179586
     mesh = orc.Mesh([n] * 3, [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
     s = orc.Solver(mesh, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT")
@@ -56,8 +64,63 @@ def cpu_baseline(n, steps):
     dt = time.perf_counter() - t0
     return {"value": n ** 3 * steps / dt, "unit": "DoF*steps/s", "cores": threads, "kind": "port",
             "sample": f"TGV {n}^3 RK3 full fractional step (FFT Poisson), {steps} steps after 1 warm-up, "
-                      f"oracle/x3d_oracle (C+OpenMP kernels, numpy FFT) on {threads} threads",
-            "seconds": dt}
+                      f"oracle/x3d_oracle (C + OpenMP kernels, pocketfft on all cores) on {threads} threads",
+            "seconds": dt, "n": n}
+
+
+REF_NML = """&domain_settings
+flow_case_name = 'tgv'
+L_global = 6.283185307179586d0, 6.283185307179586d0, 6.283185307179586d0
+dims_global = {n}, {n}, {n}
+nproc_dir = 1, 1, 1
+BC_x = 'periodic', 'periodic'
+BC_y = 'periodic', 'periodic'
+BC_z = 'periodic', 'periodic'
+/End
+&solver_params
+Re = 1600d0
+time_intg = 'RK3'
+dt = 0.001d0
+n_iters = {iters}
+n_output = 1000
+poisson_solver_type = 'CG'
+der1st_scheme = 'compact6'
+der2nd_scheme = 'compact6'
+interpl_scheme = 'classic'
+stagder_scheme = 'compact6'
+/End
+"""
+
+
+def cpu_reference(n, iters, threads):
+    """the REAL reference -- its own xcompact (OpenMP backend), compiled from /root/reference's sources where they lie
+    by oracle/ref/Makefile (flang -O3, AVX2; shipped prebuilt in oracle/_ref/fast, git-ignored) -- timed on this
+    host: TGV n^3, RK3, poisson_solver_type = 'CG' (the reference's placeholder = NO pressure solve: its FFT Poisson
+    needs 2decomp&FFT, which cannot be built here), its own "Averaged time per step" (first step excluded,
+    src/case/base_case.f90:256-260, 339-342).  None when the binary did not travel."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "fast", "xcompact")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as wd:
+        with open(os.path.join(wd, "input.x3d"), "w") as f:
+            f.write(REF_NML.format(n=n, iters=iters))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        try:
+            r = subprocess.run([exe, "input.x3d"], cwd=wd, env=env, capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+    m = re.search(r"Averaged time per step \(s\):\s*([0-9.eE+-]+)", r.stdout)
+    if r.returncode != 0 or not m:
+        return None
+    t = float(m.group(1))
+    return {"value": n ** 3 / t, "unit": "DoF*steps/s", "cores": threads, "kind": "reference",
+            "sample": f"the reference's xcompact (OpenMP backend, flang -O3 build of /root/reference's sources), TGV {n}^3 "
+                      f"RK3, derivatives + RK only (poisson_solver_type='CG': no pressure solve), {iters} steps, its own "
+                      f"average without the first step, {threads} OpenMP threads",
+            "seconds_per_step": t, "n": n}
 
 
 def spawn_ranks(n):
@@ -90,8 +153,9 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="grid points per GPU per direction")
     ap.add_argument("--time-intg", default="RK3")
     ap.add_argument("--no-poisson", action="store_true", help="BASELINE configs[1]: derivatives + RK only")
-    ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline grid (0: 512 if the host has the memory, else 256)")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the port baseline (its best measured count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
                     help="channel: BASELINE configs[4]-style wall-bounded case (1 GPU), dims from --dims")
@@ -221,23 +285,27 @@ def main():
     bytes_per_launch = total_floor / max(n_f, 1)  # per component
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
     achieved_survey = total_survey / max(n_f, 1) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC counters cannot be collected inside a timed run (rocprofv3 --pmc passes,
+    # scratch/round_artifacts.sh): the figure printed here is the one measured at the commit named next to it
+    traffic = traffic_commit = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.case == "tgv" and args.gpus == 1 and not args.op_granular:
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("n") == args.n:
+            if tj.get("n") == args.n and tj.get("commit"):
                 traffic = tj.get("transeq_component_bytes_per_launch")
+                traffic_commit = tj.get("commit")
         except Exception:
-            traffic = None
+            traffic = traffic_commit = None
     roofline = {"bound": "hbm",
                 "kernel": "transeq component (one third of a k_xscan_transeq2x3 (x) / k_ytile_transeq3 (y, z) launch at "
                           "512^3; x launches that also apply the pending velocity correction include its bytes)",
                 "three_in_one_launches": n_tq3, "launches_with_velocity_correction": n_upd,
                 "achieved_survey_per_unit": achieved_survey, "frac_survey_per_unit": achieved_survey / HBM_PEAK_GBS,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "survey_transeq_bytes_per_component": transeq_bytes, "rk_stage_fused_launches": n_fused,
                 "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
                 "avg_launch_ms": avg_ms, "launches": n_f, "per_direction": per_dir,
@@ -270,7 +338,14 @@ def main():
         "kernel_ms": prof,
     }
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
+        # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
+        # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)
+        phys = int(os.environ["OMP_NUM_THREADS"])
+        os.environ["OMP_NUM_THREADS"] = str(min(phys, args.cpu_threads))
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
+        ref = cpu_reference(256, 4, phys)
+        if ref is not None:
+            out["cpu_baseline"]["reference_nopoisson"] = ref
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import shutil
+import subprocess
 import sys
 
 prof_tag, pmc_tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -39,7 +40,11 @@ tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_t
 n_comp = sum(n * (3 if ("transeq2x3" in k or "transeq3" in k) else 1) for k, n, fe, wr in rows if any(h in k for h in heads))
 comp = tot_bytes / n_comp if n_comp else 0.0
 calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
-json.dump({"n": 512, "round": rnd, "transeq_component_bytes_per_launch": comp,
+commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "x3d2_amd", "bench.py"], capture_output=True,
+                            text=True).stdout.strip())
+json.dump({"n": 512, "round": rnd, "commit": commit + ("+uncommitted" if dirty else ""),
+           "transeq_component_bytes_per_launch": comp,
            "components_profiled": n_comp,
            "note": "HBM bytes per transport-equation component (all k_*transeq* + k_transpose64 + k_transpose_lincomb kernels / number of components; the latter also does the RK stage's linear combination) "
                    "from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
