@@ -14,7 +14,12 @@
 
 struct x3d_poisson {
     x3d_backend *b;
-    int nx, ny, nz, nxs;  // cell dims, nxs = nx/2+1
+    int nx, ny, nz;       // cell dims
+    int nxm, nxs;         // nxm = nx/2+1 modes per row; nxs = the row PITCH of every spectral-side array: nxm rounded
+                          // up to 8 complex numbers (128 B), so that the 128 / 256-byte row segments of the strided
+                          // y / z passes are line-aligned (dense rows of 257 made every segment straddle a third
+                          // 128-byte line: 1.44-1.6 x the compulsory fetch, round-1 PMC).  Pad columns hold zeros
+                          // (waves: ones) and are carried through every kernel; host arrays stay dense.
     hipfftHandle plan_fw, plan_bw;
     double2 *c;           // spectral workspace [nz][ny][nxs]
     double *waves;        // [nz][ny][nxs]
@@ -44,6 +49,22 @@ int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis
             return 3;                                                                          \
         }                                                                                      \
     } while (0)
+
+// pad columns [nxm, nxs) of a pitched array of doubles <- v
+__global__ void k_fill_pad(double *__restrict__ a, size_t rows, int nxm, int nxs, double v)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (int i = nxm; i < nxs; i++) a[r * nxs + i] = v;
+}
+
+// dense host rows [rows][nxm] -> pitched device rows [rows][nxs] (elem: bytes per element), pads = 0
+static int upload_pitched(void *dst, const void *src, size_t rows, int nxm, int nxs, size_t elem)
+{
+    X3D_HIP(hipMemset(dst, 0, rows * nxs * elem));
+    X3D_HIP(hipMemcpy2D(dst, nxs * elem, src, nxm * elem, nxm * elem, rows, hipMemcpyHostToDevice));
+    return 0;
+}
 
 // One thread per spectral entry, x fastest -> coalesced 16 B per lane.
 // 1R(c) + 1R(waves) + 1W(c): 40 B per complex entry.
@@ -101,11 +122,21 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
     x3d_poisson *p = new x3d_poisson();
     memset(p, 0, sizeof *p);
     p->b = b;
-    p->nx = n[0]; p->ny = n[1]; p->nz = n[2]; p->nxs = n[0] / 2 + 1;
-    const size_t ns = (size_t)p->nz * p->ny * p->nxs;
+    p->nx = n[0]; p->ny = n[1]; p->nz = n[2]; p->nxm = n[0] / 2 + 1;
+    {
+        const char *e = getenv("X3D_NO_SPECTRAL_PAD");  // (A/B: dense rows as in round 1)
+        p->nxs = (e && e[0] == '1') ? p->nxm : (p->nxm + 7) / 8 * 8;
+    }
+    const size_t rows = (size_t)p->nz * p->ny, ns = rows * p->nxs;
     X3D_HIP(hipMalloc(&p->c, sizeof(double2) * ns));
+    X3D_HIP(hipMemset(p->c, 0, sizeof(double2) * ns));
     X3D_HIP(hipMalloc(&p->waves, sizeof(double) * ns));
-    X3D_HIP(hipMemcpy(p->waves, waves_re, sizeof(double) * ns, hipMemcpyHostToDevice));
+    if (int rc = upload_pitched(p->waves, waves_re, rows, p->nxm, p->nxs, sizeof(double))) return rc;
+    if (p->nxs > p->nxm) {
+        hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, p->waves, rows, p->nxm,
+                           p->nxs, 1.0);
+        X3D_HIP(hipDeviceSynchronize());
+    }
     const size_t nab = 2 * ((size_t)n[0] + n[1] + n[2]);
     X3D_HIP(hipMalloc(&p->ab, sizeof(double) * nab));
     double *d = p->ab;
@@ -146,11 +177,11 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
             const char *no_rwt = getenv("X3D_NO_RWT");
             if (!(no_rwt && no_rwt[0] == '1')) {
                 const size_t nsr = (size_t)p->nz * p->ny * p->nxs;
-                std::vector<double> h(nsr);
+                std::vector<double> h(nsr, 0.0);  // (pad columns: 0)
                 for (int k = 0; k < p->nz; k++)
                     for (int j = 0; j < p->ny; j++)
-                        for (int i = 0; i < p->nxs; i++) {
-                            const double wv = waves_re[((size_t)k * p->ny + j) * p->nxs + i];
+                        for (int i = 0; i < p->nxm; i++) {
+                            const double wv = waves_re[((size_t)k * p->ny + j) * p->nxm + i];
                             h[((size_t)j * p->nxs + i) * p->nz + k] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
                         }
                 X3D_HIP(hipMalloc(&p->rwT, sizeof(double) * nsr));
@@ -503,11 +534,12 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_poisson_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
     X3D_REQUIRE(n >= 3, "x3d_poisson_set_stretching: too few rows");
-    const size_t bytes = sizeof(double) * 5 * (size_t)p->nz * n * p->nxs;
+    const size_t rows = 5 * (size_t)p->nz * n, bytes = sizeof(double) * rows * p->nxs;
     const double *src[2] = {a0, a1};
     for (int s = 0; s < (sym ? 2 : 1); s++) {
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
-        X3D_HIP(hipMemcpy(p->lu[s], src[s], bytes, hipMemcpyHostToDevice));
+        // (pad columns all zero: k_penta_factor / k_penta_solve guard their divisions by |a3| > eps)
+        if (int rc = upload_pitched(p->lu[s], src[s], rows, p->nxm, p->nxs, sizeof(double))) return rc;
         hipLaunchKernelGGL(k_penta_factor, dim3((p->nxs + 63) / 64, p->nz), dim3(64), 0, p->b->stream, p->lu[s],
                            p->nxs, n, p->nz);
         X3D_HIP(hipGetLastError());
@@ -563,17 +595,15 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
 extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, double *host)
 {
     X3D_REQUIRE(p && host, "null argument");
-    const size_t ns = (size_t)p->nz * p->ny * p->nxs;
     X3D_HIP(hipStreamSynchronize(p->b->stream));
-    X3D_HIP(hipMemcpy(host, p->c, sizeof(double2) * ns, hipMemcpyDeviceToHost));
+    X3D_HIP(hipMemcpy2D(host, p->nxm * sizeof(double2), p->c, p->nxs * sizeof(double2), p->nxm * sizeof(double2),
+                        (size_t)p->nz * p->ny, hipMemcpyDeviceToHost));
     return 0;
 }
 
 extern "C" int x3d_poisson_set_spectral(x3d_poisson *p, const double *host)
 {
     X3D_REQUIRE(p && host, "null argument");
-    const size_t ns = (size_t)p->nz * p->ny * p->nxs;
     X3D_HIP(hipStreamSynchronize(p->b->stream));
-    X3D_HIP(hipMemcpy(p->c, host, sizeof(double2) * ns, hipMemcpyHostToDevice));
-    return 0;
+    return upload_pitched(p->c, host, (size_t)p->nz * p->ny, p->nxm, p->nxs, sizeof(double2));
 }
