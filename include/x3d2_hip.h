@@ -252,6 +252,15 @@ int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double
                       double *sum_abs);
 int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out);
 /* slice_max_sum (:252-271): plane i_slice (1-based) normal to `dir` */
+/* channel case without host round trips (define_BC_channel, src/case/channel.f90:59-130; one rank):
+ *  x3d_field_shift_to_mean: f += target - volume_integral(f) / ncell, the sum finished on the device in the order of
+ *    x3d_field_volume_integral (bit-identical to field_volume_integral + field_shift, :70-77);
+ *  x3d_wall_noise: planes y = 1 and y = ny of f <- amp * (2 r - 1), r in [0, 1) from a counter-based generator
+ *    (splitmix64 of seed + draw, then of that key + (face * nz + k) * nx + i; 53 bits) instead of the host's
+ *    random_number planes and three full-block uploads per sub-step (:97-130) */
+int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target);
+int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
+                   unsigned long long draw);
 int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
                       double *max_val, double *sum_val);
 

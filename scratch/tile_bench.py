@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--dims", default="", help="nx,ny,nz (y-direction kernels only make sense with --only pairy)")
     args = ap.parse_args()
     alt = os.environ.get("X3D_LIB")
     from x3d2_amd import _lib
@@ -28,7 +29,8 @@ def main():
     import torch
     from x3d2_amd import make_tgv
     from x3d2_amd.common import DIR_X, DIR_Y, DIR_Z
-    case = make_tgv(args.n, poisson="CG", fused=True)
+    dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else args.n
+    case = make_tgv(dims, poisson="CG", fused=True)
     s = case.solver
     b, al = s.backend, s.backend.allocator
     s.w.fill(0.3)
@@ -36,6 +38,7 @@ def main():
     for f in o:
         f.fill(0.0)
     n = args.n
+    npts = (dims[0] * dims[1] * dims[2]) if args.dims else n ** 3
 
     def timed(name, fn, passes):
         for _ in range(3):
@@ -46,7 +49,7 @@ def main():
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.iters * 1e3
-        print("%-44s %7.3f ms  %5.2f TB/s (%d passes)" % (name, ms, passes * 8.0 * n ** 3 / ms / 1e9, passes), flush=True)
+        print("%-44s %7.3f ms  %5.2f TB/s (%d passes)" % (name, ms, passes * 8.0 * npts / ms / 1e9, passes), flush=True)
 
     y, z = s.ydirps, s.zdirps
     nu = s.nu
@@ -62,6 +65,18 @@ def main():
         hb = b.transeq_halo_main(DIR_Z, o[0], o[1], o[2], s.u, s.v, s.w, nu, z, True, h)
         timed("transeq z halo fix", lambda: b.transeq_halo_finish(DIR_Z, o[0], o[1], o[2], s.u, s.v, s.w, nu, z, hb), 1)
         timed("pack halos x3 + self exchange", lambda: b.transeq_halo_begin(DIR_Z, s.u, s.v, s.w), 1)
+    if args.only == "pairy":
+        d, dp, nm, nz_ = DIR_Y, y, "y", dims[2]
+        b._emulate = ""
+        j0 = (0, o[0], None, s.u, s.v, dp.interpl_v2p, dp.stagder_v2p)
+        j1 = (1, o[0], o[1], s.u, None, dp.interpl_p2v, dp.stagder_p2v)
+        j2 = (2, o[0], None, s.u, None, dp.interpl_v2p, None)
+        timed(f"pair mode 0 {nm} local", lambda: b.tds_tile_planes(d, j0, 0, nz_), 3)
+        timed(f"pair mode 1 {nm} local", lambda: b.tds_tile_planes(d, j1, 0, nz_), 3)
+        timed(f"single (mode 2) {nm} local tile", lambda: b.tds_tile_planes(d, j2, 0, nz_), 2)
+        timed(f"single {nm} K1e", lambda: b.tds_apply(o[0], s.u, dp.interpl_v2p, d), 2)
+        timed("transeq3 y local (acc)", lambda: b.transeq_planes(DIR_Y, o[0], o[1], o[2], s.u, s.v, s.w, nu, y, True, 0, nz_), 9)
+        return
     if args.only in ("", "pair"):
         for d, dp, nm in ((DIR_Y, y, "y"), (DIR_Z, z, "z")):
             b._emulate = ""

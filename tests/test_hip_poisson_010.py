@@ -208,3 +208,67 @@ def test_unchanged_reference_channel_case_through_fortran_shim(tmp_path):
     assert rows.shape[0] == mine.shape[0] == 4
     assert np.allclose(rows[:, 1], mine[:, 1], rtol=1e-11, atol=0), (rows[:, 1], mine[:, 1])
     assert np.all(rows[1:, 2] < 1e-5) and np.allclose(rows[1:, 2], mine[1:, 2], rtol=1e-3)
+
+
+def test_bulk_velocity_shift_on_the_device_is_bit_identical_to_the_host_path():
+    """define_BC_channel's correction (src/case/channel.f90:70-77): field_volume_integral -> host -> field_shift
+    against x3d_field_shift_to_mean (partial sums finished on the device in the same order)"""
+    from x3d2_amd import make_channel
+    from x3d2_amd.common import CELL
+    case = make_channel((48, 33, 20), poisson="CG")
+    s = case.solver
+    b = s.backend
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((20, 33, 48))
+    b.set_field_data(s.u, a)
+    ub = b.field_volume_integral(s.u) / float(np.prod(s.mesh.get_global_dims(CELL)))
+    b.field_shift(s.u, 2.0 / 3.0 - ub)
+    host = b.get_field_data(s.u)
+    b.set_field_data(s.u, a)
+    b.field_shift_to_mean(s.u, 2.0 / 3.0)
+    assert np.array_equal(b.get_field_data(s.u), host)
+
+
+def test_wall_noise_generated_on_the_device():
+    """x3d_wall_noise against a numpy restatement of its counter-based generator (splitmix64): the two wall
+    planes bit for bit, every other plane untouched, repeatable for a seed, a new draw differs; and the channel
+    case with inlet noise runs without host uploads and keeps the bulk velocity at 2/3"""
+    from x3d2_amd import make_channel
+    from x3d2_amd.common import CELL, DIR_X, VERT
+
+    def mix64(z):
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    nx, ny, nz = 40, 17, 12
+    case = make_channel((nx, ny, nz), poisson="CG", inlet_noise=(0.125, 0.25, 0.5), seed=1234)
+    b = case.solver.backend
+    f = b.allocator.get_block(DIR_X, VERT)
+    f.fill(7.0)
+    seed, draw, amp = 1234, 5, 0.25
+    b.wall_noise(f, amp, seed, draw)
+    got = b.get_field_data(f, VERT)
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(seed + draw))
+        q = np.arange(2 * nx * nz, dtype=np.uint64)
+        r = (mix64(key + q) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    want = (amp * (2.0 * r - 1.0)).reshape(2, nz, nx)
+    assert np.array_equal(got[:, 0, :], want[0]) and np.array_equal(got[:, -1, :], want[1])
+    assert np.all(got[:, 1:-1, :] == 7.0)
+    assert abs(want.mean()) < 0.02 and abs(want.std() - amp / np.sqrt(3.0)) < 0.02 and np.abs(want).max() <= amp
+    b.wall_noise(f, amp, seed, draw + 1)
+    assert not np.array_equal(b.get_field_data(f, VERT)[:, 0, :], want[0])
+    # the case: two steps with wall noise; the walls carry the noise, the bulk velocity stays at 2/3
+    case.step(1)
+    case.step(2)
+    s = case.solver
+    case.define_BC()
+    ub = b.field_volume_integral(s.u) / float(np.prod(s.mesh.get_global_dims(CELL)))
+    # (the reference divides the sum over VERTICES by the number of CELLS, src/case/channel.f90:68-72, so the
+    #  corrected mean sits at 2/3 only up to (ny_vert - ny_cell) / ny_cell of the shift)
+    assert abs(ub - 2.0 / 3.0) < 1e-3
+    wall = b.get_field_data(case.bc_start_y[2], VERT)
+    assert 0.0 < np.abs(wall[:, 0, :]).max() <= 0.5 and np.all(wall[:, 1:-1, :] == 0.0)
+    assert np.all(np.isfinite(b.get_field_data(s.u)))

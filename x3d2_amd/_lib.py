@@ -74,6 +74,8 @@ PROTOTYPES = {
     "x3d_scalar_product": (I, [VP, VP, VP, c_int_p, c_double_p]),
     "x3d_field_max_sum": (I, [VP, VP, c_int_p, c_double_p, c_double_p]),
     "x3d_field_volume_integral": (I, [VP, VP, c_int_p, c_double_p]),
+    "x3d_field_shift_to_mean": (I, [VP, VP, c_int_p, D, D]),
+    "x3d_wall_noise": (I, [VP, VP, c_int_p, D, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "x3d_slice_max_sum": (I, [VP, VP, c_int_p, I, I, c_double_p, c_double_p]),
     "x3d_field_set_face": (I, [VP, VP, c_int_p, D, D, I]),
     "x3d_field_set_face_from_field": (I, [VP, VP, VP, c_int_p, D, I, D]),

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .common import (DIR_C, DIR_X, DIR_Y, DIR_Z, N_HALO, NULL_LOC, X_FACE, Y_FACE, Z_FACE, X3dError,
+from .common import (CELL, DIR_C, DIR_X, DIR_Y, DIR_Z, N_HALO, NULL_LOC, VERT, X_FACE, Y_FACE, Z_FACE, X3dError,
                      get_rdr_from_dirs, move_data_loc)
 from .field import Allocator
 from .parallel import Comm
@@ -694,6 +694,24 @@ class HipBackend:
         _lib.check(self.lib.x3d_slice_max_sum(self.h, f.ptr, self._dims(loc), f.dir, int(i_slice),
                                               ctypes.byref(mx), ctypes.byref(sm)))
         return mx.value, sm.value
+
+    def field_shift_to_mean(self, f, target):
+        """f += target - volume_integral(f) / ncell_global: define_BC_channel's bulk-velocity correction
+        (src/case/channel.f90:70-77).  One rank: reduction, difference and shift stay on the device."""
+        if f.data_loc == NULL_LOC:
+            raise X3dError("You must set the data_loc before calling volume integral.")
+        if f.dir != DIR_X:
+            raise X3dError("Volume integral can only be called on DIR_X fields.")
+        ncell = float(np.prod(self.mesh.get_global_dims(CELL)))
+        if self.comm.size > 1:
+            self.field_shift(f, target - self.field_volume_integral(f) / ncell)
+            return
+        _lib.check(self.lib.x3d_field_shift_to_mean(self.h, f.ptr, self._dims(f.data_loc), ncell, float(target)))
+
+    def wall_noise(self, f, amp, seed, draw):
+        """planes y = 1 and y = ny of the (VERT) wall field f <- amp * (2 r - 1), generated on the device"""
+        _lib.check(self.lib.x3d_wall_noise(self.h, f.ptr, self._dims(VERT), float(amp), int(seed) & (2 ** 64 - 1),
+                                           int(draw) & (2 ** 64 - 1)))
 
     def field_volume_integral(self, f):
         if f.data_loc == NULL_LOC:

@@ -170,7 +170,10 @@ class ChannelCase(BaseCase):
 
     def __init__(self, solver, channel_cfg=None):
         self.channel_cfg = channel_cfg or ChannelConfig()
-        self.rng = np.random.default_rng(self.channel_cfg.seed)
+        self.rng = np.random.default_rng(self.channel_cfg.seed)  # initial condition (host, once)
+        seed = self.channel_cfg.seed
+        self.noise_seed = int(seed) if seed is not None else int(np.random.SeedSequence().entropy) & (2 ** 63 - 1)
+        self.noise_draws = 0
         self.bc_start_y = None
         super().__init__(solver)
 
@@ -194,8 +197,7 @@ class ChannelCase(BaseCase):
 
     def define_BC(self):  # :53-137
         s, b = self.solver, self.solver.backend
-        ub = b.field_volume_integral(s.u) / float(np.prod(s.mesh.get_global_dims(CELL)))
-        b.field_shift(s.u, 2.0 / 3.0 - ub)
+        b.field_shift_to_mean(s.u, 2.0 / 3.0)  # ub -> 2/3, no host round trip on one rank
         noise = self.channel_cfg.inlet_noise
         first = self.bc_start_y is None
         if first:
@@ -204,12 +206,12 @@ class ChannelCase(BaseCase):
                 f.set_data_loc(VERT)
                 f.fill(0.0)
         if any(n != 0.0 for n in noise):
-            nx, ny, nz = s.mesh.get_dims(VERT)
-            for f, n in zip(self.bc_start_y, noise):
-                a = np.zeros((nz, ny, nx))
-                a[:, 0, :] = n * (2.0 * self.rng.random((nz, nx)) - 1.0)
-                a[:, -1, :] = n * (2.0 * self.rng.random((nz, nx)) - 1.0)
-                b.set_field_data(f, a)
+            # the reference draws six random_number planes on the host and uploads three full blocks per
+            # sub-step (:97-130); here the wall planes are generated in place (x3d_wall_noise).  `draw` numbers
+            # the draws so that a run is repeatable for a given seed (the reference's is not: unseeded)
+            for c, (f, n) in enumerate(zip(self.bc_start_y, noise)):
+                b.wall_noise(f, n, self.noise_seed, 3 * self.noise_draws + c)
+            self.noise_draws += 1
 
     def forcings(self, du, dv, dw, it):  # :191-207
         c, s = self.channel_cfg, self.solver

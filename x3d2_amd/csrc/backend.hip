@@ -461,6 +461,93 @@ extern "C" int x3d_field_volume_integral(x3d_backend *b, const double *f, const 
     return run_reduce<RED_SUM>(b, f, f, dims, out, nullptr);
 }
 
+// ---------------------------------------------------------------- channel case, per sub-step, without the host
+// define_BC_channel (src/case/channel.f90:59-130) does, per sub-step: ub = field_volume_integral(u) / ncell
+// (+ MPI_Allreduce), field_shift(u, 2/3 - ub), and -- on the host -- 6 random_number planes scaled to
+// noise * (2 r - 1), uploaded as 3 full blocks.  On one rank nothing of that needs the host:
+//   x3d_field_shift_to_mean: the partial sums stay on the device, one thread adds them in the order the host
+//     would (bit-identical to x3d_field_volume_integral + x3d_field_shift), the shift kernel reads the result;
+//   x3d_wall_noise: the two wall planes are generated in place by a counter-based generator.
+__global__ void k_finish_shift(const double *__restrict__ part, int n, double ncell, double target,
+                               double *__restrict__ out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; i++) s += part[i];  // the order of run_reduce's host loop
+        out[0] = target - s / ncell;               // can = 2/3 - ub, src/case/channel.f90:70-77
+        out[1] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_shift_dev(double2 *__restrict__ f, size_t n2, const double *__restrict__ a)
+{
+    const double sh = a[0];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 v = f[i];
+        v.x += sh; v.y += sh;
+        f[i] = v;
+    }
+}
+
+extern "C" int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target)
+{
+    X3D_REQUIRE(b && f && dims && ncell > 0.0, "x3d_field_shift_to_mean: bad argument");
+    X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
+                "x3d_field_shift_to_mean: dims outside the block");
+    const long nrow = (long)dims[1] * dims[2];
+    const int grid = (int)(nrow < 2048 ? nrow : 2048);
+    {
+        ProfScope ps(b, X3D_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce<RED_SUM>, dim3(grid), dim3(256), 0, b->stream, (const double *)f, (const double *)f,
+                           dims[0], dims[1], dims[2], (long)b->nxp, (long)b->nyp, b->red_buf, b->red_buf + b->red_cap);
+        hipLaunchKernelGGL(k_finish_shift, dim3(1), dim3(64), 0, b->stream, (const double *)b->red_buf, grid, ncell,
+                           target, b->red_buf + 2 * b->red_cap - 2);
+    }
+    ProfScope ps(b, X3D_K_BLAS1);
+    const size_t n2 = b->nblock / 2;
+    hipLaunchKernelGGL(k_shift_dev, dim3(2048), dim3(256), 0, b->stream, (double2 *)f, n2,
+                       (const double *)(b->red_buf + 2 * b->red_cap - 2));
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// splitmix64 of (seed, counter): the value depends on its inputs only, not on the launch geometry
+__host__ __device__ inline unsigned long long x3d_mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// planes y = 1 and y = ny of f <- amp * (2 r - 1), r uniform in [0, 1) with 53 random bits:
+// r(face, i, k) = mix64(mix64(seed + draw) + (face * nz + k) * nx + i) >> 11) * 2^-53
+__global__ void __launch_bounds__(256) k_wall_noise(double *__restrict__ f, int nx, int ny, int nz, long nxp, long nyp,
+                                                    double amp, unsigned long long key)
+{
+    const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (q >= 2L * nx * nz) return;
+    const int face = (int)(q / ((long)nx * nz));
+    const long r = q - (long)face * nx * nz;
+    const int i = (int)(r % nx), k = (int)(r / nx);
+    const double u01 = (double)(x3d_mix64(key + (unsigned long long)q) >> 11) * 0x1.0p-53;
+    f[i + nxp * ((face ? ny - 1 : 0) + nyp * (long)k)] = amp * (2.0 * u01 - 1.0);
+}
+
+extern "C" int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
+                              unsigned long long draw)
+{
+    X3D_REQUIRE(b && f && dims, "x3d_wall_noise: null argument");
+    X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 1 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
+                "x3d_wall_noise: dims outside the block");
+    const long n = 2L * dims[0] * dims[2];
+    ProfScope ps(b, X3D_K_COPY);
+    hipLaunchKernelGGL(k_wall_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, f, dims[0], dims[1],
+                       dims[2], (long)b->nxp, (long)b->nyp, amp, x3d_mix64(seed + draw));
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
 // slice_max_sum: signed max and sum over the plane i_slice of direction dir
 __global__ void __launch_bounds__(256) k_slice(const double *__restrict__ f, int n0, int n1, long s0, long s1,
                                                long off, double *__restrict__ part_sum,

@@ -1261,7 +1261,7 @@ __global__ void __launch_bounds__(1024)
         if (MODE != 2) lt[LN + i] = tb.TL[i];
     }
     const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
-    double *tile = lt + 2 * LN;
+    double *tile = lt + (MODE == 2 ? 1 : 2) * LN;  // (a single operator stages one table set)
     // HALO, MODE 0: no room for the next tile's rows next to the second input's (with them in flight across the
     // solves the kernel spills inside the tile loop, and every reload is an exposed memory latency: 1.40 ms
     // against 0.95 for the local form): this tile's rows are requested at its top instead
@@ -1731,7 +1731,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     };
     if (!fast(ta) || !fast(tb) || (dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
     if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return 0; }
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
+    const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
@@ -1740,7 +1740,9 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
     if (ntiles <= 0) { *done = true; return 0; }
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
-    const int blocks = ntiles > 256 ? 256 : ntiles;
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
+    const int blocks = ntiles > cap ? cap : ntiles;
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_, H_)                                                                                      \
