@@ -95,6 +95,20 @@ int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tds
  * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
 int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+/* ---- compact10_penta: 10th-order first derivative with a pentadiagonal left-hand side (src/tdsops.f90:235-251,
+ * LU factors preprocess_penta_dist :971-1103; kernels der_penta_full / der_penta_periodic,
+ * src/backend/omp/kernels/distributed.f90:339-691; drivers exec_dist_penta_compact / _periodic,
+ * src/backend/omp/exec_dist.f90:188-241 -- local solves, no exchange).  The operator is created with
+ * x3d_tdsops_create (dist_fw = 1/d, dist_af = l1, dist_sa = l2, dist_bw = u1, as the reference repurposes them) and
+ * completed by x3d_tdsops_set_penta; halo_kind: 1 periodic (Sherman-Morrison-Woodbury correction), 2 BC_NEUMANN with
+ * sym (even mirror ghosts), 3 BC_NEUMANN without (odd), 4 BC_DIRICHLET (one-sided closures, ghosts unused).
+ * x3d_tds_penta_solve: u_s / u_e = ghost rows [4][npencil] or both NULL (formed in the kernel from halo_kind). */
+int x3d_tdsops_set_penta(x3d_tdsops *t, double alpha, double beta, double beta_lhs_s, const double *dist_fw,
+                         const double *dist_af, const double *dist_sa, const double *dist_bw, const double *coeffs_s,
+                         const double *coeffs_e, int halo_kind);
+int x3d_tds_penta_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, const double *u_s,
+                        const double *u_e);
+
 /* ---- decomposed (BC_HALO) y / z directions in ONE pass + a boundary-strip correction, and plane ranges.
  * The reference's exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-65, 67-186)
  * sweep, exchange one boundary value per pencil and operator with pprev / pnext, and sweep again.  Here the tile

@@ -222,6 +222,17 @@ def main():
         merged["cfg.namelist"] = np.frombuffer(NML.format(**c).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(GOLDEN, f"ref_{name}.npz"), **merged)
         print(f"ref_{name}.npz: {len(merged)} arrays")
+    # compact10_penta first derivative (the reference's pentadiagonal scheme: tdsops_init + exec_dist_penta_*),
+    # set-ups of tests/verification/test_omp_penta.f90 -- oracle/ref/drivers/dump_penta.f90
+    with tempfile.TemporaryDirectory() as wd:
+        out = os.path.join(wd, "penta.bin")
+        r = subprocess.run([os.path.join(REF_OUT, "dump_penta"), out], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
+            raise SystemExit("dump_penta failed")
+        penta = read_bin(out)
+    np.savez_compressed(os.path.join(GOLDEN, "ref_penta.npz"), **penta)
+    print(f"ref_penta.npz: {len(penta)} arrays")
     for name, c in TRACES.items():
         with tempfile.TemporaryDirectory() as wd:
             run("xcompact", c, wd)

@@ -1085,3 +1085,84 @@ def test_deferred_velocity_correction_in_transeq_x(nx):
         o.step()
     for a, fo, nm in zip(fused, (o.u, o.v, o.w), "uvw"):
         assert relerr(a, o.backend.get_field_data(fo, orc.VERT)) < 1e-10, nm
+
+
+# ---------------------------------------------------------------- compact10_penta
+@pytest.mark.parametrize("tag,bc,sym", [("dd", 2, False), ("nt", 1, True), ("nf", 1, False), ("pp", 0, False)])
+@pytest.mark.parametrize("direction", [1, 2, 3])
+def test_compact10_penta_vs_reference_vectors(tag, bc, sym, direction):
+    """the reference's pentadiagonal 10th-order first derivative (exec_dist_penta_compact / _periodic run by
+    oracle/ref/drivers/dump_penta.f90) through HipBackend.tds_solve in x, y and z: with the fixture's ghost rows
+    handed over, and with the ghosts formed in the kernel from the operator's boundary condition"""
+    import torch
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import VERT
+    g = load_golden("penta")
+    sc = g[f"penta.{tag}.scalars"]
+    n = int(sc[0])
+    u, us, ue, ref = (g[f"penta.{tag}.{k}"] for k in ("u", "u_s", "u_e", "du"))   # [block 2][row][lane 16]
+    # pencil direction -> the row axis; lanes and blocks fill the other two axes of the Cartesian [z][y][x] array
+    perm = {1: (0, 2, 1), 2: (0, 1, 2), 3: (1, 0, 2)}[direction]   # fixture axes -> (z, y, x)
+    cart = lambda a: np.ascontiguousarray(np.transpose(a, perm))
+    dims = {1: (n, 16, 2), 2: (16, n, 2), 3: (16, 2, n)}[direction]
+    per = ("periodic",) * 2
+    mesh = Mesh(dims, (1, 1, 1), (1.0,) * 3, per, per, per)
+    b = HipBackend(mesh)
+    t = b.alloc_tdsops(n, sc[8], "first-deriv", "compact10_penta", bc, bc, sym=sym)
+    al = b.allocator
+    fu, fd = al.get_block(direction, VERT), al.get_block(direction, VERT)
+    b.set_field_data(fu, cart(u))
+    b.tds_solve(fd, fu, t)                      # ghosts from the boundary condition
+    assert relerr(b.get_field_data(fd, VERT), cart(ref)) < 1e-14
+    # ghost rows handed over: [4][npencil], pencil index = the block's pencil numbering (x3d_npencils)
+    halo = lambda h: torch.tensor(np.ascontiguousarray(
+        np.transpose(cart(h), {1: (2, 0, 1), 2: (1, 0, 2), 3: (0, 1, 2)}[direction]).reshape(4, -1)),
+        dtype=torch.float64, device=b.device)
+    fd.fill(0.0)
+    b.tds_penta_solve(fd, fu, t, direction, halo(us), halo(ue))
+    assert relerr(b.get_field_data(fd, VERT), cart(ref)) < 1e-14
+
+
+def test_compact10_penta_convergence_and_oracle_at_size():
+    """acceptance criteria of tests/verification/test_omp_penta.f90 on the GPU (rates >= 4 Dirichlet, >= 9
+    Neumann / periodic) and the 512-row periodic solve against the oracle"""
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import DIR_Y, VERT
+    pi = np.pi
+    per = ("periodic",) * 2
+
+    def run(n, kind):
+        mesh = Mesh((64, n, 2), (1, 1, 1), (1.0,) * 3, per, per, per)
+        b = HipBackend(mesh)
+        if kind == "dd":
+            dx, bc, sym = 1.0 / (n + 1), 2, False
+            x = np.arange(1, n + 1) * dx
+            f, df = np.sin(pi * x) ** 3, 3 * pi * np.sin(pi * x) ** 2 * np.cos(pi * x)
+        elif kind in ("nt", "nf"):
+            dx, bc, sym = 1.0 / (n - 1), 1, kind == "nt"
+            x = np.arange(n) * dx
+            f = np.cos(10 * pi * x) if sym else np.sin(10 * pi * x)
+            df = -10 * pi * np.sin(10 * pi * x) if sym else 10 * pi * np.cos(10 * pi * x)
+        else:
+            dx, bc, sym = 1.0 / n, 0, False
+            x = np.arange(n) * dx
+            f = np.sin(2 * pi * x) + 0.3 * np.cos(4 * pi * x)
+            df = 2 * pi * np.cos(2 * pi * x) - 1.2 * pi * np.sin(4 * pi * x)
+        t = b.alloc_tdsops(n, dx, "first-deriv", "compact10_penta", bc, bc, sym=sym)
+        fu, fd = b.allocator.get_block(DIR_Y, VERT), b.allocator.get_block(DIR_Y, VERT)
+        b.set_field_data(fu, f[None, :, None] * np.ones((2, 1, 64)))
+        b.tds_solve(fd, fu, t)
+        got = b.get_field_data(fd, VERT)
+        return np.sqrt(np.mean((got[0, :, 5] - df) ** 2)), got, f
+
+    for kind, rate in (("dd", 4.0), ("nt", 9.0), ("nf", 9.0), ("pp", 9.0)):
+        errs = [run(n, kind)[0] for n in (32, 64, 128)]
+        assert np.log2(errs[0] / errs[1]) >= rate - 0.35 or errs[1] < 1e-12, (kind, errs)
+    _, got, f = run(512, "pp")
+    t = orc.PentaOps(512, 1.0 / 512, orc.BC_PERIODIC, orc.BC_PERIODIC)
+    col = lambda a: np.ascontiguousarray(a[None, :, None] * np.ones((1, 1, 16)))
+    ref = t.solve(col(f), col(f[-4:]), col(f[:4]))[0, :, 0]
+    assert relerr(got[1, :, 63], ref) < 1e-13

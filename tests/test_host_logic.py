@@ -324,3 +324,18 @@ def test_bench_spawns_its_own_ranks_without_a_launcher(tmp_path):
     r = subprocess.run([sys.executable, str(w)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert '"rank": 0, "world": 2, "addr": "127.0.0.1"' in r.stdout
+
+
+@pytest.mark.parametrize("tag,bc,sym", [("dd", 2, False), ("nt", 1, True), ("nf", 1, False), ("pp", 0, False)])
+def test_product_compact10_penta_factory_vs_reference(tag, bc, sym):
+    """x3d2_amd.tdsops with scheme 'compact10_penta' against the reference's tdsops_init (stencils, closures and
+    the pentadiagonal LU of preprocess_penta_dist): bit for bit"""
+    from x3d2_amd.tdsops import Tdsops
+    g = load_golden("penta")
+    sc = g[f"penta.{tag}.scalars"]
+    t = Tdsops(int(sc[0]), sc[8], "first-deriv", "compact10_penta", bc, bc, sym=sym)
+    assert t.pentadiag and (t.n_tds, t.n_rhs) == (int(sc[0]), int(sc[1]))
+    assert (t.alpha, t.beta, t.beta_lhs_s, t.a, t.b, t.c) == tuple(sc[2:8])
+    for k in ("dist_fw", "dist_af", "dist_sa", "dist_bw", "coeffs", "coeffs_s", "coeffs_e"):
+        assert np.array_equal(getattr(t, k), g[f"penta.{tag}.{k}"]), k
+    assert not np.any(t.dist_sc)

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "x3d_block_fill": (I, [VP, VP, D]),
     "x3d_tdsops_create": (I, [VP, ctypes.POINTER(VP), I, I, I, I] + [c_double_p] * 10),
     "x3d_tdsops_destroy": (I, [VP]),
+    "x3d_tdsops_set_penta": (I, [VP, D, D, D] + [c_double_p] * 6 + [I]),
+    "x3d_tds_penta_solve": (I, [VP, VP, VP, VP, I, VP, VP]),
     "x3d_tds_solve": (I, [VP, VP, VP, VP, I]),
     "x3d_tds_solve_acc": (I, [VP, VP, VP, VP, I, I, D]),
     "x3d_transeq_acc": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, I]),

@@ -122,6 +122,14 @@ class HipBackend:
             _dp(t.stretch), _dp(t.stretch_correct)))
         t.handle = h
         self._tdsops.append(h)
+        if t.pentadiag:  # compact10_penta: the pentadiagonal LU tables + what the ghost rows are
+            if t.bc_start != t.bc_end:
+                raise X3dError("compact10_penta: the same boundary condition is needed at both ends")
+            kind = {0: 1, 1: 2 if t.sym else 3, 2: 4}.get(t.bc_start)
+            if kind is None:
+                raise X3dError("compact10_penta: periodic, Neumann or Dirichlet ends (not BC_HALO: the solve is rank-local)")
+            _lib.check(self.lib.x3d_tdsops_set_penta(h, t.alpha, t.beta, t.beta_lhs_s, _dp(t.dist_fw), _dp(t.dist_af),
+                                                     _dp(t.dist_sa), _dp(t.dist_bw), _dp(cs), _dp(ce), kind))
         return t
 
     # ------------------------------------------------------------ transeq
@@ -564,10 +572,23 @@ class HipBackend:
         direction = u.dir
         if direction == DIR_C:
             raise X3dError("tds_solve needs a directional field")
+        if tdsops.pentadiag:
+            self.tds_penta_solve(du, u, tdsops, direction)
+            return
         if not self._decomposed(direction):
             _lib.check(self.lib.x3d_tds_solve(self.h, du.ptr, u.ptr, tdsops.handle, direction))
             return
         self._tds_dist(du, u, tdsops, direction)
+
+    def tds_penta_solve(self, du, u, tdsops, direction, u_s=None, u_e=None):
+        """exec_dist_penta_compact / exec_dist_penta_periodic (src/backend/omp/exec_dist.f90:188-241): the
+        compact10_penta first derivative, a rank-local solve.  u_s / u_e: ghost rows [4][npencil] (device tensors)
+        or None: formed in the kernel from the operator's boundary conditions."""
+        if self._decomposed(direction):
+            raise X3dError("compact10_penta is a rank-local solve: the direction must not be decomposed")
+        _lib.check(self.lib.x3d_tds_penta_solve(self.h, du.ptr, u.ptr, tdsops.handle, direction,
+                                                u_s.data_ptr() if u_s is not None else None,
+                                                u_e.data_ptr() if u_e is not None else None))
 
     def _tds_dist(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact;

@@ -142,7 +142,9 @@ struct x3d_tdsops {
     double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
     int halo_ws, halo_we;        // rows 1..ws / n-we+1..n: where |dist_sa| / |dist_sc| >= 2^-60 (xscan.hip, *_halo_fix)
+    struct x3d_penta *penta;     // compact10_penta: the pentadiagonal LU tables (penta.hip), else null
 };
+void x3d_penta_free(x3d_tdsops *t);
 
 PencilGeom x3d_geom(const x3d_backend *b, int dir);
 

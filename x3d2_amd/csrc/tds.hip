@@ -206,6 +206,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
 extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
 {
     if (!t) return 0;
+    x3d_penta_free(t);
     hipFree(t->dev);
     delete t;
     return 0;

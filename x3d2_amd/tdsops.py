@@ -44,8 +44,11 @@ class Tdsops:
         self.periodic = bc_start == BC_PERIODIC and bc_end == BC_PERIODIC
         self.alpha = self.a = self.b = 0.0
         self.c = self.d = 0.0
+        # pentadiagonal LHS schemes (compact10_penta): src/tdsops.f90:34-37
+        self.beta, self.beta_lhs_s, self.pentadiag = 0.0, 0.0, False
         self.operation, self.scheme = operation, scheme
         symmetry = bool(sym) if sym is not None else False
+        self.bc_start, self.bc_end, self.sym = int(bc_start), int(bc_end), symmetry
         if operation == "first-deriv":
             dist_b = self._deriv_1st(delta, scheme, bc_start, bc_end, symmetry)
         elif operation == "second-deriv":
@@ -56,7 +59,10 @@ class Tdsops:
             dist_b = self._stagder_1st(delta, scheme, from_to, bc_start, bc_end)
         else:
             raise X3dError("operation is not defined")
-        self._preprocess_dist(dist_b)
+        if self.pentadiag:
+            self._preprocess_penta_dist(bc_start, bc_end, symmetry)  # :398-399
+        else:
+            self._preprocess_dist(dist_b)
         self.move = {"v2p": 1, "p2v": -1}.get(from_to, 0)
         self.handle = None  # device copy, set by the backend's alloc_tdsops
         tol = 1e-16
@@ -72,13 +78,32 @@ class Tdsops:
 
     # -- src/tdsops.f90:205-405
     def _deriv_1st(self, delta, scheme, bc_start, bc_end, sym):
-        if scheme != "compact6":
+        if scheme == "compact6":
+            alpha, afi, bfi, cfi = 1.0 / 3.0, 7.0 / 9.0 / delta, 1.0 / 36.0 / delta, 0.0
+        elif scheme == "compact10_penta":
+            # Lele (1992) Table 1, 10th-order pentadiagonal first derivative (:235-251):
+            # beta f'_{i-2} + alpha f'_{i-1} + f'_i + alpha f'_{i+1} + beta f'_{i+2} = a.. b.. c..
+            self.pentadiag = True
+            alpha, self.beta = 0.5, 1.0 / 20.0
+            afi, bfi, cfi = 17.0 / 24.0 / delta, 101.0 / 600.0 / delta, 1.0 / 600.0 / delta
+        else:
             raise X3dError("scheme is not defined")
-        alpha, afi, bfi, cfi = 1.0 / 3.0, 7.0 / 9.0 / delta, 1.0 / 36.0 / delta, 0.0
         self.alpha, self.a, self.b, self.c = alpha, afi, bfi, cfi
         self.coeffs[:] = _row(0.0, -cfi, -bfi, -afi, 0.0, afi, bfi, cfi, 0.0)
         dist_b = self._bulk(alpha)
         n, cs, ce, sa, sc = self.n_tds, self.coeffs_s, self.coeffs_e, self.dist_sa, self.dist_sc
+        if self.pentadiag:
+            # the start / end stencils stay the interior one except for the compact one-sided Dirichlet closures
+            # (4th order, same alpha, beta; :322-334, 383-395); Neumann: mirror ghosts come with the halos
+            sa[:] = 0.0
+            sc[:] = 0.0
+            if bc_start == BC_DIRICHLET:
+                cs[0] = _row(0, 0, 0, 0, -529.0 / 240.0, 71.0 / 20.0, -9.0 / 4.0, 67.0 / 60.0, -17.0 / 80.0) / delta
+                cs[1] = _row(0, 0, 0, -301.0 / 240.0, 103.0 / 120.0, -3.0 / 40.0, 13.0 / 24.0, -17.0 / 240.0, 0) / delta
+            if bc_end == BC_DIRICHLET:
+                ce[3] = _row(17.0 / 80.0, -67.0 / 60.0, 9.0 / 4.0, -71.0 / 20.0, 529.0 / 240.0, 0, 0, 0, 0) / delta
+                ce[2] = _row(0, 17.0 / 240.0, -13.0 / 24.0, 3.0 / 40.0, -103.0 / 120.0, 301.0 / 240.0, 0, 0, 0) / delta
+            return dist_b
         if bc_start == BC_NEUMANN:
             if sym:
                 sa[0], sc[0] = 0.0, 0.0
@@ -282,6 +307,50 @@ class Tdsops:
         return dist_b
 
     # -- src/tdsops.f90:874-931 (sequential recurrences, same order)
+    # -- src/tdsops.f90:971-1103
+    def _preprocess_penta_dist(self, bc_start, bc_end, sym):
+        """LU of the pentadiagonal LHS for the non-periodic Thomas solve (der_penta_full); repurposed arrays:
+        dist_fw = 1 / d_i, dist_af = l1_i, dist_sa = l2_i, dist_bw = u1_i, upper-2 = beta (beta_lhs_s in row 1).
+        A periodic operator gets the Dirichlet-path (non-cyclic interior) factors, which der_penta_periodic
+        corrects by Sherman-Morrison-Woodbury."""
+        alp, bet, n = self.alpha, self.beta, self.n_tds
+        fw, af, sa, bw = self.dist_fw, self.dist_af, self.dist_sa, self.dist_bw
+        if bc_start == BC_NEUMANN:
+            u1_1, self.beta_lhs_s = (0.0, 0.0) if sym else (2.0 * alp, 2.0 * bet)
+        else:
+            u1_1, self.beta_lhs_s = alp, bet
+        sa[0], af[0], fw[0], bw[0] = 0.0, 0.0, 1.0, u1_1
+        sa[1], af[1] = 0.0, alp
+        if bc_start == BC_NEUMANN:
+            d_i = ((1.0 - bet) if sym else (1.0 + bet)) - alp * u1_1
+        else:
+            d_i = 1.0 - alp * u1_1
+        fw[1] = 1.0 / d_i
+        bw[1] = alp - alp * self.beta_lhs_s
+        l2 = bet * fw[0]
+        l1 = (alp - l2 * bw[0]) * fw[1]
+        d_i = (1.0 - l2 * self.beta_lhs_s) - l1 * bw[1]
+        sa[2], af[2], fw[2], bw[2] = l2, l1, 1.0 / d_i, alp - l1 * bet
+        for i in range(3, n):
+            l2 = bet * fw[i - 2]
+            l1 = (alp - l2 * bw[i - 2]) * fw[i - 1]
+            d_i = (1.0 - l2 * bet) - l1 * bw[i - 1]
+            sa[i], af[i], fw[i], bw[i] = l2, l1, 1.0 / d_i, alp - l1 * bet
+        if bc_end == BC_NEUMANN:
+            i = n - 2
+            l2 = bet * fw[i - 2]
+            l1 = (alp - l2 * bw[i - 2]) * fw[i - 1]
+            d_i = ((1.0 - bet - l2 * bet) if sym else (1.0 + bet - l2 * bet)) - l1 * bw[i - 1]
+            sa[i], af[i], fw[i], bw[i] = l2, l1, 1.0 / d_i, alp - l1 * bet
+            if sym:
+                sa[n - 1], af[n - 1], fw[n - 1], bw[n - 1] = 0.0, 0.0, 1.0, 0.0
+            else:
+                l2 = 2.0 * bet * fw[n - 3]
+                l1 = (2.0 * alp - l2 * bw[n - 3]) * fw[n - 2]
+                d_i = 1.0 - l2 * bet - l1 * bw[n - 2]
+                sa[n - 1], af[n - 1], fw[n - 1], bw[n - 1] = l2, l1, 1.0 / d_i, alp - l1 * bet
+        self.dist_sc[:] = 0.0
+
     def _preprocess_dist(self, b):
         n = self.n_tds
         fw, bw, sa, sc, af = self.dist_fw, self.dist_bw, self.dist_sa, self.dist_sc, self.dist_af
