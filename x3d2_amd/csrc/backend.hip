@@ -57,6 +57,16 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     b->stream = (hipStream_t)stream;
     b->nx = dims_vert[0]; b->ny = dims_vert[1]; b->nz = dims_vert[2];
     b->nxp = (b->nx + 15) / 16 * 16;
+    {
+        // Row pitches that are multiples of 512 B make the y stride (nxp * 8 B) and above all the z stride
+        // (nxp * nyp * 8 B = 2 MiB at 512^3) powers of two: the 512 row segments of a z tile then alias in the
+        // memory channels.  One more 128-byte segment per row breaks that: z operator pairs 0.91 -> 0.71 and
+        // 0.84 -> 0.68 ms, transeq_z 2.48 -> 2.32 ms, y pairs 0.67 -> 0.64 (512^3, same box; profiles/README.md)
+        // for 3 % more memory.  X3D_PAD_X=<doubles> overrides (0: none).
+        const char *e = getenv("X3D_PAD_X");
+        if (e) b->nxp += (atoi(e) + 15) / 16 * 16;
+        else if (b->nxp % 64 == 0 && b->nxp >= 256) b->nxp += 16;
+    }
     b->nyp = b->ny;
     b->nzp = b->nz;
     b->nblock = (size_t)b->nxp * b->nyp * b->nzp;

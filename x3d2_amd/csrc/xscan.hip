@@ -49,6 +49,23 @@ int npmax_of(const x3d_backend *b);
 #define LT_N(Q_) (9 * (Q_) + 12)
 #define LT_NC(Q_) (8 * (Q_) + 12)     // entries without the STC block
 
+// One lane-table value.  Two of these reads off one base register are merged by the compiler into
+// ds_read2st64_b64, which the LDS serves at HALF the rate of two ds_read_b64 (measured, scratch/ldsbench.hip:
+// 4.3 against 2.6 LDS clocks per 512-byte row; MI355X_MICROARCH.md, LDS table) -- and these kernels are
+// LDS-bound on exactly these reads (LdsUtil 83 % in k_ytile_transeq3).  The empty asm is a barrier for the
+// load / store combiner only (it ends a merge window); it emits nothing.
+#ifndef XS_READ2
+__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx)
+{
+    const double v = l[idx];
+    asm volatile("" ::: "memory");
+    return v;
+}
+#else
+__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx) { return l[idx]; }
+#endif
+#define LTR(l, e) lt_read((l), (e) * 64 + lane)
+
 // what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
 struct XOp {
     const double *TL, *Cs;
@@ -159,7 +176,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     T prev = zero_of<T>();
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        X[q] = lt[LT_F(q) * 64 + lane] * (acc[q] - lt[LT_A(q) * 64 + lane] * prev);
+        X[q] = LTR(lt, LT_F(q)) * (acc[q] - LTR(lt, LT_A(q)) * prev);
         prev = X[q];
     }
     // ---- scan of the lane-end values, then carry-in = true e at the end of lane l-1
@@ -170,12 +187,12 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 #else
     // prefix scan without LDS traffic: in-row Kogge-Stone by DPP row shifts, then lane 15 / 47 into rows
     // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0
-    v += lt[LT_MF(0) * 64 + lane] * dpp0<0x111>(v);
-    v += lt[LT_MF(1) * 64 + lane] * dpp0<0x112>(v);
-    v += lt[LT_MF(2) * 64 + lane] * dpp0<0x114>(v);
-    v += lt[LT_MF(3) * 64 + lane] * dpp0<0x118>(v);
-    v += lt[LT_MF(4) * 64 + lane] * dpp0<0x142, 0xA>(v);
-    v += lt[LT_MF(5) * 64 + lane] * dpp0<0x143, 0xC>(v);
+    v += LTR(lt, LT_MF(0)) * dpp0<0x111>(v);
+    v += LTR(lt, LT_MF(1)) * dpp0<0x112>(v);
+    v += LTR(lt, LT_MF(2)) * dpp0<0x114>(v);
+    v += LTR(lt, LT_MF(3)) * dpp0<0x118>(v);
+    v += LTR(lt, LT_MF(4)) * dpp0<0x142, 0xA>(v);
+    v += LTR(lt, LT_MF(5)) * dpp0<0x143, 0xC>(v);
     T carry = dpp0<0x138>(v);  // wave_shr:1
 #endif
     // ---- apply, lane-local back-substitution from zero
@@ -183,7 +200,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     PHASE(carry);
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
-        X[q] = (X[q] + lt[LT_PF(q) * 64 + lane] * carry) + lt[LT_H(q) * 64 + lane] * nxt;
+        X[q] = (X[q] + LTR(lt, LT_PF(q)) * carry) + LTR(lt, LT_H(q)) * nxt;
         nxt = X[q];
     }
     if (n == nr) {}  // (row n_rhs = n+1 of a v2p operator carries F = H = 0 in the tables)
@@ -193,19 +210,19 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     carry = v;
 #else
     // suffix scan: row shifts the other way, then lane 16 / 48 into rows 0 / 2 and lane 32 into rows 0, 1
-    v += lt[LT_MB(0) * 64 + lane] * dpp0<0x101>(v);
-    v += lt[LT_MB(1) * 64 + lane] * dpp0<0x102>(v);
-    v += lt[LT_MB(2) * 64 + lane] * dpp0<0x104>(v);
-    v += lt[LT_MB(3) * 64 + lane] * dpp0<0x108>(v);
+    v += LTR(lt, LT_MB(0)) * dpp0<0x101>(v);
+    v += LTR(lt, LT_MB(1)) * dpp0<0x102>(v);
+    v += LTR(lt, LT_MB(2)) * dpp0<0x104>(v);
+    v += LTR(lt, LT_MB(3)) * dpp0<0x108>(v);
     {
         const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
-        v += lt[LT_MB(4) * 64 + lane] * (lane < 32 ? s16 : s48);
-        v += lt[LT_MB(5) * 64 + lane] * readlane_d(v, 32);
+        v += LTR(lt, LT_MB(4)) * (lane < 32 ? s16 : s48);
+        v += LTR(lt, LT_MB(5)) * readlane_d(v, 32);
     }
     carry = dpp0<0x130>(v);  // wave_shl:1
 #endif
 #pragma unroll
-    for (int q = 0; q < Q; q++) X[q] = X[q] + lt[LT_QB(q) * 64 + lane] * carry;
+    for (int q = 0; q < Q; q++) X[q] = X[q] + LTR(lt, LT_QB(q)) * carry;
     // du_1 = last_r * X_1 (X_1 = e_1 - bw_1 X_2, distributed.f90:161-166); X_n = e_n
     du1 = t.last_r * readlane_d(X[0], 0);
     if constexpr (FAST) {
@@ -441,8 +458,8 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = first + q;
-            const double st = lt[LT_ST(q) * 64 + lane];
-            r[q] = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) * st;
+            const double st = LTR(lt, LT_ST(q));
+            r[q] = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
             if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
                 if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
                 if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
@@ -521,8 +538,8 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, 
         double r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const double st = lt[LT_ST(q) * 64 + lane];
-            r[q] = (X[q] - lt[LT_SA(q) * 64 + lane] * du_s - lt[LT_SC(q) * 64 + lane] * du_e) * st;
+            const double st = LTR(lt, LT_ST(q));
+            r[q] = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
             if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
             if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
         }
@@ -614,8 +631,8 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = first + q;
-                const double st = l[LT_ST(q) * 64 + lane];
-                double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                const double st = LTR(l, LT_ST(q));
+                double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
                     if (q == 0) x = (lane == 0) ? s_ * st : x;
                     if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
@@ -633,7 +650,7 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
         asm volatile("" : "+v"(lane) : "v"(r[0]));  // order the operators: bounds the live lane-table reads
         solve_subs(wu, T, l1, t1);  // du/dx
 #pragma unroll
-        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l3, t3);  // d2u/dx2
 #pragma unroll
@@ -726,8 +743,8 @@ __global__ void __launch_bounds__(512)
             const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double st = l[LT_ST(q) * 64 + lane];
-                V2 x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                const double st = LTR(l, LT_ST(q));
+                V2 x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (q == 0) x = (lane == 0) ? s_ * st : x;
                 if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                 T[q] = x;
@@ -740,7 +757,7 @@ __global__ void __launch_bounds__(512)
         asm volatile("" : "+v"(lane) : "v"(r[0].a));
         solve_subs(wu, T, l1, t1);
 #pragma unroll
-        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
         asm volatile("" : "+v"(lane) : "v"(r[0].a));
         solve_subs(wu, T, l3, t3);
         double ra[Q], rb[Q];
@@ -833,8 +850,8 @@ __global__ void __launch_bounds__(512)
                     const V2 du_s = tg.rs_s * (du1 - tg.sa1 * xn), du_e = tg.rs_e * (xn - tg.scn * du1);
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
-                        const double st = lg[LT_ST(q) * 64 + lane];
-                        V2 r = (X[q] - lg[LT_SA(q) * 64 + lane] * du_s - lg[LT_SC(q) * 64 + lane] * du_e) * st;
+                        const double st = LTR(lg, LT_ST(q));
+                        V2 r = (X[q] - LTR(lg, LT_SA(q)) * du_s - LTR(lg, LT_SC(q)) * du_e) * st;
                         if (q == 0) r = (lane == 0) ? du_s * st : r;
                         if (q == Q - 1) r = (lane == 63) ? du_e * st : r;
                         b2[q] = b2[q] + upd.scale * r;
@@ -862,8 +879,8 @@ __global__ void __launch_bounds__(512)
                 const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const double st = l[LT_ST(q) * 64 + lane];
-                    V2 x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                    const double st = LTR(l, LT_ST(q));
+                    V2 x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                     if (q == 0) x = (lane == 0) ? s_ * st : x;
                     if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                     T[q] = x;
@@ -876,7 +893,7 @@ __global__ void __launch_bounds__(512)
             asm volatile("" : "+v"(lane) : "v"(r[0].a));
             solve_subs(wu, T, l1, tD1);
 #pragma unroll
-            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
             asm volatile("" : "+v"(lane) : "v"(r[0].a));
             solve_subs(wu, T, l3, tD2);
             double ra[Q], rb[Q];
@@ -1003,8 +1020,8 @@ __global__ void __launch_bounds__(1024)
             const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double st = l[LT_ST(q) * 64 + lane];
-                double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                const double st = LTR(l, LT_ST(q));
+                double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (q == 0) x = (lane == 0) ? s_ * st : x;
                 if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                 T[q] = x;
@@ -1017,7 +1034,7 @@ __global__ void __launch_bounds__(1024)
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l1, t1);
 #pragma unroll
-        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+        for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l3, t3);
         if constexpr (!EPI) {
@@ -1198,8 +1215,8 @@ __global__ void __launch_bounds__(1024)
                 }
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const double st = l[LT_ST(q) * 64 + lane];
-                    double x = st * (T[q] - l[LT_SA(q) * 64 + lane] * s_ - l[LT_SC(q) * 64 + lane] * e_);
+                    const double st = LTR(l, LT_ST(q));
+                    double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                     if (q == 0) x = (lane == 0) ? s_ * st : x;
                     if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                     T[q] = x;
@@ -1212,11 +1229,13 @@ __global__ void __launch_bounds__(1024)
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             solve_subs(wu, T, l1, tD1, 1);
 #pragma unroll
-            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * l3[LT_STC(q) * 64 + lane]);
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             solve_subs(wu, T, l3, tD2, 2);
             {
-                // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component)
+                // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component;
+                //  with the partial result parked in the tile during the last solve to make room for them: no
+                //  spills, but 2.37 instead of 2.24 ms per launch -- the load's latency is not what limits)
                 double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
                 double2 old[NI];
                 if (ACC) gload(old, o);
@@ -1319,8 +1338,8 @@ __global__ void __launch_bounds__(1024)
         }
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const double st = l[LT_ST(q) * 64 + lane];
-            r[q] = (X[q] - l[LT_SA(q) * 64 + lane] * du_s - l[LT_SC(q) * 64 + lane] * du_e) * st;
+            const double st = LTR(l, LT_ST(q));
+            r[q] = (X[q] - LTR(l, LT_SA(q)) * du_s - LTR(l, LT_SC(q)) * du_e) * st;
             if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
             if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
         }
