@@ -65,6 +65,16 @@ def main():
         hb = b.transeq_halo_main(DIR_Z, o[0], o[1], o[2], s.u, s.v, s.w, nu, z, True, h)
         timed("transeq z halo fix", lambda: b.transeq_halo_finish(DIR_Z, o[0], o[1], o[2], s.u, s.v, s.w, nu, z, hb), 1)
         timed("pack halos x3 + self exchange", lambda: b.transeq_halo_begin(DIR_Z, s.u, s.v, s.w), 1)
+    if args.only == "x":
+        x = s.xdirps
+        b._emulate = ""
+        timed("tds_lin x, 1 term (4 passes)", lambda: b.tds_lincomb(o[0], x.stagder_v2p, DIR_X, o[1], s.u, [0.5], [s.v]), 4)
+        timed("tds_lin x, 3 terms (6 passes)", lambda: b.tds_lincomb(o[0], x.stagder_v2p, DIR_X, o[1], s.u, [0.5, 0.25, 0.1], [s.v, s.w, o[2]]), 6)
+        timed("tds x (2 passes)", lambda: b.tds_apply(o[0], s.u, x.stagder_v2p, DIR_X), 2)
+        timed("tds x acc (3 passes)", lambda: b.tds_apply(o[0], s.u, x.stagder_v2p, DIR_X, accumulate=True, scale=-1.0), 3)
+        timed("transeq x 3-in-1 (6 passes)", lambda: b.transeq_dir(DIR_X, o[0], o[1], o[2], s.u, s.v, s.w, nu, x, accumulate=False), 6)
+        timed("lincomb 3 terms (5 passes)", lambda: b.lincomb(o[1], s.u, [0.5, 0.25, 0.1], [s.v, s.w, o[2]]), 5)
+        return
     if args.only == "pairy":
         d, dp, nm, nz_ = DIR_Y, y, "y", dims[2]
         b._emulate = ""

@@ -60,9 +60,11 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     {
         // Row pitches that are multiples of 512 B make the y stride (nxp * 8 B) and above all the z stride
         // (nxp * nyp * 8 B = 2 MiB at 512^3) powers of two: the 512 row segments of a z tile then alias in the
-        // memory channels.  One more 128-byte segment per row breaks that: z operator pairs 0.91 -> 0.71 and
-        // 0.84 -> 0.68 ms, transeq_z 2.48 -> 2.32 ms, y pairs 0.67 -> 0.64 (512^3, same box; profiles/README.md)
-        // for 3 % more memory.  X3D_PAD_X=<doubles> overrides (0: none).
+        // memory channels.  One more 128-byte segment per row breaks that (512^3, same box, scratch/tile_bench.py):
+        // z operator pairs 0.91 -> 0.71 and 0.84 -> 0.68 ms, transeq_z 2.48 -> 2.29, y pairs 0.67 -> 0.64; the
+        // contiguous-row x kernels lose a little in isolation (k_xscan_tds_lin 0.81 -> 0.89 ms; two segments:
+        // 0.83), but the full step is the same for 16 / 32 / 48 / 80 doubles of padding: 49.0-49.6 ms against
+        // 51.3 without (profiles/README.md).  3 % more memory.  X3D_PAD_X=<doubles> overrides (0: none).
         const char *e = getenv("X3D_PAD_X");
         if (e) b->nxp += (atoi(e) + 15) / 16 * 16;
         else if (b->nxp % 64 == 0 && b->nxp >= 256) b->nxp += 16;
