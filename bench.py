@@ -343,9 +343,14 @@ def main():
         phys = int(os.environ["OMP_NUM_THREADS"])
         os.environ["OMP_NUM_THREADS"] = str(min(phys, args.cpu_threads))
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
-        ref = cpu_reference(256, 4, phys)
-        if ref is not None:
-            out["cpu_baseline"]["reference_nopoisson"] = ref
+        # the real reference at all physical cores and at the port's thread count; the faster one is reported,
+        # the other kept beside it
+        refs = [r for r in (cpu_reference(256, 4, t) for t in sorted({phys, min(phys, args.cpu_threads)}, reverse=True))
+                if r is not None]
+        if refs:
+            best = max(refs, key=lambda r: r["value"])
+            best["other_thread_counts"] = [{"cores": r["cores"], "value": r["value"]} for r in refs if r is not best]
+            out["cpu_baseline"]["reference_nopoisson"] = best
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
