@@ -1,0 +1,48 @@
+// Streaming rate of the y-tile access pattern as a function of the segment width: a workgroup of NPEN waves owns
+// NPEN x-adjacent y pencils of 512 rows (row segments of NPEN * 8 bytes, rows `pitch` doubles apart), reads the
+// tile (4 x 16-byte loads per thread), writes it to the same place of another block; persistent over tiles.
+//   hipcc -O2 --offload-arch=gfx950 scratch/tilecopy.hip -o scratch/tilecopy
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <int NPEN>
+__global__ void __launch_bounds__(NPEN * 64) k(const double *__restrict__ a, double *__restrict__ b, int ntx, int ntiles,
+                                               long prow, long pplane)
+{
+    constexpr int CPR = NPEN / 2;              // double2 per row segment
+    constexpr int RPI = NPEN * 64 / CPR;       // rows per load instruction (= 128)
+    const int cc = threadIdx.x % CPR, cy = threadIdx.x / CPR;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * NPEN;
+        double2 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2 *>(a + off + (long)(cy + RPI * i) * prow + 2 * cc);
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<double2 *>(b + off + (long)(cy + RPI * i) * prow + 2 * cc) = v[i];
+    }
+}
+int main()
+{
+    const int nx = 512, ny = 512, nz = 512, nxp = 528;
+    const size_t n = (size_t)nxp * ny * nz;
+    double *a, *b;
+    (void)hipMalloc(&a, n * 8 + (1 << 20)); (void)hipMalloc(&b, n * 8 + (1 << 20)); (void)hipMemset(a, 0, n * 8);
+    b += 528 * 3;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto run = [&](const char *nm, auto f) {
+        for (int i = 0; i < 2; i++) f();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 10; i++) f();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        printf("%-44s %7.3f ms %8.1f GB/s\n", nm, ms, 2.0 * nx * ny * nz * 8 / ms * 1e-6);
+    };
+    const long pxy = (long)nxp * ny;
+    // y pencils: rows nxp apart, tiles stacked over z; z pencils: rows pxy apart, tiles stacked over y
+    run("y, 16 pencils (128 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL(k<16>, dim3(256), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * nz, (long)nxp, pxy); });
+    run("y,  8 pencils ( 64 B), 512 WGs x  512", [&] { hipLaunchKernelGGL(k<8>, dim3(512), dim3(512), 0, 0, a, b, nx / 8, nx / 8 * nz, (long)nxp, pxy); });
+    run("y,  8 pencils ( 64 B), 1024 WGs x 512", [&] { hipLaunchKernelGGL(k<8>, dim3(1024), dim3(512), 0, 0, a, b, nx / 8, nx / 8 * nz, (long)nxp, pxy); });
+    run("z, 16 pencils (128 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL(k<16>, dim3(256), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * ny, pxy, (long)nxp); });
+    run("z,  8 pencils ( 64 B), 512 WGs x  512", [&] { hipLaunchKernelGGL(k<8>, dim3(512), dim3(512), 0, 0, a, b, nx / 8, nx / 8 * ny, pxy, (long)nxp); });
+    run("y, 16 pencils (128 B), 512 WGs x 1024", [&] { hipLaunchKernelGGL(k<16>, dim3(512), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * nz, (long)nxp, pxy); });
+    return 0;
+}

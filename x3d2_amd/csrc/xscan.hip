@@ -1098,12 +1098,35 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// Row segment (cy + 128 i) of a tile = uniform base (an SGPR pair, bumped per i) + ONE 32-bit lane offset shared
+// by all loads and stores of all fields (global_load_dwordx4 v, v_off, s[base:base+1]) instead of a 64-bit
+// address pair per row: 7 VGPRs less in kernels that sit on the 128-VGPR limit.  Needs 128 * prow * 8 < 4 GiB
+// (checked by the launchers).
+__device__ __forceinline__ const double2 *tile_row(const double *base, long prow, int i, unsigned voff)
+{
+    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base + (long)(128 * i) * prow) + voff);
+}
+
 // ---------------------------------------------------------------- K3y, the three components of a direction at once
 // transeq_<dir> = three components that share the advecting velocity (src/backend/omp/backend.f90:145-184):
 // component 0 is (u0, conv = u0), components 1, 2 are (u1, u0), (u2, u0).  One workgroup does all three for
 // its tile, keeping its pencil's rows of u0 in registers: u0 is read once instead of three times (9 field
 // passes instead of 11).  Needs der1st == der1st_sym and der2nd == der2nd_sym as lane tables (periodic
 // operators), so that all components use the same two table sets (tD1 for du and d(u conv), tD2 for d2u).
+#ifdef YT_TIMING
+// phase timing of k_ytile_transeq3 (scratch builds only): shader-clock ticks summed by wave 0 of every workgroup
+__device__ unsigned long long g_yt[8 + 32];  // [8..23]: per wave, ticks from component start to the end of its solves;
+                                             // [24..39]: per wave, ticks spent in the solves themselves
+extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[40] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_yt), z, sizeof z) != hipSuccess; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_yt), sizeof(unsigned long long) * 40) != hipSuccess;
+}
+#define YT_T(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_yt[k], t_ - yt_last); yt_last = t_; } } while (0)
+#else
+#define YT_T(k)
+#endif
+
 template <int Q, bool ACC, bool NARROW, bool HALO>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
@@ -1121,13 +1144,17 @@ __global__ void __launch_bounds__(1024)
     // HALO: [16 pencils][8] halo values of the current field, then the same for the advecting velocity u0
     double *hal = tile + 16 * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
     ntiles += tile0;  // tiles [tile0, tile0 + ntiles) (a range of planes: overlap of the neighbour exchange)
+#ifdef YT_TIMING
+    unsigned long long yt_last = __builtin_readcyclecounter();
+#endif
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
     auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);
     };
     auto to_tile = [&](const double2 (&v)[NI]) {
 #pragma unroll
@@ -1165,6 +1192,10 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             asm volatile("" : "+v"(lane));
+            YT_T(5);
+#ifdef YT_TIMING
+            const unsigned long long yt_c0 = __builtin_readcyclecounter();
+#endif
             double wu[Q + 8], wp[Q + 8];
             {
                 double b[Q];
@@ -1173,7 +1204,9 @@ __global__ void __launch_bounds__(1024)
                     hal[threadIdx.x] = hnx;
                     if (c == 0) hal0[threadIdx.x] = hnx;
                 }
+                YT_T(0);
                 __syncthreads();
+                YT_T(1);
                 pick(b);
                 if (c == 0) {
 #pragma unroll
@@ -1223,6 +1256,10 @@ __global__ void __launch_bounds__(1024)
                 }
             };
             double r[Q], T[Q];
+            YT_T(2);
+#ifdef YT_TIMING
+            const unsigned long long yt_s0 = __builtin_readcyclecounter();
+#endif
             solve_subs(wp, T, l1, tD1, 0);
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = T[q];
@@ -1235,22 +1272,34 @@ __global__ void __launch_bounds__(1024)
             {
                 // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component;
                 //  with the partial result parked in the tile during the last solve to make room for them: no
-                //  spills, but 2.37 instead of 2.24 ms per launch -- the load's latency is not what limits)
+                //  spills, but 2.37 instead of 2.24 ms per launch; issued after the FIRST solve, where the product
+                //  window's registers are free (123 VGPRs, no spills): 2.18 ms both ways -- the load's latency is not
+                //  what limits, the memory system is busy throughout with this pattern's 128-byte segments)
                 double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
                 double2 old[NI];
+                YT_T(3);
+#ifdef YT_TIMING
+                if (lane == 0) {
+                    const unsigned long long t_ = __builtin_readcyclecounter();
+                    atomicAdd(&g_yt[8 + wave], t_ - yt_c0);
+                    atomicAdd(&g_yt[24 + wave], t_ - yt_s0);
+                }
+#endif
                 if (ACC) gload(old, o);
                 double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
 #pragma unroll
                 for (int m = 0; m < Q / 2; m++)
                     dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
                 __syncthreads();
+                YT_T(4);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                     if (ACC) { v.x += old[i].x; v.y += old[i].y; }
-                    *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+                    *const_cast<double2 *>(tile_row(o, prow, i, voff)) = v;
                 }
             }
+            YT_T(6);
             __syncthreads();  // the tile is free again
         }
         if (HALO && threadIdx.x < 288) {  // 16 pencils x 9 operators x {du_1, X_n} (the barrier above ordered them)
@@ -1292,9 +1341,10 @@ __global__ void __launch_bounds__(1024)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
     auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);
     };
     auto to_tile = [&](const double2 (&v)[NI]) {
 #pragma unroll
@@ -1320,7 +1370,7 @@ __global__ void __launch_bounds__(1024)
     auto from_tile = [&](double *o) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) =
+            *const_cast<double2 *>(tile_row(o, prow, i, voff)) =
                 make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
     };
     // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange; HALO:
@@ -1759,6 +1809,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
     if (ntiles <= 0) { *done = true; return 0; }
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;
@@ -1837,6 +1888,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     if (ntiles <= 0) { *done = true; return 0; }
     const int blocks = ntiles > 256 ? 256 : ntiles;
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
 #define GO(Q_, A_, N_, H_)                                                                                      \
