@@ -617,11 +617,12 @@ def test_r2c512_x_pass_against_numpy():
     assert relerr(spectra[0], ref) < 1e-13
 
 
-@pytest.mark.parametrize("nx", [512, 256, 128, 192, 500])
+@pytest.mark.parametrize("nx", [512, 256, 128, 192, 500, 1024])
 def test_x_direction_scan_kernels_full_size_pencils(nx):
     """the wave-per-pencil x kernels (csrc/xscan.hip) only engage for pencils of 64*Q points
     (FAST path: 512 -> Q = 8 with prefetch / shuffled halos / quad-transposed stores, 256 -> Q = 4)
-    or, generic path, any n <= 512 that 64 lanes cover (192, 500); 128 uses the LDS-tiled kernels.
+    or, generic path, any n <= 512 that 64 lanes cover (192, 500); 128 uses the LDS-tiled kernels;
+    1024 -> Q = 16 with compressed lane tables (csrc/xwide.hip, the channel case's x pencils).
     Every x operator, transeq_x, and the fused driver's accumulating forms against the oracle."""
     from oracle import x3d_oracle as orc
     from x3d2_amd import Mesh
@@ -680,7 +681,10 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
     # transeq along x only, then the whole fused right-hand side (x writes, y and z accumulate)
     rhs_h = [al.get_block(DIR_X) for _ in range(3)]
     rhs_o = [o.backend.get_block(orc.DIR_X) for _ in range(3)]
+    n3 = int(b.lib.x3d_backend_counter(b.h, 0))
     b.transeq_x(*rhs_h, s.u, s.v, s.w, s.nu, s.xdirps)
+    if nx in (256, 512, 1024):  # the three-components-in-one kernels took it
+        assert int(b.lib.x3d_backend_counter(b.h, 0)) == n3 + 1
     o.backend.transeq_x(*rhs_o, o.u, o.v, o.w, o.nu, o.xdirps)
     for fh, fo, nm in zip(rhs_h, rhs_o, "uvw"):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm

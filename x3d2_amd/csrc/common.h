@@ -113,7 +113,7 @@ struct TdsTab {
     // PF/QB chunk-local carry multipliers (onchip.hip)
     const double *RF, *RB;
     const double *TL;   // lane tables of the wave-per-pencil x kernels (xscan.hip): [entry][64 lanes], or null
-    int Q;              // rows per lane there (4 or 8), 0 if unavailable
+    int Q;              // rows per lane there (4, 8; 16: only the compressed form is used), 0 if unavailable
     int bulk_only;      // 1: start/end stencils equal the bulk stencil (periodic / BC_HALO both ends)
     const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
     double last_r;      // dist_fw(1)
@@ -141,6 +141,7 @@ struct x3d_tdsops {
     TdsTab tab;
     double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
+    const double *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
     int halo_ws, halo_we;        // rows 1..ws / n-we+1..n: where |dist_sa| / |dist_sc| >= 2^-60 (xscan.hip, *_halo_fix)
     struct x3d_penta *penta;     // compact10_penta: the pentadiagonal LU tables (penta.hip), else null
 };

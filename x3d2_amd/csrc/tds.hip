@@ -105,7 +105,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     }
     memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
     // lane tables for the wave-per-pencil x kernels (xscan.hip): lane l owns rows l*Q+1..(l+1)*Q
-    const int Q = nr <= 256 ? 4 : (nr <= 512 ? 8 : 0);
+    const int Q = nr <= 256 ? 4 : (nr <= 512 ? 8 : (nr <= 1024 ? 16 : 0));
     const size_t tl_off = img.size();
     if (Q) {
         const int NE = 9 * Q + 12;
@@ -162,6 +162,32 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             E(8 * Q + 6 + 5, l) = row < 2 ? d32 : 0.0;
         }
     }
+    // compressed form of the row entries (xscan_core.h, LTC_*): lanes 0..7 | one value for lanes 8..55 | lanes
+    // 56..63 -- only where those middle lanes really are bitwise equal (periodic-type operators on a uniform grid)
+    size_t tlc_off = 0;
+    if (Q == 16) {
+        const double *tl = &img[tl_off];
+        bool ok = true;
+        auto row_entry = [&](int k) { return k < 8 * Q ? k : 8 * Q + 12 + (k - 8 * Q); };  // k = 0 .. 9Q-1
+        // dist_sa / dist_sc never become constant, they decay (by 0.15 - 0.38 per row): in the middle lanes (rows
+        // 129 .. 896) they are below 2^-60 and stored as 0, the truncation the HALO strip corrections use too
+        auto decaying = [&](int k) { return k >= 5 * Q && k < 7 * Q; };
+        for (int k = 0; k < 9 * Q && ok; k++)
+            for (int l = 8; l <= 55 && ok; l++) {
+                const double *v = &tl[(size_t)row_entry(k) * 64];
+                ok = decaying(k) ? fabs(v[l]) < 8.673617379884035e-19 : memcmp(&v[l], &v[8], sizeof(double)) == 0;
+            }
+        if (ok) {
+            std::vector<double> c((size_t)9 * Q * 17 + 12 * 64);
+            for (int k = 0; k < 9 * Q; k++)
+                for (int m = 0; m < 17; m++)
+                    c[(size_t)k * 17 + m] = (m == 8 && decaying(k)) ? 0.0 : tl[(size_t)row_entry(k) * 64 + (m <= 8 ? m : m + 47)];
+            for (int k = 0; k < 12; k++)
+                for (int l = 0; l < 64; l++) c[(size_t)9 * Q * 17 + k * 64 + l] = tl[(size_t)(8 * Q + k) * 64 + l];
+            tlc_off = img.size();
+            img.insert(img.end(), c.begin(), c.end());
+        }
+    }
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
     X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
     TdsTab &tb = t->tab;
@@ -174,6 +200,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         for (int m = 0; m < 9; m++)
             if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) tb.bulk_only = 0;
     tb.TL = Q ? t->dev + tl_off : nullptr;
+    t->tlc = tlc_off ? t->dev + tlc_off : nullptr;
     t->tl_hash = 1469598103934665603ull;
     if (Q) {
         const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&img[tl_off]);
@@ -596,6 +623,9 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
                        const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
                        const x3d_tdsops *op_i, double scale, bool *done);  // xscan.hip
 // xdir.hip
+int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
+                       const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
+                       bool *done);  // xwide.hip
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
@@ -924,6 +954,8 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
         if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, nullptr, nullptr, nullptr,
                                         0.0, &done))
             return rc;
+        if (done) return 0;
+        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;  // n = 1024
         if (done) return 0;
     }
     if (dir != X3D_DIR_X) {

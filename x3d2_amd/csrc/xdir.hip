@@ -387,6 +387,7 @@ static bool xdir_tiled()
 }
 
 int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done);
+int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done);  // xwide.hip
 int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 static bool use_xscan()
@@ -404,6 +405,8 @@ int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *
     if (use_xscan() && xdir_tiled()) {
         bool done = false;
         if (int rc = x3d_xscan_tds(b, du, u, t, acc, scale, &done)) return rc;
+        if (done) return 0;
+        if (int rc = x3d_xwide_tds(b, du, u, t, acc, scale, &done)) return rc;  // 1024-row pencils (xwide.hip)
         if (done) return 0;
     }
     if (!xdir_tiled()) return x3d_generic_tds_local(b, du, u, t, X3D_DIR_X, acc, scale);

@@ -34,275 +34,7 @@
 
 int npmax_of(const x3d_backend *b);
 
-// lane-table entry indices (per operator): 8*Q row entries then the scan multipliers
-#define LT_F(q) (0 * Q + (q))
-#define LT_A(q) (1 * Q + (q))
-#define LT_PF(q) (2 * Q + (q))
-#define LT_H(q) (3 * Q + (q))
-#define LT_QB(q) (4 * Q + (q))
-#define LT_SA(q) (5 * Q + (q))
-#define LT_SC(q) (6 * Q + (q))
-#define LT_ST(q) (7 * Q + (q))
-#define LT_MF(k) (8 * Q + (k))
-#define LT_MB(k) (8 * Q + 6 + (k))
-#define LT_STC(q) (8 * Q + 12 + (q))  // last: only the d2u operator of a transeq component reads it
-#define LT_N(Q_) (9 * (Q_) + 12)
-#define LT_NC(Q_) (8 * (Q_) + 12)     // entries without the STC block
-
-// One lane-table value.  Two of these reads off one base register are merged by the compiler into
-// ds_read2st64_b64, which the LDS serves at HALF the rate of two ds_read_b64 (measured, scratch/ldsbench.hip:
-// 4.3 against 2.6 LDS clocks per 512-byte row; MI355X_MICROARCH.md, LDS table) -- and these kernels are
-// LDS-bound on exactly these reads (LdsUtil 83 % in k_ytile_transeq3).  The empty asm is a barrier for the
-// load / store combiner only (it ends a merge window); it emits nothing.
-#ifndef XS_READ2
-__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx)
-{
-    const double v = l[idx];
-    asm volatile("" ::: "memory");
-    return v;
-}
-#else
-__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx) { return l[idx]; }
-#endif
-#define LTR(l, e) lt_read((l), (e) * 64 + lane)
-
-// what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
-struct XOp {
-    const double *TL, *Cs;
-    double last_r, rs_s, rs_e, sa1, scn;
-    double c[9];  // bulk stencil by value: kernel arguments live in SGPRs (a load through Cs would be a
-                  // VMEM load per pencil and operator, the stores may alias it)
-    int n_tds, n_rhs, bulk_only;
-};
-static XOp xop_of(const x3d_tdsops *t)
-{
-    const TdsTab &b = t->tab;
-    XOp o{b.TL, b.Cs, b.last_r, b.rs_s, b.rs_e, b.sa1, b.scn, {0}, b.n_tds, b.n_rhs, b.bulk_only};
-    for (int m = 0; m < 9; m++) o.c[m] = t->coeffs[m];
-    return o;
-}
-
-// DPP move of a double; lanes whose source lane does not exist (or whose row is masked out) read 0
-template <int CTRL, int ROWMASK = 0xf>
-__device__ __forceinline__ double dpp0(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_d(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// ---- two pencils per wave: every lane-table value read from LDS serves both (the kernels are LDS-pipe
-// bound on the table reads), and the two independent dependency chains interleave.  The solver below is
-// written once over T = double or V2.
-struct V2 { double a, b; };
-__device__ __forceinline__ V2 operator+(V2 x, V2 y) { return V2{x.a + y.a, x.b + y.b}; }
-__device__ __forceinline__ V2 operator-(V2 x, V2 y) { return V2{x.a - y.a, x.b - y.b}; }
-__device__ __forceinline__ V2 operator*(V2 x, V2 y) { return V2{x.a * y.a, x.b * y.b}; }
-__device__ __forceinline__ V2 operator*(double c, V2 x) { return V2{c * x.a, c * x.b}; }
-__device__ __forceinline__ V2 operator*(V2 x, double c) { return V2{x.a * c, x.b * c}; }
-__device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.a += y.a; x.b += y.b; return x; }
-template <int CTRL, int ROWMASK = 0xf>
-__device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
-__device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
-template <class T> __device__ __forceinline__ T zero_of();
-template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
-template <> __device__ __forceinline__ V2 zero_of<V2>() { return V2{0.0, 0.0}; }
-__device__ __forceinline__ double first_of(double x) { return x; }
-__device__ __forceinline__ double first_of(V2 x) { return x.a; }
-
-__device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
-{
-    const double r = __shfl_up(v, d, 64);
-    return lane >= d ? r : 0.0;
-}
-__device__ __forceinline__ double shfl_down_d(double v, int d, int lane)
-{
-    const double r = __shfl_down(v, d, 64);
-    return lane + d < 64 ? r : 0.0;
-}
-
-// extended pencil row jj in [-3, nr+4] (non-decomposed direction: periodic image,
-// src/backend/omp/sendrecv.f90:20-22); rows beyond nr+4 read as zero
-__device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, int nr, int n_wrap)
-{
-    if (jj < 1) return row[n_wrap + jj - 1];
-    if (jj > nr) return jj <= nr + 4 ? row[jj - nr - 1] : 0.0;
-    return row[jj - 1];
-}
-
-// one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
-// values (before the reduced-system substitution), du1 and xn broadcast to all lanes
-template <int Q, bool FAST, bool NARROW = false, class T = double>
-__device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du1, T &xn,
-                                           const double *__restrict__ lt, const XOp &t, int &lane, int first)
-{
-    // PHASE(x): the lane-table reads of the next phase may not be issued before x is known; without
-    // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
-#define PHASE(x) asm volatile("" : "+v"(lane) : "v"(first_of(x)))
-    const int nr = t.n_rhs, n = t.n_tds;
-    const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
-                 c7 = t.c[7], c8 = t.c[8];
-    T acc[Q];
-    // NARROW: the compact6 / classic stencils only reach 2 rows: skip the zero taps (adding 0 * w is exact,
-    // so both forms give the same bits); chosen by the launcher from the operators' coefficients
-    if (NARROW) {
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-            acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
-    } else {
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-            acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
-                     c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
-    }
-    // boundary rows (1..4 and n_rhs-3..n_rhs) use their own stencils: only the two end lanes get here
-    if (!FAST && !t.bulk_only && (first <= 4 || first + Q - 1 > nr - 4)) {
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = first + q;
-            if (j <= nr && (j <= 4 || j > nr - 4)) {
-                const double *__restrict__ cs = j <= 4 ? t.Cs + (j - 1) * 9 : t.Cs + 36 + (j - (nr - 4) - 1) * 9;
-                acc[q] = cs[0] * w[q] + cs[1] * w[q + 1] + cs[2] * w[q + 2] + cs[3] * w[q + 3] + cs[4] * w[q + 4] +
-                         cs[5] * w[q + 5] + cs[6] * w[q + 6] + cs[7] * w[q + 7] + cs[8] * w[q + 8];
-            }
-        }
-    }
-    // ---- lane-local forward elimination from zero
-    T prev = zero_of<T>();
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-        X[q] = LTR(lt, LT_F(q)) * (acc[q] - LTR(lt, LT_A(q)) * prev);
-        prev = X[q];
-    }
-    // ---- scan of the lane-end values, then carry-in = true e at the end of lane l-1
-    T v = prev;
-    PHASE(X[Q / 2]);
-#if XSCAN_EXP == 3
-    T carry = v;
-#else
-    // prefix scan without LDS traffic: in-row Kogge-Stone by DPP row shifts, then lane 15 / 47 into rows
-    // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0
-    v += LTR(lt, LT_MF(0)) * dpp0<0x111>(v);
-    v += LTR(lt, LT_MF(1)) * dpp0<0x112>(v);
-    v += LTR(lt, LT_MF(2)) * dpp0<0x114>(v);
-    v += LTR(lt, LT_MF(3)) * dpp0<0x118>(v);
-    v += LTR(lt, LT_MF(4)) * dpp0<0x142, 0xA>(v);
-    v += LTR(lt, LT_MF(5)) * dpp0<0x143, 0xC>(v);
-    T carry = dpp0<0x138>(v);  // wave_shr:1
-#endif
-    // ---- apply, lane-local back-substitution from zero
-    T nxt = zero_of<T>();
-    PHASE(carry);
-#pragma unroll
-    for (int q = Q - 1; q >= 0; q--) {
-        X[q] = (X[q] + LTR(lt, LT_PF(q)) * carry) + LTR(lt, LT_H(q)) * nxt;
-        nxt = X[q];
-    }
-    if (n == nr) {}  // (row n_rhs = n+1 of a v2p operator carries F = H = 0 in the tables)
-    v = nxt;
-    PHASE(X[Q / 2]);
-#if XSCAN_EXP == 3
-    carry = v;
-#else
-    // suffix scan: row shifts the other way, then lane 16 / 48 into rows 0 / 2 and lane 32 into rows 0, 1
-    v += LTR(lt, LT_MB(0)) * dpp0<0x101>(v);
-    v += LTR(lt, LT_MB(1)) * dpp0<0x102>(v);
-    v += LTR(lt, LT_MB(2)) * dpp0<0x104>(v);
-    v += LTR(lt, LT_MB(3)) * dpp0<0x108>(v);
-    {
-        const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
-        v += LTR(lt, LT_MB(4)) * (lane < 32 ? s16 : s48);
-        v += LTR(lt, LT_MB(5)) * readlane_d(v, 32);
-    }
-    carry = dpp0<0x130>(v);  // wave_shl:1
-#endif
-#pragma unroll
-    for (int q = 0; q < Q; q++) X[q] = X[q] + LTR(lt, LT_QB(q)) * carry;
-    // du_1 = last_r * X_1 (X_1 = e_1 - bw_1 X_2, distributed.f90:161-166); X_n = e_n
-    du1 = t.last_r * readlane_d(X[0], 0);
-    if constexpr (FAST) {
-        xn = readlane_d(X[Q - 1], 63);
-    } else {
-        const int ln = (n - 1) / Q, qn = (n - 1) % Q;
-        double xsel = 0.0;
-#pragma unroll
-        for (int q = 0; q < Q; q++) xsel = (q == qn) ? X[q] : xsel;
-        xn = __shfl(xsel, ln, 64);
-    }
-    PHASE(xn);
-#undef PHASE
-}
-
-// nr == 64*Q and n_wrap == nr: every lane's body is a full aligned vector and the halos are
-// the neighbours' rows or the periodic image -> no per-lane branches at all
-template <int Q>
-__device__ __forceinline__ void load_window_exact(double (&w)[Q + 8], const double *__restrict__ row, int lane,
-                                                  int nr)
-{
-    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
-#pragma unroll
-    for (int m = 0; m < Q / 2; m++) {
-        const double2 t2 = body[m];
-        w[4 + 2 * m] = t2.x;
-        w[5 + 2 * m] = t2.y;
-    }
-    const int il = lane == 0 ? nr - 4 : lane * Q - 4;       // rows first-4..first-1 (periodic image for lane 0)
-    const int ir = lane == 63 ? 0 : lane * Q + Q;           // rows last+1..last+4
-    const double2 *__restrict__ hl = reinterpret_cast<const double2 *>(row + il);
-    const double2 *__restrict__ hr = reinterpret_cast<const double2 *>(row + ir);
-    const double2 a0 = hl[0], a1 = hl[1], b0 = hr[0], b1 = hr[1];
-    w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
-    w[Q + 4] = b0.x; w[Q + 5] = b0.y; w[Q + 6] = b1.x; w[Q + 7] = b1.y;
-}
-
-// FAST path: only the lane's own Q rows come from memory (4 aligned 16-byte loads, issued one
-// pencil ahead); the 4+4 halo rows are the neighbour lanes' rows (periodic wrap across the wave)
-template <int Q>
-__device__ __forceinline__ void load_body(double (&b)[Q], const double *__restrict__ row, int lane)
-{
-    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
-#pragma unroll
-    for (int m = 0; m < Q / 2; m++) {
-        const double2 t2 = body[m];
-        b[2 * m] = t2.x;
-        b[2 * m + 1] = t2.y;
-    }
-}
-template <int Q, class T = double>
-__device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q], int lane)
-{
-    (void)lane;
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        w[m] = dpp0<0x13C>(b[Q - 4 + m]);      // wave_ror:1: from lane - 1, periodic wrap
-        w[Q + 4 + m] = dpp0<0x134>(b[m]);      // wave_rol:1: from lane + 1
-    }
-#pragma unroll
-    for (int q = 0; q < Q; q++) w[4 + q] = b[q];
-}
-
-// decomposed direction (BC_HALO ends): rows -3..0 and n+1..n+4 of the pencil are the neighbour ranks' rows, handed
-// over in hl[0..3] / hl[4..7] (this wave's 8 halo values, staged in LDS) instead of the periodic image
-template <int Q, class T = double>
-__device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b)[Q], int lane,
-                                                      const double *__restrict__ hl)
-{
-    window_from_body<Q, T>(w, b, lane);
-    // (two one-lane branches: selects on all lanes keep 8 more values live where the kernels have no room)
-    if (lane == 0) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) w[m] = hl[m];
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) w[Q + 4 + m] = hl[4 + m];
-    }
-}
+#include "xscan_core.h"
 
 // HALO forms of the tile kernels (K3y): the reduced 2 x 2 systems of a decomposed direction couple to the
 // NEIGHBOUR ranks' boundary values (src/backend/omp/kernels/distributed.f90:186-206), which do not exist yet

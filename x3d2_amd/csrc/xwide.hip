@@ -1,0 +1,285 @@
+// x-direction operators on 1024-row pencils, one pencil per wave (kernel family K3w): the single-pass scan
+// kernels of xscan.hip with Q = 16 rows per lane (channel case: nx = 1024, BASELINE configs[4]).
+//
+// Two things differ from the 256 / 512-row kernels:
+//  * lane tables: 156 entries x 64 lanes = 80 KB per operator would not fit twice; periodic-type operators on a
+//    uniform grid have row entries that are bitwise constant away from the pencil's ends, so the tables are staged
+//    in the compressed form of xscan_core.h (LTC_*: 26 KB per operator);
+//  * memory access: a lane's 16 rows are 128 bytes -- loading them lane by lane would touch 16 bytes of 64
+//    different lines per instruction.  Each wave moves its pencil with fully coalesced 16-byte accesses (1 KB
+//    per instruction) and redistributes through a wave-private LDS strip (lane l's rows at l * 18 doubles: the
+//    two padding doubles make both the coalesced and the lane-owned 16-byte accesses conflict-free); no barriers,
+//    a wave's LDS operations execute in order (wave_lds_fence).
+// Arithmetic: scan_solve, the same re-association of src/backend/omp/kernels/distributed.f90:34-166 (sweeps) and
+// :186-337 (2 x 2 systems, substitution) as the other scan kernels; periodic self-exchange (sendrecv.f90:20-22).
+#include "xscan_core.h"
+
+constexpr int WQ = 16;             // rows per lane
+constexpr int WSTRIP = 64 * 18;    // doubles of LDS per wave
+
+// the wave's pencil <-> registers, coalesced: instruction m moves the 16-byte pieces lane + 64 m
+__device__ __forceinline__ void wide_gload(double (&v)[16], const double *__restrict__ row, int lane)
+{
+    const double2 *__restrict__ r2 = reinterpret_cast<const double2 *>(row) + lane;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const double2 t = r2[64 * m];
+        v[2 * m] = t.x;
+        v[2 * m + 1] = t.y;
+    }
+}
+// piece g = lane + 64 m belongs to lane g / 8 (its pair g % 8)
+__device__ __forceinline__ int wide_coal_off(int lane, int m) { return ((lane >> 3) + 8 * m) * 18 + (lane & 7) * 2; }
+__device__ __forceinline__ void wide_to_strip(double *strip, const double (&v)[16], int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+        *reinterpret_cast<double2 *>(strip + wide_coal_off(lane, m)) = make_double2(v[2 * m], v[2 * m + 1]);
+}
+__device__ __forceinline__ void wide_own_rows(double (&b)[WQ], const double *strip, int lane)
+{
+    const double2 *s2 = reinterpret_cast<const double2 *>(strip + lane * 18);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const double2 t = s2[k];
+        b[2 * k] = t.x;
+        b[2 * k + 1] = t.y;
+    }
+}
+__device__ __forceinline__ void wide_put_rows(double *strip, const double (&r)[WQ], int lane)
+{
+    double2 *s2 = reinterpret_cast<double2 *>(strip + lane * 18);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s2[k] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+// strip -> memory, coalesced; ACC: out = old + scale * r (the arithmetic of k_xscan_tds<ACC>)
+template <bool ACC>
+__device__ __forceinline__ void wide_store(double *__restrict__ orow, const double *strip, int lane, double scale)
+{
+    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow) + lane;
+    double2 old[8];
+    if (ACC) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) old[m] = o2[64 * m];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double2 v = *reinterpret_cast<const double2 *>(strip + wide_coal_off(lane, m));
+        if (ACC) { v.x = old[m].x + scale * v.x; v.y = old[m].y + scale * v.y; }
+        o2[64 * m] = v;
+    }
+}
+
+// one operator on the window w: r = its tds_solve rows (closed with the periodic self-exchange)
+template <bool NARROW>
+__device__ __forceinline__ void wide_solve(const double (&w)[WQ + 8], double (&r)[WQ], const double *__restrict__ lt,
+                                           const XOp &t, int &lane, int ll)
+{
+    constexpr int Q = WQ, LS = LTC_LS;
+    double X[WQ], du1, xn;
+    scan_solve<WQ, true, NARROW, double, LTC_LS>(w, X, du1, xn, lt, t, lane, lane * WQ + 1, ll);
+    const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        const double st = LTX(lt, LT_ST(q));
+        double x = (X[q] - LTX(lt, LT_SA(q)) * du_s - LTX(lt, LT_SC(q)) * du_e) * st;
+        if (q == 0) x = (lane == 0) ? du_s * st : x;
+        if (q == WQ - 1) x = (lane == 63) ? du_e * st : x;
+        r[q] = x;
+    }
+}
+
+// ---------------------------------------------------------------- tds_solve
+template <bool ACC, bool NARROW>
+__global__ void __launch_bounds__(512) k_xwide_tds(double *__restrict__ du, const double *__restrict__ u, XOp t, int np,
+                                                   long pitch, double scale)
+{
+    extern __shared__ double lt[];  // [LTC_N(16)] tables, then one strip per wave
+    for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    double *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    const int ll = ltc_lane(lane);
+    const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
+    double nxt[16];  // next pencil's pieces, in flight while this one is solved
+    if (p0 < np) wide_gload(nxt, u + (long)p0 * pitch, lane);
+    for (int p = p0; p < np; p += nwaves) {
+        asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
+        double w[WQ + 8], r[WQ];
+        {
+            double b[WQ];
+            wide_to_strip(strip, nxt, lane);
+            wave_lds_fence();
+            wide_own_rows(b, strip, lane);
+            window_from_body<WQ>(w, b, lane);
+        }
+        if (p + nwaves < np) wide_gload(nxt, u + (long)(p + nwaves) * pitch, lane);
+        wide_solve<NARROW>(w, r, lt, t, lane, ll);
+        wave_lds_fence();  // (every lane has read its rows: the strip may be rewritten)
+        wide_put_rows(strip, r, lane);
+        wave_lds_fence();
+        wide_store<ACC>(du + (long)p * pitch, strip, lane, scale);
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------- transeq_x: the three components at once
+// (u0, conv = u0), (u1, u0), (u2, u0) as in k_xscan_transeq2x3 (src/backend/omp/backend.f90:145-184,
+// exec_dist.f90:85-169 per component): the pencil's rows of the advecting velocity stay in registers, 6 field
+// passes for the direction.  der1st == der1st_sym and der2nd == der2nd_sym as lane tables (periodic operators).
+template <bool ACC, bool NARROW>
+__global__ void __launch_bounds__(512)
+    k_xwide_transeq3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
+                     const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1,
+                     XOp tD2, int np, long pitch, double nu)
+{
+    extern __shared__ double lt[];
+    constexpr int LN = LTC_N(WQ), Q = WQ, LS = LTC_LS;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = tD1.TL[i];
+        lt[LN + i] = tD2.TL[i];
+    }
+    __syncthreads();
+    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    double *strip = lt + 2 * LN + wave * WSTRIP;
+    const int ll = ltc_lane(lane);
+    const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
+    double nxt[16];  // the rows needed next (next component's field, or the next pencil's u0)
+    if (p0 < np) wide_gload(nxt, u0 + (long)p0 * pitch, lane);
+    for (int p = p0; p < np; p += nwaves) {
+        const long ro = (long)p * pitch;
+        double cb[WQ];
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            asm volatile("" : "+v"(lane));
+            double wu[WQ + 8], wp[WQ + 8];
+            {
+                double b[WQ];
+                wide_to_strip(strip, nxt, lane);
+                wave_lds_fence();
+                wide_own_rows(b, strip, lane);
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) cb[q] = b[q];
+                }
+                window_from_body<WQ>(wu, b, lane);
+                window_from_body<WQ>(wp, cb, lane);
+#pragma unroll
+                for (int m = 0; m < WQ + 8; m++) wp[m] = wu[m] * wp[m];
+            }
+            {
+                const int pn = p + nwaves;
+                const double *nsrc = c == 0 ? u1 + ro : (c == 1 ? u2 + ro : u0 + (long)(pn < np ? pn : p) * pitch);
+                if (c < 2 || pn < np) wide_gload(nxt, nsrc, lane);
+            }
+            double r[WQ], T[WQ];
+            wide_solve<NARROW>(wp, T, l1, tD1, lane, ll);  // d(u conv)/dx first: wp is dead afterwards
+#pragma unroll
+            for (int q = 0; q < WQ; q++) r[q] = T[q];
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            wide_solve<NARROW>(wu, T, l1, tD1, lane, ll);  // du/dx
+#pragma unroll
+            for (int q = 0; q < WQ; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTX(l3, LTC_STC(q)));
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            wide_solve<NARROW>(wu, T, l3, tD2, lane, ll);  // d2u/dx2
+#pragma unroll
+            for (int q = 0; q < WQ; q++) r[q] += nu * T[q];
+            wave_lds_fence();
+            wide_put_rows(strip, r, lane);
+            wave_lds_fence();
+            wide_store<ACC>((c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + ro, strip, lane, 1.0);
+            wave_lds_fence();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static bool wide_env_on()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *names[3] = {"X3D_NO_XWIDE", "X3D_NO_XSCAN", "X3D_XDIR_GENERIC"};
+        on = 1;
+        for (const char *nm : names) { const char *e = getenv(nm); if (e && e[0] == '1') on = 0; }
+    }
+    return on == 1;
+}
+static bool wide_ok(const x3d_backend *b, const x3d_tdsops *t)
+{
+    return t->tlc != nullptr && t->tab.Q == WQ && t->tab.bulk_only && t->n_tds == 64 * WQ && t->tab.n_rhs == t->n_tds &&
+           b->nx == 64 * WQ;
+}
+static bool wide_narrow(const x3d_tdsops *t)
+{
+    return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
+}
+static XOp wide_xop(const x3d_tdsops *t)
+{
+    XOp o = xop_of(t);
+    o.TL = t->tlc;
+    return o;
+}
+
+// tds_solve along x on 1024-row pencils; *done = false: not served here
+int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done)
+{
+    *done = false;
+    if (!wide_env_on() || !wide_ok(b, t)) return 0;
+    const int np = b->ny * b->nz;
+    const size_t lds = sizeof(double) * (LTC_N(WQ) + 8 * WSTRIP);
+    int blocks = (np + 7) / 8;
+    blocks = blocks > 256 ? 256 : blocks;  // 98 KB of LDS: one 8-wave workgroup per CU
+    const bool narrow = wide_narrow(t);
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
+#define GO(A_, N_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_xwide_tds<A_, N_>));                                                                \
+        hipLaunchKernelGGL((k_xwide_tds<A_, N_>), dim3(blocks), dim3(512), lds, b->stream, du, u, wide_xop(t), np, \
+                           (long)b->nxp, A_ ? scale : 1.0);                                                     \
+    } while (0)
+    if (acc) { if (narrow) GO(true, true); else GO(true, false); }
+    else { if (narrow) GO(false, true); else GO(false, false); }
+#undef GO
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+// transeq_x in one launch; f[0] is the advecting component
+int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
+                       const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
+                       bool *done)
+{
+    *done = false;
+    if (!wide_env_on() || !wide_ok(b, der1st) || !wide_ok(b, der1st_sym) || !wide_ok(b, der2nd) || !wide_ok(b, der2nd_sym))
+        return 0;
+    if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
+    const int np = b->ny * b->nz;
+    const size_t lds = sizeof(double) * (2 * LTC_N(WQ) + 8 * WSTRIP);
+    const int blocks = (np + 7) / 8 > 256 ? 256 : (np + 7) / 8;
+    const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd);
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
+#define GO(A_, N_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_>));                                                           \
+        hipLaunchKernelGGL((k_xwide_transeq3<A_, N_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], f[0], \
+                           f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu);               \
+    } while (0)
+        if (acc) { if (narrow) GO(true, true); else GO(true, false); }
+        else { if (narrow) GO(false, true); else GO(false, false); }
+#undef GO
+    }
+    X3D_HIP(hipGetLastError());
+    b->n_tq3++;
+    if (b->prof) {  // three components (bench.py divides the direction's time by the count)
+        for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X); }
+    }
+    *done = true;
+    return 0;
+}
