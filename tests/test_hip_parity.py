@@ -694,9 +694,15 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
         assert relerr(b.get_field_data(fh, VERT), o.backend.get_field_data(fo, orc.VERT)) < TOL, nm
 
 
-@pytest.mark.parametrize("dims", [(32, 512, 8), (64, 8, 512), (32, 256, 8), (64, 8, 256), (40, 256, 9), (72, 8, 256),
-                                  (128, 256, 8)])
-def test_yz_operators_on_512_row_pencils(dims):
+@pytest.mark.parametrize("dims,bc,stretch", [
+    ((32, 512, 8), "periodic", "uniform"), ((64, 8, 512), "periodic", "uniform"), ((32, 256, 8), "periodic", "uniform"),
+    ((64, 8, 256), "periodic", "uniform"), ((40, 256, 9), "periodic", "uniform"), ((72, 8, 256), "periodic", "uniform"),
+    ((128, 256, 8), "periodic", "uniform"),
+    # non-periodic / odd-length pencils: the general tile kernels (K3g, csrc/ygen.hip); 257 stretched wall-normal
+    # vertices = the channel case's y pencils (BASELINE configs[4])
+    ((32, 257, 8), "dirichlet", "top-bottom"), ((48, 130, 8), "neumann", "uniform"), ((64, 8, 257), "dirichlet", "uniform"),
+    ((32, 384, 8), "dirichlet", "centred"), ((16, 500, 8), "dirichlet", "bottom")])
+def test_yz_operators_on_512_row_pencils(dims, bc, stretch):
     """y / z pencils of 512 (the bench size) and 256 rows: every operator incl. accumulating forms against
     the oracle.  These are the sizes at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""
     from oracle import x3d_oracle as orc
@@ -706,9 +712,13 @@ def test_yz_operators_on_512_row_pencils(dims):
     from x3d2_amd.solver import Solver, SolverConfig
     L = (2.0, 3.0, 2.5)
     per = ("periodic",) * 2
-    mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
+    d = 2 if dims[1] >= 128 else 3
+    bcs = [per, (bc,) * 2 if d == 2 else per, (bc,) * 2 if d == 3 else per]
+    strs = ("uniform", stretch, "uniform")
+    beta = (1.0, 0.259065151 if stretch == "top-bottom" else 1.3, 1.0)
+    mesh = Mesh(dims, (1, 1, 1), L, *bcs, strs, beta)
     s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True))
-    om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), *[list(x) for x in bcs], stretching=strs, beta=beta)
     o = orc.Solver(om, poisson="CG")
     rng = np.random.default_rng(7)
     b, al = s.backend, s.backend.allocator
@@ -718,7 +728,6 @@ def test_yz_operators_on_512_row_pencils(dims):
         o.backend.set_field_data(fo, a)
         fp.set_data_loc(VERT)
         b.set_field_data(fp, a)
-    d = 2 if dims[1] >= 256 else 3
     dp_h, dp_o = (s.ydirps, o.ydirps) if d == 2 else (s.zdirps, o.zdirps)
     for op in OPNAMES:
         t_h, t_o = getattr(dp_h, op), getattr(dp_o, op)

@@ -105,7 +105,8 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     }
     memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
     // lane tables for the wave-per-pencil x kernels (xscan.hip): lane l owns rows l*Q+1..(l+1)*Q
-    const int Q = nr <= 256 ? 4 : (nr <= 512 ? 8 : (nr <= 1024 ? 16 : 0));
+    // (6: 257 .. 384 rows, e.g. the channel case's 257 wall-normal vertices -- 43 of the 64 lanes busy instead of 33)
+    const int Q = nr <= 256 ? 4 : (nr <= 384 ? 6 : (nr <= 512 ? 8 : (nr <= 1024 ? 16 : 0)));
     const size_t tl_off = img.size();
     if (Q) {
         const int NE = 9 * Q + 12;
@@ -206,8 +207,8 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&img[tl_off]);
         for (size_t i = 0; i < (img.size() - tl_off) * sizeof(double); i++)
             t->tl_hash = (t->tl_hash ^ bytes[i]) * 1099511628211ull;
-        for (int m = 0; m < 9; m++) {  // + the bulk stencil and the scalars the kernels take by value
-            const unsigned char *cb = reinterpret_cast<const unsigned char *>(&coeffs[m]);
+        for (int m = 0; m < 81; m++) {  // + the boundary and bulk stencils (Cs: [4][9] start, [4][9] end, [9] bulk)
+            const unsigned char *cb = reinterpret_cast<const unsigned char *>(&Cs[m]);
             for (size_t i = 0; i < sizeof(double); i++) t->tl_hash = (t->tl_hash ^ cb[i]) * 1099511628211ull;
         }
     }
@@ -626,6 +627,11 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
                        bool *done);  // xwide.hip
+int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                  const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // ygen.hip
+int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                      const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                      const x3d_tdsops *der2nd_sym, int acc, bool *done);  // ygen.hip
 int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
 int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
@@ -713,6 +719,11 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
         if (int rc = x3d_onchip2_tds(b, du, u, t, dir, accumulate, scale, &done)) return rc;
         if (done) return 0;
     }
+    if (!accumulate) {  // K3g (ygen.hip): non-periodic / odd-length pencils through the LDS tile, single pass
+        bool done = false;
+        if (int rc = x3d_ygen_pair(b, dir, 2, du, nullptr, u, nullptr, t, t, &done)) return rc;
+        if (done) return 0;
+    }
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
@@ -745,6 +756,8 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
     if (dir != X3D_DIR_X) {
         bool done = false;
         if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, nullptr, 0, -1, &done)) return rc;
+        if (done) return 0;
+        if (int rc = x3d_ygen_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, &done)) return rc;  // K3g
         if (done) return 0;
     }
     if (int rc = x3d_tds_solve_acc(b, out1, in1, ta, dir, 0, 1.0)) return rc;
@@ -964,6 +977,12 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
         if (int rc = x3d_transeq_via_x(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;
         if (done) return 0;
     }
+    if (dir != X3D_DIR_X) {
+        // K3g (ygen.hip): non-periodic / odd-length pencils, the three components in one launch
+        bool done = false;
+        if (int rc = x3d_ygen_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;
+        if (done) return 0;
+    }
     if (int rc = transeq_component_local(b, dir, r[0], f[0], f[0], nu, der1st, der1st_sym, der2nd, a)) return rc;
     if (int rc = transeq_component_local(b, dir, r[1], f[1], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
     if (int rc = transeq_component_local(b, dir, r[2], f[2], f[0], nu, der1st_sym, der1st, der2nd_sym, a)) return rc;
@@ -1109,6 +1128,9 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1
     if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv ? &th : nullptr, other0,
                                     nother, &ok))
         return rc;
+    if (!ok && !halo_recv && other0 == 0 && (nother < 0 || nother == (dir == X3D_DIR_Y ? b->nz : b->ny))) {
+        if (int rc = x3d_ygen_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, &ok)) return rc;  // K3g, whole block only
+    }
     *done = ok ? 1 : 0;
     return 0;
 }

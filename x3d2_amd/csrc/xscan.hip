@@ -156,8 +156,10 @@ template <int Q, bool ACC, int FAST>  // FAST: 0 general, 1 branch-free periodic
 __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, const double *__restrict__ u, XOp t,
                                                    int np, long pitch, int n_wrap, double scale)
 {
-    extern __shared__ double lt[];  // [LT_N(Q)][64]
+    extern __shared__ double lt[];  // [LT_N(Q)][64], general form: + the stencil table [CS_N(Q)]
     for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
+    const double *cs = lt + LT_N(Q) * 64;
+    if (!FAST) stage_cs<Q>(lt + LT_N(Q) * 64, t);
     __syncthreads();
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 #endif
         } else if (exact) load_window_exact<Q>(w, row, lane, nr);
         else load_window<Q>(w, row, first, nr, n_wrap, interior);
-        scan_solve<Q, (FAST != 0), (FAST == 2)>(w, X, du1, xn, lt, t, lane, first);
+        scan_solve<Q, (FAST != 0), (FAST == 2)>(w, X, du1, xn, lt, t, lane, first, 0, cs);
         const double du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
         const double du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
         double *__restrict__ orow = du + (long)p * pitch;
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 #if XSCAN_EXP == 1
         if (r[0] != 12345.678) continue;
 #endif
-        if (FAST) {
+        if constexpr (FAST != 0) {
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, scale);
             else store_rows_q4<ACC>(orow, lane, r, scale);
         } else if (exact && n == nr) {
@@ -286,12 +288,18 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
                     XOp t2, XOp t3, int np, long pitch, double nu)
 {
-    extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64]
+    extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64], general form: + their stencil tables [3][CS_N(Q)]
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = t1.TL[i];
         lt[LN + i] = t2.TL[i];
         lt[2 * LN + i] = t3.TL[i];
+    }
+    const double *cs0 = lt + 3 * LN;
+    if (!FAST) {
+        stage_cs<Q>(lt + 3 * LN, t1);
+        stage_cs<Q>(lt + 3 * LN + CS_N(Q), t2);
+        stage_cs<Q>(lt + 3 * LN + 2 * CS_N(Q), t3);
     }
     __syncthreads();
     int lane = threadIdx.x & 63;
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
         // rows 1 and n take du_s*st / du_e*st, which is what the general formula gives with these temps)
         auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
             double a, b;
-            scan_solve<Q, (FAST != 0), (FAST == 2)>(w, T, a, b, l, t, lane, first);
+            scan_solve<Q, (FAST != 0), (FAST == 2)>(w, T, a, b, l, t, lane, first, 0, cs0 + (l - lt) / LN * CS_N(Q));
             const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] += nu * T[q];
         double *__restrict__ orow = rhs + (long)p * pitch;
-        if (FAST) {
+        if constexpr (FAST != 0) {
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, 1.0);
             else store_rows_q4<ACC>(orow, lane, r, 1.0);
         } else if (exact) {
@@ -1288,18 +1296,20 @@ static bool stencil_narrow(const x3d_tdsops *t)
 }
 
 static bool xscan_ok(const x3d_tdsops *t) { return t->tab.TL != nullptr && (t->tab.Q == 4 || t->tab.Q == 8); }
+// the general (FAST = 0) forms of the x kernels also exist for 6 rows per lane (257 .. 384-row pencils)
+static bool xscan_ok_gen(const x3d_tdsops *t) { return xscan_ok(t) || (t->tab.TL != nullptr && t->tab.Q == 6); }
 
 int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done)
 {
     *done = false;
-    if (!xscan_ok(t)) return 0;
+    if (!xscan_ok_gen(t)) return 0;
     const int Q = t->tab.Q, np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * LT_N(Q) * 64;
+    const size_t lds = sizeof(double) * (LT_N(Q) * 64 + CS_N(Q));
     int blocks = (np + 7) / 8;
     blocks = blocks > 768 ? 768 : blocks;  // 43 KB of lane tables per 8-wave workgroup: 3 per CU
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
     // FAST: periodic-type stencils on a pencil the 64 lanes tile exactly, p2p or v2v (n_rhs == n_tds)
-    const bool fast = t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds;
+    const bool fast = t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds && Q != 6;
     const bool narrow = stencil_narrow(t);
 #define LAUNCH(Q_, A_, F_, SC_)                                                                                \
     hipLaunchKernelGGL((k_xscan_tds<Q_, A_, F_>), dim3(blocks), dim3(512), lds, b->stream, du, u, xop_of(t), np, \
@@ -1310,7 +1320,9 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
         else if (fast) { if (acc) LAUNCH(Q_, true, 1, scale); else LAUNCH(Q_, false, 1, 1.0); }                \
         else { if (acc) LAUNCH(Q_, true, 0, scale); else LAUNCH(Q_, false, 0, 1.0); }                          \
     } while (0)
-    if (Q == 8) PICK(8); else PICK(4);
+    if (Q == 8) PICK(8);
+    else if (Q == 6) { if (acc) LAUNCH(6, true, 0, scale); else LAUNCH(6, false, 0, 1.0); }
+    else PICK(4);
 #undef PICK
 #undef LAUNCH
     X3D_HIP(hipGetLastError());
@@ -1337,16 +1349,16 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
                          int dirtag, bool *done)
 {
     *done = false;
-    if (!xscan_ok(t1) || !xscan_ok(t2) || !xscan_ok(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return 0;
+    if (!xscan_ok_gen(t1) || !xscan_ok_gen(t2) || !xscan_ok_gen(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return 0;
     const int Q = t1->tab.Q;
-    const size_t lds = sizeof(double) * 3 * LT_N(Q) * 64;
+    const size_t lds = sizeof(double) * (3 * LT_N(Q) * 64 + 3 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;  // one 8/12-wave workgroup per CU (129 KB of lane tables in LDS)
     const bool same = u == conv;
     ProfScope ps(b, X3D_K_TRANSEQ_FWD, dirtag, dirtag >= 0);  // dirtag < 0: timed by the caller
     int rc;
-    const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q;
+    const bool fast = t1->tab.bulk_only && t2->tab.bulk_only && t3->tab.bulk_only && t1->n_tds == 64 * Q && Q != 6;
     const bool narrow = stencil_narrow(t1) && stencil_narrow(t2) && stencil_narrow(t3);
 #define GO2(Q_, F_)                                                                                            \
     (same ? (acc ? launch_transeq<Q_, true, true, F_>(b, rhs, u, conv, nu, t1, t2, t3, np, blocks, lds, pitch)       \
@@ -1376,7 +1388,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
         *done = true;
         return 0;
     }
-    rc = Q == 8 ? GO(8) : GO(4);
+    rc = Q == 8 ? GO(8) : (Q == 6 ? GO2(6, 0) : GO(4));
 #undef GO
 #undef GO2
     if (rc) return rc;

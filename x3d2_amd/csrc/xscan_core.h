@@ -71,6 +71,27 @@ static inline XOp xop_of(const x3d_tdsops *t)
     return o;
 }
 
+// scan_solve's general form: the stencil weights of every row position of lane 0, lanes ls and ls + 1 (which hold
+// the boundary rows 1..4 and n_rhs-3..n_rhs; Cs = [4][9] start rows, [4][9] end rows, [9] bulk) and the bulk
+// stencil, as [4 slots][Q][10] doubles in LDS (16-byte aligned)
+#define CS_N(Q_) (4 * (Q_) * 10)
+template <int Q>
+__device__ __forceinline__ void stage_cs(double *dst, const XOp &t)
+{
+    const int nr = t.n_rhs, ls = (nr - 4) / Q;
+    for (int i = threadIdx.x; i < CS_N(Q); i += blockDim.x) {
+        const int s_ = i / (Q * 10), q = (i / 10) % Q, m = i % 10;
+        const int L = s_ == 0 ? 0 : (s_ == 1 ? ls : ls + 1), j = L * Q + q + 1;
+        double v = 0.0;
+        if (m < 9) {
+            if (s_ < 3 && j <= 4) v = t.Cs[(j - 1) * 9 + m];
+            else if (s_ < 3 && j > nr - 4 && j <= nr) v = t.Cs[36 + (j - (nr - 4) - 1) * 9 + m];
+            else v = t.Cs[72 + m];
+        }
+        dst[i] = v;
+    }
+}
+
 // DPP move of a double; lanes whose source lane does not exist (or whose row is masked out) read 0
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ double dpp0(double v)
@@ -125,10 +146,12 @@ __device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, 
 }
 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
-// values (before the reduced-system substitution), du1 and xn broadcast to all lanes
+// values (before the reduced-system substitution), du1 and xn broadcast to all lanes.
+// General form (FAST = false): cs = the operator's stencil table in LDS (stage_cs), n_rhs >= 8.
 template <int Q, bool FAST, bool NARROW = false, class T = double, int LS = 64>
 __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du1, T &xn,
-                                           const double *__restrict__ lt, const XOp &t, int &lane, int first, int ll = 0)
+                                           const double *__restrict__ lt, const XOp &t, int &lane, int first, int ll = 0,
+                                           const double *__restrict__ cs = nullptr)
 {
     // PHASE(x): the lane-table reads of the next phase may not be issued before x is known; without
     // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
@@ -139,7 +162,8 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     T acc[Q];
     // NARROW: the compact6 / classic stencils only reach 2 rows: skip the zero taps (adding 0 * w is exact,
     // so both forms give the same bits); chosen by the launcher from the operators' coefficients
-    if (NARROW) {
+    if constexpr (!FAST) {
+    } else if (NARROW) {
 #pragma unroll
         for (int q = 0; q < Q; q++)
             acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
@@ -149,16 +173,22 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
             acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
                      c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
     }
-    // boundary rows (1..4 and n_rhs-3..n_rhs) use their own stencils: only the two end lanes get here
-    if (!FAST && !t.bulk_only && (first <= 4 || first + Q - 1 > nr - 4)) {
+    // General form: rows 1..4 and n_rhs-3..n_rhs use their own stencils.  They sit in lane 0 and in lanes ls, ls + 1
+    // (ls = (n_rhs - 4) / Q); stage_cs builds a table [4 slots][Q][10] in LDS -- the nine weights of every row
+    // position of those three lanes, and the bulk stencil as slot 3 -- and EVERY lane forms its sums with weights
+    // read from its slot (lanes of slot 3 read one address: a broadcast).  No branches, static register indices,
+    // same summation order as the bulk form.  (Per-lane pointers into the stencils under a divergent branch cost
+    // the tile kernels 130+ VGPRs; separate passes over the boundary rows 72 more LDS reads and FMAs per operator.)
+    if constexpr (!FAST) {
+        const int ls = (nr - 4) / Q;
+        int co = (lane == 0 ? 0 : (lane == ls ? 1 : (lane == ls + 1 ? 2 : 3))) * (Q * 10);
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int j = first + q;
-            if (j <= nr && (j <= 4 || j > nr - 4)) {
-                const double *__restrict__ cs = j <= 4 ? t.Cs + (j - 1) * 9 : t.Cs + 36 + (j - (nr - 4) - 1) * 9;
-                acc[q] = cs[0] * w[q] + cs[1] * w[q + 1] + cs[2] * w[q + 2] + cs[3] * w[q + 3] + cs[4] * w[q + 4] +
-                         cs[5] * w[q + 5] + cs[6] * w[q + 6] + cs[7] * w[q + 7] + cs[8] * w[q + 8];
-            }
+            const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + co + q * 10);
+            const double2 ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
+            acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
+                     cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
+            asm volatile("" : "+v"(co) : "v"(first_of(acc[q])));  // one row's weights at a time (10 VGPRs, not 10 Q)
         }
     }
     // ---- lane-local forward elimination from zero
@@ -270,6 +300,19 @@ __device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q],
     for (int m = 0; m < 4; m++) {
         w[m] = dpp0<0x13C>(b[Q - 4 + m]);      // wave_ror:1: from lane - 1, periodic wrap
         w[Q + 4 + m] = dpp0<0x134>(b[m]);      // wave_rol:1: from lane + 1
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) w[4 + q] = b[q];
+}
+
+// non-periodic pencil: rows before row 1 and after row 64 Q read as zero (their stencil weights are zero)
+template <int Q>
+__device__ __forceinline__ void window_from_body_zero(double (&w)[Q + 8], const double (&b)[Q])
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        w[m] = dpp0<0x138>(b[Q - 4 + m]);      // wave_shr:1: from lane - 1, lane 0 reads 0
+        w[Q + 4 + m] = dpp0<0x130>(b[m]);      // wave_shl:1: from lane + 1, lane 63 reads 0
     }
 #pragma unroll
     for (int q = 0; q < Q; q++) w[4 + q] = b[q];

@@ -1,0 +1,362 @@
+// K3g: the LDS-tile kernels of xscan.hip (K3y) for y / z pencils of ANY length up to 512 rows and any boundary
+// closure -- non-periodic ends with their own boundary stencils, v2p operators with n_rhs = n_tds + 1, stretched
+// grids (channel case: 257 wall-normal vertices, Dirichlet, BASELINE configs[4]).  Same data movement: a workgroup
+// of 16 waves owns the 16 x-adjacent pencils of one plane, reads the [rows][16 x] tile in 128-byte row segments,
+// every wave solves its pencil out of LDS with the scan solver, the workgroup writes the tile back: every field
+// is touched once (transeq component: 3 passes, an operator pair: 3 instead of 4 + 4 of the two-sweep kernels).
+//
+// What differs from the periodic fast forms:
+//  * the tile keeps 4 zero rows before row 1 and zeros after the field's last row; a lane reads its whole window
+//    (rows first-4 .. first+Q+3) as one contiguous piece of LDS, no DPP halo moves, no periodic wrap: the boundary
+//    stencils have zero weight outside the pencil (src/tdsops.f90:357-533), the reference multiplies whatever its
+//    halo buffers hold by those zeros;
+//  * scan_solve's general form (boundary rows with their own stencils, staged in LDS; lane tables with zero
+//    multipliers beyond row n; X_n picked from the lane that holds it);
+//  * loads cover the block's rows (ny / nz), stores the operator's n_tds rows.
+// Arithmetic per operator = k_xscan_tds / k_xscan_transeq (general form): the reference's distributed.f90:34-166
+// sweeps and :186-337 substitution, re-associated by the scans.
+#include "xscan_core.h"
+
+template <int Q> struct GenGeom {
+    static constexpr int NMAX = 64 * Q;       // rows the 64 lanes cover
+    static constexpr int TP = NMAX + 10;      // doubles per pencil in the tile: 4 zero rows, NMAX rows, 4 + 2 pad
+    static constexpr int NI = (NMAX + 127) / 128;
+};
+
+// one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
+template <int Q>
+__device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ lt,
+                                          const double *__restrict__ cs, const XOp &t, int &lane)
+{
+    const int first = lane * Q + 1, n = t.n_tds;
+    double X[Q], du1, xn;
+    scan_solve<Q, false, false>(w, X, du1, xn, lt, t, lane, first, 0, cs);
+    const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int j = first + q;
+        const double st = LTR(lt, LT_ST(q));
+        double x = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
+        x = (j == 1) ? du_s * st : x;
+        x = (j == n) ? du_e * st : x;
+        r[q] = x;
+        asm volatile("" : "+v"(lane) : "v"(x));  // (one row's table reads at a time: front-loaded, they were spilled)
+    }
+}
+
+// the pieces every kernel below shares (tile <-> memory, tile <-> registers)
+template <int Q> struct GenTile {
+    using G = GenGeom<Q>;
+    double *tile;
+    int wave, lane, cy, cc, nrow;
+    long prow;
+    // rows cy + 128 i of the 16-wide segment pair cc; rows >= nrow do not exist
+    __device__ __forceinline__ void gload(double (&v)[2 * G::NI], const double *__restrict__ src) const
+    {
+#pragma unroll
+        for (int i = 0; i < G::NI; i++) {
+            double2 t = make_double2(0.0, 0.0);
+            if (cy + 128 * i < nrow) t = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+            v[2 * i] = t.x;
+            v[2 * i + 1] = t.y;
+        }
+    }
+    __device__ __forceinline__ void to_tile(const double (&v)[2 * G::NI]) const
+    {
+#pragma unroll
+        for (int i = 0; i < G::NI; i++) {
+            if (cy + 128 * i < nrow) {
+                tile[(2 * cc) * G::TP + 4 + cy + 128 * i] = v[2 * i];
+                tile[(2 * cc + 1) * G::TP + 4 + cy + 128 * i] = v[2 * i + 1];
+            }
+        }
+    }
+    // this lane's window: rows first-4 .. first+Q+3 = tile entries lane Q .. lane Q + Q + 7 of the wave's pencil
+    __device__ __forceinline__ void window(double (&w)[Q + 8]) const
+    {
+        const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(tile + wave * G::TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < (Q + 8) / 2; m++) {
+            const double2 t = s2[m];
+            w[2 * m] = t.x;
+            w[2 * m + 1] = t.y;
+        }
+    }
+    __device__ __forceinline__ void put(const double (&r)[Q]) const
+    {
+        double2 *__restrict__ d2 = reinterpret_cast<double2 *>(tile + wave * G::TP + 4 + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) d2[m] = make_double2(r[2 * m], r[2 * m + 1]);
+    }
+    // rows < nout of the tile -> memory; ACC: out = old + r with the old rows already in registers (gload)
+    template <bool ACC>
+    __device__ __forceinline__ void from_tile(double *__restrict__ o, int nout, const double (&old)[2 * G::NI]) const
+    {
+#pragma unroll
+        for (int i = 0; i < G::NI; i++) {
+            if (cy + 128 * i < nout) {
+                double2 v = make_double2(tile[(2 * cc) * G::TP + 4 + cy + 128 * i], tile[(2 * cc + 1) * G::TP + 4 + cy + 128 * i]);
+                if (ACC) { v.x += old[2 * i]; v.y += old[2 * i + 1]; }
+                *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------- operator pairs / single operators
+//   MODE 0: out1 = A(in1) + B(in2)     MODE 1: out1 = A(in1), out2 = B(in1)     MODE 2: out1 = A(in1)
+// (the pairs of divergence_v2c / gradient_c2v, src/vector_calculus.f90:142-332, as in k_ytile_tds_pair)
+template <int Q, int MODE>
+__global__ void __launch_bounds__(1024)
+    k_ygen_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2, XOp ta, XOp tb,
+                int ntx, int ntiles, long prow, long pplane, int nrow)
+{
+    using G = GenGeom<Q>;
+    extern __shared__ double lt[];
+    constexpr int LN = LT_N(Q) * 64;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = ta.TL[i];
+        if (MODE != 2) lt[LN + i] = tb.TL[i];
+    }
+    double *tile = lt + (MODE == 2 ? 1 : 2) * LN;
+    double *cs = tile + 16 * G::TP;
+    for (int i = threadIdx.x; i < 16 * G::TP; i += blockDim.x) tile[i] = 0.0;
+    stage_cs<Q>(cs, ta);
+    if (MODE != 2) stage_cs<Q>(cs + CS_N(Q), tb);
+    int lane = threadIdx.x & 63;
+    GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x >> 3), (int)(threadIdx.x & 7),
+                 nrow, prow};
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    __syncthreads();
+    double nxt[2 * G::NI];  // next tile's in1 rows, in flight during the solves
+    if ((int)blockIdx.x < ntiles) T.gload(nxt, in1 + tile_off(blockIdx.x));
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        asm volatile("" : "+v"(lane));
+        double w[Q + 8], ra[Q], rb[Q], g2[2 * G::NI];
+        const double none[2 * G::NI] = {};
+        if (MODE == 0) T.gload(g2, in2 + off);
+        T.to_tile(nxt);
+        __syncthreads();
+        T.window(w);
+        if (MODE == 0) __syncthreads();  // all windows read: the second input may overwrite the tile
+        {
+            const int tn = tl + gridDim.x;
+            if (tn < ntiles) T.gload(nxt, in1 + tile_off(tn));
+        }
+        gen_solve<Q>(w, ra, lt, cs, ta, lane);
+        if (MODE == 0) {
+            T.to_tile(g2);
+            __syncthreads();
+            T.window(w);
+        }
+        if (MODE != 2) {
+            gen_solve<Q>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];  // (the accumulating form: old + 1.0 * r)
+            }
+        }
+        T.put(ra);  // (a wave only rewrites its own pencil's rows, which only it reads)
+        __syncthreads();
+        T.template from_tile<false>(out1 + off, ta.n_tds, none);
+        if (MODE == 1) {
+            __syncthreads();
+            T.put(rb);
+            __syncthreads();
+            T.template from_tile<false>(out2 + off, tb.n_tds, none);
+        }
+        __syncthreads();  // the tile is free again
+    }
+}
+
+// ---------------------------------------------------------------- transeq: the three components of a direction
+// component 0 = (u0, conv = u0), 1, 2 = (u1, u0), (u2, u0) (src/backend/omp/backend.f90:145-184); der1st and
+// der1st_sym, der2nd and der2nd_sym must be equal as lane tables (Dirichlet ends: they are) -- two table sets.
+template <int Q, bool ACC>
+__global__ void __launch_bounds__(1024)
+    k_ygen_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0, const double *__restrict__ u1,
+                    const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
+                    double nu)
+{
+    using G = GenGeom<Q>;
+    extern __shared__ double lt[];
+    constexpr int LN = LT_N(Q) * 64;
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+        lt[i] = tD1.TL[i];
+        lt[LN + i] = tD2.TL[i];
+    }
+    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    double *tile = lt + 2 * LN;
+    double *cs = tile + 16 * G::TP;
+    for (int i = threadIdx.x; i < 16 * G::TP; i += blockDim.x) tile[i] = 0.0;
+    stage_cs<Q>(cs, tD1);
+    stage_cs<Q>(cs + CS_N(Q), tD2);
+    int lane = threadIdx.x & 63;
+    GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x >> 3), (int)(threadIdx.x & 7),
+                 nrow, prow};
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    __syncthreads();
+    double nxt[2 * G::NI];  // the rows needed next (next component's field, or the next tile's u0)
+    if ((int)blockIdx.x < ntiles) T.gload(nxt, u0 + tile_off(blockIdx.x));
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        double cb[Q];  // this pencil's rows of the advecting velocity
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            asm volatile("" : "+v"(lane));
+            double r[Q], X[Q];
+            T.to_tile(nxt);
+            __syncthreads();
+            {
+                const int tn = tl + gridDim.x;
+                const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
+                if (c < 2 || tn < ntiles) T.gload(nxt, nsrc);
+            }
+            // the rows this component is added to: requested now, used after the three solves (the memory system
+            // works during the arithmetic instead of after it)
+            double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+            double old[2 * G::NI] = {};
+            if (ACC) T.gload(old, o);
+            {
+                // d(u conv): the product window; the field's own window is read again from the tile afterwards
+                // (it stays there until the result is put back) instead of living through this solve
+                double wp[Q + 8], wc[Q + 8];
+                T.window(wp);
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) cb[q] = wp[4 + q];
+                }
+                window_from_body_zero<Q>(wc, cb);
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wc[m];
+                gen_solve<Q>(wp, X, l1, cs, tD1, lane);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = X[q];
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            {
+                double wu[Q + 8];
+                T.window(wu);
+                gen_solve<Q>(wu, X, l1, cs, tD1, lane);  // du
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, LT_STC(q)));
+            asm volatile("" : "+v"(lane) : "v"(r[0]));
+            {
+                double wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
+                T.window(wu);
+                gen_solve<Q>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] += nu * X[q];
+            T.put(r);  // (a wave only rewrites its own pencil's rows, which only it reads)
+            __syncthreads();
+            T.template from_tile<ACC>(o, tD1.n_tds, old);
+            __syncthreads();  // the tile is free again
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static bool gen_env_on()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *names[4] = {"X3D_NO_YGEN", "X3D_NO_YTILE", "X3D_NO_XSCAN", "X3D_NO_VIA_X"};
+        on = 1;
+        for (const char *nm : names) { const char *e = getenv(nm); if (e && e[0] == '1') on = 0; }
+    }
+    return on == 1;
+}
+static bool gen_ok(const x3d_backend *b, int dir, const x3d_tdsops *t, int Q)
+{
+    const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+    // (periodic-type operators need the periodic image / the neighbours' rows in the halo rows: K3y's business)
+    return t->tab.TL != nullptr && t->tab.Q == Q && (Q == 4 || Q == 6 || Q == 8) && n <= 64 * Q && t->tab.n_rhs <= n &&
+           b->nx % 16 == 0 && !t->periodic && !t->tab.bulk_only;
+}
+struct GenLaunch {
+    int ntx, ntiles, blocks, nrow;
+    long rstride, ostride;
+};
+static GenLaunch gen_launch(const x3d_backend *b, int dir)
+{
+    const long pxy = (long)b->nxp * b->nyp;
+    GenLaunch g;
+    g.ntx = b->nx / 16;
+    g.ntiles = g.ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    g.blocks = g.ntiles > 256 ? 256 : g.ntiles;
+    g.nrow = dir == X3D_DIR_Y ? b->ny : b->nz;
+    g.rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy;
+    g.ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    return g;
+}
+
+// operator pair (mode 0 / 1) or single operator (mode 2) along y or z; *done = false: not served here
+int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                  const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done)
+{
+    *done = false;
+    if (!gen_env_on() || dir == X3D_DIR_X) return 0;
+    const int Q = ta->tab.Q;
+    if (!gen_ok(b, dir, ta, Q) || (mode != 2 && !gen_ok(b, dir, tb, Q))) return 0;
+    const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    if (lds > 160 * 1024) return 0;
+    const GenLaunch g = gen_launch(b, dir);
+    const x3d_tdsops *tb_ = mode == 2 ? ta : tb;
+    ProfScope ps(b, X3D_K_TDS_FWD, dir);
+#define GO(Q_, M_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_>));                                                                \
+        hipLaunchKernelGGL((k_ygen_pair<Q_, M_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
+                           xop_of(ta), xop_of(tb_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow);             \
+    } while (0)
+#define GOM(Q_) do { if (mode == 0) GO(Q_, 0); else if (mode == 1) GO(Q_, 1); else GO(Q_, 2); } while (0)
+    if (Q == 8) GOM(8); else if (Q == 6) GOM(6); else GOM(4);
+#undef GOM
+#undef GO
+    X3D_HIP(hipGetLastError());
+    if (b->prof && mode != 2) { ProfScope ps2(b, X3D_K_TDS_FWD, dir); }  // two operators
+    *done = true;
+    return 0;
+}
+
+// transeq of direction y or z in one launch; f[0] is the advecting component
+int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+                      const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                      const x3d_tdsops *der2nd_sym, int acc, bool *done)
+{
+    *done = false;
+    if (!gen_env_on() || dir == X3D_DIR_X) return 0;
+    const int Q = der1st->tab.Q;
+    if (!gen_ok(b, dir, der1st, Q) || !gen_ok(b, dir, der1st_sym, Q) || !gen_ok(b, dir, der2nd, Q) ||
+        !gen_ok(b, dir, der2nd_sym, Q))
+        return 0;
+    if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
+    if (der1st->n_tds != der2nd->n_tds) return 0;
+    // (tl_hash covers the lane tables and the boundary / bulk stencils: tds.hip)
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    if (lds > 160 * 1024) return 0;
+    const GenLaunch g = gen_launch(b, dir);
+    {
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+#define GO(Q_, A_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_>));                                                            \
+        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
+                           f[1], f[2], xop_of(der1st), xop_of(der2nd), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
+    } while (0)
+#define GOA(Q_) do { if (acc) GO(Q_, true); else GO(Q_, false); } while (0)
+        if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else GOA(4);
+#undef GOA
+#undef GO
+    }
+    X3D_HIP(hipGetLastError());
+    b->n_tq3++;
+    if (b->prof) {
+        for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
+    }
+    *done = true;
+    return 0;
+}
