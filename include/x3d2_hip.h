@@ -116,15 +116,19 @@ int x3d_tds_penta_solve(x3d_backend *b, double *du, const double *u, const x3d_t
  * their own (bnd_send); after the exchange x3d_*_halo_fix adds what the received values contribute -- on the rows
  * where dist_sa / dist_sc are still above 2^-60 (the decay src/tdsops.f90:196-201 relies on for its 2 x 2
  * truncation).  Same linear system as the reference's.  Buffers (device):
- *   halo rows  [side 2][field nf][4][np]: side 0 = rows 1..4 (sent to pprev) / rows -3..0 (received from pprev),
+ *   halo rows  [side 2][field nf][4][hr]: side 0 = rows 1..4 (sent to pprev) / rows -3..0 (received from pprev),
  *                                         side 1 = rows n-3..n (to pnext) / n+1..n+4 (from pnext)
- *              (copy_into_buffers + sendrecv_fields, src/backend/omp/backend.f90:714-737, sendrecv.f90:10-36)
+ *              (copy_into_buffers + sendrecv_fields, src/backend/omp/backend.f90:714-737, sendrecv.f90:10-36);
+ *              hr = x3d_halo_row_size(dir).  y: a row is packed [nz][nx].  z: a row is one xy plane in the BLOCK's
+ *              own pitched layout, so rows 1..4 / n-3..n of a field are contiguous pieces of its block and can be
+ *              sent straight out of it -- x3d_pack_halos_multi is then only needed for y
  *   boundary   [side 2][nb][np]: send side 0 = du_1 (to pprev), 1 = du_n (to pnext); recv side 0 = pprev's du_n,
  *              1 = pnext's du_1 (exec_dist.f90:52-54, 163-168)
  * x3d_transeq_tile / x3d_tds_pair_tile with halo_recv == bnd_send == NULL are the local (periodic) forms over a
  * range of planes [other0, other0 + nother) (nother < 0: all), for overlapping an exchange with the remaining
  * planes.  *done == 0: pencils not served by the tile kernels, nothing was written. */
 int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2]); /* rows 1..out[0], n-out[1]+1..n get a correction */
+long x3d_halo_row_size(const x3d_backend *b, int dir);
 int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir);
 int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
                      const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,

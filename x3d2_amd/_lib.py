@@ -43,6 +43,7 @@ PROTOTYPES = {
     "x3d_tds_dist_fwd": (I, [VP, VP, VP, VP, VP, VP, VP, VP, I]),
     "x3d_tds_solve_pair": (I, [VP, I, I, VP, VP, VP, VP, VP, VP]),
     "x3d_tdsops_halo_rows": (I, [VP, c_int_p]),
+    "x3d_halo_row_size": (ctypes.c_long, [VP, I]),
     "x3d_pack_halos_multi": (I, [VP, VP, ctypes.POINTER(VP), I, I, I]),
     "x3d_transeq_tile": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, I, VP, VP, I, I, c_int_p]),
     "x3d_transeq_halo_fix": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP]),

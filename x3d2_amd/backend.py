@@ -245,9 +245,32 @@ class HipBackend:
         key = ("halo", direction, nf, nb, tag)
         if key not in self._halo:
             npn = self.lib.x3d_npencils(self.h, direction)
+            hrow = int(self.lib.x3d_halo_row_size(self.h, direction))
             z = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
-            self._halo[key] = (z(2 * nf * N_HALO * npn), z(2 * nf * N_HALO * npn), z(2 * nb * npn), z(2 * nb * npn))
+            # (z halos leave straight from the fields' blocks: no send buffer)
+            hs = z(0) if self._halo_direct(direction) else z(2 * nf * N_HALO * hrow)
+            self._halo[key] = (hs, z(2 * nf * N_HALO * hrow), z(2 * nb * npn), z(2 * nb * npn))
         return self._halo[key]
+
+    def _halo_direct(self, direction):
+        """a z halo row is one xy plane in the block's own layout (x3d_halo_row_size): rows 1..4 and n-3..n of a
+        field are contiguous pieces of its block and are sent from there (X3D_PACK_Z_HALOS=1: through the pack
+        kernel like y, for A/B runs)"""
+        return direction == DIR_Z and os.environ.get("X3D_PACK_Z_HALOS") != "1"
+
+    def _halo_exchange(self, direction, fields, n, hs, hr):
+        """start the exchange of the boundary rows 1..4 / n-3..n of `fields` with the two neighbours of the
+        direction; they arrive in hr[side][field][4][row]"""
+        nf = len(fields)
+        if not self._halo_direct(direction):
+            ptrs = (VP * nf)(*[f.ptr for f in fields])
+            _lib.check(self.lib.x3d_pack_halos_multi(self.h, hs.data_ptr(), ptrs, nf, n, direction))
+            return self.comm.isendrecv([self._halves(hs) + self._halves(hr)], *self._neighbours(direction))
+        hrow = int(self.lib.x3d_halo_row_size(self.h, direction))
+        m = N_HALO * hrow
+        pairs = [(f.data[:m], f.data[(n - N_HALO) * hrow:n * hrow], hr[i * m:(i + 1) * m],
+                  hr[(nf + i) * m:(nf + i + 1) * m]) for i, f in enumerate(fields)]
+        return self.comm.isendrecv(pairs, *self._neighbours(direction))
 
     @staticmethod
     def _halves(t):
@@ -282,10 +305,7 @@ class HipBackend:
     def transeq_halo_begin(self, direction, u, v, w):
         f = self._component_order(direction, u, v, w)
         hs, hr, _, _ = self._halo_buffers(direction, 3, 9, "tq")
-        n = self.mesh.get_n(direction, u.data_loc)
-        ptrs = (VP * 3)(*[x.ptr for x in f])
-        _lib.check(self.lib.x3d_pack_halos_multi(self.h, hs.data_ptr(), ptrs, 3, n, direction))
-        return self.comm.isendrecv([self._halves(hs) + self._halves(hr)], *self._neighbours(direction))
+        return self._halo_exchange(direction, f, self.mesh.get_n(direction, u.data_loc), hs, hr)
 
     def transeq_halo_main(self, direction, du, dv, dw, u, v, w, nu, dirps, accumulate, handle):
         _, hr, bs, br = self._halo_buffers(direction, 3, 9, "tq")
@@ -364,9 +384,7 @@ class HipBackend:
         mode, out1, out2, in1, in2, ta, tb = job
         nf, nb = self._job_sizes(job)
         hs, hr, _, _ = self._halo_buffers(direction, nf, nb, "job%d" % k)
-        ptrs = (VP * nf)(*[f.ptr for f in (in1, in2)[:nf]])
-        _lib.check(self.lib.x3d_pack_halos_multi(self.h, hs.data_ptr(), ptrs, nf, ta.n_tds, direction))
-        return self.comm.isendrecv([self._halves(hs) + self._halves(hr)], *self._neighbours(direction))
+        return self._halo_exchange(direction, (in1, in2)[:nf], ta.n_tds, hs, hr)
 
     def tds_halo_main(self, direction, job, k, handle):
         mode, out1, out2, in1, in2, ta, tb = job

@@ -151,10 +151,16 @@ PencilGeom x3d_geom(const x3d_backend *b, int dir);
 
 // decomposed direction through the tile kernels (xscan.hip, HALO forms)
 struct TileHalo {
-    const double *recv;  // halo rows [side 2][field nf][4][np] (side 0: rows -3..0 from prev, 1: n+1..n+4 from next)
+    const double *recv;  // halo rows [side 2][field nf][4][hnp] (side 0: rows -3..0 from prev, 1: n+1..n+4 from next)
     double *bsend;       // boundary values out [side 2][nb][np]: side 0 = du_1 (goes to prev), 1 = X_n (to next)
     int np, nf, nb;      // pencils of the direction, fields, operators per pencil
+    // a halo row is a plane of pencils: pencil (x, o) sits at o * hp + x.  y pencils: packed (hp = nx); z pencils:
+    // the block's own plane layout (hp = nxp, hnp = nxp * nyp) -- four halo rows are four consecutive xy planes of
+    // the neighbour's block and travel straight out of it, without a pack kernel
+    int hp;
+    long hnp;
 };
+void x3d_halo_layout(const x3d_backend *b, int dir, int *hp, long *hnp);
 
 
 

@@ -586,18 +586,35 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 // the same for nf fields at once, in the layout the HALO tile kernels read and ONE message per neighbour carries:
 // send[side][field][4][np], side 0 = rows 1..4 (to prev), side 1 = rows n-3..n (to next)
 struct PackFields { const double *f[3]; };
-__global__ void k_pack_halos_multi(double *__restrict__ send, PackFields pf, int nf, int n, PencilGeom g)
+// (hp, hnp: TileHalo's plane layout -- pencil p = (x, o) goes to o * hp + x of a plane of hnp entries)
+__global__ void k_pack_halos_multi(double *__restrict__ send, PackFields pf, int nf, int n, PencilGeom g, int hp, long hnp)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p);
+    const long hq = (long)(p / g.dim0) * hp + p % g.dim0;
     const int k = blockIdx.y;  // field
     const double *__restrict__ u = pf.f[k];
 #pragma unroll
     for (int r = 0; r < X3D_NH; r++) {
-        send[((long)k * X3D_NH + r) * g.np + p] = u[base + (long)r * g.rs];
-        send[((long)(nf + k) * X3D_NH + r) * g.np + p] = u[base + (long)(n - X3D_NH + r) * g.rs];
+        send[((long)k * X3D_NH + r) * hnp + hq] = u[base + (long)r * g.rs];
+        send[((long)(nf + k) * X3D_NH + r) * hnp + hq] = u[base + (long)(n - X3D_NH + r) * g.rs];
     }
+}
+
+void x3d_halo_layout(const x3d_backend *b, int dir, int *hp, long *hnp)
+{
+    if (dir == X3D_DIR_Z) { *hp = b->nxp; *hnp = (long)b->nxp * b->nyp; }
+    else { *hp = b->nx; *hnp = (long)x3d_geom(b, dir).np; }
+}
+// entries of one halo row of direction dir (y or z) in the tile kernels' halo buffers [side 2][nf][4][this]
+extern "C" long x3d_halo_row_size(const x3d_backend *b, int dir)
+{
+    if (!b || !x3d_dir_ok(dir)) return 0;
+    int hp;
+    long hnp;
+    x3d_halo_layout(b, dir, &hp, &hnp);
+    return hnp;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1050,7 +1067,10 @@ extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *
     PackFields pf{};
     for (int k = 0; k < nf; k++) { X3D_REQUIRE(fields[k], "x3d_pack_halos_multi: null field"); pf.f[k] = fields[k]; }
     ProfScope ps(b, X3D_K_PACK, dir);
-    hipLaunchKernelGGL(k_pack_halos_multi, dim3((g.np + 255) / 256, nf), dim3(256), 0, b->stream, send, pf, nf, n, g);
+    int hp;
+    long hnp;
+    x3d_halo_layout(b, dir, &hp, &hnp);
+    hipLaunchKernelGGL(k_pack_halos_multi, dim3((g.np + 255) / 256, nf), dim3(256), 0, b->stream, send, pf, nf, n, g, hp, hnp);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -1081,7 +1101,8 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv,
     if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; f[0] = v; f[1] = u; f[2] = w; }
     else { r[0] = dw; r[1] = du; r[2] = dv; f[0] = w; f[1] = u; f[2] = v; }
     for (int c = 0; c < 3; c++) X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_tile: outputs alias inputs");
-    const TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, 3, 9};
+    TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, 3, 9, 0, 0};
+    x3d_halo_layout(b, dir, &th.hp, &th.hnp);
     bool ok = false;
     if (int rc = x3d_ytile_transeq3(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, accumulate,
                                     halo_recv ? &th : nullptr, other0, nother, &ok))
@@ -1123,7 +1144,8 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1
     if (mode == 2) tb = ta;
     if (int rc = check_len(b, ta, dir, "tds_pair_tile")) return rc;
     if (int rc = check_len(b, tb, dir, "tds_pair_tile")) return rc;
-    const TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, mode == 0 ? 2 : 1, mode == 2 ? 1 : 2};
+    TileHalo th{halo_recv, bnd_send, x3d_geom(b, dir).np, mode == 0 ? 2 : 1, mode == 2 ? 1 : 2, 0, 0};
+    x3d_halo_layout(b, dir, &th.hp, &th.hnp);
     bool ok = false;
     if (int rc = x3d_ytile_tds_pair(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv ? &th : nullptr, other0,
                                     nother, &ok))

@@ -916,8 +916,8 @@ __global__ void __launch_bounds__(1024)
     // HALO: thread t < 128 carries halo value (pencil t >> 3, slot t & 7: 0..3 start side, 4..7 end side) of field f
     auto hload = [&](int tl, int f) {
         const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
-        const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;  // pencil = x + nx * other
-        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.np + pp];
+        const long pp = (long)(tl / ntx) * th.hp + (long)(tl % ntx) * 16 + hw;  // pencil (x, other) of a halo plane
+        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.hnp + pp];
     };
     __syncthreads();
     double2 nxt[NI];  // the rows needed next (next component's field, or the next tile's u0), in flight during the solves
@@ -1137,8 +1137,8 @@ __global__ void __launch_bounds__(1024)
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
     auto hload = [&](int tl, int f) {  // thread t < 128: halo value (pencil t >> 3, slot t & 7) of input f
         const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
-        const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;
-        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.np + pp];
+        const long pp = (long)(tl / ntx) * th.hp + (long)(tl % ntx) * 16 + hw;
+        return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.hnp + pp];
     };
     __syncthreads();
     double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
@@ -1557,7 +1557,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;
-    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
+    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_, H_)                                                                                      \
     do {                                                                                                        \
@@ -1633,7 +1633,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     const int blocks = ntiles > 256 ? 256 : ntiles;
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
-    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0};
+    const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
 #define GO(Q_, A_, N_, H_)                                                                                      \
     do {                                                                                                        \
