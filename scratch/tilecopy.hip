@@ -4,20 +4,39 @@
 //   hipcc -O2 --offload-arch=gfx950 scratch/tilecopy.hip -o scratch/tilecopy
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <int NPEN>
-__global__ void __launch_bounds__(NPEN * 64) k(const double *__restrict__ a, double *__restrict__ b, int ntx, int ntiles,
+template <int NPEN, int NT = NPEN * 64>
+__global__ void __launch_bounds__(NT) k(const double *__restrict__ a, double *__restrict__ b, int ntx, int ntiles,
                                                long prow, long pplane)
 {
     constexpr int CPR = NPEN / 2;              // double2 per row segment
-    constexpr int RPI = NPEN * 64 / CPR;       // rows per load instruction (= 128)
+    constexpr int RPI = NT / CPR;              // rows per load instruction
+    constexpr int NL = 512 / RPI;
     const int cc = threadIdx.x % CPR, cy = threadIdx.x / CPR;
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * NPEN;
-        double2 v[4];
+        double2 v[NL];
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2 *>(a + off + (long)(cy + RPI * i) * prow + 2 * cc);
+        for (int i = 0; i < NL; i++) v[i] = *reinterpret_cast<const double2 *>(a + off + (long)(cy + RPI * i) * prow + 2 * cc);
 #pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<double2 *>(b + off + (long)(cy + RPI * i) * prow + 2 * cc) = v[i];
+        for (int i = 0; i < NL; i++) *reinterpret_cast<double2 *>(b + off + (long)(cy + RPI * i) * prow + 2 * cc) = v[i];
+    }
+}
+// the accumulating pattern of the transeq tile kernels: c (+)= a, tile by tile (R a, R c, W c = 3 streams)
+template <int NPEN, int NT = NPEN * 64>
+__global__ void __launch_bounds__(NT) kacc(const double *__restrict__ a, double *c, int ntx, int ntiles, long prow, long pplane)
+{
+    constexpr int CPR = NPEN / 2, RPI = NT / CPR, NL = 512 / RPI;
+    const int cc = threadIdx.x % CPR, cy = threadIdx.x / CPR;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * NPEN;
+        double2 v[NL], w[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) v[i] = *reinterpret_cast<const double2 *>(a + off + (long)(cy + RPI * i) * prow + 2 * cc);
+#pragma unroll
+        for (int i = 0; i < NL; i++) w[i] = *reinterpret_cast<const double2 *>(c + off + (long)(cy + RPI * i) * prow + 2 * cc);
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+            *reinterpret_cast<double2 *>(c + off + (long)(cy + RPI * i) * prow + 2 * cc) = make_double2(v[i].x + w[i].x, v[i].y + w[i].y);
     }
 }
 int main()
@@ -44,5 +63,21 @@ int main()
     run("z, 16 pencils (128 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL(k<16>, dim3(256), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * ny, pxy, (long)nxp); });
     run("z,  8 pencils ( 64 B), 512 WGs x  512", [&] { hipLaunchKernelGGL(k<8>, dim3(512), dim3(512), 0, 0, a, b, nx / 8, nx / 8 * ny, pxy, (long)nxp); });
     run("y, 16 pencils (128 B), 512 WGs x 1024", [&] { hipLaunchKernelGGL(k<16>, dim3(512), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * nz, (long)nxp, pxy); });
+    auto run3 = [&](const char *nm, auto f) {
+        for (int i = 0; i < 2; i++) f();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 10; i++) f();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        printf("%-44s %7.3f ms %8.1f GB/s\n", nm, ms, 3.0 * nx * ny * nz * 8 / ms * 1e-6);
+    };
+    run3("y acc, 16 pencils (128 B), 3 streams", [&] { hipLaunchKernelGGL((kacc<16>), dim3(256), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * nz, (long)nxp, pxy); });
+    run3("z acc, 16 pencils (128 B), 3 streams", [&] { hipLaunchKernelGGL((kacc<16>), dim3(256), dim3(1024), 0, 0, a, b, nx / 16, nx / 16 * ny, pxy, (long)nxp); });
+    run3("y acc, 32 pencils (256 B), 3 streams", [&] { hipLaunchKernelGGL((kacc<32, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 32, nx / 32 * nz, (long)nxp, pxy); });
+    run3("z acc, 32 pencils (256 B), 3 streams", [&] { hipLaunchKernelGGL((kacc<32, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 32, nx / 32 * ny, pxy, (long)nxp); });
+    run("y, 32 pencils (256 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL((k<32, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 32, nx / 32 * nz, (long)nxp, pxy); });
+    run("z, 32 pencils (256 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL((k<32, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 32, nx / 32 * ny, pxy, (long)nxp); });
+    run("y, 64 pencils (512 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL((k<64, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 64, nx / 64 * nz, (long)nxp, pxy); });
+    run("z, 64 pencils (512 B), 256 WGs x 1024", [&] { hipLaunchKernelGGL((k<64, 1024>), dim3(256), dim3(1024), 0, 0, a, b, nx / 64, nx / 64 * ny, pxy, (long)nxp); });
     return 0;
 }

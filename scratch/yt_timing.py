@@ -3,7 +3,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from x3d2_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "scratch", "exp", "lib_timing.so")
+_lib.LIB_PATH = os.environ.get("X3D_LIB", os.path.join(ROOT, "scratch", "exp", "lib_timing.so"))
 import torch
 from x3d2_amd import make_tgv
 from x3d2_amd.common import DIR_X, DIR_Y, DIR_Z
