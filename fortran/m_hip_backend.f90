@@ -1,9 +1,14 @@
 !> hip_backend_t: the reference-side shim of the MI355X backend.  Extends the
 !> reference's abstract types and forwards every operation to libx3d2_hip.so
 !> through m_x3d2_hip_capi; solver.f90, vector_calculus.f90, time_integrator.f90
-!> and the cases are used UNCHANGED.  Single MPI rank per device; directions
-!> decomposed across ranks need a GPU-aware MPI for the sendrecv of device
-!> buffers and are rejected here (the Python driver covers multi-GPU over RCCL).
+!> and the cases are used UNCHANGED.  One MPI rank per device.  Directions
+!> decomposed across ranks (nproc_dir = 1, py, pz) run the library's distributed
+!> entry points with the reference's own exchange pattern (sendrecv_fields,
+!> src/backend/omp/sendrecv.f90:10-36 / src/backend/cuda/sendrecv.f90:13-42)
+!> staged through host memory, since the MPI at hand is not GPU-aware; the
+!> all-periodic FFT Poisson solver runs on the library's pencil-decomposed
+!> stages with MPI_Alltoallv between them.  (The Python driver does the same
+!> over RCCL, device to device, with the exchanges overlapped.)
 !>
 !> Pattern followed: src/backend/cuda/{allocator,tdsops,backend,poisson_fft}.f90.
 module m_hip_common
@@ -127,6 +132,7 @@ end module m_hip_tdsops
 
 module m_hip_poisson_fft
   use iso_c_binding
+  use mpi
   use m_common, only: dp, CELL
   use m_field, only: field_t
   use m_mesh, only: mesh_t
@@ -137,6 +143,12 @@ module m_hip_poisson_fft
   implicit none
   type, extends(poisson_fft_t) :: hip_poisson_fft_t
     type(c_ptr) :: handle = c_null_ptr
+    ! more than one rank: pencil-decomposed stages (csrc/pfft.hip) + MPI_Alltoallv in the py / pz groups
+    logical :: multi = .false.
+    type(c_ptr) :: backend = c_null_ptr, pf = c_null_ptr, sbuf = c_null_ptr, rbuf = c_null_ptr
+    real(dp), allocatable :: sh(:), rh(:)
+    integer :: comm_y = 0, comm_z = 0
+    integer, allocatable :: cnt_xy_s(:), cnt_xy_r(:), cnt_yz_s(:), cnt_yz_r(:)
   contains
     procedure :: fft_forward => fft_forward_hip
     procedure :: fft_backward => fft_backward_hip
@@ -165,7 +177,10 @@ contains
     type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
     integer :: dims(3), nspec(3)
     real(dp), allocatable :: wre(:, :, :)
-    if (mesh%par%nproc > 1) error stop 'hip shim: FFT Poisson solver is single rank here'
+    if (mesh%par%nproc > 1) then
+      call hip_poisson_fft_setup_multi(self, backend, mesh, xdirps, ydirps, zdirps)
+      return
+    end if
     dims = mesh%get_global_dims(CELL)
     nspec = [dims(1)/2 + 1, dims(2), dims(3)]
     ! wave numbers and BC dispatch: the reference's own base_init (src/poisson_fft.f90:120-204)
@@ -188,18 +203,115 @@ contains
     end if
   end subroutine hip_poisson_fft_setup
 
+  subroutine hip_poisson_fft_setup_multi(self, backend, mesh, xdirps, ydirps, zdirps)
+    !! [1, py, pz] ranks: this rank's spectral block is (xs, ys, nz) at offsets (xoff, yoff, 0) -- the Z-pencil
+    !! of the 2decomp&FFT layout the reference's CPU backend uses (src/backend/omp/poisson_fft.f90:72-97); the
+    !! reference's own base_init / waves_set fill the wave numbers of exactly that block (sp_st offsets).
+    class(hip_poisson_fft_t), intent(inout) :: self
+    type(c_ptr), intent(in) :: backend
+    type(mesh_t), intent(in) :: mesh
+    type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
+    integer :: dims(3), py, pz, ry, rz, r, ierr, i, j, k
+    integer(c_long) :: sz(8)
+    integer :: xs, xoff, ys, yoff, yl, zl, nxs
+    real(dp), allocatable :: wt(:, :, :)
+    if (mesh%par%nproc_dir(1) /= 1) error stop 'hip shim: nproc_dir in x-dir must be 1'
+    dims = mesh%get_global_dims(CELL)
+    py = mesh%par%nproc_dir(2); pz = mesh%par%nproc_dir(3)
+    ry = mesh%par%nrank_dir(2); rz = mesh%par%nrank_dir(3)
+    self%multi = .true.
+    self%backend = backend
+    call x3d_check(x3d_pfft_create(backend, self%pf, int(dims, c_int), int(py, c_int), int(pz, c_int), &
+                                   int(ry, c_int), int(rz, c_int)))
+    call x3d_check(x3d_pfft_sizes(self%pf, sz))
+    xs = int(sz(1)); xoff = int(sz(2)); ys = int(sz(3)); yoff = int(sz(4))
+    yl = int(sz(5)); zl = int(sz(6)); nxs = int(sz(7))
+    call self%base_init(mesh, xdirps, ydirps, zdirps, [xs, ys, dims(3)], [xoff, yoff, 0])
+    if (.not. (self%periodic_x .and. self%periodic_y .and. self%periodic_z)) then
+      error stop 'hip shim: on several ranks only the all-periodic Poisson solver is available (as in the reference)'
+    end if
+    allocate (wt(dims(3), ys, xs))  ! the library wants this block z fastest
+    do i = 1, xs
+      do j = 1, ys
+        do k = 1, dims(3)
+          wt(k, j, i) = real(self%waves(i, j, k), dp)
+        end do
+      end do
+    end do
+    call x3d_check(x3d_pfft_set_waves(self%pf, wt, self%ax, self%bx, self%ay, self%by, self%az, self%bz))
+    call x3d_check(x3d_device_alloc(backend, self%sbuf, 2_c_long*sz(8)))
+    call x3d_check(x3d_device_alloc(backend, self%rbuf, 2_c_long*sz(8)))
+    allocate (self%sh(2*sz(8)), self%rh(2*sz(8)))
+    ! the py ranks that share this rank's z position, ordered by their y position, and vice versa
+    call MPI_Comm_split(MPI_COMM_WORLD, rz, ry, self%comm_y, ierr)
+    call MPI_Comm_split(MPI_COMM_WORLD, ry, rz, self%comm_z, ierr)
+    allocate (self%cnt_xy_s(py), self%cnt_xy_r(py), self%cnt_yz_s(pz), self%cnt_yz_r(pz))
+    do r = 0, py - 1  ! peer r owns share(nxs, py, r) of the x modes; doubles per complex number: 2
+      self%cnt_xy_s(r + 1) = 2*(nxs/py + merge(1, 0, r < mod(nxs, py)))*yl*zl
+      self%cnt_xy_r(r + 1) = 2*xs*yl*zl
+    end do
+    do r = 0, pz - 1
+      self%cnt_yz_s(r + 1) = 2*(dims(2)/pz + merge(1, 0, r < mod(dims(2), pz)))*xs*zl
+      self%cnt_yz_r(r + 1) = 2*ys*xs*zl
+    end do
+  end subroutine hip_poisson_fft_setup_multi
+
+  subroutine xchg(self, comm, scnt, rcnt)
+    !! packed buffers of the library, peer r's chunk contiguous: device -> host, MPI_Alltoallv, host -> device
+    class(hip_poisson_fft_t) :: self
+    integer, intent(in) :: comm, scnt(:), rcnt(:)
+    integer :: sdis(size(scnt)), rdis(size(rcnt)), r, ierr
+    sdis(1) = 0; rdis(1) = 0
+    do r = 2, size(scnt)
+      sdis(r) = sdis(r - 1) + scnt(r - 1)
+      rdis(r) = rdis(r - 1) + rcnt(r - 1)
+    end do
+    call x3d_check(x3d_copy_to_host(self%backend, self%sh, self%sbuf, int(sum(scnt), c_long)))
+    call MPI_Alltoallv(self%sh, scnt, sdis, MPI_DOUBLE_PRECISION, self%rh, rcnt, rdis, MPI_DOUBLE_PRECISION, &
+                       comm, ierr)
+    call x3d_check(x3d_copy_to_device(self%backend, self%rbuf, self%rh, int(sum(rcnt), c_long)))
+  end subroutine xchg
+
   subroutine fft_forward_hip(self, f_in)
     class(hip_poisson_fft_t) :: self
     class(field_t), intent(in) :: f_in
+    if (self%multi) then  ! x3d2_amd/poisson_fft.py, HipPencilPoissonFFT.fft_forward
+      call x3d_check(x3d_pfft_fwd_x(self%pf, dev(f_in)))
+      call x3d_check(x3d_pfft_pack_xy(self%pf, self%sbuf))
+      call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r)
+      call x3d_check(x3d_pfft_unpack_xy(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_fft_y(self%pf, 0_c_int))
+      call x3d_check(x3d_pfft_pack_yz(self%pf, self%sbuf))
+      call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r)
+      call x3d_check(x3d_pfft_unpack_yz(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_fft_z(self%pf, 0_c_int))
+      return
+    end if
     call x3d_check(x3d_poisson_fft_forward(self%handle, dev(f_in)))
   end subroutine
   subroutine fft_backward_hip(self, f_out)
     class(hip_poisson_fft_t) :: self
     class(field_t), intent(inout) :: f_out
+    if (self%multi) then
+      call x3d_check(x3d_pfft_fft_z(self%pf, 1_c_int))
+      call x3d_check(x3d_pfft_pack_zy(self%pf, self%sbuf))
+      call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s)
+      call x3d_check(x3d_pfft_unpack_zy(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_fft_y(self%pf, 1_c_int))
+      call x3d_check(x3d_pfft_pack_yx(self%pf, self%sbuf))
+      call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s)
+      call x3d_check(x3d_pfft_unpack_yx(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_bwd_x(self%pf, dev(f_out)))
+      return
+    end if
     call x3d_check(x3d_poisson_fft_backward(self%handle, dev(f_out)))
   end subroutine
   subroutine fft_postprocess_000_hip(self)
     class(hip_poisson_fft_t) :: self
+    if (self%multi) then
+      call x3d_check(x3d_pfft_postprocess_000(self%pf))
+      return
+    end if
     call x3d_check(x3d_poisson_postprocess_000(self%handle))
   end subroutine
   subroutine fft_postprocess_010_hip(self)
@@ -258,6 +370,11 @@ module m_hip_backend
 
   type, extends(base_backend_t) :: hip_backend_t
     type(c_ptr) :: handle = c_null_ptr
+    ! decomposed directions: device exchange buffers [rows][npencil] (send_s, send_e, recv_s, recv_e) for the
+    ! halo rows of up to three fields and for the boundary values of up to three operators, + host mirrors
+    type(c_ptr) :: xb(4, 4) = c_null_ptr
+    integer :: xb_n = 0
+    real(dp), allocatable :: hs(:), he(:), hrs(:), hre(:)
   contains
     procedure :: alloc_tdsops => alloc_hip_tdsops
     procedure :: transeq_x => transeq_x_hip
@@ -301,10 +418,47 @@ contains
     class default
       error stop 'hip_backend_t needs a hip_allocator_t'
     end select
-    if (any(mesh%par%nproc_dir /= 1)) then
-      error stop 'hip shim: one rank per run (use the Python driver for multi-GPU)'
-    end if
+    if (mesh%par%nproc_dir(1) /= 1) error stop 'hip shim: x stays undecomposed (as the FFT Poisson solver needs)'
   end function hip_backend_init
+
+  logical function decomposed(self, dir)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir
+    decomposed = self%mesh%par%nproc_dir(dir) > 1
+  end function decomposed
+
+  subroutine need_buffers(self)
+    !! the four exchange buffer sets, sized for 4 rows of the larger pencil cross-section (once)
+    class(hip_backend_t) :: self
+    integer :: i, k, n
+    if (self%xb_n > 0) return
+    n = 4*max(x3d_npencils(self%handle, int(DIR_Y, c_int)), x3d_npencils(self%handle, int(DIR_Z, c_int)))
+    do k = 1, 4
+      do i = 1, 4
+        call x3d_check(x3d_device_alloc(self%handle, self%xb(i, k), int(n, c_long)))
+      end do
+    end do
+    allocate (self%hs(n), self%he(n), self%hrs(n), self%hre(n))
+    self%xb_n = n
+  end subroutine need_buffers
+
+  subroutine sendrecv_set(self, dir, k, n)
+    !! sendrecv_fields (src/backend/omp/sendrecv.f90:10-36) for buffer set k, n doubles per buffer:
+    !! send_s -> pprev (arrives in its recv_e), send_e -> pnext (arrives in its recv_s); host staged
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir, k, n
+    integer :: prev, next, req(4), ierr
+    prev = self%mesh%par%pprev(dir); next = self%mesh%par%pnext(dir)
+    call x3d_check(x3d_copy_to_host(self%handle, self%hs, self%xb(1, k), int(n, c_long)))
+    call x3d_check(x3d_copy_to_host(self%handle, self%he, self%xb(2, k), int(n, c_long)))
+    call MPI_Irecv(self%hrs, n, MPI_X3D2_DP, prev, 2, MPI_COMM_WORLD, req(1), ierr)
+    call MPI_Irecv(self%hre, n, MPI_X3D2_DP, next, 1, MPI_COMM_WORLD, req(2), ierr)
+    call MPI_Isend(self%hs, n, MPI_X3D2_DP, prev, 1, MPI_COMM_WORLD, req(3), ierr)
+    call MPI_Isend(self%he, n, MPI_X3D2_DP, next, 2, MPI_COMM_WORLD, req(4), ierr)
+    call MPI_Waitall(4, req, MPI_STATUSES_IGNORE, ierr)
+    call x3d_check(x3d_copy_to_device(self%handle, self%xb(3, k), self%hrs, int(n, c_long)))
+    call x3d_check(x3d_copy_to_device(self%handle, self%xb(4, k), self%hre, int(n, c_long)))
+  end subroutine sendrecv_set
 
   function tds_handle(t) result(h)
     class(tdsops_t), intent(in) :: t
@@ -347,6 +501,13 @@ contains
     type(dirps_t), intent(in) :: dirps
     integer :: n
     n = self%mesh%get_n(u) ! error-stops on NULL_LOC like transeq_halo_exchange
+    if (decomposed(self, dir)) then
+      call transeq_dist(self, dir, du, dv, dw, u, v, w, nu, dirps, n)
+      call du%set_data_loc(u%data_loc)
+      call dv%set_data_loc(u%data_loc)
+      call dw%set_data_loc(u%data_loc)
+      return
+    end if
     call x3d_check(x3d_transeq(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), &
                                dev(w), real(nu, c_double), tds_handle(dirps%der1st), &
                                tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), &
@@ -355,6 +516,43 @@ contains
     call dv%set_data_loc(u%data_loc)
     call dw%set_data_loc(u%data_loc)
   end subroutine transeq_any
+
+  subroutine transeq_dist(self, dir, du, dv, dw, u, v, w, nu, dirps, n)
+    !! transeq_omp_dist (src/backend/omp/backend.f90:235-338): one halo exchange of the three fields, then per
+    !! component the forward sweeps, the exchange of the boundary values of its three operators, the
+    !! substitution; the advecting component first (:145-184)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir, n
+    class(field_t), intent(inout) :: du, dv, dw
+    class(field_t), intent(in) :: u, v, w
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    type(c_ptr) :: rhs(3), fld(3), t1, t2, t3
+    integer :: i, np
+    call need_buffers(self)
+    np = x3d_npencils(self%handle, int(dir, c_int))
+    if (dir == DIR_Y) then
+      rhs = [dev(dv), dev(du), dev(dw)]; fld = [dev(v), dev(u), dev(w)]
+    else
+      rhs = [dev(dw), dev(du), dev(dv)]; fld = [dev(w), dev(u), dev(v)]
+    end if
+    do i = 1, 3
+      call x3d_check(x3d_pack_halos(self%handle, self%xb(1, i), self%xb(2, i), fld(i), int(n, c_int), int(dir, c_int)))
+      call sendrecv_set(self, dir, i, 4*np)
+    end do
+    do i = 1, 3
+      if (i == 1) then
+        t1 = tds_handle(dirps%der1st); t2 = tds_handle(dirps%der1st_sym); t3 = tds_handle(dirps%der2nd)
+      else
+        t1 = tds_handle(dirps%der1st_sym); t2 = tds_handle(dirps%der1st); t3 = tds_handle(dirps%der2nd_sym)
+      end if
+      call x3d_check(x3d_transeq_dist_fwd(self%handle, int(dir, c_int), rhs(i), self%xb(1, 4), self%xb(2, 4), fld(i), &
+                                          self%xb(3, i), self%xb(4, i), fld(1), self%xb(3, 1), self%xb(4, 1), t1, t2, t3))
+      call sendrecv_set(self, dir, 4, 3*np)
+      call x3d_check(x3d_transeq_dist_bwd(self%handle, int(dir, c_int), rhs(i), self%xb(1, 4), self%xb(3, 4), &
+                                          self%xb(4, 4), fld(1), real(nu, c_double), t1, t2, t3))
+    end do
+  end subroutine transeq_dist
 
   subroutine transeq_x_hip(self, du, dv, dw, u, v, w, nu, dirps)
     class(hip_backend_t) :: self
@@ -389,8 +587,30 @@ contains
     type(dirps_t), intent(in) :: dirps
     logical, intent(in) :: sync
     integer :: n
-    ! single-rank shim (like transeq_any): periodic / boundary closures are local, `sync` has nothing to do
     n = self%mesh%get_n(spec)
+    if (decomposed(self, dirps%dir)) then  ! the halos of uvw are exchanged whatever `sync` says
+      call need_buffers(self)
+      block
+        integer :: np, d
+        type(c_ptr) :: t1, t2, t3
+        d = dirps%dir
+        np = x3d_npencils(self%handle, int(d, c_int))
+        t1 = tds_handle(dirps%der1st); t2 = tds_handle(dirps%der1st_sym); t3 = tds_handle(dirps%der2nd)
+        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 1), self%xb(2, 1), dev(spec), int(n, c_int), int(d, c_int)))
+        call sendrecv_set(self, d, 1, 4*np)
+        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 2), self%xb(2, 2), dev(uvw), int(n, c_int), int(d, c_int)))
+        call sendrecv_set(self, d, 2, 4*np)
+        call x3d_check(x3d_transeq_dist_fwd(self%handle, int(d, c_int), dev(dspec), self%xb(1, 4), self%xb(2, 4), &
+                                            dev(spec), self%xb(3, 1), self%xb(4, 1), dev(uvw), self%xb(3, 2), &
+                                            self%xb(4, 2), t1, t2, t3))
+        call sendrecv_set(self, d, 4, 3*np)
+        call x3d_check(x3d_transeq_dist_bwd(self%handle, int(d, c_int), dev(dspec), self%xb(1, 4), self%xb(3, 4), &
+                                            self%xb(4, 4), dev(uvw), real(nu, c_double), t1, t2, t3))
+      end block
+      call dspec%set_data_loc(spec%data_loc)
+      return
+    end if
+    ! local direction: periodic / boundary closures need no exchange
     call x3d_check(x3d_transeq_species(self%handle, int(dirps%dir, c_int), dev(dspec), dev(uvw), dev(spec), &
                                        real(nu, c_double), tds_handle(dirps%der1st), &
                                        tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), 0_c_int))
@@ -405,6 +625,23 @@ contains
     if (u%dir /= du%dir) error stop 'DIR mismatch between fields in tds_solve.'
     if (u%data_loc /= NULL_LOC) then
       call du%set_data_loc(move_data_loc(u%data_loc, u%dir, tdsops%move))
+    end if
+    if (decomposed(self, u%dir)) then
+      ! tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact (exec_dist.f90:16-65)
+      call need_buffers(self)
+      block
+        integer :: np
+        np = x3d_npencils(self%handle, int(u%dir, c_int))
+        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 1), self%xb(2, 1), dev(u), int(tdsops%n_tds, c_int), &
+                                      int(u%dir, c_int)))
+        call sendrecv_set(self, u%dir, 1, 4*np)
+        call x3d_check(x3d_tds_dist_fwd(self%handle, dev(du), self%xb(1, 4), self%xb(2, 4), dev(u), self%xb(3, 1), &
+                                        self%xb(4, 1), tds_handle(tdsops), int(u%dir, c_int)))
+        call sendrecv_set(self, u%dir, 4, np)
+        call x3d_check(x3d_tds_dist_bwd(self%handle, dev(du), self%xb(1, 4), self%xb(3, 4), self%xb(4, 4), &
+                                        tds_handle(tdsops), int(u%dir, c_int)))
+      end block
+      return
     end if
     call x3d_check(x3d_tds_solve(self%handle, dev(du), dev(u), tds_handle(tdsops), int(u%dir, c_int)))
   end subroutine tds_solve_hip

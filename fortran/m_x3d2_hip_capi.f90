@@ -89,6 +89,112 @@ module m_x3d2_hip_capi
       type(c_ptr), value :: b, du, du_send_s, du_recv_s, du_recv_e, t
       integer(c_int), value :: dir
     end function
+    integer(c_int) function x3d_transeq_dist_fwd(b, dir, rhs, send_s, send_e, u, u_recv_s, u_recv_e, conv, &
+                                                 conv_recv_s, conv_recv_e, t_du, t_dud, t_d2u) &
+      bind(C, name='x3d_transeq_dist_fwd')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, rhs, send_s, send_e, u, u_recv_s, u_recv_e, conv, conv_recv_s, conv_recv_e, &
+                            t_du, t_dud, t_d2u
+      integer(c_int), value :: dir
+    end function
+    integer(c_int) function x3d_transeq_dist_bwd(b, dir, rhs, send_s, recv_s, recv_e, conv, nu, t_du, t_dud, t_d2u) &
+      bind(C, name='x3d_transeq_dist_bwd')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, rhs, send_s, recv_s, recv_e, conv, t_du, t_dud, t_d2u
+      integer(c_int), value :: dir
+      real(c_double), value :: nu
+    end function
+    ! exchange buffers and host staging (an MPI that is not GPU-aware)
+    integer(c_int) function x3d_device_alloc(b, p, n) bind(C, name='x3d_device_alloc')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: p
+      integer(c_long), value :: n
+    end function
+    integer(c_int) function x3d_copy_to_host(b, host, dev, n) bind(C, name='x3d_copy_to_host')
+      import :: c_ptr, c_int, c_long, c_double
+      type(c_ptr), value :: b, dev
+      real(c_double), intent(out) :: host(*)
+      integer(c_long), value :: n
+    end function
+    integer(c_int) function x3d_copy_to_device(b, dev, host, n) bind(C, name='x3d_copy_to_device')
+      import :: c_ptr, c_int, c_long, c_double
+      type(c_ptr), value :: b, dev
+      real(c_double), intent(in) :: host(*)
+      integer(c_long), value :: n
+    end function
+    ! pencil-decomposed 000 Poisson solver: local stages (csrc/pfft.hip); the caller exchanges the packed buffers
+    integer(c_int) function x3d_pfft_create(b, p, nglob_cell, py, pz, ry, rz) bind(C, name='x3d_pfft_create')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: p
+      integer(c_int), intent(in) :: nglob_cell(3)
+      integer(c_int), value :: py, pz, ry, rz
+    end function
+    integer(c_int) function x3d_pfft_sizes(p, sizes) bind(C, name='x3d_pfft_sizes')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: p
+      integer(c_long), intent(out) :: sizes(8)
+    end function
+    integer(c_int) function x3d_pfft_set_waves(p, waves_re, ax, bx, ay, by, az, bz) bind(C, name='x3d_pfft_set_waves')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: p
+      real(c_double), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
+    end function
+    integer(c_int) function x3d_pfft_fwd_x(p, f_in) bind(C, name='x3d_pfft_fwd_x')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_in
+    end function
+    integer(c_int) function x3d_pfft_bwd_x(p, f_out) bind(C, name='x3d_pfft_bwd_x')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out
+    end function
+    integer(c_int) function x3d_pfft_fft_y(p, inverse) bind(C, name='x3d_pfft_fft_y')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+      integer(c_int), value :: inverse
+    end function
+    integer(c_int) function x3d_pfft_fft_z(p, inverse) bind(C, name='x3d_pfft_fft_z')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+      integer(c_int), value :: inverse
+    end function
+    integer(c_int) function x3d_pfft_pack_xy(p, buf) bind(C, name='x3d_pfft_pack_xy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_unpack_xy(p, buf) bind(C, name='x3d_pfft_unpack_xy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_pack_yx(p, buf) bind(C, name='x3d_pfft_pack_yx')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_unpack_yx(p, buf) bind(C, name='x3d_pfft_unpack_yx')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_pack_yz(p, buf) bind(C, name='x3d_pfft_pack_yz')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_unpack_yz(p, buf) bind(C, name='x3d_pfft_unpack_yz')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_pack_zy(p, buf) bind(C, name='x3d_pfft_pack_zy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_unpack_zy(p, buf) bind(C, name='x3d_pfft_unpack_zy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+    end function
+    integer(c_int) function x3d_pfft_postprocess_000(p) bind(C, name='x3d_pfft_postprocess_000')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+    end function
     ! transeq_species
     integer(c_int) function x3d_transeq_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, &
                                                 accumulate) bind(C, name='x3d_transeq_species')

@@ -68,6 +68,13 @@ int x3d_device_sync(x3d_backend *b);
 int x3d_block_alloc(x3d_backend *b, double **out);
 int x3d_block_free(x3d_backend *b, double *p);
 int x3d_block_fill(x3d_backend *b, double *f, double c); /* field_t%fill, src/field.f90:47-55 */
+/* exchange buffers (n doubles, zeroed) and host staging for callers whose MPI is not GPU-aware (the Fortran shim on
+ * several ranks: sendrecv_fields through host memory, cf. src/backend/cuda/sendrecv.f90:13-42).  The copies are
+ * ordered behind the kernels queued so far and complete on return. */
+int x3d_device_alloc(x3d_backend *b, double **out, long n);
+int x3d_device_free(x3d_backend *b, double *p);
+int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n);
+int x3d_copy_to_device(x3d_backend *b, double *dev, const double *host, long n);
 
 /* ---- alloc_tdsops (src/backend/backend.f90:352-372): device copy of the
  * arrays the host-side factory tdsops_init (src/tdsops.f90:63-203) produced.

@@ -171,6 +171,37 @@ extern "C" int x3d_block_free(x3d_backend *b, double *p)
     return 0;
 }
 
+// exchange buffers + host staging for callers whose MPI is not GPU-aware (the Fortran shim on more than one rank:
+// sendrecv_fields, src/backend/cuda/sendrecv.f90:13-42, through host memory)
+extern "C" int x3d_device_alloc(x3d_backend *b, double **out, long n)
+{
+    X3D_REQUIRE(b && out && n > 0, "x3d_device_alloc: bad argument");
+    X3D_HIP(hipMalloc(reinterpret_cast<void **>(out), sizeof(double) * (size_t)n));
+    X3D_HIP(hipMemsetAsync(*out, 0, sizeof(double) * (size_t)n, b->stream));
+    return 0;
+}
+extern "C" int x3d_device_free(x3d_backend *b, double *p)
+{
+    (void)b;
+    X3D_HIP(hipFree(p));
+    return 0;
+}
+// ordered behind the kernels queued on the backend's stream; returns when the copy is complete
+extern "C" int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n)
+{
+    X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_host: bad argument");
+    X3D_HIP(hipMemcpyAsync(host, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+extern "C" int x3d_copy_to_device(x3d_backend *b, double *dev, const double *host, long n)
+{
+    X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_device: bad argument");
+    X3D_HIP(hipMemcpyAsync(dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+    X3D_HIP(hipStreamSynchronize(b->stream));  // (the host array may be reused at once)
+    return 0;
+}
+
 // ---------------------------------------------------------------- BLAS-1
 // Whole padded blocks, like the reference (src/backend/omp/backend.f90:545-557):
 // streaming, 16 B per lane, grid-stride over at most 2048 workgroups.
