@@ -133,7 +133,7 @@ end module m_hip_tdsops
 module m_hip_poisson_fft
   use iso_c_binding
   use mpi
-  use m_common, only: dp, CELL
+  use m_common, only: dp, CELL, VERT
   use m_field, only: field_t
   use m_mesh, only: mesh_t
   use m_poisson_fft, only: poisson_fft_t
@@ -144,6 +144,10 @@ module m_hip_poisson_fft
   type, extends(poisson_fft_t) :: hip_poisson_fft_t
     type(c_ptr) :: handle = c_null_ptr
     ! more than one rank: pencil-decomposed stages (csrc/pfft.hip) + MPI_Alltoallv in the py / pz groups
+    ! x non-periodic (100): the 010 machinery on the x <-> y transposed problem, as the reference's CUDA backend
+    ! does (src/backend/cuda/poisson_fft.f90:482-616, 781-820): a twin backend of the transposed dims + two blocks
+    logical :: is_100 = .false.
+    type(c_ptr) :: tb = c_null_ptr, t1 = c_null_ptr, t2 = c_null_ptr
     logical :: multi = .false.
     type(c_ptr) :: backend = c_null_ptr, pf = c_null_ptr, sbuf = c_null_ptr, rbuf = c_null_ptr
     real(dp), allocatable :: sh(:), rh(:)
@@ -154,16 +158,16 @@ module m_hip_poisson_fft
     procedure :: fft_backward => fft_backward_hip
     procedure :: fft_postprocess_000 => fft_postprocess_000_hip
     procedure :: fft_forward_010 => fft_forward_hip
-    procedure :: fft_forward_100 => fw_unsupported
+    procedure :: fft_forward_100 => fft_forward_100_hip
     procedure :: fft_forward_110 => fw_unsupported
     procedure :: fft_backward_010 => fft_backward_hip
-    procedure :: fft_backward_100 => bw_unsupported
+    procedure :: fft_backward_100 => fft_backward_100_hip
     procedure :: fft_backward_110 => bw_unsupported
     procedure :: fft_postprocess_010 => fft_postprocess_010_hip
-    procedure :: fft_postprocess_100 => pp_unsupported
+    procedure :: fft_postprocess_100 => fft_postprocess_010_hip
     procedure :: fft_postprocess_110 => pp_unsupported
-    procedure :: enforce_periodicity_x => fp_unsupported
-    procedure :: undo_periodicity_x => fp_unsupported
+    procedure :: enforce_periodicity_x => enforce_periodicity_x_hip
+    procedure :: undo_periodicity_x => undo_periodicity_x_hip
     procedure :: enforce_periodicity_y => enforce_periodicity_y_hip
     procedure :: undo_periodicity_y => undo_periodicity_y_hip
     procedure :: enforce_periodicity_xy => fp_unsupported
@@ -175,18 +179,34 @@ contains
     type(c_ptr), intent(in) :: backend
     type(mesh_t), intent(in) :: mesh
     type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
-    integer :: dims(3), nspec(3)
+    integer :: dims(3), nspec(3), vdims(3)
     real(dp), allocatable :: wre(:, :, :)
     if (mesh%par%nproc > 1) then
       call hip_poisson_fft_setup_multi(self, backend, mesh, xdirps, ydirps, zdirps)
       return
     end if
     dims = mesh%get_global_dims(CELL)
+    if ((.not. mesh%grid%periodic_BC(1)) .and. mesh%grid%periodic_BC(2) .and. mesh%grid%periodic_BC(3)) then
+      ! 100: base_init lays waves out as (y modes, x modes, z modes) (waves_set, src/poisson_fft.f90:735-779)
+      self%is_100 = .true.
+      self%backend = backend
+      nspec = [dims(2)/2 + 1, dims(1), dims(3)]
+      call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
+      vdims = mesh%get_dims(VERT)
+      call x3d_check(x3d_backend_create(self%tb, int([vdims(2), vdims(1), vdims(3)], c_int), 0_c_int, c_null_ptr))
+      call x3d_check(x3d_block_alloc(self%tb, self%t1))
+      call x3d_check(x3d_block_alloc(self%tb, self%t2))
+      allocate (wre(nspec(1), nspec(2), nspec(3)))
+      wre = real(self%waves, dp)
+      call x3d_check(x3d_poisson_create(self%tb, self%handle, int([dims(2), dims(1), dims(3)], c_int), wre, &
+                                        self%ay, self%by, self%ax, self%bx, self%az, self%bz))
+      return
+    end if
     nspec = [dims(1)/2 + 1, dims(2), dims(3)]
     ! wave numbers and BC dispatch: the reference's own base_init (src/poisson_fft.f90:120-204)
     call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
     if (.not. (self%periodic_x .and. self%periodic_z)) then
-      error stop 'hip shim: the 100 / 110 Poisson solvers are not available yet'
+      error stop 'hip shim: the 110 Poisson solver is not available yet'
     end if
     allocate (wre(nspec(1), nspec(2), nspec(3)))
     wre = real(self%waves, dp)
@@ -329,6 +349,34 @@ contains
     class(field_t), intent(inout) :: f_out
     class(field_t), intent(in) :: f_in
     call x3d_check(x3d_poisson_undo_periodicity_y(self%handle, dev(f_out), dev(f_in)))
+  end subroutine
+  ! ---- 100: poisson_100 (src/poisson_fft.f90:244-256) calls these five in this order; the transposed copies
+  ! of fft_forward_100 / fft_backward_100 are done where the data enters / leaves the twin backend
+  subroutine enforce_periodicity_x_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_transpose_xy(self%backend, self%tb, self%t1, dev(f_in), int(self%nx_glob, c_int), &
+                                    int(self%ny_glob, c_int), int(self%nz_glob, c_int)))
+    call x3d_check(x3d_poisson_enforce_periodicity_y(self%handle, self%t2, self%t1))
+  end subroutine
+  subroutine fft_forward_100_hip(self, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_fft_forward(self%handle, self%t2))
+  end subroutine
+  subroutine fft_backward_100_hip(self, f_out)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    call x3d_check(x3d_poisson_fft_backward(self%handle, self%t2))
+  end subroutine
+  subroutine undo_periodicity_x_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_undo_periodicity_y(self%handle, self%t1, self%t2))
+    call x3d_check(x3d_transpose_xy(self%tb, self%backend, dev(f_out), self%t1, int(self%ny_glob, c_int), &
+                                    int(self%nx_glob, c_int), int(self%nz_glob, c_int)))
   end subroutine
   subroutine fw_unsupported(self, f_in)
     class(hip_poisson_fft_t) :: self

@@ -104,6 +104,12 @@ module m_x3d2_hip_capi
       integer(c_int), value :: dir
       real(c_double), value :: nu
     end function
+    ! Poisson 100: copy between the block layouts of a backend and of its x <-> y transposed twin
+    integer(c_int) function x3d_transpose_xy(b_src, b_dst, dst, src, nx, ny, nz) bind(C, name='x3d_transpose_xy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b_src, b_dst, dst, src
+      integer(c_int), value :: nx, ny, nz
+    end function
     ! exchange buffers and host staging (an MPI that is not GPU-aware)
     integer(c_int) function x3d_device_alloc(b, p, n) bind(C, name='x3d_device_alloc')
       import :: c_ptr, c_int, c_long

@@ -335,6 +335,12 @@ int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double *a0, const 
 int x3d_poisson_postprocess_010(x3d_poisson *p);                  /* fft_postprocess_010    */
 int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_010          */
 /* test hook: download / upload the spectral workspace [nz][ny][nx/2+1] complex */
+/* Poisson 100 (x non-periodic, y and z periodic): the reference transposes x <-> y and runs the 010 solve on the
+ * transposed problem (fft_forward_100 / fft_postprocess_100 / fft_backward_100,
+ * src/backend/cuda/poisson_fft.f90:482-616, 781-820).  Here: a second backend of the transposed vertex dims on the
+ * same stream, an x3d_poisson on it built from the swapped wave-number arrays, and this copy between the two
+ * layouts: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz (x2d2_amd/poisson_fft.py, HipPoissonFFT100). */
+int x3d_transpose_xy(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
 int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
 int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
 

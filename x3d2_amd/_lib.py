@@ -30,6 +30,7 @@ PROTOTYPES = {
     "x3d_device_sync": (I, [VP]),
     "x3d_block_alloc": (I, [VP, ctypes.POINTER(VP)]),
     "x3d_block_free": (I, [VP, VP]),
+    "x3d_transpose_xy": (I, [VP, VP, VP, VP, I, I, I]),
     "x3d_device_alloc": (I, [VP, ctypes.POINTER(VP), ctypes.c_long]),
     "x3d_device_free": (I, [VP, VP]),
     "x3d_copy_to_host": (I, [VP, VP, VP, ctypes.c_long]),

@@ -202,6 +202,36 @@ extern "C" int x3d_copy_to_device(x3d_backend *b, double *dev, const double *hos
     return 0;
 }
 
+// ---------------------------------------------------------------- x <-> y transposed copy between two block layouts
+// Poisson 100 (x non-periodic): the reference transposes x <-> y and runs its 010 machinery on the transposed
+// problem (memcpy3D_with_transpose / _back, src/backend/cuda/kernels/spectral_processing.f90:30-76, called by
+// fft_forward_100 / fft_backward_100, src/backend/cuda/poisson_fft.f90:482-616).  dst belongs to a backend of
+// the transposed dims: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz; 32 x 32 tiles through LDS.
+__global__ void __launch_bounds__(256) k_transpose_xy(double *__restrict__ dst, const double *__restrict__ src, int nx,
+                                                      int ny, long sp_row, long sp_plane, long dp_row, long dp_plane)
+{
+    __shared__ double t[32][33];
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32, z = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (x0 + tx < nx && y0 + r < ny) t[r][tx] = src[(long)z * sp_plane + (long)(y0 + r) * sp_row + x0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (y0 + tx < ny && x0 + r < nx) dst[(long)z * dp_plane + (long)(x0 + r) * dp_row + y0 + tx] = t[tx][r];
+}
+extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny, int nz)
+{
+    X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_xy: null argument");
+    X3D_REQUIRE(nx <= bs->nxp && ny <= bs->nyp && nz <= bs->nzp && ny <= bd->nxp && nx <= bd->nyp && nz <= bd->nzp,
+                "x3d_transpose_xy: dims exceed the blocks");
+    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_xy: the two backends must share a stream");
+    ProfScope ps(bs, X3D_K_COPY);
+    hipLaunchKernelGGL(k_transpose_xy, dim3((nx + 31) / 32, (ny + 31) / 32, nz), dim3(256), 0, bs->stream, dst, src, nx, ny,
+                       (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp, (long)bd->nxp * bd->nyp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------- BLAS-1
 // Whole padded blocks, like the reference (src/backend/omp/backend.f90:545-557):
 // streaming, 16 B per lane, grid-stride over at most 2048 workgroups.

@@ -163,6 +163,9 @@ def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
         if slab_ok and force != "1":
             return HipSlabPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
         return HipPencilPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
+    per = tuple(bool(x) for x in mesh.periodic_BC)
+    if per == (False, True, True):
+        return HipPoissonFFT100(backend, mesh, xdirps, ydirps, zdirps)
     return HipPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
 
 
@@ -183,8 +186,14 @@ class HipPoissonFFT:
             if mesh.nproc > 1:
                 raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
             self.case = "010"
+        elif (not self.periodic_x) and self.periodic_y and self.periodic_z:
+            if mesh.nproc > 1:
+                raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
+            if type(self) is HipPoissonFFT:
+                raise X3dError("Poisson 100: use make_poisson_fft (HipPoissonFFT100)")
+            self.case = "100"
         elif self.periodic_z:
-            raise X3dError("HIP Poisson solver: the 100 / 110 cases are not implemented")
+            raise X3dError("HIP Poisson solver: the 110 case is not implemented")
         else:
             raise X3dError("Requested BCs are not supported in FFT-based Poisson solver!")
         self.nx_spec, self.ny_spec, self.nz_spec = self.nx_glob // 2 + 1, self.ny_glob, self.nz_glob
@@ -242,6 +251,8 @@ class HipPoissonFFT:
                       + t.d * np.cos(r * 3.5))
             return tt / (1.0 + 2 * t.alpha * np.cos(r))
 
+        self._t1d_full = (transfer(xd.interpl_v2p, exs, mesh.d[0]), transfer(yd.interpl_v2p, eys, mesh.d[1]),
+                          transfer(zd.interpl_v2p, ezs, mesh.d[2]), k2x, k2y, k2z)
         self._t1d = (transfer(xd.interpl_v2p, exs[:self.nx_spec], mesh.d[0]),
                      transfer(yd.interpl_v2p, eys, mesh.d[1]),
                      transfer(zd.interpl_v2p, ezs, mesh.d[2]),
@@ -314,6 +325,72 @@ class HipPoissonFFT:
         c = np.ascontiguousarray(c, dtype=np.complex128)
         _lib.check(self.backend.lib.x3d_poisson_set_spectral(
             self.h, c.view(np.float64).ctypes.data_as(_lib.c_double_p)))
+
+
+class HipPoissonFFT100(HipPoissonFFT):
+    """x non-periodic, y and z periodic.  The reference's poisson_100 (src/poisson_fft.f90:244-256) is its 010
+    solve on the x <-> y transposed problem: enforce_periodicity_x ; fft_forward_100 (transposed copy + R2C along
+    y) ; fft_postprocess_100 = process_spectral_010 with nx <-> ny, ax,bx <-> ay,by swapped and waves indexed
+    (y mode, x mode, z mode) (src/backend/cuda/poisson_fft.f90:482-616, 781-820; waves_set :735-779) ;
+    fft_backward_100 ; undo_periodicity_x.  Here literally: a second library backend of the transposed vertex
+    dims on the same stream, an x3d_poisson on it built from the swapped arrays, and x3d_transpose_xy between the
+    two block layouts (the even / odd interleave along x is the inner solver's enforce_periodicity_y)."""
+
+    def _create(self):
+        backend, mesh = self.backend, self.mesh
+        lib = backend.lib
+        if mesh.nproc > 1:
+            raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
+        nx, ny, nz = self.nx_glob, self.ny_glob, self.nz_glob
+        tb = VP()
+        vd = [int(v) for v in mesh.vert_dims]
+        _lib.check(lib.x3d_backend_create(ctypes.byref(tb), _lib.ints(vd[1], vd[0], vd[2]), backend.device.index,
+                                          VP(backend.stream.cuda_stream)))
+        self.tb = tb
+        self.t1, self.t2 = VP(), VP()
+        _lib.check(lib.x3d_block_alloc(tb, ctypes.byref(self.t1)))
+        _lib.check(lib.x3d_block_alloc(tb, ctypes.byref(self.t2)))
+        # waves'(y mode <= ny/2, x mode, z mode) as [z][x][y]: the 100 branch of waves_set
+        tx, ty, tz, kx2, ky2, kz2 = self._t1d_full
+        nys = ny // 2 + 1
+        TX, KX = tx[None, :, None], kx2[None, :, None]
+        TY, KY = ty[:nys][None, None, :], ky2[:nys][None, None, :]
+        TZ, KZ = tz[:, None, None], kz2[:, None, None]
+        self.waves100 = KX * (TY * TZ) ** 2 + KY * (TX * TZ) ** 2 + KZ * (TX * TY) ** 2
+        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in
+                      (self.waves100, self.ay, self.by, self.ax, self.bx, self.az, self.bz)]
+        h = VP()
+        _lib.check(lib.x3d_poisson_create(tb, ctypes.byref(h), _lib.ints(ny, nx, nz),
+                                          *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
+        self.h = h
+        self.poisson = self.poisson_100
+
+    def __del__(self):
+        try:
+            lib = self.backend.lib
+            lib.x3d_poisson_destroy(self.h)
+            lib.x3d_block_free(self.tb, self.t1)
+            lib.x3d_block_free(self.tb, self.t2)
+            lib.x3d_backend_destroy(self.tb)
+        except Exception:
+            pass
+
+    def poisson_100(self, f, temp):
+        lib, b = self.backend.lib, self.backend
+        nx, ny, nz = self.nx_glob, self.ny_glob, self.nz_glob
+        _lib.check(lib.x3d_transpose_xy(b.h, self.tb, self.t1, f.ptr, nx, ny, nz))
+        _lib.check(lib.x3d_poisson_enforce_periodicity_y(self.h, self.t2, self.t1))
+        _lib.check(lib.x3d_poisson_fft_forward(self.h, self.t2))
+        _lib.check(lib.x3d_poisson_postprocess_010(self.h))
+        _lib.check(lib.x3d_poisson_fft_backward(self.h, self.t2))
+        _lib.check(lib.x3d_poisson_undo_periodicity_y(self.h, self.t1, self.t2))
+        _lib.check(lib.x3d_transpose_xy(self.tb, b.h, f.ptr, self.t1, ny, nx, nz))
+
+    def _unsupported(self, *a):
+        raise X3dError("Poisson 100: only solve_poisson is provided (the hooks act on the transposed problem)")
+
+    fft_forward = fft_backward = fft_postprocess_000 = fft_postprocess_010 = _unsupported
+    enforce_periodicity_y = undo_periodicity_y = get_spectral = set_spectral = _unsupported
 
 
 class HipPencilPoissonFFT(HipPoissonFFT):
