@@ -159,19 +159,19 @@ module m_hip_poisson_fft
     procedure :: fft_postprocess_000 => fft_postprocess_000_hip
     procedure :: fft_forward_010 => fft_forward_hip
     procedure :: fft_forward_100 => fft_forward_100_hip
-    procedure :: fft_forward_110 => fw_unsupported
+    procedure :: fft_forward_110 => fft_forward_110_hip
     procedure :: fft_backward_010 => fft_backward_hip
     procedure :: fft_backward_100 => fft_backward_100_hip
-    procedure :: fft_backward_110 => bw_unsupported
+    procedure :: fft_backward_110 => fft_backward_110_hip
     procedure :: fft_postprocess_010 => fft_postprocess_010_hip
     procedure :: fft_postprocess_100 => fft_postprocess_010_hip
-    procedure :: fft_postprocess_110 => pp_unsupported
+    procedure :: fft_postprocess_110 => fft_postprocess_110_hip
     procedure :: enforce_periodicity_x => enforce_periodicity_x_hip
     procedure :: undo_periodicity_x => undo_periodicity_x_hip
     procedure :: enforce_periodicity_y => enforce_periodicity_y_hip
     procedure :: undo_periodicity_y => undo_periodicity_y_hip
-    procedure :: enforce_periodicity_xy => fp_unsupported
-    procedure :: undo_periodicity_xy => fp_unsupported
+    procedure :: enforce_periodicity_xy => enforce_periodicity_xy_hip
+    procedure :: undo_periodicity_xy => undo_periodicity_xy_hip
   end type hip_poisson_fft_t
 contains
   subroutine hip_poisson_fft_setup(self, backend, mesh, xdirps, ydirps, zdirps)
@@ -202,12 +202,26 @@ contains
                                         self%ay, self%by, self%ax, self%bx, self%az, self%bz))
       return
     end if
+    if ((.not. mesh%grid%periodic_BC(1)) .and. (.not. mesh%grid%periodic_BC(2)) .and. mesh%grid%periodic_BC(3)) then
+      ! 110: base_init lays waves out as (z modes, x modes, y modes) (waves_set, src/poisson_fft.f90:690-733); the
+      ! twin backend has vertex dims (nz, nx, ny)
+      self%is_100 = .true.  ! (a twin backend is in use)
+      self%backend = backend
+      nspec = [dims(3)/2 + 1, dims(1), dims(2)]
+      call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
+      vdims = mesh%get_dims(VERT)
+      call x3d_check(x3d_backend_create(self%tb, int([vdims(3), vdims(1), vdims(2)], c_int), 0_c_int, c_null_ptr))
+      call x3d_check(x3d_block_alloc(self%tb, self%t1))
+      call x3d_check(x3d_block_alloc(self%tb, self%t2))
+      allocate (wre(nspec(1), nspec(2), nspec(3)))
+      wre = real(self%waves, dp)
+      call x3d_check(x3d_poisson_create(self%tb, self%handle, int([dims(3), dims(1), dims(2)], c_int), wre, &
+                                        self%az, self%bz, self%ax, self%bx, self%ay, self%by))
+      return
+    end if
     nspec = [dims(1)/2 + 1, dims(2), dims(3)]
     ! wave numbers and BC dispatch: the reference's own base_init (src/poisson_fft.f90:120-204)
     call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
-    if (.not. (self%periodic_x .and. self%periodic_z)) then
-      error stop 'hip shim: the 110 Poisson solver is not available yet'
-    end if
     allocate (wre(nspec(1), nspec(2), nspec(3)))
     wre = real(self%waves, dp)
     call x3d_check(x3d_poisson_create(backend, self%handle, int(dims, c_int), wre, self%ax, self%bx, &
@@ -377,6 +391,39 @@ contains
     call x3d_check(x3d_poisson_undo_periodicity_y(self%handle, self%t1, self%t2))
     call x3d_check(x3d_transpose_xy(self%tb, self%backend, dev(f_out), self%t1, int(self%ny_glob, c_int), &
                                     int(self%nx_glob, c_int), int(self%nz_glob, c_int)))
+  end subroutine
+  ! ---- 110: poisson_110 (src/poisson_fft.f90:258-273)
+  subroutine enforce_periodicity_xy_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_transpose_xyz_zxy(self%backend, self%tb, self%t1, dev(f_in), int(self%nx_glob, c_int), &
+                                         int(self%ny_glob, c_int), int(self%nz_glob, c_int)))
+    call x3d_check(x3d_poisson_enforce_periodicity_y(self%handle, self%t2, self%t1))  ! along x
+    call x3d_check(x3d_poisson_enforce_periodicity_z(self%handle, self%t1, self%t2))  ! along y
+  end subroutine
+  subroutine fft_forward_110_hip(self, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_fft_forward(self%handle, self%t1))
+  end subroutine
+  subroutine fft_postprocess_110_hip(self)
+    class(hip_poisson_fft_t) :: self
+    call x3d_check(x3d_poisson_postprocess_011(self%handle))
+  end subroutine
+  subroutine fft_backward_110_hip(self, f_out)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    call x3d_check(x3d_poisson_fft_backward(self%handle, self%t1))
+  end subroutine
+  subroutine undo_periodicity_xy_hip(self, f_out, f_in)
+    class(hip_poisson_fft_t) :: self
+    class(field_t), intent(inout) :: f_out
+    class(field_t), intent(in) :: f_in
+    call x3d_check(x3d_poisson_undo_periodicity_z(self%handle, self%t2, self%t1))
+    call x3d_check(x3d_poisson_undo_periodicity_y(self%handle, self%t1, self%t2))
+    call x3d_check(x3d_transpose_zxy_xyz(self%tb, self%backend, dev(f_out), self%t1, int(self%nx_glob, c_int), &
+                                         int(self%ny_glob, c_int), int(self%nz_glob, c_int)))
   end subroutine
   subroutine fw_unsupported(self, f_in)
     class(hip_poisson_fft_t) :: self

@@ -110,6 +110,33 @@ module m_x3d2_hip_capi
       type(c_ptr), value :: b_src, b_dst, dst, src
       integer(c_int), value :: nx, ny, nz
     end function
+    ! Poisson 110: z-first twin problem
+    integer(c_int) function x3d_transpose_xyz_zxy(b_src, b_dst, dst, src, nx, ny, nz) &
+      bind(C, name='x3d_transpose_xyz_zxy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b_src, b_dst, dst, src
+      integer(c_int), value :: nx, ny, nz
+    end function
+    integer(c_int) function x3d_transpose_zxy_xyz(b_src, b_dst, dst, src, nx, ny, nz) &
+      bind(C, name='x3d_transpose_zxy_xyz')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b_src, b_dst, dst, src
+      integer(c_int), value :: nx, ny, nz
+    end function
+    integer(c_int) function x3d_poisson_enforce_periodicity_z(p, f_out, f_in) &
+      bind(C, name='x3d_poisson_enforce_periodicity_z')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out, f_in
+    end function
+    integer(c_int) function x3d_poisson_undo_periodicity_z(p, f_out, f_in) &
+      bind(C, name='x3d_poisson_undo_periodicity_z')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f_out, f_in
+    end function
+    integer(c_int) function x3d_poisson_postprocess_011(p) bind(C, name='x3d_poisson_postprocess_011')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+    end function
     ! exchange buffers and host staging (an MPI that is not GPU-aware)
     integer(c_int) function x3d_device_alloc(b, p, n) bind(C, name='x3d_device_alloc')
       import :: c_ptr, c_int, c_long

@@ -2,7 +2,8 @@
 !> tests/verification/test_poisson_bc.f90 (which instantiates the OpenMP or CUDA backend itself and so cannot be
 !> pointed at a third backend): f = product of cosines on the cell centres, solve, compare with the analytic
 !> solution up to a constant; tolerance 1e-11 on norm2(err)/N.
-!>   poisson_bc_hip <config>     config = 000 | 010 | 100   (sizes of that test: 128x64x32, 128x65x32, 129x64x32)
+!>   poisson_bc_hip <config>     config = 000 | 010 | 100 | 110
+!>                               (sizes of that test: 128x64x32, 128x65x32, 129x64x32, 129x257x64)
 !> n = 2 in every direction combination, n = 3 in the non-periodic direction (the test's n = 3 cases in periodic
 !> directions are its XFAILs).  Exit code 1 on failure.
 program poisson_bc_hip
@@ -41,8 +42,10 @@ program poisson_bc_hip
     BC_y = 'dirichlet'; dims_global(2) = 65
   case ('100')
     BC_x = 'dirichlet'; dims_global(1) = 129
+  case ('110')
+    BC_x = 'dirichlet'; BC_y = 'dirichlet'; dims_global = [129, 257, 64]
   case default
-    error stop 'poisson_bc_hip: config must be 000, 010 or 100'
+    error stop 'poisson_bc_hip: config must be 000, 010, 100 or 110'
   end select
   per = [trim(BC_x(1)) == 'periodic', trim(BC_y(1)) == 'periodic', trim(BC_z(1)) == 'periodic']
 
@@ -67,6 +70,7 @@ program poisson_bc_hip
   do kind = 1, 2   ! n = 3 where the direction is not periodic
     if (.not. per(kind)) call one(3, kind)
   end do
+  if (.not. per(1) .and. .not. per(2)) call one(3, 3)
   if (nfail > 0) then
     print *, 'poisson_bc_hip ', trim(config), ': FAILED cases: ', nfail
     call MPI_Finalize(ierr)

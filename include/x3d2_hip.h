@@ -341,6 +341,17 @@ int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_0
  * same stream, an x3d_poisson on it built from the swapped wave-number arrays, and this copy between the two
  * layouts: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz (x2d2_amd/poisson_fft.py, HipPoissonFFT100). */
 int x3d_transpose_xy(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
+/* Poisson 110 (x and y non-periodic, z periodic): the reference moves z to the front (transposed copy to
+ * (nz, nx, ny), R2C along z), applies enforce_periodicity_xy before and seven spectral kernels in between
+ * (fft_forward_110 / fft_postprocess_110 / fft_backward_110, src/backend/cuda/poisson_fft.f90:401-480, 926-989).
+ * Here: a twin backend of vertex dims (nz, nx, ny) and an x3d_poisson on it whose x is the reference's z, y its x,
+ * z its y: transposed copies, the even / odd interleave along the twin's y (x3d_poisson_enforce_periodicity_y) and
+ * z (…_z), and x3d_poisson_postprocess_011 = the seven kernels in the twin's layout (HipPoissonFFT110). */
+int x3d_transpose_xyz_zxy(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
+int x3d_transpose_zxy_xyz(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
+int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in);
+int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in);
+int x3d_poisson_postprocess_011(x3d_poisson *p);
 int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
 int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
 

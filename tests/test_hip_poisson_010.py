@@ -177,7 +177,52 @@ def test_poisson_bc_100_acceptance(n_wave, kind):
     assert np.linalg.norm(err.ravel()) / err.size <= 1e-11
 
 
-@pytest.mark.parametrize("config", ["000", "010", "100"])
+def _solvers_110(dims, L):
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.solver import Solver, SolverConfig
+    mesh = Mesh(dims, (1, 1, 1), L, ("dirichlet",) * 2, ("dirichlet",) * 2, ("periodic",) * 2)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="FFT"))
+    om = orc.Mesh(list(dims), [1, 1, 1], list(L), ["dirichlet"] * 2, ["dirichlet"] * 2, ["periodic"] * 2)
+    return s, orc.Solver(om, poisson="FFT")
+
+
+@pytest.mark.parametrize("dims", [(33, 17, 8), (65, 129, 16), (34, 21, 12)])
+def test_poisson_110_solve_vs_oracle(dims):
+    """x and y non-periodic (poisson_110, src/poisson_fft.f90:258-273; CUDA-only in the reference): HipPoissonFFT110
+    (z-first twin problem, x3d_poisson_postprocess_011) against the oracle on a seeded right-hand side; even and odd
+    cell counts"""
+    s, o = _solvers_110(dims, (1.0, 2.0, 1.5))
+    assert s.backend.poisson_fft.case == "110"
+    rng = np.random.default_rng(13)
+    f = rng.standard_normal(tuple(int(n) for n in o.mesh.global_cell_dims)[::-1])
+    f -= f.mean()
+    assert relerr(hip_poisson_solve(s, f), o.poisson_fft.solve(f)) < 1e-10
+
+
+@pytest.mark.parametrize("n_wave,kind", [(2, "COS_X"), (2, "COS_Y"), (2, "COS_XY"), (2, "COS_XYZ"), (3, "COS_X"),
+                                         (3, "COS_Y"), (3, "COS_XY")])
+def test_poisson_bc_110_acceptance(n_wave, kind):
+    """tests/verification/test_poisson_bc.f90, config 110 at its own size 129 x 257 x 64, L = 1: the analytic
+    solution to 1e-11 for every case that test expects to pass"""
+    s, _ = _solvers_110((129, 257, 64), (1.0, 1.0, 1.0))
+    m = s.mesh
+    x = m.midp_coords[0][None, None, :]
+    y = m.midp_coords[1][None, :, None]
+    z = m.midp_coords[2][:, None, None]
+    k = n_wave * np.pi
+    one = np.ones((len(m.midp_coords[2]), len(m.midp_coords[1]), len(m.midp_coords[0])))
+    f, den = {"COS_X": (np.cos(k * x) * one, 1.0), "COS_Y": (np.cos(k * y) * one, 1.0),
+              "COS_XY": (np.cos(k * x) * np.cos(k * y) * one, 2.0),
+              "COS_XYZ": (np.cos(k * x) * np.cos(k * y) * np.cos(k * z) * one, 3.0)}[kind]
+    exact = -f / (den * k * k)
+    sol = hip_poisson_solve(s, f)
+    err = (sol - sol[0, 0, 0]) - (exact - exact[0, 0, 0])
+    assert np.linalg.norm(err.ravel()) / err.size <= 1e-11
+
+
+@pytest.mark.parametrize("config", ["000", "010", "100", "110"])
 def test_poisson_bc_acceptance_through_the_fortran_shim(config, tmp_path):
     """fortran/_build/poisson_bc_hip: the reference's mesh / tdsops / poisson_fft_t%base_init (waves_set incl. its
     100 branch) and solve_poisson drivers on hip_backend_t, with the cosine checks of its test_poisson_bc.f90

@@ -31,6 +31,11 @@ PROTOTYPES = {
     "x3d_block_alloc": (I, [VP, ctypes.POINTER(VP)]),
     "x3d_block_free": (I, [VP, VP]),
     "x3d_transpose_xy": (I, [VP, VP, VP, VP, I, I, I]),
+    "x3d_transpose_xyz_zxy": (I, [VP, VP, VP, VP, I, I, I]),
+    "x3d_transpose_zxy_xyz": (I, [VP, VP, VP, VP, I, I, I]),
+    "x3d_poisson_enforce_periodicity_z": (I, [VP, VP, VP]),
+    "x3d_poisson_undo_periodicity_z": (I, [VP, VP, VP]),
+    "x3d_poisson_postprocess_011": (I, [VP]),
     "x3d_device_alloc": (I, [VP, ctypes.POINTER(VP), ctypes.c_long]),
     "x3d_device_free": (I, [VP, VP]),
     "x3d_copy_to_host": (I, [VP, VP, VP, ctypes.c_long]),

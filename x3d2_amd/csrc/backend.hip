@@ -207,17 +207,27 @@ extern "C" int x3d_copy_to_device(x3d_backend *b, double *dev, const double *hos
 // problem (memcpy3D_with_transpose / _back, src/backend/cuda/kernels/spectral_processing.f90:30-76, called by
 // fft_forward_100 / fft_backward_100, src/backend/cuda/poisson_fft.f90:482-616).  dst belongs to a backend of
 // the transposed dims: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz; 32 x 32 tiles through LDS.
-__global__ void __launch_bounds__(256) k_transpose_xy(double *__restrict__ dst, const double *__restrict__ src, int nx,
-                                                      int ny, long sp_row, long sp_plane, long dp_row, long dp_plane)
+// dst[c][a][b] = src[c][b][a] in terms of strides: a is the fast axis of src, b the fast axis of dst, c a batch
+__global__ void __launch_bounds__(256) k_transpose_ab(double *__restrict__ dst, const double *__restrict__ src, int na,
+                                                      int nb, long s_b, long s_c, long d_a, long d_c)
 {
     __shared__ double t[32][33];
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32, z = blockIdx.z;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32, c = blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8)
-        if (x0 + tx < nx && y0 + r < ny) t[r][tx] = src[(long)z * sp_plane + (long)(y0 + r) * sp_row + x0 + tx];
+        if (a0 + tx < na && b0 + r < nb) t[r][tx] = src[(long)c * s_c + (long)(b0 + r) * s_b + a0 + tx];
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
-        if (y0 + tx < ny && x0 + r < nx) dst[(long)z * dp_plane + (long)(x0 + r) * dp_row + y0 + tx] = t[tx][r];
+        if (b0 + tx < nb && a0 + r < na) dst[(long)c * d_c + (long)(a0 + r) * d_a + b0 + tx] = t[tx][r];
+}
+static int transpose_launch(x3d_backend *bs, double *dst, const double *src, int na, int nb, int nc, long s_b, long s_c,
+                            long d_a, long d_c)
+{
+    ProfScope ps(bs, X3D_K_COPY);
+    hipLaunchKernelGGL(k_transpose_ab, dim3((na + 31) / 32, (nb + 31) / 32, nc), dim3(256), 0, bs->stream, dst, src, na, nb,
+                       s_b, s_c, d_a, d_c);
+    X3D_HIP(hipGetLastError());
+    return 0;
 }
 extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny, int nz)
 {
@@ -225,11 +235,34 @@ extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, c
     X3D_REQUIRE(nx <= bs->nxp && ny <= bs->nyp && nz <= bs->nzp && ny <= bd->nxp && nx <= bd->nyp && nz <= bd->nzp,
                 "x3d_transpose_xy: dims exceed the blocks");
     X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_xy: the two backends must share a stream");
-    ProfScope ps(bs, X3D_K_COPY);
-    hipLaunchKernelGGL(k_transpose_xy, dim3((nx + 31) / 32, (ny + 31) / 32, nz), dim3(256), 0, bs->stream, dst, src, nx, ny,
-                       (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp, (long)bd->nxp * bd->nyp);
-    X3D_HIP(hipGetLastError());
-    return 0;
+    return transpose_launch(bs, dst, src, nx, ny, nz, (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp,
+                            (long)bd->nxp * bd->nyp);
+}
+// Poisson 110: the reference moves z to the front (transpose_xyz_to_zxy / _zxy_to_xyz,
+// src/backend/cuda/kernels/spectral_processing.f90:78-125, called by fft_forward_110 / fft_backward_110) so that
+// the R2C runs along the periodic z: dst(z, x, y) = src(x, y, z); dst belongs to a backend of dims (nz, nx, ny)
+extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
+                                     int nz)
+{
+    X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_xyz_zxy: null argument");
+    X3D_REQUIRE(nx <= bs->nxp && ny <= bs->nyp && nz <= bs->nzp && nz <= bd->nxp && nx <= bd->nyp && ny <= bd->nzp,
+                "x3d_transpose_xyz_zxy: dims exceed the blocks");
+    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_xyz_zxy: the two backends must share a stream");
+    // a = x (fast in src), b = z (fast in dst), batch = y
+    return transpose_launch(bs, dst, src, nx, nz, ny, (long)bs->nxp * bs->nyp, (long)bs->nxp, (long)bd->nxp,
+                            (long)bd->nxp * bd->nyp);
+}
+// and back: dst(x, y, z) = src(z, x, y); src belongs to the backend of dims (nz, nx, ny)
+extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
+                                     int nz)
+{
+    X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_zxy_xyz: null argument");
+    X3D_REQUIRE(nx <= bd->nxp && ny <= bd->nyp && nz <= bd->nzp && nz <= bs->nxp && nx <= bs->nyp && ny <= bs->nzp,
+                "x3d_transpose_zxy_xyz: dims exceed the blocks");
+    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_zxy_xyz: the two backends must share a stream");
+    // a = z (fast in src), b = x (fast in dst), batch = y
+    return transpose_launch(bs, dst, src, nz, nx, ny, (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp * bd->nyp,
+                            (long)bd->nxp);
 }
 
 // ---------------------------------------------------------------- BLAS-1

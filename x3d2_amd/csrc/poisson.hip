@@ -341,7 +341,9 @@ __device__ __forceinline__ void rot_bw(double &r, double &c, const Rot &t)
 // MODE 0: fw only (normalise, z/x rotations, y split)            -> stretched path, step 1
 // MODE 1: bw only (y recombination, z/x inverse rotations)       -> stretched path, step 3
 // MODE 2: fw, -1/waves, bw fused (uniform y): 1R + 1W of c, 1R of waves
-template <int MODE>
+// ZROT = false (Poisson 110 on the z-first transposed problem): the third direction is not periodic either -- no
+// rotation along it here, it gets its own paired split (k_spectral_pair_z)
+template <int MODE, bool ZROT = true>
 __global__ void __launch_bounds__(256)
     k_spectral_010(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx,
                    const double *__restrict__ ax, const double *__restrict__ bx, const double *__restrict__ ay,
@@ -359,11 +361,13 @@ __global__ void __launch_bounds__(256)
     double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
     if (MODE != 1) {
         l_r = l_r / nx / ny / nz; l_c = l_c / nx / ny / nz;
-        rot_fw(l_r, l_c, rz); rot_fw(l_r, l_c, rx);
+        if (ZROT) rot_fw(l_r, l_c, rz);
+        rot_fw(l_r, l_c, rx);
         if (self) { r_r = l_r; r_c = l_c; }
         else if (paired) {
             r_r = r_r / nx / ny / nz; r_c = r_c / nx / ny / nz;
-            rot_fw(r_r, r_c, rz); rot_fw(r_r, r_c, rx);
+            if (ZROT) rot_fw(r_r, r_c, rz);
+            rot_fw(r_r, r_c, rx);
         }
         if (paired) {
             const double a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
@@ -399,11 +403,94 @@ __global__ void __launch_bounds__(256)
             l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
             if (self) { l_r = r_r; l_c = r_c; }
         }
-        rot_bw(l_r, l_c, rz); rot_bw(l_r, l_c, rx);
-        if (paired && !self) { rot_bw(r_r, r_c, rz); rot_bw(r_r, r_c, rx); }
+        if (ZROT) rot_bw(l_r, l_c, rz);
+        rot_bw(l_r, l_c, rx);
+        if (paired && !self) {
+            if (ZROT) rot_bw(r_r, r_c, rz);
+            rot_bw(r_r, r_c, rx);
+        }
     }
     c[il] = make_double2(l_r, l_c);
     if (paired && !self) c[ir] = make_double2(r_r, r_c);
+}
+
+// Poisson 110, the middle of fft_postprocess_110 (src/backend/cuda/poisson_fft.f90:926-989) in the layout of the
+// z-first transposed problem c[z'][y'][x'] (x' = z: R2C; y' = x, z' = y: both non-periodic): paired split along
+// z' (process_spectral_110_y_pair_fw), division by the wave numbers with the Nyquist line zeroed (_poisson),
+// recombination (_y_pair_bw) -- src/backend/cuda/kernels/spectral_processing.f90:803-931.  All three only couple
+// planes k and nz-k+2: one thread per (x' mode, y' index, plane pair).
+__global__ void __launch_bounds__(256)
+    k_spectral_pair_z(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx,
+                      const double *__restrict__ az, const double *__restrict__ bz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, k = blockIdx.z + 1;  // k = 1 .. nz/2+1
+    if (i >= nxs) return;
+    const int kr = nz - k + 2;
+    const bool paired = k >= 2, self = paired && kr == k;
+    const size_t il = ((size_t)(k - 1) * ny + j) * nxs + i;
+    const size_t ir = paired ? ((size_t)(kr - 1) * ny + j) * nxs + i : il;
+    const double2 L = c[il], R = paired && !self ? c[ir] : L;
+    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
+    const double a = az[k - 1], b = bz[k - 1], a2 = paired ? az[kr - 1] : 0.0, b2 = paired ? bz[kr - 1] : 0.0;
+    if (paired) {
+        const double n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
+        const double n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
+        const double n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
+        const double n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
+        l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
+        if (self) { l_r = r_r; l_c = r_c; }  // the second store wins on the self-paired plane
+    }
+    {
+        // (the reference zeroes the mode that is Nyquist in its x and z: here y' and x')
+        const bool zero_line = (j + 1) == ny / 2 + 1 && (i + 1) == nx / 2 + 1;
+        const double wl = waves[il];
+        l_r = fabs(wl) < 1.e-16 ? 0.0 : -l_r / wl;
+        l_c = fabs(wl) < 1.e-16 ? 0.0 : -l_c / wl;
+        if (zero_line) { l_r = 0.0; l_c = 0.0; }
+        if (paired) {
+            const double wr = waves[ir];
+            r_r = fabs(wr) < 1.e-16 ? 0.0 : -r_r / wr;
+            r_c = fabs(wr) < 1.e-16 ? 0.0 : -r_c / wr;
+            if (zero_line) { r_r = 0.0; r_c = 0.0; }
+        }
+    }
+    if (paired) {
+        if (self) { r_r = l_r; r_c = l_c; }
+        const double n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
+        const double n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
+        const double n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
+        const double n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
+        l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
+        if (self) { l_r = r_r; l_c = r_c; }
+    }
+    c[il] = make_double2(l_r, l_c);
+    if (paired && !self) c[ir] = make_double2(r_r, r_c);
+}
+
+// even/odd interleave along z on the pitched Cartesian block (the y part of enforce_periodicity_xy / undo_..., :1116-1196,
+// in the z-first transposed problem): out(i, j, k) = in(i, j, src(k))
+template <bool UNDO>
+__global__ void __launch_bounds__(256)
+    k_periodicity_z(double *__restrict__ out, const double *__restrict__ in, int nx, int ny, int nz, long nxp, long plane)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, k = blockIdx.z + 1;
+    if (i >= nx) return;
+    const int n2 = nz / 2;
+    int ks, kd;
+    if (!UNDO) {
+        kd = k;
+        if (k <= n2) ks = 2 * k - 1;
+        else if ((nz & 1) && k == n2 + 1) ks = nz;
+        else ks = 2 * nz - 2 * k + 2;
+    } else {
+        ks = k;
+        if (k <= n2) kd = 2 * k - 1;
+        else if ((nz & 1) && k == n2 + 1) kd = nz;
+        else kd = 2 * (nz - k + 1);
+    }
+    out[(long)(kd - 1) * plane + (long)j * nxp + i] = in[(long)(ks - 1) * plane + (long)j * nxp + i];
 }
 
 // Pentadiagonal operators: the reference eliminates the matrix in place at EVERY solve
@@ -524,6 +611,52 @@ extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, con
     ProfScope ps(b, X3D_K_COPY);
     hipLaunchKernelGGL(k_periodicity_y<true>, grid, dim3(256), 0, b->stream, f_out, f_in, p->nx, p->ny, p->nz,
                        (long)b->nxp, (long)b->nxp * b->nyp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
+{
+    X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_z: bad argument");
+    x3d_backend *b = p->b;
+    dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
+    ProfScope ps(b, X3D_K_COPY);
+    hipLaunchKernelGGL(k_periodicity_z<false>, grid, dim3(256), 0, b->stream, f_out, f_in, p->nx, p->ny, p->nz,
+                       (long)b->nxp, (long)b->nxp * b->nyp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
+{
+    X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_z: bad argument");
+    x3d_backend *b = p->b;
+    dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
+    ProfScope ps(b, X3D_K_COPY);
+    hipLaunchKernelGGL(k_periodicity_z<true>, grid, dim3(256), 0, b->stream, f_out, f_in, p->nx, p->ny, p->nz,
+                       (long)b->nxp, (long)b->nxp * b->nyp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// fft_postprocess_110 (src/backend/cuda/poisson_fft.f90:926-989) on the z-first transposed problem: this plan's x is
+// the reference's z (periodic, R2C), its y the reference's x, its z the reference's y.  The reference's seven
+// launches as three: normalisation + rotation along x' + paired split along y' ; paired split along z' +
+// division + recombination along z' ; recombination along y' + inverse rotation along x'.
+extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
+{
+    X3D_REQUIRE(p, "x3d_poisson_postprocess_011: null argument");
+    X3D_REQUIRE(!p->stretched, "x3d_poisson_postprocess_011: uniform grids only");
+    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+                 *bz = az + p->nz;
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
+    hipStream_t st = p->b->stream;
+    dim3 gy((p->nxs + 255) / 256, p->ny / 2 + 1, p->nz), gz((p->nxs + 255) / 256, p->ny, p->nz / 2 + 1);
+    hipLaunchKernelGGL((k_spectral_010<0, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, ax, bx,
+                       ay, by, az, bz);
+    hipLaunchKernelGGL(k_spectral_pair_z, gz, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, az, bz);
+    hipLaunchKernelGGL((k_spectral_010<1, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, ax, bx,
+                       ay, by, az, bz);
     X3D_HIP(hipGetLastError());
     return 0;
 }

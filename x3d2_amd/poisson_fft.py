@@ -166,6 +166,8 @@ def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     per = tuple(bool(x) for x in mesh.periodic_BC)
     if per == (False, True, True):
         return HipPoissonFFT100(backend, mesh, xdirps, ydirps, zdirps)
+    if per == (False, False, True):
+        return HipPoissonFFT110(backend, mesh, xdirps, ydirps, zdirps)
     return HipPoissonFFT(backend, mesh, xdirps, ydirps, zdirps)
 
 
@@ -192,8 +194,14 @@ class HipPoissonFFT:
             if type(self) is HipPoissonFFT:
                 raise X3dError("Poisson 100: use make_poisson_fft (HipPoissonFFT100)")
             self.case = "100"
-        elif self.periodic_z:
-            raise X3dError("HIP Poisson solver: the 110 case is not implemented")
+        elif (not self.periodic_x) and (not self.periodic_y) and self.periodic_z:
+            if mesh.nproc > 1:
+                raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
+            if type(self) is HipPoissonFFT:
+                raise X3dError("Poisson 110: use make_poisson_fft (HipPoissonFFT110)")
+            if mesh.stretched[1]:
+                raise X3dError("Poisson 110: uniform grids only (as in the reference)")
+            self.case = "110"
         else:
             raise X3dError("Requested BCs are not supported in FFT-based Poisson solver!")
         self.nx_spec, self.ny_spec, self.nz_spec = self.nx_glob // 2 + 1, self.ny_glob, self.nz_glob
@@ -391,6 +399,56 @@ class HipPoissonFFT100(HipPoissonFFT):
 
     fft_forward = fft_backward = fft_postprocess_000 = fft_postprocess_010 = _unsupported
     enforce_periodicity_y = undo_periodicity_y = get_spectral = set_spectral = _unsupported
+
+
+class HipPoissonFFT110(HipPoissonFFT100):
+    """x and y non-periodic, z periodic.  The reference's poisson_110 (src/poisson_fft.f90:258-273; CUDA backend
+    only): enforce_periodicity_xy ; fft_forward_110 = transposed copy to (nz, nx, ny) + R2C along z ;
+    fft_postprocess_110 = seven kernels on the spectrum (nz/2+1, nx, ny) ; fft_backward_110 ; undo_periodicity_xy
+    (src/backend/cuda/poisson_fft.f90:401-480, 926-989; waves_set :690-733).  Here, as for 100, a twin library
+    backend -- of vertex dims (nz, nx, ny) -- with an x3d_poisson whose x is the reference's z, whose y its x and
+    whose z its y; the interleaves along x and y act on the twin's y and z, the seven kernels are
+    x3d_poisson_postprocess_011."""
+
+    def _create(self):
+        backend, mesh = self.backend, self.mesh
+        lib = backend.lib
+        nx, ny, nz = self.nx_glob, self.ny_glob, self.nz_glob
+        tb = VP()
+        vd = [int(v) for v in mesh.vert_dims]
+        _lib.check(lib.x3d_backend_create(ctypes.byref(tb), _lib.ints(vd[2], vd[0], vd[1]), backend.device.index,
+                                          VP(backend.stream.cuda_stream)))
+        self.tb = tb
+        self.t1, self.t2 = VP(), VP()
+        _lib.check(lib.x3d_block_alloc(tb, ctypes.byref(self.t1)))
+        _lib.check(lib.x3d_block_alloc(tb, ctypes.byref(self.t2)))
+        # waves(z mode <= nz/2, x mode, y mode) as [y][x][z]: the 110 branch of waves_set
+        tx, ty, tz, kx2, ky2, kz2 = self._t1d_full
+        nzs = nz // 2 + 1
+        TX, KX = tx[None, :, None], kx2[None, :, None]
+        TY, KY = ty[:, None, None], ky2[:, None, None]
+        TZ, KZ = tz[:nzs][None, None, :], kz2[:nzs][None, None, :]
+        self.waves110 = KX * (TY * TZ) ** 2 + KY * (TX * TZ) ** 2 + KZ * (TX * TY) ** 2
+        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in
+                      (self.waves110, self.az, self.bz, self.ax, self.bx, self.ay, self.by)]
+        h = VP()
+        _lib.check(lib.x3d_poisson_create(tb, ctypes.byref(h), _lib.ints(nz, nx, ny),
+                                          *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
+        self.h = h
+        self.poisson = self.poisson_110
+
+    def poisson_110(self, f, temp):
+        lib, b, h, t1, t2 = self.backend.lib, self.backend, self.h, self.t1, self.t2
+        nx, ny, nz = self.nx_glob, self.ny_glob, self.nz_glob
+        _lib.check(lib.x3d_transpose_xyz_zxy(b.h, self.tb, t1, f.ptr, nx, ny, nz))
+        _lib.check(lib.x3d_poisson_enforce_periodicity_y(h, t2, t1))  # along x
+        _lib.check(lib.x3d_poisson_enforce_periodicity_z(h, t1, t2))  # along y
+        _lib.check(lib.x3d_poisson_fft_forward(h, t1))
+        _lib.check(lib.x3d_poisson_postprocess_011(h))
+        _lib.check(lib.x3d_poisson_fft_backward(h, t1))
+        _lib.check(lib.x3d_poisson_undo_periodicity_z(h, t2, t1))
+        _lib.check(lib.x3d_poisson_undo_periodicity_y(h, t1, t2))
+        _lib.check(lib.x3d_transpose_zxy_xyz(self.tb, b.h, f.ptr, t1, nx, ny, nz))
 
 
 class HipPencilPoissonFFT(HipPoissonFFT):
