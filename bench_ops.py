@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", default="256,512")
+    ap.add_argument("--n", default="256,512,1024")  # the sizes of perf_cuda_tridiag
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     args = ap.parse_args()

@@ -15,7 +15,9 @@ import subprocess
 import sys
 
 prof_tag, pmc_tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
-stats = glob.glob(f"gpurun_out/prof_{prof_tag}/*/*kernel_stats.csv")[0]
+import os
+# (gpurun merges every run of a tag into the same directory: take the newest)
+stats = max(glob.glob(f"gpurun_out/prof_{prof_tag}/*/*kernel_stats.csv"), key=os.path.getmtime)
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 pmc = json.load(open(f"gpurun_out/pmc_{pmc_tag}_summary.json"))
 GiB = 1024.0 ** 3
