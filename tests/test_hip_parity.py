@@ -386,7 +386,13 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0, 
                                                   ((1, 1, 2), True, (32, 512, 512)),   # slab solver, z halo, y local tile
                                                   ((1, 2, 1), True, (32, 512, 64)),    # y halo
                                                   ((1, 2, 2), True, (32, 512, 512)),   # y and z halo, pencil solver
-                                                  ((1, 1, 2), False, (32, 64, 1024))])
+                                                  ((1, 1, 2), False, (32, 64, 1024)),
+                                                  # 512 planes per rank (the bench's slabs): the z stage of the slab
+                                                  # Poisson solver is ONE kernel over the N received chunks
+                                                  # (k_fft512_peers<N>: DFTs across the chunks + 512-point transforms)
+                                                  ((1, 1, 2), True, (16, 512, 1024)),
+                                                  ((1, 1, 4), True, (16, 512, 2048)),
+                                                  ((1, 1, 8), True, (16, 512, 4096))])
 def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_path):
     """DistD2 across ranks (halo + reduced-system exchange) and the pencil FFT
     Poisson solver: ranks share cuda:0 and exchange through gloo; the result
@@ -836,7 +842,9 @@ def test_slab_poisson_solver_single_rank_emulation():
     from x3d2_amd.solver import Solver, SolverConfig
     twopi = 6.283185307179586
     per = ("periodic",) * 2
-    for dims in ((24, 512, 40), (512, 512, 8)):  # nx = 512: the x pass is k_r2c512 (csrc/fft512.hip)
+    # nx = 512: the x pass is k_r2c512 (csrc/fft512.hip); nz = 512: the z stage is the single fused kernel
+    # k_fft512_peers<1> on the received array itself
+    for dims in ((24, 512, 40), (512, 512, 8), (24, 512, 512)):
         mesh = Mesh(dims, (1, 1, 1), (twopi, 3.0, 2.0), per, per, per)
         s = Solver(HipBackend(mesh), mesh, SolverConfig())
         b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft

@@ -258,7 +258,185 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
     }
 }
 
+// ---------------------------------------------------------------- z stage of the slab solver on N ranks
+// After the all-to-all a rank holds, for its share of the (x, y) modes, all 512 N points along z as N chunks of
+// 512 (chunk p = what peer p sent): R[g = 512 p + zl][W modes].  The transform of length M = 512 N is split as
+//   Y_k1[zl] = sum_p x[zl + 512 p] W_N^(p k1)        N-point DFTs ACROSS the chunks (same zl, same mode)
+//   Y'_k1[zl] = Y_k1[zl] W_M^(zl k1)                 twiddle
+//   X[k1 + N k2] = sum_zl Y'_k1[zl] W_512^(zl k2)    N transforms of 512 points, one per wave (fft512_wave)
+// so that one workgroup of 16 waves = N chunks x 16/N modes does the forward transform, process_spectral_000
+// (src/backend/omp/kernels/spectral_processing.f90:7-106, same operation order as k_process_spectral_000_slab) and
+// the inverse entirely on chip: the received array is read once and written once (2 passes) instead of transpose,
+// rocFFT forward, division, rocFFT backward, transpose (10 passes; the reference issues cuFFTMp's z transforms
+// and a separate spectral kernel, src/backend/cuda/poisson_fft.f90:519-568).
+template <int S, int N>
+__device__ __forceinline__ void dft_small(double2 (&v)[8])
+{
+    if constexpr (N == 8) fft8<S>(v);
+    else if constexpr (N == 4) {
+        const double2 c0 = cadd(v[0], v[2]), c1 = cadd(v[1], v[3]), c2 = csub(v[0], v[2]), d = csub(v[1], v[3]);
+        const double2 c3 = make_double2(-S * d.y, S * d.x);  // d * (S i)
+        v[0] = cadd(c0, c1); v[2] = csub(c0, c1); v[1] = cadd(c2, c3); v[3] = csub(c2, c3);
+    } else if constexpr (N == 2) {
+        const double2 t0 = cadd(v[0], v[1]), t1 = csub(v[0], v[1]);
+        v[0] = t0; v[1] = t1;
+    }
+}
+
+struct SpecSlab {
+    const double *waves;  // this part's -1 / waves [W][nz], z fastest (0 where waves < 1e-16)
+    const double *ax, *bx, *ay, *by, *az, *bz;
+    int nx, ny, nz, nxs, yoff;
+};
+
+// WV waves = N chunks x WV / N modes per workgroup.  N = 1 (the DFTs across the chunks done by k_radix_peers, or a
+// single rank): blockIdx.y = the chunk, whose points are the z modes chunk + nk * k2.
+template <int N, int WV>
+__global__ void __launch_bounds__(64 * WV, 16 / WV)
+    k_fft512_peers(double2 *R, const double2 *__restrict__ twg, long W, SpecSlab sp, int nk)
+{
+    constexpr int NM = WV / N;  // modes per workgroup
+    extern __shared__ double2 tile[];  // [WV pencils][FP] + 256 twiddles
+    double2 *__restrict__ tws = tile + WV * FP;
+    R += (long)blockIdx.y * 512 * W;
+    if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long w0 = (long)blockIdx.x * NM;
+    const int m = tid % NM, r = tid / NM;  // r: row (point along z) of a pass of 64 N rows
+    const bool valid = w0 + m < W;
+    // ---- cooperative load: row rr = 512 p + zl of the received array, NM adjacent modes per row
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int rr = it * (64 * N) + r, p = rr >> 9, zl = rr & 511;
+        tile[(p * NM + m) * FP + zl] = valid ? R[(long)rr * W + w0 + m] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    // ---- N-point DFTs across the chunks + twiddle W_M^(zl k1); thread -> (zl, mode)
+    if constexpr (N > 1) {
+#pragma unroll
+        for (int s_ = 0; s_ < 8 / N; s_++) {
+            const int idx = tid + 64 * WV * s_, zl = idx & 511, mm = idx >> 9;
+            double2 v[8];
+#pragma unroll
+            for (int p = 0; p < N; p++) v[p] = tile[(p * NM + mm) * FP + zl];
+            dft_small<-1, N>(v);
+#pragma unroll
+            for (int k1 = 1; k1 < N; k1++) {
+                double sn, cs;
+                sincospi(-2.0 * (double)(zl * k1) / (512.0 * N), &sn, &cs);
+                v[k1] = cmul(v[k1], make_double2(cs, sn));
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < N; k1++) tile[(k1 * NM + mm) * FP + zl] = v[k1];
+        }
+        __syncthreads();
+    }
+    // ---- wave w: pencil (k1 = w / NM, mode w % NM): 512-point transform, spectral division, inverse
+    double2 *__restrict__ pen = tile + w * FP;
+    double2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = pen[l + 64 * k];
+    fft512_wave<-1>(a, pen, tws, l);
+    {
+        const int k1 = w / NM;
+        const long wl = w0 + w % NM;
+        if (wl < W) {
+            const int i = (int)(wl % sp.nxs), j = (int)(wl / sp.nxs) + sp.yoff;
+            const double ayj = sp.ay[j], byj = sp.by[j], axi = sp.ax[i], bxi = sp.bx[i];
+            const bool fy = (j + 1) > sp.ny / 2 + 1;
+            const double *__restrict__ wv = sp.waves + wl * sp.nz;
+            const double rn = 1.0 / sp.nx / sp.ny / sp.nz;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = (N == 1 ? (int)blockIdx.y : k1) + nk * (l + 64 * kk);  // this point's z mode
+                double div_r = a[kk].x * rn, div_c = a[kk].y * rn;
+                const double azk = sp.az[k], bzk = sp.bz[k];
+                const bool fz = (k + 1) > sp.nz / 2 + 1;
+                double tr, tc;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+                const double rw = wv[k];  // (-1 / waves)
+                div_r = div_r * rw; div_c = div_c * rw;
+                tr = div_r; tc = div_c;
+                div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
+                if (fz) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * byj + tc * ayj; div_c = tc * byj - tr * ayj;
+                if (fy) { div_r = -div_r; div_c = -div_c; }
+                tr = div_r; tc = div_c;
+                div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+                a[kk] = make_double2(div_r, div_c);
+            }
+        }
+    }
+    fft512_wave<1>(a, pen, tws, l);
+#pragma unroll
+    for (int k = 0; k < 8; k++) pen[l + 64 * k] = a[k];
+    __syncthreads();
+    // ---- inverse twiddle + inverse N-point DFTs across the chunks
+    if constexpr (N > 1) {
+#pragma unroll
+        for (int s_ = 0; s_ < 8 / N; s_++) {
+            const int idx = tid + 64 * WV * s_, zl = idx & 511, mm = idx >> 9;
+            double2 v[8];
+#pragma unroll
+            for (int k1 = 0; k1 < N; k1++) v[k1] = tile[(k1 * NM + mm) * FP + zl];
+#pragma unroll
+            for (int k1 = 1; k1 < N; k1++) {
+                double sn, cs;
+                sincospi(2.0 * (double)(zl * k1) / (512.0 * N), &sn, &cs);
+                v[k1] = cmul(v[k1], make_double2(cs, sn));
+            }
+            dft_small<1, N>(v);
+#pragma unroll
+            for (int p = 0; p < N; p++) tile[(p * NM + mm) * FP + zl] = v[p];
+        }
+        __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int rr = it * (64 * N) + r, p = rr >> 9, zl = rr & 511;
+            R[(long)rr * W + w0 + m] = tile[(p * NM + m) * FP + zl];
+        }
+    }
+}
+
+// the DFTs across the chunks as a pass of their own (N = 4, 8: with 16 / N modes per workgroup the fused kernel's row
+// segments shrink to 64 / 32 bytes): one thread per (point, mode), in place; S = -1: DFT then twiddle, +1: the inverse
+template <int S, int N>
+__global__ void __launch_bounds__(256) k_radix_peers(double2 *R, long W)
+{
+    const long w = (long)blockIdx.x * 256 + threadIdx.x;
+    const int zl = blockIdx.y;
+    if (w >= W) return;
+    double2 v[8];
+#pragma unroll
+    for (int p = 0; p < N; p++) v[p] = R[((long)p * 512 + zl) * W + w];
+    if (S < 0) dft_small<-1, N>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < N; k1++) {
+        double sn, cs;
+        sincospi(S * 2.0 * (double)(zl * k1) / (512.0 * N), &sn, &cs);
+        v[k1] = cmul(v[k1], make_double2(cs, sn));
+    }
+    if (S > 0) dft_small<1, N>(v);
+#pragma unroll
+    for (int p = 0; p < N; p++) R[((long)p * 512 + zl) * W + w] = v[p];
+}
+
 static double2 *g_tw = nullptr;  // W512^k = exp(-2 pi i k / 512), first half, shared by all plans
+
+// R: one part of the received array [512 N][W]; waves: that part's [W][512 N]; returns *done = false when the
+// sizes are not served (N not 1, 2, 4, 8)
+int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
+                     int nz, int nxs, int yoff, bool *done);
 
 template <int MODE, int NP>
 static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_other, int nxs, int nother,
@@ -378,5 +556,53 @@ int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_r2c512, dim3((unsigned)blocks), dim3(512), lds, b->stream, c, f, g_tw, npairs, frow, crow);
     X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
+                     int nz, int nxs, int yoff, bool *done)
+{
+    *done = false;
+    if (!g_tw || nz != 512 * npeers || !(npeers == 1 || npeers == 2 || npeers == 4 || npeers == 8)) return 0;
+    const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    const SpecSlab sp{waves, ax, bx, ay, by, az, bz, nx, ny, nz, nxs, yoff};
+    // npeers = 8 (X3D_SLAB_Z_SPLIT=0 / 1 overrides): the DFTs across the chunks as streaming passes around the
+    // chunk-local kernel -- 6 passes with 128-byte row segments instead of 2 with 32-byte ones.  Measured per solve
+    // at 512^3 per rank (scratch/zstage_bench.py; transposes + rocFFT + division: 2.07 - 2.26 ms): 1 rank 0.78, 2 ranks
+    // 0.95, 4 ranks 1.11 (fused) / 1.62 (split), 8 ranks 1.88 (fused) / 1.86 (split)
+    static int split_env = -2;
+    if (split_env == -2) { const char *e = getenv("X3D_SLAB_Z_SPLIT"); split_env = e ? atoi(e) : -1; }
+    const bool split = npeers > 1 && (split_env >= 0 ? split_env != 0 : npeers >= 8);
+#define LOCAL(NK_)                                                                                              \
+    do {                                                                                                        \
+        const int lds8 = sizeof(double2) * (8 * FP + 256);                                                      \
+        X3D_LDS_OPTIN(b, (k_fft512_peers<1, 8>));                                                               \
+        hipLaunchKernelGGL((k_fft512_peers<1, 8>), dim3((unsigned)((W + 7) / 8), NK_), dim3(512), lds8, b->stream, R, g_tw, W, \
+                           sp, NK_);                                                                            \
+    } while (0)
+#define FUSED(N_)                                                                                               \
+    do {                                                                                                        \
+        const int lds16 = sizeof(double2) * (16 * FP + 256);                                                    \
+        const long nm = 16 / N_;                                                                                \
+        X3D_LDS_OPTIN(b, (k_fft512_peers<N_, 16>));                                                             \
+        hipLaunchKernelGGL((k_fft512_peers<N_, 16>), dim3((unsigned)((W + nm - 1) / nm)), dim3(1024), lds16, b->stream, R,   \
+                           g_tw, W, sp, N_);                                                                    \
+    } while (0)
+#define SPLIT(N_)                                                                                               \
+    do {                                                                                                        \
+        const dim3 g((unsigned)((W + 255) / 256), 512);                                                         \
+        hipLaunchKernelGGL((k_radix_peers<-1, N_>), g, dim3(256), 0, b->stream, R, W);                          \
+        LOCAL(N_);                                                                                              \
+        hipLaunchKernelGGL((k_radix_peers<1, N_>), g, dim3(256), 0, b->stream, R, W);                           \
+    } while (0)
+    if (npeers == 1) LOCAL(1);
+    else if (npeers == 2) { if (split) SPLIT(2); else FUSED(2); }
+    else if (npeers == 4) { if (split) SPLIT(4); else FUSED(4); }
+    else { if (split) SPLIT(8); else FUSED(8); }
+#undef SPLIT
+#undef FUSED
+#undef LOCAL
+    X3D_HIP(hipGetLastError());
+    *done = true;
     return 0;
 }

@@ -8,9 +8,11 @@
 //   --k_fft512 (y forward), storing straight into the exchange layout-->  S[r][zl][ys][nxs]
 //        (chunk r = the y-range that rank r will own, contiguous -> sent as is)
 //   --all-to-all among the pz ranks-->  R[r][zl][ys][nxs] = R[nz][ys][nxs]  (chunks arrive in z order)
-//   --32x32 LDS-tiled transpose to T[ys*nxs][nz], rocFFT C2C z (contiguous), process_spectral_000, inverse z,
-//     transpose back (rocFFT's strided 1-D plan on R itself takes 2.05 ms per direction at 512^3, the
-//     transpose + contiguous transform 0.42 + 0.45)
+//   --512 planes per rank: k_fft512_peers / k_radix_peers (fft512.hip) on R itself: DFTs across the pz chunks,
+//     512-point transforms, process_spectral_000 and the inverses in ONE kernel (pz = 8: three), 2 passes
+//   --other plane counts: 32x32 LDS-tiled transpose to T[ys*nxs][nz], rocFFT C2C z (contiguous),
+//     process_spectral_000, inverse z, transpose back (rocFFT's strided 1-D plan on R itself takes 2.05 ms per
+//     direction at 512^3, the transpose + contiguous transform 0.42 + 0.45)
 //   --all-to-all back (chunk r of R = rank r's z-range, contiguous)-->  S
 // Overlap: a rank's share of the y modes is cut into `parts` pieces, S = [peer][part][zl][ysc][nxs] and
 // R = [part][peer][zl][ysc][nxs] = [part][nz][ysc][nxs]: the pieces travel one after the other on the communication
@@ -37,6 +39,8 @@ int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int ax
                      const double *ab, int nx, double2 *xbuf, int ys, int ysc);
 
 int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);  // fft512.hip
+int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
+                     int nz, int nxs, int yoff, bool *done);  // fft512.hip
 
 struct x3d_sfft {
     x3d_backend *b;
@@ -46,7 +50,9 @@ struct x3d_sfft {
     hipfftHandle plan_x_fw, plan_x_bw, plan_z;
     double2 *c0;          // [zl][ny][nxs]
     double2 *t;           // [ys*nxs][nz]: z-contiguous copy of the received array
-    double *waves, *ab;   // [ys][nxs][nz]; ax bx ay by az bz
+    int fused_z;          // 512 local planes, pz in {1, 2, 4, 8}: the whole z stage is ONE kernel on the received
+                          // array itself (fft512.hip, k_fft512_peers): no transposed copy, no rocFFT z plan calls
+    double *waves, *ab;   // -1 / waves [ys][nxs][nz] (0 where waves < 1e-16); ax bx ay by az bz
     void *work;
 };
 
@@ -84,7 +90,8 @@ __global__ void __launch_bounds__(256)
     const int j = jl + yoff;
     const size_t idx = ((size_t)jl * nxs + i) * nz + k;
     double2 v = c[idx];
-    double div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
+    const double rn = 1.0 / nx / ny / nz;
+    double div_r = v.x * rn, div_c = v.y * rn;
     const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
     const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
     double tr, tc;
@@ -96,9 +103,8 @@ __global__ void __launch_bounds__(256)
     if (fy) { div_r = -div_r; div_c = -div_c; }
     tr = div_r; tc = div_c;
     div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
-    const double wv = waves[idx];
-    if (wv < 1.e-16) { div_r = 0.0; div_c = 0.0; }
-    else { div_r = -div_r / wv; div_c = -div_c / wv; }
+    const double rw = waves[idx];  // (-1 / waves, x3d_sfft_set_waves)
+    div_r = div_r * rw; div_c = div_c * rw;
     tr = div_r; tc = div_c;
     div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
     if (fz) { div_r = -div_r; div_c = -div_c; }
@@ -130,6 +136,10 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
     X3D_REQUIRE(parts >= 1 && p->ys % parts == 0, "x3d_sfft_create: %d y modes per rank do not split into %d parts",
                 p->ys, parts);
     p->parts = parts; p->ysc = p->ys / parts;
+    {
+        const char *e = getenv("X3D_NO_SLAB_FUSED_Z");
+        p->fused_z = p->zl == 512 && (pz == 1 || pz == 2 || pz == 4 || pz == 8) && !(e && e[0] == '1');
+    }
     X3D_REQUIRE(p->nx <= b->nxp && p->ny == b->nyp && p->zl <= b->nzp, "x3d_sfft_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs;
     X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
@@ -183,7 +193,14 @@ extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double
                                   const double *ay, const double *by, const double *az, const double *bz)
 {
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
-    X3D_HIP(hipMemcpy(p->waves, waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs, hipMemcpyHostToDevice));
+    {
+        // stored as -1 / waves (0 where waves < 1e-16): the kernels multiply (the reference divides per element; one
+        // reciprocal here and one of nx ny nz there: <= 2 ulp apart, as in the single-rank solver)
+        const size_t n = (size_t)p->nz * p->ys * p->nxs;
+        std::vector<double> rw(n);
+        for (size_t i = 0; i < n; i++) rw[i] = waves[i] < 1.e-16 ? 0.0 : -1.0 / waves[i];
+        X3D_HIP(hipMemcpy(p->waves, rw.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    }
     const double *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
     double *d = p->ab;
@@ -219,6 +236,7 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
 extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_fft_z_part: bad argument");
+    if (p->fused_z) return 0;  // (forward, division and backward are one kernel: x3d_sfft_postprocess_000_part)
     const int W = p->ysc * p->nxs;
     double2 *R = (double2 *)recvbuf + (size_t)part * p->nz * W, *T = p->t + (size_t)part * p->nz * W;
     if (dir == 0) {
@@ -256,6 +274,15 @@ extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int p
     const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     const size_t off = (size_t)part * p->nz * p->ysc * p->nxs;  // waves[ys][nxs][nz] and T share the part offset
+    if (p->fused_z) {
+        bool ok = false;
+        ProfScope ps(p->b, X3D_K_FFT, 3);
+        if (int rc = x3d_fft512_peers(p->b, (double2 *)recvbuf + off, (long)p->ysc * p->nxs, p->pz, p->waves + off, p->ab,
+                                      p->nx, p->ny, p->nz, p->nxs, p->rz * p->ys + part * p->ysc, &ok))
+            return rc;
+        X3D_REQUIRE(ok, "x3d_sfft_postprocess_000_part: fused z stage refused");
+        return 0;
+    }
     dim3 grid((p->nz + 255) / 256, p->nxs, p->ysc);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     hipLaunchKernelGGL(k_process_spectral_000_slab, grid, dim3(256), 0, p->b->stream, p->t + off, p->waves + off, p->nxs,
