@@ -545,9 +545,11 @@ class HipPencilPoissonFFT(HipPoissonFFT):
 class HipSlabPoissonFFT(HipPoissonFFT):
     """000 solver over a z-slab decomposition [1, 1, pz] with ny = 512 (csrc/sfft.hip): y is local, the strided
     y pass writes / reads the exchange layout directly, one all-to-all pair per solve among all pz ranks (every
-    xGMI link of a GPU is used at once), z transform strided on the received array.  The hooks keep the
-    reference's meaning (src/poisson_fft.f90:45-62): fft_forward leaves the full 3-D spectrum in this rank's
-    block [nz][ys][nx/2+1], fft_postprocess_000 divides, fft_backward returns to physical space.
+    xGMI link of a GPU is used at once), z stage on the received array.  The hooks keep the reference's order
+    (src/poisson_fft.f90:45-62: fft_forward ; fft_postprocess_000 ; fft_backward).  With 512 planes per rank the
+    whole z stage -- forward transform over the pz chunks, spectral division, inverse -- is ONE kernel launched by
+    fft_postprocess_000 (csrc/fft512.hip, k_fft512_peers); for other plane counts fft_forward leaves the full 3-D
+    spectrum in this rank's block [nz][ys][nx/2+1], fft_postprocess_000 divides, fft_backward returns.
 
     Overlap (poisson_000): this rank's share of the y modes travels in `parts` pieces on the communication
     stream (parallel.Comm.ialltoall); the z stage of a piece (transpose, z transform, spectral division, inverse
