@@ -301,7 +301,16 @@ __global__ void __launch_bounds__(64 * WV, 16 / WV)
     R += (long)blockIdx.y * 512 * W;
     if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long w0 = (long)blockIdx.x * NM;
+    // NM < 8: a workgroup's row segments are 64 / 32 bytes, 2 / 4 workgroups share every 128-byte line.  Workgroups
+    // are dealt round-robin to the 8 XCDs (each with its own L2): number the mode groups so that the workgroups
+    // that share lines are bid, bid + 8, ... -- same XCD, launched back to back -- instead of 4 different L2s
+    long grp = blockIdx.x;
+    if constexpr (NM < 8) {
+        constexpr int SH = 8 / NM;
+        const long bid = blockIdx.x, blk = bid / (8 * SH), in = bid % (8 * SH);
+        grp = blk * (8 * SH) + (in % 8) * SH + in / 8;
+    }
+    const long w0 = grp * NM;
     const int m = tid % NM, r = tid / NM;  // r: row (point along z) of a pass of 64 N rows
     const bool valid = w0 + m < W;
     // ---- cooperative load: row rr = 512 p + zl of the received array, NM adjacent modes per row
@@ -566,13 +575,13 @@ int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const doubl
     if (!g_tw || nz != 512 * npeers || !(npeers == 1 || npeers == 2 || npeers == 4 || npeers == 8)) return 0;
     const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
     const SpecSlab sp{waves, ax, bx, ay, by, az, bz, nx, ny, nz, nxs, yoff};
-    // npeers = 8 (X3D_SLAB_Z_SPLIT=0 / 1 overrides): the DFTs across the chunks as streaming passes around the
-    // chunk-local kernel -- 6 passes with 128-byte row segments instead of 2 with 32-byte ones.  Measured per solve
-    // at 512^3 per rank (scratch/zstage_bench.py; transposes + rocFFT + division: 2.07 - 2.26 ms): 1 rank 0.78, 2 ranks
-    // 0.95, 4 ranks 1.11 (fused) / 1.62 (split), 8 ranks 1.88 (fused) / 1.86 (split)
+    // X3D_SLAB_Z_SPLIT=1: the DFTs across the chunks as streaming passes (k_radix_peers) around the chunk-local kernel
+    // -- 6 passes with 128-byte row segments instead of 2 with 64- / 32-byte ones.  Measured per solve at 512^3 per
+    // rank (scratch/zstage_bench.py; transposes + rocFFT + division: 2.07 - 2.26 ms): 1 rank 0.76, 2 ranks 0.96,
+    // 4 ranks 1.07 (split 1.62), 8 ranks 1.47 (split 1.86; 1.88 before the XCD-aware numbering of the mode groups)
     static int split_env = -2;
     if (split_env == -2) { const char *e = getenv("X3D_SLAB_Z_SPLIT"); split_env = e ? atoi(e) : -1; }
-    const bool split = npeers > 1 && (split_env >= 0 ? split_env != 0 : npeers >= 8);
+    const bool split = npeers > 1 && split_env > 0;
 #define LOCAL(NK_)                                                                                              \
     do {                                                                                                        \
         const int lds8 = sizeof(double2) * (8 * FP + 256);                                                      \
@@ -583,10 +592,10 @@ int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const doubl
 #define FUSED(N_)                                                                                               \
     do {                                                                                                        \
         const int lds16 = sizeof(double2) * (16 * FP + 256);                                                    \
-        const long nm = 16 / N_;                                                                                \
+        const long nm = 16 / N_, sh = nm < 8 ? 8 * (8 / nm) : 1;                                                \
+        const long ng = ((W + nm - 1) / nm + sh - 1) / sh * sh; /* (whole blocks of the XCD numbering) */       \
         X3D_LDS_OPTIN(b, (k_fft512_peers<N_, 16>));                                                             \
-        hipLaunchKernelGGL((k_fft512_peers<N_, 16>), dim3((unsigned)((W + nm - 1) / nm)), dim3(1024), lds16, b->stream, R,   \
-                           g_tw, W, sp, N_);                                                                    \
+        hipLaunchKernelGGL((k_fft512_peers<N_, 16>), dim3((unsigned)ng), dim3(1024), lds16, b->stream, R, g_tw, W, sp, N_); \
     } while (0)
 #define SPLIT(N_)                                                                                               \
     do {                                                                                                        \
