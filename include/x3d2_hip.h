@@ -418,6 +418,7 @@ enum { X3D_K_TRANSEQ_FWD = 0, X3D_K_TRANSEQ_BWD = 1, X3D_K_TDS_FWD = 2, X3D_K_TD
        X3D_K_BLAS1 = 4, X3D_K_COPY = 5, X3D_K_REDUCE = 6, X3D_K_FFT = 7, X3D_K_SPECTRAL = 8,
        X3D_K_PACK = 9 };
 int x3d_prof_enable(x3d_backend *b, int on);
+int x3d_prof_select(x3d_backend *b, unsigned mask); /* bit k = class X3D_K_* timed while the timers are on (default all) */
 int x3d_prof_reset(x3d_backend *b);
 int x3d_prof_get(x3d_backend *b, int kind, int dir, long *count, double *total_ms);
 

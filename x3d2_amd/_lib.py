@@ -140,6 +140,7 @@ PROTOTYPES = {
     "x3d_timer_start": (I, [VP]),
     "x3d_timer_stop_ms": (I, [VP, ctypes.POINTER(ctypes.c_float)]),
     "x3d_prof_enable": (I, [VP, I]),
+    "x3d_prof_select": (I, [VP, ctypes.c_uint]),
     "x3d_prof_reset": (I, [VP]),
     "x3d_prof_get": (I, [VP, I, I, ctypes.POINTER(ctypes.c_long), c_double_p]),
 }

@@ -98,6 +98,11 @@ class HipBackend:
     def prof_enable(self, on=True):
         _lib.check(self.lib.x3d_prof_enable(self.h, int(on)))
 
+    def prof_select(self, kinds=None):
+        """time only these kernel classes while the timers are on (None: all)"""
+        mask = 0xFFFFFFFF if kinds is None else sum(1 << self.KINDS[k] for k in kinds)
+        _lib.check(self.lib.x3d_prof_select(self.h, mask))
+
     def prof_reset(self):
         _lib.check(self.lib.x3d_prof_reset(self.h))
 

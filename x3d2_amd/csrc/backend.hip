@@ -55,6 +55,7 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     x3d_backend *b = new x3d_backend();
     memset(b, 0, sizeof *b);
     b->device = device;
+    b->prof_mask = ~0u;
     b->stream = (hipStream_t)stream;
     b->nx = dims_vert[0]; b->ny = dims_vert[1]; b->nz = dims_vert[2];
     b->nxp = (b->nx + 15) / 16 * 16;

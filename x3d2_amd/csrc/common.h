@@ -70,6 +70,7 @@ struct x3d_backend {
     void *epi_dev;    // 256-byte device slot for the RK-stage description of k_ytile_transeq<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
+    unsigned prof_mask;     // kernel classes that are timed while the timers are on (bit = X3D_K_*; x3d_prof_select)
     void *lds_optin;        // kernels of this backend's device whose dynamic-LDS limit has been raised (backend.hip)
 };
 
@@ -90,7 +91,8 @@ int x3d_prof_enable_c(x3d_backend *b, int on);
 struct ProfScope {
     x3d_backend *b;
     bool on;  // false: the caller times a group of launches as one (scopes do not nest)
-    ProfScope(x3d_backend *b_, int kind, int dir = 0, bool on_ = true) : b(b_), on(on_ && b_->prof)
+    ProfScope(x3d_backend *b_, int kind, int dir = 0, bool on_ = true)
+        : b(b_), on(on_ && b_->prof && ((b_->prof_mask >> kind) & 1u))
     {
         if (on) x3d_prof_begin(b, kind, dir);
     }

@@ -62,6 +62,16 @@ extern "C" int x3d_prof_enable(x3d_backend *b, int on)
     return 0;
 }
 
+// which kernel classes are timed while the timers are on: bit k = class X3D_K_* (default: all).  A benchmark that
+// only needs the dominant class keeps the event records of the others out of its timed region.
+extern "C" int x3d_prof_select(x3d_backend *b, unsigned mask)
+{
+    X3D_REQUIRE(b, "null backend");
+    if (b->prof) prof_drain(b);
+    b->prof_mask = mask;
+    return 0;
+}
+
 extern "C" int x3d_prof_reset(x3d_backend *b)
 {
     X3D_REQUIRE(b, "null backend");
