@@ -414,6 +414,24 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
     assert rows[-1][2] < max(1e-11, 3 * rrows[-1][2])  # max |div u|: round-off level of the single-rank run
 
 
+@pytest.mark.parametrize("env", ["X3D_PACK_Z_HALOS", "X3D_NO_SLAB_FUSED_Z", "X3D_SLAB_Z_SPLIT", "X3D_NO_OVERLAP"])
+def test_multirank_alternative_paths_match_single_rank(env, tmp_path, monkeypatch):
+    """the switched-off forms of the N > 1 path stay correct: z halos through the pack kernel, the slab solver's z
+    stage as transposes + rocFFT, the cross-chunk DFTs as separate passes, exchanges ordered on the compute stream
+    (two ranks, 512 planes each, against the single-rank run)"""
+    from x3d2_amd import make_tgv
+    monkeypatch.setenv(env, "1")
+    dims = (16, 512, 1024)
+    g, rows = _run_ranks((1, 1, 2), dims, 1, True, "FFT", tmp_path)
+    monkeypatch.delenv(env)
+    ref = make_tgv(dims, fused=True)
+    ref.solver.n_output = 1
+    ref.run(n_iters=1)
+    b = ref.solver.backend
+    for name, f in zip("uvw", (ref.solver.u, ref.solver.v, ref.solver.w)):
+        assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
+
+
 @pytest.mark.parametrize("nproc_dir,dims", [((1, 1, 2), (32, 512, 512)), ((1, 2, 1), (32, 512, 64)),
                                             ((1, 1, 4), (32, 512, 1024)), ((1, 2, 4), (32, 512, 1024))])
 def test_multirank_over_rccl_one_device_per_rank(nproc_dir, dims, tmp_path):
