@@ -200,6 +200,13 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     for (int r = 0; r < 4; r++)
         for (int m = 0; m < 9; m++)
             if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) tb.bulk_only = 0;
+    t->narrow_all = 1;
+    for (int m = 0; m < 9; m++) {
+        if (m >= 2 && m <= 6) continue;
+        if (coeffs[m] != 0.0) t->narrow_all = 0;
+        for (int r = 0; r < 4; r++)
+            if (coeffs_s[r * 9 + m] != 0.0 || coeffs_e[r * 9 + m] != 0.0) t->narrow_all = 0;
+    }
     tb.TL = Q ? t->dev + tl_off : nullptr;
     t->tlc = tlc_off ? t->dev + tlc_off : nullptr;
     t->tl_hash = 1469598103934665603ull;

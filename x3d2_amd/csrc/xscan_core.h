@@ -185,9 +185,14 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + co + q * 10);
-            const double2 ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
-            acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
-                     cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
+            if (NARROW) {  // no stencil of the operator reaches beyond 2 rows (x3d_tdsops::narrow_all): taps 2..6 only
+                const double2 cb = c2[1], cc = c2[2], cd = c2[3];
+                acc[q] = cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] + cc.y * w[q + 5] + cd.x * w[q + 6];
+            } else {
+                const double2 ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
+                acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
+                         cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
+            }
             asm volatile("" : "+v"(co) : "v"(first_of(acc[q])));  // one row's weights at a time (10 VGPRs, not 10 Q)
         }
     }

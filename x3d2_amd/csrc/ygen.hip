@@ -24,13 +24,13 @@ template <int Q> struct GenGeom {
 };
 
 // one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
-template <int Q>
+template <int Q, bool NARROW>
 __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ lt,
                                           const double *__restrict__ cs, const XOp &t, int &lane)
 {
     const int first = lane * Q + 1, n = t.n_tds;
     double X[Q], du1, xn;
-    scan_solve<Q, false, false>(w, X, du1, xn, lt, t, lane, first, 0, cs);
+    scan_solve<Q, false, NARROW>(w, X, du1, xn, lt, t, lane, first, 0, cs);
     const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -106,7 +106,7 @@ template <int Q> struct GenTile {
 // ---------------------------------------------------------------- operator pairs / single operators
 //   MODE 0: out1 = A(in1) + B(in2)     MODE 1: out1 = A(in1), out2 = B(in1)     MODE 2: out1 = A(in1)
 // (the pairs of divergence_v2c / gradient_c2v, src/vector_calculus.f90:142-332, as in k_ytile_tds_pair)
-template <int Q, int MODE>
+template <int Q, int MODE, bool NARROW>
 __global__ void __launch_bounds__(1024)
     k_ygen_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2, XOp ta, XOp tb,
                 int ntx, int ntiles, long prow, long pplane, int nrow)
@@ -144,14 +144,14 @@ __global__ void __launch_bounds__(1024)
             const int tn = tl + gridDim.x;
             if (tn < ntiles) T.gload(nxt, in1 + tile_off(tn));
         }
-        gen_solve<Q>(w, ra, lt, cs, ta, lane);
+        gen_solve<Q, NARROW>(w, ra, lt, cs, ta, lane);
         if (MODE == 0) {
             T.to_tile(g2);
             __syncthreads();
             T.window(w);
         }
         if (MODE != 2) {
-            gen_solve<Q>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
+            gen_solve<Q, NARROW>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
             if (MODE == 0) {
 #pragma unroll
                 for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];  // (the accumulating form: old + 1.0 * r)
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(1024)
 // ---------------------------------------------------------------- transeq: the three components of a direction
 // component 0 = (u0, conv = u0), 1, 2 = (u1, u0), (u2, u0) (src/backend/omp/backend.f90:145-184); der1st and
 // der1st_sym, der2nd and der2nd_sym must be equal as lane tables (Dirichlet ends: they are) -- two table sets.
-template <int Q, bool ACC>
+template <int Q, bool ACC, bool NARROW>
 __global__ void __launch_bounds__(1024)
     k_ygen_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0, const double *__restrict__ u1,
                     const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(1024)
                 window_from_body_zero<Q>(wc, cb);
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wc[m];
-                gen_solve<Q>(wp, X, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW>(wp, X, l1, cs, tD1, lane);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = X[q];
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(1024)
             {
                 double wu[Q + 8];
                 T.window(wu);
-                gen_solve<Q>(wu, X, l1, cs, tD1, lane);  // du
+                gen_solve<Q, NARROW>(wu, X, l1, cs, tD1, lane);  // du
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, LT_STC(q)));
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(1024)
             {
                 double wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
                 T.window(wu);
-                gen_solve<Q>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
+                gen_solve<Q, NARROW>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] += nu * X[q];
@@ -305,17 +305,22 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
     const x3d_tdsops *tb_ = mode == 2 ? ta : tb;
+    const bool narrow = ta->narrow_all && tb_->narrow_all;
+    {
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GO(Q_, M_)                                                                                              \
+#define GO(Q_, M_, N_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_>));                                                                \
-        hipLaunchKernelGGL((k_ygen_pair<Q_, M_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
+        X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_, N_>));                                                            \
+        hipLaunchKernelGGL((k_ygen_pair<Q_, M_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
                            xop_of(ta), xop_of(tb_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow);             \
     } while (0)
-#define GOM(Q_) do { if (mode == 0) GO(Q_, 0); else if (mode == 1) GO(Q_, 1); else GO(Q_, 2); } while (0)
+#define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
+#define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
     if (Q == 8) GOM(8); else if (Q == 6) GOM(6); else GOM(4);
 #undef GOM
+#undef GON
 #undef GO
+    }
     X3D_HIP(hipGetLastError());
     if (b->prof && mode != 2) { ProfScope ps2(b, X3D_K_TDS_FWD, dir); }  // two operators
     *done = true;
@@ -339,17 +344,20 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double 
     const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
+    const bool narrow = der1st->narrow_all && der2nd->narrow_all;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-#define GO(Q_, A_)                                                                                              \
+#define GO(Q_, A_, N_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_>));                                                            \
-        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
+        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_>));                                                        \
+        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
                            f[1], f[2], xop_of(der1st), xop_of(der2nd), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
     } while (0)
-#define GOA(Q_) do { if (acc) GO(Q_, true); else GO(Q_, false); } while (0)
+#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
         if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else GOA(4);
 #undef GOA
+#undef GON
 #undef GO
     }
     X3D_HIP(hipGetLastError());
