@@ -167,6 +167,9 @@ def load():
     # torch first: its wheel bundles its own HIP runtime and must be the one the
     # process initialises (loading /opt/rocm's copy first leaves two runtimes)
     import torch  # noqa: F401
+    # rocFFT compiles its kernels at plan creation (seconds per new transform length on a fresh box); a cache file that
+    # travels with the tree (built artefact, git-ignored like the .so) spares every process that compilation
+    os.environ.setdefault("ROCFFT_RTC_CACHE_PATH", os.path.join(HERE, "rocfft_rtc_cache.db"))
     if not os.path.exists(LIB_PATH):
         raise X3dError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
                        " (the HIP backend has no CPU fallback)")
