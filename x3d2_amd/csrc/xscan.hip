@@ -28,6 +28,12 @@
 #endif
 #endif
 
+// nontemporal loads / stores of the rhs rows in the three-in-one tile kernel (-DYT_NO_NT: plain): same-box A/B
+// k_ytile_transeq3 z 2.21 -> 2.16 ms, y 2.24 -> 2.23; full step at 512^3 within noise, at 256^3 5.52 -> 5.44 ms
+#ifndef YT_NO_NT
+#define YT_NT 1
+#endif
+
 #ifndef XSCAN_EXP
 #define XSCAN_EXP 0  // timing experiments only (1: no stores, 2: no loads, 3: no scans)
 #endif
@@ -1025,7 +1031,17 @@ __global__ void __launch_bounds__(1024)
                     atomicAdd(&g_yt[24 + wave], t_ - yt_s0);
                 }
 #endif
+#ifdef YT_NT
+                if (ACC) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        const double *q_ = reinterpret_cast<const double *>(tile_row(o, prow, i, voff));
+                        old[i] = make_double2(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1));
+                    }
+                }
+#else
                 if (ACC) gload(old, o);
+#endif
                 double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
 #pragma unroll
                 for (int m = 0; m < Q / 2; m++)
@@ -1036,7 +1052,15 @@ __global__ void __launch_bounds__(1024)
                 for (int i = 0; i < NI; i++) {
                     double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                     if (ACC) { v.x += old[i].x; v.y += old[i].y; }
+#ifdef YT_NT
+                    {
+                        double *q_ = reinterpret_cast<double *>(const_cast<double2 *>(tile_row(o, prow, i, voff)));
+                        __builtin_nontemporal_store(v.x, q_);
+                        __builtin_nontemporal_store(v.y, q_ + 1);
+                    }
+#else
                     *const_cast<double2 *>(tile_row(o, prow, i, voff)) = v;
+#endif
                 }
             }
             YT_T(6);
