@@ -131,7 +131,14 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
     x3d_sfft *p = new x3d_sfft();
     memset(p, 0, sizeof *p);
     p->b = b;
-    p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2]; p->nxs = nglob[0] / 2 + 1;
+    p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2];
+    {
+        // spectral rows padded to 8 complex numbers (128 B) like the single-rank solver's: the 128 / 256-byte row
+        // segments of the strided passes are line-aligned (pad columns hold zeros, their wave numbers ones)
+        const char *e = getenv("X3D_NO_SPECTRAL_PAD");
+        const int nxm = nglob[0] / 2 + 1;
+        p->nxs = (e && e[0] == '1') ? nxm : (nxm + 7) / 8 * 8;
+    }
     p->pz = pz; p->rz = rz; p->zl = p->nz / pz; p->ys = p->ny / pz;
     X3D_REQUIRE(parts >= 1 && p->ys % parts == 0, "x3d_sfft_create: %d y modes per rank do not split into %d parts",
                 p->ys, parts);
@@ -143,6 +150,7 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
     X3D_REQUIRE(p->nx <= b->nxp && p->ny == b->nyp && p->zl <= b->nzp, "x3d_sfft_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs;
     X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
+    X3D_HIP(hipMemset(p->c0, 0, sizeof(double2) * n0));  // (the pad columns stay zero: the x transforms never write them)
     X3D_HIP(hipMalloc(&p->t, sizeof(double2) * (size_t)p->nz * p->ys * p->nxs));
     X3D_HIP(hipMalloc(&p->waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs));
     X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));

@@ -576,7 +576,9 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         self.chunk, self.zl, self.ys, nxs = [int(v) for v in sz]
         ysl = slice(self.rz * self.ys, (self.rz + 1) * self.ys)
         wl = np.ascontiguousarray(np.transpose(self.waves_block(slice(None), ysl), (1, 2, 0)),
-                                  dtype=np.float64)  # [ys][nxs][nz], z fastest
+                                  dtype=np.float64)  # [ys][nx/2+1][nz], z fastest
+        if nxs > wl.shape[1]:  # the library pads the spectral rows (pad columns: zeros, wave numbers one)
+            wl = np.ascontiguousarray(np.pad(wl, ((0, 0), (0, nxs - wl.shape[1]), (0, 0)), constant_values=1.0))
         self._keep = [wl] + [np.ascontiguousarray(a, dtype=np.float64) for a in
                              (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_sfft_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
