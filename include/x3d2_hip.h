@@ -102,6 +102,12 @@ int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tds
  * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
 int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+/* fusion extension for the 010 Poisson solve: the z pair next to the solver interleaves the y rows the way
+ * enforce_periodicity_y / undo_periodicity_y do (src/backend/cuda/kernels/spectral_processing.f90:1062-1114, ny even):
+ * mode 0 writes out1's y rows [0, ny) at their interleaved positions, mode 1 reads in1's rows from there.
+ * *done = 0: not served for these pencils, nothing was done. */
+int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                             const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done);
 /* ---- compact10_penta: 10th-order first derivative with a pentadiagonal left-hand side (src/tdsops.f90:235-251,
  * LU factors preprocess_penta_dist :971-1103; kernels der_penta_full / der_penta_periodic,
  * src/backend/omp/kernels/distributed.f90:339-691; drivers exec_dist_penta_compact / _periodic,
@@ -199,6 +205,13 @@ int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, dou
                          const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                          const x3d_tdsops *der2nd_sym, const double *gu, const double *gv, const double *gw,
                          const x3d_tdsops *op_u, const x3d_tdsops *op_vw, double scale, int *done);
+/* fusion extension: transeq_x with the channel case's rotation forcing (src/case/channel.f90:191-207, there two
+ * vecadd's after transeq: du = du - omega v, dv = dv + omega u) applied to the x contribution inside the kernel: the
+ * y / z contributions are then accumulated onto the forced values (the same sum in another order).  *done = 0: not
+ * served for these pencils, nothing was done. */
+int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, const double *u, const double *v,
+                      const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                      const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, int *done);
 /* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
  * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
  * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below

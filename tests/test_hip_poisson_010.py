@@ -266,6 +266,75 @@ def test_channel_step_at_the_bench_pencil_lengths_vs_oracle():
     lib = _lib.load()
     case = _channel_steps((1024, 257, 16), "top-bottom", 0.259065151, True, 1)
     assert int(lib.x3d_backend_counter(case.solver.backend.h, 0)) >= 6  # x and y: three-in-one launches, 3 sub-steps
+    assert case.solver.n_rot_fused == 3  # the rotation forcing rode on K3w's transeq_x (k_xwide_transeq3<ROT>)
+    assert case.solver.n_interleaved == 0  # (16-row z pencils: not the tile kernel's; the bench's 512 are)
+
+
+def test_rotation_forcing_inside_transeq_x_vs_the_two_vecadds(monkeypatch):
+    """k_xwide_transeq3<ROT>: du = transeq_x(u) - omega v, dv = transeq_x(v) + omega u formed in the x kernel
+    against the reference's order (two vecadd's after the three directions, src/case/channel.f90:191-207):
+    the same sum in another order -- equal to round-off"""
+    dims = (1024, 33, 16)
+    fusedrot = _channel_steps(dims, "top-bottom", 0.259065151, True, 1)
+    assert fusedrot.solver.n_rot_fused == 3
+    monkeypatch.setenv("X3D_NO_ROT_FUSED", "1")
+    plain = _channel_steps(dims, "top-bottom", 0.259065151, True, 1)
+    assert plain.solver.n_rot_fused == 0
+    b1, b2 = fusedrot.solver.backend, plain.solver.backend
+    for a, c in zip((fusedrot.solver.u, fusedrot.solver.v, fusedrot.solver.w), (plain.solver.u, plain.solver.v, plain.solver.w)):
+        x, y = b1.get_field_data(a), b2.get_field_data(c)
+        assert np.max(np.abs(x - y)) < 1e-13 * max(np.max(np.abs(y)), 1.0)
+
+
+@pytest.mark.parametrize("dims", [(32, 17, 256), (16, 9, 512)])
+def test_z_pairs_interleave_the_y_rows_like_the_solvers_copy_kernels(dims):
+    """x3d_tds_solve_pair_yperm: divergence's last z pair writes the y rows where enforce_periodicity_y would put
+    them, gradient's first z pair reads them where the backward transform leaves them -- bit for bit the same as
+    the pair kernel followed / preceded by the copy kernel (tile kernel K3y: periodic z pencils of 256 / 512 rows;
+    other pencils are not served: the caller keeps the copies, second test below)"""
+    from x3d2_amd.common import DIR_C, DIR_Z
+    s = product_solver(dims)
+    b, al, z = s.backend, s.backend.allocator, s.zdirps
+    pf = b.poisson_fft
+    nyc = pf.interleaved_rows()
+    assert nyc == dims[1] - 1
+    rng = np.random.default_rng(5)
+    blk = [al.get_block(DIR_C) for _ in range(7)]
+    i1, i2, o1, o2, r1, r2, tmp = blk
+    for f in (i1, i2):
+        f.data.copy_(__import__("torch").from_numpy(rng.standard_normal(tuple(f.data.shape))).to(f.data.device))
+    for f in (o1, o2, r1, r2, tmp):
+        f.fill(0.0)
+    # mode 0: out = A(in1) + B(in2), rows interleaved on the way out
+    assert b.tds_pair_yperm(0, o1, None, i1, i2, z.interpl_v2p, z.stagder_v2p, nyc)
+    b.tds_pair(0, tmp, None, i1, i2, z.interpl_v2p, z.stagder_v2p, DIR_Z)
+    pf.enforce_periodicity_y(r1, tmp)
+    nx, ny, nz = dims
+    got, ref = b.get_field_data(o1), b.get_field_data(r1)
+    assert np.array_equal(got[:, :nyc, :], ref[:, :nyc, :])
+    # mode 1: out1 = A(in1), out2 = B(in1), in1's rows read through the interleave
+    assert b.tds_pair_yperm(1, o1, o2, i1, None, z.interpl_p2v, z.stagder_p2v, nyc)
+    pf.undo_periodicity_y(tmp, i1)
+    b.tds_pair(1, r1, r2, tmp, None, z.interpl_p2v, z.stagder_p2v, DIR_Z)
+    for g, r in ((o1, r1), (o2, r2)):
+        got, ref = b.get_field_data(g), b.get_field_data(r)
+        assert np.array_equal(got[:, :nyc, :], ref[:, :nyc, :])
+    for f in blk:
+        al.release_block(f)
+
+
+@pytest.mark.parametrize("dims,taken", [((32, 17, 256), True), ((48, 33, 24), False)])
+def test_fused_channel_step_with_and_without_the_interleaving_pairs(dims, taken, monkeypatch):
+    """the fused pressure correction with the solver's two copy kernels folded into the z pairs == the same step
+    with the copies (X3D_NO_YPERM=1), bit for bit; and against the oracle.  24-row z pencils are not served by the
+    tile kernel: the driver keeps the copies by itself."""
+    case = _channel_steps(dims, "top-bottom", 0.259065151, True, 2)
+    assert case.solver.n_interleaved == (6 if taken else 0)
+    monkeypatch.setenv("X3D_NO_YPERM", "1")
+    plain = _channel_steps(dims, "top-bottom", 0.259065151, True, 2)
+    assert plain.solver.n_interleaved == 0
+    for a, c in zip((case.solver.u, case.solver.v, case.solver.w), (plain.solver.u, plain.solver.v, plain.solver.w)):
+        assert np.array_equal(case.solver.backend.get_field_data(a), plain.solver.backend.get_field_data(c))
 
 
 def _channel_steps(dims, stretching, beta, fused, nsteps):

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "x3d_pack_halos": (I, [VP, VP, VP, VP, I, I]),
     "x3d_tds_dist_fwd": (I, [VP, VP, VP, VP, VP, VP, VP, VP, I]),
     "x3d_tds_solve_pair": (I, [VP, I, I, VP, VP, VP, VP, VP, VP]),
+    "x3d_tds_solve_pair_yperm": (I, [VP, I, VP, VP, VP, VP, VP, VP, I, c_int_p]),
     "x3d_tdsops_halo_rows": (I, [VP, c_int_p]),
     "x3d_halo_row_size": (ctypes.c_long, [VP, I]),
     "x3d_pack_halos_multi": (I, [VP, VP, ctypes.POINTER(VP), I, I, I]),
@@ -78,6 +79,7 @@ PROTOTYPES = {
     "x3d_field_shift": (I, [VP, VP, D]),
     "x3d_backend_counter": (ctypes.c_long, [VP, I]),
     "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
+    "x3d_transeq_x_rot": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, D, c_int_p]),
     "x3d_transeq_x_update": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, VP, VP, VP, VP, VP, D, c_int_p]),
     "x3d_transeq_defer": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, c_int_p]),
     "x3d_pending_flush": (I, [VP, I, VP, VP]),

@@ -498,6 +498,17 @@ class HipBackend:
                                                  op_u.handle, op_vw.handle, float(scale), ctypes.byref(flag)))
         return bool(flag.value)
 
+    def transeq_x_rot(self, du, dv, dw, u, v, w, nu, dirps, omega):
+        """transeq_x with the channel's rotation forcing (du -= omega v, dv += omega u, src/case/channel.f90:191-207)
+        applied inside the kernel (csrc/xwide.hip, k_xwide_transeq3<ROT>); False: not served, nothing was done"""
+        if self._decomposed(DIR_X):
+            return False
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_x_rot(self.h, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
+                                              dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                              dirps.der2nd_sym.handle, float(omega), ctypes.byref(flag)))
+        return bool(flag.value)
+
     def transeq_dir_defer(self, direction, pend, u, v, w, nu, dirps):
         """transeq_dir(accumulate=True) with the accumulation left pending (csrc/viax.hip): the results stay in
         the blocks `pend` (pencil layout) until lincomb_pending / pending_flush.  False: not applicable here,
@@ -576,6 +587,19 @@ class HipBackend:
         _lib.check(self.lib.x3d_tds_solve_pair(self.h, direction, int(mode), out1.ptr,
                                                out2.ptr if out2 is not None else None, in1.ptr,
                                                in2.ptr if in2 is not None else None, t_a.handle, t_b.handle))
+
+    def tds_pair_yperm(self, mode, out1, out2, in1, in2, t_a, t_b, ny):
+        """tds_pair along z next to the 010 Poisson solve, doing the solver's interleave of the first ny y rows on
+        the way (mode 0: on out1, = enforce_periodicity_y of the result; mode 1: on in1, = undo_periodicity_y
+        before the operators); False: not served for these pencils, nothing was done"""
+        if self._decomposed(DIR_Z) or os.environ.get("X3D_NO_YPERM") == "1":
+            return False
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_tds_solve_pair_yperm(self.h, int(mode), out1.ptr,
+                                                     out2.ptr if out2 is not None else None, in1.ptr,
+                                                     in2.ptr if in2 is not None else None, t_a.handle, t_b.handle,
+                                                     int(ny), ctypes.byref(flag)))
+        return bool(flag.value)
 
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""

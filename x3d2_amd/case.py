@@ -213,8 +213,18 @@ class ChannelCase(BaseCase):
                 b.wall_noise(f, n, self.noise_seed, 3 * self.noise_draws + c)
             self.noise_draws += 1
 
+    def substep(self, it, last=True):
+        c, s = self.channel_cfg, self.solver
+        # fused driver: the rotation forcing is offered to transeq_x's kernel (Solver.transeq_fused); forcings()
+        # below applies it with the reference's two vecadd's when that kernel did not take it
+        s.rot_request = c.omega_rot if (s.fused and c.rotation and it < c.n_rotate) else 0.0
+        super().substep(it, last)
+
     def forcings(self, du, dv, dw, it):  # :191-207
         c, s = self.channel_cfg, self.solver
+        if s.rot_applied:
+            s.rot_applied = False
+            return
         if c.rotation and it < c.n_rotate:
             s.backend.vecadd(-c.omega_rot, s.v, 1.0, du)
             s.backend.vecadd(c.omega_rot, s.u, 1.0, dv)

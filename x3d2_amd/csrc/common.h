@@ -71,6 +71,7 @@ struct x3d_backend {
     hipEvent_t ev0, ev1;
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
     unsigned prof_mask;     // kernel classes that are timed while the timers are on (bit = X3D_K_*; x3d_prof_select)
+    int pair_yperm;          // > 0 during x3d_tds_solve_pair_yperm: the z pair kernels permute that many y rows
     void *lds_optin;        // kernels of this backend's device whose dynamic-LDS limit has been raised (backend.hip)
 };
 

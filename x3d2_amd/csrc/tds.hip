@@ -650,7 +650,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 // xdir.hip
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       bool *done);  // xwide.hip
+                       double omega, bool *done);  // xwide.hip
 int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
                   const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // ygen.hip
 int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
@@ -786,6 +786,36 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
     }
     if (int rc = x3d_tds_solve_acc(b, out1, in1, ta, dir, 0, 1.0)) return rc;
     return mode == 0 ? x3d_tds_solve_acc(b, out1, in2, tb, dir, 1, 1.0) : x3d_tds_solve_acc(b, out2, in1, tb, dir, 0, 1.0);
+}
+
+// fusion extension for the 010 Poisson solve (non-periodic y): the z pair next to the solver does the solver's
+// interleave of the y rows on the way (enforce_periodicity_y / undo_periodicity_y,
+// src/backend/cuda/kernels/spectral_processing.f90:1062-1114, ny even: row 2j-1 <-> position j, row 2j <->
+// position ny-j+1, 1-based).  mode 0 (divergence's last pair): out1's y rows [0, ny) are written at their
+// positions = what enforce_periodicity_y would have made of the result; mode 1 (gradient's first pair): in1's y rows
+// are read from their positions = in1 is what the solver's backward transform left, undo_periodicity_y not run.
+// *done = 0: these pencils are not served by a tile kernel, nothing was done (run the copies + x3d_tds_solve_pair).
+extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1,
+                                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done)
+{
+    X3D_REQUIRE(b && out1 && in1 && ta && tb && done && (mode == 0 ? in2 != nullptr : out2 != nullptr),
+                "x3d_tds_solve_pair_yperm: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_solve_pair_yperm: mode must be 0 or 1");
+    X3D_REQUIRE(out1 != in1 && out1 != in2 && out2 != in1 && (mode == 0 || out1 != out2),
+                "x3d_tds_solve_pair_yperm: outputs alias inputs");
+    X3D_REQUIRE(ny > 0 && ny <= b->ny, "x3d_tds_solve_pair_yperm: ny = %d outside the block (%d rows)", ny, b->ny);
+    *done = 0;
+    if (int rc = check_len(b, ta, X3D_DIR_Z, "tds_solve_pair_yperm")) return rc;
+    if (int rc = check_len(b, tb, X3D_DIR_Z, "tds_solve_pair_yperm")) return rc;
+    if (ny & 1) return 0;  // (the odd-size interleave keeps a centre row: the copy kernels handle it)
+    bool ok = false;
+    b->pair_yperm = ny;
+    int rc = x3d_ytile_tds_pair(b, X3D_DIR_Z, mode, out1, out2, in1, in2, ta, tb, nullptr, 0, -1, &ok);
+    if (!rc && !ok) rc = x3d_ygen_pair(b, X3D_DIR_Z, mode, out1, out2, in1, in2, ta, tb, &ok);
+    b->pair_yperm = 0;
+    if (rc) return rc;
+    *done = ok ? 1 : 0;
+    return 0;
 }
 
 int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
@@ -992,7 +1022,7 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
                                         0.0, &done))
             return rc;
         if (done) return 0;
-        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, &done)) return rc;  // n = 1024
+        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, 0.0, &done)) return rc;  // n = 1024
         if (done) return 0;
     }
     if (dir != X3D_DIR_X) {
@@ -1039,6 +1069,31 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
     bool ok = false;
     if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, g, op_u, op_vw, scale, &ok))
         return rc;
+    *done = ok ? 1 : 0;
+    return 0;
+}
+
+// fusion extension: transeq_x (du, dv, dw written) with the channel case's rotation forcing on top
+// (src/case/channel.f90:191-207: du = du - omega v, dv = dv + omega u -- there two vecadd's after transeq; here
+// applied to the x contribution, so the y / z contributions are added to the forced values: the same sum in
+// another order, round-off level).  *done = 0: not served for these pencils, nothing was done (issue x3d_transeq
+// and, after the other directions, x3d_vecadd x 2).  Served: 1024-row periodic x pencils (K3w).
+extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, const double *u, const double *v,
+                                 const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                 const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, int *done)
+{
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
+                "x3d_transeq_x_rot: null argument");
+    *done = 0;
+    if (int rc = transeq_check(b, X3D_DIR_X, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = transeq_check(b, X3D_DIR_X, der1st_sym, der1st, der2nd_sym)) return rc;
+    double *r[3] = {du, dv, dw};
+    const double *f[3] = {u, v, w};
+    for (int c = 0; c < 3; c++)
+        X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_x_rot: outputs alias inputs");
+    if (omega == 0.0) return 0;
+    bool ok = false;
+    if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, omega, &ok)) return rc;
     *done = ok ? 1 : 0;
     return 0;
 }

@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(1024)
 template <int Q, int MODE, bool NARROW, bool HALO>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
-                     XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th)
+                     XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn)
 {
     extern __shared__ double lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
@@ -1159,6 +1159,16 @@ __global__ void __launch_bounds__(1024)
         }
     };
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    // permn > 0 (z pencils, tl / ntx = the y row): the y rows of the 010 Poisson solver's input / output are
+    // interleaved (enforce / undo_periodicity_y, src/backend/cuda/kernels/spectral_processing.f90:1062-1114: row
+    // 2j-1 <-> position j, row 2j <-> position ny-j+1, 1-based): MODE 0 writes its result at the row's position,
+    // MODE 1 reads its input there -- the two copy kernels of the solver are not launched
+    auto tile_off_p = [&](int tl) {
+        int r = tl / ntx;
+        if (permn > 0 && r < permn) r = (r & 1) ? permn - ((r + 1) >> 1) : (r >> 1);
+        return (long)r * pplane + (long)(tl % ntx) * 16;
+    };
+    auto in1_off = [&](int tl) { return MODE == 1 ? tile_off_p(tl) : tile_off(tl); };
     auto hload = [&](int tl, int f) {  // thread t < 128: halo value (pencil t >> 3, slot t & 7) of input f
         const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
         const long pp = (long)(tl / ntx) * th.hp + (long)(tl % ntx) * 16 + hw;
@@ -1168,7 +1178,7 @@ __global__ void __launch_bounds__(1024)
     double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
     double hnx = 0.0;
     if (!NOPREF && tile0 + (int)blockIdx.x < ntiles) {
-        gload(nxt, in1 + tile_off(tile0 + blockIdx.x));
+        gload(nxt, in1 + in1_off(tile0 + blockIdx.x));
         if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
     }
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
@@ -1182,7 +1192,7 @@ __global__ void __launch_bounds__(1024)
             if (HALO && threadIdx.x < 128) h2 = hload(tl, 1);
         }
         if (NOPREF) {
-            gload(nxt, in1 + off);
+            gload(nxt, in1 + in1_off(tl));
             if (threadIdx.x < 128) hnx = hload(tl, 0);
         }
         to_tile(nxt);
@@ -1196,7 +1206,7 @@ __global__ void __launch_bounds__(1024)
         if (!NOPREF) {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) {
-                gload(nxt, in1 + tile_off(tn));
+                gload(nxt, in1 + in1_off(tn));
                 if (HALO && threadIdx.x < 128) hnx = hload(tn, 0);
             }
         }
@@ -1214,7 +1224,7 @@ __global__ void __launch_bounds__(1024)
             for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
             put(ra);
             __syncthreads();
-            from_tile(out1 + off);
+            from_tile(out1 + tile_off_p(tl));
         } else if (MODE == 1) {
             put(ra);
             __syncthreads();
@@ -1582,12 +1592,14 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
+    const int permn = b->pair_yperm;
+    if (permn > 0 && (dir != X3D_DIR_Z || halo || mode == 2 || tile0 != 0)) return 0;
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_, H_)                                                                                      \
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_>));                                                   \
         hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
-                           in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th);         \
+                           in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn);  \
     } while (0)
 #define GOH(Q_, M_, N_) do { if (halo) GO(Q_, M_, N_, true); else GO(Q_, M_, N_, false); } while (0)
 #define GON(Q_, M_) do { if (narrow) GOH(Q_, M_, true); else GOH(Q_, M_, false); } while (0)

@@ -70,6 +70,20 @@ __device__ __forceinline__ void wide_store(double *__restrict__ orow, const doub
     }
 }
 
+// strip -> memory with c * (another field's rows, as wide_gload delivered them) added
+__device__ __forceinline__ void wide_store_add(double *__restrict__ orow, const double *strip, int lane, double c,
+                                               const double (&add)[16])
+{
+    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow) + lane;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double2 v = *reinterpret_cast<const double2 *>(strip + wide_coal_off(lane, m));
+        v.x = c * add[2 * m] + 1.0 * v.x;
+        v.y = c * add[2 * m + 1] + 1.0 * v.y;
+        o2[64 * m] = v;
+    }
+}
+
 // one operator on the window w: r = its tds_solve rows (closed with the periodic self-exchange)
 template <bool NARROW>
 __device__ __forceinline__ void wide_solve(const double (&w)[WQ + 8], double (&r)[WQ], const double *__restrict__ lt,
@@ -129,11 +143,14 @@ __global__ void __launch_bounds__(512) k_xwide_tds(double *__restrict__ du, cons
 // (u0, conv = u0), (u1, u0), (u2, u0) as in k_xscan_transeq2x3 (src/backend/omp/backend.f90:145-184,
 // exec_dist.f90:85-169 per component): the pencil's rows of the advecting velocity stay in registers, 6 field
 // passes for the direction.  der1st == der1st_sym and der2nd == der2nd_sym as lane tables (periodic operators).
-template <bool ACC, bool NARROW>
+// ROT: the channel case's rotation forcing on top (src/case/channel.f90:191-207: du -= omega v, dv += omega u,
+// there two vecadd's after the three directions = 6 field passes): v's rows are in flight when du is stored, u's
+// rows are in registers when dv is formed -- no extra traffic.
+template <bool ACC, bool NARROW, bool ROT = false>
 __global__ void __launch_bounds__(512)
     k_xwide_transeq3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
                      const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1,
-                     XOp tD2, int np, long pitch, double nu)
+                     XOp tD2, int np, long pitch, double nu, double omega)
 {
     extern __shared__ double lt[];
     constexpr int LN = LTC_N(WQ), Q = WQ, LS = LTC_LS;
@@ -189,10 +206,15 @@ __global__ void __launch_bounds__(512)
             wide_solve<NARROW>(wu, T, l3, tD2, lane, ll);  // d2u/dx2
 #pragma unroll
             for (int q = 0; q < WQ; q++) r[q] += nu * T[q];
+            if (ROT && c == 1) {
+#pragma unroll
+                for (int q = 0; q < WQ; q++) r[q] = omega * cb[q] + 1.0 * r[q];
+            }
             wave_lds_fence();
             wide_put_rows(strip, r, lane);
             wave_lds_fence();
-            wide_store<ACC>((c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + ro, strip, lane, 1.0);
+            if (ROT && c == 0) wide_store_add(rhs0 + ro, strip, lane, -omega, nxt);  // (nxt = this pencil's u1 rows)
+            else wide_store<ACC>((c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + ro, strip, lane, 1.0);
             wave_lds_fence();
         }
     }
@@ -253,9 +275,10 @@ int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
 // transeq_x in one launch; f[0] is the advecting component
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       bool *done)
+                       double omega, bool *done)
 {
     *done = false;
+    if (omega != 0.0 && acc) return 0;
     if (!wide_env_on() || !wide_ok(b, der1st) || !wide_ok(b, der1st_sym) || !wide_ok(b, der2nd) || !wide_ok(b, der2nd_sym))
         return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
@@ -265,14 +288,15 @@ int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f
     const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd);
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
-#define GO(A_, N_)                                                                                              \
+#define GO(A_, N_, R_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_>));                                                           \
-        hipLaunchKernelGGL((k_xwide_transeq3<A_, N_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], f[0], \
-                           f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu);               \
+        X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_, R_>));                                                       \
+        hipLaunchKernelGGL((k_xwide_transeq3<A_, N_, R_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu, omega);  \
     } while (0)
-        if (acc) { if (narrow) GO(true, true); else GO(true, false); }
-        else { if (narrow) GO(false, true); else GO(false, false); }
+        if (omega != 0.0) { if (narrow) GO(false, true, true); else GO(false, false, true); }
+        else if (acc) { if (narrow) GO(true, true, false); else GO(true, false, false); }
+        else { if (narrow) GO(false, true, false); else GO(false, false, false); }
 #undef GO
     }
     X3D_HIP(hipGetLastError());

@@ -109,7 +109,7 @@ template <int Q> struct GenTile {
 template <int Q, int MODE, bool NARROW>
 __global__ void __launch_bounds__(1024)
     k_ygen_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2, XOp ta, XOp tb,
-                int ntx, int ntiles, long prow, long pplane, int nrow)
+                int ntx, int ntiles, long prow, long pplane, int nrow, int permn)
 {
     using G = GenGeom<Q>;
     extern __shared__ double lt[];
@@ -127,9 +127,16 @@ __global__ void __launch_bounds__(1024)
     GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x >> 3), (int)(threadIdx.x & 7),
                  nrow, prow};
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    // permn > 0: y rows interleaved for the 010 Poisson solver (see k_ytile_tds_pair): MODE 0 writes, MODE 1 reads there
+    auto tile_off_p = [&](int tl) {
+        int r = tl / ntx;
+        if (permn > 0 && r < permn) r = (r & 1) ? permn - ((r + 1) >> 1) : (r >> 1);
+        return (long)r * pplane + (long)(tl % ntx) * 16;
+    };
+    auto in1_off = [&](int tl) { return MODE == 1 ? tile_off_p(tl) : tile_off(tl); };
     __syncthreads();
     double nxt[2 * G::NI];  // next tile's in1 rows, in flight during the solves
-    if ((int)blockIdx.x < ntiles) T.gload(nxt, in1 + tile_off(blockIdx.x));
+    if ((int)blockIdx.x < ntiles) T.gload(nxt, in1 + in1_off(blockIdx.x));
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         asm volatile("" : "+v"(lane));
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(1024)
         if (MODE == 0) __syncthreads();  // all windows read: the second input may overwrite the tile
         {
             const int tn = tl + gridDim.x;
-            if (tn < ntiles) T.gload(nxt, in1 + tile_off(tn));
+            if (tn < ntiles) T.gload(nxt, in1 + in1_off(tn));
         }
         gen_solve<Q, NARROW>(w, ra, lt, cs, ta, lane);
         if (MODE == 0) {
@@ -159,7 +166,7 @@ __global__ void __launch_bounds__(1024)
         }
         T.put(ra);  // (a wave only rewrites its own pencil's rows, which only it reads)
         __syncthreads();
-        T.template from_tile<false>(out1 + off, ta.n_tds, none);
+        T.template from_tile<false>(out1 + (MODE == 0 ? tile_off_p(tl) : off), ta.n_tds, none);
         if (MODE == 1) {
             __syncthreads();
             T.put(rb);
@@ -306,13 +313,15 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
     const GenLaunch g = gen_launch(b, dir);
     const x3d_tdsops *tb_ = mode == 2 ? ta : tb;
     const bool narrow = ta->narrow_all && tb_->narrow_all;
+    const int permn = b->pair_yperm;
+    if (permn > 0 && (dir != X3D_DIR_Z || mode == 2)) return 0;
     {
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_)                                                                                          \
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_, N_>));                                                            \
         hipLaunchKernelGGL((k_ygen_pair<Q_, M_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
-                           xop_of(ta), xop_of(tb_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow);             \
+                           xop_of(ta), xop_of(tb_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, permn);      \
     } while (0)
 #define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)

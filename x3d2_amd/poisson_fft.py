@@ -322,6 +322,21 @@ class HipPoissonFFT:
     def solve_poisson(self, f, temp):  # :206-214
         self.poisson(f, temp)
 
+    def interleaved_rows(self):
+        """> 0: poisson_010 without its two row-interleaving copies is on offer (solve_interleaved): the caller's z
+        operators next to the solve write / read that many y rows at their interleaved positions themselves
+        (HipBackend.tds_pair_yperm)"""
+        if type(self) is HipPoissonFFT and self.case == "010" and self.ny_glob % 2 == 0:
+            return self.ny_glob
+        return 0
+
+    def solve_interleaved(self, f):
+        """poisson_010 (:228-242) on a field whose y rows are already in enforce_periodicity_y's order; the result
+        is left in that order (undo_periodicity_y not applied), in place"""
+        self.fft_forward(f)
+        self.fft_postprocess_010()
+        self.fft_backward(f)
+
     # ---- test hooks
     def get_spectral(self):
         out = np.empty((self.nz_spec, self.ny_spec, self.nx_spec), dtype=np.complex128)

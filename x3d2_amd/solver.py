@@ -96,6 +96,8 @@ class Solver:
         else:
             raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
         self.pending_grad = None
+        self.rot_request, self.rot_applied = 0.0, False  # rotation forcing handed to transeq_x (transeq_fused)
+        self.n_rot_fused = self.n_interleaved = 0        # how often those two fusions were taken (tests)
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
         backend.before_read.append(self.flush_grad)
         self.transeq = self.transeq_fused if self.fused else self.transeq_default
@@ -178,6 +180,8 @@ class Solver:
         du, dv, dw = rhs[:3]
         u, v, w = variables[:3]
         b.mesh.get_n(DIR_X, u.data_loc)
+        # a rotation forcing the case asked for (ChannelCase.substep) can ride on the x kernel
+        rot, self.rot_request, self.rot_applied = self.rot_request, 0.0, False
         if self.pending_grad is not None:
             # the previous sub-step's velocity correction is still pending (pressure_correction_fused(defer_grad)):
             # the x kernel applies it to each pencil before using it
@@ -188,6 +192,10 @@ class Solver:
                 b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
             for f in g:
                 b.allocator.release_block(f)
+        elif rot != 0.0 and os.environ.get("X3D_NO_ROT_FUSED") != "1" and \
+                b.transeq_x_rot(du, dv, dw, u, v, w, self.nu, self.xdirps, rot):
+            self.rot_applied = True  # (ChannelCase.forcings: nothing left to do)
+            self.n_rot_fused += 1
         else:
             b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
         if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
@@ -280,28 +288,48 @@ class Solver:
         jy = [(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p),   # a1 = interpl(t1) + stagder(t2)
               (2, a2, None, t3, None, y.interpl_v2p, None)]
         jz = [(0, div, None, a1, a2, z.interpl_v2p, z.stagder_v2p)]
+        # 010 Poisson solve (non-periodic y): its interleave of the y rows before / after the transforms is done by
+        # the z pairs on either side (4 field passes less per solve); nil = rows to interleave, 0 = not on offer
+        nil = 0
+        if self.cfg.poisson_solver_type == "FFT" and not (b._decomposed(DIR_Y) or b._decomposed(DIR_Z)):
+            nil = getattr(b.poisson_fft, "interleaved_rows", lambda: 0)()
         if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
             self._div_grad_decomposed(jy, jz, forward=True)
         else:
             b.tds_pair(*jy[0], DIR_Y)
             b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
-            b.tds_pair(*jz[0], DIR_Z)
+            if nil and b.tds_pair_yperm(0, t2, None, a1, a2, z.interpl_v2p, z.stagder_v2p, nil):
+                div = t2  # (t2, t3 are free after the y stage) rows interleaved
+                self.n_interleaved += 1
+            else:
+                nil = 0
+                b.tds_pair(*jz[0], DIR_Z)
         # poisson: the cell-centred divergence is already Cartesian (no Z2C / C2Z)
         p = div
-        if self.cfg.poisson_solver_type == "FFT":
+        if nil:
+            b.poisson_fft.solve_interleaved(p)
+        elif self.cfg.poisson_solver_type == "FFT":
             b.poisson_fft.solve_poisson(p, t2)  # t2 is free here: scratch of poisson_010
         else:
             p.fill(0.0)
         # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
-        jz = [(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v)]    # p_sxy, dpdz_sxy
-        jy = [(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v),   # p_sx, dpdy_sx
-              (2, t1, None, t3, None, y.interpl_p2v, None)]          # dpdz_sx
-        if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
-            self._div_grad_decomposed(jy, jz, forward=False)
+        if nil:
+            # p = t2 in the solver's row order: read through the interleave; p_sxy -> t1, dpdz_sxy -> t3
+            if not b.tds_pair_yperm(1, t1, t3, p, None, z.interpl_p2v, z.stagder_p2v, nil):
+                raise X3dError("pressure_correction: the interleaving z pair served the divergence but not the gradient")
+            b.tds_pair(1, a1, a2, t1, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
+            b.tds_apply(t2, t3, y.interpl_p2v, DIR_Y)                              # dpdz_sx
+            t1, t2 = t2, t1  # (below: t1 = dpdz_sx, t2 and t3 free)
         else:
-            b.tds_pair(*jz[0], DIR_Z)
-            b.tds_pair(*jy[0], DIR_Y)
-            b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)
+            jz = [(1, t2, t3, p, None, z.interpl_p2v, z.stagder_p2v)]    # p_sxy, dpdz_sxy
+            jy = [(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v),   # p_sx, dpdy_sx
+                  (2, t1, None, t3, None, y.interpl_p2v, None)]          # dpdz_sx
+            if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
+                self._div_grad_decomposed(jy, jz, forward=False)
+            else:
+                b.tds_pair(*jz[0], DIR_Z)
+                b.tds_pair(*jy[0], DIR_Y)
+                b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)
         if (defer_grad and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_DEFER_GRAD") != "1"
                 and self.nspecies == 0):
             # the next sub-step's transeq_x applies the correction inside its own kernel (transeq_fused)
