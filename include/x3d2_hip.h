@@ -161,6 +161,11 @@ int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, doubl
  * back; otherwise the two calls one after the other.  y may be base. */
 int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
                           int nterm, const double *c, const double *const *x);
+/* fusion extension: the same with the y faces of y (vertex rows j = 0, ny-1) stamped from `wall` before the operator
+ * acts = x3d_lincomb ; x3d_field_set_face_from_field(y, wall, Y_FACE) ; x3d_tds_solve (the RK stage, the channel
+ * case's apply_BC, src/case/channel.f90:214-231, and the first x operator of divergence_v2c) */
+int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
+                               int nterm, const double *c, const double *const *x, const double *wall);
 
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):

@@ -562,17 +562,24 @@ class HipBackend:
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
         self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
 
-    def tds_lincomb(self, du, tdsops, direction, y, base, coeffs, xs):
+    def tds_lincomb(self, du, tdsops, direction, y, base, coeffs, xs, wall=None):
         """y = base + sum c_i x_i (lincomb) and du = tds_solve(y) in one kernel where the pencils allow
-        (csrc/xscan.hip, k_xscan_tds_lin: y is not read back)"""
+        (csrc/xscan.hip k_xscan_tds_lin, csrc/xwide.hip k_xwide_tds_lin: y is not read back).  wall: the y faces of y
+        take that field's values before the operator acts (field_set_face_from_field(y, wall, 0, Y_FACE))"""
         if self._decomposed(direction):
             self.lincomb(y, base, coeffs, xs)
+            if wall is not None:
+                self.field_set_face_from_field(y, wall, 0.0, Y_FACE)
             self.tds_apply(du, y, tdsops, direction)
             return
         n = len(xs)
         c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
-        _lib.check(self.lib.x3d_tds_solve_lincomb(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p))
+        if wall is None:
+            _lib.check(self.lib.x3d_tds_solve_lincomb(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p))
+        else:
+            _lib.check(self.lib.x3d_tds_solve_lincomb_wall(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr,
+                                                           n, c, p, wall.ptr))
 
     def tds_pair(self, mode, out1, out2, in1, in2, t_a, t_b, direction):
         """two tds_solve's that share an output (mode 0: out1 = A(in1) + B(in2)) or an input

@@ -63,6 +63,11 @@ class BaseCase:
     def apply_BC(self, u, v, w):
         pass
 
+    def deferred_walls(self):
+        """three fields whose y faces are ALL that apply_BC would stamp on u, v, w (then the fused driver does it
+        inside the kernels that form the new velocity), or None: apply_BC has to run as it is"""
+        return None
+
     def postprocess(self, it, t):
         return self.monitoring.write_step(t, self.solver.u, self.solver.v, self.solver.w)
 
@@ -75,8 +80,10 @@ class BaseCase:
         deriv = [al.get_block(DIR_X) for _ in range(s.nvars)]
         # nothing reads the new velocity between the stage and the pressure correction when the case has no
         # BC hook: its update may then be formed inside the pressure correction's first kernels
-        defer_upd = (s.fused and type(self).apply_BC is BaseCase.apply_BC and os.environ.get("X3D_NO_DEFER") != "1"
-                     and s.time_integrator.sname.upper().startswith("RK"))
+        # (a case whose BC hook only stamps wall values hands them over instead: deferred_walls)
+        walls = self.deferred_walls() if s.fused and os.environ.get("X3D_NO_DEFER_WALLS") != "1" else None
+        defer_upd = (s.fused and (type(self).apply_BC is BaseCase.apply_BC or walls is not None)
+                     and os.environ.get("X3D_NO_DEFER") != "1" and s.time_integrator.sname.upper().startswith("RK"))
         if s.fused and type(self).forcings is BaseCase.forcings:
             # nothing touches the derivatives between transeq and the RK / AB stage: the last accumulation of
             # transeq may be folded into the stage's linear combination (Solver.transeq_fused)
@@ -93,7 +100,10 @@ class BaseCase:
             for f in deriv:
                 al.release_block(f)
             deriv = []
-        self.apply_BC(s.u, s.v, s.w)
+        if defer_upd and walls is not None:
+            s.pending_walls = walls  # apply_BC happens inside the pressure correction's first kernels
+        else:
+            self.apply_BC(s.u, s.v, s.w)
         # not the last sub-step of the step and no hook looks at the velocity before the next transeq: its
         # pressure-gradient correction can wait for that kernel (Solver.transeq_fused)
         defer_grad = (not last and s.fused and type(self).define_BC is BaseCase.define_BC
@@ -228,6 +238,9 @@ class ChannelCase(BaseCase):
         if c.rotation and it < c.n_rotate:
             s.backend.vecadd(-c.omega_rot, s.v, 1.0, du)
             s.backend.vecadd(c.omega_rot, s.u, 1.0, dv)
+
+    def deferred_walls(self):
+        return self.bc_start_y
 
     def apply_BC(self, u, v, w):  # :214-231
         b = self.solver.backend

@@ -819,28 +819,55 @@ extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, 
 }
 
 int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, bool *done);  // xscan.hip
+                          const double *c, const double *const *x, const double *wall, bool *done);  // xscan.hip
+int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
+                          const double *c, const double *const *x, const double *wall, bool *done);  // xwide.hip
+extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
+                                             double c_end, int face, double flow_rate_diff);
 extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
                            const double *const *x);
 
 // fusion extension: y = base + sum_i c[i] x[i] (x3d_lincomb) followed by du = tds_solve(y), in one kernel for
 // periodic 256 / 512-point x pencils (y is not read back); otherwise the two calls one after the other
-extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
-                                     const double *base, int nterm, const double *c, const double *const *x)
+static int tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
+                                  int nterm, const double *c, const double *const *x, const double *wall)
 {
     X3D_REQUIRE(b && du && t && y && base && c && x, "x3d_tds_solve_lincomb: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve_lincomb: bad dir %d", dir);
     X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_tds_solve_lincomb: nterm must be 1..5");
-    X3D_REQUIRE(du != y && du != base, "x3d_tds_solve_lincomb: du aliases an input");
+    X3D_REQUIRE(du != y && du != base && du != wall && y != wall, "x3d_tds_solve_lincomb: du aliases an input");
     for (int k = 0; k < nterm; k++) X3D_REQUIRE(du != x[k], "x3d_tds_solve_lincomb: du aliases an input");
     if (int rc = check_len(b, t, dir, "tds_solve_lincomb")) return rc;
     if (dir == X3D_DIR_X) {
         bool done = false;
-        if (int rc = x3d_xscan_tds_lincomb(b, du, t, y, base, nterm, c, x, &done)) return rc;
+        if (int rc = x3d_xscan_tds_lincomb(b, du, t, y, base, nterm, c, x, wall, &done)) return rc;
+        if (done) return 0;
+        if (int rc = x3d_xwide_tds_lincomb(b, du, t, y, base, nterm, c, x, wall, &done)) return rc;  // n = 1024
         if (done) return 0;
     }
     if (int rc = x3d_lincomb(b, y, base, nterm, c, x)) return rc;
+    if (wall) {
+        const int dims[3] = {b->nx, b->ny, b->nz};
+        if (int rc = x3d_field_set_face_from_field(b, y, wall, dims, 0.0, X3D_Y_FACE, 0.0)) return rc;
+    }
     return x3d_tds_solve_acc(b, du, y, t, dir, 0, 1.0);
+}
+
+extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
+                                     const double *base, int nterm, const double *c, const double *const *x)
+{
+    return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, nullptr);
+}
+
+// the same with the y faces of y (vertex rows j = 0 and ny - 1) stamped from `wall` before the operator acts:
+// lincomb ; field_set_face_from_field(y, wall, Y_FACE) ; tds_solve -- RK stage, the channel case's apply_BC
+// (src/case/channel.f90:214-231) and the first x operator of divergence_v2c in one kernel where the pencils allow
+extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
+                                          const double *base, int nterm, const double *c, const double *const *x,
+                                          const double *wall)
+{
+    X3D_REQUIRE(wall, "x3d_tds_solve_lincomb_wall: null argument");
+    return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall);
 }
 
 extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)

@@ -238,14 +238,9 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 // (y = base + sum c_k x_k, src/time_integrator.f90:166-282 -> divergence_v2c, src/vector_calculus.f90:160-175).
 // Here the stage's linear combination is the kernel's prologue: y is formed in registers (summation order of
 // k_lincomb, bit-identical), stored, and solved at once -- y is not read back (one field pass less per variable).
-struct LinRows {
-    double *y;
-    const double *base;
-    const double *x[5];
-    double c[5];
-    int n;
-};
-
+// lr.wall != null: the pencils of the two y faces (j = 0, ny - 1) take the rows of `wall` instead
+// (field_set_face_from_field(Y_FACE) between the stage and the divergence: the channel case's apply_BC,
+// src/case/channel.f90:214-231)
 template <int Q, bool NARROW>
 __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
 {
@@ -269,6 +264,10 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, 
 #pragma unroll
                 for (int q = 0; q < Q; q++) b[q] = lr.c[k] * xk[q] + b[q];
             }
+        if (lr.wall) {
+            const int j = p % lr.ny;
+            if (j == 0 || j == lr.ny - 1) load_body<Q>(b, lr.wall + ro, lane);
+        }
         if constexpr (Q == 8) store_rows_q8<false>(lr.y + ro, lane, b, 1.0);
         else store_rows_q4<false>(lr.y + ro, lane, b, 1.0);
         double w[Q + 8], X[Q], du1, xn;
@@ -1759,7 +1758,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 
 // du = tdsops(y) with y = base + sum c_k x_k formed (and stored) by the same kernel; x direction
 int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, bool *done)
+                          const double *c, const double *const *x, const double *wall, bool *done)
 {
     *done = false;
     static int on = -1;
@@ -1776,7 +1775,7 @@ int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, doubl
     int blocks = (np + 7) / 8;
     blocks = blocks > 768 ? 768 : blocks;
     LinRows lr;
-    lr.y = y; lr.base = base; lr.n = nterm;
+    lr.y = y; lr.base = base; lr.n = nterm; lr.wall = wall; lr.ny = b->ny;
     for (int k = 0; k < 5; k++) { lr.x[k] = k < nterm ? x[k] : x[0]; lr.c[k] = k < nterm ? c[k] : 0.0; }
     const bool narrow = stencil_narrow(t);
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);

@@ -340,3 +340,15 @@ __device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b
         for (int m = 0; m < 4; m++) w[Q + 4 + m] = hl[4 + m];
     }
 }
+
+// y = base + sum_k c[k] x[k] as the prologue of an x operator (k_xscan_tds_lin, k_xwide_tds_lin); wall != null: the
+// pencils of the two y faces take `wall`'s rows instead (ny = rows per plane)
+struct LinRows {
+    double *y;
+    const double *base;
+    const double *x[5];
+    double c[5];
+    int n;
+    const double *wall;
+    int ny;
+};

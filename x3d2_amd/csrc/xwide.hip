@@ -139,6 +139,59 @@ __global__ void __launch_bounds__(512) k_xwide_tds(double *__restrict__ du, cons
     }
 }
 
+// ---------------------------------------------------------------- tds_solve of a field that is still to be formed
+// k_xscan_tds_lin for 1024-row pencils: y = base + sum c_k x_k (the RK stage, summation order of k_lincomb) formed on
+// the coalesced pieces, the y faces stamped from `wall` if given, y stored, du = tds_solve(y) -- y is not read back.
+template <bool NARROW>
+__global__ void __launch_bounds__(512) k_xwide_tds_lin(double *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
+{
+    extern __shared__ double lt[];
+    for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    double *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    const int ll = ltc_lane(lane);
+    for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
+        const long ro = (long)p * pitch;
+        asm volatile("" : "+v"(lane));
+        double v[16];
+        wide_gload(v, lr.base + ro, lane);
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (k < lr.n) {
+                double xk[16];
+                wide_gload(xk, lr.x[k] + ro, lane);
+#pragma unroll
+                for (int m = 0; m < 16; m++) v[m] = lr.c[k] * xk[m] + v[m];
+            }
+        if (lr.wall) {
+            const int j = p % lr.ny;
+            if (j == 0 || j == lr.ny - 1) wide_gload(v, lr.wall + ro, lane);
+        }
+        {
+            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(lr.y + ro) + lane;
+#pragma unroll
+            for (int m = 0; m < 8; m++) o2[64 * m] = make_double2(v[2 * m], v[2 * m + 1]);
+        }
+        double w[WQ + 8], r[WQ];
+        {
+            double b[WQ];
+            wide_to_strip(strip, v, lane);
+            wave_lds_fence();
+            wide_own_rows(b, strip, lane);
+            window_from_body<WQ>(w, b, lane);
+        }
+        wide_solve<NARROW>(w, r, lt, t, lane, ll);
+        wave_lds_fence();
+        wide_put_rows(strip, r, lane);
+        wave_lds_fence();
+        wide_store<false>(du + ro, strip, lane, 1.0);
+        wave_lds_fence();
+    }
+}
+
 // ---------------------------------------------------------------- transeq_x: the three components at once
 // (u0, conv = u0), (u1, u0), (u2, u0) as in k_xscan_transeq2x3 (src/backend/omp/backend.f90:145-184,
 // exec_dist.f90:85-169 per component): the pencil's rows of the advecting velocity stay in registers, 6 field
@@ -267,6 +320,36 @@ int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
     if (acc) { if (narrow) GO(true, true); else GO(true, false); }
     else { if (narrow) GO(false, true); else GO(false, false); }
 #undef GO
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+// y = base + sum c_k x_k ; y faces of y <- wall (if given) ; du = tds_solve(y) along x; *done = false: not served here
+int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
+                          const double *c, const double *const *x, const double *wall, bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_TDS_LINCOMB"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (!on || !wide_env_on() || !wide_ok(b, t)) return 0;
+    const int np = b->ny * b->nz;
+    const size_t lds = sizeof(double) * (LTC_N(WQ) + 8 * WSTRIP);
+    int blocks = (np + 7) / 8;
+    blocks = blocks > 256 ? 256 : blocks;
+    LinRows lr;
+    lr.y = y; lr.base = base; lr.n = nterm; lr.wall = wall; lr.ny = b->ny;
+    for (int k = 0; k < 5; k++) { lr.x[k] = k < nterm ? x[k] : x[0]; lr.c[k] = k < nterm ? c[k] : 0.0; }
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
+    if (wide_narrow(t)) {
+        X3D_LDS_OPTIN(b, (k_xwide_tds_lin<true>));
+        hipLaunchKernelGGL((k_xwide_tds_lin<true>), dim3(blocks), dim3(512), lds, b->stream, du, lr, wide_xop(t), np,
+                           (long)b->nxp);
+    } else {
+        X3D_LDS_OPTIN(b, (k_xwide_tds_lin<false>));
+        hipLaunchKernelGGL((k_xwide_tds_lin<false>), dim3(blocks), dim3(512), lds, b->stream, du, lr, wide_xop(t), np,
+                           (long)b->nxp);
+    }
     X3D_HIP(hipGetLastError());
     *done = true;
     return 0;

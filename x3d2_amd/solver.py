@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 from .common import (BC_DIRICHLET, BC_NEUMANN, CELL, DIR_C, DIR_X, DIR_Y, DIR_Z, RDR_C2Z, RDR_X2Y, RDR_X2Z,
-                     RDR_Z2C, VERT, X3dError)
+                     RDR_Z2C, VERT, Y_FACE, X3dError)
 from .tdsops import Dirps
 from .time_integrator import TimeIntegrator
 from .vector_calculus import VectorCalculus
@@ -98,6 +98,7 @@ class Solver:
         self.pending_grad = None
         self.rot_request, self.rot_applied = 0.0, False  # rotation forcing handed to transeq_x (transeq_fused)
         self.n_rot_fused = self.n_interleaved = 0        # how often those two fusions were taken (tests)
+        self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
         backend.before_read.append(self.flush_grad)
         self.transeq = self.transeq_fused if self.fused else self.transeq_default
@@ -276,13 +277,18 @@ class Solver:
         t1, t2, t3, a1, a2 = (al.get_block(DIR_X) for _ in range(5))
         # divergence_v2c, src/vector_calculus.f90:142-246
         # (a velocity update the time integrator left pending is formed by the operator's own kernel)
+        # (pending_walls: wall values the case left to be stamped on the new velocity, ChannelCase.deferred_walls)
         upd = self.time_integrator.pending_update
-        for out, fld, op in ((t1, u, x.stagder_v2p), (t2, v, x.interpl_v2p), (t3, w, x.interpl_v2p)):
+        walls, self.pending_walls = self.pending_walls or (None, None, None), None
+        for out, fld, op, wall in ((t1, u, x.stagder_v2p, walls[0]), (t2, v, x.interpl_v2p, walls[1]),
+                                   (t3, w, x.interpl_v2p, walls[2])):
             spec = upd.pop(fld.data.data_ptr(), None)
             if spec is None:
+                if wall is not None:
+                    b.field_set_face_from_field(fld, wall, 0.0, Y_FACE)
                 b.tds_apply(out, fld, op, DIR_X)
             else:
-                b.tds_lincomb(out, op, DIR_X, *spec)
+                b.tds_lincomb(out, op, DIR_X, *spec, wall=wall)
         self.time_integrator.flush_updates()
         div = t1
         jy = [(0, a1, None, t1, t2, y.interpl_v2p, y.stagder_v2p),   # a1 = interpl(t1) + stagder(t2)
