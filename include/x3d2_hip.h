@@ -213,10 +213,12 @@ int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, dou
 /* fusion extension: transeq_x with the channel case's rotation forcing (src/case/channel.f90:191-207, there two
  * vecadd's after transeq: du = du - omega v, dv = dv + omega u) applied to the x contribution inside the kernel: the
  * y / z contributions are then accumulated onto the forced values (the same sum in another order).  *done = 0: not
- * served for these pencils, nothing was done. */
-int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, const double *u, const double *v,
+ * served for these pencils, nothing was done.  u_shift != NULL: first u += *u_shift in place (the device scalar of
+ * x3d_field_mean_shift: second half of the bulk-velocity correction, bit-identical to x3d_field_shift_by). */
+int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, double *u, const double *v,
                       const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                      const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, int *done);
+                      const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, const double *u_shift,
+                      int *done);
 /* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
  * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
  * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below
@@ -302,6 +304,11 @@ int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3]
  *    (splitmix64 of seed + draw, then of that key + (face * nz + k) * nx + i; 53 bits) instead of the host's
  *    random_number planes and three full-block uploads per sub-step (:97-130) */
 int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target);
+/* its two halves: *shift = device address of target - volume_integral(f) / ncell (valid until the backend's next
+ * reduction) ; f += that device scalar (x3d_transeq_x_rot can do the second half inside its kernel) */
+int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
+                         const double **shift);
+int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift);
 int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
                    unsigned long long draw);
 int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,

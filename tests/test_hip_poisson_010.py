@@ -337,6 +337,39 @@ def test_fused_channel_step_with_and_without_the_interleaving_pairs(dims, taken,
         assert np.array_equal(case.solver.backend.get_field_data(a), plain.solver.backend.get_field_data(c))
 
 
+@pytest.mark.parametrize("omega", [0.12, 0.0])
+def test_bulk_velocity_shift_inside_transeq_x(omega):
+    """x3d_transeq_x_rot(u_shift): u += the device scalar of x3d_field_mean_shift inside K3w's transeq_x kernel ==
+    x3d_field_shift_by followed by the same kernel without it, bit for bit (u and du, dv, dw); together the two
+    halves == x3d_field_shift_to_mean"""
+    import torch
+    from x3d2_amd.common import DIR_X, VERT
+    s = product_solver((1024, 9, 8))
+    b, al = s.backend, s.backend.allocator
+    rng = np.random.default_rng(3)
+    blk = [al.get_block(DIR_X, VERT) for _ in range(13)]
+    u, v, w, u2, u3 = blk[:5]
+    d1, d2 = blk[5:8], blk[8:11]
+    for f in (u, v, w):
+        f.data.copy_(torch.from_numpy(rng.standard_normal(tuple(f.data.shape))).to(f.data.device))
+    u2.data.copy_(u.data)
+    u3.data.copy_(u.data)
+    sh = b.field_mean_shift(u, 2.0 / 3.0)
+    assert b.transeq_x_rot(*d1, u, v, w, s.nu, s.xdirps, omega, sh)
+    b.field_shift_by(u2, sh)  # (the scalar is still in place: no reduction since)
+    if omega != 0.0:
+        assert b.transeq_x_rot(*d2, u2, v, w, s.nu, s.xdirps, omega)
+    else:
+        b.transeq_dir(DIR_X, *d2, u2, v, w, s.nu, s.xdirps)
+    b.field_shift_to_mean(u3, 2.0 / 3.0)
+    assert np.array_equal(b.get_field_data(u, VERT), b.get_field_data(u2, VERT))
+    assert np.array_equal(b.get_field_data(u, VERT), b.get_field_data(u3, VERT))
+    for x, y in zip(d1, d2):
+        assert np.array_equal(b.get_field_data(x, VERT), b.get_field_data(y, VERT))
+    for f in blk:
+        al.release_block(f)
+
+
 @pytest.mark.parametrize("nx", [1024, 256, 48])
 def test_rk_stage_wall_values_and_first_x_operator_in_one_kernel(nx):
     """x3d_tds_solve_lincomb_wall (K3w at 1024-point pencils, K3s at 256, the three calls one after the other

@@ -80,7 +80,7 @@ PROTOTYPES = {
     "x3d_field_shift": (I, [VP, VP, D]),
     "x3d_backend_counter": (ctypes.c_long, [VP, I]),
     "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
-    "x3d_transeq_x_rot": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, D, c_int_p]),
+    "x3d_transeq_x_rot": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, D, VP, c_int_p]),
     "x3d_transeq_x_update": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, VP, VP, VP, VP, VP, D, c_int_p]),
     "x3d_transeq_defer": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, c_int_p]),
     "x3d_pending_flush": (I, [VP, I, VP, VP]),
@@ -91,6 +91,8 @@ PROTOTYPES = {
     "x3d_field_max_sum": (I, [VP, VP, c_int_p, c_double_p, c_double_p]),
     "x3d_field_volume_integral": (I, [VP, VP, c_int_p, c_double_p]),
     "x3d_field_shift_to_mean": (I, [VP, VP, c_int_p, D, D]),
+    "x3d_field_mean_shift": (I, [VP, VP, c_int_p, D, D, ctypes.POINTER(VP)]),
+    "x3d_field_shift_by": (I, [VP, VP, VP]),
     "x3d_wall_noise": (I, [VP, VP, c_int_p, D, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "x3d_slice_max_sum": (I, [VP, VP, c_int_p, I, I, c_double_p, c_double_p]),
     "x3d_field_set_face": (I, [VP, VP, c_int_p, D, D, I]),

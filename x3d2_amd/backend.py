@@ -498,15 +498,16 @@ class HipBackend:
                                                  op_u.handle, op_vw.handle, float(scale), ctypes.byref(flag)))
         return bool(flag.value)
 
-    def transeq_x_rot(self, du, dv, dw, u, v, w, nu, dirps, omega):
+    def transeq_x_rot(self, du, dv, dw, u, v, w, nu, dirps, omega, u_shift=None):
         """transeq_x with the channel's rotation forcing (du -= omega v, dv += omega u, src/case/channel.f90:191-207)
-        applied inside the kernel (csrc/xwide.hip, k_xwide_transeq3<ROT>); False: not served, nothing was done"""
+        applied inside the kernel (csrc/xwide.hip, k_xwide_transeq3<ROT>) and, with u_shift (field_mean_shift), the
+        bulk-velocity shift u += *u_shift done on the way; False: not served, nothing was done"""
         if self._decomposed(DIR_X):
             return False
         flag = ctypes.c_int(0)
         _lib.check(self.lib.x3d_transeq_x_rot(self.h, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
                                               dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
-                                              dirps.der2nd_sym.handle, float(omega), ctypes.byref(flag)))
+                                              dirps.der2nd_sym.handle, float(omega), u_shift, ctypes.byref(flag)))
         return bool(flag.value)
 
     def transeq_dir_defer(self, direction, pend, u, v, w, nu, dirps):
@@ -782,6 +783,25 @@ class HipBackend:
             self.field_shift(f, target - self.field_volume_integral(f) / ncell)
             return
         _lib.check(self.lib.x3d_field_shift_to_mean(self.h, f.ptr, self._dims(f.data_loc), ncell, float(target)))
+
+    def field_mean_shift(self, f, target):
+        """first half of field_shift_to_mean: the device address of target - volume_integral(f) / ncell_global (valid
+        until this backend's next reduction), for field_shift_by / transeq_x_rot; None: several ranks (host path)"""
+        if f.data_loc == NULL_LOC:
+            raise X3dError("You must set the data_loc before calling volume integral.")
+        if f.dir != DIR_X:
+            raise X3dError("Volume integral can only be called on DIR_X fields.")
+        if self.comm.size > 1:
+            return None
+        ncell = float(np.prod(self.mesh.get_global_dims(CELL)))
+        out = VP()
+        _lib.check(self.lib.x3d_field_mean_shift(self.h, f.ptr, self._dims(f.data_loc), ncell, float(target),
+                                                 ctypes.byref(out)))
+        return out
+
+    def field_shift_by(self, f, shift):
+        """f += the device scalar `shift` (field_mean_shift)"""
+        _lib.check(self.lib.x3d_field_shift_by(self.h, f.ptr, shift))
 
     def wall_noise(self, f, amp, seed, draw):
         """planes y = 1 and y = ny of the (VERT) wall field f <- amp * (2 r - 1), generated on the device"""

@@ -207,7 +207,12 @@ class ChannelCase(BaseCase):
 
     def define_BC(self):  # :53-137
         s, b = self.solver, self.solver.backend
-        b.field_shift_to_mean(s.u, 2.0 / 3.0)  # ub -> 2/3, no host round trip on one rank
+        # ub -> 2/3, no host round trip on one rank; fused driver: the shift itself is left to transeq_x's kernel
+        sh = b.field_mean_shift(s.u, 2.0 / 3.0) if s.fused and os.environ.get("X3D_NO_ROT_FUSED") != "1" else None
+        if sh is not None:
+            s.shift_request = sh
+        else:
+            b.field_shift_to_mean(s.u, 2.0 / 3.0)
         noise = self.channel_cfg.inlet_noise
         first = self.bc_start_y is None
         if first:

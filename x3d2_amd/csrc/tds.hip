@@ -650,7 +650,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 // xdir.hip
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       double omega, bool *done);  // xwide.hip
+                       double omega, const double *ushift, bool *done);  // xwide.hip
 int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
                   const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // ygen.hip
 int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
@@ -1049,7 +1049,7 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
                                         0.0, &done))
             return rc;
         if (done) return 0;
-        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, 0.0, &done)) return rc;  // n = 1024
+        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, 0.0, nullptr, &done)) return rc;  // n = 1024
         if (done) return 0;
     }
     if (dir != X3D_DIR_X) {
@@ -1103,11 +1103,14 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
 // fusion extension: transeq_x (du, dv, dw written) with the channel case's rotation forcing on top
 // (src/case/channel.f90:191-207: du = du - omega v, dv = dv + omega u -- there two vecadd's after transeq; here
 // applied to the x contribution, so the y / z contributions are added to the forced values: the same sum in
-// another order, round-off level).  *done = 0: not served for these pencils, nothing was done (issue x3d_transeq
-// and, after the other directions, x3d_vecadd x 2).  Served: 1024-row periodic x pencils (K3w).
-extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, const double *u, const double *v,
+// another order, round-off level).  u_shift != null: first u += *u_shift in place (device scalar of
+// x3d_field_mean_shift: the second half of the bulk-velocity correction, :70-77, bit-identical to x3d_field_shift_by).
+// *done = 0: not served for these pencils, nothing was done (issue x3d_field_shift_by, x3d_transeq and, after the
+// other directions, x3d_vecadd x 2).  Served: 1024-row periodic x pencils (K3w).
+extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, double *u, const double *v,
                                  const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                                 const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, int *done)
+                                 const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega,
+                                 const double *u_shift, int *done)
 {
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
                 "x3d_transeq_x_rot: null argument");
@@ -1118,9 +1121,9 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double 
     const double *f[3] = {u, v, w};
     for (int c = 0; c < 3; c++)
         X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_x_rot: outputs alias inputs");
-    if (omega == 0.0) return 0;
+    if (omega == 0.0 && !u_shift) return 0;
     bool ok = false;
-    if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, omega, &ok)) return rc;
+    if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, omega, u_shift, &ok)) return rc;
     *done = ok ? 1 : 0;
     return 0;
 }

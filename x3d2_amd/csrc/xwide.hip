@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(512) k_xwide_tds_lin(double *__restrict__ du, 
 template <bool ACC, bool NARROW, bool ROT = false>
 __global__ void __launch_bounds__(512)
     k_xwide_transeq3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
-                     const double *__restrict__ u0, const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1,
-                     XOp tD2, int np, long pitch, double nu, double omega)
+                     const double *u0, const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1,
+                     XOp tD2, int np, long pitch, double nu, double omega, const double *__restrict__ ushift)
 {
     extern __shared__ double lt[];
     constexpr int LN = LTC_N(WQ), Q = WQ, LS = LTC_LS;
@@ -221,6 +221,9 @@ __global__ void __launch_bounds__(512)
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
     double nxt[16];  // the rows needed next (next component's field, or the next pencil's u0)
     if (p0 < np) wide_gload(nxt, u0 + (long)p0 * pitch, lane);
+    // ushift != null: u0 += *ushift first, in place (the channel case's bulk-velocity shift, x3d_field_mean_shift:
+    // the pencil is in registers anyway -- one write pass instead of a read + write pass of its own)
+    const double ush = ushift ? *ushift : 0.0;
     for (int p = p0; p < np; p += nwaves) {
         const long ro = (long)p * pitch;
         double cb[WQ];
@@ -230,6 +233,15 @@ __global__ void __launch_bounds__(512)
             double wu[WQ + 8], wp[WQ + 8];
             {
                 double b[WQ];
+                if (c == 0 && ushift) {
+                    double2 *o2 = reinterpret_cast<double2 *>(const_cast<double *>(u0) + ro) + lane;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        nxt[2 * m] += ush;
+                        nxt[2 * m + 1] += ush;
+                        o2[64 * m] = make_double2(nxt[2 * m], nxt[2 * m + 1]);
+                    }
+                }
                 wide_to_strip(strip, nxt, lane);
                 wave_lds_fence();
                 wide_own_rows(b, strip, lane);
@@ -358,7 +370,7 @@ int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, doubl
 // transeq_x in one launch; f[0] is the advecting component
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       double omega, bool *done)
+                       double omega, const double *ushift, bool *done)
 {
     *done = false;
     if (omega != 0.0 && acc) return 0;
@@ -375,7 +387,7 @@ int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_, R_>));                                                       \
         hipLaunchKernelGGL((k_xwide_transeq3<A_, N_, R_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
-                           f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu, omega);  \
+                           f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu, omega, ushift); \
     } while (0)
         if (omega != 0.0) { if (narrow) GO(false, true, true); else GO(false, false, true); }
         else if (acc) { if (narrow) GO(true, true, false); else GO(true, false, false); }

@@ -98,6 +98,7 @@ class Solver:
         self.pending_grad = None
         self.rot_request, self.rot_applied = 0.0, False  # rotation forcing handed to transeq_x (transeq_fused)
         self.n_rot_fused = self.n_interleaved = 0        # how often those two fusions were taken (tests)
+        self.shift_request = None  # device scalar to add to u before transeq_x uses it (field_mean_shift)
         self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
         backend.before_read.append(self.flush_grad)
@@ -183,6 +184,10 @@ class Solver:
         b.mesh.get_n(DIR_X, u.data_loc)
         # a rotation forcing the case asked for (ChannelCase.substep) can ride on the x kernel
         rot, self.rot_request, self.rot_applied = self.rot_request, 0.0, False
+        # ... and so can the second half of its bulk-velocity shift (ChannelCase.define_BC)
+        shift, self.shift_request = self.shift_request, None
+        if shift is not None and self.pending_grad is not None:
+            self.flush_grad()  # (the shift's mean was taken of the corrected velocity)
         if self.pending_grad is not None:
             # the previous sub-step's velocity correction is still pending (pressure_correction_fused(defer_grad)):
             # the x kernel applies it to each pencil before using it
@@ -193,11 +198,14 @@ class Solver:
                 b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
             for f in g:
                 b.allocator.release_block(f)
-        elif rot != 0.0 and os.environ.get("X3D_NO_ROT_FUSED") != "1" and \
-                b.transeq_x_rot(du, dv, dw, u, v, w, self.nu, self.xdirps, rot):
-            self.rot_applied = True  # (ChannelCase.forcings: nothing left to do)
-            self.n_rot_fused += 1
+        elif (rot != 0.0 or shift is not None) and os.environ.get("X3D_NO_ROT_FUSED") != "1" and \
+                b.transeq_x_rot(du, dv, dw, u, v, w, self.nu, self.xdirps, rot, shift):
+            if rot != 0.0:
+                self.rot_applied = True  # (ChannelCase.forcings: nothing left to do)
+                self.n_rot_fused += 1
         else:
+            if shift is not None:
+                b.field_shift_by(u, shift)
             b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
         if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
             self._transeq_yz_decomposed(du, dv, dw, u, v, w)
