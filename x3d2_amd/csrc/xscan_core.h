@@ -6,6 +6,12 @@
 #ifndef XSCAN_EXP
 #define XSCAN_EXP 0  // timing experiments only (1: no stores, 2: no loads, 3: no scans)
 #endif
+// general form: TWO rows' stencil weights / table entries in flight instead of one (row q + 2's LDS reads wait for
+// row q's result, row q + 1's do not): +11 VGPRs, K3g's transeq_y 1.42 -> 1.37 ms per component at 257 rows.
+// -DXSCAN_CS_DEPTH1: one row at a time (A/B)
+#if !defined(XSCAN_CS_DEPTH1) && !defined(XSCAN_CS_DEPTH2)
+#define XSCAN_CS_DEPTH2
+#endif
 
 // lane-table entry indices (per operator): 8*Q row entries then the scan multipliers
 #define LT_F(q) (0 * Q + (q))
@@ -182,9 +188,18 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     if constexpr (!FAST) {
         const int ls = (nr - 4) / Q;
         int co = (lane == 0 ? 0 : (lane == ls ? 1 : (lane == ls + 1 ? 2 : 3))) * (Q * 10);
+#ifdef XSCAN_CS_DEPTH2
+        int co1 = co;  // two rows' weights in flight: row q + 2's reads wait for acc[q], row q + 1's do not
+        asm volatile("" : "+v"(co1));
+#endif
 #pragma unroll
         for (int q = 0; q < Q; q++) {
+#ifdef XSCAN_CS_DEPTH2
+            int &coq = (q & 1) ? co1 : co;
+            const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + coq + q * 10);
+#else
             const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + co + q * 10);
+#endif
             if (NARROW) {  // no stencil of the operator reaches beyond 2 rows (x3d_tdsops::narrow_all): taps 2..6 only
                 const double2 cb = c2[1], cc = c2[2], cd = c2[3];
                 acc[q] = cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] + cc.y * w[q + 5] + cd.x * w[q + 6];
@@ -193,7 +208,11 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
                 acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
                          cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
             }
+#ifdef XSCAN_CS_DEPTH2
+            asm volatile("" : "+v"(coq) : "v"(first_of(acc[q])));
+#else
             asm volatile("" : "+v"(co) : "v"(first_of(acc[q])));  // one row's weights at a time (10 VGPRs, not 10 Q)
+#endif
         }
     }
     // ---- lane-local forward elimination from zero

@@ -32,6 +32,22 @@ __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[
     double X[Q], du1, xn;
     scan_solve<Q, false, NARROW>(w, X, du1, xn, lt, t, lane, first, 0, cs);
     const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+#ifdef XSCAN_CS_DEPTH2
+    int la[2] = {lane, lane};  // two rows' table reads in flight: row q + 2's wait for row q, row q + 1's do not
+    asm volatile("" : "+v"(la[1]));
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int j = first + q;
+        int &lq = la[q & 1];
+        const double st = lt_read(lt, LT_ST(q) * 64 + lq);
+        double x = (X[q] - lt_read(lt, LT_SA(q) * 64 + lq) * du_s - lt_read(lt, LT_SC(q) * 64 + lq) * du_e) * st;
+        x = (j == 1) ? du_s * st : x;
+        x = (j == n) ? du_e * st : x;
+        r[q] = x;
+        asm volatile("" : "+v"(lq) : "v"(x));
+    }
+    asm volatile("" : "+v"(lane) : "v"(r[Q - 1]));
+#else
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int j = first + q;
@@ -42,6 +58,7 @@ __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[
         r[q] = x;
         asm volatile("" : "+v"(lane) : "v"(x));  // (one row's table reads at a time: front-loaded, they were spilled)
     }
+#endif
 }
 
 // the pieces every kernel below shares (tile <-> memory, tile <-> registers)
