@@ -103,8 +103,10 @@ template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ double dpp0(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    // (all rows enabled: bound_ctrl:1 makes the lanes without a source read 0 by itself -- no zero-initialised
+    // destination, two v_mov_b32 less per move; a partial row mask needs the zeros for the disabled rows)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_d(double v, int l)
