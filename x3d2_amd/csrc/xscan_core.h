@@ -231,13 +231,15 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     T carry = v;
 #else
     // prefix scan without LDS traffic: in-row Kogge-Stone by DPP row shifts, then lane 15 / 47 into rows
-    // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0
+    // 1 / 3 and lane 31 into rows 2, 3 (row_bcast); lanes without a source read 0.  (The row_bcast moves run with
+    // all rows enabled: the rows that are not meant to receive carry a multiplier of exactly 0 in the tables,
+    // tds.hip, so whatever finite value they pick up adds 0 -- and no zeroed destination is needed.)
     v += LTM(lt, 0) * dpp0<0x111>(v);
     v += LTM(lt, 1) * dpp0<0x112>(v);
     v += LTM(lt, 2) * dpp0<0x114>(v);
     v += LTM(lt, 3) * dpp0<0x118>(v);
-    v += LTM(lt, 4) * dpp0<0x142, 0xA>(v);
-    v += LTM(lt, 5) * dpp0<0x143, 0xC>(v);
+    v += LTM(lt, 4) * dpp0<0x142>(v);
+    v += LTM(lt, 5) * dpp0<0x143>(v);
     T carry = dpp0<0x138>(v);  // wave_shr:1
 #endif
     // ---- apply, lane-local back-substitution from zero
