@@ -16,3 +16,6 @@ python bench_ops.py > gpurun_out/bench_${rnd}_ops.jsonl 2>/dev/null
 for f in opg 256 channel emulz; do python -c "
 import json,sys; d=json.loads(open('gpurun_out/bench_${rnd}_$f.json').read().strip().split('\n')[-1]); print('$f', d['value'], d['ms_per_step'])"; done
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+# kernel-trace stats of the channel bench and of the emulated N > 1 path, PMC traffic of the channel bench
+bash scratch/extra_profiles.sh > gpurun_out/${rnd}_extra_profiles.txt 2>&1
+bash scratch/pmc_channel.sh > gpurun_out/${rnd}_pmc_channel.txt 2>&1; tail -3 gpurun_out/${rnd}_pmc_channel.txt
