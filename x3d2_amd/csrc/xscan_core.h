@@ -275,11 +275,14 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     if constexpr (FAST) {
         xn = readlane_d(X[Q - 1], 63);
     } else {
-        const int ln = (n - 1) / Q, qn = (n - 1) % Q;
-        double xsel = 0.0;
+        // row n sits in lane ln at position qn, both wave-uniform: v_readlane instead of __shfl = ds_bpermute (an LDS
+        // round trip on the critical path to du_e); a scalar branch over q instead of the select chain spills in
+        // k_ygen_transeq3<6, true, false>
+        const int ln = __builtin_amdgcn_readfirstlane((n - 1) / Q), qn = __builtin_amdgcn_readfirstlane((n - 1) % Q);
+        T xsel = zero_of<T>();
 #pragma unroll
         for (int q = 0; q < Q; q++) xsel = (q == qn) ? X[q] : xsel;
-        xn = __shfl(xsel, ln, 64);
+        xn = readlane_d(xsel, ln);
     }
     PHASE(xn);
 #undef PHASE

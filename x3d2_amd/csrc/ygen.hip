@@ -41,7 +41,7 @@ __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[
         int &lq = la[q & 1];
         const double st = lt_read(lt, LT_ST(q) * 64 + lq);
         double x = (X[q] - lt_read(lt, LT_SA(q) * 64 + lq) * du_s - lt_read(lt, LT_SC(q) * 64 + lq) * du_e) * st;
-        x = (j == 1) ? du_s * st : x;
+        if (q == 0) x = (lane == 0) ? du_s * st : x;  // (row 1)
         x = (j == n) ? du_e * st : x;
         r[q] = x;
         asm volatile("" : "+v"(lq) : "v"(x));
@@ -53,7 +53,7 @@ __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[
         const int j = first + q;
         const double st = LTR(lt, LT_ST(q));
         double x = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
-        x = (j == 1) ? du_s * st : x;
+        if (q == 0) x = (lane == 0) ? du_s * st : x;  // (row 1)
         x = (j == n) ? du_e * st : x;
         r[q] = x;
         asm volatile("" : "+v"(lane) : "v"(x));  // (one row's table reads at a time: front-loaded, they were spilled)
