@@ -753,7 +753,9 @@ def test_x_direction_scan_kernels_full_size_pencils(nx):
     # non-periodic / odd-length pencils: the general tile kernels (K3g, csrc/ygen.hip); 257 stretched wall-normal
     # vertices = the channel case's y pencils (BASELINE configs[4])
     ((32, 257, 8), "dirichlet", "top-bottom"), ((48, 130, 8), "neumann", "uniform"), ((64, 8, 257), "dirichlet", "uniform"),
-    ((32, 384, 8), "dirichlet", "centred"), ((16, 500, 8), "dirichlet", "bottom")])
+    ((32, 384, 8), "dirichlet", "centred"), ((16, 500, 8), "dirichlet", "bottom"),
+    # 257..320 rows: 5 rows per lane (a second set of lane tables); 320 fills all 64 lanes, 321 is back on 6
+    ((32, 320, 8), "dirichlet", "top-bottom"), ((16, 8, 321), "neumann", "uniform")])
 def test_yz_operators_on_512_row_pencils(dims, bc, stretch):
     """y / z pencils of 512 (the bench size) and 256 rows: every operator incl. accumulating forms against
     the oracle.  These are the sizes at which the single-pass on-chip kernels (K1e, csrc/onchip.hip) engage."""

@@ -145,6 +145,7 @@ struct x3d_tdsops {
     double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
     const double *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
+    const double *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
     int halo_ws, halo_we;        // rows 1..ws / n-we+1..n: where |dist_sa| / |dist_sc| >= 2^-60 (xscan.hip, *_halo_fix)
     struct x3d_penta *penta;     // compact10_penta: the pentadiagonal LU tables (penta.hip), else null

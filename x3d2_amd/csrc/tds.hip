@@ -108,10 +108,10 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // (6: 257 .. 384 rows, e.g. the channel case's 257 wall-normal vertices -- 43 of the 64 lanes busy instead of 33)
     const int Q = nr <= 256 ? 4 : (nr <= 384 ? 6 : (nr <= 512 ? 8 : (nr <= 1024 ? 16 : 0)));
     const size_t tl_off = img.size();
-    if (Q) {
+    auto build_tl = [&](const int Q, std::vector<double> &out) {  // the [9 Q + 12][64] table for Q rows per lane
         const int NE = 9 * Q + 12;
-        img.resize(tl_off + (size_t)NE * 64, 0.0);
-        double *tl = &img[tl_off];
+        out.assign((size_t)NE * 64, 0.0);
+        double *tl = out.data();
         auto E = [&](int e, int l) -> double & { return tl[(size_t)e * 64 + l]; };
         double G[64], HL[64];
         for (int l = 0; l < 64; l++) {
@@ -162,6 +162,11 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             E(8 * Q + 6 + 4, l) = (row == 0 || row == 2) ? d16 : 0.0;
             E(8 * Q + 6 + 5, l) = row < 2 ? d32 : 0.0;
         }
+    };
+    if (Q) {
+        std::vector<double> tlv;
+        build_tl(Q, tlv);
+        img.insert(img.end(), tlv.begin(), tlv.end());
     }
     // compressed form of the row entries (xscan_core.h, LTC_*): lanes 0..7 | one value for lanes 8..55 | lanes
     // 56..63 -- only where those middle lanes really are bitwise equal (periodic-type operators on a uniform grid)
@@ -189,8 +194,18 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             img.insert(img.end(), c.begin(), c.end());
         }
     }
+    // 257 .. 320 rows: a second table with 5 rows per lane for the tile kernels of ygen.hip (52 of 64 lanes busy
+    // instead of 43 with 6; the x kernels keep the even Q: they move their rows as aligned 16-byte pairs)
+    size_t tl5_off = 0;
+    if (nr > 256 && nr <= 320) {
+        std::vector<double> tlv;
+        build_tl(5, tlv);
+        tl5_off = img.size();
+        img.insert(img.end(), tlv.begin(), tlv.end());
+    }
     X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
     X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+    t->tl5 = tl5_off ? t->dev + tl5_off : nullptr;
     TdsTab &tb = t->tab;
     tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
     tb.RF = t->dev; tb.RB = t->dev + (size_t)4 * L;

@@ -91,19 +91,31 @@ template <int Q> struct GenTile {
     // this lane's window: rows first-4 .. first+Q+3 = tile entries lane Q .. lane Q + Q + 7 of the wave's pencil
     __device__ __forceinline__ void window(double (&w)[Q + 8]) const
     {
-        const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(tile + wave * G::TP + lane * Q);
+        if constexpr (Q % 2 == 0) {
+            const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(tile + wave * G::TP + lane * Q);
 #pragma unroll
-        for (int m = 0; m < (Q + 8) / 2; m++) {
-            const double2 t = s2[m];
-            w[2 * m] = t.x;
-            w[2 * m + 1] = t.y;
+            for (int m = 0; m < (Q + 8) / 2; m++) {
+                const double2 t = s2[m];
+                w[2 * m] = t.x;
+                w[2 * m + 1] = t.y;
+            }
+        } else {  // odd Q: the window starts on an 8-byte boundary only (lane stride 40 B at Q = 5: conflict-free)
+            const double *__restrict__ s1 = tile + wave * G::TP + lane * Q;
+#pragma unroll
+            for (int m = 0; m < Q + 8; m++) w[m] = lt_read(s1, m);
         }
     }
     __device__ __forceinline__ void put(const double (&r)[Q]) const
     {
-        double2 *__restrict__ d2 = reinterpret_cast<double2 *>(tile + wave * G::TP + 4 + lane * Q);
+        if constexpr (Q % 2 == 0) {
+            double2 *__restrict__ d2 = reinterpret_cast<double2 *>(tile + wave * G::TP + 4 + lane * Q);
 #pragma unroll
-        for (int m = 0; m < Q / 2; m++) d2[m] = make_double2(r[2 * m], r[2 * m + 1]);
+            for (int m = 0; m < Q / 2; m++) d2[m] = make_double2(r[2 * m], r[2 * m + 1]);
+        } else {
+            double *__restrict__ d1 = tile + wave * G::TP + 4 + lane * Q;
+#pragma unroll
+            for (int m = 0; m < Q; m++) d1[m] = r[m];
+        }
     }
     // rows < nout of the tile -> memory; ACC: out = old + r with the old rows already in registers (gload)
     template <bool ACC>
@@ -296,9 +308,26 @@ static bool gen_env_on()
 static bool gen_ok(const x3d_backend *b, int dir, const x3d_tdsops *t, int Q)
 {
     const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+    const bool tables = Q == 5 ? t->tl5 != nullptr : (t->tab.TL != nullptr && t->tab.Q == Q && (Q == 4 || Q == 6 || Q == 8));
     // (periodic-type operators need the periodic image / the neighbours' rows in the halo rows: K3y's business)
-    return t->tab.TL != nullptr && t->tab.Q == Q && (Q == 4 || Q == 6 || Q == 8) && n <= 64 * Q && t->tab.n_rhs <= n &&
-           b->nx % 16 == 0 && !t->periodic && !t->tab.bulk_only;
+    return tables && n <= 64 * Q && t->tab.n_rhs <= n && b->nx % 16 == 0 && !t->periodic && !t->tab.bulk_only;
+}
+// rows per lane for a launch on these operators: 5 where every one of them carries the 5-row tables (257..320-row
+// pencils: 52 of 64 lanes busy instead of 43), else the operators' own Q.  X3D_NO_Q5=1: always the latter (A/B)
+static int gen_q(const x3d_backend *b, int dir, const x3d_tdsops *const *ops, int nops)
+{
+    static int q5 = -1;
+    if (q5 < 0) { const char *e = getenv("X3D_NO_Q5"); q5 = (e && e[0] == '1') ? 0 : 1; }
+    const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+    bool all5 = q5 && n <= 320;
+    for (int k = 0; k < nops; k++) all5 = all5 && ops[k]->tl5 != nullptr;
+    return all5 ? 5 : ops[0]->tab.Q;
+}
+static XOp gen_xop(const x3d_tdsops *t, int Q)
+{
+    XOp o = xop_of(t);
+    if (Q == 5) o.TL = t->tl5;
+    return o;
 }
 struct GenLaunch {
     int ntx, ntiles, blocks, nrow;
@@ -323,7 +352,8 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
 {
     *done = false;
     if (!gen_env_on() || dir == X3D_DIR_X) return 0;
-    const int Q = ta->tab.Q;
+    const x3d_tdsops *const ops[2] = {ta, mode == 2 ? ta : tb};
+    const int Q = gen_q(b, dir, ops, 2);
     if (!gen_ok(b, dir, ta, Q) || (mode != 2 && !gen_ok(b, dir, tb, Q))) return 0;
     const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
@@ -338,11 +368,11 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_, N_>));                                                            \
         hipLaunchKernelGGL((k_ygen_pair<Q_, M_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
-                           xop_of(ta), xop_of(tb_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, permn);      \
+                           gen_xop(ta, Q_), gen_xop(tb_, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, permn); \
     } while (0)
 #define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
-    if (Q == 8) GOM(8); else if (Q == 6) GOM(6); else GOM(4);
+    if (Q == 8) GOM(8); else if (Q == 6) GOM(6); else if (Q == 5) GOM(5); else GOM(4);
 #undef GOM
 #undef GON
 #undef GO
@@ -360,7 +390,8 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double 
 {
     *done = false;
     if (!gen_env_on() || dir == X3D_DIR_X) return 0;
-    const int Q = der1st->tab.Q;
+    const x3d_tdsops *const ops[4] = {der1st, der1st_sym, der2nd, der2nd_sym};
+    const int Q = gen_q(b, dir, ops, 4);
     if (!gen_ok(b, dir, der1st, Q) || !gen_ok(b, dir, der1st_sym, Q) || !gen_ok(b, dir, der2nd, Q) ||
         !gen_ok(b, dir, der2nd_sym, Q))
         return 0;
@@ -377,11 +408,11 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double 
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_>));                                                        \
         hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
-                           f[1], f[2], xop_of(der1st), xop_of(der2nd), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
+                           f[1], f[2], gen_xop(der1st, Q_), gen_xop(der2nd, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
     } while (0)
 #define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
-        if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else GOA(4);
+        if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else if (Q == 5) GOA(5); else GOA(4);
 #undef GOA
 #undef GON
 #undef GO
