@@ -270,11 +270,11 @@ def test_channel_step_at_the_bench_pencil_lengths_vs_oracle():
     assert case.solver.n_interleaved == 0  # (16-row z pencils: not the tile kernel's; the bench's 512 are)
 
 
-def test_rotation_forcing_inside_transeq_x_vs_the_two_vecadds(monkeypatch):
-    """k_xwide_transeq3<ROT>: du = transeq_x(u) - omega v, dv = transeq_x(v) + omega u formed in the x kernel
-    against the reference's order (two vecadd's after the three directions, src/case/channel.f90:191-207):
-    the same sum in another order -- equal to round-off"""
-    dims = (1024, 33, 16)
+@pytest.mark.parametrize("dims", [(1024, 33, 16), (256, 33, 16)])
+def test_rotation_forcing_inside_transeq_x_vs_the_two_vecadds(dims, monkeypatch):
+    """k_xwide_transeq3<ROT> / k_xscan_transeq2x3<CHN>: du = transeq_x(u) - omega v, dv = transeq_x(v) + omega u
+    formed in the x kernel against the reference's order (two vecadd's after the three directions,
+    src/case/channel.f90:191-207): the same sum in another order -- equal to round-off"""
     fusedrot = _channel_steps(dims, "top-bottom", 0.259065151, True, 1)
     assert fusedrot.solver.n_rot_fused == 3
     monkeypatch.setenv("X3D_NO_ROT_FUSED", "1")
@@ -337,14 +337,16 @@ def test_fused_channel_step_with_and_without_the_interleaving_pairs(dims, taken,
         assert np.array_equal(case.solver.backend.get_field_data(a), plain.solver.backend.get_field_data(c))
 
 
+@pytest.mark.parametrize("nx", [1024, 512, 256])
 @pytest.mark.parametrize("omega", [0.12, 0.0])
-def test_bulk_velocity_shift_inside_transeq_x(omega):
-    """x3d_transeq_x_rot(u_shift): u += the device scalar of x3d_field_mean_shift inside K3w's transeq_x kernel ==
+def test_bulk_velocity_shift_inside_transeq_x(omega, nx):
+    """x3d_transeq_x_rot(u_shift): u += the device scalar of x3d_field_mean_shift inside the transeq_x kernel (K3w
+    at 1024-point pencils, K3s at 256 / 512) ==
     x3d_field_shift_by followed by the same kernel without it, bit for bit (u and du, dv, dw); together the two
     halves == x3d_field_shift_to_mean"""
     import torch
     from x3d2_amd.common import DIR_X, VERT
-    s = product_solver((1024, 9, 8))
+    s = product_solver((nx, 9, 8))
     b, al = s.backend, s.backend.allocator
     rng = np.random.default_rng(3)
     blk = [al.get_block(DIR_X, VERT) for _ in range(13)]

@@ -661,7 +661,7 @@ int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, con
 int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
-                       const x3d_tdsops *op_i, double scale, bool *done);  // xscan.hip
+                       const x3d_tdsops *op_i, double scale, double omega, const double *ushift, bool *done);  // xscan.hip
 // xdir.hip
 int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
@@ -1061,7 +1061,7 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
         // the three components in one launch of the scan kernel (xscan.hip), the advecting velocity read once
         bool done = false;
         if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, nullptr, nullptr, nullptr,
-                                        0.0, &done))
+                                        0.0, 0.0, nullptr, &done))
             return rc;
         if (done) return 0;
         if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, a, 0.0, nullptr, &done)) return rc;  // n = 1024
@@ -1109,7 +1109,8 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
         for (int k = 0; k < 3; k++)
             X3D_REQUIRE(r[c] != f[k] && r[c] != g[k] && f[c] != g[k], "x3d_transeq_x_update: arguments alias");
     bool ok = false;
-    if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, g, op_u, op_vw, scale, &ok))
+    if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, g, op_u, op_vw, scale, 0.0,
+                                    nullptr, &ok))
         return rc;
     *done = ok ? 1 : 0;
     return 0;
@@ -1121,7 +1122,7 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
 // another order, round-off level).  u_shift != null: first u += *u_shift in place (device scalar of
 // x3d_field_mean_shift: the second half of the bulk-velocity correction, :70-77, bit-identical to x3d_field_shift_by).
 // *done = 0: not served for these pencils, nothing was done (issue x3d_field_shift_by, x3d_transeq and, after the
-// other directions, x3d_vecadd x 2).  Served: 1024-row periodic x pencils (K3w).
+// other directions, x3d_vecadd x 2).  Served: periodic x pencils of 256 / 512 rows (K3s) and of 1024 rows (K3w).
 extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, double *u, const double *v,
                                  const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                  const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega,
@@ -1138,7 +1139,11 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double 
         X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_x_rot: outputs alias inputs");
     if (omega == 0.0 && !u_shift) return 0;
     bool ok = false;
-    if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, omega, u_shift, &ok)) return rc;
+    if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, nullptr, nullptr, nullptr, 0.0,
+                                    omega, u_shift, &ok))
+        return rc;  // 256 / 512-row pencils
+    if (!ok)
+        if (int rc = x3d_xwide_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, omega, u_shift, &ok)) return rc;
     *done = ok ? 1 : 0;
     return 0;
 }

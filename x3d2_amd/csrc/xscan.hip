@@ -530,9 +530,13 @@ __global__ void __launch_bounds__(512)
 struct XUpd {
     const double *g[3];  // gradient inputs of u0, u1, u2
     double scale;
+    // the channel case's extras (xwide.hip, k_xwide_transeq3<ROT>, has the 1024-row form): rotation forcing
+    // rhs0 -= omega u1, rhs1 += omega u0 on top of the result; u0 += *ushift in place first
+    double omega;
+    const double *ushift;
 };
 
-template <int Q, bool ACC, bool NARROW, bool UPD>
+template <int Q, bool ACC, bool NARROW, bool UPD, bool CHN = false>  // CHN: the channel case's extras (XUpd)
 __global__ void __launch_bounds__(512)
     k_xscan_transeq2x3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2, double *u0,
                        double *u1, double *u2, XOp tD1, XOp tD2, int np, long pitch, double nu, XUpd upd, XOp tS,
@@ -609,6 +613,20 @@ __global__ void __launch_bounds__(512)
                     else { store_rows_q4<false>(uw, lane, ua, 1.0); store_rows_q4<false>(uw + pitch, lane, ub, 1.0); }
                     asm volatile("" : "+v"(lane) : "v"(b2[0].a));
                 }
+                if (CHN && c == 0 && upd.ushift) {  // (wave-uniform; never together with UPD)
+                    const double ush = *upd.ushift;
+                    double ua[Q], ub[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        b2[q].a += ush;
+                        b2[q].b += ush;
+                        ua[q] = b2[q].a;
+                        ub[q] = b2[q].b;
+                    }
+                    double *uw = u0 + (long)p * pitch;
+                    if constexpr (Q == 8) { store_rows_q8<false>(uw, lane, ua, 1.0); store_rows_q8<false>(uw + pitch, lane, ub, 1.0); }
+                    else { store_rows_q4<false>(uw, lane, ua, 1.0); store_rows_q4<false>(uw + pitch, lane, ub, 1.0); }
+                }
                 if (c == 0) {
 #pragma unroll
                     for (int q = 0; q < Q; q++) cb[q] = b2[q];
@@ -647,6 +665,15 @@ __global__ void __launch_bounds__(512)
                 const V2 v = r[q] + nu * T[q];
                 ra[q] = v.a;
                 rb[q] = v.b;
+            }
+            if (CHN && upd.omega != 0.0) {  // (na, nb = this pair's u1 rows while c == 0; cb = its u0 rows)
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) { ra[q] = -upd.omega * na[q] + 1.0 * ra[q]; rb[q] = -upd.omega * nb[q] + 1.0 * rb[q]; }
+                } else if (c == 1) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) { ra[q] = upd.omega * cb[q].a + 1.0 * ra[q]; rb[q] = upd.omega * cb[q].b + 1.0 * rb[q]; }
+                }
             }
             double *oa = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + (long)p * pitch, *ob = oa + pitch;
             if constexpr (Q == 8) { store_rows_q8<ACC>(oa, lane, ra, 1.0); store_rows_q8<ACC>(ob, lane, rb, 1.0); }
@@ -1701,9 +1728,10 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
-                       const x3d_tdsops *op_i, double scale, bool *done)
+                       const x3d_tdsops *op_i, double scale, double omega, const double *ushift, bool *done)
 {
     *done = false;
+    if ((omega != 0.0 || ushift) && (acc || upd_g)) return 0;
     static int on = -1;
     if (on < 0) {
         const char *names[4] = {"X3D_NO_TILE3", "X3D_XSCAN_P1", "X3D_NO_XSCAN", "X3D_XDIR_GENERIC"};
@@ -1727,17 +1755,23 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     const int blocks = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
     XUpd xu{};
     if (upd) { xu.g[0] = upd_g[0]; xu.g[1] = upd_g[1]; xu.g[2] = upd_g[2]; xu.scale = scale; }
+    xu.omega = omega; xu.ushift = ushift;
     const x3d_tdsops *ts = upd ? op_s : der1st, *ti = upd ? op_i : der1st;
-#define GO(Q_, A_, N_, U_)                                                                                      \
+#define GO(Q_, A_, N_, U_, C_)                                                                                  \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_>));                                                 \
-        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
+        X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_, C_>));                                             \
+        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_, C_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
                            r[2], (double *)f[0], (double *)f[1], (double *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
                            (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti));                                       \
     } while (0)
-#define GOU(Q_, A_, N_) do { if (upd) GO(Q_, A_, N_, true); else GO(Q_, A_, N_, false); } while (0)
+#define GOU(Q_, A_, N_) do { if (upd) GO(Q_, A_, N_, true, false); else GO(Q_, A_, N_, false, false); } while (0)
 #define GON(Q_, A_) do { if (narrow) GOU(Q_, A_, true); else GOU(Q_, A_, false); } while (0)
-#define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
+#define GOA(Q_)                                                                                                 \
+    do {                                                                                                        \
+        if (omega != 0.0 || ushift) { if (narrow) GO(Q_, false, true, false, true); else GO(Q_, false, false, false, true); } \
+        else if (acc) GON(Q_, true);                                                                            \
+        else GON(Q_, false);                                                                                    \
+    } while (0)
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
         if (Q == 8) GOA(8); else GOA(4);
