@@ -337,6 +337,33 @@ def test_fused_channel_step_with_and_without_the_interleaving_pairs(dims, taken,
         assert np.array_equal(case.solver.backend.get_field_data(a), plain.solver.backend.get_field_data(c))
 
 
+def test_channel_fusion_entry_points_decline_or_fail_loudly():
+    """the fusion extensions of the channel path say so when they do not apply (the caller then issues the plain
+    sequence) and reject bad arguments like the other entry points"""
+    from x3d2_amd.common import DIR_X, VERT, X3dError
+    s = product_solver((32, 18, 256))  # 17 cell rows: odd
+    b, al, z = s.backend, s.backend.allocator, s.zdirps
+    f = [al.get_block(DIR_X, VERT) for _ in range(6)]
+    for x in f:
+        x.fill(0.0)
+    assert b.poisson_fft.interleaved_rows() == 0  # odd row count: the solver keeps its copy kernels
+    assert not b.tds_pair_yperm(0, f[0], None, f[1], f[2], z.interpl_v2p, z.stagder_v2p, 17)
+    with pytest.raises(X3dError):
+        b.tds_pair_yperm(0, f[0], None, f[1], f[2], z.interpl_v2p, z.stagder_v2p, 400)   # more rows than the block has
+    with pytest.raises(X3dError):
+        b.tds_pair_yperm(0, f[0], None, f[0], f[2], z.interpl_v2p, z.stagder_v2p, 16)    # output aliases an input
+    # nothing to fuse: declined, fields untouched
+    assert not b.transeq_x_rot(f[0], f[1], f[2], f[3], f[4], f[5], s.nu, s.xdirps, 0.0)
+    # 32-point x pencils: no single-pass kernel takes the forcing
+    assert not b.transeq_x_rot(f[0], f[1], f[2], f[3], f[4], f[5], s.nu, s.xdirps, 0.12)
+    with pytest.raises(X3dError):
+        b.transeq_x_rot(f[0], f[1], f[2], f[0], f[4], f[5], s.nu, s.xdirps, 0.12)        # du aliases u
+    with pytest.raises(X3dError):
+        b.tds_lincomb(f[0], s.xdirps.stagder_v2p, DIR_X, f[1], f[2], [1.0], [f[3]], wall=f[0])  # du aliases the wall field
+    for x in f:
+        al.release_block(x)
+
+
 @pytest.mark.parametrize("nx", [1024, 512, 256])
 @pytest.mark.parametrize("omega", [0.12, 0.0])
 def test_bulk_velocity_shift_inside_transeq_x(omega, nx):
