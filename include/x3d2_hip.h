@@ -24,7 +24,10 @@
  *    src/ordering.f90:42-69 vs src/backend/cuda/kernels/reorder.f90:34,129):
  *    every block, whatever its DIR_X/Y/Z/C tag, is Cartesian x-fastest with a
  *    padded pitch: elem(i,j,k) = f[i + nxp*(j + nyp*k)], 0-based,
- *    nxp = round_up(nx_vert, 16), nyp = ny_vert, nzp = nz_vert.
+ *    nxp = round_up(nx_vert, 16), PLUS 16 where that is a multiple of 64 doubles (512^3: nxp = 528 -- keeps
+ *    the rows of a y / z tile from aliasing in the memory channels), nyp = ny_vert, nzp = nz_vert.
+ *    Never compute the pitch yourself: x3d_padded_dims() returns (nxp, nyp, nzp), x3d_block_elems() the
+ *    block size, and x3d_get/set_field_data do the pitched copies.
  *    `dir` only selects the direction an operator works along.  A reorder is
  *    therefore a device copy and sum_{y,z}intox an axpy.
  */
@@ -404,6 +407,31 @@ int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out);
 int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
 int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part);
 int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
+
+/* ---- distributed 010 solver (non-periodic y: the channel case, BASELINE configs[4]) for z-slab decompositions
+ * [1, 1, pz] (csrc/sfft010.hip).  The reference refuses this combination ("Multiple ranks are not yet supported for
+ * non-periodic BCs!", src/poisson_fft.f90:177-180): its pencil layouts split y in spectral space, while
+ * process_spectral_010 pairs the rows j and ny - j + 2 and the stretched operator is pentadiagonal along y
+ * (src/backend/cuda/poisson_fft.f90:822-924).  Here the one transpose pair of a solve splits the x MODES
+ * (xs = ceil((nx/2 + 1) / pz) columns per rank), y stays whole on every rank and the single-rank spectral kernels run
+ * unchanged on the rank's modes.  Buffers: device arrays of 2 * pz * chunk doubles (x3d_sfft010_sizes: chunk, zl, xs,
+ * i0 = first x mode of this rank, nx/2 + 1); peer r's chunk is contiguous.
+ *   periodicity_y(t, f, 0) ; forward_local(t, S) | all-to-all S -> R | fft_z(R, 0) ; postprocess_010(R) ; fft_z(R, 1)
+ *   | all-to-all R -> S | backward_local(S, t) ; periodicity_y(f, t, 1)
+ * set_waves: this rank's block [nz][ny][xs] (pad columns one) + the global ax .. bz tables; set_stretching: this
+ * rank's columns of the reference's stretching_matrix arrays, [5][nz][n][xs] (src/poisson_fft.f90:275-652). */
+typedef struct x3d_sfft010 x3d_sfft010;
+int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob_cell[3], int pz, int rz);
+int x3d_sfft010_destroy(x3d_sfft010 *p);
+int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[5]);
+int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const double *ax, const double *bx, const double *ay,
+                          const double *by, const double *az, const double *bz);
+int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double *a0, const double *a1);
+int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const double *f_in, int undo);
+int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf);
+int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir);
+int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf);
+int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out);
 
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,

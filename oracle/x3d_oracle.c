@@ -19,6 +19,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define SZ 16
 #define NH 4 /* n_halo, hard-wired in the reference: src/backend/backend.f90:28-29 */
@@ -29,6 +32,16 @@ enum { SCH_COMPACT6 = 0, SCH_COMPACT6_HYPERVISCOUS = 1, SCH_CLASSIC = 2, SCH_OPT
        SCH_AGGRESSIVE = 4 };
 enum { FT_NONE = 0, FT_V2P = 1, FT_P2V = 2 };
 enum { DIR_X = 1, DIR_Y = 2, DIR_Z = 3, DIR_C = 4 };
+
+/* threads the OpenMP loops below actually run on (bench.py's cpu_baseline reports this, not what it asked for) */
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------- */
 /* tdsops factory: src/tdsops.f90                                             */

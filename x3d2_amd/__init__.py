@@ -25,15 +25,18 @@ def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3"
 
 
 def make_channel(dims=(128, 65, 64), L=(4.0, 2.0, 2.0), stretching="top-bottom", beta=0.259065151, Re=4200.0,
-                 dt=5e-3, time_intg="RK3", poisson="FFT", fused=False, device=None, comm=None, **channel_kw):
+                 dt=5e-3, time_intg="RK3", poisson="FFT", fused=False, device=None, comm=None, nproc_dir=(1, 1, 1),
+                 rank=0, **channel_kw):
     """channel set-up of examples/channel/input.x3d: periodic x/z, no-slip y walls (Dirichlet),
-    y stretched towards the walls; channel_kw -> ChannelConfig (rotation, omega_rot, n_rotate, noise)"""
+    y stretched towards the walls; channel_kw -> ChannelConfig (rotation, omega_rot, n_rotate, noise).
+    dims, L: the GLOBAL grid; nproc_dir = (1, 1, N): z slabs (the wall-normal direction stays whole on every rank:
+    poisson_fft.HipSlabPoissonFFT010)"""
     from .backend import HipBackend
     from .case import ChannelCase, ChannelConfig
     from .solver import Solver, SolverConfig
     st = ("uniform", stretching, "uniform")
-    mesh = Mesh(tuple(dims), (1, 1, 1), tuple(L), ("periodic",) * 2, ("dirichlet",) * 2, ("periodic",) * 2,
-                st, (1.0, beta, 1.0))
+    mesh = Mesh(tuple(dims), tuple(nproc_dir), tuple(L), ("periodic",) * 2, ("dirichlet",) * 2, ("periodic",) * 2,
+                st, (1.0, beta, 1.0), nrank=rank)
     backend = HipBackend(mesh, device=device, comm=comm)
     solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson,
                                                  fused=fused))

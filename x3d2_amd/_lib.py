@@ -125,6 +125,16 @@ PROTOTYPES = {
     "x3d_sfft_fft_z": (I, [VP, VP, I]),
     "x3d_sfft_postprocess_000": (I, [VP, VP]),
     "x3d_sfft_backward_local": (I, [VP, VP, VP]),
+    "x3d_sfft010_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),
+    "x3d_sfft010_destroy": (I, [VP]),
+    "x3d_sfft010_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_sfft010_set_waves": (I, [VP] + [c_double_p] * 7),
+    "x3d_sfft010_set_stretching": (I, [VP, I, c_double_p, c_double_p]),
+    "x3d_sfft010_periodicity_y": (I, [VP, VP, VP, I]),
+    "x3d_sfft010_forward_local": (I, [VP, VP, VP]),
+    "x3d_sfft010_fft_z": (I, [VP, VP, I]),
+    "x3d_sfft010_postprocess_010": (I, [VP, VP]),
+    "x3d_sfft010_backward_local": (I, [VP, VP, VP]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
     "x3d_pfft_destroy": (I, [VP]),
     "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

@@ -7,6 +7,8 @@
 //   (slice_max_sum), :874-901 (scale/shift), :903-1021 (face setters),
 //   :1023-1066 (volume integral), src/backend/backend.f90:402-466
 //   (get/set_field_data), src/allocator.f90:64-93 (padding).
+#include <mutex>
+
 #include "common.h"
 
 #include <unordered_map>
@@ -148,15 +150,20 @@ extern "C" int x3d_device_sync(x3d_backend *b)
 // Blocks start 4224 B further into their allocation than the previous one (modulo 16): the kernels stream several
 // blocks at the same relative offset at once, and with every block on a 2 MiB boundary those streams meet in the
 // same memory channels (x3d2_amd/field.py has the measurement: -2 % per step at 512^3)
+// (process-wide table: several backends -- the twin backends of Poisson 100 / 110, one per host thread -- may
+// allocate and free at the same time)
 static std::unordered_map<double *, void *> g_block_base;
 static int g_block_count = 0;
+static std::mutex g_block_mutex;
 
 extern "C" int x3d_block_alloc(x3d_backend *b, double **out)
 {
     X3D_REQUIRE(b && out, "null argument");
     const size_t st = 528;
     void *base = nullptr;
+    X3D_HIP(hipSetDevice(b->device));
     X3D_HIP(hipMalloc(&base, sizeof(double) * (b->nblock + 16 * st)));
+    std::lock_guard<std::mutex> lock(g_block_mutex);
     *out = static_cast<double *>(base) + (size_t)(g_block_count++ % 16) * st;
     g_block_base[*out] = base;
     return 0;
@@ -165,10 +172,15 @@ extern "C" int x3d_block_alloc(x3d_backend *b, double **out)
 extern "C" int x3d_block_free(x3d_backend *b, double *p)
 {
     (void)b;
-    auto it = g_block_base.find(p);
-    X3D_REQUIRE(it != g_block_base.end(), "x3d_block_free: not a block of x3d_block_alloc");
-    X3D_HIP(hipFree(it->second));
-    g_block_base.erase(it);
+    void *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_block_mutex);
+        auto it = g_block_base.find(p);
+        X3D_REQUIRE(it != g_block_base.end(), "x3d_block_free: not a block of x3d_block_alloc");
+        base = it->second;
+        g_block_base.erase(it);
+    }
+    X3D_HIP(hipFree(base));
     return 0;
 }
 

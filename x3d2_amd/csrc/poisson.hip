@@ -294,125 +294,7 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
 //   src/backend/cuda/poisson_fft.f90:822-924                   fft_postprocess_010
 // ---------------------------------------------------------------------------
 
-// even/odd interleave along y on the pitched Cartesian block: out(i, j, k) = in(i, src(j), k)
-template <bool UNDO>
-__global__ void __launch_bounds__(256)
-    k_periodicity_y(double *__restrict__ out, const double *__restrict__ in, int nx, int ny, int nz, long nxp,
-                    long plane)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y + 1, k = blockIdx.z;  // j 1-based as in the reference
-    if (i >= nx) return;
-    const int n2 = ny / 2;
-    int js, jd;  // source / destination rows, 1-based
-    if (!UNDO) {  // :1062-1089
-        jd = j;
-        if (j <= n2) js = 2 * j - 1;
-        else if ((ny & 1) && j == n2 + 1) js = ny;
-        else js = 2 * ny - 2 * j + 2;
-    } else {      // :1091-1114: out(2j-1) = in(j), out(2j) = in(ny-j+1), odd centre out(ny) = in(n2+1)
-        js = j;
-        if (j <= n2) jd = 2 * j - 1;
-        else if ((ny & 1) && j == n2 + 1) jd = ny;
-        else jd = 2 * (ny - j + 1);
-    }
-    out[(long)k * plane + (long)(jd - 1) * nxp + i] = in[(long)k * plane + (long)(js - 1) * nxp + i];
-}
-
-struct Rot { double a, b; bool flip; };
-
-__device__ __forceinline__ void rot_fw(double &r, double &c, const Rot &t)
-{
-    const double tr = r, tc = c;
-    r = tr * t.b + tc * t.a;
-    c = tc * t.b - tr * t.a;
-    if (t.flip) { r = -r; c = -c; }
-}
-__device__ __forceinline__ void rot_bw(double &r, double &c, const Rot &t)
-{
-    const double tr = r, tc = c;
-    r = tr * t.b - tc * t.a;
-    c = tc * t.b + tr * t.a;
-    if (t.flip) { r = -r; c = -c; }
-}
-
-// One thread per (i, row pair, k): rows j and jr = ny-j+2 (j = 1 has no partner; for even ny the
-// middle row pairs with itself and keeps the second store, like the reference).
-// MODE 0: fw only (normalise, z/x rotations, y split)            -> stretched path, step 1
-// MODE 1: bw only (y recombination, z/x inverse rotations)       -> stretched path, step 3
-// MODE 2: fw, -1/waves, bw fused (uniform y): 1R + 1W of c, 1R of waves
-// ZROT = false (Poisson 110 on the z-first transposed problem): the third direction is not periodic either -- no
-// rotation along it here, it gets its own paired split (k_spectral_pair_z)
-template <int MODE, bool ZROT = true>
-__global__ void __launch_bounds__(256)
-    k_spectral_010(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx,
-                   const double *__restrict__ ax, const double *__restrict__ bx, const double *__restrict__ ay,
-                   const double *__restrict__ by, const double *__restrict__ az, const double *__restrict__ bz)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y + 1, k = blockIdx.z;  // j = 1 .. ny/2+1
-    if (i >= nxs) return;
-    const int jr = ny - j + 2;
-    const bool paired = j >= 2, self = paired && jr == j;
-    const size_t il = ((size_t)k * ny + (j - 1)) * nxs + i;
-    const size_t ir = paired ? ((size_t)k * ny + (jr - 1)) * nxs + i : il;
-    const Rot rz{az[k], bz[k], (k + 1) > nz / 2 + 1}, rx{ax[i], bx[i], (i + 1) > nx / 2 + 1};
-    double2 L = c[il], R = paired && !self ? c[ir] : L;
-    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
-    if (MODE != 1) {
-        l_r = l_r / nx / ny / nz; l_c = l_c / nx / ny / nz;
-        if (ZROT) rot_fw(l_r, l_c, rz);
-        rot_fw(l_r, l_c, rx);
-        if (self) { r_r = l_r; r_c = l_c; }
-        else if (paired) {
-            r_r = r_r / nx / ny / nz; r_c = r_c / nx / ny / nz;
-            if (ZROT) rot_fw(r_r, r_c, rz);
-            rot_fw(r_r, r_c, rx);
-        }
-        if (paired) {
-            const double a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
-            const double n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
-            const double n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
-            const double n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
-            const double n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
-            l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
-            if (self) { l_r = r_r; l_c = r_c; }  // the second store wins on the self-paired row
-        }
-    }
-    if (MODE == 2) {
-        const bool zero_line = (i + 1) == nx / 2 + 1 && (k + 1) == nz / 2 + 1;
-        const double wl = waves[il];
-        l_r = fabs(wl) < 1.e-16 ? 0.0 : -l_r / wl;
-        l_c = fabs(wl) < 1.e-16 ? 0.0 : -l_c / wl;
-        if (zero_line) { l_r = 0.0; l_c = 0.0; }
-        if (paired) {
-            const double wr = waves[ir];
-            r_r = fabs(wr) < 1.e-16 ? 0.0 : -r_r / wr;
-            r_c = fabs(wr) < 1.e-16 ? 0.0 : -r_c / wr;
-            if (zero_line) { r_r = 0.0; r_c = 0.0; }
-        }
-    }
-    if (MODE != 0) {
-        if (paired) {
-            if (self) { r_r = l_r; r_c = l_c; }
-            const double a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
-            const double n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
-            const double n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
-            const double n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
-            const double n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
-            l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
-            if (self) { l_r = r_r; l_c = r_c; }
-        }
-        if (ZROT) rot_bw(l_r, l_c, rz);
-        rot_bw(l_r, l_c, rx);
-        if (paired && !self) {
-            if (ZROT) rot_bw(r_r, r_c, rz);
-            rot_bw(r_r, r_c, rx);
-        }
-    }
-    c[il] = make_double2(l_r, l_c);
-    if (paired && !self) c[ir] = make_double2(r_r, r_c);
-}
+#include "spectral010.h"
 
 // Poisson 110, the middle of fft_postprocess_110 (src/backend/cuda/poisson_fft.f90:926-989) in the layout of the
 // z-first transposed problem c[z'][y'][x'] (x' = z: R2C; y' = x, z' = y: both non-periodic): paired split along
@@ -493,104 +375,6 @@ __global__ void __launch_bounds__(256)
     out[(long)(kd - 1) * plane + (long)j * nxp + i] = in[(long)(ks - 1) * plane + (long)j * nxp + i];
 }
 
-// Pentadiagonal operators: the reference eliminates the matrix in place at EVERY solve
-// (and re-copies it from a store first, src/backend/cuda/poisson_fft.f90:868-913).  The
-// elimination does not depend on the right-hand side, so it is done once here with the
-// reference's operation order and only what the right-hand side needs is kept, in the
-// matrix's own storage ([d][k][j][i], d = diagonal slot):
-//   slot 0 row j : m2_j  multiplier of row j into row j+2          (j <= n-2)
-//   slot 1 row j : m1_j  multiplier of row j into row j+1          (j <= n-1; j = n-1: last-row tmp)
-//   slot 2 row j : 1/a3_j (0 where |a3_j| <= eps)   (j <= n-1);  row n: the last pivot dd
-//   slot 3 row j : a4_j eliminated                                  (j <= n-1)
-//   slot 4 row j : a5_j                                             (j <= n-2)
-// so that the solve applies bit-for-bit the same operations to the right-hand side.
-__global__ void __launch_bounds__(64) k_penta_factor(double *__restrict__ a, int nxs, int n, int nz)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i >= nxs) return;
-    const double eps = 1.e-16;
-    const size_t ds = (size_t)nz * n * nxs;
-#define A(j, d) a[(size_t)((d) - 1) * ds + ((size_t)k * n + ((j) - 1)) * nxs + i]
-    for (int j = 1; j <= n - 2; j++) {
-        const double a3 = A(j, 3), a4 = A(j, 4), a5 = A(j, 5);
-        const double m1 = fabs(a3) > eps ? A(j + 1, 2) / a3 : 0.0;
-        A(j + 1, 3) = A(j + 1, 3) - m1 * a4;
-        A(j + 1, 4) = A(j + 1, 4) - m1 * a5;
-        const double m2 = fabs(a3) > eps ? A(j + 2, 1) / a3 : 0.0;
-        A(j + 2, 2) = A(j + 2, 2) - m2 * a4;
-        A(j + 2, 3) = A(j + 2, 3) - m2 * a5;
-        A(j, 1) = m2;
-        A(j, 2) = m1;
-        A(j, 3) = fabs(a3) > eps ? 1.0 / a3 : 0.0;
-    }
-    const double a3 = A(n - 1, 3);
-    const double tmp = fabs(a3) > eps ? A(n, 2) / a3 : 0.0;
-    const double dd = A(n, 3) - tmp * A(n - 1, 4);
-    A(n - 1, 2) = tmp;
-    A(n - 1, 3) = fabs(a3) > eps ? 1.0 / a3 : 0.0;
-    A(n, 3) = dd;
-#undef A
-}
-
-// One thread per (i, k): coalesced along i.  Per spectral entry: forward r/w of the rhs + m1, m2;
-// backward r/w + 1/a3, a4, a5 = 104 B.
-__global__ void __launch_bounds__(64)
-    k_penta_solve(double2 *__restrict__ c, const double *__restrict__ lu, int off, int inc, int nxs, int ny,
-                  int nz, int n, int nx)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i >= nxs) return;
-    const double eps = 1.e-16;
-    const size_t ds = (size_t)nz * n * nxs;
-#define LU(j, d) lu[(size_t)((d) - 1) * ds + ((size_t)k * n + ((j) - 1)) * nxs + i]
-#define C(jm) c[((size_t)k * ny + ((jm) - 1)) * nxs + i]
-    const int h = inc / 2;
-    // forward: rows j+1, j+2 -= m * row j; two rows are carried in registers
-    double2 r0 = C(inc * 1 + off - h), r1 = C(inc * 2 + off - h);
-    for (int j = 1; j <= n - 2; j++) {
-        const int jm = inc * j + off - h;
-        double2 r2 = C(jm + 2 * inc);
-        const double m1 = LU(j, 2), m2 = LU(j, 1);
-        r1.x = r1.x - m1 * r0.x; r1.y = r1.y - m1 * r0.y;
-        r2.x = r2.x - m2 * r0.x; r2.y = r2.y - m2 * r0.y;
-        C(jm) = r0;
-        r0 = r1; r1 = r2;
-    }
-    // last two rows: r0 = row n-1, r1 = row n
-    const int nm = inc * n + off - h;
-    const double tmp = LU(n - 1, 2), dd = LU(n, 3), inv = LU(n - 1, 3), a4n = LU(n - 1, 4);
-    double2 xn, xn1;
-    if (fabs(dd) > eps) {
-        const double t = tmp / dd;
-        xn.x = r1.x / dd - t * r0.x;
-        xn.y = r1.y / dd - t * r0.y;
-    } else {
-        xn.x = 0.0; xn.y = 0.0;
-    }
-    const double q = a4n * inv;
-    xn1.x = r0.x * inv - xn.x * q;
-    xn1.y = r0.y * inv - xn.y * q;
-    const bool zero_line = (i + 1) == nx / 2 + 1 && (k + 1) == nz / 2 + 1;
-    if (zero_line) { xn = make_double2(0.0, 0.0); xn1 = make_double2(0.0, 0.0); }
-    C(nm) = xn;
-    C(nm - inc) = xn1;
-    // backward
-    double2 x1 = xn1, x2 = xn;
-    for (int j = n - 2; j >= 1; j--) {
-        const int jm = inc * j + off - h;
-        const double2 r = C(jm);
-        const double iv = LU(j, 3), a4 = LU(j, 4), a5 = LU(j, 5);
-        double2 x;
-        x.x = iv * (r.x - a4 * x1.x - a5 * x2.x);
-        x.y = iv * (r.y - a4 * x1.y - a5 * x2.y);
-        if (zero_line) x = make_double2(0.0, 0.0);
-        C(jm) = x;
-        x2 = x1; x1 = x;
-    }
-#undef LU
-#undef C
-}
-
 extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_y: bad argument");
@@ -651,12 +435,12 @@ extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
                  *bz = az + p->nz;
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     hipStream_t st = p->b->stream;
-    dim3 gy((p->nxs + 255) / 256, p->ny / 2 + 1, p->nz), gz((p->nxs + 255) / 256, p->ny, p->nz / 2 + 1);
-    hipLaunchKernelGGL((k_spectral_010<0, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, ax, bx,
-                       ay, by, az, bz);
+    dim3 gy = spectral_010_grid(p->nxs, p->ny, p->nz), gz((p->nxs + 255) / 256, p->ny, p->nz / 2 + 1);
+    hipLaunchKernelGGL((k_spectral_010<0, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, 0, ax,
+                       bx, ay, by, az, bz);
     hipLaunchKernelGGL(k_spectral_pair_z, gz, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, az, bz);
-    hipLaunchKernelGGL((k_spectral_010<1, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, ax, bx,
-                       ay, by, az, bz);
+    hipLaunchKernelGGL((k_spectral_010<1, false>), gy, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, 0, ax,
+                       bx, ay, by, az, bz);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -673,8 +457,8 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
         // (pad columns all zero: k_penta_factor / k_penta_solve guard their divisions by |a3| > eps)
         if (int rc = upload_pitched(p->lu[s], src[s], rows, p->nxm, p->nxs, sizeof(double))) return rc;
-        hipLaunchKernelGGL(k_penta_factor, dim3((p->nxs + 63) / 64, p->nz), dim3(64), 0, p->b->stream, p->lu[s],
-                           p->nxs, n, p->nz);
+        hipLaunchKernelGGL(k_penta_factor, penta_grid(p->nxs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->nxs, n,
+                           p->nz);
         X3D_HIP(hipGetLastError());
     }
     X3D_HIP(hipStreamSynchronize(p->b->stream));
@@ -686,33 +470,9 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
 extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_010: null argument");
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
-                 *bz = az + p->nz;
-    dim3 grid((p->nxs + 255) / 256, p->ny / 2 + 1, p->nz);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
-    hipStream_t st = p->b->stream;
-#define SPEC(M_)                                                                                               \
-    hipLaunchKernelGGL(k_spectral_010<M_>, grid, dim3(256), 0, st, p->c, p->waves, p->nxs, p->ny, p->nz, p->nx, \
-                       ax, bx, ay, by, az, bz)
-    if (!p->stretched) {
-        SPEC(2);
-    } else {
-        SPEC(0);
-        dim3 g2((p->nxs + 63) / 64, p->nz);
-        if (p->sym) {  // odd rows, then even rows (src/backend/cuda/poisson_fft.f90:880-895)
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, p->c, p->lu[0], 0, 2, p->nxs, p->ny, p->nz,
-                               p->ny / 2, p->nx);
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, p->c, p->lu[1], 1, 2, p->nxs, p->ny, p->nz,
-                               p->ny / 2, p->nx);
-        } else {
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, p->c, p->lu[0], 0, 1, p->nxs, p->ny, p->nz,
-                               p->ny, p->nx);
-        }
-        SPEC(1);
-    }
-#undef SPEC
-    X3D_HIP(hipGetLastError());
-    return 0;
+    return spectral_010_launch(p->b->stream, p->c, p->waves, p->nxs, p->nx, p->ny, p->nz, 0, p->ab, p->stretched, p->sym,
+                               p->lu);
 }
 
 // poisson_010 (src/poisson_fft.f90:228-242): f holds the rhs on entry and the solution on exit

@@ -192,9 +192,6 @@ extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
     return 0;
 }
 
-// dir 0 / 1 and the spectral division for ONE part of the received array (see the header comment)
-extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part);
-extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
 
 // waves: this rank's spectral block [ys][nxs][nz], z fastest (real part = imaginary part); ax..bz: full arrays
 extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx,
@@ -241,10 +238,14 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
 
 // dir 0: part `part` of the received array, R_m[nz][ysc][nxs] -> T_m[ysc*nxs][nz], forward z transform (the
 // spectrum stays in T); dir 1: backward z transform of T_m, then back to R_m
-extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part)
+// fused_ok: the caller runs forward ; division ; backward of this part back to back (the *_part entry points of the
+// pipelined solve): with fused_z the three are ONE kernel, launched by the division call.  The plain hooks
+// (x3d_sfft_fft_z / x3d_sfft_postprocess_000 = fft_forward / fft_postprocess_000 / fft_backward of the reference,
+// src/poisson_fft.f90:45-62) keep their own meaning at every grid size: after fft_forward the spectrum IS transformed
+static int sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part, bool fused_ok)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_fft_z_part: bad argument");
-    if (p->fused_z) return 0;  // (forward, division and backward are one kernel: x3d_sfft_postprocess_000_part)
+    if (p->fused_z && fused_ok) return 0;  // (forward, division and backward are one kernel: sfft_postprocess_part)
     const int W = p->ysc * p->nxs;
     double2 *R = (double2 *)recvbuf + (size_t)part * p->nz * W, *T = p->t + (size_t)part * p->nz * W;
     if (dir == 0) {
@@ -268,21 +269,26 @@ extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int pa
     return 0;
 }
 
+extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part)
+{
+    return sfft_fft_z_part(p, recvbuf, dir, part, true);
+}
+
 extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
-        if (int rc = x3d_sfft_fft_z_part(p, recvbuf, dir, m)) return rc;
+        if (int rc = sfft_fft_z_part(p, recvbuf, dir, m, false)) return rc;
     return 0;
 }
 
-extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part)
+static int sfft_postprocess_part(x3d_sfft *p, double *recvbuf, int part, bool fused_ok)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_postprocess_000_part: bad argument");
     const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     const size_t off = (size_t)part * p->nz * p->ysc * p->nxs;  // waves[ys][nxs][nz] and T share the part offset
-    if (p->fused_z) {
+    if (p->fused_z && fused_ok) {
         bool ok = false;
         ProfScope ps(p->b, X3D_K_FFT, 3);
         if (int rc = x3d_fft512_peers(p->b, (double2 *)recvbuf + off, (long)p->ysc * p->nxs, p->pz, p->waves + off, p->ab,
@@ -299,11 +305,16 @@ extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int p
     return 0;
 }
 
+extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part)
+{
+    return sfft_postprocess_part(p, recvbuf, part, true);
+}
+
 extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
-        if (int rc = x3d_sfft_postprocess_000_part(p, recvbuf, m)) return rc;
+        if (int rc = sfft_postprocess_part(p, recvbuf, m, false)) return rc;
     return 0;
 }
 

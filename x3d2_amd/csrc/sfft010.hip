@@ -1,0 +1,257 @@
+// Distributed spectral Poisson solver for NON-PERIODIC y (010: the channel case) on z-slab decompositions [1, 1, pz]
+// -- BASELINE configs[4] on several GPUs.  The reference has no such solver: poisson_fft_t%base_init stops with
+// "Multiple ranks are not yet supported for non-periodic BCs!" (/root/reference/src/poisson_fft.f90:177-180), because
+// its 2decomp / cuFFTMp pencil layouts split y in spectral space while process_spectral_010 couples the rows j and
+// ny - j + 2 and the stretched-mesh operator is a pentadiagonal system along y
+// (src/backend/cuda/poisson_fft.f90:822-924, kernels/spectral_processing.f90:385-702).
+//
+// Here y never leaves the rank: the ONE transpose pair of a solve splits the x MODES.
+//   f[zl][ny][nx]  (rows already in enforce_periodicity_y's order)
+//   --rocFFT 2-D, R2C along x, C2C along y, batched over the zl local planes-->  C0[zl][ny][nxs]   nxs = pz * xs
+//   --pack-->  S[peer][zl][ny][xs]          (peer r gets the x modes r xs .. (r + 1) xs - 1 of every local row)
+//   --all-to-all among the pz ranks-->  R[peer][zl][ny][xs] = W[nz][ny][xs]   (chunks arrive in z order)
+//   --z transform on W itself (stride ny xs)-->  this rank's xs modes x ALL ny rows x ALL nz modes
+//   --fft_postprocess_010 on W: the single-rank kernels (spectral010.h) with the mode offset i0 = rz xs: uniform y
+//     one kernel, stretched y fw ; pentadiagonal solves (factored once at set-up) ; bw
+//   --inverse z transform, all-to-all back, unpack, inverse 2-D transform-->  f
+// xs = ceil((nx/2 + 1) / pz): every rank owns the same number of mode columns, the columns beyond nx/2 + 1 on the last
+// rank are padding (zeros in, wave numbers one, matrices zero: the kernels' guarded divisions leave zeros).
+#include <hipfft/hipfft.h>
+
+#include "spectral010.h"
+
+#define X3D_FFT(expr)                                                                          \
+    do {                                                                                       \
+        hipfftResult r_ = (expr);                                                              \
+        if (r_ != HIPFFT_SUCCESS) {                                                            \
+            x3d_set_error("%s failed: hipfft error %d (%s:%d)", #expr, (int)r_, __FILE__,      \
+                          __LINE__);                                                           \
+            return 3;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+struct x3d_sfft010 {
+    x3d_backend *b;
+    int nx, ny, nz;      // global cell dims
+    int nxm;             // nx/2 + 1 modes along x
+    int pz, rz, zl;      // ranks along z, this rank, local planes
+    int xs, nxs;         // mode columns per rank; nxs = pz * xs = row pitch of the local 2-D spectrum
+    hipfftHandle plan_xy_fw, plan_xy_bw, plan_z;
+    double2 *c0;         // [zl][ny][nxs]
+    double *waves;       // [nz][ny][xs] (pads: one)
+    double *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
+    int nab_x;           // length of the ax / bx tables on the device
+    int stretched, sym;
+    double *lu[2];       // factored pentadiagonal operators [5][nz][n][xs]
+    void *work;
+};
+
+// C0[zl][ny][nxs] -> S[peer][zl][ny][xs] (UNPACK: the other way); one thread per complex number of C0
+template <bool UNPACK>
+__global__ void __launch_bounds__(256)
+    k_sfft010_pack(double2 *__restrict__ s, double2 *__restrict__ c0, long rows, int xs, int pz)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nxs = xs * pz;
+    const long row = t / nxs;
+    if (row >= rows) return;
+    const int col = (int)(t % nxs), peer = col / xs, i = col % xs;
+    const long si = ((long)peer * rows + row) * xs + i;
+    if (UNPACK) c0[t] = s[si];
+    else s[si] = c0[t];
+}
+
+extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz)
+{
+    X3D_REQUIRE(b && out && nglob, "x3d_sfft010_create: null argument");
+    X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft010_create: bad rank grid");
+    X3D_REQUIRE(nglob[2] % pz == 0, "x3d_sfft010_create: nz = %d does not divide by pz = %d", nglob[2], pz);
+    x3d_sfft010 *p = new x3d_sfft010();
+    memset(p, 0, sizeof *p);
+    p->b = b;
+    p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2];
+    p->nxm = p->nx / 2 + 1;
+    p->pz = pz; p->rz = rz; p->zl = p->nz / pz;
+    p->xs = (p->nxm + pz - 1) / pz;
+    p->nxs = p->xs * pz;
+    X3D_REQUIRE(p->nx <= b->nxp && p->ny <= b->nyp && p->zl <= b->nzp, "x3d_sfft010_create: local block mismatch");
+    const size_t n0 = (size_t)p->zl * p->ny * p->nxs, nw = (size_t)p->nz * p->ny * p->xs;
+    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
+    X3D_HIP(hipMemset(p->c0, 0, sizeof(double2) * n0));  // (pad columns stay zero: the transforms never write them)
+    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * nw));
+    p->nab_x = p->nx > p->nxs ? p->nx : p->nxs;
+    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
+    X3D_HIP(hipMemset(p->ab, 0, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
+    hipfftHandle *pl[3] = {&p->plan_xy_fw, &p->plan_xy_bw, &p->plan_z};
+    size_t ws[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        X3D_FFT(hipfftCreate(pl[i]));
+        X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
+    }
+    // real side: the pitched block's planes; spectral side: dense rows of nxs (the first nxm are written)
+    int nn[2] = {p->ny, p->nx}, re[2] = {b->nyp, b->nxp}, ce[2] = {p->ny, p->nxs};
+    X3D_FFT(hipfftMakePlanMany(p->plan_xy_fw, 2, nn, re, 1, b->nxp * b->nyp, ce, 1, p->ny * p->nxs, HIPFFT_D2Z, p->zl,
+                               &ws[0]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_xy_bw, 2, nn, ce, 1, p->ny * p->nxs, re, 1, b->nxp * b->nyp, HIPFFT_Z2D, p->zl,
+                               &ws[1]));
+    // z transform on W[nz][ny][xs] itself: stride ny * xs, one transform per (row, mode)
+    int nzv[1] = {p->nz}, ze[1] = {p->nz};
+    const int zstride = p->ny * p->xs;
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, zstride, 1, ze, zstride, 1, HIPFFT_Z2Z, zstride, &ws[2]));
+    size_t wmax = 0;
+    for (int i = 0; i < 3; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
+    if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
+    for (int i = 0; i < 3; i++) X3D_FFT(hipfftSetWorkArea(*pl[i], p->work));
+    *out = p;
+    return 0;
+}
+
+extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
+{
+    if (!p) return 0;
+    hipfftDestroy(p->plan_xy_fw); hipfftDestroy(p->plan_xy_bw); hipfftDestroy(p->plan_z);
+    hipFree(p->c0); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->lu[0]); hipFree(p->lu[1]);
+    delete p;
+    return 0;
+}
+
+// out = {chunk (complex numbers per peer), zl, xs, i0 (first x mode of this rank), nxm}
+extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[5])
+{
+    X3D_REQUIRE(p && out, "null argument");
+    out[0] = (long)p->zl * p->ny * p->xs; out[1] = p->zl; out[2] = p->xs; out[3] = (long)p->rz * p->xs; out[4] = p->nxm;
+    return 0;
+}
+
+// waves: this rank's block [nz][ny][xs] (x fastest; pad columns: one); ax .. bz: the global tables
+extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const double *ax, const double *bx,
+                                     const double *ay, const double *by, const double *az, const double *bz)
+{
+    X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
+    X3D_HIP(hipMemcpy(p->waves, waves, sizeof(double) * (size_t)p->nz * p->ny * p->xs, hipMemcpyHostToDevice));
+    const double *src[6] = {ax, bx, ay, by, az, bz};
+    const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
+    const int slot[6] = {p->nab_x, p->nab_x, p->ny, p->ny, p->nz, p->nz};
+    double *d = p->ab;
+    for (int i = 0; i < 6; i++) {
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        d += slot[i];
+    }
+    return 0;
+}
+
+// a0, a1: this rank's columns of the pentadiagonal operators, [5][nz][n][xs] (pad columns zero); sym: odd / even rows
+extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double *a0, const double *a1)
+{
+    X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_sfft010_set_stretching: null argument");
+    X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_sfft010_set_stretching: odd/even split needs an even ny");
+    const int n = sym ? p->ny / 2 : p->ny;
+    X3D_REQUIRE(n >= 3, "x3d_sfft010_set_stretching: too few rows");
+    const size_t bytes = sizeof(double) * 5 * (size_t)p->nz * n * p->xs;
+    const double *src[2] = {a0, a1};
+    for (int s = 0; s < (sym ? 2 : 1); s++) {
+        if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
+        X3D_HIP(hipMemcpy(p->lu[s], src[s], bytes, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_penta_factor, penta_grid(p->xs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->xs, n, p->nz);
+        X3D_HIP(hipGetLastError());
+    }
+    X3D_HIP(hipStreamSynchronize(p->b->stream));
+    p->stretched = 1;
+    p->sym = sym;
+    return 0;
+}
+
+// enforce / undo_periodicity_y on the rank's zl planes (y is whole on every rank)
+extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const double *f_in, int undo)
+{
+    X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_sfft010_periodicity_y: bad argument");
+    x3d_backend *b = p->b;
+    dim3 grid((p->nx + 255) / 256, p->ny, p->zl);
+    ProfScope ps(b, X3D_K_COPY);
+    if (undo)
+        hipLaunchKernelGGL(k_periodicity_y<true>, grid, dim3(256), 0, b->stream, f_out, f_in, p->nx, p->ny, p->zl,
+                           (long)b->nxp, (long)b->nxp * b->nyp);
+    else
+        hipLaunchKernelGGL(k_periodicity_y<false>, grid, dim3(256), 0, b->stream, f_out, f_in, p->nx, p->ny, p->zl,
+                           (long)b->nxp, (long)b->nxp * b->nyp);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// 2-D transform of the local planes; the result lands in sendbuf as [peer][zl][ny][xs]
+extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf)
+{
+    X3D_REQUIRE(p && f_in && sendbuf, "null argument");
+    {
+        ProfScope ps(p->b, X3D_K_FFT, 1);
+        X3D_FFT(hipfftSetStream(p->plan_xy_fw, p->b->stream));
+        X3D_FFT(hipfftExecD2Z(p->plan_xy_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+    }
+    ProfScope ps(p->b, X3D_K_PACK);
+    const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
+    hipLaunchKernelGGL(k_sfft010_pack<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
+                       (double2 *)sendbuf, p->c0, rows, p->xs, p->pz);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// z transform of the received array W[nz][ny][xs], in place; dir 0 forward, 1 backward
+extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    ProfScope ps(p->b, X3D_K_FFT, 3);
+    X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
+    X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)recvbuf, (hipfftDoubleComplex *)recvbuf,
+                          dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    return 0;
+}
+
+// fft_postprocess_010 on this rank's x modes (all rows, all z modes)
+extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    ProfScope ps(p->b, X3D_K_SPECTRAL);
+    // tables: ax bx at pitch nab_x -- spectral_010_launch expects them nx apart: hand it the pieces
+    const double *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
+                 *bz = az + p->nz;
+    hipStream_t st = p->b->stream;
+    double2 *c = (double2 *)recvbuf;
+    const int i0 = p->rz * p->xs;
+    const dim3 grid = spectral_010_grid(p->xs, p->ny, p->nz);
+#define SPEC(M_)                                                                                                    \
+    hipLaunchKernelGGL(k_spectral_010<M_>, grid, dim3(256), 0, st, c, p->waves, p->xs, p->ny, p->nz, p->nx, i0, ax, bx, \
+                       ay, by, az, bz)
+    if (!p->stretched) {
+        SPEC(2);
+    } else {
+        SPEC(0);
+        const dim3 g2 = penta_grid(p->xs, p->nz);
+        if (p->sym) {
+            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[0], 0, 2, p->xs, p->ny, p->nz, p->ny / 2, p->nx, i0);
+            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[1], 1, 2, p->xs, p->ny, p->nz, p->ny / 2, p->nx, i0);
+        } else {
+            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[0], 0, 1, p->xs, p->ny, p->nz, p->ny, p->nx, i0);
+        }
+        SPEC(1);
+    }
+#undef SPEC
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// unpack the returned array S[peer][zl][ny][xs] and transform back to the real planes
+extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out)
+{
+    X3D_REQUIRE(p && sendbuf && f_out, "null argument");
+    {
+        ProfScope ps(p->b, X3D_K_PACK);
+        const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
+        hipLaunchKernelGGL(k_sfft010_pack<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
+                           (double2 *)sendbuf, p->c0, rows, p->xs, p->pz);
+        X3D_HIP(hipGetLastError());
+    }
+    ProfScope ps(p->b, X3D_K_FFT, 2);
+    X3D_FFT(hipfftSetStream(p->plan_xy_bw, p->b->stream));
+    X3D_FFT(hipfftExecZ2D(p->plan_xy_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+    return 0;
+}

@@ -38,6 +38,7 @@ class Allocator:
         self.device = device
         self.free = []
         self.next_id = 0
+        self.stagger = int(os.environ.get("X3D_BLOCK_STAGGER", str(self.STAGGER)))  # (read once)
 
     # Blocks start 4224 B (one padded row of a 512^3 block) further into their allocation than the previous one,
     # modulo 16: the kernels stream 4-12 blocks at the same relative offset at once, and with every block on a
@@ -47,7 +48,7 @@ class Allocator:
 
     def create_block(self):
         self.next_id += 1
-        st = int(os.environ.get("X3D_BLOCK_STAGGER", str(self.STAGGER)))
+        st = self.stagger
         if st:
             off = (self.next_id % 16) * st
             return Field(torch.zeros(self.n + 16 * st, dtype=torch.float64, device=self.device)[off:off + self.n],

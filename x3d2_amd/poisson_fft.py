@@ -43,14 +43,15 @@ def wave_numbers(n, L, d, periodic, c_a, c_b, c_alpha):
     return a, b, k, e, k2
 
 
-def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs):
+def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs, xsl=None):
     """src/poisson_fft.f90:275-652: pentadiagonal spectral operators for a stretched y
     (JCP 228 (2009) 5989, Sec. 5).  Real and imaginary copies of the reference are equal
     (every wave number is cmplx(1,1)*x), one copy is kept.  Layout [5][nz][n][nx_spec].
     Entries the reference leaves unset or reads past ky(ny) for (never used by the solve)
-    are zero here."""
+    are zero here.  xsl: only these x modes (a rank of the slab solver builds its own columns)."""
     pi = 4 * np.arctan(1.0)
     nxs, nys, nzs = pf.nx_spec, pf.ny_spec, pf.nz_spec
+    xsl = slice(0, nxs) if xsl is None else xsl
 
     def transfer(t, e, d, n):
         tmp = e[:n] * d
@@ -58,13 +59,15 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs):
         return 2 * (it.a * np.cos(tmp * 0.5) + it.b * np.cos(tmp * 1.5) + it.c * np.cos(tmp * 2.5)
                     + it.d * np.cos(tmp * 3.5)) / (1.0 + 2 * it.alpha * np.cos(tmp))
 
-    tx = transfer(xd, exs, mesh.d[0], nxs)
+    tx = transfer(xd, exs, mesh.d[0], nxs)[xsl]
     ty = transfer(yd, eys, mesh.d[1], nys)
     tz = transfer(zd, ezs, mesh.d[2], nzs)
     pf.trans_x, pf.trans_y, pf.trans_z = tx, ty, tz
     kyp = np.concatenate([pf.ky, np.zeros(4)])
     TX, TZ = tx[None, None, :], tz[:, None, None]
-    KX, KZ = pf.kx[None, None, :nxs], pf.kz[:nzs, None, None]
+    KX, KZ = pf.kx[None, None, :nxs][:, :, xsl], pf.kz[:nzs, None, None]
+    k2x_sel = pf.k2x[:nxs][xsl]
+    nxs = len(tx)
 
     def km(iy):  # get_km(ix, iy, iz), iy 1-based array -> [nz, len(iy), nx]
         return (TX * kyp[np.asarray(iy) - 1][None, :, None]) * TZ
@@ -91,7 +94,8 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs):
         a[4, :, :n - 2] = (-(a1 * a1 * km(iy + 1)) * km(iy + 2))[:, :n - 2]
         a[1, :, 1:] = (((a0 * a1) * km(np.clip(iy - 1, 1, None))) * (K + km(np.clip(iy - 1, 1, None))))[:, 1:]
         a[0, :, 2:] = (-(a1 * a1 * km(np.clip(iy - 1, 1, None))) * km(np.clip(iy - 2, 1, None)))[:, 2:]
-        a[2, 0, 0, 0] = 1.0; a[3, 0, 0, 0] = 0.0; a[4, 0, 0, 0] = 0.0
+        if xsl.start in (0, None) and nxs > 0:
+            a[2, 0, 0, 0] = 1.0; a[3, 0, 0, 0] = 0.0; a[4, 0, 0, 0] = 0.0
         pf.a_full = a
         return
     pf.stretched_y_sym = True
@@ -142,7 +146,7 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs):
         # diagonal - 2
         a[0, :, 2:] = (-(((a1 * a1) * Km2) * Km4))[:, 2:]
         out[name] = a
-    zero = (pf.k2x[:nxs][None, :] < 1e-15) & (pf.k2z[:nzs][:, None] < 1e-15)  # [nz, nx]
+    zero = (k2x_sel[None, :] < 1e-15) & (pf.k2z[:nzs][:, None] < 1e-15)  # [nz, nx]
     ao = out["odd"]
     ao[2, :, 0, :][zero] = 1.0
     ao[3, :, 0, :][zero] = 0.0
@@ -158,6 +162,9 @@ def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     if mesh.nproc > 1 or force in ("1", "slab"):
         ny = int(mesh.get_global_dims(CELL)[1])
         pz = int(mesh.nproc_dir[2])
+        if tuple(bool(x) for x in mesh.periodic_BC) == (True, False, True):
+            # non-periodic y on z slabs (the channel case): the x modes are split over the ranks, y stays whole
+            return HipSlabPoissonFFT010(backend, mesh, xdirps, ydirps, zdirps)
         slab_ok = (int(mesh.nproc_dir[1]) == 1 and ny == 512 and 512 % pz == 0 and all(mesh.periodic_BC)
                    and os.environ.get("X3D_NO_SLAB_FFT") != "1")
         if slab_ok and force != "1":
@@ -185,7 +192,7 @@ class HipPoissonFFT:
         if self.periodic_x and self.periodic_y and self.periodic_z:
             self.case = "000"
         elif self.periodic_x and (not self.periodic_y) and self.periodic_z:
-            if mesh.nproc > 1:
+            if mesh.nproc > 1 and not isinstance(self, HipSlabPoissonFFT010):
                 raise X3dError("Multiple ranks are not yet supported for non-periodic BCs!")
             self.case = "010"
         elif (not self.periodic_x) and self.periodic_y and self.periodic_z:
@@ -210,8 +217,11 @@ class HipPoissonFFT:
         self._waves_set(mesh, xdirps, ydirps, zdirps)
         if self.case == "010" and mesh.stretched[1]:
             self.stretched_y = True
-            stretching_matrix(self, mesh, xdirps, ydirps, zdirps, *self._es)
+            if not isinstance(self, HipSlabPoissonFFT010):  # (the slab solver builds its own columns only)
+                stretching_matrix(self, mesh, xdirps, ydirps, zdirps, *self._es)
+        self._dirps = (xdirps, ydirps, zdirps)
         self._create()
+        self._dirps = None
 
     def _create(self):
         backend, mesh = self.backend, self.mesh
@@ -656,6 +666,103 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         for hnd in back:
             hnd.wait()
         _lib.check(lib.x3d_sfft_backward_local(h, self.sbuf.data_ptr(), f.ptr))
+
+    def get_spectral(self):
+        raise X3dError("get_spectral: single-rank test hook")
+
+    def set_spectral(self, c):
+        raise X3dError("set_spectral: single-rank test hook")
+
+
+class HipSlabPoissonFFT010(HipPoissonFFT):
+    """010 solver (non-periodic y, uniform or stretched: the channel case) over a z-slab decomposition [1, 1, pz]
+    (csrc/sfft010.hip) -- BASELINE configs[4] on several GPUs.  The reference stops here ("Multiple ranks are not yet
+    supported for non-periodic BCs!", src/poisson_fft.f90:177-180): 2decomp's / cuFFTMp's pencils split y in spectral
+    space, and process_spectral_010 pairs the rows j, ny - j + 2 while the stretched operator is pentadiagonal along y
+    (src/backend/cuda/poisson_fft.f90:822-924).  Here the one transpose pair of a solve splits the x MODES: every rank
+    ends up with xs = ceil((nx/2 + 1) / pz) mode columns x all ny rows x all nz modes, so enforce / undo_periodicity_y,
+    the paired split, the pentadiagonal solves (factored once, this rank's columns of stretching_matrix only) are the
+    single-rank kernels.  Hooks in the reference's order (src/poisson_fft.f90:228-242)."""
+
+    def _create(self):
+        import torch
+        backend, mesh = self.backend, self.mesh
+        if int(mesh.nproc_dir[0]) != 1 or int(mesh.nproc_dir[1]) != 1:
+            raise X3dError("Poisson 010 on several ranks: z slabs only (nproc_dir = 1, 1, N)")
+        self.pz, self.rz = int(mesh.nproc_dir[2]), int(mesh.nrank_dir[2])
+        if self.nx_glob // 2 < self.pz:
+            raise X3dError("Poisson 010 on z slabs: fewer x modes than ranks")
+        h = VP()
+        _lib.check(backend.lib.x3d_sfft010_create(
+            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz))
+        self.h = h
+        sz = (ctypes.c_long * 5)()
+        _lib.check(backend.lib.x3d_sfft010_sizes(h, sz))
+        self.chunk, self.zl, self.xs, self.i0, nxm = [int(v) for v in sz]
+        i1 = min(self.i0 + self.xs, nxm)          # (the last rank's columns beyond nx/2 + 1 are padding)
+        xsl = slice(self.i0, max(i1, self.i0))
+        npad = self.xs - (xsl.stop - xsl.start)
+        wl = self.waves_block(xsl)                # [nz][ny][real columns]
+        if npad:
+            wl = np.pad(wl, ((0, 0), (0, 0), (0, npad)), constant_values=1.0)
+        self._keep = [np.ascontiguousarray(wl, dtype=np.float64)] + \
+            [np.ascontiguousarray(a, dtype=np.float64) for a in (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
+        _lib.check(backend.lib.x3d_sfft010_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
+        self._keep = None
+        if self.stretched_y:
+            stretching_matrix(self, mesh, *self._dirps, *self._es, xsl=xsl)
+            mats = (self.a_odd, self.a_even) if self.stretched_y_sym else (self.a_full, self.a_full)
+            if npad:
+                mats = [np.pad(a, ((0, 0), (0, 0), (0, 0), (0, npad))) for a in mats]
+            mats = [np.ascontiguousarray(a, dtype=np.float64) for a in mats]
+            _lib.check(backend.lib.x3d_sfft010_set_stretching(
+                h, int(self.stretched_y_sym), *[a.ctypes.data_as(_lib.c_double_p) for a in mats]))
+            if not getattr(self, "keep_matrices", False):
+                self.a_odd = self.a_even = self.a_full = None
+        n = 2 * self.pz * self.chunk
+        self.sbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.rbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.peers = [r for r in range(self.pz)]  # (x and y undivided: rank = rz)
+        self.poisson = self.poisson_010
+
+    def __del__(self):
+        try:
+            self.backend.lib.x3d_sfft010_destroy(self.h)
+        except Exception:
+            pass
+
+    def _xchg(self, src, dst):
+        cnt = [2 * self.chunk] * self.pz
+        self.backend.comm.alltoall(src, cnt, dst, cnt, self.peers)
+
+    def enforce_periodicity_y(self, f_out, f_in):
+        _lib.check(self.backend.lib.x3d_sfft010_periodicity_y(self.h, f_out.ptr, f_in.ptr, 0))
+
+    def undo_periodicity_y(self, f_out, f_in):
+        _lib.check(self.backend.lib.x3d_sfft010_periodicity_y(self.h, f_out.ptr, f_in.ptr, 1))
+
+    def fft_forward(self, f_in):
+        lib = self.backend.lib
+        _lib.check(lib.x3d_sfft010_forward_local(self.h, f_in.ptr, self.sbuf.data_ptr()))
+        self._xchg(self.sbuf, self.rbuf)
+        _lib.check(lib.x3d_sfft010_fft_z(self.h, self.rbuf.data_ptr(), 0))
+
+    def fft_postprocess_010(self):
+        _lib.check(self.backend.lib.x3d_sfft010_postprocess_010(self.h, self.rbuf.data_ptr()))
+
+    def fft_backward(self, f_out):
+        lib = self.backend.lib
+        _lib.check(lib.x3d_sfft010_fft_z(self.h, self.rbuf.data_ptr(), 1))
+        self._xchg(self.rbuf, self.sbuf)
+        _lib.check(lib.x3d_sfft010_backward_local(self.h, self.sbuf.data_ptr(), f_out.ptr))
+
+    def interleaved_rows(self):
+        return 0
+
+    def _no_000(self, *a):
+        raise X3dError("HipSlabPoissonFFT010 serves the 010 case only")
+
+    fft_postprocess_000 = poisson_000 = _no_000
 
     def get_spectral(self):
         raise X3dError("get_spectral: single-rank test hook")
