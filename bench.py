@@ -207,7 +207,12 @@ def main():
                     help="N > 1: z slabs [1,1,N] (default) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
+    ap.add_argument("--lazy", action="store_true",
+                    help="the reference's op sequence through the library's deferred execution (csrc/lazy.hip): what the "
+                         "unchanged solver.f90 gets through the Fortran shim; implies --op-granular")
     args = ap.parse_args()
+    if args.lazy:
+        args.op_granular = True
     if args.cpu_baseline_child:  # (never touches the GPU)
         print(json.dumps(cpu_baseline_child(args.cpu_n, args.cpu_steps)))
         return
@@ -259,10 +264,12 @@ def main():
         dims = (per[0], per[1], per[2] * args.gpus)
         case = make_channel(dims, L=(4.0, 2.0, 2.0 * args.gpus), time_intg=args.time_intg,
                             poisson="CG" if args.no_poisson else "FFT", fused=not args.op_granular, rotation=True,
-                            omega_rot=0.12, n_rotate=5000, comm=comm, nproc_dir=nproc_dir, rank=rank)
+                            omega_rot=0.12, n_rotate=5000, comm=comm, nproc_dir=nproc_dir, rank=rank,
+                            lazy=args.lazy)
     else:
         case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
-                        poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular)
+                        poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular,
+                        lazy=args.lazy)
     solver, backend = case.solver, case.solver.backend
     nstage = solver.time_integrator.nstage
 
@@ -425,12 +432,15 @@ def main():
                                   else "rocFFT Poisson (configs[2])" if args.case == "tgv"
                                   else "rocFFT Poisson 010, pentadiagonal spectral solve"),
                    "per_gpu": f"{args.n}^3" if args.case == "tgv" else args.dims, "nproc_dir": list(nproc_dir),
-                   "driver": "op-granular" if args.op_granular else "fused",
+                   "driver": ("op-granular calls recorded and fused inside the library (deferred execution)" if args.lazy
+                              else "op-granular" if args.op_granular else "fused"),
                    "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}"},
         "dof_substeps_per_s": value * nstage,
         "roofline": roofline,
         "kernel_ms": prof,
     }
+    if args.lazy:
+        out["lazy_stats"] = backend.lazy_stats()
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
         # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
         # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)

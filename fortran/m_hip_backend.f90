@@ -38,6 +38,7 @@ module m_hip_allocator
     type(c_ptr) :: handle = c_null_ptr
   contains
     procedure :: create_block => create_hip_block
+    procedure :: release_block => release_hip_block
   end type hip_allocator_t
 
 contains
@@ -63,6 +64,19 @@ contains
     call x3d_check(x3d_block_alloc(self%handle, newblock%dev))
     ptr => newblock
   end function create_hip_block
+
+  subroutine release_hip_block(self, handle)
+    !! allocator_t%release_block (src/allocator.f90:160-168) + the news for the library: whatever the block holds is
+    !! dead until it is written again -- lets the deferred-execution layer drop temporaries and reuse their memory
+    class(hip_allocator_t), intent(inout) :: self
+    class(field_t), pointer :: handle
+    select type (handle)
+    type is (hip_field_t)
+      call x3d_check(x3d_block_discard(self%handle, handle%dev))
+    end select
+    handle%next => self%first
+    self%first => handle
+  end subroutine release_hip_block
 
   subroutine fill_hip(self, c)
     class(hip_field_t) :: self
@@ -193,7 +207,7 @@ contains
       nspec = [dims(2)/2 + 1, dims(1), dims(3)]
       call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
       vdims = mesh%get_dims(VERT)
-      call x3d_check(x3d_backend_create(self%tb, int([vdims(2), vdims(1), vdims(3)], c_int), 0_c_int, c_null_ptr))
+      call x3d_check(x3d_backend_create_like(self%tb, backend, int([vdims(2), vdims(1), vdims(3)], c_int)))
       call x3d_check(x3d_block_alloc(self%tb, self%t1))
       call x3d_check(x3d_block_alloc(self%tb, self%t2))
       allocate (wre(nspec(1), nspec(2), nspec(3)))
@@ -210,7 +224,7 @@ contains
       nspec = [dims(3)/2 + 1, dims(1), dims(2)]
       call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
       vdims = mesh%get_dims(VERT)
-      call x3d_check(x3d_backend_create(self%tb, int([vdims(3), vdims(1), vdims(2)], c_int), 0_c_int, c_null_ptr))
+      call x3d_check(x3d_backend_create_like(self%tb, backend, int([vdims(3), vdims(1), vdims(2)], c_int)))
       call x3d_check(x3d_block_alloc(self%tb, self%t1))
       call x3d_check(x3d_block_alloc(self%tb, self%t2))
       allocate (wre(nspec(1), nspec(2), nspec(3)))
@@ -425,26 +439,6 @@ contains
     call x3d_check(x3d_transpose_zxy_xyz(self%tb, self%backend, dev(f_out), self%t1, int(self%nx_glob, c_int), &
                                          int(self%ny_glob, c_int), int(self%nz_glob, c_int)))
   end subroutine
-  subroutine fw_unsupported(self, f_in)
-    class(hip_poisson_fft_t) :: self
-    class(field_t), intent(in) :: f_in
-    error stop 'HIP backend does not support this fft_forward variant yet!'
-  end subroutine
-  subroutine bw_unsupported(self, f_out)
-    class(hip_poisson_fft_t) :: self
-    class(field_t), intent(inout) :: f_out
-    error stop 'HIP backend does not support this fft_backward variant yet!'
-  end subroutine
-  subroutine pp_unsupported(self)
-    class(hip_poisson_fft_t) :: self
-    error stop 'HIP backend does not support this fft_postprocess variant yet!'
-  end subroutine
-  subroutine fp_unsupported(self, f_out, f_in)
-    class(hip_poisson_fft_t) :: self
-    class(field_t), intent(inout) :: f_out
-    class(field_t), intent(in) :: f_in
-    error stop 'HIP backend does not support enforce/undo periodicity yet!'
-  end subroutine
 end module m_hip_poisson_fft
 
 module m_hip_backend
@@ -514,6 +508,16 @@ contains
       error stop 'hip_backend_t needs a hip_allocator_t'
     end select
     if (mesh%par%nproc_dir(1) /= 1) error stop 'hip shim: x stays undecomposed (as the FFT Poisson solver needs)'
+    ! one rank: the library records the op-granular calls of solver.f90 / time_integrator.f90 / vector_calculus.f90 and
+    ! runs them through its fused kernels (csrc/lazy.hip); X3D_NO_LAZY=1: call by call
+    block
+      character(len=8) :: v
+      integer :: stat
+      call get_environment_variable('X3D_NO_LAZY', v, status=stat)
+      if (mesh%par%nproc == 1 .and. .not. (stat == 0 .and. v(1:1) == '1')) then
+        call x3d_check(x3d_lazy_enable(backend%handle, 1_c_int))
+      end if
+    end block
   end function hip_backend_init
 
   logical function decomposed(self, dir)

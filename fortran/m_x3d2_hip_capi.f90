@@ -26,6 +26,33 @@ module m_x3d2_hip_capi
       import :: c_ptr, c_int
       type(c_ptr), value :: b
     end function
+    ! a second context on the same device and stream (the twin backends of Poisson 100 / 110)
+    integer(c_int) function x3d_backend_create_like(handle, like, dims_vert) bind(C, name='x3d_backend_create_like')
+      import :: c_ptr, c_int
+      type(c_ptr), intent(out) :: handle
+      type(c_ptr), value :: like
+      integer(c_int), intent(in) :: dims_vert(3)
+    end function
+    ! deferred execution: the op-granular calls are recorded and rewritten onto the fused kernels (csrc/lazy.hip)
+    integer(c_int) function x3d_lazy_enable(b, on) bind(C, name='x3d_lazy_enable')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      integer(c_int), value :: on
+    end function
+    integer(c_int) function x3d_lazy_sync(b) bind(C, name='x3d_lazy_sync')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+    end function
+    integer(c_int) function x3d_lazy_stats(b, out) bind(C, name='x3d_lazy_stats')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: b
+      integer(c_long), intent(out) :: out(16)
+    end function
+    ! allocator%release_block: the block's contents are dead until it is written again
+    integer(c_int) function x3d_block_discard(b, f) bind(C, name='x3d_block_discard')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, f
+    end function
     integer(c_size_t) function x3d_block_elems(b) bind(C, name='x3d_block_elems')
       import :: c_ptr, c_size_t
       type(c_ptr), value :: b

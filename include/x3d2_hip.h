@@ -58,6 +58,8 @@ int x3d_abi_version(void);
  * dims_vert: local vertex counts (mesh%get_dims(VERT)); stream: hipStream_t or NULL. */
 int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream);
 int x3d_backend_destroy(x3d_backend *b);
+/* a second context on the SAME device and stream as `like` (the twin backends of Poisson 100 / 110) */
+int x3d_backend_create_like(x3d_backend **out, const x3d_backend *like, const int dims_vert[3]);
 /* diagnostics: which = 0 -> launches of the three-components-in-one transeq kernels since creation,
  * 1 -> those of them that also applied a pending velocity correction (x3d_transeq_x_update) */
 long x3d_backend_counter(const x3d_backend *b, int which);
@@ -461,6 +463,31 @@ int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf);
 int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf);
 int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf);
 int x3d_pfft_postprocess_000(x3d_pfft *p);
+
+/* ---- deferred execution of the reference's op-granular call sequence: fusion inside the library (csrc/lazy.hip).
+ * The unchanged solver.f90 issues 16 reorder + 6 sum_*intox + ~20 veccopy / vecadd + 16 tds_solve + 3 transeq_* per
+ * sub-step (src/solver.f90:291-389, 693-739; src/time_integrator.f90:166-282; src/vector_calculus.f90:142-332).  With
+ * the mode on, x3d_transeq, x3d_tds_solve, x3d_reorder, x3d_sum_intox, x3d_veccopy, x3d_vecadd, x3d_vecmult,
+ * x3d_field_scale / _shift, x3d_block_fill and the 000 hooks x3d_poisson_fft_forward / _postprocess_000 / _fft_backward
+ * only RECORD their call; the queue is rewritten onto the fused kernels (x3d_transeq_acc, x3d_tds_solve_pair,
+ * x3d_tds_solve_acc, x3d_lincomb, x3d_tds_solve_lincomb, x3d_poisson_solve_000: the same arithmetic in the same order)
+ * and run when a result must be visible: reductions, get / set_field_data, x3d_device_sync, or any entry point that is
+ * not recorded.  reorder / veccopy become aliases (copy on write): while the mode is on a block address is a HANDLE
+ * whose data may live in another block's memory -- only pass handles back to this library; x3d_lazy_sync restores
+ * "every block holds its own data".  x3d_block_discard = allocator%release_block (src/allocator.f90:160-168): the
+ * contents are dead until the block is written again (lets the queue drop temporaries and reuse their memory).
+ * Blocks of x3d_block_alloc are handles by themselves; memory allocated elsewhere: x3d_lazy_register_block.
+ * Single rank only (the distributed entry points run at once and call x3d_lazy_sync first).
+ * x3d_lazy_stats: [0] calls recorded, [1] launches issued, [2] aliases, [3] transeq_acc, [4] pairs, [5] tds_solve_acc,
+ * [6] lincombs, [7] tds_solve_lincomb, [8] solve_000, [9] updates run out of place (buffer swaps), [10] copies made for
+ * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [13] calls dropped by the
+ * rewrite, [15] extra buffers held. */
+int x3d_lazy_enable(x3d_backend *b, int on);
+int x3d_lazy_flush(x3d_backend *b);
+int x3d_lazy_sync(x3d_backend *b);
+int x3d_lazy_register_block(x3d_backend *b, double *f);
+int x3d_block_discard(x3d_backend *b, double *f);
+int x3d_lazy_stats(x3d_backend *b, long out[16]);
 
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);

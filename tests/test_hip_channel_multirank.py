@@ -17,12 +17,16 @@ from util import relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dims,stretching,beta", [((32, 17, 24), "uniform", 1.0), ((34, 17, 24), "top-bottom", 0.259065151),
-                                                  ((48, 33, 16), "centred", 0.4), ((32, 16, 20), "bottom", 0.3),
-                                                  ((1024, 33, 16), "top-bottom", 0.259065151)])
-def test_slab_010_solver_in_one_process_equals_the_single_rank_solver(dims, stretching, beta, monkeypatch):
+@pytest.mark.parametrize("dims,stretching,beta,split", [
+    ((32, 17, 24), "uniform", 1.0, False), ((34, 17, 24), "top-bottom", 0.259065151, False),
+    ((48, 33, 16), "centred", 0.4, False), ((32, 16, 20), "bottom", 0.3, False),
+    ((1024, 33, 16), "top-bottom", 0.259065151, False),
+    ((34, 17, 24), "top-bottom", 0.259065151, True)])  # 1-D x and y plans (where rocFFT refuses the 2-D real plan)
+def test_slab_010_solver_in_one_process_equals_the_single_rank_solver(dims, stretching, beta, split, monkeypatch):
     """csrc/sfft010.hip with pz = 1 (pack / all-to-all-with-itself / strided z transform / the spectral kernels on the
     packed layout) against HipPoissonFFT (3-D rocFFT plan) and the oracle, on a seeded right-hand side"""
+    if split:
+        monkeypatch.setenv("X3D_SFFT010_SPLIT_XY", "1")
     from x3d2_amd.poisson_fft import HipPoissonFFT, HipSlabPoissonFFT010
     rng = np.random.default_rng(11)
     s1 = product_solver(dims, stretching, beta)

@@ -1,0 +1,142 @@
+"""Fusion inside the library (csrc/lazy.hip): the reference's op-granular call sequence -- what the unchanged
+solver.f90 / time_integrator.f90 / vector_calculus.f90 issue through the Fortran shim -- recorded, rewritten onto the
+fused kernels and run at the next point a result must be visible.  The rewrite must not change a bit: every test
+compares the deferred run with the same driver executing call by call (np.array_equal), and asserts through
+x3d_lazy_stats that the fused forms really engaged.  /root/reference/src/solver.f90:291-389, 693-739;
+src/time_integrator.f90:166-282; src/vector_calculus.f90:142-332."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(case):
+    s = case.solver
+    return [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)] + [s.backend.get_field_data(f) for f in s.species]
+
+
+def _same(a, b, ulps=0):
+    """ulps = 0: bit for bit; else |x - y| <= ulps * 2^-52 * max|y|"""
+    for x, y in zip(_fields(a), _fields(b)):
+        if ulps == 0:
+            assert np.array_equal(x, y)
+        else:
+            assert np.max(np.abs(x - y)) <= ulps * 2.0 ** -52 * max(np.max(np.abs(y)), 1.0)
+
+
+@pytest.mark.parametrize("n,time_intg,steps", [(64, "RK3", 3), (48, "AB3", 5), (40, "RK4", 2), (256, "RK3", 1)])
+def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, monkeypatch):
+    """TGV, full fractional step with the FFT Poisson solve, op-granular driver: deferred == call by call, bit for bit;
+    per sub-step the queue must have produced 2 accumulating transeq launches (y, z), the operator pairs of
+    divergence_v2c / gradient_c2v, the three accumulating solves of the velocity correction, one lincomb or
+    stage-in-operator launch per variable and the one-call Poisson solve -- and not a single copy.
+    256-row pencils: the operator PAIRS run on the tile kernel (k_ytile_tds_pair), single solves on the on-chip kernel
+    (k_tds_onchip2): two associations of the same sums, 1-2 ulp apart per operator -- bit for bit with the pair
+    rewrites switched off (X3D_LAZY_RULES), <= 16 ulp of the field maximum after a step with them"""
+    from x3d2_amd import make_tgv
+    eager = make_tgv(n, time_intg=time_intg, fused=False, lazy=False)
+    lazy = make_tgv(n, time_intg=time_intg, fused=False, lazy=True)
+    for it in range(1, steps + 1):
+        eager.step(it)
+        lazy.step(it)
+    _same(eager, lazy, ulps=16 if n == 256 else 0)
+    if n == 256:
+        monkeypatch.setenv("X3D_LAZY_RULES", str(127 - 2 - 4))
+        nopairs = make_tgv(n, time_intg=time_intg, fused=False, lazy=True)
+        for it in range(1, steps + 1):
+            nopairs.step(it)
+        _same(eager, nopairs)
+        assert nopairs.solver.backend.lazy_stats()["pairs"] == 0
+    st = lazy.solver.backend.lazy_stats()
+    nsub = steps * lazy.solver.time_integrator.nstage
+    assert st["transeq_acc"] == 2 * nsub
+    assert st["pairs"] == 4 * nsub          # y and z of the divergence (mode 0), z and y of the gradient (mode 1)
+    assert st["tds_acc"] == 3 * nsub        # u, v, w -= gradient
+    assert st["solve_000"] == nsub
+    assert st["tds_lincomb"] + st["lincombs"] >= 3 * nsub - 3
+    assert st["aliases"] >= 16 * nsub       # the reorders (and the veccopies that turned into buffer swaps)
+    assert st["materialised"] == 0 and st["sync_copies"] == 0
+    assert st["launched"] < 0.5 * st["recorded"]
+    # monitoring (curl, scalar products, divergence) through the queue as well
+    re = eager.postprocess(steps, 0.0)
+    rl = lazy.postprocess(steps, 0.0)
+    assert re == rl
+
+
+def test_deferred_run_equals_fused_driver_and_reference_trace():
+    """the deferred op-granular run against the fused driver (1e-13) and the reference's TGV 64^3 trace"""
+    from util import read_trace_fixture
+    from x3d2_amd import make_tgv
+    lazy = make_tgv(64, fused=False, lazy=True)
+    fused = make_tgv(64, fused=True)
+    lazy.solver.n_output = fused.solver.n_output = 10
+    rl, rf = lazy.run(n_iters=10), fused.run(n_iters=10)
+    fx = read_trace_fixture()
+    assert abs(rl[1][1] - fx[1, 1]) / 0.375 < 1e-11
+    assert abs(rl[1][1] - rf[1][1]) / 0.375 < 1e-13
+    for x, y in zip(_fields(lazy), _fields(fused)):
+        assert np.max(np.abs(x - y)) < 1e-12
+
+
+@pytest.mark.parametrize("dims,stretching,beta", [((32, 33, 24), "top-bottom", 0.259065151), ((48, 17, 16), "uniform", 1.0)])
+def test_deferred_channel_steps_are_bit_identical(dims, stretching, beta):
+    """channel case (define_BC's bulk shift, rotation forcing, wall stamping, 010 Poisson solve: entry points that run
+    at once on translated handles between the recorded ones)"""
+    from x3d2_amd import make_channel
+    kw = dict(stretching=stretching, beta=beta, fused=False, rotation=True, omega_rot=0.12, n_rotate=2)
+    eager = make_channel(dims, lazy=False, **kw)
+    lazy = make_channel(dims, lazy=True, **kw)
+    for it in (1, 2):
+        eager.step(it)
+        lazy.step(it)
+    _same(eager, lazy)
+    st = lazy.solver.backend.lazy_stats()
+    assert st["transeq_acc"] == 12 and st["pairs"] == 24 and st["tds_acc"] == 18
+
+
+def test_deferred_species_transport_is_bit_identical():
+    """transeq_species is not recorded: it runs at once after x3d_lazy_sync (every handle's data home again)"""
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import VERT
+    cases = []
+    for lz in (False, True):
+        c = make_tgv(32, fused=False, lazy=lz, n_species=1, pr_species=[0.7])
+        m = c.solver.mesh
+        x, y, z = m.vert_coords[0][None, None, :], m.vert_coords[1][None, :, None], m.vert_coords[2][:, None, None]
+        f = c.solver.species[0]
+        f.set_data_loc(VERT)
+        c.solver.backend.set_field_data(f, np.cos(x) * np.sin(y) * np.cos(2 * z) + 0.3)
+        c.step(1)
+        c.step(2)
+        cases.append(c)
+    _same(*cases)
+
+
+def test_sync_brings_every_handle_home():
+    """after x3d_lazy_sync the raw block memory holds the block's own data again (what an entry point outside the
+    queue, or anybody holding the raw address, sees)"""
+    import torch
+    from x3d2_amd import _lib, make_tgv
+    c = make_tgv(32, fused=False, lazy=True)
+    c.step(1)
+    s = c.solver
+    b = s.backend
+    want = [b.get_field_data(f) for f in (s.u, s.v, s.w)]
+    _lib.check(b.lib.x3d_lazy_sync(b.h))
+    nxp, nyp, nzp = b.padded_dims
+    torch.cuda.synchronize()
+    for f, w in zip((s.u, s.v, s.w), want):
+        raw = f.data.cpu().numpy().reshape(nzp, nyp, nxp)[:32, :32, :32]
+        assert np.array_equal(raw, w)
+    c.step(2)  # and the mode carries on
+    e = make_tgv(32, fused=False, lazy=False)
+    e.step(1)
+    e.step(2)
+    _same(e, c)
+
+
+def test_fused_driver_refuses_the_deferred_mode():
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import X3dError
+    with pytest.raises(X3dError):
+        make_tgv(32, fused=True, lazy=True)

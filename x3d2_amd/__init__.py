@@ -9,7 +9,7 @@ from .tdsops import Dirps, Tdsops  # noqa: F401
 
 
 def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3", poisson="FFT", comm=None,
-             device=None, fused=False, n_species=0, pr_species=None):
+             device=None, fused=False, n_species=0, pr_species=None, lazy=None):
     """TGV set-up of examples/TGV/input.x3d on an n^3 (or (nx,ny,nz)) grid."""
     from .backend import HipBackend
     from .case import TGVCase
@@ -18,7 +18,7 @@ def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3"
     twopi = 6.283185307179586
     mesh = Mesh(dims, nproc_dir, (twopi,) * 3, ("periodic",) * 2, ("periodic",) * 2, ("periodic",) * 2,
                 nrank=rank)
-    backend = HipBackend(mesh, device=device, comm=comm)
+    backend = HipBackend(mesh, device=device, comm=comm, lazy=lazy)
     solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson,
                                                  fused=fused, n_species=n_species, pr_species=pr_species))
     return TGVCase(solver)
@@ -26,7 +26,7 @@ def make_tgv(n, nproc_dir=(1, 1, 1), rank=0, Re=1600.0, dt=1e-3, time_intg="RK3"
 
 def make_channel(dims=(128, 65, 64), L=(4.0, 2.0, 2.0), stretching="top-bottom", beta=0.259065151, Re=4200.0,
                  dt=5e-3, time_intg="RK3", poisson="FFT", fused=False, device=None, comm=None, nproc_dir=(1, 1, 1),
-                 rank=0, **channel_kw):
+                 rank=0, lazy=None, **channel_kw):
     """channel set-up of examples/channel/input.x3d: periodic x/z, no-slip y walls (Dirichlet),
     y stretched towards the walls; channel_kw -> ChannelConfig (rotation, omega_rot, n_rotate, noise).
     dims, L: the GLOBAL grid; nproc_dir = (1, 1, N): z slabs (the wall-normal direction stays whole on every rank:
@@ -37,7 +37,7 @@ def make_channel(dims=(128, 65, 64), L=(4.0, 2.0, 2.0), stretching="top-bottom",
     st = ("uniform", stretching, "uniform")
     mesh = Mesh(tuple(dims), tuple(nproc_dir), tuple(L), ("periodic",) * 2, ("dirichlet",) * 2, ("periodic",) * 2,
                 st, (1.0, beta, 1.0), nrank=rank)
-    backend = HipBackend(mesh, device=device, comm=comm)
+    backend = HipBackend(mesh, device=device, comm=comm, lazy=lazy)
     solver = Solver(backend, mesh, SolverConfig(Re=Re, dt=dt, time_intg=time_intg, poisson_solver_type=poisson,
                                                  fused=fused))
     return ChannelCase(solver, ChannelConfig(**channel_kw))

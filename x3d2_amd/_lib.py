@@ -24,6 +24,13 @@ PROTOTYPES = {
     "x3d_abi_version": (I, []),
     "x3d_backend_create": (I, [ctypes.POINTER(VP), c_int_p, I, VP]),
     "x3d_backend_destroy": (I, [VP]),
+    "x3d_backend_create_like": (I, [ctypes.POINTER(VP), VP, c_int_p]),
+    "x3d_lazy_enable": (I, [VP, I]),
+    "x3d_lazy_flush": (I, [VP]),
+    "x3d_lazy_sync": (I, [VP]),
+    "x3d_lazy_register_block": (I, [VP, VP]),
+    "x3d_block_discard": (I, [VP, VP]),
+    "x3d_lazy_stats": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
     "x3d_backend_set_stream": (I, [VP, VP]),
     "x3d_block_elems": (SZT, [VP]),
     "x3d_padded_dims": (I, [VP, c_int_p]),

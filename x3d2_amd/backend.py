@@ -31,7 +31,10 @@ def _dp(a):
 class HipBackend:
     n_halo = N_HALO  # src/backend/backend.f90:28-29
 
-    def __init__(self, mesh, device=None, comm=None):
+    def __init__(self, mesh, device=None, comm=None, lazy=None):
+        """lazy (default: X3D_LAZY=1): the library's deferred execution (csrc/lazy.hip) -- the op-granular calls below
+        are recorded, rewritten onto the fused kernels and run when a result has to be visible.  This is what the
+        Fortran shim switches on for the unchanged solver.f90; one rank, op-granular driver (SolverConfig(fused=False))."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise X3dError("x3d2_amd: no HIP device available -- the HIP backend has no CPU path")
@@ -50,6 +53,12 @@ class HipBackend:
         _lib.check(self.lib.x3d_padded_dims(h, pd))
         self.padded_dims = tuple(pd)
         self.allocator = Allocator(self.nblock, self.device)
+        self.lazy = (os.environ.get("X3D_LAZY") == "1") if lazy is None else bool(lazy)
+        if self.lazy:
+            if self.comm.size > 1 or os.environ.get("X3D_EMULATE_DECOMP"):
+                raise X3dError("deferred execution (lazy) serves one rank")
+            _lib.check(self.lib.x3d_lazy_enable(h, 1))
+            self.allocator.lazy = (self.lib, h)
         self.poisson_fft = None
         self._halo = {}
         self._tdsops = []
@@ -90,6 +99,15 @@ class HipBackend:
 
     def sync(self):
         _lib.check(self.lib.x3d_device_sync(self.h))
+
+    LAZY_STATS = ("recorded", "launched", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
+                  "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "_", "extra_buffers")
+
+    def lazy_stats(self):
+        """counters of the deferred-execution layer (x3d_lazy_stats)"""
+        out = (ctypes.c_long * 16)()
+        _lib.check(self.lib.x3d_lazy_stats(self.h, out))
+        return dict(zip(self.LAZY_STATS, [int(v) for v in out]))
 
     # ------------------------------------------------------------ per-kernel timers
     KINDS = {"transeq_fwd": 0, "transeq_bwd": 1, "tds_fwd": 2, "tds_bwd": 3, "blas1": 4, "copy": 5,

@@ -94,6 +94,12 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     return 0;
 }
 
+extern "C" int x3d_backend_create_like(x3d_backend **out, const x3d_backend *like, const int dims_vert[3])
+{
+    X3D_REQUIRE(like, "x3d_backend_create_like: null argument");
+    return x3d_backend_create(out, dims_vert, like->device, (void *)like->stream);
+}
+
 extern "C" int x3d_backend_destroy(x3d_backend *b)
 {
     if (!b) return 0;
@@ -103,6 +109,7 @@ extern "C" int x3d_backend_destroy(x3d_backend *b)
     hipFree(b->red_buf); hipHostFree(b->red_host); hipFree(b->epi_dev);
     hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
     delete static_cast<std::unordered_set<const void *> *>(b->lds_optin);
+    x3d_lazy_destroy(b);
     delete b;
     return 0;
 }
@@ -142,6 +149,8 @@ extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])
 
 extern "C" int x3d_device_sync(x3d_backend *b)
 {
+    if (b) X3D_LAZY_FLUSH(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b, "null backend");
     X3D_HIP(hipStreamSynchronize(b->stream));
     return 0;
@@ -166,11 +175,13 @@ extern "C" int x3d_block_alloc(x3d_backend *b, double **out)
     std::lock_guard<std::mutex> lock(g_block_mutex);
     *out = static_cast<double *>(base) + (size_t)(g_block_count++ % 16) * st;
     g_block_base[*out] = base;
+    x3d_lazy_register(b, *out);  // (a handle of the deferred-execution layer, should the caller switch it on)
     return 0;
 }
 
 extern "C" int x3d_block_free(x3d_backend *b, double *p)
 {
+    if (b) { X3D_LAZY_SYNC(b); x3d_lazy_unregister(b, p); }
     (void)b;
     void *base = nullptr;
     {
@@ -244,10 +255,14 @@ static int transpose_launch(x3d_backend *bs, double *dst, const double *src, int
 }
 extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny, int nz)
 {
+    if (bs) X3D_LAZY_SYNC(bs);
+    if (bd) X3D_LAZY_SYNC(bd);
+    X3D_LAZY_EAGER(bs);
+    LazyScope lazy_scope_d_(bd);
     X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_xy: null argument");
     X3D_REQUIRE(nx <= bs->nxp && ny <= bs->nyp && nz <= bs->nzp && ny <= bd->nxp && nx <= bd->nyp && nz <= bd->nzp,
                 "x3d_transpose_xy: dims exceed the blocks");
-    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_xy: the two backends must share a stream");
+    X3D_REQUIRE(bs->stream == bd->stream && bs->device == bd->device, "x3d_transpose_xy: the two backends must share a device and a stream");
     return transpose_launch(bs, dst, src, nx, ny, nz, (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp,
                             (long)bd->nxp * bd->nyp);
 }
@@ -257,10 +272,14 @@ extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, c
 extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
                                      int nz)
 {
+    if (bs) X3D_LAZY_SYNC(bs);
+    if (bd) X3D_LAZY_SYNC(bd);
+    X3D_LAZY_EAGER(bs);
+    LazyScope lazy_scope_d_(bd);
     X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_xyz_zxy: null argument");
     X3D_REQUIRE(nx <= bs->nxp && ny <= bs->nyp && nz <= bs->nzp && nz <= bd->nxp && nx <= bd->nyp && ny <= bd->nzp,
                 "x3d_transpose_xyz_zxy: dims exceed the blocks");
-    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_xyz_zxy: the two backends must share a stream");
+    X3D_REQUIRE(bs->stream == bd->stream && bs->device == bd->device, "x3d_transpose_xyz_zxy: the two backends must share a device and a stream");
     // a = x (fast in src), b = z (fast in dst), batch = y
     return transpose_launch(bs, dst, src, nx, nz, ny, (long)bs->nxp * bs->nyp, (long)bs->nxp, (long)bd->nxp,
                             (long)bd->nxp * bd->nyp);
@@ -269,10 +288,14 @@ extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, double *d
 extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
                                      int nz)
 {
+    if (bs) X3D_LAZY_SYNC(bs);
+    if (bd) X3D_LAZY_SYNC(bd);
+    X3D_LAZY_EAGER(bs);
+    LazyScope lazy_scope_d_(bd);
     X3D_REQUIRE(bs && bd && dst && src, "x3d_transpose_zxy_xyz: null argument");
     X3D_REQUIRE(nx <= bd->nxp && ny <= bd->nyp && nz <= bd->nzp && nz <= bs->nxp && nx <= bs->nyp && ny <= bs->nzp,
                 "x3d_transpose_zxy_xyz: dims exceed the blocks");
-    X3D_REQUIRE(bs->stream == bd->stream, "x3d_transpose_zxy_xyz: the two backends must share a stream");
+    X3D_REQUIRE(bs->stream == bd->stream && bs->device == bd->device, "x3d_transpose_zxy_xyz: the two backends must share a device and a stream");
     // a = z (fast in src), b = x (fast in dst), batch = y
     return transpose_launch(bs, dst, src, nz, nx, ny, (long)bs->nxp, (long)bs->nxp * bs->nyp, (long)bd->nxp * bd->nyp,
                             (long)bd->nxp);
@@ -324,6 +347,7 @@ struct OpFill { double a; __device__ double operator()(double) const { return a;
 
 extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_copy(b, dst, src);
     X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
     ProfScope ps(b, X3D_K_COPY);
     X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
@@ -332,6 +356,7 @@ extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 
 extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_vecadd(b, a, x, bb, y);
     X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
@@ -343,6 +368,7 @@ extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, 
 
 extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 0, y, x, 0.0);
     X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
@@ -394,16 +420,21 @@ static int from_gradients(x3d_backend *b, double *out, const double *const g[9],
 
 extern "C" int x3d_compute_vorticity(x3d_backend *b, double *out, const double *const grads[9])
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, false);
 }
 
 extern "C" int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grads[9])
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, true);
 }
 
 extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 1, f, nullptr, a);
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
@@ -415,6 +446,7 @@ extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 
 extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 2, f, nullptr, a);
     X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
@@ -426,6 +458,7 @@ extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 
 extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 3, f, nullptr, c);
     X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
@@ -439,6 +472,7 @@ extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 // (reference: src/backend/omp/backend.f90:393-452; codes src/common.f90:23-26)
 extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_copy(b, u_, u);
     X3D_REQUIRE(b && u_ && u, "x3d_reorder: null argument");
     int from = rdr / 10, to = rdr % 10;
     X3D_REQUIRE(from >= 1 && from <= 4 && to >= 1 && to <= 4 && from != to,
@@ -452,6 +486,7 @@ extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
 // sum_yintox / sum_zintox: u += u_ (src/backend/omp/backend.f90:454-527)
 extern "C" int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_sum(b, u, u_, dir_from);
     X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
     X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
     ProfScope ps(b, X3D_K_BLAS1);
@@ -495,6 +530,8 @@ __global__ void __launch_bounds__(256) k_lincomb(double2 *__restrict__ y, const 
 extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
                            const double *const *x)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && y && base && c && x, "x3d_lincomb: null argument");
     X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_lincomb: nterm must be 1..5");
     ProfScope ps(b, X3D_K_BLAS1);
@@ -577,6 +614,8 @@ static int run_reduce(x3d_backend *b, const double *x, const double *y, const in
 extern "C" int x3d_scalar_product(x3d_backend *b, const double *x, const double *y, const int dims[3],
                                   double *out)
 {
+    if (b) { X3D_LAZY_IN(b, x); X3D_LAZY_IN(b, y); }
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && x && y && dims && out, "x3d_scalar_product: null argument");
     return run_reduce<RED_DOT>(b, x, y, dims, out, nullptr);
 }
@@ -584,12 +623,16 @@ extern "C" int x3d_scalar_product(x3d_backend *b, const double *x, const double 
 extern "C" int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double *max_abs,
                                  double *sum_abs)
 {
+    if (b) X3D_LAZY_IN(b, f);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && max_abs && sum_abs, "x3d_field_max_sum: null argument");
     return run_reduce<RED_ABS>(b, f, f, dims, sum_abs, max_abs);
 }
 
 extern "C" int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out)
 {
+    if (b) X3D_LAZY_IN(b, f);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && out, "x3d_field_volume_integral: null argument");
     return run_reduce<RED_SUM>(b, f, f, dims, out, nullptr);
 }
@@ -631,6 +674,8 @@ __global__ void __launch_bounds__(256) k_shift_dev(double2 *__restrict__ f, size
 extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
                                     const double **shift)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && ncell > 0.0 && shift, "x3d_field_mean_shift: bad argument");
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
                 "x3d_field_mean_shift: dims outside the block");
@@ -648,6 +693,8 @@ extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int d
 
 extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && shift, "x3d_field_shift_by: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     const size_t n2 = b->nblock / 2;
@@ -658,6 +705,8 @@ extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift
 
 extern "C" int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     const double *shift = nullptr;
     if (int rc = x3d_field_mean_shift(b, f, dims, ncell, target, &shift)) return rc;
     return x3d_field_shift_by(b, f, shift);
@@ -689,6 +738,8 @@ __global__ void __launch_bounds__(256) k_wall_noise(double *__restrict__ f, int 
 extern "C" int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
                               unsigned long long draw)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims, "x3d_wall_noise: null argument");
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 1 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
                 "x3d_wall_noise: dims outside the block");
@@ -729,6 +780,8 @@ __global__ void __launch_bounds__(256) k_slice(const double *__restrict__ f, int
 extern "C" int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
                                  double *max_val, double *sum_val)
 {
+    if (b) X3D_LAZY_IN(b, f);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && max_val && sum_val, "x3d_slice_max_sum: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "slice_max_sum does not support DIR_C fields!");
     X3D_REQUIRE(i_slice >= 1 && i_slice <= dims[dir - 1], "slice_max_sum: i_slice out of range");
@@ -786,6 +839,8 @@ __global__ void k_set_face_x_from(double *__restrict__ f, const double *__restri
 extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], double c_start, double c_end,
                                   int face)
 {
+    if (b) X3D_LAZY_OUT(b, f, false);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims, "x3d_field_set_face: null argument");
     X3D_REQUIRE(face != X3D_X_FACE, "Setting X_FACE is not yet supported.");
     X3D_REQUIRE(face != X3D_Z_FACE, "Setting Z_FACE is not yet supported.");
@@ -800,6 +855,8 @@ extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], 
 extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
                                              double c_end, int face, double flow_rate_diff)
 {
+    if (b) { X3D_LAZY_IN(b, f_start); X3D_LAZY_OUT(b, f, false); }
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && f_start && dims, "x3d_field_set_face_from_field: null argument");
     if (face == X3D_Y_FACE) {
         long n = (long)dims[0] * dims[2];
@@ -819,12 +876,16 @@ extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const do
 // ---------------------------------------------------------------- host <-> field
 extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3])
 {
+    if (b) X3D_LAZY_OUT(b, f, false);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dims, "x3d_set_field_data: null argument");
     return x3d_set_field_data_pitched(b, f, host, dims[0], dims[1], dims);
 }
 
 extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3])
 {
+    if (b) X3D_LAZY_IN(b, f);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dims, "x3d_get_field_data: null argument");
     return x3d_get_field_data_pitched(b, host, f, dims[0], dims[1], dims);
 }
@@ -832,6 +893,8 @@ extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f,
 extern "C" int x3d_set_field_data_pitched(x3d_backend *b, double *f, const double *host, int hx, int hy,
                                           const int dims[3])
 {
+    if (b) X3D_LAZY_OUT(b, f, false);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && host && dims, "x3d_set_field_data: null argument");
     X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp && dims[0] <= hx && dims[1] <= hy,
                 "x3d_set_field_data: dims exceed the block");
@@ -849,6 +912,8 @@ extern "C" int x3d_set_field_data_pitched(x3d_backend *b, double *f, const doubl
 extern "C" int x3d_get_field_data_pitched(x3d_backend *b, double *host, const double *f, int hx, int hy,
                                           const int dims[3])
 {
+    if (b) X3D_LAZY_IN(b, f);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && host && dims, "x3d_get_field_data: null argument");
     X3D_REQUIRE(dims[0] <= b->nxp && dims[1] <= b->nyp && dims[2] <= b->nzp && dims[0] <= hx && dims[1] <= hy,
                 "x3d_get_field_data: dims exceed the block");

@@ -73,7 +73,70 @@ struct x3d_backend {
     unsigned prof_mask;     // kernel classes that are timed while the timers are on (bit = X3D_K_*; x3d_prof_select)
     int pair_yperm;          // > 0 during x3d_tds_solve_pair_yperm: the z pair kernels permute that many y rows
     void *lds_optin;        // kernels of this backend's device whose dynamic-LDS limit has been raised (backend.hip)
+    struct x3d_lazy *lazy;  // deferred execution of the op-granular call sequence (lazy.hip), null until used
 };
+
+// ---- deferred execution (lazy.hip).  While the mode is on, block addresses are HANDLES: an entry point either records
+// its call (x3d_lazy_active + x3d_lazy_<op>), or runs at once on the buffers that hold the handles' data
+// (X3D_LAZY_IN / X3D_LAZY_OUT: flush the queue, translate), or first restores the identity map (X3D_LAZY_SYNC).
+bool x3d_lazy_active(const x3d_backend *b);
+void x3d_lazy_destroy(x3d_backend *b);
+void x3d_lazy_register(x3d_backend *b, double *h);
+void x3d_lazy_unregister(x3d_backend *b, double *h);
+int x3d_lazy_flush_c(x3d_backend *b);
+int x3d_lazy_sync_c(x3d_backend *b);
+int x3d_lazy_in(x3d_backend *b, const double *h, const double **out);
+int x3d_lazy_out(x3d_backend *b, double *h, bool full, double **out);
+int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
+                     const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
+                     const x3d_tdsops *t3);
+int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+int x3d_lazy_copy(x3d_backend *b, double *dst, const double *src);
+int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir);
+int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
+int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double a);  // 0 vecmult, 1 scale, 2 shift, 3 fill
+int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f);               // 0 forward, 1 postprocess_000, 2 backward
+// an entry point that runs at once while the mode is on: nothing it calls may be recorded (or have its -- already
+// translated -- pointers translated again) until it returns
+bool x3d_lazy_set_executing(x3d_backend *b, bool on);  // returns the previous state
+struct LazyScope {
+    x3d_backend *b;
+    bool prev;
+    explicit LazyScope(x3d_backend *b_) : b(b_ && b_->lazy ? b_ : nullptr), prev(false)
+    {
+        if (b) prev = x3d_lazy_set_executing(b, true);
+    }
+    ~LazyScope() { if (b) x3d_lazy_set_executing(b, prev); }
+    LazyScope(const LazyScope &) = delete;
+    LazyScope &operator=(const LazyScope &) = delete;
+};
+#define X3D_LAZY_EAGER(b) LazyScope lazy_scope_((b))
+#define X3D_LAZY_SYNC(b)                                                                       \
+    do {                                                                                       \
+        if ((b)->lazy)                                                                         \
+            if (int rc_ = x3d_lazy_sync_c(b)) return rc_;                                      \
+    } while (0)
+#define X3D_LAZY_FLUSH(b)                                                                      \
+    do {                                                                                       \
+        if ((b)->lazy)                                                                         \
+            if (int rc_ = x3d_lazy_flush_c(b)) return rc_;                                     \
+    } while (0)
+#define X3D_LAZY_IN(b, ptr)                                                                    \
+    do {                                                                                       \
+        if ((b)->lazy) {                                                                       \
+            const double *q_ = nullptr;                                                        \
+            if (int rc_ = x3d_lazy_in((b), (ptr), &q_)) return rc_;                            \
+            (ptr) = q_;                                                                        \
+        }                                                                                      \
+    } while (0)
+#define X3D_LAZY_OUT(b, ptr, full)                                                             \
+    do {                                                                                       \
+        if ((b)->lazy) {                                                                       \
+            double *q_ = nullptr;                                                              \
+            if (int rc_ = x3d_lazy_out((b), (ptr), (full), &q_)) return rc_;                   \
+            (ptr) = q_;                                                                        \
+        }                                                                                      \
+    } while (0)
 
 // > 64 KB of dynamic LDS needs an opt-in per kernel and DEVICE: raise the limit to the CU's 160 KB once per
 // (backend, kernel) -- not a process-wide flag, and not the first call's size

@@ -1,0 +1,737 @@
+// Deferred execution of the reference's OPERATOR-GRANULAR call sequence: fusion INSIDE the library.
+//
+// The unchanged solver.f90 / time_integrator.f90 / vector_calculus.f90 of the reference issue, per sub-step, 16 reorder,
+// 6 sum_{y,z}intox, ~20 veccopy / vecadd, 16 tds_solve, 3 transeq_* (/root/reference/src/solver.f90:291-389, 693-739;
+// src/time_integrator.f90:166-282; src/vector_calculus.f90:142-332).  Executed one by one those are real copies and
+// axpys: 109.6 ms per step at 512^3 against 48 for the fused driver (profiles/README.md).  With x3d_lazy_enable(b, 1)
+// the entry points of base_backend_t only RECORD their call; the queue runs when a result has to be visible to the host
+// (reductions, get / set_field_data, x3d_device_sync) or to an entry point that is not queued.  Before it runs, a
+// peephole pass rewrites the reference's fixed sequences onto the fused kernels the library already has:
+//
+//   transeq_<d>(du_d, dv_d, dw_d; ...) ; sum_<d>intox(du, du_d) x 3        -> x3d_transeq_acc(du, dv, dw; ..., accumulate)
+//   tds_solve(a; i1; A) ; tds_solve(b; i2; B) ; vecadd(1, b, 1, a)          -> x3d_tds_solve_pair(mode 0)
+//   tds_solve(a; i; A) ; tds_solve(b; i; B)                                 -> x3d_tds_solve_pair(mode 1)
+//   tds_solve(g; p; A) ; vecadd(s, g, 1, u)                                 -> x3d_tds_solve_acc(u; p; A; scale s)
+//   veccopy(y, b) ; vecadd(c1, x1, 1, y) ; vecadd(c2, x2, 1, y) ...         -> x3d_lincomb(y = b + c1 x1 + c2 x2 ...)
+//   lincomb(y) ; tds_solve(du; y; A) along x                                -> x3d_tds_solve_lincomb
+//   fft_forward(f) ; fft_postprocess_000 ; fft_backward(f)                  -> x3d_poisson_solve_000
+// every one of which is the same arithmetic in the same order as the calls it replaces (tests/test_hip_lazy.py
+// compares bit for bit).  A temporary is dropped only when the queue shows it dead: overwritten, or released to the
+// allocator (x3d_block_discard, which the shim's release_block issues) before anything reads it.
+//
+// reorder and veccopy move nothing: all four DIR tags share one device layout, so the destination becomes an ALIAS
+// of the source's buffer.  Block addresses are therefore HANDLES while the mode is on: the layer owns the map handle ->
+// physical buffer (copy on write: an operation that overwrites a handle whose buffer is shared gets a free buffer; an
+// in-place update of a shared buffer runs out of place -- veccopy(olds, curr) followed by the stage's update of curr is
+// a buffer swap, as in the fused driver, not a copy).  Entry points outside the queue see the identity map again
+// (x3d_lazy_sync: flush + move every handle's data home).
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+enum LKind {
+    L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
+    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000
+};
+
+struct LOp {
+    int kind = L_DEAD;
+    int dir = 0, mode = 0, nterm = 0;
+    double *o[3] = {nullptr, nullptr, nullptr};  // handles written (or updated in place)
+    const double *in[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const x3d_tdsops *t[4] = {nullptr, nullptr, nullptr, nullptr};
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    void *obj = nullptr;  // x3d_poisson* of the FFT hooks
+};
+
+enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
+       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_N };
+
+struct x3d_lazy {
+    bool on = false, executing = false;
+    bool keep_zero_terms = false;
+    unsigned rules = ~0u;  // X3D_LAZY_RULES: bit k = rewrite (k + 1) of optimise() allowed (A/B runs, tests)
+    std::vector<LOp> q;
+    std::unordered_map<const double *, double *> phys;  // registered handle -> physical buffer (nullptr: none yet)
+    std::unordered_map<const double *, int> users;      // physical buffer -> handles mapped to it
+    std::vector<double *> handles;                      // registration order
+    std::vector<double *> pool;                         // extra physical buffers owned by the layer
+    long stats[ST_N] = {};
+};
+
+static x3d_lazy *lazy_of(x3d_backend *b)
+{
+    if (!b->lazy) b->lazy = new x3d_lazy();
+    return b->lazy;
+}
+
+bool x3d_lazy_active(const x3d_backend *b) { return b->lazy && b->lazy->on && !b->lazy->executing; }
+
+bool x3d_lazy_set_executing(x3d_backend *b, bool on)
+{
+    if (!b->lazy) return false;
+    const bool prev = b->lazy->executing;
+    b->lazy->executing = on;
+    return prev;
+}
+
+void x3d_lazy_destroy(x3d_backend *b)
+{
+    if (!b->lazy) return;
+    for (double *p : b->lazy->pool) hipFree(p);
+    delete b->lazy;
+    b->lazy = nullptr;
+}
+
+void x3d_lazy_register(x3d_backend *b, double *h)
+{
+    x3d_lazy *L = lazy_of(b);
+    if (L->phys.count(h)) return;
+    L->phys[h] = h;
+    L->users[h] = 1;
+    L->handles.push_back(h);
+}
+
+void x3d_lazy_unregister(x3d_backend *b, double *h)
+{
+    if (!b->lazy) return;
+    x3d_lazy *L = b->lazy;
+    auto it = L->phys.find(h);
+    if (it == L->phys.end()) return;
+    if (it->second) L->users[it->second]--;
+    L->phys.erase(it);
+    L->handles.erase(std::remove(L->handles.begin(), L->handles.end(), h), L->handles.end());
+}
+
+// ---------------------------------------------------------------- physical buffers
+static bool registered(x3d_lazy *L, const double *h) { return L->phys.find(h) != L->phys.end(); }
+
+static int find_free(x3d_backend *b, double *prefer, double **out)
+{
+    x3d_lazy *L = b->lazy;
+    if (prefer && L->users[prefer] == 0) { *out = prefer; return 0; }
+    for (double *p : L->pool)
+        if (L->users[p] == 0) { *out = p; return 0; }
+    for (double *h : L->handles)
+        if (L->users[h] == 0) { *out = h; return 0; }
+    double *p = nullptr;
+    X3D_HIP(hipMalloc(reinterpret_cast<void **>(&p), sizeof(double) * b->nblock));
+    X3D_HIP(hipMemsetAsync(p, 0, sizeof(double) * b->nblock, b->stream));
+    L->pool.push_back(p);
+    L->users[p] = 0;
+    *out = p;
+    return 0;
+}
+
+static int copy_block(x3d_backend *b, double *dst, const double *src)
+{
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+
+// the buffer that holds h's data (a handle nothing was written to yet gets a free buffer: its contents are undefined anyway)
+static int resolve_in(x3d_backend *b, const double *h, const double **out)
+{
+    x3d_lazy *L = b->lazy;
+    auto it = L->phys.find(h);
+    if (it == L->phys.end()) { *out = h; return 0; }
+    if (!it->second) {
+        double *p = nullptr;
+        if (int rc = find_free(b, const_cast<double *>(h), &p)) return rc;
+        it->second = p;
+        L->users[p] = 1;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// a buffer h may be written to: its own unless that is shared (then a free one; full = false keeps the contents)
+static int prepare_out(x3d_backend *b, double *h, bool full, double **out)
+{
+    x3d_lazy *L = b->lazy;
+    auto it = L->phys.find(h);
+    if (it == L->phys.end()) { *out = h; return 0; }
+    double *p = it->second;
+    if (p && L->users[p] == 1) { *out = p; return 0; }
+    double *q = nullptr;
+    if (p) L->users[p]--;
+    if (int rc = find_free(b, h, &q)) return rc;
+    it->second = q;
+    L->users[q] = 1;
+    if (p && !full) {
+        L->stats[ST_MATERIALISE]++;
+        if (int rc = copy_block(b, q, p)) return rc;
+    }
+    *out = q;
+    return 0;
+}
+
+static void drop(x3d_lazy *L, double *h)
+{
+    auto it = L->phys.find(h);
+    if (it == L->phys.end() || !it->second) return;
+    L->users[it->second]--;
+    it->second = nullptr;
+}
+
+// every registered handle's data back in its own buffer, nothing shared
+static int normalise(x3d_backend *b)
+{
+    x3d_lazy *L = b->lazy;
+    for (double *h : L->handles) {
+        double *p = L->phys[h];
+        if (p == h && L->users[h] == 1) continue;
+        if (p == h) continue;  // (shared with handles that alias h's own buffer: they move when their turn comes)
+        if (L->users[h] > 0) {
+            // h's own buffer holds somebody else's data: move it out of the way
+            double *q = nullptr;
+            bool found = false;
+            for (double *c : L->pool)
+                if (L->users[c] == 0) { q = c; found = true; break; }
+            if (!found) {
+                X3D_HIP(hipMalloc(reinterpret_cast<void **>(&q), sizeof(double) * b->nblock));
+                L->pool.push_back(q);
+                L->users[q] = 0;
+            }
+            if (int rc = copy_block(b, q, h)) return rc;
+            L->stats[ST_NORMALISE_COPIES]++;
+            for (double *g : L->handles)
+                if (g != h && L->phys[g] == h) { L->phys[g] = q; L->users[q]++; L->users[h]--; }
+        }
+        if (p) {
+            if (int rc = copy_block(b, h, p)) return rc;
+            L->stats[ST_NORMALISE_COPIES]++;
+            L->users[p]--;
+        }
+        L->phys[h] = h;
+        L->users[h] = 1;
+    }
+    // handles that still alias another handle's own buffer (the owner is home now): give them their own copy
+    for (double *h : L->handles) {
+        double *p = L->phys[h];
+        if (p == h) continue;
+        if (L->users[h] > 0) { x3d_set_error("x3d_lazy: normalise left buffer %p occupied", (void *)h); return 2; }
+        if (p) {
+            if (int rc = copy_block(b, h, p)) return rc;
+            L->stats[ST_NORMALISE_COPIES]++;
+            L->users[p]--;
+        }
+        L->phys[h] = h;
+        L->users[h] = 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- what an operation touches
+enum { A_R = 1, A_W = 2, A_M = 4 };  // read, overwritten completely, updated in place
+
+static int nin(const LOp &op)
+{
+    switch (op.kind) {
+    case L_TRANSEQ: case L_TRANSEQ_ACC: return 3;
+    case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: return 1;
+    case L_PAIR: return op.mode == 0 ? 2 : 1;
+    case L_LINCOMB: case L_TDS_LIN: return 1 + op.nterm;  // base, x...
+    default: return 0;
+    }
+}
+static int nout(const LOp &op)
+{
+    switch (op.kind) {
+    case L_TRANSEQ: case L_TRANSEQ_ACC: return 3;
+    case L_PAIR: return op.mode == 0 ? 1 : 2;
+    case L_TDS_LIN: return 2;  // du, y
+    case L_DEAD: case L_FFT_POST000: return 0;
+    default: return 1;
+    }
+}
+static bool out_is_update(const LOp &op)
+{
+    switch (op.kind) {
+    case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
+    case L_FFT_BWD: case L_SOLVE000:
+        return true;  // (the FFT hooks: forward only reads f, backward writes the real extent of f -- keep the contents)
+    default: return false;
+    }
+}
+static int touch(const LOp &op, const double *h)
+{
+    int m = 0;
+    for (int k = 0; k < nin(op); k++)
+        if (op.in[k] == h) m |= A_R;
+    for (int k = 0; k < nout(op); k++)
+        if (op.o[k] == h) m |= out_is_update(op) ? A_M : A_W;
+    return m;
+}
+// no operation strictly between lo and hi touches any of `quiet`, none writes any of `stable`
+static bool range_clear(const std::vector<LOp> &q, int lo, int hi, std::initializer_list<const double *> quiet,
+                        const std::vector<const double *> &stable)
+{
+    for (int k = lo + 1; k < hi; k++) {
+        const LOp &op = q[k];
+        if (op.kind == L_DEAD) continue;
+        if (op.kind == L_FFT_POST000) continue;
+        for (const double *h : quiet)
+            if (h && touch(op, h)) return false;
+        for (const double *h : stable)
+            if (h && (touch(op, h) & (A_W | A_M))) return false;
+    }
+    return true;
+}
+// h's contents are not needed after position p: the next operation that touches it overwrites or releases it
+static bool dead_after(const std::vector<LOp> &q, int p, const double *h)
+{
+    for (int k = p + 1; k < (int)q.size(); k++) {
+        const int m = touch(q[k], h);
+        if (!m) continue;
+        return m == A_W;
+    }
+    return false;
+}
+static int last_touch_before(const std::vector<LOp> &q, int p, const double *h)
+{
+    for (int k = p - 1; k >= 0; k--)
+        if (touch(q[k], h)) return k;
+    return -1;
+}
+static int first_touch_after(const std::vector<LOp> &q, int p, const double *h)
+{
+    for (int k = p + 1; k < (int)q.size(); k++)
+        if (touch(q[k], h)) return k;
+    return -1;
+}
+static std::vector<const double *> inputs_of(const LOp &op)
+{
+    std::vector<const double *> v;
+    for (int k = 0; k < nin(op); k++) v.push_back(op.in[k]);
+    return v;
+}
+
+// ---------------------------------------------------------------- the peephole pass
+static void optimise(x3d_lazy *L)
+{
+    std::vector<LOp> &q = L->q;
+    const int n = (int)q.size();
+    // (0) a release takes effect right behind the last operation that touches the block (nothing else sees it): buffers
+    // become free -- and aliases exclusive -- as early as the program allows
+    for (int p = 0; p < n; p++) {
+        if (q[p].kind != L_DISCARD) continue;
+        const int k = last_touch_before(q, p, q[p].o[0]);
+        if (k + 1 >= p) continue;
+        const LOp d = q[p];
+        for (int m = p; m > k + 1; m--) q[m] = q[m - 1];
+        q[k + 1] = d;
+    }
+    // (1) transeq_<d> + the three sum_<d>intox of its outputs
+    for (int p = 0; p < n && (L->rules & 1u); p++) {
+        if (q[p].kind != L_TRANSEQ) continue;
+        int ps[3];
+        double *acc[3];
+        bool ok = true;
+        for (int c = 0; c < 3 && ok; c++) {
+            const int k = first_touch_after(q, p, q[p].o[c]);
+            ok = k > 0 && q[k].kind == L_SUM && q[k].in[0] == q[p].o[c] && q[k].dir == q[p].dir && dead_after(q, k, q[p].o[c]);
+            if (!ok) break;
+            ps[c] = k;
+            acc[c] = q[k].o[0];
+            for (int d = 0; d < 3; d++) ok = ok && acc[c] != q[p].in[d] && acc[c] != q[p].o[d];
+            for (int d = 0; d < c; d++) ok = ok && acc[c] != acc[d];
+            ok = ok && range_clear(q, p, k, {acc[c]}, {});
+        }
+        if (!ok) continue;
+        for (int c = 0; c < 3; c++) { q[ps[c]].kind = L_DEAD; q[p].o[c] = acc[c]; }
+        q[p].kind = L_TRANSEQ_ACC;
+    }
+    // (2) a = A(i1) ; b = B(i2) ; a += b   (divergence_v2c: interpl + stagder of the same direction)
+    // fused where the EARLIER solve stands if the later one may move up there, else where the later one stands
+    for (int p = 0; p < n && (L->rules & 2u); p++) {
+        if (q[p].kind != L_VECADD || q[p].s[0] != 1.0 || q[p].s[1] != 1.0) continue;
+        const double *X = q[p].in[0];
+        double *Y = q[p].o[0];
+        const int px = last_touch_before(q, p, X), py = last_touch_before(q, p, Y);
+        if (px < 0 || py < 0 || q[px].kind != L_TDS || q[py].kind != L_TDS || q[px].o[0] != X || q[py].o[0] != Y) continue;
+        if (q[px].dir != q[py].dir || q[px].dir == X3D_DIR_X || !dead_after(q, p, X)) continue;
+        const int lo = std::min(px, py), hi = std::max(px, py);
+        if (!range_clear(q, hi, p, {X, Y}, {})) continue;
+        const LOp &early = q[lo], &late = q[hi];
+        int at = -1;
+        if (range_clear(q, lo, hi, {late.o[0]}, {late.in[0]})) at = lo;
+        else if (range_clear(q, lo, hi, {early.o[0]}, {early.in[0]})) at = hi;
+        if (at < 0) continue;
+        const double *i1 = q[py].in[0], *i2 = q[px].in[0];
+        if (Y == i1 || Y == i2 || X == i1 || X == i2) continue;
+        LOp f;
+        f.kind = L_PAIR; f.mode = 0; f.dir = q[py].dir;
+        f.o[0] = Y; f.in[0] = i1; f.in[1] = i2; f.t[0] = q[py].t[0]; f.t[1] = q[px].t[0];
+        q[lo].kind = L_DEAD; q[hi].kind = L_DEAD; q[p].kind = L_DEAD;
+        q[at] = f;
+    }
+    // (3) a = A(i) ; b = B(i)   (gradient_c2v: interpl and stagder of the same field), the second right behind the first
+    // (releases of other blocks aside)
+    for (int p = 0; p < n && (L->rules & 4u); p++) {
+        if (q[p].kind != L_TDS || q[p].dir == X3D_DIR_X) continue;
+        for (int k = p + 1; k < n; k++) {
+            if (q[k].kind == L_DEAD) continue;
+            if (q[k].kind == L_DISCARD && q[k].o[0] != q[p].o[0] && q[k].o[0] != q[p].in[0]) continue;
+            if (q[k].kind == L_TDS && q[k].dir == q[p].dir && q[k].in[0] == q[p].in[0] && q[k].o[0] != q[p].o[0] &&
+                q[k].o[0] != q[p].in[0] && range_clear(q, p, k, {q[k].o[0]}, {q[p].in[0]})) {
+                LOp f;
+                f.kind = L_PAIR; f.mode = 1; f.dir = q[p].dir;
+                f.o[0] = q[p].o[0]; f.o[1] = q[k].o[0]; f.in[0] = q[p].in[0]; f.t[0] = q[p].t[0]; f.t[1] = q[k].t[0];
+                q[k].kind = L_DEAD;
+                q[p] = f;
+            }
+            break;
+        }
+    }
+    // (4) g = A(p) ; u += s g   (the velocity correction behind gradient_c2v, src/solver.f90:731-733)
+    for (int p = 0; p < n && (L->rules & 8u); p++) {
+        if (q[p].kind != L_VECADD || q[p].s[1] != 1.0) continue;
+        const double *G = q[p].in[0];
+        double *U = q[p].o[0];
+        const int pg = last_touch_before(q, p, G);
+        if (pg < 0 || q[pg].kind != L_TDS || q[pg].o[0] != G || U == q[pg].in[0] || U == G || !dead_after(q, p, G)) continue;
+        if (!range_clear(q, pg, p, {G, U}, {})) continue;
+        q[pg].kind = L_TDS_ACC; q[pg].o[0] = U; q[pg].s[0] = q[p].s[0];
+        q[p].kind = L_DEAD;
+    }
+    // (5) y = 1 y + a x  ->  lincomb; chains (and a leading veccopy) merge into one
+    for (int p = 0; p < n; p++) {
+        if (q[p].kind != L_VECADD || q[p].s[1] != 1.0) continue;
+        LOp f;
+        f.kind = L_LINCOMB; f.o[0] = q[p].o[0]; f.in[0] = q[p].o[0]; f.nterm = 1; f.in[1] = q[p].in[0]; f.s[0] = q[p].s[0];
+        q[p] = f;
+    }
+    for (int p = 0; p < n; p++) {
+        if (q[p].kind != L_LINCOMB) continue;
+        int merged_into = -1;
+        while (q[p].in[0] == q[p].o[0] && (L->rules & 16u)) {  // base == y: whatever wrote y last may be folded in
+            double *y = q[p].o[0];
+            const int k = last_touch_before(q, p, y);
+            if (k < 0) break;
+            const LOp &e = q[k];
+            int ne = 0;
+            if (e.kind == L_COPY && e.o[0] == y) ne = 0;
+            else if (e.kind == L_LINCOMB && e.o[0] == y) ne = e.nterm;
+            else break;
+            if (ne + q[p].nterm > 5) break;
+            bool selfref = false;  // (a term of the later one that reads y would see the earlier result)
+            for (int c = 1; c <= q[p].nterm; c++) selfref = selfref || q[p].in[c] == y;
+            if (selfref) break;
+            // the later combination moves UP to the earlier one (nothing in between touches y or writes its terms)
+            std::vector<const double *> later_terms;
+            for (int c = 1; c <= q[p].nterm; c++) later_terms.push_back(q[p].in[c]);
+            if (!range_clear(q, k, p, {y}, later_terms)) break;
+            LOp f;
+            f.kind = L_LINCOMB; f.o[0] = y; f.in[0] = e.in[0]; f.nterm = ne + q[p].nterm;
+            for (int c = 0; c < ne; c++) { f.in[1 + c] = e.in[1 + c]; f.s[c] = e.s[c]; }
+            for (int c = 0; c < q[p].nterm; c++) { f.in[1 + ne + c] = q[p].in[1 + c]; f.s[ne + c] = q[p].s[c]; }
+            q[p].kind = L_DEAD;
+            q[k] = f;
+            merged_into = k;
+            break;
+        }
+        (void)merged_into;
+    }
+    for (int p = 0; p < n; p++) {
+        if (q[p].kind != L_LINCOMB) continue;
+        if (!L->keep_zero_terms) {  // y + 0 x = y (up to the sign of a zero)
+            LOp &f = q[p];
+            int m = 0;
+            for (int c = 0; c < f.nterm; c++)
+                if (f.s[c] != 0.0) { f.s[m] = f.s[c]; f.in[1 + m] = f.in[1 + c]; m++; }
+            f.nterm = m;
+            if (m == 0) {
+                if (f.in[0] == f.o[0]) f.kind = L_DEAD;
+                else { f.kind = L_COPY; }
+            }
+        }
+    }
+    // (6) y = lincomb ; du = A(y) along x: the stage is the operator's prologue.  Fused where the solve stands if the
+    // combination may move down there (its terms are not overwritten or released on the way), else where the
+    // combination stands if the solve may move up (its output is not in use in between)
+    for (int p = 0; p < n && (L->rules & 32u); p++) {
+        if (q[p].kind != L_LINCOMB) continue;
+        double *y = q[p].o[0];
+        const int k = first_touch_after(q, p, y);
+        if (k < 0 || q[k].kind != L_TDS || q[k].dir != X3D_DIR_X || q[k].in[0] != y) continue;
+        double *du = q[k].o[0];
+        bool ok = du != y;
+        for (int c = 0; c <= q[p].nterm; c++) ok = ok && du != q[p].in[c];
+        if (!ok) continue;
+        int at = -1;
+        if (range_clear(q, p, k, {y}, inputs_of(q[p]))) at = k;
+        else if (range_clear(q, p, k, {y, du}, {})) at = p;
+        if (at < 0) continue;
+        LOp f = q[p];
+        f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = du; f.o[1] = y; f.t[0] = q[k].t[0];
+        q[p].kind = L_DEAD; q[k].kind = L_DEAD;
+        q[at] = f;
+    }
+    // (7) fft_forward(f) ; fft_postprocess_000 ; fft_backward(f) -> the solver's one-call form (z passes fused)
+    for (int p = 0; p + 2 < n && (L->rules & 64u); p++) {
+        if (q[p].kind != L_FFT_FWD) continue;
+        int a = p + 1;
+        while (a < n && q[a].kind == L_DEAD) a++;
+        int c = a + 1;
+        while (c < n && q[c].kind == L_DEAD) c++;
+        if (c >= n || q[a].kind != L_FFT_POST000 || q[c].kind != L_FFT_BWD) continue;
+        if (q[a].obj != q[p].obj || q[c].obj != q[p].obj || q[c].o[0] != q[p].o[0]) continue;
+        q[p].kind = L_SOLVE000;
+        q[a].kind = L_DEAD; q[c].kind = L_DEAD;
+    }
+}
+
+// ---------------------------------------------------------------- execution
+extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);
+extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p);
+extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);
+extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f);
+
+static int exec(x3d_backend *b, const LOp &op)
+{
+    x3d_lazy *L = b->lazy;
+    const double *in[7] = {};
+    double *o[3] = {};
+    if (op.kind == L_COPY) {
+        // dst becomes an alias of src's buffer
+        if (!registered(L, op.o[0]) || !registered(L, op.in[0])) {
+            if (int rc = resolve_in(b, op.in[0], &in[0])) return rc;
+            if (int rc = prepare_out(b, op.o[0], true, &o[0])) return rc;
+            return copy_block(b, o[0], in[0]);
+        }
+        if (op.o[0] == op.in[0]) return 0;
+        if (int rc = resolve_in(b, op.in[0], &in[0])) return rc;
+        drop(L, op.o[0]);
+        L->phys[op.o[0]] = const_cast<double *>(in[0]);
+        L->users[in[0]]++;
+        L->stats[ST_ALIAS]++;
+        return 0;
+    }
+    if (op.kind == L_DISCARD) { drop(L, op.o[0]); return 0; }
+    for (int k = 0; k < nin(op); k++)
+        if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
+    const bool upd = out_is_update(op);
+    for (int k = 0; k < nout(op); k++) {
+        double *before = registered(L, op.o[k]) ? L->phys[op.o[k]] : nullptr;
+        if (int rc = prepare_out(b, op.o[k], !upd, &o[k])) return rc;
+        if (before && before != o[k]) L->stats[ST_OOP]++;
+    }
+    L->stats[ST_EXECUTED]++;
+    switch (op.kind) {
+    case L_TRANSEQ_ACC: L->stats[ST_TRANSEQ_ACC]++; break;
+    case L_PAIR: L->stats[ST_PAIR]++; break;
+    case L_TDS_ACC: L->stats[ST_TDS_ACC]++; break;
+    case L_LINCOMB: L->stats[ST_LINCOMB]++; break;
+    case L_TDS_LIN: L->stats[ST_TDS_LIN]++; break;
+    case L_SOLVE000: L->stats[ST_SOLVE000]++; break;
+    default: break;
+    }
+    switch (op.kind) {
+    case L_TRANSEQ:
+        return x3d_transeq(b, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3]);
+    case L_TRANSEQ_ACC:
+        return x3d_transeq_acc(b, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1);
+    case L_TDS: return x3d_tds_solve(b, o[0], in[0], op.t[0], op.dir);
+    case L_TDS_ACC: return x3d_tds_solve_acc(b, o[0], in[0], op.t[0], op.dir, 1, op.s[0]);
+    case L_PAIR: return x3d_tds_solve_pair(b, op.dir, op.mode, o[0], o[1], in[0], in[1], op.t[0], op.t[1]);
+    case L_TDS_LIN: return x3d_tds_solve_lincomb(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1]);
+    case L_SUM: return x3d_sum_intox(b, o[0], in[0], op.dir);
+    case L_VECADD: return x3d_vecadd(b, op.s[0], in[0], op.s[1], o[0]);
+    case L_LINCOMB: return x3d_lincomb(b, o[0], in[0], op.nterm, op.s, &in[1]);
+    case L_VECMULT: return x3d_vecmult(b, o[0], in[0]);
+    case L_SCALE: return x3d_field_scale(b, o[0], op.s[0]);
+    case L_SHIFT: return x3d_field_shift(b, o[0], op.s[0]);
+    case L_FILL: return x3d_block_fill(b, o[0], op.s[0]);
+    case L_FFT_FWD: return x3d_poisson_fft_forward((x3d_poisson *)op.obj, o[0]);
+    case L_FFT_POST000: return x3d_poisson_postprocess_000((x3d_poisson *)op.obj);
+    case L_FFT_BWD: return x3d_poisson_fft_backward((x3d_poisson *)op.obj, o[0]);
+    case L_SOLVE000: return x3d_poisson_solve_000((x3d_poisson *)op.obj, o[0]);
+    default: x3d_set_error("x3d_lazy: unknown operation %d in the queue", op.kind); return 2;
+    }
+}
+
+// X3D_LAZY_DUMP=1: the queue before and after the rewrite, on stderr (handles numbered in order of appearance)
+static void dump(const x3d_lazy *L, const char *title)
+{
+    static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
+                                  "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
+                                  "solve000"};
+    std::unordered_map<const double *, int> id;
+    auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
+    fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
+    int k = 0;
+    for (const LOp &op : L->q) {
+        if (op.kind == L_DEAD) { k++; continue; }
+        fprintf(stderr, "%4d %-12s dir %d mode %d out", k++, names[op.kind], op.dir, op.mode);
+        for (int c = 0; c < nout(op); c++) fprintf(stderr, " %d", nm(op.o[c]));
+        fprintf(stderr, " | in");
+        for (int c = 0; c < nin(op); c++) fprintf(stderr, " %d", nm(op.in[c]));
+        if (op.kind == L_LINCOMB || op.kind == L_TDS_LIN || op.kind == L_VECADD) {
+            fprintf(stderr, " | c");
+            for (int c = 0; c < (op.kind == L_VECADD ? 2 : op.nterm); c++) fprintf(stderr, " %g", op.s[c]);
+        }
+        fprintf(stderr, "\n");
+    }
+}
+
+int x3d_lazy_flush_c(x3d_backend *b)
+{
+    x3d_lazy *L = b->lazy;
+    if (!L || L->executing || L->q.empty()) return 0;
+    L->stats[ST_FLUSHES]++;
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("X3D_LAZY_DUMP"); dbg = e && e[0] == '1'; }
+    if (dbg) dump(L, "recorded");
+    optimise(L);
+    if (dbg) dump(L, "rewritten");
+    L->executing = true;
+    int rc = 0;
+    for (const LOp &op : L->q) {
+        if (op.kind == L_DEAD) { L->stats[ST_DROPPED]++; continue; }
+        rc = exec(b, op);
+        if (rc) break;
+    }
+    L->executing = false;
+    L->q.clear();
+    return rc;
+}
+
+// flush, then the buffer a queued-mode caller must hand to an entry point that runs at once
+int x3d_lazy_in(x3d_backend *b, const double *h, const double **out)
+{
+    *out = h;
+    if (!b->lazy || !b->lazy->on || b->lazy->executing) return 0;
+    if (int rc = x3d_lazy_flush_c(b)) return rc;
+    return resolve_in(b, h, out);
+}
+int x3d_lazy_out(x3d_backend *b, double *h, bool full, double **out)
+{
+    *out = h;
+    if (!b->lazy || !b->lazy->on || b->lazy->executing) return 0;
+    if (int rc = x3d_lazy_flush_c(b)) return rc;
+    return prepare_out(b, h, full, out);
+}
+
+int x3d_lazy_sync_c(x3d_backend *b)
+{
+    if (!b->lazy || !b->lazy->on || b->lazy->executing) return 0;
+    if (int rc = x3d_lazy_flush_c(b)) return rc;
+    return normalise(b);
+}
+
+static int push(x3d_backend *b, const LOp &op)
+{
+    x3d_lazy *L = b->lazy;
+    L->q.push_back(op);
+    L->stats[ST_QUEUED]++;
+    if (L->q.size() >= 4096) return x3d_lazy_flush_c(b);  // (never reached by a time step: a bound, not a window)
+    return 0;
+}
+
+// ---------------------------------------------------------------- recording (called by the entry points while the mode is on)
+int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
+                     const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
+                     const x3d_tdsops *t3)
+{
+    LOp op;
+    op.kind = L_TRANSEQ; op.dir = dir;
+    op.o[0] = du; op.o[1] = dv; op.o[2] = dw; op.in[0] = u; op.in[1] = v; op.in[2] = w;
+    op.s[0] = nu; op.t[0] = t0; op.t[1] = t1; op.t[2] = t2; op.t[3] = t3;
+    return push(b, op);
+}
+int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+{
+    LOp op;
+    op.kind = L_TDS; op.dir = dir; op.o[0] = du; op.in[0] = u; op.t[0] = t;
+    return push(b, op);
+}
+int x3d_lazy_copy(x3d_backend *b, double *dst, const double *src)
+{
+    LOp op;
+    op.kind = L_COPY; op.o[0] = dst; op.in[0] = src;
+    return push(b, op);
+}
+int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir)
+{
+    LOp op;
+    op.kind = L_SUM; op.dir = dir; op.o[0] = u; op.in[0] = u_;
+    return push(b, op);
+}
+int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
+{
+    LOp op;
+    op.kind = L_VECADD; op.o[0] = y; op.in[0] = x; op.s[0] = a; op.s[1] = bb;
+    return push(b, op);
+}
+int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double a)
+{
+    LOp op;
+    op.kind = kind == 0 ? L_VECMULT : kind == 1 ? L_SCALE : kind == 2 ? L_SHIFT : L_FILL;
+    op.o[0] = f; op.in[0] = x; op.s[0] = a;
+    return push(b, op);
+}
+int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
+{
+    LOp op;
+    op.kind = which == 0 ? L_FFT_FWD : which == 1 ? L_FFT_POST000 : L_FFT_BWD;
+    op.obj = poisson; op.o[0] = f;
+    return push(b, op);
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
+{
+    X3D_REQUIRE(b, "x3d_lazy_enable: null backend");
+    x3d_lazy *L = lazy_of(b);
+    if (!on && L->on) {
+        if (int rc = x3d_lazy_sync_c(b)) return rc;
+    }
+    L->on = on != 0;
+    const char *e = getenv("X3D_LAZY_KEEP_ZERO_TERMS");
+    L->keep_zero_terms = e && e[0] == '1';
+    const char *r = getenv("X3D_LAZY_RULES");
+    L->rules = r ? (unsigned)strtoul(r, nullptr, 0) : ~0u;
+    return 0;
+}
+
+extern "C" int x3d_lazy_flush(x3d_backend *b)
+{
+    X3D_REQUIRE(b, "x3d_lazy_flush: null backend");
+    return x3d_lazy_flush_c(b);
+}
+
+extern "C" int x3d_lazy_sync(x3d_backend *b)
+{
+    X3D_REQUIRE(b, "x3d_lazy_sync: null backend");
+    return x3d_lazy_sync_c(b);
+}
+
+extern "C" int x3d_lazy_register_block(x3d_backend *b, double *f)
+{
+    X3D_REQUIRE(b && f, "x3d_lazy_register_block: null argument");
+    x3d_lazy_register(b, f);
+    return 0;
+}
+
+// allocator%release_block (src/allocator.f90:160-168): the block's contents are dead until it is written again
+extern "C" int x3d_block_discard(x3d_backend *b, double *f)
+{
+    X3D_REQUIRE(b && f, "x3d_block_discard: null argument");
+    if (!x3d_lazy_active(b)) return 0;
+    LOp op;
+    op.kind = L_DISCARD; op.o[0] = f;
+    return push(b, op);
+}
+
+extern "C" int x3d_lazy_stats(x3d_backend *b, long out[16])
+{
+    X3D_REQUIRE(b && out, "x3d_lazy_stats: null argument");
+    for (int k = 0; k < 16; k++) out[k] = 0;
+    if (!b->lazy) return 0;
+    for (int k = 0; k < ST_N; k++) out[k] = b->lazy->stats[k];
+    out[15] = (long)b->lazy->pool.size();
+    return 0;
+}

@@ -202,6 +202,8 @@ void x3d_penta_free(x3d_tdsops *t)
 extern "C" int x3d_tds_penta_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
                                    const double *u_s, const double *u_e)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && u && t, "x3d_tds_penta_solve: null argument");
     X3D_REQUIRE(t->penta, "x3d_tds_penta_solve: not a pentadiagonal operator (x3d_tdsops_set_penta)");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_penta_solve: bad dir %d", dir);

@@ -224,6 +224,7 @@ static int x_forward_512(x3d_poisson *p, const double *f)
 extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
+    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 0, p, const_cast<double *>(f_in));
     if (p->fast512) {
         if (int rc = x_forward_512(p, f_in)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
@@ -238,6 +239,7 @@ extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
 extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_000: null argument");
+    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 1, p, nullptr);
     const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     dim3 grid((p->nxs + 255) / 256, p->ny, p->nz);
@@ -251,6 +253,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
 {
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
+    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 2, p, f_out);
     if (p->fast512) {
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 1, nullptr, nullptr, p->nx)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
@@ -268,6 +271,8 @@ extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
 extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
 {
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
+    X3D_LAZY_OUT(p->b, f, false);
+    X3D_LAZY_EAGER(p->b);
     if (p->fast512) {  // x r2c ; y ; z forward + process_spectral_000 + z backward in one pass ; y ; x c2r
         if (int rc = x_forward_512(p, f)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
@@ -378,6 +383,9 @@ __global__ void __launch_bounds__(256)
 extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_y: bad argument");
+    X3D_LAZY_IN(p->b, f_in);
+    X3D_LAZY_OUT(p->b, f_out, true);
+    X3D_LAZY_EAGER(p->b);
     x3d_backend *b = p->b;
     dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
     ProfScope ps(b, X3D_K_COPY);
@@ -390,6 +398,9 @@ extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, 
 extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_y: bad argument");
+    X3D_LAZY_IN(p->b, f_in);
+    X3D_LAZY_OUT(p->b, f_out, true);
+    X3D_LAZY_EAGER(p->b);
     x3d_backend *b = p->b;
     dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
     ProfScope ps(b, X3D_K_COPY);
@@ -402,6 +413,8 @@ extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, con
 extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_z: bad argument");
+    X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_EAGER(p->b);
     x3d_backend *b = p->b;
     dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
     ProfScope ps(b, X3D_K_COPY);
@@ -414,6 +427,8 @@ extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, 
 extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_z: bad argument");
+    X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_EAGER(p->b);
     x3d_backend *b = p->b;
     dim3 grid((p->nx + 255) / 256, p->ny, p->nz);
     ProfScope ps(b, X3D_K_COPY);
@@ -430,6 +445,8 @@ extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, con
 extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_011: null argument");
+    X3D_LAZY_FLUSH(p->b);
+    X3D_LAZY_EAGER(p->b);
     X3D_REQUIRE(!p->stretched, "x3d_poisson_postprocess_011: uniform grids only");
     const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
@@ -470,6 +487,8 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
 extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_010: null argument");
+    X3D_LAZY_FLUSH(p->b);
+    X3D_LAZY_EAGER(p->b);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     return spectral_010_launch(p->b->stream, p->c, p->waves, p->nxs, p->nx, p->ny, p->nz, 0, p->ab, p->stretched, p->sym,
                                p->lu);
@@ -478,6 +497,10 @@ extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 // poisson_010 (src/poisson_fft.f90:228-242): f holds the rhs on entry and the solution on exit
 extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
 {
+    X3D_REQUIRE(p && f && temp, "x3d_poisson_solve_010: null argument");
+    X3D_LAZY_OUT(p->b, f, false);
+    X3D_LAZY_OUT(p->b, temp, true);
+    X3D_LAZY_EAGER(p->b);
     if (int rc = x3d_poisson_enforce_periodicity_y(p, temp, f)) return rc;
     if (int rc = x3d_poisson_fft_forward(p, temp)) return rc;
     if (int rc = x3d_poisson_postprocess_010(p)) return rc;
@@ -488,6 +511,8 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
 extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, double *host)
 {
     X3D_REQUIRE(p && host, "null argument");
+    X3D_LAZY_FLUSH(p->b);
+    X3D_LAZY_EAGER(p->b);
     X3D_HIP(hipStreamSynchronize(p->b->stream));
     X3D_HIP(hipMemcpy2D(host, p->nxm * sizeof(double2), p->c, p->nxs * sizeof(double2), p->nxm * sizeof(double2),
                         (size_t)p->nz * p->ny, hipMemcpyDeviceToHost));
@@ -497,6 +522,8 @@ extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, double *host)
 extern "C" int x3d_poisson_set_spectral(x3d_poisson *p, const double *host)
 {
     X3D_REQUIRE(p && host, "null argument");
+    X3D_LAZY_FLUSH(p->b);
+    X3D_LAZY_EAGER(p->b);
     X3D_HIP(hipStreamSynchronize(p->b->stream));
     return upload_pitched(p->c, host, (size_t)p->nz * p->ny, p->nxm, p->nxs, sizeof(double2));
 }

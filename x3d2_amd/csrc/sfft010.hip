@@ -37,6 +37,9 @@ struct x3d_sfft010 {
     int pz, rz, zl;      // ranks along z, this rank, local planes
     int xs, nxs;         // mode columns per rank; nxs = pz * xs = row pitch of the local 2-D spectrum
     hipfftHandle plan_xy_fw, plan_xy_bw, plan_z;
+    int split_xy;        // rocFFT refused the 2-D real plan for these lengths: 1-D x plan (batched over all local rows)
+                         // + 1-D strided y plan run once per local plane
+    hipfftHandle plan_x_fw, plan_x_bw, plan_y;
     double2 *c0;         // [zl][ny][nxs]
     double *waves;       // [nz][ny][xs] (pads: one)
     double *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
@@ -82,26 +85,42 @@ extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int n
     p->nab_x = p->nx > p->nxs ? p->nx : p->nxs;
     X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
     X3D_HIP(hipMemset(p->ab, 0, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
-    hipfftHandle *pl[3] = {&p->plan_xy_fw, &p->plan_xy_bw, &p->plan_z};
-    size_t ws[3] = {0, 0, 0};
-    for (int i = 0; i < 3; i++) {
+    hipfftHandle *pl[6] = {&p->plan_xy_fw, &p->plan_xy_bw, &p->plan_z, &p->plan_x_fw, &p->plan_x_bw, &p->plan_y};
+    size_t ws[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
         X3D_FFT(hipfftCreate(pl[i]));
         X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
     }
     // real side: the pitched block's planes; spectral side: dense rows of nxs (the first nxm are written)
     int nn[2] = {p->ny, p->nx}, re[2] = {b->nyp, b->nxp}, ce[2] = {p->ny, p->nxs};
-    X3D_FFT(hipfftMakePlanMany(p->plan_xy_fw, 2, nn, re, 1, b->nxp * b->nyp, ce, 1, p->ny * p->nxs, HIPFFT_D2Z, p->zl,
-                               &ws[0]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_xy_bw, 2, nn, ce, 1, p->ny * p->nxs, re, 1, b->nxp * b->nyp, HIPFFT_Z2D, p->zl,
-                               &ws[1]));
+    const hipfftResult r_fw = hipfftMakePlanMany(p->plan_xy_fw, 2, nn, re, 1, b->nxp * b->nyp, ce, 1, p->ny * p->nxs,
+                                                 HIPFFT_D2Z, p->zl, &ws[0]);
+    const hipfftResult r_bw = hipfftMakePlanMany(p->plan_xy_bw, 2, nn, ce, 1, p->ny * p->nxs, re, 1, b->nxp * b->nyp,
+                                                 HIPFFT_Z2D, p->zl, &ws[1]);
+    {
+        const char *e = getenv("X3D_SFFT010_SPLIT_XY");
+        p->split_xy = r_fw != HIPFFT_SUCCESS || r_bw != HIPFFT_SUCCESS || (e && e[0] == '1');
+    }
+    if (p->split_xy) {
+        ws[0] = ws[1] = 0;
+        int nx1[1] = {p->nx}, rx[1] = {b->nxp}, cx[1] = {p->nxs}, ny1[1] = {p->ny}, ey[1] = {p->ny};
+        // x: every local row (the block's rows are nxp apart whatever the plane: nyp rows per plane, of which ny are used --
+        // one batch per plane keeps to the used rows)
+        X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nx1, rx, 1, b->nxp, cx, 1, p->nxs, HIPFFT_D2Z, p->ny, &ws[3]));
+        X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nx1, cx, 1, p->nxs, rx, 1, b->nxp, HIPFFT_Z2D, p->ny, &ws[4]));
+        X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, ny1, ey, p->nxs, 1, ey, p->nxs, 1, HIPFFT_Z2Z, p->nxs, &ws[5]));
+    }
     // z transform on W[nz][ny][xs] itself: stride ny * xs, one transform per (row, mode)
     int nzv[1] = {p->nz}, ze[1] = {p->nz};
     const int zstride = p->ny * p->xs;
     X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, zstride, 1, ze, zstride, 1, HIPFFT_Z2Z, zstride, &ws[2]));
     size_t wmax = 0;
-    for (int i = 0; i < 3; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
+    for (int i = 0; i < 6; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
-    for (int i = 0; i < 3; i++) X3D_FFT(hipfftSetWorkArea(*pl[i], p->work));
+    for (int i = 0; i < 6; i++) {
+        const bool used = i == 2 || (p->split_xy ? i >= 3 : i < 2);
+        if (used) X3D_FFT(hipfftSetWorkArea(*pl[i], p->work));
+    }
     *out = p;
     return 0;
 }
@@ -110,6 +129,7 @@ extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
 {
     if (!p) return 0;
     hipfftDestroy(p->plan_xy_fw); hipfftDestroy(p->plan_xy_bw); hipfftDestroy(p->plan_z);
+    hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); hipfftDestroy(p->plan_y);
     hipFree(p->c0); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
     return 0;
@@ -182,10 +202,19 @@ extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const do
 extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
-    {
+    if (!p->split_xy) {
         ProfScope ps(p->b, X3D_K_FFT, 1);
         X3D_FFT(hipfftSetStream(p->plan_xy_fw, p->b->stream));
         X3D_FFT(hipfftExecD2Z(p->plan_xy_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+    } else {
+        ProfScope ps(p->b, X3D_K_FFT, 1);
+        X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
+        X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
+        for (int k = 0; k < p->zl; k++) {
+            hipfftDoubleComplex *c = (hipfftDoubleComplex *)(p->c0 + (size_t)k * p->ny * p->nxs);
+            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in + (size_t)k * p->b->nxp * p->b->nyp, c));
+            X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, HIPFFT_FORWARD));
+        }
     }
     ProfScope ps(p->b, X3D_K_PACK);
     const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
@@ -251,7 +280,17 @@ extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf,
         X3D_HIP(hipGetLastError());
     }
     ProfScope ps(p->b, X3D_K_FFT, 2);
-    X3D_FFT(hipfftSetStream(p->plan_xy_bw, p->b->stream));
-    X3D_FFT(hipfftExecZ2D(p->plan_xy_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+    if (!p->split_xy) {
+        X3D_FFT(hipfftSetStream(p->plan_xy_bw, p->b->stream));
+        X3D_FFT(hipfftExecZ2D(p->plan_xy_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+        return 0;
+    }
+    X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
+    X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
+    for (int k = 0; k < p->zl; k++) {
+        hipfftDoubleComplex *c = (hipfftDoubleComplex *)(p->c0 + (size_t)k * p->ny * p->nxs);
+        X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, HIPFFT_BACKWARD));
+        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, c, (hipfftDoubleReal *)f_out + (size_t)k * p->b->nxp * p->b->nyp));
+    }
     return 0;
 }

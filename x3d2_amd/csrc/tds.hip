@@ -692,6 +692,8 @@ static int check_len(const x3d_backend *b, const x3d_tdsops *t, int dir, const c
 
 extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
@@ -705,6 +707,8 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
                                 const double *u, const double *u_recv_s, const double *u_recv_e,
                                 const x3d_tdsops *t, int dir)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && du_send_s && du_send_e && u && u_recv_s && u_recv_e && t,
                 "x3d_tds_dist_fwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_fwd: bad dir %d", dir);
@@ -723,6 +727,8 @@ extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du
                                     const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
                                     double scale)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
@@ -748,6 +754,8 @@ extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_sen
 extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
                                  int accumulate, double scale)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && u && t, "x3d_tds_solve: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve: bad dir %d", dir);
     X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
@@ -784,6 +792,8 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
                                   const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && tb && (mode == 0 ? in2 != nullptr : out2 != nullptr),
                 "x3d_tds_solve_pair: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_solve_pair: mode must be 0 or 1");
@@ -813,6 +823,8 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
 extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1,
                                         const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && tb && done && (mode == 0 ? in2 != nullptr : out2 != nullptr),
                 "x3d_tds_solve_pair_yperm: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_solve_pair_yperm: mode must be 0 or 1");
@@ -871,6 +883,8 @@ static int tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d
 extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
                                      const double *base, int nterm, const double *c, const double *const *x)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, nullptr);
 }
 
@@ -881,12 +895,15 @@ extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, c
                                           const double *base, int nterm, const double *c, const double *const *x,
                                           const double *wall)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(wall, "x3d_tds_solve_lincomb_wall: null argument");
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall);
 }
 
 extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_tds(b, du, u, t, dir);
     return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);
 }
 
@@ -935,6 +952,8 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
                                     const double *conv, const double *conv_recv_s, const double *conv_recv_e,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && rhs && send_s && send_e && u && u_recv_s && u_recv_e && conv && conv_recv_s &&
                     conv_recv_e && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_fwd: null argument");
@@ -956,6 +975,8 @@ extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, co
                                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
                                         int accumulate)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && rhs && send_s && recv_s && recv_e && conv && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
@@ -1035,6 +1056,7 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, doub
                            const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                            const x3d_tdsops *der2nd_sym)
 {
+    if (b && x3d_lazy_active(b)) return x3d_lazy_transeq(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym);
     return x3d_transeq_acc(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0);
 }
 
@@ -1043,6 +1065,8 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
                                const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                const x3d_tdsops *der2nd_sym, int accumulate)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym,
                 "x3d_transeq: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq: bad dir %d", dir);
@@ -1096,6 +1120,8 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
                                     const double *gv, const double *gw, const x3d_tdsops *op_u,
                                     const x3d_tdsops *op_vw, double scale, int *done)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && gu && gv && gw &&
                     op_u && op_vw && done,
                 "x3d_transeq_x_update: null argument");
@@ -1128,6 +1154,8 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double 
                                  const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega,
                                  const double *u_shift, int *done)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
                 "x3d_transeq_x_rot: null argument");
     *done = 0;
@@ -1154,6 +1182,8 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
                                    double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                    const x3d_tdsops *der2nd, int accumulate)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_species: bad dir %d", dir);
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
@@ -1172,6 +1202,8 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
 // send[side 2][field nf][4][np]: rows 1..4 (side 0, for prev) and n-3..n (side 1, for next) of nf <= 3 fields
 extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && send && fields, "x3d_pack_halos_multi: null argument");
     X3D_REQUIRE(nf >= 1 && nf <= 3, "x3d_pack_halos_multi: 1..3 fields");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos_multi: bad dir %d", dir);
@@ -1201,6 +1233,8 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv,
                                 int accumulate, const double *halo_recv, double *bnd_send, int other0, int nother,
                                 int *done)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
                 "x3d_transeq_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_transeq_tile: halo_recv and bnd_send go together");
@@ -1229,6 +1263,8 @@ extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double 
                                     const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                                     const x3d_tdsops *der2nd, const double *bnd_recv)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der2nd && bnd_recv, "x3d_transeq_halo_fix: null argument");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_halo_fix: dir must be y or z");
     double *r[3];
@@ -1244,6 +1280,8 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1
                                  const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
                                  double *bnd_send, int other0, int nother, int *done)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && done, "x3d_tds_pair_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_tds_pair_tile: halo_recv and bnd_send go together");
     *done = 0;
@@ -1272,6 +1310,8 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && ta && bnd_recv && (mode == 2 || tb) && (mode != 1 || out2), "x3d_tds_pair_halo_fix: null argument");
     X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_halo_fix: mode must be 0, 1 or 2");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_halo_fix: dir must be y or z");

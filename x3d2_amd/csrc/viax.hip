@@ -303,6 +303,8 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv
                                  const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                  const x3d_tdsops *der2nd_sym, int *deferred)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && pu && pv && pw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && deferred,
                 "x3d_transeq_defer: null argument");
     *deferred = 0;
@@ -340,6 +342,8 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv
 // r += transpose^-1(pend): the plain completion of a deferred component
 extern "C" int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && r && pend, "x3d_pending_flush: null argument");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_pending_flush: dir must be Y or Z");
     return from_pencils(b, dir, via_geom(b, dir), r, pend, 1, 0, via_geom(b, dir).nC);
@@ -348,6 +352,8 @@ extern "C" int x3d_pending_flush(x3d_backend *b, int dir, double *r, const doubl
 extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm,
                                    const double *c, double *const *x, int ipend, const double *pend, int store)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && y && base && c && x && pend, "x3d_lincomb_pending: null argument");
     X3D_REQUIRE(nterm >= 1 && nterm <= 5 && ipend >= 0 && ipend < nterm, "x3d_lincomb_pending: bad term count / index");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_lincomb_pending: dir must be Y or Z");
@@ -394,6 +400,8 @@ extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const doub
                                    const x3d_tdsops *der2nd_sym, double *y, const double *base, int nterm,
                                    const double *c, double *const *x, int ipend, int store)
 {
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && u && conv && der1st && der1st_sym && der2nd && der2nd_sym && y && base && c && x,
                 "x3d_transeq_lincomb: null argument");
     X3D_REQUIRE(nterm >= 1 && nterm <= 5 && ipend >= 0 && ipend < nterm, "x3d_transeq_lincomb: bad term count / index");

@@ -13,10 +13,11 @@ from .common import DIR_C, DIR_X, DIR_Y, DIR_Z, NULL_LOC, X3dError
 
 class Field:
     """field_t: flat device block + dir + data_loc + refcount."""
-    __slots__ = ("data", "dir", "data_loc", "refcount", "id")
+    __slots__ = ("data", "dir", "data_loc", "refcount", "id", "owner")
 
-    def __init__(self, data, ident):
+    def __init__(self, data, ident, owner=None):
         self.data, self.dir, self.data_loc, self.refcount, self.id = data, DIR_X, NULL_LOC, 0, ident
+        self.owner = owner
 
     @property
     def ptr(self):
@@ -26,7 +27,14 @@ class Field:
         self.data_loc = data_loc
 
     def fill(self, c):
-        self.data.fill_(c)  # field_t%fill, src/field.f90:47-55
+        """field_t%fill, src/field.f90:47-55"""
+        lz = self.owner.lazy if self.owner is not None else None
+        if lz is not None:  # deferred execution: the block address is a handle, only the library may write to it
+            lib, h = lz
+            if lib.x3d_block_fill(h, self.ptr, float(c)) != 0:
+                raise X3dError(lib.x3d_last_error().decode())
+            return
+        self.data.fill_(c)
 
 
 class Allocator:
@@ -38,6 +46,7 @@ class Allocator:
         self.device = device
         self.free = []
         self.next_id = 0
+        self.lazy = None  # (lib, backend handle) while the library's deferred execution is on (HipBackend(lazy=True))
         self.stagger = int(os.environ.get("X3D_BLOCK_STAGGER", str(self.STAGGER)))  # (read once)
 
     # Blocks start 4224 B (one padded row of a 512^3 block) further into their allocation than the previous one,
@@ -51,9 +60,15 @@ class Allocator:
         st = self.stagger
         if st:
             off = (self.next_id % 16) * st
-            return Field(torch.zeros(self.n + 16 * st, dtype=torch.float64, device=self.device)[off:off + self.n],
-                         self.next_id)
-        return Field(torch.zeros(self.n, dtype=torch.float64, device=self.device), self.next_id)
+            f = Field(torch.zeros(self.n + 16 * st, dtype=torch.float64, device=self.device)[off:off + self.n],
+                      self.next_id, self)
+        else:
+            f = Field(torch.zeros(self.n, dtype=torch.float64, device=self.device), self.next_id, self)
+        if self.lazy is not None:
+            lib, h = self.lazy
+            if lib.x3d_lazy_register_block(h, f.ptr) != 0:
+                raise X3dError(lib.x3d_last_error().decode())
+        return f
 
     def get_block(self, direction, data_loc=None):
         if direction not in (DIR_X, DIR_Y, DIR_Z, DIR_C):
@@ -67,6 +82,10 @@ class Allocator:
     def release_block(self, f):
         f.refcount = 0
         self.free.append(f)
+        if self.lazy is not None:  # the contents are dead until the block is written again
+            lib, h = self.lazy
+            if lib.x3d_block_discard(h, f.ptr) != 0:
+                raise X3dError(lib.x3d_last_error().decode())
 
     def get_block_ids(self):
         return [f.id for f in reversed(self.free)]

@@ -303,8 +303,9 @@ class HipPoissonFFT:
         _lib.check(self.backend.lib.x3d_poisson_fft_backward(self.h, f_out.ptr))
 
     def poisson_000(self, f, temp):  # :216-226
-        if type(self) is HipPoissonFFT:
+        if type(self) is HipPoissonFFT and not getattr(self.backend, "lazy", False):
             # one C call: forward ; postprocess_000 ; backward (the library fuses the z passes when it can)
+            # (deferred execution: the three hooks are recorded like the Fortran shim's and merged by the queue)
             _lib.check(self.backend.lib.x3d_poisson_solve_000(self.h, f.ptr))
             return
         self.fft_forward(f)

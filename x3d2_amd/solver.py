@@ -80,6 +80,9 @@ class Solver:
             self.nu_species = [1.0 / cfg.Re / pr for pr in cfg.pr_species]
             self.species = [al.get_block(DIR_X) for _ in range(self.nspecies)]
         self.fused = bool(cfg.fused)
+        if self.fused and getattr(backend, "lazy", False):
+            raise X3dError("deferred execution (HipBackend(lazy=True)) is for the op-granular driver: the fused driver "
+                           "already issues the fused kernels itself and swaps block buffers behind the library's back")
         self.time_integrator = TimeIntegrator(backend, al, cfg.time_intg, self.nvars, fused=self.fused)
         self.dt, self.nu = cfg.dt, 1.0 / cfg.Re
         self.n_iters, self.n_output = cfg.n_iters, cfg.n_output
