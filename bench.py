@@ -274,6 +274,7 @@ def main():
     nstage = solver.time_integrator.nstage
 
     def sync_all():
+        backend.sync()  # (x3d_device_sync: also runs what the deferred-execution layer still holds)
         torch.cuda.synchronize()
         comm.barrier()
         torch.cuda.synchronize()

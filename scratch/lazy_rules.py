@@ -9,14 +9,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 only = sys.argv[3] if len(sys.argv) > 3 else None
-from x3d2_amd import make_tgv  # noqa: E402
+from x3d2_amd import make_channel, make_tgv  # noqa: E402
+chan = os.environ.get("CHANNEL")  # e.g. CHANNEL=32,33,24: the channel case instead of the TGV
 
 
 def run(lazy, mask=None, keep0=False):
     if mask is not None:
         os.environ["X3D_LAZY_RULES"] = str(mask)
     os.environ["X3D_LAZY_KEEP_ZERO_TERMS"] = "1" if keep0 else "0"
-    c = make_tgv(n, fused=False, lazy=lazy)
+    if chan:
+        c = make_channel(tuple(int(v) for v in chan.split(",")), fused=False, lazy=lazy, rotation=True, omega_rot=0.12, n_rotate=2)
+    else:
+        c = make_tgv(n, fused=False, lazy=lazy)
     for it in range(1, steps + 1):
         c.step(it)
     s = c.solver

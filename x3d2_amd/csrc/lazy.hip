@@ -636,6 +636,10 @@ int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw
                      const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
                      const x3d_tdsops *t3)
 {
+    // transeq_x opens a sub-step (src/solver.f90:320): no rewrite reaches back across it, and everything the previous
+    // sub-step released has been seen -- what has been recorded runs now, the device works on it while the host records on
+    if (dir == X3D_DIR_X)
+        if (int rc = x3d_lazy_flush_c(b)) return rc;
     LOp op;
     op.kind = L_TRANSEQ; op.dir = dir;
     op.o[0] = du; op.o[1] = dv; op.o[2] = dw; op.in[0] = u; op.in[1] = v; op.in[2] = w;
