@@ -571,17 +571,18 @@ def test_unchanged_reference_solver_through_fortran_shim_on_several_ranks(nranks
     assert rows[:, 2].max() < 1e-11
 
 
-@pytest.mark.parametrize("env", ["X3D_NO_ONCHIP2", "X3D_XDIR_GENERIC", "X3D_NO_XSCAN", "X3D_NO_YTILE", "X3D_XSCAN_P1",
-                                 "X3D_NO_TDS_PAIR", "X3D_NO_TILE3", "X3D_NO_TDS_LINCOMB"])
+@pytest.mark.parametrize("env", ["X3D_NO_ONCHIP2,X3D_NO_TDS_PAIR,X3D_NO_TILE3,X3D_NO_TDS_LINCOMB", "X3D_XDIR_GENERIC",
+                                 "X3D_NO_XSCAN", "X3D_NO_YTILE", "X3D_XSCAN_P1"])
 def test_fallback_kernel_families_pass_the_same_parity_tests(env):
     """the kernels other sizes / boundary conditions fall back to must give the same results on the sizes the
     fast paths take: two-sweep tds_solve instead of the on-chip one, generic / LDS-tiled x kernels instead of
     the wave-per-pencil scan, two-sweep y/z transeq, y through transposed copies instead of the LDS tile, one
-    pencil per wave, separate kernels instead of the pair / three-in-one / lincomb fusions"""
+    pencil per wave, separate kernels instead of the pair / three-in-one / lincomb fusions (the four fusion
+    switches are independent of each other and share one run; the switches are read once per process)"""
     import os
     import subprocess
     import sys
-    e = dict(os.environ, **{env: "1"})
+    e = dict(os.environ, **{k: "1" for k in env.split(",")})
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
                         "tds_solve_all or transeq_div_grad or fused_transeq_and_time or (512_row_pencils and periodic) "
                         "or (full_size_pencils and (512 or 256 or 192))"],
@@ -985,13 +986,14 @@ def test_tgv512_fast_paths_match_general_kernels():
     assert abs(fast[0, 1] - 0.375) < 1e-6
 
 
-@pytest.mark.parametrize("dims", [(256, 256, 256), (256, 512, 512)])
+@pytest.mark.parametrize("dims", [(256, 256, 256), (256, 512, 512), (512, 512, 512)])
 def test_fused_full_step_against_the_oracle_at_fast_path_sizes(dims):
     """one full fused time step (3 sub-steps: transeq, RK3 stage, pressure correction with the FFT Poisson
     solve) against the oracle at sizes where the size-specialised kernels all engage TOGETHER: 256^3 (x scan
-    K3s / three-in-one + deferred velocity correction, tile kernels K3y and pairs, on-chip K1e, k_xscan_tds_lin)
-    and 256 x 512 x 512 (the same with 512-row y / z pencils and the own strided 512-point FFTs with the fused
-    spectral z pass).  Velocity fields, enstrophy and max |div u|."""
+    K3s / three-in-one + deferred velocity correction, tile kernels K3y and pairs, on-chip K1e, k_xscan_tds_lin),
+    256 x 512 x 512 (the same with 512-row y / z pencils and the own strided 512-point FFTs with the fused
+    spectral z pass) and 512^3 -- BASELINE configs[2], the bench's own workload (the oracle step takes ~25 s on the
+    box's host).  Velocity fields, enstrophy and max |div u|."""
     from oracle import x3d_oracle as orc
     from x3d2_amd import make_tgv
     case = make_tgv(dims, fused=True)

@@ -49,6 +49,10 @@ class Comm:
         # depend on them (X3D_NO_OVERLAP=1: every exchange is ordered on the compute stream, for A/B runs)
         self.overlap = os.environ.get("X3D_NO_OVERLAP") != "1"
         self._cstream = None
+        # the overlapped path is verified against the ordered one on first use (self_check below): a transport
+        # whose stream semantics differ from what _start assumes costs the overlap, not the results
+        self._checked = self.host_staged or not self.enabled or self.size == 1 or not self.overlap
+        self.self_check_result = None
 
     # ------------------------------------------------------------ p2p core
     def _exchange(self, sends, recvs):
@@ -81,9 +85,14 @@ class Comm:
         communication stream: kernels launched on the compute stream afterwards run beside it"""
         if not sends and not recvs:
             return DONE
+        if not self._checked:
+            self.self_check()
         if self.host_staged or not self.overlap:
             self._exchange(sends, recvs)
             return DONE
+        return self._start_overlapped(sends, recvs)
+
+    def _start_overlapped(self, sends, recvs):
         cs = self._comm_stream()
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):  # RCCL's own stream waits for the stream that is current at posting time
@@ -91,6 +100,55 @@ class Comm:
             ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
             works = dist.batch_isend_irecv(ops)
         return _Pending(works)
+
+    def self_check(self):
+        """ONE ring exchange through the overlapped path (communication stream, handle.wait()) against the same
+        exchange through the ordered path, with a producer kernel queued right before the send and a consumer right
+        after the wait -- the two orderings _start relies on (RCCL's work waits for the stream that is current when it
+        is posted; wait() makes the compute stream wait for RCCL's).  All ranks agree on the verdict (all-reduce);
+        a mismatch or an error switches the overlap off for this run (results stay right, exchanges are ordered on
+        the compute stream) and says so on rank 0.  X3D_NO_OVERLAP=1 skips the check and the overlap."""
+        self._checked = True
+        ok = 1.0
+        try:
+            n = 1 << 21
+            dev = torch.device("cuda", torch.cuda.current_device())
+            prev, nxt = (self.rank - 1) % self.size, (self.rank + 1) % self.size
+            heavy = torch.ones(1 << 26, dtype=torch.float64, device=dev)
+            out = []
+            for overlapped in (False, True):
+                send = torch.zeros(n, dtype=torch.float64, device=dev)
+                recv = torch.full((n,), -1.0, dtype=torch.float64, device=dev)
+                # producer: a long kernel, then the values to send, both on the compute stream
+                heavy.mul_(1.0000001)
+                send.copy_(torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * (self.rank + 1))
+                sends, recvs = [(send, nxt)], [(recv, prev)]
+                if overlapped:
+                    h = self._start_overlapped(sends, recvs)
+                    heavy.mul_(1.0000001)  # (independent work beside the transfer)
+                    h.wait()
+                else:
+                    self._exchange(sends, recvs)
+                out.append(recv.clone())  # consumer on the compute stream
+            want = torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * (prev + 1)
+            torch.cuda.synchronize()
+            if not (torch.equal(out[0], want) and torch.equal(out[1], want)):
+                ok = 0.0
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the ordered path is the fallback
+            ok = 0.0
+            self.self_check_error = repr(e)
+        try:
+            t = torch.tensor([ok], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            ok = float(t.item())
+        except Exception:  # noqa: BLE001
+            ok = 0.0
+        self.self_check_result = bool(ok)
+        if not ok:
+            self.overlap = False
+            if self.rank == 0:
+                print("x3d2_amd.parallel: overlapped exchange failed its self-check against the ordered path; "
+                      "exchanges are ordered on the compute stream for this run", flush=True)
 
     # ------------------------------------------------------------ halo / boundary exchange
     def sendrecv(self, pairs, prev, nxt):
