@@ -474,7 +474,7 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
         // (pad columns all zero: k_penta_factor / k_penta_solve guard their divisions by |a3| > eps)
         if (int rc = upload_pitched(p->lu[s], src[s], rows, p->nxm, p->nxs, sizeof(double))) return rc;
-        hipLaunchKernelGGL(k_penta_factor, penta_grid(p->nxs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->nxs, n,
+        hipLaunchKernelGGL(k_penta_factor<false>, penta_grid(p->nxs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->nxs, n,
                            p->nz);
         X3D_HIP(hipGetLastError());
     }

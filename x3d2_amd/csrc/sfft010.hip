@@ -10,10 +10,12 @@
 //   --rocFFT 2-D, R2C along x, C2C along y, batched over the zl local planes-->  C0[zl][ny][nxs]   nxs = pz * xs
 //   --pack-->  S[peer][zl][ny][xs]          (peer r gets the x modes r xs .. (r + 1) xs - 1 of every local row)
 //   --all-to-all among the pz ranks-->  R[peer][zl][ny][xs] = W[nz][ny][xs]   (chunks arrive in z order)
-//   --z transform on W itself (stride ny xs)-->  this rank's xs modes x ALL ny rows x ALL nz modes
-//   --fft_postprocess_010 on W: the single-rank kernels (spectral010.h) with the mode offset i0 = rz xs: uniform y
-//     one kernel, stretched y fw ; pentadiagonal solves (factored once at set-up) ; bw
-//   --inverse z transform, all-to-all back, unpack, inverse 2-D transform-->  f
+//   --32 x 32 LDS-tiled transpose-->  T[ny][xs][nz] (z contiguous)  --rocFFT C2C along z-->  this rank's xs modes x ALL
+//     ny rows x ALL nz modes   (rocFFT's strided plan on W itself takes 2.0 - 2.1 ms per direction for 1.08 GB,
+//     transpose + contiguous plan 0.42 + 0.41, scratch/zfft_bench.hip -- and the spectral stage runs on T as it is)
+//   --fft_postprocess_010 on T: the single-rank kernels (spectral010.h) in their z-fastest form, mode offset
+//     i0 = rz xs: uniform y one kernel, stretched y fw ; pentadiagonal solves (factored once at set-up) ; bw
+//   --inverse z transform, transpose back, all-to-all back, unpack, inverse 2-D transform-->  f
 // xs = ceil((nx/2 + 1) / pz): every rank owns the same number of mode columns, the columns beyond nx/2 + 1 on the last
 // rank are padding (zeros in, wave numbers one, matrices zero: the kernels' guarded divisions leave zeros).
 #include <hipfft/hipfft.h>
@@ -41,11 +43,12 @@ struct x3d_sfft010 {
                          // + 1-D strided y plan run once per local plane
     hipfftHandle plan_x_fw, plan_x_bw, plan_y;
     double2 *c0;         // [zl][ny][nxs]
-    double *waves;       // [nz][ny][xs] (pads: one)
+    double2 *t;          // [ny][xs][nz]: z-contiguous copy of the received array; the spectral stage works here
+    double *waves;       // [ny][xs][nz] (pads: one)
     double *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
     int nab_x;           // length of the ax / bx tables on the device
     int stretched, sym;
-    double *lu[2];       // factored pentadiagonal operators [5][nz][n][xs]
+    double *lu[2];       // factored pentadiagonal operators [5][n][xs][nz]
     void *work;
 };
 
@@ -62,6 +65,34 @@ __global__ void __launch_bounds__(256)
     const long si = ((long)peer * rows + row) * xs + i;
     if (UNPACK) c0[t] = s[si];
     else s[si] = c0[t];
+}
+
+// 32 x 32 tiles through LDS: src [nB][nA] (A contiguous) -> dst [nA][nB] (B contiguous)
+template <class E>
+__global__ void __launch_bounds__(256) k_sfft010_transpose(E *__restrict__ dst, const E *__restrict__ src, long nA, long nB)
+{
+    __shared__ E tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long a0 = (long)blockIdx.x * 32, b0 = (long)blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long bb = b0 + ty + 8 * r, aa = a0 + tx;
+        if (aa < nA && bb < nB) tile[ty + 8 * r][tx] = src[bb * nA + aa];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long aa = a0 + ty + 8 * r, bb = b0 + tx;
+        if (aa < nA && bb < nB) dst[aa * nB + bb] = tile[tx][ty + 8 * r];
+    }
+}
+template <class E>
+static int transpose_launch(hipStream_t st, E *dst, const E *src, long nA, long nB)
+{
+    hipLaunchKernelGGL(k_sfft010_transpose<E>, dim3((unsigned)((nA + 31) / 32), (unsigned)((nB + 31) / 32)), dim3(256), 0, st,
+                       dst, src, nA, nB);
+    X3D_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz)
@@ -82,6 +113,7 @@ extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int n
     X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
     X3D_HIP(hipMemset(p->c0, 0, sizeof(double2) * n0));  // (pad columns stay zero: the transforms never write them)
     X3D_HIP(hipMalloc(&p->waves, sizeof(double) * nw));
+    X3D_HIP(hipMalloc(&p->t, sizeof(double2) * nw));
     p->nab_x = p->nx > p->nxs ? p->nx : p->nxs;
     X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
     X3D_HIP(hipMemset(p->ab, 0, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
@@ -110,10 +142,9 @@ extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int n
         X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nx1, cx, 1, p->nxs, rx, 1, b->nxp, HIPFFT_Z2D, p->ny, &ws[4]));
         X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, ny1, ey, p->nxs, 1, ey, p->nxs, 1, HIPFFT_Z2Z, p->nxs, &ws[5]));
     }
-    // z transform on W[nz][ny][xs] itself: stride ny * xs, one transform per (row, mode)
+    // z transform on the z-contiguous copy T[ny * xs][nz]
     int nzv[1] = {p->nz}, ze[1] = {p->nz};
-    const int zstride = p->ny * p->xs;
-    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, zstride, 1, ze, zstride, 1, HIPFFT_Z2Z, zstride, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, 1, p->nz, ze, 1, p->nz, HIPFFT_Z2Z, p->ny * p->xs, &ws[2]));
     size_t wmax = 0;
     for (int i = 0; i < 6; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
@@ -130,7 +161,7 @@ extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
     if (!p) return 0;
     hipfftDestroy(p->plan_xy_fw); hipfftDestroy(p->plan_xy_bw); hipfftDestroy(p->plan_z);
     hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); hipfftDestroy(p->plan_y);
-    hipFree(p->c0); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->lu[0]); hipFree(p->lu[1]);
+    hipFree(p->c0); hipFree(p->t); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
     return 0;
 }
@@ -148,7 +179,12 @@ extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const 
                                      const double *ay, const double *by, const double *az, const double *bz)
 {
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
-    X3D_HIP(hipMemcpy(p->waves, waves, sizeof(double) * (size_t)p->nz * p->ny * p->xs, hipMemcpyHostToDevice));
+    {   // [nz][ny][xs] on the host -> [ny][xs][nz] on the device (T serves as the landing zone)
+        const size_t nw = (size_t)p->nz * p->ny * p->xs;
+        X3D_HIP(hipMemcpy(p->t, waves, sizeof(double) * nw, hipMemcpyHostToDevice));
+        if (int rc = transpose_launch<double>(p->b->stream, p->waves, (const double *)p->t, (long)p->ny * p->xs, p->nz)) return rc;
+        X3D_HIP(hipStreamSynchronize(p->b->stream));
+    }
     const double *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
     const int slot[6] = {p->nab_x, p->nab_x, p->ny, p->ny, p->nz, p->nz};
@@ -167,15 +203,22 @@ extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double 
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_sfft010_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
     X3D_REQUIRE(n >= 3, "x3d_sfft010_set_stretching: too few rows");
-    const size_t bytes = sizeof(double) * 5 * (size_t)p->nz * n * p->xs;
+    const size_t nd = (size_t)p->nz * n * p->xs, bytes = sizeof(double) * 5 * nd;
     const double *src[2] = {a0, a1};
+    double *tmp = nullptr;  // one diagonal [nz][n][xs] as uploaded, before it goes to [n][xs][nz]
+    X3D_HIP(hipMalloc(&tmp, sizeof(double) * nd));
     for (int s = 0; s < (sym ? 2 : 1); s++) {
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
-        X3D_HIP(hipMemcpy(p->lu[s], src[s], bytes, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_penta_factor, penta_grid(p->xs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->xs, n, p->nz);
+        for (int d = 0; d < 5; d++) {
+            X3D_HIP(hipMemcpy(tmp, src[s] + d * nd, sizeof(double) * nd, hipMemcpyHostToDevice));
+            if (int rc = transpose_launch<double>(p->b->stream, p->lu[s] + d * nd, (const double *)tmp, (long)n * p->xs, p->nz)) return rc;
+            X3D_HIP(hipStreamSynchronize(p->b->stream));
+        }
+        hipLaunchKernelGGL(k_penta_factor<true>, penta_grid(p->xs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->xs, n, p->nz);
         X3D_HIP(hipGetLastError());
     }
     X3D_HIP(hipStreamSynchronize(p->b->stream));
+    X3D_HIP(hipFree(tmp));
     p->stretched = 1;
     p->sym = sym;
     return 0;
@@ -224,48 +267,38 @@ extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, dou
     return 0;
 }
 
-// z transform of the received array W[nz][ny][xs], in place; dir 0 forward, 1 backward
+// dir 0: the received array W[nz][ny][xs] -> T[ny][xs][nz], forward z transform (the spectrum stays in T);
+// dir 1: backward z transform of T, then back to W
 extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    ProfScope ps(p->b, X3D_K_FFT, 3);
-    X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-    X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)recvbuf, (hipfftDoubleComplex *)recvbuf,
-                          dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    const long cols = (long)p->ny * p->xs;
+    if (dir == 0) {
+        ProfScope ps(p->b, X3D_K_PACK);
+        if (int rc = transpose_launch<double2>(p->b->stream, p->t, (const double2 *)recvbuf, cols, p->nz)) return rc;
+    }
+    {
+        ProfScope ps(p->b, X3D_K_FFT, 3);
+        X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
+        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->t, (hipfftDoubleComplex *)p->t,
+                              dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    }
+    if (dir == 1) {
+        ProfScope ps(p->b, X3D_K_PACK);
+        if (int rc = transpose_launch<double2>(p->b->stream, (double2 *)recvbuf, (const double2 *)p->t, p->nz, cols)) return rc;
+    }
     return 0;
 }
 
-// fft_postprocess_010 on this rank's x modes (all rows, all z modes)
+// fft_postprocess_010 on this rank's x modes (all rows, all z modes), in the z-contiguous copy
 extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     ProfScope ps(p->b, X3D_K_SPECTRAL);
-    // tables: ax bx at pitch nab_x -- spectral_010_launch expects them nx apart: hand it the pieces
     const double *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
-    hipStream_t st = p->b->stream;
-    double2 *c = (double2 *)recvbuf;
-    const int i0 = p->rz * p->xs;
-    const dim3 grid = spectral_010_grid(p->xs, p->ny, p->nz);
-#define SPEC(M_)                                                                                                    \
-    hipLaunchKernelGGL(k_spectral_010<M_>, grid, dim3(256), 0, st, c, p->waves, p->xs, p->ny, p->nz, p->nx, i0, ax, bx, \
-                       ay, by, az, bz)
-    if (!p->stretched) {
-        SPEC(2);
-    } else {
-        SPEC(0);
-        const dim3 g2 = penta_grid(p->xs, p->nz);
-        if (p->sym) {
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[0], 0, 2, p->xs, p->ny, p->nz, p->ny / 2, p->nx, i0);
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[1], 1, 2, p->xs, p->ny, p->nz, p->ny / 2, p->nx, i0);
-        } else {
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, p->lu[0], 0, 1, p->xs, p->ny, p->nz, p->ny, p->nx, i0);
-        }
-        SPEC(1);
-    }
-#undef SPEC
-    X3D_HIP(hipGetLastError());
-    return 0;
+    return spectral_010_launch_t<true>(p->b->stream, p->t, p->waves, p->xs, p->nx, p->ny, p->nz, p->rz * p->xs, ax, bx, ay, by,
+                                       az, bz, p->stretched, p->sym, p->lu);
 }
 
 // unpack the returned array S[peer][zl][ny][xs] and transform back to the real planes

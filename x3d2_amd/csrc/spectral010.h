@@ -61,20 +61,27 @@ __device__ __forceinline__ void rot_bw(double &r, double &c, const Rot &t)
 // ZROT = false (Poisson 110 on the z-first transposed problem): the third direction is not periodic either -- no
 // rotation along it here, it gets its own paired split (k_spectral_pair_z)
 // ax, bx: the GLOBAL tables (indexed i0 + i); nx, ny, nz: global cell counts
-template <int MODE, bool ZROT = true>
+// ZF: the arrays are [ny][nxs][nz], z fastest (the slab solver's z-contiguous copy, sfft010.hip) instead of [nz][ny][nxs]
+template <int MODE, bool ZROT = true, bool ZF = false>
 static __global__ void __launch_bounds__(256)
     k_spectral_010(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx, int i0,
                    const double *__restrict__ ax, const double *__restrict__ bx, const double *__restrict__ ay,
                    const double *__restrict__ by, const double *__restrict__ az, const double *__restrict__ bz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(t % nxs), j = (int)(t / nxs) + 1, k = blockIdx.y;  // j = 1 .. ny/2+1
-    if (j > ny / 2 + 1) return;
+    int i, j, k;
+    if (ZF) {
+        k = (int)(t % nz); i = (int)(t / nz); j = blockIdx.y + 1;
+        if (i >= nxs) return;
+    } else {
+        i = (int)(t % nxs); j = (int)(t / nxs) + 1; k = blockIdx.y;  // j = 1 .. ny/2+1
+        if (j > ny / 2 + 1) return;
+    }
     const int ig = i0 + i;
     const int jr = ny - j + 2;
     const bool paired = j >= 2, self = paired && jr == j;
-    const size_t il = ((size_t)k * ny + (j - 1)) * nxs + i;
-    const size_t ir = paired ? ((size_t)k * ny + (jr - 1)) * nxs + i : il;
+    const size_t il = ZF ? ((size_t)(j - 1) * nxs + i) * nz + k : ((size_t)k * ny + (j - 1)) * nxs + i;
+    const size_t ir = !paired ? il : (ZF ? ((size_t)(jr - 1) * nxs + i) * nz + k : ((size_t)k * ny + (jr - 1)) * nxs + i);
     const Rot rz{az[k], bz[k], (k + 1) > nz / 2 + 1}, rx{ax[ig], bx[ig], (ig + 1) > nx / 2 + 1};
     double2 L = c[il], R = paired && !self ? c[ir] : L;
     double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
@@ -133,8 +140,9 @@ static __global__ void __launch_bounds__(256)
     if (paired && !self) c[ir] = make_double2(r_r, r_c);
 }
 
-static inline dim3 spectral_010_grid(int nxs, int ny, int nz)
+static inline dim3 spectral_010_grid(int nxs, int ny, int nz, bool zf = false)
 {
+    if (zf) return dim3((unsigned)(((long)nxs * nz + 255) / 256), (unsigned)(ny / 2 + 1));
     return dim3((unsigned)(((long)nxs * (ny / 2 + 1) + 255) / 256), (unsigned)nz);
 }
 
@@ -149,14 +157,16 @@ static inline dim3 spectral_010_grid(int nxs, int ny, int nz)
 //   slot 3 row j : a4_j eliminated                                  (j <= n-1)
 //   slot 4 row j : a5_j                                             (j <= n-2)
 // so that the solve applies bit-for-bit the same operations to the right-hand side.
+template <bool ZF = false>  // ZF: [5][n][nxs][nz] instead of [5][nz][n][nxs]
 static __global__ void __launch_bounds__(64) k_penta_factor(double *__restrict__ a, int nxs, int n, int nz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(t % nxs), k = (int)(t / nxs);
-    if (k >= nz) return;
+    const int i = ZF ? (int)(t / nz) : (int)(t % nxs), k = ZF ? (int)(t % nz) : (int)(t / nxs);
+    if (ZF ? i >= nxs : k >= nz) return;
     const double eps = 1.e-16;
     const size_t ds = (size_t)nz * n * nxs;
-#define A(j, d) a[(size_t)((d) - 1) * ds + ((size_t)k * n + ((j) - 1)) * nxs + i]
+#define A(j, d)                                                                                              \
+    a[(size_t)((d) - 1) * ds + (ZF ? ((size_t)((j) - 1) * nxs + i) * nz + k : ((size_t)k * n + ((j) - 1)) * nxs + i)]
     for (int j = 1; j <= n - 2; j++) {
         const double a3 = A(j, 3), a4 = A(j, 4), a5 = A(j, 5);
         const double m1 = fabs(a3) > eps ? A(j + 1, 2) / a3 : 0.0;
@@ -180,17 +190,19 @@ static __global__ void __launch_bounds__(64) k_penta_factor(double *__restrict__
 
 // One thread per (i, k): coalesced along i.  Per spectral entry: forward r/w of the rhs + m1, m2;
 // backward r/w + 1/a3, a4, a5 = 104 B.
+template <bool ZF = false>
 static __global__ void __launch_bounds__(64)
     k_penta_solve(double2 *__restrict__ c, const double *__restrict__ lu, int off, int inc, int nxs, int ny,
                   int nz, int n, int nx, int i0)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(t % nxs), k = (int)(t / nxs);
-    if (k >= nz) return;
+    const int i = ZF ? (int)(t / nz) : (int)(t % nxs), k = ZF ? (int)(t % nz) : (int)(t / nxs);
+    if (ZF ? i >= nxs : k >= nz) return;
     const double eps = 1.e-16;
     const size_t ds = (size_t)nz * n * nxs;
-#define LU(j, d) lu[(size_t)((d) - 1) * ds + ((size_t)k * n + ((j) - 1)) * nxs + i]
-#define C(jm) c[((size_t)k * ny + ((jm) - 1)) * nxs + i]
+#define LU(j, d)                                                                                             \
+    lu[(size_t)((d) - 1) * ds + (ZF ? ((size_t)((j) - 1) * nxs + i) * nz + k : ((size_t)k * n + ((j) - 1)) * nxs + i)]
+#define C(jm) c[ZF ? ((size_t)((jm) - 1) * nxs + i) * nz + k : ((size_t)k * ny + ((jm) - 1)) * nxs + i]
     const int h = inc / 2;
     // forward: rows j+1, j+2 -= m * row j; two rows are carried in registers
     double2 r0 = C(inc * 1 + off - h), r1 = C(inc * 2 + off - h);
@@ -240,30 +252,40 @@ static __global__ void __launch_bounds__(64)
 
 static inline dim3 penta_grid(int nxs, int nz) { return dim3((unsigned)(((long)nxs * nz + 63) / 64)); }
 
-// fft_postprocess_010 (src/backend/cuda/poisson_fft.f90:822-924) on c[nz][ny][nxs] = the x modes i0.. of the global
-// problem: uniform y: the whole of process_spectral_010 in one kernel; stretched y: fw ; pentadiagonal solves on the
-// odd rows and the even rows (sym) or on all rows ; bw.  tables = ax bx ay by az bz (global lengths nx nx ny ny nz nz)
-static inline int spectral_010_launch(hipStream_t st, double2 *c, const double *waves, int nxs, int nx, int ny, int nz, int i0,
-                                      const double *tables, int stretched, int sym, double *const lu[2])
+// fft_postprocess_010 (src/backend/cuda/poisson_fft.f90:822-924) on c[nz][ny][nxs] (zf: c[ny][nxs][nz]) = the x modes
+// i0.. of the global problem: uniform y: the whole of process_spectral_010 in one kernel; stretched y: fw ;
+// pentadiagonal solves on the odd rows and the even rows (sym) or on all rows ; bw.  ax .. bz: the global tables
+template <bool ZF>
+static inline int spectral_010_launch_t(hipStream_t st, double2 *c, const double *waves, int nxs, int nx, int ny, int nz,
+                                        int i0, const double *ax, const double *bx, const double *ay, const double *by,
+                                        const double *az, const double *bz, int stretched, int sym, double *const lu[2])
 {
-    const double *ax = tables, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
-    const dim3 grid = spectral_010_grid(nxs, ny, nz);
+    const dim3 grid = spectral_010_grid(nxs, ny, nz, ZF);
 #define SPEC(M_)                                                                                                    \
-    hipLaunchKernelGGL(k_spectral_010<M_>, grid, dim3(256), 0, st, c, waves, nxs, ny, nz, nx, i0, ax, bx, ay, by, az, bz)
+    hipLaunchKernelGGL((k_spectral_010<M_, true, ZF>), grid, dim3(256), 0, st, c, waves, nxs, ny, nz, nx, i0, ax, bx, ay, by, \
+                       az, bz)
     if (!stretched) {
         SPEC(2);
     } else {
         SPEC(0);
         const dim3 g2 = penta_grid(nxs, nz);
         if (sym) {  // odd rows, then even rows (src/backend/cuda/poisson_fft.f90:880-895)
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, lu[0], 0, 2, nxs, ny, nz, ny / 2, nx, i0);
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, lu[1], 1, 2, nxs, ny, nz, ny / 2, nx, i0);
+            hipLaunchKernelGGL(k_penta_solve<ZF>, g2, dim3(64), 0, st, c, lu[0], 0, 2, nxs, ny, nz, ny / 2, nx, i0);
+            hipLaunchKernelGGL(k_penta_solve<ZF>, g2, dim3(64), 0, st, c, lu[1], 1, 2, nxs, ny, nz, ny / 2, nx, i0);
         } else {
-            hipLaunchKernelGGL(k_penta_solve, g2, dim3(64), 0, st, c, lu[0], 0, 1, nxs, ny, nz, ny, nx, i0);
+            hipLaunchKernelGGL(k_penta_solve<ZF>, g2, dim3(64), 0, st, c, lu[0], 0, 1, nxs, ny, nz, ny, nx, i0);
         }
         SPEC(1);
     }
 #undef SPEC
     X3D_HIP(hipGetLastError());
     return 0;
+}
+
+// tables = ax bx ay by az bz back to back (global lengths nx nx ny ny nz nz), arrays [nz][ny][nxs]
+static inline int spectral_010_launch(hipStream_t st, double2 *c, const double *waves, int nxs, int nx, int ny, int nz, int i0,
+                                      const double *tables, int stretched, int sym, double *const lu[2])
+{
+    const double *ax = tables, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    return spectral_010_launch_t<false>(st, c, waves, nxs, nx, ny, nz, i0, ax, bx, ay, by, az, bz, stretched, sym, lu);
 }
