@@ -480,7 +480,8 @@ int x3d_pfft_postprocess_000(x3d_pfft *p);
  * Single rank only (the distributed entry points run at once and call x3d_lazy_sync first).
  * x3d_lazy_stats: [0] calls recorded, [1] launches issued, [2] aliases, [3] transeq_acc, [4] pairs, [5] tds_solve_acc,
  * [6] lincombs, [7] tds_solve_lincomb, [8] solve_000, [9] updates run out of place (buffer swaps), [10] copies made for
- * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [13] calls dropped by the
+ * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [14] transeq_x launches that carry the velocity
+ * correction of the pressure step (x3d_transeq_x_update), [13] calls dropped by the
  * rewrite, [15] extra buffers held. */
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);

@@ -31,7 +31,8 @@ def run(lazy, mask=None, keep0=False):
 ref, _ = run(False)
 for name, mask, keep0 in (("none", 0, True), ("none, zero terms dropped", 0, False), ("transeq_acc", 1, True), ("pair0", 2, True),
                           ("pair1", 4, True), ("tds_acc", 8, True), ("lincomb merge", 16, True),
-                          ("lincomb merge + tds_lin", 48, True), ("solve000", 64, True), ("all", 127, False)):
+                          ("lincomb merge + tds_lin", 48, True), ("solve000", 64, True), ("all but transeq_upd", 127, False), ("tds_acc + transeq_upd", 136, True),
+                          ("all", 255, False)):
     if only is not None and name != only:
         continue
     f, st = run(True, mask, keep0)

@@ -41,7 +41,7 @@ def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, mon
         lazy.step(it)
     _same(eager, lazy, ulps=16 if n == 256 else 0)
     if n == 256:
-        monkeypatch.setenv("X3D_LAZY_RULES", str(127 - 2 - 4))
+        monkeypatch.setenv("X3D_LAZY_RULES", str(255 - 2 - 4))
         nopairs = make_tgv(n, time_intg=time_intg, fused=False, lazy=True)
         for it in range(1, steps + 1):
             nopairs.step(it)
@@ -51,7 +51,9 @@ def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, mon
     nsub = steps * lazy.solver.time_integrator.nstage
     assert st["transeq_acc"] == 2 * nsub
     assert st["pairs"] == 4 * nsub          # y and z of the divergence (mode 0), z and y of the gradient (mode 1)
-    assert st["tds_acc"] == 3 * nsub        # u, v, w -= gradient
+    # u, v, w -= gradient: three accumulating solves, or (every sub-step but the last before a read of the velocity)
+    # inside the next sub-step's transeq_x launch
+    assert st["tds_acc"] + 3 * st["transeq_upd"] == 3 * nsub and st["transeq_upd"] >= nsub - steps - 1
     assert st["solve_000"] == nsub
     assert st["tds_lincomb"] + st["lincombs"] >= 3 * nsub - 3
     assert st["aliases"] >= 16 * nsub       # the reorders (and the veccopies that turned into buffer swaps)
@@ -95,11 +97,11 @@ def test_deferred_channel_steps_are_bit_identical(dims, stretching, beta, monkey
     # (the wall-normal operator pairs run on k_ygen_pair, single solves on the two-sweep kernels: 1-2 ulp per operator)
     _same(eager, lazy, ulps=16)
     st = lazy.solver.backend.lazy_stats()
-    assert st["transeq_acc"] == 12 and st["pairs"] == 24 and st["tds_acc"] == 18
+    assert st["transeq_acc"] == 12 and st["pairs"] == 24 and st["tds_acc"] + 3 * st["transeq_upd"] == 18
     assert st["materialised"] == 0
     # (bit for bit without the pair rewrites and the accumulating solve, whose kernels contract "du + s * result" into one
     #  fused multiply-add where the separate calls round twice)
-    monkeypatch.setenv("X3D_LAZY_RULES", str(127 - 2 - 4 - 8))
+    monkeypatch.setenv("X3D_LAZY_RULES", str(255 - 2 - 4 - 8))
     nopairs = make_channel(dims, lazy=True, **kw)
     for it in (1, 2):
         nopairs.step(it)

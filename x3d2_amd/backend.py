@@ -101,7 +101,8 @@ class HipBackend:
         _lib.check(self.lib.x3d_device_sync(self.h))
 
     LAZY_STATS = ("recorded", "launched", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
-                  "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "_", "extra_buffers")
+                  "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "transeq_upd",
+                  "extra_buffers")
 
     def lazy_stats(self):
         """counters of the deferred-execution layer (x3d_lazy_stats)"""

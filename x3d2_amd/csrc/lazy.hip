@@ -15,6 +15,7 @@
 //   veccopy(y, b) ; vecadd(c1, x1, 1, y) ; vecadd(c2, x2, 1, y) ...         -> x3d_lincomb(y = b + c1 x1 + c2 x2 ...)
 //   lincomb(y) ; tds_solve(du; y; A) along x                                -> x3d_tds_solve_lincomb
 //   fft_forward(f) ; fft_postprocess_000 ; fft_backward(f)                  -> x3d_poisson_solve_000
+//   u += s A(gu) ; v += s B(gv) ; w += s B(gw) ; transeq_x(...; u, v, w)    -> x3d_transeq_x_update
 // every one of which is the same arithmetic in the same order as the calls it replaces (tests/test_hip_lazy.py
 // compares bit for bit).  A temporary is dropped only when the queue shows it dead: overwritten, or released to the
 // allocator (x3d_block_discard, which the shim's release_block issues) before anything reads it.
@@ -33,21 +34,21 @@
 
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
-    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000
+    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD
 };
 
 struct LOp {
     int kind = L_DEAD;
     int dir = 0, mode = 0, nterm = 0;
-    double *o[3] = {nullptr, nullptr, nullptr};  // handles written (or updated in place)
+    double *o[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // handles written (or updated in place)
     const double *in[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const x3d_tdsops *t[4] = {nullptr, nullptr, nullptr, nullptr};
+    const x3d_tdsops *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double s[6] = {0, 0, 0, 0, 0, 0};
     void *obj = nullptr;  // x3d_poisson* of the FFT hooks
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
-       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_N };
+       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_N };
 
 struct x3d_lazy {
     bool on = false, executing = false;
@@ -230,7 +231,7 @@ enum { A_R = 1, A_W = 2, A_M = 4 };  // read, overwritten completely, updated in
 static int nin(const LOp &op)
 {
     switch (op.kind) {
-    case L_TRANSEQ: case L_TRANSEQ_ACC: return 3;
+    case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5)
     case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: return 1;
     case L_PAIR: return op.mode == 0 ? 2 : 1;
     case L_LINCOMB: case L_TDS_LIN: return 1 + op.nterm;  // base, x...
@@ -241,14 +242,16 @@ static int nout(const LOp &op)
 {
     switch (op.kind) {
     case L_TRANSEQ: case L_TRANSEQ_ACC: return 3;
+    case L_TRANSEQ_UPD: return 6;  // du, dv, dw written; u, v, w updated in place (and read)
     case L_PAIR: return op.mode == 0 ? 1 : 2;
     case L_TDS_LIN: return 2;  // du, y
     case L_DEAD: case L_FFT_POST000: return 0;
     default: return 1;
     }
 }
-static bool out_is_update(const LOp &op)
+static bool out_is_update(const LOp &op, int slot = 0)
 {
+    if (op.kind == L_TRANSEQ_UPD) return slot >= 3;
     switch (op.kind) {
     case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
     case L_FFT_BWD: case L_SOLVE000:
@@ -262,7 +265,7 @@ static int touch(const LOp &op, const double *h)
     for (int k = 0; k < nin(op); k++)
         if (op.in[k] == h) m |= A_R;
     for (int k = 0; k < nout(op); k++)
-        if (op.o[k] == h) m |= out_is_update(op) ? A_M : A_W;
+        if (op.o[k] == h) m |= out_is_update(op, k) ? A_M : A_W;
     return m;
 }
 // no operation strictly between lo and hi touches any of `quiet`, none writes any of `stable`
@@ -397,6 +400,52 @@ static void optimise(x3d_lazy *L)
         q[pg].kind = L_TDS_ACC; q[pg].o[0] = U; q[pg].s[0] = q[p].s[0];
         q[p].kind = L_DEAD;
     }
+    // (8) u += s A(gu) ; v += s B(gv) ; w += s B(gw) ; transeq_x(du, dv, dw; u, v, w): the velocity correction of the
+    // pressure step inside the next sub-step's transeq_x kernel (x3d_transeq_x_update), fused where the FIRST of the
+    // three solves stands (their inputs are released right behind them; the outputs of transeq_x are fresh blocks
+    // whose release, if it falls in between, the overwrite makes redundant)
+    for (int p = 0; p < n && (L->rules & 128u); p++) {
+        if (q[p].kind != L_TRANSEQ || q[p].dir != X3D_DIR_X) continue;
+        int ks[3];
+        bool ok = true;
+        for (int c = 0; c < 3 && ok; c++) {
+            const double *f = q[p].in[c];
+            const int k = last_touch_before(q, p, f);
+            ok = k >= 0 && q[k].kind == L_TDS_ACC && q[k].o[0] == f && q[k].dir == X3D_DIR_X;
+            ks[c] = k;
+        }
+        if (!ok || q[ks[1]].t[0] != q[ks[2]].t[0] || q[ks[0]].s[0] != q[ks[1]].s[0] || q[ks[0]].s[0] != q[ks[2]].s[0]) continue;
+        const int k0 = std::min(ks[0], std::min(ks[1], ks[2])), k1 = std::max(ks[0], std::max(ks[1], ks[2]));
+        const double *g[3] = {q[ks[0]].in[0], q[ks[1]].in[0], q[ks[2]].in[0]};
+        // the later solves move up to k0: their gradients must not be written in between
+        (void)k1;
+        bool stable = true;
+        for (int c = 0; c < 3; c++) stable = stable && range_clear(q, k0, ks[c], {}, {g[c]});
+        if (!stable) continue;
+        // transeq_x moves up to k0: nothing between may touch its outputs (a bare release aside) or u, v, w
+        bool clear = true;
+        for (int m = k0 + 1; m < p && clear; m++) {
+            const LOp &op = q[m];
+            if (op.kind == L_DEAD || m == ks[0] || m == ks[1] || m == ks[2]) continue;
+            for (int c = 0; c < 3; c++) {
+                if (touch(op, q[p].in[c])) clear = false;
+                if (touch(op, q[p].o[c]) && op.kind != L_DISCARD) clear = false;
+            }
+        }
+        for (int c = 0; c < 3; c++)
+            for (int d = 0; d < 3; d++) clear = clear && q[p].o[c] != g[d] && q[p].o[c] != q[p].in[d] && q[p].in[c] != g[d];
+        if (!clear) continue;
+        LOp f;
+        f.kind = L_TRANSEQ_UPD; f.dir = X3D_DIR_X;
+        for (int c = 0; c < 3; c++) { f.o[c] = q[p].o[c]; f.o[3 + c] = const_cast<double *>(q[p].in[c]); f.in[c] = g[c]; }
+        for (int c = 0; c < 4; c++) f.t[c] = q[p].t[c];
+        f.t[4] = q[ks[0]].t[0]; f.t[5] = q[ks[1]].t[0];
+        f.s[0] = q[p].s[0]; f.s[1] = q[ks[0]].s[0];
+        for (int m = k0 + 1; m < p; m++)  // releases of the output blocks in between: the overwrite replaces them
+            if (q[m].kind == L_DISCARD && (q[m].o[0] == f.o[0] || q[m].o[0] == f.o[1] || q[m].o[0] == f.o[2])) q[m].kind = L_DEAD;
+        q[ks[0]].kind = L_DEAD; q[ks[1]].kind = L_DEAD; q[ks[2]].kind = L_DEAD; q[p].kind = L_DEAD;
+        q[k0] = f;
+    }
     // (5) y = 1 y + a x  ->  lincomb; chains (and a leading veccopy) merge into one
     for (int p = 0; p < n; p++) {
         if (q[p].kind != L_VECADD || q[p].s[1] != 1.0) continue;
@@ -494,7 +543,7 @@ static int exec(x3d_backend *b, const LOp &op)
 {
     x3d_lazy *L = b->lazy;
     const double *in[7] = {};
-    double *o[3] = {};
+    double *o[6] = {};
     if (op.kind == L_COPY) {
         // dst becomes an alias of src's buffer
         if (!registered(L, op.o[0]) || !registered(L, op.in[0])) {
@@ -513,10 +562,9 @@ static int exec(x3d_backend *b, const LOp &op)
     if (op.kind == L_DISCARD) { drop(L, op.o[0]); return 0; }
     for (int k = 0; k < nin(op); k++)
         if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
-    const bool upd = out_is_update(op);
     for (int k = 0; k < nout(op); k++) {
         double *before = registered(L, op.o[k]) ? L->phys[op.o[k]] : nullptr;
-        if (int rc = prepare_out(b, op.o[k], !upd, &o[k])) return rc;
+        if (int rc = prepare_out(b, op.o[k], !out_is_update(op, k), &o[k])) return rc;
         if (before && before != o[k]) L->stats[ST_OOP]++;
     }
     L->stats[ST_EXECUTED]++;
@@ -527,6 +575,7 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_LINCOMB: L->stats[ST_LINCOMB]++; break;
     case L_TDS_LIN: L->stats[ST_TDS_LIN]++; break;
     case L_SOLVE000: L->stats[ST_SOLVE000]++; break;
+    case L_TRANSEQ_UPD: L->stats[ST_TRANSEQ_UPD]++; break;
     default: break;
     }
     switch (op.kind) {
@@ -549,6 +598,19 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_FFT_POST000: return x3d_poisson_postprocess_000((x3d_poisson *)op.obj);
     case L_FFT_BWD: return x3d_poisson_fft_backward((x3d_poisson *)op.obj, o[0]);
     case L_SOLVE000: return x3d_poisson_solve_000((x3d_poisson *)op.obj, o[0]);
+    case L_TRANSEQ_UPD: {
+        int done = 0;
+        if (int rc = x3d_transeq_x_update(b, o[0], o[1], o[2], o[3], o[4], o[5], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3],
+                                          in[0], in[1], in[2], op.t[4], op.t[5], op.s[1], &done))
+            return rc;
+        if (done) return 0;
+        // these pencils are not served by the kernel: the calls it stands for, one after the other
+        L->stats[ST_TRANSEQ_UPD]--;
+        if (int rc = x3d_tds_solve_acc(b, o[3], in[0], op.t[4], X3D_DIR_X, 1, op.s[1])) return rc;
+        if (int rc = x3d_tds_solve_acc(b, o[4], in[1], op.t[5], X3D_DIR_X, 1, op.s[1])) return rc;
+        if (int rc = x3d_tds_solve_acc(b, o[5], in[2], op.t[5], X3D_DIR_X, 1, op.s[1])) return rc;
+        return x3d_transeq(b, X3D_DIR_X, o[0], o[1], o[2], o[3], o[4], o[5], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3]);
+    }
     default: x3d_set_error("x3d_lazy: unknown operation %d in the queue", op.kind); return 2;
     }
 }
@@ -558,7 +620,7 @@ static void dump(const x3d_lazy *L, const char *title)
 {
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
-                                  "solve000"};
+                                  "solve000", "transeq_upd"};
     std::unordered_map<const double *, int> id;
     auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
@@ -638,13 +700,13 @@ int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw
 {
     // transeq_x opens a sub-step (src/solver.f90:320): no rewrite reaches back across it, and everything the previous
     // sub-step released has been seen -- what has been recorded runs now, the device works on it while the host records on
-    if (dir == X3D_DIR_X)
-        if (int rc = x3d_lazy_flush_c(b)) return rc;
     LOp op;
     op.kind = L_TRANSEQ; op.dir = dir;
     op.o[0] = du; op.o[1] = dv; op.o[2] = dw; op.in[0] = u; op.in[1] = v; op.in[2] = w;
     op.s[0] = nu; op.t[0] = t0; op.t[1] = t1; op.t[2] = t2; op.t[3] = t3;
-    return push(b, op);
+    if (int rc = push(b, op)) return rc;
+    // (transeq_x itself belongs to the window it closes: the velocity correction left by the pressure step folds into it)
+    return dir == X3D_DIR_X ? x3d_lazy_flush_c(b) : 0;
 }
 int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
