@@ -362,7 +362,8 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("n") == args.n and tj.get("commit"):
-                traffic = tj.get("transeq_component_bytes_per_launch")
+                # HBM bytes of ONE launch of the dominant kernel (k_ytile_transeq3), PMC FETCH_SIZE + WRITE_SIZE
+                traffic = tj.get("dominant_kernel_bytes_per_launch") or tj.get("transeq_component_bytes_per_launch")
                 traffic_commit = tj.get("commit")
         except Exception:
             traffic = traffic_commit = None
@@ -435,7 +436,10 @@ def main():
                    "per_gpu": f"{args.n}^3" if args.case == "tgv" else args.dims, "nproc_dir": list(nproc_dir),
                    "driver": ("op-granular calls recorded and fused inside the library (deferred execution)" if args.lazy
                               else "op-granular" if args.op_granular else "fused"),
-                   "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}"},
+                   "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}",
+                   # N > 1: did the overlapped exchange path pass its first-use check against the ordered path
+                   # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
+                   "overlap_self_check": getattr(comm, "self_check_result", None)},
         "dof_substeps_per_s": value * nstage,
         "roofline": roofline,
         "kernel_ms": prof,

@@ -45,11 +45,36 @@ calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "status", "--porcelain", "x3d2_amd", "bench.py"], capture_output=True,
                             text=True).stdout.strip())
+dom = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k]
 json.dump({"n": 512, "round": rnd, "commit": commit + ("+uncommitted" if dirty else ""),
            "transeq_component_bytes_per_launch": comp,
+           "dominant_kernel": "k_ytile_transeq3<8,true,true,false>",
+           "dominant_kernel_bytes_per_launch": dom[0] if dom else None,
            "components_profiled": n_comp,
            "note": "HBM bytes per transport-equation component (all k_*transeq* + k_transpose64 + k_transpose_lincomb kernels / number of components; the latter also does the RK stage's linear combination) "
                    "from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "
                    "MI355X_MICROARCH.md (calibrated in round 1 on k_tds_fwd: one 1 GiB field read = 0.508 GiB raw)"},
           open("profiles/traffic.json", "w"), indent=1)
 print("component traffic GiB:", comp / GiB, "components:", n_comp)
+
+
+# per-variant rows of k_xscan_tds_lin (one kernel name, three operand counts: the RK3 stages read 2, 2 and 4 fields
+# besides what they write): the dispatches of the kernel trace, in launch order, fall into groups of three per stage
+try:
+    trace = max(glob.glob(f"gpurun_out/prof_{prof_tag}/*/*kernel_trace.csv"), key=os.path.getmtime)
+    durs = []
+    for row in csv.DictReader(open(trace)):
+        if "k_xscan_tds_lin" in row["Kernel_Name"]:
+            durs.append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    durs = [d for _, d in sorted(durs)]
+    with open(f"profiles/{rnd}_tds_lin_variants.csv", "w") as f:
+        f.write("position_in_step,what,launches,avg_us,min_us,max_us\n")
+        names = {0: "stage 1: u = u + c d (reads base, 1 term; writes y, du)", 1: "stage 2 (reads base, 1 term; writes y, du)",
+                 2: "stage 3: u = olds1 + 3 terms (reads 4; writes y, du)"}
+        for g in range(3):
+            v = [d for i, d in enumerate(durs) if (i // 3) % 3 == g]
+            if v:
+                f.write(f"{g},\"{names[g]}\",{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}\n")
+    print("k_xscan_tds_lin dispatches:", len(durs))
+except Exception as e:  # noqa: BLE001
+    print("no per-dispatch trace for the k_xscan_tds_lin variants:", e)
