@@ -1237,3 +1237,37 @@ def test_compact10_penta_convergence_and_oracle_at_size():
     col = lambda a: np.ascontiguousarray(a[None, :, None] * np.ones((1, 1, 16)))
     ref = t.solve(col(f), col(f[-4:]), col(f[:4]))[0, :, 0]
     assert relerr(got[1, :, 63], ref) < 1e-13
+
+
+def test_slab_solver_hooks_keep_their_meaning_where_the_z_stage_is_fused(monkeypatch):
+    """512 planes per rank: poisson_000 of the slab solver runs forward z transform, division and inverse as ONE kernel
+    (k_fft512_peers).  The three hooks of the reference's interface (src/poisson_fft.f90:45-62) must still mean what
+    they say when called on their own: forward ; postprocess ; backward == poisson_000, and forward ; backward gives the
+    field back times nx ny nz (unnormalised transforms, as 2decomp's / cuFFT's)"""
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.poisson_fft import HipSlabPoissonFFT
+    monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "slab")
+    dims = (16, 512, 512)
+    s = make_tgv(dims).solver
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert type(pf) is HipSlabPoissonFFT
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((dims[2], dims[1], dims[0]))
+    f -= f.mean()
+    p = al.get_block(DIR_C, CELL)
+    out = []
+    for how in ("solve", "hooks", "roundtrip"):
+        p.fill(0.0)
+        b.set_field_data(p, f, CELL)
+        if how == "solve":
+            pf.poisson_000(p, None)
+        else:
+            pf.fft_forward(p)
+            if how == "hooks":
+                pf.fft_postprocess_000()
+            pf.fft_backward(p)
+        out.append(b.get_field_data(p, CELL))
+    assert relerr(out[1], out[0]) < 1e-12
+    assert relerr(out[2], f * float(np.prod(dims))) < 1e-12
+    al.release_block(p)

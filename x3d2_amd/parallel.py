@@ -188,7 +188,8 @@ class Comm:
         sends, recvs = [], []
         for cnt_s, cnt_r, peer in zip(send_counts, recv_counts, peers):
             if peer == self.rank:
-                recvbuf[ro:ro + cnt_r].copy_(sendbuf[so:so + cnt_s])
+                if not (recvbuf.data_ptr() == sendbuf.data_ptr() and ro == so):  # (aliased buffers: nothing to move)
+                    recvbuf[ro:ro + cnt_r].copy_(sendbuf[so:so + cnt_s])
             else:
                 if cnt_s:
                     sends.append((sendbuf[so:so + cnt_s], peer))
@@ -209,7 +210,8 @@ class Comm:
         for i, peer in enumerate(peers):
             s0, r0 = send_off + i * ss, recv_off + i * rs
             if peer == self.rank:
-                recvbuf[r0:r0 + count].copy_(sendbuf[s0:s0 + count])
+                if not (recvbuf.data_ptr() == sendbuf.data_ptr() and r0 == s0):
+                    recvbuf[r0:r0 + count].copy_(sendbuf[s0:s0 + count])
             else:
                 sends.append((sendbuf[s0:s0 + count], peer))
                 recvs.append((recvbuf[r0:r0 + count], peer))
