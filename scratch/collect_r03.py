@@ -11,7 +11,9 @@ pairs = {f"bench_{R}.json": f"{R}_bench_512_fused.json", f"bench_{R}_lazy.json":
          f"bench_{R}_opg.json": f"{R}_bench_512_opgranular.json", f"bench_{R}_256.json": f"{R}_bench_256_nopoisson.json",
          f"bench_{R}_channel.json": f"{R}_bench_channel_1024x257x512.json",
          f"bench_{R}_emulz.json": f"{R}_bench_512_emulated_z_slabs.json",
-         f"bench_{R}_channel_emulz.json": f"{R}_bench_channel_emulated_z_slabs.json", f"bench_{R}_ops.jsonl": f"{R}_bench_ops.jsonl",
+         f"bench_{R}_channel_emulz.json": f"{R}_bench_channel_emulated_z_slabs.json",
+         f"bench_{R}_emulz_alias.json": f"{R}_bench_512_emulated_z_slabs_no_standin_copies.json",
+         f"bench_{R}_channel_emulz_alias.json": f"{R}_bench_channel_emulated_z_slabs_no_standin_copies.json", f"bench_{R}_ops.jsonl": f"{R}_bench_ops.jsonl",
          "pmc_chan_traffic.csv": f"{R}_pmc_traffic_channel.csv", f"{R}_tests.txt": f"{R}_gpu_tests.txt"}
 for src, dst in pairs.items():
     p = os.path.join("gpurun_out", src)

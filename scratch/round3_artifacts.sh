@@ -19,8 +19,10 @@ python bench.py --steps 10 --warmup 2 --n 256 --no-poisson --no-cpu-baseline > g
 python bench.py --steps 5 --warmup 2 --case channel --no-cpu-baseline > gpurun_out/bench_${rnd}_channel.json 2>/dev/null
 X3D_EMULATE_DECOMP=z X3D_FORCE_PENCIL_FFT=slab python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${rnd}_emulz.json 2>/dev/null
 X3D_EMULATE_DECOMP=z X3D_FORCE_PENCIL_FFT=slab python bench.py --steps 5 --warmup 2 --case channel --no-cpu-baseline > gpurun_out/bench_${rnd}_channel_emulz.json 2>/dev/null
+X3D_EMULATE_DECOMP=z X3D_FORCE_PENCIL_FFT=slab X3D_EMULATE_ALIAS=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${rnd}_emulz_alias.json 2>/dev/null
+X3D_EMULATE_DECOMP=z X3D_FORCE_PENCIL_FFT=slab X3D_EMULATE_ALIAS=1 python bench.py --steps 5 --warmup 2 --case channel --no-cpu-baseline > gpurun_out/bench_${rnd}_channel_emulz_alias.json 2>/dev/null
 python bench_ops.py > gpurun_out/bench_${rnd}_ops.jsonl 2>/dev/null
-for f in lazy opg 256 channel emulz channel_emulz; do python -c "
+for f in lazy opg 256 channel emulz channel_emulz emulz_alias channel_emulz_alias; do python -c "
 import json,sys; d=json.loads(open('gpurun_out/bench_${rnd}_$f.json').read().strip().split('\n')[-1]); print('$f', d['value'], d['ms_per_step'])"; done
 # the unchanged reference solver through the Fortran shim: deferred execution vs call by call
 bash scratch/shim_run.sh fortran/tgv512.x3d tgv512
