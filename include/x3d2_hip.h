@@ -425,7 +425,13 @@ int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
 typedef struct x3d_sfft010 x3d_sfft010;
 int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob_cell[3], int pz, int rz);
 int x3d_sfft010_destroy(x3d_sfft010 *p);
-int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[5]);
+int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6]); /* chunk, zl, xs, i0, nx/2 + 1, parts */
+/* overlap: the rank's columns travel and are solved in `parts` groups (<= 0: chosen by the library), S =
+ * [peer][part][zl][ny][xsc], R = [part][peer][zl][ny][xsc]; a group holds all rows and all z of its columns, so the
+ * *_part calls run on it while the next groups are in flight (x3d2_amd/poisson_fft.py, HipSlabPoissonFFT010) */
+int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob_cell[3], int pz, int rz, int parts);
+int x3d_sfft010_fft_z_part(x3d_sfft010 *p, double *recvbuf, int dir, int part);
+int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, double *recvbuf, int part);
 int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const double *ax, const double *bx, const double *ay,
                           const double *by, const double *az, const double *bz);
 int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double *a0, const double *a1);

@@ -21,12 +21,16 @@ pytestmark = pytest.mark.gpu
     ((32, 17, 24), "uniform", 1.0, False), ((34, 17, 24), "top-bottom", 0.259065151, False),
     ((48, 33, 16), "centred", 0.4, False), ((32, 16, 20), "bottom", 0.3, False),
     ((1024, 33, 16), "top-bottom", 0.259065151, False),
-    ((34, 17, 24), "top-bottom", 0.259065151, True)])  # 1-D x and y plans (where rocFFT refuses the 2-D real plan)
+    ((34, 17, 24), "top-bottom", 0.259065151, True),   # 1-D x and y plans (where rocFFT refuses the 2-D real plan)
+    ((48, 33, 16), "top-bottom", 0.259065151, 3),      # the columns in 3 groups (25 modes -> 27 columns: padding)
+    ((1024, 33, 16), "top-bottom", 0.259065151, 4)])
 def test_slab_010_solver_in_one_process_equals_the_single_rank_solver(dims, stretching, beta, split, monkeypatch):
     """csrc/sfft010.hip with pz = 1 (pack / all-to-all-with-itself / strided z transform / the spectral kernels on the
     packed layout) against HipPoissonFFT (3-D rocFFT plan) and the oracle, on a seeded right-hand side"""
-    if split:
+    if split is True:
         monkeypatch.setenv("X3D_SFFT010_SPLIT_XY", "1")
+    elif split:
+        monkeypatch.setenv("X3D_SLAB_PARTS", str(split))
     from x3d2_amd.poisson_fft import HipPoissonFFT, HipSlabPoissonFFT010
     rng = np.random.default_rng(11)
     s1 = product_solver(dims, stretching, beta)
@@ -40,6 +44,22 @@ def test_slab_010_solver_in_one_process_equals_the_single_rank_solver(dims, stre
     assert type(s2.backend.poisson_fft) is HipSlabPoissonFFT010
     got = hip_poisson_solve(s2, f)
     assert relerr(got, ref) < 1e-12
+    if split and split is not True:
+        pf = s2.backend.poisson_fft
+        assert pf.parts == split
+        # the hooks one after the other (src/poisson_fft.f90:228-242) == the pipelined solve
+        from x3d2_amd.common import CELL, DIR_C
+        b, al = s2.backend, s2.backend.allocator
+        p_, t_ = al.get_block(DIR_C, CELL), al.get_block(DIR_C)
+        p_.fill(0.0)
+        b.set_field_data(p_, f, CELL)
+        pf.enforce_periodicity_y(t_, p_)
+        pf.fft_forward(t_)
+        pf.fft_postprocess_010()
+        pf.fft_backward(t_)
+        pf.undo_periodicity_y(p_, t_)
+        assert np.array_equal(b.get_field_data(p_, CELL), got)
+        al.release_block(p_); al.release_block(t_)
     o = oracle_solver(dims, stretching, beta)
     assert relerr(got, o.poisson_fft.solve(f)) < 1e-10
 

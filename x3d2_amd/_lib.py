@@ -133,6 +133,9 @@ PROTOTYPES = {
     "x3d_sfft_postprocess_000": (I, [VP, VP]),
     "x3d_sfft_backward_local": (I, [VP, VP, VP]),
     "x3d_sfft010_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),
+    "x3d_sfft010_create_parts": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I]),
+    "x3d_sfft010_fft_z_part": (I, [VP, VP, I, I]),
+    "x3d_sfft010_postprocess_010_part": (I, [VP, VP, I]),
     "x3d_sfft010_destroy": (I, [VP]),
     "x3d_sfft010_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
     "x3d_sfft010_set_waves": (I, [VP] + [c_double_p] * 7),

@@ -16,8 +16,14 @@
 //   --fft_postprocess_010 on T: the single-rank kernels (spectral010.h) in their z-fastest form, mode offset
 //     i0 = rz xs: uniform y one kernel, stretched y fw ; pentadiagonal solves (factored once at set-up) ; bw
 //   --inverse z transform, transpose back, all-to-all back, unpack, inverse 2-D transform-->  f
-// xs = ceil((nx/2 + 1) / pz): every rank owns the same number of mode columns, the columns beyond nx/2 + 1 on the last
-// rank are padding (zeros in, wave numbers one, matrices zero: the kernels' guarded divisions leave zeros).
+// xs = parts * xsc >= ceil((nx/2 + 1) / pz): every rank owns the same number of mode columns, the columns beyond
+// nx/2 + 1 on the last rank are padding (zeros in, wave numbers one, matrices zero: the kernels' guarded divisions
+// leave zeros).
+// Overlap: a rank's columns travel in `parts` groups of xsc columns, S = [peer][part][zl][ny][xsc] and
+// R = [part][peer][zl][ny][xsc] = [part][nz][ny][xsc]: every group holds ALL rows and ALL z of its columns, so its z
+// transforms, the paired split and the pentadiagonal solves run as soon as it has arrived, beside the transfer of the
+// next groups (the *_part entry points; x3d2_amd/poisson_fft.py, HipSlabPoissonFFT010.poisson_010).  T, waves and the
+// factors are stored per group: T[part][ny][xsc][nz], lu[part][5][n][xsc][nz].
 #include <hipfft/hipfft.h>
 
 #include "spectral010.h"
@@ -38,33 +44,49 @@ struct x3d_sfft010 {
     int nxm;             // nx/2 + 1 modes along x
     int pz, rz, zl;      // ranks along z, this rank, local planes
     int xs, nxs;         // mode columns per rank; nxs = pz * xs = row pitch of the local 2-D spectrum
+    int parts, xsc;      // the columns travel and are solved in `parts` groups of xsc (xs = parts * xsc)
     hipfftHandle plan_xy_fw, plan_xy_bw, plan_z;
     int split_xy;        // rocFFT refused the 2-D real plan for these lengths: 1-D x plan (batched over all local rows)
                          // + 1-D strided y plan run once per local plane
     hipfftHandle plan_x_fw, plan_x_bw, plan_y;
     double2 *c0;         // [zl][ny][nxs]
-    double2 *t;          // [ny][xs][nz]: z-contiguous copy of the received array; the spectral stage works here
-    double *waves;       // [ny][xs][nz] (pads: one)
+    double2 *t;          // [part][ny][xsc][nz]: z-contiguous copy of the received array; the spectral stage works here
+    double *waves;       // [part][ny][xsc][nz] (pads: one)
     double *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
     int nab_x;           // length of the ax / bx tables on the device
     int stretched, sym;
-    double *lu[2];       // factored pentadiagonal operators [5][n][xs][nz]
+    double *lu[2];       // factored pentadiagonal operators [part][5][n][xsc][nz]
     void *work;
 };
 
-// C0[zl][ny][nxs] -> S[peer][zl][ny][xs] (UNPACK: the other way); one thread per complex number of C0
+// C0[zl][ny][nxs] -> S[peer][part][zl][ny][xsc] (UNPACK: the other way); one thread per complex number of C0
 template <bool UNPACK>
 __global__ void __launch_bounds__(256)
-    k_sfft010_pack(double2 *__restrict__ s, double2 *__restrict__ c0, long rows, int xs, int pz)
+    k_sfft010_pack(double2 *__restrict__ s, double2 *__restrict__ c0, long rows, int xsc, int parts, int pz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nxs = xs * pz;
+    const int xs = xsc * parts, nxs = xs * pz;
     const long row = t / nxs;
     if (row >= rows) return;
-    const int col = (int)(t % nxs), peer = col / xs, i = col % xs;
-    const long si = ((long)peer * rows + row) * xs + i;
+    const int col = (int)(t % nxs), peer = col / xs, part = (col % xs) / xsc, i = col % xsc;
+    const long si = (((long)peer * parts + part) * rows + row) * xsc + i;
     if (UNPACK) c0[t] = s[si];
     else s[si] = c0[t];
+}
+
+// set-up: src [nz][rows][xs] (x fastest, as the host builds it) -> dst [part][rows][xsc][nz] with a stride between parts
+__global__ void __launch_bounds__(256)
+    k_sfft010_gather(double *__restrict__ dst, const double *__restrict__ src, int nz, int rows, int xsc, int parts,
+                     long part_stride)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int xs = xsc * parts;
+    const long n = (long)nz * rows * xs;
+    if (t >= n) return;
+    const int k = (int)(t % nz);
+    const long c = t / nz;                 // (part, row, i) flattened, k fastest on the destination side
+    const int i = (int)(c % xsc), j = (int)((c / xsc) % rows), m = (int)(c / ((long)xsc * rows));
+    dst[m * part_stride + ((long)j * xsc + i) * nz + k] = src[((long)k * rows + j) * xs + m * xsc + i];
 }
 
 // 32 x 32 tiles through LDS: src [nB][nA] (A contiguous) -> dst [nA][nB] (B contiguous)
@@ -95,7 +117,14 @@ static int transpose_launch(hipStream_t st, E *dst, const E *src, long nA, long 
     return 0;
 }
 
+extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz, int parts);
 extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz)
+{
+    return x3d_sfft010_create_parts(b, out, nglob, pz, rz, 1);
+}
+
+// parts <= 0: chosen here -- the count among 4, 5, 3 that pads the rank's columns least (8 ranks, 513 modes: 65 = 5 x 13)
+extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz, int parts)
 {
     X3D_REQUIRE(b && out && nglob, "x3d_sfft010_create: null argument");
     X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft010_create: bad rank grid");
@@ -106,7 +135,23 @@ extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int n
     p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2];
     p->nxm = p->nx / 2 + 1;
     p->pz = pz; p->rz = rz; p->zl = p->nz / pz;
-    p->xs = (p->nxm + pz - 1) / pz;
+    {
+        const int base = (p->nxm + pz - 1) / pz;
+        if (parts <= 0) {
+            const int cand[3] = {4, 5, 3};
+            int best = 1, pad = 1 << 30;
+            for (int c : cand) {
+                if (c > base) continue;
+                const int w = (base + c - 1) / c * c - base;
+                if (w < pad) { pad = w; best = c; }
+            }
+            parts = best;
+        }
+        X3D_REQUIRE(parts >= 1 && parts <= base, "x3d_sfft010_create: %d column groups for %d columns", parts, base);
+        p->parts = parts;
+        p->xsc = (base + parts - 1) / parts;
+        p->xs = p->xsc * parts;
+    }
     p->nxs = p->xs * pz;
     X3D_REQUIRE(p->nx <= b->nxp && p->ny <= b->nyp && p->zl <= b->nzp, "x3d_sfft010_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs, nw = (size_t)p->nz * p->ny * p->xs;
@@ -144,7 +189,7 @@ extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int n
     }
     // z transform on the z-contiguous copy T[ny * xs][nz]
     int nzv[1] = {p->nz}, ze[1] = {p->nz};
-    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, 1, p->nz, ze, 1, p->nz, HIPFFT_Z2Z, p->ny * p->xs, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, 1, p->nz, ze, 1, p->nz, HIPFFT_Z2Z, p->ny * p->xsc, &ws[2]));
     size_t wmax = 0;
     for (int i = 0; i < 6; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
@@ -166,11 +211,12 @@ extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
     return 0;
 }
 
-// out = {chunk (complex numbers per peer), zl, xs, i0 (first x mode of this rank), nxm}
-extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[5])
+// out = {chunk (complex numbers per peer), zl, xs, i0 (first x mode of this rank), nxm, parts}
+extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6])
 {
     X3D_REQUIRE(p && out, "null argument");
     out[0] = (long)p->zl * p->ny * p->xs; out[1] = p->zl; out[2] = p->xs; out[3] = (long)p->rz * p->xs; out[4] = p->nxm;
+    out[5] = p->parts;
     return 0;
 }
 
@@ -179,10 +225,12 @@ extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const 
                                      const double *ay, const double *by, const double *az, const double *bz)
 {
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
-    {   // [nz][ny][xs] on the host -> [ny][xs][nz] on the device (T serves as the landing zone)
+    {   // [nz][ny][xs] on the host -> [part][ny][xsc][nz] on the device (T serves as the landing zone)
         const size_t nw = (size_t)p->nz * p->ny * p->xs;
         X3D_HIP(hipMemcpy(p->t, waves, sizeof(double) * nw, hipMemcpyHostToDevice));
-        if (int rc = transpose_launch<double>(p->b->stream, p->waves, (const double *)p->t, (long)p->ny * p->xs, p->nz)) return rc;
+        hipLaunchKernelGGL(k_sfft010_gather, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, p->b->stream, p->waves,
+                           (const double *)p->t, p->nz, p->ny, p->xsc, p->parts, (long)p->ny * p->xsc * p->nz);
+        X3D_HIP(hipGetLastError());
         X3D_HIP(hipStreamSynchronize(p->b->stream));
     }
     const double *src[6] = {ax, bx, ay, by, az, bz};
@@ -205,16 +253,21 @@ extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double 
     X3D_REQUIRE(n >= 3, "x3d_sfft010_set_stretching: too few rows");
     const size_t nd = (size_t)p->nz * n * p->xs, bytes = sizeof(double) * 5 * nd;
     const double *src[2] = {a0, a1};
-    double *tmp = nullptr;  // one diagonal [nz][n][xs] as uploaded, before it goes to [n][xs][nz]
+    double *tmp = nullptr;  // one diagonal [nz][n][xs] as uploaded, before it goes to its place in [part][5][n][xsc][nz]
     X3D_HIP(hipMalloc(&tmp, sizeof(double) * nd));
+    const long ndp = (long)n * p->xsc * p->nz;  // one diagonal of one group
     for (int s = 0; s < (sym ? 2 : 1); s++) {
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
         for (int d = 0; d < 5; d++) {
             X3D_HIP(hipMemcpy(tmp, src[s] + d * nd, sizeof(double) * nd, hipMemcpyHostToDevice));
-            if (int rc = transpose_launch<double>(p->b->stream, p->lu[s] + d * nd, (const double *)tmp, (long)n * p->xs, p->nz)) return rc;
+            hipLaunchKernelGGL(k_sfft010_gather, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, p->b->stream,
+                               p->lu[s] + d * ndp, (const double *)tmp, p->nz, n, p->xsc, p->parts, 5 * ndp);
+            X3D_HIP(hipGetLastError());
             X3D_HIP(hipStreamSynchronize(p->b->stream));
         }
-        hipLaunchKernelGGL(k_penta_factor<true>, penta_grid(p->xs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->xs, n, p->nz);
+        for (int m = 0; m < p->parts; m++)
+            hipLaunchKernelGGL(k_penta_factor<true>, penta_grid(p->xsc, p->nz), dim3(64), 0, p->b->stream,
+                               p->lu[s] + (long)m * 5 * ndp, p->xsc, n, p->nz);
         X3D_HIP(hipGetLastError());
     }
     X3D_HIP(hipStreamSynchronize(p->b->stream));
@@ -241,7 +294,7 @@ extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const do
     return 0;
 }
 
-// 2-D transform of the local planes; the result lands in sendbuf as [peer][zl][ny][xs]
+// 2-D transform of the local planes; the result lands in sendbuf as [peer][part][zl][ny][xsc]
 extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
@@ -262,46 +315,66 @@ extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, dou
     ProfScope ps(p->b, X3D_K_PACK);
     const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
     hipLaunchKernelGGL(k_sfft010_pack<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
-                       (double2 *)sendbuf, p->c0, rows, p->xs, p->pz);
+                       (double2 *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-// dir 0: the received array W[nz][ny][xs] -> T[ny][xs][nz], forward z transform (the spectrum stays in T);
-// dir 1: backward z transform of T, then back to W
-extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
+// dir 0: group `part` of the received array, W_m[nz][ny][xsc] -> T_m[ny][xsc][nz], forward z transform (the spectrum
+// stays in T); dir 1: backward z transform of T_m, then back to W_m
+extern "C" int x3d_sfft010_fft_z_part(x3d_sfft010 *p, double *recvbuf, int dir, int part)
 {
-    X3D_REQUIRE(p && recvbuf, "null argument");
-    const long cols = (long)p->ny * p->xs;
+    X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_fft_z_part: bad argument");
+    const long cols = (long)p->ny * p->xsc;
+    double2 *W = (double2 *)recvbuf + (size_t)part * p->nz * cols, *T = p->t + (size_t)part * p->nz * cols;
     if (dir == 0) {
         ProfScope ps(p->b, X3D_K_PACK);
-        if (int rc = transpose_launch<double2>(p->b->stream, p->t, (const double2 *)recvbuf, cols, p->nz)) return rc;
+        if (int rc = transpose_launch<double2>(p->b->stream, T, (const double2 *)W, cols, p->nz)) return rc;
     }
     {
         ProfScope ps(p->b, X3D_K_FFT, 3);
         X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->t, (hipfftDoubleComplex *)p->t,
-                              dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)T, (hipfftDoubleComplex *)T, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     }
     if (dir == 1) {
         ProfScope ps(p->b, X3D_K_PACK);
-        if (int rc = transpose_launch<double2>(p->b->stream, (double2 *)recvbuf, (const double2 *)p->t, p->nz, cols)) return rc;
+        if (int rc = transpose_launch<double2>(p->b->stream, W, (const double2 *)T, p->nz, cols)) return rc;
     }
     return 0;
 }
 
-// fft_postprocess_010 on this rank's x modes (all rows, all z modes), in the z-contiguous copy
-extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
+extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
+    for (int m = 0; m < p->parts; m++)
+        if (int rc = x3d_sfft010_fft_z_part(p, recvbuf, dir, m)) return rc;
+    return 0;
+}
+
+// fft_postprocess_010 on one group of this rank's x modes (all rows, all z modes), in the z-contiguous copy
+extern "C" int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, double *recvbuf, int part)
+{
+    X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_postprocess_010_part: bad argument");
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     const double *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
-    return spectral_010_launch_t<true>(p->b->stream, p->t, p->waves, p->xs, p->nx, p->ny, p->nz, p->rz * p->xs, ax, bx, ay, by,
-                                       az, bz, p->stretched, p->sym, p->lu);
+    const size_t off = (size_t)part * p->nz * p->ny * p->xsc;
+    const int n = p->sym ? p->ny / 2 : p->ny;
+    double *lu[2] = {p->lu[0] ? p->lu[0] + (size_t)part * 5 * n * p->xsc * p->nz : nullptr,
+                     p->lu[1] ? p->lu[1] + (size_t)part * 5 * n * p->xsc * p->nz : nullptr};
+    return spectral_010_launch_t<true>(p->b->stream, p->t + off, p->waves + off, p->xsc, p->nx, p->ny, p->nz,
+                                       p->rz * p->xs + part * p->xsc, ax, bx, ay, by, az, bz, p->stretched, p->sym, lu);
 }
 
-// unpack the returned array S[peer][zl][ny][xs] and transform back to the real planes
+extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
+{
+    X3D_REQUIRE(p && recvbuf, "null argument");
+    for (int m = 0; m < p->parts; m++)
+        if (int rc = x3d_sfft010_postprocess_010_part(p, recvbuf, m)) return rc;
+    return 0;
+}
+
+// unpack the returned array S[peer][part][zl][ny][xsc] and transform back to the real planes
 extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out)
 {
     X3D_REQUIRE(p && sendbuf && f_out, "null argument");
@@ -309,7 +382,7 @@ extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf,
         ProfScope ps(p->b, X3D_K_PACK);
         const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
         hipLaunchKernelGGL(k_sfft010_pack<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
-                           (double2 *)sendbuf, p->c0, rows, p->xs, p->pz);
+                           (double2 *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
         X3D_HIP(hipGetLastError());
     }
     ProfScope ps(p->b, X3D_K_FFT, 2);

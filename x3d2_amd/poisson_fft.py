@@ -697,12 +697,16 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
         if self.nx_glob // 2 < self.pz:
             raise X3dError("Poisson 010 on z slabs: fewer x modes than ranks")
         h = VP()
-        _lib.check(backend.lib.x3d_sfft010_create(
-            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz))
+        # the rank's columns travel in groups (overlap of the transfers with the z stage and the pentadiagonal solves);
+        # X3D_SLAB_PARTS: how many (0 = the library's choice; default: that on several ranks, 1 in a single process)
+        parts = int(__import__("os").environ.get("X3D_SLAB_PARTS", "0" if self.pz > 1 else "1"))
+        _lib.check(backend.lib.x3d_sfft010_create_parts(
+            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.pz, self.rz, parts))
         self.h = h
-        sz = (ctypes.c_long * 5)()
+        sz = (ctypes.c_long * 6)()
         _lib.check(backend.lib.x3d_sfft010_sizes(h, sz))
-        self.chunk, self.zl, self.xs, self.i0, nxm = [int(v) for v in sz]
+        self.chunk, self.zl, self.xs, self.i0, nxm, self.parts = [int(v) for v in sz]
+        self.sub = 2 * self.chunk // self.parts  # doubles per (peer, group) message
         i1 = min(self.i0 + self.xs, nxm)          # (the last rank's columns beyond nx/2 + 1 are padding)
         xsl = slice(self.i0, max(i1, self.i0))
         npad = self.xs - (xsl.stop - xsl.start)
@@ -736,9 +740,6 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
         except Exception:
             pass
 
-    def _xchg(self, src, dst):
-        cnt = [2 * self.chunk] * self.pz
-        self.backend.comm.alltoall(src, cnt, dst, cnt, self.peers)
 
     def enforce_periodicity_y(self, f_out, f_in):
         _lib.check(self.backend.lib.x3d_sfft010_periodicity_y(self.h, f_out.ptr, f_in.ptr, 0))
@@ -749,7 +750,8 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
     def fft_forward(self, f_in):
         lib = self.backend.lib
         _lib.check(lib.x3d_sfft010_forward_local(self.h, f_in.ptr, self.sbuf.data_ptr()))
-        self._xchg(self.sbuf, self.rbuf)
+        for hnd in [self._send_part(m) for m in range(self.parts)]:
+            hnd.wait()
         _lib.check(lib.x3d_sfft010_fft_z(self.h, self.rbuf.data_ptr(), 0))
 
     def fft_postprocess_010(self):
@@ -758,8 +760,41 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
     def fft_backward(self, f_out):
         lib = self.backend.lib
         _lib.check(lib.x3d_sfft010_fft_z(self.h, self.rbuf.data_ptr(), 1))
-        self._xchg(self.rbuf, self.sbuf)
+        for hnd in [self._return_part(m) for m in range(self.parts)]:
+            hnd.wait()
         _lib.check(lib.x3d_sfft010_backward_local(self.h, self.sbuf.data_ptr(), f_out.ptr))
+
+    # S = [peer][part][...], R = [part][peer][...] (csrc/sfft010.hip)
+    def _send_part(self, m):
+        return self.backend.comm.ialltoall(self.sbuf, self.rbuf, self.sub, self.peers, send_off=m * self.sub,
+                                           send_stride=self.parts * self.sub, recv_off=m * self.pz * self.sub,
+                                           recv_stride=self.sub)
+
+    def _return_part(self, m):
+        return self.backend.comm.ialltoall(self.rbuf, self.sbuf, self.sub, self.peers, send_off=m * self.pz * self.sub,
+                                           send_stride=self.sub, recv_off=m * self.sub,
+                                           recv_stride=self.parts * self.sub)
+
+    def poisson_010(self, f, temp):
+        """poisson_010 (src/poisson_fft.f90:228-242) with the column groups pipelined: the z transforms, the paired
+        split and the pentadiagonal solves of group m run beside the transfer of the groups behind it"""
+        if temp is None:
+            raise X3dError("poisson_010 needs a scratch block")
+        lib, h, rb = self.backend.lib, self.h, self.rbuf.data_ptr()
+        self.enforce_periodicity_y(temp, f)
+        _lib.check(lib.x3d_sfft010_forward_local(h, temp.ptr, self.sbuf.data_ptr()))
+        there = [self._send_part(m) for m in range(self.parts)]
+        back = []
+        for m in range(self.parts):
+            there[m].wait()
+            _lib.check(lib.x3d_sfft010_fft_z_part(h, rb, 0, m))
+            _lib.check(lib.x3d_sfft010_postprocess_010_part(h, rb, m))
+            _lib.check(lib.x3d_sfft010_fft_z_part(h, rb, 1, m))
+            back.append(self._return_part(m))
+        for hnd in back:
+            hnd.wait()
+        _lib.check(lib.x3d_sfft010_backward_local(h, self.sbuf.data_ptr(), temp.ptr))
+        self.undo_periodicity_y(f, temp)
 
     def interleaved_rows(self):
         return 0
