@@ -45,15 +45,26 @@ def cpu_baseline(n, steps, threads):
     OMP_PROC_BIND: libgomp reads them once, when it is loaded -- and in this process torch has loaded it long before
     (setting os.environ afterwards does not reach the oracle's OpenMP loops)."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+
+    def child(nn, st, th):
+        env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-n", str(nn),
+                            "--cpu-steps", str(st)], env=env, capture_output=True, text=True, timeout=1500)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-n", str(n),
-                            "--cpu-steps", str(steps)], env=env, capture_output=True, text=True, timeout=1500)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
+        probed = None
+        if isinstance(threads, (list, tuple)):
+            # which thread count suits this host: one 256^3 step each (a few seconds), the fastest runs the sample
+            probed = {th: child(256, 1, th)["value"] for th in threads}
+            threads = max(probed, key=probed.get)
+        out = child(n, steps, threads)
+        if probed:
+            out["thread_counts_probed_at_256"] = {str(k): v for k, v in probed.items()}
+        return out
     except Exception as e:  # noqa: BLE001 -- the GPU line must still be printed
-        return {"value": None, "unit": "DoF*steps/s", "cores": threads, "kind": "port",
-                "sample": "failed: %s" % (str(e)[:200],)}
+        return {"value": None, "unit": "DoF*steps/s", "cores": threads if isinstance(threads, int) else None,
+                "kind": "port", "sample": "failed: %s" % (str(e)[:200],)}
 
 
 def cpu_baseline_child(n, steps):
@@ -197,7 +208,8 @@ def main():
     ap.add_argument("--no-poisson", action="store_true", help="BASELINE configs[1]: derivatives + RK only")
     ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline grid (0: 512 if the host has the memory, else 256)")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the port baseline (its best measured count)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the port baseline (0: 32, 64 and all physical cores are probed at 256^3, the fastest is used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
@@ -450,10 +462,11 @@ def main():
         # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
         # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)
         phys = int(os.environ["OMP_NUM_THREADS"])
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, min(phys, args.cpu_threads))
+        th = min(phys, args.cpu_threads) if args.cpu_threads > 0 else sorted({min(32, phys), min(64, phys), phys})
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, th)
         # the real reference at all physical cores and at the port's thread count; the faster one is reported,
         # the other kept beside it
-        refs = [r for r in (cpu_reference(256, 4, t) for t in sorted({phys, min(phys, args.cpu_threads)}, reverse=True))
+        refs = [r for r in (cpu_reference(256, 4, t) for t in sorted({phys, min(phys, args.cpu_threads or 32)}, reverse=True))
                 if r is not None]
         if refs:
             best = max(refs, key=lambda r: r["value"])

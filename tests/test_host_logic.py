@@ -339,3 +339,38 @@ def test_product_compact10_penta_factory_vs_reference(tag, bc, sym):
     for k in ("dist_fw", "dist_af", "dist_sa", "dist_bw", "coeffs", "coeffs_s", "coeffs_e"):
         assert np.array_equal(getattr(t, k), g[f"penta.{tag}.{k}"]), k
     assert not np.any(t.dist_sc)
+
+
+@pytest.mark.parametrize("name", ["c010_rk3", "c010c_rk3", "c010b_rk3"])
+def test_stretching_matrix_column_ranges_equal_the_full_matrices(name):
+    """poisson_fft.stretching_matrix(xsl=...): a rank of the slab 010 solver (HipSlabPoissonFFT010) builds the
+    pentadiagonal operators of its own x modes only -- every column range must carry exactly the columns of the full
+    arrays (src/poisson_fft.f90:275-652), including the mean mode's special rows on the range that holds column 0"""
+    import types
+    from x3d2_amd.common import CELL
+    from x3d2_amd.poisson_fft import HipPoissonFFT, stretching_matrix
+    g = load_golden(name)
+    c = namelist(g)
+    m = product_mesh(c)
+    xd, yd, zd = product_dirps(m, c)
+
+    def host_side():
+        pf = types.SimpleNamespace()
+        pf.nx_glob, pf.ny_glob, pf.nz_glob = (int(v) for v in m.get_global_dims(CELL))
+        pf.periodic_x, pf.periodic_y, pf.periodic_z = m.periodic_BC
+        pf.nx_spec, pf.ny_spec, pf.nz_spec = pf.nx_glob // 2 + 1, pf.ny_glob, pf.nz_glob
+        HipPoissonFFT._waves_set(pf, m, xd, yd, zd)
+        return pf
+
+    full = host_side()
+    stretching_matrix(full, m, xd, yd, zd, *full._es)
+    names = ("a_odd", "a_even") if full.stretched_y_sym else ("a_full",)
+    nxs = full.nx_spec
+    for nparts in (2, 3):
+        xs = -(-nxs // nparts)
+        for r in range(nparts):
+            sl = slice(r * xs, min((r + 1) * xs, nxs))
+            part = host_side()
+            stretching_matrix(part, m, xd, yd, zd, *part._es, xsl=sl)
+            for nm in names:
+                assert np.array_equal(getattr(part, nm), getattr(full, nm)[..., sl]), (nm, nparts, r)

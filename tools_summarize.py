@@ -42,9 +42,11 @@ tot_bytes = sum(n * (fe + wr) for k, n, fe, wr in rows if "transeq" in k or "k_t
 n_comp = sum(n * (3 if ("transeq2x3" in k or "transeq3" in k) else 1) for k, n, fe, wr in rows if any(h in k for h in heads))
 comp = tot_bytes / n_comp if n_comp else 0.0
 calib = [(fe, n) for k, n, fe, wr in rows if "k_lincomb" in k]
-commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
-dirty = bool(subprocess.run(["git", "status", "--porcelain", "x3d2_amd", "bench.py"], capture_output=True,
-                            text=True).stdout.strip())
+# X3D_ARTIFACT_COMMIT: the tree the gpurun session measured, when HEAD has moved on since
+commit = os.environ.get("X3D_ARTIFACT_COMMIT") or \
+    subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = not os.environ.get("X3D_ARTIFACT_COMMIT") and bool(
+    subprocess.run(["git", "status", "--porcelain", "x3d2_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
 dom = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k]
 json.dump({"n": 512, "round": rnd, "commit": commit + ("+uncommitted" if dirty else ""),
            "transeq_component_bytes_per_launch": comp,

@@ -606,6 +606,7 @@ static int exec(x3d_backend *b, const LOp &op)
         if (done) return 0;
         // these pencils are not served by the kernel: the calls it stands for, one after the other
         L->stats[ST_TRANSEQ_UPD]--;
+        L->stats[ST_TDS_ACC] += 3;
         if (int rc = x3d_tds_solve_acc(b, o[3], in[0], op.t[4], X3D_DIR_X, 1, op.s[1])) return rc;
         if (int rc = x3d_tds_solve_acc(b, o[4], in[1], op.t[5], X3D_DIR_X, 1, op.s[1])) return rc;
         if (int rc = x3d_tds_solve_acc(b, o[5], in[2], op.t[5], X3D_DIR_X, 1, op.s[1])) return rc;
