@@ -47,7 +47,9 @@ def cpu_baseline(n, steps, threads):
     import subprocess
 
     def child(nn, st, th):
-        env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        th, fw = th if isinstance(th, tuple) else (th, th)  # (OpenMP threads of the C loops, pocketfft workers)
+        env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                   X3D_ORACLE_FFT_WORKERS=str(fw))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-n", str(nn),
                             "--cpu-steps", str(st)], env=env, capture_output=True, text=True, timeout=1500)
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -59,8 +61,11 @@ def cpu_baseline(n, steps, threads):
             probed = {th: child(256, 1, th)["value"] for th in threads}
             threads = max(probed, key=probed.get)
         out = child(n, steps, threads)
+        if isinstance(threads, tuple):
+            out["fft_workers"] = threads[1]
         if probed:
-            out["thread_counts_probed_at_256"] = {str(k): v for k, v in probed.items()}
+            out["thread_counts_probed_at_256"] = {("%d omp, %d fft" % k if isinstance(k, tuple) else str(k)): v
+                                                  for k, v in probed.items()}
         return out
     except Exception as e:  # noqa: BLE001 -- the GPU line must still be printed
         return {"value": None, "unit": "DoF*steps/s", "cores": threads if isinstance(threads, int) else None,
@@ -76,6 +81,7 @@ def cpu_baseline_child(n, steps):
     lib = orc.lib()
     lib.orc_max_threads.restype = __import__("ctypes").c_int
     threads = int(lib.orc_max_threads())
+    fw = os.environ.get("X3D_ORACLE_FFT_WORKERS")
     if n <= 0:
         try:
             import psutil
@@ -93,7 +99,7 @@ def cpu_baseline_child(n, steps):
     dt = time.perf_counter() - t0
     return {"value": n ** 3 * steps / dt, "unit": "DoF*steps/s", "cores": threads, "kind": "port",
             "sample": f"TGV {n}^3 RK3 full fractional step (FFT Poisson), {steps} steps after 1 warm-up, "
-                      f"oracle/x3d_oracle (C + OpenMP kernels, pocketfft on all cores) on {threads} threads",
+                      f"oracle/x3d_oracle (C + OpenMP kernels on {threads} threads, pocketfft on {fw or threads} workers)",
             "seconds": dt, "n": n}
 
 
@@ -462,7 +468,9 @@ def main():
         # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
         # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)
         phys = int(os.environ["OMP_NUM_THREADS"])
-        th = min(phys, args.cpu_threads) if args.cpu_threads > 0 else sorted({min(32, phys), min(64, phys), phys})
+        # (threads of the C / OpenMP loops, pocketfft workers): they do not peak at the same count on a two-socket host
+        th = min(phys, args.cpu_threads) if args.cpu_threads > 0 else \
+            sorted({(min(32, phys), min(32, phys)), (phys, min(32, phys)), (min(64, phys), min(32, phys)), (phys, phys)})
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, th)
         # the real reference at all physical cores and at the port's thread count; the faster one is reported,
         # the other kept beside it
