@@ -265,6 +265,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif os.environ.get("X3D_COMM_SELF_VIA_NCCL") == "1":
+        # one GPU, world size 1: with X3D_EMULATE_DECOMP the N > 1 code path then exchanges with itself THROUGH RCCL
+        # (x3d2_amd/parallel.py) -- the RCCL calls, the communication stream and the wait semantics run for real
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
 
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
@@ -482,7 +491,7 @@ def main():
             out["cpu_baseline"]["reference_nopoisson"] = best
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1271,3 +1271,20 @@ def test_slab_solver_hooks_keep_their_meaning_where_the_z_stage_is_fused(monkeyp
     assert relerr(out[1], out[0]) < 1e-12
     assert relerr(out[2], f * float(np.prod(dims))) < 1e-12
     al.release_block(p)
+
+
+def test_emulated_multirank_path_with_every_exchange_through_rccl_to_self():
+    """RCCL on a one-GPU box: world size 1, X3D_EMULATE_DECOMP=z, X3D_COMM_SELF_VIA_NCCL=1 -- the halo rows, the
+    boundary values and the slab solver's all-to-all parts of the N > 1 code path are RCCL send / recv of the rank to
+    itself, posted on the communication stream exactly like exchanges with a real neighbour (parallel.Comm._start).
+    Two fused TGV steps at 64 x 512 x 512 (single-pass HALO kernels, slab solver with the on-chip z stage): bit for bit
+    the device-copy emulation, for the overlapped and the ordered path, and the overlapped path's first-use self-check
+    passes.  (What a one-GPU pool can say about the RCCL path: the calls, the streams and the wait semantics are real;
+    the links are not.)"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_worker.py"), "511"],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL-TO-SELF OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert int(r.stdout.split("halo_launches=")[1].split()[0]) > 0

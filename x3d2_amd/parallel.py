@@ -51,7 +51,12 @@ class Comm:
         self._cstream = None
         # the overlapped path is verified against the ordered one on first use (self_check below): a transport
         # whose stream semantics differ from what _start assumes costs the overlap, not the results
-        self._checked = self.host_staged or not self.enabled or self.size == 1 or not self.overlap
+        # X3D_COMM_SELF_VIA_NCCL=1 (one GPU, world size 1, X3D_EMULATE_DECOMP): exchanges with THIS rank go through
+        # RCCL send / recv to itself instead of device copies -- the only way to put the RCCL code path (group launch,
+        # communication stream, wait semantics) under a test on a one-GPU box
+        self.self_via_nccl = self.enabled and self.backend == "nccl" and os.environ.get("X3D_COMM_SELF_VIA_NCCL") == "1"
+        self._checked = self.host_staged or not self.enabled or not self.overlap or \
+            (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
 
     # ------------------------------------------------------------ p2p core
@@ -155,7 +160,7 @@ class Comm:
         """pairs: list of (send_s, send_e, recv_s, recv_e) tensors.
         send_s -> prev (arrives in prev's recv_e), send_e -> next (arrives in
         next's recv_s)."""
-        if prev == self.rank and nxt == self.rank:
+        if prev == self.rank and nxt == self.rank and not self.self_via_nccl:
             for send_s, send_e, recv_s, recv_e in pairs:  # nproc == 1 branch, sendrecv.f90:20-22
                 recv_s.copy_(send_e)
                 recv_e.copy_(send_s)
@@ -170,7 +175,7 @@ class Comm:
 
     def isendrecv(self, pairs, prev, nxt):
         """sendrecv started now and completed by the returned handle's wait()"""
-        if prev == self.rank and nxt == self.rank:
+        if prev == self.rank and nxt == self.rank and not self.self_via_nccl:
             self.sendrecv(pairs, prev, nxt)
             return DONE
         sends, recvs = [], []
@@ -187,7 +192,7 @@ class Comm:
         so = ro = 0
         sends, recvs = [], []
         for cnt_s, cnt_r, peer in zip(send_counts, recv_counts, peers):
-            if peer == self.rank:
+            if peer == self.rank and not self.self_via_nccl:
                 if not (recvbuf.data_ptr() == sendbuf.data_ptr() and ro == so):  # (aliased buffers: nothing to move)
                     recvbuf[ro:ro + cnt_r].copy_(sendbuf[so:so + cnt_s])
             else:
@@ -209,7 +214,7 @@ class Comm:
         sends, recvs = [], []
         for i, peer in enumerate(peers):
             s0, r0 = send_off + i * ss, recv_off + i * rs
-            if peer == self.rank:
+            if peer == self.rank and not self.self_via_nccl:
                 if not (recvbuf.data_ptr() == sendbuf.data_ptr() and r0 == s0):
                     recvbuf[r0:r0 + count].copy_(sendbuf[s0:s0 + count])
             else:
