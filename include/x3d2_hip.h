@@ -473,7 +473,7 @@ int x3d_pfft_postprocess_000(x3d_pfft *p);
 /* ---- deferred execution of the reference's op-granular call sequence: fusion inside the library (csrc/lazy.hip).
  * The unchanged solver.f90 issues 16 reorder + 6 sum_*intox + ~20 veccopy / vecadd + 16 tds_solve + 3 transeq_* per
  * sub-step (src/solver.f90:291-389, 693-739; src/time_integrator.f90:166-282; src/vector_calculus.f90:142-332).  With
- * the mode on, x3d_transeq, x3d_tds_solve, x3d_reorder, x3d_sum_intox, x3d_veccopy, x3d_vecadd, x3d_vecmult,
+ * the mode on, x3d_transeq, x3d_transeq_species, x3d_tds_solve, x3d_reorder, x3d_sum_intox, x3d_veccopy, x3d_vecadd, x3d_vecmult,
  * x3d_field_scale / _shift, x3d_block_fill and the 000 hooks x3d_poisson_fft_forward / _postprocess_000 / _fft_backward
  * only RECORD their call; the queue is rewritten onto the fused kernels (x3d_transeq_acc, x3d_tds_solve_pair,
  * x3d_tds_solve_acc, x3d_lincomb, x3d_tds_solve_lincomb, x3d_poisson_solve_000: the same arithmetic in the same order)

@@ -110,7 +110,7 @@ def test_deferred_channel_steps_are_bit_identical(dims, stretching, beta, monkey
 
 
 def test_deferred_species_transport_is_bit_identical():
-    """transeq_species is not recorded: it runs at once after x3d_lazy_sync (every handle's data home again)"""
+    """transeq_species (src/solver.f90:507-601) is recorded too; its y / z contributions fold their sum_<d>intox"""
     from x3d2_amd import make_tgv
     from x3d2_amd.common import VERT
     cases = []
@@ -125,6 +125,8 @@ def test_deferred_species_transport_is_bit_identical():
         c.step(2)
         cases.append(c)
     _same(*cases)
+    st = cases[1].solver.backend.lazy_stats()
+    assert st["sync_copies"] == 0 and st["materialised"] == 0
 
 
 def test_sync_brings_every_handle_home():

@@ -91,6 +91,8 @@ int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw
                      const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
                      const x3d_tdsops *t3);
 int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+int x3d_lazy_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+                     const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2, int accumulate);
 int x3d_lazy_copy(x3d_backend *b, double *dst, const double *src);
 int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir);
 int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);

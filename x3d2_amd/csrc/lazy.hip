@@ -34,7 +34,7 @@
 
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
-    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD
+    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC
 };
 
 struct LOp {
@@ -233,6 +233,7 @@ static int nin(const LOp &op)
     switch (op.kind) {
     case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5)
     case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: return 1;
+    case L_SPECIES: case L_SPECIES_ACC: return 2;  // uvw, spec
     case L_PAIR: return op.mode == 0 ? 2 : 1;
     case L_LINCOMB: case L_TDS_LIN: return 1 + op.nterm;  // base, x...
     default: return 0;
@@ -253,6 +254,7 @@ static bool out_is_update(const LOp &op, int slot = 0)
 {
     if (op.kind == L_TRANSEQ_UPD) return slot >= 3;
     switch (op.kind) {
+    case L_SPECIES_ACC:
     case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
     case L_FFT_BWD: case L_SOLVE000:
         return true;  // (the FFT hooks: forward only reads f, backward writes the real extent of f -- keep the contents)
@@ -346,6 +348,16 @@ static void optimise(x3d_lazy *L)
         if (!ok) continue;
         for (int c = 0; c < 3; c++) { q[ps[c]].kind = L_DEAD; q[p].o[c] = acc[c]; }
         q[p].kind = L_TRANSEQ_ACC;
+    }
+    // (1b) transeq_species(dspec_d; ...) ; sum_<d>intox(r, dspec_d)  (src/solver.f90:507-601)
+    for (int p = 0; p < n && (L->rules & 1u); p++) {
+        if (q[p].kind != L_SPECIES) continue;
+        const int k = first_touch_after(q, p, q[p].o[0]);
+        if (k < 0 || q[k].kind != L_SUM || q[k].in[0] != q[p].o[0] || q[k].dir != q[p].dir || !dead_after(q, k, q[p].o[0])) continue;
+        double *acc = q[k].o[0];
+        if (acc == q[p].in[0] || acc == q[p].in[1] || !range_clear(q, p, k, {acc}, {})) continue;
+        q[p].kind = L_SPECIES_ACC; q[p].o[0] = acc;
+        q[k].kind = L_DEAD;
     }
     // (2) a = A(i1) ; b = B(i2) ; a += b   (divergence_v2c: interpl + stagder of the same direction)
     // fused where the EARLIER solve stands if the later one may move up there, else where the later one stands
@@ -598,6 +610,8 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_FFT_POST000: return x3d_poisson_postprocess_000((x3d_poisson *)op.obj);
     case L_FFT_BWD: return x3d_poisson_fft_backward((x3d_poisson *)op.obj, o[0]);
     case L_SOLVE000: return x3d_poisson_solve_000((x3d_poisson *)op.obj, o[0]);
+    case L_SPECIES: case L_SPECIES_ACC:
+        return x3d_transeq_species(b, op.dir, o[0], in[0], in[1], op.s[0], op.t[0], op.t[1], op.t[2], op.kind == L_SPECIES_ACC);
     case L_TRANSEQ_UPD: {
         int done = 0;
         if (int rc = x3d_transeq_x_update(b, o[0], o[1], o[2], o[3], o[4], o[5], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3],
@@ -621,7 +635,7 @@ static void dump(const x3d_lazy *L, const char *title)
 {
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
-                                  "solve000", "transeq_upd"};
+                                  "solve000", "transeq_upd", "species", "species_acc"};
     std::unordered_map<const double *, int> id;
     auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
@@ -708,6 +722,14 @@ int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw
     if (int rc = push(b, op)) return rc;
     // (transeq_x itself belongs to the window it closes: the velocity correction left by the pressure step folds into it)
     return dir == X3D_DIR_X ? x3d_lazy_flush_c(b) : 0;
+}
+int x3d_lazy_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+                     const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2, int accumulate)
+{
+    LOp op;
+    op.kind = accumulate ? L_SPECIES_ACC : L_SPECIES; op.dir = dir;
+    op.o[0] = dspec; op.in[0] = uvw; op.in[1] = spec; op.s[0] = nu; op.t[0] = t0; op.t[1] = t1; op.t[2] = t2;
+    return push(b, op);
 }
 int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {

@@ -1182,8 +1182,7 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
                                    double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                    const x3d_tdsops *der2nd, int accumulate)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
+    if (b && x3d_lazy_active(b)) return x3d_lazy_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, accumulate);
     X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_species: bad dir %d", dir);
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
