@@ -161,6 +161,14 @@ int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *o
                       double *bnd_send, int other0, int nother, int *done);
 int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const x3d_tdsops *ta,
                           const x3d_tdsops *tb, const double *bnd_recv);
+/* x3d_tds_solve_pair_yperm for a decomposed z (the 010 solve on z slabs): the whole block through the halo form.
+ * Mode 1's halo_recv planes are cut from the neighbours' interleaved fields, so they are read through the same
+ * interleave; boundary values stay in pencil order; the strip correction of mode 0 lands on the interleaved rows. */
+int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                            const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv, double *bnd_send,
+                            int ny, int *done);
+int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out1, double *out2, const x3d_tdsops *ta,
+                                const x3d_tdsops *tb, const double *bnd_recv, int ny);
 /* fusion extension: y = base + sum_i c[i]*x[i] (x3d_lincomb: the RK / AB stage) followed by du = tds_solve(y)
  * (the first x operators of divergence_v2c): one kernel for periodic 256 / 512-point x pencils, y is not read
  * back; otherwise the two calls one after the other.  y may be base. */

@@ -50,7 +50,8 @@ def main():
     row = case.postprocess(nsteps, 0.01)
     local = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
     np.savez(out + f".{rank}.npz", u=local[0], v=local[1], w=local[2], offset=np.array(s.mesh.n_offset),
-             row=np.array(row), halo_launches=np.array([s.backend.halo_launches]))
+             row=np.array(row), halo_launches=np.array([s.backend.halo_launches]),
+             n_interleaved=np.array([s.n_interleaved]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -85,6 +85,7 @@ def _run_channel_ranks(nproc_dir, dims, nsteps, stretching, beta, fused, tmp_pat
         g[name] = full
     g["row"] = parts[0]["row"]
     g["halo_launches"] = int(parts[0]["halo_launches"][0])
+    g["n_interleaved"] = int(parts[0]["n_interleaved"][0])
     return g
 
 
@@ -110,6 +111,9 @@ def test_channel_on_z_slabs_equals_single_rank_and_oracle(nproc_dir, dims, stret
     assert abs(g["row"][2] - dmax) < 1e-6 * dmax + 1e-12
     if halo:
         assert g["halo_launches"] > 0  # the single-pass kernels of the decomposed z direction engaged
+        assert g["n_interleaved"] == 6  # and their z pairs carried the 010 solver's row interleave (2 steps x 3)
+    else:
+        assert g["n_interleaved"] == 0
 
 
 def test_channel_two_slabs_at_the_bench_pencil_lengths(tmp_path):
@@ -124,4 +128,4 @@ def test_channel_two_slabs_at_the_bench_pencil_lengths(tmp_path):
     for f, nm in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
         ref = s.backend.get_field_data(f)
         assert np.max(np.abs(g[nm] - ref)) < 1e-11 * max(np.max(np.abs(ref)), 1.0), nm
-    assert g["halo_launches"] > 0
+    assert g["halo_launches"] > 0 and g["n_interleaved"] == 3

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "x3d_transeq_halo_fix": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP]),
     "x3d_tds_pair_tile": (I, [VP, I, I, VP, VP, VP, VP, VP, VP, VP, VP, I, I, c_int_p]),
     "x3d_tds_pair_halo_fix": (I, [VP, I, I, VP, VP, VP, VP, VP]),
+    "x3d_tds_pair_tile_yperm": (I, [VP, I, VP, VP, VP, VP, VP, VP, VP, VP, I, c_int_p]),
+    "x3d_tds_pair_halo_fix_yperm": (I, [VP, I, VP, VP, VP, VP, VP, I]),
     "x3d_tds_solve_lincomb": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
     "x3d_tds_solve_lincomb_wall": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), VP]),
     "x3d_tds_dist_bwd": (I, [VP, VP, VP, VP, VP, VP, I]),

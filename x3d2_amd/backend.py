@@ -364,13 +364,20 @@ class HipBackend:
     def _job_sizes(self, job):
         return (2 if job[0] == 0 else 1), (1 if job[0] == 2 else 2)
 
-    def tds_tile_ok(self, direction, job, halo):
-        """the tile kernel takes this job (probe: zero planes)"""
+    def tds_tile_ok(self, direction, job, halo, yperm=0):
+        """the tile kernel takes this job (probe: zero planes); yperm > 0: with that many y rows interleaved on
+        the way (the halo form of tds_pair_yperm: z pairs next to the 010 Poisson solve on z slabs)"""
         mode, out1, out2, in1, in2, ta, tb = job
-        key = ("tds_ok", direction, mode, id(ta), id(tb), bool(halo))
+        key = ("tds_ok", direction, mode, id(ta), id(tb), bool(halo), int(yperm))
         if key not in self._halo:
             if os.environ.get("X3D_NO_HALO_TILE") == "1" and halo:
                 self._halo[key] = False
+            elif yperm:
+                ok = (halo and direction == DIR_Z and mode in (0, 1) and os.environ.get("X3D_NO_YPERM") != "1"
+                      and self.tds_tile_ok(direction, job, True))
+                if ok:  # (the probe of the interleaving form needs whole blocks: ask the launcher's own conditions)
+                    ok = 0 < yperm <= int(self.mesh.vert_dims[1]) and yperm % 2 == 0
+                self._halo[key] = bool(ok)
             else:
                 flag = ctypes.c_int(0)
                 hp = bp = None
@@ -410,31 +417,42 @@ class HipBackend:
         hs, hr, _, _ = self._halo_buffers(direction, nf, nb, "job%d" % k)
         return self._halo_exchange(direction, (in1, in2)[:nf], ta.n_tds, hs, hr)
 
-    def tds_halo_main(self, direction, job, k, handle):
+    def tds_halo_main(self, direction, job, k, handle, yperm=0):
         mode, out1, out2, in1, in2, ta, tb = job
         nf, nb = self._job_sizes(job)
         _, hr, bs, br = self._halo_buffers(direction, nf, nb, "job%d" % k)
         handle.wait()
         flag = ctypes.c_int(0)
-        _lib.check(self.lib.x3d_tds_pair_tile(
-            self.h, direction, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
-            in2.ptr if in2 is not None else None, ta.handle, tb.handle if tb is not None else None, hr.data_ptr(),
-            bs.data_ptr(), 0, -1, ctypes.byref(flag)))
+        if yperm:
+            _lib.check(self.lib.x3d_tds_pair_tile_yperm(
+                self.h, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
+                in2.ptr if in2 is not None else None, ta.handle, tb.handle, hr.data_ptr(), bs.data_ptr(), int(yperm),
+                ctypes.byref(flag)))
+        else:
+            _lib.check(self.lib.x3d_tds_pair_tile(
+                self.h, direction, mode, out1.ptr, out2.ptr if out2 is not None else None, in1.ptr,
+                in2.ptr if in2 is not None else None, ta.handle, tb.handle if tb is not None else None, hr.data_ptr(),
+                bs.data_ptr(), 0, -1, ctypes.byref(flag)))
         if not flag.value:
             raise X3dError("tds_halo_main: tile kernel refused (tds_tile_ok was not consulted)")
         self.halo_launches += 1
         return self.comm.isendrecv([self._halves(bs) + self._halves(br)], *self._neighbours(direction))
 
-    def tds_halo_finish(self, direction, job, k, handle):
+    def tds_halo_finish(self, direction, job, k, handle, yperm=0):
         mode, out1, out2, in1, in2, ta, tb = job
         nf, nb = self._job_sizes(job)
         _, _, _, br = self._halo_buffers(direction, nf, nb, "job%d" % k)
         handle.wait()
+        if yperm:
+            _lib.check(self.lib.x3d_tds_pair_halo_fix_yperm(self.h, mode, out1.ptr,
+                                                            out2.ptr if out2 is not None else None, ta.handle,
+                                                            tb.handle, br.data_ptr(), int(yperm)))
+            return
         _lib.check(self.lib.x3d_tds_pair_halo_fix(self.h, direction, mode, out1.ptr,
                                                   out2.ptr if out2 is not None else None, ta.handle,
                                                   tb.handle if tb is not None else None, br.data_ptr()))
 
-    def tds_jobs(self, direction, jobs, lead=None, after_lead=None, between=None):
+    def tds_jobs(self, direction, jobs, lead=None, after_lead=None, between=None, yperm=0):
         """run tds_solve jobs of one direction.
         Local direction: lead = list of (other0, nother) plane ranges to do FIRST, after which after_lead() is
         called (it starts the next direction's halo exchange on those planes) and the remaining planes follow.
@@ -467,16 +485,18 @@ class HipBackend:
             if between:
                 between()
             return
-        if direction != DIR_X and all(self.tds_tile_ok(direction, j, True) for j in jobs):
+        if direction != DIR_X and all(self.tds_tile_ok(direction, j, True, yperm=yperm) for j in jobs):
             hs = [self.tds_halo_begin(direction, j, k) for k, j in enumerate(jobs)]
-            hb = [self.tds_halo_main(direction, j, k, hs[k]) for k, j in enumerate(jobs)]
+            hb = [self.tds_halo_main(direction, j, k, hs[k], yperm=yperm) for k, j in enumerate(jobs)]
             if after_lead:
                 after_lead()
             if between:
                 between()
             for k, j in enumerate(jobs):
-                self.tds_halo_finish(direction, j, k, hb[k])
+                self.tds_halo_finish(direction, j, k, hb[k], yperm=yperm)
             return
+        if yperm:
+            raise X3dError("tds_jobs: interleaved rows need the halo form of the z pairs (tds_tile_ok)")
         for j in jobs:  # two-sweep DistD2 with its own exchanges
             self.tds_job_local(direction, j)
         if after_lead:

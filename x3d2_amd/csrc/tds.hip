@@ -1275,9 +1275,9 @@ extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double 
 // tds_solve pairs / single operators of a y or z direction through the tile kernel (modes of x3d_tds_solve_pair,
 // + mode 2: out1 = A(in1)), over a plane range as above.  halo_recv == NULL: local direction.  Otherwise
 // halo_recv[2][nf][4][np] with nf = 2 (mode 0: in1, in2) or 1, and bnd_send[2][nb][np], nb = 2 (modes 0, 1: A, B) or 1
-extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                                 const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
-                                 double *bnd_send, int other0, int nother, int *done)
+static int pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                     const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
+                     double *bnd_send, int other0, int nother, int *done)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -1306,6 +1306,38 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1
     return 0;
 }
 
+extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
+                                 const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
+                                 double *bnd_send, int other0, int nother, int *done)
+{
+    return pair_tile(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, other0, nother, done);
+}
+// the decomposed-z form of x3d_tds_solve_pair_yperm: the whole block, halo_recv's planes in the row order of in1
+// (mode 1: interleaved like the field they were cut from), bnd_send in pencil order
+extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1,
+                                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+                                       const double *halo_recv, double *bnd_send, int ny, int *done)
+{
+    X3D_REQUIRE(b && done, "x3d_tds_pair_tile_yperm: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_tile_yperm: mode must be 0 or 1");
+    X3D_REQUIRE(ny > 0 && ny <= b->ny, "x3d_tds_pair_tile_yperm: ny = %d outside the block (%d rows)", ny, b->ny);
+    X3D_REQUIRE(halo_recv && bnd_send, "x3d_tds_pair_tile_yperm: halo_recv and bnd_send are required");
+    b->pair_yperm = ny;
+    const int rc = pair_tile(b, X3D_DIR_Z, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, 0, -1, done);
+    b->pair_yperm = 0;
+    return rc;
+}
+extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out1, double *out2, const x3d_tdsops *ta,
+                                           const x3d_tdsops *tb, const double *bnd_recv, int ny)
+{
+    X3D_REQUIRE(b, "x3d_tds_pair_halo_fix_yperm: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_halo_fix_yperm: mode must be 0 or 1");
+    X3D_REQUIRE(ny > 0 && ny <= b->ny, "x3d_tds_pair_halo_fix_yperm: ny = %d outside the block (%d rows)", ny, b->ny);
+    b->pair_yperm = ny;
+    const int rc = x3d_tds_pair_halo_fix(b, X3D_DIR_Z, mode, out1, out2, ta, tb, bnd_recv);
+    b->pair_yperm = 0;
+    return rc;
+}
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
 {

@@ -1197,7 +1197,9 @@ __global__ void __launch_bounds__(1024)
     auto in1_off = [&](int tl) { return MODE == 1 ? tile_off_p(tl) : tile_off(tl); };
     auto hload = [&](int tl, int f) {  // thread t < 128: halo value (pencil t >> 3, slot t & 7) of input f
         const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
-        const long pp = (long)(tl / ntx) * th.hp + (long)(tl % ntx) * 16 + hw;
+        int r = tl / ntx;  // (MODE 1's input comes interleaved from the neighbours as well)
+        if (MODE == 1 && permn > 0 && r < permn) r = (r & 1) ? permn - ((r + 1) >> 1) : (r >> 1);
+        const long pp = (long)r * th.hp + (long)(tl % ntx) * 16 + hw;
         return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.hnp + pp];
     };
     __syncthreads();
@@ -1292,12 +1294,14 @@ __device__ __forceinline__ double halo_fix_row(const TdsTab &t, int j, int n, do
 template <int MODE>
 __global__ void __launch_bounds__(256)
     k_tds_halo_fix(double *__restrict__ out1, double *__restrict__ out2, const double *__restrict__ brecv, TdsTab ta,
-                   TdsTab tb, PencilGeom g, int ws, int we)
+                   TdsTab tb, PencilGeom g, int ws, int we, int permn)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const int nb = MODE == 2 ? 1 : 2, n = ta.n_tds, seg = blockIdx.y;  // seg 0: start strip, 1: end strip
-    const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1;
+    int r1 = p / g.dim0;  // permn > 0 (z pencils, MODE 0): out1's y rows are interleaved (k_ytile_tds_pair)
+    if (MODE == 0 && permn > 0 && r1 < permn) r1 = (r1 & 1) ? permn - ((r1 + 1) >> 1) : (r1 >> 1);
+    const long base = (long)(p % g.dim0) * g.s0 + (long)r1 * g.s1;
     const double dsa = -ta.rs_s * ta.sa1 * brecv[p], dea = -ta.rs_e * ta.scn * brecv[(long)nb * g.np + p];
     double dsb = 0.0, deb = 0.0;
     if (MODE != 2) {
@@ -1611,6 +1615,8 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     const int ntx = b->nx / 16;
     int tile0, ntiles;
     tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
+    const int permn = b->pair_yperm;  // (whole blocks of z pencils only: the interleave pairs rows across the block)
+    if (permn > 0 && (dir != X3D_DIR_Z || mode == 2 || tile0 != 0 || (ntiles > 0 && ntiles != ntx * b->ny))) return 0;
     if (ntiles <= 0) { *done = true; return 0; }
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
@@ -1618,8 +1624,6 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
-    const int permn = b->pair_yperm;
-    if (permn > 0 && (dir != X3D_DIR_Z || halo || mode == 2 || tile0 != 0)) return 0;
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_, H_)                                                                                      \
     do {                                                                                                        \
@@ -1649,10 +1653,12 @@ int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *ou
     const int we = mode == 2 ? ta->halo_we : (ta->halo_we > tb->halo_we ? ta->halo_we : tb->halo_we);
     dim3 grid((g.np + 255) / 256, ws + we >= ta->n_tds ? 1 : 2);
     const int ws1 = grid.y == 1 ? ta->n_tds : ws;
+    const int permn = b->pair_yperm;
+    X3D_REQUIRE(permn == 0 || (dir == X3D_DIR_Z && mode != 2), "tds_halo_fix: interleaved rows are for z pairs");
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
-    if (mode == 0) hipLaunchKernelGGL(k_tds_halo_fix<0>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we);
-    else if (mode == 1) hipLaunchKernelGGL(k_tds_halo_fix<1>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we);
-    else hipLaunchKernelGGL(k_tds_halo_fix<2>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, ta->tab, g, ws1, we);
+    if (mode == 0) hipLaunchKernelGGL(k_tds_halo_fix<0>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we, permn);
+    else if (mode == 1) hipLaunchKernelGGL(k_tds_halo_fix<1>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we, permn);
+    else hipLaunchKernelGGL(k_tds_halo_fix<2>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, ta->tab, g, ws1, we, 0);
     X3D_HIP(hipGetLastError());
     return 0;
 }

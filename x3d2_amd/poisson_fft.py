@@ -5,6 +5,7 @@ backend supplies (fft_forward / fft_postprocess_000 / fft_backward through
 rocFFT; reference CPU hooks: src/backend/omp/poisson_fft.f90:89-137)."""
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -157,7 +158,6 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs, xsl=None):
 def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
-    import os
     force = os.environ.get("X3D_FORCE_PENCIL_FFT")  # "1": generic pencil solver, "slab": slab solver
     if mesh.nproc > 1 or force in ("1", "slab"):
         ny = int(mesh.get_global_dims(CELL)[1])
@@ -583,7 +583,6 @@ class HipSlabPoissonFFT(HipPoissonFFT):
     result leaves at once.  X3D_SLAB_PARTS (default 4; 1 = no overlap)."""
 
     def _create(self):
-        import os
         import torch
         backend, mesh = self.backend, self.mesh
         self.pz, self.rz = int(mesh.nproc_dir[2]), int(mesh.nrank_dir[2])
@@ -780,8 +779,12 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
         split and the pentadiagonal solves of group m run beside the transfer of the groups behind it"""
         if temp is None:
             raise X3dError("poisson_010 needs a scratch block")
-        lib, h, rb = self.backend.lib, self.h, self.rbuf.data_ptr()
         self.enforce_periodicity_y(temp, f)
+        self._solve_rows_interleaved(temp)
+        self.undo_periodicity_y(f, temp)
+
+    def _solve_rows_interleaved(self, temp):
+        lib, h, rb = self.backend.lib, self.h, self.rbuf.data_ptr()
         _lib.check(lib.x3d_sfft010_forward_local(h, temp.ptr, self.sbuf.data_ptr()))
         there = [self._send_part(m) for m in range(self.parts)]
         back = []
@@ -794,10 +797,14 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
         for hnd in back:
             hnd.wait()
         _lib.check(lib.x3d_sfft010_backward_local(h, self.sbuf.data_ptr(), temp.ptr))
-        self.undo_periodicity_y(f, temp)
 
     def interleaved_rows(self):
-        return 0
+        """as HipPoissonFFT.interleaved_rows; the caller's z operators are then the halo forms
+        (HipBackend.tds_tile_ok / tds_halo_main / tds_halo_finish with yperm)"""
+        return self.ny_glob if self.ny_glob % 2 == 0 and os.environ.get("X3D_NO_YPERM") != "1" else 0
+
+    def solve_interleaved(self, f):
+        self._solve_rows_interleaved(f)
 
     def _no_000(self, *a):
         raise X3dError("HipSlabPoissonFFT010 serves the 010 case only")

@@ -308,10 +308,16 @@ class Solver:
         # 010 Poisson solve (non-periodic y): its interleave of the y rows before / after the transforms is done by
         # the z pairs on either side (4 field passes less per solve); nil = rows to interleave, 0 = not on offer
         nil = 0
-        if self.cfg.poisson_solver_type == "FFT" and not (b._decomposed(DIR_Y) or b._decomposed(DIR_Z)):
+        if self.cfg.poisson_solver_type == "FFT" and not b._decomposed(DIR_Y):
             nil = getattr(b.poisson_fft, "interleaved_rows", lambda: 0)()
         if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
-            self._div_grad_decomposed(jy, jz, forward=True)
+            # (z slabs: the halo form of the interleaving pair, t2 as above)
+            nil = nil if nil and self._zpairs_interleave(nil, jz[0]) else 0
+            if nil:
+                jz = [(0, t2, None, a1, a2, z.interpl_v2p, z.stagder_v2p)]
+                div = t2
+                self.n_interleaved += 1
+            self._div_grad_decomposed(jy, jz, forward=True, nil=nil)
         else:
             b.tds_pair(*jy[0], DIR_Y)
             b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
@@ -330,7 +336,13 @@ class Solver:
         else:
             p.fill(0.0)
         # gradient_c2v, :248-332, + velocity correction solver.f90:731-733
-        if nil:
+        if nil and b._decomposed(DIR_Z):
+            jz = [(1, t1, t3, p, None, z.interpl_p2v, z.stagder_p2v)]    # as below, through the halo forms
+            jy = [(1, a1, a2, t1, None, y.interpl_p2v, y.stagder_p2v),
+                  (2, t2, None, t3, None, y.interpl_p2v, None)]
+            self._div_grad_decomposed(jy, jz, forward=False, nil=nil)
+            t1, t2 = t2, t1
+        elif nil:
             # p = t2 in the solver's row order: read through the interleave; p_sxy -> t1, dpdz_sxy -> t3
             if not b.tds_pair_yperm(1, t1, t3, p, None, z.interpl_p2v, z.stagder_p2v, nil):
                 raise X3dError("pressure_correction: the interleaving z pair served the divergence but not the gradient")
@@ -358,7 +370,15 @@ class Solver:
         for f in (t1, t2, t3, a1, a2):
             al.release_block(f)
 
-    def _div_grad_decomposed(self, jy, jz, forward):
+    def _zpairs_interleave(self, nil, jz0):
+        """z slabs, y local: both z pairs around the 010 solve are served by the interleaving halo form"""
+        b, z = self.backend, self.zdirps
+        if b._decomposed(DIR_Y) or not b._decomposed(DIR_Z) or int(b.mesh.vert_dims[2]) <= 2 * 4:
+            return False
+        back = (1, jz0[1], jz0[4], jz0[3], None, z.interpl_p2v, z.stagder_p2v)  # (a probe: nothing is written)
+        return b.tds_tile_ok(DIR_Z, jz0, True, yperm=nil) and b.tds_tile_ok(DIR_Z, back, True, yperm=nil)
+
+    def _div_grad_decomposed(self, jy, jz, forward, nil=0):
         """the y and z operators of divergence_v2c (forward: y then z) / gradient_c2v (z then y) with at least
         one decomposed direction.  Exchanges are hidden behind the planes that do not need them:
         forward, z decomposed, y local: the y jobs do the 4 + 4 boundary z planes first, their rows leave for the
@@ -373,10 +393,12 @@ class Solver:
                 state = {}
                 b.tds_jobs(DIR_Y, jy, lead=[(0, 4), (nz - 4, 4)],
                            after_lead=lambda: state.update(h=[b.tds_halo_begin(DIR_Z, j, k) for k, j in enumerate(jz)]))
-                hb = [b.tds_halo_main(DIR_Z, j, k, state["h"][k]) for k, j in enumerate(jz)]
+                hb = [b.tds_halo_main(DIR_Z, j, k, state["h"][k], yperm=nil) for k, j in enumerate(jz)]
                 for k, j in enumerate(jz):
-                    b.tds_halo_finish(DIR_Z, j, k, hb[k])
+                    b.tds_halo_finish(DIR_Z, j, k, hb[k], yperm=nil)
             else:
+                if nil:
+                    raise X3dError("divergence: the interleaving z pair was promised (_zpairs_interleave) but not taken")
                 b.tds_jobs(DIR_Y, jy)
                 b.tds_jobs(DIR_Z, jz)
             return
@@ -386,12 +408,12 @@ class Solver:
                 def interior():
                     for j in jy:
                         b.tds_tile_planes(DIR_Y, j, ws, nz - ws - we)
-                b.tds_jobs(DIR_Z, jz, between=interior)
+                b.tds_jobs(DIR_Z, jz, between=interior, yperm=nil)
                 for j in jy:
                     b.tds_tile_planes(DIR_Y, j, 0, ws)
                     b.tds_tile_planes(DIR_Y, j, nz - we, we)
                 return
-        b.tds_jobs(DIR_Z, jz)
+        b.tds_jobs(DIR_Z, jz, yperm=nil)
         b.tds_jobs(DIR_Y, jy)
 
     def _apply_grad(self, g, u, v, w):
