@@ -477,6 +477,24 @@ int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf);
 int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf);
 int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf);
 int x3d_pfft_postprocess_000(x3d_pfft *p);
+/* the same solve in `parts` groups of zp = zl / parts local z planes (parts <= 0: the library's choice): everything
+ * before the z transform is independent from plane to plane, so a group's x transform, xy exchange, y transform and
+ * yz exchange run beside the other groups' transfers (the reference's 2decomp&FFT transposes block,
+ * src/backend/omp/poisson_fft.f90:99-137).  x3d_pfft_part_layout: out = {parts, zp, complex elements of ONE group's
+ * piece of the xy send / xy receive / yz send / yz receive buffer}; group m's piece starts at m times that; inside
+ * it peer r's chunk starts at xoff_r*yl*zp / r*xs*yl*zp / yoff_r*xs*zp / r*ys*xs*zp.
+ *   fwd_a(m): R2C x, pack -> send_xy | exchange | fwd_b(m): unpack, C2C y, pack -> send_yz | exchange |
+ *   fwd_c(m): unpack ; all groups in: fft_z ; postprocess_000 ; fft_z(inv) ; bwd_c(m) | exchange | bwd_b(m) |
+ *   exchange | bwd_a(m).  The whole-solve entry points above keep their buffer layout for any `parts`. */
+int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob_cell[3], int py, int pz, int ry, int rz,
+                          int parts);
+int x3d_pfft_part_layout(const x3d_pfft *p, long out[6]);
+int x3d_pfft_fwd_a_part(x3d_pfft *p, const double *f_in, double *send_xy, int m);
+int x3d_pfft_fwd_b_part(x3d_pfft *p, const double *recv_xy, double *send_yz, int m);
+int x3d_pfft_fwd_c_part(x3d_pfft *p, const double *recv_yz, int m);
+int x3d_pfft_bwd_c_part(x3d_pfft *p, double *send_zy, int m);
+int x3d_pfft_bwd_b_part(x3d_pfft *p, const double *recv_zy, double *send_yx, int m);
+int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m);
 
 /* ---- deferred execution of the reference's op-granular call sequence: fusion inside the library (csrc/lazy.hip).
  * The unchanged solver.f90 issues 16 reorder + 6 sum_*intox + ~20 veccopy / vecadd + 16 tds_solve + 3 transeq_* per

@@ -1288,3 +1288,48 @@ def test_emulated_multirank_path_with_every_exchange_through_rccl_to_self():
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL-TO-SELF OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert int(r.stdout.split("halo_launches=")[1].split()[0]) > 0
+
+@pytest.mark.parametrize("parts", [1, 3, 0])
+def test_pencil_solver_in_groups_of_planes_equals_hooks_single_rank_solver_and_oracle(parts, monkeypatch):
+    """csrc/pfft.hip in one process (py = pz = 1: every exchange a copy to itself): poisson_000 with the local z
+    planes going through the exchanges in groups (X3D_PENCIL_PARTS: 3 groups, the library's choice) == the three
+    hooks one after the other (the reference's blocking order, src/poisson_fft.f90:216-226) == the single-rank
+    solver == the oracle; forward ; backward gives the field back times nx ny nz"""
+    from oracle import x3d_oracle as orc
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.poisson_fft import HipPencilPoissonFFT, HipPoissonFFT
+    dims = (34, 40, 24)  # 18 x modes, odd shares when split; 24 planes = 3 x 8 or 4 x 6
+    single = make_tgv(dims).solver
+    assert type(single.backend.poisson_fft) is HipPoissonFFT
+    monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "1")
+    monkeypatch.setenv("X3D_PENCIL_PARTS", str(parts))
+    s = make_tgv(dims).solver
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert type(pf) is HipPencilPoissonFFT and pf.parts == {1: 1, 3: 3, 0: 4}[parts]
+    rng = np.random.default_rng(9)
+    f = rng.standard_normal((dims[2], dims[1], dims[0]))
+    f -= f.mean()
+    p = al.get_block(DIR_C, CELL)
+    out = []
+    for how in ("solve", "hooks", "roundtrip"):
+        p.fill(0.0)
+        b.set_field_data(p, f, CELL)
+        if how == "solve":
+            pf.poisson_000(p, None)
+        else:
+            pf.fft_forward(p)
+            if how == "hooks":
+                pf.fft_postprocess_000()
+            pf.fft_backward(p)
+        out.append(b.get_field_data(p, CELL))
+    al.release_block(p)
+    assert relerr(out[1], out[0]) < 1e-13
+    assert relerr(out[2], f * float(np.prod(dims))) < 1e-12
+    q = single.backend.allocator.get_block(DIR_C, CELL)
+    single.backend.set_field_data(q, f, CELL)
+    single.backend.poisson_fft.poisson_000(q, None)
+    assert relerr(out[0], single.backend.get_field_data(q, CELL)) < 1e-12
+    L, per = [float(v) for v in s.mesh.L], ["periodic"] * 2
+    om = orc.Mesh(list(dims), [1, 1, 1], L, per, per, per)
+    assert relerr(out[0], orc.Solver(om, poisson="FFT").poisson_fft.solve(f)) < 1e-11

@@ -164,6 +164,14 @@ PROTOTYPES = {
     "x3d_pfft_pack_zy": (I, [VP, VP]),
     "x3d_pfft_unpack_zy": (I, [VP, VP]),
     "x3d_pfft_postprocess_000": (I, [VP]),
+    "x3d_pfft_create_parts": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I, I]),
+    "x3d_pfft_part_layout": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_pfft_fwd_a_part": (I, [VP, VP, VP, I]),
+    "x3d_pfft_fwd_b_part": (I, [VP, VP, VP, I]),
+    "x3d_pfft_fwd_c_part": (I, [VP, VP, I]),
+    "x3d_pfft_bwd_c_part": (I, [VP, VP, I]),
+    "x3d_pfft_bwd_b_part": (I, [VP, VP, VP, I]),
+    "x3d_pfft_bwd_a_part": (I, [VP, VP, VP, I]),
     "x3d_timer_start": (I, [VP]),
     "x3d_timer_stop_ms": (I, [VP, ctypes.POINTER(ctypes.c_float)]),
     "x3d_prof_enable": (I, [VP, I]),

@@ -13,6 +13,12 @@
 //   --C2C z--> process_spectral_000 --> inverse path.
 // xs / ys are this rank's shares of the nx/2+1 x-modes / ny y-modes
 // (first `rem` ranks get one extra), all pencil axes are contiguous for rocFFT.
+//
+// Everything up to the z transform is independent from one local z plane to the next, so the solve can run in
+// `parts` groups of zp = zl / parts planes (x3d_pfft_create_parts, the *_part entry points): the x transform, the
+// xy exchange, the y transform and the yz exchange of a group run beside the transfers of the others; the
+// reference's 2decomp&FFT transposes are blocking (src/backend/omp/poisson_fft.f90:99-137).  Exchange buffers of a
+// group: [part][peer][zp][..][..], a peer's chunk contiguous (x3d_pfft_part_layout).
 #include <hipfft/hipfft.h>
 
 #include "common.h"
@@ -36,6 +42,7 @@ struct x3d_pfft {
     int py, pz, ry, rz;
     int yl, zl;                   // local physical extents (ny/py, nz/pz)
     int xs, xoff, ys, yoff;       // spectral shares of this rank
+    int parts, zp;                // groups of local z planes (zp = zl / parts); the x and y plans are per group
     hipfftHandle plan_r2c, plan_c2r, plan_y, plan_z;
     double2 *c0, *c1, *c2;        // stage buffers
     double *waves, *ab;
@@ -150,7 +157,16 @@ __global__ void __launch_bounds__(256)
     c[idx] = make_double2(div_r, div_c);
 }
 
+extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry,
+                                     int rz, int parts);
 extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry, int rz)
+{
+    return x3d_pfft_create_parts(b, out, nglob, py, pz, ry, rz, 1);
+}
+
+// parts <= 0: the library's choice (4, or the largest divisor of zl below it)
+extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry,
+                                     int rz, int parts)
 {
     X3D_REQUIRE(b && out && nglob, "x3d_pfft_create: null argument");
     X3D_REQUIRE(py >= 1 && pz >= 1 && ry >= 0 && ry < py && rz >= 0 && rz < pz, "x3d_pfft_create: bad rank grid");
@@ -161,7 +177,13 @@ extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3
     p->nx = nglob[0]; p->ny = nglob[1]; p->nz = nglob[2]; p->nxs = nglob[0] / 2 + 1;
     p->py = py; p->pz = pz; p->ry = ry; p->rz = rz;
     p->yl = p->ny / py; p->zl = p->nz / pz;
-    X3D_REQUIRE(p->nx <= b->nxp && p->yl <= b->nyp && p->zl <= b->nzp, "x3d_pfft_create: local block too small");
+    X3D_REQUIRE(p->nx <= b->nxp && p->yl == b->nyp && p->zl <= b->nzp,
+                "x3d_pfft_create: the block (%d x %d x %d) does not hold %d x %d x %d cells per rank", b->nxp, b->nyp,
+                b->nzp, p->nx, p->yl, p->zl);
+    if (parts <= 0) for (parts = 4; parts > 1 && p->zl % parts; parts--) {}
+    X3D_REQUIRE(parts >= 1 && p->zl % parts == 0, "x3d_pfft_create: %d parts do not divide %d local z planes", parts,
+                p->zl);
+    p->parts = parts; p->zp = p->zl / parts;
     p->xs = share(p->nxs, py, ry); p->xoff = share_off(p->nxs, py, ry);
     p->ys = share(p->ny, pz, rz); p->yoff = share_off(p->ny, pz, rz);
     const size_t n0 = (size_t)p->zl * p->yl * p->nxs, n1 = (size_t)p->zl * p->xs * p->ny,
@@ -180,10 +202,10 @@ extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3
     }
     int rembed[1] = {b->nxp}, cembed[1] = {p->nxs};
     X3D_FFT(hipfftMakePlanMany(p->plan_r2c, 1, nxv, rembed, 1, b->nxp, cembed, 1, p->nxs, HIPFFT_D2Z,
-                               p->yl * p->zl, &ws[0]));
+                               p->yl * p->zp, &ws[0]));
     X3D_FFT(hipfftMakePlanMany(p->plan_c2r, 1, nxv, cembed, 1, p->nxs, rembed, 1, b->nxp, HIPFFT_Z2D,
-                               p->yl * p->zl, &ws[1]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, nyv, nyv, 1, p->ny, nyv, 1, p->ny, HIPFFT_Z2Z, p->zl * p->xs, &ws[2]));
+                               p->yl * p->zp, &ws[1]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, nyv, nyv, 1, p->ny, nyv, 1, p->ny, HIPFFT_Z2Z, p->zp * p->xs, &ws[2]));
     X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, HIPFFT_Z2Z, p->xs * p->ys, &ws[3]));
     size_t wmax = 0;
     for (int i = 0; i < 4; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
@@ -231,37 +253,61 @@ extern "C" int x3d_pfft_set_waves(x3d_pfft *p, const double *waves_re, const dou
     return 0;
 }
 
+// ---- local stages on the planes [z0, z0 + nzp_) of this rank (a whole number of groups)
+static int fwd_x(x3d_pfft *p, const double *f_in, int m0, int m1)
+{
+    ProfScope ps(p->b, X3D_K_FFT, 1);
+    X3D_FFT(hipfftSetStream(p->plan_r2c, p->b->stream));
+    for (int m = m0; m < m1; m++)
+        X3D_FFT(hipfftExecD2Z(p->plan_r2c, (hipfftDoubleReal *)f_in + (size_t)m * p->zp * p->yl * p->b->nxp,
+                              (hipfftDoubleComplex *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs));
+    return 0;
+}
+static int bwd_x(x3d_pfft *p, double *f_out, int m0, int m1)
+{
+    ProfScope ps(p->b, X3D_K_FFT, 2);
+    X3D_FFT(hipfftSetStream(p->plan_c2r, p->b->stream));
+    for (int m = m0; m < m1; m++)
+        X3D_FFT(hipfftExecZ2D(p->plan_c2r, (hipfftDoubleComplex *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs,
+                              (hipfftDoubleReal *)f_out + (size_t)m * p->zp * p->yl * p->b->nxp));
+    return 0;
+}
+static int fft_y(x3d_pfft *p, int inverse, int m0, int m1)
+{
+    if (p->xs == 0) return 0;
+    ProfScope ps(p->b, X3D_K_FFT, 3);
+    X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
+    for (int m = m0; m < m1; m++) {
+        hipfftDoubleComplex *c = (hipfftDoubleComplex *)p->c1 + (size_t)m * p->zp * p->xs * p->ny;
+        X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+    }
+    return 0;
+}
+
 extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "null argument");
-    ProfScope ps(p->b, X3D_K_FFT, 1);
-    X3D_FFT(hipfftSetStream(p->plan_r2c, p->b->stream));
-    X3D_FFT(hipfftExecD2Z(p->plan_r2c, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
-    return 0;
+    X3D_LAZY_SYNC(p->b);
+    return fwd_x(p, f_in, 0, p->parts);
 }
 
 extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out)
 {
     X3D_REQUIRE(p && f_out, "null argument");
-    ProfScope ps(p->b, X3D_K_FFT, 2);
-    X3D_FFT(hipfftSetStream(p->plan_c2r, p->b->stream));
-    X3D_FFT(hipfftExecZ2D(p->plan_c2r, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
-    return 0;
+    X3D_LAZY_SYNC(p->b);
+    return bwd_x(p, f_out, 0, p->parts);
 }
 
 extern "C" int x3d_pfft_fft_y(x3d_pfft *p, int inverse)
 {
     X3D_REQUIRE(p, "null argument");
-    ProfScope ps(p->b, X3D_K_FFT, 3);
-    X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
-    X3D_FFT(hipfftExecZ2Z(p->plan_y, (hipfftDoubleComplex *)p->c1, (hipfftDoubleComplex *)p->c1,
-                          inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
-    return 0;
+    return fft_y(p, inverse, 0, p->parts);
 }
 
 extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
 {
     X3D_REQUIRE(p, "null argument");
+    if (p->xs == 0 || p->ys == 0) return 0;
     ProfScope ps(p->b, X3D_K_FFT, 3);
     X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
     X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->c2, (hipfftDoubleComplex *)p->c2,
@@ -269,119 +315,172 @@ extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
     return 0;
 }
 
-// ---- exchange buffers.  Peer r's chunk is contiguous; element counts and
-// offsets follow from x3d_pfft_sizes (see poisson_fft.py: _xy_layout/_yz_layout).
-// xy: send chunk r = C0[:, :, xoff_r : xoff_r+xs_r] packed [zl][yl][xs_r];
-//     recv chunk r = [zl][yl][xs] from the rank owning y-slab r  ->  C1[z][x][r*yl + y]
-extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf)
+// ---- exchange buffers.  For the planes [z0, z0 + nzl) peer r's chunk is contiguous:
+// xy: send chunk r = C0[z0.., :, xoff_r : xoff_r+xs_r] packed [nzl][yl][xs_r] at s + xoff_r * yl * nzl;
+//     recv chunk r = [nzl][yl][xs] from the rank owning y-slab r  ->  C1[z][x][r*yl + y]
+// yz: send chunk r = C1[z0.., :, yoff_r : yoff_r+ys_r] packed [nzl][xs][ys_r] at s + yoff_r * xs * nzl;
+//     recv chunk r = [nzl][xs][ys] from the rank owning z-slab r  ->  C2[x][y][r*zl + z]
+// (whole solve: z0 = 0, nzl = zl; a group: z0 = m * zp, nzl = zp, s = the group's piece of the buffer)
+static int xy_c0(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
 {
-    X3D_REQUIRE(p && sendbuf, "null argument");
-    double2 *s = (double2 *)sendbuf;
-    long off = 0;
+    double2 *c0 = p->c0 + (size_t)z0 * p->yl * p->nxs;
     for (int r = 0; r < p->py; r++) {
         const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
-        if (int rc = permute(p->b, s + off, p->c0 + xo, xr, p->yl, p->zl, 1, xr, (long)xr * p->yl, 1, p->nxs,
-                             (long)p->nxs * p->yl))
-            return rc;
-        off += (long)xr * p->yl * p->zl;
+        double2 *ch = s + (long)xo * p->yl * nzl;
+        const int rc = pack ? permute(p->b, ch, c0 + xo, xr, p->yl, nzl, 1, xr, (long)xr * p->yl, 1, p->nxs,
+                                      (long)p->nxs * p->yl)
+                            : permute(p->b, c0 + xo, ch, xr, p->yl, nzl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
+                                      (long)xr * p->yl);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int xy_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+{
+    double2 *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
+    const long chunk = (long)p->xs * p->yl * nzl;
+    for (int r = 0; r < p->py; r++) {
+        const int rc = pack ? permute(p->b, s + r * chunk, c1 + (long)r * p->yl, p->xs, p->yl, nzl, 1, p->xs,
+                                      (long)p->xs * p->yl, p->ny, 1, (long)p->xs * p->ny)
+                            : permute(p->b, c1 + (long)r * p->yl, s + r * chunk, p->xs, p->yl, nzl, p->ny, 1,
+                                      (long)p->xs * p->ny, 1, p->xs, (long)p->xs * p->yl);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int yz_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+{
+    double2 *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
+    for (int r = 0; r < p->pz; r++) {
+        const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
+        double2 *ch = s + (long)yo * p->xs * nzl;
+        const int rc = pack ? permute(p->b, ch, c1 + yo, yr, p->xs, nzl, 1, yr, (long)yr * p->xs, 1, p->ny,
+                                      (long)p->ny * p->xs)
+                            : permute(p->b, c1 + yo, ch, yr, p->xs, nzl, 1, p->ny, (long)p->ny * p->xs, 1, yr,
+                                      (long)yr * p->xs);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int yz_c2(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+{
+    const long chunk = (long)p->ys * p->xs * nzl;
+    for (int r = 0; r < p->pz; r++) {
+        double2 *c2 = p->c2 + (long)r * p->zl + z0;
+        const int rc = pack ? permute(p->b, s + r * chunk, c2, p->ys, p->xs, nzl, 1, p->ys, (long)p->ys * p->xs,
+                                      p->nz, (long)p->ys * p->nz, 1)
+                            : permute(p->b, c2, s + r * chunk, p->ys, p->xs, nzl, p->nz, (long)p->ys * p->nz, 1, 1,
+                                      p->ys, (long)p->ys * p->xs);
+        if (rc) return rc;
     }
     return 0;
 }
 
+extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf)
+{
+    X3D_REQUIRE(p && sendbuf, "null argument");
+    return xy_c0(p, (double2 *)sendbuf, 0, p->zl, true);
+}
 extern "C" int x3d_pfft_unpack_xy(x3d_pfft *p, const double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    const double2 *s = (const double2 *)recvbuf;
-    const long chunk = (long)p->xs * p->yl * p->zl;
-    for (int r = 0; r < p->py; r++)  // src [zl][yl][xs] -> dst C1[z][x][r*yl + y]
-        if (int rc = permute(p->b, p->c1 + (long)r * p->yl, s + r * chunk, p->xs, p->yl, p->zl, p->ny, 1,
-                             (long)p->xs * p->ny, 1, p->xs, (long)p->xs * p->yl))
-            return rc;
-    return 0;
+    return xy_c1(p, (double2 *)recvbuf, 0, p->zl, false);
 }
-
 // inverse of the pair above: C1 -> chunks [zl][yl][xs] per y-slab owner -> C0 columns
 extern "C" int x3d_pfft_pack_yx(x3d_pfft *p, double *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    double2 *s = (double2 *)sendbuf;
-    const long chunk = (long)p->xs * p->yl * p->zl;
-    for (int r = 0; r < p->py; r++)
-        if (int rc = permute(p->b, s + r * chunk, p->c1 + (long)r * p->yl, p->xs, p->yl, p->zl, 1, p->xs,
-                             (long)p->xs * p->yl, p->ny, 1, (long)p->xs * p->ny))
-            return rc;
-    return 0;
+    return xy_c1(p, (double2 *)sendbuf, 0, p->zl, true);
 }
-
 extern "C" int x3d_pfft_unpack_yx(x3d_pfft *p, const double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    const double2 *s = (const double2 *)recvbuf;
-    long off = 0;
-    for (int r = 0; r < p->py; r++) {
-        const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
-        if (int rc = permute(p->b, p->c0 + xo, s + off, xr, p->yl, p->zl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
-                             (long)xr * p->yl))
-            return rc;
-        off += (long)xr * p->yl * p->zl;
-    }
-    return 0;
+    return xy_c0(p, (double2 *)recvbuf, 0, p->zl, false);
 }
-
-// yz: send chunk r = C1[:, :, yoff_r : yoff_r+ys_r] packed [zl][xs][ys_r];
-//     recv chunk r = [zl][xs][ys] from the rank owning z-slab r  ->  C2[x][y][r*zl + z]
 extern "C" int x3d_pfft_pack_yz(x3d_pfft *p, double *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    double2 *s = (double2 *)sendbuf;
-    long off = 0;
-    for (int r = 0; r < p->pz; r++) {
-        const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
-        if (int rc = permute(p->b, s + off, p->c1 + yo, yr, p->xs, p->zl, 1, yr, (long)yr * p->xs, 1, p->ny,
-                             (long)p->ny * p->xs))
-            return rc;
-        off += (long)yr * p->xs * p->zl;
-    }
-    return 0;
+    return yz_c1(p, (double2 *)sendbuf, 0, p->zl, true);
 }
-
 extern "C" int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    const double2 *s = (const double2 *)recvbuf;
-    const long chunk = (long)p->ys * p->xs * p->zl;
-    for (int r = 0; r < p->pz; r++)  // src [zl][xs][ys] -> dst C2[x][y][r*zl + z]
-        if (int rc = permute(p->b, p->c2 + (long)r * p->zl, s + r * chunk, p->ys, p->xs, p->zl, p->nz,
-                             (long)p->ys * p->nz, 1, 1, p->ys, (long)p->ys * p->xs))
-            return rc;
-    return 0;
+    return yz_c2(p, (double2 *)recvbuf, 0, p->zl, false);
 }
-
 extern "C" int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    double2 *s = (double2 *)sendbuf;
-    const long chunk = (long)p->ys * p->xs * p->zl;
-    for (int r = 0; r < p->pz; r++)
-        if (int rc = permute(p->b, s + r * chunk, p->c2 + (long)r * p->zl, p->ys, p->xs, p->zl, 1, p->ys,
-                             (long)p->ys * p->xs, p->nz, (long)p->ys * p->nz, 1))
-            return rc;
-    return 0;
+    return yz_c2(p, (double2 *)sendbuf, 0, p->zl, true);
 }
-
 extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    const double2 *s = (const double2 *)recvbuf;
-    long off = 0;
-    for (int r = 0; r < p->pz; r++) {
-        const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
-        if (int rc = permute(p->b, p->c1 + yo, s + off, yr, p->xs, p->zl, 1, p->ny, (long)p->ny * p->xs, 1, yr,
-                             (long)yr * p->xs))
-            return rc;
-        off += (long)yr * p->xs * p->zl;
-    }
+    return yz_c1(p, (double2 *)recvbuf, 0, p->zl, false);
+}
+
+// ---- the solve in groups of planes.  out = {parts, zp, then in complex elements: a group's piece of the xy send
+// buffer (peer r's chunk at xoff_r * yl * zp, xs_r * yl * zp long), of the xy receive buffer (peer r's chunk at
+// r * xs * yl * zp), of the yz send buffer (peer r's chunk at yoff_r * xs * zp, ys_r * xs * zp long), of the yz
+// receive buffer (peer r's chunk at r * ys * xs * zp)}; group m's piece starts at m times that
+extern "C" int x3d_pfft_part_layout(const x3d_pfft *p, long out[6])
+{
+    X3D_REQUIRE(p && out, "null argument");
+    out[0] = p->parts; out[1] = p->zp;
+    out[2] = (long)p->nxs * p->yl * p->zp;
+    out[3] = (long)p->py * p->xs * p->yl * p->zp;
+    out[4] = (long)p->ny * p->xs * p->zp;
+    out[5] = (long)p->pz * p->ys * p->xs * p->zp;
     return 0;
+}
+#define PFFT_PART(p, m, name) \
+    X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": group %d of %d", (m), (p) ? (p)->parts : 0)
+// forward: R2C x of the group, its xy chunks into send_xy
+extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const double *f_in, double *send_xy, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_fwd_a_part");
+    X3D_REQUIRE(f_in && send_xy, "null argument");
+    if (m == 0) X3D_LAZY_SYNC(p->b);
+    if (int rc = fwd_x(p, f_in, m, m + 1)) return rc;
+    return xy_c0(p, (double2 *)send_xy + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, true);
+}
+// received xy chunks -> y pencils, C2C y, yz chunks into send_yz
+extern "C" int x3d_pfft_fwd_b_part(x3d_pfft *p, const double *recv_xy, double *send_yz, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_fwd_b_part");
+    X3D_REQUIRE(recv_xy && send_yz, "null argument");
+    if (int rc = xy_c1(p, (double2 *)recv_xy + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, false))
+        return rc;
+    if (int rc = fft_y(p, 0, m, m + 1)) return rc;
+    return yz_c1(p, (double2 *)send_yz + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, true);
+}
+// received yz chunks -> the group's planes of the z pencils (x3d_pfft_fft_z once every group is in)
+extern "C" int x3d_pfft_fwd_c_part(x3d_pfft *p, const double *recv_yz, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_fwd_c_part");
+    X3D_REQUIRE(recv_yz, "null argument");
+    return yz_c2(p, (double2 *)recv_yz + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, false);
+}
+// backward, the same three in reverse (buffers: what was received forward is sent now)
+extern "C" int x3d_pfft_bwd_c_part(x3d_pfft *p, double *send_zy, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_bwd_c_part");
+    X3D_REQUIRE(send_zy, "null argument");
+    return yz_c2(p, (double2 *)send_zy + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, true);
+}
+extern "C" int x3d_pfft_bwd_b_part(x3d_pfft *p, const double *recv_zy, double *send_yx, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_bwd_b_part");
+    X3D_REQUIRE(recv_zy && send_yx, "null argument");
+    if (int rc = yz_c1(p, (double2 *)recv_zy + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, false)) return rc;
+    if (int rc = fft_y(p, 1, m, m + 1)) return rc;
+    return xy_c1(p, (double2 *)send_yx + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, true);
+}
+extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m)
+{
+    PFFT_PART(p, m, "x3d_pfft_bwd_a_part");
+    X3D_REQUIRE(recv_yx && f_out, "null argument");
+    if (int rc = xy_c0(p, (double2 *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
+    return bwd_x(p, f_out, m, m + 1);
 }
 
 extern "C" int x3d_pfft_postprocess_000(x3d_pfft *p)

@@ -222,6 +222,23 @@ class Comm:
                 recvs.append((recvbuf[r0:r0 + count], peer))
         return self._start(sends, recvs)
 
+    def ialltoallv(self, sendbuf, send_offs, send_counts, recvbuf, recv_offs, recv_counts, peers):
+        """ialltoall with a chunk per peer of its own offset and length (the pencil Poisson solver's groups of
+        planes: x modes / y rows are shared out unevenly)"""
+        sends, recvs = [], []
+        for s0, cs, r0, cr, peer in zip(send_offs, send_counts, recv_offs, recv_counts, peers):
+            if peer == self.rank and not self.self_via_nccl:
+                if cs != cr:
+                    raise ValueError("ialltoallv: the chunk a rank keeps has one length")
+                if cs and not (recvbuf.data_ptr() == sendbuf.data_ptr() and r0 == s0):
+                    recvbuf[r0:r0 + cr].copy_(sendbuf[s0:s0 + cs])
+            else:
+                if cs:
+                    sends.append((sendbuf[s0:s0 + cs], peer))
+                if cr:
+                    recvs.append((recvbuf[r0:r0 + cr], peer))
+        return self._start(sends, recvs)
+
     # ------------------------------------------------------------ scalars
     def allreduce(self, value, op="sum"):
         if self.size == 1:

@@ -482,7 +482,13 @@ class HipPencilPoissonFFT(HipPoissonFFT):
     libx3d2_hip.so (csrc/pfft.hip), two pencil transposes per direction as
     packed point-to-point exchanges inside the py and pz rank groups (the
     reference's CPU backend gets the same from 2decomp&FFT,
-    src/backend/omp/poisson_fft.f90:72-97)."""
+    src/backend/omp/poisson_fft.f90:72-97).
+
+    Overlap (poisson_000): the local z planes go through the stages before the z transform in `parts` groups
+    (X3D_PENCIL_PARTS, default: the library's choice, 4 where zl allows; 1 = the stages one after the other): the
+    transfers of a group -- xy exchange inside the py ranks, yz exchange inside the pz ranks, started on the
+    communication stream (parallel.Comm.ialltoallv) -- run beside the transforms and packing of the others.  The
+    hooks fft_forward / fft_postprocess_000 / fft_backward keep the reference's blocking order."""
 
     def _create(self):
         import torch
@@ -492,13 +498,17 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         self.py, self.pz = int(mesh.nproc_dir[1]), int(mesh.nproc_dir[2])
         self.ry, self.rz = int(mesh.nrank_dir[1]), int(mesh.nrank_dir[2])
         h = VP()
-        _lib.check(backend.lib.x3d_pfft_create(
+        _lib.check(backend.lib.x3d_pfft_create_parts(
             backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.py, self.pz,
-            self.ry, self.rz))
+            self.ry, self.rz, int(os.environ.get("X3D_PENCIL_PARTS", "0"))))
         self.h = h
         sz = (ctypes.c_long * 8)()
         _lib.check(backend.lib.x3d_pfft_sizes(h, sz))
         self.xs, self.xoff, self.ys, self.yoff, self.yl, self.zl, nxs, nmax = [int(v) for v in sz]
+        lay = (ctypes.c_long * 6)()
+        _lib.check(backend.lib.x3d_pfft_part_layout(h, lay))
+        self.parts, self.zp = int(lay[0]), int(lay[1])
+        self.piece = [2 * int(v) for v in lay[2:6]]  # doubles per group: xy send, xy recv, yz send, yz recv
         # this rank's spectral block, z fastest: waves[x, y, z]
         xsl, ysl = slice(self.xoff, self.xoff + self.xs), slice(self.yoff, self.yoff + self.ys)
         full = self.waves_block(xsl, ysl)                   # [z, y, x] of this rank's modes only
@@ -523,6 +533,17 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         self.cnt_yz_send = [c * y * self.xs * self.zl for y in y_sh]
         self.cnt_yz_recv = [c * self.ys * self.xs * self.zl] * self.pz
         self.poisson = self.poisson_000
+        if self.parts > 1:
+            # a second buffer pair: a group's xy and yz transfers are in flight at the same time
+            self.sendbuf2 = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
+            self.recvbuf2 = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
+            zp, cum = self.zp, lambda v: [sum(v[:i]) for i in range(len(v))]
+            self.g_xy_send = [c * x * self.yl * zp for x in x_sh]
+            self.g_xy_recv = [c * self.xs * self.yl * zp] * self.py
+            self.g_yz_send = [c * y * self.xs * zp for y in y_sh]
+            self.g_yz_recv = [c * self.ys * self.xs * zp] * self.pz
+            self.o_xy_send, self.o_xy_recv = cum(self.g_xy_send), cum(self.g_xy_recv)
+            self.o_yz_send, self.o_yz_recv = cum(self.g_yz_send), cum(self.g_yz_recv)
 
     def __del__(self):
         try:
@@ -560,6 +581,54 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         self._xchg(self.cnt_xy_recv, self.cnt_xy_send, self.peers_y)
         _lib.check(lib.x3d_pfft_unpack_yx(h, rb))
         _lib.check(lib.x3d_pfft_bwd_x(h, f_out.ptr))
+
+    def _ixchg(self, kind, m, sbuf, rbuf, back):
+        """group m's exchange, started now; kind 0: xy (py ranks), 1: yz (pz ranks); back: the receive layout is
+        sent and the send layout received (the inverse transposes)"""
+        if kind == 0:
+            so, sc, ro, rc, peers = self.o_xy_send, self.g_xy_send, self.o_xy_recv, self.g_xy_recv, self.peers_y
+            ps, pr = self.piece[0], self.piece[1]
+        else:
+            so, sc, ro, rc, peers = self.o_yz_send, self.g_yz_send, self.o_yz_recv, self.g_yz_recv, self.peers_z
+            ps, pr = self.piece[2], self.piece[3]
+        if back:
+            so, sc, ro, rc, ps, pr = ro, rc, so, sc, pr, ps
+        return self.backend.comm.ialltoallv(sbuf, [m * ps + o for o in so], sc, rbuf, [m * pr + o for o in ro], rc,
+                                            peers)
+
+    def poisson_000(self, f, temp=None):
+        """poisson_000 (src/poisson_fft.f90:216-226) with the groups of planes pipelined through the exchanges"""
+        if self.parts == 1:
+            return HipPoissonFFT.poisson_000(self, f, temp)
+        lib, h, P = self.backend.lib, self.h, range(self.parts)
+        s1, r1, s2, r2 = self.sendbuf, self.recvbuf, self.sendbuf2, self.recvbuf2
+        a = []
+        for m in P:
+            _lib.check(lib.x3d_pfft_fwd_a_part(h, f.ptr, s1.data_ptr(), m))
+            a.append(self._ixchg(0, m, s1, r1, False))
+        b = []
+        for m in P:
+            a[m].wait()
+            _lib.check(lib.x3d_pfft_fwd_b_part(h, r1.data_ptr(), s2.data_ptr(), m))
+            b.append(self._ixchg(1, m, s2, r2, False))
+        for m in P:
+            b[m].wait()
+            _lib.check(lib.x3d_pfft_fwd_c_part(h, r2.data_ptr(), m))
+        _lib.check(lib.x3d_pfft_fft_z(h, 0))
+        _lib.check(lib.x3d_pfft_postprocess_000(h))
+        _lib.check(lib.x3d_pfft_fft_z(h, 1))
+        b = []
+        for m in P:  # (r2 / s2 swap roles: what was received forward is sent now)
+            _lib.check(lib.x3d_pfft_bwd_c_part(h, r2.data_ptr(), m))
+            b.append(self._ixchg(1, m, r2, s2, True))
+        a = []
+        for m in P:
+            b[m].wait()
+            _lib.check(lib.x3d_pfft_bwd_b_part(h, s2.data_ptr(), r1.data_ptr(), m))
+            a.append(self._ixchg(0, m, r1, s1, True))
+        for m in P:
+            a[m].wait()
+            _lib.check(lib.x3d_pfft_bwd_a_part(h, s1.data_ptr(), f.ptr, m))
 
     def get_spectral(self):
         raise X3dError("get_spectral: single-rank test hook")
