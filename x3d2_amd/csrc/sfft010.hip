@@ -281,6 +281,7 @@ extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double 
 extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const double *f_in, int undo)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_sfft010_periodicity_y: bad argument");
+    X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     x3d_backend *b = p->b;
     dim3 grid((p->nx + 255) / 256, p->ny, p->zl);
     ProfScope ps(b, X3D_K_COPY);
@@ -298,6 +299,7 @@ extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const do
 extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
+    X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     if (!p->split_xy) {
         ProfScope ps(p->b, X3D_K_FFT, 1);
         X3D_FFT(hipfftSetStream(p->plan_xy_fw, p->b->stream));
@@ -378,6 +380,7 @@ extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
 extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out)
 {
     X3D_REQUIRE(p && sendbuf && f_out, "null argument");
+    X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     {
         ProfScope ps(p->b, X3D_K_PACK);
         const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
