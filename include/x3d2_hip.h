@@ -449,6 +449,25 @@ int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir);
 int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf);
 int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out);
 
+/* ---- z-first form of the 000 solve (fusion extension, 512^3 cells on one rank; csrc/zfirst.hip): the transform along z
+ * is done on the LDS tile of the z operator pairs that stand next to the solve in pressure_correction
+ * (src/solver.f90:693-739: the last pair of divergence_v2c, the first of gradient_c2v), x and y follow on a spectrum
+ * C[kz][y][x] whose half axis is z, the y transform, process_spectral_000 and the inverse y transform are one kernel:
+ * 6.5 passes over the spectrum instead of 10.5; equal to x3d_poisson_solve_000 up to rounding.
+ *   x3d_poisson_zfirst_ok        *ok = 1: on offer for this solver (X3D_NO_ZFIRST=1: never)
+ *   x3d_tds_pair_zfirst mode 0   A(in1) + B(in2) -> spectrum (z transformed); out1, out2 unused
+ *   x3d_poisson_zfirst_middle    x forward ; y forward + division + y inverse ; x inverse
+ *   x3d_tds_pair_zfirst mode 1   spectrum -> out1 = A(p), out2 = B(p); in1, in2 unused.  *done = 0: nothing was done
+ *   x3d_poisson_zfirst_forward / _backward: the z transform of a field in memory (stand-alone ends of the solve),
+ *   x3d_poisson_solve_000_zfirst = forward ; middle ; backward, in place */
+int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok);
+int x3d_poisson_zfirst_middle(x3d_poisson *p);
+int x3d_poisson_zfirst_forward(x3d_poisson *p, const double *f_in);
+int x3d_poisson_zfirst_backward(x3d_poisson *p, double *f_out);
+int x3d_poisson_solve_000_zfirst(x3d_poisson *p, double *f);
+int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2, const double *in1,
+                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
+
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
  * src/decomp/decomp_2decompfft.f90:42-48).  Only LOCAL stages live here; the

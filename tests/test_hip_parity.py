@@ -1333,3 +1333,53 @@ def test_pencil_solver_in_groups_of_planes_equals_hooks_single_rank_solver_and_o
     L, per = [float(v) for v in s.mesh.L], ["periodic"] * 2
     om = orc.Mesh(list(dims), [1, 1, 1], L, per, per, per)
     assert relerr(out[0], orc.Solver(om, poisson="FFT").poisson_fft.solve(f)) < 1e-11
+
+
+def test_z_first_poisson_solve_at_512_cubed(monkeypatch):
+    """csrc/zfirst.hip, BASELINE configs[2]'s solve: (i) the z transform as tile kernels of their own -- forward then
+    backward gives the field back times 512; (ii) poisson_000 through z ; x ; y + division + y ; x ; z equals the
+    x-first solve (1e-12 of the solution's maximum); (iii) a fused step with the z transforms inside the z operator
+    pairs of divergence_v2c / gradient_c2v (Solver.n_zfirst) equals the step with X3D_NO_ZFIRST=1 (1e-12); the oracle
+    comparison of the same step is test_fused_full_step_against_the_oracle_at_fast_path_sizes[512]"""
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import CELL, DIR_C
+    n = 512
+    case = make_tgv(n, fused=True)
+    s = case.solver
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert pf.zfirst_ok() and s._zfirst
+    rng = np.random.default_rng(12)
+    f = rng.standard_normal((n, n, n))
+    f -= f.mean()
+    p, q = al.get_block(DIR_C, CELL), al.get_block(DIR_C, CELL)
+    b.set_field_data(p, f, CELL)
+    pf.zfirst_forward(p)
+    q.fill(0.0)
+    pf.zfirst_backward(q)
+    assert relerr(b.get_field_data(q, CELL), 512.0 * f) < 1e-13
+    pf.solve_zfirst(p)
+    b.set_field_data(q, f, CELL)
+    pf.poisson_000(q, None)
+    ref = b.get_field_data(q, CELL)
+    assert relerr(b.get_field_data(p, CELL), ref) < 1e-12
+    al.release_block(p); al.release_block(q)
+    del f, ref
+    case.step(1)
+    assert s.n_zfirst == 3
+    got = [b.get_field_data(x) for x in (s.u, s.v, s.w)]
+    monkeypatch.setenv("X3D_NO_ZFIRST", "1")
+    import subprocess
+    import sys
+    import os
+    # (the switch is read once per process: the x-first step runs in a child)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from x3d2_amd import make_tgv; c = make_tgv(512, fused=True); "
+            "c.step(1); s = c.solver; assert s.n_zfirst == 0; "
+            "np.savez(sys.argv[1], *[s.backend.get_field_data(x) for x in (s.u, s.v, s.w)])"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = "/tmp/x3d_zfirst_ref_%d.npz" % os.getpid()
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(out)
+    for k, g in enumerate(got):
+        assert relerr(g, ref["arr_%d" % k]) < 1e-12
+    os.remove(out)

@@ -147,6 +147,12 @@ PROTOTYPES = {
     "x3d_sfft010_fft_z": (I, [VP, VP, I]),
     "x3d_sfft010_postprocess_010": (I, [VP, VP]),
     "x3d_sfft010_backward_local": (I, [VP, VP, VP]),
+    "x3d_poisson_zfirst_ok": (I, [VP, c_int_p]),
+    "x3d_poisson_zfirst_middle": (I, [VP]),
+    "x3d_poisson_zfirst_forward": (I, [VP, VP]),
+    "x3d_poisson_zfirst_backward": (I, [VP, VP]),
+    "x3d_poisson_solve_000_zfirst": (I, [VP, VP]),
+    "x3d_tds_pair_zfirst": (I, [VP, VP, I, VP, VP, VP, VP, VP, VP, c_int_p]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
     "x3d_pfft_destroy": (I, [VP]),
     "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

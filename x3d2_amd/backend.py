@@ -648,6 +648,18 @@ class HipBackend:
                                                      int(ny), ctypes.byref(flag)))
         return bool(flag.value)
 
+    def tds_pair_zfirst(self, mode, out1, out2, in1, in2, t_a, t_b):
+        """tds_pair along z next to the z-first 000 Poisson solve: mode 0 leaves its result A(in1) + B(in2) in the
+        solver's spectrum, z-transformed (out1, out2 unused); mode 1 takes its input p from there (in1, in2 unused);
+        False: not on offer for these pencils, nothing was done"""
+        if self._decomposed(DIR_Z) or self.poisson_fft is None or not hasattr(self.poisson_fft, "zfirst_ok"):
+            return False
+        flag = ctypes.c_int(0)
+        ptr = lambda f: f.ptr if f is not None else None
+        _lib.check(self.lib.x3d_tds_pair_zfirst(self.h, self.poisson_fft.h, int(mode), ptr(out1), ptr(out2), ptr(in1),
+                                                ptr(in2), t_a.handle, t_b.handle, ctypes.byref(flag)))
+        return bool(flag.value)
+
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""
         if not self._decomposed(direction):

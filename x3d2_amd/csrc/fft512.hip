@@ -13,96 +13,7 @@
 // of 6 + the 1.5 of a separate process_spectral_000).
 #include "common.h"
 
-#define FP 584  // LDS pitch per pencil in double2 (= 8 mod 16: the 8 modes of a row go to different banks)
-
-__device__ __forceinline__ double2 cmul(double2 a, double2 b)
-{
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-
-// 8-point DFT, decimation in frequency, natural-order output.  S = -1 forward, +1 backward.
-template <int S>
-__device__ __forceinline__ void fft8(double2 (&a)[8])
-{
-    const double h = 0.70710678118654752440;
-    double2 b[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        b[k] = cadd(a[k], a[k + 4]);
-        b[k + 4] = csub(a[k], a[k + 4]);
-    }
-    // b[4+k] *= W8^k: W8^1 = (1 + S i)/sqrt2, W8^2 = S i, W8^3 = (-1 + S i)/sqrt2
-    {
-        double2 t = b[5];
-        b[5] = make_double2(h * (t.x - S * t.y), h * (t.y + S * t.x));
-        t = b[6];
-        b[6] = make_double2(-S * t.y, S * t.x);
-        t = b[7];
-        b[7] = make_double2(h * (-t.x - S * t.y), h * (-t.y + S * t.x));
-    }
-#pragma unroll
-    for (int o = 0; o < 8; o += 4) {
-        const double2 c0 = cadd(b[o], b[o + 2]), c1 = cadd(b[o + 1], b[o + 3]), c2 = csub(b[o], b[o + 2]);
-        const double2 d = csub(b[o + 1], b[o + 3]);
-        const double2 c3 = make_double2(-S * d.y, S * d.x);  // * W4^1 = S i
-        const int r = o ? 1 : 0;
-        a[r] = cadd(c0, c1);
-        a[r + 4] = csub(c0, c1);
-        a[r + 2] = cadd(c2, c3);
-        a[r + 6] = csub(c2, c3);
-    }
-}
-
-// W512^e for the transform direction S; tw holds the first half, W^(e+256) = -W^e
-template <int S>
-__device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int e)
-{
-    double2 w = tw[e & 255];
-    const double sg = (e & 256) ? -1.0 : 1.0;
-    return make_double2(sg * w.x, (S > 0 ? -sg : sg) * w.y);
-}
-
-// one pencil per wave: in/out a[k] = point l + 64 k; pen = this wave's LDS region (FP double2)
-template <int S>
-__device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict__ pen,
-                                            const double2 *__restrict__ tw, int l)
-{
-    // pass A: over n1 (stride 64), twiddle W512^(l k1)
-    wave_lds_fence();  // (the caller's reads of this region, e.g. pass C of a previous transform, come first)
-    fft8<S>(a);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) {
-        a[k1] = cmul(a[k1], twiddle<S>(tw, l * k1));
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) pen[k1 * 72 + l] = a[k1];
-    // no block barrier: the region belongs to this wave alone and a wave's LDS operations execute in order
-    wave_lds_fence();
-    // pass B: lane (k1 = l >> 3, b = l & 7) takes T1[k1][b + 8 a], twiddle W64^(b q1) = W512^(8 b q1)
-    {
-        const int k1 = l >> 3, b = l & 7;
-#pragma unroll
-        for (int q = 0; q < 8; q++) a[q] = pen[k1 * 72 + b + 8 * q];
-        fft8<S>(a);
-#pragma unroll
-        for (int q1 = 1; q1 < 8; q1++) {
-            a[q1] = cmul(a[q1], twiddle<S>(tw, 8 * b * q1));
-        }
-#pragma unroll
-        for (int q1 = 0; q1 < 8; q1++) pen[(k1 * 8 + q1) * 9 + b] = a[q1];
-    }
-    // pass C: lane (k1 = l & 7, q1 = l >> 3) takes T2[k1][q1][b]; output X[k1 + 8 q1 + 64 q2] = X[l + 64 q2]
-    wave_lds_fence();
-    {
-        const int k1 = l & 7, q1 = l >> 3;
-#pragma unroll
-        for (int b = 0; b < 8; b++) a[b] = pen[(k1 * 8 + q1) * 9 + b];
-        fft8<S>(a);
-    }
-    wave_lds_fence();
-}
+#include "fft512_core.h"
 
 struct Spec000 {
     const double *waves, *ax, *bx, *ay, *by, *az, *bz;
@@ -111,7 +22,10 @@ struct Spec000 {
 };
 
 // MODE 0: forward, MODE 1: backward, MODE 2: forward + process_spectral_000 + backward (z axis only)
-template <int MODE, int NP>
+// ZH (MODE 2 with sp.rwT): the z-first spectrum C[kz][y][x] (csrc/zfft_tile.h) -- the transformed axis is y, the rows'
+// other index is kz (the half axis: never mirrored), the mode index is the FULL x axis (mirrored above nx / 2 like y and
+// z are in the reference's kernel), sp.rwT = [kz][x][y]
+template <int MODE, int NP, bool ZH = false>
 __global__ void __launch_bounds__(64 * NP, 16 / NP)
     k_fft512(double2 *c, const double2 *__restrict__ twg, long stride_axis, long stride_other, int nxs, Spec000 sp,
              double2 *xbuf, int ys, int ysc)
@@ -162,16 +76,23 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
         // between the two transforms (src/backend/omp/kernels/spectral_processing.f90:36-99, same operation order)
         const int i = i0 + w, j = blockIdx.y;
         if (i < nxs) {
-            const double ayj = sp.ay[j], byj = sp.by[j], axi = sp.ax[i], bxi = sp.bx[i];
+            // fixed over the pencil: the x mode and the rows' other index (y; ZH: kz); per point: the axis (z; ZH: y)
+            const double a_o = ZH ? sp.az[j] : sp.ay[j], b_o = ZH ? sp.bz[j] : sp.by[j];
+            const bool f_o = ZH ? false : (j + 1) > sp.ny / 2 + 1;
+            const double axi = sp.ax[i], bxi = sp.bx[i];
+            const bool fx = ZH && (i + 1) > sp.nx / 2 + 1;
+            const double *__restrict__ a_ax = ZH ? sp.ay : sp.az, *__restrict__ b_ax = ZH ? sp.by : sp.bz;
+            const int n_ax = ZH ? sp.ny : sp.nz;
             const double rn = 1.0 / sp.nx / sp.ny / sp.nz;
-            const bool fy = (j + 1) > sp.ny / 2 + 1;
             const double *__restrict__ rwp = sp.rwT + ((size_t)j * nxs + i) * 512;
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
                 const int k = l + 64 * kk;
                 double div_r = a[kk].x * rn, div_c = a[kk].y * rn;
-                const double azk = sp.az[k], bzk = sp.bz[k];
-                const bool fz = (k + 1) > sp.nz / 2 + 1;
+                const double a_k = a_ax[k], b_k = b_ax[k];
+                const bool f_k = (k + 1) > n_ax / 2 + 1;
+                const double azk = ZH ? a_o : a_k, bzk = ZH ? b_o : b_k, ayj = ZH ? a_k : a_o, byj = ZH ? b_k : b_o;
+                const bool fz = ZH ? f_o : f_k, fy = ZH ? f_k : f_o;
                 double tr, tc;
                 tr = div_r; tc = div_c;
                 div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
@@ -181,6 +102,7 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
                 if (fy) { div_r = -div_r; div_c = -div_c; }
                 tr = div_r; tc = div_c;
                 div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+                if (fx) { div_r = -div_r; div_c = -div_c; }
                 const double rw = rwp[k];
                 div_r = div_r * rw; div_c = div_c * rw;
                 tr = div_r; tc = div_c;
@@ -191,6 +113,7 @@ __global__ void __launch_bounds__(64 * NP, 16 / NP)
                 if (fy) { div_r = -div_r; div_c = -div_c; }
                 tr = div_r; tc = div_c;
                 div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+                if (fx) { div_r = -div_r; div_c = -div_c; }
                 a[kk] = make_double2(div_r, div_c);
             }
         }
@@ -459,6 +382,33 @@ static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_o
     X3D_HIP(hipGetLastError());
     return 0;
 }
+
+// the fused y pass of the z-first solve: C[nkz][512][px] (x: 512 modes), rwZ = [nkz][512 x][512 y]
+int x3d_fft512_run_zh(x3d_backend *b, double2 *c, long px, int nkz, const double *rwZ, const double *ab, int nx, int ny,
+                      int nz)
+{
+    X3D_REQUIRE(g_tw && nx == 512 && ny == 512 && nz == 512 && rwZ, "x3d_fft512_run_zh: 512^3 only");
+    const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    const Spec000 sp{nullptr, ax, bx, ay, by, az, bz, nx, ny, nz, rwZ};
+    static int np16 = -1;
+    if (np16 < 0) { const char *e = getenv("X3D_ZFIRST_Y16"); np16 = (e && e[0] == '1') ? 1 : 0; }
+    ProfScope ps(b, X3D_K_SPECTRAL, 1);
+    if (np16) {
+        const int lds = sizeof(double2) * (16 * FP + 256);
+        X3D_LDS_OPTIN(b, (k_fft512<2, 16, true>));
+        hipLaunchKernelGGL((k_fft512<2, 16, true>), dim3(512 / 16, nkz), dim3(1024), lds, b->stream, c, g_tw, px,
+                           (long)ny * px, 512, sp, nullptr, 1, 1);
+    } else {
+        const int lds = sizeof(double2) * (8 * FP + 256);
+        X3D_LDS_OPTIN(b, (k_fft512<2, 8, true>));
+        hipLaunchKernelGGL((k_fft512<2, 8, true>), dim3(512 / 8, nkz), dim3(512), lds, b->stream, c, g_tw, px,
+                           (long)ny * px, 512, sp, nullptr, 1, 1);
+    }
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+const double2 *x3d_fft512_twiddles() { return g_tw; }
 
 int x3d_fft512_init()
 {

@@ -12,29 +12,7 @@
 
 #include "common.h"
 
-struct x3d_poisson {
-    x3d_backend *b;
-    int nx, ny, nz;       // cell dims
-    int nxm, nxs;         // nxm = nx/2+1 modes per row; nxs = the row PITCH of every spectral-side array: nxm rounded
-                          // up to 8 complex numbers (128 B), so that the 128 / 256-byte row segments of the strided
-                          // y / z passes are line-aligned (dense rows of 257 made every segment straddle a third
-                          // 128-byte line: 1.44-1.6 x the compulsory fetch, round-1 PMC).  Pad columns hold zeros
-                          // (waves: ones) and are carried through every kernel; host arrays stay dense.
-    hipfftHandle plan_fw, plan_bw;
-    double2 *c;           // spectral workspace [nz][ny][nxs]
-    double *waves;        // [nz][ny][nxs]
-    double *rwT;          // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), for the fused z pass of fft512.hip
-    double *ab;           // ax bx ay by az bz
-    void *work;
-    size_t work_size;
-    // stretched y (010): factored pentadiagonal operators, [5][nz][n][nxs] each
-    int stretched, sym;   // sym: odd/even rows decoupled (centred, top-bottom); else one full system
-    double *lu[2];        // sym: odd, even; else lu[0] only
-    // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
-    int fast512;
-    int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels
-    hipfftHandle plan_x_fw, plan_x_bw;
-};
+#include "poisson_priv.h"
 
 int x3d_fft512_init();
 int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
@@ -201,7 +179,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
     if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
-    hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->rwT);
+    hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->rwT); hipFree(p->rwZ);
     hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
     return 0;

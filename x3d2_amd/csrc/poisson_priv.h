@@ -1,0 +1,31 @@
+// the spectral Poisson solver's state, shared by csrc/poisson.hip (000 / 010 / 100 / 110 solves) and csrc/zfirst.hip
+// (the z-first form of the 000 solve at 512^3)
+#pragma once
+#include <hipfft/hipfft.h>
+
+#include "common.h"
+
+struct x3d_poisson {
+    x3d_backend *b;
+    int nx, ny, nz;       // cell dims
+    int nxm, nxs;         // nxm = nx/2+1 modes per row; nxs = the row PITCH of every spectral-side array: nxm rounded
+                          // up to 8 complex numbers (128 B), so that the 128 / 256-byte row segments of the strided
+                          // y / z passes are line-aligned (dense rows of 257 made every segment straddle a third
+                          // 128-byte line: 1.44-1.6 x the compulsory fetch, round-1 PMC).  Pad columns hold zeros
+                          // (waves: ones) and are carried through every kernel; host arrays stay dense.
+    hipfftHandle plan_fw, plan_bw;
+    double2 *c;           // spectral workspace [nz][ny][nxs]
+    double *waves;        // [nz][ny][nxs]
+    double *rwT;          // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), for the fused z pass of fft512.hip
+    double *ab;           // ax bx ay by az bz
+    void *work;
+    size_t work_size;
+    // stretched y (010): factored pentadiagonal operators, [5][nz][n][nxs] each
+    int stretched, sym;   // sym: odd/even rows decoupled (centred, top-bottom); else one full system
+    double *lu[2];        // sym: odd, even; else lu[0] only
+    // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
+    int fast512;
+    int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels
+    hipfftHandle plan_x_fw, plan_x_bw;
+    double *rwZ;          // z-first solve: [nz/2+1][nx][ny] reciprocal wave numbers (built on first use, zfirst.hip)
+};

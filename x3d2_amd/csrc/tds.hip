@@ -20,6 +20,7 @@
 // differ in their pencil base address.  Loads are coalesced whenever lanes run
 // over x (dir Y/Z); dir X goes through LDS tile transposes (xdir.hip).
 #include "common.h"
+#include "zfft_tile.h"
 
 // ------------------------------------------------------------------ tables
 extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, int n_rhs, int move,
@@ -1337,6 +1338,33 @@ extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out
     const int rc = x3d_tds_pair_halo_fix(b, X3D_DIR_Z, mode, out1, out2, ta, tb, bnd_recv);
     b->pair_yperm = 0;
     return rc;
+}
+// the z pairs on either side of the z-first Poisson solve (csrc/zfirst.hip): mode 0 = the last pair of
+// divergence_v2c, its result leaves as the spectrum's z-transformed planes (out1 unused); mode 1 = the first pair of
+// gradient_c2v, its input arrives that way (in1 unused).  *done = 0: not on offer here, nothing was done
+struct x3d_poisson;
+int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok);
+int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done);
+extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2,
+                                   const double *in1, const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+                                   int *done)
+{
+    X3D_REQUIRE(b && poisson && ta && tb && done, "x3d_tds_pair_zfirst: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_zfirst: mode must be 0 or 1");
+    X3D_REQUIRE(mode == 0 ? (in1 && in2) : (out1 && out2 && out1 != out2), "x3d_tds_pair_zfirst: null argument");
+    *done = 0;
+    X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
+    if (int rc = check_len(b, ta, X3D_DIR_Z, "tds_pair_zfirst")) return rc;
+    if (int rc = check_len(b, tb, X3D_DIR_Z, "tds_pair_zfirst")) return rc;
+    ZfArg zf{};
+    bool ok = false;
+    if (int rc = x3d_zfirst_arg(poisson, &zf, &ok)) return rc;
+    if (!ok) return 0;
+    if (int rc = x3d_ytile_tds_pair_zf(b, mode, out1, out2, in1, in2, ta, tb, zf, &ok)) return rc;
+    *done = ok ? 1 : 0;
+    return 0;
 }
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)

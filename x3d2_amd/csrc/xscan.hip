@@ -41,6 +41,7 @@
 int npmax_of(const x3d_backend *b);
 
 #include "xscan_core.h"
+#include "zfft_tile.h"
 
 // HALO forms of the tile kernels (K3y): the reduced 2 x 2 systems of a decomposed direction couple to the
 // NEIGHBOUR ranks' boundary values (src/backend/omp/kernels/distributed.f90:186-206), which do not exist yet
@@ -1107,19 +1108,29 @@ __global__ void __launch_bounds__(1024)
 //   MODE 1:  out1 = A(in1), out2 = B(in1) (interpl_y(p), stagder_y(p):         3 instead of 2 + 2)
 // Same tile mechanics as k_ytile_transeq, same arithmetic as k_xscan_tds (MODE 0 adds the two results exactly
 // like the accumulating form: old + 1.0 * r).
-template <int Q, int MODE, bool NARROW, bool HALO>
+// ZF (z pencils of 512 rows, MODE 0 / 1, local form): the z-first Poisson solve's transform along z on the tile
+// (csrc/zfft_tile.h) -- MODE 0 stores the 257 x 16 modes of its result into the spectrum instead of out1, MODE 1 builds
+// its input tile from the spectrum instead of in1 (neither array is touched).  The tile area grows to the transforms'
+// 72 KB; the table sets are staged without their STC block, which tds_solve does not read.
+template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
-                     XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn)
+                     XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn,
+                     ZfArg zf)
 {
     extern __shared__ double lt[];
-    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
+    constexpr int LN = (ZF ? LT_NC(Q) : LT_N(Q)) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
+    static_assert(!ZF || (Q == 8 && MODE != 2 && !HALO), "the z-transforming forms: local pairs on 512-row pencils");
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = ta.TL[i];
         if (MODE != 2) lt[LN + i] = tb.TL[i];
     }
     const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
     double *tile = lt + (MODE == 2 ? 1 : 2) * LN;  // (a single operator stages one table set)
+    double2 *tws = reinterpret_cast<double2 *>(tile + ZF_AREA_DOUBLES);  // ZF: W512^k behind the 72 KB tile area
+    if (ZF && threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
+    const long kzs = (long)zf.ny * zf.px;
+    auto zf_row = [&](int tl) { return zf.c + (long)(tl / ntx) * zf.px + (long)(tl % ntx) * 16; };
     // HALO, MODE 0: no room for the next tile's rows next to the second input's (with them in flight across the
     // solves the kernel spills inside the tile loop, and every reload is an exposed memory latency: 1.40 ms
     // against 0.95 for the local form): this tile's rows are requested at its top instead
@@ -1204,9 +1215,11 @@ __global__ void __launch_bounds__(1024)
     };
     __syncthreads();
     double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
+    ZfRows spn{};  // ZF, MODE 1: next tile's modes instead
     double hnx = 0.0;
     if (!NOPREF && tile0 + (int)blockIdx.x < ntiles) {
-        gload(nxt, in1 + in1_off(tile0 + blockIdx.x));
+        if constexpr (ZF && MODE == 1) spn = zf_inverse_load(zf_row(tile0 + blockIdx.x), kzs);
+        else gload(nxt, in1 + in1_off(tile0 + blockIdx.x));
         if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
     }
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
@@ -1223,9 +1236,13 @@ __global__ void __launch_bounds__(1024)
             gload(nxt, in1 + in1_off(tl));
             if (threadIdx.x < 128) hnx = hload(tl, 0);
         }
-        to_tile(nxt);
-        if (HALO && threadIdx.x < 128) hal[threadIdx.x] = hnx;
-        __syncthreads();
+        if constexpr (ZF && MODE == 1) {
+            zf_inverse<TP>(tile, tws, spn, wave, lane);  // (ends behind a barrier)
+        } else {
+            to_tile(nxt);
+            if (HALO && threadIdx.x < 128) hal[threadIdx.x] = hnx;
+            __syncthreads();
+        }
         pick(b);
         if constexpr (HALO) window_from_body_halo<Q>(w, b, lane, hal + wave * 8);
         else window_from_body<Q>(w, b, lane);
@@ -1234,7 +1251,8 @@ __global__ void __launch_bounds__(1024)
         if (!NOPREF) {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) {
-                gload(nxt, in1 + in1_off(tn));
+                if constexpr (ZF && MODE == 1) spn = zf_inverse_load(zf_row(tn), kzs);
+                else gload(nxt, in1 + in1_off(tn));
                 if (HALO && threadIdx.x < 128) hnx = hload(tn, 0);
             }
         }
@@ -1252,7 +1270,8 @@ __global__ void __launch_bounds__(1024)
             for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
             put(ra);
             __syncthreads();
-            from_tile(out1 + tile_off_p(tl));
+            if constexpr (ZF) zf_forward<TP>(tile, tws, zf_row(tl), kzs, wave, lane);
+            else from_tile(out1 + tile_off_p(tl));
         } else if (MODE == 1) {
             put(ra);
             __syncthreads();
@@ -1629,7 +1648,8 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_>));                                                   \
         hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
-                           in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn);  \
+                           in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn,   \
+                           ZfArg{});                                                                            \
     } while (0)
 #define GOH(Q_, M_, N_) do { if (halo) GO(Q_, M_, N_, true); else GO(Q_, M_, N_, false); } while (0)
 #define GON(Q_, M_) do { if (narrow) GOH(Q_, M_, true); else GOH(Q_, M_, false); } while (0)
@@ -1638,6 +1658,40 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
 #undef GOM
 #undef GON
 #undef GOH
+#undef GO
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+// the z pairs next to the z-first Poisson solve (k_ytile_tds_pair<.., ZF>): mode 0: A(in1) + B(in2) -> spectrum,
+// mode 1: spectrum -> out1 = A(p), out2 = B(p); whole blocks of 512^3
+int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done)
+{
+    *done = false;
+    if (!use_ytile() || !xscan_ok(ta) || !xscan_ok(tb) || ta->tab.Q != 8 || tb->tab.Q != 8 || mode < 0 || mode > 1) return 0;
+    auto fast = [&](const x3d_tdsops *t) { return t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == t->n_tds; };
+    if (!fast(ta) || !fast(tb) || b->nz != 512 || b->nx % 16 != 0 || b->ny != zf.ny) return 0;
+    const size_t lds = sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
+    if (lds > 160 * 1024) return 0;
+    const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
+    const long pxy = (long)b->nxp * b->nyp;
+    const int ntx = b->nx / 16, ntiles = ntx * b->ny;
+    if (128 * pxy * 8 >= (1L << 32)) return 0;
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
+    const int blocks = ntiles > cap ? cap : ntiles;
+    const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
+#define GO(M_, N_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true>));                                           \
+        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
+                           out2, in1, in2, xop_of(ta), xop_of(tb), ntx, 0, ntiles, pxy, (long)b->nxp, th, 0, zf); \
+    } while (0)
+    if (mode == 0) { if (narrow) GO(0, true); else GO(0, false); }
+    else { if (narrow) GO(1, true); else GO(1, false); }
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;

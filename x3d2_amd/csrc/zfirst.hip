@@ -1,0 +1,222 @@
+// z-first form of the all-periodic spectral Poisson solve at 512^3 on one rank (poisson_000,
+// /root/reference/src/poisson_fft.f90:216-226: fft_forward ; fft_postprocess_000 ; fft_backward).
+//
+// The reference transforms x, y, z one after the other (src/backend/omp/poisson_fft.f90:89-97, 129-137), divides in
+// a pass of its own (src/backend/omp/kernels/spectral_processing.f90:7-106) and comes back: with every 1-D stage a
+// read and a write of the spectrum that is 10.5 passes even with the middle transform, the division and its inverse in
+// one kernel (csrc/fft512.hip).  The 3-D DFT does not care about the order.  Here
+//   z   real -> complex on the LDS tile of the kernel that produced the field (k_ytile_tds_pair<.., ZF>: the last z
+//       operator pair of divergence_v2c, src/vector_calculus.f90:142-246), or k_ztile_fft<true> on a field in memory
+//   x   complex, contiguous rows (k_c2c512_x)                                        2 passes
+//   y   forward + process_spectral_000 + inverse in one kernel (k_fft512<2, ., ZH>)  2.5 passes (reciprocal wave numbers)
+//   x   inverse                                                                      2 passes
+//   z   complex -> real on the tile of the kernel that consumes the pressure (the first z pair of gradient_c2v,
+//       :248-332), or k_ztile_fft<false>
+// = 6.5 passes.  Spectrum C[kz][y][x]: the HALF axis is z (kz = 0 .. 256), x and y are full; rows of ZH_PX complex
+// numbers; it lives in the solver's spectral workspace.  The spectral operation is the reference's sequence of
+// rotations, division and inverse rotations with the x index mirrored above nx / 2 the way y and z are there (the
+// rotations cancel pairwise: |b - i a| = 1, so any consistent choice gives the result up to rounding).
+#include <vector>
+
+#include "poisson_priv.h"
+#include "zfft_tile.h"
+
+#define ZH_PX 520  // row pitch of C in complex numbers (512 + 8: consecutive y rows do not share an HBM channel pattern)
+
+int x3d_fft512_init();
+const double2 *x3d_fft512_twiddles();
+int x3d_fft512_run_zh(x3d_backend *b, double2 *c, long px, int nkz, const double *rwZ, const double *ab, int nx, int ny,
+                      int nz);
+
+// rwZ[kz][x][y] = -1 / waves(min(x, nx - x), y, kz)  (0 where waves < 1e-16); waves = [nz][ny][nxs] (x: nx/2+1 modes)
+__global__ void __launch_bounds__(256)
+    k_zh_rw(double *__restrict__ rwZ, const double *__restrict__ waves, int nx, int ny, int nxs)
+{
+    __shared__ double t[32][33];
+    const int kz = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int x = x0 + tx, y = y0 + r, xm = x <= nx / 2 ? x : nx - x;
+        const double wv = waves[((size_t)kz * ny + y) * nxs + xm];
+        t[r][tx] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) rwZ[((size_t)kz * nx + x0 + r) * ny + y0 + tx] = t[tx][r];
+}
+
+// complex transform of contiguous rows of 512 (the x axis of C), one row per wave, in place
+template <int S>
+__global__ void __launch_bounds__(512)
+    k_c2c512_x(double2 *__restrict__ c, const double2 *__restrict__ twg, long nrows, long pitch)
+{
+    extern __shared__ double2 zx[];  // [8][FP] + 256 twiddles
+    double2 *__restrict__ tws = zx + 8 * FP;
+    if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
+    __syncthreads();
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double2 *__restrict__ pen = zx + w * FP;
+    long row = (long)blockIdx.x * 8 + w;
+    const long step = (long)gridDim.x * 8;
+    double2 a[8], nx8[8];
+    if (row < nrows) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) nx8[k] = c[row * pitch + l + 64 * k];
+    }
+    for (; row < nrows; row += step) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = nx8[k];
+        if (row + step < nrows) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nx8[k] = c[(row + step) * pitch + l + 64 * k];
+        }
+        fft512_wave<S>(a, pen, tws, l);
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[row * pitch + l + 64 * k] = a[k];
+    }
+}
+
+// the z transform of a field in memory, tile by tile (FWD: f -> C, else C -> f); the same tile mechanics as the fused
+// forms in k_ytile_tds_pair
+template <bool FWD>
+__global__ void __launch_bounds__(1024)
+    k_ztile_fft(double *__restrict__ f, ZfArg zf, int ntx, int ntiles, long prow, long pplane)
+{
+    extern __shared__ double zarea[];  // ZF_AREA_DOUBLES + 256 twiddles
+    constexpr int TP = 516;
+    double2 *__restrict__ tws = reinterpret_cast<double2 *>(zarea + ZF_AREA_DOUBLES);
+    if (threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const long kzs = (long)zf.ny * zf.px;
+    __syncthreads();
+    ZfRows v{};
+    if (!FWD && (int)blockIdx.x < ntiles)
+        v = zf_inverse_load(zf.c + (long)(blockIdx.x / ntx) * zf.px + (blockIdx.x % ntx) * 16, kzs);
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
+        double2 *__restrict__ crow = zf.c + (long)(tl / ntx) * zf.px + (tl % ntx) * 16;
+        if (FWD) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double2 g = *reinterpret_cast<const double2 *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc);
+                zarea[(2 * cc) * TP + cy + 128 * i] = g.x;
+                zarea[(2 * cc + 1) * TP + cy + 128 * i] = g.y;
+            }
+            __syncthreads();
+            zf_forward<TP>(zarea, tws, crow, kzs, wave, lane);
+        } else {
+            zf_inverse<TP>(zarea, tws, v, wave, lane);
+            const int tn = tl + gridDim.x;
+            if (tn < ntiles) v = zf_inverse_load(zf.c + (long)(tn / ntx) * zf.px + (tn % ntx) * 16, kzs);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<double2 *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc) =
+                    make_double2(zarea[(2 * cc) * TP + cy + 128 * i], zarea[(2 * cc + 1) * TP + cy + 128 * i]);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static bool zfirst_sizes(const x3d_poisson *p)
+{
+    const x3d_backend *b = p->b;
+    return p->fast512 && p->nx == 512 && p->ny == 512 && p->nz == 512 && b->nx == 512 && b->ny == 512 && b->nz == 512 &&
+           (size_t)257 * 512 * ZH_PX <= (size_t)p->nz * p->ny * p->nxs && !p->stretched;
+}
+
+// the z-first solve is on offer for this solver (X3D_NO_ZFIRST=1: never); builds the reciprocal wave numbers on first use
+int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
+{
+    *ok = false;
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("X3D_NO_ZFIRST"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off || !zfirst_sizes(p)) return 0;
+    if (!p->rwZ) {
+        X3D_HIP(hipMalloc(&p->rwZ, sizeof(double) * 257 * 512 * 512));
+        hipLaunchKernelGGL(k_zh_rw, dim3(16, 16, 257), dim3(256), 0, p->b->stream, p->rwZ, p->waves, p->nx, p->ny, p->nxs);
+        X3D_HIP(hipGetLastError());
+    }
+    if (out) *out = ZfArg{p->c, x3d_fft512_twiddles(), p->ny, (long)ZH_PX};
+    *ok = true;
+    return 0;
+}
+
+extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)
+{
+    X3D_REQUIRE(p && ok, "x3d_poisson_zfirst_ok: null argument");
+    bool o = false;
+    if (int rc = x3d_zfirst_arg(p, nullptr, &o)) return rc;
+    *ok = o ? 1 : 0;
+    return 0;
+}
+
+template <int S>
+static int c2c_x(x3d_poisson *p)
+{
+    const int lds = sizeof(double2) * (8 * FP + 256);
+    X3D_LDS_OPTIN(p->b, (k_c2c512_x<S>));
+    const long nrows = (long)257 * p->ny;
+    ProfScope ps(p->b, X3D_K_FFT, S < 0 ? 1 : 2);
+    hipLaunchKernelGGL((k_c2c512_x<S>), dim3(2048), dim3(512), lds, p->b->stream, p->c, x3d_fft512_twiddles(), nrows,
+                       (long)ZH_PX);
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// C (z already transformed) -> x forward ; y forward + process_spectral_000 + y inverse ; x inverse -> C
+extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
+{
+    X3D_REQUIRE(p, "x3d_poisson_zfirst_middle: null argument");
+    bool ok = false;
+    if (int rc = x3d_zfirst_arg(p, nullptr, &ok)) return rc;
+    X3D_REQUIRE(ok, "x3d_poisson_zfirst_middle: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
+    X3D_LAZY_EAGER(p->b);
+    if (int rc = c2c_x<-1>(p)) return rc;
+    if (int rc = x3d_fft512_run_zh(p->b, p->c, ZH_PX, 257, p->rwZ, p->ab, p->nx, p->ny, p->nz)) return rc;
+    return c2c_x<1>(p);
+}
+
+static int ztile(x3d_poisson *p, double *f, bool fwd)
+{
+    ZfArg zf;
+    bool ok = false;
+    if (int rc = x3d_zfirst_arg(p, &zf, &ok)) return rc;
+    X3D_REQUIRE(ok, "x3d_poisson_zfirst: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
+    x3d_backend *b = p->b;
+    const int ntx = b->nx / 16, ntiles = ntx * b->ny;
+    const size_t lds = sizeof(double) * (ZF_AREA_DOUBLES + 512);
+    const long pxy = (long)b->nxp * b->nyp;
+    ProfScope ps(b, X3D_K_FFT, 3);
+    if (fwd) {
+        X3D_LDS_OPTIN(b, (k_ztile_fft<true>));
+        hipLaunchKernelGGL((k_ztile_fft<true>), dim3(512), dim3(1024), lds, b->stream, f, zf, ntx, ntiles, pxy, (long)b->nxp);
+    } else {
+        X3D_LDS_OPTIN(b, (k_ztile_fft<false>));
+        hipLaunchKernelGGL((k_ztile_fft<false>), dim3(512), dim3(1024), lds, b->stream, f, zf, ntx, ntiles, pxy, (long)b->nxp);
+    }
+    X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// stand-alone ends of the z-first solve: f (cell data of a block) -> C, and back
+extern "C" int x3d_poisson_zfirst_forward(x3d_poisson *p, const double *f_in)
+{
+    X3D_REQUIRE(p && f_in, "x3d_poisson_zfirst_forward: null argument");
+    X3D_LAZY_SYNC(p->b);
+    return ztile(p, const_cast<double *>(f_in), true);
+}
+extern "C" int x3d_poisson_zfirst_backward(x3d_poisson *p, double *f_out)
+{
+    X3D_REQUIRE(p && f_out, "x3d_poisson_zfirst_backward: null argument");
+    X3D_LAZY_SYNC(p->b);
+    return ztile(p, f_out, false);
+}
+// poisson_000 through the z-first stages, in place (== x3d_poisson_solve_000 up to rounding)
+extern "C" int x3d_poisson_solve_000_zfirst(x3d_poisson *p, double *f)
+{
+    X3D_REQUIRE(p && f, "x3d_poisson_solve_000_zfirst: null argument");
+    if (int rc = x3d_poisson_zfirst_forward(p, f)) return rc;
+    if (int rc = x3d_poisson_zfirst_middle(p)) return rc;
+    return x3d_poisson_zfirst_backward(p, f);
+}

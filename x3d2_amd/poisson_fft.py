@@ -333,6 +333,28 @@ class HipPoissonFFT:
     def solve_poisson(self, f, temp):  # :206-214
         self.poisson(f, temp)
 
+    def zfirst_ok(self):
+        """the z-first form of poisson_000 is on offer (512^3 on one rank, csrc/zfirst.hip): the z operator pairs next
+        to the solve transform along z on their tiles (HipBackend.tds_pair_zfirst), zfirst_middle() does the rest"""
+        if type(self) is not HipPoissonFFT or self.case != "000" or getattr(self.backend, "lazy", False):
+            return False
+        ok = ctypes.c_int(0)
+        _lib.check(self.backend.lib.x3d_poisson_zfirst_ok(self.h, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def zfirst_middle(self):
+        _lib.check(self.backend.lib.x3d_poisson_zfirst_middle(self.h))
+
+    def zfirst_forward(self, f):
+        _lib.check(self.backend.lib.x3d_poisson_zfirst_forward(self.h, f.ptr))
+
+    def zfirst_backward(self, f):
+        _lib.check(self.backend.lib.x3d_poisson_zfirst_backward(self.h, f.ptr))
+
+    def solve_zfirst(self, f):
+        """poisson_000 through the z-first stages with the z transforms as kernels of their own, in place"""
+        _lib.check(self.backend.lib.x3d_poisson_solve_000_zfirst(self.h, f.ptr))
+
     def interleaved_rows(self):
         """> 0: poisson_010 without its two row-interleaving copies is on offer (solve_interleaved): the caller's z
         operators next to the solve write / read that many y rows at their interleaved positions themselves

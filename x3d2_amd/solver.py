@@ -101,6 +101,9 @@ class Solver:
         self.pending_grad = None
         self.rot_request, self.rot_applied = 0.0, False  # rotation forcing handed to transeq_x (transeq_fused)
         self.n_rot_fused = self.n_interleaved = 0        # how often those two fusions were taken (tests)
+        self.n_zfirst = 0                                # pressure corrections through the z-first 000 solve
+        pf = backend.poisson_fft if cfg.poisson_solver_type == "FFT" else None
+        self._zfirst = bool(pf is not None and getattr(pf, "zfirst_ok", lambda: False)())
         self.shift_request = None  # device scalar to add to u before transeq_x uses it (field_mean_shift)
         self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
@@ -321,6 +324,16 @@ class Solver:
         else:
             b.tds_pair(*jy[0], DIR_Y)
             b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
+            # 000 solve at 512^3: z-first -- the z pairs on either side transform along z on their tiles, the divergence
+            # and the pressure never exist as fields (csrc/zfirst.hip)
+            if self._zfirst and b.tds_pair_zfirst(0, None, None, a1, a2, z.interpl_v2p, z.stagder_v2p):
+                b.poisson_fft.zfirst_middle()
+                if not b.tds_pair_zfirst(1, t2, t3, None, None, z.interpl_p2v, z.stagder_p2v):
+                    raise X3dError("pressure_correction: the z-first pair served the divergence but not the gradient")
+                self.n_zfirst += 1
+                b.tds_pair(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
+                b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)                              # dpdz_sx
+                return self._finish_pressure_correction(u, v, w, (t1, t2, t3, a1, a2), defer_grad)
             if nil and b.tds_pair_yperm(0, t2, None, a1, a2, z.interpl_v2p, z.stagder_v2p, nil):
                 div = t2  # (t2, t3 are free after the y stage) rows interleaved
                 self.n_interleaved += 1
@@ -359,6 +372,12 @@ class Solver:
                 b.tds_pair(*jz[0], DIR_Z)
                 b.tds_pair(*jy[0], DIR_Y)
                 b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)
+        self._finish_pressure_correction(u, v, w, (t1, t2, t3, a1, a2), defer_grad)
+
+    def _finish_pressure_correction(self, u, v, w, blocks, defer_grad):
+        """velocity correction from (a1, a2, t1) = (dpdx_sx, dpdy_sx, dpdz_sx) -- the last x operators of gradient_c2v"""
+        al = self.backend.allocator
+        t1, t2, t3, a1, a2 = blocks
         if (defer_grad and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_DEFER_GRAD") != "1"
                 and self.nspecies == 0):
             # the next sub-step's transeq_x applies the correction inside its own kernel (transeq_fused)
