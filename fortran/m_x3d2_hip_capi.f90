@@ -46,7 +46,7 @@ module m_x3d2_hip_capi
     integer(c_int) function x3d_lazy_stats(b, out) bind(C, name='x3d_lazy_stats')
       import :: c_ptr, c_int, c_long
       type(c_ptr), value :: b
-      integer(c_long), intent(out) :: out(16)
+      integer(c_long), intent(out) :: out(24)
     end function
     ! allocator%release_block: the block's contents are dead until it is written again
     integer(c_int) function x3d_block_discard(b, f) bind(C, name='x3d_block_discard')

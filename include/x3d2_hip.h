@@ -533,13 +533,13 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m
  * [6] lincombs, [7] tds_solve_lincomb, [8] solve_000, [9] updates run out of place (buffer swaps), [10] copies made for
  * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [14] transeq_x launches that carry the velocity
  * correction of the pressure step (x3d_transeq_x_update), [13] calls dropped by the
- * rewrite, [15] extra buffers held. */
+ * rewrite, [15] extra buffers held, [16] pressure corrections through the z-first solve; [17..23] reserved (0). */
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);
 int x3d_lazy_sync(x3d_backend *b);
 int x3d_lazy_register_block(x3d_backend *b, double *f);
 int x3d_block_discard(x3d_backend *b, double *f);
-int x3d_lazy_stats(x3d_backend *b, long out[16]);
+int x3d_lazy_stats(x3d_backend *b, long out[24]);
 
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);

@@ -102,11 +102,11 @@ class HipBackend:
 
     LAZY_STATS = ("recorded", "launched", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
                   "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "transeq_upd",
-                  "extra_buffers")
+                  "extra_buffers", "zfirst")
 
     def lazy_stats(self):
         """counters of the deferred-execution layer (x3d_lazy_stats)"""
-        out = (ctypes.c_long * 16)()
+        out = (ctypes.c_long * 24)()
         _lib.check(self.lib.x3d_lazy_stats(self.h, out))
         return dict(zip(self.LAZY_STATS, [int(v) for v in out]))
 

@@ -16,6 +16,7 @@
 //   lincomb(y) ; tds_solve(du; y; A) along x                                -> x3d_tds_solve_lincomb
 //   fft_forward(f) ; fft_postprocess_000 ; fft_backward(f)                  -> x3d_poisson_solve_000
 //   u += s A(gu) ; v += s B(gv) ; w += s B(gw) ; transeq_x(...; u, v, w)    -> x3d_transeq_x_update
+//   pair_z(mode 0) -> d ; reorder ; solve_000 ; reorder ; pair_z(mode 1)     -> the z-first solve (csrc/zfirst.hip)
 // every one of which is the same arithmetic in the same order as the calls it replaces (tests/test_hip_lazy.py
 // compares bit for bit).  A temporary is dropped only when the queue shows it dead: overwritten, or released to the
 // allocator (x3d_block_discard, which the shim's release_block issues) before anything reads it.
@@ -34,7 +35,7 @@
 
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
-    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC
+    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST
 };
 
 struct LOp {
@@ -48,7 +49,7 @@ struct LOp {
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
-       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_N };
+       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_POOL_SLOT, ST_ZFIRST, ST_N };
 
 struct x3d_lazy {
     bool on = false, executing = false;
@@ -234,6 +235,7 @@ static int nin(const LOp &op)
     case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5)
     case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: return 1;
     case L_SPECIES: case L_SPECIES_ACC: return 2;  // uvw, spec
+    case L_ZFIRST: return 2;
     case L_PAIR: return op.mode == 0 ? 2 : 1;
     case L_LINCOMB: case L_TDS_LIN: return 1 + op.nterm;  // base, x...
     default: return 0;
@@ -246,6 +248,7 @@ static int nout(const LOp &op)
     case L_TRANSEQ_UPD: return 6;  // du, dv, dw written; u, v, w updated in place (and read)
     case L_PAIR: return op.mode == 0 ? 1 : 2;
     case L_TDS_LIN: return 2;  // du, y
+    case L_ZFIRST: return 2;
     case L_DEAD: case L_FFT_POST000: return 0;
     default: return 1;
     }
@@ -315,8 +318,13 @@ static std::vector<const double *> inputs_of(const LOp &op)
 }
 
 // ---------------------------------------------------------------- the peephole pass
-static void optimise(x3d_lazy *L)
+struct x3d_poisson;
+bool x3d_zfirst_on_offer(x3d_poisson *p);
+bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb);
+
+static void optimise(x3d_backend *b)
 {
+    x3d_lazy *L = b->lazy;
     std::vector<LOp> &q = L->q;
     const int n = (int)q.size();
     // (0) a release takes effect right behind the last operation that touches the block (nothing else sees it): buffers
@@ -543,6 +551,52 @@ static void optimise(x3d_lazy *L)
         q[p].kind = L_SOLVE000;
         q[a].kind = L_DEAD; q[c].kind = L_DEAD;
     }
+    // (9) d = A(i1) + B(i2) along z ; [p_temp = d] ; solve_000(p_temp) ; [pressure = p_temp] ; o1 = A'(pressure),
+    // o2 = B'(pressure) along z (pressure_correction, src/solver.f90:693-739 with poisson_fft :653-678): the z-first
+    // solve -- the divergence and the pressure are never stored.  Fused where the first pair stands (o1, o2 are fresh
+    // blocks); the fields in between must be dead behind their one reader
+    for (int p = 0; p < n && (L->rules & 256u); p++) {
+        if (q[p].kind != L_SOLVE000) continue;
+        x3d_poisson *pf = (x3d_poisson *)q[p].obj;
+        if (!x3d_zfirst_on_offer(pf)) continue;
+        // backwards: whatever wrote the solve's block, through at most one alias
+        double *h1 = q[p].o[0];
+        int kw = last_touch_before(q, p, h1), c1 = -1;
+        if (kw >= 0 && q[kw].kind == L_COPY && q[kw].o[0] == h1) { c1 = kw; kw = last_touch_before(q, c1, q[c1].in[0]); }
+        const double *h0 = c1 >= 0 ? q[c1].in[0] : h1;
+        if (kw < 0 || q[kw].kind != L_PAIR || q[kw].mode != 0 || q[kw].dir != X3D_DIR_Z || q[kw].o[0] != h0) continue;
+        // forwards: the one reader of the result, through at most one alias
+        int kr = first_touch_after(q, p, h1), c2 = -1;
+        const double *h2 = h1;
+        if (kr >= 0 && q[kr].kind == L_COPY && q[kr].in[0] == h1) { c2 = kr; h2 = q[c2].o[0]; kr = first_touch_after(q, c2, h2); }
+        if (kr < 0 || q[kr].kind != L_PAIR || q[kr].mode != 1 || q[kr].dir != X3D_DIR_Z || q[kr].in[0] != h2) continue;
+        if (!x3d_zfirst_pairs_ok(b, q[kw].t[0], q[kw].t[1]) || !x3d_zfirst_pairs_ok(b, q[kr].t[0], q[kr].t[1])) continue;
+        // every intermediate dies with its reader, nothing else looks at them
+        bool ok = dead_after(q, kr, h2) && (c2 < 0 || dead_after(q, c2, h1)) && (c1 < 0 || dead_after(q, c1, h0));
+        for (int m = kw + 1; m < kr && ok; m++) {
+            if (m == c1 || m == p || m == c2 || q[m].kind == L_DEAD) continue;
+            const bool inter = touch(q[m], h0) || touch(q[m], h1) || touch(q[m], h2);
+            if (inter && q[m].kind != L_DISCARD) ok = false;  // (their releases, hoisted behind the one reader, aside)
+        }
+        // the gradient's pair moves up to the divergence's: its outputs must be untouched in between (releases aside)
+        double *o1 = q[kr].o[0], *o2 = q[kr].o[1];
+        for (int m = kw + 1; m < kr && ok; m++) {
+            if (q[m].kind == L_DEAD || q[m].kind == L_DISCARD) continue;
+            if (touch(q[m], o1) || touch(q[m], o2)) ok = false;
+        }
+        ok = ok && o1 != q[kw].in[0] && o1 != q[kw].in[1] && o2 != q[kw].in[0] && o2 != q[kw].in[1] && o1 != o2;
+        if (!ok) continue;
+        LOp f;
+        f.kind = L_ZFIRST; f.dir = X3D_DIR_Z; f.obj = pf;
+        f.in[0] = q[kw].in[0]; f.in[1] = q[kw].in[1]; f.o[0] = o1; f.o[1] = o2;
+        f.t[0] = q[kw].t[0]; f.t[1] = q[kw].t[1]; f.t[2] = q[kr].t[0]; f.t[3] = q[kr].t[1];
+        for (int m = kw + 1; m < kr; m++)  // releases of the output blocks in between: the overwrite replaces them
+            if (q[m].kind == L_DISCARD && (q[m].o[0] == o1 || q[m].o[0] == o2)) q[m].kind = L_DEAD;
+        q[p].kind = L_DEAD; q[kr].kind = L_DEAD;
+        if (c1 >= 0) q[c1].kind = L_DEAD;
+        if (c2 >= 0) q[c2].kind = L_DEAD;
+        q[kw] = f;
+    }
 }
 
 // ---------------------------------------------------------------- execution
@@ -550,6 +604,10 @@ extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);
 extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p);
 extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);
 extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f);
+extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p);
+extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2,
+                                   const double *in1, const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+                                   int *done);
 
 static int exec(x3d_backend *b, const LOp &op)
 {
@@ -588,6 +646,7 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_TDS_LIN: L->stats[ST_TDS_LIN]++; break;
     case L_SOLVE000: L->stats[ST_SOLVE000]++; break;
     case L_TRANSEQ_UPD: L->stats[ST_TRANSEQ_UPD]++; break;
+    case L_ZFIRST: L->stats[ST_ZFIRST]++; break;
     default: break;
     }
     switch (op.kind) {
@@ -626,6 +685,30 @@ static int exec(x3d_backend *b, const LOp &op)
         if (int rc = x3d_tds_solve_acc(b, o[5], in[2], op.t[5], X3D_DIR_X, 1, op.s[1])) return rc;
         return x3d_transeq(b, X3D_DIR_X, o[0], o[1], o[2], o[3], o[4], o[5], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3]);
     }
+    case L_ZFIRST: {
+        x3d_poisson *pf = (x3d_poisson *)op.obj;
+        int done = 0;
+        if (int rc = x3d_tds_pair_zfirst(b, pf, 0, nullptr, nullptr, in[0], in[1], op.t[0], op.t[1], &done)) return rc;
+        if (done) {
+            if (int rc = x3d_poisson_zfirst_middle(pf)) return rc;
+            if (int rc = x3d_tds_pair_zfirst(b, pf, 1, o[0], o[1], nullptr, nullptr, op.t[2], op.t[3], &done)) return rc;
+            if (done) return 0;
+            x3d_set_error("x3d_lazy: the z-first pair served the divergence but not the gradient");
+            return 2;
+        }
+        // not served after all: the calls it stands for, through a scratch buffer
+        L->stats[ST_ZFIRST]--;
+        L->stats[ST_PAIR] += 2;
+        L->stats[ST_SOLVE000]++;
+        double *d = nullptr;
+        if (int rc = find_free(b, nullptr, &d)) return rc;
+        L->users[d] = 1;
+        int rc = x3d_tds_solve_pair(b, X3D_DIR_Z, 0, d, nullptr, in[0], in[1], op.t[0], op.t[1]);
+        if (!rc) rc = x3d_poisson_solve_000(pf, d);
+        if (!rc) rc = x3d_tds_solve_pair(b, X3D_DIR_Z, 1, o[0], o[1], d, nullptr, op.t[2], op.t[3]);
+        L->users[d] = 0;
+        return rc;
+    }
     default: x3d_set_error("x3d_lazy: unknown operation %d in the queue", op.kind); return 2;
     }
 }
@@ -635,7 +718,7 @@ static void dump(const x3d_lazy *L, const char *title)
 {
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
-                                  "solve000", "transeq_upd", "species", "species_acc"};
+                                  "solve000", "transeq_upd", "species", "species_acc", "zfirst"};
     std::unordered_map<const double *, int> id;
     auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
@@ -662,7 +745,7 @@ int x3d_lazy_flush_c(x3d_backend *b)
     static int dbg = -1;
     if (dbg < 0) { const char *e = getenv("X3D_LAZY_DUMP"); dbg = e && e[0] == '1'; }
     if (dbg) dump(L, "recorded");
-    optimise(L);
+    optimise(b);
     if (dbg) dump(L, "rewritten");
     L->executing = true;
     int rc = 0;
@@ -815,10 +898,10 @@ extern "C" int x3d_block_discard(x3d_backend *b, double *f)
     return push(b, op);
 }
 
-extern "C" int x3d_lazy_stats(x3d_backend *b, long out[16])
+extern "C" int x3d_lazy_stats(x3d_backend *b, long out[24])
 {
     X3D_REQUIRE(b && out, "x3d_lazy_stats: null argument");
-    for (int k = 0; k < 16; k++) out[k] = 0;
+    for (int k = 0; k < 24; k++) out[k] = 0;
     if (!b->lazy) return 0;
     for (int k = 0; k < ST_N; k++) out[k] = b->lazy->stats[k];
     out[15] = (long)b->lazy->pool.size();

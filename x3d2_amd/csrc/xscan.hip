@@ -1664,21 +1664,27 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     return 0;
 }
 
+// these two operators' z pair is served by the z-transforming form of the tile kernel on this backend's blocks
+bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb)
+{
+    if (!use_ytile() || !xscan_ok(ta) || !xscan_ok(tb) || ta->tab.Q != 8 || tb->tab.Q != 8) return false;
+    auto fast = [&](const x3d_tdsops *t) { return t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == t->n_tds; };
+    if (!fast(ta) || !fast(tb) || b->nz != 512 || b->nx % 16 != 0) return false;
+    if (sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512) > 160 * 1024) return false;
+    return 128 * (long)b->nxp * b->nyp * 8 < (1L << 32);
+}
+
 // the z pairs next to the z-first Poisson solve (k_ytile_tds_pair<.., ZF>): mode 0: A(in1) + B(in2) -> spectrum,
 // mode 1: spectrum -> out1 = A(p), out2 = B(p); whole blocks of 512^3
 int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
                           const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done)
 {
     *done = false;
-    if (!use_ytile() || !xscan_ok(ta) || !xscan_ok(tb) || ta->tab.Q != 8 || tb->tab.Q != 8 || mode < 0 || mode > 1) return 0;
-    auto fast = [&](const x3d_tdsops *t) { return t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == t->n_tds; };
-    if (!fast(ta) || !fast(tb) || b->nz != 512 || b->nx % 16 != 0 || b->ny != zf.ny) return 0;
+    if (mode < 0 || mode > 1 || b->ny != zf.ny || !x3d_zfirst_pairs_ok(b, ta, tb)) return 0;
     const size_t lds = sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
-    if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * b->ny;
-    if (128 * pxy * 8 >= (1L << 32)) return 0;
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;

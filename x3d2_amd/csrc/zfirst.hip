@@ -142,6 +142,13 @@ int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
     return 0;
 }
 
+// (for the deferred-execution layer's rewrite: no side effects)
+bool x3d_zfirst_on_offer(x3d_poisson *p)
+{
+    const char *e = getenv("X3D_NO_ZFIRST");
+    return p && !(e && e[0] == '1') && zfirst_sizes(p);
+}
+
 extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)
 {
     X3D_REQUIRE(p && ok, "x3d_poisson_zfirst_ok: null argument");
