@@ -466,7 +466,11 @@ def main():
                    "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}",
                    # N > 1: did the overlapped exchange path pass its first-use check against the ordered path
                    # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
-                   "overlap_self_check": getattr(comm, "self_check_result", None)},
+                   "overlap_self_check": getattr(comm, "self_check_result", None),
+                   # 000 solve at 512^3 on one rank: transforms ordered z, x, y with the z transforms inside the
+                   # neighbouring z operator pairs (csrc/zfirst.hip); counted pressure corrections of the fused driver
+                   "poisson_z_first": (int(case.solver.n_zfirst) if not args.lazy
+                                       else int(backend.lazy_stats().get("zfirst", 0)))},
         "dof_substeps_per_s": value * nstage,
         "roofline": roofline,
         "kernel_ms": prof,
