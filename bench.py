@@ -27,7 +27,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 def decomposition(n_gpus, kind="slabs"):
     """x stays whole (src/poisson_fft.f90:131).
-    "slabs" (default) = [1, 1, N], the layout the reference's GPU backend needs too
+    "yslabs" (the TGV default since round 3) = [1, N, 1]: like z slabs ONE transpose pair per solve among all ranks, and z
+    stays whole on every rank so that the z-first Poisson solve of the single-rank path applies (csrc/sfftz.hip;
+    one process standing in for a rank: 49.8 ms per step against 52.6 on z slabs, scratch/yslab_emul.sh).
+    "slabs" = [1, 1, N], the layout the reference's GPU backend needs too
     (src/backend/cuda/poisson_fft.f90:219): y stays local -- no y exchanges at all, and the Poisson solve needs
     ONE transpose pair, an all-to-all among ALL ranks in which every GPU drives all of its N - 1 point-to-point
     xGMI links at once.  "pencils" = [1, 2, N / 2] (BASELINE configs[3]'s 2-D split, [1, 2, 4] on 8 GPUs): half
@@ -37,6 +40,10 @@ def decomposition(n_gpus, kind="slabs"):
         raise SystemExit(f"--gpus {n_gpus}: supported 1, 2, 4, 8")
     if kind == "pencils" and n_gpus > 1:
         return (1, 2, n_gpus // 2)
+    if kind == "yslabs":
+        # y slabs [1, N, 1]: z stays whole on every rank, so the z-first Poisson solve of the single-rank path applies
+        # (csrc/sfftz.hip: 6.5 instead of 10.5 passes over the spectrum, the same ONE all-to-all pair)
+        return (1, n_gpus, 1)
     return (1, 1, n_gpus)
 
 
@@ -221,8 +228,9 @@ def main():
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
                     help="channel: BASELINE configs[4]-style wall-bounded case (1 GPU), dims from --dims")
     ap.add_argument("--dims", default="1024,257,512", help="channel vertex dims nx,ny,nz")
-    ap.add_argument("--decomp", default="slabs", choices=["slabs", "pencils"],
-                    help="N > 1: z slabs [1,1,N] (default) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
+    ap.add_argument("--decomp", default="auto", choices=["auto", "slabs", "yslabs", "pencils"],
+                    help="N > 1: y slabs [1,N,1] (TGV default: z-first Poisson solve), z slabs [1,1,N] (the channel case: "
+                         "y must stay whole) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     ap.add_argument("--lazy", action="store_true",
@@ -278,6 +286,8 @@ def main():
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
 
+    if args.decomp == "auto":
+        args.decomp = "yslabs" if (args.case == "tgv" and args.n == 512 and not args.lazy and not args.op_granular) else "slabs"
     nproc_dir = decomposition(args.gpus, args.decomp)
     dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()

@@ -468,6 +468,26 @@ int x3d_poisson_solve_000_zfirst(x3d_poisson *p, double *f);
 int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2, const double *in1,
                         const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
 
+/* ---- 000 solve on y slabs, z-first (csrc/sfftz.hip): nproc_dir = [1, py, 1], py = 1, 2, 4, 8, 512^3 cells per rank.
+ * z is whole on every rank: the z operator pairs next to the solve transform along z on their tiles as on one rank
+ * (x3d_sfftz_tds_pair = x3d_tds_pair_zfirst for this solver; x3d_sfftz_z: the same transform of a field in memory, for
+ * the hooks).  Exchange buffers (caller's, x3d_sfftz_sizes out[3] complex elements each): [part][peer][512][kzc][xs];
+ * part m = the kz planes out[4 + m] .. out[5 + m] - 1, its block starts at out[4 + m] * 512 * 512 complex elements, a
+ * peer's chunk in it is 512 * kzc * xs long.  Per part: x_forward -> all-to-all -> y_stage (y forward +
+ * process_spectral_000 + y inverse on the received block, in place) -> all-to-all back -> x_backward. */
+typedef struct x3d_sfftz x3d_sfftz;
+int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob_cell[3], int py, int ry, int parts);
+int x3d_sfftz_destroy(x3d_sfftz *p);
+int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16]); /* parts, xs, xoff, buffer elements, kz0[0..parts] */
+int x3d_sfftz_set_waves(x3d_sfftz *p, const double *rw, const double *ax, const double *bx, const double *ay,
+                        const double *by, const double *az, const double *bz);
+int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                       const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
+int x3d_sfftz_z(x3d_sfftz *p, double *f, int inverse);
+int x3d_sfftz_x_forward(x3d_sfftz *p, double *sendbuf, int part);
+int x3d_sfftz_y_stage(x3d_sfftz *p, double *recvbuf, int part, int what); /* what 0: all; 1 forward, 2 inverse, 3 division */
+int x3d_sfftz_x_backward(x3d_sfftz *p, const double *buf, int part);
+
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
  * src/decomp/decomp_2decompfft.f90:42-48).  Only LOCAL stages live here; the

@@ -52,7 +52,8 @@ def main():
     local = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
     extra = {"s%d" % i: s.backend.get_field_data(f) for i, f in enumerate(s.species)}
     np.savez(out + f".{rank}.npz", u=local[0], v=local[1], w=local[2], offset=np.array(s.mesh.n_offset),
-             rows=np.array(rows), halo_launches=np.array([s.backend.halo_launches]), **extra)
+             rows=np.array(rows), halo_launches=np.array([s.backend.halo_launches]),
+             n_zfirst=np.array([s.n_zfirst]), **extra)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -374,6 +374,7 @@ def _run_ranks(nproc_dir, dims, n_iters, fused, poisson, tmp_path, n_species=0, 
             full[oz:oz + a.shape[0], oy:oy + a.shape[1], ox:ox + a.shape[2]] = a
         g[name] = full
     g["halo_launches"] = int(parts[0]["halo_launches"][0])
+    g["n_zfirst"] = int(parts[0]["n_zfirst"][0]) if "n_zfirst" in parts[0] else 0
     return g, parts[0]["rows"]
 
 
@@ -401,6 +402,7 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
     from x3d2_amd import make_tgv
     g, rows = _run_ranks(nproc_dir, dims, 2, fused, "FFT", tmp_path)
     halo = g.pop("halo_launches")
+    g.pop("n_zfirst")
     local = [d // p for d, p in zip(dims, nproc_dir)]
     if any(p > 1 and n in (256, 512) for p, n in zip(nproc_dir[1:], local[1:])) and dims[0] % 16 == 0:
         assert halo > 0  # 256 / 512 rows per rank: the single-pass kernels must have taken the decomposed direction
@@ -446,6 +448,7 @@ def test_multirank_over_rccl_one_device_per_rank(nproc_dir, dims, tmp_path):
         pytest.skip(f"{nproc} devices needed, {torch.cuda.device_count()} visible")
     g, rows = _run_ranks(nproc_dir, dims, 2, True, "FFT", tmp_path, nccl=True)
     assert g.pop("halo_launches") > 0
+    g.pop("n_zfirst")
     ref = make_tgv(dims, fused=True)
     ref.solver.n_output = 2
     rrows = ref.run(n_iters=2)
@@ -1383,3 +1386,79 @@ def test_z_first_poisson_solve_at_512_cubed(monkeypatch):
     for k, g in enumerate(got):
         assert relerr(g, ref["arr_%d" % k]) < 1e-12
     os.remove(out)
+
+
+@pytest.mark.parametrize("parts", [1, 3])
+def test_y_slab_z_first_solver_in_one_process(parts, monkeypatch):
+    """csrc/sfftz.hip with py = 1 (the all-to-all = a copy to itself): the stand-alone z transform, x forward into
+    the exchange layout, the y stage of the received rows (k_fft512_peers<1, 8, YL>), x inverse out of the exchange layout,
+    z inverse -- against the single-rank x-first solver (1e-12); hooks in the reference's order == poisson_000;
+    forward ; backward = the field times 512^3.  1 and 3 groups of kz planes (257 = 86 + 85 + 86)"""
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import CELL, DIR_C
+    from x3d2_amd.poisson_fft import HipPoissonFFT, HipSlabPoissonFFTZ
+    n = 512
+    monkeypatch.setenv("X3D_NO_ZFIRST", "0")
+    single = make_tgv(n).solver
+    assert type(single.backend.poisson_fft) is HipPoissonFFT
+    rng = np.random.default_rng(21)
+    f = rng.standard_normal((n, n, n))
+    f -= f.mean()
+    q = single.backend.allocator.get_block(DIR_C, CELL)
+    single.backend.set_field_data(q, f, CELL)
+    single.backend.poisson_fft.poisson_000(q, None)
+    ref = single.backend.get_field_data(q, CELL)
+    del single, q
+    monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "yslab")
+    monkeypatch.setenv("X3D_SLAB_PARTS", str(parts))
+    s = make_tgv(n).solver
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert type(pf) is HipSlabPoissonFFTZ and pf.parts == parts
+    p = al.get_block(DIR_C, CELL)
+    out = []
+    for how in ("solve", "hooks", "roundtrip"):
+        p.fill(0.0)
+        b.set_field_data(p, f, CELL)
+        if how == "solve":
+            pf.poisson_000(p, None)
+        else:
+            pf.fft_forward(p)
+            if how == "hooks":
+                pf.fft_postprocess_000()
+            pf.fft_backward(p)
+        out.append(b.get_field_data(p, CELL))
+    assert relerr(out[0], ref) < 1e-12
+    assert relerr(out[1], out[0]) < 1e-13
+    assert relerr(out[2], f * float(n) ** 3) < 1e-12
+
+
+def test_y_slabs_with_the_z_first_solve_emulated_and_on_two_ranks(tmp_path, monkeypatch):
+    """y slabs of 512^3 cells (the N > 1 layout that keeps z whole, so that the z-first Poisson solve applies):
+    (i) the code path in ONE process (X3D_EMULATE_DECOMP=y: HALO y kernels + strip corrections, the y-slab solver with
+    py = 1): a fused step == the plain single-rank step (1e-11), every pressure correction through the z-first pairs;
+    (ii) two ranks sharing the GPU on 512 x 1024 x 512 against the single-rank run of that size"""
+    from x3d2_amd import make_tgv
+    ref = make_tgv(512, fused=True)
+    ref.step(1)
+    want = [ref.solver.backend.get_field_data(f) for f in (ref.solver.u, ref.solver.v, ref.solver.w)]
+    del ref
+    monkeypatch.setenv("X3D_EMULATE_DECOMP", "y")
+    monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "yslab")
+    emu = make_tgv(512, fused=True)
+    emu.step(1)
+    s = emu.solver
+    assert s.n_zfirst == 3 and s.backend.halo_launches > 0
+    for g, w in zip([s.backend.get_field_data(f) for f in (s.u, s.v, s.w)], want):
+        assert relerr(g, w) < 1e-11
+    del emu, s, want
+    monkeypatch.delenv("X3D_EMULATE_DECOMP")
+    monkeypatch.delenv("X3D_FORCE_PENCIL_FFT")
+    dims = (512, 1024, 512)
+    g, rows = _run_ranks((1, 2, 1), dims, 1, True, "FFT", tmp_path)
+    assert g.pop("halo_launches") > 0 and g.pop("n_zfirst") == 3
+    big = make_tgv(dims, fused=True)
+    big.solver.n_output = 1
+    big.run(n_iters=1)
+    b = big.solver.backend
+    for name, f in zip("uvw", (big.solver.u, big.solver.v, big.solver.w)):
+        assert relerr(g[name], b.get_field_data(f)) < 1e-11, name

@@ -153,6 +153,15 @@ PROTOTYPES = {
     "x3d_poisson_zfirst_backward": (I, [VP, VP]),
     "x3d_poisson_solve_000_zfirst": (I, [VP, VP]),
     "x3d_tds_pair_zfirst": (I, [VP, VP, I, VP, VP, VP, VP, VP, VP, c_int_p]),
+    "x3d_sfftz_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I]),
+    "x3d_sfftz_destroy": (I, [VP]),
+    "x3d_sfftz_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_sfftz_set_waves": (I, [VP] + [c_double_p] * 7),
+    "x3d_sfftz_tds_pair": (I, [VP, I, VP, VP, VP, VP, VP, VP, c_int_p]),
+    "x3d_sfftz_z": (I, [VP, VP, I]),
+    "x3d_sfftz_x_forward": (I, [VP, VP, I]),
+    "x3d_sfftz_y_stage": (I, [VP, VP, I, I]),
+    "x3d_sfftz_x_backward": (I, [VP, VP, I]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
     "x3d_pfft_destroy": (I, [VP]),
     "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

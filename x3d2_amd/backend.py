@@ -654,6 +654,8 @@ class HipBackend:
         False: not on offer for these pencils, nothing was done"""
         if self._decomposed(DIR_Z) or self.poisson_fft is None or not hasattr(self.poisson_fft, "zfirst_ok"):
             return False
+        if hasattr(self.poisson_fft, "zfirst_pair"):  # (the y-slab solver keeps the spectrum: csrc/sfftz.hip)
+            return self.poisson_fft.zfirst_pair(mode, out1, out2, in1, in2, t_a, t_b)
         flag = ctypes.c_int(0)
         ptr = lambda f: f.ptr if f is not None else None
         _lib.check(self.lib.x3d_tds_pair_zfirst(self.h, self.poisson_fft.h, int(mode), ptr(out1), ptr(out2), ptr(in1),

@@ -210,11 +210,17 @@ struct SpecSlab {
     const double *waves;  // this part's -1 / waves [W][nz], z fastest (0 where waves < 1e-16)
     const double *ax, *bx, *ay, *by, *az, *bz;
     int nx, ny, nz, nxs, yoff;
+    int xoff;  // YL only
 };
 
 // WV waves = N chunks x WV / N modes per workgroup.  N = 1 (the DFTs across the chunks done by k_radix_peers, or a
 // single rank): blockIdx.y = the chunk, whose points are the z modes chunk + nk * k2.
-template <int N, int WV>
+// YL (y slabs, z-first spectrum, csrc/sfftz.hip): the long axis is y (sp.ny points, sp.waves = [W][ny]), mode wl =
+// (kz - yoff) * nxs + (kx - xoff) with kz on the half axis (never mirrored) and kx on the full x axis (mirrored above
+// nx / 2 like y and z in the reference's kernel)
+// PART 0: everything; 1: the forward transform only; 2: the inverse only; 3: the division only -- the three hooks of the
+// reference's interface one by one; a transformed row (k1, k2) stands for the mode k1 + N k2 in all of them
+template <int N, int WV, bool YL = false, int PART = 0>
 __global__ void __launch_bounds__(64 * WV, 16 / WV)
     k_fft512_peers(double2 *R, const double2 *__restrict__ twg, long W, SpecSlab sp, int nk)
 {
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(64 * WV, 16 / WV)
     }
     __syncthreads();
     // ---- N-point DFTs across the chunks + twiddle W_M^(zl k1); thread -> (zl, mode)
-    if constexpr (N > 1) {
+    if constexpr (N > 1 && (PART == 0 || PART == 1)) {
 #pragma unroll
         for (int s_ = 0; s_ < 8 / N; s_++) {
             const int idx = tid + 64 * WV * s_, zl = idx & 511, mm = idx >> 9;
@@ -268,22 +274,29 @@ __global__ void __launch_bounds__(64 * WV, 16 / WV)
     double2 a[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) a[k] = pen[l + 64 * k];
-    fft512_wave<-1>(a, pen, tws, l);
-    {
+    if constexpr (PART == 0 || PART == 1) fft512_wave<-1>(a, pen, tws, l);
+    if constexpr (PART == 0 || PART == 3) {
         const int k1 = w / NM;
         const long wl = w0 + w % NM;
         if (wl < W) {
-            const int i = (int)(wl % sp.nxs), j = (int)(wl / sp.nxs) + sp.yoff;
-            const double ayj = sp.ay[j], byj = sp.by[j], axi = sp.ax[i], bxi = sp.bx[i];
-            const bool fy = (j + 1) > sp.ny / 2 + 1;
-            const double *__restrict__ wv = sp.waves + wl * sp.nz;
+            const int i = (int)(wl % sp.nxs) + (YL ? sp.xoff : 0), j = (int)(wl / sp.nxs) + sp.yoff;
+            // fixed over the pencil: the x mode and the second mode index (y; YL: kz); per point: the long axis (z; YL: y)
+            const double a_o = YL ? sp.az[j] : sp.ay[j], b_o = YL ? sp.bz[j] : sp.by[j];
+            const bool f_o = YL ? false : (j + 1) > sp.ny / 2 + 1;
+            const double axi = sp.ax[i], bxi = sp.bx[i];
+            const bool fx = YL && (i + 1) > sp.nx / 2 + 1;
+            const double *__restrict__ a_ax = YL ? sp.ay : sp.az, *__restrict__ b_ax = YL ? sp.by : sp.bz;
+            const int n_ax = YL ? sp.ny : sp.nz;
+            const double *__restrict__ wv = sp.waves + wl * n_ax;
             const double rn = 1.0 / sp.nx / sp.ny / sp.nz;
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
-                const int k = (N == 1 ? (int)blockIdx.y : k1) + nk * (l + 64 * kk);  // this point's z mode
+                const int k = (N == 1 ? (int)blockIdx.y : k1) + nk * (l + 64 * kk);  // this point's mode on the long axis
                 double div_r = a[kk].x * rn, div_c = a[kk].y * rn;
-                const double azk = sp.az[k], bzk = sp.bz[k];
-                const bool fz = (k + 1) > sp.nz / 2 + 1;
+                const double a_k = a_ax[k], b_k = b_ax[k];
+                const bool f_k = (k + 1) > n_ax / 2 + 1;
+                const double azk = YL ? a_o : a_k, bzk = YL ? b_o : b_k, ayj = YL ? a_k : a_o, byj = YL ? b_k : b_o;
+                const bool fz = YL ? f_o : f_k, fy = YL ? f_k : f_o;
                 double tr, tc;
                 tr = div_r; tc = div_c;
                 div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
@@ -293,6 +306,7 @@ __global__ void __launch_bounds__(64 * WV, 16 / WV)
                 if (fy) { div_r = -div_r; div_c = -div_c; }
                 tr = div_r; tc = div_c;
                 div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
+                if (fx) { div_r = -div_r; div_c = -div_c; }
                 const double rw = wv[k];  // (-1 / waves)
                 div_r = div_r * rw; div_c = div_c * rw;
                 tr = div_r; tc = div_c;
@@ -303,16 +317,17 @@ __global__ void __launch_bounds__(64 * WV, 16 / WV)
                 if (fy) { div_r = -div_r; div_c = -div_c; }
                 tr = div_r; tc = div_c;
                 div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
+                if (fx) { div_r = -div_r; div_c = -div_c; }
                 a[kk] = make_double2(div_r, div_c);
             }
         }
     }
-    fft512_wave<1>(a, pen, tws, l);
+    if constexpr (PART == 0 || PART == 2) fft512_wave<1>(a, pen, tws, l);
 #pragma unroll
     for (int k = 0; k < 8; k++) pen[l + 64 * k] = a[k];
     __syncthreads();
     // ---- inverse twiddle + inverse N-point DFTs across the chunks
-    if constexpr (N > 1) {
+    if constexpr (N > 1 && (PART == 0 || PART == 2)) {
 #pragma unroll
         for (int s_ = 0; s_ < 8 / N; s_++) {
             const int idx = tid + 64 * WV * s_, zl = idx & 511, mm = idx >> 9;
@@ -518,25 +533,21 @@ int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long
     return 0;
 }
 
-int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
-                     int nz, int nxs, int yoff, bool *done)
+template <bool YL, int PART = 0>
+static int peers_run(x3d_backend *b, double2 *R, long W, int npeers, const SpecSlab &sp)
 {
-    *done = false;
-    if (!g_tw || nz != 512 * npeers || !(npeers == 1 || npeers == 2 || npeers == 4 || npeers == 8)) return 0;
-    const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
-    const SpecSlab sp{waves, ax, bx, ay, by, az, bz, nx, ny, nz, nxs, yoff};
     // X3D_SLAB_Z_SPLIT=1: the DFTs across the chunks as streaming passes (k_radix_peers) around the chunk-local kernel
     // -- 6 passes with 128-byte row segments instead of 2 with 64- / 32-byte ones.  Measured per solve at 512^3 per
     // rank (scratch/zstage_bench.py; transposes + rocFFT + division: 2.07 - 2.26 ms): 1 rank 0.76, 2 ranks 0.96,
     // 4 ranks 1.07 (split 1.62), 8 ranks 1.47 (split 1.86; 1.88 before the XCD-aware numbering of the mode groups)
     static int split_env = -2;
     if (split_env == -2) { const char *e = getenv("X3D_SLAB_Z_SPLIT"); split_env = e ? atoi(e) : -1; }
-    const bool split = npeers > 1 && split_env > 0;
+    const bool split = npeers > 1 && split_env > 0 && PART == 0;
 #define LOCAL(NK_)                                                                                              \
     do {                                                                                                        \
         const int lds8 = sizeof(double2) * (8 * FP + 256);                                                      \
-        X3D_LDS_OPTIN(b, (k_fft512_peers<1, 8>));                                                               \
-        hipLaunchKernelGGL((k_fft512_peers<1, 8>), dim3((unsigned)((W + 7) / 8), NK_), dim3(512), lds8, b->stream, R, g_tw, W, \
+        X3D_LDS_OPTIN(b, (k_fft512_peers<1, 8, YL, PART>));                                                           \
+        hipLaunchKernelGGL((k_fft512_peers<1, 8, YL, PART>), dim3((unsigned)((W + 7) / 8), NK_), dim3(512), lds8, b->stream, R, g_tw, W, \
                            sp, NK_);                                                                            \
     } while (0)
 #define FUSED(N_)                                                                                               \
@@ -544,8 +555,8 @@ int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const doubl
         const int lds16 = sizeof(double2) * (16 * FP + 256);                                                    \
         const long nm = 16 / N_, sh = nm < 8 ? 8 * (8 / nm) : 1;                                                \
         const long ng = ((W + nm - 1) / nm + sh - 1) / sh * sh; /* (whole blocks of the XCD numbering) */       \
-        X3D_LDS_OPTIN(b, (k_fft512_peers<N_, 16>));                                                             \
-        hipLaunchKernelGGL((k_fft512_peers<N_, 16>), dim3((unsigned)ng), dim3(1024), lds16, b->stream, R, g_tw, W, sp, N_); \
+        X3D_LDS_OPTIN(b, (k_fft512_peers<N_, 16, YL, PART>));                                                         \
+        hipLaunchKernelGGL((k_fft512_peers<N_, 16, YL, PART>), dim3((unsigned)ng), dim3(1024), lds16, b->stream, R, g_tw, W, sp, N_); \
     } while (0)
 #define SPLIT(N_)                                                                                               \
     do {                                                                                                        \
@@ -562,6 +573,36 @@ int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const doubl
 #undef FUSED
 #undef LOCAL
     X3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
+                     int nz, int nxs, int yoff, bool *done)
+{
+    *done = false;
+    if (!g_tw || nz != 512 * npeers || !(npeers == 1 || npeers == 2 || npeers == 4 || npeers == 8)) return 0;
+    const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    const SpecSlab sp{waves, ax, bx, ay, by, az, bz, nx, ny, nz, nxs, yoff, 0};
+    if (int rc = peers_run<false>(b, R, W, npeers, sp)) return rc;
     *done = true;
     return 0;
+}
+
+// y slabs with the z-first spectrum (csrc/sfftz.hip): R = one part of the received array [512 npeers (y)][W], W modes =
+// [kzc][xs] with kz = kz0 + ..., kx = xoff + ...; rw = that part's [W][ny] reciprocal wave numbers (y fastest)
+int x3d_fft512_peers_yl(x3d_backend *b, double2 *R, long W, int npeers, const double *rw, const double *ab, int nx, int ny,
+                        int nz, int xs, int xoff, int kz0, int part)
+{
+    X3D_REQUIRE(g_tw && ny == 512 * npeers && (npeers == 1 || npeers == 2 || npeers == 4 || npeers == 8),
+                "x3d_fft512_peers_yl: %d chunks of 512 rows along y on 1, 2, 4 or 8 ranks", npeers);
+    const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    const SpecSlab sp{rw, ax, bx, ay, by, az, bz, nx, ny, nz, xs, kz0, xoff};
+    switch (part) {  // 0: forward + division + inverse; 1 / 2 / 3: forward / inverse / division alone (the hooks)
+    case 0: return peers_run<true, 0>(b, R, W, npeers, sp);
+    case 1: return peers_run<true, 1>(b, R, W, npeers, sp);
+    case 2: return peers_run<true, 2>(b, R, W, npeers, sp);
+    case 3: return peers_run<true, 3>(b, R, W, npeers, sp);
+    }
+    x3d_set_error("x3d_fft512_peers_yl: part must be 0 .. 3");
+    return 2;
 }

@@ -184,13 +184,10 @@ extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
     return c2c_x<1>(p);
 }
 
-static int ztile(x3d_poisson *p, double *f, bool fwd)
+// the z transform of a block's field, tile by tile (also for csrc/sfftz.hip)
+int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd)
 {
-    ZfArg zf;
-    bool ok = false;
-    if (int rc = x3d_zfirst_arg(p, &zf, &ok)) return rc;
-    X3D_REQUIRE(ok, "x3d_poisson_zfirst: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
-    x3d_backend *b = p->b;
+    X3D_REQUIRE(b->nz == 512 && b->nx % 16 == 0 && b->ny == zf.ny, "x3d_ztile_fft_run: 512-row z pencils");
     const int ntx = b->nx / 16, ntiles = ntx * b->ny;
     const size_t lds = sizeof(double) * (ZF_AREA_DOUBLES + 512);
     const long pxy = (long)b->nxp * b->nyp;
@@ -204,6 +201,15 @@ static int ztile(x3d_poisson *p, double *f, bool fwd)
     }
     X3D_HIP(hipGetLastError());
     return 0;
+}
+
+static int ztile(x3d_poisson *p, double *f, bool fwd)
+{
+    ZfArg zf;
+    bool ok = false;
+    if (int rc = x3d_zfirst_arg(p, &zf, &ok)) return rc;
+    X3D_REQUIRE(ok, "x3d_poisson_zfirst: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
+    return x3d_ztile_fft_run(p->b, f, zf, fwd);
 }
 
 // stand-alone ends of the z-first solve: f (cell data of a block) -> C, and back

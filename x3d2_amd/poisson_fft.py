@@ -158,10 +158,17 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs, xsl=None):
 def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
-    force = os.environ.get("X3D_FORCE_PENCIL_FFT")  # "1": generic pencil solver, "slab": slab solver
-    if mesh.nproc > 1 or force in ("1", "slab"):
+    force = os.environ.get("X3D_FORCE_PENCIL_FFT")  # "1": generic pencil solver, "slab": z slabs, "yslab": y slabs
+    if mesh.nproc > 1 or force in ("1", "slab", "yslab"):
         ny = int(mesh.get_global_dims(CELL)[1])
         pz = int(mesh.nproc_dir[2])
+        py = int(mesh.nproc_dir[1])
+        yslab_ok = (pz == 1 and py in (1, 2, 4, 8) and all(mesh.periodic_BC) and force in (None, "yslab")
+                    and tuple(int(v) for v in mesh.get_dims(CELL)) == (512, 512, 512)
+                    and os.environ.get("X3D_NO_YSLAB_FFT") != "1")
+        if yslab_ok and (py > 1 or force == "yslab"):
+            # y slabs of 512^3 cells: z is whole on every rank, the z-first solve applies (csrc/sfftz.hip)
+            return HipSlabPoissonFFTZ(backend, mesh, xdirps, ydirps, zdirps)
         if tuple(bool(x) for x in mesh.periodic_BC) == (True, False, True):
             # non-periodic y on z slabs (the channel case): the x modes are split over the ranks, y stays whole
             return HipSlabPoissonFFT010(backend, mesh, xdirps, ydirps, zdirps)
@@ -760,6 +767,128 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         for hnd in back:
             hnd.wait()
         _lib.check(lib.x3d_sfft_backward_local(h, self.sbuf.data_ptr(), f.ptr))
+
+    def get_spectral(self):
+        raise X3dError("get_spectral: single-rank test hook")
+
+    def set_spectral(self, c):
+        raise X3dError("set_spectral: single-rank test hook")
+
+
+class HipSlabPoissonFFTZ(HipPoissonFFT):
+    """000 solver over y slabs [1, py, 1] of 512^3 cells per rank, z-first (csrc/sfftz.hip): the z transforms ride on
+    the z operator pairs next to the solve (HipBackend.tds_pair_zfirst -> x3d_sfftz_tds_pair), this rank's spectrum
+    C[kz][yl][x] goes through x forward -> all-to-all of the x modes inside the py ranks -> y forward + division + y
+    inverse on the received rows, in one kernel -> all-to-all back -> x inverse, in `parts` groups of kz planes
+    (X3D_SLAB_PARTS; default 4 on several ranks) so that a group's y stage runs beside the transfers of the others.
+    The hooks (fft_forward ; fft_postprocess_000 ; fft_backward, src/poisson_fft.f90:45-62) keep their meaning one by
+    one: forward transforms z from the field in memory, x, exchanges, transforms y; postprocess divides; backward
+    returns (the y stage's kernel in its forward-only / division-only / inverse-only forms)."""
+
+    def _create(self):
+        import torch
+        backend, mesh = self.backend, self.mesh
+        self.py, self.ry = int(mesh.nproc_dir[1]), int(mesh.nrank_dir[1])
+        parts = int(os.environ.get("X3D_SLAB_PARTS", "0"))
+        h = VP()
+        _lib.check(backend.lib.x3d_sfftz_create(
+            backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob), self.py, self.ry, parts))
+        self.h = h
+        sz = (ctypes.c_long * 16)()
+        _lib.check(backend.lib.x3d_sfftz_sizes(h, sz))
+        self.parts, self.xs, self.xoff, nbuf = int(sz[0]), int(sz[1]), int(sz[2]), int(sz[3])
+        self.kz0 = [int(sz[4 + m]) for m in range(self.parts + 1)]
+        # -1 / waves of this rank's modes [kz][x][y] (y fastest): the half axis is z, x is the full axis (mirrored)
+        kx = np.arange(self.xoff, self.xoff + self.xs)
+        kxm = np.where(kx <= self.nx_glob // 2, kx, self.nx_glob - kx)
+        w = self.waves_block(kxm, slice(None), slice(0, self.nz_glob // 2 + 1))      # [kz, y, x]
+        with np.errstate(divide="ignore"):
+            rw = np.where(w < 1.e-16, 0.0, -1.0 / w)
+        rw = np.ascontiguousarray(np.transpose(rw, (0, 2, 1)), dtype=np.float64)     # [kz, x, y]
+        self._keep = [rw] + [np.ascontiguousarray(a, dtype=np.float64) for a in
+                             (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
+        _lib.check(backend.lib.x3d_sfftz_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
+        self._keep = None
+        self.sbuf = torch.zeros(2 * nbuf, dtype=torch.float64, device=backend.device)
+        alias = self.py == 1 and os.environ.get("X3D_EMULATE_ALIAS") == "1"
+        self.rbuf = self.sbuf if alias else torch.zeros(2 * nbuf, dtype=torch.float64, device=backend.device)
+        self.peers = [r for r in range(self.py)]  # rank = ry (x and z undivided)
+        self.poisson = self.poisson_000
+
+    def __del__(self):
+        try:
+            self.backend.lib.x3d_sfftz_destroy(self.h)
+        except Exception:
+            pass
+
+    def _xchg(self, m, sbuf, rbuf):
+        kzc = self.kz0[m + 1] - self.kz0[m]
+        return self.backend.comm.ialltoall(sbuf, rbuf, 2 * 512 * kzc * self.xs, self.peers,
+                                           send_off=2 * self.kz0[m] * 512 * 512, recv_off=2 * self.kz0[m] * 512 * 512)
+
+    # ---- the z-first interface of the fused driver (HipBackend.tds_pair_zfirst / Solver.pressure_correction_fused)
+    def zfirst_ok(self):
+        return not getattr(self.backend, "lazy", False)
+
+    def zfirst_pair(self, mode, out1, out2, in1, in2, t_a, t_b):
+        flag = ctypes.c_int(0)
+        ptr = lambda f: f.ptr if f is not None else None
+        _lib.check(self.backend.lib.x3d_sfftz_tds_pair(self.h, int(mode), ptr(out1), ptr(out2), ptr(in1), ptr(in2),
+                                                       t_a.handle, t_b.handle, ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def zfirst_middle(self):
+        """spectrum (z transformed) -> x ; exchange ; y + division + y ; exchange ; x, the groups of planes pipelined"""
+        lib, h, sb, rb = self.backend.lib, self.h, self.sbuf, self.rbuf
+        there = []
+        for m in range(self.parts):
+            _lib.check(lib.x3d_sfftz_x_forward(h, sb.data_ptr(), m))
+            there.append(self._xchg(m, sb, rb))
+        back = []
+        for m in range(self.parts):
+            there[m].wait()
+            _lib.check(lib.x3d_sfftz_y_stage(h, rb.data_ptr(), m, 0))
+            back.append(self._xchg(m, rb, sb))
+        for m in range(self.parts):
+            back[m].wait()
+            _lib.check(lib.x3d_sfftz_x_backward(h, sb.data_ptr(), m))
+
+    # ---- the reference's hooks
+    def fft_forward(self, f_in):
+        lib = self.backend.lib
+        _lib.check(lib.x3d_sfftz_z(self.h, f_in.ptr, 0))
+        hs = []
+        for m in range(self.parts):
+            _lib.check(lib.x3d_sfftz_x_forward(self.h, self.sbuf.data_ptr(), m))
+            hs.append(self._xchg(m, self.sbuf, self.rbuf))
+        for m in range(self.parts):
+            hs[m].wait()
+            _lib.check(lib.x3d_sfftz_y_stage(self.h, self.rbuf.data_ptr(), m, 1))
+
+    def fft_postprocess_000(self):
+        for m in range(self.parts):
+            _lib.check(self.backend.lib.x3d_sfftz_y_stage(self.h, self.rbuf.data_ptr(), m, 3))
+
+    def fft_backward(self, f_out):
+        lib = self.backend.lib
+        hs = []
+        for m in range(self.parts):
+            _lib.check(lib.x3d_sfftz_y_stage(self.h, self.rbuf.data_ptr(), m, 2))
+            hs.append(self._xchg(m, self.rbuf, self.sbuf))
+        for hnd in hs:
+            hnd.wait()
+        for m in range(self.parts):
+            _lib.check(lib.x3d_sfftz_x_backward(self.h, self.sbuf.data_ptr(), m))
+        _lib.check(lib.x3d_sfftz_z(self.h, f_out.ptr, 1))
+
+    def poisson_000(self, f, temp=None):
+        """poisson_000 (src/poisson_fft.f90:216-226) on a field in memory"""
+        _lib.check(self.backend.lib.x3d_sfftz_z(self.h, f.ptr, 0))
+        self.zfirst_middle()
+        _lib.check(self.backend.lib.x3d_sfftz_z(self.h, f.ptr, 1))
+
+    def interleaved_rows(self):
+        return 0
 
     def get_spectral(self):
         raise X3dError("get_spectral: single-rank test hook")

@@ -313,7 +313,15 @@ class Solver:
         nil = 0
         if self.cfg.poisson_solver_type == "FFT" and not b._decomposed(DIR_Y):
             nil = getattr(b.poisson_fft, "interleaved_rows", lambda: 0)()
-        if b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
+        if self._zfirst and b._decomposed(DIR_Y) and not b._decomposed(DIR_Z):
+            # y slabs: z is whole on this rank, the z-first solve applies as on one rank (csrc/sfftz.hip)
+            b.tds_jobs(DIR_Y, jy)
+            if self._zfirst_solve(a1, a2, t2, t3):
+                b.tds_jobs(DIR_Y, [(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v),   # p_sx, dpdy_sx
+                                   (2, t1, None, t3, None, y.interpl_p2v, None)])         # dpdz_sx
+                return self._finish_pressure_correction(u, v, w, (t1, t2, t3, a1, a2), defer_grad)
+            b.tds_jobs(DIR_Z, jz)
+        elif b._decomposed(DIR_Y) or b._decomposed(DIR_Z):
             # (z slabs: the halo form of the interleaving pair, t2 as above)
             nil = nil if nil and self._zpairs_interleave(nil, jz[0]) else 0
             if nil:
@@ -326,11 +334,7 @@ class Solver:
             b.tds_apply(a2, t3, y.interpl_v2p, DIR_Y)
             # 000 solve at 512^3: z-first -- the z pairs on either side transform along z on their tiles, the divergence
             # and the pressure never exist as fields (csrc/zfirst.hip)
-            if self._zfirst and b.tds_pair_zfirst(0, None, None, a1, a2, z.interpl_v2p, z.stagder_v2p):
-                b.poisson_fft.zfirst_middle()
-                if not b.tds_pair_zfirst(1, t2, t3, None, None, z.interpl_p2v, z.stagder_p2v):
-                    raise X3dError("pressure_correction: the z-first pair served the divergence but not the gradient")
-                self.n_zfirst += 1
+            if self._zfirst and self._zfirst_solve(a1, a2, t2, t3):
                 b.tds_pair(1, a1, a2, t2, None, y.interpl_p2v, y.stagder_p2v, DIR_Y)   # p_sx, dpdy_sx
                 b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)                              # dpdz_sx
                 return self._finish_pressure_correction(u, v, w, (t1, t2, t3, a1, a2), defer_grad)
@@ -373,6 +377,18 @@ class Solver:
                 b.tds_pair(*jy[0], DIR_Y)
                 b.tds_apply(t1, t3, y.interpl_p2v, DIR_Y)
         self._finish_pressure_correction(u, v, w, (t1, t2, t3, a1, a2), defer_grad)
+
+    def _zfirst_solve(self, a1, a2, t2, t3):
+        """div = interpl_z(a1) + stagder_z(a2) ; p = poisson(div) ; t2 = interpl_z(p), t3 = stagder_z(p) with the z
+        transforms of the 000 solve on the tiles of the two z pairs; False: not served for these operators, nothing done"""
+        b, z = self.backend, self.zdirps
+        if not b.tds_pair_zfirst(0, None, None, a1, a2, z.interpl_v2p, z.stagder_v2p):
+            return False
+        b.poisson_fft.zfirst_middle()
+        if not b.tds_pair_zfirst(1, t2, t3, None, None, z.interpl_p2v, z.stagder_p2v):
+            raise X3dError("pressure_correction: the z-first pair served the divergence but not the gradient")
+        self.n_zfirst += 1
+        return True
 
     def _finish_pressure_correction(self, u, v, w, blocks, defer_grad):
         """velocity correction from (a1, a2, t1) = (dpdx_sx, dpdy_sx, dpdz_sx) -- the last x operators of gradient_c2v"""
