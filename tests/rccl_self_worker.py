@@ -12,8 +12,12 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512  # 512: the full 512^3 bench size, else (64, 512, n)
-os.environ["X3D_EMULATE_DECOMP"] = "z"
-os.environ["X3D_FORCE_PENCIL_FFT"] = "slab"
+# second argument "y": the y-slab path (HALO y kernels, the z-first solver csrc/sfftz.hip with 4 groups of planes; 512^3)
+yslabs = len(sys.argv) > 2 and sys.argv[2] == "y"
+os.environ["X3D_EMULATE_DECOMP"] = "y" if yslabs else "z"
+os.environ["X3D_FORCE_PENCIL_FFT"] = "yslab" if yslabs else "slab"
+if yslabs:
+    os.environ["X3D_SLAB_PARTS"] = "4"
 from x3d2_amd import make_tgv  # noqa: E402
 from x3d2_amd.parallel import Comm  # noqa: E402
 

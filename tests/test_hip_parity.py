@@ -1292,6 +1292,20 @@ def test_emulated_multirank_path_with_every_exchange_through_rccl_to_self():
     assert r.returncode == 0 and "RCCL-TO-SELF OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert int(r.stdout.split("halo_launches=")[1].split()[0]) > 0
 
+
+def test_emulated_y_slab_path_with_every_exchange_through_rccl_to_self():
+    """the same for the y-slab path at 512^3 (bench.py --gpus N's TGV default): HALO y kernels with packed halo rows,
+    the z-first solver's all-to-all in 4 groups of kz planes on the communication stream -- bit for bit the device-copy
+    emulation, overlapped and ordered"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_worker.py"), "512", "y"],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL-TO-SELF OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert int(r.stdout.split("halo_launches=")[1].split()[0]) > 0
+
+
 @pytest.mark.parametrize("parts", [1, 3, 0])
 def test_pencil_solver_in_groups_of_planes_equals_hooks_single_rank_solver_and_oracle(parts, monkeypatch):
     """csrc/pfft.hip in one process (py = pz = 1: every exchange a copy to itself): poisson_000 with the local z
