@@ -1476,3 +1476,45 @@ def test_y_slabs_with_the_z_first_solve_emulated_and_on_two_ranks(tmp_path, monk
     b = big.solver.backend
     for name, f in zip("uvw", (big.solver.u, big.solver.v, big.solver.w)):
         assert relerr(g[name], b.get_field_data(f)) < 1e-11, name
+
+
+def test_round3_fusion_entry_points_decline_or_fail_loudly(monkeypatch):
+    """the z-first solve, the y-slab solver and the pencil solver's groups say so when they do not apply (the caller then
+    issues the plain sequence) and reject bad arguments like the other entry points"""
+    import ctypes
+    from x3d2_amd import _lib, make_tgv
+    from x3d2_amd.common import DIR_X, VERT, X3dError
+    s = make_tgv((64, 64, 64), fused=True).solver        # not 512^3: no z-first solve
+    b, al, z = s.backend, s.backend.allocator, s.zdirps
+    pf = b.poisson_fft
+    assert not pf.zfirst_ok() and not s._zfirst
+    f = [al.get_block(DIR_X, VERT) for _ in range(4)]
+    for x in f:
+        x.fill(1.0)
+    assert not b.tds_pair_zfirst(0, None, None, f[0], f[1], z.interpl_v2p, z.stagder_v2p)    # declined, nothing done
+    assert not b.tds_pair_zfirst(1, f[2], f[3], None, None, z.interpl_p2v, z.stagder_p2v)
+    assert all(np.all(b.get_field_data(x) == 1.0) for x in f)
+    with pytest.raises(X3dError):
+        pf.zfirst_middle()                                                                   # not on offer: loud
+    with pytest.raises(X3dError):
+        pf.solve_zfirst(f[0])
+    with pytest.raises(X3dError):
+        b.tds_pair_zfirst(0, None, None, f[0], None, z.interpl_v2p, z.stagder_v2p)           # mode 0 needs both inputs
+    with pytest.raises(X3dError):
+        b.tds_pair_zfirst(1, f[2], f[2], None, None, z.interpl_p2v, z.stagder_p2v)           # outputs alias
+    # the y-slab solver serves 512^3 cells per rank on 1, 2, 4 or 8 ranks
+    h = ctypes.c_void_p()
+    for nglob, py, ry in (((64, 64, 64), 1, 0), ((512, 1536, 512), 3, 0), ((512, 1024, 512), 2, 2)):
+        with pytest.raises(X3dError):
+            _lib.check(b.lib.x3d_sfftz_create(b.h, ctypes.byref(h), _lib.ints(*nglob), py, ry, 0))
+    # the pencil solver's groups: a group index outside [0, parts) is an error, not a silent no-op
+    monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "1")
+    monkeypatch.setenv("X3D_PENCIL_PARTS", "2")
+    p = make_tgv((32, 32, 32)).solver
+    pp = p.backend.poisson_fft
+    assert pp.parts == 2
+    blk = p.backend.allocator.get_block(DIR_X, VERT)
+    with pytest.raises(X3dError):
+        _lib.check(p.backend.lib.x3d_pfft_fwd_a_part(pp.h, blk.ptr, pp.sendbuf.data_ptr(), 2))
+    with pytest.raises(X3dError):
+        _lib.check(p.backend.lib.x3d_pfft_create_parts(p.backend.h, ctypes.byref(h), _lib.ints(32, 32, 32), 1, 1, 0, 0, 5))
