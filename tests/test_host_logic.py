@@ -220,6 +220,29 @@ for part in range(2):
     for p in range(2):
         want += [100 * p + 4 * r + 2 * part, 100 * p + 4 * r + 2 * part + 1]
 assert R.tolist() == [float(v) for v in want], (r, R, want)
+# chunks of uneven length at explicit offsets, as the pencil Poisson solver's groups of planes send them
+# (x modes / y rows are shared out unevenly): rank 0 keeps 1 and sends 3, rank 1 sends 2 and keeps 2
+S = torch.arange(10, dtype=torch.float64) + 100 * r
+R = torch.full((10,), -1.0, dtype=torch.float64)
+so, sc = ([5, 6], [1, 3]) if r == 0 else ([5, 7], [2, 2])
+ro, rc = ([0, 4], [1, 2]) if r == 0 else ([1, 6], [3, 2])
+c.ialltoallv(S, so, sc, R, ro, rc, [0, 1]).wait()
+want = [-1.0] * 10
+if r == 0:
+    want[0] = 5.0; want[4:6] = [105.0, 106.0]
+else:
+    want[1:4] = [6.0, 7.0, 8.0]; want[6:8] = [107.0, 108.0]
+assert R.tolist() == want, (r, R, want)
+# the y-slab solver's exchange: [part][peer][...] blocks, a part's block contiguous, equal chunks inside it
+S = torch.arange(12, dtype=torch.float64) + 100 * r      # 2 parts of 3 elements per peer
+R = torch.zeros(12, dtype=torch.float64)
+for part in range(2):
+    c.ialltoall(S, R, 3, [0, 1], send_off=6 * part, recv_off=6 * part).wait()
+want = []
+for part in range(2):
+    for p in range(2):
+        want += [100 * p + 6 * part + 3 * r + k for k in range(3)]
+assert R.tolist() == [float(v) for v in want], (r, R, want)
 rs2, re2 = torch.zeros(4), torch.zeros(4)
 c.isendrecv([(ss, se, rs2, re2)], prev, nxt).wait()
 assert torch.equal(rs2, rs) and torch.equal(re2, re)
