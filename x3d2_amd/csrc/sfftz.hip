@@ -16,8 +16,6 @@
 // 6.5 passes over the spectrum per solve and ONE all-to-all pair, like the z-slab solver (csrc/sfft.hip) -- which
 // needs 10.5 passes because there the decomposed axis is the one the neighbouring operators work along.
 // Exchange buffers: [part][peer][yl = 512][kzc_part][xs] complex numbers, a part's block contiguous.
-#include <vector>
-
 #include "zfft_tile.h"
 
 #define SZ_PX 520

@@ -16,8 +16,6 @@
 // numbers; it lives in the solver's spectral workspace.  The spectral operation is the reference's sequence of
 // rotations, division and inverse rotations with the x index mirrored above nx / 2 the way y and z are there (the
 // rotations cancel pairwise: |b - i a| = 1, so any consistent choice gives the result up to rounding).
-#include <vector>
-
 #include "poisson_priv.h"
 #include "zfft_tile.h"
 
