@@ -399,12 +399,14 @@ static int launch512(x3d_backend *b, double2 *c, long stride_axis, long stride_o
 }
 
 // the fused y pass of the z-first solve: C[nkz][512][px] (x: 512 modes), rwZ = [nkz][512 x][512 y]
-int x3d_fft512_run_zh(x3d_backend *b, double2 *c, long px, int nkz, const double *rwZ, const double *ab, int nx, int ny,
-                      int nz)
+int x3d_fft512_run_zh(x3d_backend *b, double2 *c, long px, int kz0, int nkz, const double *rwZ, const double *ab, int nx,
+                      int ny, int nz)
 {
     X3D_REQUIRE(g_tw && nx == 512 && ny == 512 && nz == 512 && rwZ, "x3d_fft512_run_zh: 512^3 only");
     const double *ax = ab, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
-    const Spec000 sp{nullptr, ax, bx, ay, by, az, bz, nx, ny, nz, rwZ};
+    // the planes kz0 .. kz0 + nkz - 1 (the kernel numbers its rows' other index from 0)
+    c += (long)kz0 * ny * px;
+    const Spec000 sp{nullptr, ax, bx, ay, by, az + kz0, bz + kz0, nx, ny, nz, rwZ + (size_t)kz0 * 512 * 512};
     static int np16 = -1;
     if (np16 < 0) { const char *e = getenv("X3D_ZFIRST_Y16"); np16 = (e && e[0] == '1') ? 1 : 0; }
     ProfScope ps(b, X3D_K_SPECTRAL, 1);
