@@ -1518,3 +1518,40 @@ def test_round3_fusion_entry_points_decline_or_fail_loudly(monkeypatch):
         _lib.check(p.backend.lib.x3d_pfft_fwd_a_part(pp.h, blk.ptr, pp.sendbuf.data_ptr(), 2))
     with pytest.raises(X3dError):
         _lib.check(p.backend.lib.x3d_pfft_create_parts(p.backend.h, ctypes.byref(h), _lib.ints(32, 32, 32), 1, 1, 0, 0, 5))
+
+
+@pytest.mark.parametrize("interpl", ["classic", "optimised"])
+def test_z_transforming_pair_kernels_against_pair_kernel_plus_stand_alone_transform(interpl):
+    """k_ytile_tds_pair<8, MODE, NARROW, false, ZF> by itself, 512^3: mode 0 (pair -> spectrum) followed by the stand-alone
+    inverse z transform == 512 x the plain pair's result; the stand-alone forward transform followed by mode 1
+    (spectrum -> pair) == 512 x the plain pair on the field.  'optimised' interpolation has a 7-point right-hand side: the
+    kernels' wide-stencil (NARROW = false) instantiations"""
+    import torch
+    from x3d2_amd import Mesh
+    from x3d2_amd.backend import HipBackend
+    from x3d2_amd.common import CELL, DIR_X, DIR_Z, VERT
+    from x3d2_amd.solver import Solver, SolverConfig
+    twopi = 6.283185307179586
+    per = ("periodic",) * 2
+    mesh = Mesh((512, 512, 512), (1, 1, 1), (twopi,) * 3, per, per, per)
+    s = Solver(HipBackend(mesh), mesh, SolverConfig(interpl_scheme=interpl, fused=True))
+    b, al, z, pf = s.backend, s.backend.allocator, s.zdirps, s.backend.poisson_fft
+    assert pf.zfirst_ok()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    i1, i2, ref, got, o1, o2, r1, r2 = (al.get_block(DIR_X, VERT) for _ in range(8))
+    for f in (i1, i2):
+        f.data.copy_(torch.randn(tuple(f.data.shape), generator=g, dtype=torch.float64).to(f.data.device))
+    for f in (ref, got, o1, o2, r1, r2):
+        f.fill(0.0)
+    # mode 0
+    b.tds_pair(0, ref, None, i1, i2, z.interpl_v2p, z.stagder_v2p, DIR_Z)
+    assert b.tds_pair_zfirst(0, None, None, i1, i2, z.interpl_v2p, z.stagder_v2p)
+    pf.zfirst_backward(got)
+    a, w = b.get_field_data(got, VERT), b.get_field_data(ref, VERT)
+    assert relerr(a, 512.0 * w) < 1e-13
+    # mode 1 on the same field (ref = a field whose z transform is in the spectrum after zfirst_forward)
+    b.tds_pair(1, r1, r2, ref, None, z.interpl_p2v, z.stagder_p2v, DIR_Z)
+    pf.zfirst_forward(ref)
+    assert b.tds_pair_zfirst(1, o1, o2, None, None, z.interpl_p2v, z.stagder_p2v)
+    for x, y in ((o1, r1), (o2, r2)):
+        assert relerr(b.get_field_data(x, VERT), 512.0 * b.get_field_data(y, VERT)) < 1e-13
