@@ -47,6 +47,12 @@ def decomposition(n_gpus, kind="slabs"):
     return (1, 1, n_gpus)
 
 
+def auto_decomposition(case, n, lazy=False, op_granular=False):
+    """--decomp auto: y slabs where the z-first Poisson solve applies to them (the fused TGV driver at 512^3 per GPU),
+    z slabs otherwise (the channel's wall-normal y must stay whole; other sizes use the z-slab / pencil solvers)"""
+    return "yslabs" if (case == "tgv" and n == 512 and not lazy and not op_granular) else "slabs"
+
+
 def cpu_baseline(n, steps, threads):
     """the port baseline in a FRESH child process whose environment carries OMP_NUM_THREADS / OMP_PLACES /
     OMP_PROC_BIND: libgomp reads them once, when it is loaded -- and in this process torch has loaded it long before
@@ -287,7 +293,7 @@ def main():
     from x3d2_amd.parallel import Comm
 
     if args.decomp == "auto":
-        args.decomp = "yslabs" if (args.case == "tgv" and args.n == 512 and not args.lazy and not args.op_granular) else "slabs"
+        args.decomp = auto_decomposition(args.case, args.n, args.lazy, args.op_granular)
     nproc_dir = decomposition(args.gpus, args.decomp)
     dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()

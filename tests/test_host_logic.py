@@ -397,3 +397,23 @@ def test_stretching_matrix_column_ranges_equal_the_full_matrices(name):
             stretching_matrix(part, m, xd, yd, zd, *part._es, xsl=sl)
             for nm in names:
                 assert np.array_equal(getattr(part, nm), getattr(full, nm)[..., sl]), (nm, nparts, r)
+
+
+def test_bench_decomposition_choices():
+    """bench.py --decomp: y slabs are the TGV default at 512^3 per GPU (z stays whole: the z-first Poisson solve), z slabs
+    for the channel (y must stay whole) and for everything the y-slab solver does not serve; x is never split"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.auto_decomposition("tgv", 512) == "yslabs"
+    assert bench.auto_decomposition("channel", 512) == "slabs"
+    assert bench.auto_decomposition("tgv", 256) == "slabs"
+    assert bench.auto_decomposition("tgv", 512, lazy=True) == "slabs"
+    for n in (1, 2, 4, 8):
+        assert bench.decomposition(n, "yslabs") == (1, n, 1)
+        assert bench.decomposition(n, "slabs") == (1, 1, n)
+        p = bench.decomposition(n, "pencils")
+        assert p[0] == 1 and p[1] * p[2] == n
+    with pytest.raises(SystemExit):
+        bench.decomposition(3)
