@@ -41,6 +41,28 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Store acknowledgements and loop-carried prefetches (round 4).  On gfx950 loads and stores share ONE in-order counter
+// (vmcnt).  A persistent kernel that prefetches its next input before it stores its current result has, at the top of
+// the next iteration, [prefetch loads][later loads][stores] outstanding, and needs only the prefetch -- the hardware
+// can wait for exactly that (s_waitcnt vmcnt(number of later operations)).  The compiler's wait-count pass however
+// merges the loop's two entries: on the way in from the prologue the prefetch loads are the LAST operations, so the
+// merged state says "wait for everything", and every iteration starts by waiting for the previous iteration's stores
+// to be acknowledged by memory (seen in the ISA as s_waitcnt vmcnt(0) at the loop top).  Issuing as many (tiny) stores
+// in the prologue as the loop body issues operations behind its prefetch makes both entries look alike: the wait
+// becomes vmcnt(n) and the stores drain behind the next iteration's work.  Performance only: the values land in a
+// sink nobody reads.
+#ifndef X3D_NO_VMCNT_PAD
+static __device__ __attribute__((used)) float g_vmcnt_sink[32 * 1024];
+template <int N>
+__device__ __forceinline__ void vmcnt_pad_stores()
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) __builtin_nontemporal_store(0.0f, &g_vmcnt_sink[k * 1024 + (threadIdx.x & 1023)]);
+}
+#else
+template <int N> __device__ __forceinline__ void vmcnt_pad_stores() {}
+#endif
+
 // Pencil enumeration for one direction of the Cartesian-pitched block:
 // pencil p -> base = (p % dim0) * s0 + (p / dim0) * s1, rows advance by rs.
 struct PencilGeom {

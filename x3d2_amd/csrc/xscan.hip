@@ -959,6 +959,8 @@ __global__ void __launch_bounds__(1024)
         gload(nxt, u0 + tile_off(tile0 + blockIdx.x));
         if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
     }
+    // behind its prefetch a component issues NI loads of the old rhs rows (ACC) and NI stores (common.h)
+    vmcnt_pad_stores<(ACC ? 2 : 1) * NI>();
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         double cb[Q];  // this pencil's rows of the advecting velocity
