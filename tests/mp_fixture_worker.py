@@ -31,8 +31,7 @@ def battery(name, fused, rank, comm):
     g = dict(np.load(name)) if name.endswith(".npz") else load_golden(name)
     c = namelist(g)
     mesh = product_mesh(c, rank)
-    d = 1 + [int(p) > 1 for p in c["nproc"]].index(True)
-    dn = "xyz"[d - 1]
+    ds = [k + 1 for k, p in enumerate(c["nproc"]) if int(p) > 1]  # ([1, py, pz]: the operators of y and of z)
     b = HipBackend(mesh, comm=comm)
     s = Solver(b, mesh, SolverConfig(Re=c["Re"], dt=c["dt"], time_intg=c["time_intg"], poisson_solver_type="CG",
                                      interpl_scheme=c["interpl"], der2nd_scheme=c["der2nd"], fused=fused,
@@ -42,18 +41,19 @@ def battery(name, fused, rank, comm):
     for f, k in ((s.u, "in.u"), (s.v, "in.v"), (s.w, "in.w"), (s.species[0], "in.s")):
         f.set_data_loc(VERT)
         b.set_field_data(f, local(g, k, mesh))
-    dp = (s.xdirps, s.ydirps, s.zdirps)[d - 1]
-    for op in OPNAMES:
-        src = al.get_block(DIR_X, VERT)
-        b.veccopy(src, s.u)
-        if op.endswith("p2v"):
-            src.set_data_loc(move_data_loc(VERT, d, 1))
-        a, o = al.get_block(d), al.get_block(d)
-        b.reorder(a, src, 10 + d)
-        b.tds_solve(o, a, getattr(dp, op))
-        out[f"tds.{dn}.{op}"] = b.get_field_data(o)
-        for f in (src, a, o):
-            al.release_block(f)
+    for d in ds:
+        dp = (s.xdirps, s.ydirps, s.zdirps)[d - 1]
+        for op in OPNAMES:
+            src = al.get_block(DIR_X, VERT)
+            b.veccopy(src, s.u)
+            if op.endswith("p2v"):
+                src.set_data_loc(move_data_loc(VERT, d, 1))
+            a, o = al.get_block(d), al.get_block(d)
+            b.reorder(a, src, 10 + d)
+            b.tds_solve(o, a, getattr(dp, op))
+            out[f"tds.{'xyz'[d - 1]}.{op}"] = b.get_field_data(o)
+            for f in (src, a, o):
+                al.release_block(f)
     curr = [s.u, s.v, s.w, s.species[0]]
     rhs = [al.get_block(DIR_X) for _ in range(4)]
     s.transeq(rhs, curr)  # (momentum + the transported scalar, nu_species = 0.37 nu as in the dump driver)

@@ -46,6 +46,17 @@ def main():
     case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, poisson=poisson, comm=Comm(), fused=fused, n_species=nsp,
                     pr_species=[0.7] * nsp)
     set_species(case)
+    if len(sys.argv) > 8 and float(sys.argv[8]) > 0.0:
+        # initial velocity = Taylor-Green + hash noise of the GLOBAL indices (tests/util.py: the single-rank oracle
+        # evaluates the same expression on the whole grid)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from util import noisy_tgv
+        from x3d2_amd.common import VERT
+        m = case.solver.mesh
+        for f, a in zip((case.solver.u, case.solver.v, case.solver.w),
+                        noisy_tgv(dims, m.n_offset, m.vert_dims, amp=float(sys.argv[8]))):
+            f.set_data_loc(VERT)
+            case.solver.backend.set_field_data(f, np.ascontiguousarray(a))
     case.solver.n_output = n_iters
     rows = case.run(n_iters=n_iters)
     s = case.solver

@@ -1,0 +1,64 @@
+"""child process of test_random_field_pressure_correction_at_512_cubed_vs_oracle: one pressure correction of the fused
+driver on a ROUGH 512^3 velocity field (Taylor-Green + 10 % noise: every wave number present) against the oracle's
+pressure_correction (src/solver.f90:693-739) on the same input.  The kernels that exist only at this size --
+csrc/fft512.hip, csrc/zfirst.hip: Hermitian completion, Nyquist rows, the x-mirrored process_spectral_000 -- see random
+data against the ORACLE here, not only against each other.  X3D_NO_ZFIRST=1 in the environment: the x-first solve
+(the switch is read once per process, hence a child).
+
+    python pc512_worker.py <expected number of z-first solves>
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    from oracle import x3d_oracle as orc
+    from util import noisy_tgv, relerr
+    from x3d2_amd import make_tgv
+    from x3d2_amd.common import DIR_Z, VERT
+    n = 512
+    want_zfirst = int(sys.argv[1])
+    dims = (n, n, n)
+    data = [np.ascontiguousarray(a) for a in noisy_tgv(dims, (0, 0, 0), dims, amp=0.1)]
+    case = make_tgv(n, fused=True)
+    s = case.solver
+    b, al = s.backend, s.backend.allocator
+    for f, d in zip((s.u, s.v, s.w), data):
+        f.set_data_loc(VERT)
+        b.set_field_data(f, d)
+    div_u = al.get_block(DIR_Z)
+    s.divergence_v2p(div_u, s.u, s.v, s.w)
+    before, _ = b.field_max_mean(div_u)
+    al.release_block(div_u)
+    s.pressure_correction_fused(s.u, s.v, s.w)
+    assert s.n_zfirst == want_zfirst, (s.n_zfirst, want_zfirst)
+    got = [b.get_field_data(f) for f in (s.u, s.v, s.w)]
+    div_u = al.get_block(DIR_Z)
+    s.divergence_v2p(div_u, s.u, s.v, s.w)
+    after, _ = b.field_max_mean(div_u)
+    del case, s, b, al
+    twopi = 6.283185307179586
+    om = orc.Mesh([n] * 3, [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
+    o = orc.Solver(om, poisson="FFT")
+    for of, d in zip((o.u, o.v, o.w), data):
+        of.data_loc = orc.VERT
+        o.backend.set_field_data(of, d)
+    o.pressure_correction(o.u, o.v, o.w)
+    errs = [relerr(g, o.backend.get_field_data(of)) for g, of in zip(got, (o.u, o.v, o.w))]
+    _, omx, _ = o.monitor()
+    print("PC512 zfirst=%d relerr u,v,w = %.3e %.3e %.3e  max|div u| before %.3e after %.3e (oracle after %.3e)"
+          % (want_zfirst, *errs, before, after, omx), flush=True)
+    assert max(errs) < 1e-11, errs
+    # the projection removes the divergence to round-off: the noise's divergence is O(10); what is left must be at the
+    # oracle's own level
+    assert after < max(1e-10, 10.0 * omx) and after < 1e-9 * before, (before, after, omx)
+
+
+if __name__ == "__main__":
+    main()

@@ -126,7 +126,8 @@ def stitch_ranks(parts, offsets, name):
 
 
 def BATTERY_FIELDS(dn):
-    return [f"tds.{dn}.{op}" for op in OPNAMES] + ["transeq.du", "transeq.dv", "transeq.dw", "div.div_u", "grad.dpdx",
+    """dn: the decomposed direction(s), "y", "z" or "yz" (a 2-D pencil split runs the operators of both)"""
+    return [f"tds.{d}.{op}" for d in dn for op in OPNAMES] + ["transeq.du", "transeq.dv", "transeq.dw", "div.div_u", "grad.dpdx",
             "grad.dpdy", "grad.dpdz", "curl.i", "curl.j", "curl.k", "step2.u", "step2.v", "step2.w"]
 
 
@@ -136,8 +137,8 @@ def oracle_battery(g, nranks):
     global arrays.  Returns (dict of stitched global fields, list of per-rank dicts)."""
     from oracle import x3d_oracle as orc
     c = namelist(g)
-    d = 1 + [int(p) > 1 for p in c["nproc"]].index(True)
-    dn = "xyz"[d - 1]
+    ds = [k + 1 for k, p in enumerate(c["nproc"]) if int(p) > 1]  # every decomposed direction ([1, py, pz]: y and z)
+    dn = "".join("xyz"[d - 1] for d in ds)
 
     def local(key, mesh):
         ox, oy, oz = (int(v) for v in mesh.n_offset)
@@ -154,16 +155,17 @@ def oracle_battery(g, nranks):
         for f, k in ((s.u, "in.u"), (s.v, "in.v"), (s.w, "in.w")):
             f.data_loc = orc.VERT
             b.set_field_data(f, local(k, s.mesh))
-        dp = (s.xdirps, s.ydirps, s.zdirps)[d - 1]
-        for op in OPNAMES:
-            src = b.get_block(orc.DIR_X, orc.VERT)
-            b.veccopy(src, s.u)
-            if op.endswith("p2v"):
-                src.data_loc = orc.move_data_loc(orc.VERT, d, 1)
-            a, o = b.get_block(d), b.get_block(d)
-            b.reorder(a, src, orc.RDR[(1, d)])
-            b.tds_solve(o, a, getattr(dp, op))
-            out[f"tds.{dn}.{op}"] = b.get_field_data(o)
+        for d in ds:
+            dp = (s.xdirps, s.ydirps, s.zdirps)[d - 1]
+            for op in OPNAMES:
+                src = b.get_block(orc.DIR_X, orc.VERT)
+                b.veccopy(src, s.u)
+                if op.endswith("p2v"):
+                    src.data_loc = orc.move_data_loc(orc.VERT, d, 1)
+                a, o = b.get_block(d), b.get_block(d)
+                b.reorder(a, src, orc.RDR[(1, d)])
+                b.tds_solve(o, a, getattr(dp, op))
+                out[f"tds.{'xyz'[d - 1]}.{op}"] = b.get_field_data(o)
         rhs = [b.get_block(orc.DIR_X) for _ in range(3)]
         s.transeq(rhs, [s.u, s.v, s.w])
         for f, k in zip(rhs, ("du", "dv", "dw")):
@@ -233,3 +235,27 @@ def synthetic_case(dims, nproc, seed=7):
     for k, (a, b_, c) in zip(("in.u", "in.v", "in.w", "in.s"), ((1, 2, 1), (2, 1, 3), (1, 1, 2), (3, 2, 1))):
         g[k] = np.sin(a * x + 0.3) * np.cos(b_ * y) * np.cos(c * z + 0.1) + 0.1 * rng.standard_normal((nz, ny, nx))
     return g
+
+
+def hash_noise(gi, gj, gk, salt):
+    """deterministic pseudo-noise in [-0.5, 0.5) from GLOBAL grid indices (broadcastable integer arrays): every rank
+    of a decomposed run and the single-rank oracle evaluate the same expression on the same host, so they get the same
+    bits without anybody holding the global array"""
+    t = np.sin(gi * 12.9898 + gj * 78.233 + gk * 37.719 + salt * 0.618) * 43758.5453
+    return t - np.floor(t) - 0.5
+
+
+def noisy_tgv(dims, offset, local_dims, amp=0.1):
+    """Taylor-Green velocity + amp * hash noise on the box [offset, offset + local_dims) of a 2 pi periodic grid of
+    `dims` vertices; arrays [k, j, i]"""
+    ox, oy, oz = (int(v) for v in offset)
+    nx, ny, nz = (int(v) for v in local_dims)
+    gi = np.arange(ox, ox + nx)[None, None, :]
+    gj = np.arange(oy, oy + ny)[None, :, None]
+    gk = np.arange(oz, oz + nz)[:, None, None]
+    twopi = 6.283185307179586
+    x, y, z = gi * (twopi / dims[0]), gj * (twopi / dims[1]), gk * (twopi / dims[2])
+    u = np.sin(x) * np.cos(y) * np.cos(z) + amp * hash_noise(gi, gj, gk, 1)
+    v = -np.cos(x) * np.sin(y) * np.cos(z) + amp * hash_noise(gi, gj, gk, 2)
+    w = amp * hash_noise(gi, gj, gk, 3) + 0.0 * x * y
+    return u, v, w
