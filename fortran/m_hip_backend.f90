@@ -4,11 +4,18 @@
 !> and the cases are used UNCHANGED.  One MPI rank per device.  Directions
 !> decomposed across ranks (nproc_dir = 1, py, pz) run the library's distributed
 !> entry points with the reference's own exchange pattern (sendrecv_fields,
-!> src/backend/omp/sendrecv.f90:10-36 / src/backend/cuda/sendrecv.f90:13-42)
-!> staged through host memory, since the MPI at hand is not GPU-aware; the
-!> all-periodic FFT Poisson solver runs on the library's pencil-decomposed
-!> stages with MPI_Alltoallv between them.  (The Python driver does the same
-!> over RCCL, device to device, with the exchanges overlapped.)
+!> src/backend/omp/sendrecv.f90:10-36 / src/backend/cuda/sendrecv.f90:13-42).
+!> The reference's GPU backend hands its device buffers to a GPU-aware MPI;
+!> the MPI at hand is not, so the exchanges are done DEVICE TO DEVICE through
+!> HIP inter-process memory handles (round 4): every rank exports its exchange
+!> buffers once, the neighbours map them, and an exchange is a "ready" message
+!> + a device copy pulled over xGMI (or inside HBM when ranks share a GPU) on
+!> the pulling rank's stream.  X3D_SHIM_HOST_STAGED=1: rounds 2-3's staging
+!> through host memory.  The all-periodic FFT Poisson solver runs on the
+!> library's pencil-decomposed stages with the same pulls in the py and pz
+!> groups.  Deferred execution (csrc/lazy.hip) stays on: the local directions
+!> keep their fused kernels, the distributed entry points flush the queue and
+!> run on the buffers that hold their handles' data.
 !>
 !> Pattern followed: src/backend/cuda/{allocator,tdsops,backend,poisson_fft}.f90.
 module m_hip_common
@@ -167,6 +174,11 @@ module m_hip_poisson_fft
     real(dp), allocatable :: sh(:), rh(:)
     integer :: comm_y = 0, comm_z = 0
     integer, allocatable :: cnt_xy_s(:), cnt_xy_r(:), cnt_yz_s(:), cnt_yz_r(:)
+    ! device-to-device transposes: the peers' two exchange buffers, mapped (1: their sbuf, 2: their rbuf); the two
+    ! buffers swap roles after every exchange (par), so that a rank never packs into memory a peer may still be reading
+    logical :: d2d = .false.
+    integer :: par = 0
+    type(c_ptr), allocatable :: peer_y(:, :), peer_z(:, :)
   contains
     procedure :: fft_forward => fft_forward_hip
     procedure :: fft_backward => fft_backward_hip
@@ -289,10 +301,16 @@ contains
     call x3d_check(x3d_pfft_set_waves(self%pf, wt, self%ax, self%bx, self%ay, self%by, self%az, self%bz))
     call x3d_check(x3d_device_alloc(backend, self%sbuf, 2_c_long*sz(8)))
     call x3d_check(x3d_device_alloc(backend, self%rbuf, 2_c_long*sz(8)))
-    allocate (self%sh(2*sz(8)), self%rh(2*sz(8)))
     ! the py ranks that share this rank's z position, ordered by their y position, and vice versa
     call MPI_Comm_split(MPI_COMM_WORLD, rz, ry, self%comm_y, ierr)
     call MPI_Comm_split(MPI_COMM_WORLD, ry, rz, self%comm_z, ierr)
+    self%d2d = .not. host_staged()
+    if (self%d2d) then
+      call map_peers(self, self%comm_y, py, self%peer_y)
+      call map_peers(self, self%comm_z, pz, self%peer_z)
+    else
+      allocate (self%sh(2*sz(8)), self%rh(2*sz(8)))
+    end if
     allocate (self%cnt_xy_s(py), self%cnt_xy_r(py), self%cnt_yz_s(pz), self%cnt_yz_r(pz))
     do r = 0, py - 1  ! peer r owns share(nxs, py, r) of the x modes; doubles per complex number: 2
       self%cnt_xy_s(r + 1) = 2*(nxs/py + merge(1, 0, r < mod(nxs, py)))*yl*zl
@@ -304,20 +322,112 @@ contains
     end do
   end subroutine hip_poisson_fft_setup_multi
 
+  logical function host_staged()
+    !! X3D_SHIM_HOST_STAGED=1: exchanges through host memory (rounds 2-3) instead of device to device
+    character(len=8) :: v
+    integer :: stat
+    call get_environment_variable('X3D_SHIM_HOST_STAGED', v, status=stat)
+    host_staged = stat == 0 .and. v(1:1) == '1'
+  end function host_staged
+
+  function ptr_off(base, ndoubles) result(p)
+    !! base + ndoubles * 8 bytes
+    type(c_ptr), intent(in) :: base
+    integer(c_long), intent(in) :: ndoubles
+    type(c_ptr) :: p
+    p = transfer(transfer(base, 0_c_intptr_t) + int(8_c_long*ndoubles, c_intptr_t), p)
+  end function ptr_off
+
+  subroutine map_peers(self, comm, np, peer)
+    !! every rank of `comm` maps the two exchange buffers of every other one (hipIpcGetMemHandle / OpenMemHandle)
+    class(hip_poisson_fft_t) :: self
+    integer, intent(in) :: comm, np
+    type(c_ptr), allocatable, intent(out) :: peer(:, :)
+    integer(c_signed_char) :: mine(64, 2)
+    integer(c_signed_char), allocatable :: all(:, :, :)
+    integer :: r, me, ierr
+    allocate (peer(2, 0:np - 1), all(64, 2, 0:np - 1))
+    peer = c_null_ptr
+    call MPI_Comm_rank(comm, me, ierr)
+    peer(1, me) = self%sbuf; peer(2, me) = self%rbuf
+    if (np < 2) return  ! (the direction is not decomposed: the "exchange" is this rank's own copy)
+    call x3d_check(x3d_ipc_export(self%backend, self%sbuf, mine(:, 1)))
+    call x3d_check(x3d_ipc_export(self%backend, self%rbuf, mine(:, 2)))
+    call MPI_Allgather(mine, 128, MPI_BYTE, all, 128, MPI_BYTE, comm, ierr)
+    do r = 0, np - 1
+      if (r == me) then
+        peer(1, r) = self%sbuf; peer(2, r) = self%rbuf
+      else
+        call x3d_check(x3d_ipc_open(self%backend, all(:, 1, r), peer(1, r)))
+        call x3d_check(x3d_ipc_open(self%backend, all(:, 2, r), peer(2, r)))
+      end if
+    end do
+  end subroutine map_peers
+
+  function buf_out(self) result(p)
+    !! the buffer this stage packs into (the peers pull from it)
+    class(hip_poisson_fft_t) :: self
+    type(c_ptr) :: p
+    if (self%par == 0) then
+      p = self%sbuf
+    else
+      p = self%rbuf
+    end if
+  end function buf_out
+  function buf_in(self) result(p)
+    !! the buffer this stage's exchange delivers into (unpacked next)
+    class(hip_poisson_fft_t) :: self
+    type(c_ptr) :: p
+    if (self%par == 0) then
+      p = self%rbuf
+    else
+      p = self%sbuf
+    end if
+  end function buf_in
+  subroutine stage_done(self)
+    !! behind the unpack: the two buffers swap roles (device to device only) -- the next pack goes into memory nobody
+    !! else reads, the next pulls land in memory the peers have finished with (they passed the barrier since)
+    class(hip_poisson_fft_t) :: self
+    if (self%d2d) self%par = 1 - self%par
+  end subroutine stage_done
+
   subroutine xchg(self, comm, scnt, rcnt)
-    !! packed buffers of the library, peer r's chunk contiguous: device -> host, MPI_Alltoallv, host -> device
+    !! packed buffers of the library, peer r's chunk contiguous.  Device to device: every rank waits for its own
+    !! stream (its send buffer is complete, its earlier pulls are done), all ranks meet, every rank tells every peer
+    !! where that peer's chunk starts, then pulls the chunks meant for it out of the peers' send buffers on its own
+    !! stream -- the unpack kernel queued behind runs when they have arrived.  Host staged: MPI_Alltoallv.
     class(hip_poisson_fft_t) :: self
     integer, intent(in) :: comm, scnt(:), rcnt(:)
-    integer :: sdis(size(scnt)), rdis(size(rcnt)), r, ierr
+    integer :: sdis(size(scnt)), rdis(size(rcnt)), psdis(size(scnt)), r, ierr, me
+    type(c_ptr) :: mine_r, src
     sdis(1) = 0; rdis(1) = 0
     do r = 2, size(scnt)
       sdis(r) = sdis(r - 1) + scnt(r - 1)
       rdis(r) = rdis(r - 1) + rcnt(r - 1)
     end do
-    call x3d_check(x3d_copy_to_host(self%backend, self%sh, self%sbuf, int(sum(scnt), c_long)))
-    call MPI_Alltoallv(self%sh, scnt, sdis, MPI_DOUBLE_PRECISION, self%rh, rcnt, rdis, MPI_DOUBLE_PRECISION, &
-                       comm, ierr)
-    call x3d_check(x3d_copy_to_device(self%backend, self%rbuf, self%rh, int(sum(rcnt), c_long)))
+    if (.not. self%d2d) then
+      call x3d_check(x3d_copy_to_host(self%backend, self%sh, self%sbuf, int(sum(scnt), c_long)))
+      call MPI_Alltoallv(self%sh, scnt, sdis, MPI_DOUBLE_PRECISION, self%rh, rcnt, rdis, MPI_DOUBLE_PRECISION, &
+                         comm, ierr)
+      call x3d_check(x3d_copy_to_device(self%backend, self%rbuf, self%rh, int(sum(rcnt), c_long)))
+      return
+    end if
+    call x3d_check(x3d_device_sync(self%backend))
+    ! (all ranks, not only this group: the buffer pulled into now was read by the OTHER group's peers one exchange ago)
+    call MPI_Barrier(MPI_COMM_WORLD, ierr)
+    call MPI_Alltoall(sdis, 1, MPI_INTEGER, psdis, 1, MPI_INTEGER, comm, ierr)
+    call MPI_Comm_rank(comm, me, ierr)
+    mine_r = buf_in(self)
+    do r = 1, size(rcnt)
+      if (rcnt(r) == 0) cycle
+      if (comm == self%comm_y) then
+        src = self%peer_y(1 + self%par, r - 1)
+      else
+        src = self%peer_z(1 + self%par, r - 1)
+      end if
+      call x3d_check(x3d_copy_device(self%backend, ptr_off(mine_r, int(rdis(r), c_long)), &
+                                     ptr_off(src, int(psdis(r), c_long)), int(rcnt(r), c_long)))
+    end do
   end subroutine xchg
 
   subroutine fft_forward_hip(self, f_in)
@@ -325,13 +435,15 @@ contains
     class(field_t), intent(in) :: f_in
     if (self%multi) then  ! x3d2_amd/poisson_fft.py, HipPencilPoissonFFT.fft_forward
       call x3d_check(x3d_pfft_fwd_x(self%pf, dev(f_in)))
-      call x3d_check(x3d_pfft_pack_xy(self%pf, self%sbuf))
+      call x3d_check(x3d_pfft_pack_xy(self%pf, buf_out(self)))
       call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r)
-      call x3d_check(x3d_pfft_unpack_xy(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_in(self)))
+      call stage_done(self)
       call x3d_check(x3d_pfft_fft_y(self%pf, 0_c_int))
-      call x3d_check(x3d_pfft_pack_yz(self%pf, self%sbuf))
+      call x3d_check(x3d_pfft_pack_yz(self%pf, buf_out(self)))
       call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r)
-      call x3d_check(x3d_pfft_unpack_yz(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_in(self)))
+      call stage_done(self)
       call x3d_check(x3d_pfft_fft_z(self%pf, 0_c_int))
       return
     end if
@@ -342,13 +454,15 @@ contains
     class(field_t), intent(inout) :: f_out
     if (self%multi) then
       call x3d_check(x3d_pfft_fft_z(self%pf, 1_c_int))
-      call x3d_check(x3d_pfft_pack_zy(self%pf, self%sbuf))
+      call x3d_check(x3d_pfft_pack_zy(self%pf, buf_out(self)))
       call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s)
-      call x3d_check(x3d_pfft_unpack_zy(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_in(self)))
+      call stage_done(self)
       call x3d_check(x3d_pfft_fft_y(self%pf, 1_c_int))
-      call x3d_check(x3d_pfft_pack_yx(self%pf, self%sbuf))
+      call x3d_check(x3d_pfft_pack_yx(self%pf, buf_out(self)))
       call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s)
-      call x3d_check(x3d_pfft_unpack_yx(self%pf, self%rbuf))
+      call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_in(self)))
+      call stage_done(self)
       call x3d_check(x3d_pfft_bwd_x(self%pf, dev(f_out)))
       return
     end if
@@ -453,16 +567,29 @@ module m_hip_backend
   use m_tdsops, only: tdsops_t, dirps_t
   use m_hip_allocator, only: hip_allocator_t, hip_field_t, dev
   use m_hip_tdsops, only: hip_tdsops_t, hip_tdsops_init
-  use m_hip_poisson_fft, only: hip_poisson_fft_t, hip_poisson_fft_setup
+  use m_hip_poisson_fft, only: hip_poisson_fft_t, hip_poisson_fft_setup, host_staged, ptr_off
   use m_x3d2_hip_capi
   implicit none
 
   type, extends(base_backend_t) :: hip_backend_t
     type(c_ptr) :: handle = c_null_ptr
-    ! decomposed directions: device exchange buffers [rows][npencil] (send_s, send_e, recv_s, recv_e) for the
-    ! halo rows of up to three fields and for the boundary values of up to three operators, + host mirrors
-    type(c_ptr) :: xb(4, 4) = c_null_ptr
+    ! decomposed directions: device exchange buffers [rows][npencil] for the halo rows of up to three fields (sets
+    ! 1..3) and for the boundary values of up to three operators (set 4).  A set is two PAIRS of buffers (towards
+    ! prev, towards next); one pair is packed and read by the neighbours, the other receives -- and the pairs swap
+    ! roles at every use of the set (par), so that a rank never packs into memory a neighbour may still be pulling
+    ! from.  One slab per decomposed direction (y: 2, z: 3): only that direction's neighbours ever read it, and their
+    ! "ready" message of the next exchange tells that their previous pull has completed.
+    ! Sets 5..8 serve the single-pass forms (x3d_transeq_tile / x3d_tds_pair_tile + *_halo_fix): 5 = the rows of the three
+    ! transeq fields [side][3][4][hr], 6 = the boundary values of a direction's nine operators [side][9][np], 7 / 8 = the
+    ! same for one tds_solve ([side][1][4][hr], [side][1][np]); a pair's two buffers are contiguous = one [side 2][...]
+    ! array of the library.
+    type(c_ptr) :: slab(2:3) = c_null_ptr, xb(4, 8, 2:3) = c_null_ptr
+    type(c_ptr) :: peer(2, 2:3) = c_null_ptr   ! the neighbours' slabs, mapped (1: prev, 2: next)
+    integer :: par(8, 2:3) = 0
+    integer(c_long) :: cap(8, 2:3) = 0, off(8, 2:3) = 0   ! doubles per buffer of a set, the set's start in the slab
     integer :: xb_n = 0
+    integer :: tile_tq(2:3) = -1, tile_tds(2:3) = -1       ! single-pass kernels serve this direction (-1: not probed)
+    logical :: d2d = .false., one_pass = .true.
     real(dp), allocatable :: hs(:), he(:), hrs(:), hre(:)
   contains
     procedure :: alloc_tdsops => alloc_hip_tdsops
@@ -508,13 +635,15 @@ contains
       error stop 'hip_backend_t needs a hip_allocator_t'
     end select
     if (mesh%par%nproc_dir(1) /= 1) error stop 'hip shim: x stays undecomposed (as the FFT Poisson solver needs)'
-    ! one rank: the library records the op-granular calls of solver.f90 / time_integrator.f90 / vector_calculus.f90 and
-    ! runs them through its fused kernels (csrc/lazy.hip); X3D_NO_LAZY=1: call by call
+    ! the library records the op-granular calls of solver.f90 / time_integrator.f90 / vector_calculus.f90 and runs them
+    ! through its fused kernels (csrc/lazy.hip); on several ranks too (round 4): the distributed entry points of a
+    ! decomposed direction flush the queue and run at once on the buffers that hold their handles' data, the local
+    ! directions keep their rewrites.  X3D_NO_LAZY=1: call by call
     block
       character(len=8) :: v
       integer :: stat
       call get_environment_variable('X3D_NO_LAZY', v, status=stat)
-      if (mesh%par%nproc == 1 .and. .not. (stat == 0 .and. v(1:1) == '1')) then
+      if (.not. (stat == 0 .and. v(1:1) == '1')) then
         call x3d_check(x3d_lazy_enable(backend%handle, 1_c_int))
       end if
     end block
@@ -527,36 +656,119 @@ contains
   end function decomposed
 
   subroutine need_buffers(self)
-    !! the four exchange buffer sets, sized for 4 rows of the larger pencil cross-section (once)
+    !! the four exchange buffer sets of every decomposed direction, sized for 4 rows of the larger pencil
+    !! cross-section (once); device to device: one allocation per direction, exported to that direction's neighbours
     class(hip_backend_t) :: self
-    integer :: i, k, n
+    integer :: i, k, n, d, prev, next, ierr, stat
+    integer(c_long) :: hr, np, total
+    integer(c_signed_char) :: mine(64), from_prev(64), from_next(64)
+    character(len=8) :: v
     if (self%xb_n > 0) return
     n = 4*max(x3d_npencils(self%handle, int(DIR_Y, c_int)), x3d_npencils(self%handle, int(DIR_Z, c_int)))
-    do k = 1, 4
-      do i = 1, 4
-        call x3d_check(x3d_device_alloc(self%handle, self%xb(i, k), int(n, c_long)))
+    self%d2d = .not. host_staged()
+    call get_environment_variable('X3D_SHIM_TWO_PHASE', v, status=stat)  ! =1: the reference's sweep / exchange / sweep form only
+    self%one_pass = .not. (stat == 0 .and. v(1:1) == '1')
+    do d = DIR_Y, DIR_Z
+      if (.not. decomposed(self, d)) cycle
+      hr = x3d_halo_row_size(self%handle, int(d, c_int))
+      np = x3d_npencils(self%handle, int(d, c_int))
+      self%cap(1:4, d) = n
+      self%cap(5:8, d) = [12*hr, 9*np, 4*hr, np]
+      total = 0
+      do k = 1, 8
+        self%off(k, d) = total
+        total = total + 4*self%cap(k, d)
       end do
+      call x3d_check(x3d_device_alloc(self%handle, self%slab(d), total))
+      do k = 1, 8
+        do i = 1, 4
+          self%xb(i, k, d) = ptr_off(self%slab(d), self%off(k, d) + int(i - 1, c_long)*self%cap(k, d))
+        end do
+      end do
+      if (.not. self%d2d) cycle
+      prev = self%mesh%par%pprev(d); next = self%mesh%par%pnext(d)
+      call x3d_check(x3d_device_sync(self%handle))  ! (the slab's zero fill)
+      call x3d_check(x3d_ipc_export(self%handle, self%slab(d), mine))
+      call MPI_Sendrecv(mine, 64, MPI_BYTE, next, 11, from_prev, 64, MPI_BYTE, prev, 11, MPI_COMM_WORLD, &
+                        MPI_STATUS_IGNORE, ierr)
+      call MPI_Sendrecv(mine, 64, MPI_BYTE, prev, 12, from_next, 64, MPI_BYTE, next, 12, MPI_COMM_WORLD, &
+                        MPI_STATUS_IGNORE, ierr)
+      call x3d_check(x3d_ipc_open(self%handle, from_prev, self%peer(1, d)))
+      if (next == prev) then
+        self%peer(2, d) = self%peer(1, d)  ! (two ranks along d: one neighbour, mapped once)
+      else
+        call x3d_check(x3d_ipc_open(self%handle, from_next, self%peer(2, d)))
+      end if
     end do
-    allocate (self%hs(n), self%he(n), self%hrs(n), self%hre(n))
+    if (.not. self%d2d) then
+      total = n
+      do d = DIR_Y, DIR_Z
+        total = max(total, maxval(self%cap(:, d)))
+      end do
+      allocate (self%hs(total), self%he(total), self%hrs(total), self%hre(total))
+    end if
     self%xb_n = n
   end subroutine need_buffers
 
+  subroutine next_use(self, dir, k)
+    !! before set k of direction dir is packed again: its two buffer pairs swap roles (device to device only)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir, k
+    if (self%d2d) self%par(k, dir) = 1 - self%par(k, dir)
+  end subroutine next_use
+
+  function xs(self, i, k, dir) result(p)
+    !! send buffer i (1: towards prev, 2: towards next) of set k
+    class(hip_backend_t) :: self
+    integer, intent(in) :: i, k, dir
+    type(c_ptr) :: p
+    p = self%xb(i + 2*self%par(k, dir), k, dir)
+  end function xs
+  function xr(self, i, k, dir) result(p)
+    !! receive buffer i (1: from prev, 2: from next) of set k
+    class(hip_backend_t) :: self
+    integer, intent(in) :: i, k, dir
+    type(c_ptr) :: p
+    p = self%xb(i + 2*(1 - self%par(k, dir)), k, dir)
+  end function xr
+
   subroutine sendrecv_set(self, dir, k, n)
     !! sendrecv_fields (src/backend/omp/sendrecv.f90:10-36) for buffer set k, n doubles per buffer:
-    !! send_s -> pprev (arrives in its recv_e), send_e -> pnext (arrives in its recv_s); host staged
+    !! send_s -> pprev (arrives in its recv_e), send_e -> pnext (arrives in its recv_s).
+    !! Device to device (what src/backend/cuda/sendrecv.f90:13-42 gets from a GPU-aware MPI): wait for the own
+    !! stream -- the send buffers are complete, and every earlier pull of this rank has landed --, tell both
+    !! neighbours (empty messages), then PULL: recv_s <- prev's send_e, recv_e <- next's send_s, device copies on this
+    !! rank's stream; the kernels queued behind them wait for the data without another host round trip.
     class(hip_backend_t) :: self
     integer, intent(in) :: dir, k, n
-    integer :: prev, next, req(4), ierr
+    integer :: prev, next, req(4), ierr, tok(4), q
+    integer(c_long) :: off_s, off_e
     prev = self%mesh%par%pprev(dir); next = self%mesh%par%pnext(dir)
-    call x3d_check(x3d_copy_to_host(self%handle, self%hs, self%xb(1, k), int(n, c_long)))
-    call x3d_check(x3d_copy_to_host(self%handle, self%he, self%xb(2, k), int(n, c_long)))
+    if (self%d2d) then
+      call x3d_check(x3d_device_sync(self%handle))
+      tok = 0
+      call MPI_Irecv(tok(1), 1, MPI_INTEGER, prev, 2, MPI_COMM_WORLD, req(1), ierr)
+      call MPI_Irecv(tok(2), 1, MPI_INTEGER, next, 1, MPI_COMM_WORLD, req(2), ierr)
+      call MPI_Isend(tok(3), 1, MPI_INTEGER, prev, 1, MPI_COMM_WORLD, req(3), ierr)
+      call MPI_Isend(tok(4), 1, MPI_INTEGER, next, 2, MPI_COMM_WORLD, req(4), ierr)
+      call MPI_Waitall(4, req, MPI_STATUSES_IGNORE, ierr)
+      ! the neighbours' send buffers of this set: same parity as here (all ranks run the same program)
+      q = 2*self%par(k, dir)
+      off_s = self%off(k, dir) + int(q, c_long)*self%cap(k, dir)       ! their send_s (towards their prev)
+      off_e = self%off(k, dir) + int(q + 1, c_long)*self%cap(k, dir)   ! their send_e (towards their next)
+      call x3d_check(x3d_copy_device(self%handle, xr(self, 1, k, dir), ptr_off(self%peer(1, dir), off_e), int(n, c_long)))
+      call x3d_check(x3d_copy_device(self%handle, xr(self, 2, k, dir), ptr_off(self%peer(2, dir), off_s), int(n, c_long)))
+      return
+    end if
+    call x3d_check(x3d_copy_to_host(self%handle, self%hs, xs(self, 1, k, dir), int(n, c_long)))
+    call x3d_check(x3d_copy_to_host(self%handle, self%he, xs(self, 2, k, dir), int(n, c_long)))
     call MPI_Irecv(self%hrs, n, MPI_X3D2_DP, prev, 2, MPI_COMM_WORLD, req(1), ierr)
     call MPI_Irecv(self%hre, n, MPI_X3D2_DP, next, 1, MPI_COMM_WORLD, req(2), ierr)
     call MPI_Isend(self%hs, n, MPI_X3D2_DP, prev, 1, MPI_COMM_WORLD, req(3), ierr)
     call MPI_Isend(self%he, n, MPI_X3D2_DP, next, 2, MPI_COMM_WORLD, req(4), ierr)
     call MPI_Waitall(4, req, MPI_STATUSES_IGNORE, ierr)
-    call x3d_check(x3d_copy_to_device(self%handle, self%xb(3, k), self%hrs, int(n, c_long)))
-    call x3d_check(x3d_copy_to_device(self%handle, self%xb(4, k), self%hre, int(n, c_long)))
+    call x3d_check(x3d_copy_to_device(self%handle, xr(self, 1, k, dir), self%hrs, int(n, c_long)))
+    call x3d_check(x3d_copy_to_device(self%handle, xr(self, 2, k, dir), self%hre, int(n, c_long)))
   end subroutine sendrecv_set
 
   function tds_handle(t) result(h)
@@ -628,6 +840,7 @@ contains
     type(dirps_t), intent(in) :: dirps
     type(c_ptr) :: rhs(3), fld(3), t1, t2, t3
     integer :: i, np
+    integer(c_int) :: done
     call need_buffers(self)
     np = x3d_npencils(self%handle, int(dir, c_int))
     if (dir == DIR_Y) then
@@ -635,8 +848,38 @@ contains
     else
       rhs = [dev(dw), dev(du), dev(dv)]; fld = [dev(w), dev(u), dev(v)]
     end if
+    ! ONE pass where the library's tile kernels take these pencils (256 / 512 rows per rank, nx a multiple of 16): the
+    ! rows of the three fields in ONE message per neighbour, the whole local solve with the neighbours' boundary values
+    ! taken as zero, ONE exchange of this rank's nine boundary values per pencil, and the correction they add on the
+    ! boundary strips -- the same linear system as the three sweep / exchange / sweep rounds below (DESIGN 5.1)
+    if (self%one_pass .and. self%tile_tq(dir) < 0) then  ! (probe: a launch over zero planes)
+      call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), xs(self, 1, 1, dir), xs(self, 1, 2, dir), &
+                                      xs(self, 1, 3, dir), xs(self, 1, 4, dir), xr(self, 1, 1, dir), xr(self, 1, 2, dir), &
+                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
+                                      tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
+                                      xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, 0_c_int, done))
+      self%tile_tq(dir) = done
+    end if
+    if (self%one_pass .and. self%tile_tq(dir) == 1) then
+      call next_use(self, dir, 5)
+      call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 5, dir), fld, 3_c_int, int(n, c_int), int(dir, c_int)))
+      call sendrecv_set(self, dir, 5, int(self%cap(5, dir)))
+      call next_use(self, dir, 6)
+      call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), dev(w), &
+                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
+                                      tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
+                                      xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, -1_c_int, done))
+      if (done /= 1) error stop 'hip shim: the tile kernel declined pencils its probe had accepted'
+      call sendrecv_set(self, dir, 6, int(self%cap(6, dir)))
+      call x3d_check(x3d_transeq_halo_fix(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), dev(w), &
+                                          real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der2nd), &
+                                          xr(self, 1, 6, dir)))
+      return
+    end if
     do i = 1, 3
-      call x3d_check(x3d_pack_halos(self%handle, self%xb(1, i), self%xb(2, i), fld(i), int(n, c_int), int(dir, c_int)))
+      call next_use(self, dir, i)
+      call x3d_check(x3d_pack_halos(self%handle, xs(self, 1, i, dir), xs(self, 2, i, dir), fld(i), int(n, c_int), &
+                                    int(dir, c_int)))
       call sendrecv_set(self, dir, i, 4*np)
     end do
     do i = 1, 3
@@ -645,11 +888,13 @@ contains
       else
         t1 = tds_handle(dirps%der1st_sym); t2 = tds_handle(dirps%der1st); t3 = tds_handle(dirps%der2nd_sym)
       end if
-      call x3d_check(x3d_transeq_dist_fwd(self%handle, int(dir, c_int), rhs(i), self%xb(1, 4), self%xb(2, 4), fld(i), &
-                                          self%xb(3, i), self%xb(4, i), fld(1), self%xb(3, 1), self%xb(4, 1), t1, t2, t3))
+      call next_use(self, dir, 4)
+      call x3d_check(x3d_transeq_dist_fwd(self%handle, int(dir, c_int), rhs(i), xs(self, 1, 4, dir), xs(self, 2, 4, dir), &
+                                          fld(i), xr(self, 1, i, dir), xr(self, 2, i, dir), fld(1), xr(self, 1, 1, dir), &
+                                          xr(self, 2, 1, dir), t1, t2, t3))
       call sendrecv_set(self, dir, 4, 3*np)
-      call x3d_check(x3d_transeq_dist_bwd(self%handle, int(dir, c_int), rhs(i), self%xb(1, 4), self%xb(3, 4), &
-                                          self%xb(4, 4), fld(1), real(nu, c_double), t1, t2, t3))
+      call x3d_check(x3d_transeq_dist_bwd(self%handle, int(dir, c_int), rhs(i), xs(self, 1, 4, dir), xr(self, 1, 4, dir), &
+                                          xr(self, 2, 4, dir), fld(1), real(nu, c_double), t1, t2, t3))
     end do
   end subroutine transeq_dist
 
@@ -695,16 +940,21 @@ contains
         d = dirps%dir
         np = x3d_npencils(self%handle, int(d, c_int))
         t1 = tds_handle(dirps%der1st); t2 = tds_handle(dirps%der1st_sym); t3 = tds_handle(dirps%der2nd)
-        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 1), self%xb(2, 1), dev(spec), int(n, c_int), int(d, c_int)))
+        call next_use(self, d, 1)
+        call x3d_check(x3d_pack_halos(self%handle, xs(self, 1, 1, d), xs(self, 2, 1, d), dev(spec), int(n, c_int), &
+                                      int(d, c_int)))
         call sendrecv_set(self, d, 1, 4*np)
-        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 2), self%xb(2, 2), dev(uvw), int(n, c_int), int(d, c_int)))
+        call next_use(self, d, 2)
+        call x3d_check(x3d_pack_halos(self%handle, xs(self, 1, 2, d), xs(self, 2, 2, d), dev(uvw), int(n, c_int), &
+                                      int(d, c_int)))
         call sendrecv_set(self, d, 2, 4*np)
-        call x3d_check(x3d_transeq_dist_fwd(self%handle, int(d, c_int), dev(dspec), self%xb(1, 4), self%xb(2, 4), &
-                                            dev(spec), self%xb(3, 1), self%xb(4, 1), dev(uvw), self%xb(3, 2), &
-                                            self%xb(4, 2), t1, t2, t3))
+        call next_use(self, d, 4)
+        call x3d_check(x3d_transeq_dist_fwd(self%handle, int(d, c_int), dev(dspec), xs(self, 1, 4, d), xs(self, 2, 4, d), &
+                                            dev(spec), xr(self, 1, 1, d), xr(self, 2, 1, d), dev(uvw), xr(self, 1, 2, d), &
+                                            xr(self, 2, 2, d), t1, t2, t3))
         call sendrecv_set(self, d, 4, 3*np)
-        call x3d_check(x3d_transeq_dist_bwd(self%handle, int(d, c_int), dev(dspec), self%xb(1, 4), self%xb(3, 4), &
-                                            self%xb(4, 4), dev(uvw), real(nu, c_double), t1, t2, t3))
+        call x3d_check(x3d_transeq_dist_bwd(self%handle, int(d, c_int), dev(dspec), xs(self, 1, 4, d), xr(self, 1, 4, d), &
+                                            xr(self, 2, 4, d), dev(uvw), real(nu, c_double), t1, t2, t3))
       end block
       call dspec%set_data_loc(spec%data_loc)
       return
@@ -729,16 +979,44 @@ contains
       ! tds_solve_dist (src/backend/omp/backend.f90:361-391) + exec_dist_tds_compact (exec_dist.f90:16-65)
       call need_buffers(self)
       block
-        integer :: np
-        np = x3d_npencils(self%handle, int(u%dir, c_int))
-        call x3d_check(x3d_pack_halos(self%handle, self%xb(1, 1), self%xb(2, 1), dev(u), int(tdsops%n_tds, c_int), &
-                                      int(u%dir, c_int)))
-        call sendrecv_set(self, u%dir, 1, 4*np)
-        call x3d_check(x3d_tds_dist_fwd(self%handle, dev(du), self%xb(1, 4), self%xb(2, 4), dev(u), self%xb(3, 1), &
-                                        self%xb(4, 1), tds_handle(tdsops), int(u%dir, c_int)))
-        call sendrecv_set(self, u%dir, 4, np)
-        call x3d_check(x3d_tds_dist_bwd(self%handle, dev(du), self%xb(1, 4), self%xb(3, 4), self%xb(4, 4), &
-                                        tds_handle(tdsops), int(u%dir, c_int)))
+        integer :: np, d
+        integer(c_int) :: done
+        type(c_ptr) :: one(1)
+        d = u%dir
+        np = x3d_npencils(self%handle, int(d, c_int))
+        if (self%one_pass .and. self%tile_tds(d) /= 0 .and. d /= DIR_X) then
+          ! single pass (as transeq_dist): mode 2 of the pair kernel = one operator.  Probed per call: the operators
+          ! of a direction differ in length (n_tds /= n_rhs for v2p) and closure
+          call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), 2_c_int, xs(self, 1, 1, d), c_null_ptr, &
+                                           xs(self, 1, 2, d), c_null_ptr, tds_handle(tdsops), c_null_ptr, &
+                                           xr(self, 1, 7, d), xs(self, 1, 8, d), 0_c_int, 0_c_int, done))
+          if (done == 1) then
+            one(1) = dev(u)
+            call next_use(self, d, 7)
+            call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 7, d), one, 1_c_int, int(tdsops%n_tds, c_int), &
+                                                int(d, c_int)))
+            call sendrecv_set(self, d, 7, int(self%cap(7, d)))
+            call next_use(self, d, 8)
+            call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), 2_c_int, dev(du), c_null_ptr, dev(u), c_null_ptr, &
+                                             tds_handle(tdsops), c_null_ptr, xr(self, 1, 7, d), xs(self, 1, 8, d), &
+                                             0_c_int, -1_c_int, done))
+            if (done /= 1) error stop 'hip shim: the tile kernel declined pencils its probe had accepted'
+            call sendrecv_set(self, d, 8, int(self%cap(8, d)))
+            call x3d_check(x3d_tds_pair_halo_fix(self%handle, int(d, c_int), 2_c_int, dev(du), c_null_ptr, &
+                                                 tds_handle(tdsops), c_null_ptr, xr(self, 1, 8, d)))
+            return
+          end if
+        end if
+        call next_use(self, d, 1)
+        call x3d_check(x3d_pack_halos(self%handle, xs(self, 1, 1, d), xs(self, 2, 1, d), dev(u), int(tdsops%n_tds, c_int), &
+                                      int(d, c_int)))
+        call sendrecv_set(self, d, 1, 4*np)
+        call next_use(self, d, 4)
+        call x3d_check(x3d_tds_dist_fwd(self%handle, dev(du), xs(self, 1, 4, d), xs(self, 2, 4, d), dev(u), &
+                                        xr(self, 1, 1, d), xr(self, 2, 1, d), tds_handle(tdsops), int(d, c_int)))
+        call sendrecv_set(self, d, 4, np)
+        call x3d_check(x3d_tds_dist_bwd(self%handle, dev(du), xs(self, 1, 4, d), xr(self, 1, 4, d), xr(self, 2, 4, d), &
+                                        tds_handle(tdsops), int(d, c_int)))
       end block
       return
     end if

@@ -171,6 +171,70 @@ module m_x3d2_hip_capi
       type(c_ptr), intent(out) :: p
       integer(c_long), value :: n
     end function
+    ! decomposed y / z directions in ONE pass (include/x3d2_hip.h, "decomposed (BC_HALO) y / z directions in ONE pass"):
+    ! exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-186) as pack -> exchange ->
+    ! single-pass tile kernel (own boundary values out) -> exchange -> boundary-strip correction
+    integer(c_long) function x3d_halo_row_size(b, dir) bind(C, name='x3d_halo_row_size')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: b
+      integer(c_int), value :: dir
+    end function
+    integer(c_int) function x3d_pack_halos_multi(b, send, fields, nf, n, dir) bind(C, name='x3d_pack_halos_multi')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, send
+      type(c_ptr), intent(in) :: fields(*)
+      integer(c_int), value :: nf, n, dir
+    end function
+    integer(c_int) function x3d_transeq_tile(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, &
+                                             accumulate, halo_recv, bnd_send, other0, nother, done) &
+      bind(C, name='x3d_transeq_tile')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der1st_sym, der2nd, der2nd_sym, halo_recv, bnd_send
+      integer(c_int), value :: dir, accumulate, other0, nother
+      real(c_double), value :: nu
+      integer(c_int), intent(out) :: done
+    end function
+    integer(c_int) function x3d_transeq_halo_fix(b, dir, du, dv, dw, u, v, w, nu, der1st, der2nd, bnd_recv) &
+      bind(C, name='x3d_transeq_halo_fix')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der2nd, bnd_recv
+      integer(c_int), value :: dir
+      real(c_double), value :: nu
+    end function
+    integer(c_int) function x3d_tds_pair_tile(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, other0, &
+                                              nother, done) bind(C, name='x3d_tds_pair_tile')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send
+      integer(c_int), value :: dir, mode, other0, nother
+      integer(c_int), intent(out) :: done
+    end function
+    integer(c_int) function x3d_tds_pair_halo_fix(b, dir, mode, out1, out2, ta, tb, bnd_recv) &
+      bind(C, name='x3d_tds_pair_halo_fix')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, out1, out2, ta, tb, bnd_recv
+      integer(c_int), value :: dir, mode
+    end function
+    ! device-to-device exchanges between ranks of a node (HIP inter-process handles; cf. src/backend/cuda/sendrecv.f90:13-42)
+    integer(c_int) function x3d_device_count(n) bind(C, name='x3d_device_count')
+      import :: c_int
+      integer(c_int), intent(out) :: n
+    end function
+    integer(c_int) function x3d_ipc_export(b, dev, handle) bind(C, name='x3d_ipc_export')
+      import :: c_ptr, c_int, c_signed_char
+      type(c_ptr), value :: b, dev
+      integer(c_signed_char), intent(out) :: handle(64)
+    end function
+    integer(c_int) function x3d_ipc_open(b, handle, dev) bind(C, name='x3d_ipc_open')
+      import :: c_ptr, c_int, c_signed_char
+      type(c_ptr), value :: b
+      integer(c_signed_char), intent(in) :: handle(64)
+      type(c_ptr), intent(out) :: dev
+    end function
+    integer(c_int) function x3d_copy_device(b, dst, src, n) bind(C, name='x3d_copy_device')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: b, dst, src
+      integer(c_long), value :: n
+    end function
     integer(c_int) function x3d_copy_to_host(b, host, dev, n) bind(C, name='x3d_copy_to_host')
       import :: c_ptr, c_int, c_long, c_double
       type(c_ptr), value :: b, dev

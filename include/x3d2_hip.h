@@ -61,7 +61,8 @@ int x3d_backend_destroy(x3d_backend *b);
 /* a second context on the SAME device and stream as `like` (the twin backends of Poisson 100 / 110) */
 int x3d_backend_create_like(x3d_backend **out, const x3d_backend *like, const int dims_vert[3]);
 /* diagnostics: which = 0 -> launches of the three-components-in-one transeq kernels since creation,
- * 1 -> those of them that also applied a pending velocity correction (x3d_transeq_x_update) */
+ * 1 -> those of them that also applied a pending velocity correction (x3d_transeq_x_update),
+ * 2 -> launches of the single-pass HALO forms of the tile kernels (decomposed directions) */
 long x3d_backend_counter(const x3d_backend *b, int which);
 int x3d_backend_set_stream(x3d_backend *b, void *stream);
 size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
@@ -80,6 +81,16 @@ int x3d_device_alloc(x3d_backend *b, double **out, long n);
 int x3d_device_free(x3d_backend *b, double *p);
 int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n);
 int x3d_copy_to_device(x3d_backend *b, double *dev, const double *host, long n);
+/* device-to-device exchanges between the ranks of one node without a GPU-aware MPI (what src/backend/cuda/sendrecv.f90:13-42
+ * gets from one): x3d_ipc_export = hipIpcGetMemHandle of a buffer of x3d_device_alloc (64 bytes, sent to the neighbours
+ * once), x3d_ipc_open maps a neighbour's buffer, x3d_copy_device copies n doubles between own and mapped memory on the
+ * backend's stream (asynchronous, ordered like a kernel).  x3d_device_count: the devices this process sees -- the main
+ * program picks mod(nrank, ndevs) as src/xcompact.f90:57-60 does. */
+int x3d_device_count(int *n);
+int x3d_ipc_export(x3d_backend *b, const double *dev, unsigned char handle[64]);
+int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], double **dev);
+int x3d_ipc_close(x3d_backend *b, double *dev);
+int x3d_copy_device(x3d_backend *b, double *dst, const double *src, long n);
 
 /* ---- alloc_tdsops (src/backend/backend.f90:352-372): device copy of the
  * arrays the host-side factory tdsops_init (src/tdsops.f90:63-203) produced.
@@ -548,7 +559,9 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m
  * "every block holds its own data".  x3d_block_discard = allocator%release_block (src/allocator.f90:160-168): the
  * contents are dead until the block is written again (lets the queue drop temporaries and reuse their memory).
  * Blocks of x3d_block_alloc are handles by themselves; memory allocated elsewhere: x3d_lazy_register_block.
- * Single rank only (the distributed entry points run at once and call x3d_lazy_sync first).
+ * Several ranks (round 4): the two-phase distributed entry points (x3d_pack_halos, x3d_tds_dist_fwd / _bwd,
+ * x3d_transeq_dist_fwd / _bwd, x3d_pfft_fwd_x / _bwd_x) run at once on the buffers that hold their handles' data
+ * (flush + translate, no copies), so the local directions of a decomposed run keep their rewrites.
  * x3d_lazy_stats: [0] calls recorded, [1] launches issued, [2] aliases, [3] transeq_acc, [4] pairs, [5] tds_solve_acc,
  * [6] lincombs, [7] tds_solve_lincomb, [8] solve_000, [9] updates run out of place (buffer swaps), [10] copies made for
  * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [14] transeq_x launches that carry the velocity

@@ -614,10 +614,14 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
 def test_unchanged_reference_solver_through_fortran_shim_on_several_ranks(nranks, inp, tmp_path):
     """the same binary under mpirun: the reference's solver on [1, 1, 2] and [1, 2, 2] ranks (sharing the one
     GPU), decomposed directions through the library's distributed entry points with the reference's own
-    sendrecv pattern staged through host memory, FFT Poisson on the pencil-decomposed stages + MPI_Alltoallv
-    (fortran/m_hip_backend.f90).  Same trace as on one rank up to the DistD2 truncation at 32 rows per rank
+    sendrecv pattern (fortran/m_hip_backend.f90).  Round 4: the exchanges are DEVICE TO DEVICE (HIP inter-process
+    memory handles: every rank pulls its neighbours' send buffers on its own stream; the FFT transposes likewise) and
+    the deferred-execution layer stays on (the local directions keep their rewrites: X3D_LAZY_REPORT shows them
+    engaged on every rank) -- against rounds 2-3's path (host-staged MPI exchanges, call by call), whose trace it
+    must reproduce, and against the single-rank trace up to the DistD2 truncation at 32 rows per rank
     (dist_sa(32) ~ 4e-14, src/tdsops.f90:196-201)."""
     import os
+    import re
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -625,13 +629,83 @@ def test_unchanged_reference_solver_through_fortran_shim_on_several_ranks(nranks
     mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
     if not os.path.exists(exe) or not os.path.exists(mpirun):
         pytest.skip("shim binary not built (needs the reference tree at build time) or no mpirun")
-    r = subprocess.run([mpirun, "-n", str(nranks), exe, os.path.join(root, "fortran", inp)], cwd=tmp_path,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    rows = np.loadtxt(tmp_path / "monitoring.csv", delimiter=",", comments="#")
+    traces = {}
+    for name, env in (("d2d_lazy", {"X3D_LAZY_REPORT": "1"}),
+                      ("d2d_call_by_call", {"X3D_NO_LAZY": "1"}),
+                      ("host_staged_call_by_call", {"X3D_SHIM_HOST_STAGED": "1", "X3D_NO_LAZY": "1"})):
+        wd = tmp_path / name
+        wd.mkdir()
+        r = subprocess.run([mpirun, "-n", str(nranks), exe, os.path.join(root, "fortran", inp)], cwd=wd,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, name + r.stdout[-2000:] + r.stderr[-2000:]
+        traces[name] = np.loadtxt(wd / "monitoring.csv", delimiter=",", comments="#")
+        if name == "d2d_lazy":
+            reports = r.stderr.split("x3d_lazy_report pid")[1:]  # (the ranks' lines may run into one another)
+            assert len(reports) == nranks, r.stderr[-2000:]
+            for l in reports:
+                st = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", l)}
+                # the local directions' rewrites engaged on every rank: x is always local (the RK stage as the
+                # prologue of the divergence's first x operators, the velocity correction folded into tds_solve_acc or
+                # the next transeq_x), and on [1, 1, 2] y is local as well (transeq_y + its sums, the y operator pairs)
+                assert st["recorded"] > 0 and st["lincombs"] + st["tds_lincomb"] > 0 and st["aliases"] > 0, l
+                assert st["tds_acc"] + st["transeq_x_update"] > 0, l
+                if nranks == 2:
+                    assert st["transeq_acc"] > 0 and st["pairs"] > 0, l
+                assert st["sync_copies"] == 0, l  # (no entry point had to restore "every block holds its own data")
+            devs = [l for l in r.stdout.splitlines() if "on device" in l]
+            assert len(devs) == nranks  # (every rank says which device it took: mod(nrank, ndevs), src/xcompact.f90:57-60)
+    rows = traces["d2d_lazy"]
     fx = read_trace_fixture()
     assert np.all(np.abs(rows[:3, 1] - fx[:, 1]) < 1e-11)
     assert rows[:, 2].max() < 1e-11
+    # the device-to-device exchange moves the same bytes: call by call it reproduces the host-staged trace digit for
+    # digit; with the queue on, the pair / accumulate rewrites re-associate sums (1 - 2 ulp per operator, DESIGN K8)
+    assert np.array_equal(traces["d2d_call_by_call"], traces["host_staged_call_by_call"])
+    assert np.all(np.abs(rows[:, 1] - traces["host_staged_call_by_call"][:, 1]) < 1e-13)
+
+
+@pytest.mark.parametrize("nranks,inp", [(2, "tgv_z256x2.x3d"), (2, "tgv_y256x2.x3d"), (4, "tgv_yz256x4.x3d")])
+def test_fortran_shim_decomposed_directions_in_one_pass(nranks, inp, tmp_path):
+    """256 rows per rank along the decomposed direction(s): the shim's transeq_* and tds_solve take the library's
+    single-pass forms (x3d_pack_halos_multi -> exchange -> x3d_transeq_tile / x3d_tds_pair_tile -> exchange ->
+    x3d_*_halo_fix; fortran/m_hip_backend.f90, transeq_dist / tds_solve_hip) with device-to-device exchanges and the
+    deferred-execution layer on -- against the reference's own sweep / exchange / sweep order of calls with host-staged
+    exchanges, call by call (rounds 2-3's path: X3D_SHIM_TWO_PHASE=1 X3D_SHIM_HOST_STAGED=1 X3D_NO_LAZY=1) and against
+    the SAME binary on one rank: the unchanged solver.f90's monitoring.csv (enstrophy to 1e-12, div u at round-off)"""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "xcompact_hip")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if not os.path.exists(exe) or not os.path.exists(mpirun):
+        pytest.skip("shim binary not built (needs the reference tree at build time) or no mpirun")
+    traces = {}
+    for name, n, env in (("one_pass", nranks, {"X3D_LAZY_REPORT": "1"}),
+                         ("two_phase_host_staged", nranks, {"X3D_SHIM_TWO_PHASE": "1", "X3D_SHIM_HOST_STAGED": "1",
+                                                            "X3D_NO_LAZY": "1"}),
+                         ("one_rank", 1, {})):
+        wd = tmp_path / name
+        wd.mkdir()
+        r = subprocess.run([mpirun, "-n", str(n), exe, os.path.join(root, "fortran", inp)], cwd=wd,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, name + r.stdout[-2000:] + r.stderr[-2000:]
+        traces[name] = np.loadtxt(wd / "monitoring.csv", delimiter=",", comments="#")
+        if name == "one_pass":
+            reports = r.stderr.split("x3d_lazy_report pid")[1:]
+            assert len(reports) == nranks, r.stderr[-2000:]
+            for l in reports:
+                st = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", l)}
+                # 4 steps x 3 sub-steps: one HALO transeq launch per decomposed direction and sub-step + its tds_solves
+                assert st["halo_forms"] >= 12 * (2 if nranks == 4 else 1) * 5, l
+                assert st["recorded"] > 0 and st["sync_copies"] == 0, l
+    a, b, c = traces["one_pass"], traces["two_phase_host_staged"], traces["one_rank"]
+    assert a.shape == b.shape == c.shape and a.shape[0] >= 3
+    assert np.all(np.abs(a[:, 1] - b[:, 1]) < 1e-12 * 0.375) and np.all(np.abs(a[:, 1] - c[:, 1]) < 1e-12 * 0.375)
+    # (row 0 is the initial field: with nx /= ny its discrete divergence is the schemes' truncation error, 1e-8)
+    assert a[1:, 2].max() < 1e-11 and b[1:, 2].max() < 1e-11 and np.all(np.abs(a[:, 2] - c[:, 2]) < 1e-11)
 
 
 @pytest.mark.parametrize("env", ["X3D_NO_ONCHIP2,X3D_NO_TDS_PAIR,X3D_NO_TILE3,X3D_NO_TDS_LINCOMB", "X3D_XDIR_GENERIC",

@@ -47,6 +47,11 @@ PROTOTYPES = {
     "x3d_device_free": (I, [VP, VP]),
     "x3d_copy_to_host": (I, [VP, VP, VP, ctypes.c_long]),
     "x3d_copy_to_device": (I, [VP, VP, VP, ctypes.c_long]),
+    "x3d_device_count": (I, [c_int_p]),
+    "x3d_ipc_export": (I, [VP, VP, VP]),
+    "x3d_ipc_open": (I, [VP, VP, ctypes.POINTER(VP)]),
+    "x3d_ipc_close": (I, [VP, VP]),
+    "x3d_copy_device": (I, [VP, VP, VP, ctypes.c_long]),
     "x3d_block_fill": (I, [VP, VP, D]),
     "x3d_tdsops_create": (I, [VP, ctypes.POINTER(VP), I, I, I, I] + [c_double_p] * 10),
     "x3d_tdsops_destroy": (I, [VP]),

@@ -128,7 +128,7 @@ int x3d_lds_optin(x3d_backend *b, const void *kernel)
 extern "C" long x3d_backend_counter(const x3d_backend *b, int which)
 {
     if (!b) return -1;
-    return which == 0 ? b->n_tq3 : (which == 1 ? b->n_upd : -1);
+    return which == 0 ? b->n_tq3 : (which == 1 ? b->n_upd : (which == 2 ? b->n_halo : -1));
 }
 
 extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)
@@ -210,6 +210,51 @@ extern "C" int x3d_device_free(x3d_backend *b, double *p)
     X3D_HIP(hipFree(p));
     return 0;
 }
+// ---- device-to-device exchanges between the ranks of one node (round 4).  The reference's GPU backend hands device
+// buffers to a GPU-aware MPI (src/backend/cuda/sendrecv.f90:13-42); where the MPI at hand is not GPU-aware the same
+// thing is done here with HIP's inter-process memory handles: a rank exports its exchange buffers once, its neighbours
+// map them, and an exchange is a device-to-device copy on the PULLING rank's stream -- over xGMI between two GPUs, inside
+// HBM when ranks share a GPU; only the 64-byte handles and empty "ready" messages go through MPI.
+extern "C" int x3d_device_count(int *n)
+{
+    X3D_REQUIRE(n, "x3d_device_count: null argument");
+    X3D_HIP(hipGetDeviceCount(n));
+    return 0;
+}
+extern "C" int x3d_ipc_export(x3d_backend *b, const double *dev, unsigned char handle[64])
+{
+    X3D_REQUIRE(b && dev && handle, "x3d_ipc_export: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    X3D_HIP(hipIpcGetMemHandle(&h, const_cast<double *>(dev)));
+    memcpy(handle, &h, 64);
+    return 0;
+}
+extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], double **dev)
+{
+    X3D_REQUIRE(b && dev && handle, "x3d_ipc_open: null argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void *p = nullptr;
+    X3D_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *dev = static_cast<double *>(p);
+    return 0;
+}
+extern "C" int x3d_ipc_close(x3d_backend *b, double *dev)
+{
+    X3D_REQUIRE(b && dev, "x3d_ipc_close: null argument");
+    X3D_HIP(hipIpcCloseMemHandle(dev));
+    return 0;
+}
+// n doubles device to device (own or mapped memory), ordered on the backend's stream like a kernel; returns at once
+extern "C" int x3d_copy_device(x3d_backend *b, double *dst, const double *src, long n)
+{
+    X3D_REQUIRE(b && dst && src && n >= 0, "x3d_copy_device: bad argument");
+    if (n == 0) return 0;
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
+    return 0;
+}
+
 // ordered behind the kernels queued on the backend's stream; returns when the copy is complete
 extern "C" int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n)
 {

@@ -89,6 +89,7 @@ struct x3d_backend {
     int red_cap;
     long n_upd;       // ... of those, launches that also applied the pending velocity correction (UPD form)
     long n_tq3;       // launches of the three-components-in-one transeq kernels (bench.py prices them at 48 B/DoF)
+    long n_halo;      // launches of the HALO forms of the tile kernels (a decomposed direction in one pass)
     void *epi_dev;    // 256-byte device slot for the RK-stage description of k_ytile_transeq<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled

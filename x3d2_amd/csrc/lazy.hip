@@ -31,6 +31,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <unistd.h>
+
 #include "common.h"
 
 enum LKind {
@@ -79,9 +81,14 @@ bool x3d_lazy_set_executing(x3d_backend *b, bool on)
     return prev;
 }
 
+static std::vector<x3d_lazy *> g_reported;  // X3D_LAZY_REPORT (below)
+static std::vector<const x3d_backend *> g_reported_b;
+
 void x3d_lazy_destroy(x3d_backend *b)
 {
     if (!b->lazy) return;
+    for (size_t k = 0; k < g_reported.size(); k++)
+        if (g_reported[k] == b->lazy) { g_reported.erase(g_reported.begin() + k); g_reported_b.erase(g_reported_b.begin() + k); break; }
     for (double *p : b->lazy->pool) hipFree(p);
     delete b->lazy;
     b->lazy = nullptr;
@@ -854,10 +861,36 @@ int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
 }
 
 // ---------------------------------------------------------------- C ABI
+// X3D_LAZY_REPORT=1: the counters of x3d_lazy_stats on stderr when the process ends (a host side that never asks for
+// them -- the Fortran shim under mpirun -- still shows whether the rewrites engaged)
+static void report_at_exit()
+{
+    static const char *nm[ST_N] = {"recorded", "launches", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
+                                   "solve000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped",
+                                   "transeq_x_update", "pool_slot", "zfirst"};
+    for (size_t r = 0; r < g_reported.size(); r++) {
+        const x3d_lazy *L = g_reported[r];
+        char line[1024];
+        int n = snprintf(line, sizeof line, "x3d_lazy_report pid %d: three_in_one=%ld halo_forms=%ld", (int)getpid(),
+                         g_reported_b[r]->n_tq3, g_reported_b[r]->n_halo);
+        for (int k = 0; k < ST_N && n < (int)sizeof line - 40; k++) n += snprintf(line + n, sizeof line - n, " %s=%ld", nm[k], L->stats[k]);
+        n += snprintf(line + n, sizeof line - n, "\n");
+        if (write(2, line, (size_t)n) < 0) {}  // (one write per rank: the ranks of an mpirun share the stream)
+    }
+}
+
 extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
 {
     X3D_REQUIRE(b, "x3d_lazy_enable: null backend");
     x3d_lazy *L = lazy_of(b);
+    if (on && std::find(g_reported.begin(), g_reported.end(), L) == g_reported.end()) {
+        const char *rep = getenv("X3D_LAZY_REPORT");
+        if (rep && rep[0] == '1') {
+            if (g_reported.empty()) atexit(report_at_exit);
+            g_reported.push_back(L);
+            g_reported_b.push_back(b);
+        }
+    }
     if (!on && L->on) {
         if (int rc = x3d_lazy_sync_c(b)) return rc;
     }

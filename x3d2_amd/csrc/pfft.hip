@@ -287,14 +287,14 @@ static int fft_y(x3d_pfft *p, int inverse, int m0, int m1)
 extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in)
 {
     X3D_REQUIRE(p && f_in, "null argument");
-    X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_IN(p->b, f_in);
     return fwd_x(p, f_in, 0, p->parts);
 }
 
 extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out)
 {
     X3D_REQUIRE(p && f_out, "null argument");
-    X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
     return bwd_x(p, f_out, 0, p->parts);
 }
 

@@ -693,9 +693,11 @@ static int check_len(const x3d_backend *b, const x3d_tdsops *t, int dir, const c
 
 extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
+    // deferred execution on several ranks: what has been recorded runs first, then this entry point works on the
+    // buffer that holds u's data (the exchange buffers are not handles)
+    X3D_LAZY_IN(b, u);
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_PACK, dir);
@@ -708,12 +710,12 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
                                 const double *u, const double *u_recv_s, const double *u_recv_e,
                                 const x3d_tdsops *t, int dir)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && du_send_s && du_send_e && u && u_recv_s && u_recv_e && t,
                 "x3d_tds_dist_fwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_fwd: bad dir %d", dir);
     X3D_REQUIRE(du != u, "x3d_tds_dist_fwd: du and u must be distinct blocks");
+    X3D_LAZY_IN(b, u);
+    X3D_LAZY_EAGER(b);
     if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
@@ -728,10 +730,10 @@ extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du
                                     const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
                                     double scale)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
+    X3D_LAZY_OUT(b, du, !accumulate);
+    X3D_LAZY_EAGER(b);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
     if (accumulate)  // fusion extension: du += scale * result (folds the vecadd of the fused driver)
@@ -953,12 +955,13 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
                                     const double *conv, const double *conv_recv_s, const double *conv_recv_e,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && rhs && send_s && send_e && u && u_recv_s && u_recv_e && conv && conv_recv_s &&
                     conv_recv_e && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_fwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_fwd: bad dir %d", dir);
+    X3D_LAZY_IN(b, u);
+    X3D_LAZY_IN(b, conv);
+    X3D_LAZY_EAGER(b);
     if (int rc = transeq_check(b, dir, t_du, t_dud, t_d2u)) return rc;
     PencilGeom g = x3d_geom(b, dir);
     // [3][npencil] boundary buffers are contiguous with stride np
@@ -976,11 +979,12 @@ extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, co
                                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
                                         int accumulate)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && rhs && send_s && recv_s && recv_e && conv && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
+    X3D_LAZY_IN(b, conv);
+    X3D_LAZY_OUT(b, rhs, !accumulate);
+    X3D_LAZY_EAGER(b);
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
     if (accumulate)  // fusion extension: rhs += result
@@ -1202,14 +1206,18 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
 // send[side 2][field nf][4][np]: rows 1..4 (side 0, for prev) and n-3..n (side 1, for next) of nf <= 3 fields
 extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && send && fields, "x3d_pack_halos_multi: null argument");
     X3D_REQUIRE(nf >= 1 && nf <= 3, "x3d_pack_halos_multi: 1..3 fields");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos_multi: bad dir %d", dir);
     PencilGeom g = x3d_geom(b, dir);
     PackFields pf{};
-    for (int k = 0; k < nf; k++) { X3D_REQUIRE(fields[k], "x3d_pack_halos_multi: null field"); pf.f[k] = fields[k]; }
+    for (int k = 0; k < nf; k++) {
+        X3D_REQUIRE(fields[k], "x3d_pack_halos_multi: null field");
+        const double *fk = fields[k];
+        X3D_LAZY_IN(b, fk);  // (deferred execution: flush, then the buffer that holds the field)
+        pf.f[k] = fk;
+    }
+    X3D_LAZY_EAGER(b);
     ProfScope ps(b, X3D_K_PACK, dir);
     int hp;
     long hnp;
@@ -1233,12 +1241,18 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv,
                                 int accumulate, const double *halo_recv, double *bnd_send, int other0, int nother,
                                 int *done)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
                 "x3d_transeq_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_transeq_tile: halo_recv and bnd_send go together");
     *done = 0;
+    X3D_REQUIRE(du != u && du != v && du != w && dv != u && dv != v && dv != w && dw != u && dw != v && dw != w,
+                "x3d_transeq_tile: outputs alias inputs");
+    if (nother != 0) {  // (a launch over zero planes is a probe: nothing is read or written)
+        X3D_LAZY_IN(b, u); X3D_LAZY_IN(b, v); X3D_LAZY_IN(b, w);
+        const bool full = !accumulate && nother < 0;  // (a plane range leaves the other planes as they are)
+        X3D_LAZY_OUT(b, du, full); X3D_LAZY_OUT(b, dv, full); X3D_LAZY_OUT(b, dw, full);
+    }
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_tile: dir must be y or z");
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
     if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
@@ -1263,10 +1277,11 @@ extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double 
                                     const double *v, const double *w, double nu, const x3d_tdsops *der1st,
                                     const x3d_tdsops *der2nd, const double *bnd_recv)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der2nd && bnd_recv, "x3d_transeq_halo_fix: null argument");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_halo_fix: dir must be y or z");
+    X3D_LAZY_IN(b, u); X3D_LAZY_IN(b, v); X3D_LAZY_IN(b, w);
+    X3D_LAZY_OUT(b, du, false); X3D_LAZY_OUT(b, dv, false); X3D_LAZY_OUT(b, dw, false);
+    X3D_LAZY_EAGER(b);
     double *r[3];
     if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; }
     else { r[0] = dw; r[1] = du; r[2] = dv; }
@@ -1280,8 +1295,6 @@ static int pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *ou
                      const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
                      double *bnd_send, int other0, int nother, int *done)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && done, "x3d_tds_pair_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_tds_pair_tile: halo_recv and bnd_send go together");
     *done = 0;
@@ -1291,6 +1304,13 @@ static int pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *ou
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_tile: dir must be y or z");
     X3D_REQUIRE(out1 != in1 && out1 != in2 && out2 != in1 && (mode != 1 || out1 != out2),
                 "x3d_tds_pair_tile: outputs alias inputs");
+    if (nother != 0) {  // (zero planes: a probe)
+        X3D_LAZY_IN(b, in1);
+        if (mode == 0) X3D_LAZY_IN(b, in2);
+        X3D_LAZY_OUT(b, out1, nother < 0);
+        if (mode == 1) X3D_LAZY_OUT(b, out2, nother < 0);
+    }
+    X3D_LAZY_EAGER(b);
     if (mode == 2) tb = ta;
     if (int rc = check_len(b, ta, dir, "tds_pair_tile")) return rc;
     if (int rc = check_len(b, tb, dir, "tds_pair_tile")) return rc;
@@ -1369,10 +1389,11 @@ extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mod
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && ta && bnd_recv && (mode == 2 || tb) && (mode != 1 || out2), "x3d_tds_pair_halo_fix: null argument");
     X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_halo_fix: mode must be 0, 1 or 2");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_halo_fix: dir must be y or z");
+    X3D_LAZY_OUT(b, out1, false);
+    if (mode == 1) X3D_LAZY_OUT(b, out2, false);
+    X3D_LAZY_EAGER(b);
     return x3d_tds_halo_fix(b, dir, mode, out1, out2, bnd_recv, ta, mode == 2 ? ta : tb);
 }

@@ -1661,6 +1661,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
 #undef GON
 #undef GOH
 #undef GO
+    if (halo) b->n_halo++;
     X3D_HIP(hipGetLastError());
     *done = true;
     return 0;
@@ -1784,6 +1785,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 #undef GO
     X3D_HIP(hipGetLastError());
     b->n_tq3++;
+    if (halo) b->n_halo++;
     if (b->prof) {  // count the launch as three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
     }
