@@ -70,14 +70,14 @@ def cpu_baseline(n, steps, threads):
     try:
         probed = None
         if isinstance(threads, (list, tuple)):
-            # which thread count suits this host: one 256^3 step each (a few seconds), the fastest runs the sample
-            probed = {th: child(256, 1, th)["value"] for th in threads}
+            # which thread count suits this host: one 128^3 step each (about a second), the fastest runs the sample
+            probed = {th: child(128, 1, th)["value"] for th in threads}
             threads = max(probed, key=probed.get)
         out = child(n, steps, threads)
         if isinstance(threads, tuple):
             out["fft_workers"] = threads[1]
         if probed:
-            out["thread_counts_probed_at_256"] = {("%d omp, %d fft" % k if isinstance(k, tuple) else str(k)): v
+            out["thread_counts_probed_at_128"] = {("%d omp, %d fft" % k if isinstance(k, tuple) else str(k)): v
                                                   for k, v in probed.items()}
         return out
     except Exception as e:  # noqa: BLE001 -- the GPU line must still be printed
@@ -120,7 +120,7 @@ REF_NML = """&domain_settings
 flow_case_name = 'tgv'
 L_global = 6.283185307179586d0, 6.283185307179586d0, 6.283185307179586d0
 dims_global = {n}, {n}, {n}
-nproc_dir = 1, 1, 1
+nproc_dir = {nproc_dir}
 BC_x = 'periodic', 'periodic'
 BC_y = 'periodic', 'periodic'
 BC_z = 'periodic', 'periodic'
@@ -140,34 +140,46 @@ stagder_scheme = 'compact6'
 """
 
 
-def cpu_reference(n, iters, threads):
+def cpu_reference(n, iters, threads, nproc_dir=(1, 1, 1)):
     """the REAL reference -- its own xcompact (OpenMP backend), compiled from /root/reference's sources where they lie
     by oracle/ref/Makefile (flang -O3, AVX2; shipped prebuilt in oracle/_ref/fast, git-ignored) -- timed on this
     host: TGV n^3, RK3, poisson_solver_type = 'CG' (the reference's placeholder = NO pressure solve: its FFT Poisson
     needs 2decomp&FFT, which cannot be built here), its own "Averaged time per step" (first step excluded,
-    src/case/base_case.f90:256-260, 339-342).  None when the binary did not travel."""
+    src/case/base_case.f90:256-260, 339-342).  nproc_dir = [1, py, pz]: under mpirun on py * pz MPI ranks of `threads`
+    OpenMP threads each -- the reference is an MPI code first (one rank per core group), a single OpenMP rank is not its
+    CPU path at its best.  None when the binary did not travel (or there is no mpirun for a multi-rank shape)."""
     import re
+    import shutil
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "oracle", "_ref", "fast", "xcompact")
     if not os.path.exists(exe):
         return None
+    ranks = nproc_dir[0] * nproc_dir[1] * nproc_dir[2]
+    cmd = [exe, "input.x3d"]
+    if ranks > 1:
+        mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+        if not os.path.exists(mpirun):
+            return None
+        cmd = [mpirun, "-n", str(ranks)] + cmd
     with tempfile.TemporaryDirectory() as wd:
         with open(os.path.join(wd, "input.x3d"), "w") as f:
-            f.write(REF_NML.format(n=n, iters=iters))
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+            f.write(REF_NML.format(n=n, iters=iters, nproc_dir=", ".join(str(p) for p in nproc_dir)))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+        env.pop("OMP_PLACES", None)
         try:
-            r = subprocess.run([exe, "input.x3d"], cwd=wd, env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, cwd=wd, env=env, capture_output=True, text=True, timeout=120)
         except (OSError, subprocess.TimeoutExpired):
             return None
     m = re.search(r"Averaged time per step \(s\):\s*([0-9.eE+-]+)", r.stdout)
     if r.returncode != 0 or not m:
         return None
     t = float(m.group(1))
-    return {"value": n ** 3 / t, "unit": "DoF*steps/s", "cores": threads, "kind": "reference",
+    return {"value": n ** 3 / t, "unit": "DoF*steps/s", "cores": threads * ranks, "kind": "reference",
+            "mpi_ranks": ranks, "omp_threads_per_rank": threads, "nproc_dir": list(nproc_dir),
             "sample": f"the reference's xcompact (OpenMP backend, flang -O3 build of /root/reference's sources), TGV {n}^3 "
                       f"RK3, derivatives + RK only (poisson_solver_type='CG': no pressure solve), {iters} steps, its own "
-                      f"average without the first step, {threads} OpenMP threads",
+                      f"average without the first step, {ranks} MPI rank(s) x {threads} OpenMP threads",
             "seconds_per_step": t, "n": n}
 
 
@@ -226,9 +238,10 @@ def main():
     ap.add_argument("--time-intg", default="RK3")
     ap.add_argument("--no-poisson", action="store_true", help="BASELINE configs[1]: derivatives + RK only")
     ap.add_argument("--cpu-n", type=int, default=0, help="CPU baseline grid (0: 512 if the host has the memory, else 256)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=1,
+                    help="timed steps of the port baseline after its warm-up step (512^3: ~25 s each on the box's host)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="threads of the port baseline (0: 32, 64 and all physical cores are probed at 256^3, the fastest is used)")
+                    help="threads of the port baseline (0: 32, 64 and all physical cores are probed at 128^3, the fastest is used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
@@ -237,6 +250,8 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "slabs", "yslabs", "pencils"],
                     help="N > 1: y slabs [1,N,1] (TGV default: z-first Poisson solve), z slabs [1,1,N] (the channel case: "
                          "y must stay whole) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
+    ap.add_argument("--no-validate", action="store_true",
+                    help="N > 1: skip the one-step validation of the decomposition (and its fall-back chain)")
     ap.add_argument("--op-granular", action="store_true",
                     help="issue the reference's op sequence verbatim (reorders as copies, separate axpys)")
     ap.add_argument("--lazy", action="store_true",
@@ -292,11 +307,71 @@ def main():
     from x3d2_amd import make_tgv
     from x3d2_amd.parallel import Comm
 
+    requested = args.decomp
     if args.decomp == "auto":
         args.decomp = auto_decomposition(args.case, args.n, args.lazy, args.op_granular)
-    nproc_dir = decomposition(args.gpus, args.decomp)
-    dims = tuple(args.n * p for p in nproc_dir)
     comm = Comm()
+    tried = []
+
+    def build(decomp):
+        nproc_dir = decomposition(args.gpus, decomp)
+        dims = tuple(args.n * p for p in nproc_dir)
+        case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
+                        poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular,
+                        lazy=args.lazy)
+        return case, nproc_dir, dims
+
+    def validated(decomp):
+        """N > 1, TGV: build the case on this decomposition, run ONE step and look at what a wrong exchange or transpose
+        cannot get right -- the enstrophy of the Taylor-Green field after a step (3/8 at t = 0 whatever the grid) and
+        max |div u| behind the pressure correction; every rank must agree.  None: this decomposition is not usable here
+        (the reason is kept in config.decompositions_tried), the caller moves on to the next one."""
+        rec = {"decomp": decomp}
+        ok, built = 1.0, None
+        try:
+            built = build(decomp)
+            case = built[0]
+            case.step(1)
+            s_ = case.solver
+            row = case.monitoring.write_step(s_.dt, s_.u, s_.v, s_.w)
+            rec["enstrophy"], rec["max_div_u"] = float(row[1]), float(row[2])
+            good = abs(row[1] - 0.375) < 2e-3 and (args.no_poisson or row[2] < 1e-8)
+            if not (good and row[1] == row[1]):
+                ok = 0.0
+                rec["error"] = "one step from the Taylor-Green field: enstrophy / max |div u| out of range"
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the next decomposition gets its chance
+            ok = 0.0
+            rec["error"] = repr(e)[:300]
+        if comm.size > 1:
+            ok = -comm.allreduce(-ok, "max")  # (min over the ranks)
+        rec["ok"] = bool(ok)
+        tried.append(rec)
+        if not ok:
+            built = None
+            torch.cuda.empty_cache()
+        return built
+
+    if args.case == "tgv" and args.gpus > 1 and not args.no_validate:
+        # the N > 1 layouts have only ever run as several ranks on ONE GPU, as one process standing in for a rank, and
+        # through RCCL to self: the first real multi-GPU run checks what it is about to time, and falls back
+        chain = [args.decomp] + [d for d in ("yslabs", "slabs", "pencils") if d != args.decomp]
+        if requested != "auto":
+            chain = [args.decomp]
+        built = None
+        for d in chain:
+            built = validated(d)
+            if built is not None:
+                args.decomp = d
+                break
+        if built is None:
+            if rank == 0:
+                print(json.dumps({"metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step",
+                                  "value": None, "unit": "DoF*steps/s", "n_gpus": args.gpus, "error":
+                                  "no decomposition passed its one-step validation", "decompositions_tried": tried}))
+            raise SystemExit(3)
+        case, nproc_dir, dims = built
+    elif args.case == "tgv":
+        case, nproc_dir, dims = build(args.decomp)
     if args.case == "channel":
         # BASELINE configs[4]; N > 1: z slabs [1, 1, N] of --dims vertices each (weak scaling: the span grows with N,
         # the wall-normal direction stays whole on every rank -- the reference itself has no multi-rank solver for
@@ -309,10 +384,6 @@ def main():
                             poisson="CG" if args.no_poisson else "FFT", fused=not args.op_granular, rotation=True,
                             omega_rot=0.12, n_rotate=5000, comm=comm, nproc_dir=nproc_dir, rank=rank,
                             lazy=args.lazy)
-    else:
-        case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
-                        poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular,
-                        lazy=args.lazy)
     solver, backend = case.solver, case.solver.backend
     nstage = solver.time_integrator.nstage
 
@@ -365,9 +436,12 @@ def main():
     # every kernel class, from ONE more step outside the timed region
     backend.prof_select(None)
     backend.prof_reset()
+    comm.timed = comm.size > 1 or getattr(comm, "self_via_nccl", False)
     it += 1
     case.step(it)
     sync_all()
+    exchanges = comm.timing_report() if comm.timed else None
+    comm.timed = False
     prof = {"note": "one extra step after the timed region, all classes timed"}
     for kind in backend.KINDS:
         n_l, ms = backend.prof_get(kind)
@@ -483,6 +557,17 @@ def main():
                    # N > 1: did the overlapped exchange path pass its first-use check against the ordered path
                    # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
                    "overlap_self_check": getattr(comm, "self_check_result", None),
+                   "overlap_self_check_error": getattr(comm, "self_check_error", None),
+                   # N > 1: which decomposition ran, and what its one-step validation (and any it replaced) showed
+                   "decomposition": args.decomp if args.case == "tgv" else "slabs",
+                   "decomposition_requested": requested,
+                   "decompositions_tried": tried or None,
+                   "transport": ("gloo, host staged (ranks share a GPU: a dry run)" if share else
+                                 "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if world > 1 or
+                                dist.is_initialized() else None,
+                   # exchanges of ONE step after the timed region, HIP events on the stream they were posted from:
+                   # sendrecv = halo rows + boundary values of the decomposed direction, alltoall = Poisson transposes
+                   "exchanges_one_step": exchanges,
                    # 000 solve at 512^3 on one rank: transforms ordered z, x, y with the z transforms inside the
                    # neighbouring z operator pairs (csrc/zfirst.hip); counted pressure corrections of the fused driver
                    "poisson_z_first": (int(case.solver.n_zfirst) if not args.lazy
@@ -501,13 +586,25 @@ def main():
         th = min(phys, args.cpu_threads) if args.cpu_threads > 0 else \
             sorted({(min(32, phys), min(32, phys)), (phys, min(32, phys)), (min(64, phys), min(32, phys)), (phys, phys)})
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, th)
-        # the real reference at all physical cores and at the port's thread count; the faster one is reported,
-        # the other kept beside it
-        refs = [r for r in (cpu_reference(256, 4, t) for t in sorted({phys, min(phys, args.cpu_threads or 32)}, reverse=True))
-                if r is not None]
+        # the real reference as the MPI code it is: R ranks of ONE OpenMP thread under mpirun (its OpenMP loops do not
+        # scale -- 1 rank x 4 threads is slower than 1 x 1 on the build host, 4 ranks x 1 thread 3.3 x faster --, so
+        # ranks carry the cores; 16 threads per rank measured 6 x SLOWER than the single rank on the box's host), best
+        # of three rank counts, next to the single OpenMP rank rounds 1-3 timed; 3 steps each (its average excludes the
+        # first)
+        def shape(r):
+            py = 1
+            while py * py < r:
+                py *= 2
+            return (1, py, r // py)
+        shapes = [((1, 1, 1), min(phys, 32))]
+        for r in (16, 64, 128):
+            if r <= phys:
+                shapes.append((shape(r), 1))
+        refs = [r for r in (cpu_reference(256, 2 if nd == (1, 1, 1) else 3, t, nd) for nd, t in shapes) if r is not None]
         if refs:
             best = max(refs, key=lambda r: r["value"])
-            best["other_thread_counts"] = [{"cores": r["cores"], "value": r["value"]} for r in refs if r is not best]
+            best["other_shapes"] = [{"mpi_ranks": r["mpi_ranks"], "omp_threads_per_rank": r["omp_threads_per_rank"],
+                                     "value": r["value"]} for r in refs if r is not best]
             out["cpu_baseline"]["reference_nopoisson"] = best
     if rank == 0:
         print(json.dumps(out))

@@ -472,6 +472,8 @@ int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_
  *   x3d_poisson_zfirst_forward / _backward: the z transform of a field in memory (stand-alone ends of the solve),
  *   x3d_poisson_solve_000_zfirst = forward ; middle ; backward, in place */
 int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok);
+/* ... and these two operators' z pair is one the z-transforming kernels take (probe, nothing is launched) */
+int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb, int *ok);
 int x3d_poisson_zfirst_middle(x3d_poisson *p);
 int x3d_poisson_zfirst_forward(x3d_poisson *p, const double *f_in);
 int x3d_poisson_zfirst_backward(x3d_poisson *p, double *f_out);
@@ -570,6 +572,7 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);
 int x3d_lazy_sync(x3d_backend *b);
+int x3d_lazy_unregister_block(x3d_backend *b, double *f); /* sync, then forget a block of x3d_lazy_register_block */
 int x3d_lazy_register_block(x3d_backend *b, double *f);
 int x3d_block_discard(x3d_backend *b, double *f);
 int x3d_lazy_stats(x3d_backend *b, long out[24]);

@@ -44,7 +44,7 @@ def main():
     from x3d2_amd.parallel import Comm
     nsp = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, poisson=poisson, comm=Comm(), fused=fused, n_species=nsp,
-                    pr_species=[0.7] * nsp)
+                    pr_species=[0.7] * nsp, lazy=(sys.argv[4] == "lazy"))
     set_species(case)
     if len(sys.argv) > 8 and float(sys.argv[8]) > 0.0:
         # initial velocity = Taylor-Green + hash noise of the GLOBAL indices (tests/util.py: the single-rank oracle
@@ -64,7 +64,10 @@ def main():
     extra = {"s%d" % i: s.backend.get_field_data(f) for i, f in enumerate(s.species)}
     np.savez(out + f".{rank}.npz", u=local[0], v=local[1], w=local[2], offset=np.array(s.mesh.n_offset),
              rows=np.array(rows), halo_launches=np.array([s.backend.halo_launches]),
-             n_zfirst=np.array([s.n_zfirst]), **extra)
+             n_zfirst=np.array([s.n_zfirst]),
+             lazy=np.array([s.backend.lazy_stats().get(k, 0) for k in ("transeq_acc", "pairs", "lincombs", "tds_lincomb",
+                                                                        "sync_copies")] if s.backend.lazy else [0] * 5),
+             **extra)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -29,6 +29,8 @@ PROTOTYPES = {
     "x3d_lazy_flush": (I, [VP]),
     "x3d_lazy_sync": (I, [VP]),
     "x3d_lazy_register_block": (I, [VP, VP]),
+    "x3d_lazy_unregister_block": (I, [VP, VP]),
+    "x3d_tds_pair_zfirst_ok": (I, [VP, VP, VP, c_int_p]),
     "x3d_block_discard": (I, [VP, VP]),
     "x3d_lazy_stats": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
     "x3d_backend_set_stream": (I, [VP, VP]),

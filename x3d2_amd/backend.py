@@ -55,8 +55,11 @@ class HipBackend:
         self.allocator = Allocator(self.nblock, self.device)
         self.lazy = (os.environ.get("X3D_LAZY") == "1") if lazy is None else bool(lazy)
         if self.lazy:
-            if self.comm.size > 1 or os.environ.get("X3D_EMULATE_DECOMP"):
-                raise X3dError("deferred execution (lazy) serves one rank")
+            # several ranks (round 4): the distributed entry points flush the queue and run at once on the buffers that
+            # hold their handles' data; the local directions keep their rewrites.  (One process standing in for several
+            # ranks, X3D_EMULATE_DECOMP, exchanges by slicing block memory directly: not with handles.)
+            if os.environ.get("X3D_EMULATE_DECOMP"):
+                raise X3dError("deferred execution (lazy) does not serve X3D_EMULATE_DECOMP")
             _lib.check(self.lib.x3d_lazy_enable(h, 1))
             self.allocator.lazy = (self.lib, h)
         self.poisson_fft = None
@@ -67,6 +70,10 @@ class HipBackend:
         self.halo_launches = 0  # single-pass launches on decomposed directions (tests assert the path engaged)
 
     def __del__(self):
+        try:
+            self.allocator.destroy()  # (deferred execution: the layer forgets the blocks torch owns before they go)
+        except Exception:
+            pass
         try:
             for t in self._tdsops:
                 self.lib.x3d_tdsops_destroy(t)
@@ -280,7 +287,8 @@ class HipBackend:
         """a z halo row is one xy plane in the block's own layout (x3d_halo_row_size): rows 1..4 and n-3..n of a
         field are contiguous pieces of its block and are sent from there (X3D_PACK_Z_HALOS=1: through the pack
         kernel like y, for A/B runs)"""
-        return direction == DIR_Z and os.environ.get("X3D_PACK_Z_HALOS") != "1"
+        # (deferred execution: a block address is a handle, its rows may live in another buffer -- always pack)
+        return direction == DIR_Z and os.environ.get("X3D_PACK_Z_HALOS") != "1" and not self.lazy
 
     def _halo_exchange(self, direction, fields, n, hs, hr):
         """start the exchange of the boundary rows 1..4 / n-3..n of `fields` with the two neighbours of the
@@ -660,6 +668,12 @@ class HipBackend:
         ptr = lambda f: f.ptr if f is not None else None
         _lib.check(self.lib.x3d_tds_pair_zfirst(self.h, self.poisson_fft.h, int(mode), ptr(out1), ptr(out2), ptr(in1),
                                                 ptr(in2), t_a.handle, t_b.handle, ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def zfirst_pairs_ok(self, t_a, t_b):
+        """probe (nothing is launched): the z-transforming pair kernels take these two operators on this backend's blocks"""
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_tds_pair_zfirst_ok(self.h, t_a.handle, t_b.handle, ctypes.byref(flag)))
         return bool(flag.value)
 
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):

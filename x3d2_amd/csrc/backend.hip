@@ -392,8 +392,8 @@ struct OpFill { double a; __device__ double operator()(double) const { return a;
 
 extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_copy(b, dst, src);
     X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_copy(b, dst, src);  // (recorded only after the eager path's checks)
     ProfScope ps(b, X3D_K_COPY);
     X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
@@ -401,8 +401,8 @@ extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
 
 extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_vecadd(b, a, x, bb, y);
     X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_vecadd(b, a, x, bb, y);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpAxpby>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
@@ -413,8 +413,8 @@ extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, 
 
 extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 0, y, x, 0.0);
     X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 0, y, x, 0.0);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpMul>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
@@ -479,8 +479,8 @@ extern "C" int x3d_compute_qcriterion(x3d_backend *b, double *out, const double 
 
 extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 1, f, nullptr, a);
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 1, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpScale>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
@@ -491,8 +491,8 @@ extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
 
 extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 2, f, nullptr, a);
     X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 2, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpShift>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
@@ -503,8 +503,8 @@ extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
 
 extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_unary(b, 3, f, nullptr, c);
     X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
+    if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 3, f, nullptr, c);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map1<OpFill>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
@@ -517,11 +517,11 @@ extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 // (reference: src/backend/omp/backend.f90:393-452; codes src/common.f90:23-26)
 extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_copy(b, u_, u);
     X3D_REQUIRE(b && u_ && u, "x3d_reorder: null argument");
     int from = rdr / 10, to = rdr % 10;
     X3D_REQUIRE(from >= 1 && from <= 4 && to >= 1 && to <= 4 && from != to,
                 "x3d_reorder: invalid reorder code %d", rdr);
+    if (x3d_lazy_active(b)) return x3d_lazy_copy(b, u_, u);
     if (u_ == u) return 0;
     ProfScope ps(b, X3D_K_COPY);
     X3D_HIP(hipMemcpyAsync(u_, u, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
@@ -531,9 +531,9 @@ extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
 // sum_yintox / sum_zintox: u += u_ (src/backend/omp/backend.f90:454-527)
 extern "C" int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_sum(b, u, u_, dir_from);
     X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
     X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
+    if (x3d_lazy_active(b)) return x3d_lazy_sum(b, u, u_, dir_from);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
     hipLaunchKernelGGL(k_map2<OpAdd>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)u,

@@ -405,8 +405,9 @@ static void optimise(x3d_backend *b)
         for (int k = p + 1; k < n; k++) {
             if (q[k].kind == L_DEAD) continue;
             if (q[k].kind == L_DISCARD && q[k].o[0] != q[p].o[0] && q[k].o[0] != q[p].in[0]) continue;
+            // (the first solve must not run in place: the second one reads the same input)
             if (q[k].kind == L_TDS && q[k].dir == q[p].dir && q[k].in[0] == q[p].in[0] && q[k].o[0] != q[p].o[0] &&
-                q[k].o[0] != q[p].in[0] && range_clear(q, p, k, {q[k].o[0]}, {q[p].in[0]})) {
+                q[k].o[0] != q[p].in[0] && q[p].o[0] != q[p].in[0] && range_clear(q, p, k, {q[k].o[0]}, {q[p].in[0]})) {
                 LOp f;
                 f.kind = L_PAIR; f.mode = 1; f.dir = q[p].dir;
                 f.o[0] = q[p].o[0]; f.o[1] = q[k].o[0]; f.in[0] = q[p].in[0]; f.t[0] = q[p].t[0]; f.t[1] = q[k].t[0];
@@ -422,7 +423,9 @@ static void optimise(x3d_backend *b)
         const double *G = q[p].in[0];
         double *U = q[p].o[0];
         const int pg = last_touch_before(q, p, G);
-        if (pg < 0 || q[pg].kind != L_TDS || q[pg].o[0] != G || U == q[pg].in[0] || U == G || !dead_after(q, p, G)) continue;
+        if (pg < 0 || q[pg].kind != L_TDS || q[pg].o[0] != G || U == q[pg].in[0] || U == G || G == q[pg].in[0] ||
+            !dead_after(q, p, G))
+            continue;
         if (!range_clear(q, pg, p, {G, U}, {})) continue;
         q[pg].kind = L_TDS_ACC; q[pg].o[0] = U; q[pg].s[0] = q[p].s[0];
         q[p].kind = L_DEAD;
@@ -918,6 +921,19 @@ extern "C" int x3d_lazy_register_block(x3d_backend *b, double *f)
 {
     X3D_REQUIRE(b && f, "x3d_lazy_register_block: null argument");
     x3d_lazy_register(b, f);
+    return 0;
+}
+
+// before memory registered above goes back to its owner: every handle's data home, then the layer forgets the block
+// (it would otherwise keep treating the buffer as reusable storage)
+extern "C" int x3d_lazy_unregister_block(x3d_backend *b, double *f)
+{
+    X3D_REQUIRE(b && f, "x3d_lazy_unregister_block: null argument");
+    if (!b->lazy) return 0;
+    if (b->lazy->on) {
+        if (int rc = x3d_lazy_sync_c(b)) return rc;
+    }
+    x3d_lazy_unregister(b, f);
     return 0;
 }
 

@@ -439,7 +439,7 @@ extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const double *f_in, double *send
 {
     PFFT_PART(p, m, "x3d_pfft_fwd_a_part");
     X3D_REQUIRE(f_in && send_xy, "null argument");
-    if (m == 0) X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
     if (int rc = fwd_x(p, f_in, m, m + 1)) return rc;
     return xy_c0(p, (double2 *)send_xy + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, true);
 }
@@ -479,6 +479,7 @@ extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f
 {
     PFFT_PART(p, m, "x3d_pfft_bwd_a_part");
     X3D_REQUIRE(recv_yx && f_out, "null argument");
+    X3D_LAZY_OUT(p->b, f_out, false);  // (a group's planes of the real extent are written)
     if (int rc = xy_c0(p, (double2 *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
     return bwd_x(p, f_out, m, m + 1);
 }

@@ -220,7 +220,7 @@ extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double
 extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
-    X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
+    X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
     {
         ProfScope ps(p->b, X3D_K_FFT, 1);
         static int own = -1;  // single-kernel real-to-complex x pass (fft512.hip), as in the single-rank solver
@@ -323,7 +323,7 @@ extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
 extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out)
 {
     X3D_REQUIRE(p && recvbuf && f_out, "null argument");
-    X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
+    X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
     if (int rc = x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 1, nullptr, nullptr, p->nx,
                                   (double2 *)recvbuf, p->ys, p->ysc))
         return rc;

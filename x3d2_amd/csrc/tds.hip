@@ -906,7 +906,13 @@ extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, c
 
 extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_tds(b, du, u, t, dir);
+    if (b && x3d_lazy_active(b)) {  // recorded -- after the checks the eager path makes at the call site
+        X3D_REQUIRE(du && u && t, "x3d_tds_solve: null argument");
+        X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve: bad dir %d", dir);
+        X3D_REQUIRE(du != u, "x3d_tds_solve: du and u must be distinct blocks");
+        if (int rc = check_len(b, t, dir, "tds_solve")) return rc;
+        return x3d_lazy_tds(b, du, u, t, dir);
+    }
     return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);
 }
 
@@ -1061,7 +1067,15 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, doub
                            const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                            const x3d_tdsops *der2nd_sym)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_transeq(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym);
+    if (b && x3d_lazy_active(b)) {  // recorded -- after the checks the eager path makes at the call site
+        X3D_REQUIRE(du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym, "x3d_transeq: null argument");
+        X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq: bad dir %d", dir);
+        if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
+        if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
+        X3D_REQUIRE(du != u && du != v && du != w && dv != u && dv != v && dv != w && dw != u && dw != v && dw != w,
+                    "x3d_transeq: outputs alias inputs");
+        return x3d_lazy_transeq(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym);
+    }
     return x3d_transeq_acc(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0);
 }
 
@@ -1187,11 +1201,11 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
                                    double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                    const x3d_tdsops *der2nd, int accumulate)
 {
-    if (b && x3d_lazy_active(b)) return x3d_lazy_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, accumulate);
     X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_species: bad dir %d", dir);
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
+    if (x3d_lazy_active(b)) return x3d_lazy_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, accumulate);
     return transeq_component_local(b, dir, dspec, spec, uvw, nu, der1st, der1st_sym, der2nd, accumulate);
 }
 
@@ -1386,6 +1400,15 @@ extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mod
     *done = ok ? 1 : 0;
     return 0;
 }
+bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb);  // xscan.hip
+// probe: would the z-transforming pair kernels (x3d_tds_pair_zfirst, x3d_sfftz_tds_pair) take this operator pair
+extern "C" int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb, int *ok)
+{
+    X3D_REQUIRE(b && ta && tb && ok, "x3d_tds_pair_zfirst_ok: null argument");
+    *ok = x3d_zfirst_pairs_ok(b, ta, tb) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
 {

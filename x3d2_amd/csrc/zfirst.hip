@@ -123,13 +123,19 @@ static bool zfirst_sizes(const x3d_poisson *p)
            (size_t)257 * 512 * ZH_PX <= (size_t)p->nz * p->ny * p->nxs && !p->stretched;
 }
 
+// X3D_NO_ZFIRST=1, read ONCE per process (both functions below ask here)
+static bool zfirst_off()
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("X3D_NO_ZFIRST"); off = (e && e[0] == '1') ? 1 : 0; }
+    return off != 0;
+}
+
 // the z-first solve is on offer for this solver (X3D_NO_ZFIRST=1: never); builds the reciprocal wave numbers on first use
 int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
 {
     *ok = false;
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("X3D_NO_ZFIRST"); off = (e && e[0] == '1') ? 1 : 0; }
-    if (off || !zfirst_sizes(p)) return 0;
+    if (zfirst_off() || !zfirst_sizes(p)) return 0;
     if (!p->rwZ) {
         X3D_HIP(hipMalloc(&p->rwZ, sizeof(double) * 257 * 512 * 512));
         hipLaunchKernelGGL(k_zh_rw, dim3(16, 16, 257), dim3(256), 0, p->b->stream, p->rwZ, p->waves, p->nx, p->ny, p->nxs);
@@ -143,8 +149,7 @@ int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
 // (for the deferred-execution layer's rewrite: no side effects)
 bool x3d_zfirst_on_offer(x3d_poisson *p)
 {
-    const char *e = getenv("X3D_NO_ZFIRST");
-    return p && !(e && e[0] == '1') && zfirst_sizes(p);
+    return p && !zfirst_off() && zfirst_sizes(p);
 }
 
 extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)

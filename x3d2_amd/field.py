@@ -47,6 +47,7 @@ class Allocator:
         self.free = []
         self.next_id = 0
         self.lazy = None  # (lib, backend handle) while the library's deferred execution is on (HipBackend(lazy=True))
+        self._registered = []  # tensors whose memory the deferred-execution layer knows as blocks (kept alive)
         self.stagger = int(os.environ.get("X3D_BLOCK_STAGGER", str(self.STAGGER)))  # (read once)
 
     # Blocks start 4224 B (one padded row of a 512^3 block) further into their allocation than the previous one,
@@ -68,6 +69,9 @@ class Allocator:
             lib, h = self.lazy
             if lib.x3d_lazy_register_block(h, f.ptr) != 0:
                 raise X3dError(lib.x3d_last_error().decode())
+            # the layer treats a registered block's memory as reusable storage: the tensor must stay alive until the
+            # block is unregistered (destroy), whatever happens to the Field object
+            self._registered.append(f.data)
         return f
 
     def get_block(self, direction, data_loc=None):
@@ -92,3 +96,9 @@ class Allocator:
 
     def destroy(self):
         self.free.clear()
+        if self.lazy is not None:  # every handle's data home, then the layer forgets the blocks torch owns
+            lib, h = self.lazy
+            for t in self._registered:
+                if lib.x3d_lazy_unregister_block(h, t.data_ptr()) != 0:
+                    raise X3dError(lib.x3d_last_error().decode())
+        self._registered.clear()

@@ -58,12 +58,49 @@ class Comm:
         self._checked = self.host_staged or not self.enabled or not self.overlap or \
             (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
+        # event timers around the exchanges (bench.py switches them on for ONE step outside its timed region):
+        # kind -> [count, bytes, [(start event, end event)]]
+        self.timed = False
+        self._timing = {}
+        # the check is collective (a ring exchange + an all-reduce): it runs HERE, where every rank is -- not at the first
+        # exchange, which a rank whose first group is empty would skip while its neighbours wait for it
+        if not self._checked:
+            self.self_check()
 
     # ------------------------------------------------------------ p2p core
-    def _exchange(self, sends, recvs):
+    def _note(self, kind, sends, e0, e1):
+        t = self._timing.setdefault(kind, [0, 0, []])
+        t[0] += 1
+        t[1] += sum(x.numel() * x.element_size() for x, _ in sends)
+        t[2].append((e0, e1))
+
+    def timing_report(self):
+        """{kind: {"exchanges", "MB_sent", "ms"}} of the exchanges timed since `timed` was switched on (HIP events on the
+        stream the transfers were posted from: for the overlapped path the time from "the producers are done" to "RCCL's
+        work has completed", which includes RCCL's own queueing)"""
+        import torch as _t
+        _t.cuda.synchronize()
+        out = {}
+        for kind, (n, nbytes, evs) in self._timing.items():
+            out[kind] = {"exchanges": n, "MB_sent": nbytes / 1e6, "ms": float(sum(a.elapsed_time(b) for a, b in evs))}
+        self._timing = {}
+        return out
+
+    def _exchange(self, sends, recvs, kind="sendrecv"):
         """sends: [(tensor, peer)], recvs: [(tensor, peer)]; posting order
         defines the matching between a pair of ranks"""
         if not sends and not recvs:
+            return
+        if self.timed and not self.host_staged:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.timed = False
+            try:
+                self._exchange(sends, recvs)
+            finally:
+                self.timed = True
+            e1.record()
+            self._note(kind, sends, e0, e1)
             return
         if self.host_staged:
             s_host = [(t.detach().to("cpu", copy=True), p) for t, p in sends]
@@ -85,25 +122,32 @@ class Comm:
             self._cstream = torch.cuda.Stream()
         return self._cstream
 
-    def _start(self, sends, recvs):
+    def _start(self, sends, recvs, kind="sendrecv"):
         """post a group of point-to-point transfers behind everything queued on the current stream, on the
         communication stream: kernels launched on the compute stream afterwards run beside it"""
         if not sends and not recvs:
             return DONE
-        if not self._checked:
-            self.self_check()
         if self.host_staged or not self.overlap:
-            self._exchange(sends, recvs)
+            self._exchange(sends, recvs, kind)
             return DONE
-        return self._start_overlapped(sends, recvs)
+        return self._start_overlapped(sends, recvs, kind)
 
-    def _start_overlapped(self, sends, recvs):
+    def _start_overlapped(self, sends, recvs, kind="sendrecv"):
         cs = self._comm_stream()
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):  # RCCL's own stream waits for the stream that is current at posting time
+            if self.timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
             ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
             works = dist.batch_isend_irecv(ops)
+            if self.timed:  # (the communication stream waits for RCCL's work; the compute stream still waits by itself)
+                for w in works:
+                    w.wait()
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._note(kind, sends, e0, e1)
         return _Pending(works)
 
     def self_check(self):
@@ -119,7 +163,7 @@ class Comm:
             n = 1 << 21
             dev = torch.device("cuda", torch.cuda.current_device())
             prev, nxt = (self.rank - 1) % self.size, (self.rank + 1) % self.size
-            heavy = torch.ones(1 << 26, dtype=torch.float64, device=dev)
+            heavy = torch.ones(1 << 26, dtype=torch.float64, device=dev)  # (512 MiB, freed below)
             out = []
             for overlapped in (False, True):
                 send = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -139,6 +183,7 @@ class Comm:
             torch.cuda.synchronize()
             if not (torch.equal(out[0], want) and torch.equal(out[1], want)):
                 ok = 0.0
+            del heavy, out, want
         except Exception as e:  # noqa: BLE001 -- whatever it is, the ordered path is the fallback
             ok = 0.0
             self.self_check_error = repr(e)
@@ -202,7 +247,7 @@ class Comm:
                     recvs.append((recvbuf[ro:ro + cnt_r], peer))
             so += cnt_s
             ro += cnt_r
-        self._exchange(sends, recvs)
+        self._exchange(sends, recvs, "alltoall")
 
     def ialltoall(self, sendbuf, recvbuf, count, peers, send_off=0, send_stride=None, recv_off=0, recv_stride=None):
         """one part of a personalised exchange, started now: peer i gets `count` elements that start at
@@ -220,7 +265,7 @@ class Comm:
             else:
                 sends.append((sendbuf[s0:s0 + count], peer))
                 recvs.append((recvbuf[r0:r0 + count], peer))
-        return self._start(sends, recvs)
+        return self._start(sends, recvs, "alltoall")
 
     def ialltoallv(self, sendbuf, send_offs, send_counts, recvbuf, recv_offs, recv_counts, peers):
         """ialltoall with a chunk per peer of its own offset and length (the pencil Poisson solver's groups of
@@ -237,7 +282,7 @@ class Comm:
                     sends.append((sendbuf[s0:s0 + cs], peer))
                 if cr:
                     recvs.append((recvbuf[r0:r0 + cr], peer))
-        return self._start(sends, recvs)
+        return self._start(sends, recvs, "alltoall")
 
     # ------------------------------------------------------------ scalars
     def allreduce(self, value, op="sum"):

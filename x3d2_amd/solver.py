@@ -104,6 +104,12 @@ class Solver:
         self.n_zfirst = 0                                # pressure corrections through the z-first 000 solve
         pf = backend.poisson_fft if cfg.poisson_solver_type == "FFT" else None
         self._zfirst = bool(pf is not None and getattr(pf, "zfirst_ok", lambda: False)())
+        if self._zfirst:
+            # ... and BOTH z operator pairs around the solve are ones the z-transforming kernels take: asked once, here,
+            # so that _zfirst_solve never finds the divergence's pair served and the gradient's declined
+            z = self.zdirps
+            self._zfirst = (backend.zfirst_pairs_ok(z.interpl_v2p, z.stagder_v2p)
+                            and backend.zfirst_pairs_ok(z.interpl_p2v, z.stagder_p2v))
         self.shift_request = None  # device scalar to add to u before transeq_x uses it (field_mean_shift)
         self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
