@@ -1464,6 +1464,19 @@ def test_emulated_y_slab_path_with_every_exchange_through_rccl_to_self():
     assert int(r.stdout.split("halo_launches=")[1].split()[0]) > 0
 
 
+@pytest.mark.parametrize("py", [2, 8])
+def test_y_slab_all_to_all_of_py_ranks_through_rccl_to_self(py):
+    """tests/rccl_self_py8_worker.py: the y-slab solver's exchange pattern of a py-rank job (bench.py --gpus py: 4 groups
+    of kz planes, py send / recv pairs per group, the y stage beside the transfers) through RCCL with every peer this
+    rank itself -- bit for bit the device-copy exchange, overlapped and ordered; Comm.self_check passes at construction"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_py8_worker.py"),
+                        str(py)], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "RCCL-TO-SELF-PY OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("parts", [1, 3, 0])
 def test_pencil_solver_in_groups_of_planes_equals_hooks_single_rank_solver_and_oracle(parts, monkeypatch):
     """csrc/pfft.hip in one process (py = pz = 1: every exchange a copy to itself): poisson_000 with the local z

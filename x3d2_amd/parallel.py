@@ -55,6 +55,11 @@ class Comm:
         # RCCL send / recv to itself instead of device copies -- the only way to put the RCCL code path (group launch,
         # communication stream, wait semantics) under a test on a one-GPU box
         self.self_via_nccl = self.enabled and self.backend == "nccl" and os.environ.get("X3D_COMM_SELF_VIA_NCCL") == "1"
+        # X3D_COMM_FAKE_PEERS=1 (world size 1 only): EVERY peer of an all-to-all is this rank -- chunk i of the send buffer
+        # lands in slot i of the receive buffer, as a device copy or (with X3D_COMM_SELF_VIA_NCCL) as N send / recv pairs
+        # to self in one RCCL group: the group sizes, chunk lengths and part pipelining of an N-rank all-to-all run through
+        # RCCL on a one-GPU box (the numbers mean nothing: tests compare the two transports bit for bit)
+        self.fake_peers = self.size == 1 and os.environ.get("X3D_COMM_FAKE_PEERS") == "1"
         self._checked = self.host_staged or not self.enabled or not self.overlap or \
             (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
@@ -237,6 +242,7 @@ class Comm:
         so = ro = 0
         sends, recvs = [], []
         for cnt_s, cnt_r, peer in zip(send_counts, recv_counts, peers):
+            peer = self.rank if self.fake_peers else peer
             if peer == self.rank and not self.self_via_nccl:
                 if not (recvbuf.data_ptr() == sendbuf.data_ptr() and ro == so):  # (aliased buffers: nothing to move)
                     recvbuf[ro:ro + cnt_r].copy_(sendbuf[so:so + cnt_s])
@@ -258,6 +264,7 @@ class Comm:
         rs = count if recv_stride is None else recv_stride
         sends, recvs = [], []
         for i, peer in enumerate(peers):
+            peer = self.rank if self.fake_peers else peer
             s0, r0 = send_off + i * ss, recv_off + i * rs
             if peer == self.rank and not self.self_via_nccl:
                 if not (recvbuf.data_ptr() == sendbuf.data_ptr() and r0 == s0):
@@ -272,6 +279,7 @@ class Comm:
         planes: x modes / y rows are shared out unevenly)"""
         sends, recvs = [], []
         for s0, cs, r0, cr, peer in zip(send_offs, send_counts, recv_offs, recv_counts, peers):
+            peer = self.rank if self.fake_peers else peer
             if peer == self.rank and not self.self_via_nccl:
                 if cs != cr:
                     raise ValueError("ialltoallv: the chunk a rank keeps has one length")
