@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of library builds (round 4): scratch/ab4.sh "<libA.so> <libB.so> ..." [reps] [bench.py args]
 # prints ms per step, the dominant kernel's launch time, the transeq / tds / fft / spectral class times of the extra step
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.."; mkdir -p gpurun_out/r04
 LIBS=$1; REPS=${2:-2}; shift 2
 for i in $(seq $REPS); do for L in $LIBS; do
   X3D_LIB=$PWD/$L python scratch/chan_ab.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "

@@ -41,6 +41,31 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Streaming accesses (round 4).  A flat copy on this chip reaches 6.2 TB/s only with NONTEMPORAL 16-byte loads and
+// stores (5.6 with plain ones: profiles/r04_copy_ceiling.txt); every field row of the derivative kernels is read once
+// and written once per launch, so their global accesses carry the hint.  The builtin has no overload for HIP's double2
+// struct -- through an ext_vector_type the access stays ONE global_load_dwordx4 ... nt (two 8-byte builtins do not
+// always fuse back).  -DX3D_NO_NT: plain accesses (A/B builds).
+typedef double x3d_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldg_stream(const double2 *p)
+{
+#ifndef X3D_NO_NT
+    const x3d_d2v v = __builtin_nontemporal_load(reinterpret_cast<const x3d_d2v *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stg_stream(double2 *p, double2 v)
+{
+#ifndef X3D_NO_NT
+    const x3d_d2v w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<x3d_d2v *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // Store acknowledgements and loop-carried prefetches (round 4).  On gfx950 loads and stores share ONE in-order counter
 // (vmcnt).  A persistent kernel that prefetches its next input before it stores its current result has, at the top of
 // the next iteration, [prefetch loads][later loads][stores] outstanding, and needs only the prefetch -- the hardware

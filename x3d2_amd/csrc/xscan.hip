@@ -107,6 +107,7 @@ __device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lan
     } else {
         v0.x = a0; v0.y = a1; v1.x = d0; v1.y = d1; v2.x = c0; v2.y = c1; v3.x = b0; v3.y = b1;
     }
+    // (plain stores: an instruction writes whole 64-byte sectors but only half of each 128-byte line)
     o2[0] = v0; o2[4] = v1; o2[8] = v2; o2[12] = v3;
 }
 
@@ -927,7 +928,7 @@ __global__ void __launch_bounds__(1024)
     const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
     auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);
+        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
     };
     auto to_tile = [&](const double2 (&v)[NI]) {
 #pragma unroll
@@ -1147,7 +1148,7 @@ __global__ void __launch_bounds__(1024)
     const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
     auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);
+        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
     };
     auto to_tile = [&](const double2 (&v)[NI]) {
 #pragma unroll

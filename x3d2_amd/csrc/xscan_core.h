@@ -318,6 +318,9 @@ __device__ __forceinline__ void load_body(double (&b)[Q], const double *__restri
     const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
 #pragma unroll
     for (int m = 0; m < Q / 2; m++) {
+        // (plain, not ldg_stream: a lane's 64 bytes are four instructions that each touch a QUARTER of every 64-byte
+        //  sector -- the lines must stay cached between them; with the nontemporal hint the x kernels ran 25 % slower,
+        //  profiles/README.md round 4)
         const double2 t2 = body[m];
         b[2 * m] = t2.x;
         b[2 * m + 1] = t2.y;
