@@ -95,6 +95,48 @@ __global__ void __launch_bounds__(256) k_mix(const v4* __restrict__ a, v4* __res
   }
 }
 
+// the same mix with one contiguous chunk per workgroup (the shape that reaches 6.2 TB/s as a copy)
+template<int R, int U, int NTL, int NTS>
+__global__ void __launch_bounds__(256) k_mix_chunk(const v4* __restrict__ a, v4* __restrict__ b, size_t chunk, size_t fld){
+  const v4* s = a + blockIdx.x * chunk;
+  v4* d = b + blockIdx.x * chunk;
+  for (size_t i = threadIdx.x; i < chunk; i += 256 * U) {
+    v4 v[U][R];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int r = 0; r < R; r++) v[u][r] = ld<NTL>(s + r * fld + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v4 t = v[u][0];
+#pragma unroll
+      for (int r = 1; r < R; r++) t += v[u][r];
+      st<NTS>(d + i + u * 256, t);
+    }
+  }
+}
+// 2R:2W (k_xscan_tds_lin's first stage: u, rhs in; u_new, du out) and 3R:2W
+template<int R, int U, int NTL, int NTS>
+__global__ void __launch_bounds__(256) k_mix2w_chunk(const v4* __restrict__ a, v4* __restrict__ b, size_t chunk, size_t fld){
+  const v4* s = a + blockIdx.x * chunk;
+  v4* d = b + blockIdx.x * chunk;
+  for (size_t i = threadIdx.x; i < chunk; i += 256 * U) {
+    v4 v[U][R];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int r = 0; r < R; r++) v[u][r] = ld<NTL>(s + r * fld + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v4 t = v[u][0];
+#pragma unroll
+      for (int r = 1; r < R; r++) t += v[u][r];
+      st<NTS>(d + i + u * 256, t);
+      st<NTS>(d + fld + i + u * 256, t * 2.0f);
+    }
+  }
+}
+
 // in-place update b += a (the accumulating kernels' rhs read-modify-write): 2R:1W with the write onto a read line
 template<int U>
 __global__ void __launch_bounds__(256) k_rmw(const v4* __restrict__ a, v4* __restrict__ b, size_t n){
@@ -113,8 +155,8 @@ int main(int argc, char** argv){
   size_t bytes = (argc > 1 ? atof(argv[1]) : 1.0) * (1ull << 30);   // per buffer
   size_t n = bytes / 16;
   v4 *a, *b; float* out;
-  CK(hipMalloc(&a, 4 * bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&out, 64));
-  CK(hipMemset(a, 0, 4 * bytes)); CK(hipMemset(b, 0, bytes));
+  CK(hipMalloc(&a, 4 * bytes)); CK(hipMalloc(&b, 2 * bytes)); CK(hipMalloc(&out, 64));
+  CK(hipMemset(a, 0, 4 * bytes)); CK(hipMemset(b, 0, 2 * bytes));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int dev; hipGetDevice(&dev); hipDeviceProp_t pr; hipGetDeviceProperties(&pr, dev);
   printf("# %s, %d CUs, buffers of %.2f GiB\n", pr.name, pr.multiProcessorCount, bytes / double(1ull << 30));
@@ -154,5 +196,13 @@ int main(int argc, char** argv){
 #define RM(U, G) snprintf(nm, 160, "in-place b += a (2R:1W, rmw) 16B U=%d grid=%d", U, G); \
   timeit(nm, 3.0 * bytes, [&]{ hipLaunchKernelGGL((k_rmw<U>), dim3(G), dim3(256), 0, 0, a, b, n); });
   for (int g : {256 * 8, 256 * 32}) { RM(2, g) RM(4, g) }
+#define MC(R, U, NTL, NTS, G) snprintf(nm, 160, "mix %dR:1W chunk-per-workgroup U=%d ntl=%d nts=%d grid=%d", R, U, NTL, NTS, G); \
+  timeit(nm, (R + 1.0) * bytes, [&]{ hipLaunchKernelGGL((k_mix_chunk<R, U, NTL, NTS>), dim3(G), dim3(256), 0, 0, a, b, n / (G), n); });
+#define M2(R, U, NTL, NTS, G) snprintf(nm, 160, "mix %dR:2W chunk-per-workgroup U=%d ntl=%d nts=%d grid=%d", R, U, NTL, NTS, G); \
+  timeit(nm, (R + 2.0) * bytes, [&]{ hipLaunchKernelGGL((k_mix2w_chunk<R, U, NTL, NTS>), dim3(G), dim3(256), 0, 0, a, b, n / (G), n); });
+  for (int g : {256 * 32, 256 * 128}) {
+    MC(2, 2, 0, 0, g) MC(2, 2, 1, 1, g) MC(3, 2, 0, 0, g) MC(3, 2, 1, 1, g) MC(3, 1, 1, 1, g) MC(4, 1, 1, 1, g)
+    M2(2, 2, 0, 0, g) M2(2, 2, 1, 1, g) M2(3, 2, 1, 1, g) M2(3, 1, 0, 0, g)
+  }
   return 0;
 }
