@@ -10,9 +10,23 @@ __global__ void __launch_bounds__(1024) k(double *out, int iters)
     __syncthreads();
     const int lane = threadIdx.x & 63;
     unsigned addr = lane * (KIND == 2 ? 16 : 8);
+    // round 4: what does a table read cost when most lanes want the SAME value (periodic operators on a uniform grid:
+    // lanes 8..55 of every entry are bitwise equal)?  KIND 3: all lanes one address (broadcast); 4: the compressed
+    // layout (lanes 0..7 | one address for 8..55 | 56..63: 17 doubles per entry); 5 / 6: ds_read_b64 with only the 16
+    // edge lanes (0..7, 56..63) / only lanes 0..15 active
+    if (KIND == 3) addr = 0;
+    if (KIND == 4) addr = (lane < 8 ? lane : (lane > 55 ? lane - 47 : 8)) * 8;
     double acc = 0.0;
     for (int it = 0; it < iters; it++) {
-        if (KIND == 0) {  // 8 x ds_read_b64, entries 512 B apart
+        if (KIND == 5 || KIND == 6) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+            if (KIND == 5 ? (lane < 8 || lane > 55) : lane < 16) {
+                asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:512\n ds_read_b64 %2, %8 offset:1024\n ds_read_b64 %3, %8 offset:1536\n"
+                             "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(addr) : "memory");
+            }
+            acc += a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+        } else if (KIND == 0 || KIND == 3 || KIND == 4) {  // 8 x ds_read_b64, entries 512 B apart
             double a0, a1, a2, a3, a4, a5, a6, a7;
             asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:512\n ds_read_b64 %2, %8 offset:1024\n ds_read_b64 %3, %8 offset:1536\n"
                          "ds_read_b64 %4, %8 offset:2048\n ds_read_b64 %5, %8 offset:2560\n ds_read_b64 %6, %8 offset:3072\n ds_read_b64 %7, %8 offset:3584\n s_waitcnt lgkmcnt(0)"
@@ -54,5 +68,13 @@ int main()
     hipFuncSetAttribute((const void *)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     run<0>("ds_read_b64", out); run<1>("ds_read2st64_b64", out); run<2>("ds_read_b128", out);
     run<0>("ds_read_b64", out); run<1>("ds_read2st64_b64", out); run<2>("ds_read_b128", out);
+    hipFuncSetAttribute((const void *)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void *)k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void *)k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void *)k<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int r = 0; r < 2; r++) {
+        run<3>("b64, all lanes one address", out); run<4>("b64, compressed layout", out);
+        run<5>("b64, 16 edge lanes active", out); run<6>("b64, lanes 0..15 active", out);
+    }
     return 0;
 }

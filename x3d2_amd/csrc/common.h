@@ -260,6 +260,8 @@ struct x3d_tdsops {
     const double *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
     const double *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
+    int uniform;                 // 1: stretch == 1 and stretch_correct == 0 on every row (a uniform grid): kernels may skip
+                                 //    the ST / STC lane-table reads and their multiplications (x * 1.0, + nu * x * 0.0)
     int halo_ws, halo_we;        // rows 1..ws / n-we+1..n: where |dist_sa| / |dist_sc| >= 2^-60 (xscan.hip, *_halo_fix)
     struct x3d_penta *penta;     // compact10_penta: the pentadiagonal LU tables (penta.hip), else null
 };

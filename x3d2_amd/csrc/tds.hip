@@ -216,6 +216,9 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     for (int r = 0; r < 4; r++)
         for (int m = 0; m < 9; m++)
             if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) tb.bulk_only = 0;
+    t->uniform = 1;
+    for (int j = 1; j <= n; j++)
+        if (St[j] != 1.0 || Stc[j] != 0.0) t->uniform = 0;
     t->narrow_all = 1;
     for (int m = 0; m < 9; m++) {
         if (m >= 2 && m <= 6) continue;

@@ -901,7 +901,12 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 #define YT_T(k)
 #endif
 
-template <int Q, bool ACC, bool NARROW, bool HALO>
+// UNI: both operators live on a uniform grid (stretch == 1, stretch_correct == 0 on every row): the ST / STC lane-table
+// reads and their multiplications are skipped (x * 1.0 and + nu * (x * 0.0): the same values).  The solves of this
+// kernel are bound by the RATE of LDS read instructions -- 2.6 clocks per ds_read_b64 and CU whatever the lanes read
+// (scratch/ldsbench.hip, round 4: broadcast, compressed and exec-masked reads cost the same), 236 table reads per lane
+// and component; without any table read the kernel runs at its memory time (2.30 -> 1.88 ms, -DXSCAN_EXP=4).
+template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
                      const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
@@ -1024,11 +1029,18 @@ __global__ void __launch_bounds__(1024)
                 }
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const double st = LTR(l, LT_ST(q));
-                    double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
-                    if (q == 0) x = (lane == 0) ? s_ * st : x;
-                    if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
-                    T[q] = x;
+                    if constexpr (UNI) {
+                        double x = T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_;
+                        if (q == 0) x = (lane == 0) ? s_ : x;
+                        if (q == Q - 1) x = (lane == 63) ? e_ : x;
+                        T[q] = x;
+                    } else {
+                        const double st = LTR(l, LT_ST(q));
+                        double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
+                        if (q == 0) x = (lane == 0) ? s_ * st : x;
+                        if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
+                        T[q] = x;
+                    }
                 }
             };
             double r[Q], T[Q];
@@ -1042,7 +1054,10 @@ __global__ void __launch_bounds__(1024)
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             solve_subs(wu, T, l1, tD1, 1);
 #pragma unroll
-            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
+            for (int q = 0; q < Q; q++) {
+                if constexpr (UNI) r[q] = -0.5 * (cb[q] * T[q] + r[q]);
+                else r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
+            }
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             solve_subs(wu, T, l3, tD2, 2);
             {
@@ -1757,6 +1772,9 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 256 + 288 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
+    static int uni_on = -1;
+    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
+    const bool uni = uni_on && der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16;
     int tile0, ntiles;
@@ -1767,14 +1785,14 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
-#define GO(Q_, A_, N_, H_)                                                                                      \
+#define GO(Q_, A_, N_, H_, U_)                                                                                  \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_>));                                                   \
-        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_, U_>));                                               \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_, U_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
                            f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, tile0, ntiles, rstride, ostride, nu, th); \
     } while (0)
-#define GOH(Q_, A_, N_) do { if (halo) GO(Q_, A_, N_, true); else GO(Q_, A_, N_, false); } while (0)
-#define GON(Q_, A_) do { if (narrow) GOH(Q_, A_, true); else GOH(Q_, A_, false); } while (0)
+#define GOH(Q_, A_, N_, U_) do { if (halo) GO(Q_, A_, N_, true, U_); else GO(Q_, A_, N_, false, U_); } while (0)
+#define GON(Q_, A_) do { if (narrow && uni) GOH(Q_, A_, true, true); else if (narrow) GOH(Q_, A_, true, false); else GOH(Q_, A_, false, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);

@@ -33,7 +33,9 @@
 // 4.3 against 2.6 LDS clocks per 512-byte row; MI355X_MICROARCH.md, LDS table) -- and these kernels are
 // LDS-bound on exactly these reads (LdsUtil 83 % in k_ytile_transeq3).  The empty asm is a barrier for the
 // load / store combiner only (it ends a merge window); it emits nothing.
-#ifndef XS_READ2
+#if XSCAN_EXP == 4  // timing experiment: no lane-table reads at all (results are garbage): what the LDS reads cost
+__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx) { return 0.37 + 1e-3 * (idx & 7); }
+#elif !defined(XS_READ2)
 __device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx)
 {
     const double v = l[idx];
