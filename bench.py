@@ -496,7 +496,7 @@ def main():
         d_bytes = 64.0 * dof_local
         d_ach = d_bytes / (d_ms * 1e-3) / 1e9
         if args.case == "tgv" and args.gpus == 1:
-            name = "k_ytile_transeq3<8,true,true,false> (transeq_y and transeq_z, three components per launch)"
+            name = "k_ytile_transeq3<8,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
         elif args.case == "tgv":
             name = "k_ytile_transeq3 (transeq_y; HALO form + strip correction for the decomposed direction)"
         else:

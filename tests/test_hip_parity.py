@@ -1241,7 +1241,13 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec, route):
     if intg.startswith("RK"):
         assert n_fused == 3 * 2 * int(intg[2])  # every stage of every variable took the fused kernel
     for a, b_ in zip(fused, plain):
-        assert np.array_equal(a, b_)
+        if route == "tile":
+            # the stage-in-tile kernel solves a component's operators one by one, the three-in-one kernel of the plain run
+            # solves the first two as a pair (round 4, k_ytile_transeq3<.., P12>): the same sums with another choice of
+            # which product an FMA contracts -- a few ulp
+            assert relerr(a, b_) < 1e-14
+        else:
+            assert np.array_equal(a, b_)
     if nspec:
         return  # (species transport against the oracle: test_transeq_species_vs_reference)
     om = orc.Mesh(list(dims), [1, 1, 1], list(L), list(per), list(per), list(per))

@@ -906,7 +906,10 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 // kernel are bound by the RATE of LDS read instructions -- 2.6 clocks per ds_read_b64 and CU whatever the lanes read
 // (scratch/ldsbench.hip, round 4: broadcast, compressed and exec-masked reads cost the same), 236 table reads per lane
 // and component; without any table read the kernel runs at its memory time (2.30 -> 1.88 ms, -DXSCAN_EXP=4).
-template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false>
+// P12 (with UNI): the component's first two solves -- d(u conv) and du, the SAME operator on two right-hand sides -- run
+// as ONE solve over the pair type V2: every table value read from LDS serves both (204 -> 136 reads per lane and
+// component) and the two dependency chains interleave.  Same arithmetic per right-hand side, bit for bit.
+template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
                      const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
@@ -1048,6 +1051,28 @@ __global__ void __launch_bounds__(1024)
 #ifdef YT_TIMING
             const unsigned long long yt_s0 = __builtin_readcyclecounter();
 #endif
+            if constexpr (P12 && UNI) {
+                V2 w2[Q + 8], T2[Q], a2, b2;
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m] = V2{wp[m], wu[m]};
+                scan_solve<Q, true, NARROW, V2>(w2, T2, a2, b2, l1, tD1, lane, first);
+                V2 s_, e_;
+                if constexpr (HALO) {
+                    s_ = tD1.rs_s * a2; e_ = tD1.rs_e * b2;
+                    bnd[(wave * 9 + c * 3 + 0) * 2] = a2.a; bnd[(wave * 9 + c * 3 + 0) * 2 + 1] = b2.a;
+                    bnd[(wave * 9 + c * 3 + 1) * 2] = a2.b; bnd[(wave * 9 + c * 3 + 1) * 2 + 1] = b2.b;
+                } else {
+                    s_ = tD1.rs_s * (a2 - tD1.sa1 * b2); e_ = tD1.rs_e * (b2 - tD1.scn * a2);
+                }
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const double sa = LTR(l1, LT_SA(q)), sc = LTR(l1, LT_SC(q));
+                    double xa = T2[q].a - sa * s_.a - sc * e_.a, xb = T2[q].b - sa * s_.b - sc * e_.b;
+                    if (q == 0) { xa = (lane == 0) ? s_.a : xa; xb = (lane == 0) ? s_.b : xb; }
+                    if (q == Q - 1) { xa = (lane == 63) ? e_.a : xa; xb = (lane == 63) ? e_.b : xb; }
+                    r[q] = -0.5 * (cb[q] * xb + xa);
+                }
+            } else {
             solve_subs(wp, T, l1, tD1, 0);
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = T[q];
@@ -1058,7 +1083,16 @@ __global__ void __launch_bounds__(1024)
                 if constexpr (UNI) r[q] = -0.5 * (cb[q] * T[q] + r[q]);
                 else r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
             }
+            }
             asm volatile("" : "+v"(lane) : "v"(r[0]));
+            if constexpr (P12 && UNI) {
+                // the field's window again, from the tile (it still holds the component's rows): keeping wu alive
+                // across the pair solve does not fit the 128 registers (121 + 56 bytes of scratch)
+                double b[Q];
+                pick(b);
+                if constexpr (HALO) window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
+                else window_from_body<Q>(wu, b, lane);
+            }
             solve_subs(wu, T, l3, tD2, 2);
             {
                 // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component;
@@ -1787,8 +1821,9 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
 #define GO(Q_, A_, N_, H_, U_)                                                                                  \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_, U_>));                                               \
-        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_, U_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
+        /* (the pair solve P12 only in the local form: with the HALO extras it spills, 128 VGPRs + 124 bytes) */ \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_))>));                                \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_))>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
                            f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, tile0, ntiles, rstride, ostride, nu, th); \
     } while (0)
 #define GOH(Q_, A_, N_, U_) do { if (halo) GO(Q_, A_, N_, true, U_); else GO(Q_, A_, N_, false, U_); } while (0)
