@@ -329,6 +329,8 @@ def main():
         rec = {"decomp": decomp}
         ok, built = 1.0, None
         try:
+            if os.environ.get("X3D_BENCH_FAIL_DECOMP") == decomp:  # (test hook: exercise the fall-back chain)
+                raise RuntimeError("X3D_BENCH_FAIL_DECOMP")
             built = build(decomp)
             case = built[0]
             case.step(1)
