@@ -1164,7 +1164,8 @@ __global__ void __launch_bounds__(1024)
 // (csrc/zfft_tile.h) -- MODE 0 stores the 257 x 16 modes of its result into the spectrum instead of out1, MODE 1 builds
 // its input tile from the spectrum instead of in1 (neither array is touched).  The tile area grows to the transforms'
 // 72 KB; the table sets are staged without their STC block, which tds_solve does not read.
-template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false>
+// UNI: both operators on a uniform grid -- no ST reads / multiplications (see k_ytile_transeq3)
+template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
                      XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn,
@@ -1241,10 +1242,16 @@ __global__ void __launch_bounds__(1024)
         }
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const double st = LTR(l, LT_ST(q));
-            r[q] = (X[q] - LTR(l, LT_SA(q)) * du_s - LTR(l, LT_SC(q)) * du_e) * st;
-            if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
-            if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+            if constexpr (UNI) {
+                r[q] = X[q] - LTR(l, LT_SA(q)) * du_s - LTR(l, LT_SC(q)) * du_e;
+                if (q == 0) r[q] = (lane == 0) ? du_s : r[q];
+                if (q == Q - 1) r[q] = (lane == 63) ? du_e : r[q];
+            } else {
+                const double st = LTR(l, LT_ST(q));
+                r[q] = (X[q] - LTR(l, LT_SA(q)) * du_s - LTR(l, LT_SC(q)) * du_e) * st;
+                if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
+                if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+            }
         }
     };
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
@@ -1682,6 +1689,9 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
+    static int uni_on = -1;
+    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
+    const bool uni = uni_on && ta->uniform && tb->uniform;
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16;
     int tile0, ntiles;
@@ -1696,15 +1706,15 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     const int blocks = ntiles > cap ? cap : ntiles;
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GO(Q_, M_, N_, H_)                                                                                      \
+#define GO(Q_, M_, N_, H_, U_)                                                                                  \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_>));                                                   \
-        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_, false, U_>));                                        \
+        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_, false, U_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
                            in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn,   \
                            ZfArg{});                                                                            \
     } while (0)
-#define GOH(Q_, M_, N_) do { if (halo) GO(Q_, M_, N_, true); else GO(Q_, M_, N_, false); } while (0)
-#define GON(Q_, M_) do { if (narrow) GOH(Q_, M_, true); else GOH(Q_, M_, false); } while (0)
+#define GOH(Q_, M_, N_, U_) do { if (halo) GO(Q_, M_, N_, true, U_); else GO(Q_, M_, N_, false, U_); } while (0)
+#define GON(Q_, M_) do { if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
@@ -1743,14 +1753,17 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, 
     const int blocks = ntiles > cap ? cap : ntiles;
     const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
-#define GO(M_, N_)                                                                                              \
+#define GO(M_, N_, U_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true>));                                           \
-        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_>));                                       \
+        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
                            out2, in1, in2, xop_of(ta), xop_of(tb), ntx, 0, ntiles, pxy, (long)b->nxp, th, 0, zf); \
     } while (0)
-    if (mode == 0) { if (narrow) GO(0, true); else GO(0, false); }
-    else { if (narrow) GO(1, true); else GO(1, false); }
+    static int uni_on = -1;
+    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
+    const bool uni = uni_on && ta->uniform && tb->uniform;
+    if (mode == 0) { if (narrow && uni) GO(0, true, true); else if (narrow) GO(0, true, false); else GO(0, false, false); }
+    else { if (narrow && uni) GO(1, true, true); else if (narrow) GO(1, true, false); else GO(1, false, false); }
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;
