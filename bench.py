@@ -53,6 +53,25 @@ def auto_decomposition(case, n, lazy=False, op_granular=False):
     return "yslabs" if (case == "tgv" and n == 512 and not lazy and not op_granular) else "slabs"
 
 
+def effective_cpus():
+    """(physical cores, CPUs this process may actually use): the pool's boxes show 128 cores / 256 threads but run in a
+    container with a CFS quota of 16 CPUs (/sys/fs/cgroup/cpu.max = "1600000 100000") -- more busy threads or MPI ranks than
+    that are throttled (16 busy-polling ranks at the quota ran 45 x slower per DoF than 16 ranks of a short run)"""
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except ImportError:
+        phys = os.cpu_count() or 1
+    eff = phys
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            eff = max(1, min(phys, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return phys, eff
+
+
 def cpu_baseline(n, steps, threads):
     """the port baseline in a FRESH child process whose environment carries OMP_NUM_THREADS / OMP_PLACES /
     OMP_PROC_BIND: libgomp reads them once, when it is loaded -- and in this process torch has loaded it long before
@@ -241,7 +260,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1,
                     help="timed steps of the port baseline after its warm-up step (512^3: ~25 s each on the box's host)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="threads of the port baseline (0: 32, 64 and all physical cores are probed at 128^3, the fastest is used)")
+                    help="threads of the port baseline (0: the usable CPUs and twice that are probed at 128^3, the fastest is used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
@@ -266,13 +285,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
-    # the CPU baseline uses the physical cores of the host (set before libgomp starts)
-    try:
-        import psutil
-        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-    except ImportError:
-        phys = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(phys))
+    # the CPU baseline uses the cores the host really gives this process (set before libgomp starts)
+    phys, eff_cpus = effective_cpus()
+    os.environ.setdefault("OMP_NUM_THREADS", str(eff_cpus))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -583,24 +598,26 @@ def main():
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
         # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
         # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)
-        phys = int(os.environ["OMP_NUM_THREADS"])
-        # (threads of the C / OpenMP loops, pocketfft workers): they do not peak at the same count on a two-socket host
+        # (threads of the C / OpenMP loops, pocketfft workers): the CPUs the container's quota allows, and twice that
+        # (the port was measured fastest on 32 threads of a 16-CPU quota: its numpy passes overlap with the C loops)
+        eff = eff_cpus
         th = min(phys, args.cpu_threads) if args.cpu_threads > 0 else \
-            sorted({(min(32, phys), min(32, phys)), (phys, min(32, phys)), (min(64, phys), min(32, phys)), (phys, phys)})
+            sorted({(eff, eff), (min(2 * eff, phys), eff), (min(2 * eff, phys), min(2 * eff, phys))})
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, th)
+        out["cpu_baseline"]["host_cpus"] = {"physical_cores": phys, "usable_by_cgroup_quota": eff}
         # the real reference as the MPI code it is: R ranks of ONE OpenMP thread under mpirun (its OpenMP loops do not
         # scale -- 1 rank x 4 threads is slower than 1 x 1 on the build host, 4 ranks x 1 thread 3.3 x faster --, so
-        # ranks carry the cores; 16 threads per rank measured 6 x SLOWER than the single rank on the box's host), best
-        # of three rank counts, next to the single OpenMP rank rounds 1-3 timed; 3 steps each (its average excludes the
-        # first)
+        # ranks carry the cores), R = half and a quarter of the usable CPUs (AT the quota busy-polling ranks are throttled
+        # into each other's way), next to the single OpenMP rank rounds 1-3 timed; best shape reported, the others
+        # kept; 3 steps each (its average excludes the first)
         def shape(r):
             py = 1
             while py * py < r:
                 py *= 2
             return (1, py, r // py)
-        shapes = [((1, 1, 1), min(phys, 32))]
-        for r in (16, 64, 128):
-            if r <= phys:
+        shapes = [((1, 1, 1), min(phys, 2 * eff))]
+        for r in sorted({max(2, eff // 2), max(2, eff // 4)}, reverse=True):
+            if r & (r - 1) == 0:
                 shapes.append((shape(r), 1))
         refs = [r for r in (cpu_reference(256, 2 if nd == (1, 1, 1) else 3, t, nd) for nd, t in shapes) if r is not None]
         if refs:

@@ -108,7 +108,11 @@ __device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lan
         v0.x = a0; v0.y = a1; v1.x = d0; v1.y = d1; v2.x = c0; v2.y = c1; v3.x = b0; v3.y = b1;
     }
     // (plain stores: an instruction writes whole 64-byte sectors but only half of each 128-byte line)
+#ifdef XS_NT_STORES  // experiment: nontemporal stores only (the loads stay cached)
+    stg_stream(o2, v0); stg_stream(o2 + 4, v1); stg_stream(o2 + 8, v2); stg_stream(o2 + 12, v3);
+#else
     o2[0] = v0; o2[4] = v1; o2[8] = v2; o2[12] = v3;
+#endif
 }
 
 // Q = 4: a lane owns 32 B, a pair of lanes one 64-byte sector: 2 x 2 transpose of the 16-byte pairs
