@@ -626,7 +626,15 @@ def main():
                                      "value": r["value"]} for r in refs if r is not best]
             out["cpu_baseline"]["reference_nopoisson"] = best
     if rank == 0:
-        print(json.dumps(out))
+        # the JSON line is the LAST thing on stdout: whatever libraries left in C stdio's buffer (RCCL's version banner
+        # is printf'ed at init and would otherwise surface after Python's own output, at exit) goes out first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
