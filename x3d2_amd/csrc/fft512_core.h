@@ -94,3 +94,70 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
     }
     wave_lds_fence();
 }
+
+
+// ---- 256-point complex FFT of one pencil per wave, FOUR points per lane (round 4 experiment, -DZF_16WAVES, measured
+// slower and off by default -- profiles/r04_zf16_waves.txt: the z transforms on the tile of the
+// z operator pairs give every one of the 16 waves ONE real pencil -- 512 reals as 256 complex numbers -- instead of two
+// real pencils to 8 of them).  in / out a[k] = point l + 64 k; pen = this wave's LDS region (FP256 double2).
+// 256 = 4 x 4 x 4 x 4, decimation in frequency: f = f1 + 4 f2 + 16 f3 + 64 f4; every stage is a 4-point DFT in
+// registers, the three exchanges go through the wave's own region (no block barrier: a wave's LDS operations execute in
+// order).  Unnormalised, S = -1 forward / +1 backward like fft512_wave.
+#define FP256 288
+
+template <int S>
+__device__ __forceinline__ void fft4(double2 (&a)[4])
+{
+    const double2 b0 = cadd(a[0], a[2]), b1 = csub(a[0], a[2]), b2 = cadd(a[1], a[3]), d = csub(a[1], a[3]);
+    const double2 b3 = make_double2(-S * d.y, S * d.x);  // * W4^1 = S i
+    a[0] = cadd(b0, b2);
+    a[2] = csub(b0, b2);
+    a[1] = cadd(b1, b3);
+    a[3] = csub(b1, b3);
+}
+
+template <int S>
+__device__ __forceinline__ void fft256_wave(double2 (&a)[4], double2 *__restrict__ pen, const double2 *__restrict__ tw,
+                                            int l)
+{
+    wave_lds_fence();  // (the caller's accesses to this region come first)
+    // stage 1: over the points l + 64 n_a; twiddle W256^(l f1) = W512^(2 l f1)
+    fft4<S>(a);
+#pragma unroll
+    for (int f = 1; f < 4; f++) a[f] = cmul(a[f], twiddle<S>(tw, 2 * l * f));
+#pragma unroll
+    for (int f = 0; f < 4; f++) pen[f * 68 + l] = a[f];
+    wave_lds_fence();
+    {   // stage 2: lane (f1 = l >> 4, l0 = l & 15) takes the points l0 + 16 j; twiddle W64^(l0 f2) = W512^(8 l0 f2)
+        const int f1 = l >> 4, l0 = l & 15;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = pen[f1 * 68 + l0 + 16 * j];
+        fft4<S>(a);
+#pragma unroll
+        for (int f = 1; f < 4; f++) a[f] = cmul(a[f], twiddle<S>(tw, 8 * l0 * f));
+        wave_lds_fence();
+#pragma unroll
+        for (int f = 0; f < 4; f++) pen[(f1 * 4 + f) * 17 + l0] = a[f];
+    }
+    wave_lds_fence();
+    {   // stage 3: lane (f1 = l >> 4, f2 = (l >> 2) & 3, m0 = l & 3) takes the points m0 + 4 m; twiddle W16^(m0 f3) = W512^(32 m0 f3)
+        const int r = l >> 2, m0 = l & 3;
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = pen[r * 17 + m0 + 4 * m];
+        fft4<S>(a);
+#pragma unroll
+        for (int f = 1; f < 4; f++) a[f] = cmul(a[f], twiddle<S>(tw, 32 * m0 * f));
+        wave_lds_fence();
+#pragma unroll
+        for (int f = 0; f < 4; f++) pen[(r * 4 + f) * 4 + m0 + (r >> 2) * 4] = a[f];  // (+ 4 per f1: the rows of different f1 leave the same banks)
+    }
+    wave_lds_fence();
+    {   // stage 4: lane l = f1 + 4 f2 + 16 f3 takes the four m0 of its (f1, f2, f3); output a[f4] = X[l + 64 f4]
+        const int f1 = l & 3, f2 = (l >> 2) & 3, f3 = l >> 4;
+        const int row = ((f1 * 4 + f2) * 4 + f3) * 4 + f1 * 4;
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = pen[row + m];
+        fft4<S>(a);
+    }
+    wave_lds_fence();
+}

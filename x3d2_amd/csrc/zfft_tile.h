@@ -30,6 +30,53 @@ __device__ __forceinline__ int zf_t2(int m, int x) { return m * 16 + (x ^ (m & 1
 
 // area holds the real tile [16][TP] and every thread of the 16 waves has passed a barrier since it was written;
 // crow = C + y * px + x0; on return the 257 x 16 modes are stored and the area is free again
+#ifdef ZF_16WAVES
+// Round 4 experiment, measured SLOWER (profiles/r04_zf16_waves.txt; off by default): EVERY wave transforms -- wave w takes the real pencil w as 256 complex numbers z_j = x_{2j} + i x_{2j+1}
+// (fft256_wave) and splits:  E_k = (Z_k + conj Z_{256-k}) / 2,  O_k = (Z_k - conj Z_{256-k}) / (2 i),
+// X_k = E_k + W512^k O_k (k = 0 .. 255),  X_256 = E_0 - O_0.  Four radix-4 stages exchange 24 KB per real pencil through
+// LDS where the 512-point radix-8 form below exchanges 16 KB, and the transform phase is LDS-bandwidth bound.
+template <int TP>
+__device__ __forceinline__ void zf_forward(double *__restrict__ area, const double2 *__restrict__ tws,
+                                           double2 *__restrict__ crow, long kzstride, int wave, int lane)
+{
+    double2 a[4], X[4], X256 = make_double2(0.0, 0.0);
+    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    {
+        const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(area + wave * TP);
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] = pa[lane + 64 * k];
+    }
+    __syncthreads();  // (the transform regions overlap other waves' pencils)
+    {
+        double2 *__restrict__ pen = T2 + wave * FP256;
+        fft256_wave<-1>(a, pen, tws, lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) pen[lane + 64 * k] = a[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = lane + 64 * k;
+            const double2 z = a[k], c = pen[(256 - idx) & 255];
+            const double2 E = make_double2(0.5 * (z.x + c.x), 0.5 * (z.y - c.y));
+            const double2 O = make_double2(0.5 * (z.y + c.y), -0.5 * (z.x - c.x));
+            X[k] = cadd(E, cmul(twiddle<-1>(tws, idx), O));
+            if (k == 0 && lane == 0) X256 = make_double2(E.x - O.x, 0.0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) T2[zf_t2(lane + 64 * k, wave)] = X[k];
+    if (lane == 0) T2[zf_t2(256, wave)] = X256;
+    __syncthreads();
+    const int r = threadIdx.x >> 4, x = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int m = r + 64 * i;
+        if (i < 4 || threadIdx.x < 16) crow[(long)m * kzstride + x] = T2[zf_t2(m, x)];
+    }
+    __syncthreads();
+}
+#else
 template <int TP>
 __device__ __forceinline__ void zf_forward(double *__restrict__ area, const double2 *__restrict__ tws,
                                            double2 *__restrict__ crow, long kzstride, int wave, int lane)
@@ -79,6 +126,8 @@ __device__ __forceinline__ void zf_forward(double *__restrict__ area, const doub
     __syncthreads();
 }
 
+#endif
+
 // the tile's 257 x 16 modes into registers (issued early: they are in flight while the previous tile is worked on)
 struct ZfRows { double2 v0, v1, v2, v3, v4; };
 __device__ __forceinline__ ZfRows zf_inverse_load(const double2 *__restrict__ crow, long kzstride)
@@ -94,6 +143,41 @@ __device__ __forceinline__ ZfRows zf_inverse_load(const double2 *__restrict__ cr
 // the area is free (a barrier since its last use); on return it holds the real tile [16][TP], barrier passed.
 // Unnormalised inverse (e^{+i}); imaginary parts of the kz = 0 and kz = 256 planes belong to the pair's other pencil
 // only through rounding noise of a Hermitian spectrum.
+#ifdef ZF_16WAVES
+// every wave: Z_k = E_k + i O_k with E_k = X_k + conj X_{256-k}, O_k = (X_k - conj X_{256-k}) W512^{-k} (the factor 2 of
+// the 256-point transform folded in: the result is the unnormalised inverse, 512 x the pencil)
+template <int TP>
+__device__ __forceinline__ void zf_inverse(double *__restrict__ area, const double2 *__restrict__ tws,
+                                           const ZfRows &v, int wave, int lane)
+{
+    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    const int r = threadIdx.x >> 4, x = threadIdx.x & 15;
+    T2[zf_t2(r, x)] = v.v0;
+    T2[zf_t2(r + 64, x)] = v.v1;
+    T2[zf_t2(r + 128, x)] = v.v2;
+    T2[zf_t2(r + 192, x)] = v.v3;
+    if (threadIdx.x < 16) T2[zf_t2(256, x)] = v.v4;
+    __syncthreads();
+    double2 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int m = lane + 64 * k;
+        const double2 X = T2[zf_t2(m, wave)], C = T2[zf_t2(256 - m, wave)];
+        const double2 E = make_double2(X.x + C.x, X.y - C.y), D = make_double2(X.x - C.x, X.y + C.y);
+        const double2 O = cmul(D, twiddle<1>(tws, m));
+        a[k] = make_double2(E.x - O.y, E.y + O.x);
+    }
+    __syncthreads();
+    fft256_wave<1>(a, T2 + wave * FP256, tws, lane);
+    __syncthreads();
+    {
+        double2 *__restrict__ pa = reinterpret_cast<double2 *>(area + wave * TP);
+#pragma unroll
+        for (int k = 0; k < 4; k++) pa[lane + 64 * k] = a[k];
+    }
+    __syncthreads();
+}
+#else
 template <int TP>
 __device__ __forceinline__ void zf_inverse(double *__restrict__ area, const double2 *__restrict__ tws,
                                            const ZfRows &v, int wave, int lane)
@@ -129,3 +213,4 @@ __device__ __forceinline__ void zf_inverse(double *__restrict__ area, const doub
     }
     __syncthreads();
 }
+#endif
