@@ -383,6 +383,12 @@ int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, const double *
 int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double *a0, const double *a1);
 int x3d_poisson_postprocess_010(x3d_poisson *p);                  /* fft_postprocess_010    */
 int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_010          */
+/* poisson_010 (src/poisson_fft.f90:228-242) without enforce / undo_periodicity_y: the rows of f are already in
+ * enforce_periodicity_y's order (the operator pair that produces the divergence writes them so) and the solution is
+ * left in that order.  ny = 256 on a stretched grid: x and z transforms, then ONE pass over the spectrum for the y
+ * transform, fft_postprocess_010 and the inverse y transform (csrc/y010.hip); X3D_NO_Y010=1: the 3-D transforms with
+ * the post-processing kernels between them (what every other size runs). */
+int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f);
 /* test hook: download / upload the spectral workspace [nz][ny][nx/2+1] complex */
 /* Poisson 100 (x non-periodic, y and z periodic): the reference transposes x <-> y and runs the 010 solve on the
  * transposed problem (fft_forward_100 / fft_postprocess_100 / fft_backward_100,

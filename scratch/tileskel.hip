@@ -85,6 +85,43 @@ __global__ void __launch_bounds__(1024) k_skel(const double *u0, const double *u
         }
     }
 }
+// W = 32 pencils per tile: 256-byte row segments instead of 128-byte ones (would need compressed lane tables to fit the
+// 132 KB tile; the question here is only what the memory system makes of the wider segments).  No LDS trips.
+template <int NT>
+__global__ void __launch_bounds__(1024) k_skel32(const double *u0, const double *u1, const double *u2, double *r0, double *r1,
+                                                 double *r2, int ntx, int ntiles, long prow, long pplane, int sleeps)
+{
+    constexpr int NL = 8;
+    const int cc = threadIdx.x & 15, cy = threadIdx.x >> 4;
+    auto off_of = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 32; };
+    auto load = [&](double2 (&v)[NL], const double *f, long off, bool nt) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) v[i] = nt ? ldg<NT>(f + off + (long)(cy + 64 * i) * prow + 2 * cc) : ldg<0>(f + off + (long)(cy + 64 * i) * prow + 2 * cc);
+    };
+    double2 nxt[NL];
+    if ((int)blockIdx.x < ntiles) load(nxt, u0, off_of(blockIdx.x), false);
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = off_of(tl);
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            double2 v[NL], old[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) v[i] = nxt[i];
+            __syncthreads();
+            const int tn = tl + gridDim.x;
+            const double *nsrc = c == 0 ? u1 : (c == 1 ? u2 : u0);
+            if (c < 2 || tn < ntiles) load(nxt, nsrc, c < 2 ? off : off_of(tn), false);
+            double *o = c == 0 ? r0 : (c == 1 ? r1 : r2);
+            delay_us(sleeps);
+            load(old, o, off, true);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                stg<NT>(o + off + (long)(cy + 64 * i) * prow + 2 * cc, make_double2(v[i].x + old[i].x, v[i].y + old[i].y));
+            __syncthreads();
+        }
+    }
+}
 int main()
 {
     const int nx = 512, ny = 512, nz = 512, nxp = 528;
@@ -129,6 +166,16 @@ int main()
                 const int ntiles = nx / 16 * (dir ? ny : nz);
                 if (early) run(nm, [&] { hipLaunchKernelGGL((k_skel<1, 1, 1>), dim3(256), dim3(1024), lds, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 16, ntiles, prow, pplane, sl); });
                 else run(nm, [&] { hipLaunchKernelGGL((k_skel<0, 1, 1>), dim3(256), dim3(1024), lds, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 16, ntiles, prow, pplane, sl); });
+            }
+    // 32-pencil tiles (256-byte segments); the delay per tile-component doubled (twice the pencils per tile)
+    for (int dir = 0; dir < 2; dir++)
+        for (int sl : {0, 24, 48, 60})
+            for (int nt = 0; nt < 2; nt++) {
+                snprintf(nm, 128, "%s 32-pencil tiles, delay %4.1f us, rhs %s", dir ? "z" : "y", sl * 512 / 2400.0, nt ? "nontemporal" : "plain");
+                const long prow = dir ? pxy : nxp, pplane = dir ? nxp : pxy;
+                const int ntiles = nx / 32 * (dir ? ny : nz);
+                if (nt) run(nm, [&] { hipLaunchKernelGGL((k_skel32<1>), dim3(256), dim3(1024), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 32, ntiles, prow, pplane, sl); });
+                else run(nm, [&] { hipLaunchKernelGGL((k_skel32<0>), dim3(256), dim3(1024), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 32, ntiles, prow, pplane, sl); });
             }
     return 0;
 }

@@ -102,6 +102,33 @@ def test_poisson_010_solve_vs_oracle(stretching, beta):
     assert relerr(got, ref) < 1e-10, relerr(got, ref)
 
 
+@pytest.mark.parametrize("form", ["split", "fused"])
+@pytest.mark.parametrize("stretching,beta", [("top-bottom", 0.259065151), ("centred", 1.3), ("bottom", 0.5)])
+def test_poisson_010_y_last_form_at_256_cells(stretching, beta, form, monkeypatch):
+    """256 cells along a stretched y (the channel case's wall-normal direction): x and z are transformed first and
+    ONE pass over the spectrum does the y transform, fft_postprocess_010's paired split and the inverse y transform
+    (csrc/y010.hip; "fused": the pentadiagonal solves too) -- against the oracle and against the 3-D-transform form
+    (X3D_NO_Y010=1) on the same right-hand side"""
+    dims = (32, 257, 16)
+    if form == "fused":
+        monkeypatch.setenv("X3D_Y010_FUSED", "1")
+    s = product_solver(dims, stretching, beta)
+    o = oracle_solver(dims, stretching, beta)
+    rng = np.random.default_rng(12)
+    nx, ny, nz = (int(v) for v in o.mesh.global_cell_dims)
+    assert ny == 256
+    f = rng.standard_normal((nz, ny, nx))
+    got = hip_poisson_solve(s, f)
+    ref = o.poisson_fft.solve(f)
+    assert relerr(got, ref) < 1e-10, relerr(got, ref)
+    monkeypatch.setenv("X3D_NO_Y010", "1")
+    s3 = product_solver(dims, stretching, beta)
+    got3 = hip_poisson_solve(s3, f)
+    assert relerr(got3, ref) < 1e-10
+    assert relerr(got, got3) < 1e-12, relerr(got, got3)
+    assert np.max(np.abs(got - got3)) > 0.0  # (the two forms are different code: identical bits would mean one ran twice)
+
+
 @pytest.mark.parametrize("n_wave,kind", [(2, "COS_X"), (2, "COS_Y"), (2, "COS_XY"), (2, "COS_XYZ"), (3, "COS_Y")])
 def test_poisson_bc_010_acceptance(n_wave, kind):
     """tests/verification/test_poisson_bc.f90, config 010: 128 x 65 x 32, L = 1, tolerance 1e-11 on

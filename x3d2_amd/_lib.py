@@ -128,6 +128,7 @@ PROTOTYPES = {
     "x3d_poisson_set_stretching": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
     "x3d_poisson_postprocess_010": (I, [VP]),
     "x3d_poisson_solve_010": (I, [VP, VP, VP]),
+    "x3d_poisson_solve_010_rows": (I, [VP, VP]),
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
     "x3d_sfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),

@@ -179,6 +179,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
     if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
+    if (p->y010 == 1) { hipfftDestroy(p->plan_x010_fw); hipfftDestroy(p->plan_x010_bw); }
     hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->rwT); hipFree(p->rwZ);
     hipFree(p->lu[0]); hipFree(p->lu[1]);
     delete p;
@@ -480,10 +481,102 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
     X3D_LAZY_OUT(p->b, temp, true);
     X3D_LAZY_EAGER(p->b);
     if (int rc = x3d_poisson_enforce_periodicity_y(p, temp, f)) return rc;
-    if (int rc = x3d_poisson_fft_forward(p, temp)) return rc;
-    if (int rc = x3d_poisson_postprocess_010(p)) return rc;
-    if (int rc = x3d_poisson_fft_backward(p, temp)) return rc;
+    if (int rc = x3d_poisson_solve_010_rows(p, temp)) return rc;
     return x3d_poisson_undo_periodicity_y(p, f, temp);
+}
+
+int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, int mode, const double *tables, int sym,
+                 double *const lu[2], bool *done);
+
+// plans of the y-last form: 2-D transforms over (z, x) -- r2c along x on the pitched block, c2c along z -- batched over
+// the y rows (the middle dimension of both layouts is the batch: plane pitch as the inner embedding)
+static int y010_setup(x3d_poisson *p)
+{
+    if (p->y010) return 0;
+    p->y010 = -1;
+    const char *e = getenv("X3D_NO_Y010");
+    x3d_backend *b = p->b;
+    if ((e && e[0] == '1') || p->ny != 256 || p->nxs % 8 != 0) return 0;
+    int nn[2] = {p->nz, p->nx};
+    int re[2] = {b->nzp, b->nyp * b->nxp}, ce[2] = {p->nz, p->ny * p->nxs};
+    X3D_FFT(hipfftCreate(&p->plan_x010_fw));
+    X3D_FFT(hipfftCreate(&p->plan_x010_bw));
+    X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_fw, 0));
+    X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_bw, 0));
+    size_t ws_fw = 0, ws_bw = 0;
+    X3D_FFT(hipfftMakePlanMany(p->plan_x010_fw, 2, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, p->ny, &ws_fw));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x010_bw, 2, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, p->ny, &ws_bw));
+    const size_t ws = ws_fw > ws_bw ? ws_fw : ws_bw;
+    if (ws > p->work_size) {  // (the 3-D plans keep working in the larger area)
+        X3D_HIP(hipFree(p->work));
+        p->work = nullptr;
+        X3D_HIP(hipMalloc(&p->work, ws));
+        p->work_size = ws;
+        X3D_FFT(hipfftSetWorkArea(p->plan_fw, p->work));
+        X3D_FFT(hipfftSetWorkArea(p->plan_bw, p->work));
+    }
+    X3D_FFT(hipfftSetWorkArea(p->plan_x010_fw, p->work));
+    X3D_FFT(hipfftSetWorkArea(p->plan_x010_bw, p->work));
+    p->y010 = 1;
+    return 0;
+}
+
+// poisson_010 (src/poisson_fft.f90:228-242) without its two row permutations: f's y rows are already in
+// enforce_periodicity_y's order and the solution is left in that order.  ny = 256: x and z (one 2-D plan) ; the fused y pass (y010.hip:
+// y transform, fft_postprocess_010, inverse y transform in one pass over the spectrum) ; z ; x.  Otherwise the 3-D
+// transforms with the post-processing kernels between them.
+extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
+{
+    X3D_REQUIRE(p && f, "x3d_poisson_solve_010_rows: null argument");
+    X3D_LAZY_OUT(p->b, f, false);
+    X3D_LAZY_EAGER(p->b);
+    if (int rc = y010_setup(p)) return rc;
+    if (p->y010 == 1 && p->stretched) {  // (uniform y: one post-processing kernel between the 3-D transforms)
+        x3d_backend *b = p->b;
+        {
+            ProfScope ps(b, X3D_K_FFT, 1);
+            X3D_FFT(hipfftSetStream(p->plan_x010_fw, b->stream));
+            X3D_FFT(hipfftExecD2Z(p->plan_x010_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
+        }
+        bool done = false;
+        const char *ef = getenv("X3D_Y010_FUSED");
+        const bool fuse_penta = ef && ef[0] == '1';
+        if (p->stretched && fuse_penta) {
+            ProfScope ps(b, X3D_K_SPECTRAL);
+            if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 2, p->ab, p->sym, p->lu, &done)) return rc;
+        }
+        if (!done) {  // the y transforms fused with the halves of the post-processing, the pentadiagonal solves between
+                      // them as their own kernels (X3D_Y010_FUSED=1: all in one kernel -- measured, see y010.hip)
+            {
+                ProfScope ps(b, X3D_K_FFT, 1);
+                if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 0, p->ab, p->sym, p->lu, &done)) return rc;
+                X3D_REQUIRE(done, "x3d_poisson_solve_010_rows: y pass refused");
+            }
+            {
+                ProfScope ps(b, X3D_K_SPECTRAL);
+                const dim3 g2 = penta_grid(p->nxs, p->nz);
+                if (p->sym) {
+                    hipLaunchKernelGGL(k_penta_solve<false>, g2, dim3(64), 0, b->stream, p->c, p->lu[0], 0, 2, p->nxs, p->ny, p->nz,
+                                       p->ny / 2, p->nx, 0);
+                    hipLaunchKernelGGL(k_penta_solve<false>, g2, dim3(64), 0, b->stream, p->c, p->lu[1], 1, 2, p->nxs, p->ny, p->nz,
+                                       p->ny / 2, p->nx, 0);
+                } else {
+                    hipLaunchKernelGGL(k_penta_solve<false>, g2, dim3(64), 0, b->stream, p->c, p->lu[0], 0, 1, p->nxs, p->ny, p->nz,
+                                       p->ny, p->nx, 0);
+                }
+                X3D_HIP(hipGetLastError());
+            }
+            ProfScope ps(b, X3D_K_FFT, 2);
+            if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 1, p->ab, p->sym, p->lu, &done)) return rc;
+        }
+        ProfScope ps(b, X3D_K_FFT, 2);
+        X3D_FFT(hipfftSetStream(p->plan_x010_bw, b->stream));
+        X3D_FFT(hipfftExecZ2D(p->plan_x010_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f));
+        return 0;
+    }
+    if (int rc = x3d_poisson_fft_forward(p, f)) return rc;
+    if (int rc = x3d_poisson_postprocess_010(p)) return rc;
+    return x3d_poisson_fft_backward(p, f);
 }
 
 extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, double *host)

@@ -27,5 +27,8 @@ struct x3d_poisson {
     int fast512;
     int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels
     hipfftHandle plan_x_fw, plan_x_bw;
+    // ny = 256 (010, the channel case): x and z through 1-D rocFFT plans, y LAST inside the fused y pass (y010.hip)
+    int y010;             // 0: not tried yet, 1: plans made, -1: not available for these sizes / switched off
+    hipfftHandle plan_x010_fw, plan_x010_bw;  // 2-D over (z, x), batched over the y rows
     double *rwZ;          // z-first solve: [nz/2+1][nx][ny] reciprocal wave numbers (built on first use, zfirst.hip)
 };

@@ -134,6 +134,9 @@ template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
 template <> __device__ __forceinline__ V2 zero_of<V2>() { return V2{0.0, 0.0}; }
 __device__ __forceinline__ double first_of(double x) { return x; }
 __device__ __forceinline__ double first_of(V2 x) { return x.a; }
+// c ? x : y, component by component (a ternary on the struct itself goes through a stack slot)
+__device__ __forceinline__ double sel_of(bool c, double x, double y) { return c ? x : y; }
+__device__ __forceinline__ V2 sel_of(bool c, V2 x, V2 y) { return V2{c ? x.a : y.a, c ? x.b : y.b}; }
 
 __device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
 {
@@ -193,17 +196,17 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
         const int ls = (nr - 4) / Q;
         int co = (lane == 0 ? 0 : (lane == ls ? 1 : (lane == ls + 1 ? 2 : 3))) * (Q * 10);
 #ifdef XSCAN_CS_DEPTH2
-        int co1 = co;  // two rows' weights in flight: row q + 2's reads wait for acc[q], row q + 1's do not
-        asm volatile("" : "+v"(co1));
+        // (the pair type with the wide stencils: one row at a time -- two rows' ten weights each do not fit beside two windows)
+        constexpr bool D2 = NARROW || sizeof(T) == sizeof(double);
+#else
+        constexpr bool D2 = false;
 #endif
+        int co1 = co;  // two rows' weights in flight: row q + 2's reads wait for acc[q], row q + 1's do not
+        if constexpr (D2) asm volatile("" : "+v"(co1));
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-#ifdef XSCAN_CS_DEPTH2
-            int &coq = (q & 1) ? co1 : co;
+            int &coq = (D2 && (q & 1)) ? co1 : co;
             const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + coq + q * 10);
-#else
-            const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + co + q * 10);
-#endif
             if (NARROW) {  // no stencil of the operator reaches beyond 2 rows (x3d_tdsops::narrow_all): taps 2..6 only
                 const double2 cb = c2[1], cc = c2[2], cd = c2[3];
                 acc[q] = cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] + cc.y * w[q + 5] + cd.x * w[q + 6];
@@ -212,11 +215,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
                 acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
                          cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
             }
-#ifdef XSCAN_CS_DEPTH2
-            asm volatile("" : "+v"(coq) : "v"(first_of(acc[q])));
-#else
-            asm volatile("" : "+v"(co) : "v"(first_of(acc[q])));  // one row's weights at a time (10 VGPRs, not 10 Q)
-#endif
+            asm volatile("" : "+v"(coq) : "v"(first_of(acc[q])));  // (one / two rows' weights at a time: 10 VGPRs each, not 10 Q)
         }
     }
     // ---- lane-local forward elimination from zero
@@ -265,7 +264,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     v += LTM(lt, 6 + 3) * dpp0<0x108>(v);
     {
         const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
-        v += LTM(lt, 6 + 4) * (lane < 32 ? s16 : s48);
+        v += LTM(lt, 6 + 4) * sel_of(lane < 32, s16, s48);
         v += LTM(lt, 6 + 5) * readlane_d(v, 32);
     }
     carry = dpp0<0x130>(v);  // wave_shl:1
@@ -283,7 +282,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
         const int ln = __builtin_amdgcn_readfirstlane((n - 1) / Q), qn = __builtin_amdgcn_readfirstlane((n - 1) % Q);
         T xsel = zero_of<T>();
 #pragma unroll
-        for (int q = 0; q < Q; q++) xsel = (q == qn) ? X[q] : xsel;
+        for (int q = 0; q < Q; q++) xsel = sel_of(q == qn, X[q], xsel);
         xn = readlane_d(xsel, ln);
     }
     PHASE(xn);

@@ -24,14 +24,15 @@ template <int Q> struct GenGeom {
 };
 
 // one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
-template <int Q, bool NARROW>
-__device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ lt,
+// (T = V2: two right-hand sides of the SAME operator in one solve -- every table value read from LDS serves both)
+template <int Q, bool NARROW, class T = double>
+__device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const double *__restrict__ lt,
                                           const double *__restrict__ cs, const XOp &t, int &lane)
 {
     const int first = lane * Q + 1, n = t.n_tds;
-    double X[Q], du1, xn;
-    scan_solve<Q, false, NARROW>(w, X, du1, xn, lt, t, lane, first, 0, cs);
-    const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+    T X[Q], du1, xn;
+    scan_solve<Q, false, NARROW, T>(w, X, du1, xn, lt, t, lane, first, 0, cs);
+    const T du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
 #ifdef XSCAN_CS_DEPTH2
     int la[2] = {lane, lane};  // two rows' table reads in flight: row q + 2's wait for row q, row q + 1's do not
     asm volatile("" : "+v"(la[1]));
@@ -40,23 +41,23 @@ __device__ __forceinline__ void gen_solve(const double (&w)[Q + 8], double (&r)[
         const int j = first + q;
         int &lq = la[q & 1];
         const double st = lt_read(lt, LT_ST(q) * 64 + lq);
-        double x = (X[q] - lt_read(lt, LT_SA(q) * 64 + lq) * du_s - lt_read(lt, LT_SC(q) * 64 + lq) * du_e) * st;
-        if (q == 0) x = (lane == 0) ? du_s * st : x;  // (row 1)
-        x = (j == n) ? du_e * st : x;
+        T x = (X[q] - lt_read(lt, LT_SA(q) * 64 + lq) * du_s - lt_read(lt, LT_SC(q) * 64 + lq) * du_e) * st;
+        if (q == 0) x = sel_of(lane == 0, du_s * st, x);  // (row 1)
+        x = sel_of(j == n, du_e * st, x);
         r[q] = x;
-        asm volatile("" : "+v"(lq) : "v"(x));
+        asm volatile("" : "+v"(lq) : "v"(first_of(x)));
     }
-    asm volatile("" : "+v"(lane) : "v"(r[Q - 1]));
+    asm volatile("" : "+v"(lane) : "v"(first_of(r[Q - 1])));
 #else
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int j = first + q;
         const double st = LTR(lt, LT_ST(q));
-        double x = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
-        if (q == 0) x = (lane == 0) ? du_s * st : x;  // (row 1)
-        x = (j == n) ? du_e * st : x;
+        T x = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
+        if (q == 0) x = sel_of(lane == 0, du_s * st, x);  // (row 1)
+        x = sel_of(j == n, du_e * st, x);
         r[q] = x;
-        asm volatile("" : "+v"(lane) : "v"(x));  // (one row's table reads at a time: front-loaded, they were spilled)
+        asm volatile("" : "+v"(lane) : "v"(first_of(x)));  // (one row's table reads at a time: front-loaded, they were spilled)
     }
 #endif
 }
@@ -209,13 +210,23 @@ __global__ void __launch_bounds__(1024)
 // ---------------------------------------------------------------- transeq: the three components of a direction
 // component 0 = (u0, conv = u0), 1, 2 = (u1, u0), (u2, u0) (src/backend/omp/backend.f90:145-184); der1st and
 // der1st_sym, der2nd and der2nd_sym must be equal as lane tables (Dirichlet ends: they are) -- two table sets.
-template <int Q, bool ACC, bool NARROW>
+// NARROW1 / NARROW: der1st's / both operators' stencils reach 2 rows at most (the Dirichlet closure of der2nd's first
+// and last row reaches 3: the channel case runs <.., false, true>)
+template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW>
 __global__ void __launch_bounds__(1024)
     k_ygen_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0, const double *__restrict__ u1,
                     const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
                     double nu)
 {
     using G = GenGeom<Q>;
+    // the first two solves of a component as one solve over the pair type where that fits the 128 registers
+    // (Q = 8 and the wide-stencil Q = 6 form spill with it: 68 - 220 bytes of scratch)
+#ifndef YGEN_NO_P12
+    constexpr bool P12 = Q <= 5 || (NARROW1 && Q <= 6);
+#else
+    constexpr bool P12 = false;
+#endif
+    constexpr bool LATE = P12 && Q <= 5;  // where the rows the result is added to are requested (register budget)
     extern __shared__ double lt[];
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
@@ -253,7 +264,26 @@ __global__ void __launch_bounds__(1024)
             // works during the arithmetic instead of after it)
             double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
             double old[2 * G::NI] = {};
-            if (ACC) T.gload(old, o);
+            if (ACC && !LATE) T.gload(old, o);  // (LATE: after the pair solve, whose two windows need the registers)
+            if constexpr (P12) {
+                // d(u conv) and du: the same operator on two right-hand sides -- ONE solve over the pair type (round 4:
+                // the kernel is bound by the rate of its LDS read instructions; 245 -> 178 per lane and component)
+                V2 w2[Q + 8], X2[Q];
+                {
+                    double wu[Q + 8], wc[Q + 8];
+                    T.window(wu);
+                    if (c == 0) {
+#pragma unroll
+                        for (int q = 0; q < Q; q++) cb[q] = wu[4 + q];
+                    }
+                    window_from_body_zero<Q>(wc, cb);
+#pragma unroll
+                    for (int m = 0; m < Q + 8; m++) w2[m] = V2{wu[m] * wc[m], wu[m]};
+                }
+                gen_solve<Q, NARROW1, V2>(w2, X2, l1, cs, tD1, lane);
+#pragma unroll
+                for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X2[q].b + X2[q].a) + nu * (X2[q].b * LTR(l3, LT_STC(q)));
+            } else {
             {
                 // d(u conv): the product window; the field's own window is read again from the tile afterwards
                 // (it stays there until the result is put back) instead of living through this solve
@@ -266,7 +296,7 @@ __global__ void __launch_bounds__(1024)
                 window_from_body_zero<Q>(wc, cb);
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wc[m];
-                gen_solve<Q, NARROW>(wp, X, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW1>(wp, X, l1, cs, tD1, lane);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = X[q];
@@ -274,10 +304,12 @@ __global__ void __launch_bounds__(1024)
             {
                 double wu[Q + 8];
                 T.window(wu);
-                gen_solve<Q, NARROW>(wu, X, l1, cs, tD1, lane);  // du
+                gen_solve<Q, NARROW1>(wu, X, l1, cs, tD1, lane);  // du
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, LT_STC(q)));
+            }
+            if (ACC && LATE) T.gload(old, o);
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             {
                 double wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
@@ -401,16 +433,16 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double 
     const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
-    const bool narrow = der1st->narrow_all && der2nd->narrow_all;
+    const bool narrow1 = der1st->narrow_all, narrow = narrow1 && der2nd->narrow_all;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-#define GO(Q_, A_, N_)                                                                                          \
+#define GO(Q_, A_, N_, N1_)                                                                                     \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_>));                                                        \
-        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
+        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_, N1_>));                                                   \
+        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_, N1_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
                            f[1], f[2], gen_xop(der1st, Q_), gen_xop(der2nd, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
     } while (0)
-#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true); else GO(Q_, A_, false); } while (0)
+#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true, true); else if (narrow1) GO(Q_, A_, false, true); else GO(Q_, A_, false, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
         if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else if (Q == 5) GOA(5); else GOA(4);
 #undef GOA

@@ -332,9 +332,8 @@ class HipPoissonFFT:
         if temp is None:
             raise X3dError("poisson_010 needs a scratch block")
         self.enforce_periodicity_y(temp, f)
-        self.fft_forward(temp)       # fft_forward_010 => fft_forward (src/backend/cuda/poisson_fft.f90:79-86)
-        self.fft_postprocess_010()
-        self.fft_backward(temp)
+        # fft_forward_010 => fft_forward (src/backend/cuda/poisson_fft.f90:79-86) ; fft_postprocess_010 ; fft_backward
+        self.solve_interleaved(temp)
         self.undo_periodicity_y(f, temp)
 
     def solve_poisson(self, f, temp):  # :206-214
@@ -372,10 +371,15 @@ class HipPoissonFFT:
 
     def solve_interleaved(self, f):
         """poisson_010 (:228-242) on a field whose y rows are already in enforce_periodicity_y's order; the result
-        is left in that order (undo_periodicity_y not applied), in place"""
-        self.fft_forward(f)
-        self.fft_postprocess_010()
-        self.fft_backward(f)
+        is left in that order (undo_periodicity_y not applied), in place.  One library call: 256 cells along a
+        stretched y run x ; z ; ONE pass for the y transform, fft_postprocess_010 and the inverse y transform
+        (csrc/y010.hip); every other size the three steps below"""
+        if getattr(self.backend, "lazy", False):
+            self.fft_forward(f)
+            self.fft_postprocess_010()
+            self.fft_backward(f)
+            return
+        _lib.check(self.backend.lib.x3d_poisson_solve_010_rows(self.h, f.ptr))
 
     # ---- test hooks
     def get_spectral(self):
