@@ -102,16 +102,15 @@ def test_poisson_010_solve_vs_oracle(stretching, beta):
     assert relerr(got, ref) < 1e-10, relerr(got, ref)
 
 
-@pytest.mark.parametrize("form", ["split", "fused"])
+@pytest.mark.parametrize("form", ["", "split", "staged", "fused"])
 @pytest.mark.parametrize("stretching,beta", [("top-bottom", 0.259065151), ("centred", 1.3), ("bottom", 0.5)])
 def test_poisson_010_y_last_form_at_256_cells(stretching, beta, form, monkeypatch):
     """256 cells along a stretched y (the channel case's wall-normal direction): x and z are transformed first and
     ONE pass over the spectrum does the y transform, fft_postprocess_010's paired split and the inverse y transform
-    (csrc/y010.hip; "fused": the pentadiagonal solves too) -- against the oracle and against the 3-D-transform form
+    (csrc/y010.hip; "staged" / "fused": the pentadiagonal sweeps on the tile too) -- against the oracle and against the 3-D-transform form
     (X3D_NO_Y010=1) on the same right-hand side"""
     dims = (32, 257, 16)
-    if form == "fused":
-        monkeypatch.setenv("X3D_Y010_FUSED", "1")
+    monkeypatch.setenv("X3D_Y010_FORM", form)  # ("": the default form)
     s = product_solver(dims, stretching, beta)
     o = oracle_solver(dims, stretching, beta)
     rng = np.random.default_rng(12)

@@ -487,6 +487,7 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
 
 int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, int mode, const double *tables, int sym,
                  double *const lu[2], bool *done);
+#define Y010_DEFAULT_FORM 1  // staged (y010.hip has the measurements)
 
 // plans of the y-last form: 2-D transforms over (z, x) -- r2c along x on the pitched block, c2c along z -- batched over
 // the y rows (the middle dimension of both layouts is the batch: plane pitch as the inner embedding)
@@ -539,14 +540,26 @@ extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
             X3D_FFT(hipfftExecD2Z(p->plan_x010_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
         }
         bool done = false;
-        const char *ef = getenv("X3D_Y010_FUSED");
-        const bool fuse_penta = ef && ef[0] == '1';
-        if (p->stretched && fuse_penta) {
+        // X3D_Y010_FORM: "split" = k_y010<0> ; k_penta_solve x 2 ; k_y010<1>.  "staged" = the forward sweeps on the
+        // tile of the first kernel, the backward sweeps on the tile of the second, the factored operator staged in LDS
+        // (k_y010<3> ; k_y010<4>).  "fused" = everything in k_y010<2>, the operator streamed by the chains (slow).
+        const char *ef = getenv("X3D_Y010_FORM");
+        const int form = !ef || !ef[0] ? Y010_DEFAULT_FORM : (ef[0] == 'f' ? 2 : (ef[0] == 's' && ef[1] == 't' ? 1 : 0));
+        if (form == 2) {
             ProfScope ps(b, X3D_K_SPECTRAL);
             if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 2, p->ab, p->sym, p->lu, &done)) return rc;
+        } else if (form == 1) {
+            {
+                ProfScope ps(b, X3D_K_SPECTRAL);
+                if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 3, p->ab, p->sym, p->lu, &done)) return rc;
+            }
+            if (done) {
+                ProfScope ps(b, X3D_K_SPECTRAL);
+                if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 4, p->ab, p->sym, p->lu, &done)) return rc;
+                X3D_REQUIRE(done, "x3d_poisson_solve_010_rows: y pass refused");
+            }
         }
-        if (!done) {  // the y transforms fused with the halves of the post-processing, the pentadiagonal solves between
-                      // them as their own kernels (X3D_Y010_FUSED=1: all in one kernel -- measured, see y010.hip)
+        if (!done) {
             {
                 ProfScope ps(b, X3D_K_FFT, 1);
                 if (int rc = x3d_y010_run(b, p->c, p->nxs, p->nx, p->ny, p->nz, 0, p->ab, p->sym, p->lu, &done)) return rc;

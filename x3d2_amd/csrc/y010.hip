@@ -1,29 +1,32 @@
-// K6y: the y pass of the non-periodic-y (010) Poisson solve for ny = 256 cells (the channel case, BASELINE configs[4]):
-//   forward  y transform + process_spectral_010's forward part     in ONE pass over the spectrum   (MODE 0)
-//   its backward part + inverse y transform                        in ONE pass                     (MODE 1)
-//   both, with the pentadiagonal solves of the stretched-mesh operator between them, in ONE pass   (MODE 2)
-// instead of rocFFT's strided y stage, k_spectral_010<0>, k_penta_solve x 2, k_spectral_010<1>, rocFFT's inverse y
-// stage (six passes; spectral010.h has those kernels and the reference lines they mirror:
-// src/backend/cuda/kernels/spectral_processing.f90:385-702, src/backend/cuda/poisson_fft.f90:822-924).
-// The 3-D DFT is separable: the reference runs x, y, z through cuFFT / 2decomp&FFT and then post-processes; here x and z
-// are transformed first (rocFFT, 1-D batched plans, poisson.hip) and y LAST, so that everything that couples the rows
-// of one (x mode, z mode) column -- the y transform, the paired split of rows j and ny - j + 2, the pentadiagonal
-// systems along y -- happens while the column is on chip.
+// K6y: the y pass of the non-periodic-y (010) Poisson solve for ny = 256 cells on a stretched grid (the channel case,
+// BASELINE configs[4]).  The reference's fft_postprocess_010 (src/backend/cuda/poisson_fft.f90:822-924) after a 3-D
+// transform is: process_spectral_010's forward part ; pentadiagonal solves along y (odd rows, even rows) ; backward part
+// (src/backend/cuda/kernels/spectral_processing.f90:385-702; spectral010.h has them as k_spectral_010<0>, k_penta_solve,
+// k_spectral_010<1>) -- with the y stages of the transforms, six passes over the 1.07 GB spectrum, 232 B per entry.
+// The 3-D DFT is separable: here x and z are transformed first (one 2-D rocFFT plan batched over the y rows, poisson.hip)
+// and y LAST, so that everything that couples the rows of one (x mode, z mode) column -- the y transform, the paired split
+// of rows j and ny - j + 2, the pentadiagonal systems -- happens while the column is on chip.
 //
 // Work decomposition: a workgroup of 8 waves owns the 8 x-adjacent columns of one z mode: c[kz][0..255][x0..x0+7]
 // (128-byte row segments).  The tile sits in LDS as 8 pencils of Y010_P double2; wave w transforms pencil w with
 // fft256_wave (fft512_core.h, 4 points per lane, exchanges through the pencil's own LDS region) and does the paired
-// split on it; nothing but the load, the pentadiagonal phase and the store needs a block barrier.
-// Pentadiagonal phase (MODE 2, X3D_Y010_FUSED=1 -- MEASURED SLOWER, off by default): wave 0, lane = (x 0..7, re / im,
-// odd / even system): 32 independent serial chains over the 128 rows of a system, right-hand sides in LDS, the factored
-// operator (k_penta_factor's storage, 5 doubles per entry) streamed from memory in chunks of 8 rows requested one chunk
-// ahead; the eight x of a row are one 64-byte segment.  Arithmetic = k_penta_solve's, operation by operation.
-// Channel bench, 1024 x 257 x 512 (profiles/r04_channel_round4.txt): 3-D transforms + four post-processing kernels 14.9 ms per step
-// in the fft + spectral classes; MODE 0 / 1 around the two k_penta_solve launches 12.7 ms (step 60.7 -> 58.1 ms);
-// MODE 2 23.1 ms (5.85 ms per launch): 32 lanes per workgroup wait a full memory latency per 8-row chunk of the
-// operator, 32 times per tile, and 147 VGPRs leave 3 workgroups per CU to hide it.  Staging the operator in LDS by all
-// threads would need 32 + 48 KB per tile beside the 39 KB tile (one workgroup per CU).  The k_penta_solve launches
-// stay: they stream 104 B per entry at 4.6 TB/s.
+// split on it; only the load, the pentadiagonal phase and the store need block barriers.
+//
+// Forms (x3d_poisson_solve_010_rows, X3D_Y010_FORM; channel bench 1024 x 257 x 512, profiles/r04_channel_round4.txt):
+//   "3d"     X3D_NO_Y010=1: 3-D transforms + the four kernels                    fft + spectral classes 14.9 ms per step
+//   "split"  k_y010<0> (y transform + forward part) ; k_penta_solve x 2 ; k_y010<1> (backward part + inverse y transform)
+//            168 B per entry                                                                               12.8 ms
+//   "staged" k_y010<3> = <0> + the FORWARD sweeps of both systems on the tile ; k_y010<4> = the BACKWARD sweeps + <1>:
+//            104 B per entry (the spectrum twice, the factored operator once).  The operator's rows of the tile are
+//            requested by all 512 threads at kernel start and staged in LDS (<3>: 2 diagonals, 33 KB; <4>: 3 diagonals in
+//            two halves of 25 KB); wave 0 runs the 32 chains (x 0..7, re / im, odd / even system), k_penta_solve's
+//            arithmetic operation by operation.  DEFAULT                                                    11.4 ms
+//            (without the chains -- wrong results, timing only -- 9.9: they cost 0.5 ms per solve; 2 workgroups per CU)
+//   "fused"  k_y010<2>: everything in one kernel, 72 B per entry, the chains stream the operator from memory themselves:
+//            23.1 ms -- 32 lanes wait a full memory latency per 8-row chunk, 32 times per tile.  Kept as the measured
+//            negative; parity-green like the others.
+#include <type_traits>
+
 #include "fft512_core.h"
 #include "spectral010.h"
 
@@ -190,6 +193,119 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
 #undef C
 }
 
+// ---- MODES 3 / 4: the sweeps of k_penta_solve on the tile with the operator STAGED in LDS by all 512 threads.
+// Row slots: R = s n + (j - 1) in 0 .. 255 (sym: two systems of n = 128 rows; else one of 256); a thread stages
+// (x = t & 7, R = (t >> 3) + 64 h, h = 0 .. 3) of every diagonal: one 64-byte segment per row.
+// A slot = 8 doubles, 8 more between the two systems (their chains read rows R and R + n together).
+// One wave runs the 32 chains and nothing else runs beside it in the workgroup: the loops are written for a short
+// instruction stream (constant strides, a chunk's operands requested together, no register double buffer).
+#define Y010_LD (256 * 8 + 16)  // doubles per staged diagonal (MODE 3: all rows of 2 diagonals)
+#define Y010_LH (128 * 8 + 16)  // MODE 4: half the rows of 3 diagonals at a time
+
+struct Y010Chain {
+    int x, s;
+    double *pd;  // row 1 of this chain's component of column x in the tile (rows 16 inc bytes apart)
+    bool on, zero_line;
+};
+template <bool SYM>
+__device__ __forceinline__ Y010Chain y010_chain(double2 *__restrict__ sm, const Y010Arg &g, int kz, int x0, int lane, int wave)
+{
+    Y010Chain c;
+    c.x = lane & 7;
+    c.s = (lane >> 4) & 1;
+#ifdef Y010_NO_SWEEP  // (timing experiment: what the two kernels take without their chains)
+    c.on = false;
+#else
+    c.on = wave == 0 && lane < 32 && c.s < (SYM ? 2 : 1);
+#endif
+    c.pd = reinterpret_cast<double *>(sm + c.x * Y010_P) + ((lane >> 3) & 1) + 2 * c.s;
+    c.zero_line = (x0 + c.x + 1) == g.nx / 2 + 1 && (kz + 1) == g.nz / 2 + 1;
+    return c;
+}
+
+// forward sweep + the last two rows; lf = [2][Y010_LD]: diagonal 1 (m2), diagonal 2 (m1); tl = LU(n-1,2), LU(n,3),
+// LU(n-1,3), LU(n-1,4) of this chain (loaded by the caller at kernel start)
+template <bool SYM>
+__device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const double *__restrict__ lf, const double (&tl)[4])
+{
+    constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;  // RS: doubles between a chain's rows in the tile
+    const double *__restrict__ m2p = lf + (c.s * n) * 8 + c.s * 8 + c.x;  // row j at m2p[(j - 1) * 8]
+    const double *__restrict__ m1p = m2p + Y010_LD;
+    double *__restrict__ cp = c.pd;  // row j at cp[(j - 1) * RS]
+    double r0 = cp[0], r1 = cp[RS];
+    for (int jb = 1; jb <= n - 2; jb += U) {
+        double m1c[U], m2c[U], r2c[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb + u <= n - 2) {
+                m2c[u] = m2p[u * 8];
+                m1c[u] = m1p[u * 8];
+                r2c[u] = cp[(u + 2) * RS];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb + u <= n - 2) {
+                double r2 = r2c[u];
+                r1 = r1 - m1c[u] * r0;
+                r2 = r2 - m2c[u] * r0;
+                cp[u * RS] = r0;
+                r0 = r1; r1 = r2;
+            }
+        }
+        m2p += U * 8; m1p += U * 8; cp += U * RS;
+    }
+    cp = c.pd;
+    const double eps = 1.e-16;
+    const double tmp = tl[0], dd = tl[1], inv = tl[2], a4n = tl[3];
+    double xn, xn1;
+    if (fabs(dd) > eps) {
+        const double tt = tmp / dd;
+        xn = r1 / dd - tt * r0;
+    } else {
+        xn = 0.0;
+    }
+    const double q = a4n * inv;
+    xn1 = r0 * inv - xn * q;
+    if (c.zero_line) { xn = 0.0; xn1 = 0.0; }
+    cp[(n - 1) * RS] = xn;
+    cp[(n - 2) * RS] = xn1;
+}
+
+// rows jhi .. jlo (descending) of the backward sweep; lb = [3][Y010_LH]: diagonals 3 (1/a3), 4, 5 of the rows
+// jbase + 1 .. jbase + n/2 (slot = s n/2 + j - jbase - 1); x1, x2 carried by the caller
+template <bool SYM>
+__device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const double *__restrict__ lb, int jhi, int jlo, int jbase,
+                                              double &x1, double &x2)
+{
+    constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
+    const double *__restrict__ ivp = lb + (c.s * (n / 2) + jhi - jbase - 1) * 8 + c.s * 8 + c.x;  // row jhi - u at ivp[-u * 8]
+    const double *__restrict__ a4p = ivp + Y010_LH, *__restrict__ a5p = ivp + 2 * Y010_LH;
+    double *__restrict__ cp = c.pd + (jhi - 1) * RS;
+    for (int jb = jhi; jb >= jlo; jb -= U) {
+        double ivc[U], a4c[U], a5c[U], rc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb - u >= jlo) {
+                ivc[u] = ivp[-u * 8];
+                a4c[u] = a4p[-u * 8];
+                a5c[u] = a5p[-u * 8];
+                rc[u] = cp[-u * RS];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb - u >= jlo) {
+                double xv = ivc[u] * (rc[u] - a4c[u] * x1 - a5c[u] * x2);
+                if (c.zero_line) xv = 0.0;
+                cp[-u * RS] = xv;
+                x2 = x1; x1 = xv;
+            }
+        }
+        ivp -= U * 8; a4p -= U * 8; a5p -= U * 8; cp -= U * RS;
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const double2 *__restrict__ twg, Y010Arg g)
 {
@@ -202,6 +318,33 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
     const int kz = blockIdx.x / ntx, x0 = (blockIdx.x % ntx) * 8;
     double2 *__restrict__ base = c + (size_t)kz * ny * g.nxs + x0;
     const int tx = threadIdx.x & 7, tr = threadIdx.x >> 3;  // 64 rows per pass
+    // MODES 3 / 4: this thread's share of the factored operator, requested first (in flight during the transforms)
+    double *__restrict__ lst = reinterpret_cast<double *>(tws + 256);
+    constexpr int ND = MODE == 3 ? 2 : 3;
+    double lreg[MODE >= 3 ? ND * 4 : 1];
+    double tl[4] = {0.0, 0.0, 0.0, 0.0};
+    const int inc_ = g.sym ? 2 : 1, n_ = ny / inc_;
+    const size_t ds_ = (size_t)g.nz * n_ * g.nxs;
+    if constexpr (MODE >= 3) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const int R = tr + 64 * h, s_ = R / n_, j = R % n_ + 1;
+            const double *__restrict__ lu = s_ ? g.lu1 : g.lu0;
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                const int diag = MODE == 3 ? d : d + 2;  // (0-based: 0 m2, 1 m1, 2 1/a3, 3 a4, 4 a5)
+                lreg[d * 4 + h] = j <= n_ - 2 ? lu[(size_t)diag * ds_ + ((size_t)kz * n_ + (j - 1)) * g.nxs + x0 + tx] : 0.0;
+            }
+        }
+        if (MODE == 3 && wave == 0 && lane < 32 && ((lane >> 4) & 1) < (g.sym ? 2 : 1)) {
+            const double *__restrict__ lu = ((lane >> 4) & 1) ? g.lu1 : g.lu0;
+            const double *__restrict__ lb_ = lu + (size_t)kz * n_ * g.nxs + x0 + (lane & 7);
+            tl[0] = lb_[(size_t)1 * ds_ + (size_t)(n_ - 2) * g.nxs];  // LU(n-1, 2)
+            tl[1] = lb_[(size_t)2 * ds_ + (size_t)(n_ - 1) * g.nxs];  // LU(n, 3)
+            tl[2] = lb_[(size_t)2 * ds_ + (size_t)(n_ - 2) * g.nxs];  // LU(n-1, 3)
+            tl[3] = lb_[(size_t)3 * ds_ + (size_t)(n_ - 2) * g.nxs];  // LU(n-1, 4)
+        }
+    }
     {
         double2 v[4];
 #pragma unroll
@@ -214,7 +357,7 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
     const int ig = x0 + wave;
     const Rot rz{g.az[kz], g.bz[kz], (kz + 1) > g.nz / 2 + 1}, rx{g.ax[ig], g.bx[ig], (ig + 1) > g.nx / 2 + 1};
     double2 a[4];
-    if (MODE != 1) {
+    if (MODE != 1 && MODE != 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) a[k] = pen[lane + 64 * k];
         fft256_wave<-1>(a, pen, tws, lane);
@@ -232,7 +375,58 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
         if (wave == 0 && lane < 32) y010_penta(sm, g, kz, x0, lane);
         __syncthreads();
     }
-    if (MODE != 0) {
+    if constexpr (MODE == 3) {  // forward sweeps on the tile, both diagonals staged whole
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const int R = tr + 64 * h, so = (R / n_) * 8;
+            lst[R * 8 + so + tx] = lreg[h];
+            lst[Y010_LD + R * 8 + so + tx] = lreg[4 + h];
+        }
+        __syncthreads();
+        if (g.sym) {
+            const Y010Chain ch = y010_chain<true>(sm, g, kz, x0, lane, wave);
+            if (ch.on) y010_sweep_fw<true>(ch, lst, tl);
+        } else {
+            const Y010Chain ch = y010_chain<false>(sm, g, kz, x0, lane, wave);
+            if (ch.on) y010_sweep_fw<false>(ch, lst, tl);
+        }
+    }
+    if constexpr (MODE == 4) {  // backward sweeps: rows n-2 .. n/2+1 staged first, rows n/2 .. 1 behind them
+        const int nh = n_ / 2;
+        auto stage = [&](bool upper) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const int R = tr + 64 * h, s_ = R / n_, j = R % n_ + 1;
+                if ((j > nh) == upper) {
+                    const int slot = s_ * nh + (upper ? j - nh - 1 : j - 1);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) lst[d * Y010_LH + slot * 8 + s_ * 8 + tx] = lreg[d * 4 + h];
+                }
+            }
+        };
+        stage(true);
+        __syncthreads();
+        double x1 = 0.0, x2 = 0.0;
+        auto sweep = [&](auto symt, bool upper) {
+            constexpr bool SYM = decltype(symt)::value;
+            constexpr int n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
+            const Y010Chain ch = y010_chain<SYM>(sm, g, kz, x0, lane, wave);
+            if (!ch.on) return;
+            if (upper) {
+                x1 = ch.pd[(n - 2) * RS]; x2 = ch.pd[(n - 1) * RS];
+                y010_sweep_bw<SYM>(ch, lst, n - 2, n / 2 + 1, n / 2, x1, x2);
+            } else {
+                y010_sweep_bw<SYM>(ch, lst, n / 2, 1, 0, x1, x2);
+            }
+        };
+        if (g.sym) sweep(std::true_type{}, true); else sweep(std::false_type{}, true);
+        __syncthreads();
+        stage(false);
+        __syncthreads();
+        if (g.sym) sweep(std::true_type{}, false); else sweep(std::false_type{}, false);
+        __syncthreads();
+    }
+    if (MODE != 0 && MODE != 3) {
         y010_pair_bw(pen, lane, rz, rx, g.ay, g.by);
         y010_pair_bw(pen, lane + 64, rz, rx, g.ay, g.by);
         if (lane == 0) y010_pair_bw(pen, 128, rz, rx, g.ay, g.by);
@@ -258,16 +452,20 @@ int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, in
 {
     *done = false;
     if (ny != 256 || nxs % 8 != 0 || nx % 2 != 0) return 0;
-    if (mode == 2 && !(lu && lu[0] && (!sym || lu[1]))) return 0;
+    if (mode >= 2 && !(lu && lu[0] && (!sym || lu[1]))) return 0;
     if (int rc = x3d_fft512_init()) return rc;
     Y010Arg g;
     g.ax = tables; g.bx = g.ax + nx; g.ay = g.bx + nx; g.by = g.ay + ny; g.az = g.by + ny; g.bz = g.az + nz;
     g.lu0 = lu ? lu[0] : nullptr; g.lu1 = lu ? lu[1] : nullptr;
     g.nxs = nxs; g.nz = nz; g.nx = nx; g.sym = sym;
-    const size_t lds = sizeof(double2) * (8 * Y010_P + 256);
+    const size_t lds = sizeof(double2) * (8 * Y010_P + 256) + sizeof(double) * (mode == 3 ? 2 * Y010_LD : (mode == 4 ? 3 * Y010_LH : 0));
     const dim3 grid((unsigned)((size_t)nz * (nxs / 8)));
-#define GO(M_) hipLaunchKernelGGL((k_y010<M_>), grid, dim3(512), lds, b->stream, c, x3d_fft512_twiddles(), g)
-    if (mode == 0) GO(0); else if (mode == 1) GO(1); else GO(2);
+#define GO(M_)                                                                                          \
+    do {                                                                                               \
+        X3D_LDS_OPTIN(b, (k_y010<M_>));                                                                \
+        hipLaunchKernelGGL((k_y010<M_>), grid, dim3(512), lds, b->stream, c, x3d_fft512_twiddles(), g); \
+    } while (0)
+    if (mode == 0) GO(0); else if (mode == 1) GO(1); else if (mode == 2) GO(2); else if (mode == 3) GO(3); else GO(4);
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;
