@@ -109,6 +109,23 @@ def test_deferred_channel_steps_are_bit_identical(dims, stretching, beta, monkey
     _same(eager, nopairs)
 
 
+def test_deferred_channel_010_solve_takes_the_y_last_form():
+    """fft_forward_010 ; fft_postprocess_010 ; fft_backward_010 recorded one by one (the reference's poisson_010,
+    src/poisson_fft.f90:228-242) run as x3d_poisson_solve_010_rows: at 256 cells along a stretched y that is the y-last
+    form of csrc/y010.hip -- the same kernels the eager host path calls"""
+    from x3d2_amd import make_channel
+    dims = (32, 257, 16)
+    kw = dict(stretching="top-bottom", beta=0.259065151, fused=False)
+    eager = make_channel(dims, lazy=False, **kw)
+    lazy = make_channel(dims, lazy=True, **kw)
+    for it in (1, 2):
+        eager.step(it)
+        lazy.step(it)
+    _same(eager, lazy, ulps=16)
+    st = lazy.solver.backend.lazy_stats()
+    assert st["solve_000"] == 6, st  # (the counter of one-call solves: three sub-steps per step)
+
+
 def test_deferred_species_transport_is_bit_identical():
     """transeq_species (src/solver.f90:507-601) is recorded too; its y / z contributions fold their sum_<d>intox"""
     from x3d2_amd import make_tgv

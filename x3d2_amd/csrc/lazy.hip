@@ -37,7 +37,8 @@
 
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
-    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST
+    L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST,
+    L_FFT_POST010, L_SOLVE010R
 };
 
 struct LOp {
@@ -256,7 +257,7 @@ static int nout(const LOp &op)
     case L_PAIR: return op.mode == 0 ? 1 : 2;
     case L_TDS_LIN: return 2;  // du, y
     case L_ZFIRST: return 2;
-    case L_DEAD: case L_FFT_POST000: return 0;
+    case L_DEAD: case L_FFT_POST000: case L_FFT_POST010: return 0;
     default: return 1;
     }
 }
@@ -266,7 +267,7 @@ static bool out_is_update(const LOp &op, int slot = 0)
     switch (op.kind) {
     case L_SPECIES_ACC:
     case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
-    case L_FFT_BWD: case L_SOLVE000:
+    case L_FFT_BWD: case L_SOLVE000: case L_SOLVE010R:
         return true;  // (the FFT hooks: forward only reads f, backward writes the real extent of f -- keep the contents)
     default: return false;
     }
@@ -287,7 +288,7 @@ static bool range_clear(const std::vector<LOp> &q, int lo, int hi, std::initiali
     for (int k = lo + 1; k < hi; k++) {
         const LOp &op = q[k];
         if (op.kind == L_DEAD) continue;
-        if (op.kind == L_FFT_POST000) continue;
+        if (op.kind == L_FFT_POST000 || op.kind == L_FFT_POST010) continue;
         for (const double *h : quiet)
             if (h && touch(op, h)) return false;
         for (const double *h : stable)
@@ -549,16 +550,18 @@ static void optimise(x3d_backend *b)
         q[p].kind = L_DEAD; q[k].kind = L_DEAD;
         q[at] = f;
     }
-    // (7) fft_forward(f) ; fft_postprocess_000 ; fft_backward(f) -> the solver's one-call form (z passes fused)
+    // (7) fft_forward(f) ; fft_postprocess_000 ; fft_backward(f) -> the solver's one-call form (z passes fused);
+    //     with fft_postprocess_010 between them (poisson_010's middle, src/poisson_fft.f90:228-242) -> x3d_poisson_solve_010_rows
+    //     (256 cells along a stretched y: y transformed last, inside the kernels that post-process, csrc/y010.hip)
     for (int p = 0; p + 2 < n && (L->rules & 64u); p++) {
         if (q[p].kind != L_FFT_FWD) continue;
         int a = p + 1;
         while (a < n && q[a].kind == L_DEAD) a++;
         int c = a + 1;
         while (c < n && q[c].kind == L_DEAD) c++;
-        if (c >= n || q[a].kind != L_FFT_POST000 || q[c].kind != L_FFT_BWD) continue;
+        if (c >= n || (q[a].kind != L_FFT_POST000 && q[a].kind != L_FFT_POST010) || q[c].kind != L_FFT_BWD) continue;
         if (q[a].obj != q[p].obj || q[c].obj != q[p].obj || q[c].o[0] != q[p].o[0]) continue;
-        q[p].kind = L_SOLVE000;
+        q[p].kind = q[a].kind == L_FFT_POST000 ? L_SOLVE000 : L_SOLVE010R;
         q[a].kind = L_DEAD; q[c].kind = L_DEAD;
     }
     // (9) d = A(i1) + B(i2) along z ; [p_temp = d] ; solve_000(p_temp) ; [pressure = p_temp] ; o1 = A'(pressure),
@@ -654,7 +657,7 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_TDS_ACC: L->stats[ST_TDS_ACC]++; break;
     case L_LINCOMB: L->stats[ST_LINCOMB]++; break;
     case L_TDS_LIN: L->stats[ST_TDS_LIN]++; break;
-    case L_SOLVE000: L->stats[ST_SOLVE000]++; break;
+    case L_SOLVE000: case L_SOLVE010R: L->stats[ST_SOLVE000]++; break;
     case L_TRANSEQ_UPD: L->stats[ST_TRANSEQ_UPD]++; break;
     case L_ZFIRST: L->stats[ST_ZFIRST]++; break;
     default: break;
@@ -679,6 +682,8 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_FFT_POST000: return x3d_poisson_postprocess_000((x3d_poisson *)op.obj);
     case L_FFT_BWD: return x3d_poisson_fft_backward((x3d_poisson *)op.obj, o[0]);
     case L_SOLVE000: return x3d_poisson_solve_000((x3d_poisson *)op.obj, o[0]);
+    case L_FFT_POST010: return x3d_poisson_postprocess_010((x3d_poisson *)op.obj);
+    case L_SOLVE010R: return x3d_poisson_solve_010_rows((x3d_poisson *)op.obj, o[0]);
     case L_SPECIES: case L_SPECIES_ACC:
         return x3d_transeq_species(b, op.dir, o[0], in[0], in[1], op.s[0], op.t[0], op.t[1], op.t[2], op.kind == L_SPECIES_ACC);
     case L_TRANSEQ_UPD: {
@@ -858,7 +863,7 @@ int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double 
 int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
 {
     LOp op;
-    op.kind = which == 0 ? L_FFT_FWD : which == 1 ? L_FFT_POST000 : L_FFT_BWD;
+    op.kind = which == 0 ? L_FFT_FWD : which == 1 ? L_FFT_POST000 : which == 3 ? L_FFT_POST010 : L_FFT_BWD;
     op.obj = poisson; op.o[0] = f;
     return push(b, op);
 }

@@ -466,8 +466,7 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double 
 extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_010: null argument");
-    X3D_LAZY_FLUSH(p->b);
-    X3D_LAZY_EAGER(p->b);
+    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 3, p, nullptr);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     return spectral_010_launch(p->b->stream, p->c, p->waves, p->nxs, p->nx, p->ny, p->nz, 0, p->ab, p->stretched, p->sym,
                                p->lu);
