@@ -497,6 +497,11 @@ module m_x3d2_hip_capi
       import :: c_ptr, c_int
       type(c_ptr), value :: p
     end function
+    !> fft_forward_010 ; fft_postprocess_010 ; fft_backward_010 in one call (rows of f in enforce_periodicity_y's order)
+    integer(c_int) function x3d_poisson_solve_010_rows(p, f) bind(C, name='x3d_poisson_solve_010_rows')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f
+    end function
   end interface
 
 contains
