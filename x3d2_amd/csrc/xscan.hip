@@ -55,34 +55,6 @@ int npmax_of(const x3d_backend *b);
 // 3.2 TB/s); a 4x4 transpose of the 16-byte pairs inside each quad of lanes lets every instruction
 // write whole 64-byte sectors instead (5.0 TB/s).  T_j[m] = P_m[j]: rotate left by j, quad_perm
 // DPP by the register index, rotate left by j again, read out reversed.
-__device__ __forceinline__ double dpp_quad(double v, int k)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    if (k == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x93, 0xf, 0xf, false);
-                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x93, 0xf, 0xf, false); }
-    if (k == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false);
-                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
-    if (k == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x39, 0xf, 0xf, false);
-                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x39, 0xf, 0xf, false); }
-    return __hiloint2double(hi, lo);
-}
-// (scalars, not arrays: LLVM turns `c ? a[i] : a[k]` into a dynamically indexed stack array)
-__device__ __forceinline__ void rotl_pairs(double &a0, double &a1, double &b0, double &b1, double &c0, double &c1,
-                                           double &d0, double &d1, int j)
-{
-    const bool r1 = j & 1, r2 = j & 2;
-    double t0 = a0, t1 = a1;  // rotate left by one pair where r1
-    a0 = r1 ? b0 : a0; a1 = r1 ? b1 : a1;
-    b0 = r1 ? c0 : b0; b1 = r1 ? c1 : b1;
-    c0 = r1 ? d0 : c0; c1 = r1 ? d1 : c1;
-    d0 = r1 ? t0 : d0; d1 = r1 ? t1 : d1;
-    t0 = a0; t1 = a1;         // by two pairs where r2
-    a0 = r2 ? c0 : a0; a1 = r2 ? c1 : a1;
-    c0 = r2 ? t0 : c0; c1 = r2 ? t1 : c1;
-    t0 = b0; t1 = b1;
-    b0 = r2 ? d0 : b0; b1 = r2 ? d1 : b1;
-    d0 = r2 ? t0 : d0; d1 = r2 ? t1 : d1;
-}
 // out row = orow[0 .. 64*8): lane l holds r[0..8) = rows 8l .. 8l+7
 template <bool ACC>
 __device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lane, const double (&r)[8],

@@ -311,11 +311,68 @@ __device__ __forceinline__ void load_window_exact(double (&w)[Q + 8], const doub
     w[Q + 4] = b0.x; w[Q + 5] = b0.y; w[Q + 6] = b1.x; w[Q + 7] = b1.y;
 }
 
+// ---- 4 x 4 transpose of 16-byte pairs inside each quad of lanes (stores of xscan.hip; loads below)
+__device__ __forceinline__ double dpp_quad(double v, int k)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (k == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x93, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x93, 0xf, 0xf, false); }
+    if (k == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    if (k == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x39, 0xf, 0xf, false);
+                  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x39, 0xf, 0xf, false); }
+    return __hiloint2double(hi, lo);
+}
+// (scalars, not arrays: LLVM turns `c ? a[i] : a[k]` into a dynamically indexed stack array)
+__device__ __forceinline__ void rotl_pairs(double &a0, double &a1, double &b0, double &b1, double &c0, double &c1,
+                                           double &d0, double &d1, int j)
+{
+    const bool r1 = j & 1, r2 = j & 2;
+    double t0 = a0, t1 = a1;  // rotate left by one pair where r1
+    a0 = r1 ? b0 : a0; a1 = r1 ? b1 : a1;
+    b0 = r1 ? c0 : b0; b1 = r1 ? c1 : b1;
+    c0 = r1 ? d0 : c0; c1 = r1 ? d1 : c1;
+    d0 = r1 ? t0 : d0; d1 = r1 ? t1 : d1;
+    t0 = a0; t1 = a1;         // by two pairs where r2
+    a0 = r2 ? c0 : a0; a1 = r2 ? c1 : a1;
+    c0 = r2 ? t0 : c0; c1 = r2 ? t1 : c1;
+    t0 = b0; t1 = b1;
+    b0 = r2 ? d0 : b0; b1 = r2 ? d1 : b1;
+    d0 = r2 ? t0 : d0; d1 = r2 ? t1 : d1;
+}
+// XS_TLOAD (experiment, round 4): the lane's 64 bytes fetched as whole 64-byte sectors per instruction (instruction m
+// takes piece 4 m + j of the quad's 256 bytes) and transposed back by the quad; 2: with the nontemporal hint
+#ifndef XS_TLOAD
+#define XS_TLOAD 0
+#endif
+__device__ __forceinline__ void load_body_q8t(double (&b)[8], const double *__restrict__ row, int lane)
+{
+    const int j = lane & 3;
+    const double *__restrict__ q = row + (lane & ~3) * 8 + 2 * j;
+#if XS_TLOAD == 2
+    const double2 *__restrict__ qs = reinterpret_cast<const double2 *>(q);
+    const double2 v0 = ldg_stream(qs), v1 = ldg_stream(qs + 4), v2 = ldg_stream(qs + 8), v3 = ldg_stream(qs + 12);
+#else
+    const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(q);
+    const double2 v0 = q2[0], v1 = q2[4], v2 = q2[8], v3 = q2[12];
+#endif
+    double a0 = v0.x, a1 = v0.y, b0 = v1.x, b1 = v1.y, c0 = v2.x, c1 = v2.y, d0 = v3.x, d1 = v3.y;
+    rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
+    b0 = dpp_quad(b0, 1); b1 = dpp_quad(b1, 1);
+    c0 = dpp_quad(c0, 2); c1 = dpp_quad(c1, 2);
+    d0 = dpp_quad(d0, 3); d1 = dpp_quad(d1, 3);
+    rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
+    b[0] = a0; b[1] = a1; b[2] = d0; b[3] = d1; b[4] = c0; b[5] = c1; b[6] = b0; b[7] = b1;
+}
+
 // FAST path: only the lane's own Q rows come from memory (4 aligned 16-byte loads, issued one
 // pencil ahead); the 4+4 halo rows are the neighbour lanes' rows (periodic wrap across the wave)
 template <int Q>
 __device__ __forceinline__ void load_body(double (&b)[Q], const double *__restrict__ row, int lane)
 {
+#if XS_TLOAD
+    if constexpr (Q == 8) { load_body_q8t(b, row, lane); return; }
+#endif
     const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
 #pragma unroll
     for (int m = 0; m < Q / 2; m++) {
