@@ -177,5 +177,28 @@ int main()
                 if (nt) run(nm, [&] { hipLaunchKernelGGL((k_skel32<1>), dim3(256), dim3(1024), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 32, ntiles, prow, pplane, sl); });
                 else run(nm, [&] { hipLaunchKernelGGL((k_skel32<0>), dim3(256), dim3(1024), 0, 0, f[0], f[1], f[2], f[3], f[4], f[5], nx / 32, ntiles, prow, pplane, sl); });
             }
+    // x-slab order (round 4, the Infinity Cache question): for every column of 16 x-pencils the y pass and then the z pass
+    // over the same [512 z][512 y][16 x] sub-volume of the six fields (201 MB; the cache holds 256 MB) -- does the z pass
+    // find the y pass's lines?  64 launches of 512 tiles each instead of 2 of 16384.
+    {
+        auto slab = [&](int kx, int sl) {
+            for (int xt = 0; xt < nx / 16; xt += 1) {
+                const long xb = (long)xt * 16;
+                for (int dir = 0; dir < 2; dir++) {
+                    const long prow = dir ? pxy : nxp, pplane = dir ? nxp : pxy;
+                    hipLaunchKernelGGL((k_skel<0, 0>), dim3(256), dim3(1024), 0, 0, f[0] + xb, f[1] + xb, f[2] + xb, f[3] + xb, f[4] + xb, f[5] + xb, 1, 512, prow, pplane, sl);
+                }
+            }
+        };
+        for (int sl : {0, 24}) {
+            snprintf(nm, 128, "x-slab order: y then z per 16-pencil column, delay %4.1f us (BOTH directions: compare with the sum)", sl * 512 / 2400.0);
+            for (int i = 0; i < 2; i++) slab(0, sl);
+            (void)hipEventRecord(e0);
+            for (int i = 0; i < 4; i++) slab(0, sl);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 4;
+            printf("%-100s %7.3f ms for y + z  %7.1f GB/s\n", nm, ms, 18.0 * nx * ny * nz * 8 / ms * 1e-6);
+        }
+    }
     return 0;
 }
