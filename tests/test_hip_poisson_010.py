@@ -296,6 +296,35 @@ def test_channel_step_at_the_bench_pencil_lengths_vs_oracle():
     assert case.solver.n_interleaved == 0  # (16-row z pencils: not the tile kernel's; the bench's 512 are)
 
 
+def test_channel_step_at_the_bench_size_two_poisson_forms(monkeypatch):
+    """BASELINE configs[4] at its full size, 1024 x 257 x 512 (too large for the oracle): one step of the fused driver with
+    the 010 solve in its default form (x, z ; y last inside the post-processing kernels, pentadiagonal sweeps on their
+    tiles -- csrc/y010.hip) against the same step with the 3-D transforms and the stand-alone post-processing kernels
+    (X3D_NO_Y010=1), whose pieces the small-size tests pin to the oracle: different transforms, different pentadiagonal
+    code, the same velocity to 1e-11; and the projection leaves the divergence it leaves at small sizes"""
+    import gc
+    import torch
+    from x3d2_amd import make_channel
+    dims = (1024, 257, 512)
+    out = []
+    for no_y010 in ("0", "1"):
+        monkeypatch.setenv("X3D_NO_Y010", no_y010)
+        case = make_channel(dims, fused=True, rotation=True, omega_rot=0.12, n_rotate=2)
+        case.step(1)
+        s = case.solver
+        _, ens, dmax, _ = case.postprocess(1, 0.005)
+        out.append(([s.backend.get_field_data(f) for f in (s.u, s.v, s.w)], ens, dmax))
+        del case, s
+        gc.collect()
+        torch.cuda.empty_cache()
+    (fa, ea, da), (fb, eb, db) = out
+    for x, y, nm in zip(fa, fb, "uvw"):
+        assert np.max(np.abs(x - y)) < 1e-11 * max(np.max(np.abs(y)), 1.0), nm
+        assert np.max(np.abs(x - y)) > 0.0, nm  # (two different routes)
+    assert abs(ea - eb) < 1e-11 * abs(eb)
+    assert da < 1e-9 and db < 1e-9, (da, db)
+
+
 @pytest.mark.parametrize("dims", [(1024, 33, 16), (256, 33, 16)])
 def test_rotation_forcing_inside_transeq_x_vs_the_two_vecadds(dims, monkeypatch):
     """k_xwide_transeq3<ROT> / k_xscan_transeq2x3<CHN>: du = transeq_x(u) - omega v, dv = transeq_x(v) + omega u
