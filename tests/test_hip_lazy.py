@@ -57,6 +57,9 @@ def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, mon
     assert st["tds_acc"] + 3 * st["transeq_upd"] == 3 * nsub and (n != 256 or st["transeq_upd"] >= nsub - steps - 1)
     assert st["solve_000"] == nsub
     assert st["tds_lincomb"] + st["lincombs"] >= 3 * nsub - 3
+    # ... and every stage rides on its first x operator: where the blocks of the three stages change hands in a ring (RK3's
+    # last stage) the fused kernel writes into a free buffer that the handle's next life is bound to (rule 6, L_BIND)
+    assert st["lincombs"] <= 3 and st["extra_buffers"] == 0, st
     assert st["aliases"] >= 16 * nsub       # the reorders (and the veccopies that turned into buffer swaps)
     assert st["materialised"] == 0 and st["sync_copies"] == 0
     assert st["launched"] < 0.5 * st["recorded"]

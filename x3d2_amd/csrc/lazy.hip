@@ -38,7 +38,7 @@
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
     L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST,
-    L_FFT_POST010, L_SOLVE010R
+    L_FFT_POST010, L_SOLVE010R, L_BIND
 };
 
 struct LOp {
@@ -63,6 +63,7 @@ struct x3d_lazy {
     std::unordered_map<const double *, int> users;      // physical buffer -> handles mapped to it
     std::vector<double *> handles;                      // registration order
     std::vector<double *> pool;                         // extra physical buffers owned by the layer
+    std::unordered_map<const double *, double *> bind;  // handle -> the buffer an earlier operation filled for its NEXT life (L_BIND)
     long stats[ST_N] = {};
 };
 
@@ -544,7 +545,25 @@ static void optimise(x3d_backend *b)
         int at = -1;
         if (range_clear(q, p, k, {y}, inputs_of(q[p]))) at = k;
         else if (range_clear(q, p, k, {y, du}, {})) at = p;
-        if (at < 0) continue;
+        if (at < 0) {
+            // neither move is possible when the blocks of the three stages change hands in a ring (the allocator gives the
+            // solve of u the block v's stage has just released, and so on: RK3's last stage, once per step): the handle du
+            // is still in use under its previous life between p and k.  The solve starts a NEW life of it (it overwrites
+            // the whole block), so the fused kernel may run where the combination stood and write into a free buffer of
+            // the layer; an L_BIND where the solve stood hands that buffer to the handle.
+            if (!registered(L, du) || !range_clear(q, p, k, {y}, {})) continue;
+            bool busy = false;  // (one pending buffer per handle)
+            for (int m = p + 1; m < k && !busy; m++)
+                busy = (q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && q[m].mode == 1 && q[m].obj == du);
+            if (busy) continue;
+            LOp f = q[p];
+            f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = nullptr; f.obj = du; f.mode = 1; f.o[1] = y; f.t[0] = q[k].t[0];
+            q[p] = f;
+            LOp g;
+            g.kind = L_BIND; g.o[0] = du;
+            q[k] = g;
+            continue;
+        }
         LOp f = q[p];
         f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = du; f.o[1] = y; f.t[0] = q[k].t[0];
         q[p].kind = L_DEAD; q[k].kind = L_DEAD;
@@ -643,9 +662,25 @@ static int exec(x3d_backend *b, const LOp &op)
         return 0;
     }
     if (op.kind == L_DISCARD) { drop(L, op.o[0]); return 0; }
+    if (op.kind == L_BIND) {  // the handle's new life starts in the buffer a fused kernel filled earlier (rule 6)
+        auto it = L->bind.find(op.o[0]);
+        if (it == L->bind.end()) { x3d_set_error("x3d_lazy: L_BIND without a pending buffer"); return 2; }
+        drop(L, op.o[0]);
+        L->phys[op.o[0]] = it->second;  // (users[buffer] is 1 since the kernel took it)
+        L->bind.erase(it);
+        return 0;
+    }
     for (int k = 0; k < nin(op); k++)
         if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
     for (int k = 0; k < nout(op); k++) {
+        if (op.kind == L_TDS_LIN && op.mode == 1 && k == 0) {  // du goes to a free buffer, bound to its handle later
+            double *f = nullptr;
+            if (int rc = find_free(b, nullptr, &f)) return rc;
+            L->users[f] = 1;
+            L->bind[static_cast<double *>(op.obj)] = f;
+            o[0] = f;
+            continue;
+        }
         double *before = registered(L, op.o[k]) ? L->phys[op.o[k]] : nullptr;
         if (int rc = prepare_out(b, op.o[k], !out_is_update(op, k), &o[k])) return rc;
         if (before && before != o[k]) L->stats[ST_OOP]++;
@@ -733,7 +768,8 @@ static void dump(const x3d_lazy *L, const char *title)
 {
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
-                                  "solve000", "transeq_upd", "species", "species_acc", "zfirst"};
+                                  "solve000", "transeq_upd", "species", "species_acc", "zfirst", "fft_post010", "solve010_rows",
+                                  "bind"};
     std::unordered_map<const double *, int> id;
     auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
