@@ -103,6 +103,9 @@ def test_deferred_channel_steps_are_bit_identical(dims, stretching, beta, monkey
     st = lazy.solver.backend.lazy_stats()
     assert st["transeq_acc"] == 12 and st["pairs"] == 24 and st["tds_acc"] + 3 * st["transeq_upd"] == 18
     assert st["materialised"] == 0
+    # the RK stage, apply_BC's wall stamping (recorded) and the divergence's first x operator: one call per variable and
+    # sub-step (x3d_tds_solve_lincomb_wall); define_BC's bulk-velocity shift runs at once on translated handles: no copies
+    assert st["tds_lincomb"] == 18 and st["sync_copies"] == 0, st
     # (bit for bit without the pair rewrites and the accumulating solve, whose kernels contract "du + s * result" into one
     #  fused multiply-add where the separate calls round twice)
     monkeypatch.setenv("X3D_LAZY_RULES", str(255 - 2 - 4 - 8))

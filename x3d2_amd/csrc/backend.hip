@@ -716,11 +716,12 @@ __global__ void __launch_bounds__(256) k_shift_dev(double2 *__restrict__ f, size
 
 // the two halves of x3d_field_shift_to_mean: *shift = device address of target - volume_integral(f) / ncell (valid
 // until the backend's next reduction); f += that device scalar
-extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
-                                    const double **shift)
+// (the entry points below translate their field ONCE -- a translated pointer must not be translated again: the buffer that
+//  holds a handle's data is usually another handle's own block -- and run at once: X3D_LAZY_IN / _OUT, no copies; a queue
+//  flushed through X3D_LAZY_SYNC here cost the channel case five block copies per sub-step, round 4)
+static int mean_shift_impl(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
+                           const double **shift)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && ncell > 0.0 && shift, "x3d_field_mean_shift: bad argument");
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
                 "x3d_field_mean_shift: dims outside the block");
@@ -736,10 +737,17 @@ extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int d
     return 0;
 }
 
-extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift)
+extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
+                                    const double **shift)
 {
-    if (b) X3D_LAZY_SYNC(b);
+    X3D_REQUIRE(b && f, "x3d_field_mean_shift: bad argument");
+    X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
+    return mean_shift_impl(b, f, dims, ncell, target, shift);
+}
+
+static int shift_by_impl(x3d_backend *b, double *f, const double *shift)
+{
     X3D_REQUIRE(b && f && shift, "x3d_field_shift_by: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     const size_t n2 = b->nblock / 2;
@@ -748,13 +756,22 @@ extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift
     return 0;
 }
 
+extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift)
+{
+    X3D_REQUIRE(b && f, "x3d_field_shift_by: null argument");
+    X3D_LAZY_OUT(b, f, false);
+    X3D_LAZY_EAGER(b);
+    return shift_by_impl(b, f, shift);
+}
+
 extern "C" int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target)
 {
-    if (b) X3D_LAZY_SYNC(b);
+    X3D_REQUIRE(b && f, "x3d_field_shift_to_mean: bad argument");
+    X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
     const double *shift = nullptr;
-    if (int rc = x3d_field_mean_shift(b, f, dims, ncell, target, &shift)) return rc;
-    return x3d_field_shift_by(b, f, shift);
+    if (int rc = mean_shift_impl(b, f, dims, ncell, target, &shift)) return rc;
+    return shift_by_impl(b, f, shift);
 }
 
 // splitmix64 of (seed, counter): the value depends on its inputs only, not on the launch geometry
@@ -783,9 +800,9 @@ __global__ void __launch_bounds__(256) k_wall_noise(double *__restrict__ f, int 
 extern "C" int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
                               unsigned long long draw)
 {
-    if (b) X3D_LAZY_SYNC(b);
-    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims, "x3d_wall_noise: null argument");
+    X3D_LAZY_OUT(b, f, false);  // (two planes are written: the rest of the block keeps its contents)
+    X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 1 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
                 "x3d_wall_noise: dims outside the block");
     const long n = 2L * dims[0] * dims[2];
@@ -900,6 +917,12 @@ extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], 
 extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
                                              double c_end, int face, double flow_rate_diff)
 {
+    if (b && x3d_lazy_active(b) && face == X3D_Y_FACE) {  // recorded (the RK stage before it and the x operator behind it fuse)
+        X3D_REQUIRE(f && f_start && dims, "x3d_field_set_face_from_field: null argument");
+        X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
+                    "x3d_field_set_face_from_field: dims outside the block");
+        return x3d_lazy_setface(b, f, f_start, dims);
+    }
     if (b) { X3D_LAZY_IN(b, f_start); X3D_LAZY_OUT(b, f, false); }
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && f_start && dims, "x3d_field_set_face_from_field: null argument");

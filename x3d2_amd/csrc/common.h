@@ -146,6 +146,7 @@ int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir);
 int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
 int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double a);  // 0 vecmult, 1 scale, 2 shift, 3 fill
 int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f);               // 0 forward, 1 postprocess_000, 2 backward
+int x3d_lazy_setface(x3d_backend *b, double *f, const double *f_start, const int dims[3]);  // field_set_face_from_field(Y_FACE)
 // an entry point that runs at once while the mode is on: nothing it calls may be recorded (or have its -- already
 // translated -- pointers translated again) until it returns
 bool x3d_lazy_set_executing(x3d_backend *b, bool on);  // returns the previous state

@@ -38,7 +38,7 @@
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
     L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST,
-    L_FFT_POST010, L_SOLVE010R, L_BIND
+    L_FFT_POST010, L_SOLVE010R, L_BIND, L_SETFACE
 };
 
 struct LOp {
@@ -49,6 +49,7 @@ struct LOp {
     const x3d_tdsops *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double s[6] = {0, 0, 0, 0, 0, 0};
     void *obj = nullptr;  // x3d_poisson* of the FFT hooks
+    int dims[3] = {0, 0, 0};  // L_SETFACE: the field's extent
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
@@ -242,11 +243,12 @@ static int nin(const LOp &op)
 {
     switch (op.kind) {
     case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5)
-    case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: return 1;
+    case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: case L_SETFACE: return 1;
     case L_SPECIES: case L_SPECIES_ACC: return 2;  // uvw, spec
     case L_ZFIRST: return 2;
     case L_PAIR: return op.mode == 0 ? 2 : 1;
-    case L_LINCOMB: case L_TDS_LIN: return 1 + op.nterm;  // base, x...
+    case L_LINCOMB: return 1 + op.nterm;  // base, x...
+    case L_TDS_LIN: return 1 + op.nterm + ((op.mode & 2) ? 1 : 0);  // base, x..., the wall field (mode & 2)
     default: return 0;
     }
 }
@@ -268,7 +270,7 @@ static bool out_is_update(const LOp &op, int slot = 0)
     switch (op.kind) {
     case L_SPECIES_ACC:
     case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
-    case L_FFT_BWD: case L_SOLVE000: case L_SOLVE010R:
+    case L_FFT_BWD: case L_SOLVE000: case L_SOLVE010R: case L_SETFACE:
         return true;  // (the FFT hooks: forward only reads f, backward writes the real extent of f -- keep the contents)
     default: return false;
     }
@@ -536,28 +538,46 @@ static void optimise(x3d_backend *b)
     for (int p = 0; p < n && (L->rules & 32u); p++) {
         if (q[p].kind != L_LINCOMB) continue;
         double *y = q[p].o[0];
-        const int k = first_touch_after(q, p, y);
+        int k = first_touch_after(q, p, y);
+        // ... with the y faces of y stamped from a wall field in between (field_set_face_from_field(Y_FACE): the channel
+        // case's apply_BC, src/case/channel.f90:214-231): x3d_tds_solve_lincomb_wall does all three.  The stamping is taken
+        // out of the queue for the checks below and dies with the rewrite.
+        int ksf = -1;
+        const double *wall = nullptr;
+        if (k >= 0 && q[k].kind == L_SETFACE && q[k].o[0] == y && q[p].nterm <= 5 && q[k].in[0] != y &&
+            q[k].dims[0] == b->nx && q[k].dims[1] == b->ny && q[k].dims[2] == b->nz) {  // (the whole vertex block's faces)
+            ksf = k;
+            wall = q[k].in[0];
+            k = first_touch_after(q, ksf, y);
+        }
         if (k < 0 || q[k].kind != L_TDS || q[k].dir != X3D_DIR_X || q[k].in[0] != y) continue;
         double *du = q[k].o[0];
-        bool ok = du != y;
+        bool ok = du != y && du != wall;
         for (int c = 0; c <= q[p].nterm; c++) ok = ok && du != q[p].in[c];
         if (!ok) continue;
+        LOp sf;
+        if (ksf >= 0) { sf = q[ksf]; q[ksf].kind = L_DEAD; }
+        auto undo_sf = [&]() { if (ksf >= 0) q[ksf] = sf; };
+        std::vector<const double *> stable = inputs_of(q[p]);
+        if (wall) stable.push_back(wall);
         int at = -1;
-        if (range_clear(q, p, k, {y}, inputs_of(q[p]))) at = k;
-        else if (range_clear(q, p, k, {y, du}, {})) at = p;
+        if (range_clear(q, p, k, {y}, stable)) at = k;
+        else if (range_clear(q, p, k, {y, du}, wall ? std::vector<const double *>{wall} : std::vector<const double *>{})) at = p;
         if (at < 0) {
             // neither move is possible when the blocks of the three stages change hands in a ring (the allocator gives the
             // solve of u the block v's stage has just released, and so on: RK3's last stage, once per step): the handle du
             // is still in use under its previous life between p and k.  The solve starts a NEW life of it (it overwrites
             // the whole block), so the fused kernel may run where the combination stood and write into a free buffer of
             // the layer; an L_BIND where the solve stood hands that buffer to the handle.
-            if (!registered(L, du) || !range_clear(q, p, k, {y}, {})) continue;
-            bool busy = false;  // (one pending buffer per handle)
-            for (int m = p + 1; m < k && !busy; m++)
-                busy = (q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && q[m].mode == 1 && q[m].obj == du);
-            if (busy) continue;
+            bool busy = !registered(L, du) ||
+                        !range_clear(q, p, k, {y}, wall ? std::vector<const double *>{wall} : std::vector<const double *>{});
+            for (int m = p + 1; m < k && !busy; m++)  // (one pending buffer per handle)
+                busy = (q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && (q[m].mode & 1) && q[m].obj == du);
+            if (busy) { undo_sf(); continue; }
             LOp f = q[p];
-            f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = nullptr; f.obj = du; f.mode = 1; f.o[1] = y; f.t[0] = q[k].t[0];
+            f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = nullptr; f.obj = du; f.mode = 1 | (wall ? 2 : 0); f.o[1] = y;
+            f.t[0] = q[k].t[0];
+            if (wall) f.in[1 + f.nterm] = wall;
             q[p] = f;
             LOp g;
             g.kind = L_BIND; g.o[0] = du;
@@ -566,6 +586,8 @@ static void optimise(x3d_backend *b)
         }
         LOp f = q[p];
         f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = du; f.o[1] = y; f.t[0] = q[k].t[0];
+        f.mode = wall ? 2 : 0;
+        if (wall) f.in[1 + f.nterm] = wall;
         q[p].kind = L_DEAD; q[k].kind = L_DEAD;
         q[at] = f;
     }
@@ -673,7 +695,7 @@ static int exec(x3d_backend *b, const LOp &op)
     for (int k = 0; k < nin(op); k++)
         if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
     for (int k = 0; k < nout(op); k++) {
-        if (op.kind == L_TDS_LIN && op.mode == 1 && k == 0) {  // du goes to a free buffer, bound to its handle later
+        if (op.kind == L_TDS_LIN && (op.mode & 1) && k == 0) {  // du goes to a free buffer, bound to its handle later
             double *f = nullptr;
             if (int rc = find_free(b, nullptr, &f)) return rc;
             L->users[f] = 1;
@@ -705,7 +727,10 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_TDS: return x3d_tds_solve(b, o[0], in[0], op.t[0], op.dir);
     case L_TDS_ACC: return x3d_tds_solve_acc(b, o[0], in[0], op.t[0], op.dir, 1, op.s[0]);
     case L_PAIR: return x3d_tds_solve_pair(b, op.dir, op.mode, o[0], o[1], in[0], in[1], op.t[0], op.t[1]);
-    case L_TDS_LIN: return x3d_tds_solve_lincomb(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1]);
+    case L_TDS_LIN:
+        if (op.mode & 2) return x3d_tds_solve_lincomb_wall(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1], in[1 + op.nterm]);
+        return x3d_tds_solve_lincomb(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1]);
+    case L_SETFACE: return x3d_field_set_face_from_field(b, o[0], in[0], op.dims, 0.0, X3D_Y_FACE, 0.0);
     case L_SUM: return x3d_sum_intox(b, o[0], in[0], op.dir);
     case L_VECADD: return x3d_vecadd(b, op.s[0], in[0], op.s[1], o[0]);
     case L_LINCOMB: return x3d_lincomb(b, o[0], in[0], op.nterm, op.s, &in[1]);
@@ -769,7 +794,7 @@ static void dump(const x3d_lazy *L, const char *title)
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
                                   "solve000", "transeq_upd", "species", "species_acc", "zfirst", "fft_post010", "solve010_rows",
-                                  "bind"};
+                                  "bind", "setface"};
     std::unordered_map<const double *, int> id;
     auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
@@ -894,6 +919,14 @@ int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double 
     LOp op;
     op.kind = kind == 0 ? L_VECMULT : kind == 1 ? L_SCALE : kind == 2 ? L_SHIFT : L_FILL;
     op.o[0] = f; op.in[0] = x; op.s[0] = a;
+    return push(b, op);
+}
+int x3d_lazy_setface(x3d_backend *b, double *f, const double *f_start, const int dims[3])
+{
+    LOp op;
+    op.kind = L_SETFACE;
+    op.o[0] = f; op.in[0] = f_start;
+    for (int k = 0; k < 3; k++) op.dims[k] = dims[k];
     return push(b, op);
 }
 int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
