@@ -271,6 +271,8 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "slabs", "yslabs", "pencils"],
                     help="N > 1: y slabs [1,N,1] (TGV default: z-first Poisson solve), z slabs [1,1,N] (the channel case: "
                          "y must stay whole) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: do not time configs[1] (256^3, no Poisson) and the channel case after the headline")
     ap.add_argument("--no-validate", action="store_true",
                     help="N > 1: skip the one-step validation of the decomposition (and its fall-back chain)")
     ap.add_argument("--op-granular", action="store_true",
@@ -307,10 +309,15 @@ def main():
     torch.cuda.set_device(0 if share else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a collective whose peer never arrives (a rank that raised while building or validating a layout) ends after
+        # this limit instead of never: gloo raises in the waiting ranks (validated() below turns that into a failed
+        # layout), RCCL's watchdog ends the process and spawn_ranks / the launcher end the others
+        import datetime
+        pg_to = datetime.timedelta(seconds=float(os.environ.get("X3D_BENCH_PG_TIMEOUT", "300")))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_to)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_to)
     elif os.environ.get("X3D_COMM_SELF_VIA_NCCL") == "1":
         # one GPU, world size 1: with X3D_EMULATE_DECOMP the N > 1 code path then exchanges with itself THROUGH RCCL
         # (x3d2_amd/parallel.py) -- the RCCL calls, the communication stream and the wait semantics run for real
@@ -403,200 +410,245 @@ def main():
                             poisson="CG" if args.no_poisson else "FFT", fused=not args.op_granular, rotation=True,
                             omega_rot=0.12, n_rotate=5000, comm=comm, nproc_dir=nproc_dir, rank=rank,
                             lazy=args.lazy)
-    solver, backend = case.solver, case.solver.backend
-    nstage = solver.time_integrator.nstage
+    def measure(case, nproc_dir, dims, decomp_name):
+        """W warm-up steps, K timed steps between barriers + device syncs (max over the ranks), one more step with every
+        kernel class and the exchanges timed; returns the JSON object of this case on this decomposition"""
+        solver, backend = case.solver, case.solver.backend
+        nstage = solver.time_integrator.nstage
 
-    def sync_all():
-        backend.sync()  # (x3d_device_sync: also runs what the deferred-execution layer still holds)
-        torch.cuda.synchronize()
-        comm.barrier()
-        torch.cuda.synchronize()
+        def sync_all():
+            backend.sync()  # (x3d_device_sync: also runs what the deferred-execution layer still holds)
+            torch.cuda.synchronize()
+            comm.barrier()
+            torch.cuda.synchronize()
 
-    it = 0
-    for _ in range(args.warmup):
+        it = 0
+        for _ in range(args.warmup):
+            it += 1
+            case.step(it)
+        # HIP-event timers around the launches of the dominant kernel class (the roofline's kernel) during the timed
+        # region; the other classes are timed in one extra step afterwards (all classes on cost 0.4 ms per step of
+        # event records: same-box A/B 48.4 -> 48.0)
+        backend.prof_enable(True)
+        backend.prof_select(None if os.environ.get("X3D_BENCH_PROF_ALL") == "1" else ("transeq_fwd", "transeq_bwd"))
+        backend.prof_reset()
+        backend.rk_fused_passes = 0
+        backend.rk_fused_launches = 0
+        tq3_before = int(backend.lib.x3d_backend_counter(backend.h, 0))
+        upd_before = int(backend.lib.x3d_backend_counter(backend.h, 1))
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            it += 1
+            case.step(it, more=(k < args.steps - 1))  # (the last step completes its velocity correction itself)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        dof_global = dims[0] * dims[1] * dims[2]
+        dof_local = args.n ** 3 if args.case == "tgv" else dof_global // args.gpus
+        value = dof_global * args.steps / elapsed
+
+        # ---- roofline of the dominant kernel class: one transport-equation
+        # component = k_transeq_fwd + k_transeq_bwd (64 B/DoF for the three
+        # components of one direction: u-component reads 1 + writes 1, the other two
+        # read 2 + write 1 fields; SURVEY.md 8d, DESIGN.md)
+        n_f, ms_f = backend.prof_get("transeq_fwd")
+        n_b, ms_b = backend.prof_get("transeq_bwd")
+        per_dir_raw = {d: (backend.prof_get("transeq_fwd", d), backend.prof_get("transeq_bwd", d)) for d in (1, 2, 3)}
+        n_tq3 = int(backend.lib.x3d_backend_counter(backend.h, 0)) - tq3_before
+        n_upd = int(backend.lib.x3d_backend_counter(backend.h, 1)) - upd_before
+        rk_fused_passes, rk_fused_launches = backend.rk_fused_passes, backend.rk_fused_launches
+        # every kernel class, from ONE more step outside the timed region
+        backend.prof_select(None)
+        backend.prof_reset()
+        comm.timed = comm.size > 1 or getattr(comm, "self_via_nccl", False)
         it += 1
         case.step(it)
-    # HIP-event timers around the launches of the dominant kernel class (the roofline's kernel) during the timed
-    # region; the other classes are timed in one extra step afterwards (all classes on cost 0.4 ms per step of
-    # event records: same-box A/B 48.4 -> 48.0)
-    backend.prof_enable(True)
-    backend.prof_select(None if os.environ.get("X3D_BENCH_PROF_ALL") == "1" else ("transeq_fwd", "transeq_bwd"))
-    backend.prof_reset()
-    backend.rk_fused_passes = 0
-    backend.rk_fused_launches = 0
-    tq3_before = int(backend.lib.x3d_backend_counter(backend.h, 0))
-    upd_before = int(backend.lib.x3d_backend_counter(backend.h, 1))
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        it += 1
-        case.step(it, more=(k < args.steps - 1))  # (the last step completes its velocity correction itself)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        sync_all()
+        exchanges = comm.timing_report() if comm.timed else None
+        comm.timed = False
+        prof = {"note": "one extra step after the timed region, all classes timed"}
+        for kind in backend.KINDS:
+            n_l, ms = backend.prof_get(kind)
+            prof[kind] = {"launches": n_l, "ms": ms}
+        per_dir = {}
+        for d, name in ((1, "x"), (2, "y"), (3, "z")):
+            (nf, mf), (nb, mb) = per_dir_raw[d]
+            if nf:
+                per_dir[name] = {"ms_per_component": (mf + mb) / nf,
+                                 "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9,
+                                 "GB/s_at_48B_per_3_components": 16.0 * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
+        # algorithmic bytes per launch.  SURVEY.md 8d's per-unit figures price every operation on its own: a transeq
+        # component 24 B/DoF (16 when conv == u) = 64 B/DoF per direction, an accumulating tds_solve 24 B/DoF.  The fused
+        # launches of this backend have a smaller compulsory traffic -- a three-in-one launch reads the advecting
+        # velocity once (the table's "fully fused floor" of 48 B/DoF), and a transeq_x launch that also applies the
+        # pending velocity correction reads 3 gradients and writes u, v, w on top (+48 B/DoF, the velocity itself
+        # being an input it reads anyway).  Headline `achieved` / `frac`: that compulsory traffic of what a launch
+        # does; `achieved_survey_per_unit`: the per-operation figures (larger: the fusion removed re-reads).
+        comps3 = min(3 * n_tq3, n_f)
+        rk_bytes = 8.0 * dof_local * rk_fused_passes  # RK stage done by a transeq launch
+        n_fused = rk_fused_launches
+        total_floor = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0 + 48.0 * n_upd) * dof_local + rk_bytes
+        total_survey = (n_f * (64.0 / 3.0) + 72.0 * n_upd) * dof_local + rk_bytes
+        avg_ms = (ms_f + ms_b) / max(n_f, 1)
+        transeq_bytes = (64.0 / 3.0) * dof_local
+        bytes_per_launch = total_floor / max(n_f, 1)  # per component
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
+        achieved_survey = total_survey / max(n_f, 1) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
+        # HBM bytes per launch from the PMC counters cannot be collected inside a timed run (rocprofv3 --pmc passes,
+        # scratch/round_artifacts.sh): the figure printed here is the one measured at the commit named next to it
+        traffic = traffic_commit = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.case == "tgv" and args.gpus == 1 and not args.op_granular:
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("n") == args.n and tj.get("commit"):
+                    # HBM bytes of ONE launch of the dominant kernel (k_ytile_transeq3), PMC FETCH_SIZE + WRITE_SIZE
+                    traffic = tj.get("dominant_kernel_bytes_per_launch") or tj.get("transeq_component_bytes_per_launch")
+                    traffic_commit = tj.get("commit")
+            except Exception:
+                traffic = traffic_commit = None
+        # the dominant KERNEL by itself: the three-in-one tile kernel of the y and z directions (k_ytile_transeq3 at
+        # periodic 256 / 512-row pencils, k_ygen_transeq3 for the channel's wall-normal pencils), event-timed inside the
+        # timed region; bytes = SURVEY 8(d)'s unit figure for transeq_{y,z}: 64 B/DoF per launch of three components
+        dominant = None
+        # (channel: the wall-normal direction's k_ygen_transeq3 by itself -- its z launches are another kernel)
+        dom_dirs = (2,) if args.case == "channel" else (2, 3)
+        yz = [(per_dir_raw[d][0][0], per_dir_raw[d][0][1] + per_dir_raw[d][1][1]) for d in dom_dirs]
+        n_yz, ms_yz = sum(c for c, _ in yz), sum(m for _, m in yz)
+        if n_yz and n_tq3:
+            launches = n_yz / 3.0
+            d_ms = ms_yz / launches
+            d_bytes = 64.0 * dof_local
+            d_ach = d_bytes / (d_ms * 1e-3) / 1e9
+            if args.case == "tgv" and args.gpus == 1:
+                name = ("k_ytile_transeq3<%d,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
+                        % (args.n // 64))
+            elif args.case == "tgv":
+                name = "k_ytile_transeq3 (transeq_y; HALO form + strip correction for the decomposed direction)"
+            else:
+                name = "k_ygen_transeq3<5> (transeq_y on the 257-row wall-normal pencils, three components per launch)"
+            dominant = {"name": name, "launches": launches, "avg_launch_ms": d_ms, "timed": "HIP events on the backend's "
+                        "stream around every launch, inside the timed region",
+                        "algorithmic_bytes_per_launch": d_bytes, "bytes_convention": "SURVEY 8(d): transeq_{y,z} 64 B/DoF x DoF",
+                        "achieved": d_ach, "frac": d_ach / HBM_PEAK_GBS,
+                        "frac_at_48B_fused_floor": 48.0 * dof_local / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        class_average = {"what": "average over the x, y and z launches of the transport-equation class; x launches that also "
+                                 "apply the pending velocity correction are credited its 48 B/DoF",
+                         "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms}
+        head_ach = dominant["achieved"] if dominant else achieved
+        roofline = {"bound": "hbm",
+                    "kernel": dominant["name"] if dominant else
+                              "transeq component (one third of a k_xscan_transeq2x3 (x) / k_ytile_transeq3 (y, z) launch at "
+                              "512^3; x launches that also apply the pending velocity correction include its bytes)",
+                    "dominant_kernel": dominant, "class_average": class_average,
+                    "three_in_one_launches": n_tq3, "launches_with_velocity_correction": n_upd,
+                    "achieved_survey_per_unit": achieved_survey, "frac_survey_per_unit": achieved_survey / HBM_PEAK_GBS,
+                    "achieved": head_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head_ach / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
+                    "algorithmic_bytes_per_launch": dominant["algorithmic_bytes_per_launch"] if dominant else bytes_per_launch,
+                    "survey_transeq_bytes_per_component": transeq_bytes, "rk_stage_fused_launches": n_fused,
+                    "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
+                    "avg_launch_ms": dominant["avg_launch_ms"] if dominant else avg_ms, "launches": n_f, "per_direction": per_dir,
+                    "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
+                    # SURVEY.md 8d headline convention: the reference's derivative pass of one sub-step
+                    # (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time our
+                    # transeq phase takes (reorders and sums are folded into the kernels here)
+                    "tdsops_pass_GBs_survey_convention":
+                        432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
 
-    dof_global = dims[0] * dims[1] * dims[2]
-    dof_local = args.n ** 3 if args.case == "tgv" else dof_global // args.gpus
-    value = dof_global * args.steps / elapsed
+        out = {
+            "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step" if args.case == "tgv"
+                      else "DoF*steps/s, channel (stretched y, 010 Poisson), full fractional step",
+            "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # results differ from the reference's OpenMP backend by FMA contraction and re-associated scans only: every
+            # -m gpu parity test holds 1e-12 relative per operator (1e-11 on traces / full steps, 1e-10 on the stretched
+            # 010 Poisson solve); the north star asks for 1e-6 on the enstrophy trace
+            "parity_tol": {"operators_rel": 1e-12, "full_step_rel": 1e-11, "poisson_010_rel": 1e-10,
+                           "north_star_enstrophy_rel": 1e-6},
+            "config": {"workload": (f"TGV {dims[0]}x{dims[1]}x{dims[2]} all-periodic, Re=1600, dt=1e-3, "
+                                    if args.case == "tgv" else
+                                    f"channel {dims[0]}x{dims[1]}x{dims[2]} verts, y Dirichlet + top-bottom "
+                                    f"stretching, Re=4200, dt=5e-3, rotation forcing, ")
+                                   + f"{args.time_intg} ({nstage} substeps/step), compact6/classic schemes, "
+                                   + ("no pressure solve (configs[1])" if args.no_poisson
+                                      else "rocFFT Poisson (configs[2])" if args.case == "tgv"
+                                      else "rocFFT Poisson 010, pentadiagonal spectral solve"),
+                       "per_gpu": f"{args.n}^3" if args.case == "tgv" else args.dims, "nproc_dir": list(nproc_dir),
+                       "driver": ("op-granular calls recorded and fused inside the library (deferred execution)" if args.lazy
+                                  else "op-granular" if args.op_granular else "fused"),
+                       "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}",
+                       # N > 1: did the overlapped exchange path pass its first-use check against the ordered path
+                       # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
+                       "overlap_self_check": getattr(comm, "self_check_result", None),
+                       "overlap_self_check_error": getattr(comm, "self_check_error", None),
+                       # N > 1: which decomposition ran, and what its one-step validation (and any it replaced) showed
+                       "decomposition": decomp_name if args.case == "tgv" else "slabs",
+                       "decomposition_requested": requested,
+                       "decompositions_tried": tried or None,
+                       "transport": ("gloo, host staged (ranks share a GPU: a dry run)" if share else
+                                     "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if world > 1 or
+                                    dist.is_initialized() else None,
+                       # exchanges of ONE step after the timed region, HIP events on the stream they were posted from:
+                       # sendrecv = halo rows + boundary values of the decomposed direction, alltoall = Poisson transposes
+                       "exchanges_one_step": exchanges,
+                       # 000 solve at 512^3 on one rank: transforms ordered z, x, y with the z transforms inside the
+                       # neighbouring z operator pairs (csrc/zfirst.hip); counted pressure corrections of the fused driver
+                       "poisson_z_first": (int(case.solver.n_zfirst) if not args.lazy
+                                           else int(backend.lazy_stats().get("zfirst", 0)))},
+            "dof_substeps_per_s": value * nstage,
+            "roofline": roofline,
+            "kernel_ms": prof,
+        }
+        if args.lazy:
+            out["lazy_stats"] = backend.lazy_stats()
+        return out
 
-    # ---- roofline of the dominant kernel class: one transport-equation
-    # component = k_transeq_fwd + k_transeq_bwd (64 B/DoF for the three
-    # components of one direction: u-component reads 1 + writes 1, the other two
-    # read 2 + write 1 fields)
-    n_f, ms_f = backend.prof_get("transeq_fwd")
-    n_b, ms_b = backend.prof_get("transeq_bwd")
-    per_dir_raw = {d: (backend.prof_get("transeq_fwd", d), backend.prof_get("transeq_bwd", d)) for d in (1, 2, 3)}
-    n_tq3 = int(backend.lib.x3d_backend_counter(backend.h, 0)) - tq3_before
-    n_upd = int(backend.lib.x3d_backend_counter(backend.h, 1)) - upd_before
-    rk_fused_passes, rk_fused_launches = backend.rk_fused_passes, backend.rk_fused_launches
-    # every kernel class, from ONE more step outside the timed region
-    backend.prof_select(None)
-    backend.prof_reset()
-    comm.timed = comm.size > 1 or getattr(comm, "self_via_nccl", False)
-    it += 1
-    case.step(it)
-    sync_all()
-    exchanges = comm.timing_report() if comm.timed else None
-    comm.timed = False
-    prof = {"note": "one extra step after the timed region, all classes timed"}
-    for kind in backend.KINDS:
-        n_l, ms = backend.prof_get(kind)
-        prof[kind] = {"launches": n_l, "ms": ms}
-    per_dir = {}
-    for d, name in ((1, "x"), (2, "y"), (3, "z")):
-        (nf, mf), (nb, mb) = per_dir_raw[d]
-        if nf:
-            per_dir[name] = {"ms_per_component": (mf + mb) / nf,
-                             "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9,
-                             "GB/s_at_48B_per_3_components": 16.0 * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
-    # algorithmic bytes per launch.  SURVEY.md 8d's per-unit figures price every operation on its own: a transeq
-    # component 24 B/DoF (16 when conv == u) = 64 B/DoF per direction, an accumulating tds_solve 24 B/DoF.  The fused
-    # launches of this backend have a smaller compulsory traffic -- a three-in-one launch reads the advecting
-    # velocity once (the table's "fully fused floor" of 48 B/DoF), and a transeq_x launch that also applies the
-    # pending velocity correction reads 3 gradients and writes u, v, w on top (+48 B/DoF, the velocity itself
-    # being an input it reads anyway).  Headline `achieved` / `frac`: that compulsory traffic of what a launch
-    # does; `achieved_survey_per_unit`: the per-operation figures (larger: the fusion removed re-reads).
-    comps3 = min(3 * n_tq3, n_f)
-    rk_bytes = 8.0 * dof_local * rk_fused_passes  # RK stage done by a transeq launch
-    n_fused = rk_fused_launches
-    total_floor = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0 + 48.0 * n_upd) * dof_local + rk_bytes
-    total_survey = (n_f * (64.0 / 3.0) + 72.0 * n_upd) * dof_local + rk_bytes
-    avg_ms = (ms_f + ms_b) / max(n_f, 1)
-    transeq_bytes = (64.0 / 3.0) * dof_local
-    bytes_per_launch = total_floor / max(n_f, 1)  # per component
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
-    achieved_survey = total_survey / max(n_f, 1) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
-    # HBM bytes per launch from the PMC counters cannot be collected inside a timed run (rocprofv3 --pmc passes,
-    # scratch/round_artifacts.sh): the figure printed here is the one measured at the commit named next to it
-    traffic = traffic_commit = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and args.case == "tgv" and args.gpus == 1 and not args.op_granular:
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("n") == args.n and tj.get("commit"):
-                # HBM bytes of ONE launch of the dominant kernel (k_ytile_transeq3), PMC FETCH_SIZE + WRITE_SIZE
-                traffic = tj.get("dominant_kernel_bytes_per_launch") or tj.get("transeq_component_bytes_per_launch")
-                traffic_commit = tj.get("commit")
-        except Exception:
-            traffic = traffic_commit = None
-    # the dominant KERNEL by itself: the three-in-one tile kernel of the y and z directions (k_ytile_transeq3 at
-    # periodic 256 / 512-row pencils, k_ygen_transeq3 for the channel's wall-normal pencils), event-timed inside the
-    # timed region; bytes = SURVEY 8(d)'s unit figure for transeq_{y,z}: 64 B/DoF per launch of three components
-    dominant = None
-    yz = [(per_dir_raw[d][0][0], per_dir_raw[d][0][1] + per_dir_raw[d][1][1]) for d in (2, 3)]
-    n_yz, ms_yz = sum(c for c, _ in yz), sum(m for _, m in yz)
-    if n_yz and n_tq3:
-        launches = n_yz / 3.0
-        d_ms = ms_yz / launches
-        d_bytes = 64.0 * dof_local
-        d_ach = d_bytes / (d_ms * 1e-3) / 1e9
-        if args.case == "tgv" and args.gpus == 1:
-            name = "k_ytile_transeq3<8,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
-        elif args.case == "tgv":
-            name = "k_ytile_transeq3 (transeq_y; HALO form + strip correction for the decomposed direction)"
+    out = measure(case, nproc_dir, dims, args.decomp)
+
+    def brief(o):
+        r = o["roofline"]
+        return {"workload": o["config"]["workload"], "nproc_dir": o["config"]["nproc_dir"], "value": o["value"],
+                "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                "roofline": {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"],
+                             "unit": r["unit"], "frac": r["frac"], "traffic": r.get("traffic"),
+                             "avg_launch_ms": r["avg_launch_ms"],
+                             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]},
+                "exchanges_one_step": o["config"].get("exchanges_one_step")}
+
+    if args.case == "tgv" and args.gpus > 1 and requested == "auto" and os.environ.get("X3D_BENCH_ONE_LAYOUT") != "1":
+        # N > 1: BOTH layouts in one run -- the validated default (y slabs: one all-to-all pair per solve over all links)
+        # and the north star's / BASELINE configs[3]'s 2-D pencil split [1, 2, N/2] (src/decomp/decomp_2decompfft.f90:42-48);
+        # `value` is the better of the two, config.decomposition names it, both stay under `decompositions`
+        import gc
+        other = "pencils" if args.decomp != "pencils" else "yslabs"
+        layouts = {args.decomp: brief(out)}
+        if decomposition(args.gpus, other) == tuple(nproc_dir):
+            layouts[other] = {"nproc_dir": list(nproc_dir), "same_layout_as": args.decomp,
+                              "note": "at N = %d the two coincide" % args.gpus}
         else:
-            name = "k_ygen_transeq3<5> (transeq_y, 257-row wall-normal pencils) and k_ytile_transeq3 (transeq_z)"
-        dominant = {"name": name, "launches": launches, "avg_launch_ms": d_ms, "timed": "HIP events on the backend's "
-                    "stream around every launch, inside the timed region",
-                    "algorithmic_bytes_per_launch": d_bytes, "bytes_convention": "SURVEY 8(d): transeq_{y,z} 64 B/DoF x DoF",
-                    "achieved": d_ach, "frac": d_ach / HBM_PEAK_GBS,
-                    "frac_at_48B_fused_floor": 48.0 * dof_local / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    class_average = {"what": "average over the x, y and z launches of the transport-equation class; x launches that also "
-                             "apply the pending velocity correction are credited its 48 B/DoF",
-                     "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms}
-    head_ach = dominant["achieved"] if dominant else achieved
-    roofline = {"bound": "hbm",
-                "kernel": dominant["name"] if dominant else
-                          "transeq component (one third of a k_xscan_transeq2x3 (x) / k_ytile_transeq3 (y, z) launch at "
-                          "512^3; x launches that also apply the pending velocity correction include its bytes)",
-                "dominant_kernel": dominant, "class_average": class_average,
-                "three_in_one_launches": n_tq3, "launches_with_velocity_correction": n_upd,
-                "achieved_survey_per_unit": achieved_survey, "frac_survey_per_unit": achieved_survey / HBM_PEAK_GBS,
-                "achieved": head_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head_ach / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
-                "algorithmic_bytes_per_launch": dominant["algorithmic_bytes_per_launch"] if dominant else bytes_per_launch,
-                "survey_transeq_bytes_per_component": transeq_bytes, "rk_stage_fused_launches": n_fused,
-                "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
-                "avg_launch_ms": dominant["avg_launch_ms"] if dominant else avg_ms, "launches": n_f, "per_direction": per_dir,
-                "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
-                # SURVEY.md 8d headline convention: the reference's derivative pass of one sub-step
-                # (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time our
-                # transeq phase takes (reorders and sums are folded into the kernels here)
-                "tdsops_pass_GBs_survey_convention":
-                    432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
-
-    out = {
-        "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step" if args.case == "tgv"
-                  else "DoF*steps/s, channel (stretched y, 010 Poisson), full fractional step",
-        "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        # results differ from the reference's OpenMP backend by FMA contraction and re-associated scans only: every
-        # -m gpu parity test holds 1e-12 relative per operator (1e-11 on traces / full steps, 1e-10 on the stretched
-        # 010 Poisson solve); the north star asks for 1e-6 on the enstrophy trace
-        "parity_tol": {"operators_rel": 1e-12, "full_step_rel": 1e-11, "poisson_010_rel": 1e-10,
-                       "north_star_enstrophy_rel": 1e-6},
-        "config": {"workload": (f"TGV {dims[0]}x{dims[1]}x{dims[2]} all-periodic, Re=1600, dt=1e-3, "
-                                if args.case == "tgv" else
-                                f"channel {dims[0]}x{dims[1]}x{dims[2]} verts, y Dirichlet + top-bottom "
-                                f"stretching, Re=4200, dt=5e-3, rotation forcing, ")
-                               + f"{args.time_intg} ({nstage} substeps/step), compact6/classic schemes, "
-                               + ("no pressure solve (configs[1])" if args.no_poisson
-                                  else "rocFFT Poisson (configs[2])" if args.case == "tgv"
-                                  else "rocFFT Poisson 010, pentadiagonal spectral solve"),
-                   "per_gpu": f"{args.n}^3" if args.case == "tgv" else args.dims, "nproc_dir": list(nproc_dir),
-                   "driver": ("op-granular calls recorded and fused inside the library (deferred execution)" if args.lazy
-                              else "op-granular" if args.op_granular else "fused"),
-                   "parallelism": f"domain decomposition {nproc_dir[0]}x{nproc_dir[1]}x{nproc_dir[2]}",
-                   # N > 1: did the overlapped exchange path pass its first-use check against the ordered path
-                   # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
-                   "overlap_self_check": getattr(comm, "self_check_result", None),
-                   "overlap_self_check_error": getattr(comm, "self_check_error", None),
-                   # N > 1: which decomposition ran, and what its one-step validation (and any it replaced) showed
-                   "decomposition": args.decomp if args.case == "tgv" else "slabs",
-                   "decomposition_requested": requested,
-                   "decompositions_tried": tried or None,
-                   "transport": ("gloo, host staged (ranks share a GPU: a dry run)" if share else
-                                 "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if world > 1 or
-                                dist.is_initialized() else None,
-                   # exchanges of ONE step after the timed region, HIP events on the stream they were posted from:
-                   # sendrecv = halo rows + boundary values of the decomposed direction, alltoall = Poisson transposes
-                   "exchanges_one_step": exchanges,
-                   # 000 solve at 512^3 on one rank: transforms ordered z, x, y with the z transforms inside the
-                   # neighbouring z operator pairs (csrc/zfirst.hip); counted pressure corrections of the fused driver
-                   "poisson_z_first": (int(case.solver.n_zfirst) if not args.lazy
-                                       else int(backend.lazy_stats().get("zfirst", 0)))},
-        "dof_substeps_per_s": value * nstage,
-        "roofline": roofline,
-        "kernel_ms": prof,
-    }
-    if args.lazy:
-        out["lazy_stats"] = backend.lazy_stats()
+            case = built = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            built = validated(other)
+            if built is None:
+                layouts[other] = {"nproc_dir": list(decomposition(args.gpus, other)), "value": None,
+                                  "error": tried[-1].get("error", "validation failed")}
+            else:
+                o2 = measure(built[0], built[1], built[2], other)
+                layouts[other] = brief(o2)
+                if o2["value"] > out["value"]:
+                    out = o2
+            out["config"]["decompositions_tried"] = tried or None
+        out["decompositions"] = layouts
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
         # the port is measured fastest on ONE socket's worth of threads or fewer (numpy-allocated blocks are
         # first-touched by one thread, so more threads only add remote-memory traffic: profiles/README.md)
@@ -630,6 +682,31 @@ def main():
             best["other_shapes"] = [{"mpi_ranks": r["mpi_ranks"], "omp_threads_per_rank": r["omp_threads_per_rank"], "n": r["n"],
                                      "value": r["value"]} for r in refs if r is not best]
             out["cpu_baseline"]["reference_nopoisson"] = best
+    if (rank == 0 and args.gpus == 1 and args.case == "tgv" and args.n == 512 and not args.no_poisson
+            and not args.no_other_configs and not args.op_granular):
+        # the other BASELINE configs one GPU holds, each in a fresh child process after this one has let go of its
+        # blocks (5 timed + 2 warm-up steps): configs[1] = TGV 256^3 derivatives + RK only, and the one-GPU form of
+        # configs[4] = channel 1024 x 257 x 512; each with the roofline of ITS dominant kernel
+        import gc
+        import subprocess
+        case = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = {}
+        for key, extra in (("configs[1] TGV 256^3, derivatives + RK only (no pressure solve)", ["--n", "256", "--no-poisson"]),
+                           ("configs[4] on one GPU: channel 1024x257x512", ["--case", "channel", "--dims", "1024,257,512"])):
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                                    "--no-cpu-baseline", "--no-other-configs"] + extra, capture_output=True, text=True,
+                                   timeout=300)
+                o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                others[key] = brief(o)
+                others[key]["kernel_ms"] = {k: v for k, v in o["kernel_ms"].items() if isinstance(v, dict) and v["launches"]}
+            except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
+                others[key] = {"value": None, "error": repr(e)[:300]}
+            others[key]["seconds_in_all"] = time.perf_counter() - t0
+        out["other_configs"] = others
     if rank == 0:
         # the JSON line is the LAST thing on stdout: whatever libraries left in C stdio's buffer (RCCL's version banner
         # is printf'ed at init and would otherwise surface after Python's own output, at exit) goes out first

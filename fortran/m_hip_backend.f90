@@ -589,6 +589,11 @@ module m_hip_backend
     integer(c_long) :: cap(8, 2:3) = 0, off(8, 2:3) = 0   ! doubles per buffer of a set, the set's start in the slab
     integer :: xb_n = 0
     integer :: tile_tq(2:3) = -1, tile_tds(2:3) = -1       ! single-pass kernels serve this direction (-1: not probed)
+    ! one-pass verdicts per operator handle, agreed by ALL ranks (tile_verdict): a rank whose own probe accepts must not
+    ! take the one-pass form while a neighbour (a boundary rank of a non-periodic direction) takes the two-phase one --
+    ! they would pack different buffer sets and pull from buffers that were never packed
+    integer(c_intptr_t) :: tv_h(64) = 0
+    integer :: tv_ok(64) = -1, tv_n = 0
     logical :: d2d = .false., one_pass = .true.
     real(dp), allocatable :: hs(:), he(:), hrs(:), hre(:)
   contains
@@ -839,7 +844,7 @@ contains
     real(dp), intent(in) :: nu
     type(dirps_t), intent(in) :: dirps
     type(c_ptr) :: rhs(3), fld(3), t1, t2, t3
-    integer :: i, np
+    integer :: i, np, mine, ierr
     integer(c_int) :: done
     call need_buffers(self)
     np = x3d_npencils(self%handle, int(dir, c_int))
@@ -858,7 +863,9 @@ contains
                                       real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
                                       tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
                                       xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, 0_c_int, done))
-      self%tile_tq(dir) = done
+      ! collective: every rank of the run takes the same form (MIN over the ranks' probes)
+      mine = int(done)
+      call MPI_Allreduce(mine, self%tile_tq(dir), 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
     end if
     if (self%one_pass .and. self%tile_tq(dir) == 1) then
       call next_use(self, dir, 5)
@@ -985,12 +992,9 @@ contains
         d = u%dir
         np = x3d_npencils(self%handle, int(d, c_int))
         if (self%one_pass .and. self%tile_tds(d) /= 0 .and. d /= DIR_X) then
-          ! single pass (as transeq_dist): mode 2 of the pair kernel = one operator.  Probed per call: the operators
-          ! of a direction differ in length (n_tds /= n_rhs for v2p) and closure
-          call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), 2_c_int, xs(self, 1, 1, d), c_null_ptr, &
-                                           xs(self, 1, 2, d), c_null_ptr, tds_handle(tdsops), c_null_ptr, &
-                                           xr(self, 1, 7, d), xs(self, 1, 8, d), 0_c_int, 0_c_int, done))
-          if (done == 1) then
+          ! single pass (as transeq_dist): mode 2 of the pair kernel = one operator.  Probed per OPERATOR (the operators
+          ! of a direction differ in length -- n_tds /= n_rhs for v2p -- and closure), once, and agreed by all ranks
+          if (tile_verdict(self, d, tdsops) == 1) then
             one(1) = dev(u)
             call next_use(self, d, 7)
             call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 7, d), one, 1_c_int, int(tdsops%n_tds, c_int), &
@@ -1022,6 +1026,37 @@ contains
     end if
     call x3d_check(x3d_tds_solve(self%handle, dev(du), dev(u), tds_handle(tdsops), int(u%dir, c_int)))
   end subroutine tds_solve_hip
+
+  integer function tile_verdict(self, d, tdsops) result(ok)
+    !! does EVERY rank's single-pass tile kernel take this operator in direction d?  The local probe (a launch over zero
+    !! planes) is reduced with MIN over all ranks the first time an operator is seen -- all ranks issue the same
+    !! sequence of backend calls, so the reduction meets -- and remembered by the operator's handle.
+    class(hip_backend_t) :: self
+    integer, intent(in) :: d
+    class(tdsops_t), intent(in) :: tdsops
+    integer(c_intptr_t) :: key
+    integer(c_int) :: done
+    integer :: k, mine, ierr
+    key = transfer(tds_handle(tdsops), key)
+    do k = 1, self%tv_n
+      if (self%tv_h(k) == key) then
+        ok = self%tv_ok(k)
+        return
+      end if
+    end do
+    call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), 2_c_int, xs(self, 1, 1, d), c_null_ptr, &
+                                     xs(self, 1, 2, d), c_null_ptr, tds_handle(tdsops), c_null_ptr, &
+                                     xr(self, 1, 7, d), xs(self, 1, 8, d), 0_c_int, 0_c_int, done))
+    mine = int(done)
+    call MPI_Allreduce(mine, ok, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    if (self%tv_n < size(self%tv_h)) then
+      self%tv_n = self%tv_n + 1
+      self%tv_h(self%tv_n) = key
+      self%tv_ok(self%tv_n) = ok
+    else
+      ok = 0   ! (table full: the two-phase form on every rank -- the same on all ranks, they count alike)
+    end if
+  end function tile_verdict
 
   subroutine reorder_hip(self, u_, u, direction)
     class(hip_backend_t) :: self

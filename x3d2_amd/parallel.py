@@ -38,7 +38,12 @@ class _Pending:
 
 
 class Comm:
-    def __init__(self, group=None):
+    # verdict of the overlapped path's self-check per (group, backend, self-via-RCCL): the check is collective and
+    # allocates 512 MiB -- every Comm object of a process after the first reuses the verdict (all ranks construct their
+    # Comm objects in the same order, so they agree on who checks); Comm(self_check=False) opts out (ordered path)
+    _verdicts = {}
+
+    def __init__(self, group=None, self_check=True):
         self.enabled = dist.is_available() and dist.is_initialized()
         self.group = group
         self.rank = dist.get_rank(group) if self.enabled else 0
@@ -63,6 +68,7 @@ class Comm:
         self._checked = self.host_staged or not self.enabled or not self.overlap or \
             (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
+        self.self_check_error = None
         # event timers around the exchanges (bench.py switches them on for ONE step outside its timed region):
         # kind -> [count, bytes, [(start event, end event)]]
         self.timed = False
@@ -70,7 +76,16 @@ class Comm:
         # the check is collective (a ring exchange + an all-reduce): it runs HERE, where every rank is -- not at the first
         # exchange, which a rank whose first group is empty would skip while its neighbours wait for it
         if not self._checked:
-            self.self_check()
+            key = (id(group) if group is not None else None, self.backend, self.self_via_nccl)
+            if not self_check:
+                self._checked, self.overlap = True, False
+            elif key in Comm._verdicts:
+                self._checked = True
+                self.self_check_result, self.self_check_error = Comm._verdicts[key]
+                self.overlap = self.overlap and bool(self.self_check_result)
+            else:
+                self.self_check()
+                Comm._verdicts[key] = (self.self_check_result, getattr(self, "self_check_error", None))
 
     # ------------------------------------------------------------ p2p core
     def _note(self, kind, sends, e0, e1):
