@@ -271,6 +271,12 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "slabs", "yslabs", "pencils"],
                     help="N > 1: y slabs [1,N,1] (TGV default: z-first Poisson solve), z slabs [1,1,N] (the channel case: "
                          "y must stay whole) or the 2-D pencil split [1,2,N/2] of BASELINE configs[3]")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="ONE process stands in for rank 0 of a V-rank job (V = 2, 4, 8; --gpus 1): the V-rank kernels and "
+                         "exchange pattern, every peer this rank itself through RCCL (X3D_COMM_FAKE_PEERS / _SELF_VIA_NCCL), "
+                         "every exchange holding its stream for the time xGMI links of X3D_COMM_EMULATE_LINKS GB/s (default "
+                         "61.4 = 80 %% of 76.8 per link and direction) would take -- a schedule timeline on a one-GPU box, "
+                         "NOT a measurement of links; the JSON line says so")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1: do not time configs[1] (256^3, no Poisson) and the channel case after the headline")
     ap.add_argument("--no-validate", action="store_true",
@@ -288,6 +294,13 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+    if args.virtual_ranks:
+        if args.gpus != 1 or args.virtual_ranks not in (2, 4, 8) or args.case != "tgv":
+            raise SystemExit("--virtual-ranks V: V = 2, 4 or 8, with --gpus 1 and the TGV case")
+        os.environ["X3D_COMM_FAKE_PEERS"] = "1"
+        os.environ["X3D_COMM_SELF_VIA_NCCL"] = "1"
+        os.environ.setdefault("X3D_COMM_EMULATE_LINKS", "61.4")
+        args.no_cpu_baseline = args.no_other_configs = True
 
     # the CPU baseline uses the cores the host really gives this process (set before libgomp starts)
     phys, eff_cpus = effective_cpus()
@@ -338,11 +351,14 @@ def main():
     tried = []
 
     def build(decomp):
-        nproc_dir = decomposition(args.gpus, decomp)
+        nproc_dir = decomposition(args.virtual_ranks or args.gpus, decomp)
         dims = tuple(args.n * p for p in nproc_dir)
+        # (virtual ranks: the slabs are periodic replicas -- L grows with the rank count, the spacing stays -- so that
+        #  rank 0 exchanging with itself IS the V-rank job's rank 0)
+        twopi = 6.283185307179586
         case = make_tgv(dims, nproc_dir=nproc_dir, rank=rank, time_intg=args.time_intg,
                         poisson="CG" if args.no_poisson else "FFT", comm=comm, fused=not args.op_granular,
-                        lazy=args.lazy)
+                        lazy=args.lazy, L=tuple(twopi * p for p in nproc_dir) if args.virtual_ranks else None)
         return case, nproc_dir, dims
 
     def validated(decomp):
@@ -377,7 +393,7 @@ def main():
             torch.cuda.empty_cache()
         return built
 
-    if args.case == "tgv" and args.gpus > 1 and not args.no_validate:
+    if args.case == "tgv" and args.gpus > 1 and not args.no_validate and not args.virtual_ranks:
         # the N > 1 layouts have only ever run as several ranks on ONE GPU, as one process standing in for a rank, and
         # through RCCL to self: the first real multi-GPU run checks what it is about to time, and falls back
         chain = [args.decomp] + [d for d in ("yslabs", "slabs", "pencils") if d != args.decomp]
@@ -563,9 +579,24 @@ def main():
                     "tdsops_pass_GBs_survey_convention":
                         432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
 
+        emu = None
+        if args.virtual_ranks:
+            emu = {"what": "EMULATION, not a multi-GPU measurement: ONE process on ONE GPU runs rank 0's kernels and exchange "
+                           "pattern of a %d-rank job; every peer is the rank itself through RCCL; every exchange holds its "
+                           "stream for the time the message would spend on xGMI links" % args.virtual_ranks,
+                   "virtual_ranks": args.virtual_ranks,
+                   "link_GBs_per_direction": float(os.environ["X3D_COMM_EMULATE_LINKS"]),
+                   "link_model": "all-to-all among n peers: bytes / n / rate (n - 1 links at once); neighbour exchange: "
+                                 "largest message / rate; 76.8 GB/s per link and direction by the public MI355X "
+                                 "specification (7 links x 153.6 GB/s bidirectional), 61.4 = 80 % of it",
+                   "value_if_every_rank_ran_like_this_one": value,
+                   "slab_yparts": getattr(backend.poisson_fft, "yparts", None),
+                   "slab_parts": getattr(backend.poisson_fft, "parts", None)}
         out = {
-            "metric": "DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step" if args.case == "tgv"
-                      else "DoF*steps/s, channel (stretched y, 010 Poisson), full fractional step",
+            "metric": ("DoF*steps/s (whole node), TGV 512^3 per GPU, full fractional step" if args.case == "tgv"
+                       else "DoF*steps/s, channel (stretched y, 010 Poisson), full fractional step")
+                      + (" -- EMULATED %d ranks on one GPU" % args.virtual_ranks if args.virtual_ranks else ""),
+            "emulation": emu,
             "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -506,6 +506,16 @@ int x3d_sfftz_z(x3d_sfftz *p, double *f, int inverse);
 int x3d_sfftz_x_forward(x3d_sfftz *p, double *sendbuf, int part);
 int x3d_sfftz_y_stage(x3d_sfftz *p, double *recvbuf, int part, int what); /* what 0: all; 1 forward, 2 inverse, 3 division */
 int x3d_sfftz_x_backward(x3d_sfftz *p, const double *buf, int part);
+/* round 5: the same steps for the local y rows [y0, y0 + nyr) only -- a z pair works tile by tile and the rows' piece of
+ * every (part, peer) chunk of the exchange layout is contiguous, so a group of rows can leave while the next group's z
+ * pair runs, and come back while the previous group's z pair runs (poisson_fft.HipSlabPoissonFFTZ.zfirst_solve_pipelined;
+ * the reference hands its transposes to cuFFTMp / 2decomp&FFT, which block: src/backend/cuda/poisson_fft.f90:218-219,
+ * src/backend/omp/poisson_fft.f90:89-137) */
+int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                            const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done);
+int x3d_sfftz_z_rows(x3d_sfftz *p, double *f, int inverse, int y0, int nyr);
+int x3d_sfftz_x_forward_rows(x3d_sfftz *p, double *sendbuf, int part, int y0, int nyr);
+int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const double *buf, int part, int y0, int nyr);
 
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
@@ -574,7 +584,10 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m
  * [6] lincombs, [7] tds_solve_lincomb, [8] solve_000, [9] updates run out of place (buffer swaps), [10] copies made for
  * an in-place update of a shared buffer, [11] copies made by x3d_lazy_sync, [12] flushes, [14] transeq_x launches that carry the velocity
  * correction of the pressure step (x3d_transeq_x_update), [13] calls dropped by the
- * rewrite, [15] extra buffers held, [16] pressure corrections through the z-first solve; [17..23] reserved (0). */
+ * rewrite, [15] extra buffers held, [16] pressure corrections through the z-first solve, [17] DECLINED: operations that ran
+ * unfused although the reference's fixed sequences always offer a rewrite (a sum_{y,z}intox or a transeq_y / z launched by
+ * itself) -- together with [10] the witness of a call sequence the rewrites do not recognise; a process that ends with
+ * [17] + [10] > 0 says so once on stderr (results are the call-by-call ones, only slower); [18..23] reserved (0). */
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);
 int x3d_lazy_sync(x3d_backend *b);

@@ -18,6 +18,7 @@ os.environ["X3D_EMULATE_DECOMP"] = "y" if yslabs else "z"
 os.environ["X3D_FORCE_PENCIL_FFT"] = "yslab" if yslabs else "slab"
 if yslabs:
     os.environ["X3D_SLAB_PARTS"] = "4"
+    os.environ.setdefault("X3D_SLAB_YPARTS", "4")  # round 5: blocks of rows x kz planes, as on several ranks
 from x3d2_amd import make_tgv  # noqa: E402
 from x3d2_amd.parallel import Comm  # noqa: E402
 

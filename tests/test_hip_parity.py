@@ -634,6 +634,33 @@ def test_unchanged_reference_solver_through_fortran_shim(tmp_path):
     assert rows[:, 2].max() < 1e-13
 
 
+def test_reference_transeq_lowmem_through_fortran_shim(tmp_path):
+    """`lowmem_transeq = .true.` (src/solver.f90:206-207): the unchanged solver.f90 then issues transeq_lowmem's call order
+    (:391-505 -- velocity blocks released while their y / z copies are worked on, RDR_Y2Z / RDR_Z2X reorders, u, v, w rebound)
+    through the shim and the deferred-execution layer: the trace fixture to 2e-13, the same digits as the default order, the
+    rewrites engaged (two accumulating transeq launches per sub-step) and nothing declined"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "xcompact_hip")
+    if not os.path.exists(exe):
+        pytest.skip("shim binary not built (needs the reference tree at build time)")
+    rows = {}
+    for name in ("tgv64", "tgv64_lowmem"):
+        wd = tmp_path / name
+        wd.mkdir()
+        r = subprocess.run([exe, os.path.join(root, "fortran", name + ".x3d")], cwd=wd, capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, X3D_LAZY_REPORT="1"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rows[name] = np.loadtxt(wd / "monitoring.csv", delimiter=",", comments="#")
+        st = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", r.stderr.split("x3d_lazy_report pid")[1])}
+        assert st["transeq_acc"] == 2 * 3 * 20 and st["declined"] == 0 and st["materialised"] == 0, (name, st)
+        assert "x3d_lazy WARNING" not in r.stderr
+    fx = read_trace_fixture()
+    assert np.all(np.abs(rows["tgv64_lowmem"][:3, 1] - fx[:, 1]) < 2e-13)
+    assert np.array_equal(rows["tgv64_lowmem"], rows["tgv64"])
+
+
 @pytest.mark.parametrize("nranks,inp", [(2, "tgv64.x3d"), (4, "tgv64_p22.x3d")])
 def test_unchanged_reference_solver_through_fortran_shim_on_several_ranks(nranks, inp, tmp_path):
     """the same binary under mpirun: the reference's solver on [1, 1, 2] and [1, 2, 2] ranks (sharing the one
@@ -1635,13 +1662,27 @@ def test_y_slabs_with_the_z_first_solve_emulated_and_on_two_ranks(tmp_path, monk
     del ref
     monkeypatch.setenv("X3D_EMULATE_DECOMP", "y")
     monkeypatch.setenv("X3D_FORCE_PENCIL_FFT", "yslab")
-    emu = make_tgv(512, fused=True)
-    emu.step(1)
-    s = emu.solver
-    assert s.n_zfirst == 3 and s.backend.halo_launches > 0
-    for g, w in zip([s.backend.get_field_data(f) for f in (s.u, s.v, s.w)], want):
-        assert relerr(g, w) < 1e-11
-    del emu, s, want
+    got = {}
+    for yparts in ("1", "4"):
+        # round 5: "4" = the solve in blocks of 128 rows x the kz groups (the z pairs, the x transforms and the exchanges of a
+        # rows group beside the transfers of the others: HipSlabPoissonFFTZ.zfirst_solve_pipelined, the default on several
+        # ranks); "1" = rounds 3-4's schedule.  The same kernels on the same data: bit for bit.
+        monkeypatch.setenv("X3D_SLAB_YPARTS", yparts)
+        monkeypatch.setenv("X3D_SLAB_PARTS", "4")
+        emu = make_tgv(512, fused=True)
+        emu.step(1)
+        s = emu.solver
+        assert s.n_zfirst == 3 and s.backend.halo_launches > 0
+        assert s.backend.poisson_fft.n_pipelined == (3 if yparts == "4" else 0)
+        got[yparts] = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
+        for g, w in zip(got[yparts], want):
+            assert relerr(g, w) < 1e-11
+        del emu, s
+    for g1, g4 in zip(got["1"], got["4"]):
+        assert np.array_equal(g1, g4)
+    del want, got
+    monkeypatch.delenv("X3D_SLAB_YPARTS")
+    monkeypatch.delenv("X3D_SLAB_PARTS")
     monkeypatch.delenv("X3D_EMULATE_DECOMP")
     monkeypatch.delenv("X3D_FORCE_PENCIL_FFT")
     dims = (512, 1024, 512)
@@ -1671,15 +1712,17 @@ def test_random_field_pressure_correction_at_512_cubed_vs_oracle(zfirst):
     print([l for l in r.stdout.splitlines() if l.startswith("PC512")])
 
 
-@pytest.mark.parametrize("py", [2, 4, 8])
-def test_y_slab_solver_on_virtual_ranks(py):
+@pytest.mark.parametrize("py,yparts", [(2, 1), (4, 1), (8, 1), (4, 4), (8, 2)])
+def test_y_slab_solver_on_virtual_ranks(py, yparts):
     """csrc/sfftz.hip as bench.py --gpus N --decomp auto uses it (y slabs [1, py, 1] of 512^3 cells), every rank of a
     py-rank job in ONE process: py solver objects (rank r's x-mode offset, wave-number slice and k_fft512_peers<py, ., YL>
     chunk layout), the all-to-alls done by hand exactly as Comm.ialltoall lays them out (part m, slot p of rank r's
     receive buffer <- part m, slot r of rank p's send buffer).  The field is the same 512^3 array on every rank (a
     y-periodic replica; L_y = py * 2 pi keeps the spacing), so each rank's result must equal the SINGLE-RANK solve of
     that array (poisson_000, src/poisson_fft.f90:216-226) -- which pins the py = 4 and 8 layouts that no one-GPU box
-    can run as separate processes at this size."""
+    can run as separate processes at this size.  yparts > 1 (round 5): every local stage through its *_rows form, rows
+    group by rows group (x3d_sfftz_z_rows, _x_forward_rows, _x_backward_rows: the pieces zfirst_solve_pipelined sends as
+    separate blocks) -- the same buffers must come out."""
     import torch
     from x3d2_amd import Mesh, _lib
     from x3d2_amd.backend import HipBackend
@@ -1715,9 +1758,16 @@ def test_y_slab_solver_on_virtual_ranks(py):
         g = sr.backend.allocator.get_block(DIR_C, CELL)
         sr.backend.set_field_data(g, f, CELL)
         blocks.append(g)
-        _lib.check(lib.x3d_sfftz_z(pf.h, g.ptr, 0))
-        for m in range(parts):
-            _lib.check(lib.x3d_sfftz_x_forward(pf.h, pf.sbuf.data_ptr(), m))
+        if yparts == 1:
+            _lib.check(lib.x3d_sfftz_z(pf.h, g.ptr, 0))
+            for m in range(parts):
+                _lib.check(lib.x3d_sfftz_x_forward(pf.h, pf.sbuf.data_ptr(), m))
+        else:
+            for a in range(yparts):
+                y0, nyr = a * (512 // yparts), 512 // yparts
+                _lib.check(lib.x3d_sfftz_z_rows(pf.h, g.ptr, 0, y0, nyr))
+                for m in range(parts):
+                    _lib.check(lib.x3d_sfftz_x_forward_rows(pf.h, pf.sbuf.data_ptr(), m, y0, nyr))
     torch.cuda.synchronize()
 
     def alltoall(src, dst):
@@ -1735,9 +1785,16 @@ def test_y_slab_solver_on_virtual_ranks(py):
     torch.cuda.synchronize()
     alltoall("rbuf", "sbuf")
     for (sr, pf), g in zip(ranks, blocks):
-        for m in range(parts):
-            _lib.check(lib.x3d_sfftz_x_backward(pf.h, pf.sbuf.data_ptr(), m))
-        _lib.check(lib.x3d_sfftz_z(pf.h, g.ptr, 1))
+        if yparts == 1:
+            for m in range(parts):
+                _lib.check(lib.x3d_sfftz_x_backward(pf.h, pf.sbuf.data_ptr(), m))
+            _lib.check(lib.x3d_sfftz_z(pf.h, g.ptr, 1))
+        else:
+            for a in range(yparts):
+                y0, nyr = a * (512 // yparts), 512 // yparts
+                for m in range(parts):
+                    _lib.check(lib.x3d_sfftz_x_backward_rows(pf.h, pf.sbuf.data_ptr(), m, y0, nyr))
+                _lib.check(lib.x3d_sfftz_z_rows(pf.h, g.ptr, 1, y0, nyr))
         assert relerr(sr.backend.get_field_data(g, CELL), ref) < 1e-12, (py, pf.ry)
 
 

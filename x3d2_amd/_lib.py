@@ -170,6 +170,10 @@ PROTOTYPES = {
     "x3d_sfftz_x_forward": (I, [VP, VP, I]),
     "x3d_sfftz_y_stage": (I, [VP, VP, I, I]),
     "x3d_sfftz_x_backward": (I, [VP, VP, I]),
+    "x3d_sfftz_tds_pair_rows": (I, [VP, I, VP, VP, VP, VP, VP, VP, I, I, c_int_p]),
+    "x3d_sfftz_z_rows": (I, [VP, VP, I, I, I]),
+    "x3d_sfftz_x_forward_rows": (I, [VP, VP, I, I, I]),
+    "x3d_sfftz_x_backward_rows": (I, [VP, VP, I, I, I]),
     "x3d_pfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I]),
     "x3d_pfft_destroy": (I, [VP]),
     "x3d_pfft_sizes": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

@@ -109,7 +109,7 @@ class HipBackend:
 
     LAZY_STATS = ("recorded", "launched", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
                   "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "transeq_upd",
-                  "extra_buffers", "zfirst")
+                  "extra_buffers", "zfirst", "declined")
 
     def lazy_stats(self):
         """counters of the deferred-execution layer (x3d_lazy_stats)"""

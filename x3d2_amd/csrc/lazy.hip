@@ -53,7 +53,11 @@ struct LOp {
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
-       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_POOL_SLOT, ST_ZFIRST, ST_N };
+       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_POOL_SLOT, ST_ZFIRST, ST_DECLINED, ST_N };
+// ST_DECLINED: operations of the recorded sequence that no rewrite absorbed although the reference's fixed sequences
+// always offer one -- a sum_{y,z}intox launched by itself (rule 1 did not find its transeq_<d> + three sums), a transeq_y / z
+// launched without its sums, a reorder / veccopy that had to move data (materialised).  Not wrong, only slow (the
+// call-by-call speed for that piece): x3d_lazy_stats reports the count and the process says so ONCE when it ends.
 
 struct x3d_lazy {
     bool on = false, executing = false;
@@ -717,6 +721,8 @@ static int exec(x3d_backend *b, const LOp &op)
     case L_SOLVE000: case L_SOLVE010R: L->stats[ST_SOLVE000]++; break;
     case L_TRANSEQ_UPD: L->stats[ST_TRANSEQ_UPD]++; break;
     case L_ZFIRST: L->stats[ST_ZFIRST]++; break;
+    case L_SUM: L->stats[ST_DECLINED]++; break;
+    case L_TRANSEQ: if (op.dir != X3D_DIR_X) L->stats[ST_DECLINED]++; break;
     default: break;
     }
     switch (op.kind) {
@@ -940,14 +946,24 @@ int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
 // ---------------------------------------------------------------- C ABI
 // X3D_LAZY_REPORT=1: the counters of x3d_lazy_stats on stderr when the process ends (a host side that never asks for
 // them -- the Fortran shim under mpirun -- still shows whether the rewrites engaged)
+static bool g_report_all = false;
 static void report_at_exit()
 {
     static const char *nm[ST_N] = {"recorded", "launches", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
                                    "solve000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped",
-                                   "transeq_x_update", "pool_slot", "zfirst"};
+                                   "transeq_x_update", "pool_slot", "zfirst", "declined"};
     for (size_t r = 0; r < g_reported.size(); r++) {
         const x3d_lazy *L = g_reported[r];
         char line[1024];
+        const long slow = L->stats[ST_DECLINED] + L->stats[ST_MATERIALISE];
+        if (slow > 0) {  // whatever X3D_LAZY_REPORT says: a sequence the rewrites did not recognise must not pass silently
+            int n = snprintf(line, sizeof line, "x3d_lazy WARNING pid %d: %ld operation(s) of the recorded call sequence ran unfused "
+                             "(%ld sum_intox / transeq without a matching rewrite, %ld reorder / veccopy as real copies): results are "
+                             "the call-by-call ones, only slower -- X3D_LAZY_REPORT=1 prints every counter\n", (int)getpid(), slow,
+                             L->stats[ST_DECLINED], L->stats[ST_MATERIALISE]);
+            if (write(2, line, (size_t)n) < 0) {}
+        }
+        if (!g_report_all) continue;
         int n = snprintf(line, sizeof line, "x3d_lazy_report pid %d: three_in_one=%ld halo_forms=%ld", (int)getpid(),
                          g_reported_b[r]->n_tq3, g_reported_b[r]->n_halo);
         for (int k = 0; k < ST_N && n < (int)sizeof line - 40; k++) n += snprintf(line + n, sizeof line - n, " %s=%ld", nm[k], L->stats[k]);
@@ -962,11 +978,10 @@ extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
     x3d_lazy *L = lazy_of(b);
     if (on && std::find(g_reported.begin(), g_reported.end(), L) == g_reported.end()) {
         const char *rep = getenv("X3D_LAZY_REPORT");
-        if (rep && rep[0] == '1') {
-            if (g_reported.empty()) atexit(report_at_exit);
-            g_reported.push_back(L);
-            g_reported_b.push_back(b);
-        }
+        g_report_all = rep && rep[0] == '1';
+        if (g_reported.empty()) atexit(report_at_exit);
+        g_reported.push_back(L);
+        g_reported_b.push_back(b);
     }
     if (!on && L->on) {
         if (int rc = x3d_lazy_sync_c(b)) return rc;

@@ -16,6 +16,17 @@
 // 6.5 passes over the spectrum per solve and ONE all-to-all pair, like the z-slab solver (csrc/sfft.hip) -- which
 // needs 10.5 passes because there the decomposed axis is the one the neighbouring operators work along.
 // Exchange buffers: [part][peer][yl = 512][kzc_part][xs] complex numbers, a part's block contiguous.
+//
+// Round 5: BLOCKS of (y rows) x (kz planes).  The all-to-alls are the one term of a multi-GPU step that nothing hid
+// (2 x 0.95 GB per solve over 7 links: 2 x 2.2 ms at 8 GPUs): the z pair in front of the solve had to
+// finish for ALL tiles before the first group of kz planes could leave, and the z pair behind it could not start before
+// the last group was back.  But a z pair works tile by tile -- a group of local y rows yields COMPLETE kz columns of those
+// rows -- and in the exchange layout the rows yl0 .. yl1 of a (part, peer) chunk are one contiguous piece.  So the
+// *_rows entry points below take a range of y rows: the z pair and the x transforms of rows group a + 1 run beside the
+// transfers of group a, the y stage of kz group k starts when the LAST rows group's block of k has arrived (beside the
+// transfers of the kz groups behind it), its result leaves at once, and on the way back the x transforms and the z pair
+// of rows group a run when its last kz block is in, beside the transfers of the rows groups behind it
+// (poisson_fft.HipSlabPoissonFFTZ.zfirst_solve_pipelined).  Same kernels on the same data: bit for bit the unsplit solve.
 #include "zfft_tile.h"
 
 #define SZ_PX 520
@@ -25,9 +36,9 @@ int x3d_fft512_init();
 const double2 *x3d_fft512_twiddles();
 int x3d_fft512_peers_yl(x3d_backend *b, double2 *R, long W, int npeers, const double *rw, const double *ab, int nx, int ny,
                         int nz, int xs, int xoff, int kz0, int part);
-int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd);
+int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd, int y0, int nyr);
 int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done);
+                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr);
 
 struct x3d_sfftz {
     x3d_backend *b;
@@ -43,7 +54,7 @@ struct x3d_sfftz {
 template <bool PACK>
 __global__ void __launch_bounds__(512)
     k_c2c512_x_xchg(double2 *__restrict__ c, double2 *__restrict__ sm, const double2 *__restrict__ twg, int k0, int kzc,
-                    int xs)
+                    int xs, int y0, int nyr)
 {
     extern __shared__ double2 zx[];  // [8][FP] + 256 twiddles
     double2 *__restrict__ tws = zx + 8 * FP;
@@ -51,9 +62,9 @@ __global__ void __launch_bounds__(512)
     __syncthreads();
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double2 *__restrict__ pen = zx + w * FP;
-    const long nrows = (long)kzc * 512, step = (long)gridDim.x * 8;
+    const long nrows = (long)kzc * nyr, step = (long)gridDim.x * 8;  // rows (kl, yl), yl in [y0, y0 + nyr)
     for (long row = (long)blockIdx.x * 8 + w; row < nrows; row += step) {
-        const int kl = (int)(row >> 9), yl = (int)(row & 511);
+        const int kl = (int)(row / nyr), yl = y0 + (int)(row - (long)kl * nyr);
         double2 *__restrict__ cr = c + ((long)(k0 + kl) * 512 + yl) * SZ_PX;
         double2 a[8];
 #pragma unroll
@@ -144,7 +155,23 @@ extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, double *out1, double *
     X3D_LAZY_EAGER(p->b);
     bool ok = false;
     *done = 0;
-    if (int rc = x3d_ytile_tds_pair_zf(p->b, mode, out1, out2, in1, in2, ta, tb, zfarg(p), &ok)) return rc;
+    if (int rc = x3d_ytile_tds_pair_zf(p->b, mode, out1, out2, in1, in2, ta, tb, zfarg(p), &ok, 0, -1)) return rc;
+    *done = ok ? 1 : 0;
+    return 0;
+}
+// ... for the tiles of the local y rows [y0, y0 + nyr) only
+extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1,
+                                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done)
+{
+    X3D_REQUIRE(p && ta && tb && done, "x3d_sfftz_tds_pair_rows: null argument");
+    X3D_REQUIRE(mode == 0 || mode == 1, "x3d_sfftz_tds_pair_rows: mode must be 0 or 1");
+    X3D_REQUIRE(mode == 0 ? (in1 && in2) : (out1 && out2 && out1 != out2), "x3d_sfftz_tds_pair_rows: null argument");
+    X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= 512, "x3d_sfftz_tds_pair_rows: rows [%d, %d) of 512", y0, y0 + nyr);
+    X3D_LAZY_SYNC(p->b);
+    X3D_LAZY_EAGER(p->b);
+    bool ok = false;
+    *done = 0;
+    if (int rc = x3d_ytile_tds_pair_zf(p->b, mode, out1, out2, in1, in2, ta, tb, zfarg(p), &ok, y0, nyr)) return rc;
     *done = ok ? 1 : 0;
     return 0;
 }
@@ -154,22 +181,30 @@ extern "C" int x3d_sfftz_z(x3d_sfftz *p, double *f, int inverse)
 {
     X3D_REQUIRE(p && f, "null argument");
     X3D_LAZY_SYNC(p->b);
-    return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse);
+    return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, 0, -1);
+}
+extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, double *f, int inverse, int y0, int nyr)
+{
+    X3D_REQUIRE(p && f, "null argument");
+    X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= 512, "x3d_sfftz_z_rows: rows [%d, %d) of 512", y0, y0 + nyr);
+    X3D_LAZY_SYNC(p->b);
+    return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, y0, nyr);
 }
 
 #define SZ_PART(p, m, name) X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": part %d of %d", (m), (p) ? (p)->parts : 0)
 
 template <bool PACK>
-static int x_xchg(x3d_sfftz *p, double *buf, int m)
+static int x_xchg(x3d_sfftz *p, double *buf, int m, int y0 = 0, int nyr = 512)
 {
     const int lds = sizeof(double2) * (8 * FP + 256);
     X3D_LDS_OPTIN(p->b, (k_c2c512_x_xchg<PACK>));
     const int kzc = p->kz0[m + 1] - p->kz0[m];
-    long blocks = ((long)kzc * 512 + 7) / 8;
+    if (nyr == 0) return 0;
+    long blocks = ((long)kzc * nyr + 7) / 8;
     if (blocks > 2048) blocks = 2048;
     ProfScope ps(p->b, X3D_K_FFT, PACK ? 1 : 2);
     hipLaunchKernelGGL((k_c2c512_x_xchg<PACK>), dim3((unsigned)blocks), dim3(512), lds, p->b->stream, p->c,
-                       (double2 *)buf + p->off[m], x3d_fft512_twiddles(), p->kz0[m], kzc, p->xs);
+                       (double2 *)buf + p->off[m], x3d_fft512_twiddles(), p->kz0[m], kzc, p->xs, y0, nyr);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -199,4 +234,22 @@ extern "C" int x3d_sfftz_x_backward(x3d_sfftz *p, const double *buf, int m)
     SZ_PART(p, m, "x3d_sfftz_x_backward");
     X3D_REQUIRE(buf, "null argument");
     return x_xchg<false>(p, const_cast<double *>(buf), m);
+}
+
+// block (rows [y0, y0 + nyr), part m): x forward into sendbuf / x inverse out of buf -- the rows' piece of every (part, peer)
+// chunk is contiguous: complex elements [off(m) + (r 512 + y0) kzc xs, + nyr kzc xs) for peer r
+#define SZ_ROWS(y0, nyr, name) X3D_REQUIRE((y0) >= 0 && (nyr) >= 0 && (y0) + (nyr) <= 512, name ": rows [%d, %d) of 512", (y0), (y0) + (nyr))
+extern "C" int x3d_sfftz_x_forward_rows(x3d_sfftz *p, double *sendbuf, int m, int y0, int nyr)
+{
+    SZ_PART(p, m, "x3d_sfftz_x_forward_rows");
+    SZ_ROWS(y0, nyr, "x3d_sfftz_x_forward_rows");
+    X3D_REQUIRE(sendbuf, "null argument");
+    return x_xchg<true>(p, sendbuf, m, y0, nyr);
+}
+extern "C" int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const double *buf, int m, int y0, int nyr)
+{
+    SZ_PART(p, m, "x3d_sfftz_x_backward_rows");
+    SZ_ROWS(y0, nyr, "x3d_sfftz_x_backward_rows");
+    X3D_REQUIRE(buf, "null argument");
+    return x_xchg<false>(p, const_cast<double *>(buf), m, y0, nyr);
 }

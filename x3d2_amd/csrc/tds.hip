@@ -1382,7 +1382,7 @@ extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out
 struct x3d_poisson;
 int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok);
 int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done);
+                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr);
 extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2,
                                    const double *in1, const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                    int *done)
@@ -1399,7 +1399,7 @@ extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mod
     bool ok = false;
     if (int rc = x3d_zfirst_arg(poisson, &zf, &ok)) return rc;
     if (!ok) return 0;
-    if (int rc = x3d_ytile_tds_pair_zf(b, mode, out1, out2, in1, in2, ta, tb, zf, &ok)) return rc;
+    if (int rc = x3d_ytile_tds_pair_zf(b, mode, out1, out2, in1, in2, ta, tb, zf, &ok, 0, -1)) return rc;
     *done = ok ? 1 : 0;
     return 0;
 }

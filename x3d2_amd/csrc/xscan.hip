@@ -1715,15 +1715,20 @@ bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_t
 
 // the z pairs next to the z-first Poisson solve (k_ytile_tds_pair<.., ZF>): mode 0: A(in1) + B(in2) -> spectrum,
 // mode 1: spectrum -> out1 = A(p), out2 = B(p); whole blocks of 512^3
+// y0, nyr: the tiles of the y rows [y0, y0 + nyr) only (nyr < 0: all) -- csrc/sfftz.hip cuts a solve into groups of y rows
+// so that a group's exchange runs beside the next group's pair
 int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done)
+                          const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr)
 {
     *done = false;
     if (mode < 0 || mode > 1 || b->ny != zf.ny || !x3d_zfirst_pairs_ok(b, ta, tb)) return 0;
+    if (nyr < 0) { y0 = 0; nyr = b->ny; }
+    X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= b->ny, "tds_pair (z-first): rows [%d, %d) of %d", y0, y0 + nyr, b->ny);
+    if (nyr == 0) { *done = true; return 0; }
     const size_t lds = sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16, ntiles = ntx * b->ny;
+    const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = ntiles > cap ? cap : ntiles;
@@ -1733,7 +1738,7 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, 
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_>));                                       \
         hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
-                           out2, in1, in2, xop_of(ta), xop_of(tb), ntx, 0, ntiles, pxy, (long)b->nxp, th, 0, zf); \
+                           out2, in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, pxy, (long)b->nxp, th, 0, zf); \
     } while (0)
     static int uni_on = -1;
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }

@@ -77,8 +77,9 @@ __global__ void __launch_bounds__(512)
 // forms in k_ytile_tds_pair
 template <bool FWD>
 __global__ void __launch_bounds__(1024)
-    k_ztile_fft(double *__restrict__ f, ZfArg zf, int ntx, int ntiles, long prow, long pplane)
+    k_ztile_fft(double *__restrict__ f, ZfArg zf, int ntx, int tile0, int ntiles, long prow, long pplane)
 {
+    ntiles += tile0;  // tiles [tile0, tile0 + ntiles): a range of y rows (csrc/sfftz.hip)
     extern __shared__ double zarea[];  // ZF_AREA_DOUBLES + 256 twiddles
     constexpr int TP = 516;
     double2 *__restrict__ tws = reinterpret_cast<double2 *>(zarea + ZF_AREA_DOUBLES);
@@ -88,9 +89,9 @@ __global__ void __launch_bounds__(1024)
     const long kzs = (long)zf.ny * zf.px;
     __syncthreads();
     ZfRows v{};
-    if (!FWD && (int)blockIdx.x < ntiles)
-        v = zf_inverse_load(zf.c + (long)(blockIdx.x / ntx) * zf.px + (blockIdx.x % ntx) * 16, kzs);
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    if (!FWD && tile0 + (int)blockIdx.x < ntiles)
+        v = zf_inverse_load(zf.c + (long)((tile0 + blockIdx.x) / ntx) * zf.px + ((tile0 + blockIdx.x) % ntx) * 16, kzs);
+    for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
         double2 *__restrict__ crow = zf.c + (long)(tl / ntx) * zf.px + (tl % ntx) * 16;
         if (FWD) {
@@ -192,19 +193,22 @@ extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
 }
 
 // the z transform of a block's field, tile by tile (also for csrc/sfftz.hip)
-int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd)
+int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd, int y0, int nyr)
 {
     X3D_REQUIRE(b->nz == 512 && b->nx % 16 == 0 && b->ny == zf.ny, "x3d_ztile_fft_run: 512-row z pencils");
-    const int ntx = b->nx / 16, ntiles = ntx * b->ny;
+    if (nyr < 0) { y0 = 0; nyr = b->ny; }
+    X3D_REQUIRE(y0 >= 0 && y0 + nyr <= b->ny, "x3d_ztile_fft_run: rows [%d, %d) of %d", y0, y0 + nyr, b->ny);
+    if (nyr == 0) return 0;
+    const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
     const size_t lds = sizeof(double) * (ZF_AREA_DOUBLES + 512);
     const long pxy = (long)b->nxp * b->nyp;
     ProfScope ps(b, X3D_K_FFT, 3);
     if (fwd) {
         X3D_LDS_OPTIN(b, (k_ztile_fft<true>));
-        hipLaunchKernelGGL((k_ztile_fft<true>), dim3(512), dim3(1024), lds, b->stream, f, zf, ntx, ntiles, pxy, (long)b->nxp);
+        hipLaunchKernelGGL((k_ztile_fft<true>), dim3(ntiles < 512 ? ntiles : 512), dim3(1024), lds, b->stream, f, zf, ntx, tile0, ntiles, pxy, (long)b->nxp);
     } else {
         X3D_LDS_OPTIN(b, (k_ztile_fft<false>));
-        hipLaunchKernelGGL((k_ztile_fft<false>), dim3(512), dim3(1024), lds, b->stream, f, zf, ntx, ntiles, pxy, (long)b->nxp);
+        hipLaunchKernelGGL((k_ztile_fft<false>), dim3(ntiles < 512 ? ntiles : 512), dim3(1024), lds, b->stream, f, zf, ntx, tile0, ntiles, pxy, (long)b->nxp);
     }
     X3D_HIP(hipGetLastError());
     return 0;
@@ -216,7 +220,7 @@ static int ztile(x3d_poisson *p, double *f, bool fwd)
     bool ok = false;
     if (int rc = x3d_zfirst_arg(p, &zf, &ok)) return rc;
     X3D_REQUIRE(ok, "x3d_poisson_zfirst: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
-    return x3d_ztile_fft_run(p->b, f, zf, fwd);
+    return x3d_ztile_fft_run(p->b, f, zf, fwd, 0, -1);
 }
 
 // stand-alone ends of the z-first solve: f (cell data of a block) -> C, and back

@@ -37,6 +37,16 @@ class _Pending:
         self.works = []
 
 
+class _PendingEvent:
+    """an exchange that is complete when `event` (recorded on the communication stream behind it) is"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class Comm:
     # verdict of the overlapped path's self-check per (group, backend, self-via-RCCL): the check is collective and
     # allocates 512 MiB -- every Comm object of a process after the first reuses the verdict (all ranks construct their
@@ -65,6 +75,16 @@ class Comm:
         # to self in one RCCL group: the group sizes, chunk lengths and part pipelining of an N-rank all-to-all run through
         # RCCL on a one-GPU box (the numbers mean nothing: tests compare the two transports bit for bit)
         self.fake_peers = self.size == 1 and os.environ.get("X3D_COMM_FAKE_PEERS") == "1"
+        # X3D_COMM_EMULATE_LINKS=<GB/s per link and direction> (world size 1, exchanges through RCCL to self): every
+        # exchange additionally holds its stream for the time the message would spend on xGMI links of that rate -- an
+        # all-to-all among n peers sends 1 / n of its bytes over each of n - 1 links at once (bytes / n / rate), a
+        # neighbour exchange its two messages over two links at once (largest message / rate) -- so that a one-GPU box
+        # shows which part of the transfers a schedule hides (bench.py --virtual-ranks; a timeline, not a measurement of links)
+        self.link_rate = None
+        e = os.environ.get("X3D_COMM_EMULATE_LINKS")
+        if e and self.size == 1:
+            self.link_rate = float(e) * 1e9
+            self._cycles_per_s = None
         self._checked = self.host_staged or not self.enabled or not self.overlap or \
             (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
@@ -116,7 +136,7 @@ class Comm:
             e0.record()
             self.timed = False
             try:
-                self._exchange(sends, recvs)
+                self._exchange(sends, recvs, kind)
             finally:
                 self.timed = True
             e1.record()
@@ -136,11 +156,36 @@ class Comm:
         ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if self.link_rate:
+            self._link_hold(sends, kind)
 
     def _comm_stream(self):
         if self._cstream is None:
             self._cstream = torch.cuda.Stream()
         return self._cstream
+
+    def _link_hold(self, sends, kind):
+        """emulated link time of this exchange, spent on the current stream (X3D_COMM_EMULATE_LINKS)"""
+        if self._cycles_per_s is None:  # calibrate torch.cuda._sleep's unit once
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1000)
+            torch.cuda.synchronize()
+            e0.record()
+            torch.cuda._sleep(20_000_000)
+            e1.record()
+            torch.cuda.synchronize()
+            self._cycles_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+        sizes = [t.numel() * t.element_size() for t, _ in sends]
+        if not sizes:
+            return
+        if kind == "alltoall":
+            n = len(sizes)
+            sec = (sum(sizes) / n) / self.link_rate if n > 1 else 0.0  # (n chunks incl. the one a rank keeps)
+        else:
+            half = len(sizes) // 2 or 1  # [(to prev, to next)] x pairs: the two directions use two links at once
+            sec = max(sum(sizes[0::2]), sum(sizes[1::2])) / self.link_rate if half else 0.0
+        if sec > 0.0:
+            torch.cuda._sleep(int(sec * self._cycles_per_s))
 
     def _start(self, sends, recvs, kind="sendrecv"):
         """post a group of point-to-point transfers behind everything queued on the current stream, on the
@@ -162,12 +207,19 @@ class Comm:
             ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
             ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
             works = dist.batch_isend_irecv(ops)
-            if self.timed:  # (the communication stream waits for RCCL's work; the compute stream still waits by itself)
+            if self.timed or self.link_rate:  # (the communication stream waits for RCCL's work; the compute stream still waits by itself)
                 for w in works:
                     w.wait()
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                self._note(kind, sends, e0, e1)
+                if self.link_rate:
+                    self._link_hold(sends, kind)
+                if self.timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._note(kind, sends, e0, e1)
+            if self.link_rate:
+                done = torch.cuda.Event()
+                done.record()
+                return _PendingEvent(done)
         return _Pending(works)
 
     def self_check(self):
@@ -225,6 +277,8 @@ class Comm:
         """pairs: list of (send_s, send_e, recv_s, recv_e) tensors.
         send_s -> prev (arrives in prev's recv_e), send_e -> next (arrives in
         next's recv_s)."""
+        if self.fake_peers:
+            prev = nxt = self.rank
         if prev == self.rank and nxt == self.rank and not self.self_via_nccl:
             for send_s, send_e, recv_s, recv_e in pairs:  # nproc == 1 branch, sendrecv.f90:20-22
                 recv_s.copy_(send_e)
@@ -240,6 +294,8 @@ class Comm:
 
     def isendrecv(self, pairs, prev, nxt):
         """sendrecv started now and completed by the returned handle's wait()"""
+        if self.fake_peers:
+            prev = nxt = self.rank
         if prev == self.rank and nxt == self.rank and not self.self_via_nccl:
             self.sendrecv(pairs, prev, nxt)
             return DONE

@@ -818,6 +818,14 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         self.rbuf = self.sbuf if alias else torch.zeros(2 * nbuf, dtype=torch.float64, device=backend.device)
         self.peers = [r for r in range(self.py)]  # rank = ry (x and z undivided)
         self.poisson = self.poisson_000
+        # round 5: groups of local y rows x groups of kz planes (csrc/sfftz.hip, "BLOCKS"): X3D_SLAB_YPARTS groups of
+        # rows (default 4 on several ranks, 1 in a single process; 1 = rounds 3-4's schedule, kz groups only)
+        yp = int(os.environ.get("X3D_SLAB_YPARTS", "0"))
+        self.yparts = yp if yp > 0 else (4 if self.py > 1 else 1)
+        if 512 % self.yparts:
+            raise X3dError("X3D_SLAB_YPARTS must divide 512")
+        self.rows = [(a * (512 // self.yparts), 512 // self.yparts) for a in range(self.yparts)]
+        self.n_pipelined = 0  # solves through zfirst_solve_pipelined (tests)
 
     def __del__(self):
         try:
@@ -830,9 +838,70 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         return self.backend.comm.ialltoall(sbuf, rbuf, 2 * 512 * kzc * self.xs, self.peers,
                                            send_off=2 * self.kz0[m] * 512 * 512, recv_off=2 * self.kz0[m] * 512 * 512)
 
+    def _xchg_block(self, a, m, sbuf, rbuf):
+        """rows group a of kz group m: the rows' piece of every (part, peer) chunk is contiguous"""
+        kzc = self.kz0[m + 1] - self.kz0[m]
+        y0, nyr = self.rows[a]
+        off = 2 * (self.kz0[m] * 512 * 512 + y0 * kzc * self.xs)
+        return self.backend.comm.ialltoall(sbuf, rbuf, 2 * nyr * kzc * self.xs, self.peers, send_off=off,
+                                           send_stride=2 * 512 * kzc * self.xs, recv_off=off,
+                                           recv_stride=2 * 512 * kzc * self.xs)
+
+    def _pipelined(self, front, behind):
+        """the solve between the two z stages in blocks of (rows group a) x (kz group m):
+        front(a) -- rows group a of the spectrum is written (the divergence's z pair, or the z transform of a field) --
+        then its x transforms, and its blocks leave while front(a + 1) runs; the y stage of kz group m runs when the last
+        rows group's block of m is in (beside the transfers of the kz groups behind it) and its blocks go back at once;
+        rows group a's x transforms and behind(a) -- the gradient's z pair, or the inverse z transform -- run when its
+        last kz block is back, beside the transfers of the rows groups behind it"""
+        lib, h, sb, rb = self.backend.lib, self.h, self.sbuf, self.rbuf
+        A, K = self.yparts, self.parts
+        there = [[None] * K for _ in range(A)]
+        for a, (y0, nyr) in enumerate(self.rows):
+            front(a, y0, nyr)
+            for m in range(K):
+                _lib.check(lib.x3d_sfftz_x_forward_rows(h, sb.data_ptr(), m, y0, nyr))
+                there[a][m] = self._xchg_block(a, m, sb, rb)
+        back = [[None] * K for _ in range(A)]
+        for m in range(K):
+            for a in range(A):
+                there[a][m].wait()
+            _lib.check(lib.x3d_sfftz_y_stage(h, rb.data_ptr(), m, 0))
+            for a in range(A):
+                back[a][m] = self._xchg_block(a, m, rb, sb)
+        for a, (y0, nyr) in enumerate(self.rows):
+            for m in range(K):
+                back[a][m].wait()
+                _lib.check(lib.x3d_sfftz_x_backward_rows(h, sb.data_ptr(), m, y0, nyr))
+            behind(a, y0, nyr)
+        self.n_pipelined += 1
+
     # ---- the z-first interface of the fused driver (HipBackend.tds_pair_zfirst / Solver.pressure_correction_fused)
     def zfirst_ok(self):
         return not getattr(self.backend, "lazy", False)
+
+    def zfirst_solve_pipelined(self, in1, in2, out1, out2, t_a0, t_b0, t_a1, t_b1):
+        """div = A0(in1) + B0(in2) along z ; p = poisson_000(div) ; out1 = A1(p), out2 = B1(p) along z with the z pairs, the
+        x transforms and the exchanges cut into rows groups (_pipelined); False: these operators are not served by the
+        z-transforming pair kernels (nothing was done)"""
+        lib, h = self.backend.lib, self.h
+        if self.yparts <= 1 or not self.backend.zfirst_pairs_ok(t_a0, t_b0) or not self.backend.zfirst_pairs_ok(t_a1, t_b1):
+            return False
+        flag = ctypes.c_int(0)
+
+        def front(a, y0, nyr):
+            _lib.check(lib.x3d_sfftz_tds_pair_rows(h, 0, None, None, in1.ptr, in2.ptr, t_a0.handle, t_b0.handle, y0, nyr,
+                                                   ctypes.byref(flag)))
+            if not flag.value:
+                raise X3dError("y-slab solve: the z pair declined operators its probe had accepted")
+
+        def behind(a, y0, nyr):
+            _lib.check(lib.x3d_sfftz_tds_pair_rows(h, 1, out1.ptr, out2.ptr, None, None, t_a1.handle, t_b1.handle, y0, nyr,
+                                                   ctypes.byref(flag)))
+            if not flag.value:
+                raise X3dError("y-slab solve: the z pair declined operators its probe had accepted")
+        self._pipelined(front, behind)
+        return True
 
     def zfirst_pair(self, mode, out1, out2, in1, in2, t_a, t_b):
         flag = ctypes.c_int(0)
@@ -887,9 +956,14 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
 
     def poisson_000(self, f, temp=None):
         """poisson_000 (src/poisson_fft.f90:216-226) on a field in memory"""
-        _lib.check(self.backend.lib.x3d_sfftz_z(self.h, f.ptr, 0))
+        lib, h = self.backend.lib, self.h
+        if self.yparts > 1:  # the z transforms of a field in memory cut into rows groups like the z pairs
+            self._pipelined(lambda a, y0, nyr: _lib.check(lib.x3d_sfftz_z_rows(h, f.ptr, 0, y0, nyr)),
+                            lambda a, y0, nyr: _lib.check(lib.x3d_sfftz_z_rows(h, f.ptr, 1, y0, nyr)))
+            return
+        _lib.check(lib.x3d_sfftz_z(h, f.ptr, 0))
         self.zfirst_middle()
-        _lib.check(self.backend.lib.x3d_sfftz_z(self.h, f.ptr, 1))
+        _lib.check(lib.x3d_sfftz_z(h, f.ptr, 1))
 
     def interleaved_rows(self):
         return 0

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 from .common import (BC_DIRICHLET, BC_NEUMANN, CELL, DIR_C, DIR_X, DIR_Y, DIR_Z, RDR_C2Z, RDR_X2Y, RDR_X2Z,
-                     RDR_Z2C, VERT, Y_FACE, X3dError)
+                     RDR_Y2Z, RDR_Z2C, RDR_Z2X, VERT, Y_FACE, X3dError)
 from .tdsops import Dirps
 from .time_integrator import TimeIntegrator
 from .vector_calculus import VectorCalculus
@@ -114,7 +114,14 @@ class Solver:
         self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
         backend.before_read.append(self.flush_grad)
-        self.transeq = self.transeq_fused if self.fused else self.transeq_default
+        # src/solver.f90:206-210: lowmem_transeq selects the variant that gives the x-oriented velocity blocks back to the
+        # pool while y and z are worked on.  The fused driver never makes y / z copies (one device layout for every
+        # DIR tag): it already holds fewer blocks than transeq_lowmem, the flag changes nothing there.
+        self.lowmem_transeq = bool(getattr(cfg, "lowmem_transeq", False))
+        if self.fused:
+            self.transeq = self.transeq_fused
+        else:
+            self.transeq = self.transeq_lowmem if self.lowmem_transeq else self.transeq_default
         if self.fused:
             self.pressure_correction = self.pressure_correction_fused
 
@@ -149,6 +156,52 @@ class Solver:
         for f in (du_z, dv_z, dw_z):
             al.release_block(f)
         if self.nspecies > 0:  # :384-387
+            self.transeq_species(rhs[3:], variables)
+
+    # ---- src/solver.f90:391-505
+    def transeq_lowmem(self, rhs, variables):
+        """low-memory variant: u, v, w go back to the pool once their y copies exist, the y copies once the z copies
+        exist, and the x-oriented velocity is rebuilt from the z copies at the end (RDR_Z2X) -- `variables[0:3]` and
+        self.u / v / w are REBOUND to the new blocks, as the reference rebinds variables(i)%ptr and self%u (:492-497)"""
+        b, al = self.backend, self.backend.allocator
+        du, dv, dw = rhs[:3]
+        u, v, w = variables[:3]
+        b.transeq_x(du, dv, dw, u, v, w, self.nu, self.xdirps)
+        u_y, v_y, w_y = (al.get_block(DIR_Y) for _ in range(3))
+        b.reorder(u_y, u, RDR_X2Y)
+        b.reorder(v_y, v, RDR_X2Y)
+        b.reorder(w_y, w, RDR_X2Y)
+        for f in (u, v, w):  # "now release the x-directional fields for saving memory"
+            al.release_block(f)
+        du_y, dv_y, dw_y = (al.get_block(DIR_Y) for _ in range(3))
+        b.transeq_y(du_y, dv_y, dw_y, u_y, v_y, w_y, self.nu, self.ydirps)
+        b.sum_yintox(du, du_y)
+        b.sum_yintox(dv, dv_y)
+        b.sum_yintox(dw, dw_y)
+        for f in (du_y, dv_y, dw_y):
+            al.release_block(f)
+        u_z, v_z, w_z = (al.get_block(DIR_Z) for _ in range(3))
+        b.reorder(u_z, u_y, RDR_Y2Z)
+        b.reorder(v_z, v_y, RDR_Y2Z)
+        b.reorder(w_z, w_y, RDR_Y2Z)
+        for f in (u_y, v_y, w_y):
+            al.release_block(f)
+        du_z, dv_z, dw_z = (al.get_block(DIR_Z) for _ in range(3))
+        b.transeq_z(du_z, dv_z, dw_z, u_z, v_z, w_z, self.nu, self.zdirps)
+        b.sum_zintox(du, du_z)
+        b.sum_zintox(dv, dv_z)
+        b.sum_zintox(dw, dw_z)
+        for f in (du_z, dv_z, dw_z):
+            al.release_block(f)
+        u, v, w = (al.get_block(DIR_X) for _ in range(3))
+        b.reorder(u, u_z, RDR_Z2X)
+        b.reorder(v, v_z, RDR_Z2X)
+        b.reorder(w, w_z, RDR_Z2X)
+        for f in (u_z, v_z, w_z):
+            al.release_block(f)
+        variables[0], variables[1], variables[2] = u, v, w
+        self.u, self.v, self.w = u, v, w
+        if self.nspecies > 0:  # :499-502
             self.transeq_species(rhs[3:], variables)
 
     # ---- src/solver.f90:507-601
@@ -388,6 +441,12 @@ class Solver:
         """div = interpl_z(a1) + stagder_z(a2) ; p = poisson(div) ; t2 = interpl_z(p), t3 = stagder_z(p) with the z
         transforms of the 000 solve on the tiles of the two z pairs; False: not served for these operators, nothing done"""
         b, z = self.backend, self.zdirps
+        pipe = getattr(b.poisson_fft, "zfirst_solve_pipelined", None)
+        if pipe is not None and not b._decomposed(DIR_Z) and \
+                pipe(a1, a2, t2, t3, z.interpl_v2p, z.stagder_v2p, z.interpl_p2v, z.stagder_p2v):
+            # y slabs: the z pairs, the x transforms and the all-to-alls in blocks of rows x kz planes (csrc/sfftz.hip)
+            self.n_zfirst += 1
+            return True
         if not b.tds_pair_zfirst(0, None, None, a1, a2, z.interpl_v2p, z.stagder_v2p):
             return False
         b.poisson_fft.zfirst_middle()
