@@ -621,6 +621,10 @@ def main():
                        # (x3d2_amd/parallel.py, Comm.self_check; None: not exercised, e.g. one rank or host-staged)
                        "overlap_self_check": getattr(comm, "self_check_result", None),
                        "overlap_self_check_error": getattr(comm, "self_check_error", None),
+                   # (ms of two 2 ms spins: one on the candidate communication stream + one on the compute stream, both on
+                   # the compute stream) per candidate: equal = the candidate shares the compute stream's hardware queue
+                   # and was passed over (parallel.Comm._pick_stream)
+                   "comm_stream_probe_ms": getattr(comm, "stream_probe", None),
                        # N > 1: which decomposition ran, and what its one-step validation (and any it replaced) showed
                        "decomposition": decomp_name if args.case == "tgv" else "slabs",
                        "decomposition_requested": requested,

@@ -65,6 +65,11 @@ int x3d_backend_create_like(x3d_backend **out, const x3d_backend *like, const in
  * 2 -> launches of the single-pass HALO forms of the tile kernels (decomposed directions) */
 long x3d_backend_counter(const x3d_backend *b, int which);
 int x3d_backend_set_stream(x3d_backend *b, void *stream);
+/* round 5: CUs the persistent kernels (one workgroup per CU for a whole launch: the tile and scan kernels) leave FREE, so that
+ * kernels of other streams -- RCCL's send / recv kernels of an exchange meant to run beside them -- find a CU to start on
+ * before the launch ends.  0 (default): none; a multi-rank driver sets 8 (one per XCD).  The reference's GPU backend runs
+ * everything on the default stream and synchronises before MPI (src/backend/cuda/sendrecv.f90:28): nothing to reserve for. */
+int x3d_backend_set_comm_reserve(x3d_backend *b, int ncus);
 size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
 int x3d_padded_dims(const x3d_backend *b, int dims_out[3]); /* get_padded_dims(DIR_C) */
 int x3d_device_sync(x3d_backend *b);

@@ -53,6 +53,17 @@ class HipBackend:
         _lib.check(self.lib.x3d_padded_dims(h, pd))
         self.padded_dims = tuple(pd)
         self.allocator = Allocator(self.nblock, self.device)
+        # several ranks with exchanges that are meant to run BESIDE kernels (the overlapped path of parallel.Comm): the
+        # persistent tile / scan kernels can leave X3D_COMM_RESERVE_CUS CUs free for the kernels of other streams
+        # (csrc/common.h, comm_reserve)
+        c = self.comm
+        multi = (c.size > 1 and not c.host_staged) or getattr(c, "self_via_nccl", False)
+        # (default 0: with the emulated exchanges of bench.py --virtual-ranks -- one-wave kernels and device copies on the
+        #  communication stream -- 8 or 16 reserved CUs changed nothing, profiles/r05_yslab_pipeline_timeline.txt; kept as
+        #  a switch for the first run over real links, where RCCL's kernels want more room)
+        del multi
+        self.comm_reserve = int(os.environ.get("X3D_COMM_RESERVE_CUS", "0"))
+        _lib.check(self.lib.x3d_backend_set_comm_reserve(h, self.comm_reserve))
         self.lazy = (os.environ.get("X3D_LAZY") == "1") if lazy is None else bool(lazy)
         if self.lazy:
             # several ranks (round 4): the distributed entry points flush the queue and run at once on the buffers that

@@ -138,6 +138,16 @@ extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)
     return 0;
 }
 
+// CUs the persistent kernels leave free for the kernels of other streams (RCCL's send / recv kernels of an exchange that
+// is to run beside them; common.h, comm_reserve): 0 = none (one rank), a multi-rank driver sets 8 (one per XCD)
+extern "C" int x3d_backend_set_comm_reserve(x3d_backend *b, int ncus)
+{
+    X3D_REQUIRE(b, "null backend");
+    X3D_REQUIRE(ncus >= 0 && ncus < X3D_NCU / 2, "x3d_backend_set_comm_reserve: 0 .. %d CUs", X3D_NCU / 2 - 1);
+    b->comm_reserve = ncus;
+    return 0;
+}
+
 extern "C" size_t x3d_block_elems(const x3d_backend *b) { return b ? b->nblock : 0; }
 
 extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])

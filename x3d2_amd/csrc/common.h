@@ -122,7 +122,20 @@ struct x3d_backend {
     int pair_yperm;          // > 0 during x3d_tds_solve_pair_yperm: the z pair kernels permute that many y rows
     void *lds_optin;        // kernels of this backend's device whose dynamic-LDS limit has been raised (backend.hip)
     struct x3d_lazy *lazy;  // deferred execution of the op-granular call sequence (lazy.hip), null until used
+    // round 5: CUs the PERSISTENT kernels leave free (x3d_backend_set_comm_reserve).  The tile / scan kernels launch one
+    // workgroup per CU that stays for the whole launch and owns all of its CU's registers and LDS: a kernel of another
+    // stream -- RCCL's send / recv kernels of an exchange meant to run beside them -- finds no CU to start on until the
+    // launch ENDS (measured with a one-wave kernel on the communication stream: none of its time hidden,
+    // profiles/r05_yslab_pipeline_timeline.txt).  With fewer workgroups than CUs some CUs stay empty and the exchange
+    // starts at once; the kernels are memory-bound, 248 CUs stream what 256 do.  0 on one rank.
+    int comm_reserve;
 };
+#define X3D_NCU 256  // MI355X
+static inline int x3d_persistent_blocks(const x3d_backend *b, long want)
+{
+    const long cap = X3D_NCU - (b->comm_reserve > 0 && b->comm_reserve < X3D_NCU / 2 ? b->comm_reserve : 0);
+    return (int)(want > cap ? cap : want);
+}
 
 // ---- deferred execution (lazy.hip).  While the mode is on, block addresses are HANDLES: an entry point either records
 // its call (x3d_lazy_active + x3d_lazy_<op>), or runs at once on the buffers that hold the handles' data

@@ -1487,7 +1487,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
     static int p2 = -1;
     if (p2 < 0) { const char *e = getenv("X3D_XSCAN_P1"); p2 = (e && e[0] == '1') ? 0 : 1; }  // same-box A/B: 0.61 -> 0.59 ms
     if (p2 && fast && np % 2 == 0) {
-        const int blocks2 = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
+        const int blocks2 = x3d_persistent_blocks(b, (np / 2 + 7) / 8);
 #define LP2(Q_, S_, A_, N_)                                                                                    \
         do {                                                                                                   \
             X3D_LDS_OPTIN(b, (k_xscan_transeq2<Q_, S_, A_, N_>));                                              \
@@ -1548,7 +1548,7 @@ static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const doub
     // y: rows nxp apart, one tile row per z plane; z: rows nxp * nyp apart, one tile row per y
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
-    const int blocks = ntiles > 256 ? 256 : ntiles;
+    const int blocks = x3d_persistent_blocks(b, ntiles);
     if (epi) {
         // one device slot is enough: copy and kernel are ordered on the backend's stream
         X3D_HIP(hipMemcpyAsync(b->epi_dev, epi, sizeof(TileEpi), hipMemcpyHostToDevice, b->stream));
@@ -1679,7 +1679,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
-    const int blocks = ntiles > cap ? cap : ntiles;
+    const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
 #define GO(Q_, M_, N_, H_, U_)                                                                                  \
@@ -1731,7 +1731,7 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, 
     const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
-    const int blocks = ntiles > cap ? cap : ntiles;
+    const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
 #define GO(M_, N_, U_)                                                                                          \
@@ -1808,7 +1808,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     int tile0, ntiles;
     tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
     if (ntiles <= 0) { *done = true; return 0; }
-    const int blocks = ntiles > 256 ? 256 : ntiles;
+    const int blocks = x3d_persistent_blocks(b, ntiles);
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
@@ -1870,7 +1870,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     const size_t lds = sizeof(double) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd) && (!upd || (stencil_narrow(op_s) && stencil_narrow(op_i)));
-    const int blocks = (np / 2 + 7) / 8 > 256 ? 256 : (np / 2 + 7) / 8;
+    const int blocks = x3d_persistent_blocks(b, (np / 2 + 7) / 8);
     XUpd xu{};
     if (upd) { xu.g[0] = upd_g[0]; xu.g[1] = upd_g[1]; xu.g[2] = upd_g[2]; xu.scale = scale; }
     xu.omega = omega; xu.ushift = ushift;

@@ -379,7 +379,7 @@ int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int np = b->ny * b->nz;
     const size_t lds = sizeof(double) * (2 * LTC_N(WQ) + 8 * WSTRIP);
-    const int blocks = (np + 7) / 8 > 256 ? 256 : (np + 7) / 8;
+    const int blocks = x3d_persistent_blocks(b, (np + 7) / 8);
     const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd);
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);

@@ -371,7 +371,7 @@ static GenLaunch gen_launch(const x3d_backend *b, int dir)
     GenLaunch g;
     g.ntx = b->nx / 16;
     g.ntiles = g.ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
-    g.blocks = g.ntiles > 256 ? 256 : g.ntiles;
+    g.blocks = x3d_persistent_blocks(b, g.ntiles);
     g.nrow = dir == X3D_DIR_Y ? b->ny : b->nz;
     g.rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy;
     g.ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;

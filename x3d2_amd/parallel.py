@@ -64,6 +64,8 @@ class Comm:
         # depend on them (X3D_NO_OVERLAP=1: every exchange is ordered on the compute stream, for A/B runs)
         self.overlap = os.environ.get("X3D_NO_OVERLAP") != "1"
         self._cstream = None
+        self._cycles_per_s = None
+        self.stream_probe = None  # ms of each candidate's probe (_pick_stream), None until a stream was needed
         # the overlapped path is verified against the ordered one on first use (self_check below): a transport
         # whose stream semantics differ from what _start assumes costs the overlap, not the results
         # X3D_COMM_SELF_VIA_NCCL=1 (one GPU, world size 1, X3D_EMULATE_DECOMP): exchanges with THIS rank go through
@@ -84,7 +86,12 @@ class Comm:
         e = os.environ.get("X3D_COMM_EMULATE_LINKS")
         if e and self.size == 1:
             self.link_rate = float(e) * 1e9
-            self._cycles_per_s = None
+            # with the links emulated a message to self moves as a device copy on the communication stream (RCCL's
+            # send / recv to self would add a second, real copy through its own kernels on top of the emulated link
+            # time); every group additionally holds the stream X3D_COMM_EMULATE_LATENCY_US (default 30: what one RCCL
+            # point-to-point group costs to launch on this pool, profiles/r05_*) -- the RCCL calls themselves stay under
+            # test in the bit-for-bit RCCL-to-self tests, which run without the emulation
+            self.link_latency = float(os.environ.get("X3D_COMM_EMULATE_LATENCY_US", "30")) * 1e-6
         self._checked = self.host_staged or not self.enabled or not self.overlap or \
             (self.size == 1 and not self.self_via_nccl)
         self.self_check_result = None
@@ -152,6 +159,11 @@ class Comm:
             for (dst, _), (src, _) in zip(recvs, r_host):
                 dst.copy_(src)
             return
+        if self.link_rate and all(p == self.rank for _, p in sends):
+            for (src, _), (dst, _) in zip(sends, recvs):  # (see _start_overlapped)
+                dst.copy_(src)
+            self._link_hold(sends, kind)
+            return
         ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
         ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
         for req in dist.batch_isend_irecv(ops):
@@ -161,12 +173,11 @@ class Comm:
 
     def _comm_stream(self):
         if self._cstream is None:
-            self._cstream = torch.cuda.Stream()
+            self._cstream = self._pick_stream()
         return self._cstream
 
-    def _link_hold(self, sends, kind):
-        """emulated link time of this exchange, spent on the current stream (X3D_COMM_EMULATE_LINKS)"""
-        if self._cycles_per_s is None:  # calibrate torch.cuda._sleep's unit once
+    def _sleep_cycles_per_s(self):
+        if getattr(self, "_cycles_per_s", None) is None:  # calibrate torch.cuda._sleep's unit once
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
@@ -175,6 +186,50 @@ class Comm:
             e1.record()
             torch.cuda.synchronize()
             self._cycles_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+        return self._cycles_per_s
+
+    def _pick_stream(self):
+        """a stream whose work really runs BESIDE the current stream's.  HIP maps streams onto a few hardware queues
+        (GPU_MAX_HW_QUEUES, 4 by default) round robin, and two streams that share a queue run strictly one after the
+        other: measured on the pool's boxes, one torch pool stream in about six shares the compute stream's queue and
+        hides NOTHING of what is posted on it (scratch/overlap_probe2.py, profiles/r05_stream_queues.txt; with it the
+        whole overlapped exchange path ran at the ordered path's speed).  So candidates are probed -- a 1 ms one-wave
+        spin on the candidate against one on the current stream: side by side they take 1 ms, on one queue 2 -- and a
+        colliding one is kept referenced (the pool then hands out the next) and passed over."""
+        import time
+        self.stream_probe = []
+        if os.environ.get("X3D_COMM_NO_STREAM_PROBE") == "1":
+            return torch.cuda.Stream()
+        n = int(2e-3 * self._sleep_cycles_per_s())
+
+        def two_spins(side):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if side is None:
+                torch.cuda._sleep(n)
+            else:
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(n)
+            torch.cuda._sleep(n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+        serial = two_spins(None)  # both on the current stream: what sharing a queue costs
+        self._colliding = []
+        s = None
+        for _ in range(6):  # (few candidates: every stream in use takes a hardware queue, and too many of them are time-sliced)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):  # a stream's first launch sets its queue up: not part of the measurement
+                torch.cuda._sleep(1000)
+            ms = two_spins(s)
+            self.stream_probe.append((round(ms, 2), round(serial, 2)))
+            if ms < 0.75 * serial:
+                return s
+            self._colliding.append(s)
+        return s
+
+    def _link_hold(self, sends, kind):
+        """emulated link time of this exchange, spent on the current stream (X3D_COMM_EMULATE_LINKS)"""
+        cps = self._sleep_cycles_per_s()
         sizes = [t.numel() * t.element_size() for t, _ in sends]
         if not sizes:
             return
@@ -184,8 +239,14 @@ class Comm:
         else:
             half = len(sizes) // 2 or 1  # [(to prev, to next)] x pairs: the two directions use two links at once
             sec = max(sum(sizes[0::2]), sum(sizes[1::2])) / self.link_rate if half else 0.0
+        sec += self.link_latency
+        # the message to self has just moved as a device copy on this stream; on a node the link transfer IS that copy
+        # (RCCL's kernels read and write HBM while the link carries the bytes): the two are not additive -- the hold is
+        # what the link adds beyond the copy, priced at 2.5 TB/s of payload (5 TB/s of read + write traffic, what the
+        # streaming kernels of this backend reach; its HBM traffic beside the compute kernels stays real)
+        sec -= sum(sizes) / 2.5e12
         if sec > 0.0:
-            torch.cuda._sleep(int(sec * self._cycles_per_s))
+            torch.cuda._sleep(int(sec * cps))
 
     def _start(self, sends, recvs, kind="sendrecv"):
         """post a group of point-to-point transfers behind everything queued on the current stream, on the
@@ -204,9 +265,14 @@ class Comm:
             if self.timed:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
-            ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
-            works = dist.batch_isend_irecv(ops)
+            if self.link_rate and all(p == self.rank for _, p in sends):
+                for (src, _), (dst, _) in zip(sends, recvs):  # (posting order pairs them: same peer, same position)
+                    dst.copy_(src)
+                works = []
+            else:
+                ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+                ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
+                works = dist.batch_isend_irecv(ops)
             if self.timed or self.link_rate:  # (the communication stream waits for RCCL's work; the compute stream still waits by itself)
                 for w in works:
                     w.wait()
@@ -343,6 +409,23 @@ class Comm:
             else:
                 sends.append((sendbuf[s0:s0 + count], peer))
                 recvs.append((recvbuf[r0:r0 + count], peer))
+        return self._start(sends, recvs, "alltoall")
+
+    def ialltoall_chunks(self, sendbuf, recvbuf, chunks, peers):
+        """several ialltoall parts in ONE group (one RCCL group launch): chunks = [(count, off, stride)], peer i gets /
+        delivers `count` elements at off + i * stride of both buffers for every chunk (the y-slab Poisson solver's rows
+        groups: a rows group's pieces of the kz groups' blocks are separate contiguous runs per peer)"""
+        sends, recvs = [], []
+        for count, off, stride in chunks:
+            for i, peer in enumerate(peers):
+                peer = self.rank if self.fake_peers else peer
+                o = off + i * stride
+                if peer == self.rank and not self.self_via_nccl:
+                    if recvbuf.data_ptr() != sendbuf.data_ptr():
+                        recvbuf[o:o + count].copy_(sendbuf[o:o + count])
+                else:
+                    sends.append((sendbuf[o:o + count], peer))
+                    recvs.append((recvbuf[o:o + count], peer))
         return self._start(sends, recvs, "alltoall")
 
     def ialltoallv(self, sendbuf, send_offs, send_counts, recvbuf, recv_offs, recv_counts, peers):

@@ -838,40 +838,55 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         return self.backend.comm.ialltoall(sbuf, rbuf, 2 * 512 * kzc * self.xs, self.peers,
                                            send_off=2 * self.kz0[m] * 512 * 512, recv_off=2 * self.kz0[m] * 512 * 512)
 
-    def _xchg_block(self, a, m, sbuf, rbuf):
-        """rows group a of kz group m: the rows' piece of every (part, peer) chunk is contiguous"""
-        kzc = self.kz0[m + 1] - self.kz0[m]
-        y0, nyr = self.rows[a]
-        off = 2 * (self.kz0[m] * 512 * 512 + y0 * kzc * self.xs)
-        return self.backend.comm.ialltoall(sbuf, rbuf, 2 * nyr * kzc * self.xs, self.peers, send_off=off,
-                                           send_stride=2 * 512 * kzc * self.xs, recv_off=off,
-                                           recv_stride=2 * 512 * kzc * self.xs)
+    def _group(self, blocks, sbuf, rbuf):
+        """ONE exchange group of the blocks [(y0, nyr, m)]: rows [y0, y0 + nyr) of kz group m -- the rows' piece of every
+        (part, peer) chunk is one contiguous run"""
+        chunks = []
+        for y0, nyr, m in blocks:
+            kzc = self.kz0[m + 1] - self.kz0[m]
+            chunks.append((2 * nyr * kzc * self.xs, 2 * (self.kz0[m] * 512 * 512 + y0 * kzc * self.xs),
+                           2 * 512 * kzc * self.xs))
+        return self.backend.comm.ialltoall_chunks(sbuf, rbuf, chunks, self.peers)
 
     def _pipelined(self, front, behind):
-        """the solve between the two z stages in blocks of (rows group a) x (kz group m):
+        """the solve between the two z stages, rows groups a = 0 .. A - 1 x kz groups m = 0 .. K - 1:
         front(a) -- rows group a of the spectrum is written (the divergence's z pair, or the z transform of a field) --
-        then its x transforms, and its blocks leave while front(a + 1) runs; the y stage of kz group m runs when the last
-        rows group's block of m is in (beside the transfers of the kz groups behind it) and its blocks go back at once;
-        rows group a's x transforms and behind(a) -- the gradient's z pair, or the inverse z transform -- run when its
-        last kz block is back, beside the transfers of the rows groups behind it"""
+        then its x transforms, and it leaves while front(a + 1) runs.  The y stage of kz group m needs m's planes of ALL
+        rows: the rows groups before the last travel whole (one group of K runs per peer), the last one kz group by kz
+        group, so that the y stage of m starts when (A - 1, m) is in, beside the transfers behind it.  Its result goes
+        back at once -- kz groups before the last whole, the last one rows group by rows group, so that rows group a's x
+        transforms and behind(a) (the gradient's z pair, or the inverse z transform) start when (a, K - 1) is back,
+        beside the transfers of the rows groups behind it.  2 (A + K - 1) exchange groups per solve (X3D_SLAB_SCHEDULE=
+        blocks: every (a, m) block its own group, 2 A K)."""
         lib, h, sb, rb = self.backend.lib, self.h, self.sbuf, self.rbuf
         A, K = self.yparts, self.parts
-        there = [[None] * K for _ in range(A)]
+        every = os.environ.get("X3D_SLAB_SCHEDULE") == "blocks"
+        there = []
         for a, (y0, nyr) in enumerate(self.rows):
             front(a, y0, nyr)
             for m in range(K):
                 _lib.check(lib.x3d_sfftz_x_forward_rows(h, sb.data_ptr(), m, y0, nyr))
-                there[a][m] = self._xchg_block(a, m, sb, rb)
-        back = [[None] * K for _ in range(A)]
+            if a < A - 1 and not every:
+                there.append((None, self._group([(y0, nyr, m) for m in range(K)], sb, rb)))
+            else:
+                there += [(m, self._group([(y0, nyr, m)], sb, rb)) for m in range(K)]
+        back = []
         for m in range(K):
-            for a in range(A):
-                there[a][m].wait()
+            for k, hnd in there:
+                if k is None or k == m:
+                    hnd.wait()
+            there = [(k, hnd) for k, hnd in there if not (k is None or k == m)]
             _lib.check(lib.x3d_sfftz_y_stage(h, rb.data_ptr(), m, 0))
-            for a in range(A):
-                back[a][m] = self._xchg_block(a, m, rb, sb)
+            if m < K - 1 and not every:
+                back.append((None, self._group([(0, 512, m)], rb, sb)))
+            else:
+                back += [(a, self._group([(y0, nyr, m)], rb, sb)) for a, (y0, nyr) in enumerate(self.rows)]
         for a, (y0, nyr) in enumerate(self.rows):
+            for k, hnd in back:
+                if k is None or k == a:
+                    hnd.wait()
+            back = [(k, hnd) for k, hnd in back if not (k is None or k == a)]
             for m in range(K):
-                back[a][m].wait()
                 _lib.check(lib.x3d_sfftz_x_backward_rows(h, sb.data_ptr(), m, y0, nyr))
             behind(a, y0, nyr)
         self.n_pipelined += 1
