@@ -202,6 +202,51 @@ def cpu_reference(n, iters, threads, nproc_dir=(1, 1, 1)):
             "seconds_per_step": t, "n": n}
 
 
+def live_traffic(kernel_substr, extra_args, timeout=240):
+    """HBM bytes per launch of the kernels whose name contains `kernel_substr`, measured NOW: two child runs of this
+    script (--pmc-child: warm-up + ONE step, nothing timed) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` --
+    separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes, with its gfx950 correction (FETCH_SIZE counts
+    64 B per 128-B request: x 2; both counters in KB).  The children are started from here as ordinary child processes
+    (the program itself follows `--`).  None (+ the reason) when rocprofv3 is not there or a pass fails: the caller then
+    falls back to the figure recorded in profiles/traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as wd:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(wd, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"] + extra_args
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                   timeout=timeout)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, "%s pass: %r" % (counter, e)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "%s pass failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "%s pass: no launch of %s in the counter file" % (counter, kernel_substr)
+            out[counter] = (sum(vals) / len(vals), len(vals))
+    fetch = out["FETCH_SIZE"][0] * 1024.0 * 2.0
+    write = out["WRITE_SIZE"][0] * 1024.0
+    return {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+            "launches_counted": out["FETCH_SIZE"][1],
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child runs of this command (1 step), KB -> B, "
+                   "FETCH x 2 (gfx950: 64 B counted per 128-B request, MI355X_MICROARCH.md)"}, None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes here, as FRESH children of a
     parent that has not touched the GPU (never re-exec a process that has), one per device, rendezvous on
@@ -265,6 +310,9 @@ def main():
                     help="threads of the port baseline (0: the usable CPUs and twice that are probed at 128^3, the fastest is used)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not measure roofline.traffic with two rocprofv3 --pmc child runs (use profiles/traffic.json)")
     ap.add_argument("--case", default="tgv", choices=["tgv", "channel"],
                     help="channel: BASELINE configs[4]-style wall-bounded case (1 GPU), dims from --dims")
     ap.add_argument("--dims", default="1024,257,512", help="channel vertex dims nx,ny,nz")
@@ -426,6 +474,13 @@ def main():
                             poisson="CG" if args.no_poisson else "FFT", fused=not args.op_granular, rotation=True,
                             omega_rot=0.12, n_rotate=5000, comm=comm, nproc_dir=nproc_dir, rank=rank,
                             lazy=args.lazy)
+    if args.pmc_child:  # (under rocprofv3 --pmc: a warm-up step and ONE counted step, nothing timed, nothing printed)
+        case.step(1)
+        case.step(2)
+        case.solver.backend.sync()
+        torch.cuda.synchronize()
+        return
+
     def measure(case, nproc_dir, dims, decomp_name):
         """W warm-up steps, K timed steps between barriers + device syncs (max over the ranks), one more step with every
         kernel class and the exchanges timed; returns the JSON object of this case on this decomposition"""
@@ -717,6 +772,28 @@ def main():
             best["other_shapes"] = [{"mpi_ranks": r["mpi_ranks"], "omp_threads_per_rank": r["omp_threads_per_rank"], "n": r["n"],
                                      "value": r["value"]} for r in refs if r is not best]
             out["cpu_baseline"]["reference_nopoisson"] = best
+    if (rank == 0 and args.gpus == 1 and not args.virtual_ranks and not args.no_live_traffic and not args.op_granular
+            and os.environ.get("X3D_BENCH_NO_LIVE_TRAFFIC") != "1"):
+        # roofline.traffic measured in THIS run: the dominant kernel's HBM bytes per launch from the PMC counters of two
+        # child runs of the same workload (one step each); falls back to the recorded figure if a pass fails
+        import gc
+        case = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        dom = "k_ygen_transeq3" if args.case == "channel" else "k_ytile_transeq3"
+        extra = ["--case", args.case, "--n", str(args.n), "--dims", args.dims, "--time-intg", args.time_intg]
+        if args.no_poisson:
+            extra.append("--no-poisson")
+        t0 = time.perf_counter()
+        live, why = live_traffic(dom, extra)
+        r = out["roofline"]
+        if live is not None:
+            r["traffic_recorded"] = {"bytes_per_launch": r.get("traffic"), "commit": r.get("traffic_measured_at_commit")}
+            r["traffic"] = live["bytes_per_launch"]
+            r["traffic_measured_at_commit"] = "this run"
+            r["traffic_live"] = dict(live, kernel=dom, seconds=time.perf_counter() - t0)
+        else:
+            r["traffic_live"] = {"failed": why, "seconds": time.perf_counter() - t0}
     if (rank == 0 and args.gpus == 1 and args.case == "tgv" and args.n == 512 and not args.no_poisson
             and not args.no_other_configs and not args.op_granular):
         # the other BASELINE configs one GPU holds, each in a fresh child process after this one has let go of its
@@ -733,8 +810,8 @@ def main():
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                                    "--no-cpu-baseline", "--no-other-configs"] + extra, capture_output=True, text=True,
-                                   timeout=300)
+                                    "--no-cpu-baseline", "--no-other-configs", "--no-live-traffic"] + extra, capture_output=True,
+                                   text=True, timeout=300)
                 o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                 others[key] = brief(o)
                 others[key]["kernel_ms"] = {k: v for k, v in o["kernel_ms"].items() if isinstance(v, dict) and v["launches"]}
