@@ -522,6 +522,8 @@ def main():
         dof_global = dims[0] * dims[1] * dims[2]
         dof_local = args.n ** 3 if args.case == "tgv" else dof_global // args.gpus
         value = dof_global * args.steps / elapsed
+        # (bytes per DoF below are SURVEY 8(d)'s FP64 figures; the FP32 flavour of the library moves half of them)
+        dofb = dof_local * (0.5 if os.environ.get("X3D_SINGLE_PREC") == "1" else 1.0)
 
         # ---- roofline of the dominant kernel class: one transport-equation
         # component = k_transeq_fwd + k_transeq_bwd (64 B/DoF for the three
@@ -551,8 +553,8 @@ def main():
             (nf, mf), (nb, mb) = per_dir_raw[d]
             if nf:
                 per_dir[name] = {"ms_per_component": (mf + mb) / nf,
-                                 "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dof_local / ((mf + mb) / nf * 1e-3) / 1e9,
-                                 "GB/s_at_48B_per_3_components": 16.0 * dof_local / ((mf + mb) / nf * 1e-3) / 1e9}
+                                 "GB/s_at_64B_per_3_components": (64.0 / 3.0) * dofb / ((mf + mb) / nf * 1e-3) / 1e9,
+                                 "GB/s_at_48B_per_3_components": 16.0 * dofb / ((mf + mb) / nf * 1e-3) / 1e9}
         # algorithmic bytes per launch.  SURVEY.md 8d's per-unit figures price every operation on its own: a transeq
         # component 24 B/DoF (16 when conv == u) = 64 B/DoF per direction, an accumulating tds_solve 24 B/DoF.  The fused
         # launches of this backend have a smaller compulsory traffic -- a three-in-one launch reads the advecting
@@ -561,12 +563,12 @@ def main():
         # being an input it reads anyway).  Headline `achieved` / `frac`: that compulsory traffic of what a launch
         # does; `achieved_survey_per_unit`: the per-operation figures (larger: the fusion removed re-reads).
         comps3 = min(3 * n_tq3, n_f)
-        rk_bytes = 8.0 * dof_local * rk_fused_passes  # RK stage done by a transeq launch
+        rk_bytes = 8.0 * dofb * rk_fused_passes  # RK stage done by a transeq launch
         n_fused = rk_fused_launches
-        total_floor = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0 + 48.0 * n_upd) * dof_local + rk_bytes
-        total_survey = (n_f * (64.0 / 3.0) + 72.0 * n_upd) * dof_local + rk_bytes
+        total_floor = ((n_f - comps3) * (64.0 / 3.0) + comps3 * 16.0 + 48.0 * n_upd) * dofb + rk_bytes
+        total_survey = (n_f * (64.0 / 3.0) + 72.0 * n_upd) * dofb + rk_bytes
         avg_ms = (ms_f + ms_b) / max(n_f, 1)
-        transeq_bytes = (64.0 / 3.0) * dof_local
+        transeq_bytes = (64.0 / 3.0) * dofb
         bytes_per_launch = total_floor / max(n_f, 1)  # per component
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
         achieved_survey = total_survey / max(n_f, 1) / (avg_ms * 1e-3) / 1e9 if n_f else 0.0
@@ -595,7 +597,7 @@ def main():
         if n_yz and n_tq3:
             launches = n_yz / 3.0
             d_ms = ms_yz / launches
-            d_bytes = 64.0 * dof_local
+            d_bytes = 64.0 * dofb
             d_ach = d_bytes / (d_ms * 1e-3) / 1e9
             if args.case == "tgv" and args.gpus == 1:
                 name = ("k_ytile_transeq3<%d,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
@@ -608,7 +610,7 @@ def main():
                         "stream around every launch, inside the timed region",
                         "algorithmic_bytes_per_launch": d_bytes, "bytes_convention": "SURVEY 8(d): transeq_{y,z} 64 B/DoF x DoF",
                         "achieved": d_ach, "frac": d_ach / HBM_PEAK_GBS,
-                        "frac_at_48B_fused_floor": 48.0 * dof_local / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "frac_at_48B_fused_floor": 48.0 * dofb / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         class_average = {"what": "average over the x, y and z launches of the transport-equation class; x launches that also "
                                  "apply the pending velocity correction are credited its 48 B/DoF",
                          "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
@@ -632,7 +634,7 @@ def main():
                     # (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time our
                     # transeq phase takes (reorders and sums are folded into the kernels here)
                     "tdsops_pass_GBs_survey_convention":
-                        432.0 * dof_local / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
+                        432.0 * dofb / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
 
         emu = None
         if args.virtual_ranks:
@@ -654,7 +656,8 @@ def main():
             "emulation": emu,
             "value": value, "unit": "DoF*steps/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if os.environ.get("X3D_SINGLE_PREC") == "1" else "f64",
+            "data": "synthetic",
             # results differ from the reference's OpenMP backend by FMA contraction and re-associated scans only: every
             # -m gpu parity test holds 1e-12 relative per operator (1e-11 on traces / full steps, 1e-10 on the stretched
             # 010 Poisson solve); the north star asks for 1e-6 on the enstrophy trace

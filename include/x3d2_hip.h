@@ -10,7 +10,7 @@
  * `bind(C)` interface block for these prototypes is shown in INTEGRATION.md.
  *
  * Conventions
- *  - plain pointers and sizes only; every `double *` named f/u/du/... is a
+ *  - plain pointers and sizes only; every `x3d_real *` named f/u/du/... is a
  *    DEVICE pointer to one field block of x3d_block_elems() doubles
  *    (the reference's allocator block, src/allocator.f90:64-93).
  *  - return value: 0 = ok, non-zero = error (message: x3d_last_error()).
@@ -35,6 +35,16 @@
 #define X3D2_HIP_H
 
 #include <stddef.h>
+
+/* The library's real kind: the reference's `dp` (src/common.f90:6-12: double precision, or single with -DSINGLE_PREC).
+ * libx3d2_hip.so is the FP64 build; libx3d2_hip_sp.so (make SP=1: every source compiled with -DX3D_SINGLE_PREC) is the
+ * same code on 4-byte reals -- fields, tables, scalars and FFTs.  A caller compiles against this header with the same
+ * macro as the library it links. */
+#ifdef X3D_SINGLE_PREC
+typedef float x3d_real;
+#else
+typedef double x3d_real;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -76,58 +86,58 @@ int x3d_device_sync(x3d_backend *b);
 
 /* block storage for callers without their own device allocator
  * (cuda_allocator_t%create_block, src/backend/cuda/allocator.f90:81-90) */
-int x3d_block_alloc(x3d_backend *b, double **out);
-int x3d_block_free(x3d_backend *b, double *p);
-int x3d_block_fill(x3d_backend *b, double *f, double c); /* field_t%fill, src/field.f90:47-55 */
+int x3d_block_alloc(x3d_backend *b, x3d_real **out);
+int x3d_block_free(x3d_backend *b, x3d_real *p);
+int x3d_block_fill(x3d_backend *b, x3d_real *f, x3d_real c); /* field_t%fill, src/field.f90:47-55 */
 /* exchange buffers (n doubles, zeroed) and host staging for callers whose MPI is not GPU-aware (the Fortran shim on
  * several ranks: sendrecv_fields through host memory, cf. src/backend/cuda/sendrecv.f90:13-42).  The copies are
  * ordered behind the kernels queued so far and complete on return. */
-int x3d_device_alloc(x3d_backend *b, double **out, long n);
-int x3d_device_free(x3d_backend *b, double *p);
-int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n);
-int x3d_copy_to_device(x3d_backend *b, double *dev, const double *host, long n);
+int x3d_device_alloc(x3d_backend *b, x3d_real **out, long n);
+int x3d_device_free(x3d_backend *b, x3d_real *p);
+int x3d_copy_to_host(x3d_backend *b, x3d_real *host, const x3d_real *dev, long n);
+int x3d_copy_to_device(x3d_backend *b, x3d_real *dev, const x3d_real *host, long n);
 /* device-to-device exchanges between the ranks of one node without a GPU-aware MPI (what src/backend/cuda/sendrecv.f90:13-42
  * gets from one): x3d_ipc_export = hipIpcGetMemHandle of a buffer of x3d_device_alloc (64 bytes, sent to the neighbours
  * once), x3d_ipc_open maps a neighbour's buffer, x3d_copy_device copies n doubles between own and mapped memory on the
  * backend's stream (asynchronous, ordered like a kernel).  x3d_device_count: the devices this process sees -- the main
  * program picks mod(nrank, ndevs) as src/xcompact.f90:57-60 does. */
 int x3d_device_count(int *n);
-int x3d_ipc_export(x3d_backend *b, const double *dev, unsigned char handle[64]);
-int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], double **dev);
-int x3d_ipc_close(x3d_backend *b, double *dev);
-int x3d_copy_device(x3d_backend *b, double *dst, const double *src, long n);
+int x3d_ipc_export(x3d_backend *b, const x3d_real *dev, unsigned char handle[64]);
+int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], x3d_real **dev);
+int x3d_ipc_close(x3d_backend *b, x3d_real *dev);
+int x3d_copy_device(x3d_backend *b, x3d_real *dst, const x3d_real *src, long n);
 
 /* ---- alloc_tdsops (src/backend/backend.f90:352-372): device copy of the
  * arrays the host-side factory tdsops_init (src/tdsops.f90:63-203) produced.
  * coeffs[9]; coeffs_s/coeffs_e[4*9] with row r (0..3) = coeffs_s(:, r+1);
  * dist_* have n_rhs entries, stretch* n_tds entries. */
 int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, int n_rhs, int move,
-                      int periodic, const double *coeffs, const double *coeffs_s,
-                      const double *coeffs_e, const double *dist_fw, const double *dist_bw,
-                      const double *dist_sa, const double *dist_sc, const double *dist_af,
-                      const double *stretch, const double *stretch_correct);
+                      int periodic, const x3d_real *coeffs, const x3d_real *coeffs_s,
+                      const x3d_real *coeffs_e, const x3d_real *dist_fw, const x3d_real *dist_bw,
+                      const x3d_real *dist_sa, const x3d_real *dist_sc, const x3d_real *dist_af,
+                      const x3d_real *stretch, const x3d_real *stretch_correct);
 int x3d_tdsops_destroy(x3d_tdsops *t);
 
 /* ---- tds_solve (src/backend/backend.f90:131-150; omp: src/backend/omp/backend.f90:340-391
  * + src/backend/omp/exec_dist.f90:16-65).
  * Local form: the pencil direction is not decomposed (nproc_dir(dir)==1), the
  * periodic wrap / reduced 2x2 system is closed on the device. */
-int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
+int x3d_tds_solve(x3d_backend *b, x3d_real *du, const x3d_real *u, const x3d_tdsops *t, int dir);
 /* fusion extension (not in base_backend_t): accumulate != 0 gives
  * du += scale * tds_solve(u); folds sum_{y,z}intox / vecadd into the solve */
-int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
-                      int accumulate, double scale);
+int x3d_tds_solve_acc(x3d_backend *b, x3d_real *du, const x3d_real *u, const x3d_tdsops *t, int dir,
+                      int accumulate, x3d_real scale);
 
 /* fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
  *   mode 0: out1 = A(in1) + B(in2) (out2 unused)      mode 1: out1 = A(in1), out2 = B(in1) (in2 unused)
  * equal to x3d_tds_solve / x3d_tds_solve_acc issued one after the other; one kernel where the pencils allow. */
-int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
+                       const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
 /* fusion extension for the 010 Poisson solve: the z pair next to the solver interleaves the y rows the way
  * enforce_periodicity_y / undo_periodicity_y do (src/backend/cuda/kernels/spectral_processing.f90:1062-1114, ny even):
  * mode 0 writes out1's y rows [0, ny) at their interleaved positions, mode 1 reads in1's rows from there.
  * *done = 0: not served for these pencils, nothing was done. */
-int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1, const x3d_real *in2,
                              const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done);
 /* ---- compact10_penta: 10th-order first derivative with a pentadiagonal left-hand side (src/tdsops.f90:235-251,
  * LU factors preprocess_penta_dist :971-1103; kernels der_penta_full / der_penta_periodic,
@@ -137,11 +147,11 @@ int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out
  * completed by x3d_tdsops_set_penta; halo_kind: 1 periodic (Sherman-Morrison-Woodbury correction), 2 BC_NEUMANN with
  * sym (even mirror ghosts), 3 BC_NEUMANN without (odd), 4 BC_DIRICHLET (one-sided closures, ghosts unused).
  * x3d_tds_penta_solve: u_s / u_e = ghost rows [4][npencil] or both NULL (formed in the kernel from halo_kind). */
-int x3d_tdsops_set_penta(x3d_tdsops *t, double alpha, double beta, double beta_lhs_s, const double *dist_fw,
-                         const double *dist_af, const double *dist_sa, const double *dist_bw, const double *coeffs_s,
-                         const double *coeffs_e, int halo_kind);
-int x3d_tds_penta_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, const double *u_s,
-                        const double *u_e);
+int x3d_tdsops_set_penta(x3d_tdsops *t, x3d_real alpha, x3d_real beta, x3d_real beta_lhs_s, const x3d_real *dist_fw,
+                         const x3d_real *dist_af, const x3d_real *dist_sa, const x3d_real *dist_bw, const x3d_real *coeffs_s,
+                         const x3d_real *coeffs_e, int halo_kind);
+int x3d_tds_penta_solve(x3d_backend *b, x3d_real *du, const x3d_real *u, const x3d_tdsops *t, int dir, const x3d_real *u_s,
+                        const x3d_real *u_e);
 
 /* ---- decomposed (BC_HALO) y / z directions in ONE pass + a boundary-strip correction, and plane ranges.
  * The reference's exec_dist_tds_compact / exec_dist_transeq_compact (src/backend/omp/exec_dist.f90:16-65, 67-186)
@@ -163,38 +173,38 @@ int x3d_tds_penta_solve(x3d_backend *b, double *du, const double *u, const x3d_t
  * planes.  *done == 0: pencils not served by the tile kernels, nothing was written. */
 int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2]); /* rows 1..out[0], n-out[1]+1..n get a correction */
 long x3d_halo_row_size(const x3d_backend *b, int dir);
-int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir);
-int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
-                     const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                     const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int accumulate, const double *halo_recv,
-                     double *bnd_send, int other0, int nother, int *done);
-int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
-                         const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der2nd,
-                         const double *bnd_recv);
+int x3d_pack_halos_multi(x3d_backend *b, x3d_real *send, const x3d_real *const *fields, int nf, int n, int dir);
+int x3d_transeq_tile(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u, const x3d_real *v,
+                     const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                     const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int accumulate, const x3d_real *halo_recv,
+                     x3d_real *bnd_send, int other0, int nother, int *done);
+int x3d_transeq_halo_fix(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u, const x3d_real *v,
+                         const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st, const x3d_tdsops *der2nd,
+                         const x3d_real *bnd_recv);
 /* modes 0, 1 of x3d_tds_solve_pair, mode 2: out1 = A(in1) */
-int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                      const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
-                      double *bnd_send, int other0, int nother, int *done);
-int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const x3d_tdsops *ta,
-                          const x3d_tdsops *tb, const double *bnd_recv);
+int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
+                      const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const x3d_real *halo_recv,
+                      x3d_real *bnd_send, int other0, int nother, int *done);
+int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, x3d_real *out1, x3d_real *out2, const x3d_tdsops *ta,
+                          const x3d_tdsops *tb, const x3d_real *bnd_recv);
 /* x3d_tds_solve_pair_yperm for a decomposed z (the 010 solve on z slabs): the whole block through the halo form.
  * Mode 1's halo_recv planes are cut from the neighbours' interleaved fields, so they are read through the same
  * interleave; boundary values stay in pencil order; the strip correction of mode 0 lands on the interleaved rows. */
-int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
-                            const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv, double *bnd_send,
+int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1, const x3d_real *in2,
+                            const x3d_tdsops *ta, const x3d_tdsops *tb, const x3d_real *halo_recv, x3d_real *bnd_send,
                             int ny, int *done);
-int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out1, double *out2, const x3d_tdsops *ta,
-                                const x3d_tdsops *tb, const double *bnd_recv, int ny);
+int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, x3d_real *out1, x3d_real *out2, const x3d_tdsops *ta,
+                                const x3d_tdsops *tb, const x3d_real *bnd_recv, int ny);
 /* fusion extension: y = base + sum_i c[i]*x[i] (x3d_lincomb: the RK / AB stage) followed by du = tds_solve(y)
  * (the first x operators of divergence_v2c): one kernel for periodic 256 / 512-point x pencils, y is not read
  * back; otherwise the two calls one after the other.  y may be base. */
-int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
-                          int nterm, const double *c, const double *const *x);
+int x3d_tds_solve_lincomb(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsops *t, x3d_real *y, const x3d_real *base,
+                          int nterm, const x3d_real *c, const x3d_real *const *x);
 /* fusion extension: the same with the y faces of y (vertex rows j = 0, ny-1) stamped from `wall` before the operator
  * acts = x3d_lincomb ; x3d_field_set_face_from_field(y, wall, Y_FACE) ; x3d_tds_solve (the RK stage, the channel
  * case's apply_BC, src/case/channel.f90:214-231, and the first x operator of divergence_v2c) */
-int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
-                               int nterm, const double *c, const double *const *x, const double *wall);
+int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsops *t, x3d_real *y, const x3d_real *base,
+                               int nterm, const x3d_real *c, const x3d_real *const *x, const x3d_real *wall);
 
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):
@@ -204,16 +214,16 @@ int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_td
  *   <caller exchanges du_send_* -> du_recv_*>
  *   x3d_tds_dist_bwd   = der_univ_subs loop   (exec_dist.f90:55-63) */
 int x3d_npencils(const x3d_backend *b, int dir);
-int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir);
-int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, double *du_send_e,
-                     const double *u, const double *u_recv_s, const double *u_recv_e,
+int x3d_pack_halos(x3d_backend *b, x3d_real *send_s, x3d_real *send_e, const x3d_real *u, int n, int dir);
+int x3d_tds_dist_fwd(x3d_backend *b, x3d_real *du, x3d_real *du_send_s, x3d_real *du_send_e,
+                     const x3d_real *u, const x3d_real *u_recv_s, const x3d_real *u_recv_e,
                      const x3d_tdsops *t, int dir);
-int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
-                     const double *du_recv_e, const x3d_tdsops *t, int dir);
+int x3d_tds_dist_bwd(x3d_backend *b, x3d_real *du, const x3d_real *du_send_s, const x3d_real *du_recv_s,
+                     const x3d_real *du_recv_e, const x3d_tdsops *t, int dir);
 /* fusion extension: accumulate != 0 gives du += scale * result */
-int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
-                     const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
-                         double scale);
+int x3d_tds_dist_bwd_acc(x3d_backend *b, x3d_real *du, const x3d_real *du_send_s, const x3d_real *du_recv_s,
+                     const x3d_real *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
+                         x3d_real scale);
 
 /* ---- transeq_x / transeq_y / transeq_z (src/backend/backend.f90:64-92; omp:
  * src/backend/omp/backend.f90:145-184, 235-338; exec_dist.f90:67-186).
@@ -221,13 +231,13 @@ int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du_send_s, co
  * caller passes them to transeq_<dir> (the permutation that makes the
  * advecting component first, :158-184, is applied inside).
  * Local form (direction not decomposed): */
-int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+int x3d_transeq(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u,
+                const x3d_real *v, const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st,
                 const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                 const x3d_tdsops *der2nd_sym);
 /* fusion extension: accumulate != 0 gives d{u,v,w} += transeq_<dir>(u,v,w) */
-int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                    const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+int x3d_transeq_acc(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u,
+                    const x3d_real *v, const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st,
                     const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                     const x3d_tdsops *der2nd_sym, int accumulate);
 /* fusion extension: transeq_x on a velocity whose pressure-gradient correction is still pending:
@@ -235,63 +245,63 @@ int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw,
  * operators of gradient_c2v + solver.f90:731-733) is applied per pencil inside the transeq kernel, then
  * du, dv, dw = transeq_x(u, v, w).  *done = 0: not applicable, nothing was done.  Bit-identical to
  * x3d_tds_solve_acc x 3 followed by x3d_transeq. */
-int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, double *u, double *v, double *w, double nu,
+int x3d_transeq_x_update(x3d_backend *b, x3d_real *du, x3d_real *dv, x3d_real *dw, x3d_real *u, x3d_real *v, x3d_real *w, x3d_real nu,
                          const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                         const x3d_tdsops *der2nd_sym, const double *gu, const double *gv, const double *gw,
-                         const x3d_tdsops *op_u, const x3d_tdsops *op_vw, double scale, int *done);
+                         const x3d_tdsops *der2nd_sym, const x3d_real *gu, const x3d_real *gv, const x3d_real *gw,
+                         const x3d_tdsops *op_u, const x3d_tdsops *op_vw, x3d_real scale, int *done);
 /* fusion extension: transeq_x with the channel case's rotation forcing (src/case/channel.f90:191-207, there two
  * vecadd's after transeq: du = du - omega v, dv = dv + omega u) applied to the x contribution inside the kernel: the
  * y / z contributions are then accumulated onto the forced values (the same sum in another order).  *done = 0: not
  * served for these pencils, nothing was done.  u_shift != NULL: first u += *u_shift in place (the device scalar of
  * x3d_field_mean_shift: second half of the bulk-velocity correction, bit-identical to x3d_field_shift_by). */
-int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, double *u, const double *v,
-                      const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                      const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega, const double *u_shift,
+int x3d_transeq_x_rot(x3d_backend *b, x3d_real *du, x3d_real *dv, x3d_real *dw, x3d_real *u, const x3d_real *v,
+                      const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                      const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, x3d_real omega, const x3d_real *u_shift,
                       int *done);
 /* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
  * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
  * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below
  * with u = spec, conv = uvw). */
-int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+int x3d_transeq_species(x3d_backend *b, int dir, x3d_real *dspec, const x3d_real *uvw, const x3d_real *spec, x3d_real nu,
                         const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                         int accumulate);
 
 /* Distributed form for ONE component (transeq_dist_component, :299-338):
  * rhs = -1/2 (conv*du/dx + d(u*conv)/dx) + nu d2u/dx2.  send/recv are
  * [3][npencil] (du, dud, d2u boundary values), halos [4][npencil]. */
-int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double *send_s, double *send_e,
-                         const double *u, const double *u_recv_s, const double *u_recv_e,
-                         const double *conv, const double *conv_recv_s, const double *conv_recv_e,
+int x3d_transeq_dist_fwd(x3d_backend *b, int dir, x3d_real *rhs, x3d_real *send_s, x3d_real *send_e,
+                         const x3d_real *u, const x3d_real *u_recv_s, const x3d_real *u_recv_e,
+                         const x3d_real *conv, const x3d_real *conv_recv_s, const x3d_real *conv_recv_e,
                          const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u);
-int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
-                         const double *recv_s, const double *recv_e, const double *conv, double nu,
+int x3d_transeq_dist_bwd(x3d_backend *b, int dir, x3d_real *rhs, const x3d_real *send_s,
+                         const x3d_real *recv_s, const x3d_real *recv_e, const x3d_real *conv, x3d_real nu,
                          const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u);
 /* fusion extension: accumulate != 0 gives rhs += result (folds the fused driver's vecadd) */
-int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, const double *send_s,
-                         const double *recv_s, const double *recv_e, const double *conv, double nu,
+int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, x3d_real *rhs, const x3d_real *send_s,
+                         const x3d_real *recv_s, const x3d_real *recv_e, const x3d_real *conv, x3d_real nu,
                          const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
                              int accumulate);
 
 /* ---- reorder / sum_yintox / sum_zintox (src/backend/backend.f90:152-186) */
-int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr_code);
-int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from);
+int x3d_reorder(x3d_backend *b, x3d_real *u_, const x3d_real *u, int rdr_code);
+int x3d_sum_intox(x3d_backend *b, x3d_real *u, const x3d_real *u_, int dir_from);
 
 /* ---- veccopy / vecadd / vecmult / field_scale / field_shift (:188-236, 273-291) */
-int x3d_veccopy(x3d_backend *b, double *dst, const double *src);
-int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
-int x3d_vecmult(x3d_backend *b, double *y, const double *x);
-int x3d_field_scale(x3d_backend *b, double *f, double a);
-int x3d_field_shift(x3d_backend *b, double *f, double a);
+int x3d_veccopy(x3d_backend *b, x3d_real *dst, const x3d_real *src);
+int x3d_vecadd(x3d_backend *b, x3d_real a, const x3d_real *x, x3d_real bb, x3d_real *y);
+int x3d_vecmult(x3d_backend *b, x3d_real *y, const x3d_real *x);
+int x3d_field_scale(x3d_backend *b, x3d_real *f, x3d_real a);
+int x3d_field_shift(x3d_backend *b, x3d_real *f, x3d_real a);
 /* compute_vorticity / compute_qcriterion (src/backend/backend.f90:53-54, omp :616-649): pointwise,
  * grads = {dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz} device blocks, out distinct from them:
  * |curl u| and Q = -1/2 (dudx^2 + dvdy^2 + dwdz^2) - dudy dvdx - dudz dwdx - dvdz dwdy */
-int x3d_compute_vorticity(x3d_backend *b, double *out, const double *const grads[9]);
-int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grads[9]);
+int x3d_compute_vorticity(x3d_backend *b, x3d_real *out, const x3d_real *const grads[9]);
+int x3d_compute_qcriterion(x3d_backend *b, x3d_real *out, const x3d_real *const grads[9]);
 /* fused time-integrator update (an extension, not in base_backend_t):
  * y = base + sum_i c[i]*x[i], nterm <= 5; base may be y itself.  Collapses the
  * veccopy/vecadd chains of src/time_integrator.f90:166-282 into one pass. */
-int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
-                const double *const *x);
+int x3d_lincomb(x3d_backend *b, x3d_real *y, const x3d_real *base, int nterm, const x3d_real *c,
+                const x3d_real *const *x);
 /* fusion extension of the pair above for the last direction (y or z) of transeq_default when its pencils
  * run through the single-pass scan kernel (csrc/viax.hip): x3d_transeq_defer computes the three components
  * like x3d_transeq_acc(accumulate = 1) but leaves "d{u,v,w} += result" pending -- the results stay in
@@ -299,32 +309,32 @@ int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const 
  * x3d_transeq_acc).  x3d_lincomb_pending is x3d_lincomb with term x[ipend] completed on the fly,
  *   x[ipend] + pending -> d;  store != 0: x[ipend] = d;  y = base + sum_i c[i] * (i == ipend ? d : x[i]),
  * bit-identical to x3d_pending_flush (x[ipend] += pending) followed by x3d_lincomb. */
-int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv, double *pw, const double *u,
-                      const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+int x3d_transeq_defer(x3d_backend *b, int dir, x3d_real *pu, x3d_real *pv, x3d_real *pw, const x3d_real *u,
+                      const x3d_real *v, const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st,
                       const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
                       int *deferred);
-int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend);
+int x3d_pending_flush(x3d_backend *b, int dir, x3d_real *r, const x3d_real *pend);
 /* the same fusion when the last direction's pencils take the tile kernel (csrc/xscan.hip, k_ytile_transeq): the
  * component itself is computed inside the stage's linear combination.  x3d_transeq_stage_ok != 0: applicable.
  * kind 0: advecting component (der1st, der1st_sym, der2nd; conv == u), kind 1: the others (der1st_sym, der1st,
  * der2nd_sym).  Equal to x3d_transeq_species(dspec = x[ipend], accumulate = 1) followed by x3d_lincomb. */
 int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                          const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym);
-int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const double *u, const double *conv, double nu,
+int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const x3d_real *u, const x3d_real *conv, x3d_real nu,
                         const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                        const x3d_tdsops *der2nd_sym, double *y, const double *base, int nterm, const double *c,
-                        double *const *x, int ipend, int store);
-int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm, const double *c,
-                        double *const *x, int ipend, const double *pend, int store);
+                        const x3d_tdsops *der2nd_sym, x3d_real *y, const x3d_real *base, int nterm, const x3d_real *c,
+                        x3d_real *const *x, int ipend, int store);
+int x3d_lincomb_pending(x3d_backend *b, int dir, x3d_real *y, const x3d_real *base, int nterm, const x3d_real *c,
+                        x3d_real *const *x, int ipend, const x3d_real *pend, int store);
 
 /* ---- reductions over the unpadded extent dims[3] of the field's data_loc.
  * Rank-local values; the caller does the cross-rank reduction (the reference
  * calls MPI_Allreduce inside: src/backend/omp/backend.f90:708, 805-808, 1063). */
-int x3d_scalar_product(x3d_backend *b, const double *x, const double *y, const int dims[3],
-                       double *out);
-int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double *max_abs,
-                      double *sum_abs);
-int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out);
+int x3d_scalar_product(x3d_backend *b, const x3d_real *x, const x3d_real *y, const int dims[3],
+                       x3d_real *out);
+int x3d_field_max_sum(x3d_backend *b, const x3d_real *f, const int dims[3], x3d_real *max_abs,
+                      x3d_real *sum_abs);
+int x3d_field_volume_integral(x3d_backend *b, const x3d_real *f, const int dims[3], x3d_real *out);
 /* slice_max_sum (:252-271): plane i_slice (1-based) normal to `dir` */
 /* channel case without host round trips (define_BC_channel, src/case/channel.f90:59-130; one rank):
  *  x3d_field_shift_to_mean: f += target - volume_integral(f) / ncell, the sum finished on the device in the order of
@@ -332,88 +342,88 @@ int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3]
  *  x3d_wall_noise: planes y = 1 and y = ny of f <- amp * (2 r - 1), r in [0, 1) from a counter-based generator
  *    (splitmix64 of seed + draw, then of that key + (face * nz + k) * nx + i; 53 bits) instead of the host's
  *    random_number planes and three full-block uploads per sub-step (:97-130) */
-int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target);
+int x3d_field_shift_to_mean(x3d_backend *b, x3d_real *f, const int dims[3], x3d_real ncell, x3d_real target);
 /* its two halves: *shift = device address of target - volume_integral(f) / ncell (valid until the backend's next
  * reduction) ; f += that device scalar (x3d_transeq_x_rot can do the second half inside its kernel) */
-int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
-                         const double **shift);
-int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift);
-int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
+int x3d_field_mean_shift(x3d_backend *b, const x3d_real *f, const int dims[3], x3d_real ncell, x3d_real target,
+                         const x3d_real **shift);
+int x3d_field_shift_by(x3d_backend *b, x3d_real *f, const x3d_real *shift);
+int x3d_wall_noise(x3d_backend *b, x3d_real *f, const int dims[3], x3d_real amp, unsigned long long seed,
                    unsigned long long draw);
-int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
-                      double *max_val, double *sum_val);
+int x3d_slice_max_sum(x3d_backend *b, const x3d_real *f, const int dims[3], int dir, int i_slice,
+                      x3d_real *max_val, x3d_real *sum_val);
 
 /* ---- field_set_face / field_set_face_from_field (:293-337; omp :903-1021), Y_FACE and X_FACE */
-int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], double c_start, double c_end,
+int x3d_field_set_face(x3d_backend *b, x3d_real *f, const int dims[3], x3d_real c_start, x3d_real c_end,
                        int face);
-int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start,
-                                  const int dims[3], double c_end, int face,
-                                  double flow_rate_diff);
+int x3d_field_set_face_from_field(x3d_backend *b, x3d_real *f, const x3d_real *f_start,
+                                  const int dims[3], x3d_real c_end, int face,
+                                  x3d_real flow_rate_diff);
 
 /* ---- copy_data_to_f / copy_f_to_data via set/get_field_data
  * (src/backend/backend.f90:402-466): host Cartesian array [nz][ny][nx]
  * (x fastest, unpadded extents dims) <-> device block. */
-int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3]);
-int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3]);
+int x3d_set_field_data(x3d_backend *b, x3d_real *f, const x3d_real *host, const int dims[3]);
+int x3d_get_field_data(x3d_backend *b, x3d_real *host, const x3d_real *f, const int dims[3]);
 /* same with a padded host array (leading dims hx, hy): what copy_data_to_f /
  * copy_f_to_data see, whole padded DIR_C arrays (src/backend/omp/backend.f90:1068-1082) */
-int x3d_set_field_data_pitched(x3d_backend *b, double *f, const double *host, int hx, int hy,
+int x3d_set_field_data_pitched(x3d_backend *b, x3d_real *f, const x3d_real *host, int hx, int hy,
                                const int dims[3]);
-int x3d_get_field_data_pitched(x3d_backend *b, double *host, const double *f, int hx, int hy,
+int x3d_get_field_data_pitched(x3d_backend *b, x3d_real *host, const x3d_real *f, int hx, int hy,
                                const int dims[3]);
 
 /* ---- init_poisson_fft (src/backend/backend.f90:374-389) + poisson_fft_t hooks
  * (src/poisson_fft.f90:45-62).  Single-rank periodic (000) solver:
  * cell dims n[3]; waves_re[nz][ny][nx/2+1] (host, real part = imaginary part,
  * src/poisson_fft.f90:654-831); ax..bz host arrays of n[0], n[1], n[2]. */
-int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n[3], const double *waves_re,
-                       const double *ax, const double *bx, const double *ay, const double *by,
-                       const double *az, const double *bz);
+int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n[3], const x3d_real *waves_re,
+                       const x3d_real *ax, const x3d_real *bx, const x3d_real *ay, const x3d_real *by,
+                       const x3d_real *az, const x3d_real *bz);
 int x3d_poisson_destroy(x3d_poisson *p);
-int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);  /* fft_forward            */
+int x3d_poisson_fft_forward(x3d_poisson *p, const x3d_real *f_in);  /* fft_forward            */
 int x3d_poisson_postprocess_000(x3d_poisson *p);                  /* fft_postprocess_000    */
-int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);      /* fft_backward           */
-int x3d_poisson_solve_000(x3d_poisson *p, double *f);             /* poisson_000, :216-226  */
+int x3d_poisson_fft_backward(x3d_poisson *p, x3d_real *f_out);      /* fft_backward           */
+int x3d_poisson_solve_000(x3d_poisson *p, x3d_real *f);             /* poisson_000, :216-226  */
 /* ---- non-periodic y (010), single rank like the reference (src/poisson_fft.f90:177-180):
  * the same create call with the 010 waves and ay/by = sin/cos((i-1) pi / 2n);
  * poisson_010 = enforce_periodicity_y ; fft_forward ; fft_postprocess_010 ; fft_backward ;
  * undo_periodicity_y (src/poisson_fft.f90:228-242).  f_out != f_in (DIR_C blocks). */
-int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in);
-int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in);
+int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, x3d_real *f_out, const x3d_real *f_in);
+int x3d_poisson_undo_periodicity_y(x3d_poisson *p, x3d_real *f_out, const x3d_real *f_in);
 /* stretched y: the matrices of stretching_matrix (src/poisson_fft.f90:275-652), host arrays
  * [5][nz][n][nx/2+1] (diagonal -2..+2 slowest; real part = imaginary part).  sym != 0
  * ('centred' / 'top-bottom'): a0 = odd rows, a1 = even rows, n = ny/2; sym == 0 ('bottom'):
  * a0 = full system, n = ny, a1 ignored.  Factored once on the device (the reference
  * re-copies and re-eliminates them at every solve, src/backend/cuda/poisson_fft.f90:868-913). */
-int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double *a0, const double *a1);
+int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const x3d_real *a0, const x3d_real *a1);
 int x3d_poisson_postprocess_010(x3d_poisson *p);                  /* fft_postprocess_010    */
-int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp); /* poisson_010          */
+int x3d_poisson_solve_010(x3d_poisson *p, x3d_real *f, x3d_real *temp); /* poisson_010          */
 /* poisson_010 (src/poisson_fft.f90:228-242) without enforce / undo_periodicity_y: the rows of f are already in
  * enforce_periodicity_y's order (the operator pair that produces the divergence writes them so) and the solution is
  * left in that order.  ny = 256 on a stretched grid: x and z transforms, then ONE pass over the spectrum for the y
  * transform, fft_postprocess_010 and the inverse y transform (csrc/y010.hip); X3D_NO_Y010=1: the 3-D transforms with
  * the post-processing kernels between them (what every other size runs). */
-int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f);
+int x3d_poisson_solve_010_rows(x3d_poisson *p, x3d_real *f);
 /* test hook: download / upload the spectral workspace [nz][ny][nx/2+1] complex */
 /* Poisson 100 (x non-periodic, y and z periodic): the reference transposes x <-> y and runs the 010 solve on the
  * transposed problem (fft_forward_100 / fft_postprocess_100 / fft_backward_100,
  * src/backend/cuda/poisson_fft.f90:482-616, 781-820).  Here: a second backend of the transposed vertex dims on the
  * same stream, an x3d_poisson on it built from the swapped wave-number arrays, and this copy between the two
  * layouts: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz (x2d2_amd/poisson_fft.py, HipPoissonFFT100). */
-int x3d_transpose_xy(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
+int x3d_transpose_xy(x3d_backend *b_src, x3d_backend *b_dst, x3d_real *dst, const x3d_real *src, int nx, int ny, int nz);
 /* Poisson 110 (x and y non-periodic, z periodic): the reference moves z to the front (transposed copy to
  * (nz, nx, ny), R2C along z), applies enforce_periodicity_xy before and seven spectral kernels in between
  * (fft_forward_110 / fft_postprocess_110 / fft_backward_110, src/backend/cuda/poisson_fft.f90:401-480, 926-989).
  * Here: a twin backend of vertex dims (nz, nx, ny) and an x3d_poisson on it whose x is the reference's z, y its x,
  * z its y: transposed copies, the even / odd interleave along the twin's y (x3d_poisson_enforce_periodicity_y) and
  * z (…_z), and x3d_poisson_postprocess_011 = the seven kernels in the twin's layout (HipPoissonFFT110). */
-int x3d_transpose_xyz_zxy(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
-int x3d_transpose_zxy_xyz(x3d_backend *b_src, x3d_backend *b_dst, double *dst, const double *src, int nx, int ny, int nz);
-int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in);
-int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in);
+int x3d_transpose_xyz_zxy(x3d_backend *b_src, x3d_backend *b_dst, x3d_real *dst, const x3d_real *src, int nx, int ny, int nz);
+int x3d_transpose_zxy_xyz(x3d_backend *b_src, x3d_backend *b_dst, x3d_real *dst, const x3d_real *src, int nx, int ny, int nz);
+int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, x3d_real *f_out, const x3d_real *f_in);
+int x3d_poisson_undo_periodicity_z(x3d_poisson *p, x3d_real *f_out, const x3d_real *f_in);
 int x3d_poisson_postprocess_011(x3d_poisson *p);
-int x3d_poisson_get_spectral(x3d_poisson *p, double *host_interleaved);
-int x3d_poisson_set_spectral(x3d_poisson *p, const double *host_interleaved);
+int x3d_poisson_get_spectral(x3d_poisson *p, x3d_real *host_interleaved);
+int x3d_poisson_set_spectral(x3d_poisson *p, const x3d_real *host_interleaved);
 
 /* ---- distributed 000 solver for z-slab decompositions [1, 1, pz] with ny = 512 (the layout of
  * bench.py on N GPUs and of the reference's GPU backend, src/backend/cuda/poisson_fft.f90:219): one
@@ -425,20 +435,20 @@ typedef struct x3d_sfft x3d_sfft;
 int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz);
 int x3d_sfft_destroy(x3d_sfft *p);
 int x3d_sfft_sizes(const x3d_sfft *p, long out[4]);
-int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx, const double *ay,
-                       const double *by, const double *az, const double *bz);
-int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf);
-int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir);
-int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf);
-int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out);
+int x3d_sfft_set_waves(x3d_sfft *p, const x3d_real *waves, const x3d_real *ax, const x3d_real *bx, const x3d_real *ay,
+                       const x3d_real *by, const x3d_real *az, const x3d_real *bz);
+int x3d_sfft_forward_local(x3d_sfft *p, const x3d_real *f_in, x3d_real *sendbuf);
+int x3d_sfft_fft_z(x3d_sfft *p, x3d_real *recvbuf, int dir);
+int x3d_sfft_postprocess_000(x3d_sfft *p, x3d_real *recvbuf);
+int x3d_sfft_backward_local(x3d_sfft *p, const x3d_real *recvbuf, x3d_real *f_out);
 /* overlap of the all-to-all with the z stage (the reference issues cuFFTMp's slab transposes and its z
  * transforms one after the other, src/backend/cuda/poisson_fft.f90:519,568): a rank's share of ys y modes is cut
  * into `parts` pieces of ysc = ys / parts; S = [peer][part][zl][ysc][nxs], R = [part][peer][zl][ysc][nxs]; piece m
  * is sent / received as pz messages of zl * ysc * nxs complex numbers and transformed by the *_part calls while
  * the other pieces are in flight (x3d2_amd/poisson_fft.py, HipSlabPoissonFFT.poisson_000) */
 int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
-int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part);
-int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part);
+int x3d_sfft_fft_z_part(x3d_sfft *p, x3d_real *recvbuf, int dir, int part);
+int x3d_sfft_postprocess_000_part(x3d_sfft *p, x3d_real *recvbuf, int part);
 
 /* ---- distributed 010 solver (non-periodic y: the channel case, BASELINE configs[4]) for z-slab decompositions
  * [1, 1, pz] (csrc/sfft010.hip).  The reference refuses this combination ("Multiple ranks are not yet supported for
@@ -460,16 +470,16 @@ int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6]); /* chunk, zl, xs, i0, 
  * [peer][part][zl][ny][xsc], R = [part][peer][zl][ny][xsc]; a group holds all rows and all z of its columns, so the
  * *_part calls run on it while the next groups are in flight (x3d2_amd/poisson_fft.py, HipSlabPoissonFFT010) */
 int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob_cell[3], int pz, int rz, int parts);
-int x3d_sfft010_fft_z_part(x3d_sfft010 *p, double *recvbuf, int dir, int part);
-int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, double *recvbuf, int part);
-int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const double *ax, const double *bx, const double *ay,
-                          const double *by, const double *az, const double *bz);
-int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double *a0, const double *a1);
-int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const double *f_in, int undo);
-int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf);
-int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir);
-int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf);
-int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out);
+int x3d_sfft010_fft_z_part(x3d_sfft010 *p, x3d_real *recvbuf, int dir, int part);
+int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, x3d_real *recvbuf, int part);
+int x3d_sfft010_set_waves(x3d_sfft010 *p, const x3d_real *waves, const x3d_real *ax, const x3d_real *bx, const x3d_real *ay,
+                          const x3d_real *by, const x3d_real *az, const x3d_real *bz);
+int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const x3d_real *a0, const x3d_real *a1);
+int x3d_sfft010_periodicity_y(x3d_sfft010 *p, x3d_real *f_out, const x3d_real *f_in, int undo);
+int x3d_sfft010_forward_local(x3d_sfft010 *p, const x3d_real *f_in, x3d_real *sendbuf);
+int x3d_sfft010_fft_z(x3d_sfft010 *p, x3d_real *recvbuf, int dir);
+int x3d_sfft010_postprocess_010(x3d_sfft010 *p, x3d_real *recvbuf);
+int x3d_sfft010_backward_local(x3d_sfft010 *p, const x3d_real *sendbuf, x3d_real *f_out);
 
 /* ---- z-first form of the 000 solve (fusion extension, 512^3 cells on one rank; csrc/zfirst.hip): the transform along z
  * is done on the LDS tile of the z operator pairs that stand next to the solve in pressure_correction
@@ -486,11 +496,11 @@ int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok);
 /* ... and these two operators' z pair is one the z-transforming kernels take (probe, nothing is launched) */
 int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb, int *ok);
 int x3d_poisson_zfirst_middle(x3d_poisson *p);
-int x3d_poisson_zfirst_forward(x3d_poisson *p, const double *f_in);
-int x3d_poisson_zfirst_backward(x3d_poisson *p, double *f_out);
-int x3d_poisson_solve_000_zfirst(x3d_poisson *p, double *f);
-int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2, const double *in1,
-                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
+int x3d_poisson_zfirst_forward(x3d_poisson *p, const x3d_real *f_in);
+int x3d_poisson_zfirst_backward(x3d_poisson *p, x3d_real *f_out);
+int x3d_poisson_solve_000_zfirst(x3d_poisson *p, x3d_real *f);
+int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
+                        const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
 
 /* ---- 000 solve on y slabs, z-first (csrc/sfftz.hip): nproc_dir = [1, py, 1], py = 1, 2, 4, 8, 512^3 cells per rank.
  * z is whole on every rank: the z operator pairs next to the solve transform along z on their tiles as on one rank
@@ -503,24 +513,24 @@ typedef struct x3d_sfftz x3d_sfftz;
 int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob_cell[3], int py, int ry, int parts);
 int x3d_sfftz_destroy(x3d_sfftz *p);
 int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16]); /* parts, xs, xoff, buffer elements, kz0[0..parts] */
-int x3d_sfftz_set_waves(x3d_sfftz *p, const double *rw, const double *ax, const double *bx, const double *ay,
-                        const double *by, const double *az, const double *bz);
-int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_sfftz_set_waves(x3d_sfftz *p, const x3d_real *rw, const x3d_real *ax, const x3d_real *bx, const x3d_real *ay,
+                        const x3d_real *by, const x3d_real *az, const x3d_real *bz);
+int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1, const x3d_real *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
-int x3d_sfftz_z(x3d_sfftz *p, double *f, int inverse);
-int x3d_sfftz_x_forward(x3d_sfftz *p, double *sendbuf, int part);
-int x3d_sfftz_y_stage(x3d_sfftz *p, double *recvbuf, int part, int what); /* what 0: all; 1 forward, 2 inverse, 3 division */
-int x3d_sfftz_x_backward(x3d_sfftz *p, const double *buf, int part);
+int x3d_sfftz_z(x3d_sfftz *p, x3d_real *f, int inverse);
+int x3d_sfftz_x_forward(x3d_sfftz *p, x3d_real *sendbuf, int part);
+int x3d_sfftz_y_stage(x3d_sfftz *p, x3d_real *recvbuf, int part, int what); /* what 0: all; 1 forward, 2 inverse, 3 division */
+int x3d_sfftz_x_backward(x3d_sfftz *p, const x3d_real *buf, int part);
 /* round 5: the same steps for the local y rows [y0, y0 + nyr) only -- a z pair works tile by tile and the rows' piece of
  * every (part, peer) chunk of the exchange layout is contiguous, so a group of rows can leave while the next group's z
  * pair runs, and come back while the previous group's z pair runs (poisson_fft.HipSlabPoissonFFTZ.zfirst_solve_pipelined;
  * the reference hands its transposes to cuFFTMp / 2decomp&FFT, which block: src/backend/cuda/poisson_fft.f90:218-219,
  * src/backend/omp/poisson_fft.f90:89-137) */
-int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1, const x3d_real *in2,
                             const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done);
-int x3d_sfftz_z_rows(x3d_sfftz *p, double *f, int inverse, int y0, int nyr);
-int x3d_sfftz_x_forward_rows(x3d_sfftz *p, double *sendbuf, int part, int y0, int nyr);
-int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const double *buf, int part, int y0, int nyr);
+int x3d_sfftz_z_rows(x3d_sfftz *p, x3d_real *f, int inverse, int y0, int nyr);
+int x3d_sfftz_x_forward_rows(x3d_sfftz *p, x3d_real *sendbuf, int part, int y0, int nyr);
+int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const x3d_real *buf, int part, int y0, int nyr);
 
 /* ---- distributed form of the same solver: pencil FFT over a [1, py, pz]
  * decomposition (the 2decomp&FFT layout of the reference's CPU backend,
@@ -535,20 +545,20 @@ typedef struct x3d_pfft x3d_pfft;
 int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob_cell[3], int py, int pz, int ry, int rz);
 int x3d_pfft_destroy(x3d_pfft *p);
 int x3d_pfft_sizes(const x3d_pfft *p, long out[8]); /* xs,xoff,ys,yoff,yl,zl,nxs,max complex count */
-int x3d_pfft_set_waves(x3d_pfft *p, const double *waves_re, const double *ax, const double *bx,
-                       const double *ay, const double *by, const double *az, const double *bz);
-int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in);
-int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out);
+int x3d_pfft_set_waves(x3d_pfft *p, const x3d_real *waves_re, const x3d_real *ax, const x3d_real *bx,
+                       const x3d_real *ay, const x3d_real *by, const x3d_real *az, const x3d_real *bz);
+int x3d_pfft_fwd_x(x3d_pfft *p, const x3d_real *f_in);
+int x3d_pfft_bwd_x(x3d_pfft *p, x3d_real *f_out);
 int x3d_pfft_fft_y(x3d_pfft *p, int inverse);
 int x3d_pfft_fft_z(x3d_pfft *p, int inverse);
-int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf);
-int x3d_pfft_unpack_xy(x3d_pfft *p, const double *recvbuf);
-int x3d_pfft_pack_yx(x3d_pfft *p, double *sendbuf);
-int x3d_pfft_unpack_yx(x3d_pfft *p, const double *recvbuf);
-int x3d_pfft_pack_yz(x3d_pfft *p, double *sendbuf);
-int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf);
-int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf);
-int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf);
+int x3d_pfft_pack_xy(x3d_pfft *p, x3d_real *sendbuf);
+int x3d_pfft_unpack_xy(x3d_pfft *p, const x3d_real *recvbuf);
+int x3d_pfft_pack_yx(x3d_pfft *p, x3d_real *sendbuf);
+int x3d_pfft_unpack_yx(x3d_pfft *p, const x3d_real *recvbuf);
+int x3d_pfft_pack_yz(x3d_pfft *p, x3d_real *sendbuf);
+int x3d_pfft_unpack_yz(x3d_pfft *p, const x3d_real *recvbuf);
+int x3d_pfft_pack_zy(x3d_pfft *p, x3d_real *sendbuf);
+int x3d_pfft_unpack_zy(x3d_pfft *p, const x3d_real *recvbuf);
 int x3d_pfft_postprocess_000(x3d_pfft *p);
 /* the same solve in `parts` groups of zp = zl / parts local z planes (parts <= 0: the library's choice): everything
  * before the z transform is independent from plane to plane, so a group's x transform, xy exchange, y transform and
@@ -562,12 +572,12 @@ int x3d_pfft_postprocess_000(x3d_pfft *p);
 int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob_cell[3], int py, int pz, int ry, int rz,
                           int parts);
 int x3d_pfft_part_layout(const x3d_pfft *p, long out[6]);
-int x3d_pfft_fwd_a_part(x3d_pfft *p, const double *f_in, double *send_xy, int m);
-int x3d_pfft_fwd_b_part(x3d_pfft *p, const double *recv_xy, double *send_yz, int m);
-int x3d_pfft_fwd_c_part(x3d_pfft *p, const double *recv_yz, int m);
-int x3d_pfft_bwd_c_part(x3d_pfft *p, double *send_zy, int m);
-int x3d_pfft_bwd_b_part(x3d_pfft *p, const double *recv_zy, double *send_yx, int m);
-int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m);
+int x3d_pfft_fwd_a_part(x3d_pfft *p, const x3d_real *f_in, x3d_real *send_xy, int m);
+int x3d_pfft_fwd_b_part(x3d_pfft *p, const x3d_real *recv_xy, x3d_real *send_yz, int m);
+int x3d_pfft_fwd_c_part(x3d_pfft *p, const x3d_real *recv_yz, int m);
+int x3d_pfft_bwd_c_part(x3d_pfft *p, x3d_real *send_zy, int m);
+int x3d_pfft_bwd_b_part(x3d_pfft *p, const x3d_real *recv_zy, x3d_real *send_yx, int m);
+int x3d_pfft_bwd_a_part(x3d_pfft *p, const x3d_real *recv_yx, x3d_real *f_out, int m);
 
 /* ---- deferred execution of the reference's op-granular call sequence: fusion inside the library (csrc/lazy.hip).
  * The unchanged solver.f90 issues 16 reorder + 6 sum_*intox + ~20 veccopy / vecadd + 16 tds_solve + 3 transeq_* per
@@ -596,9 +606,9 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);
 int x3d_lazy_sync(x3d_backend *b);
-int x3d_lazy_unregister_block(x3d_backend *b, double *f); /* sync, then forget a block of x3d_lazy_register_block */
-int x3d_lazy_register_block(x3d_backend *b, double *f);
-int x3d_block_discard(x3d_backend *b, double *f);
+int x3d_lazy_unregister_block(x3d_backend *b, x3d_real *f); /* sync, then forget a block of x3d_lazy_register_block */
+int x3d_lazy_register_block(x3d_backend *b, x3d_real *f);
+int x3d_block_discard(x3d_backend *b, x3d_real *f);
 int x3d_lazy_stats(x3d_backend *b, long out[24]);
 
 /* ---- measurement support: HIP-event timing on the backend's stream */

@@ -38,6 +38,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.x3d_abi_version() == 1
 
 
+def test_single_precision_flavour_exports_the_same_symbols():
+    """libx3d2_hip_sp.so (make SP=1: -DX3D_SINGLE_PREC, x3d_real = float) is the same ABI on 4-byte reals"""
+    from x3d2_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libx3d2_hip_sp.so")
+    assert os.path.exists(path), "build() compiles both flavours"
+    import torch  # noqa: F401  (its HIP runtime first, as _lib.load does)
+    lib = ctypes.CDLL(path)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} missing from libx3d2_hip_sp.so"
+
+
 def test_ctypes_prototypes_match_header():
     from x3d2_amd import _lib
     assert sorted(_lib.PROTOTYPES) == declared_functions()

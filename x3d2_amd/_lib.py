@@ -9,13 +9,24 @@ import subprocess
 from .common import X3dError
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libx3d2_hip.so")
+# X3D_SINGLE_PREC=1 (read once, at import): the FP32 flavour of the library (libx3d2_hip_sp.so = the same sources compiled
+# with -DX3D_SINGLE_PREC; the reference's -DSINGLE_PREC, src/common.f90:6-12) -- fields, tables, scalars and transforms
+# on 4-byte reals.  The host side keeps computing coefficients and wave numbers in float64 and converts at this boundary.
+SINGLE = os.environ.get("X3D_SINGLE_PREC") == "1"
+LIB_PATH = os.path.join(HERE, "libx3d2_hip_sp.so" if SINGLE else "libx3d2_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
-c_double_p = ctypes.POINTER(ctypes.c_double)
+REAL = ctypes.c_float if SINGLE else ctypes.c_double  # x3d_real of include/x3d2_hip.h
+NP_REAL = "float32" if SINGLE else "float64"
+c_double_p = ctypes.POINTER(REAL)  # (name kept from the FP64-only days: pointer to the library's real kind)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 VP = ctypes.c_void_p
-I, D, SZT = ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+I, D, SZT = ctypes.c_int, REAL, ctypes.c_size_t
+
+
+def torch_real():
+    import torch
+    return torch.float32 if SINGLE else torch.float64
 
 # name -> (restype, argtypes); kept in step with include/x3d2_hip.h
 # (tests/test_abi.py parses the header and compares)
@@ -205,7 +216,7 @@ PROTOTYPES = {
     "x3d_prof_enable": (I, [VP, I]),
     "x3d_prof_select": (I, [VP, ctypes.c_uint]),
     "x3d_prof_reset": (I, [VP]),
-    "x3d_prof_get": (I, [VP, I, I, ctypes.POINTER(ctypes.c_long), c_double_p]),
+    "x3d_prof_get": (I, [VP, I, I, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None
@@ -214,11 +225,12 @@ _lib = None
 def build(verbose=False):
     """hipcc-compile every HIP source for gfx950 into x3d2_amd/libx3d2_hip.so
     (cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
-    if verbose or r.returncode != 0:
-        print(r.stdout[-4000:], r.stderr[-4000:])
-    if r.returncode != 0:
-        raise X3dError("building libx3d2_hip.so failed")
+    for flavour in ([], ["SP=1"]):  # FP64 (libx3d2_hip.so) and FP32 (libx3d2_hip_sp.so: -DX3D_SINGLE_PREC)
+        r = subprocess.run(["make", "-C", CSRC, "-j4"] + flavour, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            print(r.stdout[-4000:], r.stderr[-4000:])
+        if r.returncode != 0:
+            raise X3dError("building libx3d2_hip%s.so failed" % ("_sp" if flavour else ""))
     return LIB_PATH
 
 

@@ -25,6 +25,10 @@ VP = ctypes.c_void_p
 
 
 def _dp(a):
+    """pointer to `a` in the library's real kind (a float64 host array is converted for the FP32 flavour; the pointer
+    object keeps the converted array alive for the call)"""
+    if a.dtype != np.dtype(_lib.NP_REAL):
+        a = np.ascontiguousarray(a, dtype=_lib.NP_REAL)
     return a.ctypes.data_as(_lib.c_double_p)
 
 
@@ -111,7 +115,7 @@ class HipBackend:
         key = (direction, rows, tag)
         if key not in self._halo:
             npn = self.lib.x3d_npencils(self.h, direction)
-            self._halo[key] = tuple(torch.zeros(rows * npn, dtype=torch.float64, device=self.device)
+            self._halo[key] = tuple(torch.zeros(rows * npn, dtype=_lib.torch_real(), device=self.device)
                                     for _ in range(4))
         return self._halo[key]
 
@@ -145,7 +149,7 @@ class HipBackend:
 
     def prof_get(self, kind, direction=0):
         """(launch count, summed device ms) of one kernel class"""
-        n, ms = ctypes.c_long(), ctypes.c_double()
+        n, ms = ctypes.c_long(), ctypes.c_double()  # (timers: FP64 whatever the real kind)
         _lib.check(self.lib.x3d_prof_get(self.h, self.KINDS[kind], direction, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
 
@@ -288,7 +292,7 @@ class HipBackend:
         if key not in self._halo:
             npn = self.lib.x3d_npencils(self.h, direction)
             hrow = int(self.lib.x3d_halo_row_size(self.h, direction))
-            z = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+            z = lambda n: torch.zeros(n, dtype=_lib.torch_real(), device=self.device)
             # (z halos leave straight from the fields' blocks: no send buffer)
             hs = z(0) if self._halo_direct(direction) else z(2 * nf * N_HALO * hrow)
             self._halo[key] = (hs, z(2 * nf * N_HALO * hrow), z(2 * nb * npn), z(2 * nb * npn))
@@ -591,7 +595,7 @@ class HipBackend:
     def transeq_lincomb(self, direction, kind, u_ptr, conv_ptr, nu, dirps, y, base, coeffs, xs, ipend, store):
         """lincomb with term xs[ipend] completed by one transeq component computed in the same kernel"""
         n = len(xs)
-        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        c = (_lib.REAL * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
         _lib.check(self.lib.x3d_transeq_lincomb(self.h, direction, int(kind), u_ptr, conv_ptr, float(nu),
                                                 dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
@@ -613,7 +617,7 @@ class HipBackend:
     def lincomb_pending(self, y, base, coeffs, xs, ipend, pend, direction, store):
         """lincomb with term xs[ipend] completed on the fly from its pending transeq component"""
         n = len(xs)
-        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        c = (_lib.REAL * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
         _lib.check(self.lib.x3d_lincomb_pending(self.h, direction, y.ptr, base.ptr, n, c, p, int(ipend), pend.ptr,
                                                 int(bool(store))))
@@ -632,7 +636,7 @@ class HipBackend:
             self.tds_apply(du, y, tdsops, direction)
             return
         n = len(xs)
-        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        c = (_lib.REAL * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
         if wall is None:
             _lib.check(self.lib.x3d_tds_solve_lincomb(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p))
@@ -812,7 +816,7 @@ class HipBackend:
     def lincomb(self, y, base, coeffs, xs):
         """extension: y = base + sum c_i x_i in one pass (time-integrator fusion)"""
         n = len(xs)
-        c = (ctypes.c_double * n)(*[float(v) for v in coeffs])
+        c = (_lib.REAL * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
         _lib.check(self.lib.x3d_lincomb(self.h, y.ptr, base.ptr, n, c, p))
 
@@ -823,7 +827,7 @@ class HipBackend:
             raise X3dError("You must set the data_loc before calling scalar product")
         if x.data_loc != y.data_loc:
             raise X3dError("Called scalar product with incompatible fields")
-        out = ctypes.c_double()
+        out = _lib.REAL()
         _lib.check(self.lib.x3d_scalar_product(self.h, x.ptr, y.ptr, self._dims(x.data_loc), ctypes.byref(out)))
         return self.comm.allreduce(out.value, "sum")
 
@@ -834,7 +838,7 @@ class HipBackend:
         loc = f.data_loc if enforced_data_loc is None else enforced_data_loc
         if f.dir == DIR_C:
             raise X3dError("field_max_mean does not support DIR_C fields!")
-        mx, sm = ctypes.c_double(), ctypes.c_double()
+        mx, sm = _lib.REAL(), _lib.REAL()
         _lib.check(self.lib.x3d_field_max_sum(self.h, f.ptr, self._dims(loc), ctypes.byref(mx), ctypes.byref(sm)))
         nglob = float(np.prod(self.mesh.get_global_dims(loc)))
         return self.comm.allreduce(mx.value, "max"), self.comm.allreduce(sm.value / nglob, "sum")
@@ -844,7 +848,7 @@ class HipBackend:
         if f.data_loc == NULL_LOC and enforced_data_loc is None:
             raise X3dError("The input field to slice_max_sum does not have a valid f%data_loc.")
         loc = f.data_loc if enforced_data_loc is None else enforced_data_loc
-        mx, sm = ctypes.c_double(), ctypes.c_double()
+        mx, sm = _lib.REAL(), _lib.REAL()
         _lib.check(self.lib.x3d_slice_max_sum(self.h, f.ptr, self._dims(loc), f.dir, int(i_slice),
                                               ctypes.byref(mx), ctypes.byref(sm)))
         return mx.value, sm.value
@@ -891,7 +895,7 @@ class HipBackend:
             raise X3dError("You must set the data_loc before calling volume integral.")
         if f.dir != DIR_X:
             raise X3dError("Volume integral can only be called on DIR_X fields.")
-        out = ctypes.c_double()
+        out = _lib.REAL()
         _lib.check(self.lib.x3d_field_volume_integral(self.h, f.ptr, self._dims(f.data_loc), ctypes.byref(out)))
         return self.comm.allreduce(out.value, "sum")
 
@@ -918,7 +922,7 @@ class HipBackend:
         the extent is that of loc (default: f%data_loc, VERT if unset)."""
         loc = (f.data_loc if f.data_loc != NULL_LOC else 0) if loc is None else loc
         nx, ny, nz = self.mesh.get_dims(loc)
-        a = np.ascontiguousarray(data, dtype=np.float64)
+        a = np.ascontiguousarray(data, dtype=_lib.NP_REAL)
         if a.shape != (nz, ny, nx):
             raise X3dError(f"set_field_data: array shape {a.shape} != {(nz, ny, nx)}")
         _lib.check(self.lib.x3d_set_field_data(self.h, f.ptr, _dp(a), _lib.ints(nx, ny, nz)))
@@ -928,7 +932,7 @@ class HipBackend:
             hook()
         loc = (f.data_loc if f.data_loc != NULL_LOC else 0) if loc is None else loc
         nx, ny, nz = self.mesh.get_dims(loc)
-        out = np.empty((nz, ny, nx), dtype=np.float64)
+        out = np.empty((nz, ny, nx), dtype=_lib.NP_REAL)
         _lib.check(self.lib.x3d_get_field_data(self.h, _dp(out), f.ptr, _lib.ints(nx, ny, nz)))
         return out
 

@@ -85,13 +85,13 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     int npmax = b->ny * b->nz;
     if (b->nx * b->nz > npmax) npmax = b->nx * b->nz;
     if (b->nx * b->ny > npmax) npmax = b->nx * b->ny;
-    X3D_HIP(hipMalloc(&b->send_s, sizeof(double) * 3 * (size_t)npmax));
-    X3D_HIP(hipMalloc(&b->send_e, sizeof(double) * 3 * (size_t)npmax));
+    X3D_HIP(hipMalloc(&b->send_s, sizeof(real_t) * 3 * (size_t)npmax));
+    X3D_HIP(hipMalloc(&b->send_e, sizeof(real_t) * 3 * (size_t)npmax));
     for (int i = 0; i < 3; i++)
-        X3D_HIP(hipMalloc(&b->scratch[i], sizeof(double) * (b->nblock + 64 * (size_t)b->nxp)));
+        X3D_HIP(hipMalloc(&b->scratch[i], sizeof(real_t) * (b->nblock + 64 * (size_t)b->nxp)));
     b->red_cap = 4096;
-    X3D_HIP(hipMalloc(&b->red_buf, sizeof(double) * 2 * b->red_cap));
-    X3D_HIP(hipHostMalloc(&b->red_host, sizeof(double) * 2 * b->red_cap));
+    X3D_HIP(hipMalloc(&b->red_buf, sizeof(real_t) * 2 * b->red_cap));
+    X3D_HIP(hipHostMalloc(&b->red_host, sizeof(real_t) * 2 * b->red_cap));
     X3D_HIP(hipMalloc(&b->epi_dev, 256));
     b->lds_optin = new std::unordered_set<const void *>();
     X3D_HIP(hipEventCreate(&b->ev0));
@@ -177,25 +177,25 @@ extern "C" int x3d_device_sync(x3d_backend *b)
 // same memory channels (x3d2_amd/field.py has the measurement: -2 % per step at 512^3)
 // (process-wide table: several backends -- the twin backends of Poisson 100 / 110, one per host thread -- may
 // allocate and free at the same time)
-static std::unordered_map<double *, void *> g_block_base;
+static std::unordered_map<real_t *, void *> g_block_base;
 static int g_block_count = 0;
 static std::mutex g_block_mutex;
 
-extern "C" int x3d_block_alloc(x3d_backend *b, double **out)
+extern "C" int x3d_block_alloc(x3d_backend *b, real_t **out)
 {
     X3D_REQUIRE(b && out, "null argument");
     const size_t st = 528;
     void *base = nullptr;
     X3D_HIP(hipSetDevice(b->device));
-    X3D_HIP(hipMalloc(&base, sizeof(double) * (b->nblock + 16 * st)));
+    X3D_HIP(hipMalloc(&base, sizeof(real_t) * (b->nblock + 16 * st)));
     std::lock_guard<std::mutex> lock(g_block_mutex);
-    *out = static_cast<double *>(base) + (size_t)(g_block_count++ % 16) * st;
+    *out = static_cast<real_t *>(base) + (size_t)(g_block_count++ % 16) * st;
     g_block_base[*out] = base;
     x3d_lazy_register(b, *out);  // (a handle of the deferred-execution layer, should the caller switch it on)
     return 0;
 }
 
-extern "C" int x3d_block_free(x3d_backend *b, double *p)
+extern "C" int x3d_block_free(x3d_backend *b, real_t *p)
 {
     if (b) { X3D_LAZY_SYNC(b); x3d_lazy_unregister(b, p); }
     (void)b;
@@ -213,14 +213,14 @@ extern "C" int x3d_block_free(x3d_backend *b, double *p)
 
 // exchange buffers + host staging for callers whose MPI is not GPU-aware (the Fortran shim on more than one rank:
 // sendrecv_fields, src/backend/cuda/sendrecv.f90:13-42, through host memory)
-extern "C" int x3d_device_alloc(x3d_backend *b, double **out, long n)
+extern "C" int x3d_device_alloc(x3d_backend *b, real_t **out, long n)
 {
     X3D_REQUIRE(b && out && n > 0, "x3d_device_alloc: bad argument");
-    X3D_HIP(hipMalloc(reinterpret_cast<void **>(out), sizeof(double) * (size_t)n));
-    X3D_HIP(hipMemsetAsync(*out, 0, sizeof(double) * (size_t)n, b->stream));
+    X3D_HIP(hipMalloc(reinterpret_cast<void **>(out), sizeof(real_t) * (size_t)n));
+    X3D_HIP(hipMemsetAsync(*out, 0, sizeof(real_t) * (size_t)n, b->stream));
     return 0;
 }
-extern "C" int x3d_device_free(x3d_backend *b, double *p)
+extern "C" int x3d_device_free(x3d_backend *b, real_t *p)
 {
     (void)b;
     X3D_HIP(hipFree(p));
@@ -237,52 +237,52 @@ extern "C" int x3d_device_count(int *n)
     X3D_HIP(hipGetDeviceCount(n));
     return 0;
 }
-extern "C" int x3d_ipc_export(x3d_backend *b, const double *dev, unsigned char handle[64])
+extern "C" int x3d_ipc_export(x3d_backend *b, const real_t *dev, unsigned char handle[64])
 {
     X3D_REQUIRE(b && dev && handle, "x3d_ipc_export: null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     hipIpcMemHandle_t h;
-    X3D_HIP(hipIpcGetMemHandle(&h, const_cast<double *>(dev)));
+    X3D_HIP(hipIpcGetMemHandle(&h, const_cast<real_t *>(dev)));
     memcpy(handle, &h, 64);
     return 0;
 }
-extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], double **dev)
+extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], real_t **dev)
 {
     X3D_REQUIRE(b && dev && handle, "x3d_ipc_open: null argument");
     hipIpcMemHandle_t h;
     memcpy(&h, handle, 64);
     void *p = nullptr;
     X3D_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
-    *dev = static_cast<double *>(p);
+    *dev = static_cast<real_t *>(p);
     return 0;
 }
-extern "C" int x3d_ipc_close(x3d_backend *b, double *dev)
+extern "C" int x3d_ipc_close(x3d_backend *b, real_t *dev)
 {
     X3D_REQUIRE(b && dev, "x3d_ipc_close: null argument");
     X3D_HIP(hipIpcCloseMemHandle(dev));
     return 0;
 }
 // n doubles device to device (own or mapped memory), ordered on the backend's stream like a kernel; returns at once
-extern "C" int x3d_copy_device(x3d_backend *b, double *dst, const double *src, long n)
+extern "C" int x3d_copy_device(x3d_backend *b, real_t *dst, const real_t *src, long n)
 {
     X3D_REQUIRE(b && dst && src && n >= 0, "x3d_copy_device: bad argument");
     if (n == 0) return 0;
-    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(real_t) * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
 
 // ordered behind the kernels queued on the backend's stream; returns when the copy is complete
-extern "C" int x3d_copy_to_host(x3d_backend *b, double *host, const double *dev, long n)
+extern "C" int x3d_copy_to_host(x3d_backend *b, real_t *host, const real_t *dev, long n)
 {
     X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_host: bad argument");
-    X3D_HIP(hipMemcpyAsync(host, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    X3D_HIP(hipMemcpyAsync(host, dev, sizeof(real_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));
     return 0;
 }
-extern "C" int x3d_copy_to_device(x3d_backend *b, double *dev, const double *host, long n)
+extern "C" int x3d_copy_to_device(x3d_backend *b, real_t *dev, const real_t *host, long n)
 {
     X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_device: bad argument");
-    X3D_HIP(hipMemcpyAsync(dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->stream));
+    X3D_HIP(hipMemcpyAsync(dev, host, sizeof(real_t) * (size_t)n, hipMemcpyHostToDevice, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));  // (the host array may be reused at once)
     return 0;
 }
@@ -293,10 +293,10 @@ extern "C" int x3d_copy_to_device(x3d_backend *b, double *dev, const double *hos
 // fft_forward_100 / fft_backward_100, src/backend/cuda/poisson_fft.f90:482-616).  dst belongs to a backend of
 // the transposed dims: dst(y, x, z) = src(x, y, z) for x < nx, y < ny, z < nz; 32 x 32 tiles through LDS.
 // dst[c][a][b] = src[c][b][a] in terms of strides: a is the fast axis of src, b the fast axis of dst, c a batch
-__global__ void __launch_bounds__(256) k_transpose_ab(double *__restrict__ dst, const double *__restrict__ src, int na,
+__global__ void __launch_bounds__(256) k_transpose_ab(real_t *__restrict__ dst, const real_t *__restrict__ src, int na,
                                                       int nb, long s_b, long s_c, long d_a, long d_c)
 {
-    __shared__ double t[32][33];
+    __shared__ real_t t[32][33];
     const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32, c = blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8)
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) k_transpose_ab(double *__restrict__ dst, 
     for (int r = ty; r < 32; r += 8)
         if (b0 + tx < nb && a0 + r < na) dst[(long)c * d_c + (long)(a0 + r) * d_a + b0 + tx] = t[tx][r];
 }
-static int transpose_launch(x3d_backend *bs, double *dst, const double *src, int na, int nb, int nc, long s_b, long s_c,
+static int transpose_launch(x3d_backend *bs, real_t *dst, const real_t *src, int na, int nb, int nc, long s_b, long s_c,
                             long d_a, long d_c)
 {
     ProfScope ps(bs, X3D_K_COPY);
@@ -314,7 +314,7 @@ static int transpose_launch(x3d_backend *bs, double *dst, const double *src, int
     X3D_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny, int nz)
+extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny, int nz)
 {
     if (bs) X3D_LAZY_SYNC(bs);
     if (bd) X3D_LAZY_SYNC(bd);
@@ -330,7 +330,7 @@ extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, double *dst, c
 // Poisson 110: the reference moves z to the front (transpose_xyz_to_zxy / _zxy_to_xyz,
 // src/backend/cuda/kernels/spectral_processing.f90:78-125, called by fft_forward_110 / fft_backward_110) so that
 // the R2C runs along the periodic z: dst(z, x, y) = src(x, y, z); dst belongs to a backend of dims (nz, nx, ny)
-extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
+extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny,
                                      int nz)
 {
     if (bs) X3D_LAZY_SYNC(bs);
@@ -346,7 +346,7 @@ extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, double *d
                             (long)bd->nxp * bd->nyp);
 }
 // and back: dst(x, y, z) = src(z, x, y); src belongs to the backend of dims (nz, nx, ny)
-extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, double *dst, const double *src, int nx, int ny,
+extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny,
                                      int nz)
 {
     if (bs) X3D_LAZY_SYNC(bs);
@@ -366,13 +366,13 @@ extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, double *d
 // Whole padded blocks, like the reference (src/backend/omp/backend.f90:545-557):
 // streaming, 16 B per lane, grid-stride over at most 2048 workgroups.
 template <class F>
-__global__ void __launch_bounds__(256) k_map2(double2 *__restrict__ y, const double2 *__restrict__ x,
+__global__ void __launch_bounds__(256) k_map2(real2_t *__restrict__ y, const real2_t *__restrict__ x,
                                               size_t n2, F f)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += st) {
-        double2 a = x[i], c = y[i];
+        real2_t a = x[i], c = y[i];
         c.x = f(a.x, c.x);
         c.y = f(a.y, c.y);
         y[i] = c;
@@ -380,12 +380,12 @@ __global__ void __launch_bounds__(256) k_map2(double2 *__restrict__ y, const dou
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) k_map1(double2 *__restrict__ y, size_t n2, F f)
+__global__ void __launch_bounds__(256) k_map1(real2_t *__restrict__ y, size_t n2, F f)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += st) {
-        double2 c = y[i];
+        real2_t c = y[i];
         c.x = f(c.x);
         c.y = f(c.y);
         y[i] = c;
@@ -398,132 +398,132 @@ static inline int stream_grid(size_t n2)
     return (int)(g > 2048 ? 2048 : (g ? g : 1));
 }
 
-struct OpCopy { __device__ double operator()(double x, double) const { return x; } };
-struct OpAxpby { double a, b; __device__ double operator()(double x, double y) const { return a * x + b * y; } };
-struct OpMul { __device__ double operator()(double x, double y) const { return y * x; } };
-struct OpAdd { __device__ double operator()(double x, double y) const { return y + x; } };
-struct OpScale { double a; __device__ double operator()(double y) const { return a * y; } };
-struct OpShift { double a; __device__ double operator()(double y) const { return y + a; } };
-struct OpFill { double a; __device__ double operator()(double) const { return a; } };
+struct OpCopy { __device__ real_t operator()(real_t x, real_t) const { return x; } };
+struct OpAxpby { real_t a, b; __device__ real_t operator()(real_t x, real_t y) const { return a * x + b * y; } };
+struct OpMul { __device__ real_t operator()(real_t x, real_t y) const { return y * x; } };
+struct OpAdd { __device__ real_t operator()(real_t x, real_t y) const { return y + x; } };
+struct OpScale { real_t a; __device__ real_t operator()(real_t y) const { return a * y; } };
+struct OpShift { real_t a; __device__ real_t operator()(real_t y) const { return y + a; } };
+struct OpFill { real_t a; __device__ real_t operator()(real_t) const { return a; } };
 
-extern "C" int x3d_veccopy(x3d_backend *b, double *dst, const double *src)
+extern "C" int x3d_veccopy(x3d_backend *b, real_t *dst, const real_t *src)
 {
     X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_copy(b, dst, src);  // (recorded only after the eager path's checks)
     ProfScope ps(b, X3D_K_COPY);
-    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(real_t) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
 
-extern "C" int x3d_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
+extern "C" int x3d_vecadd(x3d_backend *b, real_t a, const real_t *x, real_t bb, real_t *y)
 {
     X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_vecadd(b, a, x, bb, y);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map2<OpAxpby>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
-                       (const double2 *)x, n2, OpAxpby{a, bb});
+    hipLaunchKernelGGL(k_map2<OpAxpby>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)y,
+                       (const real2_t *)x, n2, OpAxpby{a, bb});
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_vecmult(x3d_backend *b, double *y, const double *x)
+extern "C" int x3d_vecmult(x3d_backend *b, real_t *y, const real_t *x)
 {
     X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 0, y, x, 0.0);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map2<OpMul>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
-                       (const double2 *)x, n2, OpMul{});
+    hipLaunchKernelGGL(k_map2<OpMul>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)y,
+                       (const real2_t *)x, n2, OpMul{});
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 // compute_vorticity / compute_qcriterion (src/backend/omp/backend.f90:616-649): pointwise functions of the nine
 // velocity gradients, whole padded blocks like the reference.  g = {dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz}
-struct Grad9 { const double2 *g[9]; };
+struct Grad9 { const real2_t *g[9]; };
 template <bool QCRIT>
-__global__ void __launch_bounds__(256) k_from_gradients(double2 *__restrict__ out, Grad9 G, size_t n2)
+__global__ void __launch_bounds__(256) k_from_gradients(real2_t *__restrict__ out, Grad9 G, size_t n2)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += st) {
-        double2 v[9];
+        real2_t v[9];
 #pragma unroll
         for (int m = 0; m < 9; m++) v[m] = G.g[m][i];
-        auto f = [](double dudx, double dudy, double dudz, double dvdx, double dvdy, double dvdz, double dwdx,
-                    double dwdy, double dwdz) {
+        auto f = [](real_t dudx, real_t dudy, real_t dudz, real_t dvdx, real_t dvdy, real_t dvdz, real_t dwdx,
+                    real_t dwdy, real_t dwdz) -> real_t {
             if (QCRIT)
                 return -0.5 * (dudx * dudx + dvdy * dvdy + dwdz * dwdz) - dudy * dvdx - dudz * dwdx - dvdz * dwdy;
             return sqrt((dwdy - dvdz) * (dwdy - dvdz) + (dudz - dwdx) * (dudz - dwdx) +
                         (dvdx - dudy) * (dvdx - dudy));
         };
-        out[i] = make_double2(f(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x),
+        out[i] = make_real2(f(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x, v[8].x),
                               f(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y, v[8].y));
     }
 }
 
-static int from_gradients(x3d_backend *b, double *out, const double *const g[9], bool qcrit)
+static int from_gradients(x3d_backend *b, real_t *out, const real_t *const g[9], bool qcrit)
 {
     X3D_REQUIRE(b && out && g, "derive_field_from_gradients: null argument");
     Grad9 G;
     for (int m = 0; m < 9; m++) {
         X3D_REQUIRE(g[m] && g[m] != out, "derive_field_from_gradients: bad gradient block %d", m);
-        G.g[m] = (const double2 *)g[m];
+        G.g[m] = (const real2_t *)g[m];
     }
     ProfScope ps(b, X3D_K_BLAS1);
     const size_t n2 = b->nblock / 2;
-    if (qcrit) hipLaunchKernelGGL(k_from_gradients<true>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)out, G, n2);
-    else hipLaunchKernelGGL(k_from_gradients<false>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)out, G, n2);
+    if (qcrit) hipLaunchKernelGGL(k_from_gradients<true>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)out, G, n2);
+    else hipLaunchKernelGGL(k_from_gradients<false>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)out, G, n2);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_compute_vorticity(x3d_backend *b, double *out, const double *const grads[9])
+extern "C" int x3d_compute_vorticity(x3d_backend *b, real_t *out, const real_t *const grads[9])
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, false);
 }
 
-extern "C" int x3d_compute_qcriterion(x3d_backend *b, double *out, const double *const grads[9])
+extern "C" int x3d_compute_qcriterion(x3d_backend *b, real_t *out, const real_t *const grads[9])
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, true);
 }
 
-extern "C" int x3d_field_scale(x3d_backend *b, double *f, double a)
+extern "C" int x3d_field_scale(x3d_backend *b, real_t *f, real_t a)
 {
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 1, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map1<OpScale>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+    hipLaunchKernelGGL(k_map1<OpScale>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)f, n2,
                        OpScale{a});
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_field_shift(x3d_backend *b, double *f, double a)
+extern "C" int x3d_field_shift(x3d_backend *b, real_t *f, real_t a)
 {
     X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 2, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map1<OpShift>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+    hipLaunchKernelGGL(k_map1<OpShift>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)f, n2,
                        OpShift{a});
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
+extern "C" int x3d_block_fill(x3d_backend *b, real_t *f, real_t c)
 {
     X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 3, f, nullptr, c);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map1<OpFill>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)f, n2,
+    hipLaunchKernelGGL(k_map1<OpFill>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)f, n2,
                        OpFill{c});
     X3D_HIP(hipGetLastError());
     return 0;
@@ -531,7 +531,7 @@ extern "C" int x3d_block_fill(x3d_backend *b, double *f, double c)
 
 // reorder: every DIR_* tag shares one physical layout -> a device copy.
 // (reference: src/backend/omp/backend.f90:393-452; codes src/common.f90:23-26)
-extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
+extern "C" int x3d_reorder(x3d_backend *b, real_t *u_, const real_t *u, int rdr)
 {
     X3D_REQUIRE(b && u_ && u, "x3d_reorder: null argument");
     int from = rdr / 10, to = rdr % 10;
@@ -540,56 +540,56 @@ extern "C" int x3d_reorder(x3d_backend *b, double *u_, const double *u, int rdr)
     if (x3d_lazy_active(b)) return x3d_lazy_copy(b, u_, u);
     if (u_ == u) return 0;
     ProfScope ps(b, X3D_K_COPY);
-    X3D_HIP(hipMemcpyAsync(u_, u, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    X3D_HIP(hipMemcpyAsync(u_, u, sizeof(real_t) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
 
 // sum_yintox / sum_zintox: u += u_ (src/backend/omp/backend.f90:454-527)
-extern "C" int x3d_sum_intox(x3d_backend *b, double *u, const double *u_, int dir_from)
+extern "C" int x3d_sum_intox(x3d_backend *b, real_t *u, const real_t *u_, int dir_from)
 {
     X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
     X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
     if (x3d_lazy_active(b)) return x3d_lazy_sum(b, u, u_, dir_from);
     ProfScope ps(b, X3D_K_BLAS1);
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_map2<OpAdd>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)u,
-                       (const double2 *)u_, n2, OpAdd{});
+    hipLaunchKernelGGL(k_map2<OpAdd>, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)u,
+                       (const real2_t *)u_, n2, OpAdd{});
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 // y = base + sum_i c[i] * x[i]  (one pass instead of a veccopy/vecadd chain)
 struct LinArgs {
-    const double2 *x[5];
-    double c[5];
+    const real2_t *x[5];
+    real_t c[5];
     int n;
 };
 
-__global__ void __launch_bounds__(256) k_lincomb(double2 *__restrict__ y, const double2 *base, size_t n2,
+__global__ void __launch_bounds__(256) k_lincomb(real2_t *__restrict__ y, const real2_t *base, size_t n2,
                                                  LinArgs a)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += st) {
-        // streamed once: nontemporal (double2 has no builtin overload: two 8-byte accesses fuse back to 16)
-        const double *bp = reinterpret_cast<const double *>(base + i);
-        double2 r = make_double2(__builtin_nontemporal_load(bp), __builtin_nontemporal_load(bp + 1));
+        // streamed once: nontemporal (real2_t has no builtin overload: two 8-byte accesses fuse back to 16)
+        const real_t *bp = reinterpret_cast<const real_t *>(base + i);
+        real2_t r = make_real2(__builtin_nontemporal_load(bp), __builtin_nontemporal_load(bp + 1));
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (k < a.n) {
-                const double *xp = reinterpret_cast<const double *>(a.x[k] + i);
-                const double vx = __builtin_nontemporal_load(xp), vy = __builtin_nontemporal_load(xp + 1);
+                const real_t *xp = reinterpret_cast<const real_t *>(a.x[k] + i);
+                const real_t vx = __builtin_nontemporal_load(xp), vy = __builtin_nontemporal_load(xp + 1);
                 r.x = a.c[k] * vx + r.x;
                 r.y = a.c[k] * vy + r.y;
             }
-        double *yp = reinterpret_cast<double *>(y + i);
+        real_t *yp = reinterpret_cast<real_t *>(y + i);
         __builtin_nontemporal_store(r.x, yp);
         __builtin_nontemporal_store(r.y, yp + 1);
     }
 }
 
-extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
-                           const double *const *x)
+extern "C" int x3d_lincomb(x3d_backend *b, real_t *y, const real_t *base, int nterm, const real_t *c,
+                           const real_t *const *x)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -599,12 +599,12 @@ extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nt
     LinArgs a;
     a.n = nterm;
     for (int k = 0; k < 5; k++) {
-        a.x[k] = (const double2 *)(k < nterm ? x[k] : x[0]);
+        a.x[k] = (const real2_t *)(k < nterm ? x[k] : x[0]);
         a.c[k] = k < nterm ? c[k] : 0.0;
     }
     size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_lincomb, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (double2 *)y,
-                       (const double2 *)base, n2, a);
+    hipLaunchKernelGGL(k_lincomb, dim3(stream_grid(n2)), dim3(256), 0, b->stream, (real2_t *)y,
+                       (const real2_t *)base, n2, a);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -615,19 +615,19 @@ extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nt
 enum { RED_DOT = 0, RED_ABS = 1, RED_SUM = 2 };
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k_reduce(const double *__restrict__ x, const double *__restrict__ y,
+__global__ void __launch_bounds__(256) k_reduce(const real_t *__restrict__ x, const real_t *__restrict__ y,
                                                 int nx, int ny, int nz, long nxp, long nyp,
-                                                double *__restrict__ part_sum,
-                                                double *__restrict__ part_max)
+                                                real_t *__restrict__ part_sum,
+                                                real_t *__restrict__ part_max)
 {
-    __shared__ double ssum[4], smax[4];
-    double s = 0.0, m = 0.0;
+    __shared__ real_t ssum[4], smax[4];
+    real_t s = 0.0, m = 0.0;
     const long nrow = (long)ny * nz;
     for (long r = blockIdx.x; r < nrow; r += gridDim.x) {
         const long j = r % ny, k = r / ny;
         const long off = nxp * (j + nyp * k);
         for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-            double v = x[off + i];
+            real_t v = x[off + i];
             if (MODE == RED_DOT) s += v * y[off + i];
             else if (MODE == RED_ABS) { v = fabs(v); s += v; m = fmax(m, v); }
             else s += v;
@@ -647,8 +647,8 @@ __global__ void __launch_bounds__(256) k_reduce(const double *__restrict__ x, co
 }
 
 template <int MODE>
-static int run_reduce(x3d_backend *b, const double *x, const double *y, const int dims[3], double *sum,
-                      double *mx)
+static int run_reduce(x3d_backend *b, const real_t *x, const real_t *y, const int dims[3], real_t *sum,
+                      real_t *mx)
 {
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 &&
                     dims[2] <= b->nzp,
@@ -659,10 +659,10 @@ static int run_reduce(x3d_backend *b, const double *x, const double *y, const in
     hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(256), 0, b->stream, x, y, dims[0], dims[1], dims[2],
                        (long)b->nxp, (long)b->nyp, b->red_buf, b->red_buf + b->red_cap);
     X3D_HIP(hipGetLastError());
-    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(double) * 2 * b->red_cap, hipMemcpyDeviceToHost,
+    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(real_t) * 2 * b->red_cap, hipMemcpyDeviceToHost,
                            b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));
-    double s = 0.0, m = 0.0;
+    real_t s = 0.0, m = 0.0;
     for (int i = 0; i < grid; i++) {
         s += b->red_host[i];
         m = fmax(m, b->red_host[b->red_cap + i]);
@@ -672,8 +672,8 @@ static int run_reduce(x3d_backend *b, const double *x, const double *y, const in
     return 0;
 }
 
-extern "C" int x3d_scalar_product(x3d_backend *b, const double *x, const double *y, const int dims[3],
-                                  double *out)
+extern "C" int x3d_scalar_product(x3d_backend *b, const real_t *x, const real_t *y, const int dims[3],
+                                  real_t *out)
 {
     if (b) { X3D_LAZY_IN(b, x); X3D_LAZY_IN(b, y); }
     X3D_LAZY_EAGER(b);
@@ -681,8 +681,8 @@ extern "C" int x3d_scalar_product(x3d_backend *b, const double *x, const double 
     return run_reduce<RED_DOT>(b, x, y, dims, out, nullptr);
 }
 
-extern "C" int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims[3], double *max_abs,
-                                 double *sum_abs)
+extern "C" int x3d_field_max_sum(x3d_backend *b, const real_t *f, const int dims[3], real_t *max_abs,
+                                 real_t *sum_abs)
 {
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
@@ -690,7 +690,7 @@ extern "C" int x3d_field_max_sum(x3d_backend *b, const double *f, const int dims
     return run_reduce<RED_ABS>(b, f, f, dims, sum_abs, max_abs);
 }
 
-extern "C" int x3d_field_volume_integral(x3d_backend *b, const double *f, const int dims[3], double *out)
+extern "C" int x3d_field_volume_integral(x3d_backend *b, const real_t *f, const int dims[3], real_t *out)
 {
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
@@ -705,26 +705,26 @@ extern "C" int x3d_field_volume_integral(x3d_backend *b, const double *f, const 
 //   x3d_field_shift_to_mean: the partial sums stay on the device, one thread adds them in the order the host
 //     would (bit-identical to x3d_field_volume_integral + x3d_field_shift), the shift kernel reads the result;
 //   x3d_wall_noise: the two wall planes are generated in place by a counter-based generator.
-__global__ void k_finish_shift(const double *__restrict__ part, int n, double ncell, double target,
-                               double *__restrict__ out)
+__global__ void k_finish_shift(const real_t *__restrict__ part, int n, real_t ncell, real_t target,
+                               real_t *__restrict__ out)
 {
     // (the partials come in through LDS with all lanes: one thread chasing 2048 dependent global loads took 0.12 ms)
-    __shared__ double sp[2048];
+    __shared__ real_t sp[2048];
     for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = part[i];
     __syncthreads();
     if (threadIdx.x == 0) {
-        double s = 0.0;
+        real_t s = 0.0;
         for (int i = 0; i < n; i++) s += sp[i];    // the order of run_reduce's host loop
         out[0] = target - s / ncell;               // can = 2/3 - ub, src/case/channel.f90:70-77
         out[1] = s;
     }
 }
 
-__global__ void __launch_bounds__(256) k_shift_dev(double2 *__restrict__ f, size_t n2, const double *__restrict__ a)
+__global__ void __launch_bounds__(256) k_shift_dev(real2_t *__restrict__ f, size_t n2, const real_t *__restrict__ a)
 {
-    const double sh = a[0];
+    const real_t sh = a[0];
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        double2 v = f[i];
+        real2_t v = f[i];
         v.x += sh; v.y += sh;
         f[i] = v;
     }
@@ -735,8 +735,8 @@ __global__ void __launch_bounds__(256) k_shift_dev(double2 *__restrict__ f, size
 // (the entry points below translate their field ONCE -- a translated pointer must not be translated again: the buffer that
 //  holds a handle's data is usually another handle's own block -- and run at once: X3D_LAZY_IN / _OUT, no copies; a queue
 //  flushed through X3D_LAZY_SYNC here cost the channel case five block copies per sub-step, round 4)
-static int mean_shift_impl(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
-                           const double **shift)
+static int mean_shift_impl(x3d_backend *b, const real_t *f, const int dims[3], real_t ncell, real_t target,
+                           const real_t **shift)
 {
     X3D_REQUIRE(b && f && dims && ncell > 0.0 && shift, "x3d_field_mean_shift: bad argument");
     X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
@@ -746,15 +746,15 @@ static int mean_shift_impl(x3d_backend *b, const double *f, const int dims[3], d
     ProfScope ps(b, X3D_K_REDUCE);
     hipLaunchKernelGGL(k_reduce<RED_SUM>, dim3(grid), dim3(256), 0, b->stream, f, f, dims[0], dims[1], dims[2],
                        (long)b->nxp, (long)b->nyp, b->red_buf, b->red_buf + b->red_cap);
-    hipLaunchKernelGGL(k_finish_shift, dim3(1), dim3(256), 0, b->stream, (const double *)b->red_buf, grid, ncell, target,
+    hipLaunchKernelGGL(k_finish_shift, dim3(1), dim3(256), 0, b->stream, (const real_t *)b->red_buf, grid, ncell, target,
                        b->red_buf + 2 * b->red_cap - 2);
     X3D_HIP(hipGetLastError());
     *shift = b->red_buf + 2 * b->red_cap - 2;
     return 0;
 }
 
-extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int dims[3], double ncell, double target,
-                                    const double **shift)
+extern "C" int x3d_field_mean_shift(x3d_backend *b, const real_t *f, const int dims[3], real_t ncell, real_t target,
+                                    const real_t **shift)
 {
     X3D_REQUIRE(b && f, "x3d_field_mean_shift: bad argument");
     X3D_LAZY_IN(b, f);
@@ -762,17 +762,17 @@ extern "C" int x3d_field_mean_shift(x3d_backend *b, const double *f, const int d
     return mean_shift_impl(b, f, dims, ncell, target, shift);
 }
 
-static int shift_by_impl(x3d_backend *b, double *f, const double *shift)
+static int shift_by_impl(x3d_backend *b, real_t *f, const real_t *shift)
 {
     X3D_REQUIRE(b && f && shift, "x3d_field_shift_by: null argument");
     ProfScope ps(b, X3D_K_BLAS1);
     const size_t n2 = b->nblock / 2;
-    hipLaunchKernelGGL(k_shift_dev, dim3(2048), dim3(256), 0, b->stream, (double2 *)f, n2, shift);
+    hipLaunchKernelGGL(k_shift_dev, dim3(2048), dim3(256), 0, b->stream, (real2_t *)f, n2, shift);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift)
+extern "C" int x3d_field_shift_by(x3d_backend *b, real_t *f, const real_t *shift)
 {
     X3D_REQUIRE(b && f, "x3d_field_shift_by: null argument");
     X3D_LAZY_OUT(b, f, false);
@@ -780,12 +780,12 @@ extern "C" int x3d_field_shift_by(x3d_backend *b, double *f, const double *shift
     return shift_by_impl(b, f, shift);
 }
 
-extern "C" int x3d_field_shift_to_mean(x3d_backend *b, double *f, const int dims[3], double ncell, double target)
+extern "C" int x3d_field_shift_to_mean(x3d_backend *b, real_t *f, const int dims[3], real_t ncell, real_t target)
 {
     X3D_REQUIRE(b && f, "x3d_field_shift_to_mean: bad argument");
     X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
-    const double *shift = nullptr;
+    const real_t *shift = nullptr;
     if (int rc = mean_shift_impl(b, f, dims, ncell, target, &shift)) return rc;
     return shift_by_impl(b, f, shift);
 }
@@ -801,19 +801,19 @@ __host__ __device__ inline unsigned long long x3d_mix64(unsigned long long z)
 
 // planes y = 1 and y = ny of f <- amp * (2 r - 1), r uniform in [0, 1) with 53 random bits:
 // r(face, i, k) = mix64(mix64(seed + draw) + (face * nz + k) * nx + i) >> 11) * 2^-53
-__global__ void __launch_bounds__(256) k_wall_noise(double *__restrict__ f, int nx, int ny, int nz, long nxp, long nyp,
-                                                    double amp, unsigned long long key)
+__global__ void __launch_bounds__(256) k_wall_noise(real_t *__restrict__ f, int nx, int ny, int nz, long nxp, long nyp,
+                                                    real_t amp, unsigned long long key)
 {
     const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (q >= 2L * nx * nz) return;
     const int face = (int)(q / ((long)nx * nz));
     const long r = q - (long)face * nx * nz;
     const int i = (int)(r % nx), k = (int)(r / nx);
-    const double u01 = (double)(x3d_mix64(key + (unsigned long long)q) >> 11) * 0x1.0p-53;
+    const real_t u01 = (real_t)(x3d_mix64(key + (unsigned long long)q) >> 11) * 0x1.0p-53;
     f[i + nxp * ((face ? ny - 1 : 0) + nyp * (long)k)] = amp * (2.0 * u01 - 1.0);
 }
 
-extern "C" int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], double amp, unsigned long long seed,
+extern "C" int x3d_wall_noise(x3d_backend *b, real_t *f, const int dims[3], real_t amp, unsigned long long seed,
                               unsigned long long draw)
 {
     X3D_REQUIRE(b && f && dims, "x3d_wall_noise: null argument");
@@ -830,15 +830,15 @@ extern "C" int x3d_wall_noise(x3d_backend *b, double *f, const int dims[3], doub
 }
 
 // slice_max_sum: signed max and sum over the plane i_slice of direction dir
-__global__ void __launch_bounds__(256) k_slice(const double *__restrict__ f, int n0, int n1, long s0, long s1,
-                                               long off, double *__restrict__ part_sum,
-                                               double *__restrict__ part_max)
+__global__ void __launch_bounds__(256) k_slice(const real_t *__restrict__ f, int n0, int n1, long s0, long s1,
+                                               long off, real_t *__restrict__ part_sum,
+                                               real_t *__restrict__ part_max)
 {
-    __shared__ double ssum[4], smax[4];
-    double s = 0.0, m = -HUGE_VAL;
+    __shared__ real_t ssum[4], smax[4];
+    real_t s = 0.0, m = -HUGE_VAL;
     const long n = (long)n0 * n1;
     for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
-        double v = f[off + (q % n0) * s0 + (q / n0) * s1];
+        real_t v = f[off + (q % n0) * s0 + (q / n0) * s1];
         s += v;
         m = fmax(m, v);
     }
@@ -855,8 +855,8 @@ __global__ void __launch_bounds__(256) k_slice(const double *__restrict__ f, int
     }
 }
 
-extern "C" int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims[3], int dir, int i_slice,
-                                 double *max_val, double *sum_val)
+extern "C" int x3d_slice_max_sum(x3d_backend *b, const real_t *f, const int dims[3], int dir, int i_slice,
+                                 real_t *max_val, real_t *sum_val)
 {
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
@@ -873,10 +873,10 @@ extern "C" int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims
     hipLaunchKernelGGL(k_slice, dim3(grid), dim3(256), 0, b->stream, f, n0, n1, s0, s1, off, b->red_buf,
                        b->red_buf + b->red_cap);
     X3D_HIP(hipGetLastError());
-    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(double) * 2 * b->red_cap, hipMemcpyDeviceToHost,
+    X3D_HIP(hipMemcpyAsync(b->red_host, b->red_buf, sizeof(real_t) * 2 * b->red_cap, hipMemcpyDeviceToHost,
                            b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));
-    double s = 0.0, m = -HUGE_VAL;
+    real_t s = 0.0, m = -HUGE_VAL;
     for (int i = 0; i < grid; i++) {
         s += b->red_host[i];
         m = fmax(m, b->red_host[b->red_cap + i]);
@@ -889,8 +889,8 @@ extern "C" int x3d_slice_max_sum(x3d_backend *b, const double *f, const int dims
 // ---------------------------------------------------------------- faces
 // field_set_face(Y_FACE): plane y=1 <- c_start, plane y=ny <- c_end
 // (src/backend/omp/backend.f90:903-952; only Y_FACE is supported there).
-__global__ void k_set_face_y(double *__restrict__ f, const double *__restrict__ src, int nx, int ny, int nz,
-                             long nxp, long nyp, double c_start, double c_end, int from_field)
+__global__ void k_set_face_y(real_t *__restrict__ f, const real_t *__restrict__ src, int nx, int ny, int nz,
+                             long nxp, long nyp, real_t c_start, real_t c_end, int from_field)
 {
     long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (q >= (long)nx * nz) return;
@@ -902,19 +902,19 @@ __global__ void k_set_face_y(double *__restrict__ f, const double *__restrict__ 
 
 // field_set_face_from_field(X_FACE): inflow plane from f_start, convective
 // outflow at x = nx (src/backend/omp/backend.f90:978-1003)
-__global__ void k_set_face_x_from(double *__restrict__ f, const double *__restrict__ src, int nx, int ny,
-                                  int nz, long nxp, long nyp, double c_end, double frd)
+__global__ void k_set_face_x_from(real_t *__restrict__ f, const real_t *__restrict__ src, int nx, int ny,
+                                  int nz, long nxp, long nyp, real_t c_end, real_t frd)
 {
     long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (q >= (long)ny * nz) return;
     long j = q % ny, k = q / ny;
     long row = nxp * (j + nyp * k);
     f[row] = src[row];
-    double fd = f[row + nx - 1], fd1 = f[row + nx - 2];
+    real_t fd = f[row + nx - 1], fd1 = f[row + nx - 2];
     f[row + nx - 1] = fd - c_end * (fd - fd1) + frd;
 }
 
-extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], double c_start, double c_end,
+extern "C" int x3d_field_set_face(x3d_backend *b, real_t *f, const int dims[3], real_t c_start, real_t c_end,
                                   int face)
 {
     if (b) X3D_LAZY_OUT(b, f, false);
@@ -924,14 +924,14 @@ extern "C" int x3d_field_set_face(x3d_backend *b, double *f, const int dims[3], 
     X3D_REQUIRE(face != X3D_Z_FACE, "Setting Z_FACE is not yet supported.");
     X3D_REQUIRE(face == X3D_Y_FACE, "face is undefined.");
     long n = (long)dims[0] * dims[2];
-    hipLaunchKernelGGL(k_set_face_y, dim3((n + 255) / 256), dim3(256), 0, b->stream, f, (const double *)nullptr,
+    hipLaunchKernelGGL(k_set_face_y, dim3((n + 255) / 256), dim3(256), 0, b->stream, f, (const real_t *)nullptr,
                        dims[0], dims[1], dims[2], (long)b->nxp, (long)b->nyp, c_start, c_end, 0);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
-                                             double c_end, int face, double flow_rate_diff)
+extern "C" int x3d_field_set_face_from_field(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3],
+                                             real_t c_end, int face, real_t flow_rate_diff)
 {
     if (b && x3d_lazy_active(b) && face == X3D_Y_FACE) {  // recorded (the RK stage before it and the x operator behind it fuse)
         X3D_REQUIRE(f && f_start && dims, "x3d_field_set_face_from_field: null argument");
@@ -958,7 +958,7 @@ extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const do
 }
 
 // ---------------------------------------------------------------- host <-> field
-extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host, const int dims[3])
+extern "C" int x3d_set_field_data(x3d_backend *b, real_t *f, const real_t *host, const int dims[3])
 {
     if (b) X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
@@ -966,7 +966,7 @@ extern "C" int x3d_set_field_data(x3d_backend *b, double *f, const double *host,
     return x3d_set_field_data_pitched(b, f, host, dims[0], dims[1], dims);
 }
 
-extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f, const int dims[3])
+extern "C" int x3d_get_field_data(x3d_backend *b, real_t *host, const real_t *f, const int dims[3])
 {
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
@@ -974,7 +974,7 @@ extern "C" int x3d_get_field_data(x3d_backend *b, double *host, const double *f,
     return x3d_get_field_data_pitched(b, host, f, dims[0], dims[1], dims);
 }
 
-extern "C" int x3d_set_field_data_pitched(x3d_backend *b, double *f, const double *host, int hx, int hy,
+extern "C" int x3d_set_field_data_pitched(x3d_backend *b, real_t *f, const real_t *host, int hx, int hy,
                                           const int dims[3])
 {
     if (b) X3D_LAZY_OUT(b, f, false);
@@ -984,16 +984,16 @@ extern "C" int x3d_set_field_data_pitched(x3d_backend *b, double *f, const doubl
                 "x3d_set_field_data: dims exceed the block");
     hipMemcpy3DParms p;
     memset(&p, 0, sizeof p);
-    p.srcPtr = make_hipPitchedPtr((void *)host, sizeof(double) * hx, hx, hy);
-    p.dstPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
-    p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
+    p.srcPtr = make_hipPitchedPtr((void *)host, sizeof(real_t) * hx, hx, hy);
+    p.dstPtr = make_hipPitchedPtr((void *)f, sizeof(real_t) * b->nxp, b->nxp, b->nyp);
+    p.extent = make_hipExtent(sizeof(real_t) * dims[0], dims[1], dims[2]);
     p.kind = hipMemcpyHostToDevice;
     X3D_HIP(hipMemcpy3DAsync(&p, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));
     return 0;
 }
 
-extern "C" int x3d_get_field_data_pitched(x3d_backend *b, double *host, const double *f, int hx, int hy,
+extern "C" int x3d_get_field_data_pitched(x3d_backend *b, real_t *host, const real_t *f, int hx, int hy,
                                           const int dims[3])
 {
     if (b) X3D_LAZY_IN(b, f);
@@ -1003,9 +1003,9 @@ extern "C" int x3d_get_field_data_pitched(x3d_backend *b, double *host, const do
                 "x3d_get_field_data: dims exceed the block");
     hipMemcpy3DParms p;
     memset(&p, 0, sizeof p);
-    p.srcPtr = make_hipPitchedPtr((void *)f, sizeof(double) * b->nxp, b->nxp, b->nyp);
-    p.dstPtr = make_hipPitchedPtr((void *)host, sizeof(double) * hx, hx, hy);
-    p.extent = make_hipExtent(sizeof(double) * dims[0], dims[1], dims[2]);
+    p.srcPtr = make_hipPitchedPtr((void *)f, sizeof(real_t) * b->nxp, b->nxp, b->nyp);
+    p.dstPtr = make_hipPitchedPtr((void *)host, sizeof(real_t) * hx, hx, hy);
+    p.extent = make_hipExtent(sizeof(real_t) * dims[0], dims[1], dims[2]);
     p.kind = hipMemcpyDeviceToHost;
     X3D_HIP(hipMemcpy3DAsync(&p, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));

@@ -9,6 +9,39 @@
 
 #include "../../include/x3d2_hip.h"
 
+// the real kind of every field, table, scalar and transform (x3d_real of the public header): FP64, or FP32 with
+// -DX3D_SINGLE_PREC (the reference's -DSINGLE_PREC, src/common.f90:6-12)
+typedef x3d_real real_t;
+#ifdef X3D_SINGLE_PREC
+typedef float2 real2_t;
+#define make_real2 make_float2
+#else
+typedef double2 real2_t;
+#define make_real2 make_double2
+#endif
+// hipFFT's names for the real kind's transforms (the Poisson solvers' rocFFT plans)
+#ifdef X3D_SINGLE_PREC
+#define X3D_FFT_R2C HIPFFT_R2C
+#define X3D_FFT_C2R HIPFFT_C2R
+#define X3D_FFT_C2C HIPFFT_C2C
+#define x3d_fftExecR2C hipfftExecR2C
+#define x3d_fftExecC2R hipfftExecC2R
+#define x3d_fftExecC2C hipfftExecC2C
+#define x3d_fft_real hipfftReal
+#define x3d_fft_cplx hipfftComplex
+#else
+#define X3D_FFT_R2C HIPFFT_D2Z
+#define X3D_FFT_C2R HIPFFT_Z2D
+#define X3D_FFT_C2C HIPFFT_Z2Z
+#define x3d_fftExecR2C hipfftExecD2Z
+#define x3d_fftExecC2R hipfftExecZ2D
+#define x3d_fftExecC2C hipfftExecZ2Z
+#define x3d_fft_real hipfftDoubleReal
+#define x3d_fft_cplx hipfftDoubleComplex
+#endif
+typedef double x3d_f64;                // (where FP64 is meant whatever the real kind: twiddle generation, timers)
+#define X3D_RB ((int)sizeof(real_t))  // bytes per real
+
 #define X3D_NH 4
 
 void x3d_set_error(const char *fmt, ...);
@@ -43,20 +76,20 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // Streaming accesses (round 4).  A flat copy on this chip reaches 6.2 TB/s only with NONTEMPORAL 16-byte loads and
 // stores (5.6 with plain ones: profiles/r04_copy_ceiling.txt); every field row of the derivative kernels is read once
-// and written once per launch, so their global accesses carry the hint.  The builtin has no overload for HIP's double2
+// and written once per launch, so their global accesses carry the hint.  The builtin has no overload for HIP's real2_t
 // struct -- through an ext_vector_type the access stays ONE global_load_dwordx4 ... nt (two 8-byte builtins do not
 // always fuse back).  -DX3D_NO_NT: plain accesses (A/B builds).
-typedef double x3d_d2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 ldg_stream(const double2 *p)
+typedef real_t x3d_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ real2_t ldg_stream(const real2_t *p)
 {
 #ifndef X3D_NO_NT
     const x3d_d2v v = __builtin_nontemporal_load(reinterpret_cast<const x3d_d2v *>(p));
-    return make_double2(v.x, v.y);
+    return make_real2(v.x, v.y);
 #else
     return *p;
 #endif
 }
-__device__ __forceinline__ void stg_stream(double2 *p, double2 v)
+__device__ __forceinline__ void stg_stream(real2_t *p, real2_t v)
 {
 #ifndef X3D_NO_NT
     const x3d_d2v w = {v.x, v.y};
@@ -104,13 +137,13 @@ struct x3d_backend {
     size_t nblock;      // elements per block
     // boundary-value exchange buffers for the local (non-decomposed) forms:
     // [3 ops][npencil_max] each
-    double *send_s, *send_e;
+    real_t *send_s, *send_e;
     // two scratch blocks for the transeq intermediates (dud, d2u):
     // transeq_dist_component gets the same two from the pool,
     // src/backend/omp/backend.f90:319-320
-    double *scratch[3];  // + slack of 64 rows: x-direction kernels keep them wave-transposed
-    double *red_buf;  // reduction partials (device)
-    double *red_host; // pinned host landing zone
+    real_t *scratch[3];  // + slack of 64 rows: x-direction kernels keep them wave-transposed
+    real_t *red_buf;  // reduction partials (device)
+    real_t *red_host; // pinned host landing zone
     int red_cap;
     long n_upd;       // ... of those, launches that also applied the pending velocity correction (UPD form)
     long n_tq3;       // launches of the three-components-in-one transeq kernels (bench.py prices them at 48 B/DoF)
@@ -142,24 +175,24 @@ static inline int x3d_persistent_blocks(const x3d_backend *b, long want)
 // (X3D_LAZY_IN / X3D_LAZY_OUT: flush the queue, translate), or first restores the identity map (X3D_LAZY_SYNC).
 bool x3d_lazy_active(const x3d_backend *b);
 void x3d_lazy_destroy(x3d_backend *b);
-void x3d_lazy_register(x3d_backend *b, double *h);
-void x3d_lazy_unregister(x3d_backend *b, double *h);
+void x3d_lazy_register(x3d_backend *b, real_t *h);
+void x3d_lazy_unregister(x3d_backend *b, real_t *h);
 int x3d_lazy_flush_c(x3d_backend *b);
 int x3d_lazy_sync_c(x3d_backend *b);
-int x3d_lazy_in(x3d_backend *b, const double *h, const double **out);
-int x3d_lazy_out(x3d_backend *b, double *h, bool full, double **out);
-int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
-                     const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
+int x3d_lazy_in(x3d_backend *b, const real_t *h, const real_t **out);
+int x3d_lazy_out(x3d_backend *b, real_t *h, bool full, real_t **out);
+int x3d_lazy_transeq(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u, const real_t *v,
+                     const real_t *w, real_t nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
                      const x3d_tdsops *t3);
-int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir);
-int x3d_lazy_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+int x3d_lazy_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir);
+int x3d_lazy_species(x3d_backend *b, int dir, real_t *dspec, const real_t *uvw, const real_t *spec, real_t nu,
                      const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2, int accumulate);
-int x3d_lazy_copy(x3d_backend *b, double *dst, const double *src);
-int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir);
-int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y);
-int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double a);  // 0 vecmult, 1 scale, 2 shift, 3 fill
-int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f);               // 0 forward, 1 postprocess_000, 2 backward
-int x3d_lazy_setface(x3d_backend *b, double *f, const double *f_start, const int dims[3]);  // field_set_face_from_field(Y_FACE)
+int x3d_lazy_copy(x3d_backend *b, real_t *dst, const real_t *src);
+int x3d_lazy_sum(x3d_backend *b, real_t *u, const real_t *u_, int dir);
+int x3d_lazy_vecadd(x3d_backend *b, real_t a, const real_t *x, real_t bb, real_t *y);
+int x3d_lazy_unary(x3d_backend *b, int kind, real_t *f, const real_t *x, real_t a);  // 0 vecmult, 1 scale, 2 shift, 3 fill
+int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, real_t *f);               // 0 forward, 1 postprocess_000, 2 backward
+int x3d_lazy_setface(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3]);  // field_set_face_from_field(Y_FACE)
 // an entry point that runs at once while the mode is on: nothing it calls may be recorded (or have its -- already
 // translated -- pointers translated again) until it returns
 bool x3d_lazy_set_executing(x3d_backend *b, bool on);  // returns the previous state
@@ -188,7 +221,7 @@ struct LazyScope {
 #define X3D_LAZY_IN(b, ptr)                                                                    \
     do {                                                                                       \
         if ((b)->lazy) {                                                                       \
-            const double *q_ = nullptr;                                                        \
+            const real_t *q_ = nullptr;                                                        \
             if (int rc_ = x3d_lazy_in((b), (ptr), &q_)) return rc_;                            \
             (ptr) = q_;                                                                        \
         }                                                                                      \
@@ -196,7 +229,7 @@ struct LazyScope {
 #define X3D_LAZY_OUT(b, ptr, full)                                                             \
     do {                                                                                       \
         if ((b)->lazy) {                                                                       \
-            double *q_ = nullptr;                                                              \
+            real_t *q_ = nullptr;                                                              \
             if (int rc_ = x3d_lazy_out((b), (ptr), (full), &q_)) return rc_;                   \
             (ptr) = q_;                                                                        \
         }                                                                                      \
@@ -241,15 +274,15 @@ struct TdsTab {
     // A  forward coupling    (rows 1,2: 0; bulk: dist_af(5); else dist_af(j))
     // W  weights of d_k in du_2 (backward chain), see tds.hip
     // PF/QB chunk-local carry multipliers (onchip.hip)
-    const double *RF, *RB;
-    const double *TL;   // lane tables of the wave-per-pencil x kernels (xscan.hip): [entry][64 lanes], or null
+    const real_t *RF, *RB;
+    const real_t *TL;   // lane tables of the wave-per-pencil x kernels (xscan.hip): [entry][64 lanes], or null
     int Q;              // rows per lane there (4, 8; 16: only the compressed form is used), 0 if unavailable
     int bulk_only;      // 1: start/end stencils equal the bulk stencil (periodic / BC_HALO both ends)
-    const double *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
-    double last_r;      // dist_fw(1)
-    double bw1;         // dist_bw(1)
-    double rs_s, rs_e;  // 1/(1 - sa(1)^2), 1/(1 - sc(n)^2)
-    double sa1, scn;
+    const real_t *Cs;   // [4][9] start stencils, then [4][9] end stencils, then [9] bulk
+    real_t last_r;      // dist_fw(1)
+    real_t bw1;         // dist_bw(1)
+    real_t rs_s, rs_e;  // 1/(1 - sa(1)^2), 1/(1 - sc(n)^2)
+    real_t sa1, scn;
 };
 #define T_F(t, j) ((t).RF[4 * (j) + 0])
 #define T_A(t, j) ((t).RF[4 * (j) + 1])
@@ -267,12 +300,12 @@ struct TdsTab {
 struct x3d_tdsops {
     x3d_backend *b;
     int n_tds, n_rhs, move, periodic;
-    double *dev;  // one allocation holding all tables
+    real_t *dev;  // one allocation holding all tables
     TdsTab tab;
-    double coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
+    real_t coeffs[9];  // host copy of the bulk stencil (passed by value to the scan kernels)
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
-    const double *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
-    const double *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
+    const real_t *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
+    const real_t *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
     int uniform;                 // 1: stretch == 1 and stretch_correct == 0 on every row (a uniform grid): kernels may skip
                                  //    the ST / STC lane-table reads and their multiplications (x * 1.0, + nu * x * 0.0)
@@ -285,8 +318,8 @@ PencilGeom x3d_geom(const x3d_backend *b, int dir);
 
 // decomposed direction through the tile kernels (xscan.hip, HALO forms)
 struct TileHalo {
-    const double *recv;  // halo rows [side 2][field nf][4][hnp] (side 0: rows -3..0 from prev, 1: n+1..n+4 from next)
-    double *bsend;       // boundary values out [side 2][nb][np]: side 0 = du_1 (goes to prev), 1 = X_n (to next)
+    const real_t *recv;  // halo rows [side 2][field nf][4][hnp] (side 0: rows -3..0 from prev, 1: n+1..n+4 from next)
+    real_t *bsend;       // boundary values out [side 2][nb][np]: side 0 = du_1 (goes to prev), 1 = X_n (to next)
     int np, nf, nb;      // pencils of the direction, fields, operators per pencil
     // a halo row is a plane of pencils: pencil (x, o) sits at o * hp + x.  y pencils: packed (hp = nx); z pencils:
     // the block's own plane layout (hp = nxp, hnp = nxp * nyp) -- four halo rows are four consecutive xy planes of

@@ -4,21 +4,21 @@
 #pragma once
 #include "common.h"
 
-#define FP 584  // LDS pitch per pencil in double2 (= 8 mod 16: the 8 modes of a row go to different banks)
+#define FP 584  // LDS pitch per pencil in real2_t (= 8 mod 16: the 8 modes of a row go to different banks)
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+__device__ __forceinline__ real2_t cmul(real2_t a, real2_t b)
 {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_real2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ real2_t cadd(real2_t a, real2_t b) { return make_real2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ real2_t csub(real2_t a, real2_t b) { return make_real2(a.x - b.x, a.y - b.y); }
 
 // 8-point DFT, decimation in frequency, natural-order output.  S = -1 forward, +1 backward.
 template <int S>
-__device__ __forceinline__ void fft8(double2 (&a)[8])
+__device__ __forceinline__ void fft8(real2_t (&a)[8])
 {
-    const double h = 0.70710678118654752440;
-    double2 b[8];
+    const real_t h = 0.70710678118654752440;
+    real2_t b[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         b[k] = cadd(a[k], a[k + 4]);
@@ -26,18 +26,18 @@ __device__ __forceinline__ void fft8(double2 (&a)[8])
     }
     // b[4+k] *= W8^k: W8^1 = (1 + S i)/sqrt2, W8^2 = S i, W8^3 = (-1 + S i)/sqrt2
     {
-        double2 t = b[5];
-        b[5] = make_double2(h * (t.x - S * t.y), h * (t.y + S * t.x));
+        real2_t t = b[5];
+        b[5] = make_real2(h * (t.x - S * t.y), h * (t.y + S * t.x));
         t = b[6];
-        b[6] = make_double2(-S * t.y, S * t.x);
+        b[6] = make_real2(-S * t.y, S * t.x);
         t = b[7];
-        b[7] = make_double2(h * (-t.x - S * t.y), h * (-t.y + S * t.x));
+        b[7] = make_real2(h * (-t.x - S * t.y), h * (-t.y + S * t.x));
     }
 #pragma unroll
     for (int o = 0; o < 8; o += 4) {
-        const double2 c0 = cadd(b[o], b[o + 2]), c1 = cadd(b[o + 1], b[o + 3]), c2 = csub(b[o], b[o + 2]);
-        const double2 d = csub(b[o + 1], b[o + 3]);
-        const double2 c3 = make_double2(-S * d.y, S * d.x);  // * W4^1 = S i
+        const real2_t c0 = cadd(b[o], b[o + 2]), c1 = cadd(b[o + 1], b[o + 3]), c2 = csub(b[o], b[o + 2]);
+        const real2_t d = csub(b[o + 1], b[o + 3]);
+        const real2_t c3 = make_real2(-S * d.y, S * d.x);  // * W4^1 = S i
         const int r = o ? 1 : 0;
         a[r] = cadd(c0, c1);
         a[r + 4] = csub(c0, c1);
@@ -48,17 +48,17 @@ __device__ __forceinline__ void fft8(double2 (&a)[8])
 
 // W512^e for the transform direction S; tw holds the first half, W^(e+256) = -W^e
 template <int S>
-__device__ __forceinline__ double2 twiddle(const double2 *__restrict__ tw, int e)
+__device__ __forceinline__ real2_t twiddle(const real2_t *__restrict__ tw, int e)
 {
-    double2 w = tw[e & 255];
-    const double sg = (e & 256) ? -1.0 : 1.0;
-    return make_double2(sg * w.x, (S > 0 ? -sg : sg) * w.y);
+    real2_t w = tw[e & 255];
+    const real_t sg = (e & 256) ? -1.0 : 1.0;
+    return make_real2(sg * w.x, (S > 0 ? -sg : sg) * w.y);
 }
 
-// one pencil per wave: in/out a[k] = point l + 64 k; pen = this wave's LDS region (FP double2)
+// one pencil per wave: in/out a[k] = point l + 64 k; pen = this wave's LDS region (FP real2_t)
 template <int S>
-__device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict__ pen,
-                                            const double2 *__restrict__ tw, int l)
+__device__ __forceinline__ void fft512_wave(real2_t (&a)[8], real2_t *__restrict__ pen,
+                                            const real2_t *__restrict__ tw, int l)
 {
     // pass A: over n1 (stride 64), twiddle W512^(l k1)
     wave_lds_fence();  // (the caller's reads of this region, e.g. pass C of a previous transform, come first)
@@ -99,17 +99,17 @@ __device__ __forceinline__ void fft512_wave(double2 (&a)[8], double2 *__restrict
 // ---- 256-point complex FFT of one pencil per wave, FOUR points per lane (round 4 experiment, -DZF_16WAVES, measured
 // slower and off by default -- profiles/r04_zf16_waves.txt: the z transforms on the tile of the
 // z operator pairs give every one of the 16 waves ONE real pencil -- 512 reals as 256 complex numbers -- instead of two
-// real pencils to 8 of them).  in / out a[k] = point l + 64 k; pen = this wave's LDS region (FP256 double2).
+// real pencils to 8 of them).  in / out a[k] = point l + 64 k; pen = this wave's LDS region (FP256 real2_t).
 // 256 = 4 x 4 x 4 x 4, decimation in frequency: f = f1 + 4 f2 + 16 f3 + 64 f4; every stage is a 4-point DFT in
 // registers, the three exchanges go through the wave's own region (no block barrier: a wave's LDS operations execute in
 // order).  Unnormalised, S = -1 forward / +1 backward like fft512_wave.
 #define FP256 288
 
 template <int S>
-__device__ __forceinline__ void fft4(double2 (&a)[4])
+__device__ __forceinline__ void fft4(real2_t (&a)[4])
 {
-    const double2 b0 = cadd(a[0], a[2]), b1 = csub(a[0], a[2]), b2 = cadd(a[1], a[3]), d = csub(a[1], a[3]);
-    const double2 b3 = make_double2(-S * d.y, S * d.x);  // * W4^1 = S i
+    const real2_t b0 = cadd(a[0], a[2]), b1 = csub(a[0], a[2]), b2 = cadd(a[1], a[3]), d = csub(a[1], a[3]);
+    const real2_t b3 = make_real2(-S * d.y, S * d.x);  // * W4^1 = S i
     a[0] = cadd(b0, b2);
     a[2] = csub(b0, b2);
     a[1] = cadd(b1, b3);
@@ -117,7 +117,7 @@ __device__ __forceinline__ void fft4(double2 (&a)[4])
 }
 
 template <int S>
-__device__ __forceinline__ void fft256_wave(double2 (&a)[4], double2 *__restrict__ pen, const double2 *__restrict__ tw,
+__device__ __forceinline__ void fft256_wave(real2_t (&a)[4], real2_t *__restrict__ pen, const real2_t *__restrict__ tw,
                                             int l)
 {
     wave_lds_fence();  // (the caller's accesses to this region come first)

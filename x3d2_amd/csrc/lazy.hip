@@ -44,10 +44,10 @@ enum LKind {
 struct LOp {
     int kind = L_DEAD;
     int dir = 0, mode = 0, nterm = 0;
-    double *o[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // handles written (or updated in place)
-    const double *in[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    real_t *o[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // handles written (or updated in place)
+    const real_t *in[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const x3d_tdsops *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double s[6] = {0, 0, 0, 0, 0, 0};
+    real_t s[6] = {0, 0, 0, 0, 0, 0};
     void *obj = nullptr;  // x3d_poisson* of the FFT hooks
     int dims[3] = {0, 0, 0};  // L_SETFACE: the field's extent
 };
@@ -64,11 +64,11 @@ struct x3d_lazy {
     bool keep_zero_terms = false;
     unsigned rules = ~0u;  // X3D_LAZY_RULES: bit k = rewrite (k + 1) of optimise() allowed (A/B runs, tests)
     std::vector<LOp> q;
-    std::unordered_map<const double *, double *> phys;  // registered handle -> physical buffer (nullptr: none yet)
-    std::unordered_map<const double *, int> users;      // physical buffer -> handles mapped to it
-    std::vector<double *> handles;                      // registration order
-    std::vector<double *> pool;                         // extra physical buffers owned by the layer
-    std::unordered_map<const double *, double *> bind;  // handle -> the buffer an earlier operation filled for its NEXT life (L_BIND)
+    std::unordered_map<const real_t *, real_t *> phys;  // registered handle -> physical buffer (nullptr: none yet)
+    std::unordered_map<const real_t *, int> users;      // physical buffer -> handles mapped to it
+    std::vector<real_t *> handles;                      // registration order
+    std::vector<real_t *> pool;                         // extra physical buffers owned by the layer
+    std::unordered_map<const real_t *, real_t *> bind;  // handle -> the buffer an earlier operation filled for its NEXT life (L_BIND)
     long stats[ST_N] = {};
 };
 
@@ -96,12 +96,12 @@ void x3d_lazy_destroy(x3d_backend *b)
     if (!b->lazy) return;
     for (size_t k = 0; k < g_reported.size(); k++)
         if (g_reported[k] == b->lazy) { g_reported.erase(g_reported.begin() + k); g_reported_b.erase(g_reported_b.begin() + k); break; }
-    for (double *p : b->lazy->pool) hipFree(p);
+    for (real_t *p : b->lazy->pool) hipFree(p);
     delete b->lazy;
     b->lazy = nullptr;
 }
 
-void x3d_lazy_register(x3d_backend *b, double *h)
+void x3d_lazy_register(x3d_backend *b, real_t *h)
 {
     x3d_lazy *L = lazy_of(b);
     if (L->phys.count(h)) return;
@@ -110,7 +110,7 @@ void x3d_lazy_register(x3d_backend *b, double *h)
     L->handles.push_back(h);
 }
 
-void x3d_lazy_unregister(x3d_backend *b, double *h)
+void x3d_lazy_unregister(x3d_backend *b, real_t *h)
 {
     if (!b->lazy) return;
     x3d_lazy *L = b->lazy;
@@ -122,40 +122,40 @@ void x3d_lazy_unregister(x3d_backend *b, double *h)
 }
 
 // ---------------------------------------------------------------- physical buffers
-static bool registered(x3d_lazy *L, const double *h) { return L->phys.find(h) != L->phys.end(); }
+static bool registered(x3d_lazy *L, const real_t *h) { return L->phys.find(h) != L->phys.end(); }
 
-static int find_free(x3d_backend *b, double *prefer, double **out)
+static int find_free(x3d_backend *b, real_t *prefer, real_t **out)
 {
     x3d_lazy *L = b->lazy;
     if (prefer && L->users[prefer] == 0) { *out = prefer; return 0; }
-    for (double *p : L->pool)
+    for (real_t *p : L->pool)
         if (L->users[p] == 0) { *out = p; return 0; }
-    for (double *h : L->handles)
+    for (real_t *h : L->handles)
         if (L->users[h] == 0) { *out = h; return 0; }
-    double *p = nullptr;
-    X3D_HIP(hipMalloc(reinterpret_cast<void **>(&p), sizeof(double) * b->nblock));
-    X3D_HIP(hipMemsetAsync(p, 0, sizeof(double) * b->nblock, b->stream));
+    real_t *p = nullptr;
+    X3D_HIP(hipMalloc(reinterpret_cast<void **>(&p), sizeof(real_t) * b->nblock));
+    X3D_HIP(hipMemsetAsync(p, 0, sizeof(real_t) * b->nblock, b->stream));
     L->pool.push_back(p);
     L->users[p] = 0;
     *out = p;
     return 0;
 }
 
-static int copy_block(x3d_backend *b, double *dst, const double *src)
+static int copy_block(x3d_backend *b, real_t *dst, const real_t *src)
 {
-    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(double) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
+    X3D_HIP(hipMemcpyAsync(dst, src, sizeof(real_t) * b->nblock, hipMemcpyDeviceToDevice, b->stream));
     return 0;
 }
 
 // the buffer that holds h's data (a handle nothing was written to yet gets a free buffer: its contents are undefined anyway)
-static int resolve_in(x3d_backend *b, const double *h, const double **out)
+static int resolve_in(x3d_backend *b, const real_t *h, const real_t **out)
 {
     x3d_lazy *L = b->lazy;
     auto it = L->phys.find(h);
     if (it == L->phys.end()) { *out = h; return 0; }
     if (!it->second) {
-        double *p = nullptr;
-        if (int rc = find_free(b, const_cast<double *>(h), &p)) return rc;
+        real_t *p = nullptr;
+        if (int rc = find_free(b, const_cast<real_t *>(h), &p)) return rc;
         it->second = p;
         L->users[p] = 1;
     }
@@ -164,14 +164,14 @@ static int resolve_in(x3d_backend *b, const double *h, const double **out)
 }
 
 // a buffer h may be written to: its own unless that is shared (then a free one; full = false keeps the contents)
-static int prepare_out(x3d_backend *b, double *h, bool full, double **out)
+static int prepare_out(x3d_backend *b, real_t *h, bool full, real_t **out)
 {
     x3d_lazy *L = b->lazy;
     auto it = L->phys.find(h);
     if (it == L->phys.end()) { *out = h; return 0; }
-    double *p = it->second;
+    real_t *p = it->second;
     if (p && L->users[p] == 1) { *out = p; return 0; }
-    double *q = nullptr;
+    real_t *q = nullptr;
     if (p) L->users[p]--;
     if (int rc = find_free(b, h, &q)) return rc;
     it->second = q;
@@ -184,7 +184,7 @@ static int prepare_out(x3d_backend *b, double *h, bool full, double **out)
     return 0;
 }
 
-static void drop(x3d_lazy *L, double *h)
+static void drop(x3d_lazy *L, real_t *h)
 {
     auto it = L->phys.find(h);
     if (it == L->phys.end() || !it->second) return;
@@ -196,24 +196,24 @@ static void drop(x3d_lazy *L, double *h)
 static int normalise(x3d_backend *b)
 {
     x3d_lazy *L = b->lazy;
-    for (double *h : L->handles) {
-        double *p = L->phys[h];
+    for (real_t *h : L->handles) {
+        real_t *p = L->phys[h];
         if (p == h && L->users[h] == 1) continue;
         if (p == h) continue;  // (shared with handles that alias h's own buffer: they move when their turn comes)
         if (L->users[h] > 0) {
             // h's own buffer holds somebody else's data: move it out of the way
-            double *q = nullptr;
+            real_t *q = nullptr;
             bool found = false;
-            for (double *c : L->pool)
+            for (real_t *c : L->pool)
                 if (L->users[c] == 0) { q = c; found = true; break; }
             if (!found) {
-                X3D_HIP(hipMalloc(reinterpret_cast<void **>(&q), sizeof(double) * b->nblock));
+                X3D_HIP(hipMalloc(reinterpret_cast<void **>(&q), sizeof(real_t) * b->nblock));
                 L->pool.push_back(q);
                 L->users[q] = 0;
             }
             if (int rc = copy_block(b, q, h)) return rc;
             L->stats[ST_NORMALISE_COPIES]++;
-            for (double *g : L->handles)
+            for (real_t *g : L->handles)
                 if (g != h && L->phys[g] == h) { L->phys[g] = q; L->users[q]++; L->users[h]--; }
         }
         if (p) {
@@ -225,8 +225,8 @@ static int normalise(x3d_backend *b)
         L->users[h] = 1;
     }
     // handles that still alias another handle's own buffer (the owner is home now): give them their own copy
-    for (double *h : L->handles) {
-        double *p = L->phys[h];
+    for (real_t *h : L->handles) {
+        real_t *p = L->phys[h];
         if (p == h) continue;
         if (L->users[h] > 0) { x3d_set_error("x3d_lazy: normalise left buffer %p occupied", (void *)h); return 2; }
         if (p) {
@@ -279,7 +279,7 @@ static bool out_is_update(const LOp &op, int slot = 0)
     default: return false;
     }
 }
-static int touch(const LOp &op, const double *h)
+static int touch(const LOp &op, const real_t *h)
 {
     int m = 0;
     for (int k = 0; k < nin(op); k++)
@@ -289,22 +289,22 @@ static int touch(const LOp &op, const double *h)
     return m;
 }
 // no operation strictly between lo and hi touches any of `quiet`, none writes any of `stable`
-static bool range_clear(const std::vector<LOp> &q, int lo, int hi, std::initializer_list<const double *> quiet,
-                        const std::vector<const double *> &stable)
+static bool range_clear(const std::vector<LOp> &q, int lo, int hi, std::initializer_list<const real_t *> quiet,
+                        const std::vector<const real_t *> &stable)
 {
     for (int k = lo + 1; k < hi; k++) {
         const LOp &op = q[k];
         if (op.kind == L_DEAD) continue;
         if (op.kind == L_FFT_POST000 || op.kind == L_FFT_POST010) continue;
-        for (const double *h : quiet)
+        for (const real_t *h : quiet)
             if (h && touch(op, h)) return false;
-        for (const double *h : stable)
+        for (const real_t *h : stable)
             if (h && (touch(op, h) & (A_W | A_M))) return false;
     }
     return true;
 }
 // h's contents are not needed after position p: the next operation that touches it overwrites or releases it
-static bool dead_after(const std::vector<LOp> &q, int p, const double *h)
+static bool dead_after(const std::vector<LOp> &q, int p, const real_t *h)
 {
     for (int k = p + 1; k < (int)q.size(); k++) {
         const int m = touch(q[k], h);
@@ -313,21 +313,21 @@ static bool dead_after(const std::vector<LOp> &q, int p, const double *h)
     }
     return false;
 }
-static int last_touch_before(const std::vector<LOp> &q, int p, const double *h)
+static int last_touch_before(const std::vector<LOp> &q, int p, const real_t *h)
 {
     for (int k = p - 1; k >= 0; k--)
         if (touch(q[k], h)) return k;
     return -1;
 }
-static int first_touch_after(const std::vector<LOp> &q, int p, const double *h)
+static int first_touch_after(const std::vector<LOp> &q, int p, const real_t *h)
 {
     for (int k = p + 1; k < (int)q.size(); k++)
         if (touch(q[k], h)) return k;
     return -1;
 }
-static std::vector<const double *> inputs_of(const LOp &op)
+static std::vector<const real_t *> inputs_of(const LOp &op)
 {
-    std::vector<const double *> v;
+    std::vector<const real_t *> v;
     for (int k = 0; k < nin(op); k++) v.push_back(op.in[k]);
     return v;
 }
@@ -356,7 +356,7 @@ static void optimise(x3d_backend *b)
     for (int p = 0; p < n && (L->rules & 1u); p++) {
         if (q[p].kind != L_TRANSEQ) continue;
         int ps[3];
-        double *acc[3];
+        real_t *acc[3];
         bool ok = true;
         for (int c = 0; c < 3 && ok; c++) {
             const int k = first_touch_after(q, p, q[p].o[c]);
@@ -377,7 +377,7 @@ static void optimise(x3d_backend *b)
         if (q[p].kind != L_SPECIES) continue;
         const int k = first_touch_after(q, p, q[p].o[0]);
         if (k < 0 || q[k].kind != L_SUM || q[k].in[0] != q[p].o[0] || q[k].dir != q[p].dir || !dead_after(q, k, q[p].o[0])) continue;
-        double *acc = q[k].o[0];
+        real_t *acc = q[k].o[0];
         if (acc == q[p].in[0] || acc == q[p].in[1] || !range_clear(q, p, k, {acc}, {})) continue;
         q[p].kind = L_SPECIES_ACC; q[p].o[0] = acc;
         q[k].kind = L_DEAD;
@@ -386,8 +386,8 @@ static void optimise(x3d_backend *b)
     // fused where the EARLIER solve stands if the later one may move up there, else where the later one stands
     for (int p = 0; p < n && (L->rules & 2u); p++) {
         if (q[p].kind != L_VECADD || q[p].s[0] != 1.0 || q[p].s[1] != 1.0) continue;
-        const double *X = q[p].in[0];
-        double *Y = q[p].o[0];
+        const real_t *X = q[p].in[0];
+        real_t *Y = q[p].o[0];
         const int px = last_touch_before(q, p, X), py = last_touch_before(q, p, Y);
         if (px < 0 || py < 0 || q[px].kind != L_TDS || q[py].kind != L_TDS || q[px].o[0] != X || q[py].o[0] != Y) continue;
         if (q[px].dir != q[py].dir || q[px].dir == X3D_DIR_X || !dead_after(q, p, X)) continue;
@@ -398,7 +398,7 @@ static void optimise(x3d_backend *b)
         if (range_clear(q, lo, hi, {late.o[0]}, {late.in[0]})) at = lo;
         else if (range_clear(q, lo, hi, {early.o[0]}, {early.in[0]})) at = hi;
         if (at < 0) continue;
-        const double *i1 = q[py].in[0], *i2 = q[px].in[0];
+        const real_t *i1 = q[py].in[0], *i2 = q[px].in[0];
         if (Y == i1 || Y == i2 || X == i1 || X == i2) continue;
         LOp f;
         f.kind = L_PAIR; f.mode = 0; f.dir = q[py].dir;
@@ -428,8 +428,8 @@ static void optimise(x3d_backend *b)
     // (4) g = A(p) ; u += s g   (the velocity correction behind gradient_c2v, src/solver.f90:731-733)
     for (int p = 0; p < n && (L->rules & 8u); p++) {
         if (q[p].kind != L_VECADD || q[p].s[1] != 1.0) continue;
-        const double *G = q[p].in[0];
-        double *U = q[p].o[0];
+        const real_t *G = q[p].in[0];
+        real_t *U = q[p].o[0];
         const int pg = last_touch_before(q, p, G);
         if (pg < 0 || q[pg].kind != L_TDS || q[pg].o[0] != G || U == q[pg].in[0] || U == G || G == q[pg].in[0] ||
             !dead_after(q, p, G))
@@ -447,14 +447,14 @@ static void optimise(x3d_backend *b)
         int ks[3];
         bool ok = true;
         for (int c = 0; c < 3 && ok; c++) {
-            const double *f = q[p].in[c];
+            const real_t *f = q[p].in[c];
             const int k = last_touch_before(q, p, f);
             ok = k >= 0 && q[k].kind == L_TDS_ACC && q[k].o[0] == f && q[k].dir == X3D_DIR_X;
             ks[c] = k;
         }
         if (!ok || q[ks[1]].t[0] != q[ks[2]].t[0] || q[ks[0]].s[0] != q[ks[1]].s[0] || q[ks[0]].s[0] != q[ks[2]].s[0]) continue;
         const int k0 = std::min(ks[0], std::min(ks[1], ks[2])), k1 = std::max(ks[0], std::max(ks[1], ks[2]));
-        const double *g[3] = {q[ks[0]].in[0], q[ks[1]].in[0], q[ks[2]].in[0]};
+        const real_t *g[3] = {q[ks[0]].in[0], q[ks[1]].in[0], q[ks[2]].in[0]};
         // the later solves move up to k0: their gradients must not be written in between
         (void)k1;
         bool stable = true;
@@ -475,7 +475,7 @@ static void optimise(x3d_backend *b)
         if (!clear) continue;
         LOp f;
         f.kind = L_TRANSEQ_UPD; f.dir = X3D_DIR_X;
-        for (int c = 0; c < 3; c++) { f.o[c] = q[p].o[c]; f.o[3 + c] = const_cast<double *>(q[p].in[c]); f.in[c] = g[c]; }
+        for (int c = 0; c < 3; c++) { f.o[c] = q[p].o[c]; f.o[3 + c] = const_cast<real_t *>(q[p].in[c]); f.in[c] = g[c]; }
         for (int c = 0; c < 4; c++) f.t[c] = q[p].t[c];
         f.t[4] = q[ks[0]].t[0]; f.t[5] = q[ks[1]].t[0];
         f.s[0] = q[p].s[0]; f.s[1] = q[ks[0]].s[0];
@@ -495,7 +495,7 @@ static void optimise(x3d_backend *b)
         if (q[p].kind != L_LINCOMB) continue;
         int merged_into = -1;
         while (q[p].in[0] == q[p].o[0] && (L->rules & 16u)) {  // base == y: whatever wrote y last may be folded in
-            double *y = q[p].o[0];
+            real_t *y = q[p].o[0];
             const int k = last_touch_before(q, p, y);
             if (k < 0) break;
             const LOp &e = q[k];
@@ -508,7 +508,7 @@ static void optimise(x3d_backend *b)
             for (int c = 1; c <= q[p].nterm; c++) selfref = selfref || q[p].in[c] == y;
             if (selfref) break;
             // the later combination moves UP to the earlier one (nothing in between touches y or writes its terms)
-            std::vector<const double *> later_terms;
+            std::vector<const real_t *> later_terms;
             for (int c = 1; c <= q[p].nterm; c++) later_terms.push_back(q[p].in[c]);
             if (!range_clear(q, k, p, {y}, later_terms)) break;
             LOp f;
@@ -541,13 +541,13 @@ static void optimise(x3d_backend *b)
     // combination stands if the solve may move up (its output is not in use in between)
     for (int p = 0; p < n && (L->rules & 32u); p++) {
         if (q[p].kind != L_LINCOMB) continue;
-        double *y = q[p].o[0];
+        real_t *y = q[p].o[0];
         int k = first_touch_after(q, p, y);
         // ... with the y faces of y stamped from a wall field in between (field_set_face_from_field(Y_FACE): the channel
         // case's apply_BC, src/case/channel.f90:214-231): x3d_tds_solve_lincomb_wall does all three.  The stamping is taken
         // out of the queue for the checks below and dies with the rewrite.
         int ksf = -1;
-        const double *wall = nullptr;
+        const real_t *wall = nullptr;
         if (k >= 0 && q[k].kind == L_SETFACE && q[k].o[0] == y && q[p].nterm <= 5 && q[k].in[0] != y &&
             q[k].dims[0] == b->nx && q[k].dims[1] == b->ny && q[k].dims[2] == b->nz) {  // (the whole vertex block's faces)
             ksf = k;
@@ -555,18 +555,18 @@ static void optimise(x3d_backend *b)
             k = first_touch_after(q, ksf, y);
         }
         if (k < 0 || q[k].kind != L_TDS || q[k].dir != X3D_DIR_X || q[k].in[0] != y) continue;
-        double *du = q[k].o[0];
+        real_t *du = q[k].o[0];
         bool ok = du != y && du != wall;
         for (int c = 0; c <= q[p].nterm; c++) ok = ok && du != q[p].in[c];
         if (!ok) continue;
         LOp sf;
         if (ksf >= 0) { sf = q[ksf]; q[ksf].kind = L_DEAD; }
         auto undo_sf = [&]() { if (ksf >= 0) q[ksf] = sf; };
-        std::vector<const double *> stable = inputs_of(q[p]);
+        std::vector<const real_t *> stable = inputs_of(q[p]);
         if (wall) stable.push_back(wall);
         int at = -1;
         if (range_clear(q, p, k, {y}, stable)) at = k;
-        else if (range_clear(q, p, k, {y, du}, wall ? std::vector<const double *>{wall} : std::vector<const double *>{})) at = p;
+        else if (range_clear(q, p, k, {y, du}, wall ? std::vector<const real_t *>{wall} : std::vector<const real_t *>{})) at = p;
         if (at < 0) {
             // neither move is possible when the blocks of the three stages change hands in a ring (the allocator gives the
             // solve of u the block v's stage has just released, and so on: RK3's last stage, once per step): the handle du
@@ -574,7 +574,7 @@ static void optimise(x3d_backend *b)
             // the whole block), so the fused kernel may run where the combination stood and write into a free buffer of
             // the layer; an L_BIND where the solve stood hands that buffer to the handle.
             bool busy = !registered(L, du) ||
-                        !range_clear(q, p, k, {y}, wall ? std::vector<const double *>{wall} : std::vector<const double *>{});
+                        !range_clear(q, p, k, {y}, wall ? std::vector<const real_t *>{wall} : std::vector<const real_t *>{});
             for (int m = p + 1; m < k && !busy; m++)  // (one pending buffer per handle)
                 busy = (q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && (q[m].mode & 1) && q[m].obj == du);
             if (busy) { undo_sf(); continue; }
@@ -618,14 +618,14 @@ static void optimise(x3d_backend *b)
         x3d_poisson *pf = (x3d_poisson *)q[p].obj;
         if (!x3d_zfirst_on_offer(pf)) continue;
         // backwards: whatever wrote the solve's block, through at most one alias
-        double *h1 = q[p].o[0];
+        real_t *h1 = q[p].o[0];
         int kw = last_touch_before(q, p, h1), c1 = -1;
         if (kw >= 0 && q[kw].kind == L_COPY && q[kw].o[0] == h1) { c1 = kw; kw = last_touch_before(q, c1, q[c1].in[0]); }
-        const double *h0 = c1 >= 0 ? q[c1].in[0] : h1;
+        const real_t *h0 = c1 >= 0 ? q[c1].in[0] : h1;
         if (kw < 0 || q[kw].kind != L_PAIR || q[kw].mode != 0 || q[kw].dir != X3D_DIR_Z || q[kw].o[0] != h0) continue;
         // forwards: the one reader of the result, through at most one alias
         int kr = first_touch_after(q, p, h1), c2 = -1;
-        const double *h2 = h1;
+        const real_t *h2 = h1;
         if (kr >= 0 && q[kr].kind == L_COPY && q[kr].in[0] == h1) { c2 = kr; h2 = q[c2].o[0]; kr = first_touch_after(q, c2, h2); }
         if (kr < 0 || q[kr].kind != L_PAIR || q[kr].mode != 1 || q[kr].dir != X3D_DIR_Z || q[kr].in[0] != h2) continue;
         if (!x3d_zfirst_pairs_ok(b, q[kw].t[0], q[kw].t[1]) || !x3d_zfirst_pairs_ok(b, q[kr].t[0], q[kr].t[1])) continue;
@@ -637,7 +637,7 @@ static void optimise(x3d_backend *b)
             if (inter && q[m].kind != L_DISCARD) ok = false;  // (their releases, hoisted behind the one reader, aside)
         }
         // the gradient's pair moves up to the divergence's: its outputs must be untouched in between (releases aside)
-        double *o1 = q[kr].o[0], *o2 = q[kr].o[1];
+        real_t *o1 = q[kr].o[0], *o2 = q[kr].o[1];
         for (int m = kw + 1; m < kr && ok; m++) {
             if (q[m].kind == L_DEAD || q[m].kind == L_DISCARD) continue;
             if (touch(q[m], o1) || touch(q[m], o2)) ok = false;
@@ -658,20 +658,20 @@ static void optimise(x3d_backend *b)
 }
 
 // ---------------------------------------------------------------- execution
-extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in);
+extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const real_t *f_in);
 extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p);
-extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out);
-extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f);
+extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, real_t *f_out);
+extern "C" int x3d_poisson_solve_000(x3d_poisson *p, real_t *f);
 extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p);
-extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2,
-                                   const double *in1, const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, real_t *out1, real_t *out2,
+                                   const real_t *in1, const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                    int *done);
 
 static int exec(x3d_backend *b, const LOp &op)
 {
     x3d_lazy *L = b->lazy;
-    const double *in[7] = {};
-    double *o[6] = {};
+    const real_t *in[7] = {};
+    real_t *o[6] = {};
     if (op.kind == L_COPY) {
         // dst becomes an alias of src's buffer
         if (!registered(L, op.o[0]) || !registered(L, op.in[0])) {
@@ -682,7 +682,7 @@ static int exec(x3d_backend *b, const LOp &op)
         if (op.o[0] == op.in[0]) return 0;
         if (int rc = resolve_in(b, op.in[0], &in[0])) return rc;
         drop(L, op.o[0]);
-        L->phys[op.o[0]] = const_cast<double *>(in[0]);
+        L->phys[op.o[0]] = const_cast<real_t *>(in[0]);
         L->users[in[0]]++;
         L->stats[ST_ALIAS]++;
         return 0;
@@ -700,14 +700,14 @@ static int exec(x3d_backend *b, const LOp &op)
         if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
     for (int k = 0; k < nout(op); k++) {
         if (op.kind == L_TDS_LIN && (op.mode & 1) && k == 0) {  // du goes to a free buffer, bound to its handle later
-            double *f = nullptr;
+            real_t *f = nullptr;
             if (int rc = find_free(b, nullptr, &f)) return rc;
             L->users[f] = 1;
-            L->bind[static_cast<double *>(op.obj)] = f;
+            L->bind[static_cast<real_t *>(op.obj)] = f;
             o[0] = f;
             continue;
         }
-        double *before = registered(L, op.o[k]) ? L->phys[op.o[k]] : nullptr;
+        real_t *before = registered(L, op.o[k]) ? L->phys[op.o[k]] : nullptr;
         if (int rc = prepare_out(b, op.o[k], !out_is_update(op, k), &o[k])) return rc;
         if (before && before != o[k]) L->stats[ST_OOP]++;
     }
@@ -781,7 +781,7 @@ static int exec(x3d_backend *b, const LOp &op)
         L->stats[ST_ZFIRST]--;
         L->stats[ST_PAIR] += 2;
         L->stats[ST_SOLVE000]++;
-        double *d = nullptr;
+        real_t *d = nullptr;
         if (int rc = find_free(b, nullptr, &d)) return rc;
         L->users[d] = 1;
         int rc = x3d_tds_solve_pair(b, X3D_DIR_Z, 0, d, nullptr, in[0], in[1], op.t[0], op.t[1]);
@@ -801,8 +801,8 @@ static void dump(const x3d_lazy *L, const char *title)
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
                                   "solve000", "transeq_upd", "species", "species_acc", "zfirst", "fft_post010", "solve010_rows",
                                   "bind", "setface"};
-    std::unordered_map<const double *, int> id;
-    auto nm = [&](const double *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
+    std::unordered_map<const real_t *, int> id;
+    auto nm = [&](const real_t *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
     int k = 0;
     for (const LOp &op : L->q) {
@@ -842,14 +842,14 @@ int x3d_lazy_flush_c(x3d_backend *b)
 }
 
 // flush, then the buffer a queued-mode caller must hand to an entry point that runs at once
-int x3d_lazy_in(x3d_backend *b, const double *h, const double **out)
+int x3d_lazy_in(x3d_backend *b, const real_t *h, const real_t **out)
 {
     *out = h;
     if (!b->lazy || !b->lazy->on || b->lazy->executing) return 0;
     if (int rc = x3d_lazy_flush_c(b)) return rc;
     return resolve_in(b, h, out);
 }
-int x3d_lazy_out(x3d_backend *b, double *h, bool full, double **out)
+int x3d_lazy_out(x3d_backend *b, real_t *h, bool full, real_t **out)
 {
     *out = h;
     if (!b->lazy || !b->lazy->on || b->lazy->executing) return 0;
@@ -874,8 +874,8 @@ static int push(x3d_backend *b, const LOp &op)
 }
 
 // ---------------------------------------------------------------- recording (called by the entry points while the mode is on)
-int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u, const double *v,
-                     const double *w, double nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
+int x3d_lazy_transeq(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u, const real_t *v,
+                     const real_t *w, real_t nu, const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2,
                      const x3d_tdsops *t3)
 {
     // transeq_x opens a sub-step (src/solver.f90:320): no rewrite reaches back across it, and everything the previous
@@ -888,7 +888,7 @@ int x3d_lazy_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw
     // (transeq_x itself belongs to the window it closes: the velocity correction left by the pressure step folds into it)
     return dir == X3D_DIR_X ? x3d_lazy_flush_c(b) : 0;
 }
-int x3d_lazy_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec, double nu,
+int x3d_lazy_species(x3d_backend *b, int dir, real_t *dspec, const real_t *uvw, const real_t *spec, real_t nu,
                      const x3d_tdsops *t0, const x3d_tdsops *t1, const x3d_tdsops *t2, int accumulate)
 {
     LOp op;
@@ -896,38 +896,38 @@ int x3d_lazy_species(x3d_backend *b, int dir, double *dspec, const double *uvw, 
     op.o[0] = dspec; op.in[0] = uvw; op.in[1] = spec; op.s[0] = nu; op.t[0] = t0; op.t[1] = t1; op.t[2] = t2;
     return push(b, op);
 }
-int x3d_lazy_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+int x3d_lazy_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir)
 {
     LOp op;
     op.kind = L_TDS; op.dir = dir; op.o[0] = du; op.in[0] = u; op.t[0] = t;
     return push(b, op);
 }
-int x3d_lazy_copy(x3d_backend *b, double *dst, const double *src)
+int x3d_lazy_copy(x3d_backend *b, real_t *dst, const real_t *src)
 {
     LOp op;
     op.kind = L_COPY; op.o[0] = dst; op.in[0] = src;
     return push(b, op);
 }
-int x3d_lazy_sum(x3d_backend *b, double *u, const double *u_, int dir)
+int x3d_lazy_sum(x3d_backend *b, real_t *u, const real_t *u_, int dir)
 {
     LOp op;
     op.kind = L_SUM; op.dir = dir; op.o[0] = u; op.in[0] = u_;
     return push(b, op);
 }
-int x3d_lazy_vecadd(x3d_backend *b, double a, const double *x, double bb, double *y)
+int x3d_lazy_vecadd(x3d_backend *b, real_t a, const real_t *x, real_t bb, real_t *y)
 {
     LOp op;
     op.kind = L_VECADD; op.o[0] = y; op.in[0] = x; op.s[0] = a; op.s[1] = bb;
     return push(b, op);
 }
-int x3d_lazy_unary(x3d_backend *b, int kind, double *f, const double *x, double a)
+int x3d_lazy_unary(x3d_backend *b, int kind, real_t *f, const real_t *x, real_t a)
 {
     LOp op;
     op.kind = kind == 0 ? L_VECMULT : kind == 1 ? L_SCALE : kind == 2 ? L_SHIFT : L_FILL;
     op.o[0] = f; op.in[0] = x; op.s[0] = a;
     return push(b, op);
 }
-int x3d_lazy_setface(x3d_backend *b, double *f, const double *f_start, const int dims[3])
+int x3d_lazy_setface(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3])
 {
     LOp op;
     op.kind = L_SETFACE;
@@ -935,7 +935,7 @@ int x3d_lazy_setface(x3d_backend *b, double *f, const double *f_start, const int
     for (int k = 0; k < 3; k++) op.dims[k] = dims[k];
     return push(b, op);
 }
-int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, double *f)
+int x3d_lazy_fft(x3d_backend *b, int which, void *poisson, real_t *f)
 {
     LOp op;
     op.kind = which == 0 ? L_FFT_FWD : which == 1 ? L_FFT_POST000 : which == 3 ? L_FFT_POST010 : L_FFT_BWD;
@@ -1006,7 +1006,7 @@ extern "C" int x3d_lazy_sync(x3d_backend *b)
     return x3d_lazy_sync_c(b);
 }
 
-extern "C" int x3d_lazy_register_block(x3d_backend *b, double *f)
+extern "C" int x3d_lazy_register_block(x3d_backend *b, real_t *f)
 {
     X3D_REQUIRE(b && f, "x3d_lazy_register_block: null argument");
     x3d_lazy_register(b, f);
@@ -1015,7 +1015,7 @@ extern "C" int x3d_lazy_register_block(x3d_backend *b, double *f)
 
 // before memory registered above goes back to its owner: every handle's data home, then the layer forgets the block
 // (it would otherwise keep treating the buffer as reusable storage)
-extern "C" int x3d_lazy_unregister_block(x3d_backend *b, double *f)
+extern "C" int x3d_lazy_unregister_block(x3d_backend *b, real_t *f)
 {
     X3D_REQUIRE(b && f, "x3d_lazy_unregister_block: null argument");
     if (!b->lazy) return 0;
@@ -1027,7 +1027,7 @@ extern "C" int x3d_lazy_unregister_block(x3d_backend *b, double *f)
 }
 
 // allocator%release_block (src/allocator.f90:160-168): the block's contents are dead until it is written again
-extern "C" int x3d_block_discard(x3d_backend *b, double *f)
+extern "C" int x3d_block_discard(x3d_backend *b, real_t *f)
 {
     X3D_REQUIRE(b && f, "x3d_block_discard: null argument");
     if (!x3d_lazy_active(b)) return 0;

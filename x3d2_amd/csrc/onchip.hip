@@ -25,34 +25,34 @@
 #define K1E_M 32
 #define K1E_TAB 8  // F A PF HB QB SA SC ST
 
-struct Coef9 { double c[9]; };
+struct Coef9 { real_t c[9]; };
 
 // (wave-uniform pointer) + (32-bit per-lane BYTE offset): the form the backend turns into
 // global_load/store v, v_off, s[base:base+1].  With an element offset it cannot prove that 8*off fits 32
 // bits and builds a 64-bit address in two VGPRs per access (77 v_lshl_add_u64 in this kernel).
 // (plain accesses: nontemporal ones measured 4 % slower here, A/B on the same box)
-__device__ __forceinline__ double ldg(const double *base, unsigned boff)
+__device__ __forceinline__ real_t ldg(const real_t *base, unsigned boff)
 {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + boff);
+    return *reinterpret_cast<const real_t *>(reinterpret_cast<const char *>(base) + boff);
 }
-__device__ __forceinline__ void stg(double *base, unsigned boff, double v)
+__device__ __forceinline__ void stg(real_t *base, unsigned boff, real_t v)
 {
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + boff) = v;
+    *reinterpret_cast<real_t *>(reinterpret_cast<char *>(base) + boff) = v;
 }
 
 // M = 32: 512-row pencils, M = 16: 256-row pencils (16 chunks either way)
 template <bool ACC, int M, bool NARROW>
 __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups per CU, <= 128 VGPRs
-    k_tds_onchip2(double *__restrict__ du, const double *__restrict__ u, TdsTab t, PencilGeom g, double scale,
+    k_tds_onchip2(real_t *__restrict__ du, const real_t *__restrict__ u, TdsTab t, PencilGeom g, real_t scale,
                   Coef9 cf)
 {
     // periodic-type operator on pencils of exactly 16 * M rows (n_tds = n_rhs, bulk stencil everywhere):
     // no row guards, no boundary stencils, wrap-around halos by index arithmetic
-    extern __shared__ double lds[];  // K1E_TAB tables of LR rows, then ends[16][32], starts[16][32], misc[2][32]
+    extern __shared__ real_t lds[];  // K1E_TAB tables of LR rows, then ends[16][32], starts[16][32], misc[2][32]
     constexpr int n = 16 * M, LR = n + 8;
-    double *tF = lds, *tA = tF + LR, *tPF = tA + LR, *tHB = tPF + LR, *tQB = tHB + LR, *tSA = tQB + LR,
+    real_t *tF = lds, *tA = tF + LR, *tPF = tA + LR, *tHB = tPF + LR, *tQB = tHB + LR, *tSA = tQB + LR,
            *tSC = tSA + LR, *tST = tSC + LR;
-    double *ends = tST + LR, *starts = ends + 16 * 32, *misc = starts + 16 * 32;
+    real_t *ends = tST + LR, *starts = ends + 16 * 32, *misc = starts + 16 * 32;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xl = lane & 31, c = 2 * wv + (lane >> 5);
     const int p = blockIdx.x * 32 + xl;  // np is a multiple of 32 (launcher)
@@ -60,18 +60,18 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     const int s = c * M + 1;
     // addresses as (wave-uniform row pointer) + (one 32-bit per-lane element offset): with 40 per-lane
     // 64-bit addresses in flight the kernel spills (a block has < 2^31 elements)
-    const unsigned off = (unsigned)(base + (long)(s - 1) * rs) * 8u;  // bytes; a block is < 4 GiB
+    const unsigned off = (unsigned)(base + (long)(s - 1) * rs) * (unsigned)X3D_RB;  // bytes; a block is < 4 GiB
 
     // ---- P1: load the chunk + 4 + 4 halo rows (periodic image), chunk-local forward elimination in place.
     // x[q] is overwritten by the eliminated value, so the 4 original rows behind the current one are kept
     // in p0..p3; the rows ahead are still original in x[] (the last 4 come from the right halo, loaded late)
-    double x[M], hr[4];
+    real_t x[M], hr[4];
 #pragma unroll
     for (int q = 0; q < M; q++) x[q] = ldg(u + (long)q * rs, off);
-    double p0 = ldg(u, (unsigned)(base + (long)((s - 5 + n) & (n - 1)) * rs) * 8u),
-           p1 = ldg(u, (unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs) * 8u),
-           p2 = ldg(u, (unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs) * 8u),
-           p3 = ldg(u, (unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs) * 8u);
+    real_t p0 = ldg(u, (unsigned)(base + (long)((s - 5 + n) & (n - 1)) * rs) * (unsigned)X3D_RB),
+           p1 = ldg(u, (unsigned)(base + (long)((s - 4 + n) & (n - 1)) * rs) * (unsigned)X3D_RB),
+           p2 = ldg(u, (unsigned)(base + (long)((s - 3 + n) & (n - 1)) * rs) * (unsigned)X3D_RB),
+           p3 = ldg(u, (unsigned)(base + (long)((s - 2 + n) & (n - 1)) * rs) * (unsigned)X3D_RB);
     // the row tables are staged while the loads above are in flight
     for (int j = threadIdx.x; j < LR; j += blockDim.x) {
         const bool in = j >= 1 && j <= n;
@@ -85,24 +85,24 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
         tST[j] = in ? T_ST(t, j) : 0.0;
     }
     __syncthreads();
-    const double c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
+    const real_t c0 = cf.c[0], c1 = cf.c[1], c2 = cf.c[2], c3 = cf.c[3], c4 = cf.c[4], c5 = cf.c[5], c6 = cf.c[6],
                  c7 = cf.c[7], c8 = cf.c[8];  // kernel arguments: SGPRs
-    double prev = 0.0;
+    real_t prev = 0.0;
 #pragma unroll
     for (int q = 0; q < M; q++) {
         const int j = s + q;
         if (q == M - 12) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) hr[m] = ldg(u, (unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs) * 8u);
+            for (int m = 0; m < 4; m++) hr[m] = ldg(u, (unsigned)(base + (long)((s + M - 1 + m) & (n - 1)) * rs) * (unsigned)X3D_RB);
         }
 #define AHEAD(d) ((q + (d) < M) ? x[(q + (d)) % M] : hr[(q + (d) - M) & 3])
-        const double cur = x[q];
+        const real_t cur = x[q];
         // NARROW: compact6 / classic stencils reach 2 rows only: skip the zero taps (adding 0 * x is exact)
-        const double acc = NARROW ? c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2)
+        const real_t acc = NARROW ? c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2)
                                   : c0 * p0 + c1 * p1 + c2 * p2 + c3 * p3 + c4 * cur + c5 * AHEAD(1) + c6 * AHEAD(2) +
                                         c7 * AHEAD(3) + c8 * AHEAD(4);
 #undef AHEAD
-        const double e = tF[j] * (acc - tA[j] * prev);
+        const real_t e = tF[j] * (acc - tA[j] * prev);
         prev = e;
         x[q] = e;
         p0 = p1; p1 = p2; p2 = p3; p3 = cur;
@@ -113,13 +113,13 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
 
     // ---- P2: forward carry (serial over the chunks before this one), chunk-local back-substitution
     {
-        double carry = 0.0;
+        real_t carry = 0.0;
         for (int cc = 0; cc < c; cc++) carry = ends[cc * 32 + xl] + tPF[(cc + 1) * M] * carry;
-        double nxt = 0.0;
+        real_t nxt = 0.0;
 #pragma unroll
         for (int q = M - 1; q >= 0; q--) {
             const int j = s + q;
-            const double e = x[q] + tPF[j] * carry;
+            const real_t e = x[q] + tPF[j] * carry;
             x[q] = e + tHB[j] * nxt;
             nxt = x[q];
             if ((q & 1) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -129,19 +129,19 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
     __syncthreads();
 
     // ---- P3: backward carry (applied on the fly in P4); publish du_1 and X_n
-    double carry = 0.0;
+    real_t carry = 0.0;
     for (int cc = 15; cc > c; cc--) carry = starts[cc * 32 + xl] + tQB[cc * M + 1] * carry;
     if (c == 15) misc[32 + xl] = x[M - 1];  // carry = 0 there
     if (c == 0) misc[xl] = t.last_r * ((x[0] + tQB[1] * carry) - t.bw1 * (x[1] + tQB[2] * carry));  // :161-166
     __syncthreads();
 
     // ---- P4: reduced 2x2 systems with the periodic self-exchange, substitution, store
-    const double du1 = misc[xl], xn = misc[32 + xl];
-    const double du_s = t.rs_s * (du1 - t.sa1 * xn);
-    const double du_e = t.rs_e * (xn - t.scn * du1);
+    const real_t du1 = misc[xl], xn = misc[32 + xl];
+    const real_t du_s = t.rs_s * (du1 - t.sa1 * xn);
+    const real_t du_e = t.rs_e * (xn - t.scn * du1);
 #pragma unroll
     for (int q0 = 0; q0 < M; q0 += 2) {
-        double old[2];
+        real_t old[2];
         if (ACC) {
 #pragma unroll
             for (int k = 0; k < 2; k++) old[k] = ldg(du + (long)(q0 + k) * rs, off);
@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int q = q0 + k, j = s + q;
-            const double X = x[q] + tQB[j] * carry;
-            double r = (X - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
+            const real_t X = x[q] + tQB[j] * carry;
+            real_t r = (X - tSA[j] * du_s - tSC[j] * du_e) * tST[j];  // :215-222
             if (q == 0) r = (c == 0) ? du_s * tST[j] : r;        // row 1, :209-213
             if (q == M - 1) r = (c == 15) ? du_e * tST[j] : r;   // row n, :224-228
             stg(du + (long)q * rs, off, ACC ? old[k] + scale * r : r);
@@ -160,10 +160,10 @@ __global__ void __launch_bounds__(512, 4)  // 4 waves per SIMD = two workgroups 
 }
 
 template <int M>
-static int launch_onchip2(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, const PencilGeom &g,
-                          int dir, int acc, double scale)
+static int launch_onchip2(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, const PencilGeom &g,
+                          int dir, int acc, real_t scale)
 {
-    const size_t lds = sizeof(double) * ((size_t)K1E_TAB * (16 * M + 8) + 2 * 16 * 32 + 64);
+    const size_t lds = sizeof(real_t) * ((size_t)K1E_TAB * (16 * M + 8) + 2 * 16 * 32 + 64);
     {
         const void *ks[4] = {(const void *)k_tds_onchip2<false, M, false>, (const void *)k_tds_onchip2<true, M, false>,
                              (const void *)k_tds_onchip2<false, M, true>, (const void *)k_tds_onchip2<true, M, true>};
@@ -182,7 +182,7 @@ static int launch_onchip2(x3d_backend *b, double *du, const double *u, const x3d
     return 0;
 }
 
-int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
+int x3d_onchip2_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, int acc, real_t scale,
                     bool *done)
 {
     *done = false;

@@ -44,13 +44,13 @@ struct x3d_pfft {
     int xs, xoff, ys, yoff;       // spectral shares of this rank
     int parts, zp;                // groups of local z planes (zp = zl / parts); the x and y plans are per group
     hipfftHandle plan_r2c, plan_c2r, plan_y, plan_z;
-    double2 *c0, *c1, *c2;        // stage buffers
-    double *waves, *ab;
+    real2_t *c0, *c1, *c2;        // stage buffers
+    real_t *waves, *ab;
     void *work;
 };
 
 // dst[i*d0 + j*d1 + k*d2] = src[i*s0 + j*s1 + k*s2]; i is the fastest loop index
-__global__ void __launch_bounds__(256) k_permute(double2 *__restrict__ dst, const double2 *__restrict__ src, int n0,
+__global__ void __launch_bounds__(256) k_permute(real2_t *__restrict__ dst, const real2_t *__restrict__ src, int n0,
                                                  int n1, int n2, long d0, long d1, long d2, long s0, long s1, long s2)
 {
     const long q = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -66,14 +66,14 @@ __global__ void __launch_bounds__(256) k_permute(double2 *__restrict__ dst, cons
 // transposition): 32 x 32 tiles through LDS so that both the loads (along A) and the stores (along B) are
 // 512-byte contiguous; C is the remaining dimension.  k_permute alone runs at 2.5 TB/s on these.
 __global__ void __launch_bounds__(256)
-    k_transpose_tiled(double2 *__restrict__ dst, const double2 *__restrict__ src, int nA, int nB, int nC, long dA,
+    k_transpose_tiled(real2_t *__restrict__ dst, const real2_t *__restrict__ src, int nA, int nB, int nC, long dA,
                       long dC, long sB, long sC)
 {
-    __shared__ double2 tile[32][33];
+    __shared__ real2_t tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32, c = blockIdx.z;
-    const double2 *__restrict__ sp = src + (long)c * sC;
-    double2 *__restrict__ dp = dst + (long)c * dC;
+    const real2_t *__restrict__ sp = src + (long)c * sC;
+    real2_t *__restrict__ dp = dst + (long)c * dC;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int bb = b0 + ty + 8 * r, aa = a0 + tx;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-static int permute(x3d_backend *b, double2 *dst, const double2 *src, int n0, int n1, int n2, long d0, long d1,
+static int permute(x3d_backend *b, real2_t *dst, const real2_t *src, int n0, int n1, int n2, long d0, long d1,
                    long d2, long s0, long s1, long s2)
 {
     const long tot = (long)n0 * n1 * n2;
@@ -119,22 +119,22 @@ static int permute(x3d_backend *b, double2 *dst, const double2 *src, int n0, int
 // process_spectral_000 on the z-fastest spectral pencils C2[xs][ys][nz]
 // (src/backend/omp/kernels/spectral_processing.f90:7-106, offsets = sp_st)
 __global__ void __launch_bounds__(256)
-    k_process_spectral_000_z(double2 *__restrict__ c, const double *__restrict__ waves, int xs, int ys, int nz,
-                             int xoff, int yoff, int nx, int ny, const double *__restrict__ ax,
-                             const double *__restrict__ bx, const double *__restrict__ ay,
-                             const double *__restrict__ by, const double *__restrict__ az,
-                             const double *__restrict__ bz)
+    k_process_spectral_000_z(real2_t *__restrict__ c, const real_t *__restrict__ waves, int xs, int ys, int nz,
+                             int xoff, int yoff, int nx, int ny, const real_t *__restrict__ ax,
+                             const real_t *__restrict__ bx, const real_t *__restrict__ ay,
+                             const real_t *__restrict__ by, const real_t *__restrict__ az,
+                             const real_t *__restrict__ bz)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;  // iz - 1
     const int jl = blockIdx.y, il = blockIdx.z;
     if (k >= nz) return;
     const int i = il + xoff, j = jl + yoff;
     const size_t idx = ((size_t)il * ys + jl) * nz + k;
-    double2 v = c[idx];
-    double div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
-    const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
+    real2_t v = c[idx];
+    real_t div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
+    const real_t azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
     const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
-    double tr, tc;
+    real_t tr, tc;
     tr = div_r; tc = div_c;
     div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
     if (fz) { div_r = -div_r; div_c = -div_c; }
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256)
     if (fy) { div_r = -div_r; div_c = -div_c; }
     tr = div_r; tc = div_c;
     div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
-    const double wv = waves[idx];
+    const real_t wv = waves[idx];
     if (wv < 1.e-16) { div_r = 0.0; div_c = 0.0; }
     else { div_r = -div_r / wv; div_c = -div_c / wv; }
     tr = div_r; tc = div_c;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256)
     if (fy) { div_r = -div_r; div_c = -div_c; }
     tr = div_r; tc = div_c;
     div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
-    c[idx] = make_double2(div_r, div_c);
+    c[idx] = make_real2(div_r, div_c);
 }
 
 extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry,
@@ -188,11 +188,11 @@ extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int n
     p->ys = share(p->ny, pz, rz); p->yoff = share_off(p->ny, pz, rz);
     const size_t n0 = (size_t)p->zl * p->yl * p->nxs, n1 = (size_t)p->zl * p->xs * p->ny,
                  n2 = (size_t)p->xs * p->ys * p->nz;
-    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
-    X3D_HIP(hipMalloc(&p->c1, sizeof(double2) * n1));
-    X3D_HIP(hipMalloc(&p->c2, sizeof(double2) * n2));
-    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * n2));
-    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));
+    X3D_HIP(hipMalloc(&p->c0, sizeof(real2_t) * n0));
+    X3D_HIP(hipMalloc(&p->c1, sizeof(real2_t) * n1));
+    X3D_HIP(hipMalloc(&p->c2, sizeof(real2_t) * n2));
+    X3D_HIP(hipMalloc(&p->waves, sizeof(real_t) * n2));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(real_t) * 2 * ((size_t)p->nx + p->ny + p->nz)));
     int nxv[1] = {p->nx}, nyv[1] = {p->ny}, nzv[1] = {p->nz};
     size_t ws[4] = {0, 0, 0, 0};
     hipfftHandle *pl[4] = {&p->plan_r2c, &p->plan_c2r, &p->plan_y, &p->plan_z};
@@ -201,12 +201,12 @@ extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int n
         X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
     }
     int rembed[1] = {b->nxp}, cembed[1] = {p->nxs};
-    X3D_FFT(hipfftMakePlanMany(p->plan_r2c, 1, nxv, rembed, 1, b->nxp, cembed, 1, p->nxs, HIPFFT_D2Z,
+    X3D_FFT(hipfftMakePlanMany(p->plan_r2c, 1, nxv, rembed, 1, b->nxp, cembed, 1, p->nxs, X3D_FFT_R2C,
                                p->yl * p->zp, &ws[0]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_c2r, 1, nxv, cembed, 1, p->nxs, rembed, 1, b->nxp, HIPFFT_Z2D,
+    X3D_FFT(hipfftMakePlanMany(p->plan_c2r, 1, nxv, cembed, 1, p->nxs, rembed, 1, b->nxp, X3D_FFT_C2R,
                                p->yl * p->zp, &ws[1]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, nyv, nyv, 1, p->ny, nyv, 1, p->ny, HIPFFT_Z2Z, p->zp * p->xs, &ws[2]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, HIPFFT_Z2Z, p->xs * p->ys, &ws[3]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, nyv, nyv, 1, p->ny, nyv, 1, p->ny, X3D_FFT_C2C, p->zp * p->xs, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, X3D_FFT_C2C, p->xs * p->ys, &ws[3]));
     size_t wmax = 0;
     for (int i = 0; i < 4; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
@@ -237,39 +237,39 @@ extern "C" int x3d_pfft_sizes(const x3d_pfft *p, long out[8])
 }
 
 // waves_re: this rank's block [xs][ys][nz] (z fastest); ax..bz: global-length arrays
-extern "C" int x3d_pfft_set_waves(x3d_pfft *p, const double *waves_re, const double *ax, const double *bx,
-                                  const double *ay, const double *by, const double *az, const double *bz)
+extern "C" int x3d_pfft_set_waves(x3d_pfft *p, const real_t *waves_re, const real_t *ax, const real_t *bx,
+                                  const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
     X3D_REQUIRE(p && waves_re && ax && bx && ay && by && az && bz, "null argument");
     const size_t n2 = (size_t)p->xs * p->ys * p->nz;
-    X3D_HIP(hipMemcpy(p->waves, waves_re, sizeof(double) * n2, hipMemcpyHostToDevice));
-    double *d = p->ab;
-    const double *src[6] = {ax, bx, ay, by, az, bz};
+    X3D_HIP(hipMemcpy(p->waves, waves_re, sizeof(real_t) * n2, hipMemcpyHostToDevice));
+    real_t *d = p->ab;
+    const real_t *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
     for (int i = 0; i < 6; i++) {
-        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(real_t) * len[i], hipMemcpyHostToDevice));
         d += len[i];
     }
     return 0;
 }
 
 // ---- local stages on the planes [z0, z0 + nzp_) of this rank (a whole number of groups)
-static int fwd_x(x3d_pfft *p, const double *f_in, int m0, int m1)
+static int fwd_x(x3d_pfft *p, const real_t *f_in, int m0, int m1)
 {
     ProfScope ps(p->b, X3D_K_FFT, 1);
     X3D_FFT(hipfftSetStream(p->plan_r2c, p->b->stream));
     for (int m = m0; m < m1; m++)
-        X3D_FFT(hipfftExecD2Z(p->plan_r2c, (hipfftDoubleReal *)f_in + (size_t)m * p->zp * p->yl * p->b->nxp,
-                              (hipfftDoubleComplex *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs));
+        X3D_FFT(x3d_fftExecR2C(p->plan_r2c, (x3d_fft_real *)f_in + (size_t)m * p->zp * p->yl * p->b->nxp,
+                              (x3d_fft_cplx *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs));
     return 0;
 }
-static int bwd_x(x3d_pfft *p, double *f_out, int m0, int m1)
+static int bwd_x(x3d_pfft *p, real_t *f_out, int m0, int m1)
 {
     ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_c2r, p->b->stream));
     for (int m = m0; m < m1; m++)
-        X3D_FFT(hipfftExecZ2D(p->plan_c2r, (hipfftDoubleComplex *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs,
-                              (hipfftDoubleReal *)f_out + (size_t)m * p->zp * p->yl * p->b->nxp));
+        X3D_FFT(x3d_fftExecC2R(p->plan_c2r, (x3d_fft_cplx *)p->c0 + (size_t)m * p->zp * p->yl * p->nxs,
+                              (x3d_fft_real *)f_out + (size_t)m * p->zp * p->yl * p->b->nxp));
     return 0;
 }
 static int fft_y(x3d_pfft *p, int inverse, int m0, int m1)
@@ -278,20 +278,20 @@ static int fft_y(x3d_pfft *p, int inverse, int m0, int m1)
     ProfScope ps(p->b, X3D_K_FFT, 3);
     X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
     for (int m = m0; m < m1; m++) {
-        hipfftDoubleComplex *c = (hipfftDoubleComplex *)p->c1 + (size_t)m * p->zp * p->xs * p->ny;
-        X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+        x3d_fft_cplx *c = (x3d_fft_cplx *)p->c1 + (size_t)m * p->zp * p->xs * p->ny;
+        X3D_FFT(x3d_fftExecC2C(p->plan_y, c, c, inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     }
     return 0;
 }
 
-extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const double *f_in)
+extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_in, "null argument");
     X3D_LAZY_IN(p->b, f_in);
     return fwd_x(p, f_in, 0, p->parts);
 }
 
-extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, double *f_out)
+extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, real_t *f_out)
 {
     X3D_REQUIRE(p && f_out, "null argument");
     X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
@@ -310,7 +310,7 @@ extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
     if (p->xs == 0 || p->ys == 0) return 0;
     ProfScope ps(p->b, X3D_K_FFT, 3);
     X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-    X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)p->c2, (hipfftDoubleComplex *)p->c2,
+    X3D_FFT(x3d_fftExecC2C(p->plan_z, (x3d_fft_cplx *)p->c2, (x3d_fft_cplx *)p->c2,
                           inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     return 0;
 }
@@ -321,12 +321,12 @@ extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
 // yz: send chunk r = C1[z0.., :, yoff_r : yoff_r+ys_r] packed [nzl][xs][ys_r] at s + yoff_r * xs * nzl;
 //     recv chunk r = [nzl][xs][ys] from the rank owning z-slab r  ->  C2[x][y][r*zl + z]
 // (whole solve: z0 = 0, nzl = zl; a group: z0 = m * zp, nzl = zp, s = the group's piece of the buffer)
-static int xy_c0(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+static int xy_c0(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
 {
-    double2 *c0 = p->c0 + (size_t)z0 * p->yl * p->nxs;
+    real2_t *c0 = p->c0 + (size_t)z0 * p->yl * p->nxs;
     for (int r = 0; r < p->py; r++) {
         const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
-        double2 *ch = s + (long)xo * p->yl * nzl;
+        real2_t *ch = s + (long)xo * p->yl * nzl;
         const int rc = pack ? permute(p->b, ch, c0 + xo, xr, p->yl, nzl, 1, xr, (long)xr * p->yl, 1, p->nxs,
                                       (long)p->nxs * p->yl)
                             : permute(p->b, c0 + xo, ch, xr, p->yl, nzl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
@@ -335,9 +335,9 @@ static int xy_c0(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
     }
     return 0;
 }
-static int xy_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+static int xy_c1(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
 {
-    double2 *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
+    real2_t *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
     const long chunk = (long)p->xs * p->yl * nzl;
     for (int r = 0; r < p->py; r++) {
         const int rc = pack ? permute(p->b, s + r * chunk, c1 + (long)r * p->yl, p->xs, p->yl, nzl, 1, p->xs,
@@ -348,12 +348,12 @@ static int xy_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
     }
     return 0;
 }
-static int yz_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+static int yz_c1(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
 {
-    double2 *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
+    real2_t *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
     for (int r = 0; r < p->pz; r++) {
         const int yr = share(p->ny, p->pz, r), yo = share_off(p->ny, p->pz, r);
-        double2 *ch = s + (long)yo * p->xs * nzl;
+        real2_t *ch = s + (long)yo * p->xs * nzl;
         const int rc = pack ? permute(p->b, ch, c1 + yo, yr, p->xs, nzl, 1, yr, (long)yr * p->xs, 1, p->ny,
                                       (long)p->ny * p->xs)
                             : permute(p->b, c1 + yo, ch, yr, p->xs, nzl, 1, p->ny, (long)p->ny * p->xs, 1, yr,
@@ -362,11 +362,11 @@ static int yz_c1(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
     }
     return 0;
 }
-static int yz_c2(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
+static int yz_c2(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
 {
     const long chunk = (long)p->ys * p->xs * nzl;
     for (int r = 0; r < p->pz; r++) {
-        double2 *c2 = p->c2 + (long)r * p->zl + z0;
+        real2_t *c2 = p->c2 + (long)r * p->zl + z0;
         const int rc = pack ? permute(p->b, s + r * chunk, c2, p->ys, p->xs, nzl, 1, p->ys, (long)p->ys * p->xs,
                                       p->nz, (long)p->ys * p->nz, 1)
                             : permute(p->b, c2, s + r * chunk, p->ys, p->xs, nzl, p->nz, (long)p->ys * p->nz, 1, 1,
@@ -376,46 +376,46 @@ static int yz_c2(x3d_pfft *p, double2 *s, int z0, int nzl, bool pack)
     return 0;
 }
 
-extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, double *sendbuf)
+extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, real_t *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    return xy_c0(p, (double2 *)sendbuf, 0, p->zl, true);
+    return xy_c0(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
-extern "C" int x3d_pfft_unpack_xy(x3d_pfft *p, const double *recvbuf)
+extern "C" int x3d_pfft_unpack_xy(x3d_pfft *p, const real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    return xy_c1(p, (double2 *)recvbuf, 0, p->zl, false);
+    return xy_c1(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
 // inverse of the pair above: C1 -> chunks [zl][yl][xs] per y-slab owner -> C0 columns
-extern "C" int x3d_pfft_pack_yx(x3d_pfft *p, double *sendbuf)
+extern "C" int x3d_pfft_pack_yx(x3d_pfft *p, real_t *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    return xy_c1(p, (double2 *)sendbuf, 0, p->zl, true);
+    return xy_c1(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
-extern "C" int x3d_pfft_unpack_yx(x3d_pfft *p, const double *recvbuf)
+extern "C" int x3d_pfft_unpack_yx(x3d_pfft *p, const real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    return xy_c0(p, (double2 *)recvbuf, 0, p->zl, false);
+    return xy_c0(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
-extern "C" int x3d_pfft_pack_yz(x3d_pfft *p, double *sendbuf)
+extern "C" int x3d_pfft_pack_yz(x3d_pfft *p, real_t *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    return yz_c1(p, (double2 *)sendbuf, 0, p->zl, true);
+    return yz_c1(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
-extern "C" int x3d_pfft_unpack_yz(x3d_pfft *p, const double *recvbuf)
+extern "C" int x3d_pfft_unpack_yz(x3d_pfft *p, const real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    return yz_c2(p, (double2 *)recvbuf, 0, p->zl, false);
+    return yz_c2(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
-extern "C" int x3d_pfft_pack_zy(x3d_pfft *p, double *sendbuf)
+extern "C" int x3d_pfft_pack_zy(x3d_pfft *p, real_t *sendbuf)
 {
     X3D_REQUIRE(p && sendbuf, "null argument");
-    return yz_c2(p, (double2 *)sendbuf, 0, p->zl, true);
+    return yz_c2(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
-extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const double *recvbuf)
+extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
-    return yz_c1(p, (double2 *)recvbuf, 0, p->zl, false);
+    return yz_c1(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
 
 // ---- the solve in groups of planes.  out = {parts, zp, then in complex elements: a group's piece of the xy send
@@ -435,52 +435,52 @@ extern "C" int x3d_pfft_part_layout(const x3d_pfft *p, long out[6])
 #define PFFT_PART(p, m, name) \
     X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": group %d of %d", (m), (p) ? (p)->parts : 0)
 // forward: R2C x of the group, its xy chunks into send_xy
-extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const double *f_in, double *send_xy, int m)
+extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const real_t *f_in, real_t *send_xy, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_fwd_a_part");
     X3D_REQUIRE(f_in && send_xy, "null argument");
     X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
     if (int rc = fwd_x(p, f_in, m, m + 1)) return rc;
-    return xy_c0(p, (double2 *)send_xy + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, true);
+    return xy_c0(p, (real2_t *)send_xy + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, true);
 }
 // received xy chunks -> y pencils, C2C y, yz chunks into send_yz
-extern "C" int x3d_pfft_fwd_b_part(x3d_pfft *p, const double *recv_xy, double *send_yz, int m)
+extern "C" int x3d_pfft_fwd_b_part(x3d_pfft *p, const real_t *recv_xy, real_t *send_yz, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_fwd_b_part");
     X3D_REQUIRE(recv_xy && send_yz, "null argument");
-    if (int rc = xy_c1(p, (double2 *)recv_xy + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, false))
+    if (int rc = xy_c1(p, (real2_t *)recv_xy + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, false))
         return rc;
     if (int rc = fft_y(p, 0, m, m + 1)) return rc;
-    return yz_c1(p, (double2 *)send_yz + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, true);
+    return yz_c1(p, (real2_t *)send_yz + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, true);
 }
 // received yz chunks -> the group's planes of the z pencils (x3d_pfft_fft_z once every group is in)
-extern "C" int x3d_pfft_fwd_c_part(x3d_pfft *p, const double *recv_yz, int m)
+extern "C" int x3d_pfft_fwd_c_part(x3d_pfft *p, const real_t *recv_yz, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_fwd_c_part");
     X3D_REQUIRE(recv_yz, "null argument");
-    return yz_c2(p, (double2 *)recv_yz + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, false);
+    return yz_c2(p, (real2_t *)recv_yz + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, false);
 }
 // backward, the same three in reverse (buffers: what was received forward is sent now)
-extern "C" int x3d_pfft_bwd_c_part(x3d_pfft *p, double *send_zy, int m)
+extern "C" int x3d_pfft_bwd_c_part(x3d_pfft *p, real_t *send_zy, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_bwd_c_part");
     X3D_REQUIRE(send_zy, "null argument");
-    return yz_c2(p, (double2 *)send_zy + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, true);
+    return yz_c2(p, (real2_t *)send_zy + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, true);
 }
-extern "C" int x3d_pfft_bwd_b_part(x3d_pfft *p, const double *recv_zy, double *send_yx, int m)
+extern "C" int x3d_pfft_bwd_b_part(x3d_pfft *p, const real_t *recv_zy, real_t *send_yx, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_bwd_b_part");
     X3D_REQUIRE(recv_zy && send_yx, "null argument");
-    if (int rc = yz_c1(p, (double2 *)recv_zy + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, false)) return rc;
+    if (int rc = yz_c1(p, (real2_t *)recv_zy + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, false)) return rc;
     if (int rc = fft_y(p, 1, m, m + 1)) return rc;
-    return xy_c1(p, (double2 *)send_yx + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, true);
+    return xy_c1(p, (real2_t *)send_yx + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, true);
 }
-extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const double *recv_yx, double *f_out, int m)
+extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const real_t *recv_yx, real_t *f_out, int m)
 {
     PFFT_PART(p, m, "x3d_pfft_bwd_a_part");
     X3D_REQUIRE(recv_yx && f_out, "null argument");
     X3D_LAZY_OUT(p->b, f_out, false);  // (a group's planes of the real extent are written)
-    if (int rc = xy_c0(p, (double2 *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
+    if (int rc = xy_c0(p, (real2_t *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
     return bwd_x(p, f_out, m, m + 1);
 }
 
@@ -488,7 +488,7 @@ extern "C" int x3d_pfft_postprocess_000(x3d_pfft *p)
 {
     X3D_REQUIRE(p, "null argument");
     if (p->xs == 0 || p->ys == 0) return 0;
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+    const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     dim3 grid((p->nz + 255) / 256, p->ys, p->xs);
     ProfScope ps(p->b, X3D_K_SPECTRAL);

@@ -15,8 +15,8 @@
 #include "poisson_priv.h"
 
 int x3d_fft512_init();
-int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
-                   const double *ab, int nx);
+int x3d_fft512_run(x3d_backend *b, real2_t *c, int nxs, int ny, int nz, int axis, int mode, const real_t *waves,
+                   const real_t *ab, int nx);
 
 #define X3D_FFT(expr)                                                                          \
     do {                                                                                       \
@@ -29,7 +29,7 @@ int x3d_fft512_run(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis
     } while (0)
 
 // pad columns [nxm, nxs) of a pitched array of doubles <- v
-__global__ void k_fill_pad(double *__restrict__ a, size_t rows, int nxm, int nxs, double v)
+__global__ void k_fill_pad(real_t *__restrict__ a, size_t rows, int nxm, int nxs, real_t v)
 {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -47,21 +47,21 @@ static int upload_pitched(void *dst, const void *src, size_t rows, int nxm, int 
 // One thread per spectral entry, x fastest -> coalesced 16 B per lane.
 // 1R(c) + 1R(waves) + 1W(c): 40 B per complex entry.
 __global__ void __launch_bounds__(256)
-    k_process_spectral_000(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz,
-                           int nx, const double *__restrict__ ax, const double *__restrict__ bx,
-                           const double *__restrict__ ay, const double *__restrict__ by,
-                           const double *__restrict__ az, const double *__restrict__ bz)
+    k_process_spectral_000(real2_t *__restrict__ c, const real_t *__restrict__ waves, int nxs, int ny, int nz,
+                           int nx, const real_t *__restrict__ ax, const real_t *__restrict__ bx,
+                           const real_t *__restrict__ ay, const real_t *__restrict__ by,
+                           const real_t *__restrict__ az, const real_t *__restrict__ bz)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0-based ix-1
     const int j = blockIdx.y, k = blockIdx.z;
     if (i >= nxs) return;
     const size_t idx = ((size_t)k * ny + j) * nxs + i;
-    double2 v = c[idx];
+    real2_t v = c[idx];
     // normalisation (:36-37): the three divisions of the reference, same order
-    double div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
-    const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
+    real_t div_r = v.x / nx / ny / nz, div_c = v.y / nx / ny / nz;
+    const real_t azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
     const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
-    double tr, tc;
+    real_t tr, tc;
     tr = div_r; tc = div_c;                       // z forward (:46-51)
     div_r = tr * bzk + tc * azk;
     div_c = tc * bzk - tr * azk;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256)
     tr = div_r; tc = div_c;                       // x forward (:62-65)
     div_r = tr * bxi + tc * axi;
     div_c = tc * bxi - tr * axi;
-    const double wv = waves[idx];                 // real part == imaginary part (:68-76)
+    const real_t wv = waves[idx];                 // real part == imaginary part (:68-76)
     if (wv < 1.e-16) { div_r = 0.0; div_c = 0.0; }
     else { div_r = -div_r / wv; div_c = -div_c / wv; }
     tr = div_r; tc = div_c;                       // z backward (:80-85)
@@ -87,12 +87,12 @@ __global__ void __launch_bounds__(256)
     tr = div_r; tc = div_c;                       // x backward (:96-99)
     div_r = tr * bxi + tc * axi;
     div_c = -tc * bxi + tr * axi;
-    c[idx] = make_double2(div_r, div_c);
+    c[idx] = make_real2(div_r, div_c);
 }
 
-extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n[3], const double *waves_re,
-                                  const double *ax, const double *bx, const double *ay, const double *by,
-                                  const double *az, const double *bz)
+extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n[3], const real_t *waves_re,
+                                  const real_t *ax, const real_t *bx, const real_t *ay, const real_t *by,
+                                  const real_t *az, const real_t *bz)
 {
     X3D_REQUIRE(b && out && n && waves_re && ax && bx && ay && by && az && bz,
                 "x3d_poisson_create: null argument");
@@ -106,22 +106,22 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
         p->nxs = (e && e[0] == '1') ? p->nxm : (p->nxm + 7) / 8 * 8;
     }
     const size_t rows = (size_t)p->nz * p->ny, ns = rows * p->nxs;
-    X3D_HIP(hipMalloc(&p->c, sizeof(double2) * ns));
-    X3D_HIP(hipMemset(p->c, 0, sizeof(double2) * ns));
-    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * ns));
-    if (int rc = upload_pitched(p->waves, waves_re, rows, p->nxm, p->nxs, sizeof(double))) return rc;
+    X3D_HIP(hipMalloc(&p->c, sizeof(real2_t) * ns));
+    X3D_HIP(hipMemset(p->c, 0, sizeof(real2_t) * ns));
+    X3D_HIP(hipMalloc(&p->waves, sizeof(real_t) * ns));
+    if (int rc = upload_pitched(p->waves, waves_re, rows, p->nxm, p->nxs, sizeof(real_t))) return rc;
     if (p->nxs > p->nxm) {
         hipLaunchKernelGGL(k_fill_pad, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, p->waves, rows, p->nxm,
                            p->nxs, 1.0);
         X3D_HIP(hipDeviceSynchronize());
     }
     const size_t nab = 2 * ((size_t)n[0] + n[1] + n[2]);
-    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * nab));
-    double *d = p->ab;
-    const double *src[6] = {ax, bx, ay, by, az, bz};
+    X3D_HIP(hipMalloc(&p->ab, sizeof(real_t) * nab));
+    real_t *d = p->ab;
+    const real_t *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {n[0], n[0], n[1], n[1], n[2], n[2]};
     for (int i = 0; i < 6; i++) {
-        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(real_t) * len[i], hipMemcpyHostToDevice));
         d += len[i];
     }
     // real side lives in the pitched block: embed = {nzp, nyp, nxp}; spectral side dense
@@ -133,9 +133,9 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
     X3D_FFT(hipfftSetAutoAllocation(p->plan_fw, 0));
     X3D_FFT(hipfftSetAutoAllocation(p->plan_bw, 0));
     size_t ws_fw = 0, ws_bw = 0;
-    X3D_FFT(hipfftMakePlanMany(p->plan_fw, 3, dims, rembed, 1, (int)b->nblock, cembed, 1, (int)ns, HIPFFT_D2Z, 1,
+    X3D_FFT(hipfftMakePlanMany(p->plan_fw, 3, dims, rembed, 1, (int)b->nblock, cembed, 1, (int)ns, X3D_FFT_R2C, 1,
                                &ws_fw));
-    X3D_FFT(hipfftMakePlanMany(p->plan_bw, 3, dims, cembed, 1, (int)ns, rembed, 1, (int)b->nblock, HIPFFT_Z2D, 1,
+    X3D_FFT(hipfftMakePlanMany(p->plan_bw, 3, dims, cembed, 1, (int)ns, rembed, 1, (int)b->nblock, X3D_FFT_C2R, 1,
                                &ws_bw));
     p->work_size = ws_fw > ws_bw ? ws_fw : ws_bw;
     if (p->work_size) X3D_HIP(hipMalloc(&p->work, p->work_size));
@@ -147,23 +147,23 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
         int nn[1] = {p->nx}, re[1] = {b->nxp}, ce[1] = {p->nxs};
         const int batch = p->ny * p->nz;
         X3D_REQUIRE(b->nyp == p->ny, "x3d_poisson_create: fast path needs nyp == ny");
-        X3D_FFT(hipfftPlanMany(&p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, batch));
-        X3D_FFT(hipfftPlanMany(&p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch));
+        X3D_FFT(hipfftPlanMany(&p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, X3D_FFT_R2C, batch));
+        X3D_FFT(hipfftPlanMany(&p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, X3D_FFT_C2R, batch));
         if (int rc = x3d_fft512_init()) return rc;
         p->fast512 = 1;
         {   // z-fastest reciprocal wave numbers for the fused z pass (spectral division in the transform's layout)
             const char *no_rwt = getenv("X3D_NO_RWT");
             if (!(no_rwt && no_rwt[0] == '1')) {
                 const size_t nsr = (size_t)p->nz * p->ny * p->nxs;
-                std::vector<double> h(nsr, 0.0);  // (pad columns: 0)
+                std::vector<real_t> h(nsr, 0.0);  // (pad columns: 0)
                 for (int k = 0; k < p->nz; k++)
                     for (int j = 0; j < p->ny; j++)
                         for (int i = 0; i < p->nxm; i++) {
-                            const double wv = waves_re[((size_t)k * p->ny + j) * p->nxm + i];
+                            const real_t wv = waves_re[((size_t)k * p->ny + j) * p->nxm + i];
                             h[((size_t)j * p->nxs + i) * p->nz + k] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
                         }
-                X3D_HIP(hipMalloc(&p->rwT, sizeof(double) * nsr));
-                X3D_HIP(hipMemcpy(p->rwT, h.data(), sizeof(double) * nsr, hipMemcpyHostToDevice));
+                X3D_HIP(hipMalloc(&p->rwT, sizeof(real_t) * nsr));
+                X3D_HIP(hipMemcpy(p->rwT, h.data(), sizeof(real_t) * nsr, hipMemcpyHostToDevice));
             }
         }
         const char *no_r2c = getenv("X3D_NO_R2C512");
@@ -186,24 +186,24 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     return 0;
 }
 
-int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);
-void x3d_fft512_set_rwT(const double *rwT);
+int x3d_fft512_r2c(x3d_backend *b, real2_t *c, const real_t *f, long nrows, long frow, long crow);
+void x3d_fft512_set_rwT(const real_t *rwT);
 
 // x pass of the fast path: real rows (nxp apart) -> nxs complex modes
-static int x_forward_512(x3d_poisson *p, const double *f)
+static int x_forward_512(x3d_poisson *p, const real_t *f)
 {
     ProfScope ps(p->b, X3D_K_FFT, 1);
     if (p->r2c512)
-        return x3d_fft512_r2c(p->b, (double2 *)p->c, f, (long)p->ny * p->nz, p->b->nxp, p->nxs);
+        return x3d_fft512_r2c(p->b, (real2_t *)p->c, f, (long)p->ny * p->nz, p->b->nxp, p->nxs);
     X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
-    X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
+    X3D_FFT(x3d_fftExecR2C(p->plan_x_fw, (x3d_fft_real *)f, (x3d_fft_cplx *)p->c));
     return 0;
 }
 
-extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
+extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
-    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 0, p, const_cast<double *>(f_in));
+    if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 0, p, const_cast<real_t *>(f_in));
     if (p->fast512) {
         if (int rc = x_forward_512(p, f_in)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
@@ -211,7 +211,7 @@ extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const double *f_in)
     }
     ProfScope ps(p->b, X3D_K_FFT, 1);
     X3D_FFT(hipfftSetStream(p->plan_fw, p->b->stream));
-    X3D_FFT(hipfftExecD2Z(p->plan_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c));
+    X3D_FFT(x3d_fftExecR2C(p->plan_fw, (x3d_fft_real *)f_in, (x3d_fft_cplx *)p->c));
     return 0;
 }
 
@@ -219,7 +219,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 {
     X3D_REQUIRE(p, "x3d_poisson_postprocess_000: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 1, p, nullptr);
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+    const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     dim3 grid((p->nxs + 255) / 256, p->ny, p->nz);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
@@ -229,7 +229,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
     return 0;
 }
 
-extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
+extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, real_t *f_out)
 {
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 2, p, f_out);
@@ -238,16 +238,16 @@ extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, double *f_out)
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
         ProfScope ps(p->b, X3D_K_FFT, 2);
         X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
-        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f_out));
+        X3D_FFT(x3d_fftExecC2R(p->plan_x_bw, (x3d_fft_cplx *)p->c, (x3d_fft_real *)f_out));
         return 0;
     }
     ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_bw, p->b->stream));
-    X3D_FFT(hipfftExecZ2D(p->plan_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f_out));
+    X3D_FFT(x3d_fftExecC2R(p->plan_bw, (x3d_fft_cplx *)p->c, (x3d_fft_real *)f_out));
     return 0;
 }
 
-extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
+extern "C" int x3d_poisson_solve_000(x3d_poisson *p, real_t *f)
 {
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
     X3D_LAZY_OUT(p->b, f, false);
@@ -261,7 +261,7 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
         ProfScope ps(p->b, X3D_K_FFT, 2);
         X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
-        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f));
+        X3D_FFT(x3d_fftExecC2R(p->plan_x_bw, (x3d_fft_cplx *)p->c, (x3d_fft_real *)f));
         return 0;
     }
     if (int rc = x3d_poisson_fft_forward(p, f)) return rc;
@@ -286,8 +286,8 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, double *f)
 // recombination (_y_pair_bw) -- src/backend/cuda/kernels/spectral_processing.f90:803-931.  All three only couple
 // planes k and nz-k+2: one thread per (x' mode, y' index, plane pair).
 __global__ void __launch_bounds__(256)
-    k_spectral_pair_z(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx,
-                      const double *__restrict__ az, const double *__restrict__ bz)
+    k_spectral_pair_z(real2_t *__restrict__ c, const real_t *__restrict__ waves, int nxs, int ny, int nz, int nx,
+                      const real_t *__restrict__ az, const real_t *__restrict__ bz)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, k = blockIdx.z + 1;  // k = 1 .. nz/2+1
@@ -296,26 +296,26 @@ __global__ void __launch_bounds__(256)
     const bool paired = k >= 2, self = paired && kr == k;
     const size_t il = ((size_t)(k - 1) * ny + j) * nxs + i;
     const size_t ir = paired ? ((size_t)(kr - 1) * ny + j) * nxs + i : il;
-    const double2 L = c[il], R = paired && !self ? c[ir] : L;
-    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
-    const double a = az[k - 1], b = bz[k - 1], a2 = paired ? az[kr - 1] : 0.0, b2 = paired ? bz[kr - 1] : 0.0;
+    const real2_t L = c[il], R = paired && !self ? c[ir] : L;
+    real_t l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
+    const real_t a = az[k - 1], b = bz[k - 1], a2 = paired ? az[kr - 1] : 0.0, b2 = paired ? bz[kr - 1] : 0.0;
     if (paired) {
-        const double n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
-        const double n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
-        const double n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
-        const double n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
+        const real_t n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
+        const real_t n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
+        const real_t n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
+        const real_t n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
         l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
         if (self) { l_r = r_r; l_c = r_c; }  // the second store wins on the self-paired plane
     }
     {
         // (the reference zeroes the mode that is Nyquist in its x and z: here y' and x')
         const bool zero_line = (j + 1) == ny / 2 + 1 && (i + 1) == nx / 2 + 1;
-        const double wl = waves[il];
+        const real_t wl = waves[il];
         l_r = fabs(wl) < 1.e-16 ? 0.0 : -l_r / wl;
         l_c = fabs(wl) < 1.e-16 ? 0.0 : -l_c / wl;
         if (zero_line) { l_r = 0.0; l_c = 0.0; }
         if (paired) {
-            const double wr = waves[ir];
+            const real_t wr = waves[ir];
             r_r = fabs(wr) < 1.e-16 ? 0.0 : -r_r / wr;
             r_c = fabs(wr) < 1.e-16 ? 0.0 : -r_c / wr;
             if (zero_line) { r_r = 0.0; r_c = 0.0; }
@@ -323,22 +323,22 @@ __global__ void __launch_bounds__(256)
     }
     if (paired) {
         if (self) { r_r = l_r; r_c = l_c; }
-        const double n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
-        const double n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
-        const double n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
-        const double n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
+        const real_t n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
+        const real_t n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
+        const real_t n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
+        const real_t n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
         l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
         if (self) { l_r = r_r; l_c = r_c; }
     }
-    c[il] = make_double2(l_r, l_c);
-    if (paired && !self) c[ir] = make_double2(r_r, r_c);
+    c[il] = make_real2(l_r, l_c);
+    if (paired && !self) c[ir] = make_real2(r_r, r_c);
 }
 
 // even/odd interleave along z on the pitched Cartesian block (the y part of enforce_periodicity_xy / undo_..., :1116-1196,
 // in the z-first transposed problem): out(i, j, k) = in(i, j, src(k))
 template <bool UNDO>
 __global__ void __launch_bounds__(256)
-    k_periodicity_z(double *__restrict__ out, const double *__restrict__ in, int nx, int ny, int nz, long nxp, long plane)
+    k_periodicity_z(real_t *__restrict__ out, const real_t *__restrict__ in, int nx, int ny, int nz, long nxp, long plane)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, k = blockIdx.z + 1;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256)
     out[(long)(kd - 1) * plane + (long)j * nxp + i] = in[(long)(ks - 1) * plane + (long)j * nxp + i];
 }
 
-extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in)
+extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_y: bad argument");
     X3D_LAZY_IN(p->b, f_in);
@@ -374,7 +374,7 @@ extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, double *f_out, 
     return 0;
 }
 
-extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, const double *f_in)
+extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_y: bad argument");
     X3D_LAZY_IN(p->b, f_in);
@@ -389,7 +389,7 @@ extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, double *f_out, con
     return 0;
 }
 
-extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
+extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_z: bad argument");
     X3D_LAZY_SYNC(p->b);
@@ -403,7 +403,7 @@ extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, double *f_out, 
     return 0;
 }
 
-extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, double *f_out, const double *f_in)
+extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_z: bad argument");
     X3D_LAZY_SYNC(p->b);
@@ -427,7 +427,7 @@ extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);
     X3D_REQUIRE(!p->stretched, "x3d_poisson_postprocess_011: uniform grids only");
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+    const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     hipStream_t st = p->b->stream;
@@ -441,18 +441,18 @@ extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
     return 0;
 }
 
-extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const double *a0, const double *a1)
+extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const real_t *a0, const real_t *a1)
 {
     X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_poisson_set_stretching: null argument");
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_poisson_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
     X3D_REQUIRE(n >= 3, "x3d_poisson_set_stretching: too few rows");
-    const size_t rows = 5 * (size_t)p->nz * n, bytes = sizeof(double) * rows * p->nxs;
-    const double *src[2] = {a0, a1};
+    const size_t rows = 5 * (size_t)p->nz * n, bytes = sizeof(real_t) * rows * p->nxs;
+    const real_t *src[2] = {a0, a1};
     for (int s = 0; s < (sym ? 2 : 1); s++) {
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
         // (pad columns all zero: k_penta_factor / k_penta_solve guard their divisions by |a3| > eps)
-        if (int rc = upload_pitched(p->lu[s], src[s], rows, p->nxm, p->nxs, sizeof(double))) return rc;
+        if (int rc = upload_pitched(p->lu[s], src[s], rows, p->nxm, p->nxs, sizeof(real_t))) return rc;
         hipLaunchKernelGGL(k_penta_factor<false>, penta_grid(p->nxs, p->nz), dim3(64), 0, p->b->stream, p->lu[s], p->nxs, n,
                            p->nz);
         X3D_HIP(hipGetLastError());
@@ -473,7 +473,7 @@ extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 }
 
 // poisson_010 (src/poisson_fft.f90:228-242): f holds the rhs on entry and the solution on exit
-extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
+extern "C" int x3d_poisson_solve_010(x3d_poisson *p, real_t *f, real_t *temp)
 {
     X3D_REQUIRE(p && f && temp, "x3d_poisson_solve_010: null argument");
     X3D_LAZY_OUT(p->b, f, false);
@@ -484,8 +484,8 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, double *f, double *temp)
     return x3d_poisson_undo_periodicity_y(p, f, temp);
 }
 
-int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, int mode, const double *tables, int sym,
-                 double *const lu[2], bool *done);
+int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, int mode, const real_t *tables, int sym,
+                 real_t *const lu[2], bool *done);
 #define Y010_DEFAULT_FORM 1  // staged (y010.hip has the measurements)
 
 // plans of the y-last form: 2-D transforms over (z, x) -- r2c along x on the pitched block, c2c along z -- batched over
@@ -504,8 +504,8 @@ static int y010_setup(x3d_poisson *p)
     X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_fw, 0));
     X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_bw, 0));
     size_t ws_fw = 0, ws_bw = 0;
-    X3D_FFT(hipfftMakePlanMany(p->plan_x010_fw, 2, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, p->ny, &ws_fw));
-    X3D_FFT(hipfftMakePlanMany(p->plan_x010_bw, 2, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, p->ny, &ws_bw));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x010_fw, 2, nn, re, 1, b->nxp, ce, 1, p->nxs, X3D_FFT_R2C, p->ny, &ws_fw));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x010_bw, 2, nn, ce, 1, p->nxs, re, 1, b->nxp, X3D_FFT_C2R, p->ny, &ws_bw));
     const size_t ws = ws_fw > ws_bw ? ws_fw : ws_bw;
     if (ws > p->work_size) {  // (the 3-D plans keep working in the larger area)
         X3D_HIP(hipFree(p->work));
@@ -525,7 +525,7 @@ static int y010_setup(x3d_poisson *p)
 // enforce_periodicity_y's order and the solution is left in that order.  ny = 256: x and z (one 2-D plan) ; the fused y pass (y010.hip:
 // y transform, fft_postprocess_010, inverse y transform in one pass over the spectrum) ; z ; x.  Otherwise the 3-D
 // transforms with the post-processing kernels between them.
-extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
+extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, real_t *f)
 {
     X3D_REQUIRE(p && f, "x3d_poisson_solve_010_rows: null argument");
     X3D_LAZY_OUT(p->b, f, false);
@@ -536,7 +536,7 @@ extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
         {
             ProfScope ps(b, X3D_K_FFT, 1);
             X3D_FFT(hipfftSetStream(p->plan_x010_fw, b->stream));
-            X3D_FFT(hipfftExecD2Z(p->plan_x010_fw, (hipfftDoubleReal *)f, (hipfftDoubleComplex *)p->c));
+            X3D_FFT(x3d_fftExecR2C(p->plan_x010_fw, (x3d_fft_real *)f, (x3d_fft_cplx *)p->c));
         }
         bool done = false;
         // X3D_Y010_FORM: "split" = k_y010<0> ; k_penta_solve x 2 ; k_y010<1>.  "staged" = the forward sweeps on the
@@ -583,7 +583,7 @@ extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
         }
         ProfScope ps(b, X3D_K_FFT, 2);
         X3D_FFT(hipfftSetStream(p->plan_x010_bw, b->stream));
-        X3D_FFT(hipfftExecZ2D(p->plan_x010_bw, (hipfftDoubleComplex *)p->c, (hipfftDoubleReal *)f));
+        X3D_FFT(x3d_fftExecC2R(p->plan_x010_bw, (x3d_fft_cplx *)p->c, (x3d_fft_real *)f));
         return 0;
     }
     if (int rc = x3d_poisson_fft_forward(p, f)) return rc;
@@ -591,22 +591,22 @@ extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, double *f)
     return x3d_poisson_fft_backward(p, f);
 }
 
-extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, double *host)
+extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, real_t *host)
 {
     X3D_REQUIRE(p && host, "null argument");
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);
     X3D_HIP(hipStreamSynchronize(p->b->stream));
-    X3D_HIP(hipMemcpy2D(host, p->nxm * sizeof(double2), p->c, p->nxs * sizeof(double2), p->nxm * sizeof(double2),
+    X3D_HIP(hipMemcpy2D(host, p->nxm * sizeof(real2_t), p->c, p->nxs * sizeof(real2_t), p->nxm * sizeof(real2_t),
                         (size_t)p->nz * p->ny, hipMemcpyDeviceToHost));
     return 0;
 }
 
-extern "C" int x3d_poisson_set_spectral(x3d_poisson *p, const double *host)
+extern "C" int x3d_poisson_set_spectral(x3d_poisson *p, const real_t *host)
 {
     X3D_REQUIRE(p && host, "null argument");
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);
     X3D_HIP(hipStreamSynchronize(p->b->stream));
-    return upload_pitched(p->c, host, (size_t)p->nz * p->ny, p->nxm, p->nxs, sizeof(double2));
+    return upload_pitched(p->c, host, (size_t)p->nz * p->ny, p->nxm, p->nxs, sizeof(real2_t));
 }

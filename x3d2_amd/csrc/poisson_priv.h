@@ -14,15 +14,15 @@ struct x3d_poisson {
                           // 128-byte line: 1.44-1.6 x the compulsory fetch, round-1 PMC).  Pad columns hold zeros
                           // (waves: ones) and are carried through every kernel; host arrays stay dense.
     hipfftHandle plan_fw, plan_bw;
-    double2 *c;           // spectral workspace [nz][ny][nxs]
-    double *waves;        // [nz][ny][nxs]
-    double *rwT;          // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), for the fused z pass of fft512.hip
-    double *ab;           // ax bx ay by az bz
+    real2_t *c;           // spectral workspace [nz][ny][nxs]
+    real_t *waves;        // [nz][ny][nxs]
+    real_t *rwT;          // [ny][nxs][nz]: -1 / waves (0 where waves < 1e-16), for the fused z pass of fft512.hip
+    real_t *ab;           // ax bx ay by az bz
     void *work;
     size_t work_size;
     // stretched y (010): factored pentadiagonal operators, [5][nz][n][nxs] each
     int stretched, sym;   // sym: odd/even rows decoupled (centred, top-bottom); else one full system
-    double *lu[2];        // sym: odd, even; else lu[0] only
+    real_t *lu[2];        // sym: odd, even; else lu[0] only
     // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
     int fast512;
     int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels
@@ -30,5 +30,5 @@ struct x3d_poisson {
     // ny = 256 (010, the channel case): x and z through 1-D rocFFT plans, y LAST inside the fused y pass (y010.hip)
     int y010;             // 0: not tried yet, 1: plans made, -1: not available for these sizes / switched off
     hipfftHandle plan_x010_fw, plan_x010_bw;  // 2-D over (z, x), batched over the y rows
-    double *rwZ;          // z-first solve: [nz/2+1][nx][ny] reciprocal wave numbers (built on first use, zfirst.hip)
+    real_t *rwZ;          // z-first solve: [nz/2+1][nx][ny] reciprocal wave numbers (built on first use, zfirst.hip)
 };

@@ -35,11 +35,11 @@
     } while (0)
 
 int x3d_fft512_init();
-int x3d_fft512_run_x(x3d_backend *b, double2 *c, int nxs, int ny, int nz, int axis, int mode, const double *waves,
-                     const double *ab, int nx, double2 *xbuf, int ys, int ysc);
+int x3d_fft512_run_x(x3d_backend *b, real2_t *c, int nxs, int ny, int nz, int axis, int mode, const real_t *waves,
+                     const real_t *ab, int nx, real2_t *xbuf, int ys, int ysc);
 
-int x3d_fft512_r2c(x3d_backend *b, double2 *c, const double *f, long nrows, long frow, long crow);  // fft512.hip
-int x3d_fft512_peers(x3d_backend *b, double2 *R, long W, int npeers, const double *waves, const double *ab, int nx, int ny,
+int x3d_fft512_r2c(x3d_backend *b, real2_t *c, const real_t *f, long nrows, long frow, long crow);  // fft512.hip
+int x3d_fft512_peers(x3d_backend *b, real2_t *R, long W, int npeers, const real_t *waves, const real_t *ab, int nx, int ny,
                      int nz, int nxs, int yoff, bool *done);  // fft512.hip
 
 struct x3d_sfft {
@@ -48,19 +48,19 @@ struct x3d_sfft {
     int pz, rz, zl, ys;   // ranks along z, this rank, local z extent, this rank's share of the y modes
     int parts, ysc;       // the share is exchanged and z-transformed in `parts` pieces of ysc y modes (overlap)
     hipfftHandle plan_x_fw, plan_x_bw, plan_z;
-    double2 *c0;          // [zl][ny][nxs]
-    double2 *t;           // [ys*nxs][nz]: z-contiguous copy of the received array
+    real2_t *c0;          // [zl][ny][nxs]
+    real2_t *t;           // [ys*nxs][nz]: z-contiguous copy of the received array
     int fused_z;          // 512 local planes, pz in {1, 2, 4, 8}: the whole z stage is ONE kernel on the received
                           // array itself (fft512.hip, k_fft512_peers): no transposed copy, no rocFFT z plan calls
-    double *waves, *ab;   // -1 / waves [ys][nxs][nz] (0 where waves < 1e-16); ax bx ay by az bz
+    real_t *waves, *ab;   // -1 / waves [ys][nxs][nz] (0 where waves < 1e-16); ax bx ay by az bz
     void *work;
 };
 
 // 32 x 32 tiles through LDS: src [nB][nA] (A contiguous) -> dst [nA][nB] (B contiguous), 512-byte rows both ways
 __global__ void __launch_bounds__(256)
-    k_sfft_transpose(double2 *__restrict__ dst, const double2 *__restrict__ src, int nA, int nB)
+    k_sfft_transpose(real2_t *__restrict__ dst, const real2_t *__restrict__ src, int nA, int nB)
 {
-    __shared__ double2 tile[32][33];
+    __shared__ real2_t tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
 #pragma unroll
@@ -79,22 +79,22 @@ __global__ void __launch_bounds__(256)
 // process_spectral_000 (src/backend/omp/kernels/spectral_processing.f90:7-106) on T[ys][nxs][nz] (z fastest):
 // y index offset = rz * ys (sp_st(2)), one thread per mode
 __global__ void __launch_bounds__(256)
-    k_process_spectral_000_slab(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ys, int nz,
-                                int yoff, int nx, int ny, const double *__restrict__ ax, const double *__restrict__ bx,
-                                const double *__restrict__ ay, const double *__restrict__ by,
-                                const double *__restrict__ az, const double *__restrict__ bz)
+    k_process_spectral_000_slab(real2_t *__restrict__ c, const real_t *__restrict__ waves, int nxs, int ys, int nz,
+                                int yoff, int nx, int ny, const real_t *__restrict__ ax, const real_t *__restrict__ bx,
+                                const real_t *__restrict__ ay, const real_t *__restrict__ by,
+                                const real_t *__restrict__ az, const real_t *__restrict__ bz)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y, jl = blockIdx.z;
     if (k >= nz) return;
     const int j = jl + yoff;
     const size_t idx = ((size_t)jl * nxs + i) * nz + k;
-    double2 v = c[idx];
-    const double rn = 1.0 / nx / ny / nz;
-    double div_r = v.x * rn, div_c = v.y * rn;
-    const double azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
+    real2_t v = c[idx];
+    const real_t rn = 1.0 / nx / ny / nz;
+    real_t div_r = v.x * rn, div_c = v.y * rn;
+    const real_t azk = az[k], bzk = bz[k], ayj = ay[j], byj = by[j], axi = ax[i], bxi = bx[i];
     const bool fz = (k + 1) > nz / 2 + 1, fy = (j + 1) > ny / 2 + 1;
-    double tr, tc;
+    real_t tr, tc;
     tr = div_r; tc = div_c;
     div_r = tr * bzk + tc * azk; div_c = tc * bzk - tr * azk;
     if (fz) { div_r = -div_r; div_c = -div_c; }
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256)
     if (fy) { div_r = -div_r; div_c = -div_c; }
     tr = div_r; tc = div_c;
     div_r = tr * bxi + tc * axi; div_c = tc * bxi - tr * axi;
-    const double rw = waves[idx];  // (-1 / waves, x3d_sfft_set_waves)
+    const real_t rw = waves[idx];  // (-1 / waves, x3d_sfft_set_waves)
     div_r = div_r * rw; div_c = div_c * rw;
     tr = div_r; tc = div_c;
     div_r = tr * bzk - tc * azk; div_c = -tc * bzk - tr * azk;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256)
     if (fy) { div_r = -div_r; div_c = -div_c; }
     tr = div_r; tc = div_c;
     div_r = tr * bxi + tc * axi; div_c = -tc * bxi + tr * axi;
-    c[idx] = make_double2(div_r, div_c);
+    c[idx] = make_real2(div_r, div_c);
 }
 
 extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
@@ -149,11 +149,11 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
     }
     X3D_REQUIRE(p->nx <= b->nxp && p->ny == b->nyp && p->zl <= b->nzp, "x3d_sfft_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs;
-    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
-    X3D_HIP(hipMemset(p->c0, 0, sizeof(double2) * n0));  // (the pad columns stay zero: the x transforms never write them)
-    X3D_HIP(hipMalloc(&p->t, sizeof(double2) * (size_t)p->nz * p->ys * p->nxs));
-    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * (size_t)p->nz * p->ys * p->nxs));
-    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nx + p->ny + p->nz)));
+    X3D_HIP(hipMalloc(&p->c0, sizeof(real2_t) * n0));
+    X3D_HIP(hipMemset(p->c0, 0, sizeof(real2_t) * n0));  // (the pad columns stay zero: the x transforms never write them)
+    X3D_HIP(hipMalloc(&p->t, sizeof(real2_t) * (size_t)p->nz * p->ys * p->nxs));
+    X3D_HIP(hipMalloc(&p->waves, sizeof(real_t) * (size_t)p->nz * p->ys * p->nxs));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(real_t) * 2 * ((size_t)p->nx + p->ny + p->nz)));
     int nn[1] = {p->nx}, re[1] = {b->nxp}, ce[1] = {p->nxs}, nzv[1] = {p->nz};
     const int batch = p->ny * p->zl, zstride = p->ysc * p->nxs;  // (z plan: one part at a time)
     hipfftHandle *pl[3] = {&p->plan_x_fw, &p->plan_x_bw, &p->plan_z};
@@ -162,10 +162,10 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
         X3D_FFT(hipfftCreate(pl[i]));
         X3D_FFT(hipfftSetAutoAllocation(*pl[i], 0));
     }
-    X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, HIPFFT_D2Z, batch, &ws[0]));
-    X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, HIPFFT_Z2D, batch, &ws[1]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nn, re, 1, b->nxp, ce, 1, p->nxs, X3D_FFT_R2C, batch, &ws[0]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nn, ce, 1, p->nxs, re, 1, b->nxp, X3D_FFT_C2R, batch, &ws[1]));
     // z transform on the z-contiguous copy T[ys*nxs][nz]
-    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, HIPFFT_Z2Z, zstride, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, nzv, 1, p->nz, nzv, 1, p->nz, X3D_FFT_C2C, zstride, &ws[2]));
     size_t wmax = 0;
     for (int i = 0; i < 3; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
@@ -194,30 +194,30 @@ extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
 
 
 // waves: this rank's spectral block [ys][nxs][nz], z fastest (real part = imaginary part); ax..bz: full arrays
-extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const double *waves, const double *ax, const double *bx,
-                                  const double *ay, const double *by, const double *az, const double *bz)
+extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const real_t *waves, const real_t *ax, const real_t *bx,
+                                  const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
     {
         // stored as -1 / waves (0 where waves < 1e-16): the kernels multiply (the reference divides per element; one
         // reciprocal here and one of nx ny nz there: <= 2 ulp apart, as in the single-rank solver)
         const size_t n = (size_t)p->nz * p->ys * p->nxs;
-        std::vector<double> rw(n);
+        std::vector<real_t> rw(n);
         for (size_t i = 0; i < n; i++) rw[i] = waves[i] < 1.e-16 ? 0.0 : -1.0 / waves[i];
-        X3D_HIP(hipMemcpy(p->waves, rw.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(p->waves, rw.data(), sizeof(real_t) * n, hipMemcpyHostToDevice));
     }
-    const double *src[6] = {ax, bx, ay, by, az, bz};
+    const real_t *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
-    double *d = p->ab;
+    real_t *d = p->ab;
     for (int i = 0; i < 6; i++) {
-        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(real_t) * len[i], hipMemcpyHostToDevice));
         d += len[i];
     }
     return 0;
 }
 
 // x R2C, y forward; the result lands in sendbuf as [peer][zl][ys][nxs]
-extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *sendbuf)
+extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const real_t *f_in, real_t *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
     X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
@@ -230,10 +230,10 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
             if (int rc = x3d_fft512_r2c(p->b, p->c0, f_in, rows, p->b->nxp, p->nxs)) return rc;
         } else {
             X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
-            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+            X3D_FFT(x3d_fftExecR2C(p->plan_x_fw, (x3d_fft_real *)f_in, (x3d_fft_cplx *)p->c0));
         }
     }
-    return x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 0, nullptr, nullptr, p->nx, (double2 *)sendbuf,
+    return x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 0, nullptr, nullptr, p->nx, (real2_t *)sendbuf,
                             p->ys, p->ysc);
 }
 
@@ -243,39 +243,39 @@ extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const double *f_in, double *s
 // pipelined solve): with fused_z the three are ONE kernel, launched by the division call.  The plain hooks
 // (x3d_sfft_fft_z / x3d_sfft_postprocess_000 = fft_forward / fft_postprocess_000 / fft_backward of the reference,
 // src/poisson_fft.f90:45-62) keep their own meaning at every grid size: after fft_forward the spectrum IS transformed
-static int sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part, bool fused_ok)
+static int sfft_fft_z_part(x3d_sfft *p, real_t *recvbuf, int dir, int part, bool fused_ok)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_fft_z_part: bad argument");
     if (p->fused_z && fused_ok) return 0;  // (forward, division and backward are one kernel: sfft_postprocess_part)
     const int W = p->ysc * p->nxs;
-    double2 *R = (double2 *)recvbuf + (size_t)part * p->nz * W, *T = p->t + (size_t)part * p->nz * W;
+    real2_t *R = (real2_t *)recvbuf + (size_t)part * p->nz * W, *T = p->t + (size_t)part * p->nz * W;
     if (dir == 0) {
         ProfScope ps(p->b, X3D_K_PACK);
         hipLaunchKernelGGL(k_sfft_transpose, dim3((W + 31) / 32, (p->nz + 31) / 32), dim3(256), 0, p->b->stream, T,
-                           (const double2 *)R, W, p->nz);
+                           (const real2_t *)R, W, p->nz);
         X3D_HIP(hipGetLastError());
     }
     {
         ProfScope ps(p->b, X3D_K_FFT, 3);
         X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)T, (hipfftDoubleComplex *)T,
+        X3D_FFT(x3d_fftExecC2C(p->plan_z, (x3d_fft_cplx *)T, (x3d_fft_cplx *)T,
                               dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     }
     if (dir == 1) {
         ProfScope ps(p->b, X3D_K_PACK);
         hipLaunchKernelGGL(k_sfft_transpose, dim3((p->nz + 31) / 32, (W + 31) / 32), dim3(256), 0, p->b->stream, R,
-                           (const double2 *)T, p->nz, W);
+                           (const real2_t *)T, p->nz, W);
         X3D_HIP(hipGetLastError());
     }
     return 0;
 }
 
-extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, double *recvbuf, int dir, int part)
+extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, real_t *recvbuf, int dir, int part)
 {
     return sfft_fft_z_part(p, recvbuf, dir, part, true);
 }
 
-extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
+extern "C" int x3d_sfft_fft_z(x3d_sfft *p, real_t *recvbuf, int dir)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
@@ -283,16 +283,16 @@ extern "C" int x3d_sfft_fft_z(x3d_sfft *p, double *recvbuf, int dir)
     return 0;
 }
 
-static int sfft_postprocess_part(x3d_sfft *p, double *recvbuf, int part, bool fused_ok)
+static int sfft_postprocess_part(x3d_sfft *p, real_t *recvbuf, int part, bool fused_ok)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft_postprocess_000_part: bad argument");
-    const double *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
+    const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     const size_t off = (size_t)part * p->nz * p->ysc * p->nxs;  // waves[ys][nxs][nz] and T share the part offset
     if (p->fused_z && fused_ok) {
         bool ok = false;
         ProfScope ps(p->b, X3D_K_FFT, 3);
-        if (int rc = x3d_fft512_peers(p->b, (double2 *)recvbuf + off, (long)p->ysc * p->nxs, p->pz, p->waves + off, p->ab,
+        if (int rc = x3d_fft512_peers(p->b, (real2_t *)recvbuf + off, (long)p->ysc * p->nxs, p->pz, p->waves + off, p->ab,
                                       p->nx, p->ny, p->nz, p->nxs, p->rz * p->ys + part * p->ysc, &ok))
             return rc;
         X3D_REQUIRE(ok, "x3d_sfft_postprocess_000_part: fused z stage refused");
@@ -306,12 +306,12 @@ static int sfft_postprocess_part(x3d_sfft *p, double *recvbuf, int part, bool fu
     return 0;
 }
 
-extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, double *recvbuf, int part)
+extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, real_t *recvbuf, int part)
 {
     return sfft_postprocess_part(p, recvbuf, part, true);
 }
 
-extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
+extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
@@ -320,15 +320,15 @@ extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, double *recvbuf)
 }
 
 // y backward from the exchange layout, x C2R
-extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const double *recvbuf, double *f_out)
+extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const real_t *recvbuf, real_t *f_out)
 {
     X3D_REQUIRE(p && recvbuf && f_out, "null argument");
     X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
     if (int rc = x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 1, nullptr, nullptr, p->nx,
-                                  (double2 *)recvbuf, p->ys, p->ysc))
+                                  (real2_t *)recvbuf, p->ys, p->ysc))
         return rc;
     ProfScope ps(p->b, X3D_K_FFT, 2);
     X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
-    X3D_FFT(hipfftExecZ2D(p->plan_x_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+    X3D_FFT(x3d_fftExecC2R(p->plan_x_bw, (x3d_fft_cplx *)p->c0, (x3d_fft_real *)f_out));
     return 0;
 }

@@ -49,20 +49,20 @@ struct x3d_sfft010 {
     int split_xy;        // rocFFT refused the 2-D real plan for these lengths: 1-D x plan (batched over all local rows)
                          // + 1-D strided y plan run once per local plane
     hipfftHandle plan_x_fw, plan_x_bw, plan_y;
-    double2 *c0;         // [zl][ny][nxs]
-    double2 *t;          // [part][ny][xsc][nz]: z-contiguous copy of the received array; the spectral stage works here
-    double *waves;       // [part][ny][xsc][nz] (pads: one)
-    double *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
+    real2_t *c0;         // [zl][ny][nxs]
+    real2_t *t;          // [part][ny][xsc][nz]: z-contiguous copy of the received array; the spectral stage works here
+    real_t *waves;       // [part][ny][xsc][nz] (pads: one)
+    real_t *ab;          // ax bx (padded to max(nx, nxs)) ay by az bz
     int nab_x;           // length of the ax / bx tables on the device
     int stretched, sym;
-    double *lu[2];       // factored pentadiagonal operators [part][5][n][xsc][nz]
+    real_t *lu[2];       // factored pentadiagonal operators [part][5][n][xsc][nz]
     void *work;
 };
 
 // C0[zl][ny][nxs] -> S[peer][part][zl][ny][xsc] (UNPACK: the other way); one thread per complex number of C0
 template <bool UNPACK>
 __global__ void __launch_bounds__(256)
-    k_sfft010_pack(double2 *__restrict__ s, double2 *__restrict__ c0, long rows, int xsc, int parts, int pz)
+    k_sfft010_pack(real2_t *__restrict__ s, real2_t *__restrict__ c0, long rows, int xsc, int parts, int pz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int xs = xsc * parts, nxs = xs * pz;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256)
 
 // set-up: src [nz][rows][xs] (x fastest, as the host builds it) -> dst [part][rows][xsc][nz] with a stride between parts
 __global__ void __launch_bounds__(256)
-    k_sfft010_gather(double *__restrict__ dst, const double *__restrict__ src, int nz, int rows, int xsc, int parts,
+    k_sfft010_gather(real_t *__restrict__ dst, const real_t *__restrict__ src, int nz, int rows, int xsc, int parts,
                      long part_stride)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,13 +155,13 @@ extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const
     p->nxs = p->xs * pz;
     X3D_REQUIRE(p->nx <= b->nxp && p->ny <= b->nyp && p->zl <= b->nzp, "x3d_sfft010_create: local block mismatch");
     const size_t n0 = (size_t)p->zl * p->ny * p->nxs, nw = (size_t)p->nz * p->ny * p->xs;
-    X3D_HIP(hipMalloc(&p->c0, sizeof(double2) * n0));
-    X3D_HIP(hipMemset(p->c0, 0, sizeof(double2) * n0));  // (pad columns stay zero: the transforms never write them)
-    X3D_HIP(hipMalloc(&p->waves, sizeof(double) * nw));
-    X3D_HIP(hipMalloc(&p->t, sizeof(double2) * nw));
+    X3D_HIP(hipMalloc(&p->c0, sizeof(real2_t) * n0));
+    X3D_HIP(hipMemset(p->c0, 0, sizeof(real2_t) * n0));  // (pad columns stay zero: the transforms never write them)
+    X3D_HIP(hipMalloc(&p->waves, sizeof(real_t) * nw));
+    X3D_HIP(hipMalloc(&p->t, sizeof(real2_t) * nw));
     p->nab_x = p->nx > p->nxs ? p->nx : p->nxs;
-    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
-    X3D_HIP(hipMemset(p->ab, 0, sizeof(double) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(real_t) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
+    X3D_HIP(hipMemset(p->ab, 0, sizeof(real_t) * 2 * ((size_t)p->nab_x + p->ny + p->nz)));
     hipfftHandle *pl[6] = {&p->plan_xy_fw, &p->plan_xy_bw, &p->plan_z, &p->plan_x_fw, &p->plan_x_bw, &p->plan_y};
     size_t ws[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 6; i++) {
@@ -171,9 +171,9 @@ extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const
     // real side: the pitched block's planes; spectral side: dense rows of nxs (the first nxm are written)
     int nn[2] = {p->ny, p->nx}, re[2] = {b->nyp, b->nxp}, ce[2] = {p->ny, p->nxs};
     const hipfftResult r_fw = hipfftMakePlanMany(p->plan_xy_fw, 2, nn, re, 1, b->nxp * b->nyp, ce, 1, p->ny * p->nxs,
-                                                 HIPFFT_D2Z, p->zl, &ws[0]);
+                                                 X3D_FFT_R2C, p->zl, &ws[0]);
     const hipfftResult r_bw = hipfftMakePlanMany(p->plan_xy_bw, 2, nn, ce, 1, p->ny * p->nxs, re, 1, b->nxp * b->nyp,
-                                                 HIPFFT_Z2D, p->zl, &ws[1]);
+                                                 X3D_FFT_C2R, p->zl, &ws[1]);
     {
         const char *e = getenv("X3D_SFFT010_SPLIT_XY");
         p->split_xy = r_fw != HIPFFT_SUCCESS || r_bw != HIPFFT_SUCCESS || (e && e[0] == '1');
@@ -183,13 +183,13 @@ extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const
         int nx1[1] = {p->nx}, rx[1] = {b->nxp}, cx[1] = {p->nxs}, ny1[1] = {p->ny}, ey[1] = {p->ny};
         // x: every local row (the block's rows are nxp apart whatever the plane: nyp rows per plane, of which ny are used --
         // one batch per plane keeps to the used rows)
-        X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nx1, rx, 1, b->nxp, cx, 1, p->nxs, HIPFFT_D2Z, p->ny, &ws[3]));
-        X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nx1, cx, 1, p->nxs, rx, 1, b->nxp, HIPFFT_Z2D, p->ny, &ws[4]));
-        X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, ny1, ey, p->nxs, 1, ey, p->nxs, 1, HIPFFT_Z2Z, p->nxs, &ws[5]));
+        X3D_FFT(hipfftMakePlanMany(p->plan_x_fw, 1, nx1, rx, 1, b->nxp, cx, 1, p->nxs, X3D_FFT_R2C, p->ny, &ws[3]));
+        X3D_FFT(hipfftMakePlanMany(p->plan_x_bw, 1, nx1, cx, 1, p->nxs, rx, 1, b->nxp, X3D_FFT_C2R, p->ny, &ws[4]));
+        X3D_FFT(hipfftMakePlanMany(p->plan_y, 1, ny1, ey, p->nxs, 1, ey, p->nxs, 1, X3D_FFT_C2C, p->nxs, &ws[5]));
     }
     // z transform on the z-contiguous copy T[ny * xs][nz]
     int nzv[1] = {p->nz}, ze[1] = {p->nz};
-    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, 1, p->nz, ze, 1, p->nz, HIPFFT_Z2Z, p->ny * p->xsc, &ws[2]));
+    X3D_FFT(hipfftMakePlanMany(p->plan_z, 1, nzv, ze, 1, p->nz, ze, 1, p->nz, X3D_FFT_C2C, p->ny * p->xsc, &ws[2]));
     size_t wmax = 0;
     for (int i = 0; i < 6; i++) wmax = ws[i] > wmax ? ws[i] : wmax;
     if (wmax) X3D_HIP(hipMalloc(&p->work, wmax));
@@ -221,47 +221,47 @@ extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6])
 }
 
 // waves: this rank's block [nz][ny][xs] (x fastest; pad columns: one); ax .. bz: the global tables
-extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const double *waves, const double *ax, const double *bx,
-                                     const double *ay, const double *by, const double *az, const double *bz)
+extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const real_t *waves, const real_t *ax, const real_t *bx,
+                                     const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
     {   // [nz][ny][xs] on the host -> [part][ny][xsc][nz] on the device (T serves as the landing zone)
         const size_t nw = (size_t)p->nz * p->ny * p->xs;
-        X3D_HIP(hipMemcpy(p->t, waves, sizeof(double) * nw, hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(p->t, waves, sizeof(real_t) * nw, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_sfft010_gather, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, p->b->stream, p->waves,
-                           (const double *)p->t, p->nz, p->ny, p->xsc, p->parts, (long)p->ny * p->xsc * p->nz);
+                           (const real_t *)p->t, p->nz, p->ny, p->xsc, p->parts, (long)p->ny * p->xsc * p->nz);
         X3D_HIP(hipGetLastError());
         X3D_HIP(hipStreamSynchronize(p->b->stream));
     }
-    const double *src[6] = {ax, bx, ay, by, az, bz};
+    const real_t *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {p->nx, p->nx, p->ny, p->ny, p->nz, p->nz};
     const int slot[6] = {p->nab_x, p->nab_x, p->ny, p->ny, p->nz, p->nz};
-    double *d = p->ab;
+    real_t *d = p->ab;
     for (int i = 0; i < 6; i++) {
-        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(real_t) * len[i], hipMemcpyHostToDevice));
         d += slot[i];
     }
     return 0;
 }
 
 // a0, a1: this rank's columns of the pentadiagonal operators, [5][nz][n][xs] (pad columns zero); sym: odd / even rows
-extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double *a0, const double *a1)
+extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const real_t *a0, const real_t *a1)
 {
     X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_sfft010_set_stretching: null argument");
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_sfft010_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
     X3D_REQUIRE(n >= 3, "x3d_sfft010_set_stretching: too few rows");
-    const size_t nd = (size_t)p->nz * n * p->xs, bytes = sizeof(double) * 5 * nd;
-    const double *src[2] = {a0, a1};
-    double *tmp = nullptr;  // one diagonal [nz][n][xs] as uploaded, before it goes to its place in [part][5][n][xsc][nz]
-    X3D_HIP(hipMalloc(&tmp, sizeof(double) * nd));
+    const size_t nd = (size_t)p->nz * n * p->xs, bytes = sizeof(real_t) * 5 * nd;
+    const real_t *src[2] = {a0, a1};
+    real_t *tmp = nullptr;  // one diagonal [nz][n][xs] as uploaded, before it goes to its place in [part][5][n][xsc][nz]
+    X3D_HIP(hipMalloc(&tmp, sizeof(real_t) * nd));
     const long ndp = (long)n * p->xsc * p->nz;  // one diagonal of one group
     for (int s = 0; s < (sym ? 2 : 1); s++) {
         if (!p->lu[s]) X3D_HIP(hipMalloc(&p->lu[s], bytes));
         for (int d = 0; d < 5; d++) {
-            X3D_HIP(hipMemcpy(tmp, src[s] + d * nd, sizeof(double) * nd, hipMemcpyHostToDevice));
+            X3D_HIP(hipMemcpy(tmp, src[s] + d * nd, sizeof(real_t) * nd, hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_sfft010_gather, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, p->b->stream,
-                               p->lu[s] + d * ndp, (const double *)tmp, p->nz, n, p->xsc, p->parts, 5 * ndp);
+                               p->lu[s] + d * ndp, (const real_t *)tmp, p->nz, n, p->xsc, p->parts, 5 * ndp);
             X3D_HIP(hipGetLastError());
             X3D_HIP(hipStreamSynchronize(p->b->stream));
         }
@@ -278,7 +278,7 @@ extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const double 
 }
 
 // enforce / undo_periodicity_y on the rank's zl planes (y is whole on every rank)
-extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const double *f_in, int undo)
+extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, real_t *f_out, const real_t *f_in, int undo)
 {
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_sfft010_periodicity_y: bad argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
@@ -296,56 +296,56 @@ extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, double *f_out, const do
 }
 
 // 2-D transform of the local planes; the result lands in sendbuf as [peer][part][zl][ny][xsc]
-extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const double *f_in, double *sendbuf)
+extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const real_t *f_in, real_t *sendbuf)
 {
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     if (!p->split_xy) {
         ProfScope ps(p->b, X3D_K_FFT, 1);
         X3D_FFT(hipfftSetStream(p->plan_xy_fw, p->b->stream));
-        X3D_FFT(hipfftExecD2Z(p->plan_xy_fw, (hipfftDoubleReal *)f_in, (hipfftDoubleComplex *)p->c0));
+        X3D_FFT(x3d_fftExecR2C(p->plan_xy_fw, (x3d_fft_real *)f_in, (x3d_fft_cplx *)p->c0));
     } else {
         ProfScope ps(p->b, X3D_K_FFT, 1);
         X3D_FFT(hipfftSetStream(p->plan_x_fw, p->b->stream));
         X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
         for (int k = 0; k < p->zl; k++) {
-            hipfftDoubleComplex *c = (hipfftDoubleComplex *)(p->c0 + (size_t)k * p->ny * p->nxs);
-            X3D_FFT(hipfftExecD2Z(p->plan_x_fw, (hipfftDoubleReal *)f_in + (size_t)k * p->b->nxp * p->b->nyp, c));
-            X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, HIPFFT_FORWARD));
+            x3d_fft_cplx *c = (x3d_fft_cplx *)(p->c0 + (size_t)k * p->ny * p->nxs);
+            X3D_FFT(x3d_fftExecR2C(p->plan_x_fw, (x3d_fft_real *)f_in + (size_t)k * p->b->nxp * p->b->nyp, c));
+            X3D_FFT(x3d_fftExecC2C(p->plan_y, c, c, HIPFFT_FORWARD));
         }
     }
     ProfScope ps(p->b, X3D_K_PACK);
     const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
     hipLaunchKernelGGL(k_sfft010_pack<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
-                       (double2 *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
+                       (real2_t *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
 // dir 0: group `part` of the received array, W_m[nz][ny][xsc] -> T_m[ny][xsc][nz], forward z transform (the spectrum
 // stays in T); dir 1: backward z transform of T_m, then back to W_m
-extern "C" int x3d_sfft010_fft_z_part(x3d_sfft010 *p, double *recvbuf, int dir, int part)
+extern "C" int x3d_sfft010_fft_z_part(x3d_sfft010 *p, real_t *recvbuf, int dir, int part)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_fft_z_part: bad argument");
     const long cols = (long)p->ny * p->xsc;
-    double2 *W = (double2 *)recvbuf + (size_t)part * p->nz * cols, *T = p->t + (size_t)part * p->nz * cols;
+    real2_t *W = (real2_t *)recvbuf + (size_t)part * p->nz * cols, *T = p->t + (size_t)part * p->nz * cols;
     if (dir == 0) {
         ProfScope ps(p->b, X3D_K_PACK);
-        if (int rc = transpose_launch<double2>(p->b->stream, T, (const double2 *)W, cols, p->nz)) return rc;
+        if (int rc = transpose_launch<real2_t>(p->b->stream, T, (const real2_t *)W, cols, p->nz)) return rc;
     }
     {
         ProfScope ps(p->b, X3D_K_FFT, 3);
         X3D_FFT(hipfftSetStream(p->plan_z, p->b->stream));
-        X3D_FFT(hipfftExecZ2Z(p->plan_z, (hipfftDoubleComplex *)T, (hipfftDoubleComplex *)T, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+        X3D_FFT(x3d_fftExecC2C(p->plan_z, (x3d_fft_cplx *)T, (x3d_fft_cplx *)T, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
     }
     if (dir == 1) {
         ProfScope ps(p->b, X3D_K_PACK);
-        if (int rc = transpose_launch<double2>(p->b->stream, W, (const double2 *)T, p->nz, cols)) return rc;
+        if (int rc = transpose_launch<real2_t>(p->b->stream, W, (const real2_t *)T, p->nz, cols)) return rc;
     }
     return 0;
 }
 
-extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
+extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, real_t *recvbuf, int dir)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
@@ -354,21 +354,21 @@ extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, double *recvbuf, int dir)
 }
 
 // fft_postprocess_010 on one group of this rank's x modes (all rows, all z modes), in the z-contiguous copy
-extern "C" int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, double *recvbuf, int part)
+extern "C" int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, real_t *recvbuf, int part)
 {
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_postprocess_010_part: bad argument");
     ProfScope ps(p->b, X3D_K_SPECTRAL);
-    const double *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
+    const real_t *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     const size_t off = (size_t)part * p->nz * p->ny * p->xsc;
     const int n = p->sym ? p->ny / 2 : p->ny;
-    double *lu[2] = {p->lu[0] ? p->lu[0] + (size_t)part * 5 * n * p->xsc * p->nz : nullptr,
+    real_t *lu[2] = {p->lu[0] ? p->lu[0] + (size_t)part * 5 * n * p->xsc * p->nz : nullptr,
                      p->lu[1] ? p->lu[1] + (size_t)part * 5 * n * p->xsc * p->nz : nullptr};
     return spectral_010_launch_t<true>(p->b->stream, p->t + off, p->waves + off, p->xsc, p->nx, p->ny, p->nz,
                                        p->rz * p->xs + part * p->xsc, ax, bx, ay, by, az, bz, p->stretched, p->sym, lu);
 }
 
-extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
+extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
@@ -377,7 +377,7 @@ extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, double *recvbuf)
 }
 
 // unpack the returned array S[peer][part][zl][ny][xsc] and transform back to the real planes
-extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf, double *f_out)
+extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const real_t *sendbuf, real_t *f_out)
 {
     X3D_REQUIRE(p && sendbuf && f_out, "null argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
@@ -385,21 +385,21 @@ extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const double *sendbuf,
         ProfScope ps(p->b, X3D_K_PACK);
         const long rows = (long)p->zl * p->ny, n = rows * p->nxs;
         hipLaunchKernelGGL(k_sfft010_pack<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->b->stream,
-                           (double2 *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
+                           (real2_t *)sendbuf, p->c0, rows, p->xsc, p->parts, p->pz);
         X3D_HIP(hipGetLastError());
     }
     ProfScope ps(p->b, X3D_K_FFT, 2);
     if (!p->split_xy) {
         X3D_FFT(hipfftSetStream(p->plan_xy_bw, p->b->stream));
-        X3D_FFT(hipfftExecZ2D(p->plan_xy_bw, (hipfftDoubleComplex *)p->c0, (hipfftDoubleReal *)f_out));
+        X3D_FFT(x3d_fftExecC2R(p->plan_xy_bw, (x3d_fft_cplx *)p->c0, (x3d_fft_real *)f_out));
         return 0;
     }
     X3D_FFT(hipfftSetStream(p->plan_x_bw, p->b->stream));
     X3D_FFT(hipfftSetStream(p->plan_y, p->b->stream));
     for (int k = 0; k < p->zl; k++) {
-        hipfftDoubleComplex *c = (hipfftDoubleComplex *)(p->c0 + (size_t)k * p->ny * p->nxs);
-        X3D_FFT(hipfftExecZ2Z(p->plan_y, c, c, HIPFFT_BACKWARD));
-        X3D_FFT(hipfftExecZ2D(p->plan_x_bw, c, (hipfftDoubleReal *)f_out + (size_t)k * p->b->nxp * p->b->nyp));
+        x3d_fft_cplx *c = (x3d_fft_cplx *)(p->c0 + (size_t)k * p->ny * p->nxs);
+        X3D_FFT(x3d_fftExecC2C(p->plan_y, c, c, HIPFFT_BACKWARD));
+        X3D_FFT(x3d_fftExecC2R(p->plan_x_bw, c, (x3d_fft_real *)f_out + (size_t)k * p->b->nxp * p->b->nyp));
     }
     return 0;
 }

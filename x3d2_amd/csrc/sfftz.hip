@@ -33,11 +33,11 @@
 #define SZ_MAXPARTS 8
 
 int x3d_fft512_init();
-const double2 *x3d_fft512_twiddles();
-int x3d_fft512_peers_yl(x3d_backend *b, double2 *R, long W, int npeers, const double *rw, const double *ab, int nx, int ny,
+const real2_t *x3d_fft512_twiddles();
+int x3d_fft512_peers_yl(x3d_backend *b, real2_t *R, long W, int npeers, const real_t *rw, const real_t *ab, int nx, int ny,
                         int nz, int xs, int xoff, int kz0, int part);
-int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd, int y0, int nyr);
-int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ztile_fft_run(x3d_backend *b, real_t *f, const ZfArg &zf, bool fwd, int y0, int nyr);
+int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                           const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr);
 
 struct x3d_sfftz {
@@ -45,39 +45,39 @@ struct x3d_sfftz {
     int py, ry, xs, xoff, parts;
     int kz0[SZ_MAXPARTS + 1];   // part m: planes kz0[m] .. kz0[m + 1] - 1
     long off[SZ_MAXPARTS + 1];  // part m's block in the exchange buffers (complex elements)
-    double2 *c;                 // C[257][512][SZ_PX]
-    double *rw;                 // [257 * xs][512 py]: -1 / waves of this rank's modes, y fastest, part after part
-    double *ab;                 // ax bx (512) ay by (512 py) az bz (512)
+    real2_t *c;                 // C[257][512][SZ_PX]
+    real_t *rw;                 // [257 * xs][512 py]: -1 / waves of this rank's modes, y fastest, part after part
+    real_t *ab;                 // ax bx (512) ay by (512 py) az bz (512)
 };
 
 // rows (kz, yl) of C, kz in [k0, k1): forward transform along x, x mode kx -> peer kx / xs: S[(r * 512 + yl) * kzc + kz - k0][kx % xs]
 template <bool PACK>
 __global__ void __launch_bounds__(512)
-    k_c2c512_x_xchg(double2 *__restrict__ c, double2 *__restrict__ sm, const double2 *__restrict__ twg, int k0, int kzc,
+    k_c2c512_x_xchg(real2_t *__restrict__ c, real2_t *__restrict__ sm, const real2_t *__restrict__ twg, int k0, int kzc,
                     int xs, int y0, int nyr)
 {
-    extern __shared__ double2 zx[];  // [8][FP] + 256 twiddles
-    double2 *__restrict__ tws = zx + 8 * FP;
+    extern __shared__ real2_t zx[];  // [8][FP] + 256 twiddles
+    real2_t *__restrict__ tws = zx + 8 * FP;
     if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
     __syncthreads();
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double2 *__restrict__ pen = zx + w * FP;
+    real2_t *__restrict__ pen = zx + w * FP;
     const long nrows = (long)kzc * nyr, step = (long)gridDim.x * 8;  // rows (kl, yl), yl in [y0, y0 + nyr)
     for (long row = (long)blockIdx.x * 8 + w; row < nrows; row += step) {
         const int kl = (int)(row / nyr), yl = y0 + (int)(row - (long)kl * nyr);
-        double2 *__restrict__ cr = c + ((long)(k0 + kl) * 512 + yl) * SZ_PX;
-        double2 a[8];
+        real2_t *__restrict__ cr = c + ((long)(k0 + kl) * 512 + yl) * SZ_PX;
+        real2_t a[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int kx = l + 64 * k, r = kx / xs, xi = kx - r * xs;
-            double2 *__restrict__ sp = sm + (((long)r * 512 + yl) * kzc + kl) * xs + xi;
+            real2_t *__restrict__ sp = sm + (((long)r * 512 + yl) * kzc + kl) * xs + xi;
             if (PACK) a[k] = cr[kx]; else a[k] = *sp;
         }
         if (PACK) fft512_wave<-1>(a, pen, tws, l); else fft512_wave<1>(a, pen, tws, l);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int kx = l + 64 * k, r = kx / xs, xi = kx - r * xs;
-            double2 *__restrict__ sp = sm + (((long)r * 512 + yl) * kzc + kl) * xs + xi;
+            real2_t *__restrict__ sp = sm + (((long)r * 512 + yl) * kzc + kl) * xs + xi;
             if (PACK) *sp = a[k]; else cr[kx] = a[k];
         }
     }
@@ -100,10 +100,10 @@ extern "C" int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob
         p->kz0[m] = (int)((long)257 * m / parts);
         p->off[m] = (long)p->kz0[m] * 512 * 512;  // (py peers x 512 rows x kzc x xs = 512 x 512 per plane)
     }
-    X3D_HIP(hipMalloc(&p->c, sizeof(double2) * 257 * 512 * SZ_PX));
-    X3D_HIP(hipMemset(p->c, 0, sizeof(double2) * 257 * 512 * SZ_PX));
-    X3D_HIP(hipMalloc(&p->rw, sizeof(double) * 257 * p->xs * 512 * py));
-    X3D_HIP(hipMalloc(&p->ab, sizeof(double) * 2 * (512 + 512 * py + 512)));
+    X3D_HIP(hipMalloc(&p->c, sizeof(real2_t) * 257 * 512 * SZ_PX));
+    X3D_HIP(hipMemset(p->c, 0, sizeof(real2_t) * 257 * 512 * SZ_PX));
+    X3D_HIP(hipMalloc(&p->rw, sizeof(real_t) * 257 * p->xs * 512 * py));
+    X3D_HIP(hipMalloc(&p->ab, sizeof(real_t) * 2 * (512 + 512 * py + 512)));
     *out = p;
     return 0;
 }
@@ -127,16 +127,16 @@ extern "C" int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16])
 
 // rw: -1 / waves (0 where waves < 1e-16) of this rank's modes, [kz = 0 .. 256][x = xoff .. xoff + xs)[y = 0 .. 512 py),
 // y fastest (a part's modes are then contiguous: W = kzc * xs rows of ny); ax .. bz: global lengths
-extern "C" int x3d_sfftz_set_waves(x3d_sfftz *p, const double *rw, const double *ax, const double *bx, const double *ay,
-                                   const double *by, const double *az, const double *bz)
+extern "C" int x3d_sfftz_set_waves(x3d_sfftz *p, const real_t *rw, const real_t *ax, const real_t *bx, const real_t *ay,
+                                   const real_t *by, const real_t *az, const real_t *bz)
 {
     X3D_REQUIRE(p && rw && ax && bx && ay && by && az && bz, "null argument");
-    X3D_HIP(hipMemcpy(p->rw, rw, sizeof(double) * 257 * p->xs * 512 * p->py, hipMemcpyHostToDevice));
-    double *d = p->ab;
-    const double *src[6] = {ax, bx, ay, by, az, bz};
+    X3D_HIP(hipMemcpy(p->rw, rw, sizeof(real_t) * 257 * p->xs * 512 * p->py, hipMemcpyHostToDevice));
+    real_t *d = p->ab;
+    const real_t *src[6] = {ax, bx, ay, by, az, bz};
     const int len[6] = {512, 512, 512 * p->py, 512 * p->py, 512, 512};
     for (int i = 0; i < 6; i++) {
-        X3D_HIP(hipMemcpy(d, src[i], sizeof(double) * len[i], hipMemcpyHostToDevice));
+        X3D_HIP(hipMemcpy(d, src[i], sizeof(real_t) * len[i], hipMemcpyHostToDevice));
         d += len[i];
     }
     return 0;
@@ -145,7 +145,7 @@ extern "C" int x3d_sfftz_set_waves(x3d_sfftz *p, const double *rw, const double 
 static ZfArg zfarg(const x3d_sfftz *p) { return ZfArg{p->c, x3d_fft512_twiddles(), 512, (long)SZ_PX}; }
 
 // the z pairs next to the solve (as x3d_tds_pair_zfirst); *done = 0: these operators are not served, nothing was done
-extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1, const double *in2,
+extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                                   const x3d_tdsops *ta, const x3d_tdsops *tb, int *done)
 {
     X3D_REQUIRE(p && ta && tb && done, "x3d_sfftz_tds_pair: null argument");
@@ -160,8 +160,8 @@ extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, double *out1, double *
     return 0;
 }
 // ... for the tiles of the local y rows [y0, y0 + nyr) only
-extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, double *out1, double *out2, const double *in1,
-                                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done)
+extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                                       const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done)
 {
     X3D_REQUIRE(p && ta && tb && done, "x3d_sfftz_tds_pair_rows: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_sfftz_tds_pair_rows: mode must be 0 or 1");
@@ -177,13 +177,13 @@ extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, double *out1, dou
 }
 
 // the z transform of a field in memory (the hooks' form; the solver's fused driver uses x3d_sfftz_tds_pair)
-extern "C" int x3d_sfftz_z(x3d_sfftz *p, double *f, int inverse)
+extern "C" int x3d_sfftz_z(x3d_sfftz *p, real_t *f, int inverse)
 {
     X3D_REQUIRE(p && f, "null argument");
     X3D_LAZY_SYNC(p->b);
     return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, 0, -1);
 }
-extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, double *f, int inverse, int y0, int nyr)
+extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, real_t *f, int inverse, int y0, int nyr)
 {
     X3D_REQUIRE(p && f, "null argument");
     X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= 512, "x3d_sfftz_z_rows: rows [%d, %d) of 512", y0, y0 + nyr);
@@ -194,9 +194,9 @@ extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, double *f, int inverse, int y0, in
 #define SZ_PART(p, m, name) X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": part %d of %d", (m), (p) ? (p)->parts : 0)
 
 template <bool PACK>
-static int x_xchg(x3d_sfftz *p, double *buf, int m, int y0 = 0, int nyr = 512)
+static int x_xchg(x3d_sfftz *p, real_t *buf, int m, int y0 = 0, int nyr = 512)
 {
-    const int lds = sizeof(double2) * (8 * FP + 256);
+    const int lds = sizeof(real2_t) * (8 * FP + 256);
     X3D_LDS_OPTIN(p->b, (k_c2c512_x_xchg<PACK>));
     const int kzc = p->kz0[m + 1] - p->kz0[m];
     if (nyr == 0) return 0;
@@ -204,12 +204,12 @@ static int x_xchg(x3d_sfftz *p, double *buf, int m, int y0 = 0, int nyr = 512)
     if (blocks > 2048) blocks = 2048;
     ProfScope ps(p->b, X3D_K_FFT, PACK ? 1 : 2);
     hipLaunchKernelGGL((k_c2c512_x_xchg<PACK>), dim3((unsigned)blocks), dim3(512), lds, p->b->stream, p->c,
-                       (double2 *)buf + p->off[m], x3d_fft512_twiddles(), p->kz0[m], kzc, p->xs, y0, nyr);
+                       (real2_t *)buf + p->off[m], x3d_fft512_twiddles(), p->kz0[m], kzc, p->xs, y0, nyr);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 // part m of the spectrum: x forward, into sendbuf's part block
-extern "C" int x3d_sfftz_x_forward(x3d_sfftz *p, double *sendbuf, int m)
+extern "C" int x3d_sfftz_x_forward(x3d_sfftz *p, real_t *sendbuf, int m)
 {
     SZ_PART(p, m, "x3d_sfftz_x_forward");
     X3D_REQUIRE(sendbuf, "null argument");
@@ -217,39 +217,39 @@ extern "C" int x3d_sfftz_x_forward(x3d_sfftz *p, double *sendbuf, int m)
 }
 // part m received: y forward + process_spectral_000 + y inverse, in place (what = 0); what = 1 / 2 / 3: the forward
 // transform / the inverse / the division alone, for the hooks of the reference's interface called one by one
-extern "C" int x3d_sfftz_y_stage(x3d_sfftz *p, double *recvbuf, int m, int what)
+extern "C" int x3d_sfftz_y_stage(x3d_sfftz *p, real_t *recvbuf, int m, int what)
 {
     SZ_PART(p, m, "x3d_sfftz_y_stage");
     X3D_REQUIRE(recvbuf && what >= 0 && what <= 3, "x3d_sfftz_y_stage: bad argument");
     const int kzc = p->kz0[m + 1] - p->kz0[m];
     const long W = (long)kzc * p->xs;
     ProfScope ps(p->b, X3D_K_SPECTRAL, 1);
-    return x3d_fft512_peers_yl(p->b, (double2 *)recvbuf + p->off[m], W, p->py,
+    return x3d_fft512_peers_yl(p->b, (real2_t *)recvbuf + p->off[m], W, p->py,
                                p->rw + (long)p->kz0[m] * p->xs * 512 * p->py, p->ab, 512, 512 * p->py, 512, p->xs, p->xoff,
                                p->kz0[m], what);
 }
 // part m back in buf's part block: x inverse, into the spectrum
-extern "C" int x3d_sfftz_x_backward(x3d_sfftz *p, const double *buf, int m)
+extern "C" int x3d_sfftz_x_backward(x3d_sfftz *p, const real_t *buf, int m)
 {
     SZ_PART(p, m, "x3d_sfftz_x_backward");
     X3D_REQUIRE(buf, "null argument");
-    return x_xchg<false>(p, const_cast<double *>(buf), m);
+    return x_xchg<false>(p, const_cast<real_t *>(buf), m);
 }
 
 // block (rows [y0, y0 + nyr), part m): x forward into sendbuf / x inverse out of buf -- the rows' piece of every (part, peer)
 // chunk is contiguous: complex elements [off(m) + (r 512 + y0) kzc xs, + nyr kzc xs) for peer r
 #define SZ_ROWS(y0, nyr, name) X3D_REQUIRE((y0) >= 0 && (nyr) >= 0 && (y0) + (nyr) <= 512, name ": rows [%d, %d) of 512", (y0), (y0) + (nyr))
-extern "C" int x3d_sfftz_x_forward_rows(x3d_sfftz *p, double *sendbuf, int m, int y0, int nyr)
+extern "C" int x3d_sfftz_x_forward_rows(x3d_sfftz *p, real_t *sendbuf, int m, int y0, int nyr)
 {
     SZ_PART(p, m, "x3d_sfftz_x_forward_rows");
     SZ_ROWS(y0, nyr, "x3d_sfftz_x_forward_rows");
     X3D_REQUIRE(sendbuf, "null argument");
     return x_xchg<true>(p, sendbuf, m, y0, nyr);
 }
-extern "C" int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const double *buf, int m, int y0, int nyr)
+extern "C" int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const real_t *buf, int m, int y0, int nyr)
 {
     SZ_PART(p, m, "x3d_sfftz_x_backward_rows");
     SZ_ROWS(y0, nyr, "x3d_sfftz_x_backward_rows");
     X3D_REQUIRE(buf, "null argument");
-    return x_xchg<false>(p, const_cast<double *>(buf), m, y0, nyr);
+    return x_xchg<false>(p, const_cast<real_t *>(buf), m, y0, nyr);
 }

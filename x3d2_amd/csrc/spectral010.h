@@ -14,7 +14,7 @@
 // even/odd interleave along y on the pitched Cartesian block: out(i, j, k) = in(i, src(j), k)
 template <bool UNDO>
 static __global__ void __launch_bounds__(256)
-    k_periodicity_y(double *__restrict__ out, const double *__restrict__ in, int nx, int ny, int nz, long nxp,
+    k_periodicity_y(real_t *__restrict__ out, const real_t *__restrict__ in, int nx, int ny, int nz, long nxp,
                     long plane)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,18 +36,18 @@ static __global__ void __launch_bounds__(256)
     out[(long)k * plane + (long)(jd - 1) * nxp + i] = in[(long)k * plane + (long)(js - 1) * nxp + i];
 }
 
-struct Rot { double a, b; bool flip; };
+struct Rot { real_t a, b; bool flip; };
 
-__device__ __forceinline__ void rot_fw(double &r, double &c, const Rot &t)
+__device__ __forceinline__ void rot_fw(real_t &r, real_t &c, const Rot &t)
 {
-    const double tr = r, tc = c;
+    const real_t tr = r, tc = c;
     r = tr * t.b + tc * t.a;
     c = tc * t.b - tr * t.a;
     if (t.flip) { r = -r; c = -c; }
 }
-__device__ __forceinline__ void rot_bw(double &r, double &c, const Rot &t)
+__device__ __forceinline__ void rot_bw(real_t &r, real_t &c, const Rot &t)
 {
-    const double tr = r, tc = c;
+    const real_t tr = r, tc = c;
     r = tr * t.b - tc * t.a;
     c = tc * t.b + tr * t.a;
     if (t.flip) { r = -r; c = -c; }
@@ -64,9 +64,9 @@ __device__ __forceinline__ void rot_bw(double &r, double &c, const Rot &t)
 // ZF: the arrays are [ny][nxs][nz], z fastest (the slab solver's z-contiguous copy, sfft010.hip) instead of [nz][ny][nxs]
 template <int MODE, bool ZROT = true, bool ZF = false>
 static __global__ void __launch_bounds__(256)
-    k_spectral_010(double2 *__restrict__ c, const double *__restrict__ waves, int nxs, int ny, int nz, int nx, int i0,
-                   const double *__restrict__ ax, const double *__restrict__ bx, const double *__restrict__ ay,
-                   const double *__restrict__ by, const double *__restrict__ az, const double *__restrict__ bz)
+    k_spectral_010(real2_t *__restrict__ c, const real_t *__restrict__ waves, int nxs, int ny, int nz, int nx, int i0,
+                   const real_t *__restrict__ ax, const real_t *__restrict__ bx, const real_t *__restrict__ ay,
+                   const real_t *__restrict__ by, const real_t *__restrict__ az, const real_t *__restrict__ bz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int i, j, k;
@@ -83,8 +83,8 @@ static __global__ void __launch_bounds__(256)
     const size_t il = ZF ? ((size_t)(j - 1) * nxs + i) * nz + k : ((size_t)k * ny + (j - 1)) * nxs + i;
     const size_t ir = !paired ? il : (ZF ? ((size_t)(jr - 1) * nxs + i) * nz + k : ((size_t)k * ny + (jr - 1)) * nxs + i);
     const Rot rz{az[k], bz[k], (k + 1) > nz / 2 + 1}, rx{ax[ig], bx[ig], (ig + 1) > nx / 2 + 1};
-    double2 L = c[il], R = paired && !self ? c[ir] : L;
-    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
+    real2_t L = c[il], R = paired && !self ? c[ir] : L;
+    real_t l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
     if (MODE != 1) {
         l_r = l_r / nx / ny / nz; l_c = l_c / nx / ny / nz;
         if (ZROT) rot_fw(l_r, l_c, rz);
@@ -96,23 +96,23 @@ static __global__ void __launch_bounds__(256)
             rot_fw(r_r, r_c, rx);
         }
         if (paired) {
-            const double a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
-            const double n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
-            const double n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
-            const double n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
-            const double n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
+            const real_t a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
+            const real_t n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
+            const real_t n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
+            const real_t n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
+            const real_t n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
             l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
             if (self) { l_r = r_r; l_c = r_c; }  // the second store wins on the self-paired row
         }
     }
     if (MODE == 2) {
         const bool zero_line = (ig + 1) == nx / 2 + 1 && (k + 1) == nz / 2 + 1;
-        const double wl = waves[il];
+        const real_t wl = waves[il];
         l_r = fabs(wl) < 1.e-16 ? 0.0 : -l_r / wl;
         l_c = fabs(wl) < 1.e-16 ? 0.0 : -l_c / wl;
         if (zero_line) { l_r = 0.0; l_c = 0.0; }
         if (paired) {
-            const double wr = waves[ir];
+            const real_t wr = waves[ir];
             r_r = fabs(wr) < 1.e-16 ? 0.0 : -r_r / wr;
             r_c = fabs(wr) < 1.e-16 ? 0.0 : -r_c / wr;
             if (zero_line) { r_r = 0.0; r_c = 0.0; }
@@ -121,11 +121,11 @@ static __global__ void __launch_bounds__(256)
     if (MODE != 0) {
         if (paired) {
             if (self) { r_r = l_r; r_c = l_c; }
-            const double a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
-            const double n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
-            const double n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
-            const double n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
-            const double n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
+            const real_t a = ay[j - 1], b = by[j - 1], a2 = ay[jr - 1], b2 = by[jr - 1];
+            const real_t n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
+            const real_t n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
+            const real_t n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
+            const real_t n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
             l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
             if (self) { l_r = r_r; l_c = r_c; }
         }
@@ -136,8 +136,8 @@ static __global__ void __launch_bounds__(256)
             rot_bw(r_r, r_c, rx);
         }
     }
-    c[il] = make_double2(l_r, l_c);
-    if (paired && !self) c[ir] = make_double2(r_r, r_c);
+    c[il] = make_real2(l_r, l_c);
+    if (paired && !self) c[ir] = make_real2(r_r, r_c);
 }
 
 static inline dim3 spectral_010_grid(int nxs, int ny, int nz, bool zf = false)
@@ -158,30 +158,30 @@ static inline dim3 spectral_010_grid(int nxs, int ny, int nz, bool zf = false)
 //   slot 4 row j : a5_j                                             (j <= n-2)
 // so that the solve applies bit-for-bit the same operations to the right-hand side.
 template <bool ZF = false>  // ZF: [5][n][nxs][nz] instead of [5][nz][n][nxs]
-static __global__ void __launch_bounds__(64) k_penta_factor(double *__restrict__ a, int nxs, int n, int nz)
+static __global__ void __launch_bounds__(64) k_penta_factor(real_t *__restrict__ a, int nxs, int n, int nz)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = ZF ? (int)(t / nz) : (int)(t % nxs), k = ZF ? (int)(t % nz) : (int)(t / nxs);
     if (ZF ? i >= nxs : k >= nz) return;
-    const double eps = 1.e-16;
+    const real_t eps = 1.e-16;
     const size_t ds = (size_t)nz * n * nxs;
 #define A(j, d)                                                                                              \
     a[(size_t)((d) - 1) * ds + (ZF ? ((size_t)((j) - 1) * nxs + i) * nz + k : ((size_t)k * n + ((j) - 1)) * nxs + i)]
     for (int j = 1; j <= n - 2; j++) {
-        const double a3 = A(j, 3), a4 = A(j, 4), a5 = A(j, 5);
-        const double m1 = fabs(a3) > eps ? A(j + 1, 2) / a3 : 0.0;
+        const real_t a3 = A(j, 3), a4 = A(j, 4), a5 = A(j, 5);
+        const real_t m1 = fabs(a3) > eps ? A(j + 1, 2) / a3 : 0.0;
         A(j + 1, 3) = A(j + 1, 3) - m1 * a4;
         A(j + 1, 4) = A(j + 1, 4) - m1 * a5;
-        const double m2 = fabs(a3) > eps ? A(j + 2, 1) / a3 : 0.0;
+        const real_t m2 = fabs(a3) > eps ? A(j + 2, 1) / a3 : 0.0;
         A(j + 2, 2) = A(j + 2, 2) - m2 * a4;
         A(j + 2, 3) = A(j + 2, 3) - m2 * a5;
         A(j, 1) = m2;
         A(j, 2) = m1;
         A(j, 3) = fabs(a3) > eps ? 1.0 / a3 : 0.0;
     }
-    const double a3 = A(n - 1, 3);
-    const double tmp = fabs(a3) > eps ? A(n, 2) / a3 : 0.0;
-    const double dd = A(n, 3) - tmp * A(n - 1, 4);
+    const real_t a3 = A(n - 1, 3);
+    const real_t tmp = fabs(a3) > eps ? A(n, 2) / a3 : 0.0;
+    const real_t dd = A(n, 3) - tmp * A(n - 1, 4);
     A(n - 1, 2) = tmp;
     A(n - 1, 3) = fabs(a3) > eps ? 1.0 / a3 : 0.0;
     A(n, 3) = dd;
@@ -192,24 +192,24 @@ static __global__ void __launch_bounds__(64) k_penta_factor(double *__restrict__
 // backward r/w + 1/a3, a4, a5 = 104 B.
 template <bool ZF = false>
 static __global__ void __launch_bounds__(64)
-    k_penta_solve(double2 *__restrict__ c, const double *__restrict__ lu, int off, int inc, int nxs, int ny,
+    k_penta_solve(real2_t *__restrict__ c, const real_t *__restrict__ lu, int off, int inc, int nxs, int ny,
                   int nz, int n, int nx, int i0)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = ZF ? (int)(t / nz) : (int)(t % nxs), k = ZF ? (int)(t % nz) : (int)(t / nxs);
     if (ZF ? i >= nxs : k >= nz) return;
-    const double eps = 1.e-16;
+    const real_t eps = 1.e-16;
     const size_t ds = (size_t)nz * n * nxs;
 #define LU(j, d)                                                                                             \
     lu[(size_t)((d) - 1) * ds + (ZF ? ((size_t)((j) - 1) * nxs + i) * nz + k : ((size_t)k * n + ((j) - 1)) * nxs + i)]
 #define C(jm) c[ZF ? ((size_t)((jm) - 1) * nxs + i) * nz + k : ((size_t)k * ny + ((jm) - 1)) * nxs + i]
     const int h = inc / 2;
     // forward: rows j+1, j+2 -= m * row j; two rows are carried in registers
-    double2 r0 = C(inc * 1 + off - h), r1 = C(inc * 2 + off - h);
+    real2_t r0 = C(inc * 1 + off - h), r1 = C(inc * 2 + off - h);
     for (int j = 1; j <= n - 2; j++) {
         const int jm = inc * j + off - h;
-        double2 r2 = C(jm + 2 * inc);
-        const double m1 = LU(j, 2), m2 = LU(j, 1);
+        real2_t r2 = C(jm + 2 * inc);
+        const real_t m1 = LU(j, 2), m2 = LU(j, 1);
         r1.x = r1.x - m1 * r0.x; r1.y = r1.y - m1 * r0.y;
         r2.x = r2.x - m2 * r0.x; r2.y = r2.y - m2 * r0.y;
         C(jm) = r0;
@@ -217,32 +217,32 @@ static __global__ void __launch_bounds__(64)
     }
     // last two rows: r0 = row n-1, r1 = row n
     const int nm = inc * n + off - h;
-    const double tmp = LU(n - 1, 2), dd = LU(n, 3), inv = LU(n - 1, 3), a4n = LU(n - 1, 4);
-    double2 xn, xn1;
+    const real_t tmp = LU(n - 1, 2), dd = LU(n, 3), inv = LU(n - 1, 3), a4n = LU(n - 1, 4);
+    real2_t xn, xn1;
     if (fabs(dd) > eps) {
-        const double tt = tmp / dd;
+        const real_t tt = tmp / dd;
         xn.x = r1.x / dd - tt * r0.x;
         xn.y = r1.y / dd - tt * r0.y;
     } else {
         xn.x = 0.0; xn.y = 0.0;
     }
-    const double q = a4n * inv;
+    const real_t q = a4n * inv;
     xn1.x = r0.x * inv - xn.x * q;
     xn1.y = r0.y * inv - xn.y * q;
     const bool zero_line = (i0 + i + 1) == nx / 2 + 1 && (k + 1) == nz / 2 + 1;
-    if (zero_line) { xn = make_double2(0.0, 0.0); xn1 = make_double2(0.0, 0.0); }
+    if (zero_line) { xn = make_real2(0.0, 0.0); xn1 = make_real2(0.0, 0.0); }
     C(nm) = xn;
     C(nm - inc) = xn1;
     // backward
-    double2 x1 = xn1, x2 = xn;
+    real2_t x1 = xn1, x2 = xn;
     for (int j = n - 2; j >= 1; j--) {
         const int jm = inc * j + off - h;
-        const double2 r = C(jm);
-        const double iv = LU(j, 3), a4 = LU(j, 4), a5 = LU(j, 5);
-        double2 x;
+        const real2_t r = C(jm);
+        const real_t iv = LU(j, 3), a4 = LU(j, 4), a5 = LU(j, 5);
+        real2_t x;
         x.x = iv * (r.x - a4 * x1.x - a5 * x2.x);
         x.y = iv * (r.y - a4 * x1.y - a5 * x2.y);
-        if (zero_line) x = make_double2(0.0, 0.0);
+        if (zero_line) x = make_real2(0.0, 0.0);
         C(jm) = x;
         x2 = x1; x1 = x;
     }
@@ -256,9 +256,9 @@ static inline dim3 penta_grid(int nxs, int nz) { return dim3((unsigned)(((long)n
 // i0.. of the global problem: uniform y: the whole of process_spectral_010 in one kernel; stretched y: fw ;
 // pentadiagonal solves on the odd rows and the even rows (sym) or on all rows ; bw.  ax .. bz: the global tables
 template <bool ZF>
-static inline int spectral_010_launch_t(hipStream_t st, double2 *c, const double *waves, int nxs, int nx, int ny, int nz,
-                                        int i0, const double *ax, const double *bx, const double *ay, const double *by,
-                                        const double *az, const double *bz, int stretched, int sym, double *const lu[2])
+static inline int spectral_010_launch_t(hipStream_t st, real2_t *c, const real_t *waves, int nxs, int nx, int ny, int nz,
+                                        int i0, const real_t *ax, const real_t *bx, const real_t *ay, const real_t *by,
+                                        const real_t *az, const real_t *bz, int stretched, int sym, real_t *const lu[2])
 {
     const dim3 grid = spectral_010_grid(nxs, ny, nz, ZF);
 #define SPEC(M_)                                                                                                    \
@@ -283,9 +283,9 @@ static inline int spectral_010_launch_t(hipStream_t st, double2 *c, const double
 }
 
 // tables = ax bx ay by az bz back to back (global lengths nx nx ny ny nz nz), arrays [nz][ny][nxs]
-static inline int spectral_010_launch(hipStream_t st, double2 *c, const double *waves, int nxs, int nx, int ny, int nz, int i0,
-                                      const double *tables, int stretched, int sym, double *const lu[2])
+static inline int spectral_010_launch(hipStream_t st, real2_t *c, const real_t *waves, int nxs, int nx, int ny, int nz, int i0,
+                                      const real_t *tables, int stretched, int sym, real_t *const lu[2])
 {
-    const double *ax = tables, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
+    const real_t *ax = tables, *bx = ax + nx, *ay = bx + nx, *by = ay + ny, *az = by + ny, *bz = az + nz;
     return spectral_010_launch_t<false>(st, c, waves, nxs, nx, ny, nz, i0, ax, bx, ay, by, az, bz, stretched, sym, lu);
 }

@@ -24,10 +24,10 @@
 
 // ------------------------------------------------------------------ tables
 extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, int n_rhs, int move,
-                                 int periodic, const double *coeffs, const double *coeffs_s,
-                                 const double *coeffs_e, const double *dist_fw, const double *dist_bw,
-                                 const double *dist_sa, const double *dist_sc, const double *dist_af,
-                                 const double *stretch, const double *stretch_correct)
+                                 int periodic, const real_t *coeffs, const real_t *coeffs_s,
+                                 const real_t *coeffs_e, const real_t *dist_fw, const real_t *dist_bw,
+                                 const real_t *dist_sa, const real_t *dist_sc, const real_t *dist_af,
+                                 const real_t *stretch, const real_t *stretch_correct)
 {
     X3D_REQUIRE(b && out && coeffs && coeffs_s && coeffs_e && dist_fw && dist_bw && dist_sa && dist_sc &&
                     dist_af && stretch && stretch_correct,
@@ -36,8 +36,8 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     X3D_REQUIRE(n_tds >= 8, "x3d_tdsops_create: n_tds=%d too small (the 4+4 boundary rows need n>=8)", n_tds);
     const int n = n_tds, nr = n_rhs, L = nr + 2;  // tables are 1-based, one spare entry
     // layout: F A W Bw Sa Sc St Stc PF QB (10 tables of L) + 81 stencil coefficients
-    std::vector<double> h((size_t)10 * L + 81, 0.0);
-    double *F = &h[0], *A = &h[L], *W = &h[2 * L], *Bw = &h[3 * L], *Sa = &h[4 * L], *Sc = &h[5 * L],
+    std::vector<real_t> h((size_t)10 * L + 81, 0.0);
+    real_t *F = &h[0], *A = &h[L], *W = &h[2 * L], *Bw = &h[3 * L], *Sa = &h[4 * L], *Sc = &h[5 * L],
            *St = &h[6 * L], *Stc = &h[7 * L], *PF = &h[8 * L], *QB = &h[9 * L], *Cs = &h[10 * L];
     for (int j = 1; j <= nr; j++) {
         const bool real_row = j <= n;  // row n_tds+1 of a v2p operator is junk in the reference too
@@ -67,20 +67,20 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     const int chunk = nr <= 512 ? 32 : 64;
     for (int s0 = 1; s0 <= nr; s0 += chunk) {
         const int t0 = s0 + chunk - 1 < nr ? s0 + chunk - 1 : nr;
-        double pr = 1.0;
+        real_t pr = 1.0;
         for (int j = s0; j <= t0; j++) { pr *= -F[j] * A[j]; PF[j] = pr; }
         pr = 1.0;
         for (int j = t0; j >= s0; j--) {
-            const double hj = (j >= 2 && j <= n - 2) ? -dist_bw[j - 1] : 0.0;
+            const real_t hj = (j >= 2 && j <= n - 2) ? -dist_bw[j - 1] : 0.0;
             pr *= hj;
             QB[j] = pr;
         }
     }
     // the same for 16-row chunks (onchip.hip, 256-row pencils)
-    std::vector<double> PF16(L, 0.0), QB16(L, 0.0);
+    std::vector<real_t> PF16(L, 0.0), QB16(L, 0.0);
     for (int s0 = 1; s0 <= nr; s0 += 16) {
         const int t0 = s0 + 15 < nr ? s0 + 15 : nr;
-        double pr = 1.0;
+        real_t pr = 1.0;
         for (int j = s0; j <= t0; j++) { pr *= -F[j] * A[j]; PF16[j] = pr; }
         pr = 1.0;
         for (int j = t0; j >= s0; j--) {
@@ -88,39 +88,39 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             QB16[j] = pr;
         }
     }
-    memcpy(Cs, coeffs_s, sizeof(double) * 36);
-    memcpy(Cs + 36, coeffs_e, sizeof(double) * 36);
-    memcpy(Cs + 72, coeffs, sizeof(double) * 9);
+    memcpy(Cs, coeffs_s, sizeof(real_t) * 36);
+    memcpy(Cs + 36, coeffs_e, sizeof(real_t) * 36);
+    memcpy(Cs + 72, coeffs, sizeof(real_t) * 9);
 
     x3d_tdsops *t = new x3d_tdsops();
     for (int m = 0; m < 9; m++) t->coeffs[m] = coeffs[m];
     t->b = b; t->n_tds = n; t->n_rhs = nr; t->move = move; t->periodic = periodic;
     // device image: interleaved row records (common.h) so that one wide scalar
     // load serves a row: RF[4j..] = F A W PF ; RB[8j..] = Bw Sa Sc St Stc QB PF16 QB16 ; then Cs
-    std::vector<double> img((size_t)12 * L + 81, 0.0);
+    std::vector<real_t> img((size_t)12 * L + 81, 0.0);
     for (int j = 0; j < L; j++) {
-        double *rf = &img[(size_t)4 * j], *rb = &img[(size_t)4 * L + (size_t)8 * j];
+        real_t *rf = &img[(size_t)4 * j], *rb = &img[(size_t)4 * L + (size_t)8 * j];
         rf[0] = F[j]; rf[1] = A[j]; rf[2] = W[j]; rf[3] = PF[j];
         rb[0] = Bw[j]; rb[1] = Sa[j]; rb[2] = Sc[j]; rb[3] = St[j]; rb[4] = Stc[j]; rb[5] = QB[j];
         rb[6] = PF16[j]; rb[7] = QB16[j];
     }
-    memcpy(&img[(size_t)12 * L], Cs, sizeof(double) * 81);
+    memcpy(&img[(size_t)12 * L], Cs, sizeof(real_t) * 81);
     // lane tables for the wave-per-pencil x kernels (xscan.hip): lane l owns rows l*Q+1..(l+1)*Q
     // (6: 257 .. 384 rows, e.g. the channel case's 257 wall-normal vertices -- 43 of the 64 lanes busy instead of 33)
     const int Q = nr <= 256 ? 4 : (nr <= 384 ? 6 : (nr <= 512 ? 8 : (nr <= 1024 ? 16 : 0)));
     const size_t tl_off = img.size();
-    auto build_tl = [&](const int Q, std::vector<double> &out) {  // the [9 Q + 12][64] table for Q rows per lane
+    auto build_tl = [&](const int Q, std::vector<real_t> &out) {  // the [9 Q + 12][64] table for Q rows per lane
         const int NE = 9 * Q + 12;
         out.assign((size_t)NE * 64, 0.0);
-        double *tl = out.data();
-        auto E = [&](int e, int l) -> double & { return tl[(size_t)e * 64 + l]; };
-        double G[64], HL[64];
+        real_t *tl = out.data();
+        auto E = [&](int e, int l) -> real_t & { return tl[(size_t)e * 64 + l]; };
+        real_t G[64], HL[64];
         for (int l = 0; l < 64; l++) {
-            double pg = 1.0;
+            real_t pg = 1.0;
             for (int q = 0; q < Q; q++) {
                 const int j = l * Q + q + 1;
                 const bool in = j <= nr, real = j <= n;
-                const double f = in ? F[j] : 0.0, a = in ? A[j] : 0.0;
+                const real_t f = in ? F[j] : 0.0, a = in ? A[j] : 0.0;
                 E(0 * Q + q, l) = f;
                 E(1 * Q + q, l) = a;
                 pg *= -f * a;
@@ -132,17 +132,17 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                 E(8 * Q + 12 + q, l) = real ? Stc[j] : 0.0;  // (last block: kernels that do not need it stage 8 Q + 12 entries)
             }
             G[l] = pg;
-            double ph = 1.0;
+            real_t ph = 1.0;
             for (int q = Q - 1; q >= 0; q--) { ph *= E(3 * Q + q, l); E(4 * Q + q, l) = ph; }
             HL[l] = ph;
         }
-        double mf[64], mb[64];
+        real_t mf[64], mb[64];
         for (int l = 0; l < 64; l++) { mf[l] = G[l]; mb[l] = HL[l]; }
         // data-independent multipliers of the wave scans (xscan.hip, scan_solve): Kogge-Stone steps
         // 1, 2, 4, 8 inside each row of 16 lanes (DPP row shifts), then two steps across the rows
         for (int k = 0; k < 4; k++) {
             const int d = 1 << k;
-            double nf[64], nb[64];
+            real_t nf[64], nb[64];
             for (int l = 0; l < 64; l++) {
                 E(8 * Q + k, l) = mf[l];
                 E(8 * Q + 6 + k, l) = mb[l];
@@ -152,7 +152,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             for (int l = 0; l < 64; l++) { mf[l] = nf[l]; mb[l] = nb[l]; }
         }
         for (int l = 0; l < 64; l++) {
-            double c15 = 1.0, c31 = 1.0, d16 = 1.0, d32 = 1.0;
+            real_t c15 = 1.0, c31 = 1.0, d16 = 1.0, d32 = 1.0;
             for (int i = l & ~15; i <= l; i++) c15 *= G[i];   // row start .. l: carries lane 15 / 47 into rows 1 / 3
             for (int i = 32; i <= l; i++) c31 *= G[i];        // 32 .. l: carries lane 31 into rows 2, 3
             for (int i = l; i <= (l | 15); i++) d16 *= HL[i]; // l .. row end: carries lane 16 / 48 into rows 0 / 2
@@ -165,7 +165,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         }
     };
     if (Q) {
-        std::vector<double> tlv;
+        std::vector<real_t> tlv;
         build_tl(Q, tlv);
         img.insert(img.end(), tlv.begin(), tlv.end());
     }
@@ -173,7 +173,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // 56..63 -- only where those middle lanes really are bitwise equal (periodic-type operators on a uniform grid)
     size_t tlc_off = 0;
     if (Q == 16) {
-        const double *tl = &img[tl_off];
+        const real_t *tl = &img[tl_off];
         bool ok = true;
         auto row_entry = [&](int k) { return k < 8 * Q ? k : 8 * Q + 12 + (k - 8 * Q); };  // k = 0 .. 9Q-1
         // dist_sa / dist_sc never become constant, they decay (by 0.15 - 0.38 per row): in the middle lanes (rows
@@ -181,11 +181,11 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         auto decaying = [&](int k) { return k >= 5 * Q && k < 7 * Q; };
         for (int k = 0; k < 9 * Q && ok; k++)
             for (int l = 8; l <= 55 && ok; l++) {
-                const double *v = &tl[(size_t)row_entry(k) * 64];
-                ok = decaying(k) ? fabs(v[l]) < 8.673617379884035e-19 : memcmp(&v[l], &v[8], sizeof(double)) == 0;
+                const real_t *v = &tl[(size_t)row_entry(k) * 64];
+                ok = decaying(k) ? fabs(v[l]) < 8.673617379884035e-19 : memcmp(&v[l], &v[8], sizeof(real_t)) == 0;
             }
         if (ok) {
-            std::vector<double> c((size_t)9 * Q * 17 + 12 * 64);
+            std::vector<real_t> c((size_t)9 * Q * 17 + 12 * 64);
             for (int k = 0; k < 9 * Q; k++)
                 for (int m = 0; m < 17; m++)
                     c[(size_t)k * 17 + m] = (m == 8 && decaying(k)) ? 0.0 : tl[(size_t)row_entry(k) * 64 + (m <= 8 ? m : m + 47)];
@@ -199,13 +199,13 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // instead of 43 with 6; the x kernels keep the even Q: they move their rows as aligned 16-byte pairs)
     size_t tl5_off = 0;
     if (nr > 256 && nr <= 320) {
-        std::vector<double> tlv;
+        std::vector<real_t> tlv;
         build_tl(5, tlv);
         tl5_off = img.size();
         img.insert(img.end(), tlv.begin(), tlv.end());
     }
-    X3D_HIP(hipMalloc(&t->dev, sizeof(double) * img.size()));
-    X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+    X3D_HIP(hipMalloc(&t->dev, sizeof(real_t) * img.size()));
+    X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(real_t) * img.size(), hipMemcpyHostToDevice));
     t->tl5 = tl5_off ? t->dev + tl5_off : nullptr;
     TdsTab &tb = t->tab;
     tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
@@ -231,11 +231,11 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     t->tl_hash = 1469598103934665603ull;
     if (Q) {
         const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&img[tl_off]);
-        for (size_t i = 0; i < (img.size() - tl_off) * sizeof(double); i++)
+        for (size_t i = 0; i < (img.size() - tl_off) * sizeof(real_t); i++)
             t->tl_hash = (t->tl_hash ^ bytes[i]) * 1099511628211ull;
         for (int m = 0; m < 81; m++) {  // + the boundary and bulk stencils (Cs: [4][9] start, [4][9] end, [9] bulk)
             const unsigned char *cb = reinterpret_cast<const unsigned char *>(&Cs[m]);
-            for (size_t i = 0; i < sizeof(double); i++) t->tl_hash = (t->tl_hash ^ cb[i]) * 1099511628211ull;
+            for (size_t i = 0; i < sizeof(real_t); i++) t->tl_hash = (t->tl_hash ^ cb[i]) * 1099511628211ull;
         }
     }
     tb.last_r = dist_fw[0];
@@ -246,7 +246,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     tb.rs_e = 1.0 / (1.0 - dist_sc[n - 1] * dist_sc[n - 1]);  // distributed.f90:203-205
     // rows that still feel the reduced system's unknowns: |dist_sa(j)| decays from row 1, |dist_sc(j)| from row n
     // (the same decay lets the reference truncate the coupling to a 2 x 2 system, src/tdsops.f90:196-201)
-    const double tiny = 8.673617379884035e-19;  // 2^-60
+    const real_t tiny = 8.673617379884035e-19;  // 2^-60
     t->halo_ws = 1;
     t->halo_we = 1;
     for (int j = 1; j <= n; j++) {
@@ -288,9 +288,9 @@ extern "C" int x3d_npencils(const x3d_backend *b, int dir)
 // produces (src/backend/omp/sendrecv.f90:20-22): u_s(r) = u(n_wrap-4+r),
 // u_e(r) = u(r).
 template <bool HB>
-__device__ __forceinline__ double ext_row(const double *__restrict__ u, long base, long rs, int jj, int nr,
-                                          int n_wrap, const double *__restrict__ hs,
-                                          const double *__restrict__ he, int np, int p)
+__device__ __forceinline__ real_t ext_row(const real_t *__restrict__ u, long base, long rs, int jj, int nr,
+                                          int n_wrap, const real_t *__restrict__ hs,
+                                          const real_t *__restrict__ he, int np, int p)
 {
     if (jj < 1) {
         if (HB) return hs[(long)(jj + 3) * np + p];
@@ -305,14 +305,14 @@ __device__ __forceinline__ double ext_row(const double *__restrict__ u, long bas
                                            //  re-read by the next component's kernel)
 }
 
-__device__ __forceinline__ double dot9(const double *__restrict__ c, const double (&w)[9])
+__device__ __forceinline__ real_t dot9(const real_t *__restrict__ c, const real_t (&w)[9])
 {
     // same left-to-right order as distributed.f90:89-93
     return c[0] * w[0] + c[1] * w[1] + c[2] * w[2] + c[3] * w[3] + c[4] * w[4] + c[5] * w[5] + c[6] * w[6] +
            c[7] * w[7] + c[8] * w[8];
 }
 
-__device__ __forceinline__ const double *stencil_row(const double *__restrict__ Cs, int j, int nr)
+__device__ __forceinline__ const real_t *stencil_row(const real_t *__restrict__ Cs, int j, int nr)
 {
     if (j <= 4) return Cs + (j - 1) * 9;
     if (j > nr - 4) return Cs + 36 + (j - (nr - 4) - 1) * 9;
@@ -326,23 +326,23 @@ __device__ __forceinline__ long pencil_base(const PencilGeom &g, int p)
 
 // forward sweep, one operator (der_univ_dist without its backward loop)
 template <bool HB>
-__global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *__restrict__ send_s,
-                                                double *__restrict__ send_e, const double *__restrict__ u,
-                                                const double *__restrict__ hs, const double *__restrict__ he,
+__global__ void __launch_bounds__(64) k_tds_fwd(real_t *__restrict__ d, real_t *__restrict__ send_s,
+                                                real_t *__restrict__ send_e, const real_t *__restrict__ u,
+                                                const real_t *__restrict__ hs, const real_t *__restrict__ he,
                                                 TdsTab t, PencilGeom g, int n_wrap)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t.n_tds, nr = t.n_rhs;
-    double w[9];
+    real_t w[9];
 #pragma unroll
     for (int m = 0; m < 9; m++) w[m] = ext_row<HB>(u, base, rs, m - 3, nr, n_wrap, hs, he, g.np, p);
-    double dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
+    real_t dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
 
-    auto row = [&](int j, const double *__restrict__ c, double wnext) {
-        const double acc = dot9(c, w);
-        const double dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
+    auto row = [&](int j, const real_t *__restrict__ c, real_t wnext) {
+        const real_t acc = dot9(c, w);
+        const real_t dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
         if (j <= n) {
             __builtin_nontemporal_store(dj, &d[base + (long)(j - 1) * rs]);
             S += T_W(t, j) * dj;
@@ -358,20 +358,20 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
     for (int j = 1; j <= 4; j++)
         row(j, stencil_row(t.Cs, j, nr), ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p));
     {
-        const double *__restrict__ c = t.Cs + 72;
-        const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7],
+        const real_t *__restrict__ c = t.Cs + 72;
+        const real_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7],
                      c8 = c[8];
-        const double cb[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+        const real_t cb[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
 #pragma unroll 4
         for (int j = 5; j <= nr - 4; j++) {
             // rows j+5 <= n_rhs+1: interior except for the very last bulk row
-            const double wn = (j + 5 <= nr) ? u[base + (long)(j + 4) * rs]
+            const real_t wn = (j + 5 <= nr) ? u[base + (long)(j + 4) * rs]
                                             : ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p);
             row(j, cb, wn);
         }
     }
     for (int j = (nr - 3 > 5 ? nr - 3 : 5); j <= nr; j++) {
-        const double wn = (j < nr) ? ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p) : 0.0;
+        const real_t wn = (j < nr) ? ext_row<HB>(u, base, rs, j + 5, nr, n_wrap, hs, he, g.np, p) : 0.0;
         row(j, stencil_row(t.Cs, j, nr), wn);
     }
     send_e[p] = dn;                                 // distributed.f90:147-151
@@ -386,34 +386,34 @@ __global__ void __launch_bounds__(64) k_tds_fwd(double *__restrict__ d, double *
 // correction vecadd(-1, dpdx, 1, u) into this pass.
 #define UB 8
 template <bool ACC>
-__global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const double *__restrict__ d,
-                                                const double *__restrict__ own_s,
-                                                const double *__restrict__ recv_s,
-                                                const double *__restrict__ recv_e, TdsTab t, PencilGeom g,
-                                                double scale)
+__global__ void __launch_bounds__(64) k_tds_bwd(real_t *__restrict__ du, const real_t *__restrict__ d,
+                                                const real_t *__restrict__ own_s,
+                                                const real_t *__restrict__ recv_s,
+                                                const real_t *__restrict__ recv_e, TdsTab t, PencilGeom g,
+                                                real_t scale)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t.n_tds;
-    auto put = [&](long o, double v, double old) {
+    auto put = [&](long o, real_t v, real_t old) {
         __builtin_nontemporal_store(ACC ? old + scale * v : v, &du[o]);
     };
-    const double dn = d[base + (long)(n - 1) * rs];
-    const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);  // distributed.f90:196-199
-    const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
+    const real_t dn = d[base + (long)(n - 1) * rs];
+    const real_t du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);  // distributed.f90:196-199
+    const real_t du_e = t.rs_e * (dn - t.scn * recv_e[p]);        // distributed.f90:203-206
     {
         const long o = base + (long)(n - 1) * rs;
         put(o, du_e * T_ST(t, n), ACC ? du[o] : 0.0);  // :224-228
     }
-    double nxt = d[base + (long)(n - 2) * rs];  // row n-1: no backward update
+    real_t nxt = d[base + (long)(n - 2) * rs];  // row n-1: no backward update
     {
         const long o = base + (long)(n - 2) * rs;
         put(o, (nxt - T_SA(t, n - 1) * du_s - T_SC(t, n - 1) * du_e) * T_ST(t, n - 1), ACC ? du[o] : 0.0);
     }
     int j = n - 2;
     for (; j - UB + 1 >= 2; j -= UB) {
-        double dv[UB], ov[UB];
+        real_t dv[UB], ov[UB];
 #pragma unroll
         for (int k = 0; k < UB; k++) {
             const long o = base + (long)(j - k - 1) * rs;
@@ -423,14 +423,14 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const d
 #pragma unroll
         for (int k = 0; k < UB; k++) {
             const int jj = j - k;
-            const double cur = dv[k] - T_BW(t, jj) * nxt;                                      // :154-160
+            const real_t cur = dv[k] - T_BW(t, jj) * nxt;                                      // :154-160
             put(base + (long)(jj - 1) * rs, (cur - T_SA(t, jj) * du_s - T_SC(t, jj) * du_e) * T_ST(t, jj), ov[k]);  // :215-222
             nxt = cur;
         }
     }
     for (; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
-        const double cur = d[o] - T_BW(t, j) * nxt;
+        const real_t cur = d[o] - T_BW(t, j) * nxt;
         put(o, (cur - T_SA(t, j) * du_s - T_SC(t, j) * du_e) * T_ST(t, j), ACC ? du[o] : 0.0);
         nxt = cur;
     }
@@ -441,31 +441,31 @@ __global__ void __launch_bounds__(64) k_tds_bwd(double *__restrict__ du, const d
 // the loads of u and conv (exec_dist.f90:114-160)
 template <bool HB, bool SAME>
 __global__ void __launch_bounds__(64)
-    k_transeq_fwd(double *__restrict__ d_du, double *__restrict__ d_dud, double *__restrict__ d_d2u,
-                  double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
-                  const double *__restrict__ us, const double *__restrict__ ue, const double *__restrict__ cv,
-                  const double *__restrict__ cs, const double *__restrict__ ce, TdsTab t1, TdsTab t2, TdsTab t3,
+    k_transeq_fwd(real_t *__restrict__ d_du, real_t *__restrict__ d_dud, real_t *__restrict__ d_d2u,
+                  real_t *__restrict__ send_s, real_t *__restrict__ send_e, const real_t *__restrict__ u,
+                  const real_t *__restrict__ us, const real_t *__restrict__ ue, const real_t *__restrict__ cv,
+                  const real_t *__restrict__ cs, const real_t *__restrict__ ce, TdsTab t1, TdsTab t2, TdsTab t3,
                   PencilGeom g, int n_wrap, int npmax)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t1.n_tds;  // n_rhs == n_tds for first/second derivatives (src/tdsops.f90:114-123)
-    double wu[9], wp[9];
+    real_t wu[9], wp[9];
 #pragma unroll
     for (int m = 0; m < 9; m++) {
         wu[m] = ext_row<HB>(u, base, rs, m - 3, n, n_wrap, us, ue, g.np, p);
-        const double c = SAME ? wu[m] : ext_row<HB>(cv, base, rs, m - 3, n, n_wrap, cs, ce, g.np, p);
+        const real_t c = SAME ? wu[m] : ext_row<HB>(cv, base, rs, m - 3, n, n_wrap, cs, ce, g.np, p);
         wp[m] = wu[m] * c;  // ud = u*v incl. the halo products, exec_dist.f90:133-149
     }
-    double p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
+    real_t p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
 
-    auto row = [&](int j, const double *__restrict__ c1, const double *__restrict__ c2,
-                   const double *__restrict__ c3, double un, double pn) {
-        const double a1 = dot9(c1, wu), a3 = dot9(c3, wu), a2 = dot9(c2, wp);
-        const double e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
-        const double e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
-        const double e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
+    auto row = [&](int j, const real_t *__restrict__ c1, const real_t *__restrict__ c2,
+                   const real_t *__restrict__ c3, real_t un, real_t pn) {
+        const real_t a1 = dot9(c1, wu), a3 = dot9(c3, wu), a2 = dot9(c2, wp);
+        const real_t e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
+        const real_t e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
+        const real_t e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
         {
             const long o = base + (long)(j - 1) * rs;
             __builtin_nontemporal_store(e1, &d_du[o]); __builtin_nontemporal_store(e2, &d_dud[o]);
@@ -479,24 +479,24 @@ __global__ void __launch_bounds__(64)
         for (int m = 0; m < 8; m++) { wu[m] = wu[m + 1]; wp[m] = wp[m + 1]; }
         wu[8] = un; wp[8] = pn;
     };
-    auto nextrow = [&](int jj, double &un, double &pn) {
+    auto nextrow = [&](int jj, real_t &un, real_t &pn) {
         un = ext_row<HB>(u, base, rs, jj, n, n_wrap, us, ue, g.np, p);
-        const double c = SAME ? un : ext_row<HB>(cv, base, rs, jj, n, n_wrap, cs, ce, g.np, p);
+        const real_t c = SAME ? un : ext_row<HB>(cv, base, rs, jj, n, n_wrap, cs, ce, g.np, p);
         pn = un * c;
     };
 
     for (int j = 1; j <= 4; j++) {
-        double un, pn;
+        real_t un, pn;
         nextrow(j + 5, un, pn);
         row(j, stencil_row(t1.Cs, j, n), stencil_row(t2.Cs, j, n), stencil_row(t3.Cs, j, n), un, pn);
     }
     {
-        double b1[9], b2[9], b3[9];
+        real_t b1[9], b2[9], b3[9];
 #pragma unroll
         for (int m = 0; m < 9; m++) { b1[m] = t1.Cs[72 + m]; b2[m] = t2.Cs[72 + m]; b3[m] = t3.Cs[72 + m]; }
 #pragma unroll 2
         for (int j = 5; j <= n - 4; j++) {
-            double un, pn;
+            real_t un, pn;
             if (j + 5 <= n) {
                 un = u[base + (long)(j + 4) * rs];
                 pn = un * (SAME ? un : cv[base + (long)(j + 4) * rs]);
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64)
         }
     }
     for (int j = (n - 3 > 5 ? n - 3 : 5); j <= n; j++) {
-        double un = 0.0, pn = 0.0;
+        real_t un = 0.0, pn = 0.0;
         if (j < n) nextrow(j + 5, un, pn);
         row(j, stencil_row(t1.Cs, j, n), stencil_row(t2.Cs, j, n), stencil_row(t3.Cs, j, n), un, pn);
     }
@@ -524,10 +524,10 @@ __global__ void __launch_bounds__(64)
 #define UT 4
 template <bool ACC>
 __global__ void __launch_bounds__(64)
-    k_transeq_bwd(double *__restrict__ rhs, const double *__restrict__ d_du, const double *__restrict__ d_dud,
-                  const double *__restrict__ d_d2u, const double *__restrict__ cv,
-                  const double *__restrict__ own_s, const double *__restrict__ recv_s,
-                  const double *__restrict__ recv_e, double nu, TdsTab t1, TdsTab t2, TdsTab t3, PencilGeom g,
+    k_transeq_bwd(real_t *__restrict__ rhs, const real_t *__restrict__ d_du, const real_t *__restrict__ d_dud,
+                  const real_t *__restrict__ d_d2u, const real_t *__restrict__ cv,
+                  const real_t *__restrict__ own_s, const real_t *__restrict__ recv_s,
+                  const real_t *__restrict__ recv_e, real_t nu, TdsTab t1, TdsTab t2, TdsTab t3, PencilGeom g,
                   int npmax)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,26 +535,26 @@ __global__ void __launch_bounds__(64)
     const long base = pencil_base(g, p), rs = g.rs;
     const int n = t1.n_tds;
     const long on = base + (long)(n - 1) * rs;
-    const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
-    const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
-    const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
+    const real_t du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
+    const real_t dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
+    const real_t d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
     // streaming data (read once / written once per launch): nontemporal accesses, measured -10 % on the
     // forward and -4 % on the backward kernel
-    auto put = [&](long o, double v, double old) {
+    auto put = [&](long o, real_t v, real_t old) {
         __builtin_nontemporal_store(ACC ? old + v : v, &rhs[o]);
     };
-    double n1 = d_du[on], n2 = d_dud[on], n3 = d_d2u[on];
-    const double du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
-    const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
-    const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
+    real_t n1 = d_du[on], n2 = d_dud[on], n3 = d_d2u[on];
+    const real_t du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
+    const real_t dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
+    const real_t d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
     // row n (:328-335)
     put(on, -0.5 * (cv[on] * du_e * T_ST(t1, n) + dud_e * T_ST(t2, n)) +
                 nu * (d2u_e * T_ST(t3, n) + du_e * T_ST(t1, n) * T_STC(t3, n)), ACC ? rhs[on] : 0.0);
 
-    auto emit = [&](int j, double c1, double c2, double c3, double v, double old) {
-        const double temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
-        const double temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
-        const double temp_d2u = T_ST(t3, j) * (c3 - T_SA(t3, j) * d2u_s - T_SC(t3, j) * d2u_e) + temp_du * T_STC(t3, j);
+    auto emit = [&](int j, real_t c1, real_t c2, real_t c3, real_t v, real_t old) {
+        const real_t temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
+        const real_t temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
+        const real_t temp_d2u = T_ST(t3, j) * (c3 - T_SA(t3, j) * d2u_s - T_SC(t3, j) * d2u_e) + temp_du * T_STC(t3, j);
         put(base + (long)(j - 1) * rs, -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u, old);  // :315-324
     };
     {
@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(64)
     }
     int j = n - 2;
     for (; j - UT + 1 >= 2; j -= UT) {
-        double a1[UT], a2[UT], a3[UT], vv[UT], ov[UT];
+        real_t a1[UT], a2[UT], a3[UT], vv[UT], ov[UT];
 #pragma unroll
         for (int k = 0; k < UT; k++) {
             const long o = base + (long)(j - k - 1) * rs;
@@ -575,18 +575,18 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int k = 0; k < UT; k++) {
             const int jj = j - k;
-            const double c1 = a1[k] - T_BW(t1, jj) * n1;
-            const double c2 = a2[k] - T_BW(t2, jj) * n2;
-            const double c3 = a3[k] - T_BW(t3, jj) * n3;
+            const real_t c1 = a1[k] - T_BW(t1, jj) * n1;
+            const real_t c2 = a2[k] - T_BW(t2, jj) * n2;
+            const real_t c3 = a3[k] - T_BW(t3, jj) * n3;
             emit(jj, c1, c2, c3, vv[k], ov[k]);
             n1 = c1; n2 = c2; n3 = c3;
         }
     }
     for (; j >= 2; j--) {
         const long o = base + (long)(j - 1) * rs;
-        const double c1 = d_du[o] - T_BW(t1, j) * n1;
-        const double c2 = d_dud[o] - T_BW(t2, j) * n2;
-        const double c3 = d_d2u[o] - T_BW(t3, j) * n3;
+        const real_t c1 = d_du[o] - T_BW(t1, j) * n1;
+        const real_t c2 = d_dud[o] - T_BW(t2, j) * n2;
+        const real_t c3 = d_d2u[o] - T_BW(t3, j) * n3;
         emit(j, c1, c2, c3, cv[o], ACC ? rhs[o] : 0.0);
         n1 = c1; n2 = c2; n3 = c3;
     }
@@ -596,8 +596,8 @@ __global__ void __launch_bounds__(64)
 }
 
 // copy_into_buffers (src/backend/omp/backend.f90:714-737): rows 1..4 and n-3..n
-__global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ send_e,
-                             const double *__restrict__ u, int n, PencilGeom g)
+__global__ void k_pack_halos(real_t *__restrict__ send_s, real_t *__restrict__ send_e,
+                             const real_t *__restrict__ u, int n, PencilGeom g)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
@@ -611,16 +611,16 @@ __global__ void k_pack_halos(double *__restrict__ send_s, double *__restrict__ s
 
 // the same for nf fields at once, in the layout the HALO tile kernels read and ONE message per neighbour carries:
 // send[side][field][4][np], side 0 = rows 1..4 (to prev), side 1 = rows n-3..n (to next)
-struct PackFields { const double *f[3]; };
+struct PackFields { const real_t *f[3]; };
 // (hp, hnp: TileHalo's plane layout -- pencil p = (x, o) goes to o * hp + x of a plane of hnp entries)
-__global__ void k_pack_halos_multi(double *__restrict__ send, PackFields pf, int nf, int n, PencilGeom g, int hp, long hnp)
+__global__ void k_pack_halos_multi(real_t *__restrict__ send, PackFields pf, int nf, int n, PencilGeom g, int hp, long hnp)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const long base = pencil_base(g, p);
     const long hq = (long)(p / g.dim0) * hp + p % g.dim0;
     const int k = blockIdx.y;  // field
-    const double *__restrict__ u = pf.f[k];
+    const real_t *__restrict__ u = pf.f[k];
 #pragma unroll
     for (int r = 0; r < X3D_NH; r++) {
         send[((long)k * X3D_NH + r) * hnp + hq] = u[base + (long)r * g.rs];
@@ -644,7 +644,7 @@ extern "C" long x3d_halo_row_size(const x3d_backend *b, int dir)
 }
 
 // ------------------------------------------------------------------ launchers
-int x3d_onchip2_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc, double scale,
+int x3d_onchip2_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, int acc, real_t scale,
                     bool *done);  // onchip.hip (K1e)
 static bool use_onchip2()
 {
@@ -657,31 +657,31 @@ static bool use_onchip2()
     }
     return mode == 1;
 }
-int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_transeq_via_x(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // viax.hip
-int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+int x3d_ytile_transeq(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);  // xscan.hip
-int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
+int x3d_xscan_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f[3], real_t nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
-                       const x3d_tdsops *op_i, double scale, double omega, const double *ushift, bool *done);  // xscan.hip
+                       const x3d_tdsops *der2nd_sym, int acc, const real_t *const *upd_g, const x3d_tdsops *op_s,
+                       const x3d_tdsops *op_i, real_t scale, real_t omega, const real_t *ushift, bool *done);  // xscan.hip
 // xdir.hip
-int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
+int x3d_xwide_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f[3], real_t nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       double omega, const double *ushift, bool *done);  // xwide.hip
-int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+                       real_t omega, const real_t *ushift, bool *done);  // xwide.hip
+int x3d_ygen_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                   const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done);  // ygen.hip
-int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done);  // ygen.hip
-int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale);
-int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xdir_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale);
+int x3d_xdir_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc);
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                          double scale);
-int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+int x3d_generic_tds_local(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, int acc,
+                          real_t scale);
+int x3d_generic_transeq_local(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv,
+                              real_t nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
                               int acc);
 
 static inline dim3 grid_for(const PencilGeom &g) { return dim3((g.np + 63) / 64); }
@@ -694,7 +694,7 @@ static int check_len(const x3d_backend *b, const x3d_tdsops *t, int dir, const c
     return 0;
 }
 
-extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, const double *u, int n, int dir)
+extern "C" int x3d_pack_halos(x3d_backend *b, real_t *send_s, real_t *send_e, const real_t *u, int n, int dir)
 {
     X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
     // deferred execution on several ranks: what has been recorded runs first, then this entry point works on the
@@ -709,8 +709,8 @@ extern "C" int x3d_pack_halos(x3d_backend *b, double *send_s, double *send_e, co
     return 0;
 }
 
-extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, double *du_send_e,
-                                const double *u, const double *u_recv_s, const double *u_recv_e,
+extern "C" int x3d_tds_dist_fwd(x3d_backend *b, real_t *du, real_t *du_send_s, real_t *du_send_e,
+                                const real_t *u, const real_t *u_recv_s, const real_t *u_recv_e,
                                 const x3d_tdsops *t, int dir)
 {
     X3D_REQUIRE(b && du && du_send_s && du_send_e && u && u_recv_s && u_recv_e && t,
@@ -729,9 +729,9 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, double *du, double *du_send_s, d
     return 0;
 }
 
-extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
-                                    const double *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
-                                    double scale)
+extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, real_t *du, const real_t *du_send_s, const real_t *du_recv_s,
+                                    const real_t *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
+                                    real_t scale)
 {
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
@@ -740,25 +740,25 @@ extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, double *du, const double *du
     PencilGeom g = x3d_geom(b, dir);
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
     if (accumulate)  // fusion extension: du += scale * result (folds the vecadd of the fused driver)
-        hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
+        hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const real_t *)b->scratch[2],
                            du_send_s, du_recv_s, du_recv_e, t->tab, g, scale);
     else
-        hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)b->scratch[2],
+        hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const real_t *)b->scratch[2],
                            du_send_s, du_recv_s, du_recv_e, t->tab, g, 1.0);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_tds_dist_bwd(x3d_backend *b, double *du, const double *du_send_s, const double *du_recv_s,
-                                const double *du_recv_e, const x3d_tdsops *t, int dir)
+extern "C" int x3d_tds_dist_bwd(x3d_backend *b, real_t *du, const real_t *du_send_s, const real_t *du_recv_s,
+                                const real_t *du_recv_e, const x3d_tdsops *t, int dir)
 {
     return x3d_tds_dist_bwd_acc(b, du, du_send_s, du_recv_s, du_recv_e, t, dir, 0, 1.0);
 }
 
 // Local form: sendrecv_fields with nproc==1 hands every rank its own buffers
 // back swapped (src/backend/omp/sendrecv.f90:20-22): recv_s = send_e, recv_e = send_s.
-extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir,
-                                 int accumulate, double scale)
+extern "C" int x3d_tds_solve_acc(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir,
+                                 int accumulate, real_t scale)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -780,14 +780,14 @@ extern "C" int x3d_tds_solve_acc(x3d_backend *b, double *du, const double *u, co
     return x3d_generic_tds_local(b, du, u, t, dir, accumulate, scale);
 }
 
-int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, const TileHalo *halo, int other0, int nother,
                        bool *done);  // xscan.hip
-int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *brecv,
+int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *brecv,
                      const x3d_tdsops *ta, const x3d_tdsops *tb);  // xscan.hip
-int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, double *const r[3], const double *conv, double nu,
-                                const double *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd);  // xscan.hip
-int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, real_t *const r[3], const real_t *conv, real_t nu,
+                                const real_t *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd);  // xscan.hip
+int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother,
                        bool *done);  // xscan.hip
@@ -795,8 +795,8 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 // fusion extension for the operator pairs of divergence_v2c / gradient_c2v (src/vector_calculus.f90:142-332):
 //   mode 0: out1 = A(in1) + B(in2)          mode 1: out1 = A(in1), out2 = B(in1)
 // one kernel for periodic 256 / 512-row y pencils (xscan.hip, k_ytile_tds_pair), else the two tds_solve's
-extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                                  const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb)
+extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                                  const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -826,8 +826,8 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, double *out
 // positions = what enforce_periodicity_y would have made of the result; mode 1 (gradient's first pair): in1's y rows
 // are read from their positions = in1 is what the solver's backward transform left, undo_periodicity_y not run.
 // *done = 0: these pencils are not served by a tile kernel, nothing was done (run the copies + x3d_tds_solve_pair).
-extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1,
-                                        const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done)
+extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                                        const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -851,19 +851,19 @@ extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, double *out1, 
     return 0;
 }
 
-int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, const double *wall, bool *done);  // xscan.hip
-int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, const double *wall, bool *done);  // xwide.hip
-extern "C" int x3d_field_set_face_from_field(x3d_backend *b, double *f, const double *f_start, const int dims[3],
-                                             double c_end, int face, double flow_rate_diff);
-extern "C" int x3d_lincomb(x3d_backend *b, double *y, const double *base, int nterm, const double *c,
-                           const double *const *x);
+int x3d_xscan_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
+                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done);  // xscan.hip
+int x3d_xwide_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
+                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done);  // xwide.hip
+extern "C" int x3d_field_set_face_from_field(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3],
+                                             real_t c_end, int face, real_t flow_rate_diff);
+extern "C" int x3d_lincomb(x3d_backend *b, real_t *y, const real_t *base, int nterm, const real_t *c,
+                           const real_t *const *x);
 
 // fusion extension: y = base + sum_i c[i] x[i] (x3d_lincomb) followed by du = tds_solve(y), in one kernel for
 // periodic 256 / 512-point x pencils (y is not read back); otherwise the two calls one after the other
-static int tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y, const double *base,
-                                  int nterm, const double *c, const double *const *x, const double *wall)
+static int tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base,
+                                  int nterm, const real_t *c, const real_t *const *x, const real_t *wall)
 {
     X3D_REQUIRE(b && du && t && y && base && c && x, "x3d_tds_solve_lincomb: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve_lincomb: bad dir %d", dir);
@@ -886,8 +886,8 @@ static int tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d
     return x3d_tds_solve_acc(b, du, y, t, dir, 0, 1.0);
 }
 
-extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
-                                     const double *base, int nterm, const double *c, const double *const *x)
+extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y,
+                                     const real_t *base, int nterm, const real_t *c, const real_t *const *x)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -897,9 +897,9 @@ extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, double *du, const 
 // the same with the y faces of y (vertex rows j = 0 and ny - 1) stamped from `wall` before the operator acts:
 // lincomb ; field_set_face_from_field(y, wall, Y_FACE) ; tds_solve -- RK stage, the channel case's apply_BC
 // (src/case/channel.f90:214-231) and the first x operator of divergence_v2c in one kernel where the pencils allow
-extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, const x3d_tdsops *t, double *y,
-                                          const double *base, int nterm, const double *c, const double *const *x,
-                                          const double *wall)
+extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y,
+                                          const real_t *base, int nterm, const real_t *c, const real_t *const *x,
+                                          const real_t *wall)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -907,7 +907,7 @@ extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, double *du, c
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall);
 }
 
-extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir)
+extern "C" int x3d_tds_solve(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir)
 {
     if (b && x3d_lazy_active(b)) {  // recorded -- after the checks the eager path makes at the call site
         X3D_REQUIRE(du && u && t, "x3d_tds_solve: null argument");
@@ -919,23 +919,23 @@ extern "C" int x3d_tds_solve(x3d_backend *b, double *du, const double *u, const 
     return x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0);
 }
 
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                          double scale)
+int x3d_generic_tds_local(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, int acc,
+                          real_t scale)
 {
     PencilGeom g = x3d_geom(b, dir);
-    double *d = b->scratch[2];
+    real_t *d = b->scratch[2];
     {
         ProfScope ps(b, X3D_K_TDS_FWD, dir);
         hipLaunchKernelGGL((k_tds_fwd<false>), grid_for(g), dim3(64), 0, b->stream, d, b->send_s, b->send_e, u,
-                           (const double *)nullptr, (const double *)nullptr, t->tab, g, t->n_tds);
+                           (const real_t *)nullptr, (const real_t *)nullptr, t->tab, g, t->n_tds);
     }
     {
         ProfScope ps(b, X3D_K_TDS_BWD, dir);
         if (acc)
-            hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)d,
+            hipLaunchKernelGGL(k_tds_bwd<true>, grid_for(g), dim3(64), 0, b->stream, du, (const real_t *)d,
                                b->send_s, b->send_e, b->send_s, t->tab, g, scale);
         else
-            hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const double *)d,
+            hipLaunchKernelGGL(k_tds_bwd<false>, grid_for(g), dim3(64), 0, b->stream, du, (const real_t *)d,
                                b->send_s, b->send_e, b->send_s, t->tab, g, 1.0);
     }
     X3D_HIP(hipGetLastError());
@@ -959,9 +959,9 @@ static int transeq_check(const x3d_backend *b, int dir, const x3d_tdsops *t1, co
     return check_len(b, t1, dir, "transeq");
 }
 
-extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double *send_s, double *send_e,
-                                    const double *u, const double *u_recv_s, const double *u_recv_e,
-                                    const double *conv, const double *conv_recv_s, const double *conv_recv_e,
+extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, real_t *rhs, real_t *send_s, real_t *send_e,
+                                    const real_t *u, const real_t *u_recv_s, const real_t *u_recv_e,
+                                    const real_t *conv, const real_t *conv_recv_s, const real_t *conv_recv_e,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
     X3D_REQUIRE(b && rhs && send_s && send_e && u && u_recv_s && u_recv_e && conv && conv_recv_s &&
@@ -983,8 +983,8 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, double *rhs, double
     return 0;
 }
 
-extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, const double *send_s,
-                                        const double *recv_s, const double *recv_e, const double *conv, double nu,
+extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, real_t *rhs, const real_t *send_s,
+                                        const real_t *recv_s, const real_t *recv_e, const real_t *conv, real_t nu,
                                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
                                         int accumulate)
 {
@@ -998,25 +998,25 @@ extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, double *rhs, co
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
     if (accumulate)  // fusion extension: rhs += result
         hipLaunchKernelGGL(k_transeq_bwd<true>, grid_for(g), dim3(64), 0, b->stream, rhs,
-                           (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
+                           (const real_t *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
                            t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
     else
         hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs,
-                           (const double *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
+                           (const real_t *)b->scratch[2], b->scratch[0], b->scratch[1], conv, send_s, recv_s, recv_e, nu,
                            t_du->tab, t_dud->tab, t_d2u->tab, g, g.np);
     X3D_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, double *rhs, const double *send_s,
-                                    const double *recv_s, const double *recv_e, const double *conv, double nu,
+extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, real_t *rhs, const real_t *send_s,
+                                    const real_t *recv_s, const real_t *recv_e, const real_t *conv, real_t nu,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
     return x3d_transeq_dist_bwd_acc(b, dir, rhs, send_s, recv_s, recv_e, conv, nu, t_du, t_dud, t_d2u, 0);
 }
 
-static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                                   double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+static int transeq_component_local(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv,
+                                   real_t nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
                                    int acc)
 {
     if (dir == X3D_DIR_X) return x3d_xdir_transeq(b, rhs, u, conv, nu, t1, t2, t3, acc);
@@ -1029,14 +1029,14 @@ static int transeq_component_local(x3d_backend *b, int dir, double *rhs, const d
     return x3d_generic_transeq_local(b, dir, rhs, u, conv, nu, t1, t2, t3, acc);
 }
 
-int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+int x3d_generic_transeq_local(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv,
+                              real_t nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
                               int acc)
 {
     PencilGeom g = x3d_geom(b, dir);
-    double *d1 = b->scratch[2];
+    real_t *d1 = b->scratch[2];
     const int npm = npmax_of(b);
-    const double *z = nullptr;
+    const real_t *z = nullptr;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
         if (u == conv)
@@ -1051,11 +1051,11 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
     {
         ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
         if (acc)
-            hipLaunchKernelGGL(k_transeq_bwd<true>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)d1,
+            hipLaunchKernelGGL(k_transeq_bwd<true>, grid_for(g), dim3(64), 0, b->stream, rhs, (const real_t *)d1,
                                b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
                                t2->tab, t3->tab, g, npm);
         else
-            hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs, (const double *)d1,
+            hipLaunchKernelGGL(k_transeq_bwd<false>, grid_for(g), dim3(64), 0, b->stream, rhs, (const real_t *)d1,
                                b->scratch[0], b->scratch[1], conv, b->send_s, b->send_e, b->send_s, nu, t1->tab,
                                t2->tab, t3->tab, g, npm);
     }
@@ -1065,8 +1065,8 @@ int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double
 
 // transeq_x/y/z -> transeq_omp_dist with the component permutation of
 // src/backend/omp/backend.f90:145-184 and the operator pairing of :246-260
-extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                           const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+extern "C" int x3d_transeq(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                           const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
                            const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                            const x3d_tdsops *der2nd_sym)
 {
@@ -1082,8 +1082,8 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, double *du, double *dv, doub
     return x3d_transeq_acc(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0);
 }
 
-extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                               const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                               const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
                                const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                const x3d_tdsops *der2nd_sym, int accumulate)
 {
@@ -1094,8 +1094,8 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq: bad dir %d", dir);
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
     if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
-    double *r[3];
-    const double *f[3];
+    real_t *r[3];
+    const real_t *f[3];
     if (dir == X3D_DIR_X) { r[0] = du; r[1] = dv; r[2] = dw; f[0] = u; f[1] = v; f[2] = w; }
     else if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; f[0] = v; f[1] = u; f[2] = w; }
     else { r[0] = dw; r[1] = du; r[2] = dv; f[0] = w; f[1] = u; f[2] = v; }
@@ -1136,11 +1136,11 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, double *du, double *dv, 
 // w += scale * tds_solve(gw, op_vw) (the last x operators of gradient_c2v + the velocity update of
 // src/solver.f90:731-733), per pencil, inside the transeq kernel.  *done = 0: not applicable here, nothing was
 // done (issue x3d_tds_solve_acc x 3 and x3d_transeq).  Bit-identical to that sequence.
-extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, double *dw, double *u, double *v, double *w,
-                                    double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                                    const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, const double *gu,
-                                    const double *gv, const double *gw, const x3d_tdsops *op_u,
-                                    const x3d_tdsops *op_vw, double scale, int *done)
+extern "C" int x3d_transeq_x_update(x3d_backend *b, real_t *du, real_t *dv, real_t *dw, real_t *u, real_t *v, real_t *w,
+                                    real_t nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                    const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, const real_t *gu,
+                                    const real_t *gv, const real_t *gw, const x3d_tdsops *op_u,
+                                    const x3d_tdsops *op_vw, real_t scale, int *done)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -1151,8 +1151,8 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
     if (int rc = transeq_check(b, X3D_DIR_X, der1st, der1st_sym, der2nd)) return rc;
     if (int rc = check_len(b, op_u, X3D_DIR_X, "transeq_x_update")) return rc;
     if (int rc = check_len(b, op_vw, X3D_DIR_X, "transeq_x_update")) return rc;
-    double *r[3] = {du, dv, dw};
-    const double *f[3] = {u, v, w}, *g[3] = {gu, gv, gw};
+    real_t *r[3] = {du, dv, dw};
+    const real_t *f[3] = {u, v, w}, *g[3] = {gu, gv, gw};
     for (int c = 0; c < 3; c++)
         for (int k = 0; k < 3; k++)
             X3D_REQUIRE(r[c] != f[k] && r[c] != g[k] && f[c] != g[k], "x3d_transeq_x_update: arguments alias");
@@ -1171,10 +1171,10 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, double *du, double *dv, doub
 // x3d_field_mean_shift: the second half of the bulk-velocity correction, :70-77, bit-identical to x3d_field_shift_by).
 // *done = 0: not served for these pencils, nothing was done (issue x3d_field_shift_by, x3d_transeq and, after the
 // other directions, x3d_vecadd x 2).  Served: periodic x pencils of 256 / 512 rows (K3s) and of 1024 rows (K3w).
-extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double *dw, double *u, const double *v,
-                                 const double *w, double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
-                                 const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, double omega,
-                                 const double *u_shift, int *done)
+extern "C" int x3d_transeq_x_rot(x3d_backend *b, real_t *du, real_t *dv, real_t *dw, real_t *u, const real_t *v,
+                                 const real_t *w, real_t nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                 const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, real_t omega,
+                                 const real_t *u_shift, int *done)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -1183,8 +1183,8 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double 
     *done = 0;
     if (int rc = transeq_check(b, X3D_DIR_X, der1st, der1st_sym, der2nd)) return rc;
     if (int rc = transeq_check(b, X3D_DIR_X, der1st_sym, der1st, der2nd_sym)) return rc;
-    double *r[3] = {du, dv, dw};
-    const double *f[3] = {u, v, w};
+    real_t *r[3] = {du, dv, dw};
+    const real_t *f[3] = {u, v, w};
     for (int c = 0; c < 3; c++)
         X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_x_rot: outputs alias inputs");
     if (omega == 0.0 && !u_shift) return 0;
@@ -1200,8 +1200,8 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, double *du, double *dv, double 
 
 // transeq_species (src/backend/omp/backend.f90:186-233): one convection-diffusion component of a transported
 // scalar: field = spec, advecting velocity = uvw, operators (der1st, der1st_sym, der2nd), local direction
-extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const double *uvw, const double *spec,
-                                   double nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+extern "C" int x3d_transeq_species(x3d_backend *b, int dir, real_t *dspec, const real_t *uvw, const real_t *spec,
+                                   real_t nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                    const x3d_tdsops *der2nd, int accumulate)
 {
     X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
@@ -1221,7 +1221,7 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, double *dspec, const
 // system; the result differs from the three-sweep order by re-association and by coupling terms < 2^-60.
 
 // send[side 2][field nf][4][np]: rows 1..4 (side 0, for prev) and n-3..n (side 1, for next) of nf <= 3 fields
-extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *const *fields, int nf, int n, int dir)
+extern "C" int x3d_pack_halos_multi(x3d_backend *b, real_t *send, const real_t *const *fields, int nf, int n, int dir)
 {
     X3D_REQUIRE(b && send && fields, "x3d_pack_halos_multi: null argument");
     X3D_REQUIRE(nf >= 1 && nf <= 3, "x3d_pack_halos_multi: 1..3 fields");
@@ -1230,7 +1230,7 @@ extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *
     PackFields pf{};
     for (int k = 0; k < nf; k++) {
         X3D_REQUIRE(fields[k], "x3d_pack_halos_multi: null field");
-        const double *fk = fields[k];
+        const real_t *fk = fields[k];
         X3D_LAZY_IN(b, fk);  // (deferred execution: flush, then the buffer that holds the field)
         pf.f[k] = fk;
     }
@@ -1252,10 +1252,10 @@ extern "C" int x3d_pack_halos_multi(x3d_backend *b, double *send, const double *
 // first, src/backend/omp/backend.f90:145-184) and bnd_send[2][9][np] receives this rank's boundary values
 // ([component * 3 + {d(u conv), du, d2u}]).  *done = 0: these pencils are not served here (use x3d_transeq_acc /
 // the two-sweep x3d_transeq_dist_* calls).
-extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                                const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                                const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
                                 const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
-                                int accumulate, const double *halo_recv, double *bnd_send, int other0, int nother,
+                                int accumulate, const real_t *halo_recv, real_t *bnd_send, int other0, int nother,
                                 int *done)
 {
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
@@ -1273,8 +1273,8 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv,
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_tile: dir must be y or z");
     if (int rc = transeq_check(b, dir, der1st, der1st_sym, der2nd)) return rc;
     if (int rc = transeq_check(b, dir, der1st_sym, der1st, der2nd_sym)) return rc;
-    double *r[3];
-    const double *f[3];
+    real_t *r[3];
+    const real_t *f[3];
     if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; f[0] = v; f[1] = u; f[2] = w; }
     else { r[0] = dw; r[1] = du; r[2] = dv; f[0] = w; f[1] = u; f[2] = v; }
     for (int c = 0; c < 3; c++) X3D_REQUIRE(r[c] != f[0] && r[c] != f[1] && r[c] != f[2], "x3d_transeq_tile: outputs alias inputs");
@@ -1290,16 +1290,16 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, double *du, double *dv,
 
 // ... and the contribution of the received boundary values bnd_recv[2][9][np] (side 0: from prev = its X_n,
 // side 1: from next = its du_1), added to du, dv, dw
-extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double *dv, double *dw, const double *u,
-                                    const double *v, const double *w, double nu, const x3d_tdsops *der1st,
-                                    const x3d_tdsops *der2nd, const double *bnd_recv)
+extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                                    const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
+                                    const x3d_tdsops *der2nd, const real_t *bnd_recv)
 {
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der2nd && bnd_recv, "x3d_transeq_halo_fix: null argument");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_halo_fix: dir must be y or z");
     X3D_LAZY_IN(b, u); X3D_LAZY_IN(b, v); X3D_LAZY_IN(b, w);
     X3D_LAZY_OUT(b, du, false); X3D_LAZY_OUT(b, dv, false); X3D_LAZY_OUT(b, dw, false);
     X3D_LAZY_EAGER(b);
-    double *r[3];
+    real_t *r[3];
     if (dir == X3D_DIR_Y) { r[0] = dv; r[1] = du; r[2] = dw; }
     else { r[0] = dw; r[1] = du; r[2] = dv; }
     return x3d_transeq_halo_fix_launch(b, dir, r, dir == X3D_DIR_Y ? v : w, nu, bnd_recv, der1st, der2nd);
@@ -1308,9 +1308,9 @@ extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, double *du, double 
 // tds_solve pairs / single operators of a y or z direction through the tile kernel (modes of x3d_tds_solve_pair,
 // + mode 2: out1 = A(in1)), over a plane range as above.  halo_recv == NULL: local direction.  Otherwise
 // halo_recv[2][nf][4][np] with nf = 2 (mode 0: in1, in2) or 1, and bnd_send[2][nb][np], nb = 2 (modes 0, 1: A, B) or 1
-static int pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                     const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
-                     double *bnd_send, int other0, int nother, int *done)
+static int pair_tile(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                     const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const real_t *halo_recv,
+                     real_t *bnd_send, int other0, int nother, int *done)
 {
     X3D_REQUIRE(b && out1 && in1 && ta && done, "x3d_tds_pair_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_tds_pair_tile: halo_recv and bnd_send go together");
@@ -1344,17 +1344,17 @@ static int pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *ou
     return 0;
 }
 
-extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1,
-                                 const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const double *halo_recv,
-                                 double *bnd_send, int other0, int nother, int *done)
+extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                                 const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const real_t *halo_recv,
+                                 real_t *bnd_send, int other0, int nother, int *done)
 {
     return pair_tile(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, other0, nother, done);
 }
 // the decomposed-z form of x3d_tds_solve_pair_yperm: the whole block, halo_recv's planes in the row order of in1
 // (mode 1: interleaved like the field they were cut from), bnd_send in pencil order
-extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, double *out1, double *out2, const double *in1,
-                                       const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
-                                       const double *halo_recv, double *bnd_send, int ny, int *done)
+extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1,
+                                       const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+                                       const real_t *halo_recv, real_t *bnd_send, int ny, int *done)
 {
     X3D_REQUIRE(b && done, "x3d_tds_pair_tile_yperm: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_tile_yperm: mode must be 0 or 1");
@@ -1365,8 +1365,8 @@ extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, double *out1, d
     b->pair_yperm = 0;
     return rc;
 }
-extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out1, double *out2, const x3d_tdsops *ta,
-                                           const x3d_tdsops *tb, const double *bnd_recv, int ny)
+extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, real_t *out1, real_t *out2, const x3d_tdsops *ta,
+                                           const x3d_tdsops *tb, const real_t *bnd_recv, int ny)
 {
     X3D_REQUIRE(b, "x3d_tds_pair_halo_fix_yperm: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_halo_fix_yperm: mode must be 0 or 1");
@@ -1381,10 +1381,10 @@ extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, double *out
 // gradient_c2v, its input arrives that way (in1 unused).  *done = 0: not on offer here, nothing was done
 struct x3d_poisson;
 int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok);
-int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                           const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr);
-extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, double *out1, double *out2,
-                                   const double *in1, const double *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
+extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, real_t *out1, real_t *out2,
+                                   const real_t *in1, const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                    int *done)
 {
     X3D_REQUIRE(b && poisson && ta && tb && done, "x3d_tds_pair_zfirst: null argument");
@@ -1412,8 +1412,8 @@ extern "C" int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, cons
     return 0;
 }
 
-extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2,
-                                     const x3d_tdsops *ta, const x3d_tdsops *tb, const double *bnd_recv)
+extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2,
+                                     const x3d_tdsops *ta, const x3d_tdsops *tb, const real_t *bnd_recv)
 {
     X3D_REQUIRE(b && out1 && ta && bnd_recv && (mode == 2 || tb) && (mode != 1 || out2), "x3d_tds_pair_halo_fix: null argument");
     X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_halo_fix: mode must be 0, 1 or 2");

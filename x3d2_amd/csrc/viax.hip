@@ -15,46 +15,46 @@
 // src/backend/omp/backend.f90:145-184.
 #include "common.h"
 
-int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xscan_transeq_np(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                          const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
                          int dirtag, bool *done);
 bool x3d_xscan_fast_ok(const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
 bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3);
-int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother,
                        bool *done);
-int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
-                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
-                              const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
+int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, real_t *y,
+                              const real_t *base, int nterm, const real_t *c, real_t *const *x, int ipend, int store,
                               bool *done);
-int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+int x3d_ytile_transeq(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 
 // dst[c*dC + a*dA + b] (+)= src[c*sC + b*sB + a]: 64 x 64 tiles through LDS, 512-byte rows on both sides
 template <bool ACC, bool NT>
 __global__ void __launch_bounds__(256)
-    k_transpose64(double *__restrict__ dst, const double *__restrict__ src, int nA, int nB, long dA, long dC, long sB,
+    k_transpose64(real_t *__restrict__ dst, const real_t *__restrict__ src, int nA, int nB, long dA, long dC, long sB,
                   long sC)
 {
-    __shared__ double tile[64][65];
+    __shared__ real_t tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
     const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-    const double *__restrict__ sp = src + (long)blockIdx.z * sC;
-    double *__restrict__ dp = dst + (long)blockIdx.z * dC;
+    const real_t *__restrict__ sp = src + (long)blockIdx.z * sC;
+    real_t *__restrict__ dp = dst + (long)blockIdx.z * dC;
     const bool full = a0 + 64 <= nA && b0 + 64 <= nB;
     if (full) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
             {
-            const double *q = &sp[a0 + tx + (long)(b0 + ty + 4 * r) * sB];
+            const real_t *q = &sp[a0 + tx + (long)(b0 + ty + 4 * r) * sB];
             tile[ty + 4 * r][tx] = NT ? __builtin_nontemporal_load(q) : *q;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            double *q = &dp[(long)(a0 + ty + 4 * r) * dA + b0 + tx];
-            const double v = tile[tx][ty + 4 * r];
+            real_t *q = &dp[(long)(a0 + ty + 4 * r) * dA + b0 + tx];
+            const real_t v = tile[tx][ty + 4 * r];
             if (ACC) *q += v;
             else *q = v;
         }
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256)
         for (int r = 0; r < 16; r++) {
             const int aa = a0 + ty + 4 * r, bb = b0 + tx;
             if (aa < nA && bb < nB) {
-                double *q = &dp[(long)aa * dA + bb];
-                const double v = tile[tx][ty + 4 * r];
+                real_t *q = &dp[(long)aa * dA + bb];
+                const real_t v = tile[tx][ty + 4 * r];
                 if (ACC) *q += v;
                 else *q = v;
             }
@@ -123,7 +123,7 @@ static ViaGeom via_geom(const x3d_backend *b, int dir)
 }
 
 // (c0, nc): the slab of C planes to move
-static int to_pencils(x3d_backend *b, const ViaGeom &g, double *T, const double *f, int c0, int nc)
+static int to_pencils(x3d_backend *b, const ViaGeom &g, real_t *T, const real_t *f, int c0, int nc)
 {
     dim3 grid((g.nA + 63) / 64, (g.nB + 63) / 64, nc);
     hipLaunchKernelGGL((k_transpose64<false, false>), grid, dim3(256), 0, b->stream, T + c0 * g.f_dC, f + c0 * g.f_sC,
@@ -132,7 +132,7 @@ static int to_pencils(x3d_backend *b, const ViaGeom &g, double *T, const double 
     return 0;
 }
 
-static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *r, const double *T, int acc, int c0,
+static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, real_t *r, const real_t *T, int acc, int c0,
                         int nc)
 {
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
@@ -151,7 +151,7 @@ static int from_pencils(x3d_backend *b, int dir, const ViaGeom &g, double *r, co
 }
 
 // r[c] (+)= transeq component c of direction dir (y or z); f[0] is the advecting component
-int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_transeq_via_x(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
 {
@@ -179,7 +179,7 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
             return 0;
         }
     }
-    double *T0 = b->scratch[0], *T1 = b->scratch[1], *tmp = b->scratch[2];
+    real_t *T0 = b->scratch[0], *T1 = b->scratch[1], *tmp = b->scratch[2];
     // slabs of C planes: the transposed copies and the scan kernel's output of one slab are produced and
     // consumed back to back, so that most of their re-reads hit the 256 MB Infinity Cache
     const int nslab = via_slabs(g.nC);
@@ -189,7 +189,7 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
         const int np = nc * g.nA;
         for (int c = 0; c < 3; c++) {
             bool ok = false;
-            double *T = c == 0 ? T0 : T1;
+            real_t *T = c == 0 ? T0 : T1;
             // profiler: transpose + scan kernel = the component's "forward" launch, the accumulating
             // inverse transpose its "backward" launch (bench.py prices a component as fwd + bwd)
             {
@@ -219,24 +219,24 @@ int x3d_transeq_via_x(x3d_backend *b, int dir, double *const r[3], const double 
 // in the summation order of k_lincomb (backend.hip): bit-identical to from_pencils followed by x3d_lincomb, with
 // 4 field passes fewer per variable and RK3 step.
 struct LinPend {
-    const double *x[5];
-    double c[5];
+    const real_t *x[5];
+    real_t c[5];
     int n, ipend;
 };
 
-__device__ __forceinline__ double2 ldnt2(const double *p)
+__device__ __forceinline__ real2_t ldnt2(const real_t *p)
 {
-    return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+    return make_real2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
 }
 
 template <bool STORE>
 __global__ void __launch_bounds__(256)
-    k_transpose_lincomb(double *y, const double *base, double *xp, const double *__restrict__ src, int nA, int nB,
+    k_transpose_lincomb(real_t *y, const real_t *base, real_t *xp, const real_t *__restrict__ src, int nA, int nB,
                         long dA, long dC, long sB, long sC, LinPend a)
 {
-    __shared__ double tile[64][65];
+    __shared__ real_t tile[64][65];
     const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-    const double *__restrict__ sp = src + (long)blockIdx.z * sC;
+    const real_t *__restrict__ sp = src + (long)blockIdx.z * sC;
     const long cof = (long)blockIdx.z * dC;
     const bool full = a0 + 64 <= nA && b0 + 64 <= nB && (dA & 1) == 0 && (dC & 1) == 0;
     if (full) {
@@ -253,15 +253,15 @@ __global__ void __launch_bounds__(256)
         for (int r = 0; r < 8; r++) {
             const int al = ty + 8 * r;
             const long i = cof + (long)(a0 + al) * dA + b0 + 2 * tx;
-            double2 d = ldnt2(xp + i);
+            real2_t d = ldnt2(xp + i);
             d.x += tile[2 * tx][al];
             d.y += tile[2 * tx + 1][al];
             if (STORE) { xp[i] = d.x; xp[i + 1] = d.y; }
-            double2 v = ldnt2(base + i);
+            real2_t v = ldnt2(base + i);
 #pragma unroll
             for (int k = 0; k < 5; k++)
                 if (k < a.n) {
-                    double2 t = d;
+                    real2_t t = d;
                     if (k != a.ipend) t = ldnt2(a.x[k] + i);
                     v.x = a.c[k] * t.x + v.x;
                     v.y = a.c[k] * t.y + v.y;
@@ -281,9 +281,9 @@ __global__ void __launch_bounds__(256)
         const int aa = a0 + ty + 4 * r, bb = b0 + tx;
         if (aa < nA && bb < nB) {
             const long i = cof + (long)aa * dA + bb;
-            const double d = xp[i] + tile[tx][ty + 4 * r];
+            const real_t d = xp[i] + tile[tx][ty + 4 * r];
             if (STORE) xp[i] = d;
-            double v = base[i];
+            real_t v = base[i];
 #pragma unroll
             for (int k = 0; k < 5; k++)
                 if (k < a.n) v = a.c[k] * (k == a.ipend ? d : a.x[k][i]) + v;
@@ -298,8 +298,8 @@ static int defer_perm(int dir, int c)  // component c of direction dir -> index 
     return dir == X3D_DIR_Y ? py[c] : pz[c];
 }
 
-extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv, double *pw, const double *u,
-                                 const double *v, const double *w, double nu, const x3d_tdsops *der1st,
+extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, real_t *pu, real_t *pv, real_t *pw, const real_t *u,
+                                 const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
                                  const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                  const x3d_tdsops *der2nd_sym, int *deferred)
 {
@@ -317,12 +317,12 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv
     if (der1st->n_tds != n) return 0;
     const ViaGeom g = via_geom(b, dir);
     if (g.nC > 65535 || (size_t)b->nx * b->ny * b->nz > b->nblock) return 0;
-    double *pend[3] = {pu, pv, pw};
-    const double *fld[3] = {u, v, w};
-    double *T0 = b->scratch[0], *T1 = b->scratch[1];
+    real_t *pend[3] = {pu, pv, pw};
+    const real_t *fld[3] = {u, v, w};
+    real_t *T0 = b->scratch[0], *T1 = b->scratch[1];
     for (int c = 0; c < 3; c++) {
         const int m = defer_perm(dir, c);
-        double *T = c == 0 ? T0 : T1;
+        real_t *T = c == 0 ? T0 : T1;
         bool ok = false;
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
         if (int rc = to_pencils(b, g, T, fld[m], 0, g.nC)) return rc;
@@ -340,7 +340,7 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, double *pu, double *pv
 }
 
 // r += transpose^-1(pend): the plain completion of a deferred component
-extern "C" int x3d_pending_flush(x3d_backend *b, int dir, double *r, const double *pend)
+extern "C" int x3d_pending_flush(x3d_backend *b, int dir, real_t *r, const real_t *pend)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -349,8 +349,8 @@ extern "C" int x3d_pending_flush(x3d_backend *b, int dir, double *r, const doubl
     return from_pencils(b, dir, via_geom(b, dir), r, pend, 1, 0, via_geom(b, dir).nC);
 }
 
-extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, double *y, const double *base, int nterm,
-                                   const double *c, double *const *x, int ipend, const double *pend, int store)
+extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, real_t *y, const real_t *base, int nterm,
+                                   const real_t *c, real_t *const *x, int ipend, const real_t *pend, int store)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
@@ -395,10 +395,10 @@ extern "C" int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *d
            x3d_ytile_applicable(b, dir, der1st_sym, der1st, der2nd_sym);
 }
 
-extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const double *u, const double *conv, double nu,
+extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const real_t *u, const real_t *conv, real_t nu,
                                    const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                                   const x3d_tdsops *der2nd_sym, double *y, const double *base, int nterm,
-                                   const double *c, double *const *x, int ipend, int store)
+                                   const x3d_tdsops *der2nd_sym, real_t *y, const real_t *base, int nterm,
+                                   const real_t *c, real_t *const *x, int ipend, int store)
 {
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);

@@ -14,10 +14,10 @@
 // Reference arithmetic: src/backend/omp/kernels/distributed.f90:11-337 (see tds.hip).
 #include "common.h"
 
-int x3d_generic_tds_local(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int dir, int acc,
-                          double scale);
-int x3d_generic_transeq_local(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv,
-                              double nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
+int x3d_generic_tds_local(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, int acc,
+                          real_t scale);
+int x3d_generic_transeq_local(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv,
+                              real_t nu, const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3,
                               int acc);
 int npmax_of(const x3d_backend *b);
 
@@ -31,13 +31,13 @@ int npmax_of(const x3d_backend *b);
 #define LPR (TW / 2) // lanes per row in a fetch
 #define RPF (64 / LPR) // rows per fetch instruction
 
-__device__ __forceinline__ double dot9x(const double *__restrict__ c, const double (&w)[9])
+__device__ __forceinline__ real_t dot9x(const real_t *__restrict__ c, const real_t (&w)[9])
 {
     return c[0] * w[0] + c[1] * w[1] + c[2] * w[2] + c[3] * w[3] + c[4] * w[4] + c[5] * w[5] + c[6] * w[6] +
            c[7] * w[7] + c[8] * w[8];
 }
 
-__device__ __forceinline__ const double *stencil_row_x(const double *__restrict__ Cs, int j, int nr)
+__device__ __forceinline__ const real_t *stencil_row_x(const real_t *__restrict__ Cs, int j, int nr)
 {
     if (j <= 4) return Cs + (j - 1) * 9;
     if (j > nr - 4) return Cs + 36 + (j - (nr - 4) - 1) * 9;
@@ -46,9 +46,9 @@ __device__ __forceinline__ const double *stencil_row_x(const double *__restrict_
 
 // cooperative tile fetch: TLD x (16 B per lane); LPR lanes cover one row
 // segment of TW columns (TW*8 B contiguous), RPF rows per instruction
-struct TileRegs { double2 v[TLD]; };
+struct TileRegs { real2_t v[TLD]; };
 
-__device__ __forceinline__ void tile_load(TileRegs &r, const double *__restrict__ slab, long pitch, int col0,
+__device__ __forceinline__ void tile_load(TileRegs &r, const real_t *__restrict__ slab, long pitch, int col0,
                                           int rows_valid, int lane)
 {
     const int cp = (lane % LPR) * 2;
@@ -56,11 +56,11 @@ __device__ __forceinline__ void tile_load(TileRegs &r, const double *__restrict_
     for (int i = 0; i < TLD; i++) {
         int row = (lane / LPR) + RPF * i;
         row = row < rows_valid ? row : rows_valid - 1;  // partial wave: replicate a valid row
-        r.v[i] = *reinterpret_cast<const double2 *>(slab + (long)row * pitch + col0 + cp);
+        r.v[i] = *reinterpret_cast<const real2_t *>(slab + (long)row * pitch + col0 + cp);
     }
 }
 
-__device__ __forceinline__ void tile_to_lds(const TileRegs &r, double *__restrict__ lds, int lane)
+__device__ __forceinline__ void tile_to_lds(const TileRegs &r, real_t *__restrict__ lds, int lane)
 {
     const int cp = (lane % LPR) * 2;
 #pragma unroll
@@ -72,20 +72,20 @@ __device__ __forceinline__ void tile_to_lds(const TileRegs &r, double *__restric
 }
 
 template <bool ACC>
-__device__ __forceinline__ void tile_store(const double *__restrict__ lds, double *__restrict__ slab, long pitch,
-                                           int col0, int rows_valid, int lane, double scale)
+__device__ __forceinline__ void tile_store(const real_t *__restrict__ lds, real_t *__restrict__ slab, long pitch,
+                                           int col0, int rows_valid, int lane, real_t scale)
 {
     const int cp = (lane % LPR) * 2;
 #pragma unroll
     for (int i = 0; i < TLD; i++) {
         const int row = (lane / LPR) + RPF * i;
         if (row < rows_valid) {
-            double2 v;
+            real2_t v;
             v.x = lds[cp * TP + row];
             v.y = lds[(cp + 1) * TP + row];
-            double2 *dst = reinterpret_cast<double2 *>(slab + (long)row * pitch + col0 + cp);
+            real2_t *dst = reinterpret_cast<real2_t *>(slab + (long)row * pitch + col0 + cp);
             if (ACC) {
-                const double2 o = *dst;
+                const real2_t o = *dst;
                 v.x = o.x + scale * v.x;
                 v.y = o.y + scale * v.y;
             }
@@ -96,32 +96,32 @@ __device__ __forceinline__ void tile_store(const double *__restrict__ lds, doubl
 
 // ---------------------------------------------------------------- tds, forward
 // d (wave-transposed scratch): d[(wave*n + (j-1))*64 + lane]
-__global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double *__restrict__ send_s,
-                                                 double *__restrict__ send_e, const double *__restrict__ u,
+__global__ void __launch_bounds__(64) k_xtds_fwd(real_t *__restrict__ d, real_t *__restrict__ send_s,
+                                                 real_t *__restrict__ send_e, const real_t *__restrict__ u,
                                                  TdsTab t, int np, long pitch, int n_wrap)
 {
-    __shared__ double lds[TILE];
+    __shared__ real_t lds[TILE];
     const int lane = threadIdx.x, wave = blockIdx.x;
     const int p = wave * 64 + lane;
     int rows_valid = np - wave * 64;
     rows_valid = rows_valid > 64 ? 64 : rows_valid;
-    const double *__restrict__ slab = u + (long)wave * 64 * pitch;
+    const real_t *__restrict__ slab = u + (long)wave * 64 * pitch;
     const int n = t.n_tds, nr = t.n_rhs;
     const int my = lane < rows_valid ? lane : rows_valid - 1;
-    const double *__restrict__ mine = slab + (long)my * pitch;
+    const real_t *__restrict__ mine = slab + (long)my * pitch;
     // periodic images (sendrecv_fields nproc==1): u_s(r) = u(n_wrap-4+r), u_e(r) = u(r)
-    double w[9];
+    real_t w[9];
 #pragma unroll
     for (int m = 0; m < 5; m++) w[m] = 0.0;
 #pragma unroll
     for (int m = 0; m < 4; m++) w[5 + m] = mine[n_wrap - 4 + m];
-    double he[4];
+    real_t he[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) he[m] = mine[m];
-    double dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
-    double *__restrict__ dw = d + (long)wave * n * 64 + lane;
+    real_t dprev = 0.0, S = 0.0, d1 = 0.0, dn = 0.0;
+    real_t *__restrict__ dw = d + (long)wave * n * 64 + lane;
 
-    double cb[9];
+    real_t cb[9];
 #pragma unroll
     for (int m = 0; m < 9; m++) cb[m] = t.Cs[72 + m];
     const int ntile = (nr + TW - 1) / TW;
@@ -136,14 +136,14 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
         for (int c = 0; c < TW; c++) {
             const int e = tI * TW + c + 1;  // element fed into the window
             if (e > nr + 4) break;
-            const double ve = e <= nr ? lds[c * TP + lane] : he[e - nr - 1];
+            const real_t ve = e <= nr ? lds[c * TP + lane] : he[e - nr - 1];
 #pragma unroll
             for (int m = 0; m < 8; m++) w[m] = w[m + 1];
             w[8] = ve;
             const int j = e - 4;
             if (j >= 1 && j <= nr) {
-                const double acc = (j > 4 && j <= nr - 4) ? dot9x(cb, w) : dot9x(stencil_row_x(t.Cs, j, nr), w);
-                const double dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
+                const real_t acc = (j > 4 && j <= nr - 4) ? dot9x(cb, w) : dot9x(stencil_row_x(t.Cs, j, nr), w);
+                const real_t dj = T_F(t, j) * (acc - T_A(t, j) * dprev);
                 if (j <= n) {
                     dw[(long)(j - 1) * 64] = dj;
                     S += T_W(t, j) * dj;
@@ -162,27 +162,27 @@ __global__ void __launch_bounds__(64) k_xtds_fwd(double *__restrict__ d, double 
 
 // ---------------------------------------------------------------- tds, backward + subs
 template <bool ACC>
-__global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const double *__restrict__ d,
-                                                 const double *__restrict__ own_s,
-                                                 const double *__restrict__ recv_s,
-                                                 const double *__restrict__ recv_e, TdsTab t, int np, long pitch,
-                                                 double scale)
+__global__ void __launch_bounds__(64) k_xtds_bwd(real_t *__restrict__ du, const real_t *__restrict__ d,
+                                                 const real_t *__restrict__ own_s,
+                                                 const real_t *__restrict__ recv_s,
+                                                 const real_t *__restrict__ recv_e, TdsTab t, int np, long pitch,
+                                                 real_t scale)
 {
-    __shared__ double lds[TILE];
+    __shared__ real_t lds[TILE];
     const int lane = threadIdx.x, wave = blockIdx.x;
     int rows_valid = np - wave * 64;
     rows_valid = rows_valid > 64 ? 64 : rows_valid;
     const int p = wave * 64 + (lane < rows_valid ? lane : rows_valid - 1);
-    double *__restrict__ slab = du + (long)wave * 64 * pitch;
+    real_t *__restrict__ slab = du + (long)wave * 64 * pitch;
     const int n = t.n_tds;
-    const double *__restrict__ dw = d + (long)wave * n * 64 + lane;
-    const double dn = dw[(long)(n - 1) * 64];
-    const double du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);
-    const double du_e = t.rs_e * (dn - t.scn * recv_e[p]);
-    double nxt = 0.0;
+    const real_t *__restrict__ dw = d + (long)wave * n * 64 + lane;
+    const real_t dn = dw[(long)(n - 1) * 64];
+    const real_t du_s = t.rs_s * (own_s[p] - t.sa1 * recv_s[p]);
+    const real_t du_e = t.rs_e * (dn - t.scn * recv_e[p]);
+    real_t nxt = 0.0;
     const int ntile = (n + TW - 1) / TW;
     for (int tI = ntile - 1; tI >= 0; tI--) {
-        double dv[TW];
+        real_t dv[TW];
 #pragma unroll
         for (int c = 0; c < TW; c++) {  // unconditional, clamped: lets the loads issue back to back
             int j = tI * TW + c + 1;
@@ -193,9 +193,9 @@ __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const 
 #pragma unroll
         for (int c = TW - 1; c >= 0; c--) {
             const int j = tI * TW + c + 1;
-            double out = 0.0;
+            real_t out = 0.0;
             if (j <= n) {
-                const double cur = (j >= n - 1) ? dv[c] : dv[c] - T_BW(t, j) * nxt;
+                const real_t cur = (j >= n - 1) ? dv[c] : dv[c] - T_BW(t, j) * nxt;
                 out = (cur - T_SA(t, j) * du_s - T_SC(t, j) * du_e) * T_ST(t, j);
                 out = (j == n) ? du_e * T_ST(t, j) : out;
                 out = (j == 1) ? du_s * T_ST(t, j) : out;
@@ -211,35 +211,35 @@ __global__ void __launch_bounds__(64) k_xtds_bwd(double *__restrict__ du, const 
 // ---------------------------------------------------------------- transeq, forward
 template <bool SAME>
 __global__ void __launch_bounds__(64)
-    k_xtranseq_fwd(double *__restrict__ d1a, double *__restrict__ d2a, double *__restrict__ d3a,
-                   double *__restrict__ send_s, double *__restrict__ send_e, const double *__restrict__ u,
-                   const double *__restrict__ cv, TdsTab t1, TdsTab t2, TdsTab t3, int np, long pitch,
+    k_xtranseq_fwd(real_t *__restrict__ d1a, real_t *__restrict__ d2a, real_t *__restrict__ d3a,
+                   real_t *__restrict__ send_s, real_t *__restrict__ send_e, const real_t *__restrict__ u,
+                   const real_t *__restrict__ cv, TdsTab t1, TdsTab t2, TdsTab t3, int np, long pitch,
                    int npmax)
 {
-    __shared__ double lu[TILE], lc[SAME ? 1 : TILE];
+    __shared__ real_t lu[TILE], lc[SAME ? 1 : TILE];
     const int lane = threadIdx.x, wave = blockIdx.x;
     const int p = wave * 64 + lane;
     int rows_valid = np - wave * 64;
     rows_valid = rows_valid > 64 ? 64 : rows_valid;
-    const double *__restrict__ su = u + (long)wave * 64 * pitch;
-    const double *__restrict__ sc = cv + (long)wave * 64 * pitch;
+    const real_t *__restrict__ su = u + (long)wave * 64 * pitch;
+    const real_t *__restrict__ sc = cv + (long)wave * 64 * pitch;
     const int n = t1.n_tds;
     const int my = lane < rows_valid ? lane : rows_valid - 1;
-    double wu[9], wp[9], heu[4], hep[4];
+    real_t wu[9], wp[9], heu[4], hep[4];
 #pragma unroll
     for (int m = 0; m < 5; m++) { wu[m] = 0.0; wp[m] = 0.0; }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const double a = su[(long)my * pitch + n - 4 + m];
-        const double c = SAME ? a : sc[(long)my * pitch + n - 4 + m];
+        const real_t a = su[(long)my * pitch + n - 4 + m];
+        const real_t c = SAME ? a : sc[(long)my * pitch + n - 4 + m];
         wu[5 + m] = a; wp[5 + m] = a * c;
-        const double a2 = su[(long)my * pitch + m];
-        const double c2 = SAME ? a2 : sc[(long)my * pitch + m];
+        const real_t a2 = su[(long)my * pitch + m];
+        const real_t c2 = SAME ? a2 : sc[(long)my * pitch + m];
         heu[m] = a2; hep[m] = a2 * c2;
     }
-    double p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
+    real_t p1 = 0, p2 = 0, p3 = 0, S1 = 0, S2 = 0, S3 = 0, f1 = 0, f2 = 0, f3 = 0, l1 = 0, l2 = 0, l3 = 0;
     const long wo = (long)wave * n * 64 + lane;
-    double b1[9], b2[9], b3[9];
+    real_t b1[9], b2[9], b3[9];
 #pragma unroll
     for (int m = 0; m < 9; m++) { b1[m] = t1.Cs[72 + m]; b2[m] = t2.Cs[72 + m]; b3[m] = t3.Cs[72 + m]; }
     const int ntile = (n + TW - 1) / TW;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64)
         for (int c = 0; c < TW; c++) {
             const int e = tI * TW + c + 1;
             if (e > n + 4) break;
-            double ve, vp;
+            real_t ve, vp;
             if (e <= n) {
                 ve = lu[c * TP + lane];
                 vp = ve * (SAME ? ve : lc[c * TP + lane]);
@@ -275,12 +275,12 @@ __global__ void __launch_bounds__(64)
             const int j = e - 4;
             if (j >= 1) {
                 const bool bulk = j > 4 && j <= n - 4;
-                const double a1 = bulk ? dot9x(b1, wu) : dot9x(stencil_row_x(t1.Cs, j, n), wu);
-                const double a3 = bulk ? dot9x(b3, wu) : dot9x(stencil_row_x(t3.Cs, j, n), wu);
-                const double a2 = bulk ? dot9x(b2, wp) : dot9x(stencil_row_x(t2.Cs, j, n), wp);
-                const double e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
-                const double e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
-                const double e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
+                const real_t a1 = bulk ? dot9x(b1, wu) : dot9x(stencil_row_x(t1.Cs, j, n), wu);
+                const real_t a3 = bulk ? dot9x(b3, wu) : dot9x(stencil_row_x(t3.Cs, j, n), wu);
+                const real_t a2 = bulk ? dot9x(b2, wp) : dot9x(stencil_row_x(t2.Cs, j, n), wp);
+                const real_t e1 = T_F(t1, j) * (a1 - T_A(t1, j) * p1);
+                const real_t e2 = T_F(t2, j) * (a2 - T_A(t2, j) * p2);
+                const real_t e3 = T_F(t3, j) * (a3 - T_A(t3, j) * p3);
                 const long o = wo + (long)(j - 1) * 64;
                 d1a[o] = e1; d2a[o] = e2; d3a[o] = e3;
                 S1 += T_W(t1, j) * e1; S2 += T_W(t2, j) * e2; S3 += T_W(t3, j) * e3;
@@ -301,29 +301,29 @@ __global__ void __launch_bounds__(64)
 // ---------------------------------------------------------------- transeq, backward + fused subs
 template <bool ACC>
 __global__ void __launch_bounds__(64)
-    k_xtranseq_bwd(double *__restrict__ rhs, const double *__restrict__ d1a, const double *__restrict__ d2a,
-                   const double *__restrict__ d3a, const double *__restrict__ cv,
-                   const double *__restrict__ own_s, const double *__restrict__ recv_s,
-                   const double *__restrict__ recv_e, double nu, TdsTab t1, TdsTab t2, TdsTab t3, int np,
+    k_xtranseq_bwd(real_t *__restrict__ rhs, const real_t *__restrict__ d1a, const real_t *__restrict__ d2a,
+                   const real_t *__restrict__ d3a, const real_t *__restrict__ cv,
+                   const real_t *__restrict__ own_s, const real_t *__restrict__ recv_s,
+                   const real_t *__restrict__ recv_e, real_t nu, TdsTab t1, TdsTab t2, TdsTab t3, int np,
                    long pitch, int npmax)
 {
-    __shared__ double lo[TILE], lc[TILE];
+    __shared__ real_t lo[TILE], lc[TILE];
     const int lane = threadIdx.x, wave = blockIdx.x;
     int rows_valid = np - wave * 64;
     rows_valid = rows_valid > 64 ? 64 : rows_valid;
     const int p = wave * 64 + (lane < rows_valid ? lane : rows_valid - 1);
-    double *__restrict__ so = rhs + (long)wave * 64 * pitch;
-    const double *__restrict__ sc = cv + (long)wave * 64 * pitch;
+    real_t *__restrict__ so = rhs + (long)wave * 64 * pitch;
+    const real_t *__restrict__ sc = cv + (long)wave * 64 * pitch;
     const int n = t1.n_tds;
     const long wo = (long)wave * n * 64 + lane;
     const long on = wo + (long)(n - 1) * 64;
-    const double du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
-    const double dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
-    const double d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
-    double n1 = d1a[on], n2 = d2a[on], n3 = d3a[on];
-    const double du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
-    const double dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
-    const double d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
+    const real_t du_s = t1.rs_s * (own_s[p] - t1.sa1 * recv_s[p]);
+    const real_t dud_s = t2.rs_s * (own_s[npmax + p] - t2.sa1 * recv_s[npmax + p]);
+    const real_t d2u_s = t3.rs_s * (own_s[2 * npmax + p] - t3.sa1 * recv_s[2 * npmax + p]);
+    real_t n1 = d1a[on], n2 = d2a[on], n3 = d3a[on];
+    const real_t du_e = t1.rs_e * (n1 - t1.scn * recv_e[p]);
+    const real_t dud_e = t2.rs_e * (n2 - t2.scn * recv_e[npmax + p]);
+    const real_t d2u_e = t3.rs_e * (n3 - t3.scn * recv_e[2 * npmax + p]);
     const int ntile = (n + TW - 1) / TW;
     TileRegs rc;
     tile_load(rc, sc, pitch, (ntile - 1) * TW, rows_valid, lane);
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int h = 1; h >= 0; h--) {  // two half-tiles: their d loads are issued as one batch
             constexpr int HB_ = TW / 2;
-            double a1[HB_], a2[HB_], a3[HB_];
+            real_t a1[HB_], a2[HB_], a3[HB_];
 #pragma unroll
             for (int k = 0; k < HB_; k++) {
                 int j = tI * TW + h * HB_ + k + 1;
@@ -347,16 +347,16 @@ __global__ void __launch_bounds__(64)
             for (int k = HB_ - 1; k >= 0; k--) {
                 const int c = h * HB_ + k;
                 const int j = tI * TW + c + 1;
-                double out = 0.0;
+                real_t out = 0.0;
                 if (j <= n) {
-                    const double v = lc[c * TP + lane];
+                    const real_t v = lc[c * TP + lane];
                     const bool keep = j >= n - 1;  // rows n, n-1: forward values (distributed.f90:154)
-                    const double c1 = keep ? a1[k] : a1[k] - T_BW(t1, j) * n1;
-                    const double c2 = keep ? a2[k] : a2[k] - T_BW(t2, j) * n2;
-                    const double c3 = keep ? a3[k] : a3[k] - T_BW(t3, j) * n3;
-                    const double temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
-                    const double temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
-                    const double temp_d2u =
+                    const real_t c1 = keep ? a1[k] : a1[k] - T_BW(t1, j) * n1;
+                    const real_t c2 = keep ? a2[k] : a2[k] - T_BW(t2, j) * n2;
+                    const real_t c3 = keep ? a3[k] : a3[k] - T_BW(t3, j) * n3;
+                    const real_t temp_du = T_ST(t1, j) * (c1 - T_SA(t1, j) * du_s - T_SC(t1, j) * du_e);
+                    const real_t temp_dud = T_ST(t2, j) * (c2 - T_SA(t2, j) * dud_s - T_SC(t2, j) * dud_e);
+                    const real_t temp_d2u =
                         T_ST(t3, j) * (c3 - T_SA(t3, j) * d2u_s - T_SC(t3, j) * d2u_e) + temp_du * T_STC(t3, j);
                     out = -0.5 * (v * temp_du + temp_dud) + nu * temp_d2u;
                     if (j == n)
@@ -386,9 +386,9 @@ static bool xdir_tiled()
     return mode == 1;
 }
 
-int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done);
-int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done);  // xwide.hip
-int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xscan_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done);
+int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done);  // xwide.hip
+int x3d_xscan_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 static bool use_xscan()
 {
@@ -400,7 +400,7 @@ static bool use_xscan()
     return mode == 1;
 }
 
-int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale)
+int x3d_xdir_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale)
 {
     if (use_xscan() && xdir_tiled()) {
         bool done = false;
@@ -429,7 +429,7 @@ int x3d_xdir_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *
     return 0;
 }
 
-int x3d_xdir_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xdir_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                      const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc)
 {
     if (use_xscan() && xdir_tiled()) {

@@ -57,19 +57,19 @@ int npmax_of(const x3d_backend *b);
 // DPP by the register index, rotate left by j again, read out reversed.
 // out row = orow[0 .. 64*8): lane l holds r[0..8) = rows 8l .. 8l+7
 template <bool ACC>
-__device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lane, const double (&r)[8],
-                                              double scale)
+__device__ __forceinline__ void store_rows_q8(real_t *__restrict__ orow, int lane, const real_t (&r)[8],
+                                              real_t scale)
 {
     const int j = lane & 3;
-    double a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3], c0 = r[4], c1 = r[5], d0 = r[6], d1 = r[7];
+    real_t a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3], c0 = r[4], c1 = r[5], d0 = r[6], d1 = r[7];
     rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
     b0 = dpp_quad(b0, 1); b1 = dpp_quad(b1, 1);
     c0 = dpp_quad(c0, 2); c1 = dpp_quad(c1, 2);
     d0 = dpp_quad(d0, 3); d1 = dpp_quad(d1, 3);
     rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
-    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + (lane & ~3) * 8) + j;
+    real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow + (lane & ~3) * 8) + j;
     // instruction m stores T[m] = D[(-m) & 3]: D[0] = a, D[3] = d, D[2] = c, D[1] = b
-    double2 v0, v1, v2, v3;
+    real2_t v0, v1, v2, v3;
     if (ACC) {
         v0 = o2[0]; v1 = o2[4]; v2 = o2[8]; v3 = o2[12];
         v0.x += scale * a0; v0.y += scale * a1;
@@ -89,25 +89,25 @@ __device__ __forceinline__ void store_rows_q8(double *__restrict__ orow, int lan
 
 // Q = 4: a lane owns 32 B, a pair of lanes one 64-byte sector: 2 x 2 transpose of the 16-byte pairs
 template <bool ACC>
-__device__ __forceinline__ void store_rows_q4(double *__restrict__ orow, int lane, const double (&r)[4],
-                                              double scale)
+__device__ __forceinline__ void store_rows_q4(real_t *__restrict__ orow, int lane, const real_t (&r)[4],
+                                              real_t scale)
 {
     const bool odd = lane & 1;
-    const double s0 = odd ? r[0] : r[2], s1 = odd ? r[1] : r[3];  // what the partner needs
+    const real_t s0 = odd ? r[0] : r[2], s1 = odd ? r[1] : r[3];  // what the partner needs
     int lo, hi;
     lo = __double2loint(s0); hi = __double2hiint(s0);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false);
-    const double g0 = __hiloint2double(hi, lo);
+    const real_t g0 = __hiloint2double(hi, lo);
     lo = __double2loint(s1); hi = __double2hiint(s1);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false);
-    const double g1 = __hiloint2double(hi, lo);
+    const real_t g1 = __hiloint2double(hi, lo);
     // instruction m writes bytes [32 m + 16 p, +16) of the pair's sector: pair p of lane m of the pair
-    const double a0 = odd ? g0 : r[0], a1 = odd ? g1 : r[1];  // m = 0: P_0[p]
-    const double b0 = odd ? r[2] : g0, b1 = odd ? r[3] : g1;  // m = 1: P_1[p]
-    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + (lane & ~1) * 4) + (lane & 1);
-    double2 v0, v1;
+    const real_t a0 = odd ? g0 : r[0], a1 = odd ? g1 : r[1];  // m = 0: P_0[p]
+    const real_t b0 = odd ? r[2] : g0, b1 = odd ? r[3] : g1;  // m = 1: P_1[p]
+    real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow + (lane & ~1) * 4) + (lane & 1);
+    real2_t v0, v1;
     if (ACC) {
         v0 = o2[0]; v1 = o2[2];
         v0.x += scale * a0; v0.y += scale * a1; v1.x += scale * b0; v1.y += scale * b1;
@@ -118,14 +118,14 @@ __device__ __forceinline__ void store_rows_q4(double *__restrict__ orow, int lan
 }
 
 template <int Q>
-__device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__restrict__ row, int first, int nr,
+__device__ __forceinline__ void load_window(real_t (&w)[Q + 8], const real_t *__restrict__ row, int first, int nr,
                                             int n_wrap, bool interior)
 {
     if (interior) {  // rows first-4 .. first+Q+3 all inside [1, nr]: 16-byte aligned vector loads
-        const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(row + first - 5);
+        const real2_t *__restrict__ v2 = reinterpret_cast<const real2_t *>(row + first - 5);
 #pragma unroll
         for (int m = 0; m < (Q + 8) / 2; m++) {
-            const double2 t2 = v2[m];
+            const real2_t t2 = v2[m];
             w[2 * m] = t2.x;
             w[2 * m + 1] = t2.y;
         }
@@ -137,12 +137,12 @@ __device__ __forceinline__ void load_window(double (&w)[Q + 8], const double *__
 
 // ---------------------------------------------------------------- tds_solve
 template <int Q, bool ACC, int FAST>  // FAST: 0 general, 1 branch-free periodic form, 2 the same with the 5-tap stencil
-__global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, const double *__restrict__ u, XOp t,
-                                                   int np, long pitch, int n_wrap, double scale)
+__global__ void __launch_bounds__(512) k_xscan_tds(real_t *__restrict__ du, const real_t *__restrict__ u, XOp t,
+                                                   int np, long pitch, int n_wrap, real_t scale)
 {
-    extern __shared__ double lt[];  // [LT_N(Q)][64], general form: + the stencil table [CS_N(Q)]
+    extern __shared__ real_t lt[];  // [LT_N(Q)][64], general form: + the stencil table [CS_N(Q)]
     for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
-    const double *cs = lt + LT_N(Q) * 64;
+    const real_t *cs = lt + LT_N(Q) * 64;
     if (!FAST) stage_cs<Q>(lt + LT_N(Q) * 64, t);
     __syncthreads();
     int lane = threadIdx.x & 63;
@@ -153,12 +153,12 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
     const bool interior = first - 4 >= 1 && first + Q + 3 <= nr;
     const bool exact = FAST || (nr == 64 * Q && n_wrap == nr);
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
-    double nb[Q];  // FAST: next pencil's rows, in flight while this one is solved
+    real_t nb[Q];  // FAST: next pencil's rows, in flight while this one is solved
     if (FAST && p0 < np) load_body<Q>(nb, u + (long)p0 * pitch, lane);
     for (int p = p0; p < np; p += nwaves) {
-        const double *__restrict__ row = u + (long)p * pitch;
+        const real_t *__restrict__ row = u + (long)p * pitch;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop (no 150-VGPR hoist)
-        double w[Q + 8], X[Q], du1, xn;
+        real_t w[Q + 8], X[Q], du1, xn;
         if (FAST) {
             window_from_body<Q>(w, nb, lane);
 #if XSCAN_EXP == 2
@@ -169,14 +169,14 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
         } else if (exact) load_window_exact<Q>(w, row, lane, nr);
         else load_window<Q>(w, row, first, nr, n_wrap, interior);
         scan_solve<Q, (FAST != 0), (FAST == 2)>(w, X, du1, xn, lt, t, lane, first, 0, cs);
-        const double du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
-        const double du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
-        double *__restrict__ orow = du + (long)p * pitch;
-        double r[Q];
+        const real_t du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
+        const real_t du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
+        real_t *__restrict__ orow = du + (long)p * pitch;
+        real_t r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = first + q;
-            const double st = LTR(lt, LT_ST(q));
+            const real_t st = LTR(lt, LT_ST(q));
             r[q] = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
             if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
                 if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
@@ -193,10 +193,10 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, scale);
             else store_rows_q4<ACC>(orow, lane, r, scale);
         } else if (exact && n == nr) {
-            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
+            real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) {
-                double2 v2;
+                real2_t v2;
                 if (ACC) { v2 = o2[m]; v2.x += scale * r[2 * m]; v2.y += scale * r[2 * m + 1]; }
                 else { v2.x = r[2 * m]; v2.y = r[2 * m + 1]; }
                 o2[m] = v2;
@@ -220,9 +220,9 @@ __global__ void __launch_bounds__(512) k_xscan_tds(double *__restrict__ du, cons
 // (field_set_face_from_field(Y_FACE) between the stage and the divergence: the channel case's apply_BC,
 // src/case/channel.f90:214-231)
 template <int Q, bool NARROW>
-__global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
+__global__ void __launch_bounds__(512) k_xscan_tds_lin(real_t *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
 {
-    extern __shared__ double lt[];  // [LT_N(Q)][64]
+    extern __shared__ real_t lt[];  // [LT_N(Q)][64]
     for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
     __syncthreads();
     int lane = threadIdx.x & 63;
@@ -232,12 +232,12 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, 
     for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
         const long ro = (long)p * pitch;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
-        double b[Q];
+        real_t b[Q];
         load_body<Q>(b, lr.base + ro, lane);
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (k < lr.n) {
-                double xk[Q];
+                real_t xk[Q];
                 load_body<Q>(xk, lr.x[k] + ro, lane);
 #pragma unroll
                 for (int q = 0; q < Q; q++) b[q] = lr.c[k] * xk[q] + b[q];
@@ -248,14 +248,14 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, 
         }
         if constexpr (Q == 8) store_rows_q8<false>(lr.y + ro, lane, b, 1.0);
         else store_rows_q4<false>(lr.y + ro, lane, b, 1.0);
-        double w[Q + 8], X[Q], du1, xn;
+        real_t w[Q + 8], X[Q], du1, xn;
         window_from_body<Q>(w, b, lane);
         scan_solve<Q, true, NARROW>(w, X, du1, xn, lt, t, lane, first);
-        const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
-        double r[Q];
+        const real_t du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+        real_t r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const double st = LTR(lt, LT_ST(q));
+            const real_t st = LTR(lt, LT_ST(q));
             r[q] = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
             if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
             if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
@@ -268,17 +268,17 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(double *__restrict__ du, 
 // ---------------------------------------------------------------- transeq component
 template <int Q, bool SAME, bool ACC, int FAST>
 __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
-    k_xscan_transeq(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
-                    XOp t2, XOp t3, int np, long pitch, double nu)
+    k_xscan_transeq(real_t *__restrict__ rhs, const real_t *__restrict__ u, const real_t *__restrict__ cv, XOp t1,
+                    XOp t2, XOp t3, int np, long pitch, real_t nu)
 {
-    extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64], general form: + their stencil tables [3][CS_N(Q)]
+    extern __shared__ real_t lt[];  // three operators: [3][LT_N(Q)][64], general form: + their stencil tables [3][CS_N(Q)]
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = t1.TL[i];
         lt[LN + i] = t2.TL[i];
         lt[2 * LN + i] = t3.TL[i];
     }
-    const double *cs0 = lt + 3 * LN;
+    const real_t *cs0 = lt + 3 * LN;
     if (!FAST) {
         stage_cs<Q>(lt + 3 * LN, t1);
         stage_cs<Q>(lt + 3 * LN + CS_N(Q), t2);
@@ -291,9 +291,9 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     const int n = t1.n_tds;
     const int first = lane * Q + 1;
     const bool interior = first - 4 >= 1 && first + Q + 3 <= n;
-    const double *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
-    double nbu[Q], nbc[Q];  // FAST: next pencil's rows of u and conv, in flight during the solve
+    real_t nbu[Q], nbc[Q];  // FAST: next pencil's rows of u and conv, in flight during the solve
 #ifndef XS_NOPREF
     if (FAST && p0 < np) {
         load_body<Q>(nbu, u + (long)p0 * pitch, lane);
@@ -301,10 +301,10 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
     }
 #endif
     for (int p = p0; p < np; p += nwaves) {
-        const double *__restrict__ ru = u + (long)p * pitch;
-        const double *__restrict__ rc = cv + (long)p * pitch;
+        const real_t *__restrict__ ru = u + (long)p * pitch;
+        const real_t *__restrict__ rc = cv + (long)p * pitch;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
-        double wu[Q + 8], wp[Q + 8], vq[Q];
+        real_t wu[Q + 8], wp[Q + 8], vq[Q];
         const bool exact = FAST || n == 64 * Q;
         if (FAST) {
 #ifdef XS_NOPREF
@@ -347,15 +347,15 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
         }
         // one operator at a time, substituted at once (distributed.f90:304-335 written per operator:
         // rows 1 and n take du_s*st / du_e*st, which is what the general formula gives with these temps)
-        auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
-            double a, b;
+        auto solve_subs = [&](const real_t (&w)[Q + 8], real_t (&T)[Q], const real_t *__restrict__ l, const XOp &t) {
+            real_t a, b;
             scan_solve<Q, (FAST != 0), (FAST == 2)>(w, T, a, b, l, t, lane, first, 0, cs0 + (l - lt) / LN * CS_N(Q));
-            const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+            const real_t s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = first + q;
-                const double st = LTR(l, LT_ST(q));
-                double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
+                const real_t st = LTR(l, LT_ST(q));
+                real_t x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (FAST) {  // n = 64 Q: row 1 is (lane 0, q = 0), row n is (lane 63, q = Q - 1)
                     if (q == 0) x = (lane == 0) ? s_ * st : x;
                     if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
                 T[q] = x;
             }
         };
-        double r[Q], T[Q];
+        real_t r[Q], T[Q];
         solve_subs(wp, T, l2, t2);  // d(u*conv)/dx first: wp is dead afterwards
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] = T[q];
@@ -378,15 +378,15 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
         solve_subs(wu, T, l3, t3);  // d2u/dx2
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] += nu * T[q];
-        double *__restrict__ orow = rhs + (long)p * pitch;
+        real_t *__restrict__ orow = rhs + (long)p * pitch;
         if constexpr (FAST != 0) {
             if constexpr (Q == 8) store_rows_q8<ACC>(orow, lane, r, 1.0);
             else store_rows_q4<ACC>(orow, lane, r, 1.0);
         } else if (exact) {
-            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow + lane * Q);
+            real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow + lane * Q);
 #pragma unroll
             for (int m = 0; m < Q / 2; m++) {
-                double2 v2;
+                real2_t v2;
                 if (ACC) { v2 = o2[m]; v2.x += r[2 * m]; v2.y += r[2 * m + 1]; }
                 else { v2.x = r[2 * m]; v2.y = r[2 * m + 1]; }
                 o2[m] = v2;
@@ -406,10 +406,10 @@ __global__ void __launch_bounds__(FAST ? XS_TQ_THREADS : 512)
 // in flight per CU as k_xscan_transeq, half the LDS table traffic.
 template <int Q, bool SAME, bool ACC, bool NARROW>
 __global__ void __launch_bounds__(512)
-    k_xscan_transeq2(double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1,
-                     XOp t2, XOp t3, int np, long pitch, double nu)
+    k_xscan_transeq2(real_t *__restrict__ rhs, const real_t *__restrict__ u, const real_t *__restrict__ cv, XOp t1,
+                     XOp t2, XOp t3, int np, long pitch, real_t nu)
 {
-    extern __shared__ double lt[];  // three operators: [3][LT_N(Q)][64]
+    extern __shared__ real_t lt[];  // three operators: [3][LT_N(Q)][64]
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = t1.TL[i];
@@ -421,9 +421,9 @@ __global__ void __launch_bounds__(512)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int first = lane * Q + 1;
-    const double *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l2 = lt + LN, *__restrict__ l3 = lt + 2 * LN;
     // next pair's rows of u and conv, in flight during the solve (256-VGPR budget: 8 waves per CU)
-    double nua[Q], nub[Q], nca[Q], ncb[Q];
+    real_t nua[Q], nub[Q], nca[Q], ncb[Q];
     const int pstart = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
     if (pstart < np) {
         load_body<Q>(nua, u + (long)pstart * pitch, lane);
@@ -460,13 +460,13 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) wp[m] = SAME ? wu[m] * wu[m] : wu[m] * wp[m];
         }
-        auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const double *__restrict__ l, const XOp &t) {
+        auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const real_t *__restrict__ l, const XOp &t) {
             V2 a, b;
             scan_solve<Q, true, NARROW, V2>(w, T, a, b, l, t, lane, first);
             const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double st = LTR(l, LT_ST(q));
+                const real_t st = LTR(l, LT_ST(q));
                 V2 x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (q == 0) x = (lane == 0) ? s_ * st : x;
                 if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
@@ -483,14 +483,14 @@ __global__ void __launch_bounds__(512)
         for (int q = 0; q < Q; q++) r[q] = -0.5 * (vq[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
         asm volatile("" : "+v"(lane) : "v"(r[0].a));
         solve_subs(wu, T, l3, t3);
-        double ra[Q], rb[Q];
+        real_t ra[Q], rb[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const V2 v = r[q] + nu * T[q];
             ra[q] = v.a;
             rb[q] = v.b;
         }
-        double *__restrict__ oa = rhs + (long)p * pitch, *__restrict__ ob = oa + pitch;
+        real_t *__restrict__ oa = rhs + (long)p * pitch, *__restrict__ ob = oa + pitch;
         if constexpr (Q == 8) { store_rows_q8<ACC>(oa, lane, ra, 1.0); store_rows_q8<ACC>(ob, lane, rb, 1.0); }
         else { store_rows_q4<ACC>(oa, lane, ra, 1.0); store_rows_q4<ACC>(ob, lane, rb, 1.0); }
     }
@@ -506,21 +506,21 @@ __global__ void __launch_bounds__(512)
 // src/solver.f90:731-733): done here, per pencil, before the component is used -- u_c is written, not read back
 // (12 field passes instead of 9 + 6).  Four table sets, three of them without the STC block: 156 KB of LDS.
 struct XUpd {
-    const double *g[3];  // gradient inputs of u0, u1, u2
-    double scale;
+    const real_t *g[3];  // gradient inputs of u0, u1, u2
+    real_t scale;
     // the channel case's extras (xwide.hip, k_xwide_transeq3<ROT>, has the 1024-row form): rotation forcing
     // rhs0 -= omega u1, rhs1 += omega u0 on top of the result; u0 += *ushift in place first
-    double omega;
-    const double *ushift;
+    real_t omega;
+    const real_t *ushift;
 };
 
 template <int Q, bool ACC, bool NARROW, bool UPD, bool CHN = false>  // CHN: the channel case's extras (XUpd)
 __global__ void __launch_bounds__(512)
-    k_xscan_transeq2x3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2, double *u0,
-                       double *u1, double *u2, XOp tD1, XOp tD2, int np, long pitch, double nu, XUpd upd, XOp tS,
+    k_xscan_transeq2x3(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2, real_t *u0,
+                       real_t *u1, real_t *u2, XOp tD1, XOp tD2, int np, long pitch, real_t nu, XUpd upd, XOp tS,
                        XOp tI)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LNF = LT_N(Q) * 64, LNC = LT_NC(Q) * 64, L1N = UPD ? LNC : LNF;
     for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
     for (int i = threadIdx.x; i < LNF; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
@@ -535,8 +535,8 @@ __global__ void __launch_bounds__(512)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int first = lane * Q + 1;
-    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
-    double na[Q], nb[Q];  // the rows needed next (next component's field, or the next pair's u0)
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
+    real_t na[Q], nb[Q];  // the rows needed next (next component's field, or the next pair's u0)
     const int pstart = 2 * (blockIdx.x * (blockDim.x >> 6) + wave);
     if (pstart < np) {
         load_body<Q>(na, u0 + (long)pstart * pitch, lane);
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(512)
                 for (int q = 0; q < Q; q++) b2[q] = V2{na[q], nb[q]};
                 const int pn = p + 2 * nwaves;
                 {
-                    const double *nsrc = c == 0 ? u1 + (long)p * pitch : (c == 1 ? u2 + (long)p * pitch
+                    const real_t *nsrc = c == 0 ? u1 + (long)p * pitch : (c == 1 ? u2 + (long)p * pitch
                                                                                  : u0 + (long)(pn < np ? pn : p) * pitch);
                     if (c < 2 || pn < np) {
                         load_body<Q>(na, nsrc, lane);
@@ -563,37 +563,37 @@ __global__ void __launch_bounds__(512)
                 }
                 if constexpr (UPD) {
                     // u_c += scale * tds_solve(g_c), arithmetic of k_xscan_tds<ACC>: old + scale * r
-                    const double *gsrc = (c == 0 ? upd.g[0] : (c == 1 ? upd.g[1] : upd.g[2])) + (long)p * pitch;
-                    double ga[Q], gb[Q];
+                    const real_t *gsrc = (c == 0 ? upd.g[0] : (c == 1 ? upd.g[1] : upd.g[2])) + (long)p * pitch;
+                    real_t ga[Q], gb[Q];
                     load_body<Q>(ga, gsrc, lane);
                     load_body<Q>(gb, gsrc + pitch, lane);
                     V2 g2[Q], wg[Q + 8], X[Q], du1, xn;
 #pragma unroll
                     for (int q = 0; q < Q; q++) g2[q] = V2{ga[q], gb[q]};
                     window_from_body<Q, V2>(wg, g2, lane);
-                    const double *__restrict__ lg = lt + L1N + LNF + (c == 0 ? 0 : LNC);
+                    const real_t *__restrict__ lg = lt + L1N + LNF + (c == 0 ? 0 : LNC);
                     const XOp &tg = c == 0 ? tS : tI;
                     scan_solve<Q, true, NARROW, V2>(wg, X, du1, xn, lg, tg, lane, first);
                     const V2 du_s = tg.rs_s * (du1 - tg.sa1 * xn), du_e = tg.rs_e * (xn - tg.scn * du1);
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
-                        const double st = LTR(lg, LT_ST(q));
+                        const real_t st = LTR(lg, LT_ST(q));
                         V2 r = (X[q] - LTR(lg, LT_SA(q)) * du_s - LTR(lg, LT_SC(q)) * du_e) * st;
                         if (q == 0) r = (lane == 0) ? du_s * st : r;
                         if (q == Q - 1) r = (lane == 63) ? du_e * st : r;
                         b2[q] = b2[q] + upd.scale * r;
                     }
-                    double ua[Q], ub[Q];
+                    real_t ua[Q], ub[Q];
 #pragma unroll
                     for (int q = 0; q < Q; q++) { ua[q] = b2[q].a; ub[q] = b2[q].b; }
-                    double *uw = (c == 0 ? u0 : (c == 1 ? u1 : u2)) + (long)p * pitch;
+                    real_t *uw = (c == 0 ? u0 : (c == 1 ? u1 : u2)) + (long)p * pitch;
                     if constexpr (Q == 8) { store_rows_q8<false>(uw, lane, ua, 1.0); store_rows_q8<false>(uw + pitch, lane, ub, 1.0); }
                     else { store_rows_q4<false>(uw, lane, ua, 1.0); store_rows_q4<false>(uw + pitch, lane, ub, 1.0); }
                     asm volatile("" : "+v"(lane) : "v"(b2[0].a));
                 }
                 if (CHN && c == 0 && upd.ushift) {  // (wave-uniform; never together with UPD)
-                    const double ush = *upd.ushift;
-                    double ua[Q], ub[Q];
+                    const real_t ush = *upd.ushift;
+                    real_t ua[Q], ub[Q];
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
                         b2[q].a += ush;
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(512)
                         ua[q] = b2[q].a;
                         ub[q] = b2[q].b;
                     }
-                    double *uw = u0 + (long)p * pitch;
+                    real_t *uw = u0 + (long)p * pitch;
                     if constexpr (Q == 8) { store_rows_q8<false>(uw, lane, ua, 1.0); store_rows_q8<false>(uw + pitch, lane, ub, 1.0); }
                     else { store_rows_q4<false>(uw, lane, ua, 1.0); store_rows_q4<false>(uw + pitch, lane, ub, 1.0); }
                 }
@@ -614,13 +614,13 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
             }
-            auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const double *__restrict__ l, const XOp &t) {
+            auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const real_t *__restrict__ l, const XOp &t) {
                 V2 a, b;
                 scan_solve<Q, true, NARROW, V2>(w, T, a, b, l, t, lane, first);
                 const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const double st = LTR(l, LT_ST(q));
+                    const real_t st = LTR(l, LT_ST(q));
                     V2 x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                     if (q == 0) x = (lane == 0) ? s_ * st : x;
                     if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(512)
             for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
             asm volatile("" : "+v"(lane) : "v"(r[0].a));
             solve_subs(wu, T, l3, tD2);
-            double ra[Q], rb[Q];
+            real_t ra[Q], rb[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const V2 v = r[q] + nu * T[q];
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(512)
                     for (int q = 0; q < Q; q++) { ra[q] = upd.omega * cb[q].a + 1.0 * ra[q]; rb[q] = upd.omega * cb[q].b + 1.0 * rb[q]; }
                 }
             }
-            double *oa = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + (long)p * pitch, *ob = oa + pitch;
+            real_t *oa = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + (long)p * pitch, *ob = oa + pitch;
             if constexpr (Q == 8) { store_rows_q8<ACC>(oa, lane, ra, 1.0); store_rows_q8<ACC>(ob, lane, rb, 1.0); }
             else { store_rows_q4<ACC>(oa, lane, ra, 1.0); store_rows_q4<ACC>(ob, lane, rb, 1.0); }
         }
@@ -675,65 +675,65 @@ __global__ void __launch_bounds__(512)
 // in the summation order of k_lincomb (backend.hip): bit-identical to the accumulating form followed by
 // x3d_lincomb, without re-reading d (and without writing it after the last stage).
 struct TileEpi {
-    double *y;
-    const double *base;
-    const double *x[5];
-    double c[5];
+    real_t *y;
+    const real_t *base;
+    const real_t *x[5];
+    real_t c[5];
     int n, ipend, store;
 };
 
 template <int Q, bool SAME, bool ACC, int FAST, bool EPI = false>
 __global__ void __launch_bounds__(1024)
-    k_ytile_transeq(double *rhs, const double *__restrict__ u, const double *__restrict__ cv, XOp t1, XOp t2, XOp t3,
-                    int share12, int ntx, int ntiles, long prow, long pplane, double nu, const TileEpi *epp)
+    k_ytile_transeq(real_t *rhs, const real_t *__restrict__ u, const real_t *__restrict__ cv, XOp t1, XOp t2, XOp t3,
+                    int share12, int ntx, int ntiles, long prow, long pplane, real_t nu, const TileEpi *epp)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = t1.TL[i];
         if (!share12) lt[LN + i] = t2.TL[i];
         lt[(share12 ? 1 : 2) * LN + i] = t3.TL[i];
     }
-    const double *__restrict__ l1 = lt, *__restrict__ l2 = share12 ? lt : lt + LN,
+    const real_t *__restrict__ l1 = lt, *__restrict__ l2 = share12 ? lt : lt + LN,
                  *__restrict__ l3 = lt + (share12 ? 1 : 2) * LN;
-    double *tile = lt + (share12 ? 2 : 3) * LN;
+    real_t *tile = lt + (share12 ? 2 : 3) * LN;
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
-    // cooperative mapping: item i of thread t is the double2 (row y, columns 2c, 2c + 1)
+    // cooperative mapping: item i of thread t is the real2_t (row y, columns 2c, 2c + 1)
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
-    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
+    auto gload = [&](real2_t (&v)[NI], const real_t *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const real2_t *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
     };
-    auto to_tile = [&](const double2 (&v)[NI]) {
+    auto to_tile = [&](const real2_t (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
             tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
         }
     };
-    auto pick = [&](double (&b)[Q]) {
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+    auto pick = [&](real_t (&b)[Q]) {
+        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
         for (int m = 0; m < Q / 2; m++) {
-            const double2 t2_ = src[m];
+            const real2_t t2_ = src[m];
             b[2 * m] = t2_.x;
             b[2 * m + 1] = t2_.y;
         }
     };
     __syncthreads();
 #ifdef YT_PREF
-    double2 nxt[NI];  // next tile's u rows, in flight during the solve
+    real2_t nxt[NI];  // next tile's u rows, in flight during the solve
     if ((int)blockIdx.x < ntiles) gload(nxt, u + (long)(blockIdx.x / ntx) * pplane + (long)(blockIdx.x % ntx) * 16);
 #endif
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
-        double wu[Q + 8], wp[Q + 8], vq[Q];
+        real_t wu[Q + 8], wp[Q + 8], vq[Q];
         {
-            double b[Q];
-            double2 gu[NI], gc[NI];
+            real_t b[Q];
+            real2_t gu[NI], gc[NI];
 #ifdef YT_PREF
 #pragma unroll
             for (int i = 0; i < NI; i++) gu[i] = nxt[i];
@@ -764,20 +764,20 @@ __global__ void __launch_bounds__(1024)
             if (tn < ntiles) gload(nxt, u + (long)(tn / ntx) * pplane + (long)(tn % ntx) * 16);
         }
 #endif
-        auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t) {
-            double a, b;
+        auto solve_subs = [&](const real_t (&w)[Q + 8], real_t (&T)[Q], const real_t *__restrict__ l, const XOp &t) {
+            real_t a, b;
             scan_solve<Q, true, (FAST == 2)>(w, T, a, b, l, t, lane, first);
-            const double s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
+            const real_t s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const double st = LTR(l, LT_ST(q));
-                double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
+                const real_t st = LTR(l, LT_ST(q));
+                real_t x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                 if (q == 0) x = (lane == 0) ? s_ * st : x;
                 if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                 T[q] = x;
             }
         };
-        double r[Q], T[Q];
+        real_t r[Q], T[Q];
         solve_subs(wp, T, l2, t2);
 #pragma unroll
         for (int q = 0; q < Q; q++) r[q] = T[q];
@@ -788,18 +788,18 @@ __global__ void __launch_bounds__(1024)
         asm volatile("" : "+v"(lane) : "v"(r[0]));
         solve_subs(wu, T, l3, t3);
         if constexpr (!EPI) {
-            double *__restrict__ o = rhs + off;
-            double2 old[NI];
+            real_t *__restrict__ o = rhs + off;
+            real2_t old[NI];
             if (ACC) gload(old, o);  // in flight while the results go through the tile
-            double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+            real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
-            for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+            for (int m = 0; m < Q / 2; m++) dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < NI; i++) {
-                double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                real2_t v = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                 if (ACC) { v.x += old[i].x; v.y += old[i].y; }
-                *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+                *reinterpret_cast<real2_t *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
             }
         } else {
             // the first two terms other than the pending one travel with `old` and `base` (all an RK3 stage has);
@@ -810,38 +810,38 @@ __global__ void __launch_bounds__(1024)
             const TileEpi *pe = epp;
             asm volatile("" : "+s"(pe) : "v"(T[0]));
             const TileEpi epi = *pe;
-            double2 old[NI], bs[NI];
+            real2_t old[NI], bs[NI];
             // (the addresses are tied to the last solve: issued any earlier the loads stay live across the solves)
             int cce = cc;
             asm volatile("" : "+v"(cce) : "v"(T[0]));
-            auto eload = [&](double2 (&v)[NI], const double *src) {
+            auto eload = [&](real2_t (&v)[NI], const real_t *src) {
 #pragma unroll
                 for (int i = 0; i < NI; i++)
-                    v[i] = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cce);
+                    v[i] = *reinterpret_cast<const real2_t *>(src + (long)(cy + 128 * i) * prow + 2 * cce);
             };
             eload(old, rhs + off);
             eload(bs, epi.base + off);
-            double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+            real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
-            for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+            for (int m = 0; m < Q / 2; m++) dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const long at = off + (long)(cy + 128 * i) * prow + 2 * cce;
-                double2 d = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                real2_t d = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                 d.x += old[i].x;
                 d.y += old[i].y;
-                if (epi.store) *reinterpret_cast<double2 *>(rhs + at) = d;
-                double2 v = bs[i];
+                if (epi.store) *reinterpret_cast<real2_t *>(rhs + at) = d;
+                real2_t v = bs[i];
 #pragma unroll
                 for (int k = 0; k < 5; k++)
                     if (k < epi.n) {
-                        double2 t = d;
-                        if (k != epi.ipend) t = *reinterpret_cast<const double2 *>(epi.x[k] + at);
+                        real2_t t = d;
+                        if (k != epi.ipend) t = *reinterpret_cast<const real2_t *>(epi.x[k] + at);
                         v.x = epi.c[k] * t.x + v.x;
                         v.y = epi.c[k] * t.y + v.y;
                     }
-                *reinterpret_cast<double2 *>(epi.y + at) = v;
+                *reinterpret_cast<real2_t *>(epi.y + at) = v;
             }
         }
         __syncthreads();  // the tile is free again
@@ -852,9 +852,9 @@ __global__ void __launch_bounds__(1024)
 // by all loads and stores of all fields (global_load_dwordx4 v, v_off, s[base:base+1]) instead of a 64-bit
 // address pair per row: 7 VGPRs less in kernels that sit on the 128-VGPR limit.  Needs 128 * prow * 8 < 4 GiB
 // (checked by the launchers).
-__device__ __forceinline__ const double2 *tile_row(const double *base, long prow, int i, unsigned voff)
+__device__ __forceinline__ const real2_t *tile_row(const real_t *base, long prow, int i, unsigned voff)
 {
-    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base + (long)(128 * i) * prow) + voff);
+    return reinterpret_cast<const real2_t *>(reinterpret_cast<const char *>(base + (long)(128 * i) * prow) + voff);
 }
 
 // ---------------------------------------------------------------- K3y, the three components of a direction at once
@@ -887,20 +887,20 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 // component) and the two dependency chains interleave.  Same arithmetic per right-hand side, bit for bit.
 template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false>
 __global__ void __launch_bounds__(1024)
-    k_ytile_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0,
-                     const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
-                     int tile0, int ntiles, long prow, long pplane, double nu, TileHalo th)
+    k_ytile_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0,
+                     const real_t *__restrict__ u1, const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
+                     int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = tD1.TL[i];
         lt[LN + i] = tD2.TL[i];
     }
-    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
-    double *tile = lt + 2 * LN;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    real_t *tile = lt + 2 * LN;
     // HALO: [16 pencils][8] halo values of the current field, then the same for the advecting velocity u0
-    double *hal = tile + 16 * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
+    real_t *hal = tile + 16 * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
     ntiles += tile0;  // tiles [tile0, tile0 + ntiles) (a range of planes: overlap of the neighbour exchange)
 #ifdef YT_TIMING
     unsigned long long yt_last = __builtin_readcyclecounter();
@@ -909,23 +909,23 @@ __global__ void __launch_bounds__(1024)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
-    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
-    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
+    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * X3D_RB);
+    auto gload = [&](real2_t (&v)[NI], const real_t *__restrict__ src) {
 #pragma unroll
         for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
     };
-    auto to_tile = [&](const double2 (&v)[NI]) {
+    auto to_tile = [&](const real2_t (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
             tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
         }
     };
-    auto pick = [&](double (&b)[Q]) {
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+    auto pick = [&](real_t (&b)[Q]) {
+        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
         for (int m = 0; m < Q / 2; m++) {
-            const double2 t2_ = src[m];
+            const real2_t t2_ = src[m];
             b[2 * m] = t2_.x;
             b[2 * m + 1] = t2_.y;
         }
@@ -938,8 +938,8 @@ __global__ void __launch_bounds__(1024)
         return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.hnp + pp];
     };
     __syncthreads();
-    double2 nxt[NI];  // the rows needed next (next component's field, or the next tile's u0), in flight during the solves
-    double hnx = 0.0;
+    real2_t nxt[NI];  // the rows needed next (next component's field, or the next tile's u0), in flight during the solves
+    real_t hnx = 0.0;
     if (tile0 + (int)blockIdx.x < ntiles) {
         gload(nxt, u0 + tile_off(tile0 + blockIdx.x));
         if (HALO && threadIdx.x < 128) hnx = hload(tile0 + blockIdx.x, 0);
@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(1024)
     vmcnt_pad_stores<(ACC ? 2 : 1) * NI>();
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
-        double cb[Q];  // this pencil's rows of the advecting velocity
+        real_t cb[Q];  // this pencil's rows of the advecting velocity
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             asm volatile("" : "+v"(lane));
@@ -956,9 +956,9 @@ __global__ void __launch_bounds__(1024)
 #ifdef YT_TIMING
             const unsigned long long yt_c0 = __builtin_readcyclecounter();
 #endif
-            double wu[Q + 8], wp[Q + 8];
+            real_t wu[Q + 8], wp[Q + 8];
             {
-                double b[Q];
+                real_t b[Q];
                 to_tile(nxt);
                 if (HALO && threadIdx.x < 128) {
                     hal[threadIdx.x] = hnx;
@@ -985,18 +985,18 @@ __global__ void __launch_bounds__(1024)
             // (no barrier here: until the store phase a wave only rewrites its own pencil's region of the tile)
             {
                 const int tn = tl + gridDim.x;
-                const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
+                const real_t *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
                 if (c < 2 || tn < ntiles) {
                     gload(nxt, nsrc);
                     if (HALO && threadIdx.x < 128) hnx = hload(c < 2 ? tl : tn, c < 2 ? c + 1 : 0);
                 }
             }
 
-            auto solve_subs = [&](const double (&w)[Q + 8], double (&T)[Q], const double *__restrict__ l, const XOp &t,
+            auto solve_subs = [&](const real_t (&w)[Q + 8], real_t (&T)[Q], const real_t *__restrict__ l, const XOp &t,
                                   int op) {
-                double a, b;
+                real_t a, b;
                 scan_solve<Q, true, NARROW>(w, T, a, b, l, t, lane, first);
-                double s_, e_;
+                real_t s_, e_;
                 if constexpr (HALO) {
                     // recv_s = recv_e = 0 for now; own boundary values (wave-uniform) parked in LDS, written out
                     // after the third component for the exchange (k_transeq_halo_fix)
@@ -1009,20 +1009,20 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     if constexpr (UNI) {
-                        double x = T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_;
+                        real_t x = T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_;
                         if (q == 0) x = (lane == 0) ? s_ : x;
                         if (q == Q - 1) x = (lane == 63) ? e_ : x;
                         T[q] = x;
                     } else {
-                        const double st = LTR(l, LT_ST(q));
-                        double x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
+                        const real_t st = LTR(l, LT_ST(q));
+                        real_t x = st * (T[q] - LTR(l, LT_SA(q)) * s_ - LTR(l, LT_SC(q)) * e_);
                         if (q == 0) x = (lane == 0) ? s_ * st : x;
                         if (q == Q - 1) x = (lane == 63) ? e_ * st : x;
                         T[q] = x;
                     }
                 }
             };
-            double r[Q], T[Q];
+            real_t r[Q], T[Q];
             YT_T(2);
 #ifdef YT_TIMING
             const unsigned long long yt_s0 = __builtin_readcyclecounter();
@@ -1042,8 +1042,8 @@ __global__ void __launch_bounds__(1024)
                 }
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const double sa = LTR(l1, LT_SA(q)), sc = LTR(l1, LT_SC(q));
-                    double xa = T2[q].a - sa * s_.a - sc * e_.a, xb = T2[q].b - sa * s_.b - sc * e_.b;
+                    const real_t sa = LTR(l1, LT_SA(q)), sc = LTR(l1, LT_SC(q));
+                    real_t xa = T2[q].a - sa * s_.a - sc * e_.a, xb = T2[q].b - sa * s_.b - sc * e_.b;
                     if (q == 0) { xa = (lane == 0) ? s_.a : xa; xb = (lane == 0) ? s_.b : xb; }
                     if (q == Q - 1) { xa = (lane == 63) ? e_.a : xa; xb = (lane == 63) ? e_.b : xb; }
                     r[q] = -0.5 * (cb[q] * xb + xa);
@@ -1064,7 +1064,7 @@ __global__ void __launch_bounds__(1024)
             if constexpr (P12 && UNI) {
                 // the field's window again, from the tile (it still holds the component's rows): keeping wu alive
                 // across the pair solve does not fit the 128 registers (121 + 56 bytes of scratch)
-                double b[Q];
+                real_t b[Q];
                 pick(b);
                 if constexpr (HALO) window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
                 else window_from_body<Q>(wu, b, lane);
@@ -1076,8 +1076,8 @@ __global__ void __launch_bounds__(1024)
                 //  spills, but 2.37 instead of 2.24 ms per launch; issued after the FIRST solve, where the product
                 //  window's registers are free (123 VGPRs, no spills): 2.18 ms both ways -- the load's latency is not
                 //  what limits, the memory system is busy throughout with this pattern's 128-byte segments)
-                double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
-                double2 old[NI];
+                real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+                real2_t old[NI];
                 YT_T(3);
 #ifdef YT_TIMING
                 if (lane == 0) {
@@ -1090,31 +1090,31 @@ __global__ void __launch_bounds__(1024)
                 if (ACC) {
 #pragma unroll
                     for (int i = 0; i < NI; i++) {
-                        const double *q_ = reinterpret_cast<const double *>(tile_row(o, prow, i, voff));
-                        old[i] = make_double2(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1));
+                        const real_t *q_ = reinterpret_cast<const real_t *>(tile_row(o, prow, i, voff));
+                        old[i] = make_real2(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1));
                     }
                 }
 #else
                 if (ACC) gload(old, o);
 #endif
-                double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+                real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
                 for (int m = 0; m < Q / 2; m++)
-                    dst[m] = make_double2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+                    dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
                 __syncthreads();
                 YT_T(4);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
-                    double2 v = make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                    real2_t v = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
                     if (ACC) { v.x += old[i].x; v.y += old[i].y; }
 #ifdef YT_NT
                     {
-                        double *q_ = reinterpret_cast<double *>(const_cast<double2 *>(tile_row(o, prow, i, voff)));
+                        real_t *q_ = reinterpret_cast<real_t *>(const_cast<real2_t *>(tile_row(o, prow, i, voff)));
                         __builtin_nontemporal_store(v.x, q_);
                         __builtin_nontemporal_store(v.y, q_ + 1);
                     }
 #else
-                    *const_cast<double2 *>(tile_row(o, prow, i, voff)) = v;
+                    *const_cast<real2_t *>(tile_row(o, prow, i, voff)) = v;
 #endif
                 }
             }
@@ -1143,20 +1143,20 @@ __global__ void __launch_bounds__(1024)
 // UNI: both operators on a uniform grid -- no ST reads / multiplications (see k_ytile_transeq3)
 template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false>
 __global__ void __launch_bounds__(1024)
-    k_ytile_tds_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2,
+    k_ytile_tds_pair(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2,
                      XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn,
                      ZfArg zf)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = (ZF ? LT_NC(Q) : LT_N(Q)) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     static_assert(!ZF || (Q == 8 && MODE != 2 && !HALO), "the z-transforming forms: local pairs on 512-row pencils");
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = ta.TL[i];
         if (MODE != 2) lt[LN + i] = tb.TL[i];
     }
-    const double *__restrict__ la = lt, *__restrict__ lb = lt + LN;
-    double *tile = lt + (MODE == 2 ? 1 : 2) * LN;  // (a single operator stages one table set)
-    double2 *tws = reinterpret_cast<double2 *>(tile + ZF_AREA_DOUBLES);  // ZF: W512^k behind the 72 KB tile area
+    const real_t *__restrict__ la = lt, *__restrict__ lb = lt + LN;
+    real_t *tile = lt + (MODE == 2 ? 1 : 2) * LN;  // (a single operator stages one table set)
+    real2_t *tws = reinterpret_cast<real2_t *>(tile + ZF_AREA_DOUBLES);  // ZF: W512^k behind the 72 KB tile area
     if (ZF && threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
     const long kzs = (long)zf.ny * zf.px;
     auto zf_row = [&](int tl) { return zf.c + (long)(tl / ntx) * zf.px + (long)(tl % ntx) * 16; };
@@ -1164,51 +1164,51 @@ __global__ void __launch_bounds__(1024)
     // solves the kernel spills inside the tile loop, and every reload is an exposed memory latency: 1.40 ms
     // against 0.95 for the local form): this tile's rows are requested at its top instead
     constexpr bool NOPREF = HALO && MODE == 0;
-    double *hal = tile + 16 * TP, *bnd = hal + 128;  // HALO: [16 pencils][8] halo values of the input in the tile;
+    real_t *hal = tile + 16 * TP, *bnd = hal + 128;  // HALO: [16 pencils][8] halo values of the input in the tile;
                                                      // [16 pencils][2 ops][du_1, X_n]
     ntiles += tile0;                                 // tiles [tile0, tile0 + ntiles)
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
-    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * 8);
-    auto gload = [&](double2 (&v)[NI], const double *__restrict__ src) {
+    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * X3D_RB);
+    auto gload = [&](real2_t (&v)[NI], const real_t *__restrict__ src) {
 #pragma unroll
         for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
     };
-    auto to_tile = [&](const double2 (&v)[NI]) {
+    auto to_tile = [&](const real2_t (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
             tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
         }
     };
-    auto pick = [&](double (&b)[Q]) {
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(tile + wave * TP + lane * Q);
+    auto pick = [&](real_t (&b)[Q]) {
+        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
         for (int m = 0; m < Q / 2; m++) {
-            const double2 t2_ = src[m];
+            const real2_t t2_ = src[m];
             b[2 * m] = t2_.x;
             b[2 * m + 1] = t2_.y;
         }
     };
-    auto put = [&](const double (&r)[Q]) {
-        double2 *__restrict__ dst = reinterpret_cast<double2 *>(tile + wave * TP + lane * Q);
+    auto put = [&](const real_t (&r)[Q]) {
+        real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
 #pragma unroll
-        for (int m = 0; m < Q / 2; m++) dst[m] = make_double2(r[2 * m], r[2 * m + 1]);
+        for (int m = 0; m < Q / 2; m++) dst[m] = make_real2(r[2 * m], r[2 * m + 1]);
     };
-    auto from_tile = [&](double *o) {
+    auto from_tile = [&](real_t *o) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            *const_cast<double2 *>(tile_row(o, prow, i, voff)) =
-                make_double2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+            *const_cast<real2_t *>(tile_row(o, prow, i, voff)) =
+                make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
     };
     // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange; HALO:
     // with recv_s = recv_e = 0, the own boundary values stored for the exchange -- see TileHalo)
-    auto solve = [&](const double (&w)[Q + 8], double (&r)[Q], const double *__restrict__ l, const XOp &t, int op) {
-        double X[Q], du1, xn;
+    auto solve = [&](const real_t (&w)[Q + 8], real_t (&r)[Q], const real_t *__restrict__ l, const XOp &t, int op) {
+        real_t X[Q], du1, xn;
         scan_solve<Q, true, NARROW>(w, X, du1, xn, l, t, lane, first);
-        double du_s, du_e;
+        real_t du_s, du_e;
         if constexpr (HALO) {
             du_s = t.rs_s * du1; du_e = t.rs_e * xn;
             bnd[(wave * 2 + op) * 2] = du1;  // (wave-uniform values, parked in LDS until the tile is done)
@@ -1223,7 +1223,7 @@ __global__ void __launch_bounds__(1024)
                 if (q == 0) r[q] = (lane == 0) ? du_s : r[q];
                 if (q == Q - 1) r[q] = (lane == 63) ? du_e : r[q];
             } else {
-                const double st = LTR(l, LT_ST(q));
+                const real_t st = LTR(l, LT_ST(q));
                 r[q] = (X[q] - LTR(l, LT_SA(q)) * du_s - LTR(l, LT_SC(q)) * du_e) * st;
                 if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
                 if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
@@ -1249,9 +1249,9 @@ __global__ void __launch_bounds__(1024)
         return th.recv[((long)((hk >> 2) * th.nf + f) * 4 + (hk & 3)) * th.hnp + pp];
     };
     __syncthreads();
-    double2 nxt[NI];  // next tile's in1 rows, in flight during the solves
+    real2_t nxt[NI];  // next tile's in1 rows, in flight during the solves
     ZfRows spn{};  // ZF, MODE 1: next tile's modes instead
-    double hnx = 0.0;
+    real_t hnx = 0.0;
     if (!NOPREF && tile0 + (int)blockIdx.x < ntiles) {
         if constexpr (ZF && MODE == 1) spn = zf_inverse_load(zf_row(tile0 + blockIdx.x), kzs);
         else gload(nxt, in1 + in1_off(tile0 + blockIdx.x));
@@ -1260,9 +1260,9 @@ __global__ void __launch_bounds__(1024)
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         asm volatile("" : "+v"(lane));
-        double w[Q + 8], b[Q], ra[Q], rb[Q];
-        double2 g2[NI];
-        double h2 = 0.0;
+        real_t w[Q + 8], b[Q], ra[Q], rb[Q];
+        real2_t g2[NI];
+        real_t h2 = 0.0;
         if (MODE == 0) {
             gload(g2, in2 + off);
             if (HALO && threadIdx.x < 128) h2 = hload(tl, 1);
@@ -1337,9 +1337,9 @@ __global__ void __launch_bounds__(1024)
 // add to du_s, du_e of src/backend/omp/kernels/distributed.f90:196-206):
 //     x_j += -st_j (sa_j ds + sc_j de)   (2 <= j <= n - 1),   x_1 += st_1 ds,   x_n += st_n de
 // on rows 1..ws and n-we+1..n (the launcher cuts where |sa_j|, |sc_j| < 2^-60; ws + we >= n: every row).
-__device__ __forceinline__ double halo_fix_row(const TdsTab &t, int j, int n, double ds, double de)
+__device__ __forceinline__ real_t halo_fix_row(const TdsTab &t, int j, int n, real_t ds, real_t de)
 {
-    const double st = T_ST(t, j);
+    const real_t st = T_ST(t, j);
     if (j == 1) return st * ds;
     if (j == n) return st * de;
     return -st * (T_SA(t, j) * ds + T_SC(t, j) * de);
@@ -1347,7 +1347,7 @@ __device__ __forceinline__ double halo_fix_row(const TdsTab &t, int j, int n, do
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
-    k_tds_halo_fix(double *__restrict__ out1, double *__restrict__ out2, const double *__restrict__ brecv, TdsTab ta,
+    k_tds_halo_fix(real_t *__restrict__ out1, real_t *__restrict__ out2, const real_t *__restrict__ brecv, TdsTab ta,
                    TdsTab tb, PencilGeom g, int ws, int we, int permn)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1356,8 +1356,8 @@ __global__ void __launch_bounds__(256)
     int r1 = p / g.dim0;  // permn > 0 (z pencils, MODE 0): out1's y rows are interleaved (k_ytile_tds_pair)
     if (MODE == 0 && permn > 0 && r1 < permn) r1 = (r1 & 1) ? permn - ((r1 + 1) >> 1) : (r1 >> 1);
     const long base = (long)(p % g.dim0) * g.s0 + (long)r1 * g.s1;
-    const double dsa = -ta.rs_s * ta.sa1 * brecv[p], dea = -ta.rs_e * ta.scn * brecv[(long)nb * g.np + p];
-    double dsb = 0.0, deb = 0.0;
+    const real_t dsa = -ta.rs_s * ta.sa1 * brecv[p], dea = -ta.rs_e * ta.scn * brecv[(long)nb * g.np + p];
+    real_t dsb = 0.0, deb = 0.0;
     if (MODE != 2) {
         dsb = -tb.rs_s * tb.sa1 * brecv[(long)g.np + p];
         deb = -tb.rs_e * tb.scn * brecv[(long)(nb + 1) * g.np + p];
@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(256)
     const int j0 = seg == 0 ? 1 : (n - we + 1 > ws ? n - we + 1 : ws + 1), j1 = seg == 0 ? (ws < n ? ws : n) : n;
     for (int j = j0; j <= j1; j++) {
         const long o = base + (long)(j - 1) * g.rs;
-        const double fa = halo_fix_row(ta, j, n, dsa, dea);
+        const real_t fa = halo_fix_row(ta, j, n, dsa, dea);
         if (MODE == 0) out1[o] += fa + halo_fix_row(tb, j, n, dsb, deb);
         else out1[o] += fa;
         if (MODE == 1) out2[o] += halo_fix_row(tb, j, n, dsb, deb);
@@ -1376,31 +1376,31 @@ __global__ void __launch_bounds__(256)
 // (src/backend/omp/kernels/distributed.f90:304-335 is linear in du, dud, d2u); brecv = [side][c * 3 + op][np],
 // op 0 = d(u conv) (tD1), 1 = du (tD1), 2 = d2u (tD2); v = the advecting velocity
 __global__ void __launch_bounds__(256)
-    k_transeq_halo_fix(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
-                       const double *__restrict__ v, const double *__restrict__ brecv, TdsTab t1, TdsTab t2,
-                       PencilGeom g, double nu, int ws, int we)
+    k_transeq_halo_fix(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2,
+                       const real_t *__restrict__ v, const real_t *__restrict__ brecv, TdsTab t1, TdsTab t2,
+                       PencilGeom g, real_t nu, int ws, int we)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.np) return;
     const int n = t1.n_tds, seg = blockIdx.y;
     const long base = (long)(p % g.dim0) * g.s0 + (long)(p / g.dim0) * g.s1, np = g.np;
-    double ds[9], de[9];
+    real_t ds[9], de[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const TdsTab &t = (k % 3 == 2) ? t2 : t1;
         ds[k] = -t.rs_s * t.sa1 * brecv[k * np + p];
         de[k] = -t.rs_e * t.scn * brecv[(9 + k) * np + p];
     }
-    double *__restrict__ rhs[3] = {rhs0, rhs1, rhs2};
+    real_t *__restrict__ rhs[3] = {rhs0, rhs1, rhs2};
     const int j0 = seg == 0 ? 1 : (n - we + 1 > ws ? n - we + 1 : ws + 1), j1 = seg == 0 ? (ws < n ? ws : n) : n;
     for (int j = j0; j <= j1; j++) {
         const long o = base + (long)(j - 1) * g.rs;
-        const double vj = v[o], stc = T_STC(t2, j);
+        const real_t vj = v[o], stc = T_STC(t2, j);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const double ddud = halo_fix_row(t1, j, n, ds[3 * c], de[3 * c]);
-            const double ddu = halo_fix_row(t1, j, n, ds[3 * c + 1], de[3 * c + 1]);
-            const double dd2u = halo_fix_row(t2, j, n, ds[3 * c + 2], de[3 * c + 2]);
+            const real_t ddud = halo_fix_row(t1, j, n, ds[3 * c], de[3 * c]);
+            const real_t ddu = halo_fix_row(t1, j, n, ds[3 * c + 1], de[3 * c + 1]);
+            const real_t dd2u = halo_fix_row(t2, j, n, ds[3 * c + 2], de[3 * c + 2]);
             rhs[c][o] += -0.5 * (vj * ddu + ddud) + nu * (dd2u + ddu * stc);
         }
     }
@@ -1417,12 +1417,12 @@ static bool xscan_ok(const x3d_tdsops *t) { return t->tab.TL != nullptr && (t->t
 // the general (FAST = 0) forms of the x kernels also exist for 6 rows per lane (257 .. 384-row pencils)
 static bool xscan_ok_gen(const x3d_tdsops *t) { return xscan_ok(t) || (t->tab.TL != nullptr && t->tab.Q == 6); }
 
-int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done)
+int x3d_xscan_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done)
 {
     *done = false;
     if (!xscan_ok_gen(t)) return 0;
     const int Q = t->tab.Q, np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * (LT_N(Q) * 64 + CS_N(Q));
+    const size_t lds = sizeof(real_t) * (LT_N(Q) * 64 + CS_N(Q));
     int blocks = (np + 7) / 8;
     blocks = blocks > 768 ? 768 : blocks;  // 43 KB of lane tables per 8-wave workgroup: 3 per CU
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
@@ -1449,7 +1449,7 @@ int x3d_xscan_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
 }
 
 template <int Q, bool SAME, bool ACC, int FAST>
-static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+static int launch_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                           const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int np, int blocks,
                           size_t lds, long pitch)
 {
@@ -1462,14 +1462,14 @@ static int launch_transeq(x3d_backend *b, double *rhs, const double *u, const do
 
 // np pencils of contiguous rows, `pitch` doubles apart: the x pencils of the Cartesian block, or the pencils
 // of a transposed copy (tds.hip, transeq_via_x)
-int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xscan_transeq_np(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                          const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, int np, long pitch,
                          int dirtag, bool *done)
 {
     *done = false;
     if (!xscan_ok_gen(t1) || !xscan_ok_gen(t2) || !xscan_ok_gen(t3) || t1->tab.Q != t2->tab.Q || t1->tab.Q != t3->tab.Q) return 0;
     const int Q = t1->tab.Q;
-    const size_t lds = sizeof(double) * (3 * LT_N(Q) * 64 + 3 * CS_N(Q));
+    const size_t lds = sizeof(real_t) * (3 * LT_N(Q) * 64 + 3 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;  // one 8/12-wave workgroup per CU (129 KB of lane tables in LDS)
@@ -1514,7 +1514,7 @@ int x3d_xscan_transeq_np(x3d_backend *b, double *rhs, const double *u, const dou
     return 0;
 }
 
-int x3d_xscan_transeq(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+int x3d_xscan_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
 {
     return x3d_xscan_transeq_np(b, rhs, u, conv, nu, t1, t2, t3, acc, b->ny * b->nz, (long)b->nxp, X3D_DIR_X, done);
@@ -1540,7 +1540,7 @@ static bool use_ytile()
 }
 
 template <int Q, bool SAME, bool ACC, int FAST>
-static int launch_ytile(x3d_backend *b, double *rhs, const double *u, const double *conv, double nu,
+static int launch_ytile(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                         const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int share12, size_t lds,
                         int dir, const TileEpi *epi)
 {
@@ -1577,23 +1577,23 @@ bool x3d_ytile_applicable(x3d_backend *b, int dir, const x3d_tdsops *t1, const x
     if ((dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return false;
     if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return false; }
     const int share12 = t1->tl_hash == t2->tl_hash;
-    return sizeof(double) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4)) <= 160 * 1024;
+    return sizeof(real_t) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4)) <= 160 * 1024;
 }
 
-static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+static int ytile_transeq_impl(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                               const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc,
                               const TileEpi *epi, bool *done);
 
-int x3d_ytile_transeq(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+int x3d_ytile_transeq(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done)
 {
     return ytile_transeq_impl(b, dir, rhs, u, conv, nu, t1, t2, t3, acc, nullptr, done);
 }
 
 // the component + the stage's linear combination (TileEpi); rhs is x[ipend]
-int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
-                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, double *y,
-                              const double *base, int nterm, const double *c, double *const *x, int ipend, int store,
+int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
+                              const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, real_t *y,
+                              const real_t *base, int nterm, const real_t *c, real_t *const *x, int ipend, int store,
                               bool *done)
 {
     TileEpi e;
@@ -1602,7 +1602,7 @@ int x3d_ytile_transeq_lincomb(x3d_backend *b, int dir, double *rhs, const double
     return ytile_transeq_impl(b, dir, rhs, u, conv, nu, t1, t2, t3, 1, &e, done);
 }
 
-static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double *u, const double *conv, double nu,
+static int ytile_transeq_impl(x3d_backend *b, int dir, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                               const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc,
                               const TileEpi *epi, bool *done)
 {
@@ -1616,7 +1616,7 @@ static int ytile_transeq_impl(x3d_backend *b, int dir, double *rhs, const double
         if (!zt) return 0;
     }
     const int share12 = t1->tl_hash == t2->tl_hash;
-    const size_t lds = sizeof(double) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    const size_t lds = sizeof(real_t) * ((size_t)(share12 ? 2 : 3) * LT_N(Q) * 64 + 16 * (64 * Q + 4));
     if (lds > 160 * 1024) return 0;
     const bool same = u == conv;
     const bool narrow = stencil_narrow(t1) && stencil_narrow(t2) && stencil_narrow(t3);
@@ -1648,7 +1648,7 @@ static void tile_range(const x3d_backend *b, int dir, int other0, int nother, in
 
 // K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq).
 // mode 2: out1 = A(in1) only.  halo != null: decomposed direction (TileHalo: nf = 1 or 2 inputs, nb operators)
-int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, const TileHalo *halo, int other0, int nother,
                        bool *done)
 {
@@ -1662,7 +1662,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     };
     if (!fast(ta) || !fast(tb) || (dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
     if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return 0; }
-    const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
+    const size_t lds = sizeof(real_t) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     static int uni_on = -1;
@@ -1676,7 +1676,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, double *out1, double *
     if (permn > 0 && (dir != X3D_DIR_Z || mode == 2 || tile0 != 0 || (ntiles > 0 && ntiles != ntx * b->ny))) return 0;
     if (ntiles <= 0) { *done = true; return 0; }
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
-    if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
+    if (128 * rstride * X3D_RB >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("X3D_TILE_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
@@ -1709,15 +1709,15 @@ bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_t
     if (!use_ytile() || !xscan_ok(ta) || !xscan_ok(tb) || ta->tab.Q != 8 || tb->tab.Q != 8) return false;
     auto fast = [&](const x3d_tdsops *t) { return t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == t->n_tds; };
     if (!fast(ta) || !fast(tb) || b->nz != 512 || b->nx % 16 != 0) return false;
-    if (sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512) > 160 * 1024) return false;
-    return 128 * (long)b->nxp * b->nyp * 8 < (1L << 32);
+    if (sizeof(real_t) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512) > 160 * 1024) return false;
+    return 128 * (long)b->nxp * b->nyp * X3D_RB < (1L << 32);
 }
 
 // the z pairs next to the z-first Poisson solve (k_ytile_tds_pair<.., ZF>): mode 0: A(in1) + B(in2) -> spectrum,
 // mode 1: spectrum -> out1 = A(p), out2 = B(p); whole blocks of 512^3
 // y0, nyr: the tiles of the y rows [y0, y0 + nyr) only (nyr < 0: all) -- csrc/sfftz.hip cuts a solve into groups of y rows
 // so that a group's exchange runs beside the next group's pair
-int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                           const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr)
 {
     *done = false;
@@ -1725,7 +1725,7 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, 
     if (nyr < 0) { y0 = 0; nyr = b->ny; }
     X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= b->ny, "tds_pair (z-first): rows [%d, %d) of %d", y0, y0 + nyr, b->ny);
     if (nyr == 0) { *done = true; return 0; }
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
+    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
@@ -1752,7 +1752,7 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, double *out1, double *out2, 
 }
 
 // rows 1..ws and n-we+1..n carry more than 2^-60 of the reduced system's coupling (tds.hip, x3d_tdsops_create)
-int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *brecv,
+int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *brecv,
                      const x3d_tdsops *ta, const x3d_tdsops *tb)
 {
     const PencilGeom g = x3d_geom(b, dir);
@@ -1770,8 +1770,8 @@ int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, double *out1, double *ou
     return 0;
 }
 
-int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, double *const r[3], const double *conv, double nu,
-                                const double *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd)
+int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, real_t *const r[3], const real_t *conv, real_t nu,
+                                const real_t *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd)
 {
     const PencilGeom g = x3d_geom(b, dir);
     const int ws = der1st->halo_ws > der2nd->halo_ws ? der1st->halo_ws : der2nd->halo_ws;
@@ -1787,7 +1787,7 @@ int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, double *const r[3], con
 
 // K3y, three components in one launch (k_ytile_transeq3); f[0] is the advecting component.
 // halo != null: decomposed direction (TileHalo: nf = 3 fields in the order f[0..2], nb = 9 boundary values)
-int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                        const x3d_tdsops *der2nd_sym, int acc, const TileHalo *halo, int other0, int nother, bool *done)
 {
@@ -1797,7 +1797,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 256 + 288 : 0));
+    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 256 + 288 : 0));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     static int uni_on = -1;
@@ -1810,7 +1810,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
     if (ntiles <= 0) { *done = true; return 0; }
     const int blocks = x3d_persistent_blocks(b, ntiles);
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
-    if (128 * rstride * 8 >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
+    if (128 * rstride * X3D_RB >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
 #define GO(Q_, A_, N_, H_, U_)                                                                                  \
@@ -1843,10 +1843,10 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, double *const r[3], const double
 
 // transeq_x in one launch (k_xscan_transeq2x3); f[0] is the advecting component.  upd_g != null: the pending
 // correction f[c] += scale * tds_solve(upd_g[c]) with op_s (c = 0) / op_i (c = 1, 2) is applied first (UPD form)
-int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu,
+int x3d_xscan_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f[3], real_t nu,
                        const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
-                       const x3d_tdsops *der2nd_sym, int acc, const double *const *upd_g, const x3d_tdsops *op_s,
-                       const x3d_tdsops *op_i, double scale, double omega, const double *ushift, bool *done)
+                       const x3d_tdsops *der2nd_sym, int acc, const real_t *const *upd_g, const x3d_tdsops *op_s,
+                       const x3d_tdsops *op_i, real_t scale, real_t omega, const real_t *ushift, bool *done)
 {
     *done = false;
     if ((omega != 0.0 || ushift) && (acc || upd_g)) return 0;
@@ -1867,7 +1867,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
         };
         if (!ok(op_s) || !ok(op_i)) return 0;
     }
-    const size_t lds = sizeof(double) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
+    const size_t lds = sizeof(real_t) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
     if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd) && (!upd || (stencil_narrow(op_s) && stencil_narrow(op_i)));
     const int blocks = x3d_persistent_blocks(b, (np / 2 + 7) / 8);
@@ -1879,7 +1879,7 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_, C_>));                                             \
         hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_, C_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
-                           r[2], (double *)f[0], (double *)f[1], (double *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
+                           r[2], (real_t *)f[0], (real_t *)f[1], (real_t *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
                            (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti));                                       \
     } while (0)
 #define GOU(Q_, A_, N_) do { if (upd) GO(Q_, A_, N_, true, false); else GO(Q_, A_, N_, false, false); } while (0)
@@ -1909,8 +1909,8 @@ int x3d_xscan_transeq3(x3d_backend *b, double *const r[3], const double *const f
 }
 
 // du = tdsops(y) with y = base + sum c_k x_k formed (and stored) by the same kernel; x direction
-int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, const double *wall, bool *done)
+int x3d_xscan_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
+                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done)
 {
     *done = false;
     static int on = -1;
@@ -1923,7 +1923,7 @@ int x3d_xscan_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, doubl
     const int Q = t->tab.Q;
     if (!(t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds && b->nx == 64 * Q)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * LT_N(Q) * 64;
+    const size_t lds = sizeof(real_t) * LT_N(Q) * 64;
     int blocks = (np + 7) / 8;
     blocks = blocks > 768 ? 768 : blocks;
     LinRows lr;

@@ -34,16 +34,16 @@
 // LDS-bound on exactly these reads (LdsUtil 83 % in k_ytile_transeq3).  The empty asm is a barrier for the
 // load / store combiner only (it ends a merge window); it emits nothing.
 #if XSCAN_EXP == 4  // timing experiment: no lane-table reads at all (results are garbage): what the LDS reads cost
-__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx) { return 0.37 + 1e-3 * (idx & 7); }
+__device__ __forceinline__ real_t lt_read(const real_t *__restrict__ l, int idx) { return 0.37 + 1e-3 * (idx & 7); }
 #elif !defined(XS_READ2)
-__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx)
+__device__ __forceinline__ real_t lt_read(const real_t *__restrict__ l, int idx)
 {
-    const double v = l[idx];
+    const real_t v = l[idx];
     asm volatile("" ::: "memory");
     return v;
 }
 #else
-__device__ __forceinline__ double lt_read(const double *__restrict__ l, int idx) { return l[idx]; }
+__device__ __forceinline__ real_t lt_read(const real_t *__restrict__ l, int idx) { return l[idx]; }
 #endif
 #define LTR(l, e) lt_read((l), (e) * 64 + lane)
 
@@ -65,9 +65,9 @@ __device__ __forceinline__ int ltc_lane(int lane) { return lane < 8 ? lane : (la
 
 // what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
 struct XOp {
-    const double *TL, *Cs;
-    double last_r, rs_s, rs_e, sa1, scn;
-    double c[9];  // bulk stencil by value: kernel arguments live in SGPRs (a load through Cs would be a
+    const real_t *TL, *Cs;
+    real_t last_r, rs_s, rs_e, sa1, scn;
+    real_t c[9];  // bulk stencil by value: kernel arguments live in SGPRs (a load through Cs would be a
                   // VMEM load per pencil and operator, the stores may alias it)
     int n_tds, n_rhs, bulk_only;
 };
@@ -84,13 +84,13 @@ static inline XOp xop_of(const x3d_tdsops *t)
 // stencil, as [4 slots][Q][10] doubles in LDS (16-byte aligned)
 #define CS_N(Q_) (4 * (Q_) * 10)
 template <int Q>
-__device__ __forceinline__ void stage_cs(double *dst, const XOp &t)
+__device__ __forceinline__ void stage_cs(real_t *dst, const XOp &t)
 {
     const int nr = t.n_rhs, ls = (nr - 4) / Q;
     for (int i = threadIdx.x; i < CS_N(Q); i += blockDim.x) {
         const int s_ = i / (Q * 10), q = (i / 10) % Q, m = i % 10;
         const int L = s_ == 0 ? 0 : (s_ == 1 ? ls : ls + 1), j = L * Q + q + 1;
-        double v = 0.0;
+        real_t v = 0.0;
         if (m < 9) {
             if (s_ < 3 && j <= 4) v = t.Cs[(j - 1) * 9 + m];
             else if (s_ < 3 && j > nr - 4 && j <= nr) v = t.Cs[36 + (j - (nr - 4) - 1) * 9 + m];
@@ -100,9 +100,9 @@ __device__ __forceinline__ void stage_cs(double *dst, const XOp &t)
     }
 }
 
-// DPP move of a double; lanes whose source lane does not exist (or whose row is masked out) read 0
+// DPP move of a real_t; lanes whose source lane does not exist (or whose row is masked out) read 0
 template <int CTRL, int ROWMASK = 0xf>
-__device__ __forceinline__ double dpp0(double v)
+__device__ __forceinline__ real_t dpp0(real_t v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
     // (all rows enabled: bound_ctrl:1 makes the lanes without a source read 0 by itself -- no zero-initialised
@@ -111,47 +111,47 @@ __device__ __forceinline__ double dpp0(double v)
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double readlane_d(double v, int l)
+__device__ __forceinline__ real_t readlane_d(real_t v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                             __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 // ---- two pencils per wave: every lane-table value read from LDS serves both (the kernels are LDS-pipe
 // bound on the table reads), and the two independent dependency chains interleave.  The solver below is
-// written once over T = double or V2.
-struct V2 { double a, b; };
+// written once over T = real_t or V2.
+struct V2 { real_t a, b; };
 __device__ __forceinline__ V2 operator+(V2 x, V2 y) { return V2{x.a + y.a, x.b + y.b}; }
 __device__ __forceinline__ V2 operator-(V2 x, V2 y) { return V2{x.a - y.a, x.b - y.b}; }
 __device__ __forceinline__ V2 operator*(V2 x, V2 y) { return V2{x.a * y.a, x.b * y.b}; }
-__device__ __forceinline__ V2 operator*(double c, V2 x) { return V2{c * x.a, c * x.b}; }
-__device__ __forceinline__ V2 operator*(V2 x, double c) { return V2{x.a * c, x.b * c}; }
+__device__ __forceinline__ V2 operator*(real_t c, V2 x) { return V2{c * x.a, c * x.b}; }
+__device__ __forceinline__ V2 operator*(V2 x, real_t c) { return V2{x.a * c, x.b * c}; }
 __device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.a += y.a; x.b += y.b; return x; }
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
 __device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
 template <class T> __device__ __forceinline__ T zero_of();
-template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ real_t zero_of<real_t>() { return 0.0; }
 template <> __device__ __forceinline__ V2 zero_of<V2>() { return V2{0.0, 0.0}; }
-__device__ __forceinline__ double first_of(double x) { return x; }
-__device__ __forceinline__ double first_of(V2 x) { return x.a; }
+__device__ __forceinline__ real_t first_of(real_t x) { return x; }
+__device__ __forceinline__ real_t first_of(V2 x) { return x.a; }
 // c ? x : y, component by component (a ternary on the struct itself goes through a stack slot)
-__device__ __forceinline__ double sel_of(bool c, double x, double y) { return c ? x : y; }
+__device__ __forceinline__ real_t sel_of(bool c, real_t x, real_t y) { return c ? x : y; }
 __device__ __forceinline__ V2 sel_of(bool c, V2 x, V2 y) { return V2{c ? x.a : y.a, c ? x.b : y.b}; }
 
-__device__ __forceinline__ double shfl_up_d(double v, int d, int lane)
+__device__ __forceinline__ real_t shfl_up_d(real_t v, int d, int lane)
 {
-    const double r = __shfl_up(v, d, 64);
+    const real_t r = __shfl_up(v, d, 64);
     return lane >= d ? r : 0.0;
 }
-__device__ __forceinline__ double shfl_down_d(double v, int d, int lane)
+__device__ __forceinline__ real_t shfl_down_d(real_t v, int d, int lane)
 {
-    const double r = __shfl_down(v, d, 64);
+    const real_t r = __shfl_down(v, d, 64);
     return lane + d < 64 ? r : 0.0;
 }
 
 // extended pencil row jj in [-3, nr+4] (non-decomposed direction: periodic image,
 // src/backend/omp/sendrecv.f90:20-22); rows beyond nr+4 read as zero
-__device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, int nr, int n_wrap)
+__device__ __forceinline__ real_t ext_x(const real_t *__restrict__ row, int jj, int nr, int n_wrap)
 {
     if (jj < 1) return row[n_wrap + jj - 1];
     if (jj > nr) return jj <= nr + 4 ? row[jj - nr - 1] : 0.0;
@@ -161,16 +161,16 @@ __device__ __forceinline__ double ext_x(const double *__restrict__ row, int jj, 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
 // values (before the reduced-system substitution), du1 and xn broadcast to all lanes.
 // General form (FAST = false): cs = the operator's stencil table in LDS (stage_cs), n_rhs >= 8.
-template <int Q, bool FAST, bool NARROW = false, class T = double, int LS = 64>
+template <int Q, bool FAST, bool NARROW = false, class T = real_t, int LS = 64>
 __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du1, T &xn,
-                                           const double *__restrict__ lt, const XOp &t, int &lane, int first, int ll = 0,
-                                           const double *__restrict__ cs = nullptr)
+                                           const real_t *__restrict__ lt, const XOp &t, int &lane, int first, int ll = 0,
+                                           const real_t *__restrict__ cs = nullptr)
 {
     // PHASE(x): the lane-table reads of the next phase may not be issued before x is known; without
     // it the scheduler front-loads all ~76 reads of an operator (152 VGPRs) and spills
 #define PHASE(x) asm volatile("" : "+v"(lane) : "v"(first_of(x)))
     const int nr = t.n_rhs, n = t.n_tds;
-    const double c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
+    const real_t c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6],
                  c7 = t.c[7], c8 = t.c[8];
     T acc[Q];
     // NARROW: the compact6 / classic stencils only reach 2 rows: skip the zero taps (adding 0 * w is exact,
@@ -197,7 +197,7 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
         int co = (lane == 0 ? 0 : (lane == ls ? 1 : (lane == ls + 1 ? 2 : 3))) * (Q * 10);
 #ifdef XSCAN_CS_DEPTH2
         // (the pair type with the wide stencils: one row at a time -- two rows' ten weights each do not fit beside two windows)
-        constexpr bool D2 = NARROW || sizeof(T) == sizeof(double);
+        constexpr bool D2 = NARROW || sizeof(T) == sizeof(real_t);
 #else
         constexpr bool D2 = false;
 #endif
@@ -206,12 +206,12 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             int &coq = (D2 && (q & 1)) ? co1 : co;
-            const double2 *__restrict__ c2 = reinterpret_cast<const double2 *>(cs + coq + q * 10);
+            const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + coq + q * 10);
             if (NARROW) {  // no stencil of the operator reaches beyond 2 rows (x3d_tdsops::narrow_all): taps 2..6 only
-                const double2 cb = c2[1], cc = c2[2], cd = c2[3];
+                const real2_t cb = c2[1], cc = c2[2], cd = c2[3];
                 acc[q] = cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] + cc.y * w[q + 5] + cd.x * w[q + 6];
             } else {
-                const double2 ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
+                const real2_t ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
                 acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
                          cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
             }
@@ -292,27 +292,27 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 // nr == 64*Q and n_wrap == nr: every lane's body is a full aligned vector and the halos are
 // the neighbours' rows or the periodic image -> no per-lane branches at all
 template <int Q>
-__device__ __forceinline__ void load_window_exact(double (&w)[Q + 8], const double *__restrict__ row, int lane,
+__device__ __forceinline__ void load_window_exact(real_t (&w)[Q + 8], const real_t *__restrict__ row, int lane,
                                                   int nr)
 {
-    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
+    const real2_t *__restrict__ body = reinterpret_cast<const real2_t *>(row + lane * Q);
 #pragma unroll
     for (int m = 0; m < Q / 2; m++) {
-        const double2 t2 = body[m];
+        const real2_t t2 = body[m];
         w[4 + 2 * m] = t2.x;
         w[5 + 2 * m] = t2.y;
     }
     const int il = lane == 0 ? nr - 4 : lane * Q - 4;       // rows first-4..first-1 (periodic image for lane 0)
     const int ir = lane == 63 ? 0 : lane * Q + Q;           // rows last+1..last+4
-    const double2 *__restrict__ hl = reinterpret_cast<const double2 *>(row + il);
-    const double2 *__restrict__ hr = reinterpret_cast<const double2 *>(row + ir);
-    const double2 a0 = hl[0], a1 = hl[1], b0 = hr[0], b1 = hr[1];
+    const real2_t *__restrict__ hl = reinterpret_cast<const real2_t *>(row + il);
+    const real2_t *__restrict__ hr = reinterpret_cast<const real2_t *>(row + ir);
+    const real2_t a0 = hl[0], a1 = hl[1], b0 = hr[0], b1 = hr[1];
     w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
     w[Q + 4] = b0.x; w[Q + 5] = b0.y; w[Q + 6] = b1.x; w[Q + 7] = b1.y;
 }
 
 // ---- 4 x 4 transpose of 16-byte pairs inside each quad of lanes (stores of xscan.hip; loads below)
-__device__ __forceinline__ double dpp_quad(double v, int k)
+__device__ __forceinline__ real_t dpp_quad(real_t v, int k)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
     if (k == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x93, 0xf, 0xf, false);
@@ -324,11 +324,11 @@ __device__ __forceinline__ double dpp_quad(double v, int k)
     return __hiloint2double(hi, lo);
 }
 // (scalars, not arrays: LLVM turns `c ? a[i] : a[k]` into a dynamically indexed stack array)
-__device__ __forceinline__ void rotl_pairs(double &a0, double &a1, double &b0, double &b1, double &c0, double &c1,
-                                           double &d0, double &d1, int j)
+__device__ __forceinline__ void rotl_pairs(real_t &a0, real_t &a1, real_t &b0, real_t &b1, real_t &c0, real_t &c1,
+                                           real_t &d0, real_t &d1, int j)
 {
     const bool r1 = j & 1, r2 = j & 2;
-    double t0 = a0, t1 = a1;  // rotate left by one pair where r1
+    real_t t0 = a0, t1 = a1;  // rotate left by one pair where r1
     a0 = r1 ? b0 : a0; a1 = r1 ? b1 : a1;
     b0 = r1 ? c0 : b0; b1 = r1 ? c1 : b1;
     c0 = r1 ? d0 : c0; c1 = r1 ? d1 : c1;
@@ -345,18 +345,18 @@ __device__ __forceinline__ void rotl_pairs(double &a0, double &a1, double &b0, d
 #ifndef XS_TLOAD
 #define XS_TLOAD 0
 #endif
-__device__ __forceinline__ void load_body_q8t(double (&b)[8], const double *__restrict__ row, int lane)
+__device__ __forceinline__ void load_body_q8t(real_t (&b)[8], const real_t *__restrict__ row, int lane)
 {
     const int j = lane & 3;
-    const double *__restrict__ q = row + (lane & ~3) * 8 + 2 * j;
+    const real_t *__restrict__ q = row + (lane & ~3) * 8 + 2 * j;
 #if XS_TLOAD == 2
-    const double2 *__restrict__ qs = reinterpret_cast<const double2 *>(q);
-    const double2 v0 = ldg_stream(qs), v1 = ldg_stream(qs + 4), v2 = ldg_stream(qs + 8), v3 = ldg_stream(qs + 12);
+    const real2_t *__restrict__ qs = reinterpret_cast<const real2_t *>(q);
+    const real2_t v0 = ldg_stream(qs), v1 = ldg_stream(qs + 4), v2 = ldg_stream(qs + 8), v3 = ldg_stream(qs + 12);
 #else
-    const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(q);
-    const double2 v0 = q2[0], v1 = q2[4], v2 = q2[8], v3 = q2[12];
+    const real2_t *__restrict__ q2 = reinterpret_cast<const real2_t *>(q);
+    const real2_t v0 = q2[0], v1 = q2[4], v2 = q2[8], v3 = q2[12];
 #endif
-    double a0 = v0.x, a1 = v0.y, b0 = v1.x, b1 = v1.y, c0 = v2.x, c1 = v2.y, d0 = v3.x, d1 = v3.y;
+    real_t a0 = v0.x, a1 = v0.y, b0 = v1.x, b1 = v1.y, c0 = v2.x, c1 = v2.y, d0 = v3.x, d1 = v3.y;
     rotl_pairs(a0, a1, b0, b1, c0, c1, d0, d1, j);
     b0 = dpp_quad(b0, 1); b1 = dpp_quad(b1, 1);
     c0 = dpp_quad(c0, 2); c1 = dpp_quad(c1, 2);
@@ -368,23 +368,23 @@ __device__ __forceinline__ void load_body_q8t(double (&b)[8], const double *__re
 // FAST path: only the lane's own Q rows come from memory (4 aligned 16-byte loads, issued one
 // pencil ahead); the 4+4 halo rows are the neighbour lanes' rows (periodic wrap across the wave)
 template <int Q>
-__device__ __forceinline__ void load_body(double (&b)[Q], const double *__restrict__ row, int lane)
+__device__ __forceinline__ void load_body(real_t (&b)[Q], const real_t *__restrict__ row, int lane)
 {
 #if XS_TLOAD
     if constexpr (Q == 8) { load_body_q8t(b, row, lane); return; }
 #endif
-    const double2 *__restrict__ body = reinterpret_cast<const double2 *>(row + lane * Q);
+    const real2_t *__restrict__ body = reinterpret_cast<const real2_t *>(row + lane * Q);
 #pragma unroll
     for (int m = 0; m < Q / 2; m++) {
         // (plain, not ldg_stream: a lane's 64 bytes are four instructions that each touch a QUARTER of every 64-byte
         //  sector -- the lines must stay cached between them; with the nontemporal hint the x kernels ran 25 % slower,
         //  profiles/README.md round 4)
-        const double2 t2 = body[m];
+        const real2_t t2 = body[m];
         b[2 * m] = t2.x;
         b[2 * m + 1] = t2.y;
     }
 }
-template <int Q, class T = double>
+template <int Q, class T = real_t>
 __device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q], int lane)
 {
     (void)lane;
@@ -399,7 +399,7 @@ __device__ __forceinline__ void window_from_body(T (&w)[Q + 8], const T (&b)[Q],
 
 // non-periodic pencil: rows before row 1 and after row 64 Q read as zero (their stencil weights are zero)
 template <int Q>
-__device__ __forceinline__ void window_from_body_zero(double (&w)[Q + 8], const double (&b)[Q])
+__device__ __forceinline__ void window_from_body_zero(real_t (&w)[Q + 8], const real_t (&b)[Q])
 {
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -412,9 +412,9 @@ __device__ __forceinline__ void window_from_body_zero(double (&w)[Q + 8], const 
 
 // decomposed direction (BC_HALO ends): rows -3..0 and n+1..n+4 of the pencil are the neighbour ranks' rows, handed
 // over in hl[0..3] / hl[4..7] (this wave's 8 halo values, staged in LDS) instead of the periodic image
-template <int Q, class T = double>
+template <int Q, class T = real_t>
 __device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b)[Q], int lane,
-                                                      const double *__restrict__ hl)
+                                                      const real_t *__restrict__ hl)
 {
     window_from_body<Q, T>(w, b, lane);
     // (two one-lane branches: selects on all lanes keep 8 more values live where the kernels have no room)
@@ -431,11 +431,11 @@ __device__ __forceinline__ void window_from_body_halo(T (&w)[Q + 8], const T (&b
 // y = base + sum_k c[k] x[k] as the prologue of an x operator (k_xscan_tds_lin, k_xwide_tds_lin); wall != null: the
 // pencils of the two y faces take `wall`'s rows instead (ny = rows per plane)
 struct LinRows {
-    double *y;
-    const double *base;
-    const double *x[5];
-    double c[5];
+    real_t *y;
+    const real_t *base;
+    const real_t *x[5];
+    real_t c[5];
     int n;
-    const double *wall;
+    const real_t *wall;
     int ny;
 };

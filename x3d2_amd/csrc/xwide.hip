@@ -18,66 +18,66 @@ constexpr int WQ = 16;             // rows per lane
 constexpr int WSTRIP = 64 * 18;    // doubles of LDS per wave
 
 // the wave's pencil <-> registers, coalesced: instruction m moves the 16-byte pieces lane + 64 m
-__device__ __forceinline__ void wide_gload(double (&v)[16], const double *__restrict__ row, int lane)
+__device__ __forceinline__ void wide_gload(real_t (&v)[16], const real_t *__restrict__ row, int lane)
 {
-    const double2 *__restrict__ r2 = reinterpret_cast<const double2 *>(row) + lane;
+    const real2_t *__restrict__ r2 = reinterpret_cast<const real2_t *>(row) + lane;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        const double2 t = r2[64 * m];
+        const real2_t t = r2[64 * m];
         v[2 * m] = t.x;
         v[2 * m + 1] = t.y;
     }
 }
 // piece g = lane + 64 m belongs to lane g / 8 (its pair g % 8)
 __device__ __forceinline__ int wide_coal_off(int lane, int m) { return ((lane >> 3) + 8 * m) * 18 + (lane & 7) * 2; }
-__device__ __forceinline__ void wide_to_strip(double *strip, const double (&v)[16], int lane)
+__device__ __forceinline__ void wide_to_strip(real_t *strip, const real_t (&v)[16], int lane)
 {
 #pragma unroll
     for (int m = 0; m < 8; m++)
-        *reinterpret_cast<double2 *>(strip + wide_coal_off(lane, m)) = make_double2(v[2 * m], v[2 * m + 1]);
+        *reinterpret_cast<real2_t *>(strip + wide_coal_off(lane, m)) = make_real2(v[2 * m], v[2 * m + 1]);
 }
-__device__ __forceinline__ void wide_own_rows(double (&b)[WQ], const double *strip, int lane)
+__device__ __forceinline__ void wide_own_rows(real_t (&b)[WQ], const real_t *strip, int lane)
 {
-    const double2 *s2 = reinterpret_cast<const double2 *>(strip + lane * 18);
+    const real2_t *s2 = reinterpret_cast<const real2_t *>(strip + lane * 18);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const double2 t = s2[k];
+        const real2_t t = s2[k];
         b[2 * k] = t.x;
         b[2 * k + 1] = t.y;
     }
 }
-__device__ __forceinline__ void wide_put_rows(double *strip, const double (&r)[WQ], int lane)
+__device__ __forceinline__ void wide_put_rows(real_t *strip, const real_t (&r)[WQ], int lane)
 {
-    double2 *s2 = reinterpret_cast<double2 *>(strip + lane * 18);
+    real2_t *s2 = reinterpret_cast<real2_t *>(strip + lane * 18);
 #pragma unroll
-    for (int k = 0; k < 8; k++) s2[k] = make_double2(r[2 * k], r[2 * k + 1]);
+    for (int k = 0; k < 8; k++) s2[k] = make_real2(r[2 * k], r[2 * k + 1]);
 }
 // strip -> memory, coalesced; ACC: out = old + scale * r (the arithmetic of k_xscan_tds<ACC>)
 template <bool ACC>
-__device__ __forceinline__ void wide_store(double *__restrict__ orow, const double *strip, int lane, double scale)
+__device__ __forceinline__ void wide_store(real_t *__restrict__ orow, const real_t *strip, int lane, real_t scale)
 {
-    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow) + lane;
-    double2 old[8];
+    real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow) + lane;
+    real2_t old[8];
     if (ACC) {
 #pragma unroll
         for (int m = 0; m < 8; m++) old[m] = o2[64 * m];
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        double2 v = *reinterpret_cast<const double2 *>(strip + wide_coal_off(lane, m));
+        real2_t v = *reinterpret_cast<const real2_t *>(strip + wide_coal_off(lane, m));
         if (ACC) { v.x = old[m].x + scale * v.x; v.y = old[m].y + scale * v.y; }
         o2[64 * m] = v;
     }
 }
 
 // strip -> memory with c * (another field's rows, as wide_gload delivered them) added
-__device__ __forceinline__ void wide_store_add(double *__restrict__ orow, const double *strip, int lane, double c,
-                                               const double (&add)[16])
+__device__ __forceinline__ void wide_store_add(real_t *__restrict__ orow, const real_t *strip, int lane, real_t c,
+                                               const real_t (&add)[16])
 {
-    double2 *__restrict__ o2 = reinterpret_cast<double2 *>(orow) + lane;
+    real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(orow) + lane;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        double2 v = *reinterpret_cast<const double2 *>(strip + wide_coal_off(lane, m));
+        real2_t v = *reinterpret_cast<const real2_t *>(strip + wide_coal_off(lane, m));
         v.x = c * add[2 * m] + 1.0 * v.x;
         v.y = c * add[2 * m + 1] + 1.0 * v.y;
         o2[64 * m] = v;
@@ -86,17 +86,17 @@ __device__ __forceinline__ void wide_store_add(double *__restrict__ orow, const 
 
 // one operator on the window w: r = its tds_solve rows (closed with the periodic self-exchange)
 template <bool NARROW>
-__device__ __forceinline__ void wide_solve(const double (&w)[WQ + 8], double (&r)[WQ], const double *__restrict__ lt,
+__device__ __forceinline__ void wide_solve(const real_t (&w)[WQ + 8], real_t (&r)[WQ], const real_t *__restrict__ lt,
                                            const XOp &t, int &lane, int ll)
 {
     constexpr int Q = WQ, LS = LTC_LS;
-    double X[WQ], du1, xn;
-    scan_solve<WQ, true, NARROW, double, LTC_LS>(w, X, du1, xn, lt, t, lane, lane * WQ + 1, ll);
-    const double du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+    real_t X[WQ], du1, xn;
+    scan_solve<WQ, true, NARROW, real_t, LTC_LS>(w, X, du1, xn, lt, t, lane, lane * WQ + 1, ll);
+    const real_t du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
 #pragma unroll
     for (int q = 0; q < WQ; q++) {
-        const double st = LTX(lt, LT_ST(q));
-        double x = (X[q] - LTX(lt, LT_SA(q)) * du_s - LTX(lt, LT_SC(q)) * du_e) * st;
+        const real_t st = LTX(lt, LT_ST(q));
+        real_t x = (X[q] - LTX(lt, LT_SA(q)) * du_s - LTX(lt, LT_SC(q)) * du_e) * st;
         if (q == 0) x = (lane == 0) ? du_s * st : x;
         if (q == WQ - 1) x = (lane == 63) ? du_e * st : x;
         r[q] = x;
@@ -105,25 +105,25 @@ __device__ __forceinline__ void wide_solve(const double (&w)[WQ + 8], double (&r
 
 // ---------------------------------------------------------------- tds_solve
 template <bool ACC, bool NARROW>
-__global__ void __launch_bounds__(512) k_xwide_tds(double *__restrict__ du, const double *__restrict__ u, XOp t, int np,
-                                                   long pitch, double scale)
+__global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, const real_t *__restrict__ u, XOp t, int np,
+                                                   long pitch, real_t scale)
 {
-    extern __shared__ double lt[];  // [LTC_N(16)] tables, then one strip per wave
+    extern __shared__ real_t lt[];  // [LTC_N(16)] tables, then one strip per wave
     for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
     __syncthreads();
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    double *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    real_t *strip = lt + LTC_N(WQ) + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
-    double nxt[16];  // next pencil's pieces, in flight while this one is solved
+    real_t nxt[16];  // next pencil's pieces, in flight while this one is solved
     if (p0 < np) wide_gload(nxt, u + (long)p0 * pitch, lane);
     for (int p = p0; p < np; p += nwaves) {
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
-        double w[WQ + 8], r[WQ];
+        real_t w[WQ + 8], r[WQ];
         {
-            double b[WQ];
+            real_t b[WQ];
             wide_to_strip(strip, nxt, lane);
             wave_lds_fence();
             wide_own_rows(b, strip, lane);
@@ -143,25 +143,25 @@ __global__ void __launch_bounds__(512) k_xwide_tds(double *__restrict__ du, cons
 // k_xscan_tds_lin for 1024-row pencils: y = base + sum c_k x_k (the RK stage, summation order of k_lincomb) formed on
 // the coalesced pieces, the y faces stamped from `wall` if given, y stored, du = tds_solve(y) -- y is not read back.
 template <bool NARROW>
-__global__ void __launch_bounds__(512) k_xwide_tds_lin(double *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
+__global__ void __launch_bounds__(512) k_xwide_tds_lin(real_t *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
     __syncthreads();
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    double *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    real_t *strip = lt + LTC_N(WQ) + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
         const long ro = (long)p * pitch;
         asm volatile("" : "+v"(lane));
-        double v[16];
+        real_t v[16];
         wide_gload(v, lr.base + ro, lane);
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (k < lr.n) {
-                double xk[16];
+                real_t xk[16];
                 wide_gload(xk, lr.x[k] + ro, lane);
 #pragma unroll
                 for (int m = 0; m < 16; m++) v[m] = lr.c[k] * xk[m] + v[m];
@@ -171,13 +171,13 @@ __global__ void __launch_bounds__(512) k_xwide_tds_lin(double *__restrict__ du, 
             if (j == 0 || j == lr.ny - 1) wide_gload(v, lr.wall + ro, lane);
         }
         {
-            double2 *__restrict__ o2 = reinterpret_cast<double2 *>(lr.y + ro) + lane;
+            real2_t *__restrict__ o2 = reinterpret_cast<real2_t *>(lr.y + ro) + lane;
 #pragma unroll
-            for (int m = 0; m < 8; m++) o2[64 * m] = make_double2(v[2 * m], v[2 * m + 1]);
+            for (int m = 0; m < 8; m++) o2[64 * m] = make_real2(v[2 * m], v[2 * m + 1]);
         }
-        double w[WQ + 8], r[WQ];
+        real_t w[WQ + 8], r[WQ];
         {
-            double b[WQ];
+            real_t b[WQ];
             wide_to_strip(strip, v, lane);
             wave_lds_fence();
             wide_own_rows(b, strip, lane);
@@ -201,45 +201,45 @@ __global__ void __launch_bounds__(512) k_xwide_tds_lin(double *__restrict__ du, 
 // rows are in registers when dv is formed -- no extra traffic.
 template <bool ACC, bool NARROW, bool ROT = false>
 __global__ void __launch_bounds__(512)
-    k_xwide_transeq3(double *__restrict__ rhs0, double *__restrict__ rhs1, double *__restrict__ rhs2,
-                     const double *u0, const double *__restrict__ u1, const double *__restrict__ u2, XOp tD1,
-                     XOp tD2, int np, long pitch, double nu, double omega, const double *__restrict__ ushift)
+    k_xwide_transeq3(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2,
+                     const real_t *u0, const real_t *__restrict__ u1, const real_t *__restrict__ u2, XOp tD1,
+                     XOp tD2, int np, long pitch, real_t nu, real_t omega, const real_t *__restrict__ ushift)
 {
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = LTC_N(WQ), Q = WQ, LS = LTC_LS;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = tD1.TL[i];
         lt[LN + i] = tD2.TL[i];
     }
     __syncthreads();
-    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    double *strip = lt + 2 * LN + wave * WSTRIP;
+    real_t *strip = lt + 2 * LN + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
-    double nxt[16];  // the rows needed next (next component's field, or the next pencil's u0)
+    real_t nxt[16];  // the rows needed next (next component's field, or the next pencil's u0)
     if (p0 < np) wide_gload(nxt, u0 + (long)p0 * pitch, lane);
     // ushift != null: u0 += *ushift first, in place (the channel case's bulk-velocity shift, x3d_field_mean_shift:
     // the pencil is in registers anyway -- one write pass instead of a read + write pass of its own)
-    const double ush = ushift ? *ushift : 0.0;
+    const real_t ush = ushift ? *ushift : 0.0;
     for (int p = p0; p < np; p += nwaves) {
         const long ro = (long)p * pitch;
-        double cb[WQ];
+        real_t cb[WQ];
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             asm volatile("" : "+v"(lane));
-            double wu[WQ + 8], wp[WQ + 8];
+            real_t wu[WQ + 8], wp[WQ + 8];
             {
-                double b[WQ];
+                real_t b[WQ];
                 if (c == 0 && ushift) {
-                    double2 *o2 = reinterpret_cast<double2 *>(const_cast<double *>(u0) + ro) + lane;
+                    real2_t *o2 = reinterpret_cast<real2_t *>(const_cast<real_t *>(u0) + ro) + lane;
 #pragma unroll
                     for (int m = 0; m < 8; m++) {
                         nxt[2 * m] += ush;
                         nxt[2 * m + 1] += ush;
-                        o2[64 * m] = make_double2(nxt[2 * m], nxt[2 * m + 1]);
+                        o2[64 * m] = make_real2(nxt[2 * m], nxt[2 * m + 1]);
                     }
                 }
                 wide_to_strip(strip, nxt, lane);
@@ -256,10 +256,10 @@ __global__ void __launch_bounds__(512)
             }
             {
                 const int pn = p + nwaves;
-                const double *nsrc = c == 0 ? u1 + ro : (c == 1 ? u2 + ro : u0 + (long)(pn < np ? pn : p) * pitch);
+                const real_t *nsrc = c == 0 ? u1 + ro : (c == 1 ? u2 + ro : u0 + (long)(pn < np ? pn : p) * pitch);
                 if (c < 2 || pn < np) wide_gload(nxt, nsrc, lane);
             }
-            double r[WQ], T[WQ];
+            real_t r[WQ], T[WQ];
             wide_solve<NARROW>(wp, T, l1, tD1, lane, ll);  // d(u conv)/dx first: wp is dead afterwards
 #pragma unroll
             for (int q = 0; q < WQ; q++) r[q] = T[q];
@@ -313,12 +313,12 @@ static XOp wide_xop(const x3d_tdsops *t)
 }
 
 // tds_solve along x on 1024-row pencils; *done = false: not served here
-int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops *t, int acc, double scale, bool *done)
+int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done)
 {
     *done = false;
     if (!wide_env_on() || !wide_ok(b, t)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * (LTC_N(WQ) + 8 * WSTRIP);
+    const size_t lds = sizeof(real_t) * (LTC_N(WQ) + 8 * WSTRIP);
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;  // 98 KB of LDS: one 8-wave workgroup per CU
     const bool narrow = wide_narrow(t);
@@ -338,15 +338,15 @@ int x3d_xwide_tds(x3d_backend *b, double *du, const double *u, const x3d_tdsops 
 }
 
 // y = base + sum c_k x_k ; y faces of y <- wall (if given) ; du = tds_solve(y) along x; *done = false: not served here
-int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, double *y, const double *base, int nterm,
-                          const double *c, const double *const *x, const double *wall, bool *done)
+int x3d_xwide_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
+                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done)
 {
     *done = false;
     static int on = -1;
     if (on < 0) { const char *e = getenv("X3D_NO_TDS_LINCOMB"); on = (e && e[0] == '1') ? 0 : 1; }
     if (!on || !wide_env_on() || !wide_ok(b, t)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * (LTC_N(WQ) + 8 * WSTRIP);
+    const size_t lds = sizeof(real_t) * (LTC_N(WQ) + 8 * WSTRIP);
     int blocks = (np + 7) / 8;
     blocks = blocks > 256 ? 256 : blocks;
     LinRows lr;
@@ -368,9 +368,9 @@ int x3d_xwide_tds_lincomb(x3d_backend *b, double *du, const x3d_tdsops *t, doubl
 }
 
 // transeq_x in one launch; f[0] is the advecting component
-int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f[3], double nu, const x3d_tdsops *der1st,
+int x3d_xwide_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f[3], real_t nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
-                       double omega, const double *ushift, bool *done)
+                       real_t omega, const real_t *ushift, bool *done)
 {
     *done = false;
     if (omega != 0.0 && acc) return 0;
@@ -378,7 +378,7 @@ int x3d_xwide_transeq3(x3d_backend *b, double *const r[3], const double *const f
         return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(double) * (2 * LTC_N(WQ) + 8 * WSTRIP);
+    const size_t lds = sizeof(real_t) * (2 * LTC_N(WQ) + 8 * WSTRIP);
     const int blocks = x3d_persistent_blocks(b, (np + 7) / 8);
     const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd);
     {

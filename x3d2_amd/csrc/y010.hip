@@ -8,7 +8,7 @@
 // of rows j and ny - j + 2, the pentadiagonal systems -- happens while the column is on chip.
 //
 // Work decomposition: a workgroup of 8 waves owns the 8 x-adjacent columns of one z mode: c[kz][0..255][x0..x0+7]
-// (128-byte row segments).  The tile sits in LDS as 8 pencils of Y010_P double2; wave w transforms pencil w with
+// (128-byte row segments).  The tile sits in LDS as 8 pencils of Y010_P real2_t; wave w transforms pencil w with
 // fft256_wave (fft512_core.h, 4 points per lane, exchanges through the pencil's own LDS region) and does the paired
 // split on it; only the load, the pentadiagonal phase and the store need block barriers.
 //
@@ -33,19 +33,19 @@
 #define Y010_P 274  // >= 271 (fft256_wave's layouts) and = 2 mod 16: the 8 pencils' rows j sit in different LDS banks
 
 struct Y010Arg {
-    const double *ax, *bx, *ay, *by, *az, *bz;  // global tables (spectral010.h)
-    const double *lu0, *lu1;                    // factored pentadiagonal operators [5][nz][n][nxs]
+    const real_t *ax, *bx, *ay, *by, *az, *bz;  // global tables (spectral010.h)
+    const real_t *lu0, *lu1;                    // factored pentadiagonal operators [5][nz][n][nxs]
     int nxs, nz, nx, sym;
 };
 
-__device__ __forceinline__ void y010_pair_fw(double2 *__restrict__ pen, int j0, const Rot &rz, const Rot &rx,
-                                             const double *__restrict__ ay, const double *__restrict__ by, int nx, int nz)
+__device__ __forceinline__ void y010_pair_fw(real2_t *__restrict__ pen, int j0, const Rot &rz, const Rot &rx,
+                                             const real_t *__restrict__ ay, const real_t *__restrict__ by, int nx, int nz)
 {
     constexpr int ny = 256;
     const int jr0 = ny - j0;  // (0-based partner row; j0 = 0 has none)
     const bool paired = j0 >= 1, self = paired && jr0 == j0;
-    const double2 L = pen[j0], R = paired && !self ? pen[jr0] : L;
-    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
+    const real2_t L = pen[j0], R = paired && !self ? pen[jr0] : L;
+    real_t l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
     l_r = l_r / nx / ny / nz; l_c = l_c / nx / ny / nz;
     rot_fw(l_r, l_c, rz);
     rot_fw(l_r, l_c, rx);
@@ -56,33 +56,33 @@ __device__ __forceinline__ void y010_pair_fw(double2 *__restrict__ pen, int j0, 
         rot_fw(r_r, r_c, rx);
     }
     if (paired) {
-        const double a = ay[j0], b = by[j0], a2 = ay[jr0], b2 = by[jr0];
-        const double n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
-        const double n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
-        const double n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
-        const double n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
+        const real_t a = ay[j0], b = by[j0], a2 = ay[jr0], b2 = by[jr0];
+        const real_t n_lr = 0.5 * (l_r * b + l_c * a + r_r * b - r_c * a);
+        const real_t n_lc = 0.5 * (-l_r * a + l_c * b + r_r * a + r_c * b);
+        const real_t n_rr = 0.5 * (r_r * b2 + r_c * a2 + l_r * b2 - l_c * a2);
+        const real_t n_rc = 0.5 * (-r_r * a2 + r_c * b2 + l_r * a2 + l_c * b2);
         l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
         if (self) { l_r = r_r; l_c = r_c; }  // the second store wins on the self-paired row
     }
-    pen[j0] = make_double2(l_r, l_c);
-    if (paired && !self) pen[jr0] = make_double2(r_r, r_c);
+    pen[j0] = make_real2(l_r, l_c);
+    if (paired && !self) pen[jr0] = make_real2(r_r, r_c);
 }
 
-__device__ __forceinline__ void y010_pair_bw(double2 *__restrict__ pen, int j0, const Rot &rz, const Rot &rx,
-                                             const double *__restrict__ ay, const double *__restrict__ by)
+__device__ __forceinline__ void y010_pair_bw(real2_t *__restrict__ pen, int j0, const Rot &rz, const Rot &rx,
+                                             const real_t *__restrict__ ay, const real_t *__restrict__ by)
 {
     constexpr int ny = 256;
     const int jr0 = ny - j0;
     const bool paired = j0 >= 1, self = paired && jr0 == j0;
-    const double2 L = pen[j0], R = paired && !self ? pen[jr0] : L;
-    double l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
+    const real2_t L = pen[j0], R = paired && !self ? pen[jr0] : L;
+    real_t l_r = L.x, l_c = L.y, r_r = R.x, r_c = R.y;
     if (paired) {
         if (self) { r_r = l_r; r_c = l_c; }
-        const double a = ay[j0], b = by[j0], a2 = ay[jr0], b2 = by[jr0];
-        const double n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
-        const double n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
-        const double n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
-        const double n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
+        const real_t a = ay[j0], b = by[j0], a2 = ay[jr0], b2 = by[jr0];
+        const real_t n_lr = l_r * b - l_c * a + r_r * a + r_c * b;
+        const real_t n_lc = l_r * a + l_c * b - r_r * b + r_c * a;
+        const real_t n_rr = r_r * b2 - r_c * a2 + l_r * a2 + l_c * b2;
+        const real_t n_rc = r_r * a2 + r_c * b2 - l_r * b2 + l_c * a2;
         l_r = n_lr; l_c = n_lc; r_r = n_rr; r_c = n_rc;
         if (self) { l_r = r_r; l_c = r_c; }
     }
@@ -92,28 +92,28 @@ __device__ __forceinline__ void y010_pair_bw(double2 *__restrict__ pen, int j0, 
         rot_bw(r_r, r_c, rz);
         rot_bw(r_r, r_c, rx);
     }
-    pen[j0] = make_double2(l_r, l_c);
-    if (paired && !self) pen[jr0] = make_double2(r_r, r_c);
+    pen[j0] = make_real2(l_r, l_c);
+    if (paired && !self) pen[jr0] = make_real2(r_r, r_c);
 }
 
 // k_penta_solve (spectral010.h) on the tile in LDS: this lane's chain = component `ri` of column x, system s
 // (sym: rows 2 j + s - 2, 0-based, j = 1 .. n = 128; else all 256 rows)
-__device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010Arg &g, int kz, int x0, int lane)
+__device__ __forceinline__ void y010_penta(real2_t *__restrict__ sm, const Y010Arg &g, int kz, int x0, int lane)
 {
     constexpr int ny = 256, U = 8;
     const int x = lane & 7, ri = (lane >> 3) & 1, s = lane >> 4;
     if (s >= (g.sym ? 2 : 1)) return;
     const int inc = g.sym ? 2 : 1, n = ny / inc;
-    const double *__restrict__ lu = s ? g.lu1 : g.lu0;
+    const real_t *__restrict__ lu = s ? g.lu1 : g.lu0;
     const size_t ds = (size_t)g.nz * n * g.nxs;
-    const double *__restrict__ lub = lu + (size_t)kz * n * g.nxs + x0 + x;
+    const real_t *__restrict__ lub = lu + (size_t)kz * n * g.nxs + x0 + x;
 #define LU(j, d) lub[(size_t)((d) - 1) * ds + (size_t)((j) - 1) * g.nxs]
-    double *__restrict__ pd = reinterpret_cast<double *>(sm + x * Y010_P) + ri;
+    real_t *__restrict__ pd = reinterpret_cast<real_t *>(sm + x * Y010_P) + ri;
 #define C(j) pd[2 * (inc * (j) + s - inc)]  // (inc j + off - h - 1 with off = s, h = inc / 2: 2 j + s - 2 or j - 1)
-    const double eps = 1.e-16;
+    const real_t eps = 1.e-16;
     // forward: rows j+1, j+2 -= m * row j; two rows are carried in registers
-    double r0 = C(1), r1 = C(2);
-    double m1c[U], m2c[U], m1n[U], m2n[U];
+    real_t r0 = C(1), r1 = C(2);
+    real_t m1c[U], m2c[U], m1n[U], m2n[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int j = 1 + u;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
         for (int u = 0; u < U; u++) {
             const int j = jb + u;
             if (j <= n - 2) {
-                double r2 = C(j + 2);
+                real_t r2 = C(j + 2);
                 r1 = r1 - m1c[u] * r0;
                 r2 = r2 - m2c[u] * r0;
                 C(j) = r0;
@@ -142,9 +142,9 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
         for (int u = 0; u < U; u++) { m1c[u] = m1n[u]; m2c[u] = m2n[u]; }
     }
     // last two rows: r0 = row n-1, r1 = row n
-    const double tmp = LU(n - 1, 2), dd = LU(n, 3), inv = LU(n - 1, 3), a4n = LU(n - 1, 4);
+    const real_t tmp = LU(n - 1, 2), dd = LU(n, 3), inv = LU(n - 1, 3), a4n = LU(n - 1, 4);
     // (the first backward chunk, requested before the divisions)
-    double ivc[U], a4c[U], a5c[U], ivn[U], a4x[U], a5n[U];
+    real_t ivc[U], a4c[U], a5c[U], ivn[U], a4x[U], a5n[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int j = n - 2 - u;
@@ -152,21 +152,21 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
         a4c[u] = j >= 1 ? LU(j, 4) : 0.0;
         a5c[u] = j >= 1 ? LU(j, 5) : 0.0;
     }
-    double xn, xn1;
+    real_t xn, xn1;
     if (fabs(dd) > eps) {
-        const double tt = tmp / dd;
+        const real_t tt = tmp / dd;
         xn = r1 / dd - tt * r0;
     } else {
         xn = 0.0;
     }
-    const double q = a4n * inv;
+    const real_t q = a4n * inv;
     xn1 = r0 * inv - xn * q;
     const bool zero_line = (x0 + x + 1) == g.nx / 2 + 1 && (kz + 1) == g.nz / 2 + 1;
     if (zero_line) { xn = 0.0; xn1 = 0.0; }
     C(n) = xn;
     C(n - 1) = xn1;
     // backward
-    double x1 = xn1, x2 = xn;
+    real_t x1 = xn1, x2 = xn;
     for (int jb = n - 2; jb >= 1; jb -= U) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -179,8 +179,8 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
         for (int u = 0; u < U; u++) {
             const int j = jb - u;
             if (j >= 1) {
-                const double r = C(j);
-                double xv = ivc[u] * (r - a4c[u] * x1 - a5c[u] * x2);
+                const real_t r = C(j);
+                real_t xv = ivc[u] * (r - a4c[u] * x1 - a5c[u] * x2);
                 if (zero_line) xv = 0.0;
                 C(j) = xv;
                 x2 = x1; x1 = xv;
@@ -198,17 +198,17 @@ __device__ __forceinline__ void y010_penta(double2 *__restrict__ sm, const Y010A
 // (x = t & 7, R = (t >> 3) + 64 h, h = 0 .. 3) of every diagonal: one 64-byte segment per row.
 // A slot = 8 doubles, 8 more between the two systems (their chains read rows R and R + n together).
 // One wave runs the 32 chains and nothing else runs beside it in the workgroup: the loops are written for a short
-// instruction stream (constant strides, a chunk's operands requested together, no register double buffer).
+// instruction stream (constant strides, a chunk's operands requested together, no register real_t buffer).
 #define Y010_LD (256 * 8 + 16)  // doubles per staged diagonal (MODE 3: all rows of 2 diagonals)
 #define Y010_LH (128 * 8 + 16)  // MODE 4: half the rows of 3 diagonals at a time
 
 struct Y010Chain {
     int x, s;
-    double *pd;  // row 1 of this chain's component of column x in the tile (rows 16 inc bytes apart)
+    real_t *pd;  // row 1 of this chain's component of column x in the tile (rows 16 inc bytes apart)
     bool on, zero_line;
 };
 template <bool SYM>
-__device__ __forceinline__ Y010Chain y010_chain(double2 *__restrict__ sm, const Y010Arg &g, int kz, int x0, int lane, int wave)
+__device__ __forceinline__ Y010Chain y010_chain(real2_t *__restrict__ sm, const Y010Arg &g, int kz, int x0, int lane, int wave)
 {
     Y010Chain c;
     c.x = lane & 7;
@@ -218,7 +218,7 @@ __device__ __forceinline__ Y010Chain y010_chain(double2 *__restrict__ sm, const 
 #else
     c.on = wave == 0 && lane < 32 && c.s < (SYM ? 2 : 1);
 #endif
-    c.pd = reinterpret_cast<double *>(sm + c.x * Y010_P) + ((lane >> 3) & 1) + 2 * c.s;
+    c.pd = reinterpret_cast<real_t *>(sm + c.x * Y010_P) + ((lane >> 3) & 1) + 2 * c.s;
     c.zero_line = (x0 + c.x + 1) == g.nx / 2 + 1 && (kz + 1) == g.nz / 2 + 1;
     return c;
 }
@@ -226,15 +226,15 @@ __device__ __forceinline__ Y010Chain y010_chain(double2 *__restrict__ sm, const 
 // forward sweep + the last two rows; lf = [2][Y010_LD]: diagonal 1 (m2), diagonal 2 (m1); tl = LU(n-1,2), LU(n,3),
 // LU(n-1,3), LU(n-1,4) of this chain (loaded by the caller at kernel start)
 template <bool SYM>
-__device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const double *__restrict__ lf, const double (&tl)[4])
+__device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const real_t *__restrict__ lf, const real_t (&tl)[4])
 {
     constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;  // RS: doubles between a chain's rows in the tile
-    const double *__restrict__ m2p = lf + (c.s * n) * 8 + c.s * 8 + c.x;  // row j at m2p[(j - 1) * 8]
-    const double *__restrict__ m1p = m2p + Y010_LD;
-    double *__restrict__ cp = c.pd;  // row j at cp[(j - 1) * RS]
-    double r0 = cp[0], r1 = cp[RS];
+    const real_t *__restrict__ m2p = lf + (c.s * n) * 8 + c.s * 8 + c.x;  // row j at m2p[(j - 1) * 8]
+    const real_t *__restrict__ m1p = m2p + Y010_LD;
+    real_t *__restrict__ cp = c.pd;  // row j at cp[(j - 1) * RS]
+    real_t r0 = cp[0], r1 = cp[RS];
     for (int jb = 1; jb <= n - 2; jb += U) {
-        double m1c[U], m2c[U], r2c[U];
+        real_t m1c[U], m2c[U], r2c[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (jb + u <= n - 2) {
@@ -246,7 +246,7 @@ __device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const double *
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (jb + u <= n - 2) {
-                double r2 = r2c[u];
+                real_t r2 = r2c[u];
                 r1 = r1 - m1c[u] * r0;
                 r2 = r2 - m2c[u] * r0;
                 cp[u * RS] = r0;
@@ -256,16 +256,16 @@ __device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const double *
         m2p += U * 8; m1p += U * 8; cp += U * RS;
     }
     cp = c.pd;
-    const double eps = 1.e-16;
-    const double tmp = tl[0], dd = tl[1], inv = tl[2], a4n = tl[3];
-    double xn, xn1;
+    const real_t eps = 1.e-16;
+    const real_t tmp = tl[0], dd = tl[1], inv = tl[2], a4n = tl[3];
+    real_t xn, xn1;
     if (fabs(dd) > eps) {
-        const double tt = tmp / dd;
+        const real_t tt = tmp / dd;
         xn = r1 / dd - tt * r0;
     } else {
         xn = 0.0;
     }
-    const double q = a4n * inv;
+    const real_t q = a4n * inv;
     xn1 = r0 * inv - xn * q;
     if (c.zero_line) { xn = 0.0; xn1 = 0.0; }
     cp[(n - 1) * RS] = xn;
@@ -275,15 +275,15 @@ __device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const double *
 // rows jhi .. jlo (descending) of the backward sweep; lb = [3][Y010_LH]: diagonals 3 (1/a3), 4, 5 of the rows
 // jbase + 1 .. jbase + n/2 (slot = s n/2 + j - jbase - 1); x1, x2 carried by the caller
 template <bool SYM>
-__device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const double *__restrict__ lb, int jhi, int jlo, int jbase,
-                                              double &x1, double &x2)
+__device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const real_t *__restrict__ lb, int jhi, int jlo, int jbase,
+                                              real_t &x1, real_t &x2)
 {
     constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
-    const double *__restrict__ ivp = lb + (c.s * (n / 2) + jhi - jbase - 1) * 8 + c.s * 8 + c.x;  // row jhi - u at ivp[-u * 8]
-    const double *__restrict__ a4p = ivp + Y010_LH, *__restrict__ a5p = ivp + 2 * Y010_LH;
-    double *__restrict__ cp = c.pd + (jhi - 1) * RS;
+    const real_t *__restrict__ ivp = lb + (c.s * (n / 2) + jhi - jbase - 1) * 8 + c.s * 8 + c.x;  // row jhi - u at ivp[-u * 8]
+    const real_t *__restrict__ a4p = ivp + Y010_LH, *__restrict__ a5p = ivp + 2 * Y010_LH;
+    real_t *__restrict__ cp = c.pd + (jhi - 1) * RS;
     for (int jb = jhi; jb >= jlo; jb -= U) {
-        double ivc[U], a4c[U], a5c[U], rc[U];
+        real_t ivc[U], a4c[U], a5c[U], rc[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (jb - u >= jlo) {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const double *
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (jb - u >= jlo) {
-                double xv = ivc[u] * (rc[u] - a4c[u] * x1 - a5c[u] * x2);
+                real_t xv = ivc[u] * (rc[u] - a4c[u] * x1 - a5c[u] * x2);
                 if (c.zero_line) xv = 0.0;
                 cp[-u * RS] = xv;
                 x2 = x1; x1 = xv;
@@ -307,29 +307,29 @@ __device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const double *
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const double2 *__restrict__ twg, Y010Arg g)
+__global__ void __launch_bounds__(512) k_y010(real2_t *__restrict__ c, const real2_t *__restrict__ twg, Y010Arg g)
 {
     constexpr int ny = 256;
-    extern __shared__ double2 sm[];  // [8][Y010_P] + 256 twiddles
-    double2 *__restrict__ tws = sm + 8 * Y010_P;
+    extern __shared__ real2_t sm[];  // [8][Y010_P] + 256 twiddles
+    real2_t *__restrict__ tws = sm + 8 * Y010_P;
     if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntx = g.nxs / 8;
     const int kz = blockIdx.x / ntx, x0 = (blockIdx.x % ntx) * 8;
-    double2 *__restrict__ base = c + (size_t)kz * ny * g.nxs + x0;
+    real2_t *__restrict__ base = c + (size_t)kz * ny * g.nxs + x0;
     const int tx = threadIdx.x & 7, tr = threadIdx.x >> 3;  // 64 rows per pass
     // MODES 3 / 4: this thread's share of the factored operator, requested first (in flight during the transforms)
-    double *__restrict__ lst = reinterpret_cast<double *>(tws + 256);
+    real_t *__restrict__ lst = reinterpret_cast<real_t *>(tws + 256);
     constexpr int ND = MODE == 3 ? 2 : 3;
-    double lreg[MODE >= 3 ? ND * 4 : 1];
-    double tl[4] = {0.0, 0.0, 0.0, 0.0};
+    real_t lreg[MODE >= 3 ? ND * 4 : 1];
+    real_t tl[4] = {0.0, 0.0, 0.0, 0.0};
     const int inc_ = g.sym ? 2 : 1, n_ = ny / inc_;
     const size_t ds_ = (size_t)g.nz * n_ * g.nxs;
     if constexpr (MODE >= 3) {
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int R = tr + 64 * h, s_ = R / n_, j = R % n_ + 1;
-            const double *__restrict__ lu = s_ ? g.lu1 : g.lu0;
+            const real_t *__restrict__ lu = s_ ? g.lu1 : g.lu0;
 #pragma unroll
             for (int d = 0; d < ND; d++) {
                 const int diag = MODE == 3 ? d : d + 2;  // (0-based: 0 m2, 1 m1, 2 1/a3, 3 a4, 4 a5)
@@ -337,8 +337,8 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
             }
         }
         if (MODE == 3 && wave == 0 && lane < 32 && ((lane >> 4) & 1) < (g.sym ? 2 : 1)) {
-            const double *__restrict__ lu = ((lane >> 4) & 1) ? g.lu1 : g.lu0;
-            const double *__restrict__ lb_ = lu + (size_t)kz * n_ * g.nxs + x0 + (lane & 7);
+            const real_t *__restrict__ lu = ((lane >> 4) & 1) ? g.lu1 : g.lu0;
+            const real_t *__restrict__ lb_ = lu + (size_t)kz * n_ * g.nxs + x0 + (lane & 7);
             tl[0] = lb_[(size_t)1 * ds_ + (size_t)(n_ - 2) * g.nxs];  // LU(n-1, 2)
             tl[1] = lb_[(size_t)2 * ds_ + (size_t)(n_ - 1) * g.nxs];  // LU(n, 3)
             tl[2] = lb_[(size_t)2 * ds_ + (size_t)(n_ - 2) * g.nxs];  // LU(n-1, 3)
@@ -346,17 +346,17 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
         }
     }
     {
-        double2 v[4];
+        real2_t v[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) v[p] = base[(size_t)(tr + 64 * p) * g.nxs + tx];
 #pragma unroll
         for (int p = 0; p < 4; p++) sm[tx * Y010_P + tr + 64 * p] = v[p];
     }
     __syncthreads();
-    double2 *__restrict__ pen = sm + wave * Y010_P;
+    real2_t *__restrict__ pen = sm + wave * Y010_P;
     const int ig = x0 + wave;
     const Rot rz{g.az[kz], g.bz[kz], (kz + 1) > g.nz / 2 + 1}, rx{g.ax[ig], g.bx[ig], (ig + 1) > g.nx / 2 + 1};
-    double2 a[4];
+    real2_t a[4];
     if (MODE != 1 && MODE != 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) a[k] = pen[lane + 64 * k];
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
         };
         stage(true);
         __syncthreads();
-        double x1 = 0.0, x2 = 0.0;
+        real_t x1 = 0.0, x2 = 0.0;
         auto sweep = [&](auto symt, bool upper) {
             constexpr bool SYM = decltype(symt)::value;
             constexpr int n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
@@ -442,13 +442,13 @@ __global__ void __launch_bounds__(512) k_y010(double2 *__restrict__ c, const dou
     for (int p = 0; p < 4; p++) base[(size_t)(tr + 64 * p) * g.nxs + tx] = sm[tx * Y010_P + tr + 64 * p];
 }
 
-const double2 *x3d_fft512_twiddles();
+const real2_t *x3d_fft512_twiddles();
 int x3d_fft512_init();
 
 // c[nz][256][nxs], x and z already transformed (mode 0, 2) / still transformed (mode 1, 2).  tables = ax bx ay by az bz
 // back to back (global lengths nx nx ny ny nz nz).  *done = false: not served (other ny, odd row pitch)
-int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, int mode, const double *tables, int sym,
-                 double *const lu[2], bool *done)
+int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, int mode, const real_t *tables, int sym,
+                 real_t *const lu[2], bool *done)
 {
     *done = false;
     if (ny != 256 || nxs % 8 != 0 || nx % 2 != 0) return 0;
@@ -458,7 +458,7 @@ int x3d_y010_run(x3d_backend *b, double2 *c, int nxs, int nx, int ny, int nz, in
     g.ax = tables; g.bx = g.ax + nx; g.ay = g.bx + nx; g.by = g.ay + ny; g.az = g.by + ny; g.bz = g.az + nz;
     g.lu0 = lu ? lu[0] : nullptr; g.lu1 = lu ? lu[1] : nullptr;
     g.nxs = nxs; g.nz = nz; g.nx = nx; g.sym = sym;
-    const size_t lds = sizeof(double2) * (8 * Y010_P + 256) + sizeof(double) * (mode == 3 ? 2 * Y010_LD : (mode == 4 ? 3 * Y010_LH : 0));
+    const size_t lds = sizeof(real2_t) * (8 * Y010_P + 256) + sizeof(real_t) * (mode == 3 ? 2 * Y010_LD : (mode == 4 ? 3 * Y010_LH : 0));
     const dim3 grid((unsigned)((size_t)nz * (nxs / 8)));
 #define GO(M_)                                                                                          \
     do {                                                                                               \

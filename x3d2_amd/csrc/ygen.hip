@@ -25,9 +25,9 @@ template <int Q> struct GenGeom {
 
 // one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
 // (T = V2: two right-hand sides of the SAME operator in one solve -- every table value read from LDS serves both)
-template <int Q, bool NARROW, class T = double>
-__device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const double *__restrict__ lt,
-                                          const double *__restrict__ cs, const XOp &t, int &lane)
+template <int Q, bool NARROW, class T = real_t>
+__device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const real_t *__restrict__ lt,
+                                          const real_t *__restrict__ cs, const XOp &t, int &lane)
 {
     const int first = lane * Q + 1, n = t.n_tds;
     T X[Q], du1, xn;
@@ -40,7 +40,7 @@ __device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const 
     for (int q = 0; q < Q; q++) {
         const int j = first + q;
         int &lq = la[q & 1];
-        const double st = lt_read(lt, LT_ST(q) * 64 + lq);
+        const real_t st = lt_read(lt, LT_ST(q) * 64 + lq);
         T x = (X[q] - lt_read(lt, LT_SA(q) * 64 + lq) * du_s - lt_read(lt, LT_SC(q) * 64 + lq) * du_e) * st;
         if (q == 0) x = sel_of(lane == 0, du_s * st, x);  // (row 1)
         x = sel_of(j == n, du_e * st, x);
@@ -52,7 +52,7 @@ __device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const 
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int j = first + q;
-        const double st = LTR(lt, LT_ST(q));
+        const real_t st = LTR(lt, LT_ST(q));
         T x = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
         if (q == 0) x = sel_of(lane == 0, du_s * st, x);  // (row 1)
         x = sel_of(j == n, du_e * st, x);
@@ -65,21 +65,21 @@ __device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const 
 // the pieces every kernel below shares (tile <-> memory, tile <-> registers)
 template <int Q> struct GenTile {
     using G = GenGeom<Q>;
-    double *tile;
+    real_t *tile;
     int wave, lane, cy, cc, nrow;
     long prow;
     // rows cy + 128 i of the 16-wide segment pair cc; rows >= nrow do not exist
-    __device__ __forceinline__ void gload(double (&v)[2 * G::NI], const double *__restrict__ src) const
+    __device__ __forceinline__ void gload(real_t (&v)[2 * G::NI], const real_t *__restrict__ src) const
     {
 #pragma unroll
         for (int i = 0; i < G::NI; i++) {
-            double2 t = make_double2(0.0, 0.0);
-            if (cy + 128 * i < nrow) t = *reinterpret_cast<const double2 *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+            real2_t t = make_real2(0.0, 0.0);
+            if (cy + 128 * i < nrow) t = *reinterpret_cast<const real2_t *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
             v[2 * i] = t.x;
             v[2 * i + 1] = t.y;
         }
     }
-    __device__ __forceinline__ void to_tile(const double (&v)[2 * G::NI]) const
+    __device__ __forceinline__ void to_tile(const real_t (&v)[2 * G::NI]) const
     {
 #pragma unroll
         for (int i = 0; i < G::NI; i++) {
@@ -90,44 +90,44 @@ template <int Q> struct GenTile {
         }
     }
     // this lane's window: rows first-4 .. first+Q+3 = tile entries lane Q .. lane Q + Q + 7 of the wave's pencil
-    __device__ __forceinline__ void window(double (&w)[Q + 8]) const
+    __device__ __forceinline__ void window(real_t (&w)[Q + 8]) const
     {
         if constexpr (Q % 2 == 0) {
-            const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(tile + wave * G::TP + lane * Q);
+            const real2_t *__restrict__ s2 = reinterpret_cast<const real2_t *>(tile + wave * G::TP + lane * Q);
 #pragma unroll
             for (int m = 0; m < (Q + 8) / 2; m++) {
-                const double2 t = s2[m];
+                const real2_t t = s2[m];
                 w[2 * m] = t.x;
                 w[2 * m + 1] = t.y;
             }
         } else {  // odd Q: the window starts on an 8-byte boundary only (lane stride 40 B at Q = 5: conflict-free)
-            const double *__restrict__ s1 = tile + wave * G::TP + lane * Q;
+            const real_t *__restrict__ s1 = tile + wave * G::TP + lane * Q;
 #pragma unroll
             for (int m = 0; m < Q + 8; m++) w[m] = lt_read(s1, m);
         }
     }
-    __device__ __forceinline__ void put(const double (&r)[Q]) const
+    __device__ __forceinline__ void put(const real_t (&r)[Q]) const
     {
         if constexpr (Q % 2 == 0) {
-            double2 *__restrict__ d2 = reinterpret_cast<double2 *>(tile + wave * G::TP + 4 + lane * Q);
+            real2_t *__restrict__ d2 = reinterpret_cast<real2_t *>(tile + wave * G::TP + 4 + lane * Q);
 #pragma unroll
-            for (int m = 0; m < Q / 2; m++) d2[m] = make_double2(r[2 * m], r[2 * m + 1]);
+            for (int m = 0; m < Q / 2; m++) d2[m] = make_real2(r[2 * m], r[2 * m + 1]);
         } else {
-            double *__restrict__ d1 = tile + wave * G::TP + 4 + lane * Q;
+            real_t *__restrict__ d1 = tile + wave * G::TP + 4 + lane * Q;
 #pragma unroll
             for (int m = 0; m < Q; m++) d1[m] = r[m];
         }
     }
     // rows < nout of the tile -> memory; ACC: out = old + r with the old rows already in registers (gload)
     template <bool ACC>
-    __device__ __forceinline__ void from_tile(double *__restrict__ o, int nout, const double (&old)[2 * G::NI]) const
+    __device__ __forceinline__ void from_tile(real_t *__restrict__ o, int nout, const real_t (&old)[2 * G::NI]) const
     {
 #pragma unroll
         for (int i = 0; i < G::NI; i++) {
             if (cy + 128 * i < nout) {
-                double2 v = make_double2(tile[(2 * cc) * G::TP + 4 + cy + 128 * i], tile[(2 * cc + 1) * G::TP + 4 + cy + 128 * i]);
+                real2_t v = make_real2(tile[(2 * cc) * G::TP + 4 + cy + 128 * i], tile[(2 * cc + 1) * G::TP + 4 + cy + 128 * i]);
                 if (ACC) { v.x += old[2 * i]; v.y += old[2 * i + 1]; }
-                *reinterpret_cast<double2 *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
+                *reinterpret_cast<real2_t *>(o + (long)(cy + 128 * i) * prow + 2 * cc) = v;
             }
         }
     }
@@ -138,18 +138,18 @@ template <int Q> struct GenTile {
 // (the pairs of divergence_v2c / gradient_c2v, src/vector_calculus.f90:142-332, as in k_ytile_tds_pair)
 template <int Q, int MODE, bool NARROW>
 __global__ void __launch_bounds__(1024)
-    k_ygen_pair(double *out1, double *out2, const double *__restrict__ in1, const double *__restrict__ in2, XOp ta, XOp tb,
+    k_ygen_pair(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2, XOp ta, XOp tb,
                 int ntx, int ntiles, long prow, long pplane, int nrow, int permn)
 {
     using G = GenGeom<Q>;
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = ta.TL[i];
         if (MODE != 2) lt[LN + i] = tb.TL[i];
     }
-    double *tile = lt + (MODE == 2 ? 1 : 2) * LN;
-    double *cs = tile + 16 * G::TP;
+    real_t *tile = lt + (MODE == 2 ? 1 : 2) * LN;
+    real_t *cs = tile + 16 * G::TP;
     for (int i = threadIdx.x; i < 16 * G::TP; i += blockDim.x) tile[i] = 0.0;
     stage_cs<Q>(cs, ta);
     if (MODE != 2) stage_cs<Q>(cs + CS_N(Q), tb);
@@ -165,13 +165,13 @@ __global__ void __launch_bounds__(1024)
     };
     auto in1_off = [&](int tl) { return MODE == 1 ? tile_off_p(tl) : tile_off(tl); };
     __syncthreads();
-    double nxt[2 * G::NI];  // next tile's in1 rows, in flight during the solves
+    real_t nxt[2 * G::NI];  // next tile's in1 rows, in flight during the solves
     if ((int)blockIdx.x < ntiles) T.gload(nxt, in1 + in1_off(blockIdx.x));
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         asm volatile("" : "+v"(lane));
-        double w[Q + 8], ra[Q], rb[Q], g2[2 * G::NI];
-        const double none[2 * G::NI] = {};
+        real_t w[Q + 8], ra[Q], rb[Q], g2[2 * G::NI];
+        const real_t none[2 * G::NI] = {};
         if (MODE == 0) T.gload(g2, in2 + off);
         T.to_tile(nxt);
         __syncthreads();
@@ -214,9 +214,9 @@ __global__ void __launch_bounds__(1024)
 // and last row reaches 3: the channel case runs <.., false, true>)
 template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW>
 __global__ void __launch_bounds__(1024)
-    k_ygen_transeq3(double *rhs0, double *rhs1, double *rhs2, const double *__restrict__ u0, const double *__restrict__ u1,
-                    const double *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
-                    double nu)
+    k_ygen_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0, const real_t *__restrict__ u1,
+                    const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
+                    real_t nu)
 {
     using G = GenGeom<Q>;
     // the first two solves of a component as one solve over the pair type where that fits the 128 registers
@@ -227,15 +227,15 @@ __global__ void __launch_bounds__(1024)
     constexpr bool P12 = false;
 #endif
     constexpr bool LATE = P12 && Q <= 5;  // where the rows the result is added to are requested (register budget)
-    extern __shared__ double lt[];
+    extern __shared__ real_t lt[];
     constexpr int LN = LT_N(Q) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = tD1.TL[i];
         lt[LN + i] = tD2.TL[i];
     }
-    const double *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
-    double *tile = lt + 2 * LN;
-    double *cs = tile + 16 * G::TP;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    real_t *tile = lt + 2 * LN;
+    real_t *cs = tile + 16 * G::TP;
     for (int i = threadIdx.x; i < 16 * G::TP; i += blockDim.x) tile[i] = 0.0;
     stage_cs<Q>(cs, tD1);
     stage_cs<Q>(cs + CS_N(Q), tD2);
@@ -244,33 +244,33 @@ __global__ void __launch_bounds__(1024)
                  nrow, prow};
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
     __syncthreads();
-    double nxt[2 * G::NI];  // the rows needed next (next component's field, or the next tile's u0)
+    real_t nxt[2 * G::NI];  // the rows needed next (next component's field, or the next tile's u0)
     if ((int)blockIdx.x < ntiles) T.gload(nxt, u0 + tile_off(blockIdx.x));
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
-        double cb[Q];  // this pencil's rows of the advecting velocity
+        real_t cb[Q];  // this pencil's rows of the advecting velocity
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             asm volatile("" : "+v"(lane));
-            double r[Q], X[Q];
+            real_t r[Q], X[Q];
             T.to_tile(nxt);
             __syncthreads();
             {
                 const int tn = tl + gridDim.x;
-                const double *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
+                const real_t *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
                 if (c < 2 || tn < ntiles) T.gload(nxt, nsrc);
             }
             // the rows this component is added to: requested now, used after the three solves (the memory system
             // works during the arithmetic instead of after it)
-            double *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
-            double old[2 * G::NI] = {};
+            real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+            real_t old[2 * G::NI] = {};
             if (ACC && !LATE) T.gload(old, o);  // (LATE: after the pair solve, whose two windows need the registers)
             if constexpr (P12) {
                 // d(u conv) and du: the same operator on two right-hand sides -- ONE solve over the pair type (round 4:
                 // the kernel is bound by the rate of its LDS read instructions; 245 -> 178 per lane and component)
                 V2 w2[Q + 8], X2[Q];
                 {
-                    double wu[Q + 8], wc[Q + 8];
+                    real_t wu[Q + 8], wc[Q + 8];
                     T.window(wu);
                     if (c == 0) {
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(1024)
             {
                 // d(u conv): the product window; the field's own window is read again from the tile afterwards
                 // (it stays there until the result is put back) instead of living through this solve
-                double wp[Q + 8], wc[Q + 8];
+                real_t wp[Q + 8], wc[Q + 8];
                 T.window(wp);
                 if (c == 0) {
 #pragma unroll
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(1024)
             for (int q = 0; q < Q; q++) r[q] = X[q];
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             {
-                double wu[Q + 8];
+                real_t wu[Q + 8];
                 T.window(wu);
                 gen_solve<Q, NARROW1>(wu, X, l1, cs, tD1, lane);  // du
             }
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(1024)
             if (ACC && LATE) T.gload(old, o);
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             {
-                double wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
+                real_t wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
                 T.window(wu);
                 gen_solve<Q, NARROW>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
             }
@@ -379,7 +379,7 @@ static GenLaunch gen_launch(const x3d_backend *b, int dir)
 }
 
 // operator pair (mode 0 / 1) or single operator (mode 2) along y or z; *done = false: not served here
-int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2, const double *in1, const double *in2,
+int x3d_ygen_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                   const x3d_tdsops *ta, const x3d_tdsops *tb, bool *done)
 {
     *done = false;
@@ -387,7 +387,7 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
     const x3d_tdsops *const ops[2] = {ta, mode == 2 ? ta : tb};
     const int Q = gen_q(b, dir, ops, 2);
     if (!gen_ok(b, dir, ta, Q) || (mode != 2 && !gen_ok(b, dir, tb, Q))) return 0;
-    const size_t lds = sizeof(double) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    const size_t lds = sizeof(real_t) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
     const x3d_tdsops *tb_ = mode == 2 ? ta : tb;
@@ -416,7 +416,7 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, double *out1, double *out2,
 }
 
 // transeq of direction y or z in one launch; f[0] is the advecting component
-int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double *const f[3], double nu,
+int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
                       const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                       const x3d_tdsops *der2nd_sym, int acc, bool *done)
 {
@@ -430,7 +430,7 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, double *const r[3], const double 
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     if (der1st->n_tds != der2nd->n_tds) return 0;
     // (tl_hash covers the lane tables and the boundary / bulk stencils: tds.hip)
-    const size_t lds = sizeof(double) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
     const bool narrow1 = der1st->narrow_all, narrow = narrow1 && der2nd->narrow_all;

@@ -10,18 +10,18 @@
 // Spectrum in this form: C[kz][y][x], kz = 0 .. 256 (the half axis is z instead of x), rows of `px` complex numbers.
 // A tile = 16 x-adjacent z pencils of one y: two real pencils a, b go through ONE complex transform z = a + i b
 // (a wave per pair, csrc/fft512_core.h):  A_k = (Z_k + conj Z_{512-k}) / 2,  B_k = (Z_k - conj Z_{512-k}) / (2 i).
-// LDS `area`: 73728 B = the real tile [16][TP] (TP = 516), later the 8 waves' transform regions (576 double2 each),
+// LDS `area`: 73728 B = the real tile [16][TP] (TP = 516), later the 8 waves' transform regions (576 real2_t each),
 // later the transposed block T2[kz][16] (XOR-swizzled columns: conflict-free for the column writes of a wave and the
 // row reads of the cooperative 256-byte stores).
 #pragma once
 #include "fft512_core.h"
 
-#define ZF_AREA_DOUBLES 9216  // 8 x 576 double2
+#define ZF_AREA_DOUBLES 9216  // 8 x 576 real2_t
 #define ZF_PEN 576
 
 struct ZfArg {
-    double2 *c;         // C[257][ny][px]
-    const double2 *tw;  // W512^k, first half (fft512.hip)
+    real2_t *c;         // C[257][ny][px]
+    const real2_t *tw;  // W512^k, first half (fft512.hip)
     int ny;
     long px;
 };
@@ -36,19 +36,19 @@ __device__ __forceinline__ int zf_t2(int m, int x) { return m * 16 + (x ^ (m & 1
 // X_k = E_k + W512^k O_k (k = 0 .. 255),  X_256 = E_0 - O_0.  Four radix-4 stages exchange 24 KB per real pencil through
 // LDS where the 512-point radix-8 form below exchanges 16 KB, and the transform phase is LDS-bandwidth bound.
 template <int TP>
-__device__ __forceinline__ void zf_forward(double *__restrict__ area, const double2 *__restrict__ tws,
-                                           double2 *__restrict__ crow, long kzstride, int wave, int lane)
+__device__ __forceinline__ void zf_forward(real_t *__restrict__ area, const real2_t *__restrict__ tws,
+                                           real2_t *__restrict__ crow, long kzstride, int wave, int lane)
 {
-    double2 a[4], X[4], X256 = make_double2(0.0, 0.0);
-    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    real2_t a[4], X[4], X256 = make_real2(0.0, 0.0);
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
     {
-        const double2 *__restrict__ pa = reinterpret_cast<const double2 *>(area + wave * TP);
+        const real2_t *__restrict__ pa = reinterpret_cast<const real2_t *>(area + wave * TP);
 #pragma unroll
         for (int k = 0; k < 4; k++) a[k] = pa[lane + 64 * k];
     }
     __syncthreads();  // (the transform regions overlap other waves' pencils)
     {
-        double2 *__restrict__ pen = T2 + wave * FP256;
+        real2_t *__restrict__ pen = T2 + wave * FP256;
         fft256_wave<-1>(a, pen, tws, lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) pen[lane + 64 * k] = a[k];
@@ -56,11 +56,11 @@ __device__ __forceinline__ void zf_forward(double *__restrict__ area, const doub
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int idx = lane + 64 * k;
-            const double2 z = a[k], c = pen[(256 - idx) & 255];
-            const double2 E = make_double2(0.5 * (z.x + c.x), 0.5 * (z.y - c.y));
-            const double2 O = make_double2(0.5 * (z.y + c.y), -0.5 * (z.x - c.x));
+            const real2_t z = a[k], c = pen[(256 - idx) & 255];
+            const real2_t E = make_real2(0.5 * (z.x + c.x), 0.5 * (z.y - c.y));
+            const real2_t O = make_real2(0.5 * (z.y + c.y), -0.5 * (z.x - c.x));
             X[k] = cadd(E, cmul(twiddle<-1>(tws, idx), O));
-            if (k == 0 && lane == 0) X256 = make_double2(E.x - O.x, 0.0);
+            if (k == 0 && lane == 0) X256 = make_real2(E.x - O.x, 0.0);
         }
     }
     __syncthreads();
@@ -78,19 +78,19 @@ __device__ __forceinline__ void zf_forward(double *__restrict__ area, const doub
 }
 #else
 template <int TP>
-__device__ __forceinline__ void zf_forward(double *__restrict__ area, const double2 *__restrict__ tws,
-                                           double2 *__restrict__ crow, long kzstride, int wave, int lane)
+__device__ __forceinline__ void zf_forward(real_t *__restrict__ area, const real2_t *__restrict__ tws,
+                                           real2_t *__restrict__ crow, long kzstride, int wave, int lane)
 {
-    double2 a[8], A[5], B[5];
-    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    real2_t a[8], A[5], B[5];
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
     if (wave < 8) {
-        const double *__restrict__ pa = area + (2 * wave) * TP, *__restrict__ pb = pa + TP;
+        const real_t *__restrict__ pa = area + (2 * wave) * TP, *__restrict__ pb = pa + TP;
 #pragma unroll
-        for (int k = 0; k < 8; k++) a[k] = make_double2(pa[lane + 64 * k], pb[lane + 64 * k]);
+        for (int k = 0; k < 8; k++) a[k] = make_real2(pa[lane + 64 * k], pb[lane + 64 * k]);
     }
     __syncthreads();  // (the transform regions overlap other waves' pencils)
     if (wave < 8) {
-        double2 *__restrict__ pen = T2 + wave * ZF_PEN;
+        real2_t *__restrict__ pen = T2 + wave * ZF_PEN;
         fft512_wave<-1>(a, pen, tws, lane);
 #pragma unroll
         for (int k = 0; k < 8; k++) pen[lane + 64 * k] = a[k];
@@ -99,9 +99,9 @@ __device__ __forceinline__ void zf_forward(double *__restrict__ area, const doub
         for (int k = 0; k < 5; k++) {
             const int idx = lane + 64 * k;
             if (k < 4 || lane == 0) {
-                const double2 x = a[k], y = pen[(512 - idx) & 511];
-                A[k] = make_double2(0.5 * (x.x + y.x), 0.5 * (x.y - y.y));
-                B[k] = make_double2(0.5 * (x.y + y.y), -0.5 * (x.x - y.x));
+                const real2_t x = a[k], y = pen[(512 - idx) & 511];
+                A[k] = make_real2(0.5 * (x.x + y.x), 0.5 * (x.y - y.y));
+                B[k] = make_real2(0.5 * (x.y + y.y), -0.5 * (x.x - y.x));
             }
         }
     }
@@ -129,11 +129,11 @@ __device__ __forceinline__ void zf_forward(double *__restrict__ area, const doub
 #endif
 
 // the tile's 257 x 16 modes into registers (issued early: they are in flight while the previous tile is worked on)
-struct ZfRows { double2 v0, v1, v2, v3, v4; };
-__device__ __forceinline__ ZfRows zf_inverse_load(const double2 *__restrict__ crow, long kzstride)
+struct ZfRows { real2_t v0, v1, v2, v3, v4; };
+__device__ __forceinline__ ZfRows zf_inverse_load(const real2_t *__restrict__ crow, long kzstride)
 {
     const int r = threadIdx.x >> 4, x = threadIdx.x & 15;
-    const double2 *__restrict__ p = crow + (long)r * kzstride + x;
+    const real2_t *__restrict__ p = crow + (long)r * kzstride + x;
     ZfRows v;
     v.v0 = p[0]; v.v1 = p[64 * kzstride]; v.v2 = p[128 * kzstride]; v.v3 = p[192 * kzstride];
     v.v4 = p[threadIdx.x < 16 ? 256 * kzstride : 0];  // (row 256: 16 threads; the others repeat their first load)
@@ -147,10 +147,10 @@ __device__ __forceinline__ ZfRows zf_inverse_load(const double2 *__restrict__ cr
 // every wave: Z_k = E_k + i O_k with E_k = X_k + conj X_{256-k}, O_k = (X_k - conj X_{256-k}) W512^{-k} (the factor 2 of
 // the 256-point transform folded in: the result is the unnormalised inverse, 512 x the pencil)
 template <int TP>
-__device__ __forceinline__ void zf_inverse(double *__restrict__ area, const double2 *__restrict__ tws,
+__device__ __forceinline__ void zf_inverse(real_t *__restrict__ area, const real2_t *__restrict__ tws,
                                            const ZfRows &v, int wave, int lane)
 {
-    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
     const int r = threadIdx.x >> 4, x = threadIdx.x & 15;
     T2[zf_t2(r, x)] = v.v0;
     T2[zf_t2(r + 64, x)] = v.v1;
@@ -158,20 +158,20 @@ __device__ __forceinline__ void zf_inverse(double *__restrict__ area, const doub
     T2[zf_t2(r + 192, x)] = v.v3;
     if (threadIdx.x < 16) T2[zf_t2(256, x)] = v.v4;
     __syncthreads();
-    double2 a[4];
+    real2_t a[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int m = lane + 64 * k;
-        const double2 X = T2[zf_t2(m, wave)], C = T2[zf_t2(256 - m, wave)];
-        const double2 E = make_double2(X.x + C.x, X.y - C.y), D = make_double2(X.x - C.x, X.y + C.y);
-        const double2 O = cmul(D, twiddle<1>(tws, m));
-        a[k] = make_double2(E.x - O.y, E.y + O.x);
+        const real2_t X = T2[zf_t2(m, wave)], C = T2[zf_t2(256 - m, wave)];
+        const real2_t E = make_real2(X.x + C.x, X.y - C.y), D = make_real2(X.x - C.x, X.y + C.y);
+        const real2_t O = cmul(D, twiddle<1>(tws, m));
+        a[k] = make_real2(E.x - O.y, E.y + O.x);
     }
     __syncthreads();
     fft256_wave<1>(a, T2 + wave * FP256, tws, lane);
     __syncthreads();
     {
-        double2 *__restrict__ pa = reinterpret_cast<double2 *>(area + wave * TP);
+        real2_t *__restrict__ pa = reinterpret_cast<real2_t *>(area + wave * TP);
 #pragma unroll
         for (int k = 0; k < 4; k++) pa[lane + 64 * k] = a[k];
     }
@@ -179,10 +179,10 @@ __device__ __forceinline__ void zf_inverse(double *__restrict__ area, const doub
 }
 #else
 template <int TP>
-__device__ __forceinline__ void zf_inverse(double *__restrict__ area, const double2 *__restrict__ tws,
+__device__ __forceinline__ void zf_inverse(real_t *__restrict__ area, const real2_t *__restrict__ tws,
                                            const ZfRows &v, int wave, int lane)
 {
-    double2 *__restrict__ T2 = reinterpret_cast<double2 *>(area);
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
     const int r = threadIdx.x >> 4, x = threadIdx.x & 15;
     T2[zf_t2(r, x)] = v.v0;
     T2[zf_t2(r + 64, x)] = v.v1;
@@ -190,21 +190,21 @@ __device__ __forceinline__ void zf_inverse(double *__restrict__ area, const doub
     T2[zf_t2(r + 192, x)] = v.v3;
     if (threadIdx.x < 16) T2[zf_t2(256, x)] = v.v4;
     __syncthreads();
-    double2 a[8];
+    real2_t a[8];
     if (wave < 8) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int m = lane + 64 * k, mm = m <= 256 ? m : 512 - m;
-            double2 A = T2[zf_t2(mm, 2 * wave)], B = T2[zf_t2(mm, 2 * wave + 1)];
+            real2_t A = T2[zf_t2(mm, 2 * wave)], B = T2[zf_t2(mm, 2 * wave + 1)];
             if (m > 256) { A.y = -A.y; B.y = -B.y; }
-            a[k] = make_double2(A.x - B.y, A.y + B.x);
+            a[k] = make_real2(A.x - B.y, A.y + B.x);
         }
     }
     __syncthreads();
     if (wave < 8) fft512_wave<1>(a, T2 + wave * ZF_PEN, tws, lane);
     __syncthreads();
     if (wave < 8) {
-        double *__restrict__ pa = area + (2 * wave) * TP, *__restrict__ pb = pa + TP;
+        real_t *__restrict__ pa = area + (2 * wave) * TP, *__restrict__ pb = pa + TP;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             pa[lane + 64 * k] = a[k].x;

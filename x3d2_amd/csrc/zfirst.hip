@@ -22,20 +22,20 @@
 #define ZH_PX 520  // row pitch of C in complex numbers (512 + 8: consecutive y rows do not share an HBM channel pattern)
 
 int x3d_fft512_init();
-const double2 *x3d_fft512_twiddles();
-int x3d_fft512_run_zh(x3d_backend *b, double2 *c, long px, int kz0, int nkz, const double *rwZ, const double *ab, int nx,
+const real2_t *x3d_fft512_twiddles();
+int x3d_fft512_run_zh(x3d_backend *b, real2_t *c, long px, int kz0, int nkz, const real_t *rwZ, const real_t *ab, int nx,
                       int ny, int nz);
 
 // rwZ[kz][x][y] = -1 / waves(min(x, nx - x), y, kz)  (0 where waves < 1e-16); waves = [nz][ny][nxs] (x: nx/2+1 modes)
 __global__ void __launch_bounds__(256)
-    k_zh_rw(double *__restrict__ rwZ, const double *__restrict__ waves, int nx, int ny, int nxs)
+    k_zh_rw(real_t *__restrict__ rwZ, const real_t *__restrict__ waves, int nx, int ny, int nxs)
 {
-    __shared__ double t[32][33];
+    __shared__ real_t t[32][33];
     const int kz = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         const int x = x0 + tx, y = y0 + r, xm = x <= nx / 2 ? x : nx - x;
-        const double wv = waves[((size_t)kz * ny + y) * nxs + xm];
+        const real_t wv = waves[((size_t)kz * ny + y) * nxs + xm];
         t[r][tx] = wv < 1.e-16 ? 0.0 : -1.0 / wv;
     }
     __syncthreads();
@@ -45,17 +45,17 @@ __global__ void __launch_bounds__(256)
 // complex transform of contiguous rows of 512 (the x axis of C), one row per wave, in place
 template <int S>
 __global__ void __launch_bounds__(512)
-    k_c2c512_x(double2 *__restrict__ c, const double2 *__restrict__ twg, long nrows, long pitch)
+    k_c2c512_x(real2_t *__restrict__ c, const real2_t *__restrict__ twg, long nrows, long pitch)
 {
-    extern __shared__ double2 zx[];  // [8][FP] + 256 twiddles
-    double2 *__restrict__ tws = zx + 8 * FP;
+    extern __shared__ real2_t zx[];  // [8][FP] + 256 twiddles
+    real2_t *__restrict__ tws = zx + 8 * FP;
     if (threadIdx.x < 256) tws[threadIdx.x] = twg[threadIdx.x];
     __syncthreads();
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double2 *__restrict__ pen = zx + w * FP;
+    real2_t *__restrict__ pen = zx + w * FP;
     long row = (long)blockIdx.x * 8 + w;
     const long step = (long)gridDim.x * 8;
-    double2 a[8], nx8[8];
+    real2_t a[8], nx8[8];
     if (row < nrows) {
 #pragma unroll
         for (int k = 0; k < 8; k++) nx8[k] = c[row * pitch + l + 64 * k];
@@ -77,12 +77,12 @@ __global__ void __launch_bounds__(512)
 // forms in k_ytile_tds_pair
 template <bool FWD>
 __global__ void __launch_bounds__(1024)
-    k_ztile_fft(double *__restrict__ f, ZfArg zf, int ntx, int tile0, int ntiles, long prow, long pplane)
+    k_ztile_fft(real_t *__restrict__ f, ZfArg zf, int ntx, int tile0, int ntiles, long prow, long pplane)
 {
     ntiles += tile0;  // tiles [tile0, tile0 + ntiles): a range of y rows (csrc/sfftz.hip)
-    extern __shared__ double zarea[];  // ZF_AREA_DOUBLES + 256 twiddles
+    extern __shared__ real_t zarea[];  // ZF_AREA_DOUBLES + 256 twiddles
     constexpr int TP = 516;
-    double2 *__restrict__ tws = reinterpret_cast<double2 *>(zarea + ZF_AREA_DOUBLES);
+    real2_t *__restrict__ tws = reinterpret_cast<real2_t *>(zarea + ZF_AREA_DOUBLES);
     if (threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
@@ -93,11 +93,11 @@ __global__ void __launch_bounds__(1024)
         v = zf_inverse_load(zf.c + (long)((tile0 + blockIdx.x) / ntx) * zf.px + ((tile0 + blockIdx.x) % ntx) * 16, kzs);
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16;
-        double2 *__restrict__ crow = zf.c + (long)(tl / ntx) * zf.px + (tl % ntx) * 16;
+        real2_t *__restrict__ crow = zf.c + (long)(tl / ntx) * zf.px + (tl % ntx) * 16;
         if (FWD) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const double2 g = *reinterpret_cast<const double2 *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc);
+                const real2_t g = *reinterpret_cast<const real2_t *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc);
                 zarea[(2 * cc) * TP + cy + 128 * i] = g.x;
                 zarea[(2 * cc + 1) * TP + cy + 128 * i] = g.y;
             }
@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(1024)
             if (tn < ntiles) v = zf_inverse_load(zf.c + (long)(tn / ntx) * zf.px + (tn % ntx) * 16, kzs);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                *reinterpret_cast<double2 *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc) =
-                    make_double2(zarea[(2 * cc) * TP + cy + 128 * i], zarea[(2 * cc + 1) * TP + cy + 128 * i]);
+                *reinterpret_cast<real2_t *>(f + off + (long)(cy + 128 * i) * prow + 2 * cc) =
+                    make_real2(zarea[(2 * cc) * TP + cy + 128 * i], zarea[(2 * cc + 1) * TP + cy + 128 * i]);
             __syncthreads();
         }
     }
@@ -138,7 +138,7 @@ int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
     *ok = false;
     if (zfirst_off() || !zfirst_sizes(p)) return 0;
     if (!p->rwZ) {
-        X3D_HIP(hipMalloc(&p->rwZ, sizeof(double) * 257 * 512 * 512));
+        X3D_HIP(hipMalloc(&p->rwZ, sizeof(real_t) * 257 * 512 * 512));
         hipLaunchKernelGGL(k_zh_rw, dim3(16, 16, 257), dim3(256), 0, p->b->stream, p->rwZ, p->waves, p->nx, p->ny, p->nxs);
         X3D_HIP(hipGetLastError());
     }
@@ -165,7 +165,7 @@ extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)
 template <int S>
 static int c2c_x(x3d_poisson *p, int kz0, int nkz)
 {
-    const int lds = sizeof(double2) * (8 * FP + 256);
+    const int lds = sizeof(real2_t) * (8 * FP + 256);
     X3D_LDS_OPTIN(p->b, (k_c2c512_x<S>));
     const long nrows = (long)nkz * p->ny;
     long blocks = (nrows + 7) / 8;
@@ -193,14 +193,14 @@ extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
 }
 
 // the z transform of a block's field, tile by tile (also for csrc/sfftz.hip)
-int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd, int y0, int nyr)
+int x3d_ztile_fft_run(x3d_backend *b, real_t *f, const ZfArg &zf, bool fwd, int y0, int nyr)
 {
     X3D_REQUIRE(b->nz == 512 && b->nx % 16 == 0 && b->ny == zf.ny, "x3d_ztile_fft_run: 512-row z pencils");
     if (nyr < 0) { y0 = 0; nyr = b->ny; }
     X3D_REQUIRE(y0 >= 0 && y0 + nyr <= b->ny, "x3d_ztile_fft_run: rows [%d, %d) of %d", y0, y0 + nyr, b->ny);
     if (nyr == 0) return 0;
     const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
-    const size_t lds = sizeof(double) * (ZF_AREA_DOUBLES + 512);
+    const size_t lds = sizeof(real_t) * (ZF_AREA_DOUBLES + 512);
     const long pxy = (long)b->nxp * b->nyp;
     ProfScope ps(b, X3D_K_FFT, 3);
     if (fwd) {
@@ -214,7 +214,7 @@ int x3d_ztile_fft_run(x3d_backend *b, double *f, const ZfArg &zf, bool fwd, int 
     return 0;
 }
 
-static int ztile(x3d_poisson *p, double *f, bool fwd)
+static int ztile(x3d_poisson *p, real_t *f, bool fwd)
 {
     ZfArg zf;
     bool ok = false;
@@ -224,20 +224,20 @@ static int ztile(x3d_poisson *p, double *f, bool fwd)
 }
 
 // stand-alone ends of the z-first solve: f (cell data of a block) -> C, and back
-extern "C" int x3d_poisson_zfirst_forward(x3d_poisson *p, const double *f_in)
+extern "C" int x3d_poisson_zfirst_forward(x3d_poisson *p, const real_t *f_in)
 {
     X3D_REQUIRE(p && f_in, "x3d_poisson_zfirst_forward: null argument");
     X3D_LAZY_SYNC(p->b);
-    return ztile(p, const_cast<double *>(f_in), true);
+    return ztile(p, const_cast<real_t *>(f_in), true);
 }
-extern "C" int x3d_poisson_zfirst_backward(x3d_poisson *p, double *f_out)
+extern "C" int x3d_poisson_zfirst_backward(x3d_poisson *p, real_t *f_out)
 {
     X3D_REQUIRE(p && f_out, "x3d_poisson_zfirst_backward: null argument");
     X3D_LAZY_SYNC(p->b);
     return ztile(p, f_out, false);
 }
 // poisson_000 through the z-first stages, in place (== x3d_poisson_solve_000 up to rounding)
-extern "C" int x3d_poisson_solve_000_zfirst(x3d_poisson *p, double *f)
+extern "C" int x3d_poisson_solve_000_zfirst(x3d_poisson *p, real_t *f)
 {
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000_zfirst: null argument");
     if (int rc = x3d_poisson_zfirst_forward(p, f)) return rc;

@@ -8,6 +8,7 @@ import os
 
 import torch
 
+from . import _lib
 from .common import DIR_C, DIR_X, DIR_Y, DIR_Z, NULL_LOC, X3dError
 
 
@@ -61,10 +62,10 @@ class Allocator:
         st = self.stagger
         if st:
             off = (self.next_id % 16) * st
-            f = Field(torch.zeros(self.n + 16 * st, dtype=torch.float64, device=self.device)[off:off + self.n],
+            f = Field(torch.zeros(self.n + 16 * st, dtype=_lib.torch_real(), device=self.device)[off:off + self.n],
                       self.next_id, self)
         else:
-            f = Field(torch.zeros(self.n, dtype=torch.float64, device=self.device), self.next_id, self)
+            f = Field(torch.zeros(self.n, dtype=_lib.torch_real(), device=self.device), self.next_id, self)
         if self.lazy is not None:
             lib, h = self.lazy
             if lib.x3d_lazy_register_block(h, f.ptr) != 0:

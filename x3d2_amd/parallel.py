@@ -161,7 +161,8 @@ class Comm:
             return
         if self.link_rate and all(p == self.rank for _, p in sends):
             for (src, _), (dst, _) in zip(sends, recvs):  # (see _start_overlapped)
-                dst.copy_(src)
+                n = min(src.numel(), dst.numel())
+                dst[:n].copy_(src[:n])
             self._link_hold(sends, kind)
             return
         ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
@@ -267,7 +268,8 @@ class Comm:
                 e0.record()
             if self.link_rate and all(p == self.rank for _, p in sends):
                 for (src, _), (dst, _) in zip(sends, recvs):  # (posting order pairs them: same peer, same position)
-                    dst.copy_(src)
+                    n = min(src.numel(), dst.numel())  # (uneven shares of the pencil solver: a virtual peer's chunk
+                    dst[:n].copy_(src[:n])             #  need not have this rank's length; timing only)
                 works = []
             else:
                 ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]

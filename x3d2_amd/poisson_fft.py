@@ -235,8 +235,8 @@ class HipPoissonFFT:
         if mesh.nproc > 1:
             raise X3dError("HipPoissonFFT is the single-rank solver; use make_poisson_fft")
         h = VP()
-        dp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(_lib.c_double_p)
-        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in
+        dp = lambda a: np.ascontiguousarray(a, dtype=_lib.NP_REAL).ctypes.data_as(_lib.c_double_p)
+        self._keep = [np.ascontiguousarray(x, dtype=_lib.NP_REAL) for x in
                       (self.waves, self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_poisson_create(
             backend.h, ctypes.byref(h), _lib.ints(self.nx_glob, self.ny_glob, self.nz_glob),
@@ -383,15 +383,15 @@ class HipPoissonFFT:
 
     # ---- test hooks
     def get_spectral(self):
-        out = np.empty((self.nz_spec, self.ny_spec, self.nx_spec), dtype=np.complex128)
+        out = np.empty((self.nz_spec, self.ny_spec, self.nx_spec), dtype=np.complex64 if _lib.SINGLE else np.complex128)
         _lib.check(self.backend.lib.x3d_poisson_get_spectral(
-            self.h, out.view(np.float64).ctypes.data_as(_lib.c_double_p)))
+            self.h, out.view(_lib.NP_REAL).ctypes.data_as(_lib.c_double_p)))
         return out
 
     def set_spectral(self, c):
-        c = np.ascontiguousarray(c, dtype=np.complex128)
+        c = np.ascontiguousarray(c, dtype=np.complex64 if _lib.SINGLE else np.complex128)
         _lib.check(self.backend.lib.x3d_poisson_set_spectral(
-            self.h, c.view(np.float64).ctypes.data_as(_lib.c_double_p)))
+            self.h, c.view(_lib.NP_REAL).ctypes.data_as(_lib.c_double_p)))
 
 
 class HipPoissonFFT100(HipPoissonFFT):
@@ -424,7 +424,7 @@ class HipPoissonFFT100(HipPoissonFFT):
         TY, KY = ty[:nys][None, None, :], ky2[:nys][None, None, :]
         TZ, KZ = tz[:, None, None], kz2[:, None, None]
         self.waves100 = KX * (TY * TZ) ** 2 + KY * (TX * TZ) ** 2 + KZ * (TX * TY) ** 2
-        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in
+        self._keep = [np.ascontiguousarray(x, dtype=_lib.NP_REAL) for x in
                       (self.waves100, self.ay, self.by, self.ax, self.bx, self.az, self.bz)]
         h = VP()
         _lib.check(lib.x3d_poisson_create(tb, ctypes.byref(h), _lib.ints(ny, nx, nz),
@@ -488,7 +488,7 @@ class HipPoissonFFT110(HipPoissonFFT100):
         TY, KY = ty[:, None, None], ky2[:, None, None]
         TZ, KZ = tz[:nzs][None, None, :], kz2[:nzs][None, None, :]
         self.waves110 = KX * (TY * TZ) ** 2 + KY * (TX * TZ) ** 2 + KZ * (TX * TY) ** 2
-        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in
+        self._keep = [np.ascontiguousarray(x, dtype=_lib.NP_REAL) for x in
                       (self.waves110, self.az, self.bz, self.ax, self.bx, self.ay, self.by)]
         h = VP()
         _lib.check(lib.x3d_poisson_create(tb, ctypes.byref(h), _lib.ints(nz, nx, ny),
@@ -546,11 +546,11 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         xsl, ysl = slice(self.xoff, self.xoff + self.xs), slice(self.yoff, self.yoff + self.ys)
         full = self.waves_block(xsl, ysl)                   # [z, y, x] of this rank's modes only
         wl = np.ascontiguousarray(np.transpose(full, (2, 1, 0)))  # [x, y, z]
-        self._keep = [np.ascontiguousarray(a, dtype=np.float64) for a in
+        self._keep = [np.ascontiguousarray(a, dtype=_lib.NP_REAL) for a in
                       (wl, self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_pfft_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
-        self.sendbuf = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
-        self.recvbuf = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
+        self.sendbuf = torch.zeros(2 * nmax, dtype=_lib.torch_real(), device=backend.device)
+        self.recvbuf = torch.zeros(2 * nmax, dtype=_lib.torch_real(), device=backend.device)
 
         def share(n, p, r):
             return n // p + (1 if r < n % p else 0)
@@ -568,8 +568,8 @@ class HipPencilPoissonFFT(HipPoissonFFT):
         self.poisson = self.poisson_000
         if self.parts > 1:
             # a second buffer pair: a group's xy and yz transfers are in flight at the same time
-            self.sendbuf2 = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
-            self.recvbuf2 = torch.zeros(2 * nmax, dtype=torch.float64, device=backend.device)
+            self.sendbuf2 = torch.zeros(2 * nmax, dtype=_lib.torch_real(), device=backend.device)
+            self.recvbuf2 = torch.zeros(2 * nmax, dtype=_lib.torch_real(), device=backend.device)
             zp, cum = self.zp, lambda v: [sum(v[:i]) for i in range(len(v))]
             self.g_xy_send = [c * x * self.yl * zp for x in x_sh]
             self.g_xy_recv = [c * self.xs * self.yl * zp] * self.py
@@ -703,18 +703,18 @@ class HipSlabPoissonFFT(HipPoissonFFT):
         self.chunk, self.zl, self.ys, nxs = [int(v) for v in sz]
         ysl = slice(self.rz * self.ys, (self.rz + 1) * self.ys)
         wl = np.ascontiguousarray(np.transpose(self.waves_block(slice(None), ysl), (1, 2, 0)),
-                                  dtype=np.float64)  # [ys][nx/2+1][nz], z fastest
+                                  dtype=_lib.NP_REAL)  # [ys][nx/2+1][nz], z fastest
         if nxs > wl.shape[1]:  # the library pads the spectral rows (pad columns: zeros, wave numbers one)
             wl = np.ascontiguousarray(np.pad(wl, ((0, 0), (0, nxs - wl.shape[1]), (0, 0)), constant_values=1.0))
-        self._keep = [wl] + [np.ascontiguousarray(a, dtype=np.float64) for a in
+        self._keep = [wl] + [np.ascontiguousarray(a, dtype=_lib.NP_REAL) for a in
                              (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_sfft_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
         n = 2 * self.pz * self.chunk
-        self.sbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.sbuf = torch.zeros(n, dtype=_lib.torch_real(), device=backend.device)
         # X3D_EMULATE_ALIAS=1 (one process standing in for an N > 1 run): the "all-to-all with itself" needs no copy when
         # the receive buffer IS the send buffer -- what is left is exactly the kernels an N > 1 run adds
         alias = self.pz == 1 and os.environ.get("X3D_EMULATE_ALIAS") == "1"
-        self.rbuf = self.sbuf if alias else torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.rbuf = self.sbuf if alias else torch.zeros(n, dtype=_lib.torch_real(), device=backend.device)
         npy = int(mesh.nproc_dir[1])
         ry = int(mesh.nrank_dir[1])
         self.peers = [ry + npy * r for r in range(self.pz)]
@@ -808,14 +808,14 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         w = self.waves_block(kxm, slice(None), slice(0, self.nz_glob // 2 + 1))      # [kz, y, x]
         with np.errstate(divide="ignore"):
             rw = np.where(w < 1.e-16, 0.0, -1.0 / w)
-        rw = np.ascontiguousarray(np.transpose(rw, (0, 2, 1)), dtype=np.float64)     # [kz, x, y]
-        self._keep = [rw] + [np.ascontiguousarray(a, dtype=np.float64) for a in
+        rw = np.ascontiguousarray(np.transpose(rw, (0, 2, 1)), dtype=_lib.NP_REAL)     # [kz, x, y]
+        self._keep = [rw] + [np.ascontiguousarray(a, dtype=_lib.NP_REAL) for a in
                              (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_sfftz_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
         self._keep = None
-        self.sbuf = torch.zeros(2 * nbuf, dtype=torch.float64, device=backend.device)
+        self.sbuf = torch.zeros(2 * nbuf, dtype=_lib.torch_real(), device=backend.device)
         alias = self.py == 1 and os.environ.get("X3D_EMULATE_ALIAS") == "1"
-        self.rbuf = self.sbuf if alias else torch.zeros(2 * nbuf, dtype=torch.float64, device=backend.device)
+        self.rbuf = self.sbuf if alias else torch.zeros(2 * nbuf, dtype=_lib.torch_real(), device=backend.device)
         self.peers = [r for r in range(self.py)]  # rank = ry (x and z undivided)
         self.poisson = self.poisson_000
         # round 5: groups of local y rows x groups of kz planes (csrc/sfftz.hip, "BLOCKS"): X3D_SLAB_YPARTS groups of
@@ -1025,8 +1025,8 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
         wl = self.waves_block(xsl)                # [nz][ny][real columns]
         if npad:
             wl = np.pad(wl, ((0, 0), (0, 0), (0, npad)), constant_values=1.0)
-        self._keep = [np.ascontiguousarray(wl, dtype=np.float64)] + \
-            [np.ascontiguousarray(a, dtype=np.float64) for a in (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
+        self._keep = [np.ascontiguousarray(wl, dtype=_lib.NP_REAL)] + \
+            [np.ascontiguousarray(a, dtype=_lib.NP_REAL) for a in (self.ax, self.bx, self.ay, self.by, self.az, self.bz)]
         _lib.check(backend.lib.x3d_sfft010_set_waves(h, *[a.ctypes.data_as(_lib.c_double_p) for a in self._keep]))
         self._keep = None
         if self.stretched_y:
@@ -1034,15 +1034,15 @@ class HipSlabPoissonFFT010(HipPoissonFFT):
             mats = (self.a_odd, self.a_even) if self.stretched_y_sym else (self.a_full, self.a_full)
             if npad:
                 mats = [np.pad(a, ((0, 0), (0, 0), (0, 0), (0, npad))) for a in mats]
-            mats = [np.ascontiguousarray(a, dtype=np.float64) for a in mats]
+            mats = [np.ascontiguousarray(a, dtype=_lib.NP_REAL) for a in mats]
             _lib.check(backend.lib.x3d_sfft010_set_stretching(
                 h, int(self.stretched_y_sym), *[a.ctypes.data_as(_lib.c_double_p) for a in mats]))
             if not getattr(self, "keep_matrices", False):
                 self.a_odd = self.a_even = self.a_full = None
         n = 2 * self.pz * self.chunk
-        self.sbuf = torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.sbuf = torch.zeros(n, dtype=_lib.torch_real(), device=backend.device)
         alias = self.pz == 1 and __import__("os").environ.get("X3D_EMULATE_ALIAS") == "1"  # (see HipSlabPoissonFFT)
-        self.rbuf = self.sbuf if alias else torch.zeros(n, dtype=torch.float64, device=backend.device)
+        self.rbuf = self.sbuf if alias else torch.zeros(n, dtype=_lib.torch_real(), device=backend.device)
         self.peers = [r for r in range(self.pz)]  # (x and y undivided: rank = rz)
         self.poisson = self.poisson_010
 
