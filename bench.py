@@ -821,6 +821,28 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
                 others[key] = {"value": None, "error": repr(e)[:300]}
             others[key]["seconds_in_all"] = time.perf_counter() - t0
+        # ... and the reference's UNCHANGED solver.f90 through the Fortran shim (fortran/_build/xcompact_hip: built where the
+        # reference tree is mounted, shipped prebuilt like the library), TGV 512^3, 20 steps: its own "Averaged time per step"
+        shim = os.path.join(ROOT, "fortran", "_build", "xcompact_hip")
+        if os.path.exists(shim):
+            import re
+            import tempfile
+            t0 = time.perf_counter()
+            key = "configs[2] through the reference's own solver.f90 (Fortran shim over the C ABI, deferred execution)"
+            try:
+                with tempfile.TemporaryDirectory() as wd:
+                    r = subprocess.run([shim, os.path.join(ROOT, "fortran", "tgv512.x3d")], cwd=wd, capture_output=True,
+                                       text=True, timeout=300, env=dict(os.environ, X3D_LAZY_REPORT="1"))
+                m = re.search(r"Averaged time per step \(s\):\s*([0-9.eE+-]+)", r.stdout)
+                st = dict(re.findall(r"(\w+)=(-?\d+)", r.stderr.split("x3d_lazy_report pid")[-1])) if "x3d_lazy_report" in r.stderr else {}
+                others[key] = {"workload": "TGV 512x512x512, RK3, FFT Poisson, 20 steps, monitoring every 10 (fortran/tgv512.x3d); the "
+                                           "program's own average, first step and outputs included",
+                               "ms_per_step": float(m.group(1)) * 1e3 if m else None, "value": 512 ** 3 / float(m.group(1)) if m else None,
+                               "unit": "DoF*steps/s", "returncode": r.returncode,
+                               "lazy_declined": int(st.get("declined", -1)), "lazy_transeq_acc": int(st.get("transeq_acc", -1))}
+            except Exception as e:  # noqa: BLE001
+                others[key] = {"value": None, "error": repr(e)[:300]}
+            others[key]["seconds_in_all"] = time.perf_counter() - t0
         out["other_configs"] = others
     if rank == 0:
         # the JSON line is the LAST thing on stdout: whatever libraries left in C stdio's buffer (RCCL's version banner

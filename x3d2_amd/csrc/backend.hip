@@ -74,12 +74,6 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
         else if (b->nxp % 64 == 0 && b->nxp >= 256) b->nxp += 16;
     }
     b->nyp = b->ny;
-    {
-        // experiment (round 5, profiles/r05_tile_pattern_skeleton.txt): 528 x 512 x 8 B is exactly 66 x 32 KiB; the memory
-        // skeleton of the z tiles runs 4 % faster with 3 more rows of plane pitch.  X3D_PAD_Y=<rows>; default 0.
-        const char *e = getenv("X3D_PAD_Y");
-        if (e && atoi(e) > 0 && atoi(e) <= 64) b->nyp += atoi(e);
-    }
     b->nzp = b->nz;
     b->nblock = (size_t)b->nxp * b->nyp * b->nzp;
     int npmax = b->ny * b->nz;
