@@ -174,6 +174,7 @@ module m_hip_poisson_fft
     real(dp), allocatable :: sh(:), rh(:)
     integer :: comm_y = 0, comm_z = 0
     integer, allocatable :: cnt_xy_s(:), cnt_xy_r(:), cnt_yz_s(:), cnt_yz_r(:)
+    integer, allocatable :: psdis(:, :)   ! the peers' chunk offsets per transpose kind (xchg), exchanged once
     ! device-to-device transposes: the peers' two exchange buffers, mapped (1: their sbuf, 2: their rbuf); the two
     ! buffers swap roles after every exchange (par), so that a rank never packs into memory a peer may still be reading
     logical :: d2d = .false.
@@ -391,13 +392,14 @@ contains
     if (self%d2d) self%par = 1 - self%par
   end subroutine stage_done
 
-  subroutine xchg(self, comm, scnt, rcnt)
+  subroutine xchg(self, comm, scnt, rcnt, which)
     !! packed buffers of the library, peer r's chunk contiguous.  Device to device: every rank waits for its own
     !! stream (its send buffer is complete, its earlier pulls are done), all ranks meet, every rank tells every peer
     !! where that peer's chunk starts, then pulls the chunks meant for it out of the peers' send buffers on its own
     !! stream -- the unpack kernel queued behind runs when they have arrived.  Host staged: MPI_Alltoallv.
     class(hip_poisson_fft_t) :: self
     integer, intent(in) :: comm, scnt(:), rcnt(:)
+    integer, intent(in) :: which   !! 1..4: which of the solve's four transposes (their chunk offsets never change)
     integer :: sdis(size(scnt)), rdis(size(rcnt)), psdis(size(scnt)), r, ierr, me
     type(c_ptr) :: mine_r, src
     sdis(1) = 0; rdis(1) = 0
@@ -415,7 +417,17 @@ contains
     call x3d_check(x3d_device_sync(self%backend))
     ! (all ranks, not only this group: the buffer pulled into now was read by the OTHER group's peers one exchange ago)
     call MPI_Barrier(MPI_COMM_WORLD, ierr)
-    call MPI_Alltoall(sdis, 1, MPI_INTEGER, psdis, 1, MPI_INTEGER, comm, ierr)
+    ! where each peer keeps this rank's chunk: static counts, exchanged ONCE per transpose kind (ADVICE round 4)
+    if (.not. allocated(self%psdis)) then
+      allocate (self%psdis(max(size(self%cnt_xy_s), size(self%cnt_yz_s)), 4))
+      self%psdis = -1
+    end if
+    if (self%psdis(1, which) < 0) then
+      call MPI_Alltoall(sdis, 1, MPI_INTEGER, psdis, 1, MPI_INTEGER, comm, ierr)
+      self%psdis(1:size(scnt), which) = psdis
+    else
+      psdis = self%psdis(1:size(scnt), which)
+    end if
     call MPI_Comm_rank(comm, me, ierr)
     mine_r = buf_in(self)
     do r = 1, size(rcnt)
@@ -436,12 +448,12 @@ contains
     if (self%multi) then  ! x3d2_amd/poisson_fft.py, HipPencilPoissonFFT.fft_forward
       call x3d_check(x3d_pfft_fwd_x(self%pf, dev(f_in)))
       call x3d_check(x3d_pfft_pack_xy(self%pf, buf_out(self)))
-      call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r)
+      call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r, 1)
       call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_in(self)))
       call stage_done(self)
       call x3d_check(x3d_pfft_fft_y(self%pf, 0_c_int))
       call x3d_check(x3d_pfft_pack_yz(self%pf, buf_out(self)))
-      call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r)
+      call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r, 2)
       call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_in(self)))
       call stage_done(self)
       call x3d_check(x3d_pfft_fft_z(self%pf, 0_c_int))
@@ -455,12 +467,12 @@ contains
     if (self%multi) then
       call x3d_check(x3d_pfft_fft_z(self%pf, 1_c_int))
       call x3d_check(x3d_pfft_pack_zy(self%pf, buf_out(self)))
-      call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s)
+      call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s, 3)
       call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_in(self)))
       call stage_done(self)
       call x3d_check(x3d_pfft_fft_y(self%pf, 1_c_int))
       call x3d_check(x3d_pfft_pack_yx(self%pf, buf_out(self)))
-      call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s)
+      call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s, 4)
       call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_in(self)))
       call stage_done(self)
       call x3d_check(x3d_pfft_bwd_x(self%pf, dev(f_out)))

@@ -575,8 +575,12 @@ static void optimise(x3d_backend *b)
             // the layer; an L_BIND where the solve stood hands that buffer to the handle.
             bool busy = !registered(L, du) ||
                         !range_clear(q, p, k, {y}, wall ? std::vector<const real_t *>{wall} : std::vector<const real_t *>{});
-            for (int m = p + 1; m < k && !busy; m++)  // (one pending buffer per handle)
-                busy = (q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && (q[m].mode & 1) && q[m].obj == du);
+            // one pending buffer per handle, in the WHOLE queue: a fused solve of du before p whose bind lies behind k would
+            // enclose this pair -- its buffer would be overwritten in L->bind and leak
+            for (int m = 0; m < n && !busy; m++)
+                busy = m != p && m != k &&
+                       ((q[m].kind == L_BIND && q[m].o[0] == du) || (q[m].kind == L_TDS_LIN && (q[m].mode & 1) && q[m].obj == du));
+            busy = busy || L->bind.count(du) != 0;
             if (busy) { undo_sf(); continue; }
             LOp f = q[p];
             f.kind = L_TDS_LIN; f.dir = X3D_DIR_X; f.o[0] = nullptr; f.obj = du; f.mode = 1 | (wall ? 2 : 0); f.o[1] = y;
@@ -838,6 +842,11 @@ int x3d_lazy_flush_c(x3d_backend *b)
     }
     L->executing = false;
     L->q.clear();
+    // a fused solve whose L_BIND never ran (an error between the two): its buffer goes back to the pool, the handle keeps
+    // its old data -- nothing stays pinned behind a failed flush
+    for (auto &kv : L->bind)
+        if (kv.second) L->users[kv.second] = 0;
+    L->bind.clear();
     return rc;
 }
 

@@ -496,16 +496,28 @@ static int y010_setup(x3d_poisson *p)
     p->y010 = -1;
     const char *e = getenv("X3D_NO_Y010");
     x3d_backend *b = p->b;
-    if ((e && e[0] == '1') || p->ny != 256 || p->nxs % 8 != 0) return 0;
+    // (only the stretched solve takes the y-last path: no plans, no larger work area -- and no implicit device sync inside
+    //  a step -- for anything else)
+    if ((e && e[0] == '1') || !p->stretched || p->ny != 256 || p->nxs % 8 != 0) return 0;
     int nn[2] = {p->nz, p->nx};
     int re[2] = {b->nzp, b->nyp * b->nxp}, ce[2] = {p->nz, p->ny * p->nxs};
-    X3D_FFT(hipfftCreate(&p->plan_x010_fw));
-    X3D_FFT(hipfftCreate(&p->plan_x010_bw));
-    X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_fw, 0));
-    X3D_FFT(hipfftSetAutoAllocation(p->plan_x010_bw, 0));
+    // a plan that cannot be made is not an error of the solve: the partial plans go, y010 stays -1, the 3-D path runs
+    bool have_fw = false, have_bw = false;
+    auto give_up = [&]() {
+        if (have_fw) hipfftDestroy(p->plan_x010_fw);
+        if (have_bw) hipfftDestroy(p->plan_x010_bw);
+        return 0;
+    };
+    if (hipfftCreate(&p->plan_x010_fw) != HIPFFT_SUCCESS) return give_up();
+    have_fw = true;
+    if (hipfftCreate(&p->plan_x010_bw) != HIPFFT_SUCCESS) return give_up();
+    have_bw = true;
+    if (hipfftSetAutoAllocation(p->plan_x010_fw, 0) != HIPFFT_SUCCESS || hipfftSetAutoAllocation(p->plan_x010_bw, 0) != HIPFFT_SUCCESS)
+        return give_up();
     size_t ws_fw = 0, ws_bw = 0;
-    X3D_FFT(hipfftMakePlanMany(p->plan_x010_fw, 2, nn, re, 1, b->nxp, ce, 1, p->nxs, X3D_FFT_R2C, p->ny, &ws_fw));
-    X3D_FFT(hipfftMakePlanMany(p->plan_x010_bw, 2, nn, ce, 1, p->nxs, re, 1, b->nxp, X3D_FFT_C2R, p->ny, &ws_bw));
+    if (hipfftMakePlanMany(p->plan_x010_fw, 2, nn, re, 1, b->nxp, ce, 1, p->nxs, X3D_FFT_R2C, p->ny, &ws_fw) != HIPFFT_SUCCESS ||
+        hipfftMakePlanMany(p->plan_x010_bw, 2, nn, ce, 1, p->nxs, re, 1, b->nxp, X3D_FFT_C2R, p->ny, &ws_bw) != HIPFFT_SUCCESS)
+        return give_up();
     const size_t ws = ws_fw > ws_bw ? ws_fw : ws_bw;
     if (ws > p->work_size) {  // (the 3-D plans keep working in the larger area)
         X3D_HIP(hipFree(p->work));
