@@ -3,7 +3,7 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-live-traffic > gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 python - $tag <<'PY'
 import csv, glob, sys, collections, json
