@@ -25,18 +25,20 @@ import json
 o=json.loads([l for l in open('gpurun_out/r05/v8_n1.json') if l.startswith('{')][-1])
 print('%-34s %7.2f ms per step' % ('N = 1 (same box)', o['ms_per_step']))" >> $out
 run kz_groups_only_yparts1 X3D_SLAB_YPARTS=1
-run rows_x_kz_hybrid_yparts4 X3D_SLAB_YPARTS=4
-run rows_x_kz_hybrid_yparts2 X3D_SLAB_YPARTS=2
-run rows_x_kz_hybrid_yparts8 X3D_SLAB_YPARTS=8
-run free_links_yparts4 X3D_SLAB_YPARTS=4 X3D_COMM_EMULATE_LINKS=100000 X3D_COMM_EMULATE_LATENCY_US=0
+run blocks_yparts4_tail1 X3D_SLAB_YPARTS=4 X3D_SLAB_TAIL=1
+run blocks_yparts4_default X3D_SLAB_YPARTS=4
+run blocks_yparts8_default X3D_SLAB_YPARTS=8
+run blocks_yparts4_parts2 X3D_SLAB_YPARTS=4 X3D_SLAB_PARTS=2
+run blocks_yparts4_parts8 X3D_SLAB_YPARTS=4 X3D_SLAB_PARTS=8
+run blocks_rows_96_160_160_96 X3D_SLAB_ROWS=96,160,160,96
+run blocks_yparts4_link_peak X3D_SLAB_YPARTS=4 X3D_COMM_EMULATE_LINKS=76.8
+run blocks_yparts4_free_links X3D_SLAB_YPARTS=4 X3D_COMM_EMULATE_LINKS=100000 X3D_COMM_EMULATE_LATENCY_US=0
 run ordered_no_overlap_yparts1 X3D_SLAB_YPARTS=1 X3D_NO_OVERLAP=1
-run link_peak_hybrid_yparts4 X3D_SLAB_YPARTS=4 X3D_COMM_EMULATE_LINKS=76.8
-run reserve8_hybrid_yparts4 X3D_SLAB_YPARTS=4 X3D_COMM_RESERVE_CUS=8
-run no_stream_probe_hybrid_yparts4 X3D_SLAB_YPARTS=4 X3D_COMM_NO_STREAM_PROBE=1
+run no_stream_probe_yparts4 X3D_SLAB_YPARTS=4 X3D_COMM_NO_STREAM_PROBE=1
 cat $out
 python - <<PY
 import json
-for n in ("rows_x_kz_hybrid_yparts4", "no_stream_probe_hybrid_yparts4"):
+for n in ("blocks_yparts4_default", "no_stream_probe_yparts4"):
     o = json.loads([l for l in open("gpurun_out/r05/v8_%s.json" % n) if l.startswith("{")][-1])
     print(n, "comm stream probe (pair ms, serial ms):", o["config"]["comm_stream_probe_ms"])
 PY

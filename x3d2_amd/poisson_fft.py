@@ -825,6 +825,13 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         if 512 % self.yparts:
             raise X3dError("X3D_SLAB_YPARTS must divide 512")
         self.rows = [(a * (512 // self.yparts), 512 // self.yparts) for a in range(self.yparts)]
+        rs = os.environ.get("X3D_SLAB_ROWS")  # uneven groups, e.g. "64,160,160,128": a small first group fills the pipeline
+        if rs:                                 # sooner, a small last one drains it sooner
+            cnt = [int(v) for v in rs.split(",")]
+            if sum(cnt) != 512 or min(cnt) <= 0:
+                raise X3dError("X3D_SLAB_ROWS must be positive row counts that add up to 512")
+            self.yparts = len(cnt)
+            self.rows = [(sum(cnt[:a]), cnt[a]) for a in range(len(cnt))]
         self.n_pipelined = 0  # solves through zfirst_solve_pipelined (tests)
 
     def __del__(self):
@@ -856,8 +863,8 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
         group, so that the y stage of m starts when (A - 1, m) is in, beside the transfers behind it.  Its result goes
         back at once -- kz groups before the last whole, the last one rows group by rows group, so that rows group a's x
         transforms and behind(a) (the gradient's z pair, or the inverse z transform) start when (a, K - 1) is back,
-        beside the transfers of the rows groups behind it.  2 (A + K - 1) exchange groups per solve (X3D_SLAB_SCHEDULE=
-        blocks: every (a, m) block its own group, 2 A K)."""
+        beside the transfers of the rows groups behind it.  (A + K - 1) + (K - T + A) exchange groups per solve
+        (X3D_SLAB_SCHEDULE=blocks: every (a, m) block its own group, 2 A K)."""
         lib, h, sb, rb = self.backend.lib, self.h, self.sbuf, self.rbuf
         A, K = self.yparts, self.parts
         every = os.environ.get("X3D_SLAB_SCHEDULE") == "blocks"
@@ -871,16 +878,24 @@ class HipSlabPoissonFFTZ(HipPoissonFFT):
             else:
                 there += [(m, self._group([(y0, nyr, m)], sb, rb)) for m in range(K)]
         back = []
+        # the way back: the last T kz groups travel rows group by rows group (one exchange group of T runs per peer each), so
+        # that rows group a's x transforms and z pair start when ITS blocks are in; kz groups before them whole, as their y
+        # stages complete.  Default T = K: the whole way back is rows-major -- the y stages have run beside the forward
+        # transfers anyway, and the z pairs (1.2 ms per solve at 8 ranks) then overlap all of the transfers instead of the
+        # last kz group's only (8 emulated ranks: T = 1 57.8, 2 56.1, 3 55.0, 4 54.7 ms per step; X3D_SLAB_TAIL)
+        T = K if every else max(1, min(K, int(os.environ.get("X3D_SLAB_TAIL", str(K)))))
         for m in range(K):
             for k, hnd in there:
                 if k is None or k == m:
                     hnd.wait()
             there = [(k, hnd) for k, hnd in there if not (k is None or k == m)]
             _lib.check(lib.x3d_sfftz_y_stage(h, rb.data_ptr(), m, 0))
-            if m < K - 1 and not every:
-                back.append((None, self._group([(0, 512, m)], rb, sb)))
-            else:
+            if every:
                 back += [(a, self._group([(y0, nyr, m)], rb, sb)) for a, (y0, nyr) in enumerate(self.rows)]
+            elif m < K - T:
+                back.append((None, self._group([(0, 512, m)], rb, sb)))
+        if not every:
+            back += [(a, self._group([(y0, nyr, m) for m in range(K - T, K)], rb, sb)) for a, (y0, nyr) in enumerate(self.rows)]
         for a, (y0, nyr) in enumerate(self.rows):
             for k, hnd in back:
                 if k is None or k == a:
