@@ -24,9 +24,10 @@
 // rows -- and in the exchange layout the rows yl0 .. yl1 of a (part, peer) chunk are one contiguous piece.  So the
 // *_rows entry points below take a range of y rows: the z pair and the x transforms of rows group a + 1 run beside the
 // transfers of group a, the y stage of kz group k starts when the LAST rows group's block of k has arrived (beside the
-// transfers of the kz groups behind it), its result leaves at once, and on the way back the x transforms and the z pair
-// of rows group a run when its last kz block is in, beside the transfers of the rows groups behind it
-// (poisson_fft.HipSlabPoissonFFTZ.zfirst_solve_pipelined).  Same kernels on the same data: bit for bit the unsplit solve.
+// transfers of the kz groups behind it), and the way back is rows-major (all kz groups of a rows group in one exchange
+// group): the x transforms and the z pair of rows group a run when ITS blocks are in, beside the transfers of the rows
+// groups behind it (poisson_fft.HipSlabPoissonFFTZ._pipelined; 8 emulated ranks 63.2 -> 54.1 ms per step,
+// profiles/r05_yslab_pipeline_timeline.txt).  Same kernels on the same data: bit for bit the unsplit solve.
 #include "zfft_tile.h"
 
 #define SZ_PX 520

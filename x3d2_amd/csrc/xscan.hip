@@ -1206,6 +1206,13 @@ __global__ void __launch_bounds__(1024)
     // one operator on the window w: r = its tds_solve rows (der_univ_subs with the periodic self-exchange; HALO:
     // with recv_s = recv_e = 0, the own boundary values stored for the exchange -- see TileHalo)
     auto solve = [&](const real_t (&w)[Q + 8], real_t (&r)[Q], const real_t *__restrict__ l, const XOp &t, int op) {
+#if ZF_EXP & 2  // (timing experiment: no solve)
+        if constexpr (ZF) {
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = w[q + 4];
+            return;
+        }
+#endif
         real_t X[Q], du1, xn;
         scan_solve<Q, true, NARROW>(w, X, du1, xn, l, t, lane, first);
         real_t du_s, du_e;
@@ -1291,6 +1298,59 @@ __global__ void __launch_bounds__(1024)
                 if (HALO && threadIdx.x < 128) hnx = hload(tn, 0);
             }
         }
+#ifdef XS_DUAL
+        // DUAL (round 5 experiment, OFF: measured no better -- ZF mode 0 0.874 -> 0.905 ms, mode 1 0.773 -> 0.767, step
+        // 43.07 -> 43.2 ms; profiles/r05_zf_pair_phases.txt): the pair's two solves -- different operators -- as ONE
+        // interleaved solve over both table sets (scan_solve_dual).  The solves are bound by the rate of LDS read
+        // instructions, which interleaving does not lower, and mode 0 loses the overlap of its first solve with the
+        // second input's trip through the tile.  Parity-green (30 pair / z-first / full-step tests).
+        constexpr bool DUAL = UNI && !HALO && MODE != 2;
+#else
+        constexpr bool DUAL = false;
+#endif
+        if constexpr (DUAL) {
+            V2 w2[Q + 8];
+            if (MODE == 0) {
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m].a = w[m];
+                to_tile(g2);
+                __syncthreads();
+                pick(b);
+                window_from_body<Q>(w, b, lane);
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m].b = w[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m] = V2{w[m], w[m]};
+            }
+            V2 X2[Q], d1, xn2;
+            scan_solve_dual<Q, NARROW>(w2, X2, d1, xn2, la, lb, ta, tb, lane);
+            const real_t sa_ = ta.rs_s * (d1.a - ta.sa1 * xn2.a), ea_ = ta.rs_e * (xn2.a - ta.scn * d1.a);
+            const real_t sb_ = tb.rs_s * (d1.b - tb.sa1 * xn2.b), eb_ = tb.rs_e * (xn2.b - tb.scn * d1.b);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                ra[q] = X2[q].a - LTR(la, LT_SA(q)) * sa_ - LTR(la, LT_SC(q)) * ea_;
+                rb[q] = X2[q].b - LTR(lb, LT_SA(q)) * sb_ - LTR(lb, LT_SC(q)) * eb_;
+                if (q == 0) { ra[q] = (lane == 0) ? sa_ : ra[q]; rb[q] = (lane == 0) ? sb_ : rb[q]; }
+                if (q == Q - 1) { ra[q] = (lane == 63) ? ea_ : ra[q]; rb[q] = (lane == 63) ? eb_ : rb[q]; }
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
+                put(ra);
+                __syncthreads();
+                if constexpr (ZF) zf_forward<TP>(tile, tws, zf_row(tl), kzs, wave, lane);
+                else from_tile(out1 + tile_off_p(tl));
+            } else {
+                put(ra);
+                __syncthreads();
+                from_tile(out1 + off);
+                __syncthreads();  // out1's tile has been read
+                put(rb);
+                __syncthreads();
+                from_tile(out2 + off);
+            }
+        } else {
         solve(w, ra, la, ta, 0);
         if (MODE == 0) {
             to_tile(g2);
@@ -1322,6 +1382,7 @@ __global__ void __launch_bounds__(1024)
             __syncthreads();
             from_tile(out1 + off);
         }
+        }  // (!DUAL)
         if (HALO && threadIdx.x < 64) {  // 16 pencils x 2 operators x {du_1, X_n} (ordered by the barriers above)
             const int hw = threadIdx.x >> 2, k = threadIdx.x & 3;
             const long pp = (long)(tl / ntx) * (ntx * 16) + (long)(tl % ntx) * 16 + hw;

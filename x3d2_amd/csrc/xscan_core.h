@@ -289,6 +289,76 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 #undef PHASE
 }
 
+// Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE
+// interleaved solve -- the FAST (periodic-type) form of scan_solve with every table value read per operator: the same
+// number of LDS reads as two solves one after the other, but two independent dependency chains in flight and one pass
+// through the scan's phases (round 5: the z-transforming operator pairs are bound by their serial on-chip chain,
+// profiles/r05_zf_pair_phases.txt).  Arithmetic per right-hand side = scan_solve<Q, true, NARROW>, expression by expression.
+template <int Q, bool NARROW>
+__device__ __forceinline__ void scan_solve_dual(const V2 (&w)[Q + 8], V2 (&X)[Q], V2 &du1, V2 &xn,
+                                                const real_t *__restrict__ la, const real_t *__restrict__ lb, const XOp &ta,
+                                                const XOp &tb, int &lane)
+{
+#define PHASE2(x) asm volatile("" : "+v"(lane) : "v"((x).a))
+#define L2(e) V2{lt_read(la, (e) * 64 + lane), lt_read(lb, (e) * 64 + lane)}
+    V2 acc[Q];
+    if (NARROW) {
+        const V2 c2{ta.c[2], tb.c[2]}, c3{ta.c[3], tb.c[3]}, c4{ta.c[4], tb.c[4]}, c5{ta.c[5], tb.c[5]}, c6{ta.c[6], tb.c[6]};
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            V2 a = V2{ta.c[0], tb.c[0]} * w[q];
+#pragma unroll
+            for (int m = 1; m < 9; m++) a = a + V2{ta.c[m], tb.c[m]} * w[q + m];
+            acc[q] = a;
+        }
+    }
+    V2 prev = zero_of<V2>();
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        X[q] = L2(LT_F(q)) * (acc[q] - L2(LT_A(q)) * prev);
+        prev = X[q];
+    }
+    V2 v = prev;
+    PHASE2(X[Q / 2]);
+    v += L2(LT_MF(0)) * dpp0<0x111>(v);
+    v += L2(LT_MF(1)) * dpp0<0x112>(v);
+    v += L2(LT_MF(2)) * dpp0<0x114>(v);
+    v += L2(LT_MF(3)) * dpp0<0x118>(v);
+    v += L2(LT_MF(4)) * dpp0<0x142>(v);
+    v += L2(LT_MF(5)) * dpp0<0x143>(v);
+    V2 carry = dpp0<0x138>(v);  // wave_shr:1
+    V2 nxt = zero_of<V2>();
+    PHASE2(carry);
+#pragma unroll
+    for (int q = Q - 1; q >= 0; q--) {
+        X[q] = (X[q] + L2(LT_PF(q)) * carry) + L2(LT_H(q)) * nxt;
+        nxt = X[q];
+    }
+    v = nxt;
+    PHASE2(X[Q / 2]);
+    v += L2(LT_MB(0)) * dpp0<0x101>(v);
+    v += L2(LT_MB(1)) * dpp0<0x102>(v);
+    v += L2(LT_MB(2)) * dpp0<0x104>(v);
+    v += L2(LT_MB(3)) * dpp0<0x108>(v);
+    {
+        const V2 s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
+        v += L2(LT_MB(4)) * sel_of(lane < 32, s16, s48);
+        v += L2(LT_MB(5)) * readlane_d(v, 32);
+    }
+    carry = dpp0<0x130>(v);  // wave_shl:1
+#pragma unroll
+    for (int q = 0; q < Q; q++) X[q] = X[q] + L2(LT_QB(q)) * carry;
+    du1 = V2{ta.last_r, tb.last_r} * readlane_d(X[0], 0);
+    xn = readlane_d(X[Q - 1], 63);
+    PHASE2(xn);
+#undef PHASE2
+#undef L2
+}
+
 // nr == 64*Q and n_wrap == nr: every lane's body is a full aligned vector and the halos are
 // the neighbours' rows or the periodic image -> no per-lane branches at all
 template <int Q>

@@ -91,7 +91,9 @@ __device__ __forceinline__ void zf_forward(real_t *__restrict__ area, const real
     __syncthreads();  // (the transform regions overlap other waves' pencils)
     if (wave < 8) {
         real2_t *__restrict__ pen = T2 + wave * ZF_PEN;
+#if !(ZF_EXP & 1)
         fft512_wave<-1>(a, pen, tws, lane);
+#endif
 #pragma unroll
         for (int k = 0; k < 8; k++) pen[lane + 64 * k] = a[k];
         wave_lds_fence();
@@ -201,7 +203,9 @@ __device__ __forceinline__ void zf_inverse(real_t *__restrict__ area, const real
         }
     }
     __syncthreads();
+#if !(ZF_EXP & 1)
     if (wave < 8) fft512_wave<1>(a, T2 + wave * ZF_PEN, tws, lane);
+#endif
     __syncthreads();
     if (wave < 8) {
         real_t *__restrict__ pa = area + (2 * wave) * TP, *__restrict__ pb = pa + TP;
