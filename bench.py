@@ -740,10 +740,22 @@ def main():
                 layouts[other] = {"nproc_dir": list(decomposition(args.gpus, other)), "value": None,
                                   "error": tried[-1].get("error", "validation failed")}
             else:
-                o2 = measure(built[0], built[1], built[2], other)
-                layouts[other] = brief(o2)
-                if o2["value"] > out["value"]:
-                    out = o2
+                # (an exception while timing the second layout must not cost the first one's line; every rank takes the
+                #  same branch: the verdict is all-reduced like the validation's)
+                ok2, o2 = 1.0, None
+                try:
+                    o2 = measure(built[0], built[1], built[2], other)
+                except Exception as e:  # noqa: BLE001
+                    ok2 = 0.0
+                    layouts[other] = {"nproc_dir": list(built[1]), "value": None, "error": repr(e)[:300]}
+                if comm.size > 1:
+                    ok2 = -comm.allreduce(-ok2, "max")
+                if ok2 and o2 is not None:
+                    layouts[other] = brief(o2)
+                    if o2["value"] > out["value"]:
+                        out = o2
+                elif other not in layouts:
+                    layouts[other] = {"nproc_dir": list(built[1]), "value": None, "error": "failed on another rank"}
             out["config"]["decompositions_tried"] = tried or None
         out["decompositions"] = layouts
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.case == "tgv":
