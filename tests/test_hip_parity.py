@@ -1875,3 +1875,25 @@ def test_z_transforming_pair_kernels_against_pair_kernel_plus_stand_alone_transf
     assert b.tds_pair_zfirst(1, o1, o2, None, None, z.interpl_p2v, z.stagder_p2v)
     for x, y in ((o1, r1), (o2, r2)):
         assert relerr(b.get_field_data(x, VERT), 512.0 * b.get_field_data(y, VERT)) < 1e-13
+
+
+def test_bench_virtual_ranks_line():
+    """`bench.py --virtual-ranks 2`: one process as rank 0 of a 2-rank y-slab job, every peer itself, links emulated -- the
+    line must say EMULATION, name the link model's constants, carry the exchanges of one step and the hardware-queue probe
+    of the communication stream, and the emulated step must be a sane TGV step (a timeline tool, not a measurement)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--virtual-ranks", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "EMULATED 2 ranks" in o["metric"] and o["emulation"]["virtual_ranks"] == 2 and o["n_gpus"] == 1
+    assert o["emulation"]["link_GBs_per_direction"] == 61.4 and o["emulation"]["slab_yparts"] == 4
+    assert o["config"]["nproc_dir"] == [1, 2, 1] and o["config"]["poisson_z_first"] > 0
+    x = o["config"]["exchanges_one_step"]
+    assert x["alltoall"]["exchanges"] == 3 * (4 + 4 - 1 + 4) and x["alltoall"]["MB_sent"] > 6000 and x["sendrecv"]["exchanges"] > 0
+    probe = o["config"]["comm_stream_probe_ms"]
+    assert probe and probe[-1][0] < 0.75 * probe[-1][1]  # the stream taken runs beside the compute stream
+    assert 40.0 < o["ms_per_step"] < 80.0

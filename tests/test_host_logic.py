@@ -243,6 +243,16 @@ for part in range(2):
     for p in range(2):
         want += [100 * p + 6 * part + 3 * r + k for k in range(3)]
 assert R.tolist() == [float(v) for v in want], (r, R, want)
+# round 5: several runs per peer in ONE group (a rows group's pieces of the kz groups' blocks: ialltoall_chunks) -- the same
+# layout, part 0 and part 1 in one call, only elements 1..2 of every (part, peer) chunk (a "rows group")
+R2 = torch.zeros(12, dtype=torch.float64)
+c.ialltoall_chunks(S, R2, [(2, 6 * part + 1, 3) for part in range(2)], [0, 1]).wait()
+want2 = [0.0] * 12
+for part in range(2):
+    for p in range(2):
+        for k in (1, 2):
+            want2[6 * part + 3 * p + k] = float(100 * p + 6 * part + 3 * r + k)
+assert R2.tolist() == want2, (r, R2, want2)
 rs2, re2 = torch.zeros(4), torch.zeros(4)
 c.isendrecv([(ss, se, rs2, re2)], prev, nxt).wait()
 assert torch.equal(rs2, rs) and torch.equal(re2, re)
