@@ -202,7 +202,7 @@ def cpu_reference(n, iters, threads, nproc_dir=(1, 1, 1)):
             "seconds_per_step": t, "n": n}
 
 
-def live_traffic(kernel_substr, extra_args, timeout=240):
+def live_traffic(kernel_substr, extra_args, timeout=120):
     """HBM bytes per launch of the kernels whose name contains `kernel_substr`, measured NOW: two child runs of this
     script (--pmc-child: warm-up + ONE step, nothing timed) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` --
     separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes, with its gfx950 correction (FETCH_SIZE counts
