@@ -16,6 +16,7 @@ of the reference's OpenMP path on the host cores, bounded sample, N=1 only).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -231,18 +232,27 @@ def live_traffic(kernel_substr, extra_args, timeout=120):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "%s pass failed (rc %s): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
-            vals = []
+            vals, vals_e = [], []
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
-                        vals.append(float(row["Counter_Value"]))
+                    name = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == counter and kernel_substr in name:
+                        # (k_ytile_transeq3's seventh template flag: the launches that also do the RK stage, counted apart)
+                        m = re.search(kernel_substr + r"<([^>]*)>", name)
+                        targs = [a.strip() for a in m.group(1).split(",")] if m else []
+                        (vals_e if len(targs) == 7 and targs[6] == "true" else vals).append(float(row["Counter_Value"]))
             if not vals:
                 return None, "%s pass: no launch of %s in the counter file" % (counter, kernel_substr)
-            out[counter] = (sum(vals) / len(vals), len(vals))
+            out[counter] = (sum(vals) / len(vals), len(vals), sum(vals_e) / len(vals_e) if vals_e else None, len(vals_e))
     fetch = out["FETCH_SIZE"][0] * 1024.0 * 2.0
     write = out["WRITE_SIZE"][0] * 1024.0
+    with_stage = None
+    if out["FETCH_SIZE"][2] is not None and out["WRITE_SIZE"][2] is not None:
+        with_stage = {"bytes_per_launch": out["FETCH_SIZE"][2] * 2048.0 + out["WRITE_SIZE"][2] * 1024.0,
+                      "fetch_bytes": out["FETCH_SIZE"][2] * 2048.0, "write_bytes": out["WRITE_SIZE"][2] * 1024.0,
+                      "launches_counted": out["FETCH_SIZE"][3]}
     return {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
-            "launches_counted": out["FETCH_SIZE"][1],
+            "launches_counted": out["FETCH_SIZE"][1], "launches_with_rk_stage": with_stage,
             "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child runs of this command (1 step), KB -> B, "
                    "FETCH x 2 (gfx950: 64 B counted per 128-B request, MI355X_MICROARCH.md)"}, None
 
@@ -505,6 +515,8 @@ def main():
         backend.prof_reset()
         backend.rk_fused_passes = 0
         backend.rk_fused_launches = 0
+        backend.rk_in_tile3_passes = 0
+        backend.rk_in_tile3_launches = 0
         tq3_before = int(backend.lib.x3d_backend_counter(backend.h, 0))
         upd_before = int(backend.lib.x3d_backend_counter(backend.h, 1))
         sync_all()
@@ -615,6 +627,20 @@ def main():
                         # sum_<d>intox units of SURVEY 8(d) in one pass -- compulsory traffic R u, v, w + R rhs x 3 + W rhs x 3
                         # = 72 B/DoF (the counters say 72.0: roofline.traffic); stated next to the 64 B figure, not instead
                         "frac_at_72B_accumulating_launch": 72.0 * dofb / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the same kernel's launches that also do the RK stage of u, v, w (template flag EPI, x3d_transeq_lincomb3):
+            # timed apart (direction slot 0 of the timers); bytes = the transeq unit + the stage as the operation
+            # vecadd / lincomb it replaces (8 B/DoF per field it reads or writes)
+            n_e = n_f - sum(per_dir_raw[d][0][0] for d in (1, 2, 3))
+            ms_e = ms_f + ms_b - sum(per_dir_raw[d][0][1] + per_dir_raw[d][1][1] for d in (1, 2, 3))
+            if n_e and getattr(backend, "rk_in_tile3_launches", 0):
+                e_l = n_e / 3.0
+                e_ms = ms_e / e_l
+                e_bytes = 64.0 * dofb + 8.0 * dofb * backend.rk_in_tile3_passes / backend.rk_in_tile3_launches
+                dominant["with_rk_stage"] = {
+                    "name": dominant["name"].split(" ")[0].replace("P12>", "P12,EPI>") + " (transeq_z + the RK stage of u, v, w)",
+                    "launches": e_l, "avg_launch_ms": e_ms, "algorithmic_bytes_per_launch": e_bytes,
+                    "bytes_convention": "64 B/DoF + 8 B/DoF per field the stage reads or writes",
+                    "achieved": e_bytes / (e_ms * 1e-3) / 1e9, "frac": e_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         class_average = {"what": "average over the x, y and z launches of the transport-equation class; x launches that also "
                                  "apply the pending velocity correction are credited its 48 B/DoF",
                          "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,

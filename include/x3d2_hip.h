@@ -324,6 +324,16 @@ int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const x3d_real *u, co
                         const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                         const x3d_tdsops *der2nd_sym, x3d_real *y, const x3d_real *base, int nterm, const x3d_real *c,
                         x3d_real *const *x, int ipend, int store);
+/* round 5: transeq_<dir> (y or z, the last direction accumulated into du, dv, dw) + the stage's linear combinations of ALL
+ * THREE variables in one launch of the three-components tile kernel: d_i = dvar_i + component_i; [store_i: dvar_i = d_i;]
+ * y_i = base_i + sum_k c[5 i + k] (k == ipend_i ? d_i : x[5 i + k]), variable order u, v, w, x[5 i + ipend_i] == dvar_i.
+ * Bit-identical to x3d_transeq_acc followed by x3d_lincomb per variable (src/solver.f90:291-389 then
+ * src/time_integrator.f90:166-231).  *done = 0: not served for these pencils, nothing was done. */
+int x3d_transeq_lincomb3(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u,
+                         const x3d_real *v, const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st,
+                         const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                         x3d_real *const y[3], const x3d_real *const base[3], const int nterm[3], const x3d_real *c,
+                         x3d_real *const *x, const int ipend[3], const int store[3], int *done);
 int x3d_lincomb_pending(x3d_backend *b, int dir, x3d_real *y, const x3d_real *base, int nterm, const x3d_real *c,
                         x3d_real *const *x, int ipend, const x3d_real *pend, int store);
 

@@ -21,3 +21,7 @@ fs = glob.glob("gpurun_out/prof_chan/*/*kernel_stats.csv")
 if fs:
     shutil.copy(max(fs, key=os.path.getmtime), f"profiles/{R}_kernel_stats_channel.csv")
     print("copied kernel stats channel")
+fs = glob.glob("gpurun_out/prof_v8/*/*kernel_stats.csv")
+if fs:
+    shutil.copy(max(fs, key=os.path.getmtime), f"profiles/{R}_kernel_stats_emulated_8_ranks.csv")
+    print("copied kernel stats emulated 8 ranks")

@@ -21,6 +21,9 @@ X3D_BENCH_SHARE_GPU=1 python bench.py --gpus 4 --n 128 --steps 2 --warmup 1 > gp
 # the emulated scaling curve (one process = rank 0 of V, links at 61.4 GB/s): y slabs, V = 2, 4, 8
 for v in 2 4 8; do python bench.py --virtual-ranks $v --steps 8 --warmup 3 > gpurun_out/bench_${rnd}_virtual$v.json 2>/dev/null; python -c "
 import json; d=json.loads(open('gpurun_out/bench_${rnd}_virtual$v.json').read().strip().split('\n')[-1]); print('virtual ranks $v', d['ms_per_step'], d['config']['exchanges_one_step'])"; done
+# kernel-trace stats of the emulated 8-rank step (which kernels the N > 1 code path adds)
+rm -rf gpurun_out/prof_v8
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v8 -- python bench.py --virtual-ranks 8 --steps 2 --warmup 1 > gpurun_out/prof_v8.log 2>&1
 # kernel-trace stats of the channel bench
 rm -rf gpurun_out/prof_chan
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_chan -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --case channel --no-live-traffic > gpurun_out/prof_chan.log 2>&1

@@ -1239,6 +1239,7 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec, route):
             os.environ.pop("X3D_NO_DEFER", None)
         if route == "tile":
             os.environ["X3D_STAGE_IN_TILE"] = "1"  # (opt-in: solver.py, transeq_fused)
+        os.environ["X3D_NO_EPI3"] = "1"  # (these are the two older homes of the stage; the default one has its own test below)
         try:
             mesh = Mesh(dims, (1, 1, 1), L, per, per, per)
             s = Solver(HipBackend(mesh), mesh, SolverConfig(poisson_solver_type="CG", fused=True, time_intg=intg,
@@ -1261,6 +1262,7 @@ def test_deferred_transeq_accumulation_is_bit_identical(intg, nspec, route):
         finally:
             os.environ.pop("X3D_NO_DEFER", None)
             os.environ.pop("X3D_STAGE_IN_TILE", None)
+            os.environ.pop("X3D_NO_EPI3", None)
 
     fused, n_fused = run(False)
     plain, n_plain = run(True)
@@ -1897,3 +1899,25 @@ def test_bench_virtual_ranks_line():
     probe = o["config"]["comm_stream_probe_ms"]
     assert probe and probe[-1][0] < 0.75 * probe[-1][1]  # the stream taken runs beside the compute stream
     assert 40.0 < o["ms_per_step"] < 80.0
+
+
+@pytest.mark.parametrize("n,time_intg", [(256, "RK3"), (512, "RK3"), (256, "RK4"), (256, "RK2")])
+def test_rk_stage_inside_the_three_component_z_launch_is_bit_identical(n, time_intg, monkeypatch):
+    """round 5: in every RK stage the z launch of transeq (three components, k_ytile_transeq3<EPI>) also does
+    the stage's linear combination of u, v, w (x3d_transeq_lincomb3) -- d = rhs + component ; [rhs = d] ; y = base + sum c x in
+    k_lincomb's order.  Two steps against the same steps with the stage in the divergence's first x operators
+    (X3D_NO_EPI3=1): bit for bit, and the launches counted"""
+    from x3d2_amd import make_tgv
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("X3D_NO_EPI3", off)
+        case = make_tgv(n, time_intg=time_intg, fused=True)
+        case.step(1, more=True)
+        case.step(2)
+        s = case.solver
+        out[off] = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
+        ns = s.time_integrator.nstage
+        assert getattr(s.time_integrator, "n_stage_in_transeq", 0) == (0 if off == "1" else 2 * ns)
+        del case, s
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)

@@ -47,11 +47,17 @@ commit = os.environ.get("X3D_ARTIFACT_COMMIT") or \
     subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = not os.environ.get("X3D_ARTIFACT_COMMIT") and bool(
     subprocess.run(["git", "status", "--porcelain", "x3d2_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
-dom = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k]
+def _epi(k):
+    # k_ytile_transeq3's seventh template flag (printed only when true): the launches that also do the RK stage
+    a = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
+    return len(a) == 7 and a[6].strip() == "true"
+dom = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k and not _epi(k)]
+dom_e = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k and _epi(k)]
 json.dump({"n": 512, "round": rnd, "commit": commit + ("+uncommitted" if dirty else ""),
            "transeq_component_bytes_per_launch": comp,
            "dominant_kernel": "k_ytile_transeq3<8,true,true,false>",
            "dominant_kernel_bytes_per_launch": dom[0] if dom else None,
+           "dominant_kernel_with_rk_stage_bytes_per_launch": dom_e[0] if dom_e else None,
            "components_profiled": n_comp,
            "note": "HBM bytes per transport-equation component (all k_*transeq* + k_transpose64 + k_transpose_lincomb kernels / number of components; the latter also does the RK stage's linear combination) "
                    "from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per "

@@ -114,6 +114,8 @@ PROTOTYPES = {
     "x3d_pending_flush": (I, [VP, I, VP, VP]),
     "x3d_transeq_stage_ok": (I, [VP, I, VP, VP, VP, VP]),
     "x3d_transeq_lincomb": (I, [VP, I, I, VP, VP, D, VP, VP, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), I, I]),
+    "x3d_transeq_lincomb3": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, ctypes.POINTER(VP), ctypes.POINTER(VP), c_int_p,
+                                 c_double_p, ctypes.POINTER(VP), c_int_p, c_int_p, c_int_p]),
     "x3d_lincomb_pending": (I, [VP, I, VP, VP, I, c_double_p, ctypes.POINTER(VP), I, VP, I]),
     "x3d_scalar_product": (I, [VP, VP, VP, c_int_p, c_double_p]),
     "x3d_field_max_sum": (I, [VP, VP, c_int_p, c_double_p, c_double_p]),

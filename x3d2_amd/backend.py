@@ -604,6 +604,35 @@ class HipBackend:
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
         self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
 
+    def transeq_lincomb3(self, direction, rhs, vel, nu, dirps, specs):
+        """transeq_<direction> accumulated into rhs = (du, dv, dw) AND the stage's linear combination of every variable in
+        the same launch (csrc/xscan.hip k_ytile_transeq3<EPI>): specs[i] = (y, base, coeffs, fields, store) with rhs[i] one of
+        `fields`.  False: these pencils are not served (nothing was done)"""
+        y = (VP * 3)(*[sp[0].ptr for sp in specs])
+        base = (VP * 3)(*[sp[1].ptr for sp in specs])
+        nterm = _lib.ints(*[len(sp[3]) for sp in specs])
+        c = (_lib.REAL * 15)()
+        x = (VP * 15)()
+        ipend, store = [], []
+        for i, (_, _, coeffs, fields, st) in enumerate(specs):
+            ptrs = [f.ptr for f in fields]
+            ipend.append(ptrs.index(rhs[i].ptr))
+            store.append(int(bool(st)))
+            for k, (cv, pv) in enumerate(zip(coeffs, ptrs)):
+                c[5 * i + k] = float(cv)
+                x[5 * i + k] = pv
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_lincomb3(
+            self.h, direction, rhs[0].ptr, rhs[1].ptr, rhs[2].ptr, vel[0].ptr, vel[1].ptr, vel[2].ptr, float(nu),
+            dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle, dirps.der2nd_sym.handle, y, base, nterm, c, x,
+            _lib.ints(*ipend), _lib.ints(*store), ctypes.byref(flag)))
+        if flag.value:
+            self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + sum(len(sp[3]) + 1 for sp in specs)
+            self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
+            self.rk_in_tile3_passes = getattr(self, "rk_in_tile3_passes", 0) + sum(len(sp[3]) + 1 for sp in specs)
+            self.rk_in_tile3_launches = getattr(self, "rk_in_tile3_launches", 0) + 1
+        return bool(flag.value)
+
     def transeq_component_acc(self, direction, kind, rhs_ptr, u_ptr, conv_ptr, nu, dirps):
         """rhs += one transeq component (kind as in transeq_lincomb)"""
         ops = (dirps.der1st, dirps.der1st_sym, dirps.der2nd) if kind == 0 else \

@@ -86,7 +86,7 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
     b->red_cap = 4096;
     X3D_HIP(hipMalloc(&b->red_buf, sizeof(real_t) * 2 * b->red_cap));
     X3D_HIP(hipHostMalloc(&b->red_host, sizeof(real_t) * 2 * b->red_cap));
-    X3D_HIP(hipMalloc(&b->epi_dev, 256));
+    X3D_HIP(hipMalloc(&b->epi_dev, 512));
     b->lds_optin = new std::unordered_set<const void *>();
     X3D_HIP(hipEventCreate(&b->ev0));
     X3D_HIP(hipEventCreate(&b->ev1));

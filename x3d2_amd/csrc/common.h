@@ -148,7 +148,7 @@ struct x3d_backend {
     long n_upd;       // ... of those, launches that also applied the pending velocity correction (UPD form)
     long n_tq3;       // launches of the three-components-in-one transeq kernels (bench.py prices them at 48 B/DoF)
     long n_halo;      // launches of the HALO forms of the tile kernels (a decomposed direction in one pass)
-    void *epi_dev;    // 256-byte device slot for the RK-stage description of k_ytile_transeq<EPI> (xscan.hip)
+    void *epi_dev;    // 512-byte device slot for the RK-stage descriptions of k_ytile_transeq<EPI> / k_ytile_transeq3<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
     unsigned prof_mask;     // kernel classes that are timed while the timers are on (bit = X3D_K_*; x3d_prof_select)
@@ -162,6 +162,15 @@ struct x3d_backend {
     // profiles/r05_yslab_pipeline_timeline.txt).  With fewer workgroups than CUs some CUs stay empty and the exchange
     // starts at once; the kernels are memory-bound, 248 CUs stream what 256 do.  0 on one rank.
     int comm_reserve;
+};
+// the RK / AB stage of one variable as the epilogue of a tile kernel (xscan.hip, k_ytile_transeq<EPI> / k_ytile_transeq3<EPI>):
+// d = x[ipend] + component;  [store: x[ipend] = d;]  y = base + sum_k c[k] (k == ipend ? d : x[k])
+struct TileEpi {
+    real_t *y;
+    const real_t *base;
+    const real_t *x[5];
+    real_t c[5];
+    int n, ipend, store;
 };
 #define X3D_NCU 256  // MI355X
 static inline int x3d_persistent_blocks(const x3d_backend *b, long want)

@@ -419,3 +419,54 @@ extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const real
     X3D_REQUIRE(done, "x3d_transeq_lincomb: tile kernel refused");
     return 0;
 }
+
+// ---------------------------------------------------------------- the RK stage of u, v, w inside ONE three-component launch
+// transeq_<dir> (dir = y or z, the LAST direction accumulated into du, dv, dw) + the stage's linear combinations of the
+// three variables (src/time_integrator.f90:166-231 after src/solver.f90:291-389):
+//     d_i = dvar_i + component_i;  [store_i: dvar_i = d_i;]  y_i = base_i + sum_k c_i[k] (k == ipend_i ? d_i : x_i[k])
+// variable order u, v, w; c, x: [3][5] row by row; x_i[ipend_i] must be dvar_i.  Bit-identical to x3d_transeq_acc followed by
+// x3d_lincomb per variable.  *done = 0: these pencils are not served by the three-in-one tile kernel (nothing was done).
+int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
+                           const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                           const x3d_tdsops *der2nd_sym, const TileEpi epi[3], bool *done);
+extern "C" int x3d_transeq_lincomb3(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                                    const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
+                                    const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                                    real_t *const y[3], const real_t *const base[3], const int nterm[3], const real_t *c,
+                                    real_t *const *x, const int ipend[3], const int store[3], int *done)
+{
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && y && base && nterm &&
+                c && x && ipend && store && done, "x3d_transeq_lincomb3: null argument");
+    X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_lincomb3: dir must be y or z");
+    *done = 0;
+    real_t *dv_[3] = {du, dv, dw};
+    const real_t *fv[3] = {u, v, w};
+    TileEpi e[3];
+    // component order of the direction: the advecting variable first (x3d_transeq_acc)
+    const int var_of[3] = {dir == X3D_DIR_Y ? 1 : 2, 0, dir == X3D_DIR_Y ? 2 : 1};
+    real_t *r[3];
+    const real_t *f[3];
+    for (int cpt = 0; cpt < 3; cpt++) {
+        const int i = var_of[cpt];
+        X3D_REQUIRE(nterm[i] >= 1 && nterm[i] <= 5 && ipend[i] >= 0 && ipend[i] < nterm[i],
+                    "x3d_transeq_lincomb3: bad term count / index");
+        X3D_REQUIRE(y[i] && base[i] && x[5 * i + ipend[i]] == dv_[i], "x3d_transeq_lincomb3: x[ipend] must be the variable's derivative block");
+        // (y_i may BE the variable it updates: a workgroup owns its tile's pencils, reads field i's rows of the tile before
+        //  component i's store phase writes them, and keeps the advecting velocity's rows in registers; nothing else may alias)
+        for (int k = 0; k < 3; k++)
+            X3D_REQUIRE((y[i] != fv[k] || k == i) && y[i] != dv_[k], "x3d_transeq_lincomb3: a result aliases an input of the launch");
+        r[cpt] = dv_[i];
+        f[cpt] = fv[i];
+        e[cpt].y = y[i]; e[cpt].base = base[i]; e[cpt].n = nterm[i]; e[cpt].ipend = ipend[i]; e[cpt].store = store[i];
+        for (int k = 0; k < 5; k++) {
+            e[cpt].x[k] = k < nterm[i] ? x[5 * i + k] : x[5 * i];
+            e[cpt].c[k] = k < nterm[i] ? c[5 * i + k] : 0.0;
+        }
+    }
+    bool ok = false;
+    if (int rc = x3d_ytile_transeq3_epi(b, dir, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, e, &ok)) return rc;
+    *done = ok ? 1 : 0;
+    return 0;
+}

@@ -674,13 +674,7 @@ __global__ void __launch_bounds__(512)
 //     d = rhs + result;  [rhs = d;]  y = base + sum_k c[k] * (k == ipend ? d : x[k])
 // in the summation order of k_lincomb (backend.hip): bit-identical to the accumulating form followed by
 // x3d_lincomb, without re-reading d (and without writing it after the last stage).
-struct TileEpi {
-    real_t *y;
-    const real_t *base;
-    const real_t *x[5];
-    real_t c[5];
-    int n, ipend, store;
-};
+// (struct TileEpi: common.h)
 
 template <int Q, bool SAME, bool ACC, int FAST, bool EPI = false>
 __global__ void __launch_bounds__(1024)
@@ -885,12 +879,20 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 // P12 (with UNI): the component's first two solves -- d(u conv) and du, the SAME operator on two right-hand sides -- run
 // as ONE solve over the pair type V2: every table value read from LDS serves both (204 -> 136 reads per lane and
 // component) and the two dependency chains interleave.  Same arithmetic per right-hand side, bit for bit.
-template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false>
+// EPI (round 5; local accumulating form): the launch is the LAST contribution to rhs and the RK / AB stage follows at once
+// (time_integrator.py, runge_kutta_fused): component c's store phase also does ITS variable's linear combination,
+//     d = rhs_c + result;  [rhs_c = d;]  y_c = base_c + sum_k c_k (k == ipend ? d : x_k)
+// in the summation order of k_lincomb / k_xscan_tds_lin: bit-identical to this kernel followed by the stage, without d being
+// read back by the stage's kernel (and without writing it after the last stage).  epp: three TileEpi in device memory,
+// component order (advecting component first).  Per step the EPI launches save 6 of ~ 200 field passes (stages 1 and 3
+// of RK3; stage 2 gains nothing: DESIGN.md 3.2) and trade the stage kernel's streaming rate for the tile pattern's.
+template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false, bool EPI = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0,
                      const real_t *__restrict__ u1, const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
-                     int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th)
+                     int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th, const TileEpi *epp = nullptr)
 {
+    static_assert(!EPI || (ACC && !HALO), "EPI: the local accumulating form");
     extern __shared__ real_t lt[];
     constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
@@ -1078,6 +1080,44 @@ __global__ void __launch_bounds__(1024)
                 //  what limits, the memory system is busy throughout with this pattern's 128-byte segments)
                 real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
                 real2_t old[NI];
+                if constexpr (EPI) {
+                    // the stage's description, per component, through a laundered pointer (as kernel arguments its scalars
+                    // would stay live across the solves and overflow the SGPR file -- see k_ytile_transeq<EPI>)
+                    const TileEpi *pe = epp + c;
+                    asm volatile("" : "+s"(pe) : "v"(T[0]));
+                    const TileEpi epi = *pe;
+                    real2_t bs[NI];
+                    gload(old, o);
+                    gload(bs, epi.base + off);
+                    real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
+#pragma unroll
+                    for (int m = 0; m < Q / 2; m++)
+                        dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+                    __syncthreads();
+                    real2_t d[NI];
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        d[i] = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                        d[i].x += old[i].x;
+                        d[i].y += old[i].y;
+                        if (epi.store) *const_cast<real2_t *>(tile_row(o, prow, i, voff)) = d[i];
+                    }
+#pragma unroll  // (static indices into epi: a run-time index would put the struct on the stack)
+                    for (int k = 0; k < 5; k++) {
+                        if (k >= epi.n) continue;
+                        if (k == epi.ipend) {
+#pragma unroll
+                            for (int i = 0; i < NI; i++) { bs[i].x = epi.c[k] * d[i].x + bs[i].x; bs[i].y = epi.c[k] * d[i].y + bs[i].y; }
+                        } else {
+                            real2_t xk[NI];
+                            gload(xk, epi.x[k] + off);
+#pragma unroll
+                            for (int i = 0; i < NI; i++) { bs[i].x = epi.c[k] * xk[i].x + bs[i].x; bs[i].y = epi.c[k] * xk[i].y + bs[i].y; }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NI; i++) *const_cast<real2_t *>(tile_row(epi.y + off, prow, i, voff)) = bs[i];
+                } else {
                 YT_T(3);
 #ifdef YT_TIMING
                 if (lane == 0) {
@@ -1117,6 +1157,7 @@ __global__ void __launch_bounds__(1024)
                     *const_cast<real2_t *>(tile_row(o, prow, i, voff)) = v;
 #endif
                 }
+                }  // (!EPI)
             }
             YT_T(6);
             __syncthreads();  // the tile is free again
@@ -1897,6 +1938,55 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
     if (halo) b->n_halo++;
     if (b->prof) {  // count the launch as three components (bench.py divides the direction's time by the count)
         for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
+    }
+    *done = true;
+    return 0;
+}
+
+// ... with the RK / AB stage of the three variables in the store phases (k_ytile_transeq3<.., EPI>): epi[c] describes
+// component c's combination (c = 0: the advecting component).  Local periodic uniform-grid pencils only (the bench's form);
+// *done = false: not served, nothing was launched
+int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
+                           const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                           const x3d_tdsops *der2nd_sym, const TileEpi epi[3], bool *done)
+{
+    *done = false;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_TILE3"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
+    if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
+    const int Q = der1st->tab.Q;
+    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
+    const bool uni = der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
+    if (lds > 160 * 1024 || !narrow || !uni) return 0;
+    const long pxy = (long)b->nxp * b->nyp;
+    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const int blocks = x3d_persistent_blocks(b, ntiles);
+    const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
+    if (128 * rstride * X3D_RB >= (1L << 32)) return 0;
+    static_assert(3 * sizeof(TileEpi) <= 512, "epi_dev slot");
+    X3D_HIP(hipMemcpyAsync(b->epi_dev, epi, 3 * sizeof(TileEpi), hipMemcpyHostToDevice, b->stream));
+    const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
+    {
+        // (timed under direction slot 0: x3d_prof_get(kind, 3) stays the plain z launches, the sum over slots has these)
+        ProfScope ps(b, X3D_K_TRANSEQ_FWD, 0);
+        if (Q == 8) {
+            X3D_LDS_OPTIN(b, (k_ytile_transeq3<8, true, true, false, true, true, true>));
+            hipLaunchKernelGGL((k_ytile_transeq3<8, true, true, false, true, true, true>), dim3(blocks), dim3(1024), lds, b->stream,
+                               r[0], r[1], r[2], f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, 0, ntiles, rstride,
+                               ostride, nu, th, (const TileEpi *)b->epi_dev);
+        } else {
+            X3D_LDS_OPTIN(b, (k_ytile_transeq3<4, true, true, false, true, true, true>));
+            hipLaunchKernelGGL((k_ytile_transeq3<4, true, true, false, true, true, true>), dim3(blocks), dim3(1024), lds, b->stream,
+                               r[0], r[1], r[2], f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, 0, ntiles, rstride,
+                               ostride, nu, th, (const TileEpi *)b->epi_dev);
+        }
+    }
+    X3D_HIP(hipGetLastError());
+    b->n_tq3++;
+    if (b->prof) {
+        for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, 0); }
     }
     *done = true;
     return 0;

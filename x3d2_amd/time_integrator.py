@@ -145,30 +145,67 @@ class TimeIntegrator:
         self.defer_update = bool(defer_update)
         a, bb = self.RK_A[ns], self.RK_B[ns]
         self.gdt = bb[self.istage - 1] * dt
+        # round 5: transeq's z launch is still pending for u, v, w and will do their stage itself (Solver.transeq_fused,
+        # HipBackend.transeq_lincomb3): (direction, nu, dirps); the fields are the ones this stage's swaps leave in place
+        tile3 = pending.pop("tile3", None) if pending else None
+        in_transeq = False
         if self.istage == ns:
+            specs = []
             for i in range(self.nvars):
                 terms = [(bb[j - 1] * dt, self.olds[i][j]) for j in range(1, ns) if bb[j - 1] != 0.0]
                 terms.append((bb[ns - 1] * dt, deriv[i]))
                 base = self.olds[i][0] if ns > 1 else curr[i]
-                # the derivative of the last stage is not needed afterwards: no store
-                self._lincomb(curr[i], base, [c for c, _ in terms], [f for _, f in terms], pending, False, var=i)
+                specs.append((curr[i], base, [c for c, _ in terms], [f for _, f in terms], False))
+            if tile3 is not None:
+                # (the velocity the launch reads is curr itself, overwritten tile by tile behind its last use; the
+                #  derivative of the last stage is not needed afterwards: no store)
+                in_transeq = ns > 1 and self._stage_in_transeq(tile3, deriv[:3], curr[:3], specs[:3])
+            for i, sp in enumerate(specs):
+                if not (in_transeq and i < 3):
+                    self._lincomb(sp[0], sp[1], sp[2], sp[3], pending, False, var=i)
             self._flush(pending)
             self.istage = 1
         else:
             st = self.istage
+            specs = []
             for i in range(self.nvars):
                 if st == 1:
                     self._swap(self.olds[i][0], curr[i])     # olds1 <- curr (curr is rewritten below)
                 self._swap(self.olds[i][st], deriv[i])       # olds_{st+1} <- deriv
                 terms = [(a[st - 1][j - 1] * dt, self.olds[i][j]) for j in range(1, st + 1)
                          if a[st - 1][j - 1] != 0.0]
-                if terms:
-                    self._lincomb(curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms], pending,
-                                  True, var=i)
+                specs.append((curr[i], self.olds[i][0], [c for c, _ in terms], [f for _, f in terms], True))
+            if tile3 is not None:
+                # after the swaps the launch's derivative blocks sit in olds[.][st] and, in the first stage, the velocity
+                # it reads in olds[.][0]; the derivative must be a term of the combination (a[st][st] != 0: RK2 - RK4)
+                rhs = [self.olds[i][st] for i in range(3)]
+                vel = [self.olds[i][0] if st == 1 else curr[i] for i in range(3)]
+                ok = all(any(f is r for f in sp[3]) for sp, r in zip(specs[:3], rhs))
+                in_transeq = self._stage_in_transeq(tile3, rhs, vel, specs[:3]) if ok else self._complete_transeq(tile3, rhs, vel)
+            for i, sp in enumerate(specs):
+                if in_transeq and i < 3:
+                    continue
+                if sp[2]:
+                    self._lincomb(sp[0], sp[1], sp[2], sp[3], pending, True, var=i)
                 else:
-                    b.veccopy(curr[i], self.olds[i][0])
+                    b.veccopy(sp[0], sp[1])
             self._flush(pending)
             self.istage += 1
+
+    def _complete_transeq(self, tile3, rhs, vel):
+        """the pending z launch as a plain accumulating transeq (the stage then runs as usual); returns False"""
+        direction, nu, dirps = tile3
+        self.backend.transeq_dir(direction, rhs[0], rhs[1], rhs[2], vel[0], vel[1], vel[2], nu, dirps, accumulate=True)
+        return False
+
+    def _stage_in_transeq(self, tile3, rhs, vel, specs):
+        """transeq's pending z launch with the stage of u, v, w in its store phases (csrc/xscan.hip k_ytile_transeq3<EPI>);
+        False: not served for these pencils -- transeq was completed the plain way, the caller runs the stage as usual"""
+        direction, nu, dirps = tile3
+        if self.backend.transeq_lincomb3(direction, rhs, vel, nu, dirps, specs):
+            self.n_stage_in_transeq = getattr(self, "n_stage_in_transeq", 0) + 1
+            return True
+        return self._complete_transeq(tile3, rhs, vel)
 
     def adams_bashforth_fused(self, curr, deriv, dt, pending=None, defer_update=False):
         b = self.backend
