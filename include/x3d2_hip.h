@@ -612,7 +612,9 @@ int x3d_pfft_bwd_a_part(x3d_pfft *p, const x3d_real *recv_yx, x3d_real *f_out, i
  * rewrite, [15] extra buffers held, [16] pressure corrections through the z-first solve, [17] DECLINED: operations that ran
  * unfused although the reference's fixed sequences always offer a rewrite (a sum_{y,z}intox or a transeq_y / z launched by
  * itself) -- together with [10] the witness of a call sequence the rewrites do not recognise; a process that ends with
- * [17] + [10] > 0 says so once on stderr (results are the call-by-call ones, only slower); [18..23] reserved (0). */
+ * [17] + [10] > 0 says so once on stderr (results are the call-by-call ones, only slower); [18] sub-steps whose RK stage of
+ * u, v, w ran inside the last transeq launch (x3d_transeq_lincomb3); [19..23] reserved (0).
+ * Rewrites can be switched off one by one for A/B runs: X3D_LAZY_RULES = bit mask (bit 9 = 512: the RK stage above). */
 int x3d_lazy_enable(x3d_backend *b, int on);
 int x3d_lazy_flush(x3d_backend *b);
 int x3d_lazy_sync(x3d_backend *b);

@@ -47,16 +47,25 @@ def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, mon
             nopairs.step(it)
         _same(eager, nopairs)
         assert nopairs.solver.backend.lazy_stats()["pairs"] == 0
+        # ... and with the RK stage of u, v, w inside the z launch of transeq on top (rule 10, bit 512: round 5)
+        monkeypatch.setenv("X3D_LAZY_RULES", str(255 - 2 - 4 + 512))
+        staged = make_tgv(n, time_intg=time_intg, fused=False, lazy=True)
+        for it in range(1, steps + 1):
+            staged.step(it)
+        _same(eager, staged)
+        ss = staged.solver.backend.lazy_stats()
+        assert ss["pairs"] == 0 and ss["transeq_stage"] == steps * staged.solver.time_integrator.nstage, ss
     st = lazy.solver.backend.lazy_stats()
     nsub = steps * lazy.solver.time_integrator.nstage
-    assert st["transeq_acc"] == 2 * nsub
+    # (256- / 512-row z pencils: the z launch also does the RK stage of u, v, w -- transeq_stage, rule 10)
+    assert st["transeq_acc"] + st["transeq_stage"] == 2 * nsub and st["transeq_stage"] == (nsub if n == 256 else 0), st
     assert st["pairs"] == 4 * nsub          # y and z of the divergence (mode 0), z and y of the gradient (mode 1)
     # u, v, w -= gradient: three accumulating solves, or (every sub-step but the last before a read of the velocity)
     # inside the next sub-step's transeq_x launch
     # (the kernel that carries the correction serves periodic 256 / 512-point x pencils)
     assert st["tds_acc"] + 3 * st["transeq_upd"] == 3 * nsub and (n != 256 or st["transeq_upd"] >= nsub - steps - 1)
     assert st["solve_000"] == nsub
-    assert st["tds_lincomb"] + st["lincombs"] >= 3 * nsub - 3
+    assert st["tds_lincomb"] + st["lincombs"] + 3 * st["transeq_stage"] >= 3 * nsub - 3
     # ... and every stage rides on its first x operator: where the blocks of the three stages change hands in a ring (RK3's
     # last stage) the fused kernel writes into a free buffer that the handle's next life is bound to (rule 6, L_BIND)
     assert st["lincombs"] <= 3 and st["extra_buffers"] == 0, st
@@ -221,6 +230,7 @@ def test_deferred_pressure_correction_takes_the_z_first_solve_at_512_cubed():
     st = lazy.solver.backend.lazy_stats()
     assert st["zfirst"] == 3 and st["solve_000"] == 0 and st["pairs"] == 2 * 3
     assert st["materialised"] == 0
+    assert st["transeq_stage"] == 3 and st["transeq_acc"] == 3, st  # (the RK stage of u, v, w in the z launch: rule 10)
     for x, y in zip(got, ref):
         assert np.max(np.abs(x - y)) < 1e-12 * max(np.max(np.abs(y)), 1.0)
     del lazy, got
@@ -230,7 +240,15 @@ def test_deferred_pressure_correction_takes_the_z_first_solve_at_512_cubed():
         plain.step(1)
         got = _fields(plain)
         st = plain.solver.backend.lazy_stats()
-        assert st["zfirst"] == 0 and st["solve_000"] == 3
+        assert st["zfirst"] == 0 and st["solve_000"] == 3 and st["transeq_stage"] == 0
+        for x, y in zip(got, ref):
+            assert np.array_equal(x, y)
+        del plain, got
+        os.environ["X3D_LAZY_RULES"] = str(1023 - 256 - 2 - 4)  # ... and bit for bit with the stage in the z launch
+        staged = make_tgv(512, fused=False, lazy=True)
+        staged.step(1)
+        got = _fields(staged)
+        assert staged.solver.backend.lazy_stats()["transeq_stage"] == 3
         for x, y in zip(got, ref):
             assert np.array_equal(x, y)
     finally:

@@ -124,7 +124,7 @@ class HipBackend:
 
     LAZY_STATS = ("recorded", "launched", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
                   "solve_000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped", "transeq_upd",
-                  "extra_buffers", "zfirst", "declined")
+                  "extra_buffers", "zfirst", "declined", "transeq_stage")
 
     def lazy_stats(self):
         """counters of the deferred-execution layer (x3d_lazy_stats)"""

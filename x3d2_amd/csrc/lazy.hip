@@ -17,6 +17,8 @@
 //   fft_forward(f) ; fft_postprocess_000 ; fft_backward(f)                  -> x3d_poisson_solve_000
 //   u += s A(gu) ; v += s B(gv) ; w += s B(gw) ; transeq_x(...; u, v, w)    -> x3d_transeq_x_update
 //   pair_z(mode 0) -> d ; reorder ; solve_000 ; reorder ; pair_z(mode 1)     -> the z-first solve (csrc/zfirst.hip)
+//   transeq_acc_z(du, dv, dw) ; [olds = du] ; lincomb(u), lincomb(v), lincomb(w) that read du, dv, dw
+//                                                                             -> x3d_transeq_lincomb3 (the RK stage in the z launch)
 // every one of which is the same arithmetic in the same order as the calls it replaces (tests/test_hip_lazy.py
 // compares bit for bit).  A temporary is dropped only when the queue shows it dead: overwritten, or released to the
 // allocator (x3d_block_discard, which the shim's release_block issues) before anything reads it.
@@ -38,7 +40,7 @@
 enum LKind {
     L_DEAD = 0, L_TRANSEQ, L_TRANSEQ_ACC, L_TDS, L_TDS_ACC, L_PAIR, L_TDS_LIN, L_COPY, L_SUM, L_VECADD, L_LINCOMB, L_VECMULT,
     L_SCALE, L_SHIFT, L_FILL, L_DISCARD, L_FFT_FWD, L_FFT_POST000, L_FFT_BWD, L_SOLVE000, L_TRANSEQ_UPD, L_SPECIES, L_SPECIES_ACC, L_ZFIRST,
-    L_FFT_POST010, L_SOLVE010R, L_BIND, L_SETFACE
+    L_FFT_POST010, L_SOLVE010R, L_BIND, L_SETFACE, L_TRANSEQ_STAGE
 };
 
 struct LOp {
@@ -50,10 +52,17 @@ struct LOp {
     real_t s[6] = {0, 0, 0, 0, 0, 0};
     void *obj = nullptr;  // x3d_poisson* of the FFT hooks
     int dims[3] = {0, 0, 0};  // L_SETFACE: the field's extent
+    // L_TRANSEQ_STAGE (rule 10): o[0..2] the derivative blocks (updated), o[3..5] the stage's results, in[0..2] u, v, w;
+    // per variable c: xin[c] the base, xin[3 + 5 c + k] / xs[5 c + k] term k of xn[c], xp[c] the term that IS o[c];
+    // mode bit c: o[c] is released behind the launch (its release stood between the combinations)
+    const real_t *xin[18] = {};
+    real_t xs[15] = {};
+    int xn[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
-       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_POOL_SLOT, ST_ZFIRST, ST_DECLINED, ST_N };
+       ST_MATERIALISE, ST_NORMALISE_COPIES, ST_FLUSHES, ST_DROPPED, ST_TRANSEQ_UPD, ST_POOL_SLOT, ST_ZFIRST, ST_DECLINED,
+       ST_TRANSEQ_STAGE, ST_N };
 // ST_DECLINED: operations of the recorded sequence that no rewrite absorbed although the reference's fixed sequences
 // always offer one -- a sum_{y,z}intox launched by itself (rule 1 did not find its transeq_<d> + three sums), a transeq_y / z
 // launched without its sums, a reorder / veccopy that had to move data (materialised).  Not wrong, only slow (the
@@ -246,7 +255,7 @@ enum { A_R = 1, A_W = 2, A_M = 4 };  // read, overwritten completely, updated in
 static int nin(const LOp &op)
 {
     switch (op.kind) {
-    case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5)
+    case L_TRANSEQ: case L_TRANSEQ_ACC: case L_TRANSEQ_UPD: case L_TRANSEQ_STAGE: return 3;  // (UPD: the three gradients; u, v, w are outputs 3..5; STAGE: + xin, see touch)
     case L_TDS: case L_TDS_ACC: case L_COPY: case L_SUM: case L_VECADD: case L_VECMULT: case L_SETFACE: return 1;
     case L_SPECIES: case L_SPECIES_ACC: return 2;  // uvw, spec
     case L_ZFIRST: return 2;
@@ -261,6 +270,7 @@ static int nout(const LOp &op)
     switch (op.kind) {
     case L_TRANSEQ: case L_TRANSEQ_ACC: return 3;
     case L_TRANSEQ_UPD: return 6;  // du, dv, dw written; u, v, w updated in place (and read)
+    case L_TRANSEQ_STAGE: return 6;  // du, dv, dw updated; the three results written
     case L_PAIR: return op.mode == 0 ? 1 : 2;
     case L_TDS_LIN: return 2;  // du, y
     case L_ZFIRST: return 2;
@@ -271,6 +281,7 @@ static int nout(const LOp &op)
 static bool out_is_update(const LOp &op, int slot = 0)
 {
     if (op.kind == L_TRANSEQ_UPD) return slot >= 3;
+    if (op.kind == L_TRANSEQ_STAGE) return slot < 3;
     switch (op.kind) {
     case L_SPECIES_ACC:
     case L_TRANSEQ_ACC: case L_TDS_ACC: case L_SUM: case L_VECADD: case L_VECMULT: case L_SCALE: case L_SHIFT: case L_FFT_FWD:
@@ -286,6 +297,12 @@ static int touch(const LOp &op, const real_t *h)
         if (op.in[k] == h) m |= A_R;
     for (int k = 0; k < nout(op); k++)
         if (op.o[k] == h) m |= out_is_update(op, k) ? A_M : A_W;
+    if (op.kind == L_TRANSEQ_STAGE)
+        for (int c = 0; c < 3; c++) {
+            if (op.xin[c] == h) m |= A_R;
+            for (int k = 0; k < op.xn[c]; k++)
+                if (op.xin[3 + 5 * c + k] == h) m |= A_R;
+        }
     return m;
 }
 // no operation strictly between lo and hi touches any of `quiet`, none writes any of `stable`
@@ -329,12 +346,24 @@ static std::vector<const real_t *> inputs_of(const LOp &op)
 {
     std::vector<const real_t *> v;
     for (int k = 0; k < nin(op); k++) v.push_back(op.in[k]);
+    if (op.kind == L_TRANSEQ_STAGE)
+        for (int c = 0; c < 3; c++) {
+            v.push_back(op.xin[c]);
+            for (int k = 0; k < op.xn[c]; k++) v.push_back(op.xin[3 + 5 * c + k]);
+        }
     return v;
 }
 
 // ---------------------------------------------------------------- the peephole pass
 struct x3d_poisson;
 bool x3d_zfirst_on_offer(x3d_poisson *p);
+extern "C" int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                    const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym);
+extern "C" int x3d_transeq_lincomb3(x3d_backend *b, int dir, real_t *du, real_t *dv, real_t *dw, const real_t *u,
+                                    const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
+                                    const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                                    real_t *const y[3], const real_t *const base[3], const int nterm[3], const real_t *c,
+                                    real_t *const *x, const int ipend[3], const int store[3], int *done);
 bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb);
 
 static void optimise(x3d_backend *b)
@@ -536,6 +565,111 @@ static void optimise(x3d_backend *b)
             }
         }
     }
+    // (10) the RK stage of u, v, w inside the LAST transeq launch of the sub-step (src/time_integrator.f90:166-231 behind
+    // src/solver.f90:291-389): rhs_c += transeq_z(...) ; [X_c = rhs_c ; release rhs_c] ; y_c = base_c + sum s x, one x being
+    // rhs_c (or its alias X_c), for c = u, v, w -> ONE launch of the three-component tile kernel that forms d_c = rhs_c +
+    // component, stores it where a later stage reads it and writes y_c (x3d_transeq_lincomb3).  Fused where the LAST of the
+    // three combinations stands: the aliases and the saves of the old velocity in between have run by then.  The launch
+    // reads u, v, w themselves (the reordered copies it was recorded with are released right behind the transeq)
+    for (int p = 0; p < n && (L->rules & 512u); p++) {
+        if (q[p].kind != L_TRANSEQ_ACC || q[p].dir == X3D_DIR_X) continue;
+        if (!x3d_transeq_stage_ok(b, q[p].dir, q[p].t[0], q[p].t[1], q[p].t[2], q[p].t[3])) continue;
+        const real_t *r[3];
+        int kc[3], K = -1;
+        bool ok = true;
+        std::vector<int> rel[3];  // releases of r_c behind its combination
+        for (int c = 0; c < 3 && ok; c++) {
+            const real_t *du = q[p].o[c];
+            r[c] = du;
+            kc[c] = -1;
+            for (int m = p + 1; m < n && ok && kc[c] < 0; m++) {
+                const LOp &op = q[m];
+                if (op.kind == L_DEAD) continue;
+                const int t = touch(op, r[c]) | (r[c] != du ? touch(op, du) : 0);
+                if (!t) continue;
+                if (op.kind == L_COPY && r[c] == du && op.in[0] == du && op.o[0] != du && dead_after(q, m, du)) { r[c] = op.o[0]; continue; }
+                if (op.kind == L_DISCARD && op.o[0] == du && r[c] != du) continue;
+                if (op.kind == L_LINCOMB && op.nterm >= 1 && op.nterm <= 5 && (r[c] == du || !touch(op, du))) {
+                    int hits = 0;
+                    for (int k = 1; k <= op.nterm; k++) hits += op.in[k] == r[c];
+                    ok = hits == 1 && op.in[0] != r[c] && op.o[0] != r[c];
+                    kc[c] = m;
+                } else ok = false;
+            }
+            ok = ok && kc[c] > 0;
+            K = std::max(K, kc[c]);
+        }
+        if (!ok) continue;
+        // u, v, w behind the reordered copies the transeq was recorded with
+        const real_t *src[3];
+        for (int c = 0; c < 3 && ok; c++) {
+            const real_t *h = q[p].in[c];
+            const int k = last_touch_before(q, p, h);
+            src[c] = h;
+            if (k >= 0 && q[k].kind == L_COPY && q[k].o[0] == h && q[k].in[0] != h && range_clear(q, k, p, {}, {q[k].in[0]}))
+                src[c] = q[k].in[0];
+            for (int m = p + 1; m < K && ok; m++) {  // nothing but the three combinations writes it before the launch
+                if (q[m].kind == L_DEAD || m == kc[0] || m == kc[1] || m == kc[2]) continue;
+                if (touch(q[m], src[c]) & (A_W | A_M)) ok = false;
+            }
+        }
+        for (int c = 0; c < 3 && ok; c++) {
+            const LOp &lc = q[kc[c]];
+            real_t *y = lc.o[0];
+            // the combination moves down to K: its result untouched, its other inputs unwritten on the way; r_c may only be
+            // released there (the launch releases it instead)
+            std::vector<const real_t *> stable;
+            for (int k = 0; k <= lc.nterm; k++)
+                if (lc.in[k] != r[c] && lc.in[k] != y) stable.push_back(lc.in[k]);
+            for (int m = kc[c] + 1; m < K && ok; m++) {
+                const LOp &op = q[m];
+                if (op.kind == L_DEAD) continue;
+                if (touch(op, r[c])) {
+                    if (op.kind == L_DISCARD) rel[c].push_back(m); else ok = false;
+                }
+                if (m == kc[0] || m == kc[1] || m == kc[2]) {
+                    // (another variable's combination: it joins the launch -- it must not read or write this one's result)
+                    if (touch(op, y)) ok = false;
+                    continue;
+                }
+                if (touch(op, y)) ok = false;
+                for (const real_t *h : stable)
+                    if (touch(op, h) & (A_W | A_M)) ok = false;
+            }
+            // the launch moves down from p: nothing else reads or writes rhs_c on the way (the scan above covered p..kc)
+            for (int d = 0; d < 3; d++) {
+                ok = ok && y != r[d] && y != q[p].o[d] && (y != src[d] || d == c);
+                ok = ok && (d == c || y != q[kc[d]].o[0]);
+                for (int k = 0; k <= q[kc[d]].nterm && d != c; k++) ok = ok && q[kc[d]].in[k] != y;
+            }
+        }
+        for (int c = 0; c < 3 && ok; c++)
+            for (int d = 0; d < c; d++) ok = ok && r[c] != r[d];
+        if (!ok) continue;
+        LOp f;
+        f.kind = L_TRANSEQ_STAGE; f.dir = q[p].dir; f.s[0] = q[p].s[0];
+        for (int k = 0; k < 4; k++) f.t[k] = q[p].t[k];
+        for (int c = 0; c < 3; c++) {
+            const LOp &lc = q[kc[c]];
+            f.o[c] = const_cast<real_t *>(r[c]);
+            f.o[3 + c] = lc.o[0];
+            f.in[c] = src[c];
+            f.xin[c] = lc.in[0];
+            f.xn[c] = lc.nterm;
+            for (int k = 0; k < lc.nterm; k++) {
+                f.xin[3 + 5 * c + k] = lc.in[1 + k];
+                f.xs[5 * c + k] = lc.s[k];
+                if (lc.in[1 + k] == r[c]) f.xp[c] = k;
+            }
+            if (!rel[c].empty()) f.mode |= 1 << c;
+        }
+        for (int c = 0; c < 3; c++) {
+            for (int m : rel[c]) q[m].kind = L_DEAD;
+            q[kc[c]].kind = L_DEAD;
+        }
+        q[p].kind = L_DEAD;
+        q[K] = f;
+    }
     // (6) y = lincomb ; du = A(y) along x: the stage is the operator's prologue.  Fused where the solve stands if the
     // combination may move down there (its terms are not overwritten or released on the way), else where the
     // combination stands if the solve may move up (its output is not in use in between)
@@ -700,6 +834,56 @@ static int exec(x3d_backend *b, const LOp &op)
         L->bind.erase(it);
         return 0;
     }
+    if (op.kind == L_TRANSEQ_STAGE) {
+        const real_t *f[3], *base[3];
+        real_t *rr[3], *y[3], *x[15] = {};
+        for (int c = 0; c < 3; c++) {
+            if (int rc = resolve_in(b, op.in[c], &f[c])) return rc;
+            if (int rc = resolve_in(b, op.xin[c], &base[c])) return rc;
+            for (int k = 0; k < op.xn[c]; k++) {
+                const real_t *t = nullptr;
+                if (int rc = resolve_in(b, op.xin[3 + 5 * c + k], &t)) return rc;
+                x[5 * c + k] = const_cast<real_t *>(t);  // (read only: the C ABI's term lists are not const-qualified)
+            }
+        }
+        for (int c = 0; c < 3; c++) {
+            if (int rc = prepare_out(b, op.o[c], false, &rr[c])) return rc;
+            x[5 * c + op.xp[c]] = rr[c];
+        }
+        for (int c = 0; c < 3; c++) {
+            real_t *before = registered(L, op.o[3 + c]) ? L->phys[op.o[3 + c]] : nullptr;
+            if (int rc = prepare_out(b, op.o[3 + c], true, &y[c])) return rc;
+            if (before && before != y[c]) L->stats[ST_OOP]++;
+        }
+        int store[3], done = 0;
+        for (int c = 0; c < 3; c++) store[c] = (op.mode >> c) & 1 ? 0 : 1;
+        // (a result in a buffer the launch reads for another purpose -- only its own variable may be updated in place --
+        //  cannot happen with handles kept apart by the rule, but the call-by-call form below is always right)
+        bool clean = true;
+        for (int c = 0; c < 3; c++)
+            for (int d = 0; d < 3; d++) {
+                clean = clean && y[c] != rr[d] && (y[c] != f[d] || d == c) && (d == c || (y[c] != y[d] && y[c] != base[d]));
+                for (int k = 0; k < op.xn[d]; k++) clean = clean && y[c] != x[5 * d + k];
+            }
+        L->stats[ST_EXECUTED]++;
+        if (clean) {
+            if (int rc = x3d_transeq_lincomb3(b, op.dir, rr[0], rr[1], rr[2], f[0], f[1], f[2], op.s[0], op.t[0], op.t[1], op.t[2],
+                                              op.t[3], y, base, op.xn, op.xs, x, op.xp, store, &done))
+                return rc;
+        }
+        if (done) L->stats[ST_TRANSEQ_STAGE]++;
+        else {
+            L->stats[ST_TRANSEQ_ACC]++;
+            L->stats[ST_LINCOMB] += 3;
+            if (int rc = x3d_transeq_acc(b, op.dir, rr[0], rr[1], rr[2], f[0], f[1], f[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1))
+                return rc;
+            for (int c = 0; c < 3; c++)
+                if (int rc = x3d_lincomb(b, y[c], base[c], op.xn[c], &op.xs[5 * c], &x[5 * c])) return rc;
+        }
+        for (int c = 0; c < 3; c++)
+            if ((op.mode >> c) & 1) drop(L, op.o[c]);
+        return 0;
+    }
     for (int k = 0; k < nin(op); k++)
         if (int rc = resolve_in(b, op.in[k], &in[k])) return rc;
     for (int k = 0; k < nout(op); k++) {
@@ -804,7 +988,7 @@ static void dump(const x3d_lazy *L, const char *title)
     static const char *names[] = {"dead", "transeq", "transeq_acc", "tds", "tds_acc", "pair", "tds_lin", "copy", "sum", "vecadd",
                                   "lincomb", "vecmult", "scale", "shift", "fill", "discard", "fft_fwd", "fft_post000", "fft_bwd",
                                   "solve000", "transeq_upd", "species", "species_acc", "zfirst", "fft_post010", "solve010_rows",
-                                  "bind", "setface"};
+                                  "bind", "setface", "transeq_stage"};
     std::unordered_map<const real_t *, int> id;
     auto nm = [&](const real_t *h) { if (!h) return -1; auto it = id.find(h); if (it == id.end()) it = id.emplace(h, (int)id.size()).first; return it->second; };
     fprintf(stderr, "---- %s (%zu operations)\n", title, L->q.size());
@@ -960,7 +1144,7 @@ static void report_at_exit()
 {
     static const char *nm[ST_N] = {"recorded", "launches", "aliases", "transeq_acc", "pairs", "tds_acc", "lincombs", "tds_lincomb",
                                    "solve000", "out_of_place", "materialised", "sync_copies", "flushes", "dropped",
-                                   "transeq_x_update", "pool_slot", "zfirst", "declined"};
+                                   "transeq_x_update", "pool_slot", "zfirst", "declined", "transeq_stage"};
     for (size_t r = 0; r < g_reported.size(); r++) {
         const x3d_lazy *L = g_reported[r];
         char line[1024];
