@@ -1921,3 +1921,27 @@ def test_rk_stage_inside_the_three_component_z_launch_is_bit_identical(n, time_i
         del case, s
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(64, 33, 256), (32, 65, 512)])
+def test_channel_rk_stage_inside_the_z_launch_is_bit_identical(dims, monkeypatch):
+    """channel case (Dirichlet y, periodic 256- / 512-row z pencils): once the rotation forcing is over -- forcings() idle,
+    BaseCase.forcings_idle -- the fused driver puts the RK stage of u, v, w into the z launch of transeq as in the TGV
+    case; the wall values are stamped on the new velocity before the divergence's first x operators read it.  Four steps
+    (rotation for the first two) against the same run with X3D_NO_EPI3=1: bit for bit"""
+    from x3d2_amd import make_channel
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("X3D_NO_EPI3", off)
+        case = make_channel(dims, fused=True, rotation=True, omega_rot=0.12, n_rotate=3)
+        for it in (1, 2, 3, 4):
+            case.step(it, more=it < 4)
+        s = case.solver
+        out[off] = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
+        # iterations 3 and 4 (it >= n_rotate): every sub-step; 1 and 2: where transeq_x's kernel took the rotation
+        n_in = getattr(s.time_integrator, "n_stage_in_transeq", 0)
+        ns = s.time_integrator.nstage
+        assert n_in == 0 if off == "1" else n_in in (2 * ns, 4 * ns), n_in
+        del case, s
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)

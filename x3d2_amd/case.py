@@ -68,6 +68,11 @@ class BaseCase:
         inside the kernels that form the new velocity), or None: apply_BC has to run as it is"""
         return None
 
+    def forcings_idle(self, it):
+        """True: forcings() does not touch the derivatives in iteration `it` whenever Solver.transeq_fused leaves the last
+        accumulation of transeq pending (the fused driver may then fold it and the RK stage together)"""
+        return type(self).forcings is BaseCase.forcings
+
     def postprocess(self, it, t):
         return self.monitoring.write_step(t, self.solver.u, self.solver.v, self.solver.w)
 
@@ -84,10 +89,12 @@ class BaseCase:
         walls = self.deferred_walls() if s.fused and os.environ.get("X3D_NO_DEFER_WALLS") != "1" else None
         defer_upd = (s.fused and (type(self).apply_BC is BaseCase.apply_BC or walls is not None)
                      and os.environ.get("X3D_NO_DEFER") != "1" and s.time_integrator.sname.upper().startswith("RK"))
-        if s.fused and type(self).forcings is BaseCase.forcings:
+        if s.fused and self.forcings_idle(it):
             # nothing touches the derivatives between transeq and the RK / AB stage: the last accumulation of
             # transeq may be folded into the stage's linear combination (Solver.transeq_fused)
             pending = s.transeq(deriv, curr, defer=True)
+            if type(self).forcings is not BaseCase.forcings:
+                self.forcings(deriv[0], deriv[1], deriv[2], it)  # (idle, see forcings_idle -- or nothing is pending)
             s.time_integrator.step(curr, deriv, s.dt, pending=pending, defer_update=defer_upd)
         else:
             s.transeq(deriv, curr)
@@ -246,6 +253,11 @@ class ChannelCase(BaseCase):
 
     def deferred_walls(self):
         return self.bc_start_y
+
+    def forcings_idle(self, it):
+        # no rotation in this iteration, or transeq_x's kernel applies it (rot_request, substep above) -- and where that
+        # kernel does not, Solver.transeq_fused leaves nothing pending and forcings() below acts as in the reference
+        return True
 
     def apply_BC(self, u, v, w):  # :214-231
         b = self.solver.backend

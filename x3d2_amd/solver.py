@@ -292,6 +292,8 @@ class Solver:
         # take the tile kernel K3y, which is cheaper than transposed copies + the fused RK stage)
         pending = None
         ti = self.time_integrator
+        # (a rotation forcing the x kernel did not take is applied by the case's forcings() to the complete derivatives)
+        defer = defer and not (rot != 0.0 and not self.rot_applied)
         if (defer and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_EPI3") != "1"
                 and not b._decomposed(DIR_Z) and self.nspecies == 0 and ti.sname.upper().startswith("RK")
                 and ti.istage in self._epi3_stages and b.transeq_stage_ok(DIR_Z, self.zdirps)):
