@@ -24,7 +24,7 @@ def _same(a, b, ulps=0):
             assert np.max(np.abs(x - y)) <= ulps * 2.0 ** -52 * max(np.max(np.abs(y)), 1.0)
 
 
-@pytest.mark.parametrize("n,time_intg,steps", [(64, "RK3", 3), (48, "AB3", 5), (40, "RK4", 2), (256, "RK3", 1)])
+@pytest.mark.parametrize("n,time_intg,steps", [(64, "RK3", 3), (48, "AB3", 5), (40, "RK4", 2), (256, "RK3", 1), (256, "AB3", 4)])
 def test_deferred_tgv_steps_are_bit_identical_and_fused(n, time_intg, steps, monkeypatch):
     """TGV, full fractional step with the FFT Poisson solve, op-granular driver: deferred == call by call, bit for bit;
     per sub-step the queue must have produced 2 accumulating transeq launches (y, z), the operator pairs of

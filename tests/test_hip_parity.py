@@ -1901,23 +1901,26 @@ def test_bench_virtual_ranks_line():
     assert 40.0 < o["ms_per_step"] < 80.0
 
 
-@pytest.mark.parametrize("n,time_intg", [(256, "RK3"), (512, "RK3"), (256, "RK4"), (256, "RK2")])
+@pytest.mark.parametrize("n,time_intg", [(256, "RK3"), (512, "RK3"), (256, "RK4"), (256, "RK2"), (256, "RK1"), (256, "AB3"),
+                                         (256, "AB1")])
 def test_rk_stage_inside_the_three_component_z_launch_is_bit_identical(n, time_intg, monkeypatch):
-    """round 5: in every RK stage the z launch of transeq (three components, k_ytile_transeq3<EPI>) also does
-    the stage's linear combination of u, v, w (x3d_transeq_lincomb3) -- d = rhs + component ; [rhs = d] ; y = base + sum c x in
-    k_lincomb's order.  Two steps against the same steps with the stage in the divergence's first x operators
-    (X3D_NO_EPI3=1): bit for bit, and the launches counted"""
+    """round 5: in every RK stage (and in the one update of an AB scheme) the z launch of transeq (three components,
+    k_ytile_transeq3<EPI>) also does the linear combination of u, v, w (x3d_transeq_lincomb3) -- d = rhs + component ;
+    [rhs = d] ; y = base + sum c x in k_lincomb's order.  Two steps (AB: four, the history full) against the same steps
+    with the stage in the divergence's first x operators / a lincomb of its own (X3D_NO_EPI3=1): bit for bit, and the
+    launches counted"""
     from x3d2_amd import make_tgv
     out = {}
+    steps = 4 if time_intg.startswith("AB") else 2
     for off in ("1", "0"):
         monkeypatch.setenv("X3D_NO_EPI3", off)
         case = make_tgv(n, time_intg=time_intg, fused=True)
-        case.step(1, more=True)
-        case.step(2)
+        for it in range(1, steps + 1):
+            case.step(it, more=it < steps)
         s = case.solver
         out[off] = [s.backend.get_field_data(f) for f in (s.u, s.v, s.w)]
         ns = s.time_integrator.nstage
-        assert getattr(s.time_integrator, "n_stage_in_transeq", 0) == (0 if off == "1" else 2 * ns)
+        assert getattr(s.time_integrator, "n_stage_in_transeq", 0) == (0 if off == "1" else steps * ns)
         del case, s
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)

@@ -54,10 +54,11 @@ struct LOp {
     int dims[3] = {0, 0, 0};  // L_SETFACE: the field's extent
     // L_TRANSEQ_STAGE (rule 10): o[0..2] the derivative blocks (updated), o[3..5] the stage's results, in[0..2] u, v, w;
     // per variable c: xin[c] the base, xin[3 + 5 c + k] / xs[5 c + k] term k of xn[c], xp[c] the term that IS o[c];
-    // mode bit c: o[c] is released behind the launch (its release stood between the combinations)
+    // mode bit c: o[c] is released behind the launch (its release stood between the combinations); post[c]: see below
     const real_t *xin[18] = {};
     real_t xs[15] = {};
     int xn[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
+    real_t *post[3] = {nullptr, nullptr, nullptr};  // handle that becomes an alias of o[c] behind the launch (an AB history save)
 };
 
 enum { ST_QUEUED = 0, ST_EXECUTED, ST_ALIAS, ST_TRANSEQ_ACC, ST_PAIR, ST_TDS_ACC, ST_LINCOMB, ST_TDS_LIN, ST_SOLVE000, ST_OOP,
@@ -302,6 +303,7 @@ static int touch(const LOp &op, const real_t *h)
             if (op.xin[c] == h) m |= A_R;
             for (int k = 0; k < op.xn[c]; k++)
                 if (op.xin[3 + 5 * c + k] == h) m |= A_R;
+            if (op.post[c] && op.post[c] == h) m |= A_W;
         }
     return m;
 }
@@ -575,9 +577,10 @@ static void optimise(x3d_backend *b)
         if (q[p].kind != L_TRANSEQ_ACC || q[p].dir == X3D_DIR_X) continue;
         if (!x3d_transeq_stage_ok(b, q[p].dir, q[p].t[0], q[p].t[1], q[p].t[2], q[p].t[3])) continue;
         const real_t *r[3];
-        int kc[3], K = -1;
+        int kc[3], ip[3] = {0, 0, 0}, K = -1;
         bool ok = true;
         std::vector<int> rel[3];  // releases of r_c behind its combination
+        int cp[3] = {-1, -1, -1};  // a save X = r_c behind its combination
         for (int c = 0; c < 3 && ok; c++) {
             const real_t *du = q[p].o[c];
             r[c] = du;
@@ -591,7 +594,8 @@ static void optimise(x3d_backend *b)
                 if (op.kind == L_DISCARD && op.o[0] == du && r[c] != du) continue;
                 if (op.kind == L_LINCOMB && op.nterm >= 1 && op.nterm <= 5 && (r[c] == du || !touch(op, du))) {
                     int hits = 0;
-                    for (int k = 1; k <= op.nterm; k++) hits += op.in[k] == r[c];
+                    for (int k = 1; k <= op.nterm; k++)
+                        if (op.in[k] == r[c]) { hits++; ip[c] = k - 1; }
                     ok = hits == 1 && op.in[0] != r[c] && op.o[0] != r[c];
                     kc[c] = m;
                 } else ok = false;
@@ -625,8 +629,15 @@ static void optimise(x3d_backend *b)
                 const LOp &op = q[m];
                 if (op.kind == L_DEAD) continue;
                 if (touch(op, r[c])) {
+                    // (an Adams-Bashforth history save olds = rhs_c behind the combination -- olds' previous contents being
+                    //  one of the combination's terms: the save joins the launch and is replayed behind it)
+                    if (op.kind == L_COPY && op.in[0] == r[c] && op.o[0] != r[c] && op.o[0] != y && rel[c].empty() && cp[c] < 0) {
+                        cp[c] = m;
+                        continue;
+                    }
                     if (op.kind == L_DISCARD) rel[c].push_back(m); else ok = false;
                 }
+                if (cp[c] >= 0 && touch(op, q[cp[c]].o[0])) ok = false;  // (the saved copy's handle: quiet until the launch)
                 if (m == kc[0] || m == kc[1] || m == kc[2]) {
                     // (another variable's combination: it joins the launch -- it must not read or write this one's result)
                     if (touch(op, y)) ok = false;
@@ -636,7 +647,11 @@ static void optimise(x3d_backend *b)
                 for (const real_t *h : stable)
                     if (touch(op, h) & (A_W | A_M)) ok = false;
             }
-            // the launch moves down from p: nothing else reads or writes rhs_c on the way (the scan above covered p..kc)
+        }
+        // the launch moves down from p: nothing else reads or writes rhs_c on the way (the scans above covered p..K); a result
+        // is no other variable's input, derivative block or result
+        for (int c = 0; c < 3 && ok; c++) {
+            real_t *y = q[kc[c]].o[0];
             for (int d = 0; d < 3; d++) {
                 ok = ok && y != r[d] && y != q[p].o[d] && (y != src[d] || d == c);
                 ok = ok && (d == c || y != q[kc[d]].o[0]);
@@ -645,6 +660,12 @@ static void optimise(x3d_backend *b)
         }
         for (int c = 0; c < 3 && ok; c++)
             for (int d = 0; d < c; d++) ok = ok && r[c] != r[d];
+        for (int c = 0; c < 3 && ok; c++) {  // a save's handle: not a result, a derivative block, u, v, w or another save's
+            if (cp[c] < 0) continue;
+            const real_t *X = q[cp[c]].o[0];
+            for (int d = 0; d < 3; d++)
+                ok = ok && X != q[kc[d]].o[0] && X != r[d] && X != src[d] && (d == c || cp[d] < 0 || X != q[cp[d]].o[0]);
+        }
         if (!ok) continue;
         LOp f;
         f.kind = L_TRANSEQ_STAGE; f.dir = q[p].dir; f.s[0] = q[p].s[0];
@@ -659,12 +680,15 @@ static void optimise(x3d_backend *b)
             for (int k = 0; k < lc.nterm; k++) {
                 f.xin[3 + 5 * c + k] = lc.in[1 + k];
                 f.xs[5 * c + k] = lc.s[k];
-                if (lc.in[1 + k] == r[c]) f.xp[c] = k;
             }
+            f.xp[c] = ip[c];
+            f.xin[3 + 5 * c + ip[c]] = r[c];  // (the term that is the derivative block, under the name it has at K)
             if (!rel[c].empty()) f.mode |= 1 << c;
+            if (cp[c] >= 0) f.post[c] = q[cp[c]].o[0];
         }
         for (int c = 0; c < 3; c++) {
             for (int m : rel[c]) q[m].kind = L_DEAD;
+            if (cp[c] >= 0) q[cp[c]].kind = L_DEAD;
             q[kc[c]].kind = L_DEAD;
         }
         q[p].kind = L_DEAD;
@@ -856,7 +880,7 @@ static int exec(x3d_backend *b, const LOp &op)
             if (before && before != y[c]) L->stats[ST_OOP]++;
         }
         int store[3], done = 0;
-        for (int c = 0; c < 3; c++) store[c] = (op.mode >> c) & 1 ? 0 : 1;
+        for (int c = 0; c < 3; c++) store[c] = (op.post[c] || !((op.mode >> c) & 1)) ? 1 : 0;
         // (a result in a buffer the launch reads for another purpose -- only its own variable may be updated in place --
         //  cannot happen with handles kept apart by the rule, but the call-by-call form below is always right)
         bool clean = true;
@@ -880,8 +904,14 @@ static int exec(x3d_backend *b, const LOp &op)
             for (int c = 0; c < 3; c++)
                 if (int rc = x3d_lincomb(b, y[c], base[c], op.xn[c], &op.xs[5 * c], &x[5 * c])) return rc;
         }
-        for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3; c++) {
+            if (op.post[c]) {  // the history save that stood behind the combination
+                LOp cpy;
+                cpy.kind = L_COPY; cpy.o[0] = op.post[c]; cpy.in[0] = op.o[c];
+                if (int rc = exec(b, cpy)) return rc;
+            }
             if ((op.mode >> c) & 1) drop(L, op.o[c]);
+        }
         return 0;
     }
     for (int k = 0; k < nin(op); k++)

@@ -99,13 +99,13 @@ class Solver:
         else:
             raise X3dError('poisson_solver_type is not valid. Use "FFT" or "CG".')
         self.pending_grad = None
-        # RK stages whose z launch of transeq also does the stage (transeq_fused): every stage of a scheme with at least two
+        # RK stages whose z launch of transeq also does the stage (transeq_fused): every stage (AB schemes: their one update)
         # (X3D_EPI3_STAGES="1,3" overrides; X3D_NO_EPI3=1: none).  Field passes go away in the first stage (the derivative is
         # not read back) and the last (it is not even stored); a middle stage saves a launch only -- same-box A/B at
         # 512^3 RK3, ms per step: none 43.1-43.4, {1} 42.0, {3} 41.7-41.9, {1,3} 41.4-41.6, {1,2,3} 41.3-41.5
         ns = self.time_integrator.nstage
         e = os.environ.get("X3D_EPI3_STAGES")
-        self._epi3_stages = {int(v) for v in e.split(",")} if e else (set(range(1, ns + 1)) if ns >= 2 else set())
+        self._epi3_stages = {int(v) for v in e.split(",")} if e else set(range(1, ns + 1))
         self.n_epi3 = 0
         self.rot_request, self.rot_applied = 0.0, False  # rotation forcing handed to transeq_x (transeq_fused)
         self.n_rot_fused = self.n_interleaved = 0        # how often those two fusions were taken (tests)
@@ -295,7 +295,7 @@ class Solver:
         # (a rotation forcing the x kernel did not take is applied by the case's forcings() to the complete derivatives)
         defer = defer and not (rot != 0.0 and not self.rot_applied)
         if (defer and os.environ.get("X3D_NO_DEFER") != "1" and os.environ.get("X3D_NO_EPI3") != "1"
-                and not b._decomposed(DIR_Z) and self.nspecies == 0 and ti.sname.upper().startswith("RK")
+                and not b._decomposed(DIR_Z) and self.nspecies == 0
                 and ti.istage in self._epi3_stages and b.transeq_stage_ok(DIR_Z, self.zdirps)):
             # round 5: the z launch of the three components also does the RK stage of u, v, w (k_ytile_transeq3<EPI>,
             # HipBackend.transeq_lincomb3); TimeIntegrator.runge_kutta_fused issues it

@@ -159,7 +159,7 @@ class TimeIntegrator:
             if tile3 is not None:
                 # (the velocity the launch reads is curr itself, overwritten tile by tile behind its last use; the
                 #  derivative of the last stage is not needed afterwards: no store)
-                in_transeq = ns > 1 and self._stage_in_transeq(tile3, deriv[:3], curr[:3], specs[:3])
+                in_transeq = self._stage_in_transeq(tile3, deriv[:3], curr[:3], specs[:3])
             for i, sp in enumerate(specs):
                 if not (in_transeq and i < 3):
                     self._lincomb(sp[0], sp[1], sp[2], sp[3], pending, False, var=i)
@@ -210,13 +210,21 @@ class TimeIntegrator:
     def adams_bashforth_fused(self, curr, deriv, dt, pending=None, defer_update=False):
         b = self.backend
         self.defer_update = False  # (the AB update rotates its history right after the combination)
+        # (round 5: transeq's z launch may be pending for u, v, w -- it then does their update: u += dt sum b_k f_k, in place,
+        #  and stores the complete derivative where the history keeps it)
+        tile3 = pending.pop("tile3", None) if pending else None
         self._flush(pending)
         self.gdt = dt
         nstep = min(self.istep, self.nstep)
         c = self.AB[nstep]
+        specs = []
         for i in range(self.nvars):
             terms = [(c[0] * dt, deriv[i])] + [(c[j - 1] * dt, self.olds[i][j - 2]) for j in range(2, nstep + 1)]
-            b.lincomb(curr[i], curr[i], [x for x, _ in terms], [f for _, f in terms])
+            specs.append((curr[i], curr[i], [x for x, _ in terms], [f for _, f in terms], self.nstep > 1))
+        in_transeq = tile3 is not None and self._stage_in_transeq(tile3, deriv[:3], curr[:3], specs[:3])
+        for i in range(self.nvars):
+            if not (in_transeq and i < 3):
+                b.lincomb(curr[i], curr[i], specs[i][2], specs[i][3])
             if nstep < self.nstep:
                 if self.istep > 1:
                     self._rotate(self.olds[i], nstep)
