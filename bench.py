@@ -604,6 +604,11 @@ def main():
         dominant = None
         # (channel: the wall-normal direction's k_ygen_transeq3 by itself -- its z launches are another kernel)
         dom_dirs = (2,) if args.case == "channel" else (2, 3)
+        # (several ranks: the decomposed direction(s) only -- one HALO-form launch + its strip correction per sub-step; the
+        #  local direction runs in two half launches beside the exchanges, which would count as two launches of full bytes)
+        split_dirs = tuple(d + 1 for d in (1, 2) if nproc_dir[d] > 1)
+        if args.case == "tgv" and split_dirs:
+            dom_dirs = split_dirs
         yz = [(per_dir_raw[d][0][0], per_dir_raw[d][0][1] + per_dir_raw[d][1][1]) for d in dom_dirs]
         n_yz, ms_yz = sum(c for c, _ in yz), sum(m for _, m in yz)
         if n_yz and n_tq3:
@@ -611,11 +616,12 @@ def main():
             d_ms = ms_yz / launches
             d_bytes = 64.0 * dofb
             d_ach = d_bytes / (d_ms * 1e-3) / 1e9
-            if args.case == "tgv" and args.gpus == 1:
+            if args.case == "tgv" and not split_dirs:
                 name = ("k_ytile_transeq3<%d,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
                         % (args.n // 64))
             elif args.case == "tgv":
-                name = "k_ytile_transeq3 (transeq_y; HALO form + strip correction for the decomposed direction)"
+                name = ("k_ytile_transeq3<..,HALO> + k_transeq_halo_fix (transeq_%s: the decomposed direction in one pass + its "
+                        "strip correction)" % "/".join("xyz"[d - 1] for d in split_dirs))
             else:
                 name = "k_ygen_transeq3<5> (transeq_y on the 257-row wall-normal pencils, three components per launch)"
             dominant = {"name": name, "launches": launches, "avg_launch_ms": d_ms, "timed": "HIP events on the backend's "
