@@ -212,8 +212,11 @@ __global__ void __launch_bounds__(1024)
 // der1st_sym, der2nd and der2nd_sym must be equal as lane tables (Dirichlet ends: they are) -- two table sets.
 // NARROW1 / NARROW: der1st's / both operators' stencils reach 2 rows at most (the Dirichlet closure of der2nd's first
 // and last row reaches 3: the channel case runs <.., false, true>)
-template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW>
-__global__ void __launch_bounds__(1024)
+// NP: pencils (= waves) per workgroup.  8 (round 5, 257..320-row pencils): two workgroups per CU -- the lock-step phases of
+// one (load, solve, store, barriers) run beside the other's; their 64-byte row segments pair up into 128-byte lines, so the
+// two tiles of a pair go to workgroups of the same XCD (one L2) that run at the same time
+template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW, int NP = 16>
+__global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
     k_ygen_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0, const real_t *__restrict__ u1,
                     const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
                     real_t nu)
@@ -228,25 +231,29 @@ __global__ void __launch_bounds__(1024)
 #endif
     constexpr bool LATE = P12 && Q <= 5;  // where the rows the result is added to are requested (register budget)
     extern __shared__ real_t lt[];
-    constexpr int LN = LT_N(Q) * 64;
-    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
-        lt[i] = tD1.TL[i];
-        lt[LN + i] = tD2.TL[i];
-    }
-    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
-    real_t *tile = lt + 2 * LN;
-    real_t *cs = tile + 16 * G::TP;
-    for (int i = threadIdx.x; i < 16 * G::TP; i += blockDim.x) tile[i] = 0.0;
+    constexpr int LN = LT_N(Q) * 64, L1N = LT_NC(Q) * 64;  // (the first operator's STC block is never read)
+    for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
+    for (int i = threadIdx.x; i < LN; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
+    real_t *tile = lt + L1N + LN;
+    real_t *cs = tile + NP * G::TP;
+    for (int i = threadIdx.x; i < NP * G::TP; i += blockDim.x) tile[i] = 0.0;
     stage_cs<Q>(cs, tD1);
     stage_cs<Q>(cs + CS_N(Q), tD2);
     int lane = threadIdx.x & 63;
-    GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x >> 3), (int)(threadIdx.x & 7),
-                 nrow, prow};
-    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x / (NP / 2)),
+                 (int)(threadIdx.x % (NP / 2)), nrow, prow};
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * NP; };
+    // NP = 8: blocks b and b + 8 (same XCD, dispatched back to back) take the tiles 2 j and 2 j + 1
+    int bid = blockIdx.x;
+    if constexpr (NP == 8) {
+        const int g16 = bid / 16, r16 = bid % 16;
+        bid = g16 * 16 + 2 * (r16 % 8) + r16 / 8;
+    }
     __syncthreads();
     real_t nxt[2 * G::NI];  // the rows needed next (next component's field, or the next tile's u0)
-    if ((int)blockIdx.x < ntiles) T.gload(nxt, u0 + tile_off(blockIdx.x));
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    if (bid < ntiles) T.gload(nxt, u0 + tile_off(bid));
+    for (int tl = bid; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
         real_t cb[Q];  // this pencil's rows of the advecting velocity
 #pragma unroll 1
@@ -430,21 +437,34 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t 
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     if (der1st->n_tds != der2nd->n_tds) return 0;
     // (tl_hash covers the lane tables and the boundary / bulk stencils: tds.hip)
-    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    // 8 pencils per workgroup, two workgroups per CU: 257..320-row pencils (Q = 5), nx a multiple of 32 (tile pairs share
+    // 128-byte lines and must not straddle rows of tiles).  X3D_YGEN_NP16=1: the 16-pencil form (A/B)
+    static int np16 = -1;
+    if (np16 < 0) { const char *e = getenv("X3D_YGEN_NP16"); np16 = (e && e[0] == '1') ? 1 : 0; }
+    const int NP = (Q == 5 && !np16 && b->nx % 32 == 0) ? 8 : 16;
+    const size_t lds = sizeof(real_t) * ((size_t)(LT_NC(Q) + LT_N(Q)) * 64 + NP * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
-    const GenLaunch g = gen_launch(b, dir);
+    GenLaunch g = gen_launch(b, dir);
+    if (NP == 8) {
+        g.ntx = b->nx / 8;
+        g.ntiles = g.ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+        const long cap = 2 * (long)x3d_persistent_blocks(b, X3D_NCU);
+        g.blocks = (int)(g.ntiles > cap ? cap : g.ntiles);
+        g.blocks -= g.blocks % 16;  // (the pairing of blocks b and b + 8)
+        if (g.blocks < 16) return 0;
+    }
     const bool narrow1 = der1st->narrow_all, narrow = narrow1 && der2nd->narrow_all;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-#define GO(Q_, A_, N_, N1_)                                                                                     \
+#define GO(Q_, A_, N_, N1_, P_)                                                                                 \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_, N1_>));                                                   \
-        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_, N1_>), dim3(g.blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], f[0], \
+        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_, N1_, P_>));                                               \
+        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_, N1_, P_>), dim3(g.blocks), dim3(64 * P_), lds, b->stream, r[0], r[1], r[2], f[0], \
                            f[1], f[2], gen_xop(der1st, Q_), gen_xop(der2nd, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
     } while (0)
-#define GON(Q_, A_) do { if (narrow) GO(Q_, A_, true, true); else if (narrow1) GO(Q_, A_, false, true); else GO(Q_, A_, false, false); } while (0)
-#define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
-        if (Q == 8) GOA(8); else if (Q == 6) GOA(6); else if (Q == 5) GOA(5); else GOA(4);
+#define GON(Q_, A_, P_) do { if (narrow) GO(Q_, A_, true, true, P_); else if (narrow1) GO(Q_, A_, false, true, P_); else GO(Q_, A_, false, false, P_); } while (0)
+#define GOA(Q_, P_) do { if (acc) GON(Q_, true, P_); else GON(Q_, false, P_); } while (0)
+        if (Q == 8) GOA(8, 16); else if (Q == 6) GOA(6, 16); else if (Q == 5) { if (NP == 8) GOA(5, 8); else GOA(5, 16); } else GOA(4, 16);
 #undef GOA
 #undef GON
 #undef GO
