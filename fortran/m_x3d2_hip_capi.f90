@@ -230,6 +230,11 @@ module m_x3d2_hip_capi
       integer(c_signed_char), intent(in) :: handle(64)
       type(c_ptr), intent(out) :: dev
     end function
+    integer(c_int) function x3d_ipc_close(b, dev) bind(C, name='x3d_ipc_close')
+      !! unmap a peer's buffer (x3d_backend_destroy unmaps whatever is still mapped)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b, dev
+    end function
     integer(c_int) function x3d_copy_device(b, dst, src, n) bind(C, name='x3d_copy_device')
       import :: c_ptr, c_int, c_long
       type(c_ptr), value :: b, dst, src

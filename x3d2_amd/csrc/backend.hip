@@ -9,6 +9,9 @@
 //   (get/set_field_data), src/allocator.f90:64-93 (padding).
 #include <mutex>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 #include <unordered_map>
@@ -103,6 +106,11 @@ extern "C" int x3d_backend_create_like(x3d_backend **out, const x3d_backend *lik
 extern "C" int x3d_backend_destroy(x3d_backend *b)
 {
     if (!b) return 0;
+    if (b->ipc_maps) {  // peers' buffers still mapped: unmap them before this rank's own memory goes
+        auto *v = static_cast<std::vector<void *> *>(b->ipc_maps);
+        for (void *p : *v) (void)hipIpcCloseMemHandle(p);
+        delete v;
+    }
     hipFree(b->send_s); hipFree(b->send_e);
     hipFree(b->scratch[0]); hipFree(b->scratch[1]); hipFree(b->scratch[2]);
     x3d_prof_enable_c(b, 0);
@@ -248,12 +256,18 @@ extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], real
     void *p = nullptr;
     X3D_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
     *dev = static_cast<real_t *>(p);
+    if (!b->ipc_maps) b->ipc_maps = new std::vector<void *>();
+    static_cast<std::vector<void *> *>(b->ipc_maps)->push_back(p);  // (unmapped by x3d_backend_destroy at the latest)
     return 0;
 }
 extern "C" int x3d_ipc_close(x3d_backend *b, real_t *dev)
 {
     X3D_REQUIRE(b && dev, "x3d_ipc_close: null argument");
     X3D_HIP(hipIpcCloseMemHandle(dev));
+    if (b->ipc_maps) {
+        auto *v = static_cast<std::vector<void *> *>(b->ipc_maps);
+        v->erase(std::remove(v->begin(), v->end(), static_cast<void *>(dev)), v->end());
+    }
     return 0;
 }
 // n doubles device to device (own or mapped memory), ordered on the backend's stream like a kernel; returns at once

@@ -150,6 +150,7 @@ struct x3d_backend {
     long n_halo;      // launches of the HALO forms of the tile kernels (a decomposed direction in one pass)
     void *epi_dev;    // 512-byte device slot for the RK-stage descriptions of k_ytile_transeq<EPI> / k_ytile_transeq3<EPI> (xscan.hip)
     hipEvent_t ev0, ev1;
+    void *ipc_maps;         // peers' buffers mapped by x3d_ipc_open and not closed yet (std::vector<void *>; closed by x3d_backend_destroy)
     struct x3d_prof *prof;  // per-kernel HIP-event timers (prof.hip), null until enabled
     unsigned prof_mask;     // kernel classes that are timed while the timers are on (bit = X3D_K_*; x3d_prof_select)
     int pair_yperm;          // > 0 during x3d_tds_solve_pair_yperm: the z pair kernels permute that many y rows
