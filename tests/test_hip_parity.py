@@ -1901,6 +1901,39 @@ def test_bench_virtual_ranks_line():
     assert 40.0 < o["ms_per_step"] < 80.0
 
 
+def test_bench_line_contract_one_gpu():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the round driver reads (metric,
+    value, unit, n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config) plus
+    `roofline` (bound / achieved / peak / unit / frac / traffic of the dominant kernel, HIP-event timed inside the timed
+    region; round 5: the launches of the same kernel that also do the RK stage timed and counted apart) -- here without the
+    CPU baseline, the other configurations and the PMC child runs (their own flags), 3 timed steps"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-configs", "--no-live-traffic"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    o = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 3 and o["warmup"] == 1 and o["higher_is_better"] is True
+    assert o["dtype"] == "f64" and o["data"] == "synthetic" and o["vs_baseline"] is None and "workload" in o["config"]
+    assert abs(o["value"] - 512 ** 3 * 3 / (o["ms_per_step"] * 3e-3)) < 1e-6 * o["value"]
+    rf = o["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.3 < rf["frac"] < 0.75
+    d = rf["dominant_kernel"]
+    assert d["launches"] == 3 * 3 and d["algorithmic_bytes_per_launch"] == 64.0 * 512 ** 3   # transeq_y of every sub-step
+    e = d["with_rk_stage"]                                                                     # transeq_z + the stage
+    assert e["launches"] == 3 * 3 and e["algorithmic_bytes_per_launch"] > d["algorithmic_bytes_per_launch"]
+    assert 30.0 < o["ms_per_step"] < 60.0
+
+
 @pytest.mark.parametrize("n,time_intg", [(256, "RK3"), (512, "RK3"), (256, "RK4"), (256, "RK2"), (256, "RK1"), (256, "AB3"),
                                          (256, "AB1")])
 def test_rk_stage_inside_the_three_component_z_launch_is_bit_identical(n, time_intg, monkeypatch):
