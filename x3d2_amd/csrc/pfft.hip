@@ -294,7 +294,10 @@ extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const real_t *f_in)
 extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, real_t *f_out)
 {
     X3D_REQUIRE(p && f_out, "null argument");
-    X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
+    // the whole real extent is written and nothing reads a block's padding: a block that still shares its buffer -- the
+    // reference's p_temp is a reordered alias of div_u, released only behind the solve (src/solver.f90:653-678) -- takes a
+    // free buffer instead of a copy of the old contents
+    X3D_LAZY_OUT(p->b, f_out, true);
     return bwd_x(p, f_out, 0, p->parts);
 }
 
@@ -479,7 +482,9 @@ extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const real_t *recv_yx, real_t *f
 {
     PFFT_PART(p, m, "x3d_pfft_bwd_a_part");
     X3D_REQUIRE(recv_yx && f_out, "null argument");
-    X3D_LAZY_OUT(p->b, f_out, false);  // (a group's planes of the real extent are written)
+    // (a group's planes of the real extent are written; the first group of a solve takes the block over -- see
+    //  x3d_pfft_bwd_x -- and finds it its own from then on)
+    X3D_LAZY_OUT(p->b, f_out, true);
     if (int rc = xy_c0(p, (real2_t *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
     return bwd_x(p, f_out, m, m + 1);
 }

@@ -323,7 +323,10 @@ extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, real_t *recvbuf)
 extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const real_t *recvbuf, real_t *f_out)
 {
     X3D_REQUIRE(p && recvbuf && f_out, "null argument");
-    X3D_LAZY_OUT(p->b, f_out, false);  // (the real extent of the block is written, its padding keeps its contents)
+    // the whole real extent is written and nothing reads a block's padding: a block that still shares its buffer -- the
+    // reference's p_temp is a reordered alias of div_u, released only behind the solve (src/solver.f90:653-678) -- takes a
+    // free buffer instead of a copy of the old contents
+    X3D_LAZY_OUT(p->b, f_out, true);
     if (int rc = x3d_fft512_run_x(p->b, p->c0, p->nxs, p->ny, p->zl, 1, 1, nullptr, nullptr, p->nx,
                                   (real2_t *)recvbuf, p->ys, p->ysc))
         return rc;
