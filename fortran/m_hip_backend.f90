@@ -607,6 +607,9 @@ module m_hip_backend
     integer(c_intptr_t) :: tv_h(64) = 0
     integer :: tv_ok(64) = -1, tv_n = 0
     logical :: d2d = .false., one_pass = .true.
+    logical :: lazy_on = .false.           ! the library records the calls (x3d_lazy_enable)
+    logical :: dist_cb = .false.           ! ... and runs the transeq of a decomposed direction through dist_transeq_cb
+    integer :: tq_n(2:3) = 0               ! rows per pencil of the fields a recorded distributed transeq works on
     real(dp), allocatable :: hs(:), he(:), hrs(:), hre(:)
   contains
     procedure :: alloc_tdsops => alloc_hip_tdsops
@@ -636,6 +639,9 @@ module m_hip_backend
     procedure :: init_poisson_fft => init_hip_poisson_fft
   end type hip_backend_t
 
+  ! the backend the library's queue calls back into (dist_transeq_cb): one per process
+  class(hip_backend_t), pointer, save :: g_backend => null()
+
 contains
 
   function hip_backend_init(mesh, allocator) result(backend)
@@ -662,6 +668,7 @@ contains
       call get_environment_variable('X3D_NO_LAZY', v, status=stat)
       if (.not. (stat == 0 .and. v(1:1) == '1')) then
         call x3d_check(x3d_lazy_enable(backend%handle, 1_c_int))
+        backend%lazy_on = .true.
       end if
     end block
   end function hip_backend_init
@@ -821,7 +828,7 @@ contains
   end subroutine alloc_hip_tdsops
 
   subroutine transeq_any(self, dir, du, dv, dw, u, v, w, nu, dirps)
-    class(hip_backend_t) :: self
+    class(hip_backend_t), target :: self
     integer, intent(in) :: dir
     class(field_t), intent(inout) :: du, dv, dw
     class(field_t), intent(in) :: u, v, w
@@ -830,6 +837,20 @@ contains
     integer :: n
     n = self%mesh%get_n(u) ! error-stops on NULL_LOC like transeq_halo_exchange
     if (decomposed(self, dir)) then
+      ! round 5: with the queue on and the one-pass form agreed by all ranks the call is RECORDED like a local one -- the
+      ! three sum_<dir>intox behind it then fold into the accumulating form -- and dist_transeq_cb runs it when the
+      ! queue executes (every rank runs the same queue at the same call of the program: the exchanges meet)
+      if (self%lazy_on .and. record_distributed(self, dir, nu, dirps)) then
+        self%tq_n(dir) = n
+        call x3d_check(x3d_transeq(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), &
+                                   dev(w), real(nu, c_double), tds_handle(dirps%der1st), &
+                                   tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), &
+                                   tds_handle(dirps%der2nd_sym)))
+        call du%set_data_loc(u%data_loc)
+        call dv%set_data_loc(u%data_loc)
+        call dw%set_data_loc(u%data_loc)
+        return
+      end if
       call transeq_dist(self, dir, du, dv, dw, u, v, w, nu, dirps, n)
       call du%set_data_loc(u%data_loc)
       call dv%set_data_loc(u%data_loc)
@@ -844,6 +865,105 @@ contains
     call dv%set_data_loc(u%data_loc)
     call dw%set_data_loc(u%data_loc)
   end subroutine transeq_any
+
+  integer function one_pass_verdict(self, dir, nu, dirps) result(ok)
+    !! does EVERY rank's three-component tile kernel take transeq_<dir>?  (a launch over zero planes, MIN over all ranks,
+    !! once per direction; 0 with X3D_SHIM_TWO_PHASE=1)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    integer :: mine, ierr
+    integer(c_int) :: done
+    call need_buffers(self)
+    ok = 0
+    if (.not. self%one_pass) return
+    if (self%tile_tq(dir) < 0) then
+      call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), xs(self, 1, 1, dir), xs(self, 1, 2, dir), &
+                                      xs(self, 1, 3, dir), xs(self, 1, 4, dir), xr(self, 1, 1, dir), xr(self, 1, 2, dir), &
+                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
+                                      tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
+                                      xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, 0_c_int, done))
+      ! collective: every rank of the run takes the same form (MIN over the ranks' probes)
+      mine = int(done)
+      call MPI_Allreduce(mine, self%tile_tq(dir), 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    end if
+    ok = self%tile_tq(dir)
+  end function one_pass_verdict
+
+  logical function record_distributed(self, dir, nu, dirps)
+    !! the recorded form of a decomposed direction's transeq is on offer: the one-pass kernels serve it on every rank and
+    !! the library knows whom to call back (registered here, once).  X3D_SHIM_NO_DIST_RECORD=1: run it at once (A/B)
+    class(hip_backend_t), target :: self
+    integer, intent(in) :: dir
+    real(dp), intent(in) :: nu
+    type(dirps_t), intent(in) :: dirps
+    character(len=8) :: v
+    integer :: stat, d
+    integer(c_int) :: mask
+    record_distributed = .false.
+    if (one_pass_verdict(self, dir, nu, dirps) /= 1) return
+    if (.not. self%dist_cb) then
+      call get_environment_variable('X3D_SHIM_NO_DIST_RECORD', v, status=stat)
+      if (stat == 0 .and. v(1:1) == '1') return
+      mask = 0
+      do d = DIR_Y, DIR_Z
+        if (decomposed(self, d)) mask = ior(mask, ishft(1_c_int, d))
+      end do
+      g_backend => self
+      call x3d_check(x3d_lazy_set_dist_transeq(self%handle, mask, c_funloc(dist_transeq_cb), c_null_ptr))
+      self%dist_cb = .true.
+    end if
+    record_distributed = .true.
+  end function record_distributed
+
+  integer(c_int) function dist_transeq_cb(user, dir, du, dv, dw, u, v, w, nu, t0, t1, t2, t3, acc) bind(C)
+    !! called by the library's queue for a recorded transeq of a decomposed direction (include/x3d2_hip.h,
+    !! x3d_dist_transeq_fn): the pointers are the buffers that hold the handles' data; acc = 1: du, dv, dw are added to
+    type(c_ptr), value :: user, du, dv, dw, u, v, w, t0, t1, t2, t3
+    integer(c_int), value :: dir, acc
+    real(c_double), value :: nu
+    type(c_ptr) :: rhs(3), fld(3)
+    if (dir == DIR_Y) then
+      rhs = [dv, du, dw]; fld = [v, u, w]
+    else
+      rhs = [dw, du, dv]; fld = [w, u, v]
+    end if
+    if (.not. associated(g_backend)) error stop 'hip shim: dist_transeq_cb without a backend'
+    if (g_backend%tile_tq(dir) /= 1) error stop 'hip shim: recorded transeq of a direction the one-pass form does not serve'
+    call transeq_one_pass(g_backend, int(dir), rhs, fld, nu, t0, t1, t2, t3, int(acc), g_backend%tq_n(dir))
+    dist_transeq_cb = 0
+  end function dist_transeq_cb
+
+  subroutine transeq_one_pass(self, dir, rhs, fld, nu, t0, t1, t2, t3, acc, n)
+    !! ONE pass where the library's tile kernels take these pencils (256 / 512 rows per rank, nx a multiple of 16): the
+    !! rows of the three fields in ONE message per neighbour, the whole local solve with the neighbours' boundary values
+    !! taken as zero, ONE exchange of this rank's nine boundary values per pencil, and the correction they add on the
+    !! boundary strips -- the same linear system as the three sweep / exchange / sweep rounds (DESIGN 5.1).
+    !! rhs, fld: device pointers, the advecting component first; acc = 1: rhs is added to
+    class(hip_backend_t) :: self
+    integer, intent(in) :: dir, acc, n
+    type(c_ptr), intent(in) :: rhs(3), fld(3), t0, t1, t2, t3
+    real(c_double), intent(in) :: nu
+    type(c_ptr) :: r(3), f(3)
+    integer(c_int) :: done
+    ! (x3d_transeq_tile / _halo_fix take u, v, w and du, dv, dw in variable order)
+    if (dir == DIR_Y) then
+      r = [rhs(2), rhs(1), rhs(3)]; f = [fld(2), fld(1), fld(3)]
+    else
+      r = [rhs(2), rhs(3), rhs(1)]; f = [fld(2), fld(3), fld(1)]
+    end if
+    call next_use(self, dir, 5)
+    call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 5, dir), fld, 3_c_int, int(n, c_int), int(dir, c_int)))
+    call sendrecv_set(self, dir, 5, int(self%cap(5, dir)))
+    call next_use(self, dir, 6)
+    call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), r(1), r(2), r(3), f(1), f(2), f(3), nu, t0, t1, t2, t3, &
+                                    int(acc, c_int), xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, -1_c_int, done))
+    if (done /= 1) error stop 'hip shim: the tile kernel declined pencils its probe had accepted'
+    call sendrecv_set(self, dir, 6, int(self%cap(6, dir)))
+    call x3d_check(x3d_transeq_halo_fix(self%handle, int(dir, c_int), r(1), r(2), r(3), f(1), f(2), f(3), nu, t0, t2, &
+                                        xr(self, 1, 6, dir)))
+  end subroutine transeq_one_pass
 
   subroutine transeq_dist(self, dir, du, dv, dw, u, v, w, nu, dirps, n)
     !! transeq_omp_dist (src/backend/omp/backend.f90:235-338): one halo exchange of the three fields, then per
@@ -869,30 +989,9 @@ contains
     ! rows of the three fields in ONE message per neighbour, the whole local solve with the neighbours' boundary values
     ! taken as zero, ONE exchange of this rank's nine boundary values per pencil, and the correction they add on the
     ! boundary strips -- the same linear system as the three sweep / exchange / sweep rounds below (DESIGN 5.1)
-    if (self%one_pass .and. self%tile_tq(dir) < 0) then  ! (probe: a launch over zero planes)
-      call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), xs(self, 1, 1, dir), xs(self, 1, 2, dir), &
-                                      xs(self, 1, 3, dir), xs(self, 1, 4, dir), xr(self, 1, 1, dir), xr(self, 1, 2, dir), &
-                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
-                                      tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
-                                      xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, 0_c_int, done))
-      ! collective: every rank of the run takes the same form (MIN over the ranks' probes)
-      mine = int(done)
-      call MPI_Allreduce(mine, self%tile_tq(dir), 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
-    end if
-    if (self%one_pass .and. self%tile_tq(dir) == 1) then
-      call next_use(self, dir, 5)
-      call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 5, dir), fld, 3_c_int, int(n, c_int), int(dir, c_int)))
-      call sendrecv_set(self, dir, 5, int(self%cap(5, dir)))
-      call next_use(self, dir, 6)
-      call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), dev(w), &
-                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
-                                      tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
-                                      xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, -1_c_int, done))
-      if (done /= 1) error stop 'hip shim: the tile kernel declined pencils its probe had accepted'
-      call sendrecv_set(self, dir, 6, int(self%cap(6, dir)))
-      call x3d_check(x3d_transeq_halo_fix(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), dev(w), &
-                                          real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der2nd), &
-                                          xr(self, 1, 6, dir)))
+    if (one_pass_verdict(self, dir, nu, dirps) == 1) then
+      call transeq_one_pass(self, dir, rhs, fld, real(nu, c_double), tds_handle(dirps%der1st), &
+                            tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0, n)
       return
     end if
     do i = 1, 3

@@ -34,6 +34,13 @@ module m_x3d2_hip_capi
       integer(c_int), intent(in) :: dims_vert(3)
     end function
     ! deferred execution: the op-granular calls are recorded and rewritten onto the fused kernels (csrc/lazy.hip)
+    integer(c_int) function x3d_lazy_set_dist_transeq(b, dir_mask, fn, user) bind(C, name='x3d_lazy_set_dist_transeq')
+      !! the transeq of a decomposed direction recorded like a local one and run by fn when the queue executes it
+      import :: c_ptr, c_int, c_funptr
+      type(c_ptr), value :: b, user
+      integer(c_int), value :: dir_mask
+      type(c_funptr), value :: fn
+    end function
     integer(c_int) function x3d_lazy_enable(b, on) bind(C, name='x3d_lazy_enable')
       import :: c_ptr, c_int
       type(c_ptr), value :: b

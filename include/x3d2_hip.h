@@ -622,6 +622,15 @@ int x3d_lazy_unregister_block(x3d_backend *b, x3d_real *f); /* sync, then forget
 int x3d_lazy_register_block(x3d_backend *b, x3d_real *f);
 int x3d_block_discard(x3d_backend *b, x3d_real *f);
 int x3d_lazy_stats(x3d_backend *b, long out[24]);
+/* round 5: a transeq of a DECOMPOSED direction recorded like a local one (so that the three sum_<d>intox behind it fold
+ * into the accumulating form) and executed by the host when the queue runs: fn gets the buffers that hold the handles'
+ * data and does the exchanges + x3d_transeq_tile + x3d_transeq_halo_fix itself (fortran/m_hip_backend.f90); every rank
+ * runs the same queue at the same call of the program.  dir_mask: bit d = direction d (y = 2, z = 3); fn = NULL: off. */
+typedef int (*x3d_dist_transeq_fn)(void *user, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u,
+                                   const x3d_real *v, const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st,
+                                   const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                                   int accumulate);
+int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_dist_transeq_fn fn, void *user);
 
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);

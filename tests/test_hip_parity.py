@@ -720,8 +720,8 @@ def test_unchanged_reference_solver_through_fortran_shim_on_several_ranks(nranks
 def test_fortran_shim_decomposed_directions_in_one_pass(nranks, inp, tmp_path):
     """256 rows per rank along the decomposed direction(s): the shim's transeq_* and tds_solve take the library's
     single-pass forms (x3d_pack_halos_multi -> exchange -> x3d_transeq_tile / x3d_tds_pair_tile -> exchange ->
-    x3d_*_halo_fix; fortran/m_hip_backend.f90, transeq_dist / tds_solve_hip) with device-to-device exchanges and the
-    deferred-execution layer on -- against the reference's own sweep / exchange / sweep order of calls with host-staged
+    x3d_*_halo_fix; fortran/m_hip_backend.f90, transeq_one_pass / tds_solve_hip) with device-to-device exchanges and the
+    deferred-execution layer on (the distributed transeq recorded and run through dist_transeq_cb) -- against the reference's own sweep / exchange / sweep order of calls with host-staged
     exchanges, call by call (rounds 2-3's path: X3D_SHIM_TWO_PHASE=1 X3D_SHIM_HOST_STAGED=1 X3D_NO_LAZY=1) and against
     the SAME binary on one rank: the unchanged solver.f90's monitoring.csv (enstrophy to 1e-12, div u at round-off)"""
     import re
@@ -752,6 +752,10 @@ def test_fortran_shim_decomposed_directions_in_one_pass(nranks, inp, tmp_path):
                 # 4 steps x 3 sub-steps: one HALO transeq launch per decomposed direction and sub-step + its tds_solves
                 assert st["halo_forms"] >= 12 * (2 if nranks == 4 else 1) * 5, l
                 assert st["recorded"] > 0 and st["sync_copies"] == 0, l
+                # round 5: the transeq of a decomposed direction is RECORDED like a local one and run by the shim's callback
+                # when the queue executes it (x3d_lazy_set_dist_transeq) -- so every direction's three sum_<d>intox fold into
+                # the accumulating form: no operation runs unfused, no alias is materialised
+                assert st["transeq_acc"] + st["transeq_stage"] == 12 * 2 and st["declined"] == 0 and st["materialised"] == 0, l
     a, b, c = traces["one_pass"], traces["two_phase_host_staged"], traces["one_rank"]
     assert a.shape == b.shape == c.shape and a.shape[0] >= 3
     assert np.all(np.abs(a[:, 1] - b[:, 1]) < 1e-12 * 0.375) and np.all(np.abs(a[:, 1] - c[:, 1]) < 1e-12 * 0.375)

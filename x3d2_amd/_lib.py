@@ -37,6 +37,7 @@ PROTOTYPES = {
     "x3d_backend_destroy": (I, [VP]),
     "x3d_backend_create_like": (I, [ctypes.POINTER(VP), VP, c_int_p]),
     "x3d_lazy_enable": (I, [VP, I]),
+    "x3d_lazy_set_dist_transeq": (I, [VP, ctypes.c_uint, VP, VP]),  # (fn: a C function pointer; the Fortran shim's use)
     "x3d_lazy_flush": (I, [VP]),
     "x3d_lazy_sync": (I, [VP]),
     "x3d_lazy_register_block": (I, [VP, VP]),

@@ -79,6 +79,10 @@ struct x3d_lazy {
     std::vector<real_t *> handles;                      // registration order
     std::vector<real_t *> pool;                         // extra physical buffers owned by the layer
     std::unordered_map<const real_t *, real_t *> bind;  // handle -> the buffer an earlier operation filled for its NEXT life (L_BIND)
+    // decomposed directions whose transeq the HOST executes when the queue runs (x3d_lazy_set_dist_transeq): bit d = direction d
+    unsigned dist_mask = 0;
+    x3d_dist_transeq_fn dist_fn = nullptr;
+    void *dist_user = nullptr;
     long stats[ST_N] = {};
 };
 
@@ -575,6 +579,7 @@ static void optimise(x3d_backend *b)
     // reads u, v, w themselves (the reordered copies it was recorded with are released right behind the transeq)
     for (int p = 0; p < n && (L->rules & 512u); p++) {
         if (q[p].kind != L_TRANSEQ_ACC || q[p].dir == X3D_DIR_X) continue;
+        if ((L->dist_mask >> q[p].dir) & 1u) continue;  // (a decomposed direction runs on the host's side: x3d_lazy_set_dist_transeq)
         if (!x3d_transeq_stage_ok(b, q[p].dir, q[p].t[0], q[p].t[1], q[p].t[2], q[p].t[3])) continue;
         const real_t *r[3];
         int kc[3], ip[3] = {0, 0, 0}, K = -1;
@@ -945,8 +950,14 @@ static int exec(x3d_backend *b, const LOp &op)
     }
     switch (op.kind) {
     case L_TRANSEQ:
+        if (L->dist_fn && ((L->dist_mask >> op.dir) & 1u))
+            return L->dist_fn(L->dist_user, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 0);
         return x3d_transeq(b, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3]);
     case L_TRANSEQ_ACC:
+        // a decomposed direction: the host's pack -> exchange -> tile kernel -> exchange -> strip correction, on the buffers the
+        // queue resolved; every rank runs the same queue at the same call of the program, so the exchanges meet
+        if (L->dist_fn && ((L->dist_mask >> op.dir) & 1u))
+            return L->dist_fn(L->dist_user, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1);
         return x3d_transeq_acc(b, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1);
     case L_TDS: return x3d_tds_solve(b, o[0], in[0], op.t[0], op.dir);
     case L_TDS_ACC: return x3d_tds_solve_acc(b, o[0], in[0], op.t[0], op.dir, 1, op.s[0]);
@@ -1214,6 +1225,22 @@ extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
     L->keep_zero_terms = e && e[0] == '1';
     const char *r = getenv("X3D_LAZY_RULES");
     L->rules = r ? (unsigned)strtoul(r, nullptr, 0) : ~0u;
+    return 0;
+}
+
+// A direction decomposed over ranks: its transeq can still be RECORDED (x3d_transeq while the mode is on) -- and fold its
+// three sum_<d>intox into the accumulating form like a local one -- if the host says how to run it: when the queue
+// executes the operation it calls fn with the buffers that hold the handles' data (accumulate = 1: du, dv, dw are
+// added to).  Inside fn the library's entry points run at once, on those buffers.  dir_mask: bit d = direction d.
+extern "C" int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_dist_transeq_fn fn, void *user)
+{
+    X3D_REQUIRE(b, "x3d_lazy_set_dist_transeq: null backend");
+    X3D_REQUIRE(!(dir_mask & ~((1u << X3D_DIR_Y) | (1u << X3D_DIR_Z))), "x3d_lazy_set_dist_transeq: y and z only");
+    x3d_lazy *L = lazy_of(b);
+    if (int rc = x3d_lazy_flush_c(b)) return rc;
+    L->dist_mask = fn ? dir_mask : 0u;
+    L->dist_fn = fn;
+    L->dist_user = user;
     return 0;
 }
 
