@@ -594,11 +594,12 @@ module m_hip_backend
     ! Sets 5..8 serve the single-pass forms (x3d_transeq_tile / x3d_tds_pair_tile + *_halo_fix): 5 = the rows of the three
     ! transeq fields [side][3][4][hr], 6 = the boundary values of a direction's nine operators [side][9][np], 7 / 8 = the
     ! same for one tds_solve ([side][1][4][hr], [side][1][np]); a pair's two buffers are contiguous = one [side 2][...]
-    ! array of the library.
-    type(c_ptr) :: slab(2:3) = c_null_ptr, xb(4, 8, 2:3) = c_null_ptr
+    ! array of the library.  Sets 9 / 10 (round 5): an operator PAIR's rows of two fields [side][2][4][hr] and boundary values
+    ! of two operators [side][2][np] (dist_tds_cb).
+    type(c_ptr) :: slab(2:3) = c_null_ptr, xb(4, 10, 2:3) = c_null_ptr
     type(c_ptr) :: peer(2, 2:3) = c_null_ptr   ! the neighbours' slabs, mapped (1: prev, 2: next)
-    integer :: par(8, 2:3) = 0
-    integer(c_long) :: cap(8, 2:3) = 0, off(8, 2:3) = 0   ! doubles per buffer of a set, the set's start in the slab
+    integer :: par(10, 2:3) = 0
+    integer(c_long) :: cap(10, 2:3) = 0, off(10, 2:3) = 0   ! doubles per buffer of a set, the set's start in the slab
     integer :: xb_n = 0
     integer :: tile_tq(2:3) = -1, tile_tds(2:3) = -1       ! single-pass kernels serve this direction (-1: not probed)
     ! one-pass verdicts per operator handle, agreed by ALL ranks (tile_verdict): a rank whose own probe accepts must not
@@ -609,6 +610,10 @@ module m_hip_backend
     logical :: d2d = .false., one_pass = .true.
     logical :: lazy_on = .false.           ! the library records the calls (x3d_lazy_enable)
     logical :: dist_cb = .false.           ! ... and runs the transeq of a decomposed direction through dist_transeq_cb
+    logical :: dist_tds = .false.          ! ... and its tds_solve / operator pairs through dist_tds_cb
+    type(c_ptr) :: pair_tmp = c_null_ptr   ! scratch block of dist_tds_cb's fall-back for a mode-0 pair the tile kernel declines
+    integer(c_intptr_t) :: pv_a(64) = 0, pv_b(64) = 0   ! pair verdicts (pair_verdict): operators, mode, MIN over the ranks
+    integer :: pv_mode(64) = -1, pv_ok(64) = -1, pv_n = 0
     integer :: tq_n(2:3) = 0               ! rows per pencil of the fields a recorded distributed transeq works on
     real(dp), allocatable :: hs(:), he(:), hrs(:), hre(:)
   contains
@@ -697,14 +702,14 @@ contains
       hr = x3d_halo_row_size(self%handle, int(d, c_int))
       np = x3d_npencils(self%handle, int(d, c_int))
       self%cap(1:4, d) = n
-      self%cap(5:8, d) = [12*hr, 9*np, 4*hr, np]
+      self%cap(5:10, d) = [12*hr, 9*np, 4*hr, np, 8*hr, 2*np]
       total = 0
-      do k = 1, 8
+      do k = 1, 10
         self%off(k, d) = total
         total = total + 4*self%cap(k, d)
       end do
       call x3d_check(x3d_device_alloc(self%handle, self%slab(d), total))
-      do k = 1, 8
+      do k = 1, 10
         do i = 1, 4
           self%xb(i, k, d) = ptr_off(self%slab(d), self%off(k, d) + int(i - 1, c_long)*self%cap(k, d))
         end do
@@ -1084,6 +1089,110 @@ contains
     call dspec%set_data_loc(spec%data_loc)
   end subroutine
 
+  logical function record_tds(self)
+    !! the library calls dist_tds_cb for recorded solves of the decomposed directions (registered here, once)
+    class(hip_backend_t), target :: self
+    character(len=8) :: v
+    integer :: stat, d
+    integer(c_int) :: mask
+    record_tds = self%dist_tds
+    if (record_tds) return
+    call get_environment_variable('X3D_SHIM_NO_DIST_RECORD', v, status=stat)
+    if (stat == 0 .and. v(1:1) == '1') return
+    mask = 0
+    do d = DIR_Y, DIR_Z
+      if (decomposed(self, d)) mask = ior(mask, ishft(1_c_int, d))
+    end do
+    g_backend => self
+    call x3d_check(x3d_lazy_set_dist_tds(self%handle, mask, c_funloc(dist_tds_cb), c_null_ptr))
+    self%dist_tds = .true.
+    record_tds = .true.
+  end function record_tds
+
+  integer function pair_verdict(self, d, mode, ta, tb) result(ok)
+    !! does EVERY rank's tile kernel take this operator pair (mode 0 / 1) in direction d?  Probed when the queue first
+    !! executes such a pair -- every rank runs the same queue, so the reduction meets -- and remembered
+    class(hip_backend_t) :: self
+    integer, intent(in) :: d, mode
+    type(c_ptr), intent(in) :: ta, tb
+    integer(c_intptr_t) :: ka, kb
+    integer(c_int) :: done
+    integer :: k, mine, ierr
+    ka = transfer(ta, ka); kb = transfer(tb, kb)
+    do k = 1, self%pv_n
+      if (self%pv_a(k) == ka .and. self%pv_b(k) == kb .and. self%pv_mode(k) == mode) then
+        ok = self%pv_ok(k)
+        return
+      end if
+    end do
+    call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), int(mode, c_int), xs(self, 1, 1, d), xs(self, 1, 2, d), &
+                                     xs(self, 1, 3, d), xs(self, 1, 4, d), ta, tb, xr(self, 1, 9, d), xs(self, 1, 10, d), &
+                                     0_c_int, 0_c_int, done))
+    mine = int(done)
+    call MPI_Allreduce(mine, ok, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    if (self%pv_n < size(self%pv_a)) then
+      self%pv_n = self%pv_n + 1
+      self%pv_a(self%pv_n) = ka; self%pv_b(self%pv_n) = kb; self%pv_mode(self%pv_n) = mode; self%pv_ok(self%pv_n) = ok
+    else
+      ok = 0
+    end if
+  end function pair_verdict
+
+  subroutine tds_one_pass(self, d, mode, out1, out2, in1, in2, ta, tb)
+    !! one operator (mode 2) or an operator pair (0: out1 = ta(in1) + tb(in2); 1: out1 = ta(in1), out2 = tb(in1)) along the
+    !! decomposed direction d in one pass: rows of the input field(s) to the neighbours, the tile kernel with the neighbours'
+    !! boundary values taken as zero, exchange of this rank's boundary values, strip correction (device pointers)
+    class(hip_backend_t) :: self
+    integer, intent(in) :: d, mode
+    type(c_ptr), intent(in) :: out1, out2, in1, in2, ta, tb
+    type(c_ptr) :: flds(2)
+    integer(c_int) :: done, dims(2)
+    integer :: kh, kb, nf, nb
+    integer(c_long) :: hr, np
+    nf = merge(2, 1, mode == 0); nb = merge(1, 2, mode == 2)
+    kh = merge(9, 7, nf == 2); kb = merge(8, 10, nb == 1)
+    hr = x3d_halo_row_size(self%handle, int(d, c_int)); np = x3d_npencils(self%handle, int(d, c_int))
+    call x3d_check(x3d_tdsops_dims(ta, dims))
+    flds = [in1, in2]
+    call next_use(self, d, kh)
+    call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, kh, d), flds, int(nf, c_int), dims(1), int(d, c_int)))
+    call sendrecv_set(self, d, kh, int(nf*4*hr))
+    call next_use(self, d, kb)
+    call x3d_check(x3d_tds_pair_tile(self%handle, int(d, c_int), int(mode, c_int), out1, out2, in1, in2, ta, tb, &
+                                     xr(self, 1, kh, d), xs(self, 1, kb, d), 0_c_int, -1_c_int, done))
+    if (done /= 1) error stop 'hip shim: the tile kernel declined pencils its probe had accepted'
+    call sendrecv_set(self, d, kb, int(nb*np))
+    call x3d_check(x3d_tds_pair_halo_fix(self%handle, int(d, c_int), int(mode, c_int), out1, out2, ta, tb, xr(self, 1, kb, d)))
+  end subroutine tds_one_pass
+
+  integer(c_int) function dist_tds_cb(user, dir, mode, out1, out2, in1, in2, ta, tb) bind(C)
+    !! called by the library's queue for a recorded tds_solve / operator pair of a decomposed direction
+    !! (include/x3d2_hip.h, x3d_dist_tds_fn); the pointers are the buffers that hold the handles' data
+    type(c_ptr), value :: user, out1, out2, in1, in2, ta, tb
+    integer(c_int), value :: dir, mode
+    type(c_ptr) :: tmp
+    integer :: d
+    d = int(dir)
+    dist_tds_cb = 0
+    if (.not. associated(g_backend)) error stop 'hip shim: dist_tds_cb without a backend'
+    if (mode == 2) then
+      call tds_one_pass(g_backend, d, 2, out1, c_null_ptr, in1, c_null_ptr, ta, c_null_ptr)
+    else if (pair_verdict(g_backend, d, int(mode), ta, tb) == 1) then
+      call tds_one_pass(g_backend, d, int(mode), out1, out2, in1, in2, ta, tb)
+    else if (mode == 1) then  ! the pair kernel does not take these two: one after the other (every rank alike)
+      call tds_one_pass(g_backend, d, 2, out1, c_null_ptr, in1, c_null_ptr, ta, c_null_ptr)
+      call tds_one_pass(g_backend, d, 2, out2, c_null_ptr, in1, c_null_ptr, tb, c_null_ptr)
+    else                      ! out1 = ta(in1) + tb(in2) through a scratch block
+      if (.not. c_associated(g_backend%pair_tmp)) then
+        call x3d_check(x3d_block_alloc(g_backend%handle, g_backend%pair_tmp))
+      end if
+      tmp = g_backend%pair_tmp
+      call tds_one_pass(g_backend, d, 2, out1, c_null_ptr, in1, c_null_ptr, ta, c_null_ptr)
+      call tds_one_pass(g_backend, d, 2, tmp, c_null_ptr, in2, c_null_ptr, tb, c_null_ptr)
+      call x3d_check(x3d_vecadd(g_backend%handle, 1.0_c_double, tmp, 1.0_c_double, out1))
+    end if
+  end function dist_tds_cb
+
   subroutine tds_solve_hip(self, du, u, tdsops)
     class(hip_backend_t) :: self
     class(field_t), intent(inout) :: du
@@ -1106,6 +1215,13 @@ contains
           ! single pass (as transeq_dist): mode 2 of the pair kernel = one operator.  Probed per OPERATOR (the operators
           ! of a direction differ in length -- n_tds /= n_rhs for v2p -- and closure), once, and agreed by all ranks
           if (tile_verdict(self, d, tdsops) == 1) then
+            ! round 5: with the queue on the solve is RECORDED like a local one -- two solves and the vecadd behind them
+            ! become the pair kernel's mode 0, two solves of one field its mode 1 -- and dist_tds_cb runs it when the queue
+            ! executes (X3D_SHIM_NO_DIST_RECORD=1: at once, as in round 4)
+            if (self%lazy_on .and. record_tds(self)) then
+              call x3d_check(x3d_tds_solve(self%handle, dev(du), dev(u), tds_handle(tdsops), int(d, c_int)))
+              return
+            end if
             one(1) = dev(u)
             call next_use(self, d, 7)
             call x3d_check(x3d_pack_halos_multi(self%handle, xs(self, 1, 7, d), one, 1_c_int, int(tdsops%n_tds, c_int), &

@@ -41,6 +41,18 @@ module m_x3d2_hip_capi
       integer(c_int), value :: dir_mask
       type(c_funptr), value :: fn
     end function
+    integer(c_int) function x3d_lazy_set_dist_tds(b, dir_mask, fn, user) bind(C, name='x3d_lazy_set_dist_tds')
+      !! tds_solve along a decomposed direction recorded like a local one and run by fn when the queue executes it
+      import :: c_ptr, c_int, c_funptr
+      type(c_ptr), value :: b, user
+      integer(c_int), value :: dir_mask
+      type(c_funptr), value :: fn
+    end function
+    integer(c_int) function x3d_tdsops_dims(t, out) bind(C, name='x3d_tdsops_dims')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: t
+      integer(c_int), intent(out) :: out(2)
+    end function
     integer(c_int) function x3d_lazy_enable(b, on) bind(C, name='x3d_lazy_enable')
       import :: c_ptr, c_int
       type(c_ptr), value :: b

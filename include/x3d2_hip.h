@@ -172,6 +172,7 @@ int x3d_tds_penta_solve(x3d_backend *b, x3d_real *du, const x3d_real *u, const x
  * range of planes [other0, other0 + nother) (nother < 0: all), for overlapping an exchange with the remaining
  * planes.  *done == 0: pencils not served by the tile kernels, nothing was written. */
 int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2]); /* rows 1..out[0], n-out[1]+1..n get a correction */
+int x3d_tdsops_dims(const x3d_tdsops *t, int out[2]);      /* n_tds, n_rhs */
 long x3d_halo_row_size(const x3d_backend *b, int dir);
 int x3d_pack_halos_multi(x3d_backend *b, x3d_real *send, const x3d_real *const *fields, int nf, int n, int dir);
 int x3d_transeq_tile(x3d_backend *b, int dir, x3d_real *du, x3d_real *dv, x3d_real *dw, const x3d_real *u, const x3d_real *v,
@@ -631,6 +632,11 @@ typedef int (*x3d_dist_transeq_fn)(void *user, int dir, x3d_real *du, x3d_real *
                                    const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
                                    int accumulate);
 int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_dist_transeq_fn fn, void *user);
+/* ... and tds_solve along a decomposed direction: recorded, paired by the rewrites like local solves, executed by fn
+ * (mode 2: out1 = ta(in1); 0: out1 = ta(in1) + tb(in2); 1: out1 = ta(in1), out2 = tb(in1); unused pointers NULL) */
+typedef int (*x3d_dist_tds_fn)(void *user, int dir, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
+                               const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb);
+int x3d_lazy_set_dist_tds(x3d_backend *b, unsigned dir_mask, x3d_dist_tds_fn fn, void *user);
 
 /* ---- measurement support: HIP-event timing on the backend's stream */
 int x3d_timer_start(x3d_backend *b);

@@ -749,8 +749,10 @@ def test_fortran_shim_decomposed_directions_in_one_pass(nranks, inp, tmp_path):
             assert len(reports) == nranks, r.stderr[-2000:]
             for l in reports:
                 st = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", l)}
-                # 4 steps x 3 sub-steps: one HALO transeq launch per decomposed direction and sub-step + its tds_solves
-                assert st["halo_forms"] >= 12 * (2 if nranks == 4 else 1) * 5, l
+                # 4 steps x 3 sub-steps: one HALO transeq launch per decomposed direction and sub-step + its tds_solves (round 5:
+                # recorded and paired like local ones -- x3d_lazy_set_dist_tds --: 2 pairs + singles instead of 5 singles)
+                assert st["halo_forms"] >= 12 * (2 if nranks == 4 else 1) * 3, l
+                assert st["pairs"] >= 12 * 4 and st["lincombs"] <= 6, l   # (every direction's operators in pairs, no vecadd left)
                 assert st["recorded"] > 0 and st["sync_copies"] == 0, l
                 # round 5: the transeq of a decomposed direction is RECORDED like a local one and run by the shim's callback
                 # when the queue executes it (x3d_lazy_set_dist_transeq) -- so every direction's three sum_<d>intox fold into

@@ -37,7 +37,8 @@ PROTOTYPES = {
     "x3d_backend_destroy": (I, [VP]),
     "x3d_backend_create_like": (I, [ctypes.POINTER(VP), VP, c_int_p]),
     "x3d_lazy_enable": (I, [VP, I]),
-    "x3d_lazy_set_dist_transeq": (I, [VP, ctypes.c_uint, VP, VP]),  # (fn: a C function pointer; the Fortran shim's use)
+    "x3d_lazy_set_dist_transeq": (I, [VP, ctypes.c_uint, VP, VP]),
+    "x3d_lazy_set_dist_tds": (I, [VP, ctypes.c_uint, VP, VP]),  # (fn: a C function pointer; the Fortran shim's use)
     "x3d_lazy_flush": (I, [VP]),
     "x3d_lazy_sync": (I, [VP]),
     "x3d_lazy_register_block": (I, [VP, VP]),
@@ -81,6 +82,7 @@ PROTOTYPES = {
     "x3d_tds_solve_pair": (I, [VP, I, I, VP, VP, VP, VP, VP, VP]),
     "x3d_tds_solve_pair_yperm": (I, [VP, I, VP, VP, VP, VP, VP, VP, I, c_int_p]),
     "x3d_tdsops_halo_rows": (I, [VP, c_int_p]),
+    "x3d_tdsops_dims": (I, [VP, c_int_p]),
     "x3d_halo_row_size": (ctypes.c_long, [VP, I]),
     "x3d_pack_halos_multi": (I, [VP, VP, ctypes.POINTER(VP), I, I, I]),
     "x3d_transeq_tile": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, I, VP, VP, I, I, c_int_p]),

@@ -83,6 +83,9 @@ struct x3d_lazy {
     unsigned dist_mask = 0;
     x3d_dist_transeq_fn dist_fn = nullptr;
     void *dist_user = nullptr;
+    unsigned dist_tds_mask = 0;  // ... and whose tds_solve / operator pairs it executes (x3d_lazy_set_dist_tds)
+    x3d_dist_tds_fn dist_tds_fn = nullptr;
+    void *dist_tds_user = nullptr;
     long stats[ST_N] = {};
 };
 
@@ -469,6 +472,7 @@ static void optimise(x3d_backend *b)
         if (pg < 0 || q[pg].kind != L_TDS || q[pg].o[0] != G || U == q[pg].in[0] || U == G || G == q[pg].in[0] ||
             !dead_after(q, p, G))
             continue;
+        if ((L->dist_tds_mask >> q[pg].dir) & 1u) continue;  // (a decomposed direction's solve runs on the host's side: no accumulating form there)
         if (!range_clear(q, pg, p, {G, U}, {})) continue;
         q[pg].kind = L_TDS_ACC; q[pg].o[0] = U; q[pg].s[0] = q[p].s[0];
         q[p].kind = L_DEAD;
@@ -959,9 +963,16 @@ static int exec(x3d_backend *b, const LOp &op)
         if (L->dist_fn && ((L->dist_mask >> op.dir) & 1u))
             return L->dist_fn(L->dist_user, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1);
         return x3d_transeq_acc(b, op.dir, o[0], o[1], o[2], in[0], in[1], in[2], op.s[0], op.t[0], op.t[1], op.t[2], op.t[3], 1);
-    case L_TDS: return x3d_tds_solve(b, o[0], in[0], op.t[0], op.dir);
+    case L_TDS:
+        if (L->dist_tds_fn && ((L->dist_tds_mask >> op.dir) & 1u))
+            return L->dist_tds_fn(L->dist_tds_user, op.dir, 2, o[0], nullptr, in[0], nullptr, op.t[0], nullptr);
+        return x3d_tds_solve(b, o[0], in[0], op.t[0], op.dir);
     case L_TDS_ACC: return x3d_tds_solve_acc(b, o[0], in[0], op.t[0], op.dir, 1, op.s[0]);
-    case L_PAIR: return x3d_tds_solve_pair(b, op.dir, op.mode, o[0], o[1], in[0], in[1], op.t[0], op.t[1]);
+    case L_PAIR:
+        if (L->dist_tds_fn && ((L->dist_tds_mask >> op.dir) & 1u))
+            return L->dist_tds_fn(L->dist_tds_user, op.dir, op.mode, o[0], op.mode == 1 ? o[1] : nullptr, in[0],
+                                  op.mode == 0 ? in[1] : nullptr, op.t[0], op.t[1]);
+        return x3d_tds_solve_pair(b, op.dir, op.mode, o[0], o[1], in[0], in[1], op.t[0], op.t[1]);
     case L_TDS_LIN:
         if (op.mode & 2) return x3d_tds_solve_lincomb_wall(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1], in[1 + op.nterm]);
         return x3d_tds_solve_lincomb(b, op.dir, o[0], op.t[0], o[1], in[0], op.nterm, op.s, &in[1]);
@@ -1241,6 +1252,21 @@ extern "C" int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_
     L->dist_mask = fn ? dir_mask : 0u;
     L->dist_fn = fn;
     L->dist_user = user;
+    return 0;
+}
+
+// ... and the same for tds_solve along a decomposed direction: recorded (x3d_tds_solve while the mode is on), paired by the
+// rewrites like local solves (a = A(i1) ; b = B(i2) ; a += b -> mode 0; a = A(i) ; b = B(i) -> mode 1), executed by fn:
+// mode 2: out1 = ta(in1); 0: out1 = ta(in1) + tb(in2); 1: out1 = ta(in1), out2 = tb(in1)
+extern "C" int x3d_lazy_set_dist_tds(x3d_backend *b, unsigned dir_mask, x3d_dist_tds_fn fn, void *user)
+{
+    X3D_REQUIRE(b, "x3d_lazy_set_dist_tds: null backend");
+    X3D_REQUIRE(!(dir_mask & ~((1u << X3D_DIR_Y) | (1u << X3D_DIR_Z))), "x3d_lazy_set_dist_tds: y and z only");
+    x3d_lazy *L = lazy_of(b);
+    if (int rc = x3d_lazy_flush_c(b)) return rc;
+    L->dist_tds_mask = fn ? dir_mask : 0u;
+    L->dist_tds_fn = fn;
+    L->dist_tds_user = user;
     return 0;
 }
 

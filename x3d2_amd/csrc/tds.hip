@@ -268,6 +268,14 @@ extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
 
 // rows 1..out[0] and n-out[1]+1..n: where the coupling to the reduced system's unknowns is still above 2^-60,
 // i.e. the rows x3d_*_halo_fix touch
+extern "C" int x3d_tdsops_dims(const x3d_tdsops *t, int out[2])
+{
+    X3D_REQUIRE(t && out, "x3d_tdsops_dims: null argument");
+    out[0] = t->n_tds;
+    out[1] = t->tab.n_rhs;
+    return 0;
+}
+
 extern "C" int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2])
 {
     X3D_REQUIRE(t && out, "x3d_tdsops_halo_rows: null argument");
