@@ -170,6 +170,7 @@ module m_hip_poisson_fft
     logical :: is_100 = .false.
     type(c_ptr) :: tb = c_null_ptr, t1 = c_null_ptr, t2 = c_null_ptr
     logical :: multi = .false.
+    logical :: skip_own = .true.   ! an undivided direction's transpose is unpacked where it was packed (no exchange with oneself)
     type(c_ptr) :: backend = c_null_ptr, pf = c_null_ptr, sbuf = c_null_ptr, rbuf = c_null_ptr
     real(dp), allocatable :: sh(:), rh(:)
     integer :: comm_y = 0, comm_z = 0
@@ -306,6 +307,12 @@ contains
     call MPI_Comm_split(MPI_COMM_WORLD, rz, ry, self%comm_y, ierr)
     call MPI_Comm_split(MPI_COMM_WORLD, ry, rz, self%comm_z, ierr)
     self%d2d = .not. host_staged()
+    block  ! X3D_SHIM_EXCHANGE_OWN=1: an undivided direction's transpose goes through xchg like a divided one (A/B)
+      character(len=8) :: v
+      integer :: stat
+      call get_environment_variable('X3D_SHIM_EXCHANGE_OWN', v, status=stat)
+      self%skip_own = .not. (stat == 0 .and. v(1:1) == '1')
+    end block
     if (self%d2d) then
       call map_peers(self, self%comm_y, py, self%peer_y)
       call map_peers(self, self%comm_z, pz, self%peer_z)
@@ -448,14 +455,22 @@ contains
     if (self%multi) then  ! x3d2_amd/poisson_fft.py, HipPencilPoissonFFT.fft_forward
       call x3d_check(x3d_pfft_fwd_x(self%pf, dev(f_in)))
       call x3d_check(x3d_pfft_pack_xy(self%pf, buf_out(self)))
-      call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r, 1)
-      call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_in(self)))
-      call stage_done(self)
+      if (size(self%cnt_xy_s) == 1 .and. self%skip_own) then  ! y undivided: the one chunk is this rank's own -- unpacked where it was packed
+        call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_out(self)))  ! (no sync, no barrier, no copy, no change of roles)
+      else
+        call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r, 1)
+        call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_in(self)))
+        call stage_done(self)
+      end if
       call x3d_check(x3d_pfft_fft_y(self%pf, 0_c_int))
       call x3d_check(x3d_pfft_pack_yz(self%pf, buf_out(self)))
-      call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r, 2)
-      call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_in(self)))
-      call stage_done(self)
+      if (size(self%cnt_yz_s) == 1 .and. self%skip_own) then  ! z undivided
+        call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_out(self)))
+      else
+        call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r, 2)
+        call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_in(self)))
+        call stage_done(self)
+      end if
       call x3d_check(x3d_pfft_fft_z(self%pf, 0_c_int))
       return
     end if
@@ -467,14 +482,22 @@ contains
     if (self%multi) then
       call x3d_check(x3d_pfft_fft_z(self%pf, 1_c_int))
       call x3d_check(x3d_pfft_pack_zy(self%pf, buf_out(self)))
-      call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s, 3)
-      call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_in(self)))
-      call stage_done(self)
+      if (size(self%cnt_yz_s) == 1 .and. self%skip_own) then
+        call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_out(self)))
+      else
+        call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s, 3)
+        call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_in(self)))
+        call stage_done(self)
+      end if
       call x3d_check(x3d_pfft_fft_y(self%pf, 1_c_int))
       call x3d_check(x3d_pfft_pack_yx(self%pf, buf_out(self)))
-      call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s, 4)
-      call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_in(self)))
-      call stage_done(self)
+      if (size(self%cnt_xy_s) == 1 .and. self%skip_own) then
+        call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_out(self)))
+      else
+        call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s, 4)
+        call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_in(self)))
+        call stage_done(self)
+      end if
       call x3d_check(x3d_pfft_bwd_x(self%pf, dev(f_out)))
       return
     end if
