@@ -171,6 +171,7 @@ module m_hip_poisson_fft
     type(c_ptr) :: tb = c_null_ptr, t1 = c_null_ptr, t2 = c_null_ptr
     logical :: multi = .false.
     logical :: skip_own = .true.   ! an undivided direction's transpose is unpacked where it was packed (no exchange with oneself)
+    integer :: ry = 0              ! this rank's position in its y group (comm_y)
     type(c_ptr) :: backend = c_null_ptr, pf = c_null_ptr, sbuf = c_null_ptr, rbuf = c_null_ptr
     real(dp), allocatable :: sh(:), rh(:)
     integer :: comm_y = 0, comm_z = 0
@@ -283,6 +284,7 @@ contains
     ry = mesh%par%nrank_dir(2); rz = mesh%par%nrank_dir(3)
     self%multi = .true.
     self%backend = backend
+    self%ry = ry
     call x3d_check(x3d_pfft_create(backend, self%pf, int(dims, c_int), int(py, c_int), int(pz, c_int), &
                                    int(ry, c_int), int(rz, c_int)))
     call x3d_check(x3d_pfft_sizes(self%pf, sz))
@@ -439,6 +441,8 @@ contains
     mine_r = buf_in(self)
     do r = 1, size(rcnt)
       if (rcnt(r) == 0) cycle
+      ! (x-y transposes: the unpack takes this rank's own chunk straight out of its send buffer, x3d_pfft_own_chunk)
+      if (r - 1 == me .and. comm == self%comm_y .and. self%skip_own) cycle
       if (comm == self%comm_y) then
         src = self%peer_y(1 + self%par, r - 1)
       else
@@ -454,19 +458,20 @@ contains
     class(field_t), intent(in) :: f_in
     if (self%multi) then  ! x3d2_amd/poisson_fft.py, HipPencilPoissonFFT.fft_forward
       call x3d_check(x3d_pfft_fwd_x(self%pf, dev(f_in)))
-      call x3d_check(x3d_pfft_pack_xy(self%pf, buf_out(self)))
-      if (size(self%cnt_xy_s) == 1 .and. self%skip_own) then  ! y undivided: the one chunk is this rank's own -- unpacked where it was packed
-        call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_out(self)))  ! (no sync, no barrier, no copy, no change of roles)
+      if (size(self%cnt_xy_s) == 1 .and. self%skip_own) then  ! y undivided: the one chunk is this rank's own -- no exchange,
+        call x3d_check(x3d_pfft_transpose_local(self%pf, 0_c_int))  ! the stage buffer is transposed straight into the next one
       else
+        call x3d_check(x3d_pfft_pack_xy(self%pf, buf_out(self)))
         call xchg(self, self%comm_y, self%cnt_xy_s, self%cnt_xy_r, 1)
+        if (self%d2d .and. self%skip_own) call x3d_check(x3d_pfft_own_chunk(self%pf, buf_out(self), int(self%ry, c_int)))
         call x3d_check(x3d_pfft_unpack_xy(self%pf, buf_in(self)))
         call stage_done(self)
       end if
       call x3d_check(x3d_pfft_fft_y(self%pf, 0_c_int))
-      call x3d_check(x3d_pfft_pack_yz(self%pf, buf_out(self)))
       if (size(self%cnt_yz_s) == 1 .and. self%skip_own) then  ! z undivided
-        call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_out(self)))
+        call x3d_check(x3d_pfft_transpose_local(self%pf, 1_c_int))
       else
+        call x3d_check(x3d_pfft_pack_yz(self%pf, buf_out(self)))
         call xchg(self, self%comm_z, self%cnt_yz_s, self%cnt_yz_r, 2)
         call x3d_check(x3d_pfft_unpack_yz(self%pf, buf_in(self)))
         call stage_done(self)
@@ -481,20 +486,21 @@ contains
     class(field_t), intent(inout) :: f_out
     if (self%multi) then
       call x3d_check(x3d_pfft_fft_z(self%pf, 1_c_int))
-      call x3d_check(x3d_pfft_pack_zy(self%pf, buf_out(self)))
       if (size(self%cnt_yz_s) == 1 .and. self%skip_own) then
-        call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_out(self)))
+        call x3d_check(x3d_pfft_transpose_local(self%pf, 2_c_int))
       else
+        call x3d_check(x3d_pfft_pack_zy(self%pf, buf_out(self)))
         call xchg(self, self%comm_z, self%cnt_yz_r, self%cnt_yz_s, 3)
         call x3d_check(x3d_pfft_unpack_zy(self%pf, buf_in(self)))
         call stage_done(self)
       end if
       call x3d_check(x3d_pfft_fft_y(self%pf, 1_c_int))
-      call x3d_check(x3d_pfft_pack_yx(self%pf, buf_out(self)))
       if (size(self%cnt_xy_s) == 1 .and. self%skip_own) then
-        call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_out(self)))
+        call x3d_check(x3d_pfft_transpose_local(self%pf, 3_c_int))
       else
+        call x3d_check(x3d_pfft_pack_yx(self%pf, buf_out(self)))
         call xchg(self, self%comm_y, self%cnt_xy_r, self%cnt_xy_s, 4)
+        if (self%d2d .and. self%skip_own) call x3d_check(x3d_pfft_own_chunk(self%pf, buf_out(self), int(self%ry, c_int)))
         call x3d_check(x3d_pfft_unpack_yx(self%pf, buf_in(self)))
         call stage_done(self)
       end if

@@ -41,6 +41,18 @@ module m_x3d2_hip_capi
       integer(c_int), value :: dir_mask
       type(c_funptr), value :: fn
     end function
+    integer(c_int) function x3d_pfft_own_chunk(p, sendbuf, rank) bind(C, name='x3d_pfft_own_chunk')
+      !! the next unpack_xy / unpack_yx reads this rank's own chunk out of the send buffer
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, sendbuf
+      integer(c_int), value :: rank
+    end function
+    integer(c_int) function x3d_pfft_transpose_local(p, which) bind(C, name='x3d_pfft_transpose_local')
+      !! a transposition of the pencil solver along a direction that is not divided: one kernel, no exchange
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+      integer(c_int), value :: which
+    end function
     integer(c_int) function x3d_lazy_set_dist_tds(b, dir_mask, fn, user) bind(C, name='x3d_lazy_set_dist_tds')
       !! tds_solve along a decomposed direction recorded like a local one and run by fn when the queue executes it
       import :: c_ptr, c_int, c_funptr

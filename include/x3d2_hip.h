@@ -570,6 +570,12 @@ int x3d_pfft_pack_yz(x3d_pfft *p, x3d_real *sendbuf);
 int x3d_pfft_unpack_yz(x3d_pfft *p, const x3d_real *recvbuf);
 int x3d_pfft_pack_zy(x3d_pfft *p, x3d_real *sendbuf);
 int x3d_pfft_unpack_zy(x3d_pfft *p, const x3d_real *recvbuf);
+/* a transposition along a direction that is not divided (py == 1 / pz == 1): one kernel, no exchange buffer.
+ * which = 0: x-y forward, 1: y-z forward, 2: z-y backward, 3: y-x backward */
+int x3d_pfft_transpose_local(x3d_pfft *p, int which);
+/* the next x3d_pfft_unpack_xy / _unpack_yx takes this rank's own chunk (peer `rank` of the y group) out of `sendbuf`, the
+ * buffer the matching pack filled: no copy of the own chunk into the receive buffer */
+int x3d_pfft_own_chunk(x3d_pfft *p, const x3d_real *sendbuf, int rank);
 int x3d_pfft_postprocess_000(x3d_pfft *p);
 /* the same solve in `parts` groups of zp = zl / parts local z planes (parts <= 0: the library's choice): everything
  * before the z transform is independent from plane to plane, so a group's x transform, xy exchange, y transform and

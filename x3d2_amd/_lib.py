@@ -207,6 +207,8 @@ PROTOTYPES = {
     "x3d_pfft_unpack_yz": (I, [VP, VP]),
     "x3d_pfft_pack_zy": (I, [VP, VP]),
     "x3d_pfft_unpack_zy": (I, [VP, VP]),
+    "x3d_pfft_transpose_local": (I, [VP, I]),
+    "x3d_pfft_own_chunk": (I, [VP, VP, I]),
     "x3d_pfft_postprocess_000": (I, [VP]),
     "x3d_pfft_create_parts": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I, I, I, I]),
     "x3d_pfft_part_layout": (I, [VP, ctypes.POINTER(ctypes.c_long)]),

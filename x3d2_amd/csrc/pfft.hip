@@ -47,6 +47,9 @@ struct x3d_pfft {
     real2_t *c0, *c1, *c2;        // stage buffers
     real_t *waves, *ab;
     void *work;
+    // x3d_pfft_own_chunk: the next unpack takes the chunk of peer own_rank (this rank's own) out of the SEND buffer own
+    const real2_t *own;
+    int own_rank;
 };
 
 // dst[i*d0 + j*d1 + k*d2] = src[i*s0 + j*s1 + k*s2]; i is the fastest loop index
@@ -60,6 +63,15 @@ __global__ void __launch_bounds__(256) k_permute(real2_t *__restrict__ dst, cons
     const int j = (int)((q / n0) % n1);
     const int k = (int)(q / ((long)n0 * n1));
     dst[i * d0 + j * d1 + k * d2] = src[i * s0 + j * s1 + k * s2];
+}
+
+// ... when BOTH are contiguous along the first index (a strided copy of rows: the exchange chunks cut along x or y): no
+// index arithmetic per element -- blockIdx.y / .z are the two outer indices (k_permute's 64-bit divisions cost it half its rate)
+__global__ void __launch_bounds__(256) k_copy_rows(real2_t *__restrict__ dst, const real2_t *__restrict__ src, int n0,
+                                                   long d1, long d2, long s1, long s2)
+{
+    const long so = (long)blockIdx.y * s1 + (long)blockIdx.z * s2, dof = (long)blockIdx.y * d1 + (long)blockIdx.z * d2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += gridDim.x * blockDim.x) dst[dof + i] = src[so + i];
 }
 
 // the same when src is contiguous along dimension A and dst along a different dimension B (a genuine
@@ -109,6 +121,12 @@ static int permute(x3d_backend *b, real2_t *dst, const real2_t *src, int n0, int
             X3D_HIP(hipGetLastError());
             return 0;
         }
+    }
+    if (s0 == 1 && d0 == 1 && n1 <= 65535 && n2 <= 65535) {
+        hipLaunchKernelGGL(k_copy_rows, dim3((n0 + 255) / 256, n1, n2), dim3(n0 >= 256 ? 256 : (n0 > 64 ? 128 : 64)), 0, b->stream,
+                           dst, src, n0, d1, d2, s1, s2);
+        X3D_HIP(hipGetLastError());
+        return 0;
     }
     hipLaunchKernelGGL(k_permute, dim3((tot + 255) / 256), dim3(256), 0, b->stream, dst, src, n0, n1, n2, d0, d1, d2,
                        s0, s1, s2);
@@ -330,12 +348,14 @@ static int xy_c0(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
     for (int r = 0; r < p->py; r++) {
         const int xr = share(p->nxs, p->py, r), xo = share_off(p->nxs, p->py, r);
         real2_t *ch = s + (long)xo * p->yl * nzl;
+        const real2_t *src = (!pack && p->own && r == p->own_rank) ? p->own + (long)r * p->xs * p->yl * nzl : ch;
         const int rc = pack ? permute(p->b, ch, c0 + xo, xr, p->yl, nzl, 1, xr, (long)xr * p->yl, 1, p->nxs,
                                       (long)p->nxs * p->yl)
-                            : permute(p->b, c0 + xo, ch, xr, p->yl, nzl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
+                            : permute(p->b, c0 + xo, src, xr, p->yl, nzl, 1, p->nxs, (long)p->nxs * p->yl, 1, xr,
                                       (long)xr * p->yl);
         if (rc) return rc;
     }
+    if (!pack) p->own = nullptr;
     return 0;
 }
 static int xy_c1(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
@@ -343,12 +363,16 @@ static int xy_c1(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
     real2_t *c1 = p->c1 + (size_t)z0 * p->xs * p->ny;
     const long chunk = (long)p->xs * p->yl * nzl;
     for (int r = 0; r < p->py; r++) {
+        // (own chunk straight out of the send buffer, where xy_c0 packed it: x3d_pfft_own_chunk)
+        const real2_t *src = (!pack && p->own && r == p->own_rank) ? p->own + (long)share_off(p->nxs, p->py, r) * p->yl * nzl
+                                                                    : s + r * chunk;
         const int rc = pack ? permute(p->b, s + r * chunk, c1 + (long)r * p->yl, p->xs, p->yl, nzl, 1, p->xs,
                                       (long)p->xs * p->yl, p->ny, 1, (long)p->xs * p->ny)
-                            : permute(p->b, c1 + (long)r * p->yl, s + r * chunk, p->xs, p->yl, nzl, p->ny, 1,
+                            : permute(p->b, c1 + (long)r * p->yl, src, p->xs, p->yl, nzl, p->ny, 1,
                                       (long)p->xs * p->ny, 1, p->xs, (long)p->xs * p->yl);
         if (rc) return rc;
     }
+    if (!pack) p->own = nullptr;
     return 0;
 }
 static int yz_c1(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
@@ -419,6 +443,31 @@ extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const real_t *recvbuf)
 {
     X3D_REQUIRE(p && recvbuf, "null argument");
     return yz_c1(p, (real2_t *)recvbuf, 0, p->zl, false);
+}
+
+// A direction that is NOT divided (py == 1 or pz == 1): the "exchange" of that transposition is with oneself, the packed
+// chunk has exactly the layout of the stage buffer it was cut from -- so the stage buffer itself is the exchange buffer and
+// the transposition is one kernel.  which = 0: x-y forward (C0 -> C1), 1: y-z forward (C1 -> C2), 2: z-y backward, 3: y-x
+// the next x3d_pfft_unpack_xy / _unpack_yx reads the chunk of peer `rank` (this rank itself) out of `sendbuf`, the buffer the
+// matching pack filled, instead of the receive buffer: the host need not copy a rank's own chunk from one to the other
+extern "C" int x3d_pfft_own_chunk(x3d_pfft *p, const real_t *sendbuf, int rank)
+{
+    X3D_REQUIRE(p && sendbuf && rank >= 0 && rank < p->py, "x3d_pfft_own_chunk: bad argument");
+    p->own = (const real2_t *)sendbuf;
+    p->own_rank = rank;
+    return 0;
+}
+
+extern "C" int x3d_pfft_transpose_local(x3d_pfft *p, int which)
+{
+    X3D_REQUIRE(p && which >= 0 && which <= 3, "x3d_pfft_transpose_local: bad argument");
+    X3D_REQUIRE((which == 0 || which == 3) ? p->py == 1 : p->pz == 1, "x3d_pfft_transpose_local: the direction is divided");
+    switch (which) {
+    case 0: return xy_c1(p, p->c0, 0, p->zl, false);
+    case 1: return yz_c2(p, p->c1, 0, p->zl, false);
+    case 2: return yz_c2(p, p->c1, 0, p->zl, true);
+    default: return xy_c1(p, p->c0, 0, p->zl, true);
+    }
 }
 
 // ---- the solve in groups of planes.  out = {parts, zp, then in complex elements: a group's piece of the xy send
