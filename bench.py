@@ -94,6 +94,10 @@ def cpu_baseline(n, steps, threads):
             probed = {th: child(128, 1, th)["value"] for th in threads}
             threads = max(probed, key=probed.get)
         out = child(n, steps, threads)
+        # `cores` = the CPUs the run could actually keep busy (the container's quota), `threads` = what it started
+        out["threads"] = out.get("cores")
+        if isinstance(out.get("cores"), int):
+            out["cores"] = min(out["cores"], effective_cpus()[1])
         if isinstance(threads, tuple):
             out["fft_workers"] = threads[1]
         if probed:
@@ -195,8 +199,8 @@ def cpu_reference(n, iters, threads, nproc_dir=(1, 1, 1)):
     if r.returncode != 0 or not m:
         return None
     t = float(m.group(1))
-    return {"value": n ** 3 / t, "unit": "DoF*steps/s", "cores": threads * ranks, "kind": "reference",
-            "mpi_ranks": ranks, "omp_threads_per_rank": threads, "nproc_dir": list(nproc_dir),
+    return {"value": n ** 3 / t, "unit": "DoF*steps/s", "cores": min(threads * ranks, effective_cpus()[1]),
+            "threads": threads * ranks, "kind": "reference", "mpi_ranks": ranks, "omp_threads_per_rank": threads, "nproc_dir": list(nproc_dir),
             "sample": f"the reference's xcompact (OpenMP backend, flang -O3 build of /root/reference's sources), TGV {n}^3 "
                       f"RK3, derivatives + RK only (poisson_solver_type='CG': no pressure solve), {iters} steps, its own "
                       f"average without the first step, {ranks} MPI rank(s) x {threads} OpenMP threads",
@@ -666,11 +670,30 @@ def main():
                     "rk_stage_bytes_per_launch_avg": rk_bytes / max(n_f, 1),
                     "avg_launch_ms": dominant["avg_launch_ms"] if dominant else avg_ms, "launches": n_f, "per_direction": per_dir,
                     "share_of_step": (ms_f + ms_b) / (elapsed * 1e3),
-                    # SURVEY.md 8d headline convention: the reference's derivative pass of one sub-step
-                    # (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time our
-                    # transeq phase takes (reorders and sums are folded into the kernels here)
-                    "tdsops_pass_GBs_survey_convention":
+                    # NOT an achieved bandwidth: the bytes the reference's OP-GRANULAR derivative pass of one sub-step would
+                    # move (3 transeq + 6 reorders + 6 sum_intox = 54 field passes = 432 B/DoF) over the time
+                    # this backend's transeq phase takes -- most of those passes are never made here (folded into the kernels)
+                    "tdsops_pass_GBs_nominal_op_granular":
                         432.0 * dofb / ((ms_f + ms_b) / max(args.steps * nstage, 1) * 1e-3) / 1e9 if n_f else 0.0}
+        # (b) the instantiation that takes the most time, and the whole transport phase on the bytes it must move
+        if dominant and dominant.get("with_rk_stage"):
+            e = dominant["with_rk_stage"]
+            roofline["by_time_dominant"] = dict(e, share_of_step=e["launches"] * e["avg_launch_ms"] / (elapsed * 1e3),
+                                                what="the instantiation of the dominant kernel with the largest share of the step "
+                                                     "(z direction + RK stage); `frac` above stays the plain instantiation's")
+        if n_f and n_tq3:
+            lx, ly, lz = (per_dir_raw[d][0][0] / 3.0 for d in (1, 2, 3))
+            le = (n_f - sum(per_dir_raw[d][0][0] for d in (1, 2, 3))) / 3.0
+            # x: R u, v, w + W rhs x 3 (+ R g x 3 + W u, v, w where the velocity correction rides along); y, z: R u, v, w +
+            # R rhs x 3 + W rhs x 3; + 8 B/DoF per field the RK stage inside a z launch reads or writes
+            comp = (lx * 48.0 + n_upd * 48.0 + (ly + lz + le) * 72.0) * dofb + rk_bytes
+            ph_ms = ms_f + ms_b
+            roofline["transeq_phase"] = {
+                "what": "all transport-equation launches (x + y + z, three components each) of the timed region on their "
+                        "COMPULSORY bytes: x 48 B/DoF (+ 48 with the velocity correction), y and z 72 B/DoF (rhs is read, "
+                        "added to and written), + the RK stage's fields where a z launch carries it",
+                "launches": lx + ly + lz + le, "ms": ph_ms, "bytes": comp,
+                "achieved": comp / (ph_ms * 1e-3) / 1e9, "frac": comp / (ph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
         emu = None
         if args.virtual_ranks:
@@ -858,15 +881,23 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         others = {}
+        # (round 6: configs[1] and the channel with the PMC traffic of THEIR dominant kernel measured in their child runs too;
+        #  the headline workload under AB3, the scheme of the reference's examples/TGV/input.x3d:22 -- one sub-step per step,
+        #  3 warm-up steps fill its history)
         for key, extra in (("configs[1] TGV 256^3, derivatives + RK only (no pressure solve)", ["--n", "256", "--no-poisson"]),
-                           ("configs[4] on one GPU: channel 1024x257x512", ["--case", "channel", "--dims", "1024,257,512"])):
+                           ("configs[4] on one GPU: channel 1024x257x512", ["--case", "channel", "--dims", "1024,257,512"]),
+                           ("configs[2] with time_intg = 'AB3' (examples/TGV/input.x3d:22)",
+                            ["--time-intg", "AB3", "--warmup", "3", "--no-live-traffic"])):
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                                    "--no-cpu-baseline", "--no-other-configs", "--no-live-traffic"] + extra, capture_output=True,
+                                    "--no-cpu-baseline", "--no-other-configs"] + extra, capture_output=True,
                                    text=True, timeout=300)
                 o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                 others[key] = brief(o)
+                for extra_key in ("by_time_dominant", "transeq_phase", "frac_on_measured_traffic"):
+                    if extra_key in o["roofline"]:
+                        others[key]["roofline"][extra_key] = o["roofline"][extra_key]
                 others[key]["kernel_ms"] = {k: v for k, v in o["kernel_ms"].items() if isinstance(v, dict) and v["launches"]}
             except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
                 others[key] = {"value": None, "error": repr(e)[:300]}

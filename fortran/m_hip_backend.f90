@@ -54,6 +54,9 @@ contains
     integer, intent(in) :: dims(3), sz, device
     type(hip_allocator_t) :: allocator
     allocator%allocator_t = allocator_t(dims, sz)
+    ! this binding is real(c_double) throughout (ptr_off counts 8-byte reals): refuse the FP32 flavour of the library
+    if (x3d_real_bytes() /= int(c_sizeof(1.0_c_double), c_int)) &
+      error stop 'x3d2 hip backend: the library loaded is not the FP64 build (libx3d2_hip.so); this shim binds real(c_double)'
     call x3d_check(x3d_backend_create(allocator%handle, int(dims, c_int), int(device, c_int), c_null_ptr))
   end function hip_allocator_init
 
@@ -635,7 +638,8 @@ module m_hip_backend
     ! take the one-pass form while a neighbour (a boundary rank of a non-periodic direction) takes the two-phase one --
     ! they would pack different buffer sets and pull from buffers that were never packed
     integer(c_intptr_t) :: tv_h(64) = 0
-    integer :: tv_ok(64) = -1, tv_n = 0
+    integer :: tv_ok(64) = -1, tv_n = 0, tv_evict = 0, pv_evict = 0   ! (full table: oldest entry replaced, said once)
+    logical :: verdict_warned = .false.
     logical :: d2d = .false., one_pass = .true.
     logical :: lazy_on = .false.           ! the library records the calls (x3d_lazy_enable)
     logical :: dist_cb = .false.           ! ... and runs the transeq of a decomposed direction through dist_transeq_cb
@@ -1159,12 +1163,17 @@ contains
                                      0_c_int, 0_c_int, done))
     mine = int(done)
     call MPI_Allreduce(mine, ok, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    ! (a full table replaces its oldest entry -- every rank holds the same table, so they agree on what is re-probed --
+    !  instead of forcing 0 without remembering it: that re-ran the probe and the reduction at every later solve, ADVICE round 5)
     if (self%pv_n < size(self%pv_a)) then
       self%pv_n = self%pv_n + 1
-      self%pv_a(self%pv_n) = ka; self%pv_b(self%pv_n) = kb; self%pv_mode(self%pv_n) = mode; self%pv_ok(self%pv_n) = ok
+      k = self%pv_n
     else
-      ok = 0
+      k = 1 + mod(self%pv_evict, size(self%pv_a))
+      self%pv_evict = self%pv_evict + 1
+      call verdict_table_full(self, 'pair_verdict')
     end if
+    self%pv_a(k) = ka; self%pv_b(k) = kb; self%pv_mode(k) = mode; self%pv_ok(k) = ok
   end function pair_verdict
 
   subroutine tds_one_pass(self, d, mode, out1, out2, in1, in2, ta, tb)
@@ -1307,12 +1316,24 @@ contains
     call MPI_Allreduce(mine, ok, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
     if (self%tv_n < size(self%tv_h)) then
       self%tv_n = self%tv_n + 1
-      self%tv_h(self%tv_n) = key
-      self%tv_ok(self%tv_n) = ok
-    else
-      ok = 0   ! (table full: the two-phase form on every rank -- the same on all ranks, they count alike)
+      k = self%tv_n
+    else   ! (table full: the oldest entry goes -- the same one on all ranks, they count alike)
+      k = 1 + mod(self%tv_evict, size(self%tv_h))
+      self%tv_evict = self%tv_evict + 1
+      call verdict_table_full(self, 'tile_verdict')
     end if
+    self%tv_h(k) = key
+    self%tv_ok(k) = ok
   end function tile_verdict
+
+  subroutine verdict_table_full(self, which)
+    class(hip_backend_t) :: self
+    character(len=*), intent(in) :: which
+    if (self%verdict_warned) return
+    self%verdict_warned = .true.
+    print '(a)', 'x3d2 hip backend: more than 64 operators / operator pairs in the one-pass table ('//which// &
+      '): the oldest verdicts are re-probed (correct, slower)'
+  end subroutine verdict_table_full
 
   subroutine reorder_hip(self, u_, u, direction)
     class(hip_backend_t) :: self

@@ -14,6 +14,10 @@ module m_x3d2_hip_capi
       import :: c_ptr
       type(c_ptr) :: msg
     end function
+    integer(c_int) function x3d_real_bytes() bind(C, name='x3d_real_bytes')
+      !! sizeof(x3d_real) of the library that was loaded: 8 (libx3d2_hip.so) or 4 (libx3d2_hip_sp.so)
+      import :: c_int
+    end function
     integer(c_int) function x3d_backend_create(handle, dims_vert, device, stream) &
       bind(C, name='x3d_backend_create')
       import :: c_ptr, c_int

@@ -62,6 +62,9 @@ typedef struct x3d_poisson x3d_poisson; /* poisson_fft_t extension              
 
 const char *x3d_last_error(void);
 int x3d_abi_version(void);
+/* sizeof(x3d_real) of THIS build: 8 (libx3d2_hip.so, the reference's default dp) or 4 (libx3d2_hip_sp.so, -DSINGLE_PREC,
+ * src/common.f90:6-12) -- a binding written for one real kind checks it before the first call */
+int x3d_real_bytes(void);
 
 /* ---- construction: omp_backend_t(mesh, allocator), src/backend/omp/backend.f90:66-114 +
  *      allocator_t(dims, SZ), src/allocator.f90:64-93.
@@ -206,6 +209,15 @@ int x3d_tds_solve_lincomb(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsop
  * case's apply_BC, src/case/channel.f90:214-231, and the first x operator of divergence_v2c) */
 int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsops *t, x3d_real *y, const x3d_real *base,
                                int nterm, const x3d_real *c, const x3d_real *const *x, const x3d_real *wall);
+/* fusion extension (round 6): x3d_tds_solve_lincomb[_wall] (wall may be NULL) followed by
+ * x3d_field_mean_shift(y, dims, ncell, target, shift) -- the bulk-velocity integral the channel case's NEXT define_BC
+ * asks for (src/case/channel.f90:66-72) taken while the rows of the new u are in the kernel's registers (1024-row x
+ * pencils; elsewhere the two calls one after the other).  *shift: as x3d_field_mean_shift's (valid until the next
+ * reduction of this backend); the partial sums are formed in another order than x3d_field_mean_shift's: round-off apart. */
+int x3d_tds_solve_lincomb_wall_mean(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsops *t, x3d_real *y,
+                                    const x3d_real *base, int nterm, const x3d_real *c, const x3d_real *const *x,
+                                    const x3d_real *wall, const int dims[3], x3d_real ncell, x3d_real target,
+                                    const x3d_real **shift);
 
 /* Distributed form, one call per phase of exec_dist_tds_compact; halo and
  * boundary buffers are device arrays [rows][npencil] (npencil = x3d_npencils):
@@ -259,6 +271,19 @@ int x3d_transeq_x_rot(x3d_backend *b, x3d_real *du, x3d_real *dv, x3d_real *dw, 
                       const x3d_real *w, x3d_real nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                       const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, x3d_real omega, const x3d_real *u_shift,
                       int *done);
+/* fusion extension (round 6): x3d_transeq_x_update and x3d_transeq_x_rot in ONE launch -- the pending correction
+ * u, v, w += scale * tds_solve(g, op) applied per pencil, then u += *u_shift (NULL: no shift), then
+ * du, dv, dw = transeq_x(u, v, w) with the rotation forcing on top (omega = 0: none).  The channel case's sub-step
+ * (src/case/channel.f90:53-77, 191-207 + src/solver.f90:731-733) with the velocity correction deferred to the next
+ * transeq_x: *u_shift is then x3d_field_mean_shift's scalar taken of the UNCORRECTED u (the correction is a periodic x
+ * derivative: zero mean up to rounding).  Same arithmetic per point as x3d_tds_solve_acc x 3 ; x3d_field_shift_by ;
+ * x3d_transeq_x_rot (u, v, w bit for bit; du, dv, dw to the last bit: another kernel body, the compiler's choice of fused
+ * products).  *done = 0: not served (1024-row periodic x pencils on a uniform grid), nothing was done. */
+int x3d_transeq_x_update_rot(x3d_backend *b, x3d_real *du, x3d_real *dv, x3d_real *dw, x3d_real *u, x3d_real *v, x3d_real *w,
+                             x3d_real nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
+                             const x3d_tdsops *der2nd_sym, const x3d_real *gu, const x3d_real *gv, const x3d_real *gw,
+                             const x3d_tdsops *op_u, const x3d_tdsops *op_vw, x3d_real scale, x3d_real omega,
+                             const x3d_real *u_shift, int *done);
 /* transeq_species (src/backend/backend.f90:37, omp :186-233): convection-diffusion of ONE transported
  * scalar along `dir`: dspec = [dspec +] -1/2 (uvw d(spec) + d(uvw spec)) + nu d2(spec), operators
  * (der1st, der1st_sym, der2nd); non-decomposed direction (decomposed: the dist_fwd / dist_bwd pair below
@@ -574,7 +599,9 @@ int x3d_pfft_unpack_zy(x3d_pfft *p, const x3d_real *recvbuf);
  * which = 0: x-y forward, 1: y-z forward, 2: z-y backward, 3: y-x backward */
 int x3d_pfft_transpose_local(x3d_pfft *p, int which);
 /* the next x3d_pfft_unpack_xy / _unpack_yx takes this rank's own chunk (peer `rank` of the y group) out of `sendbuf`, the
- * buffer the matching pack filled: no copy of the own chunk into the receive buffer */
+ * buffer the matching pack filled: no copy of the own chunk into the receive buffer.  The chunk is looked up with the
+ * WHOLE-solve layout (all zl planes): it serves x3d_pfft_pack_* / _unpack_* only -- the group entry points
+ * (x3d_pfft_*_part) index a group's piece of the buffers and refuse a pending own chunk. */
 int x3d_pfft_own_chunk(x3d_pfft *p, const x3d_real *sendbuf, int rank);
 int x3d_pfft_postprocess_000(x3d_pfft *p);
 /* the same solve in `parts` groups of zp = zl / parts local z planes (parts <= 0: the library's choice): everything

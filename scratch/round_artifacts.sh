@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round from the CURRENT tree (run through gpurun, then
-# `python tools_summarize.py <tag> <tag> <round>` here, where git knows the commit):
+# `python tools/summarize.py <tag> <tag> <round>` here, where git knows the commit):
 #   bash scratch/round_artifacts.sh r02
 rnd=${1:-r02}
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/${rnd}_tests.txt; cat gpurun_out/${rnd}_tests.txt
-bash tools_prof.sh ${rnd} | grep -E "calls|total" | head -24
-bash tools_pmc.sh ${rnd} > gpurun_out/pmc_${rnd}.txt
+bash tools/prof.sh ${rnd} | grep -E "calls|total" | head -24
+bash tools/pmc.sh ${rnd} > gpurun_out/pmc_${rnd}.txt
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_${rnd}.json 2> gpurun_out/bench_${rnd}.err; tail -c 300 gpurun_out/bench_${rnd}.json
 python bench.py --steps 5 --warmup 2 --op-granular --no-cpu-baseline > gpurun_out/bench_${rnd}_opg.json 2>/dev/null
 python bench.py --steps 10 --warmup 2 --n 256 --no-poisson --no-cpu-baseline > gpurun_out/bench_${rnd}_256.json 2>/dev/null

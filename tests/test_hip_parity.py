@@ -1937,6 +1937,13 @@ def test_bench_line_contract_one_gpu():
     assert d["launches"] == 3 * 3 and d["algorithmic_bytes_per_launch"] == 64.0 * 512 ** 3   # transeq_y of every sub-step
     e = d["with_rk_stage"]                                                                     # transeq_z + the stage
     assert e["launches"] == 3 * 3 and e["algorithmic_bytes_per_launch"] > d["algorithmic_bytes_per_launch"]
+    # round 6: the instantiation with the largest share of the step, and the whole transport phase on its compulsory bytes
+    t = rf["by_time_dominant"]
+    assert t["avg_launch_ms"] == e["avg_launch_ms"] and 0.1 < t["share_of_step"] < 0.4
+    ph = rf["transeq_phase"]
+    assert ph["launches"] == 3 * 3 * 3 and abs(ph["frac"] - ph["bytes"] / (ph["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-12
+    assert 0.5 < ph["frac"] < 0.8
+    assert "tdsops_pass_GBs_nominal_op_granular" in rf and "tdsops_pass_GBs_survey_convention" not in rf
     assert 30.0 < o["ms_per_step"] < 60.0
 
 

@@ -456,6 +456,112 @@ def test_bulk_velocity_shift_inside_transeq_x(omega, nx):
         al.release_block(f)
 
 
+@pytest.mark.parametrize("omega,shift", [(0.12, True), (0.0, True), (0.12, False), (0.0, False)])
+def test_velocity_correction_shift_and_rotation_inside_transeq_x_at_1024_rows(omega, shift):
+    """x3d_transeq_x_update_rot (round 6, csrc/xwide.hip k_xwide_transeq3_upd): the pending velocity correction
+    u, v, w -= tds_solve(g), the bulk-velocity shift and the rotation forcing inside the transeq_x kernel of the
+    1024-row pencils == x3d_tds_solve_acc x 3 ; x3d_field_shift_by ; x3d_transeq_x_rot: the corrected u, v, w bit for
+    bit, du, dv, dw to the last bit or two.  Lane tables staged without the ST / STC blocks (uniform x)."""
+    import torch
+    from x3d2_amd import _lib
+    from x3d2_amd.common import DIR_X, VERT
+    s = product_solver((1024, 9, 8))
+    b, al, x = s.backend, s.backend.allocator, s.xdirps
+    rng = np.random.default_rng(11)
+    blk = [al.get_block(DIR_X, VERT) for _ in range(15)]
+    u, v, w, gu, gv, gw, u2, v2, w2 = blk[:9]
+    d1, d2 = blk[9:12], blk[12:15]
+    for f in (u, v, w, gu, gv, gw):
+        f.data.copy_(torch.from_numpy(rng.standard_normal(tuple(f.data.shape))).to(f.data.device))
+    for a, c in ((u2, u), (v2, v), (w2, w)):
+        a.data.copy_(c.data)
+    n0 = int(_lib.load().x3d_backend_counter(b.h, 1))
+    sh = b.field_mean_shift(u, 2.0 / 3.0) if shift else None
+    assert b.transeq_x_update_rot(*d1, u, v, w, s.nu, x, (gu, gv, gw), x.stagder_p2v, x.interpl_p2v, -1.0, omega, sh)
+    assert int(_lib.load().x3d_backend_counter(b.h, 1)) == n0 + 1
+    b.tds_apply(u2, gu, x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
+    b.tds_apply(v2, gv, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+    b.tds_apply(w2, gw, x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+    if omega != 0.0 or shift:
+        assert b.transeq_x_rot(*d2, u2, v2, w2, s.nu, x, omega, sh)  # (the scalar is still in place: no reduction since)
+    else:
+        b.transeq_dir(DIR_X, *d2, u2, v2, w2, s.nu, x)
+    for a, c, nm in ((u, u2, "u"), (v, v2, "v"), (w, w2, "w")):
+        x_, y_ = b.get_field_data(a, VERT), b.get_field_data(c, VERT)
+        assert np.array_equal(x_, y_), (nm, float(np.max(np.abs(x_ - y_))))
+    # du, dv, dw: the same expressions in another kernel body -- which product of a sum of two the compiler fuses is its
+    # choice per kernel (-ffp-contract=fast): a last bit may differ (observed: 1 ulp of the largest value, 2.3e-16)
+    for a, c, nm in zip(d1, d2, ("du", "dv", "dw")):
+        x_, y_ = b.get_field_data(a, VERT), b.get_field_data(c, VERT)
+        assert np.max(np.abs(x_ - y_)) <= 1e-15 * np.max(np.abs(y_)), (nm, float(np.max(np.abs(x_ - y_))), float(np.max(np.abs(y_))))
+    for f in blk:
+        al.release_block(f)
+
+
+def test_channel_steps_with_the_velocity_correction_deferred_to_transeq_x(monkeypatch):
+    """ChannelCase.correction_deferrable (round 6): the fused channel step whose pressure-gradient correction waits for
+    the next sub-step's transeq_x kernel -- the bulk-velocity shift then comes from the mean of the UNCORRECTED u (the
+    correction is a periodic x derivative: every x pencil of it sums to zero up to rounding) -- against the same steps
+    with the correction applied by the pressure step (X3D_NO_CHANNEL_DEFER_GRAD=1): round-off apart; and both against
+    the oracle (_channel_steps)."""
+    from x3d2_amd import _lib
+    dims = (1024, 33, 8)
+    case = _channel_steps(dims, "top-bottom", 0.259065151, True, 2, div_bound=None)
+    assert int(_lib.load().x3d_backend_counter(case.solver.backend.h, 1)) == 4  # sub-steps 2, 3 of both steps
+    assert case.solver.n_rot_fused == 3 and case.solver.pending_grad is None
+    # ... and the volume integral define_BC asks for was taken by the kernel that formed the new u (k_xwide_tds_lin),
+    # x3d_tds_solve_lincomb_wall_mean: another summation order than x3d_field_mean_shift's, round-off apart
+    assert case.solver.n_mean_taken == 4
+    monkeypatch.setenv("X3D_NO_MEAN_IN_LINCOMB", "1")
+    nomean = _channel_steps(dims, "top-bottom", 0.259065151, True, 2, div_bound=None)
+    assert nomean.solver.n_mean_taken == 0
+    for a, c in zip((case.solver.u, case.solver.v, case.solver.w), (nomean.solver.u, nomean.solver.v, nomean.solver.w)):
+        x, y = case.solver.backend.get_field_data(a), nomean.solver.backend.get_field_data(c)
+        assert np.max(np.abs(x - y)) < 1e-13 * max(np.max(np.abs(y)), 1.0)
+    monkeypatch.setenv("X3D_NO_CHANNEL_DEFER_GRAD", "1")
+    plain = _channel_steps(dims, "top-bottom", 0.259065151, True, 2, div_bound=None)
+    assert int(_lib.load().x3d_backend_counter(plain.solver.backend.h, 1)) == 0
+    for a, c in zip((case.solver.u, case.solver.v, case.solver.w), (plain.solver.u, plain.solver.v, plain.solver.w)):
+        x, y = case.solver.backend.get_field_data(a), plain.solver.backend.get_field_data(c)
+        assert np.max(np.abs(x - y)) < 1e-13 * max(np.max(np.abs(y)), 1.0)
+
+
+@pytest.mark.parametrize("nx,loc", [(1024, "VERT"), (1024, "CELL"), (256, "VERT")])
+def test_volume_integral_taken_by_the_kernel_that_forms_the_field(nx, loc):
+    """x3d_tds_solve_lincomb_wall_mean == x3d_tds_solve_lincomb_wall ; x3d_field_mean_shift: y and du bit for bit, the shift
+    scalar to round-off (the 1024-row kernel sums per wave, x3d_field_mean_shift per row); 256-row pencils take the
+    two calls one after the other: the same bits"""
+    import torch
+    from x3d2_amd import _lib
+    from x3d2_amd.common import CELL, DIR_X, VERT
+    s = product_solver((nx, 9, 8))
+    b, al, x = s.backend, s.backend.allocator, s.xdirps
+    dl = VERT if loc == "VERT" else CELL
+    rng = np.random.default_rng(nx)
+    blk = [al.get_block(DIR_X, dl) for _ in range(8)]
+    base, d1, d2, wall, y1, y2, o1, o2 = blk
+    for f in (base, d1, d2, wall):
+        f.data.copy_(torch.from_numpy(rng.standard_normal(tuple(f.data.shape))).to(f.data.device))
+    for f in (y1, y2, o1, o2):
+        f.fill(0.0)
+
+    def scalar(ptr):
+        t = torch.empty(1, dtype=torch.float64, device=b.device)
+        _lib.check(b.lib.x3d_copy_device(b.h, t.data_ptr(), ptr, 1))
+        b.sync()
+        return float(t.cpu()[0])
+
+    sh1 = b.tds_lincomb(o1, x.stagder_v2p, DIR_X, y1, base, [0.3, -0.7], [d1, d2], wall=wall, mean_target=2.0 / 3.0)
+    v1 = scalar(sh1)
+    b.tds_lincomb(o2, x.stagder_v2p, DIR_X, y2, base, [0.3, -0.7], [d1, d2], wall=wall)
+    v2 = scalar(b.field_mean_shift(y2, 2.0 / 3.0))
+    assert np.array_equal(b.get_field_data(y1, dl), b.get_field_data(y2, dl))
+    assert np.array_equal(b.get_field_data(o1, dl), b.get_field_data(o2, dl))
+    assert abs(v1 - v2) < 1e-14 * max(abs(v2), 1.0) and (nx == 1024 or v1 == v2)
+    for f in blk:
+        al.release_block(f)
+
+
 @pytest.mark.parametrize("nx", [1024, 256, 48])
 def test_rk_stage_wall_values_and_first_x_operator_in_one_kernel(nx):
     """x3d_tds_solve_lincomb_wall (K3w at 1024-point pencils, K3s at 256, the three calls one after the other

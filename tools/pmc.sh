@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools_pmc.sh <tag>  -- separate PMC passes as the microarch guide prescribes
+# usage (GPU box): tools/pmc.sh <tag>  -- separate PMC passes as the microarch guide prescribes
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do

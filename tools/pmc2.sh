@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ-level counters for selected kernels: tools_pmc2.sh <tag> <kernel-substring>
+# SQ-level counters for selected kernels: tools/pmc2.sh <tag> <kernel-substring>
 tag=$1; pat=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d gpurun_out/sq_$tag -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/sq_$tag.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools_prof.sh <tag>  -> gpurun_out/prof_<tag>/ + kernel stats on stdout
+# usage (on the GPU box): tools/prof.sh <tag>  -> gpurun_out/prof_<tag>/ + kernel stats on stdout
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag  # a repeated tag must not pick up the previous run's stats

@@ -5,7 +5,7 @@ gfx950 correction (FETCH_SIZE counts 64 B per 128-B request -> x2; calibrated
 here on k_tds_fwd, which reads exactly one 1 GiB field), and traffic.json that
 bench.py reads for roofline.traffic.
 
-    python tools_summarize.py <prof_tag> <pmc_tag> <round>
+    python tools/summarize.py <prof_tag> <pmc_tag> <round>
 """
 import csv
 import glob

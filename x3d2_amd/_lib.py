@@ -33,6 +33,7 @@ def torch_real():
 PROTOTYPES = {
     "x3d_last_error": (ctypes.c_char_p, []),
     "x3d_abi_version": (I, []),
+    "x3d_real_bytes": (I, []),
     "x3d_backend_create": (I, [ctypes.POINTER(VP), c_int_p, I, VP]),
     "x3d_backend_destroy": (I, [VP]),
     "x3d_backend_create_like": (I, [ctypes.POINTER(VP), VP, c_int_p]),
@@ -93,6 +94,8 @@ PROTOTYPES = {
     "x3d_tds_pair_halo_fix_yperm": (I, [VP, I, VP, VP, VP, VP, VP, I]),
     "x3d_tds_solve_lincomb": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
     "x3d_tds_solve_lincomb_wall": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), VP]),
+    "x3d_tds_solve_lincomb_wall_mean": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), VP, c_int_p, D, D,
+                                            ctypes.POINTER(VP)]),
     "x3d_tds_dist_bwd": (I, [VP, VP, VP, VP, VP, VP, I]),
     "x3d_tds_dist_bwd_acc": (I, [VP, VP, VP, VP, VP, VP, I, I, D]),
     "x3d_transeq": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP]),
@@ -113,6 +116,7 @@ PROTOTYPES = {
     "x3d_lincomb": (I, [VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
     "x3d_transeq_x_rot": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, D, VP, c_int_p]),
     "x3d_transeq_x_update": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, VP, VP, VP, VP, VP, D, c_int_p]),
+    "x3d_transeq_x_update_rot": (I, [VP, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, VP, VP, VP, VP, VP, D, D, VP, c_int_p]),
     "x3d_transeq_defer": (I, [VP, I, VP, VP, VP, VP, VP, VP, D, VP, VP, VP, VP, c_int_p]),
     "x3d_pending_flush": (I, [VP, I, VP, VP]),
     "x3d_transeq_stage_ok": (I, [VP, I, VP, VP, VP, VP]),
@@ -260,6 +264,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError = symbol missing from the .so
         fn.restype = res
         fn.argtypes = args
+    want = 4 if SINGLE else 8
+    if lib.x3d_real_bytes() != want:  # (a stale or misnamed build: every pointer below would be misread)
+        raise X3dError(f"{LIB_PATH} computes in {lib.x3d_real_bytes()}-byte reals, this process expects {want}")
     _lib = lib
     return lib
 

@@ -69,6 +69,7 @@ class HipBackend:
         self.comm_reserve = int(os.environ.get("X3D_COMM_RESERVE_CUS", "0"))
         _lib.check(self.lib.x3d_backend_set_comm_reserve(h, self.comm_reserve))
         self.lazy = (os.environ.get("X3D_LAZY") == "1") if lazy is None else bool(lazy)
+        self.red_epoch = 0  # bumped by every call that uses the library's reduction buffer (Solver.take_mean_shift)
         if self.lazy:
             # several ranks (round 4): the distributed entry points flush the queue and run at once on the buffers that
             # hold their handles' data; the local directions keep their rewrites.  (One process standing in for several
@@ -560,6 +561,19 @@ class HipBackend:
                                                  op_u.handle, op_vw.handle, float(scale), ctypes.byref(flag)))
         return bool(flag.value)
 
+    def transeq_x_update_rot(self, du, dv, dw, u, v, w, nu, dirps, grads, op_u, op_vw, scale, omega, u_shift=None):
+        """transeq_x_update and transeq_x_rot in one launch (csrc/xwide.hip, k_xwide_transeq3_upd): pending correction,
+        bulk-velocity shift, transeq_x, rotation forcing; False: not served, nothing was done"""
+        if self._decomposed(DIR_X):
+            return False
+        flag = ctypes.c_int(0)
+        _lib.check(self.lib.x3d_transeq_x_update_rot(self.h, du.ptr, dv.ptr, dw.ptr, u.ptr, v.ptr, w.ptr, float(nu),
+                                                     dirps.der1st.handle, dirps.der1st_sym.handle, dirps.der2nd.handle,
+                                                     dirps.der2nd_sym.handle, grads[0].ptr, grads[1].ptr, grads[2].ptr,
+                                                     op_u.handle, op_vw.handle, float(scale), float(omega), u_shift,
+                                                     ctypes.byref(flag)))
+        return bool(flag.value)
+
     def transeq_x_rot(self, du, dv, dw, u, v, w, nu, dirps, omega, u_shift=None):
         """transeq_x with the channel's rotation forcing (du -= omega v, dv += omega u, src/case/channel.f90:191-207)
         applied inside the kernel (csrc/xwide.hip, k_xwide_transeq3<ROT>) and, with u_shift (field_mean_shift), the
@@ -654,19 +668,30 @@ class HipBackend:
         self.rk_fused_passes = getattr(self, "rk_fused_passes", 0) + n + 1
         self.rk_fused_launches = getattr(self, "rk_fused_launches", 0) + 1
 
-    def tds_lincomb(self, du, tdsops, direction, y, base, coeffs, xs, wall=None):
+    def tds_lincomb(self, du, tdsops, direction, y, base, coeffs, xs, wall=None, mean_target=None):
         """y = base + sum c_i x_i (lincomb) and du = tds_solve(y) in one kernel where the pencils allow
         (csrc/xscan.hip k_xscan_tds_lin, csrc/xwide.hip k_xwide_tds_lin: y is not read back).  wall: the y faces of y
-        take that field's values before the operator acts (field_set_face_from_field(y, wall, 0, Y_FACE))"""
+        take that field's values before the operator acts (field_set_face_from_field(y, wall, 0, Y_FACE)).
+        mean_target (one rank): also field_mean_shift(y, mean_target) -- its device scalar is returned -- with the
+        integral taken inside the kernel where it can be (x3d_tds_solve_lincomb_wall_mean)"""
         if self._decomposed(direction):
             self.lincomb(y, base, coeffs, xs)
             if wall is not None:
                 self.field_set_face_from_field(y, wall, 0.0, Y_FACE)
             self.tds_apply(du, y, tdsops, direction)
-            return
+            return self.field_mean_shift(y, mean_target) if mean_target is not None else None
         n = len(xs)
         c = (_lib.REAL * n)(*[float(v) for v in coeffs])
         p = (VP * n)(*[x.ptr for x in xs])
+        if mean_target is not None and self.comm.size == 1:
+            if y.data_loc == NULL_LOC:
+                raise X3dError("You must set the data_loc before calling volume integral.")
+            out = VP()
+            ncell = float(np.prod(self.mesh.get_global_dims(CELL)))
+            _lib.check(self.lib.x3d_tds_solve_lincomb_wall_mean(
+                self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p, wall.ptr if wall is not None else None,
+                self._dims(y.data_loc), ncell, float(mean_target), ctypes.byref(out)))
+            return out
         if wall is None:
             _lib.check(self.lib.x3d_tds_solve_lincomb(self.h, direction, du.ptr, tdsops.handle, y.ptr, base.ptr, n, c, p))
         else:
@@ -857,6 +882,7 @@ class HipBackend:
         if x.data_loc != y.data_loc:
             raise X3dError("Called scalar product with incompatible fields")
         out = _lib.REAL()
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_scalar_product(self.h, x.ptr, y.ptr, self._dims(x.data_loc), ctypes.byref(out)))
         return self.comm.allreduce(out.value, "sum")
 
@@ -868,6 +894,7 @@ class HipBackend:
         if f.dir == DIR_C:
             raise X3dError("field_max_mean does not support DIR_C fields!")
         mx, sm = _lib.REAL(), _lib.REAL()
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_field_max_sum(self.h, f.ptr, self._dims(loc), ctypes.byref(mx), ctypes.byref(sm)))
         nglob = float(np.prod(self.mesh.get_global_dims(loc)))
         return self.comm.allreduce(mx.value, "max"), self.comm.allreduce(sm.value / nglob, "sum")
@@ -878,6 +905,7 @@ class HipBackend:
             raise X3dError("The input field to slice_max_sum does not have a valid f%data_loc.")
         loc = f.data_loc if enforced_data_loc is None else enforced_data_loc
         mx, sm = _lib.REAL(), _lib.REAL()
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_slice_max_sum(self.h, f.ptr, self._dims(loc), f.dir, int(i_slice),
                                               ctypes.byref(mx), ctypes.byref(sm)))
         return mx.value, sm.value
@@ -893,6 +921,7 @@ class HipBackend:
         if self.comm.size > 1:
             self.field_shift(f, target - self.field_volume_integral(f) / ncell)
             return
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_field_shift_to_mean(self.h, f.ptr, self._dims(f.data_loc), ncell, float(target)))
 
     def field_mean_shift(self, f, target):
@@ -906,6 +935,7 @@ class HipBackend:
             return None
         ncell = float(np.prod(self.mesh.get_global_dims(CELL)))
         out = VP()
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_field_mean_shift(self.h, f.ptr, self._dims(f.data_loc), ncell, float(target),
                                                  ctypes.byref(out)))
         return out
@@ -925,6 +955,7 @@ class HipBackend:
         if f.dir != DIR_X:
             raise X3dError("Volume integral can only be called on DIR_X fields.")
         out = _lib.REAL()
+        self.red_epoch += 1
         _lib.check(self.lib.x3d_field_volume_integral(self.h, f.ptr, self._dims(f.data_loc), ctypes.byref(out)))
         return self.comm.allreduce(out.value, "sum")
 

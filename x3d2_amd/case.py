@@ -73,6 +73,17 @@ class BaseCase:
         accumulation of transeq pending (the fused driver may then fold it and the RK stage together)"""
         return type(self).forcings is BaseCase.forcings
 
+    def correction_deferrable(self):
+        """True: between a sub-step's pressure correction and the next sub-step's transeq_x no hook of this case reads
+        the velocity in a way that needs the correction applied -- it may then wait for that kernel
+        (Solver.transeq_fused).  The base hooks read nothing; a case that overrides define_BC / apply_BC says so itself."""
+        return type(self).define_BC is BaseCase.define_BC and type(self).apply_BC is BaseCase.apply_BC
+
+    def mean_target_of_next_BC(self):
+        """the target of the field_mean_shift(u, target) this case's define_BC will ask for at the start of the next
+        sub-step, or None"""
+        return None
+
     def postprocess(self, it, t):
         return self.monitoring.write_step(t, self.solver.u, self.solver.v, self.solver.w)
 
@@ -113,9 +124,11 @@ class BaseCase:
             self.apply_BC(s.u, s.v, s.w)
         # not the last sub-step of the step and no hook looks at the velocity before the next transeq: its
         # pressure-gradient correction can wait for that kernel (Solver.transeq_fused)
-        defer_grad = (not last and s.fused and type(self).define_BC is BaseCase.define_BC
-                      and type(self).apply_BC is BaseCase.apply_BC)
+        defer_grad = not last and s.fused and self.correction_deferrable()
         if defer_grad:
+            # (a case whose next define_BC wants the volume integral of u says so: the kernel that forms the new u takes it
+            #  along, Solver.pressure_correction_fused / take_mean_shift)
+            s.mean_request = self.mean_target_of_next_BC()
             s.pressure_correction(s.u, s.v, s.w, defer_grad=True)
         else:
             s.pressure_correction(s.u, s.v, s.w)
@@ -215,7 +228,10 @@ class ChannelCase(BaseCase):
     def define_BC(self):  # :53-137
         s, b = self.solver, self.solver.backend
         # ub -> 2/3, no host round trip on one rank; fused driver: the shift itself is left to transeq_x's kernel
-        sh = b.field_mean_shift(s.u, 2.0 / 3.0) if s.fused and os.environ.get("X3D_NO_ROT_FUSED") != "1" else None
+        sh = None
+        if s.fused and os.environ.get("X3D_NO_ROT_FUSED") != "1":
+            # (round 6: the integral may have been taken by the kernel that formed this u, mean_target_of_next_BC)
+            sh = s.take_mean_shift(s.u, 2.0 / 3.0) or b.field_mean_shift(s.u, 2.0 / 3.0)
         if sh is not None:
             s.shift_request = sh
         else:
@@ -254,10 +270,27 @@ class ChannelCase(BaseCase):
     def deferred_walls(self):
         return self.bc_start_y
 
+    def mean_target_of_next_BC(self):
+        return 2.0 / 3.0 if os.environ.get("X3D_NO_MEAN_IN_LINCOMB") != "1" else None
+
+    def correction_deferrable(self):
+        # define_BC reads the volume integral of u only, and the pending correction does not change it: dp/dx is a
+        # periodic compact x derivative (stagder_p2v: A d = B p with circulant A, B and zero row sums of B), so every x
+        # pencil of it sums to zero up to rounding; apply_BC's walls are stamped BEFORE the correction (as in the
+        # reference: apply_BC ; pressure_correction) by the kernels that form the new velocity (deferred_walls).
+        # One rank only: field_mean_shift hands the shift over as a device scalar (X3D_NO_ROT_FUSED=1: host path).
+        # Offered where the x kernel takes the correction along: 1024-row x pencils (csrc/xwide.hip, k_xwide_transeq3_upd).
+        s = self.solver
+        return (s.fused and s.backend.comm.size == 1 and int(s.mesh.get_dims(VERT)[0]) == 1024
+                and os.environ.get("X3D_NO_ROT_FUSED") != "1"
+                and os.environ.get("X3D_NO_DEFER_WALLS") != "1" and os.environ.get("X3D_NO_CHANNEL_DEFER_GRAD") != "1"
+                and type(self).define_BC is ChannelCase.define_BC and type(self).apply_BC is ChannelCase.apply_BC)
+
     def forcings_idle(self, it):
         # no rotation in this iteration, or transeq_x's kernel applies it (rot_request, substep above) -- and where that
         # kernel does not, Solver.transeq_fused leaves nothing pending and forcings() below acts as in the reference
-        return True
+        # (a subclass with its own forcings() must see complete derivatives: ADVICE round 5)
+        return type(self).forcings is ChannelCase.forcings
 
     def apply_BC(self, u, v, w):  # :214-231
         b = self.solver.backend

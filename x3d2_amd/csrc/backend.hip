@@ -31,6 +31,7 @@ void x3d_set_error(const char *fmt, ...)
 
 extern "C" const char *x3d_last_error(void) { return g_err; }
 extern "C" int x3d_abi_version(void) { return 1; }
+extern "C" int x3d_real_bytes(void) { return (int)sizeof(real_t); }
 
 PencilGeom x3d_geom(const x3d_backend *b, int dir)
 {
@@ -49,6 +50,7 @@ PencilGeom x3d_geom(const x3d_backend *b, int dir)
 
 extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int device, void *stream)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(out && dims_vert, "x3d_backend_create: null argument");
     X3D_REQUIRE(dims_vert[0] > 0 && dims_vert[1] > 0 && dims_vert[2] > 0,
                 "x3d_backend_create: dims must be positive");
@@ -99,12 +101,14 @@ extern "C" int x3d_backend_create(x3d_backend **out, const int dims_vert[3], int
 
 extern "C" int x3d_backend_create_like(x3d_backend **out, const x3d_backend *like, const int dims_vert[3])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(like, "x3d_backend_create_like: null argument");
     return x3d_backend_create(out, dims_vert, like->device, (void *)like->stream);
 }
 
 extern "C" int x3d_backend_destroy(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     if (!b) return 0;
     if (b->ipc_maps) {  // peers' buffers still mapped: unmap them before this rank's own memory goes
         auto *v = static_cast<std::vector<void *> *>(b->ipc_maps);
@@ -135,12 +139,14 @@ int x3d_lds_optin(x3d_backend *b, const void *kernel)
 // also applied a pending velocity correction
 extern "C" long x3d_backend_counter(const x3d_backend *b, int which)
 {
+    X3D_RANGE(__func__);
     if (!b) return -1;
     return which == 0 ? b->n_tq3 : (which == 1 ? b->n_upd : (which == 2 ? b->n_halo : -1));
 }
 
 extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     b->stream = (hipStream_t)stream;
     return 0;
@@ -150,6 +156,7 @@ extern "C" int x3d_backend_set_stream(x3d_backend *b, void *stream)
 // is to run beside them; common.h, comm_reserve): 0 = none (one rank), a multi-rank driver sets 8 (one per XCD)
 extern "C" int x3d_backend_set_comm_reserve(x3d_backend *b, int ncus)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     X3D_REQUIRE(ncus >= 0 && ncus < X3D_NCU / 2, "x3d_backend_set_comm_reserve: 0 .. %d CUs", X3D_NCU / 2 - 1);
     b->comm_reserve = ncus;
@@ -160,6 +167,7 @@ extern "C" size_t x3d_block_elems(const x3d_backend *b) { return b ? b->nblock :
 
 extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && d, "null argument");
     d[0] = b->nxp; d[1] = b->nyp; d[2] = b->nzp;
     return 0;
@@ -167,6 +175,7 @@ extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])
 
 extern "C" int x3d_device_sync(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_FLUSH(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b, "null backend");
@@ -185,6 +194,7 @@ static std::mutex g_block_mutex;
 
 extern "C" int x3d_block_alloc(x3d_backend *b, real_t **out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out, "null argument");
     const size_t st = 528;
     void *base = nullptr;
@@ -199,6 +209,7 @@ extern "C" int x3d_block_alloc(x3d_backend *b, real_t **out)
 
 extern "C" int x3d_block_free(x3d_backend *b, real_t *p)
 {
+    X3D_RANGE(__func__);
     if (b) { X3D_LAZY_SYNC(b); x3d_lazy_unregister(b, p); }
     (void)b;
     void *base = nullptr;
@@ -217,6 +228,7 @@ extern "C" int x3d_block_free(x3d_backend *b, real_t *p)
 // sendrecv_fields, src/backend/cuda/sendrecv.f90:13-42, through host memory)
 extern "C" int x3d_device_alloc(x3d_backend *b, real_t **out, long n)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && n > 0, "x3d_device_alloc: bad argument");
     X3D_HIP(hipMalloc(reinterpret_cast<void **>(out), sizeof(real_t) * (size_t)n));
     X3D_HIP(hipMemsetAsync(*out, 0, sizeof(real_t) * (size_t)n, b->stream));
@@ -224,6 +236,7 @@ extern "C" int x3d_device_alloc(x3d_backend *b, real_t **out, long n)
 }
 extern "C" int x3d_device_free(x3d_backend *b, real_t *p)
 {
+    X3D_RANGE(__func__);
     (void)b;
     X3D_HIP(hipFree(p));
     return 0;
@@ -235,12 +248,14 @@ extern "C" int x3d_device_free(x3d_backend *b, real_t *p)
 // HBM when ranks share a GPU; only the 64-byte handles and empty "ready" messages go through MPI.
 extern "C" int x3d_device_count(int *n)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(n, "x3d_device_count: null argument");
     X3D_HIP(hipGetDeviceCount(n));
     return 0;
 }
 extern "C" int x3d_ipc_export(x3d_backend *b, const real_t *dev, unsigned char handle[64])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dev && handle, "x3d_ipc_export: null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     hipIpcMemHandle_t h;
@@ -250,6 +265,7 @@ extern "C" int x3d_ipc_export(x3d_backend *b, const real_t *dev, unsigned char h
 }
 extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], real_t **dev)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dev && handle, "x3d_ipc_open: null argument");
     hipIpcMemHandle_t h;
     memcpy(&h, handle, 64);
@@ -262,6 +278,7 @@ extern "C" int x3d_ipc_open(x3d_backend *b, const unsigned char handle[64], real
 }
 extern "C" int x3d_ipc_close(x3d_backend *b, real_t *dev)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dev, "x3d_ipc_close: null argument");
     X3D_HIP(hipIpcCloseMemHandle(dev));
     if (b->ipc_maps) {
@@ -273,6 +290,7 @@ extern "C" int x3d_ipc_close(x3d_backend *b, real_t *dev)
 // n doubles device to device (own or mapped memory), ordered on the backend's stream like a kernel; returns at once
 extern "C" int x3d_copy_device(x3d_backend *b, real_t *dst, const real_t *src, long n)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dst && src && n >= 0, "x3d_copy_device: bad argument");
     if (n == 0) return 0;
     X3D_HIP(hipMemcpyAsync(dst, src, sizeof(real_t) * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
@@ -282,6 +300,7 @@ extern "C" int x3d_copy_device(x3d_backend *b, real_t *dst, const real_t *src, l
 // ordered behind the kernels queued on the backend's stream; returns when the copy is complete
 extern "C" int x3d_copy_to_host(x3d_backend *b, real_t *host, const real_t *dev, long n)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_host: bad argument");
     X3D_HIP(hipMemcpyAsync(host, dev, sizeof(real_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));
@@ -289,6 +308,7 @@ extern "C" int x3d_copy_to_host(x3d_backend *b, real_t *host, const real_t *dev,
 }
 extern "C" int x3d_copy_to_device(x3d_backend *b, real_t *dev, const real_t *host, long n)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && host && dev && n >= 0, "x3d_copy_to_device: bad argument");
     X3D_HIP(hipMemcpyAsync(dev, host, sizeof(real_t) * (size_t)n, hipMemcpyHostToDevice, b->stream));
     X3D_HIP(hipStreamSynchronize(b->stream));  // (the host array may be reused at once)
@@ -324,6 +344,7 @@ static int transpose_launch(x3d_backend *bs, real_t *dst, const real_t *src, int
 }
 extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny, int nz)
 {
+    X3D_RANGE(__func__);
     if (bs) X3D_LAZY_SYNC(bs);
     if (bd) X3D_LAZY_SYNC(bd);
     X3D_LAZY_EAGER(bs);
@@ -341,6 +362,7 @@ extern "C" int x3d_transpose_xy(x3d_backend *bs, x3d_backend *bd, real_t *dst, c
 extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny,
                                      int nz)
 {
+    X3D_RANGE(__func__);
     if (bs) X3D_LAZY_SYNC(bs);
     if (bd) X3D_LAZY_SYNC(bd);
     X3D_LAZY_EAGER(bs);
@@ -357,6 +379,7 @@ extern "C" int x3d_transpose_xyz_zxy(x3d_backend *bs, x3d_backend *bd, real_t *d
 extern "C" int x3d_transpose_zxy_xyz(x3d_backend *bs, x3d_backend *bd, real_t *dst, const real_t *src, int nx, int ny,
                                      int nz)
 {
+    X3D_RANGE(__func__);
     if (bs) X3D_LAZY_SYNC(bs);
     if (bd) X3D_LAZY_SYNC(bd);
     X3D_LAZY_EAGER(bs);
@@ -416,6 +439,7 @@ struct OpFill { real_t a; __device__ real_t operator()(real_t) const { return a;
 
 extern "C" int x3d_veccopy(x3d_backend *b, real_t *dst, const real_t *src)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dst && src, "x3d_veccopy: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_copy(b, dst, src);  // (recorded only after the eager path's checks)
     ProfScope ps(b, X3D_K_COPY);
@@ -425,6 +449,7 @@ extern "C" int x3d_veccopy(x3d_backend *b, real_t *dst, const real_t *src)
 
 extern "C" int x3d_vecadd(x3d_backend *b, real_t a, const real_t *x, real_t bb, real_t *y)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && x && y, "x3d_vecadd: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_vecadd(b, a, x, bb, y);
     ProfScope ps(b, X3D_K_BLAS1);
@@ -437,6 +462,7 @@ extern "C" int x3d_vecadd(x3d_backend *b, real_t a, const real_t *x, real_t bb, 
 
 extern "C" int x3d_vecmult(x3d_backend *b, real_t *y, const real_t *x)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && x && y, "x3d_vecmult: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 0, y, x, 0.0);
     ProfScope ps(b, X3D_K_BLAS1);
@@ -489,6 +515,7 @@ static int from_gradients(x3d_backend *b, real_t *out, const real_t *const g[9],
 
 extern "C" int x3d_compute_vorticity(x3d_backend *b, real_t *out, const real_t *const grads[9])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, false);
@@ -496,6 +523,7 @@ extern "C" int x3d_compute_vorticity(x3d_backend *b, real_t *out, const real_t *
 
 extern "C" int x3d_compute_qcriterion(x3d_backend *b, real_t *out, const real_t *const grads[9])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     return from_gradients(b, out, grads, true);
@@ -503,6 +531,7 @@ extern "C" int x3d_compute_qcriterion(x3d_backend *b, real_t *out, const real_t 
 
 extern "C" int x3d_field_scale(x3d_backend *b, real_t *f, real_t a)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_field_scale: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 1, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
@@ -515,6 +544,7 @@ extern "C" int x3d_field_scale(x3d_backend *b, real_t *f, real_t a)
 
 extern "C" int x3d_field_shift(x3d_backend *b, real_t *f, real_t a)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_field_shift: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 2, f, nullptr, a);
     ProfScope ps(b, X3D_K_BLAS1);
@@ -527,6 +557,7 @@ extern "C" int x3d_field_shift(x3d_backend *b, real_t *f, real_t a)
 
 extern "C" int x3d_block_fill(x3d_backend *b, real_t *f, real_t c)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_block_fill: null argument");
     if (x3d_lazy_active(b)) return x3d_lazy_unary(b, 3, f, nullptr, c);
     ProfScope ps(b, X3D_K_BLAS1);
@@ -541,6 +572,7 @@ extern "C" int x3d_block_fill(x3d_backend *b, real_t *f, real_t c)
 // (reference: src/backend/omp/backend.f90:393-452; codes src/common.f90:23-26)
 extern "C" int x3d_reorder(x3d_backend *b, real_t *u_, const real_t *u, int rdr)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && u_ && u, "x3d_reorder: null argument");
     int from = rdr / 10, to = rdr % 10;
     X3D_REQUIRE(from >= 1 && from <= 4 && to >= 1 && to <= 4 && from != to,
@@ -555,6 +587,7 @@ extern "C" int x3d_reorder(x3d_backend *b, real_t *u_, const real_t *u, int rdr)
 // sum_yintox / sum_zintox: u += u_ (src/backend/omp/backend.f90:454-527)
 extern "C" int x3d_sum_intox(x3d_backend *b, real_t *u, const real_t *u_, int dir_from)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && u && u_, "x3d_sum_intox: null argument");
     X3D_REQUIRE(dir_from == X3D_DIR_Y || dir_from == X3D_DIR_Z, "x3d_sum_intox: dir must be Y or Z");
     if (x3d_lazy_active(b)) return x3d_lazy_sum(b, u, u_, dir_from);
@@ -599,6 +632,7 @@ __global__ void __launch_bounds__(256) k_lincomb(real2_t *__restrict__ y, const 
 extern "C" int x3d_lincomb(x3d_backend *b, real_t *y, const real_t *base, int nterm, const real_t *c,
                            const real_t *const *x)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && y && base && c && x, "x3d_lincomb: null argument");
@@ -683,6 +717,7 @@ static int run_reduce(x3d_backend *b, const real_t *x, const real_t *y, const in
 extern "C" int x3d_scalar_product(x3d_backend *b, const real_t *x, const real_t *y, const int dims[3],
                                   real_t *out)
 {
+    X3D_RANGE(__func__);
     if (b) { X3D_LAZY_IN(b, x); X3D_LAZY_IN(b, y); }
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && x && y && dims && out, "x3d_scalar_product: null argument");
@@ -692,6 +727,7 @@ extern "C" int x3d_scalar_product(x3d_backend *b, const real_t *x, const real_t 
 extern "C" int x3d_field_max_sum(x3d_backend *b, const real_t *f, const int dims[3], real_t *max_abs,
                                  real_t *sum_abs)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && max_abs && sum_abs, "x3d_field_max_sum: null argument");
@@ -700,6 +736,7 @@ extern "C" int x3d_field_max_sum(x3d_backend *b, const real_t *f, const int dims
 
 extern "C" int x3d_field_volume_integral(x3d_backend *b, const real_t *f, const int dims[3], real_t *out)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && out, "x3d_field_volume_integral: null argument");
@@ -761,9 +798,22 @@ static int mean_shift_impl(x3d_backend *b, const real_t *f, const int dims[3], r
     return 0;
 }
 
+// the second stage alone: `nparts` partial sums already sit in b->red_buf (k_xwide_tds_lin)
+int x3d_finish_mean_shift(x3d_backend *b, int nparts, real_t ncell, real_t target, const real_t **shift)
+{
+    X3D_REQUIRE(b && shift && nparts > 0 && nparts <= 2048 && nparts <= b->red_cap, "x3d_finish_mean_shift: %d partials", nparts);
+    ProfScope ps(b, X3D_K_REDUCE);
+    hipLaunchKernelGGL(k_finish_shift, dim3(1), dim3(256), 0, b->stream, (const real_t *)b->red_buf, nparts, ncell, target,
+                       b->red_buf + 2 * b->red_cap - 2);
+    X3D_HIP(hipGetLastError());
+    *shift = b->red_buf + 2 * b->red_cap - 2;
+    return 0;
+}
+
 extern "C" int x3d_field_mean_shift(x3d_backend *b, const real_t *f, const int dims[3], real_t ncell, real_t target,
                                     const real_t **shift)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_field_mean_shift: bad argument");
     X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
@@ -782,6 +832,7 @@ static int shift_by_impl(x3d_backend *b, real_t *f, const real_t *shift)
 
 extern "C" int x3d_field_shift_by(x3d_backend *b, real_t *f, const real_t *shift)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_field_shift_by: null argument");
     X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
@@ -790,6 +841,7 @@ extern "C" int x3d_field_shift_by(x3d_backend *b, real_t *f, const real_t *shift
 
 extern "C" int x3d_field_shift_to_mean(x3d_backend *b, real_t *f, const int dims[3], real_t ncell, real_t target)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_field_shift_to_mean: bad argument");
     X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
@@ -824,6 +876,7 @@ __global__ void __launch_bounds__(256) k_wall_noise(real_t *__restrict__ f, int 
 extern "C" int x3d_wall_noise(x3d_backend *b, real_t *f, const int dims[3], real_t amp, unsigned long long seed,
                               unsigned long long draw)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f && dims, "x3d_wall_noise: null argument");
     X3D_LAZY_OUT(b, f, false);  // (two planes are written: the rest of the block keeps its contents)
     X3D_LAZY_EAGER(b);
@@ -866,6 +919,7 @@ __global__ void __launch_bounds__(256) k_slice(const real_t *__restrict__ f, int
 extern "C" int x3d_slice_max_sum(x3d_backend *b, const real_t *f, const int dims[3], int dir, int i_slice,
                                  real_t *max_val, real_t *sum_val)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims && max_val && sum_val, "x3d_slice_max_sum: null argument");
@@ -925,6 +979,7 @@ __global__ void k_set_face_x_from(real_t *__restrict__ f, const real_t *__restri
 extern "C" int x3d_field_set_face(x3d_backend *b, real_t *f, const int dims[3], real_t c_start, real_t c_end,
                                   int face)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && dims, "x3d_field_set_face: null argument");
@@ -941,6 +996,7 @@ extern "C" int x3d_field_set_face(x3d_backend *b, real_t *f, const int dims[3], 
 extern "C" int x3d_field_set_face_from_field(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3],
                                              real_t c_end, int face, real_t flow_rate_diff)
 {
+    X3D_RANGE(__func__);
     if (b && x3d_lazy_active(b) && face == X3D_Y_FACE) {  // recorded (the RK stage before it and the x operator behind it fuse)
         X3D_REQUIRE(f && f_start && dims, "x3d_field_set_face_from_field: null argument");
         X3D_REQUIRE(dims[0] > 0 && dims[0] <= b->nxp && dims[1] > 0 && dims[1] <= b->nyp && dims[2] > 0 && dims[2] <= b->nzp,
@@ -968,6 +1024,7 @@ extern "C" int x3d_field_set_face_from_field(x3d_backend *b, real_t *f, const re
 // ---------------------------------------------------------------- host <-> field
 extern "C" int x3d_set_field_data(x3d_backend *b, real_t *f, const real_t *host, const int dims[3])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dims, "x3d_set_field_data: null argument");
@@ -976,6 +1033,7 @@ extern "C" int x3d_set_field_data(x3d_backend *b, real_t *f, const real_t *host,
 
 extern "C" int x3d_get_field_data(x3d_backend *b, real_t *host, const real_t *f, const int dims[3])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(dims, "x3d_get_field_data: null argument");
@@ -985,6 +1043,7 @@ extern "C" int x3d_get_field_data(x3d_backend *b, real_t *host, const real_t *f,
 extern "C" int x3d_set_field_data_pitched(x3d_backend *b, real_t *f, const real_t *host, int hx, int hy,
                                           const int dims[3])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_OUT(b, f, false);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && host && dims, "x3d_set_field_data: null argument");
@@ -1004,6 +1063,7 @@ extern "C" int x3d_set_field_data_pitched(x3d_backend *b, real_t *f, const real_
 extern "C" int x3d_get_field_data_pitched(x3d_backend *b, real_t *host, const real_t *f, int hx, int hy,
                                           const int dims[3])
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_IN(b, f);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && f && host && dims, "x3d_get_field_data: null argument");
@@ -1023,6 +1083,7 @@ extern "C" int x3d_get_field_data_pitched(x3d_backend *b, real_t *host, const re
 // ---------------------------------------------------------------- timing
 extern "C" int x3d_timer_start(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     X3D_HIP(hipEventRecord(b->ev0, b->stream));
     return 0;
@@ -1030,6 +1091,7 @@ extern "C" int x3d_timer_start(x3d_backend *b)
 
 extern "C" int x3d_timer_stop_ms(x3d_backend *b, float *ms)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && ms, "null argument");
     X3D_HIP(hipEventRecord(b->ev1, b->stream));
     X3D_HIP(hipEventSynchronize(b->ev1));

@@ -64,6 +64,12 @@ void x3d_set_error(const char *fmt, ...);
         }                                                                                      \
     } while (0)
 
+// a * b + c with ONE rounding, spelled out.  -ffp-contract=fast leaves it to the compiler WHICH product of
+// `x * y + u * v` it fuses (the operand order of the addition decides, and that order depends on the code around it): two
+// kernels that must give the same bits from the same source expression spell the choice out where both terms are products
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // Between the store and the load phase of a WAVE-PRIVATE exchange through LDS: a wave's LDS operations execute
 // in order, so no s_barrier is needed, but the compiler must not move one lane's load over another lane's store
 // (plain C++ semantics would allow it).  Emits no instruction.
@@ -259,6 +265,21 @@ int x3d_lds_optin(x3d_backend *b, const void *kernel);
 void x3d_prof_begin(x3d_backend *b, int kind, int dir);
 void x3d_prof_end(x3d_backend *b);
 int x3d_prof_enable_c(x3d_backend *b, int on);
+// ---- roctx ranges (round 6): every entry point of the C ABI -- one per deferred procedure of base_backend_t / poisson_fft_t
+// plus the fused forms -- and every operation the deferred-execution layer issues pushes a named range, so that a
+// `rocprofv3 --marker-trace --kernel-trace` timeline attributes kernels to the reference operation they serve (the reference
+// has wall-clock prints only, src/case/base_case.f90:258-303).  Off unless X3D_ROCTX=1; the roctx library is opened at first
+// use (no link-time dependency): librocprofiler-sdk-roctx.so, else libroctx64.so.  prof.hip
+bool x3d_roctx_on();
+void x3d_roctx_push(const char *name);
+void x3d_roctx_pop();
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(x3d_roctx_on()) { if (on) x3d_roctx_push(name); }
+    ~RoctxRange() { if (on) x3d_roctx_pop(); }
+};
+#define X3D_RANGE(name) RoctxRange x3d_range_scope_(name)
+
 struct ProfScope {
     x3d_backend *b;
     bool on;  // false: the caller times a group of launches as one (scopes do not nest)

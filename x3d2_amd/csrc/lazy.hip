@@ -838,8 +838,19 @@ extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mod
                                    const real_t *in1, const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                    int *done);
 
+// (the order of enum LKind: the roctx range of an operation the queue issues says which rewritten form it is)
+static const char *const LKIND_NAME[] = {
+    "lazy:dead", "lazy:transeq", "lazy:transeq+3sums (transeq_acc)", "lazy:tds_solve", "lazy:tds_solve+vecadd (tds_acc)",
+    "lazy:tds pair", "lazy:lincomb+tds_solve (tds_lin)", "lazy:copy/alias", "lazy:sum_intox (declined)", "lazy:vecadd", "lazy:lincomb",
+    "lazy:vecmult", "lazy:scale", "lazy:shift", "lazy:fill", "lazy:discard", "lazy:fft_forward", "lazy:fft_postprocess_000",
+    "lazy:fft_backward", "lazy:poisson_000 (one solve)", "lazy:velocity correction+transeq_x", "lazy:transeq_species",
+    "lazy:transeq_species_acc", "lazy:z-first solve", "lazy:fft_postprocess_010", "lazy:poisson_010 rows", "lazy:bind", "lazy:set_face",
+    "lazy:transeq_z+RK stage"};
+static_assert(sizeof(LKIND_NAME) / sizeof(LKIND_NAME[0]) == L_TRANSEQ_STAGE + 1, "LKIND_NAME follows enum LKind");
+
 static int exec(x3d_backend *b, const LOp &op)
 {
+    X3D_RANGE(LKIND_NAME[op.kind]);
     x3d_lazy *L = b->lazy;
     const real_t *in[7] = {};
     real_t *o[6] = {};
@@ -1219,6 +1230,7 @@ static void report_at_exit()
 
 extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_lazy_enable: null backend");
     x3d_lazy *L = lazy_of(b);
     if (on && std::find(g_reported.begin(), g_reported.end(), L) == g_reported.end()) {
@@ -1245,6 +1257,7 @@ extern "C" int x3d_lazy_enable(x3d_backend *b, int on)
 // added to).  Inside fn the library's entry points run at once, on those buffers.  dir_mask: bit d = direction d.
 extern "C" int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_dist_transeq_fn fn, void *user)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_lazy_set_dist_transeq: null backend");
     X3D_REQUIRE(!(dir_mask & ~((1u << X3D_DIR_Y) | (1u << X3D_DIR_Z))), "x3d_lazy_set_dist_transeq: y and z only");
     x3d_lazy *L = lazy_of(b);
@@ -1260,6 +1273,7 @@ extern "C" int x3d_lazy_set_dist_transeq(x3d_backend *b, unsigned dir_mask, x3d_
 // mode 2: out1 = ta(in1); 0: out1 = ta(in1) + tb(in2); 1: out1 = ta(in1), out2 = tb(in1)
 extern "C" int x3d_lazy_set_dist_tds(x3d_backend *b, unsigned dir_mask, x3d_dist_tds_fn fn, void *user)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_lazy_set_dist_tds: null backend");
     X3D_REQUIRE(!(dir_mask & ~((1u << X3D_DIR_Y) | (1u << X3D_DIR_Z))), "x3d_lazy_set_dist_tds: y and z only");
     x3d_lazy *L = lazy_of(b);
@@ -1272,18 +1286,21 @@ extern "C" int x3d_lazy_set_dist_tds(x3d_backend *b, unsigned dir_mask, x3d_dist
 
 extern "C" int x3d_lazy_flush(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_lazy_flush: null backend");
     return x3d_lazy_flush_c(b);
 }
 
 extern "C" int x3d_lazy_sync(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_lazy_sync: null backend");
     return x3d_lazy_sync_c(b);
 }
 
 extern "C" int x3d_lazy_register_block(x3d_backend *b, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_lazy_register_block: null argument");
     x3d_lazy_register(b, f);
     return 0;
@@ -1293,6 +1310,7 @@ extern "C" int x3d_lazy_register_block(x3d_backend *b, real_t *f)
 // (it would otherwise keep treating the buffer as reusable storage)
 extern "C" int x3d_lazy_unregister_block(x3d_backend *b, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_lazy_unregister_block: null argument");
     if (!b->lazy) return 0;
     if (b->lazy->on) {
@@ -1305,6 +1323,7 @@ extern "C" int x3d_lazy_unregister_block(x3d_backend *b, real_t *f)
 // allocator%release_block (src/allocator.f90:160-168): the block's contents are dead until it is written again
 extern "C" int x3d_block_discard(x3d_backend *b, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && f, "x3d_block_discard: null argument");
     if (!x3d_lazy_active(b)) return 0;
     LOp op;
@@ -1314,6 +1333,7 @@ extern "C" int x3d_block_discard(x3d_backend *b, real_t *f)
 
 extern "C" int x3d_lazy_stats(x3d_backend *b, long out[24])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out, "x3d_lazy_stats: null argument");
     for (int k = 0; k < 24; k++) out[k] = 0;
     if (!b->lazy) return 0;

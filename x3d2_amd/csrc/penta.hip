@@ -132,6 +132,7 @@ extern "C" int x3d_tdsops_set_penta(x3d_tdsops *t, real_t alpha, real_t beta, re
                                     const real_t *dist_af, const real_t *dist_sa, const real_t *dist_bw,
                                     const real_t *coeffs_s, const real_t *coeffs_e, int halo_kind)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(t && dist_fw && dist_af && dist_sa && dist_bw && coeffs_s && coeffs_e, "x3d_tdsops_set_penta: null argument");
     X3D_REQUIRE(halo_kind >= 1 && halo_kind <= 4, "x3d_tdsops_set_penta: halo_kind must be 1..4");
     X3D_REQUIRE(t->n_rhs == t->n_tds, "x3d_tdsops_set_penta: n_rhs must equal n_tds");
@@ -202,6 +203,7 @@ void x3d_penta_free(x3d_tdsops *t)
 extern "C" int x3d_tds_penta_solve(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir,
                                    const real_t *u_s, const real_t *u_e)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && u && t, "x3d_tds_penta_solve: null argument");

@@ -179,6 +179,7 @@ extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int n
                                      int rz, int parts);
 extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry, int rz)
 {
+    X3D_RANGE(__func__);
     return x3d_pfft_create_parts(b, out, nglob, py, pz, ry, rz, 1);
 }
 
@@ -186,6 +187,7 @@ extern "C" int x3d_pfft_create(x3d_backend *b, x3d_pfft **out, const int nglob[3
 extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int nglob[3], int py, int pz, int ry,
                                      int rz, int parts)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && nglob, "x3d_pfft_create: null argument");
     X3D_REQUIRE(py >= 1 && pz >= 1 && ry >= 0 && ry < py && rz >= 0 && rz < pz, "x3d_pfft_create: bad rank grid");
     X3D_REQUIRE(nglob[1] % py == 0 && nglob[2] % pz == 0, "x3d_pfft_create: ny, nz must divide by py, pz");
@@ -235,6 +237,7 @@ extern "C" int x3d_pfft_create_parts(x3d_backend *b, x3d_pfft **out, const int n
 
 extern "C" int x3d_pfft_destroy(x3d_pfft *p)
 {
+    X3D_RANGE(__func__);
     if (!p) return 0;
     hipfftDestroy(p->plan_r2c); hipfftDestroy(p->plan_c2r); hipfftDestroy(p->plan_y); hipfftDestroy(p->plan_z);
     hipFree(p->c0); hipFree(p->c1); hipFree(p->c2); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
@@ -245,6 +248,7 @@ extern "C" int x3d_pfft_destroy(x3d_pfft *p)
 // out = {xs, xoff, ys, yoff, yl, zl, nxs, n_exchange_max (complex elements)}
 extern "C" int x3d_pfft_sizes(const x3d_pfft *p, long out[8])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && out, "null argument");
     const long n0 = (long)p->zl * p->yl * p->nxs, n1 = (long)p->zl * p->xs * p->ny, n2 = (long)p->xs * p->ys * p->nz;
     long m = n0 > n1 ? n0 : n1;
@@ -258,6 +262,7 @@ extern "C" int x3d_pfft_sizes(const x3d_pfft *p, long out[8])
 extern "C" int x3d_pfft_set_waves(x3d_pfft *p, const real_t *waves_re, const real_t *ax, const real_t *bx,
                                   const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && waves_re && ax && bx && ay && by && az && bz, "null argument");
     const size_t n2 = (size_t)p->xs * p->ys * p->nz;
     X3D_HIP(hipMemcpy(p->waves, waves_re, sizeof(real_t) * n2, hipMemcpyHostToDevice));
@@ -304,6 +309,7 @@ static int fft_y(x3d_pfft *p, int inverse, int m0, int m1)
 
 extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in, "null argument");
     X3D_LAZY_IN(p->b, f_in);
     return fwd_x(p, f_in, 0, p->parts);
@@ -311,6 +317,7 @@ extern "C" int x3d_pfft_fwd_x(x3d_pfft *p, const real_t *f_in)
 
 extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, real_t *f_out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out, "null argument");
     // the whole real extent is written and nothing reads a block's padding: a block that still shares its buffer -- the
     // reference's p_temp is a reordered alias of div_u, released only behind the solve (src/solver.f90:653-678) -- takes a
@@ -321,12 +328,14 @@ extern "C" int x3d_pfft_bwd_x(x3d_pfft *p, real_t *f_out)
 
 extern "C" int x3d_pfft_fft_y(x3d_pfft *p, int inverse)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "null argument");
     return fft_y(p, inverse, 0, p->parts);
 }
 
 extern "C" int x3d_pfft_fft_z(x3d_pfft *p, int inverse)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "null argument");
     if (p->xs == 0 || p->ys == 0) return 0;
     ProfScope ps(p->b, X3D_K_FFT, 3);
@@ -405,42 +414,50 @@ static int yz_c2(x3d_pfft *p, real2_t *s, int z0, int nzl, bool pack)
 
 extern "C" int x3d_pfft_pack_xy(x3d_pfft *p, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf, "null argument");
     return xy_c0(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
 extern "C" int x3d_pfft_unpack_xy(x3d_pfft *p, const real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     return xy_c1(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
 // inverse of the pair above: C1 -> chunks [zl][yl][xs] per y-slab owner -> C0 columns
 extern "C" int x3d_pfft_pack_yx(x3d_pfft *p, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf, "null argument");
     return xy_c1(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
 extern "C" int x3d_pfft_unpack_yx(x3d_pfft *p, const real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     return xy_c0(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
 extern "C" int x3d_pfft_pack_yz(x3d_pfft *p, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf, "null argument");
     return yz_c1(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
 extern "C" int x3d_pfft_unpack_yz(x3d_pfft *p, const real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     return yz_c2(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
 extern "C" int x3d_pfft_pack_zy(x3d_pfft *p, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf, "null argument");
     return yz_c2(p, (real2_t *)sendbuf, 0, p->zl, true);
 }
 extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     return yz_c1(p, (real2_t *)recvbuf, 0, p->zl, false);
 }
@@ -452,6 +469,7 @@ extern "C" int x3d_pfft_unpack_zy(x3d_pfft *p, const real_t *recvbuf)
 // matching pack filled, instead of the receive buffer: the host need not copy a rank's own chunk from one to the other
 extern "C" int x3d_pfft_own_chunk(x3d_pfft *p, const real_t *sendbuf, int rank)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf && rank >= 0 && rank < p->py, "x3d_pfft_own_chunk: bad argument");
     p->own = (const real2_t *)sendbuf;
     p->own_rank = rank;
@@ -460,6 +478,7 @@ extern "C" int x3d_pfft_own_chunk(x3d_pfft *p, const real_t *sendbuf, int rank)
 
 extern "C" int x3d_pfft_transpose_local(x3d_pfft *p, int which)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && which >= 0 && which <= 3, "x3d_pfft_transpose_local: bad argument");
     X3D_REQUIRE((which == 0 || which == 3) ? p->py == 1 : p->pz == 1, "x3d_pfft_transpose_local: the direction is divided");
     switch (which) {
@@ -476,6 +495,7 @@ extern "C" int x3d_pfft_transpose_local(x3d_pfft *p, int which)
 // receive buffer (peer r's chunk at r * ys * xs * zp)}; group m's piece starts at m times that
 extern "C" int x3d_pfft_part_layout(const x3d_pfft *p, long out[6])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && out, "null argument");
     out[0] = p->parts; out[1] = p->zp;
     out[2] = (long)p->nxs * p->yl * p->zp;
@@ -484,11 +504,14 @@ extern "C" int x3d_pfft_part_layout(const x3d_pfft *p, long out[6])
     out[5] = (long)p->pz * p->ys * p->xs * p->zp;
     return 0;
 }
-#define PFFT_PART(p, m, name) \
-    X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": group %d of %d", (m), (p) ? (p)->parts : 0)
+// (x3d_pfft_own_chunk points at a whole-solve send buffer: a group's unpack would read another group's planes -- ADVICE round 5)
+#define PFFT_PART(p, m, name)                                                                               \
+    X3D_REQUIRE((p) && (m) >= 0 && (m) < (p)->parts, name ": group %d of %d", (m), (p) ? (p)->parts : 0);   \
+    X3D_REQUIRE(!(p)->own, name ": x3d_pfft_own_chunk is pending (whole-solve unpacks only)")
 // forward: R2C x of the group, its xy chunks into send_xy
 extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const real_t *f_in, real_t *send_xy, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_fwd_a_part");
     X3D_REQUIRE(f_in && send_xy, "null argument");
     X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
@@ -498,6 +521,7 @@ extern "C" int x3d_pfft_fwd_a_part(x3d_pfft *p, const real_t *f_in, real_t *send
 // received xy chunks -> y pencils, C2C y, yz chunks into send_yz
 extern "C" int x3d_pfft_fwd_b_part(x3d_pfft *p, const real_t *recv_xy, real_t *send_yz, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_fwd_b_part");
     X3D_REQUIRE(recv_xy && send_yz, "null argument");
     if (int rc = xy_c1(p, (real2_t *)recv_xy + (long)m * p->py * p->xs * p->yl * p->zp, m * p->zp, p->zp, false))
@@ -508,6 +532,7 @@ extern "C" int x3d_pfft_fwd_b_part(x3d_pfft *p, const real_t *recv_xy, real_t *s
 // received yz chunks -> the group's planes of the z pencils (x3d_pfft_fft_z once every group is in)
 extern "C" int x3d_pfft_fwd_c_part(x3d_pfft *p, const real_t *recv_yz, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_fwd_c_part");
     X3D_REQUIRE(recv_yz, "null argument");
     return yz_c2(p, (real2_t *)recv_yz + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, false);
@@ -515,12 +540,14 @@ extern "C" int x3d_pfft_fwd_c_part(x3d_pfft *p, const real_t *recv_yz, int m)
 // backward, the same three in reverse (buffers: what was received forward is sent now)
 extern "C" int x3d_pfft_bwd_c_part(x3d_pfft *p, real_t *send_zy, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_bwd_c_part");
     X3D_REQUIRE(send_zy, "null argument");
     return yz_c2(p, (real2_t *)send_zy + (long)m * p->pz * p->ys * p->xs * p->zp, m * p->zp, p->zp, true);
 }
 extern "C" int x3d_pfft_bwd_b_part(x3d_pfft *p, const real_t *recv_zy, real_t *send_yx, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_bwd_b_part");
     X3D_REQUIRE(recv_zy && send_yx, "null argument");
     if (int rc = yz_c1(p, (real2_t *)recv_zy + (long)m * p->ny * p->xs * p->zp, m * p->zp, p->zp, false)) return rc;
@@ -529,17 +556,21 @@ extern "C" int x3d_pfft_bwd_b_part(x3d_pfft *p, const real_t *recv_zy, real_t *s
 }
 extern "C" int x3d_pfft_bwd_a_part(x3d_pfft *p, const real_t *recv_yx, real_t *f_out, int m)
 {
+    X3D_RANGE(__func__);
     PFFT_PART(p, m, "x3d_pfft_bwd_a_part");
     X3D_REQUIRE(recv_yx && f_out, "null argument");
     // (a group's planes of the real extent are written; the first group of a solve takes the block over -- see
     //  x3d_pfft_bwd_x -- and finds it its own from then on)
-    X3D_LAZY_OUT(p->b, f_out, true);
+    // (m > 0: a block that is shared AGAIN by now -- an alias recorded between two groups -- keeps the planes the earlier
+    //  groups wrote; a solely owned block gets its own buffer back at no cost)
+    X3D_LAZY_OUT(p->b, f_out, m == 0);
     if (int rc = xy_c0(p, (real2_t *)recv_yx + (long)m * p->nxs * p->yl * p->zp, m * p->zp, p->zp, false)) return rc;
     return bwd_x(p, f_out, m, m + 1);
 }
 
 extern "C" int x3d_pfft_postprocess_000(x3d_pfft *p)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "null argument");
     if (p->xs == 0 || p->ys == 0) return 0;
     const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,

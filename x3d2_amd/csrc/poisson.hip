@@ -94,6 +94,7 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
                                   const real_t *ax, const real_t *bx, const real_t *ay, const real_t *by,
                                   const real_t *az, const real_t *bz)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && n && waves_re && ax && bx && ay && by && az && bz,
                 "x3d_poisson_create: null argument");
     X3D_REQUIRE(n[0] <= b->nxp && n[1] <= b->nyp && n[2] <= b->nzp, "x3d_poisson_create: dims exceed block");
@@ -175,6 +176,7 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
 
 extern "C" int x3d_poisson_destroy(x3d_poisson *p)
 {
+    X3D_RANGE(__func__);
     if (!p) return 0;
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
@@ -202,6 +204,7 @@ static int x_forward_512(x3d_poisson *p, const real_t *f)
 
 extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 0, p, const_cast<real_t *>(f_in));
     if (p->fast512) {
@@ -217,6 +220,7 @@ extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const real_t *f_in)
 
 extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "x3d_poisson_postprocess_000: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 1, p, nullptr);
     const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
@@ -231,6 +235,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
 
 extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, real_t *f_out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 2, p, f_out);
     if (p->fast512) {
@@ -249,6 +254,7 @@ extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, real_t *f_out)
 
 extern "C" int x3d_poisson_solve_000(x3d_poisson *p, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
     X3D_LAZY_OUT(p->b, f, false);
     X3D_LAZY_EAGER(p->b);
@@ -361,6 +367,7 @@ __global__ void __launch_bounds__(256)
 
 extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_y: bad argument");
     X3D_LAZY_IN(p->b, f_in);
     X3D_LAZY_OUT(p->b, f_out, true);
@@ -376,6 +383,7 @@ extern "C" int x3d_poisson_enforce_periodicity_y(x3d_poisson *p, real_t *f_out, 
 
 extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_y: bad argument");
     X3D_LAZY_IN(p->b, f_in);
     X3D_LAZY_OUT(p->b, f_out, true);
@@ -391,6 +399,7 @@ extern "C" int x3d_poisson_undo_periodicity_y(x3d_poisson *p, real_t *f_out, con
 
 extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_enforce_periodicity_z: bad argument");
     X3D_LAZY_SYNC(p->b);
     X3D_LAZY_EAGER(p->b);
@@ -405,6 +414,7 @@ extern "C" int x3d_poisson_enforce_periodicity_z(x3d_poisson *p, real_t *f_out, 
 
 extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, real_t *f_out, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_poisson_undo_periodicity_z: bad argument");
     X3D_LAZY_SYNC(p->b);
     X3D_LAZY_EAGER(p->b);
@@ -423,6 +433,7 @@ extern "C" int x3d_poisson_undo_periodicity_z(x3d_poisson *p, real_t *f_out, con
 // division + recombination along z' ; recombination along y' + inverse rotation along x'.
 extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "x3d_poisson_postprocess_011: null argument");
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);
@@ -443,6 +454,7 @@ extern "C" int x3d_poisson_postprocess_011(x3d_poisson *p)
 
 extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const real_t *a0, const real_t *a1)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_poisson_set_stretching: null argument");
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_poisson_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
@@ -465,6 +477,7 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const real_t 
 
 extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "x3d_poisson_postprocess_010: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 3, p, nullptr);
     ProfScope ps(p->b, X3D_K_SPECTRAL);
@@ -475,6 +488,7 @@ extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 // poisson_010 (src/poisson_fft.f90:228-242): f holds the rhs on entry and the solution on exit
 extern "C" int x3d_poisson_solve_010(x3d_poisson *p, real_t *f, real_t *temp)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f && temp, "x3d_poisson_solve_010: null argument");
     X3D_LAZY_OUT(p->b, f, false);
     X3D_LAZY_OUT(p->b, temp, true);
@@ -539,6 +553,7 @@ static int y010_setup(x3d_poisson *p)
 // transforms with the post-processing kernels between them.
 extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "x3d_poisson_solve_010_rows: null argument");
     X3D_LAZY_OUT(p->b, f, false);
     X3D_LAZY_EAGER(p->b);
@@ -605,6 +620,7 @@ extern "C" int x3d_poisson_solve_010_rows(x3d_poisson *p, real_t *f)
 
 extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, real_t *host)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && host, "null argument");
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);
@@ -616,6 +632,7 @@ extern "C" int x3d_poisson_get_spectral(x3d_poisson *p, real_t *host)
 
 extern "C" int x3d_poisson_set_spectral(x3d_poisson *p, const real_t *host)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && host, "null argument");
     X3D_LAZY_FLUSH(p->b);
     X3D_LAZY_EAGER(p->b);

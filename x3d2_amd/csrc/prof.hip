@@ -3,6 +3,37 @@
 // cross-check committed under profiles/).
 #include "common.h"
 
+#include <dlfcn.h>
+
+// ---- roctx ranges, resolved at run time (common.h, X3D_RANGE)
+static struct {
+    int state;  // 0: not tried, 1: on, -1: off
+    int (*push)(const char *);
+    int (*pop)();
+} g_roctx;
+
+bool x3d_roctx_on()
+{
+    if (g_roctx.state == 0) {
+        g_roctx.state = -1;
+        const char *e = getenv("X3D_ROCTX");
+        if (e && e[0] == '1') {
+            const char *libs[3] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so"};
+            for (const char *l : libs) {
+                void *h = dlopen(l, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) continue;
+                g_roctx.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (g_roctx.push && g_roctx.pop) { g_roctx.state = 1; break; }
+            }
+            if (g_roctx.state != 1) fprintf(stderr, "x3d2_hip: X3D_ROCTX=1 but no roctx library could be opened: no ranges\n");
+        }
+    }
+    return g_roctx.state == 1;
+}
+void x3d_roctx_push(const char *name) { g_roctx.push(name); }
+void x3d_roctx_pop() { g_roctx.pop(); }
+
 struct x3d_prof {
     static const int POOL = 2048;
     hipEvent_t e0[POOL], e1[POOL];
@@ -44,6 +75,7 @@ void x3d_prof_end(x3d_backend *b)
 
 extern "C" int x3d_prof_enable(x3d_backend *b, int on)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     if (on && !b->prof) {
         x3d_prof *p = new x3d_prof();
@@ -66,6 +98,7 @@ extern "C" int x3d_prof_enable(x3d_backend *b, int on)
 // only needs the dominant class keeps the event records of the others out of its timed region.
 extern "C" int x3d_prof_select(x3d_backend *b, unsigned mask)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     if (b->prof) prof_drain(b);
     b->prof_mask = mask;
@@ -74,6 +107,7 @@ extern "C" int x3d_prof_select(x3d_backend *b, unsigned mask)
 
 extern "C" int x3d_prof_reset(x3d_backend *b)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "null backend");
     if (!b->prof) return 0;
     prof_drain(b);
@@ -85,6 +119,7 @@ extern "C" int x3d_prof_reset(x3d_backend *b)
 // kind/dir -> launches and summed device time; dir = 0 sums over directions
 extern "C" int x3d_prof_get(x3d_backend *b, int kind, int dir, long *count, double *total_ms)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && count && total_ms, "null argument");
     X3D_REQUIRE(kind >= 0 && kind < X3D_K_NKINDS && dir >= 0 && dir <= 3, "bad kind/dir");
     *count = 0; *total_ms = 0.0;

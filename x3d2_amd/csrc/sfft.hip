@@ -119,11 +119,13 @@ __global__ void __launch_bounds__(256)
 extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts);
 extern "C" int x3d_sfft_create(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz)
 {
+    X3D_RANGE(__func__);
     return x3d_sfft_create_parts(b, out, nglob, pz, rz, 1);
 }
 
 extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int nglob[3], int pz, int rz, int parts)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && nglob, "x3d_sfft_create: null argument");
     X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft_create: bad rank grid");
     X3D_REQUIRE(nglob[1] == 512, "x3d_sfft_create: the slab solver needs ny = 512 (got %d)", nglob[1]);
@@ -177,6 +179,7 @@ extern "C" int x3d_sfft_create_parts(x3d_backend *b, x3d_sfft **out, const int n
 
 extern "C" int x3d_sfft_destroy(x3d_sfft *p)
 {
+    X3D_RANGE(__func__);
     if (!p) return 0;
     hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); hipfftDestroy(p->plan_z);
     hipFree(p->c0); hipFree(p->t); hipFree(p->waves); hipFree(p->ab); hipFree(p->work);
@@ -187,6 +190,7 @@ extern "C" int x3d_sfft_destroy(x3d_sfft *p)
 // out = {chunk (complex elements per peer), zl, ys, nxs}
 extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && out, "null argument");
     out[0] = (long)p->zl * p->ys * p->nxs; out[1] = p->zl; out[2] = p->ys; out[3] = p->nxs;
     return 0;
@@ -197,6 +201,7 @@ extern "C" int x3d_sfft_sizes(const x3d_sfft *p, long out[4])
 extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const real_t *waves, const real_t *ax, const real_t *bx,
                                   const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
     {
         // stored as -1 / waves (0 where waves < 1e-16): the kernels multiply (the reference divides per element; one
@@ -219,6 +224,7 @@ extern "C" int x3d_sfft_set_waves(x3d_sfft *p, const real_t *waves, const real_t
 // x R2C, y forward; the result lands in sendbuf as [peer][zl][ys][nxs]
 extern "C" int x3d_sfft_forward_local(x3d_sfft *p, const real_t *f_in, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
     X3D_LAZY_IN(p->b, f_in);  // (deferred execution: flush, then the buffer that holds the field)
     {
@@ -272,11 +278,13 @@ static int sfft_fft_z_part(x3d_sfft *p, real_t *recvbuf, int dir, int part, bool
 
 extern "C" int x3d_sfft_fft_z_part(x3d_sfft *p, real_t *recvbuf, int dir, int part)
 {
+    X3D_RANGE(__func__);
     return sfft_fft_z_part(p, recvbuf, dir, part, true);
 }
 
 extern "C" int x3d_sfft_fft_z(x3d_sfft *p, real_t *recvbuf, int dir)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
         if (int rc = sfft_fft_z_part(p, recvbuf, dir, m, false)) return rc;
@@ -308,11 +316,13 @@ static int sfft_postprocess_part(x3d_sfft *p, real_t *recvbuf, int part, bool fu
 
 extern "C" int x3d_sfft_postprocess_000_part(x3d_sfft *p, real_t *recvbuf, int part)
 {
+    X3D_RANGE(__func__);
     return sfft_postprocess_part(p, recvbuf, part, true);
 }
 
 extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
         if (int rc = sfft_postprocess_part(p, recvbuf, m, false)) return rc;
@@ -322,6 +332,7 @@ extern "C" int x3d_sfft_postprocess_000(x3d_sfft *p, real_t *recvbuf)
 // y backward from the exchange layout, x C2R
 extern "C" int x3d_sfft_backward_local(x3d_sfft *p, const real_t *recvbuf, real_t *f_out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf && f_out, "null argument");
     // the whole real extent is written and nothing reads a block's padding: a block that still shares its buffer -- the
     // reference's p_temp is a reordered alias of div_u, released only behind the solve (src/solver.f90:653-678) -- takes a

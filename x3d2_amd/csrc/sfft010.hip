@@ -120,12 +120,14 @@ static int transpose_launch(hipStream_t st, E *dst, const E *src, long nA, long 
 extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz, int parts);
 extern "C" int x3d_sfft010_create(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz)
 {
+    X3D_RANGE(__func__);
     return x3d_sfft010_create_parts(b, out, nglob, pz, rz, 1);
 }
 
 // parts <= 0: chosen here -- the count among 4, 5, 3 that pads the rank's columns least (8 ranks, 513 modes: 65 = 5 x 13)
 extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const int nglob[3], int pz, int rz, int parts)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && nglob, "x3d_sfft010_create: null argument");
     X3D_REQUIRE(pz >= 1 && rz >= 0 && rz < pz, "x3d_sfft010_create: bad rank grid");
     X3D_REQUIRE(nglob[2] % pz == 0, "x3d_sfft010_create: nz = %d does not divide by pz = %d", nglob[2], pz);
@@ -203,6 +205,7 @@ extern "C" int x3d_sfft010_create_parts(x3d_backend *b, x3d_sfft010 **out, const
 
 extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
 {
+    X3D_RANGE(__func__);
     if (!p) return 0;
     hipfftDestroy(p->plan_xy_fw); hipfftDestroy(p->plan_xy_bw); hipfftDestroy(p->plan_z);
     hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); hipfftDestroy(p->plan_y);
@@ -214,6 +217,7 @@ extern "C" int x3d_sfft010_destroy(x3d_sfft010 *p)
 // out = {chunk (complex numbers per peer), zl, xs, i0 (first x mode of this rank), nxm, parts}
 extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && out, "null argument");
     out[0] = (long)p->zl * p->ny * p->xs; out[1] = p->zl; out[2] = p->xs; out[3] = (long)p->rz * p->xs; out[4] = p->nxm;
     out[5] = p->parts;
@@ -224,6 +228,7 @@ extern "C" int x3d_sfft010_sizes(const x3d_sfft010 *p, long out[6])
 extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const real_t *waves, const real_t *ax, const real_t *bx,
                                      const real_t *ay, const real_t *by, const real_t *az, const real_t *bz)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && waves && ax && bx && ay && by && az && bz, "null argument");
     {   // [nz][ny][xs] on the host -> [part][ny][xsc][nz] on the device (T serves as the landing zone)
         const size_t nw = (size_t)p->nz * p->ny * p->xs;
@@ -247,6 +252,7 @@ extern "C" int x3d_sfft010_set_waves(x3d_sfft010 *p, const real_t *waves, const 
 // a0, a1: this rank's columns of the pentadiagonal operators, [5][nz][n][xs] (pad columns zero); sym: odd / even rows
 extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const real_t *a0, const real_t *a1)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_sfft010_set_stretching: null argument");
     X3D_REQUIRE(!sym || p->ny % 2 == 0, "x3d_sfft010_set_stretching: odd/even split needs an even ny");
     const int n = sym ? p->ny / 2 : p->ny;
@@ -280,6 +286,7 @@ extern "C" int x3d_sfft010_set_stretching(x3d_sfft010 *p, int sym, const real_t 
 // enforce / undo_periodicity_y on the rank's zl planes (y is whole on every rank)
 extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, real_t *f_out, const real_t *f_in, int undo)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out && f_in && f_out != f_in, "x3d_sfft010_periodicity_y: bad argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     x3d_backend *b = p->b;
@@ -298,6 +305,7 @@ extern "C" int x3d_sfft010_periodicity_y(x3d_sfft010 *p, real_t *f_out, const re
 // 2-D transform of the local planes; the result lands in sendbuf as [peer][part][zl][ny][xsc]
 extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const real_t *f_in, real_t *sendbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in && sendbuf, "null argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     if (!p->split_xy) {
@@ -326,6 +334,7 @@ extern "C" int x3d_sfft010_forward_local(x3d_sfft010 *p, const real_t *f_in, rea
 // stays in T); dir 1: backward z transform of T_m, then back to W_m
 extern "C" int x3d_sfft010_fft_z_part(x3d_sfft010 *p, real_t *recvbuf, int dir, int part)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_fft_z_part: bad argument");
     const long cols = (long)p->ny * p->xsc;
     real2_t *W = (real2_t *)recvbuf + (size_t)part * p->nz * cols, *T = p->t + (size_t)part * p->nz * cols;
@@ -347,6 +356,7 @@ extern "C" int x3d_sfft010_fft_z_part(x3d_sfft010 *p, real_t *recvbuf, int dir, 
 
 extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, real_t *recvbuf, int dir)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
         if (int rc = x3d_sfft010_fft_z_part(p, recvbuf, dir, m)) return rc;
@@ -356,6 +366,7 @@ extern "C" int x3d_sfft010_fft_z(x3d_sfft010 *p, real_t *recvbuf, int dir)
 // fft_postprocess_010 on one group of this rank's x modes (all rows, all z modes), in the z-contiguous copy
 extern "C" int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, real_t *recvbuf, int part)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf && part >= 0 && part < p->parts, "x3d_sfft010_postprocess_010_part: bad argument");
     ProfScope ps(p->b, X3D_K_SPECTRAL);
     const real_t *ax = p->ab, *bx = ax + p->nab_x, *ay = bx + p->nab_x, *by = ay + p->ny, *az = by + p->ny,
@@ -370,6 +381,7 @@ extern "C" int x3d_sfft010_postprocess_010_part(x3d_sfft010 *p, real_t *recvbuf,
 
 extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, real_t *recvbuf)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && recvbuf, "null argument");
     for (int m = 0; m < p->parts; m++)
         if (int rc = x3d_sfft010_postprocess_010_part(p, recvbuf, m)) return rc;
@@ -379,6 +391,7 @@ extern "C" int x3d_sfft010_postprocess_010(x3d_sfft010 *p, real_t *recvbuf)
 // unpack the returned array S[peer][part][zl][ny][xsc] and transform back to the real planes
 extern "C" int x3d_sfft010_backward_local(x3d_sfft010 *p, const real_t *sendbuf, real_t *f_out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && sendbuf && f_out, "null argument");
     X3D_LAZY_SYNC(p->b);  // (field blocks are read / written in place)
     {

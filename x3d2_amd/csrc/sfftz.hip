@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(512)
 
 extern "C" int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob[3], int py, int ry, int parts)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && nglob, "x3d_sfftz_create: null argument");
     X3D_REQUIRE(py == 1 || py == 2 || py == 4 || py == 8, "x3d_sfftz_create: 1, 2, 4 or 8 ranks along y");
     X3D_REQUIRE(ry >= 0 && ry < py, "x3d_sfftz_create: bad rank");
@@ -111,6 +112,7 @@ extern "C" int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob
 
 extern "C" int x3d_sfftz_destroy(x3d_sfftz *p)
 {
+    X3D_RANGE(__func__);
     if (!p) return 0;
     hipFree(p->c); hipFree(p->rw); hipFree(p->ab);
     delete p;
@@ -120,6 +122,7 @@ extern "C" int x3d_sfftz_destroy(x3d_sfftz *p)
 // out = {parts, xs, xoff, complex elements of the exchange buffers, kz0[0 .. parts]}
 extern "C" int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && out, "null argument");
     out[0] = p->parts; out[1] = p->xs; out[2] = p->xoff; out[3] = (long)257 * 512 * 512;
     for (int m = 0; m <= p->parts; m++) out[4 + m] = p->kz0[m];
@@ -131,6 +134,7 @@ extern "C" int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16])
 extern "C" int x3d_sfftz_set_waves(x3d_sfftz *p, const real_t *rw, const real_t *ax, const real_t *bx, const real_t *ay,
                                    const real_t *by, const real_t *az, const real_t *bz)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && rw && ax && bx && ay && by && az && bz, "null argument");
     X3D_HIP(hipMemcpy(p->rw, rw, sizeof(real_t) * 257 * p->xs * 512 * p->py, hipMemcpyHostToDevice));
     real_t *d = p->ab;
@@ -149,6 +153,7 @@ static ZfArg zfarg(const x3d_sfftz *p) { return ZfArg{p->c, x3d_fft512_twiddles(
 extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                                   const x3d_tdsops *ta, const x3d_tdsops *tb, int *done)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && ta && tb && done, "x3d_sfftz_tds_pair: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_sfftz_tds_pair: mode must be 0 or 1");
     X3D_REQUIRE(mode == 0 ? (in1 && in2) : (out1 && out2 && out1 != out2), "x3d_sfftz_tds_pair: null argument");
@@ -164,6 +169,7 @@ extern "C" int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, real_t *out1, real_t *
 extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, real_t *out1, real_t *out2, const real_t *in1,
                                        const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int y0, int nyr, int *done)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && ta && tb && done, "x3d_sfftz_tds_pair_rows: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_sfftz_tds_pair_rows: mode must be 0 or 1");
     X3D_REQUIRE(mode == 0 ? (in1 && in2) : (out1 && out2 && out1 != out2), "x3d_sfftz_tds_pair_rows: null argument");
@@ -180,12 +186,14 @@ extern "C" int x3d_sfftz_tds_pair_rows(x3d_sfftz *p, int mode, real_t *out1, rea
 // the z transform of a field in memory (the hooks' form; the solver's fused driver uses x3d_sfftz_tds_pair)
 extern "C" int x3d_sfftz_z(x3d_sfftz *p, real_t *f, int inverse)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "null argument");
     X3D_LAZY_SYNC(p->b);
     return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, 0, -1);
 }
 extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, real_t *f, int inverse, int y0, int nyr)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "null argument");
     X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= 512, "x3d_sfftz_z_rows: rows [%d, %d) of 512", y0, y0 + nyr);
     X3D_LAZY_SYNC(p->b);
@@ -212,6 +220,7 @@ static int x_xchg(x3d_sfftz *p, real_t *buf, int m, int y0 = 0, int nyr = 512)
 // part m of the spectrum: x forward, into sendbuf's part block
 extern "C" int x3d_sfftz_x_forward(x3d_sfftz *p, real_t *sendbuf, int m)
 {
+    X3D_RANGE(__func__);
     SZ_PART(p, m, "x3d_sfftz_x_forward");
     X3D_REQUIRE(sendbuf, "null argument");
     return x_xchg<true>(p, sendbuf, m);
@@ -220,6 +229,7 @@ extern "C" int x3d_sfftz_x_forward(x3d_sfftz *p, real_t *sendbuf, int m)
 // transform / the inverse / the division alone, for the hooks of the reference's interface called one by one
 extern "C" int x3d_sfftz_y_stage(x3d_sfftz *p, real_t *recvbuf, int m, int what)
 {
+    X3D_RANGE(__func__);
     SZ_PART(p, m, "x3d_sfftz_y_stage");
     X3D_REQUIRE(recvbuf && what >= 0 && what <= 3, "x3d_sfftz_y_stage: bad argument");
     const int kzc = p->kz0[m + 1] - p->kz0[m];
@@ -232,6 +242,7 @@ extern "C" int x3d_sfftz_y_stage(x3d_sfftz *p, real_t *recvbuf, int m, int what)
 // part m back in buf's part block: x inverse, into the spectrum
 extern "C" int x3d_sfftz_x_backward(x3d_sfftz *p, const real_t *buf, int m)
 {
+    X3D_RANGE(__func__);
     SZ_PART(p, m, "x3d_sfftz_x_backward");
     X3D_REQUIRE(buf, "null argument");
     return x_xchg<false>(p, const_cast<real_t *>(buf), m);
@@ -242,6 +253,7 @@ extern "C" int x3d_sfftz_x_backward(x3d_sfftz *p, const real_t *buf, int m)
 #define SZ_ROWS(y0, nyr, name) X3D_REQUIRE((y0) >= 0 && (nyr) >= 0 && (y0) + (nyr) <= 512, name ": rows [%d, %d) of 512", (y0), (y0) + (nyr))
 extern "C" int x3d_sfftz_x_forward_rows(x3d_sfftz *p, real_t *sendbuf, int m, int y0, int nyr)
 {
+    X3D_RANGE(__func__);
     SZ_PART(p, m, "x3d_sfftz_x_forward_rows");
     SZ_ROWS(y0, nyr, "x3d_sfftz_x_forward_rows");
     X3D_REQUIRE(sendbuf, "null argument");
@@ -249,6 +261,7 @@ extern "C" int x3d_sfftz_x_forward_rows(x3d_sfftz *p, real_t *sendbuf, int m, in
 }
 extern "C" int x3d_sfftz_x_backward_rows(x3d_sfftz *p, const real_t *buf, int m, int y0, int nyr)
 {
+    X3D_RANGE(__func__);
     SZ_PART(p, m, "x3d_sfftz_x_backward_rows");
     SZ_ROWS(y0, nyr, "x3d_sfftz_x_backward_rows");
     X3D_REQUIRE(buf, "null argument");

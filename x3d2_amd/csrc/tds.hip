@@ -29,6 +29,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                                  const real_t *dist_sa, const real_t *dist_sc, const real_t *dist_af,
                                  const real_t *stretch, const real_t *stretch_correct)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out && coeffs && coeffs_s && coeffs_e && dist_fw && dist_bw && dist_sa && dist_sc &&
                     dist_af && stretch && stretch_correct,
                 "x3d_tdsops_create: null argument");
@@ -259,6 +260,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
 
 extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
 {
+    X3D_RANGE(__func__);
     if (!t) return 0;
     x3d_penta_free(t);
     hipFree(t->dev);
@@ -270,6 +272,7 @@ extern "C" int x3d_tdsops_destroy(x3d_tdsops *t)
 // i.e. the rows x3d_*_halo_fix touch
 extern "C" int x3d_tdsops_dims(const x3d_tdsops *t, int out[2])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(t && out, "x3d_tdsops_dims: null argument");
     out[0] = t->n_tds;
     out[1] = t->tab.n_rhs;
@@ -278,6 +281,7 @@ extern "C" int x3d_tdsops_dims(const x3d_tdsops *t, int out[2])
 
 extern "C" int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2])
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(t && out, "x3d_tdsops_halo_rows: null argument");
     out[0] = t->halo_ws; out[1] = t->halo_we;
     return 0;
@@ -285,6 +289,7 @@ extern "C" int x3d_tdsops_halo_rows(const x3d_tdsops *t, int out[2])
 
 extern "C" int x3d_npencils(const x3d_backend *b, int dir)
 {
+    X3D_RANGE(__func__);
     if (!b || !x3d_dir_ok(dir)) return -1;
     return x3d_geom(b, dir).np;
 }
@@ -644,6 +649,7 @@ void x3d_halo_layout(const x3d_backend *b, int dir, int *hp, long *hnp)
 // entries of one halo row of direction dir (y or z) in the tile kernels' halo buffers [side 2][nf][4][this]
 extern "C" long x3d_halo_row_size(const x3d_backend *b, int dir)
 {
+    X3D_RANGE(__func__);
     if (!b || !x3d_dir_ok(dir)) return 0;
     int hp;
     long hnp;
@@ -675,6 +681,10 @@ int x3d_xscan_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f
                        const x3d_tdsops *der2nd_sym, int acc, const real_t *const *upd_g, const x3d_tdsops *op_s,
                        const x3d_tdsops *op_i, real_t scale, real_t omega, const real_t *ushift, bool *done);  // xscan.hip
 // xdir.hip
+int x3d_xwide_transeq3_upd(x3d_backend *b, real_t *const r[3], real_t *const f[3], real_t nu, const x3d_tdsops *der1st,
+                           const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym,
+                           const real_t *const g[3], const x3d_tdsops *op_s, const x3d_tdsops *op_i, real_t scale,
+                           real_t omega, const real_t *ushift, bool *done);
 int x3d_xwide_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f[3], real_t nu, const x3d_tdsops *der1st,
                        const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, int acc,
                        real_t omega, const real_t *ushift, bool *done);  // xwide.hip
@@ -704,6 +714,7 @@ static int check_len(const x3d_backend *b, const x3d_tdsops *t, int dir, const c
 
 extern "C" int x3d_pack_halos(x3d_backend *b, real_t *send_s, real_t *send_e, const real_t *u, int n, int dir)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && send_s && send_e && u, "x3d_pack_halos: null argument");
     // deferred execution on several ranks: what has been recorded runs first, then this entry point works on the
     // buffer that holds u's data (the exchange buffers are not handles)
@@ -721,6 +732,7 @@ extern "C" int x3d_tds_dist_fwd(x3d_backend *b, real_t *du, real_t *du_send_s, r
                                 const real_t *u, const real_t *u_recv_s, const real_t *u_recv_e,
                                 const x3d_tdsops *t, int dir)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && du && du_send_s && du_send_e && u && u_recv_s && u_recv_e && t,
                 "x3d_tds_dist_fwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_fwd: bad dir %d", dir);
@@ -741,6 +753,7 @@ extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, real_t *du, const real_t *du
                                     const real_t *du_recv_e, const x3d_tdsops *t, int dir, int accumulate,
                                     real_t scale)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && du && du_send_s && du_recv_s && du_recv_e && t, "x3d_tds_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_dist_bwd: bad dir %d", dir);
     X3D_LAZY_OUT(b, du, !accumulate);
@@ -760,6 +773,7 @@ extern "C" int x3d_tds_dist_bwd_acc(x3d_backend *b, real_t *du, const real_t *du
 extern "C" int x3d_tds_dist_bwd(x3d_backend *b, real_t *du, const real_t *du_send_s, const real_t *du_recv_s,
                                 const real_t *du_recv_e, const x3d_tdsops *t, int dir)
 {
+    X3D_RANGE(__func__);
     return x3d_tds_dist_bwd_acc(b, du, du_send_s, du_recv_s, du_recv_e, t, dir, 0, 1.0);
 }
 
@@ -768,6 +782,7 @@ extern "C" int x3d_tds_dist_bwd(x3d_backend *b, real_t *du, const real_t *du_sen
 extern "C" int x3d_tds_solve_acc(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir,
                                  int accumulate, real_t scale)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && u && t, "x3d_tds_solve: null argument");
@@ -806,6 +821,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
 extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1,
                                   const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && tb && (mode == 0 ? in2 != nullptr : out2 != nullptr),
@@ -837,6 +853,7 @@ extern "C" int x3d_tds_solve_pair(x3d_backend *b, int dir, int mode, real_t *out
 extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1,
                                         const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int ny, int *done)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && out1 && in1 && ta && tb && done && (mode == 0 ? in2 != nullptr : out2 != nullptr),
@@ -862,7 +879,8 @@ extern "C" int x3d_tds_solve_pair_yperm(x3d_backend *b, int mode, real_t *out1, 
 int x3d_xscan_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
                           const real_t *c, const real_t *const *x, const real_t *wall, bool *done);  // xscan.hip
 int x3d_xwide_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base, int nterm,
-                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done);  // xwide.hip
+                          const real_t *c, const real_t *const *x, const real_t *wall, bool *done, real_t *psum = nullptr,
+                          int ny_sum = 0, int *nsum = nullptr);  // xwide.hip
 extern "C" int x3d_field_set_face_from_field(x3d_backend *b, real_t *f, const real_t *f_start, const int dims[3],
                                              real_t c_end, int face, real_t flow_rate_diff);
 extern "C" int x3d_lincomb(x3d_backend *b, real_t *y, const real_t *base, int nterm, const real_t *c,
@@ -870,9 +888,13 @@ extern "C" int x3d_lincomb(x3d_backend *b, real_t *y, const real_t *base, int nt
 
 // fusion extension: y = base + sum_i c[i] x[i] (x3d_lincomb) followed by du = tds_solve(y), in one kernel for
 // periodic 256 / 512-point x pencils (y is not read back); otherwise the two calls one after the other
+// nsum != null: the caller wants the sum of y over dims_sum's rows as well (x3d_tds_solve_lincomb_wall_mean): where a kernel
+// takes it along, its partials are in b->red_buf and *nsum says how many; else *nsum = 0
 static int tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y, const real_t *base,
-                                  int nterm, const real_t *c, const real_t *const *x, const real_t *wall)
+                                  int nterm, const real_t *c, const real_t *const *x, const real_t *wall,
+                                  const int *dims_sum = nullptr, int *nsum = nullptr)
 {
+    if (nsum) *nsum = 0;
     X3D_REQUIRE(b && du && t && y && base && c && x, "x3d_tds_solve_lincomb: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve_lincomb: bad dir %d", dir);
     X3D_REQUIRE(nterm >= 1 && nterm <= 5, "x3d_tds_solve_lincomb: nterm must be 1..5");
@@ -883,7 +905,11 @@ static int tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, const x3d
         bool done = false;
         if (int rc = x3d_xscan_tds_lincomb(b, du, t, y, base, nterm, c, x, wall, &done)) return rc;
         if (done) return 0;
-        if (int rc = x3d_xwide_tds_lincomb(b, du, t, y, base, nterm, c, x, wall, &done)) return rc;  // n = 1024
+        // (n = 1024; the sum rides along where it covers whole x pencils and every z plane)
+        const bool sum = nsum && dims_sum && dims_sum[0] == b->nx && dims_sum[2] == b->nz && dims_sum[1] <= b->ny;
+        if (int rc = x3d_xwide_tds_lincomb(b, du, t, y, base, nterm, c, x, wall, &done, sum ? b->red_buf : nullptr,
+                                           sum ? dims_sum[1] : 0, sum ? nsum : nullptr))
+            return rc;
         if (done) return 0;
     }
     if (int rc = x3d_lincomb(b, y, base, nterm, c, x)) return rc;
@@ -897,6 +923,7 @@ static int tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, const x3d
 extern "C" int x3d_tds_solve_lincomb(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y,
                                      const real_t *base, int nterm, const real_t *c, const real_t *const *x)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, nullptr);
@@ -909,14 +936,36 @@ extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, c
                                           const real_t *base, int nterm, const real_t *c, const real_t *const *x,
                                           const real_t *wall)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(wall, "x3d_tds_solve_lincomb_wall: null argument");
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall);
 }
 
+// x3d_tds_solve_lincomb[_wall] (wall may be NULL) followed by x3d_field_mean_shift(y, dims, ncell, target, shift): the
+// channel case's RK stage + apply_BC + first x operator of the divergence, and the bulk-velocity integral its NEXT
+// define_BC needs (src/case/channel.f90:66-72), which the 1024-row kernel forms while y's rows are in its registers
+// (k_xwide_tds_lin) -- one reduction pass over u less per sub-step.  Elsewhere the two calls one after the other.
+int x3d_finish_mean_shift(x3d_backend *b, int nparts, real_t ncell, real_t target, const real_t **shift);
+extern "C" int x3d_tds_solve_lincomb_wall_mean(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y,
+                                               const real_t *base, int nterm, const real_t *c, const real_t *const *x,
+                                               const real_t *wall, const int dims[3], real_t ncell, real_t target,
+                                               const real_t **shift)
+{
+    X3D_RANGE(__func__);
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
+    X3D_REQUIRE(dims && shift && ncell > 0.0, "x3d_tds_solve_lincomb_wall_mean: bad argument");
+    int nsum = 0;
+    if (int rc = tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall, dims, &nsum)) return rc;
+    if (nsum > 0) return x3d_finish_mean_shift(b, nsum, ncell, target, shift);
+    return x3d_field_mean_shift(b, y, dims, ncell, target, shift);
+}
+
 extern "C" int x3d_tds_solve(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir)
 {
+    X3D_RANGE(__func__);
     if (b && x3d_lazy_active(b)) {  // recorded -- after the checks the eager path makes at the call site
         X3D_REQUIRE(du && u && t, "x3d_tds_solve: null argument");
         X3D_REQUIRE(x3d_dir_ok(dir), "x3d_tds_solve: bad dir %d", dir);
@@ -972,6 +1021,7 @@ extern "C" int x3d_transeq_dist_fwd(x3d_backend *b, int dir, real_t *rhs, real_t
                                     const real_t *conv, const real_t *conv_recv_s, const real_t *conv_recv_e,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && rhs && send_s && send_e && u && u_recv_s && u_recv_e && conv && conv_recv_s &&
                     conv_recv_e && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_fwd: null argument");
@@ -996,6 +1046,7 @@ extern "C" int x3d_transeq_dist_bwd_acc(x3d_backend *b, int dir, real_t *rhs, co
                                         const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u,
                                         int accumulate)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && rhs && send_s && recv_s && recv_e && conv && t_du && t_dud && t_d2u,
                 "x3d_transeq_dist_bwd: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_dist_bwd: bad dir %d", dir);
@@ -1020,6 +1071,7 @@ extern "C" int x3d_transeq_dist_bwd(x3d_backend *b, int dir, real_t *rhs, const 
                                     const real_t *recv_s, const real_t *recv_e, const real_t *conv, real_t nu,
                                     const x3d_tdsops *t_du, const x3d_tdsops *t_dud, const x3d_tdsops *t_d2u)
 {
+    X3D_RANGE(__func__);
     return x3d_transeq_dist_bwd_acc(b, dir, rhs, send_s, recv_s, recv_e, conv, nu, t_du, t_dud, t_d2u, 0);
 }
 
@@ -1078,6 +1130,7 @@ extern "C" int x3d_transeq(x3d_backend *b, int dir, real_t *du, real_t *dv, real
                            const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                            const x3d_tdsops *der2nd_sym)
 {
+    X3D_RANGE(__func__);
     if (b && x3d_lazy_active(b)) {  // recorded -- after the checks the eager path makes at the call site
         X3D_REQUIRE(du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym, "x3d_transeq: null argument");
         X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq: bad dir %d", dir);
@@ -1095,6 +1148,7 @@ extern "C" int x3d_transeq_acc(x3d_backend *b, int dir, real_t *du, real_t *dv, 
                                const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                const x3d_tdsops *der2nd_sym, int accumulate)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym,
@@ -1150,6 +1204,7 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, real_t *du, real_t *dv, real
                                     const real_t *gv, const real_t *gw, const x3d_tdsops *op_u,
                                     const x3d_tdsops *op_vw, real_t scale, int *done)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && gu && gv && gw &&
@@ -1168,6 +1223,47 @@ extern "C" int x3d_transeq_x_update(x3d_backend *b, real_t *du, real_t *dv, real
     if (int rc = x3d_xscan_transeq3(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, 0, g, op_u, op_vw, scale, 0.0,
                                     nullptr, &ok))
         return rc;
+    if (!ok) {  // 1024-row pencils (K3w)
+        real_t *fw[3] = {u, v, w};
+        if (int rc = x3d_xwide_transeq3_upd(b, r, fw, nu, der1st, der1st_sym, der2nd, der2nd_sym, g, op_u, op_vw, scale, 0.0,
+                                            nullptr, &ok))
+            return rc;
+    }
+    *done = ok ? 1 : 0;
+    return 0;
+}
+
+// fusion extension (round 6): the two above in one launch -- pending correction, bulk-velocity shift, transeq_x, rotation
+// forcing (include/x3d2_hip.h).  Served for 1024-row pencils (K3w); omega == 0 and no shift: x3d_transeq_x_update.
+extern "C" int x3d_transeq_x_update_rot(x3d_backend *b, real_t *du, real_t *dv, real_t *dw, real_t *u, real_t *v, real_t *w,
+                                        real_t nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
+                                        const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, const real_t *gu,
+                                        const real_t *gv, const real_t *gw, const x3d_tdsops *op_u,
+                                        const x3d_tdsops *op_vw, real_t scale, real_t omega, const real_t *u_shift, int *done)
+{
+    X3D_RANGE(__func__);
+    if (omega == 0.0 && !u_shift)
+        return x3d_transeq_x_update(b, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, gu, gv, gw, op_u, op_vw,
+                                    scale, done);
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
+    X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && gu && gv && gw &&
+                    op_u && op_vw && done,
+                "x3d_transeq_x_update_rot: null argument");
+    *done = 0;
+    if (int rc = transeq_check(b, X3D_DIR_X, der1st, der1st_sym, der2nd)) return rc;
+    if (int rc = transeq_check(b, X3D_DIR_X, der1st_sym, der1st, der2nd_sym)) return rc;
+    if (int rc = check_len(b, op_u, X3D_DIR_X, "transeq_x_update_rot")) return rc;
+    if (int rc = check_len(b, op_vw, X3D_DIR_X, "transeq_x_update_rot")) return rc;
+    real_t *r[3] = {du, dv, dw}, *f[3] = {u, v, w};
+    const real_t *g[3] = {gu, gv, gw};
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 3; k++)
+            X3D_REQUIRE(r[c] != f[k] && r[c] != g[k] && f[c] != g[k], "x3d_transeq_x_update_rot: arguments alias");
+    bool ok = false;
+    if (int rc = x3d_xwide_transeq3_upd(b, r, f, nu, der1st, der1st_sym, der2nd, der2nd_sym, g, op_u, op_vw, scale, omega,
+                                        u_shift, &ok))
+        return rc;
     *done = ok ? 1 : 0;
     return 0;
 }
@@ -1184,6 +1280,7 @@ extern "C" int x3d_transeq_x_rot(x3d_backend *b, real_t *du, real_t *dv, real_t 
                                  const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym, real_t omega,
                                  const real_t *u_shift, int *done)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
@@ -1212,6 +1309,7 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, real_t *dspec, const
                                    real_t nu, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                    const x3d_tdsops *der2nd, int accumulate)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && dspec && uvw && spec && der1st && der1st_sym && der2nd, "x3d_transeq_species: null argument");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_transeq_species: bad dir %d", dir);
     X3D_REQUIRE(dspec != uvw && dspec != spec, "x3d_transeq_species: output aliases an input");
@@ -1231,6 +1329,7 @@ extern "C" int x3d_transeq_species(x3d_backend *b, int dir, real_t *dspec, const
 // send[side 2][field nf][4][np]: rows 1..4 (side 0, for prev) and n-3..n (side 1, for next) of nf <= 3 fields
 extern "C" int x3d_pack_halos_multi(x3d_backend *b, real_t *send, const real_t *const *fields, int nf, int n, int dir)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && send && fields, "x3d_pack_halos_multi: null argument");
     X3D_REQUIRE(nf >= 1 && nf <= 3, "x3d_pack_halos_multi: 1..3 fields");
     X3D_REQUIRE(x3d_dir_ok(dir), "x3d_pack_halos_multi: bad dir %d", dir);
@@ -1266,6 +1365,7 @@ extern "C" int x3d_transeq_tile(x3d_backend *b, int dir, real_t *du, real_t *dv,
                                 int accumulate, const real_t *halo_recv, real_t *bnd_send, int other0, int nother,
                                 int *done)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && done,
                 "x3d_transeq_tile: null argument");
     X3D_REQUIRE((halo_recv == nullptr) == (bnd_send == nullptr), "x3d_transeq_tile: halo_recv and bnd_send go together");
@@ -1302,6 +1402,7 @@ extern "C" int x3d_transeq_halo_fix(x3d_backend *b, int dir, real_t *du, real_t 
                                     const real_t *v, const real_t *w, real_t nu, const x3d_tdsops *der1st,
                                     const x3d_tdsops *der2nd, const real_t *bnd_recv)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der2nd && bnd_recv, "x3d_transeq_halo_fix: null argument");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_transeq_halo_fix: dir must be y or z");
     X3D_LAZY_IN(b, u); X3D_LAZY_IN(b, v); X3D_LAZY_IN(b, w);
@@ -1356,6 +1457,7 @@ extern "C" int x3d_tds_pair_tile(x3d_backend *b, int dir, int mode, real_t *out1
                                  const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, const real_t *halo_recv,
                                  real_t *bnd_send, int other0, int nother, int *done)
 {
+    X3D_RANGE(__func__);
     return pair_tile(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, other0, nother, done);
 }
 // the decomposed-z form of x3d_tds_solve_pair_yperm: the whole block, halo_recv's planes in the row order of in1
@@ -1364,6 +1466,7 @@ extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, real_t *out1, r
                                        const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                        const real_t *halo_recv, real_t *bnd_send, int ny, int *done)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && done, "x3d_tds_pair_tile_yperm: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_tile_yperm: mode must be 0 or 1");
     X3D_REQUIRE(ny > 0 && ny <= b->ny, "x3d_tds_pair_tile_yperm: ny = %d outside the block (%d rows)", ny, b->ny);
@@ -1376,6 +1479,7 @@ extern "C" int x3d_tds_pair_tile_yperm(x3d_backend *b, int mode, real_t *out1, r
 extern "C" int x3d_tds_pair_halo_fix_yperm(x3d_backend *b, int mode, real_t *out1, real_t *out2, const x3d_tdsops *ta,
                                            const x3d_tdsops *tb, const real_t *bnd_recv, int ny)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b, "x3d_tds_pair_halo_fix_yperm: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_halo_fix_yperm: mode must be 0 or 1");
     X3D_REQUIRE(ny > 0 && ny <= b->ny, "x3d_tds_pair_halo_fix_yperm: ny = %d outside the block (%d rows)", ny, b->ny);
@@ -1395,6 +1499,7 @@ extern "C" int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mod
                                    const real_t *in1, const real_t *in2, const x3d_tdsops *ta, const x3d_tdsops *tb,
                                    int *done)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && poisson && ta && tb && done, "x3d_tds_pair_zfirst: null argument");
     X3D_REQUIRE(mode == 0 || mode == 1, "x3d_tds_pair_zfirst: mode must be 0 or 1");
     X3D_REQUIRE(mode == 0 ? (in1 && in2) : (out1 && out2 && out1 != out2), "x3d_tds_pair_zfirst: null argument");
@@ -1415,6 +1520,7 @@ bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_t
 // probe: would the z-transforming pair kernels (x3d_tds_pair_zfirst, x3d_sfftz_tds_pair) take this operator pair
 extern "C" int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, const x3d_tdsops *tb, int *ok)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && ta && tb && ok, "x3d_tds_pair_zfirst_ok: null argument");
     *ok = x3d_zfirst_pairs_ok(b, ta, tb) ? 1 : 0;
     return 0;
@@ -1423,6 +1529,7 @@ extern "C" int x3d_tds_pair_zfirst_ok(x3d_backend *b, const x3d_tdsops *ta, cons
 extern "C" int x3d_tds_pair_halo_fix(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2,
                                      const x3d_tdsops *ta, const x3d_tdsops *tb, const real_t *bnd_recv)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(b && out1 && ta && bnd_recv && (mode == 2 || tb) && (mode != 1 || out2), "x3d_tds_pair_halo_fix: null argument");
     X3D_REQUIRE(mode >= 0 && mode <= 2, "x3d_tds_pair_halo_fix: mode must be 0, 1 or 2");
     X3D_REQUIRE(dir == X3D_DIR_Y || dir == X3D_DIR_Z, "x3d_tds_pair_halo_fix: dir must be y or z");

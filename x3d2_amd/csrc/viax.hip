@@ -303,6 +303,7 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, real_t *pu, real_t *pv
                                  const x3d_tdsops *der1st_sym, const x3d_tdsops *der2nd,
                                  const x3d_tdsops *der2nd_sym, int *deferred)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && pu && pv && pw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && deferred,
@@ -342,6 +343,7 @@ extern "C" int x3d_transeq_defer(x3d_backend *b, int dir, real_t *pu, real_t *pv
 // r += transpose^-1(pend): the plain completion of a deferred component
 extern "C" int x3d_pending_flush(x3d_backend *b, int dir, real_t *r, const real_t *pend)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && r && pend, "x3d_pending_flush: null argument");
@@ -352,6 +354,7 @@ extern "C" int x3d_pending_flush(x3d_backend *b, int dir, real_t *r, const real_
 extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, real_t *y, const real_t *base, int nterm,
                                    const real_t *c, real_t *const *x, int ipend, const real_t *pend, int store)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && y && base && c && x && pend, "x3d_lincomb_pending: null argument");
@@ -390,6 +393,7 @@ extern "C" int x3d_lincomb_pending(x3d_backend *b, int dir, real_t *y, const rea
 extern "C" int x3d_transeq_stage_ok(x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der1st_sym,
                                     const x3d_tdsops *der2nd, const x3d_tdsops *der2nd_sym)
 {
+    X3D_RANGE(__func__);
     if (!b || !der1st || !der1st_sym || !der2nd || !der2nd_sym || (dir != X3D_DIR_Y && dir != X3D_DIR_Z)) return 0;
     return use_via_x() && x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd) &&
            x3d_ytile_applicable(b, dir, der1st_sym, der1st, der2nd_sym);
@@ -400,6 +404,7 @@ extern "C" int x3d_transeq_lincomb(x3d_backend *b, int dir, int kind, const real
                                    const x3d_tdsops *der2nd_sym, real_t *y, const real_t *base, int nterm,
                                    const real_t *c, real_t *const *x, int ipend, int store)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && u && conv && der1st && der1st_sym && der2nd && der2nd_sym && y && base && c && x,
@@ -435,6 +440,7 @@ extern "C" int x3d_transeq_lincomb3(x3d_backend *b, int dir, real_t *du, real_t 
                                     real_t *const y[3], const real_t *const base[3], const int nterm[3], const real_t *c,
                                     real_t *const *x, const int ipend[3], const int store[3], int *done)
 {
+    X3D_RANGE(__func__);
     if (b) X3D_LAZY_SYNC(b);
     X3D_LAZY_EAGER(b);
     X3D_REQUIRE(b && du && dv && dw && u && v && w && der1st && der1st_sym && der2nd && der2nd_sym && y && base && nterm &&

@@ -863,6 +863,7 @@ __device__ unsigned long long g_yt[8 + 32];  // [8..23]: per wave, ticks from co
                                              // [24..39]: per wave, ticks spent in the solves themselves
 extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 {
+    X3D_RANGE(__func__);
     if (reset) { unsigned long long z[40] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_yt), z, sizeof z) != hipSuccess; }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_yt), sizeof(unsigned long long) * 40) != hipSuccess;
 }

@@ -61,7 +61,8 @@ __device__ __forceinline__ real_t lt_read(const real_t *__restrict__ l, int idx)
 __device__ __forceinline__ int ltc_lane(int lane) { return lane < 8 ? lane : (lane > 55 ? lane - 47 : 8); }
 // inside templates with LS and ll in scope: one row entry / one scan multiplier of either layout
 #define LTX(l, e) lt_read((l), (e) * LS + (LS == 64 ? lane : ll))
-#define LTM(l, k) lt_read((l), (LS == 64 ? (8 * Q + (k)) * 64 : LTC_M0(Q) + (k) * 64) + lane)
+// (MOFF >= 0: the compressed layout WITHOUT its ST / STC blocks -- the multipliers start at MOFF, xwide.hip's uniform-grid form)
+#define LTM(l, k) lt_read((l), (LS == 64 ? (8 * Q + (k)) * 64 : (MOFF >= 0 ? MOFF : LTC_M0(Q)) + (k) * 64) + lane)
 
 // what the kernels need of one operator: 17 SGPRs instead of the whole TdsTab
 struct XOp {
@@ -161,7 +162,7 @@ __device__ __forceinline__ real_t ext_x(const real_t *__restrict__ row, int jj, 
 // one operator, lane-local + scan: in: w[Q+8] = rows first-4 .. last+4; out: X[Q] back-substituted
 // values (before the reduced-system substitution), du1 and xn broadcast to all lanes.
 // General form (FAST = false): cs = the operator's stencil table in LDS (stage_cs), n_rhs >= 8.
-template <int Q, bool FAST, bool NARROW = false, class T = real_t, int LS = 64>
+template <int Q, bool FAST, bool NARROW = false, class T = real_t, int LS = 64, int MOFF = -1>
 __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du1, T &xn,
                                            const real_t *__restrict__ lt, const XOp &t, int &lane, int first, int ll = 0,
                                            const real_t *__restrict__ cs = nullptr)

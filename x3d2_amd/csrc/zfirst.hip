@@ -155,6 +155,7 @@ bool x3d_zfirst_on_offer(x3d_poisson *p)
 
 extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && ok, "x3d_poisson_zfirst_ok: null argument");
     bool o = false;
     if (int rc = x3d_zfirst_arg(p, nullptr, &o)) return rc;
@@ -180,6 +181,7 @@ static int c2c_x(x3d_poisson *p, int kz0, int nkz)
 // C (z already transformed) -> x forward ; y forward + process_spectral_000 + y inverse ; x inverse -> C
 extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p, "x3d_poisson_zfirst_middle: null argument");
     bool ok = false;
     if (int rc = x3d_zfirst_arg(p, nullptr, &ok)) return rc;
@@ -226,12 +228,14 @@ static int ztile(x3d_poisson *p, real_t *f, bool fwd)
 // stand-alone ends of the z-first solve: f (cell data of a block) -> C, and back
 extern "C" int x3d_poisson_zfirst_forward(x3d_poisson *p, const real_t *f_in)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in, "x3d_poisson_zfirst_forward: null argument");
     X3D_LAZY_SYNC(p->b);
     return ztile(p, const_cast<real_t *>(f_in), true);
 }
 extern "C" int x3d_poisson_zfirst_backward(x3d_poisson *p, real_t *f_out)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out, "x3d_poisson_zfirst_backward: null argument");
     X3D_LAZY_SYNC(p->b);
     return ztile(p, f_out, false);
@@ -239,6 +243,7 @@ extern "C" int x3d_poisson_zfirst_backward(x3d_poisson *p, real_t *f_out)
 // poisson_000 through the z-first stages, in place (== x3d_poisson_solve_000 up to rounding)
 extern "C" int x3d_poisson_solve_000_zfirst(x3d_poisson *p, real_t *f)
 {
+    X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000_zfirst: null argument");
     if (int rc = x3d_poisson_zfirst_forward(p, f)) return rc;
     if (int rc = x3d_poisson_zfirst_middle(p)) return rc;

@@ -103,7 +103,15 @@ class Comm:
         # the check is collective (a ring exchange + an all-reduce): it runs HERE, where every rank is -- not at the first
         # exchange, which a rank whose first group is empty would skip while its neighbours wait for it
         if not self._checked:
-            key = (id(group) if group is not None else None, self.backend, self.self_via_nccl)
+            # (keyed on WHO is in the group, not on id(group): CPython reuses ids after garbage collection and a new group
+            #  may have other members or another transport -- ADVICE round 5)
+            members = None
+            if group is not None:
+                try:
+                    members = tuple(dist.get_process_group_ranks(group))
+                except Exception:
+                    members = ("group", id(group), self.size)
+            key = (members, self.size, self.backend, self.self_via_nccl)
             if not self_check:
                 self._checked, self.overlap = True, False
             elif key in Comm._verdicts:

@@ -120,6 +120,9 @@ class Solver:
                             and backend.zfirst_pairs_ok(z.interpl_p2v, z.stagder_p2v))
         self.shift_request = None  # device scalar to add to u before transeq_x uses it (field_mean_shift)
         self.pending_walls = None  # wall fields to stamp on u, v, w inside the divergence's first kernels
+        # (round 6) the case's next define_BC wants field_mean_shift(u, mean_request): taken along by the kernel that
+        # forms the new u (BaseCase.substep); _mean_ready = (u's buffer, target, shift scalar, reduction epoch)
+        self.mean_request, self._mean_ready, self.n_mean_taken = None, None, 0
         # readers of field data outside step() (get_field_data) first complete a pending velocity correction
         backend.before_read.append(self.flush_grad)
         # src/solver.f90:206-210: lowmem_transeq selects the variant that gives the x-oriented velocity blocks back to the
@@ -259,18 +262,29 @@ class Solver:
         rot, self.rot_request, self.rot_applied = self.rot_request, 0.0, False
         # ... and so can the second half of its bulk-velocity shift (ChannelCase.define_BC)
         shift, self.shift_request = self.shift_request, None
-        if shift is not None and self.pending_grad is not None:
-            self.flush_grad()  # (the shift's mean was taken of the corrected velocity)
+        x = self.xdirps
+        served = False
         if self.pending_grad is not None:
             # the previous sub-step's velocity correction is still pending (pressure_correction_fused(defer_grad)):
-            # the x kernel applies it to each pencil before using it
+            # the x kernel applies it to each pencil before using it -- together with the channel case's shift and
+            # rotation forcing where those were asked for (round 6: k_xwide_transeq3_upd; the shift's mean was then
+            # taken of the uncorrected u, BaseCase.correction_deferrable)
             g, self.pending_grad = self.pending_grad, None
-            x = self.xdirps
-            if not b.transeq_x_update(du, dv, dw, u, v, w, self.nu, x, g, x.stagder_p2v, x.interpl_p2v, -1.0):
+            if rot != 0.0 or shift is not None:
+                if os.environ.get("X3D_NO_ROT_FUSED") != "1" and \
+                        b.transeq_x_update_rot(du, dv, dw, u, v, w, self.nu, x, g, x.stagder_p2v, x.interpl_p2v, -1.0, rot, shift):
+                    served = True
+                    if rot != 0.0:
+                        self.rot_applied = True
+                        self.n_rot_fused += 1
+            elif b.transeq_x_update(du, dv, dw, u, v, w, self.nu, x, g, x.stagder_p2v, x.interpl_p2v, -1.0):
+                served = True
+            if not served:
                 self._apply_grad(g, u, v, w)
-                b.transeq_dir(DIR_X, du, dv, dw, u, v, w, self.nu, self.xdirps, accumulate=False)
             for f in g:
                 b.allocator.release_block(f)
+        if served:
+            pass
         elif (rot != 0.0 or shift is not None) and os.environ.get("X3D_NO_ROT_FUSED") != "1" and \
                 b.transeq_x_rot(du, dv, dw, u, v, w, self.nu, self.xdirps, rot, shift):
             if rot != 0.0:
@@ -373,6 +387,7 @@ class Solver:
         # (pending_walls: wall values the case left to be stamped on the new velocity, ChannelCase.deferred_walls)
         upd = self.time_integrator.pending_update
         walls, self.pending_walls = self.pending_walls or (None, None, None), None
+        mean, self.mean_request, self._mean_ready = self.mean_request, None, None
         for out, fld, op, wall in ((t1, u, x.stagder_v2p, walls[0]), (t2, v, x.interpl_v2p, walls[1]),
                                    (t3, w, x.interpl_v2p, walls[2])):
             spec = upd.pop(fld.data.data_ptr(), None)
@@ -380,6 +395,9 @@ class Solver:
                 if wall is not None:
                     b.field_set_face_from_field(fld, wall, 0.0, Y_FACE)
                 b.tds_apply(out, fld, op, DIR_X)
+            elif fld is u and mean is not None and defer_grad and b.comm.size == 1:
+                sh = b.tds_lincomb(out, op, DIR_X, *spec, wall=wall, mean_target=mean)
+                self._mean_ready = (u.data.data_ptr(), float(mean), sh, b.red_epoch)
             else:
                 b.tds_lincomb(out, op, DIR_X, *spec, wall=wall)
         self.time_integrator.flush_updates()
@@ -542,6 +560,17 @@ class Solver:
         b.tds_apply(u, g[0], x.stagder_p2v, DIR_X, accumulate=True, scale=-1.0)
         b.tds_apply(v, g[1], x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
         b.tds_apply(w, g[2], x.interpl_p2v, DIR_X, accumulate=True, scale=-1.0)
+
+    def take_mean_shift(self, f, target):
+        """the device scalar of field_mean_shift(f, target) if the kernel that formed f took the integral along
+        (pressure_correction_fused) and f has not changed since -- its velocity correction is still pending -- and no other
+        reduction has used the backend's buffer; else None"""
+        r, self._mean_ready = self._mean_ready, None
+        if (r is None or self.pending_grad is None or r[0] != f.data.data_ptr() or r[1] != float(target)
+                or r[3] != self.backend.red_epoch):
+            return None
+        self.n_mean_taken += 1
+        return r[2]
 
     def flush_grad(self):
         """apply a pending velocity correction now (anything that reads u, v, w before the next transeq)"""
