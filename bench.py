@@ -560,6 +560,35 @@ def main():
         sync_all()
         exchanges = comm.timing_report() if comm.timed else None
         comm.timed = False
+        # N > 1 (round 6): the same step once more with the exchanges ORDERED on the compute stream (no overlap) and once
+        # as timed -- what the overlap hides, and how much exchange time stays exposed, from this very run
+        overlap_report = None
+        if comm.size > 1 or getattr(comm, "self_via_nccl", False):
+            def one_step(ordered):
+                nonlocal it
+                keep = comm.overlap
+                if ordered:
+                    comm.overlap = False
+                sync_all()
+                t1 = time.perf_counter()
+                it += 1
+                case.step(it)
+                sync_all()
+                dt = time.perf_counter() - t1
+                comm.overlap = keep
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                return dt * 1e3
+            ms_over, ms_ord = one_step(False), one_step(True)
+            xms = sum(v["ms"] for v in (exchanges or {}).values())
+            overlap_report = {"one_step_overlapped_ms": ms_over, "one_step_ordered_ms": ms_ord,
+                              "hidden_by_overlap_ms": ms_ord - ms_over,
+                              "exchange_ms_one_step": xms,
+                              "exposed_exchange_ms": max(0.0, xms - max(0.0, ms_ord - ms_over)),
+                              "overlap_active": bool(comm.overlap) and not getattr(comm, "host_staged", False),
+                              "note": "max over ranks; exposed = the exchanges' own HIP-event time minus what ordering them costs"}
         prof = {"note": "one extra step after the timed region, all classes timed"}
         for kind in backend.KINDS:
             n_l, ms = backend.prof_get(kind)
@@ -752,6 +781,7 @@ def main():
                        # exchanges of ONE step after the timed region, HIP events on the stream they were posted from:
                        # sendrecv = halo rows + boundary values of the decomposed direction, alltoall = Poisson transposes
                        "exchanges_one_step": exchanges,
+                       "overlap_report": overlap_report,
                        # 000 solve at 512^3 on one rank: transforms ordered z, x, y with the z transforms inside the
                        # neighbouring z operator pairs (csrc/zfirst.hip); counted pressure corrections of the fused driver
                        "poisson_z_first": (int(case.solver.n_zfirst) if not args.lazy
@@ -774,7 +804,10 @@ def main():
                              "unit": r["unit"], "frac": r["frac"], "traffic": r.get("traffic"),
                              "avg_launch_ms": r["avg_launch_ms"],
                              "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]},
-                "exchanges_one_step": o["config"].get("exchanges_one_step")}
+                "exchanges_one_step": o["config"].get("exchanges_one_step"),
+                "overlap_report": o["config"].get("overlap_report"),
+                "overlap_self_check": o["config"].get("overlap_self_check"),
+                "comm_stream_probe_ms": o["config"].get("comm_stream_probe_ms")}
 
     if args.case == "tgv" and args.gpus > 1 and requested == "auto" and os.environ.get("X3D_BENCH_ONE_LAYOUT") != "1":
         # N > 1: BOTH layouts in one run -- the validated default (y slabs: one all-to-all pair per solve over all links)

@@ -214,6 +214,8 @@ int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, x3d_real *du, const x3d_
  * asks for (src/case/channel.f90:66-72) taken while the rows of the new u are in the kernel's registers (1024-row x
  * pencils; elsewhere the two calls one after the other).  *shift: as x3d_field_mean_shift's (valid until the next
  * reduction of this backend); the partial sums are formed in another order than x3d_field_mean_shift's: round-off apart. */
+int x3d_tds_solve_mean(x3d_backend *b, x3d_real *du, const x3d_real *u, const x3d_tdsops *t, int dir, const int dims[3],
+                       x3d_real ncell, x3d_real target, const x3d_real **shift);  /* = x3d_tds_solve ; x3d_field_mean_shift(u) */
 int x3d_tds_solve_lincomb_wall_mean(x3d_backend *b, int dir, x3d_real *du, const x3d_tdsops *t, x3d_real *y,
                                     const x3d_real *base, int nterm, const x3d_real *c, const x3d_real *const *x,
                                     const x3d_real *wall, const int dims[3], x3d_real ncell, x3d_real target,
@@ -535,6 +537,16 @@ int x3d_poisson_zfirst_middle(x3d_poisson *p);
 int x3d_poisson_zfirst_forward(x3d_poisson *p, const x3d_real *f_in);
 int x3d_poisson_zfirst_backward(x3d_poisson *p, x3d_real *f_out);
 int x3d_poisson_solve_000_zfirst(x3d_poisson *p, x3d_real *f);
+/* round 6: the same reordering for the channel's solve -- poisson_010 (src/poisson_fft.f90:228-242) on a stretched y with
+ * 256 cell rows, nx = 1024, nz = 512: fft_postprocess_010's y stage (src/backend/cuda/poisson_fft.f90:822-924) works
+ * column by column of (x mode, z mode), so the half axis may be z here too.  x3d_poisson_set_stretching_zfirst hands over
+ * the pentadiagonal operators in that layout -- [5][nz/2+1][n][nx], every x mode (wave numbers mirrored above nx / 2 as
+ * the reference mirrors them, :833-882), z modes 0 .. nz / 2 -- after x3d_poisson_set_stretching; x3d_poisson_zfirst_ok
+ * then says 1 and x3d_tds_pair_zfirst / x3d_poisson_zfirst_middle serve the solve as above (the pairs also do the
+ * solver's interleave of the y rows).  X3D_NO_ZFIRST010=1: never.  x3d_poisson_solve_010_rows_zfirst: the stand-alone
+ * form on a field whose rows are interleaved already == x3d_poisson_solve_010_rows up to rounding. */
+int x3d_poisson_set_stretching_zfirst(x3d_poisson *p, int sym, const x3d_real *a0, const x3d_real *a1);
+int x3d_poisson_solve_010_rows_zfirst(x3d_poisson *p, x3d_real *f);
 int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
                         const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
 

@@ -43,6 +43,18 @@ def main():
     s.divergence_v2p(div_u, s.u, s.v, s.w)
     after, _ = b.field_max_mean(div_u)
     del case, s, b, al
+    from util import assert_signature, load_big_steps, signature_of
+    fix = load_big_steps()
+    if fix is not None and "pc512.div_max" in fix and os.environ.get("X3D_TEST_RUN_ORACLE") != "1":
+        # round 6: the oracle's side of this test comes stored (oracle/gen_step_fixtures.py, case pc512: signatures of the
+        # oracle's u, v, w after pressure_correction on the same noisy_tgv input); X3D_TEST_RUN_ORACLE=1 runs it here instead
+        for g, nm in zip(got, "uvw"):
+            assert_signature(g, signature_of(fix, "pc512." + nm), 1e-11, nm)
+        omx = float(fix["pc512.div_max"])
+        print("PC512 zfirst=%d against the stored oracle signatures: ok; max|div u| before %.3e after %.3e (oracle after %.3e)"
+              % (want_zfirst, before, after, omx), flush=True)
+        assert after < max(1e-10, 10.0 * omx) and after < 1e-9 * before, (before, after, omx)
+        return
     twopi = 6.283185307179586
     om = orc.Mesh([n] * 3, [1, 1, 1], [twopi] * 3, ["periodic"] * 2, ["periodic"] * 2, ["periodic"] * 2)
     o = orc.Solver(om, poisson="FFT")

@@ -8,7 +8,7 @@ FP64; tolerances stated per assertion."""
 import numpy as np
 import pytest
 
-from util import load_golden, namelist, product_mesh, read_csv, relerr
+from util import assert_signature, load_big_steps, load_golden, namelist, product_mesh, read_csv, relerr, signature_of
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -309,22 +309,54 @@ def test_channel_step_at_the_bench_size_two_poisson_forms(monkeypatch):
     from x3d2_amd import make_channel
     dims = (1024, 257, 512)
     out = []
-    for no_y010 in ("0", "1"):
-        monkeypatch.setenv("X3D_NO_Y010", no_y010)
+    # round 6: the default is the z-first form (csrc/zfirst.hip: z transforms on the tiles of the z operator pairs, complex
+    # 1024-point x transforms, the y pass on [kz][y][x] with every x mode); X3D_NO_ZFIRST010=1: round 5's x-first form of the
+    # same y pass; X3D_NO_Y010=1: the 3-D transforms + stand-alone kernels
+    for envs, zf in (((), 3), (("X3D_NO_ZFIRST010",), 0), (("X3D_NO_ZFIRST010", "X3D_NO_Y010"), 0)):
+        for k in ("X3D_NO_ZFIRST010", "X3D_NO_Y010"):
+            monkeypatch.delenv(k, raising=False)
+        for k in envs:
+            monkeypatch.setenv(k, "1")
         case = make_channel(dims, fused=True, rotation=True, omega_rot=0.12, n_rotate=2)
         case.step(1)
         s = case.solver
+        assert s.n_zfirst == zf
         _, ens, dmax, _ = case.postprocess(1, 0.005)
         out.append(([s.backend.get_field_data(f) for f in (s.u, s.v, s.w)], ens, dmax))
         del case, s
         gc.collect()
         torch.cuda.empty_cache()
-    (fa, ea, da), (fb, eb, db) = out
-    for x, y, nm in zip(fa, fb, "uvw"):
-        assert np.max(np.abs(x - y)) < 1e-11 * max(np.max(np.abs(y)), 1.0), nm
-        assert np.max(np.abs(x - y)) > 0.0, nm  # (two different routes)
-    assert abs(ea - eb) < 1e-11 * abs(eb)
-    assert da < 1e-9 and db < 1e-9, (da, db)
+    (fz, ez, dz), (fa, ea, da), (fb, eb, db) = out
+    for ref, other in ((fb, fa), (fb, fz)):
+        for x, y, nm in zip(other, ref, "uvw"):
+            assert np.max(np.abs(x - y)) < 1e-11 * max(np.max(np.abs(y)), 1.0), nm
+            assert np.max(np.abs(x - y)) > 0.0, nm  # (different routes)
+    assert abs(ea - eb) < 1e-11 * abs(eb) and abs(ez - eb) < 1e-11 * abs(eb)
+    assert da < 1e-9 and db < 1e-9 and dz < 1e-9, (da, db, dz)
+
+
+@pytest.mark.parametrize("stretching,beta", [("top-bottom", 0.259065151), ("bottom", 0.3)])
+def test_zfirst_form_of_the_010_solve_vs_the_x_first_form(stretching, beta):
+    """x3d_poisson_solve_010_rows_zfirst (round 6: z transform ; complex x transform over all 1024 modes ; y pass on the
+    half-z spectrum with the operators of x3d_poisson_set_stretching_zfirst ; back) against x3d_poisson_solve_010_rows
+    (rocFFT x and z, y pass on the half-x spectrum) on one random right-hand side at the channel's size: the same solve,
+    every transform and the factored operators in another layout -- 1e-11; sym (odd / even systems) and the full system"""
+    import torch
+    from x3d2_amd.common import CELL, DIR_C
+    s = product_solver((1024, 257, 512), stretching, beta)
+    b, al, pf = s.backend, s.backend.allocator, s.backend.poisson_fft
+    assert pf.zfirst_ok() and pf.stretched_y_sym == (stretching == "top-bottom")
+    f1, f2 = al.get_block(DIR_C, CELL), al.get_block(DIR_C, CELL)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    rhs = torch.randn(tuple(f1.data.shape), generator=g, dtype=torch.float64)
+    f1.data.copy_(rhs.to(f1.data.device))
+    f2.data.copy_(f1.data)
+    pf.solve_interleaved(f1)
+    pf.solve_interleaved_zfirst(f2)
+    x, y = b.get_field_data(f2, CELL), b.get_field_data(f1, CELL)
+    assert np.all(np.isfinite(x))
+    assert np.max(np.abs(x - y)) < 1e-11 * np.max(np.abs(y)) and np.max(np.abs(x - y)) > 0.0
+    al.release_block(f1); al.release_block(f2)
 
 
 @pytest.mark.parametrize("dims", [(1024, 33, 16), (256, 33, 16)])
@@ -558,6 +590,12 @@ def test_volume_integral_taken_by_the_kernel_that_forms_the_field(nx, loc):
     assert np.array_equal(b.get_field_data(y1, dl), b.get_field_data(y2, dl))
     assert np.array_equal(b.get_field_data(o1, dl), b.get_field_data(o2, dl))
     assert abs(v1 - v2) < 1e-14 * max(abs(v2), 1.0) and (nx == 1024 or v1 == v2)
+    # ... and by the plain operator's kernel (x3d_tds_solve_mean: the form the bench's sub-step takes -- its RK stage is done by
+    # transeq's z launch, so the divergence's first x operator is the first kernel to read the new u)
+    o1.fill(0.0)
+    v3 = scalar(b.tds_apply_mean(o1, y2, x.stagder_v2p, DIR_X, 2.0 / 3.0))
+    assert np.array_equal(b.get_field_data(o1, dl), b.get_field_data(o2, dl))
+    assert abs(v3 - v2) < 1e-14 * max(abs(v2), 1.0) and (nx == 1024 or v3 == v2)
     for f in blk:
         al.release_block(f)
 
@@ -595,6 +633,9 @@ def test_channel_step_with_the_wall_values_stamped_inside_the_divergence_kernels
     """fused channel step with apply_BC folded into the kernels that form the new velocity == the step with the
     stage, the stamping and the operators as separate launches (X3D_NO_DEFER_WALLS=1), bit for bit"""
     # (div_bound: the residual of these very coarse grids is the algorithm's, equal to the oracle's; not bounded here)
+    # (round 6: the bulk-velocity integral taken by whichever kernel forms / first reads the new u sums in that kernel's order:
+    #  both runs take it by x3d_field_mean_shift here, so that the wall stamping is ALL that differs between them)
+    monkeypatch.setenv("X3D_NO_MEAN_IN_LINCOMB", "1")
     case = _channel_steps(dims, "top-bottom", 0.259065151, True, 1, div_bound=None)
     monkeypatch.setenv("X3D_NO_DEFER_WALLS", "1")
     plain = _channel_steps(dims, "top-bottom", 0.259065151, True, 1, div_bound=None)
@@ -607,6 +648,28 @@ def _channel_steps(dims, stretching, beta, fused, nsteps, div_bound=1e-6):
     from x3d2_amd.common import VERT
     case = make_channel(dims, stretching=stretching, beta=beta, fused=fused, rotation=True, omega_rot=0.12,
                         n_rotate=2)
+    key = "channel%dx%dx%d" % tuple(dims)
+    fix = load_big_steps()
+    if (fix is not None and key + ".enstrophy" in fix and nsteps == 1 and stretching == "top-bottom" and beta == 0.259065151
+            and __import__("os").environ.get("X3D_TEST_RUN_ORACLE") != "1"):
+        # round 6: the bench-size step against the oracle's STORED signatures (oracle/gen_step_fixtures.py restates the
+        # oracle side below; ~60 s of host time per call otherwise)
+        s, m = case.solver, case.solver.mesh
+        X = 2 * np.pi * m.vert_coords[0][None, None, :] / m.L[0]
+        Y = np.pi * m.vert_coords[1][None, :, None] / m.L[1]
+        Z = 2 * np.pi * m.vert_coords[2][:, None, None] / m.L[2]
+        pert = (0.05 * np.sin(X) * np.sin(Y) ** 2 * np.cos(Z), 0.04 * np.cos(X) * np.sin(Y) ** 2 * np.sin(Z),
+                0.03 * np.sin(2 * X) * np.sin(Y) ** 2 * np.cos(Z))
+        for fp, d in zip((s.u, s.v, s.w), pert):
+            s.backend.set_field_data(fp, s.backend.get_field_data(fp) + d)
+        case.step(1)
+        for fp, nm in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
+            assert_signature(s.backend.get_field_data(fp), signature_of(fix, key + "." + nm), 1e-10, nm)
+        _, ens, dmax, dmean = case.postprocess(1, 0.01)
+        eo = (float(fix[key + ".enstrophy"]), float(fix[key + ".div_max"]))
+        assert abs(ens - eo[0]) < 1e-10 * abs(eo[0])
+        assert abs(dmax - eo[1]) < 1e-6 * eo[1] + 1e-12 and (div_bound is None or dmax < div_bound)
+        return case
     o = oracle_solver(dims, stretching, beta)
     o.init_channel(rotation=True, omega_rot=0.12, n_rotate=2)
     # perturb both identically so that all three components are active (smooth: the Nyquist

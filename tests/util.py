@@ -259,3 +259,52 @@ def noisy_tgv(dims, offset, local_dims, amp=0.1):
     v = -np.cos(x) * np.sin(y) * np.cos(z) + amp * hash_noise(gi, gj, gk, 2)
     w = amp * hash_noise(gi, gj, gk, 3) + 0.0 * x * y
     return u, v, w
+
+
+# ---- signatures of large fields (round 6): the 512^3 / 1024 x 257 x 512 oracle runs of the GPU suite (25 s ... 60 s of host
+# time each on the GPU box) are paid ONCE, by oracle/gen_step_fixtures.py, which stores these signatures of the oracle's
+# fields under tests/golden/oracle_big_steps.npz; the GPU tests then compare the HIP fields' signatures with them
+def _sig_axes(shape):
+    return [np.unique(np.linspace(0, n - 1, min(n, 24)).astype(np.int64)) for n in shape]
+
+
+def _sig_weights(shape):
+    """integer-hash weights in [-1, 1): a permutation of rows or planes changes the weighted sum"""
+    nz, ny, nx = shape
+    gk = np.arange(nz, dtype=np.int64)[:, None, None]
+    gj = np.arange(ny, dtype=np.int64)[None, :, None]
+    gi = np.arange(nx, dtype=np.int64)[None, None, :]
+    return (((gi * 7 + gj * 13 + gk * 29 + (gi * gj + gk) * 3) % 64) - 31.5) / 32.0
+
+
+def field_signature(a):
+    """a: [nz, ny, nx] -> {sample (a 24^3 lattice incl. the corners), sum, sumabs, sumsq, wsum, absmax}"""
+    a = np.asarray(a, dtype=np.float64)
+    iz, iy, ix = _sig_axes(a.shape)
+    return {"sample": a[np.ix_(iz, iy, ix)].copy(), "sum": np.float64(a.sum()), "sumabs": np.float64(np.abs(a).sum()),
+            "sumsq": np.float64(np.vdot(a, a)), "wsum": np.float64((a * _sig_weights(a.shape)).sum()),
+            "absmax": np.float64(np.abs(a).max())}
+
+
+def assert_signature(a, sig, rel, what=""):
+    """the field a against a stored signature: every sampled point within rel * absmax; the plain and the hash-weighted
+    sums within 50 sqrt(n) rel absmax (round-off differences of up to rel * absmax per point add up like a random walk; a
+    coherent deviation of a tenth of that per point is caught); the sum of squares within 2 rel absmax sum|a|"""
+    got = field_signature(a)
+    scale = max(float(sig["absmax"]), 1e-300)
+    assert got["sample"].shape == sig["sample"].shape, what
+    assert np.max(np.abs(got["sample"] - sig["sample"])) <= rel * scale, (what, "sample", float(np.max(np.abs(got["sample"] - sig["sample"]))))
+    n = a.size
+    for k in ("sum", "wsum"):
+        assert abs(got[k] - float(sig[k])) <= 50.0 * np.sqrt(n) * rel * scale, (what, k, float(got[k]), float(sig[k]))
+    assert abs(got["sumsq"] - float(sig["sumsq"])) <= 2.0 * rel * scale * float(sig["sumabs"]) + 1e-300, (what, "sumsq")
+    assert abs(got["absmax"] - float(sig["absmax"])) <= rel * scale, (what, "absmax")
+
+
+def load_big_steps():
+    p = os.path.join(GOLDEN, "oracle_big_steps.npz")
+    return dict(np.load(p)) if os.path.exists(p) else None
+
+
+def signature_of(fix, prefix):
+    return {k: fix[prefix + "." + k] for k in ("sample", "sum", "sumabs", "sumsq", "wsum", "absmax")}

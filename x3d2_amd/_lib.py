@@ -94,6 +94,7 @@ PROTOTYPES = {
     "x3d_tds_pair_halo_fix_yperm": (I, [VP, I, VP, VP, VP, VP, VP, I]),
     "x3d_tds_solve_lincomb": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP)]),
     "x3d_tds_solve_lincomb_wall": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), VP]),
+    "x3d_tds_solve_mean": (I, [VP, VP, VP, VP, I, c_int_p, D, D, ctypes.POINTER(VP)]),
     "x3d_tds_solve_lincomb_wall_mean": (I, [VP, I, VP, VP, VP, VP, I, c_double_p, ctypes.POINTER(VP), VP, c_int_p, D, D,
                                             ctypes.POINTER(VP)]),
     "x3d_tds_dist_bwd": (I, [VP, VP, VP, VP, VP, VP, I]),
@@ -147,9 +148,11 @@ PROTOTYPES = {
     "x3d_poisson_enforce_periodicity_y": (I, [VP, VP, VP]),
     "x3d_poisson_undo_periodicity_y": (I, [VP, VP, VP]),
     "x3d_poisson_set_stretching": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
+    "x3d_poisson_set_stretching_zfirst": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
     "x3d_poisson_postprocess_010": (I, [VP]),
     "x3d_poisson_solve_010": (I, [VP, VP, VP]),
     "x3d_poisson_solve_010_rows": (I, [VP, VP]),
+    "x3d_poisson_solve_010_rows_zfirst": (I, [VP, VP]),
     "x3d_poisson_get_spectral": (I, [VP, c_double_p]),
     "x3d_poisson_set_spectral": (I, [VP, c_double_p]),
     "x3d_sfft_create": (I, [VP, ctypes.POINTER(VP), c_int_p, I, I]),

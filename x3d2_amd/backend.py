@@ -745,6 +745,17 @@ class HipBackend:
         _lib.check(self.lib.x3d_tds_pair_zfirst_ok(self.h, t_a.handle, t_b.handle, ctypes.byref(flag)))
         return bool(flag.value)
 
+    def tds_apply_mean(self, du, u, tdsops, direction, mean_target):
+        """tds_apply(du, u) and field_mean_shift(u, mean_target) -- its device scalar is returned -- with the integral taken
+        by the operator's kernel where it can be (x3d_tds_solve_mean: 1024-row x pencils); one rank, local direction"""
+        if u.data_loc == NULL_LOC:
+            raise X3dError("You must set the data_loc before calling volume integral.")
+        out = VP()
+        ncell = float(np.prod(self.mesh.get_global_dims(CELL)))
+        _lib.check(self.lib.x3d_tds_solve_mean(self.h, du.ptr, u.ptr, tdsops.handle, direction, self._dims(u.data_loc), ncell,
+                                               float(mean_target), ctypes.byref(out)))
+        return out
+
     def tds_apply(self, du, u, tdsops, direction, accumulate=False, scale=1.0):
         """tds_solve with an explicit direction; accumulate: du += scale * result"""
         if not self._decomposed(direction):

@@ -282,8 +282,7 @@ class ChannelCase(BaseCase):
         # Offered where the x kernel takes the correction along: 1024-row x pencils (csrc/xwide.hip, k_xwide_transeq3_upd).
         s = self.solver
         return (s.fused and s.backend.comm.size == 1 and int(s.mesh.get_dims(VERT)[0]) == 1024
-                and os.environ.get("X3D_NO_ROT_FUSED") != "1"
-                and os.environ.get("X3D_NO_DEFER_WALLS") != "1" and os.environ.get("X3D_NO_CHANNEL_DEFER_GRAD") != "1"
+                and os.environ.get("X3D_NO_ROT_FUSED") != "1" and os.environ.get("X3D_NO_CHANNEL_DEFER_GRAD") != "1"
                 and type(self).define_BC is ChannelCase.define_BC and type(self).apply_BC is ChannelCase.apply_BC)
 
     def forcings_idle(self, it):

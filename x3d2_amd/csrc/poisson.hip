@@ -107,8 +107,12 @@ extern "C" int x3d_poisson_create(x3d_backend *b, x3d_poisson **out, const int n
         p->nxs = (e && e[0] == '1') ? p->nxm : (p->nxm + 7) / 8 * 8;
     }
     const size_t rows = (size_t)p->nz * p->ny, ns = rows * p->nxs;
-    X3D_HIP(hipMalloc(&p->c, sizeof(real2_t) * ns));
-    X3D_HIP(hipMemset(p->c, 0, sizeof(real2_t) * ns));
+    {   // (room for the z-first layout of the same spectrum too: [nz / 2 + 1][ny][nx + 16], csrc/zfirst.hip)
+        const size_t nzf = (size_t)(p->nz / 2 + 1) * p->ny * (p->nx + 16);
+        p->c_elems = ns > nzf ? ns : nzf;
+    }
+    X3D_HIP(hipMalloc(&p->c, sizeof(real2_t) * p->c_elems));
+    X3D_HIP(hipMemset(p->c, 0, sizeof(real2_t) * p->c_elems));
     X3D_HIP(hipMalloc(&p->waves, sizeof(real_t) * ns));
     if (int rc = upload_pitched(p->waves, waves_re, rows, p->nxm, p->nxs, sizeof(real_t))) return rc;
     if (p->nxs > p->nxm) {
@@ -183,7 +187,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
     if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
     if (p->y010 == 1) { hipfftDestroy(p->plan_x010_fw); hipfftDestroy(p->plan_x010_bw); }
     hipFree(p->c); hipFree(p->waves); hipFree(p->ab); hipFree(p->work); hipFree(p->rwT); hipFree(p->rwZ);
-    hipFree(p->lu[0]); hipFree(p->lu[1]);
+    hipFree(p->lu[0]); hipFree(p->lu[1]); hipFree(p->luz[0]); hipFree(p->luz[1]);
     delete p;
     return 0;
 }
@@ -475,6 +479,28 @@ extern "C" int x3d_poisson_set_stretching(x3d_poisson *p, int sym, const real_t 
     return 0;
 }
 
+// the same operators for the z-first form of the solve (csrc/zfirst.hip): a0 / a1 = [5][nz / 2 + 1][n][nx] dense -- every
+// x mode (the wave numbers above nx / 2 are the mirrored ones, as the reference's are along z, src/poisson_fft.f90:833-882),
+// the z modes 0 .. nz / 2.  Factored once like x3d_poisson_set_stretching's, stored at row pitch nx + 16.
+extern "C" int x3d_poisson_set_stretching_zfirst(x3d_poisson *p, int sym, const real_t *a0, const real_t *a1)
+{
+    X3D_RANGE(__func__);
+    X3D_REQUIRE(p && a0 && (!sym || a1), "x3d_poisson_set_stretching_zfirst: null argument");
+    X3D_REQUIRE(p->stretched && p->sym == sym, "x3d_poisson_set_stretching_zfirst: call x3d_poisson_set_stretching first (same sym)");
+    X3D_REQUIRE(p->nz % 2 == 0 && (!sym || p->ny % 2 == 0), "x3d_poisson_set_stretching_zfirst: even nz (and ny with sym)");
+    const int n = sym ? p->ny / 2 : p->ny, nzh = p->nz / 2 + 1, px = p->nx + 16;
+    const size_t rows = 5 * (size_t)nzh * n, bytes = sizeof(real_t) * rows * px;
+    const real_t *src[2] = {a0, a1};
+    for (int s = 0; s < (sym ? 2 : 1); s++) {
+        if (!p->luz[s]) X3D_HIP(hipMalloc(&p->luz[s], bytes));
+        if (int rc = upload_pitched(p->luz[s], src[s], rows, p->nx, px, sizeof(real_t))) return rc;
+        hipLaunchKernelGGL(k_penta_factor<false>, penta_grid(px, nzh), dim3(64), 0, p->b->stream, p->luz[s], px, n, nzh);
+        X3D_HIP(hipGetLastError());
+    }
+    X3D_HIP(hipStreamSynchronize(p->b->stream));
+    return 0;
+}
+
 extern "C" int x3d_poisson_postprocess_010(x3d_poisson *p)
 {
     X3D_RANGE(__func__);
@@ -499,7 +525,7 @@ extern "C" int x3d_poisson_solve_010(x3d_poisson *p, real_t *f, real_t *temp)
 }
 
 int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, int mode, const real_t *tables, int sym,
-                 real_t *const lu[2], bool *done);
+                 real_t *const lu[2], bool *done, int nzl = 0);
 #define Y010_DEFAULT_FORM 1  // staged (y010.hip has the measurements)
 
 // plans of the y-last form: 2-D transforms over (z, x) -- r2c along x on the pitched block, c2c along z -- batched over

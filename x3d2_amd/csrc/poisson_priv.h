@@ -23,6 +23,9 @@ struct x3d_poisson {
     // stretched y (010): factored pentadiagonal operators, [5][nz][n][nxs] each
     int stretched, sym;   // sym: odd/even rows decoupled (centred, top-bottom); else one full system
     real_t *lu[2];        // sym: odd, even; else lu[0] only
+    real_t *luz[2];       // the same operators for the z-first form of the solve (zfirst.hip): [5][nz/2+1][n][nx + 16] --
+                          // ALL x modes (mirrored above nx / 2 like the z modes of lu), the z modes 0 .. nz / 2
+    size_t c_elems;       // complex numbers allocated behind c (room for either layout)
     // ny = nz = 512: rocFFT does only the contiguous x pass, the strided y / z passes are ours (fft512.hip)
     int fast512;
     int r2c512;  // own single-kernel r2c x pass (fft512.hip) instead of rocFFT's two kernels

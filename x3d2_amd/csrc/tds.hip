@@ -943,11 +943,36 @@ extern "C" int x3d_tds_solve_lincomb_wall(x3d_backend *b, int dir, real_t *du, c
     return tds_solve_lincomb_wall(b, dir, du, t, y, base, nterm, c, x, wall);
 }
 
+// x3d_tds_solve(du, u, t, dir) followed by x3d_field_mean_shift(u, dims, ncell, target, shift) -- the first x operator of
+// the divergence on the new u and the bulk-velocity integral the channel case's next define_BC needs: the 1024-row kernel
+// sums u's rows while it holds them (k_xwide_tds); elsewhere the two calls one after the other
+int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done,
+                  real_t *psum, int ny_sum, int *nsum);
+int x3d_finish_mean_shift(x3d_backend *b, int nparts, real_t ncell, real_t target, const real_t **shift);
+extern "C" int x3d_tds_solve_mean(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int dir, const int dims[3],
+                                  real_t ncell, real_t target, const real_t **shift)
+{
+    X3D_RANGE(__func__);
+    if (b) X3D_LAZY_SYNC(b);
+    X3D_LAZY_EAGER(b);
+    X3D_REQUIRE(b && du && u && t && dims && shift && ncell > 0.0, "x3d_tds_solve_mean: bad argument");
+    X3D_REQUIRE(x3d_dir_ok(dir) && du != u, "x3d_tds_solve_mean: bad dir / du aliases u");
+    if (int rc = check_len(b, t, dir, "tds_solve_mean")) return rc;
+    if (dir == X3D_DIR_X && dims[0] == b->nx && dims[2] == b->nz && dims[1] <= b->ny && dims[1] > 0) {
+        bool done = false;
+        int nsum = 0;
+        if (int rc = x3d_xwide_tds(b, du, u, t, 0, 1.0, &done, b->red_buf, dims[1], &nsum)) return rc;
+        if (done && nsum > 0) return x3d_finish_mean_shift(b, nsum, ncell, target, shift);
+        if (done) return x3d_field_mean_shift(b, u, dims, ncell, target, shift);
+    }
+    if (int rc = x3d_tds_solve_acc(b, du, u, t, dir, 0, 1.0)) return rc;
+    return x3d_field_mean_shift(b, u, dims, ncell, target, shift);
+}
+
 // x3d_tds_solve_lincomb[_wall] (wall may be NULL) followed by x3d_field_mean_shift(y, dims, ncell, target, shift): the
 // channel case's RK stage + apply_BC + first x operator of the divergence, and the bulk-velocity integral its NEXT
 // define_BC needs (src/case/channel.f90:66-72), which the 1024-row kernel forms while y's rows are in its registers
 // (k_xwide_tds_lin) -- one reduction pass over u less per sub-step.  Elsewhere the two calls one after the other.
-int x3d_finish_mean_shift(x3d_backend *b, int nparts, real_t ncell, real_t target, const real_t **shift);
 extern "C" int x3d_tds_solve_lincomb_wall_mean(x3d_backend *b, int dir, real_t *du, const x3d_tdsops *t, real_t *y,
                                                const real_t *base, int nterm, const real_t *c, const real_t *const *x,
                                                const real_t *wall, const int dims[3], real_t ncell, real_t target,

@@ -387,7 +387,8 @@ static bool xdir_tiled()
 }
 
 int x3d_xscan_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done);
-int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done);  // xwide.hip
+int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done,
+                  real_t *psum = nullptr, int ny_sum = 0, int *nsum = nullptr);  // xwide.hip
 int x3d_xscan_transeq(x3d_backend *b, real_t *rhs, const real_t *u, const real_t *conv, real_t nu,
                       const x3d_tdsops *t1, const x3d_tdsops *t2, const x3d_tdsops *t3, int acc, bool *done);
 static bool use_xscan()

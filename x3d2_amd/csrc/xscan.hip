@@ -1201,7 +1201,11 @@ __global__ void __launch_bounds__(1024)
     real2_t *tws = reinterpret_cast<real2_t *>(tile + ZF_AREA_DOUBLES);  // ZF: W512^k behind the 72 KB tile area
     if (ZF && threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
     const long kzs = (long)zf.ny * zf.px;
-    auto zf_row = [&](int tl) { return zf.c + (long)(tl / ntx) * zf.px + (long)(tl % ntx) * 16; };
+    auto zf_row = [&](int tl) {
+        int r = tl / ntx;  // (zf.permn: the 010 solver's row order, as tile_off_p below)
+        if (zf.permn > 0 && r < zf.permn) r = (r & 1) ? zf.permn - ((r + 1) >> 1) : (r >> 1);
+        return zf.c + (long)r * zf.px + (long)(tl % ntx) * 16;
+    };
     // HALO, MODE 0: no room for the next tile's rows next to the second input's (with them in flight across the
     // solves the kernel spills inside the tile loop, and every reload is an exposed memory latency: 1.40 ms
     // against 0.95 for the local form): this tile's rows are requested at its top instead
@@ -1824,9 +1828,12 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
                           const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done, int y0, int nyr)
 {
     *done = false;
-    if (mode < 0 || mode > 1 || b->ny != zf.ny || !x3d_zfirst_pairs_ok(b, ta, tb)) return 0;
-    if (nyr < 0) { y0 = 0; nyr = b->ny; }
-    X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= b->ny, "tds_pair (z-first): rows [%d, %d) of %d", y0, y0 + nyr, b->ny);
+    // (the spectrum may hold fewer rows than the block: the channel's 256 cell rows of 257 -- the pair then leaves the last
+    //  row alone, as the solver's own transforms do)
+    if (mode < 0 || mode > 1 || zf.ny > b->ny || (zf.permn == 0 && zf.ny != b->ny) || !x3d_zfirst_pairs_ok(b, ta, tb)) return 0;
+    if (nyr < 0) { y0 = 0; nyr = zf.ny; }
+    X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= zf.ny, "tds_pair (z-first): rows [%d, %d) of %d", y0, y0 + nyr, zf.ny);
+    X3D_REQUIRE(zf.permn == 0 || (zf.permn == zf.ny && y0 == 0 && nyr == zf.ny), "tds_pair (z-first): interleaved rows, whole blocks only");
     if (nyr == 0) { *done = true; return 0; }
     const size_t lds = sizeof(real_t) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);

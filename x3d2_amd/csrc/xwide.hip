@@ -126,9 +126,11 @@ __device__ __forceinline__ void wide_solve_u(const real_t (&w)[WQ + 8], real_t (
 }
 
 // ---------------------------------------------------------------- tds_solve
+// psum != null (ACC = false only): the sum of u over the pencils of the y rows j < ny_sum rides along, one partial per wave
+// (see k_xwide_tds_lin below: the channel case's bulk-velocity integral)
 template <bool ACC, bool NARROW>
 __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, const real_t *__restrict__ u, XOp t, int np,
-                                                   long pitch, real_t scale)
+                                                   long pitch, real_t scale, real_t *__restrict__ psum, int ny_sum, int ny)
 {
     extern __shared__ real_t lt[];  // [LTC_N(16)] tables, then one strip per wave
     for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
@@ -141,9 +143,16 @@ __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, cons
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
     real_t nxt[16];  // next pencil's pieces, in flight while this one is solved
     if (p0 < np) wide_gload(nxt, u + (long)p0 * pitch, lane);
+    real_t wsum = 0.0;
     for (int p = p0; p < np; p += nwaves) {
         asm volatile("" : "+v"(lane));  // keep the lane-table reads inside the loop
         real_t w[WQ + 8], r[WQ];
+        if (!ACC && psum && p % ny < ny_sum) {  // (wave-uniform)
+            real_t s_ = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; m++) s_ += nxt[m];
+            wsum += s_;
+        }
         {
             real_t b[WQ];
             wide_to_strip(strip, nxt, lane);
@@ -158,6 +167,11 @@ __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, cons
         wave_lds_fence();
         wide_store<ACC>(du + (long)p * pitch, strip, lane, scale);
         wave_lds_fence();
+    }
+    if (!ACC && psum) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+        if (lane == 0) psum[blockIdx.x * (blockDim.x >> 6) + wave] = wsum;
     }
 }
 
@@ -512,9 +526,13 @@ static XOp wide_xop(const x3d_tdsops *t)
 }
 
 // tds_solve along x on 1024-row pencils; *done = false: not served here
-int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done)
+// psum / ny_sum / nsum: as x3d_xwide_tds_lincomb's (the sum of u, acc == 0 only)
+int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops *t, int acc, real_t scale, bool *done,
+                  real_t *psum, int ny_sum, int *nsum)
 {
     *done = false;
+    if (nsum) *nsum = 0;
+    if (acc) psum = nullptr;
     if (!wide_env_on() || !wide_ok(b, t)) return 0;
     const int np = b->ny * b->nz;
     const size_t lds = sizeof(real_t) * (LTC_N(WQ) + 8 * WSTRIP);
@@ -526,12 +544,13 @@ int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops 
     do {                                                                                                        \
         X3D_LDS_OPTIN(b, (k_xwide_tds<A_, N_>));                                                                \
         hipLaunchKernelGGL((k_xwide_tds<A_, N_>), dim3(blocks), dim3(512), lds, b->stream, du, u, wide_xop(t), np, \
-                           (long)b->nxp, A_ ? scale : 1.0);                                                     \
+                           (long)b->nxp, A_ ? scale : 1.0, psum, ny_sum, b->ny);                                \
     } while (0)
     if (acc) { if (narrow) GO(true, true); else GO(true, false); }
     else { if (narrow) GO(false, true); else GO(false, false); }
 #undef GO
     X3D_HIP(hipGetLastError());
+    if (nsum && psum) *nsum = blocks * 8;
     *done = true;
     return 0;
 }

@@ -36,6 +36,8 @@ struct Y010Arg {
     const real_t *ax, *bx, *ay, *by, *az, *bz;  // global tables (spectral010.h)
     const real_t *lu0, *lu1;                    // factored pentadiagonal operators [5][nz][n][nxs]
     int nxs, nz, nx, sym;
+    int nzl;  // z planes held by c and by the factored operators: nz (x-first layout, x modes 0 .. nx / 2) or nz / 2 + 1 (the
+              // z-first layout, csrc/zfirst.hip: ALL x modes -- the rotation's flip above nx / 2 then applies along x)
 };
 
 __device__ __forceinline__ void y010_pair_fw(real2_t *__restrict__ pen, int j0, const Rot &rz, const Rot &rx,
@@ -105,7 +107,7 @@ __device__ __forceinline__ void y010_penta(real2_t *__restrict__ sm, const Y010A
     if (s >= (g.sym ? 2 : 1)) return;
     const int inc = g.sym ? 2 : 1, n = ny / inc;
     const real_t *__restrict__ lu = s ? g.lu1 : g.lu0;
-    const size_t ds = (size_t)g.nz * n * g.nxs;
+    const size_t ds = (size_t)g.nzl * n * g.nxs;
     const real_t *__restrict__ lub = lu + (size_t)kz * n * g.nxs + x0 + x;
 #define LU(j, d) lub[(size_t)((d) - 1) * ds + (size_t)((j) - 1) * g.nxs]
     real_t *__restrict__ pd = reinterpret_cast<real_t *>(sm + x * Y010_P) + ri;
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(512) k_y010(real2_t *__restrict__ c, const rea
     real_t lreg[MODE >= 3 ? ND * 4 : 1];
     real_t tl[4] = {0.0, 0.0, 0.0, 0.0};
     const int inc_ = g.sym ? 2 : 1, n_ = ny / inc_;
-    const size_t ds_ = (size_t)g.nz * n_ * g.nxs;
+    const size_t ds_ = (size_t)g.nzl * n_ * g.nxs;
     if constexpr (MODE >= 3) {
 #pragma unroll
         for (int h = 0; h < 4; h++) {
@@ -354,8 +356,8 @@ __global__ void __launch_bounds__(512) k_y010(real2_t *__restrict__ c, const rea
     }
     __syncthreads();
     real2_t *__restrict__ pen = sm + wave * Y010_P;
-    const int ig = x0 + wave;
-    const Rot rz{g.az[kz], g.bz[kz], (kz + 1) > g.nz / 2 + 1}, rx{g.ax[ig], g.bx[ig], (ig + 1) > g.nx / 2 + 1};
+    const int ig = x0 + wave, it = ig < g.nx ? ig : 0;  // (pad columns: any table entry, their values are never used)
+    const Rot rz{g.az[kz], g.bz[kz], (kz + 1) > g.nz / 2 + 1}, rx{g.ax[it], g.bx[it], (ig + 1) > g.nx / 2 + 1};
     real2_t a[4];
     if (MODE != 1 && MODE != 4) {
 #pragma unroll
@@ -447,8 +449,9 @@ int x3d_fft512_init();
 
 // c[nz][256][nxs], x and z already transformed (mode 0, 2) / still transformed (mode 1, 2).  tables = ax bx ay by az bz
 // back to back (global lengths nx nx ny ny nz nz).  *done = false: not served (other ny, odd row pitch)
+// nzl (0: nz): the z planes c and lu hold -- nz / 2 + 1 with every x mode for the z-first layout
 int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, int mode, const real_t *tables, int sym,
-                 real_t *const lu[2], bool *done)
+                 real_t *const lu[2], bool *done, int nzl)
 {
     *done = false;
     if (ny != 256 || nxs % 8 != 0 || nx % 2 != 0) return 0;
@@ -458,8 +461,9 @@ int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, in
     g.ax = tables; g.bx = g.ax + nx; g.ay = g.bx + nx; g.by = g.ay + ny; g.az = g.by + ny; g.bz = g.az + nz;
     g.lu0 = lu ? lu[0] : nullptr; g.lu1 = lu ? lu[1] : nullptr;
     g.nxs = nxs; g.nz = nz; g.nx = nx; g.sym = sym;
+    g.nzl = nzl > 0 ? nzl : nz;
     const size_t lds = sizeof(real2_t) * (8 * Y010_P + 256) + sizeof(real_t) * (mode == 3 ? 2 * Y010_LD : (mode == 4 ? 3 * Y010_LH : 0));
-    const dim3 grid((unsigned)((size_t)nz * (nxs / 8)));
+    const dim3 grid((unsigned)((size_t)g.nzl * (nxs / 8)));
 #define GO(M_)                                                                                          \
     do {                                                                                               \
         X3D_LDS_OPTIN(b, (k_y010<M_>));                                                                \

@@ -24,6 +24,8 @@ struct ZfArg {
     const real2_t *tw;  // W512^k, first half (fft512.hip)
     int ny;
     long px;
+    int permn;  // > 0: row r < permn of the field sits at the 010 solver's interleaved position in C (enforce_periodicity_y's
+                // order, src/backend/cuda/kernels/spectral_processing.f90:1062-1114): the channel's z-first solve
 };
 
 __device__ __forceinline__ int zf_t2(int m, int x) { return m * 16 + (x ^ (m & 15)); }

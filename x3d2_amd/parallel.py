@@ -146,7 +146,7 @@ class Comm:
         defines the matching between a pair of ranks"""
         if not sends and not recvs:
             return
-        if self.timed and not self.host_staged:
+        if self.timed:  # (host-staged dry runs too: the events then bracket the host's copies, i.e. wall time)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.timed = False

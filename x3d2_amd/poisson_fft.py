@@ -155,6 +155,27 @@ def stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs, xsl=None):
     pf.a_odd, pf.a_even = out["odd"], out["even"]
 
 
+def stretching_matrix_zfirst(pf, mesh, xd, yd, zd, eys, exs, ezs):
+    """the same operators for the z-first form of the 010 solve (csrc/zfirst.hip, round 6): EVERY x mode -- the wave numbers
+    above nx / 2 are the mirrored ones wave_numbers() builds, as the reference's are along z (src/poisson_fft.f90:833-882)
+    -- and the z modes 0 .. nz / 2 only: [5][nz/2+1][n][nx].  stretching_matrix() itself with the mode ranges swapped;
+    returns (a0, a1) for x3d_poisson_set_stretching_zfirst, pf's own matrices stay as they are."""
+    names = ("a_odd", "a_even", "a_full", "trans_x", "trans_y", "trans_z", "stretched_y_sym", "nx_spec", "nz_spec")
+    keep = {k: getattr(pf, k, None) for k in names}
+    had = {k: hasattr(pf, k) for k in names}
+    try:
+        pf.nx_spec, pf.nz_spec = pf.nx_glob, pf.nz_glob // 2 + 1
+        stretching_matrix(pf, mesh, xd, yd, zd, eys, exs, ezs)
+        out = (pf.a_odd, pf.a_even) if pf.stretched_y_sym else (pf.a_full, pf.a_full)
+    finally:
+        for k in names:
+            if had[k]:
+                setattr(pf, k, keep[k])
+            elif hasattr(pf, k):
+                delattr(pf, k)
+    return out
+
+
 def make_poisson_fft(backend, mesh, xdirps, ydirps, zdirps):
     """init_poisson_fft: single-rank 3-D rocFFT plan, or the pencil-decomposed
     solver when the domain is split over ranks"""
@@ -251,6 +272,14 @@ class HipPoissonFFT:
             _lib.check(backend.lib.x3d_poisson_set_stretching(self.h, int(self.stretched_y_sym), dp(a0), dp(a1)))
             if not getattr(self, "keep_matrices", False):  # GBs at production sizes; the device holds the factors
                 self.a_odd = self.a_even = self.a_full = None
+            # the channel's sizes on one rank: the operators once more in the z-first layout (x3d_poisson_zfirst_ok then
+            # offers the solve with its z transforms on the tiles of the neighbouring z operator pairs, csrc/zfirst.hip)
+            if (type(self) is HipPoissonFFT and (self.nx_glob, self.ny_glob, self.nz_glob) == (1024, 256, 512)
+                    and os.environ.get("X3D_NO_ZFIRST010") != "1" and os.environ.get("X3D_NO_ZFIRST") != "1"
+                    and not getattr(backend, "lazy", False)):
+                z0, z1 = stretching_matrix_zfirst(self, mesh, *self._dirps, *self._es)
+                _lib.check(backend.lib.x3d_poisson_set_stretching_zfirst(self.h, int(self.stretched_y_sym), dp(z0), dp(z1)))
+                del z0, z1
 
     def __del__(self):
         try:
@@ -342,7 +371,8 @@ class HipPoissonFFT:
     def zfirst_ok(self):
         """the z-first form of poisson_000 is on offer (512^3 on one rank, csrc/zfirst.hip): the z operator pairs next
         to the solve transform along z on their tiles (HipBackend.tds_pair_zfirst), zfirst_middle() does the rest"""
-        if type(self) is not HipPoissonFFT or self.case != "000" or getattr(self.backend, "lazy", False):
+        # (round 6: also the channel's 010 solve at 1024 x 256 x 512 cells -- the library says which)
+        if type(self) is not HipPoissonFFT or self.case not in ("000", "010") or getattr(self.backend, "lazy", False):
             return False
         ok = ctypes.c_int(0)
         _lib.check(self.backend.lib.x3d_poisson_zfirst_ok(self.h, ctypes.byref(ok)))
@@ -380,6 +410,11 @@ class HipPoissonFFT:
             self.fft_backward(f)
             return
         _lib.check(self.backend.lib.x3d_poisson_solve_010_rows(self.h, f.ptr))
+
+    def solve_interleaved_zfirst(self, f):
+        """solve_interleaved through the z-first stages with the z transforms as kernels of their own (test hook: the fused
+        driver has them inside its z operator pairs, Solver._zfirst_solve)"""
+        _lib.check(self.backend.lib.x3d_poisson_solve_010_rows_zfirst(self.h, f.ptr))
 
     # ---- test hooks
     def get_spectral(self):

@@ -391,11 +391,16 @@ class Solver:
         for out, fld, op, wall in ((t1, u, x.stagder_v2p, walls[0]), (t2, v, x.interpl_v2p, walls[1]),
                                    (t3, w, x.interpl_v2p, walls[2])):
             spec = upd.pop(fld.data.data_ptr(), None)
+            take_mean = fld is u and mean is not None and defer_grad and b.comm.size == 1 and not b._decomposed(DIR_X)
             if spec is None:
                 if wall is not None:
                     b.field_set_face_from_field(fld, wall, 0.0, Y_FACE)
-                b.tds_apply(out, fld, op, DIR_X)
-            elif fld is u and mean is not None and defer_grad and b.comm.size == 1:
+                if take_mean:  # (the stage was done by transeq's z launch: the operator's own kernel sums the new u)
+                    sh = b.tds_apply_mean(out, fld, op, DIR_X, mean)
+                    self._mean_ready = (u.data.data_ptr(), float(mean), sh, b.red_epoch)
+                else:
+                    b.tds_apply(out, fld, op, DIR_X)
+            elif take_mean:
                 sh = b.tds_lincomb(out, op, DIR_X, *spec, wall=wall, mean_target=mean)
                 self._mean_ready = (u.data.data_ptr(), float(mean), sh, b.red_epoch)
             else:
