@@ -664,7 +664,8 @@ def _channel_steps(dims, stretching, beta, fused, nsteps, div_bound=1e-6):
             s.backend.set_field_data(fp, s.backend.get_field_data(fp) + d)
         case.step(1)
         for fp, nm in ((s.u, "u"), (s.v, "v"), (s.w, "w")):
-            assert_signature(s.backend.get_field_data(fp), signature_of(fix, key + "." + nm), 1e-10, nm)
+            sg = signature_of(fix, key + "." + nm)
+            assert_signature(s.backend.get_field_data(fp), sg, 1e-10, nm, scale=max(float(sg["absmax"]), 1.0))
         _, ens, dmax, dmean = case.postprocess(1, 0.01)
         eo = (float(fix[key + ".enstrophy"]), float(fix[key + ".div_max"]))
         assert abs(ens - eo[0]) < 1e-10 * abs(eo[0])

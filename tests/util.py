@@ -286,12 +286,12 @@ def field_signature(a):
             "absmax": np.float64(np.abs(a).max())}
 
 
-def assert_signature(a, sig, rel, what=""):
+def assert_signature(a, sig, rel, what="", scale=None):
     """the field a against a stored signature: every sampled point within rel * absmax; the plain and the hash-weighted
     sums within 50 sqrt(n) rel absmax (round-off differences of up to rel * absmax per point add up like a random walk; a
     coherent deviation of a tenth of that per point is caught); the sum of squares within 2 rel absmax sum|a|"""
     got = field_signature(a)
-    scale = max(float(sig["absmax"]), 1e-300)
+    scale = max(float(sig["absmax"]), 1e-300) if scale is None else float(scale)  # (scale given: an absolute tolerance)
     assert got["sample"].shape == sig["sample"].shape, what
     assert np.max(np.abs(got["sample"] - sig["sample"])) <= rel * scale, (what, "sample", float(np.max(np.abs(got["sample"] - sig["sample"]))))
     n = a.size

@@ -36,6 +36,7 @@ struct Y010Arg {
     const real_t *ax, *bx, *ay, *by, *az, *bz;  // global tables (spectral010.h)
     const real_t *lu0, *lu1;                    // factored pentadiagonal operators [5][nz][n][nxs]
     int nxs, nz, nx, sym;
+    int db;   // 1: the double-buffered sweeps (round 6), 0: the chunk-by-chunk ones
     int nzl;  // z planes held by c and by the factored operators: nz (x-first layout, x modes 0 .. nx / 2) or nz / 2 + 1 (the
               // z-first layout, csrc/zfirst.hip: ALL x modes -- the rotation's flip above nx / 2 then applies along x)
 };
@@ -226,9 +227,113 @@ __device__ __forceinline__ Y010Chain y010_chain(real2_t *__restrict__ sm, const 
 }
 
 // forward sweep + the last two rows; lf = [2][Y010_LD]: diagonal 1 (m2), diagonal 2 (m1); tl = LU(n-1,2), LU(n,3),
-// LU(n-1,3), LU(n-1,4) of this chain (loaded by the caller at kernel start)
+// LU(n-1,3), LU(n-1,4) of this chain (loaded by the caller at kernel start).
+// Round 6: chunks of 4 rows, DOUBLE BUFFERED -- the operands of the next chunk (its multipliers and the right-hand side
+// rows two ahead, which no earlier row has written) are requested before this chunk's dependent updates run, so that an
+// LDS round trip no longer stands between the chunks of the one wave everything else waits for.  Same operations in the
+// same order on every row (k_penta_solve's, spectral010.h).
 template <bool SYM>
 __device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const real_t *__restrict__ lf, const real_t (&tl)[4])
+{
+    constexpr int U = 4, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;  // RS: doubles between a chain's rows in the tile
+    const real_t *__restrict__ m2p = lf + (c.s * n) * 8 + c.s * 8 + c.x;  // row j at m2p[(j - 1) * 8]
+    const real_t *__restrict__ m1p = m2p + Y010_LD;
+    real_t *__restrict__ cp = c.pd;  // row j at cp[(j - 1) * RS]
+    real_t r0 = cp[0], r1 = cp[RS];
+    real_t m1a[U], m2a[U], r2a[U], m1b[U], m2b[U], r2b[U];
+    auto load = [&](real_t (&m1c)[U], real_t (&m2c)[U], real_t (&r2c)[U], int jb) {  // rows jb .. jb + U - 1
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb + u <= n - 2) {
+                m2c[u] = m2p[(jb - 1 + u) * 8];
+                m1c[u] = m1p[(jb - 1 + u) * 8];
+                r2c[u] = cp[(jb - 1 + u + 2) * RS];
+            }
+        }
+    };
+    auto run = [&](const real_t (&m1c)[U], const real_t (&m2c)[U], const real_t (&r2c)[U], int jb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb + u <= n - 2) {
+                real_t r2 = r2c[u];
+                r1 = r1 - m1c[u] * r0;
+                r2 = r2 - m2c[u] * r0;
+                cp[(jb - 1 + u) * RS] = r0;
+                r0 = r1; r1 = r2;
+            }
+        }
+    };
+    load(m1a, m2a, r2a, 1);
+    for (int jb = 1; jb <= n - 2; jb += 2 * U) {
+        load(m1b, m2b, r2b, jb + U);
+        run(m1a, m2a, r2a, jb);
+        load(m1a, m2a, r2a, jb + 2 * U);
+        run(m1b, m2b, r2b, jb + U);
+    }
+    const real_t eps = 1.e-16;
+    const real_t tmp = tl[0], dd = tl[1], inv = tl[2], a4n = tl[3];
+    real_t xn, xn1;
+    if (fabs(dd) > eps) {
+        const real_t tt = tmp / dd;
+        xn = r1 / dd - tt * r0;
+    } else {
+        xn = 0.0;
+    }
+    const real_t q = a4n * inv;
+    xn1 = r0 * inv - xn * q;
+    if (c.zero_line) { xn = 0.0; xn1 = 0.0; }
+    cp[(n - 1) * RS] = xn;
+    cp[(n - 2) * RS] = xn1;
+}
+
+// rows jhi .. jlo (descending) of the backward sweep; lb = [3][Y010_LH]: diagonals 3 (1/a3), 4, 5 of the rows
+// jbase + 1 .. jbase + n/2 (slot = s n/2 + j - jbase - 1); x1, x2 carried by the caller.  Chunks of 4 rows, double buffered
+// like the forward sweep (a row's right-hand side is read before any later row of the sweep writes: rows below are untouched)
+template <bool SYM>
+__device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const real_t *__restrict__ lb, int jhi, int jlo, int jbase,
+                                              real_t &x1, real_t &x2)
+{
+    constexpr int U = 4, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
+    const real_t *__restrict__ ivp = lb + (c.s * (n / 2) - jbase - 1) * 8 + c.s * 8 + c.x;  // row j at ivp[j * 8]
+    const real_t *__restrict__ a4p = ivp + Y010_LH, *__restrict__ a5p = ivp + 2 * Y010_LH;
+    real_t *__restrict__ cp = c.pd - RS;  // row j at cp[j * RS]
+    real_t iva[U], a4a[U], a5a[U], ra[U], ivb[U], a4b[U], a5b[U], rb[U];
+    auto load = [&](real_t (&iv)[U], real_t (&a4)[U], real_t (&a5)[U], real_t (&r)[U], int jb) {  // rows jb, jb - 1, ..
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb - u >= jlo) {
+                iv[u] = ivp[(jb - u) * 8];
+                a4[u] = a4p[(jb - u) * 8];
+                a5[u] = a5p[(jb - u) * 8];
+                r[u] = cp[(jb - u) * RS];
+            }
+        }
+    };
+    auto run = [&](const real_t (&iv)[U], const real_t (&a4)[U], const real_t (&a5)[U], const real_t (&r)[U], int jb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (jb - u >= jlo) {
+                real_t xv = iv[u] * (r[u] - a4[u] * x1 - a5[u] * x2);
+                if (c.zero_line) xv = 0.0;
+                cp[(jb - u) * RS] = xv;
+                x2 = x1; x1 = xv;
+            }
+        }
+    };
+    load(iva, a4a, a5a, ra, jhi);
+    for (int jb = jhi; jb >= jlo; jb -= 2 * U) {
+        load(ivb, a4b, a5b, rb, jb - U);
+        run(iva, a4a, a5a, ra, jb);
+        load(iva, a4a, a5a, ra, jb - 2 * U);
+        run(ivb, a4b, a5b, rb, jb - U);
+    }
+}
+
+// ---- the sweeps of rounds 4-5 (8-row chunks, operands requested chunk by chunk): kept for the A/B (X3D_Y010_NO_DB=1)
+// forward sweep + the last two rows; lf = [2][Y010_LD]: diagonal 1 (m2), diagonal 2 (m1); tl = LU(n-1,2), LU(n,3),
+// LU(n-1,3), LU(n-1,4) of this chain (loaded by the caller at kernel start)
+template <bool SYM>
+__device__ __forceinline__ void y010_sweep_fw_plain(const Y010Chain &c, const real_t *__restrict__ lf, const real_t (&tl)[4])
 {
     constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;  // RS: doubles between a chain's rows in the tile
     const real_t *__restrict__ m2p = lf + (c.s * n) * 8 + c.s * 8 + c.x;  // row j at m2p[(j - 1) * 8]
@@ -277,7 +382,7 @@ __device__ __forceinline__ void y010_sweep_fw(const Y010Chain &c, const real_t *
 // rows jhi .. jlo (descending) of the backward sweep; lb = [3][Y010_LH]: diagonals 3 (1/a3), 4, 5 of the rows
 // jbase + 1 .. jbase + n/2 (slot = s n/2 + j - jbase - 1); x1, x2 carried by the caller
 template <bool SYM>
-__device__ __forceinline__ void y010_sweep_bw(const Y010Chain &c, const real_t *__restrict__ lb, int jhi, int jlo, int jbase,
+__device__ __forceinline__ void y010_sweep_bw_plain(const Y010Chain &c, const real_t *__restrict__ lb, int jhi, int jlo, int jbase,
                                               real_t &x1, real_t &x2)
 {
     constexpr int U = 8, n = SYM ? 128 : 256, RS = SYM ? 4 : 2;
@@ -387,10 +492,10 @@ __global__ void __launch_bounds__(512) k_y010(real2_t *__restrict__ c, const rea
         __syncthreads();
         if (g.sym) {
             const Y010Chain ch = y010_chain<true>(sm, g, kz, x0, lane, wave);
-            if (ch.on) y010_sweep_fw<true>(ch, lst, tl);
+            if (ch.on) { if (g.db) y010_sweep_fw<true>(ch, lst, tl); else y010_sweep_fw_plain<true>(ch, lst, tl); }
         } else {
             const Y010Chain ch = y010_chain<false>(sm, g, kz, x0, lane, wave);
-            if (ch.on) y010_sweep_fw<false>(ch, lst, tl);
+            if (ch.on) { if (g.db) y010_sweep_fw<false>(ch, lst, tl); else y010_sweep_fw_plain<false>(ch, lst, tl); }
         }
     }
     if constexpr (MODE == 4) {  // backward sweeps: rows n-2 .. n/2+1 staged first, rows n/2 .. 1 behind them
@@ -416,9 +521,11 @@ __global__ void __launch_bounds__(512) k_y010(real2_t *__restrict__ c, const rea
             if (!ch.on) return;
             if (upper) {
                 x1 = ch.pd[(n - 2) * RS]; x2 = ch.pd[(n - 1) * RS];
-                y010_sweep_bw<SYM>(ch, lst, n - 2, n / 2 + 1, n / 2, x1, x2);
+                if (g.db) y010_sweep_bw<SYM>(ch, lst, n - 2, n / 2 + 1, n / 2, x1, x2);
+                else y010_sweep_bw_plain<SYM>(ch, lst, n - 2, n / 2 + 1, n / 2, x1, x2);
             } else {
-                y010_sweep_bw<SYM>(ch, lst, n / 2, 1, 0, x1, x2);
+                if (g.db) y010_sweep_bw<SYM>(ch, lst, n / 2, 1, 0, x1, x2);
+                else y010_sweep_bw_plain<SYM>(ch, lst, n / 2, 1, 0, x1, x2);
             }
         };
         if (g.sym) sweep(std::true_type{}, true); else sweep(std::false_type{}, true);
@@ -462,6 +569,9 @@ int x3d_y010_run(x3d_backend *b, real2_t *c, int nxs, int nx, int ny, int nz, in
     g.lu0 = lu ? lu[0] : nullptr; g.lu1 = lu ? lu[1] : nullptr;
     g.nxs = nxs; g.nz = nz; g.nx = nx; g.sym = sym;
     g.nzl = nzl > 0 ? nzl : nz;
+    static int nodb = -1;
+    if (nodb < 0) { const char *e = getenv("X3D_Y010_NO_DB"); nodb = (e && e[0] == '1') ? 1 : 0; }
+    g.db = nodb ? 0 : 1;
     const size_t lds = sizeof(real2_t) * (8 * Y010_P + 256) + sizeof(real_t) * (mode == 3 ? 2 * Y010_LD : (mode == 4 ? 3 * Y010_LH : 0));
     const dim3 grid((unsigned)((size_t)g.nzl * (nxs / 8)));
 #define GO(M_)                                                                                          \
