@@ -54,9 +54,10 @@ contains
     integer, intent(in) :: dims(3), sz, device
     type(hip_allocator_t) :: allocator
     allocator%allocator_t = allocator_t(dims, sz)
-    ! this binding is real(c_double) throughout (ptr_off counts 8-byte reals): refuse the FP32 flavour of the library
-    if (x3d_real_bytes() /= int(c_sizeof(1.0_c_double), c_int)) &
-      error stop 'x3d2 hip backend: the library loaded is not the FP64 build (libx3d2_hip.so); this shim binds real(c_double)'
+    ! this binding was compiled for ONE real kind (x3d_creal: -DSINGLE_PREC or not, like the reference): refuse the other
+    ! flavour of the library instead of misreading every scalar and offset
+    if (x3d_real_bytes() /= int(c_sizeof(1.0_x3d_creal), c_int)) &
+      error stop 'x3d2 hip backend: the library loaded computes in another real kind than this shim was compiled for'
     call x3d_check(x3d_backend_create(allocator%handle, int(dims, c_int), int(device, c_int), c_null_ptr))
   end function hip_allocator_init
 
@@ -91,7 +92,7 @@ contains
   subroutine fill_hip(self, c)
     class(hip_field_t) :: self
     real(dp), intent(in) :: c
-    call x3d_check(x3d_block_fill(self%handle, self%dev, real(c, c_double)))
+    call x3d_check(x3d_block_fill(self%handle, self%dev, real(c, x3d_creal)))
   end subroutine fill_hip
 
   function get_shape_hip(self) result(dims)
@@ -157,7 +158,7 @@ end module m_hip_tdsops
 module m_hip_poisson_fft
   use iso_c_binding
   use mpi
-  use m_common, only: dp, CELL, VERT
+  use m_common, only: dp, CELL, VERT, MPI_X3D2_DP
   use m_field, only: field_t
   use m_mesh, only: mesh_t
   use m_poisson_fft, only: poisson_fft_t
@@ -344,11 +345,11 @@ contains
   end function host_staged
 
   function ptr_off(base, ndoubles) result(p)
-    !! base + ndoubles * 8 bytes
+    !! base + ndoubles reals (8 or 4 bytes each: x3d_creal)
     type(c_ptr), intent(in) :: base
     integer(c_long), intent(in) :: ndoubles
     type(c_ptr) :: p
-    p = transfer(transfer(base, 0_c_intptr_t) + int(8_c_long*ndoubles, c_intptr_t), p)
+    p = transfer(transfer(base, 0_c_intptr_t) + int(int(c_sizeof(1.0_x3d_creal), c_long)*ndoubles, c_intptr_t), p)
   end function ptr_off
 
   subroutine map_peers(self, comm, np, peer)
@@ -421,7 +422,7 @@ contains
     end do
     if (.not. self%d2d) then
       call x3d_check(x3d_copy_to_host(self%backend, self%sh, self%sbuf, int(sum(scnt), c_long)))
-      call MPI_Alltoallv(self%sh, scnt, sdis, MPI_DOUBLE_PRECISION, self%rh, rcnt, rdis, MPI_DOUBLE_PRECISION, &
+      call MPI_Alltoallv(self%sh, scnt, sdis, MPI_X3D2_DP, self%rh, rcnt, rdis, MPI_X3D2_DP, &
                          comm, ierr)
       call x3d_check(x3d_copy_to_device(self%backend, self%rbuf, self%rh, int(sum(rcnt), c_long)))
       return
@@ -881,7 +882,7 @@ contains
       if (self%lazy_on .and. record_distributed(self, dir, nu, dirps)) then
         self%tq_n(dir) = n
         call x3d_check(x3d_transeq(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), &
-                                   dev(w), real(nu, c_double), tds_handle(dirps%der1st), &
+                                   dev(w), real(nu, x3d_creal), tds_handle(dirps%der1st), &
                                    tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), &
                                    tds_handle(dirps%der2nd_sym)))
         call du%set_data_loc(u%data_loc)
@@ -896,7 +897,7 @@ contains
       return
     end if
     call x3d_check(x3d_transeq(self%handle, int(dir, c_int), dev(du), dev(dv), dev(dw), dev(u), dev(v), &
-                               dev(w), real(nu, c_double), tds_handle(dirps%der1st), &
+                               dev(w), real(nu, x3d_creal), tds_handle(dirps%der1st), &
                                tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), &
                                tds_handle(dirps%der2nd_sym)))
     call du%set_data_loc(u%data_loc)
@@ -919,7 +920,7 @@ contains
     if (self%tile_tq(dir) < 0) then
       call x3d_check(x3d_transeq_tile(self%handle, int(dir, c_int), xs(self, 1, 1, dir), xs(self, 1, 2, dir), &
                                       xs(self, 1, 3, dir), xs(self, 1, 4, dir), xr(self, 1, 1, dir), xr(self, 1, 2, dir), &
-                                      real(nu, c_double), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
+                                      real(nu, x3d_creal), tds_handle(dirps%der1st), tds_handle(dirps%der1st_sym), &
                                       tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0_c_int, &
                                       xr(self, 1, 5, dir), xs(self, 1, 6, dir), 0_c_int, 0_c_int, done))
       ! collective: every rank of the run takes the same form (MIN over the ranks' probes)
@@ -960,7 +961,7 @@ contains
     !! x3d_dist_transeq_fn): the pointers are the buffers that hold the handles' data; acc = 1: du, dv, dw are added to
     type(c_ptr), value :: user, du, dv, dw, u, v, w, t0, t1, t2, t3
     integer(c_int), value :: dir, acc
-    real(c_double), value :: nu
+    real(x3d_creal), value :: nu
     type(c_ptr) :: rhs(3), fld(3)
     if (dir == DIR_Y) then
       rhs = [dv, du, dw]; fld = [v, u, w]
@@ -982,7 +983,7 @@ contains
     class(hip_backend_t) :: self
     integer, intent(in) :: dir, acc, n
     type(c_ptr), intent(in) :: rhs(3), fld(3), t0, t1, t2, t3
-    real(c_double), intent(in) :: nu
+    real(x3d_creal), intent(in) :: nu
     type(c_ptr) :: r(3), f(3)
     integer(c_int) :: done
     ! (x3d_transeq_tile / _halo_fix take u, v, w and du, dv, dw in variable order)
@@ -1028,7 +1029,7 @@ contains
     ! taken as zero, ONE exchange of this rank's nine boundary values per pencil, and the correction they add on the
     ! boundary strips -- the same linear system as the three sweep / exchange / sweep rounds below (DESIGN 5.1)
     if (one_pass_verdict(self, dir, nu, dirps) == 1) then
-      call transeq_one_pass(self, dir, rhs, fld, real(nu, c_double), tds_handle(dirps%der1st), &
+      call transeq_one_pass(self, dir, rhs, fld, real(nu, x3d_creal), tds_handle(dirps%der1st), &
                             tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), tds_handle(dirps%der2nd_sym), 0, n)
       return
     end if
@@ -1050,7 +1051,7 @@ contains
                                           xr(self, 2, 1, dir), t1, t2, t3))
       call sendrecv_set(self, dir, 4, 3*np)
       call x3d_check(x3d_transeq_dist_bwd(self%handle, int(dir, c_int), rhs(i), xs(self, 1, 4, dir), xr(self, 1, 4, dir), &
-                                          xr(self, 2, 4, dir), fld(1), real(nu, c_double), t1, t2, t3))
+                                          xr(self, 2, 4, dir), fld(1), real(nu, x3d_creal), t1, t2, t3))
     end do
   end subroutine transeq_dist
 
@@ -1110,14 +1111,14 @@ contains
                                             xr(self, 2, 2, d), t1, t2, t3))
         call sendrecv_set(self, d, 4, 3*np)
         call x3d_check(x3d_transeq_dist_bwd(self%handle, int(d, c_int), dev(dspec), xs(self, 1, 4, d), xr(self, 1, 4, d), &
-                                            xr(self, 2, 4, d), dev(uvw), real(nu, c_double), t1, t2, t3))
+                                            xr(self, 2, 4, d), dev(uvw), real(nu, x3d_creal), t1, t2, t3))
       end block
       call dspec%set_data_loc(spec%data_loc)
       return
     end if
     ! local direction: periodic / boundary closures need no exchange
     call x3d_check(x3d_transeq_species(self%handle, int(dirps%dir, c_int), dev(dspec), dev(uvw), dev(spec), &
-                                       real(nu, c_double), tds_handle(dirps%der1st), &
+                                       real(nu, x3d_creal), tds_handle(dirps%der1st), &
                                        tds_handle(dirps%der1st_sym), tds_handle(dirps%der2nd), 0_c_int))
     call dspec%set_data_loc(spec%data_loc)
   end subroutine
@@ -1227,7 +1228,7 @@ contains
       tmp = g_backend%pair_tmp
       call tds_one_pass(g_backend, d, 2, out1, c_null_ptr, in1, c_null_ptr, ta, c_null_ptr)
       call tds_one_pass(g_backend, d, 2, tmp, c_null_ptr, in2, c_null_ptr, tb, c_null_ptr)
-      call x3d_check(x3d_vecadd(g_backend%handle, 1.0_c_double, tmp, 1.0_c_double, out1))
+      call x3d_check(x3d_vecadd(g_backend%handle, 1.0_x3d_creal, tmp, 1.0_x3d_creal, out1))
     end if
   end function dist_tds_cb
 
@@ -1373,7 +1374,7 @@ contains
     class(field_t), intent(inout) :: y
     if (x%dir /= y%dir) error stop 'Called vector add with incompatible fields'
     if (y%dir == DIR_C) error stop 'vecadd does not support DIR_C fields'
-    call x3d_check(x3d_vecadd(self%handle, real(a, c_double), dev(x), real(b, c_double), dev(y)))
+    call x3d_check(x3d_vecadd(self%handle, real(a, x3d_creal), dev(x), real(b, x3d_creal), dev(y)))
   end subroutine
   subroutine vecmult_hip(self, y, x)
     class(hip_backend_t) :: self
@@ -1387,7 +1388,7 @@ contains
   real(dp) function scalar_product_hip(self, x, y) result(s)
     class(hip_backend_t) :: self
     class(field_t), intent(in) :: x, y
-    real(c_double) :: v
+    real(x3d_creal) :: v
     integer :: ierr
     if ((x%data_loc == NULL_LOC) .or. (y%data_loc == NULL_LOC)) then
       error stop 'You must set the data_loc before calling scalar product'
@@ -1404,7 +1405,7 @@ contains
     class(field_t), intent(in) :: f
     integer, optional, intent(in) :: enforced_data_loc
     integer :: data_loc, ierr
-    real(c_double) :: mx, sm
+    real(x3d_creal) :: mx, sm
     if (f%data_loc == NULL_LOC .and. (.not. present(enforced_data_loc))) then
       error stop 'The input field to hip::field_max_mean does not have a valid f%data_loc.'
     end if
@@ -1425,7 +1426,7 @@ contains
     integer, intent(in) :: i_slice
     integer, optional, intent(in) :: enforced_data_loc
     integer :: data_loc
-    real(c_double) :: mx, sm
+    real(x3d_creal) :: mx, sm
     data_loc = f%data_loc
     if (present(enforced_data_loc)) data_loc = enforced_data_loc
     if (data_loc == NULL_LOC) error stop 'slice_max_sum needs a valid data_loc'
@@ -1438,19 +1439,19 @@ contains
     class(hip_backend_t) :: self
     class(field_t), intent(in) :: f
     real(dp), intent(in) :: a
-    call x3d_check(x3d_field_scale(self%handle, dev(f), real(a, c_double)))
+    call x3d_check(x3d_field_scale(self%handle, dev(f), real(a, x3d_creal)))
   end subroutine
   subroutine field_shift_hip(self, f, a)
     class(hip_backend_t) :: self
     class(field_t), intent(in) :: f
     real(dp), intent(in) :: a
-    call x3d_check(x3d_field_shift(self%handle, dev(f), real(a, c_double)))
+    call x3d_check(x3d_field_shift(self%handle, dev(f), real(a, x3d_creal)))
   end subroutine
 
   real(dp) function field_volume_integral_hip(self, f) result(s)
     class(hip_backend_t) :: self
     class(field_t), intent(in) :: f
-    real(c_double) :: v
+    real(x3d_creal) :: v
     integer :: ierr
     if (f%data_loc == NULL_LOC) error stop 'You must set the data_loc before calling volume integral.'
     if (f%dir /= DIR_X) error stop 'Volume integral can only be called on DIR_X fields.'
@@ -1469,7 +1470,7 @@ contains
     if (f%dir /= DIR_X) error stop 'Setting a field face is only supported for DIR_X fields.'
     if (f%data_loc == NULL_LOC) error stop 'field_set_face require a valid data_loc.'
     call x3d_check(x3d_field_set_face(self%handle, dev(f), int(self%mesh%get_dims(f%data_loc), c_int), &
-                                      real(c_start, c_double), real(c_end, c_double), int(face, c_int)))
+                                      real(c_start, x3d_creal), real(c_end, x3d_creal), int(face, c_int)))
   end subroutine field_set_face_hip
 
   subroutine field_set_face_from_field_hip(self, f, f_start, c_end, face, bc_start, bc_end, flow_rate_diff)
@@ -1487,7 +1488,7 @@ contains
     if (f%data_loc == NULL_LOC) error stop 'field_set_face_from_field: requires a valid data_loc.'
     call x3d_check(x3d_field_set_face_from_field(self%handle, dev(f), dev(f_start), &
                                                  int(self%mesh%get_dims(f%data_loc), c_int), &
-                                                 real(c_end, c_double), int(face, c_int), real(frd, c_double)))
+                                                 real(c_end, x3d_creal), int(face, c_int), real(frd, x3d_creal)))
   end subroutine field_set_face_from_field_hip
 
   subroutine compute_vorticity_hip(self, field_out, dudx, dudy, dudz, dvdx, dvdy, dvdz, dwdx, dwdy, dwdz)

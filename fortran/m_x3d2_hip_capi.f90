@@ -9,6 +9,15 @@ module m_x3d2_hip_capi
   use iso_c_binding
   implicit none
 
+  !> the C type behind x3d_real (include/x3d2_hip.h): real(c_double) for libx3d2_hip.so, real(c_float) for libx3d2_hip_sp.so
+  !> -- compile with -DSINGLE_PREC like the reference itself (src/common.f90:6-12) and link the FP32 flavour; the backend
+  !> checks x3d_real_bytes() against this kind before its first call
+#ifdef SINGLE_PREC
+  integer, parameter :: x3d_creal = c_float
+#else
+  integer, parameter :: x3d_creal = c_double
+#endif
+
   interface
     function x3d_last_error() bind(C, name='x3d_last_error') result(msg)
       import :: c_ptr
@@ -98,20 +107,20 @@ module m_x3d2_hip_capi
       type(c_ptr), intent(out) :: blk
     end function
     integer(c_int) function x3d_block_fill(b, f, c) bind(C, name='x3d_block_fill')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), value :: c
+      real(x3d_creal), value :: c
     end function
     ! alloc_tdsops: device copy of the arrays tdsops_init produced on the host
     integer(c_int) function x3d_tdsops_create(b, t, n_tds, n_rhs, move, periodic, coeffs, &
                                               coeffs_s, coeffs_e, dist_fw, dist_bw, dist_sa, &
                                               dist_sc, dist_af, stretch, stretch_correct) &
       bind(C, name='x3d_tdsops_create')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b
       type(c_ptr), intent(out) :: t
       integer(c_int), value :: n_tds, n_rhs, move, periodic
-      real(c_double), intent(in) :: coeffs(*), coeffs_s(*), coeffs_e(*), dist_fw(*), dist_bw(*), &
+      real(x3d_creal), intent(in) :: coeffs(*), coeffs_s(*), coeffs_e(*), dist_fw(*), dist_bw(*), &
                                     dist_sa(*), dist_sc(*), dist_af(*), stretch(*), stretch_correct(*)
     end function
     ! tds_solve
@@ -123,10 +132,10 @@ module m_x3d2_hip_capi
     ! transeq_x / transeq_y / transeq_z
     integer(c_int) function x3d_transeq(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, &
                                         der2nd, der2nd_sym) bind(C, name='x3d_transeq')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der1st_sym, der2nd, der2nd_sym
       integer(c_int), value :: dir
-      real(c_double), value :: nu
+      real(x3d_creal), value :: nu
     end function
     ! distributed phases of exec_dist_tds_compact / exec_dist_transeq_compact
     integer(c_int) function x3d_npencils(b, dir) bind(C, name='x3d_npencils')
@@ -161,10 +170,10 @@ module m_x3d2_hip_capi
     end function
     integer(c_int) function x3d_transeq_dist_bwd(b, dir, rhs, send_s, recv_s, recv_e, conv, nu, t_du, t_dud, t_d2u) &
       bind(C, name='x3d_transeq_dist_bwd')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, rhs, send_s, recv_s, recv_e, conv, t_du, t_dud, t_d2u
       integer(c_int), value :: dir
-      real(c_double), value :: nu
+      real(x3d_creal), value :: nu
     end function
     ! Poisson 100: copy between the block layouts of a backend and of its x <-> y transposed twin
     integer(c_int) function x3d_transpose_xy(b_src, b_dst, dst, src, nx, ny, nz) bind(C, name='x3d_transpose_xy')
@@ -223,18 +232,18 @@ module m_x3d2_hip_capi
     integer(c_int) function x3d_transeq_tile(b, dir, du, dv, dw, u, v, w, nu, der1st, der1st_sym, der2nd, der2nd_sym, &
                                              accumulate, halo_recv, bnd_send, other0, nother, done) &
       bind(C, name='x3d_transeq_tile')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der1st_sym, der2nd, der2nd_sym, halo_recv, bnd_send
       integer(c_int), value :: dir, accumulate, other0, nother
-      real(c_double), value :: nu
+      real(x3d_creal), value :: nu
       integer(c_int), intent(out) :: done
     end function
     integer(c_int) function x3d_transeq_halo_fix(b, dir, du, dv, dw, u, v, w, nu, der1st, der2nd, bnd_recv) &
       bind(C, name='x3d_transeq_halo_fix')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, du, dv, dw, u, v, w, der1st, der2nd, bnd_recv
       integer(c_int), value :: dir
-      real(c_double), value :: nu
+      real(x3d_creal), value :: nu
     end function
     integer(c_int) function x3d_tds_pair_tile(b, dir, mode, out1, out2, in1, in2, ta, tb, halo_recv, bnd_send, other0, &
                                               nother, done) bind(C, name='x3d_tds_pair_tile')
@@ -276,15 +285,15 @@ module m_x3d2_hip_capi
       integer(c_long), value :: n
     end function
     integer(c_int) function x3d_copy_to_host(b, host, dev, n) bind(C, name='x3d_copy_to_host')
-      import :: c_ptr, c_int, c_long, c_double
+      import :: c_ptr, c_int, c_long, x3d_creal
       type(c_ptr), value :: b, dev
-      real(c_double), intent(out) :: host(*)
+      real(x3d_creal), intent(out) :: host(*)
       integer(c_long), value :: n
     end function
     integer(c_int) function x3d_copy_to_device(b, dev, host, n) bind(C, name='x3d_copy_to_device')
-      import :: c_ptr, c_int, c_long, c_double
+      import :: c_ptr, c_int, c_long, x3d_creal
       type(c_ptr), value :: b, dev
-      real(c_double), intent(in) :: host(*)
+      real(x3d_creal), intent(in) :: host(*)
       integer(c_long), value :: n
     end function
     ! pencil-decomposed 000 Poisson solver: local stages (csrc/pfft.hip); the caller exchanges the packed buffers
@@ -301,9 +310,9 @@ module m_x3d2_hip_capi
       integer(c_long), intent(out) :: sizes(8)
     end function
     integer(c_int) function x3d_pfft_set_waves(p, waves_re, ax, bx, ay, by, az, bz) bind(C, name='x3d_pfft_set_waves')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: p
-      real(c_double), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
+      real(x3d_creal), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
     end function
     integer(c_int) function x3d_pfft_fwd_x(p, f_in) bind(C, name='x3d_pfft_fwd_x')
       import :: c_ptr, c_int
@@ -362,10 +371,10 @@ module m_x3d2_hip_capi
     ! transeq_species
     integer(c_int) function x3d_transeq_species(b, dir, dspec, uvw, spec, nu, der1st, der1st_sym, der2nd, &
                                                 accumulate) bind(C, name='x3d_transeq_species')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, dspec, uvw, spec, der1st, der1st_sym, der2nd
       integer(c_int), value :: dir, accumulate
-      real(c_double), value :: nu
+      real(x3d_creal), value :: nu
     end function
     ! compute_vorticity / compute_qcriterion: grads = 9 device blocks
     integer(c_int) function x3d_compute_vorticity(b, out, grads) bind(C, name='x3d_compute_vorticity')
@@ -395,93 +404,93 @@ module m_x3d2_hip_capi
       type(c_ptr), value :: b, dst, src
     end function
     integer(c_int) function x3d_vecadd(b, a, x, bb, y) bind(C, name='x3d_vecadd')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, x, y
-      real(c_double), value :: a, bb
+      real(x3d_creal), value :: a, bb
     end function
     integer(c_int) function x3d_vecmult(b, y, x) bind(C, name='x3d_vecmult')
       import :: c_ptr, c_int
       type(c_ptr), value :: b, y, x
     end function
     integer(c_int) function x3d_field_scale(b, f, a) bind(C, name='x3d_field_scale')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), value :: a
+      real(x3d_creal), value :: a
     end function
     integer(c_int) function x3d_field_shift(b, f, a) bind(C, name='x3d_field_shift')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), value :: a
+      real(x3d_creal), value :: a
     end function
     ! reductions (rank-local; the shim adds MPI_Allreduce like the reference)
     integer(c_int) function x3d_scalar_product(b, x, y, dims, s) bind(C, name='x3d_scalar_product')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, x, y
       integer(c_int), intent(in) :: dims(3)
-      real(c_double), intent(out) :: s
+      real(x3d_creal), intent(out) :: s
     end function
     integer(c_int) function x3d_field_max_sum(b, f, dims, max_abs, sum_abs) bind(C, name='x3d_field_max_sum')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
       integer(c_int), intent(in) :: dims(3)
-      real(c_double), intent(out) :: max_abs, sum_abs
+      real(x3d_creal), intent(out) :: max_abs, sum_abs
     end function
     integer(c_int) function x3d_field_volume_integral(b, f, dims, s) bind(C, name='x3d_field_volume_integral')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
       integer(c_int), intent(in) :: dims(3)
-      real(c_double), intent(out) :: s
+      real(x3d_creal), intent(out) :: s
     end function
     integer(c_int) function x3d_slice_max_sum(b, f, dims, dir, i_slice, max_val, sum_val) &
       bind(C, name='x3d_slice_max_sum')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
       integer(c_int), intent(in) :: dims(3)
       integer(c_int), value :: dir, i_slice
-      real(c_double), intent(out) :: max_val, sum_val
+      real(x3d_creal), intent(out) :: max_val, sum_val
     end function
     ! faces
     integer(c_int) function x3d_field_set_face(b, f, dims, c_start, c_end, face) bind(C, name='x3d_field_set_face')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
       integer(c_int), intent(in) :: dims(3)
-      real(c_double), value :: c_start, c_end
+      real(x3d_creal), value :: c_start, c_end
       integer(c_int), value :: face
     end function
     integer(c_int) function x3d_field_set_face_from_field(b, f, f_start, dims, c_end, face, flow_rate_diff) &
       bind(C, name='x3d_field_set_face_from_field')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f, f_start
       integer(c_int), intent(in) :: dims(3)
-      real(c_double), value :: c_end, flow_rate_diff
+      real(x3d_creal), value :: c_end, flow_rate_diff
       integer(c_int), value :: face
     end function
     ! copy_data_to_f / copy_f_to_data (Cartesian host arrays)
     integer(c_int) function x3d_set_field_data(b, f, host, dims) bind(C, name='x3d_set_field_data')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), intent(in) :: host(*)
+      real(x3d_creal), intent(in) :: host(*)
       integer(c_int), intent(in) :: dims(3)
     end function
     integer(c_int) function x3d_get_field_data(b, host, f, dims) bind(C, name='x3d_get_field_data')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), intent(out) :: host(*)
+      real(x3d_creal), intent(out) :: host(*)
       integer(c_int), intent(in) :: dims(3)
     end function
     integer(c_int) function x3d_set_field_data_pitched(b, f, host, hx, hy, dims) &
       bind(C, name='x3d_set_field_data_pitched')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), intent(in) :: host(*)
+      real(x3d_creal), intent(in) :: host(*)
       integer(c_int), value :: hx, hy
       integer(c_int), intent(in) :: dims(3)
     end function
     integer(c_int) function x3d_get_field_data_pitched(b, host, f, hx, hy, dims) &
       bind(C, name='x3d_get_field_data_pitched')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b, f
-      real(c_double), intent(out) :: host(*)
+      real(x3d_creal), intent(out) :: host(*)
       integer(c_int), value :: hx, hy
       integer(c_int), intent(in) :: dims(3)
     end function
@@ -497,11 +506,11 @@ module m_x3d2_hip_capi
     ! init_poisson_fft + poisson_fft_t hooks
     integer(c_int) function x3d_poisson_create(b, p, n, waves_re, ax, bx, ay, by, az, bz) &
       bind(C, name='x3d_poisson_create')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: b
       type(c_ptr), intent(out) :: p
       integer(c_int), intent(in) :: n(3)
-      real(c_double), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
+      real(x3d_creal), intent(in) :: waves_re(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
     end function
     integer(c_int) function x3d_poisson_fft_forward(p, f_in) bind(C, name='x3d_poisson_fft_forward')
       import :: c_ptr, c_int
@@ -528,10 +537,10 @@ module m_x3d2_hip_capi
     end function
     integer(c_int) function x3d_poisson_set_stretching(p, sym, a0, a1) &
       bind(C, name='x3d_poisson_set_stretching')
-      import :: c_ptr, c_int, c_double
+      import :: c_ptr, c_int, x3d_creal
       type(c_ptr), value :: p
       integer(c_int), value :: sym
-      real(c_double), intent(in) :: a0(*), a1(*)
+      real(x3d_creal), intent(in) :: a0(*), a1(*)
     end function
     integer(c_int) function x3d_poisson_postprocess_010(p) bind(C, name='x3d_poisson_postprocess_010')
       import :: c_ptr, c_int

@@ -61,3 +61,26 @@ def test_single_precision_step_at_the_bench_size(tmp_path):
         assert np.max(np.abs(got[k].astype(np.float64) - w)) < 2e-5 * max(np.max(np.abs(w)), 1.0), k
     assert abs(res["enstrophy"] - ens) < 1e-5 * ens
     assert res["div_max"] < 1e-3  # (max |div u| of an FP32 projection at dx = 2 pi / 512: round-off / dx)
+
+
+def test_fp32_through_the_boundary_the_reference_built_with_single_prec_on_the_fp32_library(tmp_path):
+    """round 6: the Fortran side of the boundary in single precision.  fortran/_build/sp/xcompact_hip = the reference's own
+    solver.f90 / cases / monitoring compiled with -DSINGLE_PREC (src/common.f90:6-12: dp = kind(0.0e0), MPI_REAL) + this
+    repo's shim compiled with the same flag (m_x3d2_hip_capi.f90: x3d_creal = c_float) + libx3d2_hip_sp.so.  TGV 64^3,
+    RK3, FFT Poisson, 20 steps: the enstrophy series of the FP64 fixture to 1e-5 relative (the tolerance of the FP32
+    flavour's own trace test), the projection's divergence at FP32 round-off.  (Either shim checks x3d_real_bytes() against
+    the kind it was compiled for before its first call and stops on the other flavour of the library.)"""
+    import os
+    import subprocess
+    from util import read_trace_fixture
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "sp", "xcompact_hip")
+    if not os.path.exists(exe) or not os.path.exists(os.path.join(root, "x3d2_amd", "libx3d2_hip_sp.so")):
+        pytest.skip("FP32 shim binary not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, os.path.join(root, "fortran", "tgv64.x3d")], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = np.loadtxt(tmp_path / "monitoring.csv", delimiter=",", comments="#")
+    fx = read_trace_fixture()
+    assert rows.shape[0] >= 3
+    assert np.all(np.abs(rows[:3, 1] - fx[:, 1]) < 1e-5 * fx[:, 1]), (rows[:3, 1], fx[:, 1])
+    assert rows[:, 2].max() < 1e-4  # max |div u| after the projection, FP32

@@ -173,7 +173,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // compressed form of the row entries (xscan_core.h, LTC_*): lanes 0..7 | one value for lanes 8..55 | lanes
     // 56..63 -- only where those middle lanes really are bitwise equal (periodic-type operators on a uniform grid)
     size_t tlc_off = 0;
-    if (Q == 16) {
+    if (Q == 16 || Q == 8) {  // (Q = 8, round 6: the 8-pencil z-transforming pairs, zfpair8.hip)
         const real_t *tl = &img[tl_off];
         bool ok = true;
         auto row_entry = [&](int k) { return k < 8 * Q ? k : 8 * Q + 12 + (k - 8 * Q); };  // k = 0 .. 9Q-1

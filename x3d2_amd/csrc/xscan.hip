@@ -1820,6 +1820,8 @@ bool x3d_zfirst_pairs_ok(const x3d_backend *b, const x3d_tdsops *ta, const x3d_t
     return 128 * (long)b->nxp * b->nyp * X3D_RB < (1L << 32);
 }
 
+int x3d_zfpair8(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
+                const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done);  // zfpair8.hip
 // the z pairs next to the z-first Poisson solve (k_ytile_tds_pair<.., ZF>): mode 0: A(in1) + B(in2) -> spectrum,
 // mode 1: spectrum -> out1 = A(p), out2 = B(p); whole blocks of 512^3
 // y0, nyr: the tiles of the y rows [y0, y0 + nyr) only (nyr < 0: all) -- csrc/sfftz.hip cuts a solve into groups of y rows
@@ -1835,6 +1837,10 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
     X3D_REQUIRE(y0 >= 0 && nyr >= 0 && y0 + nyr <= zf.ny, "tds_pair (z-first): rows [%d, %d) of %d", y0, y0 + nyr, zf.ny);
     X3D_REQUIRE(zf.permn == 0 || (zf.permn == zf.ny && y0 == 0 && nyr == zf.ny), "tds_pair (z-first): interleaved rows, whole blocks only");
     if (nyr == 0) { *done = true; return 0; }
+    if (y0 == 0 && nyr == zf.ny) {  // whole blocks: the 8-pencil form, two workgroups per CU (zfpair8.hip)
+        if (int rc = x3d_zfpair8(b, mode, out1, out2, in1, in2, ta, tb, zf, done)) return rc;
+        if (*done) return 0;
+    }
     const size_t lds = sizeof(real_t) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     const long pxy = (long)b->nxp * b->nyp;

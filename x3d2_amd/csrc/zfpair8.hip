@@ -1,0 +1,304 @@
+// The z operator pairs next to the z-first Poisson solves (k_ytile_tds_pair<8, 0 / 1, .., ZF> of xscan.hip) on 8-PENCIL
+// tiles with TWO workgroups per CU (round 6; VERDICT round 5, task 2).
+//
+// The 16-pencil form fills the LDS with one tile pipeline (two table sets 78 KB + the 72 KB transform area + twiddles
+// = 154 KB) and its on-chip chain per tile -- two solves, the 512-point transform of 8 of its 16 waves, the mode
+// transposition, nine barriers: 13.9 us -- is longer than the tile's memory time (9.6 us): every piece of on-chip work
+// shows 1 : 1 in the launch time (profiles/r05_zf_pair_phases.txt).  Here a workgroup is 8 waves = the 8 x-adjacent z
+// pencils of one y row:
+//   * lane tables in the COMPRESSED form of xscan_core.h (LTC_*: periodic-type operators on a uniform grid have row
+//     entries that are bitwise constant away from the pencil's ends -- lanes 0..7, one value for 8..55, lanes 56..63) and
+//     without the ST / STC blocks (uniform grid): 13.8 KB per operator instead of 38.9;
+//   * tile / transform area for 8 pencils: 36.9 KB (4 waves transform 4 pairs of real pencils);
+//   => 68.5 KB per workgroup: two per CU, one's solves and transforms run beside the other's loads and stores.
+// Row segments are 64 bytes; the two tiles of a 128-byte line go to workgroups b and b + 8 -- same XCD (one L2),
+// dispatched together -- as k_ygen_transeq3<5, .., 8> does.
+// Arithmetic per pencil = k_ytile_tds_pair<.., UNI>'s (scan_solve, the same reduced system and substitution; the
+// compressed tables store the reduced system's couplings of the middle lanes, < 2^-60, as 0: tds.hip), the transforms
+// = zfft_tile.h's on half as many pencils.
+#include "xscan_core.h"
+#include "zfft_tile.h"
+
+constexpr int Z8_Q = 8;
+constexpr int Z8_LROWS = 7 * Z8_Q * LTC_LS;  // F A PF H QB SA SC, compressed
+constexpr int Z8_LN = Z8_LROWS + 12 * 64;    // doubles per operator
+constexpr int Z8_TP = 516;                   // doubles per real pencil in the tile
+constexpr int Z8_AREA = 4 * ZF_PEN * 2;      // doubles: 4 transform regions (>= the real tile [8][516], >= T2[257][8])
+
+__device__ __forceinline__ int z8_t2(int m, int x) { return m * 8 + (x ^ (m & 7)); }
+
+// area holds the real tile [8][TP] (a barrier since it was written); on return the 257 x 8 modes are stored, area free
+__device__ __forceinline__ void z8_forward(real_t *__restrict__ area, const real2_t *__restrict__ tws,
+                                           real2_t *__restrict__ crow, long kzs, int wave, int lane)
+{
+    real2_t a[8], A[5], B[5];
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
+    if (wave < 4) {
+        const real_t *__restrict__ pa = area + (2 * wave) * Z8_TP, *__restrict__ pb = pa + Z8_TP;
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = make_real2(pa[lane + 64 * k], pb[lane + 64 * k]);
+    }
+    __syncthreads();  // (the transform regions overlap other waves' pencils)
+    if (wave < 4) {
+        real2_t *__restrict__ pen = T2 + wave * ZF_PEN;
+        fft512_wave<-1>(a, pen, tws, lane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) pen[lane + 64 * k] = a[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = lane + 64 * k;
+            if (k < 4 || lane == 0) {
+                const real2_t x = a[k], y = pen[(512 - idx) & 511];
+                A[k] = make_real2(0.5 * (x.x + y.x), 0.5 * (x.y - y.y));
+                B[k] = make_real2(0.5 * (x.y + y.y), -0.5 * (x.x - y.x));
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = lane + 64 * k;
+            if (k < 4 || lane == 0) {
+                T2[z8_t2(idx, 2 * wave)] = A[k];
+                T2[z8_t2(idx, 2 * wave + 1)] = B[k];
+            }
+        }
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 3, x = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int m = r + 64 * i;
+        if (i < 4 || threadIdx.x < 8) crow[(long)m * kzs + x] = T2[z8_t2(m, x)];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ ZfRows z8_inverse_load(const real2_t *__restrict__ crow, long kzs)
+{
+    const int r = threadIdx.x >> 3, x = threadIdx.x & 7;
+    const real2_t *__restrict__ p = crow + (long)r * kzs + x;
+    ZfRows v;
+    v.v0 = p[0]; v.v1 = p[64 * kzs]; v.v2 = p[128 * kzs]; v.v3 = p[192 * kzs];
+    v.v4 = p[threadIdx.x < 8 ? 256 * kzs : 0];
+    return v;
+}
+
+// the area is free; on return it holds the real tile [8][TP], barrier passed (unnormalised inverse)
+__device__ __forceinline__ void z8_inverse(real_t *__restrict__ area, const real2_t *__restrict__ tws, const ZfRows &v,
+                                           int wave, int lane)
+{
+    real2_t *__restrict__ T2 = reinterpret_cast<real2_t *>(area);
+    const int r = threadIdx.x >> 3, x = threadIdx.x & 7;
+    T2[z8_t2(r, x)] = v.v0;
+    T2[z8_t2(r + 64, x)] = v.v1;
+    T2[z8_t2(r + 128, x)] = v.v2;
+    T2[z8_t2(r + 192, x)] = v.v3;
+    if (threadIdx.x < 8) T2[z8_t2(256, x)] = v.v4;
+    __syncthreads();
+    real2_t a[8];
+    if (wave < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int m = lane + 64 * k, mm = m <= 256 ? m : 512 - m;
+            real2_t A = T2[z8_t2(mm, 2 * wave)], B = T2[z8_t2(mm, 2 * wave + 1)];
+            if (m > 256) { A.y = -A.y; B.y = -B.y; }
+            a[k] = make_real2(A.x - B.y, A.y + B.x);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) fft512_wave<1>(a, T2 + wave * ZF_PEN, tws, lane);
+    __syncthreads();
+    if (wave < 4) {
+        real_t *__restrict__ pa = area + (2 * wave) * Z8_TP, *__restrict__ pb = pa + Z8_TP;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            pa[lane + 64 * k] = a[k].x;
+            pb[lane + 64 * k] = a[k].y;
+        }
+    }
+    __syncthreads();
+}
+
+// MODE 0: A(in1) + B(in2) -> spectrum;  MODE 1: spectrum -> out1 = A(p), out2 = B(p)
+// prow: doubles between the rows of a z pencil (nxp * nyp), pplane: between y rows (nxp); ntx = nx / 8 tiles per y row
+template <int MODE, bool NARROW>
+__global__ void __launch_bounds__(512, 4)
+    k_zfpair8(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2, XOp ta, XOp tb,
+              int ntx, int ntiles, long prow, long pplane, ZfArg zf)
+{
+    extern __shared__ real_t lt[];
+    constexpr int Q = Z8_Q, LS = LTC_LS, NI = 4;
+    {
+        const real_t *src[2] = {ta.TL, tb.TL};
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            for (int i = threadIdx.x; i < Z8_LROWS; i += blockDim.x) lt[o * Z8_LN + i] = src[o][i];
+            for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lt[o * Z8_LN + Z8_LROWS + i] = src[o][LTC_M0(Q) + i];
+        }
+    }
+    const real_t *__restrict__ la = lt, *__restrict__ lb = lt + Z8_LN;
+    real_t *tile = lt + 2 * Z8_LN;
+    real2_t *tws = reinterpret_cast<real2_t *>(tile + Z8_AREA);
+    if (threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
+    const long kzs = (long)zf.ny * zf.px;
+    auto zf_row = [&](int tl) {
+        int r = tl / ntx;
+        if (zf.permn > 0 && r < zf.permn) r = (r & 1) ? zf.permn - ((r + 1) >> 1) : (r >> 1);
+        return zf.c + (long)r * zf.px + (long)(tl % ntx) * 8;
+    };
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 8; };
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int first = lane * Q + 1, ll = ltc_lane(lane);
+    const int cy = threadIdx.x >> 2, cc = threadIdx.x & 3;  // rows cy + 128 i of the column pair (2 cc, 2 cc + 1)
+    auto gload = [&](real2_t (&v)[NI], const real_t *__restrict__ src) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const real2_t *>(src + (long)(cy + 128 * i) * prow + 2 * cc);
+    };
+    auto to_tile = [&](const real2_t (&v)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            tile[(2 * cc) * Z8_TP + cy + 128 * i] = v[i].x;
+            tile[(2 * cc + 1) * Z8_TP + cy + 128 * i] = v[i].y;
+        }
+    };
+    auto from_tile = [&](real_t *o) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            *reinterpret_cast<real2_t *>(o + (long)(cy + 128 * i) * prow + 2 * cc) =
+                make_real2(tile[(2 * cc) * Z8_TP + cy + 128 * i], tile[(2 * cc + 1) * Z8_TP + cy + 128 * i]);
+    };
+    auto pick = [&](real_t (&b)[Q]) {
+        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + wave * Z8_TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) {
+            const real2_t t2_ = src[m];
+            b[2 * m] = t2_.x;
+            b[2 * m + 1] = t2_.y;
+        }
+    };
+    auto put = [&](const real_t (&r)[Q]) {
+        real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * Z8_TP + lane * Q);
+#pragma unroll
+        for (int m = 0; m < Q / 2; m++) dst[m] = make_real2(r[2 * m], r[2 * m + 1]);
+    };
+    auto solve = [&](const real_t (&w)[Q + 8], real_t (&r)[Q], const real_t *__restrict__ l, const XOp &t) {
+        real_t X[Q], du1, xn;
+        scan_solve<Q, true, NARROW, real_t, LTC_LS, Z8_LROWS>(w, X, du1, xn, l, t, lane, first, ll);
+        const real_t du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            r[q] = X[q] - LTX(l, LT_SA(q)) * du_s - LTX(l, LT_SC(q)) * du_e;
+            if (q == 0) r[q] = (lane == 0) ? du_s : r[q];
+            if (q == Q - 1) r[q] = (lane == 63) ? du_e : r[q];
+        }
+    };
+    // blocks b and b + 8 (same XCD, dispatched back to back) take the tiles 2 j and 2 j + 1: one 128-byte line between them
+    int bid = blockIdx.x;
+    {
+        const int g16 = bid / 16, r16 = bid % 16;
+        bid = g16 * 16 + 2 * (r16 % 8) + r16 / 8;
+    }
+    __syncthreads();
+    real2_t nxt[NI];
+    ZfRows spn{};
+    if (bid < ntiles) {
+        if constexpr (MODE == 1) spn = z8_inverse_load(zf_row(bid), kzs);
+        else gload(nxt, in1 + tile_off(bid));
+    }
+    for (int tl = bid; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        asm volatile("" : "+v"(lane));
+        real_t w[Q + 8], b[Q], ra[Q], rb[Q];
+        real2_t g2[NI];
+        if (MODE == 0) gload(g2, in2 + off);
+        if constexpr (MODE == 1) {
+            z8_inverse(tile, tws, spn, wave, lane);  // (ends behind a barrier)
+        } else {
+            to_tile(nxt);
+            __syncthreads();
+        }
+        pick(b);
+        window_from_body<Q>(w, b, lane);
+        if (MODE == 0) __syncthreads();  // all rows picked: the second input may overwrite the tile
+        {
+            const int tn = tl + gridDim.x;
+            if (tn < ntiles) {
+                if constexpr (MODE == 1) spn = z8_inverse_load(zf_row(tn), kzs);
+                else gload(nxt, in1 + tile_off(tn));
+            }
+        }
+        solve(w, ra, la, ta);
+        if (MODE == 0) {
+            to_tile(g2);
+            __syncthreads();
+            pick(b);
+            window_from_body<Q>(w, b, lane);
+            asm volatile("" : "+v"(lane) : "v"(ra[0]));
+            solve(w, rb, lb, tb);
+#pragma unroll
+            for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];
+            put(ra);
+            __syncthreads();
+            z8_forward(tile, tws, zf_row(tl), kzs, wave, lane);
+        } else {
+            put(ra);
+            __syncthreads();
+            from_tile(out1 + off);
+            asm volatile("" : "+v"(lane) : "v"(ra[0]));
+            solve(w, rb, lb, tb);
+            __syncthreads();  // out1's tile has been read
+            put(rb);
+            __syncthreads();
+            from_tile(out2 + off);
+            __syncthreads();
+        }
+    }
+}
+
+static bool z8_narrow(const x3d_tdsops *t)
+{
+    return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
+}
+
+// the 8-pencil form of x3d_ytile_tds_pair_zf (xscan.hip); whole blocks; *done = false: not served (the caller then takes the
+// 16-pencil form).  X3D_ZF_NP16=1: never (A/B)
+int x3d_zfpair8(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
+                const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done)
+{
+    *done = false;
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("X3D_ZF_NP16"); off = (e && e[0] == '1') ? 1 : 0; }
+    auto ok = [&](const x3d_tdsops *t) {
+        return t->tlc != nullptr && t->tab.Q == Z8_Q && t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == 512 && t->uniform;
+    };
+    if (off || mode < 0 || mode > 1 || !ok(ta) || !ok(tb) || b->nz != 512 || b->nx % 16 != 0 || zf.ny > b->ny) return 0;
+    const int ntx = b->nx / 8, ntiles = ntx * zf.ny;
+    if (ntiles < 16) return 0;
+    const size_t lds = sizeof(real_t) * (2 * Z8_LN + Z8_AREA + 512);
+    int blocks = 2 * x3d_persistent_blocks(b, X3D_NCU);
+    if (blocks > ntiles) blocks = ntiles;
+    blocks -= blocks % 16;  // (the pairing of blocks b and b + 8)
+    if (blocks < 16) return 0;
+    const bool narrow = z8_narrow(ta) && z8_narrow(tb);
+    const long pxy = (long)b->nxp * b->nyp;
+    XOp xa = xop_of(ta), xb = xop_of(tb);
+    xa.TL = ta->tlc;
+    xb.TL = tb->tlc;
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
+#define GO(M_, N_)                                                                                              \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_zfpair8<M_, N_>));                                                                  \
+        hipLaunchKernelGGL((k_zfpair8<M_, N_>), dim3(blocks), dim3(512), lds, b->stream, out1, out2, in1, in2, xa, xb, ntx, \
+                           ntiles, pxy, (long)b->nxp, zf);                                                      \
+    } while (0)
+    if (mode == 0) { if (narrow) GO(0, true); else GO(0, false); }
+    else { if (narrow) GO(1, true); else GO(1, false); }
+#undef GO
+    X3D_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
