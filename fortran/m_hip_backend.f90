@@ -257,6 +257,14 @@ contains
     call self%base_init(mesh, xdirps, ydirps, zdirps, nspec, [0, 0, 0])
     allocate (wre(nspec(1), nspec(2), nspec(3)))
     wre = real(self%waves, dp)
+#ifdef SINGLE_PREC
+    ! process_spectral_000 treats waves < 1e-16 as zero modes (src/backend/omp/kernels/spectral_processing.f90:7-106) -- a
+    ! DOUBLE-precision threshold: the modes that sit at the Nyquist frequency in two directions have waves ~ 1e-60 in double
+    ! (the transfer functions vanish there) but ~ cos(pi_f / 2)**2 * k2 ~ 1e-12 when waves_set runs in single precision, and
+    ! - 1 / waves then amplifies round-off by 1e12 (TGV 64^3: max |div u| 0.6 after ten steps).  What the double-precision
+    ! set-up calls zero is zero here too: below 1e-10 of the largest wave number (the smallest genuine one is >= 1 / n**2 of it)
+    where (abs(wre) < 1.0e-10_dp*maxval(abs(wre))) wre = 0.0_dp
+#endif
     call x3d_check(x3d_poisson_create(backend, self%handle, int(dims, c_int), wre, self%ax, self%bx, &
                                       self%ay, self%by, self%az, self%bz))
     ! stretched y: hand over the real parts of the matrices base_init built

@@ -1,5 +1,6 @@
 // The z operator pairs next to the z-first Poisson solves (k_ytile_tds_pair<8, 0 / 1, .., ZF> of xscan.hip) on 8-PENCIL
-// tiles with TWO workgroups per CU (round 6; VERDICT round 5, task 2).
+// tiles with TWO workgroups per CU (round 6; VERDICT round 5, task 2).  BUILT, PARITY-GREEN, MEASURED SLOWER, OFF BY DEFAULT
+// (X3D_ZF_NP8=1 switches it on; numbers at x3d_zfpair8 below).
 //
 // The 16-pencil form fills the LDS with one tile pipeline (two table sets 78 KB + the 72 KB transform area + twiddles
 // = 154 KB) and its on-chip chain per tile -- two solves, the 512-point transform of 8 of its 16 waves, the mode
@@ -265,13 +266,17 @@ static bool z8_narrow(const x3d_tdsops *t)
 }
 
 // the 8-pencil form of x3d_ytile_tds_pair_zf (xscan.hip); whole blocks; *done = false: not served (the caller then takes the
-// 16-pencil form).  X3D_ZF_NP16=1: never (A/B)
+// 16-pencil form)
 int x3d_zfpair8(x3d_backend *b, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
                 const x3d_tdsops *ta, const x3d_tdsops *tb, const ZfArg &zf, bool *done)
 {
     *done = false;
+    // MEASURED SLOWER (profiles/r06_zfpair8_two_pipelines_per_cu.txt): mode 1 1.03 against 0.79 ms, mode 0 0.85 = 0.85; TGV
+    // step 43.0 against 42.25 ms, channel 51.6 against 50.5 -- the second pipeline hides the on-chip chain, but the field
+    // side's 64-byte row segments (two output fields in mode 1) cost more than that.  OFF unless X3D_ZF_NP8=1; parity-green
+    // (tests/test_hip_parity.py runs it in a child process).
     static int off = -1;
-    if (off < 0) { const char *e = getenv("X3D_ZF_NP16"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off < 0) { const char *e = getenv("X3D_ZF_NP8"); off = (e && e[0] == '1') ? 0 : 1; }
     auto ok = [&](const x3d_tdsops *t) {
         return t->tlc != nullptr && t->tab.Q == Z8_Q && t->tab.bulk_only && t->n_tds == 512 && t->tab.n_rhs == 512 && t->uniform;
     };
