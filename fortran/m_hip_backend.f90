@@ -174,6 +174,10 @@ module m_hip_poisson_fft
     logical :: is_100 = .false.
     type(c_ptr) :: tb = c_null_ptr, t1 = c_null_ptr, t2 = c_null_ptr
     logical :: multi = .false.
+    ! y slabs [1, py, 1] of 512^3 cells per rank (round 6): the z-first slab solver of csrc/sfftz.hip in its hook forms --
+    ! ONE all-to-all pair per solve among the py ranks instead of the pencil solver's four transposes
+    logical :: yslab = .false.
+    type(c_ptr) :: sf = c_null_ptr
     logical :: skip_own = .true.   ! an undivided direction's transpose is unpacked where it was packed (no exchange with oneself)
     integer :: ry = 0              ! this rank's position in its y group (comm_y)
     type(c_ptr) :: backend = c_null_ptr, pf = c_null_ptr, sbuf = c_null_ptr, rbuf = c_null_ptr
@@ -206,6 +210,7 @@ module m_hip_poisson_fft
     procedure :: enforce_periodicity_xy => enforce_periodicity_xy_hip
     procedure :: undo_periodicity_xy => undo_periodicity_xy_hip
   end type hip_poisson_fft_t
+  class(hip_poisson_fft_t), pointer :: g_yslab => null()   ! the y-slab solver the library's middle callback works on
 contains
   subroutine hip_poisson_fft_setup(self, backend, mesh, xdirps, ydirps, zdirps)
     class(hip_poisson_fft_t), intent(inout) :: self
@@ -297,6 +302,10 @@ contains
     self%multi = .true.
     self%backend = backend
     self%ry = ry
+    if (yslab_wanted(mesh, dims, py, pz)) then
+      call hip_poisson_fft_setup_yslab(self, backend, mesh, xdirps, ydirps, zdirps, dims, py, ry)
+      return
+    end if
     call x3d_check(x3d_pfft_create(backend, self%pf, int(dims, c_int), int(py, c_int), int(pz, c_int), &
                                    int(ry, c_int), int(rz, c_int)))
     call x3d_check(x3d_pfft_sizes(self%pf, sz))
@@ -351,6 +360,97 @@ contains
     call get_environment_variable('X3D_SHIM_HOST_STAGED', v, status=stat)
     host_staged = stat == 0 .and. v(1:1) == '1'
   end function host_staged
+
+  logical function yslab_wanted(mesh, dims, py, pz)
+    !! [1, py, 1] with 512^3 cells per rank, all-periodic: the slab solver applies (X3D_SHIM_NO_SLAB_FFT=1: pencil solver)
+    type(mesh_t), intent(in) :: mesh
+    integer, intent(in) :: dims(3), py, pz
+    character(len=8) :: v
+    integer :: stat, vd(3)
+    call get_environment_variable('X3D_SHIM_NO_SLAB_FFT', v, status=stat)
+    vd = mesh%get_dims(VERT)
+    yslab_wanted = .not. (stat == 0 .and. v(1:1) == '1') .and. pz == 1 .and. (py == 2 .or. py == 4 .or. py == 8) &
+                   .and. dims(1) == 512 .and. dims(2) == 512*py .and. dims(3) == 512 .and. all(vd == 512) &
+                   .and. all(mesh%grid%periodic_BC) .and. .not. host_staged()
+  end function yslab_wanted
+
+  subroutine hip_poisson_fft_setup_yslab(self, backend, mesh, xdirps, ydirps, zdirps, dims, py, ry)
+    !! x3d2_amd/poisson_fft.py, HipSlabPoissonFFTZ._create: this rank's modes are the x modes [xoff, xoff + xs) of ALL y and
+    !! the z modes 0 .. 256 (the half axis is z); the library wants - 1 / waves of them, y fastest, the x index mirrored
+    !! above nx / 2 (src/poisson_fft.f90:833-882 mirrors the wave numbers the same way along y and z).  The reference's own
+    !! base_init / waves_set fill the wave numbers (x modes 0 .. 256, all y, z modes 0 .. 256 of its x-half layout).
+    class(hip_poisson_fft_t), intent(inout), target :: self
+    type(c_ptr), intent(in) :: backend
+    type(mesh_t), intent(in) :: mesh
+    type(dirps_t), intent(in) :: xdirps, ydirps, zdirps
+    integer, intent(in) :: dims(3), py, ry
+    integer(c_long) :: sz(16)
+    integer :: xs, xoff, i, j, k, kx, ierr
+    real(dp), allocatable :: rw(:, :, :)
+    real(dp) :: w
+    self%yslab = .true.
+    self%multi = .false.      ! (the hooks go to the proxy object below like a single rank's; the exchanges live in its middle)
+    self%skip_own = .false.   ! (the slab solver's y stage reads every peer's chunk, its own included, out of the receive buffer)
+    call x3d_check(x3d_sfftz_create(backend, self%sf, int(dims, c_int), int(py, c_int), int(ry, c_int), 1_c_int))
+    call x3d_check(x3d_sfftz_sizes(self%sf, sz))
+    xs = int(sz(2)); xoff = int(sz(3))
+    call self%base_init(mesh, xdirps, ydirps, zdirps, [dims(1)/2 + 1, dims(2), dims(3)/2 + 1], [0, 0, 0])
+    allocate (rw(dims(2), xs, dims(3)/2 + 1))
+    do k = 1, dims(3)/2 + 1
+      do i = 1, xs
+        kx = xoff + i - 1
+        if (kx > dims(1)/2) kx = dims(1) - kx
+        do j = 1, dims(2)
+          w = real(self%waves(kx + 1, j, k), dp)
+          if (w < 1.e-16_dp) then
+            rw(j, i, k) = 0._dp
+          else
+            rw(j, i, k) = -1._dp/w
+          end if
+        end do
+      end do
+    end do
+    call x3d_check(x3d_sfftz_set_waves(self%sf, rw, self%ax, self%bx, self%ay, self%by, self%az, self%bz))
+    deallocate (rw)
+    call x3d_check(x3d_device_alloc(backend, self%sbuf, 2_c_long*sz(4)))
+    call x3d_check(x3d_device_alloc(backend, self%rbuf, 2_c_long*sz(4)))
+    call MPI_Comm_split(MPI_COMM_WORLD, 0, ry, self%comm_y, ierr)
+    self%comm_z = MPI_COMM_SELF
+    self%d2d = .true.
+    call map_peers(self, self%comm_y, py, self%peer_y)
+    ! one chunk per peer: 512 rows x 257 kz planes x xs modes, complex
+    allocate (self%cnt_xy_s(py), self%cnt_xy_r(py), self%cnt_yz_s(1), self%cnt_yz_r(1))
+    self%cnt_xy_s = 2*512*257*xs
+    self%cnt_xy_r = self%cnt_xy_s
+    self%cnt_yz_s = 0; self%cnt_yz_r = 0
+    ! the hooks: a proxy poisson object whose middle is yslab_middle below -- fft_forward / fft_postprocess_000 /
+    ! fft_backward are then recorded by the deferred layer like a single rank's and take its z-first rewrite (the z
+    ! transforms on the tiles of the z operator pairs next to the solve; x3d_tds_pair_zfirst ; middle ; x3d_tds_pair_zfirst)
+    block
+      type(c_ptr) :: cspec
+      integer(c_int) :: cny
+      integer(c_long) :: cpx
+      call x3d_check(x3d_sfftz_spectrum(self%sf, cspec, cny, cpx))
+      call x3d_check(x3d_poisson_create_proxy(backend, self%handle, cspec, cny, cpx, c_funloc(yslab_middle), c_null_ptr))
+    end block
+    g_yslab => self
+  end subroutine hip_poisson_fft_setup_yslab
+
+  integer(c_int) function yslab_middle(user) bind(C) result(rc)
+    !! everything between the two z transforms of the y-slab solve (x3d2_amd/poisson_fft.py, HipSlabPoissonFFTZ.zfirst_middle):
+    !! x forward into the exchange layout ; all-to-all among the py ranks ; y forward + process_spectral_000 + y inverse on
+    !! the received rows, one kernel ; all-to-all back ; x inverse.  Called by the library when it runs the solve -- every
+    !! rank runs the same queue at the same call of the program, so the exchanges meet.
+    type(c_ptr), value :: user
+    rc = 0
+    call x3d_check(x3d_sfftz_x_forward(g_yslab%sf, buf_out(g_yslab), 0_c_int))
+    call xchg(g_yslab, g_yslab%comm_y, g_yslab%cnt_xy_s, g_yslab%cnt_xy_r, 1)
+    call stage_done(g_yslab)   ! (the received spectrum now sits in what the next exchange sends from: buf_out)
+    call x3d_check(x3d_sfftz_y_stage(g_yslab%sf, buf_out(g_yslab), 0_c_int, 0_c_int))
+    call xchg(g_yslab, g_yslab%comm_y, g_yslab%cnt_xy_r, g_yslab%cnt_xy_s, 4)
+    call x3d_check(x3d_sfftz_x_backward(g_yslab%sf, buf_in(g_yslab), 0_c_int))
+    call stage_done(g_yslab)
+  end function yslab_middle
 
   function ptr_off(base, ndoubles) result(p)
     !! base + ndoubles reals (8 or 4 bytes each: x3d_creal)

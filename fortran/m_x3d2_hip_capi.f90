@@ -297,6 +297,65 @@ module m_x3d2_hip_capi
       integer(c_long), value :: n
     end function
     ! pencil-decomposed 000 Poisson solver: local stages (csrc/pfft.hip); the caller exchanges the packed buffers
+    ! ---- 000 solve on y slabs [1, py, 1] of 512^3 cells per rank, z-first (csrc/sfftz.hip): the stand-alone hook forms
+    integer(c_int) function x3d_sfftz_create(b, handle, nglob, py, ry, parts) bind(C, name='x3d_sfftz_create')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      type(c_ptr), intent(out) :: handle
+      integer(c_int), intent(in) :: nglob(3)
+      integer(c_int), value :: py, ry, parts
+    end function
+    integer(c_int) function x3d_sfftz_destroy(p) bind(C, name='x3d_sfftz_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p
+    end function
+    integer(c_int) function x3d_sfftz_sizes(p, sz) bind(C, name='x3d_sfftz_sizes')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: p
+      integer(c_long), intent(out) :: sz(16)
+    end function
+    integer(c_int) function x3d_sfftz_set_waves(p, rw, ax, bx, ay, by, az, bz) bind(C, name='x3d_sfftz_set_waves')
+      import :: c_ptr, c_int, x3d_creal
+      type(c_ptr), value :: p
+      real(x3d_creal), intent(in) :: rw(*), ax(*), bx(*), ay(*), by(*), az(*), bz(*)
+    end function
+    integer(c_int) function x3d_sfftz_spectrum(p, c, ny, px) bind(C, name='x3d_sfftz_spectrum')
+      import :: c_ptr, c_int, c_long
+      type(c_ptr), value :: p
+      type(c_ptr), intent(out) :: c
+      integer(c_int), intent(out) :: ny
+      integer(c_long), intent(out) :: px
+    end function
+    integer(c_int) function x3d_poisson_create_proxy(b, handle, spectrum, ny, px, middle, user) &
+      bind(C, name='x3d_poisson_create_proxy')
+      !! a poisson object whose hooks are: z transform ; middle(user) ; inverse z transform (include/x3d2_hip.h)
+      import :: c_ptr, c_int, c_long, c_funptr
+      type(c_ptr), value :: b, spectrum, user
+      type(c_ptr), intent(out) :: handle
+      integer(c_int), value :: ny
+      integer(c_long), value :: px
+      type(c_funptr), value :: middle
+    end function
+    integer(c_int) function x3d_sfftz_z_field(p, f, inverse) bind(C, name='x3d_sfftz_z_field')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, f
+      integer(c_int), value :: inverse
+    end function
+    integer(c_int) function x3d_sfftz_x_forward(p, sendbuf, part) bind(C, name='x3d_sfftz_x_forward')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, sendbuf
+      integer(c_int), value :: part
+    end function
+    integer(c_int) function x3d_sfftz_y_stage(p, recvbuf, part, what) bind(C, name='x3d_sfftz_y_stage')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, recvbuf
+      integer(c_int), value :: part, what
+    end function
+    integer(c_int) function x3d_sfftz_x_backward(p, buf, part) bind(C, name='x3d_sfftz_x_backward')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: p, buf
+      integer(c_int), value :: part
+    end function
     integer(c_int) function x3d_pfft_create(b, p, nglob_cell, py, pz, ry, rz) bind(C, name='x3d_pfft_create')
       import :: c_ptr, c_int
       type(c_ptr), value :: b

@@ -546,6 +546,15 @@ int x3d_poisson_solve_000_zfirst(x3d_poisson *p, x3d_real *f);
  * solver's interleave of the y rows).  X3D_NO_ZFIRST010=1: never.  x3d_poisson_solve_010_rows_zfirst: the stand-alone
  * form on a field whose rows are interleaved already == x3d_poisson_solve_010_rows up to rounding. */
 int x3d_poisson_set_stretching_zfirst(x3d_poisson *p, int sym, const x3d_real *a0, const x3d_real *a1);
+/* round 6: a PROXY poisson object for a z-first solve whose middle -- everything between the two z transforms: x
+ * transforms, all-to-alls between ranks, y transforms + process_spectral_000 -- the caller runs (the Fortran shim's y-slab
+ * solve: fortran/m_hip_backend.f90 over csrc/sfftz.hip).  spectrum = C[257][ny][px] complex (the caller's).  The hooks
+ * x3d_poisson_fft_forward / _postprocess_000 / _fft_backward and x3d_poisson_solve_000 on the proxy mean: z transform of
+ * the field onto C ; middle(user) ; inverse z transform -- and under deferred execution the recorded hooks take the same
+ * z-first rewrite as on one rank (the z transforms move onto the tiles of the neighbouring z operator pairs:
+ * x3d_tds_pair_zfirst ; middle(user) ; x3d_tds_pair_zfirst).  middle returns 0 or an error code. */
+int x3d_poisson_create_proxy(x3d_backend *b, x3d_poisson **out, x3d_real *spectrum, int ny, long px, int (*middle)(void *user),
+                             void *user);
 int x3d_poisson_solve_010_rows_zfirst(x3d_poisson *p, x3d_real *f);
 int x3d_tds_pair_zfirst(x3d_backend *b, x3d_poisson *poisson, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1,
                         const x3d_real *in2, const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
@@ -561,11 +570,15 @@ typedef struct x3d_sfftz x3d_sfftz;
 int x3d_sfftz_create(x3d_backend *b, x3d_sfftz **out, const int nglob_cell[3], int py, int ry, int parts);
 int x3d_sfftz_destroy(x3d_sfftz *p);
 int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16]); /* parts, xs, xoff, buffer elements, kz0[0..parts] */
+int x3d_sfftz_spectrum(const x3d_sfftz *p, x3d_real **c, int *ny, long *px); /* C[257][512][px], for x3d_poisson_create_proxy */
 int x3d_sfftz_set_waves(x3d_sfftz *p, const x3d_real *rw, const x3d_real *ax, const x3d_real *bx, const x3d_real *ay,
                         const x3d_real *by, const x3d_real *az, const x3d_real *bz);
 int x3d_sfftz_tds_pair(x3d_sfftz *p, int mode, x3d_real *out1, x3d_real *out2, const x3d_real *in1, const x3d_real *in2,
                        const x3d_tdsops *ta, const x3d_tdsops *tb, int *done);
 int x3d_sfftz_z(x3d_sfftz *p, x3d_real *f, int inverse);
+/* the same as a hook of the reference under deferred execution: f is fft_forward's input (read through its handle) or
+ * fft_backward's output (written whole); what the Fortran shim's y-slab Poisson solve calls (round 6) */
+int x3d_sfftz_z_field(x3d_sfftz *p, x3d_real *f, int inverse);
 int x3d_sfftz_x_forward(x3d_sfftz *p, x3d_real *sendbuf, int part);
 int x3d_sfftz_y_stage(x3d_sfftz *p, x3d_real *recvbuf, int part, int what); /* what 0: all; 1 forward, 2 inverse, 3 division */
 int x3d_sfftz_x_backward(x3d_sfftz *p, const x3d_real *buf, int part);

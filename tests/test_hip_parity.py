@@ -765,6 +765,42 @@ def test_fortran_shim_decomposed_directions_in_one_pass(nranks, inp, tmp_path):
     assert a[1:, 2].max() < 1e-11 and b[1:, 2].max() < 1e-11 and np.all(np.abs(a[:, 2] - c[:, 2]) < 1e-11)
 
 
+def test_fortran_shim_y_slabs_take_the_slab_poisson_solver_z_first(tmp_path):
+    """round 6 (task 3): the unchanged solver.f90 on [1, 2, 1] ranks of 512^3 cells each (both on this
+    GPU) -- the shim's Poisson solve is the y-slab solver of csrc/sfftz.hip (ONE all-to-all pair per solve instead of the
+    pencil solver's four transposes) behind a PROXY poisson object (x3d_poisson_create_proxy): the reference's three hooks
+    are recorded by the deferred layer like a single rank's and take its z-first rewrite, the library calls back into the
+    shim for the middle (x transforms, the two exchanges, the y stage: yslab_middle).  Against the pencil solver
+    (X3D_SHIM_NO_SLAB_FFT=1): the same monitoring.csv to 1e-12; every solve through the z-first form, nothing declined.
+    (20 steps of the same case: 0.118 -> 0.096 s per step, profiles/r06_shim_two_ranks_512.txt)"""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran", "_build", "xcompact_hip")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if not os.path.exists(exe) or not os.path.exists(mpirun):
+        pytest.skip("shim binary not built (needs the reference tree at build time) or no mpirun")
+    traces = {}
+    for name, env in (("slab", {"X3D_LAZY_REPORT": "1"}), ("pencil", {"X3D_SHIM_NO_SLAB_FFT": "1"})):
+        wd = tmp_path / name
+        wd.mkdir()
+        r = subprocess.run([mpirun, "-n", "2", exe, os.path.join(root, "fortran", "tgv512_y2_short.x3d")], cwd=wd,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, name + r.stdout[-2000:] + r.stderr[-2000:]
+        traces[name] = np.loadtxt(wd / "monitoring.csv", delimiter=",", comments="#")
+        if name == "slab":
+            reports = r.stderr.split("x3d_lazy_report pid")[1:]
+            assert len(reports) == 2, r.stderr[-2000:]
+            for l in reports:
+                st = {k: int(v) for k, v in re.findall(r"(\w+)=(-?\d+)", l)}
+                assert st["zfirst"] == 4 * 3 and st["solve000"] == 0 and st["declined"] == 0 and st["materialised"] == 0, l
+    a, b = traces["slab"], traces["pencil"]
+    assert a.shape == b.shape and a.shape[0] == 3
+    assert np.all(np.abs(a[:, 1] - b[:, 1]) < 1e-12 * 0.375) and a[:, 2].max() < 1e-11 and b[:, 2].max() < 1e-11
+    assert abs(a[0, 1] - 0.375) < 1e-9
+
+
 @pytest.mark.parametrize("env", ["X3D_NO_ONCHIP2,X3D_NO_TDS_PAIR,X3D_NO_TILE3,X3D_NO_TDS_LINCOMB", "X3D_XDIR_GENERIC",
                                  "X3D_NO_XSCAN", "X3D_NO_YTILE", "X3D_XSCAN_P1"])
 def test_fallback_kernel_families_pass_the_same_parity_tests(env):

@@ -148,6 +148,8 @@ PROTOTYPES = {
     "x3d_poisson_enforce_periodicity_y": (I, [VP, VP, VP]),
     "x3d_poisson_undo_periodicity_y": (I, [VP, VP, VP]),
     "x3d_poisson_set_stretching": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
+    "x3d_sfftz_spectrum": (I, [VP, ctypes.POINTER(VP), c_int_p, ctypes.POINTER(ctypes.c_long)]),
+    "x3d_poisson_create_proxy": (I, [VP, ctypes.POINTER(VP), VP, I, ctypes.c_long, VP, VP]),
     "x3d_poisson_set_stretching_zfirst": (I, [VP, ctypes.c_int, c_double_p, c_double_p]),
     "x3d_poisson_postprocess_010": (I, [VP]),
     "x3d_poisson_solve_010": (I, [VP, VP, VP]),
@@ -191,6 +193,7 @@ PROTOTYPES = {
     "x3d_sfftz_set_waves": (I, [VP] + [c_double_p] * 7),
     "x3d_sfftz_tds_pair": (I, [VP, I, VP, VP, VP, VP, VP, VP, c_int_p]),
     "x3d_sfftz_z": (I, [VP, VP, I]),
+    "x3d_sfftz_z_field": (I, [VP, VP, I]),
     "x3d_sfftz_x_forward": (I, [VP, VP, I]),
     "x3d_sfftz_y_stage": (I, [VP, VP, I, I]),
     "x3d_sfftz_x_backward": (I, [VP, VP, I]),

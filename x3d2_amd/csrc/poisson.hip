@@ -13,6 +13,7 @@
 #include "common.h"
 
 #include "poisson_priv.h"
+int x3d_proxy_hook(x3d_poisson *p, int which, real_t *f);  // zfirst.hip
 
 int x3d_fft512_init();
 int x3d_fft512_run(x3d_backend *b, real2_t *c, int nxs, int ny, int nz, int axis, int mode, const real_t *waves,
@@ -182,6 +183,7 @@ extern "C" int x3d_poisson_destroy(x3d_poisson *p)
 {
     X3D_RANGE(__func__);
     if (!p) return 0;
+    if (p->ext_middle) { delete p; return 0; }  // (a proxy owns nothing)
     hipfftDestroy(p->plan_fw);
     hipfftDestroy(p->plan_bw);
     if (p->fast512) { hipfftDestroy(p->plan_x_fw); hipfftDestroy(p->plan_x_bw); }
@@ -211,6 +213,7 @@ extern "C" int x3d_poisson_fft_forward(x3d_poisson *p, const real_t *f_in)
     X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_in, "x3d_poisson_fft_forward: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 0, p, const_cast<real_t *>(f_in));
+    if (p->ext_middle) return x3d_proxy_hook(p, 0, const_cast<real_t *>(f_in));
     if (p->fast512) {
         if (int rc = x_forward_512(p, f_in)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;
@@ -227,6 +230,7 @@ extern "C" int x3d_poisson_postprocess_000(x3d_poisson *p)
     X3D_RANGE(__func__);
     X3D_REQUIRE(p, "x3d_poisson_postprocess_000: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 1, p, nullptr);
+    if (p->ext_middle) return x3d_proxy_hook(p, 1, nullptr);
     const real_t *ax = p->ab, *bx = ax + p->nx, *ay = bx + p->nx, *by = ay + p->ny, *az = by + p->ny,
                  *bz = az + p->nz;
     dim3 grid((p->nxs + 255) / 256, p->ny, p->nz);
@@ -242,6 +246,7 @@ extern "C" int x3d_poisson_fft_backward(x3d_poisson *p, real_t *f_out)
     X3D_RANGE(__func__);
     X3D_REQUIRE(p && f_out, "x3d_poisson_fft_backward: null argument");
     if (x3d_lazy_active(p->b)) return x3d_lazy_fft(p->b, 2, p, f_out);
+    if (p->ext_middle) return x3d_proxy_hook(p, 2, f_out);
     if (p->fast512) {
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 2, 1, nullptr, nullptr, p->nx)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 1, nullptr, nullptr, p->nx)) return rc;
@@ -262,6 +267,11 @@ extern "C" int x3d_poisson_solve_000(x3d_poisson *p, real_t *f)
     X3D_REQUIRE(p && f, "x3d_poisson_solve_000: null argument");
     X3D_LAZY_OUT(p->b, f, false);
     X3D_LAZY_EAGER(p->b);
+    if (p->ext_middle) {  // a proxy: z ; the caller's middle ; z
+        if (int rc = x3d_proxy_hook(p, 0, f)) return rc;
+        if (int rc = x3d_proxy_hook(p, 1, nullptr)) return rc;
+        return x3d_proxy_hook(p, 2, f);
+    }
     if (p->fast512) {  // x r2c ; y ; z forward + process_spectral_000 + z backward in one pass ; y ; x c2r
         if (int rc = x_forward_512(p, f)) return rc;
         if (int rc = x3d_fft512_run(p->b, p->c, p->nxs, p->ny, p->nz, 1, 0, nullptr, nullptr, p->nx)) return rc;

@@ -34,4 +34,14 @@ struct x3d_poisson {
     int y010;             // 0: not tried yet, 1: plans made, -1: not available for these sizes / switched off
     hipfftHandle plan_x010_fw, plan_x010_bw;  // 2-D over (z, x), batched over the y rows
     real_t *rwZ;          // z-first solve: [nz/2+1][nx][ny] reciprocal wave numbers (built on first use, zfirst.hip)
+    // PROXY of a z-first solve that lives outside this object (round 6: the Fortran shim's y-slab solve, csrc/sfftz.hip +
+    // fortran/m_hip_backend.f90): only b and the fields below are valid.  The three hooks and x3d_poisson_solve_000 then
+    // mean: z transform of the field onto ext_c ; ext_middle(ext_user) = everything between the two z transforms (x, the
+    // all-to-alls, y + division, back) ; inverse z transform -- and the deferred layer's z-first rewrite (the z transforms
+    // on the tiles of the neighbouring z operator pairs) applies to the recorded hooks as on one rank
+    int (*ext_middle)(void *user);
+    void *ext_user;
+    real2_t *ext_c;       // C[257][ext_ny][ext_px]
+    int ext_ny;
+    long ext_px;
 };

@@ -119,6 +119,15 @@ extern "C" int x3d_sfftz_destroy(x3d_sfftz *p)
     return 0;
 }
 
+// this solver's spectrum C[257][512][px] (for x3d_poisson_create_proxy: the hooks of a host that runs the middle itself)
+extern "C" int x3d_sfftz_spectrum(const x3d_sfftz *p, real_t **c, int *ny, long *px)
+{
+    X3D_RANGE(__func__);
+    X3D_REQUIRE(p && c && ny && px, "null argument");
+    *c = reinterpret_cast<real_t *>(p->c); *ny = 512; *px = SZ_PX;
+    return 0;
+}
+
 // out = {parts, xs, xoff, complex elements of the exchange buffers, kz0[0 .. parts]}
 extern "C" int x3d_sfftz_sizes(const x3d_sfftz *p, long out[16])
 {
@@ -189,6 +198,22 @@ extern "C" int x3d_sfftz_z(x3d_sfftz *p, real_t *f, int inverse)
     X3D_RANGE(__func__);
     X3D_REQUIRE(p && f, "null argument");
     X3D_LAZY_SYNC(p->b);
+    return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, 0, -1);
+}
+// the same for the reference's hooks under deferred execution (the Fortran shim, round 6): fft_forward's input / fft_backward's
+// output is a HANDLE -- the queue is flushed and the buffer that holds the field used (inverse: the whole block is written,
+// a shared buffer is not copied first) instead of restoring "every block holds its own data" (x3d_sfftz_z's X3D_LAZY_SYNC
+// would materialise the reference's p_temp, a reordered alias of div_u: a 1 GB copy per solve)
+extern "C" int x3d_sfftz_z_field(x3d_sfftz *p, real_t *f, int inverse)
+{
+    X3D_RANGE(__func__);
+    X3D_REQUIRE(p && f, "null argument");
+    if (inverse) { X3D_LAZY_OUT(p->b, f, true); }
+    else {
+        const real_t *fi = f;
+        X3D_LAZY_IN(p->b, fi);
+        f = const_cast<real_t *>(fi);
+    }
     return x3d_ztile_fft_run(p->b, f, zfarg(p), !inverse, 0, -1);
 }
 extern "C" int x3d_sfftz_z_rows(x3d_sfftz *p, real_t *f, int inverse, int y0, int nyr)

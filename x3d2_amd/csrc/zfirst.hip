@@ -25,6 +25,7 @@
 
 int x3d_fft512_init();
 const real2_t *x3d_fft512_twiddles();
+int x3d_ztile_fft_run(x3d_backend *b, real_t *f, const ZfArg &zf, bool fwd, int y0, int nyr);
 int x3d_fft512_run_zh(x3d_backend *b, real2_t *c, long px, int kz0, int nkz, const real_t *rwZ, const real_t *ab, int nx,
                       int ny, int nz);
 
@@ -218,6 +219,12 @@ static bool zfirst_off()
 int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
 {
     *ok = false;
+    if (p->ext_middle) {  // a proxy (the shim's y-slab solve): the spectrum is the slab solver's
+        if (int rc = x3d_fft512_init()) return rc;
+        if (out) *out = ZfArg{p->ext_c, x3d_fft512_twiddles(), p->ext_ny, p->ext_px, 0};
+        *ok = !zfirst_off();
+        return 0;
+    }
     if (zfirst_off()) return 0;
     if (!zfirst010_off() && zfirst010_sizes(p)) {  // the channel's 010 solve
         if (int rc = x3d_fft512_init()) return rc;
@@ -240,7 +247,7 @@ int x3d_zfirst_arg(x3d_poisson *p, ZfArg *out, bool *ok)
 // (for the deferred-execution layer's rewrite: no side effects)
 bool x3d_zfirst_on_offer(x3d_poisson *p)
 {
-    return p && !zfirst_off() && zfirst_sizes(p);
+    return p && !zfirst_off() && (p->ext_middle != nullptr || zfirst_sizes(p));
 }
 
 extern "C" int x3d_poisson_zfirst_ok(x3d_poisson *p, int *ok)
@@ -275,8 +282,9 @@ extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
     X3D_REQUIRE(p, "x3d_poisson_zfirst_middle: null argument");
     bool ok = false;
     if (int rc = x3d_zfirst_arg(p, nullptr, &ok)) return rc;
-    X3D_REQUIRE(ok, "x3d_poisson_zfirst_middle: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
+    X3D_REQUIRE(ok || p->ext_middle, "x3d_poisson_zfirst_middle: not a 512^3 all-periodic solver (x3d_poisson_zfirst_ok)");
     X3D_LAZY_EAGER(p->b);
+    if (p->ext_middle) return p->ext_middle(p->ext_user);
     if (p->stretched) {  // 010: x forward ; the y pass with the pentadiagonal sweeps on its tiles ; x inverse
         x3d_backend *b = p->b;
         const int lds = sizeof(real2_t) * (8 * FP + 256);
@@ -311,6 +319,32 @@ extern "C" int x3d_poisson_zfirst_middle(x3d_poisson *p)
     if (int rc = c2c_x<-1>(p, 0, 257)) return rc;
     if (int rc = x3d_fft512_run_zh(p->b, p->c, ZH_PX, 0, 257, p->rwZ, p->ab, p->nx, p->ny, p->nz)) return rc;
     return c2c_x<1>(p, 0, 257);
+}
+
+// ---- proxy of a z-first solve whose middle the CALLER runs (include/x3d2_hip.h, x3d_poisson_create_proxy)
+extern "C" int x3d_poisson_create_proxy(x3d_backend *b, x3d_poisson **out, x3d_real *spectrum, int ny, long px,
+                                        int (*middle)(void *), void *user)
+{
+    X3D_RANGE(__func__);
+    X3D_REQUIRE(b && out && spectrum && middle && ny > 0 && px >= b->nx, "x3d_poisson_create_proxy: bad argument");
+    X3D_REQUIRE(b->nz == 512 && b->nx % 16 == 0 && ny <= b->ny, "x3d_poisson_create_proxy: 512-row z pencils");
+    x3d_poisson *p = new x3d_poisson();
+    memset(p, 0, sizeof *p);
+    p->b = b;
+    p->nx = b->nx; p->ny = ny; p->nz = 512;
+    p->ext_middle = middle; p->ext_user = user;
+    p->ext_c = reinterpret_cast<real2_t *>(spectrum); p->ext_ny = ny; p->ext_px = px;
+    if (int rc = x3d_fft512_init()) return rc;
+    *out = p;
+    return 0;
+}
+// the proxy's hooks run eagerly (the deferred layer off): forward = z transform of the field, postprocess = the caller's
+// middle, backward = inverse z transform
+int x3d_proxy_hook(x3d_poisson *p, int which, real_t *f)
+{
+    if (which == 1) return p->ext_middle(p->ext_user);
+    ZfArg zf{p->ext_c, x3d_fft512_twiddles(), p->ext_ny, p->ext_px, 0};
+    return x3d_ztile_fft_run(p->b, f, zf, which == 0, 0, -1);
 }
 
 // the z transform of a block's field, tile by tile (also for csrc/sfftz.hip)
