@@ -337,6 +337,8 @@ struct x3d_tdsops {
     unsigned long long tl_hash;  // FNV-1a of the lane tables: equal operators can share them in LDS (xscan.hip, K3y)
     const real_t *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
     const real_t *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
+    int direct;                  // 1: non-periodic on one rank and the plain Thomas factors reproduce the reference's sweeps
+    const real_t *td5, *td8h;    // DIRECT lane tables (tds.hip, ygen.hip): 5 rows per lane; 8 rows per lane of a half-wave + row 257
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
     int uniform;                 // 1: stretch == 1 and stretch_correct == 0 on every row (a uniform grid): kernels may skip
                                  //    the ST / STC lane-table reads and their multiplications (x * 1.0, + nu * x * 0.0)

@@ -205,9 +205,155 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         tl5_off = img.size();
         img.insert(img.end(), tlv.begin(), tlv.end());
     }
+    // DIRECT tables (round 6, ygen.hip thomas_solve): a non-periodic operator on ONE rank is a plain tridiagonal system
+    // a_j x_{j-1} + b_j x_j + c_j x_{j+1} = r_j with a_1 = c_n = 0 -- the reference's distributed form (two interface
+    // rows, spike vectors dist_sa / dist_sc, 2 x 2 closure; distributed.f90:170-229) solves exactly that system when
+    // both neighbours are absent (rs_s = rs_e = 1, sa(1) = sc(n) = 0).  The tile kernels then run the Thomas
+    // recurrences themselves, parallel over lanes by the same scans, WITHOUT the closure phase (no SA / SC reads, no
+    // du_1 / X_n broadcasts, no row selects): the matrix is recovered from the preprocessed arrays (the inverse of
+    // preprocess_dist, src/tdsops.f90:874-931), factored here, and the result is checked on the host against the
+    // reference's own sweeps before the tables are offered.
+    size_t td5_off = 0, td8h_off = 0;
+    {
+        bool direct = !periodic && dist_sa[0] == 0.0 && dist_sc[n - 1] == 0.0 && n >= 8;
+        std::vector<real_t> ma(n + 2, 0.0), mb(n + 2, 0.0), mc(n + 2, 0.0), TF(L, 0.0), TFA(L, 0.0), TH(L, 0.0);
+        if (direct) {
+            auto scp = [&](int i) { return i <= n - 3 ? dist_bw[i] : dist_sc[i]; };  // (0-based) c_i after its forward step
+            for (int i = 0; i < 2; i++) {
+                mb[i + 1] = 1.0 / dist_af[i];
+                mc[i + 1] = scp(i) * mb[i + 1];
+            }
+            ma[2] = (dist_sa[1] + scp(1) * dist_sa[2]) * mb[2];  // (the backward step of preprocess_dist undone for row 2)
+            for (int i = 2; i < n; i++) {
+                ma[i + 1] = dist_af[i];
+                mb[i + 1] = 1.0 / dist_fw[i] + ma[i + 1] * scp(i - 1);
+                mc[i + 1] = scp(i) / dist_fw[i];
+            }
+            mc[n] = 0.0;
+            real_t g = 0.0;
+            for (int j = 1; j <= n; j++) {
+                const real_t f = 1.0 / (mb[j] - ma[j] * g);
+                TF[j] = f;
+                TFA[j] = -f * ma[j];
+                g = mc[j] * f;
+                TH[j] = j < n ? -g : 0.0;
+                if (!std::isfinite(f)) direct = false;
+            }
+        }
+        if (direct) {  // host check: the reference's sweeps against the plain Thomas sweeps, two right-hand sides
+            std::vector<real_t> r(n + 2), d(n + 2), x(n + 2), e(n + 2), y(n + 2);
+            unsigned long long s = 0x9E3779B97F4A7C15ull;
+            for (int rep = 0; rep < 2 && direct; rep++) {
+                for (int j = 1; j <= n; j++) {
+                    s = s * 6364136223846793005ull + 1442695040888963407ull;
+                    r[j] = (real_t)((double)(s >> 11) / 9007199254740992.0 - 0.5);
+                }
+                d[1] = r[1] * F[1];
+                d[2] = r[2] * F[2];
+                for (int j = 3; j <= n; j++) d[j] = F[j] * (r[j] - A[j] * d[j - 1]);
+                x = d;
+                for (int j = n - 2; j >= 2; j--) x[j] = d[j] - Bw[j] * x[j + 1];
+                x[1] = dist_fw[0] * (d[1] - Bw[1] * x[2]);
+                const real_t du_s = x[1], du_e = x[n];
+                real_t xmax = 0.0, emax = 0.0;
+                e[0] = 0.0;
+                for (int j = 1; j <= n; j++) e[j] = TF[j] * r[j] + TFA[j] * e[j - 1];
+                y[n + 1] = 0.0;
+                for (int j = n; j >= 1; j--) y[j] = e[j] + TH[j] * y[j + 1];
+                for (int j = 1; j <= n; j++) {
+                    const real_t ref = j == 1 ? du_s : (j == n ? du_e : x[j] - Sa[j] * du_s - Sc[j] * du_e);
+                    xmax = fmax(xmax, fabs(ref));
+                    emax = fmax(emax, fabs(ref - y[j]));
+                }
+                if (!(emax <= (sizeof(real_t) == 8 ? 1e-13 : 1e-5) * xmax)) direct = false;
+            }
+        }
+        t->direct = direct ? 1 : 0;
+        // [7 Q + 12][64]: F FA PF H QB ST | 6 + 6 scan multipliers | STC; LP lanes per pencil (32: two pencils per wave,
+        // the tables of lanes 32..63 repeat lanes 0..31); XR: row LP Q + 1 exists and is carried by the pencil's last
+        // lane (257 rows = 32 x 8 + 1): its F, FA, ST, STC go in as entries 7 Q + 12 .. + 3, every lane the same
+        auto build_direct = [&](const int Q, const int LP, std::vector<real_t> &out) {
+            const bool XR = n == LP * Q + 1;
+            const int NE = 7 * Q + 12 + 4;
+            out.assign((size_t)NE * 64, 0.0);
+            real_t *tl = out.data();
+            auto E = [&](int e, int l) -> real_t & { return tl[(size_t)e * 64 + l]; };
+            real_t G[64], HL[64];
+            for (int l = 0; l < LP; l++) {
+                real_t pg = 1.0;
+                for (int q = 0; q < Q; q++) {
+                    const int j = l * Q + q + 1;
+                    const bool real = j <= n;
+                    E(0 * Q + q, l) = real ? TF[j] : 0.0;
+                    E(1 * Q + q, l) = real ? TFA[j] : 0.0;
+                    pg *= real ? TFA[j] : 0.0;
+                    E(2 * Q + q, l) = pg;
+                    E(3 * Q + q, l) = real ? TH[j] : 0.0;
+                    E(5 * Q + q, l) = real ? St[j] : 0.0;
+                    E(6 * Q + 12 + q, l) = real ? Stc[j] : 0.0;
+                }
+                G[l] = pg;
+                real_t ph = 1.0;
+                // (XR: the last lane starts its backward sweep from the extra row's value, not from a carry)
+                for (int q = Q - 1; q >= 0; q--) { ph *= E(3 * Q + q, l); E(4 * Q + q, l) = (XR && l == LP - 1) ? 0.0 : ph; }
+                HL[l] = (XR && l == LP - 1) ? 0.0 : ph;
+            }
+            real_t mf[64], mbk[64];
+            for (int l = 0; l < LP; l++) { mf[l] = G[l]; mbk[l] = HL[l]; }
+            for (int k = 0; k < 4; k++) {
+                const int d = 1 << k;
+                real_t nf[64], nb[64];
+                for (int l = 0; l < LP; l++) {
+                    E(6 * Q + k, l) = mf[l];
+                    E(6 * Q + 6 + k, l) = mbk[l];
+                    // (DPP row shifts stay inside a row of 16 lanes)
+                    nf[l] = (l & 15) >= d ? mf[l] * mf[l - d] : mf[l];
+                    nb[l] = (l & 15) + d < 16 ? mbk[l] * mbk[l + d] : mbk[l];
+                }
+                for (int l = 0; l < LP; l++) { mf[l] = nf[l]; mbk[l] = nb[l]; }
+            }
+            for (int l = 0; l < LP; l++) {
+                real_t c15 = 1.0, c31 = 1.0, d16 = 1.0, d32 = 1.0;
+                for (int i = l & ~15; i <= l; i++) c15 *= G[i];
+                for (int i = 32; i <= l; i++) c31 *= G[i];
+                for (int i = l; i <= (l | 15); i++) d16 *= HL[i];
+                for (int i = l; i <= 31; i++) d32 *= HL[i];
+                const int row = l >> 4;
+                E(6 * Q + 4, l) = (row == 1 || row == 3) ? c15 : 0.0;
+                E(6 * Q + 5, l) = (LP == 64 && row >= 2) ? c31 : 0.0;
+                E(6 * Q + 6 + 4, l) = (row == 0 || row == 2) ? d16 : 0.0;
+                E(6 * Q + 6 + 5, l) = (LP == 64 && row < 2) ? d32 : 0.0;
+            }
+            if (XR) {
+                for (int l = 0; l < LP; l++) {
+                    E(7 * Q + 12 + 0, l) = TF[n];
+                    E(7 * Q + 12 + 1, l) = TFA[n];
+                    E(7 * Q + 12 + 2, l) = St[n];
+                    E(7 * Q + 12 + 3, l) = Stc[n];
+                }
+            }
+            if (LP == 32)
+                for (int e = 0; e < NE; e++)
+                    for (int l = 0; l < 32; l++) E(e, 32 + l) = E(e, l);
+        };
+        if (direct && nr > 256 && nr <= 320) {
+            std::vector<real_t> tlv;
+            build_direct(5, 64, tlv);
+            td5_off = img.size();
+            img.insert(img.end(), tlv.begin(), tlv.end());
+        }
+        if (direct && nr == 257 && n == 257) {
+            std::vector<real_t> tlv;
+            build_direct(8, 32, tlv);
+            td8h_off = img.size();
+            img.insert(img.end(), tlv.begin(), tlv.end());
+        }
+    }
     X3D_HIP(hipMalloc(&t->dev, sizeof(real_t) * img.size()));
     X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(real_t) * img.size(), hipMemcpyHostToDevice));
     t->tl5 = tl5_off ? t->dev + tl5_off : nullptr;
+    t->td5 = td5_off ? t->dev + td5_off : nullptr;
+    t->td8h = td8h_off ? t->dev + td8h_off : nullptr;
     TdsTab &tb = t->tab;
     tb.n_tds = n; tb.n_rhs = nr; tb.chunk = chunk;
     tb.RF = t->dev; tb.RB = t->dev + (size_t)4 * L;

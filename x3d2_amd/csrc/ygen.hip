@@ -23,12 +23,127 @@ template <int Q> struct GenGeom {
     static constexpr int NI = (NMAX + 127) / 128;
 };
 
+// ---------------------------------------------------------------- DIRECT form (round 6)
+// A non-periodic operator on one rank is a plain tridiagonal system; tds.hip recovers it from the preprocessed arrays,
+// factors it (F_j = 1 / (b_j - a_j g_{j-1}), g_j = c_j F_j) and checks the factors against the reference's sweeps.  The
+// solve is then the Thomas recurrences e_j = F_j r_j + FA_j e_{j-1}, x_j = e_j + H_j x_{j+1} (FA = -F a, H = -g), made
+// parallel over the lanes exactly like scan_solve (lane-local sweeps from zero, Kogge-Stone scans of the lane-end values
+// with precomputed multipliers, carries applied) -- and that is all: no reduced 2 x 2 system, no SA / SC spike reads, no
+// du_1 / X_n broadcasts, no row selects (scan_solve + gen_solve: ~154 vector instructions per right-hand side at Q = 5,
+// this: ~100), one dependent FMA per row in the sweeps instead of two.  Same linear system as the reference's
+// distributed.f90:34-229 with both neighbours absent; results differ by round-off (1e-15 relative, tds.hip's check).
+// LP: lanes per pencil.  32 = TWO pencils per wave (lanes 0..31, 32..63): the scans' cross-row steps shrink to one and
+// their cost is shared.  XR (LP * Q + 1 rows, the channel's 257 = 32 * 8 + 1): the pencil's last lane also carries row
+// LP Q + 1 -- its right-hand side from the lane's own window (rows first+Q-4 .. first+Q), its forward step after the carry
+// is applied, and its value starts that lane's backward sweep; xr returns the row's result.
+#define DT_F(q) (0 * Q + (q))
+#define DT_FA(q) (1 * Q + (q))
+#define DT_PF(q) (2 * Q + (q))
+#define DT_H(q) (3 * Q + (q))
+#define DT_QB(q) (4 * Q + (q))
+#define DT_ST(q) (5 * Q + (q))
+#define DT_MF(k) (6 * Q + (k))
+#define DT_MB(k) (6 * Q + 6 + (k))
+#define DT_STC(q) (6 * Q + 12 + (q))
+#define DT_X(k) (7 * Q + 12 + (k))     // XR: F, FA, ST, STC of row LP Q + 1
+#define DT_N(Q_) (7 * (Q_) + 12 + 4)
+#define DT_NC(Q_) (6 * (Q_) + 12)      // entries without the STC block (and without the XR entries)
+// stencil slots (stage_cs): lane 0, lanes ls and ls + 1 of the pencil, bulk
+template <int Q, int LP>
+__device__ __forceinline__ int cs_slot(int lane, int n_rhs)
+{
+    const int lr = lane & (LP - 1), ls = (n_rhs - 4) / Q;
+    return (lr == 0 ? 0 : (lr == ls ? 1 : (lr == ls + 1 ? 2 : 3))) * (Q * 10);
+}
+template <int Q, int LP, bool NARROW, bool XR = false, class T = real_t>
+__device__ __forceinline__ void thomas_solve(const T (&w)[Q + 8], T (&X)[Q], T &xr, const real_t *__restrict__ lt,
+                                             const real_t *__restrict__ cs, int co, int &lane)
+{
+#define PHASE(x) asm volatile("" : "+v"(lane) : "v"(first_of(x)))
+    T acc[Q], accx = zero_of<T>();
+    {
+        constexpr bool D2 = NARROW || sizeof(T) == sizeof(real_t);
+        int co1 = co;
+        if constexpr (D2) asm volatile("" : "+v"(co1));
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            int &coq = (D2 && (q & 1)) ? co1 : co;
+            const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + coq + q * 10);
+            if (NARROW) {
+                const real2_t cb = c2[1], cc = c2[2], cd = c2[3];
+                acc[q] = cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] + cc.y * w[q + 5] + cd.x * w[q + 6];
+            } else {
+                const real2_t ca = c2[0], cb = c2[1], cc = c2[2], cd = c2[3], ce = c2[4];
+                acc[q] = ca.x * w[q] + ca.y * w[q + 1] + cb.x * w[q + 2] + cb.y * w[q + 3] + cc.x * w[q + 4] +
+                         cc.y * w[q + 5] + cd.x * w[q + 6] + cd.y * w[q + 7] + ce.x * w[q + 8];
+            }
+            asm volatile("" : "+v"(coq) : "v"(first_of(acc[q])));
+        }
+        if constexpr (XR) {  // row LP Q + 1 = window entry Q + 4; its (end) stencil reaches back only: entries Q .. Q + 4
+            const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + CS_N(Q));
+            const real2_t ca = c2[0], cb = c2[1], cc = c2[2];
+            accx = ca.x * w[Q] + ca.y * w[Q + 1] + cb.x * w[Q + 2] + cb.y * w[Q + 3] + cc.x * w[Q + 4];
+        }
+    }
+    // ---- lane-local forward sweep from zero
+    T prev = zero_of<T>();
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        X[q] = LTR(lt, DT_F(q)) * acc[q] + LTR(lt, DT_FA(q)) * prev;
+        prev = X[q];
+    }
+    T v = prev;
+    PHASE(X[Q / 2]);
+    v += LTR(lt, DT_MF(0)) * dpp0<0x111>(v);
+    v += LTR(lt, DT_MF(1)) * dpp0<0x112>(v);
+    v += LTR(lt, DT_MF(2)) * dpp0<0x114>(v);
+    v += LTR(lt, DT_MF(3)) * dpp0<0x118>(v);
+    v += LTR(lt, DT_MF(4)) * dpp0<0x142>(v);
+    if constexpr (LP == 64) v += LTR(lt, DT_MF(5)) * dpp0<0x143>(v);
+    T carry = dpp0<0x138>(v);  // wave_shr:1 (lane 32 of the two-pencil form: PF = 0, its pencil starts there)
+    T nxt = zero_of<T>();
+    if constexpr (XR) {
+        // v = e at this lane's last row; in the pencil's last lane that is row LP Q: the extra row's forward step and,
+        // being the system's last row, its solution
+        const T ex = LTR(lt, DT_X(0)) * accx + LTR(lt, DT_X(1)) * v;
+        nxt = sel_of((lane & (LP - 1)) == LP - 1, ex, nxt);
+        xr = ex * LTR(lt, DT_X(2));
+    }
+    PHASE(carry);
+#pragma unroll
+    for (int q = Q - 1; q >= 0; q--) {
+        X[q] = (X[q] + LTR(lt, DT_PF(q)) * carry) + LTR(lt, DT_H(q)) * nxt;
+        nxt = X[q];
+    }
+    v = nxt;
+    PHASE(X[Q / 2]);
+    v += LTR(lt, DT_MB(0)) * dpp0<0x101>(v);
+    v += LTR(lt, DT_MB(1)) * dpp0<0x102>(v);
+    v += LTR(lt, DT_MB(2)) * dpp0<0x104>(v);
+    v += LTR(lt, DT_MB(3)) * dpp0<0x108>(v);
+    {
+        const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
+        v += LTR(lt, DT_MB(4)) * sel_of(lane < 32, s16, s48);
+        if constexpr (LP == 64) v += LTR(lt, DT_MB(5)) * readlane_d(v, 32);
+    }
+    carry = dpp0<0x130>(v);  // wave_shl:1 (a pencil's last lane: QB = 0)
+#pragma unroll
+    for (int q = 0; q < Q; q++) X[q] = (X[q] + LTR(lt, DT_QB(q)) * carry) * LTR(lt, DT_ST(q));
+    PHASE(X[0]);
+#undef PHASE
+}
+
 // one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
 // (T = V2: two right-hand sides of the SAME operator in one solve -- every table value read from LDS serves both)
-template <int Q, bool NARROW, class T = real_t>
+template <int Q, bool NARROW, class T = real_t, bool DIRECT = false>
 __device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const real_t *__restrict__ lt,
                                           const real_t *__restrict__ cs, const XOp &t, int &lane)
 {
+    if constexpr (DIRECT) {
+        T xr;
+        thomas_solve<Q, 64, NARROW, false, T>(w, r, xr, lt, cs, cs_slot<Q, 64>(lane, t.n_rhs), lane);
+        return;
+    }
     const int first = lane * Q + 1, n = t.n_tds;
     T X[Q], du1, xn;
     scan_solve<Q, false, NARROW, T>(w, X, du1, xn, lt, t, lane, first, 0, cs);
@@ -136,14 +251,14 @@ template <int Q> struct GenTile {
 // ---------------------------------------------------------------- operator pairs / single operators
 //   MODE 0: out1 = A(in1) + B(in2)     MODE 1: out1 = A(in1), out2 = B(in1)     MODE 2: out1 = A(in1)
 // (the pairs of divergence_v2c / gradient_c2v, src/vector_calculus.f90:142-332, as in k_ytile_tds_pair)
-template <int Q, int MODE, bool NARROW>
+template <int Q, int MODE, bool NARROW, bool DIRECT = false>
 __global__ void __launch_bounds__(1024)
     k_ygen_pair(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2, XOp ta, XOp tb,
                 int ntx, int ntiles, long prow, long pplane, int nrow, int permn)
 {
     using G = GenGeom<Q>;
     extern __shared__ real_t lt[];
-    constexpr int LN = LT_N(Q) * 64;
+    constexpr int LN = (DIRECT ? DT_NC(Q) : LT_N(Q)) * 64;
     for (int i = threadIdx.x; i < LN; i += blockDim.x) {
         lt[i] = ta.TL[i];
         if (MODE != 2) lt[LN + i] = tb.TL[i];
@@ -181,14 +296,14 @@ __global__ void __launch_bounds__(1024)
             const int tn = tl + gridDim.x;
             if (tn < ntiles) T.gload(nxt, in1 + in1_off(tn));
         }
-        gen_solve<Q, NARROW>(w, ra, lt, cs, ta, lane);
+        gen_solve<Q, NARROW, real_t, DIRECT>(w, ra, lt, cs, ta, lane);
         if (MODE == 0) {
             T.to_tile(g2);
             __syncthreads();
             T.window(w);
         }
         if (MODE != 2) {
-            gen_solve<Q, NARROW>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
+            gen_solve<Q, NARROW, real_t, DIRECT>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
             if (MODE == 0) {
 #pragma unroll
                 for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];  // (the accumulating form: old + 1.0 * r)
@@ -215,7 +330,7 @@ __global__ void __launch_bounds__(1024)
 // NP: pencils (= waves) per workgroup.  8 (round 5, 257..320-row pencils): two workgroups per CU -- the lock-step phases of
 // one (load, solve, store, barriers) run beside the other's; their 64-byte row segments pair up into 128-byte lines, so the
 // two tiles of a pair go to workgroups of the same XCD (one L2) that run at the same time
-template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW, int NP = 16>
+template <int Q, bool ACC, bool NARROW, bool NARROW1 = NARROW, int NP = 16, bool DIRECT = false>
 __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
     k_ygen_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0, const real_t *__restrict__ u1,
                     const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, int nrow,
@@ -231,7 +346,8 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
 #endif
     constexpr bool LATE = P12 && Q <= 5;  // where the rows the result is added to are requested (register budget)
     extern __shared__ real_t lt[];
-    constexpr int LN = LT_N(Q) * 64, L1N = LT_NC(Q) * 64;  // (the first operator's STC block is never read)
+    constexpr int LN = (DIRECT ? DT_N(Q) - 4 : LT_N(Q)) * 64, L1N = (DIRECT ? DT_NC(Q) : LT_NC(Q)) * 64;  // (the first operator's STC block is never read)
+    constexpr int E_STC = DIRECT ? DT_STC(0) : LT_STC(0);
     for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
     for (int i = threadIdx.x; i < LN; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
     const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
@@ -287,9 +403,9 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
 #pragma unroll
                     for (int m = 0; m < Q + 8; m++) w2[m] = V2{wu[m] * wc[m], wu[m]};
                 }
-                gen_solve<Q, NARROW1, V2>(w2, X2, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW1, V2, DIRECT>(w2, X2, l1, cs, tD1, lane);
 #pragma unroll
-                for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X2[q].b + X2[q].a) + nu * (X2[q].b * LTR(l3, LT_STC(q)));
+                for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X2[q].b + X2[q].a) + nu * (X2[q].b * LTR(l3, E_STC + q));
             } else {
             {
                 // d(u conv): the product window; the field's own window is read again from the tile afterwards
@@ -303,7 +419,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
                 window_from_body_zero<Q>(wc, cb);
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wc[m];
-                gen_solve<Q, NARROW1>(wp, X, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW1, real_t, DIRECT>(wp, X, l1, cs, tD1, lane);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = X[q];
@@ -311,17 +427,17 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
             {
                 real_t wu[Q + 8];
                 T.window(wu);
-                gen_solve<Q, NARROW1>(wu, X, l1, cs, tD1, lane);  // du
+                gen_solve<Q, NARROW1, real_t, DIRECT>(wu, X, l1, cs, tD1, lane);  // du
             }
 #pragma unroll
-            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, LT_STC(q)));
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, E_STC + q));
             }
             if (ACC && LATE) T.gload(old, o);
             asm volatile("" : "+v"(lane) : "v"(r[0]));
             {
                 real_t wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
                 T.window(wu);
-                gen_solve<Q, NARROW>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
+                gen_solve<Q, NARROW, real_t, DIRECT>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] += nu * X[q];
@@ -362,11 +478,20 @@ static int gen_q(const x3d_backend *b, int dir, const x3d_tdsops *const *ops, in
     for (int k = 0; k < nops; k++) all5 = all5 && ops[k]->tl5 != nullptr;
     return all5 ? 5 : ops[0]->tab.Q;
 }
-static XOp gen_xop(const x3d_tdsops *t, int Q)
+static XOp gen_xop(const x3d_tdsops *t, int Q, bool direct = false)
 {
     XOp o = xop_of(t);
-    if (Q == 5) o.TL = t->tl5;
+    if (Q == 5) o.TL = direct ? t->td5 : t->tl5;
     return o;
+}
+// the DIRECT form (thomas_solve) where every operator of the launch offers its tables.  X3D_NO_DIRECT=1: never (A/B)
+static bool gen_direct(const x3d_tdsops *const *ops, int nops, int Q)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_DIRECT"); on = (e && e[0] == '1') ? 0 : 1; }
+    bool d = on && Q == 5;
+    for (int k = 0; k < nops; k++) d = d && ops[k]->direct && ops[k]->td5 != nullptr;
+    return d;
 }
 struct GenLaunch {
     int ntx, ntiles, blocks, nrow;
@@ -394,7 +519,8 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2,
     const x3d_tdsops *const ops[2] = {ta, mode == 2 ? ta : tb};
     const int Q = gen_q(b, dir, ops, 2);
     if (!gen_ok(b, dir, ta, Q) || (mode != 2 && !gen_ok(b, dir, tb, Q))) return 0;
-    const size_t lds = sizeof(real_t) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
+    const bool direct = gen_direct(ops, 2, Q);
+    const size_t lds = sizeof(real_t) * ((size_t)(mode == 2 ? 1 : 2) * (direct ? DT_NC(Q) : LT_N(Q)) * 64 + 16 * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     const GenLaunch g = gen_launch(b, dir);
     const x3d_tdsops *tb_ = mode == 2 ? ta : tb;
@@ -403,15 +529,15 @@ int x3d_ygen_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2,
     if (permn > 0 && (dir != X3D_DIR_Z || mode == 2)) return 0;
     {
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GO(Q_, M_, N_)                                                                                          \
+#define GO(Q_, M_, N_, D_)                                                                                      \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_, N_>));                                                            \
-        hipLaunchKernelGGL((k_ygen_pair<Q_, M_, N_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
-                           gen_xop(ta, Q_), gen_xop(tb_, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, permn); \
+        X3D_LDS_OPTIN(b, (k_ygen_pair<Q_, M_, N_, D_>));                                                        \
+        hipLaunchKernelGGL((k_ygen_pair<Q_, M_, N_, D_>), dim3(g.blocks), dim3(1024), lds, b->stream, out1, out2, in1, in2, \
+                           gen_xop(ta, Q_, D_), gen_xop(tb_, Q_, D_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, permn); \
     } while (0)
-#define GON(Q_, M_) do { if (narrow) GO(Q_, M_, true); else GO(Q_, M_, false); } while (0)
-#define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
-    if (Q == 8) GOM(8); else if (Q == 6) GOM(6); else if (Q == 5) GOM(5); else GOM(4);
+#define GON(Q_, M_, D_) do { if (narrow) GO(Q_, M_, true, D_); else GO(Q_, M_, false, D_); } while (0)
+#define GOM(Q_, D_) do { if (mode == 0) GON(Q_, 0, D_); else if (mode == 1) GON(Q_, 1, D_); else GON(Q_, 2, D_); } while (0)
+    if (Q == 8) GOM(8, false); else if (Q == 6) GOM(6, false); else if (Q == 5) { if (direct) GOM(5, true); else GOM(5, false); } else GOM(4, false);
 #undef GOM
 #undef GON
 #undef GO
@@ -442,7 +568,8 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t 
     static int np16 = -1;
     if (np16 < 0) { const char *e = getenv("X3D_YGEN_NP16"); np16 = (e && e[0] == '1') ? 1 : 0; }
     const int NP = (Q == 5 && !np16 && b->nx % 32 == 0) ? 8 : 16;
-    const size_t lds = sizeof(real_t) * ((size_t)(LT_NC(Q) + LT_N(Q)) * 64 + NP * (64 * Q + 10) + 2 * CS_N(Q));
+    const bool direct = gen_direct(ops, 4, Q);
+    const size_t lds = sizeof(real_t) * ((size_t)(direct ? DT_NC(Q) + DT_N(Q) - 4 : LT_NC(Q) + LT_N(Q)) * 64 + NP * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     GenLaunch g = gen_launch(b, dir);
     if (NP == 8) {
@@ -456,15 +583,17 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t 
     const bool narrow1 = der1st->narrow_all, narrow = narrow1 && der2nd->narrow_all;
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
-#define GO(Q_, A_, N_, N1_, P_)                                                                                 \
+#define GO(Q_, A_, N_, N1_, P_, D_)                                                                             \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_, N1_, P_>));                                               \
-        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_, N1_, P_>), dim3(g.blocks), dim3(64 * P_), lds, b->stream, r[0], r[1], r[2], f[0], \
-                           f[1], f[2], gen_xop(der1st, Q_), gen_xop(der2nd, Q_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
+        X3D_LDS_OPTIN(b, (k_ygen_transeq3<Q_, A_, N_, N1_, P_, D_>));                                           \
+        hipLaunchKernelGGL((k_ygen_transeq3<Q_, A_, N_, N1_, P_, D_>), dim3(g.blocks), dim3(64 * P_), lds, b->stream, r[0], r[1], r[2], f[0], \
+                           f[1], f[2], gen_xop(der1st, Q_, D_), gen_xop(der2nd, Q_, D_), g.ntx, g.ntiles, g.rstride, g.ostride, g.nrow, nu); \
     } while (0)
-#define GON(Q_, A_, P_) do { if (narrow) GO(Q_, A_, true, true, P_); else if (narrow1) GO(Q_, A_, false, true, P_); else GO(Q_, A_, false, false, P_); } while (0)
-#define GOA(Q_, P_) do { if (acc) GON(Q_, true, P_); else GON(Q_, false, P_); } while (0)
-        if (Q == 8) GOA(8, 16); else if (Q == 6) GOA(6, 16); else if (Q == 5) { if (NP == 8) GOA(5, 8); else GOA(5, 16); } else GOA(4, 16);
+#define GON(Q_, A_, P_, D_) do { if (narrow) GO(Q_, A_, true, true, P_, D_); else if (narrow1) GO(Q_, A_, false, true, P_, D_); else GO(Q_, A_, false, false, P_, D_); } while (0)
+#define GOA(Q_, P_, D_) do { if (acc) GON(Q_, true, P_, D_); else GON(Q_, false, P_, D_); } while (0)
+        if (Q == 8) GOA(8, 16, false); else if (Q == 6) GOA(6, 16, false);
+        else if (Q == 5) { if (NP == 8) { if (direct) GOA(5, 8, true); else GOA(5, 8, false); } else { if (direct) GOA(5, 16, true); else GOA(5, 16, false); } }
+        else GOA(4, 16, false);
 #undef GOA
 #undef GON
 #undef GO
