@@ -269,12 +269,12 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             }
         }
         t->direct = direct ? 1 : 0;
-        // [7 Q + 12][64]: F FA PF H QB ST | 6 + 6 scan multipliers | STC; LP lanes per pencil (32: two pencils per wave,
-        // the tables of lanes 32..63 repeat lanes 0..31); XR: row LP Q + 1 exists and is carried by the pencil's last
-        // lane (257 rows = 32 x 8 + 1): its F, FA, ST, STC go in as entries 7 Q + 12 .. + 3, every lane the same
+        // [7 Q + 16][64]: F FA PF H QB ST | 6 + 6 scan multipliers | XR (4) | STC; LP lanes per pencil (32: two pencils per
+        // wave, the tables of lanes 32..63 repeat lanes 0..31); XR: row LP Q + 1 exists and is carried by the pencil's last
+        // lane (257 rows = 32 x 8 + 1): its F, FA, ST, STC, every lane the same
         auto build_direct = [&](const int Q, const int LP, std::vector<real_t> &out) {
             const bool XR = n == LP * Q + 1;
-            const int NE = 7 * Q + 12 + 4;
+            const int NE = 7 * Q + 16;
             out.assign((size_t)NE * 64, 0.0);
             real_t *tl = out.data();
             auto E = [&](int e, int l) -> real_t & { return tl[(size_t)e * 64 + l]; };
@@ -290,7 +290,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                     E(2 * Q + q, l) = pg;
                     E(3 * Q + q, l) = real ? TH[j] : 0.0;
                     E(5 * Q + q, l) = real ? St[j] : 0.0;
-                    E(6 * Q + 12 + q, l) = real ? Stc[j] : 0.0;
+                    E(6 * Q + 16 + q, l) = real ? Stc[j] : 0.0;
                 }
                 G[l] = pg;
                 real_t ph = 1.0;
@@ -326,10 +326,10 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             }
             if (XR) {
                 for (int l = 0; l < LP; l++) {
-                    E(7 * Q + 12 + 0, l) = TF[n];
-                    E(7 * Q + 12 + 1, l) = TFA[n];
-                    E(7 * Q + 12 + 2, l) = St[n];
-                    E(7 * Q + 12 + 3, l) = Stc[n];
+                    E(6 * Q + 12 + 0, l) = TF[n];
+                    E(6 * Q + 12 + 1, l) = TFA[n];
+                    E(6 * Q + 12 + 2, l) = St[n];
+                    E(6 * Q + 12 + 3, l) = Stc[n];
                 }
             }
             if (LP == 32)
@@ -342,7 +342,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             td5_off = img.size();
             img.insert(img.end(), tlv.begin(), tlv.end());
         }
-        if (direct && nr == 257 && n == 257) {
+        if (direct && nr == 257) {  // (n = 257: with the extra row; n = 256: a v2p operator, 32 x 8 rows)
             std::vector<real_t> tlv;
             build_direct(8, 32, tlv);
             td8h_off = img.size();

@@ -44,10 +44,10 @@ template <int Q> struct GenGeom {
 #define DT_ST(q) (5 * Q + (q))
 #define DT_MF(k) (6 * Q + (k))
 #define DT_MB(k) (6 * Q + 6 + (k))
-#define DT_STC(q) (6 * Q + 12 + (q))
-#define DT_X(k) (7 * Q + 12 + (k))     // XR: F, FA, ST, STC of row LP Q + 1
-#define DT_N(Q_) (7 * (Q_) + 12 + 4)
-#define DT_NC(Q_) (6 * (Q_) + 12)      // entries without the STC block (and without the XR entries)
+#define DT_X(k) (6 * Q + 12 + (k))     // XR: F, FA, ST, STC of row LP Q + 1 (zeros otherwise)
+#define DT_STC(q) (6 * Q + 16 + (q))
+#define DT_N(Q_) (7 * (Q_) + 16)
+#define DT_NC(Q_) (6 * (Q_) + 16)      // entries without the STC block
 // stencil slots (stage_cs): lane 0, lanes ls and ls + 1 of the pencil, bulk
 template <int Q, int LP>
 __device__ __forceinline__ int cs_slot(int lane, int n_rhs)
@@ -55,18 +55,29 @@ __device__ __forceinline__ int cs_slot(int lane, int n_rhs)
     const int lr = lane & (LP - 1), ls = (n_rhs - 4) / Q;
     return (lr == 0 ? 0 : (lr == ls ? 1 : (lr == ls + 1 ? 2 : 3))) * (Q * 10);
 }
-template <int Q, int LP, bool NARROW, bool XR = false, class T = real_t>
+// lane: the lane's index in its pencil (LP = 32: lane & 31; the tables are staged [entry][LP]), hi: upper half of the wave
+// mid(x): called once the window is dead (the right-hand sides are formed) with a value the caller can tie its loads to --
+// the place to issue global loads whose destination registers would not fit beside the window
+struct NoMid { __device__ __forceinline__ void operator()(real_t) const {} };
+template <int Q, int LP, bool NARROW, bool XR = false, class T = real_t, bool WD2 = true, class MID = NoMid>
 __device__ __forceinline__ void thomas_solve(const T (&w)[Q + 8], T (&X)[Q], T &xr, const real_t *__restrict__ lt,
-                                             const real_t *__restrict__ cs, int co, int &lane)
+                                             const real_t *__restrict__ cs, int co, int &lane, bool hi, MID mid = MID())
 {
 #define PHASE(x) asm volatile("" : "+v"(lane) : "v"(first_of(x)))
+#define DTR(e) lt_read(lt, (e) * LP + lane)
     T acc[Q], accx = zero_of<T>();
     {
-        constexpr bool D2 = NARROW || sizeof(T) == sizeof(real_t);
+        constexpr bool D2 = WD2 && (NARROW || sizeof(T) == sizeof(real_t));
         int co1 = co;
         if constexpr (D2) asm volatile("" : "+v"(co1));
+        if constexpr (XR) {  // row LP Q + 1 = window entry Q + 4; its (end) stencil reaches back only: entries Q .. Q + 4
+            const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + CS_N(Q));
+            const real2_t ca = c2[0], cb = c2[1], cc = c2[2];
+            accx = ca.x * w[Q] + ca.y * w[Q + 1] + cb.x * w[Q + 2] + cb.y * w[Q + 3] + cc.x * w[Q + 4];
+            asm volatile("" : "+v"(co) : "v"(first_of(accx)));
+        }
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
+        for (int q = Q - 1; q >= 0; q--) {  // (from the far end: the window's entries die as the sums are formed)
             int &coq = (D2 && (q & 1)) ? co1 : co;
             const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + coq + q * 10);
             if (NARROW) {
@@ -79,69 +90,67 @@ __device__ __forceinline__ void thomas_solve(const T (&w)[Q + 8], T (&X)[Q], T &
             }
             asm volatile("" : "+v"(coq) : "v"(first_of(acc[q])));
         }
-        if constexpr (XR) {  // row LP Q + 1 = window entry Q + 4; its (end) stencil reaches back only: entries Q .. Q + 4
-            const real2_t *__restrict__ c2 = reinterpret_cast<const real2_t *>(cs + CS_N(Q));
-            const real2_t ca = c2[0], cb = c2[1], cc = c2[2];
-            accx = ca.x * w[Q] + ca.y * w[Q + 1] + cb.x * w[Q + 2] + cb.y * w[Q + 3] + cc.x * w[Q + 4];
-        }
+        mid(first_of(acc[0]));
     }
     // ---- lane-local forward sweep from zero
     T prev = zero_of<T>();
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        X[q] = LTR(lt, DT_F(q)) * acc[q] + LTR(lt, DT_FA(q)) * prev;
+        X[q] = DTR(DT_F(q)) * acc[q] + DTR(DT_FA(q)) * prev;
         prev = X[q];
     }
     T v = prev;
     PHASE(X[Q / 2]);
-    v += LTR(lt, DT_MF(0)) * dpp0<0x111>(v);
-    v += LTR(lt, DT_MF(1)) * dpp0<0x112>(v);
-    v += LTR(lt, DT_MF(2)) * dpp0<0x114>(v);
-    v += LTR(lt, DT_MF(3)) * dpp0<0x118>(v);
-    v += LTR(lt, DT_MF(4)) * dpp0<0x142>(v);
-    if constexpr (LP == 64) v += LTR(lt, DT_MF(5)) * dpp0<0x143>(v);
+    v += DTR(DT_MF(0)) * dpp0<0x111>(v);
+    v += DTR(DT_MF(1)) * dpp0<0x112>(v);
+    v += DTR(DT_MF(2)) * dpp0<0x114>(v);
+    v += DTR(DT_MF(3)) * dpp0<0x118>(v);
+    v += DTR(DT_MF(4)) * dpp0<0x142>(v);
+    if constexpr (LP == 64) v += DTR(DT_MF(5)) * dpp0<0x143>(v);
     T carry = dpp0<0x138>(v);  // wave_shr:1 (lane 32 of the two-pencil form: PF = 0, its pencil starts there)
     T nxt = zero_of<T>();
     if constexpr (XR) {
         // v = e at this lane's last row; in the pencil's last lane that is row LP Q: the extra row's forward step and,
         // being the system's last row, its solution
-        const T ex = LTR(lt, DT_X(0)) * accx + LTR(lt, DT_X(1)) * v;
-        nxt = sel_of((lane & (LP - 1)) == LP - 1, ex, nxt);
-        xr = ex * LTR(lt, DT_X(2));
+        const T ex = DTR(DT_X(0)) * accx + DTR(DT_X(1)) * v;
+        nxt = sel_of(lane == LP - 1, ex, nxt);
+        xr = ex * DTR(DT_X(2));
     }
     PHASE(carry);
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
-        X[q] = (X[q] + LTR(lt, DT_PF(q)) * carry) + LTR(lt, DT_H(q)) * nxt;
+        X[q] = (X[q] + DTR(DT_PF(q)) * carry) + DTR(DT_H(q)) * nxt;
         nxt = X[q];
     }
     v = nxt;
     PHASE(X[Q / 2]);
-    v += LTR(lt, DT_MB(0)) * dpp0<0x101>(v);
-    v += LTR(lt, DT_MB(1)) * dpp0<0x102>(v);
-    v += LTR(lt, DT_MB(2)) * dpp0<0x104>(v);
-    v += LTR(lt, DT_MB(3)) * dpp0<0x108>(v);
+    v += DTR(DT_MB(0)) * dpp0<0x101>(v);
+    v += DTR(DT_MB(1)) * dpp0<0x102>(v);
+    v += DTR(DT_MB(2)) * dpp0<0x104>(v);
+    v += DTR(DT_MB(3)) * dpp0<0x108>(v);
     {
         const T s16 = readlane_d(v, 16), s48 = readlane_d(v, 48);
-        v += LTR(lt, DT_MB(4)) * sel_of(lane < 32, s16, s48);
-        if constexpr (LP == 64) v += LTR(lt, DT_MB(5)) * readlane_d(v, 32);
+        v += DTR(DT_MB(4)) * sel_of(hi, s48, s16);
+        if constexpr (LP == 64) v += DTR(DT_MB(5)) * readlane_d(v, 32);
     }
     carry = dpp0<0x130>(v);  // wave_shl:1 (a pencil's last lane: QB = 0)
 #pragma unroll
-    for (int q = 0; q < Q; q++) X[q] = (X[q] + LTR(lt, DT_QB(q)) * carry) * LTR(lt, DT_ST(q));
+    for (int q = 0; q < Q; q++) X[q] = (X[q] + DTR(DT_QB(q)) * carry) * DTR(DT_ST(q));
     PHASE(X[0]);
+#undef DTR
 #undef PHASE
 }
 
 // one operator on the window w, general form: r = its tds_solve rows (rows beyond n_tds come out as 0)
 // (T = V2: two right-hand sides of the SAME operator in one solve -- every table value read from LDS serves both)
+// (DIRECT: co = the lane's stencil slot, cs_slot, formed once per kernel and operator)
 template <int Q, bool NARROW, class T = real_t, bool DIRECT = false>
 __device__ __forceinline__ void gen_solve(const T (&w)[Q + 8], T (&r)[Q], const real_t *__restrict__ lt,
-                                          const real_t *__restrict__ cs, const XOp &t, int &lane)
+                                          const real_t *__restrict__ cs, const XOp &t, int &lane, int co = 0)
 {
     if constexpr (DIRECT) {
         T xr;
-        thomas_solve<Q, 64, NARROW, false, T>(w, r, xr, lt, cs, cs_slot<Q, 64>(lane, t.n_rhs), lane);
+        thomas_solve<Q, 64, NARROW, false, T>(w, r, xr, lt, cs, co, lane, lane >= 32);
         return;
     }
     const int first = lane * Q + 1, n = t.n_tds;
@@ -269,6 +278,7 @@ __global__ void __launch_bounds__(1024)
     stage_cs<Q>(cs, ta);
     if (MODE != 2) stage_cs<Q>(cs + CS_N(Q), tb);
     int lane = threadIdx.x & 63;
+    const int coa = cs_slot<Q, 64>(lane, ta.n_rhs), cob = cs_slot<Q, 64>(lane, tb.n_rhs);
     GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x >> 3), (int)(threadIdx.x & 7),
                  nrow, prow};
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
@@ -296,14 +306,14 @@ __global__ void __launch_bounds__(1024)
             const int tn = tl + gridDim.x;
             if (tn < ntiles) T.gload(nxt, in1 + in1_off(tn));
         }
-        gen_solve<Q, NARROW, real_t, DIRECT>(w, ra, lt, cs, ta, lane);
+        gen_solve<Q, NARROW, real_t, DIRECT>(w, ra, lt, cs, ta, lane, coa);
         if (MODE == 0) {
             T.to_tile(g2);
             __syncthreads();
             T.window(w);
         }
         if (MODE != 2) {
-            gen_solve<Q, NARROW, real_t, DIRECT>(w, rb, lt + LN, cs + CS_N(Q), tb, lane);
+            gen_solve<Q, NARROW, real_t, DIRECT>(w, rb, lt + LN, cs + CS_N(Q), tb, lane, cob);
             if (MODE == 0) {
 #pragma unroll
                 for (int q = 0; q < Q; q++) ra[q] = ra[q] + 1.0 * rb[q];  // (the accumulating form: old + 1.0 * r)
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
 #endif
     constexpr bool LATE = P12 && Q <= 5;  // where the rows the result is added to are requested (register budget)
     extern __shared__ real_t lt[];
-    constexpr int LN = (DIRECT ? DT_N(Q) - 4 : LT_N(Q)) * 64, L1N = (DIRECT ? DT_NC(Q) : LT_NC(Q)) * 64;  // (the first operator's STC block is never read)
+    constexpr int LN = (DIRECT ? DT_N(Q) : LT_N(Q)) * 64, L1N = (DIRECT ? DT_NC(Q) : LT_NC(Q)) * 64;  // (the first operator's STC block is never read)
     constexpr int E_STC = DIRECT ? DT_STC(0) : LT_STC(0);
     for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
     for (int i = threadIdx.x; i < LN; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
@@ -357,6 +367,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
     stage_cs<Q>(cs, tD1);
     stage_cs<Q>(cs + CS_N(Q), tD2);
     int lane = threadIdx.x & 63;
+    const int co1 = cs_slot<Q, 64>(lane, tD1.n_rhs), co3 = cs_slot<Q, 64>(lane, tD2.n_rhs);
     GenTile<Q> T{tile, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, (int)(threadIdx.x / (NP / 2)),
                  (int)(threadIdx.x % (NP / 2)), nrow, prow};
     auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * NP; };
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
 #pragma unroll
                     for (int m = 0; m < Q + 8; m++) w2[m] = V2{wu[m] * wc[m], wu[m]};
                 }
-                gen_solve<Q, NARROW1, V2, DIRECT>(w2, X2, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW1, V2, DIRECT>(w2, X2, l1, cs, tD1, lane, co1);
 #pragma unroll
                 for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X2[q].b + X2[q].a) + nu * (X2[q].b * LTR(l3, E_STC + q));
             } else {
@@ -419,7 +430,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
                 window_from_body_zero<Q>(wc, cb);
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wc[m];
-                gen_solve<Q, NARROW1, real_t, DIRECT>(wp, X, l1, cs, tD1, lane);
+                gen_solve<Q, NARROW1, real_t, DIRECT>(wp, X, l1, cs, tD1, lane, co1);
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = X[q];
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
             {
                 real_t wu[Q + 8];
                 T.window(wu);
-                gen_solve<Q, NARROW1, real_t, DIRECT>(wu, X, l1, cs, tD1, lane);  // du
+                gen_solve<Q, NARROW1, real_t, DIRECT>(wu, X, l1, cs, tD1, lane, co1);  // du
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * LTR(l3, E_STC + q));
@@ -437,13 +448,178 @@ __global__ void __launch_bounds__(64 * NP, NP == 8 ? 4 : 1)
             {
                 real_t wu[Q + 8];  // (read again: a window is dead once its stencil sums are formed)
                 T.window(wu);
-                gen_solve<Q, NARROW, real_t, DIRECT>(wu, X, l3, cs + CS_N(Q), tD2, lane);  // d2u
+                gen_solve<Q, NARROW, real_t, DIRECT>(wu, X, l3, cs + CS_N(Q), tD2, lane, co3);  // d2u
             }
 #pragma unroll
             for (int q = 0; q < Q; q++) r[q] += nu * X[q];
             T.put(r);  // (a wave only rewrites its own pencil's rows, which only it reads)
             __syncthreads();
             T.template from_tile<ACC>(o, tD1.n_tds, old);
+            __syncthreads();  // the tile is free again
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K3h: transeq on 257-row pencils, TWO pencils per wave
+// The channel's wall-normal direction (BASELINE configs[4]: 257 vertices, Dirichlet, stretched) in the DIRECT form with a
+// pencil per HALF-wave: lanes 0..31 / 32..63 own the pencils 2 w / 2 w + 1 of the tile, 8 rows per lane + row 257 on the
+// pencil's last lane (thomas_solve<8, 32, .., XR>).  Against k_ygen_transeq3<5, .., DIRECT> (one pencil per wave, 5 rows per
+// lane = 320 row slots for 257 rows): no idle row slots, and every wave-wide cost -- the scans' DPP steps, every lane-table
+// and stencil read -- serves two pencils.  A workgroup = 8 waves = the 16 x-adjacent pencils of one plane (128-byte row
+// segments), two workgroups per CU (76 KB of LDS each: the lane tables staged [entry][32]).
+//  * tile: [16 pencils][YH_TP]; row j of a pencil at entry yh_sw(j + 3) -- 4 zero rows before row 1, zeros after row 257,
+//    and TWO pad entries after every 32: a lane's window (entries 8 l .. 8 l + 15) is read as 8 ds_read_b128 whose 16-lane
+//    groups would otherwise hit 4 banks-quads out of 16 (lane stride 64 B); with the pads they cover all 16
+//  * the window of the advecting velocity (components 1, 2: the tile holds u1 / u2) is rebuilt from the lane's own rows
+//    by DPP; at the seam between the two pencils a lane picks up the OTHER pencil's rows -- where the stencils of its rows
+//    have zero weight (rows before row 1, rows after row 257), as with the zero rows of the tile -- except row 257 itself
+//    in the right halo of the pencil's last lane, which that lane keeps in a register
+constexpr int YH_Q = 8, YH_NP = 16, YH_TP = 282, YH_NI = 5, YH_CSN = CS_N(YH_Q) + 10;
+__device__ __forceinline__ int yh_sw(int t) { return t + 2 * (t >> 5); }
+template <bool ACC, bool NARROW, bool NARROW1>
+__global__ void __launch_bounds__(512, 4)
+    k_yhalf_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0, const real_t *__restrict__ u1,
+                     const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx, int ntiles, long prow, long pplane, real_t nu)
+{
+    constexpr int Q = YH_Q, NROW = 257;
+    extern __shared__ real_t lt[];
+    constexpr int L1N = DT_NC(Q) * 32, L3N = DT_N(Q) * 32;
+    for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[(i >> 5) * 64 + (i & 31)];
+    for (int i = threadIdx.x; i < L3N; i += blockDim.x) lt[L1N + i] = tD2.TL[(i >> 5) * 64 + (i & 31)];
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + L1N;
+    real_t *tile = lt + L1N + L3N;
+    real_t *cs = tile + YH_NP * YH_TP;
+    for (int i = threadIdx.x; i < YH_NP * YH_TP; i += blockDim.x) tile[i] = 0.0;
+    stage_cs<Q>(cs, tD1);
+    stage_cs<Q>(cs + YH_CSN, tD2);
+    if (threadIdx.x < 20) {  // row 257's stencil (the last end row), per operator: [9] + a pad
+        const int o = threadIdx.x / 10, m = threadIdx.x % 10;
+        cs[o * YH_CSN + CS_N(Q) + m] = m < 9 ? (o ? tD2 : tD1).Cs[63 + m] : 0.0;
+    }
+    const int lane = threadIdx.x & 63;
+    int ll = lane & 31;
+    const bool hi = lane >= 32;
+    const int pen = 2 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + (hi ? 1 : 0);
+    // the lane's window = entries 8 l .. 8 l + 7 (piece A) and 8 l + 8 .. 8 l + 15 (piece B); its rows = entries 8 l + 4 .. + 11
+    real_t *pA = tile + pen * YH_TP + yh_sw(8 * ll), *pB = tile + pen * YH_TP + yh_sw(8 * ll + 8);
+    const int co1 = cs_slot<Q, 32>(lane, NROW), co3 = co1;
+    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * X3D_RB);
+    real_t *tA = tile + (2 * cc) * YH_TP, *tB = tA + YH_TP;
+    auto row_ptr = [&](const real_t *base, int i) {
+        return reinterpret_cast<const real2_t *>(reinterpret_cast<const char *>(base + (long)(64 * i) * prow) + voff);
+    };
+    auto gload = [&](real2_t (&v)[YH_NI], const real_t *__restrict__ src) {
+#pragma unroll
+        for (int i = 0; i < YH_NI; i++) {
+            v[i] = make_real2(0.0, 0.0);
+            if (i < 4 || cy == 0) v[i] = *row_ptr(src, i);  // rows cy + 64 i < 257
+        }
+    };
+    auto to_tile = [&](const real2_t (&v)[YH_NI]) {
+#pragma unroll
+        for (int i = 0; i < YH_NI; i++) {
+            if (i < 4 || cy == 0) {
+                const int e = yh_sw(4 + cy + 64 * i);
+                tA[e] = v[i].x;
+                tB[e] = v[i].y;
+            }
+        }
+    };
+    auto window = [&](real_t (&w)[Q + 8]) {
+        const real2_t *__restrict__ a = reinterpret_cast<const real2_t *>(pA), *__restrict__ b_ = reinterpret_cast<const real2_t *>(pB);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const real2_t x = a[m], y = b_[m];
+            w[2 * m] = x.x; w[2 * m + 1] = x.y;
+            w[8 + 2 * m] = y.x; w[9 + 2 * m] = y.y;
+        }
+    };
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * YH_NP; };
+    __syncthreads();
+    real2_t nxt[YH_NI];
+    if ((int)blockIdx.x < ntiles) gload(nxt, u0 + tile_off(blockIdx.x));
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long off = tile_off(tl);
+        real_t cb[Q], cbx = 0.0;  // this pencil's rows of the advecting velocity (cbx: row 257, the pencil's last lane)
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            asm volatile("" : "+v"(ll));
+            to_tile(nxt);
+            __syncthreads();
+            {
+                const int tn = tl + gridDim.x;
+                const real_t *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
+                if (c < 2 || tn < ntiles) gload(nxt, nsrc);
+            }
+            real_t r[Q], rx, X[Q], xr;
+            {
+                real_t wp[Q + 8];
+                window(wp);
+                if (c == 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) cb[q] = wp[4 + q];
+                    cbx = wp[Q + 4];
+#pragma unroll
+                    for (int m = 0; m < Q + 8; m++) wp[m] = wp[m] * wp[m];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        wp[m] = wp[m] * dpp0<0x138>(cb[Q - 4 + m]);  // wave_shr:1
+                        real_t rh = dpp0<0x130>(cb[m]);               // wave_shl:1
+                        if (m == 0) rh = ll == 31 ? cbx : rh;
+                        wp[Q + 4 + m] = wp[Q + 4 + m] * rh;
+                    }
+#pragma unroll
+                    for (int q = 0; q < Q; q++) wp[4 + q] = wp[4 + q] * cb[q];
+                }
+                thomas_solve<Q, 32, NARROW1, true, real_t, NARROW1>(wp, X, xr, l1, cs, co1, ll, hi);  // d(u conv)
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = X[q];
+            rx = xr;
+            asm volatile("" : "+v"(ll) : "v"(r[0]));
+            {
+                real_t wu[Q + 8];
+                window(wu);
+                thomas_solve<Q, 32, NARROW1, true, real_t, NARROW1>(wu, X, xr, l1, cs, co1, ll, hi);  // du
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * X[q] + r[q]) + nu * (X[q] * lt_read(l3, DT_STC(q) * 32 + ll));
+            rx = -0.5 * (cbx * xr + rx) + nu * (xr * lt_read(l3, DT_X(3) * 32 + ll));
+            real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+            real2_t old[YH_NI];
+            asm volatile("" : "+v"(ll) : "v"(r[0]));
+            {
+                real_t wu[Q + 8];
+                window(wu);
+                thomas_solve<Q, 32, NARROW, true, real_t, NARROW>(wu, X, xr, l3, cs + YH_CSN, co3, ll, hi);  // d2u
+            }
+            {
+                real2_t *__restrict__ a = reinterpret_cast<real2_t *>(pA), *__restrict__ b_ = reinterpret_cast<real2_t *>(pB);
+                a[2] = make_real2(r[0] + nu * X[0], r[1] + nu * X[1]);
+                a[3] = make_real2(r[2] + nu * X[2], r[3] + nu * X[3]);
+                b_[0] = make_real2(r[4] + nu * X[4], r[5] + nu * X[5]);
+                b_[1] = make_real2(r[6] + nu * X[6], r[7] + nu * X[7]);
+                if (ll == 31) pB[4] = rx + nu * xr;  // row 257
+            }
+            if constexpr (ACC) {
+                // the rows the result is added to: requested when the solves' registers are free (any earlier and the 20
+                // registers they land in spill: 93 VGPRs to scratch); the other workgroup of the CU covers the wait
+                const real_t *oo = o;
+                asm volatile("" : "+s"(oo) : "v"(xr));
+                gload(old, oo);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < YH_NI; i++) {
+                if (i < 4 || cy == 0) {
+                    const int e = yh_sw(4 + cy + 64 * i);
+                    real2_t v = make_real2(tA[e], tB[e]);
+                    if (ACC) { v.x += old[i].x; v.y += old[i].y; }
+                    *const_cast<real2_t *>(row_ptr(o, i)) = v;
+                }
+            }
             __syncthreads();  // the tile is free again
         }
     }
@@ -563,13 +739,54 @@ int x3d_ygen_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t 
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     if (der1st->n_tds != der2nd->n_tds) return 0;
     // (tl_hash covers the lane tables and the boundary / bulk stencils: tds.hip)
+    // 257 rows, DIRECT, every operator with the half-wave tables: two pencils per wave (K3h).  Measured SLOWER than the
+    // one-pencil-per-wave DIRECT form (2.60 against 2.44 ms per launch at 1024 x 257 x 512: 30 % fewer vector instructions,
+    // but three serial 8-row solves per component where that form runs a pair solve of two interleaved 5-row chains and
+    // one more -- the kernel is bound by its dependency chains at 4 waves per SIMD): only with X3D_YHALF=1
+    {
+        static int yh = -1;
+        if (yh < 0) { const char *e = getenv("X3D_YHALF"); yh = (e && e[0] == '1') ? 1 : 0; }
+        const int n = dir == X3D_DIR_Y ? b->ny : b->nz;
+        bool ok = yh && n == 257 && der1st->n_tds == 257 && der1st->tab.n_rhs == 257 && der2nd->tab.n_rhs == 257 && gen_direct(ops, 4, 5);
+        for (int k = 0; k < 4; k++) ok = ok && ops[k]->td8h != nullptr;
+        if (ok) {
+            const size_t lds = sizeof(real_t) * ((size_t)(DT_NC(YH_Q) + DT_N(YH_Q)) * 32 + YH_NP * YH_TP + 2 * YH_CSN);
+            GenLaunch g = gen_launch(b, dir);
+            const long cap = 2 * (long)x3d_persistent_blocks(b, X3D_NCU);
+            g.blocks = (int)(g.ntiles > cap ? cap : g.ntiles);
+            XOp o1 = xop_of(der1st), o3 = xop_of(der2nd);
+            o1.TL = der1st->td8h;
+            o3.TL = der2nd->td8h;
+            const bool narrow1 = der1st->narrow_all, narrow = narrow1 && der2nd->narrow_all;
+            {
+                ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir);
+#define GOH(A_, N_, N1_)                                                                                                    \
+    do {                                                                                                                    \
+        X3D_LDS_OPTIN(b, (k_yhalf_transeq3<A_, N_, N1_>));                                                                  \
+        hipLaunchKernelGGL((k_yhalf_transeq3<A_, N_, N1_>), dim3(g.blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], f[0], f[1], \
+                           f[2], o1, o3, g.ntx, g.ntiles, g.rstride, g.ostride, nu);                                        \
+    } while (0)
+#define GOHN(A_) do { if (narrow) GOH(A_, true, true); else if (narrow1) GOH(A_, false, true); else GOH(A_, false, false); } while (0)
+                if (acc) GOHN(true); else GOHN(false);
+#undef GOHN
+#undef GOH
+            }
+            X3D_HIP(hipGetLastError());
+            b->n_tq3++;
+            if (b->prof) {
+                for (int k = 0; k < 2; k++) { ProfScope ps(b, X3D_K_TRANSEQ_FWD, dir); }
+            }
+            *done = true;
+            return 0;
+        }
+    }
     // 8 pencils per workgroup, two workgroups per CU: 257..320-row pencils (Q = 5), nx a multiple of 32 (tile pairs share
     // 128-byte lines and must not straddle rows of tiles).  X3D_YGEN_NP16=1: the 16-pencil form (A/B)
     static int np16 = -1;
     if (np16 < 0) { const char *e = getenv("X3D_YGEN_NP16"); np16 = (e && e[0] == '1') ? 1 : 0; }
     const int NP = (Q == 5 && !np16 && b->nx % 32 == 0) ? 8 : 16;
     const bool direct = gen_direct(ops, 4, Q);
-    const size_t lds = sizeof(real_t) * ((size_t)(direct ? DT_NC(Q) + DT_N(Q) - 4 : LT_NC(Q) + LT_N(Q)) * 64 + NP * (64 * Q + 10) + 2 * CS_N(Q));
+    const size_t lds = sizeof(real_t) * ((size_t)(direct ? DT_NC(Q) + DT_N(Q) : LT_NC(Q) + LT_N(Q)) * 64 + NP * (64 * Q + 10) + 2 * CS_N(Q));
     if (lds > 160 * 1024) return 0;
     GenLaunch g = gen_launch(b, dir);
     if (NP == 8) {
