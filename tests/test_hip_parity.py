@@ -1073,6 +1073,22 @@ def test_yz_operators_on_512_row_pencils(dims, bc, stretch):
             fo.data_loc = orc.VERT
 
 
+@pytest.mark.parametrize("switch", ["X3D_NO_DIRECT", "X3D_YHALF"])
+def test_wall_normal_pencils_in_their_other_forms(switch):
+    """The 257-row Dirichlet pencils of the channel case (BASELINE configs[4]) through the forms that are NOT the default:
+    X3D_NO_DIRECT=1 -- the reference's distributed form on the lanes (scan_solve + the reduced 2 x 2 system), what every
+    operator without DIRECT tables still runs; X3D_YHALF=1 -- K3h, two pencils per wave (csrc/ygen.hip).  The default, the
+    DIRECT form (thomas_solve: the plain Thomas recurrences of the tridiagonal system tds.hip recovers from the preprocessed
+    arrays), is what test_yz_operators_on_512_row_pencils runs.  The switches are read once per process: child pytest runs of
+    the 257- and 320-row cases (dims7, dims9, dims12)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
+                        "test_yz_operators_on_512_row_pencils and (dims7 or dims9 or dims12)"], env=dict(os.environ, **{switch: "1"}),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+
+
 def test_slab_poisson_solver_single_rank_emulation():
     """csrc/sfft.hip with pz = 1 (exchanges = self copies): y pass through the exchange layout, strided rocFFT
     z pass, slab spectral kernel -- against the single-rank solver and the oracle"""

@@ -328,6 +328,15 @@ struct TdsTab {
 #define T_PF16(t, j) ((t).RB[8 * (j) + 6])  // carry multipliers for 16-row chunks
 #define T_QB16(t, j) ((t).RB[8 * (j) + 7])
 
+// A periodic operator on a uniform grid is the circulant system (alpha, 1, alpha) x = r: with rho the root of
+// rho^2 - rho / alpha + 1 = 0 inside the unit circle it factors as (alpha / rho) (1 + rho z^-1) (1 + rho z), i.e. two
+// constant-coefficient first-order recurrences (xscan_core.h, circ_solve).  Filled by x3d_tdsops_create (tds.hip).
+struct CircOp {
+    real_t c[9];   // the bulk stencil times rho / alpha
+    real_t nr;     // -rho
+    real_t pf[8];  // (-rho)^(q + 1): what the value carried into a lane adds to its row q (Q rows per lane, Q <= 8)
+    real_t mu[4];  // mu, mu^2, mu^4, mu^8 with mu = (-rho)^Q: the lane-to-lane multiplier of the scans
+};
 struct x3d_tdsops {
     x3d_backend *b;
     int n_tds, n_rhs, move, periodic;
@@ -338,6 +347,8 @@ struct x3d_tdsops {
     const real_t *tlc;           // compressed lane tables (xscan_core.h, LTC_*; xwide.hip), or null
     const real_t *tl5;           // lane tables for 5 rows per lane (257..320-row pencils, ygen.hip), or null
     int direct;                  // 1: non-periodic on one rank and the plain Thomas factors reproduce the reference's sweeps
+    int circ_ok;                 // 1: periodic, uniform grid, and circ (for tab.Q rows per lane) reproduces the reference's sweeps
+    CircOp circ;
     const real_t *td5, *td8h;    // DIRECT lane tables (tds.hip, ygen.hip): 5 rows per lane; 8 rows per lane of a half-wave + row 257
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
     int uniform;                 // 1: stretch == 1 and stretch_correct == 0 on every row (a uniform grid): kernels may skip

@@ -349,6 +349,67 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             img.insert(img.end(), tlv.begin(), tlv.end());
         }
     }
+    // CIRCULANT form (round 6, xscan_core.h circ_solve): a periodic operator on a uniform grid whose rows all carry the
+    // bulk stencil is the circulant tridiagonal system (alpha, 1, alpha) -- two constant-coefficient recurrences, no lane
+    // tables at all.  alpha = dist_af(5) (the reference's one bulk alpha, distributed.f90:83); checked here against the
+    // reference's sweeps + 2 x 2 closure (periodic self-exchange) before it is offered.
+    t->circ_ok = 0;
+    memset(&t->circ, 0, sizeof(t->circ));
+    {
+        bool bulk = true, unif = true;
+        for (int r = 0; r < 4; r++)
+            for (int m = 0; m < 9; m++)
+                if (coeffs_s[r * 9 + m] != coeffs[m] || coeffs_e[r * 9 + m] != coeffs[m]) bulk = false;
+        for (int j = 1; j <= n; j++)
+            if (St[j] != 1.0 || Stc[j] != 0.0) unif = false;
+        const real_t alpha = n >= 8 ? dist_af[4] : 0.0;
+        if (periodic && bulk && unif && nr == n && Q >= 4 && Q <= 8 && n == 64 * Q && alpha != 0.0 && fabs(alpha) < 0.5) {
+            const double a = (double)alpha, rho = (1.0 - sqrt(1.0 - 4.0 * a * a)) / (2.0 * a);
+            CircOp &co = t->circ;
+            for (int m = 0; m < 9; m++) co.c[m] = (real_t)(coeffs[m] * (rho / a));
+            co.nr = (real_t)(-rho);
+            double pw = 1.0;
+            for (int q = 0; q < 8; q++) { pw *= -rho; co.pf[q] = (real_t)pw; }
+            double mu = 1.0;
+            for (int q = 0; q < Q; q++) mu *= -rho;
+            co.mu[0] = (real_t)mu; co.mu[1] = (real_t)(mu * mu); co.mu[2] = (real_t)(mu * mu * mu * mu);
+            co.mu[3] = (real_t)pow(mu, 8.0);
+            // (the scans drop mu^8 at 8 rows per lane, mu^16 at 4: below 2^-60 or the form is not offered)
+            bool ok = pow(fabs(mu), Q >= 8 ? 8.0 : 16.0) < 8.673617379884035e-19;
+            // host check: the reference's sweeps with the periodic closure against the two recurrences run twice around
+            // the ring (rho^n underflows: once around reaches the fixed point to the last bit)
+            std::vector<real_t> r(n + 2), d(n + 2), x(n + 2), e(n + 2), y(n + 2);
+            unsigned long long s = 0x9E3779B97F4A7C15ull;
+            for (int rep = 0; rep < 2 && ok; rep++) {
+                for (int j = 1; j <= n; j++) {
+                    s = s * 6364136223846793005ull + 1442695040888963407ull;
+                    r[j] = (real_t)((double)(s >> 11) / 9007199254740992.0 - 0.5);
+                }
+                d[1] = r[1] * F[1];
+                d[2] = r[2] * F[2];
+                for (int j = 3; j <= n; j++) d[j] = F[j] * (r[j] - A[j] * d[j - 1]);
+                x = d;
+                for (int j = n - 2; j >= 2; j--) x[j] = d[j] - Bw[j] * x[j + 1];
+                x[1] = dist_fw[0] * (d[1] - Bw[1] * x[2]);
+                const real_t sa1 = dist_sa[0], scn = dist_sc[n - 1];
+                const real_t du_s = (x[1] - sa1 * x[n]) / (1.0 - sa1 * sa1), du_e = (x[n] - scn * x[1]) / (1.0 - scn * scn);
+                real_t ee = 0.0;
+                for (int pass = 0; pass < 2; pass++)
+                    for (int j = 1; j <= n; j++) { ee = (real_t)(rho / a) * r[j] + co.nr * ee; e[j] = ee; }
+                real_t yy = 0.0;
+                for (int pass = 0; pass < 2; pass++)
+                    for (int j = n; j >= 1; j--) { yy = e[j] + co.nr * yy; y[j] = yy; }
+                real_t xmax = 0.0, emax = 0.0;
+                for (int j = 1; j <= n; j++) {
+                    const real_t ref = j == 1 ? du_s : (j == n ? du_e : x[j] - Sa[j] * du_s - Sc[j] * du_e);
+                    xmax = fmax(xmax, fabs(ref));
+                    emax = fmax(emax, fabs(ref - y[j]));
+                }
+                if (!(emax <= (sizeof(real_t) == 8 ? 1e-13 : 2e-5) * xmax)) ok = false;
+            }
+            t->circ_ok = ok ? 1 : 0;
+        }
+    }
     X3D_HIP(hipMalloc(&t->dev, sizeof(real_t) * img.size()));
     X3D_HIP(hipMemcpy(t->dev, img.data(), sizeof(real_t) * img.size(), hipMemcpyHostToDevice));
     t->tl5 = tl5_off ? t->dev + tl5_off : nullptr;

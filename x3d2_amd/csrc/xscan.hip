@@ -846,9 +846,10 @@ __global__ void __launch_bounds__(1024)
 // by all loads and stores of all fields (global_load_dwordx4 v, v_off, s[base:base+1]) instead of a 64-bit
 // address pair per row: 7 VGPRs less in kernels that sit on the 128-VGPR limit.  Needs 128 * prow * 8 < 4 GiB
 // (checked by the launchers).
+template <int RP = 128>
 __device__ __forceinline__ const real2_t *tile_row(const real_t *base, long prow, int i, unsigned voff)
 {
-    return reinterpret_cast<const real2_t *>(reinterpret_cast<const char *>(base + (long)(128 * i) * prow) + voff);
+    return reinterpret_cast<const real2_t *>(reinterpret_cast<const char *>(base + (long)(RP * i) * prow) + voff);
 }
 
 // ---------------------------------------------------------------- K3y, the three components of a direction at once
@@ -887,23 +888,35 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 // read back by the stage's kernel (and without writing it after the last stage).  epp: three TileEpi in device memory,
 // component order (advecting component first).  Per step the EPI launches save 6 of ~ 200 field passes (stages 1 and 3
 // of RK3; stage 2 gains nothing: DESIGN.md 3.2) and trade the stage kernel's streaming rate for the tile pattern's.
-template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false, bool EPI = false>
+// NPW (round 6): pencils per wave.  2 = a tile of 32 x-adjacent pencils, wave w solves pencils w and w + 16 one after the
+// other: 256-row FP64 pencils (BASELINE configs[1]) and every FP32 pencil then move 128-byte row segments... per 16
+// pencils, 256-byte segments per row of the tile, and a workgroup holds as many bytes in flight as a 512-row FP64 tile
+// (same register counts: NI and the advecting rows double, the windows are half as long)
+// CIRC (round 6, with UNI, P12, local form): the circulant form of both operators (xscan_core.h, circ_solve; cD1 / cD2) -- no
+// lane tables are staged (the workgroup's LDS is its tile), no closure; results equal the table form's to round-off
+template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false, bool EPI = false, int NPW = 1,
+          bool CIRC = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_transeq3(real_t *rhs0, real_t *rhs1, real_t *rhs2, const real_t *__restrict__ u0,
                      const real_t *__restrict__ u1, const real_t *__restrict__ u2, XOp tD1, XOp tD2, int ntx,
-                     int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th, const TileEpi *epp = nullptr)
+                     int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th, const TileEpi *epp,
+                     CircOp cD1, CircOp cD2)
 {
+    static_assert(!CIRC || (UNI && P12 && !HALO), "CIRC: the local uniform-grid pair-solve form");
     static_assert(!EPI || (ACC && !HALO), "EPI: the local accumulating form");
+    static_assert(NPW == 1 || !HALO, "two pencils per wave: the local form");
     extern __shared__ real_t lt[];
-    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
-    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
-        lt[i] = tD1.TL[i];
-        lt[LN + i] = tD2.TL[i];
+    constexpr int LN = LT_N(Q) * 64, n = 64 * Q, TP = n + 4, NPT = 16 * NPW, RP = 128 / NPW, NI = n / RP;
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+            lt[i] = tD1.TL[i];
+            lt[LN + i] = tD2.TL[i];
+        }
     }
     const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
-    real_t *tile = lt + 2 * LN;
+    real_t *tile = lt + (CIRC ? 0 : 2 * LN);
     // HALO: [16 pencils][8] halo values of the current field, then the same for the advecting velocity u0
-    real_t *hal = tile + 16 * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
+    real_t *hal = tile + NPT * TP, *hal0 = hal + 128, *bnd = hal0 + 128;  // bnd: [16 pencils][9 ops][du_1, X_n]
     ntiles += tile0;  // tiles [tile0, tile0 + ntiles) (a range of planes: overlap of the neighbour exchange)
 #ifdef YT_TIMING
     unsigned long long yt_last = __builtin_readcyclecounter();
@@ -911,21 +924,21 @@ __global__ void __launch_bounds__(1024)
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int first = lane * Q + 1;
-    const int cy = threadIdx.x >> 3, cc = threadIdx.x & 7;
+    const int cy = threadIdx.x / (8 * NPW), cc = threadIdx.x % (8 * NPW);
     const unsigned voff = (unsigned)(((long)cy * prow + 2 * cc) * X3D_RB);
     auto gload = [&](real2_t (&v)[NI], const real_t *__restrict__ src) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) v[i] = *tile_row(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
+        for (int i = 0; i < NI; i++) v[i] = *tile_row<RP>(src, prow, i, voff);  // (ldg_stream: same time, round 4 A/B)
     };
     auto to_tile = [&](const real2_t (&v)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-            tile[(2 * cc) * TP + cy + 128 * i] = v[i].x;
-            tile[(2 * cc + 1) * TP + cy + 128 * i] = v[i].y;
+            tile[(2 * cc) * TP + cy + RP * i] = v[i].x;
+            tile[(2 * cc + 1) * TP + cy + RP * i] = v[i].y;
         }
     };
-    auto pick = [&](real_t (&b)[Q]) {
-        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + wave * TP + lane * Q);
+    auto pick = [&](real_t (&b)[Q], int pw) {
+        const real2_t *__restrict__ src = reinterpret_cast<const real2_t *>(tile + (wave + 16 * pw) * TP + lane * Q);
 #pragma unroll
         for (int m = 0; m < Q / 2; m++) {
             const real2_t t2_ = src[m];
@@ -933,7 +946,7 @@ __global__ void __launch_bounds__(1024)
             b[2 * m + 1] = t2_.y;
         }
     };
-    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * 16; };
+    auto tile_off = [&](int tl) { return (long)(tl / ntx) * pplane + (long)(tl % ntx) * NPT; };
     // HALO: thread t < 128 carries halo value (pencil t >> 3, slot t & 7: 0..3 start side, 4..7 end side) of field f
     auto hload = [&](int tl, int f) {
         const int hw = threadIdx.x >> 3, hk = threadIdx.x & 7;
@@ -951,7 +964,7 @@ __global__ void __launch_bounds__(1024)
     vmcnt_pad_stores<(ACC ? 2 : 1) * NI>();
     for (int tl = tile0 + blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long off = tile_off(tl);
-        real_t cb[Q];  // this pencil's rows of the advecting velocity
+        real_t cb[NPW][Q];  // this wave's pencils' rows of the advecting velocity
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             asm volatile("" : "+v"(lane));
@@ -959,34 +972,40 @@ __global__ void __launch_bounds__(1024)
 #ifdef YT_TIMING
             const unsigned long long yt_c0 = __builtin_readcyclecounter();
 #endif
+            to_tile(nxt);
+            if (HALO && threadIdx.x < 128) {
+                hal[threadIdx.x] = hnx;
+                if (c == 0) hal0[threadIdx.x] = hnx;
+            }
+            YT_T(0);
+            __syncthreads();
+            YT_T(1);
+            real2_t old[NI];
+            [[maybe_unused]] real2_t bs[NI];
+            [[maybe_unused]] TileEpi epi;
+            real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
+#pragma unroll
+            for (int pw = 0; pw < NPW; pw++) {
             real_t wu[Q + 8], wp[Q + 8];
             {
                 real_t b[Q];
-                to_tile(nxt);
-                if (HALO && threadIdx.x < 128) {
-                    hal[threadIdx.x] = hnx;
-                    if (c == 0) hal0[threadIdx.x] = hnx;
-                }
-                YT_T(0);
-                __syncthreads();
-                YT_T(1);
-                pick(b);
+                pick(b, pw);
                 if (c == 0) {
 #pragma unroll
-                    for (int q = 0; q < Q; q++) cb[q] = b[q];
+                    for (int q = 0; q < Q; q++) cb[pw][q] = b[q];
                 }
                 if constexpr (HALO) {
                     window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
-                    window_from_body_halo<Q>(wp, cb, lane, hal0 + wave * 8);
+                    window_from_body_halo<Q>(wp, cb[pw], lane, hal0 + wave * 8);
                 } else {
                     window_from_body<Q>(wu, b, lane);
-                    window_from_body<Q>(wp, cb, lane);
+                    window_from_body<Q>(wp, cb[pw], lane);
                 }
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
             }
-            // (no barrier here: until the store phase a wave only rewrites its own pencil's region of the tile)
-            {
+            // (no barrier here: until the store phase a wave only rewrites its own pencils' regions of the tile)
+            if (pw == 0) {
                 const int tn = tl + gridDim.x;
                 const real_t *nsrc = c == 0 ? u1 + off : (c == 1 ? u2 + off : u0 + tile_off(tn < ntiles ? tn : tl));
                 if (c < 2 || tn < ntiles) {
@@ -1030,7 +1049,14 @@ __global__ void __launch_bounds__(1024)
 #ifdef YT_TIMING
             const unsigned long long yt_s0 = __builtin_readcyclecounter();
 #endif
-            if constexpr (P12 && UNI) {
+            if constexpr (CIRC) {
+                V2 w2[Q + 8], T2[Q];
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m] = V2{wp[m], wu[m]};
+                circ_solve<Q, NARROW, V2>(w2, T2, cD1, lane);
+#pragma unroll
+                for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[pw][q] * T2[q].b + T2[q].a);
+            } else if constexpr (P12 && UNI) {
                 V2 w2[Q + 8], T2[Q], a2, b2;
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) w2[m] = V2{wp[m], wu[m]};
@@ -1049,7 +1075,7 @@ __global__ void __launch_bounds__(1024)
                     real_t xa = T2[q].a - sa * s_.a - sc * e_.a, xb = T2[q].b - sa * s_.b - sc * e_.b;
                     if (q == 0) { xa = (lane == 0) ? s_.a : xa; xb = (lane == 0) ? s_.b : xb; }
                     if (q == Q - 1) { xa = (lane == 63) ? e_.a : xa; xb = (lane == 63) ? e_.b : xb; }
-                    r[q] = -0.5 * (cb[q] * xb + xa);
+                    r[q] = -0.5 * (cb[pw][q] * xb + xa);
                 }
             } else {
             solve_subs(wp, T, l1, tD1, 0);
@@ -1059,8 +1085,8 @@ __global__ void __launch_bounds__(1024)
             solve_subs(wu, T, l1, tD1, 1);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                if constexpr (UNI) r[q] = -0.5 * (cb[q] * T[q] + r[q]);
-                else r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
+                if constexpr (UNI) r[q] = -0.5 * (cb[pw][q] * T[q] + r[q]);
+                else r[q] = -0.5 * (cb[pw][q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
             }
             }
             asm volatile("" : "+v"(lane) : "v"(r[0]));
@@ -1068,40 +1094,66 @@ __global__ void __launch_bounds__(1024)
                 // the field's window again, from the tile (it still holds the component's rows): keeping wu alive
                 // across the pair solve does not fit the 128 registers (121 + 56 bytes of scratch)
                 real_t b[Q];
-                pick(b);
+                pick(b, pw);
                 if constexpr (HALO) window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
                 else window_from_body<Q>(wu, b, lane);
             }
-            solve_subs(wu, T, l3, tD2, 2);
-            {
-                // (issued here, not before the solves: 16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component;
-                //  with the partial result parked in the tile during the last solve to make room for them: no
-                //  spills, but 2.37 instead of 2.24 ms per launch; issued after the FIRST solve, where the product
-                //  window's registers are free (123 VGPRs, no spills): 2.18 ms both ways -- the load's latency is not
-                //  what limits, the memory system is busy throughout with this pattern's 128-byte segments)
-                real_t *o = (c == 0 ? rhs0 : (c == 1 ? rhs1 : rhs2)) + off;
-                real2_t old[NI];
+            if constexpr (CIRC) circ_solve<Q, NARROW>(wu, T, cD2, lane);
+            else solve_subs(wu, T, l3, tD2, 2);
+            // (the loads below are issued here, before the LAST pencil's rows go back into the tile, not before the solves:
+            //  16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component; with the partial result parked in the tile
+            //  during the last solve to make room for them: no spills, but 2.37 instead of 2.24 ms per launch; issued after
+            //  the FIRST solve, where the product window's registers are free (123 VGPRs, no spills): 2.18 ms both ways --
+            //  the load's latency is not what limits, the memory system is busy throughout with this pattern's segments)
+            if (pw == NPW - 1) {
                 if constexpr (EPI) {
                     // the stage's description, per component, through a laundered pointer (as kernel arguments its scalars
                     // would stay live across the solves and overflow the SGPR file -- see k_ytile_transeq<EPI>)
                     const TileEpi *pe = epp + c;
                     asm volatile("" : "+s"(pe) : "v"(T[0]));
-                    const TileEpi epi = *pe;
-                    real2_t bs[NI];
+                    epi = *pe;
                     gload(old, o);
                     gload(bs, epi.base + off);
-                    real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
+                } else {
+                    YT_T(3);
+#ifdef YT_TIMING
+                    if (lane == 0) {
+                        const unsigned long long t_ = __builtin_readcyclecounter();
+                        atomicAdd(&g_yt[8 + wave], t_ - yt_c0);
+                        atomicAdd(&g_yt[24 + wave], t_ - yt_s0);
+                    }
+#endif
+#ifdef YT_NT
+                    if (ACC) {
 #pragma unroll
-                    for (int m = 0; m < Q / 2; m++)
-                        dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+                        for (int i = 0; i < NI; i++) {
+                            const real_t *q_ = reinterpret_cast<const real_t *>(tile_row<RP>(o, prow, i, voff));
+                            old[i] = make_real2(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1));
+                        }
+                    }
+#else
+                    if (ACC) gload(old, o);
+#endif
+                }
+            }
+            {
+                real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + (wave + 16 * pw) * TP + lane * Q);
+#pragma unroll
+                for (int m = 0; m < Q / 2; m++)
+                    dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
+            }
+            if (NPW > 1) asm volatile("" : "+v"(lane) : "v"(r[0]));  // (one pencil at a time: the next one's reads wait)
+            }  // (pw)
+            {
+                if constexpr (EPI) {
                     __syncthreads();
                     real2_t d[NI];
 #pragma unroll
                     for (int i = 0; i < NI; i++) {
-                        d[i] = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                        d[i] = make_real2(tile[(2 * cc) * TP + cy + RP * i], tile[(2 * cc + 1) * TP + cy + RP * i]);
                         d[i].x += old[i].x;
                         d[i].y += old[i].y;
-                        if (epi.store) *const_cast<real2_t *>(tile_row(o, prow, i, voff)) = d[i];
+                        if (epi.store) *const_cast<real2_t *>(tile_row<RP>(o, prow, i, voff)) = d[i];
                     }
 #pragma unroll  // (static indices into epi: a run-time index would put the struct on the stack)
                     for (int k = 0; k < 5; k++) {
@@ -1117,45 +1169,22 @@ __global__ void __launch_bounds__(1024)
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < NI; i++) *const_cast<real2_t *>(tile_row(epi.y + off, prow, i, voff)) = bs[i];
+                    for (int i = 0; i < NI; i++) *const_cast<real2_t *>(tile_row<RP>(epi.y + off, prow, i, voff)) = bs[i];
                 } else {
-                YT_T(3);
-#ifdef YT_TIMING
-                if (lane == 0) {
-                    const unsigned long long t_ = __builtin_readcyclecounter();
-                    atomicAdd(&g_yt[8 + wave], t_ - yt_c0);
-                    atomicAdd(&g_yt[24 + wave], t_ - yt_s0);
-                }
-#endif
-#ifdef YT_NT
-                if (ACC) {
-#pragma unroll
-                    for (int i = 0; i < NI; i++) {
-                        const real_t *q_ = reinterpret_cast<const real_t *>(tile_row(o, prow, i, voff));
-                        old[i] = make_real2(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1));
-                    }
-                }
-#else
-                if (ACC) gload(old, o);
-#endif
-                real2_t *__restrict__ dst = reinterpret_cast<real2_t *>(tile + wave * TP + lane * Q);
-#pragma unroll
-                for (int m = 0; m < Q / 2; m++)
-                    dst[m] = make_real2(r[2 * m] + nu * T[2 * m], r[2 * m + 1] + nu * T[2 * m + 1]);
                 __syncthreads();
                 YT_T(4);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
-                    real2_t v = make_real2(tile[(2 * cc) * TP + cy + 128 * i], tile[(2 * cc + 1) * TP + cy + 128 * i]);
+                    real2_t v = make_real2(tile[(2 * cc) * TP + cy + RP * i], tile[(2 * cc + 1) * TP + cy + RP * i]);
                     if (ACC) { v.x += old[i].x; v.y += old[i].y; }
 #ifdef YT_NT
                     {
-                        real_t *q_ = reinterpret_cast<real_t *>(const_cast<real2_t *>(tile_row(o, prow, i, voff)));
+                        real_t *q_ = reinterpret_cast<real_t *>(const_cast<real2_t *>(tile_row<RP>(o, prow, i, voff)));
                         __builtin_nontemporal_store(v.x, q_);
                         __builtin_nontemporal_store(v.y, q_ + 1);
                     }
 #else
-                    *const_cast<real2_t *>(tile_row(o, prow, i, voff)) = v;
+                    *const_cast<real2_t *>(tile_row<RP>(o, prow, i, voff)) = v;
 #endif
                 }
                 }  // (!EPI)
@@ -1183,21 +1212,25 @@ __global__ void __launch_bounds__(1024)
 // its input tile from the spectrum instead of in1 (neither array is touched).  The tile area grows to the transforms'
 // 72 KB; the table sets are staged without their STC block, which tds_solve does not read.
 // UNI: both operators on a uniform grid -- no ST reads / multiplications (see k_ytile_transeq3)
-template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false>
+// CIRC (round 6, with UNI, local form): both operators in the circulant form (circ_solve; ca / cb), no lane tables staged
+template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false, bool CIRC = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2,
                      XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn,
-                     ZfArg zf)
+                     ZfArg zf, CircOp ca, CircOp cb)
 {
     extern __shared__ real_t lt[];
     constexpr int LN = (ZF ? LT_NC(Q) : LT_N(Q)) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     static_assert(!ZF || (Q == 8 && MODE != 2 && !HALO), "the z-transforming forms: local pairs on 512-row pencils");
-    for (int i = threadIdx.x; i < LN; i += blockDim.x) {
-        lt[i] = ta.TL[i];
-        if (MODE != 2) lt[LN + i] = tb.TL[i];
+    static_assert(!CIRC || (UNI && !HALO), "CIRC: the local uniform-grid form");
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LN; i += blockDim.x) {
+            lt[i] = ta.TL[i];
+            if (MODE != 2) lt[LN + i] = tb.TL[i];
+        }
     }
     const real_t *__restrict__ la = lt, *__restrict__ lb = lt + LN;
-    real_t *tile = lt + (MODE == 2 ? 1 : 2) * LN;  // (a single operator stages one table set)
+    real_t *tile = lt + (CIRC ? 0 : (MODE == 2 ? 1 : 2) * LN);  // (a single operator stages one table set)
     real2_t *tws = reinterpret_cast<real2_t *>(tile + ZF_AREA_DOUBLES);  // ZF: W512^k behind the 72 KB tile area
     if (ZF && threadIdx.x < 256) tws[threadIdx.x] = zf.tw[threadIdx.x];
     const long kzs = (long)zf.ny * zf.px;
@@ -1259,6 +1292,11 @@ __global__ void __launch_bounds__(1024)
             return;
         }
 #endif
+        if constexpr (CIRC) {
+            if (op == 0) circ_solve<Q, NARROW>(w, r, ca, lane);
+            else circ_solve<Q, NARROW>(w, r, cb, lane);
+            return;
+        }
         real_t X[Q], du1, xn;
         scan_solve<Q, true, NARROW>(w, X, du1, xn, l, t, lane, first);
         real_t du_s, du_e;
@@ -1335,7 +1373,14 @@ __global__ void __launch_bounds__(1024)
         if constexpr (HALO) window_from_body_halo<Q>(w, b, lane, hal + wave * 8);
         else window_from_body<Q>(w, b, lane);
         // (barriers only before COOPERATIVE accesses to the tile: a wave's own results go to its own pencil's region)
-        if (MODE == 0) __syncthreads();  // all rows picked: the second input may overwrite the tile
+        if (MODE == 0) {
+            // the rows must BE in registers before the barrier: pick reads through a __restrict__ pointer, which lets the
+            // compiler sink its loads below the barrier (round 6: seen in the ISA of the CIRC form, whose first solve no
+            // longer touches LDS -- two of the four ds_read_b128 landed behind the other waves' to_tile(g2))
+#pragma unroll
+            for (int q = 0; q < Q; q++) asm volatile("" : "+v"(b[q]));
+            __syncthreads();  // all rows picked: the second input may overwrite the tile
+        }
         if (!NOPREF) {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) {
@@ -1753,6 +1798,14 @@ static void tile_range(const x3d_backend *b, int dir, int other0, int nother, in
     *ntiles = nother * ntx;
 }
 
+// the circulant form (circ_solve) where every operator of the launch offers it.  X3D_NO_CIRC=1: never (A/B)
+static bool circ_env_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
+    return on == 1;
+}
+
 // K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq).
 // mode 2: out1 = A(in1) only.  halo != null: decomposed direction (TileHalo: nf = 1 or 2 inputs, nb operators)
 int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *out2, const real_t *in1, const real_t *in2,
@@ -1769,12 +1822,13 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     };
     if (!fast(ta) || !fast(tb) || (dir == X3D_DIR_Y ? b->ny : b->nz) != 64 * Q || b->nx % 16 != 0) return 0;
     if (dir == X3D_DIR_Z) { const char *e = getenv("X3D_NO_ZTILE"); if (e && e[0] == '1') return 0; }
-    const size_t lds = sizeof(real_t) * ((size_t)(mode == 2 ? 1 : 2) * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
-    if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
     static int uni_on = -1;
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
     const bool uni = uni_on && ta->uniform && tb->uniform;
+    const bool circ = narrow && uni && !halo && circ_env_on() && ta->circ_ok && tb->circ_ok;
+    const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : (mode == 2 ? 1 : 2) * LT_N(Q) * 64) + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
+    if (lds > 160 * 1024) return 0;
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16;
     int tile0, ntiles;
@@ -1789,15 +1843,16 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GO(Q_, M_, N_, H_, U_)                                                                                  \
+#define GOC(Q_, M_, N_, H_, U_, C_)                                                                             \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_, false, U_>));                                        \
-        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_, false, U_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_>));                                    \
+        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
                            in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn,   \
-                           ZfArg{});                                                                            \
+                           ZfArg{}, ta->circ, tb->circ);                                                        \
     } while (0)
+#define GO(Q_, M_, N_, H_, U_) GOC(Q_, M_, N_, H_, U_, false)
 #define GOH(Q_, M_, N_, U_) do { if (halo) GO(Q_, M_, N_, true, U_); else GO(Q_, M_, N_, false, U_); } while (0)
-#define GON(Q_, M_) do { if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
+#define GON(Q_, M_) do { if (circ) GOC(Q_, M_, true, false, true, true); else if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
@@ -1841,8 +1896,12 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
         if (int rc = x3d_zfpair8(b, mode, out1, out2, in1, in2, ta, tb, zf, done)) return rc;
         if (*done) return 0;
     }
-    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_NC(8) * 64 + ZF_AREA_DOUBLES + 512);
     const bool narrow = stencil_narrow(ta) && stencil_narrow(tb);
+    static int uni_on = -1;
+    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
+    const bool uni = uni_on && ta->uniform && tb->uniform;
+    const bool circ = narrow && uni && circ_env_on() && ta->circ_ok && tb->circ_ok;
+    const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_NC(8) * 64) + ZF_AREA_DOUBLES + 512);
     const long pxy = (long)b->nxp * b->nyp;
     const int ntx = b->nx / 16, ntiles = ntx * nyr, tile0 = ntx * y0;
     static int cap = -1;
@@ -1850,17 +1909,15 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
     const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
-#define GO(M_, N_, U_)                                                                                          \
+#define GO(M_, N_, U_, C_)                                                                                      \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_>));                                       \
-        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
-                           out2, in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, pxy, (long)b->nxp, th, 0, zf); \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_, C_>));                                   \
+        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_, C_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
+                           out2, in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, pxy, (long)b->nxp, th, 0, zf, ta->circ, tb->circ); \
     } while (0)
-    static int uni_on = -1;
-    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
-    const bool uni = uni_on && ta->uniform && tb->uniform;
-    if (mode == 0) { if (narrow && uni) GO(0, true, true); else if (narrow) GO(0, true, false); else GO(0, false, false); }
-    else { if (narrow && uni) GO(1, true, true); else if (narrow) GO(1, true, false); else GO(1, false, false); }
+#define GOU(M_) do { if (circ) GO(M_, true, true, true); else if (narrow && uni) GO(M_, true, true, false); else if (narrow) GO(M_, true, false, false); else GO(M_, false, false, false); } while (0)
+    if (mode == 0) GOU(0); else GOU(1);
+#undef GOU
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;
@@ -1901,6 +1958,24 @@ int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, real_t *const r[3], con
     return 0;
 }
 
+// pencils per wave of the tile kernels: 2 where a 16-pencil tile would move 64-byte row segments (FP32), local form, nx a
+// multiple of 32 (X3D_NO_NPW2=1: always 1).  256-row FP64 pencils (BASELINE configs[1]) with X3D_NPW2_256=1 only: measured
+// SLOWER there (5.24 against 5.04 ms per step at 256^3, k_ytile_transeq3<4> at 0.46 against 0.54 of the peak) -- a 256-row
+// solve costs what a 512-row one does less the per-row work (the scans, the reduced system), so two of them per wave double
+// the solve phase for the bytes of one 512-row tile: the 256-row tile is short of on-chip time, not of bytes in flight
+static int ytile_npw(const x3d_backend *b, int Q, bool halo)
+{
+    static int on = -1, on256 = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_NPW2"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (on256 < 0) { const char *e = getenv("X3D_NPW2_256"); on256 = (e && e[0] == '1') ? 1 : 0; }
+    return (on && !halo && b->nx % 32 == 0 && (X3D_RB == 4 || (Q == 4 && on256))) ? 2 : 1;
+}
+
+static bool ytile_circ(const x3d_tdsops *a, const x3d_tdsops *a2, const x3d_tdsops *c, const x3d_tdsops *c2)
+{
+    return circ_env_on() && a->circ_ok && a2->circ_ok && c->circ_ok && c2->circ_ok;
+}
+
 // K3y, three components in one launch (k_ytile_transeq3); f[0] is the advecting component.
 // halo != null: decomposed direction (TileHalo: nf = 3 fields in the order f[0..2], nb = 9 boundary values)
 int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t *const f[3], real_t nu,
@@ -1913,14 +1988,16 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
     if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
-    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4) + (halo ? 256 + 288 : 0));
-    if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     static int uni_on = -1;
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
     const bool uni = uni_on && der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
+    const int npw = (narrow && uni) ? ytile_npw(b, Q, halo != nullptr) : 1;  // (two pencils per wave: the uniform-grid forms)
+    const bool circ = narrow && uni && !halo && ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym);
+    const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_N(Q) * 64) + 16 * npw * (64 * Q + 4) + (halo ? 256 + 288 : 0));
+    if (lds > 160 * 1024) return 0;
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16;
+    const int ntx = b->nx / (16 * npw);
     int tile0, ntiles;
     tile_range(b, dir, other0, nother, ntx, &tile0, &ntiles);
     if (ntiles <= 0) { *done = true; return 0; }
@@ -1929,13 +2006,16 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
     if (128 * rstride * X3D_RB >= (1L << 32)) return 0;  // tile_row's 32-bit lane offset
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     // (profiler: three components = three "forward" launches of this direction, in one kernel)
-#define GO(Q_, A_, N_, H_, U_)                                                                                  \
+#define GOW(Q_, A_, N_, H_, U_, W_, C_)                                                                         \
     do {                                                                                                        \
         /* (the pair solve P12 only in the local form: with the HALO extras it spills, 128 VGPRs + 124 bytes) */ \
-        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_))>));                                \
-        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_))>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
-                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, tile0, ntiles, rstride, ostride, nu, th); \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_)), false, W_, C_>));                 \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, A_, N_, H_, U_, (U_ && !(H_)), false, W_, C_>), dim3(blocks), dim3(1024), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, tile0, ntiles, rstride, ostride, nu, th, \
+                           (const TileEpi *)nullptr, der1st->circ, der2nd->circ);                               \
     } while (0)
+#define GOC(Q_, A_, W_) do { if (circ) GOW(Q_, A_, true, false, true, W_, true); else GOW(Q_, A_, true, false, true, W_, false); } while (0)
+#define GO(Q_, A_, N_, H_, U_) do { if ((N_) && (U_) && !(H_)) { if (npw == 2) GOC(Q_, A_, 2); else GOC(Q_, A_, 1); } else GOW(Q_, A_, N_, H_, U_, 1, false); } while (0)
 #define GOH(Q_, A_, N_, U_) do { if (halo) GO(Q_, A_, N_, true, U_); else GO(Q_, A_, N_, false, U_); } while (0)
 #define GON(Q_, A_) do { if (narrow && uni) GOH(Q_, A_, true, true); else if (narrow) GOH(Q_, A_, true, false); else GOH(Q_, A_, false, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)
@@ -1947,6 +2027,8 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
 #undef GON
 #undef GOH
 #undef GO
+#undef GOC
+#undef GOW
     X3D_HIP(hipGetLastError());
     b->n_tq3++;
     if (halo) b->n_halo++;
@@ -1970,12 +2052,14 @@ int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const re
     if (!on || !x3d_ytile_applicable(b, dir, der1st, der1st_sym, der2nd)) return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
-    const size_t lds = sizeof(real_t) * ((size_t)2 * LT_N(Q) * 64 + 16 * (64 * Q + 4));
+    const int npw = ytile_npw(b, Q, false);
+    const bool circ = ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym);
+    const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_N(Q) * 64) + 16 * npw * (64 * Q + 4));
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     const bool uni = der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
     if (lds > 160 * 1024 || !narrow || !uni) return 0;
     const long pxy = (long)b->nxp * b->nyp;
-    const int ntx = b->nx / 16, ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
+    const int ntx = b->nx / (16 * npw), ntiles = ntx * (dir == X3D_DIR_Y ? b->nz : b->ny);
     const int blocks = x3d_persistent_blocks(b, ntiles);
     const long rstride = dir == X3D_DIR_Y ? (long)b->nxp : pxy, ostride = dir == X3D_DIR_Y ? pxy : (long)b->nxp;
     if (128 * rstride * X3D_RB >= (1L << 32)) return 0;
@@ -1985,17 +2069,18 @@ int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const re
     {
         // (timed under direction slot 0: x3d_prof_get(kind, 3) stays the plain z launches, the sum over slots has these)
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, 0);
-        if (Q == 8) {
-            X3D_LDS_OPTIN(b, (k_ytile_transeq3<8, true, true, false, true, true, true>));
-            hipLaunchKernelGGL((k_ytile_transeq3<8, true, true, false, true, true, true>), dim3(blocks), dim3(1024), lds, b->stream,
-                               r[0], r[1], r[2], f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, 0, ntiles, rstride,
-                               ostride, nu, th, (const TileEpi *)b->epi_dev);
-        } else {
-            X3D_LDS_OPTIN(b, (k_ytile_transeq3<4, true, true, false, true, true, true>));
-            hipLaunchKernelGGL((k_ytile_transeq3<4, true, true, false, true, true, true>), dim3(blocks), dim3(1024), lds, b->stream,
-                               r[0], r[1], r[2], f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, 0, ntiles, rstride,
-                               ostride, nu, th, (const TileEpi *)b->epi_dev);
-        }
+#define GOE(Q_, W_, C_)                                                                                         \
+    do {                                                                                                        \
+        X3D_LDS_OPTIN(b, (k_ytile_transeq3<Q_, true, true, false, true, true, true, W_, C_>));                  \
+        hipLaunchKernelGGL((k_ytile_transeq3<Q_, true, true, false, true, true, true, W_, C_>), dim3(blocks), dim3(1024), lds, b->stream, \
+                           r[0], r[1], r[2], f[0], f[1], f[2], xop_of(der1st), xop_of(der2nd), ntx, 0, ntiles, rstride, \
+                           ostride, nu, th, (const TileEpi *)b->epi_dev, der1st->circ, der2nd->circ);           \
+    } while (0)
+#define GOEC(Q_, W_) do { if (circ) GOE(Q_, W_, true); else GOE(Q_, W_, false); } while (0)
+        if (Q == 8) { if (npw == 2) GOEC(8, 2); else GOEC(8, 1); }
+        else { if (npw == 2) GOEC(4, 2); else GOEC(4, 1); }
+#undef GOEC
+#undef GOE
     }
     X3D_HIP(hipGetLastError());
     b->n_tq3++;

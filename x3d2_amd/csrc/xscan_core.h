@@ -120,6 +120,29 @@ __device__ __forceinline__ real_t readlane_d(real_t v, int l)
 // ---- two pencils per wave: every lane-table value read from LDS serves both (the kernels are LDS-pipe
 // bound on the table reads), and the two independent dependency chains interleave.  The solver below is
 // written once over T = real_t or V2.
+#ifdef X3D_SINGLE_PREC
+// FP32 (round 6): the pair IS a packed register pair -- gfx950 runs v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate
+// of their scalar forms, so a pair solve costs the vector instructions of ONE solve (the FP32 flavour moves half the bytes
+// with the FP64 flavour's instruction count otherwise: it is bound by instruction issue, not by HBM).  Same operations per
+// component, same rounding (a packed FMA is two FMAs).  X3D_SP_NO_PK: the two-scalars form (A/B)
+#ifndef X3D_SP_NO_PK
+#define X3D_V2_PACKED 1
+#endif
+#endif
+#ifdef X3D_V2_PACKED
+typedef float x3d_f2 __attribute__((ext_vector_type(2)));
+union V2 {
+    struct { real_t a, b; };
+    x3d_f2 v;
+};
+__device__ __forceinline__ V2 v2_of(x3d_f2 v) { V2 r; r.v = v; return r; }
+__device__ __forceinline__ V2 operator+(V2 x, V2 y) { return v2_of(x.v + y.v); }
+__device__ __forceinline__ V2 operator-(V2 x, V2 y) { return v2_of(x.v - y.v); }
+__device__ __forceinline__ V2 operator*(V2 x, V2 y) { return v2_of(x.v * y.v); }
+__device__ __forceinline__ V2 operator*(real_t c, V2 x) { return v2_of(c * x.v); }
+__device__ __forceinline__ V2 operator*(V2 x, real_t c) { return v2_of(x.v * c); }
+__device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.v += y.v; return x; }
+#else
 struct V2 { real_t a, b; };
 __device__ __forceinline__ V2 operator+(V2 x, V2 y) { return V2{x.a + y.a, x.b + y.b}; }
 __device__ __forceinline__ V2 operator-(V2 x, V2 y) { return V2{x.a - y.a, x.b - y.b}; }
@@ -127,6 +150,7 @@ __device__ __forceinline__ V2 operator*(V2 x, V2 y) { return V2{x.a * y.a, x.b *
 __device__ __forceinline__ V2 operator*(real_t c, V2 x) { return V2{c * x.a, c * x.b}; }
 __device__ __forceinline__ V2 operator*(V2 x, real_t c) { return V2{x.a * c, x.b * c}; }
 __device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.a += y.a; x.b += y.b; return x; }
+#endif
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
 __device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
@@ -288,6 +312,79 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
     }
     PHASE(xn);
 #undef PHASE
+}
+
+// CIRCULANT form (round 6): one periodic operator on a uniform grid, lane-local + scans, WITHOUT lane tables and without the
+// reduced system.  (alpha, 1, alpha) = (alpha / rho) (1 + rho z^-1) (1 + rho z): e_j = g r_j - rho e_{j-1} around the ring,
+// x_j = e_j - rho x_{j+1} around the ring (g = rho / alpha, folded into the stencil).  Lane l runs both recurrences over its
+// Q rows from zero; the value carried in from its neighbour is E_l = V_l + mu E_{l-1} (mu = (-rho)^Q), a CONSTANT-multiplier
+// recurrence over the lanes: Kogge-Stone inside each row of 16 lanes by DPP row shifts with mu, mu^2, mu^4 (, mu^8) from
+// SGPRs -- mu^8 (Q = 8) / mu^16 (Q = 4) are below 2^-60 for every scheme of the reference (rho <= 0.382: compact6's first
+// derivative), the truncation its own 2 x 2 closure makes (src/tdsops.f90:196-201) -- then the neighbouring row's total
+// enters through its first (last) lane by a wave rotate, which also closes the ring (lane 0 <- lane 63: the periodic wrap
+// needs no closure at all), and spreads along the row by the same shifts.  Per right-hand side at Q = 8, 5-tap stencil:
+// ~118 vector instructions and NO LDS reads (scan_solve's periodic form + substitution: ~150 and 68).
+template <int Q, bool NARROW, class T = real_t>
+__device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const CircOp &t, int lane)
+{
+    constexpr bool S8 = Q < 8;  // a fourth shift step (distance 8) where mu^8 is not yet negligible
+    const real_t c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6], c7 = t.c[7],
+                 c8 = t.c[8];
+    const real_t nr = t.nr, m1 = t.mu[0], m2 = t.mu[1], m4 = t.mu[2], m8 = t.mu[3];
+    T acc[Q];
+    if (NARROW) {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
+                     c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
+    }
+    const bool row_first = (lane & 15) == 0, row_last = (lane & 15) == 15;
+    T prev = zero_of<T>();
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        X[q] = acc[q] + nr * prev;
+        prev = X[q];
+    }
+    T v = prev;
+    v += m1 * dpp0<0x111>(v);  // row_shr:1, 2, 4 (, 8): lanes without a source read 0
+    v += m2 * dpp0<0x112>(v);
+    v += m4 * dpp0<0x114>(v);
+    if (S8) v += m8 * dpp0<0x118>(v);
+    {
+        T z = sel_of(row_first, dpp0<0x13C>(v), zero_of<T>());  // wave_ror:1: the previous row's total, lane 0 <- lane 63
+        z += m1 * dpp0<0x111>(z);
+        z += m2 * dpp0<0x112>(z);
+        z += m4 * dpp0<0x114>(z);
+        if (S8) z += m8 * dpp0<0x118>(z);
+        v += m1 * z;
+    }
+    T carry = dpp0<0x13C>(v);
+    T nxt = zero_of<T>();
+#pragma unroll
+    for (int q = Q - 1; q >= 0; q--) {
+        X[q] = (X[q] + t.pf[q] * carry) + nr * nxt;
+        nxt = X[q];
+    }
+    v = nxt;
+    v += m1 * dpp0<0x101>(v);  // row_shl:1, 2, 4 (, 8)
+    v += m2 * dpp0<0x102>(v);
+    v += m4 * dpp0<0x104>(v);
+    if (S8) v += m8 * dpp0<0x108>(v);
+    {
+        T z = sel_of(row_last, dpp0<0x134>(v), zero_of<T>());  // wave_rol:1: the next row's total, lane 63 <- lane 0
+        z += m1 * dpp0<0x101>(z);
+        z += m2 * dpp0<0x102>(z);
+        z += m4 * dpp0<0x104>(z);
+        if (S8) z += m8 * dpp0<0x108>(z);
+        v += m1 * z;
+    }
+    carry = dpp0<0x134>(v);
+#pragma unroll
+    for (int q = 0; q < Q; q++) X[q] = X[q] + t.pf[Q - 1 - q] * carry;
 }
 
 // Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE

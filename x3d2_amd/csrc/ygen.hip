@@ -301,7 +301,13 @@ __global__ void __launch_bounds__(1024)
         T.to_tile(nxt);
         __syncthreads();
         T.window(w);
-        if (MODE == 0) __syncthreads();  // all windows read: the second input may overwrite the tile
+        if (MODE == 0) {
+            // (the window must BE in registers before the barrier: its loads go through __restrict__ pointers, which the
+            //  compiler may otherwise sink below it -- see k_ytile_tds_pair)
+#pragma unroll
+            for (int m = 0; m < Q + 8; m++) asm volatile("" : "+v"(w[m]));
+            __syncthreads();  // all windows read: the second input may overwrite the tile
+        }
         {
             const int tn = tl + gridDim.x;
             if (tn < ntiles) T.gload(nxt, in1 + in1_off(tn));
