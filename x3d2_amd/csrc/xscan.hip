@@ -2053,7 +2053,9 @@ int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const re
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
     const int npw = ytile_npw(b, Q, false);
-    const bool circ = ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym);
+    // (FP64, 512 rows: the circulant form of THIS instantiation spills 14 VGPRs and runs at the table form's 3.1 ms -- kept
+    //  on the tables; 256 rows and FP32 have the registers)
+    const bool circ = ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym) && (X3D_RB == 4 || Q == 4);
     const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_N(Q) * 64) + 16 * npw * (64 * Q + 4));
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     const bool uni = der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;

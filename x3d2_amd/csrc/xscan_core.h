@@ -324,6 +324,12 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 // enters through its first (last) lane by a wave rotate, which also closes the ring (lane 0 <- lane 63: the periodic wrap
 // needs no closure at all), and spreads along the row by the same shifts.  Per right-hand side at Q = 8, 5-tap stencil:
 // ~118 vector instructions and NO LDS reads (scan_solve's periodic form + substitution: ~150 and 68).
+#ifdef CIRC_SCHED  // (experiment: scheduling barriers between the phases -- the EPI form of k_ytile_transeq3 then fits its
+                   //  128 VGPRs (14 spilled without), and runs SLOWER: 3.33 against 3.11 ms; the y launch 1.86 against 1.72)
+#define CIRC_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CIRC_SB()
+#endif
 template <int Q, bool NARROW, class T = real_t>
 __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const CircOp &t, int lane)
 {
@@ -343,6 +349,7 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
                      c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
     }
     const bool row_first = (lane & 15) == 0, row_last = (lane & 15) == 15;
+    CIRC_SB();
     T prev = zero_of<T>();
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -350,6 +357,7 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
         prev = X[q];
     }
     T v = prev;
+    CIRC_SB();
     v += m1 * dpp0<0x111>(v);  // row_shr:1, 2, 4 (, 8): lanes without a source read 0
     v += m2 * dpp0<0x112>(v);
     v += m4 * dpp0<0x114>(v);
@@ -364,12 +372,29 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     }
     T carry = dpp0<0x13C>(v);
     T nxt = zero_of<T>();
+    CIRC_SB();
+#ifdef CIRC_PF_CHAIN
+    {
+        T tq[Q];
+        tq[0] = nr * carry;
+        if (Q > 4) tq[4] = t.pf[4] * carry;
+#pragma unroll
+        for (int q = 1; q < Q; q++) if (q != 4) tq[q] = nr * tq[q - 1];
+#pragma unroll
+        for (int q = Q - 1; q >= 0; q--) {
+            X[q] = (X[q] + tq[q]) + nr * nxt;
+            nxt = X[q];
+        }
+    }
+#else
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
         X[q] = (X[q] + t.pf[q] * carry) + nr * nxt;
         nxt = X[q];
     }
+#endif
     v = nxt;
+    CIRC_SB();
     v += m1 * dpp0<0x101>(v);  // row_shl:1, 2, 4 (, 8)
     v += m2 * dpp0<0x102>(v);
     v += m4 * dpp0<0x104>(v);
@@ -383,8 +408,21 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
         v += m1 * z;
     }
     carry = dpp0<0x134>(v);
+    CIRC_SB();
+#ifdef CIRC_PF_CHAIN
+    {
+        T tq = nr * carry;
+        X[Q - 1] = X[Q - 1] + tq;
+#pragma unroll
+        for (int q = Q - 2; q >= 0; q--) {
+            tq = (Q > 4 && q == Q - 5) ? t.pf[4] * carry : nr * tq;
+            X[q] = X[q] + tq;
+        }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < Q; q++) X[q] = X[q] + t.pf[Q - 1 - q] * carry;
+#endif
 }
 
 // Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE
