@@ -244,7 +244,7 @@ def live_traffic(kernel_substr, extra_args, timeout=120):
                         # (k_ytile_transeq3's seventh template flag: the launches that also do the RK stage, counted apart)
                         m = re.search(kernel_substr + r"<([^>]*)>", name)
                         targs = [a.strip() for a in m.group(1).split(",")] if m else []
-                        (vals_e if len(targs) == 7 and targs[6] == "true" else vals).append(float(row["Counter_Value"]))
+                        (vals_e if len(targs) >= 7 and targs[6] == "true" else vals).append(float(row["Counter_Value"]))
             if not vals:
                 return None, "%s pass: no launch of %s in the counter file" % (counter, kernel_substr)
             out[counter] = (sum(vals) / len(vals), len(vals), sum(vals_e) / len(vals_e) if vals_e else None, len(vals_e))
@@ -650,13 +650,13 @@ def main():
             d_bytes = 64.0 * dofb
             d_ach = d_bytes / (d_ms * 1e-3) / 1e9
             if args.case == "tgv" and not split_dirs:
-                name = ("k_ytile_transeq3<%d,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch)"
-                        % (args.n // 64))
+                name = ("k_ytile_transeq3<%d,true,true,false,UNI,P12> (transeq_y and transeq_z, three components per launch; "
+                        "round 6: the y launch in the circulant form, no lane tables)" % (args.n // 64))
             elif args.case == "tgv":
                 name = ("k_ytile_transeq3<..,HALO> + k_transeq_halo_fix (transeq_%s: the decomposed direction in one pass + its "
                         "strip correction)" % "/".join("xyz"[d - 1] for d in split_dirs))
             else:
-                name = "k_ygen_transeq3<5> (transeq_y on the 257-row wall-normal pencils, three components per launch)"
+                name = "k_ygen_transeq3<5,..,DIRECT> (transeq_y on the 257-row wall-normal pencils, three components per launch)"
             dominant = {"name": name, "launches": launches, "avg_launch_ms": d_ms, "timed": "HIP events on the backend's "
                         "stream around every launch, inside the timed region",
                         "algorithmic_bytes_per_launch": d_bytes, "bytes_convention": "SURVEY 8(d): transeq_{y,z} 64 B/DoF x DoF",

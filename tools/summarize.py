@@ -50,7 +50,7 @@ dirty = not os.environ.get("X3D_ARTIFACT_COMMIT") and bool(
 def _epi(k):
     # k_ytile_transeq3's seventh template flag (printed only when true): the launches that also do the RK stage
     a = k[k.index("<") + 1:k.rindex(">")].split(",") if "<" in k else []
-    return len(a) == 7 and a[6].strip() == "true"
+    return len(a) >= 7 and a[6].strip() == "true"
 dom = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k and not _epi(k)]
 dom_e = [(fe + wr) for k, n, fe, wr in rows if "k_ytile_transeq3" in k and _epi(k)]
 json.dump({"n": 512, "round": rnd, "commit": commit + ("+uncommitted" if dirty else ""),

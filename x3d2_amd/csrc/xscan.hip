@@ -136,15 +136,20 @@ __device__ __forceinline__ void load_window(real_t (&w)[Q + 8], const real_t *__
 }
 
 // ---------------------------------------------------------------- tds_solve
-template <int Q, bool ACC, int FAST>  // FAST: 0 general, 1 branch-free periodic form, 2 the same with the 5-tap stencil
+// FAST: 0 general, 1 branch-free periodic form, 2 the same with the 5-tap stencil, 3 (round 6): 2 on a uniform grid in the
+// circulant form (circ_solve, co: no lane tables, no LDS at all)
+template <int Q, bool ACC, int FAST>
 __global__ void __launch_bounds__(512) k_xscan_tds(real_t *__restrict__ du, const real_t *__restrict__ u, XOp t,
-                                                   int np, long pitch, int n_wrap, real_t scale)
+                                                   int np, long pitch, int n_wrap, real_t scale, CircOp co)
 {
     extern __shared__ real_t lt[];  // [LT_N(Q)][64], general form: + the stencil table [CS_N(Q)]
-    for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
+    constexpr bool CIRC = FAST == 3;
     const real_t *cs = lt + LT_N(Q) * 64;
-    if (!FAST) stage_cs<Q>(lt + LT_N(Q) * 64, t);
-    __syncthreads();
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
+        if (!FAST) stage_cs<Q>(lt + LT_N(Q) * 64, t);
+        __syncthreads();
+    }
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -168,11 +173,14 @@ __global__ void __launch_bounds__(512) k_xscan_tds(real_t *__restrict__ du, cons
 #endif
         } else if (exact) load_window_exact<Q>(w, row, lane, nr);
         else load_window<Q>(w, row, first, nr, n_wrap, interior);
+        real_t *__restrict__ orow = du + (long)p * pitch;
+        real_t r[Q];
+        if constexpr (CIRC) {
+            circ_solve<Q, true>(w, r, co, lane);
+        } else {
         scan_solve<Q, (FAST != 0), (FAST == 2)>(w, X, du1, xn, lt, t, lane, first, 0, cs);
         const real_t du_s = t.rs_s * (du1 - t.sa1 * xn);  // periodic self-exchange: recv_s = X_n
         const real_t du_e = t.rs_e * (xn - t.scn * du1);  //                          recv_e = du_1
-        real_t *__restrict__ orow = du + (long)p * pitch;
-        real_t r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = first + q;
@@ -186,6 +194,7 @@ __global__ void __launch_bounds__(512) k_xscan_tds(real_t *__restrict__ du, cons
                 r[q] = (j == n) ? du_e * st : r[q];
             }
         }
+        }  // (!CIRC)
 #if XSCAN_EXP == 1
         if (r[0] != 12345.678) continue;
 #endif
@@ -219,12 +228,16 @@ __global__ void __launch_bounds__(512) k_xscan_tds(real_t *__restrict__ du, cons
 // lr.wall != null: the pencils of the two y faces (j = 0, ny - 1) take the rows of `wall` instead
 // (field_set_face_from_field(Y_FACE) between the stage and the divergence: the channel case's apply_BC,
 // src/case/channel.f90:214-231)
-template <int Q, bool NARROW>
-__global__ void __launch_bounds__(512) k_xscan_tds_lin(real_t *__restrict__ du, LinRows lr, XOp t, int np, long pitch)
+// CIRC: the operator in the circulant form (as k_xscan_tds<.., 3>: the two kernels must give the same bits)
+template <int Q, bool NARROW, bool CIRC = false>
+__global__ void __launch_bounds__(512) k_xscan_tds_lin(real_t *__restrict__ du, LinRows lr, XOp t, int np, long pitch,
+                                                       CircOp co)
 {
     extern __shared__ real_t lt[];  // [LT_N(Q)][64]
-    for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
-    __syncthreads();
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LT_N(Q) * 64; i += blockDim.x) lt[i] = t.TL[i];
+        __syncthreads();
+    }
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -250,15 +263,19 @@ __global__ void __launch_bounds__(512) k_xscan_tds_lin(real_t *__restrict__ du, 
         else store_rows_q4<false>(lr.y + ro, lane, b, 1.0);
         real_t w[Q + 8], X[Q], du1, xn;
         window_from_body<Q>(w, b, lane);
+        real_t r[Q];
+        if constexpr (CIRC) {
+            circ_solve<Q, NARROW>(w, r, co, lane);
+        } else {
         scan_solve<Q, true, NARROW>(w, X, du1, xn, lt, t, lane, first);
         const real_t du_s = t.rs_s * (du1 - t.sa1 * xn), du_e = t.rs_e * (xn - t.scn * du1);
-        real_t r[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const real_t st = LTR(lt, LT_ST(q));
             r[q] = (X[q] - LTR(lt, LT_SA(q)) * du_s - LTR(lt, LT_SC(q)) * du_e) * st;
             if (q == 0) r[q] = (lane == 0) ? du_s * st : r[q];
             if (q == Q - 1) r[q] = (lane == 63) ? du_e * st : r[q];
+        }
         }
         if constexpr (Q == 8) store_rows_q8<false>(du + ro, lane, r, 1.0);
         else store_rows_q4<false>(du + ro, lane, r, 1.0);
@@ -514,23 +531,29 @@ struct XUpd {
     const real_t *ushift;
 };
 
-template <int Q, bool ACC, bool NARROW, bool UPD, bool CHN = false>  // CHN: the channel case's extras (XUpd)
+// CIRC (round 6; uniform grid, NARROW): every operator in the circulant form (circ_solve; cc[0..3] = der1st, der2nd, op_s,
+// op_i) -- no lane tables, no LDS
+struct Circ4 { CircOp o[4]; };
+template <int Q, bool ACC, bool NARROW, bool UPD, bool CHN = false, bool CIRC = false>  // CHN: the channel case's extras (XUpd)
 __global__ void __launch_bounds__(512)
     k_xscan_transeq2x3(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2, real_t *u0,
                        real_t *u1, real_t *u2, XOp tD1, XOp tD2, int np, long pitch, real_t nu, XUpd upd, XOp tS,
-                       XOp tI)
+                       XOp tI, Circ4 cc)
 {
     extern __shared__ real_t lt[];
     constexpr int LNF = LT_N(Q) * 64, LNC = LT_NC(Q) * 64, L1N = UPD ? LNC : LNF;
-    for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
-    for (int i = threadIdx.x; i < LNF; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
-    if (UPD) {
-        for (int i = threadIdx.x; i < LNC; i += blockDim.x) {
-            lt[L1N + LNF + i] = tS.TL[i];
-            lt[L1N + LNF + LNC + i] = tI.TL[i];
+    static_assert(!CIRC || NARROW, "CIRC: 5-tap stencils");
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < L1N; i += blockDim.x) lt[i] = tD1.TL[i];
+        for (int i = threadIdx.x; i < LNF; i += blockDim.x) lt[L1N + i] = tD2.TL[i];
+        if (UPD) {
+            for (int i = threadIdx.x; i < LNC; i += blockDim.x) {
+                lt[L1N + LNF + i] = tS.TL[i];
+                lt[L1N + LNF + LNC + i] = tI.TL[i];
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -571,6 +594,12 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
                     for (int q = 0; q < Q; q++) g2[q] = V2{ga[q], gb[q]};
                     window_from_body<Q, V2>(wg, g2, lane);
+                    if constexpr (CIRC) {
+                        if (c == 0) circ_solve<Q, NARROW, V2>(wg, X, cc.o[2], lane);
+                        else circ_solve<Q, NARROW, V2>(wg, X, cc.o[3], lane);
+#pragma unroll
+                        for (int q = 0; q < Q; q++) b2[q] = b2[q] + upd.scale * X[q];
+                    } else {
                     const real_t *__restrict__ lg = lt + L1N + LNF + (c == 0 ? 0 : LNC);
                     const XOp &tg = c == 0 ? tS : tI;
                     scan_solve<Q, true, NARROW, V2>(wg, X, du1, xn, lg, tg, lane, first);
@@ -582,6 +611,7 @@ __global__ void __launch_bounds__(512)
                         if (q == 0) r = (lane == 0) ? du_s * st : r;
                         if (q == Q - 1) r = (lane == 63) ? du_e * st : r;
                         b2[q] = b2[q] + upd.scale * r;
+                    }
                     }
                     real_t ua[Q], ub[Q];
 #pragma unroll
@@ -615,6 +645,11 @@ __global__ void __launch_bounds__(512)
                 for (int m = 0; m < Q + 8; m++) wp[m] = wu[m] * wp[m];
             }
             auto solve_subs = [&](const V2 (&w)[Q + 8], V2 (&T)[Q], const real_t *__restrict__ l, const XOp &t) {
+                if constexpr (CIRC) {
+                    if (l == l1) circ_solve<Q, NARROW, V2>(w, T, cc.o[0], lane);
+                    else circ_solve<Q, NARROW, V2>(w, T, cc.o[1], lane);
+                    return;
+                }
                 V2 a, b;
                 scan_solve<Q, true, NARROW, V2>(w, T, a, b, l, t, lane, first);
                 const V2 s_ = t.rs_s * (a - t.sa1 * b), e_ = t.rs_e * (b - t.scn * a);
@@ -634,7 +669,10 @@ __global__ void __launch_bounds__(512)
             asm volatile("" : "+v"(lane) : "v"(r[0].a));
             solve_subs(wu, T, l1, tD1);
 #pragma unroll
-            for (int q = 0; q < Q; q++) r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
+            for (int q = 0; q < Q; q++) {
+                if constexpr (CIRC) r[q] = -0.5 * (cb[q] * T[q] + r[q]);  // (uniform grid: + nu * (T * 0.0) adds nothing)
+                else r[q] = -0.5 * (cb[q] * T[q] + r[q]) + nu * (T[q] * LTR(l3, LT_STC(q)));
+            }
             asm volatile("" : "+v"(lane) : "v"(r[0].a));
             solve_subs(wu, T, l3, tD2);
             real_t ra[Q], rb[Q];
@@ -1559,6 +1597,13 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------- launchers
+// the circulant form (circ_solve) where every operator of the launch offers it.  X3D_NO_CIRC=1: never (A/B)
+static bool circ_env_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
+    return on == 1;
+}
 // bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
 static bool stencil_narrow(const x3d_tdsops *t)
 {
@@ -1574,19 +1619,22 @@ int x3d_xscan_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops 
     *done = false;
     if (!xscan_ok_gen(t)) return 0;
     const int Q = t->tab.Q, np = b->ny * b->nz;
-    const size_t lds = sizeof(real_t) * (LT_N(Q) * 64 + CS_N(Q));
-    int blocks = (np + 7) / 8;
-    blocks = blocks > 768 ? 768 : blocks;  // 43 KB of lane tables per 8-wave workgroup: 3 per CU
-    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
     // FAST: periodic-type stencils on a pencil the 64 lanes tile exactly, p2p or v2v (n_rhs == n_tds)
     const bool fast = t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds && Q != 6;
     const bool narrow = stencil_narrow(t);
+    const bool circ = fast && narrow && t->uniform && t->circ_ok && circ_env_on();
+    const size_t lds = circ ? 0 : sizeof(real_t) * (LT_N(Q) * 64 + CS_N(Q));
+    int blocks = (np + 7) / 8;
+    const int cap = circ ? 1024 : 768;  // 43 KB of lane tables per 8-wave workgroup: 3 per CU; circulant form: no LDS, 4
+    blocks = blocks > cap ? cap : blocks;
+    ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
 #define LAUNCH(Q_, A_, F_, SC_)                                                                                \
     hipLaunchKernelGGL((k_xscan_tds<Q_, A_, F_>), dim3(blocks), dim3(512), lds, b->stream, du, u, xop_of(t), np, \
-                       (long)b->nxp, t->n_tds, SC_)
+                       (long)b->nxp, t->n_tds, SC_, t->circ)
 #define PICK(Q_)                                                                                               \
     do {                                                                                                       \
-        if (fast && narrow) { if (acc) LAUNCH(Q_, true, 2, scale); else LAUNCH(Q_, false, 2, 1.0); }           \
+        if (circ) { if (acc) LAUNCH(Q_, true, 3, scale); else LAUNCH(Q_, false, 3, 1.0); }                     \
+        else if (fast && narrow) { if (acc) LAUNCH(Q_, true, 2, scale); else LAUNCH(Q_, false, 2, 1.0); }      \
         else if (fast) { if (acc) LAUNCH(Q_, true, 1, scale); else LAUNCH(Q_, false, 1, 1.0); }                \
         else { if (acc) LAUNCH(Q_, true, 0, scale); else LAUNCH(Q_, false, 0, 1.0); }                          \
     } while (0)
@@ -1798,13 +1846,6 @@ static void tile_range(const x3d_backend *b, int dir, int other0, int nother, in
     *ntiles = nother * ntx;
 }
 
-// the circulant form (circ_solve) where every operator of the launch offers it.  X3D_NO_CIRC=1: never (A/B)
-static bool circ_env_on()
-{
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("X3D_NO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
-    return on == 1;
-}
 
 // K3y pair launcher: see k_ytile_tds_pair; y and z (rows nxp or nxp * nyp apart, as for k_ytile_transeq).
 // mode 2: out1 = A(in1) only.  halo != null: decomposed direction (TileHalo: nf = 1 or 2 inputs, nb operators)
@@ -2053,9 +2094,9 @@ int x3d_ytile_transeq3_epi(x3d_backend *b, int dir, real_t *const r[3], const re
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int Q = der1st->tab.Q;
     const int npw = ytile_npw(b, Q, false);
-    // (FP64, 512 rows: the circulant form of THIS instantiation spills 14 VGPRs and runs at the table form's 3.1 ms -- kept
-    //  on the tables; 256 rows and FP32 have the registers)
-    const bool circ = ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym) && (X3D_RB == 4 || Q == 4);
+    // (FP64, 512 rows: the circulant form of THIS instantiation spills 14 VGPRs and runs at the table form's 3.1 ms; it is
+    //  taken all the same -- the launch must give the bits of the plain z launch followed by the stage)
+    const bool circ = ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym);
     const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_N(Q) * 64) + 16 * npw * (64 * Q + 4));
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd);
     const bool uni = der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
@@ -2119,21 +2160,27 @@ int x3d_xscan_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f
         };
         if (!ok(op_s) || !ok(op_i)) return 0;
     }
-    const size_t lds = sizeof(real_t) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
-    if (lds > 160 * 1024) return 0;
     const bool narrow = stencil_narrow(der1st) && stencil_narrow(der2nd) && (!upd || (stencil_narrow(op_s) && stencil_narrow(op_i)));
+    static int xcirc = -1;
+    if (xcirc < 0) { const char *e = getenv("X3D_NO_XCIRC"); xcirc = (e && e[0] == '1') ? 0 : 1; }
+    const bool circ = xcirc && circ_env_on() && narrow && der1st->circ_ok && der1st_sym->circ_ok && der2nd->circ_ok && der2nd_sym->circ_ok &&
+                      (!upd || (op_s->circ_ok && op_i->circ_ok));
+    const size_t lds = circ ? 0 : sizeof(real_t) * 64 * (upd ? 3 * LT_NC(Q) + LT_N(Q) : 2 * LT_N(Q));
+    if (lds > 160 * 1024) return 0;
     const int blocks = x3d_persistent_blocks(b, (np / 2 + 7) / 8);
     XUpd xu{};
     if (upd) { xu.g[0] = upd_g[0]; xu.g[1] = upd_g[1]; xu.g[2] = upd_g[2]; xu.scale = scale; }
     xu.omega = omega; xu.ushift = ushift;
     const x3d_tdsops *ts = upd ? op_s : der1st, *ti = upd ? op_i : der1st;
-#define GO(Q_, A_, N_, U_, C_)                                                                                  \
+    const Circ4 c4{{der1st->circ, der2nd->circ, ts->circ, ti->circ}};
+#define GOX(Q_, A_, N_, U_, C_, X_)                                                                             \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_, C_>));                                             \
-        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_, C_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
+        X3D_LDS_OPTIN(b, (k_xscan_transeq2x3<Q_, A_, N_, U_, C_, X_>));                                         \
+        hipLaunchKernelGGL((k_xscan_transeq2x3<Q_, A_, N_, U_, C_, X_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], \
                            r[2], (real_t *)f[0], (real_t *)f[1], (real_t *)f[2], xop_of(der1st), xop_of(der2nd), np,  \
-                           (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti));                                       \
+                           (long)b->nxp, nu, xu, xop_of(ts), xop_of(ti), c4);                                   \
     } while (0)
+#define GO(Q_, A_, N_, U_, C_) do { if ((N_) && circ) GOX(Q_, A_, true, U_, C_, true); else GOX(Q_, A_, N_, U_, C_, false); } while (0)
 #define GOU(Q_, A_, N_) do { if (upd) GO(Q_, A_, N_, true, false); else GO(Q_, A_, N_, false, false); } while (0)
 #define GON(Q_, A_) do { if (narrow) GOU(Q_, A_, true); else GOU(Q_, A_, false); } while (0)
 #define GOA(Q_)                                                                                                 \
@@ -2150,6 +2197,7 @@ int x3d_xscan_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f
 #undef GON
 #undef GOU
 #undef GO
+#undef GOX
     X3D_HIP(hipGetLastError());
     b->n_tq3++;
     if (upd) b->n_upd++;
@@ -2175,17 +2223,19 @@ int x3d_xscan_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_
     const int Q = t->tab.Q;
     if (!(t->tab.bulk_only && t->n_tds == 64 * Q && t->tab.n_rhs == t->n_tds && b->nx == 64 * Q)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(real_t) * LT_N(Q) * 64;
+    const bool narrow = stencil_narrow(t);
+    const bool circ = narrow && t->uniform && t->circ_ok && circ_env_on();  // (the same choice as x3d_xscan_tds: same bits)
+    const size_t lds = circ ? 0 : sizeof(real_t) * LT_N(Q) * 64;
     int blocks = (np + 7) / 8;
-    blocks = blocks > 768 ? 768 : blocks;
+    const int cap = circ ? 1024 : 768;
+    blocks = blocks > cap ? cap : blocks;
     LinRows lr;
     lr.y = y; lr.base = base; lr.n = nterm; lr.wall = wall; lr.ny = b->ny;
     for (int k = 0; k < 5; k++) { lr.x[k] = k < nterm ? x[k] : x[0]; lr.c[k] = k < nterm ? c[k] : 0.0; }
-    const bool narrow = stencil_narrow(t);
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
-#define GO(Q_, N_) hipLaunchKernelGGL((k_xscan_tds_lin<Q_, N_>), dim3(blocks), dim3(512), lds, b->stream, du, lr, xop_of(t), np, (long)b->nxp)
-    if (Q == 8) { if (narrow) GO(8, true); else GO(8, false); }
-    else { if (narrow) GO(4, true); else GO(4, false); }
+#define GO(Q_, N_, C_) hipLaunchKernelGGL((k_xscan_tds_lin<Q_, N_, C_>), dim3(blocks), dim3(512), lds, b->stream, du, lr, xop_of(t), np, (long)b->nxp, t->circ)
+    if (Q == 8) { if (circ) GO(8, true, true); else if (narrow) GO(8, true, false); else GO(8, false, false); }
+    else { if (circ) GO(4, true, true); else if (narrow) GO(4, true, false); else GO(4, false, false); }
 #undef GO
     X3D_HIP(hipGetLastError());
     *done = true;

@@ -151,6 +151,15 @@ __device__ __forceinline__ V2 operator*(real_t c, V2 x) { return V2{c * x.a, c *
 __device__ __forceinline__ V2 operator*(V2 x, real_t c) { return V2{x.a * c, x.b * c}; }
 __device__ __forceinline__ V2 &operator+=(V2 &x, V2 y) { x.a += y.a; x.b += y.b; return x; }
 #endif
+// c * x + y with ONE rounding, spelled out: with -ffp-contract=fast the compiler otherwise picks the fused products per
+// kernel body, and two instantiations of the same solve may differ in the last bit (circ_solve: the UPD form of transeq_x
+// against k_xscan_tds<ACC> + the plain form must agree bit for bit)
+__device__ __forceinline__ real_t fma_of(real_t c, real_t x, real_t y) { return fma_r(c, x, y); }
+#ifdef X3D_V2_PACKED
+__device__ __forceinline__ V2 fma_of(real_t c, V2 x, V2 y) { const x3d_f2 cc = {c, c}; return v2_of(__builtin_elementwise_fma(cc, x.v, y.v)); }
+#else
+__device__ __forceinline__ V2 fma_of(real_t c, V2 x, V2 y) { return V2{fma_r(c, x.a, y.a), fma_r(c, x.b, y.b)}; }
+#endif
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
 __device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
@@ -341,88 +350,63 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     if (NARROW) {
 #pragma unroll
         for (int q = 0; q < Q; q++)
-            acc[q] = c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] + c6 * w[q + 6];
+            acc[q] = fma_of(c6, w[q + 6], fma_of(c5, w[q + 5], fma_of(c4, w[q + 4], fma_of(c3, w[q + 3], c2 * w[q + 2]))));
     } else {
 #pragma unroll
-        for (int q = 0; q < Q; q++)
-            acc[q] = c0 * w[q] + c1 * w[q + 1] + c2 * w[q + 2] + c3 * w[q + 3] + c4 * w[q + 4] + c5 * w[q + 5] +
-                     c6 * w[q + 6] + c7 * w[q + 7] + c8 * w[q + 8];
+        for (int q = 0; q < Q; q++) {
+            T a = fma_of(c3, w[q + 3], fma_of(c2, w[q + 2], fma_of(c1, w[q + 1], c0 * w[q])));
+            a = fma_of(c6, w[q + 6], fma_of(c5, w[q + 5], fma_of(c4, w[q + 4], a)));
+            acc[q] = fma_of(c8, w[q + 8], fma_of(c7, w[q + 7], a));
+        }
     }
     const bool row_first = (lane & 15) == 0, row_last = (lane & 15) == 15;
     CIRC_SB();
     T prev = zero_of<T>();
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        X[q] = acc[q] + nr * prev;
+        X[q] = fma_of(nr, prev, acc[q]);
         prev = X[q];
     }
     T v = prev;
     CIRC_SB();
-    v += m1 * dpp0<0x111>(v);  // row_shr:1, 2, 4 (, 8): lanes without a source read 0
-    v += m2 * dpp0<0x112>(v);
-    v += m4 * dpp0<0x114>(v);
-    if (S8) v += m8 * dpp0<0x118>(v);
+    v = fma_of(m1, dpp0<0x111>(v), v);  // row_shr:1, 2, 4 (, 8): lanes without a source read 0
+    v = fma_of(m2, dpp0<0x112>(v), v);
+    v = fma_of(m4, dpp0<0x114>(v), v);
+    if (S8) v = fma_of(m8, dpp0<0x118>(v), v);
     {
         T z = sel_of(row_first, dpp0<0x13C>(v), zero_of<T>());  // wave_ror:1: the previous row's total, lane 0 <- lane 63
-        z += m1 * dpp0<0x111>(z);
-        z += m2 * dpp0<0x112>(z);
-        z += m4 * dpp0<0x114>(z);
-        if (S8) z += m8 * dpp0<0x118>(z);
-        v += m1 * z;
+        z = fma_of(m1, dpp0<0x111>(z), z);
+        z = fma_of(m2, dpp0<0x112>(z), z);
+        z = fma_of(m4, dpp0<0x114>(z), z);
+        if (S8) z = fma_of(m8, dpp0<0x118>(z), z);
+        v = fma_of(m1, z, v);
     }
     T carry = dpp0<0x13C>(v);
     T nxt = zero_of<T>();
     CIRC_SB();
-#ifdef CIRC_PF_CHAIN
-    {
-        T tq[Q];
-        tq[0] = nr * carry;
-        if (Q > 4) tq[4] = t.pf[4] * carry;
-#pragma unroll
-        for (int q = 1; q < Q; q++) if (q != 4) tq[q] = nr * tq[q - 1];
-#pragma unroll
-        for (int q = Q - 1; q >= 0; q--) {
-            X[q] = (X[q] + tq[q]) + nr * nxt;
-            nxt = X[q];
-        }
-    }
-#else
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
-        X[q] = (X[q] + t.pf[q] * carry) + nr * nxt;
+        X[q] = fma_of(nr, nxt, fma_of(t.pf[q], carry, X[q]));
         nxt = X[q];
     }
-#endif
     v = nxt;
     CIRC_SB();
-    v += m1 * dpp0<0x101>(v);  // row_shl:1, 2, 4 (, 8)
-    v += m2 * dpp0<0x102>(v);
-    v += m4 * dpp0<0x104>(v);
-    if (S8) v += m8 * dpp0<0x108>(v);
+    v = fma_of(m1, dpp0<0x101>(v), v);  // row_shl:1, 2, 4 (, 8)
+    v = fma_of(m2, dpp0<0x102>(v), v);
+    v = fma_of(m4, dpp0<0x104>(v), v);
+    if (S8) v = fma_of(m8, dpp0<0x108>(v), v);
     {
         T z = sel_of(row_last, dpp0<0x134>(v), zero_of<T>());  // wave_rol:1: the next row's total, lane 63 <- lane 0
-        z += m1 * dpp0<0x101>(z);
-        z += m2 * dpp0<0x102>(z);
-        z += m4 * dpp0<0x104>(z);
-        if (S8) z += m8 * dpp0<0x108>(z);
-        v += m1 * z;
+        z = fma_of(m1, dpp0<0x101>(z), z);
+        z = fma_of(m2, dpp0<0x102>(z), z);
+        z = fma_of(m4, dpp0<0x104>(z), z);
+        if (S8) z = fma_of(m8, dpp0<0x108>(z), z);
+        v = fma_of(m1, z, v);
     }
     carry = dpp0<0x134>(v);
     CIRC_SB();
-#ifdef CIRC_PF_CHAIN
-    {
-        T tq = nr * carry;
-        X[Q - 1] = X[Q - 1] + tq;
 #pragma unroll
-        for (int q = Q - 2; q >= 0; q--) {
-            tq = (Q > 4 && q == Q - 5) ? t.pf[4] * carry : nr * tq;
-            X[q] = X[q] + tq;
-        }
-    }
-#else
-#pragma unroll
-    for (int q = 0; q < Q; q++) X[q] = X[q] + t.pf[Q - 1 - q] * carry;
-#endif
+    for (int q = 0; q < Q; q++) X[q] = fma_of(t.pf[Q - 1 - q], carry, X[q]);
 }
 
 // Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE
