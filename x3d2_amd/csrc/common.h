@@ -337,6 +337,7 @@ struct CircOp {
     real_t pf[8];  // (-rho)^(q + 1): what the value carried into a lane adds to its row q (Q rows per lane, Q <= 8)
     real_t mu[4];  // mu, mu^2, mu^4, mu^8 with mu = (-rho)^Q: the lane-to-lane multiplier of the scans
 };
+struct Circ4 { CircOp o[4]; };  // der1st, der2nd, op_s, op_i of a transeq_x launch
 struct x3d_tdsops {
     x3d_backend *b;
     int n_tds, n_rhs, move, periodic;

@@ -363,7 +363,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         for (int j = 1; j <= n; j++)
             if (St[j] != 1.0 || Stc[j] != 0.0) unif = false;
         const real_t alpha = n >= 8 ? dist_af[4] : 0.0;
-        if (periodic && bulk && unif && nr == n && Q >= 4 && Q <= 8 && n == 64 * Q && alpha != 0.0 && fabs(alpha) < 0.5) {
+        if (periodic && bulk && unif && nr == n && (Q == 4 || Q == 8 || Q == 16) && n == 64 * Q && alpha != 0.0 && fabs(alpha) < 0.5) {
             const double a = (double)alpha, rho = (1.0 - sqrt(1.0 - 4.0 * a * a)) / (2.0 * a);
             CircOp &co = t->circ;
             for (int m = 0; m < 9; m++) co.c[m] = (real_t)(coeffs[m] * (rho / a));

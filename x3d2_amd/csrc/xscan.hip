@@ -533,7 +533,6 @@ struct XUpd {
 
 // CIRC (round 6; uniform grid, NARROW): every operator in the circulant form (circ_solve; cc[0..3] = der1st, der2nd, op_s,
 // op_i) -- no lane tables, no LDS
-struct Circ4 { CircOp o[4]; };
 template <int Q, bool ACC, bool NARROW, bool UPD, bool CHN = false, bool CIRC = false>  // CHN: the channel case's extras (XUpd)
 __global__ void __launch_bounds__(512)
     k_xscan_transeq2x3(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2, real_t *u0,

@@ -384,9 +384,12 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     T carry = dpp0<0x13C>(v);
     T nxt = zero_of<T>();
     CIRC_SB();
+    // (16 rows per lane, the 1024-row x pencils: (-rho)^(q + 1) = (-rho)^(q - 7) (-rho)^8 for the upper eight rows)
+    T carry8 = zero_of<T>();
+    if constexpr (Q > 8) carry8 = t.pf[7] * carry;
 #pragma unroll
     for (int q = Q - 1; q >= 0; q--) {
-        X[q] = fma_of(nr, nxt, fma_of(t.pf[q], carry, X[q]));
+        X[q] = fma_of(nr, nxt, q < 8 ? fma_of(t.pf[q], carry, X[q]) : fma_of(t.pf[q - 8], carry8, X[q]));
         nxt = X[q];
     }
     v = nxt;
@@ -405,8 +408,12 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     }
     carry = dpp0<0x134>(v);
     CIRC_SB();
+    if constexpr (Q > 8) carry8 = t.pf[7] * carry;
 #pragma unroll
-    for (int q = 0; q < Q; q++) X[q] = fma_of(t.pf[Q - 1 - q], carry, X[q]);
+    for (int q = 0; q < Q; q++) {
+        const int k = Q - 1 - q;
+        X[q] = k < 8 ? fma_of(t.pf[k], carry, X[q]) : fma_of(t.pf[k - 8], carry8, X[q]);
+    }
 }
 
 // Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE

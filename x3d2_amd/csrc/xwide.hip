@@ -128,17 +128,22 @@ __device__ __forceinline__ void wide_solve_u(const real_t (&w)[WQ + 8], real_t (
 // ---------------------------------------------------------------- tds_solve
 // psum != null (ACC = false only): the sum of u over the pencils of the y rows j < ny_sum rides along, one partial per wave
 // (see k_xwide_tds_lin below: the channel case's bulk-velocity integral)
-template <bool ACC, bool NARROW>
+// CIRC (round 6): the operator in the circulant form (xscan_core.h circ_solve with 16 rows per lane; co) -- no lane tables,
+// the workgroup's LDS is its eight strips
+template <bool ACC, bool NARROW, bool CIRC = false>
 __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, const real_t *__restrict__ u, XOp t, int np,
-                                                   long pitch, real_t scale, real_t *__restrict__ psum, int ny_sum, int ny)
+                                                   long pitch, real_t scale, real_t *__restrict__ psum, int ny_sum, int ny,
+                                                   CircOp co)
 {
     extern __shared__ real_t lt[];  // [LTC_N(16)] tables, then one strip per wave
-    for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
-    __syncthreads();
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
+        __syncthreads();
+    }
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    real_t *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    real_t *strip = lt + (CIRC ? 0 : LTC_N(WQ)) + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
     real_t nxt[16];  // next pencil's pieces, in flight while this one is solved
@@ -161,7 +166,8 @@ __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, cons
             window_from_body<WQ>(w, b, lane);
         }
         if (p + nwaves < np) wide_gload(nxt, u + (long)(p + nwaves) * pitch, lane);
-        wide_solve<NARROW>(w, r, lt, t, lane, ll);
+        if constexpr (CIRC) circ_solve<WQ, NARROW>(w, r, co, lane);
+        else wide_solve<NARROW>(w, r, lt, t, lane, ll);
         wave_lds_fence();  // (every lane has read its rows: the strip may be rewritten)
         wide_put_rows(strip, r, lane);
         wave_lds_fence();
@@ -182,17 +188,19 @@ __global__ void __launch_bounds__(512) k_xwide_tds(real_t *__restrict__ du, cons
 // the channel case's next define_BC asks for (src/case/channel.f90:66-72), taken while the rows are in registers
 // instead of by a reduction pass of its own: one partial per wave in a fixed order (pencils in the wave's loop order,
 // the 16 pieces of a lane, then the lanes by butterfly), psum[global wave index]; x3d_xwide_tds_lincomb finishes them.
-template <bool NARROW>
+template <bool NARROW, bool CIRC = false>
 __global__ void __launch_bounds__(512) k_xwide_tds_lin(real_t *__restrict__ du, LinRows lr, XOp t, int np, long pitch,
-                                                       real_t *__restrict__ psum, int ny_sum)
+                                                       real_t *__restrict__ psum, int ny_sum, CircOp co)
 {
     extern __shared__ real_t lt[];
-    for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
-    __syncthreads();
+    if constexpr (!CIRC) {
+        for (int i = threadIdx.x; i < LTC_N(WQ); i += blockDim.x) lt[i] = t.TL[i];
+        __syncthreads();
+    }
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    real_t *strip = lt + LTC_N(WQ) + wave * WSTRIP;
+    real_t *strip = lt + (CIRC ? 0 : LTC_N(WQ)) + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     real_t wsum = 0.0;
     for (int p = blockIdx.x * (blockDim.x >> 6) + wave; p < np; p += nwaves) {
@@ -231,7 +239,8 @@ __global__ void __launch_bounds__(512) k_xwide_tds_lin(real_t *__restrict__ du, 
             wide_own_rows(b, strip, lane);
             window_from_body<WQ>(w, b, lane);
         }
-        wide_solve<NARROW>(w, r, lt, t, lane, ll);
+        if constexpr (CIRC) circ_solve<WQ, NARROW>(w, r, co, lane);
+        else wide_solve<NARROW>(w, r, lt, t, lane, ll);
         wave_lds_fence();
         wide_put_rows(strip, r, lane);
         wave_lds_fence();
@@ -254,15 +263,17 @@ __global__ void __launch_bounds__(512) k_xwide_tds_lin(real_t *__restrict__ du, 
 // rows are in registers when dv is formed -- no extra traffic.
 // UNI: all operators on a uniform grid -- compact tables, wide_solve_u, no stretch-correction term (x * 1 and + nu T 0
 // dropped: the same values; the compiler's choice of which products it contracts may move a last bit against the general form)
-template <bool ACC, bool NARROW, bool ROT = false, bool UNI = false>
+template <bool ACC, bool NARROW, bool ROT = false, bool UNI = false, bool CIRC = false>
 __global__ void __launch_bounds__(512)
     k_xwide_transeq3(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2,
                      const real_t *u0, const real_t *__restrict__ u1, const real_t *__restrict__ u2, XOp tD1,
-                     XOp tD2, int np, long pitch, real_t nu, real_t omega, const real_t *__restrict__ ushift)
+                     XOp tD2, int np, long pitch, real_t nu, real_t omega, const real_t *__restrict__ ushift, Circ4 cc)
 {
     extern __shared__ real_t lt[];
-    constexpr int LN = UNI ? LTU_N : LTC_N(WQ), Q = WQ, LS = LTC_LS;
-    if constexpr (UNI) {
+    constexpr int LN = CIRC ? 0 : (UNI ? LTU_N : LTC_N(WQ)), Q = WQ, LS = LTC_LS;
+    static_assert(!CIRC || UNI, "CIRC: uniform grids");
+    if constexpr (CIRC) {
+    } else if constexpr (UNI) {
         for (int i = threadIdx.x; i < LTU_ROWS; i += blockDim.x) {
             lt[i] = tD1.TL[i];
             lt[LN + i] = tD2.TL[i];
@@ -278,7 +289,7 @@ __global__ void __launch_bounds__(512)
         }
     }
     __syncthreads();
-    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LN;
+    const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + (CIRC ? 1 : LN);  // (CIRC: only told apart, never read)
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -327,7 +338,8 @@ __global__ void __launch_bounds__(512)
             }
             real_t r[WQ], T[WQ];
             auto solve = [&](const real_t (&w)[WQ + 8], const real_t *__restrict__ l, const XOp &t) {
-                if constexpr (UNI) wide_solve_u<NARROW>(w, T, l, t, lane, ll);
+                if constexpr (CIRC) { if (l == l1) circ_solve<WQ, NARROW>(w, T, cc.o[0], lane); else circ_solve<WQ, NARROW>(w, T, cc.o[1], lane); }
+                else if constexpr (UNI) wide_solve_u<NARROW>(w, T, l, t, lane, ll);
                 else wide_solve<NARROW>(w, T, l, t, lane, ll);
             };
             solve(wp, l1, tD1);  // d(u conv)/dx first: wp is dead afterwards
@@ -380,26 +392,27 @@ struct WideUpd {
     const real_t *ushift;
 };
 
-template <bool NARROW, bool ROT>
+template <bool NARROW, bool ROT, bool CIRC = false>
 __global__ void __launch_bounds__(512)
     k_xwide_transeq3_upd(real_t *__restrict__ rhs0, real_t *__restrict__ rhs1, real_t *__restrict__ rhs2, real_t *u0,
-                         real_t *u1, real_t *u2, XOp tD1, XOp tD2, XOp tS, XOp tI, WideUpd upd, int np, long pitch, real_t nu)
+                         real_t *u1, real_t *u2, XOp tD1, XOp tD2, XOp tS, XOp tI, WideUpd upd, int np, long pitch, real_t nu,
+                         Circ4 cc)
 {
     extern __shared__ real_t lt[];
-    {
+    if constexpr (!CIRC) {
         const real_t *src[4] = {tD1.TL, tD2.TL, tS.TL, tI.TL};
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             for (int i = threadIdx.x; i < LTU_ROWS; i += blockDim.x) lt[o * LTU_N + i] = src[o][i];
             for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lt[o * LTU_N + LTU_ROWS + i] = src[o][LTC_M0(WQ) + i];
         }
+        __syncthreads();
     }
-    __syncthreads();
     const real_t *__restrict__ l1 = lt, *__restrict__ l3 = lt + LTU_N;
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    real_t *strip = lt + 4 * LTU_N + wave * WSTRIP;
+    real_t *strip = lt + (CIRC ? 0 : 4 * LTU_N) + wave * WSTRIP;
     const int ll = ltc_lane(lane);
     const int p0 = blockIdx.x * (blockDim.x >> 6) + wave;
     real_t unx[16], gnx[16];  // the rows needed next: u_c's and g_c's pieces
@@ -439,7 +452,8 @@ __global__ void __launch_bounds__(512)
                     if (c < 2 || pn < np) wide_gload(gnx, nsrc, lane);
                 }
                 const real_t *__restrict__ lg = lt + (c == 0 ? 2 : 3) * LTU_N;
-                wide_solve_u<NARROW>(wg, gr, lg, c == 0 ? tS : tI, lane, ll);
+                if constexpr (CIRC) { if (c == 0) circ_solve<WQ, NARROW>(wg, gr, cc.o[2], lane); else circ_solve<WQ, NARROW>(wg, gr, cc.o[3], lane); }
+                else wide_solve_u<NARROW>(wg, gr, lg, c == 0 ? tS : tI, lane, ll);
 #pragma unroll
                 for (int q = 0; q < WQ; q++) b[q] = fma_r(upd.scale, gr[q], b[q]);
             }
@@ -462,15 +476,18 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
             for (int m = 0; m < WQ + 8; m++) wp[m] = wu[m] * wp[m];
             real_t r[WQ], T[WQ];
-            wide_solve_u<NARROW>(wp, T, l1, tD1, lane, ll);  // d(u conv)/dx
+            if constexpr (CIRC) circ_solve<WQ, NARROW>(wp, T, cc.o[0], lane);
+            else wide_solve_u<NARROW>(wp, T, l1, tD1, lane, ll);  // d(u conv)/dx
 #pragma unroll
             for (int q = 0; q < WQ; q++) r[q] = T[q];
             asm volatile("" : "+v"(lane) : "v"(r[0]));
-            wide_solve_u<NARROW>(wu, T, l1, tD1, lane, ll);  // du/dx
+            if constexpr (CIRC) circ_solve<WQ, NARROW>(wu, T, cc.o[0], lane);
+            else wide_solve_u<NARROW>(wu, T, l1, tD1, lane, ll);  // du/dx
 #pragma unroll
             for (int q = 0; q < WQ; q++) r[q] = -0.5 * fma_r(cb[q], T[q], r[q]);
             asm volatile("" : "+v"(lane) : "v"(r[0]));
-            wide_solve_u<NARROW>(wu, T, l3, tD2, lane, ll);  // d2u/dx2
+            if constexpr (CIRC) circ_solve<WQ, NARROW>(wu, T, cc.o[1], lane);
+            else wide_solve_u<NARROW>(wu, T, l3, tD2, lane, ll);  // d2u/dx2
 #pragma unroll
             for (int q = 0; q < WQ; q++) r[q] = fma_r(nu, T[q], r[q]);  // (as k_xwide_transeq3<UNI>: the same bits)
             if (ROT && c == 0) {
@@ -518,6 +535,16 @@ static bool wide_narrow(const x3d_tdsops *t)
 {
     return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
 }
+// the circulant form of the 1024-row kernels (circ_solve with 16 rows per lane).  X3D_NO_CIRC=1 / X3D_NO_XCIRC=1: not (A/B)
+static bool wide_circ(const x3d_tdsops *t)
+{
+    static int on = -1;
+    if (on < 0) {
+        on = 1;
+        for (const char *nm : {"X3D_NO_CIRC", "X3D_NO_XCIRC"}) { const char *e = getenv(nm); if (e && e[0] == '1') on = 0; }
+    }
+    return on && t->circ_ok && t->uniform && t->tab.Q == 16;
+}
 static XOp wide_xop(const x3d_tdsops *t)
 {
     XOp o = xop_of(t);
@@ -535,19 +562,23 @@ int x3d_xwide_tds(x3d_backend *b, real_t *du, const real_t *u, const x3d_tdsops 
     if (acc) psum = nullptr;
     if (!wide_env_on() || !wide_ok(b, t)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(real_t) * (LTC_N(WQ) + 8 * WSTRIP);
-    int blocks = (np + 7) / 8;
-    blocks = blocks > 256 ? 256 : blocks;  // 98 KB of LDS: one 8-wave workgroup per CU
     const bool narrow = wide_narrow(t);
+    const bool circ = narrow && wide_circ(t);
+    const size_t lds = sizeof(real_t) * ((circ ? 0 : LTC_N(WQ)) + 8 * WSTRIP);
+    int blocks = (np + 7) / 8;
+    // 98 KB of LDS: one 8-wave workgroup per CU; circulant form: 74 KB of strips, two (not with the partial sums: their
+    // finishing kernel takes up to 2048)
+    const int cap = (circ && !psum) ? 512 : 256;
+    blocks = blocks > cap ? cap : blocks;
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
-#define GO(A_, N_)                                                                                              \
+#define GO(A_, N_, C_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xwide_tds<A_, N_>));                                                                \
-        hipLaunchKernelGGL((k_xwide_tds<A_, N_>), dim3(blocks), dim3(512), lds, b->stream, du, u, wide_xop(t), np, \
-                           (long)b->nxp, A_ ? scale : 1.0, psum, ny_sum, b->ny);                                \
+        X3D_LDS_OPTIN(b, (k_xwide_tds<A_, N_, C_>));                                                            \
+        hipLaunchKernelGGL((k_xwide_tds<A_, N_, C_>), dim3(blocks), dim3(512), lds, b->stream, du, u, wide_xop(t), np, \
+                           (long)b->nxp, A_ ? scale : 1.0, psum, ny_sum, b->ny, t->circ);                       \
     } while (0)
-    if (acc) { if (narrow) GO(true, true); else GO(true, false); }
-    else { if (narrow) GO(false, true); else GO(false, false); }
+    if (acc) { if (circ) GO(true, true, true); else if (narrow) GO(true, true, false); else GO(true, false, false); }
+    else { if (circ) GO(false, true, true); else if (narrow) GO(false, true, false); else GO(false, false, false); }
 #undef GO
     X3D_HIP(hipGetLastError());
     if (nsum && psum) *nsum = blocks * 8;
@@ -566,21 +597,27 @@ int x3d_xwide_tds_lincomb(x3d_backend *b, real_t *du, const x3d_tdsops *t, real_
     if (on < 0) { const char *e = getenv("X3D_NO_TDS_LINCOMB"); on = (e && e[0] == '1') ? 0 : 1; }
     if (!on || !wide_env_on() || !wide_ok(b, t)) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(real_t) * (LTC_N(WQ) + 8 * WSTRIP);
+    const bool circ = wide_narrow(t) && wide_circ(t);  // (the same choice as x3d_xwide_tds: the same bits)
+    const size_t lds = sizeof(real_t) * ((circ ? 0 : LTC_N(WQ)) + 8 * WSTRIP);
     int blocks = (np + 7) / 8;
-    blocks = blocks > 256 ? 256 : blocks;
+    const int cap = (circ && !psum) ? 512 : 256;
+    blocks = blocks > cap ? cap : blocks;
     LinRows lr;
     lr.y = y; lr.base = base; lr.n = nterm; lr.wall = wall; lr.ny = b->ny;
     for (int k = 0; k < 5; k++) { lr.x[k] = k < nterm ? x[k] : x[0]; lr.c[k] = k < nterm ? c[k] : 0.0; }
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_X);
-    if (wide_narrow(t)) {
+    if (circ) {
+        X3D_LDS_OPTIN(b, (k_xwide_tds_lin<true, true>));
+        hipLaunchKernelGGL((k_xwide_tds_lin<true, true>), dim3(blocks), dim3(512), lds, b->stream, du, lr, wide_xop(t), np,
+                           (long)b->nxp, psum, ny_sum, t->circ);
+    } else if (wide_narrow(t)) {
         X3D_LDS_OPTIN(b, (k_xwide_tds_lin<true>));
         hipLaunchKernelGGL((k_xwide_tds_lin<true>), dim3(blocks), dim3(512), lds, b->stream, du, lr, wide_xop(t), np,
-                           (long)b->nxp, psum, ny_sum);
+                           (long)b->nxp, psum, ny_sum, t->circ);
     } else {
         X3D_LDS_OPTIN(b, (k_xwide_tds_lin<false>));
         hipLaunchKernelGGL((k_xwide_tds_lin<false>), dim3(blocks), dim3(512), lds, b->stream, du, lr, wide_xop(t), np,
-                           (long)b->nxp, psum, ny_sum);
+                           (long)b->nxp, psum, ny_sum, t->circ);
     }
     X3D_HIP(hipGetLastError());
     if (nsum) *nsum = blocks * 8;
@@ -602,23 +639,27 @@ int x3d_xwide_transeq3(x3d_backend *b, real_t *const r[3], const real_t *const f
     static int uni_on = -1;  // X3D_NO_UNIFORM=1: the general tables on uniform grids too (A/B, as for the tile kernels)
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
     const bool uni = uni_on && der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
-    const size_t lds = sizeof(real_t) * (2 * (uni ? LTU_N : LTC_N(WQ)) + 8 * WSTRIP);
-    const int blocks = x3d_persistent_blocks(b, (np + 7) / 8);
     const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd);
+    const bool circ = uni && narrow && wide_circ(der1st) && wide_circ(der1st_sym) && wide_circ(der2nd) && wide_circ(der2nd_sym);
+    const size_t lds = sizeof(real_t) * ((circ ? 0 : 2 * (uni ? LTU_N : LTC_N(WQ))) + 8 * WSTRIP);
+    const int blocks = x3d_persistent_blocks(b, (np + 7) / 8);
+    const Circ4 c4{{der1st->circ, der2nd->circ, der1st->circ, der1st->circ}};
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
-#define GO(A_, N_, R_, U_)                                                                                      \
+#define GOC(A_, N_, R_, U_, C_)                                                                                 \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_, R_, U_>));                                                   \
-        hipLaunchKernelGGL((k_xwide_transeq3<A_, N_, R_, U_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
-                           f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu, omega, ushift); \
+        X3D_LDS_OPTIN(b, (k_xwide_transeq3<A_, N_, R_, U_, C_>));                                               \
+        hipLaunchKernelGGL((k_xwide_transeq3<A_, N_, R_, U_, C_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
+                           f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), np, (long)b->nxp, nu, omega, ushift, c4); \
     } while (0)
-#define GOU(A_, N_, R_) do { if (uni) GO(A_, N_, R_, true); else GO(A_, N_, R_, false); } while (0)
+#define GO(A_, N_, R_, U_) GOC(A_, N_, R_, U_, false)
+#define GOU(A_, N_, R_) do { if (circ && (N_)) GOC(A_, true, R_, true, true); else if (uni) GO(A_, N_, R_, true); else GO(A_, N_, R_, false); } while (0)
         if (omega != 0.0) { if (narrow) GOU(false, true, true); else GOU(false, false, true); }
         else if (acc) { if (narrow) GOU(true, true, false); else GOU(true, false, false); }
         else { if (narrow) GOU(false, true, false); else GOU(false, false, false); }
 #undef GOU
 #undef GO
+#undef GOC
     }
     X3D_HIP(hipGetLastError());
     b->n_tq3++;
@@ -645,22 +686,25 @@ int x3d_xwide_transeq3_upd(x3d_backend *b, real_t *const r[3], real_t *const f[3
         if (!wide_ok(b, t) || !t->uniform) return 0;
     if (der1st->tl_hash != der1st_sym->tl_hash || der2nd->tl_hash != der2nd_sym->tl_hash) return 0;
     const int np = b->ny * b->nz;
-    const size_t lds = sizeof(real_t) * (4 * LTU_N + 8 * WSTRIP);
+    const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd) && wide_narrow(op_s) && wide_narrow(op_i);
+    bool circ = narrow;
+    for (const x3d_tdsops *t : ops) circ = circ && wide_circ(t);
+    const size_t lds = sizeof(real_t) * ((circ ? 0 : 4 * LTU_N) + 8 * WSTRIP);
     if (lds > 160 * 1024) return 0;
     const int blocks = x3d_persistent_blocks(b, (np + 7) / 8);
-    const bool narrow = wide_narrow(der1st) && wide_narrow(der2nd) && wide_narrow(op_s) && wide_narrow(op_i);
     WideUpd wu{{g[0], g[1], g[2]}, scale, omega, ushift};
+    const Circ4 c4{{der1st->circ, der2nd->circ, op_s->circ, op_i->circ}};
     {
         ProfScope ps(b, X3D_K_TRANSEQ_FWD, X3D_DIR_X);
-#define GO(N_, R_)                                                                                              \
+#define GO(N_, R_, C_)                                                                                          \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_xwide_transeq3_upd<N_, R_>));                                                       \
-        hipLaunchKernelGGL((k_xwide_transeq3_upd<N_, R_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
+        X3D_LDS_OPTIN(b, (k_xwide_transeq3_upd<N_, R_, C_>));                                                   \
+        hipLaunchKernelGGL((k_xwide_transeq3_upd<N_, R_, C_>), dim3(blocks), dim3(512), lds, b->stream, r[0], r[1], r[2], \
                            f[0], f[1], f[2], wide_xop(der1st), wide_xop(der2nd), wide_xop(op_s), wide_xop(op_i), wu, np, \
-                           (long)b->nxp, nu);                                                                   \
+                           (long)b->nxp, nu, c4);                                                               \
     } while (0)
-        if (omega != 0.0) { if (narrow) GO(true, true); else GO(false, true); }
-        else { if (narrow) GO(true, false); else GO(false, false); }
+        if (omega != 0.0) { if (circ) GO(true, true, true); else if (narrow) GO(true, true, false); else GO(false, true, false); }
+        else { if (circ) GO(true, false, true); else if (narrow) GO(true, false, false); else GO(false, false, false); }
 #undef GO
     }
     X3D_HIP(hipGetLastError());
