@@ -9,7 +9,7 @@ R = "r06"
 pairs = {f"bench_{R}.json": f"{R}_bench_512_fused.json", f"bench_{R}_lazy.json": f"{R}_bench_512_op_sequence_deferred.json",
          f"bench_{R}_channel.json": f"{R}_bench_channel_1024x257x512.json",
          f"bench_{R}_share2_dryrun.json": f"{R}_bench_2_ranks_shared_gpu_dryrun.json",
-         f"{R}_channel_ab.txt": f"{R}_channel_same_box_ab.txt"}
+         f"{R}_channel_ab.txt": f"{R}_channel_same_box_ab.txt", f"{R}_tgv_ab.txt": f"{R}_tgv_256_fp32_same_box_ab.txt"}
 for src, dst in pairs.items():
     p = os.path.join("gpurun_out", src)
     if os.path.exists(p) and os.path.getsize(p) > 0:

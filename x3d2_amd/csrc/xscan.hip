@@ -1250,7 +1250,10 @@ __global__ void __launch_bounds__(1024)
 // 72 KB; the table sets are staged without their STC block, which tds_solve does not read.
 // UNI: both operators on a uniform grid -- no ST reads / multiplications (see k_ytile_transeq3)
 // CIRC (round 6, with UNI, local form): both operators in the circulant form (circ_solve; ca / cb), no lane tables staged
-template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false, bool CIRC = false>
+// CDUAL (with CIRC, MODE 0 / 1): the pair's two solves as ONE solve over the pair type with each operator's constants
+// (circ_pair): one pass through the phases, two dependency chains in flight.  Measured even (z-transforming mode 1 0.745 ->
+// 0.716 ms, mode 0 0.782 -> 0.794, plain pairs unchanged): only with X3D_CIRC_DUAL=1
+template <int Q, int MODE, bool NARROW, bool HALO, bool ZF = false, bool UNI = false, bool CIRC = false, bool CDUAL = false>
 __global__ void __launch_bounds__(1024)
     k_ytile_tds_pair(real_t *out1, real_t *out2, const real_t *__restrict__ in1, const real_t *__restrict__ in2,
                      XOp ta, XOp tb, int ntx, int tile0, int ntiles, long prow, long pplane, TileHalo th, int permn,
@@ -1436,7 +1439,41 @@ __global__ void __launch_bounds__(1024)
 #else
         constexpr bool DUAL = false;
 #endif
-        if constexpr (DUAL) {
+        if constexpr (CIRC && CDUAL && MODE != 2) {
+            V2 w2[Q + 8], X2[Q];
+            if (MODE == 0) {
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m].a = w[m];
+                to_tile(g2);
+                __syncthreads();
+                pick(b);
+                window_from_body<Q>(w, b, lane);
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m].b = w[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < Q + 8; m++) w2[m] = V2{w[m], w[m]};
+            }
+            circ_solve<Q, NARROW, V2, CircOp2>(w2, X2, circ_pair(ca, cb), lane);
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) ra[q] = X2[q].a + 1.0 * X2[q].b;
+                put(ra);
+                __syncthreads();
+                if constexpr (ZF) zf_forward<TP>(tile, tws, zf_row(tl), kzs, wave, lane);
+                else from_tile(out1 + tile_off_p(tl));
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; q++) { ra[q] = X2[q].a; rb[q] = X2[q].b; }
+                put(ra);
+                __syncthreads();
+                from_tile(out1 + off);
+                __syncthreads();  // out1's tile has been read
+                put(rb);
+                __syncthreads();
+                from_tile(out2 + off);
+            }
+        } else if constexpr (DUAL) {
             V2 w2[Q + 8];
             if (MODE == 0) {
 #pragma unroll
@@ -1601,6 +1638,13 @@ static bool circ_env_on()
 {
     static int on = -1;
     if (on < 0) { const char *e = getenv("X3D_NO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
+    return on == 1;
+}
+// the pair kernels' two circulant solves as one over the pair type (k_ytile_tds_pair<.., CDUAL>): X3D_CIRC_DUAL=1
+static bool circ_dual_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_CIRC_DUAL"); on = e ? (e[0] == '1') : 0; }
     return on == 1;
 }
 // bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
@@ -1883,13 +1927,14 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th = halo ? *halo : TileHalo{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, dir);
-#define GOC(Q_, M_, N_, H_, U_, C_)                                                                             \
+#define GOD(Q_, M_, N_, H_, U_, C_, D_)                                                                         \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_>));                                    \
-        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_, D_>));                                \
+        hipLaunchKernelGGL((k_ytile_tds_pair<Q_, M_, N_, H_, false, U_, C_, D_>), dim3(blocks), dim3(1024), lds, b->stream, out1, out2, \
                            in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, rstride, ostride, th, permn,   \
                            ZfArg{}, ta->circ, tb->circ);                                                        \
     } while (0)
+#define GOC(Q_, M_, N_, H_, U_, C_) do { if ((C_) && (M_) != 2 && circ_dual_on()) GOD(Q_, M_, N_, H_, U_, C_, C_); else GOD(Q_, M_, N_, H_, U_, C_, false); } while (0)
 #define GO(Q_, M_, N_, H_, U_) GOC(Q_, M_, N_, H_, U_, false)
 #define GOH(Q_, M_, N_, U_) do { if (halo) GO(Q_, M_, N_, true, U_); else GO(Q_, M_, N_, false, U_); } while (0)
 #define GON(Q_, M_) do { if (circ) GOC(Q_, M_, true, false, true, true); else if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
@@ -1897,6 +1942,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
 #undef GON
+#undef GOD
 #undef GOH
 #undef GO
     if (halo) b->n_halo++;
@@ -1949,16 +1995,18 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
     const int blocks = x3d_persistent_blocks(b, ntiles > cap ? cap : ntiles);
     const TileHalo th{nullptr, nullptr, 0, 0, 0, 0, 0};
     ProfScope ps(b, X3D_K_TDS_FWD, X3D_DIR_Z);
-#define GO(M_, N_, U_, C_)                                                                                      \
+#define GOD(M_, N_, U_, C_, D_)                                                                                 \
     do {                                                                                                        \
-        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_, C_>));                                   \
-        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_, C_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
+        X3D_LDS_OPTIN(b, (k_ytile_tds_pair<8, M_, N_, false, true, U_, C_, D_>));                               \
+        hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_, C_, D_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
                            out2, in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, pxy, (long)b->nxp, th, 0, zf, ta->circ, tb->circ); \
     } while (0)
+#define GO(M_, N_, U_, C_) do { if ((C_) && circ_dual_on()) GOD(M_, N_, U_, C_, C_); else GOD(M_, N_, U_, C_, false); } while (0)
 #define GOU(M_) do { if (circ) GO(M_, true, true, true); else if (narrow && uni) GO(M_, true, true, false); else if (narrow) GO(M_, true, false, false); else GO(M_, false, false, false); } while (0)
     if (mode == 0) GOU(0); else GOU(1);
 #undef GOU
 #undef GO
+#undef GOD
     X3D_HIP(hipGetLastError());
     *done = true;
     return 0;

@@ -160,6 +160,11 @@ __device__ __forceinline__ V2 fma_of(real_t c, V2 x, V2 y) { const x3d_f2 cc = {
 #else
 __device__ __forceinline__ V2 fma_of(real_t c, V2 x, V2 y) { return V2{fma_r(c, x.a, y.a), fma_r(c, x.b, y.b)}; }
 #endif
+#ifdef X3D_V2_PACKED
+__device__ __forceinline__ V2 fma_of(V2 c, V2 x, V2 y) { return v2_of(__builtin_elementwise_fma(c.v, x.v, y.v)); }
+#else
+__device__ __forceinline__ V2 fma_of(V2 c, V2 x, V2 y) { return V2{fma_r(c.a, x.a, y.a), fma_r(c.b, x.b, y.b)}; }
+#endif
 template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ V2 dpp0(V2 v) { return V2{dpp0<CTRL, ROWMASK>(v.a), dpp0<CTRL, ROWMASK>(v.b)}; }
 __device__ __forceinline__ V2 readlane_d(V2 v, int l) { return V2{readlane_d(v.a, l), readlane_d(v.b, l)}; }
@@ -339,13 +344,31 @@ __device__ __forceinline__ void scan_solve(const T (&w)[Q + 8], T (&X)[Q], T &du
 #else
 #define CIRC_SB()
 #endif
-template <int Q, bool NARROW, class T = real_t>
-__device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const CircOp &t, int lane)
+// CircOp2: TWO operators side by side -- the pair type's two right-hand sides each take their own constants (the operator
+// pairs of the pressure correction: different operators on the same or on two inputs, ONE pass through the phases, two
+// independent dependency chains in flight)
+struct CircOp2 {
+    V2 c[9], nr, pf[8], mu[4];
+};
+__device__ __forceinline__ CircOp2 circ_pair(const CircOp &a, const CircOp &b)
+{
+    CircOp2 r;
+#pragma unroll
+    for (int m = 0; m < 9; m++) r.c[m] = V2{a.c[m], b.c[m]};
+    r.nr = V2{a.nr, b.nr};
+#pragma unroll
+    for (int m = 0; m < 8; m++) r.pf[m] = V2{a.pf[m], b.pf[m]};
+#pragma unroll
+    for (int m = 0; m < 4; m++) r.mu[m] = V2{a.mu[m], b.mu[m]};
+    return r;
+}
+template <int Q, bool NARROW, class T = real_t, class OP = CircOp>
+__device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const OP &t, int lane)
 {
     constexpr bool S8 = Q < 8;  // a fourth shift step (distance 8) where mu^8 is not yet negligible
-    const real_t c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6], c7 = t.c[7],
-                 c8 = t.c[8];
-    const real_t nr = t.nr, m1 = t.mu[0], m2 = t.mu[1], m4 = t.mu[2], m8 = t.mu[3];
+    const auto c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6], c7 = t.c[7],
+               c8 = t.c[8];
+    const auto nr = t.nr, m1 = t.mu[0], m2 = t.mu[1], m4 = t.mu[2], m8 = t.mu[3];
     T acc[Q];
     if (NARROW) {
 #pragma unroll
