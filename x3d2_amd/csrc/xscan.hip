@@ -1640,12 +1640,19 @@ static bool circ_env_on()
     if (on < 0) { const char *e = getenv("X3D_NO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
     return on == 1;
 }
-// the pair kernels' two circulant solves as one over the pair type (k_ytile_tds_pair<.., CDUAL>): X3D_CIRC_DUAL=1
+// the pair kernels' two circulant solves as one over the pair type (k_ytile_tds_pair<.., CDUAL>): X3D_CIRC_DUAL=1 everywhere,
+// default: the z-transforming mode 1 only
 static bool circ_dual_on()
 {
     static int on = -1;
     if (on < 0) { const char *e = getenv("X3D_CIRC_DUAL"); on = e ? (e[0] == '1') : 0; }
     return on == 1;
+}
+static bool circ_dual_off()  // X3D_CIRC_DUAL=0: nowhere (A/B)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("X3D_CIRC_DUAL"); off = (e && e[0] == '0') ? 1 : 0; }
+    return off == 1;
 }
 // bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
 static bool stencil_narrow(const x3d_tdsops *t)
@@ -2001,7 +2008,8 @@ int x3d_ytile_tds_pair_zf(x3d_backend *b, int mode, real_t *out1, real_t *out2, 
         hipLaunchKernelGGL((k_ytile_tds_pair<8, M_, N_, false, true, U_, C_, D_>), dim3(blocks), dim3(1024), lds, b->stream, out1, \
                            out2, in1, in2, xop_of(ta), xop_of(tb), ntx, tile0, ntiles, pxy, (long)b->nxp, th, 0, zf, ta->circ, tb->circ); \
     } while (0)
-#define GO(M_, N_, U_, C_) do { if ((C_) && circ_dual_on()) GOD(M_, N_, U_, C_, C_); else GOD(M_, N_, U_, C_, false); } while (0)
+// (the dual solve where it measured faster: the z-transforming mode 1, 0.745 -> 0.716 ms; mode 0 0.782 -> 0.794: not)
+#define GO(M_, N_, U_, C_) do { if ((C_) && ((M_) == 1 || circ_dual_on()) && !circ_dual_off()) GOD(M_, N_, U_, C_, C_); else GOD(M_, N_, U_, C_, false); } while (0)
 #define GOU(M_) do { if (circ) GO(M_, true, true, true); else if (narrow && uni) GO(M_, true, true, false); else if (narrow) GO(M_, true, false, false); else GO(M_, false, false, false); } while (0)
     if (mode == 0) GOU(0); else GOU(1);
 #undef GOU
