@@ -427,3 +427,109 @@ def test_bench_decomposition_choices():
         assert p[0] == 1 and p[1] * p[2] == n
     with pytest.raises(SystemExit):
         bench.decomposition(3)
+
+
+def _reference_sweeps(t, r):
+    """der_univ_dist + der_univ_subs of one rank on one pencil, from the operator's preprocessed arrays
+    (src/backend/omp/kernels/distributed.f90:34-229): the self-exchange of a periodic direction, no neighbours otherwise"""
+    n = t.n_tds
+    fw, bw, sa, sc, af = t.dist_fw, t.dist_bw, t.dist_sa, t.dist_sc, t.dist_af
+    d = np.zeros(n)
+    d[0], d[1] = r[0] * af[0], r[1] * af[1]
+    for j in range(2, n):
+        d[j] = fw[j] * (r[j] - af[j] * d[j - 1])
+    x = d.copy()
+    for j in range(n - 3, 0, -1):
+        x[j] = d[j] - bw[j] * x[j + 1]
+    x[0] = fw[0] * (d[0] - bw[0] * x[1])
+    du_s = (x[0] - sa[0] * x[n - 1]) / (1.0 - sa[0] * sa[0])
+    du_e = (x[n - 1] - sc[n - 1] * x[0]) / (1.0 - sc[n - 1] * sc[n - 1])
+    out = x - sa[:n] * du_s - sc[:n] * du_e
+    out[0], out[n - 1] = du_s, du_e
+    return out
+
+
+def test_direct_and_circulant_forms_reproduce_the_reference_sweeps():
+    """Round 6 (csrc/tds.hip), the arithmetic restated in numpy: (1) DIRECT form -- the tridiagonal system
+    recovered from a non-periodic operator's preprocessed arrays (the inverse of preprocess_dist) and solved by the plain
+    Thomas recurrences; (2) CIRCULANT form -- a periodic uniform-grid operator as two constant-coefficient recurrences
+    around the ring, run lane-parallel exactly as circ_solve does (Kogge-Stone inside rows of 16 lanes with mu, mu^2,
+    mu^4 (, mu^8), the neighbouring row's total through a rotate, truncation below 2^-60).  Both against the reference's
+    sweeps + 2 x 2 closure on random right-hand sides."""
+    from x3d2_amd.common import BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC
+    from x3d2_amd.tdsops import Tdsops
+    rng = np.random.default_rng(3)
+    # ---- (1)
+    cases = [("first-deriv", {}, "compact6"), ("first-deriv", {"sym": True}, "compact6"), ("second-deriv", {}, "compact6"),
+             ("second-deriv", {"sym": True}, "compact6"), ("interpolate", {"from_to": "p2v"}, "classic"),
+             ("stag-deriv", {"from_to": "p2v"}, "compact6"), ("interpolate", {"from_to": "v2p"}, "classic"),
+             ("stag-deriv", {"from_to": "v2p"}, "compact6")]
+    for op, kw, scheme in cases:
+        for bc in ((BC_DIRICHLET, BC_DIRICHLET), (BC_NEUMANN, BC_NEUMANN), (BC_DIRICHLET, BC_NEUMANN)):
+            if "from_to" in kw and BC_DIRICHLET in bc:
+                continue  # (the reference has no Dirichlet closure for the staggered operators)
+            n_tds = 256 if kw.get("from_to") == "v2p" else 257
+            t = Tdsops(n_tds, 0.01, op, scheme, bc[0], bc[1], **kw)
+            n = t.n_tds
+            assert t.dist_sa[0] == 0.0 and t.dist_sc[n - 1] == 0.0
+            fw, bw, sa, sc, af = t.dist_fw, t.dist_bw, t.dist_sa, t.dist_sc, t.dist_af
+            scp = np.where(np.arange(n) <= n - 3, bw[:n], sc[:n])  # c_i after its forward step
+            a, b, c = np.zeros(n), np.zeros(n), np.zeros(n)
+            b[:2] = 1.0 / af[:2]
+            c[:2] = scp[:2] * b[:2]
+            a[1] = (sa[1] + scp[1] * sa[2]) * b[1]
+            a[2:] = af[2:n]
+            b[2:] = 1.0 / fw[2:n] + a[2:] * scp[1:n - 1]
+            c[2:] = scp[2:] / fw[2:n]
+            r = rng.standard_normal(n)
+            e, g = np.zeros(n), np.zeros(n)
+            for j in range(n):
+                f = 1.0 / (b[j] - (a[j] * g[j - 1] if j else 0.0))
+                e[j] = f * (r[j] - (a[j] * e[j - 1] if j else 0.0))
+                g[j] = c[j] * f
+            x = e.copy()
+            for j in range(n - 2, -1, -1):
+                x[j] = e[j] - g[j] * x[j + 1]
+            ref = _reference_sweeps(t, r)
+            assert np.abs(x - ref).max() < 1e-13 * np.abs(ref).max(), (op, kw, bc)
+    # ---- (2)
+    for op, kw, scheme in cases[:1] + cases[2:3] + cases[4:]:
+        for Q in (4, 8, 16):
+            n, L = 64 * Q, 64
+            t = Tdsops(n, 0.01, op, scheme, BC_PERIODIC, BC_PERIODIC, **kw)
+            alpha = t.dist_af[4]
+            rho = (1.0 - np.sqrt(1.0 - 4.0 * alpha * alpha)) / (2.0 * alpha)
+            nr, mu = -rho, (-rho) ** Q
+            steps = (1, 2, 4) + ((8,) if Q < 8 else ())
+            assert abs(mu) ** (8 if Q >= 8 else 16) < 2.0 ** -60
+            lane = np.arange(L)
+
+            def row_shift(v, d, fwd):  # DPP row_shr / row_shl: lanes without a source read 0
+                o = np.zeros_like(v)
+                for l in range(L):
+                    s_ = l - d if fwd else l + d
+                    if (s_ >> 4) == (l >> 4) and 0 <= s_ < L:
+                        o[l] = v[s_]
+                return o
+
+            def ring_scan(v, fwd):
+                for k, d in enumerate(steps):
+                    v = v + mu ** d * row_shift(v, d, fwd)
+                z = np.where((lane & 15) == (0 if fwd else 15), np.roll(v, 1 if fwd else -1), 0.0)
+                for k, d in enumerate(steps):
+                    z = z + mu ** d * row_shift(z, d, fwd)
+                return np.roll(v + mu * z, 1 if fwd else -1)
+
+            r = rng.standard_normal(n)
+            Xf = ((rho / alpha) * r).reshape(L, Q).copy()  # lane-local forward sweep from zero ...
+            for q in range(1, Q):
+                Xf[:, q] += nr * Xf[:, q - 1]
+            carry = ring_scan(Xf[:, Q - 1].copy(), True)   # ... what the previous lane carries in ...
+            Xf += np.outer(carry, nr ** np.arange(1, Q + 1))
+            Xb = Xf.copy()                                 # ... the same backwards
+            for q in range(Q - 2, -1, -1):
+                Xb[:, q] = Xf[:, q] + nr * Xb[:, q + 1]
+            carry = ring_scan(Xb[:, 0].copy(), False)
+            Xb += np.outer(carry, nr ** np.arange(Q, 0, -1))
+            ref = _reference_sweeps(t, r)
+            assert np.abs(Xb.reshape(n) - ref).max() < 1e-13 * np.abs(ref).max(), (op, kw, Q)
