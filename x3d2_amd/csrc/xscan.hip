@@ -926,9 +926,9 @@ extern "C" int x3d_debug_yt(unsigned long long *out, int reset)
 // component order (advecting component first).  Per step the EPI launches save 6 of ~ 200 field passes (stages 1 and 3
 // of RK3; stage 2 gains nothing: DESIGN.md 3.2) and trade the stage kernel's streaming rate for the tile pattern's.
 // NPW (round 6): pencils per wave.  2 = a tile of 32 x-adjacent pencils, wave w solves pencils w and w + 16 one after the
-// other: 256-row FP64 pencils (BASELINE configs[1]) and every FP32 pencil then move 128-byte row segments... per 16
-// pencils, 256-byte segments per row of the tile, and a workgroup holds as many bytes in flight as a 512-row FP64 tile
-// (same register counts: NI and the advecting rows double, the windows are half as long)
+// other.  FP32: a row of the tile is then a 128-byte segment again (16 pencils of 4-byte reals are 64 bytes) and the
+// workgroup holds as many bytes in flight as a 512-row FP64 tile, at the same register counts (NI and the advecting rows
+// double, every value is half as wide).  256-row FP64 pencils: opt-in (ytile_npw)
 // CIRC (round 6, with UNI, P12, local form): the circulant form of both operators (xscan_core.h, circ_solve; cD1 / cD2) -- no
 // lane tables are staged (the workgroup's LDS is its tile), no closure; results equal the table form's to round-off
 template <int Q, bool ACC, bool NARROW, bool HALO, bool UNI = false, bool P12 = false, bool EPI = false, int NPW = 1,
