@@ -1097,7 +1097,7 @@ def test_slab_poisson_solver_single_rank_emulation():
     import sys
     if os.environ.get("X3D_FORCE_PENCIL_FFT") != "slab":
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k",
-                            "slab_poisson_solver"], env=dict(os.environ, X3D_FORCE_PENCIL_FFT="slab"),
+                            "test_slab_poisson_solver_single_rank_emulation"], env=dict(os.environ, X3D_FORCE_PENCIL_FFT="slab"),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         return
