@@ -805,6 +805,14 @@ contains
       error stop 'hip_backend_t needs a hip_allocator_t'
     end select
     if (mesh%par%nproc_dir(1) /= 1) error stop 'hip shim: x stays undecomposed (as the FFT Poisson solver needs)'
+    block
+      integer :: d
+      do d = 2, 3  ! a decomposed direction that is periodic over all its ranks (round 6: x3d_backend_set_ring)
+        if (mesh%par%nproc_dir(d) > 1 .and. mesh%grid%periodic_BC(d)) then
+          call x3d_check(x3d_backend_set_ring(backend%handle, int(d, c_int), 1_c_int))
+        end if
+      end do
+    end block
     ! the library records the op-granular calls of solver.f90 / time_integrator.f90 / vector_calculus.f90 and runs them
     ! through its fused kernels (csrc/lazy.hip); on several ranks too (round 4): the distributed entry points of a
     ! decomposed direction flush the queue and run at once on the buffers that hold their handles' data, the local

@@ -35,6 +35,13 @@ module m_x3d2_hip_capi
       integer(c_int), value :: device
       type(c_ptr), value :: stream
     end function
+    integer(c_int) function x3d_backend_set_ring(b, dir, periodic_over_all_ranks) bind(C, name='x3d_backend_set_ring')
+      !! direction dir is decomposed and periodic over all its ranks (mesh%grid%periodic_BC): the single-pass forms of the
+      !! decomposed direction may take the open-ended circulant solve -- every rank says the same
+      import :: c_ptr, c_int
+      type(c_ptr), value :: b
+      integer(c_int), value :: dir, periodic_over_all_ranks
+    end function
     integer(c_int) function x3d_backend_destroy(b) bind(C, name='x3d_backend_destroy')
       import :: c_ptr, c_int
       type(c_ptr), value :: b

@@ -83,6 +83,13 @@ int x3d_backend_set_stream(x3d_backend *b, void *stream);
  * before the launch ends.  0 (default): none; a multi-rank driver sets 8 (one per XCD).  The reference's GPU backend runs
  * everything on the default stream and synchronises before MPI (src/backend/cuda/sendrecv.f90:28): nothing to reserve for. */
 int x3d_backend_set_comm_reserve(x3d_backend *b, int ncus);
+/* round 6: direction `dir` is decomposed AND periodic over all its ranks (mesh%periodic_BC(dir), src/mesh.f90:44-53, with
+ * nproc_dir(dir) > 1).  The single-pass forms of a decomposed direction (x3d_transeq_tile / x3d_tds_pair_tile with halos)
+ * may then solve with the open-ended circulant recurrences instead of the reference's reduced 2 x 2 systems
+ * (src/backend/omp/kernels/distributed.f90:186-206); the values exchanged per pencil and operator are then the first
+ * row's solution and the forward end state instead of du_1 / X_n -- same count, same buffers.  Every rank of the direction
+ * must be told the same (they are: one mesh).  Default 0. */
+int x3d_backend_set_ring(x3d_backend *b, int dir, int periodic_over_all_ranks);
 size_t x3d_block_elems(const x3d_backend *b);             /* allocator%ngrid */
 int x3d_padded_dims(const x3d_backend *b, int dims_out[3]); /* get_padded_dims(DIR_C) */
 int x3d_device_sync(x3d_backend *b);

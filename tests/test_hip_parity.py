@@ -425,10 +425,13 @@ def test_multirank_full_step_matches_single_rank(nproc_dir, fused, dims, tmp_pat
     assert rows[-1][2] < max(1e-11, 3 * rrows[-1][2])  # max |div u|: round-off level of the single-rank run
 
 
-@pytest.mark.parametrize("env", ["X3D_PACK_Z_HALOS", "X3D_NO_SLAB_FUSED_Z", "X3D_SLAB_Z_SPLIT", "X3D_NO_OVERLAP"])
+@pytest.mark.parametrize("env", ["X3D_PACK_Z_HALOS", "X3D_NO_SLAB_FUSED_Z", "X3D_SLAB_Z_SPLIT", "X3D_NO_OVERLAP",
+                                 "X3D_NO_HALO_CIRC"])
 def test_multirank_alternative_paths_match_single_rank(env, tmp_path, monkeypatch):
     """the switched-off forms of the N > 1 path stay correct: z halos through the pack kernel, the slab solver's z
-    stage as transposes + rocFFT, the cross-chunk DFTs as separate passes, exchanges ordered on the compute stream
+    stage as transposes + rocFFT, the cross-chunk DFTs as separate passes, exchanges ordered on the compute stream, the
+    single-pass kernels of the decomposed direction on the lane tables + reduced 2 x 2 systems instead of the open-ended
+    circulant solve (round 6; the default is what every other multi-rank test runs)
     (two ranks, 512 planes each, against the single-rank run)"""
     from x3d2_amd import make_tgv
     monkeypatch.setenv(env, "1")

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "x3d_lazy_stats": (I, [VP, ctypes.POINTER(ctypes.c_long)]),
     "x3d_backend_set_stream": (I, [VP, VP]),
     "x3d_backend_set_comm_reserve": (I, [VP, I]),
+    "x3d_backend_set_ring": (I, [VP, I, I]),
     "x3d_block_elems": (SZT, [VP]),
     "x3d_padded_dims": (I, [VP, c_int_p]),
     "x3d_device_sync": (I, [VP]),

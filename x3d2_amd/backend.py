@@ -68,6 +68,12 @@ class HipBackend:
         del multi
         self.comm_reserve = int(os.environ.get("X3D_COMM_RESERVE_CUS", "0"))
         _lib.check(self.lib.x3d_backend_set_comm_reserve(h, self.comm_reserve))
+        # a decomposed direction that is periodic over all its ranks: its single-pass HALO kernels may take the open-ended
+        # circulant solve (x3d_backend_set_ring; every rank holds the same mesh, so every rank says the same)
+        emul = os.environ.get("X3D_EMULATE_DECOMP", "").lower()
+        for d in (2, 3):
+            split = int(mesh.nproc_dir[d - 1]) > 1 or "xyz"[d - 1] in emul
+            _lib.check(self.lib.x3d_backend_set_ring(h, d, int(split and bool(mesh.periodic_BC[d - 1]))))
         self.lazy = (os.environ.get("X3D_LAZY") == "1") if lazy is None else bool(lazy)
         self.red_epoch = 0  # bumped by every call that uses the library's reduction buffer (Solver.take_mean_shift)
         if self.lazy:

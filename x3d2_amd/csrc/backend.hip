@@ -163,6 +163,17 @@ extern "C" int x3d_backend_set_comm_reserve(x3d_backend *b, int ncus)
     return 0;
 }
 
+// a decomposed direction that is periodic over ALL its ranks (the mesh knows; an operator with BC_HALO ends does not): the
+// single-pass HALO kernels may then use the open-ended circulant solve, whose boundary values mean something else than
+// du_1 / X_n -- every rank of the ring makes the same choice because every rank is told the same.  Default 0: the table form
+extern "C" int x3d_backend_set_ring(x3d_backend *b, int dir, int periodic_over_all_ranks)
+{
+    X3D_RANGE(__func__);
+    X3D_REQUIRE(b && x3d_dir_ok(dir), "x3d_backend_set_ring: null backend or bad direction");
+    b->ring[dir] = periodic_over_all_ranks ? 1 : 0;
+    return 0;
+}
+
 extern "C" size_t x3d_block_elems(const x3d_backend *b) { return b ? b->nblock : 0; }
 
 extern "C" int x3d_padded_dims(const x3d_backend *b, int d[3])

@@ -139,6 +139,8 @@ struct x3d_backend {
     int device;
     hipStream_t stream;
     int nx, ny, nz;     // local vertex dims
+    int ring[4];        // [dir]: the decomposed direction is PERIODIC over all its ranks (x3d_backend_set_ring): the HALO forms
+                        // may then run the open-ended circulant solve -- every rank of the ring must make the same choice
     int nxp, nyp, nzp;  // pitched dims
     size_t nblock;      // elements per block
     // boundary-value exchange buffers for the local (non-decomposed) forms:
@@ -336,6 +338,7 @@ struct CircOp {
     real_t nr;     // -rho
     real_t pf[8];  // (-rho)^(q + 1): what the value carried into a lane adds to its row q (Q rows per lane, Q <= 8)
     real_t mu[4];  // mu, mu^2, mu^4, mu^8 with mu = (-rho)^Q: the lane-to-lane multiplier of the scans
+    real_t phi0;   // -rho / (1 - rho^2): what a unit forward carry into a pencil adds to the solution's first row (HALO form)
 };
 struct Circ4 { CircOp o[4]; };  // der1st, der2nd, op_s, op_i of a transeq_x launch
 struct x3d_tdsops {
@@ -350,6 +353,10 @@ struct x3d_tdsops {
     int direct;                  // 1: non-periodic on one rank and the plain Thomas factors reproduce the reference's sweeps
     int circ_ok;                 // 1: periodic, uniform grid, and circ (for tab.Q rows per lane) reproduces the reference's sweeps
     CircOp circ;
+    int circ_open_ok;            // 1: the open-ended (HALO) circulant form is on offer: as circ_ok, for periodic operators and for
+                                 //    operators whose two ends are neighbour ranks (BC_HALO: the same rows)
+    TdsTab tabc;                 // circ_open_ok: the strip corrections of the circulant HALO form in the strip kernels' table layout
+    int halo_ws_c, halo_we_c;    // ... and the rows they reach (as halo_ws / halo_we)
     const real_t *td5, *td8h;    // DIRECT lane tables (tds.hip, ygen.hip): 5 rows per lane; 8 rows per lane of a half-wave + row 257
     int narrow_all;              // 1: no stencil of the operator (bulk, start rows, end rows) reaches beyond 2 rows
     int uniform;                 // 1: stretch == 1 and stretch_correct == 0 on every row (a uniform grid): kernels may skip

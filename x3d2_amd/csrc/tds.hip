@@ -354,7 +354,11 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     // tables at all.  alpha = dist_af(5) (the reference's one bulk alpha, distributed.f90:83); checked here against the
     // reference's sweeps + 2 x 2 closure (periodic self-exchange) before it is offered.
     t->circ_ok = 0;
+    t->circ_open_ok = 0;
     memset(&t->circ, 0, sizeof(t->circ));
+    size_t circ_rb_off = 0;
+    int circ_ws = 1, circ_we = 1;
+    real_t circ_sa1 = 0.0, circ_scn = 0.0;
     {
         bool bulk = true, unif = true;
         for (int r = 0; r < 4; r++)
@@ -363,7 +367,9 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
         for (int j = 1; j <= n; j++)
             if (St[j] != 1.0 || Stc[j] != 0.0) unif = false;
         const real_t alpha = n >= 8 ? dist_af[4] : 0.0;
-        if (periodic && bulk && unif && nr == n && (Q == 4 || Q == 8 || Q == 16) && n == 64 * Q && alpha != 0.0 && fabs(alpha) < 0.5) {
+        // (bulk: periodic, or both ends open to neighbour ranks -- BC_HALO: the same rows; the closed form is offered to
+        //  periodic operators only, the open one to both)
+        if (bulk && unif && nr == n && (Q == 4 || Q == 8 || Q == 16) && n == 64 * Q && alpha != 0.0 && fabs(alpha) < 0.5) {
             const double a = (double)alpha, rho = (1.0 - sqrt(1.0 - 4.0 * a * a)) / (2.0 * a);
             CircOp &co = t->circ;
             for (int m = 0; m < 9; m++) co.c[m] = (real_t)(coeffs[m] * (rho / a));
@@ -374,6 +380,7 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
             for (int q = 0; q < Q; q++) mu *= -rho;
             co.mu[0] = (real_t)mu; co.mu[1] = (real_t)(mu * mu); co.mu[2] = (real_t)(mu * mu * mu * mu);
             co.mu[3] = (real_t)pow(mu, 8.0);
+            co.phi0 = (real_t)(-rho / (1.0 - rho * rho));
             // (the scans drop mu^8 at 8 rows per lane, mu^16 at 4: below 2^-60 or the form is not offered)
             bool ok = pow(fabs(mu), Q >= 8 ? 8.0 : 16.0) < 8.673617379884035e-19;
             // host check: the reference's sweeps with the periodic closure against the two recurrences run twice around
@@ -407,7 +414,31 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
                 }
                 if (!(emax <= (sizeof(real_t) == 8 ? 1e-13 : 2e-5) * xmax)) ok = false;
             }
-            t->circ_ok = ok ? 1 : 0;
+            t->circ_ok = (ok && periodic) ? 1 : 0;
+            t->circ_open_ok = ok ? 1 : 0;
+            if (ok) {
+                // HALO form (a decomposed direction): every rank runs the two recurrences over ITS rows with open ends, hands
+                // its forward end state E to the next rank and its first row x_1 to the previous one; what the received
+                // values add is geometric -- E_prev (-rho)^j / (1 - rho^2) from the start, x_1,next (-rho)^(n-j+1) from the
+                // end -- and goes through the strip kernels of the table form (xscan.hip, halo_fix_row) on a second set of
+                // row records: Sa'_j = -(-rho)^(j-1), Sc'_j = -(-rho)^(n-j), St = 1; ds = -(rho / (1 - rho^2)) E_prev,
+                // de = -rho x_1,next
+                circ_rb_off = img.size();
+                img.resize(img.size() + (size_t)8 * L, 0.0);
+                real_t *rb = &img[circ_rb_off];
+                const double tiny = 8.673617379884035e-19;
+                circ_ws = 1; circ_we = 1;
+                for (int j = 1; j <= n; j++) {
+                    const double sa = -pow(-rho, (double)(j - 1)), sc = -pow(-rho, (double)(n - j));
+                    rb[(size_t)8 * j + 1] = fabs(sa) >= tiny ? (real_t)sa : 0.0;
+                    rb[(size_t)8 * j + 2] = fabs(sc) >= tiny ? (real_t)sc : 0.0;
+                    rb[(size_t)8 * j + 3] = 1.0;
+                    if (fabs(sa) >= tiny) circ_ws = j;
+                    if (fabs(sc) >= tiny && n - j + 1 > circ_we) circ_we = n - j + 1;
+                }
+                circ_sa1 = (real_t)(rho / (1.0 - rho * rho));
+                circ_scn = (real_t)rho;
+            }
         }
     }
     X3D_HIP(hipMalloc(&t->dev, sizeof(real_t) * img.size()));
@@ -452,6 +483,13 @@ extern "C" int x3d_tdsops_create(x3d_backend *b, x3d_tdsops **out, int n_tds, in
     tb.scn = dist_sc[n - 1];
     tb.rs_s = 1.0 / (1.0 - dist_sa[0] * dist_sa[0]);          // distributed.f90:196-198
     tb.rs_e = 1.0 / (1.0 - dist_sc[n - 1] * dist_sc[n - 1]);  // distributed.f90:203-205
+    t->tabc = tb;
+    t->halo_ws_c = circ_ws; t->halo_we_c = circ_we;
+    if (t->circ_open_ok) {
+        t->tabc.RB = t->dev + circ_rb_off;
+        t->tabc.rs_s = 1.0; t->tabc.sa1 = circ_sa1;
+        t->tabc.rs_e = 1.0; t->tabc.scn = circ_scn;
+    }
     // rows that still feel the reduced system's unknowns: |dist_sa(j)| decays from row 1, |dist_sc(j)| from row n
     // (the same decay lets the reference truncate the coupling to a 2 x 2 system, src/tdsops.f90:196-201)
     const real_t tiny = 8.673617379884035e-19;  // 2^-60

@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(1024)
                      int tile0, int ntiles, long prow, long pplane, real_t nu, TileHalo th, const TileEpi *epp,
                      CircOp cD1, CircOp cD2)
 {
-    static_assert(!CIRC || (UNI && P12 && !HALO), "CIRC: the local uniform-grid pair-solve form");
+    static_assert(!CIRC || (UNI && (P12 != HALO)), "CIRC: uniform grids; the local form with the pair solve, the HALO form without");
     static_assert(!EPI || (ACC && !HALO), "EPI: the local accumulating form");
     static_assert(NPW == 1 || !HALO, "two pencils per wave: the local form");
     extern __shared__ real_t lt[];
@@ -1053,6 +1053,14 @@ __global__ void __launch_bounds__(1024)
 
             auto solve_subs = [&](const real_t (&w)[Q + 8], real_t (&T)[Q], const real_t *__restrict__ l, const XOp &t,
                                   int op) {
+                if constexpr (CIRC && HALO) {  // the open-ended circulant solve; its two boundary values go out as du_1 / X_n do
+                    real_t ab[2];
+                    if (op < 2) circ_solve<Q, NARROW, real_t, CircOp, true>(w, T, cD1, lane, ab);
+                    else circ_solve<Q, NARROW, real_t, CircOp, true>(w, T, cD2, lane, ab);
+                    bnd[(wave * 9 + c * 3 + op) * 2] = ab[0];
+                    bnd[(wave * 9 + c * 3 + op) * 2 + 1] = ab[1];
+                    return;
+                }
                 real_t a, b;
                 scan_solve<Q, true, NARROW>(w, T, a, b, l, t, lane, first);
                 real_t s_, e_;
@@ -1086,7 +1094,7 @@ __global__ void __launch_bounds__(1024)
 #ifdef YT_TIMING
             const unsigned long long yt_s0 = __builtin_readcyclecounter();
 #endif
-            if constexpr (CIRC) {
+            if constexpr (CIRC && !HALO) {
                 V2 w2[Q + 8], T2[Q];
 #pragma unroll
                 for (int m = 0; m < Q + 8; m++) w2[m] = V2{wp[m], wu[m]};
@@ -1135,7 +1143,7 @@ __global__ void __launch_bounds__(1024)
                 if constexpr (HALO) window_from_body_halo<Q>(wu, b, lane, hal + wave * 8);
                 else window_from_body<Q>(wu, b, lane);
             }
-            if constexpr (CIRC) circ_solve<Q, NARROW>(wu, T, cD2, lane);
+            if constexpr (CIRC && !HALO) circ_solve<Q, NARROW>(wu, T, cD2, lane);
             else solve_subs(wu, T, l3, tD2, 2);
             // (the loads below are issued here, before the LAST pencil's rows go back into the tile, not before the solves:
             //  16 more live VGPRs there spill -- 0.81 -> 1.28 ms per component; with the partial result parked in the tile
@@ -1262,7 +1270,7 @@ __global__ void __launch_bounds__(1024)
     extern __shared__ real_t lt[];
     constexpr int LN = (ZF ? LT_NC(Q) : LT_N(Q)) * 64, n = 64 * Q, TP = n + 4, NI = n / 128;
     static_assert(!ZF || (Q == 8 && MODE != 2 && !HALO), "the z-transforming forms: local pairs on 512-row pencils");
-    static_assert(!CIRC || (UNI && !HALO), "CIRC: the local uniform-grid form");
+    static_assert(!CIRC || UNI, "CIRC: uniform grids");
     if constexpr (!CIRC) {
         for (int i = threadIdx.x; i < LN; i += blockDim.x) {
             lt[i] = ta.TL[i];
@@ -1332,7 +1340,14 @@ __global__ void __launch_bounds__(1024)
             return;
         }
 #endif
-        if constexpr (CIRC) {
+        if constexpr (CIRC && HALO) {
+            real_t ab[2];
+            if (op == 0) circ_solve<Q, NARROW, real_t, CircOp, true>(w, r, ca, lane, ab);
+            else circ_solve<Q, NARROW, real_t, CircOp, true>(w, r, cb, lane, ab);
+            bnd[(wave * 2 + op) * 2] = ab[0];
+            bnd[(wave * 2 + op) * 2 + 1] = ab[1];
+            return;
+        } else if constexpr (CIRC) {
             if (op == 0) circ_solve<Q, NARROW>(w, r, ca, lane);
             else circ_solve<Q, NARROW>(w, r, cb, lane);
             return;
@@ -1633,6 +1648,11 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------- launchers
+// bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
+static bool stencil_narrow(const x3d_tdsops *t)
+{
+    return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
+}
 // the circulant form (circ_solve) where every operator of the launch offers it.  X3D_NO_CIRC=1: never (A/B)
 static bool circ_env_on()
 {
@@ -1648,16 +1668,33 @@ static bool circ_dual_on()
     if (on < 0) { const char *e = getenv("X3D_CIRC_DUAL"); on = e ? (e[0] == '1') : 0; }
     return on == 1;
 }
+// the HALO (decomposed-direction) forms in the circulant form: the same predicate picks the main kernel's solve AND the strip
+// kernel's tables, on every rank (the operators are the same everywhere).  X3D_NO_HALO_CIRC=1: the table form (A/B)
+static bool halo_circ(const x3d_tdsops *t)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("X3D_NO_HALO_CIRC"); on = (e && e[0] == '1') ? 0 : 1; }
+    return on && circ_env_on() && t->circ_open_ok && t->uniform && stencil_narrow(t);
+}
+static bool use_uniform_forms()
+{
+    static int uni_on = -1;
+    if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
+    return uni_on == 1;
+}
+static bool pair_halo_circ(const x3d_backend *b, int dir, const x3d_tdsops *ta, const x3d_tdsops *tb)
+{
+    return b->ring[dir] && use_uniform_forms() && halo_circ(ta) && halo_circ(tb);
+}
+static bool transeq_halo_circ(const x3d_backend *b, int dir, const x3d_tdsops *der1st, const x3d_tdsops *der2nd)
+{
+    return b->ring[dir] && use_uniform_forms() && halo_circ(der1st) && halo_circ(der2nd);
+}
 static bool circ_dual_off()  // X3D_CIRC_DUAL=0: nowhere (A/B)
 {
     static int off = -1;
     if (off < 0) { const char *e = getenv("X3D_CIRC_DUAL"); off = (e && e[0] == '0') ? 1 : 0; }
     return off == 1;
-}
-// bulk stencil within +-2 rows (compact6 / classic schemes): the kernels skip the four zero taps
-static bool stencil_narrow(const x3d_tdsops *t)
-{
-    return t->coeffs[0] == 0.0 && t->coeffs[1] == 0.0 && t->coeffs[7] == 0.0 && t->coeffs[8] == 0.0;
 }
 
 static bool xscan_ok(const x3d_tdsops *t) { return t->tab.TL != nullptr && (t->tab.Q == 4 || t->tab.Q == 8); }
@@ -1917,7 +1954,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     static int uni_on = -1;
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
     const bool uni = uni_on && ta->uniform && tb->uniform;
-    const bool circ = narrow && uni && !halo && circ_env_on() && ta->circ_ok && tb->circ_ok;
+    const bool circ = narrow && uni && circ_env_on() && (halo ? pair_halo_circ(b, dir, ta, tb) : (ta->circ_ok && tb->circ_ok));
     const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : (mode == 2 ? 1 : 2) * LT_N(Q) * 64) + 16 * (64 * Q + 4) + (halo ? 128 + 64 : 0));
     if (lds > 160 * 1024) return 0;
     const long pxy = (long)b->nxp * b->nyp;
@@ -1944,7 +1981,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
 #define GOC(Q_, M_, N_, H_, U_, C_) do { if ((C_) && (M_) != 2 && circ_dual_on()) GOD(Q_, M_, N_, H_, U_, C_, C_); else GOD(Q_, M_, N_, H_, U_, C_, false); } while (0)
 #define GO(Q_, M_, N_, H_, U_) GOC(Q_, M_, N_, H_, U_, false)
 #define GOH(Q_, M_, N_, U_) do { if (halo) GO(Q_, M_, N_, true, U_); else GO(Q_, M_, N_, false, U_); } while (0)
-#define GON(Q_, M_) do { if (circ) GOC(Q_, M_, true, false, true, true); else if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
+#define GON(Q_, M_) do { if (circ && halo) GOD(Q_, M_, true, true, true, true, false); else if (circ) GOC(Q_, M_, true, false, true, true); else if (narrow && uni) GOH(Q_, M_, true, true); else if (narrow) GOH(Q_, M_, true, false); else GOH(Q_, M_, false, false); } while (0)
 #define GOM(Q_) do { if (mode == 0) GON(Q_, 0); else if (mode == 1) GON(Q_, 1); else GON(Q_, 2); } while (0)
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
@@ -2025,16 +2062,21 @@ int x3d_tds_halo_fix(x3d_backend *b, int dir, int mode, real_t *out1, real_t *ou
                      const x3d_tdsops *ta, const x3d_tdsops *tb)
 {
     const PencilGeom g = x3d_geom(b, dir);
-    const int ws = mode == 2 ? ta->halo_ws : (ta->halo_ws > tb->halo_ws ? ta->halo_ws : tb->halo_ws);
-    const int we = mode == 2 ? ta->halo_we : (ta->halo_we > tb->halo_we ? ta->halo_we : tb->halo_we);
+    // (the circulant HALO form: the same launch on the second set of row records -- the choice x3d_ytile_tds_pair made)
+    const bool hc = pair_halo_circ(b, dir, ta, mode == 2 ? ta : tb);
+    const TdsTab &tta = hc ? ta->tabc : ta->tab, &ttb = hc ? tb->tabc : tb->tab;
+    const int wsa = hc ? ta->halo_ws_c : ta->halo_ws, wsb = hc ? tb->halo_ws_c : tb->halo_ws;
+    const int wea = hc ? ta->halo_we_c : ta->halo_we, web = hc ? tb->halo_we_c : tb->halo_we;
+    const int ws = mode == 2 ? wsa : (wsa > wsb ? wsa : wsb);
+    const int we = mode == 2 ? wea : (wea > web ? wea : web);
     dim3 grid((g.np + 255) / 256, ws + we >= ta->n_tds ? 1 : 2);
     const int ws1 = grid.y == 1 ? ta->n_tds : ws;
     const int permn = b->pair_yperm;
     X3D_REQUIRE(permn == 0 || (dir == X3D_DIR_Z && mode != 2), "tds_halo_fix: interleaved rows are for z pairs");
     ProfScope ps(b, X3D_K_TDS_BWD, dir);
-    if (mode == 0) hipLaunchKernelGGL(k_tds_halo_fix<0>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we, permn);
-    else if (mode == 1) hipLaunchKernelGGL(k_tds_halo_fix<1>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, tb->tab, g, ws1, we, permn);
-    else hipLaunchKernelGGL(k_tds_halo_fix<2>, grid, dim3(256), 0, b->stream, out1, out2, brecv, ta->tab, ta->tab, g, ws1, we, 0);
+    if (mode == 0) hipLaunchKernelGGL(k_tds_halo_fix<0>, grid, dim3(256), 0, b->stream, out1, out2, brecv, tta, ttb, g, ws1, we, permn);
+    else if (mode == 1) hipLaunchKernelGGL(k_tds_halo_fix<1>, grid, dim3(256), 0, b->stream, out1, out2, brecv, tta, ttb, g, ws1, we, permn);
+    else hipLaunchKernelGGL(k_tds_halo_fix<2>, grid, dim3(256), 0, b->stream, out1, out2, brecv, tta, tta, g, ws1, we, 0);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -2043,13 +2085,17 @@ int x3d_transeq_halo_fix_launch(x3d_backend *b, int dir, real_t *const r[3], con
                                 const real_t *brecv, const x3d_tdsops *der1st, const x3d_tdsops *der2nd)
 {
     const PencilGeom g = x3d_geom(b, dir);
-    const int ws = der1st->halo_ws > der2nd->halo_ws ? der1st->halo_ws : der2nd->halo_ws;
-    const int we = der1st->halo_we > der2nd->halo_we ? der1st->halo_we : der2nd->halo_we;
+    const bool hc = transeq_halo_circ(b, dir, der1st, der2nd);  // (the choice x3d_ytile_transeq3 made)
+    const TdsTab &tt1 = hc ? der1st->tabc : der1st->tab, &tt2 = hc ? der2nd->tabc : der2nd->tab;
+    const int ws1_ = hc ? der1st->halo_ws_c : der1st->halo_ws, ws2_ = hc ? der2nd->halo_ws_c : der2nd->halo_ws;
+    const int we1_ = hc ? der1st->halo_we_c : der1st->halo_we, we2_ = hc ? der2nd->halo_we_c : der2nd->halo_we;
+    const int ws = ws1_ > ws2_ ? ws1_ : ws2_;
+    const int we = we1_ > we2_ ? we1_ : we2_;
     dim3 grid((g.np + 255) / 256, ws + we >= der1st->n_tds ? 1 : 2);
     const int ws1 = grid.y == 1 ? der1st->n_tds : ws;
     ProfScope ps(b, X3D_K_TRANSEQ_BWD, dir);
-    hipLaunchKernelGGL(k_transeq_halo_fix, grid, dim3(256), 0, b->stream, r[0], r[1], r[2], conv, brecv, der1st->tab,
-                       der2nd->tab, g, nu, ws1, we);
+    hipLaunchKernelGGL(k_transeq_halo_fix, grid, dim3(256), 0, b->stream, r[0], r[1], r[2], conv, brecv, tt1,
+                       tt2, g, nu, ws1, we);
     X3D_HIP(hipGetLastError());
     return 0;
 }
@@ -2089,7 +2135,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
     if (uni_on < 0) { const char *e = getenv("X3D_NO_UNIFORM"); uni_on = (e && e[0] == '1') ? 0 : 1; }
     const bool uni = uni_on && der1st->uniform && der1st_sym->uniform && der2nd->uniform && der2nd_sym->uniform;
     const int npw = (narrow && uni) ? ytile_npw(b, Q, halo != nullptr) : 1;  // (two pencils per wave: the uniform-grid forms)
-    const bool circ = narrow && uni && !halo && ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym);
+    const bool circ = narrow && uni && (halo ? transeq_halo_circ(b, dir, der1st, der2nd) : ytile_circ(der1st, der1st_sym, der2nd, der2nd_sym));
     const size_t lds = sizeof(real_t) * ((size_t)(circ ? 0 : 2 * LT_N(Q) * 64) + 16 * npw * (64 * Q + 4) + (halo ? 256 + 288 : 0));
     if (lds > 160 * 1024) return 0;
     const long pxy = (long)b->nxp * b->nyp;
@@ -2111,7 +2157,7 @@ int x3d_ytile_transeq3(x3d_backend *b, int dir, real_t *const r[3], const real_t
                            (const TileEpi *)nullptr, der1st->circ, der2nd->circ);                               \
     } while (0)
 #define GOC(Q_, A_, W_) do { if (circ) GOW(Q_, A_, true, false, true, W_, true); else GOW(Q_, A_, true, false, true, W_, false); } while (0)
-#define GO(Q_, A_, N_, H_, U_) do { if ((N_) && (U_) && !(H_)) { if (npw == 2) GOC(Q_, A_, 2); else GOC(Q_, A_, 1); } else GOW(Q_, A_, N_, H_, U_, 1, false); } while (0)
+#define GO(Q_, A_, N_, H_, U_) do { if ((N_) && (U_) && !(H_)) { if (npw == 2) GOC(Q_, A_, 2); else GOC(Q_, A_, 1); } else if ((N_) && (U_) && (H_) && circ) GOW(Q_, A_, true, true, true, 1, true); else GOW(Q_, A_, N_, H_, U_, 1, false); } while (0)
 #define GOH(Q_, A_, N_, U_) do { if (halo) GO(Q_, A_, N_, true, U_); else GO(Q_, A_, N_, false, U_); } while (0)
 #define GON(Q_, A_) do { if (narrow && uni) GOH(Q_, A_, true, true); else if (narrow) GOH(Q_, A_, true, false); else GOH(Q_, A_, false, false); } while (0)
 #define GOA(Q_) do { if (acc) GON(Q_, true); else GON(Q_, false); } while (0)

@@ -362,8 +362,12 @@ __device__ __forceinline__ CircOp2 circ_pair(const CircOp &a, const CircOp &b)
     for (int m = 0; m < 4; m++) r.mu[m] = V2{a.mu[m], b.mu[m]};
     return r;
 }
-template <int Q, bool NARROW, class T = real_t, class OP = CircOp>
-__device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const OP &t, int lane)
+// OPEN (the HALO form: a decomposed direction, T = real_t): the pencil's two ends are open instead of joined -- nothing is
+// carried into lane 0, the backward sweep's lane 63 takes phi0 * E, what this rank's own forward end state E makes of the
+// next rank's first row; *bnd = {x_1 (for the previous rank), E (for the next)}.  What the neighbours' values add comes
+// afterwards, on the boundary strips (tds.hip, tabc).
+template <int Q, bool NARROW, class T = real_t, class OP = CircOp, bool OPEN = false>
+__device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const OP &t, int lane, T *bnd = nullptr)
 {
     constexpr bool S8 = Q < 8;  // a fourth shift step (distance 8) where mu^8 is not yet negligible
     const auto c0 = t.c[0], c1 = t.c[1], c2 = t.c[2], c3 = t.c[3], c4 = t.c[4], c5 = t.c[5], c6 = t.c[6], c7 = t.c[7],
@@ -397,15 +401,22 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     v = fma_of(m4, dpp0<0x114>(v), v);
     if (S8) v = fma_of(m8, dpp0<0x118>(v), v);
     {
-        T z = sel_of(row_first, dpp0<0x13C>(v), zero_of<T>());  // wave_ror:1: the previous row's total, lane 0 <- lane 63
+        // wave_ror:1: the previous row's total, lane 0 <- lane 63 (OPEN: wave_shr:1, lane 0 <- 0)
+        T z = sel_of(row_first, OPEN ? dpp0<0x138>(v) : dpp0<0x13C>(v), zero_of<T>());
         z = fma_of(m1, dpp0<0x111>(z), z);
         z = fma_of(m2, dpp0<0x112>(z), z);
         z = fma_of(m4, dpp0<0x114>(z), z);
         if (S8) z = fma_of(m8, dpp0<0x118>(z), z);
         v = fma_of(m1, z, v);
     }
-    T carry = dpp0<0x13C>(v);
+    T carry = OPEN ? dpp0<0x138>(v) : dpp0<0x13C>(v);
     T nxt = zero_of<T>();
+    T endc = zero_of<T>();  // OPEN: what enters the backward sweep at the pencil's end
+    if constexpr (OPEN) {
+        const T E = readlane_d(v, 63);
+        bnd[1] = E;
+        endc = t.phi0 * E;
+    }
     CIRC_SB();
     // (16 rows per lane, the 1024-row x pencils: (-rho)^(q + 1) = (-rho)^(q - 7) (-rho)^8 for the upper eight rows)
     T carry8 = zero_of<T>();
@@ -422,14 +433,15 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
     v = fma_of(m4, dpp0<0x104>(v), v);
     if (S8) v = fma_of(m8, dpp0<0x108>(v), v);
     {
-        T z = sel_of(row_last, dpp0<0x134>(v), zero_of<T>());  // wave_rol:1: the next row's total, lane 63 <- lane 0
+        // wave_rol:1: the next row's total, lane 63 <- lane 0 (OPEN: wave_shl:1, lane 63 <- endc)
+        T z = sel_of(row_last, OPEN ? sel_of(lane == 63, endc, dpp0<0x130>(v)) : dpp0<0x134>(v), zero_of<T>());
         z = fma_of(m1, dpp0<0x101>(z), z);
         z = fma_of(m2, dpp0<0x102>(z), z);
         z = fma_of(m4, dpp0<0x104>(z), z);
         if (S8) z = fma_of(m8, dpp0<0x108>(z), z);
         v = fma_of(m1, z, v);
     }
-    carry = dpp0<0x134>(v);
+    carry = OPEN ? sel_of(lane == 63, endc, dpp0<0x130>(v)) : dpp0<0x134>(v);
     CIRC_SB();
     if constexpr (Q > 8) carry8 = t.pf[7] * carry;
 #pragma unroll
@@ -437,6 +449,7 @@ __device__ __forceinline__ void circ_solve(const T (&w)[Q + 8], T (&X)[Q], const
         const int k = Q - 1 - q;
         X[q] = k < 8 ? fma_of(t.pf[k], carry, X[q]) : fma_of(t.pf[k - 8], carry8, X[q]);
     }
+    if constexpr (OPEN) bnd[0] = readlane_d(X[0], 0);
 }
 
 // Two DIFFERENT operators (lane tables la / lb, descriptors ta / tb) on two right-hand sides (w[.].a, w[.].b) as ONE
