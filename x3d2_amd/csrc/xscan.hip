@@ -1986,6 +1986,7 @@ int x3d_ytile_tds_pair(x3d_backend *b, int dir, int mode, real_t *out1, real_t *
     if (Q == 8) GOM(8); else GOM(4);
 #undef GOM
 #undef GON
+#undef GOC
 #undef GOD
 #undef GOH
 #undef GO
