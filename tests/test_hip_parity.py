@@ -276,6 +276,11 @@ def test_error_behaviour_matches_reference():
         b.scalar_product(fx, fx)
     with pytest.raises(X3dError):
         b.transeq_y(fy, fy, fy, fy, fy, fy, s.nu, s.ydirps)  # NULL_LOC -> mesh%get_n stops
+    # (round 6) x3d_backend_set_ring: a direction index, not anything else
+    from x3d2_amd import _lib
+    with pytest.raises(X3dError, match="set_ring"):
+        _lib.check(b.lib.x3d_backend_set_ring(b.h, 0, 1))
+    _lib.check(b.lib.x3d_backend_set_ring(b.h, 2, 0))
 
 
 # ---------------------------------------------------------------- fused driver
